@@ -1,0 +1,258 @@
+"""ctypes binding of the C ABI declared in include/mi_physics.h.
+
+The same binding class serves any shared library exporting that ABI under a symbol prefix
+(`mi_` for the HIP product library; the test oracle re-uses it with its own prefix from
+oracle/__init__.py — the product never imports the oracle).
+"""
+import ctypes as C
+import numpy as np
+
+MI_OK = 0
+ENTITY_DYNAMIC, ENTITY_KINEMATIC, ENTITY_STATIC = 0, 1, 2
+SPHERE, CAPSULE, CYLINDER, AABB, OBB, HULL = range(6)
+(CONSTRAINT_DISTANCE, CONSTRAINT_BALL, CONSTRAINT_FIXED, CONSTRAINT_HINGE,
+ CONSTRAINT_CONE_TWIST, CONSTRAINT_SLIDER) = range(6)
+
+# numpy mirrors of the POD structs (all 4-byte members, no padding).
+entity_desc = np.dtype([
+    ("position", "<f4", 3), ("rotation", "<f4", 4),
+    ("linear_velocity", "<f4", 3), ("angular_velocity", "<f4", 3),
+    ("gravity_factor", "<f4"), ("linear_damping", "<f4"), ("angular_damping", "<f4"),
+    ("kind", "<u4")])
+collider_desc = np.dtype([
+    ("type", "<u4"), ("object_type", "<u4"), ("shape", "<f4", 12), ("hull_geometry", "<u4"),
+    ("restitution", "<f4"), ("friction", "<f4"), ("density", "<f4")])
+contact_dtype = np.dtype([
+    ("point", "<f4", 3), ("penetration_depth", "<f4"), ("normal", "<f4", 3),
+    ("friction_restitution", "<u4"), ("collider_a", "<u4"), ("collider_b", "<u4"),
+    ("body_a", "<u4"), ("body_b", "<u4")])
+assert entity_desc.itemsize == 68 and collider_desc.itemsize == 72 and contact_dtype.itemsize == 48
+
+distance_constraint = np.dtype([("local_anchor_a", "<f4", 3), ("local_anchor_b", "<f4", 3), ("global_length", "<f4")])
+ball_constraint = np.dtype([("local_anchor_a", "<f4", 3), ("local_anchor_b", "<f4", 3)])
+fixed_constraint = np.dtype([("initial_inv_rotation_difference", "<f4", 4), ("local_anchor_a", "<f4", 3), ("local_anchor_b", "<f4", 3)])
+hinge_constraint = np.dtype([
+    ("local_anchor_a", "<f4", 3), ("local_anchor_b", "<f4", 3), ("local_hinge_axis_a", "<f4", 3), ("local_hinge_axis_b", "<f4", 3),
+    ("min_rotation_limit", "<f4"), ("max_rotation_limit", "<f4"), ("max_motor_torque", "<f4"), ("motor_type", "<u4"),
+    ("motor_velocity_or_target_angle", "<f4"),
+    ("local_hinge_tangent_a", "<f4", 3), ("local_hinge_bitangent_a", "<f4", 3), ("local_hinge_tangent_b", "<f4", 3)])
+cone_twist_constraint = np.dtype([
+    ("local_anchor_a", "<f4", 3), ("local_anchor_b", "<f4", 3), ("local_limit_axis_a", "<f4", 3), ("local_limit_axis_b", "<f4", 3),
+    ("local_limit_tangent_a", "<f4", 3), ("local_limit_bitangent_a", "<f4", 3), ("local_limit_tangent_b", "<f4", 3),
+    ("swing_limit", "<f4"), ("twist_limit", "<f4"),
+    ("swing_motor_type", "<u4"), ("swing_motor_velocity_or_target_angle", "<f4"), ("max_swing_motor_torque", "<f4"), ("swing_motor_axis", "<f4"),
+    ("twist_motor_type", "<u4"), ("twist_motor_velocity_or_target_angle", "<f4"), ("max_twist_motor_torque", "<f4")])
+slider_constraint = np.dtype([
+    ("initial_inv_rotation_difference", "<f4", 4), ("local_anchor_a", "<f4", 3), ("local_anchor_b", "<f4", 3), ("local_axis_a", "<f4", 3),
+    ("neg_distance_limit", "<f4"), ("pos_distance_limit", "<f4"), ("max_motor_force", "<f4"), ("motor_type", "<u4"),
+    ("motor_velocity_or_target_distance", "<f4")])
+CONSTRAINT_DTYPES = [distance_constraint, ball_constraint, fixed_constraint, hinge_constraint, cone_twist_constraint, slider_constraint]
+
+
+class StepSettings(C.Structure):
+    """physics_settings minus callbacks (src/physics/physics.h:382-400)."""
+    _fields_ = [("fixed_frame_rate", C.c_uint32), ("frame_rate", C.c_uint32),
+                ("max_physics_iterations_per_frame", C.c_uint32), ("num_rigid_solver_iterations", C.c_uint32)]
+
+    def __init__(self, fixed_frame_rate=1, frame_rate=120, max_physics_iterations_per_frame=4, num_rigid_solver_iterations=30):
+        super().__init__(fixed_frame_rate, frame_rate, max_physics_iterations_per_frame, num_rigid_solver_iterations)
+
+
+class StepCounts(C.Structure):
+    _fields_ = [(n, C.c_uint32) for n in ("num_rigid_bodies", "num_colliders", "num_broadphase_overlaps", "num_collisions",
+                                          "num_contacts", "num_colors", "sorting_axis", "reserved")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
+
+
+class StageTimes(C.Structure):
+    _fields_ = [(n, C.c_float) for n in ("world_colliders", "broadphase", "narrowphase", "integrate_forces", "schedule",
+                                         "init_constraints", "solve", "integrate_velocities", "total")]
+
+    def as_dict(self):
+        return {n: getattr(self, n) for n, _ in self._fields_}
+
+
+class WorldDesc(C.Structure):
+    _fields_ = [("device", C.c_int32), ("flags", C.c_uint32)]
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class PhysicsError(RuntimeError):
+    pass
+
+
+class Library:
+    """A loaded shared library exporting the ABI under `prefix`."""
+
+    def __init__(self, path, prefix="mi_"):
+        self.path = str(path)
+        self.prefix = prefix
+        self.lib = C.CDLL(self.path)
+
+    def fn(self, name, restype=C.c_int):
+        f = getattr(self.lib, self.prefix + name)
+        f.restype = restype
+        return f
+
+    def has(self, name):
+        return hasattr(self.lib, self.prefix + name)
+
+    def last_error(self):
+        if self.has("last_error"):
+            s = self.fn("last_error", C.c_char_p)()
+            return s.decode() if s else ""
+        return ""
+
+    def check(self, rc, what):
+        if rc != MI_OK:
+            raise PhysicsError(f"{self.prefix}{what} failed with status {rc}: {self.last_error()}")
+
+
+class World:
+    """Thin object wrapper over one `mi_world*` (or oracle world) handle."""
+
+    def __init__(self, library, handle):
+        self.L = library
+        self.h = handle
+        self._n_entities = 0
+
+    def close(self):
+        if self.h:
+            self.L.fn("world_destroy", None)(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # --- scene construction
+    def create_entities(self, descs):
+        descs = np.ascontiguousarray(descs, dtype=entity_desc)
+        first = C.c_uint32(0)
+        self.L.check(self.L.fn("entities_create")(self.h, C.c_uint32(len(descs)), _ptr(descs), C.byref(first)), "entities_create")
+        self._n_entities += len(descs)
+        return first.value
+
+    def add_colliders(self, entities, descs):
+        entities = np.ascontiguousarray(entities, dtype=np.uint32)
+        descs = np.ascontiguousarray(descs, dtype=collider_desc)
+        assert len(entities) == len(descs)
+        self.L.check(self.L.fn("colliders_add")(self.h, C.c_uint32(len(descs)), _ptr(entities), _ptr(descs)), "colliders_add")
+
+    def create_hull_geometry(self, vertices, triangles):
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 3)
+        t = np.ascontiguousarray(triangles, dtype=np.uint32).reshape(-1, 3)
+        out = C.c_uint32(0)
+        self.L.check(self.L.fn("hull_geometry_create")(self.h, _ptr(v), C.c_uint32(len(v)), _ptr(t), C.c_uint32(len(t)), C.byref(out)),
+                     "hull_geometry_create")
+        return out.value
+
+    def add_constraint(self, ctype, entity_a, entity_b, pod):
+        pod = np.ascontiguousarray(pod, dtype=CONSTRAINT_DTYPES[ctype]).reshape(1)
+        out = C.c_uint32(0)
+        self.L.check(self.L.fn("constraint_create")(self.h, C.c_uint32(ctype), C.c_uint32(entity_a), C.c_uint32(entity_b),
+                                                    _ptr(pod), C.c_uint32(pod.dtype.itemsize), C.byref(out)), "constraint_create")
+        return out.value
+
+    def add_constraint_from_global(self, ctype, entity_a, entity_b, anchor, axis=None, limit0=1.0, limit1=-1.0):
+        a = np.ascontiguousarray(anchor, dtype=np.float32)
+        x = np.ascontiguousarray(axis if axis is not None else (0, 0, 0), dtype=np.float32)
+        out = C.c_uint32(0)
+        self.L.check(self.L.fn("constraint_create_from_global")(self.h, C.c_uint32(ctype), C.c_uint32(entity_a), C.c_uint32(entity_b),
+                                                                _ptr(a), _ptr(x), C.c_float(limit0), C.c_float(limit1), C.byref(out)),
+                     "constraint_create_from_global")
+        return out.value
+
+    def get_constraint(self, ctype, cid):
+        pod = np.zeros(1, dtype=CONSTRAINT_DTYPES[ctype])
+        self.L.check(self.L.fn("constraint_get")(self.h, C.c_uint32(ctype), C.c_uint32(cid), _ptr(pod), C.c_uint32(pod.dtype.itemsize)),
+                     "constraint_get")
+        return pod
+
+    def update_constraint(self, ctype, cid, pod):
+        pod = np.ascontiguousarray(pod, dtype=CONSTRAINT_DTYPES[ctype]).reshape(1)
+        self.L.check(self.L.fn("constraint_update")(self.h, C.c_uint32(ctype), C.c_uint32(cid), _ptr(pod), C.c_uint32(pod.dtype.itemsize)),
+                     "constraint_update")
+
+    def apply_force(self, entity, force=None, torque=None):
+        f = np.ascontiguousarray(force, dtype=np.float32) if force is not None else None
+        t = np.ascontiguousarray(torque, dtype=np.float32) if torque is not None else None
+        self.L.check(self.L.fn("entity_apply_force")(self.h, C.c_uint32(entity), _ptr(f), _ptr(t)), "entity_apply_force")
+
+    # --- stepping
+    def step(self, settings, dt):
+        """physicsStep(scene, arena, timer, settings, dt) — src/physics/physics.cpp:1364."""
+        self.L.check(self.L.fn("world_step")(self.h, C.byref(settings), C.c_float(dt)), "world_step")
+
+    def step_fixed(self, settings, dt, n=1):
+        """n x physicsStepInternal — src/physics/physics.cpp:1180."""
+        self.L.check(self.L.fn("world_step_fixed")(self.h, C.byref(settings), C.c_float(dt), C.c_uint32(n)), "world_step_fixed")
+
+    # --- read-back
+    def num_entities(self):
+        n = C.c_uint32(0)
+        self.L.check(self.L.fn("world_num_entities")(self.h, C.byref(n)), "world_num_entities")
+        return n.value
+
+    def _get2(self, name, wa, wb):
+        n = self.num_entities()
+        a = np.zeros((n, wa), np.float32)
+        b = np.zeros((n, wb), np.float32)
+        self.L.check(self.L.fn(name)(self.h, _ptr(a), _ptr(b), C.c_uint32(n)), name)
+        return a, b
+
+    def transforms(self):
+        return self._get2("world_get_transforms", 3, 4)
+
+    def physics_transforms(self):
+        return self._get2("world_get_physics_transforms", 3, 4)
+
+    def velocities(self):
+        return self._get2("world_get_velocities", 3, 3)
+
+    def mass_properties(self):
+        n = self.num_entities()
+        im = np.zeros(n, np.float32)
+        ii = np.zeros((n, 9), np.float32)
+        cog = np.zeros((n, 3), np.float32)
+        self.L.check(self.L.fn("world_get_mass_properties")(self.h, _ptr(im), _ptr(ii), _ptr(cog), C.c_uint32(n)), "world_get_mass_properties")
+        return im, ii, cog
+
+    def counts(self):
+        c = StepCounts()
+        self.L.check(self.L.fn("world_get_counts")(self.h, C.byref(c)), "world_get_counts")
+        return c.as_dict()
+
+    def contacts(self):
+        n = C.c_uint32(0)
+        self.L.check(self.L.fn("world_get_contacts")(self.h, None, C.c_uint32(0), C.byref(n)), "world_get_contacts")
+        out = np.zeros(n.value, dtype=contact_dtype)
+        if n.value:
+            self.L.check(self.L.fn("world_get_contacts")(self.h, _ptr(out), C.c_uint32(n.value), C.byref(n)), "world_get_contacts")
+        return out
+
+    def stage_times(self):
+        t = StageTimes()
+        self.L.check(self.L.fn("world_get_stage_times")(self.h, C.byref(t)), "world_get_stage_times")
+        return t.as_dict()
+
+    def aabbs(self):
+        nc = self.counts()["num_colliders"]
+        out = np.zeros((nc, 6), np.float32)
+        self.L.check(self.L.fn("world_get_aabbs")(self.h, _ptr(out), C.c_uint32(nc)), "world_get_aabbs")
+        return out
+
+    def broadphase_pairs(self):
+        n = C.c_uint32(0)
+        self.L.check(self.L.fn("world_get_broadphase_pairs")(self.h, None, C.c_uint32(0), C.byref(n)), "world_get_broadphase_pairs")
+        out = np.zeros((n.value, 2), np.uint32)
+        if n.value:
+            self.L.check(self.L.fn("world_get_broadphase_pairs")(self.h, _ptr(out), C.c_uint32(n.value), C.byref(n)), "world_get_broadphase_pairs")
+        return out

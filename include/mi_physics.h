@@ -1,0 +1,216 @@
+/*
+ * mi_physics.h — C ABI of the MI355X-native rigid-body stepper.
+ *
+ * This is the drop-in boundary for the `src/physics` step path of pkurth/D3D12Renderer.
+ * Every entry point names the reference interface it replaces (paths relative to the
+ * reference repo root).  Plain pointers and sizes only; no C++ / torch types.  All functions
+ * return MI_OK (0) or a negative mi_status; nothing throws across this boundary.
+ *
+ * Threading: one host thread per world.  All device work runs on a world-owned HIP stream;
+ * every call returns after device completion.
+ *
+ * Index conventions (they matter for result parity):
+ *   - rigid bodies are indexed in creation order (EnTT dense storage slot,
+ *     src/physics/physics.cpp:654,1269-1273);
+ *   - colliders are world-indexed in REVERSE creation order (EnTT iterates back to front,
+ *     src/physics/physics.cpp:635-641);
+ *   - a collider without a rigid body ("static collider") uses the dummy body index N_b
+ *     (src/physics/physics.cpp:1214,1279).
+ */
+#ifndef MI_PHYSICS_H
+#define MI_PHYSICS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MI_API __attribute__((visibility("default")))
+
+typedef enum mi_status {
+    MI_OK = 0,
+    MI_ERR_INVALID_ARGUMENT = -1,
+    MI_ERR_NO_DEVICE = -2,        /* HIP device / kernels unavailable: the product path never falls back to CPU */
+    MI_ERR_OUT_OF_MEMORY = -3,
+    MI_ERR_DEVICE = -4,           /* a HIP call failed; see mi_last_error() */
+    MI_ERR_CAPACITY = -5,
+    MI_ERR_UNSUPPORTED = -6
+} mi_status;
+
+/* collider_type — src/physics/physics.h:59-70 (order is load-bearing: narrow-phase buckets). */
+typedef enum mi_collider_type {
+    MI_COLLIDER_SPHERE = 0,
+    MI_COLLIDER_CAPSULE = 1,
+    MI_COLLIDER_CYLINDER = 2,
+    MI_COLLIDER_AABB = 3,
+    MI_COLLIDER_OBB = 4,
+    MI_COLLIDER_HULL = 5,
+    MI_COLLIDER_TYPE_COUNT = 6
+} mi_collider_type;
+
+/* physics_object_type — src/physics/physics.h:49-57. */
+typedef enum mi_object_type {
+    MI_OBJECT_RIGID_BODY = 0,
+    MI_OBJECT_STATIC_COLLIDER = 1,
+    MI_OBJECT_FORCE_FIELD = 2,
+    MI_OBJECT_TRIGGER = 3
+} mi_object_type;
+
+/* constraint_type — src/physics/constraints.h:14-28. */
+typedef enum mi_constraint_type {
+    MI_CONSTRAINT_DISTANCE = 0,
+    MI_CONSTRAINT_BALL = 1,
+    MI_CONSTRAINT_FIXED = 2,
+    MI_CONSTRAINT_HINGE = 3,
+    MI_CONSTRAINT_CONE_TWIST = 4,
+    MI_CONSTRAINT_SLIDER = 5,
+    MI_CONSTRAINT_TYPE_COUNT = 6
+} mi_constraint_type;
+
+enum { MI_ENTITY_DYNAMIC = 0, MI_ENTITY_KINEMATIC = 1, MI_ENTITY_STATIC = 2 };
+
+/*
+ * An entity = transform_component (+ optional rigid_body_component).
+ * Replaces: scene.createEntity().addComponent<transform_component>(pos, rot)
+ *           .addComponent<rigid_body_component>(kinematic, gravityFactor, linearDamping, angularDamping)
+ * (src/scene/scene.h:35-112, src/physics/rigid_body.cpp:6-27).  kind == MI_ENTITY_STATIC creates
+ * the transform only: its colliders become static colliders.
+ */
+typedef struct mi_entity_desc {
+    float position[3];
+    float rotation[4];          /* quaternion x,y,z,w (src/core/math.h:292-298) */
+    float linear_velocity[3];
+    float angular_velocity[3];
+    float gravity_factor;       /* default 1 */
+    float linear_damping;       /* default 0.4 (src/physics/rigid_body.h:21) */
+    float angular_damping;      /* default 0.4 */
+    uint32_t kind;              /* MI_ENTITY_* */
+} mi_entity_desc;
+
+/*
+ * collider_component::asSphere/asCapsule/asCylinder/asAABB/asOBB/asHull + physics_material
+ * (src/physics/physics.h:108-171, 40-47).  Shapes are in the entity's local space.
+ *   sphere   : shape = {cx,cy,cz, r}
+ *   capsule  : shape = {ax,ay,az, bx,by,bz, r}
+ *   cylinder : shape = {ax,ay,az, bx,by,bz, r}
+ *   aabb     : shape = {minx,miny,minz, maxx,maxy,maxz}
+ *   obb      : shape = {qx,qy,qz,qw, cx,cy,cz, rx,ry,rz}
+ *   hull     : shape = {qx,qy,qz,qw, px,py,pz}, hull_geometry = id from mi_hull_geometry_create
+ */
+typedef struct mi_collider_desc {
+    uint32_t type;              /* mi_collider_type */
+    uint32_t object_type;       /* MI_OBJECT_RIGID_BODY (resolved from the entity) — force_field / trigger reserved */
+    float shape[12];
+    uint32_t hull_geometry;
+    float restitution;
+    float friction;
+    float density;
+} mi_collider_desc;
+
+/* physics_settings minus callbacks — src/physics/physics.h:382-400. */
+typedef struct mi_step_settings {
+    uint32_t fixed_frame_rate;              /* bool, default 1 */
+    uint32_t frame_rate;                    /* default 120 */
+    uint32_t max_physics_iterations_per_frame; /* default 4 */
+    uint32_t num_rigid_solver_iterations;   /* default 30 */
+} mi_step_settings;
+
+/* The bit-exact integers of one internal step (CPU_PROFILE_STAT names, src/physics/physics.cpp:1258-1262). */
+typedef struct mi_step_counts {
+    uint32_t num_rigid_bodies;
+    uint32_t num_colliders;
+    uint32_t num_broadphase_overlaps;
+    uint32_t num_collisions;    /* manifolds */
+    uint32_t num_contacts;
+    uint32_t num_colors;        /* contact colours used by the solver schedule */
+    uint32_t sorting_axis;      /* SAP axis used this step (src/physics/collision_broad.cpp:345) */
+    uint32_t reserved;
+} mi_step_counts;
+
+/* collision_contact + constraint_body_pair + collider_pair — src/physics/physics.h:347-354. */
+typedef struct mi_contact {
+    float point[3];
+    float penetration_depth;
+    float normal[3];
+    uint32_t friction_restitution;  /* 16:16 fixed point (src/physics/collision_narrow.cpp:2235-2238) */
+    uint32_t collider_a, collider_b;
+    uint32_t body_a, body_b;
+} mi_contact;
+
+/* Per-stage device time of the last internal step, milliseconds (profiler block names of SURVEY §5). */
+typedef struct mi_stage_times {
+    float world_colliders;
+    float broadphase;
+    float narrowphase;
+    float integrate_forces;
+    float schedule;
+    float init_constraints;
+    float solve;
+    float integrate_velocities;
+    float total;
+} mi_stage_times;
+
+typedef struct mi_world_desc {
+    int32_t device;             /* HIP device ordinal */
+    uint32_t flags;             /* reserved, 0 */
+} mi_world_desc;
+
+typedef struct mi_world mi_world;
+
+/* Library */
+MI_API const char* mi_last_error(void);
+MI_API int mi_version(void);
+
+/* physics_world ctor/dtor  <->  game_scene + memory_arena::initialize (src/physics/physics.cpp:1205). */
+MI_API int mi_world_create(const mi_world_desc* desc, mi_world** out_world);
+MI_API void mi_world_destroy(mi_world* world);
+
+/* addRigidBody  <->  createEntity().addComponent<transform_component>()...addComponent<rigid_body_component>() */
+MI_API int mi_entity_create(mi_world* world, const mi_entity_desc* desc, uint32_t* out_entity);
+MI_API int mi_entities_create(mi_world* world, uint32_t count, const mi_entity_desc* descs, uint32_t* out_first_entity);
+/* addComponent<collider_component>(collider_component::asXxx(shape, material)) (src/scene/scene.h:38-65). */
+MI_API int mi_collider_add(mi_world* world, uint32_t entity, const mi_collider_desc* desc, uint32_t* out_collider);
+MI_API int mi_colliders_add(mi_world* world, uint32_t count, const uint32_t* entities, const mi_collider_desc* descs);
+/* allocateBoundingHullGeometry (src/physics/physics.cpp:58-84) / bounding_hull_geometry::fromMesh. */
+MI_API int mi_hull_geometry_create(mi_world* world, const float* vertices_xyz, uint32_t num_vertices,
+                                   const uint32_t* triangles_abc, uint32_t num_triangles, uint32_t* out_geometry);
+
+/*
+ * addConstraint(a, b, const xxx_constraint&) (src/physics/physics.h:235-240).  `pod` is laid out like the
+ * reference structs (src/physics/constraints.h:73-80,129-135,175-183,229-257,346-380,497-520) with
+ * 4-byte packing; see mi_*_constraint in mi_constraints.h.
+ */
+MI_API int mi_constraint_create(mi_world* world, uint32_t type, uint32_t entity_a, uint32_t entity_b,
+                                const void* pod, uint32_t pod_bytes, uint32_t* out_constraint);
+/* getConstraint(scene, handle) = mutable access (motors/limits) (src/physics/physics.h:244-249). */
+MI_API int mi_constraint_update(mi_world* world, uint32_t type, uint32_t constraint, const void* pod, uint32_t pod_bytes);
+MI_API int mi_constraint_get(mi_world* world, uint32_t type, uint32_t constraint, void* pod, uint32_t pod_bytes);
+/* add{Distance,Ball,Fixed,Hinge,ConeTwist,Slider}ConstraintFromGlobalPoints (src/physics/physics.cpp:128-333). */
+MI_API int mi_constraint_create_from_global(mi_world* world, uint32_t type, uint32_t entity_a, uint32_t entity_b,
+                                            const float* global_anchor, const float* global_axis,
+                                            float limit_min_or_swing, float limit_max_or_twist, uint32_t* out_constraint);
+
+/* rb.forceAccumulator += f; rb.torqueAccumulator += tau (src/physics/physics.cpp:623-627). */
+MI_API int mi_entity_apply_force(mi_world* world, uint32_t entity, const float* force3, const float* torque3);
+
+/* physicsStep(scene, arena, timer, settings, dt) (src/physics/physics.cpp:1364-1413). */
+MI_API int mi_world_step(mi_world* world, const mi_step_settings* settings, float dt);
+/* n × physicsStepInternal(scene, arena, settings, dt) (src/physics/physics.cpp:1180-1362); no interpolation. */
+MI_API int mi_world_step_fixed(mi_world* world, const mi_step_settings* settings, float dt, uint32_t num_steps);
+
+/* Read-back (transform_component / rigid_body_component fields), entity order. */
+MI_API int mi_world_num_entities(mi_world* world, uint32_t* out);
+MI_API int mi_world_get_transforms(mi_world* world, float* positions_xyz, float* rotations_xyzw, uint32_t capacity);
+MI_API int mi_world_get_physics_transforms(mi_world* world, float* positions_xyz, float* rotations_xyzw, uint32_t capacity);
+MI_API int mi_world_get_velocities(mi_world* world, float* linear_xyz, float* angular_xyz, uint32_t capacity);
+MI_API int mi_world_get_mass_properties(mi_world* world, float* inv_mass, float* inv_inertia_9, float* local_cog_xyz, uint32_t capacity);
+MI_API int mi_world_get_counts(mi_world* world, mi_step_counts* out);
+/* Contacts of the last internal step in solver (canonical) order; returns count in *out_count. */
+MI_API int mi_world_get_contacts(mi_world* world, mi_contact* out, uint32_t capacity, uint32_t* out_count);
+MI_API int mi_world_get_stage_times(mi_world* world, mi_stage_times* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_PHYSICS_H */

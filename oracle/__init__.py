@@ -1,0 +1,44 @@
+"""CPU oracle — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.
+It builds oracle/_build/liboracle.so from the C++ restatement (oracle/Makefile) and wraps it with
+the same ctypes binding class the product uses (the oracle exports the ABI with an `ora_` prefix).
+"""
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+from d3d12renderer_amd import capi
+
+HERE = Path(__file__).resolve().parent
+LIB = HERE / "_build" / "liboracle.so"
+
+ORDER_REFERENCE = 0   # SAP sweep order + sequential PGS: the reference's scalar path as written
+ORDER_CANONICAL = 1   # same arithmetic, pairs/colours ordered like the GPU schedule (replayed sequentially)
+
+
+def build(force=False):
+    srcs = [HERE / f for f in ("ora_world.cpp", "ora_narrow.cpp", "ora_gjk.cpp", "ora_joints.cpp", "ora_math.h", "ora_world.h")]
+    srcs += [HERE.parent / "include" / "mi_physics.h", HERE.parent / "include" / "mi_constraints.h"]
+    if force or not LIB.exists() or any(s.stat().st_mtime > LIB.stat().st_mtime for s in srcs):
+        subprocess.run(["make", "-C", str(HERE)], check=True, capture_output=True)
+    return LIB
+
+
+_library = None
+
+
+def library():
+    global _library
+    if _library is None:
+        build()
+        _library = capi.Library(LIB, prefix="ora_")
+    return _library
+
+
+def create_world(order=ORDER_REFERENCE):
+    L = library()
+    h = C.c_void_p()
+    L.check(L.fn("world_create")(C.c_int(order), C.byref(h)), "world_create")
+    return capi.World(L, h)

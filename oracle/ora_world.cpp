@@ -1,0 +1,984 @@
+// ora_world.cpp — TEST INFRASTRUCTURE (CPU oracle), see ora_world.h header note.
+// Step driver, world-space colliders, SAP broad phase, contact solver, integrator, mass
+// properties.  Each function cites the reference lines it restates.
+#include "ora_world.h"
+#include <algorithm>
+#include <cstring>
+#include <cstdio>
+
+namespace ora {
+
+// ---------------------------------------------------------------- math (non-inline)
+
+mat3 invert(const mat3& m) {  // src/core/math.cpp:276-318
+    mat3 inv;
+    inv.m00 = m.m11 * m.m22 - m.m21 * m.m12;
+    inv.m01 = m.m02 * m.m21 - m.m22 * m.m01;
+    inv.m02 = m.m01 * m.m12 - m.m11 * m.m02;
+    inv.m10 = m.m12 * m.m20 - m.m22 * m.m10;
+    inv.m11 = m.m00 * m.m22 - m.m20 * m.m02;
+    inv.m12 = m.m02 * m.m10 - m.m12 * m.m00;
+    inv.m20 = m.m10 * m.m21 - m.m20 * m.m11;
+    inv.m21 = m.m01 * m.m20 - m.m21 * m.m00;
+    inv.m22 = m.m00 * m.m11 - m.m10 * m.m01;
+    float det = m.m00 * (m.m11 * m.m22 - m.m21 * m.m12) - m.m01 * (m.m10 * m.m22 - m.m20 * m.m12) + m.m02 * (m.m10 * m.m21 - m.m20 * m.m11);
+    if (det == 0.f) return mat3::zero();
+    det = 1.f / det;
+    return inv * det;
+}
+
+quat rotateFromTo(vec3 _from, vec3 _to) {  // src/core/math.cpp:538-575
+    vec3 from = normalize(_from), to = normalize(_to);
+    float d = dot(from, to);
+    if (d >= 1.f) return quat(0.f, 0.f, 0.f, 1.f);
+    quat q;
+    if (d < (1e-6f - 1.f)) {
+        vec3 axis = cross(vec3(1.f, 0.f, 0.f), from);
+        if (squaredLength(axis) == 0.f) axis = cross(vec3(0.f, 1.f, 0.f), from);
+        axis = normalize(axis);
+        // quat(axis, angle): src/core/math.h quat ctor: w = cos(angle/2), v = axis*sin(angle/2)
+        float h = kPi * 0.5f;
+        float s = det_sinf(h), c = det_cosf(h);
+        q = normalize(quat(axis.x * s, axis.y * s, axis.z * s, c));
+    } else {
+        float s = std::sqrt((1.f + d) * 2.f);
+        float invs = 1.f / s;
+        vec3 c = cross(from, to);
+        q.x = c.x * invs; q.y = c.y * invs; q.z = c.z * invs; q.w = s * 0.5f;
+        q = normalize(q);
+    }
+    return q;
+}
+
+void getAxisRotation(quat q, vec3& axis, float& angle) {  // src/core/math.cpp:577-593
+    float sqLength = squaredLength(q.v());
+    if (sqLength > 0.f) {
+        angle = 2.f * det_acosf(q.w);
+        float invLength = 1.f / std::sqrt(sqLength);
+        axis = q.v() * invLength;
+    } else {
+        angle = 0.f;
+        axis = vec3(1.f, 0.f, 0.f);
+    }
+}
+
+// Deterministic transcendentals (the same operation sequence is in d3d12renderer_amd/csrc/dmath.hpp).
+// atan(t) = t*Q(t^2) on [0, tan(pi/8)] with Q a degree-8 Chebyshev-fitted polynomial evaluated in
+// double by Horner without FMA (max abs error 1e-14, i.e. the float rounding of the result
+// dominates); [tan(pi/8), 1] is folded with atan(a) = pi/4 + atan((a-1)/(a+1)); a > 1 with
+// atan(a) = pi/2 - atan(1/a).
+static double atan_poly(double t) {
+    double u = t * t;
+    double q = 3.07024230903805012e-02;
+    q = q * u + -5.87725109466260137e-02;
+    q = q * u + 7.56446973448029469e-02;
+    q = q * u + -9.07850346883833786e-02;
+    q = q * u + 1.11103940245759952e-01;
+    q = q * u + -1.42856908172007746e-01;
+    q = q * u + 1.99999996133686908e-01;
+    q = q * u + -3.33333333308731938e-01;
+    q = q * u + 9.99999999999974576e-01;
+    return q * t;
+}
+static double atan01(double a) {  // a in [0,1]
+    if (a > 0.41421356237309503) return 0.78539816339744828 + atan_poly((a - 1.0) / (a + 1.0));
+    return atan_poly(a);
+}
+float det_atan2f(float y, float x) {
+    double ax = std::fabs((double)x), ay = std::fabs((double)y);
+    double r;
+    if (ax == 0.0 && ay == 0.0) r = 0.0;
+    else if (ay <= ax) r = atan01(ay / ax);
+    else r = 1.5707963267948966 - atan01(ax / ay);
+    if (x < 0.f) r = 3.141592653589793 - r;
+    if (y < 0.f) r = -r;
+    return (float)r;
+}
+float det_acosf(float x) {
+    float c = clampf(x, -1.f, 1.f);
+    double d = (double)c;
+    double s = std::sqrt((1.0 - d) * (1.0 + d));
+    return det_atan2f((float)s, c);
+}
+// sin/cos on [-pi, pi] via degree-limited Taylor/minimax in double after quadrant folding.
+static double sin_core(double x) {  // |x| <= pi/4
+    double x2 = x * x;
+    double p = -2.5052108385441720e-08;
+    p = p * x2 + 2.7557319223985893e-06;
+    p = p * x2 + -1.9841269841269841e-04;
+    p = p * x2 + 8.3333333333333332e-03;
+    p = p * x2 + -1.6666666666666666e-01;
+    return x + x * x2 * p;
+}
+static double cos_core(double x) {  // |x| <= pi/4
+    double x2 = x * x;
+    double p = 2.0876756987868100e-09;
+    p = p * x2 + -2.7557319223985888e-07;
+    p = p * x2 + 2.4801587301587302e-05;
+    p = p * x2 + -1.3888888888888889e-03;
+    p = p * x2 + 4.1666666666666664e-02;
+    p = p * x2 + -0.5;
+    return 1.0 + x2 * p;
+}
+static void sincos_det(double x, double& s, double& c) {
+    double q = std::floor(x * 0.6366197723675814 + 0.5);  // nearest multiple of pi/2
+    double r = x - q * 1.5707963267948966;
+    r = r - q * 6.123233995736766e-17;
+    long long k = (long long)q;
+    double sr = sin_core(r), cr = cos_core(r);
+    switch (k & 3) {
+        case 0: s = sr; c = cr; break;
+        case 1: s = cr; c = -sr; break;
+        case 2: s = -sr; c = -cr; break;
+        default: s = -cr; c = sr; break;
+    }
+}
+float det_sinf(float x) { double s, c; sincos_det((double)x, s, c); return (float)s; }
+float det_cosf(float x) { double s, c; sincos_det((double)x, s, c); return (float)c; }
+
+uint32_t hash32(uint32_t m) {  // bijective on 32 bits: unique colouring priorities
+    uint32_t h = m * 0x9E3779B1u;
+    h ^= h >> 15;
+    h *= 0x85EBCA77u;
+    h ^= h >> 13;
+    return h;
+}
+
+// ---------------------------------------------------------------- world
+
+World::World() { joints = jointsCreate(); }
+World::~World() { jointsDestroy(joints); }
+
+static float sphereVolume(float r) { float sq = r * r; float sqpi = kPi * sq; return 4.f / 3.f * sqpi * r; }  // bounding_volumes.h:34-40
+
+struct PhysProps { mat3 inertia; vec3 cog; float mass; };
+
+// collider_union::calculatePhysicsProperties — src/physics/physics.cpp:1416-1588
+static PhysProps calculatePhysicsProperties(const World& w, const Collider& c) {
+    PhysProps r; r.inertia = mat3::zero(); r.mass = 0.f;
+    const Shape& s = c.local;
+    float density = c.mat.density;
+    switch (s.type) {
+        case T_SPHERE: {
+            r.mass = sphereVolume(s.radius) * density;
+            r.cog = s.a;
+            r.inertia = mat3::identity() * (2.f / 5.f * r.mass * s.radius * s.radius);
+        } break;
+        case T_CAPSULE: {
+            vec3 axis = s.a - s.b;
+            if (axis.y < 0.f) axis *= -1.f;
+            float height = length(axis);
+            axis *= (1.f / height);
+            quat rotation = rotateFromTo(vec3(0.f, 1.f, 0.f), axis);
+            mat3 rot = quaternionToMat3(rotation);
+            float sqRadius = s.radius * s.radius;
+            float sqRadiusPI = kPi * sqRadius;
+            // capsule.volume(): bounding_volumes.h:49-57
+            float volume = (4.f / 3.f * sqRadiusPI * s.radius) + (sqRadiusPI * length(s.a - s.b));
+            r.mass = volume * density;
+            r.cog = (s.a + s.b) * 0.5f;
+            float cylinderMass = density * sqRadiusPI * height;
+            float hemiSphereMass = density * 2.f / 3.f * sqRadiusPI * s.radius;
+            float sqCapsuleHeight = height * height;
+            mat3 I = mat3::zero();
+            I.m11 = sqRadius * cylinderMass * 0.5f;
+            I.m00 = I.m22 = I.m11 * 0.5f + cylinderMass * sqCapsuleHeight / 12.f;
+            float temp0 = hemiSphereMass * 2.f * sqRadius / 5.f;
+            I.m11 += temp0 * 2.f;
+            float temp1 = height * 0.5f;
+            float temp2 = temp0 + hemiSphereMass * (temp1 * temp1 + 3.f / 8.f * sqCapsuleHeight);
+            I.m00 += temp2 * 2.f;
+            I.m22 += temp2 * 2.f;
+            r.inertia = transpose(rot) * I * rot;
+        } break;
+        case T_CYLINDER: {
+            vec3 axis = s.a - s.b;
+            if (axis.y < 0.f) axis *= -1.f;
+            float height = length(axis);
+            axis *= (1.f / height);
+            quat rotation = rotateFromTo(vec3(0.f, 1.f, 0.f), axis);
+            mat3 rot = quaternionToMat3(rotation);
+            float volume = (kPi * s.radius * s.radius) * length(s.a - s.b);  // bounding_volumes.h:66-72
+            r.mass = volume * density;
+            r.cog = (s.a + s.b) * 0.5f;
+            float sqRadius = s.radius * s.radius;
+            float sqHeight = height * height;
+            mat3 I = mat3::zero();
+            I.m11 = sqRadius * r.mass * 0.5f;
+            I.m00 = I.m22 = 1.f / 12.f * r.mass * (3.f * sqRadius + sqHeight);
+            r.inertia = transpose(rot) * I * rot;
+        } break;
+        case T_AABB: {
+            vec3 d0 = s.b - s.a;
+            r.mass = (d0.x * d0.y * d0.z) * density;
+            r.cog = (s.a + s.b) * 0.5f;
+            vec3 diameter = ((s.b - s.a) * 0.5f) * 2.f;
+            r.inertia.m00 = 1.f / 12.f * r.mass * (diameter.y * diameter.y + diameter.z * diameter.z);
+            r.inertia.m11 = 1.f / 12.f * r.mass * (diameter.x * diameter.x + diameter.z * diameter.z);
+            r.inertia.m22 = 1.f / 12.f * r.mass * (diameter.x * diameter.x + diameter.y * diameter.y);
+        } break;
+        case T_OBB: {
+            vec3 diameter = s.b * 2.f;
+            r.mass = (diameter.x * diameter.y * diameter.z) * density;
+            r.cog = s.a;
+            mat3 I = mat3::zero();
+            I.m00 = 1.f / 12.f * r.mass * (diameter.y * diameter.y + diameter.z * diameter.z);
+            I.m11 = 1.f / 12.f * r.mass * (diameter.x * diameter.x + diameter.z * diameter.z);
+            I.m22 = 1.f / 12.f * r.mass * (diameter.x * diameter.x + diameter.y * diameter.y);
+            mat3 rot = quaternionToMat3(s.rot);
+            r.inertia = transpose(rot) * I * rot;
+        } break;
+        case T_HULL: {
+            const HullGeometry& g = w.hulls[s.hull];
+            const float s60 = 1.f / 60.f, s120 = 1.f / 120.f;
+            mat3 Cc;  // mat3(row-major ctor) symmetric
+            Cc.m00 = s60; Cc.m01 = s120; Cc.m02 = s120;
+            Cc.m10 = s120; Cc.m11 = s60; Cc.m12 = s120;
+            Cc.m20 = s120; Cc.m21 = s120; Cc.m22 = s60;
+            float totalMass = 0.f; mat3 totalCov = mat3::zero(); vec3 totalCOG(0.f);
+            for (size_t f = 0; f + 2 < g.tris.size(); f += 3) {
+                vec3 w1 = s.a + s.rot * g.vertices[g.tris[f]];
+                vec3 w2 = s.a + s.rot * g.vertices[g.tris[f + 1]];
+                vec3 w3 = s.a + s.rot * g.vertices[g.tris[f + 2]];
+                mat3 A;
+                A.m00 = w1.x; A.m01 = w2.x; A.m02 = w3.x;
+                A.m10 = w1.y; A.m11 = w2.y; A.m12 = w3.y;
+                A.m20 = w1.z; A.m21 = w2.z; A.m22 = w3.z;
+                float detA = determinant(A);
+                mat3 cov = detA * A * Cc * transpose(A);
+                float volume = 1.f / 6.f * detA;
+                float mass = volume;
+                vec3 cog = (w1 + w2 + w3) * 0.25f;
+                totalMass += mass;
+                totalCov = totalCov + cov;
+                totalCOG += cog * mass;
+            }
+            totalCOG = totalCOG / totalMass;
+            mat3 Cprime = totalCov - totalMass * outerProduct(totalCOG, totalCOG);
+            r.cog = totalCOG;
+            r.mass = totalMass * density;
+            r.inertia = mat3::identity() * trace(Cprime) - Cprime;
+            r.inertia = r.inertia * density;
+        } break;
+    }
+    return r;
+}
+
+// rigid_body_component::recalculateProperties — src/physics/rigid_body.cpp:29-81
+void World::recalculateProperties() {
+    for (RigidBody& rb : bodies) {
+        if (rb.invMass == 0.f) continue;  // kinematic
+        const Entity& e = entities[rb.entity];
+        size_t n = e.colliders.size();
+        if (!n) continue;
+        std::vector<PhysProps> props(n);
+        for (size_t i = 0; i < n; ++i) props[i] = calculatePhysicsProperties(*this, colliders[e.colliders[i]]);
+        mat3 inertia = mat3::zero(); vec3 cog(0.f); float mass = 0.f;
+        for (size_t i = 0; i < n; ++i) { mass += props[i].mass; cog += props[i].cog * props[i].mass; }
+        rb.invMass = 1.f / mass;
+        rb.localCOG = cog = cog * rb.invMass;
+        for (size_t i = 0; i < n; ++i) {
+            vec3 r = props[i].cog - cog;
+            inertia = inertia + (props[i].inertia + (dot(r, r) * mat3::identity() - outerProduct(r, r)) * props[i].mass);
+        }
+        rb.invInertia = invert(inertia);
+    }
+    dirtyProps = false;
+}
+
+// ---------------------------------------------------------------- K1: world-space colliders
+
+static AABB aabbNegInf() { return AABB{vec3(FLT_MAX, FLT_MAX, FLT_MAX), vec3(-FLT_MAX, -FLT_MAX, -FLT_MAX)}; }
+static void grow(AABB& bb, vec3 o) {  // bounding_volumes.cpp:25-33
+    bb.mn.x = fmin2(bb.mn.x, o.x); bb.mn.y = fmin2(bb.mn.y, o.y); bb.mn.z = fmin2(bb.mn.z, o.z);
+    bb.mx.x = fmax2(bb.mx.x, o.x); bb.mx.y = fmax2(bb.mx.y, o.y); bb.mx.z = fmax2(bb.mx.z, o.z);
+}
+static AABB transformToAABB(vec3 mn, vec3 mx, quat rotation, vec3 translation) {  // bounding_volumes.cpp:58-70
+    AABB r = aabbNegInf();
+    grow(r, rotation * mn + translation);
+    grow(r, rotation * vec3(mx.x, mn.y, mn.z) + translation);
+    grow(r, rotation * vec3(mn.x, mx.y, mn.z) + translation);
+    grow(r, rotation * vec3(mx.x, mx.y, mn.z) + translation);
+    grow(r, rotation * vec3(mn.x, mn.y, mx.z) + translation);
+    grow(r, rotation * vec3(mx.x, mn.y, mx.z) + translation);
+    grow(r, rotation * vec3(mn.x, mx.y, mx.z) + translation);
+    grow(r, rotation * mx + translation);
+    return r;
+}
+
+// getWorldSpaceColliders — src/physics/physics.cpp:631-756.  World index k <-> creation index Nc-1-k.
+static void getWorldSpaceColliders(World& w) {
+    uint32_t nc = (uint32_t)w.colliders.size();
+    uint32_t dummy = (uint32_t)w.bodies.size();
+    w.wc.resize(nc); w.aabbs.resize(nc);
+    for (uint32_t k = 0; k < nc; ++k) {
+        const Collider& c = w.colliders[nc - 1 - k];
+        const Entity& e = w.entities[c.entity];
+        WorldCollider& col = w.wc[k]; AABB& bb = w.aabbs[k];
+        vec3 tp; quat tr;
+        if (e.rb >= 0) { tp = w.bodies[e.rb].p1; tr = w.bodies[e.rb].r1; col.objectIndex = (uint32_t)e.rb; col.objectType = MI_OBJECT_RIGID_BODY; }
+        else { tp = e.position; tr = e.rotation; col.objectIndex = dummy; col.objectType = MI_OBJECT_STATIC_COLLIDER; }
+        col.mat = c.mat;
+        col.s = Shape(); col.s.type = c.local.type;
+        const Shape& l = c.local;
+        switch (l.type) {
+            case T_SPHERE: {
+                vec3 center = tp + tr * l.a;
+                bb.mn = center - vec3(l.radius); bb.mx = center + vec3(l.radius);  // fromCenterRadius
+                col.s.a = center; col.s.radius = l.radius;
+            } break;
+            case T_CAPSULE: {
+                vec3 posA = tr * l.a + tp, posB = tr * l.b + tp;
+                vec3 r3(l.radius);
+                bb = aabbNegInf();
+                grow(bb, posA + r3); grow(bb, posA - r3); grow(bb, posB + r3); grow(bb, posB - r3);
+                col.s.a = posA; col.s.b = posB; col.s.radius = l.radius;
+            } break;
+            case T_CYLINDER: {
+                vec3 posA = tr * l.a + tp, posB = tr * l.b + tp;
+                vec3 a = posB - posA; float aa = dot(a, a);
+                float x = 1.f - a.x * a.x / aa, y = 1.f - a.y * a.y / aa, z = 1.f - a.z * a.z / aa;
+                x = std::sqrt(fmax2(0.f, x)); y = std::sqrt(fmax2(0.f, y)); z = std::sqrt(fmax2(0.f, z));
+                vec3 ev = l.radius * vec3(x, y, z);
+                bb.mn = vmin(posA - ev, posB - ev); bb.mx = vmax(posA + ev, posB + ev);
+                col.s.a = posA; col.s.b = posB; col.s.radius = l.radius;
+            } break;
+            case T_AABB: {
+                bb = transformToAABB(l.a, l.b, tr, tp);
+                if (tr == quat(0.f, 0.f, 0.f, 1.f)) { col.s.a = bb.mn; col.s.b = bb.mx; }
+                else {  // promoted to OBB (physics.cpp:725-733; transformToOBB bounding_volumes.cpp:72-79)
+                    col.s.type = T_OBB;
+                    col.s.a = tr * ((l.a + l.b) * 0.5f) + tp;
+                    col.s.b = (l.b - l.a) * 0.5f;
+                    col.s.rot = tr;
+                }
+            } break;
+            case T_OBB: {
+                // obb.transformToAABB: bounding_volumes.cpp:134-138; transformToOBB: 140-143
+                bb = transformToAABB(-l.b, l.b, tr * l.rot, tr * l.a + tp);
+                col.s.rot = tr * l.rot; col.s.a = tr * l.a + tp; col.s.b = l.b;
+            } break;
+            case T_HULL: {
+                const HullGeometry& g = w.hulls[l.hull];
+                quat rotation = tr * l.rot;
+                vec3 position = tr * l.a + tp;
+                bb = transformToAABB(g.aabbMin, g.aabbMax, rotation, position);
+                col.s.rot = rotation; col.s.a = position; col.s.hull = l.hull;
+            } break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------- broad phase
+
+static inline bool aabbVsAABB(const AABB& a, const AABB& b) {  // bounding_volumes.h:352-358
+    if (a.mx.x < b.mn.x || a.mn.x > b.mx.x) return false;
+    if (a.mx.y < b.mn.y || a.mn.y > b.mx.y) return false;
+    if (a.mx.z < b.mn.z || a.mn.z > b.mx.z) return false;
+    return true;
+}
+
+// broadphase — src/physics/collision_broad.cpp:297-447 with determineOverlapsScalar (87-166).
+static void broadphaseReference(World& w) {
+    uint32_t nc = (uint32_t)w.colliders.size();
+    w.bpPairs.clear();
+    if (!nc) return;
+    uint32_t axis = w.sortingAxis;
+    vec3 s(0.f), s2(0.f);
+    for (uint32_t index = 0; index < nc; ++index) {   // view iterates back to front: index <-> creation nc-1-index
+        uint32_t creation = nc - 1 - index;
+        const AABB& bb = w.aabbs[index];
+        uint32_t st = w.startEndpoint[creation], en = w.endEndpoint[creation];
+        w.endpoints[st].value = bb.mn[axis]; w.endpoints[en].value = bb.mx[axis];
+        w.endpoints[st].colliderIndex = index; w.endpoints[en].colliderIndex = index;
+        vec3 center = (bb.mn + bb.mx) * 0.5f;
+        s += center; s2 += center * center;
+    }
+    uint32_t ne = nc * 2;
+    std::vector<SapEndpoint>& ep = w.endpoints;
+    for (uint32_t i = 1; i < ne; ++i) {  // insertion sort (386-398)
+        SapEndpoint key = ep[i];
+        uint32_t j = i - 1;
+        while (j != UINT32_MAX && ep[j].value > key.value) { ep[j + 1] = ep[j]; j = j - 1; }
+        ep[j + 1] = key;
+    }
+    // sweep (87-166): swap-remove active list, pairs {new, active[k]}
+    std::vector<uint32_t> active; active.reserve(nc);
+    std::vector<uint32_t> posInActive(nc);
+    for (uint32_t i = 0; i < ne; ++i) {
+        const SapEndpoint& e = ep[i];
+        if (e.start) {
+            const AABB& a = w.aabbs[e.colliderIndex];
+            for (uint32_t k = 0; k < active.size(); ++k)
+                if (aabbVsAABB(a, w.aabbs[active[k]])) w.bpPairs.push_back(Pair{e.colliderIndex, active[k]});
+            posInActive[e.colliderIndex] = (uint32_t)active.size();
+            active.push_back(e.colliderIndex);
+        } else {
+            uint32_t pos = posInActive[e.colliderIndex];
+            uint32_t last = active.back();
+            posInActive[last] = pos;
+            active[pos] = last;
+            active.pop_back();
+        }
+    }
+    for (uint32_t i = 0; i < ne; ++i) {  // fix up indirections (421-440)
+        if (ep[i].start) w.startEndpoint[ep[i].creation] = i; else w.endEndpoint[ep[i].creation] = i;
+    }
+    vec3 variance = s2 - s * s / (float)nc;
+    w.sortingAxis = (variance.x > variance.y) ? ((variance.x > variance.z) ? 0 : 2) : ((variance.y > variance.z) ? 1 : 2);
+}
+
+// Deterministic variance reduction used by the canonical schedule (same tree on the GPU):
+// blocks of 256 colliders; within a block, 4 wave-sums of 64 by a butterfly (offsets 32..1) in
+// double, added wave 0..3; block partials added sequentially in double.
+static void canonicalAxisSums(const std::vector<AABB>& aabbs, double s[3], double s2[3]) {
+    uint32_t n = (uint32_t)aabbs.size();
+    for (int c = 0; c < 3; ++c) { s[c] = 0.0; s2[c] = 0.0; }
+    for (uint32_t base = 0; base < n; base += 256) {
+        double bs[3] = {0, 0, 0}, bs2[3] = {0, 0, 0};
+        for (uint32_t wv = 0; wv < 4; ++wv) {
+            double l[64][3], l2[64][3];
+            for (uint32_t lane = 0; lane < 64; ++lane) {
+                uint32_t i = base + wv * 64 + lane;
+                for (int c = 0; c < 3; ++c) {
+                    if (i < n) {
+                        float ctr = (aabbs[i].mn[c] + aabbs[i].mx[c]) * 0.5f;
+                        l[lane][c] = (double)ctr; l2[lane][c] = (double)ctr * (double)ctr;
+                    } else { l[lane][c] = 0.0; l2[lane][c] = 0.0; }
+                }
+            }
+            for (uint32_t off = 32; off >= 1; off >>= 1)
+                for (uint32_t lane = 0; lane < off; ++lane)
+                    for (int c = 0; c < 3; ++c) { l[lane][c] += l[lane + off][c]; l2[lane][c] += l2[lane + off][c]; }
+            for (int c = 0; c < 3; ++c) { bs[c] += l[0][c]; bs2[c] += l2[0][c]; }
+        }
+        for (int c = 0; c < 3; ++c) { s[c] += bs[c]; s2[c] += bs2[c]; }
+    }
+}
+
+// Canonical pair set: every unordered collider pair whose AABBs overlap (closed intervals), found
+// by an independent sort-and-sweep; equals the SAP set except for exact end==start ties.
+static void broadphaseCanonical(World& w) {
+    uint32_t nc = (uint32_t)w.colliders.size();
+    w.bpPairs.clear();
+    if (!nc) return;
+    uint32_t axis = w.sortingAxis;
+    std::vector<uint32_t> order(nc);
+    for (uint32_t i = 0; i < nc; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return w.aabbs[a].mn[axis] < w.aabbs[b].mn[axis]; });
+    for (uint32_t i = 0; i < nc; ++i) {
+        const AABB& a = w.aabbs[order[i]];
+        for (uint32_t j = i + 1; j < nc; ++j) {
+            const AABB& b = w.aabbs[order[j]];
+            if (b.mn[axis] > a.mx[axis]) break;
+            if (aabbVsAABB(a, b)) w.bpPairs.push_back(Pair{order[i], order[j]});
+        }
+    }
+    double s[3], s2[3];
+    canonicalAxisSums(w.aabbs, s, s2);
+    double var[3];
+    for (int c = 0; c < 3; ++c) var[c] = s2[c] - s[c] * s[c] / (double)nc;
+    w.sortingAxis = (var[0] > var[1]) ? ((var[0] > var[2]) ? 0 : 2) : ((var[1] > var[2]) ? 1 : 2);
+}
+
+// ---------------------------------------------------------------- narrow phase driver
+
+static inline uint32_t bucketOf(int ta, int tb) { return (uint32_t)(ta * 6 - ta * (ta - 1) / 2 + (tb - ta)); }
+
+static uint32_t packMaterial(const Material& a, const Material& b) {  // collision_narrow.cpp:2232-2238
+    float friction = clamp01(std::sqrt(a.friction * b.friction));
+    float restitution = clamp01(fmax2(a.restitution, b.restitution));
+    return ((uint32_t)(friction * 0xFFFF) << 16) | (uint32_t)(restitution * 0xFFFF);
+}
+
+static void emitManifold(World& w, const ContactManifold& m, uint32_t a, uint32_t b) {  // writeScalarContact 2221-2253
+    const WorldCollider& A = w.wc[a]; const WorldCollider& B = w.wc[b];
+    uint32_t fr = packMaterial(A.mat, B.mat);
+    w.colliderPairs.push_back(Pair{a, b});
+    w.contactCounts.push_back((uint8_t)m.numContacts);
+    for (uint32_t i = 0; i < m.numContacts; ++i) {
+        Contact c; c.normal = m.normal; c.penetrationDepth = m.depths[i]; c.point = m.points[i]; c.friction_restitution = fr;
+        w.contacts.push_back(c);
+        w.bodyPairs.push_back(Pair{A.objectIndex, B.objectIndex});
+    }
+}
+
+// Prune / orient (collision_narrow.cpp:2346-2395).  Returns false if the pair generates no collision.
+static bool pruneAndOrient(const World& w, Pair& p, bool& collision) {
+    const WorldCollider* A = &w.wc[p.a]; const WorldCollider* B = &w.wc[p.b];
+    if (A->objectType != MI_OBJECT_RIGID_BODY && B->objectType != MI_OBJECT_RIGID_BODY) return false;
+    if (A->objectType == MI_OBJECT_RIGID_BODY && B->objectType == MI_OBJECT_RIGID_BODY && A->objectIndex == B->objectIndex) return false;
+    if (!(A->s.type < B->s.type)) { std::swap(p.a, p.b); std::swap(A, B); }
+    collision = (A->objectType == MI_OBJECT_RIGID_BODY && B->objectType == MI_OBJECT_RIGID_BODY)
+             || A->objectType == MI_OBJECT_STATIC_COLLIDER || B->objectType == MI_OBJECT_STATIC_COLLIDER;
+    return true;
+}
+
+// narrowphase — src/physics/collision_narrow.cpp:2328-2603 (collision pairs only; trigger /
+// force-field overlap lists are SURVEY §8(f) item 4).
+static void narrowphaseReference(World& w) {
+    w.colliderPairs.clear(); w.contactCounts.clear(); w.contacts.clear(); w.bodyPairs.clear();
+    std::vector<Pair> buckets[21];
+    for (Pair p : w.bpPairs) {
+        bool collision;
+        if (!pruneAndOrient(w, p, collision) || !collision) continue;
+        buckets[bucketOf(w.wc[p.a].s.type, w.wc[p.b].s.type)].push_back(p);
+    }
+    for (int bk = 0; bk < 21; ++bk)
+        for (const Pair& p : buckets[bk]) {
+            ContactManifold m;
+            if (intersect(w, w.wc[p.a], w.wc[p.b], m)) emitManifold(w, m, p.a, p.b);
+        }
+}
+
+// Canonical order: orientation identical to what the SAP sweep produces ({new, active} then the
+// type swap), pairs sorted by (bucket, A, B).
+static void narrowphaseCanonical(World& w, uint32_t axisUsed) {
+    w.colliderPairs.clear(); w.contactCounts.clear(); w.contacts.clear(); w.bodyPairs.clear();
+    std::vector<uint64_t> keys; keys.reserve(w.bpPairs.size());
+    for (Pair p : w.bpPairs) {
+        // reconstruct {new, active}: new = later start on the sweep axis; tie -> later created = smaller world index
+        float ma = w.aabbs[p.a].mn[axisUsed], mb = w.aabbs[p.b].mn[axisUsed];
+        bool aIsNew = (ma > mb) || (ma == mb && p.a < p.b);
+        Pair q = aIsNew ? Pair{p.a, p.b} : Pair{p.b, p.a};
+        bool collision;
+        if (!pruneAndOrient(w, q, collision) || !collision) continue;
+        uint64_t bk = bucketOf(w.wc[q.a].s.type, w.wc[q.b].s.type);
+        keys.push_back((bk << 58) | ((uint64_t)q.a << 29) | (uint64_t)q.b);
+    }
+    std::sort(keys.begin(), keys.end());
+    for (uint64_t k : keys) {
+        uint32_t a = (uint32_t)((k >> 29) & 0x1FFFFFFFu), b = (uint32_t)(k & 0x1FFFFFFFu);
+        ContactManifold m;
+        if (intersect(w, w.wc[a], w.wc[b], m)) emitManifold(w, m, a, b);
+    }
+}
+
+// ---------------------------------------------------------------- integrator
+
+// applyGravityAndIntegrateForces — src/physics/rigid_body.cpp:95-124
+static void applyGravityAndIntegrateForces(RigidBody& rb, GlobalState& g, float dt) {
+    g.rotation = rb.r1;
+    g.position = rb.p1 + rb.r1 * rb.localCOG;
+    mat3 rot = quaternionToMat3(g.rotation);
+    g.invInertia = rot * rb.invInertia * transpose(rot);
+    g.invMass = rb.invMass;
+    if (rb.invMass > 0.f) rb.forceAccumulator.y += (-9.81f / rb.invMass * rb.gravityFactor);
+    vec3 linAcc = rb.forceAccumulator * rb.invMass;
+    vec3 angAcc = g.invInertia * rb.torqueAccumulator;
+    rb.linearVelocity += linAcc * dt;
+    rb.angularVelocity += angAcc * dt;
+    rb.linearVelocity *= 1.f / (1.f + dt * rb.linearDamping);
+    rb.angularVelocity *= 1.f / (1.f + dt * rb.angularDamping);
+    g.linearVelocity = rb.linearVelocity;
+    g.angularVelocity = rb.angularVelocity;
+    g.localCOG = rb.localCOG;
+}
+
+// integrateVelocity — src/physics/rigid_body.cpp:126-142
+static void integrateVelocity(RigidBody& rb, const GlobalState& g, float dt) {
+    rb.linearVelocity = g.linearVelocity;
+    rb.angularVelocity = g.angularVelocity;
+    quat deltaRot(0.5f * rb.angularVelocity.x, 0.5f * rb.angularVelocity.y, 0.5f * rb.angularVelocity.z, 0.f);
+    deltaRot = deltaRot * g.rotation;
+    quat rotation = normalize(g.rotation + (deltaRot * dt));
+    vec3 position = g.position + rb.linearVelocity * dt;
+    rb.forceAccumulator = vec3(0.f); rb.torqueAccumulator = vec3(0.f);
+    rb.r1 = rotation;
+    rb.p1 = position - rotation * rb.localCOG;
+}
+
+// ---------------------------------------------------------------- contact solver
+
+// initializeCollisionVelocityConstraints — src/physics/constraints.cpp:3307-3379
+static void initContact(const World& w, uint32_t id, float dt, CollisionConstraint& c) {
+    const Contact& contact = w.contacts[id];
+    const GlobalState& rbA = w.rb[w.bodyPairs[id].a];
+    const GlobalState& rbB = w.rb[w.bodyPairs[id].b];
+    float invDt = 1.f / dt;
+    c.impulseInNormalDir = 0.f; c.impulseInTangentDir = 0.f;
+    c.relGlobalAnchorA = contact.point - rbA.position;
+    c.relGlobalAnchorB = contact.point - rbB.position;
+    vec3 anchorVelocityA = rbA.linearVelocity + cross(rbA.angularVelocity, c.relGlobalAnchorA);
+    vec3 anchorVelocityB = rbB.linearVelocity + cross(rbB.angularVelocity, c.relGlobalAnchorB);
+    vec3 relVelocity = anchorVelocityB - anchorVelocityA;
+    c.tangent = relVelocity - dot(contact.normal, relVelocity) * contact.normal;
+    c.tangent = noz(c.tangent);
+    {
+        vec3 crAt = cross(c.relGlobalAnchorA, c.tangent);
+        vec3 crBt = cross(c.relGlobalAnchorB, c.tangent);
+        float invMassT = rbA.invMass + dot(crAt, rbA.invInertia * crAt) + rbB.invMass + dot(crBt, rbB.invInertia * crBt);
+        c.effectiveMassInTangentDir = (invMassT != 0.f) ? (1.f / invMassT) : 0.f;
+        c.tangentImpulseToAngularVelocityA = rbA.invInertia * crAt;
+        c.tangentImpulseToAngularVelocityB = rbB.invInertia * crBt;
+    }
+    {
+        vec3 crAn = cross(c.relGlobalAnchorA, contact.normal);
+        vec3 crBn = cross(c.relGlobalAnchorB, contact.normal);
+        float invMassN = rbA.invMass + dot(crAn, rbA.invInertia * crAn) + rbB.invMass + dot(crBn, rbB.invInertia * crBn);
+        c.effectiveMassInNormalDir = (invMassN != 0.f) ? (1.f / invMassN) : 0.f;
+        c.bias = 0.f;
+        if (dt > 1e-5f) {
+            float vRel = dot(contact.normal, relVelocity);
+            const float slop = -0.001f;
+            if (-contact.penetrationDepth < slop && vRel < 0.f) {
+                float restitution = (float)(contact.friction_restitution & 0xFFFF) / (float)0xFFFF;
+                c.bias = -restitution * vRel - 0.1f * (-contact.penetrationDepth - slop) * invDt;
+            }
+        }
+        c.normalImpulseToAngularVelocityA = rbA.invInertia * crAn;
+        c.normalImpulseToAngularVelocityB = rbB.invInertia * crBn;
+    }
+}
+
+// solveCollisionVelocityConstraints body — src/physics/constraints.cpp:3381-3449
+static void solveContact(World& w, uint32_t i, CollisionConstraint& c) {
+    const Contact& contact = w.contacts[i];
+    GlobalState& rbA = w.rb[w.bodyPairs[i].a];
+    GlobalState& rbB = w.rb[w.bodyPairs[i].b];
+    if (rbA.invMass == 0.f && rbB.invMass == 0.f) return;
+    vec3 vA = rbA.linearVelocity, wA = rbA.angularVelocity, vB = rbB.linearVelocity, wB = rbB.angularVelocity;
+    {
+        vec3 anchorVelocityA = vA + cross(wA, c.relGlobalAnchorA);
+        vec3 anchorVelocityB = vB + cross(wB, c.relGlobalAnchorB);
+        vec3 relVelocity = anchorVelocityB - anchorVelocityA;
+        float vt = dot(relVelocity, c.tangent);
+        float lambda = -c.effectiveMassInTangentDir * vt;
+        float friction = (float)(contact.friction_restitution >> 16) / (float)0xFFFF;
+        float maxFriction = friction * c.impulseInNormalDir;
+        float newImpulse = clampf(c.impulseInTangentDir + lambda, -maxFriction, maxFriction);
+        lambda = newImpulse - c.impulseInTangentDir;
+        c.impulseInTangentDir = newImpulse;
+        vec3 P = lambda * c.tangent;
+        vA -= rbA.invMass * P;
+        wA -= c.tangentImpulseToAngularVelocityA * lambda;
+        vB += rbB.invMass * P;
+        wB += c.tangentImpulseToAngularVelocityB * lambda;
+    }
+    {
+        vec3 anchorVelocityA = vA + cross(wA, c.relGlobalAnchorA);
+        vec3 anchorVelocityB = vB + cross(wB, c.relGlobalAnchorB);
+        vec3 relVelocity = anchorVelocityB - anchorVelocityA;
+        float vn = dot(relVelocity, contact.normal);
+        float lambda = -c.effectiveMassInNormalDir * (vn - c.bias);
+        float impulse = fmax2(c.impulseInNormalDir + lambda, 0.f);
+        lambda = impulse - c.impulseInNormalDir;
+        c.impulseInNormalDir = impulse;
+        vec3 P = lambda * contact.normal;
+        vA -= rbA.invMass * P;
+        wA -= c.normalImpulseToAngularVelocityA * lambda;
+        vB += rbB.invMass * P;
+        wB += c.normalImpulseToAngularVelocityB * lambda;
+    }
+    rbA.linearVelocity = vA; rbA.angularVelocity = wA;
+    rbB.linearVelocity = vB; rbB.angularVelocity = wB;
+}
+
+// Canonical contact schedule (replaces scheduleConstraintsSIMD's role, constraints.cpp:51-184):
+// greedy graph colouring of MANIFOLDS in descending hash32 priority; a manifold takes the lowest
+// colour free on both of its dynamic bodies (invMass != 0); bodies with invMass == 0 never
+// conflict (the reference exempts its dummy body, constraints.cpp:81-83).  Colour 64 = overflow,
+// solved sequentially last.  This is exactly what the Jones-Plassmann rounds on the GPU compute.
+static void colorManifolds(World& w) {
+    uint32_t nm = (uint32_t)w.colliderPairs.size();
+    w.manifoldColor.assign(nm, 64);
+    std::vector<uint32_t> order(nm);
+    for (uint32_t i = 0; i < nm; ++i) order[i] = i;
+    std::sort(order.begin(), order.end(), [](uint32_t a, uint32_t b) { return hash32(a) > hash32(b); });
+    std::vector<uint64_t> used(w.rb.size(), 0);
+    std::vector<uint32_t> firstContact(nm);
+    { uint32_t off = 0; for (uint32_t m = 0; m < nm; ++m) { firstContact[m] = off; off += w.contactCounts[m]; } }
+    for (uint32_t m : order) {
+        Pair bp = w.bodyPairs[firstContact[m]];
+        bool dynA = w.rb[bp.a].invMass != 0.f, dynB = w.rb[bp.b].invMass != 0.f;
+        uint64_t mask = (dynA ? used[bp.a] : 0) | (dynB ? used[bp.b] : 0);
+        if (~mask == 0) continue;  // overflow colour
+        uint32_t c = (uint32_t)__builtin_ctzll(~mask);
+        w.manifoldColor[m] = c;
+        if (dynA) used[bp.a] |= (1ull << c);
+        if (dynB) used[bp.b] |= (1ull << c);
+    }
+}
+
+// ---------------------------------------------------------------- step
+
+// physicsStepInternal — src/physics/physics.cpp:1180-1362
+void World::stepInternal(const mi_step_settings& settings, float dt) {
+    if (dirtyProps) recalculateProperties();
+    uint32_t nb = (uint32_t)bodies.size();
+    if (nb == 0) return;
+    uint32_t axisUsed = sortingAxis;
+    getWorldSpaceColliders(*this);
+    if (orderMode == 0) { broadphaseReference(*this); narrowphaseReference(*this); }
+    else { broadphaseCanonical(*this); narrowphaseCanonical(*this, axisUsed); }
+
+    rb.resize(nb + 1);
+    for (uint32_t i = nb; i-- > 0;) applyGravityAndIntegrateForces(bodies[i], rb[i], dt);  // back to front (1266-1276)
+    std::memset((void*)&rb[nb], 0, sizeof(GlobalState));  // dummy (1279)
+
+    uint32_t ncontacts = (uint32_t)contacts.size();
+    jointsInitialize(*this, dt);
+    std::vector<CollisionConstraint> cc(ncontacts);
+    for (uint32_t i = 0; i < ncontacts; ++i) initContact(*this, i, dt, cc[i]);
+
+    uint32_t ncolors = 0;
+    std::vector<uint32_t> solveOrder;  // contact ids in solve order
+    solveOrder.reserve(ncontacts);
+    if (orderMode == 0) {
+        for (uint32_t i = 0; i < ncontacts; ++i) solveOrder.push_back(i);
+    } else {
+        colorManifolds(*this);
+        uint32_t nm = (uint32_t)colliderPairs.size();
+        std::vector<uint32_t> firstContact(nm);
+        { uint32_t off = 0; for (uint32_t m = 0; m < nm; ++m) { firstContact[m] = off; off += contactCounts[m]; } }
+        for (uint32_t c = 0; c <= 64; ++c) {
+            bool any = false;
+            for (uint32_t m = 0; m < nm; ++m) if (manifoldColor[m] == c) {
+                any = true;
+                for (uint32_t k = 0; k < contactCounts[m]; ++k) solveOrder.push_back(firstContact[m] + k);
+            }
+            if (any) ncolors = c + 1;
+        }
+    }
+    for (uint32_t it = 0; it < settings.num_rigid_solver_iterations; ++it) {
+        jointsSolveIteration(*this);  // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
+        for (uint32_t id : solveOrder) solveContact(*this, id, cc[id]);
+    }
+    for (uint32_t i = nb; i-- > 0;) integrateVelocity(bodies[i], rb[i], dt);
+
+    counts.num_rigid_bodies = nb;
+    counts.num_colliders = (uint32_t)colliders.size();
+    counts.num_broadphase_overlaps = (uint32_t)bpPairs.size();
+    counts.num_collisions = (uint32_t)colliderPairs.size();
+    counts.num_contacts = ncontacts;
+    counts.num_colors = ncolors;
+    counts.sorting_axis = axisUsed;
+}
+
+static void syncTransformFromPhysics(World& w) {
+    for (RigidBody& b : w.bodies) { Entity& e = w.entities[b.entity]; e.position = b.p1; e.rotation = b.r1; }
+}
+
+// physicsStep — src/physics/physics.cpp:1364-1413
+void World::step(const mi_step_settings& settings, float dt) {
+    if (settings.fixed_frame_rate) {
+        const float fixedDt = 1.f / (float)settings.frame_rate;
+        timer += dt;
+        uint32_t iterations = 0;
+        if (timer >= fixedDt) {
+            for (RigidBody& b : bodies) { b.p0 = b.p1; b.r0 = b.r1; }
+            while (timer >= fixedDt && iterations++ < settings.max_physics_iterations_per_frame) {
+                stepInternal(settings, fixedDt);
+                timer -= fixedDt;
+            }
+        }
+        if (timer >= fixedDt) timer = std::fmod(timer, fixedDt);
+        float t = timer / fixedDt;
+        for (RigidBody& b : bodies) {  // lerp(trs) src/core/math.h:675-682 (nlerp on the quaternion)
+            Entity& e = entities[b.entity];
+            e.position = lerp(b.p0, b.p1, t);
+            quat q(b.r0.x + t * (b.r1.x - b.r0.x), b.r0.y + t * (b.r1.y - b.r0.y), b.r0.z + t * (b.r1.z - b.r0.z), b.r0.w + t * (b.r1.w - b.r0.w));
+            e.rotation = normalize(q);
+        }
+    } else {
+        stepInternal(settings, dt);
+        syncTransformFromPhysics(*this);
+    }
+}
+
+}  // namespace ora
+
+// ================================================================= C ABI (mirrors include/mi_physics.h with an ora_ prefix)
+using namespace ora;
+
+static void shapeFromDesc(const mi_collider_desc& d, Shape& s) {
+    s.type = (int)d.type;
+    const float* f = d.shape;
+    switch (d.type) {
+        case T_SPHERE: s.a = vec3(f[0], f[1], f[2]); s.radius = f[3]; break;
+        case T_CAPSULE: case T_CYLINDER: s.a = vec3(f[0], f[1], f[2]); s.b = vec3(f[3], f[4], f[5]); s.radius = f[6]; break;
+        case T_AABB: s.a = vec3(f[0], f[1], f[2]); s.b = vec3(f[3], f[4], f[5]); break;
+        case T_OBB: s.rot = quat(f[0], f[1], f[2], f[3]); s.a = vec3(f[4], f[5], f[6]); s.b = vec3(f[7], f[8], f[9]); break;
+        case T_HULL: s.rot = quat(f[0], f[1], f[2], f[3]); s.a = vec3(f[4], f[5], f[6]); s.hull = d.hull_geometry; break;
+    }
+}
+
+extern "C" {
+
+MI_API int ora_world_create(int order_mode, World** out) { *out = new World(); (*out)->orderMode = order_mode; return MI_OK; }
+MI_API void ora_world_destroy(World* w) { delete w; }
+
+MI_API int ora_entities_create(World* w, uint32_t count, const mi_entity_desc* descs, uint32_t* out_first) {
+    if (out_first) *out_first = (uint32_t)w->entities.size();
+    for (uint32_t i = 0; i < count; ++i) {
+        const mi_entity_desc& d = descs[i];
+        Entity e; e.position = vec3(d.position[0], d.position[1], d.position[2]);
+        e.rotation = quat(d.rotation[0], d.rotation[1], d.rotation[2], d.rotation[3]); e.kind = (int)d.kind;
+        if (d.kind != MI_ENTITY_STATIC) {
+            RigidBody rb;
+            rb.entity = (uint32_t)w->entities.size();
+            bool kinematic = d.kind == MI_ENTITY_KINEMATIC;  // rigid_body.cpp:6-27
+            rb.invMass = kinematic ? 0.f : 1.f;
+            rb.invInertia = kinematic ? mat3::zero() : mat3::identity();
+            rb.gravityFactor = d.gravity_factor; rb.linearDamping = d.linear_damping; rb.angularDamping = d.angular_damping;
+            rb.localCOG = vec3(0.f);
+            rb.linearVelocity = vec3(d.linear_velocity[0], d.linear_velocity[1], d.linear_velocity[2]);
+            rb.angularVelocity = vec3(d.angular_velocity[0], d.angular_velocity[1], d.angular_velocity[2]);
+            rb.forceAccumulator = vec3(0.f); rb.torqueAccumulator = vec3(0.f);
+            rb.p0 = rb.p1 = e.position; rb.r0 = rb.r1 = e.rotation;
+            e.rb = (int)w->bodies.size();
+            w->bodies.push_back(rb);
+        }
+        w->entities.push_back(e);
+    }
+    w->dirtyProps = true;
+    return MI_OK;
+}
+MI_API int ora_entity_create(World* w, const mi_entity_desc* d, uint32_t* out) { return ora_entities_create(w, 1, d, out); }
+
+MI_API int ora_colliders_add(World* w, uint32_t count, const uint32_t* entities, const mi_collider_desc* descs) {
+    for (uint32_t i = 0; i < count; ++i) {
+        if (entities[i] >= w->entities.size()) return MI_ERR_INVALID_ARGUMENT;
+        Collider c; shapeFromDesc(descs[i], c.local);
+        c.mat = Material{descs[i].restitution, descs[i].friction, descs[i].density};
+        c.entity = entities[i];
+        uint32_t id = (uint32_t)w->colliders.size();
+        w->colliders.push_back(c);
+        Entity& e = w->entities[entities[i]];
+        e.colliders.insert(e.colliders.begin(), id);
+        // addColliderToBroadphase — collision_broad.cpp:27-40
+        w->startEndpoint.push_back((uint32_t)w->endpoints.size());
+        w->endpoints.push_back(SapEndpoint{0.f, id, true, 0});
+        w->endEndpoint.push_back((uint32_t)w->endpoints.size());
+        w->endpoints.push_back(SapEndpoint{0.f, id, false, 0});
+    }
+    w->dirtyProps = true;
+    return MI_OK;
+}
+MI_API int ora_collider_add(World* w, uint32_t entity, const mi_collider_desc* d, uint32_t* out) {
+    if (out) *out = (uint32_t)w->colliders.size();
+    return ora_colliders_add(w, 1, &entity, d);
+}
+
+MI_API int ora_hull_geometry_create(World* w, const float* v, uint32_t nv, const uint32_t* t, uint32_t nt, uint32_t* out) {
+    HullGeometry g;
+    g.aabbMin = vec3(FLT_MAX); g.aabbMax = vec3(-FLT_MAX);
+    for (uint32_t i = 0; i < nv; ++i) {
+        vec3 p(v[3 * i], v[3 * i + 1], v[3 * i + 2]);
+        g.vertices.push_back(p);
+        g.aabbMin = vmin(g.aabbMin, p); g.aabbMax = vmax(g.aabbMax, p);
+    }
+    g.tris.assign(t, t + 3 * nt);
+    *out = (uint32_t)w->hulls.size();
+    w->hulls.push_back(g);
+    return MI_OK;
+}
+
+MI_API int ora_constraint_create(World* w, uint32_t type, uint32_t ea, uint32_t eb, const void* pod, uint32_t bytes, uint32_t* out) {
+    return jointsAdd(*w, type, ea, eb, pod, bytes, out);
+}
+MI_API int ora_constraint_update(World* w, uint32_t type, uint32_t id, const void* pod, uint32_t bytes) { return jointsUpdate(*w, type, id, pod, bytes); }
+MI_API int ora_constraint_get(World* w, uint32_t type, uint32_t id, void* pod, uint32_t bytes) { return jointsGet(*w, type, id, pod, bytes); }
+MI_API int ora_constraint_create_from_global(World* w, uint32_t type, uint32_t ea, uint32_t eb, const float* anchor, const float* axis,
+                                             float l0, float l1, uint32_t* out) {
+    return jointsAddFromGlobal(*w, type, ea, eb, anchor, axis, l0, l1, out);
+}
+
+MI_API int ora_entity_apply_force(World* w, uint32_t entity, const float* f, const float* t) {
+    if (entity >= w->entities.size() || w->entities[entity].rb < 0) return MI_ERR_INVALID_ARGUMENT;
+    RigidBody& rb = w->bodies[w->entities[entity].rb];
+    if (f) rb.forceAccumulator += vec3(f[0], f[1], f[2]);
+    if (t) rb.torqueAccumulator += vec3(t[0], t[1], t[2]);
+    return MI_OK;
+}
+
+MI_API int ora_world_step(World* w, const mi_step_settings* s, float dt) { w->step(*s, dt); return MI_OK; }
+MI_API int ora_world_step_fixed(World* w, const mi_step_settings* s, float dt, uint32_t n) {
+    for (uint32_t i = 0; i < n; ++i) w->stepInternal(*s, dt);
+    for (RigidBody& b : w->bodies) { Entity& e = w->entities[b.entity]; e.position = b.p1; e.rotation = b.r1; }
+    return MI_OK;
+}
+
+MI_API int ora_world_num_entities(World* w, uint32_t* out) { *out = (uint32_t)w->entities.size(); return MI_OK; }
+static int getTransforms(World* w, float* p, float* r, uint32_t cap, bool physics) {
+    uint32_t n = (uint32_t)w->entities.size();
+    if (cap < n) return MI_ERR_CAPACITY;
+    for (uint32_t i = 0; i < n; ++i) {
+        const Entity& e = w->entities[i];
+        vec3 pos = e.position; quat rot = e.rotation;
+        if (physics && e.rb >= 0) { pos = w->bodies[e.rb].p1; rot = w->bodies[e.rb].r1; }
+        if (p) { p[3 * i] = pos.x; p[3 * i + 1] = pos.y; p[3 * i + 2] = pos.z; }
+        if (r) { r[4 * i] = rot.x; r[4 * i + 1] = rot.y; r[4 * i + 2] = rot.z; r[4 * i + 3] = rot.w; }
+    }
+    return MI_OK;
+}
+MI_API int ora_world_get_transforms(World* w, float* p, float* r, uint32_t cap) { return getTransforms(w, p, r, cap, false); }
+MI_API int ora_world_get_physics_transforms(World* w, float* p, float* r, uint32_t cap) { return getTransforms(w, p, r, cap, true); }
+MI_API int ora_world_get_velocities(World* w, float* lin, float* ang, uint32_t cap) {
+    uint32_t n = (uint32_t)w->entities.size();
+    if (cap < n) return MI_ERR_CAPACITY;
+    for (uint32_t i = 0; i < n; ++i) {
+        vec3 v(0.f), a(0.f);
+        if (w->entities[i].rb >= 0) { v = w->bodies[w->entities[i].rb].linearVelocity; a = w->bodies[w->entities[i].rb].angularVelocity; }
+        if (lin) { lin[3 * i] = v.x; lin[3 * i + 1] = v.y; lin[3 * i + 2] = v.z; }
+        if (ang) { ang[3 * i] = a.x; ang[3 * i + 1] = a.y; ang[3 * i + 2] = a.z; }
+    }
+    return MI_OK;
+}
+MI_API int ora_world_get_mass_properties(World* w, float* invMass, float* invInertia, float* cog, uint32_t cap) {
+    if (w->dirtyProps) w->recalculateProperties();
+    uint32_t n = (uint32_t)w->entities.size();
+    if (cap < n) return MI_ERR_CAPACITY;
+    for (uint32_t i = 0; i < n; ++i) {
+        float im = 0.f; mat3 ii = mat3::zero(); vec3 c(0.f);
+        if (w->entities[i].rb >= 0) { const RigidBody& b = w->bodies[w->entities[i].rb]; im = b.invMass; ii = b.invInertia; c = b.localCOG; }
+        if (invMass) invMass[i] = im;
+        if (invInertia) std::memcpy(invInertia + 9 * i, ii.data(), 36);
+        if (cog) { cog[3 * i] = c.x; cog[3 * i + 1] = c.y; cog[3 * i + 2] = c.z; }
+    }
+    return MI_OK;
+}
+MI_API int ora_world_get_counts(World* w, mi_step_counts* out) { *out = w->counts; return MI_OK; }
+MI_API int ora_world_get_contacts(World* w, mi_contact* out, uint32_t cap, uint32_t* count) {
+    uint32_t n = (uint32_t)w->contacts.size();
+    *count = n;
+    if (!out) return MI_OK;
+    if (cap < n) return MI_ERR_CAPACITY;
+    uint32_t ci = 0;
+    for (uint32_t m = 0; m < w->colliderPairs.size(); ++m)
+        for (uint32_t k = 0; k < w->contactCounts[m]; ++k, ++ci) {
+            const Contact& c = w->contacts[ci]; mi_contact& o = out[ci];
+            o.point[0] = c.point.x; o.point[1] = c.point.y; o.point[2] = c.point.z; o.penetration_depth = c.penetrationDepth;
+            o.normal[0] = c.normal.x; o.normal[1] = c.normal.y; o.normal[2] = c.normal.z; o.friction_restitution = c.friction_restitution;
+            o.collider_a = w->colliderPairs[m].a; o.collider_b = w->colliderPairs[m].b;
+            o.body_a = w->bodyPairs[ci].a; o.body_b = w->bodyPairs[ci].b;
+        }
+    return MI_OK;
+}
+// Stage dumps for bisecting mismatches.
+MI_API int ora_world_get_aabbs(World* w, float* out6, uint32_t cap) {
+    if (cap < w->aabbs.size()) return MI_ERR_CAPACITY;
+    for (size_t i = 0; i < w->aabbs.size(); ++i) {
+        out6[6 * i] = w->aabbs[i].mn.x; out6[6 * i + 1] = w->aabbs[i].mn.y; out6[6 * i + 2] = w->aabbs[i].mn.z;
+        out6[6 * i + 3] = w->aabbs[i].mx.x; out6[6 * i + 4] = w->aabbs[i].mx.y; out6[6 * i + 5] = w->aabbs[i].mx.z;
+    }
+    return MI_OK;
+}
+MI_API int ora_world_get_broadphase_pairs(World* w, uint32_t* out2, uint32_t cap, uint32_t* count) {
+    *count = (uint32_t)w->bpPairs.size();
+    if (!out2) return MI_OK;
+    if (cap < *count) return MI_ERR_CAPACITY;
+    for (size_t i = 0; i < w->bpPairs.size(); ++i) { out2[2 * i] = w->bpPairs[i].a; out2[2 * i + 1] = w->bpPairs[i].b; }
+    return MI_OK;
+}
+MI_API int ora_world_get_manifold_colors(World* w, uint32_t* out, uint32_t cap) {
+    if (cap < w->manifoldColor.size()) return MI_ERR_CAPACITY;
+    for (size_t i = 0; i < w->manifoldColor.size(); ++i) out[i] = w->manifoldColor[i];
+    return MI_OK;
+}
+MI_API float ora_det_atan2f(float y, float x) { return det_atan2f(y, x); }
+MI_API float ora_det_acosf(float x) { return det_acosf(x); }
+MI_API float ora_det_sinf(float x) { return det_sinf(x); }
+MI_API float ora_det_cosf(float x) { return det_cosf(x); }
+
+}  // extern "C"

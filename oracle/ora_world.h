@@ -1,0 +1,151 @@
+// ora_world.h — TEST INFRASTRUCTURE (CPU oracle), see ora_math.h header note.
+//
+// Flat-array, uint32-index restatement of the reference's rigid-body step
+// (src/physics/physics.cpp:1180-1413).  Parity status: the reference cannot be compiled here
+// (Windows/MSVC-only, EnTT submodule absent) and ships no tests or golden vectors, so parity
+// against the ORIGINAL BINARY IS UNPINNED; this restatement is pinned by analytic known-answer
+// tests (tests/test_oracle_*.py) and by its two independently ordered pipelines agreeing.
+#pragma once
+#include <vector>
+#include <cstdint>
+#include "ora_math.h"
+#include "../include/mi_physics.h"
+#include "../include/mi_constraints.h"
+
+namespace ora {
+
+enum { T_SPHERE = 0, T_CAPSULE, T_CYLINDER, T_AABB, T_OBB, T_HULL, T_COUNT };
+
+struct Material { float restitution, friction, density; };
+
+struct HullGeometry {  // bounding_hull_geometry, src/physics/bounding_volumes.h:208-219
+    std::vector<vec3> vertices;
+    std::vector<uint32_t> tris;  // a,b,c per face
+    vec3 aabbMin, aabbMax;
+};
+
+// collider_union (src/physics/physics.h:84-106) with named members instead of a C union.
+struct Shape {
+    int type = 0;
+    vec3 a, b;          // sphere: a=center; capsule/cylinder: a,b; aabb: a=min,b=max; obb: a=center,b=radius; hull: a=position
+    float radius = 0;   // sphere/capsule/cylinder
+    quat rot;           // obb / hull
+    uint32_t hull = 0;  // geometry index
+};
+
+struct Collider {  // collider_component
+    Shape local;
+    Material mat;
+    uint32_t entity;
+};
+
+struct WorldCollider {  // one frame (physics.cpp:631-756)
+    Shape s;
+    Material mat;
+    int objectType;
+    uint32_t objectIndex;
+};
+
+struct AABB { vec3 mn, mx; };
+
+struct Entity {
+    vec3 position; quat rotation;       // transform_component
+    int kind;
+    int rb = -1;                        // rigid_body_component dense index or -1
+    std::vector<uint32_t> colliders;    // newest first (linked list prepend, src/scene/scene.h:52-54)
+};
+
+struct RigidBody {  // rigid_body_component + physics_transform0/1 (src/physics/rigid_body.h:18-58)
+    uint32_t entity;
+    vec3 localCOG; float invMass; mat3 invInertia;
+    float gravityFactor, linearDamping, angularDamping;
+    vec3 linearVelocity, angularVelocity, forceAccumulator, torqueAccumulator;
+    vec3 p0; quat r0;  // physics_transform0
+    vec3 p1; quat r1;  // physics_transform1
+};
+
+struct GlobalState {  // rigid_body_global_state (src/physics/rigid_body.h:6-16)
+    quat rotation; vec3 localCOG; vec3 position; mat3 invInertia; float invMass; vec3 linearVelocity; vec3 angularVelocity;
+};
+
+struct Contact {  // collision_contact (src/physics/physics.h:347-354)
+    vec3 point; float penetrationDepth; vec3 normal; uint32_t friction_restitution;
+};
+struct Pair { uint32_t a, b; };
+
+struct ContactManifold {  // src/physics/collision_narrow.cpp:40-46
+    vec3 points[4]; float depths[4];
+    vec3 normal; uint32_t numContacts;
+};
+
+struct CollisionConstraint {  // collision_constraint (src/physics/constraints.h:606-639)
+    vec3 relGlobalAnchorA, relGlobalAnchorB, tangent;
+    vec3 tangentImpulseToAngularVelocityA, tangentImpulseToAngularVelocityB;
+    vec3 normalImpulseToAngularVelocityA, normalImpulseToAngularVelocityB;
+    float impulseInNormalDir, impulseInTangentDir, effectiveMassInNormalDir, effectiveMassInTangentDir, bias;
+};
+
+struct SapEndpoint { float value; uint32_t creation; bool start; uint32_t colliderIndex; };
+
+struct JointStore;  // ora_joints.cpp
+
+struct World {
+    std::vector<Entity> entities;
+    std::vector<RigidBody> bodies;
+    std::vector<Collider> colliders;  // creation order
+    std::vector<HullGeometry> hulls;
+    JointStore* joints = nullptr;
+
+    // SAP context (src/physics/collision_broad.cpp:20-24)
+    std::vector<SapEndpoint> endpoints;
+    std::vector<uint32_t> startEndpoint, endEndpoint;  // per collider (creation index)
+    uint32_t sortingAxis = 0;
+
+    int orderMode = 0;     // 0 = reference order (SAP sweep order, sequential PGS); 1 = canonical (GPU schedule replayed sequentially)
+    bool dirtyProps = true;
+    float timer = 0.f;
+
+    // Last-step dumps
+    std::vector<WorldCollider> wc;
+    std::vector<AABB> aabbs;
+    std::vector<Pair> bpPairs;            // broad-phase pairs in emission order
+    std::vector<Pair> colliderPairs;      // manifolds
+    std::vector<uint8_t> contactCounts;
+    std::vector<Contact> contacts;
+    std::vector<Pair> bodyPairs;          // per contact
+    std::vector<uint32_t> manifoldColor;  // canonical mode
+    std::vector<GlobalState> rb;
+    mi_step_counts counts{};
+
+    World();
+    ~World();
+    void recalculateProperties();
+    void stepInternal(const mi_step_settings& s, float dt);
+    void step(const mi_step_settings& s, float dt);
+};
+
+// narrow phase (ora_narrow.cpp)
+bool intersect(const World& w, const WorldCollider& A, const WorldCollider& B, ContactManifold& out);
+// GJK / EPA (ora_gjk.cpp)
+struct SupportShape { const Shape* s; const HullGeometry* g; };
+vec3 support(const SupportShape& sh, vec3 dir);
+struct GjkSimplexPoint { vec3 shapeAPoint, shapeBPoint, minkowski; };
+struct GjkSimplex { GjkSimplexPoint a, b, c, d; uint32_t numPoints; };
+bool gjkIntersectionTest(const SupportShape& A, const SupportShape& B, GjkSimplex& simplex);
+struct EpaResult { vec3 point, normal; float penetrationDepth; };
+int epaCollisionInfo(const GjkSimplex& simplex, const SupportShape& A, const SupportShape& B, EpaResult& out);
+
+// joints (ora_joints.cpp)
+JointStore* jointsCreate();
+void jointsDestroy(JointStore*);
+int jointsAdd(World& w, uint32_t type, uint32_t entityA, uint32_t entityB, const void* pod, uint32_t bytes, uint32_t* outId);
+int jointsUpdate(World& w, uint32_t type, uint32_t id, const void* pod, uint32_t bytes);
+int jointsGet(World& w, uint32_t type, uint32_t id, void* pod, uint32_t bytes);
+int jointsAddFromGlobal(World& w, uint32_t type, uint32_t ea, uint32_t eb, const float* anchor, const float* axis, float l0, float l1, uint32_t* outId);
+void jointsInitialize(World& w, float dt);
+void jointsSolveIteration(World& w);
+uint32_t jointsCount(const World& w);
+
+uint32_t hash32(uint32_t m);  // colouring priority
+
+}  // namespace ora
