@@ -1,0 +1,47 @@
+"""Builds the HIP extension in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+LIB = HERE / "libmi_physics.so"
+SOURCES = [CSRC / "world.hip"]
+HEADERS = [CSRC / n for n in ("dmath.hpp", "narrow.hpp", "kernels.hpp", "gjk.hpp", "joints.hpp")] + \
+          [HERE.parent / "include" / n for n in ("mi_physics.h", "mi_constraints.h")]
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
+         "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
+         "-Wno-unused-result", "-Wno-unused-function"]
+
+
+def hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.sep not in c or os.path.exists(c)):
+            return c
+    raise RuntimeError("hipcc not found")
+
+
+def needs_build():
+    if not LIB.exists():
+        return True
+    t = LIB.stat().st_mtime
+    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc(), *FLAGS, "-I", str(HERE.parent / "include"), *map(str, SOURCES), "-o", str(LIB)]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc failed")
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv, verbose=True)
+    print(LIB)

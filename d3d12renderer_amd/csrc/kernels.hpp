@@ -1,0 +1,704 @@
+// kernels.hpp — HIP kernels of the rigid-body step for gfx950 (wave64).
+//
+// Stage names follow the reference's profiler blocks.  HBM layout is SoA with
+// float4 rows: a wave touching 64 consecutive bodies / contacts issues 1 KiB coalesced transactions.
+// No MFMA anywhere: there is no dense contraction on this path; the roofline is HBM bandwidth.
+#pragma once
+#include "dmath.hpp"
+#include "narrow.hpp"
+
+namespace mi {
+
+constexpr uint32_t kNoBody = 0xFFFFFFFFu;
+constexpr uint32_t kMaxCells = 1u << 22;
+constexpr uint32_t kOverflowColor = 64;
+constexpr uint32_t kUncolored = 0xFFFFFFFFu;
+
+enum : uint32_t { OBJ_RIGID_BODY = 0, OBJ_STATIC = 1, OBJ_FORCE_FIELD = 2, OBJ_TRIGGER = 3 };
+
+struct GridParams {   // written by k_bp_grid_setup, read by the broad-phase kernels
+    float origin[3];
+    float invCell;
+    uint32_t dims[3];
+    uint32_t numCells;
+    uint32_t numLarge;
+    float cell;
+    float largeThreshold;
+    uint32_t pad;
+};
+
+struct StepScalars {  // device-resident per-step scalars
+    double extentSum;
+    int boundsMin[3];     // ordered-int encoded floats
+    int boundsMax[3];
+    uint32_t numLarge;
+    uint32_t numPairs;        // broad-phase overlaps that passed pruning (collision pairs)
+    uint32_t numOverlaps;     // all AABB overlaps (CPU_PROFILE_STAT "Num broadphase overlaps")
+    uint32_t numManifolds;
+    uint32_t numContacts;
+    uint32_t uncolored;
+    uint32_t axisCur;
+    uint32_t axisNext;
+    uint32_t colorHist[kOverflowColor + 1];
+};
+
+__device__ __forceinline__ int orderedInt(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__device__ __forceinline__ float fromOrderedInt(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__device__ __forceinline__ uint32_t bucketOf(uint32_t ta, uint32_t tb) { return ta * 6u - ta * (ta - 1u) / 2u + (tb - ta); }
+
+// ------------------------------------------------------------------------------------------------
+// K1 "Get world space colliders" (src/physics/physics.cpp:631-756)
+// One lane per collider (world index = reverse creation order).  in: 48 B local shape + 32 B pose
+// (gathered by body) ; out: 48 B world shape + 2 x 16 B AABB rows whose .w carry the type/object
+// tags and the body index, so the broad phase never touches another array.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void growBox(V3& mn, V3& mx, V3 o) { mn = vmin(mn, o); mx = vmax(mx, o); }
+__device__ inline void boxToAABB(V3 lmn, V3 lmx, Q4 rot, V3 tr, V3& mn, V3& mx) {  // bounding_volumes.cpp:58-70
+    mn = V3(FLT_MAX); mx = V3(-FLT_MAX);
+    growBox(mn, mx, rotate(rot, lmn) + tr);
+    growBox(mn, mx, rotate(rot, V3(lmx.x, lmn.y, lmn.z)) + tr);
+    growBox(mn, mx, rotate(rot, V3(lmn.x, lmx.y, lmn.z)) + tr);
+    growBox(mn, mx, rotate(rot, V3(lmx.x, lmx.y, lmn.z)) + tr);
+    growBox(mn, mx, rotate(rot, V3(lmn.x, lmn.y, lmx.z)) + tr);
+    growBox(mn, mx, rotate(rot, V3(lmx.x, lmn.y, lmx.z)) + tr);
+    growBox(mn, mx, rotate(rot, V3(lmn.x, lmx.y, lmx.z)) + tr);
+    growBox(mn, mx, rotate(rot, lmx) + tr);
+}
+
+__global__ __launch_bounds__(256) void k_world_colliders(
+    uint32_t nc, uint32_t nb, const uint32_t* __restrict__ cTypeBody,  // [2*nc]: type, body (kNoBody = static)
+    const float4* __restrict__ cShape, const float4* __restrict__ cStaticPos, const float4* __restrict__ cStaticRot,
+    const float4* __restrict__ bPos, const float4* __restrict__ bRot,
+    const float4* __restrict__ hullAabb,  // [2*numHulls]
+    float4* __restrict__ wShape, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax, StepScalars* sc) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) { sc->axisCur = sc->axisNext; }
+    if (k >= nc) return;
+    uint32_t type = cTypeBody[2 * k], body = cTypeBody[2 * k + 1];
+    V3 tp; Q4 tr; uint32_t objType, objIndex;
+    if (body != kNoBody) { tp = xyz(bPos[body]); tr = toQ(bRot[body]); objType = OBJ_RIGID_BODY; objIndex = body; }
+    else { tp = xyz(cStaticPos[k]); tr = toQ(cStaticRot[k]); objType = OBJ_STATIC; objIndex = nb; }
+    float4 s0 = cShape[3 * k], s1 = cShape[3 * k + 1], s2 = cShape[3 * k + 2];
+    float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = make_float4(0, 0, 0, 1);
+    V3 mn, mx;
+    uint32_t wtype = type;
+    switch (type) {
+        case T_SPHERE: {
+            V3 c = tp + rotate(tr, xyz(s0));
+            mn = c - V3(s0.w); mx = c + V3(s0.w);
+            o0 = f4(c, s0.w);
+        } break;
+        case T_CAPSULE: {
+            V3 pa = rotate(tr, xyz(s0)) + tp, pb = rotate(tr, V3(s0.w, s1.x, s1.y)) + tp;
+            float r = s1.z; V3 r3(r);
+            mn = V3(FLT_MAX); mx = V3(-FLT_MAX);
+            growBox(mn, mx, pa + r3); growBox(mn, mx, pa - r3); growBox(mn, mx, pb + r3); growBox(mn, mx, pb - r3);
+            o0 = f4(pa, r); o1 = f4(pb, 0.f);
+        } break;
+        case T_CYLINDER: {
+            V3 pa = rotate(tr, xyz(s0)) + tp, pb = rotate(tr, V3(s0.w, s1.x, s1.y)) + tp;
+            float r = s1.z;
+            V3 a = pb - pa; float aa = dot(a, a);
+            float x = 1.f - a.x * a.x / aa, y = 1.f - a.y * a.y / aa, z = 1.f - a.z * a.z / aa;
+            x = sqrtf(fmaxr(0.f, x)); y = sqrtf(fmaxr(0.f, y)); z = sqrtf(fmaxr(0.f, z));
+            V3 e = r * V3(x, y, z);
+            mn = vmin(pa - e, pb - e); mx = vmax(pa + e, pb + e);
+            o0 = f4(pa, r); o1 = f4(pb, 0.f);
+        } break;
+        case T_AABB: {
+            V3 lmn = xyz(s0), lmx(s0.w, s1.x, s1.y);
+            boxToAABB(lmn, lmx, tr, tp, mn, mx);
+            if (isIdentity(tr)) { o0 = f4(mn, 0.f); o1 = f4(mx, 0.f); }
+            else {  // promoted to OBB (physics.cpp:725-733)
+                wtype = T_OBB;
+                o0 = f4(rotate(tr, (lmn + lmx) * 0.5f) + tp, 0.f);
+                o1 = f4((lmx - lmn) * 0.5f, 0.f);
+                o2 = fromQ(tr);
+            }
+        } break;
+        case T_OBB: {
+            Q4 lrot(s0.x, s0.y, s0.z, s0.w); V3 lc(s1.x, s1.y, s1.z), lr(s1.w, s2.x, s2.y);
+            Q4 wrot = tr * lrot; V3 wc = rotate(tr, lc) + tp;
+            boxToAABB(-lr, lr, wrot, wc, mn, mx);
+            o0 = f4(wc, 0.f); o1 = f4(lr, 0.f); o2 = fromQ(wrot);
+        } break;
+        default: {  // hull
+            Q4 lrot(s0.x, s0.y, s0.z, s0.w); V3 lp(s1.x, s1.y, s1.z);
+            uint32_t geom = __float_as_uint(s1.w);
+            Q4 wrot = tr * lrot; V3 wp = rotate(tr, lp) + tp;
+            boxToAABB(xyz(hullAabb[2 * geom]), xyz(hullAabb[2 * geom + 1]), wrot, wp, mn, mx);
+            o0 = f4(wp, s1.w); o2 = fromQ(wrot);
+        } break;
+    }
+    wShape[3 * k] = o0; wShape[3 * k + 1] = o1; wShape[3 * k + 2] = o2;
+    aabbMin[k] = f4(mn, __uint_as_float(wtype | (objType << 8)));
+    aabbMax[k] = f4(mx, __uint_as_float(objIndex));
+}
+
+// ------------------------------------------------------------------------------------------------
+// Broad phase.  The reference sorts AABB endpoints on the max-variance axis and sweeps
+// (src/physics/collision_broad.cpp:297-447).  The pair SET it produces is "all AABB-overlapping
+// pairs"; here that set comes from a uniform grid over collider centres (cell >= every "small"
+// extent => 27 neighbour cells suffice) plus a brute-force pass for the few "large" colliders
+// (ground, walls).  The SAP axis is still tracked because the reference's A/B orientation of a
+// same-type pair depends on sweep order along it.
+// ------------------------------------------------------------------------------------------------
+
+// Deterministic centre statistics for the next sorting axis: fixed butterfly per wave (double),
+// waves 0..3 added in order, block partials added sequentially by k_axis_final.
+__global__ __launch_bounds__(256) void k_axis_partials(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                       double* __restrict__ partials, StepScalars* sc) {
+    __shared__ double sm[4][6];
+    uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    float ext = 0.f;
+    if (i < nc) {
+        float4 mn = aabbMin[i], mx = aabbMax[i];
+        float cx = (mn.x + mx.x) * 0.5f, cy = (mn.y + mx.y) * 0.5f, cz = (mn.z + mx.z) * 0.5f;
+        v[0] = cx; v[1] = cy; v[2] = cz;
+        v[3] = (double)cx * (double)cx; v[4] = (double)cy * (double)cy; v[5] = (double)cz * (double)cz;
+        ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] += __shfl_down(v[c], off, 64);
+        ext += __shfl_down(ext, off, 64);
+    }
+    uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        for (int c = 0; c < 6; ++c) sm[wv][c] = v[c];
+        atomicAdd(&sc->extentSum, (double)ext);   // only steers the cell size, never results
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int c = 0; c < 6; ++c) {
+            double a = 0.0;
+            for (int w = 0; w < 4; ++w) a += sm[w][c];
+            partials[blockIdx.x * 6 + c] = a;
+        }
+    }
+}
+__global__ void k_axis_final(uint32_t nc, uint32_t numBlocks, const double* __restrict__ partials, StepScalars* sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t b = 0; b < numBlocks; ++b)
+        for (int c = 0; c < 6; ++c) s[c] += partials[b * 6 + c];
+    double var[3];
+    for (int c = 0; c < 3; ++c) var[c] = s[3 + c] - s[c] * s[c] / (double)nc;
+    sc->axisNext = (var[0] > var[1]) ? ((var[0] > var[2]) ? 0u : 2u) : ((var[1] > var[2]) ? 1u : 2u);  // collision_broad.cpp:443-444
+}
+
+__global__ __launch_bounds__(256) void k_bp_classify(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                     StepScalars* sc, uint32_t* __restrict__ largeList, uint32_t* __restrict__ isLarge) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    float thr = 2.f * (float)(sc->extentSum / (double)nc);
+    float4 mn = aabbMin[i], mx = aabbMax[i];
+    float ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
+    bool large = ext > thr;
+    isLarge[i] = large ? 1u : 0u;
+    if (large) { uint32_t slot = atomicAdd(&sc->numLarge, 1u); largeList[slot] = i; }
+    else {
+        float cx = (mn.x + mx.x) * 0.5f, cy = (mn.y + mx.y) * 0.5f, cz = (mn.z + mx.z) * 0.5f;
+        atomicMin(&sc->boundsMin[0], orderedInt(cx)); atomicMax(&sc->boundsMax[0], orderedInt(cx));
+        atomicMin(&sc->boundsMin[1], orderedInt(cy)); atomicMax(&sc->boundsMax[1], orderedInt(cy));
+        atomicMin(&sc->boundsMin[2], orderedInt(cz)); atomicMax(&sc->boundsMax[2], orderedInt(cz));
+    }
+}
+
+__global__ void k_bp_grid_setup(uint32_t nc, StepScalars* sc, GridParams* g) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float thr = 2.f * (float)(sc->extentSum / (double)nc);
+    float cell = thr * 1.001f + 1e-6f;
+    float lo[3], hi[3];
+    bool any = sc->boundsMin[0] != 0x7FFFFFFF;
+    for (int a = 0; a < 3; ++a) { lo[a] = any ? fromOrderedInt(sc->boundsMin[a]) : 0.f; hi[a] = any ? fromOrderedInt(sc->boundsMax[a]) : 0.f; }
+    for (int it = 0; it < 64; ++it) {
+        double cells = 1.0;
+        for (int a = 0; a < 3; ++a) { uint32_t d = (uint32_t)((hi[a] - lo[a]) / cell) + 2u; g->dims[a] = d; cells *= (double)d; }
+        if (cells <= (double)kMaxCells) break;
+        cell *= 1.3f;
+    }
+    g->numCells = g->dims[0] * g->dims[1] * g->dims[2];
+    g->cell = cell; g->invCell = 1.f / cell;
+    for (int a = 0; a < 3; ++a) g->origin[a] = lo[a];
+    g->numLarge = sc->numLarge;
+    g->largeThreshold = thr;
+}
+
+__device__ __forceinline__ void cellOf(const GridParams& g, float cx, float cy, float cz, uint32_t& ix, uint32_t& iy, uint32_t& iz) {
+    ix = min((uint32_t)fmaxr(0.f, (cx - g.origin[0]) * g.invCell), g.dims[0] - 1u);
+    iy = min((uint32_t)fmaxr(0.f, (cy - g.origin[1]) * g.invCell), g.dims[1] - 1u);
+    iz = min((uint32_t)fmaxr(0.f, (cz - g.origin[2]) * g.invCell), g.dims[2] - 1u);
+}
+
+__global__ __launch_bounds__(256) void k_bp_cell_ids(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                     const uint32_t* __restrict__ isLarge, const GridParams* __restrict__ gp,
+                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    GridParams g = *gp;
+    uint32_t key = 0xFFFFFFFFu;
+    if (!isLarge[i]) {
+        float4 mn = aabbMin[i], mx = aabbMax[i];
+        uint32_t ix, iy, iz;
+        cellOf(g, (mn.x + mx.x) * 0.5f, (mn.y + mx.y) * 0.5f, (mn.z + mx.z) * 0.5f, ix, iy, iz);
+        key = (ix * g.dims[1] + iy) * g.dims[2] + iz;
+    }
+    keys[i] = key; vals[i] = i;
+}
+
+__global__ __launch_bounds__(256) void k_bp_clear_cells(const GridParams* __restrict__ gp, uint32_t* __restrict__ cellStart) {
+    uint32_t n = gp->numCells;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cellStart[i] = 0xFFFFFFFFu;
+}
+
+// Sorted-order copies of the AABB rows (+ original index) so the 27-cell scan reads contiguous memory.
+__global__ __launch_bounds__(256) void k_bp_cell_bounds(uint32_t nc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                        const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                        float4* __restrict__ sMin, float4* __restrict__ sMax,
+                                                        uint32_t* __restrict__ cellStart, uint32_t* __restrict__ cellEnd) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    uint32_t key = keys[i], idx = vals[i];
+    sMin[i] = aabbMin[idx]; sMax[i] = aabbMax[idx];
+    if (key == 0xFFFFFFFFu) return;
+    if (i == 0 || keys[i - 1] != key) cellStart[key] = i;
+    if (i == nc - 1 || keys[i + 1] != key) cellEnd[key] = i + 1;
+}
+
+// Prune + orient + key (collision_narrow.cpp:2346-2395) fused into pair emission.
+// i, j: collider world indices.  The SAP sweep emits {new, active}: new = later start on the axis;
+// on a tie the later-created collider (smaller world index) is the newer endpoint.
+__device__ __forceinline__ void emitPair(uint32_t i, const float4& imn, const float4& imx, uint32_t j, const float4& jmn, const float4& jmx,
+                                         uint32_t axis, uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc) {
+    atomicAdd(&sc->numOverlaps, 1u);
+    uint32_t ti = __float_as_uint(imn.w), tj = __float_as_uint(jmn.w);
+    uint32_t oi = (ti >> 8) & 0xFF, oj = (tj >> 8) & 0xFF;
+    uint32_t bi = __float_as_uint(imx.w), bj = __float_as_uint(jmx.w);
+    if (oi != OBJ_RIGID_BODY && oj != OBJ_RIGID_BODY) return;
+    if (oi == OBJ_RIGID_BODY && oj == OBJ_RIGID_BODY && bi == bj) return;
+    float mi_ = axis == 0 ? imn.x : (axis == 1 ? imn.y : imn.z);
+    float mj_ = axis == 0 ? jmn.x : (axis == 1 ? jmn.y : jmn.z);
+    bool iIsNew = (mi_ > mj_) || (mi_ == mj_ && i < j);
+    uint32_t a = iIsNew ? i : j, b = iIsNew ? j : i;
+    uint32_t ta = (iIsNew ? ti : tj) & 0xFF, tb = (iIsNew ? tj : ti) & 0xFF;
+    uint32_t oa = iIsNew ? oi : oj, ob = iIsNew ? oj : oi;
+    if (!(ta < tb)) { uint32_t t = a; a = b; b = t; t = ta; ta = tb; tb = t; t = oa; oa = ob; ob = t; }
+    bool collision = (oa == OBJ_RIGID_BODY && ob == OBJ_RIGID_BODY) || oa == OBJ_STATIC || ob == OBJ_STATIC;
+    if (!collision) return;   // trigger / force-field overlaps: SURVEY §8(f).4
+    uint32_t slot = atomicAdd(&sc->numPairs, 1u);
+    if (slot < pairCap) pairKeys[slot] = ((uint64_t)bucketOf(ta, tb) << 58) | ((uint64_t)a << 29) | (uint64_t)b;
+}
+
+__device__ __forceinline__ bool aabbOverlap(const float4& amn, const float4& amx, const float4& bmn, const float4& bmx) {  // bounding_volumes.h:352-358
+    if (amx.x < bmn.x || amn.x > bmx.x) return false;
+    if (amx.y < bmn.y || amn.y > bmx.y) return false;
+    if (amx.z < bmn.z || amn.z > bmx.z) return false;
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                       const float4* __restrict__ sMin, const float4* __restrict__ sMax,
+                                                       const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ cellEnd,
+                                                       const GridParams* __restrict__ gp, uint64_t* __restrict__ pairKeys, uint32_t pairCap,
+                                                       StepScalars* sc) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    uint32_t key = keys[i];
+    if (key == 0xFFFFFFFFu) return;
+    const uint32_t dy = gp->dims[1], dz = gp->dims[2], dx = gp->dims[0];
+    uint32_t axis = sc->axisCur;
+    uint32_t iz = key % dz, iy = (key / dz) % dy, ix = key / (dz * dy);
+    float4 amn = sMin[i], amx = sMax[i];
+    uint32_t ci = vals[i];
+    for (int ox = -1; ox <= 1; ++ox) {
+        int x = (int)ix + ox; if (x < 0 || x >= (int)dx) continue;
+        for (int oy = -1; oy <= 1; ++oy) {
+            int y = (int)iy + oy; if (y < 0 || y >= (int)dy) continue;
+            for (int oz = -1; oz <= 1; ++oz) {
+                int z = (int)iz + oz; if (z < 0 || z >= (int)dz) continue;
+                uint32_t c = ((uint32_t)x * dy + (uint32_t)y) * dz + (uint32_t)z;
+                uint32_t s = cellStart[c];
+                if (s == 0xFFFFFFFFu) continue;
+                uint32_t e = cellEnd[c];
+                for (uint32_t j = s; j < e; ++j) {
+                    if (j <= i) continue;   // each unordered pair once
+                    float4 bmn = sMin[j], bmx = sMax[j];
+                    if (aabbOverlap(amn, amx, bmn, bmx)) emitPair(ci, amn, amx, vals[j], bmn, bmx, axis, pairKeys, pairCap, sc);
+                }
+            }
+        }
+    }
+}
+
+// Large colliders against everything: (large l) x (all colliders), grid-strided.  Large-large pairs
+// are emitted once (from the lower index).
+__global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint32_t* __restrict__ largeList, const uint32_t* __restrict__ isLarge,
+                                                        const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                        uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc) {
+    uint32_t nl = sc->numLarge;
+    uint32_t axis = sc->axisCur;
+    uint64_t total = (uint64_t)nl * nc;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t l = (uint32_t)(t / nc), j = (uint32_t)(t % nc);
+        uint32_t i = largeList[l];
+        if (i == j) continue;
+        if (isLarge[j] && j < i) continue;
+        float4 amn = aabbMin[i], amx = aabbMax[i], bmn = aabbMin[j], bmx = aabbMax[j];
+        if (aabbOverlap(amn, amx, bmn, bmx)) emitPair(i, amn, amx, j, bmn, bmx, axis, pairKeys, pairCap, sc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Narrow phase: one lane per (bucket-sorted) collision pair; a wave is type-uniform except at bucket
+// boundaries.  Writes a fixed 4-slot manifold per pair; compaction happens by prefix sums.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ Shape loadShape(const float4* __restrict__ wShape, uint32_t k, uint32_t type) {
+    Shape s; s.type = (int)type; s.radius = 0.f; s.hull = 0;
+    float4 r0 = wShape[3 * k], r1 = wShape[3 * k + 1];
+    s.a = xyz(r0); s.b = xyz(r1);
+    if (type <= T_CYLINDER) s.radius = r0.w;
+    if (type >= T_OBB) s.rot = toQ(wShape[3 * k + 2]);
+    if (type == T_HULL) s.hull = __float_as_uint(r0.w);
+    return s;
+}
+
+struct HullSet { const float4* verts; const uint32_t* ranges; };  // vertex pool + [first,count] per geometry
+
+__device__ bool intersectGjk(const Shape& a, const Shape& b, const HullSet& hs, Manifold& out, int mode);  // gjk.hpp
+
+__device__ inline bool intersectPair(const Shape& a, const Shape& b, const HullSet& hs, Manifold& out) {
+    switch (a.type) {
+        case T_SPHERE:
+            switch (b.type) {
+                case T_SPHERE: return sphereSphere(a.a, a.radius, b.a, b.radius, out);
+                case T_CAPSULE: return sphereSphere(a.a, a.radius, closestOnSegment(a.a, b.a, b.b), b.radius, out);
+                case T_CYLINDER: return sphereCylinder(a.a, a.radius, b.a, b.b, b.radius, out);
+                case T_AABB: return sphereAABB(a.a, a.radius, b.a, b.b, out);
+                case T_OBB: return sphereOBB(a.a, a.radius, b.rot, b.a, b.b, out);
+                default: return intersectGjk(a, b, hs, out, 0);
+            }
+        case T_CAPSULE:
+            switch (b.type) {
+                case T_CAPSULE: return capsuleVsSegmentShape(a, b, false, out);
+                case T_CYLINDER: return capsuleVsSegmentShape(a, b, true, out);
+                case T_AABB: return intersectGjk(a, b, hs, out, 1);
+                case T_OBB: return intersectGjk(a, b, hs, out, 2);
+                default: return intersectGjk(a, b, hs, out, 0);
+            }
+        case T_CYLINDER:
+            switch (b.type) {
+                case T_CYLINDER: return intersectGjk(a, b, hs, out, 3);
+                case T_AABB: return intersectGjk(a, b, hs, out, 1);
+                case T_OBB: return intersectGjk(a, b, hs, out, 2);
+                default: return intersectGjk(a, b, hs, out, 0);
+            }
+        case T_AABB:
+            switch (b.type) {
+                case T_AABB: return aabbAABB(a.a, a.b, b.a, b.b, out);
+                case T_OBB: return obbOBB(Q4(0.f, 0.f, 0.f, 1.f), (a.a + a.b) * 0.5f, (a.b - a.a) * 0.5f, b.rot, b.a, b.b, out);
+                default: return intersectGjk(a, b, hs, out, 0);
+            }
+        case T_OBB:
+            if (b.type == T_OBB) return obbOBB(a.rot, a.a, a.b, b.rot, b.a, b.b, out);
+            return intersectGjk(a, b, hs, out, 0);
+        default:
+            return intersectGjk(a, b, hs, out, 0);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_narrow(uint32_t numPairs, const uint64_t* __restrict__ pairKeys, const float4* __restrict__ wShape,
+                                                HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
+                                                float4* __restrict__ npPoints) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= numPairs) return;
+    uint64_t key = pairKeys[p];
+    uint32_t bucket = (uint32_t)(key >> 58), a = (uint32_t)((key >> 29) & 0x1FFFFFFFu), b = (uint32_t)(key & 0x1FFFFFFFu);
+    // bucket -> (ta, tb)
+    uint32_t ta = 0, rem = bucket;
+    while (rem >= 6u - ta) { rem -= 6u - ta; ++ta; }
+    uint32_t tb = ta + rem;
+    Shape sa = loadShape(wShape, a, ta), sb = loadShape(wShape, b, tb);
+    Manifold m; m.count = 0;
+    bool hit = intersectPair(sa, sb, hs, m);
+    uint32_t cnt = hit ? m.count : 0u;
+    npPacked[p] = cnt ? ((1ull << 32) | (uint64_t)cnt) : 0ull;   // (manifold flag, contact count): one 64-bit scan compacts both
+    if (cnt) {
+        npNormal[p] = f4(m.n, 0.f);
+        for (uint32_t k = 0; k < cnt; ++k) npPoints[4 * p + k] = f4(m.p[k], m.d[k]);
+    }
+}
+
+// After the scans: manifold m <- pair p (count > 0).
+__global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t numPairs, const uint64_t* __restrict__ pairKeys, const uint64_t* __restrict__ npPacked,
+                                                        const uint64_t* __restrict__ npScan,
+                                                        const float4* __restrict__ aabbMax, const float4* __restrict__ cMaterial,
+                                                        uint32_t* __restrict__ manPair, uint2* __restrict__ manBodies, uint2* __restrict__ manInfo,
+                                                        StepScalars* sc) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= numPairs) return;
+    uint32_t cnt = (uint32_t)(npPacked[p] & 0xFFFFFFFFull);
+    uint64_t sc64 = npScan[p];
+    uint32_t m = (uint32_t)(sc64 >> 32), conOff = (uint32_t)(sc64 & 0xFFFFFFFFull);
+    if (p == numPairs - 1) { sc->numManifolds = m + (cnt ? 1u : 0u); sc->numContacts = conOff + cnt; }
+    if (!cnt) return;
+    uint64_t key = pairKeys[p];
+    uint32_t a = (uint32_t)((key >> 29) & 0x1FFFFFFFu), b = (uint32_t)(key & 0x1FFFFFFFu);
+    float4 ma = cMaterial[a], mb = cMaterial[b];   // (restitution, friction, density, -)
+    float friction = clamp01(sqrtf(ma.y * mb.y));                      // collision_narrow.cpp:2232-2238
+    float restitution = clamp01(fmaxr(ma.x, mb.x));
+    uint32_t fr = ((uint32_t)(friction * 0xFFFF) << 16) | (uint32_t)(restitution * 0xFFFF);
+    manPair[m] = p;
+    manBodies[m] = make_uint2(__float_as_uint(aabbMax[a].w), __float_as_uint(aabbMax[b].w));
+    manInfo[m] = make_uint2(cnt | (conOff << 3), fr);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Integrator
+// ------------------------------------------------------------------------------------------------
+// K9 "Integrate rigid body forces" (src/physics/rigid_body.cpp:95-124).  One lane per body; also
+// zeroes the dummy body (physics.cpp:1279).  in ~112 B, out 112 B per body.
+__global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
+                                                          const float4* __restrict__ bCogInvMass, const float4* __restrict__ bInvI,
+                                                          const float4* __restrict__ bParams, float4* __restrict__ bLinVel,
+                                                          float4* __restrict__ bAngVel, float4* __restrict__ bForce, const float4* __restrict__ bTorque,
+                                                          float4* __restrict__ gPos, float4* __restrict__ gInvI, float4* __restrict__ gVel) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nb) return;
+    if (i == nb) {
+        float4 z = make_float4(0, 0, 0, 0);
+        gPos[i] = z; gInvI[3 * i] = z; gInvI[3 * i + 1] = z; gInvI[3 * i + 2] = z; gVel[2 * i] = z; gVel[2 * i + 1] = z;
+        return;
+    }
+    Q4 rot = toQ(bRot[i]);
+    float4 ci = bCogInvMass[i];
+    V3 cog = xyz(ci); float invMass = ci.w;
+    V3 pos = xyz(bPos[i]) + rotate(rot, cog);
+    M3 R = quatToMat(rot);
+    float4 i0 = bInvI[3 * i], i1 = bInvI[3 * i + 1], i2 = bInvI[3 * i + 2];
+    M3 I; I.m00 = i0.x; I.m01 = i0.y; I.m02 = i0.z; I.m10 = i1.x; I.m11 = i1.y; I.m12 = i1.z; I.m20 = i2.x; I.m21 = i2.y; I.m22 = i2.z;
+    M3 W = mul(mul(R, I), transpose(R));
+    float4 prm = bParams[i];
+    V3 force = xyz(bForce[i]), torque = xyz(bTorque[i]);
+    if (invMass > 0.f) force.y += (kGravity / invMass * prm.x);
+    V3 linAcc = force * invMass;
+    V3 angAcc = mul(W, torque);
+    V3 v = xyz(bLinVel[i]), w = xyz(bAngVel[i]);
+    v = v + linAcc * dt;
+    w = w + angAcc * dt;
+    v = v * (1.f / (1.f + dt * prm.y));
+    w = w * (1.f / (1.f + dt * prm.z));
+    bLinVel[i] = f4(v, 0.f); bAngVel[i] = f4(w, 0.f);
+    bForce[i] = f4(force, 0.f);
+    gPos[i] = f4(pos, invMass);
+    gInvI[3 * i] = make_float4(W.m00, W.m01, W.m02, 0.f);
+    gInvI[3 * i + 1] = make_float4(W.m10, W.m11, W.m12, 0.f);
+    gInvI[3 * i + 2] = make_float4(W.m20, W.m21, W.m22, 0.f);
+    gVel[2 * i] = f4(v, invMass); gVel[2 * i + 1] = f4(w, 0.f);
+}
+
+// K13 "Integrate rigid body velocities" (src/physics/rigid_body.cpp:126-142).
+__global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float dt, const float4* __restrict__ gPos, const float4* __restrict__ gVel,
+                                                              const float4* __restrict__ bCogInvMass, float4* __restrict__ bPos, float4* __restrict__ bRot,
+                                                              float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, float4* __restrict__ bForce,
+                                                              float4* __restrict__ bTorque) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    V3 v = xyz(gVel[2 * i]), w = xyz(gVel[2 * i + 1]);
+    Q4 rot = toQ(bRot[i]);
+    Q4 dq(0.5f * w.x, 0.5f * w.y, 0.5f * w.z, 0.f);
+    dq = dq * rot;
+    Q4 nr = normalize(Q4(rot.x + dq.x * dt, rot.y + dq.y * dt, rot.z + dq.z * dt, rot.w + dq.w * dt));
+    V3 pos = xyz(gPos[i]) + v * dt;
+    V3 cog = xyz(bCogInvMass[i]);
+    bLinVel[i] = f4(v, 0.f); bAngVel[i] = f4(w, 0.f);
+    float4 z = make_float4(0, 0, 0, 0);
+    bForce[i] = z; bTorque[i] = z;
+    bRot[i] = fromQ(nr);
+    bPos[i] = f4(pos - rotate(nr, cog), 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_iota(uint32_t n, uint32_t* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = i;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Contact schedule: Jones-Plassmann colouring of the manifold graph (replaces the serial greedy
+// scheduleConstraintsSIMD, src/physics/constraints.cpp:51-184).  Two manifolds conflict when they
+// share a body with invMass != 0 (the reference exempts its dummy body, constraints.cpp:81-83).
+// Priority = hash32(manifold index) (unique); a manifold colours itself once it is the top-priority
+// uncoloured manifold on both of its bodies, taking the lowest colour free on both.  The result
+// equals sequential greedy colouring in descending priority order, which is what the oracle runs.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_color_propose(uint32_t nm, uint32_t round, const uint2* __restrict__ manBodies, const float4* __restrict__ gPos,
+                                                       const uint32_t* __restrict__ color, unsigned long long* __restrict__ bodyTop) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nm || color[m] != kUncolored) return;
+    uint2 b = manBodies[m];
+    unsigned long long key = ((unsigned long long)(round + 1) << 32) | hash32(m);
+    if (gPos[b.x].w != 0.f) atomicMax(&bodyTop[b.x], key);
+    if (gPos[b.y].w != 0.f) atomicMax(&bodyTop[b.y], key);
+}
+__global__ __launch_bounds__(256) void k_color_commit(uint32_t nm, uint32_t round, const uint2* __restrict__ manBodies, const float4* __restrict__ gPos,
+                                                      uint32_t* __restrict__ color, const unsigned long long* __restrict__ bodyTop,
+                                                      unsigned long long* __restrict__ bodyUsed, StepScalars* sc) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= nm || color[m] != kUncolored) return;
+    uint2 b = manBodies[m];
+    unsigned long long key = ((unsigned long long)(round + 1) << 32) | hash32(m);
+    bool dynA = gPos[b.x].w != 0.f, dynB = gPos[b.y].w != 0.f;
+    if ((dynA && bodyTop[b.x] != key) || (dynB && bodyTop[b.y] != key)) { atomicAdd(&sc->uncolored, 1u); return; }
+    unsigned long long mask = (dynA ? bodyUsed[b.x] : 0ull) | (dynB ? bodyUsed[b.y] : 0ull);
+    uint32_t c = kOverflowColor;
+    if (~mask != 0ull) {
+        c = (uint32_t)__ffsll((long long)~mask) - 1u;
+        if (dynA) bodyUsed[b.x] |= (1ull << c);
+        if (dynB) bodyUsed[b.y] |= (1ull << c);
+    }
+    color[m] = c;
+    atomicAdd(&sc->colorHist[c], 1u);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Contact constraints.  Slot s = position of a manifold in colour-sorted order.  Constraint rows
+// are planes [contact k][row r][slot s] of float4, so a wave reads 64 consecutive float4 per row.
+//   r0 = (rA, effMassN)  r1 = (rB, effMassT)  r2 = (tangent, bias)  r3 = (normal, friction)
+//   r4 = I_A^-1 (rA x t)  r5 = I_B^-1 (rB x t)  r6 = I_A^-1 (rA x n)  r7 = I_B^-1 (rB x n)
+// Accumulated impulses (normal, tangent) live in their own float2 plane (the only rows rewritten).
+// ------------------------------------------------------------------------------------------------
+constexpr uint32_t kRows = 8;
+
+__device__ __forceinline__ M3 loadM3(const float4* __restrict__ p, uint32_t i) {
+    float4 a = p[3 * i], b = p[3 * i + 1], c = p[3 * i + 2];
+    M3 m; m.m00 = a.x; m.m01 = a.y; m.m02 = a.z; m.m10 = b.x; m.m11 = b.y; m.m12 = b.z; m.m20 = c.x; m.m21 = c.y; m.m22 = c.z;
+    return m;
+}
+
+// K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379), one lane per slot.
+__global__ __launch_bounds__(256) void k_contact_init(uint32_t nm, uint32_t cap, float dt, const uint32_t* __restrict__ order,
+                                                      const uint32_t* __restrict__ manPair, const uint2* __restrict__ manBodies,
+                                                      const uint2* __restrict__ manInfo, const float4* __restrict__ npNormal,
+                                                      const float4* __restrict__ npPoints, const float4* __restrict__ gPos,
+                                                      const float4* __restrict__ gInvI, const float4* __restrict__ gVel,
+                                                      float4* __restrict__ rows, float2* __restrict__ imp, uint4* __restrict__ slotMeta) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nm) return;
+    uint32_t m = order[s];
+    uint32_t p = manPair[m];
+    uint2 bodies = manBodies[m];
+    uint2 info = manInfo[m];
+    uint32_t cnt = info.x & 7u;
+    slotMeta[s] = make_uint4(bodies.x, bodies.y, cnt, info.y);
+    float4 pa = gPos[bodies.x], pb = gPos[bodies.y];
+    V3 xA = xyz(pa), xB = xyz(pb);
+    float imA = pa.w, imB = pb.w;
+    M3 IA = loadM3(gInvI, bodies.x), IB = loadM3(gInvI, bodies.y);
+    V3 vA = xyz(gVel[2 * bodies.x]), wA = xyz(gVel[2 * bodies.x + 1]);
+    V3 vB = xyz(gVel[2 * bodies.y]), wB = xyz(gVel[2 * bodies.y + 1]);
+    V3 n = xyz(npNormal[p]);
+    float invDt = 1.f / dt;
+    float friction = (float)(info.y >> 16) / (float)0xFFFF;
+    float restitution = (float)(info.y & 0xFFFF) / (float)0xFFFF;
+    for (uint32_t k = 0; k < cnt; ++k) {
+        float4 pd = npPoints[4 * p + k];
+        V3 point = xyz(pd); float depth = pd.w;
+        V3 rA = point - xA, rB = point - xB;
+        V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
+        V3 rel = avB - avA;
+        V3 t = rel - dot(n, rel) * n;
+        t = noz(t);
+        V3 crAt = cross(rA, t), crBt = cross(rB, t);
+        V3 tA = mul(IA, crAt), tB = mul(IB, crBt);
+        float invMT = imA + dot(crAt, tA) + imB + dot(crBt, tB);
+        float effT = (invMT != 0.f) ? (1.f / invMT) : 0.f;
+        V3 crAn = cross(rA, n), crBn = cross(rB, n);
+        V3 nA = mul(IA, crAn), nB = mul(IB, crBn);
+        float invMN = imA + dot(crAn, nA) + imB + dot(crBn, nB);
+        float effN = (invMN != 0.f) ? (1.f / invMN) : 0.f;
+        float bias = 0.f;
+        if (dt > 1e-5f) {
+            float vRel = dot(n, rel);
+            const float slop = -0.001f;
+            if (-depth < slop && vRel < 0.f) bias = -restitution * vRel - 0.1f * (-depth - slop) * invDt;
+        }
+        size_t base = (size_t)k * kRows * cap + s;
+        rows[base + 0 * (size_t)cap] = f4(rA, effN);
+        rows[base + 1 * (size_t)cap] = f4(rB, effT);
+        rows[base + 2 * (size_t)cap] = f4(t, bias);
+        rows[base + 3 * (size_t)cap] = f4(n, friction);
+        rows[base + 4 * (size_t)cap] = f4(tA, 0.f);
+        rows[base + 5 * (size_t)cap] = f4(tB, 0.f);
+        rows[base + 6 * (size_t)cap] = f4(nA, 0.f);
+        rows[base + 7 * (size_t)cap] = f4(nB, 0.f);
+        imp[(size_t)k * cap + s] = make_float2(0.f, 0.f);
+    }
+}
+
+// One PGS update of the contacts of slot s (src/physics/constraints.cpp:3381-3449): friction first
+// (clamped with the previous normal impulse), then the normal row.
+__device__ __forceinline__ void solveSlot(uint32_t s, uint32_t cap, const uint4 meta, const float4* __restrict__ rows, float2* __restrict__ imp,
+                                          float4* __restrict__ gVel) {
+    uint32_t bA = meta.x, bB = meta.y, cnt = meta.z;
+    float4 a0 = gVel[2 * bA], a1 = gVel[2 * bA + 1], b0 = gVel[2 * bB], b1 = gVel[2 * bB + 1];
+    float imA = a0.w, imB = b0.w;
+    if (imA == 0.f && imB == 0.f) return;
+    V3 vA = xyz(a0), wA = xyz(a1), vB = xyz(b0), wB = xyz(b1);
+    for (uint32_t k = 0; k < cnt; ++k) {
+        size_t base = (size_t)k * kRows * cap + s;
+        float4 r0 = rows[base], r1 = rows[base + (size_t)cap], r2 = rows[base + 2 * (size_t)cap], r3 = rows[base + 3 * (size_t)cap];
+        float4 r4 = rows[base + 4 * (size_t)cap], r5 = rows[base + 5 * (size_t)cap], r6 = rows[base + 6 * (size_t)cap], r7 = rows[base + 7 * (size_t)cap];
+        float2 im = imp[(size_t)k * cap + s];
+        V3 rA = xyz(r0), rB = xyz(r1), t = xyz(r2), n = xyz(r3);
+        {
+            V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
+            V3 rel = avB - avA;
+            float vt = dot(rel, t);
+            float lambda = -r1.w * vt;
+            float maxF = r3.w * im.x;
+            float ni = clampr(im.y + lambda, -maxF, maxF);
+            lambda = ni - im.y;
+            im.y = ni;
+            V3 P = lambda * t;
+            vA = vA - imA * P;
+            wA = wA - xyz(r4) * lambda;
+            vB = vB + imB * P;
+            wB = wB + xyz(r5) * lambda;
+        }
+        {
+            V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
+            V3 rel = avB - avA;
+            float vn = dot(rel, n);
+            float lambda = -r0.w * (vn - r2.w);
+            float ni = fmaxr(im.x + lambda, 0.f);
+            lambda = ni - im.x;
+            im.x = ni;
+            V3 P = lambda * n;
+            vA = vA - imA * P;
+            wA = wA - xyz(r6) * lambda;
+            vB = vB + imB * P;
+            wB = wB + xyz(r7) * lambda;
+        }
+        imp[(size_t)k * cap + s] = im;
+    }
+    if (imA != 0.f) { gVel[2 * bA] = f4(vA, imA); gVel[2 * bA + 1] = f4(wA, 0.f); }
+    if (imB != 0.f) { gVel[2 * bB] = f4(vB, imB); gVel[2 * bB + 1] = f4(wB, 0.f); }
+}
+
+// K12 "Solve collision constraints": one launch per colour; lanes own disjoint dynamic bodies.
+__global__ __launch_bounds__(256) void k_contact_solve(uint32_t s0, uint32_t s1, uint32_t cap, const uint4* __restrict__ slotMeta,
+                                                       const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+    uint32_t s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= s1) return;
+    solveSlot(s, cap, slotMeta[s], rows, imp, gVel);
+}
+// Overflow colour (a body with > 64 incident manifolds): sequential, one lane.
+__global__ void k_contact_solve_serial(uint32_t s0, uint32_t s1, uint32_t cap, const uint4* __restrict__ slotMeta,
+                                       const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (uint32_t s = s0; s < s1; ++s) { solveSlot(s, cap, slotMeta[s], rows, imp, gVel); __threadfence(); }
+}
+
+}  // namespace mi

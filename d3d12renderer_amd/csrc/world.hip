@@ -1,0 +1,748 @@
+// world.hip — host side of the MI355X rigid-body stepper: scene storage, per-step orchestration of
+// the HIP kernels (kernels.hpp) on a world-owned stream, and the C ABI of include/mi_physics.h.
+//
+// Replaces physicsStep / physicsStepInternal (src/physics/physics.cpp:1180-1413) and the scene
+// hooks that feed it (src/scene/scene.h:35-112).  There is NO CPU fallback: without a HIP device
+// mi_world_create fails with MI_ERR_NO_DEVICE.
+#include <cstring>
+#include <cstdio>
+#include <cmath>
+#include <string.h>
+#include <vector>
+#include <string>
+#include <algorithm>
+#include <hip/hip_runtime.h>
+#include <rocprim/rocprim.hpp>
+
+#include "../../include/mi_physics.h"
+#include "../../include/mi_constraints.h"
+#include "kernels.hpp"
+#include "gjk.hpp"
+#include "joints.hpp"
+
+using namespace mi;
+
+static thread_local std::string g_lastError;
+static int fail(int code, const std::string& msg) { g_lastError = msg; return code; }
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(MI_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Device buffer (grow-only)
+// ------------------------------------------------------------------------------------------------
+template <typename T>
+struct DBuf {
+    T* p = nullptr;
+    size_t cap = 0;
+    ~DBuf() { if (p) (void)hipFree(p); }
+    hipError_t ensure(size_t n, bool keep = false, hipStream_t st = nullptr) {
+        if (n <= cap) return hipSuccess;
+        size_t ncap = std::max(n, cap + cap / 2);
+        T* np = nullptr;
+        hipError_t e = hipMalloc((void**)&np, ncap * sizeof(T));
+        if (e != hipSuccess) return e;
+        if (keep && p && cap) { e = hipMemcpyAsync(np, p, cap * sizeof(T), hipMemcpyDeviceToDevice, st); if (e != hipSuccess) return e; (void)hipStreamSynchronize(st); }
+        if (p) (void)hipFree(p);
+        p = np; cap = ncap;
+        return hipSuccess;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Host scene storage
+// ------------------------------------------------------------------------------------------------
+struct HEntity { V3 pos; Q4 rot; uint32_t kind; int rb = -1; std::vector<uint32_t> colliders; /* newest first */ };
+struct HBody {
+    uint32_t entity;
+    V3 localCOG; float invMass; M3 invInertia;
+    float gravityFactor, linDamp, angDamp;
+    V3 linVel, angVel, force, torque;
+    V3 p0, p1; Q4 r0, r1;
+};
+struct HCollider { uint32_t entity; mi_collider_desc desc; };
+struct HHull { std::vector<V3> verts; std::vector<uint32_t> tris; V3 mn, mx; };
+struct MassProps { M3 inertia; V3 cog; float mass; };
+
+static uint32_t divUp(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+struct mi_world {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<HEntity> entities;
+    std::vector<HBody> bodies;
+    std::vector<HCollider> colliders;   // creation order
+    std::vector<HHull> hulls;
+    JointSet joints;
+    bool topologyDirty = true;   // entities/colliders changed -> re-upload everything
+    bool hostStale = false;      // device holds newer body state than host
+    float timer = 0.f;
+
+    // device: bodies
+    DBuf<float4> bPos, bRot, bLinVel, bAngVel, bForce, bTorque, bCogInvMass, bInvI, bParams;
+    DBuf<float4> gPos, gInvI, gVel;
+    // device: colliders
+    DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cMaterial;
+    DBuf<float4> wShape, aabbMin, aabbMax, hullAabb, hullVerts; DBuf<uint32_t> hullRanges;
+    // broad phase
+    DBuf<double> axisPartials;
+    DBuf<uint32_t> largeList, isLarge, cellKeys, cellVals, cellKeysS, cellValsS, cellStart, cellEnd;
+    DBuf<float4> sMin, sMax;
+    DBuf<GridParams> grid; DBuf<StepScalars> scalars;
+    DBuf<uint64_t> pairKeys, pairKeysS;
+    DBuf<char> temp;
+    // narrow phase
+    DBuf<uint64_t> npPacked, npScan; DBuf<float4> npNormal, npPoints;
+    DBuf<uint32_t> manPair; DBuf<uint2> manBodies, manInfo;
+    // schedule + solver
+    DBuf<uint32_t> color, colorS, order, orderS; DBuf<unsigned long long> bodyTop, bodyUsed;
+    DBuf<float4> rows; DBuf<float2> imp; DBuf<uint4> slotMeta;
+
+    StepScalars hs{};            // host copy of the last step's scalars
+    mi_step_counts counts{};
+    mi_stage_times times{};
+    hipEvent_t ev[10]{};
+    uint32_t numColorsUsed = 0;
+    std::vector<uint32_t> colorOffsets;
+
+    int init(int dev);
+    ~mi_world();
+    int recalcProperties();
+    int upload();
+    int download();
+    int stepInternal(const mi_step_settings& s, float dt);
+    int ensureTemp(size_t bytes) { return temp.ensure(bytes) == hipSuccess ? MI_OK : MI_ERR_OUT_OF_MEMORY; }
+};
+
+int mi_world::init(int dev) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(MI_ERR_NO_DEVICE, "no HIP device visible: the stepper has no CPU fallback");
+    if (dev < 0 || dev >= n) return fail(MI_ERR_INVALID_ARGUMENT, "device ordinal out of range");
+    device = dev;
+    HIP_TRY(hipSetDevice(dev));
+    HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    HIP_TRY(scalars.ensure(1));
+    HIP_TRY(grid.ensure(1));
+    HIP_TRY(hipMemsetAsync(scalars.p, 0, sizeof(StepScalars), stream));
+    return MI_OK;
+}
+mi_world::~mi_world() {
+    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Mass properties (setup time; src/physics/physics.cpp:1416-1588, src/physics/rigid_body.cpp:29-81)
+// ------------------------------------------------------------------------------------------------
+static float sphereVol(float r) { float sq = r * r; float sqpi = kPi * sq; return 4.f / 3.f * sqpi * r; }
+
+static MassProps colliderMassProps(const mi_world& w, const mi_collider_desc& d) {
+    MassProps r; r.inertia = M3::zero(); r.mass = 0.f;
+    const float* f = d.shape;
+    float density = d.density;
+    switch (d.type) {
+        case T_SPHERE: {
+            float rad = f[3];
+            r.mass = sphereVol(rad) * density;
+            r.cog = V3(f[0], f[1], f[2]);
+            r.inertia = scale(M3::identity(), 2.f / 5.f * r.mass * rad * rad);
+        } break;
+        case T_CAPSULE: case T_CYLINDER: {
+            V3 a(f[0], f[1], f[2]), b(f[3], f[4], f[5]); float rad = f[6];
+            V3 axis = a - b;
+            if (axis.y < 0.f) axis = axis * -1.f;
+            float height = len(axis);
+            axis = axis * (1.f / height);
+            M3 rot = quatToMat(rotateFromTo(V3(0.f, 1.f, 0.f), axis));
+            float sqR = rad * rad;
+            M3 I = M3::zero();
+            if (d.type == T_CAPSULE) {
+                float sqRpi = kPi * sqR;
+                float volume = (4.f / 3.f * sqRpi * rad) + (sqRpi * len(a - b));
+                r.mass = volume * density;
+                float cylMass = density * sqRpi * height;
+                float hemiMass = density * 2.f / 3.f * sqRpi * rad;
+                float sqH = height * height;
+                I.m11 = sqR * cylMass * 0.5f;
+                I.m00 = I.m22 = I.m11 * 0.5f + cylMass * sqH / 12.f;
+                float t0 = hemiMass * 2.f * sqR / 5.f;
+                I.m11 += t0 * 2.f;
+                float t1 = height * 0.5f;
+                float t2 = t0 + hemiMass * (t1 * t1 + 3.f / 8.f * sqH);
+                I.m00 += t2 * 2.f;
+                I.m22 += t2 * 2.f;
+            } else {
+                float volume = (kPi * rad * rad) * len(a - b);
+                r.mass = volume * density;
+                float sqH = height * height;
+                I.m11 = sqR * r.mass * 0.5f;
+                I.m00 = I.m22 = 1.f / 12.f * r.mass * (3.f * sqR + sqH);
+            }
+            r.cog = (a + b) * 0.5f;
+            r.inertia = mul(mul(transpose(rot), I), rot);
+        } break;
+        case T_AABB: {
+            V3 mn(f[0], f[1], f[2]), mx(f[3], f[4], f[5]);
+            V3 d0 = mx - mn;
+            r.mass = (d0.x * d0.y * d0.z) * density;
+            r.cog = (mn + mx) * 0.5f;
+            V3 dia = ((mx - mn) * 0.5f) * 2.f;
+            r.inertia.m00 = 1.f / 12.f * r.mass * (dia.y * dia.y + dia.z * dia.z);
+            r.inertia.m11 = 1.f / 12.f * r.mass * (dia.x * dia.x + dia.z * dia.z);
+            r.inertia.m22 = 1.f / 12.f * r.mass * (dia.x * dia.x + dia.y * dia.y);
+        } break;
+        case T_OBB: {
+            Q4 q(f[0], f[1], f[2], f[3]); V3 c(f[4], f[5], f[6]), rad(f[7], f[8], f[9]);
+            V3 dia = rad * 2.f;
+            r.mass = (dia.x * dia.y * dia.z) * density;
+            r.cog = c;
+            M3 I = M3::zero();
+            I.m00 = 1.f / 12.f * r.mass * (dia.y * dia.y + dia.z * dia.z);
+            I.m11 = 1.f / 12.f * r.mass * (dia.x * dia.x + dia.z * dia.z);
+            I.m22 = 1.f / 12.f * r.mass * (dia.x * dia.x + dia.y * dia.y);
+            M3 rot = quatToMat(q);
+            r.inertia = mul(mul(transpose(rot), I), rot);
+        } break;
+        default: {  // hull: tetrahedron covariance sum (physics.cpp:1517-1579)
+            Q4 q(f[0], f[1], f[2], f[3]); V3 pos(f[4], f[5], f[6]);
+            const HHull& g = w.hulls[d.hull_geometry];
+            const float s60 = 1.f / 60.f, s120 = 1.f / 120.f;
+            M3 Cc; Cc.m00 = s60; Cc.m01 = s120; Cc.m02 = s120; Cc.m10 = s120; Cc.m11 = s60; Cc.m12 = s120; Cc.m20 = s120; Cc.m21 = s120; Cc.m22 = s60;
+            float totalMass = 0.f; M3 totalCov = M3::zero(); V3 totalCOG;
+            for (size_t t = 0; t + 2 < g.tris.size(); t += 3) {
+                V3 w1 = pos + rotate(q, g.verts[g.tris[t]]), w2 = pos + rotate(q, g.verts[g.tris[t + 1]]), w3 = pos + rotate(q, g.verts[g.tris[t + 2]]);
+                M3 A; A.m00 = w1.x; A.m01 = w2.x; A.m02 = w3.x; A.m10 = w1.y; A.m11 = w2.y; A.m12 = w3.y; A.m20 = w1.z; A.m21 = w2.z; A.m22 = w3.z;
+                float dA = det(A);
+                M3 cov = mul(mul(scale(A, dA), Cc), transpose(A));
+                float mass = 1.f / 6.f * dA;
+                V3 cog = (w1 + w2 + w3) * 0.25f;
+                totalMass += mass;
+                totalCov = add(totalCov, cov);
+                totalCOG = totalCOG + cog * mass;
+            }
+            totalCOG = totalCOG / totalMass;
+            M3 Cp = sub(totalCov, scale(outer(totalCOG, totalCOG), totalMass));
+            r.cog = totalCOG;
+            r.mass = totalMass * density;
+            float tr = Cp.m00 + Cp.m11 + Cp.m22;
+            r.inertia = sub(scale(M3::identity(), tr), Cp);
+            r.inertia = scale(r.inertia, density);
+        } break;
+    }
+    return r;
+}
+
+int mi_world::recalcProperties() {
+    for (HBody& rb : bodies) {
+        if (entities[rb.entity].kind == MI_ENTITY_KINEMATIC) continue;
+        const HEntity& e = entities[rb.entity];
+        size_t n = e.colliders.size();
+        if (!n) { rb.invMass = 1.f; rb.invInertia = M3::identity(); rb.localCOG = V3(); continue; }
+        std::vector<MassProps> props(n);
+        for (size_t i = 0; i < n; ++i) props[i] = colliderMassProps(*this, colliders[e.colliders[i]].desc);
+        M3 inertia = M3::zero(); V3 cog; float mass = 0.f;
+        for (size_t i = 0; i < n; ++i) { mass += props[i].mass; cog = cog + props[i].cog * props[i].mass; }
+        rb.invMass = 1.f / mass;
+        rb.localCOG = cog = cog * rb.invMass;
+        for (size_t i = 0; i < n; ++i) {
+            V3 r = props[i].cog - cog;
+            M3 shift = scale(sub(scale(M3::identity(), dot(r, r)), outer(r, r)), props[i].mass);
+            inertia = add(inertia, add(props[i].inertia, shift));
+        }
+        rb.invInertia = invert(inertia);
+    }
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Upload / download
+// ------------------------------------------------------------------------------------------------
+static float4 h4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
+
+int mi_world::upload() {
+    recalcProperties();
+    uint32_t nb = (uint32_t)bodies.size(), nc = (uint32_t)colliders.size();
+    std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), fo(nb), to(nb), cim(nb), ii(3 * (size_t)nb), prm(nb);
+    for (uint32_t i = 0; i < nb; ++i) {
+        const HBody& b = bodies[i];
+        pos[i] = h4(b.p1, 0.f); rot[i] = make_float4(b.r1.x, b.r1.y, b.r1.z, b.r1.w);
+        lv[i] = h4(b.linVel, 0.f); av[i] = h4(b.angVel, 0.f); fo[i] = h4(b.force, 0.f); to[i] = h4(b.torque, 0.f);
+        cim[i] = h4(b.localCOG, b.invMass);
+        const M3& m = b.invInertia;
+        ii[3 * i] = make_float4(m.m00, m.m01, m.m02, 0.f); ii[3 * i + 1] = make_float4(m.m10, m.m11, m.m12, 0.f); ii[3 * i + 2] = make_float4(m.m20, m.m21, m.m22, 0.f);
+        prm[i] = make_float4(b.gravityFactor, b.linDamp, b.angDamp, 0.f);
+    }
+#define UP(buf, vec, count)                                                                                  \
+    do {                                                                                                      \
+        HIP_TRY(buf.ensure(std::max<size_t>((count), 1)));                                                    \
+        if (count) HIP_TRY(hipMemcpyAsync(buf.p, vec.data(), (count) * sizeof(vec[0]), hipMemcpyHostToDevice, stream)); \
+    } while (0)
+    UP(bPos, pos, nb); UP(bRot, rot, nb); UP(bLinVel, lv, nb); UP(bAngVel, av, nb); UP(bForce, fo, nb); UP(bTorque, to, nb);
+    UP(bCogInvMass, cim, nb); UP(bInvI, ii, 3 * (size_t)nb); UP(bParams, prm, nb);
+    HIP_TRY(gPos.ensure(nb + 1)); HIP_TRY(gInvI.ensure(3 * ((size_t)nb + 1))); HIP_TRY(gVel.ensure(2 * ((size_t)nb + 1)));
+    HIP_TRY(bodyTop.ensure(nb + 1)); HIP_TRY(bodyUsed.ensure(nb + 1));
+
+    std::vector<uint32_t> tb(2 * (size_t)nc); std::vector<float4> sh(3 * (size_t)nc), sp(nc), sr(nc), mat(nc);
+    for (uint32_t k = 0; k < nc; ++k) {   // world index k <-> creation index nc-1-k (EnTT iterates back to front, physics.cpp:635-641)
+        const HCollider& c = colliders[nc - 1 - k];
+        const HEntity& e = entities[c.entity];
+        tb[2 * k] = c.desc.type; tb[2 * k + 1] = e.rb >= 0 ? (uint32_t)e.rb : kNoBody;
+        float s[12]; std::memcpy(s, c.desc.shape, sizeof(s));
+        if (c.desc.type == T_HULL) std::memcpy(&s[7], &c.desc.hull_geometry, 4);
+        sh[3 * k] = make_float4(s[0], s[1], s[2], s[3]); sh[3 * k + 1] = make_float4(s[4], s[5], s[6], s[7]); sh[3 * k + 2] = make_float4(s[8], s[9], s[10], s[11]);
+        sp[k] = h4(e.pos, 0.f); sr[k] = make_float4(e.rot.x, e.rot.y, e.rot.z, e.rot.w);
+        mat[k] = make_float4(c.desc.restitution, c.desc.friction, c.desc.density, 0.f);
+    }
+    UP(cTypeBody, tb, 2 * (size_t)nc); UP(cShape, sh, 3 * (size_t)nc); UP(cStaticPos, sp, nc); UP(cStaticRot, sr, nc); UP(cMaterial, mat, nc);
+    HIP_TRY(wShape.ensure(3 * (size_t)nc + 1)); HIP_TRY(aabbMin.ensure(nc + 1)); HIP_TRY(aabbMax.ensure(nc + 1));
+    HIP_TRY(sMin.ensure(nc + 1)); HIP_TRY(sMax.ensure(nc + 1));
+    HIP_TRY(largeList.ensure(nc + 1)); HIP_TRY(isLarge.ensure(nc + 1));
+    HIP_TRY(cellKeys.ensure(nc + 1)); HIP_TRY(cellVals.ensure(nc + 1)); HIP_TRY(cellKeysS.ensure(nc + 1)); HIP_TRY(cellValsS.ensure(nc + 1));
+    HIP_TRY(cellStart.ensure(kMaxCells)); HIP_TRY(cellEnd.ensure(kMaxCells));
+    HIP_TRY(axisPartials.ensure(6 * (size_t)divUp(std::max(nc, 1u), 256)));
+    // hull geometry pool
+    std::vector<float4> ha(2 * hulls.size() + 1), hv; std::vector<uint32_t> hr(2 * hulls.size() + 2);
+    for (size_t h = 0; h < hulls.size(); ++h) {
+        ha[2 * h] = h4(hulls[h].mn, 0.f); ha[2 * h + 1] = h4(hulls[h].mx, 0.f);
+        hr[2 * h] = (uint32_t)hv.size(); hr[2 * h + 1] = (uint32_t)hulls[h].verts.size();
+        for (const V3& v : hulls[h].verts) hv.push_back(h4(v, 0.f));
+    }
+    if (hv.empty()) hv.push_back(make_float4(0, 0, 0, 0));
+    UP(hullAabb, ha, ha.size()); UP(hullVerts, hv, hv.size()); UP(hullRanges, hr, hr.size());
+#undef UP
+    int rc = joints.upload(*this, stream);
+    if (rc != MI_OK) return rc;
+    HIP_TRY(hipStreamSynchronize(stream));
+    topologyDirty = false; hostStale = false;
+    return MI_OK;
+}
+
+int mi_world::download() {
+    if (!hostStale) return MI_OK;
+    uint32_t nb = (uint32_t)bodies.size();
+    if (nb) {
+        std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), fo(nb), to(nb);
+        HIP_TRY(hipMemcpyAsync(pos.data(), bPos.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(rot.data(), bRot.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(lv.data(), bLinVel.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(av.data(), bAngVel.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(fo.data(), bForce.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(to.data(), bTorque.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        for (uint32_t i = 0; i < nb; ++i) {
+            HBody& b = bodies[i];
+            b.p1 = V3(pos[i].x, pos[i].y, pos[i].z); b.r1 = Q4(rot[i].x, rot[i].y, rot[i].z, rot[i].w);
+            b.linVel = V3(lv[i].x, lv[i].y, lv[i].z); b.angVel = V3(av[i].x, av[i].y, av[i].z);
+            b.force = V3(fo[i].x, fo[i].y, fo[i].z); b.torque = V3(to[i].x, to[i].y, to[i].z);
+        }
+    }
+    hostStale = false;
+    return MI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// One internal step (physicsStepInternal, src/physics/physics.cpp:1180-1362)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_reset_scalars(StepScalars* sc) {
+    uint32_t t = threadIdx.x;
+    if (t == 0) {
+        sc->extentSum = 0.0; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->uncolored = 0;
+        for (int a = 0; a < 3; ++a) { sc->boundsMin[a] = 0x7FFFFFFF; sc->boundsMax[a] = (int)0x80000000; }
+    }
+    if (t <= kOverflowColor) sc->colorHist[t] = 0;
+}
+__global__ void k_zero_u32(uint32_t* p) { *p = 0; }
+
+int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
+    HIP_TRY(hipSetDevice(device));
+    if (topologyDirty) { int rc = download(); if (rc != MI_OK) return rc; rc = upload(); if (rc != MI_OK) return rc; }
+    const uint32_t nb = (uint32_t)bodies.size(), nc = (uint32_t)colliders.size();
+    if (nb == 0) return MI_OK;
+    const uint32_t B = 256;
+    StepScalars* sc = scalars.p;
+    hipStream_t st = stream;
+    int evi = 0;
+    auto mark = [&]() { (void)hipEventRecord(ev[evi++], st); };
+
+    mark();  // 0
+    k_reset_scalars<<<1, 128, 0, st>>>(sc);
+    uint32_t numPairs = 0;
+    if (nc) {
+        k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
+                                                     wShape.p, aabbMin.p, aabbMax.p, sc);
+    }
+    mark();  // 1
+    if (nc) {
+        uint32_t nblk = divUp(nc, 256);
+        k_axis_partials<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, axisPartials.p, sc);
+        k_bp_classify<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, sc, largeList.p, isLarge.p);
+        k_bp_grid_setup<<<1, 1, 0, st>>>(nc, sc, grid.p);
+        k_bp_cell_ids<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, isLarge.p, grid.p, cellKeys.p, cellVals.p);
+        size_t tb = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, cellKeys.p, cellKeysS.p, cellVals.p, cellValsS.p, nc, 0, 32, st));
+        if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
+        HIP_TRY(rocprim::radix_sort_pairs(temp.p, tb, cellKeys.p, cellKeysS.p, cellVals.p, cellValsS.p, nc, 0, 32, st));
+        k_bp_clear_cells<<<1024, B, 0, st>>>(grid.p, cellStart.p);
+        k_bp_cell_bounds<<<divUp(nc, B), B, 0, st>>>(nc, cellKeysS.p, cellValsS.p, aabbMin.p, aabbMax.p, sMin.p, sMax.p, cellStart.p, cellEnd.p);
+        if (pairKeys.cap == 0) { HIP_TRY(pairKeys.ensure(std::max<size_t>(1u << 16, 8 * (size_t)nc))); }
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            uint32_t cap = (uint32_t)std::min<size_t>(pairKeys.cap, 0x7FFFFFFFu);
+            k_bp_pairs_grid<<<divUp(nc, B), B, 0, st>>>(nc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellStart.p, cellEnd.p, grid.p, pairKeys.p, cap, sc);
+            k_bp_pairs_large<<<2048, B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc);
+            HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            numPairs = hs.numPairs;
+            if (numPairs <= cap) break;
+            HIP_TRY(pairKeys.ensure((size_t)numPairs + numPairs / 4));   // overflow: grow and redo the pair pass
+            k_zero_u32<<<1, 1, 0, st>>>(&sc->numPairs);
+            k_zero_u32<<<1, 1, 0, st>>>(&sc->numOverlaps);
+        }
+        k_axis_final<<<1, 1, 0, st>>>(nc, nblk, axisPartials.p, sc);
+    }
+    mark();  // 2
+    uint32_t nm = 0, ncon = 0;
+    if (numPairs) {
+        HIP_TRY(pairKeysS.ensure(pairKeys.cap));
+        size_t tb = 0;
+        HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, pairKeys.p, pairKeysS.p, numPairs, 0, 64, st));
+        if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
+        HIP_TRY(rocprim::radix_sort_keys(temp.p, tb, pairKeys.p, pairKeysS.p, numPairs, 0, 64, st));
+        HIP_TRY(npPacked.ensure(numPairs)); HIP_TRY(npScan.ensure(numPairs)); HIP_TRY(npNormal.ensure(numPairs)); HIP_TRY(npPoints.ensure(4 * (size_t)numPairs));
+        HIP_TRY(manPair.ensure(numPairs)); HIP_TRY(manBodies.ensure(numPairs)); HIP_TRY(manInfo.ensure(numPairs));
+        HullSet hset{hullVerts.p, hullRanges.p};
+        k_narrow<<<divUp(numPairs, B), B, 0, st>>>(numPairs, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
+        tb = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, tb, npPacked.p, npScan.p, (uint64_t)0, numPairs, rocprim::plus<uint64_t>(), st));
+        if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
+        HIP_TRY(rocprim::exclusive_scan(temp.p, tb, npPacked.p, npScan.p, (uint64_t)0, numPairs, rocprim::plus<uint64_t>(), st));
+        k_emit_manifolds<<<divUp(numPairs, B), B, 0, st>>>(numPairs, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p,
+                                                         manPair.p, manBodies.p, manInfo.p, sc);
+    }
+    mark();  // 3
+    k_integrate_forces<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p,
+                                                       gPos.p, gInvI.p, gVel.p);
+    mark();  // 4
+    numColorsUsed = 0;
+    colorOffsets.assign(kOverflowColor + 2, 0);
+    if (numPairs) {
+        HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        nm = hs.numManifolds; ncon = hs.numContacts;
+    }
+    if (nm) {
+        HIP_TRY(color.ensure(nm)); HIP_TRY(colorS.ensure(nm)); HIP_TRY(order.ensure(nm)); HIP_TRY(orderS.ensure(nm));
+        HIP_TRY(hipMemsetAsync(color.p, 0xFF, nm * sizeof(uint32_t), st));   // 0xFFFFFFFF & 0xFF... see k_color_* (compare on low byte)
+        HIP_TRY(hipMemsetAsync(bodyTop.p, 0, (nb + 1) * sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, (nb + 1) * sizeof(unsigned long long), st));
+        uint32_t round = 0;
+        while (true) {
+            for (int r = 0; r < 4; ++r, ++round) {
+                if (r == 3) k_zero_u32<<<1, 1, 0, st>>>(&sc->uncolored);
+                k_color_propose<<<divUp(nm, B), B, 0, st>>>(nm, round, manBodies.p, gPos.p, color.p, bodyTop.p);
+                k_color_commit<<<divUp(nm, B), B, 0, st>>>(nm, round, manBodies.p, gPos.p, color.p, bodyTop.p, bodyUsed.p, sc);
+            }
+            HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (hs.uncolored == 0) break;
+            if (round > 4096) return fail(MI_ERR_DEVICE, "colouring did not converge");
+        }
+        uint32_t off = 0;
+        for (uint32_t c = 0; c <= kOverflowColor; ++c) { colorOffsets[c] = off; off += hs.colorHist[c]; if (hs.colorHist[c]) numColorsUsed = c + 1; }
+        colorOffsets[kOverflowColor + 1] = off;
+        // order manifolds by colour (stable => ascending manifold index inside a colour)
+        k_iota<<<divUp(nm, B), B, 0, st>>>(nm, order.p);
+        size_t tb = 0;
+        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, color.p, colorS.p, order.p, orderS.p, nm, 0, 8, st));
+        if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
+        HIP_TRY(rocprim::radix_sort_pairs(temp.p, tb, color.p, colorS.p, order.p, orderS.p, nm, 0, 8, st));
+    }
+    mark();  // 5
+    uint32_t cap = 0;
+    if (nm) {
+        HIP_TRY(slotMeta.ensure(nm));
+        cap = (uint32_t)slotMeta.cap;
+        HIP_TRY(rows.ensure(4 * (size_t)kRows * cap)); HIP_TRY(imp.ensure(4 * (size_t)cap));
+        k_contact_init<<<divUp(nm, B), B, 0, st>>>(nm, cap, dt, orderS.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
+                                                  gPos.p, gInvI.p, gVel.p, rows.p, imp.p, slotMeta.p);
+    }
+    int rc = joints.initialize(*this, dt, st);
+    if (rc != MI_OK) return rc;
+    mark();  // 6
+    for (uint32_t it = 0; it < settings.num_rigid_solver_iterations; ++it) {
+        joints.solveIteration(*this, st);   // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
+        for (uint32_t c = 0; c < kOverflowColor && c < numColorsUsed; ++c) {
+            uint32_t s0 = colorOffsets[c], s1 = colorOffsets[c + 1];
+            if (s1 > s0) k_contact_solve<<<divUp(s1 - s0, B), B, 0, st>>>(s0, s1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
+        }
+        uint32_t o0 = colorOffsets[kOverflowColor], o1 = colorOffsets[kOverflowColor + 1];
+        if (o1 > o0) k_contact_solve_serial<<<1, 64, 0, st>>>(o0, o1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
+    }
+    mark();  // 7
+    k_integrate_velocities<<<divUp(nb, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p);
+    mark();  // 8
+    HIP_TRY(hipStreamSynchronize(st));
+    HIP_TRY(hipGetLastError());
+    hostStale = true;
+
+    auto el = [&](int a, int b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; };
+    times.world_colliders = el(0, 1); times.broadphase = el(1, 2); times.narrowphase = el(2, 3); times.integrate_forces = el(3, 4);
+    times.schedule = el(4, 5); times.init_constraints = el(5, 6); times.solve = el(6, 7); times.integrate_velocities = el(7, 8); times.total = el(0, 8);
+    counts.num_rigid_bodies = nb; counts.num_colliders = nc; counts.num_broadphase_overlaps = nc ? hs.numOverlaps : 0;
+    counts.num_collisions = nm; counts.num_contacts = ncon; counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur;
+    return MI_OK;
+}
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+MI_API const char* mi_last_error(void) { return g_lastError.c_str(); }
+MI_API int mi_version(void) { return 1; }
+
+MI_API int mi_world_create(const mi_world_desc* desc, mi_world** out) {
+    if (!out) return fail(MI_ERR_INVALID_ARGUMENT, "out_world is null");
+    mi_world* w = new mi_world();
+    int rc = w->init(desc ? desc->device : 0);
+    if (rc != MI_OK) { delete w; *out = nullptr; return rc; }
+    *out = w;
+    return MI_OK;
+}
+MI_API void mi_world_destroy(mi_world* w) { delete w; }
+
+MI_API int mi_entities_create(mi_world* w, uint32_t count, const mi_entity_desc* descs, uint32_t* out_first) {
+    if (!w || (count && !descs)) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = w->download(); if (rc != MI_OK) return rc;
+    if (out_first) *out_first = (uint32_t)w->entities.size();
+    for (uint32_t i = 0; i < count; ++i) {
+        const mi_entity_desc& d = descs[i];
+        HEntity e; e.pos = V3(d.position[0], d.position[1], d.position[2]); e.rot = Q4(d.rotation[0], d.rotation[1], d.rotation[2], d.rotation[3]); e.kind = d.kind;
+        if (d.kind != MI_ENTITY_STATIC) {
+            HBody b;
+            b.entity = (uint32_t)w->entities.size();
+            bool kin = d.kind == MI_ENTITY_KINEMATIC;   // rigid_body_component ctor, rigid_body.cpp:6-27
+            b.invMass = kin ? 0.f : 1.f; b.invInertia = kin ? M3::zero() : M3::identity();
+            b.gravityFactor = d.gravity_factor; b.linDamp = d.linear_damping; b.angDamp = d.angular_damping;
+            b.linVel = V3(d.linear_velocity[0], d.linear_velocity[1], d.linear_velocity[2]);
+            b.angVel = V3(d.angular_velocity[0], d.angular_velocity[1], d.angular_velocity[2]);
+            b.p0 = b.p1 = e.pos; b.r0 = b.r1 = e.rot;
+            e.rb = (int)w->bodies.size();
+            w->bodies.push_back(b);
+        }
+        w->entities.push_back(e);
+    }
+    w->topologyDirty = true;
+    return MI_OK;
+}
+MI_API int mi_entity_create(mi_world* w, const mi_entity_desc* d, uint32_t* out) { return mi_entities_create(w, 1, d, out); }
+
+MI_API int mi_colliders_add(mi_world* w, uint32_t count, const uint32_t* ents, const mi_collider_desc* descs) {
+    if (!w || (count && (!ents || !descs))) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = w->download(); if (rc != MI_OK) return rc;
+    for (uint32_t i = 0; i < count; ++i) {
+        if (ents[i] >= w->entities.size()) return fail(MI_ERR_INVALID_ARGUMENT, "entity out of range");
+        if (descs[i].type >= MI_COLLIDER_TYPE_COUNT) return fail(MI_ERR_INVALID_ARGUMENT, "bad collider type");
+        if (descs[i].type == MI_COLLIDER_HULL && descs[i].hull_geometry >= w->hulls.size()) return fail(MI_ERR_INVALID_ARGUMENT, "bad hull geometry");
+        HCollider c; c.entity = ents[i]; c.desc = descs[i];
+        uint32_t id = (uint32_t)w->colliders.size();
+        w->colliders.push_back(c);
+        HEntity& e = w->entities[ents[i]];
+        e.colliders.insert(e.colliders.begin(), id);   // linked-list prepend (src/scene/scene.h:52-54)
+    }
+    if (w->colliders.size() >= (1u << 29)) return fail(MI_ERR_CAPACITY, "collider index space is 29 bits");
+    w->topologyDirty = true;
+    return MI_OK;
+}
+MI_API int mi_collider_add(mi_world* w, uint32_t entity, const mi_collider_desc* d, uint32_t* out) {
+    if (out && w) *out = (uint32_t)w->colliders.size();
+    return mi_colliders_add(w, 1, &entity, d);
+}
+
+MI_API int mi_hull_geometry_create(mi_world* w, const float* v, uint32_t nv, const uint32_t* t, uint32_t nt, uint32_t* out) {
+    if (!w || !v || !nv || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    HHull g; g.mn = V3(FLT_MAX); g.mx = V3(-FLT_MAX);
+    for (uint32_t i = 0; i < nv; ++i) { V3 p(v[3 * i], v[3 * i + 1], v[3 * i + 2]); g.verts.push_back(p); g.mn = vmin(g.mn, p); g.mx = vmax(g.mx, p); }
+    if (t) g.tris.assign(t, t + 3 * (size_t)nt);
+    *out = (uint32_t)w->hulls.size();
+    w->hulls.push_back(std::move(g));
+    w->topologyDirty = true;
+    return MI_OK;
+}
+
+MI_API int mi_constraint_create(mi_world* w, uint32_t type, uint32_t ea, uint32_t eb, const void* pod, uint32_t bytes, uint32_t* out) {
+    if (!w || !pod) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = w->joints.add(*w, type, ea, eb, pod, bytes, out);
+    if (rc == MI_OK) w->topologyDirty = true;
+    return rc;
+}
+MI_API int mi_constraint_update(mi_world* w, uint32_t type, uint32_t id, const void* pod, uint32_t bytes) {
+    if (!w || !pod) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = w->joints.update(type, id, pod, bytes);
+    if (rc == MI_OK) w->topologyDirty = true;
+    return rc;
+}
+MI_API int mi_constraint_get(mi_world* w, uint32_t type, uint32_t id, void* pod, uint32_t bytes) {
+    if (!w || !pod) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    return w->joints.get(type, id, pod, bytes);
+}
+MI_API int mi_constraint_create_from_global(mi_world* w, uint32_t type, uint32_t ea, uint32_t eb, const float* anchor, const float* axis,
+                                            float l0, float l1, uint32_t* out) {
+    if (!w || !anchor) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = w->download(); if (rc != MI_OK) return rc;
+    rc = w->joints.addFromGlobal(*w, type, ea, eb, anchor, axis, l0, l1, out);
+    if (rc == MI_OK) w->topologyDirty = true;
+    return rc;
+}
+
+MI_API int mi_entity_apply_force(mi_world* w, uint32_t entity, const float* f, const float* t) {
+    if (!w || entity >= w->entities.size() || w->entities[entity].rb < 0) return fail(MI_ERR_INVALID_ARGUMENT, "not a rigid body");
+    int rc = w->download(); if (rc != MI_OK) return rc;
+    HBody& b = w->bodies[w->entities[entity].rb];
+    if (f) b.force = b.force + V3(f[0], f[1], f[2]);
+    if (t) b.torque = b.torque + V3(t[0], t[1], t[2]);
+    w->topologyDirty = true;
+    return MI_OK;
+}
+
+MI_API int mi_world_step_fixed(mi_world* w, const mi_step_settings* s, float dt, uint32_t n) {
+    if (!w || !s) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    for (uint32_t i = 0; i < n; ++i) { int rc = w->stepInternal(*s, dt); if (rc != MI_OK) return rc; }
+    return MI_OK;
+}
+
+// physicsStep (src/physics/physics.cpp:1364-1413): accumulator, <= maxPhysicsIterationsPerFrame sub-steps, pose interpolation.
+MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
+    if (!w || !s) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (s->fixed_frame_rate) {
+        const float fixedDt = 1.f / (float)s->frame_rate;
+        w->timer += dt;
+        uint32_t iterations = 0;
+        if (w->timer >= fixedDt) {
+            int rc = w->download(); if (rc != MI_OK) return rc;
+            for (HBody& b : w->bodies) { b.p0 = b.p1; b.r0 = b.r1; }
+            while (w->timer >= fixedDt && iterations++ < s->max_physics_iterations_per_frame) {
+                rc = w->stepInternal(*s, fixedDt); if (rc != MI_OK) return rc;
+                w->timer -= fixedDt;
+            }
+        }
+        if (w->timer >= fixedDt) w->timer = fmodf(w->timer, fixedDt);
+        int rc = w->download(); if (rc != MI_OK) return rc;
+        float t = w->timer / fixedDt;
+        for (HBody& b : w->bodies) {   // lerp(trs): nlerp on the quaternion (src/core/math.h:673-682)
+            HEntity& e = w->entities[b.entity];
+            e.pos = lerp(b.p0, b.p1, t);
+            e.rot = normalize(Q4(b.r0.x + t * (b.r1.x - b.r0.x), b.r0.y + t * (b.r1.y - b.r0.y), b.r0.z + t * (b.r1.z - b.r0.z), b.r0.w + t * (b.r1.w - b.r0.w)));
+        }
+        return MI_OK;
+    }
+    int rc = w->stepInternal(*s, dt); if (rc != MI_OK) return rc;
+    rc = w->download(); if (rc != MI_OK) return rc;
+    for (HBody& b : w->bodies) { HEntity& e = w->entities[b.entity]; e.pos = b.p1; e.rot = b.r1; }
+    return MI_OK;
+}
+
+MI_API int mi_world_num_entities(mi_world* w, uint32_t* out) { if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null"); *out = (uint32_t)w->entities.size(); return MI_OK; }
+
+static int getTransforms(mi_world* w, float* p, float* r, uint32_t cap, bool physics) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    int rc = w->download(); if (rc != MI_OK) return rc;
+    uint32_t n = (uint32_t)w->entities.size();
+    if (cap < n) return fail(MI_ERR_CAPACITY, "capacity < num entities");
+    for (uint32_t i = 0; i < n; ++i) {
+        const HEntity& e = w->entities[i];
+        V3 pos = e.pos; Q4 rot = e.rot;
+        if (physics && e.rb >= 0) { pos = w->bodies[e.rb].p1; rot = w->bodies[e.rb].r1; }
+        if (p) { p[3 * i] = pos.x; p[3 * i + 1] = pos.y; p[3 * i + 2] = pos.z; }
+        if (r) { r[4 * i] = rot.x; r[4 * i + 1] = rot.y; r[4 * i + 2] = rot.z; r[4 * i + 3] = rot.w; }
+    }
+    return MI_OK;
+}
+MI_API int mi_world_get_transforms(mi_world* w, float* p, float* r, uint32_t cap) { return getTransforms(w, p, r, cap, false); }
+MI_API int mi_world_get_physics_transforms(mi_world* w, float* p, float* r, uint32_t cap) { return getTransforms(w, p, r, cap, true); }
+MI_API int mi_world_get_velocities(mi_world* w, float* lin, float* ang, uint32_t cap) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    int rc = w->download(); if (rc != MI_OK) return rc;
+    uint32_t n = (uint32_t)w->entities.size();
+    if (cap < n) return fail(MI_ERR_CAPACITY, "capacity < num entities");
+    for (uint32_t i = 0; i < n; ++i) {
+        V3 v, a;
+        if (w->entities[i].rb >= 0) { v = w->bodies[w->entities[i].rb].linVel; a = w->bodies[w->entities[i].rb].angVel; }
+        if (lin) { lin[3 * i] = v.x; lin[3 * i + 1] = v.y; lin[3 * i + 2] = v.z; }
+        if (ang) { ang[3 * i] = a.x; ang[3 * i + 1] = a.y; ang[3 * i + 2] = a.z; }
+    }
+    return MI_OK;
+}
+MI_API int mi_world_get_mass_properties(mi_world* w, float* invMass, float* invInertia, float* cog, uint32_t cap) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    w->recalcProperties();
+    uint32_t n = (uint32_t)w->entities.size();
+    if (cap < n) return fail(MI_ERR_CAPACITY, "capacity < num entities");
+    for (uint32_t i = 0; i < n; ++i) {
+        float im = 0.f; M3 ii = M3::zero(); V3 c;
+        if (w->entities[i].rb >= 0) { const HBody& b = w->bodies[w->entities[i].rb]; im = b.invMass; ii = b.invInertia; c = b.localCOG; }
+        if (invMass) invMass[i] = im;
+        if (invInertia) {   // column-major like the reference's mat3 (src/core/math.h:390-397)
+            float* o = invInertia + 9 * i;
+            o[0] = ii.m00; o[1] = ii.m10; o[2] = ii.m20; o[3] = ii.m01; o[4] = ii.m11; o[5] = ii.m21; o[6] = ii.m02; o[7] = ii.m12; o[8] = ii.m22;
+        }
+        if (cog) { cog[3 * i] = c.x; cog[3 * i + 1] = c.y; cog[3 * i + 2] = c.z; }
+    }
+    return MI_OK;
+}
+MI_API int mi_world_get_counts(mi_world* w, mi_step_counts* out) { if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null"); *out = w->counts; return MI_OK; }
+MI_API int mi_world_get_stage_times(mi_world* w, mi_stage_times* out) { if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null"); *out = w->times; return MI_OK; }
+
+MI_API int mi_world_get_contacts(mi_world* w, mi_contact* out, uint32_t cap, uint32_t* count) {
+    if (!w || !count) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    uint32_t nm = w->counts.num_collisions, nc = w->counts.num_contacts;
+    *count = nc;
+    if (!out) return MI_OK;
+    if (cap < nc) return fail(MI_ERR_CAPACITY, "capacity < num contacts");
+    if (!nm) return MI_OK;
+    uint32_t np = w->hs.numPairs;
+    std::vector<uint32_t> mp(nm); std::vector<uint2> mb(nm), mi_(nm); std::vector<uint64_t> keys(np); std::vector<float4> nrm(np), pts(4 * (size_t)np);
+    HIP_TRY(hipMemcpy(mp.data(), w->manPair.p, nm * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mb.data(), w->manBodies.p, nm * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mi_.data(), w->manInfo.p, nm * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(keys.data(), w->pairKeysS.p, np * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(nrm.data(), w->npNormal.p, np * 16, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(pts.data(), w->npPoints.p, 4 * (size_t)np * 16, hipMemcpyDeviceToHost));
+    uint32_t ci = 0;
+    for (uint32_t m = 0; m < nm; ++m) {
+        uint32_t p = mp[m], cnt = mi_[m].x & 7u;
+        for (uint32_t k = 0; k < cnt && ci < nc; ++k, ++ci) {
+            mi_contact& o = out[ci];
+            float4 pd = pts[4 * (size_t)p + k];
+            o.point[0] = pd.x; o.point[1] = pd.y; o.point[2] = pd.z; o.penetration_depth = pd.w;
+            o.normal[0] = nrm[p].x; o.normal[1] = nrm[p].y; o.normal[2] = nrm[p].z;
+            o.friction_restitution = mi_[m].y;
+            o.collider_a = (uint32_t)((keys[p] >> 29) & 0x1FFFFFFFu); o.collider_b = (uint32_t)(keys[p] & 0x1FFFFFFFu);
+            o.body_a = mb[m].x; o.body_b = mb[m].y;
+        }
+    }
+    return MI_OK;
+}
+
+// Stage dumps for parity bisecting.
+MI_API int mi_world_get_aabbs(mi_world* w, float* out6, uint32_t cap) {
+    if (!w || !out6) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    uint32_t nc = w->counts.num_colliders;
+    if (cap < nc) return fail(MI_ERR_CAPACITY, "capacity < num colliders");
+    std::vector<float4> mn(nc), mx(nc);
+    if (nc) { HIP_TRY(hipMemcpy(mn.data(), w->aabbMin.p, nc * 16, hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(mx.data(), w->aabbMax.p, nc * 16, hipMemcpyDeviceToHost)); }
+    for (uint32_t i = 0; i < nc; ++i) { out6[6 * i] = mn[i].x; out6[6 * i + 1] = mn[i].y; out6[6 * i + 2] = mn[i].z; out6[6 * i + 3] = mx[i].x; out6[6 * i + 4] = mx[i].y; out6[6 * i + 5] = mx[i].z; }
+    return MI_OK;
+}
+MI_API int mi_world_get_manifold_colors(mi_world* w, uint32_t* out, uint32_t cap) {
+    if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    uint32_t nm = w->counts.num_collisions;
+    if (cap < nm) return fail(MI_ERR_CAPACITY, "capacity < num manifolds");
+    if (nm) HIP_TRY(hipMemcpy(out, w->color.p, nm * 4, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+
+}  // extern "C"
