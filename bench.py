@@ -1,0 +1,173 @@
+#!/usr/bin/env python
+"""bench.py — physics steps/s of the MI355X rigid-body stepper on the BASELINE.json headline workload.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path (physicsStepInternal: world colliders -> broad phase -> narrow phase
+-> integrate forces -> schedule -> constraint init -> I PGS sweeps -> integrate velocities) over the
+whole synthetic scene.  Workload at N=1: cfg3, the 262 144-body OBB pile (128 x 16 x 128 boxes, half-extents
+U[0.3,0.6], friction 0.5, 20 solver iterations, walled pen) — the configuration BASELINE.json's metric is
+quoted on; it fits one GPU.  N > 1 is weak scaling: every rank steps one 262 144-body tile (see DESIGN.md
+"multi-GPU").  All scene state is resident in HBM before the timed region starts.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
+k_contact_solve, algorithmic bytes from SURVEY.md §8(d)) and `cpu_baseline` (CPU oracle, reference order,
+bounded sample) objects.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
+BYTES_PER_CONTACT_ITER = 236    # per contact per PGS sweep (124 B row + 2 x 28 B body read, 8 + 2 x 24 B written)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=240)
+    ap.add_argument("--grid", type=int, nargs=3, default=[128, 16, 128], help="boxes per axis of one GPU's tile (default = 262144 bodies)")
+    ap.add_argument("--iterations", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-grid", type=int, nargs=3, default=[32, 16, 32])
+    ap.add_argument("--cpu-warmup", type=int, default=200)
+    ap.add_argument("--cpu-steps", type=int, default=20)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, bodies_full):
+    """CPU oracle (reference order = the reference's scalar path restated), 1 thread, bounded sample of the same
+    workload: same generator and column height, smaller footprint; reported scaled to the full body count."""
+    import oracle
+    from d3d12renderer_amd import scenes
+    nx, ny, nz = args.cpu_grid
+    sc = scenes.obb_pile(nx, ny, nz, solver_iterations=args.iterations)
+    w = sc.populate(oracle.create_world(oracle.ORDER_REFERENCE))
+    s = sc.settings()
+    w.step_fixed(s, sc.dt, args.cpu_warmup)
+    t0 = time.perf_counter()
+    w.step_fixed(s, sc.dt, args.cpu_steps)
+    dt = time.perf_counter() - t0
+    nb = sc.num_bodies
+    steps_per_s = args.cpu_steps / dt
+    return {
+        "value": steps_per_s * nb / bodies_full, "unit": "steps/s", "cores": 1, "kind": "port",
+        "sample": (f"oracle (reference order, -O2 strict fp32, 1 thread) on obb_pile {nx}x{ny}x{nz} = {nb} bodies, I={args.iterations}, "
+                   f"{args.cpu_warmup} settle + {args.cpu_steps} timed steps: {steps_per_s:.2f} steps/s at {nb} bodies, "
+                   f"{w.counts()['num_contacts']} contacts; value = that rate x {nb}/{bodies_full} (linear in bodies)"),
+        "measured_steps_per_s": steps_per_s, "sample_bodies": nb,
+    }
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+    if world_size != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}; launch with torch.distributed.run", file=sys.stderr)
+        sys.exit(2)
+
+    import d3d12renderer_amd as mi
+    from d3d12renderer_amd import scenes
+    from d3d12renderer_amd.distributed import ShardedWorld
+
+    nx, ny, nz = args.grid
+    sw = ShardedWorld(lambda: mi.create_world(local_rank), rank, world_size, dist, tile=(nx, ny, nz), iterations=args.iterations)
+    settings = sw.settings()
+    dt = sw.dt
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sw.step(settings, dt)
+    barrier()
+    t0 = time.perf_counter()
+    solve_ms = 0.0; total_dev_ms = 0.0; launches = 0; contact_iters = 0; stage_acc = {}
+    for _ in range(args.steps):
+        sw.step(settings, dt)
+        st = sw.world.stage_times(); c = sw.world.counts()
+        solve_ms += st["solve"]; total_dev_ms += st["total"]
+        launches += args.iterations * max(c["num_colors"], 1)
+        contact_iters += args.iterations * c["num_contacts"]
+        for k, v in st.items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    counts = sw.world.counts()
+    bodies_per_gpu = sw.bodies_per_rank
+    total_bodies = bodies_per_gpu * world_size
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        # whole-job throughput: every rank steps its 262144-body tile each step; the job advances one scene step per `ms_per_step`
+        # and processes world_size tiles, so value = tiles-steps per second (at N=1: plain steps/s of the 262144-body scene).
+        value = world_size * args.steps / elapsed
+        achieved = (BYTES_PER_CONTACT_ITER * contact_iters) / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else 0.0
+        roofline = {
+            "bound": "hbm", "kernel": "k_contact_solve", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": _measured_traffic(),
+            "avg_launch_us": solve_ms * 1e3 / max(launches, 1), "launches_per_step": launches / args.steps,
+            "algorithmic_bytes_per_launch": BYTES_PER_CONTACT_ITER * contact_iters / max(launches, 1),
+            "note": "rank 0; launch duration = HIP-event time of the solve stage / launches (includes inter-launch gaps)",
+        }
+        out = {
+            "metric": "physics steps/sec at 262144 rigid bodies per GPU (OBB pile, 20 solver iterations)",
+            "value": value, "unit": "steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg3 obb_pile {nx}x{ny}x{nz} boxes per GPU ({bodies_per_gpu} bodies/GPU, {total_bodies} total), "
+                                   f"friction 0.5, {args.iterations} solver iterations, dt=1/120",
+                       "bodies_per_gpu": bodies_per_gpu, "contacts": counts["num_contacts"], "manifolds": counts["num_collisions"],
+                       "broadphase_overlaps": counts["num_broadphase_overlaps"], "colors": counts["num_colors"],
+                       "sharding": sw.sharding_note},
+            "roofline": roofline,
+            "stage_ms": {k: v / args.steps for k, v in stage_acc.items()},
+            "device_ms_per_step": total_dev_ms / args.steps,
+        }
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, bodies_per_gpu)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def _measured_traffic():
+    """HBM bytes per k_contact_solve launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+    p = ROOT / "profiles" / "traffic.json"
+    if p.exists():
+        try:
+            return json.loads(p.read_text()).get("k_contact_solve_bytes_per_launch")
+        except Exception:
+            return None
+    return None
+
+
+if __name__ == "__main__":
+    main()

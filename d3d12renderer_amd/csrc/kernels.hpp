@@ -40,6 +40,9 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t axisCur;
     uint32_t axisNext;
     uint32_t colorHist[kOverflowColor + 1];
+    uint32_t extentHist[256];   // log2 histogram of AABB extents (8 bins per octave) -> cell size / "large" threshold
+    float largeThreshold;
+    uint32_t pad0;
 };
 
 __device__ __forceinline__ int orderedInt(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
@@ -145,11 +148,20 @@ __global__ __launch_bounds__(256) void k_world_colliders(
 // same-type pair depends on sweep order along it.
 // ------------------------------------------------------------------------------------------------
 
+__device__ __forceinline__ uint32_t extentBin(float ext) {
+    float l = log2f(fmaxr(ext, 1e-6f)) * 8.f + 128.f;
+    return (uint32_t)fminr(fmaxr(l, 0.f), 255.f);
+}
+__device__ __forceinline__ float extentBinUpper(uint32_t b) { return exp2f(((float)b + 1.f - 128.f) / 8.f); }
+
 // Deterministic centre statistics for the next sorting axis: fixed butterfly per wave (double),
 // waves 0..3 added in order, block partials added sequentially by k_axis_final.
 __global__ __launch_bounds__(256) void k_axis_partials(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
                                                        double* __restrict__ partials, StepScalars* sc) {
     __shared__ double sm[4][6];
+    __shared__ uint32_t hist[256];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
     double v[6] = {0, 0, 0, 0, 0, 0};
     float ext = 0.f;
@@ -159,18 +171,18 @@ __global__ __launch_bounds__(256) void k_axis_partials(uint32_t nc, const float4
         v[0] = cx; v[1] = cy; v[2] = cz;
         v[3] = (double)cx * (double)cx; v[4] = (double)cy * (double)cy; v[5] = (double)cz * (double)cz;
         ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
+        atomicAdd(&hist[extentBin(ext)], 1u);   // only steers the cell size, never results
     }
     for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) v[c] += __shfl_down(v[c], off, 64);
-        ext += __shfl_down(ext, off, 64);
     }
     uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) {
         for (int c = 0; c < 6; ++c) sm[wv][c] = v[c];
-        atomicAdd(&sc->extentSum, (double)ext);   // only steers the cell size, never results
     }
     __syncthreads();
+    if (hist[threadIdx.x]) atomicAdd(&sc->extentHist[threadIdx.x], hist[threadIdx.x]);
     if (threadIdx.x == 0) {
         for (int c = 0; c < 6; ++c) {
             double a = 0.0;
@@ -179,45 +191,88 @@ __global__ __launch_bounds__(256) void k_axis_partials(uint32_t nc, const float4
         }
     }
 }
-__global__ void k_axis_final(uint32_t nc, uint32_t numBlocks, const double* __restrict__ partials, StepScalars* sc) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+// Block partials are added in block order by one lane (the deterministic part); the other lanes only stage
+// them through LDS so the serial chain is add-latency-bound, not HBM-latency-bound.
+__global__ __launch_bounds__(256) void k_axis_final(uint32_t nc, uint32_t numBlocks, const double* __restrict__ partials, StepScalars* sc) {
+    __shared__ double tile[256 * 6];
     double s[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t b = 0; b < numBlocks; ++b)
-        for (int c = 0; c < 6; ++c) s[c] += partials[b * 6 + c];
+    for (uint32_t base = 0; base < numBlocks; base += 256) {
+        uint32_t n = min(256u, numBlocks - base);
+        for (uint32_t t = threadIdx.x; t < n * 6; t += 256) tile[t] = partials[(size_t)base * 6 + t];
+        __syncthreads();
+        if (threadIdx.x == 0)
+            for (uint32_t b = 0; b < n; ++b)
+                for (int c = 0; c < 6; ++c) s[c] += tile[b * 6 + c];
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
     double var[3];
     for (int c = 0; c < 3; ++c) var[c] = s[3 + c] - s[c] * s[c] / (double)nc;
     sc->axisNext = (var[0] > var[1]) ? ((var[0] > var[2]) ? 0u : 2u) : ((var[1] > var[2]) ? 1u : 2u);  // collision_broad.cpp:443-444
 }
 
+// Cell size = smallest extent bin edge that leaves at most `limit` colliders above it; those few "large"
+// colliders (ground, walls, outliers) are handled by the brute-force pass.
+__global__ void k_bp_threshold(uint32_t nc, StepScalars* sc) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t limit = max(16u, nc / 16384u);
+    uint32_t costCap = (uint32_t)(67108864ull / (uint64_t)max(nc, 1u));
+    limit = max(8u, min(limit, costCap));
+    uint32_t above = 0; int b = 255;
+    for (; b >= 0; --b) { if (above + sc->extentHist[b] > limit) break; above += sc->extentHist[b]; }
+    sc->largeThreshold = b < 0 ? 0.f : extentBinUpper((uint32_t)b);
+}
+
 __global__ __launch_bounds__(256) void k_bp_classify(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
-                                                     StepScalars* sc, uint32_t* __restrict__ largeList, uint32_t* __restrict__ isLarge) {
+                                                     StepScalars* sc, uint32_t* __restrict__ largeList, uint32_t* __restrict__ isLarge,
+                                                     int* __restrict__ blockBounds) {
+    __shared__ int sb[4][6];
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nc) return;
-    float thr = 2.f * (float)(sc->extentSum / (double)nc);
-    float4 mn = aabbMin[i], mx = aabbMax[i];
-    float ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
-    bool large = ext > thr;
-    isLarge[i] = large ? 1u : 0u;
-    if (large) { uint32_t slot = atomicAdd(&sc->numLarge, 1u); largeList[slot] = i; }
-    else {
-        float cx = (mn.x + mx.x) * 0.5f, cy = (mn.y + mx.y) * 0.5f, cz = (mn.z + mx.z) * 0.5f;
-        atomicMin(&sc->boundsMin[0], orderedInt(cx)); atomicMax(&sc->boundsMax[0], orderedInt(cx));
-        atomicMin(&sc->boundsMin[1], orderedInt(cy)); atomicMax(&sc->boundsMax[1], orderedInt(cy));
-        atomicMin(&sc->boundsMin[2], orderedInt(cz)); atomicMax(&sc->boundsMax[2], orderedInt(cz));
+    float thr = sc->largeThreshold;
+    int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    if (i < nc) {
+        float4 mn = aabbMin[i], mx = aabbMax[i];
+        float ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
+        bool large = ext > thr;
+        isLarge[i] = large ? 1u : 0u;
+        if (large) { uint32_t slot = atomicAdd(&sc->numLarge, 1u); largeList[slot] = i; }
+        else {
+            lo[0] = hi[0] = orderedInt((mn.x + mx.x) * 0.5f);
+            lo[1] = hi[1] = orderedInt((mn.y + mx.y) * 0.5f);
+            lo[2] = hi[2] = orderedInt((mn.z + mx.z) * 0.5f);
+        }
+    }
+    for (int off = 32; off >= 1; off >>= 1)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], __shfl_xor(lo[a], off, 64)); hi[a] = max(hi[a], __shfl_xor(hi[a], off, 64)); }
+    uint32_t wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) for (int a = 0; a < 3; ++a) { sb[wv][a] = lo[a]; sb[wv][3 + a] = hi[a]; }
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        int v = sb[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) v = threadIdx.x < 3 ? min(v, sb[w][threadIdx.x]) : max(v, sb[w][threadIdx.x]);
+        blockBounds[blockIdx.x * 6 + threadIdx.x] = v;
     }
 }
 
-__global__ void k_bp_grid_setup(uint32_t nc, StepScalars* sc, GridParams* g) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float thr = 2.f * (float)(sc->extentSum / (double)nc);
+__global__ __launch_bounds__(256) void k_bp_grid_setup(uint32_t nc, uint32_t numBlocks, const int* __restrict__ blockBounds, StepScalars* sc, GridParams* g) {
+    __shared__ int red[256][6];
+    int v[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+    for (uint32_t b = threadIdx.x; b < numBlocks; b += 256)
+        for (int a = 0; a < 6; ++a) { int x = blockBounds[b * 6 + a]; v[a] = a < 3 ? min(v[a], x) : max(v[a], x); }
+    for (int a = 0; a < 6; ++a) red[threadIdx.x][a] = v[a];
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int t = 1; t < 256; ++t) for (int a = 0; a < 6; ++a) v[a] = a < 3 ? min(v[a], red[t][a]) : max(v[a], red[t][a]);
+    float thr = sc->largeThreshold;
     float cell = thr * 1.001f + 1e-6f;
     float lo[3], hi[3];
-    bool any = sc->boundsMin[0] != 0x7FFFFFFF;
-    for (int a = 0; a < 3; ++a) { lo[a] = any ? fromOrderedInt(sc->boundsMin[a]) : 0.f; hi[a] = any ? fromOrderedInt(sc->boundsMax[a]) : 0.f; }
+    bool any = v[0] != 0x7FFFFFFF;
+    for (int a = 0; a < 3; ++a) { lo[a] = any ? fromOrderedInt(v[a]) : 0.f; hi[a] = any ? fromOrderedInt(v[3 + a]) : 0.f; }
     for (int it = 0; it < 64; ++it) {
         double cells = 1.0;
         for (int a = 0; a < 3; ++a) { uint32_t d = (uint32_t)((hi[a] - lo[a]) / cell) + 2u; g->dims[a] = d; cells *= (double)d; }
-        if (cells <= (double)kMaxCells) break;
+        if (cells <= (double)(kMaxCells - 1)) break;
         cell *= 1.3f;
     }
     g->numCells = g->dims[0] * g->dims[1] * g->dims[2];
@@ -235,7 +290,7 @@ __device__ __forceinline__ void cellOf(const GridParams& g, float cx, float cy, 
 
 __global__ __launch_bounds__(256) void k_bp_cell_ids(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
                                                      const uint32_t* __restrict__ isLarge, const GridParams* __restrict__ gp,
-                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals) {
+                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ cellCount) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nc) return;
     GridParams g = *gp;
@@ -245,40 +300,32 @@ __global__ __launch_bounds__(256) void k_bp_cell_ids(uint32_t nc, const float4* 
         uint32_t ix, iy, iz;
         cellOf(g, (mn.x + mx.x) * 0.5f, (mn.y + mx.y) * 0.5f, (mn.z + mx.z) * 0.5f, ix, iy, iz);
         key = (ix * g.dims[1] + iy) * g.dims[2] + iz;
+        atomicAdd(&cellCount[key], 1u);
     }
     keys[i] = key; vals[i] = i;
 }
 
-__global__ __launch_bounds__(256) void k_bp_clear_cells(const GridParams* __restrict__ gp, uint32_t* __restrict__ cellStart) {
-    uint32_t n = gp->numCells;
-    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) cellStart[i] = 0xFFFFFFFFu;
-}
-
-// Sorted-order copies of the AABB rows (+ original index) so the 27-cell scan reads contiguous memory.
-__global__ __launch_bounds__(256) void k_bp_cell_bounds(uint32_t nc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                        const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
-                                                        float4* __restrict__ sMin, float4* __restrict__ sMax,
-                                                        uint32_t* __restrict__ cellStart, uint32_t* __restrict__ cellEnd) {
+// Sorted-order copies of the AABB rows so a column scan reads contiguous memory.
+__global__ __launch_bounds__(256) void k_bp_gather_sorted(uint32_t nc, const uint32_t* __restrict__ vals,
+                                                          const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                          float4* __restrict__ sMin, float4* __restrict__ sMax) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nc) return;
-    uint32_t key = keys[i], idx = vals[i];
+    uint32_t idx = vals[i];
     sMin[i] = aabbMin[idx]; sMax[i] = aabbMax[idx];
-    if (key == 0xFFFFFFFFu) return;
-    if (i == 0 || keys[i - 1] != key) cellStart[key] = i;
-    if (i == nc - 1 || keys[i + 1] != key) cellEnd[key] = i + 1;
 }
 
 // Prune + orient + key (collision_narrow.cpp:2346-2395) fused into pair emission.
 // i, j: collider world indices.  The SAP sweep emits {new, active}: new = later start on the axis;
 // on a tie the later-created collider (smaller world index) is the newer endpoint.
-__device__ __forceinline__ void emitPair(uint32_t i, const float4& imn, const float4& imx, uint32_t j, const float4& jmn, const float4& jmx,
-                                         uint32_t axis, uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc) {
-    atomicAdd(&sc->numOverlaps, 1u);
+// Returns false when the overlap generates no collision pair.
+__device__ __forceinline__ bool pairKey(uint32_t i, const float4& imn, const float4& imx, uint32_t j, const float4& jmn, const float4& jmx,
+                                        uint32_t axis, uint64_t& key) {
     uint32_t ti = __float_as_uint(imn.w), tj = __float_as_uint(jmn.w);
     uint32_t oi = (ti >> 8) & 0xFF, oj = (tj >> 8) & 0xFF;
     uint32_t bi = __float_as_uint(imx.w), bj = __float_as_uint(jmx.w);
-    if (oi != OBJ_RIGID_BODY && oj != OBJ_RIGID_BODY) return;
-    if (oi == OBJ_RIGID_BODY && oj == OBJ_RIGID_BODY && bi == bj) return;
+    if (oi != OBJ_RIGID_BODY && oj != OBJ_RIGID_BODY) return false;
+    if (oi == OBJ_RIGID_BODY && oj == OBJ_RIGID_BODY && bi == bj) return false;
     float mi_ = axis == 0 ? imn.x : (axis == 1 ? imn.y : imn.z);
     float mj_ = axis == 0 ? jmn.x : (axis == 1 ? jmn.y : jmn.z);
     bool iIsNew = (mi_ > mj_) || (mi_ == mj_ && i < j);
@@ -287,9 +334,26 @@ __device__ __forceinline__ void emitPair(uint32_t i, const float4& imn, const fl
     uint32_t oa = iIsNew ? oi : oj, ob = iIsNew ? oj : oi;
     if (!(ta < tb)) { uint32_t t = a; a = b; b = t; t = ta; ta = tb; tb = t; t = oa; oa = ob; ob = t; }
     bool collision = (oa == OBJ_RIGID_BODY && ob == OBJ_RIGID_BODY) || oa == OBJ_STATIC || ob == OBJ_STATIC;
-    if (!collision) return;   // trigger / force-field overlaps: SURVEY §8(f).4
-    uint32_t slot = atomicAdd(&sc->numPairs, 1u);
-    if (slot < pairCap) pairKeys[slot] = ((uint64_t)bucketOf(ta, tb) << 58) | ((uint64_t)a << 29) | (uint64_t)b;
+    if (!collision) return false;   // trigger / force-field overlaps: SURVEY §8(f).4
+    key = ((uint64_t)bucketOf(ta, tb) << 58) | ((uint64_t)a << 29) | (uint64_t)b;
+    return true;
+}
+
+// Wave-aggregated append: one atomic per wave per call (ballot + popcount prefix), not one per pair.
+__device__ __forceinline__ void waveAppendKey(bool want, uint64_t key, uint64_t* __restrict__ pairKeys, uint32_t pairCap, uint32_t* counter) {
+    unsigned long long mask = __ballot(want);
+    if (!want) return;
+    uint32_t lane = threadIdx.x & 63u;
+    uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader, 64);
+    uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (slot < pairCap) pairKeys[slot] = key;
+}
+__device__ __forceinline__ void waveAddCount(uint32_t v, uint32_t* counter) {
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((threadIdx.x & 63u) == 0 && v) atomicAdd(counter, v);
 }
 
 __device__ __forceinline__ bool aabbOverlap(const float4& amn, const float4& amx, const float4& bmn, const float4& bmx) {  // bounding_volumes.h:352-358
@@ -299,38 +363,72 @@ __device__ __forceinline__ bool aabbOverlap(const float4& amn, const float4& amx
     return true;
 }
 
+// Five lanes per small collider.  Colliders are sorted by cell key with z fastest, so the cells
+// (x', y', z-1 .. z+1) of one neighbour column are ONE contiguous range of the sorted arrays:
+// [cellLower[first], cellLower[last + 1]) with cellLower = exclusive prefix sum of the cell histogram.
+//   lane c = 0: (0,0,[z .. z+1]) starting after the collider itself     c = 1: (0,+1,[z-1 .. z+1])
+//   lane c = 2..4: (+1,{-1,0,+1},[z-1 .. z+1])            -> each unordered cell pair is visited once.
+constexpr uint32_t kPairBuf = 6;   // LDS-staged pair keys per lane before the block-level flush
+
+// Pair compaction: a same-address global atomic sustains only ~90 ops/us on this chip, so per-pair (or even
+// per-wave-iteration) atomics would bound the whole broad phase.  Each lane stages its hits in LDS, the block
+// prefix-sums the per-lane counts (wave shuffles), ONE atomic reserves the block's output range and the keys are
+// copied out; lanes with more than kPairBuf hits fall back to a direct append for the excess (rare).
 __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                        const float4* __restrict__ sMin, const float4* __restrict__ sMax,
-                                                       const uint32_t* __restrict__ cellStart, const uint32_t* __restrict__ cellEnd,
+                                                       const uint32_t* __restrict__ cellLower,
                                                        const GridParams* __restrict__ gp, uint64_t* __restrict__ pairKeys, uint32_t pairCap,
                                                        StepScalars* sc) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nc) return;
-    uint32_t key = keys[i];
-    if (key == 0xFFFFFFFFu) return;
-    const uint32_t dy = gp->dims[1], dz = gp->dims[2], dx = gp->dims[0];
-    uint32_t axis = sc->axisCur;
-    uint32_t iz = key % dz, iy = (key / dz) % dy, ix = key / (dz * dy);
-    float4 amn = sMin[i], amx = sMax[i];
-    uint32_t ci = vals[i];
-    for (int ox = -1; ox <= 1; ++ox) {
-        int x = (int)ix + ox; if (x < 0 || x >= (int)dx) continue;
-        for (int oy = -1; oy <= 1; ++oy) {
-            int y = (int)iy + oy; if (y < 0 || y >= (int)dy) continue;
-            for (int oz = -1; oz <= 1; ++oz) {
-                int z = (int)iz + oz; if (z < 0 || z >= (int)dz) continue;
-                uint32_t c = ((uint32_t)x * dy + (uint32_t)y) * dz + (uint32_t)z;
-                uint32_t s = cellStart[c];
-                if (s == 0xFFFFFFFFu) continue;
-                uint32_t e = cellEnd[c];
-                for (uint32_t j = s; j < e; ++j) {
-                    if (j <= i) continue;   // each unordered pair once
-                    float4 bmn = sMin[j], bmx = sMax[j];
-                    if (aabbOverlap(amn, amx, bmn, bmx)) emitPair(ci, amn, amx, vals[j], bmn, bmx, axis, pairKeys, pairCap, sc);
-                }
+    __shared__ uint64_t buf[256 * kPairBuf];
+    __shared__ uint32_t waveTotals[4];
+    __shared__ uint32_t blockBase;
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t i = t / 5u, col = t % 5u;
+    uint32_t overlaps = 0, nhit = 0;
+    uint32_t key = i < nc ? keys[i] : 0xFFFFFFFFu;
+    if (key != 0xFFFFFFFFu) {
+        const uint32_t dy = gp->dims[1], dz = gp->dims[2], dx = gp->dims[0];
+        uint32_t axis = sc->axisCur;
+        uint32_t iz = key % dz, iy = (key / dz) % dy, ix = key / (dz * dy);
+        int x = (int)ix + (col >= 2 ? 1 : 0);
+        int y = (int)iy + (col == 1 ? 1 : (col >= 2 ? (int)col - 3 : 0));
+        if (x < (int)dx && y >= 0 && y < (int)dy) {
+            int z0 = col == 0 ? (int)iz : (int)iz - 1, z1 = (int)iz + 1;
+            if (z0 < 0) z0 = 0;
+            if (z1 >= (int)dz) z1 = (int)dz - 1;
+            uint32_t cbase = ((uint32_t)x * dy + (uint32_t)y) * dz;
+            uint32_t s = col == 0 ? i + 1u : cellLower[cbase + (uint32_t)z0];
+            uint32_t e = cellLower[cbase + (uint32_t)z1 + 1u];
+            float4 amn = sMin[i], amx = sMax[i];
+            uint32_t ci = vals[i];
+            for (uint32_t j = s; j < e; ++j) {
+                float4 bmn = sMin[j], bmx = sMax[j];
+                if (!aabbOverlap(amn, amx, bmn, bmx)) continue;
+                ++overlaps;
+                uint64_t pk;
+                if (!pairKey(ci, amn, amx, vals[j], bmn, bmx, axis, pk)) continue;
+                if (nhit < kPairBuf) buf[threadIdx.x * kPairBuf + nhit] = pk;
+                else { uint32_t slot = atomicAdd(&sc->numPairs, 1u); if (slot < pairCap) pairKeys[slot] = pk; }
+                ++nhit;
             }
         }
     }
+    // block exclusive scan of min(nhit, kPairBuf)
+    uint32_t mine = min(nhit, kPairBuf), incl = mine;
+    uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
+    if (lane == 63) waveTotals[wv] = incl;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < wv; ++w) wbase += waveTotals[w];
+    if (threadIdx.x == 0) {
+        uint32_t total = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+        blockBase = total ? atomicAdd(&sc->numPairs, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t dst = blockBase + wbase + incl - mine;
+    for (uint32_t k = 0; k < mine; ++k) if (dst + k < pairCap) pairKeys[dst + k] = buf[threadIdx.x * kPairBuf + k];
+    waveAddCount(overlaps, &sc->numOverlaps);
 }
 
 // Large colliders against everything: (large l) x (all colliders), grid-strided.  Large-large pairs
@@ -340,15 +438,22 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
                                                         uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc) {
     uint32_t nl = sc->numLarge;
     uint32_t axis = sc->axisCur;
-    uint64_t total = (uint64_t)nl * nc;
-    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t l = (uint32_t)(t / nc), j = (uint32_t)(t % nc);
+    uint32_t overlaps = 0;
+    // blockIdx.y = large collider slot (grid-strided), x-dimension strides over all colliders: coalesced AABB reads
+    for (uint32_t l = blockIdx.y; l < nl; l += gridDim.y) {
         uint32_t i = largeList[l];
-        if (i == j) continue;
-        if (isLarge[j] && j < i) continue;
-        float4 amn = aabbMin[i], amx = aabbMax[i], bmn = aabbMin[j], bmx = aabbMax[j];
-        if (aabbOverlap(amn, amx, bmn, bmx)) emitPair(i, amn, amx, j, bmn, bmx, axis, pairKeys, pairCap, sc);
+        float4 amn = aabbMin[i], amx = aabbMax[i];
+        for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
+            bool ok = (i != j) && !(isLarge[j] && j < i);
+            float4 bmn = aabbMin[j], bmx = aabbMax[j];
+            bool ov = ok && aabbOverlap(amn, amx, bmn, bmx);
+            uint64_t pk = 0;
+            bool want = ov && pairKey(i, amn, amx, j, bmn, bmx, axis, pk);
+            overlaps += ov ? 1u : 0u;
+            waveAppendKey(want, pk, pairKeys, pairCap, &sc->numPairs);
+        }
     }
+    waveAddCount(overlaps, &sc->numOverlaps);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -545,21 +650,30 @@ __global__ __launch_bounds__(256) void k_color_propose(uint32_t nm, uint32_t rou
 __global__ __launch_bounds__(256) void k_color_commit(uint32_t nm, uint32_t round, const uint2* __restrict__ manBodies, const float4* __restrict__ gPos,
                                                       uint32_t* __restrict__ color, const unsigned long long* __restrict__ bodyTop,
                                                       unsigned long long* __restrict__ bodyUsed, StepScalars* sc) {
+    __shared__ uint32_t hist[kOverflowColor + 2];   // [65] = still uncoloured
+    if (threadIdx.x < kOverflowColor + 2) hist[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= nm || color[m] != kUncolored) return;
-    uint2 b = manBodies[m];
-    unsigned long long key = ((unsigned long long)(round + 1) << 32) | hash32(m);
-    bool dynA = gPos[b.x].w != 0.f, dynB = gPos[b.y].w != 0.f;
-    if ((dynA && bodyTop[b.x] != key) || (dynB && bodyTop[b.y] != key)) { atomicAdd(&sc->uncolored, 1u); return; }
-    unsigned long long mask = (dynA ? bodyUsed[b.x] : 0ull) | (dynB ? bodyUsed[b.y] : 0ull);
-    uint32_t c = kOverflowColor;
-    if (~mask != 0ull) {
-        c = (uint32_t)__ffsll((long long)~mask) - 1u;
-        if (dynA) bodyUsed[b.x] |= (1ull << c);
-        if (dynB) bodyUsed[b.y] |= (1ull << c);
+    if (m < nm && color[m] == kUncolored) {
+        uint2 b = manBodies[m];
+        unsigned long long key = ((unsigned long long)(round + 1) << 32) | hash32(m);
+        bool dynA = gPos[b.x].w != 0.f, dynB = gPos[b.y].w != 0.f;
+        if ((dynA && bodyTop[b.x] != key) || (dynB && bodyTop[b.y] != key)) atomicAdd(&hist[kOverflowColor + 1], 1u);
+        else {
+            unsigned long long mask = (dynA ? bodyUsed[b.x] : 0ull) | (dynB ? bodyUsed[b.y] : 0ull);
+            uint32_t c = kOverflowColor;
+            if (~mask != 0ull) {
+                c = (uint32_t)__ffsll((long long)~mask) - 1u;
+                if (dynA) bodyUsed[b.x] |= (1ull << c);
+                if (dynB) bodyUsed[b.y] |= (1ull << c);
+            }
+            color[m] = c;
+            atomicAdd(&hist[c], 1u);
+        }
     }
-    color[m] = c;
-    atomicAdd(&sc->colorHist[c], 1u);
+    __syncthreads();
+    if (threadIdx.x <= kOverflowColor && hist[threadIdx.x]) atomicAdd(&sc->colorHist[threadIdx.x], hist[threadIdx.x]);
+    if (threadIdx.x == kOverflowColor + 1 && hist[threadIdx.x]) atomicAdd(&sc->uncolored, hist[threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------

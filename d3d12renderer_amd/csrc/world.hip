@@ -89,7 +89,8 @@ struct mi_world {
     DBuf<float4> wShape, aabbMin, aabbMax, hullAabb, hullVerts; DBuf<uint32_t> hullRanges;
     // broad phase
     DBuf<double> axisPartials;
-    DBuf<uint32_t> largeList, isLarge, cellKeys, cellVals, cellKeysS, cellValsS, cellStart, cellEnd;
+    DBuf<uint32_t> largeList, isLarge, cellKeys, cellVals, cellKeysS, cellValsS, cellCount, cellLower;
+    DBuf<int> blockBounds;
     DBuf<float4> sMin, sMax;
     DBuf<GridParams> grid; DBuf<StepScalars> scalars;
     DBuf<uint64_t> pairKeys, pairKeysS;
@@ -105,7 +106,8 @@ struct mi_world {
     mi_step_counts counts{};
     mi_stage_times times{};
     hipEvent_t ev[10]{};
-    uint32_t numColorsUsed = 0;
+    uint32_t numColorsUsed = 0, colorRounds = 0;
+    uint32_t lastNumCells = kMaxCells;   // cells covered by the histogram/scan (host-side bound)
     std::vector<uint32_t> colorOffsets;
 
     int init(int dev);
@@ -302,7 +304,8 @@ int mi_world::upload() {
     HIP_TRY(sMin.ensure(nc + 1)); HIP_TRY(sMax.ensure(nc + 1));
     HIP_TRY(largeList.ensure(nc + 1)); HIP_TRY(isLarge.ensure(nc + 1));
     HIP_TRY(cellKeys.ensure(nc + 1)); HIP_TRY(cellVals.ensure(nc + 1)); HIP_TRY(cellKeysS.ensure(nc + 1)); HIP_TRY(cellValsS.ensure(nc + 1));
-    HIP_TRY(cellStart.ensure(kMaxCells)); HIP_TRY(cellEnd.ensure(kMaxCells));
+    HIP_TRY(cellCount.ensure(kMaxCells)); HIP_TRY(cellLower.ensure(kMaxCells));
+    HIP_TRY(blockBounds.ensure(6 * (size_t)divUp(std::max(nc, 1u), 256)));
     HIP_TRY(axisPartials.ensure(6 * (size_t)divUp(std::max(nc, 1u), 256)));
     // hull geometry pool
     std::vector<float4> ha(2 * hulls.size() + 1), hv; std::vector<uint32_t> hr(2 * hulls.size() + 2);
@@ -350,10 +353,11 @@ int mi_world::download() {
 __global__ void k_reset_scalars(StepScalars* sc) {
     uint32_t t = threadIdx.x;
     if (t == 0) {
-        sc->extentSum = 0.0; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->uncolored = 0;
+        sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->uncolored = 0;
         for (int a = 0; a < 3; ++a) { sc->boundsMin[a] = 0x7FFFFFFF; sc->boundsMax[a] = (int)0x80000000; }
     }
     if (t <= kOverflowColor) sc->colorHist[t] = 0;
+    sc->extentHist[t] = 0; sc->extentHist[t + 128] = 0;
 }
 __global__ void k_zero_u32(uint32_t* p) { *p = 0; }
 
@@ -379,20 +383,27 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     if (nc) {
         uint32_t nblk = divUp(nc, 256);
         k_axis_partials<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, axisPartials.p, sc);
-        k_bp_classify<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, sc, largeList.p, isLarge.p);
-        k_bp_grid_setup<<<1, 1, 0, st>>>(nc, sc, grid.p);
-        k_bp_cell_ids<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, isLarge.p, grid.p, cellKeys.p, cellVals.p);
+        k_bp_threshold<<<1, 1, 0, st>>>(nc, sc);
+        k_bp_classify<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, sc, largeList.p, isLarge.p, blockBounds.p);
+        k_bp_grid_setup<<<1, 256, 0, st>>>(nc, nblk, blockBounds.p, sc, grid.p);
+        // cell histogram -> exclusive prefix (cellLower).  The scan always covers the capped table (16 MB): its
+        // length must be known on the host and the real cell count only exists on the device.
+        HIP_TRY(hipMemsetAsync(cellCount.p, 0, (size_t)lastNumCells * sizeof(uint32_t), st));
+        k_bp_cell_ids<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, isLarge.p, grid.p, cellKeys.p, cellVals.p, cellCount.p);
         size_t tb = 0;
+        HIP_TRY(rocprim::exclusive_scan(nullptr, tb, cellCount.p, cellLower.p, 0u, (size_t)lastNumCells, rocprim::plus<uint32_t>(), st));
+        if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
+        HIP_TRY(rocprim::exclusive_scan(temp.p, tb, cellCount.p, cellLower.p, 0u, (size_t)lastNumCells, rocprim::plus<uint32_t>(), st));
+        tb = 0;
         HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, cellKeys.p, cellKeysS.p, cellVals.p, cellValsS.p, nc, 0, 32, st));
         if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
         HIP_TRY(rocprim::radix_sort_pairs(temp.p, tb, cellKeys.p, cellKeysS.p, cellVals.p, cellValsS.p, nc, 0, 32, st));
-        k_bp_clear_cells<<<1024, B, 0, st>>>(grid.p, cellStart.p);
-        k_bp_cell_bounds<<<divUp(nc, B), B, 0, st>>>(nc, cellKeysS.p, cellValsS.p, aabbMin.p, aabbMax.p, sMin.p, sMax.p, cellStart.p, cellEnd.p);
+        k_bp_gather_sorted<<<divUp(nc, B), B, 0, st>>>(nc, cellValsS.p, aabbMin.p, aabbMax.p, sMin.p, sMax.p);
         if (pairKeys.cap == 0) { HIP_TRY(pairKeys.ensure(std::max<size_t>(1u << 16, 8 * (size_t)nc))); }
         for (int attempt = 0; attempt < 2; ++attempt) {
             uint32_t cap = (uint32_t)std::min<size_t>(pairKeys.cap, 0x7FFFFFFFu);
-            k_bp_pairs_grid<<<divUp(nc, B), B, 0, st>>>(nc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellStart.p, cellEnd.p, grid.p, pairKeys.p, cap, sc);
-            k_bp_pairs_large<<<2048, B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc);
+            k_bp_pairs_grid<<<divUp(nc * 5u, B), B, 0, st>>>(nc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, grid.p, pairKeys.p, cap, sc);
+            k_bp_pairs_large<<<dim3(std::min(divUp(nc, B), 256u), 16), B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc);
             HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             numPairs = hs.numPairs;
@@ -401,7 +412,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
             k_zero_u32<<<1, 1, 0, st>>>(&sc->numPairs);
             k_zero_u32<<<1, 1, 0, st>>>(&sc->numOverlaps);
         }
-        k_axis_final<<<1, 1, 0, st>>>(nc, nblk, axisPartials.p, sc);
+        k_axis_final<<<1, 256, 0, st>>>(nc, nblk, axisPartials.p, sc);
     }
     mark();  // 2
     uint32_t nm = 0, ncon = 0;
@@ -450,6 +461,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
             if (hs.uncolored == 0) break;
             if (round > 4096) return fail(MI_ERR_DEVICE, "colouring did not converge");
         }
+        colorRounds = round;
         uint32_t off = 0;
         for (uint32_t c = 0; c <= kOverflowColor; ++c) { colorOffsets[c] = off; off += hs.colorHist[c]; if (hs.colorHist[c]) numColorsUsed = c + 1; }
         colorOffsets[kOverflowColor + 1] = off;
@@ -476,7 +488,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
         joints.solveIteration(*this, st);   // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
         for (uint32_t c = 0; c < kOverflowColor && c < numColorsUsed; ++c) {
             uint32_t s0 = colorOffsets[c], s1 = colorOffsets[c + 1];
-            if (s1 > s0) k_contact_solve<<<divUp(s1 - s0, B), B, 0, st>>>(s0, s1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
+            if (s1 > s0) k_contact_solve<<<divUp(s1 - s0, 64), 64, 0, st>>>(s0, s1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
         }
         uint32_t o0 = colorOffsets[kOverflowColor], o1 = colorOffsets[kOverflowColor + 1];
         if (o1 > o0) k_contact_solve_serial<<<1, 64, 0, st>>>(o0, o1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
@@ -492,7 +504,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     times.world_colliders = el(0, 1); times.broadphase = el(1, 2); times.narrowphase = el(2, 3); times.integrate_forces = el(3, 4);
     times.schedule = el(4, 5); times.init_constraints = el(5, 6); times.solve = el(6, 7); times.integrate_velocities = el(7, 8); times.total = el(0, 8);
     counts.num_rigid_bodies = nb; counts.num_colliders = nc; counts.num_broadphase_overlaps = nc ? hs.numOverlaps : 0;
-    counts.num_collisions = nm; counts.num_contacts = ncon; counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur;
+    counts.num_collisions = nm; counts.num_contacts = ncon; counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur; counts.reserved = colorRounds;
     return MI_OK;
 }
 

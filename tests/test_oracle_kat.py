@@ -1,0 +1,180 @@
+"""Known-answer tests that pin the CPU oracle (the reference ships no tests or golden vectors)."""
+import math
+import numpy as np
+import pytest
+
+from d3d12renderer_amd import capi, scenes
+from helpers import single_body_scene, two_body_scene, contact_set
+
+DT = 1.0 / 120.0
+
+
+def run(oracle_mod, scene, steps, order=0):
+    w = scene.populate(oracle_mod.create_world(order))
+    w.step_fixed(scene.settings(), scene.dt, steps)
+    return w
+
+
+def test_free_fall_matches_semi_implicit_euler(oracle_mod):
+    # v_{n+1} = (v_n + g dt) / (1 + dt c), x_{n+1} = x_n + v_{n+1} dt  (rigid_body.cpp:95-142)
+    sc = single_body_scene(capi.SPHERE, (0, 0, 0, 1.0), pos=(0, 50, 0), ground=False)
+    w = run(oracle_mod, sc, 100)
+    v = np.float32(0); x = np.float32(50); dt = np.float32(DT)
+    im = np.float32(1.0) / (np.float32(4.0 / 3.0) * (np.float32(3.14159265359) * np.float32(1.0)) * np.float32(1.0) * np.float32(1.0))
+    for _ in range(100):
+        f = np.float32(-9.81) / im * np.float32(1.0)
+        v = v + (f * im) * dt
+        v = v * (np.float32(1.0) / (np.float32(1.0) + dt * np.float32(0.4)))
+        x = x + v * dt
+    p, _ = w.physics_transforms()
+    lin, _ = w.velocities()
+    assert abs(p[0, 1] - x) < 1e-4
+    assert abs(lin[0, 1] - v) < 1e-5
+
+
+def test_mass_properties_analytic(oracle_mod):
+    # sphere: m = 4/3 pi r^3 rho, I = 2/5 m r^2 ; box: m = 8 hx hy hz rho, Ixx = m/12 ((2hy)^2 + (2hz)^2)
+    sc = single_body_scene(capi.SPHERE, (0, 0, 0, 0.5), density=2.0, ground=False)
+    im, ii, cog = sc.populate(oracle_mod.create_world(0)).mass_properties()
+    m = 4.0 / 3.0 * math.pi * 0.125 * 2.0
+    assert im[0] == pytest.approx(1.0 / m, rel=1e-5)
+    assert ii[0, 0] == pytest.approx(1.0 / (0.4 * m * 0.25), rel=1e-5)
+    sc = single_body_scene(capi.AABB, (-0.5, -1.0, -1.5, 0.5, 1.0, 1.5), density=3.0, ground=False)
+    im, ii, cog = sc.populate(oracle_mod.create_world(0)).mass_properties()
+    m = 1.0 * 2.0 * 3.0 * 3.0
+    assert im[0] == pytest.approx(1.0 / m, rel=1e-5)
+    assert ii[0, 0] == pytest.approx(12.0 / (m * (4.0 + 9.0)), rel=1e-5)
+    assert ii[0, 4] == pytest.approx(12.0 / (m * (1.0 + 9.0)), rel=1e-5)
+    assert ii[0, 8] == pytest.approx(12.0 / (m * (1.0 + 4.0)), rel=1e-5)
+    # capsule along y: mass = (4/3 pi r^3 + pi r^2 h) rho
+    sc = single_body_scene(capi.CAPSULE, (0, -0.5, 0, 0, 0.5, 0, 0.25), density=1.0, ground=False)
+    im, ii, cog = sc.populate(oracle_mod.create_world(0)).mass_properties()
+    m = 4.0 / 3.0 * math.pi * 0.25 ** 3 + math.pi * 0.25 ** 2 * 1.0
+    assert im[0] == pytest.approx(1.0 / m, rel=1e-5)
+    assert ii[0, 0] == pytest.approx(ii[0, 8], rel=1e-5) and ii[0, 4] > ii[0, 0]   # slender about y
+    assert np.allclose(cog[0], 0, atol=1e-7)
+
+
+def test_sphere_sphere_depth_normal_point(oracle_mod):
+    # centres 1.5 apart, radii 1 + 1 -> depth 0.5, normal from A to B, point = midpoint of the overlap
+    sc = two_body_scene([(capi.SPHERE, (0, 0, 0, 1.0), (0, 0, 0), (0, 0, 0, 1), capi.ENTITY_DYNAMIC),
+                         (capi.SPHERE, (0, 0, 0, 1.0), (1.5, 0, 0), (0, 0, 0, 1), capi.ENTITY_DYNAMIC)])
+    w = run(oracle_mod, sc, 1)
+    c = w.contacts()
+    assert len(c) == 1
+    assert c[0]["penetration_depth"] == pytest.approx(0.5, abs=1e-6)
+    # world index = reverse creation order; same type => A is the earlier endpoint on the axis (x=0 sphere, world index 1)
+    assert (c[0]["collider_a"], c[0]["collider_b"]) == (1, 0)
+    assert np.allclose(c[0]["normal"], (1, 0, 0), atol=1e-6)
+    assert np.allclose(c[0]["point"], (0.75, 0, 0), atol=1e-6)
+    # friction = sqrt(0.5*0.5) = 0.5, restitution = 0.1 packed 16:16 (collision_narrow.cpp:2232-2238)
+    assert c[0]["friction_restitution"] == (int(np.float32(0.5) * np.float32(65535)) << 16) | int(np.float32(0.1) * np.float32(65535))
+
+
+def test_box_on_ground_four_contacts_and_rest(oracle_mod):
+    sc = single_body_scene(capi.AABB, (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5), pos=(0, 0.49, 0))
+    w = run(oracle_mod, sc, 1)
+    c = w.contacts()
+    assert len(c) == 4 and w.counts()["num_collisions"] == 1
+    assert np.allclose(c["penetration_depth"], 0.01, atol=1e-6)
+    assert np.allclose(np.abs(c["normal"][:, 1]), 1.0)
+    xs = sorted((round(float(p[0]), 3), round(float(p[2]), 3)) for p in c["point"])
+    assert xs == [(-0.5, -0.5), (-0.5, 0.5), (0.5, -0.5), (0.5, 0.5)]
+    w.step_fixed(sc.settings(), sc.dt, 400)
+    p, q = w.physics_transforms()
+    assert abs(p[0, 1] - 0.5) < 5e-3 and abs(p[0, 0]) < 1e-3 and abs(p[0, 2]) < 1e-3
+    assert abs(abs(q[0, 3]) - 1.0) < 1e-4
+
+
+def test_rotated_box_obb_ground_manifold(oracle_mod):
+    # a box rotated 30 degrees about y rests on the ground with a 4-point manifold via the OBB path
+    h = math.radians(30) / 2
+    sc = single_body_scene(capi.AABB, (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5), pos=(0, 0.495, 0), rot=(0, math.sin(h), 0, math.cos(h)))
+    w = run(oracle_mod, sc, 1)
+    c = w.contacts()
+    assert len(c) == 4
+    assert np.allclose(c["penetration_depth"], 0.005, atol=1e-5)
+    r = np.hypot(c["point"][:, 0], c["point"][:, 2])
+    assert np.allclose(r, math.sqrt(0.5), atol=1e-4)
+
+
+def test_sphere_rests_on_ground(oracle_mod):
+    sc = single_body_scene(capi.SPHERE, (0, 0, 0, 1.0), pos=(0, 1.5, 0))
+    w = run(oracle_mod, sc, 600)
+    p, _ = w.physics_transforms()
+    lin, ang = w.velocities()
+    assert abs(p[0, 1] - 1.0) < 5e-3
+    assert np.abs(lin[0]).max() < 5e-2
+
+
+def test_capsule_capsule_parallel_two_contacts(oracle_mod):
+    sc = two_body_scene([(capi.CAPSULE, (-1, 0, 0, 1, 0, 0, 0.5), (0, 0, 0), (0, 0, 0, 1), capi.ENTITY_DYNAMIC),
+                         (capi.CAPSULE, (-1, 0, 0, 1, 0, 0, 0.5), (0.5, 0.8, 0), (0, 0, 0, 1), capi.ENTITY_DYNAMIC)])
+    w = run(oracle_mod, sc, 1)
+    c = w.contacts()
+    assert len(c) == 2
+    assert np.allclose(c["penetration_depth"], 0.2, atol=1e-6)
+    assert np.allclose(np.abs(c["normal"][:, 1]), 1.0, atol=1e-6)
+
+
+def test_gjk_epa_capsule_on_ground_face_clip(oracle_mod):
+    # horizontal capsule slightly sunk into the ground AABB: GJK+EPA finds the face normal, the
+    # segment is clipped against the face -> 2 contacts (collision_narrow.cpp:705-768)
+    sc = single_body_scene(capi.CAPSULE, (-0.5, 0, 0, 0.5, 0, 0, 0.25), pos=(0, 0.24, 0))
+    w = run(oracle_mod, sc, 1)
+    c = w.contacts()
+    assert len(c) == 2
+    assert np.allclose(np.abs(c["normal"][:, 1]), 1.0, atol=1e-3)
+    assert np.allclose(c["penetration_depth"], 0.01, atol=2e-3)
+
+
+def test_reference_and_canonical_orders_agree_on_first_contact_step(oracle_mod):
+    """The two pipelines (SAP sweep order vs sorted canonical order) must produce the same pair set and
+    the same manifolds bit-for-bit on identical input state."""
+    for sc in (scenes.mixed_stack(6, 3, 6), scenes.obb_pile(6, 3, 6, spacing=1.0)):
+        a = run(oracle_mod, sc, 1, 0)
+        b = run(oracle_mod, sc, 1, 1)
+        ca, cb = a.counts(), b.counts()
+        for k in ("num_broadphase_overlaps", "num_collisions", "num_contacts"):
+            assert ca[k] == cb[k] and ca[k] > 0
+        pa = {tuple(sorted(p)) for p in a.broadphase_pairs().tolist()}
+        pb = {tuple(sorted(p)) for p in b.broadphase_pairs().tolist()}
+        assert pa == pb
+        assert contact_set(a.contacts()) == contact_set(b.contacts())
+
+
+def test_contact_counts_track_between_orders_for_many_steps(oracle_mod):
+    # PGS is order dependent, so trajectories drift apart; the scene-level integers stay close and both settle.
+    sc = scenes.sphere_drop(6)
+    a = sc.populate(oracle_mod.create_world(0)); b = sc.populate(oracle_mod.create_world(1))
+    s = sc.settings()
+    a.step_fixed(s, sc.dt, 300); b.step_fixed(s, sc.dt, 300)
+    pa, _ = a.physics_transforms(); pb, _ = b.physics_transforms()
+    assert np.isfinite(pa).all() and np.isfinite(pb).all()
+    assert abs(a.counts()["num_contacts"] - b.counts()["num_contacts"]) <= 0.15 * a.counts()["num_contacts"]
+    assert pa[:-1, 1].min() > 0.9 and pb[:-1, 1].min() > 0.9   # nothing fell through the ground
+
+
+def test_oracle_is_deterministic(oracle_mod):
+    sc = scenes.obb_pile(5, 3, 5)
+    res = []
+    for _ in range(2):
+        w = run(oracle_mod, sc, 60, 1)
+        res.append(w.physics_transforms()[0].tobytes())
+    assert res[0] == res[1]
+
+
+def test_physics_step_accumulator_and_interpolation(oracle_mod):
+    # physicsStep: timer += dt; sub-steps while timer >= 1/frameRate (<= 4); pose = lerp(t0, t1, timer/fixedDt)
+    sc = single_body_scene(capi.SPHERE, (0, 0, 0, 1.0), pos=(0, 50, 0), ground=False)
+    w = sc.populate(oracle_mod.create_world(0))
+    s = capi.StepSettings(1, 120, 4, 10)
+    w.step(s, 1.0 / 240.0)                  # below one fixed step: nothing simulated
+    p, _ = w.transforms()
+    assert p[0, 1] == 50.0
+    w.step(s, 1.0 / 240.0 + 1.0 / 480.0)    # one sub-step, remainder 1/480 => t = 0.25
+    p, _ = w.transforms(); pp, _ = w.physics_transforms()
+    assert pp[0, 1] < 50.0
+    assert p[0, 1] == pytest.approx(50.0 + 0.25 * (pp[0, 1] - 50.0), abs=1e-5)
+    w.step(s, 10.0)                          # at most 4 sub-steps, the rest is dropped (fmod)
+    assert w.counts()["num_rigid_bodies"] == 1
