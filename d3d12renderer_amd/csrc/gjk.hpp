@@ -1,6 +1,385 @@
-// gjk.hpp — GJK + EPA on the device (one pair per lane).  Filled in by the GJK/EPA milestone.
+// gjk.hpp — GJK + EPA on the device, one pair per lane (src/physics/collision_gjk.{h,cpp},
+// src/physics/collision_epa.{h,cpp}) and the tests built on them (capsule/cylinder vs box with face
+// clipping, cylinder vs cylinder, every *-hull pair; src/physics/collision_narrow.cpp:496-1071,1150-1584).
+//
+// The reference's EPA polytope is a 73 KB stack object (3 x 1024-entry arrays); with <= 20 iterations at
+// most 24 points, 274 triangles and 276 edges can ever exist, so the per-lane state is 24/288/288 entries
+// (~12 KB of scratch) without changing behaviour.  GJK pairs run in their own kernel (k_narrow_gjk) so the
+// primitive buckets keep a scratch-free kernel.
 #pragma once
 #include "kernels.hpp"
+
 namespace mi {
-__device__ inline bool intersectGjk(const Shape&, const Shape&, const HullSet&, Manifold&, int) { return false; }
+
+struct SupPt { V3 a, b, m; };   // support point on A, on B, Minkowski difference
+struct Simplex { SupPt a, b, c, d; uint32_t n; };
+
+__device__ inline V3 supportOf(const Shape& s, const HullSet& hs, V3 dir) {  // collision_gjk.h:6-100
+    switch (s.type) {
+        case T_SPHERE: return normalize(dir) * s.radius + s.a;
+        case T_CAPSULE: {
+            float da = dot(dir, s.a), db = dot(dir, s.b);
+            V3 far = da > db ? s.a : s.b;
+            return normalize(dir) * s.radius + far;
+        }
+        case T_CYLINDER: {
+            float da = dot(dir, s.a), db = dot(dir, s.b);
+            V3 far = da > db ? s.a : s.b;
+            V3 n = s.a - s.b;
+            V3 pd = noz(cross(cross(n, dir), n));
+            return far + pd * s.radius;
+        }
+        case T_AABB:
+            return V3((dir.x < 0.f) ? s.a.x : s.b.x, (dir.y < 0.f) ? s.a.y : s.b.y, (dir.z < 0.f) ? s.a.z : s.b.z);
+        case T_OBB: {
+            dir = rotate(conj(s.rot), dir);
+            V3 r(dir.x < 0.f ? -s.b.x : s.b.x, dir.y < 0.f ? -s.b.y : s.b.y, dir.z < 0.f ? -s.b.z : s.b.z);
+            return s.a + rotate(s.rot, r);
+        }
+        default: {
+            dir = rotate(conj(s.rot), dir);
+            V3 best;
+            float maxD = -FLT_MAX;
+            uint32_t first = hs.ranges[2 * s.hull], count = hs.ranges[2 * s.hull + 1];
+            for (uint32_t i = 0; i < count; ++i) {
+                V3 v = xyz(hs.verts[first + i]);
+                float d = dot(dir, v);
+                if (d > maxD) { maxD = d; best = v; }
+            }
+            return s.a + rotate(s.rot, best);
+        }
+    }
+}
+
+__device__ inline SupPt supportPair(const Shape& A, const Shape& B, const HullSet& hs, V3 dir) {
+    SupPt p;
+    p.a = supportOf(A, hs, dir);
+    p.b = supportOf(B, hs, -dir);
+    p.m = p.a - p.b;
+    return p;
+}
+__device__ __forceinline__ V3 crossABA(V3 a, V3 b) { return cross(cross(a, b), a); }
+
+enum : int { GJK_STOP = 0, GJK_CONT = 1, GJK_ERR = 2 };
+
+// collision_gjk.cpp:6-212; the goto labels become an entry index into a fall-through switch.
+__device__ inline int updateSimplex(Simplex& s, const SupPt& a, V3& dir) {
+    if (s.n == 2) {
+        V3 ao = -a.m, ab = s.b.m - a.m, ac = s.c.m - a.m;
+        V3 abc = cross(ab, ac);
+        V3 abp = cross(ab, abc);
+        if (dot(ao, abp) > 0.f) { s.c = a; dir = crossABA(ab, ao); return GJK_CONT; }
+        V3 acp = cross(abc, ac);
+        if (dot(ao, acp) > 0.f) { s.b = a; dir = crossABA(ac, ao); return GJK_CONT; }
+        if (dot(ao, abc) >= 0.f) { s.d = s.b; s.b = a; s.n = 3; dir = abc; return GJK_CONT; }
+        if (dot(ao, -abc) >= 0.f) { s.d = s.c; s.c = s.b; s.b = a; s.n = 3; dir = -abc; return GJK_CONT; }
+        return GJK_ERR;
+    }
+    if (s.n == 3) {
+        V3 ao = -a.m, ab = s.b.m - a.m, ac = s.c.m - a.m, ad = s.d.m - a.m;
+        V3 bcd = cross(s.c.m - s.b.m, s.d.m - s.b.m);
+        if (dot(bcd, dir) > 0.00001f || dot(bcd, s.b.m) < -0.00001f) return GJK_ERR;
+        V3 abc = cross(ac, ab), abd = cross(ab, ad), adc = cross(ad, ac);
+        int flags = 0;
+        flags |= (dot(abc, ao) > 0.f) ? 1 : 0;
+        flags |= (dot(abd, ao) > 0.f) ? 2 : 0;
+        flags |= (dot(adc, ao) > 0.f) ? 4 : 0;
+        if (flags == 7) return GJK_ERR;
+        if (flags == 0) return GJK_STOP;
+        int label = 0;   // 1 overABC1, 2 overABC2, 3 overABD1, 4 overABD2, 5 overADC1, 6 overADC2
+        if (flags == 1) label = 1;
+        else if (flags == 2) label = 3;
+        else if (flags == 4) label = 5;
+        else if (flags == 3) label = (dot(cross(abc, ab), ao) > 0.f) ? 3 : 2;
+        else if (flags == 6) label = (dot(cross(abd, ad), ao) > 0.f) ? 5 : 4;
+        else if (flags == 5) label = (dot(cross(adc, ac), ao) > 0.f) ? 1 : 6;
+        switch (label) {
+            case 1:
+                if (dot(cross(abc, ab), ao) > 0.f) { s.c = a; s.n = 2; dir = crossABA(ab, ao); return GJK_CONT; }
+            case 2:
+                if (dot(cross(ac, abc), ao) > 0.f) { s.b = a; s.n = 2; dir = crossABA(ac, ao); return GJK_CONT; }
+                s.d = a; dir = abc; return GJK_CONT;
+            case 3:
+                if (dot(cross(abd, ad), ao) > 0.f) { s.b = s.d; s.c = a; s.n = 2; dir = crossABA(ad, ao); return GJK_CONT; }
+            case 4:
+                if (dot(cross(ab, abd), ao) > 0.f) { s.c = a; s.n = 2; dir = crossABA(ab, ao); return GJK_CONT; }
+                s.c = a; dir = abd; return GJK_CONT;
+            case 5:
+                if (dot(cross(adc, ac), ao) > 0.f) { s.b = a; s.n = 2; dir = crossABA(ac, ao); return GJK_CONT; }
+            case 6:
+                if (dot(cross(ad, adc), ao) > 0.f) { s.b = a; s.c = s.d; s.n = 2; dir = crossABA(ad, ao); return GJK_CONT; }
+                s.b = a; dir = adc; return GJK_CONT;
+        }
+        return GJK_ERR;
+    }
+    return GJK_ERR;
+}
+
+// collision_gjk.h:182-238 (+ a 64-iteration guard: a lane must terminate; treated like the reference's error path)
+__device__ inline bool gjkTest(const Shape& A, const Shape& B, const HullSet& hs, Simplex& sx) {
+    V3 dir(1.f, 0.1f, -0.2f);
+    sx.n = 0;
+    sx.c = supportPair(A, B, hs, dir);
+    if (dot(sx.c.m, dir) < 0.f) return false;
+    dir = -sx.c.m;
+    sx.b = supportPair(A, B, hs, dir);
+    if (dot(sx.b.m, dir) < 0.f) return false;
+    dir = crossABA(sx.c.m - sx.b.m, -sx.b.m);
+    sx.n = 2;
+    for (int guard = 0; guard < 64; ++guard) {
+        if (sqlen(dir) < 0.0001f) return false;
+        SupPt a = supportPair(A, B, hs, dir);
+        if (dot(a.m, dir) < 0.f) return false;
+        int r = updateSimplex(sx, a, dir);
+        if (r == GJK_STOP) { sx.a = a; sx.n = 4; return true; }
+        if (r == GJK_ERR) return false;
+    }
+    return false;
+}
+
+// ---- EPA (collision_epa.h:96-168, collision_epa.cpp)
+constexpr int kEpaPts = 24, kEpaTris = 288, kEpaEdges = 288, kEpaBorder = 32;
+struct EpaTri { uint16_t a, b, c, eA, eB, eC; V3 n; float dist; };
+struct EpaEdge { uint16_t a, b, tA, tB; };
+struct EpaState {
+    SupPt pts[kEpaPts];
+    EpaTri tris[kEpaTris];
+    EpaEdge edges[kEpaEdges];
+    uint8_t active[kEpaTris];
+    uint8_t refs[kEpaEdges];
+    uint16_t nTris, nPts, nEdges;
+};
+
+__device__ __forceinline__ void triInfo(const SupPt& a, const SupPt& b, const SupPt& c, V3& n, float& dist) {
+    n = normalize(cross(b.m - a.m, c.m - a.m));
+    dist = dot(n, a.m);
+}
+__device__ __forceinline__ uint16_t epaPushPt(EpaState& s, const SupPt& p) {
+    if (s.nPts >= kEpaPts) return 0xFFFF;
+    s.pts[s.nPts] = p; return s.nPts++;
+}
+__device__ __forceinline__ uint16_t epaPushTri(EpaState& s, uint16_t a, uint16_t b, uint16_t c, uint16_t eA, uint16_t eB, uint16_t eC, V3 n, float dist) {
+    if (s.nTris >= kEpaTris) return 0xFFFF;
+    uint16_t i = s.nTris++;
+    s.active[i] = 1;
+    EpaTri& t = s.tris[i];
+    t.a = a; t.b = b; t.c = c; t.eA = eA; t.eB = eB; t.eC = eC; t.n = n; t.dist = dist;
+    return i;
+}
+__device__ __forceinline__ uint16_t epaPushEdge(EpaState& s, uint16_t a, uint16_t b, uint16_t tA, uint16_t tB) {
+    if (s.nEdges >= kEpaEdges) return 0xFFFF;
+    uint16_t i = s.nEdges++;
+    EpaEdge e; e.a = a; e.b = b; e.tA = tA; e.tB = tB;
+    s.edges[i] = e;
+    return i;
+}
+__device__ inline bool epaAddPoint(EpaState& s, const SupPt& np) {  // collision_epa.cpp:117-240
+    for (uint32_t i = 0; i < s.nEdges; ++i) s.refs[i] = 0;
+    for (uint32_t i = 0; i < s.nTris; ++i) {
+        if (!s.active[i]) continue;
+        EpaTri& t = s.tris[i];
+        float d = dot(t.n, np.m - s.pts[t.a].m);
+        if (d > 0.f) { ++s.refs[t.eA]; ++s.refs[t.eB]; ++s.refs[t.eC]; s.active[i] = 0; }
+    }
+    uint16_t border[kEpaBorder]; uint32_t nb = 0;
+    for (uint32_t i = 0; i < s.nEdges; ++i)
+        if (s.refs[i] == 1) { if (nb >= (uint32_t)kEpaBorder) return false; border[nb++] = (uint16_t)i; }
+    uint16_t newEdgePerPoint[kEpaPts];
+    uint16_t npi = epaPushPt(s, np);
+    if (npi == 0xFFFF) return false;
+    uint16_t triOffset = s.nTris;
+    for (uint32_t i = 0; i < nb; ++i) {
+        uint16_t ei = border[i];
+        EpaEdge e = s.edges[ei];
+        bool aAct = s.active[e.tA] != 0, bAct = s.active[e.tB] != 0;
+        uint16_t connect = bAct ? e.a : e.b;
+        uint16_t triIndex = s.nTris;
+        uint16_t ne = epaPushEdge(s, connect, npi, 0xFFFF, s.nTris);
+        if (ne == 0xFFFF) return false;
+        newEdgePerPoint[connect] = ne;
+        uint16_t bI = connect, cI = bAct ? e.b : e.a;
+        V3 n; float dist;
+        triInfo(np, s.pts[bI], s.pts[cI], n, dist);
+        uint16_t test = epaPushTri(s, npi, bI, cI, ei, 0xFFFF, ne, n, dist);
+        if (test == 0xFFFF) return false;
+        if (aAct) s.edges[ei].tB = triIndex; else s.edges[ei].tA = triIndex;
+    }
+    for (uint32_t i = 0; i < nb; ++i) {
+        EpaEdge e = s.edges[border[i]];
+        bool bNew = e.tB >= triOffset;
+        uint16_t connect = bNew ? e.a : e.b;
+        uint16_t other = newEdgePerPoint[connect];
+        uint16_t triIndex = (uint16_t)(i + triOffset);
+        s.tris[triIndex].eB = other;
+        s.edges[other].tA = triIndex;
+    }
+    return true;
+}
+__device__ __forceinline__ V3 barycentric(V3 a, V3 b, V3 c, V3 p) {  // src/core/math.cpp:1391-1407
+    V3 v0 = b - a, v1 = c - a, v2 = p - a;
+    float d00 = dot(v0, v0), d01 = dot(v0, v1), d11 = dot(v1, v1), d20 = dot(v2, v0), d21 = dot(v2, v1);
+    float denom = d00 * d11 - d01 * d01;
+    denom = (fabsf(denom) < kEps) ? 1.f : denom;
+    float v = (d11 * d20 - d01 * d21) / denom;
+    float w = (d00 * d21 - d01 * d20) / denom;
+    float u = 1.0f - v - w;
+    return V3(u, v, w);
+}
+struct EpaOut { V3 point, normal; float depth; };
+
+__device__ inline void epaRun(const Simplex& g, const Shape& A, const Shape& B, const HullSet& hs, EpaState& s, EpaOut& out) {
+    s.nTris = 0; s.nPts = 0; s.nEdges = 0;
+    epaPushPt(s, g.a); epaPushPt(s, g.b); epaPushPt(s, g.c); epaPushPt(s, g.d);
+    V3 n; float dist;
+    triInfo(g.a, g.b, g.d, n, dist); epaPushTri(s, 0, 1, 3, 4, 3, 0, n, dist);
+    triInfo(g.b, g.c, g.d, n, dist); epaPushTri(s, 1, 2, 3, 5, 4, 1, n, dist);
+    triInfo(g.c, g.a, g.d, n, dist); epaPushTri(s, 2, 0, 3, 3, 5, 2, n, dist);
+    triInfo(g.a, g.c, g.b, n, dist); epaPushTri(s, 0, 2, 1, 1, 0, 2, n, dist);
+    epaPushEdge(s, 0, 1, 0, 3); epaPushEdge(s, 1, 2, 1, 3); epaPushEdge(s, 2, 0, 2, 3);
+    epaPushEdge(s, 0, 3, 2, 0); epaPushEdge(s, 1, 3, 0, 1); epaPushEdge(s, 2, 3, 1, 2);
+    uint32_t closest = 0;
+    for (uint32_t it = 0; it < 20; ++it) {
+        uint32_t prev = closest;
+        closest = 0xFFFFFFFFu; float minD = FLT_MAX;
+        for (uint32_t i = 0; i < s.nTris; ++i)
+            if (s.active[i] && s.tris[i].dist < minD) { minD = s.tris[i].dist; closest = i; }
+        if (closest == 0xFFFFFFFFu) { closest = prev; break; }   // degenerate polytope: keep the last face (the reference asserts here)
+        V3 tn = s.tris[closest].n; float td = s.tris[closest].dist;
+        SupPt a = supportPair(A, B, hs, tn);
+        float d = dot(a.m, tn);
+        if (d - td < 0.01f) break;
+        if (!epaAddPoint(s, a)) break;
+    }
+    const EpaTri& t = s.tris[closest];
+    const SupPt& a = s.pts[t.a]; const SupPt& b = s.pts[t.b]; const SupPt& c = s.pts[t.c];
+    V3 bc = barycentric(a.m, b.m, c.m, t.n * t.dist);
+    V3 pA = bc.x * a.a + bc.y * b.a + bc.z * c.a;
+    V3 pB = bc.x * a.b + bc.y * b.b + bc.z * c.b;
+    out.point = 0.5f * (pA + pB);
+    out.normal = t.n;
+    out.depth = t.dist;
+}
+
+__device__ inline bool gjkEpaSingle(const Shape& a, const Shape& b, const HullSet& hs, EpaState& st, Manifold& out, EpaOut& epa) {
+    Simplex sx;
+    if (!gjkTest(a, b, hs, sx)) return false;
+    epaRun(sx, a, b, hs, st, epa);   // EPA status is ignored by every caller (collision_narrow.cpp:509-512)
+    out.n = epa.normal;
+    out.count = 1;
+    out.d[0] = epa.depth;
+    out.p[0] = epa.point;
+    return true;
+}
+
+// capsule / cylinder vs AABB (collision_narrow.cpp:705-768, 953-1020): if EPA found a box-face normal and the
+// segment is parallel to that face, clip the segment against the face -> up to 2 contacts.
+__device__ inline bool segmentShapeVsAABB(const Shape& c, const Shape& box, const HullSet& hs, EpaState& st, Manifold& out) {
+    EpaOut epa;
+    if (!gjkEpaSingle(c, box, hs, st, out, epa)) return false;
+    V3 normal = epa.normal;
+    if (fabsf(normal.x) > 0.99f || fabsf(normal.y) > 0.99f || fabsf(normal.z) > 0.99f) {
+        V3 axis = normalize(c.b - c.a);
+        if (fabsf(dot(normal, axis)) < 0.01f) {
+            V3 cp[4], cn[4]; P4 planes[4];
+            V3 boxNormal = -normal;
+            P4 ref = boxReferencePlane(box.a, box.b, boxNormal);
+            ClipPoly poly; poly.n = 2;
+            V3 pa = c.a + normal * c.radius, pb = c.b + normal * c.radius;
+            poly.pt[0].v = pa; poly.pt[0].depth = -planeDist(pa, ref);
+            poly.pt[1].v = pb; poly.pt[1].depth = -planeDist(pb, ref);
+            V3 center = (box.a + box.b) * 0.5f;
+            boxClipPlanes((box.b - box.a) * 0.5f, boxNormal, cp, cn);
+            for (int i = 0; i < 4; ++i) { cp[i] = cp[i] + center; planes[i] = makePlane(cp[i], cn[i]); }
+            clipAndBuild(poly, planes, 4, ref, out);
+        }
+    }
+    return true;
+}
+
+__device__ inline bool cylinderCylinder(const Shape& a, const Shape& b, const HullSet& hs, EpaState& st, Manifold& out) {  // 821-951
+    V3 aDir = a.b - a.a;
+    V3 bDir = normalize(b.b - b.a);
+    float aLen = len(aDir);
+    aDir = aDir * (1.f / aLen);
+    float parallel = dot(aDir, bDir);
+    if (fabsf(parallel) > 0.99f) {
+        V3 pBa = b.a, pBb = b.b;
+        if (parallel < 0.f) { V3 t = pBa; pBa = pBb; pBb = t; }
+        V3 ref = a.a;
+        float a0 = 0.f, a1 = aLen;
+        float b0 = dot(aDir, pBa - ref), b1 = dot(aDir, pBb - ref);
+        float left = fmaxr(a0, b0), right = fminr(a1, b1);
+        if (right < left) return false;
+        V3 cA0 = ref + left * aDir, cA1 = ref + right * aDir;
+        V3 cB0 = closestOnSegment(cA0, pBa, pBb);
+        V3 cB1 = cB0 + (right - left) * aDir;
+        V3 normal = cB0 - cA0;
+        float d = len(normal);
+        float pen = (a.radius + b.radius) - d;
+        if (pen < 0.f) return false;
+        float capPen = right - left;
+        if (capPen < pen) {
+            out.count = 1;
+            out.d[0] = capPen;
+            // the reference applies the scalar to every component here (vec3 -/+ float): kept as written
+            if (b0 > a0) { out.n = aDir; out.p[0] = a.b - V3(capPen * 0.5f); }
+            else { out.n = -aDir; out.p[0] = a.a + V3(capPen * 0.5f); }
+        } else {
+            if (d < kEps) { d = 0.f; normal = V3(0.f, 1.f, 0.f); }
+            else normal = normal / d;
+            out.n = normal;
+            out.count = 2;
+            out.d[0] = pen; out.p[0] = (cA0 + cB0) * 0.5f;
+            out.d[1] = pen; out.p[1] = (cA1 + cB1) * 0.5f;
+        }
+        return true;
+    }
+    EpaOut epa;
+    return gjkEpaSingle(a, b, hs, st, out, epa);
+}
+
+// mode: 0 plain GJK+EPA single contact, 1 segment shape vs AABB, 2 segment shape vs OBB, 3 cylinder vs cylinder
+__device__ inline bool intersectGjkImpl(const Shape& a, const Shape& b, const HullSet& hs, EpaState& st, Manifold& out, int mode) {
+    EpaOut epa;
+    switch (mode) {
+        case 1: return segmentShapeVsAABB(a, b, hs, st, out);
+        case 2: {  // into the box frame and back (770-790, 1022-1043)
+            Shape c = a;
+            c.a = rotate(conj(b.rot), a.a - b.a) + b.a;
+            c.b = rotate(conj(b.rot), a.b - b.a) + b.a;
+            Shape box; box.type = T_AABB; box.a = b.a - b.b; box.b = b.a + b.b; box.radius = 0.f; box.hull = 0;
+            if (!segmentShapeVsAABB(c, box, hs, st, out)) return false;
+            out.n = rotate(b.rot, out.n);
+            for (uint32_t i = 0; i < out.count; ++i) out.p[i] = rotate(b.rot, out.p[i] - b.a) + b.a;
+            return true;
+        }
+        case 3: return cylinderCylinder(a, b, hs, st, out);
+        default: return gjkEpaSingle(a, b, hs, st, out, epa);
+    }
+}
+
+__global__ __launch_bounds__(64) void k_narrow_gjk(uint32_t numPairs, const uint64_t* __restrict__ pairKeys, const float4* __restrict__ wShape,
+                                                   HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
+                                                   float4* __restrict__ npPoints) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= numPairs) return;
+    uint64_t key = pairKeys[p];
+    uint32_t bucket = (uint32_t)(key >> 58), a = (uint32_t)((key >> 29) & 0x1FFFFFFFu), b = (uint32_t)(key & 0x1FFFFFFFu);
+    uint32_t ta = 0, rem = bucket;
+    while (rem >= 6u - ta) { rem -= 6u - ta; ++ta; }
+    uint32_t tb = ta + rem;
+    int mode = gjkMode(ta, tb);
+    if (mode < 0) return;
+    Shape sa = loadShape(wShape, a, ta), sb = loadShape(wShape, b, tb);
+    Manifold m; m.count = 0;
+    EpaState st;
+    bool hit = intersectGjkImpl(sa, sb, hs, st, m, mode);
+    uint32_t cnt = hit ? m.count : 0u;
+    npPacked[p] = cnt ? ((1ull << 32) | (uint64_t)cnt) : 0ull;
+    if (cnt) {
+        npNormal[p] = f4(m.n, 0.f);
+        for (uint32_t k = 0; k < cnt; ++k) npPoints[4 * p + k] = f4(m.p[k], m.d[k]);
+    }
+}
+
 }  // namespace mi

@@ -472,7 +472,17 @@ __device__ __forceinline__ Shape loadShape(const float4* __restrict__ wShape, ui
 
 struct HullSet { const float4* verts; const uint32_t* ranges; };  // vertex pool + [first,count] per geometry
 
-__device__ bool intersectGjk(const Shape& a, const Shape& b, const HullSet& hs, Manifold& out, int mode);  // gjk.hpp
+// Buckets that need GJK/EPA (and ~12 KB of per-lane scratch) run in k_narrow_gjk (gjk.hpp); -1 = primitive bucket.
+// mode: 0 plain GJK+EPA single contact, 1 segment shape vs AABB, 2 segment shape vs OBB, 3 cylinder vs cylinder
+__device__ __forceinline__ int gjkMode(uint32_t ta, uint32_t tb) {
+    if (tb == T_HULL) return 0;
+    if (ta == T_CAPSULE && tb == T_AABB) return 1;
+    if (ta == T_CAPSULE && tb == T_OBB) return 2;
+    if (ta == T_CYLINDER && tb == T_CYLINDER) return 3;
+    if (ta == T_CYLINDER && tb == T_AABB) return 1;
+    if (ta == T_CYLINDER && tb == T_OBB) return 2;
+    return -1;
+}
 
 __device__ inline bool intersectPair(const Shape& a, const Shape& b, const HullSet& hs, Manifold& out) {
     switch (a.type) {
@@ -483,34 +493,34 @@ __device__ inline bool intersectPair(const Shape& a, const Shape& b, const HullS
                 case T_CYLINDER: return sphereCylinder(a.a, a.radius, b.a, b.b, b.radius, out);
                 case T_AABB: return sphereAABB(a.a, a.radius, b.a, b.b, out);
                 case T_OBB: return sphereOBB(a.a, a.radius, b.rot, b.a, b.b, out);
-                default: return intersectGjk(a, b, hs, out, 0);
+                default: return false;  // GJK bucket: k_narrow_gjk
             }
         case T_CAPSULE:
             switch (b.type) {
                 case T_CAPSULE: return capsuleVsSegmentShape(a, b, false, out);
                 case T_CYLINDER: return capsuleVsSegmentShape(a, b, true, out);
-                case T_AABB: return intersectGjk(a, b, hs, out, 1);
-                case T_OBB: return intersectGjk(a, b, hs, out, 2);
-                default: return intersectGjk(a, b, hs, out, 0);
+                case T_AABB: return false;  // GJK bucket: k_narrow_gjk
+                case T_OBB: return false;  // GJK bucket: k_narrow_gjk
+                default: return false;  // GJK bucket: k_narrow_gjk
             }
         case T_CYLINDER:
             switch (b.type) {
-                case T_CYLINDER: return intersectGjk(a, b, hs, out, 3);
-                case T_AABB: return intersectGjk(a, b, hs, out, 1);
-                case T_OBB: return intersectGjk(a, b, hs, out, 2);
-                default: return intersectGjk(a, b, hs, out, 0);
+                case T_CYLINDER: return false;  // GJK bucket: k_narrow_gjk
+                case T_AABB: return false;  // GJK bucket: k_narrow_gjk
+                case T_OBB: return false;  // GJK bucket: k_narrow_gjk
+                default: return false;  // GJK bucket: k_narrow_gjk
             }
         case T_AABB:
             switch (b.type) {
                 case T_AABB: return aabbAABB(a.a, a.b, b.a, b.b, out);
                 case T_OBB: return obbOBB(Q4(0.f, 0.f, 0.f, 1.f), (a.a + a.b) * 0.5f, (a.b - a.a) * 0.5f, b.rot, b.a, b.b, out);
-                default: return intersectGjk(a, b, hs, out, 0);
+                default: return false;  // GJK bucket: k_narrow_gjk
             }
         case T_OBB:
             if (b.type == T_OBB) return obbOBB(a.rot, a.a, a.b, b.rot, b.a, b.b, out);
-            return intersectGjk(a, b, hs, out, 0);
+            return false;  // GJK bucket: k_narrow_gjk
         default:
-            return intersectGjk(a, b, hs, out, 0);
+            return false;  // GJK bucket: k_narrow_gjk
     }
 }
 
@@ -525,6 +535,7 @@ __global__ __launch_bounds__(256) void k_narrow(uint32_t numPairs, const uint64_
     uint32_t ta = 0, rem = bucket;
     while (rem >= 6u - ta) { rem -= 6u - ta; ++ta; }
     uint32_t tb = ta + rem;
+    if (gjkMode(ta, tb) >= 0) return;   // handled by k_narrow_gjk
     Shape sa = loadShape(wShape, a, ta), sb = loadShape(wShape, b, tb);
     Manifold m; m.count = 0;
     bool hit = intersectPair(sa, sb, hs, m);

@@ -107,6 +107,7 @@ struct mi_world {
     mi_stage_times times{};
     hipEvent_t ev[10]{};
     uint32_t numColorsUsed = 0, colorRounds = 0;
+    bool usesGjk = false;   // any capsule / cylinder / hull collider present (decided at upload)
     uint32_t lastNumCells = kMaxCells;   // cells covered by the histogram/scan (host-side bound)
     std::vector<uint32_t> colorOffsets;
 
@@ -288,6 +289,8 @@ int mi_world::upload() {
     HIP_TRY(gPos.ensure(nb + 1)); HIP_TRY(gInvI.ensure(3 * ((size_t)nb + 1))); HIP_TRY(gVel.ensure(2 * ((size_t)nb + 1)));
     HIP_TRY(bodyTop.ensure(nb + 1)); HIP_TRY(bodyUsed.ensure(nb + 1));
 
+    usesGjk = false;
+    for (const HCollider& c : colliders) if (c.desc.type == T_CAPSULE || c.desc.type == T_CYLINDER || c.desc.type == T_HULL) usesGjk = true;
     std::vector<uint32_t> tb(2 * (size_t)nc); std::vector<float4> sh(3 * (size_t)nc), sp(nc), sr(nc), mat(nc);
     for (uint32_t k = 0; k < nc; ++k) {   // world index k <-> creation index nc-1-k (EnTT iterates back to front, physics.cpp:635-641)
         const HCollider& c = colliders[nc - 1 - k];
@@ -426,6 +429,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
         HIP_TRY(manPair.ensure(numPairs)); HIP_TRY(manBodies.ensure(numPairs)); HIP_TRY(manInfo.ensure(numPairs));
         HullSet hset{hullVerts.p, hullRanges.p};
         k_narrow<<<divUp(numPairs, B), B, 0, st>>>(numPairs, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
+        if (usesGjk) k_narrow_gjk<<<divUp(numPairs, 64), 64, 0, st>>>(numPairs, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
         tb = 0;
         HIP_TRY(rocprim::exclusive_scan(nullptr, tb, npPacked.p, npScan.p, (uint64_t)0, numPairs, rocprim::plus<uint64_t>(), st));
         if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");

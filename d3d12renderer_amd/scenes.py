@@ -159,5 +159,54 @@ def obb_pile(nx=128, ny=16, nz=128, seed=3, solver_iterations=20, spacing=1.5):
     return Scene(f"cfg3_obb_pile_{n}", ents, np.arange(n + 5, dtype=np.uint32), cols, solver_iterations)
 
 
+def convex_hull_mesh(seed=7, n_points=24, radius=0.6):
+    """A small convex hull (vertices, triangles with outward winding) for hull colliders."""
+    from scipy.spatial import ConvexHull
+    pts = np.stack([uniform(seed, 40 + a, n_points, -1.0, 1.0) for a in range(3)], axis=1).astype(np.float64)
+    pts *= radius / np.linalg.norm(pts, axis=1, keepdims=True).clip(0.3)
+    hull = ConvexHull(pts)
+    verts = pts[hull.vertices].astype(np.float32)
+    remap = {v: i for i, v in enumerate(hull.vertices)}
+    tris = []
+    c = verts.mean(axis=0)
+    for simplex in hull.simplices:
+        a, b, cc = (remap[v] for v in simplex)
+        n = np.cross(verts[b] - verts[a], verts[cc] - verts[a])
+        if np.dot(n, verts[a] - c) < 0:
+            b, cc = cc, b
+        tris.append((a, b, cc))
+    return verts, np.asarray(tris, np.uint32)
+
+
+def shape_zoo(nx=6, ny=4, nz=6, seed=5, solver_iterations=30, spacing=1.6):
+    """Every collider type (sphere, capsule, cylinder, AABB->OBB, OBB, hull) in a jittered lattice over the
+    ground: exercises all 21 narrow-phase buckets including the GJK/EPA ones."""
+    n = nx * ny * nz
+    e = make_entities(n)
+    e["position"] = _lattice(nx, ny, nz, spacing, 1.0, seed, 0.05)
+    e["rotation"] = random_unit_quaternions(seed, 20, n)
+    c = make_colliders(n, capi.SPHERE)
+    kind = _hash_u32(seed, 50, np.arange(n)) % 6
+    r = uniform(seed, 51, n, 0.3, 0.5)
+    hl = uniform(seed, 52, n, 0.2, 0.5)
+    for i in range(n):
+        k = int(kind[i])
+        c["type"][i] = k
+        if k == capi.SPHERE:
+            c["shape"][i, :4] = (0, 0, 0, r[i])
+        elif k in (capi.CAPSULE, capi.CYLINDER):
+            c["shape"][i, :7] = (0, -hl[i], 0, 0, hl[i], 0, r[i] * 0.7)
+        elif k == capi.AABB:
+            c["shape"][i, :6] = (-r[i], -hl[i], -r[i] * 0.8, r[i], hl[i], r[i] * 0.8)
+        elif k == capi.OBB:
+            c["shape"][i, :10] = (0, 0, 0, 1, 0.05, 0, 0, r[i], hl[i], r[i])
+        else:
+            c["shape"][i, :7] = (0, 0, 0, 1, 0, 0, 0)
+            c["hull_geometry"][i] = 0
+    ge, gc = _ground(100.0)
+    return Scene(f"zoo_{n}", np.concatenate([e, ge]), np.arange(n + 1, dtype=np.uint32), np.concatenate([c, gc]), solver_iterations,
+                 hulls=[convex_hull_mesh(seed)])
+
+
 def by_name(name, **kw):
     return {"cfg1": sphere_drop, "cfg2": mixed_stack, "cfg3": obb_pile}[name](**kw)

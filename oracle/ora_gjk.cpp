@@ -257,7 +257,9 @@ int epaCollisionInfo(const GjkSimplex& g, const SupportShape& A, const SupportSh
     uint32_t closest = 0;
     int rc = 3;
     for (uint32_t it = 0; it < 20; ++it) {
+        uint32_t prev = closest;
         closest = findTriangleClosestToOrigin(s);
+        if (closest == 0xFFFFFFFFu) { closest = prev; break; }  // degenerate polytope: keep the last face (the reference asserts here)
         EpaTri& t = s.tris[closest];
         GjkSimplexPoint a = supportPoint(A, B, t.normal);
         float d = dot(a.minkowski, t.normal);

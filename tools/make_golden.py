@@ -17,6 +17,7 @@ CASES = {
     "cfg1_spheres_216": (lambda: scenes.sphere_drop(6), 140),
     "cfg2_mixed_96": (lambda: scenes.mixed_stack(4, 6, 4), 90),
     "cfg3_obb_160": (lambda: scenes.obb_pile(4, 10, 4, spacing=1.0), 90),
+    "zoo_all_shapes_144": (lambda: scenes.shape_zoo(), 160),
 }
 
 
