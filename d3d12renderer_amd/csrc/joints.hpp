@@ -1,15 +1,637 @@
-// joints.hpp — joint constraints (distance, ball, fixed, hinge, cone-twist, slider).  Filled in by
-// the joints milestone.
+// joints.hpp — joint constraints on the device: distance, ball, fixed, hinge, cone-twist, slider.
+//
+// Behavioural spec: the scalar initialize/solve routines of src/physics/constraints.cpp (distance 189-264,
+// ball 460-528, fixed 736-823, hinge 1079-1307, cone-twist 1782-2070, slider 2638-2846) with PER-CONSTRAINT
+// limit/motor gating (the reference's AVX2 path gates per batch of 8; SURVEY.md §8(a) explains why the scalar
+// semantics are the ones to keep).  One lane per joint; joints of a type are greedily coloured on the host at
+// upload (topology is static) so a colour's lanes own disjoint dynamic bodies; per iteration the types run in
+// the reference's order distance -> ball -> fixed -> hinge -> cone-twist -> slider (constraints.cpp:3764-3769).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
+#include <algorithm>
+#include <cstring>
 #include "../../include/mi_physics.h"
+#include "../../include/mi_constraints.h"
+#include "dmath.hpp"
+
+namespace mi {
+
+constexpr float kBetaDistance = 0.1f, kBetaBall = 0.1f, kBetaSlider = 0.1f, kBetaHingeRot = 0.3f, kBetaHingeLimit = 0.1f,
+                kBetaTwistLimit = 0.1f, kBetaSliderLimit = 0.1f, kDtThreshold = 1e-5f;   // constraints.cpp:9-17
+
+struct BodyView { const float4* gPos; const float4* gInvI; float4* gVel; const float4* bRot; const float4* bCog; };
+struct BodyState { Q4 rot; V3 cog, pos; M3 invI; float invMass; };
+struct BodyVel { V3 v, w; float invMass; M3 invI; };
+
+__device__ __forceinline__ M3 ldM3(const float4* __restrict__ p, uint32_t i) {
+    float4 a = p[3 * i], b = p[3 * i + 1], c = p[3 * i + 2];
+    M3 m; m.m00 = a.x; m.m01 = a.y; m.m02 = a.z; m.m10 = b.x; m.m11 = b.y; m.m12 = b.z; m.m20 = c.x; m.m21 = c.y; m.m22 = c.z;
+    return m;
+}
+__device__ __forceinline__ BodyState loadState(const BodyView& bv, uint32_t i, uint32_t dummy) {
+    BodyState s;
+    float4 p = bv.gPos[i];
+    s.pos = xyz(p); s.invMass = p.w; s.invI = ldM3(bv.gInvI, i);
+    if (i < dummy) { s.rot = toQ(bv.bRot[i]); s.cog = xyz(bv.bCog[i]); } else { s.rot = Q4(0.f, 0.f, 0.f, 0.f); s.cog = V3(); }
+    return s;
+}
+__device__ __forceinline__ BodyVel loadVel(const BodyView& bv, uint32_t i) {
+    BodyVel b; float4 a = bv.gVel[2 * i], c = bv.gVel[2 * i + 1];
+    b.v = xyz(a); b.invMass = a.w; b.w = xyz(c); b.invI = ldM3(bv.gInvI, i);
+    return b;
+}
+__device__ __forceinline__ void storeVel(const BodyView& bv, uint32_t i, const BodyVel& b) {
+    if (b.invMass == 0.f) return;   // kinematic bodies are never changed by impulses
+    bv.gVel[2 * i] = f4(b.v, b.invMass); bv.gVel[2 * i + 1] = f4(b.w, 0.f);
+}
+__device__ __forceinline__ V3 ld3(const float* f) { return V3(f[0], f[1], f[2]); }
+__device__ __forceinline__ Q4 ld4(const float* f) { return Q4(f[0], f[1], f[2], f[3]); }
+__device__ __forceinline__ float inv0(float x) { return (x != 0.f) ? (1.f / x) : 0.f; }
+__device__ __forceinline__ M3 ballInvEffMass(const BodyState& A, const BodyState& B, V3 rA, V3 rB) {
+    M3 sA = skew(rA), sB = skew(rB);
+    return add(add(mul(mul(sA, A.invI), transpose(sA)), mul(mul(sB, B.invI), transpose(sB))), scale(M3::identity(), A.invMass + B.invMass));
+}
+__device__ __forceinline__ void applyPoint(BodyVel& A, BodyVel& B, V3 rA, V3 rB, V3 P) {   // the ball / position block shared by 5 joint types
+    A.v = A.v - A.invMass * P;
+    A.w = A.w - mul(A.invI, cross(rA, P));
+    B.v = B.v + B.invMass * P;
+    B.w = B.w + mul(B.invI, cross(rB, P));
+}
+struct F2 { float x, y; };
+
+// ------------------------------------------------------------------------------------------------ distance
+struct DistanceJ {
+    typedef mi_distance_constraint Pod;
+    struct Upd { V3 rA, rB, iwA, iwB, u; float bias, effMass; };
+    __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
+        float invDt = 1.f / dt;
+        o.rA = rotate(A.rot, ld3(in.local_anchor_a) - A.cog);
+        o.rB = rotate(B.rot, ld3(in.local_anchor_b) - B.cog);
+        V3 gA = A.pos + o.rA, gB = B.pos + o.rB;
+        o.u = gB - gA;
+        float l = len(o.u);
+        o.u = (l > 0.001f) ? (o.u * (1.f / l)) : V3();
+        V3 crAu = cross(o.rA, o.u), crBu = cross(o.rB, o.u);
+        float im = A.invMass + dot(crAu, mul(A.invI, crAu)) + B.invMass + dot(crBu, mul(B.invI, crBu));
+        o.effMass = inv0(im);
+        o.bias = 0.f;
+        if (dt > kDtThreshold) o.bias = (l - in.global_length) * (kBetaDistance * invDt);
+        o.iwA = mul(A.invI, cross(o.rA, crAu));
+        o.iwB = mul(B.invI, cross(o.rB, crBu));
+    }
+    __device__ static void solve(Upd& c, BodyVel& A, BodyVel& B) {
+        V3 avA = A.v + cross(A.w, c.rA), avB = B.v + cross(B.w, c.rB);
+        float Cdot = dot(c.u, avB - avA) + c.bias;
+        float lambda = -c.effMass * Cdot;
+        V3 P = lambda * c.u;
+        A.v = A.v - A.invMass * P;
+        A.w = A.w - c.iwA * lambda;
+        B.v = B.v + B.invMass * P;
+        B.w = B.w + c.iwB * lambda;
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ ball
+struct BallJ {
+    typedef mi_ball_constraint Pod;
+    struct Upd { V3 rA, rB, bias; M3 invEff; };
+    __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
+        float invDt = 1.f / dt;
+        o.rA = rotate(A.rot, ld3(in.local_anchor_a) - A.cog);
+        o.rB = rotate(B.rot, ld3(in.local_anchor_b) - B.cog);
+        V3 gA = A.pos + o.rA, gB = B.pos + o.rB;
+        o.invEff = ballInvEffMass(A, B, o.rA, o.rB);
+        o.bias = V3();
+        if (dt > kDtThreshold) o.bias = (gB - gA) * (kBetaBall * invDt);
+    }
+    __device__ static void solve(Upd& c, BodyVel& A, BodyVel& B) {
+        V3 avA = A.v + cross(A.w, c.rA), avB = B.v + cross(B.w, c.rB);
+        V3 Cdot = avB - avA + c.bias;
+        applyPoint(A, B, c.rA, c.rB, solve3(c.invEff, -Cdot));
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ fixed
+struct FixedJ {
+    typedef mi_fixed_constraint Pod;
+    struct Upd { V3 rA, rB, tBias, rBias; M3 invEffT, invEffR; };
+    __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
+        float invDt = 1.f / dt;
+        o.rA = rotate(A.rot, ld3(in.local_anchor_a) - A.cog);
+        o.rB = rotate(B.rot, ld3(in.local_anchor_b) - B.cog);
+        V3 gA = A.pos + o.rA, gB = B.pos + o.rB;
+        o.invEffT = ballInvEffMass(A, B, o.rA, o.rB);
+        o.invEffR = add(A.invI, B.invI);
+        o.tBias = V3(); o.rBias = V3();
+        if (dt > kDtThreshold) {
+            o.tBias = (gB - gA) * (kBetaBall * invDt);
+            Q4 err = B.rot * ld4(in.initial_inv_rotation_difference) * conj(A.rot);
+            o.rBias = err.v() * (kBetaSlider * invDt * 2.f);
+        }
+    }
+    __device__ static void solve(Upd& c, BodyVel& A, BodyVel& B) {
+        {
+            V3 Cdot = B.w - A.w;
+            V3 rl = solve3(c.invEffR, -(Cdot + c.rBias));
+            A.w = A.w - mul(A.invI, rl);
+            B.w = B.w + mul(B.invI, rl);
+        }
+        {
+            V3 avA = A.v + cross(A.w, c.rA), avB = B.v + cross(B.w, c.rB);
+            V3 Cdot = avB - avA + c.tBias;
+            applyPoint(A, B, c.rA, c.rB, solve3(c.invEffT, -Cdot));
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ hinge
+struct HingeJ {
+    typedef mi_hinge_constraint Pod;
+    struct Upd {
+        V3 rA, rB, tBias; M3 invEffT; V3 bxa, cxa; float r00, r01, r10, r11; F2 rBias;
+        uint32_t solveLimit, solveMotor; V3 axis; float limitImpulse, effAxial, limitSign, maxMotorImpulse, motorImpulse, motorVelocity, limitBias;
+        V3 mlA, mlB;
+    };
+    __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
+        float invDt = 1.f / dt;
+        o.rA = rotate(A.rot, ld3(in.local_anchor_a) - A.cog);
+        o.rB = rotate(B.rot, ld3(in.local_anchor_b) - B.cog);
+        V3 gA = A.pos + o.rA, gB = B.pos + o.rB;
+        o.invEffT = ballInvEffMass(A, B, o.rA, o.rB);
+        o.tBias = V3();
+        if (dt > kDtThreshold) o.tBias = (gB - gA) * (kBetaBall * invDt);
+        V3 axA = rotate(A.rot, ld3(in.local_hinge_axis_a)), axB = rotate(B.rot, ld3(in.local_hinge_axis_b));
+        V3 tB = tangentOf(axB), btB = cross(axB, tB);
+        V3 bxa = cross(tB, axA), cxa = cross(btB, axA);
+        V3 iAbxa = mul(A.invI, bxa), iBbxa = mul(B.invI, bxa), iAcxa = mul(A.invI, cxa), iBcxa = mul(B.invI, cxa);
+        o.r00 = dot(bxa, iAbxa) + dot(bxa, iBbxa);
+        o.r01 = dot(bxa, iAcxa) + dot(bxa, iBcxa);
+        o.r10 = dot(cxa, iAbxa) + dot(cxa, iBbxa);
+        o.r11 = dot(cxa, iAcxa) + dot(cxa, iBcxa);
+        o.bxa = bxa; o.cxa = cxa;
+        o.rBias.x = 0.f; o.rBias.y = 0.f;
+        if (dt > kDtThreshold) { float k = kBetaHingeRot * invDt; o.rBias.x = dot(axA, tB) * k; o.rBias.y = dot(axA, btB) * k; }
+        o.solveLimit = 0; o.solveMotor = 0; o.axis = V3();
+        o.limitImpulse = o.effAxial = o.limitSign = o.maxMotorImpulse = o.motorImpulse = o.motorVelocity = o.limitBias = 0.f;
+        o.mlA = V3(); o.mlB = V3();
+        if (in.min_rotation_limit <= 0.f || in.max_rotation_limit >= 0.f || in.max_motor_torque > 0.f) {
+            V3 cmp = rotate(conj(A.rot), rotate(B.rot, ld3(in.local_hinge_tangent_b)));
+            float angle = detAtan2(dot(cmp, ld3(in.local_hinge_bitangent_a)), dot(cmp, ld3(in.local_hinge_tangent_a)));
+            bool minV = in.min_rotation_limit <= 0.f && angle <= in.min_rotation_limit;
+            bool maxV = in.max_rotation_limit >= 0.f && angle >= in.max_rotation_limit;
+            o.solveLimit = (minV || maxV) ? 1u : 0u;
+            o.solveMotor = in.max_motor_torque > 0.f ? 1u : 0u;
+            if (o.solveLimit || o.solveMotor) {
+                o.axis = axA;
+                float invAx = dot(axA, mul(A.invI, axA)) + dot(axA, mul(B.invI, axA));
+                o.effAxial = inv0(invAx);
+                o.limitSign = minV ? 1.f : -1.f;
+                o.maxMotorImpulse = in.max_motor_torque * dt;
+                o.mlA = mul(A.invI, o.axis); o.mlB = mul(B.invI, o.axis);
+                o.motorVelocity = in.motor_velocity_or_target_angle;
+                if (in.motor_type == MI_MOTOR_POSITION) {
+                    float minL = (in.min_rotation_limit <= 0.f) ? in.min_rotation_limit : -kPi;
+                    float maxL = (in.max_rotation_limit >= 0.f) ? in.max_rotation_limit : kPi;
+                    float target = clampr(in.motor_velocity_or_target_angle, minL, maxL);
+                    o.motorVelocity = (dt > kDtThreshold) ? ((target - angle) * invDt) : 0.f;
+                }
+                if (dt > kDtThreshold) {
+                    float d = minV ? (angle - in.min_rotation_limit) : (in.max_rotation_limit - angle);
+                    o.limitBias = d * kBetaHingeLimit * invDt;
+                }
+            }
+        }
+    }
+    __device__ static void solve(Upd& c, BodyVel& A, BodyVel& B) {
+        V3 axis = c.axis;
+        if (c.solveMotor) {
+            float aA = dot(axis, A.w), aB = dot(axis, B.w);
+            float rel = (aB - aA);
+            float cd = rel - c.motorVelocity;
+            float l = -c.effAxial * cd;
+            float old = c.motorImpulse;
+            c.motorImpulse = clampr(c.motorImpulse + l, -c.maxMotorImpulse, c.maxMotorImpulse);
+            l = c.motorImpulse - old;
+            A.w = A.w - c.mlA * l;
+            B.w = B.w + c.mlB * l;
+        }
+        if (c.solveLimit) {
+            float s = c.limitSign;
+            float aA = dot(axis, A.w), aB = dot(axis, B.w);
+            float rel = s * (aB - aA);
+            float cd = rel + c.limitBias;
+            float l = -c.effAxial * cd;
+            float imp = fmaxr(c.limitImpulse + l, 0.f);
+            l = imp - c.limitImpulse;
+            c.limitImpulse = imp;
+            l *= s;
+            A.w = A.w - c.mlA * l;
+            B.w = B.w + c.mlB * l;
+        }
+        {
+            V3 dw = B.w - A.w;
+            float cx = dot(c.bxa, dw), cy = dot(c.cxa, dw);
+            float sx = cx + c.rBias.x, sy = cy + c.rBias.y;
+            float lx, ly;
+            solve2(c.r00, c.r01, c.r10, c.r11, -sx, -sy, lx, ly);
+            V3 P = c.bxa * lx + c.cxa * ly;
+            A.w = A.w - mul(A.invI, P);
+            B.w = B.w + mul(B.invI, P);
+        }
+        {
+            V3 avA = A.v + cross(A.w, c.rA), avB = B.v + cross(B.w, c.rB);
+            V3 cd = avB - avA + c.tBias;
+            applyPoint(A, B, c.rA, c.rB, solve3(c.invEffT, -cd));
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ cone twist
+struct ConeJ {
+    typedef mi_cone_twist_constraint Pod;
+    struct Upd {
+        V3 rA, rB, bias; M3 invEff;
+        uint32_t solveSwingLimit, solveSwingMotor, solveTwistLimit, solveTwistMotor;
+        float swingImpulse; V3 swingAxis; float effSwingLimit, swingLimitBias; V3 slA, slB;
+        float maxSwingMotorImpulse, swingMotorImpulse, swingMotorVelocity, effSwingMotor; V3 swingMotorAxis, smA, smB;
+        float twistImpulse; V3 twistAxis; float effTwist, twistLimitSign, maxTwistMotorImpulse, twistMotorImpulse, twistMotorVelocity, twistLimitBias;
+        V3 tmA, tmB;
+    };
+    __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
+        float invDt = 1.f / dt;
+        o.solveSwingLimit = o.solveSwingMotor = o.solveTwistLimit = o.solveTwistMotor = 0;
+        o.swingImpulse = o.effSwingLimit = o.swingLimitBias = 0.f; o.swingAxis = V3(); o.slA = V3(); o.slB = V3();
+        o.maxSwingMotorImpulse = o.swingMotorImpulse = o.swingMotorVelocity = o.effSwingMotor = 0.f; o.swingMotorAxis = V3(); o.smA = V3(); o.smB = V3();
+        o.twistImpulse = o.effTwist = o.twistLimitSign = o.maxTwistMotorImpulse = o.twistMotorImpulse = o.twistMotorVelocity = o.twistLimitBias = 0.f;
+        o.twistAxis = V3(); o.tmA = V3(); o.tmB = V3();
+        o.rA = rotate(A.rot, ld3(in.local_anchor_a) - A.cog);
+        o.rB = rotate(B.rot, ld3(in.local_anchor_b) - B.cog);
+        V3 gA = A.pos + o.rA, gB = B.pos + o.rB;
+        o.invEff = ballInvEffMass(A, B, o.rA, o.rB);
+        o.bias = V3();
+        if (dt > kDtThreshold) o.bias = (gB - gA) * (kBetaBall * invDt);
+        Q4 btoa = conj(A.rot) * B.rot;
+        V3 axisA = ld3(in.local_limit_axis_a);
+        V3 axisCmpA = rotate(btoa, ld3(in.local_limit_axis_b));
+        Q4 swingRot = rotateFromTo(axisA, axisCmpA);
+        V3 twT = rotate(swingRot, ld3(in.local_limit_tangent_a));
+        V3 twB = rotate(swingRot, ld3(in.local_limit_bitangent_a));
+        V3 tanCmpA = rotate(btoa, ld3(in.local_limit_tangent_b));
+        float twistAngle = detAtan2(dot(tanCmpA, twB), dot(tanCmpA, twT));
+        V3 swingAxis; float swingAngle;
+        axisRotation(swingRot, swingAxis, swingAngle);
+        if (swingAngle < 0.f) { swingAngle *= -1.f; swingAxis = swingAxis * -1.f; }
+        o.solveSwingLimit = (in.swing_limit >= 0.f && swingAngle >= in.swing_limit) ? 1u : 0u;
+        if (o.solveSwingLimit) {
+            o.swingAxis = rotate(A.rot, swingAxis);
+            float im = dot(o.swingAxis, mul(A.invI, o.swingAxis)) + dot(o.swingAxis, mul(B.invI, o.swingAxis));
+            o.effSwingLimit = inv0(im);
+            if (dt > kDtThreshold) o.swingLimitBias = (in.swing_limit - swingAngle) * (kBetaHingeLimit * invDt);
+            o.slA = mul(A.invI, o.swingAxis); o.slB = mul(B.invI, o.swingAxis);
+        }
+        o.solveSwingMotor = in.max_swing_motor_torque > 0.f ? 1u : 0u;
+        if (o.solveSwingMotor) {
+            o.maxSwingMotorImpulse = in.max_swing_motor_torque * dt;
+            float axisX, axisY;
+            detSinCos(in.swing_motor_axis, axisY, axisX);
+            V3 localMotorAxis = axisX * ld3(in.local_limit_tangent_a) + axisY * ld3(in.local_limit_bitangent_a);
+            if (in.swing_motor_type == MI_MOTOR_VELOCITY) {
+                o.swingMotorAxis = rotate(A.rot, localMotorAxis);
+                o.swingMotorVelocity = in.swing_motor_velocity_or_target_angle;
+            } else {
+                float target = in.swing_motor_velocity_or_target_angle;
+                if (in.swing_limit >= 0.f) target = clampr(target, -in.swing_limit, in.swing_limit);
+                float sh, ch;
+                detSinCos(target * 0.5f, sh, ch);
+                Q4 tq(localMotorAxis.x * sh, localMotorAxis.y * sh, localMotorAxis.z * sh, ch);
+                V3 localTargetDir = rotate(tq, axisA);
+                V3 localMotorAxis2 = noz(cross(axisCmpA, localTargetDir));
+                o.swingMotorAxis = rotate(A.rot, localMotorAxis2);
+                float cosAngle = dot(localTargetDir, axisCmpA);
+                float deltaAngle = detAcos(clamp01(cosAngle));
+                o.swingMotorVelocity = (dt > kDtThreshold) ? (deltaAngle * invDt * 0.2f) : 0.f;
+            }
+            o.smA = mul(A.invI, o.swingMotorAxis); o.smB = mul(B.invI, o.swingMotorAxis);
+            float im = dot(o.swingMotorAxis, mul(A.invI, o.swingMotorAxis)) + dot(o.swingMotorAxis, mul(B.invI, o.swingMotorAxis));
+            o.effSwingMotor = inv0(im);
+        }
+        bool minTw = in.twist_limit >= 0.f && twistAngle <= -in.twist_limit;
+        bool maxTw = in.twist_limit >= 0.f && twistAngle >= in.twist_limit;
+        o.solveTwistLimit = (minTw || maxTw) ? 1u : 0u;
+        o.solveTwistMotor = in.max_twist_motor_torque > 0.f ? 1u : 0u;
+        if (o.solveTwistLimit || o.solveTwistMotor) {
+            o.twistAxis = rotate(A.rot, axisA);
+            float im = dot(o.twistAxis, mul(A.invI, o.twistAxis)) + dot(o.twistAxis, mul(B.invI, o.twistAxis));
+            o.effTwist = inv0(im);
+            o.twistLimitSign = minTw ? 1.f : -1.f;
+            o.maxTwistMotorImpulse = in.max_twist_motor_torque * dt;
+            o.tmA = mul(A.invI, o.twistAxis); o.tmB = mul(B.invI, o.twistAxis);
+            o.twistMotorVelocity = in.twist_motor_velocity_or_target_angle;
+            if (in.twist_motor_type == MI_MOTOR_POSITION) {
+                float limit = (in.twist_limit >= 0.f) ? in.twist_limit : kPi;
+                float target = clampr(in.twist_motor_velocity_or_target_angle, -limit, limit);
+                o.twistMotorVelocity = (dt > kDtThreshold) ? ((target - twistAngle) * invDt) : 0.f;
+            }
+            if (dt > kDtThreshold) {
+                float d = minTw ? (in.twist_limit + twistAngle) : (in.twist_limit - twistAngle);
+                o.twistLimitBias = d * kBetaTwistLimit * invDt;
+            }
+        }
+    }
+    __device__ static void solve(Upd& c, BodyVel& A, BodyVel& B) {
+        V3 tw = c.twistAxis;
+        if (c.solveTwistMotor) {
+            float aA = dot(tw, A.w), aB = dot(tw, B.w);
+            float rel = (aB - aA);
+            float cd = rel - c.twistMotorVelocity;
+            float l = -c.effTwist * cd;
+            float old = c.twistMotorImpulse;
+            c.twistMotorImpulse = clampr(c.twistMotorImpulse + l, -c.maxTwistMotorImpulse, c.maxTwistMotorImpulse);
+            l = c.twistMotorImpulse - old;
+            A.w = A.w - c.tmA * l;
+            B.w = B.w + c.tmB * l;
+        }
+        if (c.solveSwingMotor) {
+            V3 ax = c.swingMotorAxis;
+            float aA = dot(ax, A.w), aB = dot(ax, B.w);
+            float rel = (aB - aA);
+            float cd = rel - c.swingMotorVelocity;
+            float l = -c.effSwingMotor * cd;
+            float old = c.swingMotorImpulse;
+            c.swingMotorImpulse = clampr(c.swingMotorImpulse + l, -c.maxSwingMotorImpulse, c.maxSwingMotorImpulse);
+            l = c.swingMotorImpulse - old;
+            A.w = A.w - c.smA * l;
+            B.w = B.w + c.smB * l;
+        }
+        if (c.solveTwistLimit) {
+            float s = c.twistLimitSign;
+            float aA = dot(tw, A.w), aB = dot(tw, B.w);
+            float rel = s * (aB - aA);
+            float cd = rel + c.twistLimitBias;
+            float l = -c.effTwist * cd;
+            float imp = fmaxr(c.twistImpulse + l, 0.f);
+            l = imp - c.twistImpulse;
+            c.twistImpulse = imp;
+            l *= s;
+            A.w = A.w - c.tmA * l;
+            B.w = B.w + c.tmB * l;
+        }
+        if (c.solveSwingLimit) {
+            float aA = dot(c.swingAxis, A.w), aB = dot(c.swingAxis, B.w);
+            float cd = aA - aB + c.swingLimitBias;
+            float l = -c.effSwingLimit * cd;
+            float imp = fmaxr(c.swingImpulse + l, 0.f);
+            l = imp - c.swingImpulse;
+            c.swingImpulse = imp;
+            A.w = A.w + c.slA * l;
+            B.w = B.w - c.slB * l;
+        }
+        {
+            V3 avA = A.v + cross(A.w, c.rA), avB = B.v + cross(B.w, c.rB);
+            V3 cd = avB - avA + c.bias;
+            applyPoint(A, B, c.rA, c.rB, solve3(c.invEff, -cd));
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------ slider
+struct SliderJ {
+    typedef mi_slider_constraint Pod;
+    struct Upd {
+        V3 tangent, bitangent, rBxt, rBxb, rAuxt, rAuxb; float t00, t01, t10, t11; M3 invEffR; F2 tBias; V3 rBias;
+        V3 axis; uint32_t solveLimit, solveMotor; float limitImpulse; V3 rAuxs, rBxs; float effAxial, limitSign, limitBias; V3 llA, llB;
+        float maxMotorImpulse, motorImpulse, motorVelocity;
+    };
+    __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
+        float invDt = 1.f / dt;
+        V3 rA = rotate(A.rot, ld3(in.local_anchor_a) - A.cog);
+        V3 rB = rotate(B.rot, ld3(in.local_anchor_b) - B.cog);
+        V3 gA = A.pos + rA, gB = B.pos + rB;
+        V3 axis = rotate(A.rot, ld3(in.local_axis_a));
+        o.tangent = tangentOf(axis); o.bitangent = cross(axis, o.tangent);
+        V3 u = gB - gA;
+        V3 rAu = rA + u;
+        o.rBxt = cross(rB, o.tangent); o.rBxb = cross(rB, o.bitangent);
+        o.rAuxt = cross(rAu, o.tangent); o.rAuxb = cross(rAu, o.bitangent);
+        V3 iArAuxt = mul(A.invI, o.rAuxt), iArAuxb = mul(A.invI, o.rAuxb), iBrBxt = mul(B.invI, o.rBxt), iBrBxb = mul(B.invI, o.rBxb);
+        float ims = A.invMass + B.invMass;
+        o.t00 = dot(o.rAuxt, iArAuxt) + dot(o.rBxt, iBrBxt) + ims;
+        o.t01 = dot(o.rAuxt, iArAuxb) + dot(o.rBxt, iBrBxb);
+        o.t10 = dot(o.rAuxb, iArAuxt) + dot(o.rBxb, iBrBxt);
+        o.t11 = dot(o.rAuxb, iArAuxb) + dot(o.rBxb, iBrBxb) + ims;
+        o.invEffR = add(A.invI, B.invI);
+        o.tBias.x = 0.f; o.tBias.y = 0.f; o.rBias = V3();
+        if (dt > kDtThreshold) {
+            float a = dot(u, o.tangent), b = dot(u, o.bitangent);
+            float k = kBetaSlider * invDt;
+            o.tBias.x = a * k; o.tBias.y = b * k;
+            Q4 err = B.rot * ld4(in.initial_inv_rotation_difference) * conj(A.rot);
+            o.rBias = err.v() * (kBetaSlider * invDt * 2.f);
+        }
+        o.axis = axis;
+        float dist = dot(u, axis);
+        o.solveLimit = 0; o.limitImpulse = 0.f; o.rAuxs = V3(); o.rBxs = V3(); o.effAxial = o.limitSign = o.limitBias = 0.f; o.llA = V3(); o.llB = V3();
+        if (in.neg_distance_limit <= 0.f || in.pos_distance_limit >= 0.f) {
+            bool minV = (in.neg_distance_limit <= 0.f) && (dist < in.neg_distance_limit);
+            bool maxV = (in.pos_distance_limit >= 0.f) && (dist > in.pos_distance_limit);
+            if (minV || maxV) {
+                o.solveLimit = 1;
+                o.rAuxs = cross(rAu, axis); o.rBxs = cross(rB, axis);
+                float invAx = ims + dot(o.rAuxs, mul(A.invI, o.rAuxs)) + dot(o.rBxs, mul(B.invI, o.rBxs));
+                o.effAxial = inv0(invAx);
+                o.limitSign = minV ? 1.f : -1.f;
+                if (dt > kDtThreshold) {
+                    float err = minV ? (dist - in.neg_distance_limit) : (in.pos_distance_limit - dist);
+                    o.limitBias = err * (kBetaSliderLimit * invDt);
+                }
+                o.llA = mul(A.invI, o.rAuxs); o.llB = mul(B.invI, o.rBxs);
+            }
+        }
+        o.solveMotor = 0; o.maxMotorImpulse = o.motorImpulse = o.motorVelocity = 0.f;
+        if (in.max_motor_force > 0.f) {
+            o.solveMotor = 1;
+            o.maxMotorImpulse = in.max_motor_force * dt;
+            o.motorVelocity = in.motor_velocity_or_target_distance;
+            if (in.motor_type == MI_MOTOR_POSITION) {
+                float minL = (in.neg_distance_limit <= 0.f) ? in.neg_distance_limit : -INFINITY;
+                float maxL = (in.pos_distance_limit >= 0.f) ? in.pos_distance_limit : INFINITY;
+                float target = clampr(in.motor_velocity_or_target_distance, minL, maxL);
+                o.motorVelocity = (dt > kDtThreshold) ? ((target - dist) * invDt) : 0.f;
+            }
+        }
+    }
+    __device__ static void solve(Upd& c, BodyVel& A, BodyVel& B) {
+        if (c.solveMotor) {
+            float cd = dot(B.v, c.axis) - dot(A.v, c.axis) - c.motorVelocity;
+            float mass = 1.f / (A.invMass + B.invMass);
+            float l = -mass * cd;
+            float old = c.motorImpulse;
+            c.motorImpulse = clampr(c.motorImpulse + l, -c.maxMotorImpulse, c.maxMotorImpulse);
+            l = c.motorImpulse - old;
+            V3 P = l * c.axis;
+            A.v = A.v - A.invMass * P;
+            B.v = B.v + B.invMass * P;
+        }
+        if (c.solveLimit) {
+            float cd = dot(B.v, c.axis) + dot(B.w, c.rBxs) - dot(A.v, c.axis) - dot(A.w, c.rAuxs);
+            float l = -c.effAxial * (c.limitSign * cd + c.limitBias);
+            float imp = fmaxr(c.limitImpulse + l, 0.f);
+            l = imp - c.limitImpulse;
+            c.limitImpulse = imp;
+            l *= c.limitSign;
+            V3 P = l * c.axis;
+            A.v = A.v - A.invMass * P;
+            A.w = A.w - c.llA * l;
+            B.v = B.v + B.invMass * P;
+            B.w = B.w + c.llB * l;
+        }
+        {
+            V3 cd = B.w - A.w;
+            V3 rl = solve3(c.invEffR, -(cd + c.rBias));
+            A.w = A.w - mul(A.invI, rl);
+            B.w = B.w + mul(B.invI, rl);
+        }
+        {
+            float cx = dot(c.tangent, B.v) + dot(c.rBxt, B.w) - dot(c.tangent, A.v) - dot(c.rAuxt, A.w);
+            float cy = dot(c.bitangent, B.v) + dot(c.rBxb, B.w) - dot(c.bitangent, A.v) - dot(c.rAuxb, A.w);
+            float sx = cx + c.tBias.x, sy = cy + c.tBias.y;
+            float lx, ly;
+            solve2(c.t00, c.t01, c.t10, c.t11, -sx, -sy, lx, ly);
+            V3 tb = c.tangent * lx + c.bitangent * ly;
+            A.v = A.v - A.invMass * tb;
+            A.w = A.w - mul(A.invI, c.rAuxt * lx + c.rAuxb * ly);
+            B.v = B.v + B.invMass * tb;
+            B.w = B.w + mul(B.invI, c.rBxt * lx + c.rBxb * ly);
+        }
+    }
+};
+
+template <class J>
+__global__ __launch_bounds__(64) void k_joint_init(uint32_t n, uint32_t dummy, const typename J::Pod* __restrict__ pods, const uint2* __restrict__ bodies,
+                                                   typename J::Upd* __restrict__ upd, BodyView bv, float dt) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint2 b = bodies[i];
+    typename J::Pod in = pods[i];
+    BodyState A = loadState(bv, b.x, dummy), B = loadState(bv, b.y, dummy);
+    typename J::Upd o;
+    J::init(in, A, B, dt, o);
+    upd[i] = o;
+}
+// One colour of one joint type: lanes [s0, s1) of the colour-sorted order own disjoint dynamic bodies.
+template <class J>
+__global__ __launch_bounds__(64) void k_joint_solve(uint32_t s0, uint32_t s1, const uint32_t* __restrict__ order, const uint2* __restrict__ bodies,
+                                                    typename J::Upd* __restrict__ upd, BodyView bv) {
+    uint32_t s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= s1) return;
+    uint32_t i = order[s];
+    uint2 b = bodies[i];
+    typename J::Upd c = upd[i];
+    BodyVel A = loadVel(bv, b.x), B = loadVel(bv, b.y);
+    J::solve(c, A, B);
+    upd[i] = c;
+    storeVel(bv, b.x, A); storeVel(bv, b.y, B);
+}
+template <class J>
+__global__ void k_joint_solve_serial(uint32_t s0, uint32_t s1, const uint32_t* __restrict__ order, const uint2* __restrict__ bodies,
+                                     typename J::Upd* __restrict__ upd, BodyView bv) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    for (uint32_t s = s0; s < s1; ++s) {
+        uint32_t i = order[s];
+        uint2 b = bodies[i];
+        typename J::Upd c = upd[i];
+        BodyVel A = loadVel(bv, b.x), B = loadVel(bv, b.y);
+        J::solve(c, A, B);
+        upd[i] = c;
+        storeVel(bv, b.x, A); storeVel(bv, b.y, B);
+        __threadfence();
+    }
+}
+
+}  // namespace mi
+
+// ------------------------------------------------------------------------------------------------ host side
 struct mi_world;
+
+template <class J>
+struct JointType {
+    std::vector<typename J::Pod> pods;
+    std::vector<uint2> bodies;          // rigid body indices (A, B)
+    std::vector<uint32_t> order;        // colour-major, index-minor
+    std::vector<uint32_t> colorOffsets; // [0..65] boundaries into order (64 = overflow colour)
+    typename J::Pod* dPods = nullptr; uint2* dBodies = nullptr; uint32_t* dOrder = nullptr; typename J::Upd* dUpd = nullptr;
+    size_t dCap = 0;
+    ~JointType() { release(); }
+    void release() {
+        if (dPods) (void)hipFree(dPods); if (dBodies) (void)hipFree(dBodies); if (dOrder) (void)hipFree(dOrder); if (dUpd) (void)hipFree(dUpd);
+        dPods = nullptr; dBodies = nullptr; dOrder = nullptr; dUpd = nullptr; dCap = 0;
+    }
+    // Greedy colouring in descending hash32 priority with 64-bit per-body colour masks (same rule as the contact schedule).
+    void computeOrder(const std::vector<float>& invMass) {
+        uint32_t n = (uint32_t)bodies.size();
+        order.resize(n);
+        std::vector<uint32_t> prio(n), color(n, 64);
+        for (uint32_t i = 0; i < n; ++i) { order[i] = i; prio[i] = i; }
+        std::sort(prio.begin(), prio.end(), [](uint32_t a, uint32_t b) { return mi::hash32(a) > mi::hash32(b); });
+        std::vector<unsigned long long> used(invMass.size(), 0ull);
+        for (uint32_t j : prio) {
+            uint2 bp = bodies[j];
+            bool dynA = invMass[bp.x] != 0.f, dynB = invMass[bp.y] != 0.f;
+            unsigned long long mask = (dynA ? used[bp.x] : 0ull) | (dynB ? used[bp.y] : 0ull);
+            if (~mask == 0ull) continue;
+            uint32_t c = (uint32_t)__builtin_ctzll(~mask);
+            color[j] = c;
+            if (dynA) used[bp.x] |= 1ull << c;
+            if (dynB) used[bp.y] |= 1ull << c;
+        }
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return color[a] < color[b]; });
+        colorOffsets.assign(66, 0);
+        for (uint32_t i = 0; i < n; ++i) colorOffsets[color[order[i]] + 1]++;
+        for (int c = 0; c < 65; ++c) colorOffsets[c + 1] += colorOffsets[c];
+    }
+    hipError_t upload(hipStream_t st) {
+        size_t n = pods.size();
+        if (!n) return hipSuccess;
+        if (n > dCap) {
+            release();
+            hipError_t e;
+            if ((e = hipMalloc((void**)&dPods, n * sizeof(typename J::Pod))) != hipSuccess) return e;
+            if ((e = hipMalloc((void**)&dBodies, n * sizeof(uint2))) != hipSuccess) return e;
+            if ((e = hipMalloc((void**)&dOrder, n * sizeof(uint32_t))) != hipSuccess) return e;
+            if ((e = hipMalloc((void**)&dUpd, n * sizeof(typename J::Upd))) != hipSuccess) return e;
+            dCap = n;
+        }
+        hipError_t e;
+        if ((e = hipMemcpyAsync(dPods, pods.data(), n * sizeof(typename J::Pod), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+        if ((e = hipMemcpyAsync(dBodies, bodies.data(), n * sizeof(uint2), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
+        return hipMemcpyAsync(dOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+    }
+    void launchInit(uint32_t dummy, const mi::BodyView& bv, float dt, hipStream_t st) {
+        uint32_t n = (uint32_t)pods.size();
+        if (n) mi::k_joint_init<J><<<(n + 63) / 64, 64, 0, st>>>(n, dummy, dPods, dBodies, dUpd, bv, dt);
+    }
+    void launchSolve(const mi::BodyView& bv, hipStream_t st) {
+        if (pods.empty()) return;
+        for (int c = 0; c < 64; ++c) {
+            uint32_t s0 = colorOffsets[c], s1 = colorOffsets[c + 1];
+            if (s1 > s0) mi::k_joint_solve<J><<<(s1 - s0 + 63) / 64, 64, 0, st>>>(s0, s1, dOrder, dBodies, dUpd, bv);
+        }
+        uint32_t o0 = colorOffsets[64], o1 = colorOffsets[65];
+        if (o1 > o0) mi::k_joint_solve_serial<J><<<1, 64, 0, st>>>(o0, o1, dOrder, dBodies, dUpd, bv);
+    }
+};
+
 struct JointSet {
-    int upload(mi_world&, hipStream_t) { return MI_OK; }
-    int initialize(mi_world&, float, hipStream_t) { return MI_OK; }
-    void solveIteration(mi_world&, hipStream_t) {}
-    int add(mi_world&, uint32_t, uint32_t, uint32_t, const void*, uint32_t, uint32_t*) { return MI_ERR_UNSUPPORTED; }
-    int update(uint32_t, uint32_t, const void*, uint32_t) { return MI_ERR_UNSUPPORTED; }
-    int get(uint32_t, uint32_t, void*, uint32_t) { return MI_ERR_UNSUPPORTED; }
-    int addFromGlobal(mi_world&, uint32_t, uint32_t, uint32_t, const float*, const float*, float, float, uint32_t*) { return MI_ERR_UNSUPPORTED; }
+    JointType<mi::DistanceJ> distance; JointType<mi::BallJ> ball; JointType<mi::FixedJ> fixed;
+    JointType<mi::HingeJ> hinge; JointType<mi::ConeJ> cone; JointType<mi::SliderJ> slider;
+
+    size_t count() const { return distance.pods.size() + ball.pods.size() + fixed.pods.size() + hinge.pods.size() + cone.pods.size() + slider.pods.size(); }
+    int add(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb, const void* pod, uint32_t bytes, uint32_t* out);
+    int update(uint32_t type, uint32_t id, const void* pod, uint32_t bytes);
+    int get(uint32_t type, uint32_t id, void* pod, uint32_t bytes);
+    int addFromGlobal(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb, const float* anchor, const float* axis, float l0, float l1, uint32_t* out);
+    int upload(mi_world& w, hipStream_t st);
+    int initialize(mi_world& w, float dt, hipStream_t st);
+    void solveIteration(mi_world& w, hipStream_t st);
 };

@@ -11,6 +11,7 @@
 #include <vector>
 #include <string>
 #include <algorithm>
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <rocprim/rocprim.hpp>
 
@@ -510,6 +511,146 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     counts.num_rigid_bodies = nb; counts.num_colliders = nc; counts.num_broadphase_overlaps = nc ? hs.numOverlaps : 0;
     counts.num_collisions = nm; counts.num_contacts = ncon; counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur; counts.reserved = colorRounds;
     return MI_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Joint storage (host) — addConstraint / add*ConstraintFromGlobalPoints (src/physics/physics.cpp:128-333)
+// ------------------------------------------------------------------------------------------------
+template <class JT>
+static int jointAddTo(mi_world& w, JT& l, uint32_t ea, uint32_t eb, const void* pod, uint32_t bytes, uint32_t* out) {
+    typedef typename std::remove_reference<decltype(l.pods[0])>::type P;
+    if (bytes != sizeof(P)) return fail(MI_ERR_INVALID_ARGUMENT, "constraint pod size mismatch");
+    if (ea >= w.entities.size() || eb >= w.entities.size() || w.entities[ea].rb < 0 || w.entities[eb].rb < 0)
+        return fail(MI_ERR_INVALID_ARGUMENT, "both constraint entities must be rigid bodies");
+    P p; std::memcpy(&p, pod, sizeof(P));
+    if (out) *out = (uint32_t)l.pods.size();
+    l.pods.push_back(p);
+    l.bodies.push_back(make_uint2((uint32_t)w.entities[ea].rb, (uint32_t)w.entities[eb].rb));
+    return MI_OK;
+}
+int JointSet::add(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb, const void* pod, uint32_t bytes, uint32_t* out) {
+    switch (type) {
+        case MI_CONSTRAINT_DISTANCE: return jointAddTo(w, distance, ea, eb, pod, bytes, out);
+        case MI_CONSTRAINT_BALL: return jointAddTo(w, ball, ea, eb, pod, bytes, out);
+        case MI_CONSTRAINT_FIXED: return jointAddTo(w, fixed, ea, eb, pod, bytes, out);
+        case MI_CONSTRAINT_HINGE: return jointAddTo(w, hinge, ea, eb, pod, bytes, out);
+        case MI_CONSTRAINT_CONE_TWIST: return jointAddTo(w, cone, ea, eb, pod, bytes, out);
+        case MI_CONSTRAINT_SLIDER: return jointAddTo(w, slider, ea, eb, pod, bytes, out);
+    }
+    return fail(MI_ERR_INVALID_ARGUMENT, "bad constraint type");
+}
+template <class JT> static int jointCopy(JT& l, uint32_t id, void* dst, const void* src, uint32_t bytes) {
+    typedef typename std::remove_reference<decltype(l.pods[0])>::type P;
+    if (bytes != sizeof(P) || id >= l.pods.size()) return fail(MI_ERR_INVALID_ARGUMENT, "bad constraint id or pod size");
+    if (src) std::memcpy(&l.pods[id], src, sizeof(P)); else std::memcpy(dst, &l.pods[id], sizeof(P));
+    return MI_OK;
+}
+int JointSet::update(uint32_t type, uint32_t id, const void* pod, uint32_t bytes) {
+    switch (type) {
+        case MI_CONSTRAINT_DISTANCE: return jointCopy(distance, id, nullptr, pod, bytes);
+        case MI_CONSTRAINT_BALL: return jointCopy(ball, id, nullptr, pod, bytes);
+        case MI_CONSTRAINT_FIXED: return jointCopy(fixed, id, nullptr, pod, bytes);
+        case MI_CONSTRAINT_HINGE: return jointCopy(hinge, id, nullptr, pod, bytes);
+        case MI_CONSTRAINT_CONE_TWIST: return jointCopy(cone, id, nullptr, pod, bytes);
+        case MI_CONSTRAINT_SLIDER: return jointCopy(slider, id, nullptr, pod, bytes);
+    }
+    return fail(MI_ERR_INVALID_ARGUMENT, "bad constraint type");
+}
+int JointSet::get(uint32_t type, uint32_t id, void* pod, uint32_t bytes) {
+    switch (type) {
+        case MI_CONSTRAINT_DISTANCE: return jointCopy(distance, id, pod, nullptr, bytes);
+        case MI_CONSTRAINT_BALL: return jointCopy(ball, id, pod, nullptr, bytes);
+        case MI_CONSTRAINT_FIXED: return jointCopy(fixed, id, pod, nullptr, bytes);
+        case MI_CONSTRAINT_HINGE: return jointCopy(hinge, id, pod, nullptr, bytes);
+        case MI_CONSTRAINT_CONE_TWIST: return jointCopy(cone, id, pod, nullptr, bytes);
+        case MI_CONSTRAINT_SLIDER: return jointCopy(slider, id, pod, nullptr, bytes);
+    }
+    return fail(MI_ERR_INVALID_ARGUMENT, "bad constraint type");
+}
+static void put3(float* f, V3 v) { f[0] = v.x; f[1] = v.y; f[2] = v.z; }
+static void put4(float* f, Q4 q) { f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w; }
+int JointSet::addFromGlobal(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb, const float* anchor, const float* axisIn, float l0, float l1, uint32_t* out) {
+    if (ea >= w.entities.size() || eb >= w.entities.size()) return fail(MI_ERR_INVALID_ARGUMENT, "entity out of range");
+    const HEntity& A = w.entities[ea]; const HEntity& B = w.entities[eb];
+    auto invPos = [](const HEntity& e, V3 p) { V3 r = rotate(conj(e.rot), p - e.pos); return V3(r.x / 1.f, r.y / 1.f, r.z / 1.f); };   // inverseTransformPosition (scale = 1)
+    auto invDir = [](const HEntity& e, V3 d) { return rotate(conj(e.rot), d); };
+    V3 ga(anchor[0], anchor[1], anchor[2]);
+    V3 gx = axisIn ? V3(axisIn[0], axisIn[1], axisIn[2]) : V3();
+    switch (type) {
+        case MI_CONSTRAINT_DISTANCE: {   // anchor = globalAnchorA, axis = globalAnchorB (physics.cpp:147-156)
+            mi_distance_constraint c; put3(c.local_anchor_a, invPos(A, ga)); put3(c.local_anchor_b, invPos(B, gx)); c.global_length = len(ga - gx);
+            return add(w, type, ea, eb, &c, sizeof(c), out);
+        }
+        case MI_CONSTRAINT_BALL: {
+            mi_ball_constraint c; put3(c.local_anchor_a, invPos(A, ga)); put3(c.local_anchor_b, invPos(B, ga));
+            return add(w, type, ea, eb, &c, sizeof(c), out);
+        }
+        case MI_CONSTRAINT_FIXED: {
+            mi_fixed_constraint c; put3(c.local_anchor_a, invPos(A, ga)); put3(c.local_anchor_b, invPos(B, ga));
+            put4(c.initial_inv_rotation_difference, conj(B.rot) * A.rot);
+            return add(w, type, ea, eb, &c, sizeof(c), out);
+        }
+        case MI_CONSTRAINT_HINGE: {
+            mi_hinge_constraint c;
+            put3(c.local_anchor_a, invPos(A, ga)); put3(c.local_anchor_b, invPos(B, ga));
+            V3 axA = invDir(A, gx), axB = invDir(B, gx);
+            put3(c.local_hinge_axis_a, axA); put3(c.local_hinge_axis_b, axB);
+            V3 t = tangentOf(axA), bt = cross(axA, t);
+            put3(c.local_hinge_tangent_a, t); put3(c.local_hinge_bitangent_a, bt);
+            put3(c.local_hinge_tangent_b, rotate(conj(B.rot), rotate(A.rot, t)));
+            c.min_rotation_limit = l0; c.max_rotation_limit = l1;
+            c.motor_type = MI_MOTOR_VELOCITY; c.motor_velocity_or_target_angle = 0.f; c.max_motor_torque = -1.f;
+            return add(w, type, ea, eb, &c, sizeof(c), out);
+        }
+        case MI_CONSTRAINT_CONE_TWIST: {
+            mi_cone_twist_constraint c;
+            put3(c.local_anchor_a, invPos(A, ga)); put3(c.local_anchor_b, invPos(B, ga));
+            c.swing_limit = l0; c.twist_limit = l1;
+            V3 axA = invDir(A, gx), axB = invDir(B, gx);
+            put3(c.local_limit_axis_a, axA); put3(c.local_limit_axis_b, axB);
+            V3 t = tangentOf(axA), bt = cross(axA, t);
+            put3(c.local_limit_tangent_a, t); put3(c.local_limit_bitangent_a, bt);
+            put3(c.local_limit_tangent_b, rotate(conj(B.rot), rotate(A.rot, t)));
+            c.swing_motor_type = MI_MOTOR_VELOCITY; c.swing_motor_velocity_or_target_angle = 0.f; c.max_swing_motor_torque = -1.f; c.swing_motor_axis = 0.f;
+            c.twist_motor_type = MI_MOTOR_VELOCITY; c.twist_motor_velocity_or_target_angle = 0.f; c.max_twist_motor_torque = -1.f;
+            return add(w, type, ea, eb, &c, sizeof(c), out);
+        }
+        case MI_CONSTRAINT_SLIDER: {
+            mi_slider_constraint c;
+            put3(c.local_anchor_a, invPos(A, ga)); put3(c.local_anchor_b, invPos(B, ga));
+            put3(c.local_axis_a, invDir(A, gx));
+            put4(c.initial_inv_rotation_difference, conj(B.rot) * A.rot);
+            c.neg_distance_limit = l0; c.pos_distance_limit = l1;
+            c.motor_type = MI_MOTOR_VELOCITY; c.motor_velocity_or_target_distance = 0.f; c.max_motor_force = -1.f;
+            return add(w, type, ea, eb, &c, sizeof(c), out);
+        }
+    }
+    return fail(MI_ERR_INVALID_ARGUMENT, "bad constraint type");
+}
+int JointSet::upload(mi_world& w, hipStream_t st) {
+    if (!count()) return MI_OK;
+    std::vector<float> invMass(w.bodies.size());
+    for (size_t i = 0; i < w.bodies.size(); ++i) invMass[i] = w.bodies[i].invMass;
+    distance.computeOrder(invMass); ball.computeOrder(invMass); fixed.computeOrder(invMass);
+    hinge.computeOrder(invMass); cone.computeOrder(invMass); slider.computeOrder(invMass);
+    HIP_TRY(distance.upload(st)); HIP_TRY(ball.upload(st)); HIP_TRY(fixed.upload(st));
+    HIP_TRY(hinge.upload(st)); HIP_TRY(cone.upload(st)); HIP_TRY(slider.upload(st));
+    return MI_OK;
+}
+static BodyView bodyView(mi_world& w) { return BodyView{w.gPos.p, w.gInvI.p, w.gVel.p, w.bRot.p, w.bCogInvMass.p}; }
+int JointSet::initialize(mi_world& w, float dt, hipStream_t st) {
+    if (!count()) return MI_OK;
+    BodyView bv = bodyView(w);
+    uint32_t dummy = (uint32_t)w.bodies.size();
+    distance.launchInit(dummy, bv, dt, st); ball.launchInit(dummy, bv, dt, st); fixed.launchInit(dummy, bv, dt, st);
+    hinge.launchInit(dummy, bv, dt, st); cone.launchInit(dummy, bv, dt, st); slider.launchInit(dummy, bv, dt, st);
+    return MI_OK;
+}
+void JointSet::solveIteration(mi_world& w, hipStream_t st) {
+    if (!count()) return;
+    BodyView bv = bodyView(w);
+    distance.launchSolve(bv, st); ball.launchSolve(bv, st); fixed.launchSolve(bv, st);
+    hinge.launchSolve(bv, st); cone.launchSolve(bv, st); slider.launchSolve(bv, st);
 }
 
 // ================================================================================================

@@ -46,6 +46,7 @@ class Scene:
     dt: float = 1.0 / 120.0
     constraints: list = field(default_factory=list)   # (type, entity_a, entity_b, pod ndarray)
     hulls: list = field(default_factory=list)          # (vertices, triangles)
+    global_constraints: list = field(default_factory=list)   # (type, entity_a, entity_b, anchor, axis, limit0, limit1, {field: value})
 
     @property
     def num_bodies(self):
@@ -61,6 +62,13 @@ class Scene:
         world.add_colliders(self.collider_entities, self.colliders)
         for ctype, ea, eb, pod in self.constraints:
             world.add_constraint(ctype, ea, eb, pod)
+        for ctype, ea, eb, anchor, axis, l0, l1, edits in self.global_constraints:
+            cid = world.add_constraint_from_global(ctype, ea, eb, anchor, axis, l0, l1)   # add*ConstraintFromGlobalPoints
+            if edits:                                                                      # getConstraint(...).motor... = ...
+                pod = world.get_constraint(ctype, cid)
+                for k, v in edits.items():
+                    pod[k] = v
+                world.update_constraint(ctype, cid, pod)
         return world
 
 
@@ -208,5 +216,196 @@ def shape_zoo(nx=6, ny=4, nz=6, seed=5, solver_iterations=30, spacing=1.6):
                  hulls=[convex_hull_mesh(seed)])
 
 
+# ---- quaternion helpers (x, y, z, w) for scene construction -------------------------------------
+def q_axis_angle(axis, angle):
+    a = np.asarray(axis, np.float64)
+    return np.append(a * np.sin(angle * 0.5), np.cos(angle * 0.5))
+
+
+def q_mul(a, b):
+    av, bv = a[:3], b[:3]
+    return np.append(av * b[3] + bv * a[3] + np.cross(av, bv), a[3] * b[3] - av.dot(bv))
+
+
+def q_conj(q):
+    return np.array([-q[0], -q[1], -q[2], q[3]])
+
+
+def q_rot(q, v):
+    return q_mul(q_mul(q, np.append(v, 0.0)), q_conj(q))[:3]
+
+
+def _tangents(n):
+    t = np.array([n[1], -n[0], 0.0]) if abs(n[0]) >= 0.57735 else np.array([0.0, n[2], -n[1]])
+    t = t / np.linalg.norm(t)
+    return t, np.cross(n, t)
+
+
+_RAGDOLL_SCALE = 0.42
+# (name, position, rotation-about-z degrees, colliders) — src/physics/ragdoll.cpp:20-34, 36-105
+_RAGDOLL_PARTS = [
+    ("torso", (0, 0, 0), 0, [("cap", (-0.2, 0, 0), (0.2, 0, 0), 0.25), ("cap", (-0.16, 0.32, 0), (0.16, 0.32, 0), 0.2),
+                             ("cap", (-0.14, 0.62, 0), (0.14, 0.62, 0), 0.22), ("cap", (-0.14, 0.92, 0), (0.14, 0.92, 0), 0.2)]),
+    ("head", (0, 1.45, 0), 0, [("cap", (0, -0.075, 0), (0, 0.075, 0), 0.25)]),
+    ("l_upper_arm", (-0.6, 0.75, 0), -30, [("cap", (0, -0.2, 0), (0, 0.2, 0), 0.15)]),
+    ("l_lower_arm", (-0.884, 0.044, -0.043), -20, [("cap", (0, -0.2, 0), (0, 0.2, 0), 0.15)]),
+    ("r_upper_arm", (0.6, 0.75, 0), 30, [("cap", (0, -0.2, 0), (0, 0.2, 0), 0.15)]),
+    ("r_lower_arm", (0.884, 0.044, -0.043), 20, [("cap", (0, -0.2, 0), (0, 0.2, 0), 0.15)]),
+    ("l_upper_leg", (-0.371, -0.812, 0), -10, [("cap", (0, -0.3, 0), (0, 0.3, 0), 0.25)]),
+    ("l_lower_leg", (-0.452, -1.955, 0), -3.5, [("cap", (0, -0.3, 0), (0, 0.3, 0), 0.18)]),
+    ("l_foot", (-0.498, -2.585, -0.18), 0, [("box", (0.1587, 0.1, 0.3424))]),
+    ("l_toes", (-0.498, -2.585, -0.637), 0, [("cap", (-0.0587, 0, 0), (0.0587, 0, 0), 0.1)]),
+    ("r_upper_leg", (0.371, -0.812, 0), 10, [("cap", (0, -0.3, 0), (0, 0.3, 0), 0.25)]),
+    ("r_lower_leg", (0.452, -1.955, 0), 3.5, [("cap", (0, -0.3, 0), (0, 0.3, 0), 0.18)]),
+    ("r_foot", (0.498, -2.585, -0.18), 0, [("box", (0.1587, 0.1, 0.3424))]),
+    ("r_toes", (0.498, -2.585, -0.637), 0, [("cap", (-0.0587, 0, 0), (0.0587, 0, 0), 0.1)]),
+]
+_P = {name: i for i, (name, *_rest) in enumerate(_RAGDOLL_PARTS)}
+_S2 = 1.0 / np.sqrt(2.0)
+# (type, a, b, anchor part, local anchor (unscaled), axis spec, limit0 deg, limit1 deg) — ragdoll.cpp:107-123
+_RAGDOLL_JOINTS = [
+    ("cone", "torso", "head", "torso", (0, 1.2, 0), (0, 1, 0), 50, 90),
+    ("cone", "torso", "l_upper_arm", "torso", (-0.4, 1.0, 0), (-1, 0, 0), 130, 90),
+    ("hinge", "l_upper_arm", "l_lower_arm", "l_upper_arm", (0, -0.42, 0), (_S2, 0, _S2), -5, 85),
+    ("cone", "torso", "r_upper_arm", "torso", (0.4, 1.0, 0), (1, 0, 0), 130, 90),
+    ("hinge", "r_upper_arm", "r_lower_arm", "r_upper_arm", (0, -0.42, 0), (_S2, 0, -_S2), -5, 85),
+    ("cone", "torso", "l_upper_leg", "torso", (-0.3, -0.25, 0), ("dir", "l_upper_leg", (0, -1, 0)), None, 30),
+    ("hinge", "l_upper_leg", "l_lower_leg", "l_upper_leg", (0, -0.6, 0), (1, 0, 0), -90, 5),
+    ("cone", "l_lower_leg", "l_foot", "l_lower_leg", (0, -0.52, 0), ("dir", "l_lower_leg", (0, -1, 0)), 75, 20),
+    ("hinge", "l_foot", "l_toes", "l_foot", (0, 0, -0.36), (1, 0, 0), -45, 45),
+    ("cone", "torso", "r_upper_leg", "torso", (0.3, -0.25, 0), ("dir", "r_upper_leg", (0, -1, 0)), None, 30),
+    ("hinge", "r_upper_leg", "r_lower_leg", "r_upper_leg", (0, -0.6, 0), (1, 0, 0), -90, 5),
+    ("cone", "r_lower_leg", "r_foot", "r_lower_leg", (0, -0.52, 0), ("dir", "r_lower_leg", (0, -1, 0)), 75, 20),
+    ("hinge", "r_foot", "r_toes", "r_foot", (0, 0, -0.36), (1, 0, 0), -45, 45),
+]
+
+
+def _ragdoll_template():
+    """Base-pose transforms, colliders and joint PODs of humanoid_ragdoll::initialize (src/physics/ragdoll.cpp:12-123)."""
+    sc = _RAGDOLL_SCALE
+    pos = [sc * np.asarray(p, np.float64) for _, p, _, _ in _RAGDOLL_PARTS]
+    rot = [q_axis_angle((0, 0, 1), np.deg2rad(a)) for _, _, a, _ in _RAGDOLL_PARTS]
+    inv_pos = lambda i, g: q_rot(q_conj(rot[i]), g - pos[i])
+    inv_dir = lambda i, d: q_rot(q_conj(rot[i]), d)
+    joints = []
+    for kind, a, b, ap, la, ax, l0, l1 in _RAGDOLL_JOINTS:
+        ia, ib, ipn = _P[a], _P[b], _P[ap]
+        anchor = q_rot(rot[ipn], sc * np.asarray(la, np.float64)) + pos[ipn]
+        axis = q_rot(rot[_P[ax[1]]], np.asarray(ax[2], np.float64)) if isinstance(ax[0], str) else np.asarray(ax, np.float64)
+        axA, axB = inv_dir(ia, axis), inv_dir(ib, axis)
+        t, bt = _tangents(axA)
+        tB = q_rot(q_conj(rot[ib]), q_rot(rot[ia], t))
+        if kind == "cone":
+            c = np.zeros(1, capi.cone_twist_constraint)
+            c["local_anchor_a"], c["local_anchor_b"] = inv_pos(ia, anchor), inv_pos(ib, anchor)
+            c["local_limit_axis_a"], c["local_limit_axis_b"] = axA, axB
+            c["local_limit_tangent_a"], c["local_limit_bitangent_a"], c["local_limit_tangent_b"] = t, bt, tB
+            c["swing_limit"] = -1.0 if l0 is None else np.deg2rad(l0)
+            c["twist_limit"] = np.deg2rad(l1)
+            c["max_swing_motor_torque"] = -1.0
+            c["max_twist_motor_torque"] = -1.0
+            joints.append((capi.CONSTRAINT_CONE_TWIST, ia, ib, c))
+        else:
+            c = np.zeros(1, capi.hinge_constraint)
+            c["local_anchor_a"], c["local_anchor_b"] = inv_pos(ia, anchor), inv_pos(ib, anchor)
+            c["local_hinge_axis_a"], c["local_hinge_axis_b"] = axA, axB
+            c["local_hinge_tangent_a"], c["local_hinge_bitangent_a"], c["local_hinge_tangent_b"] = t, bt, tB
+            c["min_rotation_limit"], c["max_rotation_limit"] = np.deg2rad(l0), np.deg2rad(l1)
+            c["max_motor_torque"] = -1.0
+            joints.append((capi.CONSTRAINT_HINGE, ia, ib, c))
+    return pos, rot, joints
+
+
+def ragdolls(nx=32, nz=32, seed=4, solver_iterations=30, spacing=3.0):
+    """cfg4: nx*nz reference ragdolls (14 bodies, 17 colliders, 7 cone-twist + 6 hinge each; density 985, friction 1,
+    restitution 0.2) on a grid over the ground, hip height 1.25 + jitter, random yaw."""
+    sc = _RAGDOLL_SCALE
+    pos, rot, joints = _ragdoll_template()
+    nr = nx * nz
+    nparts = len(_RAGDOLL_PARTS)
+    e = make_entities(nr * nparts)
+    ents, cols = [], []
+    yaw = uniform(seed, 60, nr, 0.0, 2 * np.pi)
+    hip_y = 1.25 + 0.5 * uniform(seed, 61, nr, 0.0, 1.0)
+    constraints = []
+    for r in range(nr):
+        ix, iz = divmod(r, nz)
+        hip = np.array([(ix - (nx - 1) / 2) * spacing, hip_y[r], (iz - (nz - 1) / 2) * spacing])
+        qy = q_axis_angle((0, 1, 0), yaw[r])
+        for i in range(nparts):
+            k = r * nparts + i
+            e["rotation"][k] = q_mul(qy, rot[i])
+            e["position"][k] = q_rot(qy, pos[i]) + hip
+            for col in _RAGDOLL_PARTS[i][3]:
+                c = make_colliders(1, capi.CAPSULE, restitution=0.2, friction=1.0, density=985.0)
+                if col[0] == "cap":
+                    c["shape"][0, :7] = (*(sc * np.asarray(col[1])), *(sc * np.asarray(col[2])), sc * col[3])
+                else:
+                    c["type"] = capi.AABB
+                    h = sc * np.asarray(col[1])
+                    c["shape"][0, :6] = (*(-h), *h)
+                ents.append(k); cols.append(c)
+        for ctype, ia, ib, pod in joints:
+            constraints.append((ctype, r * nparts + ia, r * nparts + ib, pod))
+    ge, gc = _ground(max(100.0, max(nx, nz) * spacing))
+    ents.append(nr * nparts); cols.append(gc)
+    return Scene(f"cfg4_ragdolls_{nr}", np.concatenate([e, ge]), np.asarray(ents, np.uint32), np.concatenate(cols), solver_iterations,
+                 constraints=constraints)
+
+
+def joint_zoo(seed=6, solver_iterations=30, copies=2):
+    """Chains of 3 boxes hanging off kinematic anchors, one chain per joint flavour: distance, ball, fixed, hinge (free /
+    limited / velocity motor / position motor), cone-twist (limits / swing+twist motors), slider (limits / motor).
+    Covers every init/solve branch of src/physics/constraints.cpp's scalar joint routines."""
+    flavours = [
+        (capi.CONSTRAINT_DISTANCE, None, 1.0, -1.0, {}),
+        (capi.CONSTRAINT_BALL, None, 1.0, -1.0, {}),
+        (capi.CONSTRAINT_FIXED, None, 1.0, -1.0, {}),
+        (capi.CONSTRAINT_HINGE, (0, 0, 1), 1.0, -1.0, {}),
+        (capi.CONSTRAINT_HINGE, (0, 0, 1), -0.3, 0.4, {}),
+        (capi.CONSTRAINT_HINGE, (0, 0, 1), 1.0, -1.0, {"max_motor_torque": 40.0, "motor_type": 0, "motor_velocity_or_target_angle": 1.5}),
+        (capi.CONSTRAINT_HINGE, (0, 0, 1), -1.0, 1.0, {"max_motor_torque": 60.0, "motor_type": 1, "motor_velocity_or_target_angle": 0.6}),
+        (capi.CONSTRAINT_CONE_TWIST, (1, 0, 0), 0.5, 0.3, {}),
+        (capi.CONSTRAINT_CONE_TWIST, (1, 0, 0), 0.9, 0.6, {"max_swing_motor_torque": 30.0, "swing_motor_type": 1, "swing_motor_velocity_or_target_angle": 0.4,
+                                                         "swing_motor_axis": 0.7, "max_twist_motor_torque": 20.0, "twist_motor_type": 0,
+                                                         "twist_motor_velocity_or_target_angle": 1.0}),
+        (capi.CONSTRAINT_CONE_TWIST, (1, 0, 0), -1.0, 0.5, {"max_swing_motor_torque": 25.0, "swing_motor_type": 0, "swing_motor_velocity_or_target_angle": 0.8,
+                                                          "swing_motor_axis": 0.2, "max_twist_motor_torque": 20.0, "twist_motor_type": 1,
+                                                          "twist_motor_velocity_or_target_angle": -0.3}),
+        (capi.CONSTRAINT_SLIDER, (1, 0, 0), 1.0, -1.0, {}),
+        (capi.CONSTRAINT_SLIDER, (1, 0, 0), -0.2, 0.3, {}),
+        (capi.CONSTRAINT_SLIDER, (1, 0, 0), -0.5, 0.5, {"max_motor_force": 200.0, "motor_type": 1, "motor_velocity_or_target_distance": 0.25}),
+        (capi.CONSTRAINT_SLIDER, (0, 1, 0), 1.0, -1.0, {"max_motor_force": 150.0, "motor_type": 0, "motor_velocity_or_target_distance": -0.5}),
+    ]
+    links = 3
+    per = 1 + links
+    n = len(flavours) * copies * per
+    e = make_entities(n)
+    c = make_colliders(n, capi.AABB, restitution=0.1, friction=0.6, density=2.0)
+    gcs = []
+    k = 0
+    for cp in range(copies):
+        for f, (ctype, axis, l0, l1, edits) in enumerate(flavours):
+            base = np.array([f * 2.5 - len(flavours) * 1.25, 5.0 + 0.3 * cp, cp * 6.0 - 3.0], np.float32)
+            yaw = q_axis_angle((0, 1, 0), 0.35 * f + 0.9 * cp)
+            for l in range(per):
+                e["position"][k + l] = base + q_rot(yaw, np.array([0.9 * l, 0, 0]))
+                e["rotation"][k + l] = yaw
+                c["shape"][k + l, :6] = (-0.35, -0.15, -0.2, 0.35, 0.15, 0.2)
+            e["kind"][k] = capi.ENTITY_KINEMATIC
+            for l in range(links):
+                a, b = k + l, k + l + 1
+                anchor = (e["position"][a] + e["position"][b]) * 0.5
+                if ctype == capi.CONSTRAINT_DISTANCE:
+                    gcs.append((ctype, a, b, e["position"][a].copy(), e["position"][b].copy(), l0, l1, edits))
+                else:
+                    ax = None if axis is None else q_rot(yaw, np.asarray(axis, np.float64)).astype(np.float32)
+                    gcs.append((ctype, a, b, anchor.astype(np.float32), ax, l0, l1, edits))
+            k += per
+    ge, gc = _ground(100.0)
+    return Scene(f"joint_zoo_{n}", np.concatenate([e, ge]), np.arange(n + 1, dtype=np.uint32), np.concatenate([c, gc]), solver_iterations,
+                 global_constraints=gcs)
+
+
 def by_name(name, **kw):
-    return {"cfg1": sphere_drop, "cfg2": mixed_stack, "cfg3": obb_pile}[name](**kw)
+    return {"cfg1": sphere_drop, "cfg2": mixed_stack, "cfg3": obb_pile, "cfg4": ragdolls, "zoo": shape_zoo}[name](**kw)

@@ -45,6 +45,8 @@ def test_gpu_matches_golden_bit_exact(mi_lib, name):
     (lambda: scenes.mixed_stack(12, 6, 12), 80),
     (lambda: scenes.obb_pile(12, 8, 12, spacing=1.1), 80),
     (lambda: scenes.shape_zoo(8, 5, 8), 150),
+    (lambda: scenes.ragdolls(4, 4), 160),
+    (lambda: scenes.joint_zoo(copies=3), 200),
 ])
 def test_gpu_vs_oracle_trajectory_and_contacts(mi_lib, oracle_mod, make, steps):
     sc = make()

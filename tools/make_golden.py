@@ -18,6 +18,8 @@ CASES = {
     "cfg2_mixed_96": (lambda: scenes.mixed_stack(4, 6, 4), 90),
     "cfg3_obb_160": (lambda: scenes.obb_pile(4, 10, 4, spacing=1.0), 90),
     "zoo_all_shapes_144": (lambda: scenes.shape_zoo(), 160),
+    "cfg4_ragdolls_4": (lambda: scenes.ragdolls(2, 2), 150),
+    "joint_zoo_112": (lambda: scenes.joint_zoo(), 150),
 }
 
 
