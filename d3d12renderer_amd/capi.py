@@ -238,6 +238,32 @@ class World:
             self.L.check(self.L.fn("world_get_contacts")(self.h, _ptr(out), C.c_uint32(n.value), C.byref(n)), "world_get_contacts")
         return out
 
+    # --- ghost-region exchange (13 floats per body: pos3, rot4, lin3, ang3)
+    def get_body_states(self, entities):
+        ents = np.ascontiguousarray(entities, dtype=np.uint32)
+        out = np.zeros((len(ents), 13), np.float32)
+        self.L.check(self.L.fn("world_get_body_states")(self.h, C.c_uint32(len(ents)), _ptr(ents), _ptr(out)), "world_get_body_states")
+        return out
+
+    def set_body_states(self, entities, states):
+        ents = np.ascontiguousarray(entities, dtype=np.uint32)
+        st = np.ascontiguousarray(states, dtype=np.float32).reshape(len(ents), 13)
+        self.L.check(self.L.fn("world_set_body_states")(self.h, C.c_uint32(len(ents)), _ptr(ents), _ptr(st)), "world_set_body_states")
+
+    def entities_to_bodies(self, entities):
+        ents = np.ascontiguousarray(entities, dtype=np.uint32)
+        out = np.zeros(len(ents), np.uint32)
+        self.L.check(self.L.fn("world_entities_to_bodies")(self.h, C.c_uint32(len(ents)), _ptr(ents), _ptr(out)), "world_entities_to_bodies")
+        return out
+
+    def get_body_states_device(self, n, body_ids_ptr, out_ptr):
+        self.L.check(self.L.fn("world_get_body_states_device")(self.h, C.c_uint32(n), C.c_void_p(body_ids_ptr), C.c_void_p(out_ptr)),
+                     "world_get_body_states_device")
+
+    def set_body_states_device(self, n, body_ids_ptr, in_ptr):
+        self.L.check(self.L.fn("world_set_body_states_device")(self.h, C.c_uint32(n), C.c_void_p(body_ids_ptr), C.c_void_p(in_ptr)),
+                     "world_set_body_states_device")
+
     def stage_times(self):
         t = StageTimes()
         self.L.check(self.L.fn("world_get_stage_times")(self.h, C.byref(t)), "world_get_stage_times")

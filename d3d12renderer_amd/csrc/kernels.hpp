@@ -641,6 +641,29 @@ __global__ __launch_bounds__(256) void k_iota(uint32_t n, uint32_t* __restrict__
     if (i < n) out[i] = i;
 }
 
+// Ghost-region exchange: pack / unpack 13-float body states (pos3, rot4, lin3, ang3) by body index.
+__global__ __launch_bounds__(256) void k_gather_states(uint32_t n, const uint32_t* __restrict__ ids, const float4* __restrict__ bPos,
+                                                       const float4* __restrict__ bRot, const float4* __restrict__ bLinVel,
+                                                       const float4* __restrict__ bAngVel, float* __restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t b = ids[i];
+    float4 p = bPos[b], q = bRot[b], v = bLinVel[b], w = bAngVel[b];
+    float* o = out + 13 * (size_t)i;
+    o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = q.x; o[4] = q.y; o[5] = q.z; o[6] = q.w;
+    o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = w.x; o[11] = w.y; o[12] = w.z;
+}
+__global__ __launch_bounds__(256) void k_scatter_states(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict__ in,
+                                                        float4* __restrict__ bPos, float4* __restrict__ bRot, float4* __restrict__ bLinVel,
+                                                        float4* __restrict__ bAngVel) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t b = ids[i];
+    const float* s = in + 13 * (size_t)i;
+    bPos[b] = make_float4(s[0], s[1], s[2], 0.f); bRot[b] = make_float4(s[3], s[4], s[5], s[6]);
+    bLinVel[b] = make_float4(s[7], s[8], s[9], 0.f); bAngVel[b] = make_float4(s[10], s[11], s[12], 0.f);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Contact schedule: Jones-Plassmann colouring of the manifold graph (replaces the serial greedy
 // scheduleConstraintsSIMD, src/physics/constraints.cpp:51-184).  Two manifolds conflict when they

@@ -884,6 +884,55 @@ MI_API int mi_world_get_contacts(mi_world* w, mi_contact* out, uint32_t cap, uin
     return MI_OK;
 }
 
+// ---- ghost-region exchange (multi-GPU sharding)
+static int ensureUploaded(mi_world* w) {
+    HIP_TRY(hipSetDevice(w->device));
+    if (w->topologyDirty) { int rc = w->download(); if (rc != MI_OK) return rc; return w->upload(); }
+    return MI_OK;
+}
+MI_API int mi_world_entities_to_bodies(mi_world* w, uint32_t n, const uint32_t* ents, uint32_t* out) {
+    if (!w || (n && (!ents || !out))) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    for (uint32_t i = 0; i < n; ++i) {
+        if (ents[i] >= w->entities.size() || w->entities[ents[i]].rb < 0) return fail(MI_ERR_INVALID_ARGUMENT, "not a rigid body");
+        out[i] = (uint32_t)w->entities[ents[i]].rb;
+    }
+    return MI_OK;
+}
+MI_API int mi_world_get_body_states_device(mi_world* w, uint32_t n, const uint32_t* idsDev, float* outDev) {
+    if (!w || (n && (!idsDev || !outDev))) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    int rc = ensureUploaded(w); if (rc != MI_OK) return rc;
+    if (n) k_gather_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p, outDev);
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return MI_OK;
+}
+MI_API int mi_world_set_body_states_device(mi_world* w, uint32_t n, const uint32_t* idsDev, const float* inDev) {
+    if (!w || (n && (!idsDev || !inDev))) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    int rc = ensureUploaded(w); if (rc != MI_OK) return rc;
+    if (n) k_scatter_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, inDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p);
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->hostStale = true;
+    return MI_OK;
+}
+static int statesHost(mi_world* w, uint32_t n, const uint32_t* ents, float* out, const float* in) {
+    if (!w || (n && !ents)) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    if (!n) return MI_OK;
+    std::vector<uint32_t> ids(n);
+    int rc = mi_world_entities_to_bodies(w, n, ents, ids.data()); if (rc != MI_OK) return rc;
+    rc = ensureUploaded(w); if (rc != MI_OK) return rc;
+    DBuf<uint32_t> dIds; DBuf<float> dSt;
+    HIP_TRY(dIds.ensure(n)); HIP_TRY(dSt.ensure(13 * (size_t)n));
+    HIP_TRY(hipMemcpy(dIds.p, ids.data(), n * 4, hipMemcpyHostToDevice));
+    if (in) {
+        HIP_TRY(hipMemcpy(dSt.p, in, 13 * (size_t)n * 4, hipMemcpyHostToDevice));
+        return mi_world_set_body_states_device(w, n, dIds.p, dSt.p);
+    }
+    rc = mi_world_get_body_states_device(w, n, dIds.p, dSt.p); if (rc != MI_OK) return rc;
+    HIP_TRY(hipMemcpy(out, dSt.p, 13 * (size_t)n * 4, hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+MI_API int mi_world_get_body_states(mi_world* w, uint32_t n, const uint32_t* ents, float* out) { return statesHost(w, n, ents, out, nullptr); }
+MI_API int mi_world_set_body_states(mi_world* w, uint32_t n, const uint32_t* ents, const float* in) { return statesHost(w, n, ents, nullptr, in); }
+
 // Stage dumps for parity bisecting.
 MI_API int mi_world_get_aabbs(mi_world* w, float* out6, uint32_t cap) {
     if (!w || !out6) return fail(MI_ERR_INVALID_ARGUMENT, "null");

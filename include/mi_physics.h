@@ -214,6 +214,20 @@ MI_API int mi_world_get_stage_times(mi_world* world, mi_stage_times* out);
 MI_API int mi_world_get_aabbs(mi_world* world, float* out_min_max6, uint32_t capacity);
 MI_API int mi_world_get_manifold_colors(mi_world* world, uint32_t* out_colors, uint32_t capacity);
 
+/*
+ * Ghost-region exchange support (multi-GPU spatial sharding).  A body state is 13 floats:
+ * position[3], rotation[4] (x,y,z,w), linear_velocity[3], angular_velocity[3] — i.e. physics_transform1 +
+ * rigid_body_component velocities.  The host variants take entity ids and host buffers; the *_device variants
+ * take rigid-body indices and state buffers that already live in this world's device memory (e.g. the
+ * data_ptr() of torch CUDA tensors used with RCCL), so the exchange never round-trips through the host.
+ */
+#define MI_BODY_STATE_FLOATS 13
+MI_API int mi_world_get_body_states(mi_world* world, uint32_t count, const uint32_t* entities, float* out_states13);
+MI_API int mi_world_set_body_states(mi_world* world, uint32_t count, const uint32_t* entities, const float* states13);
+MI_API int mi_world_entities_to_bodies(mi_world* world, uint32_t count, const uint32_t* entities, uint32_t* out_body_indices);
+MI_API int mi_world_get_body_states_device(mi_world* world, uint32_t count, const uint32_t* body_indices_dev, float* out_states13_dev);
+MI_API int mi_world_set_body_states_device(mi_world* world, uint32_t count, const uint32_t* body_indices_dev, const float* states13_dev);
+
 #ifdef __cplusplus
 }
 #endif

@@ -955,6 +955,27 @@ MI_API int ora_world_get_contacts(World* w, mi_contact* out, uint32_t cap, uint3
         }
     return MI_OK;
 }
+MI_API int ora_world_get_body_states(World* w, uint32_t n, const uint32_t* ents, float* out) {
+    for (uint32_t i = 0; i < n; ++i) {
+        if (ents[i] >= w->entities.size() || w->entities[ents[i]].rb < 0) return MI_ERR_INVALID_ARGUMENT;
+        const RigidBody& b = w->bodies[w->entities[ents[i]].rb];
+        float* o = out + 13 * (size_t)i;
+        o[0] = b.p1.x; o[1] = b.p1.y; o[2] = b.p1.z; o[3] = b.r1.x; o[4] = b.r1.y; o[5] = b.r1.z; o[6] = b.r1.w;
+        o[7] = b.linearVelocity.x; o[8] = b.linearVelocity.y; o[9] = b.linearVelocity.z;
+        o[10] = b.angularVelocity.x; o[11] = b.angularVelocity.y; o[12] = b.angularVelocity.z;
+    }
+    return MI_OK;
+}
+MI_API int ora_world_set_body_states(World* w, uint32_t n, const uint32_t* ents, const float* in) {
+    for (uint32_t i = 0; i < n; ++i) {
+        if (ents[i] >= w->entities.size() || w->entities[ents[i]].rb < 0) return MI_ERR_INVALID_ARGUMENT;
+        RigidBody& b = w->bodies[w->entities[ents[i]].rb];
+        const float* s = in + 13 * (size_t)i;
+        b.p1 = vec3(s[0], s[1], s[2]); b.r1 = quat(s[3], s[4], s[5], s[6]);
+        b.linearVelocity = vec3(s[7], s[8], s[9]); b.angularVelocity = vec3(s[10], s[11], s[12]);
+    }
+    return MI_OK;
+}
 // Stage dumps for bisecting mismatches.
 MI_API int ora_world_get_aabbs(World* w, float* out6, uint32_t cap) {
     if (cap < w->aabbs.size()) return MI_ERR_CAPACITY;
