@@ -1,0 +1,172 @@
+// physics_world.hpp — header-only C++ facade over the C ABI (mi_physics.h) carrying the names BASELINE.json's
+// north_star uses (physics_world::step / addRigidBody / addConstraint) and the reference's own free-function and
+// component names (physicsStep, physics_settings, rigid_body_component, collider_component::asXxx,
+// addXxxConstraintFromGlobalPoints — src/physics/physics.h:108-264, 382-405; src/physics/rigid_body.h:18-46).
+// The reference stores components in an EnTT registry; EnTT is not vendored, so entities here are plain handles
+// owned by the world.  INTEGRATION.md shows how the reference's scene hooks would forward to these calls.
+#pragma once
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include <array>
+#include "mi_physics.h"
+#include "mi_constraints.h"
+
+namespace mi_facade {
+
+struct vec3 { float x = 0, y = 0, z = 0; };
+struct quat { float x = 0, y = 0, z = 0, w = 1; };
+struct trs { vec3 position; quat rotation; };                       // transform_component (scale is unused by physics)
+
+struct physics_material { float restitution = 0.1f, friction = 0.5f, density = 1.f; };   // src/physics/physics.h:40-47
+
+// physics_settings (src/physics/physics.h:382-400) minus the std::function callbacks.
+struct physics_settings {
+    bool fixedFrameRate = true;
+    uint32_t frameRate = 120;
+    uint32_t maxPhysicsIterationsPerFrame = 4;
+    uint32_t numRigidSolverIterations = 30;
+    mi_step_settings c() const { return mi_step_settings{fixedFrameRate ? 1u : 0u, frameRate, maxPhysicsIterationsPerFrame, numRigidSolverIterations}; }
+};
+
+// rigid_body_component(bool kinematic, float gravityFactor, float linearDamping, float angularDamping) — rigid_body.h:20-21
+struct rigid_body_component {
+    bool kinematic = false;
+    float gravityFactor = 1.f, linearDamping = 0.4f, angularDamping = 0.4f;
+    vec3 linearVelocity, angularVelocity;
+};
+
+// collider_component::asSphere / asCapsule / asCylinder / asAABB / asOBB / asHull — physics.h:110-157
+struct collider_component {
+    mi_collider_desc d{};
+    static collider_component make(uint32_t type, physics_material m) {
+        collider_component c; c.d.type = type; c.d.restitution = m.restitution; c.d.friction = m.friction; c.d.density = m.density; return c;
+    }
+    static collider_component asSphere(vec3 center, float radius, physics_material m) {
+        auto c = make(MI_COLLIDER_SPHERE, m); float s[4] = {center.x, center.y, center.z, radius}; for (int i = 0; i < 4; ++i) c.d.shape[i] = s[i]; return c;
+    }
+    static collider_component asCapsule(vec3 a, vec3 b, float radius, physics_material m) {
+        auto c = make(MI_COLLIDER_CAPSULE, m); float s[7] = {a.x, a.y, a.z, b.x, b.y, b.z, radius}; for (int i = 0; i < 7; ++i) c.d.shape[i] = s[i]; return c;
+    }
+    static collider_component asCylinder(vec3 a, vec3 b, float radius, physics_material m) {
+        auto c = asCapsule(a, b, radius, m); c.d.type = MI_COLLIDER_CYLINDER; return c;
+    }
+    static collider_component asAABB(vec3 minCorner, vec3 maxCorner, physics_material m) {
+        auto c = make(MI_COLLIDER_AABB, m); float s[6] = {minCorner.x, minCorner.y, minCorner.z, maxCorner.x, maxCorner.y, maxCorner.z};
+        for (int i = 0; i < 6; ++i) c.d.shape[i] = s[i]; return c;
+    }
+    static collider_component asOBB(quat rotation, vec3 center, vec3 radius, physics_material m) {
+        auto c = make(MI_COLLIDER_OBB, m);
+        float s[10] = {rotation.x, rotation.y, rotation.z, rotation.w, center.x, center.y, center.z, radius.x, radius.y, radius.z};
+        for (int i = 0; i < 10; ++i) c.d.shape[i] = s[i]; return c;
+    }
+    static collider_component asHull(quat rotation, vec3 position, uint32_t geometryIndex, physics_material m) {
+        auto c = make(MI_COLLIDER_HULL, m); float s[7] = {rotation.x, rotation.y, rotation.z, rotation.w, position.x, position.y, position.z};
+        for (int i = 0; i < 7; ++i) c.d.shape[i] = s[i]; c.d.hull_geometry = geometryIndex; return c;
+    }
+};
+
+struct scene_entity { uint32_t id = 0xFFFFFFFFu; };
+struct constraint_handle { uint32_t type, id; };
+
+class physics_world {
+public:
+    explicit physics_world(int device = 0) {
+        mi_world_desc d{device, 0};
+        check(mi_world_create(&d, &w_), "mi_world_create");
+    }
+    ~physics_world() { if (w_) mi_world_destroy(w_); }
+    physics_world(const physics_world&) = delete;
+    physics_world& operator=(const physics_world&) = delete;
+
+    // createEntity().addComponent<transform_component>(t).addComponent<collider_component>(...)...addComponent<rigid_body_component>(rb)
+    scene_entity addRigidBody(const trs& t, const rigid_body_component& rb, const std::vector<collider_component>& colliders) {
+        return addEntity(t, rb.kinematic ? MI_ENTITY_KINEMATIC : MI_ENTITY_DYNAMIC, &rb, colliders);
+    }
+    // An entity with colliders but no rigid_body_component: static colliders (dummy body, physics.cpp:1214).
+    scene_entity addStaticCollider(const trs& t, const std::vector<collider_component>& colliders) { return addEntity(t, MI_ENTITY_STATIC, nullptr, colliders); }
+    uint32_t allocateBoundingHullGeometry(const std::vector<vec3>& vertices, const std::vector<std::array<uint32_t, 3>>& triangles) {
+        uint32_t g = 0;
+        check(mi_hull_geometry_create(w_, &vertices[0].x, (uint32_t)vertices.size(), triangles.empty() ? nullptr : &triangles[0][0], (uint32_t)triangles.size(), &g),
+              "mi_hull_geometry_create");
+        return g;
+    }
+
+    // addConstraint(a, b, const xxx_constraint&) — physics.h:235-240
+    constraint_handle addConstraint(scene_entity a, scene_entity b, const mi_distance_constraint& c) { return add(MI_CONSTRAINT_DISTANCE, a, b, &c, sizeof(c)); }
+    constraint_handle addConstraint(scene_entity a, scene_entity b, const mi_ball_constraint& c) { return add(MI_CONSTRAINT_BALL, a, b, &c, sizeof(c)); }
+    constraint_handle addConstraint(scene_entity a, scene_entity b, const mi_fixed_constraint& c) { return add(MI_CONSTRAINT_FIXED, a, b, &c, sizeof(c)); }
+    constraint_handle addConstraint(scene_entity a, scene_entity b, const mi_hinge_constraint& c) { return add(MI_CONSTRAINT_HINGE, a, b, &c, sizeof(c)); }
+    constraint_handle addConstraint(scene_entity a, scene_entity b, const mi_cone_twist_constraint& c) { return add(MI_CONSTRAINT_CONE_TWIST, a, b, &c, sizeof(c)); }
+    constraint_handle addConstraint(scene_entity a, scene_entity b, const mi_slider_constraint& c) { return add(MI_CONSTRAINT_SLIDER, a, b, &c, sizeof(c)); }
+
+    // add*ConstraintFromGlobalPoints — physics.h:217-233
+    constraint_handle addDistanceConstraintFromGlobalPoints(scene_entity a, scene_entity b, vec3 globalAnchorA, vec3 globalAnchorB) {
+        return fromGlobal(MI_CONSTRAINT_DISTANCE, a, b, globalAnchorA, &globalAnchorB, 0.f, 0.f);
+    }
+    constraint_handle addBallConstraintFromGlobalPoints(scene_entity a, scene_entity b, vec3 globalAnchor) { return fromGlobal(MI_CONSTRAINT_BALL, a, b, globalAnchor, nullptr, 0.f, 0.f); }
+    constraint_handle addFixedConstraintFromGlobalPoints(scene_entity a, scene_entity b, vec3 globalAnchor) { return fromGlobal(MI_CONSTRAINT_FIXED, a, b, globalAnchor, nullptr, 0.f, 0.f); }
+    constraint_handle addHingeConstraintFromGlobalPoints(scene_entity a, scene_entity b, vec3 globalAnchor, vec3 globalHingeAxis, float minLimit = 1.f, float maxLimit = -1.f) {
+        return fromGlobal(MI_CONSTRAINT_HINGE, a, b, globalAnchor, &globalHingeAxis, minLimit, maxLimit);
+    }
+    constraint_handle addConeTwistConstraintFromGlobalPoints(scene_entity a, scene_entity b, vec3 globalAnchor, vec3 globalAxis, float swingLimit, float twistLimit) {
+        return fromGlobal(MI_CONSTRAINT_CONE_TWIST, a, b, globalAnchor, &globalAxis, swingLimit, twistLimit);
+    }
+    constraint_handle addSliderConstraintFromGlobalPoints(scene_entity a, scene_entity b, vec3 globalAnchor, vec3 globalAxis, float minLimit = 1.f, float maxLimit = -1.f) {
+        return fromGlobal(MI_CONSTRAINT_SLIDER, a, b, globalAnchor, &globalAxis, minLimit, maxLimit);
+    }
+    // getConstraint(scene, handle) returns a mutable reference in the reference; here: read, edit, write back.
+    template <class Pod> Pod getConstraint(constraint_handle h) { Pod p; check(mi_constraint_get(w_, h.type, h.id, &p, sizeof(p)), "mi_constraint_get"); return p; }
+    template <class Pod> void setConstraint(constraint_handle h, const Pod& p) { check(mi_constraint_update(w_, h.type, h.id, &p, sizeof(p)), "mi_constraint_update"); }
+
+    void applyForce(scene_entity e, vec3 force, vec3 torque) { check(mi_entity_apply_force(w_, e.id, &force.x, &torque.x), "mi_entity_apply_force"); }
+
+    // physicsStep(scene, arena, timer, settings, dt) — the timer and the arena live inside the world.
+    void step(const physics_settings& settings, float dt) { mi_step_settings s = settings.c(); check(mi_world_step(w_, &s, dt), "mi_world_step"); }
+    void stepFixed(const physics_settings& settings, float dt, uint32_t n = 1) { mi_step_settings s = settings.c(); check(mi_world_step_fixed(w_, &s, dt, n), "mi_world_step_fixed"); }
+
+    uint32_t numEntities() { uint32_t n = 0; check(mi_world_num_entities(w_, &n), "mi_world_num_entities"); return n; }
+    std::vector<trs> transforms() {
+        uint32_t n = numEntities();
+        std::vector<float> p(3 * n), q(4 * n);
+        check(mi_world_get_transforms(w_, p.data(), q.data(), n), "mi_world_get_transforms");
+        std::vector<trs> out(n);
+        for (uint32_t i = 0; i < n; ++i) { out[i].position = {p[3 * i], p[3 * i + 1], p[3 * i + 2]}; out[i].rotation = {q[4 * i], q[4 * i + 1], q[4 * i + 2], q[4 * i + 3]}; }
+        return out;
+    }
+    mi_step_counts counts() { mi_step_counts c; check(mi_world_get_counts(w_, &c), "mi_world_get_counts"); return c; }
+    mi_world* handle() { return w_; }
+
+private:
+    mi_world* w_ = nullptr;
+    static void check(int rc, const char* what) { if (rc != MI_OK) throw std::runtime_error(std::string(what) + ": " + mi_last_error()); }
+    scene_entity addEntity(const trs& t, uint32_t kind, const rigid_body_component* rb, const std::vector<collider_component>& colliders) {
+        mi_entity_desc d{};
+        d.position[0] = t.position.x; d.position[1] = t.position.y; d.position[2] = t.position.z;
+        d.rotation[0] = t.rotation.x; d.rotation[1] = t.rotation.y; d.rotation[2] = t.rotation.z; d.rotation[3] = t.rotation.w;
+        d.gravity_factor = rb ? rb->gravityFactor : 1.f; d.linear_damping = rb ? rb->linearDamping : 0.4f; d.angular_damping = rb ? rb->angularDamping : 0.4f;
+        if (rb) { d.linear_velocity[0] = rb->linearVelocity.x; d.linear_velocity[1] = rb->linearVelocity.y; d.linear_velocity[2] = rb->linearVelocity.z;
+                  d.angular_velocity[0] = rb->angularVelocity.x; d.angular_velocity[1] = rb->angularVelocity.y; d.angular_velocity[2] = rb->angularVelocity.z; }
+        d.kind = kind;
+        scene_entity e;
+        check(mi_entity_create(w_, &d, &e.id), "mi_entity_create");
+        for (const collider_component& c : colliders) check(mi_collider_add(w_, e.id, &c.d, nullptr), "mi_collider_add");
+        return e;
+    }
+    constraint_handle add(uint32_t type, scene_entity a, scene_entity b, const void* pod, uint32_t bytes) {
+        constraint_handle h{type, 0};
+        check(mi_constraint_create(w_, type, a.id, b.id, pod, bytes, &h.id), "mi_constraint_create");
+        return h;
+    }
+    constraint_handle fromGlobal(uint32_t type, scene_entity a, scene_entity b, vec3 anchor, const vec3* axis, float l0, float l1) {
+        constraint_handle h{type, 0};
+        check(mi_constraint_create_from_global(w_, type, a.id, b.id, &anchor.x, axis ? &axis->x : nullptr, l0, l1, &h.id), "mi_constraint_create_from_global");
+        return h;
+    }
+};
+
+// Reference-named free function: physicsStep(game_scene&, memory_arena&, float& timer, const physics_settings&, float dt)
+// (src/physics/physics.h:405).  The world owns what the scene, the arena and the timer were.
+inline void physicsStep(physics_world& world, const physics_settings& settings, float dt) { world.step(settings, dt); }
+
+}  // namespace mi_facade

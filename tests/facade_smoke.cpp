@@ -1,0 +1,29 @@
+// Compile-and-link check of include/physics_world.hpp against libmi_physics.so (run by tests/test_capi_symbols.py;
+// executing it needs a GPU, compiling/linking does not).
+#include <cstdio>
+#include "physics_world.hpp"
+using namespace mi_facade;
+int main() {
+    try {
+        physics_world world(0);
+        physics_material mat{0.1f, 0.5f, 1.f};
+        auto ground = world.addStaticCollider(trs{}, {collider_component::asAABB({-50, -4, -50}, {50, 0, 50}, mat)});
+        (void)ground;
+        trs t; t.position = {0, 2, 0};
+        auto a = world.addRigidBody(t, rigid_body_component{}, {collider_component::asSphere({0, 0, 0}, 0.5f, mat)});
+        t.position = {1.2f, 2, 0};
+        auto b = world.addRigidBody(t, rigid_body_component{}, {collider_component::asAABB({-0.5f, -0.5f, -0.5f}, {0.5f, 0.5f, 0.5f}, mat)});
+        auto h = world.addHingeConstraintFromGlobalPoints(a, b, {0.6f, 2, 0}, {0, 0, 1}, -0.5f, 0.5f);
+        auto pod = world.getConstraint<mi_hinge_constraint>(h);
+        pod.max_motor_torque = 5.f; pod.motor_velocity_or_target_angle = 1.f;
+        world.setConstraint(h, pod);
+        physics_settings settings;
+        for (int i = 0; i < 120; ++i) physicsStep(world, settings, 1.f / 60.f);
+        auto tr = world.transforms();
+        std::printf("facade ok: a.y=%f b.y=%f contacts=%u\n", tr[a.id].position.y, tr[b.id].position.y, world.counts().num_contacts);
+    } catch (const std::exception& e) {
+        std::printf("facade error: %s\n", e.what());
+        return 1;
+    }
+    return 0;
+}
