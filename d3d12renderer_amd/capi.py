@@ -65,6 +65,10 @@ class StepCounts(C.Structure):
     def as_dict(self):
         return {n: getattr(self, n) for n, _ in self._fields_ if n != "reserved"}
 
+    @property
+    def solve_launches(self):
+        return self.reserved
+
 
 class StageTimes(C.Structure):
     _fields_ = [(n, C.c_float) for n in ("world_colliders", "broadphase", "narrowphase", "integrate_forces", "schedule",
@@ -195,6 +199,12 @@ class World:
         """n x physicsStepInternal — src/physics/physics.cpp:1180."""
         self.L.check(self.L.fn("world_step_fixed")(self.h, C.byref(settings), C.c_float(dt), C.c_uint32(n)), "world_step_fixed")
 
+    def step_profiled(self, settings, dt):
+        """One internal step with per-launch HIP events around the dominant kernel -> (launches, kernel_ms, contact_updates)."""
+        n = C.c_uint32(0); ms = C.c_float(0); upd = C.c_uint64(0)
+        self.L.check(self.L.fn("world_step_profiled")(self.h, C.byref(settings), C.c_float(dt), C.byref(n), C.byref(ms), C.byref(upd)), "world_step_profiled")
+        return n.value, ms.value, upd.value
+
     # --- read-back
     def num_entities(self):
         n = C.c_uint32(0)
@@ -229,6 +239,12 @@ class World:
         c = StepCounts()
         self.L.check(self.L.fn("world_get_counts")(self.h, C.byref(c)), "world_get_counts")
         return c.as_dict()
+
+    def solve_launches(self):
+        """Contact-solve kernel launches of the last step (product library only; 0 for the oracle)."""
+        c = StepCounts()
+        self.L.check(self.L.fn("world_get_counts")(self.h, C.byref(c)), "world_get_counts")
+        return c.reserved
 
     def contacts(self):
         n = C.c_uint32(0)

@@ -787,49 +787,68 @@ __global__ __launch_bounds__(256) void k_contact_init(uint32_t nm, uint32_t cap,
 
 // One PGS update of the contacts of slot s (src/physics/constraints.cpp:3381-3449): friction first
 // (clamped with the previous normal impulse), then the normal row.
+// Latency structure: a colour launch has only a few waves per CU, so it is bound by dependent-load depth,
+// not bandwidth.  All constraint rows of the slot's (<= 4) contacts are therefore requested up front,
+// together with the two body gathers: two memory round trips per lane (meta -> everything) instead of five.
+struct ContactRows { float4 r[kRows]; float2 imp; };
+
+__device__ __forceinline__ void solveOne(const ContactRows& c, float2& im, float imA, float imB, V3& vA, V3& wA, V3& vB, V3& wB) {
+    V3 rA = xyz(c.r[0]), rB = xyz(c.r[1]), t = xyz(c.r[2]), n = xyz(c.r[3]);
+    {
+        V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
+        V3 rel = avB - avA;
+        float vt = dot(rel, t);
+        float lambda = -c.r[1].w * vt;
+        float maxF = c.r[3].w * im.x;
+        float ni = clampr(im.y + lambda, -maxF, maxF);
+        lambda = ni - im.y;
+        im.y = ni;
+        V3 P = lambda * t;
+        vA = vA - imA * P;
+        wA = wA - xyz(c.r[4]) * lambda;
+        vB = vB + imB * P;
+        wB = wB + xyz(c.r[5]) * lambda;
+    }
+    {
+        V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
+        V3 rel = avB - avA;
+        float vn = dot(rel, n);
+        float lambda = -c.r[0].w * (vn - c.r[2].w);
+        float ni = fmaxr(im.x + lambda, 0.f);
+        lambda = ni - im.x;
+        im.x = ni;
+        V3 P = lambda * n;
+        vA = vA - imA * P;
+        wA = wA - xyz(c.r[6]) * lambda;
+        vB = vB + imB * P;
+        wB = wB + xyz(c.r[7]) * lambda;
+    }
+}
+
 __device__ __forceinline__ void solveSlot(uint32_t s, uint32_t cap, const uint4 meta, const float4* __restrict__ rows, float2* __restrict__ imp,
                                           float4* __restrict__ gVel) {
     uint32_t bA = meta.x, bB = meta.y, cnt = meta.z;
+    ContactRows c[4];
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (k < cnt) {
+            size_t base = (size_t)k * kRows * cap + s;
+#pragma unroll
+            for (uint32_t r = 0; r < kRows; ++r) c[k].r[r] = rows[base + (size_t)r * cap];
+            c[k].imp = imp[(size_t)k * cap + s];
+        }
+    }
     float4 a0 = gVel[2 * bA], a1 = gVel[2 * bA + 1], b0 = gVel[2 * bB], b1 = gVel[2 * bB + 1];
     float imA = a0.w, imB = b0.w;
     if (imA == 0.f && imB == 0.f) return;
     V3 vA = xyz(a0), wA = xyz(a1), vB = xyz(b0), wB = xyz(b1);
-    for (uint32_t k = 0; k < cnt; ++k) {
-        size_t base = (size_t)k * kRows * cap + s;
-        float4 r0 = rows[base], r1 = rows[base + (size_t)cap], r2 = rows[base + 2 * (size_t)cap], r3 = rows[base + 3 * (size_t)cap];
-        float4 r4 = rows[base + 4 * (size_t)cap], r5 = rows[base + 5 * (size_t)cap], r6 = rows[base + 6 * (size_t)cap], r7 = rows[base + 7 * (size_t)cap];
-        float2 im = imp[(size_t)k * cap + s];
-        V3 rA = xyz(r0), rB = xyz(r1), t = xyz(r2), n = xyz(r3);
-        {
-            V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
-            V3 rel = avB - avA;
-            float vt = dot(rel, t);
-            float lambda = -r1.w * vt;
-            float maxF = r3.w * im.x;
-            float ni = clampr(im.y + lambda, -maxF, maxF);
-            lambda = ni - im.y;
-            im.y = ni;
-            V3 P = lambda * t;
-            vA = vA - imA * P;
-            wA = wA - xyz(r4) * lambda;
-            vB = vB + imB * P;
-            wB = wB + xyz(r5) * lambda;
+#pragma unroll
+    for (uint32_t k = 0; k < 4; ++k) {
+        if (k < cnt) {
+            float2 im = c[k].imp;
+            solveOne(c[k], im, imA, imB, vA, wA, vB, wB);
+            imp[(size_t)k * cap + s] = im;
         }
-        {
-            V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
-            V3 rel = avB - avA;
-            float vn = dot(rel, n);
-            float lambda = -r0.w * (vn - r2.w);
-            float ni = fmaxr(im.x + lambda, 0.f);
-            lambda = ni - im.x;
-            im.x = ni;
-            V3 P = lambda * n;
-            vA = vA - imA * P;
-            wA = wA - xyz(r6) * lambda;
-            vB = vB + imB * P;
-            wB = wB + xyz(r7) * lambda;
-        }
-        imp[(size_t)k * cap + s] = im;
     }
     if (imA != 0.f) { gVel[2 * bA] = f4(vA, imA); gVel[2 * bA + 1] = f4(wA, 0.f); }
     if (imB != 0.f) { gVel[2 * bB] = f4(vB, imB); gVel[2 * bB + 1] = f4(wB, 0.f); }
@@ -842,6 +861,19 @@ __global__ __launch_bounds__(256) void k_contact_solve(uint32_t s0, uint32_t s1,
     if (s >= s1) return;
     solveSlot(s, cap, slotMeta[s], rows, imp, gVel);
 }
+// Trailing colours of the greedy colouring are tiny; one 256-lane workgroup runs colours [c0, c1) back to back
+// with a workgroup barrier + workgroup-scope fence between them instead of one launch each (a colour costs one
+// dependent-load chain, ~1.5 us, inside the kernel vs ~5.5 us as its own launch).
+struct ColorRanges { uint32_t off[kOverflowColor + 2]; };
+__global__ __launch_bounds__(256) void k_contact_solve_tail(ColorRanges cr, uint32_t c0, uint32_t c1, uint32_t cap, const uint4* __restrict__ slotMeta,
+                                                             const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+    for (uint32_t c = c0; c < c1; ++c) {
+        for (uint32_t s = cr.off[c] + threadIdx.x; s < cr.off[c + 1]; s += blockDim.x) solveSlot(s, cap, slotMeta[s], rows, imp, gVel);
+        __threadfence_block();   // one workgroup = one CU = one L1: workgroup scope is enough (an agent-scope fence costs ~3.5 us per lane here)
+        __syncthreads();
+    }
+}
+
 // Overflow colour (a body with > 64 incident manifolds): sequential, one lane.
 __global__ void k_contact_solve_serial(uint32_t s0, uint32_t s1, uint32_t cap, const uint4* __restrict__ slotMeta,
                                        const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {

@@ -107,7 +107,10 @@ struct mi_world {
     mi_step_counts counts{};
     mi_stage_times times{};
     hipEvent_t ev[10]{};
-    uint32_t numColorsUsed = 0, colorRounds = 0;
+    uint32_t numColorsUsed = 0, colorRounds = 0, solveLaunches = 0;
+    bool profileSolve = false;            // per-launch HIP events around k_contact_solve (mi_world_step_profiled)
+    std::vector<hipEvent_t> profEvents;   // pairs
+    uint32_t profLaunches = 0; float profKernelMs = 0.f; uint64_t profSlots = 0, profContacts = 0;
     bool usesGjk = false;   // any capsule / cylinder / hull collider present (decided at upload)
     uint32_t lastNumCells = kMaxCells;   // cells covered by the histogram/scan (host-side bound)
     std::vector<uint32_t> colorOffsets;
@@ -136,6 +139,7 @@ int mi_world::init(int dev) {
 }
 mi_world::~mi_world() {
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    for (auto& e : profEvents) (void)hipEventDestroy(e);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
 }
 
@@ -489,16 +493,45 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     int rc = joints.initialize(*this, dt, st);
     if (rc != MI_OK) return rc;
     mark();  // 6
+    // colours [tailStart, tailEnd) are small (<= 512 manifolds each, a suffix of the used colours): one launch for all of them
+    uint32_t tailEnd = std::min(numColorsUsed, kOverflowColor), tailStart = tailEnd;
+    while (tailStart > 0 && colorOffsets[tailStart] - colorOffsets[tailStart - 1] <= 512u) --tailStart;
+    if (tailEnd - tailStart < 2) tailStart = tailEnd;
+    ColorRanges ranges;
+    for (uint32_t c = 0; c <= kOverflowColor + 1; ++c) ranges.off[c] = colorOffsets[c];
+    solveLaunches = settings.num_rigid_solver_iterations * (tailStart + (tailStart < tailEnd ? 1u : 0u));
     for (uint32_t it = 0; it < settings.num_rigid_solver_iterations; ++it) {
         joints.solveIteration(*this, st);   // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
-        for (uint32_t c = 0; c < kOverflowColor && c < numColorsUsed; ++c) {
+        for (uint32_t c = 0; c < tailStart; ++c) {
             uint32_t s0 = colorOffsets[c], s1 = colorOffsets[c + 1];
-            if (s1 > s0) k_contact_solve<<<divUp(s1 - s0, 64), 64, 0, st>>>(s0, s1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
+            if (s1 <= s0) continue;
+            if (profileSolve) {
+                size_t e = 2 * (size_t)profLaunches;
+                while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
+                (void)hipEventRecord(profEvents[e], st);
+                k_contact_solve<<<divUp(s1 - s0, 64), 64, 0, st>>>(s0, s1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
+                (void)hipEventRecord(profEvents[e + 1], st);
+                ++profLaunches; profSlots += s1 - s0;
+            } else {
+                k_contact_solve<<<divUp(s1 - s0, 64), 64, 0, st>>>(s0, s1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
+            }
         }
+        if (tailStart < tailEnd) k_contact_solve_tail<<<1, 256, 0, st>>>(ranges, tailStart, tailEnd, cap, slotMeta.p, rows.p, imp.p, gVel.p);
         uint32_t o0 = colorOffsets[kOverflowColor], o1 = colorOffsets[kOverflowColor + 1];
         if (o1 > o0) k_contact_solve_serial<<<1, 64, 0, st>>>(o0, o1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
     }
     mark();  // 7
+    if (profileSolve) {
+        // contacts covered by the profiled (non-tail) launches: read the slot metadata once
+        std::vector<uint4> meta(nm);
+        if (nm) HIP_TRY(hipMemcpyAsync(meta.data(), slotMeta.p, nm * sizeof(uint4), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        profContacts = 0;
+        for (uint32_t s_ = 0; s_ < colorOffsets[tailStart] && s_ < nm; ++s_) profContacts += meta[s_].z;
+        profContacts *= settings.num_rigid_solver_iterations;
+        profKernelMs = 0.f;
+        for (uint32_t l = 0; l < profLaunches; ++l) { float ms = 0.f; (void)hipEventElapsedTime(&ms, profEvents[2 * l], profEvents[2 * l + 1]); profKernelMs += ms; }
+    }
     k_integrate_velocities<<<divUp(nb, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p);
     mark();  // 8
     HIP_TRY(hipStreamSynchronize(st));
@@ -509,7 +542,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     times.world_colliders = el(0, 1); times.broadphase = el(1, 2); times.narrowphase = el(2, 3); times.integrate_forces = el(3, 4);
     times.schedule = el(4, 5); times.init_constraints = el(5, 6); times.solve = el(6, 7); times.integrate_velocities = el(7, 8); times.total = el(0, 8);
     counts.num_rigid_bodies = nb; counts.num_colliders = nc; counts.num_broadphase_overlaps = nc ? hs.numOverlaps : 0;
-    counts.num_collisions = nm; counts.num_contacts = ncon; counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur; counts.reserved = colorRounds;
+    counts.num_collisions = nm; counts.num_contacts = ncon; counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur; counts.reserved = solveLaunches;
     return MI_OK;
 }
 
@@ -769,6 +802,19 @@ MI_API int mi_world_step_fixed(mi_world* w, const mi_step_settings* s, float dt,
     if (!w || !s) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
     for (uint32_t i = 0; i < n; ++i) { int rc = w->stepInternal(*s, dt); if (rc != MI_OK) return rc; }
     return MI_OK;
+}
+
+// One internal step with a HIP event pair around every k_contact_solve launch (roofline measurement; bench.py).
+// out: number of profiled launches, their summed kernel time (ms), and the contact updates (contacts x iterations) they performed.
+MI_API int mi_world_step_profiled(mi_world* w, const mi_step_settings* s, float dt, uint32_t* out_launches, float* out_kernel_ms, uint64_t* out_contact_updates) {
+    if (!w || !s) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    w->profileSolve = true; w->profLaunches = 0; w->profSlots = 0; w->profKernelMs = 0.f; w->profContacts = 0;
+    int rc = w->stepInternal(*s, dt);
+    w->profileSolve = false;
+    if (out_launches) *out_launches = w->profLaunches;
+    if (out_kernel_ms) *out_kernel_ms = w->profKernelMs;
+    if (out_contact_updates) *out_contact_updates = w->profContacts;
+    return rc;
 }
 
 // physicsStep (src/physics/physics.cpp:1364-1413): accumulator, <= maxPhysicsIterationsPerFrame sub-steps, pose interpolation.

@@ -125,7 +125,7 @@ typedef struct mi_step_counts {
     uint32_t num_contacts;
     uint32_t num_colors;        /* contact colours used by the solver schedule */
     uint32_t sorting_axis;      /* SAP axis used this step (src/physics/collision_broad.cpp:345) */
-    uint32_t reserved;
+    uint32_t reserved;          /* product library: contact-solve kernel launches of the step */
 } mi_step_counts;
 
 /* collision_contact + constraint_body_pair + collider_pair — src/physics/physics.h:347-354. */
@@ -198,6 +198,11 @@ MI_API int mi_entity_apply_force(mi_world* world, uint32_t entity, const float* 
 MI_API int mi_world_step(mi_world* world, const mi_step_settings* settings, float dt);
 /* n × physicsStepInternal(scene, arena, settings, dt) (src/physics/physics.cpp:1180-1362); no interpolation. */
 MI_API int mi_world_step_fixed(mi_world* world, const mi_step_settings* settings, float dt, uint32_t num_steps);
+
+/* One internal step with a HIP event pair around every k_contact_solve launch (the dominant kernel): returns the number
+ * of launches, their summed device time and the contact updates (contacts x iterations) they performed. */
+MI_API int mi_world_step_profiled(mi_world* world, const mi_step_settings* settings, float dt, uint32_t* out_launches,
+                                  float* out_kernel_ms, uint64_t* out_contact_updates);
 
 /* Read-back (transform_component / rigid_body_component fields), entity order. */
 MI_API int mi_world_num_entities(mi_world* world, uint32_t* out);
