@@ -290,7 +290,8 @@ __device__ inline bool segmentShapeVsAABB(const Shape& c, const Shape& box, cons
             V3 center = (box.a + box.b) * 0.5f;
             boxClipPlanes((box.b - box.a) * 0.5f, boxNormal, cp, cn);
             for (int i = 0; i < 4; ++i) { cp[i] = cp[i] + center; planes[i] = makePlane(cp[i], cn[i]); }
-            clipAndBuild(poly, planes, 4, ref, out);
+            ClipPoly clipped;
+            clipAndBuild(poly, clipped, planes, 4, ref, out);
         }
     }
     return true;
@@ -358,11 +359,12 @@ __device__ inline bool intersectGjkImpl(const Shape& a, const Shape& b, const Hu
     }
 }
 
-__global__ __launch_bounds__(64) void k_narrow_gjk(uint32_t numPairs, const uint64_t* __restrict__ pairKeys, const float4* __restrict__ wShape,
+__global__ __launch_bounds__(64) void k_narrow_gjk(uint32_t pairLo, uint32_t pairHi, const uint64_t* __restrict__ pairKeys, const float4* __restrict__ wShape,
                                                    HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
                                                    float4* __restrict__ npPoints) {
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= numPairs) return;
+    // [pairLo, pairHi) = span of the bucket-partitioned pair list that holds the GJK/EPA buckets
+    uint32_t p = pairLo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= pairHi) return;
     uint64_t key = pairKeys[p];
     uint32_t bucket = (uint32_t)(key >> 58), a = (uint32_t)((key >> 29) & 0x1FFFFFFFu), b = (uint32_t)(key & 0x1FFFFFFFu);
     uint32_t ta = 0, rem = bucket;

@@ -13,6 +13,10 @@ constexpr uint32_t kNoBody = 0xFFFFFFFFu;
 constexpr uint32_t kMaxCells = 1u << 22;
 constexpr uint32_t kOverflowColor = 64;
 constexpr uint32_t kUncolored = 0xFFFFFFFFu;
+constexpr uint32_t kNumBuckets = 21;                          // 6 x 6 upper-triangular collider type pairs
+constexpr uint32_t kColorBins = (kOverflowColor + 1) * 4;     // (colour, contacts per manifold) bins of the solver schedule
+constexpr uint32_t kMaxColorRounds = 4094;                    // 12-bit round tag in the colouring keys
+constexpr uint32_t kIndexBits = 26;                           // colliders per world < 2^26 (52-bit unique pair priorities)
 
 enum : uint32_t { OBJ_RIGID_BODY = 0, OBJ_STATIC = 1, OBJ_FORCE_FIELD = 2, OBJ_TRIGGER = 3 };
 
@@ -39,11 +43,18 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t uncolored;
     uint32_t axisCur;
     uint32_t axisNext;
-    uint32_t colorHist[kOverflowColor + 1];
-    uint32_t extentHist[256];   // log2 histogram of AABB extents (8 bins per octave) -> cell size / "large" threshold
+    uint32_t bucketHist[24];       // collision pairs per narrow-phase bucket (type pair)
+    uint32_t bucketCursor[24];     // running output cursors of the bucket partition
+    uint32_t binStart[kColorBins + 4];   // first schedule slot of every (colour, contact count) bin; [kColorBins] = manifolds
     float largeThreshold;
     uint32_t pad0;
 };
+
+// Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
+// chip (one L2 channel), so thousands of workgroups adding to ONE word serialise a whole kernel behind it.
+constexpr uint32_t kShards = 16;
+struct ShardCounters { uint32_t numOverlaps; uint32_t bucketHist[24]; uint32_t pad[7]; };   // one 128-byte line per shard
+struct Shards { ShardCounters c[kShards]; uint32_t extentHist[kShards][256]; };
 
 __device__ __forceinline__ int orderedInt(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float fromOrderedInt(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
@@ -157,7 +168,7 @@ __device__ __forceinline__ float extentBinUpper(uint32_t b) { return exp2f(((flo
 // Deterministic centre statistics for the next sorting axis: fixed butterfly per wave (double),
 // waves 0..3 added in order, block partials added sequentially by k_axis_final.
 __global__ __launch_bounds__(256) void k_axis_partials(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
-                                                       double* __restrict__ partials, StepScalars* sc) {
+                                                       double* __restrict__ partials, Shards* sh) {
     __shared__ double sm[4][6];
     __shared__ uint32_t hist[256];
     hist[threadIdx.x] = 0;
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(256) void k_axis_partials(uint32_t nc, const float4
         for (int c = 0; c < 6; ++c) sm[wv][c] = v[c];
     }
     __syncthreads();
-    if (hist[threadIdx.x]) atomicAdd(&sc->extentHist[threadIdx.x], hist[threadIdx.x]);
+    if (hist[threadIdx.x]) atomicAdd(&sh->extentHist[blockIdx.x & (kShards - 1u)][threadIdx.x], hist[threadIdx.x]);
     if (threadIdx.x == 0) {
         for (int c = 0; c < 6; ++c) {
             double a = 0.0;
@@ -191,21 +202,25 @@ __global__ __launch_bounds__(256) void k_axis_partials(uint32_t nc, const float4
         }
     }
 }
-// Block partials are added in block order by one lane (the deterministic part); the other lanes only stage
-// them through LDS so the serial chain is add-latency-bound, not HBM-latency-bound.
+// Block partials are reduced by one 256-lane workgroup with a fixed tree (mirrored by the oracle): lane t adds
+// partials t, t+256, ... in ascending order, then the wave butterfly (offsets 32..1), then waves 0..3 in order.
 __global__ __launch_bounds__(256) void k_axis_final(uint32_t nc, uint32_t numBlocks, const double* __restrict__ partials, StepScalars* sc) {
-    __shared__ double tile[256 * 6];
-    double s[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t base = 0; base < numBlocks; base += 256) {
-        uint32_t n = min(256u, numBlocks - base);
-        for (uint32_t t = threadIdx.x; t < n * 6; t += 256) tile[t] = partials[(size_t)base * 6 + t];
-        __syncthreads();
-        if (threadIdx.x == 0)
-            for (uint32_t b = 0; b < n; ++b)
-                for (int c = 0; c < 6; ++c) s[c] += tile[b * 6 + c];
-        __syncthreads();
+    __shared__ double sm[4][6];
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t b = threadIdx.x; b < numBlocks; b += 256) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] += partials[(size_t)b * 6 + c];
     }
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] += __shfl_down(v[c], off, 64);
+    }
+    uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) for (int c = 0; c < 6; ++c) sm[wv][c] = v[c];
+    __syncthreads();
     if (threadIdx.x != 0) return;
+    double s[6];
+    for (int c = 0; c < 6; ++c) { double a = 0.0; for (int w = 0; w < 4; ++w) a += sm[w][c]; s[c] = a; }
     double var[3];
     for (int c = 0; c < 3; ++c) var[c] = s[3 + c] - s[c] * s[c] / (double)nc;
     sc->axisNext = (var[0] > var[1]) ? ((var[0] > var[2]) ? 0u : 2u) : ((var[1] > var[2]) ? 1u : 2u);  // collision_broad.cpp:443-444
@@ -213,13 +228,18 @@ __global__ __launch_bounds__(256) void k_axis_final(uint32_t nc, uint32_t numBlo
 
 // Cell size = smallest extent bin edge that leaves at most `limit` colliders above it; those few "large"
 // colliders (ground, walls, outliers) are handled by the brute-force pass.
-__global__ void k_bp_threshold(uint32_t nc, StepScalars* sc) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+__global__ __launch_bounds__(256) void k_bp_threshold(uint32_t nc, const Shards* __restrict__ sh, StepScalars* sc) {
+    __shared__ uint32_t hist[256];
+    uint32_t v = 0;
+    for (uint32_t k = 0; k < kShards; ++k) v += sh->extentHist[k][threadIdx.x];
+    hist[threadIdx.x] = v;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
     uint32_t limit = max(16u, nc / 16384u);
     uint32_t costCap = (uint32_t)(67108864ull / (uint64_t)max(nc, 1u));
     limit = max(8u, min(limit, costCap));
     uint32_t above = 0; int b = 255;
-    for (; b >= 0; --b) { if (above + sc->extentHist[b] > limit) break; above += sc->extentHist[b]; }
+    for (; b >= 0; --b) { if (above + hist[b] > limit) break; above += hist[b]; }
     sc->largeThreshold = b < 0 ? 0.f : extentBinUpper((uint32_t)b);
 }
 
@@ -288,31 +308,40 @@ __device__ __forceinline__ void cellOf(const GridParams& g, float cx, float cy, 
     iz = min((uint32_t)fmaxr(0.f, (cz - g.origin[2]) * g.invCell), g.dims[2] - 1u);
 }
 
+// Cell id of every small collider + its arrival rank inside the cell (the returned value of the histogram atomic):
+// after the exclusive scan of the histogram, sorted position = cellLower[key] + rank — a counting sort with no sort
+// pass.  The order inside a cell is arbitrary; nothing downstream depends on it (pairs are keyed by collider index).
 __global__ __launch_bounds__(256) void k_bp_cell_ids(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
                                                      const uint32_t* __restrict__ isLarge, const GridParams* __restrict__ gp,
-                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ vals, uint32_t* __restrict__ cellCount) {
+                                                     uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks, uint32_t* __restrict__ cellCount) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nc) return;
     GridParams g = *gp;
-    uint32_t key = 0xFFFFFFFFu;
+    uint32_t key = 0xFFFFFFFFu, rank = 0;
     if (!isLarge[i]) {
         float4 mn = aabbMin[i], mx = aabbMax[i];
         uint32_t ix, iy, iz;
         cellOf(g, (mn.x + mx.x) * 0.5f, (mn.y + mx.y) * 0.5f, (mn.z + mx.z) * 0.5f, ix, iy, iz);
         key = (ix * g.dims[1] + iy) * g.dims[2] + iz;
-        atomicAdd(&cellCount[key], 1u);
+        rank = atomicAdd(&cellCount[key], 1u);
     }
-    keys[i] = key; vals[i] = i;
+    keys[i] = key; ranks[i] = rank;
 }
 
-// Sorted-order copies of the AABB rows so a column scan reads contiguous memory.
-__global__ __launch_bounds__(256) void k_bp_gather_sorted(uint32_t nc, const uint32_t* __restrict__ vals,
-                                                          const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
-                                                          float4* __restrict__ sMin, float4* __restrict__ sMax) {
+// Cell-sorted copies of the AABB rows (a column scan reads contiguous memory), the cell key and the collider index.
+// Positions [numSmall, nc) keep the key 0xFFFFFFFF written by the host-side fill.
+__global__ __launch_bounds__(256) void k_bp_scatter_sorted(uint32_t nc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ranks,
+                                                           const uint32_t* __restrict__ cellLower,
+                                                           const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                           uint32_t* __restrict__ keysS, uint32_t* __restrict__ valsS,
+                                                           float4* __restrict__ sMin, float4* __restrict__ sMax) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nc) return;
-    uint32_t idx = vals[i];
-    sMin[i] = aabbMin[idx]; sMax[i] = aabbMax[idx];
+    uint32_t key = keys[i];
+    if (key == 0xFFFFFFFFu) return;
+    uint32_t pos = cellLower[key] + ranks[i];
+    keysS[pos] = key; valsS[pos] = i;
+    sMin[pos] = aabbMin[i]; sMax[pos] = aabbMax[i];
 }
 
 // Prune + orient + key (collision_narrow.cpp:2346-2395) fused into pair emission.
@@ -363,61 +392,87 @@ __device__ __forceinline__ bool aabbOverlap(const float4& amn, const float4& amx
     return true;
 }
 
-// Five lanes per small collider.  Colliders are sorted by cell key with z fastest, so the cells
-// (x', y', z-1 .. z+1) of one neighbour column are ONE contiguous range of the sorted arrays:
+// Five lanes per small collider, one per forward neighbour COLUMN.  Colliders are sorted by cell key with z fastest,
+// so the cells (x', y', z-1 .. z+1) of one neighbour column are ONE contiguous range of the sorted arrays:
 // [cellLower[first], cellLower[last + 1]) with cellLower = exclusive prefix sum of the cell histogram.
-//   lane c = 0: (0,0,[z .. z+1]) starting after the collider itself     c = 1: (0,+1,[z-1 .. z+1])
-//   lane c = 2..4: (+1,{-1,0,+1},[z-1 .. z+1])            -> each unordered cell pair is visited once.
-constexpr uint32_t kPairBuf = 6;   // LDS-staged pair keys per lane before the block-level flush
+//   column 0: (0,0,[z .. z+1]) starting after the collider itself     column 1: (0,+1,[z-1 .. z+1])
+//   columns 2..4: (+1,{-1,0,+1},[z-1 .. z+1])            -> each unordered cell pair is visited once.
+// A workgroup handles 256 CONSECUTIVE sorted colliders for ONE column, so its lanes walk (nearly) the same candidate
+// range at the same time: loads are shared through L1 and candidates are fetched four at a time (8 loads in flight
+// per lane) instead of one dependent load pair per loop trip.
+constexpr uint32_t kPairBuf = 6;      // LDS-staged pair keys per collider-column before the block-level flush
+constexpr uint32_t kGridChunks = 4;   // a workgroup handles 4 x 256 consecutive sorted colliders for one column
 
-// Pair compaction: a same-address global atomic sustains only ~90 ops/us on this chip, so per-pair (or even
-// per-wave-iteration) atomics would bound the whole broad phase.  Each lane stages its hits in LDS, the block
-// prefix-sums the per-lane counts (wave shuffles), ONE atomic reserves the block's output range and the keys are
-// copied out; lanes with more than kPairBuf hits fall back to a direct append for the excess (rare).
-__global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+// Pair compaction: a same-address global atomic sustains only ~90 ops/us on this chip, so per-pair, per-wave or even
+// per-256-lane-block atomics on one word bound the whole broad phase.  Each lane stages its hits in LDS (48 KiB per
+// workgroup), the block prefix-sums the per-lane counts (wave shuffles), ONE returning atomic reserves the block's
+// output range for 1024 colliders and the keys are copied out; a lane with more than kPairBuf hits in one column
+// appends the excess directly (rare).  Sum-only counters go to the block's shard line.
+__global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blocksPerColumn, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                        const float4* __restrict__ sMin, const float4* __restrict__ sMax,
                                                        const uint32_t* __restrict__ cellLower,
                                                        const GridParams* __restrict__ gp, uint64_t* __restrict__ pairKeys, uint32_t pairCap,
-                                                       StepScalars* sc) {
-    __shared__ uint64_t buf[256 * kPairBuf];
+                                                       StepScalars* sc, Shards* sh) {
+    __shared__ uint64_t buf[kGridChunks * 256 * kPairBuf];
     __shared__ uint32_t waveTotals[4];
     __shared__ uint32_t blockBase;
-    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t i = t / 5u, col = t % 5u;
-    uint32_t overlaps = 0, nhit = 0;
-    uint32_t key = i < nc ? keys[i] : 0xFFFFFFFFu;
-    if (key != 0xFFFFFFFFu) {
-        const uint32_t dy = gp->dims[1], dz = gp->dims[2], dx = gp->dims[0];
-        uint32_t axis = sc->axisCur;
-        uint32_t iz = key % dz, iy = (key / dz) % dy, ix = key / (dz * dy);
-        int x = (int)ix + (col >= 2 ? 1 : 0);
-        int y = (int)iy + (col == 1 ? 1 : (col >= 2 ? (int)col - 3 : 0));
-        if (x < (int)dx && y >= 0 && y < (int)dy) {
-            int z0 = col == 0 ? (int)iz : (int)iz - 1, z1 = (int)iz + 1;
-            if (z0 < 0) z0 = 0;
-            if (z1 >= (int)dz) z1 = (int)dz - 1;
-            uint32_t cbase = ((uint32_t)x * dy + (uint32_t)y) * dz;
-            uint32_t s = col == 0 ? i + 1u : cellLower[cbase + (uint32_t)z0];
-            uint32_t e = cellLower[cbase + (uint32_t)z1 + 1u];
-            float4 amn = sMin[i], amx = sMax[i];
-            uint32_t ci = vals[i];
-            for (uint32_t j = s; j < e; ++j) {
-                float4 bmn = sMin[j], bmx = sMax[j];
-                if (!aabbOverlap(amn, amx, bmn, bmx)) continue;
-                ++overlaps;
-                uint64_t pk;
-                if (!pairKey(ci, amn, amx, vals[j], bmn, bmx, axis, pk)) continue;
-                if (nhit < kPairBuf) buf[threadIdx.x * kPairBuf + nhit] = pk;
-                else { uint32_t slot = atomicAdd(&sc->numPairs, 1u); if (slot < pairCap) pairKeys[slot] = pk; }
-                ++nhit;
+    __shared__ uint32_t bhist[32];   // [0..20] bucket histogram, [31] overlaps
+    if (threadIdx.x < 32) bhist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t col = blockIdx.x / blocksPerColumn;
+    const uint32_t base = (blockIdx.x % blocksPerColumn) * (kGridChunks * 256u);
+    const uint32_t dy = gp->dims[1], dz = gp->dims[2], dx = gp->dims[0];
+    const uint32_t axis = sc->axisCur;
+    uint32_t overlaps = 0, nh[kGridChunks];
+#pragma unroll
+    for (uint32_t ch = 0; ch < kGridChunks; ++ch) {
+        const uint32_t i = base + ch * 256u + threadIdx.x;
+        uint64_t* mybuf = buf + (ch * 256u + threadIdx.x) * kPairBuf;
+        uint32_t nhit = 0;
+        uint32_t key = i < nc ? keys[i] : 0xFFFFFFFFu;
+        if (key != 0xFFFFFFFFu) {
+            uint32_t iz = key % dz, iy = (key / dz) % dy, ix = key / (dz * dy);
+            int x = (int)ix + (col >= 2 ? 1 : 0);
+            int y = (int)iy + (col == 1 ? 1 : (col >= 2 ? (int)col - 3 : 0));
+            if (x < (int)dx && y >= 0 && y < (int)dy) {
+                int z0 = col == 0 ? (int)iz : (int)iz - 1, z1 = (int)iz + 1;
+                if (z0 < 0) z0 = 0;
+                if (z1 >= (int)dz) z1 = (int)dz - 1;
+                uint32_t cbase = ((uint32_t)x * dy + (uint32_t)y) * dz;
+                uint32_t s = col == 0 ? i + 1u : cellLower[cbase + (uint32_t)z0];
+                uint32_t e = cellLower[cbase + (uint32_t)z1 + 1u];
+                float4 amn = sMin[i], amx = sMax[i];
+                uint32_t ci = vals[i];
+                for (uint32_t j = s; j < e; j += 4u) {
+                    float4 bmn[4], bmx[4];
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) { uint32_t jj = min(j + u, e - 1u); bmn[u] = sMin[jj]; bmx[u] = sMax[jj]; }
+#pragma unroll
+                    for (uint32_t u = 0; u < 4; ++u) {
+                        if (j + u >= e || !aabbOverlap(amn, amx, bmn[u], bmx[u])) continue;
+                        ++overlaps;
+                        uint64_t pk;
+                        if (!pairKey(ci, amn, amx, vals[j + u], bmn[u], bmx[u], axis, pk)) continue;
+                        if (nhit < kPairBuf) mybuf[nhit] = pk;
+                        else { uint32_t slot = atomicAdd(&sc->numPairs, 1u); if (slot < pairCap) pairKeys[slot] = pk; }
+                        atomicAdd(&bhist[(uint32_t)(pk >> 58)], 1u);
+                        ++nhit;
+                    }
+                }
             }
         }
+        nh[ch] = min(nhit, kPairBuf);
     }
-    // block exclusive scan of min(nhit, kPairBuf)
-    uint32_t mine = min(nhit, kPairBuf), incl = mine;
+    // block exclusive scan of the staged counts
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t ch = 0; ch < kGridChunks; ++ch) mine += nh[ch];
+    uint32_t incl = mine;
     uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
     for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
     if (lane == 63) waveTotals[wv] = incl;
+    for (int off = 32; off >= 1; off >>= 1) overlaps += __shfl_xor(overlaps, off, 64);
+    if (lane == 0 && overlaps) atomicAdd(&bhist[31], overlaps);
     __syncthreads();
     uint32_t wbase = 0;
     for (uint32_t w = 0; w < wv; ++w) wbase += waveTotals[w];
@@ -427,15 +482,24 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, const uint32
     }
     __syncthreads();
     uint32_t dst = blockBase + wbase + incl - mine;
-    for (uint32_t k = 0; k < mine; ++k) if (dst + k < pairCap) pairKeys[dst + k] = buf[threadIdx.x * kPairBuf + k];
-    waveAddCount(overlaps, &sc->numOverlaps);
+#pragma unroll
+    for (uint32_t ch = 0; ch < kGridChunks; ++ch) {
+        const uint64_t* mybuf = buf + (ch * 256u + threadIdx.x) * kPairBuf;
+        for (uint32_t k = 0; k < nh[ch]; ++k, ++dst) if (dst < pairCap) pairKeys[dst] = mybuf[k];
+    }
+    ShardCounters* shard = &sh->c[blockIdx.x & (kShards - 1u)];
+    if (threadIdx.x < kNumBuckets && bhist[threadIdx.x]) atomicAdd(&shard->bucketHist[threadIdx.x], bhist[threadIdx.x]);
+    if (threadIdx.x == 31 && bhist[31]) atomicAdd(&shard->numOverlaps, bhist[31]);
 }
 
 // Large colliders against everything: (large l) x (all colliders), grid-strided.  Large-large pairs
 // are emitted once (from the lower index).
 __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint32_t* __restrict__ largeList, const uint32_t* __restrict__ isLarge,
                                                         const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
-                                                        uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc) {
+                                                        uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc, Shards* sh) {
+    __shared__ uint32_t bhist[32];   // [0..20] bucket histogram, [31] overlaps
+    if (threadIdx.x < 32) bhist[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t nl = sc->numLarge;
     uint32_t axis = sc->axisCur;
     uint32_t overlaps = 0;
@@ -450,10 +514,50 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
             uint64_t pk = 0;
             bool want = ov && pairKey(i, amn, amx, j, bmn, bmx, axis, pk);
             overlaps += ov ? 1u : 0u;
+            if (want) atomicAdd(&bhist[(uint32_t)(pk >> 58)], 1u);
             waveAppendKey(want, pk, pairKeys, pairCap, &sc->numPairs);
         }
     }
-    waveAddCount(overlaps, &sc->numOverlaps);
+    for (int off = 32; off >= 1; off >>= 1) overlaps += __shfl_xor(overlaps, off, 64);
+    if ((threadIdx.x & 63u) == 0 && overlaps) atomicAdd(&bhist[31], overlaps);
+    __syncthreads();
+    ShardCounters* shard = &sh->c[(blockIdx.x + blockIdx.y) & (kShards - 1u)];
+    if (threadIdx.x < kNumBuckets && bhist[threadIdx.x]) atomicAdd(&shard->bucketHist[threadIdx.x], bhist[threadIdx.x]);
+    if (threadIdx.x == 31 && bhist[31]) atomicAdd(&shard->numOverlaps, bhist[31]);
+}
+
+// Shard totals -> StepScalars (read back by the host together with numPairs).
+__global__ void k_pair_totals(const Shards* __restrict__ sh, StepScalars* sc) {
+    uint32_t t = threadIdx.x;
+    if (t < 24) { uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].bucketHist[t]; sc->bucketHist[t] = v; }
+    if (t == 31) { uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].numOverlaps; sc->numOverlaps = v; }
+}
+
+// Bucket partition (replaces the reference's counting sort into [6][6] type-pair buckets, collision_narrow.cpp:2397-2453,
+// and the former full 64-bit key sort): pairs are grouped by bucket so narrow-phase waves are type-uniform; the order
+// inside a bucket is arbitrary — every later stage is keyed by the collider pair, not by the position of the pair.
+// A block ranks its 1024 keys per bucket in LDS and reserves one output range per non-empty bucket.
+struct BucketOffsets { uint32_t o[24]; };
+__global__ __launch_bounds__(256) void k_pair_partition(uint32_t n, const uint64_t* __restrict__ in, uint64_t* __restrict__ out, BucketOffsets off,
+                                                        StepScalars* sc) {
+    __shared__ uint32_t cnt[32], base[32];
+    if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
+    __syncthreads();
+    uint64_t key[4]; uint32_t rank[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t p = blockIdx.x * 1024u + (uint32_t)k * 256u + threadIdx.x;
+        key[k] = p < n ? in[p] : ~0ull;
+        rank[k] = p < n ? atomicAdd(&cnt[(uint32_t)(key[k] >> 58)], 1u) : 0u;
+    }
+    __syncthreads();
+    if (threadIdx.x < kNumBuckets) base[threadIdx.x] = cnt[threadIdx.x] ? off.o[threadIdx.x] + atomicAdd(&sc->bucketCursor[threadIdx.x], cnt[threadIdx.x]) : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        uint32_t p = blockIdx.x * 1024u + (uint32_t)k * 256u + threadIdx.x;
+        if (p < n) out[base[(uint32_t)(key[k] >> 58)] + rank[k]] = key[k];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -474,7 +578,7 @@ struct HullSet { const float4* verts; const uint32_t* ranges; };  // vertex pool
 
 // Buckets that need GJK/EPA (and ~12 KB of per-lane scratch) run in k_narrow_gjk (gjk.hpp); -1 = primitive bucket.
 // mode: 0 plain GJK+EPA single contact, 1 segment shape vs AABB, 2 segment shape vs OBB, 3 cylinder vs cylinder
-__device__ __forceinline__ int gjkMode(uint32_t ta, uint32_t tb) {
+__host__ __device__ __forceinline__ int gjkMode(uint32_t ta, uint32_t tb) {
     if (tb == T_HULL) return 0;
     if (ta == T_CAPSULE && tb == T_AABB) return 1;
     if (ta == T_CAPSULE && tb == T_OBB) return 2;
@@ -484,7 +588,7 @@ __device__ __forceinline__ int gjkMode(uint32_t ta, uint32_t tb) {
     return -1;
 }
 
-__device__ inline bool intersectPair(const Shape& a, const Shape& b, const HullSet& hs, Manifold& out) {
+__device__ inline bool intersectPair(const Shape& a, const Shape& b, const HullSet& hs, LdsPoly& polyA, LdsPoly& polyB, Manifold& out) {
     switch (a.type) {
         case T_SPHERE:
             switch (b.type) {
@@ -513,11 +617,11 @@ __device__ inline bool intersectPair(const Shape& a, const Shape& b, const HullS
         case T_AABB:
             switch (b.type) {
                 case T_AABB: return aabbAABB(a.a, a.b, b.a, b.b, out);
-                case T_OBB: return obbOBB(Q4(0.f, 0.f, 0.f, 1.f), (a.a + a.b) * 0.5f, (a.b - a.a) * 0.5f, b.rot, b.a, b.b, out);
+                case T_OBB: return obbOBB(Q4(0.f, 0.f, 0.f, 1.f), (a.a + a.b) * 0.5f, (a.b - a.a) * 0.5f, b.rot, b.a, b.b, polyA, polyB, out);
                 default: return false;  // GJK bucket: k_narrow_gjk
             }
         case T_OBB:
-            if (b.type == T_OBB) return obbOBB(a.rot, a.a, a.b, b.rot, b.a, b.b, out);
+            if (b.type == T_OBB) return obbOBB(a.rot, a.a, a.b, b.rot, b.a, b.b, polyA, polyB, out);
             return false;  // GJK bucket: k_narrow_gjk
         default:
             return false;  // GJK bucket: k_narrow_gjk
@@ -527,6 +631,7 @@ __device__ inline bool intersectPair(const Shape& a, const Shape& b, const HullS
 __global__ __launch_bounds__(256) void k_narrow(uint32_t numPairs, const uint64_t* __restrict__ pairKeys, const float4* __restrict__ wShape,
                                                 HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
                                                 float4* __restrict__ npPoints) {
+    __shared__ float4 polyMem[2 * kLdsPolyVerts * kLdsPolyStride];   // 64 KiB: two clip polygons per lane, [vertex][lane]
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= numPairs) return;
     uint64_t key = pairKeys[p];
@@ -538,7 +643,8 @@ __global__ __launch_bounds__(256) void k_narrow(uint32_t numPairs, const uint64_
     if (gjkMode(ta, tb) >= 0) return;   // handled by k_narrow_gjk
     Shape sa = loadShape(wShape, a, ta), sb = loadShape(wShape, b, tb);
     Manifold m; m.count = 0;
-    bool hit = intersectPair(sa, sb, hs, m);
+    LdsPoly polyA{polyMem + threadIdx.x, 0u}, polyB{polyMem + kLdsPolyVerts * kLdsPolyStride + threadIdx.x, 0u};
+    bool hit = intersectPair(sa, sb, hs, polyA, polyB, m);
     uint32_t cnt = hit ? m.count : 0u;
     npPacked[p] = cnt ? ((1ull << 32) | (uint64_t)cnt) : 0ull;   // (manifold flag, contact count): one 64-bit scan compacts both
     if (cnt) {
@@ -547,12 +653,25 @@ __global__ __launch_bounds__(256) void k_narrow(uint32_t numPairs, const uint64_
     }
 }
 
-// After the scans: manifold m <- pair p (count > 0).
-__global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t numPairs, const uint64_t* __restrict__ pairKeys, const uint64_t* __restrict__ npPacked,
+// Colouring priority of a manifold: a bijection on 52 bits of its oriented collider pair (same function in the oracle),
+// so priorities are unique and do not depend on where the manifold sits in memory.
+__device__ __forceinline__ uint64_t pairPriority(uint32_t a, uint32_t b) {
+    const uint64_t M52 = (1ull << 52) - 1ull;
+    uint64_t x = ((uint64_t)a << kIndexBits) | (uint64_t)b;
+    x ^= x >> 25; x = (x * 0x9E3779B97F4A7ull) & M52;
+    x ^= x >> 27; x = (x * 0xC2B2AE3D27D4Full) & M52;
+    x ^= x >> 23;
+    return x;
+}
+
+// After the scans: manifold m <- pair p (count > 0).  colWork = (bodyA | dynA << 31, bodyB | dynB << 31, priority lo, hi):
+// everything a colouring round needs in one 16-byte row.
+__global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t numPairs, uint32_t nb, const uint64_t* __restrict__ pairKeys, const uint64_t* __restrict__ npPacked,
                                                         const uint64_t* __restrict__ npScan,
                                                         const float4* __restrict__ aabbMax, const float4* __restrict__ cMaterial,
+                                                        const float4* __restrict__ bCogInvMass,
                                                         uint32_t* __restrict__ manPair, uint2* __restrict__ manBodies, uint2* __restrict__ manInfo,
-                                                        StepScalars* sc) {
+                                                        uint4* __restrict__ colWork, uint32_t* __restrict__ color, StepScalars* sc) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= numPairs) return;
     uint32_t cnt = (uint32_t)(npPacked[p] & 0xFFFFFFFFull);
@@ -566,9 +685,15 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t numPairs, const
     float friction = clamp01(sqrtf(ma.y * mb.y));                      // collision_narrow.cpp:2232-2238
     float restitution = clamp01(fmaxr(ma.x, mb.x));
     uint32_t fr = ((uint32_t)(friction * 0xFFFF) << 16) | (uint32_t)(restitution * 0xFFFF);
+    uint32_t bA = __float_as_uint(aabbMax[a].w), bB = __float_as_uint(aabbMax[b].w);
     manPair[m] = p;
-    manBodies[m] = make_uint2(__float_as_uint(aabbMax[a].w), __float_as_uint(aabbMax[b].w));
+    manBodies[m] = make_uint2(bA, bB);
     manInfo[m] = make_uint2(cnt | (conOff << 3), fr);
+    uint32_t dynA = (bA < nb && bCogInvMass[bA].w != 0.f) ? 0x80000000u : 0u;
+    uint32_t dynB = (bB < nb && bCogInvMass[bB].w != 0.f) ? 0x80000000u : 0u;
+    uint64_t prio = pairPriority(a, b);
+    colWork[m] = make_uint4(bA | dynA, bB | dynB, (uint32_t)prio, (uint32_t)(prio >> 32));
+    color[m] = kUncolored;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -668,56 +793,110 @@ __global__ __launch_bounds__(256) void k_scatter_states(uint32_t n, const uint32
 // Contact schedule: Jones-Plassmann colouring of the manifold graph (replaces the serial greedy
 // scheduleConstraintsSIMD, src/physics/constraints.cpp:51-184).  Two manifolds conflict when they
 // share a body with invMass != 0 (the reference exempts its dummy body, constraints.cpp:81-83).
-// Priority = hash32(manifold index) (unique); a manifold colours itself once it is the top-priority
-// uncoloured manifold on both of its bodies, taking the lowest colour free on both.  The result
-// equals sequential greedy colouring in descending priority order, which is what the oracle runs.
+// Priority = pairPriority(colliderA, colliderB) (unique); a manifold colours itself once it is the
+// top-priority uncoloured manifold on both of its bodies, taking the lowest colour free on both.
+// The result equals sequential greedy colouring in descending priority order, which is what the
+// oracle runs.  One launch per round: round r commits the winners of the proposals made in round
+// r-1 (keys tagged r in top[r & 1]) and lets the losers propose for round r+1 (tag r+1 in
+// top[(r+1) & 1]); a round whose predecessor left nothing uncoloured exits at once, so the host
+// enqueues a fixed batch of rounds without reading anything back in between.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_color_propose(uint32_t nm, uint32_t round, const uint2* __restrict__ manBodies, const float4* __restrict__ gPos,
-                                                       const uint32_t* __restrict__ color, unsigned long long* __restrict__ bodyTop) {
+__global__ __launch_bounds__(256) void k_color_round(uint32_t nm, uint32_t round, const uint4* __restrict__ colWork, uint32_t* __restrict__ color,
+                                                     const unsigned long long* __restrict__ topCur, unsigned long long* __restrict__ topNext,
+                                                     unsigned long long* __restrict__ bodyUsed, uint32_t* __restrict__ roundFlags) {
+    if (round > 0 && roundFlags[round - 1] == 0) return;
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= nm || color[m] != kUncolored) return;
-    uint2 b = manBodies[m];
-    unsigned long long key = ((unsigned long long)(round + 1) << 32) | hash32(m);
-    if (gPos[b.x].w != 0.f) atomicMax(&bodyTop[b.x], key);
-    if (gPos[b.y].w != 0.f) atomicMax(&bodyTop[b.y], key);
-}
-__global__ __launch_bounds__(256) void k_color_commit(uint32_t nm, uint32_t round, const uint2* __restrict__ manBodies, const float4* __restrict__ gPos,
-                                                      uint32_t* __restrict__ color, const unsigned long long* __restrict__ bodyTop,
-                                                      unsigned long long* __restrict__ bodyUsed, StepScalars* sc) {
-    __shared__ uint32_t hist[kOverflowColor + 2];   // [65] = still uncoloured
-    if (threadIdx.x < kOverflowColor + 2) hist[threadIdx.x] = 0;
-    __syncthreads();
-    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m < nm && color[m] == kUncolored) {
-        uint2 b = manBodies[m];
-        unsigned long long key = ((unsigned long long)(round + 1) << 32) | hash32(m);
-        bool dynA = gPos[b.x].w != 0.f, dynB = gPos[b.y].w != 0.f;
-        if ((dynA && bodyTop[b.x] != key) || (dynB && bodyTop[b.y] != key)) atomicAdd(&hist[kOverflowColor + 1], 1u);
-        else {
-            unsigned long long mask = (dynA ? bodyUsed[b.x] : 0ull) | (dynB ? bodyUsed[b.y] : 0ull);
-            uint32_t c = kOverflowColor;
-            if (~mask != 0ull) {
-                c = (uint32_t)__ffsll((long long)~mask) - 1u;
-                if (dynA) bodyUsed[b.x] |= (1ull << c);
-                if (dynB) bodyUsed[b.y] |= (1ull << c);
-            }
-            color[m] = c;
-            atomicAdd(&hist[c], 1u);
+    uint4 w = colWork[m];
+    bool dynA = (w.x >> 31) != 0, dynB = (w.y >> 31) != 0;
+    uint32_t bA = w.x & 0x7FFFFFFFu, bB = w.y & 0x7FFFFFFFu;
+    unsigned long long prio = ((unsigned long long)w.w << 32) | (unsigned long long)w.z;
+    bool lost = true;
+    if (round > 0) {
+        unsigned long long key = ((unsigned long long)round << 52) | prio;
+        lost = (dynA && topCur[bA] != key) || (dynB && topCur[bB] != key);
+    }
+    if (!lost) {
+        unsigned long long mask = (dynA ? bodyUsed[bA] : 0ull) | (dynB ? bodyUsed[bB] : 0ull);
+        uint32_t c = kOverflowColor;
+        if (~mask != 0ull) {
+            c = (uint32_t)__ffsll((long long)~mask) - 1u;
+            if (dynA) bodyUsed[bA] |= (1ull << c);   // only one winner per body per round: no race
+            if (dynB) bodyUsed[bB] |= (1ull << c);
         }
+        color[m] = c;
+    } else {
+        unsigned long long key = ((unsigned long long)(round + 1) << 52) | prio;
+        if (dynA) atomicMax(&topNext[bA], key);
+        if (dynB) atomicMax(&topNext[bB], key);
+        roundFlags[round] = 1u;
+    }
+}
+
+// Schedule slots: manifolds grouped by (colour, contacts per manifold) bin — one stable-enough radix pass
+// (block histograms -> exclusive scan -> scatter).  The order inside a bin is irrelevant to results
+// (manifolds of one colour share no dynamic body); grouping by contact count makes solver waves uniform.
+constexpr uint32_t kBinItems = 1024;
+__device__ __forceinline__ uint32_t binOf(uint32_t color, uint32_t cnt) { return color * 4u + (cnt - 1u); }
+__global__ __launch_bounds__(256) void k_bin_hist(uint32_t nm, uint32_t numBlocks, const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo,
+                                                  uint32_t* __restrict__ blockHist) {
+    __shared__ uint32_t h[kColorBins];
+    for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) h[b] = 0;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kBinItems / 256; ++k) {
+        uint32_t m = blockIdx.x * kBinItems + k * 256 + threadIdx.x;
+        if (m < nm) { uint32_t c = color[m]; if (c <= kOverflowColor) atomicAdd(&h[binOf(c, manInfo[m].x & 7u)], 1u); }
     }
     __syncthreads();
-    if (threadIdx.x <= kOverflowColor && hist[threadIdx.x]) atomicAdd(&sc->colorHist[threadIdx.x], hist[threadIdx.x]);
-    if (threadIdx.x == kOverflowColor + 1 && hist[threadIdx.x]) atomicAdd(&sc->uncolored, hist[threadIdx.x]);
+    for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) blockHist[(size_t)b * numBlocks + blockIdx.x] = h[b];
+}
+__global__ __launch_bounds__(256) void k_bin_scatter(uint32_t nm, uint32_t numBlocks, const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo,
+                                                     const uint32_t* __restrict__ blockScan, uint32_t* __restrict__ order, StepScalars* sc) {
+    __shared__ uint32_t cur[kColorBins];
+    for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) {
+        uint32_t v = blockScan[(size_t)b * numBlocks + blockIdx.x];
+        cur[b] = v;
+        if (blockIdx.x == 0) sc->binStart[b] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->binStart[kColorBins] = nm;
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < kBinItems / 256; ++k) {
+        uint32_t m = blockIdx.x * kBinItems + k * 256 + threadIdx.x;
+        if (m < nm) { uint32_t c = color[m]; if (c <= kOverflowColor) order[atomicAdd(&cur[binOf(c, manInfo[m].x & 7u)], 1u)] = m; }
+    }
+}
+
+// Overflow colour (a body with > 64 incident manifolds) is solved sequentially, so its slots need a defined order:
+// ascending pair key (bucket, A, B) like the oracle.  Rank sort by one workgroup; the overflow set is tiny or empty.
+__global__ __launch_bounds__(256) void k_sort_overflow(uint32_t s0, uint32_t n, const uint32_t* __restrict__ manPair, const uint64_t* __restrict__ pairKeys,
+                                                       const uint32_t* __restrict__ orderIn, uint32_t* __restrict__ orderOut) {
+    for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+        uint32_t m = orderIn[s0 + i];
+        uint64_t key = pairKeys[manPair[m]];
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < n; ++j) rank += pairKeys[manPair[orderIn[s0 + j]]] < key ? 1u : 0u;
+        orderOut[s0 + rank] = m;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
-// Contact constraints.  Slot s = position of a manifold in colour-sorted order.  Constraint rows
-// are planes [contact k][row r][slot s] of float4, so a wave reads 64 consecutive float4 per row.
+// Contact constraints.  The schedule groups manifolds into bins (colour, contacts per manifold); every
+// bin is cut into TILES of 64 slots = one wave.  All constraint data of a tile is contiguous in HBM:
+//   rows : [contact-tile ct][row r = 0..7][lane]  float4   (one contact-tile = 8 KiB)
+//   imp  : [contact-tile ct][lane]                float2   (accumulated normal / tangent impulse)
+//   meta : [tile][lane] uint4 = (bodyA, bodyB, friction|restitution, contacts; 0 = padding lane)
+// where tile T of a bin with k contacts per manifold owns contact-tiles ctStart + (T - tileStart) * k + 0..k-1,
+// so a wave streams one contiguous 8.5 * k KiB block per PGS sweep (DRAM-page and TLB friendly) and
+// its control flow is uniform (k is a template parameter).
 //   r0 = (rA, effMassN)  r1 = (rB, effMassT)  r2 = (tangent, bias)  r3 = (normal, friction)
 //   r4 = I_A^-1 (rA x t)  r5 = I_B^-1 (rB x t)  r6 = I_A^-1 (rA x n)  r7 = I_B^-1 (rB x n)
-// Accumulated impulses (normal, tangent) live in their own float2 plane (the only rows rewritten).
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kRows = 8;
+constexpr uint32_t kSchedBins = kOverflowColor * 4 + 1;   // 256 regular bins + the overflow colour as one bin (stride 4)
+
+struct BinInfo { uint32_t slotStart, count, tileStart, ctStart; };   // host-computed from StepScalars::binStart, uploaded every step
 
 __device__ __forceinline__ M3 loadM3(const float4* __restrict__ p, uint32_t i) {
     float4 a = p[3 * i], b = p[3 * i + 1], c = p[3 * i + 2];
@@ -725,21 +904,27 @@ __device__ __forceinline__ M3 loadM3(const float4* __restrict__ p, uint32_t i) {
     return m;
 }
 
-// K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379), one lane per slot.
-__global__ __launch_bounds__(256) void k_contact_init(uint32_t nm, uint32_t cap, float dt, const uint32_t* __restrict__ order,
-                                                      const uint32_t* __restrict__ manPair, const uint2* __restrict__ manBodies,
-                                                      const uint2* __restrict__ manInfo, const float4* __restrict__ npNormal,
-                                                      const float4* __restrict__ npPoints, const float4* __restrict__ gPos,
-                                                      const float4* __restrict__ gInvI, const float4* __restrict__ gVel,
-                                                      float4* __restrict__ rows, float2* __restrict__ imp, uint4* __restrict__ slotMeta) {
-    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nm) return;
-    uint32_t m = order[s];
+// K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379): one wave per tile, one lane per slot.
+__global__ __launch_bounds__(64) void k_contact_init(uint32_t dummyBody, float dt, const uint32_t* __restrict__ tileBin, const BinInfo* __restrict__ binInfo,
+                                                     const uint32_t* __restrict__ order,
+                                                     const uint32_t* __restrict__ manPair, const uint2* __restrict__ manBodies,
+                                                     const uint2* __restrict__ manInfo, const float4* __restrict__ npNormal,
+                                                     const float4* __restrict__ npPoints, const float4* __restrict__ gPos,
+                                                     const float4* __restrict__ gInvI, const float4* __restrict__ gVel,
+                                                     float4* __restrict__ rows, float2* __restrict__ imp, uint4* __restrict__ slotMeta) {
+    uint32_t tile = blockIdx.x, lane = threadIdx.x;
+    uint32_t bin = tileBin[tile];
+    BinInfo bi = binInfo[bin];
+    uint32_t tl = tile - bi.tileStart, j = tl * 64u + lane;
+    uint32_t stride = bin < kOverflowColor * 4u ? (bin & 3u) + 1u : 4u;
+    size_t ctBase = (size_t)bi.ctStart + (size_t)tl * stride;
+    if (j >= bi.count) { slotMeta[(size_t)tile * 64u + lane] = make_uint4(dummyBody, dummyBody, 0u, 0u); return; }
+    uint32_t m = order[bi.slotStart + j];
     uint32_t p = manPair[m];
     uint2 bodies = manBodies[m];
     uint2 info = manInfo[m];
     uint32_t cnt = info.x & 7u;
-    slotMeta[s] = make_uint4(bodies.x, bodies.y, cnt, info.y);
+    slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, info.y, cnt);
     float4 pa = gPos[bodies.x], pb = gPos[bodies.y];
     V3 xA = xyz(pa), xB = xyz(pb);
     float imA = pa.w, imB = pb.w;
@@ -772,24 +957,21 @@ __global__ __launch_bounds__(256) void k_contact_init(uint32_t nm, uint32_t cap,
             const float slop = -0.001f;
             if (-depth < slop && vRel < 0.f) bias = -restitution * vRel - 0.1f * (-depth - slop) * invDt;
         }
-        size_t base = (size_t)k * kRows * cap + s;
-        rows[base + 0 * (size_t)cap] = f4(rA, effN);
-        rows[base + 1 * (size_t)cap] = f4(rB, effT);
-        rows[base + 2 * (size_t)cap] = f4(t, bias);
-        rows[base + 3 * (size_t)cap] = f4(n, friction);
-        rows[base + 4 * (size_t)cap] = f4(tA, 0.f);
-        rows[base + 5 * (size_t)cap] = f4(tB, 0.f);
-        rows[base + 6 * (size_t)cap] = f4(nA, 0.f);
-        rows[base + 7 * (size_t)cap] = f4(nB, 0.f);
-        imp[(size_t)k * cap + s] = make_float2(0.f, 0.f);
+        float4* __restrict__ row = rows + (ctBase + k) * (kRows * 64u) + lane;
+        row[0 * 64] = f4(rA, effN);
+        row[1 * 64] = f4(rB, effT);
+        row[2 * 64] = f4(t, bias);
+        row[3 * 64] = f4(n, friction);
+        row[4 * 64] = f4(tA, 0.f);
+        row[5 * 64] = f4(tB, 0.f);
+        row[6 * 64] = f4(nA, 0.f);
+        row[7 * 64] = f4(nB, 0.f);
+        imp[(ctBase + k) * 64u + lane] = make_float2(0.f, 0.f);
     }
 }
 
-// One PGS update of the contacts of slot s (src/physics/constraints.cpp:3381-3449): friction first
-// (clamped with the previous normal impulse), then the normal row.
-// Latency structure: a colour launch has only a few waves per CU, so it is bound by dependent-load depth,
-// not bandwidth.  All constraint rows of the slot's (<= 4) contacts are therefore requested up front,
-// together with the two body gathers: two memory round trips per lane (meta -> everything) instead of five.
+// One PGS update of one contact (src/physics/constraints.cpp:3381-3449): friction first (clamped with the
+// previous normal impulse), then the normal row.
 struct ContactRows { float4 r[kRows]; float2 imp; };
 
 __device__ __forceinline__ void solveOne(const ContactRows& c, float2& im, float imA, float imB, V3& vA, V3& wA, V3& vB, V3& wB) {
@@ -825,60 +1007,99 @@ __device__ __forceinline__ void solveOne(const ContactRows& c, float2& im, float
     }
 }
 
-__device__ __forceinline__ void solveSlot(uint32_t s, uint32_t cap, const uint4 meta, const float4* __restrict__ rows, float2* __restrict__ imp,
-                                          float4* __restrict__ gVel) {
-    uint32_t bA = meta.x, bB = meta.y, cnt = meta.z;
-    ContactRows c[4];
+// One tile, CNT contacts per manifold.  Latency structure: a colour launch has < 1 wave per SIMD, so it is bound by
+// dependent-load depth: all constraint rows are requested up front (they do not depend on the slot metadata), the
+// body gathers follow the metadata — two memory round trips per sweep.
+template <int CNT>
+__device__ __forceinline__ void solveTile(uint32_t tile, uint32_t ctBase, uint32_t lane, const uint4* __restrict__ slotMeta,
+                                          const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+    const uint4 meta = slotMeta[(size_t)tile * 64u + lane];
+    ContactRows c[CNT];
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-        if (k < cnt) {
-            size_t base = (size_t)k * kRows * cap + s;
+    for (int k = 0; k < CNT; ++k) {
+        const float4* __restrict__ row = rows + ((size_t)ctBase + k) * (kRows * 64u) + lane;
 #pragma unroll
-            for (uint32_t r = 0; r < kRows; ++r) c[k].r[r] = rows[base + (size_t)r * cap];
-            c[k].imp = imp[(size_t)k * cap + s];
-        }
+        for (uint32_t r = 0; r < kRows; ++r) c[k].r[r] = row[r * 64u];
+        c[k].imp = imp[((size_t)ctBase + k) * 64u + lane];
     }
+    uint32_t bA = meta.x, bB = meta.y;
     float4 a0 = gVel[2 * bA], a1 = gVel[2 * bA + 1], b0 = gVel[2 * bB], b1 = gVel[2 * bB + 1];
     float imA = a0.w, imB = b0.w;
-    if (imA == 0.f && imB == 0.f) return;
+    // No early exit: a branch here would let the compiler sink the row loads below it and serialise four memory
+    // round trips (meta -> bodies -> rows -> stores).  Padding lanes (meta.w == 0) and manifolds without a dynamic
+    // body compute on whatever they loaded and simply do not store.
+    const bool live = meta.w != 0u && (imA != 0.f || imB != 0.f);
     V3 vA = xyz(a0), wA = xyz(a1), vB = xyz(b0), wB = xyz(b1);
 #pragma unroll
-    for (uint32_t k = 0; k < 4; ++k) {
-        if (k < cnt) {
-            float2 im = c[k].imp;
-            solveOne(c[k], im, imA, imB, vA, wA, vB, wB);
-            imp[(size_t)k * cap + s] = im;
-        }
+    for (int k = 0; k < CNT; ++k) {
+        float2 im = c[k].imp;
+        solveOne(c[k], im, imA, imB, vA, wA, vB, wB);
+        if (live) imp[((size_t)ctBase + k) * 64u + lane] = im;
     }
-    if (imA != 0.f) { gVel[2 * bA] = f4(vA, imA); gVel[2 * bA + 1] = f4(wA, 0.f); }
-    if (imB != 0.f) { gVel[2 * bB] = f4(vB, imB); gVel[2 * bB + 1] = f4(wB, 0.f); }
+    if (live && imA != 0.f) { gVel[2 * bA] = f4(vA, imA); gVel[2 * bA + 1] = f4(wA, 0.f); }
+    if (live && imB != 0.f) { gVel[2 * bB] = f4(vB, imB); gVel[2 * bB + 1] = f4(wB, 0.f); }
 }
 
-// K12 "Solve collision constraints": one launch per colour; lanes own disjoint dynamic bodies.
-__global__ __launch_bounds__(256) void k_contact_solve(uint32_t s0, uint32_t s1, uint32_t cap, const uint4* __restrict__ slotMeta,
-                                                       const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
-    uint32_t s = s0 + blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= s1) return;
-    solveSlot(s, cap, slotMeta[s], rows, imp, gVel);
+__device__ __forceinline__ void solveTileK(uint32_t k, uint32_t tile, uint32_t ctBase, uint32_t lane, const uint4* __restrict__ slotMeta,
+                                           const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+    switch (k) {
+        case 1: solveTile<1>(tile, ctBase, lane, slotMeta, rows, imp, gVel); break;
+        case 2: solveTile<2>(tile, ctBase, lane, slotMeta, rows, imp, gVel); break;
+        case 3: solveTile<3>(tile, ctBase, lane, slotMeta, rows, imp, gVel); break;
+        default: solveTile<4>(tile, ctBase, lane, slotMeta, rows, imp, gVel); break;
+    }
 }
+
+// K12 "Solve collision constraints": one launch per colour, one wave per tile; lanes own disjoint dynamic bodies.
+// Blocks are ordered 4-contact tiles first (longest first).  With `swizzle`, consecutive tiles (= spatially
+// coherent manifolds, hence neighbouring bodies) are dealt to one XCD (block b runs on XCD b % 8) so the body
+// velocity lines of a region stay in that XCD's L2.
+struct ColorLaunch { uint32_t tileStart[4]; uint32_t blockEnd[4]; uint32_t ctStart[4]; uint32_t numBlocks; uint32_t swizzle; };
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_contact_solve(ColorLaunch cl, const uint4* __restrict__ slotMeta,
+                                                      const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+    uint32_t b = blockIdx.x;
+    if (cl.swizzle) {
+        uint32_t per = (cl.numBlocks + 7u) >> 3;
+        b = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+        if (b >= cl.numBlocks) return;
+    }
+    uint32_t lane = threadIdx.x;
+    // blockEnd is cumulative over k = 4, 3, 2, 1
+    if (b < cl.blockEnd[0]) { solveTile<4>(cl.tileStart[3] + b, cl.ctStart[3] + b * 4u, lane, slotMeta, rows, imp, gVel); return; }
+    if (b < cl.blockEnd[1]) { uint32_t t = b - cl.blockEnd[0]; solveTile<3>(cl.tileStart[2] + t, cl.ctStart[2] + t * 3u, lane, slotMeta, rows, imp, gVel); return; }
+    if (b < cl.blockEnd[2]) { uint32_t t = b - cl.blockEnd[1]; solveTile<2>(cl.tileStart[1] + t, cl.ctStart[1] + t * 2u, lane, slotMeta, rows, imp, gVel); return; }
+    { uint32_t t = b - cl.blockEnd[2]; solveTile<1>(cl.tileStart[0] + t, cl.ctStart[0] + t, lane, slotMeta, rows, imp, gVel); }
+}
+
 // Trailing colours of the greedy colouring are tiny; one 256-lane workgroup runs colours [c0, c1) back to back
 // with a workgroup barrier + workgroup-scope fence between them instead of one launch each (a colour costs one
 // dependent-load chain, ~1.5 us, inside the kernel vs ~5.5 us as its own launch).
-struct ColorRanges { uint32_t off[kOverflowColor + 2]; };
-__global__ __launch_bounds__(256) void k_contact_solve_tail(ColorRanges cr, uint32_t c0, uint32_t c1, uint32_t cap, const uint4* __restrict__ slotMeta,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_contact_solve_tail(const BinInfo* __restrict__ binInfo, uint32_t c0, uint32_t c1, const uint4* __restrict__ slotMeta,
                                                              const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+    uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t c = c0; c < c1; ++c) {
-        for (uint32_t s = cr.off[c] + threadIdx.x; s < cr.off[c + 1]; s += blockDim.x) solveSlot(s, cap, slotMeta[s], rows, imp, gVel);
+        uint32_t g = 0;
+        for (uint32_t k = 0; k < 4; ++k) {
+            BinInfo bi = binInfo[c * 4u + k];
+            uint32_t nt = (bi.count + 63u) >> 6;
+            for (uint32_t tl = 0; tl < nt; ++tl, ++g)
+                if ((g & 3u) == wave) solveTileK(k + 1u, bi.tileStart + tl, bi.ctStart + tl * (k + 1u), lane, slotMeta, rows, imp, gVel);
+        }
         __threadfence_block();   // one workgroup = one CU = one L1: workgroup scope is enough (an agent-scope fence costs ~3.5 us per lane here)
         __syncthreads();
     }
 }
 
-// Overflow colour (a body with > 64 incident manifolds): sequential, one lane.
-__global__ void k_contact_solve_serial(uint32_t s0, uint32_t s1, uint32_t cap, const uint4* __restrict__ slotMeta,
+// Overflow colour (a body with > 64 incident manifolds): sequential, one lane, slots in ascending pair-key order.
+__global__ void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slotMeta,
                                        const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (uint32_t s = s0; s < s1; ++s) { solveSlot(s, cap, slotMeta[s], rows, imp, gVel); __threadfence(); }
+    for (uint32_t j = 0; j < bi.count; ++j) {
+        uint32_t tile = bi.tileStart + (j >> 6), lane = j & 63u, ctBase = bi.ctStart + (j >> 6) * 4u;
+        uint4 meta = slotMeta[(size_t)tile * 64u + lane];
+        solveTileK(meta.w, tile, ctBase, lane, slotMeta, rows, imp, gVel);
+        __threadfence();
+    }
 }
 
 }  // namespace mi

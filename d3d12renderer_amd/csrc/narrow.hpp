@@ -33,42 +33,60 @@ struct Manifold {
 };
 
 struct ClipVert { V3 v; float depth; };
-struct ClipPoly { ClipVert pt[16]; uint32_t n; };
+// Clip polygon in private memory (GJK kernel: segment clips) ...
+struct ClipPoly {
+    ClipVert pt[16]; uint32_t n;
+    __device__ __forceinline__ ClipVert get(uint32_t i) const { return pt[i]; }
+    __device__ __forceinline__ void put(uint32_t i, const ClipVert& v) { pt[i] = v; }
+};
+// ... and in LDS for the primitive kernel: dynamically indexed private arrays live in scratch (HBM-backed, ~1 us per
+// dependent access); a [vertex][lane] LDS plane keeps the Sutherland-Hodgman ping-pong on chip.  A quad clipped by
+// four planes has at most 8 vertices.
+constexpr uint32_t kLdsPolyVerts = 8;
+constexpr uint32_t kLdsPolyStride = 256;   // lanes per workgroup of k_narrow
+struct LdsPoly {
+    float4* p; uint32_t n;
+    __device__ __forceinline__ ClipVert get(uint32_t i) const { float4 f = p[i * kLdsPolyStride]; ClipVert c; c.v = V3(f.x, f.y, f.z); c.depth = f.w; return c; }
+    __device__ __forceinline__ void put(uint32_t i, const ClipVert& c) { p[i * kLdsPolyStride] = make_float4(c.v.x, c.v.y, c.v.z, c.depth); }
+};
 
 __device__ __forceinline__ void setc(Manifold& m, uint32_t i, V3 p, float d) { m.p[i] = p; m.d[i] = d; }
 
 // 4-point reduction (collision_narrow.cpp:56-146)
-__device__ inline void reduceManifold(const ClipVert* v, uint32_t n, V3 normal, Manifold& out) {
+template <class Poly>
+__device__ inline void reduceManifold(const Poly& v, uint32_t n, V3 normal, Manifold& out) {
     if (n > 4) {
         V3 searchDir = tangentOf(normal);
-        float best = dot(searchDir, v[0].v);
+        float best = dot(searchDir, v.get(0).v);
         uint32_t ri = 0;
-        for (uint32_t i = 1; i < n; ++i) { float dd = dot(searchDir, v[i].v); if (dd > best) { ri = i; best = dd; } }
-        setc(out, 0, v[ri].v, v[ri].depth);
+        for (uint32_t i = 1; i < n; ++i) { float dd = dot(searchDir, v.get(i).v); if (dd > best) { ri = i; best = dd; } }
+        { ClipVert c = v.get(ri); setc(out, 0, c.v, c.depth); }
         best = 0.f; ri = 0;
-        for (uint32_t i = 0; i < n; ++i) { float sq = sqlen(v[i].v - out.p[0]); if (sq > best) { ri = i; best = sq; } }
-        setc(out, 1, v[ri].v, v[ri].depth);
+        for (uint32_t i = 0; i < n; ++i) { float sq = sqlen(v.get(i).v - out.p[0]); if (sq > best) { ri = i; best = sq; } }
+        { ClipVert c = v.get(ri); setc(out, 1, c.v, c.depth); }
         float bestArea = 0.f; ri = 0;
         for (uint32_t i = 0; i < n; ++i) {
-            V3 qa = out.p[0] - v[i].v, qb = out.p[1] - v[i].v;
+            V3 vi = v.get(i).v;
+            V3 qa = out.p[0] - vi, qb = out.p[1] - vi;
             float area = 0.5f * dot(cross(qa, qb), normal);
             if (area > bestArea) { ri = i; bestArea = area; }
         }
-        setc(out, 2, v[ri].v, v[ri].depth);
+        { ClipVert c = v.get(ri); setc(out, 2, c.v, c.depth); }
         bestArea = 0.f; ri = 0;
         for (uint32_t i = 0; i < n; ++i) {
-            V3 qa = out.p[0] - v[i].v, qb = out.p[1] - v[i].v, qc = out.p[2] - v[i].v;
+            V3 vi = v.get(i).v;
+            V3 qa = out.p[0] - vi, qb = out.p[1] - vi, qc = out.p[2] - vi;
             float a1 = 0.5f * dot(cross(qa, qb), normal);
             float a2 = 0.5f * dot(cross(qb, qc), normal);
             float a3 = 0.5f * dot(cross(qc, qa), normal);
             float area = fmaxr(fmaxr(a1, a2), a3);
             if (area > bestArea) { ri = i; bestArea = area; }
         }
-        setc(out, 3, v[ri].v, v[ri].depth);
+        { ClipVert c = v.get(ri); setc(out, 3, c.v, c.depth); }
         out.count = 4;
     } else {
         out.count = n;
-        for (uint32_t i = 0; i < n; ++i) setc(out, i, v[i].v, v[i].depth);
+        for (uint32_t i = 0; i < n; ++i) { ClipVert c = v.get(i); setc(out, i, c.v, c.depth); }
     }
 }
 
@@ -81,27 +99,28 @@ __device__ __forceinline__ ClipVert clipEdge(ClipVert a, ClipVert b, float ad, f
 }
 
 // Sutherland-Hodgman against planes pointing inside (166-222); result always lands in `output`.
-__device__ inline void clipPolygon(ClipPoly& input, const P4* planes, uint32_t numPlanes, ClipPoly& output) {
-    ClipPoly* in = &input; ClipPoly* out = &output;
+template <class Poly>
+__device__ inline void clipPolygon(Poly& input, const P4* planes, uint32_t numPlanes, Poly& output) {
+    Poly* in = &input; Poly* out = &output;
     uint32_t ci = 0;
     for (; ci < numPlanes; ++ci) {
         P4 pl = planes[ci];
         out->n = 0;
         if (in->n == 0) break;
-        ClipVert start = in->pt[in->n - 1];
+        ClipVert start = in->get(in->n - 1);
         for (uint32_t i = 0; i < in->n; ++i) {
-            ClipVert end = in->pt[i];
+            ClipVert end = in->get(i);
             float sd = planeDist(start.v, pl), ed = planeDist(end.v, pl);
             bool sIn = sd > 0.f, eIn = ed > 0.f;
-            if (sIn && eIn) out->pt[out->n++] = end;
-            else if (sIn) out->pt[out->n++] = clipEdge(start, end, sd, ed);
-            else if (!sIn && eIn) { out->pt[out->n++] = clipEdge(start, end, sd, ed); out->pt[out->n++] = end; }
+            if (sIn && eIn) out->put(out->n++, end);
+            else if (sIn) out->put(out->n++, clipEdge(start, end, sd, ed));
+            else if (!sIn && eIn) { out->put(out->n++, clipEdge(start, end, sd, ed)); out->put(out->n++, end); }
             start = end;
         }
-        ClipPoly* tmp = in; in = out; out = tmp;
+        Poly* tmp = in; in = out; out = tmp;
     }
     if (ci % 2 == 0) {
-        for (uint32_t i = 0; i < input.n; ++i) output.pt[i] = input.pt[i];
+        for (uint32_t i = 0; i < input.n; ++i) output.put(i, input.get(i));
         output.n = input.n;
     }
 }
@@ -119,15 +138,15 @@ __device__ inline void boxClipPlanes(V3 radius, V3 normal, V3* pts, V3* nrm) {  
     nrm[3] = n3; pts[3] = radius;
 }
 
-__device__ inline void boxIncidentFace(V3 radius, V3 normal, ClipPoly& poly) {  // 259-293
+__device__ inline void boxIncidentFace(V3 radius, V3 normal, V3* quad) {  // 259-293
     V3 p = vabs(normal);
     uint32_t me = maxAxis(p), a0 = (me + 1) % 3, a1 = (me + 2) % 3;
     float s = normal.get(me) < 0.f ? 1.f : -1.f;
     float d = radius.get(me) * s;
     float mn0 = -radius.get(a0), mn1 = -radius.get(a1), mx0 = radius.get(a0), mx1 = radius.get(a1);
-    poly.n = 4;
     float c0[4] = {mn0, mx0, mx0, mn0}, c1[4] = {mn1, mn1, mx1, mx1};
-    for (int i = 0; i < 4; ++i) { V3 v; v.set(me, d); v.set(a0, c0[i]); v.set(a1, c1[i]); poly.pt[i].v = v; poly.pt[i].depth = 0.f; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { V3 v; v.set(me, d); v.set(a0, c0[i]); v.set(a1, c1[i]); quad[i] = v; }
 }
 
 __device__ __forceinline__ P4 boxReferencePlane(V3 mn, V3 mx, V3 normal) {  // 295-303
@@ -144,16 +163,17 @@ __device__ inline void boxIncidentEdge(V3 r, V3 normal, V3& oa, V3& ob) {  // 30
     oa = oa * s; ob = ob * s;
 }
 
-__device__ inline bool clipAndBuild(ClipPoly& poly, const P4* planes, uint32_t numPlanes, P4 ref, Manifold& out) {  // 339-369
-    ClipPoly clipped;
+template <class Poly>
+__device__ inline bool clipAndBuild(Poly& poly, Poly& clipped, const P4* planes, uint32_t numPlanes, P4 ref, Manifold& out) {  // 339-369
     clipPolygon(poly, planes, numPlanes, clipped);
     if (clipped.n > 0) {
         V3 rn(ref.x, ref.y, ref.z);
         for (uint32_t i = 0; i < clipped.n; ++i) {
-            if (clipped.pt[i].depth < 0.f) { clipped.pt[i] = clipped.pt[clipped.n - 1]; --clipped.n; --i; }
-            else clipped.pt[i].v = clipped.pt[i].v + rn * clipped.pt[i].depth;
+            ClipVert c = clipped.get(i);
+            if (c.depth < 0.f) { clipped.put(i, clipped.get(clipped.n - 1)); --clipped.n; --i; }
+            else { c.v = c.v + rn * c.depth; clipped.put(i, c); }
         }
-        if (clipped.n > 0) { reduceManifold(clipped.pt, clipped.n, out.n, out); return true; }
+        if (clipped.n > 0) { reduceManifold(clipped, clipped.n, out.n, out); return true; }
     }
     return false;
 }
@@ -327,7 +347,8 @@ __device__ __forceinline__ V3 obbSupport(Q4 rot, V3 center, V3 radius, V3 dir) {
 }
 
 // OBB vs OBB (1179-1527)
-__device__ inline bool obbOBB(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 brad, Manifold& out) {
+template <class Poly>
+__device__ inline bool obbOBB(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 brad, Poly& poly, Poly& clipped, Manifold& out) {
     V3 ax = rotate(arot, V3(1.f, 0.f, 0.f)), ay = rotate(arot, V3(0.f, 1.f, 0.f)), az = rotate(arot, V3(0.f, 0.f, 1.f));
     V3 bx = rotate(brot, V3(1.f, 0.f, 0.f)), by = rotate(brot, V3(0.f, 1.f, 0.f)), bz = rotate(brot, V3(0.f, 0.f, 1.f));
     M3 r;
@@ -391,34 +412,38 @@ __device__ inline bool obbOBB(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 br
     if (dot(normal, tw) < 0.f) normal = -normal;
     out.n = normal;
     if (faceHit) {
-        V3 cp[4], cn[4];
-        ClipPoly poly;
+        V3 cp[4], cn[4], quad[4];
         P4 plane;
         if (!bFace) {
             boxClipPlanes(arad, rotate(conj(arot), normal), cp, cn);
-            boxIncidentFace(brad, rotate(conj(brot), normal), poly);
+            boxIncidentFace(brad, rotate(conj(brot), normal), quad);
+#pragma unroll
             for (int i = 0; i < 4; ++i) {
                 cp[i] = rotate(arot, cp[i]) + acen;
                 cn[i] = rotate(arot, cn[i]);
-                poly.pt[i].v = rotate(brot, poly.pt[i].v) + bcen;
+                quad[i] = rotate(brot, quad[i]) + bcen;
             }
             plane = makePlane(obbSupport(arot, acen, arad, normal), normal);
         } else {
             boxClipPlanes(brad, rotate(conj(brot), -normal), cp, cn);
-            boxIncidentFace(arad, rotate(conj(arot), -normal), poly);
+            boxIncidentFace(arad, rotate(conj(arot), -normal), quad);
+#pragma unroll
             for (int i = 0; i < 4; ++i) {
                 cp[i] = rotate(brot, cp[i]) + bcen;
                 cn[i] = rotate(brot, cn[i]);
-                poly.pt[i].v = rotate(arot, poly.pt[i].v) + acen;
+                quad[i] = rotate(arot, quad[i]) + acen;
             }
             plane = makePlane(obbSupport(brot, bcen, brad, -normal), -normal);
         }
         P4 planes[4];
+        poly.n = 4;
+#pragma unroll
         for (int i = 0; i < 4; ++i) {
             planes[i] = makePlane(cp[i], cn[i]);
-            poly.pt[i].depth = -planeDist(poly.pt[i].v, plane);
+            ClipVert c; c.v = quad[i]; c.depth = -planeDist(quad[i], plane);
+            poly.put(i, c);
         }
-        if (!clipAndBuild(poly, planes, 4, plane, out)) return false;
+        if (!clipAndBuild(poly, clipped, planes, 4, plane, out)) return false;
     } else {
         V3 a0, a1, b0, b1;
         boxIncidentEdge(arad, rotate(conj(arot), normal), a0, a1);

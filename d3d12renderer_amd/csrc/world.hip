@@ -90,18 +90,24 @@ struct mi_world {
     DBuf<float4> wShape, aabbMin, aabbMax, hullAabb, hullVerts; DBuf<uint32_t> hullRanges;
     // broad phase
     DBuf<double> axisPartials;
-    DBuf<uint32_t> largeList, isLarge, cellKeys, cellVals, cellKeysS, cellValsS, cellCount, cellLower;
+    DBuf<uint32_t> largeList, isLarge, cellKeys, cellRanks, cellKeysS, cellValsS, cellCount, cellLower;
     DBuf<int> blockBounds;
     DBuf<float4> sMin, sMax;
-    DBuf<GridParams> grid; DBuf<StepScalars> scalars;
+    DBuf<GridParams> grid; DBuf<StepScalars> scalars; DBuf<Shards> shards;
     DBuf<uint64_t> pairKeys, pairKeysS;
     DBuf<char> temp;
     // narrow phase
     DBuf<uint64_t> npPacked, npScan; DBuf<float4> npNormal, npPoints;
-    DBuf<uint32_t> manPair; DBuf<uint2> manBodies, manInfo;
+    DBuf<uint32_t> manPair; DBuf<uint2> manBodies, manInfo; DBuf<uint4> colWork;
     // schedule + solver
-    DBuf<uint32_t> color, colorS, order, orderS; DBuf<unsigned long long> bodyTop, bodyUsed;
+    DBuf<uint32_t> color, order, orderTmp, roundFlags, blockHist, blockScan, tileBin; DBuf<unsigned long long> bodyTop, bodyUsed;
+    DBuf<BinInfo> binInfo;
     DBuf<float4> rows; DBuf<float2> imp; DBuf<uint4> slotMeta;
+    BinInfo* hBinInfo = nullptr;          // pinned staging: kSchedBins BinInfo + tile -> bin table
+    uint32_t* hTileBin = nullptr; size_t hTileBinCap = 0;
+    BinInfo bins[kSchedBins]{};           // host copy of the last step's schedule
+    uint32_t totalTiles = 0;
+    bool xcdSwizzle = false;
 
     StepScalars hs{};            // host copy of the last step's scalars
     mi_step_counts counts{};
@@ -113,7 +119,7 @@ struct mi_world {
     uint32_t profLaunches = 0; float profKernelMs = 0.f; uint64_t profSlots = 0, profContacts = 0;
     bool usesGjk = false;   // any capsule / cylinder / hull collider present (decided at upload)
     uint32_t lastNumCells = kMaxCells;   // cells covered by the histogram/scan (host-side bound)
-    std::vector<uint32_t> colorOffsets;
+    uint64_t* pairsIn = nullptr;          // bucket-partitioned pair keys of the last step (pairKeys or pairKeysS)
 
     int init(int dev);
     ~mi_world();
@@ -134,10 +140,18 @@ int mi_world::init(int dev) {
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(scalars.ensure(1));
     HIP_TRY(grid.ensure(1));
+    HIP_TRY(shards.ensure(1));
     HIP_TRY(hipMemsetAsync(scalars.p, 0, sizeof(StepScalars), stream));
+    HIP_TRY(hipHostMalloc((void**)&hBinInfo, kSchedBins * sizeof(BinInfo)));
+    HIP_TRY(binInfo.ensure(kSchedBins));
+    HIP_TRY(roundFlags.ensure(kMaxColorRounds + 2));
+    const char* sw = getenv("MI_XCD_SWIZZLE");
+    xcdSwizzle = sw && sw[0] == '1';
     return MI_OK;
 }
 mi_world::~mi_world() {
+    if (hBinInfo) (void)hipHostFree(hBinInfo);
+    if (hTileBin) (void)hipHostFree(hTileBin);
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
     for (auto& e : profEvents) (void)hipEventDestroy(e);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -292,7 +306,7 @@ int mi_world::upload() {
     UP(bPos, pos, nb); UP(bRot, rot, nb); UP(bLinVel, lv, nb); UP(bAngVel, av, nb); UP(bForce, fo, nb); UP(bTorque, to, nb);
     UP(bCogInvMass, cim, nb); UP(bInvI, ii, 3 * (size_t)nb); UP(bParams, prm, nb);
     HIP_TRY(gPos.ensure(nb + 1)); HIP_TRY(gInvI.ensure(3 * ((size_t)nb + 1))); HIP_TRY(gVel.ensure(2 * ((size_t)nb + 1)));
-    HIP_TRY(bodyTop.ensure(nb + 1)); HIP_TRY(bodyUsed.ensure(nb + 1));
+    HIP_TRY(bodyTop.ensure(2 * ((size_t)nb + 1))); HIP_TRY(bodyUsed.ensure(nb + 1));
 
     usesGjk = false;
     for (const HCollider& c : colliders) if (c.desc.type == T_CAPSULE || c.desc.type == T_CYLINDER || c.desc.type == T_HULL) usesGjk = true;
@@ -311,7 +325,7 @@ int mi_world::upload() {
     HIP_TRY(wShape.ensure(3 * (size_t)nc + 1)); HIP_TRY(aabbMin.ensure(nc + 1)); HIP_TRY(aabbMax.ensure(nc + 1));
     HIP_TRY(sMin.ensure(nc + 1)); HIP_TRY(sMax.ensure(nc + 1));
     HIP_TRY(largeList.ensure(nc + 1)); HIP_TRY(isLarge.ensure(nc + 1));
-    HIP_TRY(cellKeys.ensure(nc + 1)); HIP_TRY(cellVals.ensure(nc + 1)); HIP_TRY(cellKeysS.ensure(nc + 1)); HIP_TRY(cellValsS.ensure(nc + 1));
+    HIP_TRY(cellKeys.ensure(nc + 1)); HIP_TRY(cellRanks.ensure(nc + 1)); HIP_TRY(cellKeysS.ensure(nc + 1)); HIP_TRY(cellValsS.ensure(nc + 1));
     HIP_TRY(cellCount.ensure(kMaxCells)); HIP_TRY(cellLower.ensure(kMaxCells));
     HIP_TRY(blockBounds.ensure(6 * (size_t)divUp(std::max(nc, 1u), 256)));
     HIP_TRY(axisPartials.ensure(6 * (size_t)divUp(std::max(nc, 1u), 256)));
@@ -364,10 +378,13 @@ __global__ void k_reset_scalars(StepScalars* sc) {
         sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->uncolored = 0;
         for (int a = 0; a < 3; ++a) { sc->boundsMin[a] = 0x7FFFFFFF; sc->boundsMax[a] = (int)0x80000000; }
     }
-    if (t <= kOverflowColor) sc->colorHist[t] = 0;
-    sc->extentHist[t] = 0; sc->extentHist[t + 128] = 0;
+    if (t < 24) { sc->bucketHist[t] = 0; sc->bucketCursor[t] = 0; }
 }
-__global__ void k_zero_u32(uint32_t* p) { *p = 0; }
+__global__ void k_reset_pair_counters(StepScalars* sc) {
+    uint32_t t = threadIdx.x;
+    if (t == 0) { sc->numPairs = 0; sc->numOverlaps = 0; }
+    if (t < 24) sc->bucketHist[t] = 0;
+}
 
 int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     HIP_TRY(hipSetDevice(device));
@@ -390,145 +407,196 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     mark();  // 1
     if (nc) {
         uint32_t nblk = divUp(nc, 256);
-        k_axis_partials<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, axisPartials.p, sc);
-        k_bp_threshold<<<1, 1, 0, st>>>(nc, sc);
+        HIP_TRY(hipMemsetAsync(shards.p, 0, sizeof(Shards), st));
+        k_axis_partials<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, axisPartials.p, shards.p);
+        k_bp_threshold<<<1, 256, 0, st>>>(nc, shards.p, sc);
         k_bp_classify<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, sc, largeList.p, isLarge.p, blockBounds.p);
         k_bp_grid_setup<<<1, 256, 0, st>>>(nc, nblk, blockBounds.p, sc, grid.p);
         // cell histogram -> exclusive prefix (cellLower).  The scan always covers the capped table (16 MB): its
         // length must be known on the host and the real cell count only exists on the device.
         HIP_TRY(hipMemsetAsync(cellCount.p, 0, (size_t)lastNumCells * sizeof(uint32_t), st));
-        k_bp_cell_ids<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, isLarge.p, grid.p, cellKeys.p, cellVals.p, cellCount.p);
+        HIP_TRY(hipMemsetAsync(cellKeysS.p, 0xFF, ((size_t)nc + 1) * sizeof(uint32_t), st));
+        k_bp_cell_ids<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, isLarge.p, grid.p, cellKeys.p, cellRanks.p, cellCount.p);
         size_t tb = 0;
         HIP_TRY(rocprim::exclusive_scan(nullptr, tb, cellCount.p, cellLower.p, 0u, (size_t)lastNumCells, rocprim::plus<uint32_t>(), st));
         if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
         HIP_TRY(rocprim::exclusive_scan(temp.p, tb, cellCount.p, cellLower.p, 0u, (size_t)lastNumCells, rocprim::plus<uint32_t>(), st));
-        tb = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, cellKeys.p, cellKeysS.p, cellVals.p, cellValsS.p, nc, 0, 32, st));
-        if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
-        HIP_TRY(rocprim::radix_sort_pairs(temp.p, tb, cellKeys.p, cellKeysS.p, cellVals.p, cellValsS.p, nc, 0, 32, st));
-        k_bp_gather_sorted<<<divUp(nc, B), B, 0, st>>>(nc, cellValsS.p, aabbMin.p, aabbMax.p, sMin.p, sMax.p);
+        k_bp_scatter_sorted<<<divUp(nc, B), B, 0, st>>>(nc, cellKeys.p, cellRanks.p, cellLower.p, aabbMin.p, aabbMax.p, cellKeysS.p, cellValsS.p, sMin.p, sMax.p);
         if (pairKeys.cap == 0) { HIP_TRY(pairKeys.ensure(std::max<size_t>(1u << 16, 8 * (size_t)nc))); }
         for (int attempt = 0; attempt < 2; ++attempt) {
             uint32_t cap = (uint32_t)std::min<size_t>(pairKeys.cap, 0x7FFFFFFFu);
-            k_bp_pairs_grid<<<divUp(nc * 5u, B), B, 0, st>>>(nc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, grid.p, pairKeys.p, cap, sc);
-            k_bp_pairs_large<<<dim3(std::min(divUp(nc, B), 256u), 16), B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc);
+            const uint32_t bpc = divUp(nc, kGridChunks * 256u);
+            k_bp_pairs_grid<<<5u * bpc, B, 0, st>>>(nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, grid.p, pairKeys.p, cap, sc, shards.p);
+            k_bp_pairs_large<<<dim3(std::min(divUp(nc, B), 256u), 16), B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc, shards.p);
+            k_pair_totals<<<1, 32, 0, st>>>(shards.p, sc);
+            if (attempt == 0) k_axis_final<<<1, 256, 0, st>>>(nc, nblk, axisPartials.p, sc);
             HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             numPairs = hs.numPairs;
             if (numPairs <= cap) break;
             HIP_TRY(pairKeys.ensure((size_t)numPairs + numPairs / 4));   // overflow: grow and redo the pair pass
-            k_zero_u32<<<1, 1, 0, st>>>(&sc->numPairs);
-            k_zero_u32<<<1, 1, 0, st>>>(&sc->numOverlaps);
+            k_reset_pair_counters<<<1, 32, 0, st>>>(sc);
+            HIP_TRY(hipMemsetAsync(shards.p, 0, sizeof(ShardCounters) * kShards, st));
         }
-        k_axis_final<<<1, 256, 0, st>>>(nc, nblk, axisPartials.p, sc);
     }
     mark();  // 2
     uint32_t nm = 0, ncon = 0;
+    pairsIn = pairKeys.p;
     if (numPairs) {
-        HIP_TRY(pairKeysS.ensure(pairKeys.cap));
-        size_t tb = 0;
-        HIP_TRY(rocprim::radix_sort_keys(nullptr, tb, pairKeys.p, pairKeysS.p, numPairs, 0, 64, st));
-        if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
-        HIP_TRY(rocprim::radix_sort_keys(temp.p, tb, pairKeys.p, pairKeysS.p, numPairs, 0, 64, st));
+        // bucket partition (type-uniform narrow-phase waves); skipped when a single bucket is populated
+        uint32_t nonEmpty = 0, gjkLo = numPairs, gjkHi = 0, off = 0;
+        BucketOffsets bo{};
+        for (uint32_t bk = 0; bk < kNumBuckets; ++bk) {
+            bo.o[bk] = off;
+            uint32_t n = hs.bucketHist[bk];
+            if (n) {
+                ++nonEmpty;
+                uint32_t ta = 0, rem = bk;
+                while (rem >= 6u - ta) { rem -= 6u - ta; ++ta; }
+                if (gjkMode(ta, ta + rem) >= 0) { gjkLo = std::min(gjkLo, off); gjkHi = std::max(gjkHi, off + n); }
+            }
+            off += n;
+        }
+        if (nonEmpty > 1) {
+            HIP_TRY(pairKeysS.ensure(pairKeys.cap));
+            k_pair_partition<<<divUp(numPairs, 1024), 256, 0, st>>>(numPairs, pairKeys.p, pairKeysS.p, bo, sc);
+            pairsIn = pairKeysS.p;
+        }
         HIP_TRY(npPacked.ensure(numPairs)); HIP_TRY(npScan.ensure(numPairs)); HIP_TRY(npNormal.ensure(numPairs)); HIP_TRY(npPoints.ensure(4 * (size_t)numPairs));
         HIP_TRY(manPair.ensure(numPairs)); HIP_TRY(manBodies.ensure(numPairs)); HIP_TRY(manInfo.ensure(numPairs));
+        HIP_TRY(colWork.ensure(numPairs)); HIP_TRY(color.ensure(numPairs));
         HullSet hset{hullVerts.p, hullRanges.p};
-        k_narrow<<<divUp(numPairs, B), B, 0, st>>>(numPairs, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
-        if (usesGjk) k_narrow_gjk<<<divUp(numPairs, 64), 64, 0, st>>>(numPairs, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
-        tb = 0;
+        k_narrow<<<divUp(numPairs, B), B, 0, st>>>(numPairs, pairsIn, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
+        if (gjkHi > gjkLo)
+            k_narrow_gjk<<<divUp(gjkHi - gjkLo, 64), 64, 0, st>>>(gjkLo, gjkHi, pairsIn, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
+        size_t tb = 0;
         HIP_TRY(rocprim::exclusive_scan(nullptr, tb, npPacked.p, npScan.p, (uint64_t)0, numPairs, rocprim::plus<uint64_t>(), st));
         if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
         HIP_TRY(rocprim::exclusive_scan(temp.p, tb, npPacked.p, npScan.p, (uint64_t)0, numPairs, rocprim::plus<uint64_t>(), st));
-        k_emit_manifolds<<<divUp(numPairs, B), B, 0, st>>>(numPairs, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p,
-                                                         manPair.p, manBodies.p, manInfo.p, sc);
+        k_emit_manifolds<<<divUp(numPairs, B), B, 0, st>>>(numPairs, nb, pairsIn, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
+                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p, sc);
     }
     mark();  // 3
     k_integrate_forces<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p,
                                                        gPos.p, gInvI.p, gVel.p);
     mark();  // 4
-    numColorsUsed = 0;
-    colorOffsets.assign(kOverflowColor + 2, 0);
+    numColorsUsed = 0; totalTiles = 0;
+    for (auto& b_ : bins) b_ = BinInfo{0, 0, 0, 0};
     if (numPairs) {
         HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         nm = hs.numManifolds; ncon = hs.numContacts;
     }
+    uint32_t totalCt = 0;
     if (nm) {
-        HIP_TRY(color.ensure(nm)); HIP_TRY(colorS.ensure(nm)); HIP_TRY(order.ensure(nm)); HIP_TRY(orderS.ensure(nm));
-        HIP_TRY(hipMemsetAsync(color.p, 0xFF, nm * sizeof(uint32_t), st));   // 0xFFFFFFFF & 0xFF... see k_color_* (compare on low byte)
-        HIP_TRY(hipMemsetAsync(bodyTop.p, 0, (nb + 1) * sizeof(unsigned long long), st));
-        HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, (nb + 1) * sizeof(unsigned long long), st));
-        uint32_t round = 0;
+        HIP_TRY(order.ensure(nm)); HIP_TRY(orderTmp.ensure(nm));
+        const uint32_t binBlocks = divUp(nm, kBinItems);
+        HIP_TRY(blockHist.ensure((size_t)kColorBins * binBlocks)); HIP_TRY(blockScan.ensure((size_t)kColorBins * binBlocks));
+        HIP_TRY(hipMemsetAsync(bodyTop.p, 0, 2 * ((size_t)nb + 1) * sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, ((size_t)nb + 1) * sizeof(unsigned long long), st));
+        HIP_TRY(hipMemsetAsync(roundFlags.p, 0, (kMaxColorRounds + 2) * sizeof(uint32_t), st));
+        unsigned long long* top[2] = {bodyTop.p, bodyTop.p + (nb + 1)};
+        uint32_t round = 0, batch = 20;
         while (true) {
-            for (int r = 0; r < 4; ++r, ++round) {
-                if (r == 3) k_zero_u32<<<1, 1, 0, st>>>(&sc->uncolored);
-                k_color_propose<<<divUp(nm, B), B, 0, st>>>(nm, round, manBodies.p, gPos.p, color.p, bodyTop.p);
-                k_color_commit<<<divUp(nm, B), B, 0, st>>>(nm, round, manBodies.p, gPos.p, color.p, bodyTop.p, bodyUsed.p, sc);
-            }
+            for (uint32_t r = 0; r < batch; ++r, ++round)
+                k_color_round<<<divUp(nm, B), B, 0, st>>>(nm, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlags.p);
+            // schedule bins (speculative: valid once the last round left nothing uncoloured)
+            k_bin_hist<<<binBlocks, 256, 0, st>>>(nm, binBlocks, color.p, manInfo.p, blockHist.p);
+            size_t tb = 0;
+            HIP_TRY(rocprim::exclusive_scan(nullptr, tb, blockHist.p, blockScan.p, 0u, (size_t)kColorBins * binBlocks, rocprim::plus<uint32_t>(), st));
+            if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
+            HIP_TRY(rocprim::exclusive_scan(temp.p, tb, blockHist.p, blockScan.p, 0u, (size_t)kColorBins * binBlocks, rocprim::plus<uint32_t>(), st));
+            k_bin_scatter<<<binBlocks, 256, 0, st>>>(nm, binBlocks, color.p, manInfo.p, blockScan.p, order.p, sc);
+            uint32_t lastFlag = 1;
             HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&lastFlag, roundFlags.p + (round - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
-            if (hs.uncolored == 0) break;
-            if (round > 4096) return fail(MI_ERR_DEVICE, "colouring did not converge");
+            if (lastFlag == 0) break;
+            if (round + 8 > kMaxColorRounds) return fail(MI_ERR_DEVICE, "colouring did not converge");
+            batch = 8;
         }
         colorRounds = round;
-        uint32_t off = 0;
-        for (uint32_t c = 0; c <= kOverflowColor; ++c) { colorOffsets[c] = off; off += hs.colorHist[c]; if (hs.colorHist[c]) numColorsUsed = c + 1; }
-        colorOffsets[kOverflowColor + 1] = off;
-        // order manifolds by colour (stable => ascending manifold index inside a colour)
-        k_iota<<<divUp(nm, B), B, 0, st>>>(nm, order.p);
-        size_t tb = 0;
-        HIP_TRY(rocprim::radix_sort_pairs(nullptr, tb, color.p, colorS.p, order.p, orderS.p, nm, 0, 8, st));
-        if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
-        HIP_TRY(rocprim::radix_sort_pairs(temp.p, tb, color.p, colorS.p, order.p, orderS.p, nm, 0, 8, st));
+        // bins -> tiles
+        uint32_t tiles = 0;
+        for (uint32_t bn = 0; bn < kSchedBins; ++bn) {
+            bool ovf = bn == kSchedBins - 1;
+            uint32_t s0 = hs.binStart[bn], s1 = ovf ? hs.binStart[kColorBins] : hs.binStart[bn + 1];
+            uint32_t stride = ovf ? 4u : (bn & 3u) + 1u;
+            BinInfo bi{s0, s1 - s0, tiles, totalCt};
+            uint32_t nt = divUp(bi.count, 64);
+            tiles += nt; totalCt += nt * stride;
+            bins[bn] = bi;
+            if (bi.count) numColorsUsed = std::max(numColorsUsed, (ovf ? kOverflowColor : bn / 4u) + 1u);
+        }
+        totalTiles = tiles;
+        if (hTileBinCap < tiles) {
+            if (hTileBin) (void)hipHostFree(hTileBin);
+            hTileBinCap = (size_t)tiles + tiles / 2 + 64;
+            HIP_TRY(hipHostMalloc((void**)&hTileBin, hTileBinCap * sizeof(uint32_t)));
+        }
+        for (uint32_t bn = 0; bn < kSchedBins; ++bn) {
+            hBinInfo[bn] = bins[bn];
+            uint32_t nt = divUp(bins[bn].count, 64);
+            for (uint32_t t = 0; t < nt; ++t) hTileBin[bins[bn].tileStart + t] = bn;
+        }
+        HIP_TRY(tileBin.ensure(hTileBinCap));
+        HIP_TRY(hipMemcpyAsync(binInfo.p, hBinInfo, kSchedBins * sizeof(BinInfo), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(tileBin.p, hTileBin, (size_t)tiles * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        const BinInfo& ob = bins[kSchedBins - 1];
+        if (ob.count > 1) {   // overflow colour: sequential solve in ascending pair-key order
+            HIP_TRY(hipMemcpyAsync(orderTmp.p + ob.slotStart, order.p + ob.slotStart, ob.count * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+            k_sort_overflow<<<1, 256, 0, st>>>(ob.slotStart, ob.count, manPair.p, pairsIn, orderTmp.p, order.p);
+        }
     }
     mark();  // 5
-    uint32_t cap = 0;
     if (nm) {
-        HIP_TRY(slotMeta.ensure(nm));
-        cap = (uint32_t)slotMeta.cap;
-        HIP_TRY(rows.ensure(4 * (size_t)kRows * cap)); HIP_TRY(imp.ensure(4 * (size_t)cap));
-        k_contact_init<<<divUp(nm, B), B, 0, st>>>(nm, cap, dt, orderS.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
-                                                  gPos.p, gInvI.p, gVel.p, rows.p, imp.p, slotMeta.p);
+        HIP_TRY(slotMeta.ensure((size_t)totalTiles * 64));
+        HIP_TRY(rows.ensure((size_t)totalCt * kRows * 64)); HIP_TRY(imp.ensure((size_t)totalCt * 64));
+        k_contact_init<<<totalTiles, 64, 0, st>>>(nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
+                                                 gPos.p, gInvI.p, gVel.p, rows.p, imp.p, slotMeta.p);
     }
     int rc = joints.initialize(*this, dt, st);
     if (rc != MI_OK) return rc;
     mark();  // 6
     // colours [tailStart, tailEnd) are small (<= 512 manifolds each, a suffix of the used colours): one launch for all of them
+    auto colorCount = [&](uint32_t c) { return bins[4 * c].count + bins[4 * c + 1].count + bins[4 * c + 2].count + bins[4 * c + 3].count; };
     uint32_t tailEnd = std::min(numColorsUsed, kOverflowColor), tailStart = tailEnd;
-    while (tailStart > 0 && colorOffsets[tailStart] - colorOffsets[tailStart - 1] <= 512u) --tailStart;
+    while (tailStart > 0 && colorCount(tailStart - 1) <= 512u) --tailStart;
     if (tailEnd - tailStart < 2) tailStart = tailEnd;
-    ColorRanges ranges;
-    for (uint32_t c = 0; c <= kOverflowColor + 1; ++c) ranges.off[c] = colorOffsets[c];
+    std::vector<ColorLaunch> launches(tailStart);
+    uint64_t mainContacts = 0;
+    for (uint32_t c = 0; c < tailStart; ++c) {
+        ColorLaunch& cl = launches[c];
+        uint32_t acc = 0;
+        for (uint32_t k = 0; k < 4; ++k) { cl.tileStart[k] = bins[4 * c + k].tileStart; cl.ctStart[k] = bins[4 * c + k].ctStart; mainContacts += (uint64_t)bins[4 * c + k].count * (k + 1); }
+        for (uint32_t i = 0; i < 4; ++i) { acc += divUp(bins[4 * c + (3 - i)].count, 64); cl.blockEnd[i] = acc; }
+        cl.numBlocks = acc; cl.swizzle = xcdSwizzle ? 1u : 0u;
+    }
     solveLaunches = settings.num_rigid_solver_iterations * (tailStart + (tailStart < tailEnd ? 1u : 0u));
     for (uint32_t it = 0; it < settings.num_rigid_solver_iterations; ++it) {
         joints.solveIteration(*this, st);   // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
         for (uint32_t c = 0; c < tailStart; ++c) {
-            uint32_t s0 = colorOffsets[c], s1 = colorOffsets[c + 1];
-            if (s1 <= s0) continue;
+            const ColorLaunch& cl = launches[c];
+            if (!cl.numBlocks) continue;
+            uint32_t grid_ = cl.swizzle ? divUp(cl.numBlocks, 8) * 8 : cl.numBlocks;
             if (profileSolve) {
                 size_t e = 2 * (size_t)profLaunches;
                 while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
                 (void)hipEventRecord(profEvents[e], st);
-                k_contact_solve<<<divUp(s1 - s0, 64), 64, 0, st>>>(s0, s1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
+                k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, rows.p, imp.p, gVel.p);
                 (void)hipEventRecord(profEvents[e + 1], st);
-                ++profLaunches; profSlots += s1 - s0;
+                ++profLaunches; profSlots += colorCount(c);
             } else {
-                k_contact_solve<<<divUp(s1 - s0, 64), 64, 0, st>>>(s0, s1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
+                k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, rows.p, imp.p, gVel.p);
             }
         }
-        if (tailStart < tailEnd) k_contact_solve_tail<<<1, 256, 0, st>>>(ranges, tailStart, tailEnd, cap, slotMeta.p, rows.p, imp.p, gVel.p);
-        uint32_t o0 = colorOffsets[kOverflowColor], o1 = colorOffsets[kOverflowColor + 1];
-        if (o1 > o0) k_contact_solve_serial<<<1, 64, 0, st>>>(o0, o1, cap, slotMeta.p, rows.p, imp.p, gVel.p);
+        if (tailStart < tailEnd) k_contact_solve_tail<<<1, 256, 0, st>>>(binInfo.p, tailStart, tailEnd, slotMeta.p, rows.p, imp.p, gVel.p);
+        if (bins[kSchedBins - 1].count) k_contact_solve_serial<<<1, 64, 0, st>>>(bins[kSchedBins - 1], slotMeta.p, rows.p, imp.p, gVel.p);
     }
     mark();  // 7
     if (profileSolve) {
-        // contacts covered by the profiled (non-tail) launches: read the slot metadata once
-        std::vector<uint4> meta(nm);
-        if (nm) HIP_TRY(hipMemcpyAsync(meta.data(), slotMeta.p, nm * sizeof(uint4), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        profContacts = 0;
-        for (uint32_t s_ = 0; s_ < colorOffsets[tailStart] && s_ < nm; ++s_) profContacts += meta[s_].z;
-        profContacts *= settings.num_rigid_solver_iterations;
+        profContacts = mainContacts * settings.num_rigid_solver_iterations;
         profKernelMs = 0.f;
         for (uint32_t l = 0; l < profLaunches; ++l) { float ms = 0.f; (void)hipEventElapsedTime(&ms, profEvents[2 * l], profEvents[2 * l + 1]); profKernelMs += ms; }
     }
@@ -743,7 +811,7 @@ MI_API int mi_colliders_add(mi_world* w, uint32_t count, const uint32_t* ents, c
         HEntity& e = w->entities[ents[i]];
         e.colliders.insert(e.colliders.begin(), id);   // linked-list prepend (src/scene/scene.h:52-54)
     }
-    if (w->colliders.size() >= (1u << 29)) return fail(MI_ERR_CAPACITY, "collider index space is 29 bits");
+    if (w->colliders.size() >= (1u << kIndexBits)) return fail(MI_ERR_CAPACITY, "collider index space is 26 bits per world");
     w->topologyDirty = true;
     return MI_OK;
 }
@@ -911,11 +979,16 @@ MI_API int mi_world_get_contacts(mi_world* w, mi_contact* out, uint32_t cap, uin
     HIP_TRY(hipMemcpy(mp.data(), w->manPair.p, nm * 4, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(mb.data(), w->manBodies.p, nm * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(mi_.data(), w->manInfo.p, nm * 8, hipMemcpyDeviceToHost));
-    HIP_TRY(hipMemcpy(keys.data(), w->pairKeysS.p, np * 8, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(keys.data(), w->pairsIn, np * 8, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(nrm.data(), w->npNormal.p, np * 16, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(pts.data(), w->npPoints.p, 4 * (size_t)np * 16, hipMemcpyDeviceToHost));
+    // device manifolds are stored in arrival order; report them in ascending (bucket, colliderA, colliderB) key order
+    std::vector<uint32_t> ord(nm);
+    for (uint32_t m = 0; m < nm; ++m) ord[m] = m;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return keys[mp[x]] < keys[mp[y]]; });
     uint32_t ci = 0;
-    for (uint32_t m = 0; m < nm; ++m) {
+    for (uint32_t mo = 0; mo < nm; ++mo) {
+        uint32_t m = ord[mo];
         uint32_t p = mp[m], cnt = mi_[m].x & 7u;
         for (uint32_t k = 0; k < cnt && ci < nc; ++k, ++ci) {
             mi_contact& o = out[ci];
@@ -993,7 +1066,16 @@ MI_API int mi_world_get_manifold_colors(mi_world* w, uint32_t* out, uint32_t cap
     if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     uint32_t nm = w->counts.num_collisions;
     if (cap < nm) return fail(MI_ERR_CAPACITY, "capacity < num manifolds");
-    if (nm) HIP_TRY(hipMemcpy(out, w->color.p, nm * 4, hipMemcpyDeviceToHost));
+    if (!nm) return MI_OK;
+    // same manifold order as mi_world_get_contacts: ascending (bucket, colliderA, colliderB)
+    uint32_t np = w->hs.numPairs;
+    std::vector<uint32_t> col(nm), mp(nm), ord(nm); std::vector<uint64_t> keys(np);
+    HIP_TRY(hipMemcpy(col.data(), w->color.p, nm * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(mp.data(), w->manPair.p, nm * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(keys.data(), w->pairsIn, np * 8, hipMemcpyDeviceToHost));
+    for (uint32_t m = 0; m < nm; ++m) ord[m] = m;
+    std::sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return keys[mp[x]] < keys[mp[y]]; });
+    for (uint32_t m = 0; m < nm; ++m) out[m] = col[ord[m]];
     return MI_OK;
 }
 

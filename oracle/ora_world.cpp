@@ -136,12 +136,23 @@ static void sincos_det(double x, double& s, double& c) {
 float det_sinf(float x) { double s, c; sincos_det((double)x, s, c); return (float)s; }
 float det_cosf(float x) { double s, c; sincos_det((double)x, s, c); return (float)c; }
 
-uint32_t hash32(uint32_t m) {  // bijective on 32 bits: unique colouring priorities
+uint32_t hash32(uint32_t m) {  // bijective on 32 bits: unique colouring priorities (joints)
     uint32_t h = m * 0x9E3779B1u;
     h ^= h >> 15;
     h *= 0x85EBCA77u;
     h ^= h >> 13;
     return h;
+}
+
+// Contact-manifold colouring priority: a bijection on 52 bits of the oriented collider pair (A, B)
+// (A, B < 2^26), so priorities are unique and independent of the order manifolds are stored in.
+uint64_t pairPriority(uint32_t a, uint32_t b) {
+    const uint64_t M52 = (1ull << 52) - 1ull;
+    uint64_t x = ((uint64_t)a << 26) | (uint64_t)b;
+    x ^= x >> 25; x = (x * 0x9E3779B97F4A7ull) & M52;
+    x ^= x >> 27; x = (x * 0xC2B2AE3D27D4Full) & M52;
+    x ^= x >> 23;
+    return x;
 }
 
 // ---------------------------------------------------------------- world
@@ -430,10 +441,12 @@ static void broadphaseReference(World& w) {
 
 // Deterministic variance reduction used by the canonical schedule (same tree on the GPU):
 // blocks of 256 colliders; within a block, 4 wave-sums of 64 by a butterfly (offsets 32..1) in
-// double, added wave 0..3; block partials added sequentially in double.
+// double, added wave 0..3; the block partials are then reduced by the same 256-lane tree: lane t
+// adds partials t, t+256, t+512, ... in ascending order, followed by the wave butterfly and the
+// in-order sum of the 4 waves.
 static void canonicalAxisSums(const std::vector<AABB>& aabbs, double s[3], double s2[3]) {
     uint32_t n = (uint32_t)aabbs.size();
-    for (int c = 0; c < 3; ++c) { s[c] = 0.0; s2[c] = 0.0; }
+    std::vector<double> part[6];
     for (uint32_t base = 0; base < n; base += 256) {
         double bs[3] = {0, 0, 0}, bs2[3] = {0, 0, 0};
         for (uint32_t wv = 0; wv < 4; ++wv) {
@@ -452,7 +465,19 @@ static void canonicalAxisSums(const std::vector<AABB>& aabbs, double s[3], doubl
                     for (int c = 0; c < 3; ++c) { l[lane][c] += l[lane + off][c]; l2[lane][c] += l2[lane + off][c]; }
             for (int c = 0; c < 3; ++c) { bs[c] += l[0][c]; bs2[c] += l2[0][c]; }
         }
-        for (int c = 0; c < 3; ++c) { s[c] += bs[c]; s2[c] += bs2[c]; }
+        for (int c = 0; c < 3; ++c) { part[c].push_back(bs[c]); part[3 + c].push_back(bs2[c]); }
+    }
+    for (int c = 0; c < 6; ++c) {
+        double l[256];
+        for (uint32_t t = 0; t < 256; ++t) { l[t] = 0.0; for (size_t b = t; b < part[c].size(); b += 256) l[t] += part[c][b]; }
+        double tot = 0.0;
+        for (uint32_t wv = 0; wv < 4; ++wv) {
+            double* x = l + wv * 64;
+            for (uint32_t off = 32; off >= 1; off >>= 1)
+                for (uint32_t lane = 0; lane < off; ++lane) x[lane] += x[lane + off];
+            tot += x[0];
+        }
+        if (c < 3) s[c] = tot; else s2[c - 3] = tot;
     }
 }
 
@@ -675,7 +700,7 @@ static void solveContact(World& w, uint32_t i, CollisionConstraint& c) {
 }
 
 // Canonical contact schedule (replaces scheduleConstraintsSIMD's role, constraints.cpp:51-184):
-// greedy graph colouring of MANIFOLDS in descending hash32 priority; a manifold takes the lowest
+// greedy graph colouring of MANIFOLDS in descending pairPriority(colliderA, colliderB); a manifold takes the lowest
 // colour free on both of its dynamic bodies (invMass != 0); bodies with invMass == 0 never
 // conflict (the reference exempts its dummy body, constraints.cpp:81-83).  Colour 64 = overflow,
 // solved sequentially last.  This is exactly what the Jones-Plassmann rounds on the GPU compute.
@@ -684,7 +709,9 @@ static void colorManifolds(World& w) {
     w.manifoldColor.assign(nm, 64);
     std::vector<uint32_t> order(nm);
     for (uint32_t i = 0; i < nm; ++i) order[i] = i;
-    std::sort(order.begin(), order.end(), [](uint32_t a, uint32_t b) { return hash32(a) > hash32(b); });
+    std::vector<uint64_t> prio(nm);
+    for (uint32_t m = 0; m < nm; ++m) prio[m] = pairPriority(w.colliderPairs[m].a, w.colliderPairs[m].b);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return prio[a] > prio[b]; });
     std::vector<uint64_t> used(w.rb.size(), 0);
     std::vector<uint32_t> firstContact(nm);
     { uint32_t off = 0; for (uint32_t m = 0; m < nm; ++m) { firstContact[m] = off; off += w.contactCounts[m]; } }

@@ -146,6 +146,7 @@ void jointsInitialize(World& w, float dt);
 void jointsSolveIteration(World& w);
 uint32_t jointsCount(const World& w);
 
-uint32_t hash32(uint32_t m);  // colouring priority
+uint32_t hash32(uint32_t m);  // joint colouring priority
+uint64_t pairPriority(uint32_t a, uint32_t b);  // contact-manifold colouring priority
 
 }  // namespace ora
