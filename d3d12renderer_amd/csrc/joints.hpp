@@ -22,7 +22,7 @@ constexpr float kBetaDistance = 0.1f, kBetaBall = 0.1f, kBetaSlider = 0.1f, kBet
 
 struct BodyView { const float4* gPos; const float4* gInvI; float4* gVel; const float4* bRot; const float4* bCog; };
 struct BodyState { Q4 rot; V3 cog, pos; M3 invI; float invMass; };
-struct BodyVel { V3 v, w; float invMass; M3 invI; };
+struct BodyVel { V3 v, w; float invMass; M3 invI; float tagV, tagW; };   // tags: the contact solver's update-version words in gVel[].w, carried through untouched
 
 __device__ __forceinline__ M3 ldM3(const float4* __restrict__ p, uint32_t i) {
     float4 a = p[3 * i], b = p[3 * i + 1], c = p[3 * i + 2];
@@ -38,12 +38,13 @@ __device__ __forceinline__ BodyState loadState(const BodyView& bv, uint32_t i, u
 }
 __device__ __forceinline__ BodyVel loadVel(const BodyView& bv, uint32_t i) {
     BodyVel b; float4 a = bv.gVel[2 * i], c = bv.gVel[2 * i + 1];
-    b.v = xyz(a); b.invMass = a.w; b.w = xyz(c); b.invI = ldM3(bv.gInvI, i);
+    b.v = xyz(a); b.invMass = bv.gPos[i].w; b.w = xyz(c); b.invI = ldM3(bv.gInvI, i);
+    b.tagV = a.w; b.tagW = c.w;
     return b;
 }
 __device__ __forceinline__ void storeVel(const BodyView& bv, uint32_t i, const BodyVel& b) {
     if (b.invMass == 0.f) return;   // kinematic bodies are never changed by impulses
-    bv.gVel[2 * i] = f4(b.v, b.invMass); bv.gVel[2 * i + 1] = f4(b.w, 0.f);
+    bv.gVel[2 * i] = f4(b.v, b.tagV); bv.gVel[2 * i + 1] = f4(b.w, b.tagW);
 }
 __device__ __forceinline__ V3 ld3(const float* f) { return V3(f[0], f[1], f[2]); }
 __device__ __forceinline__ Q4 ld4(const float* f) { return Q4(f[0], f[1], f[2], f[3]); }

@@ -40,7 +40,7 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numOverlaps;     // all AABB overlaps (CPU_PROFILE_STAT "Num broadphase overlaps")
     uint32_t numManifolds;
     uint32_t numContacts;
-    uint32_t uncolored;
+    uint32_t solveError;      // set by the dataflow solver if a dependency wait ran out of its spin budget
     uint32_t axisCur;
     uint32_t axisNext;
     uint32_t bucketHist[24];       // collision pairs per narrow-phase bucket (type pair)
@@ -737,7 +737,7 @@ __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt,
     gInvI[3 * i] = make_float4(W.m00, W.m01, W.m02, 0.f);
     gInvI[3 * i + 1] = make_float4(W.m10, W.m11, W.m12, 0.f);
     gInvI[3 * i + 2] = make_float4(W.m20, W.m21, W.m22, 0.f);
-    gVel[2 * i] = f4(v, invMass); gVel[2 * i + 1] = f4(w, 0.f);
+    gVel[2 * i] = f4(v, 0.f); gVel[2 * i + 1] = f4(w, 0.f);   // .w = update-version tag of the solver (0 at step start)
 }
 
 // K13 "Integrate rigid body velocities" (src/physics/rigid_body.cpp:126-142).
@@ -884,16 +884,19 @@ __global__ __launch_bounds__(256) void k_sort_overflow(uint32_t s0, uint32_t n, 
 // ------------------------------------------------------------------------------------------------
 // Contact constraints.  The schedule groups manifolds into bins (colour, contacts per manifold); every
 // bin is cut into TILES of 64 slots = one wave.  All constraint data of a tile is contiguous in HBM:
-//   rows : [contact-tile ct][row r = 0..7][lane]  float4   (one contact-tile = 8 KiB)
+//   rows : [contact-tile ct][row r = 0..5][lane]  float4   (one contact-tile = 6 KiB)
 //   imp  : [contact-tile ct][lane]                float2   (accumulated normal / tangent impulse)
 //   meta : [tile][lane] uint4 = (bodyA, bodyB, friction|restitution, contacts; 0 = padding lane)
+//   nrm  : [tile][lane] float4 = (normal, friction) — shared by the contacts of a manifold
 // where tile T of a bin with k contacts per manifold owns contact-tiles ctStart + (T - tileStart) * k + 0..k-1,
-// so a wave streams one contiguous 8.5 * k KiB block per PGS sweep (DRAM-page and TLB friendly) and
-// its control flow is uniform (k is a template parameter).
-//   r0 = (rA, effMassN)  r1 = (rB, effMassT)  r2 = (tangent, bias)  r3 = (normal, friction)
-//   r4 = I_A^-1 (rA x t)  r5 = I_B^-1 (rB x t)  r6 = I_A^-1 (rA x n)  r7 = I_B^-1 (rB x n)
+// so a wave streams one contiguous 6.5 * k KiB block per PGS sweep (DRAM-page and TLB friendly) and
+// its control flow is uniform (k is a template parameter).  96 B per contact (the reference's scalar
+// collision_constraint is 104 B):
+//   r0 = (rA, effMassN)  r1 = (rB, effMassT)  r2 = (tangent, bias)
+//   r3 = (tA.xyz, tB.x)  r4 = (tB.yz, nA.xy)  r5 = (nA.z, nB.xyz)
+//   with tA = I_A^-1 (rA x t), tB = I_B^-1 (rB x t), nA = I_A^-1 (rA x n), nB = I_B^-1 (rB x n)
 // ------------------------------------------------------------------------------------------------
-constexpr uint32_t kRows = 8;
+constexpr uint32_t kRows = 6;
 constexpr uint32_t kSchedBins = kOverflowColor * 4 + 1;   // 256 regular bins + the overflow colour as one bin (stride 4)
 
 struct BinInfo { uint32_t slotStart, count, tileStart, ctStart; };   // host-computed from StepScalars::binStart, uploaded every step
@@ -911,23 +914,40 @@ __global__ __launch_bounds__(64) void k_contact_init(uint32_t dummyBody, float d
                                                      const uint2* __restrict__ manInfo, const float4* __restrict__ npNormal,
                                                      const float4* __restrict__ npPoints, const float4* __restrict__ gPos,
                                                      const float4* __restrict__ gInvI, const float4* __restrict__ gVel,
-                                                     float4* __restrict__ rows, float2* __restrict__ imp, uint4* __restrict__ slotMeta) {
+                                                     const uint32_t* __restrict__ color, const unsigned long long* __restrict__ bodyUsed,
+                                                     float4* __restrict__ rows, float2* __restrict__ imp, uint4* __restrict__ slotMeta,
+                                                     float4* __restrict__ slotNormal, float2* __restrict__ slotMass) {
     uint32_t tile = blockIdx.x, lane = threadIdx.x;
     uint32_t bin = tileBin[tile];
     BinInfo bi = binInfo[bin];
     uint32_t tl = tile - bi.tileStart, j = tl * 64u + lane;
     uint32_t stride = bin < kOverflowColor * 4u ? (bin & 3u) + 1u : 4u;
     size_t ctBase = (size_t)bi.ctStart + (size_t)tl * stride;
-    if (j >= bi.count) { slotMeta[(size_t)tile * 64u + lane] = make_uint4(dummyBody, dummyBody, 0u, 0u); return; }
+    if (j >= bi.count) {
+        slotMeta[(size_t)tile * 64u + lane] = make_uint4(dummyBody, dummyBody, 0u, 0u);
+        slotMass[(size_t)tile * 64u + lane] = make_float2(0.f, 0.f);
+        return;
+    }
     uint32_t m = order[bi.slotStart + j];
     uint32_t p = manPair[m];
     uint2 bodies = manBodies[m];
     uint2 info = manInfo[m];
     uint32_t cnt = info.x & 7u;
-    slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, info.y, cnt);
     float4 pa = gPos[bodies.x], pb = gPos[bodies.y];
     V3 xA = xyz(pa), xB = xyz(pb);
     float imA = pa.w, imB = pb.w;
+    // Update-version bookkeeping for the dataflow solver: the manifolds of a body have distinct colours, so the number
+    // of updates a body has received before this manifold's turn in a sweep = colours used on the body below this one.
+    //   packed = baseA | degA << 7 | baseB << 14 | degB << 21   (deg = 0: body is never written, nothing to wait for)
+    uint32_t packed = 0;
+    {
+        uint32_t c = color[m];
+        unsigned long long below = c < 64u ? ((1ull << c) - 1ull) : ~0ull;
+        if (imA != 0.f) { unsigned long long u = bodyUsed[bodies.x]; packed |= (uint32_t)__popcll(u & below) | ((uint32_t)__popcll(u) << 7); }
+        if (imB != 0.f) { unsigned long long u = bodyUsed[bodies.y]; packed |= ((uint32_t)__popcll(u & below) << 14) | ((uint32_t)__popcll(u) << 21); }
+    }
+    slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, packed, cnt);
+    slotMass[(size_t)tile * 64u + lane] = make_float2(imA, imB);
     M3 IA = loadM3(gInvI, bodies.x), IB = loadM3(gInvI, bodies.y);
     V3 vA = xyz(gVel[2 * bodies.x]), wA = xyz(gVel[2 * bodies.x + 1]);
     V3 vB = xyz(gVel[2 * bodies.y]), wB = xyz(gVel[2 * bodies.y + 1]);
@@ -935,6 +955,7 @@ __global__ __launch_bounds__(64) void k_contact_init(uint32_t dummyBody, float d
     float invDt = 1.f / dt;
     float friction = (float)(info.y >> 16) / (float)0xFFFF;
     float restitution = (float)(info.y & 0xFFFF) / (float)0xFFFF;
+    slotNormal[(size_t)tile * 64u + lane] = f4(n, friction);
     for (uint32_t k = 0; k < cnt; ++k) {
         float4 pd = npPoints[4 * p + k];
         V3 point = xyz(pd); float depth = pd.w;
@@ -961,11 +982,9 @@ __global__ __launch_bounds__(64) void k_contact_init(uint32_t dummyBody, float d
         row[0 * 64] = f4(rA, effN);
         row[1 * 64] = f4(rB, effT);
         row[2 * 64] = f4(t, bias);
-        row[3 * 64] = f4(n, friction);
-        row[4 * 64] = f4(tA, 0.f);
-        row[5 * 64] = f4(tB, 0.f);
-        row[6 * 64] = f4(nA, 0.f);
-        row[7 * 64] = f4(nB, 0.f);
+        row[3 * 64] = make_float4(tA.x, tA.y, tA.z, tB.x);
+        row[4 * 64] = make_float4(tB.y, tB.z, nA.x, nA.y);
+        row[5 * 64] = make_float4(nA.z, nB.x, nB.y, nB.z);
         imp[(ctBase + k) * 64u + lane] = make_float2(0.f, 0.f);
     }
 }
@@ -974,22 +993,23 @@ __global__ __launch_bounds__(64) void k_contact_init(uint32_t dummyBody, float d
 // previous normal impulse), then the normal row.
 struct ContactRows { float4 r[kRows]; float2 imp; };
 
-__device__ __forceinline__ void solveOne(const ContactRows& c, float2& im, float imA, float imB, V3& vA, V3& wA, V3& vB, V3& wB) {
-    V3 rA = xyz(c.r[0]), rB = xyz(c.r[1]), t = xyz(c.r[2]), n = xyz(c.r[3]);
+__device__ __forceinline__ void solveOne(const ContactRows& c, const float4 nf, float2& im, float imA, float imB, V3& vA, V3& wA, V3& vB, V3& wB) {
+    V3 rA = xyz(c.r[0]), rB = xyz(c.r[1]), t = xyz(c.r[2]), n = xyz(nf);
+    V3 tA(c.r[3].x, c.r[3].y, c.r[3].z), tB(c.r[3].w, c.r[4].x, c.r[4].y), nA(c.r[4].z, c.r[4].w, c.r[5].x), nB(c.r[5].y, c.r[5].z, c.r[5].w);
     {
         V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
         V3 rel = avB - avA;
         float vt = dot(rel, t);
         float lambda = -c.r[1].w * vt;
-        float maxF = c.r[3].w * im.x;
+        float maxF = nf.w * im.x;
         float ni = clampr(im.y + lambda, -maxF, maxF);
         lambda = ni - im.y;
         im.y = ni;
         V3 P = lambda * t;
         vA = vA - imA * P;
-        wA = wA - xyz(c.r[4]) * lambda;
+        wA = wA - tA * lambda;
         vB = vB + imB * P;
-        wB = wB + xyz(c.r[5]) * lambda;
+        wB = wB + tB * lambda;
     }
     {
         V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
@@ -1001,9 +1021,9 @@ __device__ __forceinline__ void solveOne(const ContactRows& c, float2& im, float
         im.x = ni;
         V3 P = lambda * n;
         vA = vA - imA * P;
-        wA = wA - xyz(c.r[6]) * lambda;
+        wA = wA - nA * lambda;
         vB = vB + imB * P;
-        wB = wB + xyz(c.r[7]) * lambda;
+        wB = wB + nB * lambda;
     }
 }
 
@@ -1011,9 +1031,12 @@ __device__ __forceinline__ void solveOne(const ContactRows& c, float2& im, float
 // dependent-load depth: all constraint rows are requested up front (they do not depend on the slot metadata), the
 // body gathers follow the metadata — two memory round trips per sweep.
 template <int CNT>
-__device__ __forceinline__ void solveTile(uint32_t tile, uint32_t ctBase, uint32_t lane, const uint4* __restrict__ slotMeta,
+__device__ __forceinline__ void solveTile(uint32_t tile, uint32_t ctBase, uint32_t lane, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
+                                          const float2* __restrict__ slotMass,
                                           const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
     const uint4 meta = slotMeta[(size_t)tile * 64u + lane];
+    const float4 nf = slotNormal[(size_t)tile * 64u + lane];
+    const float2 mass = slotMass[(size_t)tile * 64u + lane];
     ContactRows c[CNT];
 #pragma unroll
     for (int k = 0; k < CNT; ++k) {
@@ -1024,7 +1047,7 @@ __device__ __forceinline__ void solveTile(uint32_t tile, uint32_t ctBase, uint32
     }
     uint32_t bA = meta.x, bB = meta.y;
     float4 a0 = gVel[2 * bA], a1 = gVel[2 * bA + 1], b0 = gVel[2 * bB], b1 = gVel[2 * bB + 1];
-    float imA = a0.w, imB = b0.w;
+    float imA = mass.x, imB = mass.y;
     // No early exit: a branch here would let the compiler sink the row loads below it and serialise four memory
     // round trips (meta -> bodies -> rows -> stores).  Padding lanes (meta.w == 0) and manifolds without a dynamic
     // body compute on whatever they loaded and simply do not store.
@@ -1033,20 +1056,20 @@ __device__ __forceinline__ void solveTile(uint32_t tile, uint32_t ctBase, uint32
 #pragma unroll
     for (int k = 0; k < CNT; ++k) {
         float2 im = c[k].imp;
-        solveOne(c[k], im, imA, imB, vA, wA, vB, wB);
+        solveOne(c[k], nf, im, imA, imB, vA, wA, vB, wB);
         if (live) imp[((size_t)ctBase + k) * 64u + lane] = im;
     }
-    if (live && imA != 0.f) { gVel[2 * bA] = f4(vA, imA); gVel[2 * bA + 1] = f4(wA, 0.f); }
-    if (live && imB != 0.f) { gVel[2 * bB] = f4(vB, imB); gVel[2 * bB + 1] = f4(wB, 0.f); }
+    if (live && imA != 0.f) { gVel[2 * bA] = f4(vA, a0.w); gVel[2 * bA + 1] = f4(wA, a1.w); }   // .w: version tags, untouched by this path
+    if (live && imB != 0.f) { gVel[2 * bB] = f4(vB, b0.w); gVel[2 * bB + 1] = f4(wB, b1.w); }
 }
 
-__device__ __forceinline__ void solveTileK(uint32_t k, uint32_t tile, uint32_t ctBase, uint32_t lane, const uint4* __restrict__ slotMeta,
-                                           const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+__device__ __forceinline__ void solveTileK(uint32_t k, uint32_t tile, uint32_t ctBase, uint32_t lane, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
+                                           const float2* __restrict__ slotMass, const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
     switch (k) {
-        case 1: solveTile<1>(tile, ctBase, lane, slotMeta, rows, imp, gVel); break;
-        case 2: solveTile<2>(tile, ctBase, lane, slotMeta, rows, imp, gVel); break;
-        case 3: solveTile<3>(tile, ctBase, lane, slotMeta, rows, imp, gVel); break;
-        default: solveTile<4>(tile, ctBase, lane, slotMeta, rows, imp, gVel); break;
+        case 1: solveTile<1>(tile, ctBase, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel); break;
+        case 2: solveTile<2>(tile, ctBase, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel); break;
+        case 3: solveTile<3>(tile, ctBase, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel); break;
+        default: solveTile<4>(tile, ctBase, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel); break;
     }
 }
 
@@ -1055,8 +1078,8 @@ __device__ __forceinline__ void solveTileK(uint32_t k, uint32_t tile, uint32_t c
 // coherent manifolds, hence neighbouring bodies) are dealt to one XCD (block b runs on XCD b % 8) so the body
 // velocity lines of a region stay in that XCD's L2.
 struct ColorLaunch { uint32_t tileStart[4]; uint32_t blockEnd[4]; uint32_t ctStart[4]; uint32_t numBlocks; uint32_t swizzle; };
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_contact_solve(ColorLaunch cl, const uint4* __restrict__ slotMeta,
-                                                      const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_contact_solve(ColorLaunch cl, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
+                                                      const float2* __restrict__ slotMass, const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
     uint32_t b = blockIdx.x;
     if (cl.swizzle) {
         uint32_t per = (cl.numBlocks + 7u) >> 3;
@@ -1065,17 +1088,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
     }
     uint32_t lane = threadIdx.x;
     // blockEnd is cumulative over k = 4, 3, 2, 1
-    if (b < cl.blockEnd[0]) { solveTile<4>(cl.tileStart[3] + b, cl.ctStart[3] + b * 4u, lane, slotMeta, rows, imp, gVel); return; }
-    if (b < cl.blockEnd[1]) { uint32_t t = b - cl.blockEnd[0]; solveTile<3>(cl.tileStart[2] + t, cl.ctStart[2] + t * 3u, lane, slotMeta, rows, imp, gVel); return; }
-    if (b < cl.blockEnd[2]) { uint32_t t = b - cl.blockEnd[1]; solveTile<2>(cl.tileStart[1] + t, cl.ctStart[1] + t * 2u, lane, slotMeta, rows, imp, gVel); return; }
-    { uint32_t t = b - cl.blockEnd[2]; solveTile<1>(cl.tileStart[0] + t, cl.ctStart[0] + t, lane, slotMeta, rows, imp, gVel); }
+    if (b < cl.blockEnd[0]) { solveTile<4>(cl.tileStart[3] + b, cl.ctStart[3] + b * 4u, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel); return; }
+    if (b < cl.blockEnd[1]) { uint32_t t = b - cl.blockEnd[0]; solveTile<3>(cl.tileStart[2] + t, cl.ctStart[2] + t * 3u, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel); return; }
+    if (b < cl.blockEnd[2]) { uint32_t t = b - cl.blockEnd[1]; solveTile<2>(cl.tileStart[1] + t, cl.ctStart[1] + t * 2u, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel); return; }
+    { uint32_t t = b - cl.blockEnd[2]; solveTile<1>(cl.tileStart[0] + t, cl.ctStart[0] + t, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel); }
 }
 
 // Trailing colours of the greedy colouring are tiny; one 256-lane workgroup runs colours [c0, c1) back to back
 // with a workgroup barrier + workgroup-scope fence between them instead of one launch each (a colour costs one
 // dependent-load chain, ~1.5 us, inside the kernel vs ~5.5 us as its own launch).
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_contact_solve_tail(const BinInfo* __restrict__ binInfo, uint32_t c0, uint32_t c1, const uint4* __restrict__ slotMeta,
-                                                             const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_contact_solve_tail(const BinInfo* __restrict__ binInfo, uint32_t c0, uint32_t c1, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
+                                                             const float2* __restrict__ slotMass, const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
     uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t c = c0; c < c1; ++c) {
         uint32_t g = 0;
@@ -1083,21 +1106,147 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
             BinInfo bi = binInfo[c * 4u + k];
             uint32_t nt = (bi.count + 63u) >> 6;
             for (uint32_t tl = 0; tl < nt; ++tl, ++g)
-                if ((g & 3u) == wave) solveTileK(k + 1u, bi.tileStart + tl, bi.ctStart + tl * (k + 1u), lane, slotMeta, rows, imp, gVel);
+                if ((g & 3u) == wave) solveTileK(k + 1u, bi.tileStart + tl, bi.ctStart + tl * (k + 1u), lane, slotMeta, slotNormal, slotMass, rows, imp, gVel);
         }
         __threadfence_block();   // one workgroup = one CU = one L1: workgroup scope is enough (an agent-scope fence costs ~3.5 us per lane here)
         __syncthreads();
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Dataflow PGS sweep: ONE launch per solver iteration instead of one per colour.
+//
+// A colour launch costs ~8.5 us whatever its size (boundary + two dependent memory round trips + one
+// wave's arithmetic + drain), and a sweep needs ~8 of them back to back: the solver is bound by the
+// number of serial phases, not by bytes.  Here every tile of the sweep is in flight at once and waits
+// only for ITS OWN bodies: gVel[2b] = (v, tag), gVel[2b+1] = (w, tag) where tag counts the updates the
+// body has received this step.  The manifolds of a body have distinct colours, so "the colours used on
+// the body below mine" (k_contact_init) says how many updates precede this manifold in a sweep; lane
+// waits until both halves of the body carry tag = iteration * degree + base, solves, and publishes
+// (v, w) with tag + 1.  The execution order is therefore exactly the sequential colour-major order the
+// oracle replays — only the waiting is per body instead of per colour.
+//
+// Cross-CU visibility (MI355X_MICROARCH.md, "inter-workgroup visibility"): each half is ONE 16-byte
+// `sc1` (agent-scope, write-through) store carrying its own tag and is read with `sc1` loads (L1
+// bypass), so a reader that sees the tag sees the data of the same store: no fences, no separate flag.
+// Forward progress: tile t depends only on tiles < t (lower colours) and workgroups are dispatched in
+// index order, so the lowest unfinished tile is always resident and never waits on an undispatched one;
+// every wait is bounded anyway (spin budget -> StepScalars::solveError -> MI_ERR_DEVICE, no hang).
+// ------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr uint32_t kSpinBudget = 1u << 16;
+
+__device__ __forceinline__ void loadBodySc1(const float4* p, f32x4& h0, f32x4& h1) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(h0), "=&v"(h1) : "v"(p) : "memory");
+}
+__device__ __forceinline__ void loadBodies2Sc1(const float4* pa, const float4* pb, f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off sc1\n\tglobal_load_dwordx4 %3, %5, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(pa), "v"(pb) : "memory");
+}
+__device__ __forceinline__ void storeBodySc1(float4* p, f32x4 h0, f32x4 h1) {
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" : : "v"(p), "v"(h0), "v"(h1) : "memory");
+}
+
+template <int CNT>
+__device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_t lane, uint32_t it, const uint4* __restrict__ slotMeta,
+                                         const float4* __restrict__ slotNormal, const float2* __restrict__ slotMass,
+                                         const float4* __restrict__ rows, float2* imp, float4* gVel, uint32_t* tileIter, StepScalars* sc) {
+    const uint4 meta = slotMeta[(size_t)tile * 64u + lane];
+    const float4 nf = slotNormal[(size_t)tile * 64u + lane];
+    const float2 mass = slotMass[(size_t)tile * 64u + lane];
+    ContactRows c[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+        const float4* __restrict__ row = rows + ((size_t)ctBase + k) * (kRows * 64u) + lane;
+#pragma unroll
+        for (uint32_t r = 0; r < kRows; ++r) c[k].r[r] = row[r * 64u];
+    }
+    uint32_t budget = kSpinBudget;
+    // The accumulated impulses were written by the wave that ran this tile in the previous sweep (possibly on another
+    // XCD, possibly in the same launch): wait for its completion flag, then read them with agent-scope loads.
+    while (__hip_atomic_load(tileIter + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it) {
+        __builtin_amdgcn_s_sleep(2);
+        if (--budget == 0u) { sc->solveError = 1u; break; }
+    }
+    unsigned long long* impBits = reinterpret_cast<unsigned long long*>(imp);
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+        unsigned long long v = __hip_atomic_load(impBits + ((size_t)ctBase + k) * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        c[k].imp = make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
+    }
+    const uint32_t bA = meta.x, bB = meta.y, pk = meta.z;
+    const float imA = mass.x, imB = mass.y;
+    const bool valid = meta.w != 0u;
+    const uint32_t degA = (pk >> 7) & 127u, degB = (pk >> 21) & 127u;
+    const uint32_t expA = it * degA + (pk & 127u), expB = it * degB + ((pk >> 14) & 127u);
+    const bool needA = valid && degA != 0u, needB = valid && degB != 0u;
+    float4* pA = gVel + 2 * (size_t)bA; float4* pB = gVel + 2 * (size_t)bB;
+    f32x4 a0, a1, b0, b1;
+    loadBodies2Sc1(pA, pB, a0, a1, b0, b1);   // issued behind the row loads: the wait below also lands the rows
+    bool okA = !needA || (__float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA);
+    bool okB = !needB || (__float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB);
+    while (__ballot(!(okA && okB)) != 0ull) {   // tight polling measured fastest: only the lanes still waiting re-load
+        if (!okA) { loadBodySc1(pA, a0, a1); okA = __float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA; }
+        if (!okB) { loadBodySc1(pB, b0, b1); okB = __float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB; }
+        if (--budget == 0u) { sc->solveError = 1u; break; }
+    }
+    V3 vA(a0.x, a0.y, a0.z), wA(a1.x, a1.y, a1.z), vB(b0.x, b0.y, b0.z), wB(b1.x, b1.y, b1.z);
+    const bool live = valid && (imA != 0.f || imB != 0.f);
+    float2 out[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+        float2 im = c[k].imp;
+        solveOne(c[k], nf, im, imA, imB, vA, wA, vB, wB);
+        out[k] = im;
+    }
+    // publish the bodies first (they are on the dependency chain), then the impulses, then the tile's completion flag
+    if (needA) {
+        float t = __uint_as_float(expA + 1u);
+        f32x4 h0 = {vA.x, vA.y, vA.z, t}, h1 = {wA.x, wA.y, wA.z, t};
+        storeBodySc1(pA, h0, h1);
+    }
+    if (needB) {
+        float t = __uint_as_float(expB + 1u);
+        f32x4 h0 = {vB.x, vB.y, vB.z, t}, h1 = {wB.x, wB.y, wB.z, t};
+        storeBodySc1(pB, h0, h1);
+    }
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) {
+            unsigned long long v = (unsigned long long)__float_as_uint(out[k].x) | ((unsigned long long)__float_as_uint(out[k].y) << 32);
+            __hip_atomic_store(impBits + ((size_t)ctBase + k) * 64u + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores acknowledged before the flag goes out
+    if (lane == 0) __hip_atomic_store(tileIter + tile, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Block b runs sweep itBase + b / numTiles of tile b % numTiles (schedule order, colour-major): with no joints between the
+// sweeps ALL iterations are one launch, so the latency-bound small colours of sweep i overlap the bandwidth-bound large
+// colours of sweep i + 1.  tileDesc[tile] = (first contact-tile, contacts per manifold); tileIter[tile] = sweeps completed.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_contact_solve_flow(
+    uint32_t itBase, uint32_t numTiles, const uint2* __restrict__ tileDesc, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
+    const float2* __restrict__ slotMass, const float4* __restrict__ rows, float2* imp, float4* gVel, uint32_t* tileIter, StepScalars* sc) {
+    const uint32_t it = itBase + blockIdx.x / numTiles, tile = blockIdx.x % numTiles, lane = threadIdx.x;
+    const uint2 d = tileDesc[tile];
+    switch (d.y) {
+        case 1: flowTile<1>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, tileIter, sc); break;
+        case 2: flowTile<2>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, tileIter, sc); break;
+        case 3: flowTile<3>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, tileIter, sc); break;
+        default: flowTile<4>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, tileIter, sc); break;
+    }
+}
+
 // Overflow colour (a body with > 64 incident manifolds): sequential, one lane, slots in ascending pair-key order.
-__global__ void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slotMeta,
-                                       const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+__global__ void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
+                                       const float2* __restrict__ slotMass, const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (uint32_t j = 0; j < bi.count; ++j) {
         uint32_t tile = bi.tileStart + (j >> 6), lane = j & 63u, ctBase = bi.ctStart + (j >> 6) * 4u;
         uint4 meta = slotMeta[(size_t)tile * 64u + lane];
-        solveTileK(meta.w, tile, ctBase, lane, slotMeta, rows, imp, gVel);
+        solveTileK(meta.w, tile, ctBase, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel);
         __threadfence();
     }
 }

@@ -102,7 +102,11 @@ struct mi_world {
     // schedule + solver
     DBuf<uint32_t> color, order, orderTmp, roundFlags, blockHist, blockScan, tileBin; DBuf<unsigned long long> bodyTop, bodyUsed;
     DBuf<BinInfo> binInfo;
-    DBuf<float4> rows; DBuf<float2> imp; DBuf<uint4> slotMeta;
+    DBuf<float4> rows, slotNormal; DBuf<float2> imp, slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc; DBuf<uint32_t> tileIter;
+    uint2* hTileDesc = nullptr;
+    bool usedFlow = false;
+    uint32_t flowLds = 0;                  // dynamic LDS bytes per 64-lane workgroup: caps resident waves per CU (160 KiB / flowLds)
+    bool flowSolver = true;               // dataflow PGS sweep (one launch per iteration); MI_SOLVER=launch selects one launch per colour
     BinInfo* hBinInfo = nullptr;          // pinned staging: kSchedBins BinInfo + tile -> bin table
     uint32_t* hTileBin = nullptr; size_t hTileBinCap = 0;
     BinInfo bins[kSchedBins]{};           // host copy of the last step's schedule
@@ -147,11 +151,16 @@ int mi_world::init(int dev) {
     HIP_TRY(roundFlags.ensure(kMaxColorRounds + 2));
     const char* sw = getenv("MI_XCD_SWIZZLE");
     xcdSwizzle = sw && sw[0] == '1';
+    const char* sv = getenv("MI_SOLVER");
+    flowSolver = !(sv && std::string(sv) == "launch");
+    if (const char* fl = getenv("MI_FLOW_LDS")) flowLds = (uint32_t)strtoul(fl, nullptr, 0);
+    if (flowLds > 65536) (void)hipFuncSetAttribute((const void*)k_contact_solve_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flowLds);
     return MI_OK;
 }
 mi_world::~mi_world() {
     if (hBinInfo) (void)hipHostFree(hBinInfo);
     if (hTileBin) (void)hipHostFree(hTileBin);
+    if (hTileDesc) (void)hipHostFree(hTileDesc);
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
     for (auto& e : profEvents) (void)hipEventDestroy(e);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -375,7 +384,7 @@ int mi_world::download() {
 __global__ void k_reset_scalars(StepScalars* sc) {
     uint32_t t = threadIdx.x;
     if (t == 0) {
-        sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->uncolored = 0;
+        sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->solveError = 0;
         for (int a = 0; a < 3; ++a) { sc->boundsMin[a] = 0x7FFFFFFF; sc->boundsMax[a] = (int)0x80000000; }
     }
     if (t < 24) { sc->bucketHist[t] = 0; sc->bucketCursor[t] = 0; }
@@ -531,17 +540,25 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
         totalTiles = tiles;
         if (hTileBinCap < tiles) {
             if (hTileBin) (void)hipHostFree(hTileBin);
+            if (hTileDesc) (void)hipHostFree(hTileDesc);
+            hTileBin = nullptr; hTileDesc = nullptr;
             hTileBinCap = (size_t)tiles + tiles / 2 + 64;
             HIP_TRY(hipHostMalloc((void**)&hTileBin, hTileBinCap * sizeof(uint32_t)));
+            HIP_TRY(hipHostMalloc((void**)&hTileDesc, hTileBinCap * sizeof(uint2)));
         }
         for (uint32_t bn = 0; bn < kSchedBins; ++bn) {
             hBinInfo[bn] = bins[bn];
             uint32_t nt = divUp(bins[bn].count, 64);
-            for (uint32_t t = 0; t < nt; ++t) hTileBin[bins[bn].tileStart + t] = bn;
+            uint32_t stride = bn == kSchedBins - 1 ? 4u : (bn & 3u) + 1u;
+            for (uint32_t t = 0; t < nt; ++t) {
+                hTileBin[bins[bn].tileStart + t] = bn;
+                hTileDesc[bins[bn].tileStart + t] = make_uint2(bins[bn].ctStart + t * stride, stride);
+            }
         }
-        HIP_TRY(tileBin.ensure(hTileBinCap));
+        HIP_TRY(tileBin.ensure(hTileBinCap)); HIP_TRY(tileDesc.ensure(hTileBinCap));
         HIP_TRY(hipMemcpyAsync(binInfo.p, hBinInfo, kSchedBins * sizeof(BinInfo), hipMemcpyHostToDevice, st));
         HIP_TRY(hipMemcpyAsync(tileBin.p, hTileBin, (size_t)tiles * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(tileDesc.p, hTileDesc, (size_t)tiles * sizeof(uint2), hipMemcpyHostToDevice, st));
         const BinInfo& ob = bins[kSchedBins - 1];
         if (ob.count > 1) {   // overflow colour: sequential solve in ascending pair-key order
             HIP_TRY(hipMemcpyAsync(orderTmp.p + ob.slotStart, order.p + ob.slotStart, ob.count * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
@@ -550,10 +567,10 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     }
     mark();  // 5
     if (nm) {
-        HIP_TRY(slotMeta.ensure((size_t)totalTiles * 64));
+        HIP_TRY(slotMeta.ensure((size_t)totalTiles * 64)); HIP_TRY(slotNormal.ensure((size_t)totalTiles * 64)); HIP_TRY(slotMass.ensure((size_t)totalTiles * 64));
         HIP_TRY(rows.ensure((size_t)totalCt * kRows * 64)); HIP_TRY(imp.ensure((size_t)totalCt * 64));
         k_contact_init<<<totalTiles, 64, 0, st>>>(nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
-                                                 gPos.p, gInvI.p, gVel.p, rows.p, imp.p, slotMeta.p);
+                                                 gPos.p, gInvI.p, gVel.p, color.p, bodyUsed.p, rows.p, imp.p, slotMeta.p, slotNormal.p, slotMass.p);
     }
     int rc = joints.initialize(*this, dt, st);
     if (rc != MI_OK) return rc;
@@ -572,6 +589,30 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
         for (uint32_t i = 0; i < 4; ++i) { acc += divUp(bins[4 * c + (3 - i)].count, 64); cl.blockEnd[i] = acc; }
         cl.numBlocks = acc; cl.swizzle = xcdSwizzle ? 1u : 0u;
     }
+    const bool useFlow = flowSolver && nm && bins[kSchedBins - 1].count == 0;   // the overflow colour needs the sequential kernel
+    usedFlow = useFlow;
+    if (useFlow) {
+        uint64_t allContacts = 0;
+        for (uint32_t bn = 0; bn + 1 < kSchedBins; ++bn) allContacts += (uint64_t)bins[bn].count * ((bn & 3u) + 1u);
+        mainContacts = allContacts;
+        HIP_TRY(tileIter.ensure(totalTiles));
+        HIP_TRY(hipMemsetAsync(tileIter.p, 0, (size_t)totalTiles * sizeof(uint32_t), st));
+        const uint32_t iters = settings.num_rigid_solver_iterations;
+        // no joints between the sweeps -> all sweeps in one launch; otherwise one launch per sweep (joints run in between)
+        const uint32_t perLaunch = joints.count() == 0 && (uint64_t)totalTiles * iters < 0x7FFFFFFFull ? iters : 1u;
+        solveLaunches = (iters + perLaunch - 1) / perLaunch;
+        for (uint32_t it = 0; it < iters; it += perLaunch) {
+            if (perLaunch == 1) joints.solveIteration(*this, st);   // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
+            if (profileSolve) {
+                size_t e = 2 * (size_t)profLaunches;
+                while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
+                (void)hipEventRecord(profEvents[e], st);
+            }
+            k_contact_solve_flow<<<totalTiles * perLaunch, 64, flowLds, st>>>(it, totalTiles, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p,
+                                                                             tileIter.p, sc);
+            if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; profSlots += (uint64_t)nm * perLaunch; }
+        }
+    } else {
     solveLaunches = settings.num_rigid_solver_iterations * (tailStart + (tailStart < tailEnd ? 1u : 0u));
     for (uint32_t it = 0; it < settings.num_rigid_solver_iterations; ++it) {
         joints.solveIteration(*this, st);   // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
@@ -583,15 +624,16 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
                 size_t e = 2 * (size_t)profLaunches;
                 while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
                 (void)hipEventRecord(profEvents[e], st);
-                k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, rows.p, imp.p, gVel.p);
+                k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
                 (void)hipEventRecord(profEvents[e + 1], st);
                 ++profLaunches; profSlots += colorCount(c);
             } else {
-                k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, rows.p, imp.p, gVel.p);
+                k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
             }
         }
-        if (tailStart < tailEnd) k_contact_solve_tail<<<1, 256, 0, st>>>(binInfo.p, tailStart, tailEnd, slotMeta.p, rows.p, imp.p, gVel.p);
-        if (bins[kSchedBins - 1].count) k_contact_solve_serial<<<1, 64, 0, st>>>(bins[kSchedBins - 1], slotMeta.p, rows.p, imp.p, gVel.p);
+        if (tailStart < tailEnd) k_contact_solve_tail<<<1, 256, 0, st>>>(binInfo.p, tailStart, tailEnd, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
+        if (bins[kSchedBins - 1].count) k_contact_solve_serial<<<1, 64, 0, st>>>(bins[kSchedBins - 1], slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
+    }
     }
     mark();  // 7
     if (profileSolve) {
@@ -602,8 +644,11 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     }
     k_integrate_velocities<<<divUp(nb, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p);
     mark();  // 8
+    uint32_t solveError = 0;
+    if (useFlow) HIP_TRY(hipMemcpyAsync(&solveError, &sc->solveError, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
+    if (solveError) return fail(MI_ERR_DEVICE, "dataflow contact solver: a body dependency wait exceeded its spin budget");
     hostStale = true;
 
     auto el = [&](int a, int b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; };
