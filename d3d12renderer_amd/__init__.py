@@ -10,7 +10,10 @@ from pathlib import Path
 from . import capi, scenes  # noqa: F401
 from .capi import StepSettings, PhysicsError  # noqa: F401
 
-LIB_PATH = Path(__file__).resolve().parent / "libmi_physics.so"
+import os
+
+# MI_PHYSICS_LIB: development override (A/B-testing another build of the same HIP library); never a CPU path
+LIB_PATH = Path(os.environ["MI_PHYSICS_LIB"]).resolve() if os.environ.get("MI_PHYSICS_LIB") else Path(__file__).resolve().parent / "libmi_physics.so"
 _library = None
 
 

@@ -885,7 +885,7 @@ __global__ __launch_bounds__(256) void k_sort_overflow(uint32_t s0, uint32_t n, 
 // Contact constraints.  The schedule groups manifolds into bins (colour, contacts per manifold); every
 // bin is cut into TILES of 64 slots = one wave.  All constraint data of a tile is contiguous in HBM:
 //   rows : [contact-tile ct][row r = 0..5][lane]  float4   (one contact-tile = 6 KiB)
-//   imp  : [contact-tile ct][lane]                float2   (accumulated normal / tangent impulse)
+//   imp  : [contact-tile ct][lane]                float4   (accumulated normal, tangent impulse, sweep tag, -)
 //   meta : [tile][lane] uint4 = (bodyA, bodyB, friction|restitution, contacts; 0 = padding lane)
 //   nrm  : [tile][lane] float4 = (normal, friction) — shared by the contacts of a manifold
 // where tile T of a bin with k contacts per manifold owns contact-tiles ctStart + (T - tileStart) * k + 0..k-1,
@@ -915,7 +915,7 @@ __global__ __launch_bounds__(64) void k_contact_init(uint32_t dummyBody, float d
                                                      const float4* __restrict__ npPoints, const float4* __restrict__ gPos,
                                                      const float4* __restrict__ gInvI, const float4* __restrict__ gVel,
                                                      const uint32_t* __restrict__ color, const unsigned long long* __restrict__ bodyUsed,
-                                                     float4* __restrict__ rows, float2* __restrict__ imp, uint4* __restrict__ slotMeta,
+                                                     float4* __restrict__ rows, float4* __restrict__ imp, uint4* __restrict__ slotMeta,
                                                      float4* __restrict__ slotNormal, float2* __restrict__ slotMass) {
     uint32_t tile = blockIdx.x, lane = threadIdx.x;
     uint32_t bin = tileBin[tile];
@@ -985,13 +985,13 @@ __global__ __launch_bounds__(64) void k_contact_init(uint32_t dummyBody, float d
         row[3 * 64] = make_float4(tA.x, tA.y, tA.z, tB.x);
         row[4 * 64] = make_float4(tB.y, tB.z, nA.x, nA.y);
         row[5 * 64] = make_float4(nA.z, nB.x, nB.y, nB.z);
-        imp[(ctBase + k) * 64u + lane] = make_float2(0.f, 0.f);
+        imp[(ctBase + k) * 64u + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // no warm start (constraints.cpp:3312-3313); sweep tag 0
     }
 }
 
 // One PGS update of one contact (src/physics/constraints.cpp:3381-3449): friction first (clamped with the
 // previous normal impulse), then the normal row.
-struct ContactRows { float4 r[kRows]; float2 imp; };
+struct ContactRows { float4 r[kRows]; float4 imp; };   // imp = (normal, tangent, sweep tag, -)
 
 __device__ __forceinline__ void solveOne(const ContactRows& c, const float4 nf, float2& im, float imA, float imB, V3& vA, V3& wA, V3& vB, V3& wB) {
     V3 rA = xyz(c.r[0]), rB = xyz(c.r[1]), t = xyz(c.r[2]), n = xyz(nf);
@@ -1033,7 +1033,7 @@ __device__ __forceinline__ void solveOne(const ContactRows& c, const float4 nf, 
 template <int CNT>
 __device__ __forceinline__ void solveTile(uint32_t tile, uint32_t ctBase, uint32_t lane, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
                                           const float2* __restrict__ slotMass,
-                                          const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+                                          const float4* __restrict__ rows, float4* __restrict__ imp, float4* __restrict__ gVel) {
     const uint4 meta = slotMeta[(size_t)tile * 64u + lane];
     const float4 nf = slotNormal[(size_t)tile * 64u + lane];
     const float2 mass = slotMass[(size_t)tile * 64u + lane];
@@ -1055,16 +1055,16 @@ __device__ __forceinline__ void solveTile(uint32_t tile, uint32_t ctBase, uint32
     V3 vA = xyz(a0), wA = xyz(a1), vB = xyz(b0), wB = xyz(b1);
 #pragma unroll
     for (int k = 0; k < CNT; ++k) {
-        float2 im = c[k].imp;
+        float2 im = make_float2(c[k].imp.x, c[k].imp.y);
         solveOne(c[k], nf, im, imA, imB, vA, wA, vB, wB);
-        if (live) imp[((size_t)ctBase + k) * 64u + lane] = im;
+        if (live) imp[((size_t)ctBase + k) * 64u + lane] = make_float4(im.x, im.y, c[k].imp.z, c[k].imp.w);
     }
     if (live && imA != 0.f) { gVel[2 * bA] = f4(vA, a0.w); gVel[2 * bA + 1] = f4(wA, a1.w); }   // .w: version tags, untouched by this path
     if (live && imB != 0.f) { gVel[2 * bB] = f4(vB, b0.w); gVel[2 * bB + 1] = f4(wB, b1.w); }
 }
 
 __device__ __forceinline__ void solveTileK(uint32_t k, uint32_t tile, uint32_t ctBase, uint32_t lane, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
-                                           const float2* __restrict__ slotMass, const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+                                           const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* __restrict__ imp, float4* __restrict__ gVel) {
     switch (k) {
         case 1: solveTile<1>(tile, ctBase, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel); break;
         case 2: solveTile<2>(tile, ctBase, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel); break;
@@ -1079,7 +1079,7 @@ __device__ __forceinline__ void solveTileK(uint32_t k, uint32_t tile, uint32_t c
 // velocity lines of a region stay in that XCD's L2.
 struct ColorLaunch { uint32_t tileStart[4]; uint32_t blockEnd[4]; uint32_t ctStart[4]; uint32_t numBlocks; uint32_t swizzle; };
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_contact_solve(ColorLaunch cl, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
-                                                      const float2* __restrict__ slotMass, const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+                                                      const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* __restrict__ imp, float4* __restrict__ gVel) {
     uint32_t b = blockIdx.x;
     if (cl.swizzle) {
         uint32_t per = (cl.numBlocks + 7u) >> 3;
@@ -1098,7 +1098,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void
 // with a workgroup barrier + workgroup-scope fence between them instead of one launch each (a colour costs one
 // dependent-load chain, ~1.5 us, inside the kernel vs ~5.5 us as its own launch).
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) void k_contact_solve_tail(const BinInfo* __restrict__ binInfo, uint32_t c0, uint32_t c1, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
-                                                             const float2* __restrict__ slotMass, const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+                                                             const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* __restrict__ imp, float4* __restrict__ gVel) {
     uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t c = c0; c < c1; ++c) {
         uint32_t g = 0;
@@ -1135,6 +1135,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr uint32_t kSpinBudget = 1u << 16;
+#ifndef MI_FLOW_WAVES
+#define MI_FLOW_WAVES 1   // resident waves per SIMD the flow kernel is compiled for (measured: 1 = 0.86 ms, 2 = 1.02 ms per 20 sweeps at 262144 bodies)
+#endif
+#ifdef MI_FLOW_TRACE   // development: per-wave timestamps (100 MHz wall clock) at 6 points of flowTile, [block][8] uint64
+#define MI_TRACE_PARAM , unsigned long long* trace, uint32_t dbg
+#define MI_TRACE_ARG , trace, dbg
+#define MI_TRACE(i) if (lane == 0 && trace) trace[(size_t)blockIdx.x * 8u + (i)] = wall_clock64();
+#define MI_DBG(bit) ((dbg >> (bit)) & 1u)
+#else
+#define MI_TRACE_PARAM
+#define MI_TRACE_ARG
+#define MI_TRACE(i)
+#define MI_DBG(bit) 0u
+#endif
 
 __device__ __forceinline__ void loadBodySc1(const float4* p, f32x4& h0, f32x4& h1) {
     asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
@@ -1148,11 +1162,61 @@ __device__ __forceinline__ void loadBodies2Sc1(const float4* pa, const float4* p
 __device__ __forceinline__ void storeBodySc1(float4* p, f32x4 h0, f32x4 h1) {
     asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" : : "v"(p), "v"(h0), "v"(h1) : "memory");
 }
+// single 16-byte granule: issue only (the next waiting asm block lands it), load + wait, store
+__device__ __forceinline__ void issueGranuleSc1(const float4* p, f32x4& g) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(g) : "v"(p) : "memory"); }
+__device__ __forceinline__ void landed(f32x4& g) { asm volatile("" : "+v"(g)); }   // orders every later use of g behind the waiting block
+__device__ __forceinline__ void loadGranuleSc1(const float4* p, f32x4& g) { asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory"); }
+__device__ __forceinline__ void storeGranuleSc1(float4* p, f32x4 g) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(g) : "memory"); }
+
+// Lane pairs (2i, 2i+1) move one body per instruction: the even lane touches granule 0 and the odd lane granule 1 of the
+// SAME body, i.e. one contiguous, 32-byte-aligned transaction instead of two scattered 16-byte ones (scattered
+// write-through stores are what bounds this kernel: 4 per manifold per sweep).  Pass 0 serves the even lane's body,
+// pass 1 the odd lane's; a DPP quad swap hands each lane the half its partner moved for it.
+__device__ __forceinline__ float swz1(float v) { return __shfl_xor(v, 1, 64); }
+__device__ __forceinline__ uint32_t swz1(uint32_t v) { return (uint32_t)__shfl_xor((int)v, 1, 64); }
+__device__ __forceinline__ f32x4 swz1(f32x4 g) { f32x4 r = {swz1(g.x), swz1(g.y), swz1(g.z), swz1(g.w)}; return r; }
+__device__ __forceinline__ float4* swz1(float4* p) {
+    unsigned long long v = (unsigned long long)p;
+    uint32_t lo = swz1((uint32_t)v), hi = swz1((uint32_t)(v >> 32));
+    return (float4*)(((unsigned long long)hi << 32) | lo);
+}
+struct PairBody {   // addresses this lane touches in pass 0 / pass 1 for one body slot (A or B)
+    float4* q0; float4* q1;
+    __device__ __forceinline__ PairBody(float4* mine, bool odd) {
+        float4* partner = swz1(mine);
+        q0 = (odd ? partner : mine) + (odd ? 1 : 0);
+        q1 = (odd ? mine : partner) + (odd ? 1 : 0);
+    }
+};
+// after both passes landed: r0 / r1 = what this lane loaded in pass 0 / 1 -> this lane's own (g0, g1)
+__device__ __forceinline__ void pairGather(bool odd, f32x4 r0, f32x4 r1, f32x4& g0, f32x4& g1) {
+    f32x4 p0 = swz1(r0), p1 = swz1(r1);
+    g0 = odd ? p1 : r0;
+    g1 = odd ? r1 : p0;
+}
+__device__ __forceinline__ void loadPair4Sc1(const PairBody& A, const PairBody& B, f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1) {
+    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(A.q0), "v"(A.q1), "v"(B.q0), "v"(B.q1) : "memory");
+}
+__device__ __forceinline__ void loadPair2Sc1(const PairBody& A, f32x4& a0, f32x4& a1) {
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1) : "v"(A.q0), "v"(A.q1) : "memory");
+}
+// publish one body slot: h0 / h1 = this lane's own granules, need = this lane's body is written at all
+__device__ __forceinline__ void storePairSc1(const PairBody& X, bool odd, bool need, f32x4 h0, f32x4 h1) {
+    f32x4 recv = swz1(odd ? h0 : h1);                 // even lane receives the odd lane's g0, odd lane the even lane's g1
+    bool partnerNeed = swz1(need ? 1u : 0u) != 0u;
+    f32x4 d0 = odd ? recv : h0, d1 = odd ? h1 : recv;
+    if (odd ? partnerNeed : need) storeGranuleSc1(X.q0, d0);
+    if (odd ? need : partnerNeed) storeGranuleSc1(X.q1, d1);
+}
 
 template <int CNT>
 __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_t lane, uint32_t it, const uint4* __restrict__ slotMeta,
                                          const float4* __restrict__ slotNormal, const float2* __restrict__ slotMass,
-                                         const float4* __restrict__ rows, float2* imp, float4* gVel, uint32_t* tileIter, StepScalars* sc) {
+                                         const float4* __restrict__ rows, float4* imp, float4* gVel, StepScalars* sc MI_TRACE_PARAM) {
+    MI_TRACE(0)
     const uint4 meta = slotMeta[(size_t)tile * 64u + lane];
     const float4 nf = slotNormal[(size_t)tile * 64u + lane];
     const float2 mass = slotMass[(size_t)tile * 64u + lane];
@@ -1163,85 +1227,134 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
 #pragma unroll
         for (uint32_t r = 0; r < kRows; ++r) c[k].r[r] = row[r * 64u];
     }
-    uint32_t budget = kSpinBudget;
-    // The accumulated impulses were written by the wave that ran this tile in the previous sweep (possibly on another
-    // XCD, possibly in the same launch): wait for its completion flag, then read them with agent-scope loads.
-    while (__hip_atomic_load(tileIter + tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != it) {
-        __builtin_amdgcn_s_sleep(2);
-        if (--budget == 0u) { sc->solveError = 1u; break; }
-    }
-    unsigned long long* impBits = reinterpret_cast<unsigned long long*>(imp);
-#pragma unroll
-    for (int k = 0; k < CNT; ++k) {
-        unsigned long long v = __hip_atomic_load(impBits + ((size_t)ctBase + k) * 64u + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        c[k].imp = make_float2(__uint_as_float((uint32_t)v), __uint_as_float((uint32_t)(v >> 32)));
-    }
     const uint32_t bA = meta.x, bB = meta.y, pk = meta.z;
     const float imA = mass.x, imB = mass.y;
     const bool valid = meta.w != 0u;
+    const bool live = valid && (imA != 0.f || imB != 0.f);
     const uint32_t degA = (pk >> 7) & 127u, degB = (pk >> 21) & 127u;
     const uint32_t expA = it * degA + (pk & 127u), expB = it * degB + ((pk >> 14) & 127u);
     const bool needA = valid && degA != 0u, needB = valid && degB != 0u;
     float4* pA = gVel + 2 * (size_t)bA; float4* pB = gVel + 2 * (size_t)bB;
-    f32x4 a0, a1, b0, b1;
-    loadBodies2Sc1(pA, pB, a0, a1, b0, b1);   // issued behind the row loads: the wait below also lands the rows
+    float4* pI = imp + (size_t)ctBase * 64u + lane;
+    // Second (and last) memory round trip: the accumulated impulses (written by the wave that ran this tile in the
+    // previous sweep, tag = sweeps completed) and the two bodies, all agent-scope; the wait also lands the rows.
+    f32x4 ig[CNT], a0, a1, b0, b1;
+    const bool odd = (lane & 1u) != 0u;
+    const PairBody PA(pA, odd), PB(pB, odd);
+    MI_TRACE(1)
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) issueGranuleSc1(pI + (size_t)k * 64u, ig[k]);
+    if (MI_DBG(7)) loadBodies2Sc1(pA, pB, a0, a1, b0, b1); else
+    {
+        f32x4 ra0, ra1, rb0, rb1;
+        loadPair4Sc1(PA, PB, ra0, ra1, rb0, rb1);
+        pairGather(odd, ra0, ra1, a0, a1);
+        pairGather(odd, rb0, rb1, b0, b1);
+    }
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) landed(ig[k]);
+#ifdef MI_FLOW_TRACE
+    if (MI_DBG(9)) {   // cross-check the pair loads against plain per-lane loads
+        f32x4 x0, x1, y0, y1;
+        loadBodies2Sc1(pA, pB, x0, x1, y0, y1);
+        bool sameTagA = __float_as_uint(x0.w) == __float_as_uint(a0.w) && __float_as_uint(x1.w) == __float_as_uint(a1.w);
+        bool sameA = x0.x == a0.x && x0.y == a0.y && x0.z == a0.z && x1.x == a1.x && x1.y == a1.y && x1.z == a1.z;
+        bool sameTagB = __float_as_uint(y0.w) == __float_as_uint(b0.w) && __float_as_uint(y1.w) == __float_as_uint(b1.w);
+        bool sameB = y0.x == b0.x && y0.y == b0.y && y0.z == b0.z && y1.x == b1.x && y1.y == b1.y && y1.z == b1.z;
+        if (valid && sameTagA && !sameA) atomicAdd(&sc->bucketCursor[1], 1u);
+        if (valid && !sameTagA) atomicAdd(&sc->bucketCursor[2], 1u);
+        if (valid && sameTagB && !sameB) atomicAdd(&sc->bucketCursor[3], 1u);
+        if (valid && !sameTagB) atomicAdd(&sc->bucketCursor[4], 1u);
+        if (valid) atomicAdd(&sc->bucketCursor[5], 1u);
+        a0 = x0; a1 = x1; b0 = y0; b1 = y1;
+    }
+#endif
+    MI_TRACE(2)
     bool okA = !needA || (__float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA);
     bool okB = !needB || (__float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB);
-    while (__ballot(!(okA && okB)) != 0ull) {   // tight polling measured fastest: only the lanes still waiting re-load
-        if (!okA) { loadBodySc1(pA, a0, a1); okA = __float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA; }
-        if (!okB) { loadBodySc1(pB, b0, b1); okB = __float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB; }
+    bool okI = true;
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) okI = okI && (!live || __float_as_uint(ig[k].z) == it);
+    uint32_t budget = kSpinBudget;
+    if (MI_DBG(4)) { okA = true; okB = true; okI = true; }
+    while (__ballot(!(okA && okB && okI)) != 0ull) {   // tight polling measured fastest: only the pairs still waiting re-load
+        // both lanes of a pair must poll together; the partner flags are exchanged OUTSIDE any short-circuit so every lane
+        // takes part in the swap (inside `!okA || swap(...)` the swap would run with only the ready lanes active)
+        const uint32_t partnerOkA = swz1(okA ? 1u : 0u), partnerOkB = swz1(okB ? 1u : 0u);
+        bool pollA = !okA || partnerOkA == 0u, pollB = !okB || partnerOkB == 0u;
+        if (MI_DBG(7)) {
+            if (!okA) { loadBodySc1(pA, a0, a1); okA = __float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA; }
+            if (!okB) { loadBodySc1(pB, b0, b1); okB = __float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB; }
+            pollA = false; pollB = false;
+        }
+        if (pollA) {
+            f32x4 r0, r1, g0, g1;
+            loadPair2Sc1(PA, r0, r1);
+            pairGather(odd, r0, r1, g0, g1);
+            if (!okA) { a0 = g0; a1 = g1; okA = __float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA; }
+        }
+        if (pollB) {
+            f32x4 r0, r1, g0, g1;
+            loadPair2Sc1(PB, r0, r1);
+            pairGather(odd, r0, r1, g0, g1);
+            if (!okB) { b0 = g0; b1 = g1; okB = __float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB; }
+        }
+        if (!okI) {
+            okI = true;
+#pragma unroll
+            for (int k = 0; k < CNT; ++k) { loadGranuleSc1(pI + (size_t)k * 64u, ig[k]); okI = okI && __float_as_uint(ig[k].z) == it; }
+        }
         if (--budget == 0u) { sc->solveError = 1u; break; }
     }
+    MI_TRACE(3)
     V3 vA(a0.x, a0.y, a0.z), wA(a1.x, a1.y, a1.z), vB(b0.x, b0.y, b0.z), wB(b1.x, b1.y, b1.z);
-    const bool live = valid && (imA != 0.f || imB != 0.f);
     float2 out[CNT];
 #pragma unroll
     for (int k = 0; k < CNT; ++k) {
-        float2 im = c[k].imp;
+        float2 im = make_float2(ig[k].x, ig[k].y);
         solveOne(c[k], nf, im, imA, imB, vA, wA, vB, wB);
         out[k] = im;
     }
-    // publish the bodies first (they are on the dependency chain), then the impulses, then the tile's completion flag
-    if (needA) {
-        float t = __uint_as_float(expA + 1u);
-        f32x4 h0 = {vA.x, vA.y, vA.z, t}, h1 = {wA.x, wA.y, wA.z, t};
-        storeBodySc1(pA, h0, h1);
+    MI_TRACE(4)
+    // publish: bodies first (they are on the dependency chain), then the impulses; nothing to wait for afterwards
+    if (!MI_DBG(5)) {
+        float tA = __uint_as_float(expA + 1u), tB = __uint_as_float(expB + 1u);
+        f32x4 hA0 = {vA.x, vA.y, vA.z, tA}, hA1 = {wA.x, wA.y, wA.z, tA}, hB0 = {vB.x, vB.y, vB.z, tB}, hB1 = {wB.x, wB.y, wB.z, tB};
+        if (MI_DBG(8)) { if (needA) storeBodySc1(pA, hA0, hA1); if (needB) storeBodySc1(pB, hB0, hB1); } else {
+        storePairSc1(PA, odd, needA, hA0, hA1);
+        storePairSc1(PB, odd, needB, hB0, hB1); }
     }
-    if (needB) {
-        float t = __uint_as_float(expB + 1u);
-        f32x4 h0 = {vB.x, vB.y, vB.z, t}, h1 = {wB.x, wB.y, wB.z, t};
-        storeBodySc1(pB, h0, h1);
-    }
-    if (live) {
+    if (live && !MI_DBG(0)) {
+        float t = __uint_as_float(it + 1u);
 #pragma unroll
         for (int k = 0; k < CNT; ++k) {
-            unsigned long long v = (unsigned long long)__float_as_uint(out[k].x) | ((unsigned long long)__float_as_uint(out[k].y) << 32);
-            __hip_atomic_store(impBits + ((size_t)ctBase + k) * 64u + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f32x4 g = {out[k].x, out[k].y, t, 0.f};
+            if (MI_DBG(6)) __builtin_nontemporal_store(g, (f32x4*)(pI + (size_t)k * 64u)); else
+            storeGranuleSc1(pI + (size_t)k * 64u, g);
         }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // write-through stores acknowledged before the flag goes out
-    if (lane == 0) __hip_atomic_store(tileIter + tile, it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    MI_TRACE(5)
 }
 
 // Block b runs sweep itBase + b / numTiles of tile b % numTiles (schedule order, colour-major): with no joints between the
 // sweeps ALL iterations are one launch, so the latency-bound small colours of sweep i overlap the bandwidth-bound large
-// colours of sweep i + 1.  tileDesc[tile] = (first contact-tile, contacts per manifold); tileIter[tile] = sweeps completed.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_contact_solve_flow(
+// colours of sweep i + 1.  tileDesc[tile] = (first contact-tile, contacts per manifold).
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_WAVES))) void k_contact_solve_flow(
     uint32_t itBase, uint32_t numTiles, const uint2* __restrict__ tileDesc, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
-    const float2* __restrict__ slotMass, const float4* __restrict__ rows, float2* imp, float4* gVel, uint32_t* tileIter, StepScalars* sc) {
+    const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* imp, float4* gVel, StepScalars* sc MI_TRACE_PARAM) {
     const uint32_t it = itBase + blockIdx.x / numTiles, tile = blockIdx.x % numTiles, lane = threadIdx.x;
     const uint2 d = tileDesc[tile];
     switch (d.y) {
-        case 1: flowTile<1>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, tileIter, sc); break;
-        case 2: flowTile<2>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, tileIter, sc); break;
-        case 3: flowTile<3>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, tileIter, sc); break;
-        default: flowTile<4>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, tileIter, sc); break;
+        case 1: flowTile<1>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc MI_TRACE_ARG); break;
+        case 2: flowTile<2>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc MI_TRACE_ARG); break;
+        case 3: flowTile<3>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc MI_TRACE_ARG); break;
+        default: flowTile<4>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc MI_TRACE_ARG); break;
     }
 }
 
 // Overflow colour (a body with > 64 incident manifolds): sequential, one lane, slots in ascending pair-key order.
 __global__ void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
-                                       const float2* __restrict__ slotMass, const float4* __restrict__ rows, float2* __restrict__ imp, float4* __restrict__ gVel) {
+                                       const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* __restrict__ imp, float4* __restrict__ gVel) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     for (uint32_t j = 0; j < bi.count; ++j) {
         uint32_t tile = bi.tileStart + (j >> 6), lane = j & 63u, ctBase = bi.ctStart + (j >> 6) * 4u;

@@ -102,7 +102,7 @@ struct mi_world {
     // schedule + solver
     DBuf<uint32_t> color, order, orderTmp, roundFlags, blockHist, blockScan, tileBin; DBuf<unsigned long long> bodyTop, bodyUsed;
     DBuf<BinInfo> binInfo;
-    DBuf<float4> rows, slotNormal; DBuf<float2> imp, slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc; DBuf<uint32_t> tileIter;
+    DBuf<float4> rows, slotNormal; DBuf<float4> imp; DBuf<float2> slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc;
     uint2* hTileDesc = nullptr;
     bool usedFlow = false;
     uint32_t flowLds = 0;                  // dynamic LDS bytes per 64-lane workgroup: caps resident waves per CU (160 KiB / flowLds)
@@ -595,8 +595,6 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
         uint64_t allContacts = 0;
         for (uint32_t bn = 0; bn + 1 < kSchedBins; ++bn) allContacts += (uint64_t)bins[bn].count * ((bn & 3u) + 1u);
         mainContacts = allContacts;
-        HIP_TRY(tileIter.ensure(totalTiles));
-        HIP_TRY(hipMemsetAsync(tileIter.p, 0, (size_t)totalTiles * sizeof(uint32_t), st));
         const uint32_t iters = settings.num_rigid_solver_iterations;
         // no joints between the sweeps -> all sweeps in one launch; otherwise one launch per sweep (joints run in between)
         const uint32_t perLaunch = joints.count() == 0 && (uint64_t)totalTiles * iters < 0x7FFFFFFFull ? iters : 1u;
@@ -608,8 +606,24 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
                 while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
                 (void)hipEventRecord(profEvents[e], st);
             }
+#ifdef MI_FLOW_TRACE
+            static DBuf<unsigned long long> traceBuf;
+            const char* tracePath = getenv("MI_FLOW_TRACE_FILE");
+            static int traceCountdown = tracePath ? atoi(getenv("MI_FLOW_TRACE_STEP") ? getenv("MI_FLOW_TRACE_STEP") : "260") : -1;
+            bool doTrace = tracePath && traceCountdown-- == 0;
+            if (doTrace) { HIP_TRY(traceBuf.ensure((size_t)totalTiles * perLaunch * 8)); HIP_TRY(hipMemsetAsync(traceBuf.p, 0, (size_t)totalTiles * perLaunch * 64, st)); }
             k_contact_solve_flow<<<totalTiles * perLaunch, 64, flowLds, st>>>(it, totalTiles, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p,
-                                                                             tileIter.p, sc);
+                                                                             sc, doTrace ? traceBuf.p : nullptr, getenv("MI_FLOW_DBG") ? (uint32_t)strtoul(getenv("MI_FLOW_DBG"), nullptr, 0) : 0u);
+            if (doTrace) {
+                std::vector<unsigned long long> h((size_t)totalTiles * perLaunch * 8);
+                HIP_TRY(hipMemcpyAsync(h.data(), traceBuf.p, h.size() * 8, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                FILE* f = fopen(tracePath, "wb");
+                if (f) { uint32_t hdr[4] = {totalTiles, perLaunch, 8, 0}; fwrite(hdr, 4, 4, f); fwrite(hTileDesc, 8, totalTiles, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
+            }
+#else
+            k_contact_solve_flow<<<totalTiles * perLaunch, 64, flowLds, st>>>(it, totalTiles, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p, sc);
+#endif
             if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; profSlots += (uint64_t)nm * perLaunch; }
         }
     } else {
@@ -648,6 +662,9 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     if (useFlow) HIP_TRY(hipMemcpyAsync(&solveError, &sc->solveError, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     HIP_TRY(hipGetLastError());
+#ifdef MI_FLOW_TRACE
+    if (getenv("MI_FLOW_DBG")) { StepScalars t{}; (void)hipMemcpy(&t, sc, sizeof(t), hipMemcpyDeviceToHost); fprintf(stderr, "paircheck: A data-mismatch %u tag-mismatch %u | B data %u tag %u | lanes %u\n", t.bucketCursor[1], t.bucketCursor[2], t.bucketCursor[3], t.bucketCursor[4], t.bucketCursor[5]); }
+#endif
     if (solveError) return fail(MI_ERR_DEVICE, "dataflow contact solver: a body dependency wait exceeded its spin budget");
     hostStale = true;
 

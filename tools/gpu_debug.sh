@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev helper: tiny scene, both solver paths, no core dumps
+# dev helper: tiny scene, both solver paths against the oracle, no core dumps
 ulimit -c 0
 cd oracle && make >/dev/null 2>&1; cd ..
 mkdir -p gpurun_out
@@ -8,7 +8,6 @@ import sys, os
 sys.path.insert(0, ".")
 import numpy as np
 import d3d12renderer_amd as mi
-if os.environ.get("MI_LIB"): mi.LIB_PATH = __import__("pathlib").Path(os.environ["MI_LIB"]).resolve()
 from d3d12renderer_amd import scenes
 import oracle
 sc = scenes.obb_pile(6, 3, 6, spacing=1.0)
@@ -21,4 +20,4 @@ pg, qg = g.physics_transforms(); po, qo = o.physics_transforms()
 print(os.environ.get("MI_SOLVER", "flow"), "contacts", g.counts()["num_contacts"], "bit-exact", pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes(), "maxdiff", np.abs(pg - po).max())
 PY
 MI_SOLVER=launch timeout 120 python /tmp/dbg.py 2>&1 | tail -3 | tee gpurun_out/dbg_launch.log
-STEPS=12 timeout 120 python /tmp/dbg.py 2>&1 | tail -3 | tee gpurun_out/dbg_flow.log
+timeout 120 python /tmp/dbg.py 2>&1 | tail -3 | tee gpurun_out/dbg_flow.log
