@@ -11,9 +11,9 @@ U[0.3,0.6], friction 0.5, 20 solver iterations, walled pen) — the configuratio
 quoted on; it fits one GPU.  N > 1 is weak scaling: every rank steps one 262 144-body tile (see DESIGN.md
 "multi-GPU").  All scene state is resident in HBM before the timed region starts.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
-k_contact_solve, algorithmic bytes from SURVEY.md §8(d)) and `cpu_baseline` (CPU oracle, reference order,
-bounded sample) objects.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the
+contact PGS solver: k_contact_solve_flow, one launch for all sweeps of a step; algorithmic bytes from
+SURVEY.md §8(d)) and `cpu_baseline` (CPU oracle, reference order, bounded sample) objects.
 """
 import argparse
 import json
@@ -104,9 +104,11 @@ def main():
         sw.step(settings, dt)
     barrier()
     t0 = time.perf_counter()
-    solve_ms = 0.0; total_dev_ms = 0.0; launches = 0; contact_iters = 0; stage_acc = {}
+    solve_ms = 0.0; total_dev_ms = 0.0; launches = 0; contact_iters = 0; stage_acc = {}; step_ms = []
     for _ in range(args.steps):
+        t_step = time.perf_counter()
         sw.step(settings, dt)
+        step_ms.append((time.perf_counter() - t_step) * 1e3)
         st = sw.world.stage_times(); c = sw.world.counts()
         solve_ms += st["solve"]; total_dev_ms += st["total"]
         launches += sw.world.solve_launches()
@@ -135,21 +137,25 @@ def main():
         # whole-job throughput: every rank steps its 262144-body tile each step; the job advances one scene step per `ms_per_step`
         # and processes world_size tiles, so value = tiles-steps per second (at N=1: plain steps/s of the 262144-body scene).
         value = world_size * args.steps / elapsed
-        # Primary figure: unperturbed timed region.  achieved = algorithmic bytes of ALL contact updates / HIP-event time of the solve stage
-        # (k_contact_solve launches + the small-colour tail launch + inter-launch gaps), so it can only under-state the kernel.
+        # Dominant kernel = the contact PGS solver.  Default path: k_contact_solve_flow, ONE launch per step covering all
+        # sweeps (MI_SOLVER=launch: one k_contact_solve launch per colour per sweep).  achieved = algorithmic bytes of all
+        # contact updates (236 B per contact per sweep) / HIP-event time of the solve stage, recorded on
+        # the world's own stream around exactly those launches, averaged over the timed steps.
+        launches_per_step = launches / args.steps
+        kernel = "k_contact_solve_flow" if launches_per_step <= args.iterations else "k_contact_solve"
         achieved = (BYTES_PER_CONTACT_ITER * contact_iters) / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else 0.0
         event_pair = (BYTES_PER_CONTACT_ITER * prof_updates) / (prof_ms * 1e-3) / 1e9 if prof_ms > 0 else 0.0
         roofline = {
-            "bound": "hbm", "kernel": "k_contact_solve", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": _measured_traffic(),
-            "avg_launch_us": solve_ms * 1e3 / max(launches, 1), "launches_per_step": launches / args.steps,
+            "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": _measured_traffic(kernel),
+            "avg_launch_us": solve_ms * 1e3 / max(launches, 1), "launches_per_step": launches_per_step,
             "algorithmic_bytes_per_launch": BYTES_PER_CONTACT_ITER * contact_iters / max(launches, 1),
             "event_pair_per_launch": {"avg_launch_us": prof_ms * 1e3 / max(prof_launches, 1), "launches_per_step": prof_launches / 3,
                                       "achieved_GBps": event_pair,
-                                      "note": "3 extra steps with a HIP event pair around each k_contact_solve launch; the events themselves add ~4 us per launch"},
-            "note": ("rank 0, timed region: 236 B x (contacts x iterations) / solve-stage HIP-event time; launches = k_contact_solve per colour per "
-                     "iteration + one tail launch per iteration; rocprofv3 --stats of the same command (profiles/) gives the pure kernel time, "
-                     "which is lower by the ~1.5 us inter-launch gap"),
+                                      "note": "3 extra steps (outside the timed region) with a dedicated HIP event pair around each solver launch"},
+            "note": ("rank 0, timed region: 236 B x contacts x sweeps / HIP-event time of the solve stage on the world's stream; "
+                     "rocprofv3 --kernel-trace --stats of the same command: profiles/; traffic = HBM bytes per launch from separate "
+                     "--pmc FETCH_SIZE / WRITE_SIZE passes (profiles/traffic.json)"),
         }
         out = {
             "metric": "physics steps/sec at 262144 rigid bodies per GPU (OBB pile, 20 solver iterations)",
@@ -163,6 +169,7 @@ def main():
                        "sharding": sw.sharding_note},
             "roofline": roofline,
             "stage_ms": {k: v / args.steps for k, v in stage_acc.items()},
+            "step_ms_median": float(np.median(step_ms)), "step_ms_p95": float(np.percentile(step_ms, 95)),
             "device_ms_per_step": total_dev_ms / args.steps,
         }
         if not args.no_cpu_baseline:
@@ -173,12 +180,12 @@ def main():
         dist.destroy_process_group()
 
 
-def _measured_traffic():
-    """HBM bytes per k_contact_solve launch from the committed rocprofv3 --pmc passes (profiles/), or None."""
+def _measured_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
     p = ROOT / "profiles" / "traffic.json"
     if p.exists():
         try:
-            return json.loads(p.read_text()).get("k_contact_solve_bytes_per_launch")
+            return json.loads(p.read_text()).get(kernel + "_bytes_per_launch")
         except Exception:
             return None
     return None

@@ -9,3 +9,4 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/stats -
 timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $RAW/pmc_fetch -o r01 -- python bench.py --steps 4 --warmup 250 --no-cpu-baseline > gpurun_out/pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $RAW/pmc_write -o r01 -- python bench.py --steps 4 --warmup 250 --no-cpu-baseline > gpurun_out/pmc_write.log 2>&1
 python tools/summarize_prof.py $RAW gpurun_out/prof_summary
+timeout 600 python bench.py 2>&1 | tail -1 > gpurun_out/bench_default.log
