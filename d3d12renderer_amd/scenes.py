@@ -421,6 +421,190 @@ def joint_zoo(seed=6, solver_iterations=30, copies=2):
                  global_constraints=gcs)
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# cfg5: vehicles (src/physics/vehicle.cpp:303-497) on convex-hull terrain tiles
+# ---------------------------------------------------------------------------------------------------------------------
+def _q_from_to(a, b):
+    """Shortest-arc rotation a -> b (unit vectors); the rods it orients carry no colliders."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    c = np.cross(a, b); d = float(np.dot(a, b))
+    if d < -0.999999:
+        ax = np.cross((1.0, 0.0, 0.0), a)
+        if np.dot(ax, ax) < 1e-12:
+            ax = np.cross((0.0, 1.0, 0.0), a)
+        ax = ax / np.linalg.norm(ax)
+        return np.array([ax[0], ax[1], ax[2], 0.0])
+    q = np.array([c[0], c[1], c[2], 1.0 + d])
+    return q / np.linalg.norm(q)
+
+
+def _gear_teeth(num_teeth, cyl_radius, tooth_length, tooth_width, rod_offset):
+    """Capsule colliders of a gear's teeth (vehicle.cpp attach(), attachment_type_gear)."""
+    out = []
+    for i in range(num_teeth):
+        rot = q_axis_angle((0, 1, 0), i * 2.0 * np.pi / num_teeth)
+        center = q_rot(rot, np.array([cyl_radius + tooth_length * 0.5, 0.0, 0.0])) + np.array([0.0, rod_offset, 0.0])
+        half = q_rot(rot, np.array([tooth_length * 0.5, 0.0, 0.0]))
+        out.append(("cap", center - half, center + half, tooth_width * 0.5))
+    return out
+
+
+def _vehicle_template():
+    """Bodies, colliders and joints of vehicle::initialize in the vehicle's own frame (motor at the origin)."""
+    density = 2000.0
+    tl, tw = 0.07, 0.1                      # motorGearDesc tooth length / width
+    motor_gear_y, gear_off = 0.25, 0.26
+    drive_len, axis_len, susp_len = 4.5, 1.5, 0.4
+    wheel_h, wheel_r = 0.3, 0.7
+    gear_mat = (0.2, 0.0, density)          # (restitution, friction, density): { wood, 0.2f, desc.friction, desc.density }
+    wheel_mat = (0.2, 1.0, 50.0)
+    front_z = -drive_len * 0.5 + gear_off * 2.0
+    front = np.array([0.0, motor_gear_y + gear_off, front_z])
+    steer_rot = q_axis_angle((-1, 0, 0), np.deg2rad(-80.0))
+    steer_wheel_pos = np.array([0.0, 1.12, 0.81])
+    steer_axis_pos = np.array([0.0, motor_gear_y + gear_off + 0.06, front_z + 0.49])
+    steer_axis_len = axis_len * 1.05
+    l_att = steer_axis_pos - np.array([steer_axis_len * 0.5, 0, 0]); r_att = steer_axis_pos + np.array([steer_axis_len * 0.5, 0, 0])
+    l_susp = front - np.array([axis_len, 0, 0]); r_susp = front + np.array([axis_len, 0, 0])
+    l_susp_att = l_susp + np.array([0, 0, susp_len]); r_susp_att = r_susp + np.array([0, 0, susp_len])
+    l_fw = l_susp - np.array([susp_len * 0.5, 0, 0]); r_fw = r_susp + np.array([susp_len * 0.5, 0, 0])
+    rear_z = drive_len * 0.505
+    sun_pos = np.array([-gear_off, motor_gear_y + gear_off, rear_z])
+    spider_pos = np.array([0.11, motor_gear_y + gear_off * 2.0, rear_z])
+    l_rw = spider_pos + np.array([-gear_off, -gear_off, 0]); r_rw = spider_pos + np.array([gear_off, -gear_off, 0])
+    ident = np.array([0.0, 0.0, 0.0, 1.0])
+    rot_z90 = q_axis_angle((0, 0, 1), np.deg2rad(90.0)); rot_mz90 = q_axis_angle((0, 0, -1), np.deg2rad(90.0))
+
+    def rod(a, b):
+        d = (b - a) / np.linalg.norm(b - a)
+        return (a + b) * 0.5, _q_from_to((0, 1, 0), d)
+
+    steer_teeth = []
+    stride = (steer_axis_len - tw) / 7.0
+    for i in range(8):
+        c = np.array([-0.5 * steer_axis_len + 0.5 * tw + i * stride, tw * 0.5, 0.0])
+        steer_teeth.append(("cap", c + np.array([0, tl * 0.5, 0]), c - np.array([0, tl * 0.5, 0]), tw * 0.5))
+    wheel = lambda off: [("cyl", np.array([0.0, off - wheel_h * 0.5, 0.0]), np.array([0.0, off + wheel_h * 0.5, 0.0]), wheel_r)]
+    fa_pos, fa_rot = rod(front + np.array([axis_len, 0, 0]), front - np.array([axis_len, 0, 0]))
+    la_pos, la_rot = rod(l_att, l_susp_att); ra_pos, ra_rot = rod(r_att, r_susp_att)
+    # (name, position, rotation, colliders, material)
+    parts = [
+        ("motor", np.zeros(3), ident, [("box", np.array([0.6, 0.1, 1.0]))], gear_mat),
+        ("motor_gear", np.array([0.0, motor_gear_y, 0.0]), ident, _gear_teeth(8, 0.2, tl, tw, 0.0), gear_mat),
+        ("drive_axis", np.array([0.0, motor_gear_y + gear_off, gear_off]), q_axis_angle((-1, 0, 0), np.deg2rad(90.0)),
+         _gear_teeth(8, 0.2, tl, tw, 0.0) + _gear_teeth(8, 0.2, tl, tw, -(drive_len * 0.57 - 1.1)), gear_mat),
+        ("front_axis", fa_pos, fa_rot, [], gear_mat),
+        ("steering_wheel", steer_wheel_pos, steer_rot, _gear_teeth(8, 0.2, tl, tw, -2.0), gear_mat),
+        ("steering_axis", steer_axis_pos, steer_rot, steer_teeth, gear_mat),
+        ("l_suspension", l_susp, ident, [], gear_mat),
+        ("r_suspension", r_susp, ident, [], gear_mat),
+        ("l_front_wheel", l_fw, rot_z90, wheel(0.0), wheel_mat),
+        ("r_front_wheel", r_fw, rot_z90, wheel(0.0), wheel_mat),
+        ("l_wheel_arm", la_pos, la_rot, [], gear_mat),
+        ("r_wheel_arm", ra_pos, ra_rot, [], gear_mat),
+        ("sun_gear", sun_pos, rot_mz90, _gear_teeth(17, 0.5, tl, tw, 0.0), gear_mat),
+        ("spider_gear", spider_pos, ident, _gear_teeth(8, 0.2, tl, tw, 0.0), gear_mat),
+        ("l_rear_wheel", l_rw, rot_mz90, _gear_teeth(8, 0.2, tl, tw, 0.0) + [(k, a, b, r, wheel_mat) for k, a, b, r in wheel(-(axis_len + spider_pos[0]))], gear_mat),
+        ("r_rear_wheel", r_rw, rot_mz90, _gear_teeth(8, 0.2, tl, tw, 0.0) + [(k, a, b, r, wheel_mat) for k, a, b, r in wheel(axis_len - spider_pos[0])], gear_mat),
+    ]
+    P = {name: i for i, (name, *_r) in enumerate(parts)}
+    H, B, F, S = capi.CONSTRAINT_HINGE, capi.CONSTRAINT_BALL, capi.CONSTRAINT_FIXED, capi.CONSTRAINT_SLIDER
+    d45 = float(np.deg2rad(45.0))
+    # (type, a, b, anchor, axis, limit0, limit1, edits)
+    joints = [
+        (H, "motor", "motor_gear", np.array([0.0, motor_gear_y, 0.0]), (0, 1, 0), 1.0, -1.0, {"max_motor_torque": 500.0, "motor_velocity_or_target_angle": "drive"}),
+        (H, "motor", "drive_axis", np.array([0.0, motor_gear_y + gear_off, gear_off]), (0, 0, 1), 1.0, -1.0, {}),
+        (F, "motor", "front_axis", front, None, 1.0, -1.0, {}),
+        (H, "motor", "steering_wheel", steer_wheel_pos, q_rot(steer_rot, np.array([0.0, -1.0, 0.0])), 1.0, -1.0,
+         {"motor_type": 1, "max_motor_torque": 1000.0, "motor_velocity_or_target_angle": 0.0}),
+        (S, "motor", "steering_axis", steer_axis_pos, (1, 0, 0), -4.0, 4.0, {}),
+        (H, "motor", "l_suspension", l_susp, (0, 1, 0), -d45, d45, {}),
+        (H, "motor", "r_suspension", r_susp, (0, 1, 0), -d45, d45, {}),
+        (H, "l_front_wheel", "l_suspension", l_fw, (1, 0, 0), 1.0, -1.0, {}),
+        (H, "r_front_wheel", "r_suspension", r_fw, (1, 0, 0), 1.0, -1.0, {}),
+        (B, "l_suspension", "l_wheel_arm", l_susp_att, None, 1.0, -1.0, {}),
+        (B, "steering_axis", "l_wheel_arm", l_att, None, 1.0, -1.0, {}),
+        (B, "r_suspension", "r_wheel_arm", r_susp_att, None, 1.0, -1.0, {}),
+        (B, "steering_axis", "r_wheel_arm", r_att, None, 1.0, -1.0, {}),
+        (H, "motor", "sun_gear", sun_pos, (1, 0, 0), 1.0, -1.0, {}),
+        (H, "sun_gear", "spider_gear", spider_pos, (0, 1, 0), 1.0, -1.0, {}),
+        (H, "motor", "l_rear_wheel", l_rw, (1, 0, 0), 1.0, -1.0, {}),
+        (H, "motor", "r_rear_wheel", r_rw, (1, 0, 0), 1.0, -1.0, {}),
+    ]
+    return parts, P, joints
+
+
+def terrain_tile_hull(half=5.0, crown=0.35, thickness=1.0, grid=5):
+    """A convex terrain tile: the solid under a concave paraboloid cap over a square base (grid^2 + 4 <= 32 vertices)."""
+    from scipy.spatial import ConvexHull
+    xs = np.linspace(-half, half, grid)
+    top = [(x, -crown * ((x / half) ** 2 + (z / half) ** 2), z) for x in xs for z in xs]
+    bottom = [(sx * half, -thickness - 2.0 * crown, sz * half) for sx in (-1, 1) for sz in (-1, 1)]
+    pts = np.asarray(top + bottom, np.float64)
+    hull = ConvexHull(pts)
+    verts = pts[hull.vertices].astype(np.float32)
+    remap = {v: i for i, v in enumerate(hull.vertices)}
+    c = verts.mean(axis=0)
+    tris = []
+    for simplex in hull.simplices:
+        a, b, cc = (remap[v] for v in simplex)
+        n = np.cross(verts[b] - verts[a], verts[cc] - verts[a])
+        if np.dot(n, verts[a] - c) < 0:
+            b, cc = cc, b
+        tris.append((a, b, cc))
+    assert len(verts) <= 32
+    return verts, np.asarray(tris, np.uint32)
+
+
+def vehicles(nx=16, nz=16, seed=5, solver_iterations=30, spacing=10.0):
+    """cfg5: nx*nz reference vehicles (16 bodies, 86 colliders, 11 hinge + 4 ball + 1 fixed + 1 slider joints each; drive motor
+    torque 500, steering position motor 1000) dropped onto static convex-hull terrain tiles (one <= 32-vertex hull geometry,
+    one static hull collider per tile, alternating 0 / 90 degree yaw and seeded height offsets)."""
+    parts, P, joints = _vehicle_template()
+    nv = nx * nz
+    npart = len(parts)
+    e = make_entities(nv * npart)
+    ents, cols, gcs = [], [], []
+    yaw = uniform(seed, 70, nv, 0.0, 2 * np.pi)
+    drive = uniform(seed, 71, nv, -3.0, 3.0)
+    tile_h = uniform(seed, 72, nv, -0.15, 0.15)
+    for v in range(nv):
+        ix, iz = divmod(v, nz)
+        base = np.array([(ix - (nx - 1) / 2) * spacing, tile_h[v] + 1.0, (iz - (nz - 1) / 2) * spacing])
+        qy = q_axis_angle((0, 1, 0), yaw[v])
+        for i, (name, pos, rot, colliders, mat) in enumerate(parts):
+            k = v * npart + i
+            e["position"][k] = q_rot(qy, pos) + base
+            e["rotation"][k] = q_mul(qy, rot)
+            for col in colliders:
+                m = col[4] if len(col) > 4 else mat
+                c = make_colliders(1, capi.CAPSULE, restitution=m[0], friction=m[1], density=m[2])
+                if col[0] == "box":
+                    c["type"] = capi.AABB
+                    c["shape"][0, :6] = (*(-col[1]), *col[1])
+                else:
+                    c["type"] = capi.CAPSULE if col[0] == "cap" else capi.CYLINDER
+                    c["shape"][0, :7] = (*col[1], *col[2], col[3])
+                ents.append(k); cols.append(c)
+        for ctype, a, b, anchor, axis, l0, l1, edits in joints:
+            ed = {kk: (float(drive[v]) if vv == "drive" else vv) for kk, vv in edits.items()}
+            ax = None if axis is None else q_rot(qy, np.asarray(axis, np.float64)).astype(np.float32)
+            gcs.append((ctype, v * npart + P[a], v * npart + P[b], (q_rot(qy, anchor) + base).astype(np.float32), ax, l0, l1, ed))
+    # terrain
+    te = make_entities(nv, capi.ENTITY_STATIC)
+    tc = make_colliders(nv, capi.HULL, restitution=0.1, friction=1.0, density=4.0)
+    for v in range(nv):
+        ix, iz = divmod(v, nz)
+        te["position"][v] = ((ix - (nx - 1) / 2) * spacing, tile_h[v], (iz - (nz - 1) / 2) * spacing)
+        te["rotation"][v] = q_axis_angle((0, 1, 0), np.pi / 2 * ((ix + iz) & 1))
+        tc["shape"][v, :7] = (0, 0, 0, 1, 0, 0, 0)
+        tc["hull_geometry"][v] = 0
+        ents.append(nv * npart + v)
+    cols.append(tc)
+    return Scene(f"cfg5_vehicles_{nv}", np.concatenate([e, te]), np.asarray(ents, np.uint32), np.concatenate(cols), solver_iterations,
+                 hulls=[terrain_tile_hull(half=spacing / 2)], global_constraints=gcs)
+
+
 def obb_pile_tile(tile=0, ntiles=1, nx=128, ny=16, nz=128, ghost_cols=2, seed=3, solver_iterations=20, spacing=1.5):
     """One x-slab of the GLOBAL cfg3 pen of (ntiles*nx) x ny x nz boxes (weak scaling: the pen grows with the GPU count).
 
@@ -476,4 +660,4 @@ def obb_pile_tile(tile=0, ntiles=1, nx=128, ny=16, nz=128, ghost_cols=2, seed=3,
 
 
 def by_name(name, **kw):
-    return {"cfg1": sphere_drop, "cfg2": mixed_stack, "cfg3": obb_pile, "cfg4": ragdolls, "zoo": shape_zoo}[name](**kw)
+    return {"cfg1": sphere_drop, "cfg2": mixed_stack, "cfg3": obb_pile, "cfg4": ragdolls, "cfg5": vehicles, "zoo": shape_zoo}[name](**kw)

@@ -47,6 +47,7 @@ def test_gpu_matches_golden_bit_exact(mi_lib, name):
     (lambda: scenes.shape_zoo(8, 5, 8), 150),
     (lambda: scenes.ragdolls(4, 4), 160),
     (lambda: scenes.joint_zoo(copies=3), 200),
+    (lambda: scenes.vehicles(3, 2), 160),
 ])
 def test_gpu_vs_oracle_trajectory_and_contacts(mi_lib, oracle_mod, make, steps):
     sc = make()

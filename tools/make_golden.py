@@ -20,6 +20,7 @@ CASES = {
     "zoo_all_shapes_144": (lambda: scenes.shape_zoo(), 160),
     "cfg4_ragdolls_4": (lambda: scenes.ragdolls(2, 2), 150),
     "joint_zoo_112": (lambda: scenes.joint_zoo(), 150),
+    "cfg5_vehicles_2": (lambda: scenes.vehicles(2, 1), 150),
 }
 
 
