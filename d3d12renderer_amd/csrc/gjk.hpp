@@ -359,12 +359,14 @@ __device__ inline bool intersectGjkImpl(const Shape& a, const Shape& b, const Hu
     }
 }
 
-__global__ __launch_bounds__(64) void k_narrow_gjk(uint32_t pairLo, uint32_t pairHi, const uint64_t* __restrict__ pairKeys, const float4* __restrict__ wShape,
+__global__ __launch_bounds__(64) void k_narrow_gjk(const StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
+                                                   const float4* __restrict__ wShape,
                                                    HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
                                                    float4* __restrict__ npPoints) {
-    // [pairLo, pairHi) = span of the bucket-partitioned pair list that holds the GJK/EPA buckets
-    uint32_t p = pairLo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= pairHi) return;
+    // [gjkLo, gjkHi) = span of the bucket-partitioned pair list that holds the GJK/EPA buckets (k_pair_ranges)
+    uint32_t p = sc->gjkLo + blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= sc->gjkHi) return;
+    const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
     uint64_t key = pairKeys[p];
     uint32_t bucket = (uint32_t)(key >> 58), a = (uint32_t)((key >> 29) & 0x1FFFFFFFu), b = (uint32_t)(key & 0x1FFFFFFFu);
     uint32_t ta = 0, rem = bucket;

@@ -47,7 +47,13 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t bucketCursor[24];     // running output cursors of the bucket partition
     uint32_t binStart[kColorBins + 4];   // first schedule slot of every (colour, contact count) bin; [kColorBins] = manifolds
     float largeThreshold;
-    uint32_t pad0;
+    uint32_t bucketOffset[24];     // first pair of every bucket in the partitioned pair list
+    uint32_t gjkLo, gjkHi;         // span of the partitioned pair list holding the GJK/EPA buckets
+    uint32_t partitioned;          // 1: the narrow phase reads the partitioned copy of the pair list
+    uint32_t totalTiles, totalCt;  // schedule: tiles and contact-tiles (k_build_tiles)
+    uint32_t colorPending;         // manifolds still uncoloured after the last colouring round enqueued
+    uint32_t specOverflow;         // a speculative bound (tiles / contact-tiles capacity) was exceeded on the device
+    uint32_t numCells;             // cells of this step's broad-phase grid
 };
 
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
@@ -85,9 +91,9 @@ __global__ __launch_bounds__(256) void k_world_colliders(
     const float4* __restrict__ cShape, const float4* __restrict__ cStaticPos, const float4* __restrict__ cStaticRot,
     const float4* __restrict__ bPos, const float4* __restrict__ bRot,
     const float4* __restrict__ hullAabb,  // [2*numHulls]
-    float4* __restrict__ wShape, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax, StepScalars* sc) {
+    float4* __restrict__ wShape, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax, StepScalars* sc, uint32_t axisCur) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) { sc->axisCur = sc->axisNext; }
+    if (k == 0) { sc->axisCur = axisCur; }   // the SAP axis chosen at the end of the previous (successful) step
     if (k >= nc) return;
     uint32_t type = cTypeBody[2 * k], body = cTypeBody[2 * k + 1];
     V3 tp; Q4 tr; uint32_t objType, objIndex;
@@ -275,7 +281,7 @@ __global__ __launch_bounds__(256) void k_bp_classify(uint32_t nc, const float4* 
     }
 }
 
-__global__ __launch_bounds__(256) void k_bp_grid_setup(uint32_t nc, uint32_t numBlocks, const int* __restrict__ blockBounds, StepScalars* sc, GridParams* g) {
+__global__ __launch_bounds__(256) void k_bp_grid_setup(uint32_t nc, uint32_t numBlocks, uint32_t cellCap, const int* __restrict__ blockBounds, StepScalars* sc, GridParams* g) {
     __shared__ int red[256][6];
     int v[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
     for (uint32_t b = threadIdx.x; b < numBlocks; b += 256)
@@ -292,10 +298,11 @@ __global__ __launch_bounds__(256) void k_bp_grid_setup(uint32_t nc, uint32_t num
     for (int it = 0; it < 64; ++it) {
         double cells = 1.0;
         for (int a = 0; a < 3; ++a) { uint32_t d = (uint32_t)((hi[a] - lo[a]) / cell) + 2u; g->dims[a] = d; cells *= (double)d; }
-        if (cells <= (double)(kMaxCells - 1)) break;
+        if (cells <= (double)(cellCap - 1)) break;   // the host sized the cell table (histogram + scan) for cellCap cells
         cell *= 1.3f;
     }
     g->numCells = g->dims[0] * g->dims[1] * g->dims[2];
+    sc->numCells = g->numCells;
     g->cell = cell; g->invCell = 1.f / cell;
     for (int a = 0; a < 3; ++a) g->origin[a] = lo[a];
     g->numLarge = sc->numLarge;
@@ -533,14 +540,29 @@ __global__ void k_pair_totals(const Shards* __restrict__ sh, StepScalars* sc) {
     if (t == 31) { uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].numOverlaps; sc->numOverlaps = v; }
 }
 
+__host__ __device__ __forceinline__ int gjkMode(uint32_t ta, uint32_t tb);
 // Bucket partition (replaces the reference's counting sort into [6][6] type-pair buckets, collision_narrow.cpp:2397-2453,
 // and the former full 64-bit key sort): pairs are grouped by bucket so narrow-phase waves are type-uniform; the order
 // inside a bucket is arbitrary — every later stage is keyed by the collider pair, not by the position of the pair.
 // A block ranks its 1024 keys per bucket in LDS and reserves one output range per non-empty bucket.
-struct BucketOffsets { uint32_t o[24]; };
-__global__ __launch_bounds__(256) void k_pair_partition(uint32_t n, const uint64_t* __restrict__ in, uint64_t* __restrict__ out, BucketOffsets off,
-                                                        StepScalars* sc) {
+// k_pair_ranges (one workgroup): bucket offsets, the GJK/EPA span and whether a partition is needed at all.
+__host__ __device__ __forceinline__ int gjkModeOfBucket(uint32_t bucket);
+__global__ void k_pair_ranges(StepScalars* sc) {
+    if (threadIdx.x != 0) return;
+    uint32_t off = 0, nonEmpty = 0, lo = 0xFFFFFFFFu, hi = 0;
+    for (uint32_t bk = 0; bk < kNumBuckets; ++bk) {
+        uint32_t n = sc->bucketHist[bk];
+        sc->bucketOffset[bk] = off;
+        if (n) { ++nonEmpty; if (gjkModeOfBucket(bk) >= 0) { lo = min(lo, off); hi = max(hi, off + n); } }
+        off += n;
+    }
+    sc->gjkLo = hi > lo ? lo : 0u; sc->gjkHi = hi > lo ? hi : 0u;
+    sc->partitioned = nonEmpty > 1u ? 1u : 0u;
+}
+__global__ __launch_bounds__(256) void k_pair_partition(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, StepScalars* sc) {
     __shared__ uint32_t cnt[32], base[32];
+    const uint32_t n = sc->numPairs;
+    if (!sc->partitioned || blockIdx.x * 1024u >= n) return;
     if (threadIdx.x < 32) cnt[threadIdx.x] = 0;
     __syncthreads();
     uint64_t key[4]; uint32_t rank[4];
@@ -551,7 +573,7 @@ __global__ __launch_bounds__(256) void k_pair_partition(uint32_t n, const uint64
         rank[k] = p < n ? atomicAdd(&cnt[(uint32_t)(key[k] >> 58)], 1u) : 0u;
     }
     __syncthreads();
-    if (threadIdx.x < kNumBuckets) base[threadIdx.x] = cnt[threadIdx.x] ? off.o[threadIdx.x] + atomicAdd(&sc->bucketCursor[threadIdx.x], cnt[threadIdx.x]) : 0u;
+    if (threadIdx.x < kNumBuckets) base[threadIdx.x] = cnt[threadIdx.x] ? sc->bucketOffset[threadIdx.x] + atomicAdd(&sc->bucketCursor[threadIdx.x], cnt[threadIdx.x]) : 0u;
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -586,6 +608,12 @@ __host__ __device__ __forceinline__ int gjkMode(uint32_t ta, uint32_t tb) {
     if (ta == T_CYLINDER && tb == T_AABB) return 1;
     if (ta == T_CYLINDER && tb == T_OBB) return 2;
     return -1;
+}
+
+__host__ __device__ __forceinline__ int gjkModeOfBucket(uint32_t bucket) {
+    uint32_t ta = 0, rem = bucket;
+    while (rem >= 6u - ta) { rem -= 6u - ta; ++ta; }
+    return gjkMode(ta, ta + rem);
 }
 
 __device__ inline bool intersectPair(const Shape& a, const Shape& b, const HullSet& hs, LdsPoly& polyA, LdsPoly& polyB, Manifold& out) {
@@ -628,12 +656,17 @@ __device__ inline bool intersectPair(const Shape& a, const Shape& b, const HullS
     }
 }
 
-__global__ __launch_bounds__(256) void k_narrow(uint32_t numPairs, const uint64_t* __restrict__ pairKeys, const float4* __restrict__ wShape,
+// The pair list is read from `pairsA` (arrival order) or `pairsB` (bucket-partitioned) as StepScalars::partitioned says;
+// lanes in [numPairs, scanLen) zero their scan input so the host can size the launch and the scan from an upper bound.
+__global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, const StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
+                                                const float4* __restrict__ wShape,
                                                 HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
                                                 float4* __restrict__ npPoints) {
     __shared__ float4 polyMem[2 * kLdsPolyVerts * kLdsPolyStride];   // 64 KiB: two clip polygons per lane, [vertex][lane]
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= numPairs) return;
+    const uint32_t numPairs = sc->numPairs;
+    if (p >= numPairs) { if (p < scanLen) npPacked[p] = 0ull; return; }
+    const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
     uint64_t key = pairKeys[p];
     uint32_t bucket = (uint32_t)(key >> 58), a = (uint32_t)((key >> 29) & 0x1FFFFFFFu), b = (uint32_t)(key & 0x1FFFFFFFu);
     // bucket -> (ta, tb)
@@ -666,14 +699,16 @@ __device__ __forceinline__ uint64_t pairPriority(uint32_t a, uint32_t b) {
 
 // After the scans: manifold m <- pair p (count > 0).  colWork = (bodyA | dynA << 31, bodyB | dynB << 31, priority lo, hi):
 // everything a colouring round needs in one 16-byte row.
-__global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t numPairs, uint32_t nb, const uint64_t* __restrict__ pairKeys, const uint64_t* __restrict__ npPacked,
+__global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nb, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB, const uint64_t* __restrict__ npPacked,
                                                         const uint64_t* __restrict__ npScan,
                                                         const float4* __restrict__ aabbMax, const float4* __restrict__ cMaterial,
                                                         const float4* __restrict__ bCogInvMass,
                                                         uint32_t* __restrict__ manPair, uint2* __restrict__ manBodies, uint2* __restrict__ manInfo,
                                                         uint4* __restrict__ colWork, uint32_t* __restrict__ color, StepScalars* sc) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t numPairs = sc->numPairs;
     if (p >= numPairs) return;
+    const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
     uint32_t cnt = (uint32_t)(npPacked[p] & 0xFFFFFFFFull);
     uint64_t sc64 = npScan[p];
     uint32_t m = (uint32_t)(sc64 >> 32), conOff = (uint32_t)(sc64 & 0xFFFFFFFFull);
@@ -703,8 +738,8 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t numPairs, uint3
 // zeroes the dummy body (physics.cpp:1279).  in ~112 B, out 112 B per body.
 __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
                                                           const float4* __restrict__ bCogInvMass, const float4* __restrict__ bInvI,
-                                                          const float4* __restrict__ bParams, float4* __restrict__ bLinVel,
-                                                          float4* __restrict__ bAngVel, float4* __restrict__ bForce, const float4* __restrict__ bTorque,
+                                                          const float4* __restrict__ bParams, const float4* __restrict__ bLinVel,
+                                                          const float4* __restrict__ bAngVel, const float4* __restrict__ bForce, const float4* __restrict__ bTorque,
                                                           float4* __restrict__ gPos, float4* __restrict__ gInvI, float4* __restrict__ gVel) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > nb) return;
@@ -731,8 +766,7 @@ __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt,
     w = w + angAcc * dt;
     v = v * (1.f / (1.f + dt * prm.y));
     w = w * (1.f / (1.f + dt * prm.z));
-    bLinVel[i] = f4(v, 0.f); bAngVel[i] = f4(w, 0.f);
-    bForce[i] = f4(force, 0.f);
+    // persistent body state is NOT touched before k_integrate_velocities: a step can be re-run from scratch
     gPos[i] = f4(pos, invMass);
     gInvI[3 * i] = make_float4(W.m00, W.m01, W.m02, 0.f);
     gInvI[3 * i + 1] = make_float4(W.m10, W.m11, W.m12, 0.f);
@@ -741,14 +775,16 @@ __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt,
 }
 
 // K13 "Integrate rigid body velocities" (src/physics/rigid_body.cpp:126-142).
+// Writes the NEXT body state into the second buffer set (the host swaps the sets once the step is known to be valid).
 __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float dt, const float4* __restrict__ gPos, const float4* __restrict__ gVel,
-                                                              const float4* __restrict__ bCogInvMass, float4* __restrict__ bPos, float4* __restrict__ bRot,
+                                                              const float4* __restrict__ bCogInvMass, const float4* __restrict__ bRotIn,
+                                                              float4* __restrict__ bPos, float4* __restrict__ bRot,
                                                               float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, float4* __restrict__ bForce,
                                                               float4* __restrict__ bTorque) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
     V3 v = xyz(gVel[2 * i]), w = xyz(gVel[2 * i + 1]);
-    Q4 rot = toQ(bRot[i]);
+    Q4 rot = toQ(bRotIn[i]);
     Q4 dq(0.5f * w.x, 0.5f * w.y, 0.5f * w.z, 0.f);
     dq = dq * rot;
     Q4 nr = normalize(Q4(rot.x + dq.x * dt, rot.y + dq.y * dt, rot.z + dq.z * dt, rot.w + dq.w * dt));
@@ -801,12 +837,12 @@ __global__ __launch_bounds__(256) void k_scatter_states(uint32_t n, const uint32
 // top[(r+1) & 1]); a round whose predecessor left nothing uncoloured exits at once, so the host
 // enqueues a fixed batch of rounds without reading anything back in between.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_color_round(uint32_t nm, uint32_t round, const uint4* __restrict__ colWork, uint32_t* __restrict__ color,
+__global__ __launch_bounds__(256) void k_color_round(const StepScalars* __restrict__ sc, uint32_t round, const uint4* __restrict__ colWork, uint32_t* __restrict__ color,
                                                      const unsigned long long* __restrict__ topCur, unsigned long long* __restrict__ topNext,
                                                      unsigned long long* __restrict__ bodyUsed, uint32_t* __restrict__ roundFlags) {
     if (round > 0 && roundFlags[round - 1] == 0) return;
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= nm || color[m] != kUncolored) return;
+    if (m >= sc->numManifolds || color[m] != kUncolored) return;
     uint4 w = colWork[m];
     bool dynA = (w.x >> 31) != 0, dynB = (w.y >> 31) != 0;
     uint32_t bA = w.x & 0x7FFFFFFFu, bB = w.y & 0x7FFFFFFFu;
@@ -838,9 +874,10 @@ __global__ __launch_bounds__(256) void k_color_round(uint32_t nm, uint32_t round
 // (manifolds of one colour share no dynamic body); grouping by contact count makes solver waves uniform.
 constexpr uint32_t kBinItems = 1024;
 __device__ __forceinline__ uint32_t binOf(uint32_t color, uint32_t cnt) { return color * 4u + (cnt - 1u); }
-__global__ __launch_bounds__(256) void k_bin_hist(uint32_t nm, uint32_t numBlocks, const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo,
+__global__ __launch_bounds__(256) void k_bin_hist(const StepScalars* __restrict__ sc, uint32_t numBlocks, const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo,
                                                   uint32_t* __restrict__ blockHist) {
     __shared__ uint32_t h[kColorBins];
+    const uint32_t nm = sc->numManifolds;
     for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) h[b] = 0;
     __syncthreads();
 #pragma unroll
@@ -851,9 +888,11 @@ __global__ __launch_bounds__(256) void k_bin_hist(uint32_t nm, uint32_t numBlock
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) blockHist[(size_t)b * numBlocks + blockIdx.x] = h[b];
 }
-__global__ __launch_bounds__(256) void k_bin_scatter(uint32_t nm, uint32_t numBlocks, const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo,
+__global__ __launch_bounds__(256) void k_bin_scatter(uint32_t lastRound, const uint32_t* __restrict__ roundFlags, uint32_t numBlocks, const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo,
                                                      const uint32_t* __restrict__ blockScan, uint32_t* __restrict__ order, StepScalars* sc) {
     __shared__ uint32_t cur[kColorBins];
+    const uint32_t nm = sc->numManifolds;
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->colorPending = roundFlags[lastRound];
     for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) {
         uint32_t v = blockScan[(size_t)b * numBlocks + blockIdx.x];
         cur[b] = v;
@@ -907,8 +946,43 @@ __device__ __forceinline__ M3 loadM3(const float4* __restrict__ p, uint32_t i) {
     return m;
 }
 
+// Schedule bins -> tiles, on the device (so the host never has to read the bin sizes back before it can launch the
+// constraint kernels): BinInfo per bin, tile -> bin and tile -> (first contact-tile, contacts per manifold) tables, totals.
+// The host launches the consumers over an upper bound of tiles; tiles >= totalTiles exit.
+__global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t ctCap, StepScalars* sc, BinInfo* __restrict__ binInfo,
+                                                     uint32_t* __restrict__ tileBin, uint2* __restrict__ tileDesc) {
+    __shared__ BinInfo bins[kSchedBins];
+    __shared__ uint32_t ok;
+    if (threadIdx.x == 0) {
+        uint32_t tiles = 0, ct = 0;
+        for (uint32_t bn = 0; bn < kSchedBins; ++bn) {
+            bool ovf = bn == kSchedBins - 1;
+            uint32_t s0 = sc->binStart[bn], s1 = ovf ? sc->binStart[kColorBins] : sc->binStart[bn + 1];
+            uint32_t stride = ovf ? 4u : (bn & 3u) + 1u;
+            BinInfo bi; bi.slotStart = s0; bi.count = s1 - s0; bi.tileStart = tiles; bi.ctStart = ct;
+            uint32_t nt = (bi.count + 63u) >> 6;
+            tiles += nt; ct += nt * stride;
+            bins[bn] = bi;
+        }
+        ok = (tiles <= tilesCap && ct <= ctCap) ? 1u : 0u;
+        sc->totalTiles = ok ? tiles : 0u; sc->totalCt = ok ? ct : 0u;
+        if (!ok) sc->specOverflow = 1u;
+    }
+    __syncthreads();
+    for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) binInfo[bn] = bins[bn];
+    if (!ok) return;
+    for (uint32_t bn = 0; bn < kSchedBins; ++bn) {
+        BinInfo bi = bins[bn];
+        uint32_t nt = (bi.count + 63u) >> 6, stride = bn == kSchedBins - 1 ? 4u : (bn & 3u) + 1u;
+        for (uint32_t t = threadIdx.x; t < nt; t += blockDim.x) {
+            tileBin[bi.tileStart + t] = bn;
+            tileDesc[bi.tileStart + t] = make_uint2(bi.ctStart + t * stride, stride);
+        }
+    }
+}
+
 // K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379): one wave per tile, one lane per slot.
-__global__ __launch_bounds__(64) void k_contact_init(uint32_t dummyBody, float dt, const uint32_t* __restrict__ tileBin, const BinInfo* __restrict__ binInfo,
+__global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restrict__ sc, uint32_t dummyBody, float dt, const uint32_t* __restrict__ tileBin, const BinInfo* __restrict__ binInfo,
                                                      const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ manPair, const uint2* __restrict__ manBodies,
                                                      const uint2* __restrict__ manInfo, const float4* __restrict__ npNormal,
@@ -918,6 +992,7 @@ __global__ __launch_bounds__(64) void k_contact_init(uint32_t dummyBody, float d
                                                      float4* __restrict__ rows, float4* __restrict__ imp, uint4* __restrict__ slotMeta,
                                                      float4* __restrict__ slotNormal, float2* __restrict__ slotMass) {
     uint32_t tile = blockIdx.x, lane = threadIdx.x;
+    if (tile >= sc->totalTiles) return;
     uint32_t bin = tileBin[tile];
     BinInfo bi = binInfo[bin];
     uint32_t tl = tile - bi.tileStart, j = tl * 64u + lane;
@@ -1138,30 +1213,7 @@ constexpr uint32_t kSpinBudget = 1u << 16;
 #ifndef MI_FLOW_WAVES
 #define MI_FLOW_WAVES 1   // resident waves per SIMD the flow kernel is compiled for (measured: 1 = 0.86 ms, 2 = 1.02 ms per 20 sweeps at 262144 bodies)
 #endif
-#ifdef MI_FLOW_TRACE   // development: per-wave timestamps (100 MHz wall clock) at 6 points of flowTile, [block][8] uint64
-#define MI_TRACE_PARAM , unsigned long long* trace, uint32_t dbg
-#define MI_TRACE_ARG , trace, dbg
-#define MI_TRACE(i) if (lane == 0 && trace) trace[(size_t)blockIdx.x * 8u + (i)] = wall_clock64();
-#define MI_DBG(bit) ((dbg >> (bit)) & 1u)
-#else
-#define MI_TRACE_PARAM
-#define MI_TRACE_ARG
-#define MI_TRACE(i)
-#define MI_DBG(bit) 0u
-#endif
 
-__device__ __forceinline__ void loadBodySc1(const float4* p, f32x4& h0, f32x4& h1) {
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(h0), "=&v"(h1) : "v"(p) : "memory");
-}
-__device__ __forceinline__ void loadBodies2Sc1(const float4* pa, const float4* pb, f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1) {
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %4, off offset:16 sc1\n\t"
-                 "global_load_dwordx4 %2, %5, off sc1\n\tglobal_load_dwordx4 %3, %5, off offset:16 sc1\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(pa), "v"(pb) : "memory");
-}
-__device__ __forceinline__ void storeBodySc1(float4* p, f32x4 h0, f32x4 h1) {
-    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" : : "v"(p), "v"(h0), "v"(h1) : "memory");
-}
 // single 16-byte granule: issue only (the next waiting asm block lands it), load + wait, store
 __device__ __forceinline__ void issueGranuleSc1(const float4* p, f32x4& g) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(g) : "v"(p) : "memory"); }
 __device__ __forceinline__ void landed(f32x4& g) { asm volatile("" : "+v"(g)); }   // orders every later use of g behind the waiting block
@@ -1215,8 +1267,7 @@ __device__ __forceinline__ void storePairSc1(const PairBody& X, bool odd, bool n
 template <int CNT>
 __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_t lane, uint32_t it, const uint4* __restrict__ slotMeta,
                                          const float4* __restrict__ slotNormal, const float2* __restrict__ slotMass,
-                                         const float4* __restrict__ rows, float4* imp, float4* gVel, StepScalars* sc MI_TRACE_PARAM) {
-    MI_TRACE(0)
+                                         const float4* __restrict__ rows, float4* imp, float4* gVel, StepScalars* sc) {
     const uint4 meta = slotMeta[(size_t)tile * 64u + lane];
     const float4 nf = slotNormal[(size_t)tile * 64u + lane];
     const float2 mass = slotMass[(size_t)tile * 64u + lane];
@@ -1241,10 +1292,8 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
     f32x4 ig[CNT], a0, a1, b0, b1;
     const bool odd = (lane & 1u) != 0u;
     const PairBody PA(pA, odd), PB(pB, odd);
-    MI_TRACE(1)
 #pragma unroll
     for (int k = 0; k < CNT; ++k) issueGranuleSc1(pI + (size_t)k * 64u, ig[k]);
-    if (MI_DBG(7)) loadBodies2Sc1(pA, pB, a0, a1, b0, b1); else
     {
         f32x4 ra0, ra1, rb0, rb1;
         loadPair4Sc1(PA, PB, ra0, ra1, rb0, rb1);
@@ -1253,40 +1302,17 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
     }
 #pragma unroll
     for (int k = 0; k < CNT; ++k) landed(ig[k]);
-#ifdef MI_FLOW_TRACE
-    if (MI_DBG(9)) {   // cross-check the pair loads against plain per-lane loads
-        f32x4 x0, x1, y0, y1;
-        loadBodies2Sc1(pA, pB, x0, x1, y0, y1);
-        bool sameTagA = __float_as_uint(x0.w) == __float_as_uint(a0.w) && __float_as_uint(x1.w) == __float_as_uint(a1.w);
-        bool sameA = x0.x == a0.x && x0.y == a0.y && x0.z == a0.z && x1.x == a1.x && x1.y == a1.y && x1.z == a1.z;
-        bool sameTagB = __float_as_uint(y0.w) == __float_as_uint(b0.w) && __float_as_uint(y1.w) == __float_as_uint(b1.w);
-        bool sameB = y0.x == b0.x && y0.y == b0.y && y0.z == b0.z && y1.x == b1.x && y1.y == b1.y && y1.z == b1.z;
-        if (valid && sameTagA && !sameA) atomicAdd(&sc->bucketCursor[1], 1u);
-        if (valid && !sameTagA) atomicAdd(&sc->bucketCursor[2], 1u);
-        if (valid && sameTagB && !sameB) atomicAdd(&sc->bucketCursor[3], 1u);
-        if (valid && !sameTagB) atomicAdd(&sc->bucketCursor[4], 1u);
-        if (valid) atomicAdd(&sc->bucketCursor[5], 1u);
-        a0 = x0; a1 = x1; b0 = y0; b1 = y1;
-    }
-#endif
-    MI_TRACE(2)
     bool okA = !needA || (__float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA);
     bool okB = !needB || (__float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB);
     bool okI = true;
 #pragma unroll
     for (int k = 0; k < CNT; ++k) okI = okI && (!live || __float_as_uint(ig[k].z) == it);
     uint32_t budget = kSpinBudget;
-    if (MI_DBG(4)) { okA = true; okB = true; okI = true; }
     while (__ballot(!(okA && okB && okI)) != 0ull) {   // tight polling measured fastest: only the pairs still waiting re-load
         // both lanes of a pair must poll together; the partner flags are exchanged OUTSIDE any short-circuit so every lane
         // takes part in the swap (inside `!okA || swap(...)` the swap would run with only the ready lanes active)
         const uint32_t partnerOkA = swz1(okA ? 1u : 0u), partnerOkB = swz1(okB ? 1u : 0u);
         bool pollA = !okA || partnerOkA == 0u, pollB = !okB || partnerOkB == 0u;
-        if (MI_DBG(7)) {
-            if (!okA) { loadBodySc1(pA, a0, a1); okA = __float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA; }
-            if (!okB) { loadBodySc1(pB, b0, b1); okB = __float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB; }
-            pollA = false; pollB = false;
-        }
         if (pollA) {
             f32x4 r0, r1, g0, g1;
             loadPair2Sc1(PA, r0, r1);
@@ -1306,7 +1332,6 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
         }
         if (--budget == 0u) { sc->solveError = 1u; break; }
     }
-    MI_TRACE(3)
     V3 vA(a0.x, a0.y, a0.z), wA(a1.x, a1.y, a1.z), vB(b0.x, b0.y, b0.z), wB(b1.x, b1.y, b1.z);
     float2 out[CNT];
 #pragma unroll
@@ -1315,40 +1340,38 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
         solveOne(c[k], nf, im, imA, imB, vA, wA, vB, wB);
         out[k] = im;
     }
-    MI_TRACE(4)
     // publish: bodies first (they are on the dependency chain), then the impulses; nothing to wait for afterwards
-    if (!MI_DBG(5)) {
+    {
         float tA = __uint_as_float(expA + 1u), tB = __uint_as_float(expB + 1u);
         f32x4 hA0 = {vA.x, vA.y, vA.z, tA}, hA1 = {wA.x, wA.y, wA.z, tA}, hB0 = {vB.x, vB.y, vB.z, tB}, hB1 = {wB.x, wB.y, wB.z, tB};
-        if (MI_DBG(8)) { if (needA) storeBodySc1(pA, hA0, hA1); if (needB) storeBodySc1(pB, hB0, hB1); } else {
         storePairSc1(PA, odd, needA, hA0, hA1);
-        storePairSc1(PB, odd, needB, hB0, hB1); }
+        storePairSc1(PB, odd, needB, hB0, hB1);
     }
-    if (live && !MI_DBG(0)) {
+    if (live) {
         float t = __uint_as_float(it + 1u);
 #pragma unroll
         for (int k = 0; k < CNT; ++k) {
             f32x4 g = {out[k].x, out[k].y, t, 0.f};
-            if (MI_DBG(6)) __builtin_nontemporal_store(g, (f32x4*)(pI + (size_t)k * 64u)); else
             storeGranuleSc1(pI + (size_t)k * 64u, g);
         }
     }
-    MI_TRACE(5)
 }
 
-// Block b runs sweep itBase + b / numTiles of tile b % numTiles (schedule order, colour-major): with no joints between the
+// Block b runs sweep itBase + b / numTiles of tile b % numTiles (numTiles = StepScalars::totalTiles; schedule order, colour-major): with no joints between the
 // sweeps ALL iterations are one launch, so the latency-bound small colours of sweep i overlap the bandwidth-bound large
 // colours of sweep i + 1.  tileDesc[tile] = (first contact-tile, contacts per manifold).
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_WAVES))) void k_contact_solve_flow(
-    uint32_t itBase, uint32_t numTiles, const uint2* __restrict__ tileDesc, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
-    const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* imp, float4* gVel, StepScalars* sc MI_TRACE_PARAM) {
+    uint32_t itBase, uint32_t sweeps, const uint2* __restrict__ tileDesc, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
+    const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* imp, float4* gVel, StepScalars* sc) {
+    const uint32_t numTiles = sc->totalTiles;   // the grid is sized from an upper bound: surplus workgroups (all at the end) exit
+    if (blockIdx.x >= numTiles * sweeps) return;
     const uint32_t it = itBase + blockIdx.x / numTiles, tile = blockIdx.x % numTiles, lane = threadIdx.x;
     const uint2 d = tileDesc[tile];
     switch (d.y) {
-        case 1: flowTile<1>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc MI_TRACE_ARG); break;
-        case 2: flowTile<2>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc MI_TRACE_ARG); break;
-        case 3: flowTile<3>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc MI_TRACE_ARG); break;
-        default: flowTile<4>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc MI_TRACE_ARG); break;
+        case 1: flowTile<1>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc); break;
+        case 2: flowTile<2>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc); break;
+        case 3: flowTile<3>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc); break;
+        default: flowTile<4>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc); break;
     }
 }
 

@@ -84,6 +84,7 @@ struct mi_world {
 
     // device: bodies
     DBuf<float4> bPos, bRot, bLinVel, bAngVel, bForce, bTorque, bCogInvMass, bInvI, bParams;
+    DBuf<float4> bPosN, bRotN, bLinVelN, bAngVelN, bForceN, bTorqueN;   // second body-state set: written by k_integrate_velocities, swapped in when a step is valid
     DBuf<float4> gPos, gInvI, gVel;
     // device: colliders
     DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cMaterial;
@@ -103,12 +104,9 @@ struct mi_world {
     DBuf<uint32_t> color, order, orderTmp, roundFlags, blockHist, blockScan, tileBin; DBuf<unsigned long long> bodyTop, bodyUsed;
     DBuf<BinInfo> binInfo;
     DBuf<float4> rows, slotNormal; DBuf<float4> imp; DBuf<float2> slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc;
-    uint2* hTileDesc = nullptr;
     bool usedFlow = false;
     uint32_t flowLds = 0;                  // dynamic LDS bytes per 64-lane workgroup: caps resident waves per CU (160 KiB / flowLds)
     bool flowSolver = true;               // dataflow PGS sweep (one launch per iteration); MI_SOLVER=launch selects one launch per colour
-    BinInfo* hBinInfo = nullptr;          // pinned staging: kSchedBins BinInfo + tile -> bin table
-    uint32_t* hTileBin = nullptr; size_t hTileBinCap = 0;
     BinInfo bins[kSchedBins]{};           // host copy of the last step's schedule
     uint32_t totalTiles = 0;
     bool xcdSwizzle = false;
@@ -117,7 +115,7 @@ struct mi_world {
     mi_step_counts counts{};
     mi_stage_times times{};
     hipEvent_t ev[10]{};
-    uint32_t numColorsUsed = 0, colorRounds = 0, solveLaunches = 0;
+    uint32_t numColorsUsed = 0, solveLaunches = 0;
     bool profileSolve = false;            // per-launch HIP events around k_contact_solve (mi_world_step_profiled)
     std::vector<hipEvent_t> profEvents;   // pairs
     uint32_t profLaunches = 0; float profKernelMs = 0.f; uint64_t profSlots = 0, profContacts = 0;
@@ -131,6 +129,13 @@ struct mi_world {
     int upload();
     int download();
     int stepInternal(const mi_step_settings& s, float dt);
+    int runStep(const mi_step_settings& s, float dt, bool speculative);
+    void mirrorSchedule();
+    // speculative (single read-back) stepping: upper bounds come from the last valid step
+    struct LastCounts { uint32_t numPairs = 0, numManifolds = 0, numContacts = 0, numCells = 0, colorRounds = 0; } last;
+    bool specEnabled = true, haveEstimates = false;
+    uint32_t specRetries = 0, colorRoundsLaunched = 0;
+    uint32_t sapAxis = 0;        // sorting axis for the next step (collision_broad.cpp:443-444), host copy
     int ensureTemp(size_t bytes) { return temp.ensure(bytes) == hipSuccess ? MI_OK : MI_ERR_OUT_OF_MEMORY; }
 };
 
@@ -146,21 +151,19 @@ int mi_world::init(int dev) {
     HIP_TRY(grid.ensure(1));
     HIP_TRY(shards.ensure(1));
     HIP_TRY(hipMemsetAsync(scalars.p, 0, sizeof(StepScalars), stream));
-    HIP_TRY(hipHostMalloc((void**)&hBinInfo, kSchedBins * sizeof(BinInfo)));
     HIP_TRY(binInfo.ensure(kSchedBins));
     HIP_TRY(roundFlags.ensure(kMaxColorRounds + 2));
     const char* sw = getenv("MI_XCD_SWIZZLE");
     xcdSwizzle = sw && sw[0] == '1';
     const char* sv = getenv("MI_SOLVER");
     flowSolver = !(sv && std::string(sv) == "launch");
+    const char* as = getenv("MI_ASYNC");
+    specEnabled = !(as && as[0] == '0');
     if (const char* fl = getenv("MI_FLOW_LDS")) flowLds = (uint32_t)strtoul(fl, nullptr, 0);
     if (flowLds > 65536) (void)hipFuncSetAttribute((const void*)k_contact_solve_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flowLds);
     return MI_OK;
 }
 mi_world::~mi_world() {
-    if (hBinInfo) (void)hipHostFree(hBinInfo);
-    if (hTileBin) (void)hipHostFree(hTileBin);
-    if (hTileDesc) (void)hipHostFree(hTileDesc);
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
     for (auto& e : profEvents) (void)hipEventDestroy(e);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -314,6 +317,8 @@ int mi_world::upload() {
     } while (0)
     UP(bPos, pos, nb); UP(bRot, rot, nb); UP(bLinVel, lv, nb); UP(bAngVel, av, nb); UP(bForce, fo, nb); UP(bTorque, to, nb);
     UP(bCogInvMass, cim, nb); UP(bInvI, ii, 3 * (size_t)nb); UP(bParams, prm, nb);
+    { size_t n1 = std::max<size_t>(nb, 1);
+      HIP_TRY(bPosN.ensure(n1)); HIP_TRY(bRotN.ensure(n1)); HIP_TRY(bLinVelN.ensure(n1)); HIP_TRY(bAngVelN.ensure(n1)); HIP_TRY(bForceN.ensure(n1)); HIP_TRY(bTorqueN.ensure(n1)); }
     HIP_TRY(gPos.ensure(nb + 1)); HIP_TRY(gInvI.ensure(3 * ((size_t)nb + 1))); HIP_TRY(gVel.ensure(2 * ((size_t)nb + 1)));
     HIP_TRY(bodyTop.ensure(2 * ((size_t)nb + 1))); HIP_TRY(bodyUsed.ensure(nb + 1));
 
@@ -395,43 +400,65 @@ __global__ void k_reset_pair_counters(StepScalars* sc) {
     if (t < 24) sc->bucketHist[t] = 0;
 }
 
+// One internal step.  Two ways to run it:
+//   * synchronous: the host reads the pair count, the manifold count and the schedule back as they appear and sizes
+//     every buffer and launch exactly (first step, after a topology change, per-colour solver path, or as the retry);
+//   * speculative (default for every later step): no read-back until the very end.  Every kernel takes its sizes from
+//     StepScalars on the device; the host only needs UPPER BOUNDS for launch grids, scan lengths and capacities, and
+//     takes them from the previous step's counts (+12.5 %).  The end-of-step read-back validates the bounds (and that
+//     the colouring converged, no overflow colour appeared, ...).  Nothing persistent is modified before
+//     k_integrate_velocities, which writes into the second body-state buffer set, so an invalid speculation is simply
+//     re-run synchronously from the untouched state.  This removes ~0.35 ms of idle GPU time per step at 262144 bodies.
+enum { STEP_RETRY = 1 };
+
 int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     HIP_TRY(hipSetDevice(device));
-    if (topologyDirty) { int rc = download(); if (rc != MI_OK) return rc; rc = upload(); if (rc != MI_OK) return rc; }
+    if (topologyDirty) { int rc = download(); if (rc != MI_OK) return rc; rc = upload(); if (rc != MI_OK) return rc; haveEstimates = false; }
+    if (bodies.empty()) return MI_OK;
+    const bool spec = specEnabled && haveEstimates && flowSolver;
+    int rc = runStep(settings, dt, spec);
+    if (rc == STEP_RETRY) { ++specRetries; rc = runStep(settings, dt, false); }
+    return rc;
+}
+
+int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     const uint32_t nb = (uint32_t)bodies.size(), nc = (uint32_t)colliders.size();
-    if (nb == 0) return MI_OK;
     const uint32_t B = 256;
     StepScalars* sc = scalars.p;
     hipStream_t st = stream;
     int evi = 0;
     auto mark = [&]() { (void)hipEventRecord(ev[evi++], st); };
+    auto bound = [](uint32_t last, uint32_t slack) { return last + last / 8u + slack; };
+    auto readScalars = [&]() -> int { HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); return MI_OK; };
 
     mark();  // 0
     k_reset_scalars<<<1, 128, 0, st>>>(sc);
-    uint32_t numPairs = 0;
     if (nc) {
         k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
-                                                     wShape.p, aabbMin.p, aabbMax.p, sc);
+                                                     wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis);
     }
     mark();  // 1
+    // ---------------------------------------------------------------------------------------------- broad phase
+    uint32_t pairBound = 0;   // upper bound of this step's collision pairs that launches / scans are sized for
     if (nc) {
         uint32_t nblk = divUp(nc, 256);
+        // the cell table (histogram + scan) covers cellCap cells; k_bp_grid_setup enlarges the cells if the grid would need more
+        const uint32_t cellCap = spec ? std::min<uint32_t>(kMaxCells, std::max<uint32_t>(1u << 16, 2u * last.numCells)) : kMaxCells;
         HIP_TRY(hipMemsetAsync(shards.p, 0, sizeof(Shards), st));
         k_axis_partials<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, axisPartials.p, shards.p);
         k_bp_threshold<<<1, 256, 0, st>>>(nc, shards.p, sc);
         k_bp_classify<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, sc, largeList.p, isLarge.p, blockBounds.p);
-        k_bp_grid_setup<<<1, 256, 0, st>>>(nc, nblk, blockBounds.p, sc, grid.p);
-        // cell histogram -> exclusive prefix (cellLower).  The scan always covers the capped table (16 MB): its
-        // length must be known on the host and the real cell count only exists on the device.
-        HIP_TRY(hipMemsetAsync(cellCount.p, 0, (size_t)lastNumCells * sizeof(uint32_t), st));
+        k_bp_grid_setup<<<1, 256, 0, st>>>(nc, nblk, cellCap, blockBounds.p, sc, grid.p);
+        HIP_TRY(hipMemsetAsync(cellCount.p, 0, (size_t)cellCap * sizeof(uint32_t), st));
         HIP_TRY(hipMemsetAsync(cellKeysS.p, 0xFF, ((size_t)nc + 1) * sizeof(uint32_t), st));
         k_bp_cell_ids<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, isLarge.p, grid.p, cellKeys.p, cellRanks.p, cellCount.p);
         size_t tb = 0;
-        HIP_TRY(rocprim::exclusive_scan(nullptr, tb, cellCount.p, cellLower.p, 0u, (size_t)lastNumCells, rocprim::plus<uint32_t>(), st));
+        HIP_TRY(rocprim::exclusive_scan(nullptr, tb, cellCount.p, cellLower.p, 0u, (size_t)cellCap, rocprim::plus<uint32_t>(), st));
         if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
-        HIP_TRY(rocprim::exclusive_scan(temp.p, tb, cellCount.p, cellLower.p, 0u, (size_t)lastNumCells, rocprim::plus<uint32_t>(), st));
+        HIP_TRY(rocprim::exclusive_scan(temp.p, tb, cellCount.p, cellLower.p, 0u, (size_t)cellCap, rocprim::plus<uint32_t>(), st));
         k_bp_scatter_sorted<<<divUp(nc, B), B, 0, st>>>(nc, cellKeys.p, cellRanks.p, cellLower.p, aabbMin.p, aabbMax.p, cellKeysS.p, cellValsS.p, sMin.p, sMax.p);
         if (pairKeys.cap == 0) { HIP_TRY(pairKeys.ensure(std::max<size_t>(1u << 16, 8 * (size_t)nc))); }
+        if (spec) { HIP_TRY(pairKeys.ensure(bound(last.numPairs, 4096))); }
         for (int attempt = 0; attempt < 2; ++attempt) {
             uint32_t cap = (uint32_t)std::min<size_t>(pairKeys.cap, 0x7FFFFFFFu);
             const uint32_t bpc = divUp(nc, kGridChunks * 256u);
@@ -439,241 +466,210 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
             k_bp_pairs_large<<<dim3(std::min(divUp(nc, B), 256u), 16), B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc, shards.p);
             k_pair_totals<<<1, 32, 0, st>>>(shards.p, sc);
             if (attempt == 0) k_axis_final<<<1, 256, 0, st>>>(nc, nblk, axisPartials.p, sc);
-            HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            numPairs = hs.numPairs;
-            if (numPairs <= cap) break;
-            HIP_TRY(pairKeys.ensure((size_t)numPairs + numPairs / 4));   // overflow: grow and redo the pair pass
+            if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
+            int rc = readScalars(); if (rc != MI_OK) return rc;
+            pairBound = hs.numPairs;
+            if (pairBound <= cap) break;
+            HIP_TRY(pairKeys.ensure((size_t)pairBound + pairBound / 4));   // overflow: grow and redo the pair pass
             k_reset_pair_counters<<<1, 32, 0, st>>>(sc);
             HIP_TRY(hipMemsetAsync(shards.p, 0, sizeof(ShardCounters) * kShards, st));
         }
     }
     mark();  // 2
-    uint32_t nm = 0, ncon = 0;
-    pairsIn = pairKeys.p;
-    if (numPairs) {
-        // bucket partition (type-uniform narrow-phase waves); skipped when a single bucket is populated
-        uint32_t nonEmpty = 0, gjkLo = numPairs, gjkHi = 0, off = 0;
-        BucketOffsets bo{};
-        for (uint32_t bk = 0; bk < kNumBuckets; ++bk) {
-            bo.o[bk] = off;
-            uint32_t n = hs.bucketHist[bk];
-            if (n) {
-                ++nonEmpty;
-                uint32_t ta = 0, rem = bk;
-                while (rem >= 6u - ta) { rem -= 6u - ta; ++ta; }
-                if (gjkMode(ta, ta + rem) >= 0) { gjkLo = std::min(gjkLo, off); gjkHi = std::max(gjkHi, off + n); }
-            }
-            off += n;
-        }
-        if (nonEmpty > 1) {
-            HIP_TRY(pairKeysS.ensure(pairKeys.cap));
-            k_pair_partition<<<divUp(numPairs, 1024), 256, 0, st>>>(numPairs, pairKeys.p, pairKeysS.p, bo, sc);
-            pairsIn = pairKeysS.p;
-        }
-        HIP_TRY(npPacked.ensure(numPairs)); HIP_TRY(npScan.ensure(numPairs)); HIP_TRY(npNormal.ensure(numPairs)); HIP_TRY(npPoints.ensure(4 * (size_t)numPairs));
-        HIP_TRY(manPair.ensure(numPairs)); HIP_TRY(manBodies.ensure(numPairs)); HIP_TRY(manInfo.ensure(numPairs));
-        HIP_TRY(colWork.ensure(numPairs)); HIP_TRY(color.ensure(numPairs));
+    // ---------------------------------------------------------------------------------------------- narrow phase
+    if (pairBound) {
+        k_pair_ranges<<<1, 32, 0, st>>>(sc);
+        HIP_TRY(pairKeysS.ensure(pairKeys.cap));
+        k_pair_partition<<<divUp(pairBound, 1024), 256, 0, st>>>(pairKeys.p, pairKeysS.p, sc);
+        HIP_TRY(npPacked.ensure(pairBound)); HIP_TRY(npScan.ensure(pairBound)); HIP_TRY(npNormal.ensure(pairBound)); HIP_TRY(npPoints.ensure(4 * (size_t)pairBound));
+        HIP_TRY(manPair.ensure(pairBound)); HIP_TRY(manBodies.ensure(pairBound)); HIP_TRY(manInfo.ensure(pairBound));
+        HIP_TRY(colWork.ensure(pairBound)); HIP_TRY(color.ensure(pairBound));
         HullSet hset{hullVerts.p, hullRanges.p};
-        k_narrow<<<divUp(numPairs, B), B, 0, st>>>(numPairs, pairsIn, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
-        if (gjkHi > gjkLo)
-            k_narrow_gjk<<<divUp(gjkHi - gjkLo, 64), 64, 0, st>>>(gjkLo, gjkHi, pairsIn, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
+        k_narrow<<<divUp(pairBound, B), B, 0, st>>>(pairBound, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
+        if (usesGjk) k_narrow_gjk<<<divUp(pairBound, 64), 64, 0, st>>>(sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
         size_t tb = 0;
-        HIP_TRY(rocprim::exclusive_scan(nullptr, tb, npPacked.p, npScan.p, (uint64_t)0, numPairs, rocprim::plus<uint64_t>(), st));
+        HIP_TRY(rocprim::exclusive_scan(nullptr, tb, npPacked.p, npScan.p, (uint64_t)0, pairBound, rocprim::plus<uint64_t>(), st));
         if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
-        HIP_TRY(rocprim::exclusive_scan(temp.p, tb, npPacked.p, npScan.p, (uint64_t)0, numPairs, rocprim::plus<uint64_t>(), st));
-        k_emit_manifolds<<<divUp(numPairs, B), B, 0, st>>>(numPairs, nb, pairsIn, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
-                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p, sc);
+        HIP_TRY(rocprim::exclusive_scan(temp.p, tb, npPacked.p, npScan.p, (uint64_t)0, pairBound, rocprim::plus<uint64_t>(), st));
+        k_emit_manifolds<<<divUp(pairBound, B), B, 0, st>>>(nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
+                                                        manPair.p, manBodies.p, manInfo.p, colWork.p, color.p, sc);
     }
     mark();  // 3
     k_integrate_forces<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p,
                                                        gPos.p, gInvI.p, gVel.p);
     mark();  // 4
-    numColorsUsed = 0; totalTiles = 0;
-    for (auto& b_ : bins) b_ = BinInfo{0, 0, 0, 0};
-    if (numPairs) {
-        HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        nm = hs.numManifolds; ncon = hs.numContacts;
+    // ---------------------------------------------------------------------------------------------- schedule
+    uint32_t nmBound = 0, conBound = 0;
+    if (pairBound) {
+        if (spec) { nmBound = std::min(pairBound, bound(last.numManifolds, 1024)); conBound = bound(last.numContacts, 4096); }
+        else { int rc = readScalars(); if (rc != MI_OK) return rc; nmBound = hs.numManifolds; conBound = hs.numContacts; }
     }
-    uint32_t totalCt = 0;
-    if (nm) {
-        HIP_TRY(order.ensure(nm)); HIP_TRY(orderTmp.ensure(nm));
-        const uint32_t binBlocks = divUp(nm, kBinItems);
+    uint32_t tilesCap = 0, ctCap = 0;
+    uint32_t colorBatch = spec ? std::min<uint32_t>(96u, std::max<uint32_t>(12u, last.colorRounds + 6u)) : 20u;   // converged rounds exit at once (~2 us each)
+    if (nmBound) {
+        tilesCap = divUp(nmBound, 64) + kSchedBins + 8; ctCap = divUp(conBound, 64) + 4 * kSchedBins + 8;
+        HIP_TRY(order.ensure(nmBound)); HIP_TRY(orderTmp.ensure(nmBound));
+        const uint32_t binBlocks = divUp(nmBound, kBinItems);
         HIP_TRY(blockHist.ensure((size_t)kColorBins * binBlocks)); HIP_TRY(blockScan.ensure((size_t)kColorBins * binBlocks));
+        HIP_TRY(tileBin.ensure(tilesCap)); HIP_TRY(tileDesc.ensure(tilesCap));
         HIP_TRY(hipMemsetAsync(bodyTop.p, 0, 2 * ((size_t)nb + 1) * sizeof(unsigned long long), st));
         HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, ((size_t)nb + 1) * sizeof(unsigned long long), st));
         HIP_TRY(hipMemsetAsync(roundFlags.p, 0, (kMaxColorRounds + 2) * sizeof(uint32_t), st));
         unsigned long long* top[2] = {bodyTop.p, bodyTop.p + (nb + 1)};
-        uint32_t round = 0, batch = 20;
+        uint32_t round = 0;
         while (true) {
-            for (uint32_t r = 0; r < batch; ++r, ++round)
-                k_color_round<<<divUp(nm, B), B, 0, st>>>(nm, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlags.p);
-            // schedule bins (speculative: valid once the last round left nothing uncoloured)
-            k_bin_hist<<<binBlocks, 256, 0, st>>>(nm, binBlocks, color.p, manInfo.p, blockHist.p);
+            for (uint32_t r = 0; r < colorBatch; ++r, ++round)
+                k_color_round<<<divUp(nmBound, B), B, 0, st>>>(sc, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlags.p);
+            // schedule bins -> tiles (valid once the last round left nothing uncoloured: StepScalars::colorPending)
+            k_bin_hist<<<binBlocks, 256, 0, st>>>(sc, binBlocks, color.p, manInfo.p, blockHist.p);
             size_t tb = 0;
             HIP_TRY(rocprim::exclusive_scan(nullptr, tb, blockHist.p, blockScan.p, 0u, (size_t)kColorBins * binBlocks, rocprim::plus<uint32_t>(), st));
             if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
             HIP_TRY(rocprim::exclusive_scan(temp.p, tb, blockHist.p, blockScan.p, 0u, (size_t)kColorBins * binBlocks, rocprim::plus<uint32_t>(), st));
-            k_bin_scatter<<<binBlocks, 256, 0, st>>>(nm, binBlocks, color.p, manInfo.p, blockScan.p, order.p, sc);
-            uint32_t lastFlag = 1;
-            HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(&lastFlag, roundFlags.p + (round - 1), sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
-            if (lastFlag == 0) break;
+            k_bin_scatter<<<binBlocks, 256, 0, st>>>(round - 1, roundFlags.p, binBlocks, color.p, manInfo.p, blockScan.p, order.p, sc);
+            k_build_tiles<<<1, 256, 0, st>>>(tilesCap, ctCap, sc, binInfo.p, tileBin.p, tileDesc.p);
+            if (spec) break;
+            int rc = readScalars(); if (rc != MI_OK) return rc;
+            if (hs.colorPending == 0) break;
             if (round + 8 > kMaxColorRounds) return fail(MI_ERR_DEVICE, "colouring did not converge");
-            batch = 8;
+            colorBatch = 8;
         }
-        colorRounds = round;
-        // bins -> tiles
-        uint32_t tiles = 0;
-        for (uint32_t bn = 0; bn < kSchedBins; ++bn) {
-            bool ovf = bn == kSchedBins - 1;
-            uint32_t s0 = hs.binStart[bn], s1 = ovf ? hs.binStart[kColorBins] : hs.binStart[bn + 1];
-            uint32_t stride = ovf ? 4u : (bn & 3u) + 1u;
-            BinInfo bi{s0, s1 - s0, tiles, totalCt};
-            uint32_t nt = divUp(bi.count, 64);
-            tiles += nt; totalCt += nt * stride;
-            bins[bn] = bi;
-            if (bi.count) numColorsUsed = std::max(numColorsUsed, (ovf ? kOverflowColor : bn / 4u) + 1u);
-        }
-        totalTiles = tiles;
-        if (hTileBinCap < tiles) {
-            if (hTileBin) (void)hipHostFree(hTileBin);
-            if (hTileDesc) (void)hipHostFree(hTileDesc);
-            hTileBin = nullptr; hTileDesc = nullptr;
-            hTileBinCap = (size_t)tiles + tiles / 2 + 64;
-            HIP_TRY(hipHostMalloc((void**)&hTileBin, hTileBinCap * sizeof(uint32_t)));
-            HIP_TRY(hipHostMalloc((void**)&hTileDesc, hTileBinCap * sizeof(uint2)));
-        }
-        for (uint32_t bn = 0; bn < kSchedBins; ++bn) {
-            hBinInfo[bn] = bins[bn];
-            uint32_t nt = divUp(bins[bn].count, 64);
-            uint32_t stride = bn == kSchedBins - 1 ? 4u : (bn & 3u) + 1u;
-            for (uint32_t t = 0; t < nt; ++t) {
-                hTileBin[bins[bn].tileStart + t] = bn;
-                hTileDesc[bins[bn].tileStart + t] = make_uint2(bins[bn].ctStart + t * stride, stride);
+        colorRoundsLaunched = round;
+        if (!spec) {
+            mirrorSchedule();
+            const BinInfo& ob = bins[kSchedBins - 1];
+            if (ob.count > 1) {   // overflow colour: sequential solve in ascending pair-key order
+                HIP_TRY(hipMemcpyAsync(orderTmp.p + ob.slotStart, order.p + ob.slotStart, ob.count * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+                k_sort_overflow<<<1, 256, 0, st>>>(ob.slotStart, ob.count, manPair.p, hs.partitioned ? pairKeysS.p : pairKeys.p, orderTmp.p, order.p);
             }
-        }
-        HIP_TRY(tileBin.ensure(hTileBinCap)); HIP_TRY(tileDesc.ensure(hTileBinCap));
-        HIP_TRY(hipMemcpyAsync(binInfo.p, hBinInfo, kSchedBins * sizeof(BinInfo), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(tileBin.p, hTileBin, (size_t)tiles * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipMemcpyAsync(tileDesc.p, hTileDesc, (size_t)tiles * sizeof(uint2), hipMemcpyHostToDevice, st));
-        const BinInfo& ob = bins[kSchedBins - 1];
-        if (ob.count > 1) {   // overflow colour: sequential solve in ascending pair-key order
-            HIP_TRY(hipMemcpyAsync(orderTmp.p + ob.slotStart, order.p + ob.slotStart, ob.count * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-            k_sort_overflow<<<1, 256, 0, st>>>(ob.slotStart, ob.count, manPair.p, pairsIn, orderTmp.p, order.p);
         }
     }
     mark();  // 5
-    if (nm) {
-        HIP_TRY(slotMeta.ensure((size_t)totalTiles * 64)); HIP_TRY(slotNormal.ensure((size_t)totalTiles * 64)); HIP_TRY(slotMass.ensure((size_t)totalTiles * 64));
-        HIP_TRY(rows.ensure((size_t)totalCt * kRows * 64)); HIP_TRY(imp.ensure((size_t)totalCt * 64));
-        k_contact_init<<<totalTiles, 64, 0, st>>>(nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
-                                                 gPos.p, gInvI.p, gVel.p, color.p, bodyUsed.p, rows.p, imp.p, slotMeta.p, slotNormal.p, slotMass.p);
+    // ---------------------------------------------------------------------------------------------- constraints
+    const uint32_t tilesLaunch = spec ? tilesCap : totalTiles;   // sync mode knows the exact tile count (mirrorSchedule)
+    if (nmBound) {
+        HIP_TRY(slotMeta.ensure((size_t)tilesCap * 64)); HIP_TRY(slotNormal.ensure((size_t)tilesCap * 64)); HIP_TRY(slotMass.ensure((size_t)tilesCap * 64));
+        HIP_TRY(rows.ensure((size_t)ctCap * kRows * 64)); HIP_TRY(imp.ensure((size_t)ctCap * 64));
+        if (tilesLaunch)
+            k_contact_init<<<tilesLaunch, 64, 0, st>>>(sc, nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
+                                                      gPos.p, gInvI.p, gVel.p, color.p, bodyUsed.p, rows.p, imp.p, slotMeta.p, slotNormal.p, slotMass.p);
     }
     int rc = joints.initialize(*this, dt, st);
     if (rc != MI_OK) return rc;
     mark();  // 6
-    // colours [tailStart, tailEnd) are small (<= 512 manifolds each, a suffix of the used colours): one launch for all of them
-    auto colorCount = [&](uint32_t c) { return bins[4 * c].count + bins[4 * c + 1].count + bins[4 * c + 2].count + bins[4 * c + 3].count; };
-    uint32_t tailEnd = std::min(numColorsUsed, kOverflowColor), tailStart = tailEnd;
-    while (tailStart > 0 && colorCount(tailStart - 1) <= 512u) --tailStart;
-    if (tailEnd - tailStart < 2) tailStart = tailEnd;
-    std::vector<ColorLaunch> launches(tailStart);
-    uint64_t mainContacts = 0;
-    for (uint32_t c = 0; c < tailStart; ++c) {
-        ColorLaunch& cl = launches[c];
-        uint32_t acc = 0;
-        for (uint32_t k = 0; k < 4; ++k) { cl.tileStart[k] = bins[4 * c + k].tileStart; cl.ctStart[k] = bins[4 * c + k].ctStart; mainContacts += (uint64_t)bins[4 * c + k].count * (k + 1); }
-        for (uint32_t i = 0; i < 4; ++i) { acc += divUp(bins[4 * c + (3 - i)].count, 64); cl.blockEnd[i] = acc; }
-        cl.numBlocks = acc; cl.swizzle = xcdSwizzle ? 1u : 0u;
-    }
-    const bool useFlow = flowSolver && nm && bins[kSchedBins - 1].count == 0;   // the overflow colour needs the sequential kernel
+    const uint32_t iters = settings.num_rigid_solver_iterations;
+    const bool useFlow = flowSolver && (spec || bins[kSchedBins - 1].count == 0);   // the overflow colour needs the sequential kernel
     usedFlow = useFlow;
+    uint64_t mainContacts = 0;
     if (useFlow) {
-        uint64_t allContacts = 0;
-        for (uint32_t bn = 0; bn + 1 < kSchedBins; ++bn) allContacts += (uint64_t)bins[bn].count * ((bn & 3u) + 1u);
-        mainContacts = allContacts;
-        const uint32_t iters = settings.num_rigid_solver_iterations;
         // no joints between the sweeps -> all sweeps in one launch; otherwise one launch per sweep (joints run in between)
-        const uint32_t perLaunch = joints.count() == 0 && (uint64_t)totalTiles * iters < 0x7FFFFFFFull ? iters : 1u;
-        solveLaunches = (iters + perLaunch - 1) / perLaunch;
+        const uint32_t perLaunch = joints.count() == 0 && (uint64_t)std::max(tilesLaunch, 1u) * iters < 0x7FFFFFFFull ? iters : 1u;
+        solveLaunches = tilesLaunch ? (iters + perLaunch - 1) / perLaunch : 0;
         for (uint32_t it = 0; it < iters; it += perLaunch) {
             if (perLaunch == 1) joints.solveIteration(*this, st);   // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
+            if (!tilesLaunch) continue;
             if (profileSolve) {
                 size_t e = 2 * (size_t)profLaunches;
                 while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
                 (void)hipEventRecord(profEvents[e], st);
             }
-#ifdef MI_FLOW_TRACE
-            static DBuf<unsigned long long> traceBuf;
-            const char* tracePath = getenv("MI_FLOW_TRACE_FILE");
-            static int traceCountdown = tracePath ? atoi(getenv("MI_FLOW_TRACE_STEP") ? getenv("MI_FLOW_TRACE_STEP") : "260") : -1;
-            bool doTrace = tracePath && traceCountdown-- == 0;
-            if (doTrace) { HIP_TRY(traceBuf.ensure((size_t)totalTiles * perLaunch * 8)); HIP_TRY(hipMemsetAsync(traceBuf.p, 0, (size_t)totalTiles * perLaunch * 64, st)); }
-            k_contact_solve_flow<<<totalTiles * perLaunch, 64, flowLds, st>>>(it, totalTiles, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p,
-                                                                             sc, doTrace ? traceBuf.p : nullptr, getenv("MI_FLOW_DBG") ? (uint32_t)strtoul(getenv("MI_FLOW_DBG"), nullptr, 0) : 0u);
-            if (doTrace) {
-                std::vector<unsigned long long> h((size_t)totalTiles * perLaunch * 8);
-                HIP_TRY(hipMemcpyAsync(h.data(), traceBuf.p, h.size() * 8, hipMemcpyDeviceToHost, st));
-                HIP_TRY(hipStreamSynchronize(st));
-                FILE* f = fopen(tracePath, "wb");
-                if (f) { uint32_t hdr[4] = {totalTiles, perLaunch, 8, 0}; fwrite(hdr, 4, 4, f); fwrite(hTileDesc, 8, totalTiles, f); fwrite(h.data(), 8, h.size(), f); fclose(f); }
-            }
-#else
-            k_contact_solve_flow<<<totalTiles * perLaunch, 64, flowLds, st>>>(it, totalTiles, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p, sc);
-#endif
-            if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; profSlots += (uint64_t)nm * perLaunch; }
+            k_contact_solve_flow<<<tilesLaunch * perLaunch, 64, flowLds, st>>>(it, perLaunch, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p, sc);
+            if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
         }
     } else {
-    solveLaunches = settings.num_rigid_solver_iterations * (tailStart + (tailStart < tailEnd ? 1u : 0u));
-    for (uint32_t it = 0; it < settings.num_rigid_solver_iterations; ++it) {
-        joints.solveIteration(*this, st);   // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
+        // one launch per colour per sweep (MI_SOLVER=launch, or an overflow colour is present); synchronous mode only
+        auto colorCount = [&](uint32_t c) { return bins[4 * c].count + bins[4 * c + 1].count + bins[4 * c + 2].count + bins[4 * c + 3].count; };
+        // colours [tailStart, tailEnd) are small (<= 512 manifolds each, a suffix of the used colours): one launch for all of them
+        uint32_t tailEnd = std::min(numColorsUsed, kOverflowColor), tailStart = tailEnd;
+        while (tailStart > 0 && colorCount(tailStart - 1) <= 512u) --tailStart;
+        if (tailEnd - tailStart < 2) tailStart = tailEnd;
+        std::vector<ColorLaunch> launches(tailStart);
         for (uint32_t c = 0; c < tailStart; ++c) {
-            const ColorLaunch& cl = launches[c];
-            if (!cl.numBlocks) continue;
-            uint32_t grid_ = cl.swizzle ? divUp(cl.numBlocks, 8) * 8 : cl.numBlocks;
-            if (profileSolve) {
-                size_t e = 2 * (size_t)profLaunches;
-                while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
-                (void)hipEventRecord(profEvents[e], st);
-                k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
-                (void)hipEventRecord(profEvents[e + 1], st);
-                ++profLaunches; profSlots += colorCount(c);
-            } else {
-                k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
-            }
+            ColorLaunch& cl = launches[c];
+            uint32_t acc = 0;
+            for (uint32_t k = 0; k < 4; ++k) { cl.tileStart[k] = bins[4 * c + k].tileStart; cl.ctStart[k] = bins[4 * c + k].ctStart; mainContacts += (uint64_t)bins[4 * c + k].count * (k + 1); }
+            for (uint32_t i = 0; i < 4; ++i) { acc += divUp(bins[4 * c + (3 - i)].count, 64); cl.blockEnd[i] = acc; }
+            cl.numBlocks = acc; cl.swizzle = xcdSwizzle ? 1u : 0u;
         }
-        if (tailStart < tailEnd) k_contact_solve_tail<<<1, 256, 0, st>>>(binInfo.p, tailStart, tailEnd, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
-        if (bins[kSchedBins - 1].count) k_contact_solve_serial<<<1, 64, 0, st>>>(bins[kSchedBins - 1], slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
-    }
+        solveLaunches = iters * (tailStart + (tailStart < tailEnd ? 1u : 0u));
+        for (uint32_t it = 0; it < iters; ++it) {
+            joints.solveIteration(*this, st);
+            for (uint32_t c = 0; c < tailStart; ++c) {
+                const ColorLaunch& cl = launches[c];
+                if (!cl.numBlocks) continue;
+                uint32_t grid_ = cl.swizzle ? divUp(cl.numBlocks, 8) * 8 : cl.numBlocks;
+                if (profileSolve) {
+                    size_t e = 2 * (size_t)profLaunches;
+                    while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
+                    (void)hipEventRecord(profEvents[e], st);
+                    k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
+                    (void)hipEventRecord(profEvents[e + 1], st);
+                    ++profLaunches;
+                } else {
+                    k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
+                }
+            }
+            if (tailStart < tailEnd) k_contact_solve_tail<<<1, 256, 0, st>>>(binInfo.p, tailStart, tailEnd, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
+            if (bins[kSchedBins - 1].count) k_contact_solve_serial<<<1, 64, 0, st>>>(bins[kSchedBins - 1], slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
+        }
     }
     mark();  // 7
+    k_integrate_velocities<<<divUp(nb, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p);
+    mark();  // 8
+    // ---------------------------------------------------------------------------------------------- end of step: the one read-back
+    uint32_t flagsHost[96] = {0};
+    if (nmBound) HIP_TRY(hipMemcpyAsync(flagsHost, roundFlags.p, sizeof(flagsHost), hipMemcpyDeviceToHost, st));
+    { int rc2 = readScalars(); if (rc2 != MI_OK) return rc2; }
+    HIP_TRY(hipGetLastError());
+    if (spec) {
+        const uint32_t ovfCount = hs.binStart[kColorBins] - hs.binStart[kSchedBins - 1];
+        const bool valid = hs.numPairs <= pairBound && hs.numManifolds <= nmBound && hs.specOverflow == 0 && hs.colorPending == 0 && ovfCount == 0;
+        if (!valid) return STEP_RETRY;   // nothing persistent was modified: run the same step synchronously
+        mirrorSchedule();
+    }
+    if (hs.solveError) return fail(MI_ERR_DEVICE, "dataflow contact solver: a body dependency wait exceeded its spin budget");
     if (profileSolve) {
-        HIP_TRY(hipStreamSynchronize(st));
-        profContacts = mainContacts * settings.num_rigid_solver_iterations;
+        if (useFlow) { mainContacts = 0; for (uint32_t bn = 0; bn + 1 < kSchedBins; ++bn) mainContacts += (uint64_t)bins[bn].count * ((bn & 3u) + 1u); }
+        profContacts = mainContacts * iters;
         profKernelMs = 0.f;
         for (uint32_t l = 0; l < profLaunches; ++l) { float ms = 0.f; (void)hipEventElapsedTime(&ms, profEvents[2 * l], profEvents[2 * l + 1]); profKernelMs += ms; }
     }
-    k_integrate_velocities<<<divUp(nb, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p);
-    mark();  // 8
-    uint32_t solveError = 0;
-    if (useFlow) HIP_TRY(hipMemcpyAsync(&solveError, &sc->solveError, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipGetLastError());
-#ifdef MI_FLOW_TRACE
-    if (getenv("MI_FLOW_DBG")) { StepScalars t{}; (void)hipMemcpy(&t, sc, sizeof(t), hipMemcpyDeviceToHost); fprintf(stderr, "paircheck: A data-mismatch %u tag-mismatch %u | B data %u tag %u | lanes %u\n", t.bucketCursor[1], t.bucketCursor[2], t.bucketCursor[3], t.bucketCursor[4], t.bucketCursor[5]); }
-#endif
-    if (solveError) return fail(MI_ERR_DEVICE, "dataflow contact solver: a body dependency wait exceeded its spin budget");
+    // the step is valid: the freshly integrated state becomes the current one
+    std::swap(bPos.p, bPosN.p); std::swap(bRot.p, bRotN.p); std::swap(bLinVel.p, bLinVelN.p); std::swap(bAngVel.p, bAngVelN.p);
+    std::swap(bForce.p, bForceN.p); std::swap(bTorque.p, bTorqueN.p);
+    sapAxis = hs.axisNext;
     hostStale = true;
+    last.numPairs = hs.numPairs; last.numManifolds = hs.numManifolds; last.numContacts = hs.numContacts; last.numCells = hs.numCells;
+    last.colorRounds = 0;
+    while (last.colorRounds < 96u && flagsHost[last.colorRounds]) ++last.colorRounds;   // rounds that still had work (+1 to commit) this step
+    ++last.colorRounds;
+    haveEstimates = true;
+    pairsIn = hs.partitioned ? pairKeysS.p : pairKeys.p;
 
     auto el = [&](int a, int b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; };
     times.world_colliders = el(0, 1); times.broadphase = el(1, 2); times.narrowphase = el(2, 3); times.integrate_forces = el(3, 4);
     times.schedule = el(4, 5); times.init_constraints = el(5, 6); times.solve = el(6, 7); times.integrate_velocities = el(7, 8); times.total = el(0, 8);
     counts.num_rigid_bodies = nb; counts.num_colliders = nc; counts.num_broadphase_overlaps = nc ? hs.numOverlaps : 0;
-    counts.num_collisions = nm; counts.num_contacts = ncon; counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur; counts.reserved = solveLaunches;
+    counts.num_collisions = pairBound ? hs.numManifolds : 0; counts.num_contacts = pairBound ? hs.numContacts : 0;
+    counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur; counts.reserved = solveLaunches;
     return MI_OK;
+}
+
+// Host mirror of the device schedule (bins -> tiles), from the binStart table read back in StepScalars.
+void mi_world::mirrorSchedule() {
+    numColorsUsed = 0;
+    uint32_t tiles = 0, ct = 0;
+    for (uint32_t bn = 0; bn < kSchedBins; ++bn) {
+        bool ovf = bn == kSchedBins - 1;
+        uint32_t s0 = hs.binStart[bn], s1 = ovf ? hs.binStart[kColorBins] : hs.binStart[bn + 1];
+        uint32_t stride = ovf ? 4u : (bn & 3u) + 1u;
+        BinInfo bi{s0, s1 - s0, tiles, ct};
+        uint32_t nt = divUp(bi.count, 64);
+        tiles += nt; ct += nt * stride;
+        bins[bn] = bi;
+        if (bi.count) numColorsUsed = std::max(numColorsUsed, (ovf ? kOverflowColor : bn / 4u) + 1u);
+    }
+    totalTiles = tiles;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,0 +1,25 @@
+#!/bin/bash
+# dev helper: kernel timeline of one settled step (rocprofv3 --kernel-trace), with the gaps between kernels
+ulimit -c 0
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+RAW=/tmp/prof_tl; rm -rf $RAW; mkdir -p $RAW
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $RAW -o tl -- python bench.py --steps 4 --warmup 250 --no-cpu-baseline > gpurun_out/tl_bench.log 2>&1
+python - <<'PY'
+import csv, glob
+f = glob.glob("/tmp/prof_tl/**/tl_kernel_trace.csv", recursive=True)[0]
+rows = list(csv.DictReader(open(f)))
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+# find the last k_world_colliders -> start of the last full step before the profiled extra steps: take the 3rd from last
+idx = [i for i, r in enumerate(rows) if "k_world_colliders" in r["Kernel_Name"]]
+a, b = idx[-5], idx[-4]
+t0 = int(rows[a]["Start_Timestamp"])
+out = []
+prev_end = t0
+for r in rows[a:b]:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    out.append("%8.1f  +%6.1f gap  %7.1f us  %s" % ((s - t0) / 1e3, (s - prev_end) / 1e3, (e - s) / 1e3, r["Kernel_Name"].split("(")[0][:70]))
+    prev_end = e
+open("gpurun_out/timeline.txt", "w").write("\n".join(out) + "\n")
+print("step span us:", (prev_end - t0) / 1e3, "kernels:", b - a)
+PY
