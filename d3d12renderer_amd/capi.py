@@ -205,6 +205,12 @@ class World:
         self.L.check(self.L.fn("world_step_profiled")(self.h, C.byref(settings), C.c_float(dt), C.byref(n), C.byref(ms), C.byref(upd)), "world_step_profiled")
         return n.value, ms.value, upd.value
 
+    def step_mode_stats(self):
+        """(internal steps, speculative steps, synchronous retries) since creation (product library only)."""
+        a = C.c_uint32(0); b = C.c_uint32(0); c = C.c_uint32(0)
+        self.L.check(self.L.fn("world_get_step_mode_stats")(self.h, C.byref(a), C.byref(b), C.byref(c)), "world_get_step_mode_stats")
+        return a.value, b.value, c.value
+
     # --- read-back
     def num_entities(self):
         n = C.c_uint32(0)

@@ -54,6 +54,7 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t colorPending;         // manifolds still uncoloured after the last colouring round enqueued
     uint32_t specOverflow;         // a speculative bound (tiles / contact-tiles capacity) was exceeded on the device
     uint32_t numCells;             // cells of this step's broad-phase grid
+    uint32_t numPairsFound;        // pair count of a step whose speculative pair bound was exceeded (numPairs is zeroed then)
 };
 
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
@@ -430,13 +431,14 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
     const uint32_t base = (blockIdx.x % blocksPerColumn) * (kGridChunks * 256u);
     const uint32_t dy = gp->dims[1], dz = gp->dims[2], dx = gp->dims[0];
     const uint32_t axis = sc->axisCur;
+    const uint32_t numSmall = nc - gp->numLarge;
     uint32_t overlaps = 0, nh[kGridChunks];
 #pragma unroll
     for (uint32_t ch = 0; ch < kGridChunks; ++ch) {
         const uint32_t i = base + ch * 256u + threadIdx.x;
         uint64_t* mybuf = buf + (ch * 256u + threadIdx.x) * kPairBuf;
         uint32_t nhit = 0;
-        uint32_t key = i < nc ? keys[i] : 0xFFFFFFFFu;
+        uint32_t key = i < numSmall ? keys[i] : 0xFFFFFFFFu;   // sorted positions [0, numSmall) hold the small colliders
         if (key != 0xFFFFFFFFu) {
             uint32_t iz = key % dz, iy = (key / dz) % dy, ix = key / (dz * dy);
             int x = (int)ix + (col >= 2 ? 1 : 0);
@@ -534,8 +536,11 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
 }
 
 // Shard totals -> StepScalars (read back by the host together with numPairs).
-__global__ void k_pair_totals(const Shards* __restrict__ sh, StepScalars* sc) {
+// `pairBound`: what the launches / scans / buffers downstream are sized for.  A speculative step that found more pairs is
+// invalid as a whole (the host re-runs it synchronously): mark it and make everything downstream a no-op.
+__global__ void k_pair_totals(const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound) {
     uint32_t t = threadIdx.x;
+    if (t == 0 && sc->numPairs > pairBound) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; }
     if (t < 24) { uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].bucketHist[t]; sc->bucketHist[t] = v; }
     if (t == 31) { uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].numOverlaps; sc->numOverlaps = v; }
 }
@@ -697,6 +702,36 @@ __device__ __forceinline__ uint64_t pairPriority(uint32_t a, uint32_t b) {
     return x;
 }
 
+// Colour history: open-addressing table (linear probing, load <= 0.5) from the oriented collider pair of every manifold
+// of the previous step to its colour.  A manifold that persists keeps its colour (still conflict-free: the manifolds it
+// shared a body with kept theirs or vanished), so the Jones-Plassmann rounds only have to colour the NEW manifolds of a
+// step — a few percent of them once a pile has settled.  Stored key = (A << 26 | B) + 1 (0 = empty slot).
+__device__ __forceinline__ uint32_t tableSlot(uint64_t key, uint32_t mask) {
+    uint64_t x = key * 0x9E3779B97F4A7C15ull;
+    return (uint32_t)(x >> 40) & mask;
+}
+__device__ __forceinline__ uint32_t tableLookup(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t mask, uint64_t key) {
+    for (uint32_t s = tableSlot(key, mask), n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
+        unsigned long long k = keys[s];
+        if (k == key) return vals[s];
+        if (k == 0ull) break;
+    }
+    return kUncolored;
+}
+__global__ __launch_bounds__(256) void k_color_table_insert(const StepScalars* __restrict__ sc, const uint32_t* __restrict__ manPair,
+                                                            const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
+                                                            const uint32_t* __restrict__ color, unsigned long long* __restrict__ keys,
+                                                            uint32_t* __restrict__ vals, uint32_t mask) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= sc->numManifolds) return;
+    uint64_t pk = (sc->partitioned ? pairsB : pairsA)[manPair[m]];
+    uint64_t key = ((((pk >> 29) & 0x1FFFFFFFull) << kIndexBits) | (pk & 0x1FFFFFFFull)) + 1ull;
+    for (uint32_t s = tableSlot(key, mask), n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
+        unsigned long long old = atomicCAS(&keys[s], 0ull, (unsigned long long)key);
+        if (old == 0ull) { vals[s] = color[m]; return; }
+    }
+}
+
 // After the scans: manifold m <- pair p (count > 0).  colWork = (bodyA | dynA << 31, bodyB | dynB << 31, priority lo, hi):
 // everything a colouring round needs in one 16-byte row.
 __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nb, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB, const uint64_t* __restrict__ npPacked,
@@ -704,7 +739,9 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nb, const uint6
                                                         const float4* __restrict__ aabbMax, const float4* __restrict__ cMaterial,
                                                         const float4* __restrict__ bCogInvMass,
                                                         uint32_t* __restrict__ manPair, uint2* __restrict__ manBodies, uint2* __restrict__ manInfo,
-                                                        uint4* __restrict__ colWork, uint32_t* __restrict__ color, StepScalars* sc) {
+                                                        uint4* __restrict__ colWork, uint32_t* __restrict__ color,
+                                                        const unsigned long long* __restrict__ prevKeys, const uint32_t* __restrict__ prevVals, uint32_t prevMask,
+                                                        unsigned long long* __restrict__ bodyUsed, StepScalars* sc) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t numPairs = sc->numPairs;
     if (p >= numPairs) return;
@@ -728,7 +765,13 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nb, const uint6
     uint32_t dynB = (bB < nb && bCogInvMass[bB].w != 0.f) ? 0x80000000u : 0u;
     uint64_t prio = pairPriority(a, b);
     colWork[m] = make_uint4(bA | dynA, bB | dynB, (uint32_t)prio, (uint32_t)(prio >> 32));
-    color[m] = kUncolored;
+    // a manifold of the previous step keeps its colour (colour 64 = overflow is re-coloured)
+    uint32_t c = prevKeys ? tableLookup(prevKeys, prevVals, prevMask, (((uint64_t)a << kIndexBits) | (uint64_t)b) + 1ull) : kUncolored;
+    if (c < kOverflowColor) {
+        if (dynA) atomicOr(&bodyUsed[bA], 1ull << c);
+        if (dynB) atomicOr(&bodyUsed[bB], 1ull << c);
+    } else c = kUncolored;
+    color[m] = c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -949,36 +992,43 @@ __device__ __forceinline__ M3 loadM3(const float4* __restrict__ p, uint32_t i) {
 // Schedule bins -> tiles, on the device (so the host never has to read the bin sizes back before it can launch the
 // constraint kernels): BinInfo per bin, tile -> bin and tile -> (first contact-tile, contacts per manifold) tables, totals.
 // The host launches the consumers over an upper bound of tiles; tiles >= totalTiles exit.
-__global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t ctCap, StepScalars* sc, BinInfo* __restrict__ binInfo,
-                                                     uint32_t* __restrict__ tileBin, uint2* __restrict__ tileDesc) {
+__global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t ctCap, StepScalars* sc, BinInfo* __restrict__ binInfo) {
     __shared__ BinInfo bins[kSchedBins];
-    __shared__ uint32_t ok;
+    __shared__ uint32_t start[kColorBins + 4];
+    for (uint32_t b = threadIdx.x; b <= kColorBins; b += blockDim.x) start[b] = sc->binStart[b];
+    __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t tiles = 0, ct = 0;
         for (uint32_t bn = 0; bn < kSchedBins; ++bn) {
             bool ovf = bn == kSchedBins - 1;
-            uint32_t s0 = sc->binStart[bn], s1 = ovf ? sc->binStart[kColorBins] : sc->binStart[bn + 1];
+            uint32_t s0 = start[bn], s1 = ovf ? start[kColorBins] : start[bn + 1];
             uint32_t stride = ovf ? 4u : (bn & 3u) + 1u;
             BinInfo bi; bi.slotStart = s0; bi.count = s1 - s0; bi.tileStart = tiles; bi.ctStart = ct;
             uint32_t nt = (bi.count + 63u) >> 6;
             tiles += nt; ct += nt * stride;
             bins[bn] = bi;
         }
-        ok = (tiles <= tilesCap && ct <= ctCap) ? 1u : 0u;
+        bool ok = tiles <= tilesCap && ct <= ctCap;
         sc->totalTiles = ok ? tiles : 0u; sc->totalCt = ok ? ct : 0u;
         if (!ok) sc->specOverflow = 1u;
     }
     __syncthreads();
     for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) binInfo[bn] = bins[bn];
-    if (!ok) return;
-    for (uint32_t bn = 0; bn < kSchedBins; ++bn) {
-        BinInfo bi = bins[bn];
-        uint32_t nt = (bi.count + 63u) >> 6, stride = bn == kSchedBins - 1 ? 4u : (bn & 3u) + 1u;
-        for (uint32_t t = threadIdx.x; t < nt; t += blockDim.x) {
-            tileBin[bi.tileStart + t] = bn;
-            tileDesc[bi.tileStart + t] = make_uint2(bi.ctStart + t * stride, stride);
-        }
-    }
+}
+// tile -> bin (binary search over the bins' first tiles) and tile -> (first contact-tile, contacts per manifold)
+__global__ __launch_bounds__(256) void k_fill_tiles(const StepScalars* __restrict__ sc, const BinInfo* __restrict__ binInfo,
+                                                    uint32_t* __restrict__ tileBin, uint2* __restrict__ tileDesc) {
+    __shared__ uint32_t first[kSchedBins];
+    for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) first[bn] = binInfo[bn].tileStart;
+    __syncthreads();
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= sc->totalTiles) return;
+    uint32_t lo = 0, hi = kSchedBins - 1;   // last bin whose first tile is <= t (empty bins share a first tile with their successor)
+    while (lo < hi) { uint32_t mid = (lo + hi + 1u) >> 1; if (first[mid] <= t) lo = mid; else hi = mid - 1u; }
+    BinInfo bi = binInfo[lo];
+    uint32_t stride = lo == kSchedBins - 1 ? 4u : (lo & 3u) + 1u;
+    tileBin[t] = lo;
+    tileDesc[t] = make_uint2(bi.ctStart + (t - bi.tileStart) * stride, stride);
 }
 
 // K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379): one wave per tile, one lane per slot.

@@ -103,6 +103,9 @@ struct mi_world {
     // schedule + solver
     DBuf<uint32_t> color, order, orderTmp, roundFlags, blockHist, blockScan, tileBin; DBuf<unsigned long long> bodyTop, bodyUsed;
     DBuf<BinInfo> binInfo;
+    // colour history (pair -> colour of the previous step): two tables, the one written by a step becomes current only if the step is valid
+    DBuf<unsigned long long> tabKeys[2]; DBuf<uint32_t> tabVals[2]; uint32_t tabMask[2] = {0, 0}; int tabCur = 0; bool tabValid = false;
+    bool collidersChanged = true;
     DBuf<float4> rows, slotNormal; DBuf<float4> imp; DBuf<float2> slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc;
     bool usedFlow = false;
     uint32_t flowLds = 0;                  // dynamic LDS bytes per 64-lane workgroup: caps resident waves per CU (160 KiB / flowLds)
@@ -134,7 +137,7 @@ struct mi_world {
     // speculative (single read-back) stepping: upper bounds come from the last valid step
     struct LastCounts { uint32_t numPairs = 0, numManifolds = 0, numContacts = 0, numCells = 0, colorRounds = 0; } last;
     bool specEnabled = true, haveEstimates = false;
-    uint32_t specRetries = 0, colorRoundsLaunched = 0;
+    uint32_t specRetries = 0, specSteps = 0, totalSteps = 0, colorRoundsLaunched = 0;
     uint32_t sapAxis = 0;        // sorting axis for the next step (collision_broad.cpp:443-444), host copy
     int ensureTemp(size_t bytes) { return temp.ensure(bytes) == hipSuccess ? MI_OK : MI_ERR_OUT_OF_MEMORY; }
 };
@@ -322,6 +325,7 @@ int mi_world::upload() {
     HIP_TRY(gPos.ensure(nb + 1)); HIP_TRY(gInvI.ensure(3 * ((size_t)nb + 1))); HIP_TRY(gVel.ensure(2 * ((size_t)nb + 1)));
     HIP_TRY(bodyTop.ensure(2 * ((size_t)nb + 1))); HIP_TRY(bodyUsed.ensure(nb + 1));
 
+    if (collidersChanged) { tabValid = false; collidersChanged = false; }   // collider world indices shifted: drop the colour history
     usesGjk = false;
     for (const HCollider& c : colliders) if (c.desc.type == T_CAPSULE || c.desc.type == T_CYLINDER || c.desc.type == T_HULL) usesGjk = true;
     std::vector<uint32_t> tb(2 * (size_t)nc); std::vector<float4> sh(3 * (size_t)nc), sp(nc), sr(nc), mat(nc);
@@ -386,10 +390,13 @@ int mi_world::download() {
 // ------------------------------------------------------------------------------------------------
 // One internal step (physicsStepInternal, src/physics/physics.cpp:1180-1362)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_reset_scalars(StepScalars* sc) {
+__global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlags) {
     uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < sizeof(Shards) / 4u; i += blockDim.x) reinterpret_cast<uint32_t*>(sh)[i] = 0u;
+    for (uint32_t i = t; i < kMaxColorRounds + 2u; i += blockDim.x) roundFlags[i] = 0u;
     if (t == 0) {
         sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->solveError = 0;
+        sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0;
         for (int a = 0; a < 3; ++a) { sc->boundsMin[a] = 0x7FFFFFFF; sc->boundsMax[a] = (int)0x80000000; }
     }
     if (t < 24) { sc->bucketHist[t] = 0; sc->bucketCursor[t] = 0; }
@@ -416,6 +423,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     if (topologyDirty) { int rc = download(); if (rc != MI_OK) return rc; rc = upload(); if (rc != MI_OK) return rc; haveEstimates = false; }
     if (bodies.empty()) return MI_OK;
     const bool spec = specEnabled && haveEstimates && flowSolver;
+    ++totalSteps; if (spec) ++specSteps;
     int rc = runStep(settings, dt, spec);
     if (rc == STEP_RETRY) { ++specRetries; rc = runStep(settings, dt, false); }
     return rc;
@@ -432,7 +440,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     auto readScalars = [&]() -> int { HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); return MI_OK; };
 
     mark();  // 0
-    k_reset_scalars<<<1, 128, 0, st>>>(sc);
+    k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlags.p);
     if (nc) {
         k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis);
@@ -444,13 +452,11 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         uint32_t nblk = divUp(nc, 256);
         // the cell table (histogram + scan) covers cellCap cells; k_bp_grid_setup enlarges the cells if the grid would need more
         const uint32_t cellCap = spec ? std::min<uint32_t>(kMaxCells, std::max<uint32_t>(1u << 16, 2u * last.numCells)) : kMaxCells;
-        HIP_TRY(hipMemsetAsync(shards.p, 0, sizeof(Shards), st));
         k_axis_partials<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, axisPartials.p, shards.p);
         k_bp_threshold<<<1, 256, 0, st>>>(nc, shards.p, sc);
         k_bp_classify<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, sc, largeList.p, isLarge.p, blockBounds.p);
         k_bp_grid_setup<<<1, 256, 0, st>>>(nc, nblk, cellCap, blockBounds.p, sc, grid.p);
         HIP_TRY(hipMemsetAsync(cellCount.p, 0, (size_t)cellCap * sizeof(uint32_t), st));
-        HIP_TRY(hipMemsetAsync(cellKeysS.p, 0xFF, ((size_t)nc + 1) * sizeof(uint32_t), st));
         k_bp_cell_ids<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, isLarge.p, grid.p, cellKeys.p, cellRanks.p, cellCount.p);
         size_t tb = 0;
         HIP_TRY(rocprim::exclusive_scan(nullptr, tb, cellCount.p, cellLower.p, 0u, (size_t)cellCap, rocprim::plus<uint32_t>(), st));
@@ -464,7 +470,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             const uint32_t bpc = divUp(nc, kGridChunks * 256u);
             k_bp_pairs_grid<<<5u * bpc, B, 0, st>>>(nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, grid.p, pairKeys.p, cap, sc, shards.p);
             k_bp_pairs_large<<<dim3(std::min(divUp(nc, B), 256u), 16), B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc, shards.p);
-            k_pair_totals<<<1, 32, 0, st>>>(shards.p, sc);
+            k_pair_totals<<<1, 32, 0, st>>>(shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu);
             if (attempt == 0) k_axis_final<<<1, 256, 0, st>>>(nc, nblk, axisPartials.p, sc);
             if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
             int rc = readScalars(); if (rc != MI_OK) return rc;
@@ -484,6 +490,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         HIP_TRY(npPacked.ensure(pairBound)); HIP_TRY(npScan.ensure(pairBound)); HIP_TRY(npNormal.ensure(pairBound)); HIP_TRY(npPoints.ensure(4 * (size_t)pairBound));
         HIP_TRY(manPair.ensure(pairBound)); HIP_TRY(manBodies.ensure(pairBound)); HIP_TRY(manInfo.ensure(pairBound));
         HIP_TRY(colWork.ensure(pairBound)); HIP_TRY(color.ensure(pairBound));
+        HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, ((size_t)nb + 1) * sizeof(unsigned long long), st));   // k_emit_manifolds seeds it with the kept colours
         HullSet hset{hullVerts.p, hullRanges.p};
         k_narrow<<<divUp(pairBound, B), B, 0, st>>>(pairBound, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
         if (usesGjk) k_narrow_gjk<<<divUp(pairBound, 64), 64, 0, st>>>(sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
@@ -492,7 +499,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
         HIP_TRY(rocprim::exclusive_scan(temp.p, tb, npPacked.p, npScan.p, (uint64_t)0, pairBound, rocprim::plus<uint64_t>(), st));
         k_emit_manifolds<<<divUp(pairBound, B), B, 0, st>>>(nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
-                                                        manPair.p, manBodies.p, manInfo.p, colWork.p, color.p, sc);
+                                                        manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
+                                                        tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, sc);
     }
     mark();  // 3
     k_integrate_forces<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p,
@@ -505,16 +513,14 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         else { int rc = readScalars(); if (rc != MI_OK) return rc; nmBound = hs.numManifolds; conBound = hs.numContacts; }
     }
     uint32_t tilesCap = 0, ctCap = 0;
-    uint32_t colorBatch = spec ? std::min<uint32_t>(96u, std::max<uint32_t>(12u, last.colorRounds + 6u)) : 20u;   // converged rounds exit at once (~2 us each)
+    uint32_t colorBatch = spec ? std::min<uint32_t>(96u, last.colorRounds + std::max(3u, last.colorRounds / 4u)) : 20u;   // converged rounds exit at once
     if (nmBound) {
         tilesCap = divUp(nmBound, 64) + kSchedBins + 8; ctCap = divUp(conBound, 64) + 4 * kSchedBins + 8;
-        HIP_TRY(order.ensure(nmBound)); HIP_TRY(orderTmp.ensure(nmBound));
         const uint32_t binBlocks = divUp(nmBound, kBinItems);
+        HIP_TRY(order.ensure((size_t)binBlocks * kBinItems)); HIP_TRY(orderTmp.ensure((size_t)binBlocks * kBinItems));
         HIP_TRY(blockHist.ensure((size_t)kColorBins * binBlocks)); HIP_TRY(blockScan.ensure((size_t)kColorBins * binBlocks));
         HIP_TRY(tileBin.ensure(tilesCap)); HIP_TRY(tileDesc.ensure(tilesCap));
         HIP_TRY(hipMemsetAsync(bodyTop.p, 0, 2 * ((size_t)nb + 1) * sizeof(unsigned long long), st));
-        HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, ((size_t)nb + 1) * sizeof(unsigned long long), st));
-        HIP_TRY(hipMemsetAsync(roundFlags.p, 0, (kMaxColorRounds + 2) * sizeof(uint32_t), st));
         unsigned long long* top[2] = {bodyTop.p, bodyTop.p + (nb + 1)};
         uint32_t round = 0;
         while (true) {
@@ -527,7 +533,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
             HIP_TRY(rocprim::exclusive_scan(temp.p, tb, blockHist.p, blockScan.p, 0u, (size_t)kColorBins * binBlocks, rocprim::plus<uint32_t>(), st));
             k_bin_scatter<<<binBlocks, 256, 0, st>>>(round - 1, roundFlags.p, binBlocks, color.p, manInfo.p, blockScan.p, order.p, sc);
-            k_build_tiles<<<1, 256, 0, st>>>(tilesCap, ctCap, sc, binInfo.p, tileBin.p, tileDesc.p);
+            k_build_tiles<<<1, 256, 0, st>>>(tilesCap, ctCap, sc, binInfo.p);
+            k_fill_tiles<<<divUp(tilesCap, B), B, 0, st>>>(sc, binInfo.p, tileBin.p, tileDesc.p);
             if (spec) break;
             int rc = readScalars(); if (rc != MI_OK) return rc;
             if (hs.colorPending == 0) break;
@@ -535,6 +542,14 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             colorBatch = 8;
         }
         colorRoundsLaunched = round;
+        {   // colour history for the next step, into the OTHER table (it becomes current only if this step turns out valid)
+            const int nt = tabCur ^ 1;
+            uint32_t cap = 1024; while (cap < 2u * nmBound) cap <<= 1;
+            HIP_TRY(tabKeys[nt].ensure(cap)); HIP_TRY(tabVals[nt].ensure(cap));
+            tabMask[nt] = cap - 1u;
+            HIP_TRY(hipMemsetAsync(tabKeys[nt].p, 0, (size_t)cap * sizeof(unsigned long long), st));
+            k_color_table_insert<<<divUp(nmBound, B), B, 0, st>>>(sc, manPair.p, pairKeys.p, pairKeysS.p, color.p, tabKeys[nt].p, tabVals[nt].p, tabMask[nt]);
+        }
         if (!spec) {
             mirrorSchedule();
             const BinInfo& ob = bins[kSchedBins - 1];
@@ -638,6 +653,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     std::swap(bPos.p, bPosN.p); std::swap(bRot.p, bRotN.p); std::swap(bLinVel.p, bLinVelN.p); std::swap(bAngVel.p, bAngVelN.p);
     std::swap(bForce.p, bForceN.p); std::swap(bTorque.p, bTorqueN.p);
     sapAxis = hs.axisNext;
+    if (nmBound) { tabCur ^= 1; tabValid = true; } else tabValid = false;
     hostStale = true;
     last.numPairs = hs.numPairs; last.numManifolds = hs.numManifolds; last.numContacts = hs.numContacts; last.numCells = hs.numCells;
     last.colorRounds = 0;
@@ -870,6 +886,7 @@ MI_API int mi_colliders_add(mi_world* w, uint32_t count, const uint32_t* ents, c
         e.colliders.insert(e.colliders.begin(), id);   // linked-list prepend (src/scene/scene.h:52-54)
     }
     if (w->colliders.size() >= (1u << kIndexBits)) return fail(MI_ERR_CAPACITY, "collider index space is 26 bits per world");
+    if (count) w->collidersChanged = true;
     w->topologyDirty = true;
     return MI_OK;
 }
@@ -971,6 +988,14 @@ MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
     int rc = w->stepInternal(*s, dt); if (rc != MI_OK) return rc;
     rc = w->download(); if (rc != MI_OK) return rc;
     for (HBody& b : w->bodies) { HEntity& e = w->entities[b.entity]; e.pos = b.p1; e.rot = b.r1; }
+    return MI_OK;
+}
+
+MI_API int mi_world_get_step_mode_stats(mi_world* w, uint32_t* steps, uint32_t* spec, uint32_t* retries) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    if (steps) *steps = w->totalSteps;
+    if (spec) *spec = w->specSteps;
+    if (retries) *retries = w->specRetries;
     return MI_OK;
 }
 

@@ -199,10 +199,15 @@ MI_API int mi_world_step(mi_world* world, const mi_step_settings* settings, floa
 /* n × physicsStepInternal(scene, arena, settings, dt) (src/physics/physics.cpp:1180-1362); no interpolation. */
 MI_API int mi_world_step_fixed(mi_world* world, const mi_step_settings* settings, float dt, uint32_t num_steps);
 
-/* One internal step with a HIP event pair around every k_contact_solve launch (the dominant kernel): returns the number
- * of launches, their summed device time and the contact updates (contacts x iterations) they performed. */
+/* One internal step with a HIP event pair around every contact-solver launch (the dominant kernel: k_contact_solve_flow,
+ * or k_contact_solve per colour with MI_SOLVER=launch): returns the number of launches, their summed device time and the
+ * contact updates (contacts x iterations) they performed. */
 MI_API int mi_world_step_profiled(mi_world* world, const mi_step_settings* settings, float dt, uint32_t* out_launches,
                                   float* out_kernel_ms, uint64_t* out_contact_updates);
+
+/* Stepping statistics since world creation: internal steps taken, steps run speculatively (one host read-back at the end,
+ * sizes bounded from the previous step) and how many of those had to be re-run synchronously because a bound was exceeded. */
+MI_API int mi_world_get_step_mode_stats(mi_world* world, uint32_t* out_steps, uint32_t* out_speculative, uint32_t* out_retries);
 
 /* Read-back (transform_component / rigid_body_component fields), entity order. */
 MI_API int mi_world_num_entities(mi_world* world, uint32_t* out);

@@ -699,22 +699,35 @@ static void solveContact(World& w, uint32_t i, CollisionConstraint& c) {
     rbB.linearVelocity = vB; rbB.angularVelocity = wB;
 }
 
-// Canonical contact schedule (replaces scheduleConstraintsSIMD's role, constraints.cpp:51-184):
-// greedy graph colouring of MANIFOLDS in descending pairPriority(colliderA, colliderB); a manifold takes the lowest
-// colour free on both of its dynamic bodies (invMass != 0); bodies with invMass == 0 never
-// conflict (the reference exempts its dummy body, constraints.cpp:81-83).  Colour 64 = overflow,
-// solved sequentially last.  This is exactly what the Jones-Plassmann rounds on the GPU compute.
+// Canonical contact schedule (replaces scheduleConstraintsSIMD's role, constraints.cpp:51-184).
+// A manifold that already existed in the previous step (same oriented collider pair) KEEPS its colour — two such
+// manifolds sharing a dynamic body had different colours then, so they still do — and only the new manifolds are
+// coloured: greedy in descending pairPriority(colliderA, colliderB), each taking the lowest colour free on both of its
+// dynamic bodies (invMass != 0); bodies with invMass == 0 never conflict (the reference exempts its dummy body the
+// same way, constraints.cpp:81-83).  Colour 64 = overflow, solved sequentially last (and re-coloured next step).
+// This is exactly what the device computes (hash-table lookup of the previous colours + Jones-Plassmann rounds over
+// the rest).  The history is dropped whenever colliders are added (collider world indices shift).
 static void colorManifolds(World& w) {
     uint32_t nm = (uint32_t)w.colliderPairs.size();
     w.manifoldColor.assign(nm, 64);
-    std::vector<uint32_t> order(nm);
-    for (uint32_t i = 0; i < nm; ++i) order[i] = i;
-    std::vector<uint64_t> prio(nm);
-    for (uint32_t m = 0; m < nm; ++m) prio[m] = pairPriority(w.colliderPairs[m].a, w.colliderPairs[m].b);
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return prio[a] > prio[b]; });
     std::vector<uint64_t> used(w.rb.size(), 0);
     std::vector<uint32_t> firstContact(nm);
     { uint32_t off = 0; for (uint32_t m = 0; m < nm; ++m) { firstContact[m] = off; off += w.contactCounts[m]; } }
+    auto keyOf = [&](uint32_t m) { return ((uint64_t)w.colliderPairs[m].a << 26) | (uint64_t)w.colliderPairs[m].b; };
+    std::vector<uint32_t> order;
+    for (uint32_t m = 0; m < nm; ++m) {
+        auto it = w.prevPairColor.find(keyOf(m));
+        if (it != w.prevPairColor.end() && it->second < 64) {
+            uint32_t c = it->second;
+            Pair bp = w.bodyPairs[firstContact[m]];
+            w.manifoldColor[m] = c;
+            if (w.rb[bp.a].invMass != 0.f) used[bp.a] |= (1ull << c);
+            if (w.rb[bp.b].invMass != 0.f) used[bp.b] |= (1ull << c);
+        } else order.push_back(m);
+    }
+    std::vector<uint64_t> prio(nm);
+    for (uint32_t m : order) prio[m] = pairPriority(w.colliderPairs[m].a, w.colliderPairs[m].b);
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return prio[a] > prio[b]; });
     for (uint32_t m : order) {
         Pair bp = w.bodyPairs[firstContact[m]];
         bool dynA = w.rb[bp.a].invMass != 0.f, dynB = w.rb[bp.b].invMass != 0.f;
@@ -725,6 +738,8 @@ static void colorManifolds(World& w) {
         if (dynA) used[bp.a] |= (1ull << c);
         if (dynB) used[bp.b] |= (1ull << c);
     }
+    w.prevPairColor.clear();
+    for (uint32_t m = 0; m < nm; ++m) w.prevPairColor[keyOf(m)] = w.manifoldColor[m];
 }
 
 // ---------------------------------------------------------------- step
@@ -864,6 +879,7 @@ MI_API int ora_entities_create(World* w, uint32_t count, const mi_entity_desc* d
 MI_API int ora_entity_create(World* w, const mi_entity_desc* d, uint32_t* out) { return ora_entities_create(w, 1, d, out); }
 
 MI_API int ora_colliders_add(World* w, uint32_t count, const uint32_t* entities, const mi_collider_desc* descs) {
+    if (w && count) w->prevPairColor.clear();   // collider world indices shift: the colour history is keyed by them
     for (uint32_t i = 0; i < count; ++i) {
         if (entities[i] >= w->entities.size()) return MI_ERR_INVALID_ARGUMENT;
         Collider c; shapeFromDesc(descs[i], c.local);

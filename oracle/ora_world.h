@@ -7,6 +7,7 @@
 // tests (tests/test_oracle_*.py) and by its two independently ordered pipelines agreeing.
 #pragma once
 #include <vector>
+#include <unordered_map>
 #include <cstdint>
 #include "ora_math.h"
 #include "../include/mi_physics.h"
@@ -114,6 +115,7 @@ struct World {
     std::vector<Contact> contacts;
     std::vector<Pair> bodyPairs;          // per contact
     std::vector<uint32_t> manifoldColor;  // canonical mode
+    std::unordered_map<uint64_t, uint32_t> prevPairColor;   // canonical mode: colour of every manifold of the previous step, by (colliderA << 26 | colliderB)
     std::vector<GlobalState> rb;
     mi_step_counts counts{};
 

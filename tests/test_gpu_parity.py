@@ -114,6 +114,30 @@ def test_gpu_edge_cases(mi_lib, oracle_mod):
     assert res[0] == res[1]
 
 
+def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
+    """Steps after the first run with ONE host read-back, sized from the previous step's counts.  Teleporting the bodies into
+    a much denser pile invalidates those bounds: the step must be re-run synchronously from the untouched state and still match
+    the oracle bit for bit."""
+    sc = scenes.obb_pile(10, 4, 10, spacing=2.4)
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    for _ in range(25):
+        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+    steps, spec, retries0 = g.step_mode_stats()
+    assert steps == 25 and spec >= 20
+    ents = np.arange(sc.num_bodies, dtype=np.uint32)
+    st = g.get_body_states(ents)
+    assert st.tobytes() == o.get_body_states(ents).tobytes()
+    st[:, 0] *= 0.42; st[:, 2] *= 0.42          # squeeze the lattice: several times more overlapping pairs at once
+    g.set_body_states(ents, st); o.set_body_states(ents, st)
+    for i in range(12):
+        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        assert g.counts() == o.counts(), f"step {i}"
+    assert g.step_mode_stats()[2] > retries0, "the squeeze should have exceeded the speculative bounds"
+    pg, qg = g.physics_transforms(); po, qo = o.physics_transforms()
+    assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
+
+
 def test_gpu_full_size_properties(mi_lib):
     """BASELINE sizes are too slow for the oracle; check size-independent properties instead:
     determinism (two runs bit-identical), no body below the ground, finite state, valid colouring."""
