@@ -104,19 +104,18 @@ def main():
         sw.step(settings, dt)
     barrier()
     t0 = time.perf_counter()
-    solve_ms = 0.0; total_dev_ms = 0.0; launches = 0; contact_iters = 0; stage_acc = {}; step_ms = []
+    step_ms = []
+    sw.world.accumulated_stage_times(reset=True)      # the library sums the per-stage device times of the timed steps itself
     for _ in range(args.steps):
         t_step = time.perf_counter()
         sw.step(settings, dt)
         step_ms.append((time.perf_counter() - t_step) * 1e3)
-        st = sw.world.stage_times(); c = sw.world.counts()
-        solve_ms += st["solve"]; total_dev_ms += st["total"]
-        launches += sw.world.solve_launches()
-        contact_iters += args.iterations * c["num_contacts"]
-        for k, v in st.items():
-            stage_acc[k] = stage_acc.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
+    stage_acc, n_acc, contact_iters = sw.world.accumulated_stage_times()
+    assert n_acc == args.steps
+    solve_ms = stage_acc["solve"]; total_dev_ms = stage_acc["total"]
+    launches = sw.world.solve_launches() * args.steps
     # roofline of the dominant kernel: a few extra steps (outside the timed region) with a HIP event pair around every
     # k_contact_solve launch, on the stream the kernel is launched on
     prof_launches = 0; prof_ms = 0.0; prof_updates = 0

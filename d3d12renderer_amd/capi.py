@@ -286,6 +286,12 @@ class World:
         self.L.check(self.L.fn("world_set_body_states_device")(self.h, C.c_uint32(n), C.c_void_p(body_ids_ptr), C.c_void_p(in_ptr)),
                      "world_set_body_states_device")
 
+    def accumulated_stage_times(self, reset=False):
+        """(sum of per-stage device ms, steps, contact updates) since the last reset — product library only."""
+        t = StageTimes(); n = C.c_uint32(0); u = C.c_uint64(0)
+        self.L.check(self.L.fn("world_get_accumulated_stage_times")(self.h, C.byref(t), C.byref(n), C.byref(u), C.c_uint32(1 if reset else 0)), "world_get_accumulated_stage_times")
+        return t.as_dict(), n.value, u.value
+
     def stage_times(self):
         t = StageTimes()
         self.L.check(self.L.fn("world_get_stage_times")(self.h, C.byref(t)), "world_get_stage_times")

@@ -94,14 +94,16 @@ struct mi_world {
     DBuf<uint32_t> largeList, isLarge, cellKeys, cellRanks, cellKeysS, cellValsS, cellCount, cellLower;
     DBuf<int> blockBounds;
     DBuf<float4> sMin, sMax;
-    DBuf<GridParams> grid; DBuf<StepScalars> scalars; DBuf<Shards> shards;
+    DBuf<GridParams> grid; DBuf<char> scalarsRaw; DBuf<Shards> shards;   // scalarsRaw = [StepScalars][colouring round flags]: one read-back
+    StepScalars* scalarsPtr() { return reinterpret_cast<StepScalars*>(scalarsRaw.p); }
+    uint32_t* roundFlagsPtr() { return reinterpret_cast<uint32_t*>(scalarsRaw.p + sizeof(StepScalars)); }
     DBuf<uint64_t> pairKeys, pairKeysS;
     DBuf<char> temp;
     // narrow phase
     DBuf<uint64_t> npPacked, npScan; DBuf<float4> npNormal, npPoints;
     DBuf<uint32_t> manPair; DBuf<uint2> manBodies, manInfo; DBuf<uint4> colWork;
     // schedule + solver
-    DBuf<uint32_t> color, order, orderTmp, roundFlags, blockHist, blockScan, tileBin; DBuf<unsigned long long> bodyTop, bodyUsed;
+    DBuf<uint32_t> color, order, orderTmp, blockHist, blockScan, tileBin; DBuf<unsigned long long> bodyTop, bodyUsed;
     DBuf<BinInfo> binInfo;
     // colour history (pair -> colour of the previous step): two tables, the one written by a step becomes current only if the step is valid
     DBuf<unsigned long long> tabKeys[2]; DBuf<uint32_t> tabVals[2]; uint32_t tabMask[2] = {0, 0}; int tabCur = 0; bool tabValid = false;
@@ -115,6 +117,9 @@ struct mi_world {
     bool xcdSwizzle = false;
 
     StepScalars hs{};            // host copy of the last step's scalars
+    struct Readback { StepScalars sc; uint32_t flags[96]; };
+    Readback* hsPinned = nullptr; // pinned staging for the end-of-step read-back (one async copy, no pageable bounce)
+    mi_stage_times timesSum{}; uint32_t timesSteps = 0; uint64_t contactUpdatesSum = 0;   // accumulated since the last mi_world_get_accumulated_stage_times(reset)
     mi_step_counts counts{};
     mi_stage_times times{};
     hipEvent_t ev[10]{};
@@ -150,12 +155,12 @@ int mi_world::init(int dev) {
     HIP_TRY(hipSetDevice(dev));
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(scalars.ensure(1));
+    HIP_TRY(scalarsRaw.ensure(sizeof(StepScalars) + (kMaxColorRounds + 2) * sizeof(uint32_t)));
     HIP_TRY(grid.ensure(1));
     HIP_TRY(shards.ensure(1));
-    HIP_TRY(hipMemsetAsync(scalars.p, 0, sizeof(StepScalars), stream));
+    HIP_TRY(hipMemsetAsync(scalarsRaw.p, 0, sizeof(StepScalars) + (kMaxColorRounds + 2) * sizeof(uint32_t), stream));
     HIP_TRY(binInfo.ensure(kSchedBins));
-    HIP_TRY(roundFlags.ensure(kMaxColorRounds + 2));
+    HIP_TRY(hipHostMalloc((void**)&hsPinned, sizeof(Readback)));
     const char* sw = getenv("MI_XCD_SWIZZLE");
     xcdSwizzle = sw && sw[0] == '1';
     const char* sv = getenv("MI_SOLVER");
@@ -167,6 +172,7 @@ int mi_world::init(int dev) {
     return MI_OK;
 }
 mi_world::~mi_world() {
+    if (hsPinned) (void)hipHostFree(hsPinned);
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
     for (auto& e : profEvents) (void)hipEventDestroy(e);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -432,7 +438,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
 int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     const uint32_t nb = (uint32_t)bodies.size(), nc = (uint32_t)colliders.size();
     const uint32_t B = 256;
-    StepScalars* sc = scalars.p;
+    StepScalars* sc = scalarsPtr();
     hipStream_t st = stream;
     int evi = 0;
     auto mark = [&]() { (void)hipEventRecord(ev[evi++], st); };
@@ -440,7 +446,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     auto readScalars = [&]() -> int { HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); return MI_OK; };
 
     mark();  // 0
-    k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlags.p);
+    k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlagsPtr());
     if (nc) {
         k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis);
@@ -525,14 +531,14 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         uint32_t round = 0;
         while (true) {
             for (uint32_t r = 0; r < colorBatch; ++r, ++round)
-                k_color_round<<<divUp(nmBound, B), B, 0, st>>>(sc, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlags.p);
+                k_color_round<<<divUp(nmBound, B), B, 0, st>>>(sc, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlagsPtr());
             // schedule bins -> tiles (valid once the last round left nothing uncoloured: StepScalars::colorPending)
             k_bin_hist<<<binBlocks, 256, 0, st>>>(sc, binBlocks, color.p, manInfo.p, blockHist.p);
             size_t tb = 0;
             HIP_TRY(rocprim::exclusive_scan(nullptr, tb, blockHist.p, blockScan.p, 0u, (size_t)kColorBins * binBlocks, rocprim::plus<uint32_t>(), st));
             if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
             HIP_TRY(rocprim::exclusive_scan(temp.p, tb, blockHist.p, blockScan.p, 0u, (size_t)kColorBins * binBlocks, rocprim::plus<uint32_t>(), st));
-            k_bin_scatter<<<binBlocks, 256, 0, st>>>(round - 1, roundFlags.p, binBlocks, color.p, manInfo.p, blockScan.p, order.p, sc);
+            k_bin_scatter<<<binBlocks, 256, 0, st>>>(round - 1, roundFlagsPtr(), binBlocks, color.p, manInfo.p, blockScan.p, order.p, sc);
             k_build_tiles<<<1, 256, 0, st>>>(tilesCap, ctCap, sc, binInfo.p);
             k_fill_tiles<<<divUp(tilesCap, B), B, 0, st>>>(sc, binInfo.p, tileBin.p, tileDesc.p);
             if (spec) break;
@@ -632,9 +638,10 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     k_integrate_velocities<<<divUp(nb, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p);
     mark();  // 8
     // ---------------------------------------------------------------------------------------------- end of step: the one read-back
-    uint32_t flagsHost[96] = {0};
-    if (nmBound) HIP_TRY(hipMemcpyAsync(flagsHost, roundFlags.p, sizeof(flagsHost), hipMemcpyDeviceToHost, st));
-    { int rc2 = readScalars(); if (rc2 != MI_OK) return rc2; }
+    HIP_TRY(hipMemcpyAsync(hsPinned, sc, sizeof(Readback), hipMemcpyDeviceToHost, st));   // scalars + round flags are contiguous
+    HIP_TRY(hipStreamSynchronize(st));
+    hs = hsPinned->sc;
+    const uint32_t* flagsHost = hsPinned->flags;
     HIP_TRY(hipGetLastError());
     if (spec) {
         const uint32_t ovfCount = hs.binStart[kColorBins] - hs.binStart[kSchedBins - 1];
@@ -668,6 +675,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     counts.num_rigid_bodies = nb; counts.num_colliders = nc; counts.num_broadphase_overlaps = nc ? hs.numOverlaps : 0;
     counts.num_collisions = pairBound ? hs.numManifolds : 0; counts.num_contacts = pairBound ? hs.numContacts : 0;
     counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur; counts.reserved = solveLaunches;
+    { float* a = &timesSum.world_colliders; const float* b = &times.world_colliders; for (int i = 0; i < 9; ++i) a[i] += b[i]; ++timesSteps;
+      contactUpdatesSum += (uint64_t)counts.num_contacts * iters; }
     return MI_OK;
 }
 
@@ -1048,6 +1057,14 @@ MI_API int mi_world_get_mass_properties(mi_world* w, float* invMass, float* invI
     return MI_OK;
 }
 MI_API int mi_world_get_counts(mi_world* w, mi_step_counts* out) { if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null"); *out = w->counts; return MI_OK; }
+MI_API int mi_world_get_accumulated_stage_times(mi_world* w, mi_stage_times* out_sum, uint32_t* out_steps, uint64_t* out_contact_updates, uint32_t reset) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    if (out_sum) *out_sum = w->timesSum;
+    if (out_steps) *out_steps = w->timesSteps;
+    if (out_contact_updates) *out_contact_updates = w->contactUpdatesSum;
+    if (reset) { w->timesSum = mi_stage_times{}; w->timesSteps = 0; w->contactUpdatesSum = 0; }
+    return MI_OK;
+}
 MI_API int mi_world_get_stage_times(mi_world* w, mi_stage_times* out) { if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null"); *out = w->times; return MI_OK; }
 
 MI_API int mi_world_get_contacts(mi_world* w, mi_contact* out, uint32_t cap, uint32_t* count) {

@@ -219,6 +219,10 @@ MI_API int mi_world_get_counts(mi_world* world, mi_step_counts* out);
 /* Contacts of the last internal step in solver (canonical) order; returns count in *out_count. */
 MI_API int mi_world_get_contacts(mi_world* world, mi_contact* out, uint32_t capacity, uint32_t* out_count);
 MI_API int mi_world_get_stage_times(mi_world* world, mi_stage_times* out);
+/* Sum of the per-stage device times and of the contact updates (contacts x solver iterations) over the internal steps since
+ * the last reset (so a benchmark loop does not have to call back into the library after every step). */
+MI_API int mi_world_get_accumulated_stage_times(mi_world* world, mi_stage_times* out_sum, uint32_t* out_steps,
+                                                uint64_t* out_contact_updates, uint32_t reset);
 /* Stage dumps for parity bisecting: world AABBs (6 floats per collider, world index order) and the
  * solver colour of every manifold of the last step. */
 MI_API int mi_world_get_aabbs(mi_world* world, float* out_min_max6, uint32_t capacity);
