@@ -346,9 +346,10 @@ __device__ __forceinline__ V3 obbSupport(Q4 rot, V3 center, V3 radius, V3 dir) {
     return center + rotate(rot, r);
 }
 
-// OBB vs OBB (1179-1527)
-template <class Poly>
-__device__ inline bool obbOBB(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 brad, Poly& poly, Poly& clipped, Manifold& out) {
+// OBB vs OBB (1179-1527), in two halves so a kernel can run the cheap 15-axis SAT for every pair and the expensive
+// contact generation (clipping) only for the pairs that overlap, re-packed into dense waves.
+struct ObbSat { V3 normal; bool faceHit, bFace; };
+__device__ inline bool obbSat(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 brad, ObbSat& res) {
     V3 ax = rotate(arot, V3(1.f, 0.f, 0.f)), ay = rotate(arot, V3(0.f, 1.f, 0.f)), az = rotate(arot, V3(0.f, 0.f, 1.f));
     V3 bx = rotate(brot, V3(1.f, 0.f, 0.f)), by = rotate(brot, V3(0.f, 1.f, 0.f)), bz = rotate(brot, V3(0.f, 0.f, 1.f));
     M3 r;
@@ -410,6 +411,13 @@ __device__ inline bool obbOBB(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 br
     else normal = edgeNormal;
     normal = rotate(arot, normal);
     if (dot(normal, tw) < 0.f) normal = -normal;
+    res.normal = normal; res.faceHit = faceHit; res.bFace = bFace;
+    return true;
+}
+template <class Poly>
+__device__ inline bool obbContacts(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 brad, const ObbSat& res, Poly& poly, Poly& clipped, Manifold& out) {
+    const V3 normal = res.normal;
+    const bool faceHit = res.faceHit, bFace = res.bFace;
     out.n = normal;
     if (faceHit) {
         V3 cp[4], cn[4], quad[4];
@@ -457,6 +465,12 @@ __device__ inline bool obbOBB(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 br
         out.p[0] = (pa + pb) * 0.5f;
     }
     return true;
+}
+template <class Poly>
+__device__ inline bool obbOBB(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 brad, Poly& poly, Poly& clipped, Manifold& out) {
+    ObbSat res;
+    if (!obbSat(arot, acen, arad, brot, bcen, brad, res)) return false;
+    return obbContacts(arot, acen, arad, brot, bcen, brad, res, poly, clipped, out);
 }
 
 }  // namespace mi

@@ -100,7 +100,7 @@ struct mi_world {
     DBuf<uint64_t> pairKeys, pairKeysS;
     DBuf<char> temp;
     // narrow phase
-    DBuf<uint64_t> npPacked, npScan; DBuf<float4> npNormal, npPoints;
+    DBuf<uint64_t> npPacked, npScan; DBuf<float4> npNormal, npPoints; DBuf<BoxHit> boxQueue;
     DBuf<uint32_t> manPair; DBuf<uint2> manBodies, manInfo; DBuf<uint4> colWork;
     // schedule + solver
     DBuf<uint32_t> color, order, orderTmp, blockHist, blockScan, tileBin; DBuf<unsigned long long> bodyTop, bodyUsed;
@@ -403,6 +403,7 @@ __global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlag
     if (t == 0) {
         sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->solveError = 0;
         sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0;
+        for (int q = 0; q < 16; ++q) sc->boxHitCount[q] = 0;
         for (int a = 0; a < 3; ++a) { sc->boundsMin[a] = 0x7FFFFFFF; sc->boundsMax[a] = (int)0x80000000; }
     }
     if (t < 24) { sc->bucketHist[t] = 0; sc->bucketCursor[t] = 0; }
@@ -498,7 +499,11 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         HIP_TRY(colWork.ensure(pairBound)); HIP_TRY(color.ensure(pairBound));
         HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, ((size_t)nb + 1) * sizeof(unsigned long long), st));   // k_emit_manifolds seeds it with the kept colours
         HullSet hset{hullVerts.p, hullRanges.p};
-        k_narrow<<<divUp(pairBound, B), B, 0, st>>>(pairBound, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
+        const uint32_t narrowBlocks = divUp(pairBound, B);
+        const uint32_t queueRegion = divUp(narrowBlocks, kBoxQueues) * B;   // a queue can hold every pair of the workgroups that feed it
+        HIP_TRY(boxQueue.ensure((size_t)kBoxQueues * queueRegion));
+        k_narrow<<<narrowBlocks, B, 0, st>>>(pairBound, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p, boxQueue.p);
+        k_narrow_clip<<<kBoxQueues * (queueRegion / B), B, 0, st>>>(queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, boxQueue.p, npPacked.p, npNormal.p, npPoints.p);
         if (usesGjk) k_narrow_gjk<<<divUp(pairBound, 64), 64, 0, st>>>(sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
         size_t tb = 0;
         HIP_TRY(rocprim::exclusive_scan(nullptr, tb, npPacked.p, npScan.p, (uint64_t)0, pairBound, rocprim::plus<uint64_t>(), st));
