@@ -410,12 +410,12 @@ __device__ __forceinline__ bool aabbOverlap(const float4& amn, const float4& amx
 // range at the same time: loads are shared through L1 and candidates are fetched four at a time (8 loads in flight
 // per lane) instead of one dependent load pair per loop trip.
 constexpr uint32_t kPairBuf = 6;      // LDS-staged pair keys per collider-column before the block-level flush
-constexpr uint32_t kGridChunks = 4;   // a workgroup handles 4 x 256 consecutive sorted colliders for one column
+constexpr uint32_t kGridChunks = 2;   // a workgroup handles 2 x 256 consecutive sorted colliders for one column (24 KiB of staging: 6 workgroups per CU; measured 1: 168, 2: 148, 3: 154, 4: 171 us for the broad phase)
 
 // Pair compaction: a same-address global atomic sustains only ~90 ops/us on this chip, so per-pair, per-wave or even
-// per-256-lane-block atomics on one word bound the whole broad phase.  Each lane stages its hits in LDS (48 KiB per
+// per-256-lane-block atomics on one word bound the whole broad phase.  Each lane stages its hits in LDS (24 KiB per
 // workgroup), the block prefix-sums the per-lane counts (wave shuffles), ONE returning atomic reserves the block's
-// output range for 1024 colliders and the keys are copied out; a lane with more than kPairBuf hits in one column
+// output range for its 512 colliders and the keys are copied out; a lane with more than kPairBuf hits in one column
 // appends the excess directly (rare).  Sum-only counters go to the block's shard line.
 __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blocksPerColumn, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                        const float4* __restrict__ sMin, const float4* __restrict__ sMax,
