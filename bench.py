@@ -42,34 +42,77 @@ def parse():
     ap.add_argument("--cpu-grid", type=int, nargs=3, default=[32, 16, 32])
     ap.add_argument("--cpu-warmup", type=int, default=200)
     ap.add_argument("--cpu-steps", type=int, default=20)
+    ap.add_argument("--cpu-cores", type=int, default=0, help="oracle replicas for the CPU baseline (0 = all host cores)")
     return ap.parse_args()
 
 
-def cpu_baseline(args, bodies_full):
-    """CPU oracle (reference order = the reference's scalar path restated), 1 thread, bounded sample of the same
-    workload: same generator and column height, smaller footprint; reported scaled to the full body count."""
+def _cpu_replica(job):
+    """One oracle replica: settle, then time `steps` steps of a (nx, ny, nz) tile of the workload."""
+    nx, ny, nz, iterations, warmup, steps = job
     import oracle
     from d3d12renderer_amd import scenes
-    nx, ny, nz = args.cpu_grid
-    sc = scenes.obb_pile(nx, ny, nz, solver_iterations=args.iterations)
+    sc = scenes.obb_pile(nx, ny, nz, solver_iterations=iterations)
     w = sc.populate(oracle.create_world(oracle.ORDER_REFERENCE))
     s = sc.settings()
-    w.step_fixed(s, sc.dt, args.cpu_warmup)
+    w.step_fixed(s, sc.dt, warmup)
     t0 = time.perf_counter()
-    w.step_fixed(s, sc.dt, args.cpu_steps)
-    dt = time.perf_counter() - t0
-    nb = sc.num_bodies
-    steps_per_s = args.cpu_steps / dt
+    w.step_fixed(s, sc.dt, steps)
+    return steps / (time.perf_counter() - t0), sc.num_bodies, w.counts()["num_contacts"]
+
+
+def _usable_cores():
+    """Host cores this process may actually use: affinity mask and cgroup CPU quota, not the machine's logical CPU count."""
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_baseline(args, bodies_full):
+    """CPU oracle (reference order = the reference's scalar path restated) on a bounded sample of the same workload: same
+    generator and column height, smaller footprint.  The reference step is single-threaded, so "the host cores of the box"
+    are used the only way that code can use them: one independent replica per core, each its own
+    process; the value is the aggregate body-steps/s of all replicas expressed in steps/s of the full 262144-body scene."""
+    import subprocess
+    import oracle
+    oracle.build()
+    nx, ny, nz = args.cpu_grid
+    cores = max(1, min(args.cpu_cores or _usable_cores(), 64))
+    job = [nx, ny, nz, args.iterations, args.cpu_warmup, args.cpu_steps]
+    cmd = [sys.executable, str(Path(__file__).resolve()), "--cpu-replica", json.dumps(job)]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(cores)]
+    res = []
+    for p in procs:
+        out, _ = p.communicate(timeout=900)
+        if p.returncode == 0 and out.strip():
+            res.append(json.loads(out.strip().splitlines()[-1]))
+    if not res:
+        res = [list(_cpu_replica(job))]
+    nb = res[0][1]
+    agg = sum(r[0] for r in res)                      # replica-steps/s, all replicas together (they ran concurrently)
     return {
-        "value": steps_per_s * nb / bodies_full, "unit": "steps/s", "cores": 1, "kind": "port",
-        "sample": (f"oracle (reference order, -O2 strict fp32, 1 thread) on obb_pile {nx}x{ny}x{nz} = {nb} bodies, I={args.iterations}, "
-                   f"{args.cpu_warmup} settle + {args.cpu_steps} timed steps: {steps_per_s:.2f} steps/s at {nb} bodies, "
-                   f"{w.counts()['num_contacts']} contacts; value = that rate x {nb}/{bodies_full} (linear in bodies)"),
-        "measured_steps_per_s": steps_per_s, "sample_bodies": nb,
+        "value": agg * nb / bodies_full, "unit": "steps/s", "cores": len(res), "kind": "port",
+        "sample": (f"oracle (reference order, -O2 strict fp32) on obb_pile {nx}x{ny}x{nz} = {nb} bodies, I={args.iterations}, "
+                   f"{args.cpu_warmup} settle + {args.cpu_steps} timed steps, one independent single-threaded replica per core, "
+                   f"{len(res)} concurrent replicas: {agg:.1f} replica-steps/s in aggregate ({agg / len(res):.2f} per replica, "
+                   f"{res[0][2]} contacts each); value = aggregate x {nb}/{bodies_full} (linear in bodies)"),
+        "per_core_value": agg / len(res) * nb / bodies_full, "measured_replica_steps_per_s": agg, "sample_bodies": nb,
     }
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-replica":     # worker process of cpu_baseline()
+        print(json.dumps(list(_cpu_replica(json.loads(sys.argv[2])))))
+        return
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
