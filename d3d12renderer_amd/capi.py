@@ -22,6 +22,9 @@ entity_desc = np.dtype([
 collider_desc = np.dtype([
     ("type", "<u4"), ("object_type", "<u4"), ("shape", "<f4", 12), ("hull_geometry", "<u4"),
     ("restitution", "<f4"), ("friction", "<f4"), ("density", "<f4")])
+EVENT_COLLISION_BEGIN, EVENT_COLLISION_END = 0, 1
+event_dtype = np.dtype([("type", "<u4"), ("entity_a", "<u4"), ("entity_b", "<u4"), ("collider_a", "<u4"), ("collider_b", "<u4"),
+                        ("point", "<f4", 3), ("normal", "<f4", 3), ("relative_velocity", "<f4", 3)])
 contact_dtype = np.dtype([
     ("point", "<f4", 3), ("penetration_depth", "<f4"), ("normal", "<f4", 3),
     ("friction_restitution", "<u4"), ("collider_a", "<u4"), ("collider_b", "<u4"),
@@ -204,6 +207,18 @@ class World:
         n = C.c_uint32(0); ms = C.c_float(0); upd = C.c_uint64(0)
         self.L.check(self.L.fn("world_step_profiled")(self.h, C.byref(settings), C.c_float(dt), C.byref(n), C.byref(ms), C.byref(upd)), "world_step_profiled")
         return n.value, ms.value, upd.value
+
+    def enable_events(self, enable=True):
+        self.L.check(self.L.fn("world_enable_events")(self.h, C.c_uint32(1 if enable else 0)), "world_enable_events")
+
+    def poll_events(self):
+        """Collision begin / end events of the internal steps since the last poll (numpy structured array)."""
+        n = C.c_uint32(0)
+        self.L.check(self.L.fn("world_poll_events")(self.h, None, C.c_uint32(0), C.byref(n)), "world_poll_events")
+        out = np.zeros(n.value, dtype=event_dtype)
+        if n.value:
+            self.L.check(self.L.fn("world_poll_events")(self.h, _ptr(out), C.c_uint32(n.value), C.byref(n)), "world_poll_events")
+        return out
 
     def step_mode_stats(self):
         """(internal steps, speculative steps, synchronous retries) since creation (product library only)."""

@@ -56,6 +56,7 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numCells;             // cells of this step's broad-phase grid
     uint32_t numPairsFound;        // pair count of a step whose speculative pair bound was exceeded (numPairs is zeroed then)
     uint32_t boxHitCount[16];      // box pairs that passed the SAT, per queue (k_narrow -> k_narrow_clip)
+    uint32_t numEvents;            // collision begin / end events of this step (when events are enabled)
 };
 
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
@@ -765,6 +766,10 @@ __device__ __forceinline__ uint64_t pairPriority(uint32_t a, uint32_t b) {
 // of the previous step to its colour.  A manifold that persists keeps its colour (still conflict-free: the manifolds it
 // shared a body with kept theirs or vanished), so the Jones-Plassmann rounds only have to colour the NEW manifolds of a
 // step — a few percent of them once a pile has settled.  Stored key = (A << 26 | B) + 1 (0 = empty slot).
+// keyed by collider CREATION indices (world index = nc - 1 - creation index), so the history survives colliders being added
+__device__ __forceinline__ uint64_t historyKey(uint32_t nc, uint32_t worldA, uint32_t worldB) {
+    return (((uint64_t)(nc - 1u - worldA) << kIndexBits) | (uint64_t)(nc - 1u - worldB)) + 1ull;
+}
 __device__ __forceinline__ uint32_t tableSlot(uint64_t key, uint32_t mask) {
     uint64_t x = key * 0x9E3779B97F4A7C15ull;
     return (uint32_t)(x >> 40) & mask;
@@ -777,30 +782,82 @@ __device__ __forceinline__ uint32_t tableLookup(const unsigned long long* __rest
     }
     return kUncolored;
 }
-__global__ __launch_bounds__(256) void k_color_table_insert(const StepScalars* __restrict__ sc, const uint32_t* __restrict__ manPair,
+__global__ __launch_bounds__(256) void k_color_table_insert(uint32_t nc, const StepScalars* __restrict__ sc, const uint32_t* __restrict__ manPair,
                                                             const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                             const uint32_t* __restrict__ color, unsigned long long* __restrict__ keys,
                                                             uint32_t* __restrict__ vals, uint32_t mask) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= sc->numManifolds) return;
     uint64_t pk = (sc->partitioned ? pairsB : pairsA)[manPair[m]];
-    uint64_t key = ((((pk >> 29) & 0x1FFFFFFFull) << kIndexBits) | (pk & 0x1FFFFFFFull)) + 1ull;
+    uint64_t key = historyKey(nc, (uint32_t)((pk >> 29) & 0x1FFFFFFFull), (uint32_t)(pk & 0x1FFFFFFFull));
     for (uint32_t s = tableSlot(key, mask), n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
         unsigned long long old = atomicCAS(&keys[s], 0ull, (unsigned long long)key);
         if (old == 0ull) { vals[s] = color[m]; return; }
     }
 }
 
+// Collision events (handleCollisionCallbacks, src/physics/physics.cpp:1041-1178), device half.  A manifold whose oriented
+// collider pair is not in the previous step's history table begins (k_emit_manifolds flags it); a pair of the previous table
+// that is not in this step's table ended.  Begin records carry the mean contact point / normal and the relative point
+// velocity from the solver-side body state after force integration (rbGlobal).  Appends are wave-aggregated.
+struct DeviceEvent { uint32_t type, colliderA, colliderB, pad; float point[3]; float normal[3]; float relVel[3]; };
+__device__ __forceinline__ uint32_t waveAppendSlot(bool want, uint32_t* counter) {
+    unsigned long long mask = __ballot(want);
+    uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)mask) - 1u, base = 0;
+    if (!mask) return 0u;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = __shfl(base, (int)leader, 64);
+    return base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+}
+__global__ __launch_bounds__(256) void k_events_begin(uint32_t nc, uint32_t cap, StepScalars* sc, const uint8_t* __restrict__ isNew, const uint32_t* __restrict__ manPair,
+                                                      const uint2* __restrict__ manBodies, const uint2* __restrict__ manInfo,
+                                                      const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
+                                                      const float4* __restrict__ npNormal, const float4* __restrict__ npPoints,
+                                                      const float4* __restrict__ gPos, const float4* __restrict__ gVel, DeviceEvent* __restrict__ events) {
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    bool want = m < sc->numManifolds && isNew[m] != 0;
+    uint32_t slot = waveAppendSlot(want, &sc->numEvents);
+    if (!want) return;
+    if (slot >= cap) { sc->specOverflow = 1u; return; }
+    uint32_t p = manPair[m], n = manInfo[m].x & 7u;
+    uint64_t pk = (sc->partitioned ? pairsB : pairsA)[p];
+    uint2 bodies = manBodies[m];
+    float norm = 1.f / (float)n;
+    V3 point(0.f), normal(0.f), nrm = xyz(npNormal[p]);
+    for (uint32_t i = 0; i < n; ++i) { point = point + xyz(npPoints[4 * p + i]); normal = normal + nrm; }
+    point = point * norm; normal = normal * norm;
+    V3 vA = xyz(gVel[2 * bodies.x]), wA = xyz(gVel[2 * bodies.x + 1]), vB = xyz(gVel[2 * bodies.y]), wB = xyz(gVel[2 * bodies.y + 1]);
+    V3 velA = vA + cross(wA, point - xyz(gPos[bodies.x])), velB = vB + cross(wB, point - xyz(gPos[bodies.y]));
+    V3 rel = velB - velA;
+    DeviceEvent e; e.type = 0u; e.colliderA = nc - 1u - (uint32_t)((pk >> 29) & 0x1FFFFFFFull); e.colliderB = nc - 1u - (uint32_t)(pk & 0x1FFFFFFFull); e.pad = 0u;
+    e.point[0] = point.x; e.point[1] = point.y; e.point[2] = point.z; e.normal[0] = normal.x; e.normal[1] = normal.y; e.normal[2] = normal.z;
+    e.relVel[0] = rel.x; e.relVel[1] = rel.y; e.relVel[2] = rel.z;
+    events[slot] = e;
+}
+__global__ __launch_bounds__(256) void k_events_end(uint32_t cap, StepScalars* sc, const unsigned long long* __restrict__ prevKeys, uint32_t prevMask,
+                                                    const unsigned long long* __restrict__ curKeys, const uint32_t* __restrict__ curVals, uint32_t curMask,
+                                                    DeviceEvent* __restrict__ events) {
+    uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long key = s <= prevMask ? prevKeys[s] : 0ull;
+    bool want = key != 0ull && tableLookup(curKeys, curVals, curMask, key) == kUncolored;
+    uint32_t slot = waveAppendSlot(want, &sc->numEvents);
+    if (!want) return;
+    if (slot >= cap) { sc->specOverflow = 1u; return; }
+    DeviceEvent e{};
+    e.type = 1u; e.colliderA = (uint32_t)((key - 1ull) >> kIndexBits); e.colliderB = (uint32_t)((key - 1ull) & ((1ull << kIndexBits) - 1ull));
+    events[slot] = e;
+}
+
 // After the scans: manifold m <- pair p (count > 0).  colWork = (bodyA | dynA << 31, bodyB | dynB << 31, priority lo, hi):
 // everything a colouring round needs in one 16-byte row.
-__global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nb, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB, const uint64_t* __restrict__ npPacked,
+__global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB, const uint64_t* __restrict__ npPacked,
                                                         const uint64_t* __restrict__ npScan,
                                                         const float4* __restrict__ aabbMax, const float4* __restrict__ cMaterial,
                                                         const float4* __restrict__ bCogInvMass,
                                                         uint32_t* __restrict__ manPair, uint2* __restrict__ manBodies, uint2* __restrict__ manInfo,
                                                         uint4* __restrict__ colWork, uint32_t* __restrict__ color,
                                                         const unsigned long long* __restrict__ prevKeys, const uint32_t* __restrict__ prevVals, uint32_t prevMask,
-                                                        unsigned long long* __restrict__ bodyUsed, StepScalars* sc) {
+                                                        unsigned long long* __restrict__ bodyUsed, uint8_t* __restrict__ isNew, StepScalars* sc) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t numPairs = sc->numPairs;
     if (p >= numPairs) return;
@@ -825,7 +882,8 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nb, const uint6
     uint64_t prio = pairPriority(a, b);
     colWork[m] = make_uint4(bA | dynA, bB | dynB, (uint32_t)prio, (uint32_t)(prio >> 32));
     // a manifold of the previous step keeps its colour (colour 64 = overflow is re-coloured)
-    uint32_t c = prevKeys ? tableLookup(prevKeys, prevVals, prevMask, (((uint64_t)a << kIndexBits) | (uint64_t)b) + 1ull) : kUncolored;
+    uint32_t c = prevKeys ? tableLookup(prevKeys, prevVals, prevMask, historyKey(nc, a, b)) : kUncolored;
+    if (isNew) isNew[m] = c == kUncolored ? 1u : 0u;   // not in the previous step's collision list: collision-begin event
     if (c < kOverflowColor) {
         if (dynA) atomicOr(&bodyUsed[bA], 1ull << c);
         if (dynB) atomicOr(&bodyUsed[bB], 1ull << c);

@@ -107,7 +107,8 @@ struct mi_world {
     DBuf<BinInfo> binInfo;
     // colour history (pair -> colour of the previous step): two tables, the one written by a step becomes current only if the step is valid
     DBuf<unsigned long long> tabKeys[2]; DBuf<uint32_t> tabVals[2]; uint32_t tabMask[2] = {0, 0}; int tabCur = 0; bool tabValid = false;
-    bool collidersChanged = true;
+    // collision events (mi_world_enable_events / mi_world_poll_events)
+    bool eventsEnabled = false; DBuf<uint8_t> manIsNew; DBuf<DeviceEvent> devEvents; std::vector<mi_event> pendingEvents;
     DBuf<float4> rows, slotNormal; DBuf<float4> imp; DBuf<float2> slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc;
     bool usedFlow = false;
     uint32_t flowLds = 0;                  // dynamic LDS bytes per 64-lane workgroup: caps resident waves per CU (160 KiB / flowLds)
@@ -331,7 +332,6 @@ int mi_world::upload() {
     HIP_TRY(gPos.ensure(nb + 1)); HIP_TRY(gInvI.ensure(3 * ((size_t)nb + 1))); HIP_TRY(gVel.ensure(2 * ((size_t)nb + 1)));
     HIP_TRY(bodyTop.ensure(2 * ((size_t)nb + 1))); HIP_TRY(bodyUsed.ensure(nb + 1));
 
-    if (collidersChanged) { tabValid = false; collidersChanged = false; }   // collider world indices shifted: drop the colour history
     usesGjk = false;
     for (const HCollider& c : colliders) if (c.desc.type == T_CAPSULE || c.desc.type == T_CYLINDER || c.desc.type == T_HULL) usesGjk = true;
     std::vector<uint32_t> tb(2 * (size_t)nc); std::vector<float4> sh(3 * (size_t)nc), sp(nc), sr(nc), mat(nc);
@@ -402,7 +402,7 @@ __global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlag
     for (uint32_t i = t; i < kMaxColorRounds + 2u; i += blockDim.x) roundFlags[i] = 0u;
     if (t == 0) {
         sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->solveError = 0;
-        sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0;
+        sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0; sc->numEvents = 0;
         for (int q = 0; q < 16; ++q) sc->boxHitCount[q] = 0;
         for (int a = 0; a < 3; ++a) { sc->boundsMin[a] = 0x7FFFFFFF; sc->boundsMax[a] = (int)0x80000000; }
     }
@@ -509,9 +509,10 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         HIP_TRY(rocprim::exclusive_scan(nullptr, tb, npPacked.p, npScan.p, (uint64_t)0, pairBound, rocprim::plus<uint64_t>(), st));
         if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
         HIP_TRY(rocprim::exclusive_scan(temp.p, tb, npPacked.p, npScan.p, (uint64_t)0, pairBound, rocprim::plus<uint64_t>(), st));
-        k_emit_manifolds<<<divUp(pairBound, B), B, 0, st>>>(nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
+        if (eventsEnabled) HIP_TRY(manIsNew.ensure(pairBound));
+        k_emit_manifolds<<<divUp(pairBound, B), B, 0, st>>>(nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
-                                                        tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, sc);
+                                                        tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc);
     }
     mark();  // 3
     k_integrate_forces<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p,
@@ -523,7 +524,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         if (spec) { nmBound = std::min(pairBound, bound(last.numManifolds, 1024)); conBound = bound(last.numContacts, 4096); }
         else { int rc = readScalars(); if (rc != MI_OK) return rc; nmBound = hs.numManifolds; conBound = hs.numContacts; }
     }
-    uint32_t tilesCap = 0, ctCap = 0;
+    uint32_t tilesCap = 0, ctCap = 0, eventCap = 0;
     uint32_t colorBatch = spec ? std::min<uint32_t>(96u, last.colorRounds + std::max(3u, last.colorRounds / 4u)) : 20u;   // converged rounds exit at once
     if (nmBound) {
         tilesCap = divUp(nmBound, 64) + kSchedBins + 8; ctCap = divUp(conBound, 64) + 4 * kSchedBins + 8;
@@ -559,7 +560,14 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             HIP_TRY(tabKeys[nt].ensure(cap)); HIP_TRY(tabVals[nt].ensure(cap));
             tabMask[nt] = cap - 1u;
             HIP_TRY(hipMemsetAsync(tabKeys[nt].p, 0, (size_t)cap * sizeof(unsigned long long), st));
-            k_color_table_insert<<<divUp(nmBound, B), B, 0, st>>>(sc, manPair.p, pairKeys.p, pairKeysS.p, color.p, tabKeys[nt].p, tabVals[nt].p, tabMask[nt]);
+            k_color_table_insert<<<divUp(nmBound, B), B, 0, st>>>(nc, sc, manPair.p, pairKeys.p, pairKeysS.p, color.p, tabKeys[nt].p, tabVals[nt].p, tabMask[nt]);
+            if (eventsEnabled) {   // begins: manifolds not in the previous table; ends: previous pairs not in this step's table
+                eventCap = nmBound + (tabValid ? last.numManifolds : 0u) + 1024u;
+                HIP_TRY(devEvents.ensure(eventCap));
+                k_events_begin<<<divUp(nmBound, B), B, 0, st>>>(nc, eventCap, sc, manIsNew.p, manPair.p, manBodies.p, manInfo.p, pairKeys.p, pairKeysS.p,
+                                                               npNormal.p, npPoints.p, gPos.p, gVel.p, devEvents.p);
+                if (tabValid) k_events_end<<<divUp(tabMask[tabCur] + 1u, B), B, 0, st>>>(eventCap, sc, tabKeys[tabCur].p, tabMask[tabCur], tabKeys[nt].p, tabVals[nt].p, tabMask[nt], devEvents.p);
+            }
         }
         if (!spec) {
             mirrorSchedule();
@@ -660,6 +668,31 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         profContacts = mainContacts * iters;
         profKernelMs = 0.f;
         for (uint32_t l = 0; l < profLaunches; ++l) { float ms = 0.f; (void)hipEventElapsedTime(&ms, profEvents[2 * l], profEvents[2 * l + 1]); profKernelMs += ms; }
+    }
+    if (eventsEnabled) {
+        if (!nmBound && tabValid) {   // no manifolds at all this step: every collision of the previous step ended
+            uint32_t cap = last.numManifolds + 1024u;
+            HIP_TRY(devEvents.ensure(cap));
+            const int nt = tabCur ^ 1;
+            HIP_TRY(tabKeys[nt].ensure(1024)); HIP_TRY(tabVals[nt].ensure(1024)); tabMask[nt] = 1023u;
+            HIP_TRY(hipMemsetAsync(tabKeys[nt].p, 0, 1024 * sizeof(unsigned long long), st));
+            k_events_end<<<divUp(tabMask[tabCur] + 1u, B), B, 0, st>>>(cap, sc, tabKeys[tabCur].p, tabMask[tabCur], tabKeys[nt].p, tabVals[nt].p, tabMask[nt], devEvents.p);
+            HIP_TRY(hipMemcpyAsync(hsPinned, sc, sizeof(Readback), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            hs = hsPinned->sc;
+        }
+        if (hs.numEvents) {
+            std::vector<DeviceEvent> ev_(hs.numEvents);
+            HIP_TRY(hipMemcpyAsync(ev_.data(), devEvents.p, (size_t)hs.numEvents * sizeof(DeviceEvent), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            std::sort(ev_.begin(), ev_.end(), [](const DeviceEvent& x, const DeviceEvent& y) { return x.colliderA != y.colliderA ? x.colliderA < y.colliderA : x.colliderB < y.colliderB; });
+            for (const DeviceEvent& d : ev_) {   // the reference's sorted merge visits the pairs in ascending (a, b) order
+                mi_event e{}; e.type = d.type; e.collider_a = d.colliderA; e.collider_b = d.colliderB;
+                e.entity_a = colliders[d.colliderA].entity; e.entity_b = colliders[d.colliderB].entity;
+                for (int k = 0; k < 3; ++k) { e.point[k] = d.point[k]; e.normal[k] = d.normal[k]; e.relative_velocity[k] = d.relVel[k]; }
+                pendingEvents.push_back(e);
+            }
+        }
     }
     // the step is valid: the freshly integrated state becomes the current one
     std::swap(bPos.p, bPosN.p); std::swap(bRot.p, bRotN.p); std::swap(bLinVel.p, bLinVelN.p); std::swap(bAngVel.p, bAngVelN.p);
@@ -900,7 +933,6 @@ MI_API int mi_colliders_add(mi_world* w, uint32_t count, const uint32_t* ents, c
         e.colliders.insert(e.colliders.begin(), id);   // linked-list prepend (src/scene/scene.h:52-54)
     }
     if (w->colliders.size() >= (1u << kIndexBits)) return fail(MI_ERR_CAPACITY, "collider index space is 26 bits per world");
-    if (count) w->collidersChanged = true;
     w->topologyDirty = true;
     return MI_OK;
 }
@@ -1005,6 +1037,22 @@ MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
     return MI_OK;
 }
 
+MI_API int mi_world_enable_events(mi_world* w, uint32_t enable) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    w->eventsEnabled = enable != 0; w->pendingEvents.clear();
+    w->tabValid = false;           // the event diff starts from an empty previous frame (so does the colour history, once)
+    w->haveEstimates = false;
+    return MI_OK;
+}
+MI_API int mi_world_poll_events(mi_world* w, mi_event* out, uint32_t cap, uint32_t* count) {
+    if (!w || !count) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    *count = (uint32_t)w->pendingEvents.size();
+    if (!out) return MI_OK;
+    if (cap < w->pendingEvents.size()) return fail(MI_ERR_CAPACITY, "capacity < pending events");
+    std::memcpy(out, w->pendingEvents.data(), w->pendingEvents.size() * sizeof(mi_event));
+    w->pendingEvents.clear();
+    return MI_OK;
+}
 MI_API int mi_world_get_step_mode_stats(mi_world* w, uint32_t* steps, uint32_t* spec, uint32_t* retries) {
     if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     if (steps) *steps = w->totalSteps;

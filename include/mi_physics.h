@@ -229,6 +229,26 @@ MI_API int mi_world_get_aabbs(mi_world* world, float* out_min_max6, uint32_t cap
 MI_API int mi_world_get_manifold_colors(mi_world* world, uint32_t* out_colors, uint32_t capacity);
 
 /*
+ * Collision events — collisionBeginCallback / collisionEndCallback of physics_settings (src/physics/physics.h:398-399),
+ * fired by handleCollisionCallbacks (src/physics/physics.cpp:1041-1178).  The reference calls std::function callbacks
+ * synchronously inside the step; across a C ABI they are polled: events of the internal steps since the last poll, per step
+ * in ascending (collider_a, collider_b) order — the order of the reference's sorted merge of the previous and the current
+ * frame's collision lists.  Like there, a pair is identified by its ORIENTED collider pair (a re-oriented pair ends and begins).
+ * Disabled by default (the reference only diffs the lists when a callback is set); costs nothing when disabled.
+ */
+typedef enum mi_event_type { MI_EVENT_COLLISION_BEGIN = 0, MI_EVENT_COLLISION_END = 1 } mi_event_type;
+typedef struct mi_event {
+    uint32_t type;                  /* mi_event_type */
+    uint32_t entity_a, entity_b;    /* the colliders' parent entities (collision_begin_event::entityA/B) */
+    uint32_t collider_a, collider_b;/* collider ids as returned by mi_collider_add (creation order) */
+    float point[3];                 /* begin only: mean contact point, mean normal, velocity of B relative to A at the point */
+    float normal[3];
+    float relative_velocity[3];
+} mi_event;
+MI_API int mi_world_enable_events(mi_world* world, uint32_t enable);
+MI_API int mi_world_poll_events(mi_world* world, mi_event* out, uint32_t capacity, uint32_t* out_count);
+
+/*
  * Ghost-region exchange support (multi-GPU spatial sharding).  A body state is 13 floats:
  * position[3], rotation[4] (x,y,z,w), linear_velocity[3], angular_velocity[3] — i.e. physics_transform1 +
  * rigid_body_component velocities.  The host variants take entity ids and host buffers; the *_device variants

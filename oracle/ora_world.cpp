@@ -713,7 +713,8 @@ static void colorManifolds(World& w) {
     std::vector<uint64_t> used(w.rb.size(), 0);
     std::vector<uint32_t> firstContact(nm);
     { uint32_t off = 0; for (uint32_t m = 0; m < nm; ++m) { firstContact[m] = off; off += w.contactCounts[m]; } }
-    auto keyOf = [&](uint32_t m) { return ((uint64_t)w.colliderPairs[m].a << 26) | (uint64_t)w.colliderPairs[m].b; };
+    const uint32_t nc = (uint32_t)w.colliders.size();   // keyed by CREATION index (stable when colliders are added later)
+    auto keyOf = [&](uint32_t m) { return ((uint64_t)(nc - 1 - w.colliderPairs[m].a) << 26) | (uint64_t)(nc - 1 - w.colliderPairs[m].b); };
     std::vector<uint32_t> order;
     for (uint32_t m = 0; m < nm; ++m) {
         auto it = w.prevPairColor.find(keyOf(m));
@@ -742,6 +743,49 @@ static void colorManifolds(World& w) {
     for (uint32_t m = 0; m < nm; ++m) w.prevPairColor[keyOf(m)] = w.manifoldColor[m];
 }
 
+// handleCollisionCallbacks — src/physics/physics.cpp:1041-1178: sorted merge of the previous and the current frame's
+// collision lists; begin events carry the mean contact point / normal and the relative point velocity from rbGlobal.
+static void collisionEvents(World& w) {
+    const uint32_t nc = (uint32_t)w.colliders.size();
+    uint32_t nm = (uint32_t)w.colliderPairs.size();
+    std::vector<std::pair<uint64_t, uint32_t>> cur(nm);
+    std::vector<uint32_t> firstContact(nm);
+    { uint32_t off = 0; for (uint32_t m = 0; m < nm; ++m) { firstContact[m] = off; off += w.contactCounts[m]; } }
+    for (uint32_t m = 0; m < nm; ++m) cur[m] = {((uint64_t)(nc - 1 - w.colliderPairs[m].a) << 26) | (uint64_t)(nc - 1 - w.colliderPairs[m].b), m};
+    std::sort(cur.begin(), cur.end());
+    auto emit = [&](uint32_t type, uint64_t key, int m) {
+        mi_event e{}; e.type = type;
+        e.collider_a = (uint32_t)(key >> 26); e.collider_b = (uint32_t)(key & ((1u << 26) - 1u));
+        e.entity_a = w.colliders[e.collider_a].entity; e.entity_b = w.colliders[e.collider_b].entity;
+        if (m >= 0) {
+            uint32_t n = w.contactCounts[m], c0 = firstContact[m];
+            float norm = 1.f / (float)n;
+            vec3 point(0.f), normal(0.f);
+            for (uint32_t i = 0; i < n; ++i) { point += w.contacts[c0 + i].point; normal += w.contacts[c0 + i].normal; }
+            point *= norm; normal *= norm;
+            const GlobalState& A = w.rb[w.bodyPairs[c0].a]; const GlobalState& B = w.rb[w.bodyPairs[c0].b];
+            vec3 velA = A.linearVelocity + cross(A.angularVelocity, point - A.position);
+            vec3 velB = B.linearVelocity + cross(B.angularVelocity, point - B.position);
+            vec3 rel = velB - velA;
+            e.point[0] = point.x; e.point[1] = point.y; e.point[2] = point.z;
+            e.normal[0] = normal.x; e.normal[1] = normal.y; e.normal[2] = normal.z;
+            e.relative_velocity[0] = rel.x; e.relative_velocity[1] = rel.y; e.relative_velocity[2] = rel.z;
+        }
+        w.events.push_back(e);
+    };
+    size_t p = 0, t = 0;
+    while (p < w.prevCollisionKeys.size() && t < cur.size()) {
+        uint64_t pk = w.prevCollisionKeys[p], tk = cur[t].first;
+        if (pk == tk) { ++p; ++t; }
+        else if (pk < tk) { emit(MI_EVENT_COLLISION_END, pk, -1); ++p; }
+        else { emit(MI_EVENT_COLLISION_BEGIN, tk, (int)cur[t].second); ++t; }
+    }
+    while (p < w.prevCollisionKeys.size()) emit(MI_EVENT_COLLISION_END, w.prevCollisionKeys[p++], -1);
+    while (t < cur.size()) { emit(MI_EVENT_COLLISION_BEGIN, cur[t].first, (int)cur[t].second); ++t; }
+    w.prevCollisionKeys.resize(cur.size());
+    for (size_t i = 0; i < cur.size(); ++i) w.prevCollisionKeys[i] = cur[i].first;
+}
+
 // ---------------------------------------------------------------- step
 
 // physicsStepInternal — src/physics/physics.cpp:1180-1362
@@ -757,6 +801,7 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
     rb.resize(nb + 1);
     for (uint32_t i = nb; i-- > 0;) applyGravityAndIntegrateForces(bodies[i], rb[i], dt);  // back to front (1266-1276)
     std::memset((void*)&rb[nb], 0, sizeof(GlobalState));  // dummy (1279)
+    if (eventsEnabled) collisionEvents(*this); else prevCollisionKeys.clear();
 
     uint32_t ncontacts = (uint32_t)contacts.size();
     jointsInitialize(*this, dt);
@@ -879,7 +924,6 @@ MI_API int ora_entities_create(World* w, uint32_t count, const mi_entity_desc* d
 MI_API int ora_entity_create(World* w, const mi_entity_desc* d, uint32_t* out) { return ora_entities_create(w, 1, d, out); }
 
 MI_API int ora_colliders_add(World* w, uint32_t count, const uint32_t* entities, const mi_collider_desc* descs) {
-    if (w && count) w->prevPairColor.clear();   // collider world indices shift: the colour history is keyed by them
     for (uint32_t i = 0; i < count; ++i) {
         if (entities[i] >= w->entities.size()) return MI_ERR_INVALID_ARGUMENT;
         Collider c; shapeFromDesc(descs[i], c.local);
@@ -996,6 +1040,21 @@ MI_API int ora_world_get_contacts(World* w, mi_contact* out, uint32_t cap, uint3
             o.collider_a = w->colliderPairs[m].a; o.collider_b = w->colliderPairs[m].b;
             o.body_a = w->bodyPairs[ci].a; o.body_b = w->bodyPairs[ci].b;
         }
+    return MI_OK;
+}
+MI_API int ora_world_enable_events(World* w, uint32_t enable) {
+    if (!w) return MI_ERR_INVALID_ARGUMENT;
+    w->eventsEnabled = enable != 0; w->events.clear(); w->prevCollisionKeys.clear();
+    w->prevPairColor.clear();   // the product keeps ONE history table for colours and events; enabling events restarts it
+    return MI_OK;
+}
+MI_API int ora_world_poll_events(World* w, mi_event* out, uint32_t cap, uint32_t* count) {
+    if (!w || !count) return MI_ERR_INVALID_ARGUMENT;
+    *count = (uint32_t)w->events.size();
+    if (!out) return MI_OK;
+    if (cap < w->events.size()) return MI_ERR_CAPACITY;
+    std::memcpy(out, w->events.data(), w->events.size() * sizeof(mi_event));
+    w->events.clear();
     return MI_OK;
 }
 MI_API int ora_world_get_body_states(World* w, uint32_t n, const uint32_t* ents, float* out) {

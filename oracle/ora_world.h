@@ -115,6 +115,9 @@ struct World {
     std::vector<Contact> contacts;
     std::vector<Pair> bodyPairs;          // per contact
     std::vector<uint32_t> manifoldColor;  // canonical mode
+    bool eventsEnabled = false;
+    std::vector<uint64_t> prevCollisionKeys;   // sorted (creationA << 26 | creationB) of the previous step's manifolds
+    std::vector<mi_event> events;              // since the last poll
     std::unordered_map<uint64_t, uint32_t> prevPairColor;   // canonical mode: colour of every manifold of the previous step, by (colliderA << 26 | colliderB)
     std::vector<GlobalState> rb;
     mi_step_counts counts{};

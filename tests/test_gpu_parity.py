@@ -114,6 +114,23 @@ def test_gpu_edge_cases(mi_lib, oracle_mod):
     assert res[0] == res[1]
 
 
+def test_gpu_collision_events_match_oracle(mi_lib, oracle_mod):
+    """collisionBegin / collisionEnd events (polled): same events, same order, bit-identical payloads, every step."""
+    sc = scenes.mixed_stack(6, 5, 6)
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    g.enable_events(); o.enable_events()
+    s = sc.settings()
+    total = ends = 0
+    for i in range(150):
+        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        eg, eo = g.poll_events(), o.poll_events()
+        assert eg.tobytes() == eo.tobytes(), f"step {i}: {len(eg)} vs {len(eo)} events"
+        total += len(eg); ends += int((eg["type"] == capi.EVENT_COLLISION_END).sum())
+    assert total > 100 and ends > 0
+    pg, qg = g.physics_transforms(); po, qo = o.physics_transforms()
+    assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
+
+
 def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
     """Steps after the first run with ONE host read-back, sized from the previous step's counts.  Teleporting the bodies into
     a much denser pile invalidates those bounds: the step must be re-run synchronously from the untouched state and still match

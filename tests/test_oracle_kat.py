@@ -178,3 +178,29 @@ def test_physics_step_accumulator_and_interpolation(oracle_mod):
     assert p[0, 1] == pytest.approx(50.0 + 0.25 * (pp[0, 1] - 50.0), abs=1e-5)
     w.step(s, 10.0)                          # at most 4 sub-steps, the rest is dropped (fmod)
     assert w.counts()["num_rigid_bodies"] == 1
+
+
+def test_collision_events_begin_and_end(oracle_mod):
+    """handleCollisionCallbacks (physics.cpp:1041-1178): a sphere dropped on the ground begins exactly once, with the mean
+    contact point under the sphere, the normal from the sphere (type 0 -> collider A) towards the ground and the sphere's
+    downward velocity as -relative velocity; lifting the sphere away ends the collision exactly once."""
+    sc = single_body_scene(capi.SPHERE, (0, 0, 0, 0.5), pos=(0, 0.6, 0))
+    w = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_REFERENCE))
+    w.enable_events()
+    s = sc.settings()
+    ev = []
+    for _ in range(60):
+        w.step_fixed(s, sc.dt, 1)
+        ev.extend(w.poll_events().tolist())
+    assert len(ev) == 1
+    e = w.poll_events(); assert len(e) == 0
+    t, ea, eb, ca, cb, point, normal, rel = ev[0]
+    assert t == capi.EVENT_COLLISION_BEGIN and {ea, eb} == {0, 1}
+    assert abs(point[0]) < 1e-5 and abs(point[2]) < 1e-5 and -0.05 < point[1] < 0.05
+    assert abs(abs(normal[1]) - 1.0) < 1e-5
+    assert abs(rel[1]) > 0.5 and rel[1] * normal[1] < 0      # the bodies approach along the normal
+    st = w.get_body_states(np.array([0], np.uint32)); st[0, 1] += 5.0
+    w.set_body_states(np.array([0], np.uint32), st)
+    w.step_fixed(s, sc.dt, 1)
+    e = w.poll_events()
+    assert len(e) == 1 and e["type"][0] == capi.EVENT_COLLISION_END and e["collider_a"][0] == ca and e["collider_b"][0] == cb
