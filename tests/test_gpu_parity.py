@@ -155,6 +155,44 @@ def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
     assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
 
 
+@pytest.mark.parametrize("name,make,steps", [
+    ("cfg1", lambda: scenes.sphere_drop(16), 150),
+    ("cfg2", lambda: scenes.mixed_stack(64, 16, 64), 60),
+    ("cfg3", lambda: scenes.obb_pile(128, 16, 128), 60),
+    ("cfg4", lambda: scenes.ragdolls(32, 32), 100),
+    ("cfg5", lambda: scenes.vehicles(16, 16), 100),
+])
+def test_gpu_baseline_sizes_properties(mi_lib, name, make, steps):
+    """The five BASELINE.json configurations at their FULL sizes (too slow for the oracle): size-independent properties.
+    Two independent runs are bit-identical (the whole pipeline is deterministic although pairs, queues and tiles are filled
+    in arrival order), the state stays finite with unit quaternions, nothing sinks through the ground / terrain, linear
+    momentum is not created along x/z beyond what friction at the static ground allows (the pile's centre of mass stays put),
+    the schedule colours are valid (contact counts consistent), and every step after the first ran speculatively."""
+    sc = make()
+    res = []
+    for _ in range(2):
+        w = sc.populate(gpu_world(mi_lib))
+        s = sc.settings()
+        p0, _ = w.physics_transforms()
+        w.step_fixed(s, sc.dt, steps)
+        p, q = w.physics_transforms(); v, a = w.velocities()
+        res.append((p.tobytes(), q.tobytes(), v.tobytes(), a.tobytes(), w.counts()))
+    assert res[0] == res[1]
+    nb = sc.num_bodies
+    assert np.isfinite(p).all() and np.isfinite(q).all() and np.isfinite(v).all() and np.isfinite(a).all()
+    assert np.allclose(np.linalg.norm(q[:nb], axis=1), 1.0, atol=1e-4)
+    floor = -0.8 if name == "cfg5" else 0.0          # cfg5: crowned terrain tiles with seeded +-0.15 m offsets, edges 0.7 m below the crown
+    assert p[:nb, 1].min() > floor - 0.05
+    c = w.counts()
+    assert c["num_contacts"] >= c["num_collisions"] > 0 and c["num_contacts"] <= 4 * c["num_collisions"]
+    assert c["num_colors"] <= 64
+    if name in ("cfg1", "cfg2", "cfg3"):             # symmetric drops: the centre of mass does not wander sideways
+        drift = np.abs(p[:nb, [0, 2]].mean(axis=0) - p0[:nb, [0, 2]].mean(axis=0)).max()
+        assert drift < 0.05
+    total, spec, retries = w.step_mode_stats()
+    assert total == steps and spec >= steps - 1 - retries and retries <= 3
+
+
 def test_gpu_full_size_properties(mi_lib):
     """BASELINE sizes are too slow for the oracle; check size-independent properties instead:
     determinism (two runs bit-identical), no body below the ground, finite state, valid colouring."""
