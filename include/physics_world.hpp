@@ -8,6 +8,7 @@
 #include <stdexcept>
 #include <string>
 #include <vector>
+#include <functional>
 #include <array>
 #include "mi_physics.h"
 #include "mi_constraints.h"
@@ -21,11 +22,17 @@ struct trs { vec3 position; quat rotation; };                       // transform
 struct physics_material { float restitution = 0.1f, friction = 0.5f, density = 1.f; };   // src/physics/physics.h:40-47
 
 // physics_settings (src/physics/physics.h:382-400) minus the std::function callbacks.
+// collision_begin_event / collision_end_event — src/physics/physics.h:356-380 (entities and colliders by id)
+struct collision_begin_event { uint32_t entityA, entityB, colliderA, colliderB; vec3 position, normal, relativeVelocity; };
+struct collision_end_event { uint32_t entityA, entityB, colliderA, colliderB; };
+
 struct physics_settings {
     bool fixedFrameRate = true;
     uint32_t frameRate = 120;
     uint32_t maxPhysicsIterationsPerFrame = 4;
     uint32_t numRigidSolverIterations = 30;
+    std::function<void(const collision_begin_event&)> collisionBeginCallback;   // src/physics/physics.h:398-399
+    std::function<void(const collision_end_event&)> collisionEndCallback;
     mi_step_settings c() const { return mi_step_settings{fixedFrameRate ? 1u : 0u, frameRate, maxPhysicsIterationsPerFrame, numRigidSolverIterations}; }
 };
 
@@ -122,8 +129,10 @@ public:
     void applyForce(scene_entity e, vec3 force, vec3 torque) { check(mi_entity_apply_force(w_, e.id, &force.x, &torque.x), "mi_entity_apply_force"); }
 
     // physicsStep(scene, arena, timer, settings, dt) — the timer and the arena live inside the world.
-    void step(const physics_settings& settings, float dt) { mi_step_settings s = settings.c(); check(mi_world_step(w_, &s, dt), "mi_world_step"); }
-    void stepFixed(const physics_settings& settings, float dt, uint32_t n = 1) { mi_step_settings s = settings.c(); check(mi_world_step_fixed(w_, &s, dt, n), "mi_world_step_fixed"); }
+    void step(const physics_settings& settings, float dt) { mi_step_settings s = settings.c(); syncEvents(settings); check(mi_world_step(w_, &s, dt), "mi_world_step"); fireEvents(settings); }
+    void stepFixed(const physics_settings& settings, float dt, uint32_t n = 1) {
+        mi_step_settings s = settings.c(); syncEvents(settings); check(mi_world_step_fixed(w_, &s, dt, n), "mi_world_step_fixed"); fireEvents(settings);
+    }
 
     uint32_t numEntities() { uint32_t n = 0; check(mi_world_num_entities(w_, &n), "mi_world_num_entities"); return n; }
     std::vector<trs> transforms() {
@@ -136,6 +145,32 @@ public:
     }
     mi_step_counts counts() { mi_step_counts c; check(mi_world_get_counts(w_, &c), "mi_world_get_counts"); return c; }
     mi_world* handle() { return w_; }
+
+private:
+    // The reference fires its std::function callbacks inside the step (handleCollisionCallbacks, physics.cpp:1041-1178); here
+    // the events of the step are polled right after it and delivered in the same order.
+    void syncEvents(const physics_settings& settings) {
+        bool want = (bool)settings.collisionBeginCallback || (bool)settings.collisionEndCallback;
+        if (want != eventsOn_) { check(mi_world_enable_events(w_, want ? 1u : 0u), "mi_world_enable_events"); eventsOn_ = want; }
+    }
+    void fireEvents(const physics_settings& settings) {
+        if (!eventsOn_) return;
+        uint32_t n = 0;
+        check(mi_world_poll_events(w_, nullptr, 0, &n), "mi_world_poll_events");
+        if (!n) return;
+        std::vector<mi_event> ev(n);
+        check(mi_world_poll_events(w_, ev.data(), n, &n), "mi_world_poll_events");
+        for (const mi_event& e : ev) {
+            if (e.type == MI_EVENT_COLLISION_BEGIN) {
+                if (settings.collisionBeginCallback)
+                    settings.collisionBeginCallback(collision_begin_event{e.entity_a, e.entity_b, e.collider_a, e.collider_b, {e.point[0], e.point[1], e.point[2]},
+                                                                          {e.normal[0], e.normal[1], e.normal[2]},
+                                                                          {e.relative_velocity[0], e.relative_velocity[1], e.relative_velocity[2]}});
+            } else if (settings.collisionEndCallback) settings.collisionEndCallback(collision_end_event{e.entity_a, e.entity_b, e.collider_a, e.collider_b});
+        }
+    }
+    bool eventsOn_ = false;
+public:
 
 private:
     mi_world* w_ = nullptr;

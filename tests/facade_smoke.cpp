@@ -18,9 +18,13 @@ int main() {
         pod.max_motor_torque = 5.f; pod.motor_velocity_or_target_angle = 1.f;
         world.setConstraint(h, pod);
         physics_settings settings;
+        int begins = 0, ends = 0;
+        settings.collisionBeginCallback = [&](const collision_begin_event& e) { ++begins; (void)e; };
+        settings.collisionEndCallback = [&](const collision_end_event& e) { ++ends; (void)e; };
         for (int i = 0; i < 120; ++i) physicsStep(world, settings, 1.f / 60.f);
         auto tr = world.transforms();
-        std::printf("facade ok: a.y=%f b.y=%f contacts=%u\n", tr[a.id].position.y, tr[b.id].position.y, world.counts().num_contacts);
+        if (begins < 1) { std::printf("facade error: no collision-begin callback fired\n"); return 1; }
+        std::printf("facade ok: a.y=%f b.y=%f contacts=%u begins=%d ends=%d\n", tr[a.id].position.y, tr[b.id].position.y, world.counts().num_contacts, begins, ends);
     } catch (const std::exception& e) {
         std::printf("facade error: %s\n", e.what());
         return 1;
