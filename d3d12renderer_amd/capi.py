@@ -8,7 +8,7 @@ import ctypes as C
 import numpy as np
 
 MI_OK = 0
-ENTITY_DYNAMIC, ENTITY_KINEMATIC, ENTITY_STATIC = 0, 1, 2
+ENTITY_DYNAMIC, ENTITY_KINEMATIC, ENTITY_STATIC, ENTITY_TRIGGER, ENTITY_FORCE_FIELD = 0, 1, 2, 3, 4
 SPHERE, CAPSULE, CYLINDER, AABB, OBB, HULL = range(6)
 (CONSTRAINT_DISTANCE, CONSTRAINT_BALL, CONSTRAINT_FIXED, CONSTRAINT_HINGE,
  CONSTRAINT_CONE_TWIST, CONSTRAINT_SLIDER) = range(6)
@@ -22,7 +22,7 @@ entity_desc = np.dtype([
 collider_desc = np.dtype([
     ("type", "<u4"), ("object_type", "<u4"), ("shape", "<f4", 12), ("hull_geometry", "<u4"),
     ("restitution", "<f4"), ("friction", "<f4"), ("density", "<f4")])
-EVENT_COLLISION_BEGIN, EVENT_COLLISION_END = 0, 1
+EVENT_COLLISION_BEGIN, EVENT_COLLISION_END, EVENT_TRIGGER_ENTER, EVENT_TRIGGER_LEAVE = 0, 1, 2, 3
 event_dtype = np.dtype([("type", "<u4"), ("entity_a", "<u4"), ("entity_b", "<u4"), ("collider_a", "<u4"), ("collider_b", "<u4"),
                         ("point", "<f4", 3), ("normal", "<f4", 3), ("relative_velocity", "<f4", 3)])
 contact_dtype = np.dtype([
@@ -192,6 +192,11 @@ class World:
         f = np.ascontiguousarray(force, dtype=np.float32) if force is not None else None
         t = np.ascontiguousarray(torque, dtype=np.float32) if torque is not None else None
         self.L.check(self.L.fn("entity_apply_force")(self.h, C.c_uint32(entity), _ptr(f), _ptr(t)), "entity_apply_force")
+
+    def set_force(self, entity, force):
+        """force_field_component::force of a FORCE_FIELD entity (entity-local frame)."""
+        f = np.ascontiguousarray(force, dtype=np.float32)
+        self.L.check(self.L.fn("entity_set_force")(self.h, C.c_uint32(entity), _ptr(f)), "entity_set_force")
 
     # --- stepping
     def step(self, settings, dt):

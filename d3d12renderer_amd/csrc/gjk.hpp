@@ -137,6 +137,149 @@ __device__ inline bool gjkTest(const Shape& A, const Shape& B, const HullSet& hs
     return false;
 }
 
+// ---- boolean overlap tests for triggers / force fields: overlapCheck, src/physics/collision_narrow.cpp:1586-1689, dispatching to
+// src/physics/bounding_volumes.h:301-363 and bounding_volumes.cpp:704-835, 1079-1244.  a.type <= b.type.
+__device__ inline bool sphereSphereB(V3 ca, float ra, V3 cb, float rb) {
+    V3 d = ca - cb;
+    float dist2 = dot(d, d), rs = ra + rb;
+    return dist2 <= rs * rs;
+}
+__device__ inline bool sphereCylinderB(V3 sc, float sr, V3 ca, V3 cb, float cr) {   // compares a squared distance with the radius, as written in the reference
+    V3 ab = cb - ca;
+    float t = dot(sc - ca, ab) / sqlen(ab);
+    if (t >= 0.f && t <= 1.f) return sphereSphereB(sc, sr, lerp(ca, cb, t), cr);
+    V3 p = (t <= 0.f) ? ca : cb;
+    V3 up = (t <= 0.f) ? -ab : ab;
+    V3 proj = normalize(cross(cross(up, sc - p), up));
+    V3 endA = p + proj * cr, endB = p - proj * cr;
+    V3 closest = closestOnSegment(sc, endA, endB);
+    return sqlen(closest - sc) <= sr;
+}
+__device__ inline bool sphereAABBB(V3 sc, float sr, V3 mn, V3 mx) {
+    V3 n = closestOnAABB(sc, mn, mx) - sc;
+    return sqlen(n) <= sr * sr;
+}
+__device__ inline bool obbObbB(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 brad) {   // bounding_volumes.cpp:1079-1199: all 15 axes, no parallel shortcut
+    V3 ax = rotate(arot, V3(1.f, 0.f, 0.f)), ay = rotate(arot, V3(0.f, 1.f, 0.f)), az = rotate(arot, V3(0.f, 0.f, 1.f));
+    V3 bx = rotate(brot, V3(1.f, 0.f, 0.f)), by = rotate(brot, V3(0.f, 1.f, 0.f)), bz = rotate(brot, V3(0.f, 0.f, 1.f));
+    M3 r;
+    r.m00 = dot(ax, bx); r.m10 = dot(ay, bx); r.m20 = dot(az, bx);
+    r.m01 = dot(ax, by); r.m11 = dot(ay, by); r.m21 = dot(az, by);
+    r.m02 = dot(ax, bz); r.m12 = dot(ay, bz); r.m22 = dot(az, bz);
+    V3 tw = bcen - acen;
+    V3 t = rotate(conj(arot), tw);
+    M3 q;
+    q.m00 = fabsf(r.m00) + kEps; q.m01 = fabsf(r.m01) + kEps; q.m02 = fabsf(r.m02) + kEps;
+    q.m10 = fabsf(r.m10) + kEps; q.m11 = fabsf(r.m11) + kEps; q.m12 = fabsf(r.m12) + kEps;
+    q.m20 = fabsf(r.m20) + kEps; q.m21 = fabsf(r.m21) + kEps; q.m22 = fabsf(r.m22) + kEps;
+    float ra, rb;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ra = arad.get(i); rb = dot(q.r(i), brad);
+        if (ra + rb - fabsf(t.get(i)) < 0.f) return false;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        ra = dot(q.c(i), arad); rb = brad.get(i);
+        if (ra + rb - fabsf(dot(r.c(i), t)) < 0.f) return false;
+    }
+#define MI_EDGEB(RA, RB, D) ra = RA; rb = RB; if (ra + rb - fabsf(D) < 0.f) return false;
+    MI_EDGEB(arad.y * q.m20 + arad.z * q.m10, brad.y * q.m02 + brad.z * q.m01, t.z * r.m10 - t.y * r.m20)
+    MI_EDGEB(arad.y * q.m21 + arad.z * q.m11, brad.x * q.m02 + brad.z * q.m00, t.z * r.m11 - t.y * r.m21)
+    MI_EDGEB(arad.y * q.m22 + arad.z * q.m12, brad.x * q.m01 + brad.y * q.m00, t.z * r.m12 - t.y * r.m22)
+    MI_EDGEB(arad.x * q.m20 + arad.z * q.m00, brad.y * q.m12 + brad.z * q.m11, t.x * r.m20 - t.z * r.m00)
+    MI_EDGEB(arad.x * q.m21 + arad.z * q.m01, brad.x * q.m12 + brad.z * q.m10, t.x * r.m21 - t.z * r.m01)
+    MI_EDGEB(arad.x * q.m22 + arad.z * q.m02, brad.x * q.m11 + brad.y * q.m10, t.x * r.m22 - t.z * r.m02)
+    MI_EDGEB(arad.x * q.m10 + arad.y * q.m00, brad.y * q.m22 + brad.z * q.m21, t.y * r.m00 - t.x * r.m10)
+    MI_EDGEB(arad.x * q.m11 + arad.y * q.m01, brad.x * q.m22 + brad.z * q.m20, t.y * r.m01 - t.x * r.m11)
+    MI_EDGEB(arad.x * q.m12 + arad.y * q.m02, brad.x * q.m21 + brad.y * q.m20, t.y * r.m02 - t.x * r.m12)
+#undef MI_EDGEB
+    return true;
+}
+__device__ inline bool gjkBool(const Shape& a, const Shape& b, const HullSet& hs) { Simplex sx; return gjkTest(a, b, hs, sx); }
+__device__ inline bool segmentVsObbB(const Shape& c, const Shape& o, const HullSet& hs) {   // capsuleVsOBB / cylinderVsOBB: into the box frame, then GJK vs the AABB
+    Shape box; box.type = T_AABB; box.a = o.a - o.b; box.b = o.a + o.b; box.radius = 0.f; box.hull = 0;
+    Shape r = c;
+    r.a = rotate(conj(o.rot), c.a - o.a) + o.a;
+    r.b = rotate(conj(o.rot), c.b - o.a) + o.a;
+    return gjkBool(r, box, hs);
+}
+__device__ inline bool overlapCheck(const Shape& a, const Shape& b, const HullSet& hs) {
+    switch (a.type) {
+        case T_SPHERE:
+            switch (b.type) {
+                case T_SPHERE: return sphereSphereB(a.a, a.radius, b.a, b.radius);
+                case T_CAPSULE: return sphereSphereB(a.a, a.radius, closestOnSegment(a.a, b.a, b.b), b.radius);
+                case T_CYLINDER: return sphereCylinderB(a.a, a.radius, b.a, b.b, b.radius);
+                case T_AABB: return sphereAABBB(a.a, a.radius, b.a, b.b);
+                case T_OBB: return sphereAABBB(rotate(conj(b.rot), a.a - b.a) + b.a, a.radius, b.a - b.b, b.a + b.b);
+                default: return gjkBool(a, b, hs);
+            }
+        case T_CAPSULE:
+            switch (b.type) {
+                case T_CAPSULE: { V3 c1, c2; closestSegmentSegment(a.a, a.b, b.a, b.b, c1, c2); return sphereSphereB(c1, a.radius, c2, b.radius); }
+                case T_CYLINDER: { V3 c1, c2; closestSegmentSegment(a.a, a.b, b.a, b.b, c1, c2); return sphereCylinderB(c1, a.radius, b.a, b.b, b.radius); }
+                case T_OBB: return segmentVsObbB(a, b, hs);
+                default: return gjkBool(a, b, hs);
+            }
+        case T_CYLINDER:
+            if (b.type == T_OBB) return segmentVsObbB(a, b, hs);
+            return gjkBool(a, b, hs);
+        case T_AABB:
+            switch (b.type) {
+                case T_AABB:
+                    if (a.b.x < b.a.x || a.a.x > b.b.x) return false;
+                    if (a.b.y < b.a.y || a.a.y > b.b.y) return false;
+                    if (a.b.z < b.a.z || a.a.z > b.b.z) return false;
+                    return true;
+                case T_OBB: return obbObbB(Q4(0.f, 0.f, 0.f, 1.f), (a.a + a.b) * 0.5f, (a.b - a.a) * 0.5f, b.rot, b.a, b.b);
+                default: return gjkBool(a, b, hs);
+            }
+        case T_OBB:
+            if (b.type == T_OBB) return obbObbB(a.rot, a.a, a.b, b.rot, b.a, b.b);
+            return gjkBool(a, b, hs);
+        default:
+            return gjkBool(a, b, hs);
+    }
+}
+
+// One lane per (rigid-body collider, trigger / force-field collider) AABB-overlap: the boolean test; hits are appended as
+// non_collision_interaction records (body, other object index | type << 28, body collider, other collider).
+struct DeviceInteraction { uint32_t body, other, rbCollider, otherCollider; };
+__global__ __launch_bounds__(64) void k_overlap(StepScalars* sc, uint32_t cap, const uint64_t* __restrict__ interKeys, const float4* __restrict__ wShape,
+                                                const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax, HullSet hs,
+                                                DeviceInteraction* __restrict__ out) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= sc->numInterPairs) return;
+    uint64_t key = interKeys[p];
+    uint32_t bucket = (uint32_t)(key >> 58), a = (uint32_t)((key >> 29) & 0x1FFFFFFFu), b = (uint32_t)(key & 0x1FFFFFFFu);
+    uint32_t ta = 0, rem = bucket;
+    while (rem >= 6u - ta) { rem -= 6u - ta; ++ta; }
+    uint32_t tb = ta + rem;
+    Shape sa = loadShape(wShape, a, ta), sb = loadShape(wShape, b, tb);
+    if (!overlapCheck(sa, sb, hs)) return;
+    uint32_t tagA = __float_as_uint(aabbMin[a].w), tagB = __float_as_uint(aabbMin[b].w);
+    uint32_t oa = (tagA >> 8) & 0xFFu, ob = (tagB >> 8) & 0xFFu;
+    uint32_t ia = __float_as_uint(aabbMax[a].w), ib = __float_as_uint(aabbMax[b].w);
+    DeviceInteraction in;
+    if (oa == OBJ_RIGID_BODY) { in.body = ia; in.other = ib | (ob << 28); in.rbCollider = a; in.otherCollider = b; }
+    else { in.body = ib; in.other = ia | (oa << 28); in.rbCollider = b; in.otherCollider = a; }
+    uint32_t slot = atomicAdd(&sc->numInteractions, 1u);
+    if (slot < cap) out[slot] = in;
+}
+// Localized force fields: the host sorted the interactions into the canonical order (body, other collider, body collider);
+// the first lane of every body's segment adds the forces sequentially, like rb.forceAccumulator += ff.force in that order.
+__global__ __launch_bounds__(256) void k_apply_fields(uint32_t n, const uint2* __restrict__ sorted /* (body, force-field index) */,
+                                                      const float4* __restrict__ localForce, float4* __restrict__ bForceStep) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint2 me = sorted[i];
+    if (i > 0 && sorted[i - 1].x == me.x) return;
+    V3 f = xyz(bForceStep[me.x]);
+    for (uint32_t j = i; j < n && sorted[j].x == me.x; ++j) f = f + xyz(localForce[sorted[j].y]);
+    bForceStep[me.x] = f4(f, 0.f);
+}
+
 // ---- EPA (collision_epa.h:96-168, collision_epa.cpp)
 constexpr int kEpaPts = 24, kEpaTris = 288, kEpaEdges = 288, kEpaBorder = 32;
 struct EpaTri { uint16_t a, b, c, eA, eB, eC; V3 n; float dist; };

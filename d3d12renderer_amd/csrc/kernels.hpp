@@ -57,6 +57,8 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numPairsFound;        // pair count of a step whose speculative pair bound was exceeded (numPairs is zeroed then)
     uint32_t boxHitCount[16];      // box pairs that passed the SAT, per queue (k_narrow -> k_narrow_clip)
     uint32_t numEvents;            // collision begin / end events of this step (when events are enabled)
+    uint32_t numInterPairs;        // AABB overlaps between a rigid-body collider and a trigger / force-field collider
+    uint32_t numInteractions;      // ... of which the boolean overlap test passed (non_collision_interaction records)
 };
 
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
@@ -91,6 +93,7 @@ __device__ inline void boxToAABB(V3 lmn, V3 lmx, Q4 rot, V3 tr, V3& mn, V3& mx) 
 
 __global__ __launch_bounds__(256) void k_world_colliders(
     uint32_t nc, uint32_t nb, const uint32_t* __restrict__ cTypeBody,  // [2*nc]: type, body (kNoBody = static)
+    const uint32_t* __restrict__ cObject,   // colliders without a body: physics_object_type | object index << 8 (static / force field / trigger)
     const float4* __restrict__ cShape, const float4* __restrict__ cStaticPos, const float4* __restrict__ cStaticRot,
     const float4* __restrict__ bPos, const float4* __restrict__ bRot,
     const float4* __restrict__ hullAabb,  // [2*numHulls]
@@ -101,7 +104,11 @@ __global__ __launch_bounds__(256) void k_world_colliders(
     uint32_t type = cTypeBody[2 * k], body = cTypeBody[2 * k + 1];
     V3 tp; Q4 tr; uint32_t objType, objIndex;
     if (body != kNoBody) { tp = xyz(bPos[body]); tr = toQ(bRot[body]); objType = OBJ_RIGID_BODY; objIndex = body; }
-    else { tp = xyz(cStaticPos[k]); tr = toQ(cStaticRot[k]); objType = OBJ_STATIC; objIndex = nb; }
+    else {
+        tp = xyz(cStaticPos[k]); tr = toQ(cStaticRot[k]);
+        uint32_t o = cObject[k];
+        objType = o & 0xFFu; objIndex = objType == OBJ_STATIC ? nb : (o >> 8);
+    }
     float4 s0 = cShape[3 * k], s1 = cShape[3 * k + 1], s2 = cShape[3 * k + 2];
     float4 o0 = make_float4(0, 0, 0, 0), o1 = o0, o2 = make_float4(0, 0, 0, 1);
     V3 mn, mx;
@@ -358,8 +365,11 @@ __global__ __launch_bounds__(256) void k_bp_scatter_sorted(uint32_t nc, const ui
 // i, j: collider world indices.  The SAP sweep emits {new, active}: new = later start on the axis;
 // on a tie the later-created collider (smaller world index) is the newer endpoint.
 // Returns false when the overlap generates no collision pair.
+// `inter` (optional): AABB overlaps between a rigid-body collider and a trigger / force-field collider are appended there
+// (rare; plain atomic append) for the boolean overlap tests of k_overlap.
+struct InterSink { uint64_t* keys; uint32_t cap; uint32_t* count; };
 __device__ __forceinline__ bool pairKey(uint32_t i, const float4& imn, const float4& imx, uint32_t j, const float4& jmn, const float4& jmx,
-                                        uint32_t axis, uint64_t& key) {
+                                        uint32_t axis, uint64_t& key, const InterSink& inter = InterSink{nullptr, 0u, nullptr}) {
     uint32_t ti = __float_as_uint(imn.w), tj = __float_as_uint(jmn.w);
     uint32_t oi = (ti >> 8) & 0xFF, oj = (tj >> 8) & 0xFF;
     uint32_t bi = __float_as_uint(imx.w), bj = __float_as_uint(jmx.w);
@@ -373,8 +383,11 @@ __device__ __forceinline__ bool pairKey(uint32_t i, const float4& imn, const flo
     uint32_t oa = iIsNew ? oi : oj, ob = iIsNew ? oj : oi;
     if (!(ta < tb)) { uint32_t t = a; a = b; b = t; t = ta; ta = tb; tb = t; t = oa; oa = ob; ob = t; }
     bool collision = (oa == OBJ_RIGID_BODY && ob == OBJ_RIGID_BODY) || oa == OBJ_STATIC || ob == OBJ_STATIC;
-    if (!collision) return false;   // trigger / force-field overlaps: SURVEY §8(f).4
     key = ((uint64_t)bucketOf(ta, tb) << 58) | ((uint64_t)a << 29) | (uint64_t)b;
+    if (!collision) {   // rigid body vs trigger / force field (collision_narrow.cpp:2385-2394): boolean overlap test later
+        if (inter.keys) { uint32_t slot = atomicAdd(inter.count, 1u); if (slot < inter.cap) inter.keys[slot] = key; }
+        return false;
+    }
     return true;
 }
 
@@ -422,7 +435,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
                                                        const float4* __restrict__ sMin, const float4* __restrict__ sMax,
                                                        const uint32_t* __restrict__ cellLower,
                                                        const GridParams* __restrict__ gp, uint64_t* __restrict__ pairKeys, uint32_t pairCap,
-                                                       StepScalars* sc, Shards* sh) {
+                                                       StepScalars* sc, Shards* sh, InterSink inter) {
     __shared__ uint64_t buf[kGridChunks * 256 * kPairBuf];
     __shared__ uint32_t waveTotals[4];
     __shared__ uint32_t blockBase;
@@ -463,7 +476,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
                         if (j + u >= e || !aabbOverlap(amn, amx, bmn[u], bmx[u])) continue;
                         ++overlaps;
                         uint64_t pk;
-                        if (!pairKey(ci, amn, amx, vals[j + u], bmn[u], bmx[u], axis, pk)) continue;
+                        if (!pairKey(ci, amn, amx, vals[j + u], bmn[u], bmx[u], axis, pk, inter)) continue;
                         if (nhit < kPairBuf) mybuf[nhit] = pk;
                         else { uint32_t slot = atomicAdd(&sc->numPairs, 1u); if (slot < pairCap) pairKeys[slot] = pk; }
                         atomicAdd(&bhist[(uint32_t)(pk >> 58)], 1u);
@@ -507,7 +520,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
 // are emitted once (from the lower index).
 __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint32_t* __restrict__ largeList, const uint32_t* __restrict__ isLarge,
                                                         const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
-                                                        uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc, Shards* sh) {
+                                                        uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc, Shards* sh, InterSink inter) {
     __shared__ uint32_t bhist[32];   // [0..20] bucket histogram, [31] overlaps
     if (threadIdx.x < 32) bhist[threadIdx.x] = 0;
     __syncthreads();
@@ -523,7 +536,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
             float4 bmn = aabbMin[j], bmx = aabbMax[j];
             bool ov = ok && aabbOverlap(amn, amx, bmn, bmx);
             uint64_t pk = 0;
-            bool want = ov && pairKey(i, amn, amx, j, bmn, bmx, axis, pk);
+            bool want = ov && pairKey(i, amn, amx, j, bmn, bmx, axis, pk, inter);
             overlaps += ov ? 1u : 0u;
             if (want) atomicAdd(&bhist[(uint32_t)(pk >> 58)], 1u);
             waveAppendKey(want, pk, pairKeys, pairCap, &sc->numPairs);
@@ -896,7 +909,7 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
 // ------------------------------------------------------------------------------------------------
 // K9 "Integrate rigid body forces" (src/physics/rigid_body.cpp:95-124).  One lane per body; also
 // zeroes the dummy body (physics.cpp:1279).  in ~112 B, out 112 B per body.
-__global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
+__global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt, float3 globalForce, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
                                                           const float4* __restrict__ bCogInvMass, const float4* __restrict__ bInvI,
                                                           const float4* __restrict__ bParams, const float4* __restrict__ bLinVel,
                                                           const float4* __restrict__ bAngVel, const float4* __restrict__ bForce, const float4* __restrict__ bTorque,
@@ -918,6 +931,7 @@ __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt,
     M3 W = mul(mul(R, I), transpose(R));
     float4 prm = bParams[i];
     V3 force = xyz(bForce[i]), torque = xyz(bTorque[i]);
+    force = force + V3(globalForce.x, globalForce.y, globalForce.z);   // rb.forceAccumulator += globalForceField (physics.cpp:1273)
     if (invMass > 0.f) force.y += (kGravity / invMass * prm.x);
     V3 linAcc = force * invMass;
     V3 angAcc = mul(W, torque);
@@ -1058,13 +1072,17 @@ __global__ __launch_bounds__(256) void k_bin_scatter(uint32_t lastRound, const u
         cur[b] = v;
         if (blockIdx.x == 0) sc->binStart[b] = v;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc->binStart[kColorBins] = nm;
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < kBinItems / 256; ++k) {
         uint32_t m = blockIdx.x * kBinItems + k * 256 + threadIdx.x;
         if (m < nm) { uint32_t c = color[m]; if (c <= kOverflowColor) order[atomicAdd(&cur[binOf(c, manInfo[m].x & 7u)], 1u)] = m; }
     }
+    // End of the last bin = the number of SCHEDULED manifolds (the last workgroup's cursor of the last bin ends there).  It
+    // equals numManifolds unless a speculative step left manifolds uncoloured or beyond the launched range; those must not
+    // become slots (their `order` entries were never written), the step is then re-run anyway.
+    __syncthreads();
+    if (blockIdx.x == numBlocks - 1 && threadIdx.x == 0) sc->binStart[kColorBins] = cur[kColorBins - 1];
 }
 
 // Overflow colour (a body with > 64 incident manifolds) is solved sequentially, so its slots need a defined order:

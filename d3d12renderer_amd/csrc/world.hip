@@ -56,7 +56,7 @@ struct DBuf {
 // ------------------------------------------------------------------------------------------------
 // Host scene storage
 // ------------------------------------------------------------------------------------------------
-struct HEntity { V3 pos; Q4 rot; uint32_t kind; int rb = -1; std::vector<uint32_t> colliders; /* newest first */ };
+struct HEntity { V3 pos; Q4 rot; uint32_t kind; int rb = -1; std::vector<uint32_t> colliders; /* newest first */ V3 force; uint32_t kindIndex = 0; /* force fields, triggers */ };
 struct HBody {
     uint32_t entity;
     V3 localCOG; float invMass; M3 invInertia;
@@ -108,6 +108,13 @@ struct mi_world {
     // colour history (pair -> colour of the previous step): two tables, the one written by a step becomes current only if the step is valid
     DBuf<unsigned long long> tabKeys[2]; DBuf<uint32_t> tabVals[2]; uint32_t tabMask[2] = {0, 0}; int tabCur = 0; bool tabValid = false;
     // collision events (mi_world_enable_events / mi_world_poll_events)
+    // triggers / force fields: entity lists by dense index, per-collider object tags, rotated forces, the pair pass's
+    // rigid-body x (trigger | force field) AABB overlaps, the interactions that passed the boolean test, the per-step force accumulators
+    std::vector<uint32_t> ffEntities, triggerEntities;
+    bool usesInteractions = false; V3 globalForce;
+    DBuf<uint32_t> cObject; DBuf<float4> localForce, bForceStep; DBuf<uint64_t> interKeys; DBuf<DeviceInteraction> interList; DBuf<uint2> fieldList;
+    std::vector<uint64_t> prevTriggerOverlaps, nextTriggerOverlaps;
+    int interactions(std::vector<mi_event>& triggerEvents);
     bool eventsEnabled = false; DBuf<uint8_t> manIsNew; DBuf<DeviceEvent> devEvents; std::vector<mi_event> pendingEvents;
     DBuf<float4> rows, slotNormal; DBuf<float4> imp; DBuf<float2> slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc;
     bool usedFlow = false;
@@ -334,17 +341,29 @@ int mi_world::upload() {
 
     usesGjk = false;
     for (const HCollider& c : colliders) if (c.desc.type == T_CAPSULE || c.desc.type == T_CYLINDER || c.desc.type == T_HULL) usesGjk = true;
-    std::vector<uint32_t> tb(2 * (size_t)nc); std::vector<float4> sh(3 * (size_t)nc), sp(nc), sr(nc), mat(nc);
+    std::vector<uint32_t> tb(2 * (size_t)nc), obj(nc); std::vector<float4> sh(3 * (size_t)nc), sp(nc), sr(nc), mat(nc);
+    // force fields (getForceFieldStates, physics.cpp:759-787): rotated force per field; fields without colliders are global
+    usesInteractions = false; globalForce = V3();
+    std::vector<float4> lf(ffEntities.size());
+    for (size_t i = ffEntities.size(); i-- > 0;) {   // EnTT view order: back to front
+        const HEntity& e = entities[ffEntities[i]];
+        V3 f = rotate(e.rot, e.force);
+        if (!e.colliders.empty()) lf[i] = h4(f, 0.f); else { lf[i] = make_float4(0, 0, 0, 0); globalForce = globalForce + f; usesInteractions = true; }
+    }
     for (uint32_t k = 0; k < nc; ++k) {   // world index k <-> creation index nc-1-k (EnTT iterates back to front, physics.cpp:635-641)
         const HCollider& c = colliders[nc - 1 - k];
         const HEntity& e = entities[c.entity];
         tb[2 * k] = c.desc.type; tb[2 * k + 1] = e.rb >= 0 ? (uint32_t)e.rb : kNoBody;
+        obj[k] = e.kind == MI_ENTITY_FORCE_FIELD ? (OBJ_FORCE_FIELD | e.kindIndex << 8) : e.kind == MI_ENTITY_TRIGGER ? (OBJ_TRIGGER | e.kindIndex << 8) : OBJ_STATIC;
+        if (e.kind == MI_ENTITY_FORCE_FIELD || e.kind == MI_ENTITY_TRIGGER) usesInteractions = true;
         float s[12]; std::memcpy(s, c.desc.shape, sizeof(s));
         if (c.desc.type == T_HULL) std::memcpy(&s[7], &c.desc.hull_geometry, 4);
         sh[3 * k] = make_float4(s[0], s[1], s[2], s[3]); sh[3 * k + 1] = make_float4(s[4], s[5], s[6], s[7]); sh[3 * k + 2] = make_float4(s[8], s[9], s[10], s[11]);
         sp[k] = h4(e.pos, 0.f); sr[k] = make_float4(e.rot.x, e.rot.y, e.rot.z, e.rot.w);
         mat[k] = make_float4(c.desc.restitution, c.desc.friction, c.desc.density, 0.f);
     }
+    UP(cObject, obj, nc); UP(localForce, lf, lf.size());
+    if (usesInteractions) HIP_TRY(bForceStep.ensure(std::max<size_t>(nb, 1)));
     UP(cTypeBody, tb, 2 * (size_t)nc); UP(cShape, sh, 3 * (size_t)nc); UP(cStaticPos, sp, nc); UP(cStaticRot, sr, nc); UP(cMaterial, mat, nc);
     HIP_TRY(wShape.ensure(3 * (size_t)nc + 1)); HIP_TRY(aabbMin.ensure(nc + 1)); HIP_TRY(aabbMax.ensure(nc + 1));
     HIP_TRY(sMin.ensure(nc + 1)); HIP_TRY(sMax.ensure(nc + 1));
@@ -402,7 +421,7 @@ __global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlag
     for (uint32_t i = t; i < kMaxColorRounds + 2u; i += blockDim.x) roundFlags[i] = 0u;
     if (t == 0) {
         sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->solveError = 0;
-        sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0; sc->numEvents = 0;
+        sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0; sc->numEvents = 0; sc->numInterPairs = 0; sc->numInteractions = 0;
         for (int q = 0; q < 16; ++q) sc->boxHitCount[q] = 0;
         for (int a = 0; a < 3; ++a) { sc->boundsMin[a] = 0x7FFFFFFF; sc->boundsMax[a] = (int)0x80000000; }
     }
@@ -410,7 +429,7 @@ __global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlag
 }
 __global__ void k_reset_pair_counters(StepScalars* sc) {
     uint32_t t = threadIdx.x;
-    if (t == 0) { sc->numPairs = 0; sc->numOverlaps = 0; }
+    if (t == 0) { sc->numPairs = 0; sc->numOverlaps = 0; sc->numInterPairs = 0; }
     if (t < 24) sc->bucketHist[t] = 0;
 }
 
@@ -429,11 +448,70 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     HIP_TRY(hipSetDevice(device));
     if (topologyDirty) { int rc = download(); if (rc != MI_OK) return rc; rc = upload(); if (rc != MI_OK) return rc; haveEstimates = false; }
     if (bodies.empty()) return MI_OK;
-    const bool spec = specEnabled && haveEstimates && flowSolver;
+    const bool spec = specEnabled && haveEstimates && flowSolver && !usesInteractions;   // interactions are read back mid-step
     ++totalSteps; if (spec) ++specSteps;
     int rc = runStep(settings, dt, spec);
     if (rc == STEP_RETRY) { ++specRetries; rc = runStep(settings, dt, false); }
     return rc;
+}
+
+// handleNonCollisionInteractions (physics.cpp:952-1039) for the AABB overlaps the pair pass collected between rigid-body colliders
+// and trigger / force-field colliders.  Synchronous: the (few) interactions come back to the host, which puts them into the
+// canonical order (body, other collider, body collider); localized force fields then add up per body on the device in that
+// order, trigger overlaps are de-duplicated per (trigger entity, body entity) and diffed against the previous step.
+int mi_world::interactions(std::vector<mi_event>& out) {
+    const uint32_t nb = (uint32_t)bodies.size();
+    hipStream_t st = stream;
+    HIP_TRY(hipMemcpyAsync(bForceStep.p, bForce.p, (size_t)nb * sizeof(float4), hipMemcpyDeviceToDevice, st));
+    std::vector<DeviceInteraction> list;
+    if (hs.numInterPairs) {
+        HIP_TRY(interList.ensure(hs.numInterPairs));
+        HullSet hset{hullVerts.p, hullRanges.p};
+        k_overlap<<<divUp(hs.numInterPairs, 64), 64, 0, st>>>(scalarsPtr(), hs.numInterPairs, interKeys.p, wShape.p, aabbMin.p, aabbMax.p, hset, interList.p);
+        HIP_TRY(hipMemcpyAsync(&hs, scalarsPtr(), sizeof(StepScalars), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        list.resize(hs.numInteractions);
+        if (!list.empty()) {
+            HIP_TRY(hipMemcpyAsync(list.data(), interList.p, list.size() * sizeof(DeviceInteraction), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
+        std::sort(list.begin(), list.end(), [](const DeviceInteraction& x, const DeviceInteraction& y) {
+            if (x.body != y.body) return x.body < y.body;
+            if (x.otherCollider != y.otherCollider) return x.otherCollider < y.otherCollider;
+            return x.rbCollider < y.rbCollider;
+        });
+    }
+    std::vector<uint2> fields;
+    nextTriggerOverlaps.clear();
+    for (const DeviceInteraction& in : list) {
+        const uint32_t type = in.other >> 28, index = in.other & 0x0FFFFFFFu;
+        if (type == OBJ_FORCE_FIELD) fields.push_back(make_uint2(in.body, index));
+        else if (type == OBJ_TRIGGER) nextTriggerOverlaps.push_back(((uint64_t)triggerEntities[index] << 32) | (uint64_t)bodies[in.body].entity);
+    }
+    if (!fields.empty()) {
+        HIP_TRY(fieldList.ensure(fields.size()));
+        HIP_TRY(hipMemcpyAsync(fieldList.p, fields.data(), fields.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
+        k_apply_fields<<<divUp((uint32_t)fields.size(), 256), 256, 0, st>>>((uint32_t)fields.size(), fieldList.p, localForce.p, bForceStep.p);
+        HIP_TRY(hipStreamSynchronize(st));   // `fields` is pageable host memory
+    }
+    std::sort(nextTriggerOverlaps.begin(), nextTriggerOverlaps.end());
+    nextTriggerOverlaps.erase(std::unique(nextTriggerOverlaps.begin(), nextTriggerOverlaps.end()), nextTriggerOverlaps.end());
+    if (!eventsEnabled) { nextTriggerOverlaps.clear(); return MI_OK; }
+    auto emit = [&](uint64_t key, uint32_t type) {
+        mi_event e{}; e.type = type; e.entity_a = (uint32_t)(key >> 32); e.entity_b = (uint32_t)key; e.collider_a = e.collider_b = 0xFFFFFFFFu;
+        out.push_back(e);
+    };
+    const std::vector<uint64_t>& prev = prevTriggerOverlaps;
+    size_t p = 0, t = 0;
+    while (p < prev.size() && t < nextTriggerOverlaps.size()) {
+        uint64_t pk = prev[p], tk = nextTriggerOverlaps[t];
+        if (pk == tk) { ++p; ++t; }
+        else if (pk < tk) { emit(pk, MI_EVENT_TRIGGER_LEAVE); ++p; }
+        else { emit(tk, MI_EVENT_TRIGGER_ENTER); ++t; }
+    }
+    while (p < prev.size()) emit(prev[p++], MI_EVENT_TRIGGER_LEAVE);
+    while (t < nextTriggerOverlaps.size()) emit(nextTriggerOverlaps[t++], MI_EVENT_TRIGGER_ENTER);
+    return MI_OK;
 }
 
 int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
@@ -442,14 +520,18 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     StepScalars* sc = scalarsPtr();
     hipStream_t st = stream;
     int evi = 0;
-    auto mark = [&]() { (void)hipEventRecord(ev[evi++], st); };
+    static const bool debugSync = std::getenv("MI_DEBUG_SYNC") != nullptr;   // development: find the stage a device fault comes from
+    auto mark = [&]() {
+        (void)hipEventRecord(ev[evi++], st);
+        if (debugSync) { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) std::fprintf(stderr, "[mi_physics] step %llu (%s): stage ending at mark %d: %s\n", (unsigned long long)totalSteps, spec ? "speculative" : "synchronous", evi - 1, hipGetErrorString(e)); }
+    };
     auto bound = [](uint32_t last, uint32_t slack) { return last + last / 8u + slack; };
     auto readScalars = [&]() -> int { HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); return MI_OK; };
 
     mark();  // 0
     k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlagsPtr());
     if (nc) {
-        k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
+        k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis);
     }
     mark();  // 1
@@ -472,18 +554,22 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         k_bp_scatter_sorted<<<divUp(nc, B), B, 0, st>>>(nc, cellKeys.p, cellRanks.p, cellLower.p, aabbMin.p, aabbMax.p, cellKeysS.p, cellValsS.p, sMin.p, sMax.p);
         if (pairKeys.cap == 0) { HIP_TRY(pairKeys.ensure(std::max<size_t>(1u << 16, 8 * (size_t)nc))); }
         if (spec) { HIP_TRY(pairKeys.ensure(bound(last.numPairs, 4096))); }
-        for (int attempt = 0; attempt < 2; ++attempt) {
+        if (usesInteractions && interKeys.cap == 0) HIP_TRY(interKeys.ensure(4096));
+        for (int attempt = 0; attempt < 3; ++attempt) {
             uint32_t cap = (uint32_t)std::min<size_t>(pairKeys.cap, 0x7FFFFFFFu);
+            const InterSink inter{usesInteractions ? interKeys.p : nullptr, (uint32_t)interKeys.cap, &sc->numInterPairs};
             const uint32_t bpc = divUp(nc, kGridChunks * 256u);
-            k_bp_pairs_grid<<<5u * bpc, B, 0, st>>>(nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, grid.p, pairKeys.p, cap, sc, shards.p);
-            k_bp_pairs_large<<<dim3(std::min(divUp(nc, B), 256u), 16), B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc, shards.p);
+            k_bp_pairs_grid<<<5u * bpc, B, 0, st>>>(nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, grid.p, pairKeys.p, cap, sc, shards.p, inter);
+            k_bp_pairs_large<<<dim3(std::min(divUp(nc, B), 256u), 16), B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc, shards.p, inter);
             k_pair_totals<<<1, 32, 0, st>>>(shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu);
             if (attempt == 0) k_axis_final<<<1, 256, 0, st>>>(nc, nblk, axisPartials.p, sc);
             if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
             int rc = readScalars(); if (rc != MI_OK) return rc;
             pairBound = hs.numPairs;
-            if (pairBound <= cap) break;
-            HIP_TRY(pairKeys.ensure((size_t)pairBound + pairBound / 4));   // overflow: grow and redo the pair pass
+            if (pairBound <= cap && hs.numInterPairs <= interKeys.cap) break;
+            if (attempt == 2) return fail(MI_ERR_DEVICE, "pair pass did not settle");
+            if (pairBound > cap) HIP_TRY(pairKeys.ensure((size_t)pairBound + pairBound / 4));   // overflow: grow and redo the pair pass
+            if (hs.numInterPairs > interKeys.cap) HIP_TRY(interKeys.ensure((size_t)hs.numInterPairs + hs.numInterPairs / 4));
             k_reset_pair_counters<<<1, 32, 0, st>>>(sc);
             HIP_TRY(hipMemsetAsync(shards.p, 0, sizeof(ShardCounters) * kShards, st));
         }
@@ -514,8 +600,11 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
                                                         tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc);
     }
+    // ---------------------------------------------------------------------------------------------- triggers / force fields
+    std::vector<mi_event> triggerEvents;
+    if (usesInteractions) { int rc = interactions(triggerEvents); if (rc != MI_OK) return rc; }
     mark();  // 3
-    k_integrate_forces<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p,
+    k_integrate_forces<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, make_float3(globalForce.x, globalForce.y, globalForce.z), bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, usesInteractions ? bForceStep.p : bForce.p, bTorque.p,
                                                        gPos.p, gInvI.p, gVel.p);
     mark();  // 4
     // ---------------------------------------------------------------------------------------------- schedule
@@ -670,6 +759,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         for (uint32_t l = 0; l < profLaunches; ++l) { float ms = 0.f; (void)hipEventElapsedTime(&ms, profEvents[2 * l], profEvents[2 * l + 1]); profKernelMs += ms; }
     }
     if (eventsEnabled) {
+        pendingEvents.insert(pendingEvents.end(), triggerEvents.begin(), triggerEvents.end());   // handleNonCollisionInteractions runs before the collision events
         if (!nmBound && tabValid) {   // no manifolds at all this step: every collision of the previous step ended
             uint32_t cap = last.numManifolds + 1024u;
             HIP_TRY(devEvents.ensure(cap));
@@ -697,6 +787,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     // the step is valid: the freshly integrated state becomes the current one
     std::swap(bPos.p, bPosN.p); std::swap(bRot.p, bRotN.p); std::swap(bLinVel.p, bLinVelN.p); std::swap(bAngVel.p, bAngVelN.p);
     std::swap(bForce.p, bForceN.p); std::swap(bTorque.p, bTorqueN.p);
+    if (usesInteractions) prevTriggerOverlaps.swap(nextTriggerOverlaps);
     sapAxis = hs.axisNext;
     if (nmBound) { tabCur ^= 1; tabValid = true; } else tabValid = false;
     hostStale = true;
@@ -900,7 +991,10 @@ MI_API int mi_entities_create(mi_world* w, uint32_t count, const mi_entity_desc*
     for (uint32_t i = 0; i < count; ++i) {
         const mi_entity_desc& d = descs[i];
         HEntity e; e.pos = V3(d.position[0], d.position[1], d.position[2]); e.rot = Q4(d.rotation[0], d.rotation[1], d.rotation[2], d.rotation[3]); e.kind = d.kind;
-        if (d.kind != MI_ENTITY_STATIC) {
+        if (d.kind > MI_ENTITY_FORCE_FIELD) return fail(MI_ERR_INVALID_ARGUMENT, "bad entity kind");
+        if (d.kind == MI_ENTITY_FORCE_FIELD) { e.kindIndex = (uint32_t)w->ffEntities.size(); w->ffEntities.push_back((uint32_t)w->entities.size()); }
+        if (d.kind == MI_ENTITY_TRIGGER) { e.kindIndex = (uint32_t)w->triggerEntities.size(); w->triggerEntities.push_back((uint32_t)w->entities.size()); }
+        if (d.kind == MI_ENTITY_DYNAMIC || d.kind == MI_ENTITY_KINEMATIC) {
             HBody b;
             b.entity = (uint32_t)w->entities.size();
             bool kin = d.kind == MI_ENTITY_KINEMATIC;   // rigid_body_component ctor, rigid_body.cpp:6-27
@@ -918,6 +1012,13 @@ MI_API int mi_entities_create(mi_world* w, uint32_t count, const mi_entity_desc*
     return MI_OK;
 }
 MI_API int mi_entity_create(mi_world* w, const mi_entity_desc* d, uint32_t* out) { return mi_entities_create(w, 1, d, out); }
+MI_API int mi_entity_set_force(mi_world* w, uint32_t entity, const float* force) {   // force_field_component::force (physics.h:35-38)
+    if (!w || !force) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (entity >= w->entities.size() || w->entities[entity].kind != MI_ENTITY_FORCE_FIELD) return fail(MI_ERR_INVALID_ARGUMENT, "not a force-field entity");
+    w->entities[entity].force = V3(force[0], force[1], force[2]);
+    w->topologyDirty = true;   // the rotated forces are part of the uploaded topology
+    return MI_OK;
+}
 
 MI_API int mi_colliders_add(mi_world* w, uint32_t count, const uint32_t* ents, const mi_collider_desc* descs) {
     if (!w || (count && (!ents || !descs))) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
@@ -1039,7 +1140,7 @@ MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
 
 MI_API int mi_world_enable_events(mi_world* w, uint32_t enable) {
     if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
-    w->eventsEnabled = enable != 0; w->pendingEvents.clear();
+    w->eventsEnabled = enable != 0; w->pendingEvents.clear(); w->prevTriggerOverlaps.clear();
     w->tabValid = false;           // the event diff starts from an empty previous frame (so does the colour history, once)
     w->haveEstimates = false;
     return MI_OK;

@@ -61,6 +61,7 @@ class Scene:
     constraints: list = field(default_factory=list)   # (type, entity_a, entity_b, pod ndarray)
     hulls: list = field(default_factory=list)          # (vertices, triangles)
     global_constraints: list = field(default_factory=list)   # (type, entity_a, entity_b, anchor, axis, limit0, limit1, {field: value})
+    forces: list = field(default_factory=list)               # (force-field entity, force3)
 
     @property
     def num_bodies(self):
@@ -74,6 +75,8 @@ class Scene:
             world.create_hull_geometry(v, t)
         world.create_entities(self.entities)
         world.add_colliders(self.collider_entities, self.colliders)
+        for ent, force in self.forces:
+            world.set_force(ent, force)
         for ctype, ea, eb, pod in self.constraints:
             world.add_constraint(ctype, ea, eb, pod)
         for ctype, ea, eb, anchor, axis, l0, l1, edits in self.global_constraints:
@@ -657,6 +660,46 @@ def obb_pile_tile(tile=0, ntiles=1, nx=128, ny=16, nz=128, ghost_cols=2, seed=3,
                 send_left=np.arange(0, min(ghost_cols, nx) * per_col, dtype=np.uint32) if tile > 0 else np.zeros(0, np.uint32),
                 send_right=np.arange(n_own - min(ghost_cols, nx) * per_col, n_own, dtype=np.uint32) if tile < ntiles - 1 else np.zeros(0, np.uint32))
     return sc, info
+
+
+def zones(nx=6, ny=3, nz=6, seed=8, solver_iterations=20, spacing=1.4):
+    """Triggers and force fields (handleNonCollisionInteractions): a jittered lattice of mixed shapes falls through a wind zone
+    (localized force field made of two colliders, tilted entity so the force is rotated), a second overlapping updraft zone, a
+    global breeze (force field without colliders) and three trigger volumes of different collider types, onto the ground."""
+    n = nx * ny * nz
+    e = make_entities(n)
+    e["position"] = _lattice(nx, ny, nz, spacing, 2.5, seed, 0.05)
+    e["rotation"] = random_unit_quaternions(seed, 21, n)
+    c = make_colliders(n, capi.SPHERE)
+    kind = _hash_u32(seed, 53, np.arange(n)) % 5
+    r = uniform(seed, 54, n, 0.25, 0.4)
+    for i in range(n):
+        k = int(kind[i])
+        c["type"][i] = k
+        if k == capi.SPHERE: c["shape"][i, :4] = (0, 0, 0, r[i])
+        elif k in (capi.CAPSULE, capi.CYLINDER): c["shape"][i, :7] = (0, -r[i], 0, 0, r[i], 0, r[i] * 0.6)
+        elif k == capi.AABB: c["shape"][i, :6] = (-r[i], -r[i] * 0.8, -r[i], r[i], r[i] * 0.8, r[i])
+        else: c["shape"][i, :10] = (0, 0, 0, 1, 0, 0, 0, r[i], r[i] * 0.7, r[i])
+    z = make_entities(6, capi.ENTITY_STATIC)
+    z["kind"][:3] = capi.ENTITY_FORCE_FIELD
+    z["kind"][3:] = capi.ENTITY_TRIGGER
+    z["position"][0] = (-1.5, 1.5, 0.0); z["rotation"][0] = q_axis_angle((0, 0, 1), 0.3)     # wind zone (tilted)
+    z["position"][1] = (1.0, 1.0, 1.0)                                                        # updraft
+    z["position"][2] = (0.0, 0.0, 0.0)                                                        # global breeze: no colliders
+    z["position"][3] = (0.0, 0.8, -1.5); z["position"][4] = (2.0, 0.6, 2.0); z["position"][5] = (-2.0, 1.2, 1.5)
+    z["rotation"][5] = q_axis_angle((0, 1, 0), 0.6)
+    zc = make_colliders(5, capi.AABB)
+    zc["shape"][0, :6] = (-1.5, -1.0, -2.0, 1.5, 1.0, 2.0)
+    zc["type"][1] = capi.SPHERE; zc["shape"][1, :4] = (0.5, 1.2, 0.0, 0.9)                      # second collider of the wind zone
+    zc["type"][2] = capi.OBB; zc["shape"][2, :10] = (*q_axis_angle((0, 1, 0), 0.4), 0, 0, 0, 1.2, 0.8, 1.2)
+    zc["type"][3] = capi.CAPSULE; zc["shape"][3, :7] = (-1.0, 0, 0, 1.0, 0, 0, 0.7)
+    zc["shape"][4, :6] = (-1.0, -0.6, -1.0, 1.0, 0.6, 1.0)
+    zsphere = make_colliders(1, capi.CYLINDER); zsphere["shape"][0, :7] = (0, -0.8, 0, 0, 0.8, 0, 0.9)
+    zent = np.array([n + 0, n + 0, n + 1, n + 3, n + 4, n + 5], np.uint32)
+    ge, gc = _ground(100.0)
+    ents = np.concatenate([np.arange(n, dtype=np.uint32), zent, [n + 6]]).astype(np.uint32)
+    return Scene(f"zones_{n}", np.concatenate([e, z, ge]), ents, np.concatenate([c, zc, zsphere, gc]), solver_iterations,
+                 forces=[(n + 0, (6.0, 0.0, 1.0)), (n + 1, (0.0, 14.0, 0.0)), (n + 2, (0.3, 0.0, -0.2))])
 
 
 def by_name(name, **kw):

@@ -68,7 +68,9 @@ typedef enum mi_constraint_type {
     MI_CONSTRAINT_TYPE_COUNT = 6
 } mi_constraint_type;
 
-enum { MI_ENTITY_DYNAMIC = 0, MI_ENTITY_KINEMATIC = 1, MI_ENTITY_STATIC = 2 };
+enum { MI_ENTITY_DYNAMIC = 0, MI_ENTITY_KINEMATIC = 1, MI_ENTITY_STATIC = 2,
+       MI_ENTITY_TRIGGER = 3,        /* transform + trigger_component (src/physics/physics.h:200-203): colliders report enter / leave */
+       MI_ENTITY_FORCE_FIELD = 4 };  /* transform + force_field_component (src/physics/physics.h:182-185): see mi_entity_set_force */
 
 /*
  * An entity = transform_component (+ optional rigid_body_component).
@@ -191,6 +193,12 @@ MI_API int mi_constraint_create_from_global(mi_world* world, uint32_t type, uint
                                             const float* global_anchor, const float* global_axis,
                                             float limit_min_or_swing, float limit_max_or_twist, uint32_t* out_constraint);
 
+/* force_field_component::force (src/physics/physics.h:182-185) of a MI_ENTITY_FORCE_FIELD entity, in the entity's local frame
+ * (getForceFieldStates rotates it by the transform, src/physics/physics.cpp:759-787).  With colliders the field is localized:
+ * every overlap of one of its colliders with a rigid body's collider adds the force to that body for the step
+ * (handleNonCollisionInteractions, physics.cpp:952-970); without colliders it is global and acts on every rigid body. */
+MI_API int mi_entity_set_force(mi_world* world, uint32_t entity, const float* force3);
+
 /* rb.forceAccumulator += f; rb.torqueAccumulator += tau (src/physics/physics.cpp:623-627). */
 MI_API int mi_entity_apply_force(mi_world* world, uint32_t entity, const float* force3, const float* torque3);
 
@@ -236,7 +244,13 @@ MI_API int mi_world_get_manifold_colors(mi_world* world, uint32_t* out_colors, u
  * frame's collision lists.  Like there, a pair is identified by its ORIENTED collider pair (a re-oriented pair ends and begins).
  * Disabled by default (the reference only diffs the lists when a callback is set); costs nothing when disabled.
  */
-typedef enum mi_event_type { MI_EVENT_COLLISION_BEGIN = 0, MI_EVENT_COLLISION_END = 1 } mi_event_type;
+typedef enum mi_event_type {
+    MI_EVENT_COLLISION_BEGIN = 0, MI_EVENT_COLLISION_END = 1,
+    /* trigger_event_enter / trigger_event_leave (src/physics/physics.h:187-198): entity_a = the trigger entity, entity_b = the rigid
+     * body's entity; de-duplicated per entity pair (several colliders may overlap), fired in ascending (trigger, body) order before
+     * the collision events of the step, like handleNonCollisionInteractions (src/physics/physics.cpp:952-1039); colliders = ~0. */
+    MI_EVENT_TRIGGER_ENTER = 2, MI_EVENT_TRIGGER_LEAVE = 3
+} mi_event_type;
 typedef struct mi_event {
     uint32_t type;                  /* mi_event_type */
     uint32_t entity_a, entity_b;    /* the colliders' parent entities (collision_begin_event::entityA/B) */

@@ -558,6 +558,126 @@ static void fromBoxFrame(const Shape& o, ContactManifold& out) {
 }
 
 // intersection dispatch — the 21 collision<A,B>() instantiations (collision_narrow.cpp:2473-2570).
+// ---------------------------------------------------------------- boolean overlap tests (triggers, force fields)
+// overlapCheck — src/physics/collision_narrow.cpp:1586-1689, dispatching to the boolean tests of
+// src/physics/bounding_volumes.h:301-363 and bounding_volumes.cpp:704-835, 1079-1244.  A.type <= B.type.
+static bool sphereVsSphereB(vec3 ca, float ra, vec3 cb, float rb) {  // bounding_volumes.h:301-307
+    vec3 d = ca - cb;
+    float dist2 = dot(d, d);
+    float radiusSum = ra + rb;
+    return dist2 <= radiusSum * radiusSum;
+}
+static bool sphereVsCylinderB(vec3 sc, float sr, vec3 ca, vec3 cb, float cr) {  // bounding_volumes.cpp:704-724 (compares a squared distance with the radius, as written)
+    vec3 ab = cb - ca;
+    float t = dot(sc - ca, ab) / squaredLength(ab);
+    if (t >= 0.f && t <= 1.f) return sphereVsSphereB(sc, sr, lerp(ca, cb, t), cr);
+    vec3 p = (t <= 0.f) ? ca : cb;
+    vec3 up = (t <= 0.f) ? -ab : ab;
+    vec3 projectedDirToCenter = normalize(cross(cross(up, sc - p), up));
+    vec3 endA = p + projectedDirToCenter * cr, endB = p - projectedDirToCenter * cr;
+    vec3 closestToSphere = closestPoint_PointSegment(sc, endA, endB);
+    float sqDistance = squaredLength(closestToSphere - sc);
+    return sqDistance <= sr;
+}
+static bool sphereVsAABBB(vec3 sc, float sr, vec3 mn, vec3 mx) {  // bounding_volumes.h:320-326
+    vec3 p = closestPoint_PointAABB(sc, mn, mx);
+    vec3 n = p - sc;
+    return squaredLength(n) <= sr * sr;
+}
+static bool gjkBool(const World& w, const Shape& a, const Shape& b) {
+    SupportShape A{&a, a.type == T_HULL ? &w.hulls[a.hull] : nullptr}, B{&b, b.type == T_HULL ? &w.hulls[b.hull] : nullptr};
+    GjkSimplex sx;
+    return gjkIntersectionTest(A, B, sx);
+}
+static Shape segmentShapeInBoxFrame(const Shape& c, const Shape& o, Shape& boxOut) {  // capsuleVsOBB / cylinderVsOBB, bounding_volumes.cpp:751-760, 808-817
+    boxOut = Shape(); boxOut.type = T_AABB; boxOut.a = o.a - o.b; boxOut.b = o.a + o.b;   // fromCenterRadius
+    Shape r = c;
+    r.a = conjugate(o.rot) * (c.a - o.a) + o.a;
+    r.b = conjugate(o.rot) * (c.b - o.a) + o.a;
+    return r;
+}
+static bool obbVsOBBB(quat arot, vec3 acen, vec3 arad, quat brot, vec3 bcen, vec3 brad) {  // bounding_volumes.cpp:1079-1199
+    vec3 ax = arot * vec3(1.f, 0.f, 0.f), ay = arot * vec3(0.f, 1.f, 0.f), az = arot * vec3(0.f, 0.f, 1.f);
+    vec3 bx = brot * vec3(1.f, 0.f, 0.f), by = brot * vec3(0.f, 1.f, 0.f), bz = brot * vec3(0.f, 0.f, 1.f);
+    mat3 r;
+    r.m00 = dot(ax, bx); r.m10 = dot(ay, bx); r.m20 = dot(az, bx);
+    r.m01 = dot(ax, by); r.m11 = dot(ay, by); r.m21 = dot(az, by);
+    r.m02 = dot(ax, bz); r.m12 = dot(ay, bz); r.m22 = dot(az, bz);
+    vec3 tw = bcen - acen;
+    vec3 t = conjugate(arot) * tw;
+    mat3 q;
+    q.m00 = std::fabs(r.m00) + kEps; q.m01 = std::fabs(r.m01) + kEps; q.m02 = std::fabs(r.m02) + kEps;
+    q.m10 = std::fabs(r.m10) + kEps; q.m11 = std::fabs(r.m11) + kEps; q.m12 = std::fabs(r.m12) + kEps;
+    q.m20 = std::fabs(r.m20) + kEps; q.m21 = std::fabs(r.m21) + kEps; q.m22 = std::fabs(r.m22) + kEps;
+    float ra, rb;
+    const float ar[3] = {arad.x, arad.y, arad.z}, br[3] = {brad.x, brad.y, brad.z}, tt[3] = {t.x, t.y, t.z};
+    for (int i = 0; i < 3; ++i) {
+        ra = ar[i]; rb = dot(row(q, i), brad);
+        if (ra + rb - std::fabs(tt[i]) < 0.f) return false;
+    }
+    for (int i = 0; i < 3; ++i) {
+        ra = dot(col(q, i), arad); rb = br[i];
+        if (ra + rb - std::fabs(dot(col(r, i), t)) < 0.f) return false;
+    }
+#define ORA_EDGE(RA, RB, D) ra = RA; rb = RB; if (ra + rb - std::fabs(D) < 0.f) return false;
+    ORA_EDGE(arad.y * q.m20 + arad.z * q.m10, brad.y * q.m02 + brad.z * q.m01, t.z * r.m10 - t.y * r.m20)
+    ORA_EDGE(arad.y * q.m21 + arad.z * q.m11, brad.x * q.m02 + brad.z * q.m00, t.z * r.m11 - t.y * r.m21)
+    ORA_EDGE(arad.y * q.m22 + arad.z * q.m12, brad.x * q.m01 + brad.y * q.m00, t.z * r.m12 - t.y * r.m22)
+    ORA_EDGE(arad.x * q.m20 + arad.z * q.m00, brad.y * q.m12 + brad.z * q.m11, t.x * r.m20 - t.z * r.m00)
+    ORA_EDGE(arad.x * q.m21 + arad.z * q.m01, brad.x * q.m12 + brad.z * q.m10, t.x * r.m21 - t.z * r.m01)
+    ORA_EDGE(arad.x * q.m22 + arad.z * q.m02, brad.x * q.m11 + brad.y * q.m10, t.x * r.m22 - t.z * r.m02)
+    ORA_EDGE(arad.x * q.m10 + arad.y * q.m00, brad.y * q.m22 + brad.z * q.m21, t.y * r.m00 - t.x * r.m10)
+    ORA_EDGE(arad.x * q.m11 + arad.y * q.m01, brad.x * q.m22 + brad.z * q.m20, t.y * r.m01 - t.x * r.m11)
+    ORA_EDGE(arad.x * q.m12 + arad.y * q.m02, brad.x * q.m21 + brad.y * q.m20, t.y * r.m02 - t.x * r.m12)
+#undef ORA_EDGE
+    return true;
+}
+
+bool overlapCheck(const World& w, const WorldCollider& A, const WorldCollider& B) {
+    const Shape& a = A.s; const Shape& b = B.s;
+    switch (a.type) {
+        case T_SPHERE:
+            switch (b.type) {
+                case T_SPHERE: return sphereVsSphereB(a.a, a.radius, b.a, b.radius);
+                case T_CAPSULE: return sphereVsSphereB(a.a, a.radius, closestPoint_PointSegment(a.a, b.a, b.b), b.radius);   // bounding_volumes.h:314-318
+                case T_CYLINDER: return sphereVsCylinderB(a.a, a.radius, b.a, b.b, b.radius);
+                case T_AABB: return sphereVsAABBB(a.a, a.radius, b.a, b.b);
+                case T_OBB: return sphereVsAABBB(conjugate(b.rot) * (a.a - b.a) + b.a, a.radius, b.a - b.b, b.a + b.b);   // bounding_volumes.h:328-336
+                default: return gjkBool(w, a, b);
+            }
+        case T_CAPSULE:
+            switch (b.type) {
+                case T_CAPSULE: { vec3 c1, c2; closestPoint_SegmentSegment(a.a, a.b, b.a, b.b, c1, c2); return sphereVsSphereB(c1, a.radius, c2, b.radius); }
+                case T_CYLINDER: { vec3 c1, c2; closestPoint_SegmentSegment(a.a, a.b, b.a, b.b, c1, c2); return sphereVsCylinderB(c1, a.radius, b.a, b.b, b.radius); }
+                case T_AABB: return gjkBool(w, a, b);
+                case T_OBB: { Shape box; Shape c = segmentShapeInBoxFrame(a, b, box); return gjkBool(w, c, box); }
+                default: return gjkBool(w, a, b);
+            }
+        case T_CYLINDER:
+            switch (b.type) {
+                case T_CYLINDER: return gjkBool(w, a, b);
+                case T_AABB: return gjkBool(w, a, b);
+                case T_OBB: { Shape box; Shape c = segmentShapeInBoxFrame(a, b, box); return gjkBool(w, c, box); }
+                default: return gjkBool(w, a, b);
+            }
+        case T_AABB:
+            switch (b.type) {
+                case T_AABB:   // bounding_volumes.h:352-358
+                    if (a.b.x < b.a.x || a.a.x > b.b.x) return false;
+                    if (a.b.y < b.a.y || a.a.y > b.b.y) return false;
+                    if (a.b.z < b.a.z || a.a.z > b.b.z) return false;
+                    return true;
+                case T_OBB: return obbVsOBBB(quat(0.f, 0.f, 0.f, 1.f), (a.a + a.b) * 0.5f, (a.b - a.a) * 0.5f, b.rot, b.a, b.b);   // bounding_volumes.h:360-363
+                default: return gjkBool(w, a, b);
+            }
+        case T_OBB:
+            if (b.type == T_OBB) return obbVsOBBB(a.rot, a.a, a.b, b.rot, b.a, b.b);
+            return gjkBool(w, a, b);
+        default:
+            return gjkBool(w, a, b);
+    }
+}
+
 bool intersect(const World& w, const WorldCollider& A, const WorldCollider& B, ContactManifold& out) {
     const Shape& a = A.s; const Shape& b = B.s;
     EpaResult epa;

@@ -328,6 +328,8 @@ static void getWorldSpaceColliders(World& w) {
         WorldCollider& col = w.wc[k]; AABB& bb = w.aabbs[k];
         vec3 tp; quat tr;
         if (e.rb >= 0) { tp = w.bodies[e.rb].p1; tr = w.bodies[e.rb].r1; col.objectIndex = (uint32_t)e.rb; col.objectType = MI_OBJECT_RIGID_BODY; }
+        else if (e.kind == MI_ENTITY_FORCE_FIELD) { tp = e.position; tr = e.rotation; col.objectIndex = e.kindIndex; col.objectType = MI_OBJECT_FORCE_FIELD; }
+        else if (e.kind == MI_ENTITY_TRIGGER) { tp = e.position; tr = e.rotation; col.objectIndex = e.kindIndex; col.objectType = MI_OBJECT_TRIGGER; }
         else { tp = e.position; tr = e.rotation; col.objectIndex = dummy; col.objectType = MI_OBJECT_STATIC_COLLIDER; }
         col.mat = c.mat;
         col.s = Shape(); col.s.type = c.local.type;
@@ -541,14 +543,25 @@ static bool pruneAndOrient(const World& w, Pair& p, bool& collision) {
 
 // narrowphase — src/physics/collision_narrow.cpp:2328-2603 (collision pairs only; trigger /
 // force-field overlap lists are SURVEY §8(f) item 4).
+// overlapCheck's bookkeeping (collision_narrow.cpp:1586-1606): which side is the rigid body.
+static void pushInteraction(World& w, Pair p) {
+    const WorldCollider& A = w.wc[p.a]; const WorldCollider& B = w.wc[p.b];
+    if (!overlapCheck(w, A, B)) return;
+    Interaction in;
+    if (A.objectType == MI_OBJECT_RIGID_BODY) { in.rigidBodyIndex = A.objectIndex; in.otherIndex = B.objectIndex; in.otherType = B.objectType; in.rbCollider = p.a; in.otherCollider = p.b; }
+    else { in.rigidBodyIndex = B.objectIndex; in.otherIndex = A.objectIndex; in.otherType = A.objectType; in.rbCollider = p.b; in.otherCollider = p.a; }
+    w.interactions.push_back(in);
+}
+
 static void narrowphaseReference(World& w) {
-    w.colliderPairs.clear(); w.contactCounts.clear(); w.contacts.clear(); w.bodyPairs.clear();
-    std::vector<Pair> buckets[21];
+    w.colliderPairs.clear(); w.contactCounts.clear(); w.contacts.clear(); w.bodyPairs.clear(); w.interactions.clear();
+    std::vector<Pair> buckets[21], ibuckets[21];
     for (Pair p : w.bpPairs) {
         bool collision;
-        if (!pruneAndOrient(w, p, collision) || !collision) continue;
-        buckets[bucketOf(w.wc[p.a].s.type, w.wc[p.b].s.type)].push_back(p);
+        if (!pruneAndOrient(w, p, collision)) continue;
+        (collision ? buckets : ibuckets)[bucketOf(w.wc[p.a].s.type, w.wc[p.b].s.type)].push_back(p);
     }
+    for (int bk = 0; bk < 21; ++bk) for (const Pair& p : ibuckets[bk]) pushInteraction(w, p);   // collision_narrow.cpp:2573-2600 (after the collision tests there; independent of them)
     for (int bk = 0; bk < 21; ++bk)
         for (const Pair& p : buckets[bk]) {
             ContactManifold m;
@@ -559,7 +572,8 @@ static void narrowphaseReference(World& w) {
 // Canonical order: orientation identical to what the SAP sweep produces ({new, active} then the
 // type swap), pairs sorted by (bucket, A, B).
 static void narrowphaseCanonical(World& w, uint32_t axisUsed) {
-    w.colliderPairs.clear(); w.contactCounts.clear(); w.contacts.clear(); w.bodyPairs.clear();
+    w.colliderPairs.clear(); w.contactCounts.clear(); w.contacts.clear(); w.bodyPairs.clear(); w.interactions.clear();
+    std::vector<Pair> ipairs;
     std::vector<uint64_t> keys; keys.reserve(w.bpPairs.size());
     for (Pair p : w.bpPairs) {
         // reconstruct {new, active}: new = later start on the sweep axis; tie -> later created = smaller world index
@@ -567,7 +581,8 @@ static void narrowphaseCanonical(World& w, uint32_t axisUsed) {
         bool aIsNew = (ma > mb) || (ma == mb && p.a < p.b);
         Pair q = aIsNew ? Pair{p.a, p.b} : Pair{p.b, p.a};
         bool collision;
-        if (!pruneAndOrient(w, q, collision) || !collision) continue;
+        if (!pruneAndOrient(w, q, collision)) continue;
+        if (!collision) { ipairs.push_back(q); continue; }
         uint64_t bk = bucketOf(w.wc[q.a].s.type, w.wc[q.b].s.type);
         keys.push_back((bk << 58) | ((uint64_t)q.a << 29) | (uint64_t)q.b);
     }
@@ -577,6 +592,13 @@ static void narrowphaseCanonical(World& w, uint32_t axisUsed) {
         ContactManifold m;
         if (intersect(w, w.wc[a], w.wc[b], m)) emitManifold(w, m, a, b);
     }
+    for (const Pair& p : ipairs) pushInteraction(w, p);
+    // canonical order of the interactions = the order the device applies them in: (rigid body, other collider, body collider)
+    std::sort(w.interactions.begin(), w.interactions.end(), [](const Interaction& x, const Interaction& y) {
+        if (x.rigidBodyIndex != y.rigidBodyIndex) return x.rigidBodyIndex < y.rigidBodyIndex;
+        if (x.otherCollider != y.otherCollider) return x.otherCollider < y.otherCollider;
+        return x.rbCollider < y.rbCollider;
+    });
 }
 
 // ---------------------------------------------------------------- integrator
@@ -743,6 +765,44 @@ static void colorManifolds(World& w) {
     for (uint32_t m = 0; m < nm; ++m) w.prevPairColor[keyOf(m)] = w.manifoldColor[m];
 }
 
+// getForceFieldStates + handleNonCollisionInteractions — src/physics/physics.cpp:759-787, 952-1039.  Localized force fields add
+// their (rotated) force to the accumulator of every body they overlap, once per overlapping collider pair; trigger overlaps are
+// de-duplicated per (trigger entity, body entity) and diffed against the previous frame.  Returns the global force field.
+static vec3 nonCollisionInteractions(World& w) {
+    vec3 globalForceField(0.f);
+    std::vector<vec3> localForce(w.forceFieldEntities.size());
+    for (size_t i = w.forceFieldEntities.size(); i-- > 0;) {   // EnTT view order: back to front
+        const Entity& e = w.entities[w.forceFieldEntities[i]];
+        vec3 force = e.rotation * e.force;
+        if (!e.colliders.empty()) localForce[i] = force; else globalForceField += force;
+    }
+    std::vector<uint64_t> overlaps;
+    for (const Interaction& in : w.interactions) {
+        if (in.otherType == MI_OBJECT_FORCE_FIELD) w.bodies[in.rigidBodyIndex].forceAccumulator += localForce[in.otherIndex];
+        else if (in.otherType == MI_OBJECT_TRIGGER)
+            overlaps.push_back(((uint64_t)w.triggerEntities[in.otherIndex] << 32) | (uint64_t)w.bodies[in.rigidBodyIndex].entity);
+    }
+    std::sort(overlaps.begin(), overlaps.end());
+    overlaps.erase(std::unique(overlaps.begin(), overlaps.end()), overlaps.end());
+    if (w.eventsEnabled) {
+        auto emit = [&](uint64_t key, uint32_t type) {
+            mi_event e{}; e.type = type; e.entity_a = (uint32_t)(key >> 32); e.entity_b = (uint32_t)key; e.collider_a = e.collider_b = 0xFFFFFFFFu;
+            w.events.push_back(e);
+        };
+        size_t p = 0, t = 0;
+        while (p < w.prevTriggerOverlaps.size() && t < overlaps.size()) {
+            uint64_t pk = w.prevTriggerOverlaps[p], tk = overlaps[t];
+            if (pk == tk) { ++p; ++t; }
+            else if (pk < tk) { emit(pk, MI_EVENT_TRIGGER_LEAVE); ++p; }
+            else { emit(tk, MI_EVENT_TRIGGER_ENTER); ++t; }
+        }
+        while (p < w.prevTriggerOverlaps.size()) emit(w.prevTriggerOverlaps[p++], MI_EVENT_TRIGGER_LEAVE);
+        while (t < overlaps.size()) emit(overlaps[t++], MI_EVENT_TRIGGER_ENTER);
+        w.prevTriggerOverlaps = std::move(overlaps);
+    } else w.prevTriggerOverlaps.clear();
+    return globalForceField;
+}
+
 // handleCollisionCallbacks — src/physics/physics.cpp:1041-1178: sorted merge of the previous and the current frame's
 // collision lists; begin events carry the mean contact point / normal and the relative point velocity from rbGlobal.
 static void collisionEvents(World& w) {
@@ -798,8 +858,12 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
     if (orderMode == 0) { broadphaseReference(*this); narrowphaseReference(*this); }
     else { broadphaseCanonical(*this); narrowphaseCanonical(*this, axisUsed); }
 
+    vec3 globalForceField = nonCollisionInteractions(*this);   // force fields, triggers (physics.cpp:1253-1256)
     rb.resize(nb + 1);
-    for (uint32_t i = nb; i-- > 0;) applyGravityAndIntegrateForces(bodies[i], rb[i], dt);  // back to front (1266-1276)
+    for (uint32_t i = nb; i-- > 0;) {                           // back to front (1266-1276)
+        bodies[i].forceAccumulator += globalForceField;         // physics.cpp:1273
+        applyGravityAndIntegrateForces(bodies[i], rb[i], dt);
+    }
     std::memset((void*)&rb[nb], 0, sizeof(GlobalState));  // dummy (1279)
     if (eventsEnabled) collisionEvents(*this); else prevCollisionKeys.clear();
 
@@ -901,7 +965,9 @@ MI_API int ora_entities_create(World* w, uint32_t count, const mi_entity_desc* d
         const mi_entity_desc& d = descs[i];
         Entity e; e.position = vec3(d.position[0], d.position[1], d.position[2]);
         e.rotation = quat(d.rotation[0], d.rotation[1], d.rotation[2], d.rotation[3]); e.kind = (int)d.kind;
-        if (d.kind != MI_ENTITY_STATIC) {
+        if (d.kind == MI_ENTITY_FORCE_FIELD) { e.kindIndex = (uint32_t)w->forceFieldEntities.size(); w->forceFieldEntities.push_back((uint32_t)w->entities.size()); }
+        if (d.kind == MI_ENTITY_TRIGGER) { e.kindIndex = (uint32_t)w->triggerEntities.size(); w->triggerEntities.push_back((uint32_t)w->entities.size()); }
+        if (d.kind == MI_ENTITY_DYNAMIC || d.kind == MI_ENTITY_KINEMATIC) {
             RigidBody rb;
             rb.entity = (uint32_t)w->entities.size();
             bool kinematic = d.kind == MI_ENTITY_KINEMATIC;  // rigid_body.cpp:6-27
@@ -1042,9 +1108,14 @@ MI_API int ora_world_get_contacts(World* w, mi_contact* out, uint32_t cap, uint3
         }
     return MI_OK;
 }
+MI_API int ora_entity_set_force(World* w, uint32_t entity, const float* f) {
+    if (!w || !f || entity >= w->entities.size() || w->entities[entity].kind != MI_ENTITY_FORCE_FIELD) return MI_ERR_INVALID_ARGUMENT;
+    w->entities[entity].force = vec3(f[0], f[1], f[2]);
+    return MI_OK;
+}
 MI_API int ora_world_enable_events(World* w, uint32_t enable) {
     if (!w) return MI_ERR_INVALID_ARGUMENT;
-    w->eventsEnabled = enable != 0; w->events.clear(); w->prevCollisionKeys.clear();
+    w->eventsEnabled = enable != 0; w->events.clear(); w->prevCollisionKeys.clear(); w->prevTriggerOverlaps.clear();
     w->prevPairColor.clear();   // the product keeps ONE history table for colours and events; enabling events restarts it
     return MI_OK;
 }

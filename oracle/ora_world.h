@@ -54,7 +54,11 @@ struct Entity {
     int kind;
     int rb = -1;                        // rigid_body_component dense index or -1
     std::vector<uint32_t> colliders;    // newest first (linked list prepend, src/scene/scene.h:52-54)
+    vec3 force;                         // force_field_component::force (kind MI_ENTITY_FORCE_FIELD)
+    uint32_t kindIndex = 0;             // dense index among the entities of its kind (force fields / triggers)
 };
+
+struct Interaction { uint32_t rigidBodyIndex, otherIndex; int otherType; uint32_t rbCollider, otherCollider; };  // non_collision_interaction
 
 struct RigidBody {  // rigid_body_component + physics_transform0/1 (src/physics/rigid_body.h:18-58)
     uint32_t entity;
@@ -115,6 +119,9 @@ struct World {
     std::vector<Contact> contacts;
     std::vector<Pair> bodyPairs;          // per contact
     std::vector<uint32_t> manifoldColor;  // canonical mode
+    std::vector<uint32_t> forceFieldEntities, triggerEntities;   // entity ids by dense index
+    std::vector<Interaction> interactions;                        // last step
+    std::vector<uint64_t> prevTriggerOverlaps;                    // sorted (triggerEntity << 32 | rbEntity)
     bool eventsEnabled = false;
     std::vector<uint64_t> prevCollisionKeys;   // sorted (creationA << 26 | creationB) of the previous step's manifolds
     std::vector<mi_event> events;              // since the last poll
@@ -131,6 +138,7 @@ struct World {
 
 // narrow phase (ora_narrow.cpp)
 bool intersect(const World& w, const WorldCollider& A, const WorldCollider& B, ContactManifold& out);
+bool overlapCheck(const World& w, const WorldCollider& A, const WorldCollider& B);   // boolean tests for triggers / force fields
 // GJK / EPA (ora_gjk.cpp)
 struct SupportShape { const Shape* s; const HullGeometry* g; };
 vec3 support(const SupportShape& sh, vec3 dir);

@@ -131,6 +131,31 @@ def test_gpu_collision_events_match_oracle(mi_lib, oracle_mod):
     assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
 
 
+def test_gpu_triggers_and_force_fields_match_oracle(mi_lib, oracle_mod):
+    """handleNonCollisionInteractions (physics.cpp:952-1039): localized + global force fields and trigger enter / leave events
+    over every collider type, bit-exact against the oracle's canonical schedule, every step."""
+    sc = scenes.zones()
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    g.enable_events(); o.enable_events()
+    s = sc.settings()
+    enters = leaves = 0
+    for i in range(240):
+        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        eg, eo = g.poll_events(), o.poll_events()
+        assert eg.tobytes() == eo.tobytes(), f"step {i}: {len(eg)} vs {len(eo)} events"
+        enters += int((eg["type"] == capi.EVENT_TRIGGER_ENTER).sum()); leaves += int((eg["type"] == capi.EVENT_TRIGGER_LEAVE).sum())
+        if i % 40 == 0:
+            vg, wg = g.velocities(); vo, wo = o.velocities()
+            assert vg.tobytes() == vo.tobytes() and wg.tobytes() == wo.tobytes(), f"step {i}"
+    assert enters > 10 and leaves > 5
+    pg, qg = g.physics_transforms(); po, qo = o.physics_transforms()
+    assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
+    # without events the forces still apply and the state stays identical
+    g2 = sc.populate(gpu_world(mi_lib)); o2 = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    g2.step_fixed(s, sc.dt, 60); o2.step_fixed(s, sc.dt, 60)
+    assert g2.physics_transforms()[0].tobytes() == o2.physics_transforms()[0].tobytes()
+
+
 def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
     """Steps after the first run with ONE host read-back, sized from the previous step's counts.  Teleporting the bodies into
     a much denser pile invalidates those bounds: the step must be re-run synchronously from the untouched state and still match

@@ -204,3 +204,42 @@ def test_collision_events_begin_and_end(oracle_mod):
     w.step_fixed(s, sc.dt, 1)
     e = w.poll_events()
     assert len(e) == 1 and e["type"][0] == capi.EVENT_COLLISION_END and e["collider_a"][0] == ca and e["collider_b"][0] == cb
+
+
+def test_force_fields_and_triggers(oracle_mod):
+    """getForceFieldStates / handleNonCollisionInteractions (physics.cpp:759-787, 952-1039): a localized field pushes only the
+    body inside it, with the force rotated by the field entity; a collider-less field is global; a trigger reports one enter and
+    one leave per entity pair however many colliders overlap."""
+    e = scenes.make_entities(5)
+    e["gravity_factor"] = 0.0; e["linear_damping"] = 0.0
+    e["position"][0] = (0, 0, 0); e["position"][1] = (10, 0, 0)
+    e["kind"][2] = capi.ENTITY_FORCE_FIELD; e["position"][2] = (0, 0, 0); e["rotation"][2] = scenes.q_axis_angle((0, 0, 1), np.pi / 2)
+    e["kind"][3] = capi.ENTITY_FORCE_FIELD                                  # global: no colliders
+    e["kind"][4] = capi.ENTITY_TRIGGER; e["position"][4] = (10, 0, 0)
+    c = scenes.make_colliders(5, capi.SPHERE)
+    c["shape"][:2, 3] = 0.5
+    c["type"][2] = capi.AABB; c["shape"][2, :6] = (-1, -1, -1, 1, 1, 1)     # the localized field's volume
+    c["shape"][3, :4] = (0, 0, 0, 0.6); c["shape"][4, :4] = (0.2, 0, 0, 0.6)  # two trigger colliders, both around body 1
+    for mode in (oracle_mod.ORDER_REFERENCE, oracle_mod.ORDER_CANONICAL):
+        w = oracle_mod.create_world(mode)
+        w.create_entities(e)
+        w.add_colliders(np.array([0, 1, 2, 4, 4], np.uint32), c)
+        w.set_force(2, (4.0, 0.0, 0.0)); w.set_force(3, (0.0, 0.0, 1.5))
+        w.enable_events()
+        s = capi.StepSettings(1, 120, 4, 4)
+        dt = 1 / 120
+        w.step_fixed(s, dt, 1)
+        v, _ = w.velocities()
+        im = w.mass_properties()[0]
+        rot_force = np.array([0.0, 4.0, 0.0])                               # (4,0,0) rotated by +90 deg about z
+        assert np.allclose(v[0], (rot_force + (0, 0, 1.5)) * im[0] * dt, rtol=1e-5, atol=1e-7)
+        assert np.allclose(v[1], np.array([0, 0, 1.5]) * im[1] * dt, rtol=1e-5, atol=1e-7)
+        ev = w.poll_events()
+        assert len(ev) == 1 and ev["type"][0] == capi.EVENT_TRIGGER_ENTER and ev["entity_a"][0] == 4 and ev["entity_b"][0] == 1
+        w.step_fixed(s, dt, 3)
+        assert len(w.poll_events()) == 0
+        st = w.get_body_states(np.array([1], np.uint32)); st[0, 0] += 5.0
+        w.set_body_states(np.array([1], np.uint32), st)
+        w.step_fixed(s, dt, 1)
+        ev = w.poll_events()
+        assert len(ev) == 1 and ev["type"][0] == capi.EVENT_TRIGGER_LEAVE and ev["entity_a"][0] == 4 and ev["entity_b"][0] == 1
