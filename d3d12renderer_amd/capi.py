@@ -198,6 +198,25 @@ class World:
         f = np.ascontiguousarray(force, dtype=np.float32)
         self.L.check(self.L.fn("entity_set_force")(self.h, C.c_uint32(entity), _ptr(f)), "entity_set_force")
 
+    # --- heightmap terrain (heightmap_collider_component, src/terrain/heightmap_collider.h:126-151)
+    def create_heightmap(self, chunks_per_dim, chunk_size, restitution=0.0, friction=1.0):
+        self.L.check(self.L.fn("heightmap_create")(self.h, C.c_uint32(chunks_per_dim), C.c_float(chunk_size), C.c_float(restitution), C.c_float(friction)), "heightmap_create")
+
+    def set_chunk_heights(self, x, z, heights):
+        """collider(x, z).setHeights: 129 x 129 uint16, [z][x]."""
+        h = np.ascontiguousarray(heights, dtype=np.uint16)
+        assert h.shape == (129, 129)
+        self.L.check(self.L.fn("heightmap_set_chunk_heights")(self.h, C.c_uint32(x), C.c_uint32(z), _ptr(h)), "heightmap_set_chunk_heights")
+
+    def update_heightmap(self, min_corner, amplitude_scale):
+        c = np.ascontiguousarray(min_corner, dtype=np.float32)
+        self.L.check(self.L.fn("heightmap_update")(self.h, _ptr(c), C.c_float(amplitude_scale)), "heightmap_update")
+
+    def heightmap_height(self, x, z):
+        out = C.c_float()
+        self.L.check(self.L.fn("heightmap_get_height")(self.h, C.c_float(x), C.c_float(z), C.byref(out)), "heightmap_get_height")
+        return out.value
+
     # --- stepping
     def step(self, settings, dt):
         """physicsStep(scene, arena, timer, settings, dt) — src/physics/physics.cpp:1364."""

@@ -62,6 +62,7 @@ class Scene:
     hulls: list = field(default_factory=list)          # (vertices, triangles)
     global_constraints: list = field(default_factory=list)   # (type, entity_a, entity_b, anchor, axis, limit0, limit1, {field: value})
     forces: list = field(default_factory=list)               # (force-field entity, force3)
+    heightmap: dict = None    # chunks_per_dim, chunk_size, restitution, friction, min_corner, amplitude, chunks {(x, z): uint16[129][129]}
 
     @property
     def num_bodies(self):
@@ -77,6 +78,12 @@ class Scene:
         world.add_colliders(self.collider_entities, self.colliders)
         for ent, force in self.forces:
             world.set_force(ent, force)
+        if self.heightmap is not None:
+            hm = self.heightmap
+            world.create_heightmap(hm["chunks_per_dim"], hm["chunk_size"], hm["restitution"], hm["friction"])
+            for (x, z), heights in hm["chunks"].items():
+                world.set_chunk_heights(x, z, heights)
+            world.update_heightmap(hm["min_corner"], hm["amplitude"])
         for ctype, ea, eb, pod in self.constraints:
             world.add_constraint(ctype, ea, eb, pod)
         for ctype, ea, eb, anchor, axis, l0, l1, edits in self.global_constraints:
@@ -700,6 +707,56 @@ def zones(nx=6, ny=3, nz=6, seed=8, solver_iterations=20, spacing=1.4):
     ents = np.concatenate([np.arange(n, dtype=np.uint32), zent, [n + 6]]).astype(np.uint32)
     return Scene(f"zones_{n}", np.concatenate([e, z, ge]), ents, np.concatenate([c, zc, zsphere, gc]), solver_iterations,
                  forces=[(n + 0, (6.0, 0.0, 1.0)), (n + 1, (0.0, 14.0, 0.0)), (n + 2, (0.3, 0.0, -0.2))])
+
+
+def rolling_heightmap(chunks_per_dim=2, chunk_size=16.0, amplitude=6.0, seed=9, min_corner=None, holes=()):
+    """Deterministic rolling hills as uint16 chunks (129 x 129 vertices each, shared edge rows).  `holes`: chunks left without
+    heights (they collide with nothing, like the reference's unloaded chunks)."""
+    n = chunks_per_dim * 128 + 1
+    gx, gz = np.meshgrid(np.arange(n, dtype=np.float64), np.arange(n, dtype=np.float64))
+    ph = uniform(seed, 70, 6).astype(np.float64) * 2 * np.pi
+    h = (0.30 + 0.12 * np.sin(gx * 0.045 + ph[0]) * np.cos(gz * 0.038 + ph[1]) + 0.07 * np.sin(gx * 0.11 + gz * 0.09 + ph[2])
+         + 0.03 * np.cos(gx * 0.31 + ph[3]) * np.sin(gz * 0.27 + ph[4]))
+    q = np.clip(np.rint(h * 65535.0), 0, 65535).astype(np.uint16)
+    chunks = {(x, z): np.ascontiguousarray(q[z * 128:z * 128 + 129, x * 128:x * 128 + 129])
+              for z in range(chunks_per_dim) for x in range(chunks_per_dim) if (x, z) not in holes}
+    half = chunks_per_dim * chunk_size / 2
+    corner = (-half, 0.0, -half) if min_corner is None else min_corner
+    return dict(chunks_per_dim=chunks_per_dim, chunk_size=chunk_size, restitution=0.05, friction=0.8,
+                min_corner=np.asarray(corner, np.float32), amplitude=amplitude, chunks=chunks)
+
+
+def terrain_field(nx=10, ny=2, nz=10, seed=9, solver_iterations=20, spacing=1.6, with_unsupported=True):
+    """Heightmap terrain (heightmapCollision): mixed spheres, capsules, AABB boxes (upright -> AABB, tumbling -> promoted to
+    OBB) and OBBs dropped on rolling hills; two of them over the edge of the map (they fall past it); optionally a cylinder
+    and a hull, which the terrain ignores."""
+    n = nx * ny * nz
+    e = make_entities(n)
+    e["position"] = _lattice(nx, ny, nz, spacing, 5.5, seed, 0.08)
+    rot = random_unit_quaternions(seed, 22, n)
+    kind = _hash_u32(seed, 55, np.arange(n)) % 5          # 0 sphere, 1 capsule, 2 upright AABB, 3 tumbling AABB, 4 OBB
+    rot[kind == 2] = (0, 0, 0, 1)
+    e["rotation"] = rot
+    e["angular_velocity"] = (uniform(seed, 57, 3 * n, -1.0, 1.0).reshape(n, 3) * (kind != 2)[:, None]).astype(np.float32)
+    e["position"][0] = (-40.0, 8.0, 0.0); e["position"][1] = (3.0, 8.0, 40.0)      # outside the 32 m x 32 m map
+    c = make_colliders(n, capi.SPHERE)
+    r = uniform(seed, 56, n, 0.25, 0.45)
+    for i in range(n):
+        k = int(kind[i])
+        if k == 0: c["shape"][i, :4] = (0, 0, 0, r[i])
+        elif k == 1: c["type"][i] = capi.CAPSULE; c["shape"][i, :7] = (0, -r[i], 0, 0, r[i], 0, r[i] * 0.6)
+        elif k in (2, 3): c["type"][i] = capi.AABB; c["shape"][i, :6] = (-r[i], -r[i] * 0.7, -r[i] * 1.2, r[i], r[i] * 0.7, r[i] * 1.2)
+        else: c["type"][i] = capi.OBB; c["shape"][i, :10] = (*q_axis_angle((1, 0, 0), 0.5), 0.05, 0, 0, r[i], r[i] * 0.6, r[i] * 0.9)
+    ents = np.arange(n, dtype=np.uint32)
+    hulls = []
+    if with_unsupported:
+        x = make_entities(2); x["position"][0] = (0.5, 9.0, 0.5); x["position"][1] = (-1.5, 9.0, 1.0)
+        xc = make_colliders(2, capi.CYLINDER); xc["shape"][0, :7] = (0, -0.3, 0, 0, 0.3, 0, 0.3)
+        hv, ht = convex_hull_mesh(seed)
+        hulls = [(hv, ht)]
+        xc["type"][1] = capi.HULL; xc["hull_geometry"][1] = 0; xc["shape"][1, :7] = (0, 0, 0, 1, 0, 0, 0)
+        e = np.concatenate([e, x]); c = np.concatenate([c, xc]); ents = np.concatenate([ents, [n, n + 1]]).astype(np.uint32)
+    return Scene(f"terrain_field_{n}", e, ents, c, solver_iterations, hulls=hulls, heightmap=rolling_heightmap(seed=seed))
 
 
 def by_name(name, **kw):

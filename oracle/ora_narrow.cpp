@@ -156,7 +156,7 @@ static bool clipPointsAndBuildContact(ClipPoly& poly, const vec4* planes, uint32
 }
 
 // closestPoint_PointSegment — bounding_volumes.h:365-371
-static vec3 closestPoint_PointSegment(vec3 q, vec3 la, vec3 lb) {
+vec3 closestPoint_PointSegment(vec3 q, vec3 la, vec3 lb) {
     vec3 ab = lb - la;
     float t = dot(q - la, ab) / squaredLength(ab);
     t = clampf(t, 0.f, 1.f);

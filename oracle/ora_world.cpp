@@ -158,7 +158,7 @@ uint64_t pairPriority(uint32_t a, uint32_t b) {
 // ---------------------------------------------------------------- world
 
 World::World() { joints = jointsCreate(); }
-World::~World() { jointsDestroy(joints); }
+World::~World() { jointsDestroy(joints); delete heightmap; }
 
 static float sphereVolume(float r) { float sq = r * r; float sqpi = kPi * sq; return 4.f / 3.f * sqpi * r; }  // bounding_volumes.h:34-40
 
@@ -736,7 +736,10 @@ static void colorManifolds(World& w) {
     std::vector<uint32_t> firstContact(nm);
     { uint32_t off = 0; for (uint32_t m = 0; m < nm; ++m) { firstContact[m] = off; off += w.contactCounts[m]; } }
     const uint32_t nc = (uint32_t)w.colliders.size();   // keyed by CREATION index (stable when colliders are added later)
-    auto keyOf = [&](uint32_t m) { return ((uint64_t)(nc - 1 - w.colliderPairs[m].a) << 26) | (uint64_t)(nc - 1 - w.colliderPairs[m].b); };
+    auto keyOf = [&](uint32_t m) {
+        uint32_t b = w.colliderPairs[m].b;
+        return ((uint64_t)(nc - 1 - w.colliderPairs[m].a) << 26) | (uint64_t)(b >= kHeightmapVirtualBase ? b : nc - 1 - b);
+    };
     std::vector<uint32_t> order;
     for (uint32_t m = 0; m < nm; ++m) {
         auto it = w.prevPairColor.find(keyOf(m));
@@ -808,10 +811,13 @@ static vec3 nonCollisionInteractions(World& w) {
 static void collisionEvents(World& w) {
     const uint32_t nc = (uint32_t)w.colliders.size();
     uint32_t nm = (uint32_t)w.colliderPairs.size();
-    std::vector<std::pair<uint64_t, uint32_t>> cur(nm);
+    std::vector<std::pair<uint64_t, uint32_t>> cur;
     std::vector<uint32_t> firstContact(nm);
     { uint32_t off = 0; for (uint32_t m = 0; m < nm; ++m) { firstContact[m] = off; off += w.contactCounts[m]; } }
-    for (uint32_t m = 0; m < nm; ++m) cur[m] = {((uint64_t)(nc - 1 - w.colliderPairs[m].a) << 26) | (uint64_t)(nc - 1 - w.colliderPairs[m].b), m};
+    for (uint32_t m = 0; m < nm; ++m) {
+        if (w.colliderPairs[m].b >= kHeightmapVirtualBase) continue;   // heightmap pairs raise no events (physics.cpp:1050: colliderB < numColliders)
+        cur.push_back({((uint64_t)(nc - 1 - w.colliderPairs[m].a) << 26) | (uint64_t)(nc - 1 - w.colliderPairs[m].b), m});
+    }
     std::sort(cur.begin(), cur.end());
     auto emit = [&](uint32_t type, uint64_t key, int m) {
         mi_event e{}; e.type = type;
@@ -857,6 +863,7 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
     getWorldSpaceColliders(*this);
     if (orderMode == 0) { broadphaseReference(*this); narrowphaseReference(*this); }
     else { broadphaseCanonical(*this); narrowphaseCanonical(*this, axisUsed); }
+    heightmapCollision(*this);   // physics.cpp:1237-1248: after the narrow phase, into the same contact arrays
 
     vec3 globalForceField = nonCollisionInteractions(*this);   // force fields, triggers (physics.cpp:1253-1256)
     rb.resize(nb + 1);
@@ -900,7 +907,7 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
     counts.num_rigid_bodies = nb;
     counts.num_colliders = (uint32_t)colliders.size();
     counts.num_broadphase_overlaps = (uint32_t)bpPairs.size();
-    counts.num_collisions = (uint32_t)colliderPairs.size();
+    counts.num_collisions = (uint32_t)colliderPairs.size() - heightmapContacts + heightmapCollisions;   // one collision per collider on the terrain
     counts.num_contacts = ncontacts;
     counts.num_colors = ncolors;
     counts.sorting_axis = axisUsed;
@@ -1103,9 +1110,29 @@ MI_API int ora_world_get_contacts(World* w, mi_contact* out, uint32_t cap, uint3
             const Contact& c = w->contacts[ci]; mi_contact& o = out[ci];
             o.point[0] = c.point.x; o.point[1] = c.point.y; o.point[2] = c.point.z; o.penetration_depth = c.penetrationDepth;
             o.normal[0] = c.normal.x; o.normal[1] = c.normal.y; o.normal[2] = c.normal.z; o.friction_restitution = c.friction_restitution;
-            o.collider_a = w->colliderPairs[m].a; o.collider_b = w->colliderPairs[m].b;
+            o.collider_a = w->colliderPairs[m].a; o.collider_b = w->colliderPairs[m].b >= kHeightmapVirtualBase ? 0xFFFFFFFFu : w->colliderPairs[m].b;
             o.body_a = w->bodyPairs[ci].a; o.body_b = w->bodyPairs[ci].b;
         }
+    return MI_OK;
+}
+MI_API int ora_heightmap_create(World* w, uint32_t chunksPerDim, float chunkSize, float restitution, float friction) {
+    if (!w || !chunksPerDim || !(chunkSize > 0.f) || w->heightmap) return MI_ERR_INVALID_ARGUMENT;
+    w->heightmap = new Heightmap(chunksPerDim, chunkSize, Material{restitution, friction, 0.f});
+    return MI_OK;
+}
+MI_API int ora_heightmap_set_chunk_heights(World* w, uint32_t x, uint32_t z, const uint16_t* heights) {
+    if (!w || !w->heightmap || !heights || x >= w->heightmap->chunksPerDim || z >= w->heightmap->chunksPerDim) return MI_ERR_INVALID_ARGUMENT;
+    w->heightmap->setHeights(x, z, heights);
+    return MI_OK;
+}
+MI_API int ora_heightmap_update(World* w, const float* minCorner, float amplitudeScale) {
+    if (!w || !w->heightmap || !minCorner) return MI_ERR_INVALID_ARGUMENT;
+    w->heightmap->update(vec3(minCorner[0], minCorner[1], minCorner[2]), amplitudeScale);
+    return MI_OK;
+}
+MI_API int ora_heightmap_get_height(World* w, float x, float z, float* out) {
+    if (!w || !w->heightmap || !out) return MI_ERR_INVALID_ARGUMENT;
+    *out = w->heightmap->heightAt(x, z);
     return MI_OK;
 }
 MI_API int ora_entity_set_force(World* w, uint32_t entity, const float* f) {

@@ -90,6 +90,22 @@ struct CollisionConstraint {  // collision_constraint (src/physics/constraints.h
     float impulseInNormalDir, impulseInTangentDir, effectiveMassInNormalDir, effectiveMassInTangentDir, bias;
 };
 
+// heightmap_collider_component + heightmap_collider_chunk (src/terrain/heightmap_collider.h:13-33, 126-151)
+struct Heightmap {
+    struct MinMax { uint16_t mn, mx; };
+    struct Chunk { std::vector<uint16_t> heights; std::vector<std::vector<MinMax>> mips; };   // 129 x 129 heights or none
+    uint32_t chunksPerDim; float chunkSize; Material material;
+    vec3 minCorner; float invAmplitudeScale = 1.f, invChunkSize, chunkScale, heightScale = 0.f;
+    std::vector<Chunk> chunks;
+    Heightmap(uint32_t cpd, float size, Material m) : chunksPerDim(cpd), chunkSize(size), material(m), invChunkSize(1.f / size), chunkScale(size / 128.f), chunks((size_t)cpd * cpd) {}
+    void setHeights(uint32_t x, uint32_t z, const uint16_t* heights);
+    void update(vec3 minCorner, float amplitudeScale);
+    float heightAt(float worldX, float worldZ) const;   // -FLT_MAX outside
+};
+// A heightmap contact is a one-contact manifold {collider, kHeightmapVirtualBase + j}: the virtual second index keeps pair
+// keys, colouring priorities and the colour history unique (real collider indices stay below it).
+static const uint32_t kHeightmapVirtualBase = (1u << 26) - 256u;
+
 struct SapEndpoint { float value; uint32_t creation; bool start; uint32_t colliderIndex; };
 
 struct JointStore;  // ora_joints.cpp
@@ -122,6 +138,8 @@ struct World {
     std::vector<uint32_t> forceFieldEntities, triggerEntities;   // entity ids by dense index
     std::vector<Interaction> interactions;                        // last step
     std::vector<uint64_t> prevTriggerOverlaps;                    // sorted (triggerEntity << 32 | rbEntity)
+    Heightmap* heightmap = nullptr;                               // at most one per world
+    uint32_t heightmapCollisions = 0, heightmapContacts = 0;     // last step: colliders touching the terrain, their contacts
     bool eventsEnabled = false;
     std::vector<uint64_t> prevCollisionKeys;   // sorted (creationA << 26 | creationB) of the previous step's manifolds
     std::vector<mi_event> events;              // since the last poll
@@ -139,6 +157,9 @@ struct World {
 // narrow phase (ora_narrow.cpp)
 bool intersect(const World& w, const WorldCollider& A, const WorldCollider& B, ContactManifold& out);
 bool overlapCheck(const World& w, const WorldCollider& A, const WorldCollider& B);   // boolean tests for triggers / force fields
+vec3 closestPoint_PointSegment(vec3 q, vec3 la, vec3 lb);
+float closestPoint_SegmentSegment(vec3 l1a, vec3 l1b, vec3 l2a, vec3 l2b, vec3& c1, vec3& c2);
+void heightmapCollision(World& w);   // ora_heightmap.cpp: appends to colliderPairs / contactCounts / contacts / bodyPairs
 // GJK / EPA (ora_gjk.cpp)
 struct SupportShape { const Shape* s; const HullGeometry* g; };
 vec3 support(const SupportShape& sh, vec3 dir);

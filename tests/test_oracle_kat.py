@@ -243,3 +243,97 @@ def test_force_fields_and_triggers(oracle_mod):
         w.step_fixed(s, dt, 1)
         ev = w.poll_events()
         assert len(ev) == 1 and ev["type"][0] == capi.EVENT_TRIGGER_LEAVE and ev["entity_a"][0] == 4 and ev["entity_b"][0] == 1
+
+
+def _flat_heightmap(world, height_u16=16384, chunks=1, chunk_size=16.0, amplitude=8.0, corner=(-8.0, 1.0, -8.0)):
+    world.create_heightmap(chunks, chunk_size, 0.0, 1.0)
+    for z in range(chunks):
+        for x in range(chunks):
+            world.set_chunk_heights(x, z, np.full((129, 129), height_u16, np.uint16))
+    world.update_heightmap(corner, amplitude)
+    return corner[1] + np.float32(height_u16) * (np.float32(amplitude) / np.float32(65535.0))
+
+
+def test_heightmap_height_query_and_flat_rest(oracle_mod):
+    """getHeightAt (heightmap_collider.cpp:21-40, 116-153) and heightmapCollision on a flat map: bilinear height is exact on a
+    plane, -FLT_MAX outside; a sphere comes to rest on the plane (centre = height + radius); every sphere contact is a triangle
+    contact with the plane's normal (pointing from the body into the terrain) or the lowest-point contact (0,-1,0)."""
+    for mode in (oracle_mod.ORDER_REFERENCE, oracle_mod.ORDER_CANONICAL):
+        w = oracle_mod.create_world(mode)
+        e = scenes.make_entities(1); e["position"][0] = (0.3, 4.0, -0.2)
+        c = scenes.make_colliders(1, capi.SPHERE, restitution=0.0); c["shape"][0, :4] = (0, 0, 0, 0.5)
+        w.create_entities(e); w.add_colliders(np.array([0], np.uint32), c)
+        h = _flat_heightmap(w)
+        assert abs(w.heightmap_height(1.234, -3.21) - h) < 1e-6
+        assert w.heightmap_height(8.5, 0.0) < -1e30 and w.heightmap_height(0.0, -8.01) < -1e30
+        s = capi.StepSettings(1, 120, 4, 10)
+        w.step_fixed(s, 1 / 120, 400)
+        p, _ = w.physics_transforms()
+        assert abs(p[0, 1] - (h + 0.5)) < 5e-3 and abs(p[0, 0] - 0.3) < 0.5   # slanted edge contacts during the impact push sideways (no de-duplication in the reference)
+        con = w.contacts()
+        assert len(con) >= 1 and (con["collider_b"] == 0xFFFFFFFF).all() and (con["body_b"] == 1).all()
+        assert np.allclose(con["normal"], (0, -1, 0), atol=0.05) and (con["normal"][:, 1] == -1.0).any()   # neighbour triangles touch at their edges
+        assert w.counts()["num_collisions"] == 1 and w.counts()["num_contacts"] == len(con)
+
+
+def test_heightmap_slope_normals_and_box(oracle_mod):
+    """A planar slope: every triangle contact of a sphere has the slope's normal (into the terrain) and the right depth; an
+    upright box resting on a flat map gets triangle contacts with normal (0,-1,0) from the 13-axis SAT; a cylinder is ignored."""
+    w = oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)
+    e = scenes.make_entities(1); e["position"][0] = (0.0, 0.0, 0.0); e["gravity_factor"] = 0.0
+    c = scenes.make_colliders(1, capi.SPHERE); c["shape"][0, :4] = (0, 0, 0, 0.5)
+    w.create_entities(e); w.add_colliders(np.array([0], np.uint32), c)
+    w.create_heightmap(1, 16.0, 0.0, 1.0)
+    xs = np.arange(129, dtype=np.float64)
+    heights = np.broadcast_to(np.rint(20000 + 100 * xs), (129, 129)).astype(np.uint16)   # rises along +x only
+    w.set_chunk_heights(0, 0, heights)
+    amp = 8.0
+    w.update_heightmap((-8.0, 0.0, -8.0), amp)
+    slope = (100 * amp / 65535.0) / (16.0 / 128.0)                                      # dh/dx
+    nrm = np.array([slope, -1.0, 0.0]); nrm /= np.linalg.norm(nrm)                      # from the sphere into the ground
+    h0 = w.heightmap_height(0.0, 0.0)
+    st = w.get_body_states(np.array([0], np.uint32)); st[0, 1] = h0 + 0.3; w.set_body_states(np.array([0], np.uint32), st)
+    w.step_fixed(capi.StepSettings(1, 120, 4, 0), 1 / 120, 1)                           # 0 solver iterations: contacts only
+    con = w.contacts()
+    tri = con[con["normal"][:, 1] > -1.0]                                               # all but the lowest-point contact
+    deepest = tri[np.argmax(tri["penetration_depth"])]                                  # the triangle under the centre: face region
+    assert len(tri) >= 2 and np.allclose(deepest["normal"], nrm, atol=2e-4)
+    dist = 0.3 / np.sqrt(1 + slope * slope)                                             # plane distance of the centre
+    assert abs(deepest["penetration_depth"] - (0.5 - dist)) < 2e-3
+    assert (tri["penetration_depth"] >= 0).all() and np.allclose(np.linalg.norm(tri["normal"], axis=1), 1.0, atol=1e-5)
+    assert (np.linalg.norm(tri["point"] - st[0, :3], axis=1) <= 0.5 + 1e-5).all()        # every contact point is inside the sphere
+    # box + cylinder on a flat map
+    w = oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)
+    e = scenes.make_entities(2); e["position"][0] = (0.1, 3.3, 0.1); e["position"][1] = (3.0, 3.3, 3.0)
+    c = scenes.make_colliders(2, capi.AABB, restitution=0.0); c["shape"][0, :6] = (-0.5, -0.25, -0.5, 0.5, 0.25, 0.5)
+    c["type"][1] = capi.CYLINDER; c["shape"][1, :7] = (0, -0.3, 0, 0, 0.3, 0, 0.3)
+    w.create_entities(e); w.add_colliders(np.array([0, 1], np.uint32), c)
+    h = _flat_heightmap(w)
+    w.step_fixed(capi.StepSettings(1, 120, 4, 12), 1 / 120, 300)
+    p, _ = w.physics_transforms()
+    assert abs(p[0, 1] - (h + 0.25)) < 1e-2 and p[1, 1] < h - 5.0                       # the box rests, the cylinder fell through
+    con = w.contacts()
+    assert len(con) >= 4 and (con["collider_a"] == con["collider_a"][0]).all()
+    assert np.allclose(con["normal"], (0, -1, 0), atol=5e-3)
+    assert w.counts()["num_collisions"] == 1
+
+
+def test_heightmap_scene_both_orders_agree(oracle_mod):
+    """The terrain scene in the reference order and in the canonical (device) order: same contacts at the first touching step
+    (the narrow phase does not depend on the solve order), both stay on the terrain."""
+    sc = scenes.terrain_field(5, 1, 5)
+    a = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_REFERENCE)); b = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    for i in range(200):
+        a.step_fixed(s, sc.dt, 1); b.step_fixed(s, sc.dt, 1)
+        if a.counts()["num_contacts"]:
+            break
+    ca, cb = a.contacts(), b.contacts()
+    assert len(ca) and np.sort(ca, order=["collider_a", "point"]).tobytes() == np.sort(cb, order=["collider_a", "point"]).tobytes()
+    a.step_fixed(s, sc.dt, 300); b.step_fixed(s, sc.dt, 300)
+    for w in (a, b):
+        p, _ = w.physics_transforms()
+        on_map = np.arange(2, 25)
+        hts = np.array([w.heightmap_height(float(p[i, 0]), float(p[i, 2])) for i in on_map])
+        assert (p[on_map, 1] > hts - 0.05).all() and p[0, 1] < -5.0 and p[1, 1] < -5.0       # the two off-map bodies keep falling
+        assert p[25, 1] < -5.0 and p[26, 1] < -5.0                                            # cylinder and hull are ignored
