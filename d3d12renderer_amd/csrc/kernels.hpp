@@ -59,6 +59,8 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numEvents;            // collision begin / end events of this step (when events are enabled)
     uint32_t numInterPairs;        // AABB overlaps between a rigid-body collider and a trigger / force-field collider
     uint32_t numInteractions;      // ... of which the boolean overlap test passed (non_collision_interaction records)
+    uint32_t numHmContacts;        // heightmap terrain: contacts of this step (each is a one-contact manifold) ...
+    uint32_t numHmColliders;       // ... and the colliders they belong to (= the reference's collision count for the terrain)
 };
 
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
@@ -780,8 +782,11 @@ __device__ __forceinline__ uint64_t pairPriority(uint32_t a, uint32_t b) {
 // shared a body with kept theirs or vanished), so the Jones-Plassmann rounds only have to colour the NEW manifolds of a
 // step — a few percent of them once a pile has settled.  Stored key = (A << 26 | B) + 1 (0 = empty slot).
 // keyed by collider CREATION indices (world index = nc - 1 - creation index), so the history survives colliders being added
+// The second index of a heightmap contact is virtual (kHeightmapVirtualBase + j, above every real collider index): it is its
+// own "creation index".
+constexpr uint32_t kHeightmapVirtualBase = (1u << kIndexBits) - 256u;
 __device__ __forceinline__ uint64_t historyKey(uint32_t nc, uint32_t worldA, uint32_t worldB) {
-    return (((uint64_t)(nc - 1u - worldA) << kIndexBits) | (uint64_t)(nc - 1u - worldB)) + 1ull;
+    return (((uint64_t)(nc - 1u - worldA) << kIndexBits) | (uint64_t)(worldB >= kHeightmapVirtualBase ? worldB : nc - 1u - worldB)) + 1ull;
 }
 __device__ __forceinline__ uint32_t tableSlot(uint64_t key, uint32_t mask) {
     uint64_t x = key * 0x9E3779B97F4A7C15ull;
@@ -852,7 +857,8 @@ __global__ __launch_bounds__(256) void k_events_end(uint32_t cap, StepScalars* s
                                                     DeviceEvent* __restrict__ events) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long key = s <= prevMask ? prevKeys[s] : 0ull;
-    bool want = key != 0ull && tableLookup(curKeys, curVals, curMask, key) == kUncolored;
+    bool want = key != 0ull && ((key - 1ull) & ((1ull << kIndexBits) - 1ull)) < kHeightmapVirtualBase   // heightmap contacts raise no events
+                && tableLookup(curKeys, curVals, curMask, key) == kUncolored;
     uint32_t slot = waveAppendSlot(want, &sc->numEvents);
     if (!want) return;
     if (slot >= cap) { sc->specOverflow = 1u; return; }
@@ -870,7 +876,8 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
                                                         uint32_t* __restrict__ manPair, uint2* __restrict__ manBodies, uint2* __restrict__ manInfo,
                                                         uint4* __restrict__ colWork, uint32_t* __restrict__ color,
                                                         const unsigned long long* __restrict__ prevKeys, const uint32_t* __restrict__ prevVals, uint32_t prevMask,
-                                                        unsigned long long* __restrict__ bodyUsed, uint8_t* __restrict__ isNew, StepScalars* sc) {
+                                                        unsigned long long* __restrict__ bodyUsed, uint8_t* __restrict__ isNew, StepScalars* sc,
+                                                        float2 terrainMaterial /* (restitution, friction) of the heightmap */) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t numPairs = sc->numPairs;
     if (p >= numPairs) return;
@@ -882,11 +889,12 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
     if (!cnt) return;
     uint64_t key = pairKeys[p];
     uint32_t a = (uint32_t)((key >> 29) & 0x1FFFFFFFu), b = (uint32_t)(key & 0x1FFFFFFFu);
-    float4 ma = cMaterial[a], mb = cMaterial[b];   // (restitution, friction, density, -)
+    const bool terrain = b >= kHeightmapVirtualBase;   // heightmap contact: body B = the static dummy, material of the heightmap
+    float4 ma = cMaterial[a], mb = terrain ? make_float4(terrainMaterial.x, terrainMaterial.y, 0.f, 0.f) : cMaterial[b];   // (restitution, friction, density, -)
     float friction = clamp01(sqrtf(ma.y * mb.y));                      // collision_narrow.cpp:2232-2238
     float restitution = clamp01(fmaxr(ma.x, mb.x));
     uint32_t fr = ((uint32_t)(friction * 0xFFFF) << 16) | (uint32_t)(restitution * 0xFFFF);
-    uint32_t bA = __float_as_uint(aabbMax[a].w), bB = __float_as_uint(aabbMax[b].w);
+    uint32_t bA = __float_as_uint(aabbMax[a].w), bB = terrain ? nb : __float_as_uint(aabbMax[b].w);
     manPair[m] = p;
     manBodies[m] = make_uint2(bA, bB);
     manInfo[m] = make_uint2(cnt | (conOff << 3), fr);
@@ -896,7 +904,7 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
     colWork[m] = make_uint4(bA | dynA, bB | dynB, (uint32_t)prio, (uint32_t)(prio >> 32));
     // a manifold of the previous step keeps its colour (colour 64 = overflow is re-coloured)
     uint32_t c = prevKeys ? tableLookup(prevKeys, prevVals, prevMask, historyKey(nc, a, b)) : kUncolored;
-    if (isNew) isNew[m] = c == kUncolored ? 1u : 0u;   // not in the previous step's collision list: collision-begin event
+    if (isNew) isNew[m] = (c == kUncolored && !terrain) ? 1u : 0u;   // not in the previous step's collision list: collision-begin event
     if (c < kOverflowColor) {
         if (dynA) atomicOr(&bodyUsed[bA], 1ull << c);
         if (dynB) atomicOr(&bodyUsed[bB], 1ull << c);

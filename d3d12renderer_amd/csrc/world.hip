@@ -20,6 +20,7 @@
 #include "kernels.hpp"
 #include "gjk.hpp"
 #include "joints.hpp"
+#include "heightmap.hpp"
 
 using namespace mi;
 
@@ -115,6 +116,18 @@ struct mi_world {
     DBuf<uint32_t> cObject; DBuf<float4> localForce, bForceStep; DBuf<uint64_t> interKeys; DBuf<DeviceInteraction> interList; DBuf<uint2> fieldList;
     std::vector<uint64_t> prevTriggerOverlaps, nextTriggerOverlaps;
     int interactions(std::vector<mi_event>& triggerEvents);
+    // heightmap terrain: host copy of the chunks (heights + min/max mips), device pool, per-collider contact counts
+    struct HHeightmap {
+        uint32_t chunksPerDim; float chunkSize, restitution, friction; V3 minCorner; float amplitudeScale = 1.f;
+        std::vector<std::vector<uint16_t>> heights;    // per chunk: empty or 129 * 129
+        bool dirty = true;
+    };
+    HHeightmap* heightmap = nullptr;
+    HeightmapParams hmParams{};
+    std::vector<uint16_t> hmHostHeights; std::vector<uint32_t> hmHostSlots;   // host mirror of the device pool (mi_heightmap_get_height)
+    DBuf<uint16_t> hmHeights; DBuf<uint32_t> hmMips, hmChunkSlot, hmCount;
+    uint32_t manifoldsLast = 0;   // device manifolds of the last step (heightmap contacts are one-contact manifolds; counts.num_collisions is per collider)
+    int uploadHeightmap();
     bool eventsEnabled = false; DBuf<uint8_t> manIsNew; DBuf<DeviceEvent> devEvents; std::vector<mi_event> pendingEvents;
     DBuf<float4> rows, slotNormal; DBuf<float4> imp; DBuf<float2> slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc;
     bool usedFlow = false;
@@ -184,6 +197,7 @@ mi_world::~mi_world() {
     if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
     for (auto& e : profEvents) (void)hipEventDestroy(e);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    delete heightmap;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -384,8 +398,57 @@ int mi_world::upload() {
 #undef UP
     int rc = joints.upload(*this, stream);
     if (rc != MI_OK) return rc;
+    if (heightmap) { HIP_TRY(hmCount.ensure(nc + 1)); rc = uploadHeightmap(); if (rc != MI_OK) return rc; }
     HIP_TRY(hipStreamSynchronize(stream));
     topologyDirty = false; hostStale = false;
+    return MI_OK;
+}
+
+// heightmap_collider_chunk::setHeights (heightmap_collider.cpp:42-114): the min/max pyramid of every chunk that has heights,
+// built on the host at upload time (setup cost, not per step) and pooled on the device next to the heights.
+int mi_world::uploadHeightmap() {
+    HHeightmap& h = *heightmap;
+    const uint32_t nchunks = h.chunksPerDim * h.chunksPerDim;
+    if (h.dirty) {
+        hmHostSlots.assign(nchunks, 0xFFFFFFFFu);
+        uint32_t used = 0;
+        for (uint32_t c = 0; c < nchunks; ++c) if (!h.heights[c].empty()) hmHostSlots[c] = used++;
+        hmHostHeights.assign((size_t)std::max(used, 1u) * kHmVerts * kHmVerts, 0);
+        std::vector<uint32_t> mips((size_t)std::max(used, 1u) * kHmMipEntries, 0u);
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            if (hmHostSlots[c] == 0xFFFFFFFFu) continue;
+            const uint16_t* src = h.heights[c].data();
+            std::copy(src, src + kHmVerts * kHmVerts, hmHostHeights.begin() + (size_t)hmHostSlots[c] * kHmVerts * kHmVerts);
+            uint32_t* mp = mips.data() + (size_t)hmHostSlots[c] * kHmMipEntries;
+            for (uint32_t z = 0; z < kHmSegs; ++z)
+                for (uint32_t x = 0; x < kHmSegs; ++x) {
+                    uint16_t v[4] = {src[kHmVerts * z + x], src[kHmVerts * (z + 1) + x], src[kHmVerts * z + x + 1], src[kHmVerts * (z + 1) + x + 1]};
+                    mp[z * kHmSegs + x] = (uint32_t)*std::min_element(v, v + 4) | ((uint32_t)*std::max_element(v, v + 4) << 16);
+                }
+            for (uint32_t mip = 1; mip < 8; ++mip) {
+                const uint32_t n = kHmSegs >> mip, rs = n * 2;
+                const uint32_t* rd = mp + hmMipOffset(mip - 1); uint32_t* wr = mp + hmMipOffset(mip);
+                for (uint32_t z = 0; z < n; ++z)
+                    for (uint32_t x = 0; x < n; ++x) {
+                        uint32_t q[4] = {rd[rs * (2 * z) + 2 * x], rd[rs * (2 * z + 1) + 2 * x], rd[rs * (2 * z) + 2 * x + 1], rd[rs * (2 * z + 1) + 2 * x + 1]};
+                        uint32_t mn = 0xFFFFu, mx = 0u;
+                        for (uint32_t k = 0; k < 4; ++k) { mn = std::min(mn, q[k] & 0xFFFFu); mx = std::max(mx, q[k] >> 16); }
+                        wr[z * n + x] = mn | (mx << 16);
+                    }
+            }
+        }
+        HIP_TRY(hmHeights.ensure(hmHostHeights.size())); HIP_TRY(hmMips.ensure(mips.size())); HIP_TRY(hmChunkSlot.ensure(nchunks));
+        HIP_TRY(hipMemcpyAsync(hmHeights.p, hmHostHeights.data(), hmHostHeights.size() * sizeof(uint16_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(hmMips.p, mips.data(), mips.size() * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(hmChunkSlot.p, hmHostSlots.data(), nchunks * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));   // `mips` is a local
+        h.dirty = false;
+    }
+    HeightmapParams& q = hmParams;   // heightmap_collider_component ctor + update (heightmap_collider.cpp:5-19)
+    q.heights = hmHeights.p; q.mips = hmMips.p; q.chunkSlot = hmChunkSlot.p; q.chunksPerDim = h.chunksPerDim;
+    q.chunkSize = h.chunkSize; q.invChunkSize = 1.f / h.chunkSize; q.chunkScale = h.chunkSize / (float)kHmSegs;
+    q.heightScale = h.amplitudeScale / 65535.f; q.invAmplitudeScale = 1.f / h.amplitudeScale;
+    q.minX = h.minCorner.x; q.minY = h.minCorner.y; q.minZ = h.minCorner.z; q.restitution = h.restitution; q.friction = h.friction;
     return MI_OK;
 }
 
@@ -421,7 +484,7 @@ __global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlag
     for (uint32_t i = t; i < kMaxColorRounds + 2u; i += blockDim.x) roundFlags[i] = 0u;
     if (t == 0) {
         sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->solveError = 0;
-        sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0; sc->numEvents = 0; sc->numInterPairs = 0; sc->numInteractions = 0;
+        sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0; sc->numEvents = 0; sc->numInterPairs = 0; sc->numInteractions = 0; sc->numHmContacts = 0; sc->numHmColliders = 0;
         for (int q = 0; q < 16; ++q) sc->boxHitCount[q] = 0;
         for (int a = 0; a < 3; ++a) { sc->boundsMin[a] = 0x7FFFFFFF; sc->boundsMax[a] = (int)0x80000000; }
     }
@@ -533,6 +596,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     if (nc) {
         k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis);
+        if (heightmap)   // terrain contacts per collider and in total (the write pass runs after the collider-pair narrow phase)
+            k_heightmap<false><<<divUp(nc, B), B, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmCount.p, sc, 0u, nullptr, nullptr, nullptr, nullptr, nullptr);
     }
     mark();  // 1
     // ---------------------------------------------------------------------------------------------- broad phase
@@ -565,7 +630,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             if (attempt == 0) k_axis_final<<<1, 256, 0, st>>>(nc, nblk, axisPartials.p, sc);
             if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
             int rc = readScalars(); if (rc != MI_OK) return rc;
-            pairBound = hs.numPairs;
+            pairBound = hs.numPairs + hs.numHmContacts;   // the terrain contacts are appended to the pair list after the narrow phase
             if (pairBound <= cap && hs.numInterPairs <= interKeys.cap) break;
             if (attempt == 2) return fail(MI_ERR_DEVICE, "pair pass did not settle");
             if (pairBound > cap) HIP_TRY(pairKeys.ensure((size_t)pairBound + pairBound / 4));   // overflow: grow and redo the pair pass
@@ -591,6 +656,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         k_narrow<<<narrowBlocks, B, 0, st>>>(pairBound, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p, boxQueue.p);
         k_narrow_clip<<<kBoxQueues * (queueRegion / B), B, 0, st>>>(queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, boxQueue.p, npPacked.p, npNormal.p, npPoints.p);
         if (usesGjk) k_narrow_gjk<<<divUp(pairBound, 64), 64, 0, st>>>(sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
+        if (heightmap)
+            k_heightmap<true><<<divUp(nc, B), B, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmCount.p, sc, pairBound, pairKeys.p, pairKeysS.p, npPacked.p, npNormal.p, npPoints.p);
         size_t tb = 0;
         HIP_TRY(rocprim::exclusive_scan(nullptr, tb, npPacked.p, npScan.p, (uint64_t)0, pairBound, rocprim::plus<uint64_t>(), st));
         if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
@@ -598,7 +665,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         if (eventsEnabled) HIP_TRY(manIsNew.ensure(pairBound));
         k_emit_manifolds<<<divUp(pairBound, B), B, 0, st>>>(nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
-                                                        tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc);
+                                                        tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc,
+                                                        heightmap ? make_float2(hmParams.restitution, hmParams.friction) : make_float2(0.f, 0.f));
     }
     // ---------------------------------------------------------------------------------------------- triggers / force fields
     std::vector<mi_event> triggerEvents;
@@ -802,7 +870,9 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     times.world_colliders = el(0, 1); times.broadphase = el(1, 2); times.narrowphase = el(2, 3); times.integrate_forces = el(3, 4);
     times.schedule = el(4, 5); times.init_constraints = el(5, 6); times.solve = el(6, 7); times.integrate_velocities = el(7, 8); times.total = el(0, 8);
     counts.num_rigid_bodies = nb; counts.num_colliders = nc; counts.num_broadphase_overlaps = nc ? hs.numOverlaps : 0;
-    counts.num_collisions = pairBound ? hs.numManifolds : 0; counts.num_contacts = pairBound ? hs.numContacts : 0;
+    manifoldsLast = pairBound ? hs.numManifolds : 0;
+    counts.num_collisions = manifoldsLast - (manifoldsLast ? hs.numHmContacts - hs.numHmColliders : 0u);   // terrain: one collision per collider (heightmap_collision.cpp:582-594)
+    counts.num_contacts = pairBound ? hs.numContacts : 0;
     counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur; counts.reserved = solveLaunches;
     { float* a = &timesSum.world_colliders; const float* b = &times.world_colliders; for (int i = 0; i < 9; ++i) a[i] += b[i]; ++timesSteps;
       contactUpdatesSum += (uint64_t)counts.num_contacts * iters; }
@@ -1012,6 +1082,39 @@ MI_API int mi_entities_create(mi_world* w, uint32_t count, const mi_entity_desc*
     return MI_OK;
 }
 MI_API int mi_entity_create(mi_world* w, const mi_entity_desc* d, uint32_t* out) { return mi_entities_create(w, 1, d, out); }
+// ---- heightmap terrain (heightmap_collider_component, src/terrain/heightmap_collider.h:126-151)
+MI_API int mi_heightmap_create(mi_world* w, uint32_t chunksPerDim, float chunkSize, float restitution, float friction) {
+    if (!w || !chunksPerDim || !(chunkSize > 0.f)) return fail(MI_ERR_INVALID_ARGUMENT, "bad heightmap parameters");
+    if (w->heightmap) return fail(MI_ERR_INVALID_ARGUMENT, "a world holds one heightmap");
+    if (w->colliders.size() >= kHeightmapVirtualBase) return fail(MI_ERR_CAPACITY, "collider index space");
+    w->heightmap = new mi_world::HHeightmap();
+    w->heightmap->chunksPerDim = chunksPerDim; w->heightmap->chunkSize = chunkSize; w->heightmap->restitution = restitution; w->heightmap->friction = friction;
+    w->heightmap->heights.resize((size_t)chunksPerDim * chunksPerDim);
+    w->topologyDirty = true;
+    return MI_OK;
+}
+MI_API int mi_heightmap_set_chunk_heights(mi_world* w, uint32_t x, uint32_t z, const uint16_t* heights) {
+    if (!w || !w->heightmap || !heights) return fail(MI_ERR_INVALID_ARGUMENT, "no heightmap / null heights");
+    if (x >= w->heightmap->chunksPerDim || z >= w->heightmap->chunksPerDim) return fail(MI_ERR_INVALID_ARGUMENT, "chunk out of range");
+    w->heightmap->heights[(size_t)z * w->heightmap->chunksPerDim + x].assign(heights, heights + kHmVerts * kHmVerts);
+    w->heightmap->dirty = true; w->topologyDirty = true;
+    return MI_OK;
+}
+MI_API int mi_heightmap_update(mi_world* w, const float* minCorner, float amplitudeScale) {
+    if (!w || !w->heightmap || !minCorner) return fail(MI_ERR_INVALID_ARGUMENT, "no heightmap / null corner");
+    w->heightmap->minCorner = V3(minCorner[0], minCorner[1], minCorner[2]); w->heightmap->amplitudeScale = amplitudeScale;
+    w->topologyDirty = true;
+    return MI_OK;
+}
+MI_API int mi_heightmap_get_height(mi_world* w, float x, float z, float* out) {
+    if (!w || !w->heightmap || !out) return fail(MI_ERR_INVALID_ARGUMENT, "no heightmap / null out");
+    HIP_TRY(hipSetDevice(w->device));
+    int rc = w->uploadHeightmap(); if (rc != MI_OK) return rc;   // refreshes the host mirror + parameters if needed
+    HeightmapParams q = w->hmParams;
+    q.heights = w->hmHostHeights.data(); q.chunkSlot = w->hmHostSlots.data(); q.mips = nullptr;
+    *out = hmHeightAt(q, x, z);
+    return MI_OK;
+}
 MI_API int mi_entity_set_force(mi_world* w, uint32_t entity, const float* force) {   // force_field_component::force (physics.h:35-38)
     if (!w || !force) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
     if (entity >= w->entities.size() || w->entities[entity].kind != MI_ENTITY_FORCE_FIELD) return fail(MI_ERR_INVALID_ARGUMENT, "not a force-field entity");
@@ -1223,7 +1326,7 @@ MI_API int mi_world_get_stage_times(mi_world* w, mi_stage_times* out) { if (!w |
 
 MI_API int mi_world_get_contacts(mi_world* w, mi_contact* out, uint32_t cap, uint32_t* count) {
     if (!w || !count) return fail(MI_ERR_INVALID_ARGUMENT, "null");
-    uint32_t nm = w->counts.num_collisions, nc = w->counts.num_contacts;
+    uint32_t nm = w->manifoldsLast, nc = w->counts.num_contacts;
     *count = nc;
     if (!out) return MI_OK;
     if (cap < nc) return fail(MI_ERR_CAPACITY, "capacity < num contacts");
@@ -1251,6 +1354,7 @@ MI_API int mi_world_get_contacts(mi_world* w, mi_contact* out, uint32_t cap, uin
             o.normal[0] = nrm[p].x; o.normal[1] = nrm[p].y; o.normal[2] = nrm[p].z;
             o.friction_restitution = mi_[m].y;
             o.collider_a = (uint32_t)((keys[p] >> 29) & 0x1FFFFFFFu); o.collider_b = (uint32_t)(keys[p] & 0x1FFFFFFFu);
+            if (o.collider_b >= kHeightmapVirtualBase) o.collider_b = 0xFFFFFFFFu;   // terrain contact
             o.body_a = mb[m].x; o.body_b = mb[m].y;
         }
     }
@@ -1318,7 +1422,7 @@ MI_API int mi_world_get_aabbs(mi_world* w, float* out6, uint32_t cap) {
 }
 MI_API int mi_world_get_manifold_colors(mi_world* w, uint32_t* out, uint32_t cap) {
     if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null");
-    uint32_t nm = w->counts.num_collisions;
+    uint32_t nm = w->manifoldsLast;
     if (cap < nm) return fail(MI_ERR_CAPACITY, "capacity < num manifolds");
     if (!nm) return MI_OK;
     // same manifold order as mi_world_get_contacts: ascending (bucket, colliderA, colliderB)

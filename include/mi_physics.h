@@ -199,6 +199,23 @@ MI_API int mi_constraint_create_from_global(mi_world* world, uint32_t type, uint
  * (handleNonCollisionInteractions, physics.cpp:952-970); without colliders it is global and acts on every rigid body. */
 MI_API int mi_entity_set_force(mi_world* world, uint32_t entity, const float* force3);
 
+/*
+ * Heightmap terrain — heightmap_collider_component (src/terrain/heightmap_collider.h:126-151), collided by heightmapCollision
+ * (src/physics/heightmap_collision.cpp:509-618) right after the narrow phase, into the same contact arrays.  One per world.
+ *   mi_heightmap_create            = heightmap_collider_component(chunksPerDim, chunkSize, material)
+ *   mi_heightmap_set_chunk_heights = collider(x, z).setHeights(heights): 129 x 129 uint16, row-major [z][x]
+ *                                    (TERRAIN_LOD_0_VERTICES_PER_DIMENSION); chunks without heights collide with nothing
+ *   mi_heightmap_update            = update(minCorner, amplitudeScale): height = minCorner.y + h / 65535 * amplitudeScale
+ *   mi_heightmap_get_height        = getHeightAt(coord): bilinear height, -FLT_MAX outside
+ * Sphere, capsule, AABB and OBB colliders of rigid bodies collide with the terrain triangles (one contact per touched
+ * triangle plus the lowest-point contact, at most 255 per collider); cylinders and hulls do not (the reference reads an
+ * uninitialised point for them).  mi_contact::collider_b of a terrain contact is 0xFFFFFFFF and its body_b is the static dummy.
+ */
+MI_API int mi_heightmap_create(mi_world* world, uint32_t chunks_per_dim, float chunk_size, float restitution, float friction);
+MI_API int mi_heightmap_set_chunk_heights(mi_world* world, uint32_t chunk_x, uint32_t chunk_z, const uint16_t* heights129x129);
+MI_API int mi_heightmap_update(mi_world* world, const float* min_corner3, float amplitude_scale);
+MI_API int mi_heightmap_get_height(mi_world* world, float x, float z, float* out_height);
+
 /* rb.forceAccumulator += f; rb.torqueAccumulator += tau (src/physics/physics.cpp:623-627). */
 MI_API int mi_entity_apply_force(mi_world* world, uint32_t entity, const float* force3, const float* torque3);
 

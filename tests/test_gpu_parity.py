@@ -48,6 +48,7 @@ def test_gpu_matches_golden_bit_exact(mi_lib, name):
     (lambda: scenes.ragdolls(4, 4), 160),
     (lambda: scenes.joint_zoo(copies=3), 200),
     (lambda: scenes.vehicles(3, 2), 160),
+    (lambda: scenes.terrain_field(10, 2, 10), 260),     # heightmap terrain: quadtree walk + triangle tests + lowest-point contacts
 ])
 def test_gpu_vs_oracle_trajectory_and_contacts(mi_lib, oracle_mod, make, steps):
     sc = make()
@@ -154,6 +155,29 @@ def test_gpu_triggers_and_force_fields_match_oracle(mi_lib, oracle_mod):
     g2 = sc.populate(gpu_world(mi_lib)); o2 = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     g2.step_fixed(s, sc.dt, 60); o2.step_fixed(s, sc.dt, 60)
     assert g2.physics_transforms()[0].tobytes() == o2.physics_transforms()[0].tobytes()
+
+
+def test_gpu_heightmap_full_size_properties(mi_lib):
+    """65 536 mixed bodies on a 4 x 4-chunk heightmap (too slow for the oracle): deterministic across runs, finite state,
+    nothing ends up under the terrain surface, and the steps after the first run speculatively."""
+    sc = scenes.terrain_field(128, 4, 128, spacing=1.1, with_unsupported=False)
+    sc.heightmap = scenes.rolling_heightmap(chunks_per_dim=4, chunk_size=40.0, amplitude=8.0)
+    res = []
+    for _ in range(2):
+        w = sc.populate(gpu_world(mi_lib))
+        w.step_fixed(sc.settings(), sc.dt, 120)
+        p, q = w.physics_transforms()
+        res.append((p.tobytes(), q.tobytes(), w.counts()))
+    assert res[0] == res[1]
+    assert np.isfinite(p).all() and np.isfinite(q).all()
+    c = w.counts()
+    assert c["num_contacts"] > c["num_collisions"] > 10000
+    on_map = (np.abs(p[:, 0]) < 79.0) & (np.abs(p[:, 2]) < 79.0)
+    idx = np.flatnonzero(on_map)[::97]
+    h = np.array([w.heightmap_height(float(p[i, 0]), float(p[i, 2])) for i in idx])
+    assert (p[idx, 1] > h - 0.3).all()
+    total, spec, retries = w.step_mode_stats()
+    assert spec >= total - 1 - retries and retries <= 20   # everything lands within a few steps: the contact count jumps past the speculative bounds
 
 
 def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
