@@ -1,14 +1,14 @@
 // heightmap.hpp — heightmap terrain narrow phase on the device.
 //
 // heightmapCollision (src/physics/heightmap_collision.cpp:509-618) over the min/max-mip quadtree of
-// src/terrain/heightmap_collider.h:35-118, 153-207.  One lane per rigid-body collider walks the quadtree of the chunks its
-// (upward-extended) AABB touches and tests the surviving triangles; the triangle order is the reference's stack (LIFO) order,
-// so contact j of a collider is the same contact as in the sequential code.  Every contact becomes a one-contact manifold
+// src/terrain/heightmap_collider.h:35-118, 153-207.  Every rigid-body collider visits the quads of the chunks its
+// (upward-extended) AABB touches and tests the surviving triangles; contacts are numbered in the reference's stack (LIFO)
+// order, so contact j of a collider is the same contact as in the sequential code.  Every contact becomes a one-contact manifold
 // appended to the pair list AFTER the collider-pair narrow phase: key = (bucket 21, collider, kHeightmapVirtualBase + j),
 // body B = the static dummy.  From there on the contacts take the normal path (colouring, constraint init, solver).
 //
-// Two passes over the same walk: k_heightmap<false> counts (per collider and in total, so the host / the speculative bounds
-// can size the buffers), k_heightmap<true> reserves one slot range per workgroup and writes.
+// The usual collider spans a few terrain cells: one wave per collider tests those cells in parallel (k_hm_contacts, see the
+// pipeline comment below); the sequential stack walk remains for colliders with a large cell window.
 //
 // Stated deviations from the reference: cylinder / hull colliders are skipped (the reference reads an uninitialised point
 // for them); float -> uint32 conversions of possibly negative values go through int64 (what x86-64 code does); at most 255
@@ -159,20 +159,18 @@ __device__ inline bool boxVsTriangle(V3 center, V3 radius, V3 a, V3 b, V3 c, Tri
     return true;
 }
 
-// One collider against the terrain.  `sink(j, contact)` receives contact j (j < 255) in the reference's order; returns the count.
-template <typename Sink>
-__device__ inline uint32_t heightmapContacts(const HeightmapParams& hm, const Shape& s, V3 vmin, V3 vmax, const Sink& sink) {
-    uint32_t found = 0;
-    const V3 corner(hm.minX, hm.minY, hm.minZ);
-    // per-shape constants of the triangle tests
-    const V3 boxCenter = s.type == T_AABB ? (s.a + s.b) * 0.5f : V3();
-    const V3 boxRadius = s.type == T_AABB ? (s.b - s.a) * 0.5f : s.b;
-    const Q4 inv = conj(s.rot);
-    const V3 capDir = s.type == T_CAPSULE ? normalize(s.b - s.a) : V3();
-    auto triangle = [&](V3 a, V3 b, V3 c) {
-        TriContact t; bool hit;
-        if (s.type == T_SPHERE) hit = sphereVsTriangle(s.a, s.radius, a, b, c, t);
-        else if (s.type == T_CAPSULE) {   // heightmap_collision.cpp:445-471
+// The triangle test of one collider shape (the four `intersection` overloads, heightmap_collision.cpp:431-507).
+struct TriShape {
+    Shape s; V3 boxCenter, boxRadius, capDir; Q4 inv;
+    __device__ explicit TriShape(const Shape& sh) : s(sh) {
+        boxCenter = s.type == T_AABB ? (s.a + s.b) * 0.5f : V3();
+        boxRadius = s.type == T_AABB ? (s.b - s.a) * 0.5f : s.b;
+        inv = conj(s.rot);
+        capDir = s.type == T_CAPSULE ? normalize(s.b - s.a) : V3();
+    }
+    __device__ bool test(V3 a, V3 b, V3 c, TriContact& t) const {
+        if (s.type == T_SPHERE) return sphereVsTriangle(s.a, s.radius, a, b, c, t);
+        if (s.type == T_CAPSULE) {   // heightmap_collision.cpp:445-471
             V3 triNormal = normalize(cross(b - a, c - a));
             float d = -dot(triNormal, a);
             float ndotd = dot(capDir, triNormal);
@@ -180,35 +178,74 @@ __device__ inline uint32_t heightmapContacts(const HeightmapParams& hm, const Sh
             V3 trace = s.a + tt * capDir;
             V3 closest = closestOnTriangle(trace, a, b, c);
             V3 reference = closestOnSegment(closest, s.a, s.b);
-            hit = sphereVsTriangle(reference, s.radius, a, b, c, t);
-        } else if (s.type == T_AABB) hit = boxVsTriangle(boxCenter, boxRadius, a, b, c, t);
-        else {                            // OBB: triangle into the box frame, contact back (heightmap_collision.cpp:492-507)
-            hit = boxVsTriangle(V3(), boxRadius, rotate(inv, a - s.a), rotate(inv, b - s.a), rotate(inv, c - s.a), t);
-            if (hit) { t.normal = rotate(s.rot, t.normal); t.point = rotate(s.rot, t.point) + s.a; }
+            return sphereVsTriangle(reference, s.radius, a, b, c, t);
         }
-        if (hit && found < kHmMaxContacts) { sink(found, t); ++found; }
+        // boxes: an OBB takes the triangle into its frame and the contact back (heightmap_collision.cpp:473-507)
+        const bool obb = s.type == T_OBB;
+        if (obb) { a = rotate(inv, a - s.a); b = rotate(inv, b - s.a); c = rotate(inv, c - s.a); }
+        bool hit = boxVsTriangle(boxCenter, boxRadius, a, b, c, t);
+        if (hit && obb) { t.normal = rotate(s.rot, t.normal); t.point = rotate(s.rot, t.point) + s.a; }
+        return hit;
+    }
+};
+
+// heightmap_collider_component::iterateTrianglesInVolume, outer level (heightmap_collider.h:153-205): the chunk range and,
+// per chunk, the cell window [volMinX, volMaxX] x [volMinZ, volMaxZ] and the uint16 height window.
+struct HmVolume {
+    V3 vmin, vmax, corner;
+    uint32_t minCX, minCZ, maxCX, maxCZ, volMinY, volMaxY;
+    __device__ HmVolume(const HeightmapParams& hm, V3 mn, V3 mx) : corner(hm.minX, hm.minY, hm.minZ) {
+        vmin = mn - corner; vmax = mx - corner;
+        vmin.x *= hm.invChunkSize; vmin.z *= hm.invChunkSize; vmax.x *= hm.invChunkSize; vmax.z *= hm.invChunkSize;
+        const int cpd = (int)hm.chunksPerDim;
+        minCX = (uint32_t)max((int)vmin.x, 0); minCZ = (uint32_t)max((int)vmin.z, 0);
+        maxCX = (uint32_t)min(max((int)vmax.x, 0), cpd - 1); maxCZ = (uint32_t)min(max((int)vmax.z, 0), cpd - 1);
+        vmin.y *= hm.invAmplitudeScale; vmax.y *= hm.invAmplitudeScale;
+        volMinY = hmToU32(clamp01(vmin.y) * 65535.f) & 0xFFFFu; volMaxY = hmToU32(clamp01(vmax.y) * 65535.f) & 0xFFFFu;
+    }
+    __device__ void window(uint32_t x, uint32_t z, uint32_t& x0, uint32_t& z0, uint32_t& x1, uint32_t& z1) const {
+        const float relMinX = fmaxr(vmin.x - (float)x, 0.f), relMinZ = fmaxr(vmin.z - (float)z, 0.f);
+        const float relMaxX = (vmax.x > (float)(x + 1u)) ? 1.f : hmFrac(vmax.x), relMaxZ = (vmax.z > (float)(z + 1u)) ? 1.f : hmFrac(vmax.z);
+        x0 = hmToU32(relMinX * (float)kHmVerts); z0 = hmToU32(relMinZ * (float)kHmVerts);
+        x1 = hmToU32(relMaxX * (float)kHmVerts); z1 = hmToU32(relMaxZ * (float)kHmVerts);
+    }
+};
+__device__ __forceinline__ V3 hmVertex(const HeightmapParams& hm, const uint16_t* __restrict__ heights, V3 chunkMin, uint32_t vx, uint32_t vz) {
+    float h = (float)heights[kHmVerts * vz + vx] * hm.heightScale;
+    return V3((float)vx * hm.chunkScale, h, (float)vz * hm.chunkScale) + chunkMin;
+}
+// the collider's lowest point under the bilinear surface (heightmap_collision.cpp:572-580)
+__device__ inline bool hmLowestPoint(const HeightmapParams& hm, const Shape& s, TriContact& t) {
+    HullSet none{nullptr, nullptr};
+    V3 lowest = supportOf(s, none, V3(0.f, -1.f, 0.f));
+    float h = hmHeightAt(hm, lowest.x, lowest.z);
+    if (!(lowest.y < h)) return false;
+    t.point = lowest; t.normal = V3(0.f, -1.f, 0.f); t.depth = h - lowest.y;
+    return true;
+}
+
+// One collider against the terrain, sequentially (the reference's stack walk, heightmap_collider.h:35-118).
+// `sink(j, contact)` receives contact j (j < 255) in the reference's order; returns the count.  The general path: used for
+// colliders whose cell window is too large for the wave-parallel kernel below.
+template <typename Sink>
+__device__ inline uint32_t heightmapContacts(const HeightmapParams& hm, const Shape& s, V3 mn, V3 mx, const Sink& sink) {
+    uint32_t found = 0;
+    const TriShape ts(s);
+    const HmVolume vol(hm, mn, mx);
+    auto triangle = [&](V3 a, V3 b, V3 c) {
+        TriContact t;
+        if (ts.test(a, b, c, t) && found < kHmMaxContacts) { sink(found, t); ++found; }
     };
-    // heightmap_collider_component::iterateTrianglesInVolume — heightmap_collider.h:153-205
-    vmin = vmin - corner; vmax = vmax - corner;
-    vmin.x *= hm.invChunkSize; vmin.z *= hm.invChunkSize; vmax.x *= hm.invChunkSize; vmax.z *= hm.invChunkSize;
-    const int cpd = (int)hm.chunksPerDim;
-    const uint32_t minCX = (uint32_t)max((int)vmin.x, 0), minCZ = (uint32_t)max((int)vmin.z, 0);
-    const uint32_t maxCX = (uint32_t)min(max((int)vmax.x, 0), cpd - 1), maxCZ = (uint32_t)min(max((int)vmax.z, 0), cpd - 1);
-    vmin.y *= hm.invAmplitudeScale; vmax.y *= hm.invAmplitudeScale;
-    const uint32_t volMinY = hmToU32(clamp01(vmin.y) * 65535.f) & 0xFFFFu, volMaxY = hmToU32(clamp01(vmax.y) * 65535.f) & 0xFFFFu;
-    for (uint32_t z = minCZ; z <= maxCZ; ++z)
-        for (uint32_t x = minCX; x <= maxCX; ++x) {
+    for (uint32_t z = vol.minCZ; z <= vol.maxCZ; ++z)
+        for (uint32_t x = vol.minCX; x <= vol.maxCX; ++x) {
             const uint32_t slot = hm.chunkSlot[z * hm.chunksPerDim + x];
             if (slot == 0xFFFFFFFFu) continue;
-            const float relMinX = fmaxr(vmin.x - (float)x, 0.f), relMinZ = fmaxr(vmin.z - (float)z, 0.f);
-            const float relMaxX = (vmax.x > (float)(x + 1u)) ? 1.f : hmFrac(vmax.x), relMaxZ = (vmax.z > (float)(z + 1u)) ? 1.f : hmFrac(vmax.z);
-            const uint32_t volMinX = hmToU32(relMinX * (float)kHmVerts), volMinZ = hmToU32(relMinZ * (float)kHmVerts);
-            const uint32_t volMaxX = hmToU32(relMaxX * (float)kHmVerts), volMaxZ = hmToU32(relMaxZ * (float)kHmVerts);
-            const V3 chunkMin = V3((float)x * hm.chunkSize, 0.f, (float)z * hm.chunkSize) + corner;
+            uint32_t volMinX, volMinZ, volMaxX, volMaxZ;
+            vol.window(x, z, volMinX, volMinZ, volMaxX, volMaxZ);
+            const V3 chunkMin = V3((float)x * hm.chunkSize, 0.f, (float)z * hm.chunkSize) + vol.corner;
             const uint16_t* __restrict__ heights = hm.heights + (size_t)slot * kHmVerts * kHmVerts;
             const uint32_t* __restrict__ mips = hm.mips + (size_t)slot * kHmMipEntries;
-            // heightmap_collider_chunk::iterateTrianglesInVolume — heightmap_collider.h:35-118.  Node = mip << 16 | x << 8 | z.
-            uint32_t stack[28]; uint32_t top = 0;
+            uint32_t stack[28]; uint32_t top = 0;   // node = mip << 16 | x << 8 | z
             stack[top++] = 7u << 16;
             while (top) {
                 const uint32_t e = stack[--top];
@@ -217,13 +254,10 @@ __device__ inline uint32_t heightmapContacts(const HeightmapParams& hm, const Sh
                 if (x1 < volMinX || x0 > volMaxX) continue;
                 if (z1 < volMinZ || z0 > volMaxZ) continue;
                 const uint32_t mm = mips[hmMipOffset(mip) + ez * (kHmSegs >> mip) + ex];
-                if ((mm >> 16) < volMinY || (mm & 0xFFFFu) > volMaxY) continue;
+                if ((mm >> 16) < vol.volMinY || (mm & 0xFFFFu) > vol.volMaxY) continue;
                 if (mip == 0u) {
-                    auto vertex = [&](uint32_t vx, uint32_t vz) {
-                        float h = (float)heights[kHmVerts * vz + vx] * hm.heightScale;
-                        return V3((float)vx * hm.chunkScale, h, (float)vz * hm.chunkScale) + chunkMin;
-                    };
-                    V3 pa = vertex(ex, ez), pb = vertex(ex, ez + 1u), pc = vertex(ex + 1u, ez), pd = vertex(ex + 1u, ez + 1u);
+                    V3 pa = hmVertex(hm, heights, chunkMin, ex, ez), pb = hmVertex(hm, heights, chunkMin, ex, ez + 1u);
+                    V3 pc = hmVertex(hm, heights, chunkMin, ex + 1u, ez), pd = hmVertex(hm, heights, chunkMin, ex + 1u, ez + 1u);
                     triangle(pa, pb, pc);
                     triangle(pc, pb, pd);
                 } else {
@@ -235,72 +269,150 @@ __device__ inline uint32_t heightmapContacts(const HeightmapParams& hm, const Sh
                 }
             }
         }
-    // the collider's lowest point under the bilinear surface (heightmap_collision.cpp:572-580)
-    HullSet none{nullptr, nullptr};
-    V3 lowest = supportOf(s, none, V3(0.f, -1.f, 0.f));
-    float h = hmHeightAt(hm, lowest.x, lowest.z);
-    if (lowest.y < h && found < kHmMaxContacts) { TriContact t; t.point = lowest; t.normal = V3(0.f, -1.f, 0.f); t.depth = h - lowest.y; sink(found, t); ++found; }
+    TriContact t;
+    if (hmLowestPoint(hm, s, t) && found < kHmMaxContacts) { sink(found, t); ++found; }
     return found;
 }
 
-// WRITE = false: hmCount[collider] and the step totals.  WRITE = true: one slot range per workgroup at the end of the pair
-// list (sc->numPairs grows), one-contact manifolds written straight into the narrow-phase output arrays.
-template <bool WRITE>
-__global__ __launch_bounds__(256) void k_heightmap(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
-                                                   const float4* __restrict__ aabbMax, uint32_t* __restrict__ hmCount, StepScalars* sc,
-                                                   uint32_t pairCap, uint64_t* __restrict__ pairsA, uint64_t* __restrict__ pairsB,
-                                                   uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints) {
-    __shared__ uint32_t waveSum[4], blockBase, blockColliders;
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    uint32_t type = 0; bool active = false;
-    float4 mn, mx;
-    if (i < nc) {
-        mn = aabbMin[i]; mx = aabbMax[i];
-        const uint32_t tag = __float_as_uint(mn.w);
-        type = tag & 0xFFu;
-        active = ((tag >> 8) & 0xFFu) == OBJ_RIGID_BODY && (type == T_SPHERE || type == T_CAPSULE || type == T_AABB || type == T_OBB);
-    }
-    uint32_t count = 0;
-    if (WRITE) { if (active) count = hmCount[i]; if (sc->specOverflow) count = 0; }
-    else if (active) {
-        Shape s = loadShape(wShape, i, type);
-        count = heightmapContacts(hm, s, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [](uint32_t, const TriContact&) {});
-        hmCount[i] = count;
-    }
-    // workgroup totals: inclusive wave scan, then one atomic per workgroup
-    uint32_t incl = count;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { uint32_t v = __shfl_up(incl, d); if ((int)lane >= d) incl += v; }
-    if (lane == 63u) waveSum[wave] = incl;
-    unsigned long long touching = __ballot(count != 0u);
-    if (threadIdx.x == 0) blockColliders = 0;
-    __syncthreads();
-    if (lane == 0 && touching) atomicAdd(&blockColliders, (uint32_t)__popcll(touching));
-    uint32_t before = 0, total = 0;
-    for (uint32_t w = 0; w < 4; ++w) { if (w < wave) before += waveSum[w]; total += waveSum[w]; }
-    __syncthreads();
-    if (threadIdx.x == 0 && total) {
-        if (WRITE) {
-            uint32_t base = atomicAdd(&sc->numPairs, total);
-            if (base + total > pairCap) { sc->specOverflow = 1u; base = 0xFFFFFFFFu; }
-            blockBase = base;
-        } else { atomicAdd(&sc->numHmContacts, total); atomicAdd(&sc->numHmColliders, blockColliders); }
-    }
-    if (!WRITE) return;
-    __syncthreads();
-    if (!count || blockBase == 0xFFFFFFFFu) return;
-    const uint32_t first = blockBase + before + (incl - count);
-    uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
-    Shape s = loadShape(wShape, i, type);
-    heightmapContacts(hm, s, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [&](uint32_t j, const TriContact& t) {
-        if (j >= count) return;
+// ---- the device pipeline ------------------------------------------------------------------------------------------------
+// k_hm_contacts<WRITE>  one WAVE per collider, one lane per TRIANGLE of the collider's cell window (<= 64 quads per chunk; the
+//                 usual case: a body spans a few cells).  The stack walk visits exactly the quads that pass their own x/z and
+//                 min/max-height test (an ancestor's box contains the quad's), in DESCENDING Morton order with x as the high
+//                 bit (children are pushed (0,0) (0,1) (1,0) (1,1) and popped in reverse), first triangle before second.  So
+//                 the lanes test their triangles independently and contact j = the number of hit triangles that precede it in
+//                 that order (found by comparing sort keys against the hit lanes only).  Colliders with a larger window are
+//                 flagged for k_hm_slow.  WRITE = false: count per collider.  WRITE = true: the same walk again, contacts
+//                 written straight to their final slots.
+// k_hm_slow<WRITE>      one lane per flagged collider: the sequential walk.
+// (exclusive scan of the packed counts on the stream: contact offsets + colliders touching the terrain)
+// k_hm_totals     StepScalars::numHmContacts / numHmColliders for the host's sizing read-back.
+// k_hm_finish     numPairs += numHmContacts (after the WRITE passes, which address slots relative to the collider pairs).
+// Counting happens with the world colliders (the host sizes the narrow-phase buffers from the totals), writing after the
+// collider-pair narrow phase: slot = numPairs + offset(collider) + j — deterministic positions, no atomics.
+__device__ __forceinline__ uint32_t hmSpread7(uint32_t v) {   // bit i -> bit 2 i (7 bits)
+    v = (v | (v << 4)) & 0x0F0Fu; v = (v | (v << 2)) & 0x3333u; v = (v | (v << 1)) & 0x5555u;
+    return v;
+}
+__device__ __forceinline__ bool hmActive(uint32_t tag, uint32_t& type) {
+    type = tag & 0xFFu;
+    return ((tag >> 8) & 0xFFu) == OBJ_RIGID_BODY && (type == T_SPHERE || type == T_CAPSULE || type == T_AABB || type == T_OBB);
+}
+struct HmOut {   // where the WRITE passes put contact j of collider i
+    StepScalars* sc; uint32_t pairCap; uint64_t* pairsA; uint64_t* pairsB; uint64_t* npPacked; float4* npNormal; float4* npPoints;
+    __device__ bool ready() const { return !sc->specOverflow && sc->numPairs + sc->numHmContacts <= pairCap; }
+    __device__ void put(uint32_t first, uint32_t i, uint32_t j, const TriContact& t) const {
         const uint32_t p = first + j;
-        pairKeys[p] = ((uint64_t)kHmBucket << 58) | ((uint64_t)i << 29) | (uint64_t)(kHeightmapVirtualBase + j);
+        (sc->partitioned ? pairsB : pairsA)[p] = ((uint64_t)kHmBucket << 58) | ((uint64_t)i << 29) | (uint64_t)(kHeightmapVirtualBase + j);
         npPacked[p] = (1ull << 32) | 1ull;
         npNormal[p] = f4(t.normal, 0.f);
         npPoints[4 * (size_t)p] = f4(t.point, t.depth);
-    });
+    }
+};
+
+template <bool WRITE>
+__global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
+                                                     const float4* __restrict__ aabbMax, unsigned long long* __restrict__ hmPacked, uint8_t* __restrict__ hmSlow,
+                                                     const unsigned long long* __restrict__ hmScan, HmOut out) {
+    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (i >= nc) return;
+    const float4 mn = aabbMin[i], mx = aabbMax[i];
+    uint32_t type;
+    const bool active = hmActive(__float_as_uint(mn.w), type);
+    uint32_t count = 0, first = 0;
+    if (WRITE) {
+        count = active ? (uint32_t)hmPacked[i] : 0u;
+        if (!count || hmSlow[i] || !out.ready()) return;
+        first = out.sc->numPairs + (uint32_t)hmScan[i];
+    } else if (!active) { if (lane == 0) { hmPacked[i] = 0ull; hmSlow[i] = 0; } return; }
+    const Shape s = loadShape(wShape, i, type);
+    const TriShape ts(s);
+    const HmVolume vol(hm, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z));
+    uint32_t found = 0; bool slow = false;
+    for (uint32_t z = vol.minCZ; z <= vol.maxCZ && !slow; ++z)
+        for (uint32_t x = vol.minCX; x <= vol.maxCX; ++x) {
+            const uint32_t slot = hm.chunkSlot[z * hm.chunksPerDim + x];
+            if (slot == 0xFFFFFFFFu) continue;
+            uint32_t x0, z0, x1, z1;
+            vol.window(x, z, x0, z0, x1, z1);
+            x1 = min(x1, kHmSegs - 1u); z1 = min(z1, kHmSegs - 1u);
+            if (x0 > x1 || z0 > z1) continue;
+            const uint32_t w = x1 - x0 + 1u, n = w * (z1 - z0 + 1u);
+            if (n > 64u) { slow = true; break; }
+            const V3 chunkMin = V3((float)x * hm.chunkSize, 0.f, (float)z * hm.chunkSize) + vol.corner;
+            const uint16_t* __restrict__ heights = hm.heights + (size_t)slot * kHmVerts * kHmVerts;
+            // item = 2 * quad + triangle, 64 items per batch, at most two batches
+            uint32_t sk[2] = {0u, 0u}; bool hit[2] = {false, false}; TriContact tc[2];
+#pragma unroll
+            for (uint32_t b = 0; b < 2u; ++b) {
+                const uint32_t item = b * 64u + lane;
+                if (b * 64u >= 2u * n) break;          // wave-uniform
+                if (item < 2u * n) {
+                    const uint32_t q = item >> 1, tri = item & 1u, qx = x0 + q % w, qz = z0 + q / w;
+                    sk[b] = (((hmSpread7(qx) << 1) | hmSpread7(qz)) << 1) | (1u - tri);   // descending: larger Morton first, first triangle first
+                    const uint32_t ha = heights[kHmVerts * qz + qx], hb = heights[kHmVerts * (qz + 1u) + qx], hc = heights[kHmVerts * qz + qx + 1u], hd = heights[kHmVerts * (qz + 1u) + qx + 1u];
+                    const uint32_t lo = min(min(ha, hb), min(hc, hd)), hi = max(max(ha, hb), max(hc, hd));
+                    if (!(hi < vol.volMinY || lo > vol.volMaxY)) {
+                        // triangles (A, B, C) and (C, B, D) of the quad (heightmap_collider.h:85-106)
+                        const V3 pb = hmVertex(hm, heights, chunkMin, qx, qz + 1u), pc = hmVertex(hm, heights, chunkMin, qx + 1u, qz);
+                        const V3 pe = tri ? hmVertex(hm, heights, chunkMin, qx + 1u, qz + 1u) : hmVertex(hm, heights, chunkMin, qx, qz);
+                        hit[b] = tri ? ts.test(pc, pb, pe, tc[b]) : ts.test(pe, pb, pc, tc[b]);
+                    }
+                }
+            }
+            const unsigned long long m0 = __ballot(hit[0]), m1 = __ballot(hit[1]);
+            uint32_t before[2] = {0u, 0u};
+            for (unsigned long long m = m0; m; m &= m - 1ull) {
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)sk[0], (int)(__ffsll((long long)m) - 1));
+                before[0] += k > sk[0] ? 1u : 0u; before[1] += k > sk[1] ? 1u : 0u;
+            }
+            for (unsigned long long m = m1; m; m &= m - 1ull) {
+                const uint32_t k = (uint32_t)__builtin_amdgcn_readlane((int)sk[1], (int)(__ffsll((long long)m) - 1));
+                before[0] += k > sk[0] ? 1u : 0u; before[1] += k > sk[1] ? 1u : 0u;
+            }
+            if (WRITE) {
+#pragma unroll
+                for (uint32_t b = 0; b < 2u; ++b) if (hit[b] && found + before[b] < count) out.put(first, i, found + before[b], tc[b]);
+            }
+            found = min(found + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1), kHmMaxContacts);
+        }
+    if (lane != 0) return;
+    if (WRITE) {
+        TriContact t;
+        if (found < count && hmLowestPoint(hm, s, t)) out.put(first, i, found, t);
+        return;
+    }
+    if (slow) { hmPacked[i] = 0ull; hmSlow[i] = 1; return; }
+    TriContact t;
+    if (hmLowestPoint(hm, s, t) && found < kHmMaxContacts) ++found;
+    hmPacked[i] = (unsigned long long)found | (found ? 1ull << 32 : 0ull);
+    hmSlow[i] = 0;
+}
+template <bool WRITE>
+__global__ __launch_bounds__(64) void k_hm_slow(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
+                                                const float4* __restrict__ aabbMax, unsigned long long* __restrict__ hmPacked, const uint8_t* __restrict__ hmSlow,
+                                                const unsigned long long* __restrict__ hmScan, HmOut out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc || !hmSlow[i]) return;
+    const float4 mn = aabbMin[i], mx = aabbMax[i];
+    const Shape s = loadShape(wShape, i, __float_as_uint(mn.w) & 0xFFu);
+    if (WRITE) {
+        const uint32_t count = (uint32_t)hmPacked[i];
+        if (!count || !out.ready()) return;
+        const uint32_t first = out.sc->numPairs + (uint32_t)hmScan[i];
+        heightmapContacts(hm, s, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [&](uint32_t j, const TriContact& t) { if (j < count) out.put(first, i, j, t); });
+    } else {
+        const uint32_t found = heightmapContacts(hm, s, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [](uint32_t, const TriContact&) {});
+        hmPacked[i] = (unsigned long long)found | (found ? 1ull << 32 : 0ull);
+    }
+}
+__global__ void k_hm_totals(uint32_t nc, const unsigned long long* __restrict__ hmPacked, const unsigned long long* __restrict__ hmScan, StepScalars* sc) {
+    const unsigned long long t = nc ? hmScan[nc - 1u] + hmPacked[nc - 1u] : 0ull;
+    sc->numHmContacts = (uint32_t)t; sc->numHmColliders = (uint32_t)(t >> 32);
+}
+__global__ void k_hm_finish(StepScalars* sc, uint32_t pairCap) {
+    if (sc->specOverflow) return;
+    if (sc->numPairs + sc->numHmContacts > pairCap) { sc->specOverflow = 1u; return; }
+    sc->numPairs += sc->numHmContacts;
 }
 
 }  // namespace mi

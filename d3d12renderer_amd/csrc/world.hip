@@ -125,7 +125,8 @@ struct mi_world {
     HHeightmap* heightmap = nullptr;
     HeightmapParams hmParams{};
     std::vector<uint16_t> hmHostHeights; std::vector<uint32_t> hmHostSlots;   // host mirror of the device pool (mi_heightmap_get_height)
-    DBuf<uint16_t> hmHeights; DBuf<uint32_t> hmMips, hmChunkSlot, hmCount;
+    DBuf<uint16_t> hmHeights; DBuf<uint32_t> hmMips, hmChunkSlot;
+    DBuf<unsigned long long> hmPacked, hmScan; DBuf<uint8_t> hmSlow;   // per collider: contacts | touching << 32, its exclusive scan, sequential-walk flag
     uint32_t manifoldsLast = 0;   // device manifolds of the last step (heightmap contacts are one-contact manifolds; counts.num_collisions is per collider)
     int uploadHeightmap();
     bool eventsEnabled = false; DBuf<uint8_t> manIsNew; DBuf<DeviceEvent> devEvents; std::vector<mi_event> pendingEvents;
@@ -398,7 +399,10 @@ int mi_world::upload() {
 #undef UP
     int rc = joints.upload(*this, stream);
     if (rc != MI_OK) return rc;
-    if (heightmap) { HIP_TRY(hmCount.ensure(nc + 1)); rc = uploadHeightmap(); if (rc != MI_OK) return rc; }
+    if (heightmap) {
+        HIP_TRY(hmPacked.ensure(nc + 1)); HIP_TRY(hmScan.ensure(nc + 1)); HIP_TRY(hmSlow.ensure(nc + 1));
+        rc = uploadHeightmap(); if (rc != MI_OK) return rc;
+    }
     HIP_TRY(hipStreamSynchronize(stream));
     topologyDirty = false; hostStale = false;
     return MI_OK;
@@ -596,8 +600,15 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     if (nc) {
         k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis);
-        if (heightmap)   // terrain contacts per collider and in total (the write pass runs after the collider-pair narrow phase)
-            k_heightmap<false><<<divUp(nc, B), B, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmCount.p, sc, 0u, nullptr, nullptr, nullptr, nullptr, nullptr);
+        if (heightmap) {   // terrain contacts per collider, their offsets and totals (they join the pair list after the collider-pair narrow phase)
+            k_hm_contacts<false><<<divUp(nc, 4), 256, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
+            k_hm_slow<false><<<divUp(nc, 64), 64, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
+            size_t tb = 0;
+            HIP_TRY(rocprim::exclusive_scan(nullptr, tb, hmPacked.p, hmScan.p, 0ull, (size_t)nc, rocprim::plus<unsigned long long>(), st));
+            if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
+            HIP_TRY(rocprim::exclusive_scan(temp.p, tb, hmPacked.p, hmScan.p, 0ull, (size_t)nc, rocprim::plus<unsigned long long>(), st));
+            k_hm_totals<<<1, 1, 0, st>>>(nc, hmPacked.p, hmScan.p, sc);
+        }
     }
     mark();  // 1
     // ---------------------------------------------------------------------------------------------- broad phase
@@ -656,8 +667,12 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         k_narrow<<<narrowBlocks, B, 0, st>>>(pairBound, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p, boxQueue.p);
         k_narrow_clip<<<kBoxQueues * (queueRegion / B), B, 0, st>>>(queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, boxQueue.p, npPacked.p, npNormal.p, npPoints.p);
         if (usesGjk) k_narrow_gjk<<<divUp(pairBound, 64), 64, 0, st>>>(sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
-        if (heightmap)
-            k_heightmap<true><<<divUp(nc, B), B, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmCount.p, sc, pairBound, pairKeys.p, pairKeysS.p, npPacked.p, npNormal.p, npPoints.p);
+        if (heightmap) {
+            const HmOut hmOut{sc, pairBound, pairKeys.p, pairKeysS.p, npPacked.p, npNormal.p, npPoints.p};
+            k_hm_contacts<true><<<divUp(nc, 4), 256, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut);
+            k_hm_slow<true><<<divUp(nc, 64), 64, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut);
+            k_hm_finish<<<1, 1, 0, st>>>(sc, pairBound);
+        }
         size_t tb = 0;
         HIP_TRY(rocprim::exclusive_scan(nullptr, tb, npPacked.p, npScan.p, (uint64_t)0, pairBound, rocprim::plus<uint64_t>(), st));
         if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");

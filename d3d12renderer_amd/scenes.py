@@ -759,5 +759,12 @@ def terrain_field(nx=10, ny=2, nz=10, seed=9, solver_iterations=20, spacing=1.6,
     return Scene(f"terrain_field_{n}", e, ents, c, solver_iterations, hulls=hulls, heightmap=rolling_heightmap(seed=seed))
 
 
+def terrain_big(nx=128, ny=4, nz=128):
+    """65 536 mixed bodies on a 4 x 4-chunk (160 m) heightmap: the full-size terrain case."""
+    sc = terrain_field(nx, ny, nz, spacing=1.1, with_unsupported=False)
+    sc.heightmap = rolling_heightmap(chunks_per_dim=4, chunk_size=40.0, amplitude=8.0)
+    return sc
+
+
 def by_name(name, **kw):
     return {"cfg1": sphere_drop, "cfg2": mixed_stack, "cfg3": obb_pile, "cfg4": ragdolls, "cfg5": vehicles, "zoo": shape_zoo}[name](**kw)

@@ -160,8 +160,7 @@ def test_gpu_triggers_and_force_fields_match_oracle(mi_lib, oracle_mod):
 def test_gpu_heightmap_full_size_properties(mi_lib):
     """65 536 mixed bodies on a 4 x 4-chunk heightmap (too slow for the oracle): deterministic across runs, finite state,
     nothing ends up under the terrain surface, and the steps after the first run speculatively."""
-    sc = scenes.terrain_field(128, 4, 128, spacing=1.1, with_unsupported=False)
-    sc.heightmap = scenes.rolling_heightmap(chunks_per_dim=4, chunk_size=40.0, amplitude=8.0)
+    sc = scenes.terrain_big()
     res = []
     for _ in range(2):
         w = sc.populate(gpu_world(mi_lib))

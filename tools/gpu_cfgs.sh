@@ -10,7 +10,8 @@ import d3d12renderer_amd as mi
 from d3d12renderer_amd import scenes
 out = {}
 for name, make, warm, steps in (("cfg1_spheres_4096", lambda: scenes.sphere_drop(16), 240, 60), ("cfg2_mixed_65536", lambda: scenes.mixed_stack(64, 16, 64), 240, 60),
-                                ("cfg4_ragdolls_1024", lambda: scenes.ragdolls(32, 32), 240, 60), ("cfg5_vehicles_256", lambda: scenes.vehicles(16, 16), 240, 60)):
+                                ("cfg4_ragdolls_1024", lambda: scenes.ragdolls(32, 32), 240, 60), ("cfg5_vehicles_256", lambda: scenes.vehicles(16, 16), 240, 60),
+                                ("terrain_65536", lambda: scenes.terrain_big(), 300, 60), ("zones_6912", lambda: scenes.zones(48, 3, 48), 200, 60)):
     sc = make()
     w = sc.populate(mi.create_world(0))
     s = sc.settings()
@@ -25,4 +26,4 @@ for name, make, warm, steps in (("cfg1_spheres_4096", lambda: scenes.sphere_drop
     print(name, json.dumps(out[name]), flush=True)
 json.dump(out, open("gpurun_out/cfgs.json", "w"), indent=1)
 PY
-timeout 900 python /tmp/cfgs.py 2>&1 | tail -6
+timeout 900 python /tmp/cfgs.py 2>&1 | tail -8
