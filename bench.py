@@ -119,9 +119,9 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
+    torch.cuda.set_device(local_rank)   # torch's HIP runtime comes up before the library touches the device
     if world_size > 1:
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
     if world_size != args.gpus:
         if rank == 0:

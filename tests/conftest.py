@@ -26,4 +26,10 @@ def mi_lib():
     import d3d12renderer_amd as mi
     from d3d12renderer_amd import build
     build.build()
+    try:   # torch bundles its own HIP runtime: initialise it before the library touches the device (as bench.py does), not in between
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:   # noqa: BLE001 - CPU-only machine
+        pass
     return mi

@@ -3,5 +3,5 @@
 ulimit -c 0
 mkdir -p gpurun_out
 cd oracle && make >/dev/null 2>&1; cd ..
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "heightmap or trajectory" 2>&1 | tail -30 | tee gpurun_out/two.log
-bash tools/gpu_cfgs.sh 2>&1 | tail -3 | cut -c1-900
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "sharded" 2>&1 | tail -120 | tee gpurun_out/two.log
+
