@@ -193,6 +193,28 @@ class World:
         t = np.ascontiguousarray(torque, dtype=np.float32) if torque is not None else None
         self.L.check(self.L.fn("entity_apply_force")(self.h, C.c_uint32(entity), _ptr(f), _ptr(t)), "entity_apply_force")
 
+    def apply_forces(self, entities, forces=None, torques=None):
+        """rb.forceAccumulator += f; rb.torqueAccumulator += tau for many bodies, in order."""
+        e = np.ascontiguousarray(entities, dtype=np.uint32)
+        f = np.ascontiguousarray(forces, dtype=np.float32).reshape(len(e), 3) if forces is not None else None
+        t = np.ascontiguousarray(torques, dtype=np.float32).reshape(len(e), 3) if torques is not None else None
+        self.L.check(self.L.fn("entities_apply_forces")(self.h, C.c_uint32(len(e)), _ptr(e), _ptr(f), _ptr(t)), "entities_apply_forces")
+
+    def test_interactions(self, origins, directions, strengths=None, entity_ranges=None):
+        """testPhysicsInteraction(scene, ray, strength) for several rays (src/physics/physics.cpp:555-629)."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        s = np.ascontiguousarray(strengths, dtype=np.float32) if strengths is not None else None
+        r = np.ascontiguousarray(entity_ranges, dtype=np.uint32).reshape(-1, 2) if entity_ranges is not None else None
+        self.L.check(self.L.fn("world_test_interactions")(self.h, C.c_uint32(len(o)), _ptr(o), _ptr(d), _ptr(s), _ptr(r)), "world_test_interactions")
+
+    def update_constraints(self, ctype, ids, pods):
+        """getConstraint(scene, handle) = ... for many constraints of one type."""
+        i = np.ascontiguousarray(ids, dtype=np.uint32)
+        p = np.ascontiguousarray(pods)
+        assert len(p) == len(i)
+        self.L.check(self.L.fn("constraints_update")(self.h, C.c_uint32(ctype), C.c_uint32(len(i)), _ptr(i), _ptr(p), C.c_uint32(p.dtype.itemsize)), "constraints_update")
+
     def set_force(self, entity, force):
         """force_field_component::force of a FORCE_FIELD entity (entity-local frame)."""
         f = np.ascontiguousarray(force, dtype=np.float32)

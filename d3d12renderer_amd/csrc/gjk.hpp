@@ -280,6 +280,156 @@ __global__ __launch_bounds__(256) void k_apply_fields(uint32_t n, const uint2* _
     bForceStep[me.x] = f4(f, 0.f);
 }
 
+// ---- ray tests (testPhysicsInteraction, src/physics/physics.cpp:555-629; ray::intersect*, bounding_volumes.cpp:197-398, 677-702).
+// Stated deviation: the cylinder test's outT is 0 (not uninitialised) when the origin is inside the infinite cylinder and
+// neither cap is hit.
+__device__ inline bool rayPlane(V3 o, V3 d, V3 normal, float pd, float& t) {
+    float ndotd = dot(d, normal);
+    if (fabsf(ndotd) < 1e-6f) return false;
+    t = -(dot(o, normal) + pd) / ndotd;
+    return true;
+}
+__device__ inline bool rayDisk(V3 o, V3 d, V3 pos, V3 normal, float radius, float& t) {
+    if (!rayPlane(o, d, normal, -dot(normal, pos), t)) return false;
+    return len(o + t * d - pos) <= radius;
+}
+__device__ inline bool raySphere(V3 o, V3 d, V3 center, float radius, float& t) {
+    V3 m = o - center;
+    float b = dot(m, d), c = dot(m, m) - radius * radius;
+    if (c > 0.f && b > 0.f) return false;
+    float discr = b * b - c;
+    if (discr < 0.f) return false;
+    t = -b - sqrtf(discr);
+    if (t < 0.f) t = 0.f;
+    return true;
+}
+__device__ inline bool rayCylinder(V3 o, V3 d, V3 pa, V3 pb, float radius, float& t) {
+    V3 axis = pb - pa;
+    float height = len(axis);
+    Q4 q = rotateFromTo(axis, V3(0.f, 1.f, 0.f));
+    o = rotate(q, o - pa); d = rotate(q, d);
+    const float epsilon = 1e-6f;
+    float y = -1.f;
+    t = 0.f;
+    if (o.x * o.x + o.z * o.z > radius * radius) {
+        float a = d.x * d.x + d.z * d.z, b = d.x * o.x + d.z * o.z, c = o.x * o.x + o.z * o.z - radius * radius;
+        float delta = b * b - a * c;
+        if (delta < epsilon) return false;
+        t = (-b - sqrtf(delta)) / a;
+        if (t <= epsilon) return false;
+        y = o.y + t * d.y;
+    }
+    if (y > height + epsilon || y < -epsilon) {
+        float dist;
+        if (d.y < 0.f && rayDisk(o, d, V3(0.f, height, 0.f), V3(0.f, 1.f, 0.f), radius, dist)) t = dist;
+        if (d.y > 0.f && rayDisk(o, d, V3(0.f, 0.f, 0.f), V3(0.f, -1.f, 0.f), radius, dist)) t = dist;
+        y = o.y + t * d.y;
+    }
+    return y > -epsilon && y < height + epsilon;
+}
+__device__ inline bool rayAABB(V3 o, V3 d, V3 mn, V3 mx, float& t) {
+    V3 inv(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    float tx1 = (mn.x - o.x) * inv.x, tx2 = (mx.x - o.x) * inv.x;
+    t = fminr(tx1, tx2);
+    float tmax = fmaxr(tx1, tx2);
+    float ty1 = (mn.y - o.y) * inv.y, ty2 = (mx.y - o.y) * inv.y;
+    t = fmaxr(t, fminr(ty1, ty2)); tmax = fminr(tmax, fmaxr(ty1, ty2));
+    float tz1 = (mn.z - o.z) * inv.z, tz2 = (mx.z - o.z) * inv.z;
+    t = fmaxr(t, fminr(tz1, tz2)); tmax = fminr(tmax, fmaxr(tz1, tz2));
+    return tmax >= t && t > 0.f;
+}
+__device__ inline bool pointInTriangle(V3 point, V3 a, V3 b, V3 c) {   // math.cpp:1273-1290
+    V3 e10 = b - a, e20 = c - a;
+    float aa = dot(e10, e10), bb = dot(e10, e20), cc = dot(e20, e20);
+    float ac_bb = (aa * cc) - (bb * bb);
+    V3 vp = point - a;
+    float dd = dot(vp, e10), ee = dot(vp, e20);
+    float x = (dd * cc) - (ee * bb), y = (ee * aa) - (dd * bb), z = x + y - ac_bb;
+    return ((__float_as_uint(z) & ~(__float_as_uint(x) | __float_as_uint(y))) & 0x80000000u) != 0u;
+}
+__device__ inline bool rayTriangle(V3 o, V3 d, V3 a, V3 b, V3 c, float& t) {
+    V3 normal = noz(cross(b - a, c - a));
+    float pd = -dot(normal, a);
+    float nDotR = dot(d, normal);
+    if (fabsf(nDotR) <= 1e-6f) return false;
+    t = -(dot(o, normal) + pd) / nDotR;
+    V3 q = o + t * d;
+    return t >= 0.f && pointInTriangle(q, a, b, c);
+}
+struct HullFaces { const float4* verts; const uint32_t* ranges; const uint32_t* tris; const uint32_t* triRanges; };
+// One collider in its entity's local frame; `s0..s2` = the collider_desc shape words.
+__device__ inline bool rayVsCollider(uint32_t type, float4 s0, float4 s1, float4 s2, const HullFaces& hf, V3 o, V3 d, float& t) {
+    switch (type) {
+        case T_SPHERE: return raySphere(o, d, xyz(s0), s0.w, t);
+        case T_CAPSULE: {
+            V3 pa = xyz(s0), pb(s0.w, s1.x, s1.y); float r = s1.z;
+            t = FLT_MAX;
+            float tt; bool result = false;
+            if (rayCylinder(o, d, pa, pb, r, tt)) { t = tt; result = true; }
+            if (raySphere(o, d, pa, r, tt)) { t = fminr(t, tt); result = true; }
+            if (raySphere(o, d, pb, r, tt)) { t = fminr(t, tt); result = true; }
+            return result;
+        }
+        case T_CYLINDER: return rayCylinder(o, d, xyz(s0), V3(s0.w, s1.x, s1.y), s1.z, t);
+        case T_AABB: return rayAABB(o, d, xyz(s0), V3(s0.w, s1.x, s1.y), t);
+        case T_OBB: {
+            Q4 inv = conj(Q4(s0.x, s0.y, s0.z, s0.w)); V3 c(s1.x, s1.y, s1.z), r(s1.w, s2.x, s2.y);
+            return rayAABB(rotate(inv, o - c), rotate(inv, d), V3() - r, V3() + r, t);
+        }
+        default: {
+            Q4 inv = conj(Q4(s0.x, s0.y, s0.z, s0.w)); V3 pos(s1.x, s1.y, s1.z);
+            const uint32_t geom = __float_as_uint(s1.w);
+            V3 lo = rotate(inv, o - pos), ld = rotate(inv, d);
+            const uint32_t v0 = hf.ranges[2 * geom], f0 = hf.triRanges[2 * geom], nf = hf.triRanges[2 * geom + 1];
+            float minT = FLT_MAX; bool result = false;
+            for (uint32_t f = 0; f < nf; ++f) {
+                float tt;
+                V3 a = xyz(hf.verts[v0 + hf.tris[3 * (f0 + f)]]), b = xyz(hf.verts[v0 + hf.tris[3 * (f0 + f) + 1]]), c = xyz(hf.verts[v0 + hf.tris[3 * (f0 + f) + 2]]);
+                if (rayTriangle(lo, ld, a, b, c, tt) && tt < minT) { minT = tt; result = true; }
+            }
+            t = minT;
+            return result;
+        }
+    }
+}
+// One workgroup per ray over all colliders (world index order = the reference's view order; the first collider with the
+// smallest t wins: strict `<`).  Output per ray: body (or ~0u) and (force, torque) for k_add_forces.
+__global__ __launch_bounds__(256) void k_ray_interactions(uint32_t nc, const float* __restrict__ rays /* origin3, direction3, strength, - */, const uint32_t* __restrict__ ranges,
+                                                          const uint32_t* __restrict__ cTypeBody, const uint32_t* __restrict__ cEntity, const float4* __restrict__ cShape,
+                                                          const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bCogInvMass,
+                                                          HullFaces hf, uint32_t* __restrict__ outBody, float* __restrict__ outFT) {
+    __shared__ unsigned long long best[256];
+    const uint32_t r = blockIdx.x;
+    const V3 ro(rays[8 * r], rays[8 * r + 1], rays[8 * r + 2]), rd(rays[8 * r + 3], rays[8 * r + 4], rays[8 * r + 5]);
+    const float strength = rays[8 * r + 6];
+    const uint32_t lo = ranges[2 * r], hi = ranges[2 * r + 1];
+    unsigned long long mine = ~0ull;   // (t bits << 32 | collider): t >= 0, so the bit pattern orders like the value
+    for (uint32_t k = threadIdx.x; k < nc; k += blockDim.x) {
+        const uint32_t body = cTypeBody[2 * k + 1], ent = cEntity[k];
+        if (body == kNoBody || ent < lo || ent >= hi) continue;
+        const Q4 inv = conj(toQ(bRot[body]));
+        float t;
+        if (rayVsCollider(cTypeBody[2 * k], cShape[3 * k], cShape[3 * k + 1], cShape[3 * k + 2], hf, rotate(inv, ro - xyz(bPos[body])), rotate(inv, rd), t) && t < FLT_MAX) {
+            unsigned long long key = ((unsigned long long)__float_as_uint(t + 0.f) << 32) | k;   // -0 -> +0
+            if (key < mine) mine = key;
+        }
+    }
+    best[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t s = 128; s > 0; s >>= 1) { if (threadIdx.x < s && best[threadIdx.x + s] < best[threadIdx.x]) best[threadIdx.x] = best[threadIdx.x + s]; __syncthreads(); }
+    if (threadIdx.x != 0) return;
+    if (best[0] == ~0ull) { outBody[r] = 0xFFFFFFFFu; return; }
+    const uint32_t k = (uint32_t)best[0], body = cTypeBody[2 * k + 1];
+    const float t = __uint_as_float((uint32_t)(best[0] >> 32));
+    const Q4 rot = toQ(bRot[body]); const V3 pos = xyz(bPos[body]);
+    const V3 lo_ = rotate(conj(rot), ro - pos), ld = rotate(conj(rot), rd);
+    const V3 globalHit = rotate(rot, lo_ + t * ld) + pos;
+    const V3 cog = pos + rotate(rot, xyz(bCogInvMass[body]));
+    const V3 force = rd * strength, torque = cross(globalHit - cog, force);
+    outBody[r] = body;
+    outFT[6 * r] = force.x; outFT[6 * r + 1] = force.y; outFT[6 * r + 2] = force.z; outFT[6 * r + 3] = torque.x; outFT[6 * r + 4] = torque.y; outFT[6 * r + 5] = torque.z;
+}
+
 // ---- EPA (collision_epa.h:96-168, collision_epa.cpp)
 constexpr int kEpaPts = 24, kEpaTris = 288, kEpaEdges = 288, kEpaBorder = 32;
 struct EpaTri { uint16_t a, b, c, eA, eB, eC; V3 n; float dist; };

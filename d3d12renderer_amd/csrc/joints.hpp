@@ -608,6 +608,12 @@ struct JointType {
         if ((e = hipMemcpyAsync(dBodies, bodies.data(), n * sizeof(uint2), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
         return hipMemcpyAsync(dOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, st);
     }
+    bool podsDirty = false;   // mi_constraint_update since the last upload: only the POD array changed (motors, limits), not the topology
+    hipError_t uploadPods(hipStream_t st) {
+        podsDirty = false;
+        if (pods.empty() || !dPods) return hipSuccess;
+        return hipMemcpyAsync(dPods, pods.data(), pods.size() * sizeof(typename J::Pod), hipMemcpyHostToDevice, st);
+    }
     void launchInit(uint32_t dummy, const mi::BodyView& bv, float dt, hipStream_t st) {
         uint32_t n = (uint32_t)pods.size();
         if (n) mi::k_joint_init<J><<<(n + 63) / 64, 64, 0, st>>>(n, dummy, dPods, dBodies, dUpd, bv, dt);
@@ -633,6 +639,8 @@ struct JointSet {
     int get(uint32_t type, uint32_t id, void* pod, uint32_t bytes);
     int addFromGlobal(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb, const float* anchor, const float* axis, float l0, float l1, uint32_t* out);
     int upload(mi_world& w, hipStream_t st);
+    bool podsDirty() const { return distance.podsDirty || ball.podsDirty || fixed.podsDirty || hinge.podsDirty || cone.podsDirty || slider.podsDirty; }
+    int uploadPods(hipStream_t st);
     int initialize(mi_world& w, float dt, hipStream_t st);
     void solveIteration(mi_world& w, hipStream_t st);
 };

@@ -113,6 +113,7 @@ struct mi_world {
     // rigid-body x (trigger | force field) AABB overlaps, the interactions that passed the boolean test, the per-step force accumulators
     std::vector<uint32_t> ffEntities, triggerEntities;
     bool usesInteractions = false; V3 globalForce;
+    DBuf<uint32_t> cEntity, hullTris, hullTriRanges;   // ray tests (testPhysicsInteraction): entity of every collider, hull faces
     DBuf<uint32_t> cObject; DBuf<float4> localForce, bForceStep; DBuf<uint64_t> interKeys; DBuf<DeviceInteraction> interList; DBuf<uint2> fieldList;
     std::vector<uint64_t> prevTriggerOverlaps, nextTriggerOverlaps;
     int interactions(std::vector<mi_event>& triggerEvents);
@@ -356,7 +357,7 @@ int mi_world::upload() {
 
     usesGjk = false;
     for (const HCollider& c : colliders) if (c.desc.type == T_CAPSULE || c.desc.type == T_CYLINDER || c.desc.type == T_HULL) usesGjk = true;
-    std::vector<uint32_t> tb(2 * (size_t)nc), obj(nc); std::vector<float4> sh(3 * (size_t)nc), sp(nc), sr(nc), mat(nc);
+    std::vector<uint32_t> tb(2 * (size_t)nc), obj(nc), cent(nc); std::vector<float4> sh(3 * (size_t)nc), sp(nc), sr(nc), mat(nc);
     // force fields (getForceFieldStates, physics.cpp:759-787): rotated force per field; fields without colliders are global
     usesInteractions = false; globalForce = V3();
     std::vector<float4> lf(ffEntities.size());
@@ -369,6 +370,7 @@ int mi_world::upload() {
         const HCollider& c = colliders[nc - 1 - k];
         const HEntity& e = entities[c.entity];
         tb[2 * k] = c.desc.type; tb[2 * k + 1] = e.rb >= 0 ? (uint32_t)e.rb : kNoBody;
+        cent[k] = c.entity;
         obj[k] = e.kind == MI_ENTITY_FORCE_FIELD ? (OBJ_FORCE_FIELD | e.kindIndex << 8) : e.kind == MI_ENTITY_TRIGGER ? (OBJ_TRIGGER | e.kindIndex << 8) : OBJ_STATIC;
         if (e.kind == MI_ENTITY_FORCE_FIELD || e.kind == MI_ENTITY_TRIGGER) usesInteractions = true;
         float s[12]; std::memcpy(s, c.desc.shape, sizeof(s));
@@ -377,7 +379,7 @@ int mi_world::upload() {
         sp[k] = h4(e.pos, 0.f); sr[k] = make_float4(e.rot.x, e.rot.y, e.rot.z, e.rot.w);
         mat[k] = make_float4(c.desc.restitution, c.desc.friction, c.desc.density, 0.f);
     }
-    UP(cObject, obj, nc); UP(localForce, lf, lf.size());
+    UP(cObject, obj, nc); UP(localForce, lf, lf.size()); UP(cEntity, cent, nc);
     if (usesInteractions) HIP_TRY(bForceStep.ensure(std::max<size_t>(nb, 1)));
     UP(cTypeBody, tb, 2 * (size_t)nc); UP(cShape, sh, 3 * (size_t)nc); UP(cStaticPos, sp, nc); UP(cStaticRot, sr, nc); UP(cMaterial, mat, nc);
     HIP_TRY(wShape.ensure(3 * (size_t)nc + 1)); HIP_TRY(aabbMin.ensure(nc + 1)); HIP_TRY(aabbMax.ensure(nc + 1));
@@ -395,6 +397,10 @@ int mi_world::upload() {
         for (const V3& v : hulls[h].verts) hv.push_back(h4(v, 0.f));
     }
     if (hv.empty()) hv.push_back(make_float4(0, 0, 0, 0));
+    std::vector<uint32_t> ht, htr(2 * hulls.size() + 2);
+    for (size_t h = 0; h < hulls.size(); ++h) { htr[2 * h] = (uint32_t)(ht.size() / 3); htr[2 * h + 1] = (uint32_t)(hulls[h].tris.size() / 3); ht.insert(ht.end(), hulls[h].tris.begin(), hulls[h].tris.end()); }
+    if (ht.empty()) ht.push_back(0u);
+    UP(hullTris, ht, ht.size()); UP(hullTriRanges, htr, htr.size());
     UP(hullAabb, ha, ha.size()); UP(hullVerts, hv, hv.size()); UP(hullRanges, hr, hr.size());
 #undef UP
     int rc = joints.upload(*this, stream);
@@ -404,7 +410,7 @@ int mi_world::upload() {
         rc = uploadHeightmap(); if (rc != MI_OK) return rc;
     }
     HIP_TRY(hipStreamSynchronize(stream));
-    topologyDirty = false; hostStale = false;
+    topologyDirty = false; hostStale = false; haveEstimates = false;   // the previous step's counts say nothing about the new topology
     return MI_OK;
 }
 
@@ -514,6 +520,7 @@ enum { STEP_RETRY = 1 };
 int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     HIP_TRY(hipSetDevice(device));
     if (topologyDirty) { int rc = download(); if (rc != MI_OK) return rc; rc = upload(); if (rc != MI_OK) return rc; haveEstimates = false; }
+    else if (joints.podsDirty()) { int rc = joints.uploadPods(stream); if (rc != MI_OK) return rc; HIP_TRY(hipStreamSynchronize(stream)); }
     if (bodies.empty()) return MI_OK;
     const bool spec = specEnabled && haveEstimates && flowSolver && !usesInteractions;   // interactions are read back mid-step
     ++totalSteps; if (spec) ++specSteps;
@@ -945,14 +952,23 @@ template <class JT> static int jointCopy(JT& l, uint32_t id, void* dst, const vo
 }
 int JointSet::update(uint32_t type, uint32_t id, const void* pod, uint32_t bytes) {
     switch (type) {
-        case MI_CONSTRAINT_DISTANCE: return jointCopy(distance, id, nullptr, pod, bytes);
-        case MI_CONSTRAINT_BALL: return jointCopy(ball, id, nullptr, pod, bytes);
-        case MI_CONSTRAINT_FIXED: return jointCopy(fixed, id, nullptr, pod, bytes);
-        case MI_CONSTRAINT_HINGE: return jointCopy(hinge, id, nullptr, pod, bytes);
-        case MI_CONSTRAINT_CONE_TWIST: return jointCopy(cone, id, nullptr, pod, bytes);
-        case MI_CONSTRAINT_SLIDER: return jointCopy(slider, id, nullptr, pod, bytes);
+        case MI_CONSTRAINT_DISTANCE: distance.podsDirty = true; return jointCopy(distance, id, nullptr, pod, bytes);
+        case MI_CONSTRAINT_BALL: ball.podsDirty = true; return jointCopy(ball, id, nullptr, pod, bytes);
+        case MI_CONSTRAINT_FIXED: fixed.podsDirty = true; return jointCopy(fixed, id, nullptr, pod, bytes);
+        case MI_CONSTRAINT_HINGE: hinge.podsDirty = true; return jointCopy(hinge, id, nullptr, pod, bytes);
+        case MI_CONSTRAINT_CONE_TWIST: cone.podsDirty = true; return jointCopy(cone, id, nullptr, pod, bytes);
+        case MI_CONSTRAINT_SLIDER: slider.podsDirty = true; return jointCopy(slider, id, nullptr, pod, bytes);
     }
     return fail(MI_ERR_INVALID_ARGUMENT, "bad constraint type");
+}
+int JointSet::uploadPods(hipStream_t st) {   // the host copy is authoritative for the PODs (the device never writes them)
+    if (distance.podsDirty) HIP_TRY(distance.uploadPods(st));
+    if (ball.podsDirty) HIP_TRY(ball.uploadPods(st));
+    if (fixed.podsDirty) HIP_TRY(fixed.uploadPods(st));
+    if (hinge.podsDirty) HIP_TRY(hinge.uploadPods(st));
+    if (cone.podsDirty) HIP_TRY(cone.uploadPods(st));
+    if (slider.podsDirty) HIP_TRY(slider.uploadPods(st));
+    return MI_OK;
 }
 int JointSet::get(uint32_t type, uint32_t id, void* pod, uint32_t bytes) {
     switch (type) {
@@ -1033,6 +1049,7 @@ int JointSet::upload(mi_world& w, hipStream_t st) {
     hinge.computeOrder(invMass); cone.computeOrder(invMass); slider.computeOrder(invMass);
     HIP_TRY(distance.upload(st)); HIP_TRY(ball.upload(st)); HIP_TRY(fixed.upload(st));
     HIP_TRY(hinge.upload(st)); HIP_TRY(cone.upload(st)); HIP_TRY(slider.upload(st));
+    distance.podsDirty = ball.podsDirty = fixed.podsDirty = hinge.podsDirty = cone.podsDirty = slider.podsDirty = false;
     return MI_OK;
 }
 static BodyView bodyView(mi_world& w) { return BodyView{w.gPos.p, w.gInvI.p, w.gVel.p, w.bRot.p, w.bCogInvMass.p}; }
@@ -1179,9 +1196,16 @@ MI_API int mi_constraint_create(mi_world* w, uint32_t type, uint32_t ea, uint32_
 }
 MI_API int mi_constraint_update(mi_world* w, uint32_t type, uint32_t id, const void* pod, uint32_t bytes) {
     if (!w || !pod) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
-    int rc = w->joints.update(type, id, pod, bytes);
-    if (rc == MI_OK) w->topologyDirty = true;
-    return rc;
+    return w->joints.update(type, id, pod, bytes);   // motors / limits: the POD array is re-sent before the next step, nothing else changes
+}
+// Many constraints of one type at once (a policy writing the motor targets of thousands of ragdolls per step).
+MI_API int mi_constraints_update(mi_world* w, uint32_t type, uint32_t count, const uint32_t* ids, const void* pods, uint32_t podBytes) {
+    if (!w || (count && (!ids || !pods))) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    for (uint32_t i = 0; i < count; ++i) {
+        int rc = w->joints.update(type, ids[i], (const char*)pods + (size_t)i * podBytes, podBytes);
+        if (rc != MI_OK) return rc;
+    }
+    return MI_OK;
 }
 MI_API int mi_constraint_get(mi_world* w, uint32_t type, uint32_t id, void* pod, uint32_t bytes) {
     if (!w || !pod) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
@@ -1196,13 +1220,75 @@ MI_API int mi_constraint_create_from_global(mi_world* w, uint32_t type, uint32_t
     return rc;
 }
 
-MI_API int mi_entity_apply_force(mi_world* w, uint32_t entity, const float* f, const float* t) {
-    if (!w || entity >= w->entities.size() || w->entities[entity].rb < 0) return fail(MI_ERR_INVALID_ARGUMENT, "not a rigid body");
-    int rc = w->download(); if (rc != MI_OK) return rc;
-    HBody& b = w->bodies[w->entities[entity].rb];
-    if (f) b.force = b.force + V3(f[0], f[1], f[2]);
-    if (t) b.torque = b.torque + V3(t[0], t[1], t[2]);
-    w->topologyDirty = true;
+__global__ void k_add_forces(uint32_t n, const uint32_t* __restrict__ bodies, const float* __restrict__ ft, float4* __restrict__ bForce, float4* __restrict__ bTorque) {
+    // one lane, in order: several entries may name the same body and the sums must not depend on scheduling
+    for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t b = bodies[i];
+        if (b == 0xFFFFFFFFu) continue;   // a ray that hit nothing
+        float4 f = bForce[b], t = bTorque[b];
+        f.x += ft[6 * i]; f.y += ft[6 * i + 1]; f.z += ft[6 * i + 2]; t.x += ft[6 * i + 3]; t.y += ft[6 * i + 4]; t.z += ft[6 * i + 5];
+        bForce[b] = f; bTorque[b] = t;
+    }
+}
+static int ensureUploaded(mi_world* w) {
+    HIP_TRY(hipSetDevice(w->device));
+    if (w->topologyDirty) { int rc = w->download(); if (rc != MI_OK) return rc; return w->upload(); }
+    return MI_OK;
+}
+// rb.forceAccumulator += f; rb.torqueAccumulator += tau for many bodies.  While the host copy is authoritative (topology edits
+// pending) the sums go there; otherwise they are added on the device without a download / re-upload.
+MI_API int mi_entities_apply_forces(mi_world* w, uint32_t count, const uint32_t* ents, const float* forces3, const float* torques3) {
+    if (!w || (count && !ents)) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    for (uint32_t i = 0; i < count; ++i)
+        if (ents[i] >= w->entities.size() || w->entities[ents[i]].rb < 0) return fail(MI_ERR_INVALID_ARGUMENT, "not a rigid body");
+    if (!count) return MI_OK;
+    if (w->topologyDirty) {
+        int rc = w->download(); if (rc != MI_OK) return rc;
+        for (uint32_t i = 0; i < count; ++i) {
+            HBody& b = w->bodies[w->entities[ents[i]].rb];
+            if (forces3) b.force = b.force + V3(forces3[3 * i], forces3[3 * i + 1], forces3[3 * i + 2]);
+            if (torques3) b.torque = b.torque + V3(torques3[3 * i], torques3[3 * i + 1], torques3[3 * i + 2]);
+        }
+        return MI_OK;
+    }
+    HIP_TRY(hipSetDevice(w->device));
+    std::vector<uint32_t> ids(count); std::vector<float> ft(6 * (size_t)count, 0.f);
+    for (uint32_t i = 0; i < count; ++i) {
+        ids[i] = (uint32_t)w->entities[ents[i]].rb;
+        for (int k = 0; k < 3; ++k) { if (forces3) ft[6 * i + k] = forces3[3 * i + k]; if (torques3) ft[6 * i + 3 + k] = torques3[3 * i + k]; }
+    }
+    DBuf<uint32_t> dIds; DBuf<float> dFt;
+    HIP_TRY(dIds.ensure(count)); HIP_TRY(dFt.ensure(6 * (size_t)count));
+    HIP_TRY(hipMemcpyAsync(dIds.p, ids.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(dFt.p, ft.data(), ft.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    k_add_forces<<<1, 1, 0, w->stream>>>(count, dIds.p, dFt.p, w->bForce.p, w->bTorque.p);
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->hostStale = true;
+    return MI_OK;
+}
+MI_API int mi_entity_apply_force(mi_world* w, uint32_t entity, const float* f, const float* t) { return mi_entities_apply_forces(w, 1, &entity, f, t); }
+// testPhysicsInteraction(scene, ray, strength) (src/physics/physics.cpp:555-629) for `count` rays, applied in order.
+MI_API int mi_world_test_interactions(mi_world* w, uint32_t count, const float* origins, const float* directions, const float* strengths, const uint32_t* ranges) {
+    if (!w || (count && (!origins || !directions))) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (!count) return MI_OK;
+    int rc = ensureUploaded(w); if (rc != MI_OK) return rc;
+    const uint32_t nc = (uint32_t)w->colliders.size();
+    if (!nc || w->bodies.empty()) return MI_OK;
+    std::vector<float> rays(8 * (size_t)count, 0.f); std::vector<uint32_t> rg(2 * (size_t)count);
+    for (uint32_t r = 0; r < count; ++r) {
+        for (int k = 0; k < 3; ++k) { rays[8 * r + k] = origins[3 * r + k]; rays[8 * r + 3 + k] = directions[3 * r + k]; }
+        rays[8 * r + 6] = strengths ? strengths[r] : 1000.f;
+        rg[2 * r] = ranges ? ranges[2 * r] : 0u; rg[2 * r + 1] = ranges ? ranges[2 * r + 1] : 0xFFFFFFFFu;
+    }
+    DBuf<float> dRays, dFT; DBuf<uint32_t> dRanges, dBody;
+    HIP_TRY(dRays.ensure(rays.size())); HIP_TRY(dRanges.ensure(rg.size())); HIP_TRY(dBody.ensure(count)); HIP_TRY(dFT.ensure(6 * (size_t)count));
+    HIP_TRY(hipMemcpyAsync(dRays.p, rays.data(), rays.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipMemcpyAsync(dRanges.p, rg.data(), rg.size() * sizeof(uint32_t), hipMemcpyHostToDevice, w->stream));
+    HullFaces hf{w->hullVerts.p, w->hullRanges.p, w->hullTris.p, w->hullTriRanges.p};
+    k_ray_interactions<<<count, 256, 0, w->stream>>>(nc, dRays.p, dRanges.p, w->cTypeBody.p, w->cEntity.p, w->cShape.p, w->bPos.p, w->bRot.p, w->bCogInvMass.p, hf, dBody.p, dFT.p);
+    k_add_forces<<<1, 1, 0, w->stream>>>(count, dBody.p, dFT.p, w->bForce.p, w->bTorque.p);
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->hostStale = true;
     return MI_OK;
 }
 
@@ -1377,11 +1463,6 @@ MI_API int mi_world_get_contacts(mi_world* w, mi_contact* out, uint32_t cap, uin
 }
 
 // ---- ghost-region exchange (multi-GPU sharding)
-static int ensureUploaded(mi_world* w) {
-    HIP_TRY(hipSetDevice(w->device));
-    if (w->topologyDirty) { int rc = w->download(); if (rc != MI_OK) return rc; return w->upload(); }
-    return MI_OK;
-}
 MI_API int mi_world_entities_to_bodies(mi_world* w, uint32_t n, const uint32_t* ents, uint32_t* out) {
     if (!w || (n && (!ents || !out))) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     for (uint32_t i = 0; i < n; ++i) {

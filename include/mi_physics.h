@@ -188,6 +188,9 @@ MI_API int mi_constraint_create(mi_world* world, uint32_t type, uint32_t entity_
 /* getConstraint(scene, handle) = mutable access (motors/limits) (src/physics/physics.h:244-249). */
 MI_API int mi_constraint_update(mi_world* world, uint32_t type, uint32_t constraint, const void* pod, uint32_t pod_bytes);
 MI_API int mi_constraint_get(mi_world* world, uint32_t type, uint32_t constraint, void* pod, uint32_t pod_bytes);
+/* mi_constraint_update for `count` constraints of one type (pods = count consecutive PODs of pod_bytes each): a policy writing the
+ * motor targets of thousands of ragdolls per step.  Updates only re-send the POD arrays; the step stays on its fast path. */
+MI_API int mi_constraints_update(mi_world* world, uint32_t type, uint32_t count, const uint32_t* constraints, const void* pods, uint32_t pod_bytes);
 /* add{Distance,Ball,Fixed,Hinge,ConeTwist,Slider}ConstraintFromGlobalPoints (src/physics/physics.cpp:128-333). */
 MI_API int mi_constraint_create_from_global(mi_world* world, uint32_t type, uint32_t entity_a, uint32_t entity_b,
                                             const float* global_anchor, const float* global_axis,
@@ -218,6 +221,15 @@ MI_API int mi_heightmap_get_height(mi_world* world, float x, float z, float* out
 
 /* rb.forceAccumulator += f; rb.torqueAccumulator += tau (src/physics/physics.cpp:623-627). */
 MI_API int mi_entity_apply_force(mi_world* world, uint32_t entity, const float* force3, const float* torque3);
+/* The same for many rigid bodies at once, in order (either array may be NULL); added on the device when no topology edit is pending. */
+MI_API int mi_entities_apply_forces(mi_world* world, uint32_t count, const uint32_t* entities, const float* forces3, const float* torques3);
+/* testPhysicsInteraction(scene, ray, strength) (src/physics/physics.h:404, physics.cpp:555-629) for `count` rays, applied in
+ * order: the closest rigid-body collider along ray i (ray::intersectSphere/Capsule/Cylinder/AABB/OBB/Hull in the entity's
+ * physics_transform1 frame) receives force = direction * strength at the hit point.  strengths NULL = 1000 (the reference's
+ * default); entity_ranges2 NULL = the whole scene, otherwise ray i only sees colliders of entities [lo_i, hi_i) — batched
+ * environments in one world. */
+MI_API int mi_world_test_interactions(mi_world* world, uint32_t count, const float* origins3, const float* directions3,
+                                      const float* strengths, const uint32_t* entity_ranges2);
 
 /* physicsStep(scene, arena, timer, settings, dt) (src/physics/physics.cpp:1364-1413). */
 MI_API int mi_world_step(mi_world* world, const mi_step_settings* settings, float dt);

@@ -2,6 +2,7 @@
 // Scalar shape-pair intersection() routines of src/physics/collision_narrow.cpp, same operation
 // order.  Normal points from A to B; penetrationDepth >= 0; contact point = midpoint.
 #include "ora_world.h"
+#include <cstring>
 #include <algorithm>
 
 namespace ora {
@@ -735,6 +736,114 @@ bool intersect(const World& w, const WorldCollider& A, const WorldCollider& B, C
             break;
     }
     return false;
+}
+
+
+// ---------------------------------------------------------------- ray tests (testPhysicsInteraction)
+// ray::intersectSphere / Cylinder / Capsule / AABB / OBB / Hull — src/physics/bounding_volumes.cpp:197-398, 677-702.
+// Stated deviation: intersectCylinder leaves outT unset when the origin is inside the infinite cylinder and neither cap is hit
+// (the reference then reads it uninitialised); here it is 0 in that case (the ray starts inside the cylinder's slab).
+static bool rayPlane(vec3 o, vec3 d, vec3 normal, float pd, float& t) {
+    float ndotd = dot(d, normal);
+    if (std::fabs(ndotd) < 1e-6f) return false;
+    t = -(dot(o, normal) + pd) / ndotd;
+    return true;
+}
+static bool rayDisk(vec3 o, vec3 d, vec3 pos, vec3 normal, float radius, float& t) {
+    if (!rayPlane(o, d, normal, -dot(normal, pos), t)) return false;
+    return length(o + t * d - pos) <= radius;
+}
+static bool raySphere(vec3 o, vec3 d, vec3 center, float radius, float& t) {
+    vec3 m = o - center;
+    float b = dot(m, d), c = dot(m, m) - radius * radius;
+    if (c > 0.f && b > 0.f) return false;
+    float discr = b * b - c;
+    if (discr < 0.f) return false;
+    t = -b - std::sqrt(discr);
+    if (t < 0.f) t = 0.f;
+    return true;
+}
+static bool rayCylinder(vec3 o, vec3 d, vec3 pa, vec3 pb, float radius, float& t) {
+    vec3 axis = pb - pa;
+    float height = length(axis);
+    quat q = rotateFromTo(axis, vec3(0.f, 1.f, 0.f));
+    o = q * (o - pa); d = q * d;
+    const float epsilon = 1e-6f;
+    float y = -1.f;
+    t = 0.f;
+    if (o.x * o.x + o.z * o.z > radius * radius) {   // outside the infinite cylinder: the side can be hit
+        float a = d.x * d.x + d.z * d.z, b = d.x * o.x + d.z * o.z, c = o.x * o.x + o.z * o.z - radius * radius;
+        float delta = b * b - a * c;
+        if (delta < epsilon) return false;
+        t = (-b - std::sqrt(delta)) / a;
+        if (t <= epsilon) return false;
+        y = o.y + t * d.y;
+    }
+    if (y > height + epsilon || y < -epsilon) {       // caps
+        float dist;
+        if (d.y < 0.f && rayDisk(o, d, vec3(0.f, height, 0.f), vec3(0.f, 1.f, 0.f), radius, dist)) t = dist;
+        if (d.y > 0.f && rayDisk(o, d, vec3(0.f, 0.f, 0.f), vec3(0.f, -1.f, 0.f), radius, dist)) t = dist;
+        y = o.y + t * d.y;
+    }
+    return y > -epsilon && y < height + epsilon;
+}
+static bool rayAABB(vec3 o, vec3 d, vec3 mn, vec3 mx, float& t) {
+    vec3 inv(1.f / d.x, 1.f / d.y, 1.f / d.z);
+    float tx1 = (mn.x - o.x) * inv.x, tx2 = (mx.x - o.x) * inv.x;
+    t = fmin2(tx1, tx2);
+    float tmax = fmax2(tx1, tx2);
+    float ty1 = (mn.y - o.y) * inv.y, ty2 = (mx.y - o.y) * inv.y;
+    t = fmax2(t, fmin2(ty1, ty2)); tmax = fmin2(tmax, fmax2(ty1, ty2));
+    float tz1 = (mn.z - o.z) * inv.z, tz2 = (mx.z - o.z) * inv.z;
+    t = fmax2(t, fmin2(tz1, tz2)); tmax = fmin2(tmax, fmax2(tz1, tz2));
+    return tmax >= t && t > 0.f;
+}
+static bool pointInTriangle(vec3 point, vec3 a, vec3 b, vec3 c) {   // math.cpp:1273-1290 (sign-bit test)
+    vec3 e10 = b - a, e20 = c - a;
+    float aa = dot(e10, e10), bb = dot(e10, e20), cc = dot(e20, e20);
+    float ac_bb = (aa * cc) - (bb * bb);
+    vec3 vp = point - a;
+    float dd = dot(vp, e10), ee = dot(vp, e20);
+    float x = (dd * cc) - (ee * bb), y = (ee * aa) - (dd * bb), z = x + y - ac_bb;
+    uint32_t ux, uy, uz; std::memcpy(&ux, &x, 4); std::memcpy(&uy, &y, 4); std::memcpy(&uz, &z, 4);
+    return ((uz & ~(ux | uy)) & 0x80000000u) != 0;
+}
+static bool rayTriangle(vec3 o, vec3 d, vec3 a, vec3 b, vec3 c, float& t) {
+    vec3 normal = noz(cross(b - a, c - a));
+    float pd = -dot(normal, a);
+    float nDotR = dot(d, normal);
+    if (std::fabs(nDotR) <= 1e-6f) return false;
+    t = -(dot(o, normal) + pd) / nDotR;
+    vec3 q = o + t * d;
+    return t >= 0.f && pointInTriangle(q, a, b, c);
+}
+// One collider in its entity's local frame (collider shapes are stored entity-local; physics.cpp:571-606).
+bool rayVsCollider(const World& w, const Shape& s, vec3 o, vec3 d, float& t) {
+    switch (s.type) {
+        case T_SPHERE: return raySphere(o, d, s.a, s.radius, t);
+        case T_CAPSULE: {
+            t = FLT_MAX;
+            float tt; bool result = false;
+            if (rayCylinder(o, d, s.a, s.b, s.radius, tt)) { t = tt; result = true; }
+            if (raySphere(o, d, s.a, s.radius, tt)) { t = fmin2(t, tt); result = true; }
+            if (raySphere(o, d, s.b, s.radius, tt)) { t = fmin2(t, tt); result = true; }
+            return result;
+        }
+        case T_CYLINDER: return rayCylinder(o, d, s.a, s.b, s.radius, t);
+        case T_AABB: return rayAABB(o, d, s.a, s.b, t);
+        case T_OBB: return rayAABB(conjugate(s.rot) * (o - s.a), conjugate(s.rot) * d, vec3(0.f) - s.b, vec3(0.f) + s.b, t);
+        default: {
+            const HullGeometry& g = w.hulls[s.hull];
+            vec3 lo = conjugate(s.rot) * (o - s.a), ld = conjugate(s.rot) * d;
+            float minT = FLT_MAX; bool result = false;
+            for (size_t f = 0; f + 2 < g.tris.size(); f += 3) {
+                float tt;
+                if (rayTriangle(lo, ld, g.vertices[g.tris[f]], g.vertices[g.tris[f + 1]], g.vertices[g.tris[f + 2]], tt) && tt < minT) { minT = tt; result = true; }
+            }
+            t = minT;
+            return result;
+        }
+    }
 }
 
 }  // namespace ora

@@ -1052,6 +1052,51 @@ MI_API int ora_entity_apply_force(World* w, uint32_t entity, const float* f, con
     return MI_OK;
 }
 
+MI_API int ora_entities_apply_forces(World* w, uint32_t count, const uint32_t* ents, const float* f, const float* t) {
+    for (uint32_t i = 0; i < count; ++i) {
+        int rc = ora_entity_apply_force(w, ents[i], f ? f + 3 * i : nullptr, t ? t + 3 * i : nullptr);
+        if (rc != MI_OK) return rc;
+    }
+    return MI_OK;
+}
+MI_API int ora_constraints_update(World* w, uint32_t type, uint32_t count, const uint32_t* ids, const void* pods, uint32_t podBytes) {
+    for (uint32_t i = 0; i < count; ++i) {
+        int rc = jointsUpdate(*w, type, ids[i], (const char*)pods + (size_t)i * podBytes, podBytes);
+        if (rc != MI_OK) return rc;
+    }
+    return MI_OK;
+}
+// testPhysicsInteraction — src/physics/physics.cpp:555-629: the closest rigid-body collider along the ray (strict `<`, colliders in
+// EnTT view order = newest first) gets force = direction * strength at the hit point.  Ray i only sees the colliders of the
+// entities [ranges[2i], ranges[2i+1]) (null: the whole scene).
+MI_API int ora_world_test_interactions(World* w, uint32_t count, const float* origins, const float* directions, const float* strengths, const uint32_t* ranges) {
+    if (!w || (count && (!origins || !directions))) return MI_ERR_INVALID_ARGUMENT;
+    if (w->dirtyProps) w->recalculateProperties();
+    for (uint32_t r = 0; r < count; ++r) {
+        vec3 ro(origins[3 * r], origins[3 * r + 1], origins[3 * r + 2]), rd(directions[3 * r], directions[3 * r + 1], directions[3 * r + 2]);
+        float strength = strengths ? strengths[r] : 1000.f;
+        uint32_t lo = ranges ? ranges[2 * r] : 0u, hi = ranges ? ranges[2 * r + 1] : 0xFFFFFFFFu;
+        float minT = FLT_MAX; RigidBody* minRB = nullptr; vec3 force, torque;
+        for (size_t k = w->colliders.size(); k-- > 0;) {
+            const Collider& c = w->colliders[k];
+            const Entity& e = w->entities[c.entity];
+            if (e.rb < 0 || c.entity < lo || c.entity >= hi) continue;
+            RigidBody& rb = w->bodies[e.rb];
+            vec3 lo_ = conjugate(rb.r1) * (ro - rb.p1), ld = conjugate(rb.r1) * rd;   // physics_transform1
+            float t;
+            if (rayVsCollider(*w, c.local, lo_, ld, t) && t < minT) {
+                minT = t; minRB = &rb;
+                vec3 localHit = lo_ + t * ld;
+                vec3 globalHit = rb.r1 * localHit + rb.p1;
+                vec3 cog = rb.p1 + rb.r1 * rb.localCOG;
+                force = rd * strength;
+                torque = cross(globalHit - cog, force);
+            }
+        }
+        if (minRB) { minRB->torqueAccumulator += torque; minRB->forceAccumulator += force; }
+    }
+    return MI_OK;
+}
 MI_API int ora_world_step(World* w, const mi_step_settings* s, float dt) { w->step(*s, dt); return MI_OK; }
 MI_API int ora_world_step_fixed(World* w, const mi_step_settings* s, float dt, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) w->stepInternal(*s, dt);

@@ -159,6 +159,7 @@ bool intersect(const World& w, const WorldCollider& A, const WorldCollider& B, C
 bool overlapCheck(const World& w, const WorldCollider& A, const WorldCollider& B);   // boolean tests for triggers / force fields
 vec3 closestPoint_PointSegment(vec3 q, vec3 la, vec3 lb);
 float closestPoint_SegmentSegment(vec3 l1a, vec3 l1b, vec3 l2a, vec3 l2b, vec3& c1, vec3& c2);
+bool rayVsCollider(const World& w, const Shape& localShape, vec3 localOrigin, vec3 localDirection, float& outT);   // ray::intersect*
 void heightmapCollision(World& w);   // ora_heightmap.cpp: appends to colliderPairs / contactCounts / contacts / bodyPairs
 // GJK / EPA (ora_gjk.cpp)
 struct SupportShape { const Shape* s; const HullGeometry* g; };

@@ -179,6 +179,49 @@ def test_gpu_heightmap_full_size_properties(mi_lib):
     assert spec >= total - 1 - retries and retries <= 20   # everything lands within a few steps: the contact count jumps past the speculative bounds
 
 
+def test_gpu_ray_interactions_and_batched_edits_match_oracle(mi_lib, oracle_mod):
+    """testPhysicsInteraction over every collider type (sphere, capsule, cylinder, AABB, OBB, hull), many rays per call, with
+    and without entity ranges, interleaved with steps; batched force application and batched constraint (motor) updates on
+    the fast path (no topology re-upload): GPU state stays bit-identical to the oracle's."""
+    sc = scenes.shape_zoo(6, 3, 6)
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    nb = sc.num_bodies
+    rng = np.random.default_rng(5)
+    for it in range(40):
+        g.step_fixed(s, sc.dt, 3); o.step_fixed(s, sc.dt, 3)
+        p, _ = o.physics_transforms()
+        nrays = 24
+        target = p[rng.integers(0, nb, nrays)] + rng.uniform(-0.2, 0.2, (nrays, 3)).astype(np.float32)
+        direction = rng.normal(size=(nrays, 3)).astype(np.float32); direction /= np.linalg.norm(direction, axis=1, keepdims=True)
+        origin = (target - 6.0 * direction).astype(np.float32)
+        strength = rng.uniform(50, 400, nrays).astype(np.float32)
+        lo = rng.integers(0, nb, nrays); ranges = np.stack([lo, lo + rng.integers(1, 40, nrays)], axis=1).astype(np.uint32)
+        use_ranges = ranges if it % 2 else None
+        g.test_interactions(origin, direction, strength, use_ranges); o.test_interactions(origin, direction, strength, use_ranges)
+        ents = rng.integers(0, nb, 16).astype(np.uint32)
+        f = rng.uniform(-20, 20, (16, 3)).astype(np.float32); t = rng.uniform(-2, 2, (16, 3)).astype(np.float32)
+        g.apply_forces(ents, f, t); o.apply_forces(ents, f, t)
+    steps, spec, retries = g.step_mode_stats()
+    assert spec >= steps - 2 - retries                     # the edits did not throw the world off its fast path
+    pg, qg = g.physics_transforms(); po, qo = o.physics_transforms()
+    vg, wg = g.velocities(); vo, wo = o.velocities()
+    assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes() and vg.tobytes() == vo.tobytes() and wg.tobytes() == wo.tobytes()
+    # motors through the batched update: ragdoll hinges driven to a target angle
+    sc = scenes.ragdolls(3, 3)
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    nh = 6 * 9
+    for it in range(30):
+        pods = np.concatenate([g.get_constraint(capi.CONSTRAINT_HINGE, i) for i in range(nh)])
+        pods["motor_type"] = 1; pods["max_motor_torque"] = 200.0; pods["motor_velocity_or_target_angle"] = 0.3 * np.sin(0.2 * it)
+        g.update_constraints(capi.CONSTRAINT_HINGE, np.arange(nh), pods); o.update_constraints(capi.CONSTRAINT_HINGE, np.arange(nh), pods)
+        g.step_fixed(s, sc.dt, 2); o.step_fixed(s, sc.dt, 2)
+    assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
+    steps, spec, retries = g.step_mode_stats()
+    assert spec >= steps - 2 - retries
+
+
 def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
     """Steps after the first run with ONE host read-back, sized from the previous step's counts.  Teleporting the bodies into
     a much denser pile invalidates those bounds: the step must be re-run synchronously from the untouched state and still match

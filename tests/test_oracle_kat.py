@@ -337,3 +337,44 @@ def test_heightmap_scene_both_orders_agree(oracle_mod):
         hts = np.array([w.heightmap_height(float(p[i, 0]), float(p[i, 2])) for i in on_map])
         assert (p[on_map, 1] > hts - 0.05).all() and p[0, 1] < -5.0 and p[1, 1] < -5.0       # the two off-map bodies keep falling
         assert p[25, 1] < -5.0 and p[26, 1] < -5.0                                            # cylinder and hull are ignored
+
+
+def test_ray_interaction_known_answers(oracle_mod):
+    """testPhysicsInteraction (physics.cpp:555-629): the closest rigid-body collider along the ray gets force = direction *
+    strength at the hit point; static colliders are ignored; an entity range restricts a ray to one environment."""
+    w = oracle_mod.create_world(oracle_mod.ORDER_REFERENCE)
+    e = scenes.make_entities(4); e["gravity_factor"] = 0.0; e["linear_damping"] = 0.0; e["angular_damping"] = 0.0
+    e["position"][0] = (0, 0, 0); e["position"][1] = (0, 0, 5); e["position"][2] = (0, 3, 0); e["kind"][3] = capi.ENTITY_STATIC
+    e["position"][3] = (0, 0, -3)
+    c = scenes.make_colliders(4, capi.SPHERE)
+    c["shape"][0, :4] = (0, 0, 0, 1.0)                                     # unit sphere at the origin
+    c["shape"][1, :4] = (0, 0, 0, 1.0)                                     # same, 5 m behind
+    c["type"][2] = capi.AABB; c["shape"][2, :6] = (-1, -0.5, -1, 1, 0.5, 1)  # box above
+    c["shape"][3, :4] = (0, 0, 0, 1.0)                                     # static sphere in FRONT of body 0: ignored
+    w.create_entities(e); w.add_colliders(np.arange(4, dtype=np.uint32), c)
+    s = capi.StepSettings(1, 120, 4, 1); dt = 1 / 120
+    im, _, _ = w.mass_properties()
+    # ray along +z through the static sphere, body 0, body 1: hits body 0 at z = -1 (t = 9), central hit -> no torque
+    w.test_interactions([(0, 0, -10)], [(0, 0, 1)], [600.0])
+    w.step_fixed(s, dt, 1)
+    v, om = w.velocities()
+    assert np.allclose(v[0], (0, 0, 600.0 * im[0] * dt), rtol=1e-5) and np.allclose(v[1], 0) and np.allclose(om[0], 0, atol=1e-7)
+    # off-centre ray (x = 0.5) onto the sphere: torque = (hit - cog) x force, hit = (0.5, 0, -sqrt(0.75))
+    w.test_interactions([(0.5, 0, -10)], [(0, 0, 1)])                       # default strength 1000
+    v0 = w.velocities()[0][0].copy()
+    w.step_fixed(s, dt, 1)
+    v, om = w.velocities()
+    p0 = w.physics_transforms()[0][0]
+    assert abs((v[0, 2] - v0[2]) - 1000.0 * im[0] * dt) < 1e-4 * 1000.0 * im[0] * dt + 1e-6
+    assert om[0, 1] < 0 and abs(om[0, 0]) < 1e-6 and abs(om[0, 2]) < 1e-6    # (0.5,0,-z) x (0,0,F) = (0, -0.5 F, 0)
+    # a ray from above hits the box top face (y = 3.5): restricted to entity 0 it passes through the box and hits the sphere
+    before = w.velocities()[0].copy()
+    w.test_interactions([(0.2, 10, 0.1)], [(0, -1, 0)], [100.0], [(0, 1)])
+    w.step_fixed(s, dt, 1)
+    after = w.velocities()[0]
+    assert after[0, 1] < before[0, 1] - 1e-4 and abs(after[2, 1] - before[2, 1]) < 1e-9
+    w.test_interactions([(0.2, 10, 0.1)], [(0, -1, 0)], [100.0])
+    before = w.velocities()[0].copy()
+    w.step_fixed(s, dt, 1)
+    after = w.velocities()[0]
+    assert after[2, 1] < before[2, 1] - 1e-4
