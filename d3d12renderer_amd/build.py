@@ -8,7 +8,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libmi_physics.so"
 SOURCES = [CSRC / "world.hip"]
-HEADERS = [CSRC / n for n in ("dmath.hpp", "narrow.hpp", "kernels.hpp", "gjk.hpp", "joints.hpp")] + \
+HEADERS = [CSRC / n for n in ("dmath.hpp", "narrow.hpp", "kernels.hpp", "gjk.hpp", "joints.hpp", "heightmap.hpp")] + \
           [HERE.parent / "include" / n for n in ("mi_physics.h", "mi_constraints.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
@@ -29,7 +29,33 @@ def needs_build():
     return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
 
 
+LEARNING_LIB = HERE / "libPhysics-Lib.so"      # the reference's learning DLL ("Physics-Lib.dll") over libmi_physics.so
+LEARNING_SRC = CSRC / "learning.cpp"
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math"]
+
+
+def build_learning(force=False, verbose=False):
+    """libPhysics-Lib.so: host-only C++ (g++) linked against libmi_physics.so next to it ($ORIGIN rpath)."""
+    deps = [LEARNING_SRC, LIB] + HEADERS[-2:]
+    if not force and LEARNING_LIB.exists() and all(p.stat().st_mtime <= LEARNING_LIB.stat().st_mtime for p in deps):
+        return LEARNING_LIB
+    cmd = [os.environ.get("CXX", "g++"), *HOST_FLAGS, str(LEARNING_SRC), "-o", str(LEARNING_LIB), "-L", str(HERE), "-l:libmi_physics.so", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("g++ failed (learning library)")
+    return LEARNING_LIB
+
+
 def build(force=False, verbose=False):
+    lib = _build_physics(force, verbose)
+    build_learning(force, verbose)
+    return lib
+
+
+def _build_physics(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
     cmd = [hipcc(), *FLAGS, "-I", str(HERE.parent / "include"), *map(str, SOURCES), "-o", str(LIB)]

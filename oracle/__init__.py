@@ -26,6 +26,21 @@ def build(force=False):
     return LIB
 
 
+LEARNING_LIB = HERE / "_build" / "liboracle_learning.so"
+
+
+def build_learning():
+    """The product's learning environment code (d3d12renderer_amd/csrc/learning.cpp) compiled against the ORACLE's C ABI, so the
+    parity tests can run identical environment code over both physics backends.  Test infrastructure only."""
+    build()
+    src = HERE.parent / "d3d12renderer_amd" / "csrc" / "learning.cpp"
+    if not LEARNING_LIB.exists() or any(p.stat().st_mtime > LEARNING_LIB.stat().st_mtime for p in (src, LIB)):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math",
+                        "-DLEARNING_BACKEND_ORACLE", str(src), "-o", str(LEARNING_LIB), "-L", str(LIB.parent), "-l:liboracle.so", "-Wl,-rpath,$ORIGIN"],
+                       check=True, capture_output=True)
+    return LEARNING_LIB
+
+
 _library = None
 
 

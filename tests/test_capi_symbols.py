@@ -28,6 +28,18 @@ def test_library_exports_every_declared_symbol(mi_lib):
     assert not missing, missing
 
 
+def test_learning_library_exports_the_reference_abi(mi_lib):
+    """libPhysics-Lib.so exports every function include/mi_learning.h declares (the five of learned_locomotion.cpp:395-489 first)."""
+    import ctypes
+    from d3d12renderer_amd import learning
+    names = re.findall(r"MI_LEARNING_API\s+[\w\s\*]+?\b(\w+)\s*\(", (ROOT / "include" / "mi_learning.h").read_text())
+    assert names[:5] == ["getPhysicsStateSize", "getPhysicsActionSize", "getPhysicsRanges", "resetPhysics", "updatePhysics"]
+    lib = ctypes.CDLL(str(learning.LIB_PATH))
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+    assert lib.getPhysicsStateSize() == 66 and lib.getPhysicsActionSize() == 27
+
+
 def test_no_cpu_fallback_without_device(mi_lib):
     import torch
     if torch.cuda.is_available():

@@ -1,7 +1,6 @@
 #!/bin/bash
-# scratch: run selected GPU tests + config timings
+# scratch: run selected GPU tests
 ulimit -c 0
 mkdir -p gpurun_out
 cd oracle && make >/dev/null 2>&1; cd ..
-timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "ray_interactions" 2>&1 | tail -120 | tee gpurun_out/two.log
-
+timeout 600 python -m pytest tests/test_learning.py -x -q -m gpu 2>&1 | tail -40 | tee gpurun_out/two.log
