@@ -239,6 +239,18 @@ class World:
         self.L.check(self.L.fn("heightmap_get_height")(self.h, C.c_float(x), C.c_float(z), C.byref(out)), "heightmap_get_height")
         return out.value
 
+    # --- checkpoint / resume
+    def save_checkpoint(self):
+        size = C.c_uint64()
+        self.L.check(self.L.fn("world_save_checkpoint")(self.h, None, C.c_uint64(0), C.byref(size)), "world_save_checkpoint")
+        buf = np.zeros(size.value, np.uint8)
+        self.L.check(self.L.fn("world_save_checkpoint")(self.h, _ptr(buf), C.c_uint64(len(buf)), C.byref(size)), "world_save_checkpoint")
+        return buf.tobytes()
+
+    def load_checkpoint(self, blob):
+        buf = np.frombuffer(blob, np.uint8)
+        self.L.check(self.L.fn("world_load_checkpoint")(self.h, _ptr(buf), C.c_uint64(len(buf))), "world_load_checkpoint")
+
     # --- stepping
     def step(self, settings, dt):
         """physicsStep(scene, arena, timer, settings, dt) — src/physics/physics.cpp:1364."""

@@ -1342,6 +1342,95 @@ MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
     return MI_OK;
 }
 
+// ---- checkpoint / resume (the solver-relevant state of a world)
+// Everything a bit-identical continuation needs that is not the scene description itself: body states (physics_transform1,
+// velocities, accumulators), physics_transform0 + the interpolated entity transforms, the step accumulator, the SAP axis chosen
+// for the next step, the colour history (pair -> colour, which is also the previous step's collision list of the events), the
+// previous step's trigger overlaps and the constraint PODs (motors / limits may have been edited).  The blob is tied to the
+// topology: it can only be loaded into a world built from the same scene (same bodies, colliders, constraints).
+extern "C++" {
+namespace {
+struct CheckpointHeader { uint32_t magic, version, numEntities, numBodies, numColliders, numHistory, numTriggerOverlaps, sapAxis; float timer; uint32_t eventsEnabled, jointCounts[6], reserved; };
+constexpr uint32_t kCheckpointMagic = 0x4350494Du;   // "MIPC"
+template <class T> void put(std::vector<uint8_t>& out, const T* p, size_t n) { const uint8_t* b = reinterpret_cast<const uint8_t*>(p); out.insert(out.end(), b, b + n * sizeof(T)); }
+template <class T> bool take(const uint8_t*& p, const uint8_t* end, T* out, size_t n) { if ((size_t)(end - p) < n * sizeof(T)) return false; std::memcpy(out, p, n * sizeof(T)); p += n * sizeof(T); return true; }
+template <class JT> void putPods(std::vector<uint8_t>& out, const JT& j) { if (!j.pods.empty()) put(out, j.pods.data(), j.pods.size()); }
+template <class JT> bool takePods(const uint8_t*& p, const uint8_t* end, JT& j) { return j.pods.empty() || take(p, end, j.pods.data(), j.pods.size()); }
+}
+}
+MI_API int mi_world_save_checkpoint(mi_world* w, void* out, uint64_t capacity, uint64_t* out_size) {
+    if (!w || !out_size) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    HIP_TRY(hipSetDevice(w->device));
+    int rc = w->download(); if (rc != MI_OK) return rc;
+    std::vector<unsigned long long> keys; std::vector<uint32_t> vals;
+    if (w->tabValid && !w->topologyDirty) {
+        const size_t cap = (size_t)w->tabMask[w->tabCur] + 1;
+        std::vector<unsigned long long> k(cap); std::vector<uint32_t> v(cap);
+        HIP_TRY(hipMemcpy(k.data(), w->tabKeys[w->tabCur].p, cap * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        HIP_TRY(hipMemcpy(v.data(), w->tabVals[w->tabCur].p, cap * sizeof(uint32_t), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cap; ++i) if (k[i]) { keys.push_back(k[i]); vals.push_back(v[i]); }
+    }
+    CheckpointHeader h{};
+    h.magic = kCheckpointMagic; h.version = 1; h.numEntities = (uint32_t)w->entities.size(); h.numBodies = (uint32_t)w->bodies.size();
+    h.numColliders = (uint32_t)w->colliders.size(); h.numHistory = (uint32_t)keys.size(); h.numTriggerOverlaps = (uint32_t)w->prevTriggerOverlaps.size();
+    h.sapAxis = w->sapAxis; h.timer = w->timer; h.eventsEnabled = w->eventsEnabled ? 1u : 0u;
+    const JointSet& j = w->joints;
+    h.jointCounts[0] = (uint32_t)j.distance.pods.size(); h.jointCounts[1] = (uint32_t)j.ball.pods.size(); h.jointCounts[2] = (uint32_t)j.fixed.pods.size();
+    h.jointCounts[3] = (uint32_t)j.hinge.pods.size(); h.jointCounts[4] = (uint32_t)j.cone.pods.size(); h.jointCounts[5] = (uint32_t)j.slider.pods.size();
+    std::vector<uint8_t> blob;
+    put(blob, &h, 1);
+    for (const HEntity& e : w->entities) { put(blob, &e.pos, 1); put(blob, &e.rot, 1); }
+    for (const HBody& b : w->bodies) { put(blob, &b.p0, 1); put(blob, &b.r0, 1); put(blob, &b.p1, 1); put(blob, &b.r1, 1); put(blob, &b.linVel, 1); put(blob, &b.angVel, 1); put(blob, &b.force, 1); put(blob, &b.torque, 1); }
+    if (!keys.empty()) { put(blob, keys.data(), keys.size()); put(blob, vals.data(), vals.size()); }
+    if (!w->prevTriggerOverlaps.empty()) put(blob, w->prevTriggerOverlaps.data(), w->prevTriggerOverlaps.size());
+    putPods(blob, j.distance); putPods(blob, j.ball); putPods(blob, j.fixed); putPods(blob, j.hinge); putPods(blob, j.cone); putPods(blob, j.slider);
+    *out_size = blob.size();
+    if (!out) return MI_OK;
+    if (capacity < blob.size()) return fail(MI_ERR_CAPACITY, "capacity < checkpoint size");
+    std::memcpy(out, blob.data(), blob.size());
+    return MI_OK;
+}
+MI_API int mi_world_load_checkpoint(mi_world* w, const void* data, uint64_t size) {
+    if (!w || !data) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    HIP_TRY(hipSetDevice(w->device));
+    const uint8_t* p = static_cast<const uint8_t*>(data); const uint8_t* end = p + size;
+    CheckpointHeader h;
+    if (!take(p, end, &h, 1) || h.magic != kCheckpointMagic || h.version != 1) return fail(MI_ERR_INVALID_ARGUMENT, "not a checkpoint of this library version");
+    JointSet& j = w->joints;
+    const uint32_t jc[6] = {(uint32_t)j.distance.pods.size(), (uint32_t)j.ball.pods.size(), (uint32_t)j.fixed.pods.size(), (uint32_t)j.hinge.pods.size(), (uint32_t)j.cone.pods.size(), (uint32_t)j.slider.pods.size()};
+    if (h.numEntities != w->entities.size() || h.numBodies != w->bodies.size() || h.numColliders != w->colliders.size() || std::memcmp(jc, h.jointCounts, sizeof(jc)) != 0)
+        return fail(MI_ERR_INVALID_ARGUMENT, "checkpoint belongs to a different scene (entity / body / collider / constraint counts differ)");
+    int rc = w->download(); if (rc != MI_OK) return rc;   // the host copy becomes authoritative; everything is re-sent before the next step
+    bool okay = true;
+    for (HEntity& e : w->entities) okay = okay && take(p, end, &e.pos, 1) && take(p, end, &e.rot, 1);
+    for (HBody& b : w->bodies) okay = okay && take(p, end, &b.p0, 1) && take(p, end, &b.r0, 1) && take(p, end, &b.p1, 1) && take(p, end, &b.r1, 1) && take(p, end, &b.linVel, 1) && take(p, end, &b.angVel, 1) && take(p, end, &b.force, 1) && take(p, end, &b.torque, 1);
+    std::vector<unsigned long long> keys(h.numHistory); std::vector<uint32_t> vals(h.numHistory);
+    okay = okay && take(p, end, keys.data(), keys.size()) && take(p, end, vals.data(), vals.size());
+    w->prevTriggerOverlaps.resize(h.numTriggerOverlaps);
+    okay = okay && take(p, end, w->prevTriggerOverlaps.data(), w->prevTriggerOverlaps.size());
+    okay = okay && takePods(p, end, j.distance) && takePods(p, end, j.ball) && takePods(p, end, j.fixed) && takePods(p, end, j.hinge) && takePods(p, end, j.cone) && takePods(p, end, j.slider);
+    if (!okay || p != end) return fail(MI_ERR_INVALID_ARGUMENT, "truncated or oversized checkpoint");
+    w->timer = h.timer; w->sapAxis = h.sapAxis; w->eventsEnabled = h.eventsEnabled != 0; w->pendingEvents.clear();
+    w->topologyDirty = true; w->haveEstimates = false;
+    // colour history: same open-addressing layout the kernels probe (tableSlot / linear probing)
+    w->tabValid = !keys.empty();
+    if (w->tabValid) {
+        uint32_t cap = 1024; while (cap < 2u * h.numHistory) cap <<= 1;
+        std::vector<unsigned long long> tk(cap, 0ull); std::vector<uint32_t> tv(cap, 0u);
+        for (uint32_t i = 0; i < h.numHistory; ++i) {
+            uint32_t s_ = (uint32_t)((keys[i] * 0x9E3779B97F4A7C15ull) >> 40) & (cap - 1u);
+            while (tk[s_]) s_ = (s_ + 1u) & (cap - 1u);
+            tk[s_] = keys[i]; tv[s_] = vals[i];
+        }
+        const int c = w->tabCur;
+        HIP_TRY(w->tabKeys[c].ensure(cap)); HIP_TRY(w->tabVals[c].ensure(cap)); w->tabMask[c] = cap - 1u;
+        HIP_TRY(hipMemcpy(w->tabKeys[c].p, tk.data(), cap * sizeof(unsigned long long), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(w->tabVals[c].p, tv.data(), cap * sizeof(uint32_t), hipMemcpyHostToDevice));
+        w->last.numManifolds = h.numHistory;
+    }
+    return MI_OK;
+}
+
 MI_API int mi_world_enable_events(mi_world* w, uint32_t enable) {
     if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     w->eventsEnabled = enable != 0; w->pendingEvents.clear(); w->prevTriggerOverlaps.clear();

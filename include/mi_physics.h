@@ -266,6 +266,15 @@ MI_API int mi_world_get_aabbs(mi_world* world, float* out_min_max6, uint32_t cap
 MI_API int mi_world_get_manifold_colors(mi_world* world, uint32_t* out_colors, uint32_t capacity);
 
 /*
+ * Checkpoint / resume of the solver-relevant state: body states and accumulators, physics_transform0 and the
+ * interpolated transforms, the step accumulator, the SAP axis of the next step, the contact-colour history (= the previous
+ * step's collision list), the previous trigger overlaps, the constraint PODs.  A world built from the same scene description
+ * that loads the blob continues bit-identically to the world that saved it.  save: out == NULL only reports the size.
+ */
+MI_API int mi_world_save_checkpoint(mi_world* world, void* out, uint64_t capacity, uint64_t* out_size);
+MI_API int mi_world_load_checkpoint(mi_world* world, const void* data, uint64_t size);
+
+/*
  * Collision events — collisionBeginCallback / collisionEndCallback of physics_settings (src/physics/physics.h:398-399),
  * fired by handleCollisionCallbacks (src/physics/physics.cpp:1041-1178).  The reference calls std::function callbacks
  * synchronously inside the step; across a C ABI they are polled: events of the internal steps since the last poll, per step

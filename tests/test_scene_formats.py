@@ -1,0 +1,133 @@
+"""Scene import / export in the reference's YAML schema (src/scene/serialization_yaml.cpp:74-233, 364-524) and the
+checkpoint of the solver-relevant state."""
+import numpy as np
+import pytest
+
+from d3d12renderer_amd import capi, scene_yaml, scenes
+
+REFERENCE_STYLE = """
+Scene: My scene
+Camera: {Position: [0, 5, 10], Rotation: [0, 0, 0, 1], Near plane: 0.1}
+Entities:
+  - Tag: Platform
+    Transform: {Position: [0, -0.5, 0], Rotation: [0, 0, 0, 1], Scale: [1, 1, 1]}
+    Mesh: {Handle: 1234, Flags: 0}
+    Colliders:
+      - {Type: AABB, Min corner: [-10, -0.5, -10], Max corner: [10, 0.5, 10], Restitution: 0.1, Friction: 1, Density: 4}
+  - Tag: Ball
+    Transform: {Position: [0.1, 3, 0], Rotation: [0, 0, 0, 1], Scale: [1, 1, 1]}
+    Dynamic: true
+    Rigid body: {Local COG: [0, 0, 0], Inv mass: 0.25, Inv inertia: [1, 0, 0, 0, 1, 0, 0, 0, 1], Gravity factor: 1, Linear damping: 0.4, Angular damping: 0.4}
+    Colliders:
+      - {Type: Sphere, Center: [0, 0, 0], Radius: 0.5, Restitution: 0.3, Friction: 0.6, Density: 2}
+  - Tag: Crate
+    Transform: {Position: [0.3, 1, 0.2], Rotation: [0, 0.38268343, 0, 0.92387953], Scale: [1, 1, 1]}
+    Dynamic: true
+    Rigid body: {Local COG: [0, 0, 0], Inv mass: 1, Inv inertia: [1, 0, 0, 0, 1, 0, 0, 0, 1], Gravity factor: 0.5, Linear damping: 0.1, Angular damping: 0.2}
+    Colliders:
+      - {Type: OBB, Center: [0, 0, 0], Radius: [0.5, 0.4, 0.3], Rotation: [0, 0, 0, 1], Restitution: 0.1, Friction: 0.5, Density: 1}
+      - {Type: Capsule, Position A: [0, 0.4, 0], Position B: [0, 0.9, 0], Radius: 0.2, Restitution: 0.1, Friction: 0.5, Density: 1}
+  - Tag: Mover
+    Transform: {Position: [4, 1, 0], Rotation: [0, 0, 0, 1], Scale: [1, 1, 1]}
+    Rigid body: {Local COG: [0, 0, 0], Inv mass: 0, Inv inertia: [0, 0, 0, 0, 0, 0, 0, 0, 0], Gravity factor: 1, Linear damping: 0.4, Angular damping: 0.4}
+    Colliders:
+      - {Type: AABB, Min corner: [-1, -1, -1], Max corner: [1, 1, 1], Restitution: 0.1, Friction: 0.5, Density: 1}
+  - Tag: Wind
+    Transform: {Position: [0, 0, 0], Rotation: [0, 0, 0, 1], Scale: [1, 1, 1]}
+    Force field: {Force: [1.5, 0, 0]}
+  - Tag: Lamp
+    Position: {Position: [0, 8, 0]}
+    Point light: {Color: [1, 1, 1], Intensity: 10, Radius: 20}
+"""
+
+
+def test_load_reference_style_scene_and_simulate(oracle_mod):
+    sc = scene_yaml.load_scene(REFERENCE_STYLE)
+    assert sc.tags == ["Platform", "Ball", "Crate", "Mover", "Wind", "Lamp"]
+    k = sc.entities["kind"]
+    assert list(k) == [capi.ENTITY_STATIC, capi.ENTITY_DYNAMIC, capi.ENTITY_DYNAMIC, capi.ENTITY_KINEMATIC, capi.ENTITY_FORCE_FIELD, capi.ENTITY_STATIC]
+    assert len(sc.colliders) == 5 and list(sc.collider_entities) == [0, 1, 2, 2, 3]
+    assert np.allclose(sc.entities["gravity_factor"][2], 0.5) and sc.forces == [(4, (1.5, 0, 0))]
+    assert np.allclose(sc.colliders["shape"][2, :10], (0, 0, 0, 1, 0, 0, 0, 0.5, 0.4, 0.3))     # OBB: rotation, centre, radius
+    w = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_REFERENCE))
+    im, _, _ = w.mass_properties()
+    assert np.isclose(1 / im[1], 2 * 4 / 3 * np.pi * 0.5 ** 3, rtol=1e-5)                       # recomputed from the collider, not "Inv mass: 0.25"
+    assert im[3] == 0                                                                          # kinematic
+    w.step_fixed(sc.settings(), sc.dt, 240)
+    p, _ = w.physics_transforms()
+    assert abs(p[1, 1] - 0.5) < 0.05 and p[1, 0] > 0.15          # the ball rests on the platform, blown along +x by the global field
+    assert np.allclose(p[3], (4, 1, 0)) and np.allclose(p[5], (0, 8, 0))
+
+
+def test_yaml_round_trip_is_exact(oracle_mod):
+    sc = scenes.mixed_stack(5, 3, 5)
+    w = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    text = scene_yaml.dump_scene(sc, w)
+    back = scene_yaml.load_scene(text, solver_iterations=sc.solver_iterations)
+    assert back.entities.tobytes() == sc.entities.tobytes() and back.colliders.tobytes() == sc.colliders.tobytes()
+    assert np.array_equal(back.collider_entities, sc.collider_entities)
+    a = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)); b = back.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    a.step_fixed(sc.settings(), sc.dt, 60); b.step_fixed(back.settings(), back.dt, 60)
+    assert a.physics_transforms()[0].tobytes() == b.physics_transforms()[0].tobytes()
+    # like the reference, saving walks an entity's collider list newest first, so a multi-collider entity comes back reversed
+    multi = scene_yaml.load_scene(scene_yaml.dump_scene(scene_yaml.load_scene(REFERENCE_STYLE)))
+    assert [int(t) for t in multi.colliders["type"][multi.collider_entities == 2]] == [capi.CAPSULE, capi.OBB]
+    # what the format cannot hold is refused, not dropped silently
+    with pytest.raises(ValueError):
+        scene_yaml.dump_scene(scenes.ragdolls(1, 1))          # constraints
+    with pytest.raises(ValueError):
+        scene_yaml.dump_scene(scenes.shape_zoo(2, 2, 2))      # cylinders / hulls
+    with pytest.raises(ValueError):
+        scene_yaml.load_scene("Camera: {Near plane: 0.1}\nSun: {Intensity: 50}\n")
+
+
+@pytest.mark.gpu
+def test_gpu_yaml_scene_matches_oracle(mi_lib, oracle_mod):
+    sc = scene_yaml.load_scene(REFERENCE_STYLE)
+    g = sc.populate(mi_lib.create_world(0)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    for i in range(200):
+        g.step_fixed(sc.settings(), sc.dt, 1); o.step_fixed(sc.settings(), sc.dt, 1)
+        assert g.counts() == o.counts(), f"step {i}"
+    assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("make,events", [(lambda: scenes.zones(), True), (lambda: scenes.ragdolls(3, 3), False), (lambda: scenes.terrain_field(6, 2, 6), False)])
+def test_gpu_checkpoint_resume_is_bit_identical(mi_lib, oracle_mod, make, events):
+    """Save after 70 steps, load into a FRESH world built from the same scene, continue: poses, velocities, counts and events
+    equal the uninterrupted run (and the oracle) bit for bit — colour history, SAP axis, trigger overlaps, accumulators, motor
+    PODs and the step accumulator all travel in the blob."""
+    sc = make()
+    s = sc.settings()
+    a = sc.populate(mi_lib.create_world(0)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    if events:
+        a.enable_events(); o.enable_events()
+    nh = 6 * 9
+    def drive(w, it):
+        if sc.constraints and it % 5 == 0:       # ragdolls: keep editing the hinge motors
+            pods = np.concatenate([w.get_constraint(capi.CONSTRAINT_HINGE, i) for i in range(nh)])
+            pods["motor_type"] = 1; pods["max_motor_torque"] = 150.0; pods["motor_velocity_or_target_angle"] = 0.4 * np.sin(0.1 * it)
+            w.update_constraints(capi.CONSTRAINT_HINGE, np.arange(nh), pods)
+        w.step(s, 1.0 / 90.0)                     # physicsStep with a frame time that is not a multiple of the fixed step
+    for it in range(70):
+        drive(a, it); drive(o, it)
+        if events:
+            assert a.poll_events().tobytes() == o.poll_events().tobytes()
+    blob = a.save_checkpoint()
+    b = sc.populate(mi_lib.create_world(0))
+    if events:
+        b.enable_events()
+    b.load_checkpoint(blob)
+    assert b.transforms()[0].tobytes() == a.transforms()[0].tobytes()
+    for it in range(70, 140):
+        drive(a, it); drive(b, it); drive(o, it)
+        assert a.counts() == b.counts() == o.counts(), f"step {it}"
+        if events:
+            ea = a.poll_events()
+            assert ea.tobytes() == b.poll_events().tobytes() == o.poll_events().tobytes()
+    for x, y, z in zip(a.transforms() + a.velocities(), b.transforms() + b.velocities(), o.transforms() + o.velocities()):
+        assert x.tobytes() == y.tobytes() == z.tobytes()
+    with pytest.raises(mi_lib.PhysicsError):
+        scenes.obb_pile(3, 2, 3).populate(mi_lib.create_world(0)).load_checkpoint(blob)     # other scene
+    with pytest.raises(mi_lib.PhysicsError):
+        b.load_checkpoint(blob[:-8])                                                         # truncated
