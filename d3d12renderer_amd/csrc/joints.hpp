@@ -550,6 +550,66 @@ __global__ void k_joint_solve_serial(uint32_t s0, uint32_t s1, const uint32_t* _
     }
 }
 
+// ---- articulated islands: ONE launch per sweep for all joint types ---------------------------------------------------
+// Joints only couple the bodies of their own articulated island (a ragdoll, a vehicle): islands share no dynamic body, so
+// their joint phases are independent and need no ordering against each other.  One wave per island runs the island's joints
+// of a sweep in the canonical order — type-major (distance, ball, fixed, hinge, cone-twist, slider: constraints.cpp:3764-3769),
+// colour-major inside a type — one lane per joint, active when its (type, colour) group is up, the island's body velocities
+// staged in LDS between groups.  A sweep's joint phase is then one launch instead of one per (type, colour): 8-15 launches less per
+// sweep on the ragdoll / vehicle configurations, where launch latency, not work, bounded the solver.  Islands with more than
+// 64 bodies or more than 64 joints (or an overflow-coloured joint) stay on the per-colour kernels above.
+struct IslandStep { uint32_t joint; uint16_t a, b, type, group; };   // joint index in its type's arrays; island-local body slots; (type, colour) group
+struct IslandDesc { uint32_t bodyBegin, numBodies, stepBegin, numJoints; uint32_t typeGroups[7]; };   // groups of type t: [typeGroups[t], typeGroups[t + 1])
+struct IslandUpd { DistanceJ::Upd* distance; BallJ::Upd* ball; FixedJ::Upd* fixed; HingeJ::Upd* hinge; ConeJ::Upd* cone; SliderJ::Upd* slider; };
+constexpr uint32_t kIslandMaxBodies = 64, kIslandMaxJoints = 64;
+
+struct IslandLds { float4 v[kIslandMaxBodies], w[kIslandMaxBodies], inertia[3 * kIslandMaxBodies]; float invMass[kIslandMaxBodies]; };
+// One joint type of one island: the lanes owning a joint of this type keep its per-step data (Upd) in registers across the
+// type's colour groups — one global round trip per type and sweep, not one per group.
+template <class J>
+__device__ __forceinline__ void islandType(uint32_t type, const IslandDesc& d, bool hasJoint, const IslandStep& st, typename J::Upd* __restrict__ upd, IslandLds& lds) {
+    const uint32_t g0 = d.typeGroups[type], g1 = d.typeGroups[type + 1];
+    if (g0 == g1) return;   // wave-uniform
+    const bool mine = hasJoint && st.type == type;
+    typename J::Upd c;
+    if (mine) c = upd[st.joint];
+    for (uint32_t g = g0; g < g1; ++g) {
+        if (mine && st.group == g) {
+            BodyVel A, B;
+            { float4 a = lds.v[st.a], w = lds.w[st.a]; A.v = xyz(a); A.tagV = a.w; A.w = xyz(w); A.tagW = w.w; A.invMass = lds.invMass[st.a]; A.invI = ldM3(lds.inertia, st.a); }
+            { float4 a = lds.v[st.b], w = lds.w[st.b]; B.v = xyz(a); B.tagV = a.w; B.w = xyz(w); B.tagW = w.w; B.invMass = lds.invMass[st.b]; B.invI = ldM3(lds.inertia, st.b); }
+            J::solve(c, A, B);
+            if (A.invMass != 0.f) { lds.v[st.a] = f4(A.v, A.tagV); lds.w[st.a] = f4(A.w, A.tagW); }   // kinematic bodies are never changed by impulses
+            if (B.invMass != 0.f) { lds.v[st.b] = f4(B.v, B.tagV); lds.w[st.b] = f4(B.w, B.tagW); }
+        }
+        __syncthreads();
+    }
+    if (mine) upd[st.joint] = c;
+}
+__global__ __launch_bounds__(64) void k_joint_islands(const IslandDesc* __restrict__ islands, const IslandStep* __restrict__ steps,
+                                                      const uint32_t* __restrict__ islandBodies, IslandUpd upd, BodyView bv) {
+    __shared__ IslandLds lds;
+    const IslandDesc d = islands[blockIdx.x];
+    const uint32_t lane = threadIdx.x;
+    uint32_t body = 0;
+    if (lane < d.numBodies) {
+        body = islandBodies[d.bodyBegin + lane];
+        lds.v[lane] = bv.gVel[2 * body]; lds.w[lane] = bv.gVel[2 * body + 1]; lds.invMass[lane] = bv.gPos[body].w;
+        lds.inertia[3 * lane] = bv.gInvI[3 * body]; lds.inertia[3 * lane + 1] = bv.gInvI[3 * body + 1]; lds.inertia[3 * lane + 2] = bv.gInvI[3 * body + 2];
+    }
+    const bool hasJoint = lane < d.numJoints;
+    IslandStep st{};
+    if (hasJoint) st = steps[d.stepBegin + lane];
+    __syncthreads();
+    islandType<DistanceJ>(0, d, hasJoint, st, upd.distance, lds);
+    islandType<BallJ>(1, d, hasJoint, st, upd.ball, lds);
+    islandType<FixedJ>(2, d, hasJoint, st, upd.fixed, lds);
+    islandType<HingeJ>(3, d, hasJoint, st, upd.hinge, lds);
+    islandType<ConeJ>(4, d, hasJoint, st, upd.cone, lds);
+    islandType<SliderJ>(5, d, hasJoint, st, upd.slider, lds);
+    if (lane < d.numBodies && lds.invMass[lane] != 0.f) { bv.gVel[2 * body] = lds.v[lane]; bv.gVel[2 * body + 1] = lds.w[lane]; }
+}
+
 }  // namespace mi
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -559,8 +619,10 @@ template <class J>
 struct JointType {
     std::vector<typename J::Pod> pods;
     std::vector<uint2> bodies;          // rigid body indices (A, B)
-    std::vector<uint32_t> order;        // colour-major, index-minor
+    std::vector<uint32_t> order;        // colour-major, index-minor; only the joints the per-colour kernels solve (see JointSet::buildIslands)
     std::vector<uint32_t> colorOffsets; // [0..65] boundaries into order (64 = overflow colour)
+    std::vector<uint32_t> colorOf;      // colour of every joint of this type
+    std::vector<uint8_t> inIsland;      // joint is solved by k_joint_islands
     typename J::Pod* dPods = nullptr; uint2* dBodies = nullptr; uint32_t* dOrder = nullptr; typename J::Upd* dUpd = nullptr;
     size_t dCap = 0;
     ~JointType() { release(); }
@@ -586,9 +648,16 @@ struct JointType {
             if (dynA) used[bp.x] |= 1ull << c;
             if (dynB) used[bp.y] |= 1ull << c;
         }
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return color[a] < color[b]; });
+        colorOf = color;
+        inIsland.assign(n, 0);
+    }
+    // after JointSet::buildIslands has claimed its joints: the colour-sorted order of the rest
+    void finishOrder() {
+        order.clear();
+        for (uint32_t i = 0; i < (uint32_t)bodies.size(); ++i) if (!inIsland[i]) order.push_back(i);
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return colorOf[a] < colorOf[b]; });
         colorOffsets.assign(66, 0);
-        for (uint32_t i = 0; i < n; ++i) colorOffsets[color[order[i]] + 1]++;
+        for (uint32_t i : order) colorOffsets[colorOf[i] + 1]++;
         for (int c = 0; c < 65; ++c) colorOffsets[c + 1] += colorOffsets[c];
     }
     hipError_t upload(hipStream_t st) {
@@ -606,7 +675,8 @@ struct JointType {
         hipError_t e;
         if ((e = hipMemcpyAsync(dPods, pods.data(), n * sizeof(typename J::Pod), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
         if ((e = hipMemcpyAsync(dBodies, bodies.data(), n * sizeof(uint2), hipMemcpyHostToDevice, st)) != hipSuccess) return e;
-        return hipMemcpyAsync(dOrder, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, st);
+        if (order.empty()) return hipSuccess;
+        return hipMemcpyAsync(dOrder, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
     }
     bool podsDirty = false;   // mi_constraint_update since the last upload: only the POD array changed (motors, limits), not the topology
     hipError_t uploadPods(hipStream_t st) {
@@ -619,7 +689,7 @@ struct JointType {
         if (n) mi::k_joint_init<J><<<(n + 63) / 64, 64, 0, st>>>(n, dummy, dPods, dBodies, dUpd, bv, dt);
     }
     void launchSolve(const mi::BodyView& bv, hipStream_t st) {
-        if (pods.empty()) return;
+        if (order.empty()) return;
         for (int c = 0; c < 64; ++c) {
             uint32_t s0 = colorOffsets[c], s1 = colorOffsets[c + 1];
             if (s1 > s0) mi::k_joint_solve<J><<<(s1 - s0 + 63) / 64, 64, 0, st>>>(s0, s1, dOrder, dBodies, dUpd, bv);
@@ -639,6 +709,15 @@ struct JointSet {
     int get(uint32_t type, uint32_t id, void* pod, uint32_t bytes);
     int addFromGlobal(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb, const float* anchor, const float* axis, float l0, float l1, uint32_t* out);
     int upload(mi_world& w, hipStream_t st);
+    // articulated islands (k_joint_islands)
+    uint32_t numIslands = 0;
+    mi::IslandDesc* dIslands = nullptr; mi::IslandStep* dSteps = nullptr; uint32_t* dIslandBodies = nullptr;
+    void buildIslands(const std::vector<float>& invMass, std::vector<mi::IslandDesc>& islands, std::vector<mi::IslandStep>& steps, std::vector<uint32_t>& islandBodies);
+    ~JointSet() { releaseIslands(); }
+    void releaseIslands() {
+        if (dIslands) (void)hipFree(dIslands); if (dSteps) (void)hipFree(dSteps); if (dIslandBodies) (void)hipFree(dIslandBodies);
+        dIslands = nullptr; dSteps = nullptr; dIslandBodies = nullptr; numIslands = 0;
+    }
     bool podsDirty() const { return distance.podsDirty || ball.podsDirty || fixed.podsDirty || hinge.podsDirty || cone.podsDirty || slider.podsDirty; }
     int uploadPods(hipStream_t st);
     int initialize(mi_world& w, float dt, hipStream_t st);

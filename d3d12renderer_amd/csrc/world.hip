@@ -1047,10 +1047,80 @@ int JointSet::upload(mi_world& w, hipStream_t st) {
     for (size_t i = 0; i < w.bodies.size(); ++i) invMass[i] = w.bodies[i].invMass;
     distance.computeOrder(invMass); ball.computeOrder(invMass); fixed.computeOrder(invMass);
     hinge.computeOrder(invMass); cone.computeOrder(invMass); slider.computeOrder(invMass);
+    {
+        std::vector<IslandDesc> islands; std::vector<IslandStep> steps; std::vector<uint32_t> islandBodies;
+        static const bool useIslands = !(std::getenv("MI_JOINT_ISLANDS") && std::getenv("MI_JOINT_ISLANDS")[0] == '0');
+        if (useIslands) buildIslands(invMass, islands, steps, islandBodies);
+        releaseIslands();
+        if (!islands.empty()) {
+            HIP_TRY(hipMalloc((void**)&dIslands, islands.size() * sizeof(IslandDesc)));
+            HIP_TRY(hipMalloc((void**)&dSteps, steps.size() * sizeof(IslandStep))); HIP_TRY(hipMalloc((void**)&dIslandBodies, islandBodies.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpyAsync(dIslands, islands.data(), islands.size() * sizeof(IslandDesc), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(dSteps, steps.data(), steps.size() * sizeof(IslandStep), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(dIslandBodies, islandBodies.data(), islandBodies.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));   // the staging vectors are locals
+            numIslands = (uint32_t)islands.size();
+        }
+    }
+    distance.finishOrder(); ball.finishOrder(); fixed.finishOrder(); hinge.finishOrder(); cone.finishOrder(); slider.finishOrder();
     HIP_TRY(distance.upload(st)); HIP_TRY(ball.upload(st)); HIP_TRY(fixed.upload(st));
     HIP_TRY(hinge.upload(st)); HIP_TRY(cone.upload(st)); HIP_TRY(slider.upload(st));
     distance.podsDirty = ball.podsDirty = fixed.podsDirty = hinge.podsDirty = cone.podsDirty = slider.podsDirty = false;
     return MI_OK;
+}
+// Connected components of the joint graph over DYNAMIC bodies; an island small enough for one wave gets a program of
+// (type, colour) groups in canonical order, the rest stays with the per-colour kernels.
+void JointSet::buildIslands(const std::vector<float>& invMass, std::vector<IslandDesc>& islands, std::vector<IslandStep>& steps, std::vector<uint32_t>& islandBodies) {
+    const uint32_t nb = (uint32_t)invMass.size();
+    std::vector<uint32_t> parent(nb);
+    for (uint32_t i = 0; i < nb; ++i) parent[i] = i;
+    auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    struct Ref { uint32_t type, joint, color; uint2 bodies; };
+    std::vector<Ref> all;
+    auto collect = [&](uint32_t type, const std::vector<uint2>& bodies, const std::vector<uint32_t>& colorOf) {
+        for (uint32_t j = 0; j < (uint32_t)bodies.size(); ++j) {
+            uint2 b = bodies[j];
+            bool dynA = b.x < nb && invMass[b.x] != 0.f, dynB = b.y < nb && invMass[b.y] != 0.f;
+            if (dynA && dynB) parent[find(b.x)] = find(b.y);
+            all.push_back(Ref{type, j, colorOf[j], b});
+        }
+    };
+    collect(0, distance.bodies, distance.colorOf); collect(1, ball.bodies, ball.colorOf); collect(2, fixed.bodies, fixed.colorOf);
+    collect(3, hinge.bodies, hinge.colorOf); collect(4, cone.bodies, cone.colorOf); collect(5, slider.bodies, slider.colorOf);
+    // joints by island root (a joint between two non-dynamic bodies does nothing; it stays with the per-colour kernels)
+    std::vector<std::vector<uint32_t>> byRoot(nb);
+    for (uint32_t r = 0; r < (uint32_t)all.size(); ++r) {
+        const Ref& ref = all[r];
+        bool dynA = ref.bodies.x < nb && invMass[ref.bodies.x] != 0.f, dynB = ref.bodies.y < nb && invMass[ref.bodies.y] != 0.f;
+        if (dynA || dynB) byRoot[find(dynA ? ref.bodies.x : ref.bodies.y)].push_back(r);
+    }
+    uint8_t* flags[6] = {distance.inIsland.data(), ball.inIsland.data(), fixed.inIsland.data(), hinge.inIsland.data(), cone.inIsland.data(), slider.inIsland.data()};
+    for (uint32_t root = 0; root < nb; ++root) {
+        std::vector<uint32_t>& js = byRoot[root];
+        if (js.empty()) continue;
+        std::stable_sort(js.begin(), js.end(), [&](uint32_t x, uint32_t y) { return all[x].type != all[y].type ? all[x].type < all[y].type : all[x].color < all[y].color; });
+        std::vector<uint32_t> slots;   // island-local body table (dynamic and static bodies alike; the static dummy is body index nb)
+        auto slotOf = [&](uint32_t body) { for (uint32_t k = 0; k < (uint32_t)slots.size(); ++k) if (slots[k] == body) return k; slots.push_back(body); return (uint32_t)slots.size() - 1u; };
+        bool fits = js.size() <= kIslandMaxJoints;
+        std::vector<IslandStep> st;
+        IslandDesc d{};
+        uint32_t group = 0;   // groups are numbered type-major, colour-major within the island
+        for (size_t k = 0; fits && k < js.size(); ++k) {
+            const Ref& ref = all[js[k]];
+            if (ref.color >= 64u) { fits = false; break; }
+            if (k > 0 && (all[js[k - 1]].type != ref.type || all[js[k - 1]].color != ref.color)) ++group;
+            st.push_back(IslandStep{ref.joint, (uint16_t)slotOf(ref.bodies.x), (uint16_t)slotOf(ref.bodies.y), (uint16_t)ref.type, (uint16_t)group});
+            d.typeGroups[ref.type + 1] = group + 1;   // end of this type's groups so far
+            if (slots.size() > kIslandMaxBodies) fits = false;
+        }
+        if (!fits) continue;
+        for (uint32_t t = 1; t <= 6; ++t) d.typeGroups[t] = std::max(d.typeGroups[t], d.typeGroups[t - 1]);   // absent types: empty range
+        d.bodyBegin = (uint32_t)islandBodies.size(); d.numBodies = (uint32_t)slots.size(); d.stepBegin = (uint32_t)steps.size(); d.numJoints = (uint32_t)st.size();
+        steps.insert(steps.end(), st.begin(), st.end());
+        islandBodies.insert(islandBodies.end(), slots.begin(), slots.end());
+        islands.push_back(d);
+        for (uint32_t r : js) flags[all[r].type][all[r].joint] = 1;
+    }
 }
 static BodyView bodyView(mi_world& w) { return BodyView{w.gPos.p, w.gInvI.p, w.gVel.p, w.bRot.p, w.bCogInvMass.p}; }
 int JointSet::initialize(mi_world& w, float dt, hipStream_t st) {
@@ -1064,6 +1134,7 @@ int JointSet::initialize(mi_world& w, float dt, hipStream_t st) {
 void JointSet::solveIteration(mi_world& w, hipStream_t st) {
     if (!count()) return;
     BodyView bv = bodyView(w);
+    if (numIslands) k_joint_islands<<<numIslands, 64, 0, st>>>(dIslands, dSteps, dIslandBodies, IslandUpd{distance.dUpd, ball.dUpd, fixed.dUpd, hinge.dUpd, cone.dUpd, slider.dUpd}, bv);
     distance.launchSolve(bv, st); ball.launchSolve(bv, st); fixed.launchSolve(bv, st);
     hinge.launchSolve(bv, st); cone.launchSolve(bv, st); slider.launchSolve(bv, st);
 }
