@@ -31,7 +31,7 @@ def needs_build():
 
 LEARNING_LIB = HERE / "libPhysics-Lib.so"      # the reference's learning DLL ("Physics-Lib.dll") over libmi_physics.so
 LEARNING_SRC = CSRC / "learning.cpp"
-HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math"]
+HOST_FLAGS = ["-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math", "-fopenmp"]
 
 
 def build_learning(force=False, verbose=False):

@@ -65,6 +65,10 @@ struct F2 { float x, y; };
 struct DistanceJ {
     typedef mi_distance_constraint Pod;
     struct Upd { V3 rA, rB, iwA, iwB, u; float bias, effMass; };
+    // impulses accumulated ACROSS sweeps (what a later sweep must see of an earlier one): none — every sweep is a plain velocity solve
+    static constexpr int kAcc = 0;
+    __device__ static void getAcc(const Upd&, float*) {}
+    __device__ static void setAcc(Upd&, const float*) {}
     __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
         float invDt = 1.f / dt;
         o.rA = rotate(A.rot, ld3(in.local_anchor_a) - A.cog);
@@ -97,6 +101,10 @@ struct DistanceJ {
 struct BallJ {
     typedef mi_ball_constraint Pod;
     struct Upd { V3 rA, rB, bias; M3 invEff; };
+    // impulses accumulated ACROSS sweeps (what a later sweep must see of an earlier one): none — every sweep is a plain velocity solve
+    static constexpr int kAcc = 0;
+    __device__ static void getAcc(const Upd&, float*) {}
+    __device__ static void setAcc(Upd&, const float*) {}
     __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
         float invDt = 1.f / dt;
         o.rA = rotate(A.rot, ld3(in.local_anchor_a) - A.cog);
@@ -117,6 +125,10 @@ struct BallJ {
 struct FixedJ {
     typedef mi_fixed_constraint Pod;
     struct Upd { V3 rA, rB, tBias, rBias; M3 invEffT, invEffR; };
+    // impulses accumulated ACROSS sweeps (what a later sweep must see of an earlier one): none — every sweep is a plain velocity solve
+    static constexpr int kAcc = 0;
+    __device__ static void getAcc(const Upd&, float*) {}
+    __device__ static void setAcc(Upd&, const float*) {}
     __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
         float invDt = 1.f / dt;
         o.rA = rotate(A.rot, ld3(in.local_anchor_a) - A.cog);
@@ -154,6 +166,9 @@ struct HingeJ {
         uint32_t solveLimit, solveMotor; V3 axis; float limitImpulse, effAxial, limitSign, maxMotorImpulse, motorImpulse, motorVelocity, limitBias;
         V3 mlA, mlB;
     };
+    static constexpr int kAcc = 2;   // the clamped accumulators: limit and motor impulse
+    __device__ static void getAcc(const Upd& c, float* a) { a[0] = c.limitImpulse; a[1] = c.motorImpulse; }
+    __device__ static void setAcc(Upd& c, const float* a) { c.limitImpulse = a[0]; c.motorImpulse = a[1]; }
     __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
         float invDt = 1.f / dt;
         o.rA = rotate(A.rot, ld3(in.local_anchor_a) - A.cog);
@@ -259,6 +274,9 @@ struct ConeJ {
         float twistImpulse; V3 twistAxis; float effTwist, twistLimitSign, maxTwistMotorImpulse, twistMotorImpulse, twistMotorVelocity, twistLimitBias;
         V3 tmA, tmB;
     };
+    static constexpr int kAcc = 4;
+    __device__ static void getAcc(const Upd& c, float* a) { a[0] = c.swingImpulse; a[1] = c.swingMotorImpulse; a[2] = c.twistImpulse; a[3] = c.twistMotorImpulse; }
+    __device__ static void setAcc(Upd& c, const float* a) { c.swingImpulse = a[0]; c.swingMotorImpulse = a[1]; c.twistImpulse = a[2]; c.twistMotorImpulse = a[3]; }
     __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
         float invDt = 1.f / dt;
         o.solveSwingLimit = o.solveSwingMotor = o.solveTwistLimit = o.solveTwistMotor = 0;
@@ -404,6 +422,9 @@ struct SliderJ {
         V3 axis; uint32_t solveLimit, solveMotor; float limitImpulse; V3 rAuxs, rBxs; float effAxial, limitSign, limitBias; V3 llA, llB;
         float maxMotorImpulse, motorImpulse, motorVelocity;
     };
+    static constexpr int kAcc = 2;
+    __device__ static void getAcc(const Upd& c, float* a) { a[0] = c.limitImpulse; a[1] = c.motorImpulse; }
+    __device__ static void setAcc(Upd& c, const float* a) { c.limitImpulse = a[0]; c.motorImpulse = a[1]; }
     __device__ static void init(const Pod& in, const BodyState& A, const BodyState& B, float dt, Upd& o) {
         float invDt = 1.f / dt;
         V3 rA = rotate(A.rot, ld3(in.local_anchor_a) - A.cog);
@@ -510,7 +531,7 @@ struct SliderJ {
 
 template <class J>
 __global__ __launch_bounds__(64) void k_joint_init(uint32_t n, uint32_t dummy, const typename J::Pod* __restrict__ pods, const uint2* __restrict__ bodies,
-                                                   typename J::Upd* __restrict__ upd, BodyView bv, float dt) {
+                                                   typename J::Upd* __restrict__ upd, float4* __restrict__ acc, BodyView bv, float dt) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint2 b = bodies[i];
@@ -519,6 +540,8 @@ __global__ __launch_bounds__(64) void k_joint_init(uint32_t n, uint32_t dummy, c
     typename J::Upd o;
     J::init(in, A, B, dt, o);
     upd[i] = o;
+    // accumulator granules of the fused solver (x, y = two accumulators, z = sweeps completed): start of the step
+    if (J::kAcc > 0) { float a[4] = {0.f, 0.f, 0.f, 0.f}; J::getAcc(o, a); acc[2 * i] = make_float4(a[0], a[1], 0.f, 0.f); acc[2 * i + 1] = make_float4(a[2], a[3], 0.f, 0.f); }
 }
 // One colour of one joint type: lanes [s0, s1) of the colour-sorted order own disjoint dynamic bodies.
 template <class J>
@@ -610,6 +633,134 @@ __global__ __launch_bounds__(64) void k_joint_islands(const IslandDesc* __restri
     if (lane < d.numBodies && lds.invMass[lane] != 0.f) { bv.gVel[2 * body] = lds.v[lane]; bv.gVel[2 * body + 1] = lds.w[lane]; }
 }
 
+// ---- contacts AND joints of all sweeps in one launch --------------------------------------------------------------------
+// When every joint lives in an island, the joint phase joins the dataflow solver (k_contact_solve_flow): per sweep the grid
+// holds the islands first, then the contact tiles.  A body in an island gets one more version per sweep: the island block of
+// sweep `it` waits until each of its dynamic bodies carries tag it * (deg + 1) (deg = contact colours on the body: every
+// contact update of the previous sweep has landed), solves the island's joints in canonical order and publishes tag + 1; the
+// body's contact manifolds of that sweep then expect it * (deg + 1) + 1 + (colours below) — k_contact_init folds the extra
+// version into their packed (base, deg).  The clamped joint accumulators (limit / motor impulses) travel between sweeps as
+// tagged 16-byte granules like the contact impulses; everything else of a joint's per-step data is constant after
+// k_joint_init.  No kernel boundary is left inside the solver: 2 x iterations launches less per step.
+struct IslandAcc { float4* hinge; float4* cone; float4* slider; };
+// the colour groups of one joint type; `c` (this lane's joint data, accumulators already merged) stays in registers
+template <class J>
+__device__ __forceinline__ void fusedGroups(uint32_t type, const IslandDesc& d, bool mine, const IslandStep& st, typename J::Upd& c, IslandLds& lds) {
+    const uint32_t g0 = d.typeGroups[type], g1 = d.typeGroups[type + 1];
+    for (uint32_t g = g0; g < g1; ++g) {   // wave-uniform bounds
+        if (mine && st.group == g) {
+            BodyVel A, B;
+            { float4 a = lds.v[st.a], w = lds.w[st.a]; A.v = xyz(a); A.tagV = a.w; A.w = xyz(w); A.tagW = w.w; A.invMass = lds.invMass[st.a]; A.invI = ldM3(lds.inertia, st.a); }
+            { float4 a = lds.v[st.b], w = lds.w[st.b]; B.v = xyz(a); B.tagV = a.w; B.w = xyz(w); B.tagW = w.w; B.invMass = lds.invMass[st.b]; B.invI = ldM3(lds.inertia, st.b); }
+            J::solve(c, A, B);
+            if (A.invMass != 0.f) { lds.v[st.a] = f4(A.v, A.tagV); lds.w[st.a] = f4(A.w, A.tagW); }
+            if (B.invMass != 0.f) { lds.v[st.b] = f4(B.v, B.tagV); lds.w[st.b] = f4(B.w, B.tagW); }
+        }
+        __syncthreads();
+    }
+}
+template <class J>
+__device__ __forceinline__ void fusedPublish(bool mine, uint32_t it, const IslandStep& st, const typename J::Upd& c, float4* acc) {
+    if (!mine) return;
+    float a[4] = {0.f, 0.f, 0.f, 0.f}; J::getAcc(c, a);
+    const float t = __uint_as_float(it + 1u);
+    f32x4 q0 = {a[0], a[1], t, 0.f}, q1 = {a[2], a[3], t, 0.f};
+    storeGranuleSc1(acc + 2 * (size_t)st.joint, q0);
+    if (J::kAcc > 2) storeGranuleSc1(acc + 2 * (size_t)st.joint + 1, q1);
+}
+__device__ __forceinline__ void fusedIsland(uint32_t it, const IslandDesc& d, const IslandStep* __restrict__ steps, const uint32_t* __restrict__ islandBodies, const IslandUpd& upd,
+                                            const IslandAcc& acc, const BodyView& bv, const unsigned long long* __restrict__ bodyUsed, IslandLds& lds, StepScalars* sc) {
+    const uint32_t lane = threadIdx.x;
+    // everything this block needs is requested up front, so the waits below overlap in ONE memory round trip: the island's
+    // bodies (tagged granules), this lane's joint data (constant after k_joint_init) and its accumulator granules
+    const bool hasJoint = lane < d.numJoints;
+    IslandStep st{};
+    if (hasJoint) st = steps[d.stepBegin + lane];
+    uint32_t body = 0, expect = 0; bool dynamic = false;
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, q0 = g0, q1 = g0;
+    const bool isBody = lane < d.numBodies;
+    if (isBody) {
+        body = islandBodies[d.bodyBegin + lane];
+        issueGranuleSc1(bv.gVel + 2 * (size_t)body, g0); issueGranuleSc1(bv.gVel + 2 * (size_t)body + 1, g1);
+    }
+    const uint32_t type = hasJoint ? st.type : 0xFFFFu;
+    float4* accPtr = type == 3u ? acc.hinge : type == 4u ? acc.cone : type == 5u ? acc.slider : nullptr;
+    const bool twoGranules = type == 4u;
+    if (accPtr) { accPtr += 2 * (size_t)st.joint; issueGranuleSc1(accPtr, q0); if (twoGranules) issueGranuleSc1(accPtr + 1, q1); }
+    DistanceJ::Upd cDistance; BallJ::Upd cBall; FixedJ::Upd cFixed; HingeJ::Upd cHinge; ConeJ::Upd cCone; SliderJ::Upd cSlider;
+    switch (type) {
+        case 0: cDistance = upd.distance[st.joint]; break;
+        case 1: cBall = upd.ball[st.joint]; break;
+        case 2: cFixed = upd.fixed[st.joint]; break;
+        case 3: cHinge = upd.hinge[st.joint]; break;
+        case 4: cCone = upd.cone[st.joint]; break;
+        case 5: cSlider = upd.slider[st.joint]; break;
+        default: break;
+    }
+    if (isBody) {
+        const float im = bv.gPos[body].w;
+        lds.invMass[lane] = im; dynamic = im != 0.f;
+        lds.inertia[3 * lane] = bv.gInvI[3 * body]; lds.inertia[3 * lane + 1] = bv.gInvI[3 * body + 1]; lds.inertia[3 * lane + 2] = bv.gInvI[3 * body + 2];
+        expect = it * ((uint32_t)__popcll(bodyUsed[body]) + 1u);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    landed(g0); landed(g1); landed(q0); landed(q1);
+    {   // dynamic bodies must carry the tag that says "every update of the previous sweep has landed"; accumulators the sweep count
+        bool okBody = !isBody || !dynamic || (__float_as_uint(g0.w) == expect && __float_as_uint(g1.w) == expect);
+        bool okAcc = !accPtr || (__float_as_uint(q0.z) == it && (!twoGranules || __float_as_uint(q1.z) == it));
+        uint32_t budget = kSpinBudget;
+        while (__ballot(!(okBody && okAcc)) != 0ull) {
+            if (!okBody) {
+                loadGranuleSc1(bv.gVel + 2 * (size_t)body, g0); loadGranuleSc1(bv.gVel + 2 * (size_t)body + 1, g1);
+                okBody = __float_as_uint(g0.w) == expect && __float_as_uint(g1.w) == expect;
+            }
+            if (!okAcc) {
+                loadGranuleSc1(accPtr, q0); if (twoGranules) loadGranuleSc1(accPtr + 1, q1);
+                okAcc = __float_as_uint(q0.z) == it && (!twoGranules || __float_as_uint(q1.z) == it);
+            }
+            if (--budget == 0u) { sc->solveError = 1u; break; }
+        }
+        if (isBody) { lds.v[lane] = make_float4(g0.x, g0.y, g0.z, g0.w); lds.w[lane] = make_float4(g1.x, g1.y, g1.z, g1.w); }
+    }
+    { const float a[4] = {q0.x, q0.y, q1.x, q1.y}; if (type == 3u) HingeJ::setAcc(cHinge, a); else if (type == 4u) ConeJ::setAcc(cCone, a); else if (type == 5u) SliderJ::setAcc(cSlider, a); }
+    __syncthreads();
+    fusedGroups<DistanceJ>(0, d, type == 0u, st, cDistance, lds);
+    fusedGroups<BallJ>(1, d, type == 1u, st, cBall, lds);
+    fusedGroups<FixedJ>(2, d, type == 2u, st, cFixed, lds);
+    fusedGroups<HingeJ>(3, d, type == 3u, st, cHinge, lds);
+    fusedPublish<HingeJ>(type == 3u, it, st, cHinge, acc.hinge);
+    fusedGroups<ConeJ>(4, d, type == 4u, st, cCone, lds);
+    fusedPublish<ConeJ>(type == 4u, it, st, cCone, acc.cone);
+    fusedGroups<SliderJ>(5, d, type == 5u, st, cSlider, lds);
+    fusedPublish<SliderJ>(type == 5u, it, st, cSlider, acc.slider);
+    if (isBody && dynamic) {
+        const float t = __uint_as_float(expect + 1u);
+        const float4 v = lds.v[lane], w = lds.w[lane];
+        f32x4 o0 = {v.x, v.y, v.z, t}, o1 = {w.x, w.y, w.z, t};
+        storeGranuleSc1(bv.gVel + 2 * (size_t)body, o0); storeGranuleSc1(bv.gVel + 2 * (size_t)body + 1, o1);
+    }
+}
+// Block b of sweep s = itBase + b / (numIslands + numTiles): island b' < numIslands, else contact tile b' - numIslands.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_WAVES))) void k_solve_flow_islands(
+    uint32_t itBase, uint32_t sweeps, uint32_t numIslands, const IslandDesc* __restrict__ islands, const IslandStep* __restrict__ steps, const uint32_t* __restrict__ islandBodies,
+    IslandUpd upd, IslandAcc acc, BodyView bv, const unsigned long long* __restrict__ bodyUsed,
+    const uint2* __restrict__ tileDesc, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal, const float2* __restrict__ slotMass,
+    const float4* __restrict__ rows, float4* imp, StepScalars* sc) {
+    __shared__ IslandLds lds;
+    const uint32_t numTiles = sc->totalTiles, per = numIslands + numTiles;
+    if (blockIdx.x >= per * sweeps) return;
+    const uint32_t it = itBase + blockIdx.x / per, idx = blockIdx.x % per;
+    if (idx < numIslands) { fusedIsland(it, islands[idx], steps, islandBodies, upd, acc, bv, bodyUsed, lds, sc); return; }
+    const uint32_t tile = idx - numIslands, lane = threadIdx.x;
+    const uint2 d = tileDesc[tile];
+    switch (d.y) {
+        case 1: flowTile<1>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, bv.gVel, sc); break;
+        case 2: flowTile<2>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, bv.gVel, sc); break;
+        case 3: flowTile<3>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, bv.gVel, sc); break;
+        default: flowTile<4>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, bv.gVel, sc); break;
+    }
+}
+
 }  // namespace mi
 
 // ------------------------------------------------------------------------------------------------ host side
@@ -623,12 +774,12 @@ struct JointType {
     std::vector<uint32_t> colorOffsets; // [0..65] boundaries into order (64 = overflow colour)
     std::vector<uint32_t> colorOf;      // colour of every joint of this type
     std::vector<uint8_t> inIsland;      // joint is solved by k_joint_islands
-    typename J::Pod* dPods = nullptr; uint2* dBodies = nullptr; uint32_t* dOrder = nullptr; typename J::Upd* dUpd = nullptr;
+    typename J::Pod* dPods = nullptr; uint2* dBodies = nullptr; uint32_t* dOrder = nullptr; typename J::Upd* dUpd = nullptr; float4* dAcc = nullptr;
     size_t dCap = 0;
     ~JointType() { release(); }
     void release() {
-        if (dPods) (void)hipFree(dPods); if (dBodies) (void)hipFree(dBodies); if (dOrder) (void)hipFree(dOrder); if (dUpd) (void)hipFree(dUpd);
-        dPods = nullptr; dBodies = nullptr; dOrder = nullptr; dUpd = nullptr; dCap = 0;
+        if (dPods) (void)hipFree(dPods); if (dBodies) (void)hipFree(dBodies); if (dOrder) (void)hipFree(dOrder); if (dUpd) (void)hipFree(dUpd); if (dAcc) (void)hipFree(dAcc);
+        dPods = nullptr; dBodies = nullptr; dOrder = nullptr; dUpd = nullptr; dAcc = nullptr; dCap = 0;
     }
     // Greedy colouring in descending hash32 priority with 64-bit per-body colour masks (same rule as the contact schedule).
     void computeOrder(const std::vector<float>& invMass) {
@@ -670,6 +821,7 @@ struct JointType {
             if ((e = hipMalloc((void**)&dBodies, n * sizeof(uint2))) != hipSuccess) return e;
             if ((e = hipMalloc((void**)&dOrder, n * sizeof(uint32_t))) != hipSuccess) return e;
             if ((e = hipMalloc((void**)&dUpd, n * sizeof(typename J::Upd))) != hipSuccess) return e;
+            if ((e = hipMalloc((void**)&dAcc, 2 * n * sizeof(float4))) != hipSuccess) return e;
             dCap = n;
         }
         hipError_t e;
@@ -686,7 +838,7 @@ struct JointType {
     }
     void launchInit(uint32_t dummy, const mi::BodyView& bv, float dt, hipStream_t st) {
         uint32_t n = (uint32_t)pods.size();
-        if (n) mi::k_joint_init<J><<<(n + 63) / 64, 64, 0, st>>>(n, dummy, dPods, dBodies, dUpd, bv, dt);
+        if (n) mi::k_joint_init<J><<<(n + 63) / 64, 64, 0, st>>>(n, dummy, dPods, dBodies, dUpd, dAcc, bv, dt);
     }
     void launchSolve(const mi::BodyView& bv, hipStream_t st) {
         if (order.empty()) return;
@@ -712,11 +864,13 @@ struct JointSet {
     // articulated islands (k_joint_islands)
     uint32_t numIslands = 0;
     mi::IslandDesc* dIslands = nullptr; mi::IslandStep* dSteps = nullptr; uint32_t* dIslandBodies = nullptr;
+    uint8_t* dBodyJ = nullptr;          // [bodies + 1]: 1 = dynamic body of an island (one extra version per sweep in the fused solver)
+    bool allInIslands() const { return numIslands && distance.order.empty() && ball.order.empty() && fixed.order.empty() && hinge.order.empty() && cone.order.empty() && slider.order.empty(); }
     void buildIslands(const std::vector<float>& invMass, std::vector<mi::IslandDesc>& islands, std::vector<mi::IslandStep>& steps, std::vector<uint32_t>& islandBodies);
     ~JointSet() { releaseIslands(); }
     void releaseIslands() {
-        if (dIslands) (void)hipFree(dIslands); if (dSteps) (void)hipFree(dSteps); if (dIslandBodies) (void)hipFree(dIslandBodies);
-        dIslands = nullptr; dSteps = nullptr; dIslandBodies = nullptr; numIslands = 0;
+        if (dIslands) (void)hipFree(dIslands); if (dSteps) (void)hipFree(dSteps); if (dIslandBodies) (void)hipFree(dIslandBodies); if (dBodyJ) (void)hipFree(dBodyJ);
+        dIslands = nullptr; dSteps = nullptr; dIslandBodies = nullptr; dBodyJ = nullptr; numIslands = 0;
     }
     bool podsDirty() const { return distance.podsDirty || ball.podsDirty || fixed.podsDirty || hinge.podsDirty || cone.podsDirty || slider.podsDirty; }
     int uploadPods(hipStream_t st);

@@ -1182,6 +1182,7 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
                                                      const float4* __restrict__ npPoints, const float4* __restrict__ gPos,
                                                      const float4* __restrict__ gInvI, const float4* __restrict__ gVel,
                                                      const uint32_t* __restrict__ color, const unsigned long long* __restrict__ bodyUsed,
+                                                     const uint8_t* __restrict__ bodyJ /* fused joint islands: 1 = the body gets one joint version per sweep, or null */,
                                                      float4* __restrict__ rows, float4* __restrict__ imp, uint4* __restrict__ slotMeta,
                                                      float4* __restrict__ slotNormal, float2* __restrict__ slotMass) {
     uint32_t tile = blockIdx.x, lane = threadIdx.x;
@@ -1211,8 +1212,9 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
     {
         uint32_t c = color[m];
         unsigned long long below = c < 64u ? ((1ull << c) - 1ull) : ~0ull;
-        if (imA != 0.f) { unsigned long long u = bodyUsed[bodies.x]; packed |= (uint32_t)__popcll(u & below) | ((uint32_t)__popcll(u) << 7); }
-        if (imB != 0.f) { unsigned long long u = bodyUsed[bodies.y]; packed |= ((uint32_t)__popcll(u & below) << 14) | ((uint32_t)__popcll(u) << 21); }
+        // a body of a joint island is first updated by its island's block in every sweep (k_solve_flow_islands): one more version
+        if (imA != 0.f) { unsigned long long u = bodyUsed[bodies.x]; uint32_t j = bodyJ ? bodyJ[bodies.x] : 0u; packed |= ((uint32_t)__popcll(u & below) + j) | (((uint32_t)__popcll(u) + j) << 7); }
+        if (imB != 0.f) { unsigned long long u = bodyUsed[bodies.y]; uint32_t j = bodyJ ? bodyJ[bodies.y] : 0u; packed |= (((uint32_t)__popcll(u & below) + j) << 14) | (((uint32_t)__popcll(u) + j) << 21); }
     }
     slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, packed, cnt);
     slotMass[(size_t)tile * 64u + lane] = make_float2(imA, imB);

@@ -16,6 +16,9 @@
 // the push RNG is seeded with a fixed default instead of time(0) (setPhysicsSeed changes it); an episode reset puts the
 // ragdoll back in place instead of rebuilding the scene (the contact-colour history of the world survives the reset).
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cfloat>
 #include <cmath>
 #include <cstdint>
@@ -162,6 +165,9 @@ struct Batch {
     std::string error;
 };
 Batch g;
+// host threads of the per-environment loops: a fixed small number (MI_LEARN_THREADS overrides) — containers often expose far
+// more logical CPUs than their quota allows, and an OpenMP team sized from that count is slower than one thread
+const int g_threads = [] { const char* e = std::getenv("MI_LEARN_THREADS"); int t = e ? std::atoi(e) : 8; return t < 1 ? 1 : t; }();
 
 bool ok(int rc, const char* what) {
     if (rc == MI_OK) return true;
@@ -214,8 +220,11 @@ void localPositionsOf(int part, v3 out[6]) {
 // learned_locomotion::updateConstraint x13 over the smoothed action (learned_locomotion.cpp:74-115) -> one batched update per type
 bool applyActions(const float* actions /* [n][27] or null = all zero */, const std::vector<int>* only = nullptr) {
     const float beta = 0.1f;
+    std::vector<uint8_t> pick;
+    if (only) { pick.assign(g.n, 0); for (int e : *only) pick[e] = 1; }
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g.n >= 256)
     for (int e = 0; e < g.n; ++e) {
-        if (only && std::find(only->begin(), only->end(), e) == only->end()) continue;
+        if (only && !pick[e]) continue;
         Env& env = g.envs[e];
         for (int i = 0; i < kActionFloats; ++i) env.smoothed[i] = lerpf(env.smoothed[i], actions ? actions[e * kActionFloats + i] : 0.f, beta);
         for (int s = 0; s < kCone; ++s) {
@@ -429,9 +438,25 @@ bool ensureBatch(int n) {
     return resetEnvs(all);
 }
 
+// MI_LEARN_PROFILE=1: wall time per phase of the batched step, printed every 100 steps (development aid)
+struct PhaseTimer {
+    double acc[6] = {0, 0, 0, 0, 0, 0}; int steps = 0; bool on = std::getenv("MI_LEARN_PROFILE") != nullptr;
+    std::chrono::steady_clock::time_point t0;
+    void start() { if (on) t0 = std::chrono::steady_clock::now(); }
+    void lap(int k) { if (!on) return; auto t = std::chrono::steady_clock::now(); acc[k] += std::chrono::duration<double, std::milli>(t - t0).count(); t0 = t; }
+    void end() {
+        if (!on || ++steps % 100) return;
+        std::fprintf(stderr, "[learning] per step (ms): actions %.3f pushes %.3f physics %.3f readback %.3f state+reward %.3f resets %.3f\n",
+                     acc[0] / 100, acc[1] / 100, acc[2] / 100, acc[3] / 100, acc[4] / 100, acc[5] / 100);
+        for (double& a : acc) a = 0;
+    }
+} g_timer;
+
 // updatePhysics (learned_locomotion.cpp:452-489) for every environment
 bool stepAll(const float* actions, float* outStates, float* outRewards, int* outDone) {
+    g_timer.start();
     if (!applyActions(actions)) return false;
+    g_timer.lap(0);
     // random pushes: with probability 0.02 a ray from 5 m away at a random body part (458-468), strength 1000
     std::vector<float> origins, directions; std::vector<uint32_t> ranges;
     for (int e = 0; e < g.n; ++e) {
@@ -451,20 +476,29 @@ bool stepAll(const float* actions, float* outStates, float* outRewards, int* out
     // up at physics_transform0, i.e. the pose BEFORE this step, while the velocities are the new ones (physics.cpp:1364-1402)
     mi_step_settings settings; std::memset(&settings, 0, sizeof(settings));
     settings.fixed_frame_rate = 1; settings.frame_rate = 60; settings.max_physics_iterations_per_frame = 4; settings.num_rigid_solver_iterations = 30;
+    g_timer.lap(1);
     if (!ok(PHYS(world_step)(g.world, &settings, 1.f / 60.f), "world_step")) return false;
+    g_timer.lap(2);
     if (!refreshTransforms()) return false;
+    g_timer.lap(3);
     std::vector<int> failed;
+    std::vector<uint8_t> fell(g.n, 0);
+#pragma omp parallel for schedule(static) num_threads(g_threads) if (g.n >= 256)   // environments are independent: the host-side state / reward arithmetic scales over the cores
     for (int e = 0; e < g.n; ++e) {
         float state[kStateFloats];
         bool failure = stateOf(e, state);
         float reward = 0.f;
         if (!failure) { reward = rewardOf(e); g.envs[e].totalReward += reward; }
-        else failed.push_back(e);
+        else fell[e] = 1;
         if (outStates) std::memcpy(outStates + (size_t)e * kStateFloats, state, sizeof(state));
         if (outRewards) outRewards[e] = reward;
         if (outDone) outDone[e] = failure ? 1 : 0;
     }
-    return outDone ? resetEnvs(failed) : true;   // the batch API resets fallen ragdolls itself; the single-environment API leaves that to resetPhysics
+    for (int e = 0; e < g.n; ++e) if (fell[e]) failed.push_back(e);
+    g_timer.lap(4);
+    const bool done = outDone ? resetEnvs(failed) : true;   // the batch API resets fallen ragdolls itself; the single-environment API leaves that to resetPhysics
+    g_timer.lap(5); g_timer.end();
+    return done;
 }
 
 }  // namespace

@@ -760,21 +760,42 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     mark();  // 5
     // ---------------------------------------------------------------------------------------------- constraints
     const uint32_t tilesLaunch = spec ? tilesCap : totalTiles;   // sync mode knows the exact tile count (mirrorSchedule)
+    const bool useFlow = flowSolver && (spec || bins[kSchedBins - 1].count == 0 || !nmBound);   // the overflow colour needs the sequential kernel
+    static const bool fuseEnabled = !(std::getenv("MI_FUSE_JOINTS") && std::getenv("MI_FUSE_JOINTS")[0] == '0');
+    const bool fused = useFlow && fuseEnabled && joints.allInIslands();   // joints of all sweeps inside the dataflow launch
+    if (fused && !pairBound) HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, ((size_t)nb + 1) * sizeof(unsigned long long), st));   // no contacts at all: no contact versions
     if (nmBound) {
         HIP_TRY(slotMeta.ensure((size_t)tilesCap * 64)); HIP_TRY(slotNormal.ensure((size_t)tilesCap * 64)); HIP_TRY(slotMass.ensure((size_t)tilesCap * 64));
         HIP_TRY(rows.ensure((size_t)ctCap * kRows * 64)); HIP_TRY(imp.ensure((size_t)ctCap * 64));
         if (tilesLaunch)
             k_contact_init<<<tilesLaunch, 64, 0, st>>>(sc, nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
-                                                      gPos.p, gInvI.p, gVel.p, color.p, bodyUsed.p, rows.p, imp.p, slotMeta.p, slotNormal.p, slotMass.p);
+                                                      gPos.p, gInvI.p, gVel.p, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, imp.p, slotMeta.p, slotNormal.p, slotMass.p);
     }
     int rc = joints.initialize(*this, dt, st);
     if (rc != MI_OK) return rc;
     mark();  // 6
     const uint32_t iters = settings.num_rigid_solver_iterations;
-    const bool useFlow = flowSolver && (spec || bins[kSchedBins - 1].count == 0);   // the overflow colour needs the sequential kernel
     usedFlow = useFlow;
     uint64_t mainContacts = 0;
-    if (useFlow) {
+    if (fused) {
+        // contacts and joint islands of every sweep in one launch (k_solve_flow_islands)
+        const uint64_t per = (uint64_t)joints.numIslands + tilesLaunch;
+        const uint32_t perLaunch = per * iters < 0x7FFFFFFFull ? iters : 1u;
+        solveLaunches = (iters + perLaunch - 1) / perLaunch;
+        BodyView bv{gPos.p, gInvI.p, gVel.p, bRot.p, bCogInvMass.p};
+        const IslandUpd iu{joints.distance.dUpd, joints.ball.dUpd, joints.fixed.dUpd, joints.hinge.dUpd, joints.cone.dUpd, joints.slider.dUpd};
+        const IslandAcc ia{joints.hinge.dAcc, joints.cone.dAcc, joints.slider.dAcc};
+        for (uint32_t it = 0; it < iters; it += perLaunch) {
+            if (profileSolve) {
+                size_t e = 2 * (size_t)profLaunches;
+                while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
+                (void)hipEventRecord(profEvents[e], st);
+            }
+            k_solve_flow_islands<<<(uint32_t)(per * perLaunch), 64, flowLds, st>>>(it, perLaunch, joints.numIslands, joints.dIslands, joints.dSteps, joints.dIslandBodies, iu, ia, bv, bodyUsed.p,
+                                                                                   tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, sc);
+            if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
+        }
+    } else if (useFlow) {
         // no joints between the sweeps -> all sweeps in one launch; otherwise one launch per sweep (joints run in between)
         const uint32_t perLaunch = joints.count() == 0 && (uint64_t)std::max(tilesLaunch, 1u) * iters < 0x7FFFFFFFull ? iters : 1u;
         solveLaunches = tilesLaunch ? (iters + perLaunch - 1) / perLaunch : 0;
@@ -793,6 +814,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         // one launch per colour per sweep (MI_SOLVER=launch, or an overflow colour is present); synchronous mode only
         auto colorCount = [&](uint32_t c) { return bins[4 * c].count + bins[4 * c + 1].count + bins[4 * c + 2].count + bins[4 * c + 3].count; };
         // colours [tailStart, tailEnd) are small (<= 512 manifolds each, a suffix of the used colours): one launch for all of them
+        if (!nmBound) { numColorsUsed = 0; for (BinInfo& b : bins) b.count = 0; }   // no manifolds this step: the mirrored schedule is the previous step's
         uint32_t tailEnd = std::min(numColorsUsed, kOverflowColor), tailStart = tailEnd;
         while (tailStart > 0 && colorCount(tailStart - 1) <= 512u) --tailStart;
         if (tailEnd - tailStart < 2) tailStart = tailEnd;
@@ -1058,6 +1080,10 @@ int JointSet::upload(mi_world& w, hipStream_t st) {
             HIP_TRY(hipMemcpyAsync(dIslands, islands.data(), islands.size() * sizeof(IslandDesc), hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(dSteps, steps.data(), steps.size() * sizeof(IslandStep), hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(dIslandBodies, islandBodies.data(), islandBodies.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            std::vector<uint8_t> bodyJ(invMass.size() + 1, 0);
+            for (uint32_t b : islandBodies) if (b < invMass.size() && invMass[b] != 0.f) bodyJ[b] = 1;
+            HIP_TRY(hipMalloc((void**)&dBodyJ, bodyJ.size()));
+            HIP_TRY(hipMemcpyAsync(dBodyJ, bodyJ.data(), bodyJ.size(), hipMemcpyHostToDevice, st));
             HIP_TRY(hipStreamSynchronize(st));   // the staging vectors are locals
             numIslands = (uint32_t)islands.size();
         }

@@ -35,7 +35,7 @@ def build_learning():
     build()
     src = HERE.parent / "d3d12renderer_amd" / "csrc" / "learning.cpp"
     if not LEARNING_LIB.exists() or any(p.stat().st_mtime > LEARNING_LIB.stat().st_mtime for p in (src, LIB)):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math",
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
                         "-DLEARNING_BACKEND_ORACLE", str(src), "-o", str(LEARNING_LIB), "-L", str(LIB.parent), "-l:liboracle.so", "-Wl,-rpath,$ORIGIN"],
                        check=True, capture_output=True)
     return LEARNING_LIB
