@@ -183,6 +183,17 @@ class World:
                      "constraint_get")
         return pod
 
+    def destroy_constraint(self, ctype, cid):
+        """deleteConstraint(scene, handle) — src/physics/physics.cpp:474-521."""
+        self.L.check(self.L.fn("constraint_destroy")(self.h, C.c_uint32(ctype), C.c_uint32(cid)), "constraint_destroy")
+
+    def destroy_all_constraints(self):
+        self.L.check(self.L.fn("constraints_destroy_all")(self.h), "constraints_destroy_all")
+
+    def destroy_entity_constraints(self, entity):
+        """deleteAllConstraintsFromEntity(entity) — src/physics/physics.cpp:523-539."""
+        self.L.check(self.L.fn("entity_destroy_constraints")(self.h, C.c_uint32(entity)), "entity_destroy_constraints")
+
     def update_constraint(self, ctype, cid, pod):
         pod = np.ascontiguousarray(pod, dtype=CONSTRAINT_DTYPES[ctype]).reshape(1)
         self.L.check(self.L.fn("constraint_update")(self.h, C.c_uint32(ctype), C.c_uint32(cid), _ptr(pod), C.c_uint32(pod.dtype.itemsize)),

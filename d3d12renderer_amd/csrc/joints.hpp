@@ -770,6 +770,20 @@ template <class J>
 struct JointType {
     std::vector<typename J::Pod> pods;
     std::vector<uint2> bodies;          // rigid body indices (A, B)
+    // dense arrays in EnTT pool order (append on create, swap-and-pop on destroy); public handles stay valid through denseOf
+    std::vector<uint32_t> handleAt; std::vector<int32_t> denseOf; std::vector<uint2> ents; std::vector<uint64_t> seq;
+    int dense(uint32_t handle) const { return handle < denseOf.size() ? denseOf[handle] : -1; }
+    bool destroy(uint32_t handle) {
+        int d = dense(handle);
+        if (d < 0) return false;
+        size_t last = pods.size() - 1;
+        pods[d] = pods[last]; bodies[d] = bodies[last]; handleAt[d] = handleAt[last]; ents[d] = ents[last]; seq[d] = seq[last];
+        denseOf[handleAt[d]] = d;
+        pods.pop_back(); bodies.pop_back(); handleAt.pop_back(); ents.pop_back(); seq.pop_back();
+        denseOf[handle] = -1;
+        return true;
+    }
+    void clearAll() { pods.clear(); bodies.clear(); handleAt.clear(); ents.clear(); seq.clear(); std::fill(denseOf.begin(), denseOf.end(), -1); }
     std::vector<uint32_t> order;        // colour-major, index-minor; only the joints the per-colour kernels solve (see JointSet::buildIslands)
     std::vector<uint32_t> colorOffsets; // [0..65] boundaries into order (64 = overflow colour)
     std::vector<uint32_t> colorOf;      // colour of every joint of this type
@@ -858,6 +872,10 @@ struct JointSet {
     size_t count() const { return distance.pods.size() + ball.pods.size() + fixed.pods.size() + hinge.pods.size() + cone.pods.size() + slider.pods.size(); }
     int add(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb, const void* pod, uint32_t bytes, uint32_t* out);
     int update(uint32_t type, uint32_t id, const void* pod, uint32_t bytes);
+    uint64_t nextSeq = 0;
+    int destroy(uint32_t type, uint32_t id);
+    void destroyAll();
+    void destroyOfEntity(uint32_t entity);
     int get(uint32_t type, uint32_t id, void* pod, uint32_t bytes);
     int addFromGlobal(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb, const float* anchor, const float* axis, float l0, float l1, uint32_t* out);
     int upload(mi_world& w, hipStream_t st);

@@ -950,10 +950,36 @@ static int jointAddTo(mi_world& w, JT& l, uint32_t ea, uint32_t eb, const void* 
     if (ea >= w.entities.size() || eb >= w.entities.size() || w.entities[ea].rb < 0 || w.entities[eb].rb < 0)
         return fail(MI_ERR_INVALID_ARGUMENT, "both constraint entities must be rigid bodies");
     P p; std::memcpy(&p, pod, sizeof(P));
-    if (out) *out = (uint32_t)l.pods.size();
+    const uint32_t handle = (uint32_t)l.denseOf.size();
+    if (out) *out = handle;
+    l.denseOf.push_back((int32_t)l.pods.size()); l.handleAt.push_back(handle);
+    l.ents.push_back(make_uint2(ea, eb)); l.seq.push_back(w.joints.nextSeq++);
     l.pods.push_back(p);
     l.bodies.push_back(make_uint2((uint32_t)w.entities[ea].rb, (uint32_t)w.entities[eb].rb));
     return MI_OK;
+}
+// deleteConstraint / deleteAllConstraints / deleteAllConstraintsFromEntity — src/physics/physics.cpp:443-539
+int JointSet::destroy(uint32_t type, uint32_t id) {
+    bool ok = false;
+    switch (type) {
+        case MI_CONSTRAINT_DISTANCE: ok = distance.destroy(id); break;
+        case MI_CONSTRAINT_BALL: ok = ball.destroy(id); break;
+        case MI_CONSTRAINT_FIXED: ok = fixed.destroy(id); break;
+        case MI_CONSTRAINT_HINGE: ok = hinge.destroy(id); break;
+        case MI_CONSTRAINT_CONE_TWIST: ok = cone.destroy(id); break;
+        case MI_CONSTRAINT_SLIDER: ok = slider.destroy(id); break;
+    }
+    return ok ? MI_OK : fail(MI_ERR_INVALID_ARGUMENT, "bad constraint type or id");
+}
+void JointSet::destroyAll() { distance.clearAll(); ball.clearAll(); fixed.clearAll(); hinge.clearAll(); cone.clearAll(); slider.clearAll(); }
+void JointSet::destroyOfEntity(uint32_t entity) {
+    struct Hit { uint64_t seq; uint32_t type, handle; };
+    std::vector<Hit> hits;
+    auto scan = [&](uint32_t type, const auto& l) { for (size_t d = 0; d < l.pods.size(); ++d) if (l.ents[d].x == entity || l.ents[d].y == entity) hits.push_back(Hit{l.seq[d], type, l.handleAt[d]}); };
+    scan(MI_CONSTRAINT_DISTANCE, distance); scan(MI_CONSTRAINT_BALL, ball); scan(MI_CONSTRAINT_FIXED, fixed);
+    scan(MI_CONSTRAINT_HINGE, hinge); scan(MI_CONSTRAINT_CONE_TWIST, cone); scan(MI_CONSTRAINT_SLIDER, slider);
+    std::sort(hits.begin(), hits.end(), [](const Hit& x, const Hit& y) { return x.seq > y.seq; });   // the entity's edge list is newest first
+    for (const Hit& h : hits) (void)destroy(h.type, h.handle);
 }
 int JointSet::add(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb, const void* pod, uint32_t bytes, uint32_t* out) {
     switch (type) {
@@ -968,8 +994,8 @@ int JointSet::add(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb, const vo
 }
 template <class JT> static int jointCopy(JT& l, uint32_t id, void* dst, const void* src, uint32_t bytes) {
     typedef typename std::remove_reference<decltype(l.pods[0])>::type P;
-    if (bytes != sizeof(P) || id >= l.pods.size()) return fail(MI_ERR_INVALID_ARGUMENT, "bad constraint id or pod size");
-    if (src) std::memcpy(&l.pods[id], src, sizeof(P)); else std::memcpy(dst, &l.pods[id], sizeof(P));
+    if (bytes != sizeof(P) || l.dense(id) < 0) return fail(MI_ERR_INVALID_ARGUMENT, "bad constraint id or pod size");
+    if (src) std::memcpy(&l.pods[l.dense(id)], src, sizeof(P)); else std::memcpy(dst, &l.pods[l.dense(id)], sizeof(P));
     return MI_OK;
 }
 int JointSet::update(uint32_t type, uint32_t id, const void* pod, uint32_t bytes) {
@@ -1064,7 +1090,11 @@ int JointSet::addFromGlobal(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb
     return fail(MI_ERR_INVALID_ARGUMENT, "bad constraint type");
 }
 int JointSet::upload(mi_world& w, hipStream_t st) {
-    if (!count()) return MI_OK;
+    if (!count()) {   // the last constraint may just have been deleted: nothing of the previous topology may survive
+        releaseIslands();
+        distance.order.clear(); ball.order.clear(); fixed.order.clear(); hinge.order.clear(); cone.order.clear(); slider.order.clear();
+        return MI_OK;
+    }
     std::vector<float> invMass(w.bodies.size());
     for (size_t i = 0; i < w.bodies.size(); ++i) invMass[i] = w.bodies[i].invMass;
     distance.computeOrder(invMass); ball.computeOrder(invMass); fixed.computeOrder(invMass);
@@ -1302,6 +1332,22 @@ MI_API int mi_constraints_update(mi_world* w, uint32_t type, uint32_t count, con
         int rc = w->joints.update(type, ids[i], (const char*)pods + (size_t)i * podBytes, podBytes);
         if (rc != MI_OK) return rc;
     }
+    return MI_OK;
+}
+MI_API int mi_constraint_destroy(mi_world* w, uint32_t type, uint32_t id) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    int rc = w->joints.destroy(type, id);
+    if (rc == MI_OK) w->topologyDirty = true;
+    return rc;
+}
+MI_API int mi_constraints_destroy_all(mi_world* w) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    w->joints.destroyAll(); w->topologyDirty = true;
+    return MI_OK;
+}
+MI_API int mi_entity_destroy_constraints(mi_world* w, uint32_t entity) {
+    if (!w || entity >= w->entities.size()) return fail(MI_ERR_INVALID_ARGUMENT, "bad entity");
+    w->joints.destroyOfEntity(entity); w->topologyDirty = true;
     return MI_OK;
 }
 MI_API int mi_constraint_get(mi_world* w, uint32_t type, uint32_t id, void* pod, uint32_t bytes) {

@@ -191,6 +191,12 @@ MI_API int mi_constraint_get(mi_world* world, uint32_t type, uint32_t constraint
 /* mi_constraint_update for `count` constraints of one type (pods = count consecutive PODs of pod_bytes each): a policy writing the
  * motor targets of thousands of ragdolls per step.  Updates only re-send the POD arrays; the step stays on its fast path. */
 MI_API int mi_constraints_update(mi_world* world, uint32_t type, uint32_t count, const uint32_t* constraints, const void* pods, uint32_t pod_bytes);
+/* deleteConstraint(scene, handle), deleteAllConstraints(scene), deleteAllConstraintsFromEntity(entity)
+ * (src/physics/physics.h:251-260, physics.cpp:443-539).  Constraint ids stay valid across deletions of other constraints; the
+ * solver's pool order follows EnTT's swap-and-pop (the last constraint of the type moves into the freed slot). */
+MI_API int mi_constraint_destroy(mi_world* world, uint32_t type, uint32_t constraint);
+MI_API int mi_constraints_destroy_all(mi_world* world);
+MI_API int mi_entity_destroy_constraints(mi_world* world, uint32_t entity);
 /* add{Distance,Ball,Fixed,Hinge,ConeTwist,Slider}ConstraintFromGlobalPoints (src/physics/physics.cpp:128-333). */
 MI_API int mi_constraint_create_from_global(mi_world* world, uint32_t type, uint32_t entity_a, uint32_t entity_b,
                                             const float* global_anchor, const float* global_axis,

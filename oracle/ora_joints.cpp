@@ -38,7 +38,25 @@ struct SliderUpd {
     float maxMotorImpulse, motorImpulse, motorVelocity;
 };
 
-template <typename P> struct JointList { std::vector<P> pods; std::vector<Pair> bodies; std::vector<uint32_t> order; };
+// Dense arrays in EnTT pool order (append on create, swap-and-pop on destroy); the public handle of a constraint stays valid
+// across deletions through handle -> dense index.  `ents` / `seq`: the two entities and a world-wide creation counter
+// (deleteAllConstraintsFromEntity walks an entity's edge list, newest constraint first: physics.cpp:87-111, 523-539).
+template <typename P> struct JointList {
+    std::vector<P> pods; std::vector<Pair> bodies; std::vector<uint32_t> order;
+    std::vector<uint32_t> handleAt; std::vector<int32_t> denseOf; std::vector<Pair> ents; std::vector<uint64_t> seq;
+    int dense(uint32_t handle) const { return handle < denseOf.size() ? denseOf[handle] : -1; }
+    bool destroy(uint32_t handle) {   // registry.destroy(constraintEntity): swap-and-pop in the component pool
+        int d = dense(handle);
+        if (d < 0) return false;
+        size_t last = pods.size() - 1;
+        pods[d] = pods[last]; bodies[d] = bodies[last]; handleAt[d] = handleAt[last]; ents[d] = ents[last]; seq[d] = seq[last];
+        denseOf[handleAt[d]] = d;
+        pods.pop_back(); bodies.pop_back(); handleAt.pop_back(); ents.pop_back(); seq.pop_back();
+        denseOf[handle] = -1;
+        return true;
+    }
+    void clear() { pods.clear(); bodies.clear(); handleAt.clear(); ents.clear(); seq.clear(); std::fill(denseOf.begin(), denseOf.end(), -1); }
+};
 
 struct JointStore {
     JointList<mi_distance_constraint> distance; JointList<mi_ball_constraint> ball; JointList<mi_fixed_constraint> fixed;
@@ -46,6 +64,7 @@ struct JointStore {
     std::vector<DistanceUpd> uDistance; std::vector<BallUpd> uBall; std::vector<FixedUpd> uFixed;
     std::vector<HingeUpd> uHinge; std::vector<ConeUpd> uCone; std::vector<SliderUpd> uSlider;
     bool orderDirty = true;
+    uint64_t nextSeq = 0;
 };
 
 JointStore* jointsCreate() { return new JointStore(); }
@@ -65,7 +84,10 @@ static int addTo(World& w, JointList<P>& l, uint32_t ea, uint32_t eb, const void
     if (bytes != sizeof(P)) return MI_ERR_INVALID_ARGUMENT;
     if (ea >= w.entities.size() || eb >= w.entities.size() || w.entities[ea].rb < 0 || w.entities[eb].rb < 0) return MI_ERR_INVALID_ARGUMENT;
     P p; std::memcpy(&p, pod, sizeof(P));
-    if (out) *out = (uint32_t)l.pods.size();
+    const uint32_t handle = (uint32_t)l.denseOf.size();
+    if (out) *out = handle;
+    l.denseOf.push_back((int32_t)l.pods.size()); l.handleAt.push_back(handle);
+    l.ents.push_back(Pair{ea, eb}); l.seq.push_back(w.joints->nextSeq++);
     l.pods.push_back(p);
     l.bodies.push_back(Pair{(uint32_t)w.entities[ea].rb, (uint32_t)w.entities[eb].rb});
     w.joints->orderDirty = true;
@@ -84,12 +106,43 @@ int jointsAdd(World& w, uint32_t type, uint32_t ea, uint32_t eb, const void* pod
     return MI_ERR_INVALID_ARGUMENT;
 }
 template <typename P> static int updIn(JointList<P>& l, uint32_t id, const void* pod, uint32_t bytes) {
-    if (bytes != sizeof(P) || id >= l.pods.size()) return MI_ERR_INVALID_ARGUMENT;
-    std::memcpy(&l.pods[id], pod, sizeof(P)); return MI_OK;
+    if (bytes != sizeof(P) || l.dense(id) < 0) return MI_ERR_INVALID_ARGUMENT;
+    std::memcpy(&l.pods[l.dense(id)], pod, sizeof(P)); return MI_OK;
 }
 template <typename P> static int getIn(JointList<P>& l, uint32_t id, void* pod, uint32_t bytes) {
-    if (bytes != sizeof(P) || id >= l.pods.size()) return MI_ERR_INVALID_ARGUMENT;
-    std::memcpy(pod, &l.pods[id], sizeof(P)); return MI_OK;
+    if (bytes != sizeof(P) || l.dense(id) < 0) return MI_ERR_INVALID_ARGUMENT;
+    std::memcpy(pod, &l.pods[l.dense(id)], sizeof(P)); return MI_OK;
+}
+// deleteConstraint / deleteAllConstraints / deleteAllConstraintsFromEntity — src/physics/physics.cpp:443-539
+int jointsDestroy(World& w, uint32_t type, uint32_t id) {
+    JointStore& j = *w.joints;
+    bool ok = false;
+    switch (type) {
+        case MI_CONSTRAINT_DISTANCE: ok = j.distance.destroy(id); break;
+        case MI_CONSTRAINT_BALL: ok = j.ball.destroy(id); break;
+        case MI_CONSTRAINT_FIXED: ok = j.fixed.destroy(id); break;
+        case MI_CONSTRAINT_HINGE: ok = j.hinge.destroy(id); break;
+        case MI_CONSTRAINT_CONE_TWIST: ok = j.cone.destroy(id); break;
+        case MI_CONSTRAINT_SLIDER: ok = j.slider.destroy(id); break;
+    }
+    j.orderDirty = true;
+    return ok ? MI_OK : MI_ERR_INVALID_ARGUMENT;
+}
+void jointsDestroyAll(World& w) {
+    JointStore& j = *w.joints;
+    j.distance.clear(); j.ball.clear(); j.fixed.clear(); j.hinge.clear(); j.cone.clear(); j.slider.clear();
+    j.orderDirty = true;
+}
+int jointsDestroyOfEntity(World& w, uint32_t entity) {
+    JointStore& j = *w.joints;
+    struct Hit { uint64_t seq; uint32_t type, handle; };
+    std::vector<Hit> hits;
+    auto scan = [&](uint32_t type, const auto& l) { for (size_t d = 0; d < l.pods.size(); ++d) if (l.ents[d].a == entity || l.ents[d].b == entity) hits.push_back(Hit{l.seq[d], type, l.handleAt[d]}); };
+    scan(MI_CONSTRAINT_DISTANCE, j.distance); scan(MI_CONSTRAINT_BALL, j.ball); scan(MI_CONSTRAINT_FIXED, j.fixed);
+    scan(MI_CONSTRAINT_HINGE, j.hinge); scan(MI_CONSTRAINT_CONE_TWIST, j.cone); scan(MI_CONSTRAINT_SLIDER, j.slider);
+    std::sort(hits.begin(), hits.end(), [](const Hit& x, const Hit& y) { return x.seq > y.seq; });   // the edge list is newest first
+    for (const Hit& h : hits) jointsDestroy(w, h.type, h.handle);
+    return MI_OK;
 }
 int jointsUpdate(World& w, uint32_t type, uint32_t id, const void* pod, uint32_t bytes) {
     JointStore& j = *w.joints;

@@ -1039,6 +1039,9 @@ MI_API int ora_constraint_create(World* w, uint32_t type, uint32_t ea, uint32_t 
 }
 MI_API int ora_constraint_update(World* w, uint32_t type, uint32_t id, const void* pod, uint32_t bytes) { return jointsUpdate(*w, type, id, pod, bytes); }
 MI_API int ora_constraint_get(World* w, uint32_t type, uint32_t id, void* pod, uint32_t bytes) { return jointsGet(*w, type, id, pod, bytes); }
+MI_API int ora_constraint_destroy(World* w, uint32_t type, uint32_t id) { return jointsDestroy(*w, type, id); }
+MI_API int ora_constraints_destroy_all(World* w) { jointsDestroyAll(*w); return MI_OK; }
+MI_API int ora_entity_destroy_constraints(World* w, uint32_t entity) { return entity < w->entities.size() ? jointsDestroyOfEntity(*w, entity) : MI_ERR_INVALID_ARGUMENT; }
 MI_API int ora_constraint_create_from_global(World* w, uint32_t type, uint32_t ea, uint32_t eb, const float* anchor, const float* axis,
                                              float l0, float l1, uint32_t* out) {
     return jointsAddFromGlobal(*w, type, ea, eb, anchor, axis, l0, l1, out);

@@ -176,6 +176,9 @@ void jointsDestroy(JointStore*);
 int jointsAdd(World& w, uint32_t type, uint32_t entityA, uint32_t entityB, const void* pod, uint32_t bytes, uint32_t* outId);
 int jointsUpdate(World& w, uint32_t type, uint32_t id, const void* pod, uint32_t bytes);
 int jointsGet(World& w, uint32_t type, uint32_t id, void* pod, uint32_t bytes);
+int jointsDestroy(World& w, uint32_t type, uint32_t id);
+void jointsDestroyAll(World& w);
+int jointsDestroyOfEntity(World& w, uint32_t entity);
 int jointsAddFromGlobal(World& w, uint32_t type, uint32_t ea, uint32_t eb, const float* anchor, const float* axis, float l0, float l1, uint32_t* outId);
 void jointsInitialize(World& w, float dt);
 void jointsSolveIteration(World& w);

@@ -222,6 +222,40 @@ def test_gpu_ray_interactions_and_batched_edits_match_oracle(mi_lib, oracle_mod)
     assert spec >= steps - 2 - retries
 
 
+def test_gpu_constraint_deletion_matches_oracle(mi_lib, oracle_mod):
+    """deleteConstraint / deleteAllConstraintsFromEntity / deleteAllConstraints while the simulation runs: the pool order after
+    EnTT's swap-and-pop decides the joint colouring priorities and the island programs, so GPU and oracle must reorder alike."""
+    sc = scenes.ragdolls(4, 3)
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    both = (g, o)
+    def run(n):
+        for i in range(n):
+            for w in both: w.step_fixed(s, sc.dt, 1)
+            assert g.counts() == o.counts()
+        assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
+    run(30)
+    for w in both:                                   # scattered single deletions: knees, elbows, a few cone twists
+        for cid in (2, 9, 17, 40, 41, 65):
+            w.destroy_constraint(capi.CONSTRAINT_HINGE, cid)
+        for cid in (0, 8, 30, 83):
+            w.destroy_constraint(capi.CONSTRAINT_CONE_TWIST, cid)
+    run(40)
+    for w in both:                                   # every constraint of three torsos (entities 0, 14, 28)
+        for ent in (0, 14, 28):
+            w.destroy_entity_constraints(ent)
+    run(40)
+    pod = g.get_constraint(capi.CONSTRAINT_HINGE, 71)
+    for w in both:                                   # handles stay valid: re-create one and edit another
+        assert w.add_constraint(capi.CONSTRAINT_HINGE, 14 * 11 + 2, 14 * 11 + 3, pod) == 72
+        p = w.get_constraint(capi.CONSTRAINT_HINGE, 70); p["motor_type"] = 1; p["max_motor_torque"] = 90.0; p["motor_velocity_or_target_angle"] = 0.4
+        w.update_constraint(capi.CONSTRAINT_HINGE, 70, p)
+    run(30)
+    for w in both:
+        w.destroy_all_constraints()
+    run(30)
+
+
 def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
     """Steps after the first run with ONE host read-back, sized from the previous step's counts.  Teleporting the bodies into
     a much denser pile invalidates those bounds: the step must be re-run synchronously from the untouched state and still match

@@ -150,3 +150,37 @@ def test_ragdoll_mass_and_joint_counts(oracle_mod):
     w.step_fixed(sc.settings(), sc.dt, 200)
     p, _ = w.physics_transforms()
     assert np.isfinite(p).all() and p[:-1, 1].min() > -0.05
+
+
+def test_constraint_deletion_semantics(oracle_mod):
+    """deleteConstraint / deleteAllConstraintsFromEntity / deleteAllConstraints (physics.cpp:443-539): handles of the other
+    constraints stay valid (EnTT swap-and-pop only reorders the pool), a released body falls freely."""
+    from d3d12renderer_amd import scenes
+    sc = scenes.ragdolls(1, 1)
+    w = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_REFERENCE))
+    before = [w.get_constraint(capi.CONSTRAINT_HINGE, i).copy() for i in range(6)]
+    w.destroy_constraint(capi.CONSTRAINT_HINGE, 1)
+    with pytest.raises(capi.PhysicsError):
+        w.get_constraint(capi.CONSTRAINT_HINGE, 1)
+    with pytest.raises(capi.PhysicsError):
+        w.destroy_constraint(capi.CONSTRAINT_HINGE, 1)
+    for i in (0, 2, 3, 4, 5):
+        assert w.get_constraint(capi.CONSTRAINT_HINGE, i).tobytes() == before[i].tobytes()
+    pod = w.get_constraint(capi.CONSTRAINT_HINGE, 5); pod["max_motor_torque"] = 77.0
+    w.update_constraint(capi.CONSTRAINT_HINGE, 5, pod)
+    assert w.get_constraint(capi.CONSTRAINT_HINGE, 5)["max_motor_torque"][0] == 77.0
+    new_id = w.add_constraint(capi.CONSTRAINT_HINGE, 2, 3, before[1])       # ids are never reused
+    assert new_id == 6
+    # the head (entity 1) hangs on the neck cone-twist only: release it and it is a free body
+    w.destroy_entity_constraints(1)
+    with pytest.raises(capi.PhysicsError):
+        w.get_constraint(capi.CONSTRAINT_CONE_TWIST, 0)
+    w.get_constraint(capi.CONSTRAINT_CONE_TWIST, 1)
+    w.step_fixed(sc.settings(), sc.dt, 1)
+    w.destroy_all_constraints()
+    for t, n in ((capi.CONSTRAINT_HINGE, 7), (capi.CONSTRAINT_CONE_TWIST, 7)):
+        for i in range(n):
+            with pytest.raises(capi.PhysicsError):
+                w.get_constraint(t, i)
+    w.step_fixed(sc.settings(), sc.dt, 30)
+    assert np.isfinite(w.physics_transforms()[0]).all()
