@@ -33,6 +33,8 @@ assert entity_desc.itemsize == 68 and collider_desc.itemsize == 72 and contact_d
 
 distance_constraint = np.dtype([("local_anchor_a", "<f4", 3), ("local_anchor_b", "<f4", 3), ("global_length", "<f4")])
 ball_constraint = np.dtype([("local_anchor_a", "<f4", 3), ("local_anchor_b", "<f4", 3)])
+cloth_desc = np.dtype([("width", "<f4"), ("height", "<f4"), ("grid_size_x", "<u4"), ("grid_size_y", "<u4"), ("total_mass", "<f4"), ("stiffness", "<f4"),
+                       ("damping", "<f4"), ("gravity_factor", "<f4")])
 fixed_constraint = np.dtype([("initial_inv_rotation_difference", "<f4", 4), ("local_anchor_a", "<f4", 3), ("local_anchor_b", "<f4", 3)])
 hinge_constraint = np.dtype([
     ("local_anchor_a", "<f4", 3), ("local_anchor_b", "<f4", 3), ("local_hinge_axis_a", "<f4", 3), ("local_hinge_axis_b", "<f4", 3),
@@ -249,6 +251,31 @@ class World:
         out = C.c_float()
         self.L.check(self.L.fn("heightmap_get_height")(self.h, C.c_float(x), C.c_float(z), C.byref(out)), "heightmap_get_height")
         return out.value
+
+    # --- cloth (cloth_component, src/physics/cloth.h:5-60)
+    def create_cloth(self, width, height, grid_x, grid_y, total_mass, stiffness=0.5, damping=0.3, gravity_factor=1.0):
+        d = np.zeros(1, cloth_desc)
+        d["width"], d["height"], d["grid_size_x"], d["grid_size_y"] = width, height, grid_x, grid_y
+        d["total_mass"], d["stiffness"], d["damping"], d["gravity_factor"] = total_mass, stiffness, damping, gravity_factor
+        out = C.c_uint32()
+        self.L.check(self.L.fn("cloth_create")(self.h, _ptr(d), C.byref(out)), "cloth_create")
+        return out.value
+
+    def set_cloth_fixed_vertices(self, cloth, position, rotation=(0, 0, 0, 1), move_rigid=False):
+        p = np.ascontiguousarray(position, np.float32); r = np.ascontiguousarray(rotation, np.float32)
+        self.L.check(self.L.fn("cloth_set_fixed_vertices")(self.h, C.c_uint32(cloth), _ptr(p), _ptr(r), C.c_uint32(1 if move_rigid else 0)), "cloth_set_fixed_vertices")
+
+    def set_cloth_properties(self, cloth, total_mass, stiffness, damping, gravity_factor):
+        self.L.check(self.L.fn("cloth_set_properties")(self.h, C.c_uint32(cloth), C.c_float(total_mass), C.c_float(stiffness), C.c_float(damping), C.c_float(gravity_factor)),
+                     "cloth_set_properties")
+
+    def cloth_state(self, cloth, num_particles):
+        pos = np.zeros((num_particles, 3), np.float32); vel = np.zeros((num_particles, 3), np.float32)
+        self.L.check(self.L.fn("cloth_get_state")(self.h, C.c_uint32(cloth), _ptr(pos), _ptr(vel), C.c_uint32(num_particles)), "cloth_get_state")
+        return pos, vel
+
+    def set_cloth_iterations(self, velocity=0, position=1, drift=0):
+        self.L.check(self.L.fn("world_set_cloth_iterations")(self.h, C.c_uint32(velocity), C.c_uint32(position), C.c_uint32(drift)), "world_set_cloth_iterations")
 
     # --- checkpoint / resume
     def save_checkpoint(self):

@@ -21,6 +21,7 @@
 #include "gjk.hpp"
 #include "joints.hpp"
 #include "heightmap.hpp"
+#include "cloth.hpp"
 
 using namespace mi;
 
@@ -117,6 +118,17 @@ struct mi_world {
     DBuf<uint32_t> cObject; DBuf<float4> localForce, bForceStep; DBuf<uint64_t> interKeys; DBuf<DeviceInteraction> interList; DBuf<uint2> fieldList;
     std::vector<uint64_t> prevTriggerOverlaps, nextTriggerOverlaps;
     int interactions(std::vector<mi_event>& triggerEvents);
+    // cloth (cloth_component): host description + device state per cloth, one descriptor array for the single launch
+    struct HCloth {
+        mi_cloth_desc desc; float oldTotalMass, oldStiffness;
+        std::vector<float> invMasses; std::vector<uint2> pairs; std::vector<float2> restInvMass; std::vector<uint32_t> order; uint32_t colourOffsets[13];
+        DBuf<float4> pos, prev, vel, force, temp; DBuf<uint2> dPairs; DBuf<float2> dRestInvMass; DBuf<uint32_t> dOrder;
+        bool constraintsDirty = true;
+    };
+    std::vector<HCloth*> cloths;
+    DBuf<ClothDev> clothDescs; bool clothsDirty = true;
+    uint32_t clothIterations[3] = {0, 1, 0};   // numClothVelocity / Position / DriftIterations (physics.h:390-392)
+    int stepCloths(float dt);
     // heightmap terrain: host copy of the chunks (heights + min/max mips), device pool, per-collider contact counts
     struct HHeightmap {
         uint32_t chunksPerDim; float chunkSize, restitution, friction; V3 minCorner; float amplitudeScale = 1.f;
@@ -200,6 +212,7 @@ mi_world::~mi_world() {
     for (auto& e : profEvents) (void)hipEventDestroy(e);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     delete heightmap;
+    for (HCloth* c : cloths) delete c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -521,12 +534,57 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     HIP_TRY(hipSetDevice(device));
     if (topologyDirty) { int rc = download(); if (rc != MI_OK) return rc; rc = upload(); if (rc != MI_OK) return rc; haveEstimates = false; }
     else if (joints.podsDirty()) { int rc = joints.uploadPods(stream); if (rc != MI_OK) return rc; HIP_TRY(hipStreamSynchronize(stream)); }
-    if (bodies.empty()) return MI_OK;
+    if (bodies.empty()) return cloths.empty() ? MI_OK : stepCloths(dt);   // physics.cpp:1184-1189: cloth alone still steps
     const bool spec = specEnabled && haveEstimates && flowSolver && !usesInteractions;   // interactions are read back mid-step
     ++totalSteps; if (spec) ++specSteps;
     int rc = runStep(settings, dt, spec);
     if (rc == STEP_RETRY) { ++specRetries; rc = runStep(settings, dt, false); }
+    if (rc == MI_OK && !cloths.empty()) rc = stepCloths(dt);   // after the rigid bodies (physics.cpp:1352-1358); once per VALID step: cloth state is updated in place
     return rc;
+}
+
+// cloth_component::applyWindForce(globalForceField) + simulate(...) for every cloth: one launch, one workgroup per cloth.
+int mi_world::stepCloths(float dt) {
+    for (HCloth* c : cloths) {
+        if (c->desc.total_mass != c->oldTotalMass || c->desc.stiffness != c->oldStiffness) {   // recalculateProperties (cloth.cpp:299-317)
+            const uint32_t n = c->desc.grid_size_x * c->desc.grid_size_y;
+            const float invMassPerParticle = (float)n / c->desc.total_mass;
+            for (float& im : c->invMasses) im = (im != 0.f) ? invMassPerParticle : 0.f;
+            c->desc.stiffness = clampr(c->desc.stiffness, 0.01f, 1.f);
+            const float invStiffness = 1.f / c->desc.stiffness;
+            for (size_t k = 0; k < c->pairs.size(); ++k) c->restInvMass[k].y = (c->invMasses[c->pairs[k].x] + c->invMasses[c->pairs[k].y]) * invStiffness;
+            c->oldTotalMass = c->desc.total_mass; c->oldStiffness = c->desc.stiffness;
+            c->constraintsDirty = true;
+            // the inverse masses ride in pos.w
+            std::vector<float4> p(n);
+            HIP_TRY(hipMemcpyAsync(p.data(), c->pos.p, n * sizeof(float4), hipMemcpyDeviceToHost, stream)); HIP_TRY(hipStreamSynchronize(stream));
+            for (uint32_t i = 0; i < n; ++i) p[i].w = c->invMasses[i];
+            HIP_TRY(hipMemcpyAsync(c->pos.p, p.data(), n * sizeof(float4), hipMemcpyHostToDevice, stream)); HIP_TRY(hipStreamSynchronize(stream));
+        }
+        if (c->constraintsDirty) {
+            HIP_TRY(hipMemcpyAsync(c->dRestInvMass.p, c->restInvMass.data(), c->restInvMass.size() * sizeof(float2), hipMemcpyHostToDevice, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            c->constraintsDirty = false; clothsDirty = true;
+        }
+    }
+    if (clothsDirty) {
+        std::vector<ClothDev> d(cloths.size());
+        for (size_t i = 0; i < cloths.size(); ++i) {
+            HCloth& c = *cloths[i];
+            ClothDev& o = d[i];
+            o.pos = c.pos.p; o.prev = c.prev.p; o.vel = c.vel.p; o.force = c.force.p; o.pairs = c.dPairs.p; o.restInvMass = c.dRestInvMass.p; o.temp = c.temp.p; o.order = c.dOrder.p;
+            std::memcpy(o.colourOffsets, c.colourOffsets, sizeof(o.colourOffsets));
+            o.gridX = c.desc.grid_size_x; o.gridY = c.desc.grid_size_y; o.numConstraints = (uint32_t)c.pairs.size();
+            o.gravityFactor = c.desc.gravity_factor; o.damping = c.desc.damping;
+        }
+        HIP_TRY(clothDescs.ensure(d.size()));
+        HIP_TRY(hipMemcpyAsync(clothDescs.p, d.data(), d.size() * sizeof(ClothDev), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        clothsDirty = false;
+    }
+    k_cloth_step<<<(uint32_t)cloths.size(), 256, 0, stream>>>(clothDescs.p, make_float3(globalForce.x, globalForce.y, globalForce.z), dt, clothIterations[0], clothIterations[1], clothIterations[2]);
+    HIP_TRY(hipGetLastError());
+    return MI_OK;
 }
 
 // handleNonCollisionInteractions (physics.cpp:952-1039) for the AABB overlaps the pair pass collected between rigid-body colliders
@@ -1241,6 +1299,117 @@ MI_API int mi_entities_create(mi_world* w, uint32_t count, const mi_entity_desc*
     return MI_OK;
 }
 MI_API int mi_entity_create(mi_world* w, const mi_entity_desc* d, uint32_t* out) { return mi_entities_create(w, 1, d, out); }
+// ---- cloth (cloth_component, src/physics/cloth.h:5-60)
+static V3 clothParticlePosition(const mi_cloth_desc& d, float relX, float relY) {   // getParticlePosition, cloth.cpp:126-132
+    V3 p(relX * d.width, -relY * d.height, 0.f);
+    p.x -= d.width * 0.5f;
+    float t = p.y; p.y = p.z; p.z = t;
+    return p;
+}
+MI_API int mi_cloth_create(mi_world* w, const mi_cloth_desc* d, uint32_t* out) {   // cloth_component ctor, cloth.cpp:7-85
+    if (!w || !d) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (d->grid_size_x < 2 || d->grid_size_y < 2 || !(d->total_mass > 0.f) || !(d->stiffness > 0.f)) return fail(MI_ERR_INVALID_ARGUMENT, "bad cloth description");
+    HIP_TRY(hipSetDevice(w->device));
+    mi_world::HCloth* c = new mi_world::HCloth();
+    c->desc = *d; c->oldTotalMass = d->total_mass; c->oldStiffness = d->stiffness;
+    const uint32_t gx = d->grid_size_x, gy = d->grid_size_y, n = gx * gy;
+    const float invMassPerParticle = (float)n / d->total_mass;
+    std::vector<float4> pos(n);
+    c->invMasses.resize(n);
+    for (uint32_t y = 0; y < gy; ++y)
+        for (uint32_t x = 0; x < gx; ++x) {
+            const float im = (y == 0) ? 0.f : invMassPerParticle;   // upper row locked
+            V3 p = clothParticlePosition(*d, (float)x / (float)(gx - 1), (float)y / (float)(gy - 1));
+            pos[y * gx + x] = make_float4(p.x, p.y, p.z, im); c->invMasses[y * gx + x] = im;
+        }
+    std::vector<uint32_t> colours;
+    auto add = [&](uint32_t a, uint32_t b, uint32_t colour) {
+        V3 d_ = V3(pos[a].x, pos[a].y, pos[a].z) - V3(pos[b].x, pos[b].y, pos[b].z);
+        c->pairs.push_back(make_uint2(a, b));
+        c->restInvMass.push_back(make_float2(len(d_), (c->invMasses[a] + c->invMasses[b]) / d->stiffness));
+        colours.push_back(colour);
+    };
+    for (uint32_t y = 0; y < gy; ++y)
+        for (uint32_t x = 0; x < gx; ++x) {   // creation order of cloth.cpp:46-80; colour = family x parity (cloth.hpp)
+            const uint32_t i = y * gx + x;
+            if (x < gx - 1) add(i, i + 1, 0 + (x & 1u));
+            if (y < gy - 1) add(i, i + gx, 2 + (y & 1u));
+            if (x < gx - 1 && y < gy - 1) { add(i, i + gx + 1, 4 + (x & 1u)); add(i + gx, i + 1, 6 + (x & 1u)); }
+            if (x < gx - 2) add(i, i + 2, 8 + ((x >> 1) & 1u));
+            if (y < gy - 2) add(i, i + gx * 2, 10 + ((y >> 1) & 1u));
+        }
+    const uint32_t nc = (uint32_t)c->pairs.size();
+    c->order.resize(nc);
+    for (uint32_t k = 0; k < nc; ++k) c->order[k] = k;
+    std::stable_sort(c->order.begin(), c->order.end(), [&](uint32_t a, uint32_t b) { return colours[a] < colours[b]; });
+    std::memset(c->colourOffsets, 0, sizeof(c->colourOffsets));
+    for (uint32_t k = 0; k < nc; ++k) c->colourOffsets[colours[k] + 1]++;
+    for (int k = 0; k < 12; ++k) c->colourOffsets[k + 1] += c->colourOffsets[k];
+    int rc = MI_OK;
+    auto up = [&]() -> int {
+        HIP_TRY(c->pos.ensure(n)); HIP_TRY(c->prev.ensure(n)); HIP_TRY(c->vel.ensure(n)); HIP_TRY(c->force.ensure(n)); HIP_TRY(c->temp.ensure(nc));
+        HIP_TRY(c->dPairs.ensure(nc)); HIP_TRY(c->dRestInvMass.ensure(nc)); HIP_TRY(c->dOrder.ensure(nc));
+        HIP_TRY(hipMemcpy(c->pos.p, pos.data(), n * sizeof(float4), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(c->prev.p, pos.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemset(c->vel.p, 0, n * sizeof(float4))); HIP_TRY(hipMemset(c->force.p, 0, n * sizeof(float4)));
+        HIP_TRY(hipMemcpy(c->dPairs.p, c->pairs.data(), nc * sizeof(uint2), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->dOrder.p, c->order.data(), nc * sizeof(uint32_t), hipMemcpyHostToDevice));
+        return MI_OK;
+    };
+    rc = up();
+    if (rc != MI_OK) { delete c; return rc; }
+    if (out) *out = (uint32_t)w->cloths.size();
+    w->cloths.push_back(c); w->clothsDirty = true;
+    return MI_OK;
+}
+MI_API int mi_cloth_set_fixed_vertices(mi_world* w, uint32_t cloth, const float* p3, const float* r4, uint32_t moveRigid) {   // cloth.cpp:87-124
+    if (!w || cloth >= w->cloths.size() || !p3 || !r4) return fail(MI_ERR_INVALID_ARGUMENT, "bad cloth / null argument");
+    HIP_TRY(hipSetDevice(w->device));
+    mi_world::HCloth& c = *w->cloths[cloth];
+    const uint32_t gx = c.desc.grid_size_x, gy = c.desc.grid_size_y, n = gx * gy;
+    std::vector<float4> pos(n);
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    HIP_TRY(hipMemcpy(pos.data(), c.pos.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+    const V3 tp(p3[0], p3[1], p3[2]); const Q4 tr(r4[0], r4[1], r4[2], r4[3]);
+    auto xf = [&](V3 p) { return rotate(tr, p) + tp; };
+    auto at = [&](uint32_t i) { return V3(pos[i].x, pos[i].y, pos[i].z); };
+    if (moveRigid) {
+        V3 pivot = (gx % 2 == 1) ? at(gx / 2) : (at(gx / 2) + at(gx / 2 - 1)) * 0.5f;
+        V3 currentAxis = normalize(at(gx - 1) - at(0));
+        V3 newAxis = normalize(xf(clothParticlePosition(c.desc, 1.f, 0.f)) - xf(clothParticlePosition(c.desc, 0.f, 0.f)));
+        V3 newPivot = xf(clothParticlePosition(c.desc, 0.5f, 0.f));
+        Q4 deltaRotation = rotateFromTo(currentAxis, newAxis);
+        for (uint32_t y = 1; y < gy; ++y)
+            for (uint32_t x = 0; x < gx; ++x) { V3 q = rotate(deltaRotation, at(y * gx + x) - pivot) + newPivot; float4& o = pos[y * gx + x]; o.x = q.x; o.y = q.y; o.z = q.z; }
+    }
+    for (uint32_t x = 0; x < gx; ++x) { V3 q = xf(clothParticlePosition(c.desc, (float)x / (float)(gx - 1), 0.f)); pos[x].x = q.x; pos[x].y = q.y; pos[x].z = q.z; }
+    HIP_TRY(hipMemcpy(c.pos.p, pos.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    return MI_OK;
+}
+MI_API int mi_cloth_set_properties(mi_world* w, uint32_t cloth, float totalMass, float stiffness, float damping, float gravityFactor) {
+    if (!w || cloth >= w->cloths.size()) return fail(MI_ERR_INVALID_ARGUMENT, "bad cloth");
+    mi_cloth_desc& d = w->cloths[cloth]->desc;
+    d.total_mass = totalMass; d.stiffness = stiffness; d.damping = damping; d.gravity_factor = gravityFactor;
+    w->clothsDirty = true;
+    return MI_OK;
+}
+MI_API int mi_cloth_get_state(mi_world* w, uint32_t cloth, float* outPos, float* outVel, uint32_t cap) {
+    if (!w || cloth >= w->cloths.size()) return fail(MI_ERR_INVALID_ARGUMENT, "bad cloth");
+    HIP_TRY(hipSetDevice(w->device));
+    mi_world::HCloth& c = *w->cloths[cloth];
+    const uint32_t n = c.desc.grid_size_x * c.desc.grid_size_y;
+    if (cap < n) return fail(MI_ERR_CAPACITY, "capacity < particles");
+    std::vector<float4> buf(n);
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    if (outPos) { HIP_TRY(hipMemcpy(buf.data(), c.pos.p, n * sizeof(float4), hipMemcpyDeviceToHost)); for (uint32_t i = 0; i < n; ++i) { outPos[3 * i] = buf[i].x; outPos[3 * i + 1] = buf[i].y; outPos[3 * i + 2] = buf[i].z; } }
+    if (outVel) { HIP_TRY(hipMemcpy(buf.data(), c.vel.p, n * sizeof(float4), hipMemcpyDeviceToHost)); for (uint32_t i = 0; i < n; ++i) { outVel[3 * i] = buf[i].x; outVel[3 * i + 1] = buf[i].y; outVel[3 * i + 2] = buf[i].z; } }
+    return MI_OK;
+}
+MI_API int mi_world_set_cloth_iterations(mi_world* w, uint32_t v, uint32_t p, uint32_t d) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    w->clothIterations[0] = v; w->clothIterations[1] = p; w->clothIterations[2] = d;
+    return MI_OK;
+}
+
 // ---- heightmap terrain (heightmap_collider_component, src/terrain/heightmap_collider.h:126-151)
 MI_API int mi_heightmap_create(mi_world* w, uint32_t chunksPerDim, float chunkSize, float restitution, float friction) {
     if (!w || !chunksPerDim || !(chunkSize > 0.f)) return fail(MI_ERR_INVALID_ARGUMENT, "bad heightmap parameters");
@@ -1527,6 +1696,20 @@ MI_API int mi_world_save_checkpoint(mi_world* w, void* out, uint64_t capacity, u
     if (!keys.empty()) { put(blob, keys.data(), keys.size()); put(blob, vals.data(), vals.size()); }
     if (!w->prevTriggerOverlaps.empty()) put(blob, w->prevTriggerOverlaps.data(), w->prevTriggerOverlaps.size());
     putPods(blob, j.distance); putPods(blob, j.ball); putPods(blob, j.fixed); putPods(blob, j.hinge); putPods(blob, j.cone); putPods(blob, j.slider);
+    {   // cloths: particle state (positions incl. inverse mass, previous positions, velocities, force accumulators) and the editable properties
+        const uint32_t numCloths = (uint32_t)w->cloths.size();
+        put(blob, &numCloths, 1);
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        for (mi_world::HCloth* c : w->cloths) {
+            const uint32_t n = c->desc.grid_size_x * c->desc.grid_size_y;
+            put(blob, &c->desc, 1); put(blob, &c->oldTotalMass, 1); put(blob, &c->oldStiffness, 1);
+            std::vector<float4> buf(4 * (size_t)n);
+            HIP_TRY(hipMemcpy(buf.data(), c->pos.p, n * sizeof(float4), hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(buf.data() + n, c->prev.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(buf.data() + 2 * (size_t)n, c->vel.p, n * sizeof(float4), hipMemcpyDeviceToHost)); HIP_TRY(hipMemcpy(buf.data() + 3 * (size_t)n, c->force.p, n * sizeof(float4), hipMemcpyDeviceToHost));
+            put(blob, buf.data(), buf.size());
+            put(blob, c->restInvMass.data(), c->restInvMass.size());
+        }
+    }
     *out_size = blob.size();
     if (!out) return MI_OK;
     if (capacity < blob.size()) return fail(MI_ERR_CAPACITY, "capacity < checkpoint size");
@@ -1552,6 +1735,25 @@ MI_API int mi_world_load_checkpoint(mi_world* w, const void* data, uint64_t size
     w->prevTriggerOverlaps.resize(h.numTriggerOverlaps);
     okay = okay && take(p, end, w->prevTriggerOverlaps.data(), w->prevTriggerOverlaps.size());
     okay = okay && takePods(p, end, j.distance) && takePods(p, end, j.ball) && takePods(p, end, j.fixed) && takePods(p, end, j.hinge) && takePods(p, end, j.cone) && takePods(p, end, j.slider);
+    uint32_t numCloths = 0;
+    okay = okay && take(p, end, &numCloths, 1);
+    if (okay && numCloths != w->cloths.size()) return fail(MI_ERR_INVALID_ARGUMENT, "checkpoint belongs to a different scene (cloth count differs)");
+    for (mi_world::HCloth* c : w->cloths) {
+        if (!okay) break;
+        mi_cloth_desc d; float oldMass = 0.f, oldStiff = 0.f;
+        okay = take(p, end, &d, 1) && take(p, end, &oldMass, 1) && take(p, end, &oldStiff, 1);
+        if (okay && (d.grid_size_x != c->desc.grid_size_x || d.grid_size_y != c->desc.grid_size_y)) return fail(MI_ERR_INVALID_ARGUMENT, "checkpoint belongs to a different scene (cloth grid differs)");
+        const uint32_t n = c->desc.grid_size_x * c->desc.grid_size_y;
+        std::vector<float4> buf(4 * (size_t)n);
+        okay = okay && take(p, end, buf.data(), buf.size()) && take(p, end, c->restInvMass.data(), c->restInvMass.size());
+        if (!okay) break;
+        c->desc = d; c->oldTotalMass = oldMass; c->oldStiffness = oldStiff;
+        for (uint32_t i = 0; i < n; ++i) c->invMasses[i] = buf[i].w;
+        HIP_TRY(hipMemcpy(c->pos.p, buf.data(), n * sizeof(float4), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(c->prev.p, buf.data() + n, n * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->vel.p, buf.data() + 2 * (size_t)n, n * sizeof(float4), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(c->force.p, buf.data() + 3 * (size_t)n, n * sizeof(float4), hipMemcpyHostToDevice));
+        c->constraintsDirty = true;
+    }
+    w->clothsDirty = true;
     if (!okay || p != end) return fail(MI_ERR_INVALID_ARGUMENT, "truncated or oversized checkpoint");
     w->timer = h.timer; w->sapAxis = h.sapAxis; w->eventsEnabled = h.eventsEnabled != 0; w->pendingEvents.clear();
     w->topologyDirty = true; w->haveEstimates = false;

@@ -272,6 +272,30 @@ MI_API int mi_world_get_aabbs(mi_world* world, float* out_min_max6, uint32_t cap
 MI_API int mi_world_get_manifold_colors(mi_world* world, uint32_t* out_colors, uint32_t capacity);
 
 /*
+ * Cloth — cloth_component (src/physics/cloth.h:5-60, cloth.cpp): a gridSizeX x gridSizeY particle grid (upper row fixed) with
+ * stretch / shear / bend distance constraints, stepped after the rigid bodies of every internal step
+ * (physics.cpp:1352-1358): wind from the global force field, gravity, then numClothVelocityIterations /
+ * numClothPositionIterations / numClothDriftIterations Gauss-Seidel passes (physics_settings defaults 0 / 1 / 0,
+ * src/physics/physics.h:390-392; mi_world_set_cloth_iterations changes them).  Cloth does not interact with rigid bodies.
+ *   mi_cloth_create             = cloth_component(width, height, gridSizeX, gridSizeY, totalMass, stiffness, damping, gravityFactor)
+ *   mi_cloth_set_fixed_vertices = setWorldPositionOfFixedVertices(transform, moveRigid)
+ *   mi_cloth_set_properties     = writing totalMass / stiffness / damping / gravityFactor (recalculateProperties on the next step)
+ */
+typedef struct mi_cloth_desc {
+    float width, height;
+    uint32_t grid_size_x, grid_size_y;
+    float total_mass;
+    float stiffness;        /* default 0.5 */
+    float damping;          /* default 0.3 */
+    float gravity_factor;   /* default 1 */
+} mi_cloth_desc;
+MI_API int mi_cloth_create(mi_world* world, const mi_cloth_desc* desc, uint32_t* out_cloth);
+MI_API int mi_cloth_set_fixed_vertices(mi_world* world, uint32_t cloth, const float* position3, const float* rotation4, uint32_t move_rigid);
+MI_API int mi_cloth_set_properties(mi_world* world, uint32_t cloth, float total_mass, float stiffness, float damping, float gravity_factor);
+MI_API int mi_cloth_get_state(mi_world* world, uint32_t cloth, float* out_positions3, float* out_velocities3, uint32_t capacity_particles);
+MI_API int mi_world_set_cloth_iterations(mi_world* world, uint32_t velocity_iterations, uint32_t position_iterations, uint32_t drift_iterations);
+
+/*
  * Checkpoint / resume of the solver-relevant state: body states and accumulators, physics_transform0 and the
  * interpolated transforms, the step accumulator, the SAP axis of the next step, the contact-colour history (= the previous
  * step's collision list), the previous trigger overlaps, the constraint PODs.  A world built from the same scene description

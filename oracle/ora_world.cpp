@@ -158,7 +158,7 @@ uint64_t pairPriority(uint32_t a, uint32_t b) {
 // ---------------------------------------------------------------- world
 
 World::World() { joints = jointsCreate(); }
-World::~World() { jointsDestroy(joints); delete heightmap; }
+World::~World() { jointsDestroy(joints); delete heightmap; for (Cloth* c : cloths) delete c; }
 
 static float sphereVolume(float r) { float sq = r * r; float sqpi = kPi * sq; return 4.f / 3.f * sqpi * r; }  // bounding_volumes.h:34-40
 
@@ -858,7 +858,12 @@ static void collisionEvents(World& w) {
 void World::stepInternal(const mi_step_settings& settings, float dt) {
     if (dirtyProps) recalculateProperties();
     uint32_t nb = (uint32_t)bodies.size();
-    if (nb == 0) return;
+    if (nb == 0 && cloths.empty()) return;   // physics.cpp:1184-1189
+    if (nb == 0) {                           // cloth only: the rigid-body stages run over nothing
+        vec3 wind = nonCollisionInteractions(*this);
+        for (Cloth* c : cloths) { c->applyWindForce(wind); c->simulate(clothIterations[0], clothIterations[1], clothIterations[2], dt, orderMode != 0); }
+        return;
+    }
     uint32_t axisUsed = sortingAxis;
     getWorldSpaceColliders(*this);
     if (orderMode == 0) { broadphaseReference(*this); narrowphaseReference(*this); }
@@ -903,6 +908,10 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
         for (uint32_t id : solveOrder) solveContact(*this, id, cc[id]);
     }
     for (uint32_t i = nb; i-- > 0;) integrateVelocity(bodies[i], rb[i], dt);
+    for (Cloth* c : cloths) {   // physics.cpp:1352-1358
+        c->applyWindForce(globalForceField);
+        c->simulate(clothIterations[0], clothIterations[1], clothIterations[2], dt, orderMode != 0);
+    }
 
     counts.num_rigid_bodies = nb;
     counts.num_colliders = (uint32_t)colliders.size();
@@ -1161,6 +1170,38 @@ MI_API int ora_world_get_contacts(World* w, mi_contact* out, uint32_t cap, uint3
             o.collider_a = w->colliderPairs[m].a; o.collider_b = w->colliderPairs[m].b >= kHeightmapVirtualBase ? 0xFFFFFFFFu : w->colliderPairs[m].b;
             o.body_a = w->bodyPairs[ci].a; o.body_b = w->bodyPairs[ci].b;
         }
+    return MI_OK;
+}
+MI_API int ora_cloth_create(World* w, const mi_cloth_desc* d, uint32_t* out) {
+    if (!w || !d || d->grid_size_x < 2 || d->grid_size_y < 2 || !(d->total_mass > 0.f) || !(d->stiffness > 0.f)) return MI_ERR_INVALID_ARGUMENT;
+    if (out) *out = (uint32_t)w->cloths.size();
+    w->cloths.push_back(new Cloth(*d));
+    return MI_OK;
+}
+MI_API int ora_cloth_set_fixed_vertices(World* w, uint32_t cloth, const float* p, const float* r, uint32_t moveRigid) {
+    if (!w || cloth >= w->cloths.size() || !p || !r) return MI_ERR_INVALID_ARGUMENT;
+    w->cloths[cloth]->setFixedVertices(vec3(p[0], p[1], p[2]), quat(r[0], r[1], r[2], r[3]), moveRigid != 0);
+    return MI_OK;
+}
+MI_API int ora_cloth_set_properties(World* w, uint32_t cloth, float totalMass, float stiffness, float damping, float gravityFactor) {
+    if (!w || cloth >= w->cloths.size()) return MI_ERR_INVALID_ARGUMENT;
+    Cloth& c = *w->cloths[cloth];
+    c.totalMass = totalMass; c.stiffness = stiffness; c.damping = damping; c.gravityFactor = gravityFactor;
+    return MI_OK;
+}
+MI_API int ora_cloth_get_state(World* w, uint32_t cloth, float* pos, float* vel, uint32_t cap) {
+    if (!w || cloth >= w->cloths.size()) return MI_ERR_INVALID_ARGUMENT;
+    const Cloth& c = *w->cloths[cloth];
+    if (cap < c.positions.size()) return MI_ERR_CAPACITY;
+    for (size_t i = 0; i < c.positions.size(); ++i) {
+        if (pos) { pos[3 * i] = c.positions[i].x; pos[3 * i + 1] = c.positions[i].y; pos[3 * i + 2] = c.positions[i].z; }
+        if (vel) { vel[3 * i] = c.velocities[i].x; vel[3 * i + 1] = c.velocities[i].y; vel[3 * i + 2] = c.velocities[i].z; }
+    }
+    return MI_OK;
+}
+MI_API int ora_world_set_cloth_iterations(World* w, uint32_t v, uint32_t p, uint32_t d) {
+    if (!w) return MI_ERR_INVALID_ARGUMENT;
+    w->clothIterations[0] = v; w->clothIterations[1] = p; w->clothIterations[2] = d;
     return MI_OK;
 }
 MI_API int ora_heightmap_create(World* w, uint32_t chunksPerDim, float chunkSize, float restitution, float friction) {

@@ -106,6 +106,22 @@ struct Heightmap {
 // keys, colouring priorities and the colour history unique (real collider indices stay below it).
 static const uint32_t kHeightmapVirtualBase = (1u << 26) - 256u;
 
+// cloth_component (src/physics/cloth.h:5-60)
+struct Cloth {
+    struct Constraint { uint32_t a, b; float restDistance, inverseMassSum; };
+    float width, height; uint32_t gridSizeX, gridSizeY;
+    float totalMass, gravityFactor, damping, stiffness, oldTotalMass, oldStiffness;
+    std::vector<vec3> positions, prevPositions, velocities, forces;
+    std::vector<float> invMasses;
+    std::vector<Constraint> constraints;
+    std::vector<uint32_t> colours, canonicalOrder;   // device order: colour-major (12 colours: family x parity)
+    explicit Cloth(const mi_cloth_desc& d);
+    void setFixedVertices(vec3 position, quat rotation, bool moveRigid);
+    void applyWindForce(vec3 force);
+    void recalculateProperties();
+    void simulate(uint32_t velocityIterations, uint32_t positionIterations, uint32_t driftIterations, float dt, bool canonical);
+};
+
 struct SapEndpoint { float value; uint32_t creation; bool start; uint32_t colliderIndex; };
 
 struct JointStore;  // ora_joints.cpp
@@ -138,6 +154,8 @@ struct World {
     std::vector<uint32_t> forceFieldEntities, triggerEntities;   // entity ids by dense index
     std::vector<Interaction> interactions;                        // last step
     std::vector<uint64_t> prevTriggerOverlaps;                    // sorted (triggerEntity << 32 | rbEntity)
+    std::vector<Cloth*> cloths;
+    uint32_t clothIterations[3] = {0, 1, 0};                      // velocity, position, drift (physics_settings defaults)
     Heightmap* heightmap = nullptr;                               // at most one per world
     uint32_t heightmapCollisions = 0, heightmapContacts = 0;     // last step: colliders touching the terrain, their contacts
     bool eventsEnabled = false;

@@ -378,3 +378,47 @@ def test_ray_interaction_known_answers(oracle_mod):
     w.step_fixed(s, dt, 1)
     after = w.velocities()[0]
     assert after[2, 1] < before[2, 1] - 1e-4
+
+
+def test_cloth_known_answers(oracle_mod):
+    """cloth_component (cloth.cpp): grid layout, locked upper row, first-step free fall of the loose particles, hanging
+    equilibrium with near-rest constraint lengths, wind along the global force field, both constraint orders close."""
+    gx, gy, width, height, mass = 9, 7, 2.0, 1.5, 3.0
+    for mode in (oracle_mod.ORDER_REFERENCE, oracle_mod.ORDER_CANONICAL):
+        w = oracle_mod.create_world(mode)
+        c = w.create_cloth(width, height, gx, gy, mass)
+        p0, v0 = w.cloth_state(c, gx * gy)
+        grid = p0.reshape(gy, gx, 3)
+        assert np.allclose(grid[0, :, 0], np.linspace(-width / 2, width / 2, gx), atol=1e-6)      # getParticlePosition: x across,
+        assert np.allclose(grid[:, 0, 2], -np.linspace(0, height, gy), atol=1e-6) and np.allclose(p0[:, 1], 0)   # y and z swapped: the sheet lies in the x-z plane
+        s = capi.StepSettings(1, 120, 4, 1); dt = 1 / 120
+        w.set_cloth_iterations(0, 0, 0)                          # no constraint passes: pure integration
+        w.step_fixed(s, dt, 1)
+        p1, v1 = w.cloth_state(c, gx * gy)
+        damp = 1 / (1 + dt * 0.3)
+        assert np.allclose(p1[:gx], p0[:gx]) and np.allclose(v1[:gx], 0)                          # locked row
+        assert np.allclose(v1[gx:, 1], -9.81 * dt * damp, rtol=1e-5) and np.allclose(p1[gx:, 1], -9.81 * dt * dt, rtol=1e-5)
+        w.set_cloth_iterations(0, 1, 0)
+        w.set_cloth_properties(c, mass, 0.5, 4.0, 1.0)           # heavier damping: the sheet swings down around its locked row and settles
+        w.step_fixed(s, dt, 2400)
+        p, v = w.cloth_state(c, gx * gy)
+        assert np.abs(v).max() < 0.05 and np.allclose(p[:gx], p0[:gx])
+        g2 = p.reshape(gy, gx, 3)
+        assert (g2[1:, :, 1] < -0.05).all() and (np.diff(g2[:, gx // 2, 1]) < 0).all()            # hangs below the locked row, monotonically
+        seg = np.linalg.norm(np.diff(g2, axis=0), axis=2)
+        assert np.allclose(seg, height / (gy - 1), rtol=0.25)                                       # vertical constraints close to rest (soft: stiffness 0.5)
+    # wind: a global force field along +z pushes the hanging sheet to +z (the sheet normal is +-y / z after it has swung down)
+    res = {}
+    for mode in (oracle_mod.ORDER_REFERENCE, oracle_mod.ORDER_CANONICAL):
+        w = oracle_mod.create_world(mode)
+        e = scenes.make_entities(1, capi.ENTITY_FORCE_FIELD)
+        w.create_entities(e); w.set_force(0, (0.0, 0.0, 6.0))
+        c = w.create_cloth(width, height, gx, gy, mass)
+        w.set_cloth_fixed_vertices(c, (0.0, 3.0, 0.0), move_rigid=True)   # the whole sheet moves up to y = 3, then swings down around its locked row
+        w.step_fixed(capi.StepSettings(1, 120, 4, 1), 1 / 120, 90)
+        res[mode] = w.cloth_state(c, gx * gy)[0]                    # early: the two Gauss-Seidel orders have not drifted apart yet
+        w.step_fixed(capi.StepSettings(1, 120, 4, 1), 1 / 120, 510)
+        p = w.cloth_state(c, gx * gy)[0]
+        assert np.allclose(p[:gx, 1], 3.0, atol=1e-5)
+        assert p[gx:, 2].mean() > 0.05
+    assert np.abs(res[oracle_mod.ORDER_REFERENCE] - res[oracle_mod.ORDER_CANONICAL]).max() < 0.02

@@ -99,7 +99,11 @@ def test_gpu_checkpoint_resume_is_bit_identical(mi_lib, oracle_mod, make, events
     PODs and the step accumulator all travel in the blob."""
     sc = make()
     s = sc.settings()
-    a = sc.populate(mi_lib.create_world(0)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    def build(world):
+        w = sc.populate(world)
+        w.create_cloth(2.0, 1.5, 10, 8, 3.0)      # a cloth rides along: its particle state is part of the checkpoint
+        return w
+    a = build(mi_lib.create_world(0)); o = build(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     if events:
         a.enable_events(); o.enable_events()
     nh = 6 * 9
@@ -113,8 +117,9 @@ def test_gpu_checkpoint_resume_is_bit_identical(mi_lib, oracle_mod, make, events
         drive(a, it); drive(o, it)
         if events:
             assert a.poll_events().tobytes() == o.poll_events().tobytes()
+    a.set_cloth_properties(0, 4.0, 0.7, 0.5, 0.9); o.set_cloth_properties(0, 4.0, 0.7, 0.5, 0.9)
     blob = a.save_checkpoint()
-    b = sc.populate(mi_lib.create_world(0))
+    b = build(mi_lib.create_world(0))
     if events:
         b.enable_events()
     b.load_checkpoint(blob)
@@ -125,7 +130,8 @@ def test_gpu_checkpoint_resume_is_bit_identical(mi_lib, oracle_mod, make, events
         if events:
             ea = a.poll_events()
             assert ea.tobytes() == b.poll_events().tobytes() == o.poll_events().tobytes()
-    for x, y, z in zip(a.transforms() + a.velocities(), b.transforms() + b.velocities(), o.transforms() + o.velocities()):
+    for x, y, z in zip(a.transforms() + a.velocities() + a.cloth_state(0, 80), b.transforms() + b.velocities() + b.cloth_state(0, 80),
+                       o.transforms() + o.velocities() + o.cloth_state(0, 80)):
         assert x.tobytes() == y.tobytes() == z.tobytes()
     with pytest.raises(mi_lib.PhysicsError):
         scenes.obb_pile(3, 2, 3).populate(mi_lib.create_world(0)).load_checkpoint(blob)     # other scene
