@@ -397,6 +397,20 @@ class World:
         self.L.check(self.L.fn("world_set_body_states_device")(self.h, C.c_uint32(n), C.c_void_p(body_ids_ptr), C.c_void_p(in_ptr)),
                      "world_set_body_states_device")
 
+    def get_body_states_device_async(self, n, body_ids_ptr, out_ptr):
+        self.L.check(self.L.fn("world_get_body_states_device_async")(self.h, C.c_uint32(n), C.c_void_p(body_ids_ptr), C.c_void_p(out_ptr)),
+                     "world_get_body_states_device_async")
+
+    def set_body_states_device_async(self, n, body_ids_ptr, in_ptr):
+        self.L.check(self.L.fn("world_set_body_states_device_async")(self.h, C.c_uint32(n), C.c_void_p(body_ids_ptr), C.c_void_p(in_ptr)),
+                     "world_set_body_states_device_async")
+
+    def stream_ptr(self):
+        """The world's hipStream_t as an integer (for torch.cuda.ExternalStream)."""
+        out = C.c_void_p()
+        self.L.check(self.L.fn("world_get_stream")(self.h, C.byref(out)), "world_get_stream")
+        return out.value or 0
+
     def accumulated_stage_times(self, reset=False):
         """(sum of per-stage device ms, steps, contact updates) since the last reset — product library only."""
         t = StageTimes(); n = C.c_uint32(0); u = C.c_uint64(0)

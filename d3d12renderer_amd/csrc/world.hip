@@ -1905,19 +1905,24 @@ MI_API int mi_world_entities_to_bodies(mi_world* w, uint32_t n, const uint32_t* 
     }
     return MI_OK;
 }
-MI_API int mi_world_get_body_states_device(mi_world* w, uint32_t n, const uint32_t* idsDev, float* outDev) {
-    if (!w || (n && (!idsDev || !outDev))) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+static int statesDevice(mi_world* w, uint32_t n, const uint32_t* idsDev, float* outDev, const float* inDev, bool sync) {
+    if (!w || (n && (!idsDev || (!outDev && !inDev)))) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     int rc = ensureUploaded(w); if (rc != MI_OK) return rc;
-    if (n) k_gather_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p, outDev);
-    HIP_TRY(hipStreamSynchronize(w->stream));
+    if (n && outDev) k_gather_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p, outDev);
+    if (n && inDev) { k_scatter_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, inDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p); w->hostStale = true; }
+    if (sync) HIP_TRY(hipStreamSynchronize(w->stream));
     return MI_OK;
 }
-MI_API int mi_world_set_body_states_device(mi_world* w, uint32_t n, const uint32_t* idsDev, const float* inDev) {
-    if (!w || (n && (!idsDev || !inDev))) return fail(MI_ERR_INVALID_ARGUMENT, "null");
-    int rc = ensureUploaded(w); if (rc != MI_OK) return rc;
-    if (n) k_scatter_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, inDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p);
-    HIP_TRY(hipStreamSynchronize(w->stream));
-    w->hostStale = true;
+MI_API int mi_world_get_body_states_device(mi_world* w, uint32_t n, const uint32_t* idsDev, float* outDev) { return statesDevice(w, n, idsDev, outDev, nullptr, true); }
+MI_API int mi_world_set_body_states_device(mi_world* w, uint32_t n, const uint32_t* idsDev, const float* inDev) { return statesDevice(w, n, idsDev, nullptr, inDev, true); }
+// The same without a host synchronisation: the copy kernels are only ENQUEUED on the world's stream (mi_world_get_stream).  A
+// caller that runs its collective on that stream (e.g. torch.cuda.ExternalStream + RCCL) gets gather -> exchange -> scatter ->
+// next step ordered on the device with no host round trip in between.
+MI_API int mi_world_get_body_states_device_async(mi_world* w, uint32_t n, const uint32_t* idsDev, float* outDev) { return statesDevice(w, n, idsDev, outDev, nullptr, false); }
+MI_API int mi_world_set_body_states_device_async(mi_world* w, uint32_t n, const uint32_t* idsDev, const float* inDev) { return statesDevice(w, n, idsDev, nullptr, inDev, false); }
+MI_API int mi_world_get_stream(mi_world* w, void** out) {
+    if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    *out = (void*)w->stream;
     return MI_OK;
 }
 static int statesHost(mi_world* w, uint32_t n, const uint32_t* ents, float* out, const float* in) {

@@ -65,6 +65,9 @@ class ShardedWorld:
             self.recv_body_ids = torch.from_numpy(self.world.entities_to_bodies(self.recv_entities).astype(np.int32)).to(dev)
             self.send_buf = torch.zeros(max(ns, 1) * STATE_FLOATS, dtype=torch.float32, device=dev)
             self.recv_buf = torch.zeros(max(nr, 1) * STATE_FLOATS, dtype=torch.float32, device=dev)
+            # the collective runs ON the world's stream: gather -> all-to-all -> scatter -> next step are ordered on the device
+            self.stream = torch.cuda.ExternalStream(self.world.stream_ptr(), device=dev)
+            torch.cuda.synchronize()   # the id tensors were filled on torch's default stream
         else:
             self.send_buf = torch.zeros(max(ns, 1) * STATE_FLOATS, dtype=torch.float32)
             self.recv_buf = torch.zeros(max(nr, 1) * STATE_FLOATS, dtype=torch.float32)
@@ -78,12 +81,14 @@ class ShardedWorld:
         in_splits = [c * STATE_FLOATS for c in self.send_counts]
         out_splits = [c * STATE_FLOATS for c in self.recv_counts]
         if self.device_exchange:
-            if ns:
-                self.world.get_body_states_device(ns, self.send_body_ids.data_ptr(), self.send_buf.data_ptr())
-            self.dist.all_to_all_single(self.recv_buf[: nr * STATE_FLOATS], self.send_buf[: ns * STATE_FLOATS], out_splits, in_splits)
-            torch.cuda.current_stream().synchronize()
-            if nr:
-                self.world.set_body_states_device(nr, self.recv_body_ids.data_ptr(), self.recv_buf.data_ptr())
+            # no host synchronisation: the copy kernels and the collective are enqueued on the world's own stream (RCCL's
+            # internal stream is fenced against the current stream by torch on both sides of the call)
+            with torch.cuda.stream(self.stream):
+                if ns:
+                    self.world.get_body_states_device_async(ns, self.send_body_ids.data_ptr(), self.send_buf.data_ptr())
+                self.dist.all_to_all_single(self.recv_buf[: nr * STATE_FLOATS], self.send_buf[: ns * STATE_FLOATS], out_splits, in_splits)
+                if nr:
+                    self.world.set_body_states_device_async(nr, self.recv_body_ids.data_ptr(), self.recv_buf.data_ptr())
         else:
             if ns:
                 self.send_buf[: ns * STATE_FLOATS] = torch.from_numpy(self.world.get_body_states(self.send_entities).reshape(-1))

@@ -343,6 +343,12 @@ MI_API int mi_world_set_body_states(mi_world* world, uint32_t count, const uint3
 MI_API int mi_world_entities_to_bodies(mi_world* world, uint32_t count, const uint32_t* entities, uint32_t* out_body_indices);
 MI_API int mi_world_get_body_states_device(mi_world* world, uint32_t count, const uint32_t* body_indices_dev, float* out_states13_dev);
 MI_API int mi_world_set_body_states_device(mi_world* world, uint32_t count, const uint32_t* body_indices_dev, const float* states13_dev);
+/* The *_device calls without the host synchronisation: the copy kernels are only enqueued on the world's HIP stream
+ * (mi_world_get_stream returns the hipStream_t).  Running the collective on that stream (torch.cuda.ExternalStream + RCCL) orders
+ * gather -> exchange -> scatter -> next step on the device, with no host round trip in between. */
+MI_API int mi_world_get_body_states_device_async(mi_world* world, uint32_t count, const uint32_t* body_indices_dev, float* out_states13_dev);
+MI_API int mi_world_set_body_states_device_async(mi_world* world, uint32_t count, const uint32_t* body_indices_dev, const float* states13_dev);
+MI_API int mi_world_get_stream(mi_world* world, void** out_hip_stream);
 
 #ifdef __cplusplus
 }

@@ -441,6 +441,9 @@ class _LocalCollectives:
 
     def all_to_all_single(self, out, inp, out_splits, in_splits):
         sh = self.shared
+        import torch
+        if inp.is_cuda:
+            torch.cuda.current_stream().synchronize()   # RCCL orders the ranks' streams against each other; here the host does
         sh["inp"][self.rank] = (inp, list(in_splits))
         sh["barrier"].wait()
         o = 0
@@ -450,6 +453,8 @@ class _LocalCollectives:
             out[o: o + out_splits[peer]] = peer_inp[start: start + peer_splits[self.rank]]
             assert peer_splits[self.rank] == out_splits[peer]
             o += out_splits[peer]
+        if inp.is_cuda:
+            torch.cuda.current_stream().synchronize()
         sh["barrier"].wait()
 
     def all_reduce(self, t):

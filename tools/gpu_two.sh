@@ -2,4 +2,4 @@
 ulimit -c 0
 mkdir -p gpurun_out
 cd oracle && make >/dev/null 2>&1; cd ..
-timeout 600 python -m pytest tests/test_scene_formats.py tests/test_gpu_parity.py -x -q -m gpu -k "cloth or checkpoint" 2>&1 | tail -25 | tee gpurun_out/two.log
+timeout 600 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "sharded or exchange" 2>&1 | tail -25 | tee gpurun_out/two.log
