@@ -553,22 +553,31 @@ __device__ inline void epaRun(const Simplex& g, const Shape& A, const Shape& B, 
     out.depth = t.dist;
 }
 
-__device__ inline bool gjkEpaSingle(const Shape& a, const Shape& b, const HullSet& hs, EpaState& st, Manifold& out, EpaOut& epa) {
-    Simplex sx;
-    if (!gjkTest(a, b, hs, sx)) return false;
+// The second half of every GJK+EPA test, from the simplex GJK ended with: penetration by EPA -> one contact.
+__device__ inline void epaSingle(const Simplex& sx, const Shape& a, const Shape& b, const HullSet& hs, EpaState& st, Manifold& out, EpaOut& epa) {
     epaRun(sx, a, b, hs, st, epa);   // EPA status is ignored by every caller (collision_narrow.cpp:509-512)
     out.n = epa.normal;
     out.count = 1;
     out.d[0] = epa.depth;
     out.p[0] = epa.point;
+}
+__device__ inline bool gjkEpaSingle(const Shape& a, const Shape& b, const HullSet& hs, EpaState& st, Manifold& out, EpaOut& epa) {
+    Simplex sx;
+    if (!gjkTest(a, b, hs, sx)) return false;
+    epaSingle(sx, a, b, hs, st, out, epa);
     return true;
 }
 
 // capsule / cylinder vs AABB (collision_narrow.cpp:705-768, 953-1020): if EPA found a box-face normal and the
 // segment is parallel to that face, clip the segment against the face -> up to 2 contacts.
+__device__ inline void segmentShapeVsAABBAfterEpa(const Shape& c, const Shape& box, const EpaOut& epa, Manifold& out);
 __device__ inline bool segmentShapeVsAABB(const Shape& c, const Shape& box, const HullSet& hs, EpaState& st, Manifold& out) {
     EpaOut epa;
     if (!gjkEpaSingle(c, box, hs, st, out, epa)) return false;
+    segmentShapeVsAABBAfterEpa(c, box, epa, out);
+    return true;
+}
+__device__ inline void segmentShapeVsAABBAfterEpa(const Shape& c, const Shape& box, const EpaOut& epa, Manifold& out) {
     V3 normal = epa.normal;
     if (fabsf(normal.x) > 0.99f || fabsf(normal.y) > 0.99f || fabsf(normal.z) > 0.99f) {
         V3 axis = normalize(c.b - c.a);
@@ -587,10 +596,11 @@ __device__ inline bool segmentShapeVsAABB(const Shape& c, const Shape& box, cons
             clipAndBuild(poly, clipped, planes, 4, ref, out);
         }
     }
-    return true;
 }
 
-__device__ inline bool cylinderCylinder(const Shape& a, const Shape& b, const HullSet& hs, EpaState& st, Manifold& out) {  // 821-951
+// cylinder vs cylinder, the closed-form case of (nearly) parallel axes (collision_narrow.cpp:821-925).  Returns false when the
+// axes are not parallel (GJK + EPA decide then); otherwise `hit` / `out` are final.
+__device__ inline bool cylinderCylinderParallel(const Shape& a, const Shape& b, bool& hit, Manifold& out) {
     V3 aDir = a.b - a.a;
     V3 bDir = normalize(b.b - b.a);
     float aLen = len(aDir);
@@ -603,14 +613,16 @@ __device__ inline bool cylinderCylinder(const Shape& a, const Shape& b, const Hu
         float a0 = 0.f, a1 = aLen;
         float b0 = dot(aDir, pBa - ref), b1 = dot(aDir, pBb - ref);
         float left = fmaxr(a0, b0), right = fminr(a1, b1);
-        if (right < left) return false;
+        hit = false;
+        if (right < left) return true;
         V3 cA0 = ref + left * aDir, cA1 = ref + right * aDir;
         V3 cB0 = closestOnSegment(cA0, pBa, pBb);
         V3 cB1 = cB0 + (right - left) * aDir;
         V3 normal = cB0 - cA0;
         float d = len(normal);
         float pen = (a.radius + b.radius) - d;
-        if (pen < 0.f) return false;
+        if (pen < 0.f) return true;
+        hit = true;
         float capPen = right - left;
         if (capPen < pen) {
             out.count = 1;
@@ -628,6 +640,11 @@ __device__ inline bool cylinderCylinder(const Shape& a, const Shape& b, const Hu
         }
         return true;
     }
+    return false;
+}
+__device__ inline bool cylinderCylinder(const Shape& a, const Shape& b, const HullSet& hs, EpaState& st, Manifold& out) {  // 821-951
+    bool hit;
+    if (cylinderCylinderParallel(a, b, hit, out)) return hit;
     EpaOut epa;
     return gjkEpaSingle(a, b, hs, st, out, epa);
 }

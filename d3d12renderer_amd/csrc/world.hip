@@ -731,6 +731,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         HIP_TRY(boxQueue.ensure((size_t)kBoxQueues * queueRegion));
         k_narrow<<<narrowBlocks, B, 0, st>>>(pairBound, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p, boxQueue.p);
         k_narrow_clip<<<kBoxQueues * (queueRegion / B), B, 0, st>>>(queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, boxQueue.p, npPacked.p, npNormal.p, npPoints.p);
+        // (a GJK-only kernel feeding a queue of hits to an EPA kernel was measured: no gain — the GJK half already needs ~250 VGPRs)
         if (usesGjk) k_narrow_gjk<<<divUp(pairBound, 64), 64, 0, st>>>(sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
         if (heightmap) {
             const HmOut hmOut{sc, pairBound, pairKeys.p, pairKeysS.p, npPacked.p, npNormal.p, npPoints.p};
