@@ -1459,10 +1459,15 @@ __device__ __forceinline__ void storePairSc1(const PairBody& X, bool odd, bool n
     if (odd ? need : partnerNeed) storeGranuleSc1(X.q1, d1);
 }
 
-template <int CNT>
+// LDSIMP: the accumulated impulses live in LDS (`ldsImp`, [k][lane]) because the same wave runs this tile in every sweep
+// (k_contact_solve_persist); otherwise they travel between sweeps as tagged granules in `imp`.
+template <int CNT, bool LDSIMP>
+__device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint32_t it, const uint4 meta, const float4 nf, const float2 mass, const ContactRows* c,
+                                            float4* imp, float4* gVel, StepScalars* sc, float2* ldsImp);
+template <int CNT, bool LDSIMP = false>
 __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_t lane, uint32_t it, const uint4* __restrict__ slotMeta,
                                          const float4* __restrict__ slotNormal, const float2* __restrict__ slotMass,
-                                         const float4* __restrict__ rows, float4* imp, float4* gVel, StepScalars* sc) {
+                                         const float4* __restrict__ rows, float4* imp, float4* gVel, StepScalars* sc, float2* ldsImp = nullptr) {
     const uint4 meta = slotMeta[(size_t)tile * 64u + lane];
     const float4 nf = slotNormal[(size_t)tile * 64u + lane];
     const float2 mass = slotMass[(size_t)tile * 64u + lane];
@@ -1473,6 +1478,13 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
 #pragma unroll
         for (uint32_t r = 0; r < kRows; ++r) c[k].r[r] = row[r * 64u];
     }
+    processTile<CNT, LDSIMP>(ctBase, lane, it, meta, nf, mass, c, imp, gVel, sc, ldsImp);
+}
+// The tile proper, from data already requested (flowTile) or prefetched (k_contact_solve_persist): wait for the bodies (and the
+// impulse granules), solve, publish.
+template <int CNT, bool LDSIMP>
+__device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint32_t it, const uint4 meta, const float4 nf, const float2 mass, const ContactRows* c,
+                                            float4* imp, float4* gVel, StepScalars* sc, float2* ldsImp) {
     const uint32_t bA = meta.x, bB = meta.y, pk = meta.z;
     const float imA = mass.x, imB = mass.y;
     const bool valid = meta.w != 0u;
@@ -1487,21 +1499,30 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
     f32x4 ig[CNT], a0, a1, b0, b1;
     const bool odd = (lane & 1u) != 0u;
     const PairBody PA(pA, odd), PB(pB, odd);
+    if (!LDSIMP) {
 #pragma unroll
-    for (int k = 0; k < CNT; ++k) issueGranuleSc1(pI + (size_t)k * 64u, ig[k]);
+        for (int k = 0; k < CNT; ++k) issueGranuleSc1(pI + (size_t)k * 64u, ig[k]);
+    }
     {
         f32x4 ra0, ra1, rb0, rb1;
         loadPair4Sc1(PA, PB, ra0, ra1, rb0, rb1);
         pairGather(odd, ra0, ra1, a0, a1);
         pairGather(odd, rb0, rb1, b0, b1);
     }
+    if (!LDSIMP) {
 #pragma unroll
-    for (int k = 0; k < CNT; ++k) landed(ig[k]);
+        for (int k = 0; k < CNT; ++k) landed(ig[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) { float2 v = ldsImp[k * 64 + lane]; ig[k].x = v.x; ig[k].y = v.y; ig[k].z = 0.f; ig[k].w = 0.f; }
+    }
     bool okA = !needA || (__float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA);
     bool okB = !needB || (__float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB);
     bool okI = true;
+    if (!LDSIMP) {
 #pragma unroll
-    for (int k = 0; k < CNT; ++k) okI = okI && (!live || __float_as_uint(ig[k].z) == it);
+        for (int k = 0; k < CNT; ++k) okI = okI && (!live || __float_as_uint(ig[k].z) == it);
+    }
     uint32_t budget = kSpinBudget;
     while (__ballot(!(okA && okB && okI)) != 0ull) {   // tight polling measured fastest: only the pairs still waiting re-load
         // both lanes of a pair must poll together; the partner flags are exchanged OUTSIDE any short-circuit so every lane
@@ -1542,7 +1563,10 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
         storePairSc1(PA, odd, needA, hA0, hA1);
         storePairSc1(PB, odd, needB, hB0, hB1);
     }
-    if (live) {
+    if (LDSIMP) {
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) ldsImp[k * 64 + lane] = out[k];
+    } else if (live) {
         float t = __uint_as_float(it + 1u);
 #pragma unroll
         for (int k = 0; k < CNT; ++k) {
@@ -1568,6 +1592,73 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_W
         case 3: flowTile<3>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc); break;
         default: flowTile<4>(tile, d.x, lane, it, slotMeta, slotNormal, slotMass, rows, imp, gVel, sc); break;
     }
+}
+
+// Persistent variant: `numWaves` workgroups (one per SIMD of the chip, all resident at once), workgroup w owns the tiles
+// w, w + numWaves, ... in EVERY sweep and walks them in schedule order, sweep after sweep.  Because a tile never changes
+// hands, its accumulated impulses stay in LDS: no impulse granules are read, polled or written (one 16-byte write-through
+// store and one tagged load less per contact and sweep; 13 % fewer bytes).  Dependencies between tiles are the body tags as
+// before.  Forward progress: every wave runs its tiles in ascending (sweep, tile) order and a tile only waits for smaller
+// (sweep, tile) pairs, so the wave owning the smallest unfinished pair is never blocked — provided all workgroups are
+// resident, which the host guarantees by launching at most one per SIMD (waits are bounded by the spin budget regardless).
+#ifndef MI_PERSIST_WPE
+#define MI_PERSIST_WPE 1
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIST_WPE))) void k_contact_solve_persist(
+    uint32_t sweeps, uint32_t maxSlots, const uint2* __restrict__ tileDesc, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
+    const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* gVel, StepScalars* sc) {
+    // LDS per workgroup: [maxSlots] x { meta uint4[64], normal float4[64], mass float2[64] } (constant over the sweeps), then the
+    // impulses float2[4 * maxSlots][64], then the per-slot (first contact-tile, contacts per manifold, impulse offset)
+    extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    uint4* lMeta = reinterpret_cast<uint4*>(ldsRaw);
+    float4* lNormal = reinterpret_cast<float4*>(lMeta + (size_t)maxSlots * 64u);
+    float2* lMass = reinterpret_cast<float2*>(lNormal + (size_t)maxSlots * 64u);
+    float2* lImp = lMass + (size_t)maxSlots * 64u;
+    uint32_t* lDesc = reinterpret_cast<uint32_t*>(lImp + (size_t)maxSlots * 4u * 64u);   // [maxSlots][3]
+    const uint32_t numTiles = sc->totalTiles, numWaves = gridDim.x, lane = threadIdx.x;
+    uint32_t mySlots = 0, off = 0;
+    for (uint32_t tile = blockIdx.x; tile < numTiles && mySlots < maxSlots; tile += numWaves, ++mySlots) {
+        const uint2 d = tileDesc[tile];
+        lMeta[mySlots * 64u + lane] = slotMeta[(size_t)tile * 64u + lane];
+        lNormal[mySlots * 64u + lane] = slotNormal[(size_t)tile * 64u + lane];
+        lMass[mySlots * 64u + lane] = slotMass[(size_t)tile * 64u + lane];
+        if (lane == 0) { lDesc[3 * mySlots] = d.x; lDesc[3 * mySlots + 1] = d.y; lDesc[3 * mySlots + 2] = off; }
+        for (uint32_t k = 0; k < d.y; ++k) lImp[(size_t)(off + k) * 64u + lane] = make_float2(0.f, 0.f);
+        off += d.y;
+    }
+    if (blockIdx.x + (size_t)mySlots * numWaves < numTiles) { if (lane == 0) sc->solveError = 2u; return; }   // more tiles than the host sized LDS for
+    __syncthreads();
+    if (!mySlots) return;
+    // software pipeline over (sweep, slot): the rows of the NEXT tile are requested before this tile waits for its bodies
+    ContactRows nx[4];
+    auto fetchRows = [&](uint32_t slot) {
+        const uint32_t ct = lDesc[3 * slot], cnt = lDesc[3 * slot + 1];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k)
+            if (k < cnt) {
+                const float4* __restrict__ row = rows + ((size_t)ct + k) * (kRows * 64u) + lane;
+#pragma unroll
+                for (uint32_t r = 0; r < kRows; ++r) nx[k].r[r] = row[r * 64u];
+            }
+    };
+    fetchRows(0);
+    for (uint32_t it = 0; it < sweeps; ++it)
+        for (uint32_t slot = 0; slot < mySlots; ++slot) {
+            ContactRows cur[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4u; ++k) cur[k] = nx[k];
+            const uint32_t ct = lDesc[3 * slot], cnt = lDesc[3 * slot + 1], io = lDesc[3 * slot + 2];
+            const uint4 meta = lMeta[slot * 64u + lane]; const float4 nf = lNormal[slot * 64u + lane]; const float2 mass = lMass[slot * 64u + lane];
+            const uint32_t nextSlot = slot + 1u < mySlots ? slot + 1u : 0u;
+            if (slot + 1u < mySlots || it + 1u < sweeps) fetchRows(nextSlot);
+            float2* li = lImp + (size_t)io * 64u;
+            switch (cnt) {
+                case 1: processTile<1, true>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li); break;
+                case 2: processTile<2, true>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li); break;
+                case 3: processTile<3, true>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li); break;
+                default: processTile<4, true>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li); break;
+            }
+        }
 }
 
 // Overflow colour (a body with > 64 incident manifolds): sequential, one lane, slots in ascending pair-key order.

@@ -145,6 +145,7 @@ struct mi_world {
     bool eventsEnabled = false; DBuf<uint8_t> manIsNew; DBuf<DeviceEvent> devEvents; std::vector<mi_event> pendingEvents;
     DBuf<float4> rows, slotNormal; DBuf<float4> imp; DBuf<float2> slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc;
     bool usedFlow = false;
+    bool persistSolver = false; uint32_t persistWaves = 1024;   // MI_SOLVER=persist: one resident workgroup per SIMD owns its tiles through all sweeps
     uint32_t flowLds = 0;                  // dynamic LDS bytes per 64-lane workgroup: caps resident waves per CU (160 KiB / flowLds)
     bool flowSolver = true;               // dataflow PGS sweep (one launch per iteration); MI_SOLVER=launch selects one launch per colour
     BinInfo bins[kSchedBins]{};           // host copy of the last step's schedule
@@ -203,6 +204,9 @@ int mi_world::init(int dev) {
     const char* as = getenv("MI_ASYNC");
     specEnabled = !(as && as[0] == '0');
     if (const char* fl = getenv("MI_FLOW_LDS")) flowLds = (uint32_t)strtoul(fl, nullptr, 0);
+    { const char* sv = getenv("MI_SOLVER"); persistSolver = sv && std::string(sv) == "persist";
+      hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) persistWaves = 4u * (uint32_t)prop.multiProcessorCount;
+      if (const char* pw = getenv("MI_PERSIST_WAVES")) persistWaves = (uint32_t)strtoul(pw, nullptr, 0); }
     if (flowLds > 65536) (void)hipFuncSetAttribute((const void*)k_contact_solve_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flowLds);
     return MI_OK;
 }
@@ -854,6 +858,17 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                                                                                    tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, sc);
             if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
         }
+    } else if (useFlow && persistSolver && joints.count() == 0 && tilesLaunch && divUp(tilesLaunch, persistWaves) * (64u * 40u + 4u * 512u + 12u) <= 38u * 1024u) {
+        // persistent waves: one workgroup per SIMD owns its tiles through all sweeps, slot data and impulses in LDS (k_contact_solve_persist)
+        const uint32_t maxSlots = divUp(tilesLaunch, persistWaves);
+        solveLaunches = 1;
+        if (profileSolve) {
+            size_t e = 2 * (size_t)profLaunches;
+            while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
+            (void)hipEventRecord(profEvents[e], st);
+        }
+        k_contact_solve_persist<<<persistWaves, 64, maxSlots * (64u * 40u + 4u * 512u + 12u) + 16u, st>>>(iters, maxSlots, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, sc);
+        if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
     } else if (useFlow) {
         // no joints between the sweeps -> all sweeps in one launch; otherwise one launch per sweep (joints run in between)
         const uint32_t perLaunch = joints.count() == 0 && (uint64_t)std::max(tilesLaunch, 1u) * iters < 0x7FFFFFFFull ? iters : 1u;

@@ -299,6 +299,21 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
     assert g2.cloth_state(0, 144)[0].tobytes() == o2.cloth_state(0, 144)[0].tobytes()
 
 
+def test_gpu_persistent_solver_variant_matches_oracle(mi_lib, oracle_mod, monkeypatch):
+    """MI_SOLVER=persist (k_contact_solve_persist: one resident workgroup per SIMD owns its tiles through all sweeps, slot data
+    and impulses in LDS, next tile's rows prefetched) is an opt-in variant of the dataflow solver: same results, bit for bit."""
+    monkeypatch.setenv("MI_SOLVER", "persist")
+    sc = scenes.obb_pile(14, 8, 14, spacing=1.05)
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    for i in range(70):
+        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        assert g.counts() == o.counts(), f"step {i}"
+    assert g.counts()["num_contacts"] > 3000
+    assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
+    monkeypatch.delenv("MI_SOLVER")
+
+
 def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
     """Steps after the first run with ONE host read-back, sized from the previous step's counts.  Teleporting the bodies into
     a much denser pile invalidates those bounds: the step must be re-run synchronously from the untouched state and still match
