@@ -12,7 +12,7 @@ quoted on; it fits one GPU.  N > 1 is weak scaling: every rank steps one 262 144
 "multi-GPU").  All scene state is resident in HBM before the timed region starts.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the
-contact PGS solver: k_contact_solve_flow, one launch for all sweeps of a step; algorithmic bytes from
+contact PGS solver: k_contact_solve_persist (k_contact_solve_flow with MI_SOLVER=flow), one launch for all sweeps of a step; algorithmic bytes from
 SURVEY.md §8(d)) and `cpu_baseline` (CPU oracle, reference order, bounded sample) objects.
 """
 import argparse
@@ -179,12 +179,12 @@ def main():
         # whole-job throughput: every rank steps its 262144-body tile each step; the job advances one scene step per `ms_per_step`
         # and processes world_size tiles, so value = tiles-steps per second (at N=1: plain steps/s of the 262144-body scene).
         value = world_size * args.steps / elapsed
-        # Dominant kernel = the contact PGS solver.  Default path: k_contact_solve_flow, ONE launch per step covering all
-        # sweeps (MI_SOLVER=launch: one k_contact_solve launch per colour per sweep).  achieved = algorithmic bytes of all
+        # Dominant kernel = the contact PGS solver.  Default path: k_contact_solve_persist, ONE launch per step covering all
+        # sweeps (MI_SOLVER=flow: k_contact_solve_flow, also one launch; MI_SOLVER=launch: one k_contact_solve launch per colour per sweep).  achieved = algorithmic bytes of all
         # contact updates (236 B per contact per sweep) / HIP-event time of the solve stage, recorded on
         # the world's own stream around exactly those launches, averaged over the timed steps.
         launches_per_step = launches / args.steps
-        kernel = "k_contact_solve_flow" if launches_per_step <= args.iterations else "k_contact_solve"
+        kernel = sw.world.solver_kernel()   # k_contact_solve_persist by default (k_contact_solve_flow / k_contact_solve with MI_SOLVER=flow / launch)
         achieved = (BYTES_PER_CONTACT_ITER * contact_iters) / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else 0.0
         event_pair = (BYTES_PER_CONTACT_ITER * prof_updates) / (prof_ms * 1e-3) / 1e9 if prof_ms > 0 else 0.0
         roofline = {

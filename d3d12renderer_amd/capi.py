@@ -411,6 +411,14 @@ class World:
         self.L.check(self.L.fn("world_get_stream")(self.h, C.byref(out)), "world_get_stream")
         return out.value or 0
 
+    SOLVER_KERNELS = ("k_contact_solve", "k_contact_solve_flow", "k_contact_solve_persist", "k_solve_flow_islands")
+
+    def solver_kernel(self):
+        """Name of the contact-solver kernel the last internal step ran."""
+        k = C.c_uint32()
+        self.L.check(self.L.fn("world_get_solver_kind")(self.h, C.byref(k)), "world_get_solver_kind")
+        return self.SOLVER_KERNELS[k.value]
+
     def accumulated_stage_times(self, reset=False):
         """(sum of per-stage device ms, steps, contact updates) since the last reset — product library only."""
         t = StageTimes(); n = C.c_uint32(0); u = C.c_uint64(0)

@@ -1404,16 +1404,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 2))) voi
 // every wait is bounded anyway (spin budget -> StepScalars::solveError -> MI_ERR_DEVICE, no hang).
 // ------------------------------------------------------------------------------------------------
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef MI_SC_LOAD
+#define MI_SC_LOAD " sc1"    // cache-policy bits of the granule loads / stores (development experiments override them)
+#endif
+#ifndef MI_SC_STORE
+#define MI_SC_STORE " sc1"
+#endif
 constexpr uint32_t kSpinBudget = 1u << 16;
 #ifndef MI_FLOW_WAVES
 #define MI_FLOW_WAVES 1   // resident waves per SIMD the flow kernel is compiled for (measured: 1 = 0.86 ms, 2 = 1.02 ms per 20 sweeps at 262144 bodies)
 #endif
 
 // single 16-byte granule: issue only (the next waiting asm block lands it), load + wait, store
-__device__ __forceinline__ void issueGranuleSc1(const float4* p, f32x4& g) { asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=&v"(g) : "v"(p) : "memory"); }
+__device__ __forceinline__ void issueGranuleSc1(const float4* p, f32x4& g) { asm volatile("global_load_dwordx4 %0, %1, off" MI_SC_LOAD : "=&v"(g) : "v"(p) : "memory"); }
 __device__ __forceinline__ void landed(f32x4& g) { asm volatile("" : "+v"(g)); }   // orders every later use of g behind the waiting block
-__device__ __forceinline__ void loadGranuleSc1(const float4* p, f32x4& g) { asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory"); }
-__device__ __forceinline__ void storeGranuleSc1(float4* p, f32x4 g) { asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(g) : "memory"); }
+__device__ __forceinline__ void loadGranuleSc1(const float4* p, f32x4& g) { asm volatile("global_load_dwordx4 %0, %1, off" MI_SC_LOAD "\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory"); }
+__device__ __forceinline__ void storeGranuleSc1(float4* p, f32x4 g) { asm volatile("global_store_dwordx4 %0, %1, off" MI_SC_STORE : : "v"(p), "v"(g) : "memory"); }
 
 // Lane pairs (2i, 2i+1) move one body per instruction: the even lane touches granule 0 and the odd lane granule 1 of the
 // SAME body, i.e. one contiguous, 32-byte-aligned transaction instead of two scattered 16-byte ones (scattered
@@ -1442,12 +1448,12 @@ __device__ __forceinline__ void pairGather(bool odd, f32x4 r0, f32x4 r1, f32x4& 
     g1 = odd ? r1 : p0;
 }
 __device__ __forceinline__ void loadPair4Sc1(const PairBody& A, const PairBody& B, f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1) {
-    asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
-                 "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+    asm volatile("global_load_dwordx4 %0, %4, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %1, %5, off" MI_SC_LOAD "\n\t"
+                 "global_load_dwordx4 %2, %6, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %3, %7, off" MI_SC_LOAD "\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(A.q0), "v"(A.q1), "v"(B.q0), "v"(B.q1) : "memory");
 }
 __device__ __forceinline__ void loadPair2Sc1(const PairBody& A, f32x4& a0, f32x4& a1) {
-    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+    asm volatile("global_load_dwordx4 %0, %2, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %1, %3, off" MI_SC_LOAD "\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a0), "=&v"(a1) : "v"(A.q0), "v"(A.q1) : "memory");
 }
 // publish one body slot: h0 / h1 = this lane's own granules, need = this lane's body is written at all

@@ -299,10 +299,10 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
     assert g2.cloth_state(0, 144)[0].tobytes() == o2.cloth_state(0, 144)[0].tobytes()
 
 
-def test_gpu_persistent_solver_variant_matches_oracle(mi_lib, oracle_mod, monkeypatch):
-    """MI_SOLVER=persist (k_contact_solve_persist: one resident workgroup per SIMD owns its tiles through all sweeps, slot data
-    and impulses in LDS, next tile's rows prefetched) is an opt-in variant of the dataflow solver: same results, bit for bit."""
-    monkeypatch.setenv("MI_SOLVER", "persist")
+def test_gpu_dispatch_ordered_flow_solver_matches_oracle(mi_lib, oracle_mod, monkeypatch):
+    """MI_SOLVER=flow selects k_contact_solve_flow (one workgroup per (sweep, tile), dispatch-ordered; also the automatic
+    fallback of the default persistent kernel and the path taken with joints): same results, bit for bit."""
+    monkeypatch.setenv("MI_SOLVER", "flow")
     sc = scenes.obb_pile(14, 8, 14, spacing=1.05)
     g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     s = sc.settings()
