@@ -835,7 +835,8 @@ struct JointType {
             if ((e = hipMalloc((void**)&dBodies, n * sizeof(uint2))) != hipSuccess) return e;
             if ((e = hipMalloc((void**)&dOrder, n * sizeof(uint32_t))) != hipSuccess) return e;
             if ((e = hipMalloc((void**)&dUpd, n * sizeof(typename J::Upd))) != hipSuccess) return e;
-            if ((e = hipMalloc((void**)&dAcc, 2 * n * sizeof(float4))) != hipSuccess) return e;
+            // exchanged between workgroups as tagged sc1 granules: uncached memory serves those fastest (see world.hip, gVel)
+            if ((e = hipExtMallocWithFlags((void**)&dAcc, 2 * n * sizeof(float4), hipDeviceMallocUncached)) != hipSuccess) return e;
             dCap = n;
         }
         hipError_t e;
