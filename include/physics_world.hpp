@@ -26,6 +26,10 @@ struct physics_material { float restitution = 0.1f, friction = 0.5f, density = 1
 struct collision_begin_event { uint32_t entityA, entityB, colliderA, colliderB; vec3 position, normal, relativeVelocity; };
 struct collision_end_event { uint32_t entityA, entityB, colliderA, colliderB; };
 
+enum trigger_event_type { trigger_event_enter, trigger_event_leave };                    // src/physics/physics.h:187-198
+struct trigger_event { uint32_t trigger, other; trigger_event_type type; };
+struct ray { vec3 origin, direction; };
+
 struct physics_settings {
     bool fixedFrameRate = true;
     uint32_t frameRate = 120;
@@ -127,6 +131,48 @@ public:
     template <class Pod> void setConstraint(constraint_handle h, const Pod& p) { check(mi_constraint_update(w_, h.type, h.id, &p, sizeof(p)), "mi_constraint_update"); }
 
     void applyForce(scene_entity e, vec3 force, vec3 torque) { check(mi_entity_apply_force(w_, e.id, &force.x, &torque.x), "mi_entity_apply_force"); }
+    // testPhysicsInteraction(scene, ray, strength) — src/physics/physics.h:404
+    void testPhysicsInteraction(ray r, float strength = 1000.f) { check(mi_world_test_interactions(w_, 1, &r.origin.x, &r.direction.x, &strength, nullptr), "mi_world_test_interactions"); }
+
+    // deleteConstraint / deleteAllConstraintsFromEntity / deleteAllConstraints — src/physics/physics.h:251-260
+    void deleteConstraint(constraint_handle h) { check(mi_constraint_destroy(w_, h.type, h.id), "mi_constraint_destroy"); }
+    void deleteAllConstraintsFromEntity(scene_entity e) { check(mi_entity_destroy_constraints(w_, e.id), "mi_entity_destroy_constraints"); }
+    void deleteAllConstraints() { check(mi_constraints_destroy_all(w_), "mi_constraints_destroy_all"); }
+
+    // force_field_component / trigger_component entities (src/physics/physics.h:182-203): colliders define the volume; a force
+    // field without colliders is global.  The trigger callback fires from step() like the collision callbacks.
+    scene_entity addForceField(const trs& t, vec3 force, const std::vector<collider_component>& colliders = {}) {
+        scene_entity e = addEntity(t, MI_ENTITY_FORCE_FIELD, nullptr, colliders);
+        check(mi_entity_set_force(w_, e.id, &force.x), "mi_entity_set_force");
+        return e;
+    }
+    scene_entity addTrigger(const trs& t, const std::vector<collider_component>& colliders, std::function<void(const trigger_event&)> callback) {
+        scene_entity e = addEntity(t, MI_ENTITY_TRIGGER, nullptr, colliders);
+        triggerCallbacks_.emplace_back(e.id, std::move(callback));
+        return e;
+    }
+
+    // heightmap_collider_component (src/terrain/heightmap_collider.h:126-151): one per world; heights = 129 x 129 uint16 per chunk
+    void addHeightmap(uint32_t chunksPerDim, float chunkSize, physics_material m) { check(mi_heightmap_create(w_, chunksPerDim, chunkSize, m.restitution, m.friction), "mi_heightmap_create"); }
+    void setHeightmapChunk(uint32_t x, uint32_t z, const uint16_t* heights) { check(mi_heightmap_set_chunk_heights(w_, x, z, heights), "mi_heightmap_set_chunk_heights"); }
+    void updateHeightmap(vec3 minCorner, float amplitudeScale) { check(mi_heightmap_update(w_, &minCorner.x, amplitudeScale), "mi_heightmap_update"); }
+    float getHeightAt(float x, float z) { float h = 0.f; check(mi_heightmap_get_height(w_, x, z, &h), "mi_heightmap_get_height"); return h; }
+
+    // cloth_component (src/physics/cloth.h:5-60)
+    uint32_t addCloth(float width, float height, uint32_t gridSizeX, uint32_t gridSizeY, float totalMass, float stiffness = 0.5f, float damping = 0.3f, float gravityFactor = 1.f) {
+        mi_cloth_desc d{width, height, gridSizeX, gridSizeY, totalMass, stiffness, damping, gravityFactor};
+        uint32_t id = 0; check(mi_cloth_create(w_, &d, &id), "mi_cloth_create"); return id;
+    }
+    void setWorldPositionOfFixedVertices(uint32_t cloth, const trs& t, bool moveRigid = false) {
+        check(mi_cloth_set_fixed_vertices(w_, cloth, &t.position.x, &t.rotation.x, moveRigid ? 1u : 0u), "mi_cloth_set_fixed_vertices");
+    }
+    std::vector<vec3> clothPositions(uint32_t cloth, uint32_t numParticles) {
+        std::vector<float> p(3 * (size_t)numParticles);
+        check(mi_cloth_get_state(w_, cloth, p.data(), nullptr, numParticles), "mi_cloth_get_state");
+        std::vector<vec3> out(numParticles);
+        for (uint32_t i = 0; i < numParticles; ++i) out[i] = {p[3 * i], p[3 * i + 1], p[3 * i + 2]};
+        return out;
+    }
 
     // physicsStep(scene, arena, timer, settings, dt) — the timer and the arena live inside the world.
     void step(const physics_settings& settings, float dt) { mi_step_settings s = settings.c(); syncEvents(settings); check(mi_world_step(w_, &s, dt), "mi_world_step"); fireEvents(settings); }
@@ -150,7 +196,7 @@ private:
     // The reference fires its std::function callbacks inside the step (handleCollisionCallbacks, physics.cpp:1041-1178); here
     // the events of the step are polled right after it and delivered in the same order.
     void syncEvents(const physics_settings& settings) {
-        bool want = (bool)settings.collisionBeginCallback || (bool)settings.collisionEndCallback;
+        bool want = (bool)settings.collisionBeginCallback || (bool)settings.collisionEndCallback || !triggerCallbacks_.empty();
         if (want != eventsOn_) { check(mi_world_enable_events(w_, want ? 1u : 0u), "mi_world_enable_events"); eventsOn_ = want; }
     }
     void fireEvents(const physics_settings& settings) {
@@ -161,7 +207,10 @@ private:
         std::vector<mi_event> ev(n);
         check(mi_world_poll_events(w_, ev.data(), n, &n), "mi_world_poll_events");
         for (const mi_event& e : ev) {
-            if (e.type == MI_EVENT_COLLISION_BEGIN) {
+            if (e.type == MI_EVENT_TRIGGER_ENTER || e.type == MI_EVENT_TRIGGER_LEAVE) {   // trigger_component::callback (physics.cpp:1004-1036)
+                for (auto& tc : triggerCallbacks_)
+                    if (tc.first == e.entity_a && tc.second) tc.second(trigger_event{e.entity_a, e.entity_b, e.type == MI_EVENT_TRIGGER_ENTER ? trigger_event_enter : trigger_event_leave});
+            } else if (e.type == MI_EVENT_COLLISION_BEGIN) {
                 if (settings.collisionBeginCallback)
                     settings.collisionBeginCallback(collision_begin_event{e.entity_a, e.entity_b, e.collider_a, e.collider_b, {e.point[0], e.point[1], e.point[2]},
                                                                           {e.normal[0], e.normal[1], e.normal[2]},
@@ -170,6 +219,7 @@ private:
         }
     }
     bool eventsOn_ = false;
+    std::vector<std::pair<uint32_t, std::function<void(const trigger_event&)>>> triggerCallbacks_;
 public:
 
 private:

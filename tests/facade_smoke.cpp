@@ -21,9 +21,23 @@ int main() {
         int begins = 0, ends = 0;
         settings.collisionBeginCallback = [&](const collision_begin_event& e) { ++begins; (void)e; };
         settings.collisionEndCallback = [&](const collision_end_event& e) { ++ends; (void)e; };
-        for (int i = 0; i < 120; ++i) physicsStep(world, settings, 1.f / 60.f);
+        // the wider surface: trigger + force field entities, a cloth, a ray push, constraint deletion
+        int enters = 0;
+        trs tt; tt.position = {0, 1, 0};
+        world.addTrigger(tt, {collider_component::asSphere({0, 0, 0}, 1.5f, mat)}, [&](const trigger_event& e) { if (e.type == trigger_event_enter) ++enters; });
+        world.addForceField(trs{}, {0.5f, 0.f, 0.f});
+        uint32_t cloth = world.addCloth(2.f, 2.f, 8, 8, 1.f);
+        trs ct; ct.position = {5, 4, 0};
+        world.setWorldPositionOfFixedVertices(cloth, ct, true);
+        for (int i = 0; i < 60; ++i) physicsStep(world, settings, 1.f / 60.f);
+        world.testPhysicsInteraction(ray{{-5.f, 0.5f, 0.f}, {1.f, 0.f, 0.f}}, 200.f);
+        world.deleteConstraint(h);
+        for (int i = 0; i < 60; ++i) physicsStep(world, settings, 1.f / 60.f);
         auto tr = world.transforms();
+        auto cp = world.clothPositions(cloth, 64);
         if (begins < 1) { std::printf("facade error: no collision-begin callback fired\n"); return 1; }
+        if (enters < 1) { std::printf("facade error: no trigger-enter callback fired\n"); return 1; }
+        if (!(cp[63].y < 3.9f)) { std::printf("facade error: the cloth did not move\n"); return 1; }
         std::printf("facade ok: a.y=%f b.y=%f contacts=%u begins=%d ends=%d\n", tr[a.id].position.y, tr[b.id].position.y, world.counts().num_contacts, begins, ends);
     } catch (const std::exception& e) {
         std::printf("facade error: %s\n", e.what());
