@@ -61,6 +61,8 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numInteractions;      // ... of which the boolean overlap test passed (non_collision_interaction records)
     uint32_t numHmContacts;        // heightmap terrain: contacts of this step (each is a one-contact manifold) ...
     uint32_t numHmColliders;       // ... and the colliders they belong to (= the reference's collision count for the terrain)
+    uint32_t xcdCount[8];          // XCD-partitioned solver: tiles owned by each XCD (k_build_tiles)
+    uint32_t xccOf[8];             // ... and the hardware XCC id the workgroups with blockIdx % 8 == i really ran on (0xFFFFFFFF = none yet)
 };
 
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
@@ -921,12 +923,16 @@ __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt,
                                                           const float4* __restrict__ bCogInvMass, const float4* __restrict__ bInvI,
                                                           const float4* __restrict__ bParams, const float4* __restrict__ bLinVel,
                                                           const float4* __restrict__ bAngVel, const float4* __restrict__ bForce, const float4* __restrict__ bTorque,
-                                                          float4* __restrict__ gPos, float4* __restrict__ gInvI, float4* __restrict__ gVel) {
+                                                          float4* __restrict__ gPos, float4* __restrict__ gInvI, float4* __restrict__ gVel,
+                                                          float4* __restrict__ gVelL /* XCD-partitioned solver: cached copy for the XCD-local bodies, or null */,
+                                                          unsigned long long* __restrict__ bodyOwner /* ... and the per-body XCD flags (8 bytes), cleared here */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > nb) return;
+    if (bodyOwner) bodyOwner[i] = 0ull;
     if (i == nb) {
         float4 z = make_float4(0, 0, 0, 0);
         gPos[i] = z; gInvI[3 * i] = z; gInvI[3 * i + 1] = z; gInvI[3 * i + 2] = z; gVel[2 * i] = z; gVel[2 * i + 1] = z;
+        if (gVelL) { gVelL[2 * i] = z; gVelL[2 * i + 1] = z; }
         return;
     }
     Q4 rot = toQ(bRot[i]);
@@ -954,6 +960,7 @@ __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt,
     gInvI[3 * i + 1] = make_float4(W.m10, W.m11, W.m12, 0.f);
     gInvI[3 * i + 2] = make_float4(W.m20, W.m21, W.m22, 0.f);
     gVel[2 * i] = f4(v, 0.f); gVel[2 * i + 1] = f4(w, 0.f);   // .w = update-version tag of the solver (0 at step start)
+    if (gVelL) { gVelL[2 * i] = f4(v, 0.f); gVelL[2 * i + 1] = f4(w, 0.f); }
 }
 
 // K13 "Integrate rigid body velocities" (src/physics/rigid_body.cpp:126-142).
@@ -962,9 +969,11 @@ __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float
                                                               const float4* __restrict__ bCogInvMass, const float4* __restrict__ bRotIn,
                                                               float4* __restrict__ bPos, float4* __restrict__ bRot,
                                                               float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, float4* __restrict__ bForce,
-                                                              float4* __restrict__ bTorque) {
+                                                              float4* __restrict__ bTorque,
+                                                              const float4* __restrict__ gVelL, const unsigned long long* __restrict__ bodyOwner /* XCD-partitioned solver, or null */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nb) return;
+    if (bodyOwner && __popcll(bodyOwner[i]) == 1) gVel = gVelL;   // a body only one XCD touched lives in the cached copy
     V3 v = xyz(gVel[2 * i]), w = xyz(gVel[2 * i + 1]);
     Q4 rot = toQ(bRotIn[i]);
     Q4 dq(0.5f * w.x, 0.5f * w.y, 0.5f * w.z, 0.f);
@@ -1056,8 +1065,95 @@ __global__ __launch_bounds__(256) void k_color_round(const StepScalars* __restri
 // (manifolds of one colour share no dynamic body); grouping by contact count makes solver waves uniform.
 constexpr uint32_t kBinItems = 1024;
 __device__ __forceinline__ uint32_t binOf(uint32_t color, uint32_t cnt) { return color * 4u + (cnt - 1u); }
-__global__ __launch_bounds__(256) void k_bin_hist(const StepScalars* __restrict__ sc, uint32_t numBlocks, const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo,
-                                                  uint32_t* __restrict__ blockHist) {
+
+// XCD-partitioned solver (k_contact_solve_persist<.., true>): the slots of every bin are laid out in ascending order of a
+// spatial key (`perm` below), so a bin's tiles sweep the scene along its longest axis; tile `tl` of the bin's `nt` tiles
+// belongs to XCD floor(8 tl / nt), i.e. every XCD gets an equal share of EVERY bin (balanced) and always the same slab of
+// the scene (bodies away from the slab seams are only ever touched from one XCD).  Bins shorter than 8 tiles are dealt
+// round-robin instead.  Results do not depend on any of this: which lane / wave / XCD runs a slot is invisible to the
+// body-version dataflow.
+__host__ __device__ __forceinline__ uint32_t tileOwner(uint32_t tl, uint32_t nt, uint32_t bin) { return nt >= 8u ? (tl * 8u) / nt : ((tl * 8u) / nt + bin) & 7u; }
+// number of tiles tl' < tl of the same bin with the same owner
+__host__ __device__ __forceinline__ uint32_t tileOwnerRank(uint32_t tl, uint32_t nt, uint32_t bin) {
+    if (nt >= 8u) { uint32_t x = (tl * 8u) / nt; return tl - (x * nt + 7u) / 8u; }
+    uint32_t x = tileOwner(tl, nt, bin), r = 0;
+    for (uint32_t k = 0; k < tl; ++k) r += tileOwner(k, nt, bin) == x ? 1u : 0u;
+    return r;
+}
+__host__ __device__ __forceinline__ uint32_t tileOwnerCount(uint32_t x, uint32_t nt, uint32_t bin) {
+    if (nt >= 8u) return ((x + 1u) * nt + 7u) / 8u - (x * nt + 7u) / 8u;
+    uint32_t r = 0;
+    for (uint32_t k = 0; k < nt; ++k) r += tileOwner(k, nt, bin) == x ? 1u : 0u;
+    return r;
+}
+// Spatial order of the manifolds: a counting sort by the position of the manifold's (first dynamic) body along the
+// longest axis of the broad-phase grid, kSpatialKeys levels; the order inside one level is arbitrary.  Two kernels:
+//   k_manifold_keys   key + arrival rank.  Neighbouring manifolds mostly share a key, so the ranks are taken in an LDS
+//                     histogram per workgroup and only one global atomic per (workgroup, key present) reserves the range;
+//   k_manifold_place  every workgroup scans the 4096 counts itself (cheaper than a separate scan launch) and places its items.
+constexpr uint32_t kSpatialKeys = 4096;
+constexpr uint32_t kKeyItems = 1024;   // manifolds per workgroup of k_manifold_keys
+__global__ __launch_bounds__(256) void k_manifold_keys(uint32_t n, const StepScalars* __restrict__ sc, const GridParams* __restrict__ gp, const uint2* __restrict__ manBodies,
+                                                       const float4* __restrict__ gPos, uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks, uint32_t* __restrict__ keyCount) {
+    __shared__ uint32_t hist[kSpatialKeys];   // local count, then the global base of this workgroup's range
+    for (uint32_t k = threadIdx.x; k < kSpatialKeys; k += 256) hist[k] = 0u;
+    __syncthreads();
+    const uint32_t nm = min(n, sc->numManifolds);
+    const GridParams g = *gp;
+    const uint32_t axis = g.dims[0] >= g.dims[1] && g.dims[0] >= g.dims[2] ? 0u : g.dims[2] >= g.dims[1] ? 2u : 1u;
+    const float scale = g.invCell * ((float)kSpatialKeys / (float)g.dims[axis]);
+    uint32_t key[kKeyItems / 256], local[kKeyItems / 256];
+#pragma unroll
+    for (uint32_t i = 0; i < kKeyItems / 256; ++i) {
+        const uint32_t m = blockIdx.x * kKeyItems + i * 256 + threadIdx.x;
+        key[i] = 0xFFFFFFFFu;
+        if (m < nm) {
+            uint2 b = manBodies[m];
+            float4 pa = gPos[b.x], pb = gPos[b.y];
+            float4 p = pa.w != 0.f ? pa : pb;
+            float c = axis == 0u ? p.x : axis == 1u ? p.y : p.z;
+            key[i] = (uint32_t)fminf(fmaxf((c - g.origin[axis]) * scale, 0.f), (float)(kSpatialKeys - 1u));
+            local[i] = atomicAdd(&hist[key[i]], 1u);
+        }
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < kSpatialKeys; k += 256) { uint32_t c = hist[k]; if (c) hist[k] = atomicAdd(&keyCount[k], c); }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kKeyItems / 256; ++i) {
+        const uint32_t m = blockIdx.x * kKeyItems + i * 256 + threadIdx.x;
+        if (key[i] != 0xFFFFFFFFu) { keys[m] = key[i]; ranks[m] = hist[key[i]] + local[i]; }
+    }
+}
+__global__ __launch_bounds__(256) void k_manifold_place(uint32_t n, const StepScalars* __restrict__ sc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ranks,
+                                                        const uint32_t* __restrict__ keyCount, uint32_t* __restrict__ perm) {
+    __shared__ uint32_t lower[kSpatialKeys];
+    __shared__ uint32_t part[256];
+    constexpr uint32_t per = kSpatialKeys / 256;
+    uint32_t v[per], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < per; ++k) { v[k] = keyCount[threadIdx.x * per + k]; sum += v[k]; }
+    part[threadIdx.x] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        uint32_t add = threadIdx.x >= d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    uint32_t run = part[threadIdx.x] - sum;
+#pragma unroll
+    for (uint32_t k = 0; k < per; ++k) { lower[threadIdx.x * per + k] = run; run += v[k]; }
+    __syncthreads();
+    const uint32_t nm = min(n, sc->numManifolds);
+#pragma unroll
+    for (uint32_t i = 0; i < kKeyItems / 256; ++i) {
+        const uint32_t m = blockIdx.x * kKeyItems + i * 256 + threadIdx.x;
+        if (m < nm) perm[lower[keys[m]] + ranks[m]] = m;
+    }
+}
+__global__ __launch_bounds__(256) void k_bin_hist(const StepScalars* __restrict__ sc, uint32_t numBlocks, const uint32_t* __restrict__ perm /* spatially sorted manifold ids, or null */,
+                                                  const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo, uint32_t* __restrict__ blockHist) {
     __shared__ uint32_t h[kColorBins];
     const uint32_t nm = sc->numManifolds;
     for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) h[b] = 0;
@@ -1065,12 +1161,14 @@ __global__ __launch_bounds__(256) void k_bin_hist(const StepScalars* __restrict_
 #pragma unroll
     for (uint32_t k = 0; k < kBinItems / 256; ++k) {
         uint32_t m = blockIdx.x * kBinItems + k * 256 + threadIdx.x;
+        if (perm && m < nm) m = perm[m];
         if (m < nm) { uint32_t c = color[m]; if (c <= kOverflowColor) atomicAdd(&h[binOf(c, manInfo[m].x & 7u)], 1u); }
     }
     __syncthreads();
     for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) blockHist[(size_t)b * numBlocks + blockIdx.x] = h[b];
 }
-__global__ __launch_bounds__(256) void k_bin_scatter(uint32_t lastRound, const uint32_t* __restrict__ roundFlags, uint32_t numBlocks, const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo,
+__global__ __launch_bounds__(256) void k_bin_scatter(uint32_t lastRound, const uint32_t* __restrict__ roundFlags, uint32_t numBlocks, const uint32_t* __restrict__ perm,
+                                                     const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo,
                                                      const uint32_t* __restrict__ blockScan, uint32_t* __restrict__ order, StepScalars* sc) {
     __shared__ uint32_t cur[kColorBins];
     const uint32_t nm = sc->numManifolds;
@@ -1084,6 +1182,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(uint32_t lastRound, const u
 #pragma unroll
     for (uint32_t k = 0; k < kBinItems / 256; ++k) {
         uint32_t m = blockIdx.x * kBinItems + k * 256 + threadIdx.x;
+        if (perm && m < nm) m = perm[m];
         if (m < nm) { uint32_t c = color[m]; if (c <= kOverflowColor) order[atomicAdd(&cur[binOf(c, manInfo[m].x & 7u)], 1u)] = m; }
     }
     // End of the last bin = the number of SCHEDULED manifolds (the last workgroup's cursor of the last bin ends there).  It
@@ -1135,7 +1234,7 @@ __device__ __forceinline__ M3 loadM3(const float4* __restrict__ p, uint32_t i) {
 // Schedule bins -> tiles, on the device (so the host never has to read the bin sizes back before it can launch the
 // constraint kernels): BinInfo per bin, tile -> bin and tile -> (first contact-tile, contacts per manifold) tables, totals.
 // The host launches the consumers over an upper bound of tiles; tiles >= totalTiles exit.
-__global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t ctCap, StepScalars* sc, BinInfo* __restrict__ binInfo) {
+__global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t ctCap, StepScalars* sc, BinInfo* __restrict__ binInfo, uint32_t* __restrict__ xcdBase /* [kSchedBins][8] or null */) {
     __shared__ BinInfo bins[kSchedBins];
     __shared__ uint32_t start[kColorBins + 4];
     for (uint32_t b = threadIdx.x; b <= kColorBins; b += blockDim.x) start[b] = sc->binStart[b];
@@ -1157,10 +1256,22 @@ __global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t
     }
     __syncthreads();
     for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) binInfo[bn] = bins[bn];
+    if (xcdBase) {   // per-XCD tile lists: first list position of every bin's share, and the list lengths
+        __shared__ uint32_t share[kSchedBins * 8u];
+        for (uint32_t i = threadIdx.x; i < kSchedBins * 8u; i += blockDim.x) share[i] = tileOwnerCount(i & 7u, (bins[i >> 3].count + 63u) >> 6, i >> 3);
+        __syncthreads();
+        if (threadIdx.x < 8u) {
+            const uint32_t x = threadIdx.x;
+            uint32_t at = 0;
+            for (uint32_t bn = 0; bn < kSchedBins; ++bn) { uint32_t c = share[bn * 8u + x]; xcdBase[bn * 8u + x] = at; at += c; }
+            sc->xcdCount[x] = sc->totalTiles ? at : 0u;
+        }
+    }
 }
 // tile -> bin (binary search over the bins' first tiles) and tile -> (first contact-tile, contacts per manifold)
 __global__ __launch_bounds__(256) void k_fill_tiles(const StepScalars* __restrict__ sc, const BinInfo* __restrict__ binInfo,
-                                                    uint32_t* __restrict__ tileBin, uint2* __restrict__ tileDesc) {
+                                                    uint32_t* __restrict__ tileBin, uint2* __restrict__ tileDesc,
+                                                    const uint32_t* __restrict__ xcdBase, uint32_t* __restrict__ xcdTiles /* [8][listCap] or null */, uint32_t listCap) {
     __shared__ uint32_t first[kSchedBins];
     for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) first[bn] = binInfo[bn].tileStart;
     __syncthreads();
@@ -1172,6 +1283,11 @@ __global__ __launch_bounds__(256) void k_fill_tiles(const StepScalars* __restric
     uint32_t stride = lo == kSchedBins - 1 ? 4u : (lo & 3u) + 1u;
     tileBin[t] = lo;
     tileDesc[t] = make_uint2(bi.ctStart + (t - bi.tileStart) * stride, stride);
+    if (xcdTiles) {
+        const uint32_t tl = t - bi.tileStart, nt = (bi.count + 63u) >> 6;
+        const uint32_t x = tileOwner(tl, nt, lo), at = xcdBase[lo * 8u + x] + tileOwnerRank(tl, nt, lo);
+        if (at < listCap) xcdTiles[(size_t)x * listCap + at] = t;   // (a longer list is reported by the solver kernel: solveError 2)
+    }
 }
 
 // K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379): one wave per tile, one lane per slot.
@@ -1184,7 +1300,8 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
                                                      const uint32_t* __restrict__ color, const unsigned long long* __restrict__ bodyUsed,
                                                      const uint8_t* __restrict__ bodyJ /* fused joint islands: 1 = the body gets one joint version per sweep, or null */,
                                                      float4* __restrict__ rows, float4* __restrict__ imp, uint4* __restrict__ slotMeta,
-                                                     float4* __restrict__ slotNormal, float2* __restrict__ slotMass) {
+                                                     float4* __restrict__ slotNormal, float2* __restrict__ slotMass,
+                                                     uint8_t* __restrict__ bodyOwner /* XCD-partitioned solver: [body][8] flags, 1 = a tile of that XCD touches the body; or null */) {
     uint32_t tile = blockIdx.x, lane = threadIdx.x;
     if (tile >= sc->totalTiles) return;
     uint32_t bin = tileBin[tile];
@@ -1218,6 +1335,11 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
     }
     slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, packed, cnt);
     slotMass[(size_t)tile * 64u + lane] = make_float2(imA, imB);
+    if (bodyOwner) {   // one byte per (body, XCD): plain idempotent stores, no atomics
+        const uint32_t x = tileOwner(tl, (bi.count + 63u) >> 6, bin);
+        if (imA != 0.f) bodyOwner[(size_t)bodies.x * 8u + x] = 1u;
+        if (imB != 0.f) bodyOwner[(size_t)bodies.y * 8u + x] = 1u;
+    }
     M3 IA = loadM3(gInvI, bodies.x), IB = loadM3(gInvI, bodies.y);
     V3 vA = xyz(gVel[2 * bodies.x]), wA = xyz(gVel[2 * bodies.x + 1]);
     V3 vB = xyz(gVel[2 * bodies.y]), wB = xyz(gVel[2 * bodies.y + 1]);
@@ -1452,6 +1574,11 @@ __device__ __forceinline__ void loadPair4Sc1(const PairBody& A, const PairBody& 
                  "global_load_dwordx4 %2, %6, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %3, %7, off" MI_SC_LOAD "\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(A.q0), "v"(A.q1), "v"(B.q0), "v"(B.q1) : "memory");
 }
+__device__ __forceinline__ void issuePair4Sc1(const PairBody& A, const PairBody& B, f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1) {   // no wait: waitVmcnt + landed follow
+    asm volatile("global_load_dwordx4 %0, %4, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %1, %5, off" MI_SC_LOAD "\n\t"
+                 "global_load_dwordx4 %2, %6, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %3, %7, off" MI_SC_LOAD
+                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(A.q0), "v"(A.q1), "v"(B.q0), "v"(B.q1) : "memory");
+}
 __device__ __forceinline__ void loadPair2Sc1(const PairBody& A, f32x4& a0, f32x4& a1) {
     asm volatile("global_load_dwordx4 %0, %2, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %1, %3, off" MI_SC_LOAD "\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a0), "=&v"(a1) : "v"(A.q0), "v"(A.q1) : "memory");
@@ -1464,12 +1591,48 @@ __device__ __forceinline__ void storePairSc1(const PairBody& X, bool odd, bool n
     if (odd ? partnerNeed : need) storeGranuleSc1(X.q0, d0);
     if (odd ? need : partnerNeed) storeGranuleSc1(X.q1, d1);
 }
+// the same with a choice per body: XCD-local bodies are published with plain stores (they stay in this XCD's L2)
+__device__ __forceinline__ void storeGranulePlain(float4* p, f32x4 g) { asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(g) : "memory"); }
+__device__ __forceinline__ void storePairXcd(const PairBody& X, bool odd, bool need, bool local, f32x4 h0, f32x4 h1) {
+    f32x4 recv = swz1(odd ? h0 : h1);
+    bool partnerNeed = swz1(need ? 1u : 0u) != 0u, partnerLocal = swz1(local ? 1u : 0u) != 0u;
+    f32x4 d0 = odd ? recv : h0, d1 = odd ? h1 : recv;
+    const bool n0 = odd ? partnerNeed : need, l0 = odd ? partnerLocal : local;     // pass 0 moves the even lane's body,
+    const bool n1 = odd ? need : partnerNeed, l1 = odd ? local : partnerLocal;     // pass 1 the odd lane's
+    if (n0 && l0) storeGranulePlain(X.q0, d0);
+    if (n0 && !l0) storeGranuleSc1(X.q0, d0);
+    if (n1 && l1) storeGranulePlain(X.q1, d1);
+    if (n1 && !l1) storeGranuleSc1(X.q1, d1);
+}
 
 // LDSIMP: the accumulated impulses live in LDS (`ldsImp`, [k][lane]) because the same wave runs this tile in every sweep
 // (k_contact_solve_persist); otherwise they travel between sweeps as tagged granules in `imp`.
-template <int CNT, bool LDSIMP>
+#ifndef MI_LATE_PREFETCH
+#define MI_LATE_PREFETCH 0
+#endif
+#ifdef MI_DBG_TIMELINE
+__device__ unsigned long long* g_dbgTimeline = nullptr;   // development: [wave][visit][8] wall-clock stamps of k_contact_solve_persist
+__device__ __forceinline__ void dbgStamp(unsigned long long* rec, int i) { if (rec && threadIdx.x == 0) rec[i] = wall_clock64(); }
+#define MI_STAMP(rec, i) dbgStamp(rec, i)
+#else
+#define MI_STAMP(rec, i) ((void)0)
+#endif
+// Hook of processTile: early() runs right after the body loads were issued and returns how many loads it issued itself (they
+// may stay in flight across the first tag check); late(waited) runs once the tags are satisfied, waited = the tile had to poll.
+struct NoHook { unsigned long long* rec = nullptr; __device__ __forceinline__ uint32_t early() const { return 0u; } __device__ __forceinline__ void late(bool) const {} };
+// wait until at most n of the newest vector-memory operations are outstanding (n = a count the caller issued itself)
+__device__ __forceinline__ void waitVmcnt(uint32_t n) {
+    switch (n) {
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
+        case 24: asm volatile("s_waitcnt vmcnt(24)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+}
+template <int CNT, bool LDSIMP, bool XCD = false, class Hook = NoHook>
 __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint32_t it, const uint4 meta, const float4 nf, const float2 mass, const ContactRows* c,
-                                            float4* imp, float4* gVel, StepScalars* sc, float2* ldsImp);
+                                            float4* imp, float4* gVel, StepScalars* sc, float2* ldsImp, float4* gVelL = nullptr, Hook hook = Hook());
 template <int CNT, bool LDSIMP = false>
 __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_t lane, uint32_t it, const uint4* __restrict__ slotMeta,
                                          const float4* __restrict__ slotNormal, const float2* __restrict__ slotMass,
@@ -1488,17 +1651,24 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
 }
 // The tile proper, from data already requested (flowTile) or prefetched (k_contact_solve_persist): wait for the bodies (and the
 // impulse granules), solve, publish.
-template <int CNT, bool LDSIMP>
+template <int CNT, bool LDSIMP, bool XCD, class Hook>
 __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint32_t it, const uint4 meta, const float4 nf, const float2 mass, const ContactRows* c,
-                                            float4* imp, float4* gVel, StepScalars* sc, float2* ldsImp) {
+                                            float4* imp, float4* gVel, StepScalars* sc, float2* ldsImp, float4* gVelL, Hook hook) {
     const uint32_t bA = meta.x, bB = meta.y, pk = meta.z;
     const float imA = mass.x, imB = mass.y;
     const bool valid = meta.w != 0u;
+    // XCD: bits 8 / 9 of meta.w = body A / B is touched from this XCD only -> it lives in the cached copy and is handed
+    // over through this XCD's L2 (plain stores, L1-bypassing loads) instead of write-through transactions to memory
+#ifdef MI_DBG_ALLLOCAL
+    const bool locA = XCD, locB = XCD;   // development knock-out: every body through the L2 path (results are garbage)
+#else
+    const bool locA = XCD && (meta.w & 0x100u) != 0u, locB = XCD && (meta.w & 0x200u) != 0u;
+#endif
     const bool live = valid && (imA != 0.f || imB != 0.f);
     const uint32_t degA = (pk >> 7) & 127u, degB = (pk >> 21) & 127u;
     const uint32_t expA = it * degA + (pk & 127u), expB = it * degB + ((pk >> 14) & 127u);
     const bool needA = valid && degA != 0u, needB = valid && degB != 0u;
-    float4* pA = gVel + 2 * (size_t)bA; float4* pB = gVel + 2 * (size_t)bB;
+    float4* pA = (locA ? gVelL : gVel) + 2 * (size_t)bA; float4* pB = (locB ? gVelL : gVel) + 2 * (size_t)bB;
     float4* pI = imp + (size_t)ctBase * 64u + lane;
     // Second (and last) memory round trip: the accumulated impulses (written by the wave that ran this tile in the
     // previous sweep, tag = sweeps completed) and the two bodies, all agent-scope; the wait also lands the rows.
@@ -1511,7 +1681,10 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
     }
     {
         f32x4 ra0, ra1, rb0, rb1;
-        loadPair4Sc1(PA, PB, ra0, ra1, rb0, rb1);
+        issuePair4Sc1(PA, PB, ra0, ra1, rb0, rb1);
+        MI_STAMP(hook.rec, 2);
+        waitVmcnt(hook.early());   // the hook's loads are younger than the body loads: they may stay in flight
+        landed(ra0); landed(ra1); landed(rb0); landed(rb1);
         pairGather(odd, ra0, ra1, a0, a1);
         pairGather(odd, rb0, rb1, b0, b1);
     }
@@ -1530,6 +1703,11 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
         for (int k = 0; k < CNT; ++k) okI = okI && (!live || __float_as_uint(ig[k].z) == it);
     }
     uint32_t budget = kSpinBudget;
+#ifdef MI_DBG_NOWAIT
+    okA = okB = okI = true;   // development knock-out: timing without dependency waits (results are garbage)
+#endif
+    const bool polled = __ballot(!(okA && okB && okI)) != 0ull;
+    MI_STAMP(hook.rec, 3);
     while (__ballot(!(okA && okB && okI)) != 0ull) {   // tight polling measured fastest: only the pairs still waiting re-load
         // both lanes of a pair must poll together; the partner flags are exchanged OUTSIDE any short-circuit so every lane
         // takes part in the swap (inside `!okA || swap(...)` the swap would run with only the ready lanes active)
@@ -1554,6 +1732,8 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
         }
         if (--budget == 0u) { sc->solveError = 1u; break; }
     }
+    hook.late(polled);
+    MI_STAMP(hook.rec, 4);
     V3 vA(a0.x, a0.y, a0.z), wA(a1.x, a1.y, a1.z), vB(b0.x, b0.y, b0.z), wB(b1.x, b1.y, b1.z);
     float2 out[CNT];
 #pragma unroll
@@ -1566,8 +1746,9 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
     {
         float tA = __uint_as_float(expA + 1u), tB = __uint_as_float(expB + 1u);
         f32x4 hA0 = {vA.x, vA.y, vA.z, tA}, hA1 = {wA.x, wA.y, wA.z, tA}, hB0 = {vB.x, vB.y, vB.z, tB}, hB1 = {wB.x, wB.y, wB.z, tB};
-        storePairSc1(PA, odd, needA, hA0, hA1);
-        storePairSc1(PB, odd, needB, hB0, hB1);
+        MI_STAMP(hook.rec, 5);
+        if (XCD) { storePairXcd(PA, odd, needA, locA, hA0, hA1); storePairXcd(PB, odd, needB, locB, hB0, hB1); }
+        else { storePairSc1(PA, odd, needA, hA0, hA1); storePairSc1(PB, odd, needB, hB0, hB1); }
     }
     if (LDSIMP) {
 #pragma unroll
@@ -1610,59 +1791,171 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_W
 #ifndef MI_PERSIST_WPE
 #define MI_PERSIST_WPE 1
 #endif
+// a 16-byte load into four FIXED accumulator registers / reading them back (k_contact_solve_persist's row prefetch)
+#define MI_ACC_LOAD(A0, A1, A2, A3, addr) asm volatile("global_load_dwordx4 a[" #A0 ":" #A3 "], %0, off" : : "v"(addr) : "memory", "a" #A0, "a" #A1, "a" #A2, "a" #A3)
+#define MI_ACC_READ(dst, A0, A1, A2, A3) do { float x_, y_, z_, w_; \
+    asm volatile("v_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1 "\n\tv_accvgpr_read_b32 %2, a" #A2 "\n\tv_accvgpr_read_b32 %3, a" #A3 \
+                 : "=v"(x_), "=v"(y_), "=v"(z_), "=v"(w_)); (dst) = make_float4(x_, y_, z_, w_); } while (0)
+
+// METALDS = false (larger problems): only the impulses live in LDS (2060 B per slot instead of 4620); the constant slot data is
+// prefetched from global memory together with the rows of the next tile.
+// XCD = true (XCD-partitioned): workgroup w belongs to XCD w % 8 (verified against the hardware id: anything else is
+// reported as solveError 3 and the host falls back) and owns entries w / 8, w / 8 + gridDim / 8, ... of THAT XCD's tile
+// list (xcdTiles, ascending = schedule order).  Bodies only this XCD touches (bodyOwner has exactly this XCD's bit) are
+// handed over through the XCD's L2 in the cached array gVelL; all others through memory in gVel as before.
+template <bool METALDS, bool XCD>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIST_WPE))) void k_contact_solve_persist(
-    uint32_t sweeps, uint32_t maxSlots, const uint2* __restrict__ tileDesc, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
-    const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* gVel, StepScalars* sc) {
-    // LDS per workgroup: [maxSlots] x { meta uint4[64], normal float4[64], mass float2[64] } (constant over the sweeps), then the
+    uint32_t sweeps, uint32_t maxSlots, const uint2* __restrict__ tileDesc, const uint4* slotMeta, const float4* __restrict__ slotNormal,
+    const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* gVel, StepScalars* sc, uint32_t xcdOnly,
+    const uint32_t* __restrict__ xcdTiles, uint32_t listCap, const unsigned long long* __restrict__ bodyOwner, float4* gVelL, uint4* slotMetaW) {
+    // LDS per workgroup: [maxSlots] x { meta uint4[64], normal float4[64], mass float2[64] } (constant over the sweeps; METALDS only), then the
     // impulses float2[4 * maxSlots][64], then the per-slot (first contact-tile, contacts per manifold, impulse offset)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
+    const size_t metaSlots = METALDS ? (size_t)maxSlots : 0;
     uint4* lMeta = reinterpret_cast<uint4*>(ldsRaw);
-    float4* lNormal = reinterpret_cast<float4*>(lMeta + (size_t)maxSlots * 64u);
-    float2* lMass = reinterpret_cast<float2*>(lNormal + (size_t)maxSlots * 64u);
-    float2* lImp = lMass + (size_t)maxSlots * 64u;
+    float4* lNormal = reinterpret_cast<float4*>(lMeta + metaSlots * 64u);
+    float2* lMass = reinterpret_cast<float2*>(lNormal + metaSlots * 64u);
+    float2* lImp = lMass + metaSlots * 64u;
     uint32_t* lDesc = reinterpret_cast<uint32_t*>(lImp + (size_t)maxSlots * 4u * 64u);   // [maxSlots][3]
-    const uint32_t numTiles = sc->totalTiles, numWaves = gridDim.x, lane = threadIdx.x;
+    if (xcdOnly && (blockIdx.x & 7u) != 0u) return;   // development experiment: only the workgroups of one XCD work
+    const uint32_t lane = threadIdx.x;
+    const uint32_t xcd = blockIdx.x & 7u;
+    uint32_t numTiles = sc->totalTiles, numWaves = xcdOnly ? gridDim.x / 8u : gridDim.x, wid = xcdOnly ? blockIdx.x / 8u : blockIdx.x;
+    if (XCD) {
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));
+        hw &= 15u;
+        uint32_t seen = 0u;
+        if (lane == 0) { seen = atomicCAS(&sc->xccOf[xcd], 0xFFFFFFFFu, hw); if (seen == 0xFFFFFFFFu) seen = hw; }
+        seen = (uint32_t)__shfl((int)seen, 0, 64);
+        if (seen != hw) { if (lane == 0) sc->solveError = 3u; return; }   // blockIdx % 8 does not identify the XCD on this device
+        numTiles = sc->totalTiles ? sc->xcdCount[xcd] : 0u; numWaves = gridDim.x / 8u; wid = blockIdx.x / 8u;
+        xcdTiles += (size_t)xcd * listCap;
+        if (numTiles > listCap) { if (lane == 0) sc->solveError = 2u; return; }
+    }
+    uint32_t* lTile = reinterpret_cast<uint32_t*>(lDesc + 3u * (size_t)maxSlots);   // [maxSlots] tile of every slot
+    uint32_t* lCrit = lTile + maxSlots;                                             // [maxSlots] 1: the slot had to poll in the previous sweep
     uint32_t mySlots = 0, off = 0;
-    for (uint32_t tile = blockIdx.x; tile < numTiles && mySlots < maxSlots; tile += numWaves, ++mySlots) {
+    for (uint32_t li = wid; li < numTiles && mySlots < maxSlots; li += numWaves, ++mySlots) {
+        const uint32_t tile = XCD ? xcdTiles[li] : li;
         const uint2 d = tileDesc[tile];
-        lMeta[mySlots * 64u + lane] = slotMeta[(size_t)tile * 64u + lane];
-        lNormal[mySlots * 64u + lane] = slotNormal[(size_t)tile * 64u + lane];
-        lMass[mySlots * 64u + lane] = slotMass[(size_t)tile * 64u + lane];
+        if (lane == 0) { lTile[mySlots] = tile; lCrit[mySlots] = 0u; }
+        if (XCD) {   // which of this slot's two bodies are XCD-local -> bits 8 / 9 of meta.w (read back from LDS or global below)
+            uint4 m = slotMeta[(size_t)tile * 64u + lane];
+            const unsigned long long mine = 1ull << (8u * xcd);
+            if (m.w != 0u) m.w |= (bodyOwner[m.x] == mine ? 0x100u : 0u) | (bodyOwner[m.y] == mine ? 0x200u : 0u);
+            if (METALDS) lMeta[mySlots * 64u + lane] = m; else slotMetaW[(size_t)tile * 64u + lane] = m;
+        }
+        if (METALDS) {
+            if (!XCD) lMeta[mySlots * 64u + lane] = slotMeta[(size_t)tile * 64u + lane];
+            lNormal[mySlots * 64u + lane] = slotNormal[(size_t)tile * 64u + lane];
+            lMass[mySlots * 64u + lane] = slotMass[(size_t)tile * 64u + lane];
+        }
         if (lane == 0) { lDesc[3 * mySlots] = d.x; lDesc[3 * mySlots + 1] = d.y; lDesc[3 * mySlots + 2] = off; }
         for (uint32_t k = 0; k < d.y; ++k) lImp[(size_t)(off + k) * 64u + lane] = make_float2(0.f, 0.f);
         off += d.y;
     }
-    if (blockIdx.x + (size_t)mySlots * numWaves < numTiles) { if (lane == 0) sc->solveError = 2u; return; }   // more tiles than the host sized LDS for
+    if (wid + (size_t)mySlots * numWaves < numTiles) { if (lane == 0) sc->solveError = 2u; return; }   // more tiles than the host sized LDS for
     __syncthreads();
     if (!mySlots) return;
-    // software pipeline over (sweep, slot): the rows of the NEXT tile are requested before this tile waits for its bodies
-    ContactRows nx[4];
-    auto fetchRows = [&](uint32_t slot) {
+    // Software pipeline over (sweep, slot): the rows of the NEXT tile are requested while this tile waits for its bodies.
+    // Loads retire in order, so the request order matters: this tile's body loads go first, the prefetch second, and the
+    // first tag check waits with vmcnt(number of prefetch loads) — the bodies are back, the prefetch may still be in flight.
+    // The prefetch is inline asm with its exact instruction count known, into FIXED accumulator registers a160..a255 that
+    // the compiler never allocates (tests/test_capi_symbols.py checks the ISA for that); they are read back, again by
+    // inline asm, after the explicit vmcnt(0) at the top of the next iteration.  (Compiler-allocated registers do not
+    // work here: the allocator copies in-flight values around at loop boundaries.)
+    uint4 nxMeta = make_uint4(0u, 0u, 0u, 0u); float4 nxNf = make_float4(0.f, 0.f, 0.f, 0.f); float2 nxMass = make_float2(0.f, 0.f);
+    auto fetchRows = [&](uint32_t slot) -> uint32_t {
         const uint32_t ct = lDesc[3 * slot], cnt = lDesc[3 * slot + 1];
-#pragma unroll
-        for (uint32_t k = 0; k < 4u; ++k)
-            if (k < cnt) {
-                const float4* __restrict__ row = rows + ((size_t)ct + k) * (kRows * 64u) + lane;
-#pragma unroll
-                for (uint32_t r = 0; r < kRows; ++r) nx[k].r[r] = row[r * 64u];
-            }
+        if (!METALDS) {
+            const size_t at = (size_t)lTile[slot] * 64u + lane;
+            nxMeta = XCD ? slotMetaW[at] : slotMeta[at]; nxNf = slotNormal[at]; nxMass = slotMass[at];
+        }
+        {
+            const float4* row = rows + (size_t)ct * (kRows * 64u) + lane;   // row (k, r) of the tile at + (k * kRows + r) * 64
+            if (0u < cnt) MI_ACC_LOAD(160, 161, 162, 163, row + 0u * 64u);
+            if (0u < cnt) MI_ACC_LOAD(164, 165, 166, 167, row + 1u * 64u);
+            if (0u < cnt) MI_ACC_LOAD(168, 169, 170, 171, row + 2u * 64u);
+            if (0u < cnt) MI_ACC_LOAD(172, 173, 174, 175, row + 3u * 64u);
+            if (0u < cnt) MI_ACC_LOAD(176, 177, 178, 179, row + 4u * 64u);
+            if (0u < cnt) MI_ACC_LOAD(180, 181, 182, 183, row + 5u * 64u);
+            if (1u < cnt) MI_ACC_LOAD(184, 185, 186, 187, row + 6u * 64u);
+            if (1u < cnt) MI_ACC_LOAD(188, 189, 190, 191, row + 7u * 64u);
+            if (1u < cnt) MI_ACC_LOAD(192, 193, 194, 195, row + 8u * 64u);
+            if (1u < cnt) MI_ACC_LOAD(196, 197, 198, 199, row + 9u * 64u);
+            if (1u < cnt) MI_ACC_LOAD(200, 201, 202, 203, row + 10u * 64u);
+            if (1u < cnt) MI_ACC_LOAD(204, 205, 206, 207, row + 11u * 64u);
+            if (2u < cnt) MI_ACC_LOAD(208, 209, 210, 211, row + 12u * 64u);
+            if (2u < cnt) MI_ACC_LOAD(212, 213, 214, 215, row + 13u * 64u);
+            if (2u < cnt) MI_ACC_LOAD(216, 217, 218, 219, row + 14u * 64u);
+            if (2u < cnt) MI_ACC_LOAD(220, 221, 222, 223, row + 15u * 64u);
+            if (2u < cnt) MI_ACC_LOAD(224, 225, 226, 227, row + 16u * 64u);
+            if (2u < cnt) MI_ACC_LOAD(228, 229, 230, 231, row + 17u * 64u);
+            if (3u < cnt) MI_ACC_LOAD(232, 233, 234, 235, row + 18u * 64u);
+            if (3u < cnt) MI_ACC_LOAD(236, 237, 238, 239, row + 19u * 64u);
+            if (3u < cnt) MI_ACC_LOAD(240, 241, 242, 243, row + 20u * 64u);
+            if (3u < cnt) MI_ACC_LOAD(244, 245, 246, 247, row + 21u * 64u);
+            if (3u < cnt) MI_ACC_LOAD(248, 249, 250, 251, row + 22u * 64u);
+            if (3u < cnt) MI_ACC_LOAD(252, 253, 254, 255, row + 23u * 64u);
+        }
+        return cnt * kRows;
     };
-    fetchRows(0);
+    (void)fetchRows(0);
     for (uint32_t it = 0; it < sweeps; ++it)
         for (uint32_t slot = 0; slot < mySlots; ++slot) {
             ContactRows cur[4];
-#pragma unroll
-            for (uint32_t k = 0; k < 4u; ++k) cur[k] = nx[k];
+            unsigned long long* rec = nullptr;
+#ifdef MI_DBG_TIMELINE
+            if (g_dbgTimeline && it * mySlots + slot < 256u) rec = g_dbgTimeline + ((size_t)blockIdx.x * 256u + it * mySlots + slot) * 8u;
+            if (rec && threadIdx.x == 0) { rec[6] = ((unsigned long long)it << 32) | slot; rec[7] = lTile[slot]; }
+#endif
+            MI_STAMP(rec, 0);
             const uint32_t ct = lDesc[3 * slot], cnt = lDesc[3 * slot + 1], io = lDesc[3 * slot + 2];
-            const uint4 meta = lMeta[slot * 64u + lane]; const float4 nf = lNormal[slot * 64u + lane]; const float2 mass = lMass[slot * 64u + lane];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            MI_STAMP(rec, 1);
+            if (0u < cnt) MI_ACC_READ(cur[0].r[0], 160, 161, 162, 163);
+            if (0u < cnt) MI_ACC_READ(cur[0].r[1], 164, 165, 166, 167);
+            if (0u < cnt) MI_ACC_READ(cur[0].r[2], 168, 169, 170, 171);
+            if (0u < cnt) MI_ACC_READ(cur[0].r[3], 172, 173, 174, 175);
+            if (0u < cnt) MI_ACC_READ(cur[0].r[4], 176, 177, 178, 179);
+            if (0u < cnt) MI_ACC_READ(cur[0].r[5], 180, 181, 182, 183);
+            if (1u < cnt) MI_ACC_READ(cur[1].r[0], 184, 185, 186, 187);
+            if (1u < cnt) MI_ACC_READ(cur[1].r[1], 188, 189, 190, 191);
+            if (1u < cnt) MI_ACC_READ(cur[1].r[2], 192, 193, 194, 195);
+            if (1u < cnt) MI_ACC_READ(cur[1].r[3], 196, 197, 198, 199);
+            if (1u < cnt) MI_ACC_READ(cur[1].r[4], 200, 201, 202, 203);
+            if (1u < cnt) MI_ACC_READ(cur[1].r[5], 204, 205, 206, 207);
+            if (2u < cnt) MI_ACC_READ(cur[2].r[0], 208, 209, 210, 211);
+            if (2u < cnt) MI_ACC_READ(cur[2].r[1], 212, 213, 214, 215);
+            if (2u < cnt) MI_ACC_READ(cur[2].r[2], 216, 217, 218, 219);
+            if (2u < cnt) MI_ACC_READ(cur[2].r[3], 220, 221, 222, 223);
+            if (2u < cnt) MI_ACC_READ(cur[2].r[4], 224, 225, 226, 227);
+            if (2u < cnt) MI_ACC_READ(cur[2].r[5], 228, 229, 230, 231);
+            if (3u < cnt) MI_ACC_READ(cur[3].r[0], 232, 233, 234, 235);
+            if (3u < cnt) MI_ACC_READ(cur[3].r[1], 236, 237, 238, 239);
+            if (3u < cnt) MI_ACC_READ(cur[3].r[2], 240, 241, 242, 243);
+            if (3u < cnt) MI_ACC_READ(cur[3].r[3], 244, 245, 246, 247);
+            if (3u < cnt) MI_ACC_READ(cur[3].r[4], 248, 249, 250, 251);
+            if (3u < cnt) MI_ACC_READ(cur[3].r[5], 252, 253, 254, 255);
+            uint4 meta; float4 nf; float2 mass;
+            if (METALDS) { meta = lMeta[slot * 64u + lane]; nf = lNormal[slot * 64u + lane]; mass = lMass[slot * 64u + lane]; }
+            else { meta = nxMeta; nf = nxNf; mass = nxMass; }
             const uint32_t nextSlot = slot + 1u < mySlots ? slot + 1u : 0u;
-            if (slot + 1u < mySlots || it + 1u < sweeps) fetchRows(nextSlot);
+            const bool more = slot + 1u < mySlots || it + 1u < sweeps;
+            // (MI_LATE_PREFETCH: a tile that had to poll in the previous sweep prefetches after its wait, so that its polls do not
+            // queue behind the prefetch.  Measured slower — 0.68 vs 0.63 ms — the rows arriving late costs more; off.)
+            struct Prefetch {
+                decltype(fetchRows)& fetch; uint32_t* crit; uint32_t next; bool more, critical, issued; unsigned long long* rec;
+                __device__ __forceinline__ uint32_t early() { if (more && !critical) { issued = true; return fetch(next); } return 0u; }
+                __device__ __forceinline__ void late(bool waited) { if (more && !issued) (void)fetch(next); if (threadIdx.x == 0) *crit = waited ? 1u : 0u; }
+            } prefetch{fetchRows, &lCrit[slot], nextSlot, more, MI_LATE_PREFETCH && lCrit[slot] != 0u, false, rec};
             float2* li = lImp + (size_t)io * 64u;
             switch (cnt) {
-                case 1: processTile<1, true>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li); break;
-                case 2: processTile<2, true>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li); break;
-                case 3: processTile<3, true>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li); break;
-                default: processTile<4, true>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li); break;
+                case 1: processTile<1, true, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li, gVelL, prefetch); break;
+                case 2: processTile<2, true, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li, gVelL, prefetch); break;
+                case 3: processTile<3, true, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li, gVelL, prefetch); break;
+                default: processTile<4, true, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li, gVelL, prefetch); break;
             }
         }
 }

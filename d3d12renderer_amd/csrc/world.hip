@@ -89,6 +89,9 @@ struct mi_world {
     DBuf<float4> bPos, bRot, bLinVel, bAngVel, bForce, bTorque, bCogInvMass, bInvI, bParams;
     DBuf<float4> bPosN, bRotN, bLinVelN, bAngVelN, bForceN, bTorqueN;   // second body-state set: written by k_integrate_velocities, swapped in when a step is valid
     DBuf<float4> gPos, gInvI, gVel;
+    // XCD-partitioned persistent solver: cached velocity copy for XCD-local bodies, per-body XCD set, spatial sort of the manifolds, per-XCD tile lists
+    DBuf<float4> gVelL; DBuf<unsigned long long> bodyOwner; DBuf<uint32_t> sortKeys[2], sortVals[2], xcdBase, xcdTiles, keyCount;
+    bool persistXcd = true, usedXcd = false, haveXcdEstimate = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
     // device: colliders
     DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cMaterial;
     DBuf<float4> wShape, aabbMin, aabbMax, hullAabb, hullVerts; DBuf<uint32_t> hullRanges;
@@ -147,7 +150,7 @@ struct mi_world {
     DBuf<float4> rows, slotNormal; DBuf<float4> imp; DBuf<float2> slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc;
     bool usedFlow = false;
     bool usedFused = false;
-    bool persistSolver = true, usedPersist = false; uint32_t persistWaves = 1024;   // one resident workgroup per SIMD owns its tiles through all sweeps (k_contact_solve_persist)
+    bool persistSolver = true, persistMetaLds = true, usedPersist = false; uint32_t xcdOnly = 0; uint32_t persistWaves = 1024;   // one resident workgroup per SIMD owns its tiles through all sweeps (k_contact_solve_persist)
     uint32_t flowLds = 0;                  // dynamic LDS bytes per 64-lane workgroup: caps resident waves per CU (160 KiB / flowLds)
     bool flowSolver = true;               // dataflow PGS sweep (one launch per iteration); MI_SOLVER=launch selects one launch per colour
     BinInfo bins[kSchedBins]{};           // host copy of the last step's schedule
@@ -216,9 +219,13 @@ int mi_world::init(int dev) {
     };
     gVel.flags = allocFlags("MI_GVEL_ALLOC", hipDeviceMallocUncached);
     imp.flags = allocFlags("MI_IMP_ALLOC", 0u);
-    { const char* sv = getenv("MI_SOLVER"); persistSolver = !sv || std::string(sv) == "persist";   // default; MI_SOLVER=flow / launch select the other contact solvers
+    { const char* sv = getenv("MI_SOLVER"); persistSolver = !sv || std::string(sv) == "persist" || std::string(sv) == "persist-global";   // default; MI_SOLVER=flow / launch select the other contact solvers
+      persistMetaLds = !sv || std::string(sv) != "persist-global";   // persist-global: slot data always from global memory (the variant larger problems get automatically)
       hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) persistWaves = 4u * (uint32_t)prop.multiProcessorCount;
-      if (const char* pw = getenv("MI_PERSIST_WAVES")) persistWaves = (uint32_t)strtoul(pw, nullptr, 0); }
+      if (const char* pw = getenv("MI_PERSIST_WAVES")) persistWaves = (uint32_t)strtoul(pw, nullptr, 0);
+      xcdOnly = getenv("MI_PERSIST_XCD_ONLY") ? 1u : 0u;
+      if (const char* px = getenv("MI_PERSIST_XCD")) persistXcd = px[0] != '0';
+      if (const char* pm = getenv("MI_PERSIST_XCD_MIN")) xcdMinManifolds = (uint32_t)strtoul(pm, nullptr, 0); }   // smallest manifold count that is partitioned (tests: 1)   // MI_PERSIST_XCD=0: no XCD partitioning (every body through memory)   // development experiment: one XCD's workgroups do all the work
     if (flowLds > 65536) (void)hipFuncSetAttribute((const void*)k_contact_solve_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flowLds);
     return MI_OK;
 }
@@ -383,6 +390,7 @@ int mi_world::upload() {
       HIP_TRY(bPosN.ensure(n1)); HIP_TRY(bRotN.ensure(n1)); HIP_TRY(bLinVelN.ensure(n1)); HIP_TRY(bAngVelN.ensure(n1)); HIP_TRY(bForceN.ensure(n1)); HIP_TRY(bTorqueN.ensure(n1)); }
     HIP_TRY(gPos.ensure(nb + 1)); HIP_TRY(gInvI.ensure(3 * ((size_t)nb + 1))); HIP_TRY(gVel.ensure(2 * ((size_t)nb + 1)));
     HIP_TRY(bodyTop.ensure(2 * ((size_t)nb + 1))); HIP_TRY(bodyUsed.ensure(nb + 1));
+    HIP_TRY(gVelL.ensure(2 * ((size_t)nb + 1))); HIP_TRY(bodyOwner.ensure(nb + 1)); HIP_TRY(xcdBase.ensure(kSchedBins * 8)); HIP_TRY(keyCount.ensure(kSpatialKeys));
 
     usesGjk = false;
     for (const HCollider& c : colliders) if (c.desc.type == T_CAPSULE || c.desc.type == T_CYLINDER || c.desc.type == T_HULL) usesGjk = true;
@@ -517,14 +525,16 @@ int mi_world::download() {
 // ------------------------------------------------------------------------------------------------
 // One internal step (physicsStepInternal, src/physics/physics.cpp:1180-1362)
 // ------------------------------------------------------------------------------------------------
-__global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlags) {
+__global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlags, uint32_t* keyCount) {
     uint32_t t = threadIdx.x;
+    for (uint32_t i = t; i < kSpatialKeys; i += blockDim.x) keyCount[i] = 0u;
     for (uint32_t i = t; i < sizeof(Shards) / 4u; i += blockDim.x) reinterpret_cast<uint32_t*>(sh)[i] = 0u;
     for (uint32_t i = t; i < kMaxColorRounds + 2u; i += blockDim.x) roundFlags[i] = 0u;
     if (t == 0) {
         sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->solveError = 0;
         sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0; sc->numEvents = 0; sc->numInterPairs = 0; sc->numInteractions = 0; sc->numHmContacts = 0; sc->numHmColliders = 0;
         for (int q = 0; q < 16; ++q) sc->boxHitCount[q] = 0;
+        for (int q = 0; q < 8; ++q) { sc->xcdCount[q] = 0; sc->xccOf[q] = 0xFFFFFFFFu; }
         for (int a = 0; a < 3; ++a) { sc->boundsMin[a] = 0x7FFFFFFF; sc->boundsMax[a] = (int)0x80000000; }
     }
     if (t < 24) { sc->bucketHist[t] = 0; sc->bucketCursor[t] = 0; }
@@ -677,7 +687,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     auto readScalars = [&]() -> int { HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); return MI_OK; };
 
     mark();  // 0
-    k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlagsPtr());
+    k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlagsPtr(), keyCount.p);
     if (nc) {
         k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis);
@@ -770,7 +780,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     if (usesInteractions) { int rc = interactions(triggerEvents); if (rc != MI_OK) return rc; }
     mark();  // 3
     k_integrate_forces<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, make_float3(globalForce.x, globalForce.y, globalForce.z), bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, usesInteractions ? bForceStep.p : bForce.p, bTorque.p,
-                                                       gPos.p, gInvI.p, gVel.p);
+                                                       gPos.p, gInvI.p, gVel.p, gVelL.p, bodyOwner.p);
     mark();  // 4
     // ---------------------------------------------------------------------------------------------- schedule
     uint32_t nmBound = 0, conBound = 0;
@@ -778,7 +788,9 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         if (spec) { nmBound = std::min(pairBound, bound(last.numManifolds, 1024)); conBound = bound(last.numContacts, 4096); }
         else { int rc = readScalars(); if (rc != MI_OK) return rc; nmBound = hs.numManifolds; conBound = hs.numContacts; }
     }
-    uint32_t tilesCap = 0, ctCap = 0, eventCap = 0;
+    uint32_t tilesCap = 0, ctCap = 0, eventCap = 0, xcdListCap = 0;
+    // XCD partitioning pays once the pile is big enough to keep eight L2s busy; it needs the persistent kernel (no joints)
+    const bool xcdPlan = flowSolver && persistSolver && persistXcd && !xcdOnly && joints.count() == 0 && (persistWaves & 7u) == 0u && nmBound >= xcdMinManifolds;
     uint32_t colorBatch = spec ? std::min<uint32_t>(96u, last.colorRounds + std::max(3u, last.colorRounds / 4u)) : 20u;   // converged rounds exit at once
     if (nmBound) {
         tilesCap = divUp(nmBound, 64) + kSchedBins + 8; ctCap = divUp(conBound, 64) + 4 * kSchedBins + 8;
@@ -786,6 +798,15 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         HIP_TRY(order.ensure((size_t)binBlocks * kBinItems)); HIP_TRY(orderTmp.ensure((size_t)binBlocks * kBinItems));
         HIP_TRY(blockHist.ensure((size_t)kColorBins * binBlocks)); HIP_TRY(blockScan.ensure((size_t)kColorBins * binBlocks));
         HIP_TRY(tileBin.ensure(tilesCap)); HIP_TRY(tileDesc.ensure(tilesCap));
+        if (xcdPlan) {   // slots in spatial order inside every bin + per-XCD tile lists (k_contact_solve_persist<.., true>)
+            xcdListCap = divUp(tilesCap, 8) + kSchedBins;
+            HIP_TRY(sortKeys[0].ensure(nmBound)); for (int k = 0; k < 2; ++k) HIP_TRY(sortVals[k].ensure(nmBound));
+            HIP_TRY(xcdTiles.ensure((size_t)8 * xcdListCap));
+            k_manifold_keys<<<divUp(nmBound, kKeyItems), 256, 0, st>>>(nmBound, sc, grid.p, manBodies.p, gPos.p, sortKeys[0].p, sortVals[0].p, keyCount.p);
+            k_manifold_place<<<divUp(nmBound, kKeyItems), 256, 0, st>>>(nmBound, sc, sortKeys[0].p, sortVals[0].p, keyCount.p, sortVals[1].p);
+        }
+        static const bool xcdNoSort = std::getenv("MI_XCD_NOSORT") != nullptr;   // development: manifold order as emitted
+        const uint32_t* perm = xcdPlan && !xcdNoSort ? sortVals[1].p : nullptr;
         HIP_TRY(hipMemsetAsync(bodyTop.p, 0, 2 * ((size_t)nb + 1) * sizeof(unsigned long long), st));
         unsigned long long* top[2] = {bodyTop.p, bodyTop.p + (nb + 1)};
         uint32_t round = 0;
@@ -793,14 +814,14 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             for (uint32_t r = 0; r < colorBatch; ++r, ++round)
                 k_color_round<<<divUp(nmBound, B), B, 0, st>>>(sc, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlagsPtr());
             // schedule bins -> tiles (valid once the last round left nothing uncoloured: StepScalars::colorPending)
-            k_bin_hist<<<binBlocks, 256, 0, st>>>(sc, binBlocks, color.p, manInfo.p, blockHist.p);
+            k_bin_hist<<<binBlocks, 256, 0, st>>>(sc, binBlocks, perm, color.p, manInfo.p, blockHist.p);
             size_t tb = 0;
             HIP_TRY(rocprim::exclusive_scan(nullptr, tb, blockHist.p, blockScan.p, 0u, (size_t)kColorBins * binBlocks, rocprim::plus<uint32_t>(), st));
             if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
             HIP_TRY(rocprim::exclusive_scan(temp.p, tb, blockHist.p, blockScan.p, 0u, (size_t)kColorBins * binBlocks, rocprim::plus<uint32_t>(), st));
-            k_bin_scatter<<<binBlocks, 256, 0, st>>>(round - 1, roundFlagsPtr(), binBlocks, color.p, manInfo.p, blockScan.p, order.p, sc);
-            k_build_tiles<<<1, 256, 0, st>>>(tilesCap, ctCap, sc, binInfo.p);
-            k_fill_tiles<<<divUp(tilesCap, B), B, 0, st>>>(sc, binInfo.p, tileBin.p, tileDesc.p);
+            k_bin_scatter<<<binBlocks, 256, 0, st>>>(round - 1, roundFlagsPtr(), binBlocks, perm, color.p, manInfo.p, blockScan.p, order.p, sc);
+            k_build_tiles<<<1, 256, 0, st>>>(tilesCap, ctCap, sc, binInfo.p, xcdPlan ? xcdBase.p : nullptr);
+            k_fill_tiles<<<divUp(tilesCap, B), B, 0, st>>>(sc, binInfo.p, tileBin.p, tileDesc.p, xcdBase.p, xcdPlan ? xcdTiles.p : nullptr, xcdListCap);
             if (spec) break;
             int rc = readScalars(); if (rc != MI_OK) return rc;
             if (hs.colorPending == 0) break;
@@ -844,13 +865,22 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         HIP_TRY(rows.ensure((size_t)ctCap * kRows * 64)); HIP_TRY(imp.ensure((size_t)ctCap * 64));
         if (tilesLaunch)
             k_contact_init<<<tilesLaunch, 64, 0, st>>>(sc, nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
-                                                      gPos.p, gInvI.p, gVel.p, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, imp.p, slotMeta.p, slotNormal.p, slotMass.p);
+                                                      gPos.p, gInvI.p, gVel.p, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, imp.p, slotMeta.p, slotNormal.p, slotMass.p,
+                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr);
     }
     int rc = joints.initialize(*this, dt, st);
     if (rc != MI_OK) return rc;
     mark();  // 6
     const uint32_t iters = settings.num_rigid_solver_iterations;
-    usedFlow = useFlow; usedPersist = false; usedFused = fused;
+    usedFlow = useFlow; usedPersist = false; usedFused = fused; usedXcd = false;
+    // slots (tiles) one persistent workgroup must hold: exact in a synchronous step, from the previous step's lists (+ slack) in a speculative one
+    auto persistSlots = [&](uint32_t tiles, bool xcd, bool speculative) -> uint32_t {
+        if (!xcd) return divUp(tiles, xcdOnly ? persistWaves / 8u : persistWaves);
+        uint32_t longest = 0;
+        if (speculative) longest = haveXcdEstimate ? lastXcdMax + lastXcdMax / 8u + 16u : divUp(tiles, 8) + 64u;
+        else for (uint32_t x = 0; x < 8u; ++x) { uint32_t n = 0; for (uint32_t bn = 0; bn < kSchedBins; ++bn) n += tileOwnerCount(x, divUp(bins[bn].count, 64), bn); longest = std::max(longest, n); }
+        return divUp(std::max(longest, 1u), persistWaves / 8u);
+    };
     uint64_t mainContacts = 0;
     if (fused) {
         // contacts and joint islands of every sweep in one launch (k_solve_flow_islands)
@@ -870,16 +900,27 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                                                                                    tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, sc);
             if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
         }
-    } else if (useFlow && persistSolver && joints.count() == 0 && tilesLaunch && divUp(tilesLaunch, persistWaves) * (64u * 40u + 4u * 512u + 12u) <= 38u * 1024u) {
-        // persistent waves: one workgroup per SIMD owns its tiles through all sweeps, slot data and impulses in LDS (k_contact_solve_persist)
-        const uint32_t maxSlots = divUp(tilesLaunch, persistWaves);
+    } else if (useFlow && persistSolver && joints.count() == 0 && tilesLaunch && persistSlots(tilesLaunch, xcdPlan, spec) * (4u * 512u + 20u) <= 38u * 1024u) {
+        // persistent waves: one workgroup per SIMD owns its tiles through all sweeps, impulses (and, while they fit, the constant slot data) in LDS (k_contact_solve_persist)
+        const uint32_t maxSlots = persistSlots(tilesLaunch, xcdPlan, spec);
+        const bool metaLds = persistMetaLds && maxSlots * (64u * 40u + 4u * 512u + 20u) <= 38u * 1024u;
+        usedXcd = xcdPlan;
         solveLaunches = 1; usedPersist = true;
         if (profileSolve) {
             size_t e = 2 * (size_t)profLaunches;
             while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
             (void)hipEventRecord(profEvents[e], st);
         }
-        k_contact_solve_persist<<<persistWaves, 64, maxSlots * (64u * 40u + 4u * 512u + 12u) + 16u, st>>>(iters, maxSlots, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, sc);
+        const uint32_t ldsMeta = maxSlots * (64u * 40u + 4u * 512u + 20u) + 16u, ldsImp = maxSlots * (4u * 512u + 20u) + 16u;
+#define MI_PERSIST_ARGS iters, maxSlots, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, sc, xcdOnly, xcdTiles.p, xcdListCap, bodyOwner.p, gVelL.p, slotMeta.p
+        if (usedXcd) {
+            if (metaLds) k_contact_solve_persist<true, true><<<persistWaves, 64, ldsMeta, st>>>(MI_PERSIST_ARGS);
+            else k_contact_solve_persist<false, true><<<persistWaves, 64, ldsImp, st>>>(MI_PERSIST_ARGS);
+        } else {
+            if (metaLds) k_contact_solve_persist<true, false><<<persistWaves, 64, ldsMeta, st>>>(MI_PERSIST_ARGS);
+            else k_contact_solve_persist<false, false><<<persistWaves, 64, ldsImp, st>>>(MI_PERSIST_ARGS);
+        }
+#undef MI_PERSIST_ARGS
         if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
     } else if (useFlow) {
         // no joints between the sweeps -> all sweeps in one launch; otherwise one launch per sweep (joints run in between)
@@ -935,7 +976,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         }
     }
     mark();  // 7
-    k_integrate_velocities<<<divUp(nb, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p);
+    k_integrate_velocities<<<divUp(nb, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
+                                                      gVelL.p, usedXcd ? bodyOwner.p : nullptr);
     mark();  // 8
     // ---------------------------------------------------------------------------------------------- end of step: the one read-back
     HIP_TRY(hipMemcpyAsync(hsPinned, sc, sizeof(Readback), hipMemcpyDeviceToHost, st));   // scalars + round flags are contiguous
@@ -949,10 +991,29 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         if (!valid) return STEP_RETRY;   // nothing persistent was modified: run the same step synchronously
         mirrorSchedule();
     }
+#ifdef MI_DBG_TIMELINE
+    if (usedPersist && std::getenv("MI_DBG_TIMELINE_OUT")) {   // development: per-visit wall-clock stamps of the persistent solver, dumped after step MI_DBG_TIMELINE_STEP
+        static unsigned long long* dbgBuf = nullptr;
+        const size_t words = (size_t)persistWaves * 256 * 8;
+        if (dbgBuf && totalSteps == (unsigned long long)atoll(std::getenv("MI_DBG_TIMELINE_STEP") ? std::getenv("MI_DBG_TIMELINE_STEP") : "3")) {
+            std::vector<unsigned long long> h(words);
+            HIP_TRY(hipMemcpy(h.data(), dbgBuf, words * 8, hipMemcpyDeviceToHost));
+            FILE* f = fopen(std::getenv("MI_DBG_TIMELINE_OUT"), "wb"); if (f) { fwrite(h.data(), 8, words, f); fclose(f); }
+        }
+        if (!dbgBuf) {
+            HIP_TRY(hipMalloc(&dbgBuf, words * 8)); HIP_TRY(hipMemset(dbgBuf, 0, words * 8));
+            HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_dbgTimeline), &dbgBuf, sizeof(dbgBuf)));
+        }
+    }
+#endif
     if (hs.solveError && usedPersist) {
-        // the persistent kernel needs all its workgroups resident at once; if the device could not grant that (or its LDS bound
-        // was exceeded) nothing persistent has been written yet: fall back to the dispatch-ordered dataflow kernel for good
-        persistSolver = false;
+        // nothing persistent has been written yet, the step is simply run again:
+        //   2 with XCD lists: a list outgrew the speculative LDS sizing -> the synchronous run sizes it exactly;
+        //   3: blockIdx % 8 does not identify the XCD on this device -> no XCD partitioning from now on;
+        //   otherwise: the persistent kernel needs all its workgroups resident at once and the device did not grant that (or
+        //   a wait ran out of budget) -> the dispatch-ordered dataflow kernel for good
+        if (hs.solveError == 2u && usedXcd && spec) { haveXcdEstimate = false; return STEP_RETRY; }
+        if (usedXcd) persistXcd = false; else persistSolver = false;
         return STEP_RETRY;
     }
     if (hs.solveError) return fail(MI_ERR_DEVICE, "dataflow contact solver: a body dependency wait exceeded its spin budget");
@@ -996,6 +1057,17 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     if (nmBound) { tabCur ^= 1; tabValid = true; } else tabValid = false;
     hostStale = true;
     last.numPairs = hs.numPairs; last.numManifolds = hs.numManifolds; last.numContacts = hs.numContacts; last.numCells = hs.numCells;
+    static const bool xcdStats = std::getenv("MI_XCD_STATS") != nullptr;   // development: how many bodies stayed XCD-local
+    if (xcdStats && usedXcd && ((totalSteps % 50u) == 0u || std::getenv("MI_XCD_NOSORT"))) {
+        std::vector<unsigned long long> own(nb);
+        HIP_TRY(hipMemcpy(own.data(), bodyOwner.p, (size_t)nb * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        size_t loc = 0, shared = 0; for (unsigned long long o : own) { int c = __builtin_popcountll(o); loc += c == 1; shared += c > 1; }
+        std::fprintf(stderr, "[mi_physics] step %llu: XCD-local bodies %zu, shared %zu, lists", (unsigned long long)totalSteps, loc, shared);
+        for (int x = 0; x < 8; ++x) std::fprintf(stderr, " %u", hs.xcdCount[x]);
+        std::fprintf(stderr, "\n");
+    }
+    haveXcdEstimate = usedXcd;
+    if (usedXcd) { lastXcdMax = 0; for (int x = 0; x < 8; ++x) lastXcdMax = std::max(lastXcdMax, hs.xcdCount[x]); }
     last.colorRounds = 0;
     while (last.colorRounds < 96u && flagsHost[last.colorRounds]) ++last.colorRounds;   // rounds that still had work (+1 to commit) this step
     ++last.colorRounds;

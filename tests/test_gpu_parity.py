@@ -299,10 +299,12 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
     assert g2.cloth_state(0, 144)[0].tobytes() == o2.cloth_state(0, 144)[0].tobytes()
 
 
-def test_gpu_dispatch_ordered_flow_solver_matches_oracle(mi_lib, oracle_mod, monkeypatch):
+@pytest.mark.parametrize("solver,kernel", [("flow", "k_contact_solve_flow"), ("persist-global", "k_contact_solve_persist")])
+def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch, solver, kernel):
     """MI_SOLVER=flow selects k_contact_solve_flow (one workgroup per (sweep, tile), dispatch-ordered; also the automatic
-    fallback of the default persistent kernel and the path taken with joints): same results, bit for bit."""
-    monkeypatch.setenv("MI_SOLVER", "flow")
+    fallback of the default persistent kernel and the path taken with joints); persist-global is the persistent kernel with
+    the slot data read from global memory instead of LDS (what piles beyond ~500 k manifolds get): same results, bit for bit."""
+    monkeypatch.setenv("MI_SOLVER", solver)
     sc = scenes.obb_pile(14, 8, 14, spacing=1.05)
     g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     s = sc.settings()
@@ -311,6 +313,7 @@ def test_gpu_dispatch_ordered_flow_solver_matches_oracle(mi_lib, oracle_mod, mon
         assert g.counts() == o.counts(), f"step {i}"
     assert g.counts()["num_contacts"] > 3000
     assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
+    assert g.solver_kernel() == kernel
     monkeypatch.delenv("MI_SOLVER")
 
 
