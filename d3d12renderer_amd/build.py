@@ -68,6 +68,18 @@ def _build_physics(force=False, verbose=False):
     return LIB
 
 
+def device_asm(out_path):
+    """gfx950 assembly of the device code (hipcc -S --cuda-device-only): inline-asm blocks stay delimited by #ASMSTART / #ASMEND,
+    which tests/test_capi_symbols.py uses to check what the compiler did around the persistent solver's hand-placed registers."""
+    flags = [f for f in FLAGS if f not in ("-shared", "-fPIC", "-fvisibility=hidden")]
+    cmd = [hipcc(), *flags, "-I", str(HERE.parent / "include"), "-S", "--cuda-device-only", *map(str, SOURCES), "-o", str(out_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(r.stdout + r.stderr)
+        raise RuntimeError("hipcc -S failed")
+    return out_path
+
+
 if __name__ == "__main__":
     build(force="--force" in sys.argv, verbose=True)
     print(LIB)

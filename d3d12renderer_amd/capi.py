@@ -411,13 +411,17 @@ class World:
         self.L.check(self.L.fn("world_get_stream")(self.h, C.byref(out)), "world_get_stream")
         return out.value or 0
 
-    SOLVER_KERNELS = ("k_contact_solve", "k_contact_solve_flow", "k_contact_solve_persist", "k_solve_flow_islands")
+    SOLVER_KERNELS = ("k_contact_solve", "k_contact_solve_flow", "k_contact_solve_persist", "k_solve_flow_islands", "k_contact_solve_persist")
+
+    def solver_kind(self):
+        """mi_world_get_solver_kind: 0 per-colour launches, 1 flow, 2 persistent, 3 flow + joint islands, 4 persistent, XCD-partitioned."""
+        k = C.c_uint32()
+        self.L.check(self.L.fn("world_get_solver_kind")(self.h, C.byref(k)), "world_get_solver_kind")
+        return k.value
 
     def solver_kernel(self):
         """Name of the contact-solver kernel the last internal step ran."""
-        k = C.c_uint32()
-        self.L.check(self.L.fn("world_get_solver_kind")(self.h, C.byref(k)), "world_get_solver_kind")
-        return self.SOLVER_KERNELS[k.value]
+        return self.SOLVER_KERNELS[self.solver_kind()]
 
     def accumulated_stage_times(self, reset=False):
         """(sum of per-stage device ms, steps, contact updates) since the last reset — product library only."""

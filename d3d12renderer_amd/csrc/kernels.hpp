@@ -1419,6 +1419,47 @@ __device__ __forceinline__ void solveOne(const ContactRows& c, const float4 nf, 
     }
 }
 
+// The same update with bodies A and B side by side in packed-fp32 lanes (v_pk_mul_f32 / v_pk_add_f32: two IEEE operations
+// per instruction, bit-identical to the scalar ones).  The solve of a tile sits on the dependency chain between tiles, so
+// its instruction count is latency, not just throughput.  Signs are folded into the operands: x - a*b == x + (-a)*b exactly.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct P3 { f32x2 x, y, z; };   // one vector per body: lane 0 = body A, lane 1 = body B
+__device__ __forceinline__ f32x2 pk2(float a, float b) { f32x2 r = {a, b}; return r; }
+__device__ __forceinline__ P3 pcross(const P3& a, const P3& b) { P3 r; r.x = a.y * b.z - a.z * b.y; r.y = a.z * b.x - a.x * b.z; r.z = a.x * b.y - a.y * b.x; return r; }
+__device__ __forceinline__ void solveOnePk(const ContactRows& c, const float4 nf, float2& im, const f32x2 sMass /* (-imA, imB) */, P3& v, P3& w) {
+    const V3 t = xyz(c.r[2]), n = xyz(nf);
+    P3 r; r.x = pk2(c.r[0].x, c.r[1].x); r.y = pk2(c.r[0].y, c.r[1].y); r.z = pk2(c.r[0].z, c.r[1].z);
+    P3 T; T.x = pk2(-c.r[3].x, c.r[3].w); T.y = pk2(-c.r[3].y, c.r[4].x); T.z = pk2(-c.r[3].z, c.r[4].y);
+    P3 N; N.x = pk2(-c.r[4].z, c.r[5].y); N.y = pk2(-c.r[4].w, c.r[5].z); N.z = pk2(-c.r[5].x, c.r[5].w);
+    {
+        P3 cr = pcross(w, r);
+        f32x2 ax = v.x + cr.x, ay = v.y + cr.y, az = v.z + cr.z;
+        V3 rel(ax.y - ax.x, ay.y - ay.x, az.y - az.x);
+        float vt = dot(rel, t);
+        float lambda = -c.r[1].w * vt;
+        float maxF = nf.w * im.x;
+        float ni = clampr(im.y + lambda, -maxF, maxF);
+        lambda = ni - im.y;
+        im.y = ni;
+        V3 P = lambda * t;
+        v.x = v.x + sMass * P.x; v.y = v.y + sMass * P.y; v.z = v.z + sMass * P.z;
+        w.x = w.x + T.x * lambda; w.y = w.y + T.y * lambda; w.z = w.z + T.z * lambda;
+    }
+    {
+        P3 cr = pcross(w, r);
+        f32x2 ax = v.x + cr.x, ay = v.y + cr.y, az = v.z + cr.z;
+        V3 rel(ax.y - ax.x, ay.y - ay.x, az.y - az.x);
+        float vn = dot(rel, n);
+        float lambda = -c.r[0].w * (vn - c.r[2].w);
+        float ni = fmaxr(im.x + lambda, 0.f);
+        lambda = ni - im.x;
+        im.x = ni;
+        V3 P = lambda * n;
+        v.x = v.x + sMass * P.x; v.y = v.y + sMass * P.y; v.z = v.z + sMass * P.z;
+        w.x = w.x + N.x * lambda; w.y = w.y + N.y * lambda; w.z = w.z + N.z * lambda;
+    }
+}
+
 // One tile, CNT contacts per manifold.  Latency structure: a colour launch has < 1 wave per SIMD, so it is bound by
 // dependent-load depth: all constraint rows are requested up front (they do not depend on the slot metadata), the
 // body gathers follow the metadata — two memory round trips per sweep.
@@ -1579,6 +1620,10 @@ __device__ __forceinline__ void issuePair4Sc1(const PairBody& A, const PairBody&
                  "global_load_dwordx4 %2, %6, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %3, %7, off" MI_SC_LOAD
                  : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(A.q0), "v"(A.q1), "v"(B.q0), "v"(B.q1) : "memory");
 }
+__device__ __forceinline__ void issuePair2Sc1(const PairBody& A, f32x4& a0, f32x4& a1) {   // no wait ("+v": lanes that do not take part keep their values)
+    asm volatile("global_load_dwordx4 %0, %2, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %1, %3, off" MI_SC_LOAD
+                 : "+v"(a0), "+v"(a1) : "v"(A.q0), "v"(A.q1) : "memory");
+}
 __device__ __forceinline__ void loadPair2Sc1(const PairBody& A, f32x4& a0, f32x4& a1) {
     asm volatile("global_load_dwordx4 %0, %2, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %1, %3, off" MI_SC_LOAD "\n\ts_waitcnt vmcnt(0)"
                  : "=&v"(a0), "=&v"(a1) : "v"(A.q0), "v"(A.q1) : "memory");
@@ -1713,16 +1758,20 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
         // takes part in the swap (inside `!okA || swap(...)` the swap would run with only the ready lanes active)
         const uint32_t partnerOkA = swz1(okA ? 1u : 0u), partnerOkB = swz1(okB ? 1u : 0u);
         bool pollA = !okA || partnerOkA == 0u, pollB = !okB || partnerOkB == 0u;
+        // both bodies' polls are in flight together: one round trip per iteration, not two
+        f32x4 ra0 = a0, ra1 = a1, rb0 = b0, rb1 = b1;
+        if (pollA) issuePair2Sc1(PA, ra0, ra1);
+        if (pollB) issuePair2Sc1(PB, rb0, rb1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        landed(ra0); landed(ra1); landed(rb0); landed(rb1);
         if (pollA) {
-            f32x4 r0, r1, g0, g1;
-            loadPair2Sc1(PA, r0, r1);
-            pairGather(odd, r0, r1, g0, g1);
+            f32x4 g0, g1;
+            pairGather(odd, ra0, ra1, g0, g1);
             if (!okA) { a0 = g0; a1 = g1; okA = __float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA; }
         }
         if (pollB) {
-            f32x4 r0, r1, g0, g1;
-            loadPair2Sc1(PB, r0, r1);
-            pairGather(odd, r0, r1, g0, g1);
+            f32x4 g0, g1;
+            pairGather(odd, rb0, rb1, g0, g1);
             if (!okB) { b0 = g0; b1 = g1; okB = __float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB; }
         }
         if (!okI) {
@@ -1734,14 +1783,18 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
     }
     hook.late(polled);
     MI_STAMP(hook.rec, 4);
-    V3 vA(a0.x, a0.y, a0.z), wA(a1.x, a1.y, a1.z), vB(b0.x, b0.y, b0.z), wB(b1.x, b1.y, b1.z);
+    P3 pv, pw;
+    pv.x = pk2(a0.x, b0.x); pv.y = pk2(a0.y, b0.y); pv.z = pk2(a0.z, b0.z);
+    pw.x = pk2(a1.x, b1.x); pw.y = pk2(a1.y, b1.y); pw.z = pk2(a1.z, b1.z);
+    const f32x2 sMass = pk2(-imA, imB);
     float2 out[CNT];
 #pragma unroll
     for (int k = 0; k < CNT; ++k) {
         float2 im = make_float2(ig[k].x, ig[k].y);
-        solveOne(c[k], nf, im, imA, imB, vA, wA, vB, wB);
+        solveOnePk(c[k], nf, im, sMass, pv, pw);
         out[k] = im;
     }
+    V3 vA(pv.x.x, pv.y.x, pv.z.x), wA(pw.x.x, pw.y.x, pw.z.x), vB(pv.x.y, pv.y.y, pv.z.y), wB(pw.x.y, pw.y.y, pw.z.y);
     // publish: bodies first (they are on the dependency chain), then the impulses; nothing to wait for afterwards
     {
         float tA = __uint_as_float(expA + 1u), tB = __uint_as_float(expB + 1u);
@@ -1859,8 +1912,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
     __syncthreads();
     if (!mySlots) return;
     // Software pipeline over (sweep, slot): the rows of the NEXT tile are requested while this tile waits for its bodies.
-    // Loads retire in order, so the request order matters: this tile's body loads go first, the prefetch second, and the
-    // first tag check waits with vmcnt(number of prefetch loads) — the bodies are back, the prefetch may still be in flight.
+    // Loads retire in order, so the request order matters: this tile's body loads go first (even before its own rows are
+    // taken out of the ACC registers: vmcnt(4)), the prefetch second, and the first tag check waits with vmcnt(number of
+    // prefetch loads) — the bodies are back, the prefetch may still be in flight.
     // The prefetch is inline asm with its exact instruction count known, into FIXED accumulator registers a160..a255 that
     // the compiler never allocates (tests/test_capi_symbols.py checks the ISA for that); they are read back, again by
     // inline asm, after the explicit vmcnt(0) at the top of the next iteration.  (Compiler-allocated registers do not
@@ -1901,6 +1955,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
         }
         return cnt * kRows;
     };
+    // this tile's rows out of the ACC registers; the body loads of the tile (4, issued just before) may still be in flight
+    auto readRows = [&](ContactRows* cur, uint32_t cnt) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (0u < cnt) MI_ACC_READ(cur[0].r[0], 160, 161, 162, 163);
+        if (0u < cnt) MI_ACC_READ(cur[0].r[1], 164, 165, 166, 167);
+        if (0u < cnt) MI_ACC_READ(cur[0].r[2], 168, 169, 170, 171);
+        if (0u < cnt) MI_ACC_READ(cur[0].r[3], 172, 173, 174, 175);
+        if (0u < cnt) MI_ACC_READ(cur[0].r[4], 176, 177, 178, 179);
+        if (0u < cnt) MI_ACC_READ(cur[0].r[5], 180, 181, 182, 183);
+        if (1u < cnt) MI_ACC_READ(cur[1].r[0], 184, 185, 186, 187);
+        if (1u < cnt) MI_ACC_READ(cur[1].r[1], 188, 189, 190, 191);
+        if (1u < cnt) MI_ACC_READ(cur[1].r[2], 192, 193, 194, 195);
+        if (1u < cnt) MI_ACC_READ(cur[1].r[3], 196, 197, 198, 199);
+        if (1u < cnt) MI_ACC_READ(cur[1].r[4], 200, 201, 202, 203);
+        if (1u < cnt) MI_ACC_READ(cur[1].r[5], 204, 205, 206, 207);
+        if (2u < cnt) MI_ACC_READ(cur[2].r[0], 208, 209, 210, 211);
+        if (2u < cnt) MI_ACC_READ(cur[2].r[1], 212, 213, 214, 215);
+        if (2u < cnt) MI_ACC_READ(cur[2].r[2], 216, 217, 218, 219);
+        if (2u < cnt) MI_ACC_READ(cur[2].r[3], 220, 221, 222, 223);
+        if (2u < cnt) MI_ACC_READ(cur[2].r[4], 224, 225, 226, 227);
+        if (2u < cnt) MI_ACC_READ(cur[2].r[5], 228, 229, 230, 231);
+        if (3u < cnt) MI_ACC_READ(cur[3].r[0], 232, 233, 234, 235);
+        if (3u < cnt) MI_ACC_READ(cur[3].r[1], 236, 237, 238, 239);
+        if (3u < cnt) MI_ACC_READ(cur[3].r[2], 240, 241, 242, 243);
+        if (3u < cnt) MI_ACC_READ(cur[3].r[3], 244, 245, 246, 247);
+        if (3u < cnt) MI_ACC_READ(cur[3].r[4], 248, 249, 250, 251);
+        if (3u < cnt) MI_ACC_READ(cur[3].r[5], 252, 253, 254, 255);
+    };
     (void)fetchRows(0);
     for (uint32_t it = 0; it < sweeps; ++it)
         for (uint32_t slot = 0; slot < mySlots; ++slot) {
@@ -1912,32 +1994,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
 #endif
             MI_STAMP(rec, 0);
             const uint32_t ct = lDesc[3 * slot], cnt = lDesc[3 * slot + 1], io = lDesc[3 * slot + 2];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            MI_STAMP(rec, 1);
-            if (0u < cnt) MI_ACC_READ(cur[0].r[0], 160, 161, 162, 163);
-            if (0u < cnt) MI_ACC_READ(cur[0].r[1], 164, 165, 166, 167);
-            if (0u < cnt) MI_ACC_READ(cur[0].r[2], 168, 169, 170, 171);
-            if (0u < cnt) MI_ACC_READ(cur[0].r[3], 172, 173, 174, 175);
-            if (0u < cnt) MI_ACC_READ(cur[0].r[4], 176, 177, 178, 179);
-            if (0u < cnt) MI_ACC_READ(cur[0].r[5], 180, 181, 182, 183);
-            if (1u < cnt) MI_ACC_READ(cur[1].r[0], 184, 185, 186, 187);
-            if (1u < cnt) MI_ACC_READ(cur[1].r[1], 188, 189, 190, 191);
-            if (1u < cnt) MI_ACC_READ(cur[1].r[2], 192, 193, 194, 195);
-            if (1u < cnt) MI_ACC_READ(cur[1].r[3], 196, 197, 198, 199);
-            if (1u < cnt) MI_ACC_READ(cur[1].r[4], 200, 201, 202, 203);
-            if (1u < cnt) MI_ACC_READ(cur[1].r[5], 204, 205, 206, 207);
-            if (2u < cnt) MI_ACC_READ(cur[2].r[0], 208, 209, 210, 211);
-            if (2u < cnt) MI_ACC_READ(cur[2].r[1], 212, 213, 214, 215);
-            if (2u < cnt) MI_ACC_READ(cur[2].r[2], 216, 217, 218, 219);
-            if (2u < cnt) MI_ACC_READ(cur[2].r[3], 220, 221, 222, 223);
-            if (2u < cnt) MI_ACC_READ(cur[2].r[4], 224, 225, 226, 227);
-            if (2u < cnt) MI_ACC_READ(cur[2].r[5], 228, 229, 230, 231);
-            if (3u < cnt) MI_ACC_READ(cur[3].r[0], 232, 233, 234, 235);
-            if (3u < cnt) MI_ACC_READ(cur[3].r[1], 236, 237, 238, 239);
-            if (3u < cnt) MI_ACC_READ(cur[3].r[2], 240, 241, 242, 243);
-            if (3u < cnt) MI_ACC_READ(cur[3].r[3], 244, 245, 246, 247);
-            if (3u < cnt) MI_ACC_READ(cur[3].r[4], 248, 249, 250, 251);
-            if (3u < cnt) MI_ACC_READ(cur[3].r[5], 252, 253, 254, 255);
             uint4 meta; float4 nf; float2 mass;
             if (METALDS) { meta = lMeta[slot * 64u + lane]; nf = lNormal[slot * 64u + lane]; mass = lMass[slot * 64u + lane]; }
             else { meta = nxMeta; nf = nxNf; mass = nxMass; }
@@ -1946,10 +2002,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
             // (MI_LATE_PREFETCH: a tile that had to poll in the previous sweep prefetches after its wait, so that its polls do not
             // queue behind the prefetch.  Measured slower — 0.68 vs 0.63 ms — the rows arriving late costs more; off.)
             struct Prefetch {
-                decltype(fetchRows)& fetch; uint32_t* crit; uint32_t next; bool more, critical, issued; unsigned long long* rec;
-                __device__ __forceinline__ uint32_t early() { if (more && !critical) { issued = true; return fetch(next); } return 0u; }
+                decltype(fetchRows)& fetch; decltype(readRows)& read; ContactRows* cur; uint32_t cnt; uint32_t* crit; uint32_t next; bool more, critical, issued; unsigned long long* rec;
+                __device__ __forceinline__ uint32_t early() { read(cur, cnt); MI_STAMP(rec, 1); if (more && !critical) { issued = true; return fetch(next); } return 0u; }
                 __device__ __forceinline__ void late(bool waited) { if (more && !issued) (void)fetch(next); if (threadIdx.x == 0) *crit = waited ? 1u : 0u; }
-            } prefetch{fetchRows, &lCrit[slot], nextSlot, more, MI_LATE_PREFETCH && lCrit[slot] != 0u, false, rec};
+            } prefetch{fetchRows, readRows, cur, cnt, &lCrit[slot], nextSlot, more, MI_LATE_PREFETCH && lCrit[slot] != 0u, false, rec};
             float2* li = lImp + (size_t)io * 64u;
             switch (cnt) {
                 case 1: processTile<1, true, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li, gVelL, prefetch); break;

@@ -1964,10 +1964,10 @@ MI_API int mi_world_get_accumulated_stage_times(mi_world* w, mi_stage_times* out
     return MI_OK;
 }
 // Which contact-solver kernel the last internal step ran: 0 k_contact_solve (one launch per colour per sweep), 1 k_contact_solve_flow,
-// 2 k_contact_solve_persist, 3 k_solve_flow_islands (contacts + joint islands fused).
+// 2 k_contact_solve_persist, 3 k_solve_flow_islands (contacts + joint islands fused), 4 k_contact_solve_persist XCD-partitioned.
 MI_API int mi_world_get_solver_kind(mi_world* w, uint32_t* out) {
     if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null");
-    *out = w->usedFused ? 3u : w->usedPersist ? 2u : w->usedFlow ? 1u : 0u;
+    *out = w->usedFused ? 3u : w->usedPersist ? (w->usedXcd ? 4u : 2u) : w->usedFlow ? 1u : 0u;
     return MI_OK;
 }
 MI_API int mi_world_get_stage_times(mi_world* w, mi_stage_times* out) { if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null"); *out = w->times; return MI_OK; }

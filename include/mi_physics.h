@@ -263,7 +263,8 @@ MI_API int mi_world_get_counts(mi_world* world, mi_step_counts* out);
 MI_API int mi_world_get_contacts(mi_world* world, mi_contact* out, uint32_t capacity, uint32_t* out_count);
 MI_API int mi_world_get_stage_times(mi_world* world, mi_stage_times* out);
 /* Contact-solver kernel of the last internal step: 0 k_contact_solve (a launch per colour per sweep), 1 k_contact_solve_flow,
- * 2 k_contact_solve_persist (default without joints), 3 k_solve_flow_islands (contacts + joint islands in one launch). */
+ * 2 k_contact_solve_persist (default without joints), 3 k_solve_flow_islands (contacts + joint islands in one launch),
+ * 4 k_contact_solve_persist with the tiles partitioned over the XCDs (default from 16384 manifolds up). */
 MI_API int mi_world_get_solver_kind(mi_world* world, uint32_t* out_kind);
 /* Sum of the per-stage device times and of the contact updates (contacts x solver iterations) over the internal steps since
  * the last reset (so a benchmark loop does not have to call back into the library after every step). */

@@ -88,3 +88,33 @@ def test_cpp_facade_runs_on_gpu(tmp_path, mi_lib):
     exe = _build_facade(tmp_path, mi_lib)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0 and "facade ok" in r.stdout, r.stdout + r.stderr
+
+
+def test_persistent_solver_keeps_its_acc_registers_to_itself(tmp_path, mi_lib):
+    """k_contact_solve_persist prefetches the next tile's constraint rows with inline-asm loads into the FIXED accumulator
+    registers a160..a255 and reads them back with inline asm after an explicit wait.  That is only sound if the compiler never
+    touches those registers itself (it may spill into low ACC registers): every reference to a160 and above must sit inside an
+    #ASMSTART/#ASMEND block, nothing may go to scratch, and the prefetch / read-back come in whole tiles (24 loads, 24 moves per
+    contact)."""
+    from d3d12renderer_amd import build
+    asm = build.device_asm(tmp_path / "device.s").read_text().split("\n")
+    starts = [i for i, l in enumerate(asm) if re.match(r"^_ZN2mi23k_contact_solve_persistILb[01]ELb[01]EE.*:", l)]
+    assert len(starts) == 4, "four variants: slot data in LDS or not, XCD-partitioned or not"
+    for st in starts:
+        in_asm, stray, loads, reads = False, [], 0, 0
+        i = st
+        while ".amdhsa_kernel" not in asm[i]:
+            line = asm[i]; i += 1
+            if "#ASMSTART" in line:
+                in_asm = True; continue
+            if "#ASMEND" in line:
+                in_asm = False; continue
+            code = line.split(";")[0]
+            if in_asm:
+                loads += len(re.findall(r"global_load_dwordx4 a\[", code))
+                reads += len(re.findall(r"v_accvgpr_read_b32", code))
+            elif "scratch_" in code or any(int(n) >= 160 for n in re.findall(r"\ba\[?(\d+)", code)):
+                stray.append(line.strip())
+        assert not stray, stray[:5]
+        # the prefetch is inlined once per call site (24 loads each); the read-back once per contact count (24 moves per contact)
+        assert loads > 0 and loads % 24 == 0 and reads > 0 and reads % 24 == 0, (loads, reads)

@@ -299,12 +299,17 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
     assert g2.cloth_state(0, 144)[0].tobytes() == o2.cloth_state(0, 144)[0].tobytes()
 
 
-@pytest.mark.parametrize("solver,kernel", [("flow", "k_contact_solve_flow"), ("persist-global", "k_contact_solve_persist")])
-def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch, solver, kernel):
-    """MI_SOLVER=flow selects k_contact_solve_flow (one workgroup per (sweep, tile), dispatch-ordered; also the automatic
-    fallback of the default persistent kernel and the path taken with joints); persist-global is the persistent kernel with
-    the slot data read from global memory instead of LDS (what piles beyond ~500 k manifolds get): same results, bit for bit."""
-    monkeypatch.setenv("MI_SOLVER", solver)
+@pytest.mark.parametrize("env,kind", [({"MI_SOLVER": "flow"}, 1), ({"MI_SOLVER": "persist-global"}, 2), ({"MI_PERSIST_XCD": "0"}, 2),
+                                      ({"MI_PERSIST_XCD_MIN": "1"}, 4), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-global"}, 4)])
+def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch, env, kind):
+    """Every dataflow contact solver gives the same results, bit for bit (which lane / wave / XCD runs a slot is invisible to the
+    body-version dataflow):  MI_SOLVER=flow -> k_contact_solve_flow (one workgroup per (sweep, tile), dispatch-ordered; also the
+    automatic fallback and the path taken with joints);  persist-global -> the persistent kernel with the slot data read from
+    global memory instead of LDS (what piles beyond ~500 k manifolds get);  MI_PERSIST_XCD_MIN=1 -> XCD partitioning (spatially
+    sorted slots, per-XCD tile lists, XCD-local bodies through L2) even on this small pile (default from 16384 manifolds up);
+    MI_PERSIST_XCD=0 -> never partitioned."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
     sc = scenes.obb_pile(14, 8, 14, spacing=1.05)
     g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     s = sc.settings()
@@ -313,8 +318,8 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
         assert g.counts() == o.counts(), f"step {i}"
     assert g.counts()["num_contacts"] > 3000
     assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
-    assert g.solver_kernel() == kernel
-    monkeypatch.delenv("MI_SOLVER")
+    assert g.solver_kind() == kind
+    assert g.step_mode_stats()[2] <= 2, "the partitioned solver must not keep falling back"
 
 
 def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
@@ -377,6 +382,29 @@ def test_gpu_baseline_sizes_properties(mi_lib, name, make, steps):
         assert drift < 0.05
     total, spec, retries = w.step_mode_stats()
     assert total == steps and spec >= steps - 1 - retries and retries <= 3
+
+
+def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
+    """BASELINE's 262 144-body pile, far beyond the oracle's reach: the default solver (XCD-partitioned persistent kernel: eight
+    tile lists, ~95 % of the bodies handed over through an XCD's L2, the seam bodies through memory) must end bit-identical to
+    the dispatch-ordered flow kernel and to the unpartitioned persistent kernel, which the small cases pin to the oracle."""
+    import hashlib
+    sc = scenes.obb_pile(128, 16, 128)
+    out = {}
+    for name, env in (("default", {}), ("flow", {"MI_SOLVER": "flow"}), ("unpartitioned", {"MI_PERSIST_XCD": "0"})):
+        for k in ("MI_SOLVER", "MI_PERSIST_XCD"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        w = sc.populate(gpu_world(mi_lib))
+        w.step_fixed(sc.settings(), sc.dt, 120)
+        p, q = w.physics_transforms()
+        out[name] = (hashlib.sha1(p.tobytes() + q.tobytes()).hexdigest(), w.counts()["num_contacts"], w.solver_kind(), w.step_mode_stats()[2])
+        w.close()
+    assert out["default"][2] == 4 and out["flow"][2] == 1 and out["unpartitioned"][2] == 2, out
+    assert out["default"][:2] == out["flow"][:2] == out["unpartitioned"][:2], out
+    assert out["default"][1] > 150000
+    assert out["default"][3] <= 12, "speculative retries while the pile lands are fine; a solver that keeps falling back is not"
 
 
 def test_gpu_full_size_properties(mi_lib):
