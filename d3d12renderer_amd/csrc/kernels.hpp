@@ -1856,11 +1856,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_W
 // reported as solveError 3 and the host falls back) and owns entries w / 8, w / 8 + gridDim / 8, ... of THAT XCD's tile
 // list (xcdTiles, ascending = schedule order).  Bodies only this XCD touches (bodyOwner has exactly this XCD's bit) are
 // handed over through the XCD's L2 in the cached array gVelL; all others through memory in gVel as before.
-template <bool METALDS, bool XCD>
+// IMPLDS = false (piles beyond ~1.2 M manifolds): nothing per slot but a 20-byte descriptor stays in LDS; the accumulated
+// impulses travel as tagged granules in `imp` exactly as in k_contact_solve_flow (no size limit left).
+template <bool METALDS, bool XCD, bool IMPLDS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIST_WPE))) void k_contact_solve_persist(
     uint32_t sweeps, uint32_t maxSlots, const uint2* __restrict__ tileDesc, const uint4* slotMeta, const float4* __restrict__ slotNormal,
     const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* gVel, StepScalars* sc, uint32_t xcdOnly,
-    const uint32_t* __restrict__ xcdTiles, uint32_t listCap, const unsigned long long* __restrict__ bodyOwner, float4* gVelL, uint4* slotMetaW) {
+    const uint32_t* __restrict__ xcdTiles, uint32_t listCap, const unsigned long long* __restrict__ bodyOwner, float4* gVelL, uint4* slotMetaW, float4* imp) {
     // LDS per workgroup: [maxSlots] x { meta uint4[64], normal float4[64], mass float2[64] } (constant over the sweeps; METALDS only), then the
     // impulses float2[4 * maxSlots][64], then the per-slot (first contact-tile, contacts per manifold, impulse offset)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
@@ -1869,7 +1871,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
     float4* lNormal = reinterpret_cast<float4*>(lMeta + metaSlots * 64u);
     float2* lMass = reinterpret_cast<float2*>(lNormal + metaSlots * 64u);
     float2* lImp = lMass + metaSlots * 64u;
-    uint32_t* lDesc = reinterpret_cast<uint32_t*>(lImp + (size_t)maxSlots * 4u * 64u);   // [maxSlots][3]
+    uint32_t* lDesc = reinterpret_cast<uint32_t*>(lImp + (IMPLDS ? (size_t)maxSlots * 4u * 64u : 0));   // [maxSlots][3]
     if (xcdOnly && (blockIdx.x & 7u) != 0u) return;   // development experiment: only the workgroups of one XCD work
     const uint32_t lane = threadIdx.x;
     const uint32_t xcd = blockIdx.x & 7u;
@@ -1905,7 +1907,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
             lMass[mySlots * 64u + lane] = slotMass[(size_t)tile * 64u + lane];
         }
         if (lane == 0) { lDesc[3 * mySlots] = d.x; lDesc[3 * mySlots + 1] = d.y; lDesc[3 * mySlots + 2] = off; }
-        for (uint32_t k = 0; k < d.y; ++k) lImp[(size_t)(off + k) * 64u + lane] = make_float2(0.f, 0.f);
+        if (IMPLDS) for (uint32_t k = 0; k < d.y; ++k) lImp[(size_t)(off + k) * 64u + lane] = make_float2(0.f, 0.f);
         off += d.y;
     }
     if (wid + (size_t)mySlots * numWaves < numTiles) { if (lane == 0) sc->solveError = 2u; return; }   // more tiles than the host sized LDS for
@@ -2008,10 +2010,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
             } prefetch{fetchRows, readRows, cur, cnt, &lCrit[slot], nextSlot, more, MI_LATE_PREFETCH && lCrit[slot] != 0u, false, rec};
             float2* li = lImp + (size_t)io * 64u;
             switch (cnt) {
-                case 1: processTile<1, true, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li, gVelL, prefetch); break;
-                case 2: processTile<2, true, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li, gVelL, prefetch); break;
-                case 3: processTile<3, true, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li, gVelL, prefetch); break;
-                default: processTile<4, true, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, nullptr, gVel, sc, li, gVelL, prefetch); break;
+                case 1: processTile<1, IMPLDS, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, imp, gVel, sc, li, gVelL, prefetch); break;
+                case 2: processTile<2, IMPLDS, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, imp, gVel, sc, li, gVelL, prefetch); break;
+                case 3: processTile<3, IMPLDS, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, imp, gVel, sc, li, gVelL, prefetch); break;
+                default: processTile<4, IMPLDS, XCD, Prefetch&>(ct, lane, it, meta, nf, mass, cur, imp, gVel, sc, li, gVelL, prefetch); break;
             }
         }
 }

@@ -150,7 +150,7 @@ struct mi_world {
     DBuf<float4> rows, slotNormal; DBuf<float4> imp; DBuf<float2> slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc;
     bool usedFlow = false;
     bool usedFused = false;
-    bool persistSolver = true, persistMetaLds = true, usedPersist = false; uint32_t xcdOnly = 0; uint32_t persistWaves = 1024;   // one resident workgroup per SIMD owns its tiles through all sweeps (k_contact_solve_persist)
+    bool persistSolver = true, persistMetaLds = true, persistImpLds = true, usedPersist = false; uint32_t xcdOnly = 0; uint32_t persistWaves = 1024;   // one resident workgroup per SIMD owns its tiles through all sweeps (k_contact_solve_persist)
     uint32_t flowLds = 0;                  // dynamic LDS bytes per 64-lane workgroup: caps resident waves per CU (160 KiB / flowLds)
     bool flowSolver = true;               // dataflow PGS sweep (one launch per iteration); MI_SOLVER=launch selects one launch per colour
     BinInfo bins[kSchedBins]{};           // host copy of the last step's schedule
@@ -220,7 +220,9 @@ int mi_world::init(int dev) {
     gVel.flags = allocFlags("MI_GVEL_ALLOC", hipDeviceMallocUncached);
     imp.flags = allocFlags("MI_IMP_ALLOC", 0u);
     { const char* sv = getenv("MI_SOLVER"); persistSolver = !sv || std::string(sv) == "persist" || std::string(sv) == "persist-global";   // default; MI_SOLVER=flow / launch select the other contact solvers
-      persistMetaLds = !sv || std::string(sv) != "persist-global";   // persist-global: slot data always from global memory (the variant larger problems get automatically)
+      persistImpLds = !sv || std::string(sv) != "persist-granules";   // persist-granules: impulses as tagged granules as well (what the largest piles get automatically)
+      if (sv && std::string(sv) == "persist-granules") persistSolver = true;
+      persistMetaLds = !sv || (std::string(sv) != "persist-global" && std::string(sv) != "persist-granules");   // persist-global: slot data always from global memory (the variant larger problems get automatically)
       hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) persistWaves = 4u * (uint32_t)prop.multiProcessorCount;
       if (const char* pw = getenv("MI_PERSIST_WAVES")) persistWaves = (uint32_t)strtoul(pw, nullptr, 0);
       xcdOnly = getenv("MI_PERSIST_XCD_ONLY") ? 1u : 0u;
@@ -900,7 +902,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                                                                                    tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, sc);
             if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
         }
-    } else if (useFlow && persistSolver && joints.count() == 0 && tilesLaunch && persistSlots(tilesLaunch, xcdPlan, spec) * (4u * 512u + 20u) <= 38u * 1024u) {
+    } else if (useFlow && persistSolver && joints.count() == 0 && tilesLaunch && persistSlots(tilesLaunch, xcdPlan, spec) * 20u <= 38u * 1024u) {
         // persistent waves: one workgroup per SIMD owns its tiles through all sweeps, impulses (and, while they fit, the constant slot data) in LDS (k_contact_solve_persist)
         const uint32_t maxSlots = persistSlots(tilesLaunch, xcdPlan, spec);
         const bool metaLds = persistMetaLds && maxSlots * (64u * 40u + 4u * 512u + 20u) <= 38u * 1024u;
@@ -911,14 +913,17 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
             (void)hipEventRecord(profEvents[e], st);
         }
-        const uint32_t ldsMeta = maxSlots * (64u * 40u + 4u * 512u + 20u) + 16u, ldsImp = maxSlots * (4u * 512u + 20u) + 16u;
-#define MI_PERSIST_ARGS iters, maxSlots, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, sc, xcdOnly, xcdTiles.p, xcdListCap, bodyOwner.p, gVelL.p, slotMeta.p
+        const bool impLds = persistImpLds && maxSlots * (4u * 512u + 20u) <= 38u * 1024u;   // beyond that the impulses travel as granules in `imp` (no size limit)
+        const uint32_t ldsMeta = maxSlots * (64u * 40u + 4u * 512u + 20u) + 16u, ldsImp = maxSlots * (4u * 512u + 20u) + 16u, ldsDesc = maxSlots * 20u + 16u;
+#define MI_PERSIST_ARGS iters, maxSlots, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, sc, xcdOnly, xcdTiles.p, xcdListCap, bodyOwner.p, gVelL.p, slotMeta.p, imp.p
         if (usedXcd) {
-            if (metaLds) k_contact_solve_persist<true, true><<<persistWaves, 64, ldsMeta, st>>>(MI_PERSIST_ARGS);
-            else k_contact_solve_persist<false, true><<<persistWaves, 64, ldsImp, st>>>(MI_PERSIST_ARGS);
+            if (metaLds && impLds) k_contact_solve_persist<true, true, true><<<persistWaves, 64, ldsMeta, st>>>(MI_PERSIST_ARGS);
+            else if (impLds) k_contact_solve_persist<false, true, true><<<persistWaves, 64, ldsImp, st>>>(MI_PERSIST_ARGS);
+            else k_contact_solve_persist<false, true, false><<<persistWaves, 64, ldsDesc, st>>>(MI_PERSIST_ARGS);
         } else {
-            if (metaLds) k_contact_solve_persist<true, false><<<persistWaves, 64, ldsMeta, st>>>(MI_PERSIST_ARGS);
-            else k_contact_solve_persist<false, false><<<persistWaves, 64, ldsImp, st>>>(MI_PERSIST_ARGS);
+            if (metaLds && impLds) k_contact_solve_persist<true, false, true><<<persistWaves, 64, ldsMeta, st>>>(MI_PERSIST_ARGS);
+            else if (impLds) k_contact_solve_persist<false, false, true><<<persistWaves, 64, ldsImp, st>>>(MI_PERSIST_ARGS);
+            else k_contact_solve_persist<false, false, false><<<persistWaves, 64, ldsDesc, st>>>(MI_PERSIST_ARGS);
         }
 #undef MI_PERSIST_ARGS
         if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }

@@ -98,8 +98,8 @@ def test_persistent_solver_keeps_its_acc_registers_to_itself(tmp_path, mi_lib):
     contact)."""
     from d3d12renderer_amd import build
     asm = build.device_asm(tmp_path / "device.s").read_text().split("\n")
-    starts = [i for i, l in enumerate(asm) if re.match(r"^_ZN2mi23k_contact_solve_persistILb[01]ELb[01]EE.*:", l)]
-    assert len(starts) == 4, "four variants: slot data in LDS or not, XCD-partitioned or not"
+    starts = [i for i, l in enumerate(asm) if re.match(r"^_ZN2mi23k_contact_solve_persistILb[01]ELb[01]ELb[01]EE.*:", l)]
+    assert len(starts) == 6, "variants: slot data / impulses in LDS or not, XCD-partitioned or not"
     for st in starts:
         in_asm, stray, loads, reads = False, [], 0, 0
         i = st

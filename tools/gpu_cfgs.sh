@@ -11,7 +11,8 @@ from d3d12renderer_amd import scenes
 out = {}
 for name, make, warm, steps in (("cfg1_spheres_4096", lambda: scenes.sphere_drop(16), 240, 60), ("cfg2_mixed_65536", lambda: scenes.mixed_stack(64, 16, 64), 240, 60),
                                 ("cfg4_ragdolls_1024", lambda: scenes.ragdolls(32, 32), 240, 60), ("cfg5_vehicles_256", lambda: scenes.vehicles(16, 16), 240, 60),
-                                ("terrain_65536", lambda: scenes.terrain_big(), 300, 60), ("zones_6912", lambda: scenes.zones(48, 3, 48), 200, 60)):
+                                ("terrain_65536", lambda: scenes.terrain_big(), 300, 60), ("zones_6912", lambda: scenes.zones(48, 3, 48), 200, 60),
+                                ("cfg3_settled_pile_262144", lambda: scenes.obb_pile(128, 16, 128), 1500, 60), ("pile_1048576", lambda: scenes.obb_pile(256, 16, 256), 240, 30)):
     sc = make()
     w = sc.populate(mi.create_world(0))
     s = sc.settings()
@@ -22,7 +23,7 @@ for name, make, warm, steps in (("cfg1_spheres_4096", lambda: scenes.sphere_drop
         for k, v in w.stage_times().items(): acc[k] = acc.get(k, 0.0) + v / steps
     dt = (time.perf_counter() - t0) / steps
     p, q = w.physics_transforms()
-    out[name] = dict(bodies=sc.num_bodies, ms_per_step=dt * 1e3, steps_per_s=1 / dt, counts=w.counts(), finite=bool(np.isfinite(p).all()), stage_ms={k: round(v, 4) for k, v in acc.items()})
+    out[name] = dict(bodies=sc.num_bodies, solver=w.solver_kernel(), solver_kind=w.solver_kind(), ms_per_step=dt * 1e3, steps_per_s=1 / dt, counts=w.counts(), finite=bool(np.isfinite(p).all()), stage_ms={k: round(v, 4) for k, v in acc.items()})
     print(name, json.dumps(out[name]), flush=True)
 json.dump(out, open("gpurun_out/cfgs.json", "w"), indent=1)
 PY

@@ -38,7 +38,7 @@ traffic = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARAT
 if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
     for k in summary["FETCH_SIZE"]:
         if "contact_solve" in k and k in summary["WRITE_SIZE"]:
-            name = k.split("::")[-1]
+            name = k.split("::")[-1].split("<")[0]   # template arguments (k_contact_solve_persist<slot data in LDS, XCD-partitioned>) dropped
             f_, w_ = summary["FETCH_SIZE"][k]["steady_mean"], summary["WRITE_SIZE"][k]["steady_mean"]
             traffic[name + "_bytes_per_launch"] = (2 * f_ + w_) * 1024
             traffic[name + "_raw"] = {"FETCH_SIZE_KB_steady": f_, "WRITE_SIZE_KB_steady": w_, "dispatches": summary["FETCH_SIZE"][k]["dispatches"]}
