@@ -296,14 +296,18 @@ __global__ __launch_bounds__(256) void k_bp_classify(uint32_t nc, const float4* 
 }
 
 __global__ __launch_bounds__(256) void k_bp_grid_setup(uint32_t nc, uint32_t numBlocks, uint32_t cellCap, const int* __restrict__ blockBounds, StepScalars* sc, GridParams* g) {
-    __shared__ int red[256][6];
+    __shared__ int red[4][6];
     int v[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
     for (uint32_t b = threadIdx.x; b < numBlocks; b += 256)
         for (int a = 0; a < 6; ++a) { int x = blockBounds[b * 6 + a]; v[a] = a < 3 ? min(v[a], x) : max(v[a], x); }
-    for (int a = 0; a < 6; ++a) red[threadIdx.x][a] = v[a];
+#pragma unroll
+    for (int a = 0; a < 6; ++a)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(v[a], d, 64); v[a] = a < 3 ? min(v[a], o) : max(v[a], o); }
+    if ((threadIdx.x & 63u) == 0) for (int a = 0; a < 6; ++a) red[threadIdx.x >> 6][a] = v[a];
     __syncthreads();
     if (threadIdx.x != 0) return;
-    for (int t = 1; t < 256; ++t) for (int a = 0; a < 6; ++a) v[a] = a < 3 ? min(v[a], red[t][a]) : max(v[a], red[t][a]);
+    for (int t = 1; t < 4; ++t) for (int a = 0; a < 6; ++a) v[a] = a < 3 ? min(v[a], red[t][a]) : max(v[a], red[t][a]);
     float thr = sc->largeThreshold;
     float cell = thr * 1.001f + 1e-6f;
     float lo[3], hi[3];
@@ -970,9 +974,13 @@ __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float
                                                               float4* __restrict__ bPos, float4* __restrict__ bRot,
                                                               float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, float4* __restrict__ bForce,
                                                               float4* __restrict__ bTorque,
-                                                              const float4* __restrict__ gVelL, const unsigned long long* __restrict__ bodyOwner /* XCD-partitioned solver, or null */) {
+                                                              const float4* __restrict__ gVelL, const unsigned long long* __restrict__ bodyOwner /* XCD-partitioned solver, or null */,
+                                                              unsigned long long* __restrict__ bodyUsed, unsigned long long* __restrict__ bodyTop) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nb) return;
+    if (i > nb) return;
+    // the per-body colouring scratch of the NEXT step starts out cleared (saves two memset launches per step); launched over nb + 1
+    bodyUsed[i] = 0ull; bodyTop[i] = 0ull; bodyTop[(size_t)nb + 1u + i] = 0ull;
+    if (i == nb) return;
     if (bodyOwner && __popcll(bodyOwner[i]) == 1) gVel = gVelL;   // a body only one XCD touched lives in the cached copy
     V3 v = xyz(gVel[2 * i]), w = xyz(gVel[2 * i + 1]);
     Q4 rot = toQ(bRotIn[i]);
@@ -1234,37 +1242,49 @@ __device__ __forceinline__ M3 loadM3(const float4* __restrict__ p, uint32_t i) {
 // Schedule bins -> tiles, on the device (so the host never has to read the bin sizes back before it can launch the
 // constraint kernels): BinInfo per bin, tile -> bin and tile -> (first contact-tile, contacts per manifold) tables, totals.
 // The host launches the consumers over an upper bound of tiles; tiles >= totalTiles exit.
+// exclusive prefix sum over n values by ONE wave (64-value chunks, shuffle scan inside a chunk); returns the total
+template <class Get, class Put>
+__device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t n, Get get, Put put) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < n; base += 64u) {
+        const uint32_t i = base + lane;
+        const uint32_t v = i < n ? get(i) : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) { uint32_t o = (uint32_t)__shfl_up((int)incl, d, 64); if (lane >= d) incl += o; }
+        if (i < n) put(i, carry + incl - v);
+        carry += (uint32_t)__shfl((int)incl, 63, 64);
+    }
+    return carry;
+}
 __global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t ctCap, StepScalars* sc, BinInfo* __restrict__ binInfo, uint32_t* __restrict__ xcdBase /* [kSchedBins][8] or null */) {
     __shared__ BinInfo bins[kSchedBins];
     __shared__ uint32_t start[kColorBins + 4];
+    __shared__ uint32_t totals[2];
     for (uint32_t b = threadIdx.x; b <= kColorBins; b += blockDim.x) start[b] = sc->binStart[b];
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tiles = 0, ct = 0;
-        for (uint32_t bn = 0; bn < kSchedBins; ++bn) {
-            bool ovf = bn == kSchedBins - 1;
-            uint32_t s0 = start[bn], s1 = ovf ? start[kColorBins] : start[bn + 1];
-            uint32_t stride = ovf ? 4u : (bn & 3u) + 1u;
-            BinInfo bi; bi.slotStart = s0; bi.count = s1 - s0; bi.tileStart = tiles; bi.ctStart = ct;
-            uint32_t nt = (bi.count + 63u) >> 6;
-            tiles += nt; ct += nt * stride;
-            bins[bn] = bi;
-        }
-        bool ok = tiles <= tilesCap && ct <= ctCap;
-        sc->totalTiles = ok ? tiles : 0u; sc->totalCt = ok ? ct : 0u;
-        if (!ok) sc->specOverflow = 1u;
+    for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) {
+        const bool ovf = bn == kSchedBins - 1;
+        bins[bn].slotStart = start[bn]; bins[bn].count = (ovf ? start[kColorBins] : start[bn + 1]) - start[bn];
     }
     __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6;
+    auto tilesOf = [&](uint32_t bn) { return (bins[bn].count + 63u) >> 6; };
+    if (wave == 0) { uint32_t t = waveExclusiveScan(kSchedBins, tilesOf, [&](uint32_t bn, uint32_t v) { bins[bn].tileStart = v; }); if ((threadIdx.x & 63u) == 0) totals[0] = t; }
+    if (wave == 1) { uint32_t t = waveExclusiveScan(kSchedBins, [&](uint32_t bn) { return tilesOf(bn) * (bn == kSchedBins - 1 ? 4u : (bn & 3u) + 1u); },
+                                                    [&](uint32_t bn, uint32_t v) { bins[bn].ctStart = v; }); if ((threadIdx.x & 63u) == 0) totals[1] = t; }
+    __syncthreads();
+    const bool ok = totals[0] <= tilesCap && totals[1] <= ctCap;
+    if (threadIdx.x == 0) {
+        sc->totalTiles = ok ? totals[0] : 0u; sc->totalCt = ok ? totals[1] : 0u;
+        if (!ok) sc->specOverflow = 1u;
+    }
     for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) binInfo[bn] = bins[bn];
-    if (xcdBase) {   // per-XCD tile lists: first list position of every bin's share, and the list lengths
-        __shared__ uint32_t share[kSchedBins * 8u];
-        for (uint32_t i = threadIdx.x; i < kSchedBins * 8u; i += blockDim.x) share[i] = tileOwnerCount(i & 7u, (bins[i >> 3].count + 63u) >> 6, i >> 3);
-        __syncthreads();
-        if (threadIdx.x < 8u) {
-            const uint32_t x = threadIdx.x;
-            uint32_t at = 0;
-            for (uint32_t bn = 0; bn < kSchedBins; ++bn) { uint32_t c = share[bn * 8u + x]; xcdBase[bn * 8u + x] = at; at += c; }
-            sc->xcdCount[x] = sc->totalTiles ? at : 0u;
+    if (xcdBase) {   // per-XCD tile lists: first list position of every bin's share (wave w scans XCDs 2w and 2w + 1), and the list lengths
+        for (uint32_t x = 2u * wave; x < 2u * wave + 2u; ++x) {
+            uint32_t t = waveExclusiveScan(kSchedBins, [&](uint32_t bn) { return tileOwnerCount(x, tilesOf(bn), bn); }, [&](uint32_t bn, uint32_t v) { xcdBase[bn * 8u + x] = v; });
+            if ((threadIdx.x & 63u) == 0) sc->xcdCount[x] = ok && totals[0] ? t : 0u;
         }
     }
 }

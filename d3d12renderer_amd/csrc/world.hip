@@ -392,6 +392,8 @@ int mi_world::upload() {
       HIP_TRY(bPosN.ensure(n1)); HIP_TRY(bRotN.ensure(n1)); HIP_TRY(bLinVelN.ensure(n1)); HIP_TRY(bAngVelN.ensure(n1)); HIP_TRY(bForceN.ensure(n1)); HIP_TRY(bTorqueN.ensure(n1)); }
     HIP_TRY(gPos.ensure(nb + 1)); HIP_TRY(gInvI.ensure(3 * ((size_t)nb + 1))); HIP_TRY(gVel.ensure(2 * ((size_t)nb + 1)));
     HIP_TRY(bodyTop.ensure(2 * ((size_t)nb + 1))); HIP_TRY(bodyUsed.ensure(nb + 1));
+    HIP_TRY(hipMemsetAsync(bodyTop.p, 0, 2 * ((size_t)nb + 1) * sizeof(unsigned long long), stream));   // from here on k_integrate_velocities leaves both cleared for the next step
+    HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, ((size_t)nb + 1) * sizeof(unsigned long long), stream));
     HIP_TRY(gVelL.ensure(2 * ((size_t)nb + 1))); HIP_TRY(bodyOwner.ensure(nb + 1)); HIP_TRY(xcdBase.ensure(kSchedBins * 8)); HIP_TRY(keyCount.ensure(kSpatialKeys));
 
     usesGjk = false;
@@ -752,7 +754,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         HIP_TRY(npPacked.ensure(pairBound)); HIP_TRY(npScan.ensure(pairBound)); HIP_TRY(npNormal.ensure(pairBound)); HIP_TRY(npPoints.ensure(4 * (size_t)pairBound));
         HIP_TRY(manPair.ensure(pairBound)); HIP_TRY(manBodies.ensure(pairBound)); HIP_TRY(manInfo.ensure(pairBound));
         HIP_TRY(colWork.ensure(pairBound)); HIP_TRY(color.ensure(pairBound));
-        HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, ((size_t)nb + 1) * sizeof(unsigned long long), st));   // k_emit_manifolds seeds it with the kept colours
+        // bodyUsed is all zero here (k_integrate_velocities of the previous step / upload cleared it); k_emit_manifolds seeds it with the kept colours
         HullSet hset{hullVerts.p, hullRanges.p};
         const uint32_t narrowBlocks = divUp(pairBound, B);
         const uint32_t queueRegion = divUp(narrowBlocks, kBoxQueues) * B;   // a queue can hold every pair of the workgroups that feed it
@@ -809,7 +811,6 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         }
         static const bool xcdNoSort = std::getenv("MI_XCD_NOSORT") != nullptr;   // development: manifold order as emitted
         const uint32_t* perm = xcdPlan && !xcdNoSort ? sortVals[1].p : nullptr;
-        HIP_TRY(hipMemsetAsync(bodyTop.p, 0, 2 * ((size_t)nb + 1) * sizeof(unsigned long long), st));
         unsigned long long* top[2] = {bodyTop.p, bodyTop.p + (nb + 1)};
         uint32_t round = 0;
         while (true) {
@@ -861,7 +862,6 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     const bool useFlow = flowSolver && (spec || bins[kSchedBins - 1].count == 0 || !nmBound);   // the overflow colour needs the sequential kernel
     static const bool fuseEnabled = !(std::getenv("MI_FUSE_JOINTS") && std::getenv("MI_FUSE_JOINTS")[0] == '0');
     const bool fused = useFlow && fuseEnabled && joints.allInIslands();   // joints of all sweeps inside the dataflow launch
-    if (fused && !pairBound) HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, ((size_t)nb + 1) * sizeof(unsigned long long), st));   // no contacts at all: no contact versions
     if (nmBound) {
         HIP_TRY(slotMeta.ensure((size_t)tilesCap * 64)); HIP_TRY(slotNormal.ensure((size_t)tilesCap * 64)); HIP_TRY(slotMass.ensure((size_t)tilesCap * 64));
         HIP_TRY(rows.ensure((size_t)ctCap * kRows * 64)); HIP_TRY(imp.ensure((size_t)ctCap * 64));
@@ -981,8 +981,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         }
     }
     mark();  // 7
-    k_integrate_velocities<<<divUp(nb, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
-                                                      gVelL.p, usedXcd ? bodyOwner.p : nullptr);
+    k_integrate_velocities<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
+                                                      gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p);
     mark();  // 8
     // ---------------------------------------------------------------------------------------------- end of step: the one read-back
     HIP_TRY(hipMemcpyAsync(hsPinned, sc, sizeof(Readback), hipMemcpyDeviceToHost, st));   // scalars + round flags are contiguous
