@@ -1322,16 +1322,21 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
                                                      float4* __restrict__ rows, float4* __restrict__ imp, uint4* __restrict__ slotMeta,
                                                      float4* __restrict__ slotNormal, float2* __restrict__ slotMass,
                                                      uint8_t* __restrict__ bodyOwner /* XCD-partitioned solver: [body][8] flags, 1 = a tile of that XCD touches the body; or null */) {
-    uint32_t tile = blockIdx.x, lane = threadIdx.x;
+    // (one wave per contact index — four waves per tile, the per-manifold gathers repeated — measured slower: 52 -> 73 us; the kernel
+    // is bound by those gathers)
+    uint32_t tile = blockIdx.x, lane = threadIdx.x; const uint32_t kw = 0;
     if (tile >= sc->totalTiles) return;
     uint32_t bin = tileBin[tile];
     BinInfo bi = binInfo[bin];
     uint32_t tl = tile - bi.tileStart, j = tl * 64u + lane;
     uint32_t stride = bin < kOverflowColor * 4u ? (bin & 3u) + 1u : 4u;
+    if (kw >= stride) return;
     size_t ctBase = (size_t)bi.ctStart + (size_t)tl * stride;
     if (j >= bi.count) {
-        slotMeta[(size_t)tile * 64u + lane] = make_uint4(dummyBody, dummyBody, 0u, 0u);
-        slotMass[(size_t)tile * 64u + lane] = make_float2(0.f, 0.f);
+        if (kw == 0) {
+            slotMeta[(size_t)tile * 64u + lane] = make_uint4(dummyBody, dummyBody, 0u, 0u);
+            slotMass[(size_t)tile * 64u + lane] = make_float2(0.f, 0.f);
+        }
         return;
     }
     uint32_t m = order[bi.slotStart + j];
@@ -1346,16 +1351,18 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
     // of updates a body has received before this manifold's turn in a sweep = colours used on the body below this one.
     //   packed = baseA | degA << 7 | baseB << 14 | degB << 21   (deg = 0: body is never written, nothing to wait for)
     uint32_t packed = 0;
-    {
+    if (kw == 0) {
         uint32_t c = color[m];
         unsigned long long below = c < 64u ? ((1ull << c) - 1ull) : ~0ull;
         // a body of a joint island is first updated by its island's block in every sweep (k_solve_flow_islands): one more version
         if (imA != 0.f) { unsigned long long u = bodyUsed[bodies.x]; uint32_t j = bodyJ ? bodyJ[bodies.x] : 0u; packed |= ((uint32_t)__popcll(u & below) + j) | (((uint32_t)__popcll(u) + j) << 7); }
         if (imB != 0.f) { unsigned long long u = bodyUsed[bodies.y]; uint32_t j = bodyJ ? bodyJ[bodies.y] : 0u; packed |= (((uint32_t)__popcll(u & below) + j) << 14) | (((uint32_t)__popcll(u) + j) << 21); }
     }
-    slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, packed, cnt);
-    slotMass[(size_t)tile * 64u + lane] = make_float2(imA, imB);
-    if (bodyOwner) {   // one byte per (body, XCD): plain idempotent stores, no atomics
+    if (kw == 0) {
+        slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, packed, cnt);
+        slotMass[(size_t)tile * 64u + lane] = make_float2(imA, imB);
+    }
+    if (bodyOwner && kw == 0) {   // one byte per (body, XCD): plain idempotent stores, no atomics
         const uint32_t x = tileOwner(tl, (bi.count + 63u) >> 6, bin);
         if (imA != 0.f) bodyOwner[(size_t)bodies.x * 8u + x] = 1u;
         if (imB != 0.f) bodyOwner[(size_t)bodies.y * 8u + x] = 1u;
@@ -1367,7 +1374,7 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
     float invDt = 1.f / dt;
     float friction = (float)(info.y >> 16) / (float)0xFFFF;
     float restitution = (float)(info.y & 0xFFFF) / (float)0xFFFF;
-    slotNormal[(size_t)tile * 64u + lane] = f4(n, friction);
+    if (kw == 0) slotNormal[(size_t)tile * 64u + lane] = f4(n, friction);
     for (uint32_t k = 0; k < cnt; ++k) {
         float4 pd = npPoints[4 * p + k];
         V3 point = xyz(pd); float depth = pd.w;
@@ -1397,7 +1404,7 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
         row[3 * 64] = make_float4(tA.x, tA.y, tA.z, tB.x);
         row[4 * 64] = make_float4(tB.y, tB.z, nA.x, nA.y);
         row[5 * 64] = make_float4(nA.z, nB.x, nB.y, nB.z);
-        imp[(ctBase + k) * 64u + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // no warm start (constraints.cpp:3312-3313); sweep tag 0
+        if (imp) imp[(ctBase + k) * 64u + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // no warm start (constraints.cpp:3312-3313); sweep tag 0 (null: the solver keeps the impulses in LDS)
     }
 }
 

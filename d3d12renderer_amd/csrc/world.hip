@@ -862,19 +862,6 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     const bool useFlow = flowSolver && (spec || bins[kSchedBins - 1].count == 0 || !nmBound);   // the overflow colour needs the sequential kernel
     static const bool fuseEnabled = !(std::getenv("MI_FUSE_JOINTS") && std::getenv("MI_FUSE_JOINTS")[0] == '0');
     const bool fused = useFlow && fuseEnabled && joints.allInIslands();   // joints of all sweeps inside the dataflow launch
-    if (nmBound) {
-        HIP_TRY(slotMeta.ensure((size_t)tilesCap * 64)); HIP_TRY(slotNormal.ensure((size_t)tilesCap * 64)); HIP_TRY(slotMass.ensure((size_t)tilesCap * 64));
-        HIP_TRY(rows.ensure((size_t)ctCap * kRows * 64)); HIP_TRY(imp.ensure((size_t)ctCap * 64));
-        if (tilesLaunch)
-            k_contact_init<<<tilesLaunch, 64, 0, st>>>(sc, nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
-                                                      gPos.p, gInvI.p, gVel.p, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, imp.p, slotMeta.p, slotNormal.p, slotMass.p,
-                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr);
-    }
-    int rc = joints.initialize(*this, dt, st);
-    if (rc != MI_OK) return rc;
-    mark();  // 6
-    const uint32_t iters = settings.num_rigid_solver_iterations;
-    usedFlow = useFlow; usedPersist = false; usedFused = fused; usedXcd = false;
     // slots (tiles) one persistent workgroup must hold: exact in a synchronous step, from the previous step's lists (+ slack) in a speculative one
     auto persistSlots = [&](uint32_t tiles, bool xcd, bool speculative) -> uint32_t {
         if (!xcd) return divUp(tiles, xcdOnly ? persistWaves / 8u : persistWaves);
@@ -883,6 +870,23 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         else for (uint32_t x = 0; x < 8u; ++x) { uint32_t n = 0; for (uint32_t bn = 0; bn < kSchedBins; ++bn) n += tileOwnerCount(x, divUp(bins[bn].count, 64), bn); longest = std::max(longest, n); }
         return divUp(std::max(longest, 1u), persistWaves / 8u);
     };
+    // the persistent kernel keeps the accumulated impulses in LDS while they fit: k_contact_init then need not write the impulse granules
+    const bool persistPlan = !fused && useFlow && persistSolver && joints.count() == 0 && tilesLaunch;
+    const uint32_t persistMaxSlots = persistPlan ? persistSlots(tilesLaunch, xcdPlan, spec) : 0u;
+    const bool impNeeded = !(persistPlan && persistImpLds && persistMaxSlots * (4u * 512u + 20u) <= 38u * 1024u);
+    if (nmBound) {
+        HIP_TRY(slotMeta.ensure((size_t)tilesCap * 64)); HIP_TRY(slotNormal.ensure((size_t)tilesCap * 64)); HIP_TRY(slotMass.ensure((size_t)tilesCap * 64));
+        HIP_TRY(rows.ensure((size_t)ctCap * kRows * 64)); HIP_TRY(imp.ensure((size_t)ctCap * 64));
+        if (tilesLaunch)
+            k_contact_init<<<tilesLaunch, 64, 0, st>>>(sc, nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
+                                                      gPos.p, gInvI.p, gVel.p, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, impNeeded ? imp.p : nullptr, slotMeta.p, slotNormal.p, slotMass.p,
+                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr);
+    }
+    int rc = joints.initialize(*this, dt, st);
+    if (rc != MI_OK) return rc;
+    mark();  // 6
+    const uint32_t iters = settings.num_rigid_solver_iterations;
+    usedFlow = useFlow; usedPersist = false; usedFused = fused; usedXcd = false;
     uint64_t mainContacts = 0;
     if (fused) {
         // contacts and joint islands of every sweep in one launch (k_solve_flow_islands)
@@ -902,9 +906,9 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                                                                                    tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, sc);
             if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
         }
-    } else if (useFlow && persistSolver && joints.count() == 0 && tilesLaunch && persistSlots(tilesLaunch, xcdPlan, spec) * 20u <= 38u * 1024u) {
+    } else if (persistPlan && persistMaxSlots * 20u <= 38u * 1024u) {
         // persistent waves: one workgroup per SIMD owns its tiles through all sweeps, impulses (and, while they fit, the constant slot data) in LDS (k_contact_solve_persist)
-        const uint32_t maxSlots = persistSlots(tilesLaunch, xcdPlan, spec);
+        const uint32_t maxSlots = persistMaxSlots;
         const bool metaLds = persistMetaLds && maxSlots * (64u * 40u + 4u * 512u + 20u) <= 38u * 1024u;
         usedXcd = xcdPlan;
         solveLaunches = 1; usedPersist = true;
