@@ -1889,7 +1889,7 @@ template <bool METALDS, bool XCD, bool IMPLDS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIST_WPE))) void k_contact_solve_persist(
     uint32_t sweeps, uint32_t maxSlots, const uint2* __restrict__ tileDesc, const uint4* slotMeta, const float4* __restrict__ slotNormal,
     const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* gVel, StepScalars* sc, uint32_t xcdOnly,
-    const uint32_t* __restrict__ xcdTiles, uint32_t listCap, const unsigned long long* __restrict__ bodyOwner, float4* gVelL, uint4* slotMetaW, float4* imp) {
+    const uint32_t* __restrict__ xcdTiles, uint32_t listCap, const unsigned long long* __restrict__ bodyOwner, float4* gVelL, uint4* slotMetaW, float4* imp, uint32_t xcdFault) {
     // LDS per workgroup: [maxSlots] x { meta uint4[64], normal float4[64], mass float2[64] } (constant over the sweeps; METALDS only), then the
     // impulses float2[4 * maxSlots][64], then the per-slot (first contact-tile, contacts per manifold, impulse offset)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
@@ -1910,7 +1910,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
         uint32_t seen = 0u;
         if (lane == 0) { seen = atomicCAS(&sc->xccOf[xcd], 0xFFFFFFFFu, hw); if (seen == 0xFFFFFFFFu) seen = hw; }
         seen = (uint32_t)__shfl((int)seen, 0, 64);
-        if (seen != hw) { if (lane == 0) sc->solveError = 3u; return; }   // blockIdx % 8 does not identify the XCD on this device
+        if (seen != hw || (xcdFault && blockIdx.x == 9u)) { if (lane == 0) sc->solveError = 3u; return; }   // blockIdx % 8 does not identify the XCD on this device (xcdFault: test injection)
         numTiles = sc->totalTiles ? sc->xcdCount[xcd] : 0u; numWaves = gridDim.x / 8u; wid = blockIdx.x / 8u;
         xcdTiles += (size_t)xcd * listCap;
         if (numTiles > listCap) { if (lane == 0) sc->solveError = 2u; return; }

@@ -91,7 +91,7 @@ struct mi_world {
     DBuf<float4> gPos, gInvI, gVel;
     // XCD-partitioned persistent solver: cached velocity copy for XCD-local bodies, per-body XCD set, spatial sort of the manifolds, per-XCD tile lists
     DBuf<float4> gVelL; DBuf<unsigned long long> bodyOwner; DBuf<uint32_t> sortKeys[2], sortVals[2], xcdBase, xcdTiles, keyCount;
-    bool persistXcd = true, usedXcd = false, haveXcdEstimate = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
+    bool persistXcd = true, usedXcd = false, haveXcdEstimate = false, xcdFaultFired = false, xcdFaultTest = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
     // device: colliders
     DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cMaterial;
     DBuf<float4> wShape, aabbMin, aabbMax, hullAabb, hullVerts; DBuf<uint32_t> hullRanges;
@@ -227,6 +227,7 @@ int mi_world::init(int dev) {
       if (const char* pw = getenv("MI_PERSIST_WAVES")) persistWaves = (uint32_t)strtoul(pw, nullptr, 0);
       xcdOnly = getenv("MI_PERSIST_XCD_ONLY") ? 1u : 0u;
       if (const char* px = getenv("MI_PERSIST_XCD")) persistXcd = px[0] != '0';
+      xcdFaultTest = getenv("MI_PERSIST_XCD_FAULT") != nullptr;
       if (const char* pm = getenv("MI_PERSIST_XCD_MIN")) xcdMinManifolds = (uint32_t)strtoul(pm, nullptr, 0); }   // smallest manifold count that is partitioned (tests: 1)   // MI_PERSIST_XCD=0: no XCD partitioning (every body through memory)   // development experiment: one XCD's workgroups do all the work
     if (flowLds > 65536) (void)hipFuncSetAttribute((const void*)k_contact_solve_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flowLds);
     return MI_OK;
@@ -911,6 +912,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         const uint32_t maxSlots = persistMaxSlots;
         const bool metaLds = persistMetaLds && maxSlots * (64u * 40u + 4u * 512u + 20u) <= 38u * 1024u;
         usedXcd = xcdPlan;
+        const uint32_t xcdFault = xcdFaultTest && usedXcd && !xcdFaultFired ? 1u : 0u;   // tests: one workgroup reports a placement mismatch once
+        if (xcdFault) xcdFaultFired = true;
         solveLaunches = 1; usedPersist = true;
         if (profileSolve) {
             size_t e = 2 * (size_t)profLaunches;
@@ -919,7 +922,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         }
         const bool impLds = persistImpLds && maxSlots * (4u * 512u + 20u) <= 38u * 1024u;   // beyond that the impulses travel as granules in `imp` (no size limit)
         const uint32_t ldsMeta = maxSlots * (64u * 40u + 4u * 512u + 20u) + 16u, ldsImp = maxSlots * (4u * 512u + 20u) + 16u, ldsDesc = maxSlots * 20u + 16u;
-#define MI_PERSIST_ARGS iters, maxSlots, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, sc, xcdOnly, xcdTiles.p, xcdListCap, bodyOwner.p, gVelL.p, slotMeta.p, imp.p
+#define MI_PERSIST_ARGS iters, maxSlots, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, sc, xcdOnly, xcdTiles.p, xcdListCap, bodyOwner.p, gVelL.p, slotMeta.p, imp.p, xcdFault
         if (usedXcd) {
             if (metaLds && impLds) k_contact_solve_persist<true, true, true><<<persistWaves, 64, ldsMeta, st>>>(MI_PERSIST_ARGS);
             else if (impLds) k_contact_solve_persist<false, true, true><<<persistWaves, 64, ldsImp, st>>>(MI_PERSIST_ARGS);
@@ -1015,6 +1018,13 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         }
     }
 #endif
+    if (usedXcd && !hs.solveError) {
+        // partitioning is only trusted when the eight residue classes of blockIdx really sat on eight DIFFERENT XCDs (a device
+        // that exposes fewer XCDs, or hides the id, runs unpartitioned)
+        bool distinct = true;
+        for (int a = 0; a < 8 && distinct; ++a) for (int b = a + 1; b < 8; ++b) if (hs.xccOf[a] == hs.xccOf[b]) { distinct = false; break; }
+        if (!distinct) { persistXcd = false; return STEP_RETRY; }
+    }
     if (hs.solveError && usedPersist) {
         // nothing persistent has been written yet, the step is simply run again:
         //   2 with XCD lists: a list outgrew the speculative LDS sizing -> the synchronous run sizes it exactly;

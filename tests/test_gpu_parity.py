@@ -301,7 +301,8 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
 
 @pytest.mark.parametrize("env,kind", [({"MI_SOLVER": "flow"}, 1), ({"MI_SOLVER": "persist-global"}, 2), ({"MI_PERSIST_XCD": "0"}, 2),
                                       ({"MI_PERSIST_XCD_MIN": "1"}, 4), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-global"}, 4),
-                                      ({"MI_SOLVER": "persist-granules"}, 2), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-granules"}, 4)])
+                                      ({"MI_SOLVER": "persist-granules"}, 2), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-granules"}, 4),
+                                      ({"MI_PERSIST_XCD_MIN": "1", "MI_PERSIST_XCD_FAULT": "1"}, 2)])
 def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch, env, kind):
     """Every dataflow contact solver gives the same results, bit for bit (which lane / wave / XCD runs a slot is invisible to the
     body-version dataflow):  MI_SOLVER=flow -> k_contact_solve_flow (one workgroup per (sweep, tile), dispatch-ordered; also the
@@ -309,7 +310,8 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
     global memory instead of LDS (what piles beyond ~500 k manifolds get);  persist-granules -> the accumulated impulses as
     tagged granules in memory as well (piles beyond ~1.2 M manifolds);  MI_PERSIST_XCD_MIN=1 -> XCD partitioning (spatially
     sorted slots, per-XCD tile lists, XCD-local bodies through L2) even on this small pile (default from 16384 manifolds up);
-    MI_PERSIST_XCD=0 -> never partitioned."""
+    MI_PERSIST_XCD=0 -> never partitioned;  MI_PERSIST_XCD_FAULT -> one workgroup reports that blockIdx % 8 did not identify its
+    XCD: the step is re-run from untouched state and the world continues unpartitioned."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sc = scenes.obb_pile(14, 8, 14, spacing=1.05)
