@@ -1615,8 +1615,10 @@ __device__ __forceinline__ void storeGranuleSc1(float4* p, f32x4 g) { asm volati
 // SAME body, i.e. one contiguous, 32-byte-aligned transaction instead of two scattered 16-byte ones (scattered
 // write-through stores are what bounds this kernel: 4 per manifold per sweep).  Pass 0 serves the even lane's body,
 // pass 1 the odd lane's; a DPP quad swap hands each lane the half its partner moved for it.
-__device__ __forceinline__ float swz1(float v) { return __shfl_xor(v, 1, 64); }
-__device__ __forceinline__ uint32_t swz1(uint32_t v) { return (uint32_t)__shfl_xor((int)v, 1, 64); }
+// lane 2i <-> lane 2i+1 as a DPP quad permute [1,0,3,2]: one VALU move, no trip through the LDS crossbar (ds_bpermute) — these
+// exchanges sit between a tile's body loads and its stores, i.e. on the dependency chain.  Both lanes of a pair are always active together.
+__device__ __forceinline__ uint32_t swz1(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true); }
+__device__ __forceinline__ float swz1(float v) { return __uint_as_float(swz1(__float_as_uint(v))); }
 __device__ __forceinline__ f32x4 swz1(f32x4 g) { f32x4 r = {swz1(g.x), swz1(g.y), swz1(g.z), swz1(g.w)}; return r; }
 __device__ __forceinline__ float4* swz1(float4* p) {
     unsigned long long v = (unsigned long long)p;
