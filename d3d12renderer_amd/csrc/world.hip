@@ -9,6 +9,7 @@
 #include <cmath>
 #include <string.h>
 #include <vector>
+#include <chrono>
 #include <string>
 #include <algorithm>
 #include <type_traits>
@@ -158,7 +159,8 @@ struct mi_world {
     bool xcdSwizzle = false;
 
     StepScalars hs{};            // host copy of the last step's scalars
-    struct Readback { StepScalars sc; uint32_t flags[96]; };
+    struct Readback { StepScalars sc; uint32_t flags[96]; uint32_t seq; uint32_t pad[3]; };   // seq: written last by k_publish_readback (the host spins on it)
+    uint32_t readbackSeq = 0; bool spinReadback = true, stageEvents = false;
     Readback* hsPinned = nullptr; // pinned staging for the end-of-step read-back (one async copy, no pageable bounce)
     mi_stage_times timesSum{}; uint32_t timesSteps = 0; uint64_t contactUpdatesSum = 0;   // accumulated since the last mi_world_get_accumulated_stage_times(reset)
     mi_step_counts counts{};
@@ -201,7 +203,10 @@ int mi_world::init(int dev) {
     HIP_TRY(shards.ensure(1));
     HIP_TRY(hipMemsetAsync(scalarsRaw.p, 0, sizeof(StepScalars) + (kMaxColorRounds + 2) * sizeof(uint32_t), stream));
     HIP_TRY(binInfo.ensure(kSchedBins));
-    HIP_TRY(hipHostMalloc((void**)&hsPinned, sizeof(Readback)));
+    HIP_TRY(hipHostMalloc((void**)&hsPinned, sizeof(Readback), hipHostMallocMapped | hipHostMallocCoherent));
+    std::memset(hsPinned, 0, sizeof(Readback));
+    if (const char* sr = getenv("MI_READBACK")) spinReadback = std::string(sr) != "copy";   // MI_READBACK=copy: hipMemcpyAsync + hipStreamSynchronize
+    stageEvents = getenv("MI_STAGE_EVENTS") && getenv("MI_STAGE_EVENTS")[0] != '0';   // default: only the whole step and the solve stage are timed (mi_world_set_stage_timing)
     const char* sw = getenv("MI_XCD_SWIZZLE");
     xcdSwizzle = sw && sw[0] == '1';
     const char* sv = getenv("MI_SOLVER");
@@ -544,6 +549,15 @@ __global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlag
     }
     if (t < 24) { sc->bucketHist[t] = 0; sc->bucketCursor[t] = 0; }
 }
+// End-of-step read-back without a copy engine round trip and without a driver wake-up: one workgroup writes the scalars and the
+// colouring round flags straight into pinned host memory, fences at system scope and then publishes the step's sequence number,
+// which the host thread spins on.
+__global__ __launch_bounds__(256) void k_publish_readback(const uint32_t* __restrict__ src, uint32_t words, uint32_t* dstHost, uint32_t seqWord, uint32_t seq) {
+    for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dstHost[i] = src[i];
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(dstHost + seqWord, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 __global__ void k_reset_pair_counters(StepScalars* sc) {
     uint32_t t = threadIdx.x;
     if (t == 0) { sc->numPairs = 0; sc->numOverlaps = 0; sc->numInterPairs = 0; }
@@ -685,7 +699,9 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     int evi = 0;
     static const bool debugSync = std::getenv("MI_DEBUG_SYNC") != nullptr;   // development: find the stage a device fault comes from
     auto mark = [&]() {
-        (void)hipEventRecord(ev[evi++], st);
+        const int id = evi++;
+        if (!stageEvents && id != 0 && id != 6 && id != 7 && id != 8) return;   // by default only the step and the solve stage are timed
+        (void)hipEventRecord(ev[id], st);
         if (debugSync) { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) std::fprintf(stderr, "[mi_physics] step %llu (%s): stage ending at mark %d: %s\n", (unsigned long long)totalSteps, spec ? "speculative" : "synchronous", evi - 1, hipGetErrorString(e)); }
     };
     auto bound = [](uint32_t last, uint32_t slack) { return last + last / 8u + slack; };
@@ -992,8 +1008,25 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                                                       gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p);
     mark();  // 8
     // ---------------------------------------------------------------------------------------------- end of step: the one read-back
-    HIP_TRY(hipMemcpyAsync(hsPinned, sc, sizeof(Readback), hipMemcpyDeviceToHost, st));   // scalars + round flags are contiguous
-    HIP_TRY(hipStreamSynchronize(st));
+    if (spinReadback) {
+        const uint32_t seq = ++readbackSeq ? readbackSeq : ++readbackSeq;   // never 0
+        const uint32_t words = (uint32_t)(offsetof(Readback, seq) / 4u);
+        k_publish_readback<<<1, 256, 0, st>>>(reinterpret_cast<const uint32_t*>(sc), words, reinterpret_cast<uint32_t*>(hsPinned), words, seq);
+        volatile uint32_t* flag = &hsPinned->seq;
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t spins = 0;
+        while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+            __builtin_ia32_pause();
+            if ((++spins & 0xFFFu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) {
+                HIP_TRY(hipStreamSynchronize(st));   // a long step, a device fault or a lost store: let the runtime report it
+                if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) return fail(MI_ERR_DEVICE, "end-of-step read-back did not arrive");
+                break;
+            }
+        }
+    } else {
+        HIP_TRY(hipMemcpyAsync(hsPinned, sc, offsetof(Readback, seq), hipMemcpyDeviceToHost, st));   // scalars + round flags are contiguous
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     hs = hsPinned->sc;
     const uint32_t* flagsHost = hsPinned->flags;
     HIP_TRY(hipGetLastError());
@@ -1051,7 +1084,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             HIP_TRY(tabKeys[nt].ensure(1024)); HIP_TRY(tabVals[nt].ensure(1024)); tabMask[nt] = 1023u;
             HIP_TRY(hipMemsetAsync(tabKeys[nt].p, 0, 1024 * sizeof(unsigned long long), st));
             k_events_end<<<divUp(tabMask[tabCur] + 1u, B), B, 0, st>>>(cap, sc, tabKeys[tabCur].p, tabMask[tabCur], tabKeys[nt].p, tabVals[nt].p, tabMask[nt], devEvents.p);
-            HIP_TRY(hipMemcpyAsync(hsPinned, sc, sizeof(Readback), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(hsPinned, sc, offsetof(Readback, seq), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             hs = hsPinned->sc;
         }
@@ -1094,8 +1127,11 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     pairsIn = hs.partitioned ? pairKeysS.p : pairKeys.p;
 
     auto el = [&](int a, int b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; };
-    times.world_colliders = el(0, 1); times.broadphase = el(1, 2); times.narrowphase = el(2, 3); times.integrate_forces = el(3, 4);
-    times.schedule = el(4, 5); times.init_constraints = el(5, 6); times.solve = el(6, 7); times.integrate_velocities = el(7, 8); times.total = el(0, 8);
+    if (stageEvents) {
+        times.world_colliders = el(0, 1); times.broadphase = el(1, 2); times.narrowphase = el(2, 3); times.integrate_forces = el(3, 4);
+        times.schedule = el(4, 5); times.init_constraints = el(5, 6);
+    } else { times.world_colliders = times.broadphase = times.narrowphase = times.integrate_forces = times.schedule = times.init_constraints = 0.f; }
+    times.solve = el(6, 7); times.integrate_velocities = el(7, 8); times.total = el(0, 8);
     counts.num_rigid_bodies = nb; counts.num_colliders = nc; counts.num_broadphase_overlaps = nc ? hs.numOverlaps : 0;
     manifoldsLast = pairBound ? hs.numManifolds : 0;
     counts.num_collisions = manifoldsLast - (manifoldsLast ? hs.numHmContacts - hs.numHmColliders : 0u);   // terrain: one collision per collider (heightmap_collision.cpp:582-594)
@@ -1989,6 +2025,9 @@ MI_API int mi_world_get_solver_kind(mi_world* w, uint32_t* out) {
     *out = w->usedFused ? 3u : w->usedPersist ? (w->usedXcd ? 4u : 2u) : w->usedFlow ? 1u : 0u;
     return MI_OK;
 }
+// Event pairs around every stage cost a few microseconds of device time per step each: off by default (the whole step and the
+// solve stage are always timed), on for profiling.
+MI_API int mi_world_set_stage_timing(mi_world* w, uint32_t enable) { if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null"); w->stageEvents = enable != 0; return MI_OK; }
 MI_API int mi_world_get_stage_times(mi_world* w, mi_stage_times* out) { if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null"); *out = w->times; return MI_OK; }
 
 MI_API int mi_world_get_contacts(mi_world* w, mi_contact* out, uint32_t cap, uint32_t* count) {

@@ -261,6 +261,9 @@ MI_API int mi_world_get_mass_properties(mi_world* world, float* inv_mass, float*
 MI_API int mi_world_get_counts(mi_world* world, mi_step_counts* out);
 /* Contacts of the last internal step in solver (canonical) order; returns count in *out_count. */
 MI_API int mi_world_get_contacts(mi_world* world, mi_contact* out, uint32_t capacity, uint32_t* out_count);
+/* Per-stage device times of the last internal step.  Only `total` and `solve` are measured by default; the other stages are
+ * timed (a HIP event pair each, a few microseconds of device time per step) after mi_world_set_stage_timing(world, 1). */
+MI_API int mi_world_set_stage_timing(mi_world* world, uint32_t enable);
 MI_API int mi_world_get_stage_times(mi_world* world, mi_stage_times* out);
 /* Contact-solver kernel of the last internal step: 0 k_contact_solve (a launch per colour per sweep), 1 k_contact_solve_flow,
  * 2 k_contact_solve_persist (default without joints), 3 k_solve_flow_islands (contacts + joint islands in one launch),

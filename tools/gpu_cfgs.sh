@@ -15,6 +15,7 @@ for name, make, warm, steps in (("cfg1_spheres_4096", lambda: scenes.sphere_drop
                                 ("cfg3_settled_pile_262144", lambda: scenes.obb_pile(128, 16, 128), 1500, 60), ("pile_1048576", lambda: scenes.obb_pile(256, 16, 256), 240, 30)):
     sc = make()
     w = sc.populate(mi.create_world(0))
+    w.set_stage_timing(True)
     s = sc.settings()
     w.step_fixed(s, sc.dt, warm)
     t0 = time.perf_counter(); acc = {}
