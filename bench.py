@@ -192,9 +192,14 @@ def main():
         kernel = sw.world.solver_kernel()   # k_contact_solve_persist by default (k_contact_solve_flow / k_contact_solve with MI_SOLVER=flow / launch)
         achieved = (BYTES_PER_CONTACT_ITER * contact_iters) / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else 0.0
         event_pair = (BYTES_PER_CONTACT_ITER * prof_updates) / (prof_ms * 1e-3) / 1e9 if prof_ms > 0 else 0.0
+        traffic = _measured_traffic(kernel)
+        avg_launch_s = solve_ms * 1e-3 / max(launches, 1)
         roofline = {
             "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "traffic": _measured_traffic(kernel),
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+            # what really crossed the HBM interface per second (committed PMC pass / this run's launch time): the persistent kernel
+            # serves a good part of the algorithmic bytes from LDS (accumulated impulses) and the XCDs' L2s (body hand-overs)
+            "traffic_GBps": (traffic / avg_launch_s / 1e9) if traffic and avg_launch_s > 0 else None,
             "avg_launch_us": solve_ms * 1e3 / max(launches, 1), "launches_per_step": launches_per_step,
             "algorithmic_bytes_per_launch": BYTES_PER_CONTACT_ITER * contact_iters / max(launches, 1),
             "event_pair_per_launch": {"avg_launch_us": prof_ms * 1e3 / max(prof_launches, 1), "launches_per_step": prof_launches / 3,
