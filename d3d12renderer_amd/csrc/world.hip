@@ -2025,6 +2025,13 @@ MI_API int mi_world_get_solver_kind(mi_world* w, uint32_t* out) {
     *out = w->usedFused ? 3u : w->usedPersist ? (w->usedXcd ? 4u : 2u) : w->usedFlow ? 1u : 0u;
     return MI_OK;
 }
+// Host-side evaluation of the tile -> XCD assignment the XCD-partitioned solver uses on the device (tests: the per-XCD shares of
+// a bin must add up, and (owner, rank) must enumerate every tile of a bin exactly once).  out = { owner, rank inside the owner's share, share of `query_xcd` }.
+MI_API int mi_debug_tile_owner(uint32_t tile_in_bin, uint32_t tiles_in_bin, uint32_t bin, uint32_t query_xcd, uint32_t* out) {
+    if (!out || tile_in_bin >= tiles_in_bin || query_xcd >= 8u) return fail(MI_ERR_INVALID_ARGUMENT, "tile_in_bin < tiles_in_bin, query_xcd < 8");
+    out[0] = tileOwner(tile_in_bin, tiles_in_bin, bin); out[1] = tileOwnerRank(tile_in_bin, tiles_in_bin, bin); out[2] = tileOwnerCount(query_xcd, tiles_in_bin, bin);
+    return MI_OK;
+}
 // Event pairs around every stage cost a few microseconds of device time per step each: off by default (the whole step and the
 // solve stage are always timed), on for profiling.
 MI_API int mi_world_set_stage_timing(mi_world* w, uint32_t enable) { if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null"); w->stageEvents = enable != 0; return MI_OK; }

@@ -261,6 +261,10 @@ MI_API int mi_world_get_mass_properties(mi_world* world, float* inv_mass, float*
 MI_API int mi_world_get_counts(mi_world* world, mi_step_counts* out);
 /* Contacts of the last internal step in solver (canonical) order; returns count in *out_count. */
 MI_API int mi_world_get_contacts(mi_world* world, mi_contact* out, uint32_t capacity, uint32_t* out_count);
+/* Diagnostics (no device needed): the tile -> XCD assignment of the XCD-partitioned contact solver for tile `tile_in_bin` of a
+ * schedule bin with `tiles_in_bin` tiles: out[0] = owning XCD, out[1] = its rank inside that XCD's share of the bin,
+ * out[2] = size of `query_xcd`'s share of the bin. */
+MI_API int mi_debug_tile_owner(uint32_t tile_in_bin, uint32_t tiles_in_bin, uint32_t bin, uint32_t query_xcd, uint32_t* out);
 /* Per-stage device times of the last internal step.  Only `total` and `solve` are measured by default; the other stages are
  * timed (a HIP event pair each, a few microseconds of device time per step) after mi_world_set_stage_timing(world, 1). */
 MI_API int mi_world_set_stage_timing(mi_world* world, uint32_t enable);

@@ -118,3 +118,30 @@ def test_persistent_solver_keeps_its_acc_registers_to_itself(tmp_path, mi_lib):
         assert not stray, stray[:5]
         # the prefetch is inlined once per call site (24 loads each); the read-back once per contact count (24 moves per contact)
         assert loads > 0 and loads % 24 == 0 and reads > 0 and reads % 24 == 0, (loads, reads)
+
+
+def test_tile_to_xcd_assignment_is_a_partition(mi_lib):
+    """The XCD-partitioned solver gives tile tl of a bin's nt tiles to XCD floor(8 tl / nt) (short bins round-robin) and finds a
+    tile's place in that XCD's list from closed forms.  For every bin size up to 70 tiles (and a few large ones) and several bin
+    indices: the eight shares add up to nt, (owner, rank) enumerates each share exactly once in ascending tile order, and the
+    shares of a long bin differ by at most one tile."""
+    import ctypes
+    lib = mi_lib.library().lib
+    fn = lib.mi_debug_tile_owner
+    fn.restype = ctypes.c_int
+    out = (ctypes.c_uint32 * 3)()
+    for nt in list(range(1, 71)) + [127, 128, 1000, 4097]:
+        for b in (0, 1, 5, 43, 255, 256):
+            shares = []
+            for x in range(8):
+                assert fn(0, nt, b, x, out) == 0
+                shares.append(out[2])
+            assert sum(shares) == nt
+            if nt >= 8:
+                assert max(shares) - min(shares) <= 1
+            seen = [[] for _ in range(8)]
+            for tl in range(nt):
+                assert fn(tl, nt, b, 0, out) == 0
+                seen[out[0]].append(out[1])
+            for x in range(8):
+                assert seen[x] == list(range(shares[x])), (nt, b, x)
