@@ -203,9 +203,13 @@ int mi_world::init(int dev) {
     HIP_TRY(shards.ensure(1));
     HIP_TRY(hipMemsetAsync(scalarsRaw.p, 0, sizeof(StepScalars) + (kMaxColorRounds + 2) * sizeof(uint32_t), stream));
     HIP_TRY(binInfo.ensure(kSchedBins));
-    HIP_TRY(hipHostMalloc((void**)&hsPinned, sizeof(Readback), hipHostMallocMapped | hipHostMallocCoherent));
+    if (hipHostMalloc((void**)&hsPinned, sizeof(Readback), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();   // no device-visible coherent host memory here: plain pinned staging and the copy path
+        HIP_TRY(hipHostMalloc((void**)&hsPinned, sizeof(Readback)));
+        spinReadback = false;
+    }
     std::memset(hsPinned, 0, sizeof(Readback));
-    if (const char* sr = getenv("MI_READBACK")) spinReadback = std::string(sr) != "copy";   // MI_READBACK=copy: hipMemcpyAsync + hipStreamSynchronize
+    if (const char* sr = getenv("MI_READBACK")) spinReadback = spinReadback && std::string(sr) != "copy";   // MI_READBACK=copy: hipMemcpyAsync + hipStreamSynchronize
     stageEvents = getenv("MI_STAGE_EVENTS") && getenv("MI_STAGE_EVENTS")[0] != '0';   // default: only the whole step and the solve stage are timed (mi_world_set_stage_timing)
     const char* sw = getenv("MI_XCD_SWIZZLE");
     xcdSwizzle = sw && sw[0] == '1';

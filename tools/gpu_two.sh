@@ -1,25 +1,20 @@
 #!/bin/bash
-# dev helper: A/B of host-side stepping options on the bench scene and a small scene
+# dev helper: colour histogram of the bench scene's schedule
 ulimit -c 0
 mkdir -p gpurun_out
-cat > /tmp/ab.py <<'PY'
-import sys, time, hashlib
+cat > /tmp/col.py <<'PY'
+import sys, ctypes as C
 sys.path.insert(0, ".")
 import numpy as np
 import torch; torch.cuda.set_device(0)
 import d3d12renderer_amd as mi
 from d3d12renderer_amd import scenes
-for name, make, warm, steps in (("pile262144", lambda: scenes.obb_pile(128, 16, 128), 250, 60), ("spheres4096", lambda: scenes.sphere_drop(16), 240, 200)):
+for name, make, warm in (("pile", lambda: scenes.obb_pile(128, 16, 128), 290), ("mixed", lambda: scenes.mixed_stack(64, 16, 64), 290)):
     sc = make(); w = sc.populate(mi.create_world(0)); s = sc.settings()
     w.step_fixed(s, sc.dt, warm)
-    t0 = time.perf_counter()
-    for _ in range(steps): w.step_fixed(s, sc.dt, 1)
-    dt = (time.perf_counter() - t0) / steps
-    st = w.stage_times()
-    print(sys.argv[1], name, round(dt * 1e3, 4), "ms/step", round(1 / dt, 1), "steps/s; device total", round(st["total"], 4), "solve", round(st["solve"], 4), hashlib.sha1(w.physics_transforms()[0].tobytes()).hexdigest()[:10], flush=True)
+    nm = w.counts()["num_collisions"]
+    colors = np.zeros(nm, np.uint32)
+    w.L.check(w.L.fn("world_get_manifold_colors")(w.h, colors.ctypes.data_as(C.c_void_p), C.c_uint32(nm)), "colors")
+    print(name, nm, np.bincount(colors).tolist(), flush=True)
 PY
-run() { timeout 300 python /tmp/ab.py "$@" 2>&1 | grep -v "Warning\|amdgpu.ids" | tail -2; }
-run spin
-MI_READBACK=copy run copy
-MI_STAGE_EVENTS=0 run spin-noevents
-MI_READBACK=copy MI_STAGE_EVENTS=0 run copy-noevents
+timeout 200 python /tmp/col.py 2>&1 | tail -2
