@@ -302,7 +302,7 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
 @pytest.mark.parametrize("env,kind", [({"MI_SOLVER": "flow"}, 1), ({"MI_SOLVER": "persist-global"}, 2), ({"MI_PERSIST_XCD": "0"}, 2),
                                       ({"MI_PERSIST_XCD_MIN": "1"}, 4), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-global"}, 4),
                                       ({"MI_SOLVER": "persist-granules"}, 2), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-granules"}, 4),
-                                      ({"MI_PERSIST_XCD_MIN": "1", "MI_PERSIST_XCD_FAULT": "1"}, 2)])
+                                      ({"MI_PERSIST_XCD_MIN": "1", "MI_PERSIST_XCD_FAULT": "1"}, 2), ({"MI_READBACK": "copy"}, 2)])
 def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch, env, kind):
     """Every dataflow contact solver gives the same results, bit for bit (which lane / wave / XCD runs a slot is invisible to the
     body-version dataflow):  MI_SOLVER=flow -> k_contact_solve_flow (one workgroup per (sweep, tile), dispatch-ordered; also the
@@ -311,7 +311,8 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
     tagged granules in memory as well (piles beyond ~1.2 M manifolds);  MI_PERSIST_XCD_MIN=1 -> XCD partitioning (spatially
     sorted slots, per-XCD tile lists, XCD-local bodies through L2) even on this small pile (default from 16384 manifolds up);
     MI_PERSIST_XCD=0 -> never partitioned;  MI_PERSIST_XCD_FAULT -> one workgroup reports that blockIdx % 8 did not identify its
-    XCD: the step is re-run from untouched state and the world continues unpartitioned."""
+    XCD: the step is re-run from untouched state and the world continues unpartitioned;  MI_READBACK=copy -> the end-of-step
+    read-back as an async copy + stream synchronise instead of the kernel-published record the host spins on."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sc = scenes.obb_pile(14, 8, 14, spacing=1.05)
@@ -324,6 +325,14 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
     assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
     assert g.solver_kind() == kind
     assert g.step_mode_stats()[2] <= 2, "the partitioned solver must not keep falling back"
+    # per-stage timing is opt-in: only the whole step and the solve stage are timed by default
+    t = g.stage_times()
+    assert t["total"] > 0 and t["solve"] > 0 and t["broadphase"] == 0
+    g.set_stage_timing(True)
+    g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+    t = g.stage_times()
+    assert t["broadphase"] > 0 and t["narrowphase"] > 0 and abs(t["total"] - sum(v for k, v in t.items() if k != "total")) < 0.2 * t["total"]
+    assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
 
 
 def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
