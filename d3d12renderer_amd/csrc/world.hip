@@ -816,7 +816,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     uint32_t tilesCap = 0, ctCap = 0, eventCap = 0, xcdListCap = 0;
     // XCD partitioning pays once the pile is big enough to keep eight L2s busy; it needs the persistent kernel (no joints)
     const bool xcdPlan = flowSolver && persistSolver && persistXcd && !xcdOnly && joints.count() == 0 && (persistWaves & 7u) == 0u && nmBound >= xcdMinManifolds;
-    uint32_t colorBatch = spec ? std::min<uint32_t>(96u, last.colorRounds + std::max(3u, last.colorRounds / 4u)) : 20u;   // converged rounds exit at once
+    static const uint32_t colorMargin = std::getenv("MI_COLOR_MARGIN") ? (uint32_t)atoi(std::getenv("MI_COLOR_MARGIN")) : 3u;   // extra rounds enqueued beyond the previous step's count
+    uint32_t colorBatch = spec ? std::min<uint32_t>(96u, last.colorRounds + std::max(colorMargin, last.colorRounds / 4u)) : 20u;   // converged rounds exit at once
     if (nmBound) {
         tilesCap = divUp(nmBound, 64) + kSchedBins + 8; ctCap = divUp(conBound, 64) + 4 * kSchedBins + 8;
         const uint32_t binBlocks = divUp(nmBound, kBinItems);
