@@ -673,7 +673,7 @@ __global__ __launch_bounds__(64) void k_narrow_gjk(const StepScalars* __restrict
                                                    const float4* __restrict__ wShape,
                                                    HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
                                                    float4* __restrict__ npPoints) {
-    // [gjkLo, gjkHi) = span of the bucket-partitioned pair list that holds the GJK/EPA buckets (k_pair_ranges)
+    // [gjkLo, gjkHi) = span of the bucket-partitioned pair list that holds the GJK/EPA buckets (k_pair_finish)
     uint32_t p = sc->gjkLo + blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= sc->gjkHi) return;
     const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;

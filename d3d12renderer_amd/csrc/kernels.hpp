@@ -186,7 +186,7 @@ __device__ __forceinline__ uint32_t extentBin(float ext) {
 __device__ __forceinline__ float extentBinUpper(uint32_t b) { return exp2f(((float)b + 1.f - 128.f) / 8.f); }
 
 // Deterministic centre statistics for the next sorting axis: fixed butterfly per wave (double),
-// waves 0..3 added in order, block partials added sequentially by k_axis_final.
+// waves 0..3 added in order, block partials added sequentially by k_pair_finish.
 __global__ __launch_bounds__(256) void k_axis_partials(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
                                                        double* __restrict__ partials, Shards* sh) {
     __shared__ double sm[4][6];
@@ -224,28 +224,6 @@ __global__ __launch_bounds__(256) void k_axis_partials(uint32_t nc, const float4
 }
 // Block partials are reduced by one 256-lane workgroup with a fixed tree (mirrored by the oracle): lane t adds
 // partials t, t+256, ... in ascending order, then the wave butterfly (offsets 32..1), then waves 0..3 in order.
-__global__ __launch_bounds__(256) void k_axis_final(uint32_t nc, uint32_t numBlocks, const double* __restrict__ partials, StepScalars* sc) {
-    __shared__ double sm[4][6];
-    double v[6] = {0, 0, 0, 0, 0, 0};
-    for (uint32_t b = threadIdx.x; b < numBlocks; b += 256) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) v[c] += partials[(size_t)b * 6 + c];
-    }
-    for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) v[c] += __shfl_down(v[c], off, 64);
-    }
-    uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) for (int c = 0; c < 6; ++c) sm[wv][c] = v[c];
-    __syncthreads();
-    if (threadIdx.x != 0) return;
-    double s[6];
-    for (int c = 0; c < 6; ++c) { double a = 0.0; for (int w = 0; w < 4; ++w) a += sm[w][c]; s[c] = a; }
-    double var[3];
-    for (int c = 0; c < 3; ++c) var[c] = s[3 + c] - s[c] * s[c] / (double)nc;
-    sc->axisNext = (var[0] > var[1]) ? ((var[0] > var[2]) ? 0u : 2u) : ((var[1] > var[2]) ? 1u : 2u);  // collision_broad.cpp:443-444
-}
-
 // Cell size = smallest extent bin edge that leaves at most `limit` colliders above it; those few "large"
 // colliders (ground, walls, outliers) are handled by the brute-force pass.
 __global__ __launch_bounds__(256) void k_bp_threshold(uint32_t nc, const Shards* __restrict__ sh, StepScalars* sc) {
@@ -561,31 +539,50 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
 // Shard totals -> StepScalars (read back by the host together with numPairs).
 // `pairBound`: what the launches / scans / buffers downstream are sized for.  A speculative step that found more pairs is
 // invalid as a whole (the host re-runs it synchronously): mark it and make everything downstream a no-op.
-__global__ void k_pair_totals(const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound) {
-    uint32_t t = threadIdx.x;
-    if (t == 0 && sc->numPairs > pairBound) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; }
-    if (t < 24) { uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].bucketHist[t]; sc->bucketHist[t] = v; }
-    if (t == 31) { uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].numOverlaps; sc->numOverlaps = v; }
-}
-
 __host__ __device__ __forceinline__ int gjkMode(uint32_t ta, uint32_t tb);
 // Bucket partition (replaces the reference's counting sort into [6][6] type-pair buckets, collision_narrow.cpp:2397-2453,
 // and the former full 64-bit key sort): pairs are grouped by bucket so narrow-phase waves are type-uniform; the order
 // inside a bucket is arbitrary — every later stage is keyed by the collider pair, not by the position of the pair.
 // A block ranks its 1024 keys per bucket in LDS and reserves one output range per non-empty bucket.
-// k_pair_ranges (one workgroup): bucket offsets, the GJK/EPA span and whether a partition is needed at all.
 __host__ __device__ __forceinline__ int gjkModeOfBucket(uint32_t bucket);
-__global__ void k_pair_ranges(StepScalars* sc) {
-    if (threadIdx.x != 0) return;
-    uint32_t off = 0, nonEmpty = 0, lo = 0xFFFFFFFFu, hi = 0;
-    for (uint32_t bk = 0; bk < kNumBuckets; ++bk) {
-        uint32_t n = sc->bucketHist[bk];
-        sc->bucketOffset[bk] = off;
-        if (n) { ++nonEmpty; if (gjkModeOfBucket(bk) >= 0) { lo = min(lo, off); hi = max(hi, off + n); } }
-        off += n;
+// One workgroup after the pair pass: the sharded counters summed (k_pair_totals), the bucket offsets / GJK span / "partition needed"
+// (formerly k_pair_ranges) and — with `partials` — the next sweep axis (formerly k_axis_final): three single-workgroup launches in one.
+__global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound, uint32_t nc, uint32_t numBlocks, const double* __restrict__ partials) {
+    const uint32_t t = threadIdx.x;
+    if (t < 64u) {   // wave 0
+        if (t == 0 && sc->numPairs > pairBound) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; }
+        uint32_t v = 0;
+        if (t < kNumBuckets) { for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].bucketHist[t]; sc->bucketHist[t] = v; }
+        if (t == 31) { uint32_t o = 0; for (uint32_t k = 0; k < kShards; ++k) o += sh->c[k].numOverlaps; sc->numOverlaps = o; }
+        uint32_t off = 0, nonEmpty = 0, lo = 0xFFFFFFFFu, hi = 0;
+        for (uint32_t bk = 0; bk < kNumBuckets; ++bk) {   // every lane walks the buckets (the counts come over by shuffle), lane 0 writes
+            const uint32_t n = (uint32_t)__shfl((int)v, (int)bk, 64);
+            if (t == 0) sc->bucketOffset[bk] = off;
+            if (n) { ++nonEmpty; if (gjkModeOfBucket(bk) >= 0) { lo = min(lo, off); hi = max(hi, off + n); } }
+            off += n;
+        }
+        if (t == 0) { sc->gjkLo = hi > lo ? lo : 0u; sc->gjkHi = hi > lo ? hi : 0u; sc->partitioned = nonEmpty > 1u ? 1u : 0u; }
     }
-    sc->gjkLo = hi > lo ? lo : 0u; sc->gjkHi = hi > lo ? hi : 0u;
-    sc->partitioned = nonEmpty > 1u ? 1u : 0u;
+    if (!partials) return;
+    __shared__ double sm[4][6];
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    for (uint32_t b = t; b < numBlocks; b += 256) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] += partials[(size_t)b * 6 + c];
+    }
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] += __shfl_down(v[c], off, 64);
+    }
+    const uint32_t lane = t & 63, wv = t >> 6;
+    if (lane == 0) for (int c = 0; c < 6; ++c) sm[wv][c] = v[c];
+    __syncthreads();
+    if (t != 0) return;
+    double s6[6];
+    for (int c = 0; c < 6; ++c) { double a = 0.0; for (int w = 0; w < 4; ++w) a += sm[w][c]; s6[c] = a; }
+    double var[3];
+    for (int c = 0; c < 3; ++c) var[c] = s6[3 + c] - s6[c] * s6[c] / (double)nc;
+    sc->axisNext = (var[0] > var[1]) ? ((var[0] > var[2]) ? 0u : 2u) : ((var[1] > var[2]) ? 1u : 2u);  // collision_broad.cpp:443-444
 }
 __global__ __launch_bounds__(256) void k_pair_partition(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, StepScalars* sc) {
     __shared__ uint32_t cnt[32], base[32];

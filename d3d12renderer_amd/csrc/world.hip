@@ -753,8 +753,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             const uint32_t bpc = divUp(nc, kGridChunks * 256u);
             k_bp_pairs_grid<<<5u * bpc, B, 0, st>>>(nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, grid.p, pairKeys.p, cap, sc, shards.p, inter);
             k_bp_pairs_large<<<dim3(std::min(divUp(nc, B), 256u), 16), B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc, shards.p, inter);
-            k_pair_totals<<<1, 32, 0, st>>>(shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu);
-            if (attempt == 0) k_axis_final<<<1, 256, 0, st>>>(nc, nblk, axisPartials.p, sc);
+            k_pair_finish<<<1, 256, 0, st>>>(shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu, nc, nblk, attempt == 0 ? axisPartials.p : nullptr);
             if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
             int rc = readScalars(); if (rc != MI_OK) return rc;
             pairBound = hs.numPairs + hs.numHmContacts;   // the terrain contacts are appended to the pair list after the narrow phase
@@ -769,7 +768,6 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     mark();  // 2
     // ---------------------------------------------------------------------------------------------- narrow phase
     if (pairBound) {
-        k_pair_ranges<<<1, 32, 0, st>>>(sc);
         HIP_TRY(pairKeysS.ensure(pairKeys.cap));
         k_pair_partition<<<divUp(pairBound, 1024), 256, 0, st>>>(pairKeys.p, pairKeysS.p, sc);
         HIP_TRY(npPacked.ensure(pairBound)); HIP_TRY(npScan.ensure(pairBound)); HIP_TRY(npNormal.ensure(pairBound)); HIP_TRY(npPoints.ensure(4 * (size_t)pairBound));
