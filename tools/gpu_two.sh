@@ -1,17 +1,25 @@
 #!/bin/bash
-# dev helper: how many extra colouring rounds does speculation need? (retries vs margin)
+# dev helper: A/B of stepping options (environment) on the bench scene and a small scene
 ulimit -c 0
 mkdir -p gpurun_out
-cat > /tmp/cm.py <<'PY'
-import sys, time
+cat > /tmp/ab.py <<'PY'
+import sys, time, hashlib
 sys.path.insert(0, ".")
+import numpy as np
 import torch; torch.cuda.set_device(0)
 import d3d12renderer_amd as mi
 from d3d12renderer_amd import scenes
-for name, make in (("pile", lambda: scenes.obb_pile(128, 16, 128)), ("mixed", lambda: scenes.mixed_stack(64, 16, 64))):
+for name, make, warm, steps in (("pile262144", lambda: scenes.obb_pile(128, 16, 128), 250, 60), ("spheres4096", lambda: scenes.sphere_drop(16), 240, 200), ("mixed65536", lambda: scenes.mixed_stack(64, 16, 64), 240, 60)):
     sc = make(); w = sc.populate(mi.create_world(0)); s = sc.settings()
-    w.step_fixed(s, sc.dt, 200); r0 = w.step_mode_stats()[2]
-    t0 = time.perf_counter(); w.step_fixed(s, sc.dt, 600); dt = (time.perf_counter() - t0) / 600
-    print(sys.argv[1], name, "ms/step", round(dt * 1e3, 4), "retries in 600 steps", w.step_mode_stats()[2] - r0, "(first 200:", r0, ")", flush=True)
+    w.step_fixed(s, sc.dt, warm)
+    t0 = time.perf_counter()
+    for _ in range(steps): w.step_fixed(s, sc.dt, 1)
+    dt = (time.perf_counter() - t0) / steps
+    st = w.stage_times()
+    print(sys.argv[1], name, round(dt * 1e3, 4), "ms/step", round(1 / dt, 1), "steps/s; device total", round(st["total"], 4), "solve", round(st["solve"], 4), w.step_mode_stats(), hashlib.sha1(w.physics_transforms()[0].tobytes()).hexdigest()[:10], flush=True)
 PY
-for m in 3 2 1 0; do MI_COLOR_MARGIN=$m timeout 300 python /tmp/cm.py margin$m 2>&1 | tail -2; done
+run() { timeout 300 python /tmp/ab.py "$@" 2>&1 | grep -v "Warning\|amdgpu.ids" | tail -3; }
+run aux
+MI_AUX_STREAM=0 run noaux
+run aux
+MI_AUX_STREAM=0 run noaux
