@@ -1318,10 +1318,18 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
                                                      const uint8_t* __restrict__ bodyJ /* fused joint islands: 1 = the body gets one joint version per sweep, or null */,
                                                      float4* __restrict__ rows, float4* __restrict__ imp, uint4* __restrict__ slotMeta,
                                                      float4* __restrict__ slotNormal, float2* __restrict__ slotMass,
-                                                     uint8_t* __restrict__ bodyOwner /* XCD-partitioned solver: [body][8] flags, 1 = a tile of that XCD touches the body; or null */) {
+                                                     uint8_t* __restrict__ bodyOwner /* XCD-partitioned solver: [body][8] flags, 1 = a tile of that XCD touches the body; or null */,
+                                                     const uint32_t* __restrict__ xcdTiles, uint32_t listCap /* with bodyOwner: workgroup b prepares entry b / 8 of XCD (b % 8)'s tile list */) {
     // (one wave per contact index — four waves per tile, the per-manifold gathers repeated — measured slower: 52 -> 73 us; the kernel
     // is bound by those gathers)
     uint32_t tile = blockIdx.x, lane = threadIdx.x; const uint32_t kw = 0;
+    if (bodyOwner) {
+        // XCD-partitioned: the workgroups that land on XCD x (blockIdx % 8, a speed assumption only) prepare the tiles XCD x will solve,
+        // i.e. gather the bodies of ONE slab of the scene — they fit that XCD's L2 instead of streaming all bodies through every L2
+        const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+        if (!sc->totalTiles || j >= sc->xcdCount[x] || j >= listCap) return;
+        tile = xcdTiles[(size_t)x * listCap + j];
+    }
     if (tile >= sc->totalTiles) return;
     uint32_t bin = tileBin[tile];
     BinInfo bi = binInfo[bin];

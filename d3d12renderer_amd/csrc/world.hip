@@ -898,9 +898,9 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         HIP_TRY(slotMeta.ensure((size_t)tilesCap * 64)); HIP_TRY(slotNormal.ensure((size_t)tilesCap * 64)); HIP_TRY(slotMass.ensure((size_t)tilesCap * 64));
         HIP_TRY(rows.ensure((size_t)ctCap * kRows * 64)); HIP_TRY(imp.ensure((size_t)ctCap * 64));
         if (tilesLaunch)
-            k_contact_init<<<tilesLaunch, 64, 0, st>>>(sc, nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
-                                                      gPos.p, gInvI.p, gVel.p, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, impNeeded ? imp.p : nullptr, slotMeta.p, slotNormal.p, slotMass.p,
-                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr);
+            k_contact_init<<<xcdPlan ? 8u * xcdListCap : tilesLaunch, 64, 0, st>>>(sc, nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
+                                                      gPos.p, gInvI.p, xcdPlan ? gVelL.p : gVel.p /* same content here; the cached copy */, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, impNeeded ? imp.p : nullptr, slotMeta.p, slotNormal.p, slotMass.p,
+                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, xcdTiles.p, xcdListCap);
     }
     int rc = joints.initialize(*this, dt, st);
     if (rc != MI_OK) return rc;
