@@ -429,7 +429,10 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
     if (threadIdx.x < 32) bhist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t col = blockIdx.x / blocksPerColumn;
-    const uint32_t base = (blockIdx.x % blocksPerColumn) * (kGridChunks * 256u);
+    // blocksPerColumn is a multiple of 8: the workgroups of one XCD (blockIdx % 8, a speed assumption only) walk ONE contiguous
+    // eighth of the cell-sorted colliders instead of every eighth block of all of them, so the AABB rows they share stay in that XCD's L2
+    const uint32_t inCol = blockIdx.x % blocksPerColumn;
+    const uint32_t base = ((inCol & 7u) * (blocksPerColumn >> 3) + (inCol >> 3)) * (kGridChunks * 256u);
     const uint32_t dy = gp->dims[1], dz = gp->dims[2], dx = gp->dims[0];
     const uint32_t axis = sc->axisCur;
     const uint32_t numSmall = nc - gp->numLarge;
