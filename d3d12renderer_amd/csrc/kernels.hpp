@@ -1789,14 +1789,15 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
     okA = okB = okI = true;   // development knock-out: timing without dependency waits (results are garbage)
 #endif
     const bool polled = __ballot(!(okA && okB && okI)) != 0ull;
+    f32x4 ra0 = a0, ra1 = a1, rb0 = b0, rb1 = b1;   // raw poll destinations
     MI_STAMP(hook.rec, 3);
     while (__ballot(!(okA && okB && okI)) != 0ull) {   // tight polling measured fastest: only the pairs still waiting re-load
         // both lanes of a pair must poll together; the partner flags are exchanged OUTSIDE any short-circuit so every lane
         // takes part in the swap (inside `!okA || swap(...)` the swap would run with only the ready lanes active)
         const uint32_t partnerOkA = swz1(okA ? 1u : 0u), partnerOkB = swz1(okB ? 1u : 0u);
         bool pollA = !okA || partnerOkA == 0u, pollB = !okB || partnerOkB == 0u;
-        // both bodies' polls are in flight together: one round trip per iteration, not two
-        f32x4 ra0 = a0, ra1 = a1, rb0 = b0, rb1 = b1;
+        // both bodies' polls are in flight together: one round trip per iteration, not two (the raw registers are only read by the
+        // lanes that just loaded into them)
         if (pollA) issuePair2Sc1(PA, ra0, ra1);
         if (pollB) issuePair2Sc1(PB, rb0, rb1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
