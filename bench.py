@@ -224,7 +224,7 @@ def main():
             "step_ms_median": float(np.median(step_ms)), "step_ms_p95": float(np.percentile(step_ms, 95)),
             "device_ms_per_step": total_dev_ms / args.steps,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world_size == 1:   # rank 0 at N = 1 only (the other ranks' hosts would wait in the next collective)
             out["cpu_baseline"] = cpu_baseline(args, bodies_per_gpu)
         print(json.dumps(out), flush=True)
     if dist is not None:
