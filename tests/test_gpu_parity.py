@@ -64,6 +64,28 @@ def test_gpu_vs_oracle_trajectory_and_contacts(mi_lib, oracle_mod, make, steps):
     assert g.counts()["num_contacts"] > 0
 
 
+@pytest.mark.parametrize("make,steps", [
+    (lambda: scenes.shape_zoo(8, 5, 8), 150),             # every collider type, GJK / EPA manifolds, mixed contact counts
+    (lambda: scenes.terrain_field(10, 2, 10), 260),       # terrain contacts: one-contact manifolds against a virtual static body
+    (lambda: scenes.mixed_stack(12, 6, 12), 80),
+])
+def test_gpu_xcd_partitioned_solver_on_other_scene_types(mi_lib, oracle_mod, monkeypatch, make, steps):
+    """The XCD-partitioned persistent solver (forced on for these small scenes; default from 16 384 manifolds) with the other
+    manifold sources: same trajectory as the oracle, bit for bit."""
+    monkeypatch.setenv("MI_PERSIST_XCD_MIN", "1")
+    sc = make()
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    kinds = set()
+    for i in range(steps):
+        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        assert g.counts() == o.counts(), f"step {i}"
+        kinds.add(g.solver_kind())
+    pg, qg = g.physics_transforms(); po, qo = o.physics_transforms()
+    assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
+    assert 4 in kinds, kinds
+
+
 def test_gpu_contact_set_equals_reference_order_oracle_first_step(mi_lib, oracle_mod):
     """The GPU's grid broad phase + canonical orientation must reproduce the SAP pipeline's manifolds."""
     sc = scenes.obb_pile(10, 4, 10, spacing=1.0)
