@@ -57,3 +57,36 @@ def create_world(order=ORDER_REFERENCE):
     h = C.c_void_p()
     L.check(L.fn("world_create")(C.c_int(order), C.byref(h)), "world_create")
     return capi.World(L, h)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# oracle/_ref: the REFERENCE's own sources compiled here (oracle/refbuild/build_ref.py) — what the restatement is pinned to.
+REF_LIB = HERE / "_ref" / "libref.so"
+_ref_library = None
+
+
+def reference_available():
+    """True when libref.so exists or can be built (it needs /root/reference; the prebuilt library travels to the GPU box)."""
+    from oracle.refbuild import build_ref
+    return REF_LIB.exists() or (build_ref.REFERENCE_ROOT / "src").exists()
+
+
+def build_reference(force=False):
+    from oracle.refbuild import build_ref
+    return build_ref.build(force=force)
+
+
+def reference_library():
+    global _ref_library
+    if _ref_library is None:
+        build_reference()
+        _ref_library = capi.Library(REF_LIB, prefix="ref_")
+    return _ref_library
+
+
+def create_reference_world(simd=False):
+    """A world stepped by the reference's physicsStep itself (scalar path, or its AVX2 path with simd=True)."""
+    L = reference_library()
+    h = C.c_void_p()
+    L.check(L.fn("world_create")(C.c_int(1 if simd else 0), C.byref(h)), "world_create")
+    return capi.World(L, h)

@@ -1,0 +1,3 @@
+// see registry.hpp (EnTT stand-in, test infrastructure)
+#pragma once
+#include "registry.hpp"
