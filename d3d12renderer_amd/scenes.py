@@ -669,10 +669,11 @@ def obb_pile_tile(tile=0, ntiles=1, nx=128, ny=16, nz=128, ghost_cols=2, seed=3,
     return sc, info
 
 
-def zones(nx=6, ny=3, nz=6, seed=8, solver_iterations=20, spacing=1.4):
+def zones(nx=6, ny=3, nz=6, seed=8, solver_iterations=20, spacing=1.4, localized=True):
     """Triggers and force fields (handleNonCollisionInteractions): a jittered lattice of mixed shapes falls through a wind zone
     (localized force field made of two colliders, tilted entity so the force is rotated), a second overlapping updraft zone, a
-    global breeze (force field without colliders) and three trigger volumes of different collider types, onto the ground."""
+    global breeze (force field without colliders) and three trigger volumes of different collider types, onto the ground.
+    localized=False leaves the force fields without colliders (all three global)."""
     n = nx * ny * nz
     e = make_entities(n)
     e["position"] = _lattice(nx, ny, nz, spacing, 2.5, seed, 0.05)
@@ -703,6 +704,8 @@ def zones(nx=6, ny=3, nz=6, seed=8, solver_iterations=20, spacing=1.4):
     zc["shape"][4, :6] = (-1.0, -0.6, -1.0, 1.0, 0.6, 1.0)
     zsphere = make_colliders(1, capi.CYLINDER); zsphere["shape"][0, :7] = (0, -0.8, 0, 0, 0.8, 0, 0.9)
     zent = np.array([n + 0, n + 0, n + 1, n + 3, n + 4, n + 5], np.uint32)
+    if not localized:
+        zc, zent = zc[3:], zent[3:]
     ge, gc = _ground(100.0)
     ents = np.concatenate([np.arange(n, dtype=np.uint32), zent, [n + 6]]).astype(np.uint32)
     return Scene(f"zones_{n}", np.concatenate([e, z, ge]), ents, np.concatenate([c, zc, zsphere, gc]), solver_iterations,

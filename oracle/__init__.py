@@ -19,7 +19,7 @@ ORDER_CANONICAL = 1   # same arithmetic, pairs/colours ordered like the GPU sche
 
 
 def build(force=False):
-    srcs = [HERE / f for f in ("ora_world.cpp", "ora_narrow.cpp", "ora_gjk.cpp", "ora_joints.cpp", "ora_heightmap.cpp", "ora_cloth.cpp", "ora_math.h", "ora_world.h")]
+    srcs = [HERE / f for f in ("ora_world.cpp", "ora_det.cpp", "ora_narrow.cpp", "ora_gjk.cpp", "ora_joints.cpp", "ora_heightmap.cpp", "ora_cloth.cpp", "ora_math.h", "ora_world.h")]
     srcs += [HERE.parent / "include" / "mi_physics.h", HERE.parent / "include" / "mi_constraints.h"]
     if force or not LIB.exists() or any(s.stat().st_mtime > LIB.stat().st_mtime for s in srcs):
         subprocess.run(["make", "-C", str(HERE)], check=True, capture_output=True)

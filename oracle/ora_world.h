@@ -1,10 +1,11 @@
 // ora_world.h — TEST INFRASTRUCTURE (CPU oracle), see ora_math.h header note.
 //
 // Flat-array, uint32-index restatement of the reference's rigid-body step
-// (src/physics/physics.cpp:1180-1413).  Parity status: the reference cannot be compiled here
-// (Windows/MSVC-only, EnTT submodule absent) and ships no tests or golden vectors, so parity
-// against the ORIGINAL BINARY IS UNPINNED; this restatement is pinned by analytic known-answer
-// tests (tests/test_oracle_*.py) and by its two independently ordered pipelines agreeing.
+// (src/physics/physics.cpp:1180-1413).  Parity status: PINNED to the reference's own code — oracle/refbuild/build_ref.py
+// compiles the reference's physics-only source set into oracle/_ref/libref.so and tests/test_reference_pin.py steps the same
+// scenes through its physicsStep and through this restatement (ORDER_REFERENCE): bit-identical poses, velocities, counts,
+// contact lists, events and cloth particles.  (The reference ships no tests or golden vectors of its own.)  Also pinned by
+// analytic known-answer tests (tests/test_oracle_*.py) and by its two independently ordered pipelines agreeing.
 #pragma once
 #include <vector>
 #include <unordered_map>

@@ -140,7 +140,7 @@ def build(force=False, verbose=False, keep=False):
         if OUT.exists():
             return OUT          # prebuilt library travels to the GPU box; the reference does not
         raise RuntimeError(f"{src_root} not present and no prebuilt {OUT}")
-    deps = [src_root / f for f in FILES] + [HERE / "ref_shim.cpp", HERE / "ref_pch.h", Path(__file__)] + list((HERE / "stubs").rglob("*.h"))
+    deps = [src_root / f for f in FILES] + [HERE / "ref_shim.cpp", HERE / "ref_pch.h", HERE.parent / "ora_det.cpp", HERE.parent / "ora_math.h", Path(__file__)] + list((HERE / "stubs").rglob("*.h"))
     if not force and OUT.exists() and all(p.stat().st_mtime <= OUT.stat().st_mtime for p in deps if p.exists()):
         return OUT
     OUT_DIR.mkdir(exist_ok=True)
@@ -153,10 +153,12 @@ def build(force=False, verbose=False, keep=False):
         flags = ["-std=c++17", "-O2", "-fPIC", "-fms-extensions", "-ffp-contract=off", "-fno-fast-math", "-mavx2", "-mfma", "-msse4.1",
                  "-fno-lax-vector-conversions", "-DPHYSICS_ONLY", "-fdelayed-template-parsing", "-w", "-include", str(HERE / "ref_pch.h"), "-I", str(HERE / "stubs"), "-I", str(tmp / "src"), "-I", str(tmp / "src" / "physics"), "-I", str(REFERENCE_ROOT / "ext"), "-I", str(HERE.parent.parent / "include")]
         objs = []
-        for u in UNITS + ["ref_shim.cpp"]:
-            src = (HERE / u) if u == "ref_shim.cpp" else (tmp / "src" / u)
+        for u in UNITS + ["ref_shim.cpp", "ora_det.cpp"]:
+            src = (HERE / u) if u == "ref_shim.cpp" else (HERE.parent / u) if u == "ora_det.cpp" else (tmp / "src" / u)
             obj = tmp / (u.replace("/", "_") + ".o")
             cmd = [CLANG, *flags, "-c", str(src), "-o", str(obj)]
+            if u == "ora_det.cpp":      # our own file: no reference prefix header
+                cmd = [CLANG, "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-c", str(src), "-o", str(obj)]
             if verbose:
                 print(" ".join(cmd), flush=True)
             r = subprocess.run(cmd, capture_output=True, text=True)

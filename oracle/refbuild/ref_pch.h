@@ -76,3 +76,23 @@ static inline int VirtualFree(void* address, size_t, unsigned)
 	return 0;
 }
 namespace fs = std::filesystem;
+
+// ---- transcendental functions: the reference's float calls of acos / atan2 / sin / cos go to the oracle's fixed operation
+// sequences (oracle/ora_det.cpp, linked into libref.so) instead of glibc, because the last ulp of libm differs between C
+// runtimes and would otherwise be the only difference between the reference and the restatement.  Double and SIMD
+// overloads keep their own definitions (the function-like macros rename the whole overload set consistently).
+namespace ora { float det_atan2f(float y, float x); float det_acosf(float x); float det_sinf(float x); float det_cosf(float x); }
+static inline float ref_acos(float x) { return ora::det_acosf(x); }
+static inline double ref_acos(double x) { return ::acos(x); }
+static inline float ref_atan2(float y, float x) { return ora::det_atan2f(y, x); }
+static inline double ref_atan2(double y, double x) { return ::atan2(y, x); }
+static inline float ref_sin(float x) { return ora::det_sinf(x); }
+static inline double ref_sin(double x) { return ::sin(x); }
+static inline float ref_cos(float x) { return ora::det_cosf(x); }
+static inline double ref_cos(double x) { return ::cos(x); }
+#ifndef REF_NATIVE_LIBM
+#define acos(x) ref_acos(x)
+#define atan2(y, x) ref_atan2(y, x)
+#define sin(x) ref_sin(x)
+#define cos(x) ref_cos(x)
+#endif

@@ -9,7 +9,9 @@
 //   physicsStep                                                                                                  (src/physics/physics.cpp:1364)
 // The per-step dumps (AABBs, broad-phase pairs, contacts) come from two instrumentation calls that build_ref.py inserts into
 // the temporary copy of physicsStepInternal (ref_tap_broadphase / ref_tap_step): they read, never write.
+#define private public      // cloth_component keeps its particles private; the shim only reads them (ref_cloth_get_state)
 #include "physics/physics.h"
+#undef private
 #include "physics/collision_broad.h"
 #include "scene/scene.h"
 #include "terrain/heightmap_collider.h"
@@ -36,6 +38,8 @@ struct ref_world
 	std::unordered_map<uint32, uint32> entityIdOfHandle;
 	std::unordered_map<uint32, uint32> colliderIdOfHandle;
 	scene_entity heightmapEntity;
+	std::vector<scene_entity> cloths;
+	std::vector<uint32> hullIds;              // world-local hull geometry id -> index into the reference's process-wide boundingHullGeometries
 	bool eventsEnabled = false;
 	std::vector<mi_event> events;
 
@@ -53,7 +57,7 @@ quat q4(const float* f) { return quat(f[0], f[1], f[2], f[3]); }
 void put3(float* o, vec3 v) { o[0] = v.x; o[1] = v.y; o[2] = v.z; }
 void put4(float* o, quat q) { o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w; }
 
-collider_component colliderFromDesc(const mi_collider_desc& d)
+collider_component colliderFromDesc(const ref_world* w, const mi_collider_desc& d)
 {
 	physics_material mat = { physics_material_type_none, d.restitution, d.friction, d.density };
 	const float* f = d.shape;
@@ -64,7 +68,7 @@ collider_component colliderFromDesc(const mi_collider_desc& d)
 		case MI_COLLIDER_CYLINDER: return collider_component::asCylinder(bounding_cylinder{ v3(f), v3(f + 3), f[6] }, mat);
 		case MI_COLLIDER_AABB: return collider_component::asAABB(bounding_box{ v3(f), v3(f + 3) }, mat);
 		case MI_COLLIDER_OBB: { bounding_oriented_box b; b.rotation = q4(f); b.center = v3(f + 4); b.radius = v3(f + 7); return collider_component::asOBB(b, mat); }
-		default: { bounding_hull h; h.rotation = q4(f); h.position = v3(f + 4); h.geometryIndex = d.hull_geometry; return collider_component::asHull(h, mat); }
+		default: { bounding_hull h; h.rotation = q4(f); h.position = v3(f + 4); h.geometryIndex = w->hullIds[d.hull_geometry]; return collider_component::asHull(h, mat); }
 	}
 }
 
@@ -238,7 +242,7 @@ REF_API int ref_colliders_add(ref_world* w, uint32 count, const uint32* entities
 	{
 		if (entities[i] >= w->entities.size()) { return MI_ERR_INVALID_ARGUMENT; }
 		scene_entity& e = w->entities[entities[i]];
-		e.addComponent<collider_component>(colliderFromDesc(descs[i]));
+		e.addComponent<collider_component>(colliderFromDesc(w, descs[i]));
 		entity_handle child = e.getComponent<physics_reference_component>().firstColliderEntity;
 		w->colliderIdOfHandle[(uint32)child] = (uint32)w->colliderEntities.size();
 		w->colliderEntities.push_back(child);
@@ -251,13 +255,14 @@ REF_API int ref_collider_add(ref_world* w, uint32 entity, const mi_collider_desc
 	return ref_colliders_add(w, 1, &entity, d);
 }
 
-REF_API int ref_hull_geometry_create(ref_world*, const float* v, uint32 nv, const uint32* t, uint32 nt, uint32* out)
+REF_API int ref_hull_geometry_create(ref_world* w, const float* v, uint32 nv, const uint32* t, uint32 nt, uint32* out)
 {
 	std::vector<vec3> verts(nv);
 	for (uint32 i = 0; i < nv; ++i) { verts[i] = v3(v + 3 * i); }
 	std::vector<indexed_triangle16> tris(nt);
 	for (uint32 i = 0; i < nt; ++i) { tris[i] = { (uint16)t[3 * i], (uint16)t[3 * i + 1], (uint16)t[3 * i + 2] }; }
-	*out = ref_allocate_hull_geometry(verts.data(), nv, tris.data(), nt);
+	*out = (uint32)w->hullIds.size();
+	w->hullIds.push_back(ref_allocate_hull_geometry(verts.data(), nv, tris.data(), nt));
 	return MI_OK;
 }
 
@@ -478,6 +483,41 @@ REF_API int ref_world_step_fixed(ref_world* w, const mi_step_settings* s, float 
 REF_API int ref_world_set_cloth_iterations(ref_world* w, uint32 v, uint32 p, uint32 d)
 {
 	w->settings.numClothVelocityIterations = v; w->settings.numClothPositionIterations = p; w->settings.numClothDriftIterations = d;
+	return MI_OK;
+}
+
+// --- cloth (cloth_component, src/physics/cloth.h)
+REF_API int ref_cloth_create(ref_world* w, const mi_cloth_desc* d, uint32* out)
+{
+	scene_entity e = w->scene.createEntity("cloth");
+	e.addComponent<cloth_component>(d->width, d->height, d->grid_size_x, d->grid_size_y, d->total_mass, d->stiffness, d->damping, d->gravity_factor);
+	if (out) { *out = (uint32)w->cloths.size(); }
+	w->cloths.push_back(e);
+	return MI_OK;
+}
+REF_API int ref_cloth_set_fixed_vertices(ref_world* w, uint32 cloth, const float* p, const float* r, uint32 moveRigid)
+{
+	if (cloth >= w->cloths.size()) { return MI_ERR_INVALID_ARGUMENT; }
+	w->cloths[cloth].getComponent<cloth_component>().setWorldPositionOfFixedVertices(trs(v3(p), q4(r)), moveRigid != 0);
+	return MI_OK;
+}
+REF_API int ref_cloth_set_properties(ref_world* w, uint32 cloth, float totalMass, float stiffness, float damping, float gravityFactor)
+{
+	if (cloth >= w->cloths.size()) { return MI_ERR_INVALID_ARGUMENT; }
+	cloth_component& c = w->cloths[cloth].getComponent<cloth_component>();
+	c.totalMass = totalMass; c.stiffness = stiffness; c.damping = damping; c.gravityFactor = gravityFactor;
+	return MI_OK;
+}
+REF_API int ref_cloth_get_state(ref_world* w, uint32 cloth, float* pos, float* vel, uint32 cap)
+{
+	if (cloth >= w->cloths.size()) { return MI_ERR_INVALID_ARGUMENT; }
+	const cloth_component& c = w->cloths[cloth].getComponent<cloth_component>();
+	if (cap < c.positions.size()) { return MI_ERR_CAPACITY; }
+	for (size_t i = 0; i < c.positions.size(); ++i)
+	{
+		if (pos) { put3(pos + 3 * i, c.positions[i]); }
+		if (vel) { put3(vel + 3 * i, c.velocities[i]); }
+	}
 	return MI_OK;
 }
 
