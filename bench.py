@@ -8,12 +8,18 @@ A "step" is one pass of the hot path (physicsStepInternal: world colliders -> br
 -> integrate forces -> schedule -> constraint init -> I PGS sweeps -> integrate velocities) over the
 whole synthetic scene.  Workload at N=1: cfg3, the 262 144-body OBB pile (128 x 16 x 128 boxes, half-extents
 U[0.3,0.6], friction 0.5, 20 solver iterations, walled pen) — the configuration BASELINE.json's metric is
-quoted on; it fits one GPU.  N > 1 is weak scaling: every rank steps one 262 144-body tile (see DESIGN.md
-"multi-GPU").  All scene state is resident in HBM before the timed region starts.
+quoted on; it fits one GPU.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the
-contact PGS solver: k_contact_solve_persist (k_contact_solve_flow with MI_SOLVER=flow), one launch for all sweeps of a step; algorithmic bytes from
-SURVEY.md §8(d)) and `cpu_baseline` (CPU oracle, reference order, bounded sample) objects.
+THE TIMED STATE IS PART OF THE WORKLOAD, NOT OF THE FLAGS.  The lattice is first stepped SETTLE_STEPS = 240 times
+(untimed, always; BASELINE.md §2 "settle") so that the boxes are piled up (~3.3 contacts per body); only then come the
+caller's W warm-up steps and the K timed steps.  The CPU baseline settles its sample with the same 240 steps.  `--warmup`
+therefore no longer changes what is being measured; the line carries `settle_steps`, contacts and contacts per body, and
+the run refuses to time a scene with fewer than 2 contacts per body.  A second figure, `at_rest`, times the same pile after
+1 500 steps in total (everything has come to rest: ~4.7 contacts per body).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel = the contact PGS solver,
+k_contact_solve_persist, one launch for all sweeps of a step; algorithmic bytes from SURVEY.md §8(d)) and `cpu_baseline`
+(the REFERENCE's own code, oracle/_ref/libref_fast.so: scalar path and AVX2 path, on the host cores) objects.
 """
 import argparse
 import json
@@ -29,35 +35,54 @@ sys.path.insert(0, str(ROOT))
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s achievable)
 BYTES_PER_CONTACT_ITER = 236    # per contact per PGS sweep (124 B row + 2 x 28 B body read, 8 + 2 x 24 B written)
+SETTLE_STEPS = 240              # part of the workload definition (see module docstring)
+AT_REST_STEPS = 1500            # total steps before the `at_rest` measurement
+MIN_CONTACTS_PER_BODY = 2.0
 
 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
-    ap.add_argument("--warmup", type=int, default=240)
+    ap.add_argument("--steps", type=int, default=240, help="timed steps (BASELINE.md §2: 240)")
+    ap.add_argument("--warmup", type=int, default=10, help="untimed steps right before the timed region (the pile is settled separately, always)")
     ap.add_argument("--grid", type=int, nargs=3, default=[128, 16, 128], help="boxes per axis of one GPU's tile (default = 262144 bodies)")
     ap.add_argument("--iterations", type=int, default=20)
+    ap.add_argument("--settle", type=int, default=SETTLE_STEPS, help="development only: anything but 240 is flagged in the output")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-at-rest", action="store_true", help="skip the second measurement after 1500 steps")
     ap.add_argument("--cpu-grid", type=int, nargs=3, default=[32, 16, 32])
-    ap.add_argument("--cpu-warmup", type=int, default=200)
     ap.add_argument("--cpu-steps", type=int, default=20)
-    ap.add_argument("--cpu-cores", type=int, default=0, help="oracle replicas for the CPU baseline (0 = all host cores)")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="reference replicas for the CPU baseline (0 = all usable host cores)")
     return ap.parse_args()
 
 
+# --------------------------------------------------------------------------------------------------------------- CPU baseline
 def _cpu_replica(job):
-    """One oracle replica: settle, then time `steps` steps of a (nx, ny, nz) tile of the workload."""
-    nx, ny, nz, iterations, warmup, steps = job
+    """One replica of the CPU baseline: the same generator at a smaller footprint, settled with the same SETTLE_STEPS, then timed.
+    kind "reference": the reference's own physicsStep (oracle/_ref/libref_fast.so), AVX2 path and, optionally, scalar path from
+    the same state; kind "port": the oracle restatement (only if the reference library is unavailable)."""
+    nx, ny, nz, iterations, settle, steps, kind, with_scalar = job
+    import ctypes as C
     import oracle
     from d3d12renderer_amd import scenes
     sc = scenes.obb_pile(nx, ny, nz, solver_iterations=iterations)
-    w = sc.populate(oracle.create_world(oracle.ORDER_REFERENCE))
     s = sc.settings()
-    w.step_fixed(s, sc.dt, warmup)
-    t0 = time.perf_counter()
-    w.step_fixed(s, sc.dt, steps)
-    return steps / (time.perf_counter() - t0), sc.num_bodies, w.counts()["num_contacts"]
+    out = {"bodies": sc.num_bodies}
+    if kind == "reference":
+        w = sc.populate(oracle.create_reference_world(simd=True, fast=True))
+        w.step_fixed(s, sc.dt, settle)
+        t0 = time.perf_counter(); w.step_fixed(s, sc.dt, steps); out["avx2"] = steps / (time.perf_counter() - t0)
+        out["contacts"] = w.counts()["num_contacts"]
+        if with_scalar:
+            w.L.check(w.L.fn("world_set_simd")(w.h, C.c_uint32(0)), "world_set_simd")
+            n = max(4, steps // 2)
+            t0 = time.perf_counter(); w.step_fixed(s, sc.dt, n); out["scalar"] = n / (time.perf_counter() - t0)
+    else:
+        w = sc.populate(oracle.create_world(oracle.ORDER_REFERENCE))
+        w.step_fixed(s, sc.dt, settle)
+        t0 = time.perf_counter(); w.step_fixed(s, sc.dt, steps); out["scalar"] = steps / (time.perf_counter() - t0)
+        out["contacts"] = w.counts()["num_contacts"]
+    return out
 
 
 def _usable_cores():
@@ -76,42 +101,81 @@ def _usable_cores():
     return n
 
 
-def cpu_baseline(args, bodies_full):
-    """CPU oracle (reference order = the reference's scalar path restated) on a bounded sample of the same workload: same
-    generator and column height, smaller footprint.  The reference step is single-threaded, so "the host cores of the box"
-    are used the only way that code can use them: one independent replica per core, each its own
-    process; the value is the aggregate body-steps/s of all replicas expressed in steps/s of the full 262144-body scene."""
+def cpu_baseline(args, bodies_full, settle):
+    """The reference timed beside the GPU on this box's host cores: (i) its scalar path on 1 core, (ii) its AVX2
+    path (physics_settings::simd* = true, the default of the original) on 1 core, (iii) the AVX2 path on all usable cores as
+    independent replicas (the reference step has no intra-step threading).  Sample: the same generator, 32 x 16 x 32 = 16 384
+    boxes (the reference's 16-bit collider indices end at 65 535), settled with the same 240 steps; throughput is expressed in
+    steps/s of the full 262 144-body scene, assuming cost linear in bodies (contacts per body are the same)."""
     import subprocess
     import oracle
     oracle.build()
+    kind = "reference" if (oracle.REF_LIB.with_name("libref_fast.so").exists() or oracle.reference_available()) else "port"
+    if kind == "reference":
+        oracle.build_reference()
     nx, ny, nz = args.cpu_grid
     cores = max(1, min(args.cpu_cores or _usable_cores(), 64))
-    job = [nx, ny, nz, args.iterations, args.cpu_warmup, args.cpu_steps]
-    cmd = [sys.executable, str(Path(__file__).resolve()), "--cpu-replica", json.dumps(job)]
     env = dict(os.environ, OMP_NUM_THREADS="1")
-    procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(cores)]
-    res = []
-    for p in procs:
-        out, _ = p.communicate(timeout=900)
-        if p.returncode == 0 and out.strip():
-            res.append(json.loads(out.strip().splitlines()[-1]))
-    if not res:
-        res = [list(_cpu_replica(job))]
-    nb = res[0][1]
-    agg = sum(r[0] for r in res)                      # replica-steps/s, all replicas together (they ran concurrently)
-    return {
-        "value": agg * nb / bodies_full, "unit": "steps/s", "cores": len(res), "kind": "port",
-        "sample": (f"oracle (reference order, -O2 strict fp32) on obb_pile {nx}x{ny}x{nz} = {nb} bodies, I={args.iterations}, "
-                   f"{args.cpu_warmup} settle + {args.cpu_steps} timed steps, one independent single-threaded replica per core, "
-                   f"{len(res)} concurrent replicas: {agg:.1f} replica-steps/s in aggregate ({agg / len(res):.2f} per replica, "
-                   f"{res[0][2]} contacts each); value = aggregate x {nb}/{bodies_full} (linear in bodies)"),
-        "per_core_value": agg / len(res) * nb / bodies_full, "measured_replica_steps_per_s": agg, "sample_bodies": nb,
+
+    def launch(n, with_scalar):
+        job = [nx, ny, nz, args.iterations, settle, args.cpu_steps, kind, with_scalar]
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--cpu-replica", json.dumps(job)]
+        procs = [subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, env=env) for _ in range(n)]
+        res = []
+        for p in procs:
+            out, _ = p.communicate(timeout=1200)
+            if p.returncode == 0 and out.strip():
+                res.append(json.loads(out.strip().splitlines()[-1]))
+        return res
+
+    single = launch(1, True)           # one replica alone on the box: uncontended 1-core figures
+    if not single:
+        raise RuntimeError("cpu_baseline: the replica process failed")
+    nb = single[0]["bodies"]; scale = nb / bodies_full
+    fastest = "avx2" if kind == "reference" else "scalar"
+    many = launch(cores, False) if cores > 1 else single
+    agg = sum(r[fastest] for r in many)
+    out = {
+        "value": agg * scale, "unit": "steps/s", "cores": len(many), "kind": kind,
+        "sample": (f"{'the reference itself (oracle/_ref/libref_fast.so: its sources, -O2 -ffast-math -mavx2 -mfma), AVX2 path' if kind == 'reference' else 'oracle restatement (scalar, -O2 strict fp32)'} "
+                   f"on obb_pile {nx}x{ny}x{nz} = {nb} bodies, I={args.iterations}, {settle} settle + {args.cpu_steps} timed steps "
+                   f"({single[0]['contacts']} contacts = {single[0]['contacts'] / nb:.2f} per body), {len(many)} independent single-threaded replicas "
+                   f"running concurrently: {agg:.1f} replica-steps/s in aggregate; value = aggregate x {nb}/{bodies_full} (linear in bodies)"),
+        "sample_bodies": nb, "sample_contacts": single[0]["contacts"], "settle_steps": settle,
+        "scalar_1core": single[0].get("scalar", 0.0) * scale,
+        "avx2_1core": single[0].get("avx2", 0.0) * scale if kind == "reference" else None,
+        "avx2_all_cores": agg * scale if kind == "reference" else None,
+        "measured_replica_steps_per_s": {"scalar_1core": single[0].get("scalar"), "avx2_1core": single[0].get("avx2"), "aggregate": agg},
     }
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------- GPU legs
+def step_algorithmic_bytes(c, iterations):
+    """B_step of SURVEY.md §8(d) / BASELINE.md §3 for a contacts-only scene, from this step's own counts."""
+    nc, nb, p, m, k = c["num_colliders"], c["num_rigid_bodies"], c["num_broadphase_overlaps"], c["num_collisions"], c["num_contacts"]
+    return (160 * nc + (24 * nc + 8 * p) + (112 * p + 40 * k + 9 * m) + 270 * nb + 316 * k + iterations * BYTES_PER_CONTACT_ITER * k + 140 * nb)
+
+
+def timed_region(sw, settings, dt, steps, barrier):
+    barrier()
+    t0 = time.perf_counter()
+    step_ms = []
+    sw.world.accumulated_stage_times(reset=True)      # the library sums the per-stage device times of the timed steps itself
+    for _ in range(steps):
+        t_step = time.perf_counter()
+        sw.step(settings, dt)
+        step_ms.append((time.perf_counter() - t_step) * 1e3)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stage_acc, n_acc, contact_iters = sw.world.accumulated_stage_times()
+    assert n_acc == steps
+    return elapsed, step_ms, stage_acc, contact_iters
 
 
 def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--cpu-replica":     # worker process of cpu_baseline()
-        print(json.dumps(list(_cpu_replica(json.loads(sys.argv[2])))))
+        print(json.dumps(_cpu_replica(json.loads(sys.argv[2]))))
         return
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -129,13 +193,14 @@ def main():
         sys.exit(2)
 
     import d3d12renderer_amd as mi
-    from d3d12renderer_amd import scenes
     from d3d12renderer_amd.distributed import ShardedWorld
 
     nx, ny, nz = args.grid
     sw = ShardedWorld(lambda: mi.create_world(local_rank), rank, world_size, dist, tile=(nx, ny, nz), iterations=args.iterations)
     settings = sw.settings()
     dt = sw.dt
+    bodies_per_gpu = sw.bodies_per_rank
+    total_bodies = bodies_per_gpu * world_size
 
     def barrier():
         torch.cuda.synchronize()
@@ -143,26 +208,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # ---- the workload's state: settle (always, untimed), then the caller's warm-up
+    for _ in range(args.settle):
+        sw.step(settings, dt)
     for _ in range(args.warmup):
         sw.step(settings, dt)
     barrier()
-    t0 = time.perf_counter()
-    step_ms = []
-    sw.world.accumulated_stage_times(reset=True)      # the library sums the per-stage device times of the timed steps itself
-    for _ in range(args.steps):
-        t_step = time.perf_counter()
-        sw.step(settings, dt)
-        step_ms.append((time.perf_counter() - t_step) * 1e3)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    stage_acc, n_acc, contact_iters = sw.world.accumulated_stage_times()
-    assert n_acc == args.steps
+    c0 = sw.world.counts()
+    contacts_per_body = c0["num_contacts"] / max(1, c0["num_rigid_bodies"])
+    if contacts_per_body < MIN_CONTACTS_PER_BODY and args.settle >= SETTLE_STEPS:
+        raise SystemExit(f"bench.py: {contacts_per_body:.2f} contacts per body after {args.settle} settle steps — this is not the piled-up workload")
+
+    elapsed, step_ms, stage_acc, contact_iters = timed_region(sw, settings, dt, args.steps, barrier)
     solve_ms = stage_acc["solve"]; total_dev_ms = stage_acc["total"]
     launches = sw.world.solve_launches() * args.steps
-    # roofline of the dominant kernel: a few extra steps (outside the timed region) with a HIP event pair around every
-    # k_contact_solve launch, on the stream the kernel is launched on
+    counts = sw.world.counts()
+
+    # per-stage breakdown + a dedicated HIP event pair around every solver launch: 3 extra steps outside the timed region
     prof_launches = 0; prof_ms = 0.0; prof_updates = 0
-    sw.world.set_stage_timing(True)     # the per-stage breakdown comes from these extra steps too (an event pair per stage costs device time)
+    sw.world.set_stage_timing(True)
     stage_prof = {}
     for _ in range(3):
         n_l, ms, upd = sw.world.step_profiled(settings, dt)
@@ -171,52 +235,69 @@ def main():
         sw.exchange_ghosts()
         prof_launches += n_l; prof_ms += ms; prof_updates += upd
     sw.world.set_stage_timing(False)
+
+    # ---- second state: the same pile at rest (1500 steps in total)
+    at_rest = None
+    if not args.no_at_rest and world_size == 1 and args.settle >= SETTLE_STEPS:
+        done = args.settle + args.warmup + args.steps + 3
+        for _ in range(max(0, AT_REST_STEPS - done)):
+            sw.step(settings, dt)
+        n_rest = min(120, args.steps)
+        e2, sm2, acc2, ci2 = timed_region(sw, settings, dt, n_rest, barrier)
+        c2 = sw.world.counts()
+        at_rest = {"steps_before": max(done, AT_REST_STEPS), "timed_steps": n_rest, "value": n_rest / e2, "unit": "steps/s", "ms_per_step": e2 / n_rest * 1e3,
+                   "contacts": c2["num_contacts"], "manifolds": c2["num_collisions"], "broadphase_overlaps": c2["num_broadphase_overlaps"],
+                   "contacts_per_body": c2["num_contacts"] / max(1, c2["num_rigid_bodies"]),
+                   "solver_avg_launch_us": acc2["solve"] * 1e3 / max(1, sw.world.solve_launches() * n_rest),
+                   "solver_frac_algorithmic": (BYTES_PER_CONTACT_ITER * ci2) / (acc2["solve"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if acc2["solve"] > 0 else None,
+                   "step_frac_algorithmic": step_algorithmic_bytes(c2, args.iterations) / (e2 / n_rest) / 1e9 / HBM_PEAK_GBPS}
+
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    counts = sw.world.counts()
-    bodies_per_gpu = sw.bodies_per_rank
-    total_bodies = bodies_per_gpu * world_size
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        # whole-job throughput: every rank steps its 262144-body tile each step; the job advances one scene step per `ms_per_step`
-        # and processes world_size tiles, so value = tiles-steps per second (at N=1: plain steps/s of the 262144-body scene).
+        # whole-job throughput: every rank steps its 262144-body tile each step; value = tiles-steps per second (N=1: steps/s)
         value = world_size * args.steps / elapsed
-        # Dominant kernel = the contact PGS solver.  Default path: k_contact_solve_persist, ONE launch per step covering all
-        # sweeps (MI_SOLVER=flow: k_contact_solve_flow, also one launch; MI_SOLVER=launch: one k_contact_solve launch per colour per sweep).  achieved = algorithmic bytes of all
-        # contact updates (236 B per contact per sweep) / HIP-event time of the solve stage, recorded on
-        # the world's own stream around exactly those launches, averaged over the timed steps.
         launches_per_step = launches / args.steps
-        kernel = sw.world.solver_kernel()   # k_contact_solve_persist by default (k_contact_solve_flow / k_contact_solve with MI_SOLVER=flow / launch)
-        achieved = (BYTES_PER_CONTACT_ITER * contact_iters) / (solve_ms * 1e-3) / 1e9 if solve_ms > 0 else 0.0
-        event_pair = (BYTES_PER_CONTACT_ITER * prof_updates) / (prof_ms * 1e-3) / 1e9 if prof_ms > 0 else 0.0
-        traffic = _measured_traffic(kernel)
+        kernel = sw.world.solver_kernel()
         avg_launch_s = solve_ms * 1e-3 / max(launches, 1)
+        alg_per_launch = BYTES_PER_CONTACT_ITER * contact_iters / max(launches, 1)
+        achieved = alg_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
+        traffic, traffic_note = _scaled_traffic(kernel, contact_iters / max(launches, 1))
+        b_step = step_algorithmic_bytes(counts, args.iterations)
         roofline = {
             "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-            # what really crossed the HBM interface per second (committed PMC pass / this run's launch time): the persistent kernel
-            # serves a good part of the algorithmic bytes from LDS (accumulated impulses) and the XCDs' L2s (body hand-overs)
-            "traffic_GBps": (traffic / avg_launch_s / 1e9) if traffic and avg_launch_s > 0 else None,
-            "avg_launch_us": solve_ms * 1e3 / max(launches, 1), "launches_per_step": launches_per_step,
-            "algorithmic_bytes_per_launch": BYTES_PER_CONTACT_ITER * contact_iters / max(launches, 1),
+            # what crosses the HBM interface is LESS than the algorithmic bytes (impulses stay in LDS, ~95 % of the body hand-overs in L2):
+            # `frac` says how fast the algorithmic work is done, `traffic_frac` how busy the memory interface really is
+            "traffic_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBPS) if traffic and avg_launch_s > 0 else None,
+            "traffic_note": traffic_note,
+            "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_step,
+            "algorithmic_bytes_per_launch": alg_per_launch,
+            "bound_note": ("the kernel is bound by its dependency chain (colours x sweeps serial hops), not by bytes: DESIGN.md §4"),
             "event_pair_per_launch": {"avg_launch_us": prof_ms * 1e3 / max(prof_launches, 1), "launches_per_step": prof_launches / 3,
-                                      "achieved_GBps": event_pair,
+                                      "achieved_GBps": (BYTES_PER_CONTACT_ITER * prof_updates) / (prof_ms * 1e-3) / 1e9 if prof_ms > 0 else 0.0,
                                       "note": "3 extra steps (outside the timed region) with a dedicated HIP event pair around each solver launch"},
+            "whole_step": {"algorithmic_bytes": b_step, "ms": total_dev_ms / args.steps, "achieved_GBps": b_step / (total_dev_ms / args.steps * 1e-3) / 1e9,
+                           "frac": b_step / (total_dev_ms / args.steps * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                           "note": "B_step of SURVEY.md §8(d) from this step's counts / device time of the whole step (HIP events on the world's stream)"},
             "note": ("rank 0, timed region: 236 B x contacts x sweeps / HIP-event time of the solve stage on the world's stream; "
-                     "rocprofv3 --kernel-trace --stats of the same command: profiles/; traffic = HBM bytes per launch from separate "
-                     "--pmc FETCH_SIZE / WRITE_SIZE passes (profiles/traffic.json)"),
+                     "rocprofv3 --kernel-trace --stats of the same command: profiles/"),
         }
         out = {
             "metric": "physics steps/sec at 262144 rigid bodies per GPU (OBB pile, 20 solver iterations)",
             "value": value, "unit": "steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"cfg3 obb_pile {nx}x{ny}x{nz} boxes per GPU ({bodies_per_gpu} bodies/GPU, {total_bodies} total), "
-                                   f"friction 0.5, {args.iterations} solver iterations, dt=1/120",
+            "config": {"workload": (f"cfg3 obb_pile {nx}x{ny}x{nz} boxes per GPU ({bodies_per_gpu} bodies/GPU, {total_bodies} total), friction 0.5, "
+                                    f"{args.iterations} solver iterations, dt=1/120, settled {args.settle} steps before warm-up "
+                                    f"({counts['num_contacts'] / max(1, counts['num_rigid_bodies']):.2f} contacts per body when timed)"),
+                       "settle_steps": args.settle, "settle_is_standard": args.settle == SETTLE_STEPS,
                        "bodies_per_gpu": bodies_per_gpu, "contacts": counts["num_contacts"], "manifolds": counts["num_collisions"],
+                       "contacts_per_body": counts["num_contacts"] / max(1, counts["num_rigid_bodies"]),
                        "broadphase_overlaps": counts["num_broadphase_overlaps"], "colors": counts["num_colors"],
                        "sharding": sw.sharding_note},
             "roofline": roofline,
@@ -224,23 +305,29 @@ def main():
             "step_ms_median": float(np.median(step_ms)), "step_ms_p95": float(np.percentile(step_ms, 95)),
             "device_ms_per_step": total_dev_ms / args.steps,
         }
-        if not args.no_cpu_baseline and world_size == 1:   # rank 0 at N = 1 only (the other ranks' hosts would wait in the next collective)
-            out["cpu_baseline"] = cpu_baseline(args, bodies_per_gpu)
+        if at_rest is not None:
+            out["at_rest"] = at_rest
+        if not args.no_cpu_baseline and world_size == 1:   # rank 0 at N = 1 only
+            out["cpu_baseline"] = cpu_baseline(args, bodies_per_gpu, args.settle)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def _measured_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (profiles/traffic.json), or None."""
+def _scaled_traffic(kernel, contact_sweeps_per_launch):
+    """HBM bytes per launch of the dominant kernel: the committed rocprofv3 --pmc passes (profiles/traffic.json: separate FETCH_SIZE /
+    WRITE_SIZE passes, gfx950 corrections) give bytes per contact-sweep of that kernel at the profiled state; scaled by THIS run's
+    contact-sweeps per launch.  None when there is no committed figure for the kernel (PMC counters cannot be read from inside this
+    process)."""
     p = ROOT / "profiles" / "traffic.json"
-    if p.exists():
-        try:
-            return json.loads(p.read_text()).get(kernel + "_bytes_per_launch")
-        except Exception:
-            return None
-    return None
+    try:
+        t = json.loads(p.read_text())
+        per = t[kernel + "_bytes_per_contact_sweep"]
+        return per * contact_sweeps_per_launch, (f"{per:.1f} B per contact-sweep from the committed PMC passes ({t.get('source', 'profiles/')}) x this run's "
+                                                 f"{contact_sweeps_per_launch:.0f} contact-sweeps per launch")
+    except Exception:   # noqa: BLE001
+        return None, "no committed PMC figure for this kernel"
 
 
 if __name__ == "__main__":

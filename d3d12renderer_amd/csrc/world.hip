@@ -153,6 +153,9 @@ struct mi_world {
     bool usedFused = false;
     bool persistSolver = true, persistMetaLds = true, persistImpLds = true, usedPersist = false; uint32_t xcdOnly = 0; uint32_t persistWaves = 1024;   // one resident workgroup per SIMD owns its tiles through all sweeps (k_contact_solve_persist)
     uint32_t flowLds = 0;                  // dynamic LDS bytes per 64-lane workgroup: caps resident waves per CU (160 KiB / flowLds)
+    uint32_t flowFallbacks = 0;
+    uint32_t launchFallbackSteps = 0;     // > 0: the dispatch-ordered dataflow kernel ran out of spin budget (shared device?) -> per-colour launches for this many steps
+    bool flowFaultTest = false, flowFaultFired = false;   // MI_FLOW_FAULT: tests inject one such failure
     bool flowSolver = true;               // dataflow PGS sweep (one launch per iteration); MI_SOLVER=launch selects one launch per colour
     BinInfo bins[kSchedBins]{};           // host copy of the last step's schedule
     uint32_t totalTiles = 0;
@@ -237,13 +240,17 @@ int mi_world::init(int dev) {
       xcdOnly = getenv("MI_PERSIST_XCD_ONLY") ? 1u : 0u;
       if (const char* px = getenv("MI_PERSIST_XCD")) persistXcd = px[0] != '0';
       xcdFaultTest = getenv("MI_PERSIST_XCD_FAULT") != nullptr;
+      flowFaultTest = getenv("MI_FLOW_FAULT") != nullptr;
       if (const char* pm = getenv("MI_PERSIST_XCD_MIN")) xcdMinManifolds = (uint32_t)strtoul(pm, nullptr, 0); }   // smallest manifold count that is partitioned (tests: 1)   // MI_PERSIST_XCD=0: no XCD partitioning (every body through memory)   // development experiment: one XCD's workgroups do all the work
     if (flowLds > 65536) (void)hipFuncSetAttribute((const void*)k_contact_solve_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flowLds);
     return MI_OK;
 }
 mi_world::~mi_world() {
+    // nothing may still be writing into the pinned read-back record or reading the device buffers the members' destructors free
+    if (stream) (void)hipStreamSynchronize(stream);
+    (void)hipDeviceSynchronize();
     if (hsPinned) (void)hipHostFree(hsPinned);
-    if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+    if (stream) (void)hipStreamDestroy(stream);
     for (auto& e : profEvents) (void)hipEventDestroy(e);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
     delete heightmap;
@@ -584,10 +591,14 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     if (topologyDirty) { int rc = download(); if (rc != MI_OK) return rc; rc = upload(); if (rc != MI_OK) return rc; haveEstimates = false; }
     else if (joints.podsDirty()) { int rc = joints.uploadPods(stream); if (rc != MI_OK) return rc; HIP_TRY(hipStreamSynchronize(stream)); }
     if (bodies.empty()) return cloths.empty() ? MI_OK : stepCloths(dt);   // physics.cpp:1184-1189: cloth alone still steps
-    const bool spec = specEnabled && haveEstimates && flowSolver && !usesInteractions;   // interactions are read back mid-step
+    const bool spec = specEnabled && haveEstimates && flowSolver && !launchFallbackSteps && !usesInteractions;   // interactions are read back mid-step
     ++totalSteps; if (spec) ++specSteps;
     int rc = runStep(settings, dt, spec);
-    if (rc == STEP_RETRY) { ++specRetries; rc = runStep(settings, dt, false); }
+    // a step that asks to be re-run has written nothing persistent; each re-run is synchronous and one rung further down the ladder
+    // speculative -> exact sizes -> unpartitioned -> dispatch-ordered dataflow kernel -> one launch per colour
+    for (int attempt = 0; rc == STEP_RETRY && attempt < 6; ++attempt) { ++specRetries; rc = runStep(settings, dt, false); }
+    if (rc == STEP_RETRY) return fail(MI_ERR_DEVICE, "step could not be completed on any solver path");
+    if (rc == MI_OK && launchFallbackSteps) --launchFallbackSteps;
     if (rc == MI_OK && !cloths.empty()) rc = stepCloths(dt);   // after the rigid bodies (physics.cpp:1352-1358); once per VALID step: cloth state is updated in place
     return rc;
 }
@@ -879,7 +890,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     mark();  // 5
     // ---------------------------------------------------------------------------------------------- constraints
     const uint32_t tilesLaunch = spec ? tilesCap : totalTiles;   // sync mode knows the exact tile count (mirrorSchedule)
-    const bool useFlow = flowSolver && (spec || bins[kSchedBins - 1].count == 0 || !nmBound);   // the overflow colour needs the sequential kernel
+    const bool useFlow = flowSolver && !launchFallbackSteps && (spec || bins[kSchedBins - 1].count == 0 || !nmBound);   // the overflow colour needs the sequential kernel
     static const bool fuseEnabled = !(std::getenv("MI_FUSE_JOINTS") && std::getenv("MI_FUSE_JOINTS")[0] == '0');
     const bool fused = useFlow && fuseEnabled && joints.allInIslands();   // joints of all sweeps inside the dataflow launch
     // slots (tiles) one persistent workgroup must hold: exact in a synchronous step, from the previous step's lists (+ slack) in a speculative one
@@ -1071,7 +1082,14 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         if (usedXcd) persistXcd = false; else persistSolver = false;
         return STEP_RETRY;
     }
-    if (hs.solveError) return fail(MI_ERR_DEVICE, "dataflow contact solver: a body dependency wait exceeded its spin budget");
+    if (flowFaultTest && !flowFaultFired && useFlow && !usedPersist && !hs.solveError) { flowFaultFired = true; hs.solveError = 1u; }   // test injection
+    if (hs.solveError && useFlow) {
+        // the dispatch-ordered kernels rely on workgroups being started in index order on a device that is not shared; when a wait
+        // runs out of budget nothing persistent has been written: run the step again with one launch per colour, and stay there a while
+        launchFallbackSteps = 256u; ++flowFallbacks;
+        return STEP_RETRY;
+    }
+    if (hs.solveError) return fail(MI_ERR_DEVICE, "contact solver reported an error on the per-colour path");
     if (profileSolve) {
         if (useFlow) { mainContacts = 0; for (uint32_t bn = 0; bn + 1 < kSchedBins; ++bn) mainContacts += (uint64_t)bins[bn].count * ((bn & 3u) + 1u); }
         profContacts = mainContacts * iters;
@@ -1839,7 +1857,7 @@ MI_API int mi_world_save_checkpoint(mi_world* w, void* out, uint64_t capacity, u
     HIP_TRY(hipSetDevice(w->device));
     int rc = w->download(); if (rc != MI_OK) return rc;
     std::vector<unsigned long long> keys; std::vector<uint32_t> vals;
-    if (w->tabValid && !w->topologyDirty) {
+    if (w->tabValid) {   // also with a pending topology edit: the keys are creation indices, the live world keeps the history across it
         const size_t cap = (size_t)w->tabMask[w->tabCur] + 1;
         std::vector<unsigned long long> k(cap); std::vector<uint32_t> v(cap);
         HIP_TRY(hipMemcpy(k.data(), w->tabKeys[w->tabCur].p, cap * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1883,61 +1901,102 @@ MI_API int mi_world_save_checkpoint(mi_world* w, void* out, uint64_t capacity, u
 MI_API int mi_world_load_checkpoint(mi_world* w, const void* data, uint64_t size) {
     if (!w || !data) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     HIP_TRY(hipSetDevice(w->device));
-    const uint8_t* p = static_cast<const uint8_t*>(data); const uint8_t* end = p + size;
-    CheckpointHeader h;
-    if (!take(p, end, &h, 1) || h.magic != kCheckpointMagic || h.version != 1) return fail(MI_ERR_INVALID_ARGUMENT, "not a checkpoint of this library version");
-    JointSet& j = w->joints;
-    const uint32_t jc[6] = {(uint32_t)j.distance.pods.size(), (uint32_t)j.ball.pods.size(), (uint32_t)j.fixed.pods.size(), (uint32_t)j.hinge.pods.size(), (uint32_t)j.cone.pods.size(), (uint32_t)j.slider.pods.size()};
-    if (h.numEntities != w->entities.size() || h.numBodies != w->bodies.size() || h.numColliders != w->colliders.size() || std::memcmp(jc, h.jointCounts, sizeof(jc)) != 0)
-        return fail(MI_ERR_INVALID_ARGUMENT, "checkpoint belongs to a different scene (entity / body / collider / constraint counts differ)");
-    int rc = w->download(); if (rc != MI_OK) return rc;   // the host copy becomes authoritative; everything is re-sent before the next step
-    bool okay = true;
-    for (HEntity& e : w->entities) okay = okay && take(p, end, &e.pos, 1) && take(p, end, &e.rot, 1);
-    for (HBody& b : w->bodies) okay = okay && take(p, end, &b.p0, 1) && take(p, end, &b.r0, 1) && take(p, end, &b.p1, 1) && take(p, end, &b.r1, 1) && take(p, end, &b.linVel, 1) && take(p, end, &b.angVel, 1) && take(p, end, &b.force, 1) && take(p, end, &b.torque, 1);
-    std::vector<unsigned long long> keys(h.numHistory); std::vector<uint32_t> vals(h.numHistory);
-    okay = okay && take(p, end, keys.data(), keys.size()) && take(p, end, vals.data(), vals.size());
-    w->prevTriggerOverlaps.resize(h.numTriggerOverlaps);
-    okay = okay && take(p, end, w->prevTriggerOverlaps.data(), w->prevTriggerOverlaps.size());
-    okay = okay && takePods(p, end, j.distance) && takePods(p, end, j.ball) && takePods(p, end, j.fixed) && takePods(p, end, j.hinge) && takePods(p, end, j.cone) && takePods(p, end, j.slider);
-    uint32_t numCloths = 0;
-    okay = okay && take(p, end, &numCloths, 1);
-    if (okay && numCloths != w->cloths.size()) return fail(MI_ERR_INVALID_ARGUMENT, "checkpoint belongs to a different scene (cloth count differs)");
-    for (mi_world::HCloth* c : w->cloths) {
-        if (!okay) break;
-        mi_cloth_desc d; float oldMass = 0.f, oldStiff = 0.f;
-        okay = take(p, end, &d, 1) && take(p, end, &oldMass, 1) && take(p, end, &oldStiff, 1);
-        if (okay && (d.grid_size_x != c->desc.grid_size_x || d.grid_size_y != c->desc.grid_size_y)) return fail(MI_ERR_INVALID_ARGUMENT, "checkpoint belongs to a different scene (cloth grid differs)");
-        const uint32_t n = c->desc.grid_size_x * c->desc.grid_size_y;
-        std::vector<float4> buf(4 * (size_t)n);
-        okay = okay && take(p, end, buf.data(), buf.size()) && take(p, end, c->restInvMass.data(), c->restInvMass.size());
-        if (!okay) break;
-        c->desc = d; c->oldTotalMass = oldMass; c->oldStiffness = oldStiff;
-        for (uint32_t i = 0; i < n; ++i) c->invMasses[i] = buf[i].w;
-        HIP_TRY(hipMemcpy(c->pos.p, buf.data(), n * sizeof(float4), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(c->prev.p, buf.data() + n, n * sizeof(float4), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->vel.p, buf.data() + 2 * (size_t)n, n * sizeof(float4), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(c->force.p, buf.data() + 3 * (size_t)n, n * sizeof(float4), hipMemcpyHostToDevice));
-        c->constraintsDirty = true;
-    }
-    w->clothsDirty = true;
-    if (!okay || p != end) return fail(MI_ERR_INVALID_ARGUMENT, "truncated or oversized checkpoint");
-    w->timer = h.timer; w->sapAxis = h.sapAxis; w->eventsEnabled = h.eventsEnabled != 0; w->pendingEvents.clear();
-    w->topologyDirty = true; w->haveEstimates = false;
-    // colour history: same open-addressing layout the kernels probe (tableSlot / linear probing)
-    w->tabValid = !keys.empty();
-    if (w->tabValid) {
-        uint32_t cap = 1024; while (cap < 2u * h.numHistory) cap <<= 1;
-        std::vector<unsigned long long> tk(cap, 0ull); std::vector<uint32_t> tv(cap, 0u);
-        for (uint32_t i = 0; i < h.numHistory; ++i) {
-            uint32_t s_ = (uint32_t)((keys[i] * 0x9E3779B97F4A7C15ull) >> 40) & (cap - 1u);
-            while (tk[s_]) s_ = (s_ + 1u) & (cap - 1u);
-            tk[s_] = keys[i]; tv[s_] = vals[i];
+    // Transactional: the blob is validated against the scene and its own header BEFORE anything is allocated from its counts,
+    // parsed into temporaries, and only committed to the world once it has been consumed completely.  Nothing throws across the ABI.
+    try {
+        const uint8_t* p = static_cast<const uint8_t*>(data); const uint8_t* end = p + size;
+        CheckpointHeader h;
+        if (!take(p, end, &h, 1) || h.magic != kCheckpointMagic || h.version != 1) return fail(MI_ERR_INVALID_ARGUMENT, "not a checkpoint of this library version");
+        JointSet& j = w->joints;
+        const uint32_t jc[6] = {(uint32_t)j.distance.pods.size(), (uint32_t)j.ball.pods.size(), (uint32_t)j.fixed.pods.size(), (uint32_t)j.hinge.pods.size(), (uint32_t)j.cone.pods.size(), (uint32_t)j.slider.pods.size()};
+        if (h.numEntities != w->entities.size() || h.numBodies != w->bodies.size() || h.numColliders != w->colliders.size() || std::memcmp(jc, h.jointCounts, sizeof(jc)) != 0)
+            return fail(MI_ERR_INVALID_ARGUMENT, "checkpoint belongs to a different scene (entity / body / collider / constraint counts differ)");
+        // exact size the header implies (64-bit arithmetic; the cloth section is checked against the world's own cloths)
+        const uint64_t entityBytes = sizeof(w->entities[0].pos) + sizeof(w->entities[0].rot);
+        const uint64_t bodyBytes = sizeof(HBody::p0) + sizeof(HBody::r0) + sizeof(HBody::p1) + sizeof(HBody::r1) + sizeof(HBody::linVel) + sizeof(HBody::angVel) + sizeof(HBody::force) + sizeof(HBody::torque);
+        auto podBytes = [](const auto& t) -> uint64_t { return t.pods.empty() ? 0ull : (uint64_t)t.pods.size() * sizeof(t.pods[0]); };
+        uint64_t expect = sizeof(CheckpointHeader) + (uint64_t)h.numEntities * entityBytes + (uint64_t)h.numBodies * bodyBytes
+                        + (uint64_t)h.numHistory * (sizeof(unsigned long long) + sizeof(uint32_t)) + (uint64_t)h.numTriggerOverlaps * sizeof(w->prevTriggerOverlaps[0])
+                        + podBytes(j.distance) + podBytes(j.ball) + podBytes(j.fixed) + podBytes(j.hinge) + podBytes(j.cone) + podBytes(j.slider) + sizeof(uint32_t);
+        for (const mi_world::HCloth* c : w->cloths) {
+            const uint64_t n = (uint64_t)c->desc.grid_size_x * c->desc.grid_size_y;
+            expect += sizeof(mi_cloth_desc) + 2 * sizeof(float) + 4 * n * sizeof(float4) + (uint64_t)c->restInvMass.size() * sizeof(c->restInvMass[0]);
         }
-        const int c = w->tabCur;
-        HIP_TRY(w->tabKeys[c].ensure(cap)); HIP_TRY(w->tabVals[c].ensure(cap)); w->tabMask[c] = cap - 1u;
-        HIP_TRY(hipMemcpy(w->tabKeys[c].p, tk.data(), cap * sizeof(unsigned long long), hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(w->tabVals[c].p, tv.data(), cap * sizeof(uint32_t), hipMemcpyHostToDevice));
-        w->last.numManifolds = h.numHistory;
+        if (expect != size) return fail(MI_ERR_INVALID_ARGUMENT, "truncated or oversized checkpoint (size does not match its header and this scene)");
+        // ---- parse into temporaries
+        struct EntityState { decltype(HEntity::pos) pos; decltype(HEntity::rot) rot; };
+        struct BodyState { decltype(HBody::p0) p0; decltype(HBody::r0) r0; decltype(HBody::p1) p1; decltype(HBody::r1) r1; decltype(HBody::linVel) linVel, angVel, force, torque; };
+        std::vector<EntityState> es(h.numEntities); std::vector<BodyState> bs(h.numBodies);
+        bool okay = true;
+        for (EntityState& e : es) okay = okay && take(p, end, &e.pos, 1) && take(p, end, &e.rot, 1);
+        for (BodyState& b : bs) okay = okay && take(p, end, &b.p0, 1) && take(p, end, &b.r0, 1) && take(p, end, &b.p1, 1) && take(p, end, &b.r1, 1) && take(p, end, &b.linVel, 1) && take(p, end, &b.angVel, 1) && take(p, end, &b.force, 1) && take(p, end, &b.torque, 1);
+        std::vector<unsigned long long> keys(h.numHistory); std::vector<uint32_t> vals(h.numHistory);
+        okay = okay && take(p, end, keys.data(), keys.size()) && take(p, end, vals.data(), vals.size());
+        auto overlaps = w->prevTriggerOverlaps; overlaps.resize(h.numTriggerOverlaps);
+        okay = okay && take(p, end, overlaps.data(), overlaps.size());
+        auto pDistance = j.distance.pods; auto pBall = j.ball.pods; auto pFixed = j.fixed.pods; auto pHinge = j.hinge.pods; auto pCone = j.cone.pods; auto pSlider = j.slider.pods;
+        auto takeVec = [&](auto& v) { return v.empty() || take(p, end, v.data(), v.size()); };
+        okay = okay && takeVec(pDistance) && takeVec(pBall) && takeVec(pFixed) && takeVec(pHinge) && takeVec(pCone) && takeVec(pSlider);
+        uint32_t numCloths = 0;
+        okay = okay && take(p, end, &numCloths, 1);
+        if (!okay) return fail(MI_ERR_INVALID_ARGUMENT, "truncated checkpoint");
+        if (numCloths != w->cloths.size()) return fail(MI_ERR_INVALID_ARGUMENT, "checkpoint belongs to a different scene (cloth count differs)");
+        struct ClothState { mi_cloth_desc d; float oldMass, oldStiff; std::vector<float4> buf; std::vector<float2> rest; };
+        std::vector<ClothState> cs(w->cloths.size());
+        for (size_t k = 0; k < cs.size(); ++k) {
+            const mi_world::HCloth* c = w->cloths[k]; ClothState& t = cs[k];
+            okay = take(p, end, &t.d, 1) && take(p, end, &t.oldMass, 1) && take(p, end, &t.oldStiff, 1);
+            if (!okay) return fail(MI_ERR_INVALID_ARGUMENT, "truncated checkpoint");
+            if (t.d.grid_size_x != c->desc.grid_size_x || t.d.grid_size_y != c->desc.grid_size_y) return fail(MI_ERR_INVALID_ARGUMENT, "checkpoint belongs to a different scene (cloth grid differs)");
+            const size_t n = (size_t)c->desc.grid_size_x * c->desc.grid_size_y;
+            t.buf.resize(4 * n); t.rest.resize(c->restInvMass.size());
+            if (!take(p, end, t.buf.data(), t.buf.size()) || !take(p, end, t.rest.data(), t.rest.size())) return fail(MI_ERR_INVALID_ARGUMENT, "truncated checkpoint");
+        }
+        if (p != end) return fail(MI_ERR_INVALID_ARGUMENT, "oversized checkpoint");
+        // colour history table: same open-addressing layout the kernels probe (tableSlot / linear probing)
+        uint32_t cap = 1024; while ((uint64_t)cap < 2ull * h.numHistory) cap <<= 1;
+        std::vector<unsigned long long> tk; std::vector<uint32_t> tv;
+        if (h.numHistory) {
+            tk.assign(cap, 0ull); tv.assign(cap, 0u);
+            for (uint32_t i = 0; i < h.numHistory; ++i) {
+                if (!keys[i]) return fail(MI_ERR_INVALID_ARGUMENT, "corrupt checkpoint (null history key)");
+                uint32_t s_ = (uint32_t)((keys[i] * 0x9E3779B97F4A7C15ull) >> 40) & (cap - 1u);
+                while (tk[s_]) s_ = (s_ + 1u) & (cap - 1u);
+                tk[s_] = keys[i]; tv[s_] = vals[i];
+            }
+        }
+        // ---- commit
+        int rc = w->download(); if (rc != MI_OK) return rc;   // the host copy becomes authoritative; everything is re-sent before the next step
+        if (h.numHistory) { const int c = w->tabCur; HIP_TRY(w->tabKeys[c].ensure(cap)); HIP_TRY(w->tabVals[c].ensure(cap)); }
+        for (size_t i = 0; i < es.size(); ++i) { w->entities[i].pos = es[i].pos; w->entities[i].rot = es[i].rot; }
+        for (size_t i = 0; i < bs.size(); ++i) { HBody& b = w->bodies[i]; b.p0 = bs[i].p0; b.r0 = bs[i].r0; b.p1 = bs[i].p1; b.r1 = bs[i].r1; b.linVel = bs[i].linVel; b.angVel = bs[i].angVel; b.force = bs[i].force; b.torque = bs[i].torque; }
+        w->prevTriggerOverlaps = std::move(overlaps);
+        j.distance.pods = std::move(pDistance); j.ball.pods = std::move(pBall); j.fixed.pods = std::move(pFixed); j.hinge.pods = std::move(pHinge); j.cone.pods = std::move(pCone); j.slider.pods = std::move(pSlider);
+        for (size_t k = 0; k < cs.size(); ++k) {
+            mi_world::HCloth* c = w->cloths[k]; ClothState& t = cs[k];
+            const uint32_t n = c->desc.grid_size_x * c->desc.grid_size_y;
+            c->desc = t.d; c->oldTotalMass = t.oldMass; c->oldStiffness = t.oldStiff; c->restInvMass.assign(t.rest.begin(), t.rest.end());
+            for (uint32_t i = 0; i < n; ++i) c->invMasses[i] = t.buf[i].w;
+            HIP_TRY(hipMemcpy(c->pos.p, t.buf.data(), n * sizeof(float4), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(c->prev.p, t.buf.data() + n, n * sizeof(float4), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->vel.p, t.buf.data() + 2 * (size_t)n, n * sizeof(float4), hipMemcpyHostToDevice)); HIP_TRY(hipMemcpy(c->force.p, t.buf.data() + 3 * (size_t)n, n * sizeof(float4), hipMemcpyHostToDevice));
+            c->constraintsDirty = true;
+        }
+        w->clothsDirty = true;
+        w->timer = h.timer; w->sapAxis = h.sapAxis; w->eventsEnabled = h.eventsEnabled != 0; w->pendingEvents.clear();
+        w->topologyDirty = true; w->haveEstimates = false;
+        w->tabValid = h.numHistory != 0;
+        if (w->tabValid) {
+            const int c = w->tabCur; w->tabMask[c] = cap - 1u;
+            HIP_TRY(hipMemcpy(w->tabKeys[c].p, tk.data(), cap * sizeof(unsigned long long), hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(w->tabVals[c].p, tv.data(), cap * sizeof(uint32_t), hipMemcpyHostToDevice));
+            w->last.numManifolds = h.numHistory;
+        }
+        return MI_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(MI_ERR_OUT_OF_MEMORY, "out of host memory while loading a checkpoint");
+    } catch (...) {
+        return fail(MI_ERR_INVALID_ARGUMENT, "checkpoint could not be loaded");
     }
-    return MI_OK;
 }
 
 MI_API int mi_world_enable_events(mi_world* w, uint32_t enable) {

@@ -72,7 +72,9 @@ def reference_available():
 
 
 def build_reference(force=False):
+    """Both builds of the reference: libref.so (strict, the pin) and libref_fast.so (the reference's own AVX2 + fast-math flags, timing only)."""
     from oracle.refbuild import build_ref
+    build_ref.build(force=force, variant="fast")
     return build_ref.build(force=force)
 
 
@@ -84,9 +86,20 @@ def reference_library():
     return _ref_library
 
 
-def create_reference_world(simd=False):
-    """A world stepped by the reference's physicsStep itself (scalar path, or its AVX2 path with simd=True)."""
-    L = reference_library()
+_ref_fast_library = None
+
+
+def create_reference_world(simd=False, fast=False):
+    """A world stepped by the reference's physicsStep itself (scalar path, or its AVX2 path with simd=True).
+    fast=True uses libref_fast.so (timing build, not bit-comparable)."""
+    global _ref_fast_library
+    if fast:
+        if _ref_fast_library is None:
+            build_reference()
+            _ref_fast_library = capi.Library(REF_LIB.with_name("libref_fast.so"), prefix="ref_")
+        L = _ref_fast_library
+    else:
+        L = reference_library()
     h = C.c_void_p()
     L.check(L.fn("world_create")(C.c_int(1 if simd else 0), C.byref(h)), "world_create")
     return capi.World(L, h)

@@ -29,6 +29,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 OUT_DIR = HERE.parent / "_ref"
 OUT = OUT_DIR / "libref.so"
+OUT_FAST = OUT_DIR / "libref_fast.so"     # timing build: the reference's own flags (premake5.lua:266-267: AVX2 + /fp:fast), libm left alone
 REFERENCE_ROOT = Path(os.environ.get("REFERENCE_ROOT", "/root/reference"))
 CLANG = os.environ.get("REF_CXX", "/opt/rocm/lib/llvm/bin/clang++")
 
@@ -134,7 +135,11 @@ SPECIAL = {"core/math.h": _math_h, "core/math_simd.h": _math_simd_h, "scene/scen
            "physics/physics.cpp": _physics_cpp, "physics/collision_broad.cpp": _collision_broad_cpp}
 
 
-def build(force=False, verbose=False, keep=False):
+def build(force=False, verbose=False, keep=False, variant="strict"):
+    """variant "strict": -O2, IEEE float evaluation, transcendental calls routed to ora_det.cpp — what the oracle is pinned to.
+    variant "fast": -O2 -ffast-math -mavx2 -mfma (MSVC /O2 /fp:fast /arch:AVX2; clang -O3 miscompiles or exposes UB here and crashes) with the C library's own libm — the reference as its project file builds it,
+    used only as the timed CPU baseline (bench.py cpu_baseline kind "reference")."""
+    OUT = OUT_FAST if variant == "fast" else globals()["OUT"]
     src_root = REFERENCE_ROOT / "src"
     if not src_root.exists():
         if OUT.exists():
@@ -150,7 +155,8 @@ def build(force=False, verbose=False, keep=False):
             dst = tmp / "src" / rel
             dst.parent.mkdir(parents=True, exist_ok=True)
             dst.write_text(patch_text(rel, (src_root / rel).read_text(encoding="utf-8", errors="replace")))
-        flags = ["-std=c++17", "-O2", "-fPIC", "-fms-extensions", "-ffp-contract=off", "-fno-fast-math", "-mavx2", "-mfma", "-msse4.1",
+        opt = os.environ.get("REF_FAST_FLAGS", "-O2 -ffast-math").split() + ["-DREF_NATIVE_LIBM"] if variant == "fast" else ["-O2", "-ffp-contract=off", "-fno-fast-math"]
+        flags = ["-std=c++17", *opt, "-fPIC", "-fms-extensions", "-mavx2", "-mfma", "-msse4.1",
                  "-fno-lax-vector-conversions", "-DPHYSICS_ONLY", "-fdelayed-template-parsing", "-w", "-include", str(HERE / "ref_pch.h"), "-I", str(HERE / "stubs"), "-I", str(tmp / "src"), "-I", str(tmp / "src" / "physics"), "-I", str(REFERENCE_ROOT / "ext"), "-I", str(HERE.parent.parent / "include")]
         objs = []
         for u in UNITS + ["ref_shim.cpp", "ora_det.cpp"]:
@@ -180,3 +186,4 @@ def build(force=False, verbose=False, keep=False):
 
 if __name__ == "__main__":
     print(build(force=True, verbose="-v" in sys.argv, keep="--keep" in sys.argv))
+    print(build(force=True, verbose="-v" in sys.argv, variant="fast"))

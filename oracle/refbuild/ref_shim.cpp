@@ -199,6 +199,12 @@ REF_API int ref_world_create(int flags, ref_world** out)
 	return MI_OK;
 }
 REF_API void ref_world_destroy(ref_world* w) { delete w; }
+// physics_settings::simdBroadPhase / simdNarrowPhase / simdConstraintSolver (src/physics/physics.h:394-396) can be flipped between steps
+REF_API int ref_world_set_simd(ref_world* w, uint32 enable)
+{
+	w->settings.simdBroadPhase = w->settings.simdNarrowPhase = w->settings.simdConstraintSolver = enable != 0;
+	return MI_OK;
+}
 
 REF_API int ref_entities_create(ref_world* w, uint32 count, const mi_entity_desc* descs, uint32* outFirst)
 {

@@ -325,7 +325,8 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
                                       ({"MI_PERSIST_XCD_MIN": "1"}, 4), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-global"}, 4),
                                       ({"MI_SOLVER": "persist-granules"}, 2), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-granules"}, 4),
                                       ({"MI_PERSIST_XCD_MIN": "1", "MI_PERSIST_XCD_FAULT": "1"}, 2), ({"MI_READBACK": "copy"}, 2),
-                                      ({"MI_PERSIST_WAVES": "8"}, 2), ({"MI_PERSIST_WAVES": "2"}, 2)])
+                                      ({"MI_PERSIST_WAVES": "8"}, 2), ({"MI_PERSIST_WAVES": "2"}, 2),
+                                      ({"MI_SOLVER": "flow", "MI_FLOW_FAULT": "1"}, 0)])
 def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch, env, kind):
     """Every dataflow contact solver gives the same results, bit for bit (which lane / wave / XCD runs a slot is invisible to the
     body-version dataflow):  MI_SOLVER=flow -> k_contact_solve_flow (one workgroup per (sweep, tile), dispatch-ordered; also the
@@ -336,6 +337,8 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
     MI_PERSIST_XCD=0 -> never partitioned;  MI_PERSIST_XCD_FAULT -> one workgroup reports that blockIdx % 8 did not identify its
     XCD: the step is re-run from untouched state and the world continues unpartitioned;  MI_READBACK=copy -> the end-of-step
     read-back as an async copy + stream synchronise instead of the kernel-published record the host spins on;
+    MI_FLOW_FAULT -> the dispatch-ordered kernel reports an exhausted spin budget once (what a shared device can cause): the step
+    is re-run from untouched state with one launch per colour (solver kind 0) and stays there for the next 256 steps;
     MI_PERSIST_WAVES=8 / 2 -> so few persistent workgroups that each owns many tiles: the library itself then moves first the slot
     data and then the impulses out of LDS (the choices it makes for piles of 0.5 M / 1.2 M manifolds and more)."""
     for k, v in env.items():

@@ -137,3 +137,43 @@ def test_gpu_checkpoint_resume_is_bit_identical(mi_lib, oracle_mod, make, events
         scenes.obb_pile(3, 2, 3).populate(mi_lib.create_world(0)).load_checkpoint(blob)     # other scene
     with pytest.raises(mi_lib.PhysicsError):
         b.load_checkpoint(blob[:-8])                                                         # truncated
+
+
+@pytest.mark.gpu
+def test_gpu_rejected_checkpoint_leaves_the_world_untouched(mi_lib, oracle_mod):
+    """mi_world_load_checkpoint validates the blob against its own header and the scene BEFORE it allocates or overwrites anything:
+    truncated, oversized and corrupt-header blobs (history / overlap counts in the billions) are refused with an error status, and
+    the world that refused them continues bit-identically to one that never saw them.  A checkpoint taken while a topology edit is
+    pending keeps the colour history, like the live world does."""
+    import struct
+    sc = scenes.obb_pile(8, 4, 8, spacing=1.0)
+    s = sc.settings()
+    a = sc.populate(mi_lib.create_world(0)); b = sc.populate(mi_lib.create_world(0)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    for w in (a, b, o):
+        w.step_fixed(s, sc.dt, 60)
+    blob = a.save_checkpoint()
+    words = list(struct.unpack_from("<8I", blob, 0))        # magic, version, numEntities, numBodies, numColliders, numHistory, numTriggerOverlaps, sapAxis
+    bad = [blob[:-1], blob + b"\0", blob[: len(blob) // 2], b"", blob[:16]]
+    for idx, val in ((5, 0xFFFFFFF0), (5, 0x7FFFFFFF), (6, 0xFFFFFFFF), (5, words[5] + 1), (2, words[2] + 1)):
+        w2 = list(words); w2[idx] = val
+        bad.append(struct.pack("<8I", *w2) + blob[32:])
+    for k, x in enumerate(bad):
+        with pytest.raises(mi_lib.PhysicsError):
+            a.load_checkpoint(x)
+    for i in range(40):
+        for w in (a, b, o):
+            w.step_fixed(s, sc.dt, 1)
+        assert a.counts() == b.counts() == o.counts(), f"step {i}"
+    assert a.physics_transforms()[0].tobytes() == b.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
+    # save with a pending topology edit (a force applied through the host path marks nothing dirty; adding a collider does)
+    e = scenes.make_entities(1); e["position"][0] = (0.0, 30.0, 0.0)
+    c = scenes.make_colliders(1, capi.SPHERE); c["shape"][0, :4] = (0, 0, 0, 0.4)
+    for w in (a, o):
+        first = w.create_entities(e); w.add_colliders([first], c)
+    blob2 = a.save_checkpoint()
+    words2 = struct.unpack_from("<8I", blob2, 0)
+    assert words2[5] > 0, "colour history dropped from a checkpoint taken with a pending topology edit"
+    for i in range(30):
+        a.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        assert a.counts() == o.counts(), f"after edit, step {i}"
+    assert a.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
