@@ -74,6 +74,20 @@ uint32_t jointsCount(const World& w) {
     return (uint32_t)(j.distance.pods.size() + j.ball.pods.size() + j.fixed.pods.size() + j.hinge.pods.size() + j.cone.pods.size() + j.slider.pods.size());
 }
 
+int jointsLoadPods(World& w, const uint8_t*& p, const uint8_t* end, const uint32_t counts[6]) {
+    JointStore& j = *w.joints;
+    auto load = [&](auto& list, uint32_t n) {
+        if (n != list.pods.size()) return false;
+        const size_t bytes = list.pods.size() * sizeof(list.pods[0]);
+        if ((size_t)(end - p) < bytes) return false;
+        if (bytes) std::memcpy(list.pods.data(), p, bytes);
+        p += bytes;
+        return true;
+    };
+    bool okay = load(j.distance, counts[0]) && load(j.ball, counts[1]) && load(j.fixed, counts[2]) && load(j.hinge, counts[3]) && load(j.cone, counts[4]) && load(j.slider, counts[5]);
+    return okay ? MI_OK : MI_ERR_INVALID_ARGUMENT;
+}
+
 static inline vec3 v3(const float* f) { return vec3(f[0], f[1], f[2]); }
 static inline quat q4(const float* f) { return quat(f[0], f[1], f[2], f[3]); }
 static inline void st3(float* f, vec3 v) { f[0] = v.x; f[1] = v.y; f[2] = v.z; }

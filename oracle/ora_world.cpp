@@ -1214,6 +1214,55 @@ MI_API int ora_world_get_manifold_colors(World* w, uint32_t* out, uint32_t cap) 
     for (size_t i = 0; i < w->manifoldColor.size(); ++i) out[i] = w->manifoldColor[i];
     return MI_OK;
 }
+// Loads a checkpoint blob written by the PRODUCT (mi_world_save_checkpoint, d3d12renderer_amd/csrc/world.hip: header, entity
+// transforms, body states, colour history as (key + 1, colour) pairs, trigger overlaps, constraint PODs in pool order, cloths)
+// into an oracle world built from the same scene, so that the GPU can settle a full-size scene (where the oracle would take
+// minutes) and both continue from the same state.  Cloth sections are not supported (MI_ERR_UNSUPPORTED).
+extern "C++" {
+namespace {
+struct CheckpointHeader { uint32_t magic, version, numEntities, numBodies, numColliders, numHistory, numTriggerOverlaps, sapAxis; float timer; uint32_t eventsEnabled, jointCounts[6], reserved; };
+template <class T> bool take(const uint8_t*& p, const uint8_t* end, T* out, size_t n) { if ((size_t)(end - p) < n * sizeof(T)) return false; std::memcpy(out, p, n * sizeof(T)); p += n * sizeof(T); return true; }
+}
+}
+MI_API int ora_world_load_checkpoint(World* w, const void* data, uint64_t size) {
+    if (!w || !data) return MI_ERR_INVALID_ARGUMENT;
+    const uint8_t* p = static_cast<const uint8_t*>(data); const uint8_t* end = p + size;
+    CheckpointHeader h;
+    if (!take(p, end, &h, 1) || h.magic != 0x4350494Du || h.version != 1) return MI_ERR_INVALID_ARGUMENT;
+    if (h.numEntities != w->entities.size() || h.numBodies != w->bodies.size() || h.numColliders != w->colliders.size()) return MI_ERR_INVALID_ARGUMENT;
+    if (w->dirtyProps) w->recalculateProperties();
+    struct F3 { float x, y, z; }; struct F4 { float x, y, z, w; };
+    bool okay = true;
+    for (Entity& e : w->entities) { F3 pos; F4 rot; okay = okay && take(p, end, &pos, 1) && take(p, end, &rot, 1); if (okay) { e.position = vec3(pos.x, pos.y, pos.z); e.rotation = quat(rot.x, rot.y, rot.z, rot.w); } }
+    for (RigidBody& b : w->bodies) {
+        F3 p0, p1, lv, av, f, t; F4 r0, r1;
+        okay = okay && take(p, end, &p0, 1) && take(p, end, &r0, 1) && take(p, end, &p1, 1) && take(p, end, &r1, 1) && take(p, end, &lv, 1) && take(p, end, &av, 1) && take(p, end, &f, 1) && take(p, end, &t, 1);
+        if (!okay) break;
+        b.p0 = vec3(p0.x, p0.y, p0.z); b.r0 = quat(r0.x, r0.y, r0.z, r0.w); b.p1 = vec3(p1.x, p1.y, p1.z); b.r1 = quat(r1.x, r1.y, r1.z, r1.w);
+        b.linearVelocity = vec3(lv.x, lv.y, lv.z); b.angularVelocity = vec3(av.x, av.y, av.z); b.forceAccumulator = vec3(f.x, f.y, f.z); b.torqueAccumulator = vec3(t.x, t.y, t.z);
+    }
+    std::vector<unsigned long long> keys(h.numHistory); std::vector<uint32_t> vals(h.numHistory);
+    okay = okay && take(p, end, keys.data(), keys.size()) && take(p, end, vals.data(), vals.size());
+    std::vector<uint64_t> overlaps(h.numTriggerOverlaps);
+    okay = okay && take(p, end, overlaps.data(), overlaps.size());
+    if (!okay) return MI_ERR_INVALID_ARGUMENT;
+    int rc = jointsLoadPods(*w, p, end, h.jointCounts);
+    if (rc != MI_OK) return rc;
+    uint32_t numCloths = 0;
+    if (!take(p, end, &numCloths, 1)) return MI_ERR_INVALID_ARGUMENT;
+    if (numCloths != 0 || !w->cloths.empty()) return MI_ERR_UNSUPPORTED;
+    if (p != end) return MI_ERR_INVALID_ARGUMENT;
+    w->timer = h.timer; w->sortingAxis = h.sapAxis; w->eventsEnabled = h.eventsEnabled != 0; w->events.clear();
+    w->prevTriggerOverlaps.assign(overlaps.begin(), overlaps.end());
+    w->prevPairColor.clear(); w->prevCollisionKeys.clear();
+    for (uint32_t i = 0; i < h.numHistory; ++i) {
+        const uint64_t key = keys[i] - 1ull;                       // the device table stores key + 1 (0 = empty slot)
+        w->prevPairColor[key] = vals[i];
+        if (w->eventsEnabled && (key & ((1ull << 26) - 1ull)) < kHeightmapVirtualBase) w->prevCollisionKeys.push_back(key);
+    }
+    std::sort(w->prevCollisionKeys.begin(), w->prevCollisionKeys.end());
+    return MI_OK;
+}
 MI_API float ora_det_atan2f(float y, float x) { return det_atan2f(y, x); }
 MI_API float ora_det_acosf(float x) { return det_acosf(x); }
 MI_API float ora_det_sinf(float x) { return det_sinf(x); }

@@ -202,6 +202,7 @@ int jointsAddFromGlobal(World& w, uint32_t type, uint32_t ea, uint32_t eb, const
 void jointsInitialize(World& w, float dt);
 void jointsSolveIteration(World& w);
 uint32_t jointsCount(const World& w);
+int jointsLoadPods(World& w, const uint8_t*& p, const uint8_t* end, const uint32_t counts[6]);   // checkpoint: PODs of all six types in pool order
 
 uint32_t hash32(uint32_t m);  // joint colouring priority
 uint64_t pairPriority(uint32_t a, uint32_t b);  // contact-manifold colouring priority

@@ -4,10 +4,12 @@ from pathlib import Path
 
 raw = Path(sys.argv[1]); out = Path(sys.argv[2]); out.mkdir(parents=True, exist_ok=True)
 # 1. kernel stats csv: copy (small)
-ks = raw / "stats" / "r01_kernel_stats.csv"
+found = sorted((raw / "stats").glob("*_kernel_stats.csv"))
+ks = found[0] if found else raw / "stats" / "missing"
+prefix = ks.name.replace("_kernel_stats.csv", "") if found else "r02"
 if ks.exists():
     rows = list(csv.reader(open(ks)))
-    with open(out / "r01_kernel_stats.csv", "w", newline="") as f:
+    with open(out / f"{prefix}_kernel_stats.csv", "w", newline="") as f:
         w = csv.writer(f)
         for r in rows:
             r[0] = r[0][:110]
@@ -15,9 +17,10 @@ if ks.exists():
 # 2. PMC: per-kernel mean of the counter
 summary = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
-    p = raw / ("pmc_fetch" if name == "FETCH_SIZE" else "pmc_write") / "r01_counter_collection.csv"
-    if not p.exists():
+    cand = sorted((raw / ("pmc_fetch" if name == "FETCH_SIZE" else "pmc_write")).glob("*_counter_collection.csv"))
+    if not cand:
         continue
+    p = cand[0]
     vals = collections.defaultdict(list)
     with open(p) as f:
         rd = csv.DictReader(f)
@@ -28,7 +31,7 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
     # steady state = the last quarter of a kernel's dispatches (the pile is settling during the warm-up steps)
     summary[name] = {k: {"mean": sum(v) / len(v), "steady_mean": sum(v[-max(1, len(v) // 4):]) / max(1, len(v) // 4),
                          "dispatches": len(v), "sum": sum(v)} for k, v in vals.items()}
-json.dump(summary, open(out / "r01_pmc_summary.json", "w"), indent=1)
+json.dump(summary, open(out / f"{prefix}_pmc_summary.json", "w"), indent=1)
 print(json.dumps({n: {k: round(v["steady_mean"], 1) for k, v in d.items() if "contact_solve" in k or "narrow" in k or "pairs_grid" in k} for n, d in summary.items()}))
 # HBM traffic of the dominant kernel(s), per launch, steady state.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 # reports half the bytes of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE as reported.
