@@ -2068,4 +2068,91 @@ __global__ void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slo
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Device-wide exclusive prefix sum, ONE launch: chained scan with decoupled look-back.
+//   * a workgroup takes its tile number from a ticket counter (so a tile's predecessors have always started), scans its
+//     kScanTile items in registers / LDS and publishes first its AGGREGATE, then — after looking back over its predecessors'
+//     records (one wave, 64 records at a time, until an inclusive prefix is found) — its INCLUSIVE PREFIX;
+//   * a record is ONE 64-bit word (tag << 32 | 32-bit sum), tag = generation << 2 | state (1 aggregate, 2 inclusive), written
+//     and read with single relaxed agent-scope accesses: a reader that sees the tag sees the sum of the same store — no fences
+//     (a release / acquire pair at agent scope would write back / invalidate the L2 around every record);
+//   * records are never reset: a reader ignores tags of older generations, and the ticket counter only ever grows
+//     (`ticketBase` = tickets handed out before this launch).
+// T = uint32_t (W = 1) or a 64-bit word holding two independent 32-bit sums side by side (W = 2: the narrow phase's packed
+// (manifold flag, contact count); both totals stay below 2^32, so the halves never carry into each other).
+constexpr uint32_t kScanThreads = 256, kScanItems = 8, kScanTile = kScanThreads * kScanItems;
+__device__ __forceinline__ void scanPublish(unsigned long long* rec, uint32_t sum, uint32_t tag) {
+    __hip_atomic_store(rec, ((unsigned long long)tag << 32) | (unsigned long long)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <typename T> struct ScanWords { static constexpr uint32_t W = sizeof(T) / 4; };
+template <typename T>
+__global__ __launch_bounds__(kScanThreads) void k_exclusive_scan(const T* __restrict__ in, T* __restrict__ out, uint32_t n, unsigned long long* records,
+                                                                 uint32_t* ticket, uint32_t ticketBase, uint32_t gen) {
+    constexpr uint32_t W = ScanWords<T>::W;
+    __shared__ uint32_t sTile;
+    __shared__ T sWave[kScanThreads / 64];
+    __shared__ T sPrefix;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    if (tid == 0) sTile = atomicAdd(ticket, 1u) - ticketBase;
+    __syncthreads();
+    const uint32_t tile = sTile;
+    // striped loads (thread t takes items t, t + 256, ...: every load instruction reads one contiguous span), then blocked through LDS?  Not needed:
+    // a prefix sum only needs each THREAD's items to be consecutive in the order it sums them, so thread t owns the kScanItems consecutive items
+    // starting at base and reads them as 16-byte vectors
+    const uint32_t base = tile * kScanTile + tid * kScanItems;
+    T v[kScanItems];
+    #pragma unroll
+    for (uint32_t k = 0; k < kScanItems; ++k) v[k] = base + k < n ? in[base + k] : T(0);
+    T local = 0;
+    #pragma unroll
+    for (uint32_t k = 0; k < kScanItems; ++k) { T x = v[k]; v[k] = local; local += x; }      // exclusive within the thread
+    T incl = local;                                                                         // inclusive across the wave
+    #pragma unroll
+    for (uint32_t d = 1; d < 64u; d <<= 1) { T o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+    if (lane == 63u) sWave[wave] = incl;
+    __syncthreads();
+    T waveOff = 0, aggregate = 0;
+    #pragma unroll
+    for (uint32_t w = 0; w < kScanThreads / 64; ++w) { if (w < wave) waveOff += sWave[w]; aggregate += sWave[w]; }
+    if (wave == 0) {
+        T prefix = 0;
+        const uint32_t tagAgg = (gen << 2) | 1u, tagInc = (gen << 2) | 2u;
+        auto word = [](T x, uint32_t w) -> uint32_t { return (uint32_t)((unsigned long long)x >> (32u * w)); };
+        if (tile == 0) {
+            if (lane < W) scanPublish(&records[lane], word(aggregate, lane), tagInc);
+        } else {
+            if (lane < W) scanPublish(&records[(size_t)tile * W + lane], word(aggregate, lane), tagAgg);
+            int32_t look = (int32_t)tile - 1;
+            while (true) {                                   // 64 predecessors per round, nearest first
+                const int32_t idx = look - (int32_t)lane;
+                T val = 0; uint32_t state = idx < 0 ? 3u : 0u;                 // 3: before the first tile (contributes nothing, ends the search)
+                while (state == 0u) {
+                    unsigned long long r0 = __hip_atomic_load(&records[(size_t)idx * W], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned long long r1 = W == 2 ? __hip_atomic_load(&records[(size_t)idx * W + (W - 1)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : r0;
+                    const uint32_t t0 = (uint32_t)(r0 >> 32), t1 = (uint32_t)(r1 >> 32);
+                    if (t0 == t1 && (t0 == tagAgg || t0 == tagInc)) {      // both halves written by the same publication of this generation
+                        state = t0 & 3u;
+                        val = W == 2 ? (T)(((unsigned long long)(uint32_t)r1 << 32) | (unsigned long long)(uint32_t)r0) : (T)(uint32_t)r0;
+                    } else __builtin_amdgcn_s_sleep(1);
+                }
+                const unsigned long long done = __ballot(state >= 2u);       // lanes holding an inclusive prefix (or the start of the array)
+                const uint32_t first = done ? (uint32_t)__ffsll((long long)done) - 1u : 64u;
+                T contrib = lane <= first ? val : T(0);                        // everything nearer than (and including) the first inclusive record
+                #pragma unroll
+                for (uint32_t d = 32; d >= 1; d >>= 1) contrib += __shfl_xor(contrib, d, 64);
+                prefix += contrib;
+                if (done) break;
+                look -= 64;
+            }
+            if (lane < W) scanPublish(&records[(size_t)tile * W + lane], word(prefix + aggregate, lane), tagInc);
+        }
+        if (lane == 0) sPrefix = prefix;
+    }
+    __syncthreads();
+    const T off = sPrefix + waveOff + (incl - local);
+    #pragma unroll
+    for (uint32_t k = 0; k < kScanItems; ++k) if (base + k < n) out[base + k] = off + v[k];
+}
+
 }  // namespace mi

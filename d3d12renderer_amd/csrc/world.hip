@@ -14,7 +14,6 @@
 #include <algorithm>
 #include <type_traits>
 #include <hip/hip_runtime.h>
-#include <rocprim/rocprim.hpp>
 
 #include "../../include/mi_physics.h"
 #include "../../include/mi_constraints.h"
@@ -54,6 +53,28 @@ struct DBuf {
         if (p) (void)hipFree(p);
         p = np; cap = ncap;
         return hipSuccess;
+    }
+};
+
+// One scan site: the record arrays, ticket counter and generation of k_exclusive_scan (kernels.hpp).  Nothing is reset between
+// launches; the records are zeroed when (re)allocated and when the 32-bit generation wraps.
+template <typename T>
+struct DeviceScan {
+    DBuf<unsigned long long> records; DBuf<uint32_t> ticket;
+    uint32_t ticketBase = 0, gen = 0;
+    hipError_t run(const T* in, T* out, uint32_t n, hipStream_t st) {
+        const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+        if (!tiles) return hipSuccess;
+        hipError_t e;
+        if (!ticket.p) { if ((e = ticket.ensure(1)) != hipSuccess) return e; if ((e = hipMemsetAsync(ticket.p, 0, sizeof(uint32_t), st)) != hipSuccess) return e; ticketBase = 0; }
+        bool clear = false;
+        if (++gen >= (1u << 30)) { gen = 1u; clear = true; }       // the tag holds 30 generation bits
+        const size_t words = (size_t)tiles * ScanWords<T>::W;
+        if (records.cap < words) { if ((e = records.ensure(words)) != hipSuccess) return e; clear = true; }
+        if (clear && (e = hipMemsetAsync(records.p, 0, records.cap * sizeof(unsigned long long), st)) != hipSuccess) return e;
+        k_exclusive_scan<T><<<tiles, kScanThreads, 0, st>>>(in, out, n, records.p, ticket.p, ticketBase, gen);
+        ticketBase += tiles;
+        return hipGetLastError();
     }
 };
 
@@ -105,7 +126,7 @@ struct mi_world {
     StepScalars* scalarsPtr() { return reinterpret_cast<StepScalars*>(scalarsRaw.p); }
     uint32_t* roundFlagsPtr() { return reinterpret_cast<uint32_t*>(scalarsRaw.p + sizeof(StepScalars)); }
     DBuf<uint64_t> pairKeys, pairKeysS;
-    DBuf<char> temp;
+    DeviceScan<uint32_t> scanCells, scanBins; DeviceScan<unsigned long long> scanPairs, scanTerrain;   // one per scan site (own tickets / generations)
     // narrow phase
     DBuf<uint64_t> npPacked, npScan; DBuf<float4> npNormal, npPoints; DBuf<BoxHit> boxQueue;
     DBuf<uint32_t> manPair; DBuf<uint2> manBodies, manInfo; DBuf<uint4> colWork;
@@ -190,7 +211,6 @@ struct mi_world {
     bool specEnabled = true, haveEstimates = false;
     uint32_t specRetries = 0, specSteps = 0, totalSteps = 0, colorRoundsLaunched = 0;
     uint32_t sapAxis = 0;        // sorting axis for the next step (collision_broad.cpp:443-444), host copy
-    int ensureTemp(size_t bytes) { return temp.ensure(bytes) == hipSuccess ? MI_OK : MI_ERR_OUT_OF_MEMORY; }
 };
 
 int mi_world::init(int dev) {
@@ -730,10 +750,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         if (heightmap) {   // terrain contacts per collider, their offsets and totals (they join the pair list after the collider-pair narrow phase)
             k_hm_contacts<false><<<divUp(nc, 4), 256, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
             k_hm_slow<false><<<divUp(nc, 64), 64, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
-            size_t tb = 0;
-            HIP_TRY(rocprim::exclusive_scan(nullptr, tb, hmPacked.p, hmScan.p, 0ull, (size_t)nc, rocprim::plus<unsigned long long>(), st));
-            if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
-            HIP_TRY(rocprim::exclusive_scan(temp.p, tb, hmPacked.p, hmScan.p, 0ull, (size_t)nc, rocprim::plus<unsigned long long>(), st));
+            HIP_TRY(scanTerrain.run(hmPacked.p, hmScan.p, nc, st));
             k_hm_totals<<<1, 1, 0, st>>>(nc, hmPacked.p, hmScan.p, sc);
         }
     }
@@ -750,10 +767,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         k_bp_grid_setup<<<1, 256, 0, st>>>(nc, nblk, cellCap, blockBounds.p, sc, grid.p);
         HIP_TRY(hipMemsetAsync(cellCount.p, 0, (size_t)cellCap * sizeof(uint32_t), st));
         k_bp_cell_ids<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, isLarge.p, grid.p, cellKeys.p, cellRanks.p, cellCount.p);
-        size_t tb = 0;
-        HIP_TRY(rocprim::exclusive_scan(nullptr, tb, cellCount.p, cellLower.p, 0u, (size_t)cellCap, rocprim::plus<uint32_t>(), st));
-        if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
-        HIP_TRY(rocprim::exclusive_scan(temp.p, tb, cellCount.p, cellLower.p, 0u, (size_t)cellCap, rocprim::plus<uint32_t>(), st));
+        HIP_TRY(scanCells.run(cellCount.p, cellLower.p, cellCap, st));
         k_bp_scatter_sorted<<<divUp(nc, B), B, 0, st>>>(nc, cellKeys.p, cellRanks.p, cellLower.p, aabbMin.p, aabbMax.p, cellKeysS.p, cellValsS.p, sMin.p, sMax.p);
         if (pairKeys.cap == 0) { HIP_TRY(pairKeys.ensure(std::max<size_t>(1u << 16, 8 * (size_t)nc))); }
         if (spec) { HIP_TRY(pairKeys.ensure(bound(last.numPairs, 4096))); }
@@ -799,10 +813,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             k_hm_slow<true><<<divUp(nc, 64), 64, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut);
             k_hm_finish<<<1, 1, 0, st>>>(sc, pairBound);
         }
-        size_t tb = 0;
-        HIP_TRY(rocprim::exclusive_scan(nullptr, tb, npPacked.p, npScan.p, (uint64_t)0, pairBound, rocprim::plus<uint64_t>(), st));
-        if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
-        HIP_TRY(rocprim::exclusive_scan(temp.p, tb, npPacked.p, npScan.p, (uint64_t)0, pairBound, rocprim::plus<uint64_t>(), st));
+        HIP_TRY(scanPairs.run(reinterpret_cast<const unsigned long long*>(npPacked.p), reinterpret_cast<unsigned long long*>(npScan.p), pairBound, st));
         if (eventsEnabled) HIP_TRY(manIsNew.ensure(pairBound));
         k_emit_manifolds<<<divUp(pairBound, B), B, 0, st>>>(nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
@@ -849,10 +860,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                 k_color_round<<<divUp(nmBound, B), B, 0, st>>>(sc, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlagsPtr());
             // schedule bins -> tiles (valid once the last round left nothing uncoloured: StepScalars::colorPending)
             k_bin_hist<<<binBlocks, 256, 0, st>>>(sc, binBlocks, perm, color.p, manInfo.p, blockHist.p);
-            size_t tb = 0;
-            HIP_TRY(rocprim::exclusive_scan(nullptr, tb, blockHist.p, blockScan.p, 0u, (size_t)kColorBins * binBlocks, rocprim::plus<uint32_t>(), st));
-            if (ensureTemp(tb) != MI_OK) return fail(MI_ERR_OUT_OF_MEMORY, "temp storage");
-            HIP_TRY(rocprim::exclusive_scan(temp.p, tb, blockHist.p, blockScan.p, 0u, (size_t)kColorBins * binBlocks, rocprim::plus<uint32_t>(), st));
+            HIP_TRY(scanBins.run(blockHist.p, blockScan.p, kColorBins * binBlocks, st));
             k_bin_scatter<<<binBlocks, 256, 0, st>>>(round - 1, roundFlagsPtr(), binBlocks, perm, color.p, manInfo.p, blockScan.p, order.p, sc);
             k_build_tiles<<<1, 256, 0, st>>>(tilesCap, ctCap, sc, binInfo.p, xcdPlan ? xcdBase.p : nullptr);
             k_fill_tiles<<<divUp(tilesCap, B), B, 0, st>>>(sc, binInfo.p, tileBin.p, tileDesc.p, xcdBase.p, xcdPlan ? xcdTiles.p : nullptr, xcdListCap);
