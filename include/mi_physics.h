@@ -68,6 +68,7 @@ typedef enum mi_constraint_type {
     MI_CONSTRAINT_TYPE_COUNT = 6
 } mi_constraint_type;
 
+enum { MI_ENTITY_DESTROYED = 0xFFFFFFFFu };   /* kind of an entity slot after mi_entity_destroy (read-back only) */
 enum { MI_ENTITY_DYNAMIC = 0, MI_ENTITY_KINEMATIC = 1, MI_ENTITY_STATIC = 2,
        MI_ENTITY_TRIGGER = 3,        /* transform + trigger_component (src/physics/physics.h:200-203): colliders report enter / leave */
        MI_ENTITY_FORCE_FIELD = 4 };  /* transform + force_field_component (src/physics/physics.h:182-185): see mi_entity_set_force */
@@ -171,6 +172,16 @@ MI_API void mi_world_destroy(mi_world* world);
 /* addRigidBody  <->  createEntity().addComponent<transform_component>()...addComponent<rigid_body_component>() */
 MI_API int mi_entity_create(mi_world* world, const mi_entity_desc* desc, uint32_t* out_entity);
 MI_API int mi_entities_create(mi_world* world, uint32_t count, const mi_entity_desc* descs, uint32_t* out_first_entity);
+/*
+ * game_scene::deleteEntity (src/scene/scene.cpp:124-150): the entity's colliders (removeColliderFromBroadphase,
+ * src/physics/collision_broad.cpp:62-75), its constraints (deleteAllConstraintsFromEntity) and its rigid body / trigger / force field
+ * go.  EnTT pool semantics decide the order everything else is processed in afterwards: in every component pool the LAST element
+ * moves into the freed slot (rigid bodies, colliders — hence collider ids reported by events are pool positions and change for the
+ * moved collider —, triggers, force fields).  Entity ids stay valid; the destroyed id is never reused.  The colour history and the
+ * previous-step collision / trigger lists (which are keyed by pool positions) restart, so the next step reports every live
+ * collision as begun again.
+ */
+MI_API int mi_entity_destroy(mi_world* world, uint32_t entity);
 /* addComponent<collider_component>(collider_component::asXxx(shape, material)) (src/scene/scene.h:38-65). */
 MI_API int mi_collider_add(mi_world* world, uint32_t entity, const mi_collider_desc* desc, uint32_t* out_collider);
 MI_API int mi_colliders_add(mi_world* world, uint32_t count, const uint32_t* entities, const mi_collider_desc* descs);

@@ -158,6 +158,14 @@ int jointsDestroyOfEntity(World& w, uint32_t entity) {
     for (const Hit& h : hits) jointsDestroy(w, h.type, h.handle);
     return MI_OK;
 }
+// A rigid body moved inside the body pool (swap-and-pop on deletion): the reference derives a constraint's body pair from its
+// entities every step (getConstraintBodyPairs, physics.cpp:789-806), here the cached pair is re-pointed.
+void jointsRemapBody(World& w, uint32_t from, uint32_t to) {
+    JointStore& j = *w.joints;
+    auto fix = [&](auto& l) { for (Pair& b : l.bodies) { if (b.a == from) b.a = to; if (b.b == from) b.b = to; } };
+    fix(j.distance); fix(j.ball); fix(j.fixed); fix(j.hinge); fix(j.cone); fix(j.slider);
+    j.orderDirty = true;
+}
 int jointsUpdate(World& w, uint32_t type, uint32_t id, const void* pod, uint32_t bytes) {
     JointStore& j = *w.joints;
     switch (type) {

@@ -883,6 +883,59 @@ void World::step(const mi_step_settings& settings, float dt) {
 
 }  // namespace ora
 
+// game_scene::deleteEntity — src/scene/scene.cpp:124-150 with EnTT's pool semantics: every component pool is a packed array, erase =
+// swap with the last element and pop.  Colliders are walked newest first (the entity's linked list), each leaves the SAP
+// endpoint array (removeColliderFromBroadphase / removeEndpoint, collision_broad.cpp:42-75: the LAST endpoint moves into the
+// freed slot) and the collider pool; then the entity's constraints go (deleteAllConstraintsFromEntity), then its rigid body,
+// trigger or force-field component.  Entity ids of the ABI stay valid (the slot becomes a tombstone).  The colour history and
+// the previous collision / trigger-overlap lists are dropped: they are keyed by pool positions, which just changed
+// (the reference keeps its previous-frame list and would compare shifted indices; documented deviation).
+namespace ora {
+int World::destroyEntity(uint32_t entity) {
+    if (entity >= entities.size() || entities[entity].kind == MI_ENTITY_DESTROYED) return MI_ERR_INVALID_ARGUMENT;
+    Entity& e = entities[entity];
+    auto removeEndpoint = [&](uint32_t index) {
+        SapEndpoint last = endpoints.back();
+        endpoints[index] = last;
+        if (last.start) startEndpoint[last.creation] = index; else endEndpoint[last.creation] = index;
+        endpoints.pop_back();
+    };
+    const std::vector<uint32_t> mine = e.colliders;      // newest first
+    for (size_t k = 0; k < mine.size(); ++k) {
+        // ids of colliders that were moved by earlier removals of this loop have been patched in `live` below
+        uint32_t id = entities[entity].colliders[0];
+        removeEndpoint(startEndpoint[id]);
+        removeEndpoint(endEndpoint[id]);
+        const uint32_t last = (uint32_t)colliders.size() - 1;
+        entities[entity].colliders.erase(entities[entity].colliders.begin());
+        if (id != last) {                                   // the last collider of the pool moves into the freed slot
+            colliders[id] = colliders[last];
+            startEndpoint[id] = startEndpoint[last]; endEndpoint[id] = endEndpoint[last];
+            endpoints[startEndpoint[id]].creation = id; endpoints[endEndpoint[id]].creation = id;
+            for (uint32_t& c : entities[colliders[id].entity].colliders) if (c == last) c = id;
+        }
+        colliders.pop_back(); startEndpoint.pop_back(); endEndpoint.pop_back();
+    }
+    jointsDestroyOfEntity(*this, entity);
+    if (e.rb >= 0) {
+        const uint32_t p = (uint32_t)e.rb, last = (uint32_t)bodies.size() - 1;
+        if (p != last) { bodies[p] = bodies[last]; entities[bodies[p].entity].rb = (int)p; jointsRemapBody(*this, last, p); }
+        bodies.pop_back();
+    }
+    auto dropFrom = [&](std::vector<uint32_t>& pool) {      // trigger_component / force_field_component pools
+        const uint32_t p = e.kindIndex, last = (uint32_t)pool.size() - 1;
+        if (p != last) { pool[p] = pool[last]; entities[pool[p]].kindIndex = p; }
+        pool.pop_back();
+    };
+    if (e.kind == MI_ENTITY_TRIGGER) dropFrom(triggerEntities);
+    if (e.kind == MI_ENTITY_FORCE_FIELD) dropFrom(forceFieldEntities);
+    e.kind = MI_ENTITY_DESTROYED; e.rb = -1; e.colliders.clear();
+    prevPairColor.clear(); prevCollisionKeys.clear(); prevTriggerOverlaps.clear();
+    dirtyProps = true;
+    return MI_OK;
+}
+}  // namespace ora
+
 // ================================================================= C ABI (mirrors include/mi_physics.h with an ora_ prefix)
 using namespace ora;
 
@@ -932,6 +985,7 @@ MI_API int ora_entities_create(World* w, uint32_t count, const mi_entity_desc* d
     return MI_OK;
 }
 MI_API int ora_entity_create(World* w, const mi_entity_desc* d, uint32_t* out) { return ora_entities_create(w, 1, d, out); }
+MI_API int ora_entity_destroy(World* w, uint32_t entity) { return w ? w->destroyEntity(entity) : MI_ERR_INVALID_ARGUMENT; }
 
 MI_API int ora_colliders_add(World* w, uint32_t count, const uint32_t* entities, const mi_collider_desc* descs) {
     for (uint32_t i = 0; i < count; ++i) {

@@ -169,6 +169,7 @@ struct World {
     World();
     ~World();
     void recalculateProperties();
+    int destroyEntity(uint32_t entity);   // game_scene::deleteEntity (src/scene/scene.cpp:124-150)
     void stepInternal(const mi_step_settings& s, float dt);
     void step(const mi_step_settings& s, float dt);
 };
@@ -202,6 +203,7 @@ int jointsAddFromGlobal(World& w, uint32_t type, uint32_t ea, uint32_t eb, const
 void jointsInitialize(World& w, float dt);
 void jointsSolveIteration(World& w);
 uint32_t jointsCount(const World& w);
+void jointsRemapBody(World& w, uint32_t from, uint32_t to);
 int jointsLoadPods(World& w, const uint8_t*& p, const uint8_t* end, const uint32_t counts[6]);   // checkpoint: PODs of all six types in pool order
 
 uint32_t hash32(uint32_t m);  // joint colouring priority

@@ -28,15 +28,15 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
             if r.get("Counter_Name") != name:
                 continue
             vals[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-    # steady state = the last quarter of a kernel's dispatches (the pile is settling during the warm-up steps)
-    summary[name] = {k: {"mean": sum(v) / len(v), "steady_mean": sum(v[-max(1, len(v) // 4):]) / max(1, len(v) // 4),
+    # steady state = the kernel's last 20 dispatches = the timed steps of `bench.py --steps 20` and its 3 profiled steps (the 240 settle steps come before)
+    summary[name] = {k: {"mean": sum(v) / len(v), "steady_mean": sum(v[-min(20, len(v)):]) / min(20, len(v)),
                          "dispatches": len(v), "sum": sum(v)} for k, v in vals.items()}
 json.dump(summary, open(out / f"{prefix}_pmc_summary.json", "w"), indent=1)
 print(json.dumps({n: {k: round(v["steady_mean"], 1) for k, v in d.items() if "contact_solve" in k or "narrow" in k or "pairs_grid" in k} for n, d in summary.items()}))
 # HBM traffic of the dominant kernel(s), per launch, steady state.  FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 # reports half the bytes of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section) -> doubled; WRITE_SIZE as reported.
 traffic = {"method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in SEPARATE passes (tools/gpu_pmc.sh); per-launch mean over the last "
-                     "quarter of the dispatches (settled pile); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE on gfx950 reports half "
+                     "20 dispatches (timed + profiled steps after the 240 settle steps); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024: FETCH_SIZE on gfx950 reports half "
                      "of a wide coalesced read stream (MI355X_MICROARCH.md, HBM section); WRITE_SIZE used as reported (uncalibrated)"}
 if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
     for k in summary["FETCH_SIZE"]:
@@ -45,4 +45,16 @@ if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
             f_, w_ = summary["FETCH_SIZE"][k]["steady_mean"], summary["WRITE_SIZE"][k]["steady_mean"]
             traffic[name + "_bytes_per_launch"] = (2 * f_ + w_) * 1024
             traffic[name + "_raw"] = {"FETCH_SIZE_KB_steady": f_, "WRITE_SIZE_KB_steady": w_, "dispatches": summary["FETCH_SIZE"][k]["dispatches"]}
+    # contacts of the profiled state: from the bench line the PMC run itself printed (third argument: its log)
+    try:
+        line = [l for l in open(sys.argv[3]).read().splitlines() if l.startswith("{")][-1]
+        b = json.loads(line)
+        contacts, sweeps = b["config"]["contacts"], 20
+        traffic["profiled_state"] = {"contacts": contacts, "sweeps": sweeps, "settle_steps": b["config"].get("settle_steps")}
+        traffic["source"] = f"{prefix}_pmc_summary.json, {contacts} contacts x {sweeps} sweeps per launch"
+        for k in list(traffic):
+            if k.endswith("_bytes_per_launch"):
+                traffic[k.replace("_bytes_per_launch", "_bytes_per_contact_sweep")] = traffic[k] / (contacts * sweeps)
+    except Exception as e:   # noqa: BLE001
+        traffic["profiled_state_error"] = str(e)
     json.dump(traffic, open(out / "traffic.json", "w"), indent=1)
