@@ -149,6 +149,10 @@ class World:
         self._n_entities += len(descs)
         return first.value
 
+    def destroy_entity(self, entity):
+        """game_scene::deleteEntity(entity) — src/scene/scene.cpp:124-150."""
+        self.L.check(self.L.fn("entity_destroy")(self.h, C.c_uint32(entity)), "entity_destroy")
+
     def add_colliders(self, entities, descs):
         entities = np.ascontiguousarray(entities, dtype=np.uint32)
         descs = np.ascontiguousarray(descs, dtype=collider_desc)
@@ -276,6 +280,14 @@ class World:
 
     def set_cloth_iterations(self, velocity=0, position=1, drift=0):
         self.L.check(self.L.fn("world_set_cloth_iterations")(self.h, C.c_uint32(velocity), C.c_uint32(position), C.c_uint32(drift)), "world_set_cloth_iterations")
+
+    def serialize_entity_native(self, entity):
+        """serializeEntityToMemory written by the library itself (only the reference build under oracle/_ref exports it: its stream is
+        made from the reference's own struct definitions and pins d3d12renderer_amd/scene_binary.py)."""
+        size = C.c_uint64()
+        buf = np.zeros(1 << 16, np.uint8)
+        self.L.check(self.L.fn("entity_serialize")(self.h, C.c_uint32(entity), _ptr(buf), C.c_uint64(len(buf)), C.byref(size)), "entity_serialize")
+        return buf[: size.value].tobytes()
 
     # --- checkpoint / resume
     def save_checkpoint(self):

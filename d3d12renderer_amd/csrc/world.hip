@@ -1489,6 +1489,48 @@ MI_API int mi_entities_create(mi_world* w, uint32_t count, const mi_entity_desc*
     return MI_OK;
 }
 MI_API int mi_entity_create(mi_world* w, const mi_entity_desc* d, uint32_t* out) { return mi_entities_create(w, 1, d, out); }
+// game_scene::deleteEntity — src/scene/scene.cpp:124-150.  Host-side pool bookkeeping with EnTT's swap-and-pop (the LAST collider /
+// rigid body / trigger / force field moves into the freed slot: world indices follow the pools, so the order downstream stages
+// see changes exactly like the reference's); the scene is re-uploaded before the next step.  The colour history and the previous
+// collision / trigger-overlap lists are keyed by pool positions and restart.
+MI_API int mi_entity_destroy(mi_world* w, uint32_t entity) {
+    if (!w || entity >= w->entities.size() || w->entities[entity].kind == MI_ENTITY_DESTROYED) return fail(MI_ERR_INVALID_ARGUMENT, "bad entity");
+    int rc = w->download(); if (rc != MI_OK) return rc;
+    const size_t mine = w->entities[entity].colliders.size();
+    for (size_t k = 0; k < mine; ++k) {                       // the entity's colliders, newest first (removeColliderFromBroadphase + destroy)
+        HEntity& e = w->entities[entity];
+        const uint32_t id = e.colliders[0], last = (uint32_t)w->colliders.size() - 1u;
+        e.colliders.erase(e.colliders.begin());
+        if (id != last) {
+            w->colliders[id] = w->colliders[last];
+            for (uint32_t& c : w->entities[w->colliders[id].entity].colliders) if (c == last) c = id;
+        }
+        w->colliders.pop_back();
+    }
+    w->joints.destroyOfEntity(entity);                         // deleteAllConstraintsFromEntity
+    HEntity& e = w->entities[entity];
+    if (e.rb >= 0) {
+        const uint32_t p = (uint32_t)e.rb, last = (uint32_t)w->bodies.size() - 1u;
+        if (p != last) {
+            w->bodies[p] = w->bodies[last]; w->entities[w->bodies[p].entity].rb = (int)p;
+            JointSet& j = w->joints;   // the reference derives body pairs from the entities every step (physics.cpp:789-806): re-point the cached ones
+            auto fix = [&](auto& t) { for (uint2& b : t.bodies) { if (b.x == last) b.x = p; if (b.y == last) b.y = p; } };
+            fix(j.distance); fix(j.ball); fix(j.fixed); fix(j.hinge); fix(j.cone); fix(j.slider);
+        }
+        w->bodies.pop_back();
+    }
+    auto dropFrom = [&](std::vector<uint32_t>& pool) {
+        const uint32_t p = e.kindIndex, last = (uint32_t)pool.size() - 1u;
+        if (p != last) { pool[p] = pool[last]; w->entities[pool[p]].kindIndex = p; }
+        pool.pop_back();
+    };
+    if (e.kind == MI_ENTITY_TRIGGER) dropFrom(w->triggerEntities);
+    if (e.kind == MI_ENTITY_FORCE_FIELD) dropFrom(w->ffEntities);
+    e.kind = MI_ENTITY_DESTROYED; e.rb = -1; e.colliders.clear(); e.pos = V3(0.f, 0.f, 0.f); e.rot = Q4(0.f, 0.f, 0.f, 1.f);
+    w->tabValid = false; w->prevTriggerOverlaps.clear();
+    w->topologyDirty = true; w->haveEstimates = false;
+    return MI_OK;
+}
 // ---- cloth (cloth_component, src/physics/cloth.h:5-60)
 static V3 clothParticlePosition(const mi_cloth_desc& d, float relX, float relY) {   // getParticlePosition, cloth.cpp:126-132
     V3 p(relX * d.width, -relY * d.height, 0.f);

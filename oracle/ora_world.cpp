@@ -892,7 +892,7 @@ void World::step(const mi_step_settings& settings, float dt) {
 // (the reference keeps its previous-frame list and would compare shifted indices; documented deviation).
 namespace ora {
 int World::destroyEntity(uint32_t entity) {
-    if (entity >= entities.size() || entities[entity].kind == MI_ENTITY_DESTROYED) return MI_ERR_INVALID_ARGUMENT;
+    if (entity >= entities.size() || (uint32_t)entities[entity].kind == MI_ENTITY_DESTROYED) return MI_ERR_INVALID_ARGUMENT;
     Entity& e = entities[entity];
     auto removeEndpoint = [&](uint32_t index) {
         SapEndpoint last = endpoints.back();
@@ -1106,6 +1106,7 @@ static int getTransforms(World* w, float* p, float* r, uint32_t cap, bool physic
         const Entity& e = w->entities[i];
         vec3 pos = e.position; quat rot = e.rotation;
         if (physics && e.rb >= 0) { pos = w->bodies[e.rb].p1; rot = w->bodies[e.rb].r1; }
+        if ((uint32_t)e.kind == MI_ENTITY_DESTROYED) { pos = vec3(0.f); rot = quat(0.f, 0.f, 0.f, 1.f); }
         if (p) { p[3 * i] = pos.x; p[3 * i + 1] = pos.y; p[3 * i + 2] = pos.z; }
         if (r) { r[4 * i] = rot.x; r[4 * i + 1] = rot.y; r[4 * i + 2] = rot.z; r[4 * i + 3] = rot.w; }
     }

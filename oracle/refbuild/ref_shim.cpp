@@ -185,7 +185,8 @@ extern "C" {
 
 #define REF_API __attribute__((visibility("default")))
 
-REF_API int ref_version() { return 2; }
+static void forgetDeadConstraints(ref_world* w);
+REF_API int ref_version() { return 3; }
 REF_API const char* ref_last_error() { return ""; }
 
 // flags bit 0: physics_settings::simdBroadPhase / simdNarrowPhase / simdConstraintSolver (the reference's AVX2 path) on
@@ -241,6 +242,15 @@ REF_API int ref_entities_create(ref_world* w, uint32 count, const mi_entity_desc
 	return MI_OK;
 }
 REF_API int ref_entity_create(ref_world* w, const mi_entity_desc* d, uint32* out) { return ref_entities_create(w, 1, d, out); }
+// game_scene::deleteEntity (src/scene/scene.cpp:124-150)
+REF_API int ref_entity_destroy(ref_world* w, uint32 entity)
+{
+	if (entity >= w->entities.size() || w->kinds[entity] == MI_ENTITY_DESTROYED) { return MI_ERR_INVALID_ARGUMENT; }
+	w->scene.deleteEntity(w->entities[entity]);
+	w->kinds[entity] = MI_ENTITY_DESTROYED;
+	forgetDeadConstraints(w);
+	return MI_OK;
+}
 
 REF_API int ref_colliders_add(ref_world* w, uint32 count, const uint32* entities, const mi_collider_desc* descs)
 {
@@ -527,6 +537,78 @@ REF_API int ref_cloth_get_state(ref_world* w, uint32 cloth, float* pos, float* v
 	return MI_OK;
 }
 
+// --- binary entity stream (serializeEntityToMemory / deserializeEntityFromMemory, src/scene/serialization_binary.cpp:484-497).
+// That translation unit needs the renderer's component types and cannot be compiled here; what follows walks the SAME component
+// list in the SAME order (serialized_components, lines 105-133) and writes each physics component exactly as its
+// serializeToMemoryStream does — `stream.write(component)` = the raw struct image, taken here from the reference's own struct
+// definitions — with `false` for every renderer / terrain-rendering component.  Entity handles inside the stream are this ABI's
+// entity ids (the reference writes EnTT identifiers, which only mean something inside one registry).
+extern "C++" {
+namespace {
+struct byte_writer
+{
+	uint8* buffer; uint64 cap; uint64 offset = 0; bool overflow = false;
+	template <typename T> void write(const T& t) { if (offset + sizeof(T) > cap) { overflow = true; offset += sizeof(T); return; } memcpy(buffer + offset, &t, sizeof(T)); offset += sizeof(T); }
+};
+}
+}
+static_assert(sizeof(tag_component) == 16 && sizeof(transform_component) == 48 && sizeof(rigid_body_component) == 112 && sizeof(force_field_component) == 12, "component images");
+static_assert(sizeof(collider_union) == 80 && sizeof(physics_material) == 16 && sizeof(constraint_type) == 4, "collider image");
+static_assert(sizeof(distance_constraint) == 28 && sizeof(ball_constraint) == 24 && sizeof(fixed_constraint) == 48 && sizeof(hinge_constraint) == 104 &&
+	sizeof(cone_twist_constraint) == 120 && sizeof(slider_constraint) == 80, "constraint images");
+REF_API int ref_entity_serialize(ref_world* w, uint32 entity, void* out, uint64 cap, uint64* outSize)
+{
+	if (entity >= w->entities.size() || w->kinds[entity] == MI_ENTITY_DESTROYED) { return MI_ERR_INVALID_ARGUMENT; }
+	scene_entity e = w->entities[entity];
+	byte_writer s{ (uint8*)out, out ? cap : 0 };
+	auto flag = [&](bool has) { s.write(has); return has; };
+	if (flag(e.hasComponent<tag_component>())) { s.write(e.getComponent<tag_component>()); }
+	if (flag(e.hasComponent<transform_component>())) { s.write(e.getComponent<transform_component>()); }
+	flag(false); flag(false); flag(false);                              // position / position_rotation / position_scale
+	flag(e.hasComponent<dynamic_transform_component>());               // no payload
+	flag(false); flag(false); flag(false);                              // mesh, point light, spot light
+	if (flag(e.hasComponent<rigid_body_component>())) { s.write(e.getComponent<rigid_body_component>()); }
+	if (flag(e.hasComponent<force_field_component>())) { s.write(e.getComponent<force_field_component>()); }
+	if (flag(e.hasComponent<cloth_component>()))
+	{
+		const cloth_component& c = e.getComponent<cloth_component>();
+		s.write(c.width); s.write(c.height); s.write(c.gridSizeX); s.write(c.gridSizeY); s.write(c.totalMass); s.write(c.stiffness); s.write(c.damping); s.write(c.gravityFactor);
+	}
+	flag(false);                                                        // cloth_render_component
+	if (flag(e.hasComponent<physics_reference_component>()))
+	{
+		const physics_reference_component& ref = e.getComponent<physics_reference_component>();
+		s.write(ref.numColliders);
+		for (collider_component& collider : collider_component_iterator(e)) { collider_union u; memcpy(&u, &collider, sizeof(u)); if (u.type == collider_type_hull) { u.hull.geometryPtr = nullptr; for (uint32 k = 0; k < w->hullIds.size(); ++k) { if (w->hullIds[k] == collider.hull.geometryIndex) { u.hull.geometryIndex = k; } } } s.write(u); }
+		s.write(ref.numConstraints);
+		for (auto [constraintEntity, constraintType] : constraint_entity_iterator(e))
+		{
+			auto& cr = constraintEntity.getComponent<constraint_entity_reference_component>();
+			s.write(constraintType);
+			s.write((uint32)w->entityIdOfHandle[(uint32)cr.entityA]); s.write((uint32)w->entityIdOfHandle[(uint32)cr.entityB]);
+			switch (constraintType)
+			{
+				case constraint_type_distance: s.write(constraintEntity.getComponent<distance_constraint>()); break;
+				case constraint_type_ball: s.write(constraintEntity.getComponent<ball_constraint>()); break;
+				case constraint_type_fixed: s.write(constraintEntity.getComponent<fixed_constraint>()); break;
+				case constraint_type_hinge: s.write(constraintEntity.getComponent<hinge_constraint>()); break;
+				case constraint_type_cone_twist: s.write(constraintEntity.getComponent<cone_twist_constraint>()); break;
+				case constraint_type_slider: s.write(constraintEntity.getComponent<slider_constraint>()); break;
+				default: break;
+			}
+		}
+	}
+	flag(false);                                                        // terrain_component
+	if (flag(e.hasComponent<heightmap_collider_component>()))
+	{
+		const heightmap_collider_component& h = e.getComponent<heightmap_collider_component>();
+		s.write(h.chunksPerDim); s.write(h.chunkSize); s.write(h.material);
+	}
+	flag(false); flag(false); flag(false);                              // grass, proc placement, water
+	*outSize = s.offset;
+	return s.overflow ? MI_ERR_CAPACITY : MI_OK;
+}
+
 // --- read-back
 REF_API int ref_world_num_entities(ref_world* w, uint32* out) { *out = (uint32)w->entities.size(); return MI_OK; }
 static int getTransforms(ref_world* w, float* p, float* r, uint32 cap, bool physics)
@@ -535,6 +617,7 @@ static int getTransforms(ref_world* w, float* p, float* r, uint32 cap, bool phys
 	if (cap < n) { return MI_ERR_CAPACITY; }
 	for (uint32 i = 0; i < n; ++i)
 	{
+		if (w->kinds[i] == MI_ENTITY_DESTROYED) { if (p) { put3(p + 3 * i, vec3(0.f)); } if (r) { put4(r + 4 * i, quat(0.f, 0.f, 0.f, 1.f)); } continue; }
 		scene_entity& e = w->entities[i];
 		const trs* t = &e.getComponent<transform_component>();
 		if (physics) { if (auto* pt = e.getComponentIfExists<physics_transform1_component>()) { t = pt; } }
@@ -552,6 +635,7 @@ REF_API int ref_world_get_velocities(ref_world* w, float* lin, float* ang, uint3
 	for (uint32 i = 0; i < n; ++i)
 	{
 		vec3 v(0.f), a(0.f);
+		if (w->kinds[i] == MI_ENTITY_DESTROYED) { if (lin) { put3(lin + 3 * i, v); } if (ang) { put3(ang + 3 * i, a); } continue; }
 		if (auto* rb = w->entities[i].getComponentIfExists<rigid_body_component>()) { v = rb->linearVelocity; a = rb->angularVelocity; }
 		if (lin) { put3(lin + 3 * i, v); }
 		if (ang) { put3(ang + 3 * i, a); }
@@ -565,6 +649,7 @@ REF_API int ref_world_get_mass_properties(ref_world* w, float* invMass, float* i
 	for (uint32 i = 0; i < n; ++i)
 	{
 		float im = 0.f; mat3 ii = mat3::zero; vec3 c(0.f);
+		if (w->kinds[i] == MI_ENTITY_DESTROYED) { if (invMass) { invMass[i] = im; } if (invInertia) { memcpy(invInertia + 9 * i, &ii, 36); } if (cog) { put3(cog + 3 * i, c); } continue; }
 		if (auto* rb = w->entities[i].getComponentIfExists<rigid_body_component>()) { im = rb->invMass; ii = rb->invInertia; c = rb->localCOGPosition; }
 		if (invMass) { invMass[i] = im; }
 		if (invInertia) { memcpy(invInertia + 9 * i, &ii, 36); }

@@ -588,3 +588,29 @@ def test_gpu_sharded_three_tiles_device_exchange_matches_oracle_tiles(mi_lib, or
         assert g[r][0].tobytes() == o[r][0].tobytes(), f"tile {r}"
         assert g[r][1] == o[r][1] and g[r][1]["num_contacts"] > 0
     assert g[0][1]["num_rigid_bodies"] == g[1][1]["num_rigid_bodies"] == g[2][1]["num_rigid_bodies"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("make,victims", [(lambda: scenes.shape_zoo(), [3, 77, 143, 10, 11, 142]), (lambda: scenes.ragdolls(3, 3), [5, 20, 55, 0, 100]),
+                                          (lambda: scenes.zones(), [4, 111, 60, 113, 108])], ids=["zoo", "ragdolls", "zones"])
+def test_gpu_entity_deletion_matches_oracle(mi_lib, oracle_mod, make, victims):
+    """mi_entity_destroy = game_scene::deleteEntity (scene.cpp:124-150) while the simulation runs: bodies with one and several
+    colliders, bodies with joints, triggers, a force field.  The pools follow EnTT's swap-and-pop (the oracle's deletion is pinned
+    to the reference's own, tests/test_reference_pin.py), events keep flowing, everything stays bit-identical."""
+    sc = make()
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    for w in (g, o):
+        w.enable_events(True)
+    s = sc.settings()
+    schedule = {15 + 12 * k: v for k, v in enumerate(victims)}
+    for i in range(120):
+        if i in schedule:
+            for w in (g, o):
+                w.destroy_entity(schedule[i])
+        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        assert g.counts() == o.counts(), f"step {i}"
+        assert g.poll_events().tobytes() == o.poll_events().tobytes(), f"step {i}: events"
+    for a, b in zip(g.physics_transforms() + g.velocities() + g.transforms(), o.physics_transforms() + o.velocities() + o.transforms()):
+        assert a.tobytes() == b.tobytes()
+    with pytest.raises(mi_lib.PhysicsError):
+        g.destroy_entity(victims[0])

@@ -261,3 +261,25 @@ def test_canonical_schedule_divergence_from_reference_is_reported(oracle_mod, re
     assert out["stack5"]["contacts_reference"] == out["stack5"]["contacts_canonical"] == 20
     record_property("canonical_vs_reference", str(out))
     print("canonical schedule vs the reference:", out)
+
+
+def test_entity_deletion_equals_reference(oracle_mod):
+    """game_scene::deleteEntity (scene.cpp:124-150) in the middle of a simulation: rigid bodies (single- and multi-collider, with
+    joints), a static collider entity and a trigger.  EnTT's swap-and-pop moves the LAST body / collider / trigger into the freed
+    slot, removeColliderFromBroadphase moves the LAST SAP endpoint — both change the order everything is processed in, and the
+    restatement has to follow them exactly to stay bit-identical."""
+    for make, victims in ((lambda: scenes.shape_zoo(), [3, 77, 143, 10, 11, 142]), (lambda: scenes.ragdolls(2, 2), [5, 20, 55, 0]),
+                          (lambda: scenes.zones(localized=False), [4, 111, 60, 113])):
+        sc = make()
+        r, o = _worlds(oracle_mod, sc)
+        s = sc.settings()
+        schedule = {15 + 12 * k: v for k, v in enumerate(victims)}
+        for i in range(110):
+            if i in schedule:
+                for w in (r, o):
+                    w.destroy_entity(schedule[i])
+            r.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+            _assert_same_step(r, o, f"{sc.name} step {i}")
+        assert r.broadphase_pairs().tobytes() == o.broadphase_pairs().tobytes()
+        with pytest.raises(capi.PhysicsError):
+            o.destroy_entity(victims[0])          # already gone
