@@ -105,6 +105,7 @@ struct mi_world {
     JointSet joints;
     bool topologyDirty = true;   // entities/colliders changed -> re-upload everything
     bool hostStale = false;      // device holds newer body state than host
+    bool transformsFollowPhysics = false;   // last stepped through mi_world_step_fixed: entity transforms = physics_transform1 at the next download
     float timer = 0.f;
 
     // device: bodies
@@ -557,6 +558,8 @@ int mi_world::download() {
             b.p1 = V3(pos[i].x, pos[i].y, pos[i].z); b.r1 = Q4(rot[i].x, rot[i].y, rot[i].z, rot[i].w);
             b.linVel = V3(lv[i].x, lv[i].y, lv[i].z); b.angVel = V3(av[i].x, av[i].y, av[i].z);
             b.force = V3(fo[i].x, fo[i].y, fo[i].z); b.torque = V3(to[i].x, to[i].y, to[i].z);
+            // after n x physicsStepInternal without interpolation (mi_world_step_fixed) the transform is physics_transform1 (physics.cpp:1408-1411)
+            if (transformsFollowPhysics) { HEntity& e = entities[b.entity]; e.pos = b.p1; e.rot = b.r1; }
         }
     }
     hostStale = false;
@@ -1838,6 +1841,7 @@ MI_API int mi_world_test_interactions(mi_world* w, uint32_t count, const float* 
 
 MI_API int mi_world_step_fixed(mi_world* w, const mi_step_settings* s, float dt, uint32_t n) {
     if (!w || !s) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (n) w->transformsFollowPhysics = true;
     for (uint32_t i = 0; i < n; ++i) { int rc = w->stepInternal(*s, dt); if (rc != MI_OK) return rc; }
     return MI_OK;
 }
@@ -1858,6 +1862,7 @@ MI_API int mi_world_step_profiled(mi_world* w, const mi_step_settings* s, float 
 // physicsStep (src/physics/physics.cpp:1364-1413): accumulator, <= maxPhysicsIterationsPerFrame sub-steps, pose interpolation.
 MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
     if (!w || !s) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (w->transformsFollowPhysics) { int rc = w->download(); if (rc != MI_OK) return rc; w->transformsFollowPhysics = false; }   // from here on this function writes the transforms itself
     if (s->fixed_frame_rate) {
         const float fixedDt = 1.f / (float)s->frame_rate;
         w->timer += dt;
