@@ -83,6 +83,15 @@ class StageTimes(C.Structure):
         return {n: getattr(self, n) for n, _ in self._fields_}
 
 
+class ShardDesc(C.Structure):
+    """mi_shard_desc (include/mi_shard.h)."""
+    _fields_ = [("rank", C.c_uint32), ("num_ranks", C.c_uint32), ("origin_x", C.c_float), ("origin_z", C.c_float), ("tile_size_x", C.c_float),
+                ("tile_size_z", C.c_float), ("tiles_x", C.c_uint32), ("tiles_z", C.c_uint32), ("ghost_margin", C.c_float), ("max_records", C.c_uint32)]
+
+
+SHARD_RECORD_FLOATS = 14
+
+
 class WorldDesc(C.Structure):
     _fields_ = [("device", C.c_int32), ("flags", C.c_uint32)]
 
@@ -116,6 +125,17 @@ class Library:
             s = self.fn("last_error", C.c_char_p)()
             return s.decode() if s else ""
         return ""
+
+    def shard_unique_id(self):
+        """ncclGetUniqueId through the library (rank 0; distribute the 128 bytes to every rank)."""
+        buf = np.zeros(128, np.uint8)
+        self.check(self.fn("shard_get_unique_id")(_ptr(buf)), "shard_get_unique_id")
+        return buf.tobytes()
+
+    def shard_tile_of_rank(self, tiles_x, tiles_z, rank):
+        out = C.c_uint32()
+        self.check(self.fn("shard_tile_of_rank")(C.c_uint32(tiles_x), C.c_uint32(tiles_z), C.c_uint32(rank), C.byref(out)), "shard_tile_of_rank")
+        return out.value
 
     def check(self, rc, what):
         if rc != MI_OK:
@@ -382,6 +402,47 @@ class World:
         if n.value:
             self.L.check(self.L.fn("world_get_contacts")(self.h, _ptr(out), C.c_uint32(n.value), C.byref(n)), "world_get_contacts")
         return out
+
+    # --- sharded world (include/mi_shard.h)
+    def shard_enable(self, desc):
+        self.L.check(self.L.fn("world_shard_enable")(self.h, C.byref(desc)), "world_shard_enable")
+
+    def shard_neighbours(self):
+        out = np.zeros(8, np.uint32); n = C.c_uint32()
+        self.L.check(self.L.fn("world_shard_neighbours")(self.h, _ptr(out), C.byref(n)), "world_shard_neighbours")
+        return [int(x) for x in out[: n.value]]
+
+    def shard_counts(self):
+        b = C.c_uint32(); m = C.c_uint32(); c = C.c_uint32()
+        self.L.check(self.L.fn("world_shard_counts")(self.h, C.byref(b), C.byref(m), C.byref(c)), "world_shard_counts")
+        return {"owned_bodies": b.value, "owned_manifolds": m.value, "owned_contacts": c.value}
+
+    def shard_owned_entities(self):
+        n = C.c_uint32()
+        self.L.check(self.L.fn("world_shard_owned_entities")(self.h, None, C.c_uint32(0), C.byref(n)), "world_shard_owned_entities")
+        out = np.zeros(max(n.value, 1), np.uint32)
+        self.L.check(self.L.fn("world_shard_owned_entities")(self.h, _ptr(out), C.c_uint32(len(out)), C.byref(n)), "world_shard_owned_entities")
+        return out[: n.value]
+
+    def shard_message_bytes(self):
+        n = C.c_uint64()
+        self.L.check(self.L.fn("world_shard_message_bytes")(self.h, C.byref(n)), "world_shard_message_bytes")
+        return n.value
+
+    def shard_export(self, slot):
+        """The message for neighbour slot `slot` after the last internal step: float32 array, record 0 = (count, ...)."""
+        out = np.zeros(self.shard_message_bytes() // 4, np.float32)
+        self.L.check(self.L.fn("world_shard_export")(self.h, C.c_uint32(slot), _ptr(out)), "world_shard_export")
+        return out
+
+    def shard_import(self, message):
+        m = np.ascontiguousarray(message, np.float32)
+        self.L.check(self.L.fn("world_shard_import")(self.h, _ptr(m)), "world_shard_import")
+
+    def shard_attach_rccl(self, unique_id128):
+        buf = np.frombuffer(bytes(unique_id128), np.uint8).copy()
+        assert len(buf) == 128
+        self.L.check(self.L.fn("world_shard_attach_rccl")(self.h, _ptr(buf)), "world_shard_attach_rccl")
 
     # --- ghost-region exchange (13 floats per body: pos3, rot4, lin3, ang3)
     def get_body_states(self, entities):

@@ -19,6 +19,7 @@ constexpr uint32_t kMaxColorRounds = 4094;                    // 12-bit round ta
 constexpr uint32_t kIndexBits = 26;                           // colliders per world < 2^26 (52-bit unique pair priorities)
 
 enum : uint32_t { OBJ_RIGID_BODY = 0, OBJ_STATIC = 1, OBJ_FORCE_FIELD = 2, OBJ_TRIGGER = 3 };
+constexpr float kDeadBox = 3.0e38f;                           // sharded world: min = +kDeadBox, max = -kDeadBox marks a collider that is not simulated here
 
 struct GridParams {   // written by k_bp_grid_setup, read by the broad-phase kernels
     float origin[3];
@@ -63,6 +64,9 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numHmColliders;       // ... and the colliders they belong to (= the reference's collision count for the terrain)
     uint32_t xcdCount[8];          // XCD-partitioned solver: tiles owned by each XCD (k_build_tiles)
     uint32_t xccOf[8];             // ... and the hardware XCC id the workgroups with blockIdx % 8 == i really ran on (0xFFFFFFFF = none yet)
+    uint32_t numDead;              // sharded world: colliders of bodies this rank does not simulate this step (they take no part in the broad phase)
+    uint32_t shardOwned[3];        // sharded world: bodies / manifolds / contacts OWNED by this rank (owner rule: the manifold's first dynamic body)
+    uint32_t shardSent[8];         // sharded world: records packed for each neighbour this step (slot order of ShardParams::peers)
 };
 
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
@@ -101,11 +105,19 @@ __global__ __launch_bounds__(256) void k_world_colliders(
     const float4* __restrict__ cShape, const float4* __restrict__ cStaticPos, const float4* __restrict__ cStaticRot,
     const float4* __restrict__ bPos, const float4* __restrict__ bRot,
     const float4* __restrict__ hullAabb,  // [2*numHulls]
-    float4* __restrict__ wShape, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax, StepScalars* sc, uint32_t axisCur) {
+    float4* __restrict__ wShape, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax, StepScalars* sc, uint32_t axisCur,
+    const uint8_t* __restrict__ bodyActive /* sharded world: 0 = body not simulated by this rank this step, or null */) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) { sc->axisCur = axisCur; }   // the SAP axis chosen at the end of the previous (successful) step
     if (k >= nc) return;
     uint32_t type = cTypeBody[2 * k], body = cTypeBody[2 * k + 1];
+    if (bodyActive && body != kNoBody && !bodyActive[body]) {
+        // a DEAD collider: inverted box (overlaps nothing, centre exactly 0 so the axis statistics are unaffected), skipped by the grid
+        wShape[3 * k] = make_float4(0, 0, 0, 0); wShape[3 * k + 1] = make_float4(0, 0, 0, 0); wShape[3 * k + 2] = make_float4(0, 0, 0, 1);
+        aabbMin[k] = make_float4(kDeadBox, kDeadBox, kDeadBox, __uint_as_float(type | (OBJ_RIGID_BODY << 8)));
+        aabbMax[k] = make_float4(-kDeadBox, -kDeadBox, -kDeadBox, __uint_as_float(body));
+        return;
+    }
     V3 tp; Q4 tr; uint32_t objType, objIndex;
     if (body != kNoBody) { tp = xyz(bPos[body]); tr = toQ(bRot[body]); objType = OBJ_RIGID_BODY; objIndex = body; }
     else {
@@ -248,18 +260,22 @@ __global__ __launch_bounds__(256) void k_bp_classify(uint32_t nc, const float4* 
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     float thr = sc->largeThreshold;
     int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    bool dead = false;
     if (i < nc) {
         float4 mn = aabbMin[i], mx = aabbMax[i];
         float ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
         bool large = ext > thr;
-        isLarge[i] = large ? 1u : 0u;
-        if (large) { uint32_t slot = atomicAdd(&sc->numLarge, 1u); largeList[slot] = i; }
+        dead = mx.x < mn.x;                                   // sharded world: not simulated by this rank (k_world_colliders)
+        isLarge[i] = dead ? 2u : large ? 1u : 0u;             // anything non-zero keeps the collider out of the grid
+        if (dead) {}
+        else if (large) { uint32_t slot = atomicAdd(&sc->numLarge, 1u); largeList[slot] = i; }
         else {
             lo[0] = hi[0] = orderedInt((mn.x + mx.x) * 0.5f);
             lo[1] = hi[1] = orderedInt((mn.y + mx.y) * 0.5f);
             lo[2] = hi[2] = orderedInt((mn.z + mx.z) * 0.5f);
         }
     }
+    { const unsigned long long deadMask = __ballot(dead); if (deadMask && (threadIdx.x & 63u) == 0u) atomicAdd(&sc->numDead, (uint32_t)__popcll(deadMask)); }
     for (int off = 32; off >= 1; off >>= 1)
 #pragma unroll
         for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], __shfl_xor(lo[a], off, 64)); hi[a] = max(hi[a], __shfl_xor(hi[a], off, 64)); }
@@ -301,7 +317,7 @@ __global__ __launch_bounds__(256) void k_bp_grid_setup(uint32_t nc, uint32_t num
     sc->numCells = g->numCells;
     g->cell = cell; g->invCell = 1.f / cell;
     for (int a = 0; a < 3; ++a) g->origin[a] = lo[a];
-    g->numLarge = sc->numLarge;
+    g->numLarge = sc->numLarge + sc->numDead;   // everything that is not in the cell-sorted arrays
     g->largeThreshold = thr;
 }
 
@@ -929,10 +945,12 @@ __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt,
                                                           const float4* __restrict__ bAngVel, const float4* __restrict__ bForce, const float4* __restrict__ bTorque,
                                                           float4* __restrict__ gPos, float4* __restrict__ gInvI, float4* __restrict__ gVel,
                                                           float4* __restrict__ gVelL /* XCD-partitioned solver: cached copy for the XCD-local bodies, or null */,
-                                                          unsigned long long* __restrict__ bodyOwner /* ... and the per-body XCD flags (8 bytes), cleared here */) {
+                                                          unsigned long long* __restrict__ bodyOwner /* ... and the per-body XCD flags (8 bytes), cleared here */,
+                                                          const uint8_t* __restrict__ bodyActive /* sharded world, or null */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > nb) return;
     if (bodyOwner) bodyOwner[i] = 0ull;
+    if (bodyActive && i < nb && !bodyActive[i]) return;   // not simulated by this rank: no contact can reference it
     if (i == nb) {
         float4 z = make_float4(0, 0, 0, 0);
         gPos[i] = z; gInvI[3 * i] = z; gInvI[3 * i + 1] = z; gInvI[3 * i + 2] = z; gVel[2 * i] = z; gVel[2 * i + 1] = z;
@@ -975,12 +993,19 @@ __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float
                                                               float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, float4* __restrict__ bForce,
                                                               float4* __restrict__ bTorque,
                                                               const float4* __restrict__ gVelL, const unsigned long long* __restrict__ bodyOwner /* XCD-partitioned solver, or null */,
-                                                              unsigned long long* __restrict__ bodyUsed, unsigned long long* __restrict__ bodyTop) {
+                                                              unsigned long long* __restrict__ bodyUsed, unsigned long long* __restrict__ bodyTop,
+                                                              const uint8_t* __restrict__ bodyActive /* sharded world (1 = owned), or null */, const float4* __restrict__ bPosIn,
+                                                              const float4* __restrict__ bLinVelIn, const float4* __restrict__ bAngVelIn, const float4* __restrict__ bForceIn,
+                                                              const float4* __restrict__ bTorqueIn) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > nb) return;
     // the per-body colouring scratch of the NEXT step starts out cleared (saves two memset launches per step); launched over nb + 1
     bodyUsed[i] = 0ull; bodyTop[i] = 0ull; bodyTop[(size_t)nb + 1u + i] = 0ull;
     if (i == nb) return;
+    if (bodyActive && bodyActive[i] != 1u) {   // sharded world: only the OWNER advances a body; ghosts and bodies elsewhere keep their state (the owner's arrives by exchange)
+        bPos[i] = bPosIn[i]; bRot[i] = bRotIn[i]; bLinVel[i] = bLinVelIn[i]; bAngVel[i] = bAngVelIn[i]; bForce[i] = bForceIn[i]; bTorque[i] = bTorqueIn[i];
+        return;
+    }
     if (bodyOwner && __popcll(bodyOwner[i]) == 1) gVel = gVelL;   // a body only one XCD touched lives in the cached copy
     V3 v = xyz(gVel[2 * i]), w = xyz(gVel[2 * i + 1]);
     Q4 rot = toQ(bRotIn[i]);
@@ -2068,6 +2093,100 @@ __global__ void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slo
     }
 }
 
+
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// Sharded world (multi-GPU): every rank holds the WHOLE scene (same body / collider indices everywhere — priorities,
+// pair keys and colour history mean the same thing on every rank) and simulates one tile of an x-z grid: the bodies whose centre
+// of gravity lies in its tile (OWNED: it integrates them) plus those within `margin` of the tile (GHOSTS: they take part in its
+// collision detection and solve, their new state comes from their owner).  Tiles on the rim of the grid extend to infinity.
+// Ownership follows the bodies: it is recomputed from the positions at the start of every step (migration needs no bookkeeping).
+struct ShardParams {
+    float originX, originZ, tileX, tileZ, margin;
+    uint32_t tilesX, tilesZ, myTile;
+    uint32_t numPeers; uint32_t peers[8];     // neighbouring tiles (|dx| <= 1, |dz| <= 1), ascending tile index
+};
+__device__ __forceinline__ uint32_t shardTileOf(const ShardParams& sp, float x, float z) {
+    const int tx = min(max((int)floorf((x - sp.originX) / sp.tileX), 0), (int)sp.tilesX - 1);
+    const int tz = min(max((int)floorf((z - sp.originZ) / sp.tileZ), 0), (int)sp.tilesZ - 1);
+    return (uint32_t)tz * sp.tilesX + (uint32_t)tx;
+}
+// is (x, z) inside tile `t` grown by the margin?  (rim tiles are unbounded outwards)
+__device__ __forceinline__ bool shardInExtended(const ShardParams& sp, uint32_t t, float x, float z) {
+    const uint32_t tx = t % sp.tilesX, tz = t / sp.tilesX;
+    const float x0 = sp.originX + (float)tx * sp.tileX - sp.margin, x1 = sp.originX + (float)(tx + 1u) * sp.tileX + sp.margin;
+    const float z0 = sp.originZ + (float)tz * sp.tileZ - sp.margin, z1 = sp.originZ + (float)(tz + 1u) * sp.tileZ + sp.margin;
+    return (tx == 0u || x >= x0) && (tx + 1u == sp.tilesX || x < x1) && (tz == 0u || z >= z0) && (tz + 1u == sp.tilesZ || z < z1);
+}
+__device__ __forceinline__ V3 shardCog(float4 pos, float4 rot, float4 cogInvMass) { return xyz(pos) + rotate(toQ(rot), xyz(cogInvMass)); }
+
+// start of a step: 1 = owned, 2 = ghost, 0 = not simulated here
+__global__ __launch_bounds__(256) void k_shard_classify(uint32_t nb, ShardParams sp, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
+                                                        const float4* __restrict__ bCogInvMass, uint8_t* __restrict__ bodyActive, StepScalars* sc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool owned = false;
+    if (i < nb) {
+        const V3 c = shardCog(bPos[i], bRot[i], bCogInvMass[i]);
+        owned = shardTileOf(sp, c.x, c.z) == sp.myTile;
+        bodyActive[i] = owned ? 1u : shardInExtended(sp, sp.myTile, c.x, c.z) ? 2u : 0u;
+    }
+    const unsigned long long m = __ballot(owned);
+    if (m && (threadIdx.x & 63u) == 0u) atomicAdd(&sc->shardOwned[0], (uint32_t)__popcll(m));
+}
+// owner rule for the counts: a manifold belongs to the rank that owns its first dynamic body (A unless A has no inverse mass / is the static dummy)
+__global__ __launch_bounds__(256) void k_shard_count(uint32_t nb, const uint2* __restrict__ manBodies, const uint2* __restrict__ manInfo,
+                                                     const float4* __restrict__ bCogInvMass, const uint8_t* __restrict__ bodyActive, StepScalars* sc) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t mine = 0, contacts = 0;
+    if (m < sc->numManifolds) {
+        const uint2 b = manBodies[m];
+        const uint32_t first = (b.x < nb && bCogInvMass[b.x].w != 0.f) ? b.x : b.y;
+        if (first < nb && bodyActive[first] == 1u) { mine = 1u; contacts = manInfo[m].x & 7u; }
+    }
+    for (int off = 32; off >= 1; off >>= 1) { mine += __shfl_xor(mine, off, 64); contacts += __shfl_xor(contacts, off, 64); }
+    if ((threadIdx.x & 63u) == 0u && mine) { atomicAdd(&sc->shardOwned[1], mine); atomicAdd(&sc->shardOwned[2], contacts); }
+}
+// after a valid step (body buffers already swapped: bPos = new state, bPosOld = state the step started from): the records this rank
+// owes neighbour `slot` — every body it OWNED this step whose old or new centre of gravity lies in that neighbour's extended tile
+// (old: so that the neighbour learns the body has left).  Record = (body index, 13 floats); record 0 of the buffer = (count, ...).
+constexpr uint32_t kShardRecordFloats = 14;
+__global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp, uint32_t slot, const uint8_t* __restrict__ bodyActive,
+                                                    const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bLinVel,
+                                                    const float4* __restrict__ bAngVel, const float4* __restrict__ bPosOld, const float4* __restrict__ bRotOld,
+                                                    const float4* __restrict__ bCogInvMass, float* __restrict__ out, uint32_t capacity, StepScalars* sc) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool want = false;
+    if (i < nb && bodyActive[i] == 1u) {
+        const float4 cm = bCogInvMass[i];
+        const V3 cn = shardCog(bPos[i], bRot[i], cm), co = shardCog(bPosOld[i], bRotOld[i], cm);
+        want = shardInExtended(sp, sp.peers[slot], cn.x, cn.z) || shardInExtended(sp, sp.peers[slot], co.x, co.z);
+    }
+    const unsigned long long mask = __ballot(want);
+    if (!mask) return;
+    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&sc->shardSent[slot], (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (!want) return;
+    const uint32_t r = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (r >= capacity) return;                                   // the count still grows: the host sees the overflow
+    float* o = out + (size_t)(r + 1u) * kShardRecordFloats;
+    const float4 p = bPos[i], q = bRot[i], v = bLinVel[i], w = bAngVel[i];
+    o[0] = __uint_as_float(i); o[1] = p.x; o[2] = p.y; o[3] = p.z; o[4] = q.x; o[5] = q.y; o[6] = q.z; o[7] = q.w;
+    o[8] = v.x; o[9] = v.y; o[10] = v.z; o[11] = w.x; o[12] = w.y; o[13] = w.z;
+}
+__global__ void k_shard_pack_header(uint32_t slot, const StepScalars* __restrict__ sc, float* __restrict__ out) { out[0] = __uint_as_float(sc->shardSent[slot]); }
+__global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, const float* __restrict__ in, uint32_t capacity, float4* __restrict__ bPos, float4* __restrict__ bRot,
+                                                      float4* __restrict__ bLinVel, float4* __restrict__ bAngVel) {
+    const uint32_t count = min(__float_as_uint(in[0]), capacity);
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= count) return;
+    const float* s = in + (size_t)(r + 1u) * kShardRecordFloats;
+    const uint32_t b = __float_as_uint(s[0]);
+    if (b >= nb) return;
+    bPos[b] = make_float4(s[1], s[2], s[3], 0.f); bRot[b] = make_float4(s[4], s[5], s[6], s[7]);
+    bLinVel[b] = make_float4(s[8], s[9], s[10], 0.f); bAngVel[b] = make_float4(s[11], s[12], s[13], 0.f);
+}
 
 // ------------------------------------------------------------------------------------------------------------------------------
 // Device-wide exclusive prefix sum, ONE launch: chained scan with decoupled look-back.

@@ -16,6 +16,8 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/mi_physics.h"
+#include "../../include/mi_shard.h"
+#include <dlfcn.h>
 #include "../../include/mi_constraints.h"
 #include "kernels.hpp"
 #include "gjk.hpp"
@@ -105,6 +107,20 @@ struct mi_world {
     JointSet joints;
     bool topologyDirty = true;   // entities/colliders changed -> re-upload everything
     bool hostStale = false;      // device holds newer body state than host
+    // sharded world (include/mi_shard.h): the rank's tile, per-body activity (1 owned, 2 ghost, 0 elsewhere), message buffers, transport
+    struct ShardState {
+        bool enabled = false, rccl = false;
+        mi_shard_desc desc{}; ShardParams sp{};
+        uint32_t capacity = 0; std::vector<uint32_t> peerRanks;
+        DBuf<uint8_t> active; DBuf<float> sendBuf[8], recvBuf[8]; DBuf<uint32_t> sent;
+        uint32_t* sentHost = nullptr;            // pinned: the records packed per slot in the previous exchange (overflow check)
+        bool sentPending = false;
+        uint32_t owned[3] = {0, 0, 0};
+        void* comm = nullptr;                    // ncclComm_t
+        size_t messageFloats() const { return (size_t)(capacity + 1u) * kShardRecordFloats; }
+    } shard;
+    int shardExchange();
+    void shardReleaseComm();
     bool transformsFollowPhysics = false;   // last stepped through mi_world_step_fixed: entity transforms = physics_transform1 at the next download
     float timer = 0.f;
 
@@ -271,6 +287,8 @@ mi_world::~mi_world() {
     if (stream) (void)hipStreamSynchronize(stream);
     (void)hipDeviceSynchronize();
     if (hsPinned) (void)hipHostFree(hsPinned);
+    if (shard.sentHost) (void)hipHostFree(shard.sentHost);
+    shardReleaseComm();
     if (stream) (void)hipStreamDestroy(stream);
     for (auto& e : profEvents) (void)hipEventDestroy(e);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -575,6 +593,7 @@ __global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlag
     for (uint32_t i = t; i < sizeof(Shards) / 4u; i += blockDim.x) reinterpret_cast<uint32_t*>(sh)[i] = 0u;
     for (uint32_t i = t; i < kMaxColorRounds + 2u; i += blockDim.x) roundFlags[i] = 0u;
     if (t == 0) {
+        sc->numDead = 0; sc->shardOwned[0] = sc->shardOwned[1] = sc->shardOwned[2] = 0;
         sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->solveError = 0;
         sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0; sc->numEvents = 0; sc->numInterPairs = 0; sc->numInteractions = 0; sc->numHmContacts = 0; sc->numHmColliders = 0;
         for (int q = 0; q < 16; ++q) sc->boxHitCount[q] = 0;
@@ -622,6 +641,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     for (int attempt = 0; rc == STEP_RETRY && attempt < 6; ++attempt) { ++specRetries; rc = runStep(settings, dt, false); }
     if (rc == STEP_RETRY) return fail(MI_ERR_DEVICE, "step could not be completed on any solver path");
     if (rc == MI_OK && launchFallbackSteps) --launchFallbackSteps;
+    if (rc == MI_OK && shard.enabled) rc = shardExchange();
     if (rc == MI_OK && !cloths.empty()) rc = stepCloths(dt);   // after the rigid bodies (physics.cpp:1352-1358); once per VALID step: cloth state is updated in place
     return rc;
 }
@@ -747,9 +767,10 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
 
     mark();  // 0
     k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlagsPtr(), keyCount.p);
+    if (shard.enabled && nb) k_shard_classify<<<divUp(nb, B), B, 0, st>>>(nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, sc);
     if (nc) {
         k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
-                                                     wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis);
+                                                     wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis, shard.enabled ? shard.active.p : nullptr);
         if (heightmap) {   // terrain contacts per collider, their offsets and totals (they join the pair list after the collider-pair narrow phase)
             k_hm_contacts<false><<<divUp(nc, 4), 256, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
             k_hm_slow<false><<<divUp(nc, 64), 64, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
@@ -822,13 +843,14 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
                                                         tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc,
                                                         heightmap ? make_float2(hmParams.restitution, hmParams.friction) : make_float2(0.f, 0.f));
+        if (shard.enabled) k_shard_count<<<divUp(pairBound, B), B, 0, st>>>(nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc);
     }
     // ---------------------------------------------------------------------------------------------- triggers / force fields
     std::vector<mi_event> triggerEvents;
     if (usesInteractions) { int rc = interactions(triggerEvents); if (rc != MI_OK) return rc; }
     mark();  // 3
     k_integrate_forces<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, make_float3(globalForce.x, globalForce.y, globalForce.z), bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, usesInteractions ? bForceStep.p : bForce.p, bTorque.p,
-                                                       gPos.p, gInvI.p, gVel.p, gVelL.p, bodyOwner.p);
+                                                       gPos.p, gInvI.p, gVel.p, gVelL.p, bodyOwner.p, shard.enabled ? shard.active.p : nullptr);
     mark();  // 4
     // ---------------------------------------------------------------------------------------------- schedule
     uint32_t nmBound = 0, conBound = 0;
@@ -1030,7 +1052,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     }
     mark();  // 7
     k_integrate_velocities<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
-                                                      gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p);
+                                                      gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p,
+                                                      shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p);
     mark();  // 8
     // ---------------------------------------------------------------------------------------------- end of step: the one read-back
     if (spinReadback) {
@@ -1141,6 +1164,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     if (nmBound) { tabCur ^= 1; tabValid = true; } else tabValid = false;
     hostStale = true;
     last.numPairs = hs.numPairs; last.numManifolds = hs.numManifolds; last.numContacts = hs.numContacts; last.numCells = hs.numCells;
+    for (int k = 0; k < 3; ++k) shard.owned[k] = hs.shardOwned[k];
     static const bool xcdStats = std::getenv("MI_XCD_STATS") != nullptr;   // development: how many bodies stayed XCD-local
     if (xcdStats && usedXcd && ((totalSteps % 50u) == 0u || std::getenv("MI_XCD_NOSORT"))) {
         std::vector<unsigned long long> own(nb);
@@ -1841,6 +1865,7 @@ MI_API int mi_world_test_interactions(mi_world* w, uint32_t count, const float* 
 
 MI_API int mi_world_step_fixed(mi_world* w, const mi_step_settings* s, float dt, uint32_t n) {
     if (!w || !s) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (n > 1 && w->shard.enabled && !w->shard.rccl) return fail(MI_ERR_INVALID_ARGUMENT, "a sharded world with the caller's transport takes one internal step per call (exchange in between)");
     if (n) w->transformsFollowPhysics = true;
     for (uint32_t i = 0; i < n; ++i) { int rc = w->stepInternal(*s, dt); if (rc != MI_OK) return rc; }
     return MI_OK;
@@ -1888,6 +1913,190 @@ MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
     int rc = w->stepInternal(*s, dt); if (rc != MI_OK) return rc;
     rc = w->download(); if (rc != MI_OK) return rc;
     for (HBody& b : w->bodies) { HEntity& e = w->entities[b.entity]; e.pos = b.p1; e.rot = b.r1; }
+    return MI_OK;
+}
+
+// ================================================================================================ sharded world (include/mi_shard.h)
+extern "C++" {
+namespace {
+// tile -> rank: tiles in ascending Morton code of (tx, tz); rank r simulates the r-th of them
+uint32_t mortonCode(uint32_t x, uint32_t z) { uint32_t c = 0; for (uint32_t b = 0; b < 16; ++b) c |= ((x >> b) & 1u) << (2 * b) | ((z >> b) & 1u) << (2 * b + 1); return c; }
+std::vector<uint32_t> tilesInRankOrder(uint32_t tx, uint32_t tz) {
+    std::vector<uint32_t> t((size_t)tx * tz);
+    for (uint32_t i = 0; i < t.size(); ++i) t[i] = i;
+    std::sort(t.begin(), t.end(), [&](uint32_t a, uint32_t b) { uint32_t ca = mortonCode(a % tx, a / tx), cb = mortonCode(b % tx, b / tx); return ca != cb ? ca < cb : a < b; });
+    return t;
+}
+struct Id128 { char bytes[128]; };   // ncclUniqueId
+// RCCL, resolved at run time (the library has no link-time dependency on it; a process that already loaded librccl.so.1 — torch — shares it)
+struct Rccl {
+    void* lib = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl* rccl() {
+    static Rccl r; static bool tried = false;
+    if (tried) return r.lib ? &r : nullptr;
+    tried = true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD); if (r.lib) break;
+    }
+    if (!r.lib) for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) { r.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL); if (r.lib) break; }
+    if (!r.lib) return nullptr;
+    auto sym = [&](const char* n) { return dlsym(r.lib, n); };
+    r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId"); r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
+    r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy"); r.Send = (decltype(r.Send))sym("ncclSend"); r.Recv = (decltype(r.Recv))sym("ncclRecv");
+    r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart"); r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd"); r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    if (!r.GetUniqueId || !r.CommInitRank || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd) { r.lib = nullptr; return nullptr; }
+    return &r;
+}
+constexpr int kNcclFloat32 = 7;   // ncclFloat32 (rccl.h)
+}
+}
+
+// Pack the records every neighbour is owed (device), then — library transport — one RCCL group of sends / receives on the world's stream and
+// the unpack kernels behind it; nothing is read back in between.  With the caller's transport the messages wait in sendBuf for mi_world_shard_export.
+void mi_world::shardReleaseComm() { if (shard.comm) { if (Rccl* r = rccl()) if (r->CommDestroy) (void)r->CommDestroy(shard.comm); shard.comm = nullptr; } }
+int mi_world::shardExchange() {
+    const uint32_t nb = (uint32_t)bodies.size();
+    if (!nb) return MI_OK;
+    ShardState& sh = shard;
+    if (sh.sentPending) {     // the previous exchange's counts have long arrived: a message that did not fit is an error, not a silent loss
+        sh.sentPending = false;
+        for (uint32_t k = 0; k < sh.sp.numPeers; ++k) if (sh.sentHost[k] > sh.capacity) return fail(MI_ERR_CAPACITY, "shard message overflow: raise mi_shard_desc::max_records (equal on all ranks)");
+    }
+    hipStream_t st = stream;
+    HIP_TRY(hipMemsetAsync(sh.sent.p, 0, 8 * sizeof(uint32_t), st));
+    StepScalars* sc = scalarsPtr();
+    HIP_TRY(hipMemsetAsync(&sc->shardSent[0], 0, 8 * sizeof(uint32_t), st));
+    for (uint32_t k = 0; k < sh.sp.numPeers; ++k) {
+        // after a valid step the buffer sets are swapped: bPos = the new state, bPosN = the state the step started from
+        k_shard_pack<<<divUp(nb, 256), 256, 0, st>>>(nb, sh.sp, k, sh.active.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bPosN.p, bRotN.p, bCogInvMass.p, sh.sendBuf[k].p, sh.capacity, sc);
+        k_shard_pack_header<<<1, 1, 0, st>>>(k, sc, sh.sendBuf[k].p);
+    }
+    HIP_TRY(hipMemcpyAsync(sh.sentHost, &sc->shardSent[0], 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    sh.sentPending = true;
+    if (!sh.rccl) { HIP_TRY(hipStreamSynchronize(st)); return MI_OK; }     // caller's transport: the messages are complete when this returns
+    Rccl* r = rccl();
+    const size_t n = sh.messageFloats();
+    int e = r->GroupStart(); if (e) return fail(MI_ERR_DEVICE, "ncclGroupStart failed");
+    for (uint32_t k = 0; k < sh.sp.numPeers && !e; ++k) {
+        e = r->Send(sh.sendBuf[k].p, n, kNcclFloat32, (int)sh.peerRanks[k], sh.comm, st);
+        if (!e) e = r->Recv(sh.recvBuf[k].p, n, kNcclFloat32, (int)sh.peerRanks[k], sh.comm, st);
+    }
+    const int e2 = r->GroupEnd();
+    if (e || e2) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e ? e : e2) : "RCCL send / receive failed");
+    for (uint32_t k = 0; k < sh.sp.numPeers; ++k)
+        k_shard_unpack<<<divUp(sh.capacity, 256), 256, 0, st>>>(nb, sh.recvBuf[k].p, sh.capacity, bPos.p, bRot.p, bLinVel.p, bAngVel.p);
+    hostStale = true;
+    return MI_OK;
+}
+
+MI_API int mi_shard_tile_of_rank(uint32_t tx, uint32_t tz, uint32_t rank, uint32_t* out) {
+    if (!out || !tx || !tz || tx > 65535u || tz > 65535u || rank >= tx * tz) return fail(MI_ERR_INVALID_ARGUMENT, "bad tile grid / rank");
+    *out = tilesInRankOrder(tx, tz)[rank]; return MI_OK;
+}
+MI_API int mi_shard_rank_of_tile(uint32_t tx, uint32_t tz, uint32_t tile, uint32_t* out) {
+    if (!out || !tx || !tz || tx > 65535u || tz > 65535u || tile >= tx * tz) return fail(MI_ERR_INVALID_ARGUMENT, "bad tile grid / tile");
+    const std::vector<uint32_t> t = tilesInRankOrder(tx, tz);
+    *out = (uint32_t)(std::find(t.begin(), t.end(), tile) - t.begin()); return MI_OK;
+}
+MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
+    if (!w || !d) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    if (!d->tiles_x || !d->tiles_z || d->tiles_x > 65535u || d->tiles_z > 65535u || d->num_ranks != d->tiles_x * d->tiles_z || d->rank >= d->num_ranks) return fail(MI_ERR_INVALID_ARGUMENT, "num_ranks must equal tiles_x * tiles_z");
+    if (!(d->tile_size_x > 0.f) || !(d->tile_size_z > 0.f) || !(d->ghost_margin > 0.f) || d->ghost_margin >= d->tile_size_x || d->ghost_margin >= d->tile_size_z) return fail(MI_ERR_INVALID_ARGUMENT, "0 < ghost_margin < tile size");
+    if (w->joints.count()) return fail(MI_ERR_UNSUPPORTED, "sharded worlds with constraints are not supported yet (an articulated island must stay on one rank)");
+    if (w->heightmap || !w->cloths.empty()) return fail(MI_ERR_UNSUPPORTED, "sharded worlds with heightmap terrain or cloth are not supported yet");
+    HIP_TRY(hipSetDevice(w->device));
+    mi_world::ShardState& sh = w->shard;
+    sh.desc = *d;
+    const std::vector<uint32_t> order = tilesInRankOrder(d->tiles_x, d->tiles_z);
+    ShardParams& sp = sh.sp;
+    sp.originX = d->origin_x; sp.originZ = d->origin_z; sp.tileX = d->tile_size_x; sp.tileZ = d->tile_size_z; sp.margin = d->ghost_margin;
+    sp.tilesX = d->tiles_x; sp.tilesZ = d->tiles_z; sp.myTile = order[d->rank]; sp.numPeers = 0; sh.peerRanks.clear();
+    const int mx = (int)(sp.myTile % sp.tilesX), mz = (int)(sp.myTile / sp.tilesX);
+    for (int z = mz - 1; z <= mz + 1; ++z) for (int x = mx - 1; x <= mx + 1; ++x) {          // ascending tile index
+        if ((x == mx && z == mz) || x < 0 || z < 0 || x >= (int)sp.tilesX || z >= (int)sp.tilesZ) continue;
+        const uint32_t t = (uint32_t)z * sp.tilesX + (uint32_t)x;
+        sp.peers[sp.numPeers++] = t;
+        sh.peerRanks.push_back((uint32_t)(std::find(order.begin(), order.end(), t) - order.begin()));
+    }
+    const uint32_t nb = (uint32_t)w->bodies.size();
+    sh.capacity = d->max_records ? d->max_records : std::max(4096u, nb / 4u);
+    HIP_TRY(sh.active.ensure(std::max(nb, 1u))); HIP_TRY(sh.sent.ensure(8));
+    for (uint32_t k = 0; k < sp.numPeers; ++k) {
+        HIP_TRY(sh.sendBuf[k].ensure(sh.messageFloats())); HIP_TRY(sh.recvBuf[k].ensure(sh.messageFloats()));
+        HIP_TRY(hipMemset(sh.sendBuf[k].p, 0, sh.messageFloats() * sizeof(float))); HIP_TRY(hipMemset(sh.recvBuf[k].p, 0, sh.messageFloats() * sizeof(float)));
+    }
+    if (!sh.sentHost) HIP_TRY(hipHostMalloc((void**)&sh.sentHost, 8 * sizeof(uint32_t)));
+    std::memset(sh.sentHost, 0, 8 * sizeof(uint32_t)); sh.sentPending = false;
+    sh.enabled = true;
+    w->haveEstimates = false;   // the first sharded step sizes itself exactly
+    return MI_OK;
+}
+MI_API int mi_world_shard_neighbours(mi_world* w, uint32_t* out, uint32_t* count) {
+    if (!w || !count || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    *count = w->shard.sp.numPeers;
+    if (out) for (uint32_t k = 0; k < w->shard.sp.numPeers; ++k) out[k] = w->shard.peerRanks[k];
+    return MI_OK;
+}
+MI_API int mi_world_shard_counts(mi_world* w, uint32_t* bodies, uint32_t* manifolds, uint32_t* contacts) {
+    if (!w || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    if (bodies) *bodies = w->shard.owned[0]; if (manifolds) *manifolds = w->shard.owned[1]; if (contacts) *contacts = w->shard.owned[2];
+    return MI_OK;
+}
+MI_API int mi_world_shard_owned_entities(mi_world* w, uint32_t* out, uint32_t cap, uint32_t* count) {
+    if (!w || !count || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    HIP_TRY(hipSetDevice(w->device));
+    const uint32_t nb = (uint32_t)w->bodies.size();
+    std::vector<uint8_t> act(nb);
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    if (nb) HIP_TRY(hipMemcpy(act.data(), w->shard.active.p, nb, hipMemcpyDeviceToHost));
+    uint32_t n = 0;
+    for (uint32_t b = 0; b < nb; ++b) if (act[b] == 1u) { if (out && n < cap) out[n] = w->bodies[b].entity; ++n; }
+    *count = n;
+    return (out && n > cap) ? fail(MI_ERR_CAPACITY, "capacity < owned bodies") : MI_OK;
+}
+MI_API int mi_shard_get_unique_id(void* out) {
+    if (!out) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    Rccl* r = rccl(); if (!r) return fail(MI_ERR_UNSUPPORTED, "librccl.so.1 not found");
+    return r->GetUniqueId(out) == 0 ? MI_OK : fail(MI_ERR_DEVICE, "ncclGetUniqueId failed");
+}
+MI_API int mi_world_shard_attach_rccl(mi_world* w, const void* id) {
+    if (!w || !id || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "enable sharding first");
+    Rccl* r = rccl(); if (!r) return fail(MI_ERR_UNSUPPORTED, "librccl.so.1 not found");
+    HIP_TRY(hipSetDevice(w->device));
+    Id128 uid; std::memcpy(uid.bytes, id, sizeof(uid.bytes));
+    const int e = r->CommInitRank(&w->shard.comm, (int)w->shard.desc.num_ranks, uid, (int)w->shard.desc.rank);
+    if (e) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e) : "ncclCommInitRank failed");
+    w->shard.rccl = true;
+    return MI_OK;
+}
+MI_API int mi_world_shard_message_bytes(mi_world* w, uint64_t* out) {
+    if (!w || !out || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    *out = (uint64_t)w->shard.messageFloats() * sizeof(float); return MI_OK;
+}
+MI_API int mi_world_shard_export(mi_world* w, uint32_t slot, void* out) {
+    if (!w || !out || !w->shard.enabled || slot >= w->shard.sp.numPeers) return fail(MI_ERR_INVALID_ARGUMENT, "bad slot");
+    HIP_TRY(hipSetDevice(w->device));
+    HIP_TRY(hipMemcpy(out, w->shard.sendBuf[slot].p, w->shard.messageFloats() * sizeof(float), hipMemcpyDeviceToHost));
+    return MI_OK;
+}
+MI_API int mi_world_shard_import(mi_world* w, const void* msg) {
+    if (!w || !msg || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    HIP_TRY(hipSetDevice(w->device));
+    uint32_t count; std::memcpy(&count, msg, 4);
+    if (count > w->shard.capacity) return fail(MI_ERR_CAPACITY, "shard message overflow: raise mi_shard_desc::max_records (equal on all ranks)");
+    const uint32_t nb = (uint32_t)w->bodies.size();
+    HIP_TRY(hipMemcpyAsync(w->shard.recvBuf[0].p, msg, (size_t)(count + 1u) * kShardRecordFloats * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    if (count) k_shard_unpack<<<divUp(count, 256), 256, 0, w->stream>>>(nb, w->shard.recvBuf[0].p, w->shard.capacity, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p);
+    HIP_TRY(hipStreamSynchronize(w->stream));     // `msg` is the caller's (possibly pageable) memory
+    w->hostStale = true;
     return MI_OK;
 }
 

@@ -1,0 +1,101 @@
+"""Driver of a sharded world (include/mi_shard.h) from Python: tile grid from the scene, and the three ways the neighbour messages
+can travel.  The sharding itself — ownership by the position of the centre of gravity, ghosts, migration, packing and unpacking the
+records, the owner rule for counts — is in the library (csrc/kernels.hpp k_shard_*, csrc/world.hip) behind the C ABI; a C++ host uses
+mi_world_shard_* directly and never sees this file.
+
+  transport "rccl"   the library's own: RCCL send / receive on the world's stream (one process per GPU; torch.distributed is only used
+                     to hand the 128-byte ncclUniqueId round)
+  transport "dist"   the caller's, over torch.distributed point-to-point with host buffers (gloo on CPU: the tests)
+  transport "local"  the caller's, between several worlds of ONE process (virtual ranks: what the multi-process result is compared with)
+"""
+import numpy as np
+
+from . import capi
+
+
+def tile_grid(scene, num_ranks, tiles_z=1, margin=2.5):
+    """An x-z tile grid over the dynamic bodies of `scene`: num_ranks / tiles_z tiles along x, tiles_z along z."""
+    assert num_ranks % tiles_z == 0
+    tiles_x = num_ranks // tiles_z
+    dyn = scene.entities["kind"] != capi.ENTITY_STATIC
+    p = scene.entities["position"][dyn]
+    lo = p.min(axis=0) - 0.5; hi = p.max(axis=0) + 0.5
+    d = capi.ShardDesc()
+    d.num_ranks = num_ranks; d.tiles_x = tiles_x; d.tiles_z = tiles_z
+    d.origin_x = float(lo[0]); d.origin_z = float(lo[2])
+    d.tile_size_x = float((hi[0] - lo[0]) / tiles_x); d.tile_size_z = float((hi[2] - lo[2]) / tiles_z)
+    d.ghost_margin = float(min(margin, 0.45 * d.tile_size_x, 0.45 * d.tile_size_z))
+    d.max_records = 0
+    return d
+
+
+def _desc_for(desc, rank):
+    d = capi.ShardDesc()
+    for name, _ in capi.ShardDesc._fields_:
+        setattr(d, name, getattr(desc, name))
+    d.rank = rank
+    return d
+
+
+class ShardedWorld:
+    """One rank of a sharded scene.  `world` already holds the WHOLE scene (every rank populates the same one)."""
+
+    def __init__(self, world, desc, rank, transport="local", dist=None):
+        self.world, self.rank, self.transport, self.dist = world, rank, transport, dist
+        self.desc = _desc_for(desc, rank)
+        world.shard_enable(self.desc)
+        self.neighbours = world.shard_neighbours()
+        if transport == "rccl":
+            import torch
+            ident = [world.L.shard_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ident, src=0)
+            world.shard_attach_rccl(ident[0])
+            torch.cuda.synchronize()
+
+    def step(self, settings, dt):
+        """One internal step of this rank's tile; with the library transport the exchange is part of it."""
+        self.world.step_fixed(settings, dt, 1)
+        if self.transport == "dist":
+            self._exchange_dist()
+
+    def outgoing(self):
+        return {peer: self.world.shard_export(slot) for slot, peer in enumerate(self.neighbours)}
+
+    def _exchange_dist(self):
+        import torch
+        ops, inbox, keep = [], [], []
+        for slot, peer in enumerate(self.neighbours):
+            out = torch.from_numpy(self.world.shard_export(slot)); keep.append(out)
+            buf = torch.zeros(out.numel(), dtype=torch.float32); inbox.append(buf)
+            ops.append(self.dist.P2POp(self.dist.isend, out, peer)); ops.append(self.dist.P2POp(self.dist.irecv, buf, peer))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        for buf in inbox:
+            self.world.shard_import(buf.numpy())
+
+    def owned_states(self):
+        ents = np.sort(self.world.shard_owned_entities())
+        return ents, self.world.get_body_states(ents)
+
+
+def step_local(ranks, settings, dt):
+    """Virtual ranks in one process: every tile steps, then the messages are handed over — what R processes do, sequentially."""
+    for r in ranks:
+        r.world.step_fixed(settings, dt, 1)
+    mail = [r.outgoing() for r in ranks]
+    for r in ranks:
+        for peer in r.neighbours:
+            r.world.shard_import(mail[peer][r.rank])
+
+
+def gather_owned(ranks, num_bodies_entities):
+    """(entity -> 13-float state) over all ranks; asserts that the owned sets partition the bodies."""
+    seen = {}
+    for r in ranks:
+        ents, st = r.owned_states()
+        for e, s in zip(ents, st):
+            assert int(e) not in seen, f"entity {e} owned twice"
+            seen[int(e)] = s
+    assert len(seen) == num_bodies_entities, f"{len(seen)} of {num_bodies_entities} bodies owned"
+    return np.stack([seen[k] for k in sorted(seen)])

@@ -1,0 +1,73 @@
+/*
+ * mi_shard.h — one scene on several GPUs: spatial sharding of an mi_world (the reference has no multi-GPU path).
+ *
+ * Model.  One process per GPU.  EVERY rank creates the SAME scene (same entities, colliders, in the same order: body and
+ * collider indices, pair priorities and colour-history keys then mean the same thing everywhere; 288 GB of HBM hold tens of
+ * millions of bodies) and enables sharding with its own rank.  The x-z plane is cut into tiles_x * tiles_z tiles, one per rank
+ * (tile -> rank in Morton order of the tile coordinates); rim tiles extend to infinity.  At the start of every internal step a
+ * rank classifies every body by the position of its centre of gravity:
+ *     OWNED  its tile contains the centre          -> simulated and integrated here
+ *     GHOST  within `ghost_margin` of its tile     -> takes part in collision detection and in the solve here; its new state
+ *                                                     is taken from its owner
+ *     else                                         -> not simulated here this step (its colliders leave the broad phase)
+ * so a body that crosses a tile border simply changes owner at the next step (MIGRATION needs no bookkeeping: the new owner has
+ * had the body as a ghost).  After the step every rank sends, to each of its <= 8 neighbour tiles, the new state (56-byte
+ * record: body index + position, rotation, linear and angular velocity) of every body it owned whose OLD or NEW centre lies in
+ * that neighbour's extended tile, and applies what it receives.  Counts follow an owner rule (a manifold belongs to the owner of
+ * its first dynamic body), so the sum over ranks counts every manifold once.
+ *
+ * What this is numerically: block Jacobi across the tile seams — each tile solves its extended region for all PGS sweeps of a
+ * step from the same start state, owners' results win.  Inside a tile everything is the single-GPU pipeline, bit for bit.  The
+ * result of R ranks equals, bit for bit, R such worlds stepped one after the other in ONE process with the records copied by hand
+ * (tests do exactly that, on the CPU oracle over gloo and on one GPU); it does NOT equal the unsharded world — the seam coupling
+ * of a step is one step late — and tests bound that difference.  Worlds with constraints are refused (an articulated island
+ * would have to stay on one rank: next).
+ *
+ * Transport.  Either the library's own: RCCL point-to-point (ncclSend / ncclRecv in one group per step, on the world's stream,
+ * fixed-size messages so that no host read-back sits between the step and the exchange) — mi_shard_get_unique_id on rank 0,
+ * distribute the 128 bytes by any means, mi_world_shard_attach_rccl everywhere.  Or the caller's: mi_world_shard_export /
+ * mi_world_shard_import move the same messages through host memory (MPI, gloo, a test harness).
+ */
+#ifndef MI_SHARD_H
+#define MI_SHARD_H
+#include "mi_physics.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mi_shard_desc {
+    uint32_t rank, num_ranks;       /* num_ranks == tiles_x * tiles_z */
+    float origin_x, origin_z;       /* min corner of the tile grid */
+    float tile_size_x, tile_size_z;
+    uint32_t tiles_x, tiles_z;
+    float ghost_margin;             /* >= largest collider extent + the distance a body can travel in one step; < tile size */
+    uint32_t max_records;           /* capacity of one neighbour message in records (0 = max(4096, bodies / 4)); must be equal on all ranks */
+} mi_shard_desc;
+
+#define MI_SHARD_RECORD_FLOATS 14   /* body index (bit pattern) + 13 state floats; record 0 of a message = (count, unused...) */
+
+/* Tile of a rank / rank of a tile under the Morton mapping (pure functions; tiles are numbered tz * tiles_x + tx). */
+MI_API int mi_shard_tile_of_rank(uint32_t tiles_x, uint32_t tiles_z, uint32_t rank, uint32_t* out_tile);
+MI_API int mi_shard_rank_of_tile(uint32_t tiles_x, uint32_t tiles_z, uint32_t tile, uint32_t* out_rank);
+
+MI_API int mi_world_shard_enable(mi_world* world, const mi_shard_desc* desc);
+/* Neighbour ranks of this world's tile, ascending tile order (the order of the message slots); returns the count (<= 8). */
+MI_API int mi_world_shard_neighbours(mi_world* world, uint32_t* out_ranks8, uint32_t* out_count);
+/* Owned bodies / manifolds / contacts of the last internal step (sum over ranks = every body / manifold / contact once). */
+MI_API int mi_world_shard_counts(mi_world* world, uint32_t* out_bodies, uint32_t* out_manifolds, uint32_t* out_contacts);
+/* Entity ids of the bodies this rank owned in the last internal step (their read-backs are authoritative). */
+MI_API int mi_world_shard_owned_entities(mi_world* world, uint32_t* out_entities, uint32_t capacity, uint32_t* out_count);
+
+/* Library transport: RCCL.  out_id128 / id128: the 128 bytes of an ncclUniqueId. */
+MI_API int mi_shard_get_unique_id(void* out_id128);
+MI_API int mi_world_shard_attach_rccl(mi_world* world, const void* id128);
+/* Caller's transport: after mi_world_step_fixed(world, ..., 1) copy the message for neighbour slot `slot` out (host memory,
+ * mi_world_shard_message_bytes bytes) and hand the neighbours' messages in; both may be called in any order across slots. */
+MI_API int mi_world_shard_message_bytes(mi_world* world, uint64_t* out_bytes);
+MI_API int mi_world_shard_export(mi_world* world, uint32_t slot, void* out_message);
+MI_API int mi_world_shard_import(mi_world* world, const void* message);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MI_SHARD_H */

@@ -255,6 +255,11 @@ static void getWorldSpaceColliders(World& w) {
         const Entity& e = w.entities[c.entity];
         WorldCollider& col = w.wc[k]; AABB& bb = w.aabbs[k];
         vec3 tp; quat tr;
+        if (w.shard.enabled && e.rb >= 0 && !w.shard.active[e.rb]) {   // sharded world: a body this rank does not simulate this step (k_world_colliders)
+            col.objectIndex = (uint32_t)e.rb; col.objectType = MI_OBJECT_RIGID_BODY; col.mat = c.mat; col.s = Shape(); col.s.type = c.local.type;
+            bb.mn = vec3(3.0e38f); bb.mx = vec3(-3.0e38f);
+            continue;
+        }
         if (e.rb >= 0) { tp = w.bodies[e.rb].p1; tr = w.bodies[e.rb].r1; col.objectIndex = (uint32_t)e.rb; col.objectType = MI_OBJECT_RIGID_BODY; }
         else if (e.kind == MI_ENTITY_FORCE_FIELD) { tp = e.position; tr = e.rotation; col.objectIndex = e.kindIndex; col.objectType = MI_OBJECT_FORCE_FIELD; }
         else if (e.kind == MI_ENTITY_TRIGGER) { tp = e.position; tr = e.rotation; col.objectIndex = e.kindIndex; col.objectType = MI_OBJECT_TRIGGER; }
@@ -793,6 +798,8 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
         return;
     }
     uint32_t axisUsed = sortingAxis;
+    std::vector<vec3> cogBefore;
+    if (shard.enabled) { shardClassify(); cogBefore.resize(nb); for (uint32_t i = 0; i < nb; ++i) cogBefore[i] = bodies[i].p1 + bodies[i].r1 * bodies[i].localCOG; }
     getWorldSpaceColliders(*this);
     if (orderMode == 0) { broadphaseReference(*this); narrowphaseReference(*this); }
     else { broadphaseCanonical(*this); narrowphaseCanonical(*this, axisUsed); }
@@ -801,6 +808,10 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
     vec3 globalForceField = nonCollisionInteractions(*this);   // force fields, triggers (physics.cpp:1253-1256)
     rb.resize(nb + 1);
     for (uint32_t i = nb; i-- > 0;) {                           // back to front (1266-1276)
+        if (shard.enabled && shard.active[i] != 1) {            // sharded world: only the owner advances a body; a ghost gets its solver-side state from a copy
+            if (shard.active[i] == 2) { RigidBody tmp = bodies[i]; tmp.forceAccumulator += globalForceField; applyGravityAndIntegrateForces(tmp, rb[i], dt); }
+            continue;
+        }
         bodies[i].forceAccumulator += globalForceField;         // physics.cpp:1273
         applyGravityAndIntegrateForces(bodies[i], rb[i], dt);
     }
@@ -835,7 +846,18 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
         jointsSolveIteration(*this);  // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
         for (uint32_t id : solveOrder) solveContact(*this, id, cc[id]);
     }
-    for (uint32_t i = nb; i-- > 0;) integrateVelocity(bodies[i], rb[i], dt);
+    for (uint32_t i = nb; i-- > 0;) { if (shard.enabled && shard.active[i] != 1) continue; integrateVelocity(bodies[i], rb[i], dt); }
+    if (shard.enabled) {
+        shard.owned[1] = shard.owned[2] = 0;                    // owner rule: a manifold belongs to the owner of its first dynamic body
+        uint32_t off = 0;
+        for (uint32_t m = 0; m < (uint32_t)colliderPairs.size(); ++m) {
+            Pair bp = bodyPairs[off];
+            uint32_t first = (bp.a < nb && bodies[bp.a].invMass != 0.f) ? bp.a : bp.b;
+            if (first < nb && shard.active[first] == 1) { ++shard.owned[1]; shard.owned[2] += contactCounts[m]; }
+            off += contactCounts[m];
+        }
+        shardPack(cogBefore);
+    }
     for (Cloth* c : cloths) {   // physics.cpp:1352-1358
         c->applyWindForce(globalForceField);
         c->simulate(clothIterations[0], clothIterations[1], clothIterations[2], dt, orderMode != 0);
@@ -933,6 +955,61 @@ int World::destroyEntity(uint32_t entity) {
     prevPairColor.clear(); prevCollisionKeys.clear(); prevTriggerOverlaps.clear();
     dirtyProps = true;
     return MI_OK;
+}
+}  // namespace ora
+
+// ---------------------------------------------------------------- sharded world (include/mi_shard.h; mirrors k_shard_* of the product)
+namespace ora {
+static uint32_t mortonCode(uint32_t x, uint32_t z) { uint32_t c = 0; for (uint32_t b = 0; b < 16; ++b) c |= ((x >> b) & 1u) << (2 * b) | ((z >> b) & 1u) << (2 * b + 1); return c; }
+static std::vector<uint32_t> tilesInRankOrder(uint32_t tx, uint32_t tz) {
+    std::vector<uint32_t> t((size_t)tx * tz);
+    for (uint32_t i = 0; i < t.size(); ++i) t[i] = i;
+    std::sort(t.begin(), t.end(), [&](uint32_t a, uint32_t b) { uint32_t ca = mortonCode(a % tx, a / tx), cb = mortonCode(b % tx, b / tx); return ca != cb ? ca < cb : a < b; });
+    return t;
+}
+static uint32_t shardTileOf(const mi_shard_desc& d, float x, float z) {
+    int tx = std::min(std::max((int)std::floor((x - d.origin_x) / d.tile_size_x), 0), (int)d.tiles_x - 1);
+    int tz = std::min(std::max((int)std::floor((z - d.origin_z) / d.tile_size_z), 0), (int)d.tiles_z - 1);
+    return (uint32_t)tz * d.tiles_x + (uint32_t)tx;
+}
+static bool shardInExtended(const mi_shard_desc& d, uint32_t t, float x, float z) {
+    const uint32_t tx = t % d.tiles_x, tz = t / d.tiles_x;
+    const float x0 = d.origin_x + (float)tx * d.tile_size_x - d.ghost_margin, x1 = d.origin_x + (float)(tx + 1u) * d.tile_size_x + d.ghost_margin;
+    const float z0 = d.origin_z + (float)tz * d.tile_size_z - d.ghost_margin, z1 = d.origin_z + (float)(tz + 1u) * d.tile_size_z + d.ghost_margin;
+    return (tx == 0u || x >= x0) && (tx + 1u == d.tiles_x || x < x1) && (tz == 0u || z >= z0) && (tz + 1u == d.tiles_z || z < z1);
+}
+void World::shardClassify() {
+    const uint32_t nb = (uint32_t)bodies.size();
+    shard.active.assign(nb, 0); shard.owned[0] = 0;
+    for (uint32_t i = 0; i < nb; ++i) {
+        vec3 c = bodies[i].p1 + bodies[i].r1 * bodies[i].localCOG;
+        bool owned = shardTileOf(shard.desc, c.x, c.z) == shard.myTile;
+        shard.active[i] = owned ? 1 : shardInExtended(shard.desc, shard.myTile, c.x, c.z) ? 2 : 0;
+        shard.owned[0] += owned ? 1u : 0u;
+    }
+}
+void World::shardPack(const std::vector<vec3>& oldCog) {
+    const uint32_t nb = (uint32_t)bodies.size();
+    for (size_t k = 0; k < shard.peers.size(); ++k) {
+        std::vector<float>& msg = shard.sendBuf[k];
+        msg.assign((size_t)(shard.capacity + 1u) * MI_SHARD_RECORD_FLOATS, 0.f);
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < nb; ++i) {
+            if (shard.active[i] != 1) continue;
+            const RigidBody& b = bodies[i];
+            vec3 cn = b.p1 + b.r1 * b.localCOG, co = oldCog[i];
+            if (!shardInExtended(shard.desc, shard.peers[k], cn.x, cn.z) && !shardInExtended(shard.desc, shard.peers[k], co.x, co.z)) continue;
+            if (n < shard.capacity) {
+                float* o = msg.data() + (size_t)(n + 1u) * MI_SHARD_RECORD_FLOATS;
+                std::memcpy(o, &i, 4);
+                o[1] = b.p1.x; o[2] = b.p1.y; o[3] = b.p1.z; o[4] = b.r1.x; o[5] = b.r1.y; o[6] = b.r1.z; o[7] = b.r1.w;
+                o[8] = b.linearVelocity.x; o[9] = b.linearVelocity.y; o[10] = b.linearVelocity.z;
+                o[11] = b.angularVelocity.x; o[12] = b.angularVelocity.y; o[13] = b.angularVelocity.z;
+            }
+            ++n;
+        }
+        std::memcpy(msg.data(), &n, 4);
+    }
 }
 }  // namespace ora
 
@@ -1316,6 +1393,71 @@ MI_API int ora_world_load_checkpoint(World* w, const void* data, uint64_t size) 
         if (w->eventsEnabled && (key & ((1ull << 26) - 1ull)) < kHeightmapVirtualBase) w->prevCollisionKeys.push_back(key);
     }
     std::sort(w->prevCollisionKeys.begin(), w->prevCollisionKeys.end());
+    return MI_OK;
+}
+MI_API int ora_shard_tile_of_rank(uint32_t tx, uint32_t tz, uint32_t rank, uint32_t* out) { if (!out || !tx || !tz || rank >= tx * tz) return MI_ERR_INVALID_ARGUMENT; *out = ora::tilesInRankOrder(tx, tz)[rank]; return MI_OK; }
+MI_API int ora_shard_rank_of_tile(uint32_t tx, uint32_t tz, uint32_t tile, uint32_t* out) {
+    if (!out || !tx || !tz || tile >= tx * tz) return MI_ERR_INVALID_ARGUMENT;
+    auto t = ora::tilesInRankOrder(tx, tz); *out = (uint32_t)(std::find(t.begin(), t.end(), tile) - t.begin()); return MI_OK;
+}
+MI_API int ora_world_shard_enable(World* w, const mi_shard_desc* d) {
+    if (!w || !d || !d->tiles_x || !d->tiles_z || d->num_ranks != d->tiles_x * d->tiles_z || d->rank >= d->num_ranks) return MI_ERR_INVALID_ARGUMENT;
+    if (!(d->tile_size_x > 0.f) || !(d->tile_size_z > 0.f) || !(d->ghost_margin > 0.f) || d->ghost_margin >= d->tile_size_x || d->ghost_margin >= d->tile_size_z) return MI_ERR_INVALID_ARGUMENT;
+    if (w->orderMode != 1 || jointsCount(*w) || w->heightmap || !w->cloths.empty()) return MI_ERR_UNSUPPORTED;
+    World::Shard& sh = w->shard;
+    sh.desc = *d;
+    auto order = ora::tilesInRankOrder(d->tiles_x, d->tiles_z);
+    sh.myTile = order[d->rank]; sh.peers.clear(); sh.peerRanks.clear();
+    const int mx = (int)(sh.myTile % d->tiles_x), mz = (int)(sh.myTile / d->tiles_x);
+    for (int z = mz - 1; z <= mz + 1; ++z) for (int x = mx - 1; x <= mx + 1; ++x) {
+        if ((x == mx && z == mz) || x < 0 || z < 0 || x >= (int)d->tiles_x || z >= (int)d->tiles_z) continue;
+        const uint32_t t = (uint32_t)z * d->tiles_x + (uint32_t)x;
+        sh.peers.push_back(t); sh.peerRanks.push_back((uint32_t)(std::find(order.begin(), order.end(), t) - order.begin()));
+    }
+    sh.capacity = d->max_records ? d->max_records : std::max<uint32_t>(4096u, (uint32_t)w->bodies.size() / 4u);
+    sh.sendBuf.assign(sh.peers.size(), std::vector<float>((size_t)(sh.capacity + 1u) * MI_SHARD_RECORD_FLOATS, 0.f));
+    sh.enabled = true;
+    return MI_OK;
+}
+MI_API int ora_world_shard_neighbours(World* w, uint32_t* out, uint32_t* count) {
+    if (!w || !count || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
+    *count = (uint32_t)w->shard.peers.size();
+    if (out) for (size_t k = 0; k < w->shard.peers.size(); ++k) out[k] = w->shard.peerRanks[k];
+    return MI_OK;
+}
+MI_API int ora_world_shard_counts(World* w, uint32_t* b, uint32_t* m, uint32_t* c) {
+    if (!w || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
+    if (b) *b = w->shard.owned[0]; if (m) *m = w->shard.owned[1]; if (c) *c = w->shard.owned[2];
+    return MI_OK;
+}
+MI_API int ora_world_shard_owned_entities(World* w, uint32_t* out, uint32_t cap, uint32_t* count) {
+    if (!w || !count || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < w->shard.active.size(); ++i) if (w->shard.active[i] == 1) { if (out && n < cap) out[n] = w->bodies[i].entity; ++n; }
+    *count = n;
+    return (out && n > cap) ? MI_ERR_CAPACITY : MI_OK;
+}
+MI_API int ora_world_shard_message_bytes(World* w, uint64_t* out) {
+    if (!w || !out || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
+    *out = (uint64_t)(w->shard.capacity + 1u) * MI_SHARD_RECORD_FLOATS * sizeof(float); return MI_OK;
+}
+MI_API int ora_world_shard_export(World* w, uint32_t slot, void* out) {
+    if (!w || !out || !w->shard.enabled || slot >= w->shard.sendBuf.size()) return MI_ERR_INVALID_ARGUMENT;
+    std::memcpy(out, w->shard.sendBuf[slot].data(), w->shard.sendBuf[slot].size() * sizeof(float)); return MI_OK;
+}
+MI_API int ora_world_shard_import(World* w, const void* msg) {
+    if (!w || !msg || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
+    uint32_t count; std::memcpy(&count, msg, 4);
+    if (count > w->shard.capacity) return MI_ERR_CAPACITY;
+    const float* f = static_cast<const float*>(msg);
+    for (uint32_t r = 0; r < count; ++r) {
+        const float* s = f + (size_t)(r + 1u) * MI_SHARD_RECORD_FLOATS;
+        uint32_t b; std::memcpy(&b, s, 4);
+        if (b >= w->bodies.size()) continue;
+        RigidBody& rb = w->bodies[b];
+        rb.p1 = vec3(s[1], s[2], s[3]); rb.r1 = quat(s[4], s[5], s[6], s[7]);
+        rb.linearVelocity = vec3(s[8], s[9], s[10]); rb.angularVelocity = vec3(s[11], s[12], s[13]);
+    }
     return MI_OK;
 }
 MI_API float ora_det_atan2f(float y, float x) { return det_atan2f(y, x); }

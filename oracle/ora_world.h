@@ -13,6 +13,7 @@
 #include "ora_math.h"
 #include "../include/mi_physics.h"
 #include "../include/mi_constraints.h"
+#include "../include/mi_shard.h"
 
 namespace ora {
 
@@ -165,6 +166,16 @@ struct World {
     std::unordered_map<uint64_t, uint32_t> prevPairColor;   // canonical mode: colour of every manifold of the previous step, by (colliderA << 26 | colliderB)
     std::vector<GlobalState> rb;
     mi_step_counts counts{};
+    // sharded world (include/mi_shard.h), canonical order only: this rank's tile, per-body activity (1 owned, 2 ghost, 0 elsewhere)
+    struct Shard {
+        bool enabled = false; mi_shard_desc desc{}; uint32_t myTile = 0, capacity = 0;
+        std::vector<uint32_t> peers, peerRanks;
+        std::vector<uint8_t> active;
+        std::vector<std::vector<float>> sendBuf;      // one message per neighbour slot (record 0 = count)
+        uint32_t owned[3] = {0, 0, 0};
+    } shard;
+    void shardClassify();
+    void shardPack(const std::vector<vec3>& oldCog);
 
     World();
     ~World();
