@@ -8,7 +8,9 @@ A "step" is one pass of the hot path (physicsStepInternal: world colliders -> br
 -> integrate forces -> schedule -> constraint init -> I PGS sweeps -> integrate velocities) over the
 whole synthetic scene.  Workload at N=1: cfg3, the 262 144-body OBB pile (128 x 16 x 128 boxes, half-extents
 U[0.3,0.6], friction 0.5, 20 solver iterations, walled pen) — the configuration BASELINE.json's metric is
-quoted on; it fits one GPU.
+quoted on; it fits one GPU.  N > 1 (one process per GPU, include/mi_shard.h): every rank holds the whole scene and simulates one
+x tile of it (ownership by position, ghost strip, neighbour exchange over RCCL inside the library).  `--scaling weak` (default): the
+pen grows with N (128 N x 16 x 128 boxes: 262 144 bodies per GPU); `--scaling strong`: the one 262 144-body pile is cut into N tiles.
 
 THE TIMED STATE IS PART OF THE WORKLOAD, NOT OF THE FLAGS.  The lattice is first stepped SETTLE_STEPS = 240 times
 (untimed, always; BASELINE.md §2 "settle") so that the boxes are piled up (~3.3 contacts per body); only then come the
@@ -48,6 +50,11 @@ def parse():
     ap.add_argument("--grid", type=int, nargs=3, default=[128, 16, 128], help="boxes per axis of one GPU's tile (default = 262144 bodies)")
     ap.add_argument("--iterations", type=int, default=20)
     ap.add_argument("--settle", type=int, default=SETTLE_STEPS, help="development only: anything but 240 is flagged in the output")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak", help="N > 1: grow the pen with N (weak) or cut the one pile into N tiles (strong)")
+    ap.add_argument("--tiles-z", type=int, default=1, help="N > 1: tiles along z (tiles along x = N / tiles-z)")
+    ap.add_argument("--ghost-margin", type=float, default=2.5)
+    ap.add_argument("--transport", choices=["rccl", "dist"], default=os.environ.get("MI_SHARD_TRANSPORT", "rccl"),
+                    help="N > 1: neighbour exchange by the library's own RCCL send/recv (default) or by torch.distributed point-to-point through host buffers")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-at-rest", action="store_true", help="skip the second measurement after 1500 steps")
     ap.add_argument("--cpu-grid", type=int, nargs=3, default=[32, 16, 32])
@@ -183,24 +190,40 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     dist = None
-    torch.cuda.set_device(local_rank)   # torch's HIP runtime comes up before the library touches the device
+    device = local_rank % max(1, torch.cuda.device_count())     # (several ranks on one GPU only make sense with --transport dist: a functional check)
+    torch.cuda.set_device(device)   # torch's HIP runtime comes up before the library touches the device
+    red_dev = "cuda"
     if world_size > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", local_rank))
+        if args.transport == "rccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", device))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world_size); red_dev = "cpu"
     if world_size != args.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world_size}; launch with torch.distributed.run", file=sys.stderr)
         sys.exit(2)
 
     import d3d12renderer_amd as mi
-    from d3d12renderer_amd.distributed import ShardedWorld
+    from d3d12renderer_amd import scenes, sharding
 
     nx, ny, nz = args.grid
-    sw = ShardedWorld(lambda: mi.create_world(local_rank), rank, world_size, dist, tile=(nx, ny, nz), iterations=args.iterations)
-    settings = sw.settings()
-    dt = sw.dt
-    bodies_per_gpu = sw.bodies_per_rank
-    total_bodies = bodies_per_gpu * world_size
+    gx = nx * world_size if (world_size > 1 and args.scaling == "weak") else nx
+    scene = scenes.obb_pile(gx, ny, nz, solver_iterations=args.iterations)       # the WHOLE scene, on every rank
+    world = scene.populate(mi.create_world(device))
+
+    class _Single:                      # N = 1: the plain world
+        def __init__(self, w): self.world = w
+        def step(self, s, dt): self.world.step_fixed(s, dt, 1)
+    if world_size > 1:
+        desc = sharding.tile_grid(scene, world_size, args.tiles_z, args.ghost_margin)
+        sw = sharding.ShardedWorld(world, desc, rank, args.transport, dist)
+        sharding_note = (f"{world_size} tiles ({desc.tiles_x} x {desc.tiles_z}) of one replicated scene, ghost margin {desc.ghost_margin:.2f} m, ownership by position each step, "
+                         f"neighbour exchange: {'RCCL send/recv inside the library' if args.transport == 'rccl' else 'torch.distributed p2p via host'}; {args.scaling} scaling")
+    else:
+        sw = _Single(world); sharding_note = "single GPU, whole scene"
+    settings = scene.settings()
+    dt = scene.dt
 
     def barrier():
         torch.cuda.synchronize()
@@ -215,7 +238,10 @@ def main():
         sw.step(settings, dt)
     barrier()
     c0 = sw.world.counts()
-    contacts_per_body = c0["num_contacts"] / max(1, c0["num_rigid_bodies"])
+    total_bodies = scene.num_bodies
+    bodies_per_gpu = sw.world.shard_counts()["owned_bodies"] if world_size > 1 else total_bodies
+    local_bodies = max(1, bodies_per_gpu)            # N > 1: local counts cover the tile + its ghost strip; per owned body is close enough for the guard
+    contacts_per_body = c0["num_contacts"] / (local_bodies if world_size > 1 else max(1, c0["num_rigid_bodies"]))
     if contacts_per_body < MIN_CONTACTS_PER_BODY and args.settle >= SETTLE_STEPS:
         raise SystemExit(f"bench.py: {contacts_per_body:.2f} contacts per body after {args.settle} settle steps — this is not the piled-up workload")
 
@@ -230,9 +256,10 @@ def main():
     stage_prof = {}
     for _ in range(3):
         n_l, ms, upd = sw.world.step_profiled(settings, dt)
+        if world_size > 1:
+            sw.exchange()
         for k, v in sw.world.stage_times().items():
             stage_prof[k] = stage_prof.get(k, 0.0) + v / 3.0
-        sw.exchange_ghosts()
         prof_launches += n_l; prof_ms += ms; prof_updates += upd
     sw.world.set_stage_timing(False)
 
@@ -252,15 +279,21 @@ def main():
                    "solver_frac_algorithmic": (BYTES_PER_CONTACT_ITER * ci2) / (acc2["solve"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if acc2["solve"] > 0 else None,
                    "step_frac_algorithmic": step_algorithmic_bytes(c2, args.iterations) / (e2 / n_rest) / 1e9 / HBM_PEAK_GBPS}
 
+    global_counts = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        oc = sw.world.shard_counts()
+        g = torch.tensor([oc["owned_bodies"], oc["owned_manifolds"], oc["owned_contacts"]], dtype=torch.int64, device=red_dev)
+        dist.all_reduce(g)
+        global_counts = {"bodies": int(g[0]), "manifolds": int(g[1]), "contacts": int(g[2])}
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
-        # whole-job throughput: every rank steps its 262144-body tile each step; value = tiles-steps per second (N=1: steps/s)
-        value = world_size * args.steps / elapsed
+        # whole-job throughput.  weak: every rank steps a 262144-body tile of an N times larger pen per step -> tiles-steps per second
+        # (N = 1: plain steps/s of the 262144-body scene); strong: steps per second of the ONE 262144-body scene
+        value = (world_size if args.scaling == "weak" else 1) * args.steps / elapsed
         launches_per_step = launches / args.steps
         kernel = sw.world.solver_kernel()
         avg_launch_s = solve_ms * 1e-3 / max(launches, 1)
@@ -290,16 +323,16 @@ def main():
         out = {
             "metric": "physics steps/sec at 262144 rigid bodies per GPU (OBB pile, 20 solver iterations)",
             "value": value, "unit": "steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling if world_size > 1 else "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": (f"cfg3 obb_pile {nx}x{ny}x{nz} boxes per GPU ({bodies_per_gpu} bodies/GPU, {total_bodies} total), friction 0.5, "
+            "config": {"workload": (f"cfg3 obb_pile {gx}x{ny}x{nz} boxes ({total_bodies} bodies in total, {bodies_per_gpu} owned by rank 0), friction 0.5, "
                                     f"{args.iterations} solver iterations, dt=1/120, settled {args.settle} steps before warm-up "
                                     f"({counts['num_contacts'] / max(1, counts['num_rigid_bodies']):.2f} contacts per body when timed)"),
                        "settle_steps": args.settle, "settle_is_standard": args.settle == SETTLE_STEPS,
                        "bodies_per_gpu": bodies_per_gpu, "contacts": counts["num_contacts"], "manifolds": counts["num_collisions"],
                        "contacts_per_body": counts["num_contacts"] / max(1, counts["num_rigid_bodies"]),
                        "broadphase_overlaps": counts["num_broadphase_overlaps"], "colors": counts["num_colors"],
-                       "sharding": sw.sharding_note},
+                       "global_counts": global_counts, "sharding": sharding_note},
             "roofline": roofline,
             "stage_ms": stage_prof, "stage_ms_note": "per-stage device times of the 3 extra steps after the timed region (stage timing enabled only there)",
             "step_ms_median": float(np.median(step_ms)), "step_ms_p95": float(np.percentile(step_ms, 95)),

@@ -55,6 +55,10 @@ class ShardedWorld:
     def step(self, settings, dt):
         """One internal step of this rank's tile; with the library transport the exchange is part of it."""
         self.world.step_fixed(settings, dt, 1)
+        self.exchange()
+
+    def exchange(self):
+        """The caller's-transport half of a step (nothing to do when the library exchanges itself)."""
         if self.transport == "dist":
             self._exchange_dist()
 
