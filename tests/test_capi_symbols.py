@@ -58,6 +58,7 @@ def test_struct_sizes_match_header():
     assert capi.hinge_constraint.itemsize == 104 and capi.cone_twist_constraint.itemsize == 120   # = reference sizes
     assert capi.distance_constraint.itemsize == 28 and capi.ball_constraint.itemsize == 24
     assert capi.fixed_constraint.itemsize == 40 and capi.slider_constraint.itemsize == 72
+    assert C.sizeof(capi.ShardDesc) == 40 and capi.SHARD_RECORD_FLOATS == 14                       # mi_shard_desc, MI_SHARD_RECORD_FLOATS
 
 
 def _build_facade(tmp_path, mi_lib):
