@@ -64,6 +64,7 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numHmColliders;       // ... and the colliders they belong to (= the reference's collision count for the terrain)
     uint32_t xcdCount[8];          // XCD-partitioned solver: tiles owned by each XCD (k_build_tiles)
     uint32_t xccOf[8];             // ... and the hardware XCC id the workgroups with blockIdx % 8 == i really ran on (0xFFFFFFFF = none yet)
+    uint32_t numCellsNext;         // cells of the grid k_pair_finish prepared for the next step
     uint32_t numDead;              // sharded world: colliders of bodies this rank does not simulate this step (they take no part in the broad phase)
     uint32_t shardOwned[3];        // sharded world: bodies / manifolds / contacts OWNED by this rank (owner rule: the manifold's first dynamic body)
     uint32_t shardSent[8];         // sharded world: records packed for each neighbour this step (slot order of ShardParams::peers)
@@ -347,6 +348,69 @@ __global__ __launch_bounds__(256) void k_bp_cell_ids(uint32_t nc, const float4* 
     keys[i] = key; ranks[i] = rank;
 }
 
+
+// Steps after the first use the grid computed at the END OF THE PREVIOUS STEP (k_pair_finish): threshold, cell size, origin and dims
+// only steer which colliders go through the grid and how fine it is, never the pair set — every small collider still has an extent
+// <= the cell (it is classified against the same threshold), and centres outside the old bounds clamp to the rim cells, which keeps
+// neighbours neighbours.  That takes k_bp_threshold and k_bp_grid_setup off the step's critical path and lets ONE kernel do what
+// k_axis_partials, k_bp_classify and k_bp_cell_ids did: centre statistics (same fixed reduction shape), extent histogram,
+// dead / large / small classification, bounds of the small centres, cell id + arrival rank.
+__global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax, const GridParams* __restrict__ gp,
+                                                    double* __restrict__ partials, Shards* sh, StepScalars* sc, uint32_t* __restrict__ largeList, uint32_t* __restrict__ isLarge,
+                                                    int* __restrict__ blockBounds, uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks, uint32_t* __restrict__ cellCount) {
+    __shared__ double sm[4][6];
+    __shared__ uint32_t hist[256];
+    __shared__ int sb[4][6];
+    hist[threadIdx.x] = 0;
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const GridParams g = *gp;
+    double v[6] = {0, 0, 0, 0, 0, 0};
+    int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
+    bool dead = false;
+    if (i < nc) {
+        const float4 mn = aabbMin[i], mx = aabbMax[i];
+        const float cx = (mn.x + mx.x) * 0.5f, cy = (mn.y + mx.y) * 0.5f, cz = (mn.z + mx.z) * 0.5f;
+        v[0] = cx; v[1] = cy; v[2] = cz;
+        v[3] = (double)cx * (double)cx; v[4] = (double)cy * (double)cy; v[5] = (double)cz * (double)cz;
+        const float ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
+        atomicAdd(&hist[extentBin(ext)], 1u);   // only steers the NEXT step's cell size
+        dead = mx.x < mn.x;
+        const bool large = ext > g.largeThreshold;
+        isLarge[i] = dead ? 2u : large ? 1u : 0u;
+        uint32_t key = 0xFFFFFFFFu, rank = 0;
+        if (dead) {}
+        else if (large) { uint32_t slot = atomicAdd(&sc->numLarge, 1u); largeList[slot] = i; }
+        else {
+            lo[0] = hi[0] = orderedInt(cx); lo[1] = hi[1] = orderedInt(cy); lo[2] = hi[2] = orderedInt(cz);
+            uint32_t ix, iy, iz;
+            cellOf(g, cx, cy, cz, ix, iy, iz);
+            key = (ix * g.dims[1] + iy) * g.dims[2] + iz;
+            rank = atomicAdd(&cellCount[key], 1u);
+        }
+        keys[i] = key; ranks[i] = rank;
+    }
+    { const unsigned long long deadMask = __ballot(dead); if (deadMask && (threadIdx.x & 63u) == 0u) atomicAdd(&sc->numDead, (uint32_t)__popcll(deadMask)); }
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (int c = 0; c < 6; ++c) v[c] += __shfl_down(v[c], off, 64);
+#pragma unroll
+        for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], __shfl_xor(lo[a], off, 64)); hi[a] = max(hi[a], __shfl_xor(hi[a], off, 64)); }
+    }
+    const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) { for (int c = 0; c < 6; ++c) sm[wv][c] = v[c]; for (int a = 0; a < 3; ++a) { sb[wv][a] = lo[a]; sb[wv][3 + a] = hi[a]; } }
+    __syncthreads();
+    if (hist[threadIdx.x]) atomicAdd(&sh->extentHist[blockIdx.x & (kShards - 1u)][threadIdx.x], hist[threadIdx.x]);
+    if (threadIdx.x == 0) {
+        for (int c = 0; c < 6; ++c) { double a = 0.0; for (int w = 0; w < 4; ++w) a += sm[w][c]; partials[blockIdx.x * 6 + c] = a; }
+    }
+    if (threadIdx.x < 6) {
+        int x = sb[0][threadIdx.x];
+        for (int w = 1; w < 4; ++w) x = threadIdx.x < 3 ? min(x, sb[w][threadIdx.x]) : max(x, sb[w][threadIdx.x]);
+        blockBounds[blockIdx.x * 6 + threadIdx.x] = x;
+    }
+}
+
 // Cell-sorted copies of the AABB rows (a column scan reads contiguous memory), the cell key and the collider index.
 // Positions [numSmall, nc) keep the key 0xFFFFFFFF written by the host-side fill.
 __global__ __launch_bounds__(256) void k_bp_scatter_sorted(uint32_t nc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ranks,
@@ -451,7 +515,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
     const uint32_t base = ((inCol & 7u) * (blocksPerColumn >> 3) + (inCol >> 3)) * (kGridChunks * 256u);
     const uint32_t dy = gp->dims[1], dz = gp->dims[2], dx = gp->dims[0];
     const uint32_t axis = sc->axisCur;
-    const uint32_t numSmall = nc - gp->numLarge;
+    const uint32_t numSmall = nc - sc->numLarge - sc->numDead;   // this step's own counts (the grid record may be the one computed a step earlier)
     uint32_t overlaps = 0, nh[kGridChunks];
 #pragma unroll
     for (uint32_t ch = 0; ch < kGridChunks; ++ch) {
@@ -566,7 +630,8 @@ __host__ __device__ __forceinline__ int gjkMode(uint32_t ta, uint32_t tb);
 __host__ __device__ __forceinline__ int gjkModeOfBucket(uint32_t bucket);
 // One workgroup after the pair pass: the sharded counters summed (k_pair_totals), the bucket offsets / GJK span / "partition needed"
 // (formerly k_pair_ranges) and — with `partials` — the next sweep axis (formerly k_axis_final): three single-workgroup launches in one.
-__global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound, uint32_t nc, uint32_t numBlocks, const double* __restrict__ partials) {
+__global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound, uint32_t nc, uint32_t numBlocks, const double* __restrict__ partials,
+                                                     const int* __restrict__ blockBounds, GridParams* gridNext /* the NEXT step's grid (null: not wanted) */, uint32_t cellCapNext) {
     const uint32_t t = threadIdx.x;
     if (t < 64u) {   // wave 0
         if (t == 0 && sc->numPairs > pairBound) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; }
@@ -596,6 +661,59 @@ __global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ 
     const uint32_t lane = t & 63, wv = t >> 6;
     if (lane == 0) for (int c = 0; c < 6; ++c) sm[wv][c] = v[c];
     __syncthreads();
+    if (gridNext) {   // k_bp_threshold + k_bp_grid_setup for the next step, from this step's extent histogram and centre bounds
+        __shared__ uint32_t hist[256];
+        __shared__ int red[4][6];
+        { uint32_t h = 0; for (uint32_t k = 0; k < kShards; ++k) h += sh->extentHist[k][t]; hist[t] = h; }
+        int b6[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
+        for (uint32_t b = t; b < numBlocks; b += 256)
+            for (int a = 0; a < 6; ++a) { int x = blockBounds[b * 6 + a]; b6[a] = a < 3 ? min(b6[a], x) : max(b6[a], x); }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { int o = __shfl_xor(b6[a], d, 64); b6[a] = a < 3 ? min(b6[a], o) : max(b6[a], o); }
+        if (lane == 0) for (int a = 0; a < 6; ++a) red[wv][a] = b6[a];
+        __syncthreads();
+        // threshold = upper edge of the highest bin b whose bins ABOVE hold <= limit colliders while b itself would exceed it: a suffix
+        // sum over the 256 bins (wave shuffles + the 4 wave totals) instead of a serial walk
+        __shared__ uint32_t wsum[4];
+        __shared__ float thrShared;
+        if (t == 0) thrShared = 0.f;
+        uint32_t suf = hist[t];                                         // inclusive suffix sum within the wave
+#pragma unroll
+        for (uint32_t d = 1; d < 64u; d <<= 1) { uint32_t o = (uint32_t)__shfl_down((int)suf, d, 64); if (lane + d < 64u) suf += o; }
+        if (lane == 0) wsum[wv] = suf;
+        __syncthreads();
+        for (uint32_t w = wv + 1; w < 4; ++w) suf += wsum[w];
+        {
+            const uint32_t live = nc - sc->numDead;
+            uint32_t limit = max(16u, live / 16384u);
+            const uint32_t costCap = (uint32_t)(67108864ull / (uint64_t)max(live, 1u));
+            limit = max(8u, min(limit, costCap));
+            const uint32_t above = suf - hist[t];                       // colliders in bins > t
+            if (above <= limit && suf > limit) thrShared = extentBinUpper(t);
+        }
+        __syncthreads();
+        if (t == 0) {
+            const float thr = thrShared;
+            for (int w = 1; w < 4; ++w) for (int a = 0; a < 6; ++a) b6[a] = a < 3 ? min(b6[a], red[w][a]) : max(b6[a], red[w][a]);
+            float cell = thr * 1.001f + 1e-6f;
+            float lo[3], hi[3];
+            const bool any = b6[0] != 0x7FFFFFFF;
+            for (int a = 0; a < 3; ++a) { lo[a] = any ? fromOrderedInt(b6[a]) : 0.f; hi[a] = any ? fromOrderedInt(b6[3 + a]) : 0.f; }
+            for (int it = 0; it < 64; ++it) {
+                double cells = 1.0;
+                for (int a = 0; a < 3; ++a) { uint32_t d = (uint32_t)((hi[a] - lo[a]) / cell) + 2u; gridNext->dims[a] = d; cells *= (double)d; }
+                if (cells <= (double)(cellCapNext - 1)) break;
+                cell *= 1.3f;
+            }
+            gridNext->numCells = gridNext->dims[0] * gridNext->dims[1] * gridNext->dims[2];
+            sc->numCellsNext = gridNext->numCells;
+            gridNext->cell = cell; gridNext->invCell = 1.f / cell;
+            for (int a = 0; a < 3; ++a) gridNext->origin[a] = lo[a];
+            gridNext->numLarge = 0; gridNext->largeThreshold = thr;
+        }
+    }
     if (t != 0) return;
     double s6[6];
     for (int c = 0; c < 6; ++c) { double a = 0.0; for (int w = 0; w < 4; ++w) a += sm[w][c]; s6[c] = a; }
@@ -2206,8 +2324,8 @@ __device__ __forceinline__ void scanPublish(unsigned long long* rec, uint32_t su
 }
 template <typename T> struct ScanWords { static constexpr uint32_t W = sizeof(T) / 4; };
 template <typename T>
-__global__ __launch_bounds__(kScanThreads) void k_exclusive_scan(const T* __restrict__ in, T* __restrict__ out, uint32_t n, unsigned long long* records,
-                                                                 uint32_t* ticket, uint32_t ticketBase, uint32_t gen) {
+__global__ __launch_bounds__(kScanThreads) void k_exclusive_scan(T* __restrict__ in, T* __restrict__ out, uint32_t n, unsigned long long* records,
+                                                                 uint32_t* ticket, uint32_t ticketBase, uint32_t gen, uint32_t zeroInput /* histograms: leave the input cleared for its next use */) {
     constexpr uint32_t W = ScanWords<T>::W;
     __shared__ uint32_t sTile;
     __shared__ T sWave[kScanThreads / 64];
@@ -2223,6 +2341,10 @@ __global__ __launch_bounds__(kScanThreads) void k_exclusive_scan(const T* __rest
     T v[kScanItems];
     #pragma unroll
     for (uint32_t k = 0; k < kScanItems; ++k) v[k] = base + k < n ? in[base + k] : T(0);
+    if (zeroInput) {
+#pragma unroll
+        for (uint32_t k = 0; k < kScanItems; ++k) if (base + k < n) in[base + k] = T(0);
+    }
     T local = 0;
     #pragma unroll
     for (uint32_t k = 0; k < kScanItems; ++k) { T x = v[k]; v[k] = local; local += x; }      // exclusive within the thread

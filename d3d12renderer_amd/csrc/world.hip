@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <type_traits>
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "../../include/mi_physics.h"
 #include "../../include/mi_shard.h"
@@ -64,7 +65,7 @@ template <typename T>
 struct DeviceScan {
     DBuf<unsigned long long> records; DBuf<uint32_t> ticket;
     uint32_t ticketBase = 0, gen = 0;
-    hipError_t run(const T* in, T* out, uint32_t n, hipStream_t st) {
+    hipError_t run(T* in, T* out, uint32_t n, hipStream_t st, bool zeroInput = false) {
         const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
         if (!tiles) return hipSuccess;
         hipError_t e;
@@ -74,7 +75,7 @@ struct DeviceScan {
         const size_t words = (size_t)tiles * ScanWords<T>::W;
         if (records.cap < words) { if ((e = records.ensure(words)) != hipSuccess) return e; clear = true; }
         if (clear && (e = hipMemsetAsync(records.p, 0, records.cap * sizeof(unsigned long long), st)) != hipSuccess) return e;
-        k_exclusive_scan<T><<<tiles, kScanThreads, 0, st>>>(in, out, n, records.p, ticket.p, ticketBase, gen);
+        k_exclusive_scan<T><<<tiles, kScanThreads, 0, st>>>(in, out, n, records.p, ticket.p, ticketBase, gen, zeroInput ? 1u : 0u);
         ticketBase += tiles;
         return hipGetLastError();
     }
@@ -139,7 +140,8 @@ struct mi_world {
     DBuf<uint32_t> largeList, isLarge, cellKeys, cellRanks, cellKeysS, cellValsS, cellCount, cellLower;
     DBuf<int> blockBounds;
     DBuf<float4> sMin, sMax;
-    DBuf<GridParams> grid; DBuf<char> scalarsRaw; DBuf<Shards> shards;   // scalarsRaw = [StepScalars][colouring round flags]: one read-back
+    DBuf<GridParams> grid;   // [2]: the grid a step uses and the one its k_pair_finish prepares for the next step
+    uint32_t gridCur = 0; bool gridValid = false; uint32_t gridNextCells = 0; DBuf<char> scalarsRaw; DBuf<Shards> shards;   // scalarsRaw = [StepScalars][colouring round flags]: one read-back
     StepScalars* scalarsPtr() { return reinterpret_cast<StepScalars*>(scalarsRaw.p); }
     uint32_t* roundFlagsPtr() { return reinterpret_cast<uint32_t*>(scalarsRaw.p + sizeof(StepScalars)); }
     DBuf<uint64_t> pairKeys, pairKeysS;
@@ -239,7 +241,7 @@ int mi_world::init(int dev) {
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(scalarsRaw.ensure(sizeof(StepScalars) + (kMaxColorRounds + 2) * sizeof(uint32_t)));
-    HIP_TRY(grid.ensure(1));
+    HIP_TRY(grid.ensure(2));
     HIP_TRY(shards.ensure(1));
     HIP_TRY(hipMemsetAsync(scalarsRaw.p, 0, sizeof(StepScalars) + (kMaxColorRounds + 2) * sizeof(uint32_t), stream));
     HIP_TRY(binInfo.ensure(kSchedBins));
@@ -484,6 +486,7 @@ int mi_world::upload() {
     HIP_TRY(largeList.ensure(nc + 1)); HIP_TRY(isLarge.ensure(nc + 1));
     HIP_TRY(cellKeys.ensure(nc + 1)); HIP_TRY(cellRanks.ensure(nc + 1)); HIP_TRY(cellKeysS.ensure(nc + 1)); HIP_TRY(cellValsS.ensure(nc + 1));
     HIP_TRY(cellCount.ensure(kMaxCells)); HIP_TRY(cellLower.ensure(kMaxCells));
+    HIP_TRY(hipMemsetAsync(cellCount.p, 0, (size_t)kMaxCells * sizeof(uint32_t), stream));   // from here on every scan clears what it read
     HIP_TRY(blockBounds.ensure(6 * (size_t)divUp(std::max(nc, 1u), 256)));
     HIP_TRY(axisPartials.ensure(6 * (size_t)divUp(std::max(nc, 1u), 256)));
     // hull geometry pool
@@ -507,7 +510,7 @@ int mi_world::upload() {
         rc = uploadHeightmap(); if (rc != MI_OK) return rc;
     }
     HIP_TRY(hipStreamSynchronize(stream));
-    topologyDirty = false; hostStale = false; haveEstimates = false;   // the previous step's counts say nothing about the new topology
+    topologyDirty = false; hostStale = false; haveEstimates = false; gridValid = false;   // the previous step's counts say nothing about the new topology
     return MI_OK;
 }
 
@@ -756,8 +759,13 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     hipStream_t st = stream;
     int evi = 0;
     static const bool debugSync = std::getenv("MI_DEBUG_SYNC") != nullptr;   // development: find the stage a device fault comes from
+    // The step (events 0 / 8) and the solve stage (6 / 7) are always timed.  A recorded event is a barrier packet of its own (~6 us of
+    // idle device per event: 24 us per step); where the stage is ONE kernel the events ride on that kernel's dispatch instead
+    // (hipExtLaunchKernelGGL start / stop events): no packet, no gap.  `attached` = this step's 0 / 6 / 7 / 8 are attached ones.
+    bool attached = !debugSync;
     auto mark = [&]() {
         const int id = evi++;
+        if (attached && (id == 0 || id == 6 || id == 7 || id == 8)) return;
         if (!stageEvents && id != 0 && id != 6 && id != 7 && id != 8) return;   // by default only the step and the solve stage are timed
         (void)hipEventRecord(ev[id], st);
         if (debugSync) { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) std::fprintf(stderr, "[mi_physics] step %llu (%s): stage ending at mark %d: %s\n", (unsigned long long)totalSteps, spec ? "speculative" : "synchronous", evi - 1, hipGetErrorString(e)); }
@@ -766,7 +774,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     auto readScalars = [&]() -> int { HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); return MI_OK; };
 
     mark();  // 0
-    k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlagsPtr(), keyCount.p);
+    if (attached) hipExtLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(128), 0, st, ev[0], nullptr, 0, sc, shards.p, roundFlagsPtr(), keyCount.p);
+    else k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlagsPtr(), keyCount.p);
     if (shard.enabled && nb) k_shard_classify<<<divUp(nb, B), B, 0, st>>>(nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, sc);
     if (nc) {
         k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
@@ -784,14 +793,21 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     if (nc) {
         uint32_t nblk = divUp(nc, 256);
         // the cell table (histogram + scan) covers cellCap cells; k_bp_grid_setup enlarges the cells if the grid would need more
-        const uint32_t cellCap = spec ? std::min<uint32_t>(kMaxCells, std::max<uint32_t>(1u << 16, 2u * last.numCells)) : kMaxCells;
-        k_axis_partials<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, axisPartials.p, shards.p);
-        k_bp_threshold<<<1, 256, 0, st>>>(nc, shards.p, sc);
-        k_bp_classify<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, sc, largeList.p, isLarge.p, blockBounds.p);
-        k_bp_grid_setup<<<1, 256, 0, st>>>(nc, nblk, cellCap, blockBounds.p, sc, grid.p);
-        HIP_TRY(hipMemsetAsync(cellCount.p, 0, (size_t)cellCap * sizeof(uint32_t), st));
-        k_bp_cell_ids<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, isLarge.p, grid.p, cellKeys.p, cellRanks.p, cellCount.p);
-        HIP_TRY(scanCells.run(cellCount.p, cellLower.p, cellCap, st));
+        const uint32_t cellCapNext = std::min<uint32_t>(kMaxCells, std::max<uint32_t>(1u << 16, 4u * nc));
+        const uint32_t cellCap = gridValid ? gridNextCells + 1u : spec ? std::min<uint32_t>(kMaxCells, std::max<uint32_t>(1u << 16, 2u * last.numCells)) : kMaxCells;
+        GridParams* gridUse = grid.p + gridCur; GridParams* gridNext = grid.p + (gridCur ^ 1u);
+        if (gridValid) {
+            // the grid prepared at the end of the previous step (k_pair_finish): one fused kernel instead of five launches; the cell histogram
+            // is all zero here (cleared once at upload, and every scan clears the cells it has read)
+            k_bp_prepare<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, gridUse, axisPartials.p, shards.p, sc, largeList.p, isLarge.p, blockBounds.p, cellKeys.p, cellRanks.p, cellCount.p);
+        } else {
+            k_axis_partials<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, axisPartials.p, shards.p);
+            k_bp_threshold<<<1, 256, 0, st>>>(nc, shards.p, sc);
+            k_bp_classify<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, sc, largeList.p, isLarge.p, blockBounds.p);
+            k_bp_grid_setup<<<1, 256, 0, st>>>(nc, nblk, cellCap, blockBounds.p, sc, gridUse);
+            k_bp_cell_ids<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, isLarge.p, gridUse, cellKeys.p, cellRanks.p, cellCount.p);
+        }
+        HIP_TRY(scanCells.run(cellCount.p, cellLower.p, cellCap, st, true));
         k_bp_scatter_sorted<<<divUp(nc, B), B, 0, st>>>(nc, cellKeys.p, cellRanks.p, cellLower.p, aabbMin.p, aabbMax.p, cellKeysS.p, cellValsS.p, sMin.p, sMax.p);
         if (pairKeys.cap == 0) { HIP_TRY(pairKeys.ensure(std::max<size_t>(1u << 16, 8 * (size_t)nc))); }
         if (spec) { HIP_TRY(pairKeys.ensure(bound(last.numPairs, 4096))); }
@@ -800,9 +816,9 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             uint32_t cap = (uint32_t)std::min<size_t>(pairKeys.cap, 0x7FFFFFFFu);
             const InterSink inter{usesInteractions ? interKeys.p : nullptr, (uint32_t)interKeys.cap, &sc->numInterPairs};
             const uint32_t bpc = (divUp(nc, kGridChunks * 256u) + 7u) & ~7u;   // a multiple of 8 (XCD-contiguous block order in k_bp_pairs_grid)
-            k_bp_pairs_grid<<<5u * bpc, B, 0, st>>>(nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, grid.p, pairKeys.p, cap, sc, shards.p, inter);
+            k_bp_pairs_grid<<<5u * bpc, B, 0, st>>>(nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
             k_bp_pairs_large<<<dim3(std::min(divUp(nc, B), 256u), 16), B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc, shards.p, inter);
-            k_pair_finish<<<1, 256, 0, st>>>(shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu, nc, nblk, attempt == 0 ? axisPartials.p : nullptr);
+            k_pair_finish<<<1, 256, 0, st>>>(shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu, nc, nblk, attempt == 0 ? axisPartials.p : nullptr, blockBounds.p, attempt == 0 ? gridNext : nullptr, cellCapNext);
             if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
             int rc = readScalars(); if (rc != MI_OK) return rc;
             pairBound = hs.numPairs + hs.numHmContacts;   // the terrain contacts are appended to the pair list after the narrow phase
@@ -837,7 +853,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             k_hm_slow<true><<<divUp(nc, 64), 64, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut);
             k_hm_finish<<<1, 1, 0, st>>>(sc, pairBound);
         }
-        HIP_TRY(scanPairs.run(reinterpret_cast<const unsigned long long*>(npPacked.p), reinterpret_cast<unsigned long long*>(npScan.p), pairBound, st));
+        HIP_TRY(scanPairs.run(reinterpret_cast<unsigned long long*>(npPacked.p), reinterpret_cast<unsigned long long*>(npScan.p), pairBound, st));
         if (eventsEnabled) HIP_TRY(manIsNew.ensure(pairBound));
         k_emit_manifolds<<<divUp(pairBound, B), B, 0, st>>>(nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
@@ -873,7 +889,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             xcdListCap = divUp(tilesCap, 8) + kSchedBins;
             HIP_TRY(sortKeys[0].ensure(nmBound)); for (int k = 0; k < 2; ++k) HIP_TRY(sortVals[k].ensure(nmBound));
             HIP_TRY(xcdTiles.ensure((size_t)8 * xcdListCap));
-            k_manifold_keys<<<divUp(nmBound, kKeyItems), 256, 0, st>>>(nmBound, sc, grid.p, manBodies.p, gPos.p, sortKeys[0].p, sortVals[0].p, keyCount.p);
+            k_manifold_keys<<<divUp(nmBound, kKeyItems), 256, 0, st>>>(nmBound, sc, grid.p + gridCur, manBodies.p, gPos.p, sortKeys[0].p, sortVals[0].p, keyCount.p);
             k_manifold_place<<<divUp(nmBound, kKeyItems), 256, 0, st>>>(nmBound, sc, sortKeys[0].p, sortVals[0].p, keyCount.p, sortVals[1].p);
         }
         static const bool xcdNoSort = std::getenv("MI_XCD_NOSORT") != nullptr;   // development: manifold order as emitted
@@ -949,6 +965,9 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     int rc = joints.initialize(*this, dt, st);
     if (rc != MI_OK) return rc;
     mark();  // 6
+    bool solveAttached = false;
+    const bool willPersist = !(useFlow && fuseEnabled && joints.allInIslands()) && persistPlan && persistMaxSlots * 20u <= 38u * 1024u;
+    if (attached && !willPersist) (void)hipEventRecord(ev[6], st);   // another solver path (several launches): classic recorded events
     const uint32_t iters = settings.num_rigid_solver_iterations;
     usedFlow = useFlow; usedPersist = false; usedFused = fused; usedXcd = false;
     uint64_t mainContacts = 0;
@@ -986,15 +1005,20 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         const bool impLds = persistImpLds && maxSlots * (4u * 512u + 20u) <= 38u * 1024u;   // beyond that the impulses travel as granules in `imp` (no size limit)
         const uint32_t ldsMeta = maxSlots * (64u * 40u + 4u * 512u + 20u) + 16u, ldsImp = maxSlots * (4u * 512u + 20u) + 16u, ldsDesc = maxSlots * 20u + 16u;
 #define MI_PERSIST_ARGS iters, maxSlots, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, sc, xcdOnly, xcdTiles.p, xcdListCap, bodyOwner.p, gVelL.p, slotMeta.p, imp.p, xcdFault
+        // the solve stage IS this launch: its timing events ride on the dispatch (when this path is not taken they are recorded below)
+        hipEvent_t e6 = attached ? ev[6] : nullptr, e7 = attached ? ev[7] : nullptr;
+        solveAttached = attached;
+#define MI_PERSIST_LAUNCH(A, B_, C_, LDS) hipExtLaunchKernelGGL((k_contact_solve_persist<A, B_, C_>), dim3(persistWaves), dim3(64), LDS, st, e6, e7, 0, MI_PERSIST_ARGS)
         if (usedXcd) {
-            if (metaLds && impLds) k_contact_solve_persist<true, true, true><<<persistWaves, 64, ldsMeta, st>>>(MI_PERSIST_ARGS);
-            else if (impLds) k_contact_solve_persist<false, true, true><<<persistWaves, 64, ldsImp, st>>>(MI_PERSIST_ARGS);
-            else k_contact_solve_persist<false, true, false><<<persistWaves, 64, ldsDesc, st>>>(MI_PERSIST_ARGS);
+            if (metaLds && impLds) MI_PERSIST_LAUNCH(true, true, true, ldsMeta);
+            else if (impLds) MI_PERSIST_LAUNCH(false, true, true, ldsImp);
+            else MI_PERSIST_LAUNCH(false, true, false, ldsDesc);
         } else {
-            if (metaLds && impLds) k_contact_solve_persist<true, false, true><<<persistWaves, 64, ldsMeta, st>>>(MI_PERSIST_ARGS);
-            else if (impLds) k_contact_solve_persist<false, false, true><<<persistWaves, 64, ldsImp, st>>>(MI_PERSIST_ARGS);
-            else k_contact_solve_persist<false, false, false><<<persistWaves, 64, ldsDesc, st>>>(MI_PERSIST_ARGS);
+            if (metaLds && impLds) MI_PERSIST_LAUNCH(true, false, true, ldsMeta);
+            else if (impLds) MI_PERSIST_LAUNCH(false, false, true, ldsImp);
+            else MI_PERSIST_LAUNCH(false, false, false, ldsDesc);
         }
+#undef MI_PERSIST_LAUNCH
 #undef MI_PERSIST_ARGS
         if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
     } else if (useFlow) {
@@ -1051,7 +1075,11 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         }
     }
     mark();  // 7
-    k_integrate_velocities<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
+    if (attached && !solveAttached) (void)hipEventRecord(ev[7], st);
+    if (attached) hipExtLaunchKernelGGL(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nullptr, ev[8], 0, nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
+                                      gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p,
+                                      shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p);
+    else k_integrate_velocities<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
                                                       gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p,
                                                       shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p);
     mark();  // 8
@@ -1161,6 +1189,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     std::swap(bForce.p, bForceN.p); std::swap(bTorque.p, bTorqueN.p);
     if (usesInteractions) prevTriggerOverlaps.swap(nextTriggerOverlaps);
     sapAxis = hs.axisNext;
+    if (nc) { gridCur ^= 1u; gridValid = true; gridNextCells = hs.numCellsNext; }   // the grid k_pair_finish prepared becomes the next step's
     if (nmBound) { tabCur ^= 1; tabValid = true; } else tabValid = false;
     hostStale = true;
     last.numPairs = hs.numPairs; last.numManifolds = hs.numManifolds; last.numContacts = hs.numContacts; last.numCells = hs.numCells;

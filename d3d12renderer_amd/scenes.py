@@ -615,60 +615,6 @@ def vehicles(nx=16, nz=16, seed=5, solver_iterations=30, spacing=10.0):
                  hulls=[terrain_tile_hull(half=spacing / 2)], global_constraints=gcs)
 
 
-def obb_pile_tile(tile=0, ntiles=1, nx=128, ny=16, nz=128, ghost_cols=2, seed=3, solver_iterations=20, spacing=1.5):
-    """One x-slab of the GLOBAL cfg3 pen of (ntiles*nx) x ny x nz boxes (weak scaling: the pen grows with the GPU count).
-
-    Entities, in order: the tile's owned boxes (global x-columns [tile*nx, (tile+1)*nx)), ghost copies of the `ghost_cols`
-    nearest columns of the left neighbour, then of the right neighbour, then the statics (ground + the global pen's 4 walls).
-    Every per-box random draw is keyed by the GLOBAL box index, so a ghost copy is bit-identical to its original.
-    Returns (scene, info) with info = dict(owned=n, ghost_left=ids, ghost_right=ids, send_left=ids, send_right=ids) of entity ids.
-    """
-    NX = ntiles * nx
-    def cols(c0, c1):
-        c0, c1 = max(c0, 0), min(c1, NX)
-        if c1 <= c0:
-            return np.zeros((0, 3), np.int64)
-        gx, iy, iz = np.meshgrid(np.arange(c0, c1), np.arange(ny), np.arange(nz), indexing="ij")
-        return np.stack([gx.ravel(), iy.ravel(), iz.ravel()], axis=1)
-    own = cols(tile * nx, (tile + 1) * nx)
-    gl = cols(tile * nx - ghost_cols, tile * nx) if tile > 0 else np.zeros((0, 3), np.int64)
-    gr = cols((tile + 1) * nx, (tile + 1) * nx + ghost_cols) if tile < ntiles - 1 else np.zeros((0, 3), np.int64)
-    idx3 = np.concatenate([own, gl, gr])
-    n = len(idx3)
-    g = (idx3[:, 0] * ny + idx3[:, 1]) * nz + idx3[:, 2]          # global box index
-    e = make_entities(n)
-    p = np.stack([(idx3[:, 0] - (NX - 1) / 2) * spacing, 0.9 + idx3[:, 1] * spacing, (idx3[:, 2] - (nz - 1) / 2) * spacing], axis=1).astype(np.float32)
-    for a in range(3):
-        p[:, a] += uniform_idx(seed, 10 + a, g, -0.02, 0.02)
-    e["position"] = p
-    e["rotation"] = random_unit_quaternions_idx(seed, 20, g)
-    c = make_colliders(n, capi.AABB, restitution=0.1, friction=0.5)
-    h = np.stack([uniform_idx(seed, 30 + a, g, 0.3, 0.6) for a in range(3)], axis=1)
-    c["shape"][:, 0:3] = -h
-    c["shape"][:, 3:6] = h
-    hx, hz = NX * spacing / 2 + 1.0, nz * spacing / 2 + 1.0
-    ge, gc = _ground(max(hx, hz) + 10.0)
-    we = make_entities(4, capi.ENTITY_STATIC)
-    wc = make_colliders(4, capi.OBB, restitution=0.1, friction=0.5)
-    wall_h = ny * spacing + 4.0
-    centers = [(-hx - 0.5, wall_h / 2, 0), (hx + 0.5, wall_h / 2, 0), (0, wall_h / 2, -hz - 0.5), (0, wall_h / 2, hz + 0.5)]
-    radii = [(0.5, wall_h / 2, hz + 1.0), (0.5, wall_h / 2, hz + 1.0), (hx + 1.0, wall_h / 2, 0.5), (hx + 1.0, wall_h / 2, 0.5)]
-    for i in range(4):
-        wc["shape"][i, 0:4] = (0, 0, 0, 1)
-        wc["shape"][i, 4:7] = centers[i]
-        wc["shape"][i, 7:10] = radii[i]
-    sc = Scene(f"cfg3_tile{tile}of{ntiles}_{len(own)}", np.concatenate([e, ge, we]), np.arange(n + 5, dtype=np.uint32), np.concatenate([c, gc, wc]),
-               solver_iterations)
-    n_own, n_gl = len(own), len(gl)
-    per_col = ny * nz
-    info = dict(owned=n_own,
-                ghost_left=np.arange(n_own, n_own + n_gl, dtype=np.uint32),
-                ghost_right=np.arange(n_own + n_gl, n, dtype=np.uint32),
-                send_left=np.arange(0, min(ghost_cols, nx) * per_col, dtype=np.uint32) if tile > 0 else np.zeros(0, np.uint32),
-                send_right=np.arange(n_own - min(ghost_cols, nx) * per_col, n_own, dtype=np.uint32) if tile < ntiles - 1 else np.zeros(0, np.uint32))
-    return sc, info
-
-
 def zones(nx=6, ny=3, nz=6, seed=8, solver_iterations=20, spacing=1.4, localized=True):
     """Triggers and force fields (handleNonCollisionInteractions): a jittered lattice of mixed shapes falls through a wind zone
     (localized force field made of two colliders, tilted entity so the force is rotated), a second overlapping updraft zone, a

@@ -504,90 +504,7 @@ def test_gpu_body_state_exchange_api(mi_lib):
     assert np.isfinite(w.physics_transforms()[0]).all()
 
 
-def test_gpu_sharded_world_single_rank_equals_plain_world(mi_lib):
-    from d3d12renderer_amd.distributed import ShardedWorld
-    sw = ShardedWorld(lambda: gpu_world(mi_lib), 0, 1, None, tile=(8, 4, 8), iterations=20)
-    sc = scenes.obb_pile(8, 4, 8, solver_iterations=20)
-    w = sc.populate(gpu_world(mi_lib))
-    for _ in range(30):
-        sw.step(sw.settings(), sw.dt); w.step_fixed(sc.settings(), sc.dt, 1)
-    n = sc.num_bodies
-    assert np.array_equal(sw.world.physics_transforms()[0][:n], w.physics_transforms()[0][:n])
-
-
-class _LocalCollectives:
-    """Stand-in for torch.distributed inside ONE process: every 'rank' runs in its own thread and the collectives copy between
-    the ranks' buffers.  Lets the N > 1 code path — boundary gather kernel, all-to-all-v split layout, ghost scatter kernel,
-    all-reduce of the counts — run with DEVICE buffers on the single GPU of the test box (RCCL itself needs one GPU per rank)."""
-
-    def __init__(self, shared, rank, backend):
-        self.shared, self.rank, self.backend = shared, rank, backend
-
-    def get_backend(self):
-        return self.backend
-
-    def all_to_all_single(self, out, inp, out_splits, in_splits):
-        sh = self.shared
-        import torch
-        if inp.is_cuda:
-            torch.cuda.current_stream().synchronize()   # RCCL orders the ranks' streams against each other; here the host does
-        sh["inp"][self.rank] = (inp, list(in_splits))
-        sh["barrier"].wait()
-        o = 0
-        for peer in range(sh["n"]):
-            peer_inp, peer_splits = sh["inp"][peer]
-            start = sum(peer_splits[: self.rank])
-            out[o: o + out_splits[peer]] = peer_inp[start: start + peer_splits[self.rank]]
-            assert peer_splits[self.rank] == out_splits[peer]
-            o += out_splits[peer]
-        if inp.is_cuda:
-            torch.cuda.current_stream().synchronize()
-        sh["barrier"].wait()
-
-    def all_reduce(self, t):
-        sh = self.shared
-        sh["red"][self.rank] = t.clone()
-        sh["barrier"].wait()
-        total = sum(sh["red"][p].to(t.device) for p in range(sh["n"]))
-        sh["barrier"].wait()
-        t.copy_(total)
-
-
-def _run_local_ranks(make_world, backend, n, tile, steps):
-    import threading
-    from d3d12renderer_amd.distributed import ShardedWorld
-    shared = {"n": n, "inp": [None] * n, "red": [None] * n, "barrier": threading.Barrier(n)}
-    out, err = [None] * n, []
-
-    def work(rank):
-        try:
-            sw = ShardedWorld(make_world, rank, n, _LocalCollectives(shared, rank, backend), tile=tile, iterations=20, ghost_cols=2)
-            for _ in range(steps):
-                sw.step(sw.settings(), sw.dt)
-            out[rank] = (sw.owned_states(), sw.total_counts())
-        except Exception as e:   # noqa: BLE001
-            err.append(e); shared["barrier"].abort()
-
-    threads = [threading.Thread(target=work, args=(r,)) for r in range(n)]
-    [t.start() for t in threads]; [t.join() for t in threads]
-    if err:
-        raise err[0]
-    return out
-
-
-def test_gpu_sharded_three_tiles_device_exchange_matches_oracle_tiles(mi_lib, oracle_mod):
-    """The multi-GPU path with device buffers end to end (gather kernel -> all-to-all-v layout -> scatter kernel, counts
-    all-reduce), three x-slab tiles (a middle tile has two seams) on one GPU, against the same three tiles run by the oracle
-    with host buffers: the seam approximation is deterministic, so the two must agree bit for bit."""
-    import torch
-    torch.cuda.set_device(0)
-    tile, steps = (6, 4, 6), 60
-    g = _run_local_ranks(lambda: gpu_world(mi_lib), "nccl", 3, tile, steps)
-    o = _run_local_ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), "gloo", 3, tile, steps)
-    for r in range(3):
-        assert g[r][0].tobytes() == o[r][0].tobytes(), f"tile {r}"
-        assert g[r][1] == o[r][1] and g[r][1]["num_contacts"] > 0
-    assert g[0][1]["num_rigid_bodies"] == g[1][1]["num_rigid_bodies"] == g[2][1]["num_rigid_bodies"]
+# (the sharded-world tests live in tests/test_gpu_sharding.py)
 
 
 @pytest.mark.gpu
