@@ -315,7 +315,9 @@ bool buildWorld(int n) {
     destroyWorld();
     g.error.clear();
 #ifdef LEARNING_BACKEND_ORACLE
-    if (!ok(ora_world_create(1 /* canonical order: the schedule the device runs */, &g.world), "world_create")) return false;
+    // canonical order = the schedule the device runs; MI_LEARNING_ORACLE_ORDER=0 (tests): the reference's own order, to compare with oracle/_ref
+    const char* om = std::getenv("MI_LEARNING_ORACLE_ORDER");
+    if (!ok(ora_world_create(om ? std::atoi(om) : 1, &g.world), "world_create")) return false;
 #else
     mi_world_desc desc{}; desc.device = g.device;
     if (!ok(mi_world_create(&desc, &g.world), "world_create")) return false;

@@ -46,10 +46,12 @@ FILES = [
     "core/memory.h", "core/memory.cpp", "core/reflect.h", "core/preprocessor_for_each.h",
     "scene/scene.h", "scene/scene.cpp", "scene/components.h",
     "terrain/heightmap_collider.h", "terrain/heightmap_collider.cpp",
+    "physics/ragdoll.h", "physics/ragdoll.cpp", "learning/learned_locomotion.h", "learning/learned_locomotion.cpp",
 ]
 UNITS = ["core/math.cpp", "core/memory.cpp", "physics/bounding_volumes.cpp", "physics/collision_gjk.cpp", "physics/collision_epa.cpp",
          "physics/collision_broad.cpp", "physics/collision_narrow.cpp", "physics/constraints.cpp", "physics/rigid_body.cpp",
-         "physics/heightmap_collision.cpp", "physics/cloth.cpp", "physics/physics.cpp", "scene/scene.cpp", "terrain/heightmap_collider.cpp"]
+         "physics/heightmap_collision.cpp", "physics/cloth.cpp", "physics/physics.cpp", "scene/scene.cpp", "terrain/heightmap_collider.cpp",
+         "physics/ragdoll.cpp", "learning/learned_locomotion.cpp"]
 
 LANE = r"([A-Za-z_0-9\.>\-]+)"
 # (file glob or None for all, regex, replacement, reason)
@@ -131,7 +133,18 @@ def _collision_broad_cpp(text):
                    "\treturn c ? c->sortingAxis : 0;\n}\n")
 
 
-SPECIAL = {"core/math.h": _math_h, "core/math_simd.h": _math_simd_h, "scene/scene.cpp": _scene_cpp,
+def _learned_locomotion_cpp(text):
+    # test hooks: a settable push-RNG state instead of time(0), and the choice of the scalar step (the DLL steps with the
+    # default physics_settings, i.e. the AVX2 path, which is not bit-comparable with anything)
+    text = text.replace("static random_number_generator rng = { (uint32)time(0) };",
+                        "static random_number_generator rng = { (uint32)time(0) };\nstatic bool refLearningSimd = true;\n"
+                        "extern \"C\" void refLearningConfigure(unsigned long long rngState, int simd) { rng.state = rngState; refLearningSimd = simd != 0; }")
+    text = text.replace("\tphysicsSettings.frameRate = 60;\n",
+                        "\tphysicsSettings.frameRate = 60;\n\tphysicsSettings.simdBroadPhase = physicsSettings.simdNarrowPhase = physicsSettings.simdConstraintSolver = refLearningSimd;\n", 1)
+    return text
+
+
+SPECIAL = {"learning/learned_locomotion.cpp": _learned_locomotion_cpp, "core/math.h": _math_h, "core/math_simd.h": _math_simd_h, "scene/scene.cpp": _scene_cpp,
            "physics/physics.cpp": _physics_cpp, "physics/collision_broad.cpp": _collision_broad_cpp}
 
 
@@ -163,6 +176,8 @@ def build(force=False, verbose=False, keep=False, variant="strict"):
             src = (HERE / u) if u == "ref_shim.cpp" else (HERE.parent / u) if u == "ora_det.cpp" else (tmp / "src" / u)
             obj = tmp / (u.replace("/", "_") + ".o")
             cmd = [CLANG, *flags, "-c", str(src), "-o", str(obj)]
+            if u == "learning/learned_locomotion.cpp":   # the environment's own state / reward arithmetic (host code in the product too) keeps the C library's acos / exp
+                cmd.insert(1, "-DREF_NATIVE_LIBM")
             if u == "ora_det.cpp":      # our own file: no reference prefix header
                 cmd = [CLANG, "-std=c++17", "-O2", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-c", str(src), "-o", str(obj)]
             if verbose:

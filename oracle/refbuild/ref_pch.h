@@ -96,3 +96,4 @@ static inline double ref_cos(double x) { return ::cos(x); }
 #define sin(x) ref_sin(x)
 #define cos(x) ref_cos(x)
 #endif
+#define __declspec(x)

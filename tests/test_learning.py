@@ -122,3 +122,14 @@ def test_gpu_learning_library_matches_oracle_backend(mi_lib, oracle_env):
         resets += int(dg.sum())
     assert resets > 0
     g.shutdown(); o.shutdown()
+
+
+@pytest.mark.skipif(not __import__("oracle").reference_available(), reason="needs oracle/_ref")
+def test_environment_equals_the_reference_dll_itself():
+    """The environment code of libPhysics-Lib.so (state, reward, actions, random pushes, the humanoid) against the REFERENCE's own
+    DLL functions compiled from src/learning/learned_locomotion.cpp + src/physics/ragdoll.cpp: sizes, ranges, and every state /
+    reward / done of three episodes with random actions and pushes, bit for bit (tests/ref_learning_check.py, own process)."""
+    import subprocess, sys
+    from pathlib import Path
+    out = subprocess.run([sys.executable, str(Path(__file__).with_name("ref_learning_check.py"))], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "REFERENCE_DLL_OK" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
