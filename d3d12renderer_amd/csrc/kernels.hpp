@@ -489,6 +489,7 @@ __device__ __forceinline__ bool aabbOverlap(const float4& amn, const float4& amx
 // A workgroup handles 256 CONSECUTIVE sorted colliders for ONE column, so its lanes walk (nearly) the same candidate
 // range at the same time: loads are shared through L1 and candidates are fetched four at a time (8 loads in flight
 // per lane) instead of one dependent load pair per loop trip.
+constexpr uint32_t kPairOverflow = 512;   // block-shared overflow slots of k_bp_pairs_grid (4 KiB)
 constexpr uint32_t kPairBuf = 6;      // LDS-staged pair keys per collider-column before the block-level flush
 constexpr uint32_t kGridChunks = 2;   // a workgroup handles 2 x 256 consecutive sorted colliders for one column (24 KiB of staging: 6 workgroups per CU; measured 1: 168, 2: 148, 3: 154, 4: 171 us for the broad phase)
 
@@ -503,10 +504,13 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
                                                        const GridParams* __restrict__ gp, uint64_t* __restrict__ pairKeys, uint32_t pairCap,
                                                        StepScalars* sc, Shards* sh, InterSink inter) {
     __shared__ uint64_t buf[kGridChunks * 256 * kPairBuf];
+    __shared__ uint64_t ovf[kPairOverflow];   // second chance of a lane whose own kPairBuf slots are full (dense piles: ~3 % of the lane-columns); LDS atomics,
+    __shared__ uint32_t ovfCount;             // not one same-address GLOBAL atomic per excess pair (that serialised the kernel in the settled pile: 473 us)
     __shared__ uint32_t waveTotals[4];
     __shared__ uint32_t blockBase;
     __shared__ uint32_t bhist[32];   // [0..20] bucket histogram, [31] overlaps
     if (threadIdx.x < 32) bhist[threadIdx.x] = 0;
+    if (threadIdx.x == 32) ovfCount = 0;
     __syncthreads();
     const uint32_t col = blockIdx.x / blocksPerColumn;
     // blocksPerColumn is a multiple of 8: the workgroups of one XCD (blockIdx % 8, a speed assumption only) walk ONE contiguous
@@ -547,7 +551,11 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
                         uint64_t pk;
                         if (!pairKey(ci, amn, amx, vals[j + u], bmn[u], bmx[u], axis, pk, inter)) continue;
                         if (nhit < kPairBuf) mybuf[nhit] = pk;
-                        else { uint32_t slot = atomicAdd(&sc->numPairs, 1u); if (slot < pairCap) pairKeys[slot] = pk; }
+                        else {
+                            const uint32_t o = atomicAdd(&ovfCount, 1u);
+                            if (o < kPairOverflow) ovf[o] = pk;
+                            else { uint32_t slot = atomicAdd(&sc->numPairs, 1u); if (slot < pairCap) pairKeys[slot] = pk; }   // both stagings full: rare
+                        }
                         atomicAdd(&bhist[(uint32_t)(pk >> 58)], 1u);
                         ++nhit;
                     }
@@ -569,11 +577,14 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
     __syncthreads();
     uint32_t wbase = 0;
     for (uint32_t w = 0; w < wv; ++w) wbase += waveTotals[w];
+    const uint32_t staged = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+    const uint32_t nOvf = min(ovfCount, kPairOverflow);
     if (threadIdx.x == 0) {
-        uint32_t total = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+        const uint32_t total = staged + nOvf;
         blockBase = total ? atomicAdd(&sc->numPairs, total) : 0u;
     }
     __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nOvf; k += 256u) { const uint32_t d = blockBase + staged + k; if (d < pairCap) pairKeys[d] = ovf[k]; }
     uint32_t dst = blockBase + wbase + incl - mine;
 #pragma unroll
     for (uint32_t ch = 0; ch < kGridChunks; ++ch) {
@@ -590,12 +601,21 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
 __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint32_t* __restrict__ largeList, const uint32_t* __restrict__ isLarge,
                                                         const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
                                                         uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc, Shards* sh, InterSink inter) {
+    // hits are staged like in k_bp_pairs_grid (kLargeBuf slots per lane, then a block-shared overflow area, then — rare — a direct append)
+    // and flushed with ONE returning atomic per workgroup: the ground of a settled pile touches tens of thousands of boxes, and a
+    // same-address atomic per wave per hit-iteration made this kernel 40 us
+    constexpr uint32_t kLargeBuf = 4;
+    __shared__ uint64_t buf[256 * kLargeBuf];
+    __shared__ uint64_t ovf[kPairOverflow];
+    __shared__ uint32_t ovfCount, blockBase, waveTotals[4];
     __shared__ uint32_t bhist[32];   // [0..20] bucket histogram, [31] overlaps
     if (threadIdx.x < 32) bhist[threadIdx.x] = 0;
+    if (threadIdx.x == 32) ovfCount = 0;
     __syncthreads();
     uint32_t nl = sc->numLarge;
     uint32_t axis = sc->axisCur;
-    uint32_t overlaps = 0;
+    uint32_t overlaps = 0, nhit = 0;
+    uint64_t* mybuf = buf + threadIdx.x * kLargeBuf;
     // blockIdx.y = large collider slot (grid-strided), x-dimension strides over all colliders: coalesced AABB reads
     for (uint32_t l = blockIdx.y; l < nl; l += gridDim.y) {
         uint32_t i = largeList[l];
@@ -607,13 +627,35 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
             uint64_t pk = 0;
             bool want = ov && pairKey(i, amn, amx, j, bmn, bmx, axis, pk, inter);
             overlaps += ov ? 1u : 0u;
-            if (want) atomicAdd(&bhist[(uint32_t)(pk >> 58)], 1u);
-            waveAppendKey(want, pk, pairKeys, pairCap, &sc->numPairs);
+            if (want) {
+                atomicAdd(&bhist[(uint32_t)(pk >> 58)], 1u);
+                if (nhit < kLargeBuf) mybuf[nhit] = pk;
+                else {
+                    const uint32_t o = atomicAdd(&ovfCount, 1u);
+                    if (o < kPairOverflow) ovf[o] = pk;
+                    else { uint32_t slot = atomicAdd(&sc->numPairs, 1u); if (slot < pairCap) pairKeys[slot] = pk; }
+                }
+                ++nhit;
+            }
         }
     }
+    const uint32_t mine = min(nhit, kLargeBuf);
+    uint32_t incl = mine;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    for (int off = 1; off < 64; off <<= 1) { uint32_t v = __shfl_up(incl, off, 64); if (lane >= (uint32_t)off) incl += v; }
+    if (lane == 63) waveTotals[wv] = incl;
     for (int off = 32; off >= 1; off >>= 1) overlaps += __shfl_xor(overlaps, off, 64);
-    if ((threadIdx.x & 63u) == 0 && overlaps) atomicAdd(&bhist[31], overlaps);
+    if (lane == 0 && overlaps) atomicAdd(&bhist[31], overlaps);
     __syncthreads();
+    uint32_t wbase = 0;
+    for (uint32_t w = 0; w < wv; ++w) wbase += waveTotals[w];
+    const uint32_t staged = waveTotals[0] + waveTotals[1] + waveTotals[2] + waveTotals[3];
+    const uint32_t nOvf = min(ovfCount, kPairOverflow);
+    if (threadIdx.x == 0) { const uint32_t total = staged + nOvf; blockBase = total ? atomicAdd(&sc->numPairs, total) : 0u; }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < nOvf; k += 256u) { const uint32_t d = blockBase + staged + k; if (d < pairCap) pairKeys[d] = ovf[k]; }
+    uint32_t dst = blockBase + wbase + incl - mine;
+    for (uint32_t k = 0; k < mine; ++k, ++dst) if (dst < pairCap) pairKeys[dst] = mybuf[k];
     ShardCounters* shard = &sh->c[(blockIdx.x + blockIdx.y) & (kShards - 1u)];
     if (threadIdx.x < kNumBuckets && bhist[threadIdx.x]) atomicAdd(&shard->bucketHist[threadIdx.x], bhist[threadIdx.x]);
     if (threadIdx.x == 31 && bhist[31]) atomicAdd(&shard->numOverlaps, bhist[31]);

@@ -4,7 +4,7 @@ ulimit -c 0
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 RAW=/tmp/prof_tl; rm -rf $RAW; mkdir -p $RAW
-timeout 400 rocprofv3 --kernel-trace --output-format csv -d $RAW -o tl -- python bench.py --steps 8 --warmup 5 --no-cpu-baseline --no-at-rest > gpurun_out/tl_bench.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --output-format csv -d $RAW -o tl -- python bench.py --steps 8 --warmup 5 --no-cpu-baseline --no-at-rest ${TL_EXTRA} > gpurun_out/tl_bench.log 2>&1
 python - <<'PY'
 import csv, glob
 f = glob.glob("/tmp/prof_tl/**/tl_kernel_trace.csv", recursive=True)[0]
