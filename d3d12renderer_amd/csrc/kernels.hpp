@@ -457,6 +457,11 @@ __device__ __forceinline__ bool pairKey(uint32_t i, const float4& imn, const flo
     return true;
 }
 
+
+// (A software version of a keyed LDS histogram increment — one atomic per distinct key of the wave, lanes ranked by ballot — was
+// measured against plain same-address LDS atomics in k_manifold_keys / k_bin_hist / k_bin_scatter: 2-2.5x SLOWER; the LDS resolves
+// the conflicts faster than a loop over the distinct keys does.)
+
 // Wave-aggregated append: one atomic per wave per call (ballot + popcount prefix), not one per pair.
 __device__ __forceinline__ void waveAppendKey(bool want, uint64_t key, uint64_t* __restrict__ pairKeys, uint32_t pairCap, uint32_t* counter) {
     unsigned long long mask = __ballot(want);
@@ -521,6 +526,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
     const uint32_t axis = sc->axisCur;
     const uint32_t numSmall = nc - sc->numLarge - sc->numDead;   // this step's own counts (the grid record may be the one computed a step earlier)
     uint32_t overlaps = 0, nh[kGridChunks];
+    uint32_t runBucket = 0, runCount = 0;   // this lane's hits go to the bucket histogram in runs (a pile: one bucket -> one LDS atomic per lane, not per hit)
 #pragma unroll
     for (uint32_t ch = 0; ch < kGridChunks; ++ch) {
         const uint32_t i = base + ch * 256u + threadIdx.x;
@@ -556,7 +562,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
                             if (o < kPairOverflow) ovf[o] = pk;
                             else { uint32_t slot = atomicAdd(&sc->numPairs, 1u); if (slot < pairCap) pairKeys[slot] = pk; }   // both stagings full: rare
                         }
-                        atomicAdd(&bhist[(uint32_t)(pk >> 58)], 1u);
+                        { const uint32_t bk = (uint32_t)(pk >> 58); if (bk != runBucket && runCount) { atomicAdd(&bhist[runBucket], runCount); runCount = 0; } runBucket = bk; ++runCount; }
                         ++nhit;
                     }
                 }
@@ -564,6 +570,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
         }
         nh[ch] = min(nhit, kPairBuf);
     }
+    if (runCount) atomicAdd(&bhist[runBucket], runCount);
     // block exclusive scan of the staged counts
     uint32_t mine = 0;
 #pragma unroll
@@ -614,7 +621,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
     __syncthreads();
     uint32_t nl = sc->numLarge;
     uint32_t axis = sc->axisCur;
-    uint32_t overlaps = 0, nhit = 0;
+    uint32_t overlaps = 0, nhit = 0, runBucket = 0, runCount = 0;
     uint64_t* mybuf = buf + threadIdx.x * kLargeBuf;
     // blockIdx.y = large collider slot (grid-strided), x-dimension strides over all colliders: coalesced AABB reads
     for (uint32_t l = blockIdx.y; l < nl; l += gridDim.y) {
@@ -628,7 +635,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
             bool want = ov && pairKey(i, amn, amx, j, bmn, bmx, axis, pk, inter);
             overlaps += ov ? 1u : 0u;
             if (want) {
-                atomicAdd(&bhist[(uint32_t)(pk >> 58)], 1u);
+                { const uint32_t bk = (uint32_t)(pk >> 58); if (bk != runBucket && runCount) { atomicAdd(&bhist[runBucket], runCount); runCount = 0; } runBucket = bk; ++runCount; }
                 if (nhit < kLargeBuf) mybuf[nhit] = pk;
                 else {
                     const uint32_t o = atomicAdd(&ovfCount, 1u);
@@ -639,6 +646,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
             }
         }
     }
+    if (runCount) atomicAdd(&bhist[runBucket], runCount);
     const uint32_t mine = min(nhit, kLargeBuf);
     uint32_t incl = mine;
     const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
@@ -680,14 +688,17 @@ __global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ 
         uint32_t v = 0;
         if (t < kNumBuckets) { for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].bucketHist[t]; sc->bucketHist[t] = v; }
         if (t == 31) { uint32_t o = 0; for (uint32_t k = 0; k < kShards; ++k) o += sh->c[k].numOverlaps; sc->numOverlaps = o; }
-        uint32_t off = 0, nonEmpty = 0, lo = 0xFFFFFFFFu, hi = 0;
+        uint32_t off = 0, nonEmpty = 0, lo = 0xFFFFFFFFu, hi = 0, largest = 0;
         for (uint32_t bk = 0; bk < kNumBuckets; ++bk) {   // every lane walks the buckets (the counts come over by shuffle), lane 0 writes
             const uint32_t n = (uint32_t)__shfl((int)v, (int)bk, 64);
             if (t == 0) sc->bucketOffset[bk] = off;
-            if (n) { ++nonEmpty; if (gjkModeOfBucket(bk) >= 0) { lo = min(lo, off); hi = max(hi, off + n); } }
+            if (n) { ++nonEmpty; largest = max(largest, n); if (gjkModeOfBucket(bk) >= 0) { lo = min(lo, off); hi = max(hi, off + n); } }
             off += n;
         }
-        if (t == 0) { sc->gjkLo = hi > lo ? lo : 0u; sc->gjkHi = hi > lo ? hi : 0u; sc->partitioned = nonEmpty > 1u ? 1u : 0u; }
+        // the partition exists to make narrow-phase waves type-uniform and to give the GJK kernel its span; when nearly every pair is of
+        // ONE type (a box pile: box-box, plus the boxes on the ground) it only costs (a pass over the keys + a reservation per workgroup):
+        // partition if a GJK bucket is populated or more than an eighth of the pairs lies outside the largest bucket
+        if (t == 0) { sc->gjkLo = hi > lo ? lo : 0u; sc->gjkHi = hi > lo ? hi : 0u; sc->partitioned = (nonEmpty > 1u && (hi > lo || (off - largest) * 8u > off)) ? 1u : 0u; }
     }
     if (!partials) return;
     __shared__ double sm[4][6];
@@ -897,6 +908,7 @@ __global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queue
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t numPairs = sc->numPairs;
     const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
+    bool boxHit = false; BoxHit mineHit{};
     if (p >= numPairs) { if (p < scanLen) npPacked[p] = 0ull; }
     else {
         uint64_t key = pairKeys[p];
@@ -909,16 +921,22 @@ __global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queue
             Q4 arot, brot; V3 acen, arad, bcen, brad;
             boxPairShapes(wShape, a, b, ta, arot, acen, arad, brot, bcen, brad);
             ObbSat res;
-            if (obbSat(arot, acen, arad, brot, bcen, brad, res)) {
-                uint32_t slot = atomicAdd(&numHits, 1u);
-                hits[slot] = BoxHit{p, res.normal.x, res.normal.y, res.normal.z, (res.faceHit ? 1u : 0u) | (res.bFace ? 2u : 0u)};
-            } else npPacked[p] = 0ull;
+            if (obbSat(arot, acen, arad, brot, bcen, brad, res)) { boxHit = true; mineHit = BoxHit{p, res.normal.x, res.normal.y, res.normal.z, (res.faceHit ? 1u : 0u) | (res.bFace ? 2u : 0u)}; }
+            else npPacked[p] = 0ull;
         } else {
             Shape sa = loadShape(wShape, a, ta), sb = loadShape(wShape, b, tb);
             Manifold m; m.count = 0;
             bool hit = intersectPair(sa, sb, hs, m);
             writeManifold(p, hit, m, npPacked, npNormal, npPoints);
         }
+    }
+    {   // queue slots of the SAT hits: one LDS atomic per wave (ballot + popcount), not one per hitting lane
+        const unsigned long long hm = __ballot(boxHit);
+        const uint32_t lane = threadIdx.x & 63u;
+        uint32_t base = 0;
+        if (hm && lane == (uint32_t)__ffsll((long long)hm) - 1u) base = atomicAdd(&numHits, (uint32_t)__popcll(hm));
+        base = (uint32_t)__shfl((int)base, hm ? __ffsll((long long)hm) - 1 : 0, 64);
+        if (boxHit) hits[base + (uint32_t)__popcll(hm & ((1ull << lane) - 1ull))] = mineHit;
     }
     __syncthreads();
     const uint32_t q = blockIdx.x & (kBoxQueues - 1u);
@@ -2360,7 +2378,10 @@ __global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, const float* 
 //     (`ticketBase` = tickets handed out before this launch).
 // T = uint32_t (W = 1) or a 64-bit word holding two independent 32-bit sums side by side (W = 2: the narrow phase's packed
 // (manifold flag, contact count); both totals stay below 2^32, so the halves never carry into each other).
-constexpr uint32_t kScanThreads = 256, kScanItems = 8, kScanTile = kScanThreads * kScanItems;
+constexpr uint32_t kScanThreads = 256;
+// items per lane: the long 64-bit scan (one item per collision pair) takes 16 — half the tiles, half the look-back chain (16.3 -> 13.7 us
+// at 750 k pairs); the short 32-bit ones (cell histogram, schedule bins) are faster with 8 (6 vs 9 us)
+template <typename T> struct ScanItems { static constexpr uint32_t N = sizeof(T) == 8 ? 16u : 8u; static constexpr uint32_t Tile = kScanThreads * N; };
 __device__ __forceinline__ void scanPublish(unsigned long long* rec, uint32_t sum, uint32_t tag) {
     __hip_atomic_store(rec, ((unsigned long long)tag << 32) | (unsigned long long)sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -2369,6 +2390,7 @@ template <typename T>
 __global__ __launch_bounds__(kScanThreads) void k_exclusive_scan(T* __restrict__ in, T* __restrict__ out, uint32_t n, unsigned long long* records,
                                                                  uint32_t* ticket, uint32_t ticketBase, uint32_t gen, uint32_t zeroInput /* histograms: leave the input cleared for its next use */) {
     constexpr uint32_t W = ScanWords<T>::W;
+    constexpr uint32_t kScanItems = ScanItems<T>::N, kScanTile = ScanItems<T>::Tile;
     __shared__ uint32_t sTile;
     __shared__ T sWave[kScanThreads / 64];
     __shared__ T sPrefix;

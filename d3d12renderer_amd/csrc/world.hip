@@ -66,7 +66,7 @@ struct DeviceScan {
     DBuf<unsigned long long> records; DBuf<uint32_t> ticket;
     uint32_t ticketBase = 0, gen = 0;
     hipError_t run(T* in, T* out, uint32_t n, hipStream_t st, bool zeroInput = false) {
-        const uint32_t tiles = (n + kScanTile - 1) / kScanTile;
+        const uint32_t tiles = (n + ScanItems<T>::Tile - 1) / ScanItems<T>::Tile;
         if (!tiles) return hipSuccess;
         hipError_t e;
         if (!ticket.p) { if ((e = ticket.ensure(1)) != hipSuccess) return e; if ((e = hipMemsetAsync(ticket.p, 0, sizeof(uint32_t), st)) != hipSuccess) return e; ticketBase = 0; }
