@@ -1003,9 +1003,9 @@ __device__ __forceinline__ uint32_t tableLookup(const unsigned long long* __rest
 __global__ __launch_bounds__(256) void k_color_table_insert(uint32_t nc, const StepScalars* __restrict__ sc, const uint32_t* __restrict__ manPair,
                                                             const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                             const uint32_t* __restrict__ color, unsigned long long* __restrict__ keys,
-                                                            uint32_t* __restrict__ vals, uint32_t mask) {
+                                                            uint32_t* __restrict__ vals, uint32_t mask, const uint8_t* __restrict__ manKept) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= sc->numManifolds) return;
+    if (m >= sc->numManifolds || manKept[m]) return;      // kept colours were inserted by k_emit_manifolds
     uint64_t pk = (sc->partitioned ? pairsB : pairsA)[manPair[m]];
     uint64_t key = historyKey(nc, (uint32_t)((pk >> 29) & 0x1FFFFFFFull), (uint32_t)(pk & 0x1FFFFFFFull));
     for (uint32_t s = tableSlot(key, mask), n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
@@ -1077,7 +1077,8 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
                                                         uint4* __restrict__ colWork, uint32_t* __restrict__ color,
                                                         const unsigned long long* __restrict__ prevKeys, const uint32_t* __restrict__ prevVals, uint32_t prevMask,
                                                         unsigned long long* __restrict__ bodyUsed, uint8_t* __restrict__ isNew, StepScalars* sc,
-                                                        float2 terrainMaterial /* (restitution, friction) of the heightmap */) {
+                                                        float2 terrainMaterial /* (restitution, friction) of the heightmap */,
+                                                        unsigned long long* __restrict__ nextKeys, uint32_t* __restrict__ nextVals, uint32_t nextMask, uint8_t* __restrict__ manKept) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t numPairs = sc->numPairs;
     if (p >= numPairs) return;
@@ -1103,12 +1104,18 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
     uint64_t prio = pairPriority(a, b);
     colWork[m] = make_uint4(bA | dynA, bB | dynB, (uint32_t)prio, (uint32_t)(prio >> 32));
     // a manifold of the previous step keeps its colour (colour 64 = overflow is re-coloured)
-    uint32_t c = prevKeys ? tableLookup(prevKeys, prevVals, prevMask, historyKey(nc, a, b)) : kUncolored;
+    const uint64_t hk = historyKey(nc, a, b);
+    uint32_t c = prevKeys ? tableLookup(prevKeys, prevVals, prevMask, hk) : kUncolored;
     if (isNew) isNew[m] = (c == kUncolored && !terrain) ? 1u : 0u;   // not in the previous step's collision list: collision-begin event
     if (c < kOverflowColor) {
         if (dynA) atomicOr(&bodyUsed[bA], 1ull << c);
         if (dynB) atomicOr(&bodyUsed[bB], 1ull << c);
-    } else c = kUncolored;
+        // its colour is final: it enters the NEXT step's history right here (k_color_table_insert then only has the few new manifolds left)
+        for (uint32_t s = tableSlot(hk, nextMask), n = 0; n <= nextMask; s = (s + 1u) & nextMask, ++n) {
+            if (atomicCAS(&nextKeys[s], 0ull, (unsigned long long)hk) == 0ull) { nextVals[s] = c; break; }
+        }
+        manKept[m] = 1u;
+    } else { c = kUncolored; manKept[m] = 0u; }
     color[m] = c;
 }
 

@@ -144,7 +144,7 @@ struct mi_world {
     uint32_t gridCur = 0; bool gridValid = false; uint32_t gridNextCells = 0; DBuf<char> scalarsRaw; DBuf<Shards> shards;   // scalarsRaw = [StepScalars][colouring round flags]: one read-back
     StepScalars* scalarsPtr() { return reinterpret_cast<StepScalars*>(scalarsRaw.p); }
     uint32_t* roundFlagsPtr() { return reinterpret_cast<uint32_t*>(scalarsRaw.p + sizeof(StepScalars)); }
-    DBuf<uint64_t> pairKeys, pairKeysS;
+    DBuf<uint64_t> pairKeys, pairKeysS; DBuf<uint8_t> manKept;   // manKept: manifold kept its colour (already in the next step's history)
     DeviceScan<uint32_t> scanCells, scanBins; DeviceScan<unsigned long long> scanPairs, scanTerrain;   // one per scan site (own tickets / generations)
     // narrow phase
     DBuf<uint64_t> npPacked, npScan; DBuf<float4> npNormal, npPoints; DBuf<BoxHit> boxQueue;
@@ -855,10 +855,19 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         }
         HIP_TRY(scanPairs.run(reinterpret_cast<unsigned long long*>(npPacked.p), reinterpret_cast<unsigned long long*>(npScan.p), pairBound, st));
         if (eventsEnabled) HIP_TRY(manIsNew.ensure(pairBound));
+        {   // the NEXT step's colour history: sized and cleared before k_emit_manifolds, which already enters the manifolds that keep their colour
+            const uint32_t histBound = spec ? std::min(pairBound, bound(last.numManifolds, 1024)) : pairBound;
+            const int nt = tabCur ^ 1;
+            uint32_t cap = 1024; while (cap < 2u * histBound) cap <<= 1;
+            HIP_TRY(tabKeys[nt].ensure(cap)); HIP_TRY(tabVals[nt].ensure(cap)); HIP_TRY(manKept.ensure(pairBound));
+            tabMask[nt] = cap - 1u;
+            HIP_TRY(hipMemsetAsync(tabKeys[nt].p, 0, (size_t)cap * sizeof(unsigned long long), st));
+        }
         k_emit_manifolds<<<divUp(pairBound, B), B, 0, st>>>(nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
                                                         tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc,
-                                                        heightmap ? make_float2(hmParams.restitution, hmParams.friction) : make_float2(0.f, 0.f));
+                                                        heightmap ? make_float2(hmParams.restitution, hmParams.friction) : make_float2(0.f, 0.f),
+                                                        tabKeys[tabCur ^ 1].p, tabVals[tabCur ^ 1].p, tabMask[tabCur ^ 1], manKept.p);
         if (shard.enabled) k_shard_count<<<divUp(pairBound, B), B, 0, st>>>(nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc);
     }
     // ---------------------------------------------------------------------------------------------- triggers / force fields
@@ -913,12 +922,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         }
         colorRoundsLaunched = round;
         {   // colour history for the next step, into the OTHER table (it becomes current only if this step turns out valid)
-            const int nt = tabCur ^ 1;
-            uint32_t cap = 1024; while (cap < 2u * nmBound) cap <<= 1;
-            HIP_TRY(tabKeys[nt].ensure(cap)); HIP_TRY(tabVals[nt].ensure(cap));
-            tabMask[nt] = cap - 1u;
-            HIP_TRY(hipMemsetAsync(tabKeys[nt].p, 0, (size_t)cap * sizeof(unsigned long long), st));
-            k_color_table_insert<<<divUp(nmBound, B), B, 0, st>>>(nc, sc, manPair.p, pairKeys.p, pairKeysS.p, color.p, tabKeys[nt].p, tabVals[nt].p, tabMask[nt]);
+            const int nt = tabCur ^ 1;   // sized and cleared before k_emit_manifolds (narrow phase stage)
+            k_color_table_insert<<<divUp(nmBound, B), B, 0, st>>>(nc, sc, manPair.p, pairKeys.p, pairKeysS.p, color.p, tabKeys[nt].p, tabVals[nt].p, tabMask[nt], manKept.p);
             if (eventsEnabled) {   // begins: manifolds not in the previous table; ends: previous pairs not in this step's table
                 eventCap = nmBound + (tabValid ? last.numManifolds : 0u) + 1024u;
                 HIP_TRY(devEvents.ensure(eventCap));
