@@ -20,7 +20,7 @@ namespace mi {
 constexpr float kBetaDistance = 0.1f, kBetaBall = 0.1f, kBetaSlider = 0.1f, kBetaHingeRot = 0.3f, kBetaHingeLimit = 0.1f,
                 kBetaTwistLimit = 0.1f, kBetaSliderLimit = 0.1f, kDtThreshold = 1e-5f;   // constraints.cpp:9-17
 
-struct BodyView { const float4* gPos; const float4* gInvI; float4* gVel; const float4* bRot; const float4* bCog; };
+struct BodyView { const float4* gPos; const float4* gInvI; float4* gVel; const float4* bRot; const float4* bCog; const uint8_t* active /* sharded world: 0 = body (and so its whole island) is not simulated by this rank; or null */; };
 struct BodyState { Q4 rot; V3 cog, pos; M3 invI; float invMass; };
 struct BodyVel { V3 v, w; float invMass; M3 invI; float tagV, tagW; };   // tags: the contact solver's update-version words in gVel[].w, carried through untouched
 
@@ -535,6 +535,7 @@ __global__ __launch_bounds__(64) void k_joint_init(uint32_t n, uint32_t dummy, c
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint2 b = bodies[i];
+    if (bv.active && !bv.active[b.x]) return;
     typename J::Pod in = pods[i];
     BodyState A = loadState(bv, b.x, dummy), B = loadState(bv, b.y, dummy);
     typename J::Upd o;
@@ -551,6 +552,7 @@ __global__ __launch_bounds__(64) void k_joint_solve(uint32_t s0, uint32_t s1, co
     if (s >= s1) return;
     uint32_t i = order[s];
     uint2 b = bodies[i];
+    if (bv.active && !bv.active[b.x]) return;
     typename J::Upd c = upd[i];
     BodyVel A = loadVel(bv, b.x), B = loadVel(bv, b.y);
     J::solve(c, A, B);
@@ -564,6 +566,7 @@ __global__ void k_joint_solve_serial(uint32_t s0, uint32_t s1, const uint32_t* _
     for (uint32_t s = s0; s < s1; ++s) {
         uint32_t i = order[s];
         uint2 b = bodies[i];
+        if (bv.active && !bv.active[b.x]) continue;
         typename J::Upd c = upd[i];
         BodyVel A = loadVel(bv, b.x), B = loadVel(bv, b.y);
         J::solve(c, A, B);
@@ -613,6 +616,7 @@ __global__ __launch_bounds__(64) void k_joint_islands(const IslandDesc* __restri
                                                       const uint32_t* __restrict__ islandBodies, IslandUpd upd, BodyView bv) {
     __shared__ IslandLds lds;
     const IslandDesc d = islands[blockIdx.x];
+    if (bv.active && !bv.active[islandBodies[d.bodyBegin]]) return;   // an island is simulated as a whole or not at all
     const uint32_t lane = threadIdx.x;
     uint32_t body = 0;
     if (lane < d.numBodies) {
@@ -750,7 +754,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_W
     const uint32_t numTiles = sc->totalTiles, per = numIslands + numTiles;
     if (blockIdx.x >= per * sweeps) return;
     const uint32_t it = itBase + blockIdx.x / per, idx = blockIdx.x % per;
-    if (idx < numIslands) { fusedIsland(it, islands[idx], steps, islandBodies, upd, acc, bv, bodyUsed, lds, sc); return; }
+    if (idx < numIslands) { if (bv.active && !bv.active[islandBodies[islands[idx].bodyBegin]]) return; fusedIsland(it, islands[idx], steps, islandBodies, upd, acc, bv, bodyUsed, lds, sc); return; }
     const uint32_t tile = idx - numIslands, lane = threadIdx.x;
     const uint2 d = tileDesc[tile];
     switch (d.y) {

@@ -2307,11 +2307,13 @@ __device__ __forceinline__ V3 shardCog(float4 pos, float4 rot, float4 cogInvMass
 
 // start of a step: 1 = owned, 2 = ghost, 0 = not simulated here
 __global__ __launch_bounds__(256) void k_shard_classify(uint32_t nb, ShardParams sp, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
-                                                        const float4* __restrict__ bCogInvMass, uint8_t* __restrict__ bodyActive, StepScalars* sc) {
+                                                        const float4* __restrict__ bCogInvMass, uint8_t* __restrict__ bodyActive, StepScalars* sc,
+                                                        const uint32_t* __restrict__ root /* lowest body index of the body's articulated island: the island is classified as ONE */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool owned = false;
     if (i < nb) {
-        const V3 c = shardCog(bPos[i], bRot[i], bCogInvMass[i]);
+        const uint32_t r = root[i];
+        const V3 c = shardCog(bPos[r], bRot[r], bCogInvMass[r]);
         owned = shardTileOf(sp, c.x, c.z) == sp.myTile;
         bodyActive[i] = owned ? 1u : shardInExtended(sp, sp.myTile, c.x, c.z) ? 2u : 0u;
     }
@@ -2338,12 +2340,14 @@ constexpr uint32_t kShardRecordFloats = 14;
 __global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp, uint32_t slot, const uint8_t* __restrict__ bodyActive,
                                                     const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bLinVel,
                                                     const float4* __restrict__ bAngVel, const float4* __restrict__ bPosOld, const float4* __restrict__ bRotOld,
-                                                    const float4* __restrict__ bCogInvMass, float* __restrict__ out, uint32_t capacity, StepScalars* sc) {
+                                                    const float4* __restrict__ bCogInvMass, float* __restrict__ out, uint32_t capacity, StepScalars* sc,
+                                                    const uint32_t* __restrict__ root) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool want = false;
     if (i < nb && bodyActive[i] == 1u) {
-        const float4 cm = bCogInvMass[i];
-        const V3 cn = shardCog(bPos[i], bRot[i], cm), co = shardCog(bPosOld[i], bRotOld[i], cm);
+        const uint32_t r = root[i];
+        const float4 cm = bCogInvMass[r];
+        const V3 cn = shardCog(bPos[r], bRot[r], cm), co = shardCog(bPosOld[r], bRotOld[r], cm);
         want = shardInExtended(sp, sp.peers[slot], cn.x, cn.z) || shardInExtended(sp, sp.peers[slot], co.x, co.z);
     }
     const unsigned long long mask = __ballot(want);

@@ -114,6 +114,7 @@ struct mi_world {
         mi_shard_desc desc{}; ShardParams sp{};
         uint32_t capacity = 0; std::vector<uint32_t> peerRanks;
         DBuf<uint8_t> active; DBuf<float> sendBuf[8], recvBuf[8]; DBuf<uint32_t> sent;
+        DBuf<uint32_t> root; size_t rootJoints = ~size_t(0), rootBodies = 0;   // island root of every body (union-find over the joints), rebuilt when the scene changes
         uint32_t* sentHost = nullptr;            // pinned: the records packed per slot in the previous exchange (overflow check)
         bool sentPending = false;
         uint32_t owned[3] = {0, 0, 0};
@@ -121,6 +122,7 @@ struct mi_world {
         size_t messageFloats() const { return (size_t)(capacity + 1u) * kShardRecordFloats; }
     } shard;
     int shardExchange();
+    int shardBuildRoots();
     void shardReleaseComm();
     bool transformsFollowPhysics = false;   // last stepped through mi_world_step_fixed: entity transforms = physics_transform1 at the next download
     float timer = 0.f;
@@ -510,7 +512,8 @@ int mi_world::upload() {
         rc = uploadHeightmap(); if (rc != MI_OK) return rc;
     }
     HIP_TRY(hipStreamSynchronize(stream));
-    topologyDirty = false; hostStale = false; haveEstimates = false; gridValid = false;   // the previous step's counts say nothing about the new topology
+    topologyDirty = false; hostStale = false; haveEstimates = false; gridValid = false;
+    if (shard.enabled) { int rc = shardBuildRoots(); if (rc != MI_OK) return rc; }   // the previous step's counts say nothing about the new topology
     return MI_OK;
 }
 
@@ -776,7 +779,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     mark();  // 0
     if (attached) hipExtLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(128), 0, st, ev[0], nullptr, 0, sc, shards.p, roundFlagsPtr(), keyCount.p);
     else k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlagsPtr(), keyCount.p);
-    if (shard.enabled && nb) k_shard_classify<<<divUp(nb, B), B, 0, st>>>(nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, sc);
+    if (shard.enabled && nb) k_shard_classify<<<divUp(nb, B), B, 0, st>>>(nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, sc, shard.root.p);
     if (nc) {
         k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis, shard.enabled ? shard.active.p : nullptr);
@@ -981,7 +984,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         const uint64_t per = (uint64_t)joints.numIslands + tilesLaunch;
         const uint32_t perLaunch = per * iters < 0x7FFFFFFFull ? iters : 1u;
         solveLaunches = (iters + perLaunch - 1) / perLaunch;
-        BodyView bv{gPos.p, gInvI.p, gVel.p, bRot.p, bCogInvMass.p};
+        BodyView bv{gPos.p, gInvI.p, gVel.p, bRot.p, bCogInvMass.p, shard.enabled ? shard.active.p : nullptr};
         const IslandUpd iu{joints.distance.dUpd, joints.ball.dUpd, joints.fixed.dUpd, joints.hinge.dUpd, joints.cone.dUpd, joints.slider.dUpd};
         const IslandAcc ia{joints.hinge.dAcc, joints.cone.dAcc, joints.slider.dAcc};
         for (uint32_t it = 0; it < iters; it += perLaunch) {
@@ -1487,7 +1490,7 @@ void JointSet::buildIslands(const std::vector<float>& invMass, std::vector<Islan
         for (uint32_t r : js) flags[all[r].type][all[r].joint] = 1;
     }
 }
-static BodyView bodyView(mi_world& w) { return BodyView{w.gPos.p, w.gInvI.p, w.gVel.p, w.bRot.p, w.bCogInvMass.p}; }
+static BodyView bodyView(mi_world& w) { return BodyView{w.gPos.p, w.gInvI.p, w.gVel.p, w.bRot.p, w.bCogInvMass.p, w.shard.enabled ? w.shard.active.p : nullptr}; }
 int JointSet::initialize(mi_world& w, float dt, hipStream_t st) {
     if (!count()) return MI_OK;
     BodyView bv = bodyView(w);
@@ -1995,6 +1998,20 @@ constexpr int kNcclFloat32 = 7;   // ncclFloat32 (rccl.h)
 
 // Pack the records every neighbour is owed (device), then — library transport — one RCCL group of sends / receives on the world's stream and
 // the unpack kernels behind it; nothing is read back in between.  With the caller's transport the messages wait in sendBuf for mi_world_shard_export.
+// An articulated island is owned / ghosted / ignored as ONE (its root = lowest body index decides): union-find over the joints' body pairs.
+int mi_world::shardBuildRoots() {
+    const uint32_t nb = (uint32_t)bodies.size();
+    std::vector<uint32_t> parent(nb);
+    for (uint32_t i = 0; i < nb; ++i) parent[i] = i;
+    auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    auto link = [&](const auto& t) { for (const uint2& b : t.bodies) { uint32_t x = find(b.x), y = find(b.y); if (x != y) parent[std::max(x, y)] = std::min(x, y); } };
+    link(joints.distance); link(joints.ball); link(joints.fixed); link(joints.hinge); link(joints.cone); link(joints.slider);
+    for (uint32_t i = 0; i < nb; ++i) parent[i] = find(i);
+    HIP_TRY(shard.root.ensure(std::max(nb, 1u))); HIP_TRY(shard.active.ensure(std::max(nb, 1u)));
+    if (nb) HIP_TRY(hipMemcpy(shard.root.p, parent.data(), (size_t)nb * sizeof(uint32_t), hipMemcpyHostToDevice));
+    shard.rootJoints = joints.count(); shard.rootBodies = nb;
+    return MI_OK;
+}
 void mi_world::shardReleaseComm() { if (shard.comm) { if (Rccl* r = rccl()) if (r->CommDestroy) (void)r->CommDestroy(shard.comm); shard.comm = nullptr; } }
 int mi_world::shardExchange() {
     const uint32_t nb = (uint32_t)bodies.size();
@@ -2010,7 +2027,7 @@ int mi_world::shardExchange() {
     HIP_TRY(hipMemsetAsync(&sc->shardSent[0], 0, 8 * sizeof(uint32_t), st));
     for (uint32_t k = 0; k < sh.sp.numPeers; ++k) {
         // after a valid step the buffer sets are swapped: bPos = the new state, bPosN = the state the step started from
-        k_shard_pack<<<divUp(nb, 256), 256, 0, st>>>(nb, sh.sp, k, sh.active.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bPosN.p, bRotN.p, bCogInvMass.p, sh.sendBuf[k].p, sh.capacity, sc);
+        k_shard_pack<<<divUp(nb, 256), 256, 0, st>>>(nb, sh.sp, k, sh.active.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bPosN.p, bRotN.p, bCogInvMass.p, sh.sendBuf[k].p, sh.capacity, sc, sh.root.p);
         k_shard_pack_header<<<1, 1, 0, st>>>(k, sc, sh.sendBuf[k].p);
     }
     HIP_TRY(hipMemcpyAsync(sh.sentHost, &sc->shardSent[0], 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -2044,7 +2061,6 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
     if (!w || !d) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     if (!d->tiles_x || !d->tiles_z || d->tiles_x > 65535u || d->tiles_z > 65535u || d->num_ranks != d->tiles_x * d->tiles_z || d->rank >= d->num_ranks) return fail(MI_ERR_INVALID_ARGUMENT, "num_ranks must equal tiles_x * tiles_z");
     if (!(d->tile_size_x > 0.f) || !(d->tile_size_z > 0.f) || !(d->ghost_margin > 0.f) || d->ghost_margin >= d->tile_size_x || d->ghost_margin >= d->tile_size_z) return fail(MI_ERR_INVALID_ARGUMENT, "0 < ghost_margin < tile size");
-    if (w->joints.count()) return fail(MI_ERR_UNSUPPORTED, "sharded worlds with constraints are not supported yet (an articulated island must stay on one rank)");
     if (w->heightmap || !w->cloths.empty()) return fail(MI_ERR_UNSUPPORTED, "sharded worlds with heightmap terrain or cloth are not supported yet");
     HIP_TRY(hipSetDevice(w->device));
     mi_world::ShardState& sh = w->shard;
@@ -2062,7 +2078,8 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
     }
     const uint32_t nb = (uint32_t)w->bodies.size();
     sh.capacity = d->max_records ? d->max_records : std::max(4096u, nb / 4u);
-    HIP_TRY(sh.active.ensure(std::max(nb, 1u))); HIP_TRY(sh.sent.ensure(8));
+    { int rc = w->shardBuildRoots(); if (rc != MI_OK) return rc; }
+    HIP_TRY(sh.sent.ensure(8));
     for (uint32_t k = 0; k < sp.numPeers; ++k) {
         HIP_TRY(sh.sendBuf[k].ensure(sh.messageFloats())); HIP_TRY(sh.recvBuf[k].ensure(sh.messageFloats()));
         HIP_TRY(hipMemset(sh.sendBuf[k].p, 0, sh.messageFloats() * sizeof(float))); HIP_TRY(hipMemset(sh.recvBuf[k].p, 0, sh.messageFloats() * sizeof(float)));

@@ -74,6 +74,17 @@ uint32_t jointsCount(const World& w) {
     return (uint32_t)(j.distance.pods.size() + j.ball.pods.size() + j.fixed.pods.size() + j.hinge.pods.size() + j.cone.pods.size() + j.slider.pods.size());
 }
 
+void jointsIslandRoots(const World& w, std::vector<uint32_t>& root) {
+    const uint32_t nb = (uint32_t)w.bodies.size();
+    std::vector<uint32_t> parent(nb);
+    for (uint32_t i = 0; i < nb; ++i) parent[i] = i;
+    auto find = [&](uint32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    const JointStore& j = *w.joints;
+    auto link = [&](const auto& l) { for (const Pair& b : l.bodies) { uint32_t x = find(b.a), y = find(b.b); if (x != y) parent[std::max(x, y)] = std::min(x, y); } };   // the root is the lowest index
+    link(j.distance); link(j.ball); link(j.fixed); link(j.hinge); link(j.cone); link(j.slider);
+    root.resize(nb);
+    for (uint32_t i = 0; i < nb; ++i) root[i] = find(i);
+}
 int jointsLoadPods(World& w, const uint8_t*& p, const uint8_t* end, const uint32_t counts[6]) {
     JointStore& j = *w.joints;
     auto load = [&](auto& list, uint32_t n) {
@@ -298,6 +309,7 @@ void jointsInitialize(World& w, float dt) {
         const mi_distance_constraint& in = J.distance.pods[i]; DistanceUpd& o = J.uDistance[i];
         o.a = J.distance.bodies[i].a; o.b = J.distance.bodies[i].b;
         const GlobalState& A = rb[o.a]; const GlobalState& B = rb[o.b];
+        if (w.shard.enabled && !w.shard.active[o.a]) continue;
         o.rA = A.rotation * (v3(in.local_anchor_a) - A.localCOG);
         o.rB = B.rotation * (v3(in.local_anchor_b) - B.localCOG);
         vec3 gA = A.position + o.rA, gB = B.position + o.rB;
@@ -317,6 +329,7 @@ void jointsInitialize(World& w, float dt) {
         const mi_ball_constraint& in = J.ball.pods[i]; BallUpd& o = J.uBall[i];
         o.a = J.ball.bodies[i].a; o.b = J.ball.bodies[i].b;
         const GlobalState& A = rb[o.a]; const GlobalState& B = rb[o.b];
+        if (w.shard.enabled && !w.shard.active[o.a]) continue;
         o.rA = A.rotation * (v3(in.local_anchor_a) - A.localCOG);
         o.rB = B.rotation * (v3(in.local_anchor_b) - B.localCOG);
         vec3 gA = A.position + o.rA, gB = B.position + o.rB;
@@ -329,6 +342,7 @@ void jointsInitialize(World& w, float dt) {
         const mi_fixed_constraint& in = J.fixed.pods[i]; FixedUpd& o = J.uFixed[i];
         o.a = J.fixed.bodies[i].a; o.b = J.fixed.bodies[i].b;
         const GlobalState& A = rb[o.a]; const GlobalState& B = rb[o.b];
+        if (w.shard.enabled && !w.shard.active[o.a]) continue;
         o.rA = A.rotation * (v3(in.local_anchor_a) - A.localCOG);
         o.rB = B.rotation * (v3(in.local_anchor_b) - B.localCOG);
         vec3 gA = A.position + o.rA, gB = B.position + o.rB;
@@ -346,6 +360,7 @@ void jointsInitialize(World& w, float dt) {
         const mi_hinge_constraint& in = J.hinge.pods[i]; HingeUpd& o = J.uHinge[i];
         o.a = J.hinge.bodies[i].a; o.b = J.hinge.bodies[i].b;
         const GlobalState& A = rb[o.a]; const GlobalState& B = rb[o.b];
+        if (w.shard.enabled && !w.shard.active[o.a]) continue;
         o.rA = A.rotation * (v3(in.local_anchor_a) - A.localCOG);
         o.rB = B.rotation * (v3(in.local_anchor_b) - B.localCOG);
         vec3 gA = A.position + o.rA, gB = B.position + o.rB;
@@ -403,6 +418,7 @@ void jointsInitialize(World& w, float dt) {
         std::memset((void*)&o, 0, sizeof(o));
         o.a = J.cone.bodies[i].a; o.b = J.cone.bodies[i].b;
         const GlobalState& A = rb[o.a]; const GlobalState& B = rb[o.b];
+        if (w.shard.enabled && !w.shard.active[o.a]) continue;
         o.rA = A.rotation * (v3(in.local_anchor_a) - A.localCOG);
         o.rB = B.rotation * (v3(in.local_anchor_b) - B.localCOG);
         vec3 gA = A.position + o.rA, gB = B.position + o.rB;
@@ -488,6 +504,7 @@ void jointsInitialize(World& w, float dt) {
         std::memset((void*)&o, 0, sizeof(o));
         o.a = J.slider.bodies[i].a; o.b = J.slider.bodies[i].b;
         const GlobalState& A = rb[o.a]; const GlobalState& B = rb[o.b];
+        if (w.shard.enabled && !w.shard.active[o.a]) continue;
         vec3 rA = A.rotation * (v3(in.local_anchor_a) - A.localCOG);
         vec3 rB = B.rotation * (v3(in.local_anchor_b) - B.localCOG);
         vec3 gA = A.position + rA, gB = B.position + rB;
@@ -556,6 +573,7 @@ void jointsSolveIteration(World& w) {
     std::vector<GlobalState>& rb = w.rb;
     for (uint32_t i : J.distance.order) {  // 239-264
         DistanceUpd& c = J.uDistance[i]; GlobalState& A = rb[c.a]; GlobalState& B = rb[c.b];
+        if (w.shard.enabled && !w.shard.active[c.a]) continue;   // sharded world: an island this rank does not simulate
         vec3 avA = A.linearVelocity + cross(A.angularVelocity, c.rA);
         vec3 avB = B.linearVelocity + cross(B.angularVelocity, c.rB);
         float Cdot = dot(c.u, avB - avA) + c.bias;
@@ -568,6 +586,7 @@ void jointsSolveIteration(World& w) {
     }
     for (uint32_t i : J.ball.order) {  // 505-528
         BallUpd& c = J.uBall[i]; GlobalState& A = rb[c.a]; GlobalState& B = rb[c.b];
+        if (w.shard.enabled && !w.shard.active[c.a]) continue;   // sharded world: an island this rank does not simulate
         vec3 avA = A.linearVelocity + cross(A.angularVelocity, c.rA);
         vec3 avB = B.linearVelocity + cross(B.angularVelocity, c.rB);
         vec3 Cdot = avB - avA + c.bias;
@@ -579,6 +598,7 @@ void jointsSolveIteration(World& w) {
     }
     for (uint32_t i : J.fixed.order) {  // 789-823
         FixedUpd& c = J.uFixed[i]; GlobalState& A = rb[c.a]; GlobalState& B = rb[c.b];
+        if (w.shard.enabled && !w.shard.active[c.a]) continue;   // sharded world: an island this rank does not simulate
         {
             vec3 Cdot = B.angularVelocity - A.angularVelocity;
             vec3 rl = solveLinearSystem(c.invEffR, -(Cdot + c.rBias));
@@ -598,6 +618,7 @@ void jointsSolveIteration(World& w) {
     }
     for (uint32_t i : J.hinge.order) {  // 1213-1307
         HingeUpd& c = J.uHinge[i]; GlobalState& A = rb[c.a]; GlobalState& B = rb[c.b];
+        if (w.shard.enabled && !w.shard.active[c.a]) continue;   // sharded world: an island this rank does not simulate
         vec3 vA = A.linearVelocity, wA = A.angularVelocity, vB = B.linearVelocity, wB = B.angularVelocity;
         vec3 axis = c.axis;
         if (c.solveMotor) {
@@ -647,6 +668,7 @@ void jointsSolveIteration(World& w) {
     }
     for (uint32_t i : J.cone.order) {  // 1952-2070
         ConeUpd& c = J.uCone[i]; GlobalState& A = rb[c.a]; GlobalState& B = rb[c.b];
+        if (w.shard.enabled && !w.shard.active[c.a]) continue;   // sharded world: an island this rank does not simulate
         vec3 vA = A.linearVelocity, wA = A.angularVelocity, vB = B.linearVelocity, wB = B.angularVelocity;
         vec3 tw = c.twistAxis;
         if (c.solveTwistMotor) {
@@ -709,6 +731,7 @@ void jointsSolveIteration(World& w) {
     }
     for (uint32_t i : J.slider.order) {  // 2764-2846
         SliderUpd& c = J.uSlider[i]; GlobalState& A = rb[c.a]; GlobalState& B = rb[c.b];
+        if (w.shard.enabled && !w.shard.active[c.a]) continue;   // sharded world: an island this rank does not simulate
         vec3 vA = A.linearVelocity, wA = A.angularVelocity, vB = B.linearVelocity, wB = B.angularVelocity;
         if (c.solveMotor) {
             float cd = dot(vB, c.axis) - dot(vA, c.axis) - c.motorVelocity;

@@ -981,8 +981,10 @@ static bool shardInExtended(const mi_shard_desc& d, uint32_t t, float x, float z
 void World::shardClassify() {
     const uint32_t nb = (uint32_t)bodies.size();
     shard.active.assign(nb, 0); shard.owned[0] = 0;
+    jointsIslandRoots(*this, shard.root);                        // an articulated island is owned / ghosted / ignored as ONE: by its root body's centre
     for (uint32_t i = 0; i < nb; ++i) {
-        vec3 c = bodies[i].p1 + bodies[i].r1 * bodies[i].localCOG;
+        const RigidBody& rbody = bodies[shard.root[i]];
+        vec3 c = rbody.p1 + rbody.r1 * rbody.localCOG;
         bool owned = shardTileOf(shard.desc, c.x, c.z) == shard.myTile;
         shard.active[i] = owned ? 1 : shardInExtended(shard.desc, shard.myTile, c.x, c.z) ? 2 : 0;
         shard.owned[0] += owned ? 1u : 0u;
@@ -997,7 +999,8 @@ void World::shardPack(const std::vector<vec3>& oldCog) {
         for (uint32_t i = 0; i < nb; ++i) {
             if (shard.active[i] != 1) continue;
             const RigidBody& b = bodies[i];
-            vec3 cn = b.p1 + b.r1 * b.localCOG, co = oldCog[i];
+            const RigidBody& rbody = bodies[shard.root[i]];
+            vec3 cn = rbody.p1 + rbody.r1 * rbody.localCOG, co = oldCog[shard.root[i]];
             if (!shardInExtended(shard.desc, shard.peers[k], cn.x, cn.z) && !shardInExtended(shard.desc, shard.peers[k], co.x, co.z)) continue;
             if (n < shard.capacity) {
                 float* o = msg.data() + (size_t)(n + 1u) * MI_SHARD_RECORD_FLOATS;
@@ -1403,7 +1406,7 @@ MI_API int ora_shard_rank_of_tile(uint32_t tx, uint32_t tz, uint32_t tile, uint3
 MI_API int ora_world_shard_enable(World* w, const mi_shard_desc* d) {
     if (!w || !d || !d->tiles_x || !d->tiles_z || d->num_ranks != d->tiles_x * d->tiles_z || d->rank >= d->num_ranks) return MI_ERR_INVALID_ARGUMENT;
     if (!(d->tile_size_x > 0.f) || !(d->tile_size_z > 0.f) || !(d->ghost_margin > 0.f) || d->ghost_margin >= d->tile_size_x || d->ghost_margin >= d->tile_size_z) return MI_ERR_INVALID_ARGUMENT;
-    if (w->orderMode != 1 || jointsCount(*w) || w->heightmap || !w->cloths.empty()) return MI_ERR_UNSUPPORTED;
+    if (w->orderMode != 1 || w->heightmap || !w->cloths.empty()) return MI_ERR_UNSUPPORTED;
     World::Shard& sh = w->shard;
     sh.desc = *d;
     auto order = ora::tilesInRankOrder(d->tiles_x, d->tiles_z);

@@ -171,6 +171,7 @@ struct World {
         bool enabled = false; mi_shard_desc desc{}; uint32_t myTile = 0, capacity = 0;
         std::vector<uint32_t> peers, peerRanks;
         std::vector<uint8_t> active;
+        std::vector<uint32_t> root;                   // lowest body index of the body's articulated island (itself without joints): the island is classified as one
         std::vector<std::vector<float>> sendBuf;      // one message per neighbour slot (record 0 = count)
         uint32_t owned[3] = {0, 0, 0};
     } shard;
@@ -215,6 +216,7 @@ void jointsInitialize(World& w, float dt);
 void jointsSolveIteration(World& w);
 uint32_t jointsCount(const World& w);
 void jointsRemapBody(World& w, uint32_t from, uint32_t to);
+void jointsIslandRoots(const World& w, std::vector<uint32_t>& root);   // union-find over the joints' body pairs
 int jointsLoadPods(World& w, const uint8_t*& p, const uint8_t* end, const uint32_t counts[6]);   // checkpoint: PODs of all six types in pool order
 
 uint32_t hash32(uint32_t m);  // joint colouring priority

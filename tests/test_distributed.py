@@ -18,8 +18,11 @@ ROOT = Path(__file__).resolve().parent.parent
 STEPS = 80
 
 
-def _scene():
-    return scenes.obb_pile(12, 4, 8, spacing=1.0)
+def _scene(kind="pile"):
+    return scenes.ragdolls(4, 3) if kind == "ragdolls" else scenes.obb_pile(12, 4, 8, spacing=1.0)
+
+
+MARGIN = {"pile": 2.5, "ragdolls": 3.5}      # islands are classified by their root body: the margin has to cover an island's reach
 
 
 def _virtual_ranks(make_world, sc, num_ranks, tiles_z=1, margin=2.5):
@@ -27,14 +30,14 @@ def _virtual_ranks(make_world, sc, num_ranks, tiles_z=1, margin=2.5):
     return [sharding.ShardedWorld(sc.populate(make_world()), desc, r, "local") for r in range(num_ranks)], desc
 
 
-def _worker(rank, world_size, port, out_dir, tiles_z):
+def _worker(rank, world_size, port, out_dir, tiles_z, kind="pile"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, str(ROOT))
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     import oracle
-    sc = _scene()
-    desc = sharding.tile_grid(sc, world_size, tiles_z)
+    sc = _scene(kind)
+    desc = sharding.tile_grid(sc, world_size, tiles_z, MARGIN[kind])
     sw = sharding.ShardedWorld(sc.populate(oracle.create_world(oracle.ORDER_CANONICAL)), desc, rank, "dist", dist)
     s = sc.settings()
     owned_per_step = []
@@ -47,14 +50,14 @@ def _worker(rank, world_size, port, out_dir, tiles_z):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world_size,tiles_z", [(2, 1), (4, 2)], ids=["2 ranks, x slabs", "4 ranks, 2 x 2 tiles"])
-def test_processes_over_gloo_equal_virtual_ranks_bit_for_bit(tmp_path, oracle_mod, world_size, tiles_z):
+@pytest.mark.parametrize("world_size,tiles_z,kind", [(2, 1, "pile"), (4, 2, "pile"), (2, 1, "ragdolls")], ids=["2 ranks, x slabs", "4 ranks, 2 x 2 tiles", "2 ranks, ragdolls"])
+def test_processes_over_gloo_equal_virtual_ranks_bit_for_bit(tmp_path, oracle_mod, world_size, tiles_z, kind):
     """R processes exchanging the neighbour messages over gloo == R worlds of one process with the messages copied by hand:
     the transport carries exactly what the library packed, nothing depends on timing or on who runs a tile."""
     port = 29500 + (os.getpid() % 2000) + world_size
-    mp.spawn(_worker, args=(world_size, port, str(tmp_path), tiles_z), nprocs=world_size, join=True)
-    sc = _scene()
-    ranks, _ = _virtual_ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), sc, world_size, tiles_z)
+    mp.spawn(_worker, args=(world_size, port, str(tmp_path), tiles_z, kind), nprocs=world_size, join=True)
+    sc = _scene(kind)
+    ranks, _ = _virtual_ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), sc, world_size, tiles_z, MARGIN[kind])
     s = sc.settings()
     owned = []
     for _ in range(STEPS):
@@ -123,11 +126,38 @@ def test_sharded_pile_stays_close_to_the_single_world(oracle_mod, record_propert
     assert np.median(err) < 0.25
 
 
+def test_articulated_islands_stay_on_one_rank(oracle_mod):
+    """cfg4-style scene in three x tiles: every ragdoll (14 bodies, 13 joints) is owned, ghosted or ignored as ONE — its root body's
+    centre decides — so no joint ever spans ranks; ragdolls that tumble across a border migrate whole."""
+    sc = scenes.ragdolls(6, 2)
+    ranks, _ = _virtual_ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), sc, 3, 1, margin=3.5)
+    s = sc.settings()
+    rng = np.random.default_rng(5)
+    for r in ranks:                                             # a sideways shove so that some ragdolls cross a tile border
+        r.world.apply_forces(np.arange(0, sc.num_bodies, 14, dtype=np.uint32), np.tile([[9000.0, 0.0, 0.0]], (sc.num_bodies // 14, 1)))
+    first = None; moved = 0
+    for i in range(150):
+        sharding.step_local(ranks, s, sc.dt)
+        owner = np.full(sc.num_bodies, -1)
+        for r in ranks:
+            e = r.world.shard_owned_entities(); e = e[e < sc.num_bodies]
+            assert (owner[e] == -1).all(); owner[e] = r.rank
+        assert (owner >= 0).all()
+        per_doll = owner.reshape(-1, 14)
+        assert (per_doll == per_doll[:, :1]).all(), f"step {i}: a ragdoll is split between ranks"
+        if first is None:
+            first = per_doll[:, 0].copy()
+        moved = max(moved, int((per_doll[:, 0] != first).sum()))
+    assert moved > 0, "no ragdoll ever changed rank"
+    st = sharding.gather_owned(ranks, sc.num_bodies)
+    assert np.isfinite(st).all() and st[:, 1].min() > -0.2
+
+
 def test_shard_api_rejects_what_it_cannot_do(oracle_mod):
-    sc = scenes.ragdolls(1, 1)
+    sc = scenes.terrain_field(4, 1, 4, with_unsupported=False)
     w = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     with pytest.raises(capi.PhysicsError):
-        w.shard_enable(sharding._desc_for(sharding.tile_grid(sc, 2), 0))          # constraints: islands would have to stay on one rank
+        w.shard_enable(sharding._desc_for(sharding.tile_grid(sc, 2), 0))          # heightmap terrain: not sharded yet
     sc = _scene()
     w = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     bad = sharding._desc_for(sharding.tile_grid(sc, 2), 0); bad.num_ranks = 3

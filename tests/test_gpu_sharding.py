@@ -15,12 +15,14 @@ def _ranks(make_world, sc, n, tiles_z=1, margin=2.5):
     return [sharding.ShardedWorld(sc.populate(make_world()), desc, r, "local") for r in range(n)]
 
 
-@pytest.mark.parametrize("n,tiles_z,make", [(3, 1, lambda: scenes.obb_pile(12, 4, 8, spacing=1.0)), (4, 2, lambda: scenes.mixed_stack(10, 4, 10)),
-                                            (2, 1, lambda: scenes.shape_zoo())], ids=["3 slabs boxes", "2x2 tiles mixed", "2 slabs all shapes"])
-def test_gpu_virtual_ranks_match_oracle_virtual_ranks(mi_lib, oracle_mod, n, tiles_z, make):
+@pytest.mark.parametrize("n,tiles_z,make,margin", [(3, 1, lambda: scenes.obb_pile(12, 4, 8, spacing=1.0), 2.5), (4, 2, lambda: scenes.mixed_stack(10, 4, 10), 2.5),
+                                                   (2, 1, lambda: scenes.shape_zoo(), 2.5), (3, 1, lambda: scenes.ragdolls(6, 3), 3.5), (2, 2, lambda: scenes.vehicles(4, 4), 6.0)],
+                         ids=["3 slabs boxes", "2x2 tiles mixed", "2 slabs all shapes", "3 slabs ragdolls (cfg4)", "2x1 tiles vehicles (cfg5)"])
+def test_gpu_virtual_ranks_match_oracle_virtual_ranks(mi_lib, oracle_mod, n, tiles_z, make, margin):
+    """Joint scenes too: an articulated island (ragdoll, vehicle) is owned / ghosted / ignored as one, decided by its root body."""
     sc = make()
-    g = _ranks(lambda: mi_lib.create_world(0), sc, n, tiles_z)
-    o = _ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), sc, n, tiles_z)
+    g = _ranks(lambda: mi_lib.create_world(0), sc, n, tiles_z, margin)
+    o = _ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), sc, n, tiles_z, margin)
     s = sc.settings()
     migrated = False; first = None
     for i in range(100):
@@ -39,7 +41,7 @@ def test_gpu_virtual_ranks_match_oracle_virtual_ranks(mi_lib, oracle_mod, n, til
             if first is None:
                 first = cur
             migrated |= bool((cur != first).any())
-    assert migrated or n != 3, "no body changed owner in the spreading box pile"
+    assert migrated or n != 3 or margin != 2.5, "no body changed owner in the spreading box pile"
 
 
 def test_gpu_one_tile_is_the_unsharded_world(mi_lib):
@@ -73,3 +75,22 @@ def test_gpu_bench_scene_in_two_tiles(mi_lib):
         assert r.world.counts()["num_contacts"] < 0.75 * sum(o["owned_contacts"] for o in owned)
     st = np.concatenate([r.owned_states()[1] for r in ranks])
     assert np.isfinite(st).all() and st[:, 1].min() > -0.05
+
+
+def test_gpu_library_rccl_transport_comes_up(mi_lib):
+    """The library's own transport with ONE rank on this one GPU: librccl is found at run time (dlopen), ncclGetUniqueId and
+    ncclCommInitRank succeed, a sharded step runs its (empty) send / receive group on the world's stream and the communicator is
+    destroyed with the world.  (Sends and receives themselves need one GPU per rank; RCCL refuses two ranks on one device.)"""
+    sc = scenes.obb_pile(8, 4, 8, spacing=1.0)
+    plain = sc.populate(mi_lib.create_world(0))
+    w = sc.populate(mi_lib.create_world(0))
+    desc = sharding._desc_for(sharding.tile_grid(sc, 1), 0)
+    w.shard_enable(desc)
+    ident = w.L.shard_unique_id()
+    assert len(ident) == 128 and any(ident)
+    w.shard_attach_rccl(ident)
+    s = sc.settings()
+    w.step_fixed(s, sc.dt, 30); plain.step_fixed(s, sc.dt, 30)       # with the library transport several internal steps per call are fine
+    assert w.physics_transforms()[0].tobytes() == plain.physics_transforms()[0].tobytes()
+    assert w.shard_counts()["owned_bodies"] == sc.num_bodies
+    w.close()
