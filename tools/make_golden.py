@@ -1,9 +1,12 @@
-"""Generates tests/golden/*.npz from the CPU oracle (canonical order).
+"""Generates tests/golden/*.npz.
 
-The reference ships no golden vectors and cannot be built here, so these are
-ORACLE-generated regression vectors: they pin (a) the oracle against silent drift and (b) the HIP
-path bit-for-bit on the GPU box, where the oracle is rebuilt from source and re-checked against
-them first.  Run: python tools/make_golden.py
+  *_reference.npz   outputs of THE REFERENCE ITSELF: the reference's own physics sources compiled into oracle/_ref/libref.so
+                    (oracle/refbuild/build_ref.py) and stepped through its own physicsStep.  The reference ships no golden vectors of
+                    its own; these are the vectors the oracle (reference order) has to reproduce bit for bit on any machine,
+                    including the GPU box, where /root/reference does not exist.
+  *_canonical.npz   the oracle replaying the GPU's canonical schedule (same arithmetic, colour-major PGS order): what the HIP path
+                    has to reproduce bit for bit.
+Run here (needs /root/reference): python tools/make_golden.py
 """
 import sys
 from pathlib import Path
@@ -24,9 +27,9 @@ CASES = {
 }
 
 
-def run_case(make, steps, order):
+def run_case(make, steps, order, from_reference=False):
     sc = make()
-    w = sc.populate(oracle.create_world(order))
+    w = sc.populate(oracle.create_reference_world() if from_reference else oracle.create_world(order))
     s = sc.settings()
     counts = []
     for _ in range(steps):
@@ -43,6 +46,8 @@ if __name__ == "__main__":
     out.mkdir(parents=True, exist_ok=True)
     for name, (make, steps) in CASES.items():
         for order, tag in ((oracle.ORDER_CANONICAL, "canonical"), (oracle.ORDER_REFERENCE, "reference")):
-            r = run_case(make, steps, order)
-            np.savez_compressed(out / f"{name}_{tag}.npz", steps=np.uint32(steps), **r)
+            from_ref = tag == "reference"
+            r = run_case(make, steps, order, from_reference=from_ref)
+            source = "reference: oracle/_ref/libref.so = /root/reference sources, own physicsStep" if from_ref else "oracle, canonical schedule"
+            np.savez_compressed(out / f"{name}_{tag}.npz", steps=np.uint32(steps), source=np.array(source), **r)
             print(name, tag, r["counts"][-1])
