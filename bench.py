@@ -219,7 +219,8 @@ def main():
         desc = sharding.tile_grid(scene, world_size, args.tiles_z, args.ghost_margin)
         sw = sharding.ShardedWorld(world, desc, rank, args.transport, dist)
         sharding_note = (f"{world_size} tiles ({desc.tiles_x} x {desc.tiles_z}) of one replicated scene, ghost margin {desc.ghost_margin:.2f} m, ownership by position each step, "
-                         f"neighbour exchange: {'RCCL send/recv inside the library' if args.transport == 'rccl' else 'torch.distributed p2p via host'}; {args.scaling} scaling")
+                         f"neighbour exchange: {'RCCL send/recv inside the library' if sw.transport == 'rccl' else 'torch.distributed p2p via host'}; {args.scaling} scaling"
+                         + (f"; {sw.note}" if sw.note else ""))
     else:
         sw = _Single(world); sharding_note = "single GPU, whole scene"
     settings = scene.settings()

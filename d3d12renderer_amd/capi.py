@@ -429,6 +429,9 @@ class World:
         self.L.check(self.L.fn("world_shard_message_bytes")(self.h, C.byref(n)), "world_shard_message_bytes")
         return n.value
 
+    def shard_detach_rccl(self):
+        self.L.check(self.L.fn("world_shard_detach_rccl")(self.h), "world_shard_detach_rccl")
+
     def shard_export(self, slot):
         """The message for neighbour slot `slot` after the last internal step: float32 array, record 0 = (count, ...)."""
         out = np.zeros(self.shard_message_bytes() // 4, np.float32)

@@ -2128,6 +2128,13 @@ MI_API int mi_world_shard_attach_rccl(mi_world* w, const void* id) {
     w->shard.rccl = true;
     return MI_OK;
 }
+MI_API int mi_world_shard_detach_rccl(mi_world* w) {
+    if (!w || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    HIP_TRY(hipSetDevice(w->device));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->shardReleaseComm(); w->shard.rccl = false;
+    return MI_OK;
+}
 MI_API int mi_world_shard_message_bytes(mi_world* w, uint64_t* out) {
     if (!w || !out || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
     *out = (uint64_t)w->shard.messageFloats() * sizeof(float); return MI_OK;

@@ -717,3 +717,51 @@ def terrain_big(nx=128, ny=4, nz=128):
 
 def by_name(name, **kw):
     return {"cfg1": sphere_drop, "cfg2": mixed_stack, "cfg3": obb_pile, "cfg4": ragdolls, "cfg5": vehicles, "zoo": shape_zoo}[name](**kw)
+
+
+# ---- degenerate / boundary configurations (tests/test_reference_pin.py, tests/test_gpu_parity.py) ----
+def scene_from_parts(parts, iterations=30):
+    """parts: list of (kind, pos, rot, [(ctype, shape, material overrides)], entity overrides)."""
+    ents, cols, cent = [], [], []
+    for i, (kind, pos, rot, colliders, over) in enumerate(parts):
+        e = make_entities(1, kind); e["position"][0] = pos; e["rotation"][0] = rot
+        for k, v in over.items():
+            e[k][0] = v
+        ents.append(e)
+        for ctype, shape, mat in colliders:
+            c = make_colliders(1, ctype, **mat); c["shape"][0, :len(shape)] = shape
+            cols.append(c); cent.append(i)
+    return Scene("edge", np.concatenate(ents), np.asarray(cent, np.uint32), np.concatenate(cols), iterations)
+
+
+EDGE_CASES = {
+    # axis-aligned boxes resting exactly face to face: the SAT's parallel-axes shortcut (absR >= 0.99, collision_narrow.cpp:1219-1226),
+    # depths at the slop, AABB (unrotated) next to OBB (a hair rotated: |dot| > 0.99 but not identity)
+    "aligned boxes": lambda: scene_from_parts(
+        [(capi.ENTITY_DYNAMIC, (0.0, 0.5 + 1.0 * k, 0.0), (0, 0, 0, 1) if k % 2 == 0 else tuple(q_axis_angle((0, 1, 0), 1e-3)),
+          [(capi.AABB, (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5), {})], {}) for k in range(6)]
+        + [(capi.ENTITY_STATIC, (0, -2.0, 0), (0, 0, 0, 1), [(capi.AABB, (-20, -2, -20, 20, 2, 20), {"friction": 1.0})], {})]),
+    # capsules and cylinders lying parallel to each other and to box faces (the |dot| > 0.99 branches of capsule-capsule,
+    # capsule-box and cylinder-cylinder, collision_narrow.cpp:532, 623, 830)
+    "parallel capsules and cylinders": lambda: scene_from_parts(
+        [(capi.ENTITY_DYNAMIC, (0.0, 0.3 + 0.62 * k, 0.0), (0, 0, 0, 1), [(capi.CAPSULE if k % 2 == 0 else capi.CYLINDER, (-0.8, 0, 0, 0.8, 0, 0, 0.3), {})], {}) for k in range(5)]
+        + [(capi.ENTITY_DYNAMIC, (3.0, 0.3, 0.0), (0, 0, 0, 1), [(capi.CYLINDER, (0, -0.3, 0, 0, 0.3, 0, 0.5), {})], {}),
+           (capi.ENTITY_DYNAMIC, (3.0, 0.95, 0.0), (0, 0, 0, 1), [(capi.CYLINDER, (0, -0.3, 0, 0, 0.3, 0, 0.5), {})], {}),
+           (capi.ENTITY_STATIC, (0, -0.5, 0), (0, 0, 0, 1), [(capi.OBB, (0, 0, 0, 1, 0, 0, 0, 20, 0.5, 20), {"friction": 0.9})], {})]),
+    # a kinematic platform moving sideways under bodies, a compound body (three colliders of three types), a body without gravity,
+    # an undamped spinning body, a body made of one huge and one tiny collider
+    "kinematic, compound, odd parameters": lambda: scene_from_parts(
+        [(capi.ENTITY_KINEMATIC, (0, 0.0, 0), (0, 0, 0, 1), [(capi.AABB, (-4, -0.25, -4, 4, 0.25, 4), {"friction": 1.0})], {"linear_velocity": (0.8, 0.0, 0.0)}),
+         (capi.ENTITY_DYNAMIC, (0.0, 1.2, 0.0), tuple(q_axis_angle((0, 0, 1), 0.3)),
+          [(capi.SPHERE, (0.6, 0, 0, 0.35), {}), (capi.CAPSULE, (-0.6, -0.3, 0, -0.6, 0.3, 0, 0.2), {"density": 3.0}), (capi.OBB, (0, 0, 0, 1, 0, 0, 0, 0.5, 0.15, 0.3), {})], {}),
+         (capi.ENTITY_DYNAMIC, (2.0, 2.0, 0.5), (0, 0, 0, 1), [(capi.SPHERE, (0, 0, 0, 0.4), {})], {"gravity_factor": 0.0, "linear_velocity": (-1.0, -0.5, 0.0)}),
+         (capi.ENTITY_DYNAMIC, (-2.0, 0.8, -1.0), (0, 0, 0, 1), [(capi.AABB, (-0.3, -0.3, -0.3, 0.3, 0.3, 0.3), {"restitution": 0.9})],
+          {"linear_damping": 0.0, "angular_damping": 0.0, "angular_velocity": (0.0, 9.0, 3.0)}),
+         (capi.ENTITY_DYNAMIC, (1.0, 1.5, -2.0), (0, 0, 0, 1), [(capi.AABB, (-1.0, -0.2, -1.0, 1.0, 0.2, 1.0), {}), (capi.SPHERE, (0, 0.25, 0, 0.05), {"density": 50.0})], {}),
+         (capi.ENTITY_STATIC, (0, -3.0, 0), (0, 0, 0, 1), [(capi.AABB, (-30, -1, -30, 30, 1, 30), {})], {})]),
+    # nothing dynamic touches anything; then only static colliders; both must step without contacts
+    "free flight only": lambda: scene_from_parts(
+        [(capi.ENTITY_DYNAMIC, (3.0 * k, 50.0, 0), tuple(q_axis_angle((1, 0, 0), 0.2 * k)), [(k % 6 if k % 6 != capi.HULL else capi.SPHERE,
+          {0: (0, 0, 0, 0.5), 1: (0, -0.4, 0, 0, 0.4, 0, 0.2), 2: (0, -0.4, 0, 0, 0.4, 0, 0.3), 3: (-0.3, -0.4, -0.5, 0.3, 0.4, 0.5), 4: (0, 0, 0, 1, 0, 0, 0, 0.3, 0.4, 0.5), 5: (0, 0, 0, 0.5)}[k % 6], {})],
+          {"angular_velocity": (0.5 * k, 1.0, -0.3 * k)}) for k in range(7)]),
+}

@@ -45,12 +45,32 @@ class ShardedWorld:
         self.desc = _desc_for(desc, rank)
         world.shard_enable(self.desc)
         self.neighbours = world.shard_neighbours()
+        self.note = ""
         if transport == "rccl":
+            # the library's own transport; if it cannot come up on ANY rank (no librccl, communicator refused) every rank falls back to
+            # the caller's transport over the process group that is already there — slower (messages via host), same results
             import torch
-            ident = [world.L.shard_unique_id() if rank == 0 else None]
+            failed = 0
+            try:
+                ident = [world.L.shard_unique_id() if rank == 0 else None]
+            except Exception as e:      # noqa: BLE001
+                ident, failed, self.note = [None], 1, str(e)
             dist.broadcast_object_list(ident, src=0)
-            world.shard_attach_rccl(ident[0])
-            torch.cuda.synchronize()
+            if ident[0] is None:
+                failed = 1
+            else:
+                try:
+                    world.shard_attach_rccl(ident[0])
+                    torch.cuda.synchronize()
+                except Exception as e:  # noqa: BLE001
+                    failed, self.note = 1, str(e)
+            flag = torch.tensor([failed], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+            if int(flag.item()):
+                if not failed:
+                    world.shard_detach_rccl()
+                self.transport = "dist"
+                self.note = "library RCCL transport unavailable (" + (self.note or "on another rank") + "): neighbour messages go through torch.distributed"
 
     def step(self, settings, dt):
         """One internal step of this rank's tile; with the library transport the exchange is part of it."""
@@ -67,16 +87,17 @@ class ShardedWorld:
 
     def _exchange_dist(self):
         import torch
+        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"      # RCCL moves device memory only
         ops, inbox, keep = [], [], []
         for slot, peer in enumerate(self.neighbours):
-            out = torch.from_numpy(self.world.shard_export(slot)); keep.append(out)
-            buf = torch.zeros(out.numel(), dtype=torch.float32); inbox.append(buf)
+            out = torch.from_numpy(self.world.shard_export(slot)).to(dev); keep.append(out)
+            buf = torch.zeros(out.numel(), dtype=torch.float32, device=dev); inbox.append(buf)
             ops.append(self.dist.P2POp(self.dist.isend, out, peer)); ops.append(self.dist.P2POp(self.dist.irecv, buf, peer))
         if ops:
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
         for buf in inbox:
-            self.world.shard_import(buf.numpy())
+            self.world.shard_import(buf.cpu().numpy())
 
     def owned_states(self):
         ents = np.sort(self.world.shard_owned_entities())

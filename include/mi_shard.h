@@ -62,6 +62,8 @@ MI_API int mi_world_shard_owned_entities(mi_world* world, uint32_t* out_entities
 /* Library transport: RCCL.  out_id128 / id128: the 128 bytes of an ncclUniqueId. */
 MI_API int mi_shard_get_unique_id(void* out_id128);
 MI_API int mi_world_shard_attach_rccl(mi_world* world, const void* id128);
+/* Back to the caller's transport (destroys the communicator; e.g. when another rank could not attach). */
+MI_API int mi_world_shard_detach_rccl(mi_world* world);
 /* Caller's transport: after mi_world_step_fixed(world, ..., 1) copy the message for neighbour slot `slot` out (host memory,
  * mi_world_shard_message_bytes bytes) and hand the neighbours' messages in; both may be called in any order across slots. */
 MI_API int mi_world_shard_message_bytes(mi_world* world, uint64_t* out_bytes);

@@ -30,7 +30,7 @@ def _virtual_ranks(make_world, sc, num_ranks, tiles_z=1, margin=2.5):
     return [sharding.ShardedWorld(sc.populate(make_world()), desc, r, "local") for r in range(num_ranks)], desc
 
 
-def _worker(rank, world_size, port, out_dir, tiles_z, kind="pile"):
+def _worker(rank, world_size, port, out_dir, tiles_z, kind="pile", transport="dist"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     sys.path.insert(0, str(ROOT))
@@ -38,7 +38,8 @@ def _worker(rank, world_size, port, out_dir, tiles_z, kind="pile"):
     import oracle
     sc = _scene(kind)
     desc = sharding.tile_grid(sc, world_size, tiles_z, MARGIN[kind])
-    sw = sharding.ShardedWorld(sc.populate(oracle.create_world(oracle.ORDER_CANONICAL)), desc, rank, "dist", dist)
+    sw = sharding.ShardedWorld(sc.populate(oracle.create_world(oracle.ORDER_CANONICAL)), desc, rank, transport, dist)
+    assert sw.transport == "dist" and (transport == "dist" or "unavailable" in sw.note)
     s = sc.settings()
     owned_per_step = []
     for _ in range(STEPS):
@@ -50,12 +51,14 @@ def _worker(rank, world_size, port, out_dir, tiles_z, kind="pile"):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world_size,tiles_z,kind", [(2, 1, "pile"), (4, 2, "pile"), (2, 1, "ragdolls")], ids=["2 ranks, x slabs", "4 ranks, 2 x 2 tiles", "2 ranks, ragdolls"])
-def test_processes_over_gloo_equal_virtual_ranks_bit_for_bit(tmp_path, oracle_mod, world_size, tiles_z, kind):
+@pytest.mark.parametrize("world_size,tiles_z,kind,transport", [(2, 1, "pile", "dist"), (4, 2, "pile", "dist"), (2, 1, "ragdolls", "dist"), (2, 1, "pile", "rccl")],
+                         ids=["2 ranks, x slabs", "4 ranks, 2 x 2 tiles", "2 ranks, ragdolls", "2 ranks, library transport unavailable -> caller's transport"])
+def test_processes_over_gloo_equal_virtual_ranks_bit_for_bit(tmp_path, oracle_mod, world_size, tiles_z, kind, transport):
     """R processes exchanging the neighbour messages over gloo == R worlds of one process with the messages copied by hand:
-    the transport carries exactly what the library packed, nothing depends on timing or on who runs a tile."""
+    the transport carries exactly what the library packed, nothing depends on timing or on who runs a tile.  Last case: the ranks
+    ask for the library's own RCCL transport, which the CPU oracle does not have — all of them agree to fall back (sharding.py)."""
     port = 29500 + (os.getpid() % 2000) + world_size
-    mp.spawn(_worker, args=(world_size, port, str(tmp_path), tiles_z, kind), nprocs=world_size, join=True)
+    mp.spawn(_worker, args=(world_size, port, str(tmp_path), tiles_z, kind, transport), nprocs=world_size, join=True)
     sc = _scene(kind)
     ranks, _ = _virtual_ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), sc, world_size, tiles_z, MARGIN[kind])
     s = sc.settings()

@@ -108,6 +108,21 @@ def test_gpu_physics_step_accumulator(mi_lib, oracle_mod):
         assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
 
 
+@pytest.mark.parametrize("name", sorted(scenes.EDGE_CASES))
+def test_gpu_degenerate_scenes_match_oracle(mi_lib, oracle_mod, name):
+    """scenes.EDGE_CASES (exactly aligned faces, parallel capsule / cylinder branches, kinematic platform, compound bodies, odd body
+    parameters, a world without contacts): the same scenes tests/test_reference_pin.py steps through the reference itself."""
+    sc = scenes.EDGE_CASES[name]()
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    for i in range(180):
+        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        assert g.counts() == o.counts(), f"step {i}"
+        assert contact_set(g.contacts()) == contact_set(o.contacts()), f"step {i}"
+        pg, qg = g.physics_transforms(); po, qo = o.physics_transforms()
+        assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes(), f"step {i}"
+
+
 def test_gpu_edge_cases(mi_lib, oracle_mod):
     # empty world steps; bodies without colliders integrate and take external forces
     w = gpu_world(mi_lib)

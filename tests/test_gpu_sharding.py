@@ -93,4 +93,7 @@ def test_gpu_library_rccl_transport_comes_up(mi_lib):
     w.step_fixed(s, sc.dt, 30); plain.step_fixed(s, sc.dt, 30)       # with the library transport several internal steps per call are fine
     assert w.physics_transforms()[0].tobytes() == plain.physics_transforms()[0].tobytes()
     assert w.shard_counts()["owned_bodies"] == sc.num_bodies
+    w.shard_detach_rccl()                                             # back to the caller's transport (what a rank does when a peer could not attach)
+    w.step_fixed(s, sc.dt, 1); plain.step_fixed(s, sc.dt, 1)
+    assert w.physics_transforms()[0].tobytes() == plain.physics_transforms()[0].tobytes()
     w.close()
