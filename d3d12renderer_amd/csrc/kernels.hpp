@@ -73,7 +73,7 @@ struct StepScalars {  // device-resident per-step scalars
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
 // chip (one L2 channel), so thousands of workgroups adding to ONE word serialise a whole kernel behind it.
 constexpr uint32_t kShards = 16;
-struct ShardCounters { uint32_t numOverlaps; uint32_t bucketHist[24]; uint32_t pad[7]; };   // one 128-byte line per shard
+struct ShardCounters { uint32_t numOverlaps; uint32_t bucketHist[24]; uint32_t owned[3]; uint32_t pad[4]; };   // one 128-byte line per shard; owned: sharded world (bodies / manifolds / contacts of this rank)
 struct Shards { ShardCounters c[kShards]; uint32_t extentHist[kShards][256]; };
 
 __device__ __forceinline__ int orderedInt(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_axis_partials(uint32_t nc, const float4
         v[0] = cx; v[1] = cy; v[2] = cz;
         v[3] = (double)cx * (double)cx; v[4] = (double)cy * (double)cy; v[5] = (double)cz * (double)cz;
         ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
-        atomicAdd(&hist[extentBin(ext)], 1u);   // only steers the cell size, never results
+        if (!(mx.x < mn.x)) atomicAdd(&hist[extentBin(ext)], 1u);   // only steers the cell size, never results; dead colliders (sharded world) stay out: the histogram total = live colliders
     }
     for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
@@ -374,8 +374,9 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
         v[0] = cx; v[1] = cy; v[2] = cz;
         v[3] = (double)cx * (double)cx; v[4] = (double)cy * (double)cy; v[5] = (double)cz * (double)cz;
         const float ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
-        atomicAdd(&hist[extentBin(ext)], 1u);   // only steers the NEXT step's cell size
         dead = mx.x < mn.x;
+        if (!dead) atomicAdd(&hist[extentBin(ext)], 1u);   // only steers the NEXT step's cell size; its total = live colliders (k_pair_finish derives numDead from it:
+                                                            // a counter bumped once per wave of dead colliders cost 0.3 ms in an 8-tile world, ~90 same-address atomics per us)
         const bool large = ext > g.largeThreshold;
         isLarge[i] = dead ? 2u : large ? 1u : 0u;
         uint32_t key = 0xFFFFFFFFu, rank = 0;
@@ -390,7 +391,6 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
         }
         keys[i] = key; ranks[i] = rank;
     }
-    { const unsigned long long deadMask = __ballot(dead); if (deadMask && (threadIdx.x & 63u) == 0u) atomicAdd(&sc->numDead, (uint32_t)__popcll(deadMask)); }
     for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
         for (int c = 0; c < 6; ++c) v[c] += __shfl_down(v[c], off, 64);
@@ -514,17 +514,22 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
     __shared__ uint32_t waveTotals[4];
     __shared__ uint32_t blockBase;
     __shared__ uint32_t bhist[32];   // [0..20] bucket histogram, [31] overlaps
-    if (threadIdx.x < 32) bhist[threadIdx.x] = 0;
-    if (threadIdx.x == 32) ovfCount = 0;
-    __syncthreads();
     const uint32_t col = blockIdx.x / blocksPerColumn;
     // blocksPerColumn is a multiple of 8: the workgroups of one XCD (blockIdx % 8, a speed assumption only) walk ONE contiguous
     // eighth of the cell-sorted colliders instead of every eighth block of all of them, so the AABB rows they share stay in that XCD's L2
     const uint32_t inCol = blockIdx.x % blocksPerColumn;
-    const uint32_t base = ((inCol & 7u) * (blocksPerColumn >> 3) + (inCol >> 3)) * (kGridChunks * 256u);
     const uint32_t dy = gp->dims[1], dz = gp->dims[2], dx = gp->dims[0];
     const uint32_t axis = sc->axisCur;
-    const uint32_t numSmall = nc - sc->numLarge - sc->numDead;   // this step's own counts (the grid record may be the one computed a step earlier)
+    const uint32_t numSmall = cellLower[gp->numCells];   // total of the cell histogram = this step's small colliders = the filled part of the sorted arrays
+    // The host sizes the launch for the small colliders it EXPECTS (previous step's count + slack; a sharded world holds mostly dead
+    // colliders, and an idle workgroup still costs its dispatch slot: 0.27 ms in an 8-tile world); if there are more, the workgroups go round again.
+    const uint32_t perRound = blocksPerColumn * (kGridChunks * 256u);
+    for (uint32_t roundBase = 0; roundBase < numSmall; roundBase += perRound) {
+    if (roundBase) __syncthreads();
+    if (threadIdx.x < 32) bhist[threadIdx.x] = 0;
+    if (threadIdx.x == 32) ovfCount = 0;
+    __syncthreads();
+    const uint32_t base = roundBase + ((inCol & 7u) * (blocksPerColumn >> 3) + (inCol >> 3)) * (kGridChunks * 256u);
     uint32_t overlaps = 0, nh[kGridChunks];
     uint32_t runBucket = 0, runCount = 0;   // this lane's hits go to the bucket histogram in runs (a pile: one bucket -> one LDS atomic per lane, not per hit)
 #pragma unroll
@@ -601,12 +606,15 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
     ShardCounters* shard = &sh->c[blockIdx.x & (kShards - 1u)];
     if (threadIdx.x < kNumBuckets && bhist[threadIdx.x]) atomicAdd(&shard->bucketHist[threadIdx.x], bhist[threadIdx.x]);
     if (threadIdx.x == 31 && bhist[31]) atomicAdd(&shard->numOverlaps, bhist[31]);
+    }
 }
 
 // Large colliders against everything: (large l) x (all colliders), grid-strided.  Large-large pairs
 // are emitted once (from the lower index).
-__global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint32_t* __restrict__ largeList, const uint32_t* __restrict__ isLarge,
+__global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint32_t* __restrict__ largeList,
                                                         const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                        const uint32_t* __restrict__ vals, const float4* __restrict__ sMin, const float4* __restrict__ sMax,
+                                                        const uint32_t* __restrict__ cellLower, const GridParams* __restrict__ gp,
                                                         uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc, Shards* sh, InterSink inter) {
     // hits are staged like in k_bp_pairs_grid (kLargeBuf slots per lane, then a block-shared overflow area, then — rare — a direct append)
     // and flushed with ONE returning atomic per workgroup: the ground of a settled pile touches tens of thousands of boxes, and a
@@ -621,15 +629,20 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
     __syncthreads();
     uint32_t nl = sc->numLarge;
     uint32_t axis = sc->axisCur;
+    const uint32_t numSmall = cellLower[gp->numCells];
     uint32_t overlaps = 0, nhit = 0, runBucket = 0, runCount = 0;
     uint64_t* mybuf = buf + threadIdx.x * kLargeBuf;
     // blockIdx.y = large collider slot (grid-strided), x-dimension strides over all colliders: coalesced AABB reads
     for (uint32_t l = blockIdx.y; l < nl; l += gridDim.y) {
         uint32_t i = largeList[l];
         float4 amn = aabbMin[i], amx = aabbMax[i];
-        for (uint32_t j = blockIdx.x * blockDim.x + threadIdx.x; j < nc; j += gridDim.x * blockDim.x) {
-            bool ok = (i != j) && !(isLarge[j] && j < i);
-            float4 bmn = aabbMin[j], bmx = aabbMax[j];
+        // candidates: the cell-sorted small colliders [0, numSmall) (contiguous rows) and then the large list itself — not all nc colliders:
+        // the dead ones of a sharded world (most of them, in a many-tile scene) are in neither
+        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < numSmall + nl; q += gridDim.x * blockDim.x) {
+            const bool small = q < numSmall;
+            const uint32_t j = small ? vals[q] : largeList[q - numSmall];
+            bool ok = small || j > i;          // large-large pairs once, from the lower index
+            float4 bmn = small ? sMin[q] : aabbMin[j], bmx = small ? sMax[q] : aabbMax[j];
             bool ov = ok && aabbOverlap(amn, amx, bmn, bmx);
             uint64_t pk = 0;
             bool want = ov && pairKey(i, amn, amx, j, bmn, bmx, axis, pk, inter);
@@ -739,7 +752,10 @@ __global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ 
         __syncthreads();
         for (uint32_t w = wv + 1; w < 4; ++w) suf += wsum[w];
         {
-            const uint32_t live = nc - sc->numDead;
+            __shared__ uint32_t liveShared;
+            if (t == 0) { liveShared = suf; sc->numDead = nc - suf; }   // histogram total = live colliders (dead ones of a sharded world are not in it)
+            __syncthreads();
+            const uint32_t live = liveShared;
             uint32_t limit = max(16u, live / 16384u);
             const uint32_t costCap = (uint32_t)(67108864ull / (uint64_t)max(live, 1u));
             limit = max(8u, min(limit, costCap));
@@ -1181,9 +1197,17 @@ __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float
                                                               unsigned long long* __restrict__ bodyUsed, unsigned long long* __restrict__ bodyTop,
                                                               const uint8_t* __restrict__ bodyActive /* sharded world (1 = owned), or null */, const float4* __restrict__ bPosIn,
                                                               const float4* __restrict__ bLinVelIn, const float4* __restrict__ bAngVelIn, const float4* __restrict__ bForceIn,
-                                                              const float4* __restrict__ bTorqueIn) {
+                                                              const float4* __restrict__ bTorqueIn,
+                                                              const uint8_t* __restrict__ bodyActivePrev /* the previous step's flags */, const Shards* __restrict__ sh, StepScalars* sc) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (bodyActive && blockIdx.x == 0 && threadIdx.x < 3) {   // sharded world: this rank's owned bodies / manifolds / contacts, from the per-line counters
+        uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].owned[threadIdx.x];
+        sc->shardOwned[threadIdx.x] = v;
+    }
     if (i > nb) return;
+    // a body this rank neither simulates now nor simulated in the previous step: nothing of it was touched, both state sets already agree
+    const bool idle = bodyActive && i < nb && bodyActive[i] == 0u && bodyActivePrev[i] == 0u;
+    if (idle) return;
     // the per-body colouring scratch of the NEXT step starts out cleared (saves two memset launches per step); launched over nb + 1
     bodyUsed[i] = 0ull; bodyTop[i] = 0ull; bodyTop[(size_t)nb + 1u + i] = 0ull;
     if (i == nb) return;
@@ -2307,7 +2331,7 @@ __device__ __forceinline__ V3 shardCog(float4 pos, float4 rot, float4 cogInvMass
 
 // start of a step: 1 = owned, 2 = ghost, 0 = not simulated here
 __global__ __launch_bounds__(256) void k_shard_classify(uint32_t nb, ShardParams sp, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
-                                                        const float4* __restrict__ bCogInvMass, uint8_t* __restrict__ bodyActive, StepScalars* sc,
+                                                        const float4* __restrict__ bCogInvMass, uint8_t* __restrict__ bodyActive, Shards* sh,
                                                         const uint32_t* __restrict__ root /* lowest body index of the body's articulated island: the island is classified as ONE */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool owned = false;
@@ -2317,13 +2341,22 @@ __global__ __launch_bounds__(256) void k_shard_classify(uint32_t nb, ShardParams
         owned = shardTileOf(sp, c.x, c.z) == sp.myTile;
         bodyActive[i] = owned ? 1u : shardInExtended(sp, sp.myTile, c.x, c.z) ? 2u : 0u;
     }
+    // counted per workgroup into one of kShards lines (summed by k_integrate_velocities): a same-address atomic per wave was 45 us of a 2 M-body scene
+    __shared__ uint32_t cnt;
+    if (threadIdx.x == 0) cnt = 0;
+    __syncthreads();
     const unsigned long long m = __ballot(owned);
-    if (m && (threadIdx.x & 63u) == 0u) atomicAdd(&sc->shardOwned[0], (uint32_t)__popcll(m));
+    if (m && (threadIdx.x & 63u) == 0u) atomicAdd(&cnt, (uint32_t)__popcll(m));
+    __syncthreads();
+    if (threadIdx.x == 0 && cnt) atomicAdd(&sh->c[blockIdx.x & (kShards - 1u)].owned[0], cnt);
 }
 // owner rule for the counts: a manifold belongs to the rank that owns its first dynamic body (A unless A has no inverse mass / is the static dummy)
 __global__ __launch_bounds__(256) void k_shard_count(uint32_t nb, const uint2* __restrict__ manBodies, const uint2* __restrict__ manInfo,
-                                                     const float4* __restrict__ bCogInvMass, const uint8_t* __restrict__ bodyActive, StepScalars* sc) {
+                                                     const float4* __restrict__ bCogInvMass, const uint8_t* __restrict__ bodyActive, const StepScalars* __restrict__ sc, Shards* sh) {
     const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t cnt[2];
+    if (threadIdx.x < 2) cnt[threadIdx.x] = 0;
+    __syncthreads();
     uint32_t mine = 0, contacts = 0;
     if (m < sc->numManifolds) {
         const uint2 b = manBodies[m];
@@ -2331,7 +2364,9 @@ __global__ __launch_bounds__(256) void k_shard_count(uint32_t nb, const uint2* _
         if (first < nb && bodyActive[first] == 1u) { mine = 1u; contacts = manInfo[m].x & 7u; }
     }
     for (int off = 32; off >= 1; off >>= 1) { mine += __shfl_xor(mine, off, 64); contacts += __shfl_xor(contacts, off, 64); }
-    if ((threadIdx.x & 63u) == 0u && mine) { atomicAdd(&sc->shardOwned[1], mine); atomicAdd(&sc->shardOwned[2], contacts); }
+    if ((threadIdx.x & 63u) == 0u && mine) { atomicAdd(&cnt[0], mine); atomicAdd(&cnt[1], contacts); }
+    __syncthreads();
+    if (threadIdx.x < 2 && cnt[threadIdx.x]) atomicAdd(&sh->c[blockIdx.x & (kShards - 1u)].owned[1 + threadIdx.x], cnt[threadIdx.x]);   // (was: two same-address atomics per wave, 0.14 ms)
 }
 // after a valid step (body buffers already swapped: bPos = new state, bPosOld = state the step started from): the records this rank
 // owes neighbour `slot` — every body it OWNED this step whose old or new centre of gravity lies in that neighbour's extended tile

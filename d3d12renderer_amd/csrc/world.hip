@@ -113,7 +113,8 @@ struct mi_world {
         bool enabled = false, rccl = false;
         mi_shard_desc desc{}; ShardParams sp{};
         uint32_t capacity = 0; std::vector<uint32_t> peerRanks;
-        DBuf<uint8_t> active; DBuf<float> sendBuf[8], recvBuf[8]; DBuf<uint32_t> sent;
+        DBuf<uint8_t> active, activePrev; bool prevValid = false, flagsSwapPending = false;   // activePrev: the previous valid step's flags (k_integrate_velocities skips bodies idle in both)
+        DBuf<float> sendBuf[8], recvBuf[8]; DBuf<uint32_t> sent;
         DBuf<uint32_t> root; size_t rootJoints = ~size_t(0), rootBodies = 0;   // island root of every body (union-find over the joints), rebuilt when the scene changes
         uint32_t* sentHost = nullptr;            // pinned: the records packed per slot in the previous exchange (overflow check)
         bool sentPending = false;
@@ -228,7 +229,7 @@ struct mi_world {
     int runStep(const mi_step_settings& s, float dt, bool speculative);
     void mirrorSchedule();
     // speculative (single read-back) stepping: upper bounds come from the last valid step
-    struct LastCounts { uint32_t numPairs = 0, numManifolds = 0, numContacts = 0, numCells = 0, colorRounds = 0; } last;
+    struct LastCounts { uint32_t numPairs = 0, numManifolds = 0, numContacts = 0, numCells = 0, colorRounds = 0, numSmall = 0; } last;
     bool specEnabled = true, haveEstimates = false;
     uint32_t specRetries = 0, specSteps = 0, totalSteps = 0, colorRoundsLaunched = 0;
     uint32_t sapAxis = 0;        // sorting axis for the next step (collision_broad.cpp:443-444), host copy
@@ -430,6 +431,7 @@ static float4 h4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 
 int mi_world::upload() {
     recalcProperties();
+    shard.prevValid = false; shard.flagsSwapPending = false;
     uint32_t nb = (uint32_t)bodies.size(), nc = (uint32_t)colliders.size();
     std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), fo(nb), to(nb), cim(nb), ii(3 * (size_t)nb), prm(nb);
     for (uint32_t i = 0; i < nb; ++i) {
@@ -617,10 +619,11 @@ __global__ __launch_bounds__(256) void k_publish_readback(const uint32_t* __rest
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(dstHost + seqWord, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-__global__ void k_reset_pair_counters(StepScalars* sc) {
+__global__ void k_reset_pair_counters(StepScalars* sc, Shards* sh) {
     uint32_t t = threadIdx.x;
     if (t == 0) { sc->numPairs = 0; sc->numOverlaps = 0; sc->numInterPairs = 0; }
     if (t < 24) sc->bucketHist[t] = 0;
+    for (uint32_t k = 0; k < kShards; ++k) { if (t == 0) sh->c[k].numOverlaps = 0; if (t < 24) sh->c[k].bucketHist[t] = 0; }   // the pair pass's counters only (owned[] of a sharded world stays)
 }
 
 // One internal step.  Two ways to run it:
@@ -779,7 +782,12 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     mark();  // 0
     if (attached) hipExtLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(128), 0, st, ev[0], nullptr, 0, sc, shards.p, roundFlagsPtr(), keyCount.p);
     else k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlagsPtr(), keyCount.p);
-    if (shard.enabled && nb) k_shard_classify<<<divUp(nb, B), B, 0, st>>>(nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, sc, shard.root.p);
+    if (shard.enabled && nb) {
+        HIP_TRY(shard.activePrev.ensure(std::max(nb, 1u)));
+        if (shard.flagsSwapPending) { std::swap(shard.active.p, shard.activePrev.p); std::swap(shard.active.cap, shard.activePrev.cap); shard.flagsSwapPending = false; }   // (not on the synchronous re-run of a step)
+        if (!shard.prevValid) { HIP_TRY(hipMemsetAsync(shard.activePrev.p, 1, nb, st)); shard.prevValid = true; }   // after an upload / an outside write: every body is copied once
+        k_shard_classify<<<divUp(nb, B), B, 0, st>>>(nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, shards.p, shard.root.p);
+    }
     if (nc) {
         k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis, shard.enabled ? shard.active.p : nullptr);
@@ -818,9 +826,11 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         for (int attempt = 0; attempt < 3; ++attempt) {
             uint32_t cap = (uint32_t)std::min<size_t>(pairKeys.cap, 0x7FFFFFFFu);
             const InterSink inter{usesInteractions ? interKeys.p : nullptr, (uint32_t)interKeys.cap, &sc->numInterPairs};
-            const uint32_t bpc = (divUp(nc, kGridChunks * 256u) + 7u) & ~7u;   // a multiple of 8 (XCD-contiguous block order in k_bp_pairs_grid)
+            // sized for the small (grid) colliders expected — in a sharded world most colliders are dead and in no list; more than expected: the workgroups loop
+            const uint32_t smallBound = spec ? std::min(nc, bound(last.numSmall, 4096)) : nc;
+            const uint32_t bpc = (divUp(smallBound, kGridChunks * 256u) + 7u) & ~7u;   // a multiple of 8 (XCD-contiguous block order in k_bp_pairs_grid)
             k_bp_pairs_grid<<<5u * bpc, B, 0, st>>>(nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
-            k_bp_pairs_large<<<dim3(std::min(divUp(nc, B), 256u), 16), B, 0, st>>>(nc, largeList.p, isLarge.p, aabbMin.p, aabbMax.p, pairKeys.p, cap, sc, shards.p, inter);
+            k_bp_pairs_large<<<dim3(std::min(divUp(smallBound, B), 256u), 16), B, 0, st>>>(nc, largeList.p, aabbMin.p, aabbMax.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
             k_pair_finish<<<1, 256, 0, st>>>(shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu, nc, nblk, attempt == 0 ? axisPartials.p : nullptr, blockBounds.p, attempt == 0 ? gridNext : nullptr, cellCapNext);
             if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
             int rc = readScalars(); if (rc != MI_OK) return rc;
@@ -829,8 +839,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             if (attempt == 2) return fail(MI_ERR_DEVICE, "pair pass did not settle");
             if (pairBound > cap) HIP_TRY(pairKeys.ensure((size_t)pairBound + pairBound / 4));   // overflow: grow and redo the pair pass
             if (hs.numInterPairs > interKeys.cap) HIP_TRY(interKeys.ensure((size_t)hs.numInterPairs + hs.numInterPairs / 4));
-            k_reset_pair_counters<<<1, 32, 0, st>>>(sc);
-            HIP_TRY(hipMemsetAsync(shards.p, 0, sizeof(ShardCounters) * kShards, st));
+            k_reset_pair_counters<<<1, 32, 0, st>>>(sc, shards.p);
         }
     }
     mark();  // 2
@@ -871,7 +880,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                                                         tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc,
                                                         heightmap ? make_float2(hmParams.restitution, hmParams.friction) : make_float2(0.f, 0.f),
                                                         tabKeys[tabCur ^ 1].p, tabVals[tabCur ^ 1].p, tabMask[tabCur ^ 1], manKept.p);
-        if (shard.enabled) k_shard_count<<<divUp(pairBound, B), B, 0, st>>>(nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc);
+        if (shard.enabled) k_shard_count<<<divUp(pairBound, B), B, 0, st>>>(nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc, shards.p);
     }
     // ---------------------------------------------------------------------------------------------- triggers / force fields
     std::vector<mi_event> triggerEvents;
@@ -1086,10 +1095,10 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     if (attached && !solveAttached) (void)hipEventRecord(ev[7], st);
     if (attached) hipExtLaunchKernelGGL(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nullptr, ev[8], 0, nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
                                       gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p,
-                                      shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p);
+                                      shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p, shard.activePrev.p, shards.p, sc);
     else k_integrate_velocities<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
                                                       gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p,
-                                                      shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p);
+                                                      shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p, shard.activePrev.p, shards.p, sc);
     mark();  // 8
     // ---------------------------------------------------------------------------------------------- end of step: the one read-back
     if (spinReadback) {
@@ -1201,7 +1210,9 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     if (nmBound) { tabCur ^= 1; tabValid = true; } else tabValid = false;
     hostStale = true;
     last.numPairs = hs.numPairs; last.numManifolds = hs.numManifolds; last.numContacts = hs.numContacts; last.numCells = hs.numCells;
+    last.numSmall = nc - std::min(nc, hs.numLarge + hs.numDead);
     for (int k = 0; k < 3; ++k) shard.owned[k] = hs.shardOwned[k];
+    shard.flagsSwapPending = shard.enabled;
     static const bool xcdStats = std::getenv("MI_XCD_STATS") != nullptr;   // development: how many bodies stayed XCD-local
     if (xcdStats && usedXcd && ((totalSteps % 50u) == 0u || std::getenv("MI_XCD_NOSORT"))) {
         std::vector<unsigned long long> own(nb);
@@ -1870,6 +1881,7 @@ MI_API int mi_entities_apply_forces(mi_world* w, uint32_t count, const uint32_t*
     HIP_TRY(hipMemcpyAsync(dIds.p, ids.data(), count * sizeof(uint32_t), hipMemcpyHostToDevice, w->stream));
     HIP_TRY(hipMemcpyAsync(dFt.p, ft.data(), ft.size() * sizeof(float), hipMemcpyHostToDevice, w->stream));
     k_add_forces<<<1, 1, 0, w->stream>>>(count, dIds.p, dFt.p, w->bForce.p, w->bTorque.p);
+    w->shard.prevValid = false;
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->hostStale = true;
     return MI_OK;
@@ -2471,7 +2483,7 @@ static int statesDevice(mi_world* w, uint32_t n, const uint32_t* idsDev, float* 
     if (!w || (n && (!idsDev || (!outDev && !inDev)))) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     int rc = ensureUploaded(w); if (rc != MI_OK) return rc;
     if (n && outDev) k_gather_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p, outDev);
-    if (n && inDev) { k_scatter_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, inDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p); w->hostStale = true; }
+    if (n && inDev) { k_scatter_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, inDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p); w->hostStale = true; w->shard.prevValid = false; }
     if (sync) HIP_TRY(hipStreamSynchronize(w->stream));
     return MI_OK;
 }
