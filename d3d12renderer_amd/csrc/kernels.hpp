@@ -107,12 +107,14 @@ __global__ __launch_bounds__(256) void k_world_colliders(
     const float4* __restrict__ bPos, const float4* __restrict__ bRot,
     const float4* __restrict__ hullAabb,  // [2*numHulls]
     float4* __restrict__ wShape, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax, StepScalars* sc, uint32_t axisCur,
-    const uint8_t* __restrict__ bodyActive /* sharded world: 0 = body not simulated by this rank this step, or null */) {
+    const uint8_t* __restrict__ bodyActive /* sharded world: 0 = body not simulated by this rank this step, or null */,
+    const uint8_t* __restrict__ bodyActivePrev /* ... and in the previous step */) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k == 0) { sc->axisCur = axisCur; }   // the SAP axis chosen at the end of the previous (successful) step
     if (k >= nc) return;
     uint32_t type = cTypeBody[2 * k], body = cTypeBody[2 * k + 1];
     if (bodyActive && body != kNoBody && !bodyActive[body]) {
+        if (!bodyActivePrev[body]) return;   // dead before as well: its rows already hold what follows (most colliders of a many-tile scene, every step)
         // a DEAD collider: inverted box (overlaps nothing, centre exactly 0 so the axis statistics are unaffected), skipped by the grid
         wShape[3 * k] = make_float4(0, 0, 0, 0); wShape[3 * k + 1] = make_float4(0, 0, 0, 0); wShape[3 * k + 2] = make_float4(0, 0, 0, 1);
         aabbMin[k] = make_float4(kDeadBox, kDeadBox, kDeadBox, __uint_as_float(type | (OBJ_RIGID_BODY << 8)));
@@ -357,7 +359,8 @@ __global__ __launch_bounds__(256) void k_bp_cell_ids(uint32_t nc, const float4* 
 // dead / large / small classification, bounds of the small centres, cell id + arrival rank.
 __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax, const GridParams* __restrict__ gp,
                                                     double* __restrict__ partials, Shards* sh, StepScalars* sc, uint32_t* __restrict__ largeList, uint32_t* __restrict__ isLarge,
-                                                    int* __restrict__ blockBounds, uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks, uint32_t* __restrict__ cellCount) {
+                                                    int* __restrict__ blockBounds, uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks, uint32_t* __restrict__ cellCount,
+                                                    const uint8_t* __restrict__ bodyActivePrev /* sharded world: the previous step's body flags, or null */) {
     __shared__ double sm[4][6];
     __shared__ uint32_t hist[256];
     __shared__ int sb[4][6];
@@ -378,7 +381,9 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
         if (!dead) atomicAdd(&hist[extentBin(ext)], 1u);   // only steers the NEXT step's cell size; its total = live colliders (k_pair_finish derives numDead from it:
                                                             // a counter bumped once per wave of dead colliders cost 0.3 ms in an 8-tile world, ~90 same-address atomics per us)
         const bool large = ext > g.largeThreshold;
-        isLarge[i] = dead ? 2u : large ? 1u : 0u;
+        // a collider that was dead in the previous step too already has (2, 0xFFFFFFFF, 0) in these rows
+        const bool stale = dead && bodyActivePrev && !bodyActivePrev[__float_as_uint(mx.w)];
+        if (!stale) isLarge[i] = dead ? 2u : large ? 1u : 0u;
         uint32_t key = 0xFFFFFFFFu, rank = 0;
         if (dead) {}
         else if (large) { uint32_t slot = atomicAdd(&sc->numLarge, 1u); largeList[slot] = i; }
@@ -389,7 +394,7 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
             key = (ix * g.dims[1] + iy) * g.dims[2] + iz;
             rank = atomicAdd(&cellCount[key], 1u);
         }
-        keys[i] = key; ranks[i] = rank;
+        if (!stale) { keys[i] = key; ranks[i] = rank; }
     }
     for (int off = 32; off >= 1; off >>= 1) {
 #pragma unroll
@@ -2372,40 +2377,50 @@ __global__ __launch_bounds__(256) void k_shard_count(uint32_t nb, const uint2* _
 // owes neighbour `slot` — every body it OWNED this step whose old or new centre of gravity lies in that neighbour's extended tile
 // (old: so that the neighbour learns the body has left).  Record = (body index, 13 floats); record 0 of the buffer = (count, ...).
 constexpr uint32_t kShardRecordFloats = 14;
-__global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp, uint32_t slot, const uint8_t* __restrict__ bodyActive,
+struct ShardBufs { float* p[8]; };   // one message buffer per neighbour slot
+// one launch for all neighbours (the record counts start at zero: k_reset_scalars)
+__global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp, const uint8_t* __restrict__ bodyActive,
                                                     const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bLinVel,
                                                     const float4* __restrict__ bAngVel, const float4* __restrict__ bPosOld, const float4* __restrict__ bRotOld,
-                                                    const float4* __restrict__ bCogInvMass, float* __restrict__ out, uint32_t capacity, StepScalars* sc,
+                                                    const float4* __restrict__ bCogInvMass, ShardBufs out, uint32_t capacity, StepScalars* sc,
                                                     const uint32_t* __restrict__ root) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool want = false;
-    if (i < nb && bodyActive[i] == 1u) {
+    const bool owned = i < nb && bodyActive[i] == 1u;
+    if (!__ballot(owned)) return;
+    V3 cn(0.f, 0.f, 0.f), co(0.f, 0.f, 0.f);
+    float4 p = make_float4(0, 0, 0, 0), q = p, v = p, w = p;
+    if (owned) {
         const uint32_t r = root[i];
         const float4 cm = bCogInvMass[r];
-        const V3 cn = shardCog(bPos[r], bRot[r], cm), co = shardCog(bPosOld[r], bRotOld[r], cm);
-        want = shardInExtended(sp, sp.peers[slot], cn.x, cn.z) || shardInExtended(sp, sp.peers[slot], co.x, co.z);
+        cn = shardCog(bPos[r], bRot[r], cm); co = shardCog(bPosOld[r], bRotOld[r], cm);
+        p = bPos[i]; q = bRot[i]; v = bLinVel[i]; w = bAngVel[i];
     }
-    const unsigned long long mask = __ballot(want);
-    if (!mask) return;
-    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)mask) - 1u;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(&sc->shardSent[slot], (uint32_t)__popcll(mask));
-    base = (uint32_t)__shfl((int)base, (int)leader, 64);
-    if (!want) return;
-    const uint32_t r = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
-    if (r >= capacity) return;                                   // the count still grows: the host sees the overflow
-    float* o = out + (size_t)(r + 1u) * kShardRecordFloats;
-    const float4 p = bPos[i], q = bRot[i], v = bLinVel[i], w = bAngVel[i];
-    o[0] = __uint_as_float(i); o[1] = p.x; o[2] = p.y; o[3] = p.z; o[4] = q.x; o[5] = q.y; o[6] = q.z; o[7] = q.w;
-    o[8] = v.x; o[9] = v.y; o[10] = v.z; o[11] = w.x; o[12] = w.y; o[13] = w.z;
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t slot = 0; slot < sp.numPeers; ++slot) {
+        const bool want = owned && (shardInExtended(sp, sp.peers[slot], cn.x, cn.z) || shardInExtended(sp, sp.peers[slot], co.x, co.z));
+        const unsigned long long mask = __ballot(want);
+        if (!mask) continue;
+        const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&sc->shardSent[slot], (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, (int)leader, 64);
+        if (!want) continue;
+        const uint32_t r = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (r >= capacity) continue;                                 // the count still grows: the host sees the overflow
+        float* o = out.p[slot] + (size_t)(r + 1u) * kShardRecordFloats;
+        o[0] = __uint_as_float(i); o[1] = p.x; o[2] = p.y; o[3] = p.z; o[4] = q.x; o[5] = q.y; o[6] = q.z; o[7] = q.w;
+        o[8] = v.x; o[9] = v.y; o[10] = v.z; o[11] = w.x; o[12] = w.y; o[13] = w.z;
+    }
 }
-__global__ void k_shard_pack_header(uint32_t slot, const StepScalars* __restrict__ sc, float* __restrict__ out) { out[0] = __uint_as_float(sc->shardSent[slot]); }
-__global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, const float* __restrict__ in, uint32_t capacity, float4* __restrict__ bPos, float4* __restrict__ bRot,
+__global__ void k_shard_pack_headers(uint32_t numPeers, const StepScalars* __restrict__ sc, ShardBufs out) { if (threadIdx.x < numPeers) out.p[threadIdx.x][0] = __uint_as_float(sc->shardSent[threadIdx.x]); }
+// blockIdx.y = neighbour slot (a body has one owner: the messages never touch the same body)
+__global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, ShardBufs in, uint32_t capacity, float4* __restrict__ bPos, float4* __restrict__ bRot,
                                                       float4* __restrict__ bLinVel, float4* __restrict__ bAngVel) {
-    const uint32_t count = min(__float_as_uint(in[0]), capacity);
+    const float* msg = in.p[blockIdx.y];
+    const uint32_t count = min(__float_as_uint(msg[0]), capacity);
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= count) return;
-    const float* s = in + (size_t)(r + 1u) * kShardRecordFloats;
+    const float* s = msg + (size_t)(r + 1u) * kShardRecordFloats;
     const uint32_t b = __float_as_uint(s[0]);
     if (b >= nb) return;
     bPos[b] = make_float4(s[1], s[2], s[3], 0.f); bRot[b] = make_float4(s[4], s[5], s[6], s[7]);

@@ -113,7 +113,7 @@ struct mi_world {
         bool enabled = false, rccl = false;
         mi_shard_desc desc{}; ShardParams sp{};
         uint32_t capacity = 0; std::vector<uint32_t> peerRanks;
-        DBuf<uint8_t> active, activePrev; bool prevValid = false, flagsSwapPending = false;   // activePrev: the previous valid step's flags (k_integrate_velocities skips bodies idle in both)
+        DBuf<uint8_t> active, activePrev; bool prevValid = false, flagsSwapPending = false, stepOpen = false;   // activePrev: the previous valid step's flags (k_integrate_velocities skips bodies idle in both)
         DBuf<float> sendBuf[8], recvBuf[8]; DBuf<uint32_t> sent;
         DBuf<uint32_t> root; size_t rootJoints = ~size_t(0), rootBodies = 0;   // island root of every body (union-find over the joints), rebuilt when the scene changes
         uint32_t* sentHost = nullptr;            // pinned: the records packed per slot in the previous exchange (overflow check)
@@ -602,6 +602,7 @@ __global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlag
     for (uint32_t i = t; i < kMaxColorRounds + 2u; i += blockDim.x) roundFlags[i] = 0u;
     if (t == 0) {
         sc->numDead = 0; sc->shardOwned[0] = sc->shardOwned[1] = sc->shardOwned[2] = 0;
+        for (int q = 0; q < 8; ++q) sc->shardSent[q] = 0;
         sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->solveError = 0;
         sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0; sc->numEvents = 0; sc->numInterPairs = 0; sc->numInteractions = 0; sc->numHmContacts = 0; sc->numHmColliders = 0;
         for (int q = 0; q < 16; ++q) sc->boxHitCount[q] = 0;
@@ -640,6 +641,8 @@ enum { STEP_RETRY = 1 };
 int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     HIP_TRY(hipSetDevice(device));
     if (topologyDirty) { int rc = download(); if (rc != MI_OK) return rc; rc = upload(); if (rc != MI_OK) return rc; haveEstimates = false; }
+    if (shard.stepOpen) shard.prevValid = false;   // the previous step ended in an error: what its kernels left behind is not what the flags describe
+    shard.stepOpen = true;
     else if (joints.podsDirty()) { int rc = joints.uploadPods(stream); if (rc != MI_OK) return rc; HIP_TRY(hipStreamSynchronize(stream)); }
     if (bodies.empty()) return cloths.empty() ? MI_OK : stepCloths(dt);   // physics.cpp:1184-1189: cloth alone still steps
     const bool spec = specEnabled && haveEstimates && flowSolver && !launchFallbackSteps && !usesInteractions;   // interactions are read back mid-step
@@ -790,7 +793,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     }
     if (nc) {
         k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
-                                                     wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis, shard.enabled ? shard.active.p : nullptr);
+                                                     wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis, shard.enabled ? shard.active.p : nullptr, shard.activePrev.p);
         if (heightmap) {   // terrain contacts per collider, their offsets and totals (they join the pair list after the collider-pair narrow phase)
             k_hm_contacts<false><<<divUp(nc, 4), 256, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
             k_hm_slow<false><<<divUp(nc, 64), 64, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
@@ -810,7 +813,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         if (gridValid) {
             // the grid prepared at the end of the previous step (k_pair_finish): one fused kernel instead of five launches; the cell histogram
             // is all zero here (cleared once at upload, and every scan clears the cells it has read)
-            k_bp_prepare<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, gridUse, axisPartials.p, shards.p, sc, largeList.p, isLarge.p, blockBounds.p, cellKeys.p, cellRanks.p, cellCount.p);
+            k_bp_prepare<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, gridUse, axisPartials.p, shards.p, sc, largeList.p, isLarge.p, blockBounds.p, cellKeys.p, cellRanks.p, cellCount.p, shard.enabled ? shard.activePrev.p : nullptr);
         } else {
             k_axis_partials<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, axisPartials.p, shards.p);
             k_bp_threshold<<<1, 256, 0, st>>>(nc, shards.p, sc);
@@ -1212,7 +1215,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     last.numPairs = hs.numPairs; last.numManifolds = hs.numManifolds; last.numContacts = hs.numContacts; last.numCells = hs.numCells;
     last.numSmall = nc - std::min(nc, hs.numLarge + hs.numDead);
     for (int k = 0; k < 3; ++k) shard.owned[k] = hs.shardOwned[k];
-    shard.flagsSwapPending = shard.enabled;
+    shard.flagsSwapPending = shard.enabled; shard.stepOpen = false;
     static const bool xcdStats = std::getenv("MI_XCD_STATS") != nullptr;   // development: how many bodies stayed XCD-local
     if (xcdStats && usedXcd && ((totalSteps % 50u) == 0u || std::getenv("MI_XCD_NOSORT"))) {
         std::vector<unsigned long long> own(nb);
@@ -2034,14 +2037,12 @@ int mi_world::shardExchange() {
         for (uint32_t k = 0; k < sh.sp.numPeers; ++k) if (sh.sentHost[k] > sh.capacity) return fail(MI_ERR_CAPACITY, "shard message overflow: raise mi_shard_desc::max_records (equal on all ranks)");
     }
     hipStream_t st = stream;
-    HIP_TRY(hipMemsetAsync(sh.sent.p, 0, 8 * sizeof(uint32_t), st));
     StepScalars* sc = scalarsPtr();
-    HIP_TRY(hipMemsetAsync(&sc->shardSent[0], 0, 8 * sizeof(uint32_t), st));
-    for (uint32_t k = 0; k < sh.sp.numPeers; ++k) {
-        // after a valid step the buffer sets are swapped: bPos = the new state, bPosN = the state the step started from
-        k_shard_pack<<<divUp(nb, 256), 256, 0, st>>>(nb, sh.sp, k, sh.active.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bPosN.p, bRotN.p, bCogInvMass.p, sh.sendBuf[k].p, sh.capacity, sc, sh.root.p);
-        k_shard_pack_header<<<1, 1, 0, st>>>(k, sc, sh.sendBuf[k].p);
-    }
+    ShardBufs sendBufs{}, recvBufs{};
+    for (uint32_t k = 0; k < sh.sp.numPeers; ++k) { sendBufs.p[k] = sh.sendBuf[k].p; recvBufs.p[k] = sh.recvBuf[k].p; }
+    // after a valid step the buffer sets are swapped: bPos = the new state, bPosN = the state the step started from; the record counts were cleared by k_reset_scalars
+    k_shard_pack<<<divUp(nb, 256), 256, 0, st>>>(nb, sh.sp, sh.active.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bPosN.p, bRotN.p, bCogInvMass.p, sendBufs, sh.capacity, sc, sh.root.p);
+    k_shard_pack_headers<<<1, 8, 0, st>>>(sh.sp.numPeers, sc, sendBufs);
     HIP_TRY(hipMemcpyAsync(sh.sentHost, &sc->shardSent[0], 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     sh.sentPending = true;
     if (!sh.rccl) { HIP_TRY(hipStreamSynchronize(st)); return MI_OK; }     // caller's transport: the messages are complete when this returns
@@ -2054,8 +2055,7 @@ int mi_world::shardExchange() {
     }
     const int e2 = r->GroupEnd();
     if (e || e2) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e ? e : e2) : "RCCL send / receive failed");
-    for (uint32_t k = 0; k < sh.sp.numPeers; ++k)
-        k_shard_unpack<<<divUp(sh.capacity, 256), 256, 0, st>>>(nb, sh.recvBuf[k].p, sh.capacity, bPos.p, bRot.p, bLinVel.p, bAngVel.p);
+    if (sh.sp.numPeers) k_shard_unpack<<<dim3(divUp(sh.capacity, 256), sh.sp.numPeers), 256, 0, st>>>(nb, recvBufs, sh.capacity, bPos.p, bRot.p, bLinVel.p, bAngVel.p);
     hostStale = true;
     return MI_OK;
 }
@@ -2089,7 +2089,7 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
         sh.peerRanks.push_back((uint32_t)(std::find(order.begin(), order.end(), t) - order.begin()));
     }
     const uint32_t nb = (uint32_t)w->bodies.size();
-    sh.capacity = d->max_records ? d->max_records : std::max(4096u, nb / 4u);
+    sh.capacity = d->max_records ? d->max_records : std::max(4096u, nb / d->num_ranks / 4u);   // a message always travels whole: (capacity + 1) records of 56 bytes
     { int rc = w->shardBuildRoots(); if (rc != MI_OK) return rc; }
     HIP_TRY(sh.sent.ensure(8));
     for (uint32_t k = 0; k < sp.numPeers; ++k) {
@@ -2164,7 +2164,8 @@ MI_API int mi_world_shard_import(mi_world* w, const void* msg) {
     if (count > w->shard.capacity) return fail(MI_ERR_CAPACITY, "shard message overflow: raise mi_shard_desc::max_records (equal on all ranks)");
     const uint32_t nb = (uint32_t)w->bodies.size();
     HIP_TRY(hipMemcpyAsync(w->shard.recvBuf[0].p, msg, (size_t)(count + 1u) * kShardRecordFloats * sizeof(float), hipMemcpyHostToDevice, w->stream));
-    if (count) k_shard_unpack<<<divUp(count, 256), 256, 0, w->stream>>>(nb, w->shard.recvBuf[0].p, w->shard.capacity, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p);
+    ShardBufs one{}; one.p[0] = w->shard.recvBuf[0].p;
+    if (count) k_shard_unpack<<<dim3(divUp(count, 256), 1), 256, 0, w->stream>>>(nb, one, w->shard.capacity, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p);
     HIP_TRY(hipStreamSynchronize(w->stream));     // `msg` is the caller's (possibly pageable) memory
     w->hostStale = true;
     return MI_OK;

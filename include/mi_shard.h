@@ -42,7 +42,9 @@ typedef struct mi_shard_desc {
     float tile_size_x, tile_size_z;
     uint32_t tiles_x, tiles_z;
     float ghost_margin;             /* >= largest collider extent + the distance a body can travel in one step; < tile size */
-    uint32_t max_records;           /* capacity of one neighbour message in records (0 = max(4096, bodies / 4)); must be equal on all ranks */
+    uint32_t max_records;           /* capacity of one neighbour message in records (0 = max(4096, bodies / num_ranks / 4)); equal on all ranks.
+                                     * A message always travels whole — (max_records + 1) * 56 bytes per neighbour per step — so size it for the bodies in
+                                     * one margin strip (the library reports an overflow as MI_ERR_CAPACITY, it never drops records silently) */
 } mi_shard_desc;
 
 #define MI_SHARD_RECORD_FLOATS 14   /* body index (bit pattern) + 13 state floats; record 0 of a message = (count, unused...) */

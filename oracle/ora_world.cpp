@@ -1417,7 +1417,7 @@ MI_API int ora_world_shard_enable(World* w, const mi_shard_desc* d) {
         const uint32_t t = (uint32_t)z * d->tiles_x + (uint32_t)x;
         sh.peers.push_back(t); sh.peerRanks.push_back((uint32_t)(std::find(order.begin(), order.end(), t) - order.begin()));
     }
-    sh.capacity = d->max_records ? d->max_records : std::max<uint32_t>(4096u, (uint32_t)w->bodies.size() / 4u);
+    sh.capacity = d->max_records ? d->max_records : std::max<uint32_t>(4096u, (uint32_t)w->bodies.size() / d->num_ranks / 4u);
     sh.sendBuf.assign(sh.peers.size(), std::vector<float>((size_t)(sh.capacity + 1u) * MI_SHARD_RECORD_FLOATS, 0.f));
     sh.enabled = true;
     return MI_OK;
