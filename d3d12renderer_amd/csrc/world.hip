@@ -641,10 +641,10 @@ enum { STEP_RETRY = 1 };
 int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     HIP_TRY(hipSetDevice(device));
     if (topologyDirty) { int rc = download(); if (rc != MI_OK) return rc; rc = upload(); if (rc != MI_OK) return rc; haveEstimates = false; }
-    if (shard.stepOpen) shard.prevValid = false;   // the previous step ended in an error: what its kernels left behind is not what the flags describe
-    shard.stepOpen = true;
     else if (joints.podsDirty()) { int rc = joints.uploadPods(stream); if (rc != MI_OK) return rc; HIP_TRY(hipStreamSynchronize(stream)); }
     if (bodies.empty()) return cloths.empty() ? MI_OK : stepCloths(dt);   // physics.cpp:1184-1189: cloth alone still steps
+    if (shard.stepOpen) shard.prevValid = false;   // the previous step ended in an error: what its kernels left behind is not what the flags describe
+    shard.stepOpen = true;
     const bool spec = specEnabled && haveEstimates && flowSolver && !launchFallbackSteps && !usesInteractions;   // interactions are read back mid-step
     ++totalSteps; if (spec) ++specSteps;
     int rc = runStep(settings, dt, spec);
