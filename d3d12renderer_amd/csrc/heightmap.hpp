@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
     if (i >= nc) return;
     const float4 mn = aabbMin[i], mx = aabbMax[i];
     uint32_t type;
-    const bool active = hmActive(__float_as_uint(mn.w), type);
+    const bool active = hmActive(__float_as_uint(mn.w), type) && !(mx.x < mn.x);   // (inverted box: sharded world, a body this rank does not simulate this step)
     uint32_t count = 0, first = 0;
     if (WRITE) {
         count = active ? (uint32_t)hmPacked[i] : 0u;

@@ -2073,7 +2073,6 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
     if (!w || !d) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     if (!d->tiles_x || !d->tiles_z || d->tiles_x > 65535u || d->tiles_z > 65535u || d->num_ranks != d->tiles_x * d->tiles_z || d->rank >= d->num_ranks) return fail(MI_ERR_INVALID_ARGUMENT, "num_ranks must equal tiles_x * tiles_z");
     if (!(d->tile_size_x > 0.f) || !(d->tile_size_z > 0.f) || !(d->ghost_margin > 0.f) || d->ghost_margin >= d->tile_size_x || d->ghost_margin >= d->tile_size_z) return fail(MI_ERR_INVALID_ARGUMENT, "0 < ghost_margin < tile size");
-    if (w->heightmap || !w->cloths.empty()) return fail(MI_ERR_UNSUPPORTED, "sharded worlds with heightmap terrain or cloth are not supported yet");
     HIP_TRY(hipSetDevice(w->device));
     mi_world::ShardState& sh = w->shard;
     sh.desc = *d;

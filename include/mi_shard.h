@@ -22,7 +22,8 @@
  * (tests do exactly that, on the CPU oracle over gloo and on one GPU); it does NOT equal the unsharded world — the seam coupling
  * of a step is one step late — and tests bound that difference.  An ARTICULATED ISLAND (bodies connected by constraints: a ragdoll,
  * a vehicle) is classified as one — by the centre of its root body (lowest body index) — so no constraint ever spans ranks and islands
- * migrate whole; ghost_margin then has to cover an island's reach as well.  Worlds with heightmap terrain or cloth are refused for now.
+ * migrate whole; ghost_margin then has to cover an island's reach as well.  Heightmap terrain is static and replicated (a collider of a
+ * body this rank does not simulate takes no part in it); cloths do not interact with rigid bodies, every rank steps all of them identically.
  *
  * Transport.  Either the library's own: RCCL point-to-point (ncclSend / ncclRecv in one group per step, on the world's stream,
  * fixed-size messages so that no host read-back sits between the step and the exchange) — mi_shard_get_unique_id on rank 0,

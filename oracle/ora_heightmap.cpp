@@ -240,6 +240,7 @@ void heightmapCollision(World& w) {
     for (uint32_t i = 0; i < w.wc.size(); ++i) {
         const WorldCollider& col = w.wc[i];
         if (col.objectType != MI_OBJECT_RIGID_BODY) continue;
+        if (w.aabbs[i].mx.x < w.aabbs[i].mn.x) continue;   // sharded world: a collider of a body this rank does not simulate this step
         const Shape& s = col.s;
         if (s.type != T_SPHERE && s.type != T_CAPSULE && s.type != T_AABB && s.type != T_OBB) continue;
         vec3 vmin = w.aabbs[i].mn, vmax = w.aabbs[i].mx;

@@ -1406,7 +1406,7 @@ MI_API int ora_shard_rank_of_tile(uint32_t tx, uint32_t tz, uint32_t tile, uint3
 MI_API int ora_world_shard_enable(World* w, const mi_shard_desc* d) {
     if (!w || !d || !d->tiles_x || !d->tiles_z || d->num_ranks != d->tiles_x * d->tiles_z || d->rank >= d->num_ranks) return MI_ERR_INVALID_ARGUMENT;
     if (!(d->tile_size_x > 0.f) || !(d->tile_size_z > 0.f) || !(d->ghost_margin > 0.f) || d->ghost_margin >= d->tile_size_x || d->ghost_margin >= d->tile_size_z) return MI_ERR_INVALID_ARGUMENT;
-    if (w->orderMode != 1 || w->heightmap || !w->cloths.empty()) return MI_ERR_UNSUPPORTED;
+    if (w->orderMode != 1) return MI_ERR_UNSUPPORTED;   // (terrain is static and replicated; cloths do not interact with bodies: every rank steps all of them identically)
     World::Shard& sh = w->shard;
     sh.desc = *d;
     auto order = ora::tilesInRankOrder(d->tiles_x, d->tiles_z);

@@ -19,10 +19,12 @@ STEPS = 80
 
 
 def _scene(kind="pile"):
+    if kind == "terrain":
+        return scenes.terrain_field(8, 2, 8, with_unsupported=False)
     return scenes.ragdolls(4, 3) if kind == "ragdolls" else scenes.obb_pile(12, 4, 8, spacing=1.0)
 
 
-MARGIN = {"pile": 2.5, "ragdolls": 3.5}      # islands are classified by their root body: the margin has to cover an island's reach
+MARGIN = {"pile": 2.5, "ragdolls": 3.5, "terrain": 2.5}      # islands are classified by their root body: the margin has to cover an island's reach
 
 
 def _virtual_ranks(make_world, sc, num_ranks, tiles_z=1, margin=2.5):
@@ -51,8 +53,8 @@ def _worker(rank, world_size, port, out_dir, tiles_z, kind="pile", transport="di
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world_size,tiles_z,kind,transport", [(2, 1, "pile", "dist"), (4, 2, "pile", "dist"), (2, 1, "ragdolls", "dist"), (2, 1, "pile", "rccl")],
-                         ids=["2 ranks, x slabs", "4 ranks, 2 x 2 tiles", "2 ranks, ragdolls", "2 ranks, library transport unavailable -> caller's transport"])
+@pytest.mark.parametrize("world_size,tiles_z,kind,transport", [(2, 1, "pile", "dist"), (4, 2, "pile", "dist"), (2, 1, "ragdolls", "dist"), (2, 1, "pile", "rccl"), (2, 1, "terrain", "dist")],
+                         ids=["2 ranks, x slabs", "4 ranks, 2 x 2 tiles", "2 ranks, ragdolls", "2 ranks, library transport unavailable -> caller's transport", "2 ranks, heightmap terrain"])
 def test_processes_over_gloo_equal_virtual_ranks_bit_for_bit(tmp_path, oracle_mod, world_size, tiles_z, kind, transport):
     """R processes exchanging the neighbour messages over gloo == R worlds of one process with the messages copied by hand:
     the transport carries exactly what the library packed, nothing depends on timing or on who runs a tile.  Last case: the ranks
@@ -161,10 +163,6 @@ def test_articulated_islands_stay_on_one_rank(oracle_mod):
 
 
 def test_shard_api_rejects_what_it_cannot_do(oracle_mod):
-    sc = scenes.terrain_field(4, 1, 4, with_unsupported=False)
-    w = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
-    with pytest.raises(capi.PhysicsError):
-        w.shard_enable(sharding._desc_for(sharding.tile_grid(sc, 2), 0))          # heightmap terrain: not sharded yet
     sc = _scene()
     w = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     bad = sharding._desc_for(sharding.tile_grid(sc, 2), 0); bad.num_ranks = 3

@@ -16,8 +16,9 @@ def _ranks(make_world, sc, n, tiles_z=1, margin=2.5):
 
 
 @pytest.mark.parametrize("n,tiles_z,make,margin", [(3, 1, lambda: scenes.obb_pile(12, 4, 8, spacing=1.0), 2.5), (4, 2, lambda: scenes.mixed_stack(10, 4, 10), 2.5),
-                                                   (2, 1, lambda: scenes.shape_zoo(), 2.5), (3, 1, lambda: scenes.ragdolls(6, 3), 3.5), (2, 2, lambda: scenes.vehicles(4, 4), 6.0)],
-                         ids=["3 slabs boxes", "2x2 tiles mixed", "2 slabs all shapes", "3 slabs ragdolls (cfg4)", "2x1 tiles vehicles (cfg5)"])
+                                                   (2, 1, lambda: scenes.shape_zoo(), 2.5), (3, 1, lambda: scenes.ragdolls(6, 3), 3.5), (2, 2, lambda: scenes.vehicles(4, 4), 6.0),
+                                                   (2, 2, lambda: scenes.terrain_field(9, 2, 9, with_unsupported=False), 2.5)],
+                         ids=["3 slabs boxes", "2x2 tiles mixed", "2 slabs all shapes", "3 slabs ragdolls (cfg4)", "2x1 tiles vehicles (cfg5)", "2x2 tiles on heightmap terrain"])
 def test_gpu_virtual_ranks_match_oracle_virtual_ranks(mi_lib, oracle_mod, n, tiles_z, make, margin):
     """Joint scenes too: an articulated island (ragdoll, vehicle) is owned / ghosted / ignored as one, decided by its root body."""
     sc = make()
@@ -42,6 +43,26 @@ def test_gpu_virtual_ranks_match_oracle_virtual_ranks(mi_lib, oracle_mod, n, til
                 first = cur
             migrated |= bool((cur != first).any())
     assert migrated or n != 3 or margin != 2.5, "no body changed owner in the spreading box pile"
+
+
+def test_gpu_cloth_in_a_sharded_world(mi_lib):
+    """Cloths do not interact with rigid bodies (cloth.cpp): every rank steps all of them, identically — the same vertices on every
+    rank and in the unsharded world, while the rigid bodies are sharded as usual."""
+    sc = scenes.obb_pile(8, 3, 8, spacing=1.0)
+    worlds = [sc.populate(mi_lib.create_world(0)) for _ in range(3)]
+    for w in worlds:
+        c = w.create_cloth(3.0, 2.0, 16, 12, 4.0, stiffness=0.6, damping=0.4)
+        w.set_cloth_fixed_vertices(c, (0.0, 6.0, 0.0), move_rigid=True)
+    desc = sharding.tile_grid(sc, 2)
+    ranks = [sharding.ShardedWorld(worlds[r], desc, r, "local") for r in range(2)]
+    s = sc.settings()
+    for _ in range(60):
+        sharding.step_local(ranks, s, sc.dt); worlds[2].step_fixed(s, sc.dt, 1)
+    ref = worlds[2].cloth_state(0, 16 * 12)
+    for r in ranks:
+        got = r.world.cloth_state(0, 16 * 12)
+        assert np.isfinite(got[0]).all() and got[0].tobytes() == ref[0].tobytes() and got[1].tobytes() == ref[1].tobytes()
+    assert sum(r.world.shard_counts()["owned_bodies"] for r in ranks) == sc.num_bodies
 
 
 def test_gpu_one_tile_is_the_unsharded_world(mi_lib):
