@@ -487,10 +487,10 @@ class World:
         self.L.check(self.L.fn("world_get_stream")(self.h, C.byref(out)), "world_get_stream")
         return out.value or 0
 
-    SOLVER_KERNELS = ("k_contact_solve", "k_contact_solve_flow", "k_contact_solve_persist", "k_solve_flow_islands", "k_contact_solve_persist")
+    SOLVER_KERNELS = ("k_contact_solve", "k_contact_solve_flow", "k_contact_solve_persist", "k_solve_flow_islands", "k_contact_solve_persist", "k_contact_solve_persist")
 
     def solver_kind(self):
-        """mi_world_get_solver_kind: 0 per-colour launches, 1 flow, 2 persistent, 3 flow + joint islands, 4 persistent, XCD-partitioned."""
+        """mi_world_get_solver_kind: 0 per-colour launches, 1 flow, 2 persistent, 3 flow + joint islands, 4 persistent, XCD-partitioned, 5 persistent, all tiles on one XCD (small piles)."""
         k = C.c_uint32()
         self.L.check(self.L.fn("world_get_solver_kind")(self.h, C.byref(k)), "world_get_solver_kind")
         return k.value

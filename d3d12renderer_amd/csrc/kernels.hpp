@@ -1319,15 +1319,23 @@ __device__ __forceinline__ uint32_t binOf(uint32_t color, uint32_t cnt) { return
 // the scene (bodies away from the slab seams are only ever touched from one XCD).  Bins shorter than 8 tiles are dealt
 // round-robin instead.  Results do not depend on any of this: which lane / wave / XCD runs a slot is invisible to the
 // body-version dataflow.
-__host__ __device__ __forceinline__ uint32_t tileOwner(uint32_t tl, uint32_t nt, uint32_t bin) { return nt >= 8u ? (tl * 8u) / nt : ((tl * 8u) / nt + bin) & 7u; }
+// `single` (small piles, < 16384 manifolds): EVERY tile belongs to XCD 0 — the 128 waves of one XCD run the whole solve and every
+// body is "local", i.e. all hand-overs go through one L2 instead of through memory (a third of the round trip, and the small
+// piles are bound by exactly that: ~10 colours x sweeps hand-overs in a row, a handful of tiles per colour).
+__host__ __device__ __forceinline__ uint32_t tileOwner(uint32_t tl, uint32_t nt, uint32_t bin, uint32_t single = 0u) {
+    if (single) return 0u;
+    return nt >= 8u ? (tl * 8u) / nt : ((tl * 8u) / nt + bin) & 7u;
+}
 // number of tiles tl' < tl of the same bin with the same owner
-__host__ __device__ __forceinline__ uint32_t tileOwnerRank(uint32_t tl, uint32_t nt, uint32_t bin) {
+__host__ __device__ __forceinline__ uint32_t tileOwnerRank(uint32_t tl, uint32_t nt, uint32_t bin, uint32_t single = 0u) {
+    if (single) return tl;
     if (nt >= 8u) { uint32_t x = (tl * 8u) / nt; return tl - (x * nt + 7u) / 8u; }
     uint32_t x = tileOwner(tl, nt, bin), r = 0;
     for (uint32_t k = 0; k < tl; ++k) r += tileOwner(k, nt, bin) == x ? 1u : 0u;
     return r;
 }
-__host__ __device__ __forceinline__ uint32_t tileOwnerCount(uint32_t x, uint32_t nt, uint32_t bin) {
+__host__ __device__ __forceinline__ uint32_t tileOwnerCount(uint32_t x, uint32_t nt, uint32_t bin, uint32_t single = 0u) {
+    if (single) return x == 0u ? nt : 0u;
     if (nt >= 8u) return ((x + 1u) * nt + 7u) / 8u - (x * nt + 7u) / 8u;
     uint32_t r = 0;
     for (uint32_t k = 0; k < nt; ++k) r += tileOwner(k, nt, bin) == x ? 1u : 0u;
@@ -1497,7 +1505,7 @@ __device__ __forceinline__ uint32_t waveExclusiveScan(uint32_t n, Get get, Put p
     }
     return carry;
 }
-__global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t ctCap, StepScalars* sc, BinInfo* __restrict__ binInfo, uint32_t* __restrict__ xcdBase /* [kSchedBins][8] or null */) {
+__global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t ctCap, StepScalars* sc, BinInfo* __restrict__ binInfo, uint32_t* __restrict__ xcdBase /* [kSchedBins][8] or null */, uint32_t xcdSingle) {
     __shared__ BinInfo bins[kSchedBins];
     __shared__ uint32_t start[kColorBins + 4];
     __shared__ uint32_t totals[2];
@@ -1522,7 +1530,7 @@ __global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t
     for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) binInfo[bn] = bins[bn];
     if (xcdBase) {   // per-XCD tile lists: first list position of every bin's share (wave w scans XCDs 2w and 2w + 1), and the list lengths
         for (uint32_t x = 2u * wave; x < 2u * wave + 2u; ++x) {
-            uint32_t t = waveExclusiveScan(kSchedBins, [&](uint32_t bn) { return tileOwnerCount(x, tilesOf(bn), bn); }, [&](uint32_t bn, uint32_t v) { xcdBase[bn * 8u + x] = v; });
+            uint32_t t = waveExclusiveScan(kSchedBins, [&](uint32_t bn) { return tileOwnerCount(x, tilesOf(bn), bn, xcdSingle); }, [&](uint32_t bn, uint32_t v) { xcdBase[bn * 8u + x] = v; });
             if ((threadIdx.x & 63u) == 0) sc->xcdCount[x] = ok && totals[0] ? t : 0u;
         }
     }
@@ -1530,7 +1538,7 @@ __global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t
 // tile -> bin (binary search over the bins' first tiles) and tile -> (first contact-tile, contacts per manifold)
 __global__ __launch_bounds__(256) void k_fill_tiles(const StepScalars* __restrict__ sc, const BinInfo* __restrict__ binInfo,
                                                     uint32_t* __restrict__ tileBin, uint2* __restrict__ tileDesc,
-                                                    const uint32_t* __restrict__ xcdBase, uint32_t* __restrict__ xcdTiles /* [8][listCap] or null */, uint32_t listCap) {
+                                                    const uint32_t* __restrict__ xcdBase, uint32_t* __restrict__ xcdTiles /* [8][listCap] or null */, uint32_t listCap, uint32_t xcdSingle) {
     __shared__ uint32_t first[kSchedBins];
     for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) first[bn] = binInfo[bn].tileStart;
     __syncthreads();
@@ -1544,7 +1552,7 @@ __global__ __launch_bounds__(256) void k_fill_tiles(const StepScalars* __restric
     tileDesc[t] = make_uint2(bi.ctStart + (t - bi.tileStart) * stride, stride);
     if (xcdTiles) {
         const uint32_t tl = t - bi.tileStart, nt = (bi.count + 63u) >> 6;
-        const uint32_t x = tileOwner(tl, nt, lo), at = xcdBase[lo * 8u + x] + tileOwnerRank(tl, nt, lo);
+        const uint32_t x = tileOwner(tl, nt, lo, xcdSingle), at = xcdBase[lo * 8u + x] + tileOwnerRank(tl, nt, lo, xcdSingle);
         if (at < listCap) xcdTiles[(size_t)x * listCap + at] = t;   // (a longer list is reported by the solver kernel: solveError 2)
     }
 }
@@ -1561,7 +1569,7 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
                                                      float4* __restrict__ rows, float4* __restrict__ imp, uint4* __restrict__ slotMeta,
                                                      float4* __restrict__ slotNormal, float2* __restrict__ slotMass,
                                                      uint8_t* __restrict__ bodyOwner /* XCD-partitioned solver: [body][8] flags, 1 = a tile of that XCD touches the body; or null */,
-                                                     const uint32_t* __restrict__ xcdTiles, uint32_t listCap /* with bodyOwner: workgroup b prepares entry b / 8 of XCD (b % 8)'s tile list */) {
+                                                     const uint32_t* __restrict__ xcdTiles, uint32_t listCap /* with bodyOwner: workgroup b prepares entry b / 8 of XCD (b % 8)'s tile list */, uint32_t xcdSingle) {
     // (one wave per contact index — four waves per tile, the per-manifold gathers repeated — measured slower: 52 -> 73 us; the kernel
     // is bound by those gathers)
     uint32_t tile = blockIdx.x, lane = threadIdx.x; const uint32_t kw = 0;
@@ -1610,7 +1618,7 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
         slotMass[(size_t)tile * 64u + lane] = make_float2(imA, imB);
     }
     if (bodyOwner && kw == 0) {   // one byte per (body, XCD): plain idempotent stores, no atomics
-        const uint32_t x = tileOwner(tl, (bi.count + 63u) >> 6, bin);
+        const uint32_t x = tileOwner(tl, (bi.count + 63u) >> 6, bin, xcdSingle);
         if (imA != 0.f) bodyOwner[(size_t)bodies.x * 8u + x] = 1u;
         if (imB != 0.f) bodyOwner[(size_t)bodies.y * 8u + x] = 1u;
     }

@@ -134,7 +134,7 @@ struct mi_world {
     DBuf<float4> gPos, gInvI, gVel;
     // XCD-partitioned persistent solver: cached velocity copy for XCD-local bodies, per-body XCD set, spatial sort of the manifolds, per-XCD tile lists
     DBuf<float4> gVelL; DBuf<unsigned long long> bodyOwner; DBuf<uint32_t> sortKeys[2], sortVals[2], xcdBase, xcdTiles, keyCount;
-    bool persistXcd = true, usedXcd = false, haveXcdEstimate = false, xcdFaultFired = false, xcdFaultTest = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
+    bool persistXcd = true, persistXcdSingle = true, usedXcd = false, usedXcdSingle = false, lastXcdSingle = false, haveXcdEstimate = false, xcdFaultFired = false, xcdFaultTest = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
     // device: colliders
     DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cMaterial;
     DBuf<float4> wShape, aabbMin, aabbMax, hullAabb, hullVerts; DBuf<uint32_t> hullRanges;
@@ -281,6 +281,7 @@ int mi_world::init(int dev) {
       if (const char* pw = getenv("MI_PERSIST_WAVES")) persistWaves = (uint32_t)strtoul(pw, nullptr, 0);
       xcdOnly = getenv("MI_PERSIST_XCD_ONLY") ? 1u : 0u;
       if (const char* px = getenv("MI_PERSIST_XCD")) persistXcd = px[0] != '0';
+      if (const char* px = getenv("MI_PERSIST_XCD_SINGLE")) persistXcdSingle = px[0] != '0';   // 0: small piles on all XCDs, every body through memory
       xcdFaultTest = getenv("MI_PERSIST_XCD_FAULT") != nullptr;
       flowFaultTest = getenv("MI_FLOW_FAULT") != nullptr;
       if (const char* pm = getenv("MI_PERSIST_XCD_MIN")) xcdMinManifolds = (uint32_t)strtoul(pm, nullptr, 0); }   // smallest manifold count that is partitioned (tests: 1)   // MI_PERSIST_XCD=0: no XCD partitioning (every body through memory)   // development experiment: one XCD's workgroups do all the work
@@ -900,7 +901,10 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     }
     uint32_t tilesCap = 0, ctCap = 0, eventCap = 0, xcdListCap = 0;
     // XCD partitioning pays once the pile is big enough to keep eight L2s busy; it needs the persistent kernel (no joints)
-    const bool xcdPlan = flowSolver && persistSolver && persistXcd && !xcdOnly && joints.count() == 0 && (persistWaves & 7u) == 0u && nmBound >= xcdMinManifolds;
+    const bool xcdAble = flowSolver && persistSolver && persistXcd && !xcdOnly && joints.count() == 0 && (persistWaves & 7u) == 0u;
+    // small piles: the 128 waves of ONE XCD run the whole solve, every body hand-over goes through that XCD's L2 (tileOwner(..., single))
+    const bool xcdSingle = xcdAble && persistXcdSingle && nmBound && nmBound < xcdMinManifolds && divUp(divUp(nmBound, 64) + kSchedBins + 8, persistWaves / 8u) <= 16u;
+    const bool xcdPlan = xcdAble && (nmBound >= xcdMinManifolds || xcdSingle);
     static const uint32_t colorMargin = std::getenv("MI_COLOR_MARGIN") ? (uint32_t)atoi(std::getenv("MI_COLOR_MARGIN")) : 3u;   // extra rounds enqueued beyond the previous step's count
     uint32_t colorBatch = spec ? std::min<uint32_t>(96u, last.colorRounds + std::max(colorMargin, last.colorRounds / 4u)) : 20u;   // converged rounds exit at once
     if (nmBound) {
@@ -910,14 +914,16 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         HIP_TRY(blockHist.ensure((size_t)kColorBins * binBlocks)); HIP_TRY(blockScan.ensure((size_t)kColorBins * binBlocks));
         HIP_TRY(tileBin.ensure(tilesCap)); HIP_TRY(tileDesc.ensure(tilesCap));
         if (xcdPlan) {   // slots in spatial order inside every bin + per-XCD tile lists (k_contact_solve_persist<.., true>)
-            xcdListCap = divUp(tilesCap, 8) + kSchedBins;
+            xcdListCap = xcdSingle ? tilesCap + kSchedBins : divUp(tilesCap, 8) + kSchedBins;
             HIP_TRY(sortKeys[0].ensure(nmBound)); for (int k = 0; k < 2; ++k) HIP_TRY(sortVals[k].ensure(nmBound));
             HIP_TRY(xcdTiles.ensure((size_t)8 * xcdListCap));
-            k_manifold_keys<<<divUp(nmBound, kKeyItems), 256, 0, st>>>(nmBound, sc, grid.p + gridCur, manBodies.p, gPos.p, sortKeys[0].p, sortVals[0].p, keyCount.p);
-            k_manifold_place<<<divUp(nmBound, kKeyItems), 256, 0, st>>>(nmBound, sc, sortKeys[0].p, sortVals[0].p, keyCount.p, sortVals[1].p);
+            if (!xcdSingle) {   // (one XCD: nothing to keep apart, the emission order will do)
+                k_manifold_keys<<<divUp(nmBound, kKeyItems), 256, 0, st>>>(nmBound, sc, grid.p + gridCur, manBodies.p, gPos.p, sortKeys[0].p, sortVals[0].p, keyCount.p);
+                k_manifold_place<<<divUp(nmBound, kKeyItems), 256, 0, st>>>(nmBound, sc, sortKeys[0].p, sortVals[0].p, keyCount.p, sortVals[1].p);
+            }
         }
         static const bool xcdNoSort = std::getenv("MI_XCD_NOSORT") != nullptr;   // development: manifold order as emitted
-        const uint32_t* perm = xcdPlan && !xcdNoSort ? sortVals[1].p : nullptr;
+        const uint32_t* perm = xcdPlan && !xcdSingle && !xcdNoSort ? sortVals[1].p : nullptr;
         unsigned long long* top[2] = {bodyTop.p, bodyTop.p + (nb + 1)};
         uint32_t round = 0;
         while (true) {
@@ -927,8 +933,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             k_bin_hist<<<binBlocks, 256, 0, st>>>(sc, binBlocks, perm, color.p, manInfo.p, blockHist.p);
             HIP_TRY(scanBins.run(blockHist.p, blockScan.p, kColorBins * binBlocks, st));
             k_bin_scatter<<<binBlocks, 256, 0, st>>>(round - 1, roundFlagsPtr(), binBlocks, perm, color.p, manInfo.p, blockScan.p, order.p, sc);
-            k_build_tiles<<<1, 256, 0, st>>>(tilesCap, ctCap, sc, binInfo.p, xcdPlan ? xcdBase.p : nullptr);
-            k_fill_tiles<<<divUp(tilesCap, B), B, 0, st>>>(sc, binInfo.p, tileBin.p, tileDesc.p, xcdBase.p, xcdPlan ? xcdTiles.p : nullptr, xcdListCap);
+            k_build_tiles<<<1, 256, 0, st>>>(tilesCap, ctCap, sc, binInfo.p, xcdPlan ? xcdBase.p : nullptr, xcdSingle ? 1u : 0u);
+            k_fill_tiles<<<divUp(tilesCap, B), B, 0, st>>>(sc, binInfo.p, tileBin.p, tileDesc.p, xcdBase.p, xcdPlan ? xcdTiles.p : nullptr, xcdListCap, xcdSingle ? 1u : 0u);
             if (spec) break;
             int rc = readScalars(); if (rc != MI_OK) return rc;
             if (hs.colorPending == 0) break;
@@ -966,8 +972,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     auto persistSlots = [&](uint32_t tiles, bool xcd, bool speculative) -> uint32_t {
         if (!xcd) return divUp(tiles, xcdOnly ? persistWaves / 8u : persistWaves);
         uint32_t longest = 0;
-        if (speculative) longest = haveXcdEstimate ? lastXcdMax + lastXcdMax / 8u + 16u : divUp(tiles, 8) + 64u;
-        else for (uint32_t x = 0; x < 8u; ++x) { uint32_t n = 0; for (uint32_t bn = 0; bn < kSchedBins; ++bn) n += tileOwnerCount(x, divUp(bins[bn].count, 64), bn); longest = std::max(longest, n); }
+        if (speculative) longest = (haveXcdEstimate && lastXcdSingle == xcdSingle) ? lastXcdMax + lastXcdMax / 8u + 16u : xcdSingle ? tiles + 16u : divUp(tiles, 8) + 64u;
+        else for (uint32_t x = 0; x < 8u; ++x) { uint32_t n = 0; for (uint32_t bn = 0; bn < kSchedBins; ++bn) n += tileOwnerCount(x, divUp(bins[bn].count, 64), bn, xcdSingle ? 1u : 0u); longest = std::max(longest, n); }
         return divUp(std::max(longest, 1u), persistWaves / 8u);
     };
     // the persistent kernel keeps the accumulated impulses in LDS while they fit: k_contact_init then need not write the impulse granules
@@ -980,7 +986,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         if (tilesLaunch)
             k_contact_init<<<xcdPlan ? 8u * xcdListCap : tilesLaunch, 64, 0, st>>>(sc, nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
                                                       gPos.p, gInvI.p, xcdPlan ? gVelL.p : gVel.p /* same content here; the cached copy */, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, impNeeded ? imp.p : nullptr, slotMeta.p, slotNormal.p, slotMass.p,
-                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, xcdTiles.p, xcdListCap);
+                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, xcdTiles.p, xcdListCap, xcdSingle ? 1u : 0u);
     }
     int rc = joints.initialize(*this, dt, st);
     if (rc != MI_OK) return rc;
@@ -989,7 +995,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     const bool willPersist = !(useFlow && fuseEnabled && joints.allInIslands()) && persistPlan && persistMaxSlots * 20u <= 38u * 1024u;
     if (attached && !willPersist) (void)hipEventRecord(ev[6], st);   // another solver path (several launches): classic recorded events
     const uint32_t iters = settings.num_rigid_solver_iterations;
-    usedFlow = useFlow; usedPersist = false; usedFused = fused; usedXcd = false;
+    usedFlow = useFlow; usedPersist = false; usedFused = fused; usedXcd = false; usedXcdSingle = false;
     uint64_t mainContacts = 0;
     if (fused) {
         // contacts and joint islands of every sweep in one launch (k_solve_flow_islands)
@@ -1013,7 +1019,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         // persistent waves: one workgroup per SIMD owns its tiles through all sweeps, impulses (and, while they fit, the constant slot data) in LDS (k_contact_solve_persist)
         const uint32_t maxSlots = persistMaxSlots;
         const bool metaLds = persistMetaLds && maxSlots * (64u * 40u + 4u * 512u + 20u) <= 38u * 1024u;
-        usedXcd = xcdPlan;
+        usedXcd = xcdPlan; usedXcdSingle = xcdPlan && xcdSingle;
         const uint32_t xcdFault = xcdFaultTest && usedXcd && !xcdFaultFired ? 1u : 0u;   // tests: one workgroup reports a placement mismatch once
         if (xcdFault) xcdFaultFired = true;
         solveLaunches = 1; usedPersist = true;
@@ -1225,7 +1231,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         for (int x = 0; x < 8; ++x) std::fprintf(stderr, " %u", hs.xcdCount[x]);
         std::fprintf(stderr, "\n");
     }
-    haveXcdEstimate = usedXcd;
+    haveXcdEstimate = usedXcd; lastXcdSingle = usedXcdSingle;
     if (usedXcd) { lastXcdMax = 0; for (int x = 0; x < 8; ++x) lastXcdMax = std::max(lastXcdMax, hs.xcdCount[x]); }
     last.colorRounds = 0;
     while (last.colorRounds < 96u && flagsHost[last.colorRounds]) ++last.colorRounds;   // rounds that still had work (+1 to commit) this step
@@ -2418,7 +2424,7 @@ MI_API int mi_world_get_accumulated_stage_times(mi_world* w, mi_stage_times* out
 // 2 k_contact_solve_persist, 3 k_solve_flow_islands (contacts + joint islands fused), 4 k_contact_solve_persist XCD-partitioned.
 MI_API int mi_world_get_solver_kind(mi_world* w, uint32_t* out) {
     if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null");
-    *out = w->usedFused ? 3u : w->usedPersist ? (w->usedXcd ? 4u : 2u) : w->usedFlow ? 1u : 0u;
+    *out = w->usedFused ? 3u : w->usedPersist ? (w->usedXcdSingle ? 5u : w->usedXcd ? 4u : 2u) : w->usedFlow ? 1u : 0u;
     return MI_OK;
 }
 // Host-side evaluation of the tile -> XCD assignment the XCD-partitioned solver uses on the device (tests: the per-XCD shares of

@@ -282,7 +282,8 @@ MI_API int mi_world_set_stage_timing(mi_world* world, uint32_t enable);
 MI_API int mi_world_get_stage_times(mi_world* world, mi_stage_times* out);
 /* Contact-solver kernel of the last internal step: 0 k_contact_solve (a launch per colour per sweep), 1 k_contact_solve_flow,
  * 2 k_contact_solve_persist (default without joints), 3 k_solve_flow_islands (contacts + joint islands in one launch),
- * 4 k_contact_solve_persist with the tiles partitioned over the XCDs (default from 16384 manifolds up). */
+ * 4 k_contact_solve_persist with the tiles partitioned over the XCDs (default from 16384 manifolds up), 5 the same kernel with all
+ * tiles on ONE XCD (default below that: every body hand-over through one L2). */
 MI_API int mi_world_get_solver_kind(mi_world* world, uint32_t* out_kind);
 /* Sum of the per-stage device times and of the contact updates (contacts x solver iterations) over the internal steps since
  * the last reset (so a benchmark loop does not have to call back into the library after every step). */

@@ -336,10 +336,11 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
     assert g2.cloth_state(0, 144)[0].tobytes() == o2.cloth_state(0, 144)[0].tobytes()
 
 
-@pytest.mark.parametrize("env,kind", [({"MI_SOLVER": "flow"}, 1), ({"MI_SOLVER": "persist-global"}, 2), ({"MI_PERSIST_XCD": "0"}, 2),
+@pytest.mark.parametrize("env,kind", [({}, 5), ({"MI_SOLVER": "flow"}, 1), ({"MI_SOLVER": "persist-global"}, 5), ({"MI_PERSIST_XCD": "0"}, 2), ({"MI_PERSIST_XCD_SINGLE": "0"}, 2),
+                                      ({"MI_PERSIST_XCD_SINGLE": "0", "MI_SOLVER": "persist-global"}, 2), ({"MI_PERSIST_XCD_SINGLE": "0", "MI_SOLVER": "persist-granules"}, 2),
                                       ({"MI_PERSIST_XCD_MIN": "1"}, 4), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-global"}, 4),
-                                      ({"MI_SOLVER": "persist-granules"}, 2), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-granules"}, 4),
-                                      ({"MI_PERSIST_XCD_MIN": "1", "MI_PERSIST_XCD_FAULT": "1"}, 2), ({"MI_READBACK": "copy"}, 2),
+                                      ({"MI_SOLVER": "persist-granules"}, 5), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-granules"}, 4),
+                                      ({"MI_PERSIST_XCD_MIN": "1", "MI_PERSIST_XCD_FAULT": "1"}, 2), ({"MI_PERSIST_XCD_FAULT": "1"}, 2), ({"MI_READBACK": "copy"}, 5),
                                       ({"MI_PERSIST_WAVES": "8"}, 2), ({"MI_PERSIST_WAVES": "2"}, 2),
                                       ({"MI_SOLVER": "flow", "MI_FLOW_FAULT": "1"}, 0)])
 def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch, env, kind):
@@ -349,7 +350,8 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
     global memory instead of LDS (what piles beyond ~500 k manifolds get);  persist-granules -> the accumulated impulses as
     tagged granules in memory as well (piles beyond ~1.2 M manifolds);  MI_PERSIST_XCD_MIN=1 -> XCD partitioning (spatially
     sorted slots, per-XCD tile lists, XCD-local bodies through L2) even on this small pile (default from 16384 manifolds up);
-    MI_PERSIST_XCD=0 -> never partitioned;  MI_PERSIST_XCD_FAULT -> one workgroup reports that blockIdx % 8 did not identify its
+    MI_PERSIST_XCD=0 -> never partitioned;  no variable at all -> a pile this small runs on ONE XCD (kind 5: all tiles in XCD 0's list, every
+    body hand-over through its L2); MI_PERSIST_XCD_SINGLE=0 -> small piles on all XCDs, bodies through memory;  MI_PERSIST_XCD_FAULT -> one workgroup reports that blockIdx % 8 did not identify its
     XCD: the step is re-run from untouched state and the world continues unpartitioned;  MI_READBACK=copy -> the end-of-step
     read-back as an async copy + stream synchronise instead of the kernel-published record the host spins on;
     MI_FLOW_FAULT -> the dispatch-ordered kernel reports an exhausted spin budget once (what a shared device can cause): the step
