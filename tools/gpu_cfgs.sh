@@ -13,6 +13,8 @@ for name, make, warm, steps in (("cfg1_spheres_4096", lambda: scenes.sphere_drop
                                 ("cfg4_ragdolls_1024", lambda: scenes.ragdolls(32, 32), 240, 60), ("cfg5_vehicles_256", lambda: scenes.vehicles(16, 16), 240, 60),
                                 ("terrain_65536", lambda: scenes.terrain_big(), 300, 60), ("zones_6912", lambda: scenes.zones(48, 3, 48), 200, 60),
                                 ("cfg3_settled_pile_262144", lambda: scenes.obb_pile(128, 16, 128), 1500, 60), ("pile_1048576", lambda: scenes.obb_pile(256, 16, 256), 240, 30)):
+    import os
+    if os.environ.get('CFGS') and not any(k in name for k in os.environ['CFGS'].split(',')): continue
     sc = make()
     w = sc.populate(mi.create_world(0))
     w.set_stage_timing(True)
