@@ -195,9 +195,15 @@ def main():
     red_dev = "cuda"
     if world_size > 1:
         import torch.distributed as dist
+        if args.transport == "rccl" and torch.cuda.device_count() < world_size:
+            args.transport = "dist"      # ranks share a GPU (a functional check on a small box): RCCL wants one device per rank
         if args.transport == "rccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", device))
-        else:
+            try:
+                dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", device))
+            except Exception as e:      # noqa: BLE001 — every rank sees the same failure (same image, same topology); the run goes on over gloo
+                print(f"bench.py: RCCL process group failed ({e}); neighbour messages via host over gloo", file=sys.stderr)
+                args.transport = "dist"
+        if args.transport != "rccl":
             dist.init_process_group("gloo", rank=rank, world_size=world_size); red_dev = "cpu"
     if world_size != args.gpus:
         if rank == 0:
@@ -321,6 +327,8 @@ def main():
             "note": ("rank 0, timed region: 236 B x contacts x sweeps / HIP-event time of the solve stage on the world's stream; "
                      "rocprofv3 --kernel-trace --stats of the same command: profiles/"),
         }
+        # N > 1: the whole scene's contacts per body (owner-rule counts summed over the ranks); rank 0's local counts cover its tile + ghost strip
+        cpb_timed = (global_counts["contacts"] / max(1, global_counts["bodies"])) if global_counts else counts["num_contacts"] / max(1, counts["num_rigid_bodies"])
         out = {
             "metric": "physics steps/sec at 262144 rigid bodies per GPU (OBB pile, 20 solver iterations)",
             "value": value, "unit": "steps/s", "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup,
@@ -328,10 +336,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": (f"cfg3 obb_pile {gx}x{ny}x{nz} boxes ({total_bodies} bodies in total, {bodies_per_gpu} owned by rank 0), friction 0.5, "
                                     f"{args.iterations} solver iterations, dt=1/120, settled {args.settle} steps before warm-up "
-                                    f"({counts['num_contacts'] / max(1, counts['num_rigid_bodies']):.2f} contacts per body when timed)"),
+                                    f"({cpb_timed:.2f} contacts per body when timed)"),
                        "settle_steps": args.settle, "settle_is_standard": args.settle == SETTLE_STEPS,
                        "bodies_per_gpu": bodies_per_gpu, "contacts": counts["num_contacts"], "manifolds": counts["num_collisions"],
-                       "contacts_per_body": counts["num_contacts"] / max(1, counts["num_rigid_bodies"]),
+                       "contacts_per_body": cpb_timed,
                        "broadphase_overlaps": counts["num_broadphase_overlaps"], "colors": counts["num_colors"],
                        "global_counts": global_counts, "sharding": sharding_note},
             "roofline": roofline,
