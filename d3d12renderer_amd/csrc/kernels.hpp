@@ -637,30 +637,47 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
     const uint32_t numSmall = cellLower[gp->numCells];
     uint32_t overlaps = 0, nhit = 0, runBucket = 0, runCount = 0;
     uint64_t* mybuf = buf + threadIdx.x * kLargeBuf;
-    // blockIdx.y = large collider slot (grid-strided), x-dimension strides over all colliders: coalesced AABB reads
-    for (uint32_t l = blockIdx.y; l < nl; l += gridDim.y) {
-        uint32_t i = largeList[l];
-        float4 amn = aabbMin[i], amx = aabbMax[i];
-        // candidates: the cell-sorted small colliders [0, numSmall) (contiguous rows) and then the large list itself — not all nc colliders:
-        // the dead ones of a sharded world (most of them, in a many-tile scene) are in neither
-        for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < numSmall + nl; q += gridDim.x * blockDim.x) {
-            const bool small = q < numSmall;
-            const uint32_t j = small ? vals[q] : largeList[q - numSmall];
-            bool ok = small || j > i;          // large-large pairs once, from the lower index
-            float4 bmn = small ? sMin[q] : aabbMin[j], bmx = small ? sMax[q] : aabbMax[j];
-            bool ov = ok && aabbOverlap(amn, amx, bmn, bmx);
-            uint64_t pk = 0;
-            bool want = ov && pairKey(i, amn, amx, j, bmn, bmx, axis, pk, inter);
-            overlaps += ov ? 1u : 0u;
-            if (want) {
-                { const uint32_t bk = (uint32_t)(pk >> 58); if (bk != runBucket && runCount) { atomicAdd(&bhist[runBucket], runCount); runCount = 0; } runBucket = bk; ++runCount; }
-                if (nhit < kLargeBuf) mybuf[nhit] = pk;
-                else {
-                    const uint32_t o = atomicAdd(&ovfCount, 1u);
-                    if (o < kPairOverflow) ovf[o] = pk;
-                    else { uint32_t slot = atomicAdd(&sc->numPairs, 1u); if (slot < pairCap) pairKeys[slot] = pk; }
+    // One lane per CANDIDATE — the cell-sorted small colliders [0, numSmall) (contiguous rows) and then the large list itself, not all
+    // nc colliders: the dead ones of a sharded world are in neither — which it loads once and tests against every large collider,
+    // 256 of them staged in LDS at a time (a few walls and a ground in a pile; hundreds of terrain tiles under vehicles).
+    constexpr uint32_t kSlice = 64;
+    __shared__ float4 lMin[kSlice], lMax[kSlice];
+    __shared__ uint32_t lIdx[kSlice];
+    for (uint32_t q0 = blockIdx.x * blockDim.x; q0 < numSmall + nl; q0 += gridDim.x * blockDim.x) {
+        const uint32_t q = q0 + threadIdx.x;
+        const bool have = q < numSmall + nl, small = q < numSmall;
+        uint32_t j = 0; float4 bmn = make_float4(0, 0, 0, 0), bmx = bmn;
+        if (have) { j = small ? vals[q] : largeList[q - numSmall]; bmn = small ? sMin[q] : aabbMin[j]; bmx = small ? sMax[q] : aabbMax[j]; }
+        for (uint32_t l0 = blockIdx.y * kSlice; l0 < nl; l0 += gridDim.y * kSlice) {   // blockIdx.y: a 64-wide slice of the large list (more workgroups, shorter loops)
+            __syncthreads();
+            if (threadIdx.x < kSlice && l0 + threadIdx.x < nl) { const uint32_t i = largeList[l0 + threadIdx.x]; lIdx[threadIdx.x] = i; lMin[threadIdx.x] = aabbMin[i]; lMax[threadIdx.x] = aabbMax[i]; }
+            __syncthreads();
+            const uint32_t n = min(kSlice, nl - l0);
+            if (!have) continue;
+            // pass 1: which of the staged large boxes overlap mine (a cheap, convergent loop); pass 2: only those — a hit costs ~10 x a
+            // test, and with the hits handled inside the first loop every lane of a wave paid for every other lane's hits
+            for (uint32_t w0 = 0; w0 < n; w0 += 64u) {
+                unsigned long long hitMask = 0ull;
+                const uint32_t m = min(64u, n - w0);
+                for (uint32_t l = 0; l < m; ++l) {
+                    const bool ok = small || j > lIdx[w0 + l];          // large-large pairs once, from the lower index
+                    if (ok && aabbOverlap(lMin[w0 + l], lMax[w0 + l], bmn, bmx)) hitMask |= 1ull << l;
                 }
-                ++nhit;
+                overlaps += (uint32_t)__popcll(hitMask);
+                while (hitMask) {
+                    const uint32_t l = w0 + (uint32_t)__ffsll((long long)hitMask) - 1u;
+                    hitMask &= hitMask - 1ull;
+                    uint64_t pk = 0;
+                    if (!pairKey(lIdx[l], lMin[l], lMax[l], j, bmn, bmx, axis, pk, inter)) continue;
+                    { const uint32_t bk = (uint32_t)(pk >> 58); if (bk != runBucket && runCount) { atomicAdd(&bhist[runBucket], runCount); runCount = 0; } runBucket = bk; ++runCount; }
+                    if (nhit < kLargeBuf) mybuf[nhit] = pk;
+                    else {
+                        const uint32_t o = atomicAdd(&ovfCount, 1u);
+                        if (o < kPairOverflow) ovf[o] = pk;
+                        else { uint32_t slot = atomicAdd(&sc->numPairs, 1u); if (slot < pairCap) pairKeys[slot] = pk; }
+                    }
+                    ++nhit;
+                }
             }
         }
     }
@@ -748,8 +765,8 @@ __global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ 
         // threshold = upper edge of the highest bin b whose bins ABOVE hold <= limit colliders while b itself would exceed it: a suffix
         // sum over the 256 bins (wave shuffles + the 4 wave totals) instead of a serial walk
         __shared__ uint32_t wsum[4];
-        __shared__ float thrShared;
-        if (t == 0) thrShared = 0.f;
+        __shared__ float thrShared, thrShared2;
+        if (t == 0) { thrShared = 0.f; thrShared2 = 0.f; }
         uint32_t suf = hist[t];                                         // inclusive suffix sum within the wave
 #pragma unroll
         for (uint32_t d = 1; d < 64u; d <<= 1) { uint32_t o = (uint32_t)__shfl_down((int)suf, d, 64); if (lane + d < 64u) suf += o; }
@@ -766,10 +783,17 @@ __global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ 
             limit = max(8u, min(limit, costCap));
             const uint32_t above = suf - hist[t];                       // colliders in bins > t
             if (above <= limit && suf > limit) thrShared = extentBinUpper(t);
+            // A second candidate with a much larger budget of "large" colliders: worth it only where the sizes are bimodal — a few hundred
+            // terrain tiles among tens of thousands of vehicle parts (cfg5) would otherwise set the cell size, every cell then holds a whole
+            // vehicle and the column scans do 64 x the tests (k_bp_pairs_grid 102 us for 22 k colliders).  The brute-force pass over the
+            // large ones streams numLarge x live boxes; it stays under the same cost cap.
+            const uint32_t limit2 = max(limit, min(live / 32u, costCap));
+            if (above <= limit2 && suf > limit2) thrShared2 = extentBinUpper(t);
         }
         __syncthreads();
         if (t == 0) {
-            const float thr = thrShared;
+            float thr = thrShared;
+            if (thrShared2 > 0.f && thrShared2 <= 0.5f * thr) thr = thrShared2;   // only when the cells shrink at least 2 x (8 x fewer candidates each)
             for (int w = 1; w < 4; ++w) for (int a = 0; a < 6; ++a) b6[a] = a < 3 ? min(b6[a], red[w][a]) : max(b6[a], red[w][a]);
             float cell = thr * 1.001f + 1e-6f;
             float lo[3], hi[3];

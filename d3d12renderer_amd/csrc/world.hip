@@ -229,7 +229,7 @@ struct mi_world {
     int runStep(const mi_step_settings& s, float dt, bool speculative);
     void mirrorSchedule();
     // speculative (single read-back) stepping: upper bounds come from the last valid step
-    struct LastCounts { uint32_t numPairs = 0, numManifolds = 0, numContacts = 0, numCells = 0, colorRounds = 0, numSmall = 0; } last;
+    struct LastCounts { uint32_t numPairs = 0, numManifolds = 0, numContacts = 0, numCells = 0, colorRounds = 0, numSmall = 0, numLarge = 0; } last;
     bool specEnabled = true, haveEstimates = false;
     uint32_t specRetries = 0, specSteps = 0, totalSteps = 0, colorRoundsLaunched = 0;
     uint32_t sapAxis = 0;        // sorting axis for the next step (collision_broad.cpp:443-444), host copy
@@ -834,7 +834,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             const uint32_t smallBound = spec ? std::min(nc, bound(last.numSmall, 4096)) : nc;
             const uint32_t bpc = (divUp(smallBound, kGridChunks * 256u) + 7u) & ~7u;   // a multiple of 8 (XCD-contiguous block order in k_bp_pairs_grid)
             k_bp_pairs_grid<<<5u * bpc, B, 0, st>>>(nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
-            k_bp_pairs_large<<<dim3(std::min(divUp(smallBound, B), 256u), 16), B, 0, st>>>(nc, largeList.p, aabbMin.p, aabbMax.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
+            k_bp_pairs_large<<<dim3(std::min(divUp(smallBound + 1024u, B), 4096u), std::min(16u, std::max(1u, divUp(spec ? last.numLarge + last.numLarge / 4u : 1024u, 64u)))), B, 0, st>>>(nc, largeList.p, aabbMin.p, aabbMax.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
             k_pair_finish<<<1, 256, 0, st>>>(shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu, nc, nblk, attempt == 0 ? axisPartials.p : nullptr, blockBounds.p, attempt == 0 ? gridNext : nullptr, cellCapNext);
             if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
             int rc = readScalars(); if (rc != MI_OK) return rc;
@@ -1219,7 +1219,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     if (nmBound) { tabCur ^= 1; tabValid = true; } else tabValid = false;
     hostStale = true;
     last.numPairs = hs.numPairs; last.numManifolds = hs.numManifolds; last.numContacts = hs.numContacts; last.numCells = hs.numCells;
-    last.numSmall = nc - std::min(nc, hs.numLarge + hs.numDead);
+    last.numSmall = nc - std::min(nc, hs.numLarge + hs.numDead); last.numLarge = hs.numLarge;
     for (int k = 0; k < 3; ++k) shard.owned[k] = hs.shardOwned[k];
     shard.flagsSwapPending = shard.enabled; shard.stepOpen = false;
     static const bool xcdStats = std::getenv("MI_XCD_STATS") != nullptr;   // development: how many bodies stayed XCD-local
