@@ -489,6 +489,12 @@ class World:
 
     SOLVER_KERNELS = ("k_contact_solve", "k_contact_solve_flow", "k_contact_solve_persist", "k_solve_flow_islands", "k_contact_solve_persist", "k_contact_solve_persist")
 
+    def step_graph_stats(self):
+        """mi_debug_step_graph_stats: (enabled, steps replayed as a HIP graph, graphs captured, speculative steps launched plainly)."""
+        out = (C.c_uint32 * 4)()
+        self.L.check(self.L.fn("debug_step_graph_stats")(self.h, out), "debug_step_graph_stats")
+        return tuple(int(x) for x in out)
+
     def solver_kind(self):
         """mi_world_get_solver_kind: 0 per-colour launches, 1 flow, 2 persistent, 3 flow + joint islands, 4 persistent, XCD-partitioned, 5 persistent, all tiles on one XCD (small piles)."""
         k = C.c_uint32()

@@ -855,18 +855,18 @@ struct JointType {
         if (pods.empty() || !dPods) return hipSuccess;
         return hipMemcpyAsync(dPods, pods.data(), pods.size() * sizeof(typename J::Pod), hipMemcpyHostToDevice, st);
     }
-    void launchInit(uint32_t dummy, const mi::BodyView& bv, float dt, hipStream_t st) {
+    void launchInit(mi::Launcher& L, uint32_t dummy, const mi::BodyView& bv, float dt, hipStream_t st) {
         uint32_t n = (uint32_t)pods.size();
-        if (n) mi::k_joint_init<J><<<(n + 63) / 64, 64, 0, st>>>(n, dummy, dPods, dBodies, dUpd, dAcc, bv, dt);
+        if (n) L.launch(mi::k_joint_init<J>, dim3((n + 63) / 64), dim3(64), 0, st, n, dummy, dPods, dBodies, dUpd, dAcc, bv, dt);
     }
-    void launchSolve(const mi::BodyView& bv, hipStream_t st) {
+    void launchSolve(mi::Launcher& L, const mi::BodyView& bv, hipStream_t st) {
         if (order.empty()) return;
         for (int c = 0; c < 64; ++c) {
             uint32_t s0 = colorOffsets[c], s1 = colorOffsets[c + 1];
-            if (s1 > s0) mi::k_joint_solve<J><<<(s1 - s0 + 63) / 64, 64, 0, st>>>(s0, s1, dOrder, dBodies, dUpd, bv);
+            if (s1 > s0) L.launch(mi::k_joint_solve<J>, dim3((s1 - s0 + 63) / 64), dim3(64), 0, st, s0, s1, dOrder, dBodies, dUpd, bv);
         }
         uint32_t o0 = colorOffsets[64], o1 = colorOffsets[65];
-        if (o1 > o0) mi::k_joint_solve_serial<J><<<1, 64, 0, st>>>(o0, o1, dOrder, dBodies, dUpd, bv);
+        if (o1 > o0) L.launch(mi::k_joint_solve_serial<J>, dim3(1), dim3(64), 0, st, o0, o1, dOrder, dBodies, dUpd, bv);
     }
 };
 

@@ -2468,7 +2468,7 @@ __global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, ShardBufs in,
 //     and read with single relaxed agent-scope accesses: a reader that sees the tag sees the sum of the same store — no fences
 //     (a release / acquire pair at agent scope would write back / invalidate the L2 around every record);
 //   * records are never reset: a reader ignores tags of older generations, and the ticket counter only ever grows
-//     (`ticketBase` = tickets handed out before this launch).
+//     (`state[0]` = tickets handed out before this launch, `state[1]` = generation; the host clears everything long before the 30 generation bits wrap).
 // T = uint32_t (W = 1) or a 64-bit word holding two independent 32-bit sums side by side (W = 2: the narrow phase's packed
 // (manifold flag, contact count); both totals stay below 2^32, so the halves never carry into each other).
 constexpr uint32_t kScanThreads = 256;
@@ -2481,16 +2481,29 @@ __device__ __forceinline__ void scanPublish(unsigned long long* rec, uint32_t su
 template <typename T> struct ScanWords { static constexpr uint32_t W = sizeof(T) / 4; };
 template <typename T>
 __global__ __launch_bounds__(kScanThreads) void k_exclusive_scan(T* __restrict__ in, T* __restrict__ out, uint32_t n, unsigned long long* records,
-                                                                 uint32_t* ticket, uint32_t ticketBase, uint32_t gen, uint32_t zeroInput /* histograms: leave the input cleared for its next use */) {
+                                                                 uint32_t* ticket, uint32_t* state /* [0] tickets handed out before this launch, [1] generation: kept ON THE DEVICE so that
+                                                                 the launch has the same arguments every step (a captured HIP graph replays it) */, uint32_t zeroInput /* histograms: leave the input cleared for its next use */) {
     constexpr uint32_t W = ScanWords<T>::W;
     constexpr uint32_t kScanItems = ScanItems<T>::N, kScanTile = ScanItems<T>::Tile;
     __shared__ uint32_t sTile;
     __shared__ T sWave[kScanThreads / 64];
     __shared__ T sPrefix;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    if (tid == 0) sTile = atomicAdd(ticket, 1u) - ticketBase;
+    __shared__ uint32_t sGen;
+    if (tid == 0) {
+        // the state is read BEFORE the ticket is taken (the ticket address depends on it), and only the workgroup holding the launch's
+        // LAST ticket advances it — by then every other workgroup of the launch has taken its ticket, i.e. has read the state
+        const uint32_t ticketBase = __hip_atomic_load(&state[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t g = __hip_atomic_load(&state[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t t = atomicAdd(ticket + ((ticketBase ^ g) >> 31 >> 1), 1u) - ticketBase;
+        sTile = t; sGen = g;
+        if (t == gridDim.x - 1u) {
+            __hip_atomic_store(&state[0], ticketBase + gridDim.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&state[1], (g + 1u) & 0x3FFFFFFFu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
     __syncthreads();
-    const uint32_t tile = sTile;
+    const uint32_t tile = sTile, gen = sGen;
     // striped loads (thread t takes items t, t + 256, ...: every load instruction reads one contiguous span), then blocked through LDS?  Not needed:
     // a prefix sum only needs each THREAD's items to be consecutive in the order it sums them, so thread t owns the kScanItems consecutive items
     // starting at base and reads them as 16-byte vectors

@@ -22,6 +22,7 @@
 #include "../../include/mi_constraints.h"
 #include "kernels.hpp"
 #include "gjk.hpp"
+#include "launcher.hpp"
 #include "joints.hpp"
 #include "heightmap.hpp"
 #include "cloth.hpp"
@@ -63,21 +64,24 @@ struct DBuf {
 // launches; the records are zeroed when (re)allocated and when the 32-bit generation wraps.
 template <typename T>
 struct DeviceScan {
-    DBuf<unsigned long long> records; DBuf<uint32_t> ticket;
-    uint32_t ticketBase = 0, gen = 0;
-    hipError_t run(T* in, T* out, uint32_t n, hipStream_t st, bool zeroInput = false) {
+    DBuf<unsigned long long> records; DBuf<uint32_t> ticket;   // ticket.p[0] = ticket counter, [1] = tickets handed out before the next launch, [2] = generation
+    uint32_t launches = 0;   // upper bound of the launches since the last clear (dry signature passes count too)
+    bool clearPending = false;
+    hipError_t run(Launcher& L, T* in, T* out, uint32_t n, hipStream_t st, bool zeroInput = false) {
         const uint32_t tiles = (n + ScanItems<T>::Tile - 1) / ScanItems<T>::Tile;
         if (!tiles) return hipSuccess;
         hipError_t e;
-        if (!ticket.p) { if ((e = ticket.ensure(1)) != hipSuccess) return e; if ((e = hipMemsetAsync(ticket.p, 0, sizeof(uint32_t), st)) != hipSuccess) return e; ticketBase = 0; }
-        bool clear = false;
-        if (++gen >= (1u << 30)) { gen = 1u; clear = true; }       // the tag holds 30 generation bits
+        if (!ticket.p) { if ((e = ticket.ensure(4)) != hipSuccess) return e; clearPending = true; }
+        if (++launches >= (1u << 29)) clearPending = true;       // the tag holds 30 generation bits
         const size_t words = (size_t)tiles * ScanWords<T>::W;
-        if (records.cap < words) { if ((e = records.ensure(words)) != hipSuccess) return e; clear = true; }
-        if (clear && (e = hipMemsetAsync(records.p, 0, records.cap * sizeof(unsigned long long), st)) != hipSuccess) return e;
-        k_exclusive_scan<T><<<tiles, kScanThreads, 0, st>>>(in, out, n, records.p, ticket.p, ticketBase, gen, zeroInput ? 1u : 0u);
-        ticketBase += tiles;
-        return hipGetLastError();
+        if (records.cap < words) { if ((e = records.ensure(words)) != hipSuccess) return e; clearPending = true; }
+        if (clearPending) {
+            if ((e = L.memsetAsync(records.p, 0, records.cap * sizeof(unsigned long long), st)) != hipSuccess) return e;
+            if ((e = L.memsetAsync(ticket.p, 0, 4 * sizeof(uint32_t), st)) != hipSuccess) return e;
+            if (!L.dry) { clearPending = false; launches = 1; }   // (a signature pass enqueues nothing: the clear is still owed)
+        }
+        L.launch(k_exclusive_scan<T>, dim3(tiles), dim3(kScanThreads), 0, st, in, out, n, records.p, ticket.p, ticket.p + 1, zeroInput ? 1u : 0u);
+        return L.firstError;
     }
 };
 
@@ -97,6 +101,16 @@ struct HHull { std::vector<V3> verts; std::vector<uint32_t> tris; V3 mn, mx; };
 struct MassProps { M3 inertia; V3 cog; float mass; };
 
 static uint32_t divUp(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+
+// kernel arguments with padding bytes enter a step's signature field by field (launcher.hpp)
+namespace mi {
+template <> inline void sigMix<InterSink>(Launcher& L, const InterSink& v) { L.pod(v.keys); L.pod(v.cap); L.pod(v.count); }
+template <> inline void sigMix<HmOut>(Launcher& L, const HmOut& v) { L.pod(v.sc); L.pod(v.pairCap); L.pod(v.pairsA); L.pod(v.pairsB); L.pod(v.npPacked); L.pod(v.npNormal); L.pod(v.npPoints); }
+template <> inline void sigMix<HeightmapParams>(Launcher& L, const HeightmapParams& v) {
+    L.pod(v.heights); L.pod(v.mips); L.pod(v.chunkSlot); L.pod(v.chunksPerDim); L.pod(v.chunkSize); L.pod(v.invChunkSize); L.pod(v.chunkScale); L.pod(v.heightScale);
+    L.pod(v.invAmplitudeScale); L.pod(v.minX); L.pod(v.minY); L.pod(v.minZ); L.pod(v.restitution); L.pod(v.friction);
+}
+}
 
 struct mi_world {
     int device = 0;
@@ -218,6 +232,7 @@ struct mi_world {
     uint32_t profLaunches = 0; float profKernelMs = 0.f; uint64_t profSlots = 0, profContacts = 0;
     bool usesGjk = false;   // any capsule / cylinder / hull collider present (decided at upload)
     uint32_t lastNumCells = kMaxCells;   // cells covered by the histogram/scan (host-side bound)
+    uint32_t lastCellCap = 0;            // sticky length of the cell scan (a few thousand cells more than the grid has: zeros)
     uint64_t* pairsIn = nullptr;          // bucket-partitioned pair keys of the last step (pairKeys or pairKeysS)
 
     int init(int dev);
@@ -227,6 +242,19 @@ struct mi_world {
     int download();
     int stepInternal(const mi_step_settings& s, float dt);
     int runStep(const mi_step_settings& s, float dt, bool speculative);
+    // Every enqueue of a step goes through L (launcher.hpp).  Steps of a small scene are replayed as ONE HIP graph when their
+    // signature (every launch, pointer, size and scalar) equals that of a captured step: ~35 launches of 2-5 us kernels are bound by
+    // the host's launch rate otherwise.
+    Launcher L;
+    struct StepGraph { uint64_t sig = 0; hipGraphExec_t exec = nullptr; uint64_t lastUse = 0; };
+    std::vector<StepGraph> stepGraphs;   // never evicted while the world lives (destroying an executable graph next to live ones corrupted replays under the HIP 7.0 runtime); at most kMaxStepGraphs
+    static constexpr size_t kMaxStepGraphs = 64;
+    bool graphsEnabled = true, graphsForAll = false, graphNoEvents = false, graphNoCapture = false; uint32_t graphMaxColliders = 32768;
+    uint64_t graphLastSig = 0, graphPrevSig = 0, graphUseClock = 0;   // signatures of the last two steps (the buffer sets alternate: a steady scene repeats with period 2)
+    uint32_t graphHits = 0, graphCaptures = 0, graphPlain = 0; bool graphDebug = false;
+    std::vector<uint64_t> graphPrevOps, graphPrevOps2;
+    DBuf<uint32_t> readbackSeqDev;   // the read-back sequence number lives on the device (k_publish_readback increments it): the launch has constant arguments
+    void dropStepGraphs() { for (StepGraph& g : stepGraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); stepGraphs.clear(); graphLastSig = graphPrevSig = 0; }
     void mirrorSchedule();
     // speculative (single read-back) stepping: upper bounds come from the last valid step
     struct LastCounts { uint32_t numPairs = 0, numManifolds = 0, numContacts = 0, numCells = 0, colorRounds = 0, numSmall = 0, numLarge = 0; } last;
@@ -254,6 +282,15 @@ int mi_world::init(int dev) {
         spinReadback = false;
     }
     std::memset(hsPinned, 0, sizeof(Readback));
+    HIP_TRY(readbackSeqDev.ensure(1)); HIP_TRY(hipMemsetAsync(readbackSeqDev.p, 0, sizeof(uint32_t), stream));
+    {   // Replays diverged from plain launches under the HIP 7.0.x runtime (the one PyTorch 2.10 bundles; whole joint islands / history
+        // colours off after ~70-120 steps, tools/dbg_graph2.py), never under 7.2: graphs are used from 7.2 on (MI_GRAPH=force overrides).
+        int ver = 0; if (hipRuntimeGetVersion(&ver) != hipSuccess) ver = 0;
+        graphsEnabled = ver >= 70200000;
+    }
+    if (const char* g = getenv("MI_GRAPH")) { const std::string v(g); if (v == "0") graphsEnabled = false; if (v == "force") graphsEnabled = true; graphsForAll = v == "all"; }   // 0: never replay steps as HIP graphs; all: also the large scenes
+    if (const char* g = getenv("MI_GRAPH_MAX_COLLIDERS")) graphMaxColliders = (uint32_t)strtoul(g, nullptr, 0);
+    graphDebug = getenv("MI_GRAPH_DEBUG") != nullptr; graphNoEvents = getenv("MI_GRAPH_NOEVENTS") != nullptr; graphNoCapture = getenv("MI_GRAPH_NOCAPTURE") != nullptr;
     if (const char* sr = getenv("MI_READBACK")) spinReadback = spinReadback && std::string(sr) != "copy";   // MI_READBACK=copy: hipMemcpyAsync + hipStreamSynchronize
     stageEvents = getenv("MI_STAGE_EVENTS") && getenv("MI_STAGE_EVENTS")[0] != '0';   // default: only the whole step and the solve stage are timed (mi_world_set_stage_timing)
     const char* sw = getenv("MI_XCD_SWIZZLE");
@@ -295,6 +332,8 @@ mi_world::~mi_world() {
     if (hsPinned) (void)hipHostFree(hsPinned);
     if (shard.sentHost) (void)hipHostFree(shard.sentHost);
     shardReleaseComm();
+    if (graphDebug) std::fprintf(stderr, "[mi_physics] step graphs: %u replayed, %u captured, %u plain speculative steps, %llu steps in total\n", graphHits, graphCaptures, graphPlain, (unsigned long long)totalSteps);
+    dropStepGraphs();
     if (stream) (void)hipStreamDestroy(stream);
     for (auto& e : profEvents) (void)hipEventDestroy(e);
     for (auto& e : ev) if (e) (void)hipEventDestroy(e);
@@ -432,6 +471,7 @@ static float4 h4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 
 int mi_world::upload() {
     recalcProperties();
+    dropStepGraphs();
     shard.prevValid = false; shard.flagsSwapPending = false;
     uint32_t nb = (uint32_t)bodies.size(), nc = (uint32_t)colliders.size();
     std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), fo(nb), to(nb), cim(nb), ii(3 * (size_t)nb), prm(nb);
@@ -615,11 +655,15 @@ __global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlag
 // End-of-step read-back without a copy engine round trip and without a driver wake-up: one workgroup writes the scalars and the
 // colouring round flags straight into pinned host memory, fences at system scope and then publishes the step's sequence number,
 // which the host thread spins on.
-__global__ __launch_bounds__(256) void k_publish_readback(const uint32_t* __restrict__ src, uint32_t words, uint32_t* dstHost, uint32_t seqWord, uint32_t seq) {
+__global__ __launch_bounds__(256) void k_publish_readback(const uint32_t* __restrict__ src, uint32_t words, uint32_t* dstHost, uint32_t seqWord, uint32_t* seqDev) {
     for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) dstHost[i] = src[i];
     __threadfence_system();
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(dstHost + seqWord, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) {
+        uint32_t seq = *seqDev + 1u; if (seq == 0u) seq = 1u;   // never 0 (the host counts the same way)
+        *seqDev = seq;
+        __hip_atomic_store(dstHost + seqWord, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
 }
 __global__ void k_reset_pair_counters(StepScalars* sc, Shards* sh) {
     uint32_t t = threadIdx.x;
@@ -772,34 +816,47 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     // The step (events 0 / 8) and the solve stage (6 / 7) are always timed.  A recorded event is a barrier packet of its own (~6 us of
     // idle device per event: 24 us per step); where the stage is ONE kernel the events ride on that kernel's dispatch instead
     // (hipExtLaunchKernelGGL start / stop events): no packet, no gap.  `attached` = this step's 0 / 6 / 7 / 8 are attached ones.
-    bool attached = !debugSync;
+    bool attached = !debugSync;   // (set per pass below: a graph cannot hold the attached form, it gets recorded events)
     auto mark = [&]() {
         const int id = evi++;
         if (attached && (id == 0 || id == 6 || id == 7 || id == 8)) return;
         if (!stageEvents && id != 0 && id != 6 && id != 7 && id != 8) return;   // by default only the step and the solve stage are timed
-        (void)hipEventRecord(ev[id], st);
+        if (L.hashing && !stageEvents && graphNoEvents) return;
+        L.eventRecord(ev[id], st);
         if (debugSync) { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) std::fprintf(stderr, "[mi_physics] step %llu (%s): stage ending at mark %d: %s\n", (unsigned long long)totalSteps, spec ? "speculative" : "synchronous", evi - 1, hipGetErrorString(e)); }
     };
     auto bound = [](uint32_t last, uint32_t slack) { return last + last / 8u + slack; };
     auto readScalars = [&]() -> int { HIP_TRY(hipMemcpyAsync(&hs, sc, sizeof(StepScalars), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); return MI_OK; };
 
+    // Passes over the enqueue section below (launcher.hpp): a speculative step of a small scene first runs it DRY (signature only); a known
+    // signature is replayed from its captured graph, one seen in the previous step as well is captured now, anything else runs plainly.
+    static const bool debugSyncG = debugSync;
+    const bool graphStep = spec && graphsEnabled && !profileSolve && !xcdFaultTest && !flowFaultTest && !debugSyncG && !launchFallbackSteps &&
+                           (graphsForAll || nc <= graphMaxColliders) && readbackSeqDev.p;
+    enum { PASS_PLAIN, PASS_DRY, PASS_CAPTURE };
+    int pass = graphStep ? PASS_DRY : PASS_PLAIN;
+enqueue_section:
+    evi = 0;
+    L.trace = graphDebug;
+    L.begin(pass == PASS_DRY, pass != PASS_PLAIN);
+    attached = !debugSync && pass == PASS_PLAIN;
     mark();  // 0
     if (attached) hipExtLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(128), 0, st, ev[0], nullptr, 0, sc, shards.p, roundFlagsPtr(), keyCount.p);
-    else k_reset_scalars<<<1, 128, 0, st>>>(sc, shards.p, roundFlagsPtr(), keyCount.p);
+    else L.launch(k_reset_scalars, dim3(1), dim3(128), 0, st, sc, shards.p, roundFlagsPtr(), keyCount.p);
     if (shard.enabled && nb) {
         HIP_TRY(shard.activePrev.ensure(std::max(nb, 1u)));
         if (shard.flagsSwapPending) { std::swap(shard.active.p, shard.activePrev.p); std::swap(shard.active.cap, shard.activePrev.cap); shard.flagsSwapPending = false; }   // (not on the synchronous re-run of a step)
-        if (!shard.prevValid) { HIP_TRY(hipMemsetAsync(shard.activePrev.p, 1, nb, st)); shard.prevValid = true; }   // after an upload / an outside write: every body is copied once
-        k_shard_classify<<<divUp(nb, B), B, 0, st>>>(nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, shards.p, shard.root.p);
+        if (!shard.prevValid) { HIP_TRY(L.memsetAsync(shard.activePrev.p, 1, nb, st)); if (!L.dry) shard.prevValid = true; }   // after an upload / an outside write: every body is copied once
+        L.launch(k_shard_classify, dim3(divUp(nb, B)), dim3(B), 0, st, nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, shards.p, shard.root.p);
     }
     if (nc) {
-        k_world_colliders<<<divUp(nc, B), B, 0, st>>>(nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
+        L.launch(k_world_colliders, dim3(divUp(nc, B)), dim3(B), 0, st, nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis, shard.enabled ? shard.active.p : nullptr, shard.activePrev.p);
         if (heightmap) {   // terrain contacts per collider, their offsets and totals (they join the pair list after the collider-pair narrow phase)
-            k_hm_contacts<false><<<divUp(nc, 4), 256, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
-            k_hm_slow<false><<<divUp(nc, 64), 64, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
-            HIP_TRY(scanTerrain.run(hmPacked.p, hmScan.p, nc, st));
-            k_hm_totals<<<1, 1, 0, st>>>(nc, hmPacked.p, hmScan.p, sc);
+            L.launch(k_hm_contacts<false>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
+            L.launch(k_hm_slow<false>, dim3(divUp(nc, 64)), dim3(64), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
+            HIP_TRY(scanTerrain.run(L, hmPacked.p, hmScan.p, nc, st));
+            L.launch(k_hm_totals, dim3(1), dim3(1), 0, st, nc, hmPacked.p, hmScan.p, sc);
         }
     }
     mark();  // 1
@@ -809,21 +866,21 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         uint32_t nblk = divUp(nc, 256);
         // the cell table (histogram + scan) covers cellCap cells; k_bp_grid_setup enlarges the cells if the grid would need more
         const uint32_t cellCapNext = std::min<uint32_t>(kMaxCells, std::max<uint32_t>(1u << 16, 4u * nc));
-        const uint32_t cellCap = gridValid ? gridNextCells + 1u : spec ? std::min<uint32_t>(kMaxCells, std::max<uint32_t>(1u << 16, 2u * last.numCells)) : kMaxCells;
+        const uint32_t cellCap = gridValid ? (lastCellCap = std::min<uint32_t>(kMaxCells, (lastCellCap > gridNextCells && lastCellCap - gridNextCells <= 8192u) ? lastCellCap : ((gridNextCells + 1u + 4095u) & ~4095u))) : spec ? std::min<uint32_t>(kMaxCells, std::max<uint32_t>(1u << 16, 2u * last.numCells)) : kMaxCells;
         GridParams* gridUse = grid.p + gridCur; GridParams* gridNext = grid.p + (gridCur ^ 1u);
         if (gridValid) {
             // the grid prepared at the end of the previous step (k_pair_finish): one fused kernel instead of five launches; the cell histogram
             // is all zero here (cleared once at upload, and every scan clears the cells it has read)
-            k_bp_prepare<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, gridUse, axisPartials.p, shards.p, sc, largeList.p, isLarge.p, blockBounds.p, cellKeys.p, cellRanks.p, cellCount.p, shard.enabled ? shard.activePrev.p : nullptr);
+            L.launch(k_bp_prepare, dim3(nblk), dim3(256), 0, st, nc, aabbMin.p, aabbMax.p, gridUse, axisPartials.p, shards.p, sc, largeList.p, isLarge.p, blockBounds.p, cellKeys.p, cellRanks.p, cellCount.p, shard.enabled ? shard.activePrev.p : nullptr);
         } else {
-            k_axis_partials<<<nblk, 256, 0, st>>>(nc, aabbMin.p, aabbMax.p, axisPartials.p, shards.p);
-            k_bp_threshold<<<1, 256, 0, st>>>(nc, shards.p, sc);
-            k_bp_classify<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, sc, largeList.p, isLarge.p, blockBounds.p);
-            k_bp_grid_setup<<<1, 256, 0, st>>>(nc, nblk, cellCap, blockBounds.p, sc, gridUse);
-            k_bp_cell_ids<<<divUp(nc, B), B, 0, st>>>(nc, aabbMin.p, aabbMax.p, isLarge.p, gridUse, cellKeys.p, cellRanks.p, cellCount.p);
+            L.launch(k_axis_partials, dim3(nblk), dim3(256), 0, st, nc, aabbMin.p, aabbMax.p, axisPartials.p, shards.p);
+            L.launch(k_bp_threshold, dim3(1), dim3(256), 0, st, nc, shards.p, sc);
+            L.launch(k_bp_classify, dim3(divUp(nc, B)), dim3(B), 0, st, nc, aabbMin.p, aabbMax.p, sc, largeList.p, isLarge.p, blockBounds.p);
+            L.launch(k_bp_grid_setup, dim3(1), dim3(256), 0, st, nc, nblk, cellCap, blockBounds.p, sc, gridUse);
+            L.launch(k_bp_cell_ids, dim3(divUp(nc, B)), dim3(B), 0, st, nc, aabbMin.p, aabbMax.p, isLarge.p, gridUse, cellKeys.p, cellRanks.p, cellCount.p);
         }
-        HIP_TRY(scanCells.run(cellCount.p, cellLower.p, cellCap, st, true));
-        k_bp_scatter_sorted<<<divUp(nc, B), B, 0, st>>>(nc, cellKeys.p, cellRanks.p, cellLower.p, aabbMin.p, aabbMax.p, cellKeysS.p, cellValsS.p, sMin.p, sMax.p);
+        HIP_TRY(scanCells.run(L, cellCount.p, cellLower.p, cellCap, st, true));
+        L.launch(k_bp_scatter_sorted, dim3(divUp(nc, B)), dim3(B), 0, st, nc, cellKeys.p, cellRanks.p, cellLower.p, aabbMin.p, aabbMax.p, cellKeysS.p, cellValsS.p, sMin.p, sMax.p);
         if (pairKeys.cap == 0) { HIP_TRY(pairKeys.ensure(std::max<size_t>(1u << 16, 8 * (size_t)nc))); }
         if (spec) { HIP_TRY(pairKeys.ensure(bound(last.numPairs, 4096))); }
         if (usesInteractions && interKeys.cap == 0) HIP_TRY(interKeys.ensure(4096));
@@ -833,9 +890,9 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             // sized for the small (grid) colliders expected — in a sharded world most colliders are dead and in no list; more than expected: the workgroups loop
             const uint32_t smallBound = spec ? std::min(nc, bound(last.numSmall, 4096)) : nc;
             const uint32_t bpc = (divUp(smallBound, kGridChunks * 256u) + 7u) & ~7u;   // a multiple of 8 (XCD-contiguous block order in k_bp_pairs_grid)
-            k_bp_pairs_grid<<<5u * bpc, B, 0, st>>>(nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
-            k_bp_pairs_large<<<dim3(std::min(divUp(smallBound + 1024u, B), 4096u), std::min(16u, std::max(1u, divUp(spec ? last.numLarge + last.numLarge / 4u : 1024u, 64u)))), B, 0, st>>>(nc, largeList.p, aabbMin.p, aabbMax.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
-            k_pair_finish<<<1, 256, 0, st>>>(shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu, nc, nblk, attempt == 0 ? axisPartials.p : nullptr, blockBounds.p, attempt == 0 ? gridNext : nullptr, cellCapNext);
+            L.launch(k_bp_pairs_grid, dim3(5u * bpc), dim3(B), 0, st, nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
+            L.launch(k_bp_pairs_large, dim3(std::min(divUp(smallBound + 1024u, B), 4096u), std::min(16u, std::max(1u, divUp(spec ? last.numLarge + last.numLarge / 4u : 1024u, 64u)))), dim3(B), 0, st, nc, largeList.p, aabbMin.p, aabbMax.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
+            L.launch(k_pair_finish, dim3(1), dim3(256), 0, st, shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu, nc, nblk, attempt == 0 ? axisPartials.p : nullptr, blockBounds.p, attempt == 0 ? gridNext : nullptr, cellCapNext);
             if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
             int rc = readScalars(); if (rc != MI_OK) return rc;
             pairBound = hs.numPairs + hs.numHmContacts;   // the terrain contacts are appended to the pair list after the narrow phase
@@ -843,14 +900,14 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             if (attempt == 2) return fail(MI_ERR_DEVICE, "pair pass did not settle");
             if (pairBound > cap) HIP_TRY(pairKeys.ensure((size_t)pairBound + pairBound / 4));   // overflow: grow and redo the pair pass
             if (hs.numInterPairs > interKeys.cap) HIP_TRY(interKeys.ensure((size_t)hs.numInterPairs + hs.numInterPairs / 4));
-            k_reset_pair_counters<<<1, 32, 0, st>>>(sc, shards.p);
+            L.launch(k_reset_pair_counters, dim3(1), dim3(32), 0, st, sc, shards.p);
         }
     }
     mark();  // 2
     // ---------------------------------------------------------------------------------------------- narrow phase
     if (pairBound) {
         HIP_TRY(pairKeysS.ensure(pairKeys.cap));
-        k_pair_partition<<<divUp(pairBound, 1024), 256, 0, st>>>(pairKeys.p, pairKeysS.p, sc);
+        L.launch(k_pair_partition, dim3(divUp(pairBound, 1024)), dim3(256), 0, st, pairKeys.p, pairKeysS.p, sc);
         HIP_TRY(npPacked.ensure(pairBound)); HIP_TRY(npScan.ensure(pairBound)); HIP_TRY(npNormal.ensure(pairBound)); HIP_TRY(npPoints.ensure(4 * (size_t)pairBound));
         HIP_TRY(manPair.ensure(pairBound)); HIP_TRY(manBodies.ensure(pairBound)); HIP_TRY(manInfo.ensure(pairBound));
         HIP_TRY(colWork.ensure(pairBound)); HIP_TRY(color.ensure(pairBound));
@@ -859,17 +916,17 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         const uint32_t narrowBlocks = divUp(pairBound, B);
         const uint32_t queueRegion = divUp(narrowBlocks, kBoxQueues) * B;   // a queue can hold every pair of the workgroups that feed it
         HIP_TRY(boxQueue.ensure((size_t)kBoxQueues * queueRegion));
-        k_narrow<<<narrowBlocks, B, 0, st>>>(pairBound, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p, boxQueue.p);
-        k_narrow_clip<<<kBoxQueues * (queueRegion / B), B, 0, st>>>(queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, boxQueue.p, npPacked.p, npNormal.p, npPoints.p);
+        L.launch(k_narrow, dim3(narrowBlocks), dim3(B), 0, st, pairBound, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p, boxQueue.p);
+        L.launch(k_narrow_clip, dim3(kBoxQueues * (queueRegion / B)), dim3(B), 0, st, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, boxQueue.p, npPacked.p, npNormal.p, npPoints.p);
         // (a GJK-only kernel feeding a queue of hits to an EPA kernel was measured: no gain — the GJK half already needs ~250 VGPRs)
-        if (usesGjk) k_narrow_gjk<<<divUp(pairBound, 64), 64, 0, st>>>(sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
+        if (usesGjk) L.launch(k_narrow_gjk, dim3(divUp(pairBound, 64)), dim3(64), 0, st, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
         if (heightmap) {
             const HmOut hmOut{sc, pairBound, pairKeys.p, pairKeysS.p, npPacked.p, npNormal.p, npPoints.p};
-            k_hm_contacts<true><<<divUp(nc, 4), 256, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut);
-            k_hm_slow<true><<<divUp(nc, 64), 64, 0, st>>>(nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut);
-            k_hm_finish<<<1, 1, 0, st>>>(sc, pairBound);
+            L.launch(k_hm_contacts<true>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut);
+            L.launch(k_hm_slow<true>, dim3(divUp(nc, 64)), dim3(64), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut);
+            L.launch(k_hm_finish, dim3(1), dim3(1), 0, st, sc, pairBound);
         }
-        HIP_TRY(scanPairs.run(reinterpret_cast<unsigned long long*>(npPacked.p), reinterpret_cast<unsigned long long*>(npScan.p), pairBound, st));
+        HIP_TRY(scanPairs.run(L, reinterpret_cast<unsigned long long*>(npPacked.p), reinterpret_cast<unsigned long long*>(npScan.p), pairBound, st));
         if (eventsEnabled) HIP_TRY(manIsNew.ensure(pairBound));
         {   // the NEXT step's colour history: sized and cleared before k_emit_manifolds, which already enters the manifolds that keep their colour
             const uint32_t histBound = spec ? std::min(pairBound, bound(last.numManifolds, 1024)) : pairBound;
@@ -877,20 +934,20 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             uint32_t cap = 1024; while (cap < 2u * histBound) cap <<= 1;
             HIP_TRY(tabKeys[nt].ensure(cap)); HIP_TRY(tabVals[nt].ensure(cap)); HIP_TRY(manKept.ensure(pairBound));
             tabMask[nt] = cap - 1u;
-            HIP_TRY(hipMemsetAsync(tabKeys[nt].p, 0, (size_t)cap * sizeof(unsigned long long), st));
+            HIP_TRY(L.memsetAsync(tabKeys[nt].p, 0, (size_t)cap * sizeof(unsigned long long), st));
         }
-        k_emit_manifolds<<<divUp(pairBound, B), B, 0, st>>>(nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
+        L.launch(k_emit_manifolds, dim3(divUp(pairBound, B)), dim3(B), 0, st, nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
                                                         tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc,
                                                         heightmap ? make_float2(hmParams.restitution, hmParams.friction) : make_float2(0.f, 0.f),
                                                         tabKeys[tabCur ^ 1].p, tabVals[tabCur ^ 1].p, tabMask[tabCur ^ 1], manKept.p);
-        if (shard.enabled) k_shard_count<<<divUp(pairBound, B), B, 0, st>>>(nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc, shards.p);
+        if (shard.enabled) L.launch(k_shard_count, dim3(divUp(pairBound, B)), dim3(B), 0, st, nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc, shards.p);
     }
     // ---------------------------------------------------------------------------------------------- triggers / force fields
     std::vector<mi_event> triggerEvents;
     if (usesInteractions) { int rc = interactions(triggerEvents); if (rc != MI_OK) return rc; }
     mark();  // 3
-    k_integrate_forces<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, make_float3(globalForce.x, globalForce.y, globalForce.z), bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, usesInteractions ? bForceStep.p : bForce.p, bTorque.p,
+    L.launch(k_integrate_forces, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nb, dt, make_float3(globalForce.x, globalForce.y, globalForce.z), bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, usesInteractions ? bForceStep.p : bForce.p, bTorque.p,
                                                        gPos.p, gInvI.p, gVel.p, gVelL.p, bodyOwner.p, shard.enabled ? shard.active.p : nullptr);
     mark();  // 4
     // ---------------------------------------------------------------------------------------------- schedule
@@ -906,7 +963,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     const bool xcdSingle = xcdAble && persistXcdSingle && nmBound && nmBound < xcdMinManifolds && divUp(divUp(nmBound, 64) + kSchedBins + 8, persistWaves / 8u) <= 16u;
     const bool xcdPlan = xcdAble && (nmBound >= xcdMinManifolds || xcdSingle);
     static const uint32_t colorMargin = std::getenv("MI_COLOR_MARGIN") ? (uint32_t)atoi(std::getenv("MI_COLOR_MARGIN")) : 3u;   // extra rounds enqueued beyond the previous step's count
-    uint32_t colorBatch = spec ? std::min<uint32_t>(96u, last.colorRounds + std::max(colorMargin, last.colorRounds / 4u)) : 20u;   // converged rounds exit at once
+    uint32_t colorBatch = spec ? std::min<uint32_t>(96u, (last.colorRounds + std::max(colorMargin, last.colorRounds / 4u) + 3u) & ~3u) : 20u;   // converged rounds exit at once; a multiple of 4: the same launches step after step
     if (nmBound) {
         tilesCap = divUp(nmBound, 64) + kSchedBins + 8; ctCap = divUp(conBound, 64) + 4 * kSchedBins + 8;
         const uint32_t binBlocks = divUp(nmBound, kBinItems);
@@ -918,8 +975,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             HIP_TRY(sortKeys[0].ensure(nmBound)); for (int k = 0; k < 2; ++k) HIP_TRY(sortVals[k].ensure(nmBound));
             HIP_TRY(xcdTiles.ensure((size_t)8 * xcdListCap));
             if (!xcdSingle) {   // (one XCD: nothing to keep apart, the emission order will do)
-                k_manifold_keys<<<divUp(nmBound, kKeyItems), 256, 0, st>>>(nmBound, sc, grid.p + gridCur, manBodies.p, gPos.p, sortKeys[0].p, sortVals[0].p, keyCount.p);
-                k_manifold_place<<<divUp(nmBound, kKeyItems), 256, 0, st>>>(nmBound, sc, sortKeys[0].p, sortVals[0].p, keyCount.p, sortVals[1].p);
+                L.launch(k_manifold_keys, dim3(divUp(nmBound, kKeyItems)), dim3(256), 0, st, nmBound, sc, grid.p + gridCur, manBodies.p, gPos.p, sortKeys[0].p, sortVals[0].p, keyCount.p);
+                L.launch(k_manifold_place, dim3(divUp(nmBound, kKeyItems)), dim3(256), 0, st, nmBound, sc, sortKeys[0].p, sortVals[0].p, keyCount.p, sortVals[1].p);
             }
         }
         static const bool xcdNoSort = std::getenv("MI_XCD_NOSORT") != nullptr;   // development: manifold order as emitted
@@ -928,13 +985,13 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         uint32_t round = 0;
         while (true) {
             for (uint32_t r = 0; r < colorBatch; ++r, ++round)
-                k_color_round<<<divUp(nmBound, B), B, 0, st>>>(sc, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlagsPtr());
+                L.launch(k_color_round, dim3(divUp(nmBound, B)), dim3(B), 0, st, sc, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlagsPtr());
             // schedule bins -> tiles (valid once the last round left nothing uncoloured: StepScalars::colorPending)
-            k_bin_hist<<<binBlocks, 256, 0, st>>>(sc, binBlocks, perm, color.p, manInfo.p, blockHist.p);
-            HIP_TRY(scanBins.run(blockHist.p, blockScan.p, kColorBins * binBlocks, st));
-            k_bin_scatter<<<binBlocks, 256, 0, st>>>(round - 1, roundFlagsPtr(), binBlocks, perm, color.p, manInfo.p, blockScan.p, order.p, sc);
-            k_build_tiles<<<1, 256, 0, st>>>(tilesCap, ctCap, sc, binInfo.p, xcdPlan ? xcdBase.p : nullptr, xcdSingle ? 1u : 0u);
-            k_fill_tiles<<<divUp(tilesCap, B), B, 0, st>>>(sc, binInfo.p, tileBin.p, tileDesc.p, xcdBase.p, xcdPlan ? xcdTiles.p : nullptr, xcdListCap, xcdSingle ? 1u : 0u);
+            L.launch(k_bin_hist, dim3(binBlocks), dim3(256), 0, st, sc, binBlocks, perm, color.p, manInfo.p, blockHist.p);
+            HIP_TRY(scanBins.run(L, blockHist.p, blockScan.p, kColorBins * binBlocks, st));
+            L.launch(k_bin_scatter, dim3(binBlocks), dim3(256), 0, st, round - 1, roundFlagsPtr(), binBlocks, perm, color.p, manInfo.p, blockScan.p, order.p, sc);
+            L.launch(k_build_tiles, dim3(1), dim3(256), 0, st, tilesCap, ctCap, sc, binInfo.p, xcdPlan ? xcdBase.p : nullptr, xcdSingle ? 1u : 0u);
+            L.launch(k_fill_tiles, dim3(divUp(tilesCap, B)), dim3(B), 0, st, sc, binInfo.p, tileBin.p, tileDesc.p, xcdBase.p, xcdPlan ? xcdTiles.p : nullptr, xcdListCap, xcdSingle ? 1u : 0u);
             if (spec) break;
             int rc = readScalars(); if (rc != MI_OK) return rc;
             if (hs.colorPending == 0) break;
@@ -944,21 +1001,21 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         colorRoundsLaunched = round;
         {   // colour history for the next step, into the OTHER table (it becomes current only if this step turns out valid)
             const int nt = tabCur ^ 1;   // sized and cleared before k_emit_manifolds (narrow phase stage)
-            k_color_table_insert<<<divUp(nmBound, B), B, 0, st>>>(nc, sc, manPair.p, pairKeys.p, pairKeysS.p, color.p, tabKeys[nt].p, tabVals[nt].p, tabMask[nt], manKept.p);
+            L.launch(k_color_table_insert, dim3(divUp(nmBound, B)), dim3(B), 0, st, nc, sc, manPair.p, pairKeys.p, pairKeysS.p, color.p, tabKeys[nt].p, tabVals[nt].p, tabMask[nt], manKept.p);
             if (eventsEnabled) {   // begins: manifolds not in the previous table; ends: previous pairs not in this step's table
                 eventCap = nmBound + (tabValid ? last.numManifolds : 0u) + 1024u;
                 HIP_TRY(devEvents.ensure(eventCap));
-                k_events_begin<<<divUp(nmBound, B), B, 0, st>>>(nc, eventCap, sc, manIsNew.p, manPair.p, manBodies.p, manInfo.p, pairKeys.p, pairKeysS.p,
+                L.launch(k_events_begin, dim3(divUp(nmBound, B)), dim3(B), 0, st, nc, eventCap, sc, manIsNew.p, manPair.p, manBodies.p, manInfo.p, pairKeys.p, pairKeysS.p,
                                                                npNormal.p, npPoints.p, gPos.p, gVel.p, devEvents.p);
-                if (tabValid) k_events_end<<<divUp(tabMask[tabCur] + 1u, B), B, 0, st>>>(eventCap, sc, tabKeys[tabCur].p, tabMask[tabCur], tabKeys[nt].p, tabVals[nt].p, tabMask[nt], devEvents.p);
+                if (tabValid) L.launch(k_events_end, dim3(divUp(tabMask[tabCur] + 1u, B)), dim3(B), 0, st, eventCap, sc, tabKeys[tabCur].p, tabMask[tabCur], tabKeys[nt].p, tabVals[nt].p, tabMask[nt], devEvents.p);
             }
         }
         if (!spec) {
             mirrorSchedule();
             const BinInfo& ob = bins[kSchedBins - 1];
             if (ob.count > 1) {   // overflow colour: sequential solve in ascending pair-key order
-                HIP_TRY(hipMemcpyAsync(orderTmp.p + ob.slotStart, order.p + ob.slotStart, ob.count * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
-                k_sort_overflow<<<1, 256, 0, st>>>(ob.slotStart, ob.count, manPair.p, hs.partitioned ? pairKeysS.p : pairKeys.p, orderTmp.p, order.p);
+                HIP_TRY(L.memcpyAsync(orderTmp.p + ob.slotStart, order.p + ob.slotStart, ob.count * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
+                L.launch(k_sort_overflow, dim3(1), dim3(256), 0, st, ob.slotStart, ob.count, manPair.p, hs.partitioned ? pairKeysS.p : pairKeys.p, orderTmp.p, order.p);
             }
         }
     }
@@ -984,11 +1041,11 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         HIP_TRY(slotMeta.ensure((size_t)tilesCap * 64)); HIP_TRY(slotNormal.ensure((size_t)tilesCap * 64)); HIP_TRY(slotMass.ensure((size_t)tilesCap * 64));
         HIP_TRY(rows.ensure((size_t)ctCap * kRows * 64)); HIP_TRY(imp.ensure((size_t)ctCap * 64));
         if (tilesLaunch)
-            k_contact_init<<<xcdPlan ? 8u * xcdListCap : tilesLaunch, 64, 0, st>>>(sc, nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
+            L.launch(k_contact_init, dim3(xcdPlan ? 8u * xcdListCap : tilesLaunch), dim3(64), 0, st, sc, nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
                                                       gPos.p, gInvI.p, xcdPlan ? gVelL.p : gVel.p /* same content here; the cached copy */, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, impNeeded ? imp.p : nullptr, slotMeta.p, slotNormal.p, slotMass.p,
                                                       xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, xcdTiles.p, xcdListCap, xcdSingle ? 1u : 0u);
     }
-    int rc = joints.initialize(*this, dt, st);
+    int rc = joints.initialize(*this, dt, st);   // (through L)
     if (rc != MI_OK) return rc;
     mark();  // 6
     bool solveAttached = false;
@@ -1011,7 +1068,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                 while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
                 (void)hipEventRecord(profEvents[e], st);
             }
-            k_solve_flow_islands<<<(uint32_t)(per * perLaunch), 64, flowLds, st>>>(it, perLaunch, joints.numIslands, joints.dIslands, joints.dSteps, joints.dIslandBodies, iu, ia, bv, bodyUsed.p,
+            L.launch(k_solve_flow_islands, dim3((uint32_t)(per * perLaunch)), dim3(64), flowLds, st, it, perLaunch, joints.numIslands, joints.dIslands, joints.dSteps, joints.dIslandBodies, iu, ia, bv, bodyUsed.p,
                                                                                    tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, sc);
             if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
         }
@@ -1034,7 +1091,8 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         // the solve stage IS this launch: its timing events ride on the dispatch (when this path is not taken they are recorded below)
         hipEvent_t e6 = attached ? ev[6] : nullptr, e7 = attached ? ev[7] : nullptr;
         solveAttached = attached;
-#define MI_PERSIST_LAUNCH(A, B_, C_, LDS) hipExtLaunchKernelGGL((k_contact_solve_persist<A, B_, C_>), dim3(persistWaves), dim3(64), LDS, st, e6, e7, 0, MI_PERSIST_ARGS)
+#define MI_PERSIST_LAUNCH(A, B_, C_, LDS) do { if (attached) hipExtLaunchKernelGGL((k_contact_solve_persist<A, B_, C_>), dim3(persistWaves), dim3(64), LDS, st, e6, e7, 0, MI_PERSIST_ARGS); \
+                                              else L.launch(k_contact_solve_persist<A, B_, C_>, dim3(persistWaves), dim3(64), LDS, st, MI_PERSIST_ARGS); } while (0)
         if (usedXcd) {
             if (metaLds && impLds) MI_PERSIST_LAUNCH(true, true, true, ldsMeta);
             else if (impLds) MI_PERSIST_LAUNCH(false, true, true, ldsImp);
@@ -1059,7 +1117,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                 while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
                 (void)hipEventRecord(profEvents[e], st);
             }
-            k_contact_solve_flow<<<tilesLaunch * perLaunch, 64, flowLds, st>>>(it, perLaunch, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p, sc);
+            L.launch(k_contact_solve_flow, dim3(tilesLaunch * perLaunch), dim3(64), flowLds, st, it, perLaunch, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p, sc);
             if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
         }
     } else {
@@ -1089,15 +1147,15 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
                     size_t e = 2 * (size_t)profLaunches;
                     while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
                     (void)hipEventRecord(profEvents[e], st);
-                    k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
+                    L.launch(k_contact_solve, dim3(grid_), dim3(64), 0, st, cl, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
                     (void)hipEventRecord(profEvents[e + 1], st);
                     ++profLaunches;
                 } else {
-                    k_contact_solve<<<grid_, 64, 0, st>>>(cl, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
+                    L.launch(k_contact_solve, dim3(grid_), dim3(64), 0, st, cl, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
                 }
             }
-            if (tailStart < tailEnd) k_contact_solve_tail<<<1, 256, 0, st>>>(binInfo.p, tailStart, tailEnd, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
-            if (bins[kSchedBins - 1].count) k_contact_solve_serial<<<1, 64, 0, st>>>(bins[kSchedBins - 1], slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
+            if (tailStart < tailEnd) L.launch(k_contact_solve_tail, dim3(1), dim3(256), 0, st, binInfo.p, tailStart, tailEnd, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
+            if (bins[kSchedBins - 1].count) L.launch(k_contact_solve_serial, dim3(1), dim3(64), 0, st, bins[kSchedBins - 1], slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
         }
     }
     mark();  // 7
@@ -1105,15 +1163,53 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     if (attached) hipExtLaunchKernelGGL(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nullptr, ev[8], 0, nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
                                       gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p,
                                       shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p, shard.activePrev.p, shards.p, sc);
-    else k_integrate_velocities<<<divUp(nb + 1, B), B, 0, st>>>(nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
+    else L.launch(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
                                                       gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p,
                                                       shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p, shard.activePrev.p, shards.p, sc);
     mark();  // 8
     // ---------------------------------------------------------------------------------------------- end of step: the one read-back
-    if (spinReadback) {
-        const uint32_t seq = ++readbackSeq ? readbackSeq : ++readbackSeq;   // never 0
+    {
         const uint32_t words = (uint32_t)(offsetof(Readback, seq) / 4u);
-        k_publish_readback<<<1, 256, 0, st>>>(reinterpret_cast<const uint32_t*>(sc), words, reinterpret_cast<uint32_t*>(hsPinned), words, seq);
+        if (spinReadback) L.launch(k_publish_readback, dim3(1), dim3(256), 0, st, reinterpret_cast<const uint32_t*>(sc), words, reinterpret_cast<uint32_t*>(hsPinned), words, readbackSeqDev.p);
+        else HIP_TRY(L.memcpyAsync(hsPinned, sc, offsetof(Readback, seq), hipMemcpyDeviceToHost, st));   // scalars + round flags are contiguous
+    }
+    if (pass == PASS_DRY) {
+        const uint64_t sig = L.h ^ ((uint64_t)L.ops << 48);
+        StepGraph* hit = nullptr;
+        for (StepGraph& g : stepGraphs) if (g.sig == sig && g.exec) { hit = &g; break; }
+        if (graphDebug) {
+            if (!hit && !graphPrevOps2.empty()) {   // compare with the step before the previous one (same buffer parity)
+                size_t k = 0; while (k < graphPrevOps2.size() && k < L.opHashes.size() && graphPrevOps2[k] == L.opHashes[k]) ++k;
+                std::fprintf(stderr, "[mi_physics] step %llu: graph signature differs from that of two steps ago at operation %zu of %zu (then %zu)\n", (unsigned long long)totalSteps, k, L.opHashes.size(), graphPrevOps2.size());
+            }
+            graphPrevOps2 = graphPrevOps; graphPrevOps = L.opHashes;
+        }
+        if (hit) {
+            hit->lastUse = ++graphUseClock; ++graphHits;
+            if (hipGraphLaunch(hit->exec, st) != hipSuccess) { (void)hipGetLastError(); graphsEnabled = false; dropStepGraphs(); pass = PASS_PLAIN; goto enqueue_section; }
+        } else if (!graphNoCapture && stepGraphs.size() < kMaxStepGraphs && (sig == graphLastSig || sig == graphPrevSig)) {      // seen within the last two steps as well: capture it
+            graphPrevSig = graphLastSig; graphLastSig = sig;
+            if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graphsEnabled = false; pass = PASS_PLAIN; }
+            else pass = PASS_CAPTURE;
+            goto enqueue_section;
+        } else { graphPrevSig = graphLastSig; graphLastSig = sig; ++graphPlain; pass = PASS_PLAIN; goto enqueue_section; }
+    } else if (pass == PASS_CAPTURE) {
+        hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr;
+        bool ok = hipStreamEndCapture(st, &graph) == hipSuccess && graph && L.firstError == hipSuccess;
+        if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (ok) ok = hipGraphLaunch(exec, st) == hipSuccess;
+        if (!ok) {   // this runtime cannot hold the step in a graph: plain launches from now on (nothing has been enqueued yet)
+            (void)hipGetLastError();
+            if (exec) (void)hipGraphExecDestroy(exec);
+            graphsEnabled = false; dropStepGraphs(); pass = PASS_PLAIN; goto enqueue_section;
+        }
+        const uint64_t sig = graphLastSig;
+        stepGraphs.push_back(StepGraph{sig, exec, ++graphUseClock}); ++graphCaptures;
+    }
+    if (spinReadback) {
+        const uint32_t seq = readbackSeq + 1u ? readbackSeq + 1u : 1u;   // never 0; the device counts the same way (k_publish_readback)
+        readbackSeq = seq;
         volatile uint32_t* flag = &hsPinned->seq;
         const auto t0 = std::chrono::steady_clock::now();
         uint32_t spins = 0;
@@ -1126,7 +1222,6 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
             }
         }
     } else {
-        HIP_TRY(hipMemcpyAsync(hsPinned, sc, offsetof(Readback, seq), hipMemcpyDeviceToHost, st));   // scalars + round flags are contiguous
         HIP_TRY(hipStreamSynchronize(st));
     }
     hs = hsPinned->sc;
@@ -1218,8 +1313,16 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     if (nc) { gridCur ^= 1u; gridValid = true; gridNextCells = hs.numCellsNext; }   // the grid k_pair_finish prepared becomes the next step's
     if (nmBound) { tabCur ^= 1; tabValid = true; } else tabValid = false;
     hostStale = true;
-    last.numPairs = hs.numPairs; last.numManifolds = hs.numManifolds; last.numContacts = hs.numContacts; last.numCells = hs.numCells;
-    last.numSmall = nc - std::min(nc, hs.numLarge + hs.numDead); last.numLarge = hs.numLarge;
+    // The next step's launch sizes derive from these counts; they are kept as snug, STICKY upper bounds (12.5 % granules, unchanged while
+    // they still fit) so that consecutive steps of a scene in a steady state enqueue identical work — which a captured graph can replay.
+    auto sticky = [](uint32_t x, uint32_t prev, uint32_t minGranule) {
+        const uint32_t g = std::max(minGranule, (x ? 1u << (31 - __builtin_clz(x)) : 1u) >> 3);
+        if (prev >= x && prev - x <= 2u * g) return prev;
+        return (x / g + 1u) * g;
+    };
+    last.numPairs = sticky(hs.numPairs, last.numPairs, 256); last.numManifolds = sticky(hs.numManifolds, last.numManifolds, 256);
+    last.numContacts = sticky(hs.numContacts, last.numContacts, 256); last.numCells = sticky(hs.numCells, last.numCells, 1024);
+    last.numSmall = sticky(nc - std::min(nc, hs.numLarge + hs.numDead), last.numSmall, 256); last.numLarge = sticky(hs.numLarge, last.numLarge, 16);
     for (int k = 0; k < 3; ++k) shard.owned[k] = hs.shardOwned[k];
     shard.flagsSwapPending = shard.enabled; shard.stepOpen = false;
     static const bool xcdStats = std::getenv("MI_XCD_STATS") != nullptr;   // development: how many bodies stayed XCD-local
@@ -1232,7 +1335,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
         std::fprintf(stderr, "\n");
     }
     haveXcdEstimate = usedXcd; lastXcdSingle = usedXcdSingle;
-    if (usedXcd) { lastXcdMax = 0; for (int x = 0; x < 8; ++x) lastXcdMax = std::max(lastXcdMax, hs.xcdCount[x]); }
+    if (usedXcd) { uint32_t m = 0; for (int x = 0; x < 8; ++x) m = std::max(m, hs.xcdCount[x]); lastXcdMax = sticky(m, lastXcdMax, 16); }
     last.colorRounds = 0;
     while (last.colorRounds < 96u && flagsHost[last.colorRounds]) ++last.colorRounds;   // rounds that still had work (+1 to commit) this step
     ++last.colorRounds;
@@ -1515,16 +1618,18 @@ int JointSet::initialize(mi_world& w, float dt, hipStream_t st) {
     if (!count()) return MI_OK;
     BodyView bv = bodyView(w);
     uint32_t dummy = (uint32_t)w.bodies.size();
-    distance.launchInit(dummy, bv, dt, st); ball.launchInit(dummy, bv, dt, st); fixed.launchInit(dummy, bv, dt, st);
-    hinge.launchInit(dummy, bv, dt, st); cone.launchInit(dummy, bv, dt, st); slider.launchInit(dummy, bv, dt, st);
+    mi::Launcher& L = w.L;
+    distance.launchInit(L, dummy, bv, dt, st); ball.launchInit(L, dummy, bv, dt, st); fixed.launchInit(L, dummy, bv, dt, st);
+    hinge.launchInit(L, dummy, bv, dt, st); cone.launchInit(L, dummy, bv, dt, st); slider.launchInit(L, dummy, bv, dt, st);
     return MI_OK;
 }
 void JointSet::solveIteration(mi_world& w, hipStream_t st) {
     if (!count()) return;
     BodyView bv = bodyView(w);
-    if (numIslands) k_joint_islands<<<numIslands, 64, 0, st>>>(dIslands, dSteps, dIslandBodies, IslandUpd{distance.dUpd, ball.dUpd, fixed.dUpd, hinge.dUpd, cone.dUpd, slider.dUpd}, bv);
-    distance.launchSolve(bv, st); ball.launchSolve(bv, st); fixed.launchSolve(bv, st);
-    hinge.launchSolve(bv, st); cone.launchSolve(bv, st); slider.launchSolve(bv, st);
+    mi::Launcher& L = w.L;
+    if (numIslands) L.launch(k_joint_islands, dim3(numIslands), dim3(64), 0, st, dIslands, dSteps, dIslandBodies, IslandUpd{distance.dUpd, ball.dUpd, fixed.dUpd, hinge.dUpd, cone.dUpd, slider.dUpd}, bv);
+    distance.launchSolve(L, bv, st); ball.launchSolve(L, bv, st); fixed.launchSolve(L, bv, st);
+    hinge.launchSolve(L, bv, st); cone.launchSolve(L, bv, st); slider.launchSolve(L, bv, st);
 }
 
 // ================================================================================================
@@ -2422,6 +2527,11 @@ MI_API int mi_world_get_accumulated_stage_times(mi_world* w, mi_stage_times* out
 }
 // Which contact-solver kernel the last internal step ran: 0 k_contact_solve (one launch per colour per sweep), 1 k_contact_solve_flow,
 // 2 k_contact_solve_persist, 3 k_solve_flow_islands (contacts + joint islands fused), 4 k_contact_solve_persist XCD-partitioned.
+MI_API int mi_debug_step_graph_stats(mi_world* w, uint32_t* out4) {
+    if (!w || !out4) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    out4[0] = w->graphsEnabled ? 1u : 0u; out4[1] = w->graphHits; out4[2] = w->graphCaptures; out4[3] = w->graphPlain;
+    return MI_OK;
+}
 MI_API int mi_world_get_solver_kind(mi_world* w, uint32_t* out) {
     if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     *out = w->usedFused ? 3u : w->usedPersist ? (w->usedXcdSingle ? 5u : w->usedXcd ? 4u : 2u) : w->usedFlow ? 1u : 0u;

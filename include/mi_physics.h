@@ -285,6 +285,10 @@ MI_API int mi_world_get_stage_times(mi_world* world, mi_stage_times* out);
  * 4 k_contact_solve_persist with the tiles partitioned over the XCDs (default from 16384 manifolds up), 5 the same kernel with all
  * tiles on ONE XCD (default below that: every body hand-over through one L2). */
 MI_API int mi_world_get_solver_kind(mi_world* world, uint32_t* out_kind);
+/* Diagnostics: steps of a small scene whose enqueued work is bit-identical to that of a captured step are replayed as ONE HIP graph
+ * (HIP runtime >= 7.2; MI_GRAPH=0 / force / all).  out[0] = enabled, out[1] = steps replayed, out[2] = graphs captured,
+ * out[3] = speculative steps launched plainly. */
+MI_API int mi_debug_step_graph_stats(mi_world* world, uint32_t* out4);
 /* Sum of the per-stage device times and of the contact updates (contacts x solver iterations) over the internal steps since
  * the last reset (so a benchmark loop does not have to call back into the library after every step). */
 MI_API int mi_world_get_accumulated_stage_times(mi_world* world, mi_stage_times* out_sum, uint32_t* out_steps,
