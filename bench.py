@@ -225,6 +225,7 @@ def main():
         desc = sharding.tile_grid(scene, world_size, args.tiles_z, args.ghost_margin)
         sw = sharding.ShardedWorld(world, desc, rank, args.transport, dist)
         sharding_note = (f"{world_size} tiles ({desc.tiles_x} x {desc.tiles_z}) of one replicated scene, ghost margin {desc.ghost_margin:.2f} m, ownership by position each step, "
+                         f"{desc.max_records} records (56 B) per neighbour message, "
                          f"neighbour exchange: {'RCCL send/recv inside the library' if sw.transport == 'rccl' else 'torch.distributed p2p via host'}; {args.scaling} scaling"
                          + (f"; {sw.note}" if sw.note else ""))
     else:

@@ -25,12 +25,12 @@ def tile_grid(scene, num_ranks, tiles_z=1, margin=2.5):
     d.origin_x = float(lo[0]); d.origin_z = float(lo[2])
     d.tile_size_x = float((hi[0] - lo[0]) / tiles_x); d.tile_size_z = float((hi[2] - lo[2]) / tiles_z)
     d.ghost_margin = float(min(margin, 0.45 * d.tile_size_x, 0.45 * d.tile_size_z))
-    # A neighbour message always travels whole, so its capacity is sized for what a margin strip can hold (x 4: piles shift), not for
+    # A neighbour message always travels whole, so its capacity is sized for what a margin strip can hold (x 6: piles shift and compact), not for
     # the library's size-blind default: records = owned bodies whose centre lies within `margin` of the border to that neighbour.
     per_tile = int(dyn.sum()) / num_ranks
     strip = d.ghost_margin / d.tile_size_x if tiles_x > 1 else 0.0
     strip = max(strip, d.ghost_margin / d.tile_size_z if tiles_z > 1 else 0.0)
-    d.max_records = max(4096, int(4.0 * strip * per_tile) + 1024)
+    d.max_records = max(4096, int(6.0 * strip * per_tile) + 1024)
     return d
 
 
