@@ -140,10 +140,15 @@ struct mi_world {
     int shardBuildRoots();
     void shardReleaseComm();
     bool transformsFollowPhysics = false;   // last stepped through mi_world_step_fixed: entity transforms = physics_transform1 at the next download
+    // mi_world_step (physicsStep): physics_transform0 is kept ON THE DEVICE (bPos0 / bRot0, copied from transform1 before the sub-steps) and the
+    // interpolated entity transforms are produced at the next download — the call itself moves nothing to the host (it used to download the
+    // whole body state twice per call: at 57 k bodies that was most of a batched learning step)
+    bool lerpPending = false, p0OnDevice = false; float lerpT = 0.f;
     float timer = 0.f;
 
     // device: bodies
     DBuf<float4> bPos, bRot, bLinVel, bAngVel, bForce, bTorque, bCogInvMass, bInvI, bParams;
+    DBuf<float4> bPos0, bRot0;   // physics_transform0 (see lerpPending)
     DBuf<float4> bPosN, bRotN, bLinVelN, bAngVelN, bForceN, bTorqueN;   // second body-state set: written by k_integrate_velocities, swapped in when a step is valid
     DBuf<float4> gPos, gInvI, gVel;
     // XCD-partitioned persistent solver: cached velocity copy for XCD-local bodies, per-body XCD set, spatial sort of the manifolds, per-XCD tile lists
@@ -619,15 +624,28 @@ int mi_world::download() {
         HIP_TRY(hipMemcpyAsync(av.data(), bAngVel.p, nb * 16, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(fo.data(), bForce.p, nb * 16, hipMemcpyDeviceToHost, stream));
         HIP_TRY(hipMemcpyAsync(to.data(), bTorque.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        std::vector<float4> pos0, rot0;
+        if (p0OnDevice) {
+            pos0.resize(nb); rot0.resize(nb);
+            HIP_TRY(hipMemcpyAsync(pos0.data(), bPos0.p, nb * 16, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(rot0.data(), bRot0.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        }
         HIP_TRY(hipStreamSynchronize(stream));
         for (uint32_t i = 0; i < nb; ++i) {
             HBody& b = bodies[i];
+            if (p0OnDevice) { b.p0 = V3(pos0[i].x, pos0[i].y, pos0[i].z); b.r0 = Q4(rot0[i].x, rot0[i].y, rot0[i].z, rot0[i].w); }
             b.p1 = V3(pos[i].x, pos[i].y, pos[i].z); b.r1 = Q4(rot[i].x, rot[i].y, rot[i].z, rot[i].w);
             b.linVel = V3(lv[i].x, lv[i].y, lv[i].z); b.angVel = V3(av[i].x, av[i].y, av[i].z);
             b.force = V3(fo[i].x, fo[i].y, fo[i].z); b.torque = V3(to[i].x, to[i].y, to[i].z);
             // after n x physicsStepInternal without interpolation (mi_world_step_fixed) the transform is physics_transform1 (physics.cpp:1408-1411)
             if (transformsFollowPhysics) { HEntity& e = entities[b.entity]; e.pos = b.p1; e.rot = b.r1; }
+            else if (lerpPending) {   // lerp(trs): nlerp on the quaternion (src/core/math.h:673-682)
+                HEntity& e = entities[b.entity]; const float t = lerpT;
+                e.pos = lerp(b.p0, b.p1, t);
+                e.rot = normalize(Q4(b.r0.x + t * (b.r1.x - b.r0.x), b.r0.y + t * (b.r1.y - b.r0.y), b.r0.z + t * (b.r1.z - b.r0.z), b.r0.w + t * (b.r1.w - b.r0.w)));
+            }
         }
+        p0OnDevice = false; lerpPending = false;
     }
     hostStale = false;
     return MI_OK;
@@ -2050,23 +2068,33 @@ MI_API int mi_world_step_profiled(mi_world* w, const mi_step_settings* s, float 
 // physicsStep (src/physics/physics.cpp:1364-1413): accumulator, <= maxPhysicsIterationsPerFrame sub-steps, pose interpolation.
 MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
     if (!w || !s) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
-    if (w->transformsFollowPhysics) { int rc = w->download(); if (rc != MI_OK) return rc; w->transformsFollowPhysics = false; }   // from here on this function writes the transforms itself
+    if (w->transformsFollowPhysics) { int rc = w->download(); if (rc != MI_OK) return rc; w->transformsFollowPhysics = false; }   // settle what mi_world_step_fixed left pending
     if (s->fixed_frame_rate) {
         const float fixedDt = 1.f / (float)s->frame_rate;
         w->timer += dt;
         uint32_t iterations = 0;
         if (w->timer >= fixedDt) {
-            int rc = w->download(); if (rc != MI_OK) return rc;
-            for (HBody& b : w->bodies) { b.p0 = b.p1; b.r0 = b.r1; }
+            // physics_transform0 = physics_transform1 (physics.cpp:1380-1384), on the device
+            HIP_TRY(hipSetDevice(w->device));
+            if (w->topologyDirty) { int rc = w->download(); if (rc != MI_OK) return rc; rc = w->upload(); if (rc != MI_OK) return rc; w->haveEstimates = false; }
+            const uint32_t nb = (uint32_t)w->bodies.size();
+            if (nb) {
+                HIP_TRY(w->bPos0.ensure(nb)); HIP_TRY(w->bRot0.ensure(nb));
+                HIP_TRY(hipMemcpyAsync(w->bPos0.p, w->bPos.p, (size_t)nb * sizeof(float4), hipMemcpyDeviceToDevice, w->stream));
+                HIP_TRY(hipMemcpyAsync(w->bRot0.p, w->bRot.p, (size_t)nb * sizeof(float4), hipMemcpyDeviceToDevice, w->stream));
+                w->p0OnDevice = true; w->hostStale = true;
+            }
             while (w->timer >= fixedDt && iterations++ < s->max_physics_iterations_per_frame) {
-                rc = w->stepInternal(*s, fixedDt); if (rc != MI_OK) return rc;
+                int rc = w->stepInternal(*s, fixedDt); if (rc != MI_OK) return rc;
                 w->timer -= fixedDt;
             }
         }
         if (w->timer >= fixedDt) w->timer = fmodf(w->timer, fixedDt);
-        int rc = w->download(); if (rc != MI_OK) return rc;
-        float t = w->timer / fixedDt;
-        for (HBody& b : w->bodies) {   // lerp(trs): nlerp on the quaternion (src/core/math.h:673-682)
+        // the interpolated transforms lerp(transform0, transform1, timer / fixedDt) are produced when somebody asks for them (download)
+        w->lerpT = w->timer / fixedDt;
+        if (w->hostStale) { w->lerpPending = true; return MI_OK; }
+        const float t = w->lerpT;   // nothing newer on the device (no sub-step in this call, host state current): interpolate right here
+        for (HBody& b : w->bodies) {
             HEntity& e = w->entities[b.entity];
             e.pos = lerp(b.p0, b.p1, t);
             e.rot = normalize(Q4(b.r0.x + t * (b.r1.x - b.r0.x), b.r0.y + t * (b.r1.y - b.r0.y), b.r0.z + t * (b.r1.z - b.r0.z), b.r0.w + t * (b.r1.w - b.r0.w)));
@@ -2074,8 +2102,7 @@ MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
         return MI_OK;
     }
     int rc = w->stepInternal(*s, dt); if (rc != MI_OK) return rc;
-    rc = w->download(); if (rc != MI_OK) return rc;
-    for (HBody& b : w->bodies) { HEntity& e = w->entities[b.entity]; e.pos = b.p1; e.rot = b.r1; }
+    w->transformsFollowPhysics = true;   // transform = physics_transform1, at the next download
     return MI_OK;
 }
 
