@@ -144,6 +144,7 @@ struct mi_world {
     // interpolated entity transforms are produced at the next download — the call itself moves nothing to the host (it used to download the
     // whole body state twice per call: at 57 k bodies that was most of a batched learning step)
     bool lerpPending = false, p0OnDevice = false; float lerpT = 0.f;
+    float4* downloadStage = nullptr; size_t downloadStageCap = 0;   // pinned staging of download()
     float timer = 0.f;
 
     // device: bodies
@@ -335,6 +336,7 @@ mi_world::~mi_world() {
     if (stream) (void)hipStreamSynchronize(stream);
     (void)hipDeviceSynchronize();
     if (hsPinned) (void)hipHostFree(hsPinned);
+    if (downloadStage) (void)hipHostFree(downloadStage);
     if (shard.sentHost) (void)hipHostFree(shard.sentHost);
     shardReleaseComm();
     if (graphDebug) std::fprintf(stderr, "[mi_physics] step graphs: %u replayed, %u captured, %u plain speculative steps, %llu steps in total\n", graphHits, graphCaptures, graphPlain, (unsigned long long)totalSteps);
@@ -617,18 +619,25 @@ int mi_world::download() {
     if (!hostStale) return MI_OK;
     uint32_t nb = (uint32_t)bodies.size();
     if (nb) {
-        std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), fo(nb), to(nb);
-        HIP_TRY(hipMemcpyAsync(pos.data(), bPos.p, nb * 16, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(rot.data(), bRot.p, nb * 16, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(lv.data(), bLinVel.p, nb * 16, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(av.data(), bAngVel.p, nb * 16, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(fo.data(), bForce.p, nb * 16, hipMemcpyDeviceToHost, stream));
-        HIP_TRY(hipMemcpyAsync(to.data(), bTorque.p, nb * 16, hipMemcpyDeviceToHost, stream));
-        std::vector<float4> pos0, rot0;
+        // pinned staging, kept: pageable std::vectors made this 2.5 ms per call at 57 k bodies (allocation + staged copies), which was
+        // the largest part of a batched learning step once mi_world_step stopped downloading
+        const size_t rows = (p0OnDevice ? 8u : 6u) * (size_t)nb;
+        if (rows > downloadStageCap) {
+            if (downloadStage) (void)hipHostFree(downloadStage);
+            downloadStage = nullptr; downloadStageCap = 0;
+            HIP_TRY(hipHostMalloc((void**)&downloadStage, (rows + rows / 4) * sizeof(float4)));
+            downloadStageCap = rows + rows / 4;
+        }
+        float4 *pos = downloadStage, *rot = pos + nb, *lv = rot + nb, *av = lv + nb, *fo = av + nb, *to = fo + nb, *pos0 = to + nb, *rot0 = pos0 + nb;
+        HIP_TRY(hipMemcpyAsync(pos, bPos.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(rot, bRot.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(lv, bLinVel.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(av, bAngVel.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(fo, bForce.p, nb * 16, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(hipMemcpyAsync(to, bTorque.p, nb * 16, hipMemcpyDeviceToHost, stream));
         if (p0OnDevice) {
-            pos0.resize(nb); rot0.resize(nb);
-            HIP_TRY(hipMemcpyAsync(pos0.data(), bPos0.p, nb * 16, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(hipMemcpyAsync(rot0.data(), bRot0.p, nb * 16, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(pos0, bPos0.p, nb * 16, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipMemcpyAsync(rot0, bRot0.p, nb * 16, hipMemcpyDeviceToHost, stream));
         }
         HIP_TRY(hipStreamSynchronize(stream));
         for (uint32_t i = 0; i < nb; ++i) {
