@@ -280,6 +280,48 @@ __global__ __launch_bounds__(256) void k_apply_fields(uint32_t n, const uint2* _
     bForceStep[me.x] = f4(f, 0.f);
 }
 
+// The same without the host (speculative steps): the interactions are put into the canonical order ON THE DEVICE — their keys
+// (body, other collider, body collider) are unique, so the sorted position of an entry is the number of entries with a smaller key
+// (a rank sort: n x n comparisons through LDS tiles; n is hundreds to a few thousand, the host path takes over beyond `cap`) — and the
+// first entry of every body's run adds that body's force-field forces in order.  Trigger overlaps are read from the sorted list
+// after the step.
+__device__ __forceinline__ bool interLess(const DeviceInteraction& x, const DeviceInteraction& y) {
+    if (x.body != y.body) return x.body < y.body;
+    if (x.otherCollider != y.otherCollider) return x.otherCollider < y.otherCollider;
+    return x.rbCollider < y.rbCollider;
+}
+__global__ __launch_bounds__(256) void k_inter_sort(const StepScalars* __restrict__ sc, uint32_t cap, const DeviceInteraction* __restrict__ in, DeviceInteraction* __restrict__ out) {
+    __shared__ DeviceInteraction tile[256];
+    const uint32_t n = min(sc->numInteractions, cap);
+    if (blockIdx.x * 256u >= n) return;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    DeviceInteraction me{0xFFFFFFFFu, 0u, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    if (i < n) me = in[i];
+    uint32_t rank = 0;
+    for (uint32_t j0 = 0; j0 < n; j0 += 256u) {
+        __syncthreads();
+        if (j0 + threadIdx.x < n) tile[threadIdx.x] = in[j0 + threadIdx.x];
+        __syncthreads();
+        const uint32_t m = min(256u, n - j0);
+        for (uint32_t j = 0; j < m; ++j) rank += interLess(tile[j], me) ? 1u : 0u;
+    }
+    if (i < n) out[rank] = me;
+}
+__global__ __launch_bounds__(256) void k_apply_fields_sorted(const StepScalars* __restrict__ sc, uint32_t cap, const DeviceInteraction* __restrict__ sorted,
+                                                             const float4* __restrict__ localForce, float4* __restrict__ bForceStep) {
+    const uint32_t n = min(sc->numInteractions, cap);
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t body = sorted[i].body;
+    if (i > 0 && sorted[i - 1].body == body) return;
+    V3 f = xyz(bForceStep[body]); bool any = false;
+    for (uint32_t j = i; j < n && sorted[j].body == body; ++j) {
+        const uint32_t other = sorted[j].other;
+        if ((other >> 28) == OBJ_FORCE_FIELD) { f = f + xyz(localForce[other & 0x0FFFFFFFu]); any = true; }
+    }
+    if (any) bForceStep[body] = f4(f, 0.f);
+}
+
 // ---- ray tests (testPhysicsInteraction, src/physics/physics.cpp:555-629; ray::intersect*, bounding_volumes.cpp:197-398, 677-702).
 // Stated deviation: the cylinder test's outT is 0 (not uninitialised) when the origin is inside the infinite cylinder and
 // neither cap is hit.

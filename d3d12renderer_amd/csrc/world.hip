@@ -186,6 +186,9 @@ struct mi_world {
     DBuf<uint32_t> cObject; DBuf<float4> localForce, bForceStep; DBuf<uint64_t> interKeys; DBuf<DeviceInteraction> interList; DBuf<uint2> fieldList;
     std::vector<uint64_t> prevTriggerOverlaps, nextTriggerOverlaps;
     int interactions(std::vector<mi_event>& triggerEvents);
+    int interactionsDevice(uint32_t interPairBound);                                  // the speculative form: everything stays on the device
+    int triggerEventsFrom(const std::vector<DeviceInteraction>& sortedList, std::vector<mi_event>& out);   // host half: trigger overlaps of a step, diffed against the previous step's
+    DBuf<DeviceInteraction> interSorted;
     // cloth (cloth_component): host description + device state per cloth, one descriptor array for the single launch
     struct HCloth {
         mi_cloth_desc desc; float oldTotalMass, oldStiffness;
@@ -263,7 +266,7 @@ struct mi_world {
     void dropStepGraphs() { for (StepGraph& g : stepGraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); stepGraphs.clear(); graphLastSig = graphPrevSig = 0; }
     void mirrorSchedule();
     // speculative (single read-back) stepping: upper bounds come from the last valid step
-    struct LastCounts { uint32_t numPairs = 0, numManifolds = 0, numContacts = 0, numCells = 0, colorRounds = 0, numSmall = 0, numLarge = 0; } last;
+    struct LastCounts { uint32_t numPairs = 0, numManifolds = 0, numContacts = 0, numCells = 0, colorRounds = 0, numSmall = 0, numLarge = 0, numInterPairs = 0, numInteractions = 0; } last;
     bool specEnabled = true, haveEstimates = false;
     uint32_t specRetries = 0, specSteps = 0, totalSteps = 0, colorRoundsLaunched = 0;
     uint32_t sapAxis = 0;        // sorting axis for the next step (collision_broad.cpp:443-444), host copy
@@ -717,7 +720,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     if (bodies.empty()) return cloths.empty() ? MI_OK : stepCloths(dt);   // physics.cpp:1184-1189: cloth alone still steps
     if (shard.stepOpen) shard.prevValid = false;   // the previous step ended in an error: what its kernels left behind is not what the flags describe
     shard.stepOpen = true;
-    const bool spec = specEnabled && haveEstimates && flowSolver && !launchFallbackSteps && !usesInteractions;   // interactions are read back mid-step
+    const bool spec = specEnabled && haveEstimates && flowSolver && !launchFallbackSteps && (!usesInteractions || last.numInteractions <= 32768u);   // (triggers / force fields: ordered and applied on the device while there are at most 32 k interactions)
     ++totalSteps; if (spec) ++specSteps;
     int rc = runStep(settings, dt, spec);
     // a step that asks to be re-run has written nothing persistent; each re-run is synchronous and one rung further down the ladder
@@ -801,17 +804,20 @@ int mi_world::interactions(std::vector<mi_event>& out) {
         });
     }
     std::vector<uint2> fields;
-    nextTriggerOverlaps.clear();
-    for (const DeviceInteraction& in : list) {
-        const uint32_t type = in.other >> 28, index = in.other & 0x0FFFFFFFu;
-        if (type == OBJ_FORCE_FIELD) fields.push_back(make_uint2(in.body, index));
-        else if (type == OBJ_TRIGGER) nextTriggerOverlaps.push_back(((uint64_t)triggerEntities[index] << 32) | (uint64_t)bodies[in.body].entity);
-    }
+    for (const DeviceInteraction& in : list) if ((in.other >> 28) == OBJ_FORCE_FIELD) fields.push_back(make_uint2(in.body, in.other & 0x0FFFFFFFu));
     if (!fields.empty()) {
         HIP_TRY(fieldList.ensure(fields.size()));
         HIP_TRY(hipMemcpyAsync(fieldList.p, fields.data(), fields.size() * sizeof(uint2), hipMemcpyHostToDevice, st));
         k_apply_fields<<<divUp((uint32_t)fields.size(), 256), 256, 0, st>>>((uint32_t)fields.size(), fieldList.p, localForce.p, bForceStep.p);
         HIP_TRY(hipStreamSynchronize(st));   // `fields` is pageable host memory
+    }
+    return triggerEventsFrom(list, out);
+}
+int mi_world::triggerEventsFrom(const std::vector<DeviceInteraction>& list, std::vector<mi_event>& out) {
+    nextTriggerOverlaps.clear();
+    for (const DeviceInteraction& in : list) {
+        const uint32_t type = in.other >> 28, index = in.other & 0x0FFFFFFFu;
+        if (type == OBJ_TRIGGER) nextTriggerOverlaps.push_back(((uint64_t)triggerEntities[index] << 32) | (uint64_t)bodies[in.body].entity);
     }
     std::sort(nextTriggerOverlaps.begin(), nextTriggerOverlaps.end());
     nextTriggerOverlaps.erase(std::unique(nextTriggerOverlaps.begin(), nextTriggerOverlaps.end()), nextTriggerOverlaps.end());
@@ -830,6 +836,20 @@ int mi_world::interactions(std::vector<mi_event>& out) {
     }
     while (p < prev.size()) emit(prev[p++], MI_EVENT_TRIGGER_LEAVE);
     while (t < nextTriggerOverlaps.size()) emit(nextTriggerOverlaps[t++], MI_EVENT_TRIGGER_ENTER);
+    return MI_OK;
+}
+// Speculative form: k_overlap over the bound of the candidate pairs, canonical order by a device rank sort, force fields applied from the
+// sorted list — nothing comes back to the host inside the step; the trigger overlaps are taken from the sorted list after the read-back.
+int mi_world::interactionsDevice(uint32_t interPairBound) {
+    const uint32_t nb = (uint32_t)bodies.size();
+    hipStream_t st = stream;
+    HIP_TRY(L.memcpyAsync(bForceStep.p, bForce.p, (size_t)nb * sizeof(float4), hipMemcpyDeviceToDevice, st));
+    if (!interPairBound) return MI_OK;
+    const uint32_t cap = (uint32_t)interList.cap;
+    HullSet hset{hullVerts.p, hullRanges.p};
+    L.launch(k_overlap, dim3(divUp(interPairBound, 64)), dim3(64), 0, st, scalarsPtr(), cap, interKeys.p, wShape.p, aabbMin.p, aabbMax.p, hset, interList.p);
+    L.launch(k_inter_sort, dim3(divUp(cap, 256)), dim3(256), 0, st, scalarsPtr(), cap, interList.p, interSorted.p);
+    L.launch(k_apply_fields_sorted, dim3(divUp(cap, 256)), dim3(256), 0, st, scalarsPtr(), cap, interSorted.p, localForce.p, bForceStep.p);
     return MI_OK;
 }
 
@@ -911,6 +931,7 @@ enqueue_section:
         if (pairKeys.cap == 0) { HIP_TRY(pairKeys.ensure(std::max<size_t>(1u << 16, 8 * (size_t)nc))); }
         if (spec) { HIP_TRY(pairKeys.ensure(bound(last.numPairs, 4096))); }
         if (usesInteractions && interKeys.cap == 0) HIP_TRY(interKeys.ensure(4096));
+        if (usesInteractions && spec) HIP_TRY(interKeys.ensure(bound(last.numInterPairs, 1024)));
         for (int attempt = 0; attempt < 3; ++attempt) {
             uint32_t cap = (uint32_t)std::min<size_t>(pairKeys.cap, 0x7FFFFFFFu);
             const InterSink inter{usesInteractions ? interKeys.p : nullptr, (uint32_t)interKeys.cap, &sc->numInterPairs};
@@ -972,7 +993,12 @@ enqueue_section:
     }
     // ---------------------------------------------------------------------------------------------- triggers / force fields
     std::vector<mi_event> triggerEvents;
-    if (usesInteractions) { int rc = interactions(triggerEvents); if (rc != MI_OK) return rc; }
+    uint32_t interPairBound = 0;
+    if (usesInteractions && spec) {
+        interPairBound = (uint32_t)std::min<size_t>(interKeys.cap, bound(last.numInterPairs, 1024));
+        HIP_TRY(interList.ensure(bound(last.numInteractions, 1024))); HIP_TRY(interSorted.ensure(interList.cap));
+        int rc = interactionsDevice(interPairBound); if (rc != MI_OK) return rc;
+    } else if (usesInteractions) { int rc = interactions(triggerEvents); if (rc != MI_OK) return rc; }
     mark();  // 3
     L.launch(k_integrate_forces, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nb, dt, make_float3(globalForce.x, globalForce.y, globalForce.z), bPos.p, bRot.p, bCogInvMass.p, bInvI.p, bParams.p, bLinVel.p, bAngVel.p, usesInteractions ? bForceStep.p : bForce.p, bTorque.p,
                                                        gPos.p, gInvI.p, gVel.p, gVelL.p, bodyOwner.p, shard.enabled ? shard.active.p : nullptr);
@@ -1256,7 +1282,8 @@ enqueue_section:
     HIP_TRY(hipGetLastError());
     if (spec) {
         const uint32_t ovfCount = hs.binStart[kColorBins] - hs.binStart[kSchedBins - 1];
-        const bool valid = hs.numPairs <= pairBound && hs.numManifolds <= nmBound && hs.specOverflow == 0 && hs.colorPending == 0 && ovfCount == 0;
+        const bool valid = hs.numPairs <= pairBound && hs.numManifolds <= nmBound && hs.specOverflow == 0 && hs.colorPending == 0 && ovfCount == 0 &&
+                           (!usesInteractions || (hs.numInterPairs <= interPairBound && hs.numInteractions <= interList.cap && hs.numInteractions <= 32768u));
         if (!valid) return STEP_RETRY;   // nothing persistent was modified: run the same step synchronously
         mirrorSchedule();
     }
@@ -1306,6 +1333,11 @@ enqueue_section:
         profKernelMs = 0.f;
         for (uint32_t l = 0; l < profLaunches; ++l) { float ms = 0.f; (void)hipEventElapsedTime(&ms, profEvents[2 * l], profEvents[2 * l + 1]); profKernelMs += ms; }
     }
+    if (spec && usesInteractions) {   // the trigger overlaps of this step, from the device-sorted interaction list (force fields were applied in-stream)
+        std::vector<DeviceInteraction> list(eventsEnabled ? hs.numInteractions : 0u);
+        if (!list.empty()) { HIP_TRY(hipMemcpyAsync(list.data(), interSorted.p, list.size() * sizeof(DeviceInteraction), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
+        int rc = triggerEventsFrom(list, triggerEvents); if (rc != MI_OK) return rc;
+    }
     if (eventsEnabled) {
         pendingEvents.insert(pendingEvents.end(), triggerEvents.begin(), triggerEvents.end());   // handleNonCollisionInteractions runs before the collision events
         if (!nmBound && tabValid) {   // no manifolds at all this step: every collision of the previous step ended
@@ -1350,6 +1382,7 @@ enqueue_section:
     last.numPairs = sticky(hs.numPairs, last.numPairs, 256); last.numManifolds = sticky(hs.numManifolds, last.numManifolds, 256);
     last.numContacts = sticky(hs.numContacts, last.numContacts, 256); last.numCells = sticky(hs.numCells, last.numCells, 1024);
     last.numSmall = sticky(nc - std::min(nc, hs.numLarge + hs.numDead), last.numSmall, 256); last.numLarge = sticky(hs.numLarge, last.numLarge, 16);
+    last.numInterPairs = sticky(hs.numInterPairs, last.numInterPairs, 256); last.numInteractions = sticky(hs.numInteractions, last.numInteractions, 256);
     for (int k = 0; k < 3; ++k) shard.owned[k] = hs.shardOwned[k];
     shard.flagsSwapPending = shard.enabled; shard.stepOpen = false;
     static const bool xcdStats = std::getenv("MI_XCD_STATS") != nullptr;   // development: how many bodies stayed XCD-local
