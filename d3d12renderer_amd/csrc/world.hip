@@ -293,7 +293,7 @@ int mi_world::init(int dev) {
     std::memset(hsPinned, 0, sizeof(Readback));
     HIP_TRY(readbackSeqDev.ensure(1)); HIP_TRY(hipMemsetAsync(readbackSeqDev.p, 0, sizeof(uint32_t), stream));
     {   // Replays diverged from plain launches under the HIP 7.0.x runtime (the one PyTorch 2.10 bundles; whole joint islands / history
-        // colours off after ~70-120 steps, tools/dbg_graph2.py), never under 7.2: graphs are used from 7.2 on (MI_GRAPH=force overrides).
+        // colours off after ~70-120 steps; WITH_TORCH=1 MI_GRAPH=force tools/check_step_graphs.py), never under 7.2: graphs are used from 7.2 on (MI_GRAPH=force overrides).
         int ver = 0; if (hipRuntimeGetVersion(&ver) != hipSuccess) ver = 0;
         graphsEnabled = ver >= 70200000;
     }
