@@ -292,8 +292,9 @@ int mi_world::init(int dev) {
     }
     std::memset(hsPinned, 0, sizeof(Readback));
     HIP_TRY(readbackSeqDev.ensure(1)); HIP_TRY(hipMemsetAsync(readbackSeqDev.p, 0, sizeof(uint32_t), stream));
-    {   // Replays diverged from plain launches under the HIP 7.0.x runtime (the one PyTorch 2.10 bundles; whole joint islands / history
-        // colours off after ~70-120 steps; WITH_TORCH=1 MI_GRAPH=force tools/check_step_graphs.py), never under 7.2: graphs are used from 7.2 on (MI_GRAPH=force overrides).
+    {   // Replays diverged from plain launches under the HIP 7.0.x runtime (the one PyTorch 2.10 bundles) while the host read the state back
+        // through pageable buffers every step; not reproduced since download() stages through pinned memory, cause not established:
+        // graphs are used by default from 7.2 on (MI_GRAPH=force overrides; DESIGN.md "Step graphs").
         int ver = 0; if (hipRuntimeGetVersion(&ver) != hipSuccess) ver = 0;
         graphsEnabled = ver >= 70200000;
     }

@@ -14,9 +14,11 @@ for name, make, steps in (("spheres", lambda: scenes.sphere_drop(10), 260), ("bo
                           ("ragdolls", lambda: scenes.ragdolls(4, 4), 260), ("vehicles", lambda: scenes.vehicles(3, 2), 200), ("terrain", lambda: scenes.terrain_field(8, 2, 8), 260)):
     sc = make()
     a = sc.populate(mi.create_world(0))
+    outer = os.environ.get("MI_GRAPH")
     os.environ["MI_GRAPH"] = "0"
     b = sc.populate(mi.create_world(0))
-    del os.environ["MI_GRAPH"]
+    if outer is None: del os.environ["MI_GRAPH"]
+    else: os.environ["MI_GRAPH"] = outer
     s = sc.settings()
     first_bad = None
     for i in range(steps):
@@ -29,6 +31,7 @@ for name, make, steps in (("spheres", lambda: scenes.sphere_drop(10), 260), ("bo
                            "times_ok": bool(ta["total"] > 0 and ta["solve"] > 0)}
     a.close(); b.close()
 # what a replay saves: a small pile, graphs on / off
+outer = os.environ.get("MI_GRAPH")
 for label, env in (("graph", None), ("plain", "0")):
     if env is not None: os.environ["MI_GRAPH"] = env
     sc = scenes.sphere_drop(16); w = sc.populate(mi.create_world(0)); s = sc.settings()
@@ -36,5 +39,7 @@ for label, env in (("graph", None), ("plain", "0")):
     t0 = time.perf_counter(); w.step_fixed(s, sc.dt, 300); w.counts()
     out["cfg1_ms_per_step_" + label] = (time.perf_counter() - t0) / 300 * 1e3
     w.close()
-    if env is not None: del os.environ["MI_GRAPH"]
+    if env is not None:
+        if outer is None: del os.environ["MI_GRAPH"]
+        else: os.environ["MI_GRAPH"] = outer
 print(json.dumps(out))
