@@ -519,7 +519,7 @@ int mi_world::upload() {
     for (size_t i = ffEntities.size(); i-- > 0;) {   // EnTT view order: back to front
         const HEntity& e = entities[ffEntities[i]];
         V3 f = rotate(e.rot, e.force);
-        if (!e.colliders.empty()) lf[i] = h4(f, 0.f); else { lf[i] = make_float4(0, 0, 0, 0); globalForce = globalForce + f; usesInteractions = true; }
+        if (!e.colliders.empty()) lf[i] = h4(f, 0.f); else { lf[i] = make_float4(0, 0, 0, 0); globalForce = globalForce + f; }   // (a global field needs no interaction pass: k_integrate_forces adds it)
     }
     for (uint32_t k = 0; k < nc; ++k) {   // world index k <-> creation index nc-1-k (EnTT iterates back to front, physics.cpp:635-641)
         const HCollider& c = colliders[nc - 1 - k];
