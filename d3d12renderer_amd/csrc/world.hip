@@ -10,6 +10,7 @@
 #include <string.h>
 #include <vector>
 #include <chrono>
+#include <thread>
 #include <string>
 #include <algorithm>
 #include <type_traits>
@@ -101,6 +102,20 @@ struct HHull { std::vector<V3> verts; std::vector<uint32_t> tris; V3 mn, mx; };
 struct MassProps { M3 inertia; V3 cog; float mass; };
 
 static uint32_t divUp(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+// Host loops over every body / entity (read-back conversions, interpolation) in slices on a few threads once they are long: at 57 k bodies
+// the serial loop of download() — a quaternion normalisation per body — was 1.4 ms of a 4.5 ms batched learning step.  Independent iterations only.
+template <class F>
+static void hostParallelFor(uint32_t n, F&& fn) {
+    const uint32_t kMinPerThread = 8192;
+    uint32_t threads = std::min<uint32_t>({8u, std::max(1u, std::thread::hardware_concurrency()), n / kMinPerThread});
+    if (threads <= 1) { for (uint32_t i = 0; i < n; ++i) fn(i); return; }
+    std::vector<std::thread> pool; pool.reserve(threads - 1);
+    const uint32_t per = (n + threads - 1) / threads;
+    for (uint32_t t = 1; t < threads; ++t)
+        pool.emplace_back([&fn, t, per, n]() { const uint32_t lo = t * per, hi = std::min(n, lo + per); for (uint32_t i = lo; i < hi; ++i) fn(i); });
+    for (uint32_t i = 0; i < std::min(n, per); ++i) fn(i);
+    for (std::thread& th : pool) th.join();
+}
 
 // kernel arguments with padding bytes enter a step's signature field by field (launcher.hpp)
 namespace mi {
@@ -644,7 +659,7 @@ int mi_world::download() {
             HIP_TRY(hipMemcpyAsync(rot0, bRot0.p, nb * 16, hipMemcpyDeviceToHost, stream));
         }
         HIP_TRY(hipStreamSynchronize(stream));
-        for (uint32_t i = 0; i < nb; ++i) {
+        hostParallelFor(nb, [&](uint32_t i) {   // a body writes its own HBody and its own entity only
             HBody& b = bodies[i];
             if (p0OnDevice) { b.p0 = V3(pos0[i].x, pos0[i].y, pos0[i].z); b.r0 = Q4(rot0[i].x, rot0[i].y, rot0[i].z, rot0[i].w); }
             b.p1 = V3(pos[i].x, pos[i].y, pos[i].z); b.r1 = Q4(rot[i].x, rot[i].y, rot[i].z, rot[i].w);
@@ -657,7 +672,7 @@ int mi_world::download() {
                 e.pos = lerp(b.p0, b.p1, t);
                 e.rot = normalize(Q4(b.r0.x + t * (b.r1.x - b.r0.x), b.r0.y + t * (b.r1.y - b.r0.y), b.r0.z + t * (b.r1.z - b.r0.z), b.r0.w + t * (b.r1.w - b.r0.w)));
             }
-        }
+        });
         p0OnDevice = false; lerpPending = false;
     }
     hostStale = false;
@@ -2545,13 +2560,13 @@ static int getTransforms(mi_world* w, float* p, float* r, uint32_t cap, bool phy
     int rc = w->download(); if (rc != MI_OK) return rc;
     uint32_t n = (uint32_t)w->entities.size();
     if (cap < n) return fail(MI_ERR_CAPACITY, "capacity < num entities");
-    for (uint32_t i = 0; i < n; ++i) {
+    hostParallelFor(n, [&](uint32_t i) {
         const HEntity& e = w->entities[i];
         V3 pos = e.pos; Q4 rot = e.rot;
         if (physics && e.rb >= 0) { pos = w->bodies[e.rb].p1; rot = w->bodies[e.rb].r1; }
         if (p) { p[3 * i] = pos.x; p[3 * i + 1] = pos.y; p[3 * i + 2] = pos.z; }
         if (r) { r[4 * i] = rot.x; r[4 * i + 1] = rot.y; r[4 * i + 2] = rot.z; r[4 * i + 3] = rot.w; }
-    }
+    });
     return MI_OK;
 }
 MI_API int mi_world_get_transforms(mi_world* w, float* p, float* r, uint32_t cap) { return getTransforms(w, p, r, cap, false); }
@@ -2561,12 +2576,12 @@ MI_API int mi_world_get_velocities(mi_world* w, float* lin, float* ang, uint32_t
     int rc = w->download(); if (rc != MI_OK) return rc;
     uint32_t n = (uint32_t)w->entities.size();
     if (cap < n) return fail(MI_ERR_CAPACITY, "capacity < num entities");
-    for (uint32_t i = 0; i < n; ++i) {
+    hostParallelFor(n, [&](uint32_t i) {
         V3 v, a;
         if (w->entities[i].rb >= 0) { v = w->bodies[w->entities[i].rb].linVel; a = w->bodies[w->entities[i].rb].angVel; }
         if (lin) { lin[3 * i] = v.x; lin[3 * i + 1] = v.y; lin[3 * i + 2] = v.z; }
         if (ang) { ang[3 * i] = a.x; ang[3 * i + 1] = a.y; ang[3 * i + 2] = a.z; }
-    }
+    });
     return MI_OK;
 }
 MI_API int mi_world_get_mass_properties(mi_world* w, float* invMass, float* invInertia, float* cog, uint32_t cap) {
