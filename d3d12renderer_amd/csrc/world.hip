@@ -271,7 +271,7 @@ struct mi_world {
     // the host's launch rate otherwise.
     Launcher L;
     struct StepGraph { uint64_t sig = 0; hipGraphExec_t exec = nullptr; uint64_t lastUse = 0; };
-    std::vector<StepGraph> stepGraphs;   // never evicted while the world lives (destroying an executable graph next to live ones corrupted replays under the HIP 7.0 runtime); at most kMaxStepGraphs
+    std::vector<StepGraph> stepGraphs;   // at most kMaxStepGraphs; when full, ALL are dropped with the stream idle (never one next to live ones)
     static constexpr size_t kMaxStepGraphs = 64;
     bool graphsEnabled = true, graphsForAll = false, graphNoEvents = false, graphNoCapture = false; uint32_t graphMaxColliders = 32768;
     uint64_t graphLastSig = 0, graphPrevSig = 0, graphUseClock = 0;   // signatures of the last two steps (the buffer sets alternate: a steady scene repeats with period 2)
@@ -1256,7 +1256,8 @@ enqueue_section:
         if (hit) {
             hit->lastUse = ++graphUseClock; ++graphHits;
             if (hipGraphLaunch(hit->exec, st) != hipSuccess) { (void)hipGetLastError(); graphsEnabled = false; dropStepGraphs(); pass = PASS_PLAIN; goto enqueue_section; }
-        } else if (!graphNoCapture && stepGraphs.size() < kMaxStepGraphs && (sig == graphLastSig || sig == graphPrevSig)) {      // seen within the last two steps as well: capture it
+        } else if (!graphNoCapture && (sig == graphLastSig || sig == graphPrevSig)) {      // seen within the last two steps as well: capture it
+            if (stepGraphs.size() >= kMaxStepGraphs) { HIP_TRY(hipStreamSynchronize(st)); dropStepGraphs(); }   // a long-lived scene keeps changing shape: start over (all at once, with the stream idle)
             graphPrevSig = graphLastSig; graphLastSig = sig;
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) != hipSuccess) { (void)hipGetLastError(); graphsEnabled = false; pass = PASS_PLAIN; }
             else pass = PASS_CAPTURE;
