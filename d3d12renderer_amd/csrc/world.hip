@@ -143,7 +143,7 @@ struct mi_world {
         mi_shard_desc desc{}; ShardParams sp{};
         uint32_t capacity = 0; std::vector<uint32_t> peerRanks;
         DBuf<uint8_t> active, activePrev; bool prevValid = false, flagsSwapPending = false, stepOpen = false;   // activePrev: the previous valid step's flags (k_integrate_velocities skips bodies idle in both)
-        DBuf<float> sendBuf[8], recvBuf[8]; DBuf<uint32_t> sent;
+        DBuf<float> sendBuf[8], recvBuf[8];
         DBuf<uint32_t> root; size_t rootJoints = ~size_t(0), rootBodies = 0;   // island root of every body (union-find over the joints), rebuilt when the scene changes
         uint32_t* sentHost = nullptr;            // pinned: the records packed per slot in the previous exchange (overflow check)
         bool sentPending = false;
@@ -2287,7 +2287,6 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
     const uint32_t nb = (uint32_t)w->bodies.size();
     sh.capacity = d->max_records ? d->max_records : std::max(4096u, nb / d->num_ranks / 4u);   // a message always travels whole: (capacity + 1) records of 56 bytes
     { int rc = w->shardBuildRoots(); if (rc != MI_OK) return rc; }
-    HIP_TRY(sh.sent.ensure(8));
     for (uint32_t k = 0; k < sp.numPeers; ++k) {
         HIP_TRY(sh.sendBuf[k].ensure(sh.messageFloats())); HIP_TRY(sh.recvBuf[k].ensure(sh.messageFloats()));
         HIP_TRY(hipMemset(sh.sendBuf[k].p, 0, sh.messageFloats() * sizeof(float))); HIP_TRY(hipMemset(sh.recvBuf[k].p, 0, sh.messageFloats() * sizeof(float)));
