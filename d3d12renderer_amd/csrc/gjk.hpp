@@ -595,6 +595,161 @@ __device__ inline void epaRun(const Simplex& g, const Shape& A, const Shape& B, 
     out.depth = t.dist;
 }
 
+// ---- EPA by ONE WAVE per pair (k_narrow_epa).  The polytope lives in LDS; the lanes share the three scans that make a per-lane EPA
+// slow — closest face, faces the new point can see, hull vertices of a support query — and the arithmetic of every face / vertex is
+// the very same sequence of operations, so is what they pick: minima and maxima keep the FIRST best element of the sequential scan
+// (ties go to the lower index), horizon edges are taken in ascending edge order.  The few order-sensitive link updates stay with lane 0.
+struct EpaLds {
+    SupPt pts[kEpaPts];
+    EpaTri tris[kEpaTris];
+    EpaEdge edges[kEpaEdges];
+    uint32_t refs[kEpaEdges];
+    uint8_t active[kEpaTris];
+    uint16_t border[kEpaBorder];
+    uint16_t newEdgePerPoint[kEpaPts];
+    float bestD[2]; uint32_t bestI[2];
+};
+__device__ __forceinline__ void waveSync() { __syncthreads(); }   // one wave per workgroup: orders its LDS traffic
+__device__ inline V3 supportOfWave(const Shape& s, const HullSet& hs, V3 dir, uint32_t lane) {
+    if (s.type != T_HULL) return supportOf(s, hs, dir);
+    dir = rotate(conj(s.rot), dir);
+    const uint32_t first = hs.ranges[2 * s.hull], count = hs.ranges[2 * s.hull + 1];
+    float maxD = -FLT_MAX; uint32_t bestI = 0xFFFFFFFFu;
+    for (uint32_t i = lane; i < count; i += 64u) {
+        const float d = dot(dir, xyz(hs.verts[first + i]));
+        if (d > maxD) { maxD = d; bestI = i; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {   // first maximum of the sequential scan = largest value, lowest index among equals
+        const float od = __shfl_xor(maxD, off, 64); const uint32_t oi = (uint32_t)__shfl_xor((int)bestI, off, 64);
+        if (oi != 0xFFFFFFFFu && (bestI == 0xFFFFFFFFu || od > maxD || (od == maxD && oi < bestI))) { maxD = od; bestI = oi; }
+    }
+    V3 best;   // (no vertex beat -FLT_MAX: the sequential code leaves `best` unset; hull vertices are finite, this does not happen)
+    if (bestI != 0xFFFFFFFFu) best = xyz(hs.verts[first + bestI]);
+    return s.a + rotate(s.rot, best);
+}
+__device__ inline SupPt supportPairWave(const Shape& A, const Shape& B, const HullSet& hs, V3 dir, uint32_t lane) {
+    SupPt p;
+    p.a = supportOfWave(A, hs, dir, lane);
+    p.b = supportOfWave(B, hs, -dir, lane);
+    p.m = p.a - p.b;
+    return p;
+}
+__device__ inline bool epaAddPointWave(EpaLds& s, uint32_t& nTris, uint32_t& nPts, uint32_t& nEdges, const SupPt& np, uint32_t lane) {  // = epaAddPoint
+    for (uint32_t i = lane; i < nEdges; i += 64u) s.refs[i] = 0u;
+    waveSync();
+    for (uint32_t i = lane; i < nTris; i += 64u) {
+        if (!s.active[i]) continue;
+        const EpaTri t = s.tris[i];
+        const float d = dot(t.n, np.m - s.pts[t.a].m);
+        if (d > 0.f) { atomicAdd(&s.refs[t.eA], 1u); atomicAdd(&s.refs[t.eB], 1u); atomicAdd(&s.refs[t.eC], 1u); s.active[i] = 0; }
+    }
+    waveSync();
+    uint32_t nb = 0;   // horizon = edges referenced once, in ascending edge order
+    for (uint32_t base = 0; base < nEdges; base += 64u) {
+        const uint32_t i = base + lane;
+        const bool flag = i < nEdges && s.refs[i] == 1u;
+        const unsigned long long mask = __ballot(flag);
+        if (flag) { const uint32_t pos = nb + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull)); if (pos < (uint32_t)kEpaBorder) s.border[pos] = (uint16_t)i; }
+        nb += (uint32_t)__popcll(mask);
+    }
+    if (nb > (uint32_t)kEpaBorder) return false;
+    if (nPts >= (uint32_t)kEpaPts) return false;
+    const uint16_t npi = (uint16_t)nPts;
+    if (lane == 0) s.pts[nPts] = np;
+    ++nPts;
+    const uint32_t triOffset = nTris, edgeOffset = nEdges;
+    // (the sequential code stops at the first push that does not fit and leaves the polytope half-extended; the caller then ends the
+    // iteration and only reads the face it had chosen before, which nothing here touches — so the check can come first)
+    if (edgeOffset + nb > (uint32_t)kEpaEdges || triOffset + nb > (uint32_t)kEpaTris) return false;
+    waveSync();
+    if (lane < nb) {
+        const uint16_t ei = s.border[lane];
+        const EpaEdge e = s.edges[ei];
+        const bool bAct = s.active[e.tB] != 0;
+        const uint16_t connect = bAct ? e.a : e.b;
+        const uint16_t triIndex = (uint16_t)(triOffset + lane), ne = (uint16_t)(edgeOffset + lane);
+        EpaEdge nw; nw.a = connect; nw.b = npi; nw.tA = 0xFFFF; nw.tB = triIndex;
+        s.edges[ne] = nw;
+        const uint16_t bI = connect, cI = bAct ? e.b : e.a;
+        V3 n; float dist;
+        triInfo(np, s.pts[bI], s.pts[cI], n, dist);
+        EpaTri t; t.a = npi; t.b = bI; t.c = cI; t.eA = ei; t.eB = 0xFFFF; t.eC = ne; t.n = n; t.dist = dist;
+        s.tris[triIndex] = t;
+    }
+    waveSync();
+    if (lane == 0) {   // the order-sensitive part of both sequential loops (a point may be the `connect` of two horizon edges on a degenerate polytope)
+        for (uint32_t i = 0; i < nb; ++i) {
+            const uint16_t ei = s.border[i];
+            const EpaEdge e = s.edges[ei];
+            const bool aAct = s.active[e.tA] != 0, bAct = s.active[e.tB] != 0;
+            const uint16_t connect = bAct ? e.a : e.b;
+            const uint16_t triIndex = (uint16_t)(triOffset + i);
+            s.newEdgePerPoint[connect] = (uint16_t)(edgeOffset + i);
+            s.active[triIndex] = 1;
+            if (aAct) s.edges[ei].tB = triIndex; else s.edges[ei].tA = triIndex;
+        }
+        for (uint32_t i = 0; i < nb; ++i) {
+            const EpaEdge e = s.edges[s.border[i]];
+            const bool bNew = e.tB >= triOffset;
+            const uint16_t connect = bNew ? e.a : e.b;
+            const uint16_t other = s.newEdgePerPoint[connect];
+            const uint16_t triIndex = (uint16_t)(i + triOffset);
+            s.tris[triIndex].eB = other;
+            s.edges[other].tA = triIndex;
+        }
+    }
+    nTris += nb; nEdges += nb;
+    waveSync();
+    return true;
+}
+__device__ inline void epaRunWave(const Simplex& g, const Shape& A, const Shape& B, const HullSet& hs, EpaLds& s, EpaOut& out, uint32_t lane) {  // = epaRun
+    uint32_t nTris = 4, nPts = 4, nEdges = 6;
+    if (lane == 0) {
+        s.pts[0] = g.a; s.pts[1] = g.b; s.pts[2] = g.c; s.pts[3] = g.d;
+        auto tri = [&](uint32_t i, const SupPt& a, const SupPt& b, const SupPt& c, uint16_t ia, uint16_t ib, uint16_t ic, uint16_t eA, uint16_t eB, uint16_t eC) {
+            V3 n; float dist; triInfo(a, b, c, n, dist);
+            EpaTri t; t.a = ia; t.b = ib; t.c = ic; t.eA = eA; t.eB = eB; t.eC = eC; t.n = n; t.dist = dist;
+            s.tris[i] = t; s.active[i] = 1;
+        };
+        tri(0, g.a, g.b, g.d, 0, 1, 3, 4, 3, 0);
+        tri(1, g.b, g.c, g.d, 1, 2, 3, 5, 4, 1);
+        tri(2, g.c, g.a, g.d, 2, 0, 3, 3, 5, 2);
+        tri(3, g.a, g.c, g.b, 0, 2, 1, 1, 0, 2);
+        auto edge = [&](uint32_t i, uint16_t a, uint16_t b, uint16_t tA, uint16_t tB) { EpaEdge e; e.a = a; e.b = b; e.tA = tA; e.tB = tB; s.edges[i] = e; };
+        edge(0, 0, 1, 0, 3); edge(1, 1, 2, 1, 3); edge(2, 2, 0, 2, 3);
+        edge(3, 0, 3, 2, 0); edge(4, 1, 3, 0, 1); edge(5, 2, 3, 1, 2);
+    }
+    waveSync();
+    uint32_t closest = 0;
+    for (uint32_t it = 0; it < 20; ++it) {
+        const uint32_t prev = closest;
+        float minD = FLT_MAX; uint32_t best = 0xFFFFFFFFu;   // first minimum of the sequential scan
+        for (uint32_t i = lane; i < nTris; i += 64u)
+            if (s.active[i]) { const float d = s.tris[i].dist; if (d < minD) { minD = d; best = i; } }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            const float od = __shfl_xor(minD, off, 64); const uint32_t oi = (uint32_t)__shfl_xor((int)best, off, 64);
+            if (oi != 0xFFFFFFFFu && (best == 0xFFFFFFFFu || od < minD || (od == minD && oi < best))) { minD = od; best = oi; }
+        }
+        closest = best;
+        if (closest == 0xFFFFFFFFu) { closest = prev; break; }
+        const V3 tn = s.tris[closest].n; const float td = s.tris[closest].dist;
+        const SupPt a = supportPairWave(A, B, hs, tn, lane);
+        const float d = dot(a.m, tn);
+        if (d - td < 0.01f) break;
+        if (!epaAddPointWave(s, nTris, nPts, nEdges, a, lane)) break;
+    }
+    const EpaTri t = s.tris[closest];
+    const SupPt a = s.pts[t.a], b = s.pts[t.b], c = s.pts[t.c];
+    V3 bc = barycentric(a.m, b.m, c.m, t.n * t.dist);
+    V3 pA = bc.x * a.a + bc.y * b.a + bc.z * c.a;
+    V3 pB = bc.x * a.b + bc.y * b.b + bc.z * c.b;
+    out.point = 0.5f * (pA + pB);
+    out.normal = t.n;
+    out.depth = t.dist;
+}
+
 // The second half of every GJK+EPA test, from the simplex GJK ended with: penetration by EPA -> one contact.
 __device__ inline void epaSingle(const Simplex& sx, const Shape& a, const Shape& b, const HullSet& hs, EpaState& st, Manifold& out, EpaOut& epa) {
     epaRun(sx, a, b, hs, st, epa);   // EPA status is ignored by every caller (collision_narrow.cpp:509-512)
@@ -711,30 +866,130 @@ __device__ inline bool intersectGjkImpl(const Shape& a, const Shape& b, const Hu
     }
 }
 
-__global__ __launch_bounds__(64) void k_narrow_gjk(const StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
-                                                   const float4* __restrict__ wShape,
-                                                   HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
-                                                   float4* __restrict__ npPoints) {
-    // [gjkLo, gjkHi) = span of the bucket-partitioned pair list that holds the GJK/EPA buckets (k_pair_finish)
-    uint32_t p = sc->gjkLo + blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= sc->gjkHi) return;
-    const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
-    uint64_t key = pairKeys[p];
+// GJK / EPA in two kernels.  k_narrow_gjk: one LANE per pair of the GJK buckets — the shape preparation, the closed-form parallel-cylinder
+// case and GJK itself (a handful of iterations); a pair whose shapes intersect goes, with its final simplex, into the EPA queue.
+// k_narrow_epa: one WAVE per queued pair — EPA with the polytope in LDS and its scans shared by the lanes (epaRunWave), then the
+// shape-specific contact construction.  (One lane per pair for EPA as well made the whole kernel as slow as its slowest lane: ~100 us
+// for a single pair that runs all 20 iterations with ~12 KB of per-lane scratch, on a chip the few thousand pairs leave idle.)
+// gjkPhase: 0 = no contact, 1 = `out` is final, 2 = intersecting, EPA to follow from `sx`
+__device__ inline int gjkPhase(const Shape& a, const Shape& b, const HullSet& hs, int mode, Simplex& sx, Manifold& out) {
+    switch (mode) {
+        case 2: {  // into the box frame (770-790, 1022-1043)
+            Shape c = a;
+            c.a = rotate(conj(b.rot), a.a - b.a) + b.a;
+            c.b = rotate(conj(b.rot), a.b - b.a) + b.a;
+            Shape box; box.type = T_AABB; box.a = b.a - b.b; box.b = b.a + b.b; box.radius = 0.f; box.hull = 0;
+            return gjkTest(c, box, hs, sx) ? 2 : 0;
+        }
+        case 3: {
+            bool hit;
+            if (cylinderCylinderParallel(a, b, hit, out)) return hit ? 1 : 0;
+            return gjkTest(a, b, hs, sx) ? 2 : 0;
+        }
+        default: return gjkTest(a, b, hs, sx) ? 2 : 0;
+    }
+}
+// = the EPA half of intersectGjkImpl, by one wave (every lane ends with the same `out`)
+__device__ inline void epaPhaseWave(const Shape& a, const Shape& b, const HullSet& hs, int mode, const Simplex& sx, EpaLds& lds, Manifold& out, uint32_t lane) {
+    EpaOut epa;
+    auto single = [&]() { out.n = epa.normal; out.count = 1; out.d[0] = epa.depth; out.p[0] = epa.point; };
+    switch (mode) {
+        case 1: epaRunWave(sx, a, b, hs, lds, epa, lane); single(); segmentShapeVsAABBAfterEpa(a, b, epa, out); break;
+        case 2: {
+            Shape c = a;
+            c.a = rotate(conj(b.rot), a.a - b.a) + b.a;
+            c.b = rotate(conj(b.rot), a.b - b.a) + b.a;
+            Shape box; box.type = T_AABB; box.a = b.a - b.b; box.b = b.a + b.b; box.radius = 0.f; box.hull = 0;
+            epaRunWave(sx, c, box, hs, lds, epa, lane); single(); segmentShapeVsAABBAfterEpa(c, box, epa, out);
+            out.n = rotate(b.rot, out.n);
+            for (uint32_t i = 0; i < out.count; ++i) out.p[i] = rotate(b.rot, out.p[i] - b.a) + b.a;
+        } break;
+        default: epaRunWave(sx, a, b, hs, lds, epa, lane); single(); break;
+    }
+}
+__device__ __forceinline__ int gjkPairShapes(uint64_t key, const float4* __restrict__ wShape, Shape& sa, Shape& sb) {
     uint32_t bucket = (uint32_t)(key >> 58), a = (uint32_t)((key >> 29) & 0x1FFFFFFFu), b = (uint32_t)(key & 0x1FFFFFFFu);
     uint32_t ta = 0, rem = bucket;
     while (rem >= 6u - ta) { rem -= 6u - ta; ++ta; }
     uint32_t tb = ta + rem;
     int mode = gjkMode(ta, tb);
-    if (mode < 0) return;
-    Shape sa = loadShape(wShape, a, ta), sb = loadShape(wShape, b, tb);
-    Manifold m; m.count = 0;
-    EpaState st;
-    bool hit = intersectGjkImpl(sa, sb, hs, st, m, mode);
-    uint32_t cnt = hit ? m.count : 0u;
-    npPacked[p] = cnt ? ((1ull << 32) | (uint64_t)cnt) : 0ull;
-    if (cnt) {
-        npNormal[p] = f4(m.n, 0.f);
-        for (uint32_t k = 0; k < cnt; ++k) npPoints[4 * p + k] = f4(m.p[k], m.d[k]);
+    if (mode < 0) return mode;
+    sa = loadShape(wShape, a, ta); sb = loadShape(wShape, b, tb);
+    return mode;
+}
+constexpr uint32_t kEpaSimplexRows = 9;   // 4 support points x (a, b, m) = 36 floats
+__global__ __launch_bounds__(64) void k_narrow_gjk(StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
+                                                   const float4* __restrict__ wShape,
+                                                   HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
+                                                   float4* __restrict__ npPoints, uint32_t* __restrict__ epaQueue, float4* __restrict__ epaSimplex, uint32_t epaCap) {
+    // [gjkLo, gjkHi) = span of the bucket-partitioned pair list that holds the GJK/EPA buckets (k_pair_finish)
+    uint32_t p = sc->gjkLo + blockIdx.x * blockDim.x + threadIdx.x;
+    int r = -1; Simplex sx; Manifold m; m.count = 0;
+    if (p < sc->gjkHi) {
+        const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
+        Shape sa, sb;
+        const int mode = gjkPairShapes(pairKeys[p], wShape, sa, sb);
+        if (mode >= 0) r = gjkPhase(sa, sb, hs, mode, sx, m);
+    }
+    if (r == 0 || r == 1) {
+        uint32_t cnt = r == 1 ? m.count : 0u;
+        npPacked[p] = cnt ? ((1ull << 32) | (uint64_t)cnt) : 0ull;
+        if (cnt) {
+            npNormal[p] = f4(m.n, 0.f);
+            for (uint32_t k = 0; k < cnt; ++k) npPoints[4 * p + k] = f4(m.p[k], m.d[k]);
+        }
+    }
+    // queue slots of the intersecting pairs: one atomic per wave
+    const bool want = r == 2;
+    const unsigned long long mask = __ballot(want);
+    if (!mask) return;
+    const uint32_t lane = threadIdx.x & 63u, leader = (uint32_t)__ffsll((long long)mask) - 1u;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(&sc->numEpa, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, (int)leader, 64);
+    if (!want) return;
+    const uint32_t slot = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+    if (slot >= epaCap) { sc->specOverflow = 1u; npPacked[p] = 0ull; return; }   // cannot happen: the queue holds as many entries as there are pairs
+    epaQueue[slot] = p;
+    float4* o = epaSimplex + (size_t)slot * kEpaSimplexRows;
+    const SupPt* q[4] = {&sx.a, &sx.b, &sx.c, &sx.d};
+    float f[36];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { f[9 * k] = q[k]->a.x; f[9 * k + 1] = q[k]->a.y; f[9 * k + 2] = q[k]->a.z; f[9 * k + 3] = q[k]->b.x; f[9 * k + 4] = q[k]->b.y; f[9 * k + 5] = q[k]->b.z; f[9 * k + 6] = q[k]->m.x; f[9 * k + 7] = q[k]->m.y; f[9 * k + 8] = q[k]->m.z; }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) o[k] = make_float4(f[4 * k], f[4 * k + 1], f[4 * k + 2], f[4 * k + 3]);
+}
+__global__ __launch_bounds__(64) void k_narrow_epa(const StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
+                                                   const float4* __restrict__ wShape, HullSet hs, const uint32_t* __restrict__ epaQueue, const float4* __restrict__ epaSimplex,
+                                                   uint32_t epaCap, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints) {
+    __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[sizeof(EpaLds)];   // (V3 has constructors: raw storage)
+    EpaLds& lds = *reinterpret_cast<EpaLds*>(ldsRaw);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n = min(sc->numEpa, epaCap);
+    const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
+    for (uint32_t entry = blockIdx.x; entry < n; entry += gridDim.x) {
+        const uint32_t p = epaQueue[entry];
+        Shape sa, sb;
+        const int mode = gjkPairShapes(pairKeys[p], wShape, sa, sb);
+        const float4* q = epaSimplex + (size_t)entry * kEpaSimplexRows;
+        float f[36];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { const float4 v = q[k]; f[4 * k] = v.x; f[4 * k + 1] = v.y; f[4 * k + 2] = v.z; f[4 * k + 3] = v.w; }
+        Simplex sx; sx.n = 4;
+        SupPt* d[4] = {&sx.a, &sx.b, &sx.c, &sx.d};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { d[k]->a = V3(f[9 * k], f[9 * k + 1], f[9 * k + 2]); d[k]->b = V3(f[9 * k + 3], f[9 * k + 4], f[9 * k + 5]); d[k]->m = V3(f[9 * k + 6], f[9 * k + 7], f[9 * k + 8]); }
+        Manifold m; m.count = 0;
+        epaPhaseWave(sa, sb, hs, mode, sx, lds, m, lane);
+        if (lane == 0) {
+            const uint32_t cnt = m.count;
+            npPacked[p] = cnt ? ((1ull << 32) | (uint64_t)cnt) : 0ull;
+            if (cnt) {
+                npNormal[p] = f4(m.n, 0.f);
+                for (uint32_t k = 0; k < cnt; ++k) npPoints[4 * p + k] = f4(m.p[k], m.d[k]);
+            }
+        }
+        __syncthreads();   // the polytope in LDS is reused by the next entry
     }
 }
 

@@ -62,6 +62,7 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numInteractions;      // ... of which the boolean overlap test passed (non_collision_interaction records)
     uint32_t numHmContacts;        // heightmap terrain: contacts of this step (each is a one-contact manifold) ...
     uint32_t numHmColliders;       // ... and the colliders they belong to (= the reference's collision count for the terrain)
+    uint32_t numEpa;               // intersecting GJK pairs queued for k_narrow_epa
     uint32_t xcdCount[8];          // XCD-partitioned solver: tiles owned by each XCD (k_build_tiles)
     uint32_t xccOf[8];             // ... and the hardware XCC id the workgroups with blockIdx % 8 == i really ran on (0xFFFFFFFF = none yet)
     uint32_t numCellsNext;         // cells of the grid k_pair_finish prepared for the next step

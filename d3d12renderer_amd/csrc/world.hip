@@ -182,7 +182,7 @@ struct mi_world {
     uint32_t gridCur = 0; bool gridValid = false; uint32_t gridNextCells = 0; DBuf<char> scalarsRaw; DBuf<Shards> shards;   // scalarsRaw = [StepScalars][colouring round flags]: one read-back
     StepScalars* scalarsPtr() { return reinterpret_cast<StepScalars*>(scalarsRaw.p); }
     uint32_t* roundFlagsPtr() { return reinterpret_cast<uint32_t*>(scalarsRaw.p + sizeof(StepScalars)); }
-    DBuf<uint64_t> pairKeys, pairKeysS; DBuf<uint8_t> manKept;   // manKept: manifold kept its colour (already in the next step's history)
+    DBuf<uint64_t> pairKeys, pairKeysS; DBuf<uint8_t> manKept; DBuf<uint32_t> epaQueue; DBuf<float4> epaSimplex;   // epaQueue / epaSimplex: k_narrow_gjk -> k_narrow_epa   // manKept: manifold kept its colour (already in the next step's history)
     DeviceScan<uint32_t> scanCells, scanBins; DeviceScan<unsigned long long> scanPairs, scanTerrain;   // one per scan site (own tickets / generations)
     // narrow phase
     DBuf<uint64_t> npPacked, npScan; DBuf<float4> npNormal, npPoints; DBuf<BoxHit> boxQueue;
@@ -691,7 +691,7 @@ __global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlag
         sc->numDead = 0; sc->shardOwned[0] = sc->shardOwned[1] = sc->shardOwned[2] = 0;
         for (int q = 0; q < 8; ++q) sc->shardSent[q] = 0;
         sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->solveError = 0;
-        sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0; sc->numEvents = 0; sc->numInterPairs = 0; sc->numInteractions = 0; sc->numHmContacts = 0; sc->numHmColliders = 0;
+        sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0; sc->numEvents = 0; sc->numInterPairs = 0; sc->numInteractions = 0; sc->numHmContacts = 0; sc->numHmColliders = 0; sc->numEpa = 0;
         for (int q = 0; q < 16; ++q) sc->boxHitCount[q] = 0;
         for (int q = 0; q < 8; ++q) { sc->xcdCount[q] = 0; sc->xccOf[q] = 0xFFFFFFFFu; }
         for (int a = 0; a < 3; ++a) { sc->boundsMin[a] = 0x7FFFFFFF; sc->boundsMax[a] = (int)0x80000000; }
@@ -983,7 +983,11 @@ enqueue_section:
         L.launch(k_narrow, dim3(narrowBlocks), dim3(B), 0, st, pairBound, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p, boxQueue.p);
         L.launch(k_narrow_clip, dim3(kBoxQueues * (queueRegion / B)), dim3(B), 0, st, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, boxQueue.p, npPacked.p, npNormal.p, npPoints.p);
         // (a GJK-only kernel feeding a queue of hits to an EPA kernel was measured: no gain — the GJK half already needs ~250 VGPRs)
-        if (usesGjk) L.launch(k_narrow_gjk, dim3(divUp(pairBound, 64)), dim3(64), 0, st, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
+        if (usesGjk) {
+            HIP_TRY(epaQueue.ensure(pairBound)); HIP_TRY(epaSimplex.ensure((size_t)pairBound * kEpaSimplexRows));
+            L.launch(k_narrow_gjk, dim3(divUp(pairBound, 64)), dim3(64), 0, st, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p, epaQueue.p, epaSimplex.p, pairBound);
+            L.launch(k_narrow_epa, dim3(std::min(pairBound, 8192u)), dim3(64), 0, st, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, epaQueue.p, epaSimplex.p, pairBound, npPacked.p, npNormal.p, npPoints.p);
+        }
         if (heightmap) {
             const HmOut hmOut{sc, pairBound, pairKeys.p, pairKeysS.p, npPacked.p, npNormal.p, npPoints.p};
             L.launch(k_hm_contacts<true>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut);
