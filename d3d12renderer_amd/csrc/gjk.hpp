@@ -917,6 +917,69 @@ __device__ __forceinline__ int gjkPairShapes(uint64_t key, const float4* __restr
     sa = loadShape(wShape, a, ta); sb = loadShape(wShape, b, tb);
     return mode;
 }
+// gjkTest / gjkPhase with the support queries shared by the lanes of a wave (hull vertices), everything else computed by every lane alike
+__device__ inline bool gjkTestWave(const Shape& A, const Shape& B, const HullSet& hs, Simplex& sx, uint32_t lane) {
+    V3 dir(1.f, 0.1f, -0.2f);
+    sx.n = 0;
+    sx.c = supportPairWave(A, B, hs, dir, lane);
+    if (dot(sx.c.m, dir) < 0.f) return false;
+    dir = -sx.c.m;
+    sx.b = supportPairWave(A, B, hs, dir, lane);
+    if (dot(sx.b.m, dir) < 0.f) return false;
+    dir = crossABA(sx.c.m - sx.b.m, -sx.b.m);
+    sx.n = 2;
+    for (int guard = 0; guard < 64; ++guard) {
+        if (sqlen(dir) < 0.0001f) return false;
+        SupPt a = supportPairWave(A, B, hs, dir, lane);
+        if (dot(a.m, dir) < 0.f) return false;
+        int r = updateSimplex(sx, a, dir);
+        if (r == GJK_STOP) { sx.a = a; sx.n = 4; return true; }
+        if (r == GJK_ERR) return false;
+    }
+    return false;
+}
+__device__ inline int gjkPhaseWave(const Shape& a, const Shape& b, const HullSet& hs, int mode, Simplex& sx, Manifold& out, uint32_t lane) {
+    switch (mode) {
+        case 2: {
+            Shape c = a;
+            c.a = rotate(conj(b.rot), a.a - b.a) + b.a;
+            c.b = rotate(conj(b.rot), a.b - b.a) + b.a;
+            Shape box; box.type = T_AABB; box.a = b.a - b.b; box.b = b.a + b.b; box.radius = 0.f; box.hull = 0;
+            return gjkTestWave(c, box, hs, sx, lane) ? 2 : 0;
+        }
+        case 3: {
+            bool hit;
+            if (cylinderCylinderParallel(a, b, hit, out)) return hit ? 1 : 0;
+            return gjkTestWave(a, b, hs, sx, lane) ? 2 : 0;
+        }
+        default: return gjkTestWave(a, b, hs, sx, lane) ? 2 : 0;
+    }
+}
+// GJK and EPA of a pair by one wave, no queue: the variant for FEW pairs (a lane-per-pair GJK lasts as long as its slowest lane)
+__global__ __launch_bounds__(64) void k_narrow_gjk_wave(const StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
+                                                        const float4* __restrict__ wShape, HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints) {
+    __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[sizeof(EpaLds)];
+    EpaLds& lds = *reinterpret_cast<EpaLds*>(ldsRaw);
+    const uint32_t lane = threadIdx.x;
+    const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
+    for (uint32_t p = sc->gjkLo + blockIdx.x; p < sc->gjkHi; p += gridDim.x) {
+        Shape sa, sb;
+        const int mode = gjkPairShapes(pairKeys[p], wShape, sa, sb);
+        if (mode < 0) continue;
+        Simplex sx; Manifold m; m.count = 0;
+        const int r = gjkPhaseWave(sa, sb, hs, mode, sx, m, lane);
+        if (r == 2) epaPhaseWave(sa, sb, hs, mode, sx, lds, m, lane);
+        if (lane == 0) {
+            const uint32_t cnt = r ? m.count : 0u;
+            npPacked[p] = cnt ? ((1ull << 32) | (uint64_t)cnt) : 0ull;
+            if (cnt) {
+                npNormal[p] = f4(m.n, 0.f);
+                for (uint32_t k = 0; k < cnt; ++k) npPoints[4 * p + k] = f4(m.p[k], m.d[k]);
+            }
+        }
+        __syncthreads();
+    }
+}
 constexpr uint32_t kEpaSimplexRows = 9;   // 4 support points x (a, b, m) = 36 floats
 __global__ __launch_bounds__(64) void k_narrow_gjk(StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                    const float4* __restrict__ wShape,

@@ -281,7 +281,8 @@ struct mi_world {
     void dropStepGraphs() { for (StepGraph& g : stepGraphs) if (g.exec) (void)hipGraphExecDestroy(g.exec); stepGraphs.clear(); graphLastSig = graphPrevSig = 0; }
     void mirrorSchedule();
     // speculative (single read-back) stepping: upper bounds come from the last valid step
-    struct LastCounts { uint32_t numPairs = 0, numManifolds = 0, numContacts = 0, numCells = 0, colorRounds = 0, numSmall = 0, numLarge = 0, numInterPairs = 0, numInteractions = 0; } last;
+    struct LastCounts { uint32_t numPairs = 0, numManifolds = 0, numContacts = 0, numCells = 0, colorRounds = 0, numSmall = 0, numLarge = 0, numInterPairs = 0, numInteractions = 0, gjkSpan = 0; } last;
+    uint32_t gjkWaveMaxPairs = 16384;   // GJK bucket span up to which k_narrow_gjk_wave (one wave per pair) beats lanes + EPA queue
     bool specEnabled = true, haveEstimates = false;
     uint32_t specRetries = 0, specSteps = 0, totalSteps = 0, colorRoundsLaunched = 0;
     uint32_t sapAxis = 0;        // sorting axis for the next step (collision_broad.cpp:443-444), host copy
@@ -358,6 +359,7 @@ mi_world::~mi_world() {
     if (downloadStage) (void)hipHostFree(downloadStage);
     if (shard.sentHost) (void)hipHostFree(shard.sentHost);
     shardReleaseComm();
+    if (graphDebug) std::fprintf(stderr, "[mi_physics] GJK bucket span of the last step (sticky bound): %u pairs\n", last.gjkSpan);
     if (graphDebug) std::fprintf(stderr, "[mi_physics] step graphs: %u replayed, %u captured, %u plain speculative steps, %llu steps in total\n", graphHits, graphCaptures, graphPlain, (unsigned long long)totalSteps);
     dropStepGraphs();
     if (stream) (void)hipStreamDestroy(stream);
@@ -985,8 +987,14 @@ enqueue_section:
         // (a GJK-only kernel feeding a queue of hits to an EPA kernel was measured: no gain — the GJK half already needs ~250 VGPRs)
         if (usesGjk) {
             HIP_TRY(epaQueue.ensure(pairBound)); HIP_TRY(epaSimplex.ensure((size_t)pairBound * kEpaSimplexRows));
+            // few GJK pairs (vehicles on hull tiles, a handful of capsules): one WAVE per pair for GJK as well; many: GJK by lanes, EPA by waves
+            static const int gjkWaveMode = std::getenv("MI_GJK_WAVE") ? atoi(std::getenv("MI_GJK_WAVE")) : -1;   // 0 / 1 force a variant (tests, tuning)
+            const bool gjkWave = gjkWaveMode >= 0 ? gjkWaveMode != 0 : (spec ? last.gjkSpan <= gjkWaveMaxPairs : false);
+            if (gjkWave) L.launch(k_narrow_gjk_wave, dim3(std::min(pairBound, 16384u)), dim3(64), 0, st, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p);
+            else {
             L.launch(k_narrow_gjk, dim3(divUp(pairBound, 64)), dim3(64), 0, st, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p, epaQueue.p, epaSimplex.p, pairBound);
             L.launch(k_narrow_epa, dim3(std::min(pairBound, 8192u)), dim3(64), 0, st, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, epaQueue.p, epaSimplex.p, pairBound, npPacked.p, npNormal.p, npPoints.p);
+            }
         }
         if (heightmap) {
             const HmOut hmOut{sc, pairBound, pairKeys.p, pairKeysS.p, npPacked.p, npNormal.p, npPoints.p};
@@ -1403,6 +1411,7 @@ enqueue_section:
     last.numPairs = sticky(hs.numPairs, last.numPairs, 256); last.numManifolds = sticky(hs.numManifolds, last.numManifolds, 256);
     last.numContacts = sticky(hs.numContacts, last.numContacts, 256); last.numCells = sticky(hs.numCells, last.numCells, 1024);
     last.numSmall = sticky(nc - std::min(nc, hs.numLarge + hs.numDead), last.numSmall, 256); last.numLarge = sticky(hs.numLarge, last.numLarge, 16);
+    last.gjkSpan = sticky(hs.gjkHi - hs.gjkLo, last.gjkSpan, 256);
     last.numInterPairs = sticky(hs.numInterPairs, last.numInterPairs, 256); last.numInteractions = sticky(hs.numInteractions, last.numInteractions, 256);
     for (int k = 0; k < 3; ++k) shard.owned[k] = hs.shardOwned[k];
     shard.flagsSwapPending = shard.enabled; shard.stepOpen = false;

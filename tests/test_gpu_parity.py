@@ -380,6 +380,26 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
     assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
 
 
+@pytest.mark.parametrize("variant", ["0", "1"], ids=["GJK by lanes + EPA queue", "GJK and EPA by one wave per pair"])
+@pytest.mark.parametrize("make", [lambda: scenes.shape_zoo(8, 5, 8), lambda: scenes.vehicles(3, 2), lambda: scenes.zones(8, 3, 8)], ids=["all shape pairs", "hull terrain", "triggers"])
+def test_gpu_gjk_epa_variants_match_oracle(mi_lib, oracle_mod, monkeypatch, make, variant):
+    """The two mappings of GJK / EPA to the chip (the library picks by the number of GJK pairs; MI_GJK_WAVE forces one): EPA always by
+    one wave per pair with the polytope in LDS — closest face, visible faces, horizon edges and hull supports found by the lanes
+    together, picking what the sequential scans pick — GJK either by one lane per pair or by the same wave.  Bit-identical to the
+    oracle (which restates the reference's sequential EPA, and is pinned to the reference's own code)."""
+    monkeypatch.setenv("MI_GJK_WAVE", variant)
+    sc = make()
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    for i in range(160):
+        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        assert g.counts() == o.counts(), f"step {i}"
+        if i % 40 == 0:
+            assert contact_set(g.contacts()) == contact_set(o.contacts()), f"step {i}"
+    pg, qg = g.physics_transforms(); po, qo = o.physics_transforms()
+    assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
+
+
 def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
     """Steps after the first run with ONE host read-back, sized from the previous step's counts.  Teleporting the bodies into
     a much denser pile invalidates those bounds: the step must be re-run synchronously from the untouched state and still match
