@@ -678,7 +678,35 @@ __device__ inline bool epaAddPointWave(EpaLds& s, uint32_t& nTris, uint32_t& nPt
         s.tris[triIndex] = t;
     }
     waveSync();
-    if (lane == 0) {   // the order-sensitive part of both sequential loops (a point may be the `connect` of two horizon edges on a degenerate polytope)
+    // The link updates of both sequential loops are order-sensitive only if a point is the `connect` of two horizon edges (a degenerate
+    // polytope): with distinct points — a proper horizon loop — every lane links its own edge, else lane 0 replays the loops in order.
+    uint32_t myConnect = 0xFFFFFFFFu, myOther = 0xFFFFFFFFu;   // the edge's end the new edge starts from (first loop) / the end whose new edge closes the face (second loop)
+    if (lane < nb) { const EpaEdge e = s.edges[s.border[lane]]; const bool aAct = s.active[e.tA] != 0, bAct = s.active[e.tB] != 0; myConnect = bAct ? e.a : e.b; myOther = aAct ? e.a : e.b; }
+    unsigned int pointBits = lane < nb ? (1u << myConnect) : 0u, otherBits = lane < nb ? (1u << myOther) : 0u;   // kEpaPts = 24 points
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { pointBits |= (unsigned int)__shfl_xor((int)pointBits, off, 64); otherBits |= (unsigned int)__shfl_xor((int)otherBits, off, 64); }
+    const bool distinct = (uint32_t)__popc(pointBits) == nb && (uint32_t)__popc(otherBits) == nb;
+    if (distinct) {
+        if (lane < nb) {
+            const uint16_t ei = s.border[lane];
+            const EpaEdge e = s.edges[ei];
+            const bool aAct = s.active[e.tA] != 0;
+            const uint16_t triIndex = (uint16_t)(triOffset + lane);
+            s.newEdgePerPoint[myConnect] = (uint16_t)(edgeOffset + lane);
+            if (aAct) s.edges[ei].tB = triIndex; else s.edges[ei].tA = triIndex;
+        }
+        waveSync();
+        if (lane < nb) {
+            s.active[triOffset + lane] = 1;
+            const EpaEdge e = s.edges[s.border[lane]];
+            const bool bNew = e.tB >= triOffset;
+            const uint16_t connect = bNew ? e.a : e.b;
+            const uint16_t other = s.newEdgePerPoint[connect];
+            const uint16_t triIndex = (uint16_t)(lane + triOffset);
+            s.tris[triIndex].eB = other;
+            s.edges[other].tA = triIndex;
+        }
+    } else if (lane == 0) {
         for (uint32_t i = 0; i < nb; ++i) {
             const uint16_t ei = s.border[i];
             const EpaEdge e = s.edges[ei];
