@@ -111,9 +111,13 @@ static void hostParallelFor(uint32_t n, F&& fn) {
     if (threads <= 1) { for (uint32_t i = 0; i < n; ++i) fn(i); return; }
     std::vector<std::thread> pool; pool.reserve(threads - 1);
     const uint32_t per = (n + threads - 1) / threads;
-    for (uint32_t t = 1; t < threads; ++t)
-        pool.emplace_back([&fn, t, per, n]() { const uint32_t lo = t * per, hi = std::min(n, lo + per); for (uint32_t i = lo; i < hi; ++i) fn(i); });
+    uint32_t started = 1;
+    for (uint32_t t = 1; t < threads; ++t) {
+        try { pool.emplace_back([&fn, t, per, n]() { const uint32_t lo = t * per, hi = std::min(n, lo + per); for (uint32_t i = lo; i < hi; ++i) fn(i); }); ++started; }
+        catch (...) { break; }   // no more threads to be had: this thread takes the rest
+    }
     for (uint32_t i = 0; i < std::min(n, per); ++i) fn(i);
+    for (uint32_t i = std::min(n, started * per); i < n; ++i) fn(i);
     for (std::thread& th : pool) th.join();
 }
 
