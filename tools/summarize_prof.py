@@ -14,6 +14,18 @@ if ks.exists():
         for r in rows:
             r[0] = r[0][:110]
             w.writerow(r)
+# 1b. kernel trace of the same pass: per-kernel mean duration of the LAST 20 dispatches = the timed steps of `bench.py --steps 20` (+ its 3
+# profiled steps): the figure bench.py's roofline.avg_launch_us has to agree with (the stats csv above averages over the settle phase too)
+tr = sorted((raw / "stats").glob("*_kernel_trace.csv"))
+if tr:
+    dur = collections.defaultdict(list)
+    rows = list(csv.DictReader(open(tr[0])))
+    rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+    for r in rows:
+        dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    steady = {k: {"steady_avg_us": sum(v[-min(20, len(v)):]) / min(20, len(v)), "avg_us": sum(v) / len(v), "dispatches": len(v)} for k, v in dur.items()}
+    json.dump(steady, open(out / f"{prefix}_kernel_steady.json", "w"), indent=1)
+    print(json.dumps({k: round(v["steady_avg_us"], 1) for k, v in steady.items() if "contact_solve" in k}))
 # 2. PMC: per-kernel mean of the counter
 summary = {}
 for name in ("FETCH_SIZE", "WRITE_SIZE"):
