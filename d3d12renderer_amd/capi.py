@@ -137,6 +137,14 @@ class Library:
         self.check(self.fn("shard_tile_of_rank")(C.c_uint32(tiles_x), C.c_uint32(tiles_z), C.c_uint32(rank), C.byref(out)), "shard_tile_of_rank")
         return out.value
 
+    def shard_balance_borders(self, hist, lo, hi, tiles, cur, margin):
+        """Borders (tiles - 1) that even out the body counts of `hist` (bins over [lo, hi), summed over all ranks), clamped to what one
+        change may do from `cur` (include/mi_shard.h); the same on every rank for the same input."""
+        h = np.ascontiguousarray(hist, np.uint64); c = np.ascontiguousarray(cur, np.float32); out = np.zeros(max(tiles - 1, 1), np.float32)
+        self.check(self.fn("shard_balance_borders")(_ptr(h), C.c_uint32(len(h)), C.c_float(lo), C.c_float(hi), C.c_uint32(tiles), _ptr(c) if tiles > 1 else None,
+                                                    C.c_float(margin), _ptr(out) if tiles > 1 else None), "shard_balance_borders")
+        return out[: tiles - 1]
+
     def check(self, rc, what):
         if rc != MI_OK:
             raise PhysicsError(f"{self.prefix}{what} failed with status {rc}: {self.last_error()}")
@@ -423,6 +431,23 @@ class World:
         out = np.zeros(max(n.value, 1), np.uint32)
         self.L.check(self.L.fn("world_shard_owned_entities")(self.h, _ptr(out), C.c_uint32(len(out)), C.byref(n)), "world_shard_owned_entities")
         return out[: n.value]
+
+    def shard_histogram(self, axis, lo, hi, bins):
+        """Owned bodies of the last step per bin of [lo, hi) along x (axis 0) or z (axis 1)."""
+        out = np.zeros(bins, np.uint32)
+        self.L.check(self.L.fn("world_shard_histogram")(self.h, C.c_uint32(axis), C.c_float(lo), C.c_float(hi), C.c_uint32(bins), _ptr(out)), "world_shard_histogram")
+        return out
+
+    def shard_get_borders(self, tiles_x, tiles_z):
+        bx = np.zeros(max(tiles_x - 1, 1), np.float32); bz = np.zeros(max(tiles_z - 1, 1), np.float32)
+        self.L.check(self.L.fn("world_shard_get_borders")(self.h, _ptr(bx), _ptr(bz)), "world_shard_get_borders")
+        return bx[: tiles_x - 1], bz[: tiles_z - 1]
+
+    def shard_set_borders(self, borders_x=None, borders_z=None):
+        """New interior tile borders (None = unchanged), in force after the next internal step's exchange; identical on every rank."""
+        bx = None if borders_x is None else np.ascontiguousarray(borders_x, np.float32)
+        bz = None if borders_z is None else np.ascontiguousarray(borders_z, np.float32)
+        self.L.check(self.L.fn("world_shard_set_borders")(self.h, _ptr(bx) if bx is not None and len(bx) else None, _ptr(bz) if bz is not None and len(bz) else None), "world_shard_set_borders")
 
     def shard_message_bytes(self):
         n = C.c_uint64()

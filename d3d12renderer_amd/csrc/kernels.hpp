@@ -1279,10 +1279,11 @@ __global__ __launch_bounds__(256) void k_gather_states(uint32_t n, const uint32_
 }
 __global__ __launch_bounds__(256) void k_scatter_states(uint32_t n, const uint32_t* __restrict__ ids, const float* __restrict__ in,
                                                         float4* __restrict__ bPos, float4* __restrict__ bRot, float4* __restrict__ bLinVel,
-                                                        float4* __restrict__ bAngVel) {
+                                                        float4* __restrict__ bAngVel, uint8_t* __restrict__ shardKnown /* sharded world: the caller's state is authoritative; or null */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t b = ids[i];
+    if (shardKnown) shardKnown[b] = 1u;
     const float* s = in + 13 * (size_t)i;
     bPos[b] = make_float4(s[0], s[1], s[2], 0.f); bRot[b] = make_float4(s[3], s[4], s[5], s[6]);
     bLinVel[b] = make_float4(s[7], s[8], s[9], 0.f); bAngVel[b] = make_float4(s[10], s[11], s[12], 0.f);
@@ -2348,36 +2349,35 @@ __global__ void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slo
 // of gravity lies in its tile (OWNED: it integrates them) plus those within `margin` of the tile (GHOSTS: they take part in its
 // collision detection and solve, their new state comes from their owner).  Tiles on the rim of the grid extend to infinity.
 // Ownership follows the bodies: it is recomputed from the positions at the start of every step (migration needs no bookkeeping).
+// Tiles are cut by BORDERS, uniform when sharding is enabled and moved by mi_world_shard_set_borders (load balance).  A rank only ever tests its own
+// tile and its <= 8 neighbours', so it carries the borders of tile columns / rows (mine - 1) .. (mine + 2): bx[1] <= x < bx[2] is this rank's column,
+// -inf / +inf beyond the rim of the grid (rim tiles are unbounded outwards).
 struct ShardParams {
-    float originX, originZ, tileX, tileZ, margin;
+    float bx[4], bz[4], margin;
     uint32_t tilesX, tilesZ, myTile;
     uint32_t numPeers; uint32_t peers[8];     // neighbouring tiles (|dx| <= 1, |dz| <= 1), ascending tile index
 };
-__device__ __forceinline__ uint32_t shardTileOf(const ShardParams& sp, float x, float z) {
-    const int tx = min(max((int)floorf((x - sp.originX) / sp.tileX), 0), (int)sp.tilesX - 1);
-    const int tz = min(max((int)floorf((z - sp.originZ) / sp.tileZ), 0), (int)sp.tilesZ - 1);
-    return (uint32_t)tz * sp.tilesX + (uint32_t)tx;
-}
-// is (x, z) inside tile `t` grown by the margin?  (rim tiles are unbounded outwards)
+__device__ __forceinline__ bool shardOwns(const ShardParams& sp, float x, float z) { return x >= sp.bx[1] && x < sp.bx[2] && z >= sp.bz[1] && z < sp.bz[2]; }
+// is (x, z) inside tile `t` (this rank's or a neighbour's) grown by the margin?
 __device__ __forceinline__ bool shardInExtended(const ShardParams& sp, uint32_t t, float x, float z) {
-    const uint32_t tx = t % sp.tilesX, tz = t / sp.tilesX;
-    const float x0 = sp.originX + (float)tx * sp.tileX - sp.margin, x1 = sp.originX + (float)(tx + 1u) * sp.tileX + sp.margin;
-    const float z0 = sp.originZ + (float)tz * sp.tileZ - sp.margin, z1 = sp.originZ + (float)(tz + 1u) * sp.tileZ + sp.margin;
-    return (tx == 0u || x >= x0) && (tx + 1u == sp.tilesX || x < x1) && (tz == 0u || z >= z0) && (tz + 1u == sp.tilesZ || z < z1);
+    const uint32_t dx = t % sp.tilesX + 1u - sp.myTile % sp.tilesX, dz = t / sp.tilesX + 1u - sp.myTile / sp.tilesX;   // 0 .. 2
+    return x >= sp.bx[dx] - sp.margin && x < sp.bx[dx + 1u] + sp.margin && z >= sp.bz[dz] - sp.margin && z < sp.bz[dz + 1u] + sp.margin;
 }
 __device__ __forceinline__ V3 shardCog(float4 pos, float4 rot, float4 cogInvMass) { return xyz(pos) + rotate(toQ(rot), xyz(cogInvMass)); }
 
 // start of a step: 1 = owned, 2 = ghost, 0 = not simulated here
 __global__ __launch_bounds__(256) void k_shard_classify(uint32_t nb, ShardParams sp, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
                                                         const float4* __restrict__ bCogInvMass, uint8_t* __restrict__ bodyActive, Shards* sh,
-                                                        const uint32_t* __restrict__ root /* lowest body index of the body's articulated island: the island is classified as ONE */) {
+                                                        const uint32_t* __restrict__ root /* lowest body index of the body's articulated island: the island is classified as ONE */,
+                                                        const uint8_t* __restrict__ known /* 1 = this rank's copy of the body is current (owned in the last step, or a record arrived) */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     bool owned = false;
     if (i < nb) {
         const uint32_t r = root[i];
         const V3 c = shardCog(bPos[r], bRot[r], bCogInvMass[r]);
-        owned = shardTileOf(sp, c.x, c.z) == sp.myTile;
-        bodyActive[i] = owned ? 1u : shardInExtended(sp, sp.myTile, c.x, c.z) ? 2u : 0u;
+        const bool k = known[r] != 0u;      // a copy that is not current says nothing about where the body is (it may lie in a tile that has since grown)
+        owned = k && shardOwns(sp, c.x, c.z);
+        bodyActive[i] = owned ? 1u : (k && shardInExtended(sp, sp.myTile, c.x, c.z)) ? 2u : 0u;
     }
     // counted per workgroup into one of kShards lines (summed by k_integrate_velocities): a same-address atomic per wave was 45 us of a 2 M-body scene
     __shared__ uint32_t cnt;
@@ -2412,13 +2412,14 @@ __global__ __launch_bounds__(256) void k_shard_count(uint32_t nb, const uint2* _
 constexpr uint32_t kShardRecordFloats = 14;
 struct ShardBufs { float* p[8]; };   // one message buffer per neighbour slot
 // one launch for all neighbours (the record counts start at zero: k_reset_scalars)
-__global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp, const uint8_t* __restrict__ bodyActive,
+__global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp, ShardParams spNext, uint32_t bordersPending, uint8_t* __restrict__ known, const uint8_t* __restrict__ bodyActive,
                                                     const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bLinVel,
                                                     const float4* __restrict__ bAngVel, const float4* __restrict__ bPosOld, const float4* __restrict__ bRotOld,
                                                     const float4* __restrict__ bCogInvMass, ShardBufs out, uint32_t capacity, StepScalars* sc,
                                                     const uint32_t* __restrict__ root) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const bool owned = i < nb && bodyActive[i] == 1u;
+    if (i < nb) known[i] = owned ? 1u : 0u;   // what this rank knows from here on: the bodies it owned; the records about to arrive add the neighbours' (k_shard_unpack)
     if (!__ballot(owned)) return;
     V3 cn(0.f, 0.f, 0.f), co(0.f, 0.f, 0.f);
     float4 p = make_float4(0, 0, 0, 0), q = p, v = p, w = p;
@@ -2430,7 +2431,9 @@ __global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp,
     }
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t slot = 0; slot < sp.numPeers; ++slot) {
-        const bool want = owned && (shardInExtended(sp, sp.peers[slot], cn.x, cn.z) || shardInExtended(sp, sp.peers[slot], co.x, co.z));
+        // borders about to move: also what the neighbour simulates under the NEW borders (it classifies with them from the next step on)
+        const bool want = owned && (shardInExtended(sp, sp.peers[slot], cn.x, cn.z) || shardInExtended(sp, sp.peers[slot], co.x, co.z) ||
+                                    (bordersPending && shardInExtended(spNext, sp.peers[slot], cn.x, cn.z)));
         const unsigned long long mask = __ballot(want);
         if (!mask) continue;
         const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
@@ -2448,7 +2451,7 @@ __global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp,
 __global__ void k_shard_pack_headers(uint32_t numPeers, const StepScalars* __restrict__ sc, ShardBufs out) { if (threadIdx.x < numPeers) out.p[threadIdx.x][0] = __uint_as_float(sc->shardSent[threadIdx.x]); }
 // blockIdx.y = neighbour slot (a body has one owner: the messages never touch the same body)
 __global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, ShardBufs in, uint32_t capacity, float4* __restrict__ bPos, float4* __restrict__ bRot,
-                                                      float4* __restrict__ bLinVel, float4* __restrict__ bAngVel) {
+                                                      float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, uint8_t* __restrict__ known) {
     const float* msg = in.p[blockIdx.y];
     const uint32_t count = min(__float_as_uint(msg[0]), capacity);
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -2458,6 +2461,19 @@ __global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, ShardBufs in,
     if (b >= nb) return;
     bPos[b] = make_float4(s[1], s[2], s[3], 0.f); bRot[b] = make_float4(s[4], s[5], s[6], s[7]);
     bLinVel[b] = make_float4(s[8], s[9], s[10], 0.f); bAngVel[b] = make_float4(s[11], s[12], s[13], 0.f);
+    known[b] = 1u;
+}
+// owned bodies per bin of [lo, hi) along x (axis 0) or z (1), by the centre their island was classified with; the end bins take what lies outside
+__global__ __launch_bounds__(256) void k_shard_histogram(uint32_t nb, uint32_t axis, float lo, float scale, uint32_t bins, const uint8_t* __restrict__ bodyActive,
+                                                         const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bCogInvMass,
+                                                         const uint32_t* __restrict__ root, uint32_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb || bodyActive[i] != 1u) return;
+    const uint32_t r = root[i];
+    const V3 c = shardCog(bPos[r], bRot[r], bCogInvMass[r]);
+    const float v = ((axis ? c.z : c.x) - lo) * scale;
+    const uint32_t bin = v >= (float)bins ? bins - 1u : v > 0.f ? (uint32_t)(int)v : 0u;
+    atomicAdd(&out[bin], 1u);
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------

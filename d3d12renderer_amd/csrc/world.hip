@@ -5,6 +5,7 @@
 // hooks that feed it (src/scene/scene.h:35-112).  There is NO CPU fallback: without a HIP device
 // mi_world_create fails with MI_ERR_NO_DEVICE.
 #include <cstring>
+#include <limits>
 #include <cstdio>
 #include <cmath>
 #include <string.h>
@@ -96,6 +97,7 @@ struct HBody {
     float gravityFactor, linDamp, angDamp;
     V3 linVel, angVel, force, torque;
     V3 p0, p1; Q4 r0, r1;
+    uint8_t shardKnown = 1;   // sharded world: this rank's copy of the body is current (mirror of ShardState::known across re-uploads; follows the body through deletions)
 };
 struct HCollider { uint32_t entity; mi_collider_desc desc; };
 struct HHull { std::vector<V3> verts; std::vector<uint32_t> tris; V3 mn, mx; };
@@ -145,6 +147,10 @@ struct mi_world {
     struct ShardState {
         bool enabled = false, rccl = false;
         mi_shard_desc desc{}; ShardParams sp{};
+        std::vector<float> bordersX, bordersZ;   // interior tile borders (tiles - 1 per axis): uniform at enable, moved by mi_world_shard_set_borders
+        std::vector<float> nextX, nextZ; ShardParams spNext{}; bool bordersPending = false;   // ... in force after the next step's exchange
+        DBuf<uint8_t> known;                     // per body: this rank's copy is current (owned in the last step, or a record arrived)
+        DBuf<uint32_t> hist;
         uint32_t capacity = 0; std::vector<uint32_t> peerRanks;
         DBuf<uint8_t> active, activePrev; bool prevValid = false, flagsSwapPending = false, stepOpen = false;   // activePrev: the previous valid step's flags (k_integrate_velocities skips bodies idle in both)
         DBuf<float> sendBuf[8], recvBuf[8];
@@ -156,6 +162,7 @@ struct mi_world {
         size_t messageFloats() const { return (size_t)(capacity + 1u) * kShardRecordFloats; }
     } shard;
     int shardExchange();
+    void shardFillBorders(ShardParams& sp, const std::vector<float>& bx, const std::vector<float>& bz) const;
     int shardBuildRoots();
     void shardReleaseComm();
     bool transformsFollowPhysics = false;   // last stepped through mi_world_step_fixed: entity transforms = physics_transform1 at the next download
@@ -588,7 +595,12 @@ int mi_world::upload() {
     }
     HIP_TRY(hipStreamSynchronize(stream));
     topologyDirty = false; hostStale = false; haveEstimates = false; gridValid = false;
-    if (shard.enabled) { int rc = shardBuildRoots(); if (rc != MI_OK) return rc; }   // the previous step's counts say nothing about the new topology
+    if (shard.enabled) {   // the previous step's counts say nothing about the new topology
+        int rc = shardBuildRoots(); if (rc != MI_OK) return rc;
+        std::vector<uint8_t> kn(std::max(nb, 1u), 1u);
+        for (uint32_t i = 0; i < nb; ++i) kn[i] = bodies[i].shardKnown;
+        HIP_TRY(shard.known.ensure(kn.size())); HIP_TRY(hipMemcpy(shard.known.p, kn.data(), kn.size(), hipMemcpyHostToDevice));
+    }
     return MI_OK;
 }
 
@@ -680,6 +692,11 @@ int mi_world::download() {
             }
         });
         p0OnDevice = false; lerpPending = false;
+        if (shard.enabled && shard.known.p && shard.known.cap >= nb) {
+            std::vector<uint8_t> kn(nb);
+            HIP_TRY(hipMemcpy(kn.data(), shard.known.p, nb, hipMemcpyDeviceToHost));
+            for (uint32_t i = 0; i < nb; ++i) bodies[i].shardKnown = kn[i];
+        }
     }
     hostStale = false;
     return MI_OK;
@@ -916,7 +933,7 @@ enqueue_section:
         HIP_TRY(shard.activePrev.ensure(std::max(nb, 1u)));
         if (shard.flagsSwapPending) { std::swap(shard.active.p, shard.activePrev.p); std::swap(shard.active.cap, shard.activePrev.cap); shard.flagsSwapPending = false; }   // (not on the synchronous re-run of a step)
         if (!shard.prevValid) { HIP_TRY(L.memsetAsync(shard.activePrev.p, 1, nb, st)); if (!L.dry) shard.prevValid = true; }   // after an upload / an outside write: every body is copied once
-        L.launch(k_shard_classify, dim3(divUp(nb, B)), dim3(B), 0, st, nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, shards.p, shard.root.p);
+        L.launch(k_shard_classify, dim3(divUp(nb, B)), dim3(B), 0, st, nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, shards.p, shard.root.p, shard.known.p);
     }
     if (nc) {
         L.launch(k_world_colliders, dim3(divUp(nc, B)), dim3(B), 0, st, nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
@@ -2255,10 +2272,11 @@ int mi_world::shardExchange() {
     ShardBufs sendBufs{}, recvBufs{};
     for (uint32_t k = 0; k < sh.sp.numPeers; ++k) { sendBufs.p[k] = sh.sendBuf[k].p; recvBufs.p[k] = sh.recvBuf[k].p; }
     // after a valid step the buffer sets are swapped: bPos = the new state, bPosN = the state the step started from; the record counts were cleared by k_reset_scalars
-    k_shard_pack<<<divUp(nb, 256), 256, 0, st>>>(nb, sh.sp, sh.active.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bPosN.p, bRotN.p, bCogInvMass.p, sendBufs, sh.capacity, sc, sh.root.p);
+    k_shard_pack<<<divUp(nb, 256), 256, 0, st>>>(nb, sh.sp, sh.bordersPending ? sh.spNext : sh.sp, sh.bordersPending ? 1u : 0u, sh.known.p, sh.active.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bPosN.p, bRotN.p, bCogInvMass.p, sendBufs, sh.capacity, sc, sh.root.p);
     k_shard_pack_headers<<<1, 8, 0, st>>>(sh.sp.numPeers, sc, sendBufs);
     HIP_TRY(hipMemcpyAsync(sh.sentHost, &sc->shardSent[0], 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     sh.sentPending = true;
+    if (sh.bordersPending) { sh.sp = sh.spNext; sh.bordersX = sh.nextX; sh.bordersZ = sh.nextZ; sh.bordersPending = false; }   // the next step classifies with the new borders
     if (!sh.rccl) { HIP_TRY(hipStreamSynchronize(st)); return MI_OK; }     // caller's transport: the messages are complete when this returns
     Rccl* r = rccl();
     const size_t n = sh.messageFloats();
@@ -2269,7 +2287,7 @@ int mi_world::shardExchange() {
     }
     const int e2 = r->GroupEnd();
     if (e || e2) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e ? e : e2) : "RCCL send / receive failed");
-    if (sh.sp.numPeers) k_shard_unpack<<<dim3(divUp(sh.capacity, 256), sh.sp.numPeers), 256, 0, st>>>(nb, recvBufs, sh.capacity, bPos.p, bRot.p, bLinVel.p, bAngVel.p);
+    if (sh.sp.numPeers) k_shard_unpack<<<dim3(divUp(sh.capacity, 256), sh.sp.numPeers), 256, 0, st>>>(nb, recvBufs, sh.capacity, bPos.p, bRot.p, bLinVel.p, bAngVel.p, sh.known.p);
     hostStale = true;
     return MI_OK;
 }
@@ -2292,8 +2310,12 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
     sh.desc = *d;
     const std::vector<uint32_t> order = tilesInRankOrder(d->tiles_x, d->tiles_z);
     ShardParams& sp = sh.sp;
-    sp.originX = d->origin_x; sp.originZ = d->origin_z; sp.tileX = d->tile_size_x; sp.tileZ = d->tile_size_z; sp.margin = d->ghost_margin;
+    sp.margin = d->ghost_margin;
     sp.tilesX = d->tiles_x; sp.tilesZ = d->tiles_z; sp.myTile = order[d->rank]; sp.numPeers = 0; sh.peerRanks.clear();
+    sh.bordersX.clear(); sh.bordersZ.clear(); sh.bordersPending = false;
+    for (uint32_t i = 1; i < d->tiles_x; ++i) sh.bordersX.push_back((float)((double)d->origin_x + (double)i * (double)d->tile_size_x));
+    for (uint32_t i = 1; i < d->tiles_z; ++i) sh.bordersZ.push_back((float)((double)d->origin_z + (double)i * (double)d->tile_size_z));
+    w->shardFillBorders(sp, sh.bordersX, sh.bordersZ);
     const int mx = (int)(sp.myTile % sp.tilesX), mz = (int)(sp.myTile / sp.tilesX);
     for (int z = mz - 1; z <= mz + 1; ++z) for (int x = mx - 1; x <= mx + 1; ++x) {          // ascending tile index
         if ((x == mx && z == mz) || x < 0 || z < 0 || x >= (int)sp.tilesX || z >= (int)sp.tilesZ) continue;
@@ -2304,6 +2326,8 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
     const uint32_t nb = (uint32_t)w->bodies.size();
     sh.capacity = d->max_records ? d->max_records : std::max(4096u, nb / d->num_ranks / 4u);   // a message always travels whole: (capacity + 1) records of 56 bytes
     { int rc = w->shardBuildRoots(); if (rc != MI_OK) return rc; }
+    for (HBody& b : w->bodies) b.shardKnown = 1;                     // every rank was given the same scene
+    HIP_TRY(sh.known.ensure(std::max(nb, 1u))); HIP_TRY(hipMemset(sh.known.p, 1, std::max(nb, 1u)));
     for (uint32_t k = 0; k < sp.numPeers; ++k) {
         HIP_TRY(sh.sendBuf[k].ensure(sh.messageFloats())); HIP_TRY(sh.recvBuf[k].ensure(sh.messageFloats()));
         HIP_TRY(hipMemset(sh.sendBuf[k].p, 0, sh.messageFloats() * sizeof(float))); HIP_TRY(hipMemset(sh.recvBuf[k].p, 0, sh.messageFloats() * sizeof(float)));
@@ -2323,6 +2347,86 @@ MI_API int mi_world_shard_neighbours(mi_world* w, uint32_t* out, uint32_t* count
 MI_API int mi_world_shard_counts(mi_world* w, uint32_t* bodies, uint32_t* manifolds, uint32_t* contacts) {
     if (!w || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
     if (bodies) *bodies = w->shard.owned[0]; if (manifolds) *manifolds = w->shard.owned[1]; if (contacts) *contacts = w->shard.owned[2];
+    return MI_OK;
+}
+// ---- load balance: the tile borders follow the bodies
+extern "C++" {
+namespace {
+// What ONE change of the borders may do.  A body's new owner, and every rank that newly holds it as a ghost, must be the old owner's tile or one of
+// its neighbours (only those exchange messages): new border i stays within [old border i-1 + margin, old border i+1 - margin]; and a tile stays
+// wider than the margin (its ghost region must not reach past its neighbours).
+bool shardBordersValid(const std::vector<float>& cur, const float* nb, uint32_t n, float m) {
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!(nb[i] == nb[i])) return false;
+        if (i > 0 && !(nb[i] - nb[i - 1] > m)) return false;
+        if (i > 0 && nb[i] < cur[i - 1] + m) return false;
+        if (i + 1 < n && nb[i] > cur[i + 1] - m) return false;
+    }
+    return true;
+}
+}
+}
+void mi_world::shardFillBorders(ShardParams& sp, const std::vector<float>& bx, const std::vector<float>& bz) const {
+    const float inf = std::numeric_limits<float>::infinity();
+    auto lower = [&](const std::vector<float>& b, int tile) { return tile <= 0 ? -inf : tile > (int)b.size() ? inf : b[(size_t)tile - 1]; };   // lower border of `tile`
+    const int mx = (int)(sp.myTile % sp.tilesX), mz = (int)(sp.myTile / sp.tilesX);
+    for (int k = 0; k < 4; ++k) { sp.bx[k] = lower(bx, mx - 1 + k); sp.bz[k] = lower(bz, mz - 1 + k); }
+}
+MI_API int mi_world_shard_set_borders(mi_world* w, const float* bx, const float* bz) {
+    if (!w || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    mi_world::ShardState& sh = w->shard;
+    const float m = sh.desc.ghost_margin;
+    if ((bx && !shardBordersValid(sh.bordersX, bx, (uint32_t)sh.bordersX.size(), m)) || (bz && !shardBordersValid(sh.bordersZ, bz, (uint32_t)sh.bordersZ.size(), m)))
+        return fail(MI_ERR_INVALID_ARGUMENT, "borders: ascending, tiles wider than ghost_margin, and border i within [old border i-1 + margin, old border i+1 - margin]");
+    sh.nextX = bx ? std::vector<float>(bx, bx + sh.bordersX.size()) : sh.bordersX;
+    sh.nextZ = bz ? std::vector<float>(bz, bz + sh.bordersZ.size()) : sh.bordersZ;
+    sh.spNext = sh.sp; w->shardFillBorders(sh.spNext, sh.nextX, sh.nextZ);
+    sh.bordersPending = true;
+    return MI_OK;
+}
+MI_API int mi_world_shard_get_borders(mi_world* w, float* bx, float* bz) {
+    if (!w || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    if (bx) std::copy(w->shard.bordersX.begin(), w->shard.bordersX.end(), bx);
+    if (bz) std::copy(w->shard.bordersZ.begin(), w->shard.bordersZ.end(), bz);
+    return MI_OK;
+}
+MI_API int mi_world_shard_histogram(mi_world* w, uint32_t axis, float lo, float hi, uint32_t bins, uint32_t* out) {
+    if (!w || !out || !w->shard.enabled || axis > 1u || !bins || !(hi > lo)) return fail(MI_ERR_INVALID_ARGUMENT, "axis 0 | 1, bins > 0, lo < hi");
+    HIP_TRY(hipSetDevice(w->device));
+    const uint32_t nb = (uint32_t)w->bodies.size();
+    std::fill(out, out + bins, 0u);
+    if (!nb || w->topologyDirty || !w->shard.active.p) return MI_OK;       // no step yet: nothing is owned
+    HIP_TRY(w->shard.hist.ensure(bins));
+    HIP_TRY(hipMemsetAsync(w->shard.hist.p, 0, bins * sizeof(uint32_t), w->stream));
+    k_shard_histogram<<<divUp(nb, 256), 256, 0, w->stream>>>(nb, axis, lo, (float)bins / (hi - lo), bins, w->shard.active.p, w->bPos.p, w->bRot.p, w->bCogInvMass.p, w->shard.root.p, w->shard.hist.p);
+    HIP_TRY(hipMemcpyAsync(out, w->shard.hist.p, bins * sizeof(uint32_t), hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return MI_OK;
+}
+// Borders that even out the body counts: hist = bodies per bin of [lo, hi) along one axis, summed over all ranks.  Border i goes where the cumulative
+// count reaches i / tiles of the total (linear inside a bin), clamped to what one change may do; pure arithmetic, the same on every rank.
+MI_API int mi_shard_balance_borders(const uint64_t* hist, uint32_t bins, float lo, float hi, uint32_t tiles, const float* cur, float margin, float* out) {
+    if (!hist || !bins || !(hi > lo) || !tiles || (tiles > 1 && (!cur || !out))) return fail(MI_ERR_INVALID_ARGUMENT, "null / empty");
+    const uint32_t n = tiles - 1u;
+    if (!n) return MI_OK;
+    const std::vector<float> c(cur, cur + n);
+    std::vector<float> nb(c);
+    double total = 0; for (uint32_t b = 0; b < bins; ++b) total += (double)hist[b];
+    if (total > 0) {
+        const double width = ((double)hi - (double)lo) / (double)bins;
+        uint32_t b = 0; double below = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const double target = total * (double)(i + 1u) / (double)tiles;
+            while (b + 1u < bins && below + (double)hist[b] < target) { below += (double)hist[b]; ++b; }
+            const double frac = hist[b] ? std::min(1.0, std::max(0.0, (target - below) / (double)hist[b])) : 0.5;
+            double v = (double)lo + ((double)b + frac) * width;
+            if (i > 0) v = std::max(v, std::max((double)c[i - 1] + (double)margin, (double)nb[i - 1] + 1.25 * (double)margin));   // (x 1.25: room to move next time)
+            if (i + 1u < n) v = std::min(v, (double)c[i + 1] - (double)margin);
+            nb[i] = (float)v;
+        }
+    }
+    const bool ok = shardBordersValid(c, nb.data(), n, margin);
+    for (uint32_t i = 0; i < n; ++i) out[i] = ok ? nb[i] : c[i];
     return MI_OK;
 }
 MI_API int mi_world_shard_owned_entities(mi_world* w, uint32_t* out, uint32_t cap, uint32_t* count) {
@@ -2377,7 +2481,7 @@ MI_API int mi_world_shard_import(mi_world* w, const void* msg) {
     const uint32_t nb = (uint32_t)w->bodies.size();
     HIP_TRY(hipMemcpyAsync(w->shard.recvBuf[0].p, msg, (size_t)(count + 1u) * kShardRecordFloats * sizeof(float), hipMemcpyHostToDevice, w->stream));
     ShardBufs one{}; one.p[0] = w->shard.recvBuf[0].p;
-    if (count) k_shard_unpack<<<dim3(divUp(count, 256), 1), 256, 0, w->stream>>>(nb, one, w->shard.capacity, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p);
+    if (count) k_shard_unpack<<<dim3(divUp(count, 256), 1), 256, 0, w->stream>>>(nb, one, w->shard.capacity, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p, w->shard.known.p);
     HIP_TRY(hipStreamSynchronize(w->stream));     // `msg` is the caller's (possibly pageable) memory
     w->hostStale = true;
     return MI_OK;
@@ -2701,7 +2805,7 @@ static int statesDevice(mi_world* w, uint32_t n, const uint32_t* idsDev, float* 
     if (!w || (n && (!idsDev || (!outDev && !inDev)))) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     int rc = ensureUploaded(w); if (rc != MI_OK) return rc;
     if (n && outDev) k_gather_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p, outDev);
-    if (n && inDev) { k_scatter_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, inDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p); w->hostStale = true; w->shard.prevValid = false; }
+    if (n && inDev) { k_scatter_states<<<divUp(n, 256), 256, 0, w->stream>>>(n, idsDev, inDev, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p, w->shard.enabled ? w->shard.known.p : nullptr); w->hostStale = true; w->shard.prevValid = false; }
     if (sync) HIP_TRY(hipStreamSynchronize(w->stream));
     return MI_OK;
 }

@@ -104,6 +104,37 @@ class ShardedWorld:
         for buf in inbox:
             self.world.shard_import(buf.cpu().numpy())
 
+    # --- load balance: move the tile borders to where the bodies are ("rebalanced every K steps by body count")
+    BALANCE_BINS = 256
+
+    def _extent(self, axis):
+        d = self.desc
+        return (d.origin_x, d.origin_x + d.tiles_x * d.tile_size_x) if axis == 0 else (d.origin_z, d.origin_z + d.tiles_z * d.tile_size_z)
+
+    def histograms(self):
+        """This rank's owned bodies along x and z (uint64, BALANCE_BINS each, over the extent of the tile grid): summed over the ranks
+        they are the input of `apply_balance`."""
+        return np.stack([self.world.shard_histogram(a, *self._extent(a), self.BALANCE_BINS).astype(np.uint64) for a in (0, 1)])
+
+    def apply_balance(self, global_hist):
+        """New borders from the global histograms (the same on every rank), set for the next step; returns (borders_x, borders_z)."""
+        d = self.desc
+        cur_x, cur_z = self.world.shard_get_borders(d.tiles_x, d.tiles_z)
+        nx = self.world.L.shard_balance_borders(global_hist[0], *self._extent(0), d.tiles_x, cur_x, d.ghost_margin)
+        nz = self.world.L.shard_balance_borders(global_hist[1], *self._extent(1), d.tiles_z, cur_z, d.ghost_margin)
+        self.world.shard_set_borders(nx, nz)
+        return nx, nz
+
+    def rebalance(self):
+        """One rebalancing round of a multi-process run (between two steps, on every rank): all-reduce the histograms over the process
+        group — control plane, a few KB every K steps — and move the borders."""
+        import torch
+        h = torch.from_numpy(self.histograms().astype(np.int64))
+        if self.dist.get_backend() == "nccl":
+            h = h.cuda()
+        self.dist.all_reduce(h)
+        return self.apply_balance(h.cpu().numpy().astype(np.uint64))
+
     def owned_states(self):
         ents = np.sort(self.world.shard_owned_entities())
         return ents, self.world.get_body_states(ents)
@@ -117,6 +148,12 @@ def step_local(ranks, settings, dt):
     for r in ranks:
         for peer in r.neighbours:
             r.world.shard_import(mail[peer][r.rank])
+
+
+def rebalance_local(ranks):
+    """Virtual ranks: what `ShardedWorld.rebalance` does over a process group."""
+    total = sum(r.histograms() for r in ranks)
+    return [r.apply_balance(total) for r in ranks][0]
 
 
 def gather_owned(ranks, num_bodies_entities):

@@ -11,7 +11,7 @@
  *                                                     is taken from its owner
  *     else                                         -> not simulated here this step (its colliders leave the broad phase)
  * so a body that crosses a tile border simply changes owner at the next step (MIGRATION needs no bookkeeping: the new owner has
- * had the body as a ghost).  After the step every rank sends, to each of its <= 8 neighbour tiles, the new state (56-byte
+ * had the body as a ghost).  The borders themselves can move to where the bodies are (load balance, below).  After the step every rank sends, to each of its <= 8 neighbour tiles, the new state (56-byte
  * record: body index + position, rotation, linear and angular velocity) of every body it owned whose OLD or NEW centre lies in
  * that neighbour's extended tile, and applies what it receives.  Counts follow an owner rule (a manifold belongs to the owner of
  * its first dynamic body), so the sum over ranks counts every manifold once.
@@ -61,6 +61,22 @@ MI_API int mi_world_shard_neighbours(mi_world* world, uint32_t* out_ranks8, uint
 MI_API int mi_world_shard_counts(mi_world* world, uint32_t* out_bodies, uint32_t* out_manifolds, uint32_t* out_contacts);
 /* Entity ids of the bodies this rank owned in the last internal step (their read-backs are authoritative). */
 MI_API int mi_world_shard_owned_entities(mi_world* world, uint32_t* out_entities, uint32_t capacity, uint32_t* out_count);
+
+/* Load balance: the tile borders follow the bodies ("rebalanced every K steps by body count").  Tiles are cut by tiles_x - 1
+ * interior borders along x and tiles_z - 1 along z (ascending; uniform — origin + i * tile_size — when sharding is enabled).  Every K steps, between
+ * two steps and on every rank:
+ *     mi_world_shard_histogram       this rank's owned bodies per bin along an axis          -> sum over the ranks (the caller's all-reduce: 2 KB)
+ *     mi_shard_balance_borders       borders that even out the counts, clamped to one change  (pure arithmetic: every rank computes the same)
+ *     mi_world_shard_set_borders     in force after the NEXT internal step's exchange
+ * That next step still simulates under the old borders; its messages additionally carry every owned body the neighbour will own or hold as a ghost
+ * under the new ones, so the switch needs no extra round trip and no rank ever classifies a body from a copy that is not current (a rank only trusts
+ * its copy of a body it owned in the last step or got a record for).  What one change may do: border i stays within
+ * [old border i-1 + ghost_margin, old border i+1 - ghost_margin] (a body's new owner is then the old owner's tile or a neighbour of it) and tiles stay
+ * wider than ghost_margin; anything else is MI_ERR_INVALID_ARGUMENT.  A null axis stays as it is.  Identical values on all ranks, between the same steps. */
+MI_API int mi_world_shard_histogram(mi_world* world, uint32_t axis /* 0 = x, 1 = z */, float lo, float hi, uint32_t bins, uint32_t* out_counts /* the end bins take what lies outside [lo, hi) */);
+MI_API int mi_shard_balance_borders(const uint64_t* hist, uint32_t bins, float lo, float hi, uint32_t tiles, const float* current_borders, float ghost_margin, float* out_borders /* tiles - 1 */);
+MI_API int mi_world_shard_set_borders(mi_world* world, const float* borders_x /* tiles_x - 1, or null */, const float* borders_z /* tiles_z - 1, or null */);
+MI_API int mi_world_shard_get_borders(mi_world* world, float* out_borders_x, float* out_borders_z);   /* the borders in force (either may be null) */
 
 /* Library transport: RCCL.  out_id128 / id128: the 128 bytes of an ncclUniqueId. */
 MI_API int mi_shard_get_unique_id(void* out_id128);

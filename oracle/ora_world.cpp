@@ -4,6 +4,7 @@
 #include "ora_world.h"
 #include <algorithm>
 #include <cstring>
+#include <limits>
 #include <cstdio>
 
 namespace ora {
@@ -967,16 +968,18 @@ static std::vector<uint32_t> tilesInRankOrder(uint32_t tx, uint32_t tz) {
     std::sort(t.begin(), t.end(), [&](uint32_t a, uint32_t b) { uint32_t ca = mortonCode(a % tx, a / tx), cb = mortonCode(b % tx, b / tx); return ca != cb ? ca < cb : a < b; });
     return t;
 }
-static uint32_t shardTileOf(const mi_shard_desc& d, float x, float z) {
-    int tx = std::min(std::max((int)std::floor((x - d.origin_x) / d.tile_size_x), 0), (int)d.tiles_x - 1);
-    int tz = std::min(std::max((int)std::floor((z - d.origin_z) / d.tile_size_z), 0), (int)d.tiles_z - 1);
-    return (uint32_t)tz * d.tiles_x + (uint32_t)tx;
+// Tiles are cut by BORDERS (tiles - 1 per axis, ascending; tile i of an axis = [border i, border i + 1) with -inf / +inf beyond the rim):
+// uniform when sharding is enabled, moved by ora_world_shard_set_borders (load balance).
+static const float kInf = std::numeric_limits<float>::infinity();
+static float borderLo(const std::vector<float>& b, int tile) { return tile <= 0 ? -kInf : tile > (int)b.size() ? kInf : b[(size_t)tile - 1]; }   // lower border of `tile` (tile may be one past either rim)
+static bool shardOwns(const World::Shard& sh, const std::vector<float>& bx, const std::vector<float>& bz, uint32_t t, float x, float z) {
+    const int tx = (int)(t % sh.desc.tiles_x), tz = (int)(t / sh.desc.tiles_x);
+    return x >= borderLo(bx, tx) && x < borderLo(bx, tx + 1) && z >= borderLo(bz, tz) && z < borderLo(bz, tz + 1);
 }
-static bool shardInExtended(const mi_shard_desc& d, uint32_t t, float x, float z) {
-    const uint32_t tx = t % d.tiles_x, tz = t / d.tiles_x;
-    const float x0 = d.origin_x + (float)tx * d.tile_size_x - d.ghost_margin, x1 = d.origin_x + (float)(tx + 1u) * d.tile_size_x + d.ghost_margin;
-    const float z0 = d.origin_z + (float)tz * d.tile_size_z - d.ghost_margin, z1 = d.origin_z + (float)(tz + 1u) * d.tile_size_z + d.ghost_margin;
-    return (tx == 0u || x >= x0) && (tx + 1u == d.tiles_x || x < x1) && (tz == 0u || z >= z0) && (tz + 1u == d.tiles_z || z < z1);
+static bool shardInExtended(const World::Shard& sh, const std::vector<float>& bx, const std::vector<float>& bz, uint32_t t, float x, float z) {
+    const int tx = (int)(t % sh.desc.tiles_x), tz = (int)(t / sh.desc.tiles_x);
+    const float m = sh.desc.ghost_margin;
+    return x >= borderLo(bx, tx) - m && x < borderLo(bx, tx + 1) + m && z >= borderLo(bz, tz) - m && z < borderLo(bz, tz + 1) + m;
 }
 void World::shardClassify() {
     const uint32_t nb = (uint32_t)bodies.size();
@@ -984,9 +987,10 @@ void World::shardClassify() {
     jointsIslandRoots(*this, shard.root);                        // an articulated island is owned / ghosted / ignored as ONE: by its root body's centre
     for (uint32_t i = 0; i < nb; ++i) {
         const RigidBody& rbody = bodies[shard.root[i]];
+        if (!rbody.shardKnown) continue;                         // a copy that is not current says nothing about where the body is
         vec3 c = rbody.p1 + rbody.r1 * rbody.localCOG;
-        bool owned = shardTileOf(shard.desc, c.x, c.z) == shard.myTile;
-        shard.active[i] = owned ? 1 : shardInExtended(shard.desc, shard.myTile, c.x, c.z) ? 2 : 0;
+        bool owned = shardOwns(shard, shard.bordersX, shard.bordersZ, shard.myTile, c.x, c.z);
+        shard.active[i] = owned ? 1 : shardInExtended(shard, shard.bordersX, shard.bordersZ, shard.myTile, c.x, c.z) ? 2 : 0;
         shard.owned[0] += owned ? 1u : 0u;
     }
 }
@@ -1001,7 +1005,10 @@ void World::shardPack(const std::vector<vec3>& oldCog) {
             const RigidBody& b = bodies[i];
             const RigidBody& rbody = bodies[shard.root[i]];
             vec3 cn = rbody.p1 + rbody.r1 * rbody.localCOG, co = oldCog[shard.root[i]];
-            if (!shardInExtended(shard.desc, shard.peers[k], cn.x, cn.z) && !shardInExtended(shard.desc, shard.peers[k], co.x, co.z)) continue;
+            bool want = shardInExtended(shard, shard.bordersX, shard.bordersZ, shard.peers[k], cn.x, cn.z) || shardInExtended(shard, shard.bordersX, shard.bordersZ, shard.peers[k], co.x, co.z);
+            // borders about to move: also what the neighbour simulates under the NEW borders (it classifies with them from the next step on)
+            if (shard.bordersPending) want = want || shardInExtended(shard, shard.nextX, shard.nextZ, shard.peers[k], cn.x, cn.z);
+            if (!want) continue;
             if (n < shard.capacity) {
                 float* o = msg.data() + (size_t)(n + 1u) * MI_SHARD_RECORD_FLOATS;
                 std::memcpy(o, &i, 4);
@@ -1013,6 +1020,20 @@ void World::shardPack(const std::vector<vec3>& oldCog) {
         }
         std::memcpy(msg.data(), &n, 4);
     }
+    // what this rank knows from here on: the bodies it owned; the records about to arrive add the neighbours' (ora_world_shard_import)
+    for (uint32_t i = 0; i < nb; ++i) bodies[i].shardKnown = shard.active[i] == 1 ? 1 : 0;
+    if (shard.bordersPending) { shard.bordersX = shard.nextX; shard.bordersZ = shard.nextZ; shard.bordersPending = false; }
+}
+// Borders that even out the body counts: hist = bodies per bin of [lo, hi) along one axis, summed over all ranks.  Border i goes where the
+// cumulative count reaches i / tiles of the total (linear inside a bin), then is clamped to what one change may do (see shardBordersValid).
+static bool shardBordersValid(const std::vector<float>& cur, const float* nb, uint32_t n, float m) {
+    for (uint32_t i = 0; i < n; ++i) {
+        if (!(nb[i] == nb[i])) return false;
+        if (i > 0 && !(nb[i] - nb[i - 1] > m)) return false;                       // a tile narrower than the margin would need more than its 8 neighbours
+        if (i > 0 && nb[i] < cur[i - 1] + m) return false;                         // new owner / ghost holder of a body = old owner's tile or one next to it
+        if (i + 1 < n && nb[i] > cur[i + 1] - m) return false;
+    }
+    return true;
 }
 }  // namespace ora
 
@@ -1325,6 +1346,7 @@ MI_API int ora_world_set_body_states(World* w, uint32_t n, const uint32_t* ents,
         const float* s = in + 13 * (size_t)i;
         b.p1 = vec3(s[0], s[1], s[2]); b.r1 = quat(s[3], s[4], s[5], s[6]);
         b.linearVelocity = vec3(s[7], s[8], s[9]); b.angularVelocity = vec3(s[10], s[11], s[12]);
+        b.shardKnown = 1;   // (sharded world) the caller's state is authoritative
     }
     return MI_OK;
 }
@@ -1419,7 +1441,70 @@ MI_API int ora_world_shard_enable(World* w, const mi_shard_desc* d) {
     }
     sh.capacity = d->max_records ? d->max_records : std::max<uint32_t>(4096u, (uint32_t)w->bodies.size() / d->num_ranks / 4u);
     sh.sendBuf.assign(sh.peers.size(), std::vector<float>((size_t)(sh.capacity + 1u) * MI_SHARD_RECORD_FLOATS, 0.f));
+    sh.bordersX.clear(); sh.bordersZ.clear(); sh.bordersPending = false;
+    for (uint32_t i = 1; i < d->tiles_x; ++i) sh.bordersX.push_back((float)((double)d->origin_x + (double)i * (double)d->tile_size_x));
+    for (uint32_t i = 1; i < d->tiles_z; ++i) sh.bordersZ.push_back((float)((double)d->origin_z + (double)i * (double)d->tile_size_z));
+    for (RigidBody& b : w->bodies) b.shardKnown = 1;             // every rank was given the same scene
     sh.enabled = true;
+    return MI_OK;
+}
+// Load balance (include/mi_shard.h): new interior borders, in force after the NEXT internal step's exchange (that step still simulates under the
+// old ones; its messages carry what the neighbours need under the new ones).  Null = that axis stays.
+MI_API int ora_world_shard_set_borders(World* w, const float* bx, const float* bz) {
+    if (!w || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
+    World::Shard& sh = w->shard;
+    const float m = sh.desc.ghost_margin;
+    if (bx && !ora::shardBordersValid(sh.bordersX, bx, (uint32_t)sh.bordersX.size(), m)) return MI_ERR_INVALID_ARGUMENT;
+    if (bz && !ora::shardBordersValid(sh.bordersZ, bz, (uint32_t)sh.bordersZ.size(), m)) return MI_ERR_INVALID_ARGUMENT;
+    sh.nextX = bx ? std::vector<float>(bx, bx + sh.bordersX.size()) : sh.bordersX;
+    sh.nextZ = bz ? std::vector<float>(bz, bz + sh.bordersZ.size()) : sh.bordersZ;
+    sh.bordersPending = true;
+    return MI_OK;
+}
+MI_API int ora_world_shard_get_borders(World* w, float* bx, float* bz) {
+    if (!w || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
+    if (bx) std::copy(w->shard.bordersX.begin(), w->shard.bordersX.end(), bx);
+    if (bz) std::copy(w->shard.bordersZ.begin(), w->shard.bordersZ.end(), bz);
+    return MI_OK;
+}
+// owned bodies of the last step per bin of [lo, hi) along x (axis 0) or z (1), by the centre their island was classified with; the end bins take what lies outside
+MI_API int ora_world_shard_histogram(World* w, uint32_t axis, float lo, float hi, uint32_t bins, uint32_t* out) {
+    if (!w || !out || !w->shard.enabled || axis > 1u || !bins || !(hi > lo)) return MI_ERR_INVALID_ARGUMENT;
+    std::fill(out, out + bins, 0u);
+    const float scale = (float)bins / (hi - lo);
+    for (uint32_t i = 0; i < w->shard.active.size(); ++i) {
+        if (w->shard.active[i] != 1) continue;
+        const RigidBody& r = w->bodies[w->shard.root[i]];
+        const vec3 c = r.p1 + r.r1 * r.localCOG;
+        const float v = ((axis ? c.z : c.x) - lo) * scale;
+        const int bin = v >= (float)bins ? (int)bins - 1 : v > 0.f ? (int)v : 0;
+        ++out[bin];
+    }
+    return MI_OK;
+}
+MI_API int ora_shard_balance_borders(const uint64_t* hist, uint32_t bins, float lo, float hi, uint32_t tiles, const float* cur, float margin, float* out) {
+    if (!hist || !bins || !(hi > lo) || !tiles || (tiles > 1 && (!cur || !out))) return MI_ERR_INVALID_ARGUMENT;
+    const uint32_t n = tiles - 1u;
+    if (!n) return MI_OK;
+    const std::vector<float> c(cur, cur + n);
+    double total = 0; for (uint32_t b = 0; b < bins; ++b) total += (double)hist[b];
+    std::vector<float> nb(c);
+    if (total > 0) {
+        const double width = ((double)hi - (double)lo) / (double)bins;
+        uint32_t b = 0; double below = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            const double target = total * (double)(i + 1u) / (double)tiles;
+            while (b + 1u < bins && below + (double)hist[b] < target) { below += (double)hist[b]; ++b; }
+            const double frac = hist[b] ? std::min(1.0, std::max(0.0, (target - below) / (double)hist[b])) : 0.5;
+            double v = (double)lo + ((double)b + frac) * width;
+            // what ONE change may do: stay between the old neighbours' borders (margin inside), keep tiles wider than the margin (x 1.25: room to move next time)
+            if (i > 0) v = std::max(v, std::max((double)c[i - 1] + (double)margin, (double)nb[i - 1] + 1.25 * (double)margin));
+            if (i + 1u < n) v = std::min(v, (double)c[i + 1] - (double)margin);
+            nb[i] = (float)v;
+        }
+    }
+    const bool ok = ora::shardBordersValid(c, nb.data(), n, margin);
+    for (uint32_t i = 0; i < n; ++i) out[i] = ok ? nb[i] : c[i];
     return MI_OK;
 }
 MI_API int ora_world_shard_neighbours(World* w, uint32_t* out, uint32_t* count) {
@@ -1460,6 +1545,7 @@ MI_API int ora_world_shard_import(World* w, const void* msg) {
         RigidBody& rb = w->bodies[b];
         rb.p1 = vec3(s[1], s[2], s[3]); rb.r1 = quat(s[4], s[5], s[6], s[7]);
         rb.linearVelocity = vec3(s[8], s[9], s[10]); rb.angularVelocity = vec3(s[11], s[12], s[13]);
+        rb.shardKnown = 1;
     }
     return MI_OK;
 }

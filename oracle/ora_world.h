@@ -69,6 +69,7 @@ struct RigidBody {  // rigid_body_component + physics_transform0/1 (src/physics/
     vec3 linearVelocity, angularVelocity, forceAccumulator, torqueAccumulator;
     vec3 p0; quat r0;  // physics_transform0
     vec3 p1; quat r1;  // physics_transform1
+    uint8_t shardKnown = 1;  // sharded world (include/mi_shard.h): this rank's copy of the body's state is current (it owned the body in the last step, or got a record for it)
 };
 
 struct GlobalState {  // rigid_body_global_state (src/physics/rigid_body.h:6-16)
@@ -170,6 +171,8 @@ struct World {
     struct Shard {
         bool enabled = false; mi_shard_desc desc{}; uint32_t myTile = 0, capacity = 0;
         std::vector<uint32_t> peers, peerRanks;
+        std::vector<float> bordersX, bordersZ;        // interior tile borders (tiles - 1 per axis, ascending); uniform at enable, moved by ora_world_shard_set_borders
+        std::vector<float> nextX, nextZ; bool bordersPending = false;   // set_borders: in force after the next step's exchange
         std::vector<uint8_t> active;
         std::vector<uint32_t> root;                   // lowest body index of the body's articulated island (itself without joints): the island is classified as one
         std::vector<std::vector<float>> sendBuf;      // one message per neighbour slot (record 0 = count)

@@ -21,14 +21,26 @@ STEPS = 80
 def _scene(kind="pile"):
     if kind == "terrain":
         return scenes.terrain_field(8, 2, 8, with_unsupported=False)
+    if kind == "lopsided":
+        return scenes.obb_pile(16, 3, 8, spacing=1.0)
     return scenes.ragdolls(4, 3) if kind == "ragdolls" else scenes.obb_pile(12, 4, 8, spacing=1.0)
 
 
-MARGIN = {"pile": 2.5, "ragdolls": 3.5, "terrain": 2.5}      # islands are classified by their root body: the margin has to cover an island's reach
+MARGIN = {"pile": 2.5, "ragdolls": 3.5, "terrain": 2.5, "lopsided": 1.5}      # islands are classified by their root body: the margin has to cover an island's reach
+REBALANCE_EVERY = 8
 
 
-def _virtual_ranks(make_world, sc, num_ranks, tiles_z=1, margin=2.5):
-    desc = sharding.tile_grid(sc, num_ranks, tiles_z, margin)
+def _grid(sc, kind, num_ranks, tiles_z):
+    """The tile grid of a test scene.  "lopsided": the pile under a grid that was laid out for something else — the first column of tiles holds
+    nothing, the last one most of the pile — so that the load balance has work to do."""
+    desc = sharding.tile_grid(sc, num_ranks, tiles_z, MARGIN[kind])
+    if kind == "lopsided":
+        desc.origin_x -= desc.tile_size_x
+    return desc
+
+
+def _virtual_ranks(make_world, sc, num_ranks, tiles_z=1, margin=2.5, kind=None):
+    desc = _grid(sc, kind, num_ranks, tiles_z) if kind else sharding.tile_grid(sc, num_ranks, tiles_z, margin)
     return [sharding.ShardedWorld(sc.populate(make_world()), desc, r, "local") for r in range(num_ranks)], desc
 
 
@@ -39,22 +51,27 @@ def _worker(rank, world_size, port, out_dir, tiles_z, kind="pile", transport="di
     dist.init_process_group("gloo", rank=rank, world_size=world_size)
     import oracle
     sc = _scene(kind)
-    desc = sharding.tile_grid(sc, world_size, tiles_z, MARGIN[kind])
+    desc = _grid(sc, kind, world_size, tiles_z)
     sw = sharding.ShardedWorld(sc.populate(oracle.create_world(oracle.ORDER_CANONICAL)), desc, rank, transport, dist)
     assert sw.transport == "dist" and (transport == "dist" or "unavailable" in sw.note)
     s = sc.settings()
     owned_per_step = []
-    for _ in range(STEPS):
+    for i in range(STEPS):
         sw.step(s, sc.dt)
         owned_per_step.append(sw.world.shard_counts()["owned_bodies"])
+        if kind == "lopsided" and i % REBALANCE_EVERY == REBALANCE_EVERY - 1:
+            sw.rebalance()                                      # histograms all-reduced over gloo, borders moved for the next step
     ents, st = sw.owned_states()
-    np.savez(Path(out_dir) / f"rank{rank}.npz", ents=ents, states=st, owned=np.asarray(owned_per_step), counts=np.asarray(list(sw.world.shard_counts().values())))
+    np.savez(Path(out_dir) / f"rank{rank}.npz", ents=ents, states=st, owned=np.asarray(owned_per_step), counts=np.asarray(list(sw.world.shard_counts().values())),
+             borders=np.concatenate(sw.world.shard_get_borders(desc.tiles_x, desc.tiles_z)))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world_size,tiles_z,kind,transport", [(2, 1, "pile", "dist"), (4, 2, "pile", "dist"), (2, 1, "ragdolls", "dist"), (2, 1, "pile", "rccl"), (2, 1, "terrain", "dist")],
-                         ids=["2 ranks, x slabs", "4 ranks, 2 x 2 tiles", "2 ranks, ragdolls", "2 ranks, library transport unavailable -> caller's transport", "2 ranks, heightmap terrain"])
+@pytest.mark.parametrize("world_size,tiles_z,kind,transport", [(2, 1, "pile", "dist"), (4, 2, "pile", "dist"), (2, 1, "ragdolls", "dist"), (2, 1, "pile", "rccl"), (2, 1, "terrain", "dist"),
+                                                               (3, 1, "lopsided", "dist")],
+                         ids=["2 ranks, x slabs", "4 ranks, 2 x 2 tiles", "2 ranks, ragdolls", "2 ranks, library transport unavailable -> caller's transport", "2 ranks, heightmap terrain",
+                              "3 ranks, borders rebalanced every 8 steps"])
 def test_processes_over_gloo_equal_virtual_ranks_bit_for_bit(tmp_path, oracle_mod, world_size, tiles_z, kind, transport):
     """R processes exchanging the neighbour messages over gloo == R worlds of one process with the messages copied by hand:
     the transport carries exactly what the library packed, nothing depends on timing or on who runs a tile.  Last case: the ranks
@@ -62,13 +79,17 @@ def test_processes_over_gloo_equal_virtual_ranks_bit_for_bit(tmp_path, oracle_mo
     port = 29500 + (os.getpid() % 2000) + world_size
     mp.spawn(_worker, args=(world_size, port, str(tmp_path), tiles_z, kind, transport), nprocs=world_size, join=True)
     sc = _scene(kind)
-    ranks, _ = _virtual_ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), sc, world_size, tiles_z, MARGIN[kind])
+    ranks, desc = _virtual_ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), sc, world_size, tiles_z, kind=kind)
     s = sc.settings()
     owned = []
-    for _ in range(STEPS):
+    for i in range(STEPS):
         sharding.step_local(ranks, s, sc.dt)
         owned.append([r.world.shard_counts()["owned_bodies"] for r in ranks])
+        if kind == "lopsided" and i % REBALANCE_EVERY == REBALANCE_EVERY - 1:
+            sharding.rebalance_local(ranks)
     owned = np.asarray(owned)
+    if kind == "lopsided":
+        assert owned[0].max() > 0.6 * sc.num_bodies and owned[-1].max() < 0.42 * sc.num_bodies, f"load balance: {owned[0]} -> {owned[-1]}"
     assert (owned.sum(axis=1) == sc.num_bodies).all(), "every body has exactly one owner in every step"
     for r in range(world_size):
         got = np.load(tmp_path / f"rank{r}.npz")
@@ -76,6 +97,7 @@ def test_processes_over_gloo_equal_virtual_ranks_bit_for_bit(tmp_path, oracle_mo
         assert np.array_equal(got["ents"], ents) and got["states"].tobytes() == st.tobytes(), f"rank {r}"
         assert np.array_equal(got["owned"], owned[:, r])
         assert np.array_equal(got["counts"], np.asarray(list(ranks[r].world.shard_counts().values())))
+        assert got["borders"].tobytes() == np.concatenate(ranks[r].world.shard_get_borders(desc.tiles_x, desc.tiles_z)).tobytes()
 
 
 def test_migration_ghosts_and_owner_rule(oracle_mod):
@@ -173,3 +195,97 @@ def test_shard_api_rejects_what_it_cannot_do(oracle_mod):
         w.shard_enable(bad)
     assert [w.L.shard_tile_of_rank(2, 2, r) for r in range(4)] == [0, 1, 2, 3]
     assert sorted(w.L.shard_tile_of_rank(4, 2, r) for r in range(8)) == list(range(8))
+
+
+def test_rebalancing_moves_the_borders_to_the_bodies(oracle_mod):
+    """SURVEY §8(e) "rebalanced every K steps by body count".  A 2 x 2 grid laid out badly for the pile (one column of tiles nearly empty): every
+    8 steps the borders move towards equal counts — by what one change may do — and through every switch each body keeps exactly one owner, a
+    new owner continues from the old owner's exact state, and the pile behaves."""
+    sc = scenes.obb_pile(14, 3, 10, spacing=1.0)
+    desc = sharding.tile_grid(sc, 4, 2, 1.5)
+    desc.origin_x -= 0.7 * desc.tile_size_x; desc.origin_z += 0.5 * desc.tile_size_z
+    ranks = [sharding.ShardedWorld(sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)), desc, r, "local") for r in range(4)]
+    s = sc.settings()
+    ids = np.arange(sc.num_bodies, dtype=np.uint32)
+    first = None; moved = []; handed_over = 0
+    truth = copies = owners_before = None
+    for i in range(96):
+        sharding.step_local(ranks, s, sc.dt)
+        owned = [r.world.shard_counts()["owned_bodies"] for r in ranks]
+        assert sum(owned) == sc.num_bodies, f"step {i}: {owned}"
+        owners = np.full(len(sc.entities), -1)
+        for r in ranks:
+            e = r.world.shard_owned_entities()
+            assert (owners[e] == -1).all(), f"step {i}: a body has two owners"
+            owners[e] = r.rank
+            if truth is not None:      # whatever a rank owned in this step, it started from the previous owner's exact state — also across a border move
+                assert copies[r.rank][e].tobytes() == truth[e].tobytes(), f"step {i} rank {r.rank}: an owner started from a copy that was not current"
+        if owners_before is not None and i % 8 == 1:
+            handed_over += int((owners != owners_before)[: sc.num_bodies].sum())
+        owners_before = owners
+        truth = sharding.gather_owned(ranks, sc.num_bodies)    # (asserts the partition once more)
+        copies = {r.rank: r.world.get_body_states(ids) for r in ranks}
+        if first is None:
+            first = owned
+        if i % 8 == 7:
+            bx, bz = sharding.rebalance_local(ranks)           # in force from step i + 2 (step i + 1 still runs under the old borders and hands over)
+            moved.append((float(bx[0]), float(bz[0])))
+    assert handed_over > 0.3 * sc.num_bodies, "the border moves handed bodies over"
+    assert max(first) > 0.55 * sc.num_bodies and max(owned) < 0.36 * sc.num_bodies, f"{first} -> {owned}"
+    assert len(set(moved)) > 3, "the borders moved in several steps (one change is bounded)"
+    st = sharding.gather_owned(ranks, sc.num_bodies)
+    assert np.isfinite(st).all() and st[:, 1].min() > -0.05
+
+
+def test_a_rank_never_trusts_a_copy_that_is_not_current(oracle_mod):
+    """Why a rank keeps a `known` flag per body.  A body drifts out of the right tile's reach; that rank's last copy of it stays where it left.
+    Then the border moves so that the right tile covers that stale position: classified by it, the rank would claim a body that is metres away in
+    the left tile.  It must not: the body keeps exactly one owner."""
+    parts = [(capi.ENTITY_DYNAMIC, (0.6, 1.0, 0.0), (0, 0, 0, 1), [(capi.SPHERE, (0, 0, 0, 0.3), {})], {"linear_velocity": (-6.0, 0, 0), "gravity_factor": 0.0, "linear_damping": 0.0}),
+             (capi.ENTITY_DYNAMIC, (-8.5, 0.5, 0.0), (0, 0, 0, 1), [(capi.AABB, (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5), {})], {}),
+             (capi.ENTITY_DYNAMIC, (6.0, 0.5, 0.0), (0, 0, 0, 1), [(capi.AABB, (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5), {})], {}),
+             (capi.ENTITY_STATIC, (0, -2.0, 0), (0, 0, 0, 1), [(capi.AABB, (-30, -2, -30, 30, 2, 30), {})], {})]
+    sc = scenes.scene_from_parts(parts, iterations=10)
+    d = capi.ShardDesc(); d.num_ranks = 2; d.tiles_x = 2; d.tiles_z = 1; d.origin_x = -10.0; d.origin_z = -10.0; d.tile_size_x = 10.0; d.tile_size_z = 20.0; d.ghost_margin = 1.0
+    ranks = [sharding.ShardedWorld(sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)), d, r, "local") for r in range(2)]
+    s = sc.settings()
+    for _ in range(100):                                         # 0.83 s at 6 m/s: the runner is at x = -4.4, far past the right tile's reach (x >= -1)
+        sharding.step_local(ranks, s, sc.dt)
+    runner = 0
+    right_copy = ranks[1].world.get_body_states(np.asarray([runner], np.uint32))[0]
+    truth = ranks[0].world.get_body_states(np.asarray([runner], np.uint32))[0]
+    assert runner in ranks[0].world.shard_owned_entities() and truth[0] < -4.0 and -1.3 < right_copy[0] < -0.9, "the right rank's copy stopped where the body left its reach"
+    for r in ranks:
+        r.world.shard_set_borders(np.asarray([-1.6], np.float32), None)      # the right tile now covers the stale copy's position, not the body's
+    for i in range(20):
+        sharding.step_local(ranks, s, sc.dt)
+        owners = [r.rank for r in ranks if runner in r.world.shard_owned_entities()]
+        assert owners == [0], f"step {i}: owners of the runner {owners}"
+    assert ranks[0].world.shard_get_borders(2, 1)[0][0] == np.float32(-1.6)
+
+
+def test_border_changes_are_validated(oracle_mod):
+    sc = _scene()
+    w = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    d = sharding._desc_for(sharding.tile_grid(sc, 4, 1, 0.5), 0)
+    w.shard_enable(d)
+    bx, bz = w.shard_get_borders(4, 1)
+    assert len(bx) == 3 and len(bz) == 0 and np.allclose(bx, d.origin_x + d.tile_size_x * np.arange(1, 4))
+    m = d.ghost_margin
+    for bad in ([bx[1], bx[0], bx[2]],                           # not ascending
+                [bx[0], bx[0] + 0.5 * m, bx[2]],                 # a tile narrower than the margin
+                [bx[0], bx[2] - 0.5 * m, bx[2] + 0.0],           # border 1 within a margin of old border 2: a body could skip a tile
+                [bx[1], bx[1] + 2 * m, bx[2]],                   # border 0 moved onto old border 1
+                [np.nan, bx[1], bx[2]]):
+        with pytest.raises(capi.PhysicsError):
+            w.shard_set_borders(np.asarray(bad, np.float32), None)
+    w.shard_set_borders(np.asarray([bx[0] + 0.2, bx[1], bx[2] - 0.2], np.float32), None)
+    # the balance arithmetic: equal counts, bounded moves, nothing to do without bodies
+    L = w.L
+    hist = np.zeros(64, np.uint64); hist[48:] = 10                # everything in the last quarter of [0, 64)
+    cur = np.asarray([16.0, 32.0, 48.0], np.float32)
+    out = L.shard_balance_borders(hist, 0.0, 64.0, 4, cur, 1.0)
+    assert out[0] == np.float32(31.0) and out[1] == np.float32(47.0) and out[2] == np.float32(60.0), out   # one change: up to a margin before the old next border
+    out2 = L.shard_balance_borders(hist, 0.0, 64.0, 4, out, 1.0)
+    assert out2[0] == np.float32(46.0) and out2[1] == np.float32(56.0) and out2[2] == np.float32(60.0), out2
+    assert np.array_equal(L.shard_balance_borders(np.zeros(64, np.uint64), 0.0, 64.0, 4, cur, 1.0), cur)

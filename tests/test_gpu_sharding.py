@@ -5,7 +5,7 @@ processes over a real transport give exactly what such virtual ranks give."""
 import numpy as np
 import pytest
 
-from d3d12renderer_amd import scenes, sharding
+from d3d12renderer_amd import capi, scenes, sharding
 
 pytestmark = pytest.mark.gpu
 
@@ -43,6 +43,78 @@ def test_gpu_virtual_ranks_match_oracle_virtual_ranks(mi_lib, oracle_mod, n, til
                 first = cur
             migrated |= bool((cur != first).any())
     assert migrated or n != 3 or margin != 2.5, "no body changed owner in the spreading box pile"
+
+
+def _lopsided(sc, n, tiles_z, margin):
+    """A tile grid laid out badly for the scene: one column of tiles nearly empty, so the load balance has work to do."""
+    desc = sharding.tile_grid(sc, n, tiles_z, margin)
+    desc.origin_x -= 0.7 * desc.tile_size_x
+    if tiles_z > 1:
+        desc.origin_z += 0.5 * desc.tile_size_z
+    return desc
+
+
+@pytest.mark.parametrize("n,tiles_z,make,margin", [(3, 1, lambda: scenes.obb_pile(16, 3, 8, spacing=1.0), 1.5), (4, 2, lambda: scenes.mixed_stack(12, 3, 10), 1.5),
+                                                   (3, 1, lambda: scenes.ragdolls(8, 2), 3.5)],
+                         ids=["3 slabs boxes", "2x2 tiles mixed", "3 slabs ragdolls"])
+def test_gpu_rebalanced_ranks_match_oracle(mi_lib, oracle_mod, n, tiles_z, make, margin):
+    """Load balance (mi_world_shard_histogram / mi_shard_balance_borders / mi_world_shard_set_borders): the borders move every 8 steps, on the
+    GPU ranks and on their oracle twins — same histograms, same borders, and every count and owned state stays bit-identical through the hand-overs."""
+    sc = make()
+    desc = _lopsided(sc, n, tiles_z, margin)
+    g = [sharding.ShardedWorld(sc.populate(mi_lib.create_world(0)), desc, r, "local") for r in range(n)]
+    o = [sharding.ShardedWorld(sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)), desc, r, "local") for r in range(n)]
+    s = sc.settings()
+    first = None; borders = [np.concatenate(g[0].world.shard_get_borders(desc.tiles_x, desc.tiles_z)).tobytes()]
+    for i in range(80):
+        sharding.step_local(g, s, sc.dt); sharding.step_local(o, s, sc.dt)
+        owned = [a.world.shard_counts()["owned_bodies"] for a in g]
+        assert sum(owned) == sc.num_bodies
+        first = first or owned
+        for a, b in zip(g, o):
+            assert a.world.counts() == b.world.counts(), f"step {i} rank {a.rank}: local counts"
+            assert a.world.shard_counts() == b.world.shard_counts(), f"step {i} rank {a.rank}: owned counts"
+        if i % 8 == 7 or i == 79:
+            for a, b in zip(g, o):
+                ea, sa = a.owned_states(); eb, sb = b.owned_states()
+                assert np.array_equal(ea, eb) and sa.tobytes() == sb.tobytes(), f"step {i} rank {a.rank}: owned states"
+                assert np.array_equal(a.histograms(), b.histograms()), f"step {i} rank {a.rank}: histograms"
+            bg = sharding.rebalance_local(g); bo = sharding.rebalance_local(o)
+            assert bg[0].tobytes() == bo[0].tobytes() and bg[1].tobytes() == bo[1].tobytes()
+            borders.append(bg[0].tobytes() + bg[1].tobytes())
+    assert len(set(borders)) > 1, "the borders moved"
+    assert max(owned) < max(first) - 0.1 * sc.num_bodies, f"load balance: {first} -> {owned}"
+
+
+def test_gpu_rank_never_trusts_a_copy_that_is_not_current(mi_lib):
+    """tests/test_distributed.py::test_a_rank_never_trusts_a_copy_that_is_not_current on the GPU: a border moves over the place where a rank last
+    saw a body that has long left — the rank must not claim it.  Then entities are deleted on every rank (re-upload of everything, body indices
+    shift): what a rank knows follows the bodies."""
+    parts = [(capi.ENTITY_DYNAMIC, (0.6, 1.0, 0.0), (0, 0, 0, 1), [(capi.SPHERE, (0, 0, 0, 0.3), {})], {"linear_velocity": (-6.0, 0, 0), "gravity_factor": 0.0, "linear_damping": 0.0}),
+             (capi.ENTITY_DYNAMIC, (-8.5, 0.5, 0.0), (0, 0, 0, 1), [(capi.AABB, (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5), {})], {}),
+             (capi.ENTITY_DYNAMIC, (6.0, 0.5, 0.0), (0, 0, 0, 1), [(capi.AABB, (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5), {})], {}),
+             (capi.ENTITY_DYNAMIC, (7.5, 0.5, 0.0), (0, 0, 0, 1), [(capi.AABB, (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5), {})], {}),
+             (capi.ENTITY_STATIC, (0, -2.0, 0), (0, 0, 0, 1), [(capi.AABB, (-30, -2, -30, 30, 2, 30), {})], {})]
+    sc = scenes.scene_from_parts(parts, iterations=10)
+    d = capi.ShardDesc(); d.num_ranks = 2; d.tiles_x = 2; d.tiles_z = 1; d.origin_x = -10.0; d.origin_z = -10.0; d.tile_size_x = 10.0; d.tile_size_z = 20.0; d.ghost_margin = 1.0
+    ranks = [sharding.ShardedWorld(sc.populate(mi_lib.create_world(0)), d, r, "local") for r in range(2)]
+    s = sc.settings()
+    for _ in range(100):
+        sharding.step_local(ranks, s, sc.dt)
+    right_copy = ranks[1].world.get_body_states(np.asarray([0], np.uint32))[0]
+    truth = ranks[0].world.get_body_states(np.asarray([0], np.uint32))[0]
+    assert 0 in ranks[0].world.shard_owned_entities() and truth[0] < -4.0 and -1.3 < right_copy[0] < -0.9
+    for r in ranks:
+        r.world.shard_set_borders(np.asarray([-1.6], np.float32), None)
+    for i in range(6):
+        sharding.step_local(ranks, s, sc.dt)
+        assert [r.rank for r in ranks if 0 in r.world.shard_owned_entities()] == [0], f"step {i}"
+    for r in ranks:                                              # entity 2 (a body of the right tile) goes: the runner stays body 0, body 3 moves into slot 2 (swap and pop)
+        r.world.destroy_entity(2)
+    for i in range(6):
+        sharding.step_local(ranks, s, sc.dt)
+        owned = [sorted(r.world.shard_owned_entities().tolist()) for r in ranks]
+        assert owned == [[0, 1], [3]], f"step {i} after the deletion: {owned}"
 
 
 def test_gpu_cloth_in_a_sharded_world(mi_lib):
