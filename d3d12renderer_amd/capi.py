@@ -449,6 +449,15 @@ class World:
         bz = None if borders_z is None else np.ascontiguousarray(borders_z, np.float32)
         self.L.check(self.L.fn("world_shard_set_borders")(self.h, _ptr(bx) if bx is not None and len(bx) else None, _ptr(bz) if bz is not None and len(bz) else None), "world_shard_set_borders")
 
+    def shard_allreduce_u64(self, values):
+        """Sum over all ranks through the library transport (one ncclAllReduce on the world's stream)."""
+        v = np.ascontiguousarray(values, np.uint64).copy()
+        self.L.check(self.L.fn("world_shard_allreduce_u64")(self.h, _ptr(v), C.c_uint32(len(v))), "world_shard_allreduce_u64")
+        return v
+
+    def shard_rebalance(self, bins=256):
+        self.L.check(self.L.fn("world_shard_rebalance")(self.h, C.c_uint32(bins)), "world_shard_rebalance")
+
     def shard_message_bytes(self):
         n = C.c_uint64()
         self.L.check(self.L.fn("world_shard_message_bytes")(self.h, C.byref(n)), "world_shard_message_bytes")

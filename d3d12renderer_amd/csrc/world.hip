@@ -150,7 +150,7 @@ struct mi_world {
         std::vector<float> bordersX, bordersZ;   // interior tile borders (tiles - 1 per axis): uniform at enable, moved by mi_world_shard_set_borders
         std::vector<float> nextX, nextZ; ShardParams spNext{}; bool bordersPending = false;   // ... in force after the next step's exchange
         DBuf<uint8_t> known;                     // per body: this rank's copy is current (owned in the last step, or a record arrived)
-        DBuf<uint32_t> hist;
+        DBuf<uint32_t> hist; DBuf<uint64_t> reduceBuf;
         uint32_t capacity = 0; std::vector<uint32_t> peerRanks;
         DBuf<uint8_t> active, activePrev; bool prevValid = false, flagsSwapPending = false, stepOpen = false;   // activePrev: the previous valid step's flags (k_integrate_velocities skips bodies idle in both)
         DBuf<float> sendBuf[8], recvBuf[8];
@@ -2220,6 +2220,7 @@ struct Rccl {
     int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr; int (*GroupEnd)() = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
 };
 Rccl* rccl() {
@@ -2235,10 +2236,12 @@ Rccl* rccl() {
     r.GetUniqueId = (decltype(r.GetUniqueId))sym("ncclGetUniqueId"); r.CommInitRank = (decltype(r.CommInitRank))sym("ncclCommInitRank");
     r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy"); r.Send = (decltype(r.Send))sym("ncclSend"); r.Recv = (decltype(r.Recv))sym("ncclRecv");
     r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart"); r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd"); r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
+    r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
     if (!r.GetUniqueId || !r.CommInitRank || !r.Send || !r.Recv || !r.GroupStart || !r.GroupEnd) { r.lib = nullptr; return nullptr; }
     return &r;
 }
 constexpr int kNcclFloat32 = 7;   // ncclFloat32 (rccl.h)
+constexpr int kNcclUint64 = 5, kNcclSum = 0;
 }
 }
 
@@ -2428,6 +2431,39 @@ MI_API int mi_shard_balance_borders(const uint64_t* hist, uint32_t bins, float l
     const bool ok = shardBordersValid(c, nb.data(), n, margin);
     for (uint32_t i = 0; i < n; ++i) out[i] = ok ? nb[i] : c[i];
     return MI_OK;
+}
+// Sum of n 64-bit counters over all ranks: ONE ncclAllReduce on the world's stream (global counts; the histograms of the load balance)
+MI_API int mi_world_shard_allreduce_u64(mi_world* w, uint64_t* inout, uint32_t n) {
+    if (!w || !w->shard.enabled || (n && !inout)) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world / null");
+    if (!w->shard.rccl) return fail(MI_ERR_UNSUPPORTED, "the library's all-reduce needs the library transport (mi_world_shard_attach_rccl); with the caller's transport reduce the values yourself");
+    Rccl* r = rccl(); if (!r || !r->AllReduce) return fail(MI_ERR_UNSUPPORTED, "ncclAllReduce not found");
+    if (!n) return MI_OK;
+    HIP_TRY(hipSetDevice(w->device));
+    HIP_TRY(w->shard.reduceBuf.ensure(n));
+    HIP_TRY(hipMemcpyAsync(w->shard.reduceBuf.p, inout, n * sizeof(uint64_t), hipMemcpyHostToDevice, w->stream));
+    const int e = r->AllReduce(w->shard.reduceBuf.p, w->shard.reduceBuf.p, n, kNcclUint64, kNcclSum, w->shard.comm, w->stream);
+    if (e) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e) : "ncclAllReduce failed");
+    HIP_TRY(hipMemcpyAsync(inout, w->shard.reduceBuf.p, n * sizeof(uint64_t), hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return MI_OK;
+}
+// One rebalancing round in one call (library transport): histograms of both axes over the extent of the tile grid as enabled, all-reduced, balanced, set.
+MI_API int mi_world_shard_rebalance(mi_world* w, uint32_t bins) {
+    if (!w || !w->shard.enabled || !bins || bins > 65536u) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world / bins");
+    if (!w->shard.rccl) return fail(MI_ERR_UNSUPPORTED, "mi_world_shard_rebalance needs the library transport; with the caller's transport: mi_world_shard_histogram, your all-reduce, mi_shard_balance_borders, mi_world_shard_set_borders");
+    const mi_shard_desc& d = w->shard.desc;
+    const float lo[2] = {d.origin_x, d.origin_z};
+    const float hi[2] = {(float)((double)d.origin_x + (double)d.tiles_x * (double)d.tile_size_x), (float)((double)d.origin_z + (double)d.tiles_z * (double)d.tile_size_z)};
+    std::vector<uint32_t> h32(bins); std::vector<uint64_t> h((size_t)2 * bins);
+    for (uint32_t a = 0; a < 2; ++a) {
+        int rc = mi_world_shard_histogram(w, a, lo[a], hi[a], bins, h32.data()); if (rc != MI_OK) return rc;
+        for (uint32_t b = 0; b < bins; ++b) h[(size_t)a * bins + b] = h32[b];
+    }
+    int rc = mi_world_shard_allreduce_u64(w, h.data(), 2u * bins); if (rc != MI_OK) return rc;
+    std::vector<float> nx(w->shard.bordersX), nz(w->shard.bordersZ);
+    rc = mi_shard_balance_borders(h.data(), bins, lo[0], hi[0], d.tiles_x, w->shard.bordersX.data(), d.ghost_margin, nx.data()); if (rc != MI_OK) return rc;
+    rc = mi_shard_balance_borders(h.data() + bins, bins, lo[1], hi[1], d.tiles_z, w->shard.bordersZ.data(), d.ghost_margin, nz.data()); if (rc != MI_OK) return rc;
+    return mi_world_shard_set_borders(w, nx.empty() ? nullptr : nx.data(), nz.empty() ? nullptr : nz.data());
 }
 MI_API int mi_world_shard_owned_entities(mi_world* w, uint32_t* out, uint32_t cap, uint32_t* count) {
     if (!w || !count || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");

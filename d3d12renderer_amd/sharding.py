@@ -128,6 +128,9 @@ class ShardedWorld:
     def rebalance(self):
         """One rebalancing round of a multi-process run (between two steps, on every rank): all-reduce the histograms over the process
         group — control plane, a few KB every K steps — and move the borders."""
+        if self.transport == "rccl":     # the library does the whole round: histograms, ONE ncclAllReduce on the world's stream, new borders
+            self.world.shard_rebalance(self.BALANCE_BINS)
+            return self.world.shard_get_borders(self.desc.tiles_x, self.desc.tiles_z)   # (still the old ones: the new ones are in force after the next step)
         import torch
         h = torch.from_numpy(self.histograms().astype(np.int64))
         if self.dist.get_backend() == "nccl":

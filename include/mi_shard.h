@@ -81,6 +81,12 @@ MI_API int mi_world_shard_get_borders(mi_world* world, float* out_borders_x, flo
 /* Library transport: RCCL.  out_id128 / id128: the 128 bytes of an ncclUniqueId. */
 MI_API int mi_shard_get_unique_id(void* out_id128);
 MI_API int mi_world_shard_attach_rccl(mi_world* world, const void* id128);
+/* Sum of `n` 64-bit counters over all ranks through the library transport: ONE ncclAllReduce on the world's stream (global body / manifold /
+ * contact counts; the histograms of the load balance).  MI_ERR_UNSUPPORTED with the caller's transport (reduce them yourself). */
+MI_API int mi_world_shard_allreduce_u64(mi_world* world, uint64_t* inout, uint32_t n);
+/* One rebalancing round in one call (library transport; every rank, between the same two steps): histograms of both axes (`bins` each, over the
+ * extent of the tile grid as enabled) -> all-reduce -> mi_shard_balance_borders -> mi_world_shard_set_borders. */
+MI_API int mi_world_shard_rebalance(mi_world* world, uint32_t bins);
 /* Back to the caller's transport (destroys the communicator; e.g. when another rank could not attach). */
 MI_API int mi_world_shard_detach_rccl(mi_world* world);
 /* Caller's transport: after mi_world_step_fixed(world, ..., 1) copy the message for neighbour slot `slot` out (host memory,

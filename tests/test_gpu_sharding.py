@@ -186,7 +186,11 @@ def test_gpu_library_rccl_transport_comes_up(mi_lib):
     w.step_fixed(s, sc.dt, 30); plain.step_fixed(s, sc.dt, 30)       # with the library transport several internal steps per call are fine
     assert w.physics_transforms()[0].tobytes() == plain.physics_transforms()[0].tobytes()
     assert w.shard_counts()["owned_bodies"] == sc.num_bodies
+    assert np.array_equal(w.shard_allreduce_u64([3, 1 << 40, 0]), np.asarray([3, 1 << 40, 0], np.uint64))   # one rank: the sum is the value (ncclAllReduce resolved and run)
+    w.shard_rebalance(64)                                             # a whole round through the library (one tile: no border to move)
     w.shard_detach_rccl()                                             # back to the caller's transport (what a rank does when a peer could not attach)
     w.step_fixed(s, sc.dt, 1); plain.step_fixed(s, sc.dt, 1)
     assert w.physics_transforms()[0].tobytes() == plain.physics_transforms()[0].tobytes()
+    with pytest.raises(capi.PhysicsError):
+        w.shard_rebalance(64)                                         # caller's transport: the caller reduces the histograms
     w.close()
