@@ -55,6 +55,7 @@ def parse():
     ap.add_argument("--ghost-margin", type=float, default=2.5)
     ap.add_argument("--transport", choices=["rccl", "dist"], default=os.environ.get("MI_SHARD_TRANSPORT", "rccl"),
                     help="N > 1: neighbour exchange by the library's own RCCL send/recv (default) or by torch.distributed point-to-point through host buffers")
+    ap.add_argument("--rebalance-every", type=int, default=0, help="N > 1: a load-balance round (tile borders follow the body counts) every K steps of the untimed settle phase; 0 = fixed uniform tiles")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-at-rest", action="store_true", help="skip the second measurement after 1500 steps")
     ap.add_argument("--cpu-grid", type=int, nargs=3, default=[32, 16, 32])
@@ -240,8 +241,10 @@ def main():
         torch.cuda.synchronize()
 
     # ---- the workload's state: settle (always, untimed), then the caller's warm-up
-    for _ in range(args.settle):
+    for i in range(args.settle):
         sw.step(settings, dt)
+        if world_size > 1 and args.rebalance_every and i % args.rebalance_every == args.rebalance_every - 1 and i + 2 < args.settle:
+            sw.rebalance()                              # (control plane: one small all-reduce; never inside the timed region)
     for _ in range(args.warmup):
         sw.step(settings, dt)
     barrier()
@@ -349,6 +352,10 @@ def main():
             "step_ms_median": float(np.median(step_ms)), "step_ms_p95": float(np.percentile(step_ms, 95)),
             "device_ms_per_step": total_dev_ms / args.steps,
         }
+        if world_size > 1:
+            bx, bz = sw.world.shard_get_borders(desc.tiles_x, desc.tiles_z)
+            out["config"]["tile_borders"] = {"x": [float(v) for v in bx], "z": [float(v) for v in bz],
+                                             "rebalanced_every": args.rebalance_every if args.rebalance_every else "never (uniform tiles)"}
         if at_rest is not None:
             out["at_rest"] = at_rest
         if not args.no_cpu_baseline and world_size == 1:   # rank 0 at N = 1 only
