@@ -184,6 +184,25 @@ def test_articulated_islands_stay_on_one_rank(oracle_mod):
     assert np.isfinite(st).all() and st[:, 1].min() > -0.2
 
 
+def test_sharded_independent_islands_equal_the_single_world(oracle_mod):
+    """cfg4-style scene ("independent units"): ragdolls that touch the ground but not each other.  Block Jacobi across the seam then
+    has nothing to approximate, and the schedule of an island is graph-local (priorities, colour history and joint order do not look past the
+    island): the sharded result IS the single world's, bit for bit, every step — as long as ONE global quantity agrees, the sweep axis.  It is
+    chosen from the variance of the colliders a world simulates and orients pairs of EQUAL shape type the way the reference's sweep emits them
+    (collision_narrow.cpp:2374): a rank that sees a quarter of a scene may pick another axis and orient a capsule-capsule or gear-tooth pair the
+    other way round (same contact, A and B swapped: last-bit differences from there on).  Here the axes agree throughout, which is asserted."""
+    sc = scenes.ragdolls(4, 3, spacing=4.0)
+    ranks, _ = _virtual_ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), sc, 2, 1, margin=3.5)
+    single = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings(); ids = np.arange(sc.num_bodies, dtype=np.uint32)
+    for i in range(150):
+        sharding.step_local(ranks, s, sc.dt); single.step_fixed(s, sc.dt, 1)
+        assert {r.world.counts()["sorting_axis"] for r in ranks} == {single.counts()["sorting_axis"]}, f"step {i}: the precondition of this test"
+        assert sharding.gather_owned(ranks, sc.num_bodies).tobytes() == single.get_body_states(ids).tobytes(), f"step {i}"
+        assert sum(r.world.shard_counts()["owned_contacts"] for r in ranks) == single.counts()["num_contacts"]
+    assert single.counts()["num_contacts"] > 100
+
+
 def test_shard_api_rejects_what_it_cannot_do(oracle_mod):
     sc = _scene()
     w = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
