@@ -932,7 +932,8 @@ __device__ __forceinline__ void writeManifold(uint32_t p, bool hit, const Manifo
     npPacked[p] = cnt ? ((1ull << 32) | (uint64_t)cnt) : 0ull;   // (manifold flag, contact count): one 64-bit scan compacts both
     if (cnt) {
         npNormal[p] = f4(m.n, 0.f);
-        for (uint32_t k = 0; k < cnt; ++k) npPoints[4 * p + k] = f4(m.p[k], m.d[k]);
+#pragma unroll
+        for (uint32_t k = 0; k < 4; ++k) if (k < cnt) npPoints[4 * p + k] = f4(m.p[k], m.d[k]);   // (static indices: the manifold stays in registers, not in scratch)
     }
 }
 __device__ __forceinline__ void boxPairShapes(const float4* __restrict__ wShape, uint32_t a, uint32_t b, uint32_t ta,
@@ -1382,7 +1383,9 @@ __global__ __launch_bounds__(256) void k_manifold_keys(uint32_t n, const StepSca
     const uint32_t nm = min(n, sc->numManifolds);
     const GridParams g = *gp;
     const uint32_t axis = g.dims[0] >= g.dims[1] && g.dims[0] >= g.dims[2] ? 0u : g.dims[2] >= g.dims[1] ? 2u : 1u;
-    const float scale = g.invCell * ((float)kSpatialKeys / (float)g.dims[axis]);
+    const uint32_t dimA = axis == 0u ? g.dims[0] : axis == 1u ? g.dims[1] : g.dims[2];          // (selects, not g.dims[axis]: a dynamically indexed copy lives in scratch)
+    const float originA = axis == 0u ? g.origin[0] : axis == 1u ? g.origin[1] : g.origin[2];
+    const float scale = g.invCell * ((float)kSpatialKeys / (float)dimA);
     uint32_t key[kKeyItems / 256], local[kKeyItems / 256];
 #pragma unroll
     for (uint32_t i = 0; i < kKeyItems / 256; ++i) {
@@ -1393,7 +1396,7 @@ __global__ __launch_bounds__(256) void k_manifold_keys(uint32_t n, const StepSca
             float4 pa = gPos[b.x], pb = gPos[b.y];
             float4 p = pa.w != 0.f ? pa : pb;
             float c = axis == 0u ? p.x : axis == 1u ? p.y : p.z;
-            key[i] = (uint32_t)fminf(fmaxf((c - g.origin[axis]) * scale, 0.f), (float)(kSpatialKeys - 1u));
+            key[i] = (uint32_t)fminf(fmaxf((c - originA) * scale, 0.f), (float)(kSpatialKeys - 1u));
             local[i] = atomicAdd(&hist[key[i]], 1u);
         }
     }

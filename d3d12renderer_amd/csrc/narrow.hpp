@@ -86,7 +86,8 @@ __device__ inline void reduceManifold(const Poly& v, uint32_t n, V3 normal, Mani
         out.count = 4;
     } else {
         out.count = n;
-        for (uint32_t i = 0; i < n; ++i) { ClipVert c = v.get(i); setc(out, i, c.v, c.depth); }
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) if (i < n) { ClipVert c = v.get(i); setc(out, i, c.v, c.depth); }   // (static indices: the manifold stays in registers)
     }
 }
 
