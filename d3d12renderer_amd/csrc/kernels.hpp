@@ -1566,8 +1566,10 @@ __global__ __launch_bounds__(256) void k_build_tiles(uint32_t tilesCap, uint32_t
 }
 // tile -> bin (binary search over the bins' first tiles) and tile -> (first contact-tile, contacts per manifold)
 __global__ __launch_bounds__(256) void k_fill_tiles(const StepScalars* __restrict__ sc, const BinInfo* __restrict__ binInfo,
-                                                    uint32_t* __restrict__ tileBin, uint2* __restrict__ tileDesc,
-                                                    const uint32_t* __restrict__ xcdBase, uint32_t* __restrict__ xcdTiles /* [8][listCap] or null */, uint32_t listCap, uint32_t xcdSingle) {
+                                                    uint4* __restrict__ tileInfo /* what k_contact_init needs of a tile in ONE load: (tile, first slot, count | stride << 8 | XCD << 12, first contact-tile) */,
+                                                    uint2* __restrict__ tileDesc,
+                                                    const uint32_t* __restrict__ xcdBase, uint32_t* __restrict__ xcdTiles /* [8][listCap] or null */, uint4* __restrict__ xcdInfo /* the same entries in list order */,
+                                                    uint32_t listCap, uint32_t xcdSingle) {
     __shared__ uint32_t first[kSchedBins];
     for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) first[bn] = binInfo[bn].tileStart;
     __syncthreads();
@@ -1577,17 +1579,19 @@ __global__ __launch_bounds__(256) void k_fill_tiles(const StepScalars* __restric
     while (lo < hi) { uint32_t mid = (lo + hi + 1u) >> 1; if (first[mid] <= t) lo = mid; else hi = mid - 1u; }
     BinInfo bi = binInfo[lo];
     uint32_t stride = lo == kSchedBins - 1 ? 4u : (lo & 3u) + 1u;
-    tileBin[t] = lo;
-    tileDesc[t] = make_uint2(bi.ctStart + (t - bi.tileStart) * stride, stride);
+    const uint32_t tl = t - bi.tileStart, nt = (bi.count + 63u) >> 6;
+    const uint32_t x = xcdTiles ? tileOwner(tl, nt, lo, xcdSingle) : 0u;
+    const uint4 info = make_uint4(t, bi.slotStart + tl * 64u, min(64u, bi.count - tl * 64u) | (stride << 8) | (x << 12), bi.ctStart + tl * stride);
+    tileInfo[t] = info;
+    tileDesc[t] = make_uint2(bi.ctStart + tl * stride, stride);
     if (xcdTiles) {
-        const uint32_t tl = t - bi.tileStart, nt = (bi.count + 63u) >> 6;
-        const uint32_t x = tileOwner(tl, nt, lo, xcdSingle), at = xcdBase[lo * 8u + x] + tileOwnerRank(tl, nt, lo, xcdSingle);
-        if (at < listCap) xcdTiles[(size_t)x * listCap + at] = t;   // (a longer list is reported by the solver kernel: solveError 2)
+        const uint32_t at = xcdBase[lo * 8u + x] + tileOwnerRank(tl, nt, lo, xcdSingle);
+        if (at < listCap) { xcdTiles[(size_t)x * listCap + at] = t; xcdInfo[(size_t)x * listCap + at] = info; }   // (a longer list is reported by the solver kernel: solveError 2)
     }
 }
 
 // K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379): one wave per tile, one lane per slot.
-__global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restrict__ sc, uint32_t dummyBody, float dt, const uint32_t* __restrict__ tileBin, const BinInfo* __restrict__ binInfo,
+__global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restrict__ sc, uint32_t dummyBody, float dt, const uint4* __restrict__ tileInfo /* k_fill_tiles: per tile, or (XCD-partitioned) per entry of the XCD tile lists */,
                                                      const uint32_t* __restrict__ order,
                                                      const uint32_t* __restrict__ manPair, const uint2* __restrict__ manBodies,
                                                      const uint2* __restrict__ manInfo, const float4* __restrict__ npNormal,
@@ -1598,32 +1602,30 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
                                                      float4* __restrict__ rows, float4* __restrict__ imp, uint4* __restrict__ slotMeta,
                                                      float4* __restrict__ slotNormal, float2* __restrict__ slotMass,
                                                      uint8_t* __restrict__ bodyOwner /* XCD-partitioned solver: [body][8] flags, 1 = a tile of that XCD touches the body; or null */,
-                                                     const uint32_t* __restrict__ xcdTiles, uint32_t listCap /* with bodyOwner: workgroup b prepares entry b / 8 of XCD (b % 8)'s tile list */, uint32_t xcdSingle) {
-    // (one wave per contact index — four waves per tile, the per-manifold gathers repeated — measured slower: 52 -> 73 us; the kernel
-    // is bound by those gathers)
-    uint32_t tile = blockIdx.x, lane = threadIdx.x; const uint32_t kw = 0;
-    if (bodyOwner) {
-        // XCD-partitioned: the workgroups that land on XCD x (blockIdx % 8, a speed assumption only) prepare the tiles XCD x will solve,
-        // i.e. gather the bodies of ONE slab of the scene — they fit that XCD's L2 instead of streaming all bodies through every L2
-        const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
-        if (!sc->totalTiles || j >= sc->xcdCount[x] || j >= listCap) return;
-        tile = xcdTiles[(size_t)x * listCap + j];
-    }
-    if (tile >= sc->totalTiles) return;
-    uint32_t bin = tileBin[tile];
-    BinInfo bi = binInfo[bin];
-    uint32_t tl = tile - bi.tileStart, j = tl * 64u + lane;
-    uint32_t stride = bin < kOverflowColor * 4u ? (bin & 3u) + 1u : 4u;
+                                                     uint32_t listCap /* with bodyOwner: workgroup b prepares entry b / 8 of XCD (b % 8)'s tile list */, uint32_t infoCap) {
+    // Measured and not kept: one wave per contact index (four waves per tile, the per-manifold gathers repeated): 52 -> 73 us; 5 or 6 waves per
+    // SIMD instead of 4 by capping the registers (96 / 80 VGPRs, 96 / 164 bytes of scratch): 66 -> 84 / 94 us.  Everything the kernel needs of
+    // its tile comes in ONE 16-byte entry (k_fill_tiles; was list -> tile -> bin -> bin info): no faster either — the kernel moves ~390 MB
+    // (PMC) in 67 us, it is bound by the body gathers and the row stream, not by the length of its dependent-load chain.
+    const uint32_t lane = threadIdx.x; const uint32_t kw = 0;
+    // XCD-partitioned: the workgroups that land on XCD x (blockIdx % 8, a speed assumption only) prepare the tiles XCD x will solve,
+    // i.e. gather the bodies of ONE slab of the scene — they fit that XCD's L2 instead of streaming all bodies through every L2
+    const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
+    const uint32_t entry = bodyOwner ? x * listCap + j : blockIdx.x;
+    const uint4 te = entry < infoCap ? tileInfo[entry] : make_uint4(0u, 0u, 0u, 0u);   // (requested before the validity checks below: their loads run beside it)
+    if (bodyOwner) { if (!sc->totalTiles || j >= sc->xcdCount[x] || j >= listCap) return; }
+    else if (entry >= sc->totalTiles) return;
+    const uint32_t tile = te.x, count = te.z & 0xFFu, stride = (te.z >> 8) & 0xFu;
     if (kw >= stride) return;
-    size_t ctBase = (size_t)bi.ctStart + (size_t)tl * stride;
-    if (j >= bi.count) {
+    const size_t ctBase = te.w;
+    if (lane >= count) {
         if (kw == 0) {
             slotMeta[(size_t)tile * 64u + lane] = make_uint4(dummyBody, dummyBody, 0u, 0u);
             slotMass[(size_t)tile * 64u + lane] = make_float2(0.f, 0.f);
         }
         return;
     }
-    uint32_t m = order[bi.slotStart + j];
+    uint32_t m = order[te.y + lane];
     uint32_t p = manPair[m];
     uint2 bodies = manBodies[m];
     uint2 info = manInfo[m];
@@ -1647,9 +1649,9 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
         slotMass[(size_t)tile * 64u + lane] = make_float2(imA, imB);
     }
     if (bodyOwner && kw == 0) {   // one byte per (body, XCD): plain idempotent stores, no atomics
-        const uint32_t x = tileOwner(tl, (bi.count + 63u) >> 6, bin, xcdSingle);
-        if (imA != 0.f) bodyOwner[(size_t)bodies.x * 8u + x] = 1u;
-        if (imB != 0.f) bodyOwner[(size_t)bodies.y * 8u + x] = 1u;
+        const uint32_t xo = te.z >> 12;
+        if (imA != 0.f) bodyOwner[(size_t)bodies.x * 8u + xo] = 1u;
+        if (imB != 0.f) bodyOwner[(size_t)bodies.y * 8u + xo] = 1u;
     }
     M3 IA = loadM3(gInvI, bodies.x), IB = loadM3(gInvI, bodies.y);
     V3 vA = xyz(gVel[2 * bodies.x]), wA = xyz(gVel[2 * bodies.x + 1]);

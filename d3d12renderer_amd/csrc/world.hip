@@ -199,7 +199,7 @@ struct mi_world {
     DBuf<uint64_t> npPacked, npScan; DBuf<float4> npNormal, npPoints; DBuf<BoxHit> boxQueue;
     DBuf<uint32_t> manPair; DBuf<uint2> manBodies, manInfo; DBuf<uint4> colWork;
     // schedule + solver
-    DBuf<uint32_t> color, order, orderTmp, blockHist, blockScan, tileBin; DBuf<unsigned long long> bodyTop, bodyUsed;
+    DBuf<uint32_t> color, order, orderTmp, blockHist, blockScan; DBuf<uint4> tileInfo, xcdInfo; DBuf<unsigned long long> bodyTop, bodyUsed;
     DBuf<BinInfo> binInfo;
     // colour history (pair -> colour of the previous step): two tables, the one written by a step becomes current only if the step is valid
     DBuf<unsigned long long> tabKeys[2]; DBuf<uint32_t> tabVals[2]; uint32_t tabMask[2] = {0, 0}; int tabCur = 0; bool tabValid = false;
@@ -1071,11 +1071,11 @@ enqueue_section:
         const uint32_t binBlocks = divUp(nmBound, kBinItems);
         HIP_TRY(order.ensure((size_t)binBlocks * kBinItems)); HIP_TRY(orderTmp.ensure((size_t)binBlocks * kBinItems));
         HIP_TRY(blockHist.ensure((size_t)kColorBins * binBlocks)); HIP_TRY(blockScan.ensure((size_t)kColorBins * binBlocks));
-        HIP_TRY(tileBin.ensure(tilesCap)); HIP_TRY(tileDesc.ensure(tilesCap));
+        HIP_TRY(tileInfo.ensure(tilesCap)); HIP_TRY(tileDesc.ensure(tilesCap));
         if (xcdPlan) {   // slots in spatial order inside every bin + per-XCD tile lists (k_contact_solve_persist<.., true>)
             xcdListCap = xcdSingle ? tilesCap + kSchedBins : divUp(tilesCap, 8) + kSchedBins;
             HIP_TRY(sortKeys[0].ensure(nmBound)); for (int k = 0; k < 2; ++k) HIP_TRY(sortVals[k].ensure(nmBound));
-            HIP_TRY(xcdTiles.ensure((size_t)8 * xcdListCap));
+            HIP_TRY(xcdTiles.ensure((size_t)8 * xcdListCap)); HIP_TRY(xcdInfo.ensure((size_t)8 * xcdListCap));
             if (!xcdSingle) {   // (one XCD: nothing to keep apart, the emission order will do)
                 L.launch(k_manifold_keys, dim3(divUp(nmBound, kKeyItems)), dim3(256), 0, st, nmBound, sc, grid.p + gridCur, manBodies.p, gPos.p, sortKeys[0].p, sortVals[0].p, keyCount.p);
                 L.launch(k_manifold_place, dim3(divUp(nmBound, kKeyItems)), dim3(256), 0, st, nmBound, sc, sortKeys[0].p, sortVals[0].p, keyCount.p, sortVals[1].p);
@@ -1093,7 +1093,7 @@ enqueue_section:
             HIP_TRY(scanBins.run(L, blockHist.p, blockScan.p, kColorBins * binBlocks, st));
             L.launch(k_bin_scatter, dim3(binBlocks), dim3(256), 0, st, round - 1, roundFlagsPtr(), binBlocks, perm, color.p, manInfo.p, blockScan.p, order.p, sc);
             L.launch(k_build_tiles, dim3(1), dim3(256), 0, st, tilesCap, ctCap, sc, binInfo.p, xcdPlan ? xcdBase.p : nullptr, xcdSingle ? 1u : 0u);
-            L.launch(k_fill_tiles, dim3(divUp(tilesCap, B)), dim3(B), 0, st, sc, binInfo.p, tileBin.p, tileDesc.p, xcdBase.p, xcdPlan ? xcdTiles.p : nullptr, xcdListCap, xcdSingle ? 1u : 0u);
+            L.launch(k_fill_tiles, dim3(divUp(tilesCap, B)), dim3(B), 0, st, sc, binInfo.p, tileInfo.p, tileDesc.p, xcdBase.p, xcdPlan ? xcdTiles.p : nullptr, xcdInfo.p, xcdListCap, xcdSingle ? 1u : 0u);
             if (spec) break;
             int rc = readScalars(); if (rc != MI_OK) return rc;
             if (hs.colorPending == 0) break;
@@ -1143,9 +1143,9 @@ enqueue_section:
         HIP_TRY(slotMeta.ensure((size_t)tilesCap * 64)); HIP_TRY(slotNormal.ensure((size_t)tilesCap * 64)); HIP_TRY(slotMass.ensure((size_t)tilesCap * 64));
         HIP_TRY(rows.ensure((size_t)ctCap * kRows * 64)); HIP_TRY(imp.ensure((size_t)ctCap * 64));
         if (tilesLaunch)
-            L.launch(k_contact_init, dim3(xcdPlan ? 8u * xcdListCap : tilesLaunch), dim3(64), 0, st, sc, nb, dt, tileBin.p, binInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
+            L.launch(k_contact_init, dim3(xcdPlan ? 8u * xcdListCap : tilesLaunch), dim3(64), 0, st, sc, nb, dt, xcdPlan ? xcdInfo.p : tileInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
                                                       gPos.p, gInvI.p, xcdPlan ? gVelL.p : gVel.p /* same content here; the cached copy */, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, impNeeded ? imp.p : nullptr, slotMeta.p, slotNormal.p, slotMass.p,
-                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, xcdTiles.p, xcdListCap, xcdSingle ? 1u : 0u);
+                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, xcdListCap, xcdPlan ? 8u * xcdListCap : tilesCap);
     }
     int rc = joints.initialize(*this, dt, st);   // (through L)
     if (rc != MI_OK) return rc;
