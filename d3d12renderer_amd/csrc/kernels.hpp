@@ -1118,8 +1118,8 @@ __global__ __launch_bounds__(256) void k_events_end(uint32_t cap, StepScalars* s
 // everything a colouring round needs in one 16-byte row.
 __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB, const uint64_t* __restrict__ npPacked,
                                                         const uint64_t* __restrict__ npScan,
-                                                        const float4* __restrict__ aabbMax, const float4* __restrict__ cMaterial,
-                                                        const float4* __restrict__ bCogInvMass,
+                                                        const float4* __restrict__ cEmit /* per collider, static between uploads: (restitution, friction, body index | nb for a static collider, 1 if that body is dynamic) —
+                                                                                            ONE 16-byte gather per side instead of material + world box + body (three sectors, the last one dependent) */,
                                                         uint32_t* __restrict__ manPair, uint2* __restrict__ manBodies, uint2* __restrict__ manInfo,
                                                         uint4* __restrict__ colWork, uint32_t* __restrict__ color,
                                                         const unsigned long long* __restrict__ prevKeys, const uint32_t* __restrict__ prevVals, uint32_t prevMask,
@@ -1138,16 +1138,16 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
     uint64_t key = pairKeys[p];
     uint32_t a = (uint32_t)((key >> 29) & 0x1FFFFFFFu), b = (uint32_t)(key & 0x1FFFFFFFu);
     const bool terrain = b >= kHeightmapVirtualBase;   // heightmap contact: body B = the static dummy, material of the heightmap
-    float4 ma = cMaterial[a], mb = terrain ? make_float4(terrainMaterial.x, terrainMaterial.y, 0.f, 0.f) : cMaterial[b];   // (restitution, friction, density, -)
+    float4 ma = cEmit[a], mb = terrain ? make_float4(terrainMaterial.x, terrainMaterial.y, __uint_as_float(nb), 0.f) : cEmit[b];
     float friction = clamp01(sqrtf(ma.y * mb.y));                      // collision_narrow.cpp:2232-2238
     float restitution = clamp01(fmaxr(ma.x, mb.x));
     uint32_t fr = ((uint32_t)(friction * 0xFFFF) << 16) | (uint32_t)(restitution * 0xFFFF);
-    uint32_t bA = __float_as_uint(aabbMax[a].w), bB = terrain ? nb : __float_as_uint(aabbMax[b].w);
+    uint32_t bA = __float_as_uint(ma.z), bB = __float_as_uint(mb.z);
     manPair[m] = p;
     manBodies[m] = make_uint2(bA, bB);
     manInfo[m] = make_uint2(cnt | (conOff << 3), fr);
-    uint32_t dynA = (bA < nb && bCogInvMass[bA].w != 0.f) ? 0x80000000u : 0u;
-    uint32_t dynB = (bB < nb && bCogInvMass[bB].w != 0.f) ? 0x80000000u : 0u;
+    uint32_t dynA = __float_as_uint(ma.w) ? 0x80000000u : 0u;
+    uint32_t dynB = __float_as_uint(mb.w) ? 0x80000000u : 0u;
     uint64_t prio = pairPriority(a, b);
     colWork[m] = make_uint4(bA | dynA, bB | dynB, (uint32_t)prio, (uint32_t)(prio >> 32));
     // a manifold of the previous step keeps its colour (colour 64 = overflow is re-coloured)

@@ -104,6 +104,13 @@ struct HHull { std::vector<V3> verts; std::vector<uint32_t> tris; V3 mn, mx; };
 struct MassProps { M3 inertia; V3 cog; float mass; };
 
 static uint32_t divUp(uint32_t a, uint32_t b) { return (a + b - 1) / b; }
+static float elapsedMs(hipEvent_t a, hipEvent_t b) {
+    float ms = 0.f;
+    hipError_t e = hipEventElapsedTime(&ms, a, b);
+    if (e == hipErrorNotReady) { (void)hipGetLastError(); (void)hipEventSynchronize(a); (void)hipEventSynchronize(b); e = hipEventElapsedTime(&ms, a, b); }
+    if (e != hipSuccess) { (void)hipGetLastError(); ms = 0.f; }
+    return ms;
+}
 // Host loops over every body / entity (read-back conversions, interpolation) in slices on a few threads once they are long: at 57 k bodies
 // the serial loop of download() — a quaternion normalisation per body — was 1.4 ms of a 4.5 ms batched learning step.  Independent iterations only.
 template <class F>
@@ -182,7 +189,7 @@ struct mi_world {
     DBuf<float4> gVelL; DBuf<unsigned long long> bodyOwner; DBuf<uint32_t> sortKeys[2], sortVals[2], xcdBase, xcdTiles, keyCount;
     bool persistXcd = true, persistXcdSingle = true, usedXcd = false, usedXcdSingle = false, lastXcdSingle = false, haveXcdEstimate = false, xcdFaultFired = false, xcdFaultTest = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
     // device: colliders
-    DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cMaterial;
+    DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cEmit;
     DBuf<float4> wShape, aabbMin, aabbMax, hullAabb, hullVerts; DBuf<uint32_t> hullRanges;
     // broad phase
     DBuf<double> axisPartials;
@@ -540,7 +547,7 @@ int mi_world::upload() {
 
     usesGjk = false;
     for (const HCollider& c : colliders) if (c.desc.type == T_CAPSULE || c.desc.type == T_CYLINDER || c.desc.type == T_HULL) usesGjk = true;
-    std::vector<uint32_t> tb(2 * (size_t)nc), obj(nc), cent(nc); std::vector<float4> sh(3 * (size_t)nc), sp(nc), sr(nc), mat(nc);
+    std::vector<uint32_t> tb(2 * (size_t)nc), obj(nc), cent(nc); std::vector<float4> sh(3 * (size_t)nc), sp(nc), sr(nc), emit(nc);
     // force fields (getForceFieldStates, physics.cpp:759-787): rotated force per field; fields without colliders are global
     usesInteractions = false; globalForce = V3();
     std::vector<float4> lf(ffEntities.size());
@@ -560,11 +567,15 @@ int mi_world::upload() {
         if (c.desc.type == T_HULL) std::memcpy(&s[7], &c.desc.hull_geometry, 4);
         sh[3 * k] = make_float4(s[0], s[1], s[2], s[3]); sh[3 * k + 1] = make_float4(s[4], s[5], s[6], s[7]); sh[3 * k + 2] = make_float4(s[8], s[9], s[10], s[11]);
         sp[k] = h4(e.pos, 0.f); sr[k] = make_float4(e.rot.x, e.rot.y, e.rot.z, e.rot.w);
-        mat[k] = make_float4(c.desc.restitution, c.desc.friction, c.desc.density, 0.f);
+        // what k_emit_manifolds needs of a collider in one gather (objIndex as k_world_colliders writes it: the body, or the static dummy `nb`)
+        const uint32_t obj = e.rb >= 0 ? (uint32_t)e.rb : e.kind == MI_ENTITY_FORCE_FIELD || e.kind == MI_ENTITY_TRIGGER ? e.kindIndex : nb;
+        const uint32_t dyn = e.rb >= 0 && bodies[e.rb].invMass != 0.f ? 1u : 0u;
+        emit[k] = make_float4(c.desc.restitution, c.desc.friction, 0.f, 0.f);
+        std::memcpy(&emit[k].z, &obj, 4); std::memcpy(&emit[k].w, &dyn, 4);
     }
     UP(cObject, obj, nc); UP(localForce, lf, lf.size()); UP(cEntity, cent, nc);
     if (usesInteractions) HIP_TRY(bForceStep.ensure(std::max<size_t>(nb, 1)));
-    UP(cTypeBody, tb, 2 * (size_t)nc); UP(cShape, sh, 3 * (size_t)nc); UP(cStaticPos, sp, nc); UP(cStaticRot, sr, nc); UP(cMaterial, mat, nc);
+    UP(cTypeBody, tb, 2 * (size_t)nc); UP(cShape, sh, 3 * (size_t)nc); UP(cStaticPos, sp, nc); UP(cStaticRot, sr, nc); UP(cEmit, emit, nc);
     HIP_TRY(wShape.ensure(3 * (size_t)nc + 1)); HIP_TRY(aabbMin.ensure(nc + 1)); HIP_TRY(aabbMax.ensure(nc + 1));
     HIP_TRY(sMin.ensure(nc + 1)); HIP_TRY(sMax.ensure(nc + 1));
     HIP_TRY(largeList.ensure(nc + 1)); HIP_TRY(isLarge.ensure(nc + 1));
@@ -1033,7 +1044,7 @@ enqueue_section:
             tabMask[nt] = cap - 1u;
             HIP_TRY(L.memsetAsync(tabKeys[nt].p, 0, (size_t)cap * sizeof(unsigned long long), st));
         }
-        L.launch(k_emit_manifolds, dim3(divUp(pairBound, B)), dim3(B), 0, st, nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, aabbMax.p, cMaterial.p, bCogInvMass.p,
+        L.launch(k_emit_manifolds, dim3(divUp(pairBound, B)), dim3(B), 0, st, nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, cEmit.p,
                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
                                                         tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc,
                                                         heightmap ? make_float2(hmParams.restitution, hmParams.friction) : make_float2(0.f, 0.f),
@@ -1381,7 +1392,7 @@ enqueue_section:
         if (useFlow) { mainContacts = 0; for (uint32_t bn = 0; bn + 1 < kSchedBins; ++bn) mainContacts += (uint64_t)bins[bn].count * ((bn & 3u) + 1u); }
         profContacts = mainContacts * iters;
         profKernelMs = 0.f;
-        for (uint32_t l = 0; l < profLaunches; ++l) { float ms = 0.f; (void)hipEventElapsedTime(&ms, profEvents[2 * l], profEvents[2 * l + 1]); profKernelMs += ms; }
+        for (uint32_t l = 0; l < profLaunches; ++l) profKernelMs += elapsedMs(profEvents[2 * l], profEvents[2 * l + 1]);
     }
     if (spec && usesInteractions) {   // the trigger overlaps of this step, from the device-sorted interaction list (force fields were applied in-stream)
         std::vector<DeviceInteraction> list(eventsEnabled ? hs.numInteractions : 0u);
@@ -1453,7 +1464,9 @@ enqueue_section:
     haveEstimates = true;
     pairsIn = hs.partitioned ? pairKeysS.p : pairKeys.p;
 
-    auto el = [&](int a, int b) { float ms = 0.f; (void)hipEventElapsedTime(&ms, ev[a], ev[b]); return ms; };
+    // (the host got here on the published read-back, i.e. after the kernels the events belong to — but the HIP 7.0 runtime now and then still
+    // reports an event attached to a kernel as not ready, ~1 step in 1000: wait for it then instead of reporting 0 ms)
+    auto el = [&](int a, int b) { return elapsedMs(ev[a], ev[b]); };
     if (stageEvents) {
         times.world_colliders = el(0, 1); times.broadphase = el(1, 2); times.narrowphase = el(2, 3); times.integrate_forces = el(3, 4);
         times.schedule = el(4, 5); times.init_constraints = el(5, 6);
