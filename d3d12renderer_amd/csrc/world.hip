@@ -2727,9 +2727,53 @@ MI_API int mi_world_num_entities(mi_world* w, uint32_t* out) { if (!w || !out) r
 
 static int getTransforms(mi_world* w, float* p, float* r, uint32_t cap, bool physics) {
     if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
-    int rc = w->download(); if (rc != MI_OK) return rc;
     uint32_t n = (uint32_t)w->entities.size();
     if (cap < n) return fail(MI_ERR_CAPACITY, "capacity < num entities");
+    {   // The caller that reads the poses after every step (a renderer): positions and rotations come straight from the device — 2 arrays (4 while an
+        // interpolation is pending) instead of the 6-8 of a full download() — and the host mirror of the bodies is left alone (still stale: whoever
+        // needs it downloads it).  Same arithmetic as download(), which keeps producing the same values later.
+        const uint32_t nb = (uint32_t)w->bodies.size();
+        const bool follow = physics || w->transformsFollowPhysics, lerpNow = !follow && w->lerpPending;
+        if (w->hostStale && !w->topologyDirty && nb && (follow || lerpNow)) {
+            HIP_TRY(hipSetDevice(w->device));
+            const bool p0Dev = lerpNow && w->p0OnDevice;
+            const size_t rows = (p0Dev ? 4u : 2u) * (size_t)nb;
+            if (rows > w->downloadStageCap) {
+                if (w->downloadStage) (void)hipHostFree(w->downloadStage);
+                w->downloadStage = nullptr; w->downloadStageCap = 0;
+                HIP_TRY(hipHostMalloc((void**)&w->downloadStage, (8u * (size_t)nb + 2u * (size_t)nb) * sizeof(float4)));   // what download() will ask for, once
+                w->downloadStageCap = 8u * (size_t)nb + 2u * (size_t)nb;
+            }
+            float4 *pos = w->downloadStage, *rot = pos + nb, *pos0 = rot + nb, *rot0 = pos0 + nb;
+            HIP_TRY(hipMemcpyAsync(pos, w->bPos.p, (size_t)nb * 16, hipMemcpyDeviceToHost, w->stream));
+            HIP_TRY(hipMemcpyAsync(rot, w->bRot.p, (size_t)nb * 16, hipMemcpyDeviceToHost, w->stream));
+            if (p0Dev) {
+                HIP_TRY(hipMemcpyAsync(pos0, w->bPos0.p, (size_t)nb * 16, hipMemcpyDeviceToHost, w->stream));
+                HIP_TRY(hipMemcpyAsync(rot0, w->bRot0.p, (size_t)nb * 16, hipMemcpyDeviceToHost, w->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(w->stream));
+            const float t = w->lerpT;
+            hostParallelFor(n, [&](uint32_t i) {
+                const HEntity& e = w->entities[i];
+                V3 ps = e.pos; Q4 rt = e.rot;
+                if (e.rb >= 0) {
+                    const uint32_t b = (uint32_t)e.rb;
+                    const V3 p1(pos[b].x, pos[b].y, pos[b].z); const Q4 r1(rot[b].x, rot[b].y, rot[b].z, rot[b].w);
+                    if (follow) { ps = p1; rt = r1; }
+                    else {   // lerp(trs): nlerp on the quaternion (src/core/math.h:673-682)
+                        const V3 p0 = p0Dev ? V3(pos0[b].x, pos0[b].y, pos0[b].z) : w->bodies[b].p0;
+                        const Q4 r0 = p0Dev ? Q4(rot0[b].x, rot0[b].y, rot0[b].z, rot0[b].w) : w->bodies[b].r0;
+                        ps = lerp(p0, p1, t);
+                        rt = normalize(Q4(r0.x + t * (r1.x - r0.x), r0.y + t * (r1.y - r0.y), r0.z + t * (r1.z - r0.z), r0.w + t * (r1.w - r0.w)));
+                    }
+                }
+                if (p) { p[3 * i] = ps.x; p[3 * i + 1] = ps.y; p[3 * i + 2] = ps.z; }
+                if (r) { r[4 * i] = rt.x; r[4 * i + 1] = rt.y; r[4 * i + 2] = rt.z; r[4 * i + 3] = rt.w; }
+            });
+            return MI_OK;
+        }
+    }
+    int rc = w->download(); if (rc != MI_OK) return rc;
     hostParallelFor(n, [&](uint32_t i) {
         const HEntity& e = w->entities[i];
         V3 pos = e.pos; Q4 rot = e.rot;
@@ -2743,9 +2787,31 @@ MI_API int mi_world_get_transforms(mi_world* w, float* p, float* r, uint32_t cap
 MI_API int mi_world_get_physics_transforms(mi_world* w, float* p, float* r, uint32_t cap) { return getTransforms(w, p, r, cap, true); }
 MI_API int mi_world_get_velocities(mi_world* w, float* lin, float* ang, uint32_t cap) {
     if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
-    int rc = w->download(); if (rc != MI_OK) return rc;
     uint32_t n = (uint32_t)w->entities.size();
     if (cap < n) return fail(MI_ERR_CAPACITY, "capacity < num entities");
+    const uint32_t nb = (uint32_t)w->bodies.size();
+    if (w->hostStale && !w->topologyDirty && nb) {   // straight from the device, like the poses (getTransforms): two arrays, host mirror left alone
+        HIP_TRY(hipSetDevice(w->device));
+        if (2u * (size_t)nb > w->downloadStageCap) {
+            if (w->downloadStage) (void)hipHostFree(w->downloadStage);
+            w->downloadStage = nullptr; w->downloadStageCap = 0;
+            HIP_TRY(hipHostMalloc((void**)&w->downloadStage, 10u * (size_t)nb * sizeof(float4)));
+            w->downloadStageCap = 10u * (size_t)nb;
+        }
+        float4 *lv = w->downloadStage, *av = lv + nb;
+        HIP_TRY(hipMemcpyAsync(lv, w->bLinVel.p, (size_t)nb * 16, hipMemcpyDeviceToHost, w->stream));
+        HIP_TRY(hipMemcpyAsync(av, w->bAngVel.p, (size_t)nb * 16, hipMemcpyDeviceToHost, w->stream));
+        HIP_TRY(hipStreamSynchronize(w->stream));
+        hostParallelFor(n, [&](uint32_t i) {
+            V3 v, a;
+            const int b = w->entities[i].rb;
+            if (b >= 0) { v = V3(lv[b].x, lv[b].y, lv[b].z); a = V3(av[b].x, av[b].y, av[b].z); }
+            if (lin) { lin[3 * i] = v.x; lin[3 * i + 1] = v.y; lin[3 * i + 2] = v.z; }
+            if (ang) { ang[3 * i] = a.x; ang[3 * i + 1] = a.y; ang[3 * i + 2] = a.z; }
+        });
+        return MI_OK;
+    }
+    int rc = w->download(); if (rc != MI_OK) return rc;
     hostParallelFor(n, [&](uint32_t i) {
         V3 v, a;
         if (w->entities[i].rb >= 0) { v = w->bodies[w->entities[i].rb].linVel; a = w->bodies[w->entities[i].rb].angVel; }
