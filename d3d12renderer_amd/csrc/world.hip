@@ -159,7 +159,7 @@ struct mi_world {
         DBuf<uint8_t> known;                     // per body: this rank's copy is current (owned in the last step, or a record arrived)
         DBuf<uint32_t> hist; DBuf<uint64_t> reduceBuf;
         uint32_t capacity = 0; std::vector<uint32_t> peerRanks;
-        DBuf<uint8_t> active, activePrev; bool prevValid = false, flagsSwapPending = false, stepOpen = false;   // activePrev: the previous valid step's flags (k_integrate_velocities skips bodies idle in both)
+        DBuf<uint8_t> active, activePrev; bool prevValid = false, flagsSwapPending = false, stepOpen = false, flagsOfAStep = false;   // flagsOfAStep: `active` holds what the last step classified (not so right after enable / a re-upload)   // activePrev: the previous valid step's flags (k_integrate_velocities skips bodies idle in both)
         DBuf<float> sendBuf[8], recvBuf[8];
         DBuf<uint32_t> root; size_t rootJoints = ~size_t(0), rootBodies = 0;   // island root of every body (union-find over the joints), rebuilt when the scene changes
         uint32_t* sentHost = nullptr;            // pinned: the records packed per slot in the previous exchange (overflow check)
@@ -518,7 +518,7 @@ static float4 h4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 int mi_world::upload() {
     recalcProperties();
     dropStepGraphs();
-    shard.prevValid = false; shard.flagsSwapPending = false;
+    shard.prevValid = false; shard.flagsSwapPending = false; shard.flagsOfAStep = false;
     uint32_t nb = (uint32_t)bodies.size(), nc = (uint32_t)colliders.size();
     std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), fo(nb), to(nb), cim(nb), ii(3 * (size_t)nb), prm(nb);
     for (uint32_t i = 0; i < nb; ++i) {
@@ -1446,7 +1446,7 @@ enqueue_section:
     last.gjkSpan = sticky(hs.gjkHi - hs.gjkLo, last.gjkSpan, 256);
     last.numInterPairs = sticky(hs.numInterPairs, last.numInterPairs, 256); last.numInteractions = sticky(hs.numInteractions, last.numInteractions, 256);
     for (int k = 0; k < 3; ++k) shard.owned[k] = hs.shardOwned[k];
-    shard.flagsSwapPending = shard.enabled; shard.stepOpen = false;
+    shard.flagsSwapPending = shard.enabled; shard.stepOpen = false; shard.flagsOfAStep = shard.enabled;
     static const bool xcdStats = std::getenv("MI_XCD_STATS") != nullptr;   // development: how many bodies stayed XCD-local
     if (xcdStats && usedXcd && ((totalSteps % 50u) == 0u || std::getenv("MI_XCD_NOSORT"))) {
         std::vector<unsigned long long> own(nb);
@@ -2328,7 +2328,7 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
     ShardParams& sp = sh.sp;
     sp.margin = d->ghost_margin;
     sp.tilesX = d->tiles_x; sp.tilesZ = d->tiles_z; sp.myTile = order[d->rank]; sp.numPeers = 0; sh.peerRanks.clear();
-    sh.bordersX.clear(); sh.bordersZ.clear(); sh.bordersPending = false;
+    sh.bordersX.clear(); sh.bordersZ.clear(); sh.bordersPending = false; sh.flagsOfAStep = false;
     for (uint32_t i = 1; i < d->tiles_x; ++i) sh.bordersX.push_back((float)((double)d->origin_x + (double)i * (double)d->tile_size_x));
     for (uint32_t i = 1; i < d->tiles_z; ++i) sh.bordersZ.push_back((float)((double)d->origin_z + (double)i * (double)d->tile_size_z));
     w->shardFillBorders(sp, sh.bordersX, sh.bordersZ);
@@ -2411,7 +2411,7 @@ MI_API int mi_world_shard_histogram(mi_world* w, uint32_t axis, float lo, float 
     HIP_TRY(hipSetDevice(w->device));
     const uint32_t nb = (uint32_t)w->bodies.size();
     std::fill(out, out + bins, 0u);
-    if (!nb || w->topologyDirty || !w->shard.active.p) return MI_OK;       // no step yet: nothing is owned
+    if (!nb || w->topologyDirty || !w->shard.flagsOfAStep) return MI_OK;   // no step since the scene was (re)built: nothing is owned yet
     HIP_TRY(w->shard.hist.ensure(bins));
     HIP_TRY(hipMemsetAsync(w->shard.hist.p, 0, bins * sizeof(uint32_t), w->stream));
     k_shard_histogram<<<divUp(nb, 256), 256, 0, w->stream>>>(nb, axis, lo, (float)bins / (hi - lo), bins, w->shard.active.p, w->bPos.p, w->bRot.p, w->bCogInvMass.p, w->shard.root.p, w->shard.hist.p);
@@ -2482,9 +2482,9 @@ MI_API int mi_world_shard_owned_entities(mi_world* w, uint32_t* out, uint32_t ca
     if (!w || !count || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
     HIP_TRY(hipSetDevice(w->device));
     const uint32_t nb = (uint32_t)w->bodies.size();
-    std::vector<uint8_t> act(nb);
+    std::vector<uint8_t> act(nb, 0);
     HIP_TRY(hipStreamSynchronize(w->stream));
-    if (nb) HIP_TRY(hipMemcpy(act.data(), w->shard.active.p, nb, hipMemcpyDeviceToHost));
+    if (nb && w->shard.flagsOfAStep && !w->topologyDirty) HIP_TRY(hipMemcpy(act.data(), w->shard.active.p, nb, hipMemcpyDeviceToHost));   // (no step since the scene was (re)built: nothing is owned yet)
     uint32_t n = 0;
     for (uint32_t b = 0; b < nb; ++b) if (act[b] == 1u) { if (out && n < cap) out[n] = w->bodies[b].entity; ++n; }
     *count = n;
