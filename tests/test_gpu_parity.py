@@ -108,6 +108,30 @@ def test_gpu_physics_step_accumulator(mi_lib, oracle_mod):
         assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
 
 
+def test_gpu_pose_and_velocity_readbacks_agree_with_a_full_download(mi_lib, oracle_mod):
+    """mi_world_get_transforms / _physics_transforms / _velocities read straight from the device (2-4 arrays, host mirror untouched); everything
+    else goes through a full download of the body state.  Both give the same bytes, in any order, interpolated or not, and equal the oracle."""
+    sc = scenes.mixed_stack(6, 4, 6)
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings(); ids = np.arange(sc.num_bodies, dtype=np.uint32)
+    for i, dt in enumerate((1 / 120, 1 / 240 + 1 / 480, 1 / 60, 1 / 480, 0.03)):
+        g.step(s, dt); o.step(s, dt)
+        fast = (g.transforms(), g.physics_transforms(), g.velocities())          # device -> caller, the mirror stays stale
+        again = (g.transforms(), g.physics_transforms(), g.velocities())         # idempotent
+        st = g.get_body_states(ids)                                             # forces the full download (and settles a pending interpolation)
+        slow = (g.transforms(), g.physics_transforms(), g.velocities())          # now from the host mirror
+        ref = (o.transforms(), o.physics_transforms(), o.velocities())
+        for a, b, c, d in zip(fast, again, slow, ref):
+            for k in range(2):
+                assert a[k].tobytes() == b[k].tobytes() == c[k].tobytes() == d[k].tobytes(), f"call {i}"
+        assert st.tobytes() == o.get_body_states(ids).tobytes()
+    for _ in range(3):                                                           # and after plain internal steps (transform = physics_transform1)
+        g.step_fixed(s, sc.dt, 2); o.step_fixed(s, sc.dt, 2)
+        assert g.transforms()[0].tobytes() == o.transforms()[0].tobytes() and g.velocities()[1].tobytes() == o.velocities()[1].tobytes()
+        g.get_body_states(ids)
+        assert g.transforms()[1].tobytes() == o.transforms()[1].tobytes()
+
+
 @pytest.mark.parametrize("name", sorted(scenes.EDGE_CASES))
 def test_gpu_degenerate_scenes_match_oracle(mi_lib, oracle_mod, name):
     """scenes.EDGE_CASES (exactly aligned faces, parallel capsule / cylinder branches, kinematic platform, compound bodies, odd body
