@@ -2438,6 +2438,9 @@ MI_API int mi_shard_balance_borders(const uint64_t* hist, uint32_t bins, float l
             double v = (double)lo + ((double)b + frac) * width;
             if (i > 0) v = std::max(v, std::max((double)c[i - 1] + (double)margin, (double)nb[i - 1] + 1.25 * (double)margin));   // (x 1.25: room to move next time)
             if (i + 1u < n) v = std::min(v, (double)c[i + 1] - (double)margin);
+            // ... and move by at most two margins: the hand-over rides in ONE neighbour message, whose capacity is sized in margin strips
+            v = std::min(std::max(v, (double)c[i] - 2.0 * (double)margin), (double)c[i] + 2.0 * (double)margin);
+            if (i > 0) v = std::max(v, (double)nb[i - 1] + 1.25 * (double)margin);
             nb[i] = (float)v;
         }
     }

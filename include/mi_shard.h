@@ -72,7 +72,8 @@ MI_API int mi_world_shard_owned_entities(mi_world* world, uint32_t* out_entities
  * under the new ones, so the switch needs no extra round trip and no rank ever classifies a body from a copy that is not current (a rank only trusts
  * its copy of a body it owned in the last step or got a record for).  What one change may do: border i stays within
  * [old border i-1 + ghost_margin, old border i+1 - ghost_margin] (a body's new owner is then the old owner's tile or a neighbour of it) and tiles stay
- * wider than ghost_margin; anything else is MI_ERR_INVALID_ARGUMENT.  A null axis stays as it is.  Identical values on all ranks, between the same steps. */
+ * wider than ghost_margin; anything else is MI_ERR_INVALID_ARGUMENT.  mi_shard_balance_borders moves a border by at most two margins per round (the
+ * hand-over has to fit the one neighbour message, whose capacity max_records is sized in margin strips): a badly laid out grid converges over a few rounds.  A null axis stays as it is.  Identical values on all ranks, between the same steps. */
 MI_API int mi_world_shard_histogram(mi_world* world, uint32_t axis /* 0 = x, 1 = z */, float lo, float hi, uint32_t bins, uint32_t* out_counts /* the end bins take what lies outside [lo, hi) */);
 MI_API int mi_shard_balance_borders(const uint64_t* hist, uint32_t bins, float lo, float hi, uint32_t tiles, const float* current_borders, float ghost_margin, float* out_borders /* tiles - 1 */);
 MI_API int mi_world_shard_set_borders(mi_world* world, const float* borders_x /* tiles_x - 1, or null */, const float* borders_z /* tiles_z - 1, or null */);
