@@ -283,6 +283,18 @@ def test_a_rank_never_trusts_a_copy_that_is_not_current(oracle_mod):
     assert ranks[0].world.shard_get_borders(2, 1)[0][0] == np.float32(-1.6)
 
 
+def test_gpu_sharding_scenarios_on_the_oracle(oracle_mod):
+    """The scenario bodies of tests/test_gpu_sharding.py that only need "a library" run here with the oracle in the product's place: the stale
+    copy under a moving border followed by an entity deletion on every rank (what a rank knows follows the bodies through the swap-and-pop), and
+    the rebalanced ranks — so the N > 1 logic they cover is exercised on every CPU run as well."""
+    import types
+    import test_gpu_sharding as G
+    lib = types.SimpleNamespace(create_world=lambda device: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    G.test_gpu_rank_never_trusts_a_copy_that_is_not_current(lib)
+    G.test_gpu_rebalanced_ranks_match_oracle(lib, oracle_mod, 3, 1, lambda: scenes.ragdolls(8, 2), 3.5)      # islands move whole
+    G.test_gpu_cloth_in_a_sharded_world(lib)
+
+
 def test_border_changes_are_validated(oracle_mod):
     sc = _scene()
     w = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
