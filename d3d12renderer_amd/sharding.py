@@ -128,6 +128,8 @@ class ShardedWorld:
     def rebalance(self):
         """One rebalancing round of a multi-process run (between two steps, on every rank): all-reduce the histograms over the process
         group — control plane, a few KB every K steps — and move the borders."""
+        if self.dist is None:
+            raise RuntimeError("virtual ranks of one process rebalance together: sharding.rebalance_local(ranks)")
         if self.transport == "rccl":     # the library does the whole round: histograms, ONE ncclAllReduce on the world's stream, new borders
             self.world.shard_rebalance(self.BALANCE_BINS)
             return self.world.shard_get_borders(self.desc.tiles_x, self.desc.tiles_z)   # (still the old ones: the new ones are in force after the next step)
