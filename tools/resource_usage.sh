@@ -5,7 +5,7 @@ import sys,re
 out=[]
 for line in sys.stdin:
     m=re.search(r"remark: +Function Name: (\S+)",line)
-    if m: out.append([m.group(1)[:64]]); continue
+    if m: out.append([m.group(1)]); continue
     m=re.search(r"remark: +(TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (\d+)",line)
     if m and out: out[-1].append(m.group(1).split()[0]+"="+m.group(2))
 for o in out: print(" ".join(o))'
