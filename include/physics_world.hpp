@@ -12,6 +12,7 @@
 #include <array>
 #include "mi_physics.h"
 #include "mi_constraints.h"
+#include "mi_shard.h"
 
 namespace mi_facade {
 
@@ -191,6 +192,22 @@ public:
     }
     mi_step_counts counts() { mi_step_counts c; check(mi_world_get_counts(w_, &c), "mi_world_get_counts"); return c; }
     mi_world* handle() { return w_; }
+
+    // One scene on several GPUs (include/mi_shard.h; the reference has no such path): every process builds the same scene and simulates one tile.
+    void enableSharding(const mi_shard_desc& d) { check(mi_world_shard_enable(w_, &d), "mi_world_shard_enable"); }
+    static std::array<char, 128> shardUniqueId() { std::array<char, 128> id{}; if (mi_shard_get_unique_id(id.data()) != MI_OK) throw std::runtime_error(std::string("mi_shard_get_unique_id: ") + mi_last_error()); return id; }
+    void attachRccl(const std::array<char, 128>& id) { check(mi_world_shard_attach_rccl(w_, id.data()), "mi_world_shard_attach_rccl"); }   // neighbour exchange inside step()
+    std::vector<scene_entity> ownedEntities() {            // whose read-backs are authoritative on this rank
+        uint32_t n = 0; check(mi_world_shard_owned_entities(w_, nullptr, 0, &n), "mi_world_shard_owned_entities");
+        std::vector<uint32_t> ids(n); if (n) check(mi_world_shard_owned_entities(w_, ids.data(), n, &n), "mi_world_shard_owned_entities");
+        std::vector<scene_entity> out(n); for (uint32_t i = 0; i < n; ++i) out[i].id = ids[i];
+        return out;
+    }
+    void rebalance(uint32_t bins = 256) { check(mi_world_shard_rebalance(w_, bins), "mi_world_shard_rebalance"); }   // load balance: every rank, between the same two steps
+    std::array<uint64_t, 3> globalCounts() {               // bodies, manifolds, contacts of the whole scene (one all-reduce)
+        uint32_t b = 0, m = 0, c = 0; check(mi_world_shard_counts(w_, &b, &m, &c), "mi_world_shard_counts");
+        std::array<uint64_t, 3> v{b, m, c}; check(mi_world_shard_allreduce_u64(w_, v.data(), 3), "mi_world_shard_allreduce_u64"); return v;
+    }
 
 private:
     // The reference fires its std::function callbacks inside the step (handleCollisionCallbacks, physics.cpp:1041-1178); here

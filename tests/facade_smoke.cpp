@@ -1,6 +1,7 @@
 // Compile-and-link check of include/physics_world.hpp against libmi_physics.so (run by tests/test_capi_symbols.py;
 // executing it needs a GPU, compiling/linking does not).
 #include <cstdio>
+#include <cstdlib>
 #include "physics_world.hpp"
 using namespace mi_facade;
 int main() {
@@ -38,6 +39,19 @@ int main() {
         if (begins < 1) { std::printf("facade error: no collision-begin callback fired\n"); return 1; }
         if (enters < 1) { std::printf("facade error: no trigger-enter callback fired\n"); return 1; }
         if (!(cp[63].y < 3.9f)) { std::printf("facade error: the cloth did not move\n"); return 1; }
+        if (std::getenv("MI_FACADE_SHARD")) {   // the multi-GPU surface with ONE rank (opt-in: the default run of this check stays what it was)
+            physics_world tile(0);
+            tile.addStaticCollider(trs{}, {collider_component::asAABB({-50, -4, -50}, {50, 0, 50}, mat)});
+            trs tt; tt.position = {0, 1, 0};
+            tile.addRigidBody(tt, rigid_body_component{}, {collider_component::asSphere({0, 0, 0}, 0.5f, mat)});
+            mi_shard_desc d{}; d.rank = 0; d.num_ranks = 1; d.tiles_x = d.tiles_z = 1; d.origin_x = d.origin_z = -10.f; d.tile_size_x = d.tile_size_z = 20.f; d.ghost_margin = 2.f;
+            tile.enableSharding(d);
+            tile.attachRccl(physics_world::shardUniqueId());
+            for (int i = 0; i < 30; ++i) tile.stepFixed(settings, 1.f / 120.f);
+            tile.rebalance();
+            auto g = tile.globalCounts();
+            if (tile.ownedEntities().size() != 1 || g[0] != 1) { std::printf("facade error: sharded world with one rank\n"); return 1; }
+        }
         std::printf("facade ok: a.y=%f b.y=%f contacts=%u begins=%d ends=%d\n", tr[a.id].position.y, tr[b.id].position.y, world.counts().num_contacts, begins, ends);
     } catch (const std::exception& e) {
         std::printf("facade error: %s\n", e.what());
