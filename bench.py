@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--transport", choices=["rccl", "dist"], default=os.environ.get("MI_SHARD_TRANSPORT", "rccl"),
                     help="N > 1: neighbour exchange by the library's own RCCL send/recv (default) or by torch.distributed point-to-point through host buffers")
     ap.add_argument("--rebalance-every", type=int, default=0, help="N > 1: a load-balance round (tile borders follow the body counts) every K steps of the untimed settle phase; 0 = fixed uniform tiles")
+    ap.add_argument("--pmc", action="store_true", help="N = 1: measure roofline.traffic for THIS run (two extra rocprofv3 --pmc passes of the same command: FETCH_SIZE, WRITE_SIZE) "
+                                                      "instead of scaling the committed figure of profiles/traffic.json")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-at-rest", action="store_true", help="skip the second measurement after 1500 steps")
     ap.add_argument("--cpu-grid", type=int, nargs=3, default=[32, 16, 32])
@@ -186,6 +188,10 @@ def main():
         print(json.dumps(_cpu_replica(json.loads(sys.argv[2]))))
         return
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: become the launcher of N ranks (one process per GPU, torch.distributed.run on this node) and pass
+        # their output through — rank 0 prints the ONE JSON line.  (Launched by torch.distributed.run already: WORLD_SIZE is set, this is a rank.)
+        sys.exit(_launch_ranks(args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
@@ -256,6 +262,8 @@ def main():
     if contacts_per_body < MIN_CONTACTS_PER_BODY and args.settle >= SETTLE_STEPS:
         raise SystemExit(f"bench.py: {contacts_per_body:.2f} contacts per body after {args.settle} settle steps — this is not the piled-up workload")
 
+    if world_size > 1:
+        sw.world.shard_exchange_stats(reset=True)       # (also reports a message overflow of the settle phase before anything is timed)
     elapsed, step_ms, stage_acc, contact_iters = timed_region(sw, settings, dt, args.steps, barrier)
     solve_ms = stage_acc["solve"]; total_dev_ms = stage_acc["total"]
     launches = sw.world.solve_launches() * args.steps
@@ -291,7 +299,28 @@ def main():
                    "step_frac_algorithmic": step_algorithmic_bytes(c2, args.iterations) / (e2 / n_rest) / 1e9 / HBM_PEAK_GBPS}
 
     global_counts = None
+    per_rank = None
     if dist is not None:
+        # what explains a scaling curve: every rank's own clock, solver roofline, exchange cost and what it moved (gathered on rank 0)
+        ex = sw.world.shard_exchange_stats()
+        lc = sw.world.counts()
+        l_launches = max(sw.world.solve_launches() * args.steps, 1)
+        l_solve_s = stage_acc["solve"] * 1e-3 / l_launches
+        mine = {
+            "rank": rank, "device": device, "elapsed_s": elapsed, "ms_per_step": elapsed / args.steps * 1e3, "device_ms_per_step": stage_acc["total"] / args.steps,
+            "owned_bodies": ex["owned_bodies"], "ghost_bodies": ex["ghost_bodies"], "local_contacts": lc["num_contacts"], "local_manifolds": lc["num_collisions"], "colors": lc["num_colors"],
+            "roofline": {"kernel": sw.world.solver_kernel(), "avg_launch_us": l_solve_s * 1e6,
+                         "achieved_GBps": (BYTES_PER_CONTACT_ITER * contact_iters / l_launches) / l_solve_s / 1e9 if l_solve_s > 0 else 0.0,
+                         "frac": (BYTES_PER_CONTACT_ITER * contact_iters / l_launches) / l_solve_s / 1e9 / HBM_PEAK_GBPS if l_solve_s > 0 else 0.0},
+            "exchange": {"transport": "library RCCL (ncclSend / ncclRecv + 72-byte ncclAllReduce on the world's stream)" if ex["library_transport"] else "caller's (torch.distributed via host)",
+                         "exchanges_timed": ex["exchanges"], "device_ms_per_exchange": ex["device_ms_sum"] / max(1, ex["exchanges"]),
+                         "message_bytes_per_neighbour": ex["message_bytes"], "neighbours": ex["neighbour_rank"],
+                         "records_per_exchange": [v / max(1, ex["exchanges"]) for v in ex["records_sum"]],
+                         "payload_bytes_per_exchange": [56 * v / max(1, ex["exchanges"]) for v in ex["records_sum"]]},
+        }
+        gathered = [None] * world_size
+        dist.all_gather_object(gathered, mine)
+        per_rank = gathered
         t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -311,6 +340,13 @@ def main():
         alg_per_launch = BYTES_PER_CONTACT_ITER * contact_iters / max(launches, 1)
         achieved = alg_per_launch / avg_launch_s / 1e9 if avg_launch_s > 0 else 0.0
         traffic, traffic_note = _scaled_traffic(kernel, contact_iters / max(launches, 1))
+        traffic_source = "committed constant (profiles/traffic.json) x this run's contact-sweeps" if traffic else None
+        if args.pmc and world_size == 1:
+            m, note = _measured_traffic(kernel, args)
+            if m:
+                traffic, traffic_note, traffic_source = m, note, "measured: rocprofv3 --pmc passes of this command, this run"
+            else:
+                traffic_note += f" (--pmc asked for but not measured: {note})"
         b_step = step_algorithmic_bytes(counts, args.iterations)
         roofline = {
             "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -318,7 +354,7 @@ def main():
             # what crosses the HBM interface is LESS than the algorithmic bytes (impulses stay in LDS, ~95 % of the body hand-overs in L2):
             # `frac` says how fast the algorithmic work is done, `traffic_frac` how busy the memory interface really is
             "traffic_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBPS) if traffic and avg_launch_s > 0 else None,
-            "traffic_note": traffic_note,
+            "traffic_note": traffic_note, "traffic_source": traffic_source,
             "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_step,
             "algorithmic_bytes_per_launch": alg_per_launch,
             "bound_note": ("the kernel is bound by its dependency chain (colours x sweeps serial hops), not by bytes: DESIGN.md §4"),
@@ -349,9 +385,17 @@ def main():
                        "global_counts": global_counts, "sharding": sharding_note},
             "roofline": roofline,
             "stage_ms": stage_prof, "stage_ms_note": "per-stage device times of the 3 extra steps after the timed region (stage timing enabled only there)",
-            "step_ms_median": float(np.median(step_ms)), "step_ms_p95": float(np.percentile(step_ms, 95)),
+            "step_ms_median": float(np.median(step_ms)),
+            "step_ms_p95": float(np.percentile(step_ms, 95)) if args.steps >= 50 else None,
+            "step_ms_p95_note": None if args.steps >= 50 else f"not reported: {args.steps} timed steps are too few for a 95th percentile (>= 50); step_ms_max is the slowest of them",
+            "step_ms_max": float(np.max(step_ms)),
+            "timed_ms_total": elapsed * 1e3,
             "device_ms_per_step": total_dev_ms / args.steps,
         }
+        if per_rank is not None:
+            out["per_rank"] = per_rank
+            out["per_rank_note"] = ("every rank's own wall clock over the timed steps, its solver launch against the HBM roofline, the device time of one exchange "
+                                    "(pack -> send / receive -> unpack -> axis) and the records (56 B) it sent per neighbour; value uses the slowest rank")
         if world_size > 1:
             bx, bz = sw.world.shard_get_borders(desc.tiles_x, desc.tiles_z)
             out["config"]["tile_borders"] = {"x": [float(v) for v in bx], "z": [float(v) for v in bz],
@@ -364,6 +408,55 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _launch_ranks(n):
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0"); env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           str(Path(__file__).resolve()), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
+def _measured_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` for THIS workload: two extra passes of the same command under rocprofv3 (--pmc FETCH_SIZE, then
+    --pmc WRITE_SIZE — separately, kernel-trace only, as MI355X_MICROARCH.md prescribes), mean over the kernel's last steps + 3 dispatches
+    (the timed and the profiled steps); bytes = (2 x FETCH_SIZE + WRITE_SIZE) x 1024 (gfx950: FETCH_SIZE reports half of a wide read stream)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if Path("/opt/rocm/bin/rocprofv3").exists() else None)
+    if not prof:
+        return None, "rocprofv3 not found"
+    child = [sys.executable, str(Path(__file__).resolve()), "--gpus", "1", "--steps", str(args.steps), "--warmup", str(args.warmup), "--grid", *map(str, args.grid),
+             "--iterations", str(args.iterations), "--settle", str(args.settle), "--no-cpu-baseline", "--no-at-rest"]
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([prof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "pmc", "--", *child],
+                               capture_output=True, text=True, timeout=1200, env=dict(os.environ, TMPDIR="/tmp"), cwd="/tmp")
+            files = sorted(Path(d).rglob("*_counter_collection.csv"))
+            if r.returncode != 0 or not files:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            v = []
+            with open(files[0]) as f:
+                for row in csv.DictReader(f):
+                    if row.get("Counter_Name") == counter and kernel in row["Kernel_Name"]:
+                        v.append(float(row["Counter_Value"]))
+            if not v:
+                return None, f"no {counter} samples for {kernel}"
+            n = min(len(v), args.steps + 3)
+            vals[counter] = sum(v[-n:]) / n
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    b = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
+    return b, (f"(2 x FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB + WRITE_SIZE {vals['WRITE_SIZE']:.0f} KiB) per launch, mean of the kernel's last {args.steps + 3} dispatches in two separate "
+               f"rocprofv3 --pmc passes of this command (gfx950: FETCH_SIZE reports half of a wide coalesced read stream)")
 
 
 def _scaled_traffic(kernel, contact_sweeps_per_launch):

@@ -89,6 +89,12 @@ class ShardDesc(C.Structure):
                 ("tile_size_z", C.c_float), ("tiles_x", C.c_uint32), ("tiles_z", C.c_uint32), ("ghost_margin", C.c_float), ("max_records", C.c_uint32)]
 
 
+class ShardExchangeStats(C.Structure):
+    """mi_shard_exchange_stats (include/mi_shard.h)."""
+    _fields_ = [("exchanges", C.c_uint64), ("device_ms_sum", C.c_double), ("message_bytes", C.c_uint64), ("num_neighbours", C.c_uint32), ("library_transport", C.c_uint32),
+                ("neighbour_rank", C.c_uint32 * 8), ("records_last", C.c_uint32 * 8), ("records_sum", C.c_uint64 * 8), ("owned_bodies", C.c_uint32), ("ghost_bodies", C.c_uint32)]
+
+
 SHARD_RECORD_FLOATS = 14
 
 
@@ -131,6 +137,10 @@ class Library:
         buf = np.zeros(128, np.uint8)
         self.check(self.fn("shard_get_unique_id")(_ptr(buf)), "shard_get_unique_id")
         return buf.tobytes()
+
+    def shard_library_transport_available(self):
+        """Non-collective probe: can this process use the library's RCCL transport?  (Agree on it over all ranks before anyone attaches.)"""
+        return bool(self.fn("shard_library_transport_available")()) if self.has("shard_library_transport_available") else False
 
     def shard_tile_of_rank(self, tiles_x, tiles_z, rank):
         out = C.c_uint32()
@@ -475,6 +485,26 @@ class World:
     def shard_import(self, message):
         m = np.ascontiguousarray(message, np.float32)
         self.L.check(self.L.fn("world_shard_import")(self.h, _ptr(m)), "world_shard_import")
+
+    def shard_axis_sums(self):
+        """This rank's centre statistics of the last internal step (9 uint64: S1[3], S2lo[3], S2hi[3]); summed over all ranks they give
+        the global sweep axis (include/mi_shard.h "Global sweep axis")."""
+        out = np.zeros(9, np.uint64)
+        self.L.check(self.L.fn("world_shard_axis_sums")(self.h, _ptr(out)), "world_shard_axis_sums")
+        return out
+
+    def shard_set_axis_sums(self, global_sums):
+        v = np.ascontiguousarray(global_sums, np.uint64)
+        assert len(v) == 9
+        self.L.check(self.L.fn("world_shard_set_axis_sums")(self.h, _ptr(v)), "world_shard_set_axis_sums")
+
+    def shard_exchange_stats(self, reset=False):
+        st = ShardExchangeStats()
+        self.L.check(self.L.fn("world_shard_exchange_stats")(self.h, C.byref(st), C.c_uint32(1 if reset else 0)), "world_shard_exchange_stats")
+        n = st.num_neighbours
+        return {"exchanges": st.exchanges, "device_ms_sum": st.device_ms_sum, "message_bytes": st.message_bytes, "num_neighbours": n,
+                "library_transport": bool(st.library_transport), "neighbour_rank": list(st.neighbour_rank[:n]), "records_last": list(st.records_last[:n]),
+                "records_sum": list(st.records_sum[:n]), "owned_bodies": st.owned_bodies, "ghost_bodies": st.ghost_bodies}
 
     def shard_attach_rccl(self, unique_id128):
         buf = np.frombuffer(bytes(unique_id128), np.uint8).copy()

@@ -69,6 +69,7 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numDead;              // sharded world: colliders of bodies this rank does not simulate this step (they take no part in the broad phase)
     uint32_t shardOwned[3];        // sharded world: bodies / manifolds / contacts OWNED by this rank (owner rule: the manifold's first dynamic body)
     uint32_t shardSent[8];         // sharded world: records packed for each neighbour this step (slot order of ShardParams::peers)
+    unsigned long long axisSums[9]; // centre statistics of the colliders this world counts (k_pair_finish): S1[3], S2lo[3], S2hi[3]; a sharded world's are added over the ranks
 };
 
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
@@ -109,9 +110,10 @@ __global__ __launch_bounds__(256) void k_world_colliders(
     const float4* __restrict__ hullAabb,  // [2*numHulls]
     float4* __restrict__ wShape, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax, StepScalars* sc, uint32_t axisCur,
     const uint8_t* __restrict__ bodyActive /* sharded world: 0 = body not simulated by this rank this step, or null */,
-    const uint8_t* __restrict__ bodyActivePrev /* ... and in the previous step */) {
+    const uint8_t* __restrict__ bodyActivePrev /* ... and in the previous step */,
+    const uint32_t* __restrict__ axisDev /* sharded world: the sweep axis lives on the device (k_shard_axis, from the sums over all ranks), or null */) {
     uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) { sc->axisCur = axisCur; }   // the SAP axis chosen at the end of the previous (successful) step
+    if (k == 0) { sc->axisCur = axisDev ? *axisDev : axisCur; }   // the SAP axis chosen at the end of the previous (successful) step
     if (k >= nc) return;
     uint32_t type = cTypeBody[2 * k], body = cTypeBody[2 * k + 1];
     if (bodyActive && body != kNoBody && !bodyActive[body]) {
@@ -201,45 +203,77 @@ __device__ __forceinline__ uint32_t extentBin(float ext) {
 }
 __device__ __forceinline__ float extentBinUpper(uint32_t b) { return exp2f(((float)b + 1.f - 128.f) / 8.f); }
 
-// Deterministic centre statistics for the next sorting axis: fixed butterfly per wave (double),
-// waves 0..3 added in order, block partials added sequentially by k_pair_finish.
+// Centre statistics for the next sorting axis (the reference sums centres and squared centres in float, sequentially:
+// collision_broad.cpp:376-384, 443-444).  Here the statistic must not depend on the order of the sum — nor on the PARTITION: in a sharded
+// world (include/mi_shard.h) every rank sums the colliders it owns and the sums are added over the ranks (one 72-byte all-reduce), so the
+// axis is the single world's whatever the tiling.  The centre is quantised to 1/1024 m (clamped to +-2^20 m) and q and q^2 are added as
+// INTEGERS: S1 (two's complement, 64 bits), q^2 split into its low 32 bits and the rest (S2lo, S2hi: 2^26 colliders overflow neither).
+// k_pair_finish compares n * S2 - S1^2 exactly in 128 bits.  (Mirrored by the oracle: ora::axisTerms / ora::axisFromSums.)
+constexpr uint32_t kAxisSums = 9;   // S1[3], S2lo[3], S2hi[3]
+__device__ __forceinline__ void axisTerms(float c, unsigned long long& q, unsigned long long& lo, unsigned long long& hi) {
+    const float lim = 1048576.f;
+    c = (c > -lim) ? c : -lim;   // (a NaN centre counts as -2^20, like in the oracle)
+    c = (c < lim) ? c : lim;
+    const long long qi = (long long)rintf(c * 1024.f);
+    const unsigned long long sq = (unsigned long long)(qi * qi);
+    q = (unsigned long long)qi; lo = sq & 0xFFFFFFFFull; hi = sq >> 32;
+}
+// argmax of the variance n * S2 - S1^2 per axis, exactly (128-bit integers), in the shape of collision_broad.cpp:443-444
+__host__ __device__ inline uint32_t axisFromSums(const unsigned long long s[kAxisSums], uint32_t n) {
+    unsigned __int128 var[3];
+    for (int a = 0; a < 3; ++a) {
+        const long long s1 = (long long)s[a];
+        const unsigned __int128 s2 = ((unsigned __int128)s[6 + a] << 32) + (unsigned __int128)s[3 + a];
+        const unsigned __int128 m = (unsigned __int128)(s1 < 0 ? (unsigned long long)(-s1) : (unsigned long long)s1);
+        const unsigned __int128 ns2 = (unsigned __int128)n * s2, sq = m * m;
+        var[a] = ns2 > sq ? ns2 - sq : (unsigned __int128)0;   // (>= 0 by Cauchy-Schwarz; a rank's partial sums with the global n always satisfy it too)
+    }
+    return (var[0] > var[1]) ? ((var[0] > var[2]) ? 0u : 2u) : ((var[1] > var[2]) ? 1u : 2u);
+}
+// Does this world count collider (mn, mx) in its centre statistics?  All of them — or, sharded, those of the bodies this rank OWNS plus,
+// on rank 0 only, the colliders without a rigid body (statics, triggers, force fields are replicated on every rank).
+__device__ __forceinline__ bool axisCounted(const float4& mn, const float4& mx, const uint8_t* __restrict__ bodyActive, uint32_t countUnowned) {
+    if (!bodyActive) return true;
+    const uint32_t objType = (__float_as_uint(mn.w) >> 8) & 0xFFu;
+    return objType == OBJ_RIGID_BODY ? bodyActive[__float_as_uint(mx.w)] == 1u : countUnowned != 0u;
+}
+__device__ __forceinline__ void axisAccumulate(bool counted, float cx, float cy, float cz, unsigned long long v[kAxisSums]) {
+#pragma unroll
+    for (uint32_t c = 0; c < kAxisSums; ++c) v[c] = 0ull;
+    if (!counted) return;
+    axisTerms(cx, v[0], v[3], v[6]); axisTerms(cy, v[1], v[4], v[7]); axisTerms(cz, v[2], v[5], v[8]);
+}
+// wave sums (any order: integers) -> sm[wave][9]; after a barrier thread 0 adds the four and writes the block's partial
+__device__ __forceinline__ void axisWaveReduce(unsigned long long v[kAxisSums], unsigned long long (*sm)[kAxisSums]) {
+    for (int off = 32; off >= 1; off >>= 1) {
+#pragma unroll
+        for (uint32_t c = 0; c < kAxisSums; ++c) v[c] += (unsigned long long)__shfl_down((long long)v[c], off, 64);
+    }
+    if ((threadIdx.x & 63u) == 0u) { for (uint32_t c = 0; c < kAxisSums; ++c) sm[threadIdx.x >> 6][c] = v[c]; }
+}
 __global__ __launch_bounds__(256) void k_axis_partials(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
-                                                       double* __restrict__ partials, Shards* sh) {
-    __shared__ double sm[4][6];
+                                                       unsigned long long* __restrict__ partials, Shards* sh,
+                                                       const uint8_t* __restrict__ bodyActive /* sharded world: this step's body flags, or null */, uint32_t countUnowned) {
+    __shared__ unsigned long long sm[4][kAxisSums];
     __shared__ uint32_t hist[256];
     hist[threadIdx.x] = 0;
     __syncthreads();
     uint32_t i = blockIdx.x * 256 + threadIdx.x;
-    double v[6] = {0, 0, 0, 0, 0, 0};
-    float ext = 0.f;
+    unsigned long long v[kAxisSums];
+    bool counted = false; float cx = 0.f, cy = 0.f, cz = 0.f;
     if (i < nc) {
         float4 mn = aabbMin[i], mx = aabbMax[i];
-        float cx = (mn.x + mx.x) * 0.5f, cy = (mn.y + mx.y) * 0.5f, cz = (mn.z + mx.z) * 0.5f;
-        v[0] = cx; v[1] = cy; v[2] = cz;
-        v[3] = (double)cx * (double)cx; v[4] = (double)cy * (double)cy; v[5] = (double)cz * (double)cz;
-        ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
+        cx = (mn.x + mx.x) * 0.5f; cy = (mn.y + mx.y) * 0.5f; cz = (mn.z + mx.z) * 0.5f;
+        counted = axisCounted(mn, mx, bodyActive, countUnowned);
+        const float ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
         if (!(mx.x < mn.x)) atomicAdd(&hist[extentBin(ext)], 1u);   // only steers the cell size, never results; dead colliders (sharded world) stay out: the histogram total = live colliders
     }
-    for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) v[c] += __shfl_down(v[c], off, 64);
-    }
-    uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) {
-        for (int c = 0; c < 6; ++c) sm[wv][c] = v[c];
-    }
+    axisAccumulate(counted, cx, cy, cz, v);
+    axisWaveReduce(v, sm);
     __syncthreads();
     if (hist[threadIdx.x]) atomicAdd(&sh->extentHist[blockIdx.x & (kShards - 1u)][threadIdx.x], hist[threadIdx.x]);
-    if (threadIdx.x == 0) {
-        for (int c = 0; c < 6; ++c) {
-            double a = 0.0;
-            for (int w = 0; w < 4; ++w) a += sm[w][c];
-            partials[blockIdx.x * 6 + c] = a;
-        }
-    }
+    if (threadIdx.x < kAxisSums) partials[blockIdx.x * kAxisSums + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
-// Block partials are reduced by one 256-lane workgroup with a fixed tree (mirrored by the oracle): lane t adds
-// partials t, t+256, ... in ascending order, then the wave butterfly (offsets 32..1), then waves 0..3 in order.
 // Cell size = smallest extent bin edge that leaves at most `limit` colliders above it; those few "large"
 // colliders (ground, walls, outliers) are handled by the brute-force pass.
 __global__ __launch_bounds__(256) void k_bp_threshold(uint32_t nc, const Shards* __restrict__ sh, StepScalars* sc) {
@@ -359,24 +393,24 @@ __global__ __launch_bounds__(256) void k_bp_cell_ids(uint32_t nc, const float4* 
 // k_axis_partials, k_bp_classify and k_bp_cell_ids did: centre statistics (same fixed reduction shape), extent histogram,
 // dead / large / small classification, bounds of the small centres, cell id + arrival rank.
 __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax, const GridParams* __restrict__ gp,
-                                                    double* __restrict__ partials, Shards* sh, StepScalars* sc, uint32_t* __restrict__ largeList, uint32_t* __restrict__ isLarge,
+                                                    unsigned long long* __restrict__ partials, Shards* sh, StepScalars* sc, uint32_t* __restrict__ largeList, uint32_t* __restrict__ isLarge,
                                                     int* __restrict__ blockBounds, uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks, uint32_t* __restrict__ cellCount,
-                                                    const uint8_t* __restrict__ bodyActivePrev /* sharded world: the previous step's body flags, or null */) {
-    __shared__ double sm[4][6];
+                                                    const uint8_t* __restrict__ bodyActivePrev /* sharded world: the previous step's body flags, or null */,
+                                                    const uint8_t* __restrict__ bodyActive /* sharded world: this step's body flags, or null */, uint32_t countUnowned) {
+    __shared__ unsigned long long sm[4][kAxisSums];
     __shared__ uint32_t hist[256];
     __shared__ int sb[4][6];
     hist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     const GridParams g = *gp;
-    double v[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long v[kAxisSums];
     int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
-    bool dead = false;
+    bool dead = false, counted = false; float cx = 0.f, cy = 0.f, cz = 0.f;
     if (i < nc) {
         const float4 mn = aabbMin[i], mx = aabbMax[i];
-        const float cx = (mn.x + mx.x) * 0.5f, cy = (mn.y + mx.y) * 0.5f, cz = (mn.z + mx.z) * 0.5f;
-        v[0] = cx; v[1] = cy; v[2] = cz;
-        v[3] = (double)cx * (double)cx; v[4] = (double)cy * (double)cy; v[5] = (double)cz * (double)cz;
+        cx = (mn.x + mx.x) * 0.5f; cy = (mn.y + mx.y) * 0.5f; cz = (mn.z + mx.z) * 0.5f;
+        counted = axisCounted(mn, mx, bodyActive, countUnowned);
         const float ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
         dead = mx.x < mn.x;
         if (!dead) atomicAdd(&hist[extentBin(ext)], 1u);   // only steers the NEXT step's cell size; its total = live colliders (k_pair_finish derives numDead from it:
@@ -397,19 +431,17 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
         }
         if (!stale) { keys[i] = key; ranks[i] = rank; }
     }
+    axisAccumulate(counted, cx, cy, cz, v);
+    axisWaveReduce(v, sm);
     for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) v[c] += __shfl_down(v[c], off, 64);
 #pragma unroll
         for (int a = 0; a < 3; ++a) { lo[a] = min(lo[a], __shfl_xor(lo[a], off, 64)); hi[a] = max(hi[a], __shfl_xor(hi[a], off, 64)); }
     }
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (lane == 0) { for (int c = 0; c < 6; ++c) sm[wv][c] = v[c]; for (int a = 0; a < 3; ++a) { sb[wv][a] = lo[a]; sb[wv][3 + a] = hi[a]; } }
+    if (lane == 0) { for (int a = 0; a < 3; ++a) { sb[wv][a] = lo[a]; sb[wv][3 + a] = hi[a]; } }
     __syncthreads();
     if (hist[threadIdx.x]) atomicAdd(&sh->extentHist[blockIdx.x & (kShards - 1u)][threadIdx.x], hist[threadIdx.x]);
-    if (threadIdx.x == 0) {
-        for (int c = 0; c < 6; ++c) { double a = 0.0; for (int w = 0; w < 4; ++w) a += sm[w][c]; partials[blockIdx.x * 6 + c] = a; }
-    }
+    if (threadIdx.x < kAxisSums) partials[blockIdx.x * kAxisSums + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
     if (threadIdx.x < 6) {
         int x = sb[0][threadIdx.x];
         for (int w = 1; w < 4; ++w) x = threadIdx.x < 3 ? min(x, sb[w][threadIdx.x]) : max(x, sb[w][threadIdx.x]);
@@ -716,7 +748,7 @@ __host__ __device__ __forceinline__ int gjkMode(uint32_t ta, uint32_t tb);
 __host__ __device__ __forceinline__ int gjkModeOfBucket(uint32_t bucket);
 // One workgroup after the pair pass: the sharded counters summed (k_pair_totals), the bucket offsets / GJK span / "partition needed"
 // (formerly k_pair_ranges) and — with `partials` — the next sweep axis (formerly k_axis_final): three single-workgroup launches in one.
-__global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound, uint32_t nc, uint32_t numBlocks, const double* __restrict__ partials,
+__global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound, uint32_t nc, uint32_t numBlocks, const unsigned long long* __restrict__ partials,
                                                      const int* __restrict__ blockBounds, GridParams* gridNext /* the NEXT step's grid (null: not wanted) */, uint32_t cellCapNext) {
     const uint32_t t = threadIdx.x;
     if (t < 64u) {   // wave 0
@@ -737,18 +769,16 @@ __global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ 
         if (t == 0) { sc->gjkLo = hi > lo ? lo : 0u; sc->gjkHi = hi > lo ? hi : 0u; sc->partitioned = (nonEmpty > 1u && (hi > lo || (off - largest) * 8u > off)) ? 1u : 0u; }
     }
     if (!partials) return;
-    __shared__ double sm[4][6];
-    double v[6] = {0, 0, 0, 0, 0, 0};
+    __shared__ unsigned long long sm[4][kAxisSums];
+    unsigned long long v[kAxisSums];
+#pragma unroll
+    for (uint32_t c = 0; c < kAxisSums; ++c) v[c] = 0ull;
     for (uint32_t b = t; b < numBlocks; b += 256) {
 #pragma unroll
-        for (int c = 0; c < 6; ++c) v[c] += partials[(size_t)b * 6 + c];
+        for (uint32_t c = 0; c < kAxisSums; ++c) v[c] += partials[(size_t)b * kAxisSums + c];
     }
-    for (int off = 32; off >= 1; off >>= 1) {
-#pragma unroll
-        for (int c = 0; c < 6; ++c) v[c] += __shfl_down(v[c], off, 64);
-    }
+    axisWaveReduce(v, sm);
     const uint32_t lane = t & 63, wv = t >> 6;
-    if (lane == 0) for (int c = 0; c < 6; ++c) sm[wv][c] = v[c];
     __syncthreads();
     if (gridNext) {   // k_bp_threshold + k_bp_grid_setup for the next step, from this step's extent histogram and centre bounds
         __shared__ uint32_t hist[256];
@@ -814,11 +844,9 @@ __global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ 
         }
     }
     if (t != 0) return;
-    double s6[6];
-    for (int c = 0; c < 6; ++c) { double a = 0.0; for (int w = 0; w < 4; ++w) a += sm[w][c]; s6[c] = a; }
-    double var[3];
-    for (int c = 0; c < 3; ++c) var[c] = s6[3 + c] - s6[c] * s6[c] / (double)nc;
-    sc->axisNext = (var[0] > var[1]) ? ((var[0] > var[2]) ? 0u : 2u) : ((var[1] > var[2]) ? 1u : 2u);  // collision_broad.cpp:443-444
+    unsigned long long s9[kAxisSums];
+    for (uint32_t c = 0; c < kAxisSums; ++c) { s9[c] = sm[0][c] + sm[1][c] + sm[2][c] + sm[3][c]; sc->axisSums[c] = s9[c]; }
+    sc->axisNext = axisFromSums(s9, nc);   // (sharded world: from this rank's own sums — the exchange replaces it by the axis of the sums over all ranks)
 }
 __global__ __launch_bounds__(256) void k_pair_partition(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, StepScalars* sc) {
     __shared__ uint32_t cnt[32], base[32];
@@ -2453,6 +2481,8 @@ __global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp,
         o[8] = v.x; o[9] = v.y; o[10] = v.z; o[11] = w.x; o[12] = w.y; o[13] = w.z;
     }
 }
+// The next step's sweep axis of a sharded world, from centre statistics summed over all ranks (or, before / without that sum, this rank's own)
+__global__ void k_shard_axis(const unsigned long long* __restrict__ sums9, uint32_t nc, uint32_t* __restrict__ axisDev) { if (threadIdx.x == 0 && blockIdx.x == 0) *axisDev = axisFromSums(sums9, nc); }
 __global__ void k_shard_pack_headers(uint32_t numPeers, const StepScalars* __restrict__ sc, ShardBufs out) { if (threadIdx.x < numPeers) out.p[threadIdx.x][0] = __uint_as_float(sc->shardSent[threadIdx.x]); }
 // blockIdx.y = neighbour slot (a body has one owner: the messages never touch the same body)
 __global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, ShardBufs in, uint32_t capacity, float4* __restrict__ bPos, float4* __restrict__ bRot,

@@ -158,17 +158,23 @@ struct mi_world {
         std::vector<float> nextX, nextZ; ShardParams spNext{}; bool bordersPending = false;   // ... in force after the next step's exchange
         DBuf<uint8_t> known;                     // per body: this rank's copy is current (owned in the last step, or a record arrived)
         DBuf<uint32_t> hist; DBuf<uint64_t> reduceBuf;
+        DBuf<uint32_t> axisDev; DBuf<unsigned long long> axisGlobal;   // the sweep axis of the next step lives on the device (k_shard_axis: from the centre statistics summed over all ranks, include/mi_shard.h "Global sweep axis")
+        bool axisHostCurrent = true;                 // sapAxis (host) equals *axisDev (not so after a library-transport exchange, until somebody asks)
         uint32_t capacity = 0; std::vector<uint32_t> peerRanks;
         DBuf<uint8_t> active, activePrev; bool prevValid = false, flagsSwapPending = false, stepOpen = false, flagsOfAStep = false;   // flagsOfAStep: `active` holds what the last step classified (not so right after enable / a re-upload)   // activePrev: the previous valid step's flags (k_integrate_velocities skips bodies idle in both)
-        DBuf<float> sendBuf[8], recvBuf[8];
+        DBuf<float> sendBuf[8], recvBuf[8], importBuf;   // importBuf: staging of mi_world_shard_import (a tile without neighbours has no recvBuf)
         DBuf<uint32_t> root; size_t rootJoints = ~size_t(0), rootBodies = 0;   // island root of every body (union-find over the joints), rebuilt when the scene changes
         uint32_t* sentHost = nullptr;            // pinned: the records packed per slot in the previous exchange (overflow check)
         bool sentPending = false;
+        hipEvent_t exEv[2] = {nullptr, nullptr}; bool exchangeTimed = false; double exchangeMsSum = 0.0; uint64_t exchangesTimed = 0;   // device time of the exchanges (pack -> send / receive -> unpack -> axis)
+        uint32_t sentLast[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t sentSum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         uint32_t owned[3] = {0, 0, 0};
         void* comm = nullptr;                    // ncclComm_t
         size_t messageFloats() const { return (size_t)(capacity + 1u) * kShardRecordFloats; }
     } shard;
     int shardExchange();
+    int shardCheckOverflow(bool sync);
+    int shardSyncAxis();
     void shardFillBorders(ShardParams& sp, const std::vector<float>& bx, const std::vector<float>& bz) const;
     int shardBuildRoots();
     void shardReleaseComm();
@@ -192,7 +198,7 @@ struct mi_world {
     DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cEmit;
     DBuf<float4> wShape, aabbMin, aabbMax, hullAabb, hullVerts; DBuf<uint32_t> hullRanges;
     // broad phase
-    DBuf<double> axisPartials;
+    DBuf<unsigned long long> axisPartials;
     DBuf<uint32_t> largeList, isLarge, cellKeys, cellRanks, cellKeysS, cellValsS, cellCount, cellLower;
     DBuf<int> blockBounds;
     DBuf<float4> sMin, sMax;
@@ -376,6 +382,7 @@ mi_world::~mi_world() {
     if (hsPinned) (void)hipHostFree(hsPinned);
     if (downloadStage) (void)hipHostFree(downloadStage);
     if (shard.sentHost) (void)hipHostFree(shard.sentHost);
+    for (hipEvent_t& e : shard.exEv) if (e) (void)hipEventDestroy(e);
     shardReleaseComm();
     if (graphDebug) std::fprintf(stderr, "[mi_physics] GJK bucket span of the last step (sticky bound): %u pairs\n", last.gjkSpan);
     if (graphDebug) std::fprintf(stderr, "[mi_physics] step graphs: %u replayed, %u captured, %u plain speculative steps, %llu steps in total\n", graphHits, graphCaptures, graphPlain, (unsigned long long)totalSteps);
@@ -583,7 +590,7 @@ int mi_world::upload() {
     HIP_TRY(cellCount.ensure(kMaxCells)); HIP_TRY(cellLower.ensure(kMaxCells));
     HIP_TRY(hipMemsetAsync(cellCount.p, 0, (size_t)kMaxCells * sizeof(uint32_t), stream));   // from here on every scan clears what it read
     HIP_TRY(blockBounds.ensure(6 * (size_t)divUp(std::max(nc, 1u), 256)));
-    HIP_TRY(axisPartials.ensure(6 * (size_t)divUp(std::max(nc, 1u), 256)));
+    HIP_TRY(axisPartials.ensure(kAxisSums * (size_t)divUp(std::max(nc, 1u), 256)));
     // hull geometry pool
     std::vector<float4> ha(2 * hulls.size() + 1), hv; std::vector<uint32_t> hr(2 * hulls.size() + 2);
     for (size_t h = 0; h < hulls.size(); ++h) {
@@ -948,7 +955,7 @@ enqueue_section:
     }
     if (nc) {
         L.launch(k_world_colliders, dim3(divUp(nc, B)), dim3(B), 0, st, nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
-                                                     wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis, shard.enabled ? shard.active.p : nullptr, shard.activePrev.p);
+                                                     wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis, shard.enabled ? shard.active.p : nullptr, shard.activePrev.p, shard.enabled ? shard.axisDev.p : nullptr);
         if (heightmap) {   // terrain contacts per collider, their offsets and totals (they join the pair list after the collider-pair narrow phase)
             L.launch(k_hm_contacts<false>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
             L.launch(k_hm_slow<false>, dim3(divUp(nc, 64)), dim3(64), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
@@ -968,9 +975,9 @@ enqueue_section:
         if (gridValid) {
             // the grid prepared at the end of the previous step (k_pair_finish): one fused kernel instead of five launches; the cell histogram
             // is all zero here (cleared once at upload, and every scan clears the cells it has read)
-            L.launch(k_bp_prepare, dim3(nblk), dim3(256), 0, st, nc, aabbMin.p, aabbMax.p, gridUse, axisPartials.p, shards.p, sc, largeList.p, isLarge.p, blockBounds.p, cellKeys.p, cellRanks.p, cellCount.p, shard.enabled ? shard.activePrev.p : nullptr);
+            L.launch(k_bp_prepare, dim3(nblk), dim3(256), 0, st, nc, aabbMin.p, aabbMax.p, gridUse, axisPartials.p, shards.p, sc, largeList.p, isLarge.p, blockBounds.p, cellKeys.p, cellRanks.p, cellCount.p, shard.enabled ? shard.activePrev.p : nullptr, shard.enabled ? shard.active.p : nullptr, shard.enabled && shard.desc.rank != 0u ? 0u : 1u);
         } else {
-            L.launch(k_axis_partials, dim3(nblk), dim3(256), 0, st, nc, aabbMin.p, aabbMax.p, axisPartials.p, shards.p);
+            L.launch(k_axis_partials, dim3(nblk), dim3(256), 0, st, nc, aabbMin.p, aabbMax.p, axisPartials.p, shards.p, shard.enabled ? shard.active.p : nullptr, shard.enabled && shard.desc.rank != 0u ? 0u : 1u);
             L.launch(k_bp_threshold, dim3(1), dim3(256), 0, st, nc, shards.p, sc);
             L.launch(k_bp_classify, dim3(divUp(nc, B)), dim3(B), 0, st, nc, aabbMin.p, aabbMax.p, sc, largeList.p, isLarge.p, blockBounds.p);
             L.launch(k_bp_grid_setup, dim3(1), dim3(256), 0, st, nc, nblk, cellCap, blockBounds.p, sc, gridUse);
@@ -2174,6 +2181,8 @@ MI_API int mi_world_step_profiled(mi_world* w, const mi_step_settings* s, float 
 // physicsStep (src/physics/physics.cpp:1364-1413): accumulator, <= maxPhysicsIterationsPerFrame sub-steps, pose interpolation.
 MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
     if (!w || !s) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
+    if (w->shard.enabled && !w->shard.rccl && s->fixed_frame_rate && s->max_physics_iterations_per_frame > 1u)
+        return fail(MI_ERR_INVALID_ARGUMENT, "a sharded world with the caller's transport takes ONE internal step per call (the exchange lies in between): max_physics_iterations_per_frame = 1, or mi_world_step_fixed");
     if (w->transformsFollowPhysics) { int rc = w->download(); if (rc != MI_OK) return rc; w->transformsFollowPhysics = false; }   // settle what mi_world_step_fixed left pending
     if (s->fixed_frame_rate) {
         const float fixedDt = 1.f / (float)s->frame_rate;
@@ -2275,25 +2284,45 @@ int mi_world::shardBuildRoots() {
     return MI_OK;
 }
 void mi_world::shardReleaseComm() { if (shard.comm) { if (Rccl* r = rccl()) if (r->CommDestroy) (void)r->CommDestroy(shard.comm); shard.comm = nullptr; } }
+// A neighbour message that did not fit is an error, never a silent loss: the packed record counts of the last exchange are checked as soon as
+// they are on the host — right after the exchange with the caller's transport (it synchronises anyway), and with the library transport at the
+// next exchange or whenever the caller looks at the world in between (counts, owned entities, exchange statistics, checkpoint, detach).
+int mi_world::shardCheckOverflow(bool sync) {
+    ShardState& sh = shard;
+    if (!sh.sentPending) return MI_OK;
+    if (sync) HIP_TRY(hipStreamSynchronize(stream));
+    sh.sentPending = false;
+    if (sh.exchangeTimed) { sh.exchangeMsSum += (double)elapsedMs(sh.exEv[0], sh.exEv[1]); ++sh.exchangesTimed; sh.exchangeTimed = false; }
+    for (uint32_t k = 0; k < sh.sp.numPeers; ++k) { sh.sentLast[k] = sh.sentHost[k]; sh.sentSum[k] += sh.sentHost[k]; }
+    for (uint32_t k = 0; k < sh.sp.numPeers; ++k) if (sh.sentHost[k] > sh.capacity) return fail(MI_ERR_CAPACITY, "shard message overflow: raise mi_shard_desc::max_records (equal on all ranks)");
+    return MI_OK;
+}
 int mi_world::shardExchange() {
-    const uint32_t nb = (uint32_t)bodies.size();
+    const uint32_t nb = (uint32_t)bodies.size(), nc = (uint32_t)colliders.size();
     if (!nb) return MI_OK;
     ShardState& sh = shard;
-    if (sh.sentPending) {     // the previous exchange's counts have long arrived: a message that did not fit is an error, not a silent loss
-        sh.sentPending = false;
-        for (uint32_t k = 0; k < sh.sp.numPeers; ++k) if (sh.sentHost[k] > sh.capacity) return fail(MI_ERR_CAPACITY, "shard message overflow: raise mi_shard_desc::max_records (equal on all ranks)");
-    }
+    { int rc = shardCheckOverflow(false); if (rc != MI_OK) return rc; }   // (the previous exchange's counts have long arrived: the end-of-step read-back came after them)
     hipStream_t st = stream;
     StepScalars* sc = scalarsPtr();
     ShardBufs sendBufs{}, recvBufs{};
     for (uint32_t k = 0; k < sh.sp.numPeers; ++k) { sendBufs.p[k] = sh.sendBuf[k].p; recvBufs.p[k] = sh.recvBuf[k].p; }
+    if (!sh.exEv[0]) { HIP_TRY(hipEventCreate(&sh.exEv[0])); HIP_TRY(hipEventCreate(&sh.exEv[1])); }
+    HIP_TRY(hipEventRecord(sh.exEv[0], st));
     // after a valid step the buffer sets are swapped: bPos = the new state, bPosN = the state the step started from; the record counts were cleared by k_reset_scalars
     k_shard_pack<<<divUp(nb, 256), 256, 0, st>>>(nb, sh.sp, sh.bordersPending ? sh.spNext : sh.sp, sh.bordersPending ? 1u : 0u, sh.known.p, sh.active.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bPosN.p, bRotN.p, bCogInvMass.p, sendBufs, sh.capacity, sc, sh.root.p);
     k_shard_pack_headers<<<1, 8, 0, st>>>(sh.sp.numPeers, sc, sendBufs);
     HIP_TRY(hipMemcpyAsync(sh.sentHost, &sc->shardSent[0], 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    sh.sentPending = true;
+    sh.sentPending = true; sh.exchangeTimed = true;
     if (sh.bordersPending) { sh.sp = sh.spNext; sh.bordersX = sh.nextX; sh.bordersZ = sh.nextZ; sh.bordersPending = false; }   // the next step classifies with the new borders
-    if (!sh.rccl) { HIP_TRY(hipStreamSynchronize(st)); return MI_OK; }     // caller's transport: the messages are complete when this returns
+    if (!sh.rccl) {
+        // caller's transport: until the caller hands in the centre statistics summed over all ranks (mi_world_shard_set_axis_sums), the next
+        // step's sweep axis is the one of this rank's own sums (k_pair_finish computed it: hs.axisNext, already in sapAxis)
+        k_shard_axis<<<1, 64, 0, st>>>(sc->axisSums, nc, sh.axisDev.p);
+        HIP_TRY(hipEventRecord(sh.exEv[1], st));
+        HIP_TRY(hipStreamSynchronize(st));     // the messages are complete when this returns
+        sh.axisHostCurrent = true;
+        return shardCheckOverflow(false);
+    }
     Rccl* r = rccl();
     const size_t n = sh.messageFloats();
     int e = r->GroupStart(); if (e) return fail(MI_ERR_DEVICE, "ncclGroupStart failed");
@@ -2304,7 +2333,24 @@ int mi_world::shardExchange() {
     const int e2 = r->GroupEnd();
     if (e || e2) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e ? e : e2) : "RCCL send / receive failed");
     if (sh.sp.numPeers) k_shard_unpack<<<dim3(divUp(sh.capacity, 256), sh.sp.numPeers), 256, 0, st>>>(nb, recvBufs, sh.capacity, bPos.p, bRot.p, bLinVel.p, bAngVel.p, sh.known.p);
+    // global sweep axis: the centre statistics of the colliders every rank owns, summed over all ranks (72 bytes), stay on the device
+    if (r->AllReduce) {
+        const int e3 = r->AllReduce(sc->axisSums, sh.axisGlobal.p, kAxisSums, kNcclUint64, kNcclSum, sh.comm, st);
+        if (e3) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e3) : "ncclAllReduce failed");
+        k_shard_axis<<<1, 64, 0, st>>>(sh.axisGlobal.p, nc, sh.axisDev.p);
+    } else k_shard_axis<<<1, 64, 0, st>>>(sc->axisSums, nc, sh.axisDev.p);
+    sh.axisHostCurrent = false;
+    HIP_TRY(hipEventRecord(sh.exEv[1], st));
     hostStale = true;
+    return MI_OK;
+}
+// sapAxis (host) <- the device word, when a library-transport exchange has moved it on
+int mi_world::shardSyncAxis() {
+    if (!shard.enabled || shard.axisHostCurrent || !shard.axisDev.p) return MI_OK;
+    HIP_TRY(hipSetDevice(device));
+    HIP_TRY(hipMemcpyAsync(&sapAxis, shard.axisDev.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    shard.axisHostCurrent = true;
     return MI_OK;
 }
 
@@ -2349,7 +2395,9 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
         HIP_TRY(hipMemset(sh.sendBuf[k].p, 0, sh.messageFloats() * sizeof(float))); HIP_TRY(hipMemset(sh.recvBuf[k].p, 0, sh.messageFloats() * sizeof(float)));
     }
     if (!sh.sentHost) HIP_TRY(hipHostMalloc((void**)&sh.sentHost, 8 * sizeof(uint32_t)));
-    std::memset(sh.sentHost, 0, 8 * sizeof(uint32_t)); sh.sentPending = false;
+    std::memset(sh.sentHost, 0, 8 * sizeof(uint32_t)); sh.sentPending = false; sh.exchangeTimed = false;
+    HIP_TRY(sh.axisDev.ensure(1)); HIP_TRY(sh.axisGlobal.ensure(kAxisSums)); HIP_TRY(sh.importBuf.ensure(sh.messageFloats()));
+    HIP_TRY(hipMemcpy(sh.axisDev.p, &w->sapAxis, sizeof(uint32_t), hipMemcpyHostToDevice)); sh.axisHostCurrent = true;
     sh.enabled = true;
     w->haveEstimates = false;   // the first sharded step sizes itself exactly
     return MI_OK;
@@ -2362,8 +2410,10 @@ MI_API int mi_world_shard_neighbours(mi_world* w, uint32_t* out, uint32_t* count
 }
 MI_API int mi_world_shard_counts(mi_world* w, uint32_t* bodies, uint32_t* manifolds, uint32_t* contacts) {
     if (!w || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
-    if (bodies) *bodies = w->shard.owned[0]; if (manifolds) *manifolds = w->shard.owned[1]; if (contacts) *contacts = w->shard.owned[2];
-    return MI_OK;
+    if (bodies) *bodies = w->shard.owned[0];
+    if (manifolds) *manifolds = w->shard.owned[1];
+    if (contacts) *contacts = w->shard.owned[2];
+    return w->shardCheckOverflow(true);   // (an overflow in the LAST exchange of a run is reported here at the latest)
 }
 // ---- load balance: the tile borders follow the bodies
 extern "C++" {
@@ -2487,6 +2537,7 @@ MI_API int mi_world_shard_owned_entities(mi_world* w, uint32_t* out, uint32_t ca
     const uint32_t nb = (uint32_t)w->bodies.size();
     std::vector<uint8_t> act(nb, 0);
     HIP_TRY(hipStreamSynchronize(w->stream));
+    { int rc = w->shardCheckOverflow(false); if (rc != MI_OK) return rc; }
     if (nb && w->shard.flagsOfAStep && !w->topologyDirty) HIP_TRY(hipMemcpy(act.data(), w->shard.active.p, nb, hipMemcpyDeviceToHost));   // (no step since the scene was (re)built: nothing is owned yet)
     uint32_t n = 0;
     for (uint32_t b = 0; b < nb; ++b) if (act[b] == 1u) { if (out && n < cap) out[n] = w->bodies[b].entity; ++n; }
@@ -2498,6 +2549,7 @@ MI_API int mi_shard_get_unique_id(void* out) {
     Rccl* r = rccl(); if (!r) return fail(MI_ERR_UNSUPPORTED, "librccl.so.1 not found");
     return r->GetUniqueId(out) == 0 ? MI_OK : fail(MI_ERR_DEVICE, "ncclGetUniqueId failed");
 }
+MI_API int mi_shard_library_transport_available(void) { Rccl* r = rccl(); return r && r->AllReduce && r->CommDestroy ? 1 : 0; }
 MI_API int mi_world_shard_attach_rccl(mi_world* w, const void* id) {
     if (!w || !id || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "enable sharding first");
     Rccl* r = rccl(); if (!r) return fail(MI_ERR_UNSUPPORTED, "librccl.so.1 not found");
@@ -2513,7 +2565,8 @@ MI_API int mi_world_shard_detach_rccl(mi_world* w) {
     HIP_TRY(hipSetDevice(w->device));
     HIP_TRY(hipStreamSynchronize(w->stream));
     w->shardReleaseComm(); w->shard.rccl = false;
-    return MI_OK;
+    { int rc = w->shardSyncAxis(); if (rc != MI_OK) return rc; }
+    return w->shardCheckOverflow(false);
 }
 MI_API int mi_world_shard_message_bytes(mi_world* w, uint64_t* out) {
     if (!w || !out || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
@@ -2527,16 +2580,56 @@ MI_API int mi_world_shard_export(mi_world* w, uint32_t slot, void* out) {
 }
 MI_API int mi_world_shard_import(mi_world* w, const void* msg) {
     if (!w || !msg || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    if (w->shard.rccl) return fail(MI_ERR_INVALID_ARGUMENT, "mi_world_shard_import belongs to the caller's transport; this world exchanges through the library's (mi_world_shard_detach_rccl first)");
     HIP_TRY(hipSetDevice(w->device));
     uint32_t count; std::memcpy(&count, msg, 4);
     if (count > w->shard.capacity) return fail(MI_ERR_CAPACITY, "shard message overflow: raise mi_shard_desc::max_records (equal on all ranks)");
     const uint32_t nb = (uint32_t)w->bodies.size();
-    HIP_TRY(hipMemcpyAsync(w->shard.recvBuf[0].p, msg, (size_t)(count + 1u) * kShardRecordFloats * sizeof(float), hipMemcpyHostToDevice, w->stream));
-    ShardBufs one{}; one.p[0] = w->shard.recvBuf[0].p;
+    HIP_TRY(w->shard.importBuf.ensure(w->shard.messageFloats()));   // its own staging: a tile without neighbours (1 x 1 grid) has no receive buffer
+    HIP_TRY(hipMemcpyAsync(w->shard.importBuf.p, msg, (size_t)(count + 1u) * kShardRecordFloats * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    ShardBufs one{}; one.p[0] = w->shard.importBuf.p;
     if (count) k_shard_unpack<<<dim3(divUp(count, 256), 1), 256, 0, w->stream>>>(nb, one, w->shard.capacity, w->bPos.p, w->bRot.p, w->bLinVel.p, w->bAngVel.p, w->shard.known.p);
     HIP_TRY(hipStreamSynchronize(w->stream));     // `msg` is the caller's (possibly pageable) memory
     w->hostStale = true;
     return MI_OK;
+}
+
+// Global sweep axis with the caller's transport: this rank's centre statistics of the last internal step (the colliders of the bodies it owned;
+// rank 0 also the colliders without a rigid body) — add them over all ranks and hand the sums to every rank before its next step.
+MI_API int mi_world_shard_axis_sums(mi_world* w, uint64_t* out9) {
+    if (!w || !out9 || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    for (uint32_t c = 0; c < kAxisSums; ++c) out9[c] = w->hs.axisSums[c];
+    return MI_OK;
+}
+MI_API int mi_world_shard_set_axis_sums(mi_world* w, const uint64_t* global9) {
+    if (!w || !global9 || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    if (w->shard.rccl) return fail(MI_ERR_INVALID_ARGUMENT, "with the library transport the exchange sums the statistics itself (ncclAllReduce)");
+    HIP_TRY(hipSetDevice(w->device));
+    unsigned long long s9[kAxisSums]; for (uint32_t c = 0; c < kAxisSums; ++c) s9[c] = global9[c];
+    w->sapAxis = axisFromSums(s9, (uint32_t)w->colliders.size());
+    HIP_TRY(hipMemcpyAsync(w->shard.axisDev.p, &w->sapAxis, sizeof(uint32_t), hipMemcpyHostToDevice, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    w->shard.axisHostCurrent = true;
+    return MI_OK;
+}
+// What the exchanges cost and moved (bench.py's N > 1 line): device time between the pack kernel and the end of the unpack / axis kernels.
+MI_API int mi_world_shard_exchange_stats(mi_world* w, mi_shard_exchange_stats* out, uint32_t reset) {
+    if (!w || !out || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    HIP_TRY(hipSetDevice(w->device));
+    mi_world::ShardState& sh = w->shard;
+    int rc = w->shardCheckOverflow(true);
+    std::memset(out, 0, sizeof(*out));
+    out->exchanges = sh.exchangesTimed; out->device_ms_sum = sh.exchangeMsSum; out->num_neighbours = sh.sp.numPeers;
+    out->message_bytes = (uint64_t)sh.messageFloats() * sizeof(float); out->library_transport = sh.rccl ? 1u : 0u;
+    for (uint32_t k = 0; k < sh.sp.numPeers; ++k) { out->neighbour_rank[k] = sh.peerRanks[k]; out->records_last[k] = sh.sentLast[k]; out->records_sum[k] = sh.sentSum[k]; }
+    const uint32_t nb = (uint32_t)w->bodies.size();
+    if (nb && sh.flagsOfAStep && !w->topologyDirty) {
+        std::vector<uint8_t> act(nb);
+        HIP_TRY(hipMemcpy(act.data(), sh.active.p, nb, hipMemcpyDeviceToHost));
+        for (uint8_t a : act) { out->owned_bodies += a == 1u; out->ghost_bodies += a == 2u; }
+    }
+    if (reset) { sh.exchangesTimed = 0; sh.exchangeMsSum = 0.0; for (uint64_t& v : sh.sentSum) v = 0; }
+    return rc;
 }
 
 // ---- checkpoint / resume (the solver-relevant state of a world)
@@ -2549,6 +2642,12 @@ extern "C++" {
 namespace {
 struct CheckpointHeader { uint32_t magic, version, numEntities, numBodies, numColliders, numHistory, numTriggerOverlaps, sapAxis; float timer; uint32_t eventsEnabled, jointCounts[6], reserved; };
 constexpr uint32_t kCheckpointMagic = 0x4350494Du;   // "MIPC"
+// CheckpointHeader::reserved bit 0: a SHARD SECTION follows the cloths — the blob is ONE RANK's view of a sharded world (include/mi_shard.h): which of
+// its body copies are current (a rank only trusts a copy it owned in the last step or got a record for), the tile borders in force and the pending
+// ones of a load-balance round.  Without it a restore to an earlier step would classify with the flags and borders of the LATER moment: bodies that
+// migrated in between would be owned by nobody (or by two ranks) and silently drop out.  Such a blob only loads into the same rank of the same grid.
+constexpr uint32_t kCheckpointHasShard = 1u;
+struct CheckpointShard { uint32_t numRanks, rank, tilesX, tilesZ, bordersPending, knownBytes; };
 template <class T> void put(std::vector<uint8_t>& out, const T* p, size_t n) { const uint8_t* b = reinterpret_cast<const uint8_t*>(p); out.insert(out.end(), b, b + n * sizeof(T)); }
 template <class T> bool take(const uint8_t*& p, const uint8_t* end, T* out, size_t n) { if ((size_t)(end - p) < n * sizeof(T)) return false; std::memcpy(out, p, n * sizeof(T)); p += n * sizeof(T); return true; }
 template <class JT> void putPods(std::vector<uint8_t>& out, const JT& j) { if (!j.pods.empty()) put(out, j.pods.data(), j.pods.size()); }
@@ -2559,6 +2658,7 @@ MI_API int mi_world_save_checkpoint(mi_world* w, void* out, uint64_t capacity, u
     if (!w || !out_size) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     HIP_TRY(hipSetDevice(w->device));
     int rc = w->download(); if (rc != MI_OK) return rc;
+    if (w->shard.enabled) { rc = w->shardCheckOverflow(true); if (rc != MI_OK) return rc; rc = w->shardSyncAxis(); if (rc != MI_OK) return rc; }
     std::vector<unsigned long long> keys; std::vector<uint32_t> vals;
     if (w->tabValid) {   // also with a pending topology edit: the keys are creation indices, the live world keeps the history across it
         const size_t cap = (size_t)w->tabMask[w->tabCur] + 1;
@@ -2571,6 +2671,7 @@ MI_API int mi_world_save_checkpoint(mi_world* w, void* out, uint64_t capacity, u
     h.magic = kCheckpointMagic; h.version = 1; h.numEntities = (uint32_t)w->entities.size(); h.numBodies = (uint32_t)w->bodies.size();
     h.numColliders = (uint32_t)w->colliders.size(); h.numHistory = (uint32_t)keys.size(); h.numTriggerOverlaps = (uint32_t)w->prevTriggerOverlaps.size();
     h.sapAxis = w->sapAxis; h.timer = w->timer; h.eventsEnabled = w->eventsEnabled ? 1u : 0u;
+    h.reserved = w->shard.enabled ? kCheckpointHasShard : 0u;
     const JointSet& j = w->joints;
     h.jointCounts[0] = (uint32_t)j.distance.pods.size(); h.jointCounts[1] = (uint32_t)j.ball.pods.size(); h.jointCounts[2] = (uint32_t)j.fixed.pods.size();
     h.jointCounts[3] = (uint32_t)j.hinge.pods.size(); h.jointCounts[4] = (uint32_t)j.cone.pods.size(); h.jointCounts[5] = (uint32_t)j.slider.pods.size();
@@ -2594,6 +2695,17 @@ MI_API int mi_world_save_checkpoint(mi_world* w, void* out, uint64_t capacity, u
             put(blob, buf.data(), buf.size());
             put(blob, c->restInvMass.data(), c->restInvMass.size());
         }
+    }
+    if (w->shard.enabled) {   // this rank's view: current copies, borders (download() has mirrored the device's `known` flags into the host bodies)
+        const mi_world::ShardState& sh = w->shard;
+        const uint32_t nb = (uint32_t)w->bodies.size();
+        CheckpointShard cs{sh.desc.num_ranks, sh.desc.rank, sh.desc.tiles_x, sh.desc.tiles_z, sh.bordersPending ? 1u : 0u, (nb + 3u) & ~3u};
+        put(blob, &cs, 1);
+        std::vector<uint8_t> known(cs.knownBytes, 0); for (uint32_t i = 0; i < nb; ++i) known[i] = w->bodies[i].shardKnown;
+        put(blob, known.data(), known.size());
+        const std::vector<float>& nx = sh.bordersPending ? sh.nextX : sh.bordersX; const std::vector<float>& nz = sh.bordersPending ? sh.nextZ : sh.bordersZ;
+        if (!sh.bordersX.empty()) { put(blob, sh.bordersX.data(), sh.bordersX.size()); put(blob, nx.data(), nx.size()); }
+        if (!sh.bordersZ.empty()) { put(blob, sh.bordersZ.data(), sh.bordersZ.size()); put(blob, nz.data(), nz.size()); }
     }
     *out_size = blob.size();
     if (!out) return MI_OK;
@@ -2625,6 +2737,12 @@ MI_API int mi_world_load_checkpoint(mi_world* w, const void* data, uint64_t size
             const uint64_t n = (uint64_t)c->desc.grid_size_x * c->desc.grid_size_y;
             expect += sizeof(mi_cloth_desc) + 2 * sizeof(float) + 4 * n * sizeof(float4) + (uint64_t)c->restInvMass.size() * sizeof(c->restInvMass[0]);
         }
+        const bool hasShard = (h.reserved & kCheckpointHasShard) != 0u;
+        if (h.reserved & ~kCheckpointHasShard) return fail(MI_ERR_INVALID_ARGUMENT, "not a checkpoint of this library version");
+        if (hasShard) {
+            if (!w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "the checkpoint is one rank's view of a sharded world: enable sharding (same grid, same rank) before loading it");
+            expect += sizeof(CheckpointShard) + (((uint64_t)h.numBodies + 3u) & ~3ull) + 2ull * sizeof(float) * (w->shard.bordersX.size() + w->shard.bordersZ.size());
+        }
         if (expect != size) return fail(MI_ERR_INVALID_ARGUMENT, "truncated or oversized checkpoint (size does not match its header and this scene)");
         // ---- parse into temporaries
         struct EntityState { decltype(HEntity::pos) pos; decltype(HEntity::rot) rot; };
@@ -2654,6 +2772,20 @@ MI_API int mi_world_load_checkpoint(mi_world* w, const void* data, uint64_t size
             const size_t n = (size_t)c->desc.grid_size_x * c->desc.grid_size_y;
             t.buf.resize(4 * n); t.rest.resize(c->restInvMass.size());
             if (!take(p, end, t.buf.data(), t.buf.size()) || !take(p, end, t.rest.data(), t.rest.size())) return fail(MI_ERR_INVALID_ARGUMENT, "truncated checkpoint");
+        }
+        CheckpointShard shardHdr{}; std::vector<uint8_t> known; std::vector<float> curX, nextX, curZ, nextZ;
+        if (hasShard) {
+            const mi_world::ShardState& sh = w->shard;
+            if (!take(p, end, &shardHdr, 1)) return fail(MI_ERR_INVALID_ARGUMENT, "truncated checkpoint");
+            if (shardHdr.numRanks != sh.desc.num_ranks || shardHdr.rank != sh.desc.rank || shardHdr.tilesX != sh.desc.tiles_x || shardHdr.tilesZ != sh.desc.tiles_z || shardHdr.knownBytes != ((h.numBodies + 3u) & ~3u))
+                return fail(MI_ERR_INVALID_ARGUMENT, "the checkpoint belongs to another rank or another tile grid of the sharded world");
+            known.resize(shardHdr.knownBytes); curX.resize(sh.bordersX.size()); nextX.resize(sh.bordersX.size()); curZ.resize(sh.bordersZ.size()); nextZ.resize(sh.bordersZ.size());
+            bool ok2 = take(p, end, known.data(), known.size());
+            if (!curX.empty()) ok2 = ok2 && take(p, end, curX.data(), curX.size()) && take(p, end, nextX.data(), nextX.size());
+            if (!curZ.empty()) ok2 = ok2 && take(p, end, curZ.data(), curZ.size()) && take(p, end, nextZ.data(), nextZ.size());
+            if (!ok2) return fail(MI_ERR_INVALID_ARGUMENT, "truncated checkpoint");
+            auto ascending = [](const std::vector<float>& b) { for (size_t i = 0; i < b.size(); ++i) { if (!(b[i] == b[i])) return false; if (i && !(b[i] > b[i - 1])) return false; } return true; };
+            if (!ascending(curX) || !ascending(curZ) || !ascending(nextX) || !ascending(nextZ)) return fail(MI_ERR_INVALID_ARGUMENT, "corrupt checkpoint (tile borders)");
         }
         if (p != end) return fail(MI_ERR_INVALID_ARGUMENT, "oversized checkpoint");
         // colour history table: same open-addressing layout the kernels probe (tableSlot / linear probing)
@@ -2687,6 +2819,17 @@ MI_API int mi_world_load_checkpoint(mi_world* w, const void* data, uint64_t size
         w->clothsDirty = true;
         w->timer = h.timer; w->sapAxis = h.sapAxis; w->eventsEnabled = h.eventsEnabled != 0; w->pendingEvents.clear();
         w->topologyDirty = true; w->haveEstimates = false;
+        if (w->shard.enabled) {   // the rank's view of that moment (or, from a blob of an unsharded / fully synchronised world: every copy is current)
+            mi_world::ShardState& sh = w->shard;
+            for (size_t i = 0; i < w->bodies.size(); ++i) w->bodies[i].shardKnown = hasShard ? (known[i] ? 1 : 0) : 1;
+            if (hasShard) {
+                sh.bordersX = curX; sh.bordersZ = curZ; w->shardFillBorders(sh.sp, sh.bordersX, sh.bordersZ);
+                sh.bordersPending = shardHdr.bordersPending != 0u;
+                if (sh.bordersPending) { sh.nextX = nextX; sh.nextZ = nextZ; sh.spNext = sh.sp; w->shardFillBorders(sh.spNext, sh.nextX, sh.nextZ); }
+            }
+            sh.flagsOfAStep = false; sh.prevValid = false; sh.sentPending = false; sh.exchangeTimed = false;
+            HIP_TRY(hipMemcpy(sh.axisDev.p, &w->sapAxis, sizeof(uint32_t), hipMemcpyHostToDevice)); sh.axisHostCurrent = true;
+        }
         w->tabValid = h.numHistory != 0;
         if (w->tabValid) {
             const int c = w->tabCur; w->tabMask[c] = cap - 1u;

@@ -53,25 +53,35 @@ class ShardedWorld:
         self.note = ""
         if transport == "rccl":
             # the library's own transport; if it cannot come up on ANY rank (no librccl, communicator refused) every rank falls back to
-            # the caller's transport over the process group that is already there — slower (messages via host), same results
+            # the caller's transport over the process group that is already there — slower (messages via host), same results.
+            # ncclCommInitRank blocks until EVERY rank has entered it, so the ranks first agree — with a cheap, non-collective probe and one
+            # all-reduce over the existing group — that all of them can; only then does anyone attach.
             import torch
-            failed = 0
+            dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+
+            def agree(failed):
+                flag = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                return bool(int(flag.item()))
+
+            if agree(not world.L.shard_library_transport_available()):
+                self.transport = "dist"; self.note = "library RCCL transport unavailable on some rank (librccl not found): neighbour messages go through torch.distributed"
+                return
+            failed = False
             try:
                 ident = [world.L.shard_unique_id() if rank == 0 else None]
             except Exception as e:      # noqa: BLE001
-                ident, failed, self.note = [None], 1, str(e)
+                ident, failed, self.note = [None], True, str(e)
             dist.broadcast_object_list(ident, src=0)
-            if ident[0] is None:
-                failed = 1
-            else:
-                try:
-                    world.shard_attach_rccl(ident[0])
-                    torch.cuda.synchronize()
-                except Exception as e:  # noqa: BLE001
-                    failed, self.note = 1, str(e)
-            flag = torch.tensor([failed], dtype=torch.int32, device="cuda" if dist.get_backend() == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-            if int(flag.item()):
+            if ident[0] is None:        # rank 0 could not create the id: everybody learns it from the broadcast, nobody attaches
+                self.transport = "dist"; self.note = "library RCCL transport unavailable (" + (self.note or "no unique id from rank 0") + "): neighbour messages go through torch.distributed"
+                return
+            try:
+                world.shard_attach_rccl(ident[0])
+                torch.cuda.synchronize()
+            except Exception as e:  # noqa: BLE001
+                failed, self.note = True, str(e)
+            if agree(failed):
                 if not failed:
                     world.shard_detach_rccl()
                 self.transport = "dist"
@@ -103,6 +113,10 @@ class ShardedWorld:
                 w.wait()
         for buf in inbox:
             self.world.shard_import(buf.cpu().numpy())
+        # global sweep axis: the centre statistics of the colliders every rank owns, summed over the ranks (9 integers)
+        sums = torch.from_numpy(self.world.shard_axis_sums().view(np.int64).copy()).to(dev)
+        self.dist.all_reduce(sums)
+        self.world.shard_set_axis_sums(sums.cpu().numpy().view(np.uint64))
 
     # --- load balance: move the tile borders to where the bodies are ("rebalanced every K steps by body count")
     BALANCE_BINS = 256
@@ -153,6 +167,10 @@ def step_local(ranks, settings, dt):
     for r in ranks:
         for peer in r.neighbours:
             r.world.shard_import(mail[peer][r.rank])
+    with np.errstate(over="ignore"):
+        total = np.sum([r.world.shard_axis_sums() for r in ranks], axis=0, dtype=np.uint64)   # (wrap-around addition: S1 is two's complement)
+    for r in ranks:
+        r.world.shard_set_axis_sums(total)
 
 
 def rebalance_local(ranks):

@@ -79,9 +79,36 @@ MI_API int mi_shard_balance_borders(const uint64_t* hist, uint32_t bins, float l
 MI_API int mi_world_shard_set_borders(mi_world* world, const float* borders_x /* tiles_x - 1, or null */, const float* borders_z /* tiles_z - 1, or null */);
 MI_API int mi_world_shard_get_borders(mi_world* world, float* out_borders_x, float* out_borders_z);   /* the borders in force (either may be null) */
 
+/* Global sweep axis.  The one global quantity of the pipeline is the broad phase's sweep axis (the reference: largest variance of the collider
+ * centres, src/physics/collision_broad.cpp:376-384, 443-444): it orients pairs of equal shape type, so ranks that disagreed on it would give
+ * last-bit differences from the single world even for bodies that never meet a seam.  The statistic is therefore a sum of INTEGERS (centres
+ * quantised to 1/1024 m; q and q * q, the latter in two 32-bit halves: 9 counters), which does not depend on how the colliders are partitioned:
+ * every rank sums the colliders of the bodies it OWNS (rank 0 also the colliders without a rigid body — statics, triggers, force fields are
+ * replicated), the sums are added over all ranks and every rank derives the same axis as the unsharded world.  The library transport does
+ * that inside the exchange (one 72-byte ncclAllReduce on the world's stream, the axis never leaves the device).  With the caller's transport:
+ *     mi_world_shard_axis_sums      this rank's 9 counters of the last internal step        -> sum over the ranks (the caller's all-reduce)
+ *     mi_world_shard_set_axis_sums  the global sums, on every rank, before its next step
+ * (skipped: a rank falls back to the axis of its own sums — valid, but no longer the single world's orientation of equal-type pairs). */
+MI_API int mi_world_shard_axis_sums(mi_world* world, uint64_t* out9);
+MI_API int mi_world_shard_set_axis_sums(mi_world* world, const uint64_t* global9);
+
+/* What the exchanges of this rank cost and moved (diagnostics; bench.py's N > 1 line).  device_ms_sum: time on the world's stream from the pack
+ * kernel to the end of the unpack / axis kernels (library transport: including the RCCL sends and receives), summed over `exchanges`. */
+typedef struct mi_shard_exchange_stats {
+    uint64_t exchanges; double device_ms_sum;
+    uint64_t message_bytes;               /* one neighbour message, as it travels (fixed size) */
+    uint32_t num_neighbours, library_transport;
+    uint32_t neighbour_rank[8], records_last[8]; uint64_t records_sum[8];   /* per neighbour slot: records (56 B) packed in the last exchange / since the last reset */
+    uint32_t owned_bodies, ghost_bodies;  /* of the last internal step */
+} mi_shard_exchange_stats;
+MI_API int mi_world_shard_exchange_stats(mi_world* world, mi_shard_exchange_stats* out, uint32_t reset);
+
 /* Library transport: RCCL.  out_id128 / id128: the 128 bytes of an ncclUniqueId. */
 MI_API int mi_shard_get_unique_id(void* out_id128);
 MI_API int mi_world_shard_attach_rccl(mi_world* world, const void* id128);
+/* 1 if this process can use the library transport (librccl found, all entry points resolved) — a cheap, NON-collective probe: agree on it over
+ * all ranks BEFORE any rank calls mi_world_shard_attach_rccl (ncclCommInitRank blocks until every rank has entered it). */
+MI_API int mi_shard_library_transport_available(void);
 /* Sum of `n` 64-bit counters over all ranks through the library transport: ONE ncclAllReduce on the world's stream (global body / manifold /
  * contact counts; the histograms of the load balance).  MI_ERR_UNSUPPORTED with the caller's transport (reduce them yourself). */
 MI_API int mi_world_shard_allreduce_u64(mi_world* world, uint64_t* inout, uint32_t n);
@@ -91,7 +118,12 @@ MI_API int mi_world_shard_rebalance(mi_world* world, uint32_t bins);
 /* Back to the caller's transport (destroys the communicator; e.g. when another rank could not attach). */
 MI_API int mi_world_shard_detach_rccl(mi_world* world);
 /* Caller's transport: after mi_world_step_fixed(world, ..., 1) copy the message for neighbour slot `slot` out (host memory,
- * mi_world_shard_message_bytes bytes) and hand the neighbours' messages in; both may be called in any order across slots. */
+ * mi_world_shard_message_bytes bytes) and hand the neighbours' messages in; both may be called in any order across slots.  ONE internal step per
+ * call in this mode (the exchange lies between two steps): mi_world_step_fixed(…, 1), or mi_world_step with max_physics_iterations_per_frame = 1;
+ * anything else is MI_ERR_INVALID_ARGUMENT.  mi_world_shard_import is MI_ERR_INVALID_ARGUMENT on a world attached to the library transport.
+ * Overflow: a message that did not fit is MI_ERR_CAPACITY from the step that packed it (caller's transport) or — library transport, which does
+ * not wait for the counts — from the next step, mi_world_shard_counts, mi_world_shard_owned_entities, mi_world_shard_exchange_stats,
+ * mi_world_save_checkpoint or mi_world_shard_detach_rccl, whichever comes first: call one of them after the last step of a run. */
 MI_API int mi_world_shard_message_bytes(mi_world* world, uint64_t* out_bytes);
 MI_API int mi_world_shard_export(mi_world* world, uint32_t slot, void* out_message);
 MI_API int mi_world_shard_import(mi_world* world, const void* message);

@@ -99,6 +99,15 @@ int jointsLoadPods(World& w, const uint8_t*& p, const uint8_t* end, const uint32
     return okay ? MI_OK : MI_ERR_INVALID_ARGUMENT;
 }
 
+void jointsSavePods(const World& w, std::vector<uint8_t>& out, uint32_t counts[6]) {
+    const JointStore& j = *w.joints;
+    auto save = [&](const auto& list, uint32_t& n) {
+        n = (uint32_t)list.pods.size();
+        if (n) { const uint8_t* b = reinterpret_cast<const uint8_t*>(list.pods.data()); out.insert(out.end(), b, b + list.pods.size() * sizeof(list.pods[0])); }
+    };
+    save(j.distance, counts[0]); save(j.ball, counts[1]); save(j.fixed, counts[2]); save(j.hinge, counts[3]); save(j.cone, counts[4]); save(j.slider, counts[5]);
+}
+
 static inline vec3 v3(const float* f) { return vec3(f[0], f[1], f[2]); }
 static inline quat q4(const float* f) { return quat(f[0], f[1], f[2], f[3]); }
 static inline void st3(float* f, vec3 v) { f[0] = v.x; f[1] = v.y; f[2] = v.z; }

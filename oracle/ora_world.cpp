@@ -375,45 +375,46 @@ static void broadphaseReference(World& w) {
     w.sortingAxis = (variance.x > variance.y) ? ((variance.x > variance.z) ? 0 : 2) : ((variance.y > variance.z) ? 1 : 2);
 }
 
-// Deterministic variance reduction used by the canonical schedule (same tree on the GPU):
-// blocks of 256 colliders; within a block, 4 wave-sums of 64 by a butterfly (offsets 32..1) in
-// double, added wave 0..3; the block partials are then reduced by the same 256-lane tree: lane t
-// adds partials t, t+256, t+512, ... in ascending order, followed by the wave butterfly and the
-// in-order sum of the 4 waves.
-static void canonicalAxisSums(const std::vector<AABB>& aabbs, double s[3], double s2[3]) {
-    uint32_t n = (uint32_t)aabbs.size();
-    std::vector<double> part[6];
-    for (uint32_t base = 0; base < n; base += 256) {
-        double bs[3] = {0, 0, 0}, bs2[3] = {0, 0, 0};
-        for (uint32_t wv = 0; wv < 4; ++wv) {
-            double l[64][3], l2[64][3];
-            for (uint32_t lane = 0; lane < 64; ++lane) {
-                uint32_t i = base + wv * 64 + lane;
-                for (int c = 0; c < 3; ++c) {
-                    if (i < n) {
-                        float ctr = (aabbs[i].mn[c] + aabbs[i].mx[c]) * 0.5f;
-                        l[lane][c] = (double)ctr; l2[lane][c] = (double)ctr * (double)ctr;
-                    } else { l[lane][c] = 0.0; l2[lane][c] = 0.0; }
-                }
-            }
-            for (uint32_t off = 32; off >= 1; off >>= 1)
-                for (uint32_t lane = 0; lane < off; ++lane)
-                    for (int c = 0; c < 3; ++c) { l[lane][c] += l[lane + off][c]; l2[lane][c] += l2[lane + off][c]; }
-            for (int c = 0; c < 3; ++c) { bs[c] += l[0][c]; bs2[c] += l2[0][c]; }
-        }
-        for (int c = 0; c < 3; ++c) { part[c].push_back(bs[c]); part[3 + c].push_back(bs2[c]); }
+// Centre statistics of the canonical schedule's next sweep axis (same integers on the GPU: k_bp_prepare / k_pair_finish).
+// The reference sums centres and squared centres in float, sequentially (collision_broad.cpp:376-384, 443-444); a parallel machine
+// needs a statistic whose value does not depend on the order — or on the PARTITION: in a sharded world (include/mi_shard.h) every
+// rank sums the colliders it owns and the sums are added over the ranks.  So the centre is quantised to 1/1024 m (clamped to
+// +-2^20 m) and q, q^2 are added as INTEGERS: S1 (two's complement in 64 bits), q^2 split into its low 32 bits and the rest
+// (S2lo, S2hi; 2^26 colliders cannot overflow either).  Variance order = order of n * S2 - S1^2, compared exactly in 128 bits.
+void axisTerms(float c, uint64_t out[3]) {
+    const float lim = 1048576.f;
+    c = (c > -lim) ? c : -lim;          // (a NaN centre counts as -2^20 on both sides)
+    c = (c < lim) ? c : lim;
+    const long long q = (long long)rintf(c * 1024.f);
+    const uint64_t sq = (uint64_t)(q * q);
+    out[0] = (uint64_t)q; out[1] = sq & 0xFFFFFFFFull; out[2] = sq >> 32;
+}
+uint32_t axisFromSums(const uint64_t s[9], uint32_t n) {
+    unsigned __int128 var[3];
+    for (int a = 0; a < 3; ++a) {
+        const long long s1 = (long long)s[a];
+        const unsigned __int128 s2 = ((unsigned __int128)s[6 + a] << 32) + (unsigned __int128)s[3 + a];
+        const unsigned __int128 m = (unsigned __int128)(s1 < 0 ? (unsigned long long)(-s1) : (unsigned long long)s1);
+        const unsigned __int128 ns2 = (unsigned __int128)n * s2, sq = m * m;
+        var[a] = ns2 > sq ? ns2 - sq : 0;     // (>= 0 by Cauchy-Schwarz; a partial, unreduced set of sums may violate it)
     }
-    for (int c = 0; c < 6; ++c) {
-        double l[256];
-        for (uint32_t t = 0; t < 256; ++t) { l[t] = 0.0; for (size_t b = t; b < part[c].size(); b += 256) l[t] += part[c][b]; }
-        double tot = 0.0;
-        for (uint32_t wv = 0; wv < 4; ++wv) {
-            double* x = l + wv * 64;
-            for (uint32_t off = 32; off >= 1; off >>= 1)
-                for (uint32_t lane = 0; lane < off; ++lane) x[lane] += x[lane + off];
-            tot += x[0];
+    return (var[0] > var[1]) ? ((var[0] > var[2]) ? 0u : 2u) : ((var[1] > var[2]) ? 1u : 2u);   // shape of collision_broad.cpp:443-444
+}
+// Which colliders a world counts: all of them — or, sharded, those of the bodies it OWNS plus (rank 0 only) the colliders without a
+// rigid body (statics, triggers, force fields: replicated on every rank), so that the sum over the ranks counts every collider once.
+static void canonicalAxisSums(const World& w, uint64_t s[9]) {
+    for (int c = 0; c < 9; ++c) s[c] = 0;
+    const uint32_t n = (uint32_t)w.aabbs.size();
+    for (uint32_t i = 0; i < n; ++i) {
+        if (w.shard.enabled) {
+            const WorldCollider& col = w.wc[i];
+            const bool counted = col.objectType == MI_OBJECT_RIGID_BODY ? w.shard.active[col.objectIndex] == 1 : w.shard.desc.rank == 0;
+            if (!counted) continue;
         }
-        if (c < 3) s[c] = tot; else s2[c - 3] = tot;
+        for (int c = 0; c < 3; ++c) {
+            uint64_t t[3]; axisTerms((w.aabbs[i].mn[c] + w.aabbs[i].mx[c]) * 0.5f, t);
+            s[c] += t[0]; s[3 + c] += t[1]; s[6 + c] += t[2];
+        }
     }
 }
 
@@ -435,11 +436,9 @@ static void broadphaseCanonical(World& w) {
             if (aabbVsAABB(a, b)) w.bpPairs.push_back(Pair{order[i], order[j]});
         }
     }
-    double s[3], s2[3];
-    canonicalAxisSums(w.aabbs, s, s2);
-    double var[3];
-    for (int c = 0; c < 3; ++c) var[c] = s2[c] - s[c] * s[c] / (double)nc;
-    w.sortingAxis = (var[0] > var[1]) ? ((var[0] > var[2]) ? 0 : 2) : ((var[1] > var[2]) ? 1 : 2);
+    // the next sweep axis.  Sharded: from this rank's own sums until the caller hands in the sums over all ranks (ora_world_shard_set_axis_sums)
+    canonicalAxisSums(w, w.axisSums);
+    w.sortingAxis = axisFromSums(w.axisSums, nc);
 }
 
 // ---------------------------------------------------------------- narrow phase driver
@@ -1381,6 +1380,50 @@ struct CheckpointHeader { uint32_t magic, version, numEntities, numBodies, numCo
 template <class T> bool take(const uint8_t*& p, const uint8_t* end, T* out, size_t n) { if ((size_t)(end - p) < n * sizeof(T)) return false; std::memcpy(out, p, n * sizeof(T)); p += n * sizeof(T); return true; }
 }
 }
+// The product's checkpoint format (csrc/world.hip "checkpoint / resume"), written from the oracle's state: lets the CPU tests save, run on,
+// restore and compare without a GPU — also rank by rank in a sharded world (shard section) — and hand oracle states to the product.
+MI_API int ora_world_save_checkpoint(World* w, void* out, uint64_t capacity, uint64_t* out_size) {
+    if (!w || !out_size) return MI_ERR_INVALID_ARGUMENT;
+    if (!w->cloths.empty()) return MI_ERR_UNSUPPORTED;
+    if (w->dirtyProps) w->recalculateProperties();
+    std::vector<uint8_t> blob;
+    auto put = [&](const void* p, size_t n) { const uint8_t* b = static_cast<const uint8_t*>(p); blob.insert(blob.end(), b, b + n); };
+    CheckpointHeader h{};
+    h.magic = 0x4350494Du; h.version = 1; h.numEntities = (uint32_t)w->entities.size(); h.numBodies = (uint32_t)w->bodies.size(); h.numColliders = (uint32_t)w->colliders.size();
+    h.numHistory = (uint32_t)w->prevPairColor.size(); h.numTriggerOverlaps = (uint32_t)w->prevTriggerOverlaps.size();
+    h.sapAxis = w->sortingAxis; h.timer = w->timer; h.eventsEnabled = w->eventsEnabled ? 1u : 0u; h.reserved = w->shard.enabled ? 1u : 0u;
+    std::vector<uint8_t> pods; ora::jointsSavePods(*w, pods, h.jointCounts);
+    put(&h, sizeof(h));
+    for (const Entity& e : w->entities) { const float v[7] = {e.position.x, e.position.y, e.position.z, e.rotation.x, e.rotation.y, e.rotation.z, e.rotation.w}; put(v, sizeof(v)); }
+    for (const RigidBody& b : w->bodies) {
+        const float v[28] = {b.p0.x, b.p0.y, b.p0.z, b.r0.x, b.r0.y, b.r0.z, b.r0.w, b.p1.x, b.p1.y, b.p1.z, b.r1.x, b.r1.y, b.r1.z, b.r1.w,
+                             b.linearVelocity.x, b.linearVelocity.y, b.linearVelocity.z, b.angularVelocity.x, b.angularVelocity.y, b.angularVelocity.z,
+                             b.forceAccumulator.x, b.forceAccumulator.y, b.forceAccumulator.z, b.torqueAccumulator.x, b.torqueAccumulator.y, b.torqueAccumulator.z, 0.f, 0.f};
+        put(v, 26 * sizeof(float));
+    }
+    std::vector<std::pair<uint64_t, uint32_t>> hist(w->prevPairColor.begin(), w->prevPairColor.end());
+    std::sort(hist.begin(), hist.end());
+    for (const auto& kv : hist) { const unsigned long long k = kv.first + 1ull; put(&k, sizeof(k)); }   // the device table stores key + 1 (0 = empty slot)
+    for (const auto& kv : hist) put(&kv.second, sizeof(uint32_t));
+    if (!w->prevTriggerOverlaps.empty()) put(w->prevTriggerOverlaps.data(), w->prevTriggerOverlaps.size() * sizeof(uint64_t));
+    if (!pods.empty()) put(pods.data(), pods.size());
+    const uint32_t numCloths = 0; put(&numCloths, sizeof(numCloths));
+    if (w->shard.enabled) {
+        const World::Shard& sh = w->shard; const uint32_t nb = (uint32_t)w->bodies.size();
+        const uint32_t hdr[6] = {sh.desc.num_ranks, sh.desc.rank, sh.desc.tiles_x, sh.desc.tiles_z, sh.bordersPending ? 1u : 0u, (nb + 3u) & ~3u};
+        put(hdr, sizeof(hdr));
+        std::vector<uint8_t> known(hdr[5], 0); for (uint32_t i = 0; i < nb; ++i) known[i] = w->bodies[i].shardKnown;
+        put(known.data(), known.size());
+        const std::vector<float>& nx = sh.bordersPending ? sh.nextX : sh.bordersX; const std::vector<float>& nz = sh.bordersPending ? sh.nextZ : sh.bordersZ;
+        if (!sh.bordersX.empty()) { put(sh.bordersX.data(), sh.bordersX.size() * sizeof(float)); put(nx.data(), nx.size() * sizeof(float)); }
+        if (!sh.bordersZ.empty()) { put(sh.bordersZ.data(), sh.bordersZ.size() * sizeof(float)); put(nz.data(), nz.size() * sizeof(float)); }
+    }
+    *out_size = blob.size();
+    if (!out) return MI_OK;
+    if (capacity < blob.size()) return MI_ERR_CAPACITY;
+    std::memcpy(out, blob.data(), blob.size());
+    return MI_OK;
+}
 MI_API int ora_world_load_checkpoint(World* w, const void* data, uint64_t size) {
     if (!w || !data) return MI_ERR_INVALID_ARGUMENT;
     const uint8_t* p = static_cast<const uint8_t*>(data); const uint8_t* end = p + size;
@@ -1408,7 +1451,26 @@ MI_API int ora_world_load_checkpoint(World* w, const void* data, uint64_t size) 
     uint32_t numCloths = 0;
     if (!take(p, end, &numCloths, 1)) return MI_ERR_INVALID_ARGUMENT;
     if (numCloths != 0 || !w->cloths.empty()) return MI_ERR_UNSUPPORTED;
+    // shard section (header.reserved bit 0): one RANK's view of a sharded world — which body copies are current, the tile borders in force / pending
+    struct CheckpointShard { uint32_t numRanks, rank, tilesX, tilesZ, bordersPending, knownBytes; } sh{};
+    std::vector<uint8_t> known; std::vector<float> curX, nextX, curZ, nextZ;
+    const bool hasShard = (h.reserved & 1u) != 0u;
+    if (h.reserved & ~1u) return MI_ERR_INVALID_ARGUMENT;
+    if (hasShard) {
+        if (!w->shard.enabled || !take(p, end, &sh, 1)) return MI_ERR_INVALID_ARGUMENT;
+        const mi_shard_desc& d = w->shard.desc;
+        if (sh.numRanks != d.num_ranks || sh.rank != d.rank || sh.tilesX != d.tiles_x || sh.tilesZ != d.tiles_z || sh.knownBytes != ((h.numBodies + 3u) & ~3u)) return MI_ERR_INVALID_ARGUMENT;
+        known.resize(sh.knownBytes); curX.resize(w->shard.bordersX.size()); nextX.resize(curX.size()); curZ.resize(w->shard.bordersZ.size()); nextZ.resize(curZ.size());
+        bool ok2 = take(p, end, known.data(), known.size());
+        if (!curX.empty()) ok2 = ok2 && take(p, end, curX.data(), curX.size()) && take(p, end, nextX.data(), nextX.size());
+        if (!curZ.empty()) ok2 = ok2 && take(p, end, curZ.data(), curZ.size()) && take(p, end, nextZ.data(), nextZ.size());
+        if (!ok2) return MI_ERR_INVALID_ARGUMENT;
+    }
     if (p != end) return MI_ERR_INVALID_ARGUMENT;
+    if (w->shard.enabled) {
+        for (size_t i = 0; i < w->bodies.size(); ++i) w->bodies[i].shardKnown = hasShard ? (known[i] ? 1 : 0) : 1;
+        if (hasShard) { w->shard.bordersX = curX; w->shard.bordersZ = curZ; w->shard.bordersPending = sh.bordersPending != 0u; if (w->shard.bordersPending) { w->shard.nextX = nextX; w->shard.nextZ = nextZ; } }
+    }
     w->timer = h.timer; w->sortingAxis = h.sapAxis; w->eventsEnabled = h.eventsEnabled != 0; w->events.clear();
     w->prevTriggerOverlaps.assign(overlaps.begin(), overlaps.end());
     w->prevPairColor.clear(); w->prevCollisionKeys.clear();
@@ -1552,6 +1614,17 @@ MI_API int ora_world_shard_import(World* w, const void* msg) {
     }
     return MI_OK;
 }
+// Global sweep axis of a sharded world: every rank's sums (the colliders it owns; rank 0 also the ones without a rigid body) added over
+// the ranks by the caller, handed back to every rank — the axis of the next step is then the single world's, whatever the tiling.
+MI_API int ora_world_shard_axis_sums(World* w, uint64_t* out9) {
+    if (!w || !out9 || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
+    std::memcpy(out9, w->axisSums, sizeof(w->axisSums)); return MI_OK;
+}
+MI_API int ora_world_shard_set_axis_sums(World* w, const uint64_t* global9) {
+    if (!w || !global9 || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
+    w->sortingAxis = ora::axisFromSums(global9, (uint32_t)w->colliders.size()); return MI_OK;
+}
+MI_API uint32_t ora_axis_from_sums(const uint64_t* sums9, uint32_t numColliders) { return ora::axisFromSums(sums9, numColliders); }
 MI_API float ora_det_atan2f(float y, float x) { return det_atan2f(y, x); }
 MI_API float ora_det_acosf(float x) { return det_acosf(x); }
 MI_API float ora_det_sinf(float x) { return det_sinf(x); }

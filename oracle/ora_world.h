@@ -140,6 +140,7 @@ struct World {
     std::vector<SapEndpoint> endpoints;
     std::vector<uint32_t> startEndpoint, endEndpoint;  // per collider (creation index)
     uint32_t sortingAxis = 0;
+    uint64_t axisSums[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // canonical mode: centre statistics of the last step (S1[3], S2lo[3], S2hi[3]) of the colliders this world counts
 
     int orderMode = 0;     // 0 = reference order (SAP sweep order, sequential PGS); 1 = canonical (GPU schedule replayed sequentially)
     bool dirtyProps = true;
@@ -220,8 +221,11 @@ void jointsSolveIteration(World& w);
 uint32_t jointsCount(const World& w);
 void jointsRemapBody(World& w, uint32_t from, uint32_t to);
 void jointsIslandRoots(const World& w, std::vector<uint32_t>& root);   // union-find over the joints' body pairs
-int jointsLoadPods(World& w, const uint8_t*& p, const uint8_t* end, const uint32_t counts[6]);   // checkpoint: PODs of all six types in pool order
+int jointsLoadPods(World& w, const uint8_t*& p, const uint8_t* end, const uint32_t counts[6]);
+void jointsSavePods(const World& w, std::vector<uint8_t>& out, uint32_t counts[6]);                 // ... appended to `out`, their numbers to `counts`   // checkpoint: PODs of all six types in pool order
 
+void axisTerms(float centre, uint64_t out[3]);                 // canonical sweep-axis statistic: one centre coordinate -> (q, low 32 bits of q^2, the rest)
+uint32_t axisFromSums(const uint64_t sums[9], uint32_t numColliders);
 uint32_t hash32(uint32_t m);  // joint colouring priority
 uint64_t pairPriority(uint32_t a, uint32_t b);  // contact-manifold colouring priority
 

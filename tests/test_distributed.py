@@ -293,6 +293,7 @@ def test_gpu_sharding_scenarios_on_the_oracle(oracle_mod):
     G.test_gpu_rank_never_trusts_a_copy_that_is_not_current(lib)
     G.test_gpu_rebalanced_ranks_match_oracle(lib, oracle_mod, 3, 1, lambda: scenes.ragdolls(8, 2), 3.5)      # islands move whole
     G.test_gpu_cloth_in_a_sharded_world(lib)
+    G.test_gpu_sharded_checkpoint_restores_every_ranks_view(lib, oracle_mod)
 
 
 def test_border_changes_are_validated(oracle_mod):
@@ -321,3 +322,92 @@ def test_border_changes_are_validated(oracle_mod):
         out = L.shard_balance_borders(hist, 0.0, 64.0, 4, out, 1.0)
     assert np.array_equal(out, np.asarray([52.0, 56.0, 60.0], np.float32)), out     # ... and the rounds converge to equal counts
     assert np.array_equal(L.shard_balance_borders(np.zeros(64, np.uint64), 0.0, 64.0, 4, cur, 1.0), cur)
+
+
+def test_global_sweep_axis_does_not_depend_on_the_tiling(oracle_mod):
+    """The one global quantity of the pipeline (include/mi_shard.h "Global sweep axis").  The centre statistics are sums of integers, every rank
+    sums the colliders it owns (rank 0 also the colliders without a rigid body), and the sums over the ranks are the single world's EXACTLY, as
+    9 integers, every step — so every rank sweeps along the single world's axis whatever the tiling, and independent islands (ragdolls that
+    touch the ground, not each other) give the single world's result bit for bit under ANY tiling: four x slabs, 2 x 2 tiles."""
+    sc = scenes.ragdolls(8, 2, spacing=4.0)
+    s = sc.settings(); ids = np.arange(sc.num_bodies, dtype=np.uint32)
+    for num_ranks, tiles_z in ((4, 1), (4, 2)):
+        ranks, _ = _virtual_ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), sc, num_ranks, tiles_z, margin=3.5)
+        plain = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+        one = sharding.ShardedWorld(sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)), sharding.tile_grid(sc, 1), 0, "local")   # one tile: the single world, with the shard API
+        for i in range(100):
+            sharding.step_local(ranks, s, sc.dt); sharding.step_local([one], s, sc.dt); plain.step_fixed(s, sc.dt, 1)
+            with np.errstate(over="ignore"):
+                total = np.sum([r.world.shard_axis_sums() for r in ranks], axis=0, dtype=np.uint64)
+            assert np.array_equal(total, one.world.shard_axis_sums()), f"{num_ranks} ranks, step {i}: the statistic depends on the partition"
+            assert {r.world.counts()["sorting_axis"] for r in ranks} == {plain.counts()["sorting_axis"]}, f"step {i}"
+            assert sharding.gather_owned(ranks, sc.num_bodies).tobytes() == plain.get_body_states(ids).tobytes(), f"{num_ranks} ranks ({tiles_z} along z), step {i}"
+        assert one.world.get_body_states(ids).tobytes() == plain.get_body_states(ids).tobytes()
+        assert plain.counts()["num_contacts"] > 100
+
+
+def test_axis_statistic_known_answers(oracle_mod):
+    """ora::axisFromSums / axisTerms (the product's axisFromSums / axisTerms): variance order of quantised centres, exact in 128 bits."""
+    import ctypes as C
+    f = oracle_mod.library().fn("axis_from_sums", restype=C.c_uint32)
+
+    def axis(points):
+        p = np.asarray(points, np.float64)
+        q = np.rint(np.clip(p, -1048576.0, 1048576.0) * 1024.0).astype(np.int64)
+        s1 = q.sum(axis=0); sq = (q.astype(object) ** 2)
+        lo = np.asarray([int(sum(int(v) & 0xFFFFFFFF for v in sq[:, c])) for c in range(3)], dtype=object)
+        hi = np.asarray([int(sum(int(v) >> 32 for v in sq[:, c])) for c in range(3)], dtype=object)
+        sums = np.asarray([int(v) & 0xFFFFFFFFFFFFFFFF for v in s1] + [int(v) for v in lo] + [int(v) for v in hi], dtype=np.uint64)
+        var = [len(p) * (int(hi[c]) * 2 ** 32 + int(lo[c])) - int(s1[c]) ** 2 for c in range(3)]
+        expect = (0 if var[0] > var[2] else 2) if var[0] > var[1] else (1 if var[1] > var[2] else 2)
+        got = f(sums.ctypes.data_as(C.c_void_p), C.c_uint32(len(p)))
+        assert got == expect, (points, var)
+        return got
+    assert axis([(0, 0, 0), (10, 1, 2)]) == 0
+    assert axis([(0, 0, 0), (1, 10, 2)]) == 1
+    assert axis([(0, 0, 0), (1, 2, 10)]) == 2
+    assert axis([(1, 1, 1), (2, 2, 2)]) == 2                      # all equal: the reference's comparison chain ends at z
+    assert axis([(-5e5, 0, 0), (5e5, 1, 1)] * 1000) == 0           # large coordinates, many colliders: no overflow
+    assert axis([(3e6, 0, 0), (-3e6, 0.5, 0.25)]) == 0             # clamped to +-2^20 m
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        axis(rng.normal(0, rng.uniform(0.1, 1e4, 3), (rng.integers(1, 200), 3)))
+
+
+def test_sharded_checkpoint_restores_every_ranks_view(oracle_mod):
+    """A checkpoint of a sharded world is ONE RANK's view: which of its body copies are current, the tile borders in force and the pending ones.
+    Save on every rank, run on through a load-balance round and migrations, restore, run again: the same states, bit for bit — and every body
+    keeps exactly one owner right after the restore.  (Before the shard section existed, a restore classified with the flags and borders of the
+    LATER moment: bodies that had changed rank in between were owned by nobody, or twice, and dropped out of the simulation.)"""
+    sc = scenes.obb_pile(16, 3, 8, spacing=1.0)
+    desc = _grid(sc, "lopsided", 3, 1)
+    ranks = [sharding.ShardedWorld(sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)), desc, r, "local") for r in range(3)]
+    s = sc.settings()
+
+    def run(n, start):
+        owned = []
+        for i in range(start, start + n):
+            sharding.step_local(ranks, s, sc.dt)
+            owned.append([r.world.shard_counts()["owned_bodies"] for r in ranks])
+            assert sum(owned[-1]) == sc.num_bodies, f"step {i}: {owned[-1]}"
+            if i % REBALANCE_EVERY == REBALANCE_EVERY - 1:
+                sharding.rebalance_local(ranks)
+        return owned
+    run(12, 0)                                                   # borders have moved once (after step 7, in force from step 9)
+    sharding.rebalance_local(ranks)                              # ... and a change is PENDING at the moment of the save
+    blobs = [r.world.save_checkpoint() for r in ranks]
+    borders_at_save = [r.world.shard_get_borders(3, 1)[0].copy() for r in ranks]
+    owned_a = run(28, 12)
+    final_a = sharding.gather_owned(ranks, sc.num_bodies)
+    assert any(not np.array_equal(r.world.shard_get_borders(3, 1)[0], b) for r, b in zip(ranks, borders_at_save)), "the borders moved on after the save"
+    for r, blob in zip(ranks, blobs):
+        r.world.load_checkpoint(blob)
+    assert all(np.array_equal(r.world.shard_get_borders(3, 1)[0], b) for r, b in zip(ranks, borders_at_save))
+    owned_b = run(28, 12)
+    assert owned_a == owned_b
+    assert sharding.gather_owned(ranks, sc.num_bodies).tobytes() == final_a.tobytes()
+    # a blob of another rank, or a rank's blob in an unsharded world, is refused
+    with pytest.raises(capi.PhysicsError):
+        ranks[0].world.load_checkpoint(blobs[1])
+    with pytest.raises(capi.PhysicsError):
+        sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)).load_checkpoint(blobs[0])

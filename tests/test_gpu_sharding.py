@@ -194,3 +194,164 @@ def test_gpu_library_rccl_transport_comes_up(mi_lib):
     with pytest.raises(capi.PhysicsError):
         w.shard_rebalance(64)                                         # caller's transport: the caller reduces the histograms
     w.close()
+
+
+def test_gpu_global_sweep_axis_and_independent_islands_under_any_tiling(mi_lib, oracle_mod):
+    """include/mi_shard.h "Global sweep axis": the 9 integer centre statistics summed over the ranks equal the single world's exactly, so all
+    ranks sweep along the single world's axis and independent islands (cfg4: ragdolls on the ground; cfg5: vehicles on hull tiles, whose
+    gear-tooth and wheel pairs are of EQUAL shape type — the pairs the axis orients) give the single world's result bit for bit, whatever the
+    tiling.  GPU ranks, the GPU single world and the oracle's ranks all agree."""
+    for sc, grids, margin, steps in ((scenes.ragdolls(8, 2, spacing=4.0), ((4, 1), (4, 2)), 3.5, 80), (scenes.vehicles(4, 2), ((2, 1), (4, 2)), 6.0, 60)):
+        s = sc.settings(); ids = np.arange(sc.num_bodies, dtype=np.uint32)
+        for num_ranks, tiles_z in grids:
+            g = _ranks(lambda: mi_lib.create_world(0), sc, num_ranks, tiles_z, margin)
+            o = _ranks(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), sc, num_ranks, tiles_z, margin)
+            plain = sc.populate(mi_lib.create_world(0))
+            one = sharding.ShardedWorld(sc.populate(mi_lib.create_world(0)), sharding.tile_grid(sc, 1), 0, "local")
+            for i in range(steps):
+                sharding.step_local(g, s, sc.dt); sharding.step_local(o, s, sc.dt); sharding.step_local([one], s, sc.dt); plain.step_fixed(s, sc.dt, 1)
+                with np.errstate(over="ignore"):
+                    total = np.sum([r.world.shard_axis_sums() for r in g], axis=0, dtype=np.uint64)
+                assert np.array_equal(total, one.world.shard_axis_sums()), f"{num_ranks} ranks, step {i}: the statistic depends on the partition"
+                for a, b in zip(g, o):
+                    assert np.array_equal(a.world.shard_axis_sums(), b.world.shard_axis_sums()), f"step {i} rank {a.rank}: GPU sums != oracle sums"
+                assert {r.world.counts()["sorting_axis"] for r in g} == {plain.counts()["sorting_axis"]}, f"step {i}"
+                if i % 10 == 9 or i == steps - 1:
+                    assert sharding.gather_owned(g, sc.num_bodies).tobytes() == plain.get_body_states(ids).tobytes(), f"{num_ranks} ranks ({tiles_z} along z), step {i}: sharded != single world"
+            assert plain.counts()["num_contacts"] > 50
+            for r in g + [one]:
+                r.world.close()
+            plain.close()
+
+
+def test_gpu_sharded_checkpoint_restores_every_ranks_view(mi_lib, oracle_mod):
+    """mi_world_save_checkpoint / _load_checkpoint on the ranks of a sharded world (shard section of the blob: current copies, borders in force
+    and pending): save mid-run with a border change pending, run on through migrations, restore, run again — bit-identical; the oracle's ranks
+    load the GPU ranks' blobs and continue identically; another rank's blob is refused."""
+    sc = scenes.obb_pile(16, 3, 8, spacing=1.0)
+    desc = _lopsided(sc, 3, 1, 1.5)
+    g = [sharding.ShardedWorld(sc.populate(mi_lib.create_world(0)), desc, r, "local") for r in range(3)]
+    s = sc.settings()
+
+    def run(ranks, n, start):
+        owned = []
+        for i in range(start, start + n):
+            sharding.step_local(ranks, s, sc.dt)
+            owned.append([r.world.shard_counts()["owned_bodies"] for r in ranks])
+            assert sum(owned[-1]) == sc.num_bodies, f"step {i}: {owned[-1]}"
+            if i % 8 == 7:
+                sharding.rebalance_local(ranks)
+        return owned
+    run(g, 12, 0)
+    sharding.rebalance_local(g)                                   # a change is pending at the moment of the save
+    blobs = [r.world.save_checkpoint() for r in g]
+    borders_at_save = [r.world.shard_get_borders(3, 1)[0].copy() for r in g]
+    owned_a = run(g, 28, 12)
+    final_a = sharding.gather_owned(g, sc.num_bodies)
+    assert any(not np.array_equal(r.world.shard_get_borders(3, 1)[0], b) for r, b in zip(g, borders_at_save))
+    for r, blob in zip(g, blobs):
+        r.world.load_checkpoint(blob)
+    assert all(np.array_equal(r.world.shard_get_borders(3, 1)[0], b) for r, b in zip(g, borders_at_save))
+    assert run(g, 28, 12) == owned_a
+    assert sharding.gather_owned(g, sc.num_bodies).tobytes() == final_a.tobytes()
+    o = [sharding.ShardedWorld(sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)), desc, r, "local") for r in range(3)]
+    for r, blob in zip(o, blobs):
+        r.world.load_checkpoint(blob)
+    assert run(o, 28, 12) == owned_a
+    assert sharding.gather_owned(o, sc.num_bodies).tobytes() == final_a.tobytes()
+    with pytest.raises(capi.PhysicsError):
+        g[0].world.load_checkpoint(blobs[1])
+    with pytest.raises(capi.PhysicsError):
+        sc.populate(mi_lib.create_world(0)).load_checkpoint(blobs[0])
+
+
+def test_gpu_shard_entry_points_reject_misuse(mi_lib):
+    """mi_world_shard_import on a tile without neighbours (its own staging buffer: a 1 x 1 grid has no receive buffer), on a world attached to
+    the library transport (refused), mi_world_step with several sub-steps on the caller's transport (refused: the exchange lies in between)."""
+    sc = scenes.obb_pile(6, 3, 6, spacing=1.0)
+    w = sc.populate(mi_lib.create_world(0))
+    w.shard_enable(sharding._desc_for(sharding.tile_grid(sc, 1), 0))
+    s = sc.settings()
+    w.step_fixed(s, sc.dt, 1)
+    empty = np.zeros(w.shard_message_bytes() // 4, np.float32)
+    w.shard_import(empty)                                          # no neighbours, no records: accepted, nothing to apply
+    st = w.shard_exchange_stats()
+    assert st["num_neighbours"] == 0 and st["owned_bodies"] == sc.num_bodies and st["ghost_bodies"] == 0 and st["exchanges"] == 1
+    several = capi.StepSettings(1, 120, 4, s.num_rigid_solver_iterations)
+    with pytest.raises(capi.PhysicsError):
+        w.step(several, 4.0 / 120.0)
+    one = capi.StepSettings(1, 120, 1, s.num_rigid_solver_iterations)
+    w.step(one, 1.0 / 120.0)
+    if w.L.shard_library_transport_available():
+        w.shard_attach_rccl(w.L.shard_unique_id())
+        with pytest.raises(capi.PhysicsError):
+            w.shard_import(empty)
+        with pytest.raises(capi.PhysicsError):
+            w.shard_set_axis_sums(np.zeros(9, np.uint64))
+        w.step(several, 4.0 / 120.0)                               # the library transport exchanges inside every internal step
+        w.shard_detach_rccl()
+    w.close()
+
+
+def _rccl_rank(rank, world_size, port, out_dir, tiles_z, steps):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", rank))
+    import d3d12renderer_amd as mi
+    sc = scenes.obb_pile(12, 4, 8, spacing=1.0)
+    desc = sharding.tile_grid(sc, world_size, tiles_z, 2.5)
+    sw = sharding.ShardedWorld(sc.populate(mi.create_world(rank)), desc, rank, "rccl", dist)
+    assert sw.transport == "rccl", sw.note
+    s = sc.settings()
+    owned = []
+    for i in range(steps):
+        sw.step(s, sc.dt)
+        owned.append(sw.world.shard_counts()["owned_bodies"])
+        if i == steps // 2:
+            sw.rebalance()                                         # one load-balance round through the library (ncclAllReduce of the histograms)
+    ents, st = sw.owned_states()
+    stats = sw.world.shard_exchange_stats()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ents=ents, states=st, owned=np.asarray(owned), axis=sw.world.counts()["sorting_axis"],
+             exchanges=stats["exchanges"], records=np.asarray(stats["records_sum"], np.uint64), borders=np.concatenate(sw.world.shard_get_borders(desc.tiles_x, desc.tiles_z)))
+    dist.barrier(); dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world_size,tiles_z", [(2, 1), (4, 2)], ids=["2 GPUs, x slabs", "4 GPUs, 2 x 2 tiles"])
+def test_gpu_real_rccl_ranks_equal_virtual_ranks(mi_lib, tmp_path, world_size, tiles_z):
+    """One process per GPU, the library's own transport: ncclSend / ncclRecv of the neighbour messages and the 72-byte ncclAllReduce of the
+    sweep-axis statistics on every world's stream (csrc/world.hip shardExchange), a load-balance round through ncclAllReduce — compared, bit
+    for bit, with the same ranks run as virtual ranks of this process on one GPU.  Needs as many visible devices as ranks (skipped otherwise:
+    RCCL refuses two ranks on one device)."""
+    import torch
+    if torch.cuda.device_count() < world_size:
+        pytest.skip(f"needs {world_size} visible GPUs, this box has {torch.cuda.device_count()}")
+    import os
+    import torch.multiprocessing as mp
+    steps = 60
+    port = 29700 + (os.getpid() % 2000) + world_size
+    mp.spawn(_rccl_rank, args=(world_size, port, str(tmp_path), tiles_z, steps), nprocs=world_size, join=True)
+    sc = scenes.obb_pile(12, 4, 8, spacing=1.0)
+    ranks = _ranks(lambda: mi_lib.create_world(0), sc, world_size, tiles_z, 2.5)
+    s = sc.settings()
+    owned = [[] for _ in ranks]
+    for i in range(steps):
+        sharding.step_local(ranks, s, sc.dt)
+        for r in ranks:
+            owned[r.rank].append(r.world.shard_counts()["owned_bodies"])
+        if i == steps // 2:
+            sharding.rebalance_local(ranks)
+    moved = 0
+    for r in ranks:
+        got = np.load(tmp_path / f"rank{r.rank}.npz")
+        ents, st = r.owned_states()
+        assert np.array_equal(got["owned"], np.asarray(owned[r.rank])), f"rank {r.rank}: owned bodies per step"
+        assert np.array_equal(got["ents"], ents) and got["states"].tobytes() == st.tobytes(), f"rank {r.rank}: owned states"
+        assert int(got["axis"]) == r.world.counts()["sorting_axis"]
+        assert np.array_equal(got["borders"], np.concatenate(r.world.shard_get_borders(ranks[0].desc.tiles_x, ranks[0].desc.tiles_z)))
+        assert int(got["exchanges"]) >= steps - 1
+        moved += int(got["records"].sum())
+    assert moved > 0, "no record ever crossed a link"
