@@ -328,6 +328,15 @@ class World:
         return buf[: size.value].tobytes()
 
     # --- checkpoint / resume
+    def debug_set_sweep_axis(self, axis):
+        self.L.check(self.L.fn("debug_set_sweep_axis")(self.h, C.c_uint32(axis)), "debug_set_sweep_axis")
+
+    def debug_set_solve_order(self, pairs):
+        """The next internal step solves exactly these oriented collider pairs ((n, 2) world indices), sequentially, in this order (and the
+        joints in pool order): the reference's own constraint order (include/mi_physics.h)."""
+        p = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
+        self.L.check(self.L.fn("debug_set_solve_order")(self.h, _ptr(p) if len(p) else None, C.c_uint32(len(p))), "debug_set_solve_order")
+
     def save_checkpoint(self):
         size = C.c_uint64()
         self.L.check(self.L.fn("world_save_checkpoint")(self.h, None, C.c_uint64(0), C.byref(size)), "world_save_checkpoint")

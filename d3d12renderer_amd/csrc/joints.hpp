@@ -797,6 +797,7 @@ struct JointType {
     ~JointType() { release(); }
     void release() {
         if (dPods) (void)hipFree(dPods); if (dBodies) (void)hipFree(dBodies); if (dOrder) (void)hipFree(dOrder); if (dUpd) (void)hipFree(dUpd); if (dAcc) (void)hipFree(dAcc);
+        if (dIdentity) (void)hipFree(dIdentity); dIdentity = nullptr; identityCap = 0;
         dPods = nullptr; dBodies = nullptr; dOrder = nullptr; dUpd = nullptr; dAcc = nullptr; dCap = 0;
     }
     // Greedy colouring in descending hash32 priority with 64-bit per-body colour masks (same rule as the contact schedule).
@@ -849,6 +850,22 @@ struct JointType {
         if (order.empty()) return hipSuccess;
         return hipMemcpyAsync(dOrder, order.data(), order.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st);
     }
+    // mi_debug_set_solve_order: the reference's order — every joint of the type, one after the other, in pool order
+    uint32_t* dIdentity = nullptr; size_t identityCap = 0;
+    hipError_t launchSolveReference(mi::Launcher& L, const mi::BodyView& bv, hipStream_t st) {
+        const uint32_t n = (uint32_t)pods.size();
+        if (!n) return hipSuccess;
+        if (n > identityCap) {
+            if (dIdentity) (void)hipFree(dIdentity);
+            dIdentity = nullptr; identityCap = 0;
+            hipError_t e = hipMalloc((void**)&dIdentity, n * sizeof(uint32_t)); if (e != hipSuccess) return e;
+            std::vector<uint32_t> id(n); for (uint32_t i = 0; i < n; ++i) id[i] = i;
+            e = hipMemcpy(dIdentity, id.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice); if (e != hipSuccess) return e;
+            identityCap = n;
+        }
+        L.launch(mi::k_joint_solve_serial<J>, dim3(1), dim3(64), 0, st, 0u, n, dIdentity, dBodies, dUpd, bv);
+        return hipSuccess;
+    }
     bool podsDirty = false;   // mi_constraint_update since the last upload: only the POD array changed (motors, limits), not the topology
     hipError_t uploadPods(hipStream_t st) {
         podsDirty = false;
@@ -899,4 +916,5 @@ struct JointSet {
     int uploadPods(hipStream_t st);
     int initialize(mi_world& w, float dt, hipStream_t st);
     void solveIteration(mi_world& w, hipStream_t st);
+    int solveIterationReference(mi_world& w, hipStream_t st);   // mi_debug_set_solve_order: sequentially, type by type, pool order
 };

@@ -10,6 +10,7 @@
 #include <cmath>
 #include <string.h>
 #include <vector>
+#include <unordered_map>
 #include <chrono>
 #include <thread>
 #include <string>
@@ -310,6 +311,9 @@ struct mi_world {
     bool specEnabled = true, haveEstimates = false;
     uint32_t specRetries = 0, specSteps = 0, totalSteps = 0, colorRoundsLaunched = 0;
     uint32_t sapAxis = 0;        // sorting axis for the next step (collision_broad.cpp:443-444), host copy
+    // mi_debug_set_solve_order: the next internal step solves these oriented collider pairs (a << 29 | b) sequentially, in this order, and the joints in pool order
+    std::vector<uint64_t> debugOrder; std::vector<uint32_t> debugRank; bool debugOrderPending = false;
+    int applyDebugOrder();       // all manifolds into the sequential (overflow) colour; their slots in the caller's order
 };
 
 int mi_world::init(int dev) {
@@ -777,7 +781,8 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     if (bodies.empty()) return cloths.empty() ? MI_OK : stepCloths(dt);   // physics.cpp:1184-1189: cloth alone still steps
     if (shard.stepOpen) shard.prevValid = false;   // the previous step ended in an error: what its kernels left behind is not what the flags describe
     shard.stepOpen = true;
-    const bool spec = specEnabled && haveEstimates && flowSolver && !launchFallbackSteps && (!usesInteractions || last.numInteractions <= 32768u);   // (triggers / force fields: ordered and applied on the device while there are at most 32 k interactions)
+    if (debugOrderPending && (heightmap || shard.enabled)) return fail(MI_ERR_UNSUPPORTED, "mi_debug_set_solve_order: not with heightmap terrain or sharding");
+    const bool spec = specEnabled && haveEstimates && flowSolver && !launchFallbackSteps && !debugOrderPending && (!usesInteractions || last.numInteractions <= 32768u);   // (triggers / force fields: ordered and applied on the device while there are at most 32 k interactions)
     ++totalSteps; if (spec) ++specSteps;
     int rc = runStep(settings, dt, spec);
     // a step that asks to be re-run has written nothing persistent; each re-run is synchronous and one rung further down the ladder
@@ -785,6 +790,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     for (int attempt = 0; rc == STEP_RETRY && attempt < 6; ++attempt) { ++specRetries; rc = runStep(settings, dt, false); }
     if (rc == STEP_RETRY) return fail(MI_ERR_DEVICE, "step could not be completed on any solver path");
     if (rc == MI_OK && launchFallbackSteps) --launchFallbackSteps;
+    debugOrderPending = false; debugOrder.clear();   // (one step only, whatever became of it)
     if (rc == MI_OK && shard.enabled) rc = shardExchange();
     if (rc == MI_OK && !cloths.empty()) rc = stepCloths(dt);   // after the rigid bodies (physics.cpp:1352-1358); once per VALID step: cloth state is updated in place
     return rc;
@@ -1078,7 +1084,7 @@ enqueue_section:
     }
     uint32_t tilesCap = 0, ctCap = 0, eventCap = 0, xcdListCap = 0;
     // XCD partitioning pays once the pile is big enough to keep eight L2s busy; it needs the persistent kernel (no joints)
-    const bool xcdAble = flowSolver && persistSolver && persistXcd && !xcdOnly && joints.count() == 0 && (persistWaves & 7u) == 0u;
+    const bool xcdAble = flowSolver && persistSolver && persistXcd && !xcdOnly && joints.count() == 0 && (persistWaves & 7u) == 0u && !debugOrderPending;
     // small piles: the 128 waves of ONE XCD run the whole solve, every body hand-over goes through that XCD's L2 (tileOwner(..., single))
     const bool xcdSingle = xcdAble && persistXcdSingle && nmBound && nmBound < xcdMinManifolds && divUp(divUp(nmBound, 64) + kSchedBins + 8, persistWaves / 8u) <= 16u;
     const bool xcdPlan = xcdAble && (nmBound >= xcdMinManifolds || xcdSingle);
@@ -1102,6 +1108,7 @@ enqueue_section:
         static const bool xcdNoSort = std::getenv("MI_XCD_NOSORT") != nullptr;   // development: manifold order as emitted
         const uint32_t* perm = xcdPlan && !xcdSingle && !xcdNoSort ? sortVals[1].p : nullptr;
         unsigned long long* top[2] = {bodyTop.p, bodyTop.p + (nb + 1)};
+        if (debugOrderPending) { int rc = applyDebugOrder(); if (rc != MI_OK) return rc; }   // (synchronous step: hs holds this step's counts) every manifold -> the sequential colour
         uint32_t round = 0;
         while (true) {
             for (uint32_t r = 0; r < colorBatch; ++r, ++round)
@@ -1133,16 +1140,26 @@ enqueue_section:
         if (!spec) {
             mirrorSchedule();
             const BinInfo& ob = bins[kSchedBins - 1];
+            if (debugOrderPending) {   // the caller's order (applyDebugOrder left every manifold's rank in debugRank)
+                if (ob.count != hs.numManifolds) return fail(MI_ERR_DEVICE, "mi_debug_set_solve_order: schedule did not put every manifold into the sequential bin");
+                if (ob.count) {
+                    std::vector<uint32_t> ord(ob.count);
+                    for (uint32_t m = 0; m < ob.count; ++m) ord[debugRank[m]] = m;
+                    HIP_TRY(hipMemcpyAsync(order.p + ob.slotStart, ord.data(), ob.count * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+                    HIP_TRY(hipStreamSynchronize(st));
+                }
+            } else
             if (ob.count > 1) {   // overflow colour: sequential solve in ascending pair-key order
                 HIP_TRY(L.memcpyAsync(orderTmp.p + ob.slotStart, order.p + ob.slotStart, ob.count * sizeof(uint32_t), hipMemcpyDeviceToDevice, st));
                 L.launch(k_sort_overflow, dim3(1), dim3(256), 0, st, ob.slotStart, ob.count, manPair.p, hs.partitioned ? pairKeysS.p : pairKeys.p, orderTmp.p, order.p);
             }
         }
     }
+    if (debugOrderPending && !nmBound && !debugOrder.empty()) return fail(MI_ERR_INVALID_ARGUMENT, "mi_debug_set_solve_order: the step found no contact manifold, the list holds " + std::to_string(debugOrder.size()));
     mark();  // 5
     // ---------------------------------------------------------------------------------------------- constraints
     const uint32_t tilesLaunch = spec ? tilesCap : totalTiles;   // sync mode knows the exact tile count (mirrorSchedule)
-    const bool useFlow = flowSolver && !launchFallbackSteps && (spec || bins[kSchedBins - 1].count == 0 || !nmBound);   // the overflow colour needs the sequential kernel
+    const bool useFlow = flowSolver && !launchFallbackSteps && !debugOrderPending && (spec || bins[kSchedBins - 1].count == 0 || !nmBound);   // the overflow colour needs the sequential kernel
     static const bool fuseEnabled = !(std::getenv("MI_FUSE_JOINTS") && std::getenv("MI_FUSE_JOINTS")[0] == '0');
     const bool fused = useFlow && fuseEnabled && joints.allInIslands();   // joints of all sweeps inside the dataflow launch
     // slots (tiles) one persistent workgroup must hold: exact in a synchronous step, from the previous step's lists (+ slack) in a speculative one
@@ -1258,7 +1275,8 @@ enqueue_section:
         }
         solveLaunches = iters * (tailStart + (tailStart < tailEnd ? 1u : 0u));
         for (uint32_t it = 0; it < iters; ++it) {
-            joints.solveIteration(*this, st);
+            if (debugOrderPending) { int rcj = joints.solveIterationReference(*this, st); if (rcj != MI_OK) return rcj; }
+            else joints.solveIteration(*this, st);
             for (uint32_t c = 0; c < tailStart; ++c) {
                 const ColorLaunch& cl = launches[c];
                 if (!cl.numBlocks) continue;
@@ -1487,6 +1505,50 @@ enqueue_section:
     { float* a = &timesSum.world_colliders; const float* b = &times.world_colliders; for (int i = 0; i < 9; ++i) a[i] += b[i]; ++timesSteps;
       contactUpdatesSum += (uint64_t)counts.num_contacts * iters; }
     return MI_OK;
+}
+
+// mi_debug_set_solve_order, inside a synchronous step after the manifolds are known (hs = this step's counts): every manifold is given the
+// sequential colour (kOverflowColor: one lane solves that bin slot by slot), and its rank in the caller's list is remembered for the slot order.
+int mi_world::applyDebugOrder() {
+    const uint32_t nm = hs.numManifolds;
+    if (nm != debugOrder.size()) return fail(MI_ERR_INVALID_ARGUMENT, "mi_debug_set_solve_order: the step found " + std::to_string(nm) + " contact manifolds, the list holds " + std::to_string(debugOrder.size()));
+    debugRank.assign(nm, 0u);
+    if (!nm) return MI_OK;
+    std::vector<uint32_t> mp(nm), col(nm, kOverflowColor);
+    HIP_TRY(hipMemcpyAsync(mp.data(), manPair.p, nm * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    std::vector<uint64_t> keys(hs.numPairs);
+    HIP_TRY(hipMemcpyAsync(keys.data(), hs.partitioned ? pairKeysS.p : pairKeys.p, keys.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::unordered_map<uint64_t, uint32_t> rank; rank.reserve(2 * (size_t)nm);
+    for (uint32_t i = 0; i < nm; ++i) if (!rank.emplace(debugOrder[i], i).second) return fail(MI_ERR_INVALID_ARGUMENT, "mi_debug_set_solve_order: a collider pair is listed twice");
+    for (uint32_t m = 0; m < nm; ++m) {
+        if (mp[m] >= keys.size()) return fail(MI_ERR_DEVICE, "mi_debug_set_solve_order: manifold without a pair");
+        const uint64_t k = keys[mp[m]] & ((1ull << 58) - 1ull);   // (bucket bits dropped: a << 29 | b)
+        auto it = rank.find(k);
+        if (it == rank.end()) return fail(MI_ERR_INVALID_ARGUMENT, "mi_debug_set_solve_order: the step found a contact manifold (colliders " + std::to_string(k >> 29) + ", " + std::to_string(k & 0x1FFFFFFFull) + ") that is not in the list");
+        debugRank[m] = it->second;
+    }
+    HIP_TRY(hipMemcpyAsync(color.p, col.data(), nm * sizeof(uint32_t), hipMemcpyHostToDevice, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    return MI_OK;
+}
+extern "C" {
+MI_API int mi_debug_set_sweep_axis(mi_world* w, uint32_t axis) {
+    if (!w || axis > 2u) return fail(MI_ERR_INVALID_ARGUMENT, "axis 0 | 1 | 2");
+    w->sapAxis = axis;
+    if (w->shard.enabled && w->shard.axisDev.p) { HIP_TRY(hipSetDevice(w->device)); HIP_TRY(hipMemcpy(w->shard.axisDev.p, &axis, sizeof(uint32_t), hipMemcpyHostToDevice)); w->shard.axisHostCurrent = true; }
+    return MI_OK;
+}
+MI_API int mi_debug_set_solve_order(mi_world* w, const uint32_t* pairs, uint32_t count) {
+    if (!w || (count && !pairs)) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    w->debugOrder.resize(count);
+    for (uint32_t i = 0; i < count; ++i) {
+        if (pairs[2 * i] >= (1u << 29) || pairs[2 * i + 1] >= (1u << 29)) return fail(MI_ERR_INVALID_ARGUMENT, "collider index out of range");
+        w->debugOrder[i] = ((uint64_t)pairs[2 * i] << 29) | (uint64_t)pairs[2 * i + 1];
+    }
+    w->debugOrderPending = true;
+    return MI_OK;
+}
 }
 
 // Host mirror of the device schedule (bins -> tiles), from the binStart table read back in StepScalars.
@@ -1752,6 +1814,14 @@ int JointSet::initialize(mi_world& w, float dt, hipStream_t st) {
     mi::Launcher& L = w.L;
     distance.launchInit(L, dummy, bv, dt, st); ball.launchInit(L, dummy, bv, dt, st); fixed.launchInit(L, dummy, bv, dt, st);
     hinge.launchInit(L, dummy, bv, dt, st); cone.launchInit(L, dummy, bv, dt, st); slider.launchInit(L, dummy, bv, dt, st);
+    return MI_OK;
+}
+int JointSet::solveIterationReference(mi_world& w, hipStream_t st) {
+    if (!count()) return MI_OK;
+    BodyView bv = bodyView(w);
+    mi::Launcher& L = w.L;
+    HIP_TRY(distance.launchSolveReference(L, bv, st)); HIP_TRY(ball.launchSolveReference(L, bv, st)); HIP_TRY(fixed.launchSolveReference(L, bv, st));
+    HIP_TRY(hinge.launchSolveReference(L, bv, st)); HIP_TRY(cone.launchSolveReference(L, bv, st)); HIP_TRY(slider.launchSolveReference(L, bv, st));
     return MI_OK;
 }
 void JointSet::solveIteration(mi_world& w, hipStream_t st) {

@@ -297,6 +297,21 @@ MI_API int mi_world_get_accumulated_stage_times(mi_world* world, mi_stage_times*
  * solver colour of every manifold of the last step. */
 MI_API int mi_world_get_aabbs(mi_world* world, float* out_min_max6, uint32_t capacity);
 MI_API int mi_world_get_manifold_colors(mi_world* world, uint32_t* out_colors, uint32_t capacity);
+/* Parity against the reference's own constraint order (debug speed: everything below runs sequentially).
+ * PGS is order dependent; the library's canonical order is colour-major, the reference solves, per iteration, the joints of
+ * every type in pool order and then the contacts in emission order (src/physics/constraints.cpp:3748-3770, 3381-3449).  These two calls make
+ * the NEXT internal step follow what the caller says the reference did, so that a test can hold the library against the reference itself,
+ * bit for bit, step after step:
+ *   mi_debug_set_sweep_axis    the axis that step sweeps along (the reference picks it from float sums in pool order,
+ *                              collision_broad.cpp:376-384, 443-444 — the library from an order-free integer statistic; they agree except
+ *                              in near ties); later steps choose their own again
+ *   mi_debug_set_solve_order   `pairs` = the oriented collider pairs (world indices A, B: 2 * count values) of the step's contact manifolds
+ *                              in the order the reference emitted them.  The step then solves exactly these manifolds one after the other
+ *                              in that order (one lane), the joints of each type one after the other in pool order, instead of the coloured
+ *                              schedule; a manifold the step finds that is not in the list (or a listed one it does not find) makes the
+ *                              step fail with MI_ERR_INVALID_ARGUMENT.  Not with heightmap terrain or sharding (MI_ERR_UNSUPPORTED). */
+MI_API int mi_debug_set_sweep_axis(mi_world* world, uint32_t axis);
+MI_API int mi_debug_set_solve_order(mi_world* world, const uint32_t* pairs, uint32_t count);
 
 /*
  * Cloth — cloth_component (src/physics/cloth.h:5-60, cloth.cpp): a gridSizeX x gridSizeY particle grid (upper row fixed) with

@@ -279,7 +279,7 @@ static void computeOrder(const World& w, const std::vector<Pair>& bodies, std::v
     uint32_t n = (uint32_t)bodies.size();
     order.resize(n);
     for (uint32_t i = 0; i < n; ++i) order[i] = i;
-    if (w.orderMode == 0 || n == 0) return;
+    if (w.orderMode == 0 || w.debugOrderPending || n == 0) return;   // (ora_debug_set_solve_order: one step in the reference's order)
     std::vector<uint32_t> prio(order);
     std::sort(prio.begin(), prio.end(), [](uint32_t a, uint32_t b) { return hash32(a) > hash32(b); });
     std::vector<uint64_t> used(w.bodies.size(), 0);
@@ -303,6 +303,7 @@ static mat3 ballInvEffMass(const GlobalState& A, const GlobalState& B, vec3 rA, 
 }
 static inline float inv0(float x) { return (x != 0.f) ? (1.f / x) : 0.f; }
 
+void jointsMarkOrderDirty(World& w) { w.joints->orderDirty = true; }
 void jointsInitialize(World& w, float dt) {
     JointStore& J = *w.joints;
     if (J.orderDirty) {

@@ -819,6 +819,7 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
     if (eventsEnabled) collisionEvents(*this); else prevCollisionKeys.clear();
 
     uint32_t ncontacts = (uint32_t)contacts.size();
+    if (debugOrderPending) jointsMarkOrderDirty(*this);
     jointsInitialize(*this, dt);
     std::vector<CollisionConstraint> cc(ncontacts);
     for (uint32_t i = 0; i < ncontacts; ++i) initContact(*this, i, dt, cc[i]);
@@ -828,6 +829,20 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
     solveOrder.reserve(ncontacts);
     if (orderMode == 0) {
         for (uint32_t i = 0; i < ncontacts; ++i) solveOrder.push_back(i);
+    } else if (debugOrderPending) {   // the caller's manifold order (mi_debug_set_solve_order); the colouring still runs: the history stays what the product's is
+        colorManifolds(*this);
+        uint32_t nm = (uint32_t)colliderPairs.size();
+        std::vector<uint32_t> firstContact(nm);
+        { uint32_t off = 0; for (uint32_t m = 0; m < nm; ++m) { firstContact[m] = off; off += contactCounts[m]; } }
+        std::unordered_map<uint64_t, uint32_t> byPair;
+        for (uint32_t m = 0; m < nm; ++m) byPair[((uint64_t)colliderPairs[m].a << 32) | colliderPairs[m].b] = m;
+        debugOrderError = nm != debugOrder.size();
+        for (const Pair& p : debugOrder) {
+            auto it = byPair.find(((uint64_t)p.a << 32) | p.b);
+            if (it == byPair.end()) { debugOrderError = true; continue; }
+            for (uint32_t k = 0; k < contactCounts[it->second]; ++k) solveOrder.push_back(firstContact[it->second] + k);
+        }
+        ncolors = 65;
     } else {
         colorManifolds(*this);
         uint32_t nm = (uint32_t)colliderPairs.size();
@@ -846,6 +861,7 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
         jointsSolveIteration(*this);  // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
         for (uint32_t id : solveOrder) solveContact(*this, id, cc[id]);
     }
+    if (debugOrderPending) { debugOrderPending = false; debugOrder.clear(); jointsMarkOrderDirty(*this); }
     for (uint32_t i = nb; i-- > 0;) { if (shard.enabled && shard.active[i] != 1) continue; integrateVelocity(bodies[i], rb[i], dt); }
     if (shard.enabled) {
         shard.owned[1] = shard.owned[2] = 0;                    // owner rule: a manifold belongs to the owner of its first dynamic body
@@ -1195,6 +1211,7 @@ MI_API int ora_world_step(World* w, const mi_step_settings* s, float dt) { w->st
 MI_API int ora_world_step_fixed(World* w, const mi_step_settings* s, float dt, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) w->stepInternal(*s, dt);
     for (RigidBody& b : w->bodies) { Entity& e = w->entities[b.entity]; e.position = b.p1; e.rotation = b.r1; }
+    if (w->debugOrderError) { w->debugOrderError = false; return MI_ERR_INVALID_ARGUMENT; }   // ora_debug_set_solve_order: the list did not match the step's manifolds
     return MI_OK;
 }
 
@@ -1624,6 +1641,14 @@ MI_API int ora_world_shard_set_axis_sums(World* w, const uint64_t* global9) {
     if (!w || !global9 || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
     w->sortingAxis = ora::axisFromSums(global9, (uint32_t)w->colliders.size()); return MI_OK;
 }
+MI_API int ora_debug_set_solve_order(World* w, const uint32_t* pairs, uint32_t count) {   // (mi_debug_set_solve_order)
+    if (!w || (count && !pairs) || w->orderMode != 1) return MI_ERR_INVALID_ARGUMENT;
+    w->debugOrder.resize(count);
+    for (uint32_t i = 0; i < count; ++i) w->debugOrder[i] = Pair{pairs[2 * i], pairs[2 * i + 1]};
+    w->debugOrderPending = true; w->debugOrderError = false;
+    return MI_OK;
+}
+MI_API int ora_debug_set_sweep_axis(World* w, uint32_t axis) { if (!w || axis > 2u) return MI_ERR_INVALID_ARGUMENT; w->sortingAxis = axis; return MI_OK; }   // (mi_debug_set_sweep_axis)
 MI_API uint32_t ora_axis_from_sums(const uint64_t* sums9, uint32_t numColliders) { return ora::axisFromSums(sums9, numColliders); }
 MI_API float ora_det_atan2f(float y, float x) { return det_atan2f(y, x); }
 MI_API float ora_det_acosf(float x) { return det_acosf(x); }

@@ -142,6 +142,7 @@ struct World {
     uint32_t sortingAxis = 0;
     uint64_t axisSums[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // canonical mode: centre statistics of the last step (S1[3], S2lo[3], S2hi[3]) of the colliders this world counts
 
+    std::vector<Pair> debugOrder; bool debugOrderPending = false, debugOrderError = false;   // ora_debug_set_solve_order (mirror of mi_debug_set_solve_order): the next step solves these manifolds in this order, joints in pool order
     int orderMode = 0;     // 0 = reference order (SAP sweep order, sequential PGS); 1 = canonical (GPU schedule replayed sequentially)
     bool dirtyProps = true;
     float timer = 0.f;
@@ -217,6 +218,7 @@ void jointsDestroyAll(World& w);
 int jointsDestroyOfEntity(World& w, uint32_t entity);
 int jointsAddFromGlobal(World& w, uint32_t type, uint32_t ea, uint32_t eb, const float* anchor, const float* axis, float l0, float l1, uint32_t* outId);
 void jointsInitialize(World& w, float dt);
+void jointsMarkOrderDirty(World& w);
 void jointsSolveIteration(World& w);
 uint32_t jointsCount(const World& w);
 void jointsRemapBody(World& w, uint32_t from, uint32_t to);

@@ -40,3 +40,78 @@ def contact_set(contacts):
         rows.append((int(k["collider_a"]), int(k["collider_b"]), k["point"].tobytes(), k["penetration_depth"].tobytes(),
                      k["normal"].tobytes(), int(k["friction_restitution"]), int(k["body_a"]), int(k["body_b"])))
     return sorted(rows)
+
+
+# --------------------------------------------------------------------------------------------------------------------------------------
+# Holding a library directly against the reference itself (oracle/_ref/libref.so stepping the reference's own physicsStep)
+def manifold_order(contacts):
+    """The oriented collider pairs (world indices A, B) of a contact list's manifolds, in list order (contacts of a manifold are consecutive)."""
+    if len(contacts) == 0:
+        return np.zeros((0, 2), np.uint32)
+    ab = np.stack([contacts["collider_a"], contacts["collider_b"]], axis=1).astype(np.uint32)
+    keep = np.ones(len(ab), bool); keep[1:] = (ab[1:] != ab[:-1]).any(axis=1)
+    return ab[keep]
+
+
+def _same_counts(cc, cr, i):
+    """Bodies, colliders, collisions (manifolds) and contacts: bit-exact.  AABB overlaps: the reference's sweep misses a pair whose intervals
+    touch EXACTLY on the sweep axis when the end point happens to sort before the start point (collision_broad.cpp:87-166; terrain tiles laid
+    edge to edge do that — static against static, never a collision pair); the grid finds every closed-interval overlap."""
+    for k in ("num_rigid_bodies", "num_colliders", "num_collisions", "num_contacts"):
+        assert cc[k] == cr[k], f"step {i}: {k} {cc[k]} != reference {cr[k]}"
+    assert cc["num_broadphase_overlaps"] >= cr["num_broadphase_overlaps"], f"step {i}: AABB overlaps {cc['num_broadphase_overlaps']} < reference {cr['num_broadphase_overlaps']}"
+
+
+def teacher_forced(make_candidate, make_reference, sc, steps, check_every=1):
+    """Every step: the reference steps from its own state S_k; the candidate is put into S_k (and given the axis the reference swept along),
+    steps ONCE in its own (canonical) constraint order, and is compared with the reference after that one step:
+      * the contact list, as a set, bit for bit (points, depths, normals, materials, body pairs, collider pairs) and every count;
+      * positions / orientations / velocities: the only order-dependent part — returned as the largest deviations seen.
+    Returns dict(max_pos_rel, max_rot_abs, max_lin, max_ang, contacts_min, contacts_max, steps)."""
+    ref = sc.populate(make_reference()); cand = sc.populate(make_candidate())
+    s = sc.settings(); ids = np.arange(sc.num_bodies, dtype=np.uint32)
+    # `ids` are ENTITY ids; scenes create the dynamic bodies first
+    out = dict(max_pos_rel=0.0, max_rot_abs=0.0, max_lin=0.0, max_ang=0.0, max_lin_rel=0.0, contacts_min=1 << 30, contacts_max=0, steps=steps)
+    for i in range(steps):
+        before = ref.get_body_states(ids)
+        ref.step_fixed(s, sc.dt, 1)
+        cr = ref.counts()
+        cand.set_body_states(ids, before)
+        cand.debug_set_sweep_axis(cr["sorting_axis"])
+        cand.step_fixed(s, sc.dt, 1)
+        cc = cand.counts()
+        _same_counts(cc, cr, i)
+        if i % check_every == 0 or i == steps - 1:
+            assert contact_set(cand.contacts()) == contact_set(ref.contacts()), f"step {i}: the contact lists differ as sets"
+        a = cand.get_body_states(ids).astype(np.float64); b = ref.get_body_states(ids).astype(np.float64)
+        assert np.isfinite(a).all() and np.isfinite(b).all()
+        scale = np.maximum(1.0, np.abs(b[:, 0:3]).max(axis=1))
+        out["max_pos_rel"] = max(out["max_pos_rel"], float((np.abs(a[:, 0:3] - b[:, 0:3]).max(axis=1) / scale).max()))
+        out["max_rot_abs"] = max(out["max_rot_abs"], float(np.abs(a[:, 3:7] - b[:, 3:7]).max()))
+        out["max_lin"] = max(out["max_lin"], float(np.abs(a[:, 7:10] - b[:, 7:10]).max()))
+        out["max_ang"] = max(out["max_ang"], float(np.abs(a[:, 10:13] - b[:, 10:13]).max()))
+        vs = np.maximum(1.0, np.abs(b[:, 7:10]).max())
+        out["max_lin_rel"] = max(out["max_lin_rel"], float(np.abs(a[:, 7:10] - b[:, 7:10]).max() / vs))
+        out["contacts_min"] = min(out["contacts_min"], cr["num_contacts"]); out["contacts_max"] = max(out["contacts_max"], cr["num_contacts"])
+    return out
+
+
+def replay_reference_order(make_candidate, make_reference, sc, steps):
+    """Free-running, no state is ever copied: every step the candidate is told the axis the reference swept along and the order in which the
+    reference emitted (= solves) its contact manifolds, and solves sequentially in that order (joints in pool order).  It must then BE the
+    reference: every count, the contact list in order, every pose and velocity bit, every step."""
+    ref = sc.populate(make_reference()); cand = sc.populate(make_candidate())
+    s = sc.settings(); ids = np.arange(sc.num_bodies, dtype=np.uint32)
+    most = 0
+    for i in range(steps):
+        ref.step_fixed(s, sc.dt, 1)
+        cr = ref.counts(); con = ref.contacts()
+        cand.debug_set_sweep_axis(cr["sorting_axis"])
+        cand.debug_set_solve_order(manifold_order(con))
+        cand.step_fixed(s, sc.dt, 1)
+        cc = cand.counts()
+        _same_counts(cc, cr, i)
+        assert contact_set(cand.contacts()) == contact_set(con), f"step {i}: contact lists"
+        assert cand.get_body_states(ids).tobytes() == ref.get_body_states(ids).tobytes(), f"step {i}: body states differ from the reference's"
+        most = max(most, cr["num_contacts"])
+    return most
