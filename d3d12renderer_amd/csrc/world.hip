@@ -314,6 +314,7 @@ struct mi_world {
     // mi_debug_set_solve_order: the next internal step solves these oriented collider pairs (a << 29 | b) sequentially, in this order, and the joints in pool order
     std::vector<uint64_t> debugOrder; std::vector<uint32_t> debugRank; bool debugOrderPending = false;
     int applyDebugOrder();       // all manifolds into the sequential (overflow) colour; their slots in the caller's order
+    int orientPairsLikeDebugOrder();   // equal-type pairs listed the other way round are turned (ties on the sweep axis: the reference's orientation follows its endpoint array's history)
 };
 
 int mi_world::init(int dev) {
@@ -1007,7 +1008,7 @@ enqueue_section:
             if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
             int rc = readScalars(); if (rc != MI_OK) return rc;
             pairBound = hs.numPairs + hs.numHmContacts;   // the terrain contacts are appended to the pair list after the narrow phase
-            if (pairBound <= cap && hs.numInterPairs <= interKeys.cap) break;
+            if (pairBound <= cap && hs.numInterPairs <= interKeys.cap) { if (debugOrderPending) { int rco = orientPairsLikeDebugOrder(); if (rco != MI_OK) return rco; } break; }
             if (attempt == 2) return fail(MI_ERR_DEVICE, "pair pass did not settle");
             if (pairBound > cap) HIP_TRY(pairKeys.ensure((size_t)pairBound + pairBound / 4));   // overflow: grow and redo the pair pass
             if (hs.numInterPairs > interKeys.cap) HIP_TRY(interKeys.ensure((size_t)hs.numInterPairs + hs.numInterPairs / 4));
@@ -1532,6 +1533,28 @@ int mi_world::applyDebugOrder() {
     HIP_TRY(hipStreamSynchronize(stream));
     return MI_OK;
 }
+// mi_debug_set_solve_order also ORIENTS: a pair of equal shape type whose AABB starts tie exactly on the sweep axis is oriented by the reference
+// according to the history of its persistent, stably sorted endpoint array (collision_broad.cpp:386-398) — no rule of the current state reproduces
+// that, the canonical rule (later created = new) is only the first frame's.  Synchronous step, right after the pair pass: pairs that the list holds
+// the other way round (and not this way) are turned before the narrow phase sees them.
+int mi_world::orientPairsLikeDebugOrder() {
+    const uint32_t np = hs.numPairs;
+    if (!np || debugOrder.empty()) return MI_OK;
+    std::vector<uint64_t> keys(np);
+    HIP_TRY(hipMemcpyAsync(keys.data(), pairKeys.p, (size_t)np * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    std::unordered_map<uint64_t, uint32_t> listed; listed.reserve(2 * debugOrder.size());
+    for (uint64_t k : debugOrder) listed.emplace(k, 0u);
+    bool turned = false;
+    for (uint64_t& k : keys) {
+        const uint64_t bucket = k >> 58, a = (k >> 29) & 0x1FFFFFFFull, b = k & 0x1FFFFFFFull;
+        uint32_t ta = 0, rem = (uint32_t)bucket; while (rem >= 6u - ta) { rem -= 6u - ta; ++ta; }
+        if (rem != 0u) continue;                                      // different shape types: ordered by type on both sides
+        if (!listed.count((a << 29) | b) && listed.count((b << 29) | a)) { k = (bucket << 58) | (b << 29) | a; turned = true; }
+    }
+    if (turned) { HIP_TRY(hipMemcpyAsync(pairKeys.p, keys.data(), (size_t)np * sizeof(uint64_t), hipMemcpyHostToDevice, stream)); HIP_TRY(hipStreamSynchronize(stream)); }
+    return MI_OK;
+}
 extern "C" {
 MI_API int mi_debug_set_sweep_axis(mi_world* w, uint32_t axis) {
     if (!w || axis > 2u) return fail(MI_ERR_INVALID_ARGUMENT, "axis 0 | 1 | 2");
@@ -1571,10 +1594,17 @@ void mi_world::mirrorSchedule() {
 // ------------------------------------------------------------------------------------------------
 // Joint storage (host) — addConstraint / add*ConstraintFromGlobalPoints (src/physics/physics.cpp:128-333)
 // ------------------------------------------------------------------------------------------------
+// A constraint POD may be handed over packed (sizeof(mi_*_constraint)) or AS THE REFERENCE'S STRUCT LIES IN MEMORY (src/physics/constraints.h): the
+// fields are the same in the same order; a leading quat makes fixed_constraint and slider_constraint 16-byte aligned, i.e. 8 bytes of tail
+// padding (40 -> 48, 72 -> 80: MI_REF_SIZEOF_*).  Only the fields are read / written, the padding is ignored / left untouched.
+template <class P> constexpr uint32_t refSizeof() { return (std::is_same<P, mi_fixed_constraint>::value || std::is_same<P, mi_slider_constraint>::value) ? (uint32_t)((sizeof(P) + 15u) & ~15u) : (uint32_t)sizeof(P); }
+static_assert(refSizeof<mi_distance_constraint>() == MI_REF_SIZEOF_DISTANCE_CONSTRAINT && refSizeof<mi_ball_constraint>() == MI_REF_SIZEOF_BALL_CONSTRAINT && refSizeof<mi_fixed_constraint>() == MI_REF_SIZEOF_FIXED_CONSTRAINT &&
+              refSizeof<mi_hinge_constraint>() == MI_REF_SIZEOF_HINGE_CONSTRAINT && refSizeof<mi_cone_twist_constraint>() == MI_REF_SIZEOF_CONE_TWIST_CONSTRAINT && refSizeof<mi_slider_constraint>() == MI_REF_SIZEOF_SLIDER_CONSTRAINT, "reference struct sizes");
+template <class P> static bool podSizeOk(uint32_t bytes) { return bytes == sizeof(P) || bytes == refSizeof<P>(); }
 template <class JT>
 static int jointAddTo(mi_world& w, JT& l, uint32_t ea, uint32_t eb, const void* pod, uint32_t bytes, uint32_t* out) {
     typedef typename std::remove_reference<decltype(l.pods[0])>::type P;
-    if (bytes != sizeof(P)) return fail(MI_ERR_INVALID_ARGUMENT, "constraint pod size mismatch");
+    if (!podSizeOk<P>(bytes)) return fail(MI_ERR_INVALID_ARGUMENT, "constraint pod size mismatch");
     if (ea >= w.entities.size() || eb >= w.entities.size() || w.entities[ea].rb < 0 || w.entities[eb].rb < 0)
         return fail(MI_ERR_INVALID_ARGUMENT, "both constraint entities must be rigid bodies");
     P p; std::memcpy(&p, pod, sizeof(P));
@@ -1622,7 +1652,7 @@ int JointSet::add(mi_world& w, uint32_t type, uint32_t ea, uint32_t eb, const vo
 }
 template <class JT> static int jointCopy(JT& l, uint32_t id, void* dst, const void* src, uint32_t bytes) {
     typedef typename std::remove_reference<decltype(l.pods[0])>::type P;
-    if (bytes != sizeof(P) || l.dense(id) < 0) return fail(MI_ERR_INVALID_ARGUMENT, "bad constraint id or pod size");
+    if (!podSizeOk<P>(bytes) || l.dense(id) < 0) return fail(MI_ERR_INVALID_ARGUMENT, "bad constraint id or pod size");
     if (src) std::memcpy(&l.pods[l.dense(id)], src, sizeof(P)); else std::memcpy(dst, &l.pods[l.dense(id)], sizeof(P));
     return MI_OK;
 }

@@ -4,8 +4,13 @@
  * Field-for-field the reference's constraint structs (src/physics/constraints.h), as plain
  * 4-byte-packed floats: quaternions are x,y,z,w; the anonymous motor unions are single floats;
  * constraint_motor_type is a uint32 (0 = velocity motor, 1 = position motor,
- * src/physics/constraints.h:41-45).  The reference's 16-byte alignment padding after a leading
- * quat (fixed: 40 -> 48 B, slider: 72 -> 80 B) is NOT part of this ABI.
+ * src/physics/constraints.h:41-45).
+ *
+ * Reference layout.  The structs below ARE the reference's structs as they lie in memory, except for the 8 bytes
+ * of tail padding that a leading quat (16-byte aligned) gives fixed_constraint (40 -> 48 B) and slider_constraint
+ * (72 -> 80 B).  mi_constraint_create / _update / _get / mi_constraints_update therefore accept `bytes` = the packed size
+ * OR the reference's sizeof (MI_REF_SIZEOF_*): a reference-side caller passes `&constraint, sizeof(constraint)` of its own
+ * struct, no member-wise conversion (the padding is ignored on the way in and left untouched on the way out).
  */
 #ifndef MI_CONSTRAINTS_H
 #define MI_CONSTRAINTS_H
@@ -15,6 +20,9 @@ extern "C" {
 #endif
 
 enum { MI_MOTOR_VELOCITY = 0, MI_MOTOR_POSITION = 1 };
+/* sizeof of the reference's structs (src/physics/constraints.h:73-80, 129-135, 175-183, 229-257, 346-380, 497-520) */
+enum { MI_REF_SIZEOF_DISTANCE_CONSTRAINT = 28, MI_REF_SIZEOF_BALL_CONSTRAINT = 24, MI_REF_SIZEOF_FIXED_CONSTRAINT = 48, MI_REF_SIZEOF_HINGE_CONSTRAINT = 104,
+       MI_REF_SIZEOF_CONE_TWIST_CONSTRAINT = 120, MI_REF_SIZEOF_SLIDER_CONSTRAINT = 80 };
 
 /* distance_constraint — src/physics/constraints.h:73-80 */
 typedef struct mi_distance_constraint {

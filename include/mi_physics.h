@@ -309,7 +309,11 @@ MI_API int mi_world_get_manifold_colors(mi_world* world, uint32_t* out_colors, u
  *                              in the order the reference emitted them.  The step then solves exactly these manifolds one after the other
  *                              in that order (one lane), the joints of each type one after the other in pool order, instead of the coloured
  *                              schedule; a manifold the step finds that is not in the list (or a listed one it does not find) makes the
- *                              step fail with MI_ERR_INVALID_ARGUMENT.  Not with heightmap terrain or sharding (MI_ERR_UNSUPPORTED). */
+ *                              step fail with MI_ERR_INVALID_ARGUMENT.  The list also ORIENTS pairs of equal shape type: where the AABB starts of
+ *                              such a pair tie exactly on the sweep axis, the reference's (A, B) follows the history of its persistent endpoint
+ *                              array (stable insertion sort, collision_broad.cpp:386-398), which no rule of the current state reproduces; a pair
+ *                              listed the other way round is turned before the narrow phase.  Not with heightmap terrain or sharding
+ *                              (MI_ERR_UNSUPPORTED). */
 MI_API int mi_debug_set_sweep_axis(mi_world* world, uint32_t axis);
 MI_API int mi_debug_set_solve_order(mi_world* world, const uint32_t* pairs, uint32_t count);
 

@@ -78,6 +78,15 @@ def build_reference(force=False):
     return build_ref.build(force=force)
 
 
+def build_binding():
+    """oracle/_ref/binding_check (+ _oracle): the reference-side backend stub (oracle/refbuild/binding/physics_mi355x.cpp) compiled against the reference's
+    real headers together with the reference's scene / physics code, linked to libmi_physics.so (GPU) or to this oracle (CPU).  Returns the two paths
+    (prebuilt ones when /root/reference is not mounted)."""
+    from oracle.refbuild.binding import build_binding as B
+    build()
+    return B.build(backend="product"), B.build(backend="oracle")
+
+
 def reference_library():
     global _ref_library
     if _ref_library is None:

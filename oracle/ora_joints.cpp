@@ -5,6 +5,7 @@
 // distance -> ball -> fixed -> hinge -> cone-twist -> slider (constraints.cpp:3764-3769).
 #include "ora_world.h"
 #include <algorithm>
+#include <type_traits>
 #include <cstring>
 
 namespace ora {
@@ -113,9 +114,14 @@ static inline quat q4(const float* f) { return quat(f[0], f[1], f[2], f[3]); }
 static inline void st3(float* f, vec3 v) { f[0] = v.x; f[1] = v.y; f[2] = v.z; }
 static inline void st4(float* f, quat q) { f[0] = q.x; f[1] = q.y; f[2] = q.z; f[3] = q.w; }
 
+// packed size, or the reference's own sizeof (a leading quat pads fixed / slider by 8 bytes: include/mi_constraints.h "Reference layout")
+template <typename P> static bool podSizeOk(uint32_t bytes) {
+    const uint32_t ref = (std::is_same<P, mi_fixed_constraint>::value || std::is_same<P, mi_slider_constraint>::value) ? (uint32_t)((sizeof(P) + 15u) & ~15u) : (uint32_t)sizeof(P);
+    return bytes == sizeof(P) || bytes == ref;
+}
 template <typename P>
 static int addTo(World& w, JointList<P>& l, uint32_t ea, uint32_t eb, const void* pod, uint32_t bytes, uint32_t* out) {
-    if (bytes != sizeof(P)) return MI_ERR_INVALID_ARGUMENT;
+    if (!podSizeOk<P>(bytes)) return MI_ERR_INVALID_ARGUMENT;
     if (ea >= w.entities.size() || eb >= w.entities.size() || w.entities[ea].rb < 0 || w.entities[eb].rb < 0) return MI_ERR_INVALID_ARGUMENT;
     P p; std::memcpy(&p, pod, sizeof(P));
     const uint32_t handle = (uint32_t)l.denseOf.size();
@@ -140,11 +146,11 @@ int jointsAdd(World& w, uint32_t type, uint32_t ea, uint32_t eb, const void* pod
     return MI_ERR_INVALID_ARGUMENT;
 }
 template <typename P> static int updIn(JointList<P>& l, uint32_t id, const void* pod, uint32_t bytes) {
-    if (bytes != sizeof(P) || l.dense(id) < 0) return MI_ERR_INVALID_ARGUMENT;
+    if (!podSizeOk<P>(bytes) || l.dense(id) < 0) return MI_ERR_INVALID_ARGUMENT;
     std::memcpy(&l.pods[l.dense(id)], pod, sizeof(P)); return MI_OK;
 }
 template <typename P> static int getIn(JointList<P>& l, uint32_t id, void* pod, uint32_t bytes) {
-    if (bytes != sizeof(P) || l.dense(id) < 0) return MI_ERR_INVALID_ARGUMENT;
+    if (!podSizeOk<P>(bytes) || l.dense(id) < 0) return MI_ERR_INVALID_ARGUMENT;
     std::memcpy(pod, &l.pods[l.dense(id)], sizeof(P)); return MI_OK;
 }
 // deleteConstraint / deleteAllConstraints / deleteAllConstraintsFromEntity — src/physics/physics.cpp:443-539

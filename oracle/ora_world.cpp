@@ -3,6 +3,7 @@
 // properties.  Each function cites the reference lines it restates.
 #include "ora_world.h"
 #include <algorithm>
+#include <unordered_set>
 #include <cstring>
 #include <limits>
 #include <cstdio>
@@ -508,6 +509,8 @@ static void narrowphaseCanonical(World& w, uint32_t axisUsed) {
     w.colliderPairs.clear(); w.contactCounts.clear(); w.contacts.clear(); w.bodyPairs.clear(); w.interactions.clear();
     std::vector<Pair> ipairs;
     std::vector<uint64_t> keys; keys.reserve(w.bpPairs.size());
+    std::unordered_set<uint64_t> debugListed;
+    if (w.debugOrderPending) for (const Pair& p : w.debugOrder) debugListed.insert(((uint64_t)p.a << 32) | p.b);
     for (Pair p : w.bpPairs) {
         // reconstruct {new, active}: new = later start on the sweep axis; tie -> later created = smaller world index
         float ma = w.aabbs[p.a].mn[axisUsed], mb = w.aabbs[p.b].mn[axisUsed];
@@ -516,6 +519,9 @@ static void narrowphaseCanonical(World& w, uint32_t axisUsed) {
         bool collision;
         if (!pruneAndOrient(w, q, collision)) continue;
         if (!collision) { ipairs.push_back(q); continue; }
+        // ora_debug_set_solve_order: the caller's list also ORIENTS a pair of equal shape type whose AABB starts tie exactly on the sweep axis —
+        // there the reference's orientation follows the history of its persistent endpoint array (stable insertion sort), which no rule reproduces
+        if (w.debugOrderPending && w.wc[q.a].s.type == w.wc[q.b].s.type && debugListed.count(((uint64_t)q.b << 32) | q.a) && !debugListed.count(((uint64_t)q.a << 32) | q.b)) std::swap(q.a, q.b);
         uint64_t bk = bucketOf(w.wc[q.a].s.type, w.wc[q.b].s.type);
         keys.push_back((bk << 58) | ((uint64_t)q.a << 29) | (uint64_t)q.b);
     }
@@ -1207,7 +1213,11 @@ MI_API int ora_world_test_interactions(World* w, uint32_t count, const float* or
     }
     return MI_OK;
 }
-MI_API int ora_world_step(World* w, const mi_step_settings* s, float dt) { w->step(*s, dt); return MI_OK; }
+MI_API int ora_world_step(World* w, const mi_step_settings* s, float dt) {
+    w->step(*s, dt);
+    if (w->debugOrderError) { w->debugOrderError = false; return MI_ERR_INVALID_ARGUMENT; }   // ora_debug_set_solve_order: the list did not match the step's manifolds
+    return MI_OK;
+}
 MI_API int ora_world_step_fixed(World* w, const mi_step_settings* s, float dt, uint32_t n) {
     for (uint32_t i = 0; i < n; ++i) w->stepInternal(*s, dt);
     for (RigidBody& b : w->bodies) { Entity& e = w->entities[b.entity]; e.position = b.p1; e.rotation = b.r1; }

@@ -28,6 +28,7 @@ def ref_world(oracle_mod):
 
 REPLAY = {
     "cfg1 spheres on the ground": (lambda: scenes.sphere_drop(6), 200),
+    "cfg1 at full size: 4096 spheres (columns of spheres tie on the sweep axis)": (lambda: scenes.sphere_drop(16), 240),
     "cfg2 mixed sphere / box stack": (lambda: scenes.mixed_stack(6, 4, 6), 200),
     "cfg3 box pile": (lambda: scenes.obb_pile(8, 4, 8, spacing=1.0), 240),
     "all 21 shape pairs": (lambda: scenes.shape_zoo(), 200),

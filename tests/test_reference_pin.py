@@ -339,3 +339,19 @@ def test_canonical_pipeline_replaying_the_reference_order_is_the_reference(oracl
     from helpers import replay_reference_order
     most = replay_reference_order(lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL), lambda: oracle_mod.create_reference_world(), make(), steps)
     assert most > 0
+
+
+def test_reference_side_binding_compiles_against_the_reference_and_runs(oracle_mod):
+    """INTEGRATION.md §2 as a compiled program: oracle/refbuild/binding/physics_mi355x.cpp (the stub a maintainer adds) built against the reference's
+    real physics.h / scene.h, with the one-line hook patched into scene_entity::addComponent, together with the reference's own scene and physics code.
+    The driver builds the reference's demo scene (application.cpp:183-251) and its ragdoll scene (learned_locomotion.cpp:442-446, ragdoll.cpp) with the
+    reference's API, steps one copy with the reference's physicsStep and one through the stub -> C ABI, and compares what game code reads.  Here the C
+    ABI is served by the CPU oracle (canonical order: what the GPU computes, bit for bit); tests/test_gpu_binding.py runs the same program over
+    libmi_physics.so.  In the reference's constraint order the two are bit-identical for all steps, incl. a force push, a velocity edit, a motor edit
+    through getConstraint() and an entity created mid-run."""
+    import subprocess
+    _, exe = oracle_mod.build_binding()
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "BINDING CHECK OK" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if "reference order" in l]
+    assert len(lines) == 2 and all("bit-identical steps 2" in l and "max position difference 0 m" in l for l in lines), r.stdout
