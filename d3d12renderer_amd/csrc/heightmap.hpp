@@ -169,6 +169,7 @@ struct TriShape {
         capDir = s.type == T_CAPSULE ? normalize(s.b - s.a) : V3();
     }
     __device__ bool test(V3 a, V3 b, V3 c, TriContact& t) const {
+        if (s.type == T_CYLINDER || s.type == T_HULL) return false;   // no shape-vs-triangle routine in the reference: only the lowest point is tested (below)
         if (s.type == T_SPHERE) return sphereVsTriangle(s.a, s.radius, a, b, c, t);
         if (s.type == T_CAPSULE) {   // heightmap_collision.cpp:445-471
             V3 triNormal = normalize(cross(b - a, c - a));
@@ -215,9 +216,8 @@ __device__ __forceinline__ V3 hmVertex(const HeightmapParams& hm, const uint16_t
     return V3((float)vx * hm.chunkScale, h, (float)vz * hm.chunkScale) + chunkMin;
 }
 // the collider's lowest point under the bilinear surface (heightmap_collision.cpp:572-580)
-__device__ inline bool hmLowestPoint(const HeightmapParams& hm, const Shape& s, TriContact& t) {
-    HullSet none{nullptr, nullptr};
-    V3 lowest = supportOf(s, none, V3(0.f, -1.f, 0.f));
+__device__ inline bool hmLowestPoint(const HeightmapParams& hm, const Shape& s, const HullSet& hulls, TriContact& t) {
+    V3 lowest = supportOf(s, hulls, V3(0.f, -1.f, 0.f));
     float h = hmHeightAt(hm, lowest.x, lowest.z);
     if (!(lowest.y < h)) return false;
     t.point = lowest; t.normal = V3(0.f, -1.f, 0.f); t.depth = h - lowest.y;
@@ -228,7 +228,7 @@ __device__ inline bool hmLowestPoint(const HeightmapParams& hm, const Shape& s, 
 // `sink(j, contact)` receives contact j (j < 255) in the reference's order; returns the count.  The general path: used for
 // colliders whose cell window is too large for the wave-parallel kernel below.
 template <typename Sink>
-__device__ inline uint32_t heightmapContacts(const HeightmapParams& hm, const Shape& s, V3 mn, V3 mx, const Sink& sink) {
+__device__ inline uint32_t heightmapContacts(const HeightmapParams& hm, const Shape& s, const HullSet& hulls, V3 mn, V3 mx, const Sink& sink) {
     uint32_t found = 0;
     const TriShape ts(s);
     const HmVolume vol(hm, mn, mx);
@@ -270,7 +270,7 @@ __device__ inline uint32_t heightmapContacts(const HeightmapParams& hm, const Sh
             }
         }
     TriContact t;
-    if (hmLowestPoint(hm, s, t) && found < kHmMaxContacts) { sink(found, t); ++found; }
+    if (hmLowestPoint(hm, s, hulls, t) && found < kHmMaxContacts) { sink(found, t); ++found; }
     return found;
 }
 
@@ -295,7 +295,9 @@ __device__ __forceinline__ uint32_t hmSpread7(uint32_t v) {   // bit i -> bit 2 
 }
 __device__ __forceinline__ bool hmActive(uint32_t tag, uint32_t& type) {
     type = tag & 0xFFu;
-    return ((tag >> 8) & 0xFFu) == OBJ_RIGID_BODY && (type == T_SPHERE || type == T_CAPSULE || type == T_AABB || type == T_OBB);
+    // cylinders and hulls too: the reference's switch has no case for them and reads an UNINITIALISED lowestPoint (heightmap_collision.cpp:533-573: undefined
+    // behaviour); what it evidently means — their lowest point against the surface, like every other type, no triangle routine — is what runs here
+    return ((tag >> 8) & 0xFFu) == OBJ_RIGID_BODY;
 }
 struct HmOut {   // where the WRITE passes put contact j of collider i
     StepScalars* sc; uint32_t pairCap; uint64_t* pairsA; uint64_t* pairsB; uint64_t* npPacked; float4* npNormal; float4* npPoints;
@@ -312,7 +314,7 @@ struct HmOut {   // where the WRITE passes put contact j of collider i
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
                                                      const float4* __restrict__ aabbMax, unsigned long long* __restrict__ hmPacked, uint8_t* __restrict__ hmSlow,
-                                                     const unsigned long long* __restrict__ hmScan, HmOut out) {
+                                                     const unsigned long long* __restrict__ hmScan, HmOut out, HullSet hulls) {
     const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (i >= nc) return;
     const float4 mn = aabbMin[i], mx = aabbMax[i];
@@ -328,7 +330,8 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
     const TriShape ts(s);
     const HmVolume vol(hm, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z));
     uint32_t found = 0; bool slow = false;
-    for (uint32_t z = vol.minCZ; z <= vol.maxCZ && !slow; ++z)
+    const bool triangles = type != T_CYLINDER && type != T_HULL;     // (wave-uniform: one collider per wave)
+    for (uint32_t z = vol.minCZ; triangles && z <= vol.maxCZ && !slow; ++z)
         for (uint32_t x = vol.minCX; x <= vol.maxCX; ++x) {
             const uint32_t slot = hm.chunkSlot[z * hm.chunksPerDim + x];
             if (slot == 0xFFFFFFFFu) continue;
@@ -378,19 +381,19 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
     if (lane != 0) return;
     if (WRITE) {
         TriContact t;
-        if (found < count && hmLowestPoint(hm, s, t)) out.put(first, i, found, t);
+        if (found < count && hmLowestPoint(hm, s, hulls, t)) out.put(first, i, found, t);
         return;
     }
     if (slow) { hmPacked[i] = 0ull; hmSlow[i] = 1; return; }
     TriContact t;
-    if (hmLowestPoint(hm, s, t) && found < kHmMaxContacts) ++found;
+    if (hmLowestPoint(hm, s, hulls, t) && found < kHmMaxContacts) ++found;
     hmPacked[i] = (unsigned long long)found | (found ? 1ull << 32 : 0ull);
     hmSlow[i] = 0;
 }
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_hm_slow(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
                                                 const float4* __restrict__ aabbMax, unsigned long long* __restrict__ hmPacked, const uint8_t* __restrict__ hmSlow,
-                                                const unsigned long long* __restrict__ hmScan, HmOut out) {
+                                                const unsigned long long* __restrict__ hmScan, HmOut out, HullSet hulls) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nc || !hmSlow[i]) return;
     const float4 mn = aabbMin[i], mx = aabbMax[i];
@@ -399,9 +402,9 @@ __global__ __launch_bounds__(64) void k_hm_slow(uint32_t nc, HeightmapParams hm,
         const uint32_t count = (uint32_t)hmPacked[i];
         if (!count || !out.ready()) return;
         const uint32_t first = out.sc->numPairs + (uint32_t)hmScan[i];
-        heightmapContacts(hm, s, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [&](uint32_t j, const TriContact& t) { if (j < count) out.put(first, i, j, t); });
+        heightmapContacts(hm, s, hulls, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [&](uint32_t j, const TriContact& t) { if (j < count) out.put(first, i, j, t); });
     } else {
-        const uint32_t found = heightmapContacts(hm, s, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [](uint32_t, const TriContact&) {});
+        const uint32_t found = heightmapContacts(hm, s, hulls, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [](uint32_t, const TriContact&) {});
         hmPacked[i] = (unsigned long long)found | (found ? 1ull << 32 : 0ull);
     }
 }

@@ -749,7 +749,8 @@ __host__ __device__ __forceinline__ int gjkModeOfBucket(uint32_t bucket);
 // One workgroup after the pair pass: the sharded counters summed (k_pair_totals), the bucket offsets / GJK span / "partition needed"
 // (formerly k_pair_ranges) and — with `partials` — the next sweep axis (formerly k_axis_final): three single-workgroup launches in one.
 __global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound, uint32_t nc, uint32_t numBlocks, const unsigned long long* __restrict__ partials,
-                                                     const int* __restrict__ blockBounds, GridParams* gridNext /* the NEXT step's grid (null: not wanted) */, uint32_t cellCapNext) {
+                                                     const int* __restrict__ blockBounds, GridParams* gridNext /* the NEXT step's grid (null: not wanted) */, uint32_t cellCapNext,
+                                                     uint32_t allowPartition /* 0: k_pair_partition is not going to run in this step */) {
     const uint32_t t = threadIdx.x;
     if (t < 64u) {   // wave 0
         if (t == 0 && sc->numPairs > pairBound) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; }
@@ -766,7 +767,14 @@ __global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ 
         // the partition exists to make narrow-phase waves type-uniform and to give the GJK kernel its span; when nearly every pair is of
         // ONE type (a box pile: box-box, plus the boxes on the ground) it only costs (a pass over the keys + a reservation per workgroup):
         // partition if a GJK bucket is populated or more than an eighth of the pairs lies outside the largest bucket
-        if (t == 0) { sc->gjkLo = hi > lo ? lo : 0u; sc->gjkHi = hi > lo ? hi : 0u; sc->partitioned = (nonEmpty > 1u && (hi > lo || (off - largest) * 8u > off)) ? 1u : 0u; }
+        if (t == 0) {
+            sc->gjkLo = hi > lo ? lo : 0u; sc->gjkHi = hi > lo ? hi : 0u;
+            const uint32_t want = (nonEmpty > 1u && (hi > lo || (off - largest) * 8u > off)) ? 1u : 0u;
+            sc->partitioned = want;
+            // a speculative step that left k_pair_partition out (its predecessor did not partition) must not go on with a partitioned list that was never
+            // written: everything downstream becomes a no-op, the step is invalid as a whole and is re-run
+            if (want && !allowPartition) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; sc->partitioned = 0u; sc->gjkLo = sc->gjkHi = 0u; }
+        }
     }
     if (!partials) return;
     __shared__ unsigned long long sm[4][kAxisSums];
@@ -1023,7 +1031,11 @@ __global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queue
 __global__ __launch_bounds__(256) void k_narrow_clip(uint32_t queueRegion, const StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                      const float4* __restrict__ wShape, const BoxHit* __restrict__ boxQueue,
                                                      uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints) {
+#ifdef MI_CLIP_PINGPONG
     __shared__ float4 polyMem[2 * kLdsPolyVerts * kLdsPolyStride];   // 64 KiB: two clip polygons per lane, [vertex][lane]
+#else
+    __shared__ float4 polyMem[kLdsPolyVerts * kLdsPolyStride];       // 32 KiB: ONE clip polygon per lane, [vertex][lane], clipped in place (narrow.hpp clipPolygonLds)
+#endif
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t q = t / queueRegion, idx = t % queueRegion;       // queueRegion is a multiple of 256: a workgroup never straddles queues
     if (q >= kBoxQueues || idx >= sc->boxHitCount[q]) return;
@@ -1036,8 +1048,13 @@ __global__ __launch_bounds__(256) void k_narrow_clip(uint32_t queueRegion, const
     boxPairShapes(wShape, a, b, ta, arot, acen, arad, brot, bcen, brad);
     ObbSat res; res.normal = V3(h.nx, h.ny, h.nz); res.faceHit = (h.flags & 1u) != 0u; res.bFace = (h.flags & 2u) != 0u;
     Manifold m; m.count = 0;
+#ifdef MI_CLIP_PINGPONG
     LdsPoly polyA{polyMem + threadIdx.x, 0u}, polyB{polyMem + kLdsPolyVerts * kLdsPolyStride + threadIdx.x, 0u};
     bool hit = obbContacts(arot, acen, arad, brot, bcen, brad, res, polyA, polyB, m);
+#else
+    LdsPoly poly{polyMem + threadIdx.x, 0u};
+    bool hit = obbContactsLds(arot, acen, arad, brot, bcen, brad, res, poly, m);
+#endif
     writeManifold(h.pair, hit, m, npPacked, npNormal, npPoints);
 }
 
@@ -1067,26 +1084,29 @@ __device__ __forceinline__ uint32_t tableSlot(uint64_t key, uint32_t mask) {
     uint64_t x = key * 0x9E3779B97F4A7C15ull;
     return (uint32_t)(x >> 40) & mask;
 }
-__device__ __forceinline__ uint32_t tableLookup(const unsigned long long* __restrict__ keys, const uint32_t* __restrict__ vals, uint32_t mask, uint64_t key) {
+// One slot = one 16-byte row (key, colour): a probe touches ONE sector — key and colour used to live in two arrays, two random sectors per probe and
+// two more per insert, and k_emit_manifolds is bound by exactly those.
+struct alignas(16) HistSlot { unsigned long long key; unsigned long long val; };
+__device__ __forceinline__ uint32_t tableLookup(const HistSlot* __restrict__ tab, uint32_t mask, uint64_t key) {
     for (uint32_t s = tableSlot(key, mask), n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
-        unsigned long long k = keys[s];
-        if (k == key) return vals[s];
-        if (k == 0ull) break;
+        const ulonglong2 e = *reinterpret_cast<const ulonglong2*>(tab + s);
+        if (e.x == key) return (uint32_t)e.y;
+        if (e.x == 0ull) break;
     }
     return kUncolored;
 }
+__device__ __forceinline__ void tableInsert(HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, uint32_t val) {
+    for (uint32_t s = tableSlot(key, mask), n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
+        if (atomicCAS(&tab[s].key, 0ull, (unsigned long long)key) == 0ull) { tab[s].val = val; return; }   // (the colour is read in the NEXT step only)
+    }
+}
 __global__ __launch_bounds__(256) void k_color_table_insert(uint32_t nc, const StepScalars* __restrict__ sc, const uint32_t* __restrict__ manPair,
                                                             const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
-                                                            const uint32_t* __restrict__ color, unsigned long long* __restrict__ keys,
-                                                            uint32_t* __restrict__ vals, uint32_t mask, const uint8_t* __restrict__ manKept) {
+                                                            const uint32_t* __restrict__ color, HistSlot* __restrict__ tab, uint32_t mask, const uint8_t* __restrict__ manKept) {
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= sc->numManifolds || manKept[m]) return;      // kept colours were inserted by k_emit_manifolds
     uint64_t pk = (sc->partitioned ? pairsB : pairsA)[manPair[m]];
-    uint64_t key = historyKey(nc, (uint32_t)((pk >> 29) & 0x1FFFFFFFull), (uint32_t)(pk & 0x1FFFFFFFull));
-    for (uint32_t s = tableSlot(key, mask), n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
-        unsigned long long old = atomicCAS(&keys[s], 0ull, (unsigned long long)key);
-        if (old == 0ull) { vals[s] = color[m]; return; }
-    }
+    tableInsert(tab, mask, historyKey(nc, (uint32_t)((pk >> 29) & 0x1FFFFFFFull), (uint32_t)(pk & 0x1FFFFFFFull)), color[m]);
 }
 
 // Collision events (handleCollisionCallbacks, src/physics/physics.cpp:1041-1178), device half.  A manifold whose oriented
@@ -1127,13 +1147,13 @@ __global__ __launch_bounds__(256) void k_events_begin(uint32_t nc, uint32_t cap,
     e.relVel[0] = rel.x; e.relVel[1] = rel.y; e.relVel[2] = rel.z;
     events[slot] = e;
 }
-__global__ __launch_bounds__(256) void k_events_end(uint32_t cap, StepScalars* sc, const unsigned long long* __restrict__ prevKeys, uint32_t prevMask,
-                                                    const unsigned long long* __restrict__ curKeys, const uint32_t* __restrict__ curVals, uint32_t curMask,
+__global__ __launch_bounds__(256) void k_events_end(uint32_t cap, StepScalars* sc, const HistSlot* __restrict__ prevTab, uint32_t prevMask,
+                                                    const HistSlot* __restrict__ curTab, uint32_t curMask,
                                                     DeviceEvent* __restrict__ events) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    unsigned long long key = s <= prevMask ? prevKeys[s] : 0ull;
+    unsigned long long key = s <= prevMask ? prevTab[s].key : 0ull;
     bool want = key != 0ull && ((key - 1ull) & ((1ull << kIndexBits) - 1ull)) < kHeightmapVirtualBase   // heightmap contacts raise no events
-                && tableLookup(curKeys, curVals, curMask, key) == kUncolored;
+                && tableLookup(curTab, curMask, key) == kUncolored;
     uint32_t slot = waveAppendSlot(want, &sc->numEvents);
     if (!want) return;
     if (slot >= cap) { sc->specOverflow = 1u; return; }
@@ -1150,10 +1170,10 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
                                                                                             ONE 16-byte gather per side instead of material + world box + body (three sectors, the last one dependent) */,
                                                         uint32_t* __restrict__ manPair, uint2* __restrict__ manBodies, uint2* __restrict__ manInfo,
                                                         uint4* __restrict__ colWork, uint32_t* __restrict__ color,
-                                                        const unsigned long long* __restrict__ prevKeys, const uint32_t* __restrict__ prevVals, uint32_t prevMask,
+                                                        const HistSlot* __restrict__ prevTab, uint32_t prevMask,
                                                         unsigned long long* __restrict__ bodyUsed, uint8_t* __restrict__ isNew, StepScalars* sc,
                                                         float2 terrainMaterial /* (restitution, friction) of the heightmap */,
-                                                        unsigned long long* __restrict__ nextKeys, uint32_t* __restrict__ nextVals, uint32_t nextMask, uint8_t* __restrict__ manKept) {
+                                                        HistSlot* __restrict__ nextTab, uint32_t nextMask, uint8_t* __restrict__ manKept) {
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t numPairs = sc->numPairs;
     if (p >= numPairs) return;
@@ -1180,15 +1200,13 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
     colWork[m] = make_uint4(bA | dynA, bB | dynB, (uint32_t)prio, (uint32_t)(prio >> 32));
     // a manifold of the previous step keeps its colour (colour 64 = overflow is re-coloured)
     const uint64_t hk = historyKey(nc, a, b);
-    uint32_t c = prevKeys ? tableLookup(prevKeys, prevVals, prevMask, hk) : kUncolored;
+    uint32_t c = prevTab ? tableLookup(prevTab, prevMask, hk) : kUncolored;
     if (isNew) isNew[m] = (c == kUncolored && !terrain) ? 1u : 0u;   // not in the previous step's collision list: collision-begin event
     if (c < kOverflowColor) {
         if (dynA) atomicOr(&bodyUsed[bA], 1ull << c);
         if (dynB) atomicOr(&bodyUsed[bB], 1ull << c);
         // its colour is final: it enters the NEXT step's history right here (k_color_table_insert then only has the few new manifolds left)
-        for (uint32_t s = tableSlot(hk, nextMask), n = 0; n <= nextMask; s = (s + 1u) & nextMask, ++n) {
-            if (atomicCAS(&nextKeys[s], 0ull, (unsigned long long)hk) == 0ull) { nextVals[s] = c; break; }
-        }
+        tableInsert(nextTab, nextMask, hk, c);
         manKept[m] = 1u;
     } else { c = kUncolored; manKept[m] = 0u; }
     color[m] = c;

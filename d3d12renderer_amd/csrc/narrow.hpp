@@ -179,6 +179,93 @@ __device__ inline bool clipAndBuild(Poly& poly, Poly& clipped, const P4* planes,
     return false;
 }
 
+// The same clip + reduction for the LDS polygon of k_narrow_clip, arranged for the machine: every pass first reads the WHOLE polygon into registers
+// (<= 8 vertices, the loads issued back to back: one LDS latency per pass instead of one per vertex — the compiler cannot overlap them itself, reads
+// and writes of the ping-pong planes may alias for all it knows), then walks it with static indices and writes the surviving vertices back IN PLACE
+// (everything a pass needs is already in registers, so one [vertex][lane] plane per lane suffices: 32 KiB per workgroup instead of 64).  The
+// arithmetic per vertex, and the order of the vertices, are exactly clipPolygon's / clipAndBuild's / reduceManifold's above.
+__device__ inline void clipPolygonLds(LdsPoly& poly, const P4* planes, uint32_t numPlanes) {
+    for (uint32_t ci = 0; ci < numPlanes; ++ci) {
+        const uint32_t n = poly.n;
+        if (n == 0) break;
+        const P4 pl = planes[ci];
+        ClipVert v[kLdsPolyVerts];
+#pragma unroll
+        for (uint32_t i = 0; i < kLdsPolyVerts; ++i) if (i < n) v[i] = poly.get(i);
+        ClipVert start = poly.get(n - 1);
+        uint32_t on = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kLdsPolyVerts; ++i) {
+            if (i < n) {
+                const ClipVert end = v[i];
+                const float sd = planeDist(start.v, pl), ed = planeDist(end.v, pl);
+                const bool sIn = sd > 0.f, eIn = ed > 0.f;
+                if (sIn && eIn) poly.put(on++, end);
+                else if (sIn) poly.put(on++, clipEdge(start, end, sd, ed));
+                else if (!sIn && eIn) { poly.put(on++, clipEdge(start, end, sd, ed)); poly.put(on++, end); }
+                start = end;
+            }
+        }
+        poly.n = on;
+    }
+}
+__device__ inline void reduceManifoldLds(const LdsPoly& poly, uint32_t n, V3 normal, Manifold& out) {
+    ClipVert v[kLdsPolyVerts];
+#pragma unroll
+    for (uint32_t i = 0; i < kLdsPolyVerts; ++i) if (i < n) v[i] = poly.get(i);
+    if (n > 4) {
+        const V3 searchDir = tangentOf(normal);
+        float best = dot(searchDir, v[0].v);
+        uint32_t ri = 0;
+#pragma unroll
+        for (uint32_t i = 1; i < kLdsPolyVerts; ++i) if (i < n) { float dd = dot(searchDir, v[i].v); if (dd > best) { ri = i; best = dd; } }
+        { ClipVert c = poly.get(ri); setc(out, 0, c.v, c.depth); }
+        best = 0.f; ri = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kLdsPolyVerts; ++i) if (i < n) { float sq = sqlen(v[i].v - out.p[0]); if (sq > best) { ri = i; best = sq; } }
+        { ClipVert c = poly.get(ri); setc(out, 1, c.v, c.depth); }
+        float bestArea = 0.f; ri = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kLdsPolyVerts; ++i) if (i < n) {
+            V3 vi = v[i].v;
+            V3 qa = out.p[0] - vi, qb = out.p[1] - vi;
+            float area = 0.5f * dot(cross(qa, qb), normal);
+            if (area > bestArea) { ri = i; bestArea = area; }
+        }
+        { ClipVert c = poly.get(ri); setc(out, 2, c.v, c.depth); }
+        bestArea = 0.f; ri = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < kLdsPolyVerts; ++i) if (i < n) {
+            V3 vi = v[i].v;
+            V3 qa = out.p[0] - vi, qb = out.p[1] - vi, qc = out.p[2] - vi;
+            float a1 = 0.5f * dot(cross(qa, qb), normal);
+            float a2 = 0.5f * dot(cross(qb, qc), normal);
+            float a3 = 0.5f * dot(cross(qc, qa), normal);
+            float area = fmaxr(fmaxr(a1, a2), a3);
+            if (area > bestArea) { ri = i; bestArea = area; }
+        }
+        { ClipVert c = poly.get(ri); setc(out, 3, c.v, c.depth); }
+        out.count = 4;
+    } else {
+        out.count = n;
+#pragma unroll
+        for (uint32_t i = 0; i < 4; ++i) if (i < n) setc(out, i, v[i].v, v[i].depth);
+    }
+}
+__device__ inline bool clipAndBuildLds(LdsPoly& poly, const P4* planes, uint32_t numPlanes, P4 ref, Manifold& out) {
+    clipPolygonLds(poly, planes, numPlanes);
+    if (poly.n > 0) {
+        V3 rn(ref.x, ref.y, ref.z);
+        for (uint32_t i = 0; i < poly.n; ++i) {       // (swap-and-pop: the order of the survivors is part of the result)
+            ClipVert c = poly.get(i);
+            if (c.depth < 0.f) { poly.put(i, poly.get(poly.n - 1)); --poly.n; --i; }
+            else { c.v = c.v + rn * c.depth; poly.put(i, c); }
+        }
+        if (poly.n > 0) { reduceManifoldLds(poly, poly.n, out.n, out); return true; }
+    }
+    return false;
+}
+
 __device__ __forceinline__ V3 closestOnSegment(V3 q, V3 la, V3 lb) {  // bounding_volumes.h:365-371
     V3 ab = lb - la;
     float t = dot(q - la, ab) / sqlen(ab);
@@ -466,6 +553,45 @@ __device__ inline bool obbContacts(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, 
         out.p[0] = (pa + pb) * 0.5f;
     }
     return true;
+}
+// obbContacts for k_narrow_clip: the face case clips in place in one LDS polygon (clipAndBuildLds); everything else is obbContacts itself
+__device__ inline bool obbContactsLds(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 brad, const ObbSat& res, LdsPoly& poly, Manifold& out) {
+    if (!res.faceHit) { LdsPoly none{poly.p, 0u}; return obbContacts(arot, acen, arad, brot, bcen, brad, res, poly, none, out); }   // (edge case: no polygon involved)
+    const V3 normal = res.normal;
+    const bool bFace = res.bFace;
+    out.n = normal;
+    V3 cp[4], cn[4], quad[4];
+    P4 plane;
+    if (!bFace) {
+        boxClipPlanes(arad, rotate(conj(arot), normal), cp, cn);
+        boxIncidentFace(brad, rotate(conj(brot), normal), quad);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cp[i] = rotate(arot, cp[i]) + acen;
+            cn[i] = rotate(arot, cn[i]);
+            quad[i] = rotate(brot, quad[i]) + bcen;
+        }
+        plane = makePlane(obbSupport(arot, acen, arad, normal), normal);
+    } else {
+        boxClipPlanes(brad, rotate(conj(brot), -normal), cp, cn);
+        boxIncidentFace(arad, rotate(conj(arot), -normal), quad);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cp[i] = rotate(brot, cp[i]) + bcen;
+            cn[i] = rotate(brot, cn[i]);
+            quad[i] = rotate(arot, quad[i]) + acen;
+        }
+        plane = makePlane(obbSupport(brot, bcen, brad, -normal), -normal);
+    }
+    P4 planes[4];
+    poly.n = 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        planes[i] = makePlane(cp[i], cn[i]);
+        ClipVert c; c.v = quad[i]; c.depth = -planeDist(quad[i], plane);
+        poly.put(i, c);
+    }
+    return clipAndBuildLds(poly, planes, 4, plane, out);
 }
 template <class Poly>
 __device__ inline bool obbOBB(Q4 arot, V3 acen, V3 arad, Q4 brot, V3 bcen, V3 brad, Poly& poly, Poly& clipped, Manifold& out) {

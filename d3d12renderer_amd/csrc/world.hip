@@ -216,7 +216,7 @@ struct mi_world {
     DBuf<uint32_t> color, order, orderTmp, blockHist, blockScan; DBuf<uint4> tileInfo, xcdInfo; DBuf<unsigned long long> bodyTop, bodyUsed;
     DBuf<BinInfo> binInfo;
     // colour history (pair -> colour of the previous step): two tables, the one written by a step becomes current only if the step is valid
-    DBuf<unsigned long long> tabKeys[2]; DBuf<uint32_t> tabVals[2]; uint32_t tabMask[2] = {0, 0}; int tabCur = 0; bool tabValid = false;
+    DBuf<HistSlot> tab[2]; uint32_t tabMask[2] = {0, 0}; int tabCur = 0; bool tabValid = false;
     // collision events (mi_world_enable_events / mi_world_poll_events)
     // triggers / force fields: entity lists by dense index, per-collider object tags, rotated forces, the pair pass's
     // rigid-body x (trigger | force field) AABB overlaps, the interactions that passed the boolean test, the per-step force accumulators
@@ -255,7 +255,7 @@ struct mi_world {
     int uploadHeightmap();
     bool eventsEnabled = false; DBuf<uint8_t> manIsNew; DBuf<DeviceEvent> devEvents; std::vector<mi_event> pendingEvents;
     DBuf<float4> rows, slotNormal; DBuf<float4> imp; DBuf<float2> slotMass; DBuf<uint4> slotMeta; DBuf<uint2> tileDesc;
-    bool usedFlow = false;
+    bool usedFlow = false, skippedPartition = false, havePartitionFlag = false, lastPartitioned = false;
     bool usedFused = false;
     bool persistSolver = true, persistMetaLds = true, persistImpLds = true, usedPersist = false; uint32_t xcdOnly = 0; uint32_t persistWaves = 1024;   // one resident workgroup per SIMD owns its tiles through all sweeps (k_contact_solve_persist)
     uint32_t flowLds = 0;                  // dynamic LDS bytes per 64-lane workgroup: caps resident waves per CU (160 KiB / flowLds)
@@ -947,7 +947,7 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     enum { PASS_PLAIN, PASS_DRY, PASS_CAPTURE };
     int pass = graphStep ? PASS_DRY : PASS_PLAIN;
 enqueue_section:
-    evi = 0;
+    evi = 0; skippedPartition = false;
     L.trace = graphDebug;
     L.begin(pass == PASS_DRY, pass != PASS_PLAIN);
     attached = !debugSync && pass == PASS_PLAIN;
@@ -964,8 +964,9 @@ enqueue_section:
         L.launch(k_world_colliders, dim3(divUp(nc, B)), dim3(B), 0, st, nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis, shard.enabled ? shard.active.p : nullptr, shard.activePrev.p, shard.enabled ? shard.axisDev.p : nullptr);
         if (heightmap) {   // terrain contacts per collider, their offsets and totals (they join the pair list after the collider-pair narrow phase)
-            L.launch(k_hm_contacts<false>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
-            L.launch(k_hm_slow<false>, dim3(divUp(nc, 64)), dim3(64), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{});
+            const HullSet hmHulls{hullVerts.p, hullRanges.p};
+            L.launch(k_hm_contacts<false>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{}, hmHulls);
+            L.launch(k_hm_slow<false>, dim3(divUp(nc, 64)), dim3(64), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{}, hmHulls);
             HIP_TRY(scanTerrain.run(L, hmPacked.p, hmScan.p, nc, st));
             L.launch(k_hm_totals, dim3(1), dim3(1), 0, st, nc, hmPacked.p, hmScan.p, sc);
         }
@@ -1004,7 +1005,12 @@ enqueue_section:
             const uint32_t bpc = (divUp(smallBound, kGridChunks * 256u) + 7u) & ~7u;   // a multiple of 8 (XCD-contiguous block order in k_bp_pairs_grid)
             L.launch(k_bp_pairs_grid, dim3(5u * bpc), dim3(B), 0, st, nc, bpc, cellKeysS.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
             L.launch(k_bp_pairs_large, dim3(std::min(divUp(smallBound + 1024u, B), 4096u), std::min(16u, std::max(1u, divUp(spec ? last.numLarge + last.numLarge / 4u : 1024u, 64u)))), dim3(B), 0, st, nc, largeList.p, aabbMin.p, aabbMax.p, cellValsS.p, sMin.p, sMax.p, cellLower.p, gridUse, pairKeys.p, cap, sc, shards.p, inter);
-            L.launch(k_pair_finish, dim3(1), dim3(256), 0, st, shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu, nc, nblk, attempt == 0 ? axisPartials.p : nullptr, blockBounds.p, attempt == 0 ? gridNext : nullptr, cellCapNext);
+            // (a box pile: nearly every pair is of one type and k_pair_finish decides against partitioning — k_pair_partition then does nothing but cost its
+            // launch slot: a speculative step whose predecessor was not partitioned leaves it out; if this step wants it after all, k_pair_finish voids the step)
+            static const bool skipPartitionEnabled = !(std::getenv("MI_SKIP_PARTITION") && std::getenv("MI_SKIP_PARTITION")[0] == '0');
+            skippedPartition = spec && skipPartitionEnabled && havePartitionFlag && !lastPartitioned;
+            L.launch(k_pair_finish, dim3(1), dim3(256), 0, st, shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu, nc, nblk, attempt == 0 ? axisPartials.p : nullptr, blockBounds.p, attempt == 0 ? gridNext : nullptr, cellCapNext,
+                     skippedPartition ? 0u : 1u);
             if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
             int rc = readScalars(); if (rc != MI_OK) return rc;
             pairBound = hs.numPairs + hs.numHmContacts;   // the terrain contacts are appended to the pair list after the narrow phase
@@ -1019,7 +1025,7 @@ enqueue_section:
     // ---------------------------------------------------------------------------------------------- narrow phase
     if (pairBound) {
         HIP_TRY(pairKeysS.ensure(pairKeys.cap));
-        L.launch(k_pair_partition, dim3(divUp(pairBound, 1024)), dim3(256), 0, st, pairKeys.p, pairKeysS.p, sc);
+        if (!skippedPartition) L.launch(k_pair_partition, dim3(divUp(pairBound, 1024)), dim3(256), 0, st, pairKeys.p, pairKeysS.p, sc);
         HIP_TRY(npPacked.ensure(pairBound)); HIP_TRY(npScan.ensure(pairBound)); HIP_TRY(npNormal.ensure(pairBound)); HIP_TRY(npPoints.ensure(4 * (size_t)pairBound));
         HIP_TRY(manPair.ensure(pairBound)); HIP_TRY(manBodies.ensure(pairBound)); HIP_TRY(manInfo.ensure(pairBound));
         HIP_TRY(colWork.ensure(pairBound)); HIP_TRY(color.ensure(pairBound));
@@ -1044,8 +1050,8 @@ enqueue_section:
         }
         if (heightmap) {
             const HmOut hmOut{sc, pairBound, pairKeys.p, pairKeysS.p, npPacked.p, npNormal.p, npPoints.p};
-            L.launch(k_hm_contacts<true>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut);
-            L.launch(k_hm_slow<true>, dim3(divUp(nc, 64)), dim3(64), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut);
+            L.launch(k_hm_contacts<true>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut, hset);
+            L.launch(k_hm_slow<true>, dim3(divUp(nc, 64)), dim3(64), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut, hset);
             L.launch(k_hm_finish, dim3(1), dim3(1), 0, st, sc, pairBound);
         }
         HIP_TRY(scanPairs.run(L, reinterpret_cast<unsigned long long*>(npPacked.p), reinterpret_cast<unsigned long long*>(npScan.p), pairBound, st));
@@ -1054,15 +1060,15 @@ enqueue_section:
             const uint32_t histBound = spec ? std::min(pairBound, bound(last.numManifolds, 1024)) : pairBound;
             const int nt = tabCur ^ 1;
             uint32_t cap = 1024; while (cap < 2u * histBound) cap <<= 1;
-            HIP_TRY(tabKeys[nt].ensure(cap)); HIP_TRY(tabVals[nt].ensure(cap)); HIP_TRY(manKept.ensure(pairBound));
+            HIP_TRY(tab[nt].ensure(cap)); HIP_TRY(manKept.ensure(pairBound));
             tabMask[nt] = cap - 1u;
-            HIP_TRY(L.memsetAsync(tabKeys[nt].p, 0, (size_t)cap * sizeof(unsigned long long), st));
+            HIP_TRY(L.memsetAsync(tab[nt].p, 0, (size_t)cap * sizeof(HistSlot), st));
         }
         L.launch(k_emit_manifolds, dim3(divUp(pairBound, B)), dim3(B), 0, st, nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, cEmit.p,
                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
-                                                        tabValid ? tabKeys[tabCur].p : nullptr, tabVals[tabCur].p, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc,
+                                                        tabValid ? tab[tabCur].p : nullptr, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc,
                                                         heightmap ? make_float2(hmParams.restitution, hmParams.friction) : make_float2(0.f, 0.f),
-                                                        tabKeys[tabCur ^ 1].p, tabVals[tabCur ^ 1].p, tabMask[tabCur ^ 1], manKept.p);
+                                                        tab[tabCur ^ 1].p, tabMask[tabCur ^ 1], manKept.p);
         if (shard.enabled) L.launch(k_shard_count, dim3(divUp(pairBound, B)), dim3(B), 0, st, nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc, shards.p);
     }
     // ---------------------------------------------------------------------------------------------- triggers / force fields
@@ -1129,13 +1135,13 @@ enqueue_section:
         colorRoundsLaunched = round;
         {   // colour history for the next step, into the OTHER table (it becomes current only if this step turns out valid)
             const int nt = tabCur ^ 1;   // sized and cleared before k_emit_manifolds (narrow phase stage)
-            L.launch(k_color_table_insert, dim3(divUp(nmBound, B)), dim3(B), 0, st, nc, sc, manPair.p, pairKeys.p, pairKeysS.p, color.p, tabKeys[nt].p, tabVals[nt].p, tabMask[nt], manKept.p);
+            L.launch(k_color_table_insert, dim3(divUp(nmBound, B)), dim3(B), 0, st, nc, sc, manPair.p, pairKeys.p, pairKeysS.p, color.p, tab[nt].p, tabMask[nt], manKept.p);
             if (eventsEnabled) {   // begins: manifolds not in the previous table; ends: previous pairs not in this step's table
                 eventCap = nmBound + (tabValid ? last.numManifolds : 0u) + 1024u;
                 HIP_TRY(devEvents.ensure(eventCap));
                 L.launch(k_events_begin, dim3(divUp(nmBound, B)), dim3(B), 0, st, nc, eventCap, sc, manIsNew.p, manPair.p, manBodies.p, manInfo.p, pairKeys.p, pairKeysS.p,
                                                                npNormal.p, npPoints.p, gPos.p, gVel.p, devEvents.p);
-                if (tabValid) L.launch(k_events_end, dim3(divUp(tabMask[tabCur] + 1u, B)), dim3(B), 0, st, eventCap, sc, tabKeys[tabCur].p, tabMask[tabCur], tabKeys[nt].p, tabVals[nt].p, tabMask[nt], devEvents.p);
+                if (tabValid) L.launch(k_events_end, dim3(divUp(tabMask[tabCur] + 1u, B)), dim3(B), 0, st, eventCap, sc, tab[tabCur].p, tabMask[tabCur], tab[nt].p, tabMask[nt], devEvents.p);
             }
         }
         if (!spec) {
@@ -1431,9 +1437,9 @@ enqueue_section:
             uint32_t cap = last.numManifolds + 1024u;
             HIP_TRY(devEvents.ensure(cap));
             const int nt = tabCur ^ 1;
-            HIP_TRY(tabKeys[nt].ensure(1024)); HIP_TRY(tabVals[nt].ensure(1024)); tabMask[nt] = 1023u;
-            HIP_TRY(hipMemsetAsync(tabKeys[nt].p, 0, 1024 * sizeof(unsigned long long), st));
-            k_events_end<<<divUp(tabMask[tabCur] + 1u, B), B, 0, st>>>(cap, sc, tabKeys[tabCur].p, tabMask[tabCur], tabKeys[nt].p, tabVals[nt].p, tabMask[nt], devEvents.p);
+            HIP_TRY(tab[nt].ensure(1024)); tabMask[nt] = 1023u;
+            HIP_TRY(hipMemsetAsync(tab[nt].p, 0, 1024 * sizeof(HistSlot), st));
+            k_events_end<<<divUp(tabMask[tabCur] + 1u, B), B, 0, st>>>(cap, sc, tab[tabCur].p, tabMask[tabCur], tab[nt].p, tabMask[nt], devEvents.p);
             HIP_TRY(hipMemcpyAsync(hsPinned, sc, offsetof(Readback, seq), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             hs = hsPinned->sc;
@@ -1489,10 +1495,12 @@ enqueue_section:
     ++last.colorRounds;
     haveEstimates = true;
     pairsIn = hs.partitioned ? pairKeysS.p : pairKeys.p;
+    lastPartitioned = hs.partitioned != 0u; havePartitionFlag = pairBound != 0u;
 
     // (the host got here on the published read-back, i.e. after the kernels the events belong to — but the HIP 7.0 runtime now and then still
     // reports an event attached to a kernel as not ready, ~1 step in 1000: wait for it then instead of reporting 0 ms)
-    auto el = [&](int a, int b) { return elapsedMs(ev[a], ev[b]); };
+    static const bool noTimes = std::getenv("MI_NO_TIMES") != nullptr;   // development: what the three hipEventElapsedTime calls per step cost the host
+    auto el = [&](int a, int b) { return noTimes ? 0.f : elapsedMs(ev[a], ev[b]); };
     if (stageEvents) {
         times.world_colliders = el(0, 1); times.broadphase = el(1, 2); times.narrowphase = el(2, 3); times.integrate_forces = el(3, 4);
         times.schedule = el(4, 5); times.init_constraints = el(5, 6);
@@ -2762,10 +2770,9 @@ MI_API int mi_world_save_checkpoint(mi_world* w, void* out, uint64_t capacity, u
     std::vector<unsigned long long> keys; std::vector<uint32_t> vals;
     if (w->tabValid) {   // also with a pending topology edit: the keys are creation indices, the live world keeps the history across it
         const size_t cap = (size_t)w->tabMask[w->tabCur] + 1;
-        std::vector<unsigned long long> k(cap); std::vector<uint32_t> v(cap);
-        HIP_TRY(hipMemcpy(k.data(), w->tabKeys[w->tabCur].p, cap * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        HIP_TRY(hipMemcpy(v.data(), w->tabVals[w->tabCur].p, cap * sizeof(uint32_t), hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < cap; ++i) if (k[i]) { keys.push_back(k[i]); vals.push_back(v[i]); }
+        std::vector<HistSlot> t(cap);
+        HIP_TRY(hipMemcpy(t.data(), w->tab[w->tabCur].p, cap * sizeof(HistSlot), hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < cap; ++i) if (t[i].key) { keys.push_back(t[i].key); vals.push_back((uint32_t)t[i].val); }
     }
     CheckpointHeader h{};
     h.magic = kCheckpointMagic; h.version = 1; h.numEntities = (uint32_t)w->entities.size(); h.numBodies = (uint32_t)w->bodies.size();
@@ -2902,7 +2909,7 @@ MI_API int mi_world_load_checkpoint(mi_world* w, const void* data, uint64_t size
         }
         // ---- commit
         int rc = w->download(); if (rc != MI_OK) return rc;   // the host copy becomes authoritative; everything is re-sent before the next step
-        if (h.numHistory) { const int c = w->tabCur; HIP_TRY(w->tabKeys[c].ensure(cap)); HIP_TRY(w->tabVals[c].ensure(cap)); }
+        if (h.numHistory) { const int c = w->tabCur; HIP_TRY(w->tab[c].ensure(cap)); }
         for (size_t i = 0; i < es.size(); ++i) { w->entities[i].pos = es[i].pos; w->entities[i].rot = es[i].rot; }
         for (size_t i = 0; i < bs.size(); ++i) { HBody& b = w->bodies[i]; b.p0 = bs[i].p0; b.r0 = bs[i].r0; b.p1 = bs[i].p1; b.r1 = bs[i].r1; b.linVel = bs[i].linVel; b.angVel = bs[i].angVel; b.force = bs[i].force; b.torque = bs[i].torque; }
         w->prevTriggerOverlaps = std::move(overlaps);
@@ -2933,8 +2940,9 @@ MI_API int mi_world_load_checkpoint(mi_world* w, const void* data, uint64_t size
         w->tabValid = h.numHistory != 0;
         if (w->tabValid) {
             const int c = w->tabCur; w->tabMask[c] = cap - 1u;
-            HIP_TRY(hipMemcpy(w->tabKeys[c].p, tk.data(), cap * sizeof(unsigned long long), hipMemcpyHostToDevice));
-            HIP_TRY(hipMemcpy(w->tabVals[c].p, tv.data(), cap * sizeof(uint32_t), hipMemcpyHostToDevice));
+            std::vector<HistSlot> t(cap);
+            for (uint32_t i = 0; i < cap; ++i) { t[i].key = tk[i]; t[i].val = tv[i]; }
+            HIP_TRY(hipMemcpy(w->tab[c].p, t.data(), cap * sizeof(HistSlot), hipMemcpyHostToDevice));
             w->last.numManifolds = h.numHistory;
         }
         return MI_OK;

@@ -678,7 +678,7 @@ def rolling_heightmap(chunks_per_dim=2, chunk_size=16.0, amplitude=6.0, seed=9, 
 def terrain_field(nx=10, ny=2, nz=10, seed=9, solver_iterations=20, spacing=1.6, with_unsupported=True):
     """Heightmap terrain (heightmapCollision): mixed spheres, capsules, AABB boxes (upright -> AABB, tumbling -> promoted to
     OBB) and OBBs dropped on rolling hills; two of them over the edge of the map (they fall past it); optionally a cylinder
-    and a hull, which the terrain ignores."""
+    and a hull (the reference has no triangle routine for them: they are held by their lowest point)."""
     n = nx * ny * nz
     e = make_entities(n)
     e["position"] = _lattice(nx, ny, nz, spacing, 5.5, seed, 0.08)

@@ -242,14 +242,17 @@ void heightmapCollision(World& w) {
         if (col.objectType != MI_OBJECT_RIGID_BODY) continue;
         if (w.aabbs[i].mx.x < w.aabbs[i].mn.x) continue;   // sharded world: a collider of a body this rank does not simulate this step
         const Shape& s = col.s;
-        if (s.type != T_SPHERE && s.type != T_CAPSULE && s.type != T_AABB && s.type != T_OBB) continue;
+        // (cylinders and hulls: the reference's switch has no case for them and then reads an UNINITIALISED `lowestPoint`, heightmap_collision.cpp:533-573 —
+        // undefined behaviour, nothing to reproduce.  What the code evidently means — no triangle routine exists for them, the lowest point of the shape
+        // is tested against the surface like for every other type — is what runs here: support(0, -1, 0) of the cylinder / hull, one contact.)
         vec3 vmin = w.aabbs[i].mn, vmax = w.aabbs[i].mx;
         vmax.y += 10.f;
         std::vector<TriContact> found;
         auto keep = [&](bool hit, const TriContact& c) { if (hit && found.size() < 255) found.push_back(c); };
         vec3 lowest;
-        SupportShape sup{&s, nullptr};
+        SupportShape sup{&s, s.type == T_HULL ? &w.hulls[s.hull] : nullptr};
         switch (s.type) {
+            case T_CYLINDER: case T_HULL: break;   // no shape-vs-triangle routine in the reference: the lowest point only
             case T_SPHERE:
                 trianglesInVolume(hm, vmin, vmax, [&](vec3 a, vec3 b, vec3 c) { TriContact t; keep(sphereVsTriangle(s.a, s.radius, a, b, c, t), t); });
                 break;

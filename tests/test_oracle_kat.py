@@ -278,7 +278,7 @@ def test_heightmap_height_query_and_flat_rest(oracle_mod):
 
 def test_heightmap_slope_normals_and_box(oracle_mod):
     """A planar slope: every triangle contact of a sphere has the slope's normal (into the terrain) and the right depth; an
-    upright box resting on a flat map gets triangle contacts with normal (0,-1,0) from the 13-axis SAT; a cylinder is ignored."""
+    upright box resting on a flat map gets triangle contacts with normal (0,-1,0) from the 13-axis SAT; a cylinder stands on its lowest point."""
     w = oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)
     e = scenes.make_entities(1); e["position"][0] = (0.0, 0.0, 0.0); e["gravity_factor"] = 0.0
     c = scenes.make_colliders(1, capi.SPHERE); c["shape"][0, :4] = (0, 0, 0, 0.5)
@@ -311,11 +311,15 @@ def test_heightmap_slope_normals_and_box(oracle_mod):
     h = _flat_heightmap(w)
     w.step_fixed(capi.StepSettings(1, 120, 4, 12), 1 / 120, 300)
     p, _ = w.physics_transforms()
-    assert abs(p[0, 1] - (h + 0.25)) < 1e-2 and p[1, 1] < h - 5.0                       # the box rests, the cylinder fell through
+    # the box rests on its triangle contacts; the cylinder — no shape-vs-triangle routine exists for it in the reference, whose switch leaves `lowestPoint`
+    # uninitialised for it (heightmap_collision.cpp:533-573) — is held by the one contact its lowest point gives: an upright cylinder stands on it
+    assert abs(p[0, 1] - (h + 0.25)) < 1e-2 and abs(p[1, 1] - (h + 0.3)) < 2e-2
     con = w.contacts()
-    assert len(con) >= 4 and (con["collider_a"] == con["collider_a"][0]).all()
-    assert np.allclose(con["normal"], (0, -1, 0), atol=5e-3)
-    assert w.counts()["num_collisions"] == 1
+    box = con[con["collider_a"] == con["collider_a"].max()]          # world index = reverse creation order: the box was created first
+    cyl = con[con["collider_a"] == con["collider_a"].min()]
+    assert len(box) >= 4 and np.allclose(box["normal"], (0, -1, 0), atol=5e-3)
+    assert len(cyl) == 1 and tuple(cyl["normal"][0]) == (0.0, -1.0, 0.0) and abs(cyl["point"][0][1] - h) < 2e-2 and cyl["penetration_depth"][0] >= 0.0
+    assert w.counts()["num_collisions"] == 2
 
 
 def test_heightmap_scene_both_orders_agree(oracle_mod):
@@ -336,7 +340,8 @@ def test_heightmap_scene_both_orders_agree(oracle_mod):
         on_map = np.arange(2, 25)
         hts = np.array([w.heightmap_height(float(p[i, 0]), float(p[i, 2])) for i in on_map])
         assert (p[on_map, 1] > hts - 0.05).all() and p[0, 1] < -5.0 and p[1, 1] < -5.0       # the two off-map bodies keep falling
-        assert p[25, 1] < -5.0 and p[26, 1] < -5.0                                            # cylinder and hull are ignored
+        for i in (25, 26):                                                                     # cylinder and hull: held by their lowest point
+            assert p[i, 1] > w.heightmap_height(float(p[i, 0]), float(p[i, 2])) - 0.05
 
 
 def test_ray_interaction_known_answers(oracle_mod):

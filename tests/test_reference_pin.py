@@ -212,9 +212,11 @@ def test_cloth_reference_order_equals_reference(oracle_mod):
 
 
 def test_reference_undefined_behaviour_is_where_the_restatement_deviates(oracle_mod):
-    """heightmapCollision reads an uninitialised `lowestPoint` for cylinders and hulls (heightmap_collision.cpp:538-573): the reference
-    emits a garbage contact for them, the restatement (and the product) skip them.  Everything else in the scene is unaffected
-    until that garbage contact pushes its body around, so only the first step is compared — the supported colliders agree."""
+    """heightmapCollision reads an uninitialised `lowestPoint` for cylinders and hulls (heightmap_collision.cpp:538-573): whatever the stack
+    held decides whether the reference emits a contact for them, and where.  The restatement (and the product) run what the code evidently means:
+    the lowest point of the cylinder / hull against the surface, like for the four types that have a case (no triangle routine exists for these
+    two).  Everything else in the scene is unaffected until a garbage contact pushes its body around, so only the first step is compared — the
+    colliders the reference handles agree bit for bit; tests/test_oracle_kat.py holds the cylinder / hull behaviour against known answers."""
     sc = scenes.terrain_field(with_unsupported=True)
     r, o = _worlds(oracle_mod, sc)
     s = sc.settings()

@@ -1,0 +1,20 @@
+#!/bin/bash
+# round 3, call E: in-place batched clip, 16-byte history slots, partition launch skipped (safe), parity after them
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+ulimit -c 0
+B="python bench.py --steps 60 --warmup 5 --no-cpu-baseline --no-at-rest"
+show() { python - "$1" "$2" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[2]))
+    print(sys.argv[1], "steps/s", round(d["value"], 1), "ms", round(d["ms_per_step"], 4), "dev ms", round(d["device_ms_per_step"], 4), "solver us", round(d["roofline"]["avg_launch_us"], 1), "stage", {k: round(v, 3) for k, v in d["stage_ms"].items()})
+except Exception as e: print(sys.argv[1], "FAILED", e)
+PY
+}
+timeout 300 $B 2>/dev/null | tail -1 > gpurun_out/r3e_new.json; show "new default  " gpurun_out/r3e_new.json
+MI_SKIP_PARTITION=0 timeout 300 $B 2>/dev/null | tail -1 > gpurun_out/r3e_noskip.json; show "partition run" gpurun_out/r3e_noskip.json
+timeout 300 $B 2>/dev/null | tail -1 > gpurun_out/r3e_new2.json; show "new default 2" gpurun_out/r3e_new2.json
+bash tools/gpu_timeline.sh 2>&1 | tail -2
+cp gpurun_out/timeline.txt gpurun_out/r3e_timeline.txt
+timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fullsize.py tests/test_gpu_step_graphs.py tests/test_scene_formats.py tests/test_gpu_reference_direct.py tests/test_gpu_sharding.py -q -m gpu -x 2>&1 | tail -8 | tee gpurun_out/r3e_pytest.log
