@@ -264,7 +264,9 @@ def main():
 
     if world_size > 1:
         sw.world.shard_exchange_stats(reset=True)       # (also reports a message overflow of the settle phase before anything is timed)
+    mode0 = sw.world.step_mode_stats()
     elapsed, step_ms, stage_acc, contact_iters = timed_region(sw, settings, dt, args.steps, barrier)
+    mode1 = sw.world.step_mode_stats()
     solve_ms = stage_acc["solve"]; total_dev_ms = stage_acc["total"]
     launches = sw.world.solve_launches() * args.steps
     counts = sw.world.counts()
@@ -390,6 +392,8 @@ def main():
             "step_ms_p95_note": None if args.steps >= 50 else f"not reported: {args.steps} timed steps are too few for a 95th percentile (>= 50); step_ms_max is the slowest of them",
             "step_ms_max": float(np.max(step_ms)),
             "timed_ms_total": elapsed * 1e3,
+            "step_modes_timed": {"internal_steps": mode1[0] - mode0[0], "speculative": mode1[1] - mode0[1], "synchronous_reruns": mode1[2] - mode0[2],
+                                 "note": "a speculative step sizes its launches from the previous step and reads back once; one whose bounds did not hold is re-run synchronously (counted here, timed like any step)"},
             "device_ms_per_step": total_dev_ms / args.steps,
         }
         if per_rank is not None:

@@ -102,26 +102,25 @@ __device__ inline void boxToAABB(V3 lmn, V3 lmx, Q4 rot, V3 tr, V3& mn, V3& mx) 
     growBox(mn, mx, rotate(rot, lmx) + tr);
 }
 
-__global__ __launch_bounds__(256) void k_world_colliders(
-    uint32_t nc, uint32_t nb, const uint32_t* __restrict__ cTypeBody,  // [2*nc]: type, body (kNoBody = static)
+// one collider: world shape + AABB rows (written unless the collider is dead in this and the previous step: its rows already hold the dead box);
+// mnOut / mxOut = the rows in either case
+__device__ __forceinline__ void worldCollider(
+    uint32_t k, uint32_t nb, const uint32_t* __restrict__ cTypeBody,  // [2*nc]: type, body (kNoBody = static)
     const uint32_t* __restrict__ cObject,   // colliders without a body: physics_object_type | object index << 8 (static / force field / trigger)
     const float4* __restrict__ cShape, const float4* __restrict__ cStaticPos, const float4* __restrict__ cStaticRot,
     const float4* __restrict__ bPos, const float4* __restrict__ bRot,
     const float4* __restrict__ hullAabb,  // [2*numHulls]
-    float4* __restrict__ wShape, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax, StepScalars* sc, uint32_t axisCur,
+    float4* __restrict__ wShape, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax,
     const uint8_t* __restrict__ bodyActive /* sharded world: 0 = body not simulated by this rank this step, or null */,
-    const uint8_t* __restrict__ bodyActivePrev /* ... and in the previous step */,
-    const uint32_t* __restrict__ axisDev /* sharded world: the sweep axis lives on the device (k_shard_axis, from the sums over all ranks), or null */) {
-    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k == 0) { sc->axisCur = axisDev ? *axisDev : axisCur; }   // the SAP axis chosen at the end of the previous (successful) step
-    if (k >= nc) return;
+    const uint8_t* __restrict__ bodyActivePrev /* ... and in the previous step */, float4& mnOut, float4& mxOut) {
     uint32_t type = cTypeBody[2 * k], body = cTypeBody[2 * k + 1];
     if (bodyActive && body != kNoBody && !bodyActive[body]) {
-        if (!bodyActivePrev[body]) return;   // dead before as well: its rows already hold what follows (most colliders of a many-tile scene, every step)
         // a DEAD collider: inverted box (overlaps nothing, centre exactly 0 so the axis statistics are unaffected), skipped by the grid
+        mnOut = make_float4(kDeadBox, kDeadBox, kDeadBox, __uint_as_float(type | (OBJ_RIGID_BODY << 8)));
+        mxOut = make_float4(-kDeadBox, -kDeadBox, -kDeadBox, __uint_as_float(body));
+        if (!bodyActivePrev[body]) return;   // dead before as well: its rows already hold this (most colliders of a many-tile scene, every step)
         wShape[3 * k] = make_float4(0, 0, 0, 0); wShape[3 * k + 1] = make_float4(0, 0, 0, 0); wShape[3 * k + 2] = make_float4(0, 0, 0, 1);
-        aabbMin[k] = make_float4(kDeadBox, kDeadBox, kDeadBox, __uint_as_float(type | (OBJ_RIGID_BODY << 8)));
-        aabbMax[k] = make_float4(-kDeadBox, -kDeadBox, -kDeadBox, __uint_as_float(body));
+        aabbMin[k] = mnOut; aabbMax[k] = mxOut;
         return;
     }
     V3 tp; Q4 tr; uint32_t objType, objIndex;
@@ -184,8 +183,22 @@ __global__ __launch_bounds__(256) void k_world_colliders(
         } break;
     }
     wShape[3 * k] = o0; wShape[3 * k + 1] = o1; wShape[3 * k + 2] = o2;
-    aabbMin[k] = f4(mn, __uint_as_float(wtype | (objType << 8)));
-    aabbMax[k] = f4(mx, __uint_as_float(objIndex));
+    mnOut = f4(mn, __uint_as_float(wtype | (objType << 8)));
+    mxOut = f4(mx, __uint_as_float(objIndex));
+    aabbMin[k] = mnOut; aabbMax[k] = mxOut;
+}
+__global__ __launch_bounds__(256) void k_world_colliders(
+    uint32_t nc, uint32_t nb, const uint32_t* __restrict__ cTypeBody, const uint32_t* __restrict__ cObject,
+    const float4* __restrict__ cShape, const float4* __restrict__ cStaticPos, const float4* __restrict__ cStaticRot,
+    const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ hullAabb,
+    float4* __restrict__ wShape, float4* __restrict__ aabbMin, float4* __restrict__ aabbMax, StepScalars* sc, uint32_t axisCur,
+    const uint8_t* __restrict__ bodyActive, const uint8_t* __restrict__ bodyActivePrev,
+    const uint32_t* __restrict__ axisDev /* sharded world: the sweep axis lives on the device (k_shard_axis, from the sums over all ranks), or null */) {
+    uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k == 0) { sc->axisCur = axisDev ? *axisDev : axisCur; }   // the SAP axis chosen at the end of the previous (successful) step
+    if (k >= nc) return;
+    float4 mn, mx;
+    worldCollider(k, nb, cTypeBody, cObject, cShape, cStaticPos, cStaticRot, bPos, bRot, hullAabb, wShape, aabbMin, aabbMax, bodyActive, bodyActivePrev, mn, mx);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,19 +409,28 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
                                                     unsigned long long* __restrict__ partials, Shards* sh, StepScalars* sc, uint32_t* __restrict__ largeList, uint32_t* __restrict__ isLarge,
                                                     int* __restrict__ blockBounds, uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks, uint32_t* __restrict__ cellCount,
                                                     const uint8_t* __restrict__ bodyActivePrev /* sharded world: the previous step's body flags, or null */,
-                                                    const uint8_t* __restrict__ bodyActive /* sharded world: this step's body flags, or null */, uint32_t countUnowned) {
+                                                    const uint8_t* __restrict__ bodyActive /* sharded world: this step's body flags, or null */, uint32_t countUnowned,
+                                                    // FUSED with k_world_colliders (cTypeBody non-null): the lane computes its collider's world shape and AABB first and goes on
+                                                    // with them in registers — one launch and one pass over the AABB rows less (the grid it classifies against is the previous step's)
+                                                    uint32_t nb, const uint32_t* __restrict__ cTypeBody, const uint32_t* __restrict__ cObject, const float4* __restrict__ cShape,
+                                                    const float4* __restrict__ cStaticPos, const float4* __restrict__ cStaticRot, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
+                                                    const float4* __restrict__ hullAabb, float4* __restrict__ wShape, float4* __restrict__ aabbMinW, float4* __restrict__ aabbMaxW,
+                                                    uint32_t axisCur, const uint32_t* __restrict__ axisDev) {
     __shared__ unsigned long long sm[4][kAxisSums];
     __shared__ uint32_t hist[256];
     __shared__ int sb[4][6];
     hist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    if (cTypeBody && i == 0) { sc->axisCur = axisDev ? *axisDev : axisCur; }
     const GridParams g = *gp;
     unsigned long long v[kAxisSums];
     int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
     bool dead = false, counted = false; float cx = 0.f, cy = 0.f, cz = 0.f;
     if (i < nc) {
-        const float4 mn = aabbMin[i], mx = aabbMax[i];
+        float4 mn, mx;
+        if (cTypeBody) worldCollider(i, nb, cTypeBody, cObject, cShape, cStaticPos, cStaticRot, bPos, bRot, hullAabb, wShape, aabbMinW, aabbMaxW, bodyActive, bodyActivePrev, mn, mx);
+        else { mn = aabbMin[i]; mx = aabbMax[i]; }
         cx = (mn.x + mx.x) * 0.5f; cy = (mn.y + mx.y) * 0.5f; cz = (mn.z + mx.z) * 0.5f;
         counted = axisCounted(mn, mx, bodyActive, countUnowned);
         const float ext = fmaxr(fmaxr(mx.x - mn.x, mx.y - mn.y), mx.z - mn.z);
@@ -748,35 +770,12 @@ __host__ __device__ __forceinline__ int gjkMode(uint32_t ta, uint32_t tb);
 __host__ __device__ __forceinline__ int gjkModeOfBucket(uint32_t bucket);
 // One workgroup after the pair pass: the sharded counters summed (k_pair_totals), the bucket offsets / GJK span / "partition needed"
 // (formerly k_pair_ranges) and — with `partials` — the next sweep axis (formerly k_axis_final): three single-workgroup launches in one.
-__global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound, uint32_t nc, uint32_t numBlocks, const unsigned long long* __restrict__ partials,
-                                                     const int* __restrict__ blockBounds, GridParams* gridNext /* the NEXT step's grid (null: not wanted) */, uint32_t cellCapNext,
-                                                     uint32_t allowPartition /* 0: k_pair_partition is not going to run in this step */) {
+// The part of the pair stage that nothing in the rest of the step waits for: the centre statistics -> next sweep axis, and the NEXT step's grid (threshold,
+// cell size, origin, dims) from this step's extent histogram and centre bounds.  One workgroup of 256; it used to be the tail of k_pair_finish, i.e. ~10 us
+// of single-workgroup work on the step's critical path — now an extra workgroup of k_emit_manifolds runs it beside that kernel's thousands.
+__device__ inline void pairFinishStats(const Shards* __restrict__ sh, StepScalars* sc, uint32_t nc, uint32_t numBlocks, const unsigned long long* __restrict__ partials,
+                                       const int* __restrict__ blockBounds, GridParams* gridNext, uint32_t cellCapNext) {
     const uint32_t t = threadIdx.x;
-    if (t < 64u) {   // wave 0
-        if (t == 0 && sc->numPairs > pairBound) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; }
-        uint32_t v = 0;
-        if (t < kNumBuckets) { for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].bucketHist[t]; sc->bucketHist[t] = v; }
-        if (t == 31) { uint32_t o = 0; for (uint32_t k = 0; k < kShards; ++k) o += sh->c[k].numOverlaps; sc->numOverlaps = o; }
-        uint32_t off = 0, nonEmpty = 0, lo = 0xFFFFFFFFu, hi = 0, largest = 0;
-        for (uint32_t bk = 0; bk < kNumBuckets; ++bk) {   // every lane walks the buckets (the counts come over by shuffle), lane 0 writes
-            const uint32_t n = (uint32_t)__shfl((int)v, (int)bk, 64);
-            if (t == 0) sc->bucketOffset[bk] = off;
-            if (n) { ++nonEmpty; largest = max(largest, n); if (gjkModeOfBucket(bk) >= 0) { lo = min(lo, off); hi = max(hi, off + n); } }
-            off += n;
-        }
-        // the partition exists to make narrow-phase waves type-uniform and to give the GJK kernel its span; when nearly every pair is of
-        // ONE type (a box pile: box-box, plus the boxes on the ground) it only costs (a pass over the keys + a reservation per workgroup):
-        // partition if a GJK bucket is populated or more than an eighth of the pairs lies outside the largest bucket
-        if (t == 0) {
-            sc->gjkLo = hi > lo ? lo : 0u; sc->gjkHi = hi > lo ? hi : 0u;
-            const uint32_t want = (nonEmpty > 1u && (hi > lo || (off - largest) * 8u > off)) ? 1u : 0u;
-            sc->partitioned = want;
-            // a speculative step that left k_pair_partition out (its predecessor did not partition) must not go on with a partitioned list that was never
-            // written: everything downstream becomes a no-op, the step is invalid as a whole and is re-run
-            if (want && !allowPartition) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; sc->partitioned = 0u; sc->gjkLo = sc->gjkHi = 0u; }
-        }
-    }
-    if (!partials) return;
     __shared__ unsigned long long sm[4][kAxisSums];
     unsigned long long v[kAxisSums];
 #pragma unroll
@@ -855,6 +854,38 @@ __global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ 
     unsigned long long s9[kAxisSums];
     for (uint32_t c = 0; c < kAxisSums; ++c) { s9[c] = sm[0][c] + sm[1][c] + sm[2][c] + sm[3][c]; sc->axisSums[c] = s9[c]; }
     sc->axisNext = axisFromSums(s9, nc);   // (sharded world: from this rank's own sums — the exchange replaces it by the axis of the sums over all ranks)
+}
+__global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound, uint32_t nc, uint32_t numBlocks, const unsigned long long* __restrict__ partials,
+                                                     const int* __restrict__ blockBounds, GridParams* gridNext /* the NEXT step's grid (null: not wanted) */, uint32_t cellCapNext,
+                                                     uint32_t allowPartition /* 0: k_pair_partition is not going to run in this step */,
+                                                     uint32_t doStats /* 0: an extra workgroup of k_emit_manifolds runs pairFinishStats */) {
+    const uint32_t t = threadIdx.x;
+    if (t < 64u) {   // wave 0
+        if (t == 0 && sc->numPairs > pairBound) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; }
+        uint32_t v = 0;
+        if (t < kNumBuckets) { for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].bucketHist[t]; sc->bucketHist[t] = v; }
+        if (t == 31) { uint32_t o = 0; for (uint32_t k = 0; k < kShards; ++k) o += sh->c[k].numOverlaps; sc->numOverlaps = o; }
+        uint32_t off = 0, nonEmpty = 0, lo = 0xFFFFFFFFu, hi = 0, largest = 0;
+        for (uint32_t bk = 0; bk < kNumBuckets; ++bk) {   // every lane walks the buckets (the counts come over by shuffle), lane 0 writes
+            const uint32_t n = (uint32_t)__shfl((int)v, (int)bk, 64);
+            if (t == 0) sc->bucketOffset[bk] = off;
+            if (n) { ++nonEmpty; largest = max(largest, n); if (gjkModeOfBucket(bk) >= 0) { lo = min(lo, off); hi = max(hi, off + n); } }
+            off += n;
+        }
+        // the partition exists to make narrow-phase waves type-uniform and to give the GJK kernel its span; when nearly every pair is of
+        // ONE type (a box pile: box-box, plus the boxes on the ground) it only costs (a pass over the keys + a reservation per workgroup):
+        // partition if a GJK bucket is populated or more than an eighth of the pairs lies outside the largest bucket
+        if (t == 0) {
+            sc->gjkLo = hi > lo ? lo : 0u; sc->gjkHi = hi > lo ? hi : 0u;
+            const uint32_t want = (nonEmpty > 1u && (hi > lo || (off - largest) * 8u > off)) ? 1u : 0u;
+            sc->partitioned = want;
+            // a speculative step that left k_pair_partition out (its predecessor did not partition) must not go on with a partitioned list that was never
+            // written: everything downstream becomes a no-op, the step is invalid as a whole and is re-run
+            if (want && !allowPartition) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; sc->partitioned = 0u; sc->gjkLo = sc->gjkHi = 0u; }
+        }
+    }
+    if (!partials || !doStats) return;
+    pairFinishStats(sh, sc, nc, numBlocks, partials, blockBounds, gridNext, cellCapNext);
 }
 __global__ __launch_bounds__(256) void k_pair_partition(const uint64_t* __restrict__ in, uint64_t* __restrict__ out, StepScalars* sc) {
     __shared__ uint32_t cnt[32], base[32];
@@ -983,10 +1014,12 @@ constexpr uint32_t kBoxQueues = 16;
 __global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queueRegion, StepScalars* sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                 const float4* __restrict__ wShape,
                                                 HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
-                                                float4* __restrict__ npPoints, BoxHit* __restrict__ boxQueue) {
+                                                float4* __restrict__ npPoints, BoxHit* __restrict__ boxQueue,
+                                                ulonglong2* __restrict__ clearTab /* the NEXT step's colour history, cleared here on the side (was a launch of its own) */, uint32_t clearSlots) {
     __shared__ BoxHit hits[256];
     __shared__ uint32_t numHits, queueBase;
     if (threadIdx.x == 0) numHits = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < clearSlots; i += gridDim.x * blockDim.x) clearTab[i] = make_ulonglong2(0ull, 0ull);
     __syncthreads();
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t numPairs = sc->numPairs;
@@ -1097,7 +1130,8 @@ __device__ __forceinline__ uint32_t tableLookup(const HistSlot* __restrict__ tab
 }
 __device__ __forceinline__ void tableInsert(HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, uint32_t val) {
     for (uint32_t s = tableSlot(key, mask), n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
-        if (atomicCAS(&tab[s].key, 0ull, (unsigned long long)key) == 0ull) { tab[s].val = val; return; }   // (the colour is read in the NEXT step only)
+        const unsigned long long old = atomicCAS(&tab[s].key, 0ull, (unsigned long long)key);
+        if (old == 0ull || old == key) { tab[s].val = val; return; }   // (the colour is read in the NEXT step only; the same key again — a schedule built twice in a synchronous step — overwrites)
     }
 }
 __global__ __launch_bounds__(256) void k_color_table_insert(uint32_t nc, const StepScalars* __restrict__ sc, const uint32_t* __restrict__ manPair,
@@ -1173,7 +1207,10 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
                                                         const HistSlot* __restrict__ prevTab, uint32_t prevMask,
                                                         unsigned long long* __restrict__ bodyUsed, uint8_t* __restrict__ isNew, StepScalars* sc,
                                                         float2 terrainMaterial /* (restitution, friction) of the heightmap */,
-                                                        HistSlot* __restrict__ nextTab, uint32_t nextMask, uint8_t* __restrict__ manKept) {
+                                                        HistSlot* __restrict__ nextTab, uint32_t nextMask, uint8_t* __restrict__ manKept,
+                                                        const Shards* __restrict__ statsShards /* non-null: the LAST workgroup runs pairFinishStats instead */, uint32_t statsBlocks,
+                                                        const unsigned long long* __restrict__ statsPartials, const int* __restrict__ statsBounds, GridParams* statsGridNext, uint32_t statsCellCap) {
+    if (statsShards && blockIdx.x == gridDim.x - 1u) { pairFinishStats(statsShards, sc, nc, statsBlocks, statsPartials, statsBounds, statsGridNext, statsCellCap); return; }
     uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t numPairs = sc->numPairs;
     if (p >= numPairs) return;
@@ -1632,6 +1669,94 @@ __global__ __launch_bounds__(256) void k_fill_tiles(const StepScalars* __restric
     tileDesc[t] = make_uint2(bi.ctStart + tl * stride, stride);
     if (xcdTiles) {
         const uint32_t at = xcdBase[lo * 8u + x] + tileOwnerRank(tl, nt, lo, xcdSingle);
+        if (at < listCap) { xcdTiles[(size_t)x * listCap + at] = t; xcdInfo[(size_t)x * listCap + at] = info; }   // (a longer list is reported by the solver kernel: solveError 2)
+    }
+}
+
+// k_bin_scatter + k_color_table_insert + k_build_tiles + k_fill_tiles in ONE launch (each was a 5-10 us launch doing ~1 us of work, one behind the
+// other): workgroups [0, numBlocks) scatter their manifolds into the schedule slots and enter the newly coloured ones into the next step's colour
+// history; workgroups [numBlocks, ...) turn the bins into tiles — every one of them derives the bin table itself (257 bins: three wave scans, from the
+// first column of the block scan, i.e. without waiting for the scatter) and then fills its 256 tiles; the first of them also publishes the table.
+__global__ __launch_bounds__(256) void k_schedule_finish(uint32_t lastRound, const uint32_t* __restrict__ roundFlags, uint32_t numBlocks, const uint32_t* __restrict__ perm,
+                                                         const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo, const uint32_t* __restrict__ blockHist,
+                                                         const uint32_t* __restrict__ blockScan, uint32_t* __restrict__ order, StepScalars* sc,
+                                                         uint32_t nc, const uint32_t* __restrict__ manPair, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
+                                                         HistSlot* __restrict__ tab, uint32_t tabMask, const uint8_t* __restrict__ manKept,
+                                                         uint32_t tilesCap, uint32_t ctCap, BinInfo* __restrict__ binInfo, uint32_t* __restrict__ xcdBase /* [kSchedBins][8] or null */, uint32_t xcdSingle,
+                                                         uint4* __restrict__ tileInfo, uint2* __restrict__ tileDesc, uint32_t* __restrict__ xcdTiles /* [8][listCap] or null */, uint4* __restrict__ xcdInfo, uint32_t listCap) {
+    __shared__ uint32_t cur[kColorBins + 4];
+    if (blockIdx.x < numBlocks) {   // ---- scatter (k_bin_scatter) + history insert (k_color_table_insert)
+        const uint32_t nm = sc->numManifolds;
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc->colorPending = roundFlags[lastRound];
+        for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) {
+            uint32_t v = blockScan[(size_t)b * numBlocks + blockIdx.x];
+            cur[b] = v;
+            if (blockIdx.x == 0) sc->binStart[b] = v;
+        }
+        __syncthreads();
+        const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
+#pragma unroll
+        for (uint32_t k = 0; k < kBinItems / 256; ++k) {
+            uint32_t m = blockIdx.x * kBinItems + k * 256 + threadIdx.x;
+            if (perm && m < nm) m = perm[m];
+            if (m < nm) {
+                const uint32_t c = color[m];
+                if (c <= kOverflowColor) order[atomicAdd(&cur[binOf(c, manInfo[m].x & 7u)], 1u)] = m;
+                if (!manKept[m]) {      // kept colours were entered by k_emit_manifolds
+                    const uint64_t pk = pairKeys[manPair[m]];
+                    tableInsert(tab, tabMask, historyKey(nc, (uint32_t)((pk >> 29) & 0x1FFFFFFFull), (uint32_t)(pk & 0x1FFFFFFFull)), c);
+                }
+            }
+        }
+        __syncthreads();
+        if (blockIdx.x == numBlocks - 1 && threadIdx.x == 0) sc->binStart[kColorBins] = cur[kColorBins - 1];   // = the number of SCHEDULED manifolds (see k_bin_scatter)
+        return;
+    }
+    // ---- bins -> tiles (k_build_tiles, by every workgroup for itself) + the tile tables (k_fill_tiles)
+    __shared__ BinInfo bins[kSchedBins];
+    __shared__ uint32_t totals[2];
+    __shared__ uint32_t xb[kSchedBins * 8u];
+    const uint32_t tb = blockIdx.x - numBlocks;      // tile workgroup
+    for (uint32_t b = threadIdx.x; b < kColorBins; b += blockDim.x) cur[b] = blockScan[(size_t)b * numBlocks];
+    if (threadIdx.x == 0) { const size_t lastEl = (size_t)(kColorBins - 1u) * numBlocks + (numBlocks - 1u); cur[kColorBins] = blockScan[lastEl] + blockHist[lastEl]; }   // end of the last bin
+    __syncthreads();
+    for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) {
+        const bool ovf = bn == kSchedBins - 1;
+        bins[bn].slotStart = cur[bn]; bins[bn].count = (ovf ? cur[kColorBins] : cur[bn + 1]) - cur[bn];
+    }
+    __syncthreads();
+    const uint32_t wave = threadIdx.x >> 6;
+    auto tilesOf = [&](uint32_t bn) { return (bins[bn].count + 63u) >> 6; };
+    if (wave == 0) { uint32_t t = waveExclusiveScan(kSchedBins, tilesOf, [&](uint32_t bn, uint32_t v) { bins[bn].tileStart = v; }); if ((threadIdx.x & 63u) == 0) totals[0] = t; }
+    if (wave == 1) { uint32_t t = waveExclusiveScan(kSchedBins, [&](uint32_t bn) { return tilesOf(bn) * (bn == kSchedBins - 1 ? 4u : (bn & 3u) + 1u); },
+                                                    [&](uint32_t bn, uint32_t v) { bins[bn].ctStart = v; }); if ((threadIdx.x & 63u) == 0) totals[1] = t; }
+    __syncthreads();
+    const bool ok = totals[0] <= tilesCap && totals[1] <= ctCap;
+    if (xcdTiles) {
+        for (uint32_t x = 2u * wave; x < 2u * wave + 2u; ++x) {
+            uint32_t t = waveExclusiveScan(kSchedBins, [&](uint32_t bn) { return tileOwnerCount(x, tilesOf(bn), bn, xcdSingle); }, [&](uint32_t bn, uint32_t v) { xb[bn * 8u + x] = v; });
+            if (tb == 0 && (threadIdx.x & 63u) == 0) sc->xcdCount[x] = ok && totals[0] ? t : 0u;
+        }
+    }
+    if (tb == 0) {      // publish the table (the host mirrors binStart; the per-colour fallback kernels read binInfo)
+        if (threadIdx.x == 0) { sc->totalTiles = ok ? totals[0] : 0u; sc->totalCt = ok ? totals[1] : 0u; if (!ok) sc->specOverflow = 1u; }
+        for (uint32_t bn = threadIdx.x; bn < kSchedBins; bn += blockDim.x) binInfo[bn] = bins[bn];
+    }
+    __syncthreads();
+    if (tb == 0 && xcdBase && xcdTiles) for (uint32_t i = threadIdx.x; i < kSchedBins * 8u; i += blockDim.x) xcdBase[i] = xb[i];
+    const uint32_t t = tb * blockDim.x + threadIdx.x;
+    if (!ok || t >= totals[0]) return;
+    uint32_t lo = 0, hi = kSchedBins - 1;   // last bin whose first tile is <= t (empty bins share a first tile with their successor)
+    while (lo < hi) { uint32_t mid = (lo + hi + 1u) >> 1; if (bins[mid].tileStart <= t) lo = mid; else hi = mid - 1u; }
+    const BinInfo bi = bins[lo];
+    const uint32_t stride = lo == kSchedBins - 1 ? 4u : (lo & 3u) + 1u;
+    const uint32_t tl = t - bi.tileStart, nt = (bi.count + 63u) >> 6;
+    const uint32_t x = xcdTiles ? tileOwner(tl, nt, lo, xcdSingle) : 0u;
+    const uint4 info = make_uint4(t, bi.slotStart + tl * 64u, min(64u, bi.count - tl * 64u) | (stride << 8) | (x << 12), bi.ctStart + tl * stride);
+    tileInfo[t] = info;
+    tileDesc[t] = make_uint2(bi.ctStart + tl * stride, stride);
+    if (xcdTiles) {
+        const uint32_t at = xb[lo * 8u + x] + tileOwnerRank(tl, nt, lo, xcdSingle);
         if (at < listCap) { xcdTiles[(size_t)x * listCap + at] = t; xcdInfo[(size_t)x * listCap + at] = info; }   // (a longer list is reported by the solver kernel: solveError 2)
     }
 }

@@ -960,7 +960,17 @@ enqueue_section:
         if (!shard.prevValid) { HIP_TRY(L.memsetAsync(shard.activePrev.p, 1, nb, st)); if (!L.dry) shard.prevValid = true; }   // after an upload / an outside write: every body is copied once
         L.launch(k_shard_classify, dim3(divUp(nb, B)), dim3(B), 0, st, nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, shards.p, shard.root.p, shard.known.p);
     }
+    // with a grid prepared by the previous step the world colliders are computed INSIDE k_bp_prepare (one launch, one pass over the AABB rows less)
+    static const bool fuseWorldEnabled = !(std::getenv("MI_FUSE_WORLD") && std::getenv("MI_FUSE_WORLD")[0] == '0');
+    const bool fuseWorld = nc && gridValid && fuseWorldEnabled;
+    bool prepared = false;
     if (nc) {
+        if (fuseWorld) {   // (the cell histogram is all zero here: cleared once at upload, and every scan clears the cells it has read)
+            L.launch(k_bp_prepare, dim3(divUp(nc, 256)), dim3(256), 0, st, nc, aabbMin.p, aabbMax.p, grid.p + gridCur, axisPartials.p, shards.p, sc, largeList.p, isLarge.p, blockBounds.p, cellKeys.p, cellRanks.p, cellCount.p,
+                     shard.enabled ? shard.activePrev.p : nullptr, shard.enabled ? shard.active.p : nullptr, shard.enabled && shard.desc.rank != 0u ? 0u : 1u,
+                     nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p, wShape.p, aabbMin.p, aabbMax.p, sapAxis, shard.enabled ? shard.axisDev.p : nullptr);
+            prepared = true;
+        } else
         L.launch(k_world_colliders, dim3(divUp(nc, B)), dim3(B), 0, st, nc, nb, cTypeBody.p, cObject.p, cShape.p, cStaticPos.p, cStaticRot.p, bPos.p, bRot.p, hullAabb.p,
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis, shard.enabled ? shard.active.p : nullptr, shard.activePrev.p, shard.enabled ? shard.axisDev.p : nullptr);
         if (heightmap) {   // terrain contacts per collider, their offsets and totals (they join the pair list after the collider-pair narrow phase)
@@ -974,16 +984,20 @@ enqueue_section:
     mark();  // 1
     // ---------------------------------------------------------------------------------------------- broad phase
     uint32_t pairBound = 0;   // upper bound of this step's collision pairs that launches / scans are sized for
+    GridParams* statsGridNext = nullptr; uint32_t statsCellCap = 0, statsBlocks = 0;   // (speculative steps: pairFinishStats runs beside k_emit_manifolds)
     if (nc) {
         uint32_t nblk = divUp(nc, 256);
         // the cell table (histogram + scan) covers cellCap cells; k_bp_grid_setup enlarges the cells if the grid would need more
         const uint32_t cellCapNext = std::min<uint32_t>(kMaxCells, std::max<uint32_t>(1u << 16, 4u * nc));
         const uint32_t cellCap = gridValid ? (lastCellCap = std::min<uint32_t>(kMaxCells, (lastCellCap > gridNextCells && lastCellCap - gridNextCells <= 8192u) ? lastCellCap : ((gridNextCells + 1u + 4095u) & ~4095u))) : spec ? std::min<uint32_t>(kMaxCells, std::max<uint32_t>(1u << 16, 2u * last.numCells)) : kMaxCells;
         GridParams* gridUse = grid.p + gridCur; GridParams* gridNext = grid.p + (gridCur ^ 1u);
-        if (gridValid) {
+        statsGridNext = gridNext; statsCellCap = cellCapNext; statsBlocks = nblk;
+        if (prepared) {}   // k_bp_prepare ran with the world colliders
+        else if (gridValid) {
             // the grid prepared at the end of the previous step (k_pair_finish): one fused kernel instead of five launches; the cell histogram
             // is all zero here (cleared once at upload, and every scan clears the cells it has read)
-            L.launch(k_bp_prepare, dim3(nblk), dim3(256), 0, st, nc, aabbMin.p, aabbMax.p, gridUse, axisPartials.p, shards.p, sc, largeList.p, isLarge.p, blockBounds.p, cellKeys.p, cellRanks.p, cellCount.p, shard.enabled ? shard.activePrev.p : nullptr, shard.enabled ? shard.active.p : nullptr, shard.enabled && shard.desc.rank != 0u ? 0u : 1u);
+            L.launch(k_bp_prepare, dim3(nblk), dim3(256), 0, st, nc, aabbMin.p, aabbMax.p, gridUse, axisPartials.p, shards.p, sc, largeList.p, isLarge.p, blockBounds.p, cellKeys.p, cellRanks.p, cellCount.p, shard.enabled ? shard.activePrev.p : nullptr, shard.enabled ? shard.active.p : nullptr, shard.enabled && shard.desc.rank != 0u ? 0u : 1u,
+                     nb, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0u, nullptr);
         } else {
             L.launch(k_axis_partials, dim3(nblk), dim3(256), 0, st, nc, aabbMin.p, aabbMax.p, axisPartials.p, shards.p, shard.enabled ? shard.active.p : nullptr, shard.enabled && shard.desc.rank != 0u ? 0u : 1u);
             L.launch(k_bp_threshold, dim3(1), dim3(256), 0, st, nc, shards.p, sc);
@@ -1010,7 +1024,7 @@ enqueue_section:
             static const bool skipPartitionEnabled = !(std::getenv("MI_SKIP_PARTITION") && std::getenv("MI_SKIP_PARTITION")[0] == '0');
             skippedPartition = spec && skipPartitionEnabled && havePartitionFlag && !lastPartitioned;
             L.launch(k_pair_finish, dim3(1), dim3(256), 0, st, shards.p, sc, spec ? std::min(cap, bound(last.numPairs, 4096)) : 0xFFFFFFFFu, nc, nblk, attempt == 0 ? axisPartials.p : nullptr, blockBounds.p, attempt == 0 ? gridNext : nullptr, cellCapNext,
-                     skippedPartition ? 0u : 1u);
+                     skippedPartition ? 0u : 1u, spec ? 0u : 1u /* speculative: an extra workgroup of k_emit_manifolds does the statistics, off the critical path */);
             if (spec) { pairBound = std::min(cap, bound(last.numPairs, 4096)); break; }
             int rc = readScalars(); if (rc != MI_OK) return rc;
             pairBound = hs.numPairs + hs.numHmContacts;   // the terrain contacts are appended to the pair list after the narrow phase
@@ -1034,7 +1048,16 @@ enqueue_section:
         const uint32_t narrowBlocks = divUp(pairBound, B);
         const uint32_t queueRegion = divUp(narrowBlocks, kBoxQueues) * B;   // a queue can hold every pair of the workgroups that feed it
         HIP_TRY(boxQueue.ensure((size_t)kBoxQueues * queueRegion));
-        L.launch(k_narrow, dim3(narrowBlocks), dim3(B), 0, st, pairBound, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p, boxQueue.p);
+        uint32_t histCap = 1024;
+        {   // the NEXT step's colour history: sized here, cleared by k_narrow on the side (k_emit_manifolds already enters the manifolds that keep their colour)
+            const uint32_t histBound = spec ? std::min(pairBound, bound(last.numManifolds, 1024)) : pairBound;
+            const int nt = tabCur ^ 1;
+            while (histCap < 2u * histBound) histCap <<= 1;
+            HIP_TRY(tab[nt].ensure(histCap)); HIP_TRY(manKept.ensure(pairBound));
+            tabMask[nt] = histCap - 1u;
+        }
+        L.launch(k_narrow, dim3(narrowBlocks), dim3(B), 0, st, pairBound, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, hset, npPacked.p, npNormal.p, npPoints.p, boxQueue.p,
+                 reinterpret_cast<ulonglong2*>(tab[tabCur ^ 1].p), histCap);
         L.launch(k_narrow_clip, dim3(kBoxQueues * (queueRegion / B)), dim3(B), 0, st, queueRegion, sc, pairKeys.p, pairKeysS.p, wShape.p, boxQueue.p, npPacked.p, npNormal.p, npPoints.p);
         // (a GJK-only kernel feeding a queue of hits to an EPA kernel was measured: no gain — the GJK half already needs ~250 VGPRs)
         if (usesGjk) {
@@ -1056,19 +1079,13 @@ enqueue_section:
         }
         HIP_TRY(scanPairs.run(L, reinterpret_cast<unsigned long long*>(npPacked.p), reinterpret_cast<unsigned long long*>(npScan.p), pairBound, st));
         if (eventsEnabled) HIP_TRY(manIsNew.ensure(pairBound));
-        {   // the NEXT step's colour history: sized and cleared before k_emit_manifolds, which already enters the manifolds that keep their colour
-            const uint32_t histBound = spec ? std::min(pairBound, bound(last.numManifolds, 1024)) : pairBound;
-            const int nt = tabCur ^ 1;
-            uint32_t cap = 1024; while (cap < 2u * histBound) cap <<= 1;
-            HIP_TRY(tab[nt].ensure(cap)); HIP_TRY(manKept.ensure(pairBound));
-            tabMask[nt] = cap - 1u;
-            HIP_TRY(L.memsetAsync(tab[nt].p, 0, (size_t)cap * sizeof(HistSlot), st));
-        }
-        L.launch(k_emit_manifolds, dim3(divUp(pairBound, B)), dim3(B), 0, st, nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, cEmit.p,
+        const bool statsInEmit = spec && statsGridNext != nullptr;   // (a synchronous step: k_pair_finish did it)
+        L.launch(k_emit_manifolds, dim3(divUp(pairBound, B) + (statsInEmit ? 1u : 0u)), dim3(B), 0, st, nc, nb, pairKeys.p, pairKeysS.p, npPacked.p, npScan.p, cEmit.p,
                                                         manPair.p, manBodies.p, manInfo.p, colWork.p, color.p,
                                                         tabValid ? tab[tabCur].p : nullptr, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc,
                                                         heightmap ? make_float2(hmParams.restitution, hmParams.friction) : make_float2(0.f, 0.f),
-                                                        tab[tabCur ^ 1].p, tabMask[tabCur ^ 1], manKept.p);
+                                                        tab[tabCur ^ 1].p, tabMask[tabCur ^ 1], manKept.p,
+                                                        statsInEmit ? shards.p : nullptr, statsBlocks, axisPartials.p, blockBounds.p, statsGridNext, statsCellCap);
         if (shard.enabled) L.launch(k_shard_count, dim3(divUp(pairBound, B)), dim3(B), 0, st, nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc, shards.p);
     }
     // ---------------------------------------------------------------------------------------------- triggers / force fields
@@ -1096,7 +1113,10 @@ enqueue_section:
     const bool xcdSingle = xcdAble && persistXcdSingle && nmBound && nmBound < xcdMinManifolds && divUp(divUp(nmBound, 64) + kSchedBins + 8, persistWaves / 8u) <= 16u;
     const bool xcdPlan = xcdAble && (nmBound >= xcdMinManifolds || xcdSingle);
     static const uint32_t colorMargin = std::getenv("MI_COLOR_MARGIN") ? (uint32_t)atoi(std::getenv("MI_COLOR_MARGIN")) : 3u;   // extra rounds enqueued beyond the previous step's count
-    uint32_t colorBatch = spec ? std::min<uint32_t>(96u, (last.colorRounds + std::max(colorMargin, last.colorRounds / 4u) + 3u) & ~3u) : 20u;   // converged rounds exit at once; a multiple of 4: the same launches step after step
+    // converged rounds exit at once, but every enqueued round costs its launch slot (~4.6 us): a scene that replays its steps as graphs wants the same
+    // launches step after step (a multiple of 4), a large one exactly what the previous step needed plus the margin
+    uint32_t colorBatch = !spec ? 20u : graphStep ? std::min<uint32_t>(96u, (last.colorRounds + std::max(colorMargin, last.colorRounds / 4u) + 3u) & ~3u)
+                                                  : std::min<uint32_t>(96u, last.colorRounds + std::max(colorMargin, last.colorRounds / 4u));
     if (nmBound) {
         tilesCap = divUp(nmBound, 64) + kSchedBins + 8; ctCap = divUp(conBound, 64) + 4 * kSchedBins + 8;
         const uint32_t binBlocks = divUp(nmBound, kBinItems);
@@ -1123,9 +1143,12 @@ enqueue_section:
             // schedule bins -> tiles (valid once the last round left nothing uncoloured: StepScalars::colorPending)
             L.launch(k_bin_hist, dim3(binBlocks), dim3(256), 0, st, sc, binBlocks, perm, color.p, manInfo.p, blockHist.p);
             HIP_TRY(scanBins.run(L, blockHist.p, blockScan.p, kColorBins * binBlocks, st));
-            L.launch(k_bin_scatter, dim3(binBlocks), dim3(256), 0, st, round - 1, roundFlagsPtr(), binBlocks, perm, color.p, manInfo.p, blockScan.p, order.p, sc);
-            L.launch(k_build_tiles, dim3(1), dim3(256), 0, st, tilesCap, ctCap, sc, binInfo.p, xcdPlan ? xcdBase.p : nullptr, xcdSingle ? 1u : 0u);
-            L.launch(k_fill_tiles, dim3(divUp(tilesCap, B)), dim3(B), 0, st, sc, binInfo.p, tileInfo.p, tileDesc.p, xcdBase.p, xcdPlan ? xcdTiles.p : nullptr, xcdInfo.p, xcdListCap, xcdSingle ? 1u : 0u);
+            {   // slots, colour history of the new manifolds, bins -> tiles, tile tables: one launch (k_schedule_finish)
+                const int ntab = tabCur ^ 1;   // the NEXT step's colour history (sized and cleared in the narrow-phase stage; current only if this step turns out valid)
+                L.launch(k_schedule_finish, dim3(binBlocks + divUp(tilesCap, B)), dim3(256), 0, st, round - 1, roundFlagsPtr(), binBlocks, perm, color.p, manInfo.p, blockHist.p, blockScan.p, order.p, sc,
+                         nc, manPair.p, pairKeys.p, pairKeysS.p, tab[ntab].p, tabMask[ntab], manKept.p,
+                         tilesCap, ctCap, binInfo.p, xcdPlan ? xcdBase.p : nullptr, xcdSingle ? 1u : 0u, tileInfo.p, tileDesc.p, xcdPlan ? xcdTiles.p : nullptr, xcdInfo.p, xcdListCap);
+            }
             if (spec) break;
             int rc = readScalars(); if (rc != MI_OK) return rc;
             if (hs.colorPending == 0) break;
@@ -1135,7 +1158,6 @@ enqueue_section:
         colorRoundsLaunched = round;
         {   // colour history for the next step, into the OTHER table (it becomes current only if this step turns out valid)
             const int nt = tabCur ^ 1;   // sized and cleared before k_emit_manifolds (narrow phase stage)
-            L.launch(k_color_table_insert, dim3(divUp(nmBound, B)), dim3(B), 0, st, nc, sc, manPair.p, pairKeys.p, pairKeysS.p, color.p, tab[nt].p, tabMask[nt], manKept.p);
             if (eventsEnabled) {   // begins: manifolds not in the previous table; ends: previous pairs not in this step's table
                 eventCap = nmBound + (tabValid ? last.numManifolds : 0u) + 1024u;
                 HIP_TRY(devEvents.ensure(eventCap));
