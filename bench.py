@@ -267,6 +267,7 @@ def main():
     mode0 = sw.world.step_mode_stats()
     elapsed, step_ms, stage_acc, contact_iters = timed_region(sw, settings, dt, args.steps, barrier)
     mode1 = sw.world.step_mode_stats()
+    ex_timed = sw.world.shard_exchange_stats() if world_size > 1 else None     # (the exchanges of exactly the timed steps)
     solve_ms = stage_acc["solve"]; total_dev_ms = stage_acc["total"]
     launches = sw.world.solve_launches() * args.steps
     counts = sw.world.counts()
@@ -304,7 +305,7 @@ def main():
     per_rank = None
     if dist is not None:
         # what explains a scaling curve: every rank's own clock, solver roofline, exchange cost and what it moved (gathered on rank 0)
-        ex = sw.world.shard_exchange_stats()
+        ex = ex_timed
         lc = sw.world.counts()
         l_launches = max(sw.world.solve_launches() * args.steps, 1)
         l_solve_s = stage_acc["solve"] * 1e-3 / l_launches

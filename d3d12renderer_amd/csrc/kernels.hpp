@@ -669,6 +669,10 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
     }
 }
 
+// (Measured and not kept, round 3: the candidate rows of a workgroup's column staged in LDS — its colliders are consecutive in the cell-sorted order, so
+// the union of their candidate ranges is one contiguous span; 32 KiB for 1024 rows, every lane then walks its own range in LDS.  The kernel waits on
+// L2 round trips (15 % of its cycles issue, 91 % L2 hits: profiles/r03_pmc_kernels.json), but per-lane 16-byte LDS reads at unrelated addresses
+// conflict and the 48 KiB cut the occupancy from 5 to 3 workgroups per CU: 55 -> 115 us.)
 // Large colliders against everything: (large l) x (all colliders), grid-strided.  Large-large pairs
 // are emitted once (from the lower index).
 __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint32_t* __restrict__ largeList,

@@ -274,7 +274,11 @@ struct mi_world {
     mi_stage_times timesSum{}; uint32_t timesSteps = 0; uint64_t contactUpdatesSum = 0;   // accumulated since the last mi_world_get_accumulated_stage_times(reset)
     mi_step_counts counts{};
     mi_stage_times times{};
-    hipEvent_t ev[10]{};
+    // two sets of step events, alternating per valid step: the elapsed times of step k are read at the START of step k + 1, after its first launches are
+    // enqueued (three hipEventElapsedTime calls cost the host ~10 us it would otherwise spend with the device idle between two steps), or by whoever asks first
+    hipEvent_t evSets[2][10]{}; hipEvent_t* ev = evSets[0]; int evSet = 0;
+    bool timesPending = false; int timesPendingSet = 0; bool timesPendingStages = false; uint64_t timesPendingUpdates = 0;
+    void finishTimes();
     uint32_t numColorsUsed = 0, solveLaunches = 0;
     bool profileSolve = false;            // per-launch HIP events around k_contact_solve (mi_world_step_profiled)
     std::vector<hipEvent_t> profEvents;   // pairs
@@ -324,7 +328,7 @@ int mi_world::init(int dev) {
     device = dev;
     HIP_TRY(hipSetDevice(dev));
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    for (auto& set : evSets) for (auto& e : set) HIP_TRY(hipEventCreate(&e));
     HIP_TRY(scalarsRaw.ensure(sizeof(StepScalars) + (kMaxColorRounds + 2) * sizeof(uint32_t)));
     HIP_TRY(grid.ensure(2));
     HIP_TRY(shards.ensure(1));
@@ -394,7 +398,7 @@ mi_world::~mi_world() {
     dropStepGraphs();
     if (stream) (void)hipStreamDestroy(stream);
     for (auto& e : profEvents) (void)hipEventDestroy(e);
-    for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+    for (auto& set : evSets) for (auto& e : set) if (e) (void)hipEventDestroy(e);
     delete heightmap;
     for (HCloth* c : cloths) delete c;
 }
@@ -1035,6 +1039,7 @@ enqueue_section:
             L.launch(k_reset_pair_counters, dim3(1), dim3(32), 0, st, sc, shards.p);
         }
     }
+    if (pass == PASS_PLAIN) finishTimes();   // the previous step's event times, now that this step's first kernels keep the device busy
     mark();  // 2
     // ---------------------------------------------------------------------------------------------- narrow phase
     if (pairBound) {
@@ -1519,23 +1524,33 @@ enqueue_section:
     pairsIn = hs.partitioned ? pairKeysS.p : pairKeys.p;
     lastPartitioned = hs.partitioned != 0u; havePartitionFlag = pairBound != 0u;
 
-    // (the host got here on the published read-back, i.e. after the kernels the events belong to — but the HIP 7.0 runtime now and then still
-    // reports an event attached to a kernel as not ready, ~1 step in 1000: wait for it then instead of reporting 0 ms)
-    static const bool noTimes = std::getenv("MI_NO_TIMES") != nullptr;   // development: what the three hipEventElapsedTime calls per step cost the host
-    auto el = [&](int a, int b) { return noTimes ? 0.f : elapsedMs(ev[a], ev[b]); };
-    if (stageEvents) {
-        times.world_colliders = el(0, 1); times.broadphase = el(1, 2); times.narrowphase = el(2, 3); times.integrate_forces = el(3, 4);
-        times.schedule = el(4, 5); times.init_constraints = el(5, 6);
-    } else { times.world_colliders = times.broadphase = times.narrowphase = times.integrate_forces = times.schedule = times.init_constraints = 0.f; }
-    times.solve = el(6, 7); times.integrate_velocities = el(7, 8); times.total = el(0, 8);
     counts.num_rigid_bodies = nb; counts.num_colliders = nc; counts.num_broadphase_overlaps = nc ? hs.numOverlaps : 0;
     manifoldsLast = pairBound ? hs.numManifolds : 0;
     counts.num_collisions = manifoldsLast - (manifoldsLast ? hs.numHmContacts - hs.numHmColliders : 0u);   // terrain: one collision per collider (heightmap_collision.cpp:582-594)
     counts.num_contacts = pairBound ? hs.numContacts : 0;
     counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur; counts.reserved = solveLaunches;
-    { float* a = &timesSum.world_colliders; const float* b = &times.world_colliders; for (int i = 0; i < 9; ++i) a[i] += b[i]; ++timesSteps;
-      contactUpdatesSum += (uint64_t)counts.num_contacts * iters; }
+    // the step's device times: read from its events LATER (finishTimes), the next step records into the other set
+    finishTimes();   // (normally done already, at the start of this step)
+    timesPending = true; timesPendingSet = evSet; timesPendingStages = stageEvents; timesPendingUpdates = (uint64_t)counts.num_contacts * iters;
+    evSet ^= 1; ev = evSets[evSet];
+    static const bool eagerTimes = std::getenv("MI_EAGER_TIMES") != nullptr;   // development: read them right here, as before
+    if (eagerTimes) finishTimes();
     return MI_OK;
+}
+// (the host gets here after the published read-back of the step the events belong to — but the HIP 7.0 runtime now and then still reports an event
+// attached to a kernel as not ready, ~1 step in 1000: elapsedMs waits for it then instead of reporting 0 ms)
+void mi_world::finishTimes() {
+    if (!timesPending) return;
+    timesPending = false;
+    hipEvent_t* e = evSets[timesPendingSet];
+    auto el = [&](int a, int b) { return elapsedMs(e[a], e[b]); };
+    if (timesPendingStages) {
+        times.world_colliders = el(0, 1); times.broadphase = el(1, 2); times.narrowphase = el(2, 3); times.integrate_forces = el(3, 4);
+        times.schedule = el(4, 5); times.init_constraints = el(5, 6);
+    } else { times.world_colliders = times.broadphase = times.narrowphase = times.integrate_forces = times.schedule = times.init_constraints = 0.f; }
+    times.solve = el(6, 7); times.integrate_velocities = el(7, 8); times.total = el(0, 8);
+    { float* a = &timesSum.world_colliders; const float* b = &times.world_colliders; for (int i = 0; i < 9; ++i) a[i] += b[i]; ++timesSteps;
+      contactUpdatesSum += timesPendingUpdates; }
 }
 
 // mi_debug_set_solve_order, inside a synchronous step after the manifolds are known (hs = this step's counts): every manifold is given the
@@ -3116,6 +3131,7 @@ MI_API int mi_world_get_mass_properties(mi_world* w, float* invMass, float* invI
 MI_API int mi_world_get_counts(mi_world* w, mi_step_counts* out) { if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null"); *out = w->counts; return MI_OK; }
 MI_API int mi_world_get_accumulated_stage_times(mi_world* w, mi_stage_times* out_sum, uint32_t* out_steps, uint64_t* out_contact_updates, uint32_t reset) {
     if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    w->finishTimes();
     if (out_sum) *out_sum = w->timesSum;
     if (out_steps) *out_steps = w->timesSteps;
     if (out_contact_updates) *out_contact_updates = w->contactUpdatesSum;
@@ -3144,7 +3160,7 @@ MI_API int mi_debug_tile_owner(uint32_t tile_in_bin, uint32_t tiles_in_bin, uint
 // Event pairs around every stage cost a few microseconds of device time per step each: off by default (the whole step and the
 // solve stage are always timed), on for profiling.
 MI_API int mi_world_set_stage_timing(mi_world* w, uint32_t enable) { if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null"); w->stageEvents = enable != 0; return MI_OK; }
-MI_API int mi_world_get_stage_times(mi_world* w, mi_stage_times* out) { if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null"); *out = w->times; return MI_OK; }
+MI_API int mi_world_get_stage_times(mi_world* w, mi_stage_times* out) { if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null"); w->finishTimes(); *out = w->times; return MI_OK; }
 
 MI_API int mi_world_get_contacts(mi_world* w, mi_contact* out, uint32_t cap, uint32_t* count) {
     if (!w || !count) return fail(MI_ERR_INVALID_ARGUMENT, "null");
