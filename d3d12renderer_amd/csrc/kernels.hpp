@@ -1258,6 +1258,9 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
 // ------------------------------------------------------------------------------------------------
 // K9 "Integrate rigid body forces" (src/physics/rigid_body.cpp:95-124).  One lane per body; also
 // zeroes the dummy body (physics.cpp:1279).  in ~112 B, out 112 B per body.
+// (Measured and not kept, round 3: as GUEST workgroups of k_emit_manifolds — nothing between the two depends on the other, that kernel waits on random
+// sectors and atomics, this one streams; interleaved every 4th workgroup.  k_emit_manifolds 54 -> 68 us for the 21 us saved: they compete for the same
+// memory system; 938 vs 937 steps/s.)
 __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt, float3 globalForce, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
                                                           const float4* __restrict__ bCogInvMass, const float4* __restrict__ bInvI,
                                                           const float4* __restrict__ bParams, const float4* __restrict__ bLinVel,
@@ -1765,6 +1768,17 @@ __global__ __launch_bounds__(256) void k_schedule_finish(uint32_t lastRound, con
     }
 }
 
+// The constraint rows are written once here and read by the solver from memory: stored non-temporally they do not push the bodies this kernel gathers
+// (one slab of the scene per XCD) out of that XCD's L2: 81 -> 76 us for the stage (A/B against a build with plain stores, same box; -DMI_NO_STREAM_ROWS).
+typedef float mi_vf4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void storeStream(float4* p, float4 v) {
+#ifdef MI_NO_STREAM_ROWS
+    *p = v;
+#else
+    mi_vf4 x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<mi_vf4*>(p));
+#endif
+}
 // K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379): one wave per tile, one lane per slot.
 __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restrict__ sc, uint32_t dummyBody, float dt, const uint4* __restrict__ tileInfo /* k_fill_tiles: per tile, or (XCD-partitioned) per entry of the XCD tile lists */,
                                                      const uint32_t* __restrict__ order,
@@ -1859,12 +1873,12 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
             if (-depth < slop && vRel < 0.f) bias = -restitution * vRel - 0.1f * (-depth - slop) * invDt;
         }
         float4* __restrict__ row = rows + (ctBase + k) * (kRows * 64u) + lane;
-        row[0 * 64] = f4(rA, effN);
-        row[1 * 64] = f4(rB, effT);
-        row[2 * 64] = f4(t, bias);
-        row[3 * 64] = make_float4(tA.x, tA.y, tA.z, tB.x);
-        row[4 * 64] = make_float4(tB.y, tB.z, nA.x, nA.y);
-        row[5 * 64] = make_float4(nA.z, nB.x, nB.y, nB.z);
+        storeStream(row + 0 * 64, f4(rA, effN));
+        storeStream(row + 1 * 64, f4(rB, effT));
+        storeStream(row + 2 * 64, f4(t, bias));
+        storeStream(row + 3 * 64, make_float4(tA.x, tA.y, tA.z, tB.x));
+        storeStream(row + 4 * 64, make_float4(tB.y, tB.z, nA.x, nA.y));
+        storeStream(row + 5 * 64, make_float4(nA.z, nB.x, nB.y, nB.z));
         if (imp) imp[(ctBase + k) * 64u + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // no warm start (constraints.cpp:3312-3313); sweep tag 0 (null: the solver keeps the impulses in LDS)
     }
 }
