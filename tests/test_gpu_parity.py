@@ -448,6 +448,34 @@ def test_gpu_speculative_step_retry_keeps_parity(mi_lib, oracle_mod):
     assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
 
 
+def test_gpu_pair_partition_appearing_mid_run_keeps_parity(mi_lib, oracle_mod):
+    """A box pile's pair list is of one type and is NOT partitioned by type; speculative steps then leave the partition pass out
+    altogether.  The first cylinder that reaches a box populates a GJK bucket, so the list must be partitioned from that step
+    on: the speculative step that left the pass out voids itself (k_pair_finish) and is re-run synchronously, and the
+    trajectory stays the oracle's bit for bit across the switch and after it."""
+    sc = scenes.obb_pile(8, 3, 8)
+    n_new = 6
+    e = scenes.make_entities(n_new)
+    e["position"] = [(-3 + 1.3 * i, 7.5 + 0.4 * i, 0.7 * i - 2) for i in range(n_new)]
+    e["rotation"][:, 3] = 1.0
+    c = scenes.make_colliders(n_new, capi.CYLINDER)
+    c["shape"][:, :7] = (0, -0.4, 0, 0, 0.4, 0, 0.35)
+    ents = np.concatenate([sc.entities, e])
+    first = len(sc.entities)
+    sc = scenes.Scene("pile_then_cylinders", ents, np.concatenate([sc.collider_entities, np.arange(first, first + n_new, dtype=np.uint32)]),
+                      np.concatenate([sc.colliders, c]), sc.solver_iterations)
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    for i in range(170):
+        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        assert g.counts() == o.counts(), f"step {i}"
+    pg, qg = g.physics_transforms(); po, qo = o.physics_transforms()
+    assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
+    assert pg[-n_new:, 1].max() < 6.0, "the cylinders were meant to land on the pile"
+    steps, spec, retries = g.step_mode_stats()
+    assert retries >= 1 and spec >= steps - 1 - 2 * retries
+
+
 @pytest.mark.parametrize("name,make,steps", [
     ("cfg1", lambda: scenes.sphere_drop(16), 150),
     ("cfg2", lambda: scenes.mixed_stack(64, 16, 64), 60),
