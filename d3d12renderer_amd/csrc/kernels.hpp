@@ -423,6 +423,17 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
     __syncthreads();
     const uint32_t i = blockIdx.x * 256 + threadIdx.x;
     if (cTypeBody && i == 0) { sc->axisCur = axisDev ? *axisDev : axisCur; }
+    if (cTypeBody && bodyActive) {
+        // sharded world: a workgroup whose colliders are all dead now and were dead in the previous step (7 of 8 workgroups of an 8-tile scene) has nothing to
+        // compute, nothing to reduce and nothing to rewrite but its own (empty) partial results
+        bool stale = true;
+        if (i < nc) { const uint32_t body = cTypeBody[2 * i + 1]; stale = body != kNoBody && !bodyActive[body] && !bodyActivePrev[body]; }
+        if (!__syncthreads_or(stale ? 0 : 1)) {
+            if (threadIdx.x < kAxisSums) partials[blockIdx.x * kAxisSums + threadIdx.x] = 0ull;
+            if (threadIdx.x < 6) blockBounds[blockIdx.x * 6 + threadIdx.x] = threadIdx.x < 3 ? 0x7FFFFFFF : (int)0x80000000;
+            return;
+        }
+    }
     const GridParams g = *gp;
     unsigned long long v[kAxisSums];
     int lo[3] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF}, hi[3] = {(int)0x80000000, (int)0x80000000, (int)0x80000000};
@@ -1212,10 +1223,12 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
                                                         unsigned long long* __restrict__ bodyUsed, uint8_t* __restrict__ isNew, StepScalars* sc,
                                                         float2 terrainMaterial /* (restitution, friction) of the heightmap */,
                                                         HistSlot* __restrict__ nextTab, uint32_t nextMask, uint8_t* __restrict__ manKept,
-                                                        const Shards* __restrict__ statsShards /* non-null: the LAST workgroup runs pairFinishStats instead */, uint32_t statsBlocks,
+                                                        const Shards* __restrict__ statsShards /* non-null: workgroup 0 runs pairFinishStats instead */, uint32_t statsBlocks,
                                                         const unsigned long long* __restrict__ statsPartials, const int* __restrict__ statsBounds, GridParams* statsGridNext, uint32_t statsCellCap) {
-    if (statsShards && blockIdx.x == gridDim.x - 1u) { pairFinishStats(statsShards, sc, nc, statsBlocks, statsPartials, statsBounds, statsGridNext, statsCellCap); return; }
-    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    // (workgroup 0, not the last one: dispatched first, it runs beside all the others; as the last one its ~4 us — 12 us over the 8 192 partial rows
+    // of a 2 M-collider sharded scene — started when the kernel was all but over and became its tail)
+    if (statsShards && blockIdx.x == 0u) { pairFinishStats(statsShards, sc, nc, statsBlocks, statsPartials, statsBounds, statsGridNext, statsCellCap); return; }
+    uint32_t p = (blockIdx.x - (statsShards ? 1u : 0u)) * blockDim.x + threadIdx.x;
     const uint32_t numPairs = sc->numPairs;
     if (p >= numPairs) return;
     const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
@@ -1271,8 +1284,9 @@ __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt,
                                                           const uint8_t* __restrict__ bodyActive /* sharded world, or null */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i > nb) return;
+    if (bodyActive && i < nb && !bodyActive[i]) return;   // not simulated by this rank: no contact can reference it (nor its XCD flags: they are only ever read for
+                                                          // bodies of this step's contacts and for owned bodies, all of which pass here first)
     if (bodyOwner) bodyOwner[i] = 0ull;
-    if (bodyActive && i < nb && !bodyActive[i]) return;   // not simulated by this rank: no contact can reference it
     if (i == nb) {
         float4 z = make_float4(0, 0, 0, 0);
         gPos[i] = z; gInvI[3 * i] = z; gInvI[3 * i + 1] = z; gInvI[3 * i + 2] = z; gVel[2 * i] = z; gVel[2 * i + 1] = z;
@@ -1466,8 +1480,14 @@ __host__ __device__ __forceinline__ uint32_t tileOwnerCount(uint32_t x, uint32_t
 constexpr uint32_t kSpatialKeys = 4096;
 constexpr uint32_t kKeyItems = 1024;   // manifolds per workgroup of k_manifold_keys
 __global__ __launch_bounds__(256) void k_manifold_keys(uint32_t n, const StepScalars* __restrict__ sc, const GridParams* __restrict__ gp, const uint2* __restrict__ manBodies,
-                                                       const float4* __restrict__ gPos, uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks, uint32_t* __restrict__ keyCount) {
+                                                       const float4* __restrict__ gPos, uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks, uint32_t* __restrict__ keyCount,
+                                                       // sharded world (bodyActive non-null): also what k_shard_count counts — this rank's manifolds / contacts by the owner rule —
+                                                       // from the rows this kernel gathers anyway (gPos.w = inverse mass), one launch less
+                                                       uint32_t nb, const uint8_t* __restrict__ bodyActive, const uint2* __restrict__ manInfo, Shards* sh) {
     __shared__ uint32_t hist[kSpatialKeys];   // local count, then the global base of this workgroup's range
+    __shared__ uint32_t ownedCnt[2];
+    if (threadIdx.x < 2) ownedCnt[threadIdx.x] = 0u;
+    uint32_t mine = 0, contacts = 0;
     for (uint32_t k = threadIdx.x; k < kSpatialKeys; k += 256) hist[k] = 0u;
     __syncthreads();
     const uint32_t nm = min(n, sc->numManifolds);
@@ -1488,9 +1508,18 @@ __global__ __launch_bounds__(256) void k_manifold_keys(uint32_t n, const StepSca
             float c = axis == 0u ? p.x : axis == 1u ? p.y : p.z;
             key[i] = (uint32_t)fminf(fmaxf((c - originA) * scale, 0.f), (float)(kSpatialKeys - 1u));
             local[i] = atomicAdd(&hist[key[i]], 1u);
+            if (bodyActive) {
+                const uint32_t first = (b.x < nb && pa.w != 0.f) ? b.x : b.y;
+                if (first < nb && bodyActive[first] == 1u) { ++mine; contacts += manInfo[m].x & 7u; }
+            }
         }
     }
+    if (bodyActive) {
+        for (int off = 32; off >= 1; off >>= 1) { mine += __shfl_xor(mine, off, 64); contacts += __shfl_xor(contacts, off, 64); }
+        if ((threadIdx.x & 63u) == 0u && mine) { atomicAdd(&ownedCnt[0], mine); atomicAdd(&ownedCnt[1], contacts); }
+    }
     __syncthreads();
+    if (bodyActive && threadIdx.x < 2 && ownedCnt[threadIdx.x]) atomicAdd(&sh->c[blockIdx.x & (kShards - 1u)].owned[1 + threadIdx.x], ownedCnt[threadIdx.x]);
     for (uint32_t k = threadIdx.x; k < kSpatialKeys; k += 256) { uint32_t c = hist[k]; if (c) hist[k] = atomicAdd(&keyCount[k], c); }
     __syncthreads();
 #pragma unroll
@@ -2568,10 +2597,14 @@ __global__ __launch_bounds__(256) void k_shard_classify(uint32_t nb, ShardParams
     bool owned = false;
     if (i < nb) {
         const uint32_t r = root[i];
-        const V3 c = shardCog(bPos[r], bRot[r], bCogInvMass[r]);
         const bool k = known[r] != 0u;      // a copy that is not current says nothing about where the body is (it may lie in a tile that has since grown)
-        owned = k && shardOwns(sp, c.x, c.z);
-        bodyActive[i] = owned ? 1u : (k && shardInExtended(sp, sp.myTile, c.x, c.z)) ? 2u : 0u;
+        uint8_t flag = 0u;
+        if (k) {                            // (most bodies of a many-tile scene are not known here: 5 bytes read for them instead of 53)
+            const V3 c = shardCog(bPos[r], bRot[r], bCogInvMass[r]);
+            owned = shardOwns(sp, c.x, c.z);
+            flag = owned ? 1u : shardInExtended(sp, sp.myTile, c.x, c.z) ? 2u : 0u;
+        }
+        bodyActive[i] = flag;
     }
     // counted per workgroup into one of kShards lines (summed by k_integrate_velocities): a same-address atomic per wave was 45 us of a 2 M-body scene
     __shared__ uint32_t cnt;
@@ -2605,16 +2638,11 @@ __global__ __launch_bounds__(256) void k_shard_count(uint32_t nb, const uint2* _
 // (old: so that the neighbour learns the body has left).  Record = (body index, 13 floats); record 0 of the buffer = (count, ...).
 constexpr uint32_t kShardRecordFloats = 14;
 struct ShardBufs { float* p[8]; };   // one message buffer per neighbour slot
-// one launch for all neighbours (the record counts start at zero: k_reset_scalars)
-__global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp, ShardParams spNext, uint32_t bordersPending, uint8_t* __restrict__ known, const uint8_t* __restrict__ bodyActive,
-                                                    const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bLinVel,
-                                                    const float4* __restrict__ bAngVel, const float4* __restrict__ bPosOld, const float4* __restrict__ bRotOld,
-                                                    const float4* __restrict__ bCogInvMass, ShardBufs out, uint32_t capacity, StepScalars* sc,
-                                                    const uint32_t* __restrict__ root) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool owned = i < nb && bodyActive[i] == 1u;
-    if (i < nb) known[i] = owned ? 1u : 0u;   // what this rank knows from here on: the bodies it owned; the records about to arrive add the neighbours' (k_shard_unpack)
-    if (!__ballot(owned)) return;
+__device__ __forceinline__ void shardPackWave(uint32_t i, bool owned, const ShardParams& sp, const ShardParams& spNext, uint32_t bordersPending,
+                                              const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bLinVel,
+                                              const float4* __restrict__ bAngVel, const float4* __restrict__ bPosOld, const float4* __restrict__ bRotOld,
+                                              const float4* __restrict__ bCogInvMass, const ShardBufs& out, uint32_t capacity, StepScalars* sc,
+                                              const uint32_t* __restrict__ root) {
     V3 cn(0.f, 0.f, 0.f), co(0.f, 0.f, 0.f);
     float4 p = make_float4(0, 0, 0, 0), q = p, v = p, w = p;
     if (owned) {
@@ -2642,9 +2670,25 @@ __global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp,
         o[8] = v.x; o[9] = v.y; o[10] = v.z; o[11] = w.x; o[12] = w.y; o[13] = w.z;
     }
 }
+// one launch for all neighbours (the record counts start at zero: k_reset_scalars)
+__global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp, ShardParams spNext, uint32_t bordersPending, uint8_t* __restrict__ known, const uint8_t* __restrict__ bodyActive,
+                                                    const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bLinVel,
+                                                    const float4* __restrict__ bAngVel, const float4* __restrict__ bPosOld, const float4* __restrict__ bRotOld,
+                                                    const float4* __restrict__ bCogInvMass, ShardBufs out, uint32_t capacity, StepScalars* sc,
+                                                    const uint32_t* __restrict__ root) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool owned = i < nb && bodyActive[i] == 1u;
+    if (i < nb) known[i] = owned ? 1u : 0u;   // what this rank knows from here on: the bodies it owned; the records about to arrive add the neighbours' (k_shard_unpack)
+    if (__ballot(owned)) shardPackWave(i, owned, sp, spNext, bordersPending, bPos, bRot, bLinVel, bAngVel, bPosOld, bRotOld, bCogInvMass, out, capacity, sc, root);
+}
 // The next step's sweep axis of a sharded world, from centre statistics summed over all ranks (or, before / without that sum, this rank's own)
 __global__ void k_shard_axis(const unsigned long long* __restrict__ sums9, uint32_t nc, uint32_t* __restrict__ axisDev) { if (threadIdx.x == 0 && blockIdx.x == 0) *axisDev = axisFromSums(sums9, nc); }
-__global__ void k_shard_pack_headers(uint32_t numPeers, const StepScalars* __restrict__ sc, ShardBufs out) { if (threadIdx.x < numPeers) out.p[threadIdx.x][0] = __uint_as_float(sc->shardSent[threadIdx.x]); }
+// (a done-ticket in k_shard_pack instead of this launch: 8 192 same-address atomics in a 2 M-body scene, ~90 us)
+__global__ void k_shard_pack_headers(uint32_t numPeers, const StepScalars* __restrict__ sc, ShardBufs out,
+                                     uint32_t nc, uint32_t* __restrict__ axisOwn /* caller's transport: the next sweep axis from this rank's own sums (k_shard_axis), or null */) {
+    if (threadIdx.x < numPeers) out.p[threadIdx.x][0] = __uint_as_float(sc->shardSent[threadIdx.x]);
+    if (axisOwn && threadIdx.x == 63) *axisOwn = axisFromSums(sc->axisSums, nc);
+}
 // blockIdx.y = neighbour slot (a body has one owner: the messages never touch the same body)
 __global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, ShardBufs in, uint32_t capacity, float4* __restrict__ bPos, float4* __restrict__ bRot,
                                                       float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, uint8_t* __restrict__ known) {

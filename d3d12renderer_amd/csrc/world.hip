@@ -1091,7 +1091,6 @@ enqueue_section:
                                                         heightmap ? make_float2(hmParams.restitution, hmParams.friction) : make_float2(0.f, 0.f),
                                                         tab[tabCur ^ 1].p, tabMask[tabCur ^ 1], manKept.p,
                                                         statsInEmit ? shards.p : nullptr, statsBlocks, axisPartials.p, blockBounds.p, statsGridNext, statsCellCap);
-        if (shard.enabled) L.launch(k_shard_count, dim3(divUp(pairBound, B)), dim3(B), 0, st, nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc, shards.p);
     }
     // ---------------------------------------------------------------------------------------------- triggers / force fields
     std::vector<mi_event> triggerEvents;
@@ -1112,6 +1111,7 @@ enqueue_section:
         else { int rc = readScalars(); if (rc != MI_OK) return rc; nmBound = hs.numManifolds; conBound = hs.numContacts; }
     }
     uint32_t tilesCap = 0, ctCap = 0, eventCap = 0, xcdListCap = 0;
+    bool shardCounted = false;   // sharded world: this rank's manifolds / contacts are counted inside k_manifold_keys when that runs, else by k_shard_count
     // XCD partitioning pays once the pile is big enough to keep eight L2s busy; it needs the persistent kernel (no joints)
     const bool xcdAble = flowSolver && persistSolver && persistXcd && !xcdOnly && joints.count() == 0 && (persistWaves & 7u) == 0u && !debugOrderPending;
     // small piles: the 128 waves of ONE XCD run the whole solve, every body hand-over goes through that XCD's L2 (tileOwner(..., single))
@@ -1133,7 +1133,9 @@ enqueue_section:
             HIP_TRY(sortKeys[0].ensure(nmBound)); for (int k = 0; k < 2; ++k) HIP_TRY(sortVals[k].ensure(nmBound));
             HIP_TRY(xcdTiles.ensure((size_t)8 * xcdListCap)); HIP_TRY(xcdInfo.ensure((size_t)8 * xcdListCap));
             if (!xcdSingle) {   // (one XCD: nothing to keep apart, the emission order will do)
-                L.launch(k_manifold_keys, dim3(divUp(nmBound, kKeyItems)), dim3(256), 0, st, nmBound, sc, grid.p + gridCur, manBodies.p, gPos.p, sortKeys[0].p, sortVals[0].p, keyCount.p);
+                L.launch(k_manifold_keys, dim3(divUp(nmBound, kKeyItems)), dim3(256), 0, st, nmBound, sc, grid.p + gridCur, manBodies.p, gPos.p, sortKeys[0].p, sortVals[0].p, keyCount.p,
+                         nb, shard.enabled ? shard.active.p : nullptr, manInfo.p, shards.p);
+                shardCounted = shard.enabled;
                 L.launch(k_manifold_place, dim3(divUp(nmBound, kKeyItems)), dim3(256), 0, st, nmBound, sc, sortKeys[0].p, sortVals[0].p, keyCount.p, sortVals[1].p);
             }
         }
@@ -1330,6 +1332,7 @@ enqueue_section:
             if (bins[kSchedBins - 1].count) L.launch(k_contact_solve_serial, dim3(1), dim3(64), 0, st, bins[kSchedBins - 1], slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
         }
     }
+    if (shard.enabled && pairBound && !shardCounted) L.launch(k_shard_count, dim3(divUp(nmBound ? nmBound : 1u, B)), dim3(B), 0, st, nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc, shards.p);
     mark();  // 7
     if (attached && !solveAttached) (void)hipEventRecord(ev[7], st);
     if (attached) hipExtLaunchKernelGGL(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nullptr, ev[8], 0, nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
@@ -2455,14 +2458,13 @@ int mi_world::shardExchange() {
     HIP_TRY(hipEventRecord(sh.exEv[0], st));
     // after a valid step the buffer sets are swapped: bPos = the new state, bPosN = the state the step started from; the record counts were cleared by k_reset_scalars
     k_shard_pack<<<divUp(nb, 256), 256, 0, st>>>(nb, sh.sp, sh.bordersPending ? sh.spNext : sh.sp, sh.bordersPending ? 1u : 0u, sh.known.p, sh.active.p, bPos.p, bRot.p, bLinVel.p, bAngVel.p, bPosN.p, bRotN.p, bCogInvMass.p, sendBufs, sh.capacity, sc, sh.root.p);
-    k_shard_pack_headers<<<1, 8, 0, st>>>(sh.sp.numPeers, sc, sendBufs);
+    k_shard_pack_headers<<<1, 64, 0, st>>>(sh.sp.numPeers, sc, sendBufs, nc, sh.rccl ? nullptr : sh.axisDev.p);   // caller's transport: until the caller hands in the centre statistics
+                                                                                                                    // summed over all ranks (mi_world_shard_set_axis_sums), the next step's sweep axis is the one of this rank's own sums
     HIP_TRY(hipMemcpyAsync(sh.sentHost, &sc->shardSent[0], 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     sh.sentPending = true; sh.exchangeTimed = true;
     if (sh.bordersPending) { sh.sp = sh.spNext; sh.bordersX = sh.nextX; sh.bordersZ = sh.nextZ; sh.bordersPending = false; }   // the next step classifies with the new borders
     if (!sh.rccl) {
-        // caller's transport: until the caller hands in the centre statistics summed over all ranks (mi_world_shard_set_axis_sums), the next
-        // step's sweep axis is the one of this rank's own sums (k_pair_finish computed it: hs.axisNext, already in sapAxis)
-        k_shard_axis<<<1, 64, 0, st>>>(sc->axisSums, nc, sh.axisDev.p);
+        // (the axis of this rank's own sums is also what k_pair_finish computed: hs.axisNext, already in sapAxis)
         HIP_TRY(hipEventRecord(sh.exEv[1], st));
         HIP_TRY(hipStreamSynchronize(st));     // the messages are complete when this returns
         sh.axisHostCurrent = true;
