@@ -89,6 +89,9 @@ class ShardDesc(C.Structure):
                 ("tile_size_z", C.c_float), ("tiles_x", C.c_uint32), ("tiles_z", C.c_uint32), ("ghost_margin", C.c_float), ("max_records", C.c_uint32)]
 
 
+SWEEP_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_uint32)   # mi_shard_sweep_fn
+
+
 class ShardExchangeStats(C.Structure):
     """mi_shard_exchange_stats (include/mi_shard.h)."""
     _fields_ = [("exchanges", C.c_uint64), ("device_ms_sum", C.c_double), ("message_bytes", C.c_uint64), ("num_neighbours", C.c_uint32), ("library_transport", C.c_uint32),
@@ -514,6 +517,47 @@ class World:
         return {"exchanges": st.exchanges, "device_ms_sum": st.device_ms_sum, "message_bytes": st.message_bytes, "num_neighbours": n,
                 "library_transport": bool(st.library_transport), "neighbour_rank": list(st.neighbour_rank[:n]), "records_last": list(st.records_last[:n]),
                 "records_sum": list(st.records_sum[:n]), "owned_bodies": st.owned_bodies, "ghost_bodies": st.ghost_bodies}
+
+    # --- exact seam (include/mi_shard.h "Exact seam")
+    def set_seam_tiling(self, desc):
+        """A single world orders its contact solve the way the exact-seam sharded worlds of this tiling do (None: plain schedule)."""
+        self.L.check(self.L.fn("world_set_seam_tiling")(self.h, C.byref(desc) if desc is not None else None), "world_set_seam_tiling")
+
+    def shard_set_exact_seam(self, enable=True, exchange=None):
+        """`exchange(sweep)` is called after every sweep of every internal step (caller's transport); it returns None / 0, or an error code."""
+        if exchange is None:
+            self._sweep_cb = None
+            cb = C.cast(None, SWEEP_FN)
+        else:
+            def tramp(user, world, sweep):
+                try:
+                    rc = exchange(int(sweep))
+                    return 0 if rc is None else int(rc)
+                except BaseException as e:   # an exception cannot cross the C frames: remember it, fail the step
+                    self._sweep_error = e
+                    return -1
+            cb = SWEEP_FN(tramp)
+            self._sweep_cb = cb          # keep the trampoline alive as long as the world may call it
+        self.L.check(self.L.fn("world_shard_set_exact_seam")(self.h, C.c_uint32(1 if enable else 0), cb, None), "world_shard_set_exact_seam")
+
+    def shard_sweep_message_bytes(self):
+        n = C.c_uint64()
+        self.L.check(self.L.fn("world_shard_sweep_message_bytes")(self.h, C.byref(n)), "world_shard_sweep_message_bytes")
+        return n.value
+
+    def shard_export_sweep(self, slot):
+        out = np.zeros(self.shard_sweep_message_bytes() // 4, np.float32)
+        self.L.check(self.L.fn("world_shard_export_sweep")(self.h, C.c_uint32(slot), _ptr(out)), "world_shard_export_sweep")
+        return out
+
+    def shard_import_sweep(self, message):
+        m = np.ascontiguousarray(message, np.float32)
+        self.L.check(self.L.fn("world_shard_import_sweep")(self.h, _ptr(m)), "world_shard_import_sweep")
+
+    def seam_stats(self):
+        a = C.c_uint32(); b = C.c_uint32(); c = C.c_uint32()
+        self.L.check(self.L.fn("world_seam_stats")(self.h, C.byref(a), C.byref(b), C.byref(c)), "world_seam_stats")
+        return {"seam_manifolds": a.value, "seam_colors": b.value, "violations": c.value}
 
     def shard_attach_rccl(self, unique_id128):
         buf = np.frombuffer(bytes(unique_id128), np.uint8).copy()

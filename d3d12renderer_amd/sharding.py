@@ -173,6 +173,54 @@ def step_local(ranks, settings, dt):
         r.world.shard_set_axis_sums(total)
 
 
+def step_local_exact(ranks, settings, dt):
+    """Virtual ranks with the EXACT seam (include/mi_shard.h): every sweep of the step ends with an exchange between the tiles, so the tiles have to
+    step side by side — one thread per virtual rank (the library releases the GIL while it steps), meeting at a barrier inside the per-sweep
+    callback: all export, barrier, all import, barrier.  What R processes do over their transport, in one process."""
+    import threading
+    n = len(ranks)
+    barrier = threading.Barrier(n)
+    mail = [None] * n
+    errors = []
+
+    def make_exchange(r):
+        def exchange(sweep):
+            try:
+                mail[r.rank] = {peer: r.world.shard_export_sweep(slot) for slot, peer in enumerate(r.neighbours)}
+                barrier.wait()
+                for peer in r.neighbours:
+                    r.world.shard_import_sweep(mail[peer][r.rank])
+                barrier.wait()
+            except threading.BrokenBarrierError:
+                return -1
+            except BaseException:
+                barrier.abort()
+                raise
+        return exchange
+
+    def run(r):
+        try:
+            r.world.shard_set_exact_seam(True, make_exchange(r))
+            r.world.step_fixed(settings, dt, 1)
+        except BaseException as e:
+            errors.append((r.rank, e, getattr(r.world, "_sweep_error", None)))
+            barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in ranks]
+    for t in threads: t.start()
+    for t in threads: t.join()
+    if errors:
+        raise RuntimeError(f"exact-seam step failed: {errors}")
+    mail = [r.outgoing() for r in ranks]
+    for r in ranks:
+        for peer in r.neighbours:
+            r.world.shard_import(mail[peer][r.rank])
+    with np.errstate(over="ignore"):
+        total = np.sum([r.world.shard_axis_sums() for r in ranks], axis=0, dtype=np.uint64)
+    for r in ranks:
+        r.world.shard_set_axis_sums(total)
+
+
 def rebalance_local(ranks):
     """Virtual ranks: what `ShardedWorld.rebalance` does over a process group."""
     total = sum(r.histograms() for r in ranks)

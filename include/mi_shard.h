@@ -128,6 +128,39 @@ MI_API int mi_world_shard_message_bytes(mi_world* world, uint64_t* out_bytes);
 MI_API int mi_world_shard_export(mi_world* world, uint32_t slot, void* out_message);
 MI_API int mi_world_shard_import(mi_world* world, const void* message);
 
+/* Exact seam (an OPTION; the default stays block Jacobi).  What the block-Jacobi seam drops is the coupling, within one step, between the sweeps of
+ * neighbouring tiles (the reference solves all constraints of a sweep one after the other: src/physics/constraints.cpp:3748-3770).  The exact mode
+ * keeps it by ORDERING the solve around the tiling:
+ *     shared body    its centre (its island root's) lies in the extended region of at least two tiles — every rank that sees it says so from
+ *                    the same positions;
+ *     seam manifold  every dynamic body of it is shared.  Both tiles of the seam see it with all of its bodies.
+ * Seam manifolds are coloured among themselves and take the LEADING colours [0, MI_SEAM_COLORS), everything else the colours behind them (a manifold
+ * that changes class is re-coloured).  A sweep is then: joints; the seam colours — every rank that sees a seam manifold solves it, redundantly, from
+ * identical inputs, to identical results; the interior colours — each rank its own; and one exchange: every rank sends the velocities of the shared
+ * bodies it OWNS (they alone changed through manifolds the neighbour does not see) to the neighbour that holds them as ghosts.  20 sweeps = 20 small
+ * exchanges per step instead of one.
+ * The result is, bit for bit, that of ONE world which was told the tiling (mi_world_set_seam_tiling: it classifies shared bodies the same way and
+ * orders its colours the same way, nothing else changes) — tests assert that on virtual ranks of one GPU and on the CPU oracle.  Conditions, all
+ * checked: x- or z-slabs only (tiles_x == 1 or tiles_z == 1: at a corner a shared body is seen by four tiles); ghost_margin covers the reach of a
+ * contact and of an island (a manifold outside the seam class touching a ghost, or a seam manifold that found no colour among the MI_SEAM_COLORS,
+ * is counted as a violation: mi_world_seam_stats; the step still completes, as block Jacobi would for that manifold).
+ * Transport.  Library transport (RCCL attached): the per-sweep send / receive runs inside mi_world_step on the world's stream.  Caller's transport:
+ * the library calls `exchange(user, world, sweep)` after every sweep of every internal step, on the stepping thread; inside it the caller moves
+ * mi_world_shard_export_sweep(slot) of every rank to mi_world_shard_import_sweep of the neighbour (fixed-size messages of
+ * mi_world_shard_sweep_message_bytes: count + records of MI_SHARD_SWEEP_FLOATS floats = body index, linear velocity, angular velocity) and returns
+ * MI_OK.  Every rank makes the same number of calls (the sweeps of the step), so a barrier inside the callback is safe.  Steps run one at a time
+ * and synchronously in this mode (no speculation: every rank must take the same path through the step). */
+#define MI_SEAM_COLORS 24
+#define MI_SHARD_SWEEP_FLOATS 8
+typedef int (*mi_shard_sweep_fn)(void* user, mi_world* world, uint32_t sweep);
+MI_API int mi_world_set_seam_tiling(mi_world* world, const mi_shard_desc* desc /* rank / num_ranks ignored; null: back to the plain schedule */);
+MI_API int mi_world_shard_set_exact_seam(mi_world* world, uint32_t enable, mi_shard_sweep_fn exchange /* null with the library transport */, void* user);
+MI_API int mi_world_shard_sweep_message_bytes(mi_world* world, uint64_t* out_bytes);
+MI_API int mi_world_shard_export_sweep(mi_world* world, uint32_t slot, void* out_message);
+MI_API int mi_world_shard_import_sweep(mi_world* world, const void* message);
+/* Of the last internal step: manifolds in the seam class, colours they used, violations of the conditions above since the mode was set. */
+MI_API int mi_world_seam_stats(mi_world* world, uint32_t* out_seam_manifolds, uint32_t* out_seam_colors, uint32_t* out_violations);
+
 #ifdef __cplusplus
 }
 #endif

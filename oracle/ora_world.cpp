@@ -679,10 +679,25 @@ static void colorManifolds(World& w) {
         uint32_t b = w.colliderPairs[m].b;
         return ((uint64_t)(nc - 1 - w.colliderPairs[m].a) << 26) | (uint64_t)(b >= kHeightmapVirtualBase ? b : nc - 1 - b);
     };
+    // exact seam: a SEAM manifold (all of its dynamic bodies are shared between tiles) takes its colour from [0, MI_SEAM_COLORS), any other one from
+    // the colours behind them; the two classes never conflict (they are solved one after the other), and a manifold that changed class is re-coloured
+    const bool seamMode = w.seamActive();
+    const uint64_t seamRange = (1ull << MI_SEAM_COLORS) - 1ull;
+    std::vector<uint8_t> isSeam(nm, 0);
+    w.seam.manifolds = 0; w.seam.colors = 0;
+    if (seamMode) for (uint32_t m = 0; m < nm; ++m) {
+        Pair bp = w.bodyPairs[firstContact[m]];
+        const bool dynA = w.rb[bp.a].invMass != 0.f, dynB = w.rb[bp.b].invMass != 0.f;
+        const uint32_t idA = dynA && bp.a < w.seam.shared.size() ? w.seam.shared[bp.a] : 0u, idB = dynB && bp.b < w.seam.shared.size() ? w.seam.shared[bp.b] : 0u;
+        isSeam[m] = (dynA || dynB) && (!dynA || idA) && (!dynB || idB) && (!(dynA && dynB) || idA == idB);   // ... shared across the SAME border
+        w.seam.manifolds += isSeam[m];
+        // the margin must cover the reach of a contact: a manifold outside the seam class may only touch bodies this rank owns
+        if (!isSeam[m] && w.shard.enabled && ((dynA && w.shard.active[bp.a] == 2) || (dynB && w.shard.active[bp.b] == 2))) ++w.seam.violations;
+    }
     std::vector<uint32_t> order;
     for (uint32_t m = 0; m < nm; ++m) {
         auto it = w.prevPairColor.find(keyOf(m));
-        if (it != w.prevPairColor.end() && it->second < 64) {
+        if (it != w.prevPairColor.end() && it->second < 64 && (!seamMode || (it->second < MI_SEAM_COLORS) == (isSeam[m] != 0))) {
             uint32_t c = it->second;
             Pair bp = w.bodyPairs[firstContact[m]];
             w.manifoldColor[m] = c;
@@ -697,7 +712,8 @@ static void colorManifolds(World& w) {
         Pair bp = w.bodyPairs[firstContact[m]];
         bool dynA = w.rb[bp.a].invMass != 0.f, dynB = w.rb[bp.b].invMass != 0.f;
         uint64_t mask = (dynA ? used[bp.a] : 0) | (dynB ? used[bp.b] : 0);
-        if (~mask == 0) continue;  // overflow colour
+        if (seamMode) mask |= isSeam[m] ? ~seamRange : seamRange;
+        if (~mask == 0) { if (seamMode && isSeam[m]) ++w.seam.violations; continue; }  // overflow colour (a seam manifold there would be solved after the interior: not exact)
         uint32_t c = (uint32_t)__builtin_ctzll(~mask);
         w.manifoldColor[m] = c;
         if (dynA) used[bp.a] |= (1ull << c);
@@ -705,6 +721,7 @@ static void colorManifolds(World& w) {
     }
     w.prevPairColor.clear();
     for (uint32_t m = 0; m < nm; ++m) w.prevPairColor[keyOf(m)] = w.manifoldColor[m];
+    if (seamMode) for (uint32_t m = 0; m < nm; ++m) if (isSeam[m] && w.manifoldColor[m] < MI_SEAM_COLORS) w.seam.colors = std::max(w.seam.colors, w.manifoldColor[m] + 1u);
 }
 
 // getForceFieldStates + handleNonCollisionInteractions — src/physics/physics.cpp:759-787, 952-1039.  Localized force fields add
@@ -806,6 +823,7 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
     uint32_t axisUsed = sortingAxis;
     std::vector<vec3> cogBefore;
     if (shard.enabled) { shardClassify(); cogBefore.resize(nb); for (uint32_t i = 0; i < nb; ++i) cogBefore[i] = bodies[i].p1 + bodies[i].r1 * bodies[i].localCOG; }
+    if (seamActive()) seamClassify();
     getWorldSpaceColliders(*this);
     if (orderMode == 0) { broadphaseReference(*this); narrowphaseReference(*this); }
     else { broadphaseCanonical(*this); narrowphaseCanonical(*this, axisUsed); }
@@ -866,6 +884,8 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
     for (uint32_t it = 0; it < settings.num_rigid_solver_iterations; ++it) {
         jointsSolveIteration(*this);  // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
         for (uint32_t id : solveOrder) solveContact(*this, id, cc[id]);
+        // exact seam: the owners' velocities of the shared bodies replace the ghost copies before the next sweep (the caller's exchange)
+        if (shard.enabled && seam.exact && seam.fn) { int rc = seam.fn(seam.user, this, it); if (rc != MI_OK && seam.error == MI_OK) seam.error = rc; }
     }
     if (debugOrderPending) { debugOrderPending = false; debugOrder.clear(); jointsMarkOrderDirty(*this); }
     for (uint32_t i = nb; i-- > 0;) { if (shard.enabled && shard.active[i] != 1) continue; integrateVelocity(bodies[i], rb[i], dt); }
@@ -1045,6 +1065,32 @@ void World::shardPack(const std::vector<vec3>& oldCog) {
     for (uint32_t i = 0; i < nb; ++i) bodies[i].shardKnown = shard.active[i] == 1 ? 1 : 0;
     if (shard.bordersPending) { shard.bordersX = shard.nextX; shard.bordersZ = shard.nextZ; shard.bordersPending = false; }
 }
+// Which tile border is (x, z) within the margin of, i.e. which neighbour of the tile that contains it sees it as well?  0 = none, else 1 + the border's
+// index along x | (1 + index along z) << 16 (the same comparisons as shardInExtended; tiles are at least two margins wide, so at most one per axis).
+static uint32_t seamBorderOf(const std::vector<float>& bx, const std::vector<float>& bz, float m, float x, float z) {
+    auto near = [&](const std::vector<float>& b, float v) -> uint32_t {
+        int t = 0; while (t < (int)b.size() && v >= b[(size_t)t]) ++t;       // tile index along this axis: borders b[t - 1] <= v < b[t]
+        if (t > 0 && v < b[(size_t)t - 1] + m) return (uint32_t)t;           // border t - 1
+        if (t < (int)b.size() && v >= b[(size_t)t] - m) return (uint32_t)t + 1u;
+        return 0u;
+    };
+    return near(bx, x) | (near(bz, z) << 16);
+}
+void World::seamClassify() {
+    const uint32_t nb = (uint32_t)bodies.size();
+    seam.shared.assign(nb, 0); seam.cogStart.resize(nb);
+    std::vector<uint32_t> root;
+    if (shard.enabled) root = shard.root; else jointsIslandRoots(*this, root);
+    const std::vector<float>& bx = shard.enabled ? shard.bordersX : seam.bx;
+    const std::vector<float>& bz = shard.enabled ? shard.bordersZ : seam.bz;
+    const float m = shard.enabled ? shard.desc.ghost_margin : seam.margin;
+    for (uint32_t i = 0; i < nb; ++i) {
+        const RigidBody& rbody = bodies[root[i]];
+        const vec3 c = rbody.p1 + rbody.r1 * rbody.localCOG;
+        seam.cogStart[i] = c;
+        seam.shared[i] = (!shard.enabled || shard.active[i] != 0) ? seamBorderOf(bx, bz, m, c.x, c.z) : 0u;   // (a ghost is within the margin of one of this tile's borders)
+    }
+}
 // Borders that even out the body counts: hist = bodies per bin of [lo, hi) along one axis, summed over all ranks.  Border i goes where the
 // cumulative count reaches i / tiles of the total (linear inside a bin), then is clamped to what one change may do (see shardBordersValid).
 static bool shardBordersValid(const std::vector<float>& cur, const float* nb, uint32_t n, float m) {
@@ -1222,6 +1268,7 @@ MI_API int ora_world_step_fixed(World* w, const mi_step_settings* s, float dt, u
     for (uint32_t i = 0; i < n; ++i) w->stepInternal(*s, dt);
     for (RigidBody& b : w->bodies) { Entity& e = w->entities[b.entity]; e.position = b.p1; e.rotation = b.r1; }
     if (w->debugOrderError) { w->debugOrderError = false; return MI_ERR_INVALID_ARGUMENT; }   // ora_debug_set_solve_order: the list did not match the step's manifolds
+    if (w->seam.error != MI_OK) { const int rc = w->seam.error; w->seam.error = MI_OK; return rc; }   // the exact seam's sweep exchange failed
     return MI_OK;
 }
 
@@ -1639,6 +1686,73 @@ MI_API int ora_world_shard_import(World* w, const void* msg) {
         rb.linearVelocity = vec3(s[8], s[9], s[10]); rb.angularVelocity = vec3(s[11], s[12], s[13]);
         rb.shardKnown = 1;
     }
+    return MI_OK;
+}
+// ---- exact seam (include/mi_shard.h)
+MI_API int ora_world_set_seam_tiling(World* w, const mi_shard_desc* d) {
+    if (!w) return MI_ERR_INVALID_ARGUMENT;
+    w->prevPairColor.clear();
+    if (!d) { w->seam.tiling = false; return MI_OK; }
+    if (w->shard.enabled || w->orderMode != 1) return MI_ERR_UNSUPPORTED;
+    if (!d->tiles_x || !d->tiles_z || !(d->tile_size_x > 0.f) || !(d->tile_size_z > 0.f) || !(d->ghost_margin > 0.f) || 2.f * d->ghost_margin > d->tile_size_x || 2.f * d->ghost_margin > d->tile_size_z) return MI_ERR_INVALID_ARGUMENT;
+    w->seam.bx.clear(); w->seam.bz.clear(); w->seam.margin = d->ghost_margin;
+    for (uint32_t i = 1; i < d->tiles_x; ++i) w->seam.bx.push_back((float)((double)d->origin_x + (double)i * (double)d->tile_size_x));
+    for (uint32_t i = 1; i < d->tiles_z; ++i) w->seam.bz.push_back((float)((double)d->origin_z + (double)i * (double)d->tile_size_z));
+    w->seam.tiling = true;
+    return MI_OK;
+}
+MI_API int ora_world_shard_set_exact_seam(World* w, uint32_t enable, int (*fn)(void*, World*, uint32_t), void* user) {
+    if (!w || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
+    if (enable && w->shard.desc.tiles_x > 1u && w->shard.desc.tiles_z > 1u) return MI_ERR_UNSUPPORTED;   // slabs only: at a corner a shared body is seen by four tiles
+    if (enable && (2.f * w->shard.desc.ghost_margin > w->shard.desc.tile_size_x || 2.f * w->shard.desc.ghost_margin > w->shard.desc.tile_size_z)) return MI_ERR_INVALID_ARGUMENT;   // a body is shared across ONE border
+    if (w->seam.exact != (enable != 0u)) w->prevPairColor.clear();   // the colour ranges mean something else from here on
+    w->seam.exact = enable != 0u; w->seam.fn = fn; w->seam.user = user; w->seam.error = MI_OK;
+    return MI_OK;
+}
+MI_API int ora_world_shard_sweep_message_bytes(World* w, uint64_t* out) {
+    if (!w || !out || !w->shard.enabled) return MI_ERR_INVALID_ARGUMENT;
+    *out = (uint64_t)(w->shard.capacity + 1u) * MI_SHARD_SWEEP_FLOATS * sizeof(float); return MI_OK;
+}
+// inside the sweep callback: (body index, linear velocity, angular velocity) of every body this rank owns that neighbour `slot` holds as a ghost
+MI_API int ora_world_shard_export_sweep(World* w, uint32_t slot, void* out) {
+    if (!w || !out || !w->shard.enabled || !w->seam.exact || slot >= w->shard.peers.size()) return MI_ERR_INVALID_ARGUMENT;
+    float* msg = static_cast<float*>(out);
+    std::memset(msg, 0, (size_t)(w->shard.capacity + 1u) * MI_SHARD_SWEEP_FLOATS * sizeof(float));
+    uint32_t n = 0;
+    for (uint32_t i = 0; i < (uint32_t)w->bodies.size(); ++i) {
+        if (w->shard.active[i] != 1) continue;
+        const vec3 c = w->seam.cogStart[i];
+        if (!ora::shardInExtended(w->shard, w->shard.bordersX, w->shard.bordersZ, w->shard.peers[slot], c.x, c.z)) continue;
+        if (n < w->shard.capacity) {
+            float* o = msg + (size_t)(n + 1u) * MI_SHARD_SWEEP_FLOATS;
+            std::memcpy(o, &i, 4);
+            const GlobalState& g = w->rb[i];
+            o[1] = g.linearVelocity.x; o[2] = g.linearVelocity.y; o[3] = g.linearVelocity.z;
+            o[4] = g.angularVelocity.x; o[5] = g.angularVelocity.y; o[6] = g.angularVelocity.z;
+        }
+        ++n;
+    }
+    std::memcpy(msg, &n, 4);
+    return n > w->shard.capacity ? MI_ERR_CAPACITY : MI_OK;
+}
+MI_API int ora_world_shard_import_sweep(World* w, const void* msg) {
+    if (!w || !msg || !w->shard.enabled || !w->seam.exact) return MI_ERR_INVALID_ARGUMENT;
+    uint32_t count; std::memcpy(&count, msg, 4);
+    if (count > w->shard.capacity) return MI_ERR_CAPACITY;
+    const float* f = static_cast<const float*>(msg);
+    for (uint32_t r = 0; r < count; ++r) {
+        const float* s = f + (size_t)(r + 1u) * MI_SHARD_SWEEP_FLOATS;
+        uint32_t b; std::memcpy(&b, s, 4);
+        if (b >= w->bodies.size() || w->shard.active[b] != 2) continue;   // only a ghost's copy is replaced
+        w->rb[b].linearVelocity = vec3(s[1], s[2], s[3]); w->rb[b].angularVelocity = vec3(s[4], s[5], s[6]);
+    }
+    return MI_OK;
+}
+MI_API int ora_world_seam_stats(World* w, uint32_t* manifolds, uint32_t* colors, uint32_t* violations) {
+    if (!w) return MI_ERR_INVALID_ARGUMENT;
+    if (manifolds) *manifolds = w->seam.manifolds;
+    if (colors) *colors = w->seam.colors;
+    if (violations) *violations = w->seam.violations;
     return MI_OK;
 }
 // Global sweep axis of a sharded world: every rank's sums (the colliders it owns; rank 0 also the ones without a rigid body) added over

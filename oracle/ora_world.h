@@ -182,6 +182,21 @@ struct World {
     } shard;
     void shardClassify();
     void shardPack(const std::vector<vec3>& oldCog);
+    // Exact seam (include/mi_shard.h): the contact schedule puts the SEAM manifolds (every dynamic body lies in the extended region of at least two
+    // tiles) into the leading colours [0, MI_SEAM_COLORS) and everything else behind them.  A single world given the tiling orders its solve that way;
+    // sharded worlds in exact mode do too, solve the seam manifolds redundantly and hand the owners' velocities of the shared bodies over after every sweep.
+    struct Seam {
+        bool tiling = false;                          // single world: virtual tiling (ora_world_set_seam_tiling)
+        std::vector<float> bx, bz; float margin = 0.f;
+        bool exact = false;                           // sharded world: exact mode (ora_world_shard_set_exact_seam)
+        int (*fn)(void*, World*, uint32_t) = nullptr; void* user = nullptr;
+        std::vector<vec3> cogStart;                   // island-root centres the step classified with
+        std::vector<uint32_t> shared;                 // per body, this step: 0 = seen by its own tile only, else the border it is shared across (seamBorderOf)
+        uint32_t manifolds = 0, colors = 0, violations = 0;
+        int error = MI_OK;
+    } seam;
+    bool seamActive() const { return seam.tiling || (shard.enabled && seam.exact); }
+    void seamClassify();
 
     World();
     ~World();
