@@ -13,6 +13,8 @@ constexpr uint32_t kNoBody = 0xFFFFFFFFu;
 constexpr uint32_t kMaxCells = 1u << 22;
 constexpr uint32_t kOverflowColor = 64;
 constexpr uint32_t kUncolored = 0xFFFFFFFFu;
+constexpr uint32_t kSeamColors = 24;                                  // exact seam (include/mi_shard.h MI_SEAM_COLORS): the seam manifolds' colours
+constexpr unsigned long long kSeamRange = (1ull << kSeamColors) - 1ull;
 constexpr uint32_t kNumBuckets = 21;                          // 6 x 6 upper-triangular collider type pairs
 constexpr uint32_t kColorBins = (kOverflowColor + 1) * 4;     // (colour, contacts per manifold) bins of the solver schedule
 constexpr uint32_t kMaxColorRounds = 4094;                    // 12-bit round tag in the colouring keys
@@ -69,6 +71,7 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numDead;              // sharded world: colliders of bodies this rank does not simulate this step (they take no part in the broad phase)
     uint32_t shardOwned[3];        // sharded world: bodies / manifolds / contacts OWNED by this rank (owner rule: the manifold's first dynamic body)
     uint32_t shardSent[8];         // sharded world: records packed for each neighbour this step (slot order of ShardParams::peers)
+    uint32_t seamStats[3];         // exact seam (include/mi_shard.h): manifolds of the seam class, colours they use, violations of this step (k_seam_stats)
     unsigned long long axisSums[9]; // centre statistics of the colliders this world counts (k_pair_finish): S1[3], S2lo[3], S2hi[3]; a sharded world's are added over the ranks
 };
 
@@ -1224,7 +1227,8 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
                                                         float2 terrainMaterial /* (restitution, friction) of the heightmap */,
                                                         HistSlot* __restrict__ nextTab, uint32_t nextMask, uint8_t* __restrict__ manKept,
                                                         const Shards* __restrict__ statsShards /* non-null: workgroup 0 runs pairFinishStats instead */, uint32_t statsBlocks,
-                                                        const unsigned long long* __restrict__ statsPartials, const int* __restrict__ statsBounds, GridParams* statsGridNext, uint32_t statsCellCap) {
+                                                        const unsigned long long* __restrict__ statsPartials, const int* __restrict__ statsBounds, GridParams* statsGridNext, uint32_t statsCellCap,
+                                                        const uint32_t* __restrict__ seamId /* exact seam: per body, the tile border it is shared across (0 = none); or null */) {
     // (workgroup 0, not the last one: dispatched first, it runs beside all the others; as the last one its ~4 us — 12 us over the 8 192 partial rows
     // of a 2 M-collider sharded scene — started when the kernel was all but over and became its tail)
     if (statsShards && blockIdx.x == 0u) { pairFinishStats(statsShards, sc, nc, statsBlocks, statsPartials, statsBounds, statsGridNext, statsCellCap); return; }
@@ -1251,11 +1255,19 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
     uint32_t dynA = __float_as_uint(ma.w) ? 0x80000000u : 0u;
     uint32_t dynB = __float_as_uint(mb.w) ? 0x80000000u : 0u;
     uint64_t prio = pairPriority(a, b);
-    colWork[m] = make_uint4(bA | dynA, bB | dynB, (uint32_t)prio, (uint32_t)(prio >> 32));
+    // exact seam: a SEAM manifold (all of its dynamic bodies are shared across the same tile border) takes its colour from [0, kSeamColors), any other
+    // one from the colours behind them; bit 30 of the first word tells the colouring rounds which
+    uint32_t seam = 0u;
+    if (seamId) {
+        const uint32_t idA = dynA ? seamId[bA] : 0u, idB = dynB ? seamId[bB] : 0u;
+        seam = ((dynA || dynB) && (!dynA || idA) && (!dynB || idB) && (!(dynA && dynB) || idA == idB)) ? 0x40000000u : 0u;
+    }
+    colWork[m] = make_uint4(bA | dynA | seam, bB | dynB, (uint32_t)prio, (uint32_t)(prio >> 32));
     // a manifold of the previous step keeps its colour (colour 64 = overflow is re-coloured)
     const uint64_t hk = historyKey(nc, a, b);
     uint32_t c = prevTab ? tableLookup(prevTab, prevMask, hk) : kUncolored;
     if (isNew) isNew[m] = (c == kUncolored && !terrain) ? 1u : 0u;   // not in the previous step's collision list: collision-begin event
+    if (seamId && c < kOverflowColor && (c < kSeamColors) != (seam != 0u)) c = kOverflowColor;   // it changed class: re-coloured
     if (c < kOverflowColor) {
         if (dynA) atomicOr(&bodyUsed[bA], 1ull << c);
         if (dynB) atomicOr(&bodyUsed[bB], 1ull << c);
@@ -1408,13 +1420,14 @@ __global__ __launch_bounds__(256) void k_scatter_states(uint32_t n, const uint32
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_color_round(const StepScalars* __restrict__ sc, uint32_t round, const uint4* __restrict__ colWork, uint32_t* __restrict__ color,
                                                      const unsigned long long* __restrict__ topCur, unsigned long long* __restrict__ topNext,
-                                                     unsigned long long* __restrict__ bodyUsed, uint32_t* __restrict__ roundFlags) {
+                                                     unsigned long long* __restrict__ bodyUsed, uint32_t* __restrict__ roundFlags, uint32_t seamMode /* exact seam: two colour ranges */) {
     if (round > 0 && roundFlags[round - 1] == 0) return;
     uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= sc->numManifolds || color[m] != kUncolored) return;
     uint4 w = colWork[m];
     bool dynA = (w.x >> 31) != 0, dynB = (w.y >> 31) != 0;
-    uint32_t bA = w.x & 0x7FFFFFFFu, bB = w.y & 0x7FFFFFFFu;
+    const bool seam = (w.x & 0x40000000u) != 0u;
+    uint32_t bA = w.x & 0x3FFFFFFFu, bB = w.y & 0x7FFFFFFFu;
     unsigned long long prio = ((unsigned long long)w.w << 32) | (unsigned long long)w.z;
     bool lost = true;
     if (round > 0) {
@@ -1423,6 +1436,7 @@ __global__ __launch_bounds__(256) void k_color_round(const StepScalars* __restri
     }
     if (!lost) {
         unsigned long long mask = (dynA ? bodyUsed[bA] : 0ull) | (dynB ? bodyUsed[bB] : 0ull);
+        if (seamMode) mask |= seam ? ~kSeamRange : kSeamRange;
         uint32_t c = kOverflowColor;
         if (~mask != 0ull) {
             c = (uint32_t)__ffsll((long long)~mask) - 1u;
@@ -2702,6 +2716,111 @@ __global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, ShardBufs in,
     bPos[b] = make_float4(s[1], s[2], s[3], 0.f); bRot[b] = make_float4(s[4], s[5], s[6], s[7]);
     bLinVel[b] = make_float4(s[8], s[9], s[10], 0.f); bAngVel[b] = make_float4(s[11], s[12], s[13], 0.f);
     known[b] = 1u;
+}
+// ---- exact seam (include/mi_shard.h "Exact seam")
+// Which tile border is v within the margin of?  b4 = the borders around this rank's column (ShardParams::bx / bz), mine = its index; 0 = none,
+// else 1 + the border's index.  Same comparisons as shardInExtended; tiles are at least two margins wide (at most one border per axis).
+__device__ __forceinline__ uint32_t seamNear(const float* b4, uint32_t mine, float m, float v) {
+    const uint32_t c = v < b4[1] ? 0u : v < b4[2] ? 1u : 2u;      // the column v lies in, relative to mine - 1 (only bodies this rank simulates are asked about)
+    const uint32_t t = mine + c;                                   // = (that column's index) + 1
+    if (v < b4[c] + m) return t - 1u;                              // its lower border (index t - 2): id t - 1   (-inf at the rim: never)
+    if (v >= b4[c + 1u] - m) return t;                             // its upper border (index t - 1): id t
+    return 0u;
+}
+__device__ __forceinline__ uint32_t seamBorderOf(const ShardParams& sp, float x, float z) {
+    return seamNear(sp.bx, sp.myTile % sp.tilesX, sp.margin, x) | (seamNear(sp.bz, sp.myTile / sp.tilesX, sp.margin, z) << 16);
+}
+// sharded world in exact mode: after k_shard_classify, for the bodies this rank simulates
+__global__ __launch_bounds__(256) void k_seam_classify_shard(uint32_t nb, ShardParams sp, const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bCogInvMass,
+                                                             const uint32_t* __restrict__ root, const uint8_t* __restrict__ bodyActive, uint32_t* __restrict__ seamId) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    uint32_t id = 0u;
+    if (bodyActive[i]) { const uint32_t r = root[i]; const V3 c = shardCog(bPos[r], bRot[r], bCogInvMass[r]); id = seamBorderOf(sp, c.x, c.z); }
+    seamId[i] = id;
+}
+// single world that was told a tiling (mi_world_set_seam_tiling): all borders, linear search (a handful of tiles per axis)
+__global__ __launch_bounds__(256) void k_seam_classify_tiling(uint32_t nb, const float* __restrict__ bx, uint32_t nx, const float* __restrict__ bz, uint32_t nz, float m,
+                                                              const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bCogInvMass,
+                                                              const uint32_t* __restrict__ root, uint32_t* __restrict__ seamId) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nb) return;
+    const uint32_t r = root[i];
+    const V3 c = shardCog(bPos[r], bRot[r], bCogInvMass[r]);
+    auto near = [&](const float* b, uint32_t n, float v) -> uint32_t {
+        uint32_t t = 0; while (t < n && v >= b[t]) ++t;
+        if (t > 0u && v < b[t - 1u] + m) return t;
+        if (t < n && v >= b[t] - m) return t + 1u;
+        return 0u;
+    };
+    seamId[i] = near(bx, nx, c.x) | (near(bz, nz, c.z) << 16);
+}
+// after the colouring: seam manifolds, the colours they use, violations (a manifold outside the seam class that touches a ghost: the margin does not cover
+// the reach of a contact; a seam manifold that found no colour among the kSeamColors: it would be solved after the interior)
+__global__ __launch_bounds__(256) void k_seam_stats(StepScalars* sc, const uint4* __restrict__ colWork, const uint32_t* __restrict__ color, const uint8_t* __restrict__ bodyActive /* or null */) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    bool seam = false, bad = false; uint32_t c = 0u;
+    if (m < sc->numManifolds) {
+        const uint4 w = colWork[m];
+        const bool dynA = (w.x >> 31) != 0u, dynB = (w.y >> 31) != 0u;
+        seam = (w.x & 0x40000000u) != 0u;
+        c = color[m];
+        if (seam) bad = c >= kSeamColors;
+        else if (bodyActive) bad = (dynA && bodyActive[w.x & 0x3FFFFFFFu] == 2u) || (dynB && bodyActive[w.y & 0x7FFFFFFFu] == 2u);
+    }
+    const unsigned long long ms = __ballot(seam), mb = __ballot(bad);
+    if (seam && c < kSeamColors) atomicMax(&sc->seamStats[1], c + 1u);
+    if ((threadIdx.x & 63u) == 0u) { if (ms) atomicAdd(&sc->seamStats[0], (uint32_t)__popcll(ms)); if (mb) atomicAdd(&sc->seamStats[2], (uint32_t)__popcll(mb)); }
+}
+// Per-sweep hand-over.  At the start of the step: for every neighbour slot the bodies this rank OWNS that the neighbour holds as ghosts (their centres, as
+// classified, lie in its extended tile); after every sweep their velocities are gathered into one fixed-size message per neighbour (record 0 = count; a
+// record = body index, linear velocity, angular velocity, pad) and the neighbours' are scattered into the ghost copies — the version tags in .w stay.
+constexpr uint32_t kSweepRecordFloats = 8;
+struct SweepLists { uint32_t* p[8]; };
+__global__ __launch_bounds__(256) void k_seam_sweep_list(uint32_t nb, ShardParams sp, const uint8_t* __restrict__ bodyActive, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
+                                                         const float4* __restrict__ bCogInvMass, const uint32_t* __restrict__ root, SweepLists lists, uint32_t capacity, uint32_t* __restrict__ counts) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool owned = i < nb && bodyActive[i] == 1u;
+    if (!__ballot(owned)) return;
+    V3 c(0.f, 0.f, 0.f);
+    if (owned) { const uint32_t r = root[i]; c = shardCog(bPos[r], bRot[r], bCogInvMass[r]); }
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t slot = 0; slot < sp.numPeers; ++slot) {
+        const bool want = owned && shardInExtended(sp, sp.peers[slot], c.x, c.z);
+        const unsigned long long mask = __ballot(want);
+        if (!mask) continue;
+        const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
+        uint32_t base = 0;
+        if (lane == leader) base = atomicAdd(&counts[slot], (uint32_t)__popcll(mask));
+        base = (uint32_t)__shfl((int)base, (int)leader, 64);
+        if (!want) continue;
+        const uint32_t r = base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull));
+        if (r < capacity) lists.p[slot][r] = i;                       // (the count still grows: the host sees the overflow)
+    }
+}
+// blockIdx.y = neighbour slot
+__global__ __launch_bounds__(256) void k_seam_sweep_pack(SweepLists lists, const uint32_t* __restrict__ counts, uint32_t capacity, const float4* __restrict__ gVel, ShardBufs out) {
+    const uint32_t slot = blockIdx.y, r = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t n = counts[slot];
+    float* msg = out.p[slot];
+    if (r == 0u) msg[0] = __uint_as_float(n);
+    if (r >= min(n, capacity)) return;
+    const uint32_t b = lists.p[slot][r];
+    const float4 v = gVel[2 * (size_t)b], w = gVel[2 * (size_t)b + 1];
+    float4* o = reinterpret_cast<float4*>(msg + (size_t)(r + 1u) * kSweepRecordFloats);
+    o[0] = make_float4(__uint_as_float(b), v.x, v.y, v.z); o[1] = make_float4(w.x, w.y, w.z, 0.f);
+}
+__global__ __launch_bounds__(256) void k_seam_sweep_unpack(uint32_t nb, ShardBufs in, uint32_t capacity, const uint8_t* __restrict__ bodyActive, float4* __restrict__ gVel) {
+    const float* msg = in.p[blockIdx.y];
+    const uint32_t count = min(__float_as_uint(msg[0]), capacity);
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= count) return;
+    const float4* s = reinterpret_cast<const float4*>(msg + (size_t)(r + 1u) * kSweepRecordFloats);
+    const float4 a = s[0], w = s[1];
+    const uint32_t b = __float_as_uint(a.x);
+    if (b >= nb || bodyActive[b] != 2u) return;                        // only a ghost's copy is replaced
+    float4* g = gVel + 2 * (size_t)b;
+    g[0] = make_float4(a.y, a.z, a.w, g[0].w); g[1] = make_float4(w.x, w.y, w.z, g[1].w);
 }
 // owned bodies per bin of [lo, hi) along x (axis 0) or z (1), by the centre their island was classified with; the end bins take what lies outside
 __global__ __launch_bounds__(256) void k_shard_histogram(uint32_t nb, uint32_t axis, float lo, float scale, uint32_t bins, const uint8_t* __restrict__ bodyActive,

@@ -172,7 +172,17 @@ struct mi_world {
         uint32_t owned[3] = {0, 0, 0};
         void* comm = nullptr;                    // ncclComm_t
         size_t messageFloats() const { return (size_t)(capacity + 1u) * kShardRecordFloats; }
+        // exact seam (include/mi_shard.h): per-sweep hand-over of the owners' velocities of the shared bodies
+        bool exact = false; mi_shard_sweep_fn sweepFn = nullptr; void* sweepUser = nullptr;
+        DBuf<float> sweepSend[8], sweepRecv[8], sweepImport; DBuf<uint32_t> sweepList[8], sweepCount;
+        uint32_t sweepsDone = 0; uint32_t* sweepCountHost = nullptr; bool sweepCountPending = false;
+        size_t sweepFloats() const { return (size_t)(capacity + 1u) * kSweepRecordFloats; }
     } shard;
+    // exact seam: a single world that was told a tiling orders its colours the same way (mi_world_set_seam_tiling)
+    struct SeamTiling { bool on = false; std::vector<float> bx, bz; float margin = 0.f; DBuf<float> dBx, dBz; } seamTiling;
+    DBuf<uint32_t> seamId; uint32_t seamLast[2] = {0, 0}; uint64_t seamViolations = 0;
+    bool seamMode() const { return seamTiling.on || (shard.enabled && shard.exact); }
+    int shardSweepExchange(uint32_t sweep);
     int shardExchange();
     int shardCheckOverflow(bool sync);
     int shardSyncAxis();
@@ -622,6 +632,7 @@ int mi_world::upload() {
     }
     HIP_TRY(hipStreamSynchronize(stream));
     topologyDirty = false; hostStale = false; haveEstimates = false; gridValid = false;
+    if (seamTiling.on && !shard.enabled) { int rc = shardBuildRoots(); if (rc != MI_OK) return rc; }
     if (shard.enabled) {   // the previous step's counts say nothing about the new topology
         int rc = shardBuildRoots(); if (rc != MI_OK) return rc;
         std::vector<uint8_t> kn(std::max(nb, 1u), 1u);
@@ -740,6 +751,7 @@ __global__ void k_reset_scalars(StepScalars* sc, Shards* sh, uint32_t* roundFlag
     if (t == 0) {
         sc->numDead = 0; sc->shardOwned[0] = sc->shardOwned[1] = sc->shardOwned[2] = 0;
         for (int q = 0; q < 8; ++q) sc->shardSent[q] = 0;
+        sc->seamStats[0] = sc->seamStats[1] = sc->seamStats[2] = 0;
         sc->extentSum = 0.0; sc->largeThreshold = 0.f; sc->numLarge = 0; sc->numPairs = 0; sc->numOverlaps = 0; sc->numManifolds = 0; sc->numContacts = 0; sc->solveError = 0;
         sc->specOverflow = 0; sc->totalTiles = 0; sc->totalCt = 0; sc->colorPending = 0; sc->partitioned = 0; sc->gjkLo = 0; sc->gjkHi = 0; sc->numCells = 0; sc->numPairsFound = 0; sc->numEvents = 0; sc->numInterPairs = 0; sc->numInteractions = 0; sc->numHmContacts = 0; sc->numHmColliders = 0; sc->numEpa = 0;
         for (int q = 0; q < 16; ++q) sc->boxHitCount[q] = 0;
@@ -787,12 +799,17 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     if (shard.stepOpen) shard.prevValid = false;   // the previous step ended in an error: what its kernels left behind is not what the flags describe
     shard.stepOpen = true;
     if (debugOrderPending && (heightmap || shard.enabled)) return fail(MI_ERR_UNSUPPORTED, "mi_debug_set_solve_order: not with heightmap terrain or sharding");
-    const bool spec = specEnabled && haveEstimates && flowSolver && !launchFallbackSteps && !debugOrderPending && (!usesInteractions || last.numInteractions <= 32768u);   // (triggers / force fields: ordered and applied on the device while there are at most 32 k interactions)
+    const bool exactSeam = shard.enabled && shard.exact;   // every rank must take the same path through the step (its sweeps end in an exchange): no speculation
+    shard.sweepsDone = 0;
+    const bool spec = specEnabled && haveEstimates && flowSolver && !launchFallbackSteps && !debugOrderPending && !exactSeam && (!usesInteractions || last.numInteractions <= 32768u);   // (triggers / force fields: ordered and applied on the device while there are at most 32 k interactions)
     ++totalSteps; if (spec) ++specSteps;
     int rc = runStep(settings, dt, spec);
     // a step that asks to be re-run has written nothing persistent; each re-run is synchronous and one rung further down the ladder
     // speculative -> exact sizes -> unpartitioned -> dispatch-ordered dataflow kernel -> one launch per colour
-    for (int attempt = 0; rc == STEP_RETRY && attempt < 6; ++attempt) { ++specRetries; rc = runStep(settings, dt, false); }
+    for (int attempt = 0; rc == STEP_RETRY && attempt < 6; ++attempt) {
+        if (exactSeam && shard.sweepsDone) return fail(MI_ERR_DEVICE, "exact seam: the step would have to be re-run after sweeps were already exchanged with the neighbours");
+        ++specRetries; rc = runStep(settings, dt, false);
+    }
     if (rc == STEP_RETRY) return fail(MI_ERR_DEVICE, "step could not be completed on any solver path");
     if (rc == MI_OK && launchFallbackSteps) --launchFallbackSteps;
     debugOrderPending = false; debugOrder.clear();   // (one step only, whatever became of it)
@@ -964,6 +981,19 @@ enqueue_section:
         if (!shard.prevValid) { HIP_TRY(L.memsetAsync(shard.activePrev.p, 1, nb, st)); if (!L.dry) shard.prevValid = true; }   // after an upload / an outside write: every body is copied once
         L.launch(k_shard_classify, dim3(divUp(nb, B)), dim3(B), 0, st, nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.active.p, shards.p, shard.root.p, shard.known.p);
     }
+    const bool seamOn = seamMode() && nb;
+    if (seamOn) {   // exact seam: which tile border every body is shared across (decides the class of its manifolds)
+        HIP_TRY(seamId.ensure(nb));
+        if (shard.enabled) L.launch(k_seam_classify_shard, dim3(divUp(nb, B)), dim3(B), 0, st, nb, shard.sp, bPos.p, bRot.p, bCogInvMass.p, shard.root.p, shard.active.p, seamId.p);
+        else L.launch(k_seam_classify_tiling, dim3(divUp(nb, B)), dim3(B), 0, st, nb, seamTiling.dBx.p, (uint32_t)seamTiling.bx.size(), seamTiling.dBz.p, (uint32_t)seamTiling.bz.size(), seamTiling.margin,
+                      bPos.p, bRot.p, bCogInvMass.p, shard.root.p, seamId.p);
+    }
+    if (shard.enabled && shard.exact && nb) {   // ... and the bodies whose velocities go to each neighbour after every sweep
+        HIP_TRY(shard.sweepCount.ensure(8));
+        HIP_TRY(L.memsetAsync(shard.sweepCount.p, 0, 8 * sizeof(uint32_t), st));
+        SweepLists lists{}; for (uint32_t k = 0; k < shard.sp.numPeers; ++k) { HIP_TRY(shard.sweepList[k].ensure(shard.capacity)); lists.p[k] = shard.sweepList[k].p; }
+        L.launch(k_seam_sweep_list, dim3(divUp(nb, B)), dim3(B), 0, st, nb, shard.sp, shard.active.p, bPos.p, bRot.p, bCogInvMass.p, shard.root.p, lists, shard.capacity, shard.sweepCount.p);
+    }
     // with a grid prepared by the previous step the world colliders are computed INSIDE k_bp_prepare (one launch, one pass over the AABB rows less)
     static const bool fuseWorldEnabled = !(std::getenv("MI_FUSE_WORLD") && std::getenv("MI_FUSE_WORLD")[0] == '0');
     const bool fuseWorld = nc && gridValid && fuseWorldEnabled;
@@ -1090,7 +1120,7 @@ enqueue_section:
                                                         tabValid ? tab[tabCur].p : nullptr, tabMask[tabCur], bodyUsed.p, eventsEnabled ? manIsNew.p : nullptr, sc,
                                                         heightmap ? make_float2(hmParams.restitution, hmParams.friction) : make_float2(0.f, 0.f),
                                                         tab[tabCur ^ 1].p, tabMask[tabCur ^ 1], manKept.p,
-                                                        statsInEmit ? shards.p : nullptr, statsBlocks, axisPartials.p, blockBounds.p, statsGridNext, statsCellCap);
+                                                        statsInEmit ? shards.p : nullptr, statsBlocks, axisPartials.p, blockBounds.p, statsGridNext, statsCellCap, seamOn ? seamId.p : nullptr);
     }
     // ---------------------------------------------------------------------------------------------- triggers / force fields
     std::vector<mi_event> triggerEvents;
@@ -1113,7 +1143,8 @@ enqueue_section:
     uint32_t tilesCap = 0, ctCap = 0, eventCap = 0, xcdListCap = 0;
     bool shardCounted = false;   // sharded world: this rank's manifolds / contacts are counted inside k_manifold_keys when that runs, else by k_shard_count
     // XCD partitioning pays once the pile is big enough to keep eight L2s busy; it needs the persistent kernel (no joints)
-    const bool xcdAble = flowSolver && persistSolver && persistXcd && !xcdOnly && joints.count() == 0 && (persistWaves & 7u) == 0u && !debugOrderPending;
+    const bool exactSeamStep = shard.enabled && shard.exact;   // every sweep ends in an exchange with the neighbours: one launch per sweep (the generic dataflow path), nothing persistent
+    const bool xcdAble = flowSolver && persistSolver && persistXcd && !xcdOnly && joints.count() == 0 && (persistWaves & 7u) == 0u && !debugOrderPending && !exactSeamStep;
     // small piles: the 128 waves of ONE XCD run the whole solve, every body hand-over goes through that XCD's L2 (tileOwner(..., single))
     const bool xcdSingle = xcdAble && persistXcdSingle && nmBound && nmBound < xcdMinManifolds && divUp(divUp(nmBound, 64) + kSchedBins + 8, persistWaves / 8u) <= 16u;
     const bool xcdPlan = xcdAble && (nmBound >= xcdMinManifolds || xcdSingle);
@@ -1146,7 +1177,7 @@ enqueue_section:
         uint32_t round = 0;
         while (true) {
             for (uint32_t r = 0; r < colorBatch; ++r, ++round)
-                L.launch(k_color_round, dim3(divUp(nmBound, B)), dim3(B), 0, st, sc, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlagsPtr());
+                L.launch(k_color_round, dim3(divUp(nmBound, B)), dim3(B), 0, st, sc, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlagsPtr(), seamOn ? 1u : 0u);
             // schedule bins -> tiles (valid once the last round left nothing uncoloured: StepScalars::colorPending)
             L.launch(k_bin_hist, dim3(binBlocks), dim3(256), 0, st, sc, binBlocks, perm, color.p, manInfo.p, blockHist.p);
             HIP_TRY(scanBins.run(L, blockHist.p, blockScan.p, kColorBins * binBlocks, st));
@@ -1163,6 +1194,7 @@ enqueue_section:
             colorBatch = 8;
         }
         colorRoundsLaunched = round;
+        if (seamOn) L.launch(k_seam_stats, dim3(divUp(nmBound, B)), dim3(B), 0, st, sc, colWork.p, color.p, shard.enabled ? shard.active.p : nullptr);
         {   // colour history for the next step, into the OTHER table (it becomes current only if this step turns out valid)
             const int nt = tabCur ^ 1;   // sized and cleared before k_emit_manifolds (narrow phase stage)
             if (eventsEnabled) {   // begins: manifolds not in the previous table; ends: previous pairs not in this step's table
@@ -1197,7 +1229,7 @@ enqueue_section:
     const uint32_t tilesLaunch = spec ? tilesCap : totalTiles;   // sync mode knows the exact tile count (mirrorSchedule)
     const bool useFlow = flowSolver && !launchFallbackSteps && !debugOrderPending && (spec || bins[kSchedBins - 1].count == 0 || !nmBound);   // the overflow colour needs the sequential kernel
     static const bool fuseEnabled = !(std::getenv("MI_FUSE_JOINTS") && std::getenv("MI_FUSE_JOINTS")[0] == '0');
-    const bool fused = useFlow && fuseEnabled && joints.allInIslands();   // joints of all sweeps inside the dataflow launch
+    const bool fused = useFlow && fuseEnabled && joints.allInIslands() && !exactSeamStep;   // joints of all sweeps inside the dataflow launch
     // slots (tiles) one persistent workgroup must hold: exact in a synchronous step, from the previous step's lists (+ slack) in a speculative one
     auto persistSlots = [&](uint32_t tiles, bool xcd, bool speculative) -> uint32_t {
         if (!xcd) return divUp(tiles, xcdOnly ? persistWaves / 8u : persistWaves);
@@ -1207,7 +1239,7 @@ enqueue_section:
         return divUp(std::max(longest, 1u), persistWaves / 8u);
     };
     // the persistent kernel keeps the accumulated impulses in LDS while they fit: k_contact_init then need not write the impulse granules
-    const bool persistPlan = !fused && useFlow && persistSolver && joints.count() == 0 && tilesLaunch;
+    const bool persistPlan = !fused && useFlow && persistSolver && joints.count() == 0 && tilesLaunch && !exactSeamStep;
     const uint32_t persistMaxSlots = persistPlan ? persistSlots(tilesLaunch, xcdPlan, spec) : 0u;
     const bool impNeeded = !(persistPlan && persistImpLds && persistMaxSlots * (4u * 512u + 20u) <= 38u * 1024u);
     if (nmBound) {
@@ -1222,7 +1254,7 @@ enqueue_section:
     if (rc != MI_OK) return rc;
     mark();  // 6
     bool solveAttached = false;
-    const bool willPersist = !(useFlow && fuseEnabled && joints.allInIslands()) && persistPlan && persistMaxSlots * 20u <= 38u * 1024u;
+    const bool willPersist = !fused && persistPlan && persistMaxSlots * 20u <= 38u * 1024u;
     if (attached && !willPersist) (void)hipEventRecord(ev[6], st);   // another solver path (several launches): classic recorded events
     const uint32_t iters = settings.num_rigid_solver_iterations;
     usedFlow = useFlow; usedPersist = false; usedFused = fused; usedXcd = false; usedXcdSingle = false;
@@ -1280,11 +1312,11 @@ enqueue_section:
         if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
     } else if (useFlow) {
         // no joints between the sweeps -> all sweeps in one launch; otherwise one launch per sweep (joints run in between)
-        const uint32_t perLaunch = joints.count() == 0 && (uint64_t)std::max(tilesLaunch, 1u) * iters < 0x7FFFFFFFull ? iters : 1u;
+        const uint32_t perLaunch = joints.count() == 0 && !exactSeamStep && (uint64_t)std::max(tilesLaunch, 1u) * iters < 0x7FFFFFFFull ? iters : 1u;
         solveLaunches = tilesLaunch ? (iters + perLaunch - 1) / perLaunch : 0;
         for (uint32_t it = 0; it < iters; it += perLaunch) {
             if (perLaunch == 1) joints.solveIteration(*this, st);   // distance, ball, fixed, hinge, cone-twist, slider (constraints.cpp:3764-3769)
-            if (!tilesLaunch) continue;
+            if (!tilesLaunch) { if (exactSeamStep) { int rcx = shardSweepExchange(it); if (rcx != MI_OK) return rcx; } continue; }
             if (profileSolve) {
                 size_t e = 2 * (size_t)profLaunches;
                 while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
@@ -1292,6 +1324,7 @@ enqueue_section:
             }
             L.launch(k_contact_solve_flow, dim3(tilesLaunch * perLaunch), dim3(64), flowLds, st, it, perLaunch, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p, sc);
             if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
+            if (exactSeamStep) { int rcx = shardSweepExchange(it); if (rcx != MI_OK) return rcx; }   // exact seam: the owners' velocities of the shared bodies replace the ghost copies
         }
     } else {
         // one launch per colour per sweep (MI_SOLVER=launch, or an overflow colour is present); synchronous mode only
@@ -1330,6 +1363,7 @@ enqueue_section:
             }
             if (tailStart < tailEnd) L.launch(k_contact_solve_tail, dim3(1), dim3(256), 0, st, binInfo.p, tailStart, tailEnd, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
             if (bins[kSchedBins - 1].count) L.launch(k_contact_solve_serial, dim3(1), dim3(64), 0, st, bins[kSchedBins - 1], slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, gVel.p);
+            if (exactSeamStep) { int rcx = shardSweepExchange(it); if (rcx != MI_OK) return rcx; }
         }
     }
     if (shard.enabled && pairBound && !shardCounted) L.launch(k_shard_count, dim3(divUp(nmBound ? nmBound : 1u, B)), dim3(B), 0, st, nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc, shards.p);
@@ -1508,6 +1542,7 @@ enqueue_section:
     last.gjkSpan = sticky(hs.gjkHi - hs.gjkLo, last.gjkSpan, 256);
     last.numInterPairs = sticky(hs.numInterPairs, last.numInterPairs, 256); last.numInteractions = sticky(hs.numInteractions, last.numInteractions, 256);
     for (int k = 0; k < 3; ++k) shard.owned[k] = hs.shardOwned[k];
+    if (seamMode()) { seamLast[0] = hs.seamStats[0]; seamLast[1] = hs.seamStats[1]; seamViolations += hs.seamStats[2]; }
     shard.flagsSwapPending = shard.enabled; shard.stepOpen = false; shard.flagsOfAStep = shard.enabled;
     static const bool xcdStats = std::getenv("MI_XCD_STATS") != nullptr;   // development: how many bodies stayed XCD-local
     if (xcdStats && usedXcd && ((totalSteps % 50u) == 0u || std::getenv("MI_XCD_NOSORT"))) {
@@ -2489,6 +2524,104 @@ int mi_world::shardExchange() {
     sh.axisHostCurrent = false;
     HIP_TRY(hipEventRecord(sh.exEv[1], st));
     hostStale = true;
+    return MI_OK;
+}
+// Exact seam: the hand-over after sweep `sweep` (include/mi_shard.h).  The velocities of the bodies this rank owns and a neighbour holds as ghosts are gathered
+// into one fixed-size message per neighbour; library transport: sent / received / scattered on the world's stream; caller's transport: the stream is
+// drained and the caller's function moves mi_world_shard_export_sweep -> mi_world_shard_import_sweep.
+int mi_world::shardSweepExchange(uint32_t sweep) {
+    ShardState& sh = shard;
+    hipStream_t st = stream;
+    const uint32_t nb = (uint32_t)bodies.size();
+    ShardBufs send{}, recv{}; SweepLists lists{};
+    for (uint32_t k = 0; k < sh.sp.numPeers; ++k) {
+        HIP_TRY(sh.sweepSend[k].ensure(sh.sweepFloats())); HIP_TRY(sh.sweepRecv[k].ensure(sh.sweepFloats()));
+        send.p[k] = sh.sweepSend[k].p; recv.p[k] = sh.sweepRecv[k].p; lists.p[k] = sh.sweepList[k].p;
+    }
+    if (sh.sp.numPeers) k_seam_sweep_pack<<<dim3(divUp(sh.capacity, 256), sh.sp.numPeers), 256, 0, st>>>(lists, sh.sweepCount.p, sh.capacity, gVel.p, send);
+    if (sh.sweepsDone++ == 0u && sh.sp.numPeers) {   // once per step: did the lists fit?  (the step is synchronous in this mode anyway)
+        uint32_t counts[8];
+        HIP_TRY(hipMemcpyAsync(counts, sh.sweepCount.p, sizeof counts, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (uint32_t k = 0; k < sh.sp.numPeers; ++k) if (counts[k] > sh.capacity) return fail(MI_ERR_CAPACITY, "exact seam: more shared bodies than a neighbour message holds (mi_shard_desc::max_records)");
+    }
+    if (sh.rccl) {
+        Rccl* r = rccl();
+        const size_t n = sh.sweepFloats();
+        int e = r->GroupStart(); if (e) return fail(MI_ERR_DEVICE, "ncclGroupStart failed");
+        for (uint32_t k = 0; k < sh.sp.numPeers && !e; ++k) {
+            e = r->Send(sh.sweepSend[k].p, n, kNcclFloat32, (int)sh.peerRanks[k], sh.comm, st);
+            if (!e) e = r->Recv(sh.sweepRecv[k].p, n, kNcclFloat32, (int)sh.peerRanks[k], sh.comm, st);
+        }
+        const int e2 = r->GroupEnd();
+        if (e || e2) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e ? e : e2) : "RCCL send / receive failed");
+        if (sh.sp.numPeers) k_seam_sweep_unpack<<<dim3(divUp(sh.capacity, 256), sh.sp.numPeers), 256, 0, st>>>(nb, recv, sh.capacity, sh.active.p, gVel.p);
+        return MI_OK;
+    }
+    HIP_TRY(hipStreamSynchronize(st));   // the messages are complete
+    if (sh.sweepFn) { const int rc = sh.sweepFn(sh.sweepUser, this, sweep); if (rc != MI_OK) return fail(MI_ERR_DEVICE, "exact seam: the caller's sweep exchange failed"); }
+    return MI_OK;
+}
+MI_API int mi_world_set_seam_tiling(mi_world* w, const mi_shard_desc* d) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    HIP_TRY(hipSetDevice(w->device));
+    w->tabValid = false; w->haveEstimates = false;   // the colour ranges mean something else from here on
+    if (!d) { w->seamTiling.on = false; return MI_OK; }
+    if (w->shard.enabled) return fail(MI_ERR_UNSUPPORTED, "a sharded world takes its tiling from mi_world_shard_enable (mi_world_shard_set_exact_seam)");
+    if (!d->tiles_x || !d->tiles_z || !(d->tile_size_x > 0.f) || !(d->tile_size_z > 0.f) || !(d->ghost_margin > 0.f) || 2.f * d->ghost_margin > d->tile_size_x || 2.f * d->ghost_margin > d->tile_size_z)
+        return fail(MI_ERR_INVALID_ARGUMENT, "tiles must be at least two ghost margins wide");
+    mi_world::SeamTiling& t = w->seamTiling;
+    t.bx.clear(); t.bz.clear(); t.margin = d->ghost_margin;
+    for (uint32_t i = 1; i < d->tiles_x; ++i) t.bx.push_back((float)((double)d->origin_x + (double)i * (double)d->tile_size_x));
+    for (uint32_t i = 1; i < d->tiles_z; ++i) t.bz.push_back((float)((double)d->origin_z + (double)i * (double)d->tile_size_z));
+    HIP_TRY(t.dBx.ensure(std::max<size_t>(t.bx.size(), 1))); HIP_TRY(t.dBz.ensure(std::max<size_t>(t.bz.size(), 1)));
+    if (!t.bx.empty()) HIP_TRY(hipMemcpy(t.dBx.p, t.bx.data(), t.bx.size() * sizeof(float), hipMemcpyHostToDevice));
+    if (!t.bz.empty()) HIP_TRY(hipMemcpy(t.dBz.p, t.bz.data(), t.bz.size() * sizeof(float), hipMemcpyHostToDevice));
+    t.on = true;
+    if (!w->topologyDirty) { int rc = w->shardBuildRoots(); if (rc != MI_OK) return rc; }   // (an upload builds them otherwise)
+    return MI_OK;
+}
+MI_API int mi_world_shard_set_exact_seam(mi_world* w, uint32_t enable, mi_shard_sweep_fn fn, void* user) {
+    if (!w || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    mi_world::ShardState& sh = w->shard;
+    if (enable && sh.desc.tiles_x > 1u && sh.desc.tiles_z > 1u) return fail(MI_ERR_UNSUPPORTED, "exact seam: x- or z-slabs only (at a corner a shared body is seen by four tiles)");
+    if (enable && (2.f * sh.desc.ghost_margin > sh.desc.tile_size_x || 2.f * sh.desc.ghost_margin > sh.desc.tile_size_z)) return fail(MI_ERR_INVALID_ARGUMENT, "exact seam: tiles must be at least two ghost margins wide");
+    HIP_TRY(hipSetDevice(w->device));
+    if (sh.exact != (enable != 0u)) { w->tabValid = false; w->haveEstimates = false; }   // the colour ranges mean something else from here on
+    sh.exact = enable != 0u; sh.sweepFn = fn; sh.sweepUser = user;
+    if (sh.exact) { HIP_TRY(sh.sweepImport.ensure(sh.sweepFloats())); HIP_TRY(w->seamId.ensure(std::max<size_t>(w->bodies.size(), 1))); }
+    return MI_OK;
+}
+MI_API int mi_world_shard_sweep_message_bytes(mi_world* w, uint64_t* out) {
+    if (!w || !out || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
+    *out = (uint64_t)w->shard.sweepFloats() * sizeof(float); return MI_OK;
+}
+MI_API int mi_world_shard_export_sweep(mi_world* w, uint32_t slot, void* out) {
+    if (!w || !out || !w->shard.enabled || !w->shard.exact || slot >= w->shard.sp.numPeers || !w->shard.sweepSend[slot].p) return fail(MI_ERR_INVALID_ARGUMENT, "no sweep message for this slot");
+    HIP_TRY(hipSetDevice(w->device));
+    HIP_TRY(hipMemcpyAsync(out, w->shard.sweepSend[slot].p, w->shard.sweepFloats() * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    return MI_OK;
+}
+MI_API int mi_world_shard_import_sweep(mi_world* w, const void* msg) {
+    if (!w || !msg || !w->shard.enabled || !w->shard.exact) return fail(MI_ERR_INVALID_ARGUMENT, "not an exact-seam world");
+    if (w->shard.rccl) return fail(MI_ERR_INVALID_ARGUMENT, "the library transport exchanges the sweeps itself");
+    mi_world::ShardState& sh = w->shard;
+    uint32_t count; std::memcpy(&count, msg, 4);
+    if (count > sh.capacity) return fail(MI_ERR_CAPACITY, "sweep message holds more records than max_records");
+    HIP_TRY(hipSetDevice(w->device));
+    HIP_TRY(sh.sweepImport.ensure(sh.sweepFloats()));
+    HIP_TRY(hipMemcpyAsync(sh.sweepImport.p, msg, (size_t)(count + 1u) * kSweepRecordFloats * sizeof(float), hipMemcpyHostToDevice, w->stream));
+    ShardBufs in{}; in.p[0] = sh.sweepImport.p;
+    if (count) k_seam_sweep_unpack<<<dim3(divUp(count, 256), 1), 256, 0, w->stream>>>((uint32_t)w->bodies.size(), in, sh.capacity, sh.active.p, w->gVel.p);
+    HIP_TRY(hipStreamSynchronize(w->stream));   // the staging buffer is free again
+    return MI_OK;
+}
+MI_API int mi_world_seam_stats(mi_world* w, uint32_t* manifolds, uint32_t* colors, uint32_t* violations) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    if (manifolds) *manifolds = w->seamLast[0];
+    if (colors) *colors = w->seamLast[1];
+    if (violations) *violations = (uint32_t)std::min<uint64_t>(w->seamViolations, 0xFFFFFFFFull);
     return MI_OK;
 }
 // sapAxis (host) <- the device word, when a library-transport exchange has moved it on
