@@ -87,6 +87,31 @@ class ShardedWorld:
                 self.transport = "dist"
                 self.note = "library RCCL transport unavailable (" + (self.note or "on another rank") + "): neighbour messages go through torch.distributed"
 
+    def enable_exact_seam(self, enable=True):
+        """The exact seam (include/mi_shard.h): every sweep of a step ends with a hand-over of the shared bodies' velocities.  Library transport: inside
+        the step, on the world's stream.  "dist": this process's sweep callback exchanges the messages with the neighbours over torch.distributed.
+        "local" (virtual ranks): see step_local_exact — the ranks have to step side by side."""
+        if self.transport == "rccl":
+            self.world.shard_set_exact_seam(enable, None)
+        elif self.transport == "dist":
+            self.world.shard_set_exact_seam(enable, self._sweep_dist if enable else None)
+        else:
+            raise RuntimeError("virtual ranks step side by side: sharding.step_local_exact(ranks, ...)")
+
+    def _sweep_dist(self, sweep):
+        import torch
+        dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
+        ops, inbox, keep = [], [], []
+        for slot, peer in enumerate(self.neighbours):
+            out = torch.from_numpy(self.world.shard_export_sweep(slot)).to(dev); keep.append(out)
+            buf = torch.zeros(out.numel(), dtype=torch.float32, device=dev); inbox.append(buf)
+            ops.append(self.dist.P2POp(self.dist.isend, out, peer)); ops.append(self.dist.P2POp(self.dist.irecv, buf, peer))
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+        for buf in inbox:
+            self.world.shard_import_sweep(buf.cpu().numpy())
+
     def step(self, settings, dt):
         """One internal step of this rank's tile; with the library transport the exchange is part of it."""
         self.world.step_fixed(settings, dt, 1)
@@ -200,7 +225,7 @@ def step_local_exact(ranks, settings, dt):
 
     def run(r):
         try:
-            r.world.shard_set_exact_seam(True, make_exchange(r))
+            r.world.shard_set_exact_seam(True, make_exchange(r))   # (the mode stays; only the callback — it closes over this step's barrier — is new)
             r.world.step_fixed(settings, dt, 1)
         except BaseException as e:
             errors.append((r.rank, e, getattr(r.world, "_sweep_error", None)))

@@ -411,3 +411,95 @@ def test_sharded_checkpoint_restores_every_ranks_view(oracle_mod):
         ranks[0].world.load_checkpoint(blobs[1])
     with pytest.raises(capi.PhysicsError):
         sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)).load_checkpoint(blobs[0])
+
+
+# ---------------------------------------------------------------------------------------------------------------- exact seam (include/mi_shard.h)
+def _exact_case(kind):
+    sc = _scene("ragdolls") if kind == "ragdolls" else scenes.obb_pile(12, 4, 8, spacing=1.0)
+    return sc, (3.5 if kind == "ragdolls" else 2.5)
+
+
+@pytest.mark.parametrize("kind,num_ranks,tiles_z", [("pile", 2, 1), ("pile", 3, 1), ("ragdolls", 2, 1), ("pile", 2, 2)], ids=["pile, 2 x slabs", "pile, 3 x slabs", "ragdolls, 2 x slabs", "pile, 2 z slabs"])
+def test_exact_seam_virtual_ranks_equal_the_single_world_told_the_tiling(oracle_mod, kind, num_ranks, tiles_z):
+    """The exact seam: seam manifolds (all dynamic bodies shared across the same tile border) in the leading colours, solved redundantly by both tiles,
+    the owners' velocities of the shared bodies handed over after EVERY sweep.  R ranks then give, bit for bit, what ONE world gives that was told the
+    tiling (it only orders its colours the same way) — unlike the default block-Jacobi seam, which differs from any single world after the first step."""
+    sc, margin = _exact_case(kind)
+    tz = num_ranks if tiles_z == 2 else 1
+    desc = sharding.tile_grid(sc, num_ranks, tz, margin)
+    make = lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)
+    single = sc.populate(make()); single.set_seam_tiling(desc)
+    exact = [sharding.ShardedWorld(sc.populate(make()), desc, r, "local") for r in range(num_ranks)]
+    jacobi = [sharding.ShardedWorld(sc.populate(make()), desc, r, "local") for r in range(num_ranks)]
+    s = sc.settings()
+    ents = np.flatnonzero(sc.entities["kind"] != capi.ENTITY_STATIC).astype(np.uint32)
+    seam_max = 0
+    for i in range(50):
+        single.step_fixed(s, sc.dt, 1)
+        sharding.step_local_exact(exact, s, sc.dt); sharding.step_local(jacobi, s, sc.dt)
+        assert sharding.gather_owned(exact, len(ents)).tobytes() == single.get_body_states(ents).tobytes(), f"step {i}"
+        assert sum(r.world.shard_counts()["owned_contacts"] for r in exact) == single.counts()["num_contacts"]
+        st = single.seam_stats(); seam_max = max(seam_max, st["seam_manifolds"])
+        assert st["violations"] == 0 and all(r.world.seam_stats()["violations"] == 0 for r in exact)
+        assert st["seam_manifolds"] == max(r.world.seam_stats()["seam_manifolds"] for r in exact) or num_ranks > 2
+    assert seam_max > 0, "no manifold ever lay on the seam"
+    if kind == "pile":
+        assert sharding.gather_owned(jacobi, len(ents)).tobytes() != single.get_body_states(ents).tobytes(), "block Jacobi is not expected to equal a single world"
+
+
+def _exact_worker(rank, world_size, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    sys.path.insert(0, str(ROOT))
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    import oracle
+    sc, margin = _exact_case("pile")
+    desc = sharding.tile_grid(sc, world_size, 1, margin)
+    sw = sharding.ShardedWorld(sc.populate(oracle.create_world(oracle.ORDER_CANONICAL)), desc, rank, "dist", dist)
+    sw.enable_exact_seam()
+    s = sc.settings()
+    for _ in range(30):
+        sw.step(s, sc.dt)
+    ents, st = sw.owned_states()
+    np.savez(Path(out_dir) / f"rank{rank}.npz", ents=ents, states=st, violations=sw.world.seam_stats()["violations"])
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_exact_seam_processes_over_gloo_equal_the_single_world(tmp_path, oracle_mod):
+    """Two real processes, the per-sweep messages over gloo from inside the library's sweep callback: the union of what the ranks own is the single
+    world told the tiling, bit for bit."""
+    port = 29900 + (os.getpid() % 2000)
+    mp.spawn(_exact_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    sc, margin = _exact_case("pile")
+    desc = sharding.tile_grid(sc, 2, 1, margin)
+    single = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)); single.set_seam_tiling(desc)
+    s = sc.settings()
+    for _ in range(30):
+        single.step_fixed(s, sc.dt, 1)
+    seen = {}
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert int(got["violations"]) == 0
+        for e, st in zip(got["ents"], got["states"]):
+            assert int(e) not in seen; seen[int(e)] = st
+    ents = np.asarray(sorted(seen), np.uint32)
+    assert len(ents) == sc.num_bodies
+    assert np.stack([seen[int(e)] for e in ents]).tobytes() == single.get_body_states(ents).tobytes()
+
+
+def test_exact_seam_conditions_are_checked(oracle_mod):
+    """Slabs only; tiles at least two margins wide; a margin that does not cover the reach of a contact is REPORTED (violations), never silent."""
+    sc, _ = _exact_case("pile")
+    make = lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)
+    w = sc.populate(make()); w.shard_enable(sharding._desc_for(sharding.tile_grid(sc, 4, 2, 2.5), 0))
+    with pytest.raises(capi.PhysicsError):
+        w.shard_set_exact_seam(True, None)                       # 2 x 2 tiles: a corner body is seen by four tiles
+    narrow = sharding.tile_grid(sc, 2, 1, 2.5); narrow.ghost_margin = 0.6 * narrow.tile_size_x
+    w2 = sc.populate(make())
+    with pytest.raises(capi.PhysicsError):
+        w2.set_seam_tiling(narrow)
+    desc = sharding.tile_grid(sc, 2, 1, 0.2)                     # boxes are up to 1.2 m across: a 0.2 m margin cannot cover a contact
+    ranks = [sharding.ShardedWorld(sc.populate(make()), desc, r, "local") for r in range(2)]
+    s = sc.settings()
+    for _ in range(40):
+        sharding.step_local_exact(ranks, s, sc.dt)
+    assert sum(r.world.seam_stats()["violations"] for r in ranks) > 0

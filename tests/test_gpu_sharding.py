@@ -355,3 +355,83 @@ def test_gpu_real_rccl_ranks_equal_virtual_ranks(mi_lib, tmp_path, world_size, t
         assert int(got["exchanges"]) >= steps - 1
         moved += int(got["records"].sum())
     assert moved > 0, "no record ever crossed a link"
+
+
+# ---------------------------------------------------------------------------------------------------------------- exact seam (include/mi_shard.h)
+@pytest.mark.parametrize("make,num_ranks,z_slabs,margin", [(lambda: scenes.obb_pile(12, 4, 8, spacing=1.0), 3, False, 2.5), (lambda: scenes.ragdolls(4, 3), 2, False, 3.5),
+                                                           (lambda: scenes.mixed_stack(10, 4, 10), 2, True, 2.5)],
+                         ids=["pile, 3 x slabs", "ragdolls, 2 x slabs", "mixed stack, 2 z slabs"])
+def test_gpu_exact_seam_ranks_equal_the_single_world_and_the_oracle(mi_lib, oracle_mod, make, num_ranks, z_slabs, margin):
+    """Exact seam on the GPU: virtual ranks stepping side by side (one thread each, the per-sweep messages handed over inside the library's sweep
+    callback) == ONE GPU world told the tiling == the ORACLE told the tiling, bit for bit, step after step.  The seam manifolds take the leading
+    colours (k_emit_manifolds / k_color_round), every sweep is one launch followed by the hand-over (k_seam_sweep_pack / _unpack)."""
+    sc = make()
+    desc = sharding.tile_grid(sc, num_ranks, num_ranks if z_slabs else 1, margin)
+    single = sc.populate(mi_lib.create_world(0)); single.set_seam_tiling(desc)
+    ora = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)); ora.set_seam_tiling(desc)
+    ranks = [sharding.ShardedWorld(sc.populate(mi_lib.create_world(0)), desc, r, "local") for r in range(num_ranks)]
+    s = sc.settings()
+    ents = np.flatnonzero(sc.entities["kind"] != capi.ENTITY_STATIC).astype(np.uint32)
+    seam_max = 0
+    for i in range(60):
+        single.step_fixed(s, sc.dt, 1); ora.step_fixed(s, sc.dt, 1)
+        sharding.step_local_exact(ranks, s, sc.dt)
+        ref = single.get_body_states(ents)
+        assert single.counts() == ora.counts() and ref.tobytes() == ora.get_body_states(ents).tobytes(), f"step {i}: GPU world told the tiling vs the oracle told the tiling"
+        assert sharding.gather_owned(ranks, len(ents)).tobytes() == ref.tobytes(), f"step {i}: exact-seam ranks vs the single world"
+        assert single.seam_stats() == ora.seam_stats()
+        seam_max = max(seam_max, single.seam_stats()["seam_manifolds"])
+    assert seam_max > 0 and single.seam_stats()["violations"] == 0 and all(r.world.seam_stats()["violations"] == 0 for r in ranks)
+    total, spec, _ = single.step_mode_stats()
+    assert spec >= total - 3, "the single world told the tiling keeps its speculative fast path"
+    w = sc.populate(mi_lib.create_world(0)); w.shard_enable(sharding._desc_for(sharding.tile_grid(sc, 4, 2, margin), 0))
+    with pytest.raises(capi.PhysicsError):
+        w.shard_set_exact_seam(True, None)                         # 2 x 2 tiles: slabs only
+    w.close()
+
+
+def _rccl_exact_rank(rank, world_size, port, out_dir, steps):
+    import os
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world_size, device_id=torch.device("cuda", rank))
+    import d3d12renderer_amd as mi
+    sc = scenes.obb_pile(12, 4, 8, spacing=1.0)
+    desc = sharding.tile_grid(sc, world_size, 1, 2.5)
+    sw = sharding.ShardedWorld(sc.populate(mi.create_world(rank)), desc, rank, "rccl", dist)
+    assert sw.transport == "rccl", sw.note
+    sw.enable_exact_seam()                                         # per-sweep ncclSend / ncclRecv on the world's stream
+    s = sc.settings()
+    for _ in range(steps):
+        sw.step(s, sc.dt)
+    ents, st = sw.owned_states()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), ents=ents, states=st, violations=sw.world.seam_stats()["violations"])
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_gpu_exact_seam_real_rccl_ranks_equal_the_single_world(mi_lib, tmp_path):
+    """One process per GPU, library transport: 20 small ncclSend / ncclRecv groups per step (one per sweep) — the union of what the ranks own equals
+    the single GPU world told the tiling, bit for bit.  Needs 2 visible devices (skipped otherwise)."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip(f"needs 2 visible GPUs, this box has {torch.cuda.device_count()}")
+    import os
+    import torch.multiprocessing as mp
+    steps = 40
+    mp.spawn(_rccl_exact_rank, args=(2, 29800 + (os.getpid() % 2000), str(tmp_path), steps), nprocs=2, join=True)
+    sc = scenes.obb_pile(12, 4, 8, spacing=1.0)
+    single = sc.populate(mi_lib.create_world(0)); single.set_seam_tiling(sharding.tile_grid(sc, 2, 1, 2.5))
+    s = sc.settings()
+    for _ in range(steps):
+        single.step_fixed(s, sc.dt, 1)
+    seen = {}
+    for r in range(2):
+        got = np.load(tmp_path / f"rank{r}.npz")
+        assert int(got["violations"]) == 0
+        for e, st in zip(got["ents"], got["states"]):
+            assert int(e) not in seen; seen[int(e)] = st
+    ents = np.asarray(sorted(seen), np.uint32)
+    assert len(ents) == sc.num_bodies and np.stack([seen[int(e)] for e in ents]).tobytes() == single.get_body_states(ents).tobytes()
