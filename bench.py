@@ -55,6 +55,9 @@ def parse():
     ap.add_argument("--ghost-margin", type=float, default=2.5)
     ap.add_argument("--transport", choices=["rccl", "dist"], default=os.environ.get("MI_SHARD_TRANSPORT", "rccl"),
                     help="N > 1: neighbour exchange by the library's own RCCL send/recv (default) or by torch.distributed point-to-point through host buffers")
+    ap.add_argument("--seam", choices=["jacobi", "exact"], default="jacobi",
+                    help="N > 1: block-Jacobi seam (default: one exchange per step) or the exact seam (slabs only: seam colours first, one hand-over per sweep; "
+                         "== one world told the tiling, bit for bit; about twice the cost) — include/mi_shard.h")
     ap.add_argument("--rebalance-every", type=int, default=0, help="N > 1: a load-balance round (tile borders follow the body counts) every K steps of the untimed settle phase; 0 = fixed uniform tiles")
     ap.add_argument("--pmc", action="store_true", help="N = 1: measure roofline.traffic for THIS run (two extra rocprofv3 --pmc passes of the same command: FETCH_SIZE, WRITE_SIZE) "
                                                       "instead of scaling the committed figure of profiles/traffic.json")
@@ -231,9 +234,11 @@ def main():
     if world_size > 1:
         desc = sharding.tile_grid(scene, world_size, args.tiles_z, args.ghost_margin)
         sw = sharding.ShardedWorld(world, desc, rank, args.transport, dist)
+        if args.seam == "exact":
+            sw.enable_exact_seam()
         sharding_note = (f"{world_size} tiles ({desc.tiles_x} x {desc.tiles_z}) of one replicated scene, ghost margin {desc.ghost_margin:.2f} m, ownership by position each step, "
                          f"{desc.max_records} records (56 B) per neighbour message, "
-                         f"neighbour exchange: {'RCCL send/recv inside the library' if sw.transport == 'rccl' else 'torch.distributed p2p via host'}; {args.scaling} scaling"
+                         f"neighbour exchange: {'RCCL send/recv inside the library' if sw.transport == 'rccl' else 'torch.distributed p2p via host'}; {args.scaling} scaling; seam: {'exact (one hand-over per sweep)' if args.seam == 'exact' else 'block Jacobi'}"
                          + (f"; {sw.note}" if sw.note else ""))
     else:
         sw = _Single(world); sharding_note = "single GPU, whole scene"

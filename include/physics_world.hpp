@@ -204,6 +204,9 @@ public:
         return out;
     }
     void rebalance(uint32_t bins = 256) { check(mi_world_shard_rebalance(w_, bins), "mi_world_shard_rebalance"); }   // load balance: every rank, between the same two steps
+    // exact seam (option, slabs only): per-sweep hand-over inside step() with the library transport; a single world told the tiling gives the ranks' result bit for bit
+    void setExactSeam(bool on, mi_shard_sweep_fn exchange = nullptr, void* user = nullptr) { check(mi_world_shard_set_exact_seam(w_, on ? 1u : 0u, exchange, user), "mi_world_shard_set_exact_seam"); }
+    void setSeamTiling(const mi_shard_desc* d) { check(mi_world_set_seam_tiling(w_, d), "mi_world_set_seam_tiling"); }
     std::array<uint64_t, 3> globalCounts() {               // bodies, manifolds, contacts of the whole scene (one all-reduce)
         uint32_t b = 0, m = 0, c = 0; check(mi_world_shard_counts(w_, &b, &m, &c), "mi_world_shard_counts");
         std::array<uint64_t, 3> v{b, m, c}; check(mi_world_shard_allreduce_u64(w_, v.data(), 3), "mi_world_shard_allreduce_u64"); return v;

@@ -49,6 +49,9 @@ int main() {
             tile.attachRccl(physics_world::shardUniqueId());
             for (int i = 0; i < 30; ++i) tile.stepFixed(settings, 1.f / 120.f);
             tile.rebalance();
+            tile.setExactSeam(true);                        // per-sweep hand-over through the library transport (no neighbour here: nothing to send)
+            for (int i = 0; i < 5; ++i) tile.stepFixed(settings, 1.f / 120.f);
+            tile.setExactSeam(false);
             auto g = tile.globalCounts();
             if (tile.ownedEntities().size() != 1 || g[0] != 1) { std::printf("facade error: sharded world with one rank\n"); return 1; }
         }

@@ -289,6 +289,12 @@ def test_gpu_shard_entry_points_reject_misuse(mi_lib):
         with pytest.raises(capi.PhysicsError):
             w.shard_set_axis_sums(np.zeros(9, np.uint64))
         w.step(several, 4.0 / 120.0)                               # the library transport exchanges inside every internal step
+        w.shard_set_exact_seam(True, None)                         # exact seam through the library transport: one (here empty) send / receive group per sweep
+        w.step(several, 4.0 / 120.0)
+        assert w.seam_stats()["violations"] == 0
+        with pytest.raises(capi.PhysicsError):
+            w.shard_import_sweep(np.zeros(w.shard_sweep_message_bytes() // 4, np.float32))   # the library exchanges the sweeps itself
+        w.shard_set_exact_seam(False, None)
         w.shard_detach_rccl()
     w.close()
 
