@@ -1285,7 +1285,9 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
 // zeroes the dummy body (physics.cpp:1279).  in ~112 B, out 112 B per body.
 // (Measured and not kept, round 3: as GUEST workgroups of k_emit_manifolds — nothing between the two depends on the other, that kernel waits on random
 // sectors and atomics, this one streams; interleaved every 4th workgroup.  k_emit_manifolds 54 -> 68 us for the 21 us saved: they compete for the same
-// memory system; 938 vs 937 steps/s.)
+// memory system; 938 vs 937 steps/s.  Nor as guests of the colouring rounds — launch-floor kernels between which nothing reads what this one writes: a slice of
+// the bodies per round made every round 9-10 us instead of 4.8 (the body rows are a chain of dependent gathers: ~5 us however few bodies), 8 x 5 us for the 19 saved:
+// 962 vs 987 steps/s.)
 __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt, float3 globalForce, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
                                                           const float4* __restrict__ bCogInvMass, const float4* __restrict__ bInvI,
                                                           const float4* __restrict__ bParams, const float4* __restrict__ bLinVel,
