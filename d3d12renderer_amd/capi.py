@@ -546,9 +546,13 @@ class World:
         return n.value
 
     def shard_export_sweep(self, slot):
-        out = np.zeros(self.shard_sweep_message_bytes() // 4, np.float32)
+        """The used prefix of the sweep message for neighbour `slot`: header (record 0 = count) + count records of 8 floats."""
+        if getattr(self, "_sweep_buf", None) is None or len(self._sweep_buf) != self.shard_sweep_message_bytes() // 4:
+            self._sweep_buf = np.zeros(self.shard_sweep_message_bytes() // 4, np.float32)
+        out = self._sweep_buf
         self.L.check(self.L.fn("world_shard_export_sweep")(self.h, C.c_uint32(slot), _ptr(out)), "world_shard_export_sweep")
-        return out
+        n = int(out[:1].view(np.uint32)[0])
+        return out[: (n + 1) * 8].copy()
 
     def shard_import_sweep(self, message):
         m = np.ascontiguousarray(message, np.float32)

@@ -175,7 +175,7 @@ struct mi_world {
         // exact seam (include/mi_shard.h): per-sweep hand-over of the owners' velocities of the shared bodies
         bool exact = false; mi_shard_sweep_fn sweepFn = nullptr; void* sweepUser = nullptr;
         DBuf<float> sweepSend[8], sweepRecv[8], sweepImport; DBuf<uint32_t> sweepList[8], sweepCount;
-        uint32_t sweepsDone = 0; uint32_t* sweepCountHost = nullptr; bool sweepCountPending = false;
+        uint32_t sweepsDone = 0; uint32_t sweepCounts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // records per neighbour message of this step (the lists are built once per step)
         size_t sweepFloats() const { return (size_t)(capacity + 1u) * kSweepRecordFloats; }
     } shard;
     // exact seam: a single world that was told a tiling orders its colours the same way (mi_world_set_seam_tiling)
@@ -2540,8 +2540,8 @@ int mi_world::shardSweepExchange(uint32_t sweep) {
     }
     if (sh.sp.numPeers) k_seam_sweep_pack<<<dim3(divUp(sh.capacity, 256), sh.sp.numPeers), 256, 0, st>>>(lists, sh.sweepCount.p, sh.capacity, gVel.p, send);
     if (sh.sweepsDone++ == 0u && sh.sp.numPeers) {   // once per step: did the lists fit?  (the step is synchronous in this mode anyway)
-        uint32_t counts[8];
-        HIP_TRY(hipMemcpyAsync(counts, sh.sweepCount.p, sizeof counts, hipMemcpyDeviceToHost, st));
+        uint32_t* counts = sh.sweepCounts;
+        HIP_TRY(hipMemcpyAsync(counts, sh.sweepCount.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (uint32_t k = 0; k < sh.sp.numPeers; ++k) if (counts[k] > sh.capacity) return fail(MI_ERR_CAPACITY, "exact seam: more shared bodies than a neighbour message holds (mi_shard_desc::max_records)");
     }
@@ -2599,7 +2599,8 @@ MI_API int mi_world_shard_sweep_message_bytes(mi_world* w, uint64_t* out) {
 MI_API int mi_world_shard_export_sweep(mi_world* w, uint32_t slot, void* out) {
     if (!w || !out || !w->shard.enabled || !w->shard.exact || slot >= w->shard.sp.numPeers || !w->shard.sweepSend[slot].p) return fail(MI_ERR_INVALID_ARGUMENT, "no sweep message for this slot");
     HIP_TRY(hipSetDevice(w->device));
-    HIP_TRY(hipMemcpyAsync(out, w->shard.sweepSend[slot].p, w->shard.sweepFloats() * sizeof(float), hipMemcpyDeviceToHost, w->stream));
+    // (only what the message holds: its header and `count` records; the rest of the caller's buffer is not touched)
+    HIP_TRY(hipMemcpyAsync(out, w->shard.sweepSend[slot].p, (size_t)(std::min(w->shard.sweepCounts[slot], w->shard.capacity) + 1u) * kSweepRecordFloats * sizeof(float), hipMemcpyDeviceToHost, w->stream));
     HIP_TRY(hipStreamSynchronize(w->stream));
     return MI_OK;
 }

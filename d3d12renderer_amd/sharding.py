@@ -102,8 +102,10 @@ class ShardedWorld:
         import torch
         dev = "cuda" if self.dist.get_backend() == "nccl" else "cpu"
         ops, inbox, keep = [], [], []
+        full = self.world.shard_sweep_message_bytes() // 4          # point-to-point messages of a fixed size (the receiver does not know the count)
         for slot, peer in enumerate(self.neighbours):
-            out = torch.from_numpy(self.world.shard_export_sweep(slot)).to(dev); keep.append(out)
+            msg = np.zeros(full, np.float32); part = self.world.shard_export_sweep(slot); msg[: len(part)] = part
+            out = torch.from_numpy(msg).to(dev); keep.append(out)
             buf = torch.zeros(out.numel(), dtype=torch.float32, device=dev); inbox.append(buf)
             ops.append(self.dist.P2POp(self.dist.isend, out, peer)); ops.append(self.dist.P2POp(self.dist.irecv, buf, peer))
         if ops:

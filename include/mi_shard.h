@@ -147,7 +147,8 @@ MI_API int mi_world_shard_import(mi_world* world, const void* message);
  * Transport.  Library transport (RCCL attached): the per-sweep send / receive runs inside mi_world_step on the world's stream.  Caller's transport:
  * the library calls `exchange(user, world, sweep)` after every sweep of every internal step, on the stepping thread; inside it the caller moves
  * mi_world_shard_export_sweep(slot) of every rank to mi_world_shard_import_sweep of the neighbour (fixed-size messages of
- * mi_world_shard_sweep_message_bytes: count + records of MI_SHARD_SWEEP_FLOATS floats = body index, linear velocity, angular velocity) and returns
+ * mi_world_shard_sweep_message_bytes: count + records of MI_SHARD_SWEEP_FLOATS floats = body index, linear velocity, angular velocity; only the
+ * header and the `count` records are written / read, so a transport may send just that prefix) and returns
  * MI_OK.  Every rank makes the same number of calls (the sweeps of the step), so a barrier inside the callback is safe.  Steps run one at a time
  * and synchronously in this mode (no speculation: every rank must take the same path through the step). */
 #define MI_SEAM_COLORS 24
