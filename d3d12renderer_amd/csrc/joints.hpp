@@ -744,17 +744,141 @@ __device__ __forceinline__ void fusedIsland(uint32_t it, const IslandDesc& d, co
         storeGranuleSc1(bv.gVel + 2 * (size_t)body, o0); storeGranuleSc1(bv.gVel + 2 * (size_t)body + 1, o1);
     }
 }
+// ---- PRIVATE islands: joints AND contacts of all sweeps inside the island's one workgroup ------------------------------------
+// An island is private in a step when every manifold that touches one of its dynamic bodies has no dynamic body outside the island (a ragdoll on the
+// ground, limbs touching limbs; a vehicle on static hull tiles — every island of cfg4 / cfg5), there are at most kIslandMaxContacts of them and none
+// is overflow-coloured.  Nothing outside then reads or writes the island's velocities during the solve, so there is nothing to hand over: workgroup
+// (island, sweep 0) keeps the bodies in LDS, its joints' data, each lane ONE manifold's rows and accumulated impulses in registers, and runs ALL sweeps —
+// per sweep the joint groups in canonical order, then the island's manifolds colour after colour (one lane per manifold; manifolds of a colour share
+// no dynamic body) — and writes the velocities back once.  The arithmetic is the tile solver's (solveOnePk) in the canonical order restricted to the
+// island, which is all that order means for bodies nobody else touches: bit-identical results, and the ~19 us island -> contacts -> island hand-over per
+// sweep (the whole cost of the solve on these scenes) is gone.  The manifolds stay in their global tiles for k_contact_init (rows are computed there) but
+// are marked invalid for the tile solver; k_contact_init appends (slot, first contact-tile, colour, contacts) to the island's list.
+// after the colouring, before k_contact_init: which islands are private this step
+__global__ __launch_bounds__(256) void k_island_classify(const StepScalars* __restrict__ sc, const uint4* __restrict__ colWork, const uint32_t* __restrict__ color, IslandPrivate ip) {
+    const uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= sc->numManifolds) return;
+    const uint4 w = colWork[m];
+    const bool dynA = (w.x >> 31) != 0u, dynB = (w.y >> 31) != 0u;
+    const uint32_t iA = dynA ? ip.bodyIsland[w.x & 0x3FFFFFFFu] : 0xFFFFFFFFu, iB = dynB ? ip.bodyIsland[w.y & 0x7FFFFFFFu] : 0xFFFFFFFFu;
+    const bool freeA = dynA && iA == 0xFFFFFFFFu, freeB = dynB && iB == 0xFFFFFFFFu;            // a dynamic body that belongs to no island
+    const bool coupled = (dynA && dynB && iA != iB) || freeA || freeB || color[m] >= kOverflowColor;
+    if (iA != 0xFFFFFFFFu) { atomicAdd(&ip.count[iA], 1u); if (coupled) ip.shared[iA] = 1u; }
+    if (iB != 0xFFFFFFFFu && iB != iA) { atomicAdd(&ip.count[iB], 1u); if (coupled) ip.shared[iB] = 1u; }
+}
+struct PrivateLds { uint32_t bodyId[kIslandMaxBodies]; unsigned long long colours; };
+__device__ __forceinline__ void privateIsland(uint32_t sweeps, uint32_t island, const IslandDesc& d, const IslandStep* __restrict__ steps, const uint32_t* __restrict__ islandBodies,
+                                              const IslandUpd& upd, const IslandAcc& acc, const BodyView& bv, const IslandPrivate& ip,
+                                              const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal, const float2* __restrict__ slotMass, const float4* __restrict__ rows,
+                                              IslandLds& lds, PrivateLds& pl) {
+    const uint32_t lane = threadIdx.x;
+    const bool hasJoint = lane < d.numJoints, isBody = lane < d.numBodies;
+    IslandStep st{};
+    if (hasJoint) st = steps[d.stepBegin + lane];
+    uint32_t body = 0; bool dynamic = false;
+    if (lane == 0) pl.colours = 0ull;
+    if (isBody) {
+        body = islandBodies[d.bodyBegin + lane];
+        pl.bodyId[lane] = body;
+        lds.v[lane] = bv.gVel[2 * (size_t)body]; lds.w[lane] = bv.gVel[2 * (size_t)body + 1];
+        const float im = bv.gPos[body].w;
+        lds.invMass[lane] = im; dynamic = im != 0.f;
+        lds.inertia[3 * lane] = bv.gInvI[3 * body]; lds.inertia[3 * lane + 1] = bv.gInvI[3 * body + 1]; lds.inertia[3 * lane + 2] = bv.gInvI[3 * body + 2];
+    }
+    const uint32_t type = hasJoint ? st.type : 0xFFFFu;
+    DistanceJ::Upd cDistance; BallJ::Upd cBall; FixedJ::Upd cFixed; HingeJ::Upd cHinge; ConeJ::Upd cCone; SliderJ::Upd cSlider;
+    switch (type) {
+        case 0: cDistance = upd.distance[st.joint]; break;
+        case 1: cBall = upd.ball[st.joint]; break;
+        case 2: cFixed = upd.fixed[st.joint]; break;
+        case 3: cHinge = upd.hinge[st.joint]; break;
+        case 4: cCone = upd.cone[st.joint]; break;
+        case 5: cSlider = upd.slider[st.joint]; break;
+        default: break;
+    }
+    {   // the clamped accumulators start from what k_joint_init left in the granules (sweep tag 0) and then stay in registers
+        const float4* accPtr = type == 3u ? acc.hinge : type == 4u ? acc.cone : type == 5u ? acc.slider : nullptr;
+        if (accPtr) {
+            const float4 q0 = accPtr[2 * (size_t)st.joint], q1 = type == 4u ? accPtr[2 * (size_t)st.joint + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float a[4] = {q0.x, q0.y, q1.x, q1.y};
+            if (type == 3u) HingeJ::setAcc(cHinge, a); else if (type == 4u) ConeJ::setAcc(cCone, a); else SliderJ::setAcc(cSlider, a);
+        }
+    }
+    // this lane's manifold
+    const uint32_t nPriv = min(ip.fill[island], kIslandMaxContacts);
+    const bool hasContact = lane < nPriv;
+    uint32_t colour = 0xFFFFFFFFu, cnt = 0;
+    uint4 meta = make_uint4(0u, 0u, 0u, 0u); float4 nf = make_float4(0.f, 0.f, 0.f, 0.f); float2 mass = make_float2(0.f, 0.f);
+    ContactRows c[4];
+    float2 im[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};   // no warm start (constraints.cpp:3312-3313)
+    if (hasContact) {
+        const uint4 e = ip.entries[(size_t)island * kIslandMaxContacts + lane];
+        const uint32_t slot = e.x, ln = slot & 63u;
+        colour = e.z & 0xFFu; cnt = e.z >> 8;
+        meta = slotMeta[slot]; nf = slotNormal[slot]; mass = slotMass[slot];
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) if (k < cnt) {
+            const float4* __restrict__ row = rows + ((size_t)e.y + k) * (kRows * 64u) + ln;
+#pragma unroll
+            for (uint32_t r = 0; r < kRows; ++r) c[k].r[r] = row[r * 64u];
+        }
+    }
+    __syncthreads();
+    if (hasContact) atomicOr(&pl.colours, 1ull << colour);
+    // island-local slots of the manifold's bodies; a body outside the island (static, kinematic: never changed by impulses) keeps its velocity in registers
+    int la = -1, lb = -1;
+    float4 extVA = make_float4(0.f, 0.f, 0.f, 0.f), extWA = extVA, extVB = extVA, extWB = extVA;
+    if (hasContact) {
+        for (uint32_t k = 0; k < d.numBodies; ++k) { const uint32_t id = pl.bodyId[k]; if (id == meta.x) la = (int)k; if (id == meta.y) lb = (int)k; }
+        if (la < 0) { extVA = bv.gVel[2 * (size_t)meta.x]; extWA = bv.gVel[2 * (size_t)meta.x + 1]; }
+        if (lb < 0) { extVB = bv.gVel[2 * (size_t)meta.y]; extWB = bv.gVel[2 * (size_t)meta.y + 1]; }
+    }
+    __syncthreads();
+    const unsigned long long colours = pl.colours;
+    const f32x2 sMass = pk2(-mass.x, mass.y);
+    for (uint32_t it = 0; it < sweeps; ++it) {
+        fusedGroups<DistanceJ>(0, d, type == 0u, st, cDistance, lds);
+        fusedGroups<BallJ>(1, d, type == 1u, st, cBall, lds);
+        fusedGroups<FixedJ>(2, d, type == 2u, st, cFixed, lds);
+        fusedGroups<HingeJ>(3, d, type == 3u, st, cHinge, lds);
+        fusedGroups<ConeJ>(4, d, type == 4u, st, cCone, lds);
+        fusedGroups<SliderJ>(5, d, type == 5u, st, cSlider, lds);
+        for (unsigned long long rest = colours; rest; rest &= rest - 1ull) {   // wave-uniform
+            const uint32_t cur = (uint32_t)__ffsll((long long)rest) - 1u;
+            if (hasContact && colour == cur) {
+                const float4 a0 = la >= 0 ? lds.v[la] : extVA, a1 = la >= 0 ? lds.w[la] : extWA, b0 = lb >= 0 ? lds.v[lb] : extVB, b1 = lb >= 0 ? lds.w[lb] : extWB;
+                P3 pv, pw;
+                pv.x = pk2(a0.x, b0.x); pv.y = pk2(a0.y, b0.y); pv.z = pk2(a0.z, b0.z);
+                pw.x = pk2(a1.x, b1.x); pw.y = pk2(a1.y, b1.y); pw.z = pk2(a1.z, b1.z);
+#pragma unroll
+                for (uint32_t k = 0; k < 4u; ++k) if (k < cnt) solveOnePk(c[k], nf, im[k], sMass, pv, pw);
+                if (la >= 0 && mass.x != 0.f) { lds.v[la] = make_float4(pv.x.x, pv.y.x, pv.z.x, a0.w); lds.w[la] = make_float4(pw.x.x, pw.y.x, pw.z.x, a1.w); }
+                if (lb >= 0 && mass.y != 0.f) { lds.v[lb] = make_float4(pv.x.y, pv.y.y, pv.z.y, b0.w); lds.w[lb] = make_float4(pw.x.y, pw.y.y, pw.z.y, b1.w); }
+            }
+            __syncthreads();
+        }
+    }
+    if (isBody && dynamic) { bv.gVel[2 * (size_t)body] = lds.v[lane]; bv.gVel[2 * (size_t)body + 1] = lds.w[lane]; }
+}
 // Block b of sweep s = itBase + b / (numIslands + numTiles): island b' < numIslands, else contact tile b' - numIslands.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_WAVES))) void k_solve_flow_islands(
     uint32_t itBase, uint32_t sweeps, uint32_t numIslands, const IslandDesc* __restrict__ islands, const IslandStep* __restrict__ steps, const uint32_t* __restrict__ islandBodies,
     IslandUpd upd, IslandAcc acc, BodyView bv, const unsigned long long* __restrict__ bodyUsed,
     const uint2* __restrict__ tileDesc, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal, const float2* __restrict__ slotMass,
-    const float4* __restrict__ rows, float4* imp, StepScalars* sc) {
+    const float4* __restrict__ rows, float4* imp, StepScalars* sc, IslandPrivate ip /* bodyIsland == null: every island goes through the dataflow */, uint32_t totalSweeps) {
     __shared__ IslandLds lds;
+    __shared__ PrivateLds pl;
     const uint32_t numTiles = sc->totalTiles, per = numIslands + numTiles;
     if (blockIdx.x >= per * sweeps) return;
     const uint32_t it = itBase + blockIdx.x / per, idx = blockIdx.x % per;
-    if (idx < numIslands) { if (bv.active && !bv.active[islandBodies[islands[idx].bodyBegin]]) return; fusedIsland(it, islands[idx], steps, islandBodies, upd, acc, bv, bodyUsed, lds, sc); return; }
+    if (idx < numIslands) {
+        if (bv.active && !bv.active[islandBodies[islands[idx].bodyBegin]]) return;
+        if (ip.bodyIsland && islandIsPrivate(ip, idx)) {   // all sweeps in the block of sweep 0; the island's blocks of the later sweeps have nothing to do
+            if (it == 0u) privateIsland(totalSweeps, idx, islands[idx], steps, islandBodies, upd, acc, bv, ip, slotMeta, slotNormal, slotMass, rows, lds, pl);
+            return;
+        }
+        fusedIsland(it, islands[idx], steps, islandBodies, upd, acc, bv, bodyUsed, lds, sc); return;
+    }
     const uint32_t tile = idx - numIslands, lane = threadIdx.x;
     const uint2 d = tileDesc[tile];
     switch (d.y) {
@@ -905,12 +1029,17 @@ struct JointSet {
     uint32_t numIslands = 0;
     mi::IslandDesc* dIslands = nullptr; mi::IslandStep* dSteps = nullptr; uint32_t* dIslandBodies = nullptr;
     uint8_t* dBodyJ = nullptr;          // [bodies + 1]: 1 = dynamic body of an island (one extra version per sweep in the fused solver)
+    uint32_t* dBodyIsland = nullptr;    // [bodies + 1]: island of a dynamic island body, else 0xFFFFFFFF (private islands: IslandPrivate)
+    uint32_t* dIslState = nullptr;      // [3][islands]: shared / count / fill of this step
+    uint4* dIslEntries = nullptr;       // [islands][kIslandMaxContacts]
+    mi::IslandPrivate islandPrivate() const { return mi::IslandPrivate{dBodyIsland, dIslState, dIslState ? dIslState + numIslands : nullptr, dIslState ? dIslState + 2 * (size_t)numIslands : nullptr, dIslEntries}; }
     bool allInIslands() const { return numIslands && distance.order.empty() && ball.order.empty() && fixed.order.empty() && hinge.order.empty() && cone.order.empty() && slider.order.empty(); }
     void buildIslands(const std::vector<float>& invMass, std::vector<mi::IslandDesc>& islands, std::vector<mi::IslandStep>& steps, std::vector<uint32_t>& islandBodies);
     ~JointSet() { releaseIslands(); }
     void releaseIslands() {
         if (dIslands) (void)hipFree(dIslands); if (dSteps) (void)hipFree(dSteps); if (dIslandBodies) (void)hipFree(dIslandBodies); if (dBodyJ) (void)hipFree(dBodyJ);
-        dIslands = nullptr; dSteps = nullptr; dIslandBodies = nullptr; dBodyJ = nullptr; numIslands = 0;
+        if (dBodyIsland) (void)hipFree(dBodyIsland); if (dIslState) (void)hipFree(dIslState); if (dIslEntries) (void)hipFree(dIslEntries);
+        dIslands = nullptr; dSteps = nullptr; dIslandBodies = nullptr; dBodyJ = nullptr; dBodyIsland = nullptr; dIslState = nullptr; dIslEntries = nullptr; numIslands = 0;
     }
     bool podsDirty() const { return distance.podsDirty || ball.podsDirty || fixed.podsDirty || hinge.podsDirty || cone.podsDirty || slider.podsDirty; }
     int uploadPods(hipStream_t st);

@@ -1824,6 +1824,16 @@ __device__ __forceinline__ void storeStream(float4* p, float4 v) {
     __builtin_nontemporal_store(x, reinterpret_cast<mi_vf4*>(p));
 #endif
 }
+// private joint islands (joints.hpp "PRIVATE islands"): what k_contact_init needs of them
+constexpr uint32_t kIslandMaxContacts = 64;
+struct IslandPrivate {
+    const uint32_t* bodyIsland;   // [bodies + 1]: island of a dynamic island body, else 0xFFFFFFFF
+    uint32_t* shared;             // [islands] this step: 1 = some manifold couples the island to a dynamic body outside it (or is overflow-coloured)
+    uint32_t* count;              // [islands] this step: manifolds touching the island
+    uint32_t* fill;               // [islands] this step: entries appended by k_contact_init
+    uint4* entries;               // [islands][kIslandMaxContacts]: (slot, first contact-tile, colour | contacts << 8, -)
+};
+__device__ __forceinline__ bool islandIsPrivate(const IslandPrivate& ip, uint32_t island) { return ip.shared[island] == 0u && ip.count[island] <= kIslandMaxContacts; }
 // K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379): one wave per tile, one lane per slot.
 __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restrict__ sc, uint32_t dummyBody, float dt, const uint4* __restrict__ tileInfo /* k_fill_tiles: per tile, or (XCD-partitioned) per entry of the XCD tile lists */,
                                                      const uint32_t* __restrict__ order,
@@ -1836,7 +1846,8 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
                                                      float4* __restrict__ rows, float4* __restrict__ imp, uint4* __restrict__ slotMeta,
                                                      float4* __restrict__ slotNormal, float2* __restrict__ slotMass,
                                                      uint8_t* __restrict__ bodyOwner /* XCD-partitioned solver: [body][8] flags, 1 = a tile of that XCD touches the body; or null */,
-                                                     uint32_t listCap /* with bodyOwner: workgroup b prepares entry b / 8 of XCD (b % 8)'s tile list */, uint32_t infoCap) {
+                                                     uint32_t listCap /* with bodyOwner: workgroup b prepares entry b / 8 of XCD (b % 8)'s tile list */, uint32_t infoCap,
+                                                     IslandPrivate ip /* bodyIsland non-null: manifolds of private islands are handed to their island's workgroup, invalid for the tile solver */) {
     // Measured and not kept: one wave per contact index (four waves per tile, the per-manifold gathers repeated): 52 -> 73 us; 5 or 6 waves per
     // SIMD instead of 4 by capping the registers (96 / 80 VGPRs, 96 / 164 bytes of scratch): 66 -> 84 / 94 us.  Everything the kernel needs of
     // its tile comes in ONE 16-byte entry (k_fill_tiles; was list -> tile -> bin -> bin info): no faster either — the kernel moves ~390 MB
@@ -1878,8 +1889,18 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
         if (imA != 0.f) { unsigned long long u = bodyUsed[bodies.x]; uint32_t j = bodyJ ? bodyJ[bodies.x] : 0u; packed |= ((uint32_t)__popcll(u & below) + j) | (((uint32_t)__popcll(u) + j) << 7); }
         if (imB != 0.f) { unsigned long long u = bodyUsed[bodies.y]; uint32_t j = bodyJ ? bodyJ[bodies.y] : 0u; packed |= (((uint32_t)__popcll(u & below) + j) << 14) | (((uint32_t)__popcll(u) + j) << 21); }
     }
+    bool priv = false;
+    if (ip.bodyIsland) {
+        const uint32_t iA = imA != 0.f ? ip.bodyIsland[bodies.x] : 0xFFFFFFFFu, iB = imB != 0.f ? ip.bodyIsland[bodies.y] : 0xFFFFFFFFu;
+        const uint32_t isl = iA != 0xFFFFFFFFu ? iA : iB;
+        if (isl != 0xFFFFFFFFu && islandIsPrivate(ip, isl)) {   // (a private island's manifolds have no dynamic body outside it: k_island_classify)
+            priv = true;
+            const uint32_t at = atomicAdd(&ip.fill[isl], 1u);
+            if (at < kIslandMaxContacts) ip.entries[(size_t)isl * kIslandMaxContacts + at] = make_uint4(tile * 64u + lane, (uint32_t)ctBase, color[m] | (cnt << 8), m);
+        }
+    }
     if (kw == 0) {
-        slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, packed, cnt);
+        slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, packed, priv ? 0u : cnt);   // (.w = 0: not a slot of the tile solver)
         slotMass[(size_t)tile * 64u + lane] = make_float2(imA, imB);
     }
     if (bodyOwner && kw == 0) {   // one byte per (body, XCD): plain idempotent stores, no atomics
@@ -2232,6 +2253,7 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
                                          const float4* __restrict__ slotNormal, const float2* __restrict__ slotMass,
                                          const float4* __restrict__ rows, float4* imp, float4* gVel, StepScalars* sc, float2* ldsImp = nullptr) {
     const uint4 meta = slotMeta[(size_t)tile * 64u + lane];
+    if (__ballot(meta.w != 0u) == 0ull) return;   // nothing of this tile is the tile solver's (manifolds of private joint islands: their island's workgroup solves them)
     const float4 nf = slotNormal[(size_t)tile * 64u + lane];
     const float2 mass = slotMass[(size_t)tile * 64u + lane];
     ContactRows c[CNT];

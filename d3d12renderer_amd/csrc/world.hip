@@ -204,6 +204,7 @@ struct mi_world {
     DBuf<float4> gPos, gInvI, gVel;
     // XCD-partitioned persistent solver: cached velocity copy for XCD-local bodies, per-body XCD set, spatial sort of the manifolds, per-XCD tile lists
     DBuf<float4> gVelL; DBuf<unsigned long long> bodyOwner; DBuf<uint32_t> sortKeys[2], sortVals[2], xcdBase, xcdTiles, keyCount;
+    bool privateIslandsEnabled = true;
     bool persistXcd = true, persistXcdSingle = true, usedXcd = false, usedXcdSingle = false, lastXcdSingle = false, haveXcdEstimate = false, xcdFaultFired = false, xcdFaultTest = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
     // device: colliders
     DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cEmit;
@@ -387,6 +388,7 @@ int mi_world::init(int dev) {
       if (const char* pw = getenv("MI_PERSIST_WAVES")) persistWaves = (uint32_t)strtoul(pw, nullptr, 0);
       xcdOnly = getenv("MI_PERSIST_XCD_ONLY") ? 1u : 0u;
       if (const char* px = getenv("MI_PERSIST_XCD")) persistXcd = px[0] != '0';
+      if (const char* pi = getenv("MI_ISLAND_PRIVATE")) privateIslandsEnabled = pi[0] != '0';   // development / tests: every island through the dataflow
       if (const char* px = getenv("MI_PERSIST_XCD_SINGLE")) persistXcdSingle = px[0] != '0';   // 0: small piles on all XCDs, every body through memory
       xcdFaultTest = getenv("MI_PERSIST_XCD_FAULT") != nullptr;
       flowFaultTest = getenv("MI_FLOW_FAULT") != nullptr;
@@ -1241,14 +1243,20 @@ enqueue_section:
     // the persistent kernel keeps the accumulated impulses in LDS while they fit: k_contact_init then need not write the impulse granules
     const bool persistPlan = !fused && useFlow && persistSolver && joints.count() == 0 && tilesLaunch && !exactSeamStep;
     const uint32_t persistMaxSlots = persistPlan ? persistSlots(tilesLaunch, xcdPlan, spec) : 0u;
+    const bool privateIslands = fused && privateIslandsEnabled && !shard.enabled && joints.dBodyIsland && nmBound && tilesLaunch;
+    const IslandPrivate islandPriv = privateIslands ? joints.islandPrivate() : IslandPrivate{nullptr, nullptr, nullptr, nullptr, nullptr};
     const bool impNeeded = !(persistPlan && persistImpLds && persistMaxSlots * (4u * 512u + 20u) <= 38u * 1024u);
     if (nmBound) {
         HIP_TRY(slotMeta.ensure((size_t)tilesCap * 64)); HIP_TRY(slotNormal.ensure((size_t)tilesCap * 64)); HIP_TRY(slotMass.ensure((size_t)tilesCap * 64));
         HIP_TRY(rows.ensure((size_t)ctCap * kRows * 64)); HIP_TRY(imp.ensure((size_t)ctCap * 64));
+        if (privateIslands) {   // which joint islands are private this step (joints.hpp "PRIVATE islands"): their manifolds go to the island's own workgroup
+            HIP_TRY(L.memsetAsync(joints.dIslState, 0, 3 * (size_t)joints.numIslands * sizeof(uint32_t), st));
+            L.launch(k_island_classify, dim3(divUp(nmBound, B)), dim3(B), 0, st, sc, colWork.p, color.p, islandPriv);
+        }
         if (tilesLaunch)
             L.launch(k_contact_init, dim3(xcdPlan ? 8u * xcdListCap : tilesLaunch), dim3(64), 0, st, sc, nb, dt, xcdPlan ? xcdInfo.p : tileInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
                                                       gPos.p, gInvI.p, xcdPlan ? gVelL.p : gVel.p /* same content here; the cached copy */, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, impNeeded ? imp.p : nullptr, slotMeta.p, slotNormal.p, slotMass.p,
-                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, xcdListCap, xcdPlan ? 8u * xcdListCap : tilesCap);
+                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, xcdListCap, xcdPlan ? 8u * xcdListCap : tilesCap, islandPriv);
     }
     int rc = joints.initialize(*this, dt, st);   // (through L)
     if (rc != MI_OK) return rc;
@@ -1274,7 +1282,7 @@ enqueue_section:
                 (void)hipEventRecord(profEvents[e], st);
             }
             L.launch(k_solve_flow_islands, dim3((uint32_t)(per * perLaunch)), dim3(64), flowLds, st, it, perLaunch, joints.numIslands, joints.dIslands, joints.dSteps, joints.dIslandBodies, iu, ia, bv, bodyUsed.p,
-                                                                                   tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, sc);
+                                                                                   tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, sc, islandPriv, iters);
             if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
         }
     } else if (persistPlan && persistMaxSlots * 20u <= 38u * 1024u) {
@@ -1855,6 +1863,14 @@ int JointSet::upload(mi_world& w, hipStream_t st) {
             for (uint32_t b : islandBodies) if (b < invMass.size() && invMass[b] != 0.f) bodyJ[b] = 1;
             HIP_TRY(hipMalloc((void**)&dBodyJ, bodyJ.size()));
             HIP_TRY(hipMemcpyAsync(dBodyJ, bodyJ.data(), bodyJ.size(), hipMemcpyHostToDevice, st));
+            // private islands (joints.hpp): island of every dynamic island body; per-step state and the islands' manifold lists
+            std::vector<uint32_t> bodyIsland(invMass.size() + 1, 0xFFFFFFFFu);
+            for (uint32_t i = 0; i < (uint32_t)islands.size(); ++i)
+                for (uint32_t k = 0; k < islands[i].numBodies; ++k) { const uint32_t b = islandBodies[islands[i].bodyBegin + k]; if (b < invMass.size() && invMass[b] != 0.f) bodyIsland[b] = i; }
+            HIP_TRY(hipMalloc((void**)&dBodyIsland, bodyIsland.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMemcpyAsync(dBodyIsland, bodyIsland.data(), bodyIsland.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMalloc((void**)&dIslState, 3 * islands.size() * sizeof(uint32_t)));
+            HIP_TRY(hipMalloc((void**)&dIslEntries, islands.size() * (size_t)mi::kIslandMaxContacts * sizeof(uint4)));
             HIP_TRY(hipStreamSynchronize(st));   // the staging vectors are locals
             numIslands = (uint32_t)islands.size();
         }

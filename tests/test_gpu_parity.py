@@ -514,6 +514,52 @@ def test_gpu_baseline_sizes_properties(mi_lib, name, make, steps):
     assert total == steps and spec >= steps - 1 - retries and retries <= 3
 
 
+def _ragdolls_and_loose_boxes():
+    """Ragdolls on the ground plus loose boxes dropped on some of them: islands that only touch the ground and themselves (private) next to
+    islands coupled to a free body — and, once ragdolls are pushed into each other, to another island."""
+    sc = scenes.ragdolls(4, 4)
+    n_new = 6
+    e = scenes.make_entities(n_new)
+    first_body = sc.entities["position"][sc.entities["kind"] == capi.ENTITY_DYNAMIC]
+    e["position"] = [first_body[i * 29 % len(first_body)] + np.array([0.1, 1.2 + 0.1 * i, 0.0], np.float32) for i in range(n_new)]
+    e["rotation"][:, 3] = 1.0
+    e["linear_velocity"][:, 0] = [1.5, -1.5, 0.0, 2.5, 0.0, -2.5]
+    c = scenes.make_colliders(n_new, capi.AABB)
+    c["shape"][:, :6] = (-0.25, -0.25, -0.25, 0.25, 0.25, 0.25)
+    first = len(sc.entities)
+    return scenes.Scene("ragdolls_and_boxes", np.concatenate([sc.entities, e]), np.concatenate([sc.collider_entities, np.arange(first, first + n_new, dtype=np.uint32)]),
+                        np.concatenate([sc.colliders, c]), sc.solver_iterations, sc.dt, constraints=sc.constraints, global_constraints=sc.global_constraints)
+
+
+@pytest.mark.parametrize("make,steps", [(lambda: scenes.ragdolls(5, 5), 150), (lambda: scenes.vehicles(4, 4), 120), (_ragdolls_and_loose_boxes, 150)],
+                         ids=["ragdolls (cfg4): every island private", "vehicles on hull tiles (cfg5)", "ragdolls + loose boxes: private and coupled islands side by side"])
+def test_gpu_private_islands_match_oracle_and_the_dataflow_path(mi_lib, oracle_mod, monkeypatch, make, steps):
+    """An articulated island whose manifolds touch no dynamic body outside it (a ragdoll on the ground, a vehicle on static tiles) is solved by ONE
+    workgroup for all sweeps — joints and contacts, bodies in LDS, a manifold's rows in a lane's registers (joints.hpp privateIsland) — instead of
+    handing its bodies over to the contact tiles and back in every sweep.  Same canonical order restricted to the island: bit-identical to the oracle and
+    to the world that sends every island through the dataflow (MI_ISLAND_PRIVATE=0), also while islands switch between the two treatments."""
+    sc = make()
+    monkeypatch.delenv("MI_ISLAND_PRIVATE", raising=False)
+    g = sc.populate(gpu_world(mi_lib))
+    monkeypatch.setenv("MI_ISLAND_PRIVATE", "0")
+    d = sc.populate(gpu_world(mi_lib))
+    monkeypatch.delenv("MI_ISLAND_PRIVATE", raising=False)
+    o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    for i in range(steps):
+        g.step_fixed(s, sc.dt, 1); d.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        assert g.counts() == o.counts() == d.counts(), f"step {i}"
+        if i % 10 == 9 or i == steps - 1:
+            pg, qg = g.physics_transforms(); po, qo = o.physics_transforms(); pd, qd = d.physics_transforms()
+            assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes(), f"step {i}: private islands vs oracle"
+            assert pd.tobytes() == po.tobytes() and qd.tobytes() == qo.tobytes(), f"step {i}: dataflow islands vs oracle"
+    vg, wg = g.velocities(); vo, wo = o.velocities()
+    assert vg.tobytes() == vo.tobytes() and wg.tobytes() == wo.tobytes()
+    assert g.solver_kind() == 3 and d.solver_kind() == 3
+    total, spec, retries = g.step_mode_stats()
+    assert spec >= total - 2 - retries
+
+
 def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
     """BASELINE's 262 144-body pile, far beyond the oracle's reach: the default solver (XCD-partitioned persistent kernel: eight
     tile lists, ~95 % of the bodies handed over through an XCD's L2, the seam bodies through memory) must end bit-identical to
