@@ -672,6 +672,33 @@ __device__ __forceinline__ void fusedPublish(bool mine, uint32_t it, const Islan
     storeGranuleSc1(acc + 2 * (size_t)st.joint, q0);
     if (J::kAcc > 2) storeGranuleSc1(acc + 2 * (size_t)st.joint + 1, q1);
 }
+// A lane owns ONE joint of ONE type, but which type is only known at run time: six typed copies of the per-step joint data side by side (~250 registers) spilled
+// to scratch inside the sweep loop (620 bytes per lane; every joint group then waited for scratch).  The data therefore lives in one untyped block sized for the
+// largest type and is viewed as its type only inside that type's groups.
+constexpr size_t kUpdMaxBytes = std::max({sizeof(DistanceJ::Upd), sizeof(BallJ::Upd), sizeof(FixedJ::Upd), sizeof(HingeJ::Upd), sizeof(ConeJ::Upd), sizeof(SliderJ::Upd)});
+struct UpdRaw { uint32_t w[(kUpdMaxBytes + 3) / 4]; };
+template <class J>
+__device__ __forceinline__ void rawGroups(uint32_t type, const IslandDesc& d, bool mine, const IslandStep& st, UpdRaw& raw, IslandLds& lds) {
+    if (d.typeGroups[type] == d.typeGroups[type + 1]) return;   // wave-uniform
+    typename J::Upd c;
+    if (mine) __builtin_memcpy(&c, raw.w, sizeof(c));
+    fusedGroups<J>(type, d, mine, st, c, lds);
+    if (mine) __builtin_memcpy(raw.w, &c, sizeof(c));
+}
+template <class J>
+__device__ __forceinline__ void rawLoad(UpdRaw& raw, const typename J::Upd* __restrict__ upd, uint32_t joint, const float* a /* accumulators, or null */) {
+    typename J::Upd c = upd[joint];
+    if (a) J::setAcc(c, a);
+    __builtin_memcpy(raw.w, &c, sizeof(c));
+}
+template <class J>
+__device__ __forceinline__ void rawSetAcc(UpdRaw& raw, const float* a) { typename J::Upd c; __builtin_memcpy(&c, raw.w, sizeof(c)); J::setAcc(c, a); __builtin_memcpy(raw.w, &c, sizeof(c)); }
+template <class J>
+__device__ __forceinline__ void rawPublish(bool mine, uint32_t it, const IslandStep& st, const UpdRaw& raw, float4* acc) {
+    if (!mine) return;
+    typename J::Upd c; __builtin_memcpy(&c, raw.w, sizeof(c));
+    fusedPublish<J>(true, it, st, c, acc);
+}
 __device__ __forceinline__ void fusedIsland(uint32_t it, const IslandDesc& d, const IslandStep* __restrict__ steps, const uint32_t* __restrict__ islandBodies, const IslandUpd& upd,
                                             const IslandAcc& acc, const BodyView& bv, const unsigned long long* __restrict__ bodyUsed, IslandLds& lds, StepScalars* sc) {
     const uint32_t lane = threadIdx.x;
@@ -691,14 +718,14 @@ __device__ __forceinline__ void fusedIsland(uint32_t it, const IslandDesc& d, co
     float4* accPtr = type == 3u ? acc.hinge : type == 4u ? acc.cone : type == 5u ? acc.slider : nullptr;
     const bool twoGranules = type == 4u;
     if (accPtr) { accPtr += 2 * (size_t)st.joint; issueGranuleSc1(accPtr, q0); if (twoGranules) issueGranuleSc1(accPtr + 1, q1); }
-    DistanceJ::Upd cDistance; BallJ::Upd cBall; FixedJ::Upd cFixed; HingeJ::Upd cHinge; ConeJ::Upd cCone; SliderJ::Upd cSlider;
+    UpdRaw raw;   // (one untyped block instead of six typed copies: see UpdRaw)
     switch (type) {
-        case 0: cDistance = upd.distance[st.joint]; break;
-        case 1: cBall = upd.ball[st.joint]; break;
-        case 2: cFixed = upd.fixed[st.joint]; break;
-        case 3: cHinge = upd.hinge[st.joint]; break;
-        case 4: cCone = upd.cone[st.joint]; break;
-        case 5: cSlider = upd.slider[st.joint]; break;
+        case 0: rawLoad<DistanceJ>(raw, upd.distance, st.joint, nullptr); break;
+        case 1: rawLoad<BallJ>(raw, upd.ball, st.joint, nullptr); break;
+        case 2: rawLoad<FixedJ>(raw, upd.fixed, st.joint, nullptr); break;
+        case 3: rawLoad<HingeJ>(raw, upd.hinge, st.joint, nullptr); break;
+        case 4: rawLoad<ConeJ>(raw, upd.cone, st.joint, nullptr); break;
+        case 5: rawLoad<SliderJ>(raw, upd.slider, st.joint, nullptr); break;
         default: break;
     }
     if (isBody) {
@@ -726,17 +753,17 @@ __device__ __forceinline__ void fusedIsland(uint32_t it, const IslandDesc& d, co
         }
         if (isBody) { lds.v[lane] = make_float4(g0.x, g0.y, g0.z, g0.w); lds.w[lane] = make_float4(g1.x, g1.y, g1.z, g1.w); }
     }
-    { const float a[4] = {q0.x, q0.y, q1.x, q1.y}; if (type == 3u) HingeJ::setAcc(cHinge, a); else if (type == 4u) ConeJ::setAcc(cCone, a); else if (type == 5u) SliderJ::setAcc(cSlider, a); }
+    { const float a[4] = {q0.x, q0.y, q1.x, q1.y}; if (type == 3u) rawSetAcc<HingeJ>(raw, a); else if (type == 4u) rawSetAcc<ConeJ>(raw, a); else if (type == 5u) rawSetAcc<SliderJ>(raw, a); }
     __syncthreads();
-    fusedGroups<DistanceJ>(0, d, type == 0u, st, cDistance, lds);
-    fusedGroups<BallJ>(1, d, type == 1u, st, cBall, lds);
-    fusedGroups<FixedJ>(2, d, type == 2u, st, cFixed, lds);
-    fusedGroups<HingeJ>(3, d, type == 3u, st, cHinge, lds);
-    fusedPublish<HingeJ>(type == 3u, it, st, cHinge, acc.hinge);
-    fusedGroups<ConeJ>(4, d, type == 4u, st, cCone, lds);
-    fusedPublish<ConeJ>(type == 4u, it, st, cCone, acc.cone);
-    fusedGroups<SliderJ>(5, d, type == 5u, st, cSlider, lds);
-    fusedPublish<SliderJ>(type == 5u, it, st, cSlider, acc.slider);
+    rawGroups<DistanceJ>(0, d, type == 0u, st, raw, lds);
+    rawGroups<BallJ>(1, d, type == 1u, st, raw, lds);
+    rawGroups<FixedJ>(2, d, type == 2u, st, raw, lds);
+    rawGroups<HingeJ>(3, d, type == 3u, st, raw, lds);
+    rawPublish<HingeJ>(type == 3u, it, st, raw, acc.hinge);
+    rawGroups<ConeJ>(4, d, type == 4u, st, raw, lds);
+    rawPublish<ConeJ>(type == 4u, it, st, raw, acc.cone);
+    rawGroups<SliderJ>(5, d, type == 5u, st, raw, lds);
+    rawPublish<SliderJ>(type == 5u, it, st, raw, acc.slider);
     if (isBody && dynamic) {
         const float t = __uint_as_float(expect + 1u);
         const float4 v = lds.v[lane], w = lds.w[lane];
@@ -786,22 +813,22 @@ __device__ __forceinline__ void privateIsland(uint32_t sweeps, uint32_t island, 
         lds.inertia[3 * lane] = bv.gInvI[3 * body]; lds.inertia[3 * lane + 1] = bv.gInvI[3 * body + 1]; lds.inertia[3 * lane + 2] = bv.gInvI[3 * body + 2];
     }
     const uint32_t type = hasJoint ? st.type : 0xFFFFu;
-    DistanceJ::Upd cDistance; BallJ::Upd cBall; FixedJ::Upd cFixed; HingeJ::Upd cHinge; ConeJ::Upd cCone; SliderJ::Upd cSlider;
-    switch (type) {
-        case 0: cDistance = upd.distance[st.joint]; break;
-        case 1: cBall = upd.ball[st.joint]; break;
-        case 2: cFixed = upd.fixed[st.joint]; break;
-        case 3: cHinge = upd.hinge[st.joint]; break;
-        case 4: cCone = upd.cone[st.joint]; break;
-        case 5: cSlider = upd.slider[st.joint]; break;
-        default: break;
-    }
+    UpdRaw raw;
     {   // the clamped accumulators start from what k_joint_init left in the granules (sweep tag 0) and then stay in registers
         const float4* accPtr = type == 3u ? acc.hinge : type == 4u ? acc.cone : type == 5u ? acc.slider : nullptr;
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
         if (accPtr) {
             const float4 q0 = accPtr[2 * (size_t)st.joint], q1 = type == 4u ? accPtr[2 * (size_t)st.joint + 1] : make_float4(0.f, 0.f, 0.f, 0.f);
-            const float a[4] = {q0.x, q0.y, q1.x, q1.y};
-            if (type == 3u) HingeJ::setAcc(cHinge, a); else if (type == 4u) ConeJ::setAcc(cCone, a); else SliderJ::setAcc(cSlider, a);
+            a[0] = q0.x; a[1] = q0.y; a[2] = q1.x; a[3] = q1.y;
+        }
+        switch (type) {
+            case 0: rawLoad<DistanceJ>(raw, upd.distance, st.joint, nullptr); break;
+            case 1: rawLoad<BallJ>(raw, upd.ball, st.joint, nullptr); break;
+            case 2: rawLoad<FixedJ>(raw, upd.fixed, st.joint, nullptr); break;
+            case 3: rawLoad<HingeJ>(raw, upd.hinge, st.joint, a); break;
+            case 4: rawLoad<ConeJ>(raw, upd.cone, st.joint, a); break;
+            case 5: rawLoad<SliderJ>(raw, upd.slider, st.joint, a); break;
+            default: break;
         }
     }
     // this lane's manifold
@@ -837,12 +864,12 @@ __device__ __forceinline__ void privateIsland(uint32_t sweeps, uint32_t island, 
     const unsigned long long colours = pl.colours;
     const f32x2 sMass = pk2(-mass.x, mass.y);
     for (uint32_t it = 0; it < sweeps; ++it) {
-        fusedGroups<DistanceJ>(0, d, type == 0u, st, cDistance, lds);
-        fusedGroups<BallJ>(1, d, type == 1u, st, cBall, lds);
-        fusedGroups<FixedJ>(2, d, type == 2u, st, cFixed, lds);
-        fusedGroups<HingeJ>(3, d, type == 3u, st, cHinge, lds);
-        fusedGroups<ConeJ>(4, d, type == 4u, st, cCone, lds);
-        fusedGroups<SliderJ>(5, d, type == 5u, st, cSlider, lds);
+        rawGroups<DistanceJ>(0, d, type == 0u, st, raw, lds);
+        rawGroups<BallJ>(1, d, type == 1u, st, raw, lds);
+        rawGroups<FixedJ>(2, d, type == 2u, st, raw, lds);
+        rawGroups<HingeJ>(3, d, type == 3u, st, raw, lds);
+        rawGroups<ConeJ>(4, d, type == 4u, st, raw, lds);
+        rawGroups<SliderJ>(5, d, type == 5u, st, raw, lds);
         for (unsigned long long rest = colours; rest; rest &= rest - 1ull) {   // wave-uniform
             const uint32_t cur = (uint32_t)__ffsll((long long)rest) - 1u;
             if (hasContact && colour == cur) {
