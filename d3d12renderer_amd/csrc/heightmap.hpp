@@ -311,10 +311,16 @@ struct HmOut {   // where the WRITE passes put contact j of collider i
     }
 };
 
+// The counting pass keeps WHICH triangles it hit: the first kHmStash hits of a collider go to a stash ([collider][kHmStash] packed (chunk, quad, triangle); the
+// lowest-point contact of a capsule / cylinder / hull as kHmStashLowest) and the WRITE pass recomputes just those — one lane per contact — instead of walking the
+// collider's whole window of triangles a second time (65 536 bodies on terrain: the second walk was 212 us).  The counting pass itself stays what it was (it never
+// needed the contact geometry: keeping the contacts themselves doubled its time).  A collider with more hits than the stash holds is walked again as before.
+constexpr uint32_t kHmStashLowest = 0xFFFFFFFFu;
+constexpr uint32_t kHmStash = 16;
 template <bool WRITE>
 __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
                                                      const float4* __restrict__ aabbMax, unsigned long long* __restrict__ hmPacked, uint8_t* __restrict__ hmSlow,
-                                                     const unsigned long long* __restrict__ hmScan, HmOut out, HullSet hulls) {
+                                                     const unsigned long long* __restrict__ hmScan, HmOut out, HullSet hulls, uint32_t* __restrict__ stash) {
     const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
     if (i >= nc) return;
     const float4 mn = aabbMin[i], mx = aabbMax[i];
@@ -325,7 +331,9 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
         count = active ? (uint32_t)hmPacked[i] : 0u;
         if (!count || hmSlow[i] || !out.ready()) return;
         first = out.sc->numPairs + (uint32_t)hmScan[i];
+        if (stash && count <= kHmStash && hm.chunksPerDim <= 256u) return;   // every hit of this collider is in the stash: k_hm_write_stashed recomputes just those
     } else if (!active) { if (lane == 0) { hmPacked[i] = 0ull; hmSlow[i] = 0; } return; }
+    auto keep = [&](uint32_t j, uint32_t id) { if (stash && j < kHmStash) stash[(size_t)i * kHmStash + j] = id; };
     const Shape s = loadShape(wShape, i, type);
     const TriShape ts(s);
     const HmVolume vol(hm, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z));
@@ -375,6 +383,12 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
             if (WRITE) {
 #pragma unroll
                 for (uint32_t b = 0; b < 2u; ++b) if (hit[b] && found + before[b] < count) out.put(first, i, found + before[b], tc[b]);
+            } else {
+#pragma unroll
+                for (uint32_t b = 0; b < 2u; ++b) if (hit[b]) {
+                    const uint32_t item = b * 64u + lane, q = item >> 1;
+                    keep(found + before[b], (x << 23) | (z << 15) | ((x0 + q % w) << 8) | ((z0 + q / w) << 1) | (item & 1u));
+                }
             }
             found = min(found + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1), kHmMaxContacts);
         }
@@ -386,9 +400,37 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
     }
     if (slow) { hmPacked[i] = 0ull; hmSlow[i] = 1; return; }
     TriContact t;
-    if (hmLowestPoint(hm, s, hulls, t) && found < kHmMaxContacts) ++found;
+    if (hmLowestPoint(hm, s, hulls, t) && found < kHmMaxContacts) { keep(found, kHmStashLowest); ++found; }
     hmPacked[i] = (unsigned long long)found | (found ? 1ull << 32 : 0ull);
     hmSlow[i] = 0;
+}
+// WRITE pass for the stashed colliders: one LANE per terrain contact.  Contact t belongs to the collider i with offset(i) <= t < offset(i) + count(i) (binary search
+// over the scanned counts) and is its hit number j = t - offset(i): the lane recomputes that one triangle (or the lowest point) and writes the contact to its final slot.
+__global__ __launch_bounds__(256) void k_hm_write_stashed(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
+                                                          const float4* __restrict__ aabbMax, const unsigned long long* __restrict__ hmPacked, const uint8_t* __restrict__ hmSlow,
+                                                          const unsigned long long* __restrict__ hmScan, HmOut out, HullSet hulls, const uint32_t* __restrict__ stash) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= out.sc->numHmContacts || !out.ready() || hm.chunksPerDim > 256u) return;
+    uint32_t lo = 0, hi = nc;                       // the last collider whose offset is <= t (colliders without contacts share their successor's offset)
+    while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)hmScan[mid] <= t) lo = mid; else hi = mid; }
+    const uint32_t i = lo, count = (uint32_t)hmPacked[i], j = t - (uint32_t)hmScan[i];
+    if (j >= count || count > kHmStash || hmSlow[i]) return;     // (the wave-per-collider pass / k_hm_slow write those)
+    const float4 mn = aabbMin[i], mx = aabbMax[i];
+    const Shape s = loadShape(wShape, i, __float_as_uint(mn.w) & 0xFFu);
+    const uint32_t id = stash[(size_t)i * kHmStash + j];
+    TriContact tc; bool ok;
+    if (id == kHmStashLowest) ok = hmLowestPoint(hm, s, hulls, tc);
+    else {
+        const uint32_t x = id >> 23, z = (id >> 15) & 0xFFu, qx = (id >> 8) & 0x7Fu, qz = (id >> 1) & 0x7Fu, tri = id & 1u;
+        const HmVolume vol(hm, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z));
+        const V3 chunkMin = V3((float)x * hm.chunkSize, 0.f, (float)z * hm.chunkSize) + vol.corner;
+        const uint16_t* __restrict__ heights = hm.heights + (size_t)hm.chunkSlot[z * hm.chunksPerDim + x] * kHmVerts * kHmVerts;
+        const TriShape ts(s);
+        const V3 pb = hmVertex(hm, heights, chunkMin, qx, qz + 1u), pc = hmVertex(hm, heights, chunkMin, qx + 1u, qz);
+        const V3 pe = tri ? hmVertex(hm, heights, chunkMin, qx + 1u, qz + 1u) : hmVertex(hm, heights, chunkMin, qx, qz);
+        ok = tri ? ts.test(pc, pb, pe, tc) : ts.test(pe, pb, pc, tc);
+    }
+    if (ok) out.put(out.sc->numPairs + (uint32_t)hmScan[i], i, j, tc);
 }
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_hm_slow(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,

@@ -261,6 +261,7 @@ struct mi_world {
     HeightmapParams hmParams{};
     std::vector<uint16_t> hmHostHeights; std::vector<uint32_t> hmHostSlots;   // host mirror of the device pool (mi_heightmap_get_height)
     DBuf<uint16_t> hmHeights; DBuf<uint32_t> hmMips, hmChunkSlot;
+    DBuf<uint32_t> hmStash;   // [colliders][kHmStash]: which triangles the counting pass of k_hm_contacts hit (the WRITE pass recomputes just those)
     DBuf<unsigned long long> hmPacked, hmScan; DBuf<uint8_t> hmSlow;   // per collider: contacts | touching << 32, its exclusive scan, sequential-walk flag
     uint32_t manifoldsLast = 0;   // device manifolds of the last step (heightmap contacts are one-contact manifolds; counts.num_collisions is per collider)
     int uploadHeightmap();
@@ -630,6 +631,7 @@ int mi_world::upload() {
     if (rc != MI_OK) return rc;
     if (heightmap) {
         HIP_TRY(hmPacked.ensure(nc + 1)); HIP_TRY(hmScan.ensure(nc + 1)); HIP_TRY(hmSlow.ensure(nc + 1));
+        { static const bool stashOn = !(std::getenv("MI_HM_STASH") && std::getenv("MI_HM_STASH")[0] == '0'); if (stashOn) HIP_TRY(hmStash.ensure((size_t)(nc + 1) * kHmStash)); }
         rc = uploadHeightmap(); if (rc != MI_OK) return rc;
     }
     HIP_TRY(hipStreamSynchronize(stream));
@@ -1011,7 +1013,7 @@ enqueue_section:
                                                      wShape.p, aabbMin.p, aabbMax.p, sc, sapAxis, shard.enabled ? shard.active.p : nullptr, shard.activePrev.p, shard.enabled ? shard.axisDev.p : nullptr);
         if (heightmap) {   // terrain contacts per collider, their offsets and totals (they join the pair list after the collider-pair narrow phase)
             const HullSet hmHulls{hullVerts.p, hullRanges.p};
-            L.launch(k_hm_contacts<false>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{}, hmHulls);
+            L.launch(k_hm_contacts<false>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{}, hmHulls, hmStash.p);
             L.launch(k_hm_slow<false>, dim3(divUp(nc, 64)), dim3(64), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, nullptr, HmOut{}, hmHulls);
             HIP_TRY(scanTerrain.run(L, hmPacked.p, hmScan.p, nc, st));
             L.launch(k_hm_totals, dim3(1), dim3(1), 0, st, nc, hmPacked.p, hmScan.p, sc);
@@ -1110,8 +1112,9 @@ enqueue_section:
         }
         if (heightmap) {
             const HmOut hmOut{sc, pairBound, pairKeys.p, pairKeysS.p, npPacked.p, npNormal.p, npPoints.p};
-            L.launch(k_hm_contacts<true>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut, hset);
+            L.launch(k_hm_contacts<true>, dim3(divUp(nc, 4)), dim3(256), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut, hset, hmStash.p);
             L.launch(k_hm_slow<true>, dim3(divUp(nc, 64)), dim3(64), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut, hset);
+            if (hmStash.p && pairBound) L.launch(k_hm_write_stashed, dim3(divUp(pairBound, B)), dim3(B), 0, st, nc, hmParams, wShape.p, aabbMin.p, aabbMax.p, hmPacked.p, hmSlow.p, hmScan.p, hmOut, hset, hmStash.p);   // (sized for all pairs: the terrain contacts are among them)
             L.launch(k_hm_finish, dim3(1), dim3(1), 0, st, sc, pairBound);
         }
         HIP_TRY(scanPairs.run(L, reinterpret_cast<unsigned long long*>(npPacked.p), reinterpret_cast<unsigned long long*>(npScan.p), pairBound, st));
