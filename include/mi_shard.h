@@ -150,7 +150,8 @@ MI_API int mi_world_shard_import(mi_world* world, const void* message);
  * mi_world_shard_sweep_message_bytes: count + records of MI_SHARD_SWEEP_FLOATS floats = body index, linear velocity, angular velocity; only the
  * header and the `count` records are written / read, so a transport may send just that prefix) and returns
  * MI_OK.  Every rank makes the same number of calls (the sweeps of the step), so a barrier inside the callback is safe.  Steps run one at a time
- * and synchronously in this mode (no speculation: every rank must take the same path through the step). */
+ * and synchronously in this mode (no speculation: every rank must take the same path through the step).  A checkpoint does not carry the mode
+ * (nor a single world's tiling): set it before loading one — setting it drops the colour history, the checkpoint then brings its own. */
 #define MI_SEAM_COLORS 24
 #define MI_SHARD_SWEEP_FLOATS 8
 typedef int (*mi_shard_sweep_fn)(void* user, mi_world* world, uint32_t sweep);

@@ -503,3 +503,27 @@ def test_exact_seam_conditions_are_checked(oracle_mod):
     for _ in range(40):
         sharding.step_local_exact(ranks, s, sc.dt)
     assert sum(r.world.seam_stats()["violations"] for r in ranks) > 0
+
+
+def test_exact_seam_checkpoint_round_trip(oracle_mod):
+    """Save every rank in the middle of an exact-seam run, go on, restore (the mode is set on the worlds — it is not part of the blob), go on again:
+    the same states, bit for bit, and still the single world told the tiling."""
+    sc, margin = _exact_case("pile")
+    desc = sharding.tile_grid(sc, 2, 1, margin)
+    make = lambda: oracle_mod.create_world(oracle_mod.ORDER_CANONICAL)
+    ranks = [sharding.ShardedWorld(sc.populate(make()), desc, r, "local") for r in range(2)]
+    single = sc.populate(make()); single.set_seam_tiling(desc)
+    s = sc.settings()
+    ents = np.flatnonzero(sc.entities["kind"] != capi.ENTITY_STATIC).astype(np.uint32)
+    for _ in range(15):
+        sharding.step_local_exact(ranks, s, sc.dt); single.step_fixed(s, sc.dt, 1)
+    blobs = [r.world.save_checkpoint() for r in ranks]
+    for _ in range(15):
+        sharding.step_local_exact(ranks, s, sc.dt); single.step_fixed(s, sc.dt, 1)
+    final = sharding.gather_owned(ranks, len(ents))
+    assert final.tobytes() == single.get_body_states(ents).tobytes()
+    for r, blob in zip(ranks, blobs):
+        r.world.load_checkpoint(blob)
+    for _ in range(15):
+        sharding.step_local_exact(ranks, s, sc.dt)
+    assert sharding.gather_owned(ranks, len(ents)).tobytes() == final.tobytes()
