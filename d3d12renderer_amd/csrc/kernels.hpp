@@ -1287,7 +1287,9 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
 // sectors and atomics, this one streams; interleaved every 4th workgroup.  k_emit_manifolds 54 -> 68 us for the 21 us saved: they compete for the same
 // memory system; 938 vs 937 steps/s.  Nor as guests of the colouring rounds — launch-floor kernels between which nothing reads what this one writes: a slice of
 // the bodies per round made every round 9-10 us instead of 4.8 (the body rows are a chain of dependent gathers: ~5 us however few bodies), 8 x 5 us for the 19 saved:
-// 962 vs 987 steps/s.)
+// 962 vs 987 steps/s.  The same with k_manifold_keys / k_manifold_place as guests of rounds 0 / 1: 17.6 + 10.9 us for the two rounds, i.e. guest time + the round's own
+// ~4.7 us — a kernel's launch floor is start-up and drain in series with its work, not a window other work can hide in.  A guest only pays inside a kernel whose OWN work
+// outlasts it (the statistics workgroup of k_emit_manifolds).)
 __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt, float3 globalForce, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
                                                           const float4* __restrict__ bCogInvMass, const float4* __restrict__ bInvI,
                                                           const float4* __restrict__ bParams, const float4* __restrict__ bLinVel,
