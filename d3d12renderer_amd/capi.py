@@ -632,9 +632,9 @@ class World:
         self.L.check(self.L.fn("world_get_accumulated_stage_times")(self.h, C.byref(t), C.byref(n), C.byref(u), C.c_uint32(1 if reset else 0)), "world_get_accumulated_stage_times")
         return t.as_dict(), n.value, u.value
 
-    def set_stage_timing(self, enable=True):
-        """Time every stage of a step (default: only the whole step and the solve stage)."""
-        self.L.check(self.L.fn("world_set_stage_timing")(self.h, C.c_uint32(1 if enable else 0)), "world_set_stage_timing")
+    def set_stage_timing(self, level=1):
+        """0 / False: nothing is timed (default); 1 / True: every stage; 2: the whole step and the solve stage only (mi_physics.h)."""
+        self.L.check(self.L.fn("world_set_stage_timing")(self.h, C.c_uint32(int(level))), "world_set_stage_timing")
 
     def stage_times(self):
         t = StageTimes()

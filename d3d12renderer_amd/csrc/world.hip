@@ -281,7 +281,7 @@ struct mi_world {
 
     StepScalars hs{};            // host copy of the last step's scalars
     struct Readback { StepScalars sc; uint32_t flags[96]; uint32_t seq; uint32_t pad[3]; };   // seq: written last by k_publish_readback (the host spins on it)
-    uint32_t readbackSeq = 0; bool spinReadback = true, stageEvents = false;
+    uint32_t readbackSeq = 0; bool spinReadback = true, stageEvents = false /* time every stage */, stepEvents = false /* time the whole step and the solve stage */;
     Readback* hsPinned = nullptr; // pinned staging for the end-of-step read-back (one async copy, no pageable bounce)
     mi_stage_times timesSum{}; uint32_t timesSteps = 0; uint64_t contactUpdatesSum = 0;   // accumulated since the last mi_world_get_accumulated_stage_times(reset)
     mi_step_counts counts{};
@@ -363,7 +363,8 @@ int mi_world::init(int dev) {
     if (const char* g = getenv("MI_GRAPH_MAX_COLLIDERS")) graphMaxColliders = (uint32_t)strtoul(g, nullptr, 0);
     graphDebug = getenv("MI_GRAPH_DEBUG") != nullptr; graphNoEvents = getenv("MI_GRAPH_NOEVENTS") != nullptr; graphNoCapture = getenv("MI_GRAPH_NOCAPTURE") != nullptr;
     if (const char* sr = getenv("MI_READBACK")) spinReadback = spinReadback && std::string(sr) != "copy";   // MI_READBACK=copy: hipMemcpyAsync + hipStreamSynchronize
-    stageEvents = getenv("MI_STAGE_EVENTS") && getenv("MI_STAGE_EVENTS")[0] != '0';   // default: only the whole step and the solve stage are timed (mi_world_set_stage_timing)
+    stageEvents = getenv("MI_STAGE_EVENTS") && getenv("MI_STAGE_EVENTS")[0] != '0';   // default: nothing is timed (mi_world_set_stage_timing)
+    stepEvents = getenv("MI_STEP_EVENTS") && getenv("MI_STEP_EVENTS")[0] != '0';
     const char* sw = getenv("MI_XCD_SWIZZLE");
     xcdSwizzle = sw && sw[0] == '1';
     const char* sv = getenv("MI_SOLVER");
@@ -953,10 +954,14 @@ int mi_world::runStep(const mi_step_settings& settings, float dt, bool spec) {
     // idle device per event: 24 us per step); where the stage is ONE kernel the events ride on that kernel's dispatch instead
     // (hipExtLaunchKernelGGL start / stop events): no packet, no gap.  `attached` = this step's 0 / 6 / 7 / 8 are attached ones.
     bool attached = !debugSync;   // (set per pass below: a graph cannot hold the attached form, it gets recorded events)
+    // Timing is opt-in (mi_world_set_stage_timing): even ATTACHED events are not free — the start / stop events riding on the solver's dispatch cost ~11 us of idle
+    // device per step (the kernels before / after wait for the signals), the step's two ~1.5 us: 12 us of a 1.0 ms step for numbers nobody asked for.
+    const int stepEventsMode = stepEvents || stageEvents ? 2 : 0;   // (0 none; 2 step + solve stage)
     auto mark = [&]() {
         const int id = evi++;
+        if (!stageEvents && (stepEventsMode == 0 || (stepEventsMode == 1 && (id == 0 || id == 8)))) return;
         if (attached && (id == 0 || id == 6 || id == 7 || id == 8)) return;
-        if (!stageEvents && id != 0 && id != 6 && id != 7 && id != 8) return;   // by default only the step and the solve stage are timed
+        if (!stageEvents && id != 0 && id != 6 && id != 7 && id != 8) return;   // level 2: only the step and the solve stage
         if (L.hashing && !stageEvents && graphNoEvents) return;
         L.eventRecord(ev[id], st);
         if (debugSync) { hipError_t e = hipStreamSynchronize(st); if (e != hipSuccess) std::fprintf(stderr, "[mi_physics] step %llu (%s): stage ending at mark %d: %s\n", (unsigned long long)totalSteps, spec ? "speculative" : "synchronous", evi - 1, hipGetErrorString(e)); }
@@ -977,7 +982,7 @@ enqueue_section:
     L.begin(pass == PASS_DRY, pass != PASS_PLAIN);
     attached = !debugSync && pass == PASS_PLAIN;
     mark();  // 0
-    if (attached) hipExtLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(128), 0, st, ev[0], nullptr, 0, sc, shards.p, roundFlagsPtr(), keyCount.p);
+    if (attached && (stepEventsMode == 2 || stageEvents)) hipExtLaunchKernelGGL(k_reset_scalars, dim3(1), dim3(128), 0, st, ev[0], nullptr, 0, sc, shards.p, roundFlagsPtr(), keyCount.p);
     else L.launch(k_reset_scalars, dim3(1), dim3(128), 0, st, sc, shards.p, roundFlagsPtr(), keyCount.p);
     if (shard.enabled && nb) {
         HIP_TRY(shard.activePrev.ensure(std::max(nb, 1u)));
@@ -1305,7 +1310,7 @@ enqueue_section:
         const uint32_t ldsMeta = maxSlots * (64u * 40u + 4u * 512u + 20u) + 16u, ldsImp = maxSlots * (4u * 512u + 20u) + 16u, ldsDesc = maxSlots * 20u + 16u;
 #define MI_PERSIST_ARGS iters, maxSlots, tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, sc, xcdOnly, xcdTiles.p, xcdListCap, bodyOwner.p, gVelL.p, slotMeta.p, imp.p, xcdFault
         // the solve stage IS this launch: its timing events ride on the dispatch (when this path is not taken they are recorded below)
-        hipEvent_t e6 = attached ? ev[6] : nullptr, e7 = attached ? ev[7] : nullptr;
+        hipEvent_t e6 = attached && (stepEventsMode || stageEvents) ? ev[6] : nullptr, e7 = attached && (stepEventsMode || stageEvents) ? ev[7] : nullptr;
         solveAttached = attached;
 #define MI_PERSIST_LAUNCH(A, B_, C_, LDS) do { if (attached) hipExtLaunchKernelGGL((k_contact_solve_persist<A, B_, C_>), dim3(persistWaves), dim3(64), LDS, st, e6, e7, 0, MI_PERSIST_ARGS); \
                                               else L.launch(k_contact_solve_persist<A, B_, C_>, dim3(persistWaves), dim3(64), LDS, st, MI_PERSIST_ARGS); } while (0)
@@ -1380,7 +1385,7 @@ enqueue_section:
     if (shard.enabled && pairBound && !shardCounted) L.launch(k_shard_count, dim3(divUp(nmBound ? nmBound : 1u, B)), dim3(B), 0, st, nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc, shards.p);
     mark();  // 7
     if (attached && !solveAttached) (void)hipEventRecord(ev[7], st);
-    if (attached) hipExtLaunchKernelGGL(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nullptr, ev[8], 0, nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
+    if (attached && (stepEventsMode == 2 || stageEvents)) hipExtLaunchKernelGGL(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nullptr, ev[8], 0, nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
                                       gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p,
                                       shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p, shard.activePrev.p, shards.p, sc);
     else L.launch(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
@@ -1580,7 +1585,7 @@ enqueue_section:
     counts.num_colors = numColorsUsed; counts.sorting_axis = hs.axisCur; counts.reserved = solveLaunches;
     // the step's device times: read from its events LATER (finishTimes), the next step records into the other set
     finishTimes();   // (normally done already, at the start of this step)
-    timesPending = true; timesPendingSet = evSet; timesPendingStages = stageEvents; timesPendingUpdates = (uint64_t)counts.num_contacts * iters;
+    timesPending = stepEventsMode == 2 || stageEvents; timesPendingSet = evSet; timesPendingStages = stageEvents; timesPendingUpdates = (uint64_t)counts.num_contacts * iters;
     evSet ^= 1; ev = evSets[evSet];
     static const bool eagerTimes = std::getenv("MI_EAGER_TIMES") != nullptr;   // development: read them right here, as before
     if (eagerTimes) finishTimes();
@@ -3314,7 +3319,10 @@ MI_API int mi_debug_tile_owner(uint32_t tile_in_bin, uint32_t tiles_in_bin, uint
 }
 // Event pairs around every stage cost a few microseconds of device time per step each: off by default (the whole step and the
 // solve stage are always timed), on for profiling.
-MI_API int mi_world_set_stage_timing(mi_world* w, uint32_t enable) { if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null"); w->stageEvents = enable != 0; return MI_OK; }
+MI_API int mi_world_set_stage_timing(mi_world* w, uint32_t level) {
+    if (!w || level > 2u) return fail(MI_ERR_INVALID_ARGUMENT, "level: 0 off, 1 every stage, 2 the whole step and the solve stage");
+    w->stageEvents = level == 1u; w->stepEvents = level == 2u; return MI_OK;
+}
 MI_API int mi_world_get_stage_times(mi_world* w, mi_stage_times* out) { if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null"); w->finishTimes(); *out = w->times; return MI_OK; }
 
 MI_API int mi_world_get_contacts(mi_world* w, mi_contact* out, uint32_t cap, uint32_t* count) {

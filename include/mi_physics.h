@@ -276,9 +276,10 @@ MI_API int mi_world_get_contacts(mi_world* world, mi_contact* out, uint32_t capa
  * schedule bin with `tiles_in_bin` tiles: out[0] = owning XCD, out[1] = its rank inside that XCD's share of the bin,
  * out[2] = size of `query_xcd`'s share of the bin. */
 MI_API int mi_debug_tile_owner(uint32_t tile_in_bin, uint32_t tiles_in_bin, uint32_t bin, uint32_t query_xcd, uint32_t* out);
-/* Per-stage device times of the last internal step.  Only `total` and `solve` are measured by default; the other stages are
- * timed (a HIP event pair each, a few microseconds of device time per step) after mi_world_set_stage_timing(world, 1). */
-MI_API int mi_world_set_stage_timing(mi_world* world, uint32_t enable);
+/* Per-stage device times of the last internal step (HIP events on the world's stream).  Nothing is timed by default — even events attached to a
+ * kernel's dispatch leave the device idle for a few microseconds (the solver's start / stop pair: ~11 us of a 1 ms step).  level 2: the whole step
+ * (`total`) and the solve stage; level 1: every stage (an event pair each); level 0: off. */
+MI_API int mi_world_set_stage_timing(mi_world* world, uint32_t level);
 MI_API int mi_world_get_stage_times(mi_world* world, mi_stage_times* out);
 /* Contact-solver kernel of the last internal step: 0 k_contact_solve (a launch per colour per sweep), 1 k_contact_solve_flow,
  * 2 k_contact_solve_persist (default without joints), 3 k_solve_flow_islands (contacts + joint islands in one launch),

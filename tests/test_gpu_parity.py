@@ -394,10 +394,14 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
     assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
     assert g.solver_kind() == kind
     assert g.step_mode_stats()[2] <= 2, "the partitioned solver must not keep falling back"
-    # per-stage timing is opt-in: only the whole step and the solve stage are timed by default
+    # timing is opt-in: nothing by default; level 2 = the whole step and the solve stage; level 1 = every stage
+    t = g.stage_times()
+    assert t["total"] == 0 and t["solve"] == 0
+    g.set_stage_timing(2)
+    g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
     t = g.stage_times()
     assert t["total"] > 0 and t["solve"] > 0 and t["broadphase"] == 0
-    g.set_stage_timing(True)
+    g.set_stage_timing(1)
     g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
     t = g.stage_times()
     assert t["broadphase"] > 0 and t["narrowphase"] > 0 and abs(t["total"] - sum(v for k, v in t.items() if k != "total")) < 0.2 * t["total"]

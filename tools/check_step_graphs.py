@@ -20,6 +20,7 @@ for name, make, steps in (("spheres", lambda: scenes.sphere_drop(10), 260), ("bo
     if outer is None: del os.environ["MI_GRAPH"]
     else: os.environ["MI_GRAPH"] = outer
     s = sc.settings()
+    a.set_stage_timing(2); b.set_stage_timing(2)      # the whole step and the solve stage timed (recorded events inside a graph): they must survive a replay
     first_bad = None
     for i in range(steps):
         a.step_fixed(s, sc.dt, 1); b.step_fixed(s, sc.dt, 1)
