@@ -175,6 +175,7 @@ struct mi_world {
         // exact seam (include/mi_shard.h): per-sweep hand-over of the owners' velocities of the shared bodies
         bool exact = false; mi_shard_sweep_fn sweepFn = nullptr; void* sweepUser = nullptr;
         DBuf<float> sweepSend[8], sweepRecv[8], sweepImport; DBuf<uint32_t> sweepList[8], sweepCount;
+        uint64_t sweepExchanges = 0;
         uint32_t sweepsDone = 0; uint32_t sweepCounts[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // records per neighbour message of this step (the lists are built once per step)
         size_t sweepFloats() const { return (size_t)(capacity + 1u) * kSweepRecordFloats; }
     } shard;
@@ -2563,6 +2564,7 @@ int mi_world::shardSweepExchange(uint32_t sweep) {
         send.p[k] = sh.sweepSend[k].p; recv.p[k] = sh.sweepRecv[k].p; lists.p[k] = sh.sweepList[k].p;
     }
     if (sh.sp.numPeers) k_seam_sweep_pack<<<dim3(divUp(sh.capacity, 256), sh.sp.numPeers), 256, 0, st>>>(lists, sh.sweepCount.p, sh.capacity, gVel.p, send);
+    ++sh.sweepExchanges;
     if (sh.sweepsDone++ == 0u && sh.sp.numPeers) {   // once per step: did the lists fit?  (the step is synchronous in this mode anyway)
         uint32_t* counts = sh.sweepCounts;
         HIP_TRY(hipMemcpyAsync(counts, sh.sweepCount.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
@@ -2933,7 +2935,9 @@ MI_API int mi_world_shard_exchange_stats(mi_world* w, mi_shard_exchange_stats* o
         HIP_TRY(hipMemcpy(act.data(), sh.active.p, nb, hipMemcpyDeviceToHost));
         for (uint8_t a : act) { out->owned_bodies += a == 1u; out->ghost_bodies += a == 2u; }
     }
-    if (reset) { sh.exchangesTimed = 0; sh.exchangeMsSum = 0.0; for (uint64_t& v : sh.sentSum) v = 0; }
+    out->sweep_exchanges = sh.sweepExchanges; out->sweep_message_bytes = sh.exact ? (uint64_t)sh.sweepFloats() * sizeof(float) : 0ull;
+    for (uint32_t k = 0; k < sh.sp.numPeers; ++k) out->sweep_records_last[k] = sh.exact ? sh.sweepCounts[k] : 0u;
+    if (reset) { sh.exchangesTimed = 0; sh.exchangeMsSum = 0.0; for (uint64_t& v : sh.sentSum) v = 0; sh.sweepExchanges = 0; }
     return rc;
 }
 

@@ -100,6 +100,9 @@ typedef struct mi_shard_exchange_stats {
     uint32_t num_neighbours, library_transport;
     uint32_t neighbour_rank[8], records_last[8]; uint64_t records_sum[8];   /* per neighbour slot: records (56 B) packed in the last exchange / since the last reset */
     uint32_t owned_bodies, ghost_bodies;  /* of the last internal step */
+    uint64_t sweep_exchanges;             /* exact seam: hand-overs after a sweep since the last reset (iterations per internal step each) */
+    uint64_t sweep_message_bytes;         /* ... one sweep message as the library transport sends it (fixed size) */
+    uint32_t sweep_records_last[8];       /* ... records (32 B) per neighbour message of the last internal step */
 } mi_shard_exchange_stats;
 MI_API int mi_world_shard_exchange_stats(mi_world* world, mi_shard_exchange_stats* out, uint32_t reset);
 
