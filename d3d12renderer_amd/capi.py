@@ -359,7 +359,17 @@ class World:
 
     def step_fixed(self, settings, dt, n=1):
         """n x physicsStepInternal — src/physics/physics.cpp:1180."""
-        self.L.check(self.L.fn("world_step_fixed")(self.h, C.byref(settings), C.c_float(dt), C.c_uint32(n)), "world_step_fixed")
+        # the hot call of every stepping loop: bound once, arguments converted once per (settings, dt, n) — the generic path costs ~6 us of Python per call, which
+        # a loop that steps a 1 ms world one step per call pays as idle GPU between two steps
+        key = (id(settings), dt, n)
+        if getattr(self, "_step_key", None) != key:
+            f = self.L.fn("world_step_fixed")
+            self._step_call = (f, self.h, C.byref(settings), C.c_float(dt), C.c_uint32(n), settings)   # (settings kept alive)
+            self._step_key = key
+        f, h, ps, cdt, cn, _ = self._step_call
+        rc = f(h, ps, cdt, cn)
+        if rc != MI_OK:
+            self.L.check(rc, "world_step_fixed")
 
     def step_profiled(self, settings, dt):
         """One internal step with per-launch HIP events around the dominant kernel -> (launches, kernel_ms, contact_updates)."""
