@@ -171,6 +171,15 @@ def step_algorithmic_bytes(c, iterations):
 
 
 def timed_region(sw, settings, dt, steps, barrier):
+    import gc
+    gc.collect(); gc.disable()          # a generation-2 collection of the interpreter inside a 20 ms window is a 10 % outlier; nothing is allocated in the loop but floats
+    try:
+        return _timed_region(sw, settings, dt, steps, barrier)
+    finally:
+        gc.enable()
+
+
+def _timed_region(sw, settings, dt, steps, barrier):
     barrier()
     t0 = time.perf_counter()
     step_ms = []
