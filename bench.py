@@ -416,6 +416,8 @@ def main():
             "step_modes_timed": {"internal_steps": mode1[0] - mode0[0], "speculative": mode1[1] - mode0[1], "synchronous_reruns": mode1[2] - mode0[2],
                                  "note": "a speculative step sizes its launches from the previous step and reads back once; one whose bounds did not hold is re-run synchronously (counted here, timed like any step)"},
             "device_ms_per_step": total_dev_ms / args.steps,
+            "solver_kind": sw.world.solver_kind(),
+            "block_solver": sw.world.block_stats() if sw.world.solver_kind() == 6 else None,
         }
         if per_rank is not None:
             out["per_rank"] = per_rank

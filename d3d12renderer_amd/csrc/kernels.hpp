@@ -34,6 +34,17 @@ struct GridParams {   // written by k_bp_grid_setup, read by the broad-phase ker
     uint32_t pad;
 };
 
+struct BlockState {   // per-step words of the block path (device memory; the launches carry the same arguments every step: step graphs)
+    uint32_t stamp;        // launch stamp of the mailbox tags (k_block_sched increments it)
+    uint32_t need;         // largest list (entries) any block wanted this step
+    uint32_t needExtra;    // largest number of foreign boundary entries any block was sent
+    uint32_t needBodies;   // largest number of home bodies any block held
+    uint32_t needPasses;   // largest number of passes any wave ran per sweep
+    uint32_t needImp;      // largest number of accumulated impulses (contacts) any wave held
+    uint32_t overflow;     // 1: a capacity of the block path was exceeded (the step is void)
+    uint32_t ghostLanes;   // statistics: boundary entries of this step (both copies)
+};
+
 struct StepScalars {  // device-resident per-step scalars
     double extentSum;
     int boundsMin[3];     // ordered-int encoded floats
@@ -73,6 +84,7 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t shardSent[8];         // sharded world: records packed for each neighbour this step (slot order of ShardParams::peers)
     uint32_t seamStats[3];         // exact seam (include/mi_shard.h): manifolds of the seam class, colours they use, violations of this step (k_seam_stats)
     unsigned long long axisSums[9]; // centre statistics of the colliders this world counts (k_pair_finish): S1[3], S2lo[3], S2hi[3]; a sharded world's are added over the ranks
+    BlockState blk;                 // spatial blocks in LDS (blocks.hpp)
 };
 
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
@@ -1349,7 +1361,8 @@ __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float
                                                               const uint8_t* __restrict__ bodyActive /* sharded world (1 = owned), or null */, const float4* __restrict__ bPosIn,
                                                               const float4* __restrict__ bLinVelIn, const float4* __restrict__ bAngVelIn, const float4* __restrict__ bForceIn,
                                                               const float4* __restrict__ bTorqueIn,
-                                                              const uint8_t* __restrict__ bodyActivePrev /* the previous step's flags */, const Shards* __restrict__ sh, StepScalars* sc) {
+                                                              const uint8_t* __restrict__ bodyActivePrev /* the previous step's flags */, const Shards* __restrict__ sh, StepScalars* sc,
+                                                              unsigned long long* __restrict__ bndMask /* block solver: per-body boundary colours, cleared like bodyUsed; or null */) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (bodyActive && blockIdx.x == 0 && threadIdx.x < 3) {   // sharded world: this rank's owned bodies / manifolds / contacts, from the per-line counters
         uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].owned[threadIdx.x];
@@ -1361,6 +1374,7 @@ __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float
     if (idle) return;
     // the per-body colouring scratch of the NEXT step starts out cleared (saves two memset launches per step); launched over nb + 1
     bodyUsed[i] = 0ull; bodyTop[i] = 0ull; bodyTop[(size_t)nb + 1u + i] = 0ull;
+    if (bndMask) bndMask[i] = 0ull;
     if (i == nb) return;
     if (bodyActive && bodyActive[i] != 1u) {   // sharded world: only the OWNER advances a body; ghosts and bodies elsewhere keep their state (the owner's arrives by exchange)
         bPos[i] = bPosIn[i]; bRot[i] = bRotIn[i]; bLinVel[i] = bLinVelIn[i]; bAngVel[i] = bAngVelIn[i]; bForce[i] = bForceIn[i]; bTorque[i] = bTorqueIn[i];
@@ -1836,6 +1850,25 @@ struct IslandPrivate {
     uint4* entries;               // [islands][kIslandMaxContacts]: (slot, first contact-tile, colour | contacts << 8, -)
 };
 __device__ __forceinline__ bool islandIsPrivate(const IslandPrivate& ip, uint32_t island) { return ip.shared[island] == 0u && ip.count[island] <= kIslandMaxContacts; }
+// Spatial blocks in LDS (blocks.hpp): what the schedule and k_contact_init share with the block solver.
+constexpr uint32_t kMailRanks = 8;            // mailbox slots per body = boundary manifolds on one body (more: the step falls back)
+constexpr uint32_t kOrderMask = 0x3FFFFFFFu;  // block mode: order[slot] = manifold | boundary << 30 | home-is-B << 31
+// block-mode slot word: contacts [0:3] | colour [3:9] | boundary [9] | home-is-B [10] | export A: on [11] same sweep [12] rank [13:16] | export B [16] [17] [18:21] | ghost rank [21:24]
+__device__ __forceinline__ uint32_t blockMetaW(uint32_t cnt, uint32_t colour, bool bnd, bool homeB, uint32_t expA, uint32_t expB, uint32_t ghostRank) {
+    return cnt | (colour << 3) | (bnd ? 1u << 9 : 0u) | (homeB ? 1u << 10 : 0u) | (expA << 11) | (expB << 16) | (ghostRank << 21);
+}
+// export word of a home body (5 bits): on | same sweep << 1 | rank << 2.  A home body is exported right after the update that precedes a boundary manifold on it
+// (cyclically in colour order: the body's own colour again if it has one manifold) into that manifold's mailbox slot = its rank among the body's boundary colours.
+__device__ __forceinline__ uint32_t blockExportBits(unsigned long long used, unsigned long long bm, uint32_t c, bool& rankOverflow) {
+    if (!bm) return 0u;
+    const unsigned long long above = c >= 63u ? 0ull : used & ~((2ull << c) - 1ull);
+    const bool same = above != 0ull;
+    const uint32_t cn = (uint32_t)__ffsll((long long)(same ? above : used)) - 1u;
+    if (!((bm >> cn) & 1ull)) return 0u;
+    const uint32_t rank = (uint32_t)__popcll(bm & ((1ull << cn) - 1ull));
+    if (rank >= kMailRanks) { rankOverflow = true; return 0u; }
+    return 1u | (same ? 2u : 0u) | (rank << 2);
+}
 // K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379): one wave per tile, one lane per slot.
 __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restrict__ sc, uint32_t dummyBody, float dt, const uint4* __restrict__ tileInfo /* k_fill_tiles: per tile, or (XCD-partitioned) per entry of the XCD tile lists */,
                                                      const uint32_t* __restrict__ order,
@@ -1849,7 +1882,8 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
                                                      float4* __restrict__ slotNormal, float2* __restrict__ slotMass,
                                                      uint8_t* __restrict__ bodyOwner /* XCD-partitioned solver: [body][8] flags, 1 = a tile of that XCD touches the body; or null */,
                                                      uint32_t listCap /* with bodyOwner: workgroup b prepares entry b / 8 of XCD (b % 8)'s tile list */, uint32_t infoCap,
-                                                     IslandPrivate ip /* bodyIsland non-null: manifolds of private islands are handed to their island's workgroup, invalid for the tile solver */) {
+                                                     IslandPrivate ip /* bodyIsland non-null: manifolds of private islands are handed to their island's workgroup, invalid for the tile solver */,
+                                                     const unsigned long long* __restrict__ bndMask /* block mode (blocks.hpp): per body, the colours of its boundary manifolds; or null */, BlockState* bs) {
     // Measured and not kept: one wave per contact index (four waves per tile, the per-manifold gathers repeated): 52 -> 73 us; 5 or 6 waves per
     // SIMD instead of 4 by capping the registers (96 / 80 VGPRs, 96 / 164 bytes of scratch): 66 -> 84 / 94 us.  Everything the kernel needs of
     // its tile comes in ONE 16-byte entry (k_fill_tiles; was list -> tile -> bin -> bin info): no faster either — the kernel moves ~390 MB
@@ -1872,7 +1906,8 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
         }
         return;
     }
-    uint32_t m = order[te.y + lane];
+    const uint32_t ord = order[te.y + lane];
+    uint32_t m = bndMask ? ord & kOrderMask : ord;
     uint32_t p = manPair[m];
     uint2 bodies = manBodies[m];
     uint2 info = manInfo[m];
@@ -1901,8 +1936,23 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
             if (at < kIslandMaxContacts) ip.entries[(size_t)isl * kIslandMaxContacts + at] = make_uint4(tile * 64u + lane, (uint32_t)ctBase, color[m] | (cnt << 8), m);
         }
     }
+    uint32_t metaW = priv ? 0u : cnt;   // (.w = 0: not a slot of the tile solver)
+    if (bndMask) {   // block mode: colour, boundary flags, and which home body is exported after this manifold's update (blocks.hpp)
+        const uint32_t c = color[m];
+        const bool bnd = (ord >> 30) & 1u, homeB = (ord >> 31) != 0u;
+        const bool ghostA = bnd && homeB, ghostB = bnd && !homeB;
+        bool over = c >= kOverflowColor;
+        uint32_t expA = 0u, expB = 0u, gRank = 0u;
+        if (!over) {
+            if (imA != 0.f && !ghostA) expA = blockExportBits(bodyUsed[bodies.x], bndMask[bodies.x], c, over);
+            if (imB != 0.f && !ghostB) expB = blockExportBits(bodyUsed[bodies.y], bndMask[bodies.y], c, over);
+            if (bnd) { gRank = (uint32_t)__popcll(bndMask[ghostA ? bodies.x : bodies.y] & ((1ull << c) - 1ull)); if (gRank >= kMailRanks) { over = true; gRank = 0u; } }
+        }
+        if (over) { bs->overflow = 1u; const_cast<StepScalars*>(sc)->specOverflow = 1u; }
+        metaW = blockMetaW(cnt, c & 63u, bnd, homeB, expA, expB, gRank);
+    }
     if (kw == 0) {
-        slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, packed, priv ? 0u : cnt);   // (.w = 0: not a slot of the tile solver)
+        slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, packed, metaW);
         slotMass[(size_t)tile * 64u + lane] = make_float2(imA, imB);
     }
     if (bodyOwner && kw == 0) {   // one byte per (body, XCD): plain idempotent stores, no atomics

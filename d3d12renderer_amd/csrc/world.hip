@@ -24,6 +24,7 @@
 #include <dlfcn.h>
 #include "../../include/mi_constraints.h"
 #include "kernels.hpp"
+#include "blocks.hpp"
 #include "gjk.hpp"
 #include "launcher.hpp"
 #include "joints.hpp"
@@ -206,6 +207,12 @@ struct mi_world {
     // XCD-partitioned persistent solver: cached velocity copy for XCD-local bodies, per-body XCD set, spatial sort of the manifolds, per-XCD tile lists
     DBuf<float4> gVelL; DBuf<unsigned long long> bodyOwner; DBuf<uint32_t> sortKeys[2], sortVals[2], xcdBase, xcdTiles, keyCount;
     bool privateIslandsEnabled = true;
+    // spatial blocks in LDS (blocks.hpp): one workgroup per block of the scene, home bodies in LDS, boundary manifolds solved by both neighbours
+    DBuf<uint32_t> blkKeys, blkRanks, blkPerm, blkStart, blkExtra, blkExtraCount; DBuf<uint16_t> blkCell; DBuf<unsigned long long> bndMask; DBuf<float4> mail;
+    bool blockSolver = true, usedBlocks = false, blockFaultTest = false, blockFaultFired = false;
+    struct BlockCaps { uint32_t nbe = 0, tiles = 0, extraCap = 0, bodyCap = 0, hashSize = 0, maxPasses = 0, impCap = 0; size_t lds = 0; } blkCaps;   // sticky: the same launches step after step (step graphs)
+    BlockState lastBlk{}; bool haveBlkEstimate = false; uint32_t blkFailures = 0, blkDisabledSteps = 0, blkLaunches = 0, blkMaxBlocks = 256, blkSteps = 0;
+    bool planBlocks(uint32_t nmLast, uint32_t nbBodies);
     bool persistXcd = true, persistXcdSingle = true, usedXcd = false, usedXcdSingle = false, lastXcdSingle = false, haveXcdEstimate = false, xcdFaultFired = false, xcdFaultTest = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
     // device: colliders
     DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cEmit;
@@ -383,7 +390,7 @@ int mi_world::init(int dev) {
     };
     gVel.flags = allocFlags("MI_GVEL_ALLOC", hipDeviceMallocUncached);
     imp.flags = allocFlags("MI_IMP_ALLOC", 0u);
-    { const char* sv = getenv("MI_SOLVER"); persistSolver = !sv || std::string(sv) == "persist" || std::string(sv) == "persist-global";   // default; MI_SOLVER=flow / launch select the other contact solvers
+    { const char* sv = getenv("MI_SOLVER"); persistSolver = !sv || std::string(sv) == "persist" || std::string(sv) == "persist-global" || std::string(sv) == "blocks";   // default; MI_SOLVER=flow / launch select the other contact solvers
       persistImpLds = !sv || std::string(sv) != "persist-granules";   // persist-granules: impulses as tagged granules as well (what the largest piles get automatically)
       if (sv && std::string(sv) == "persist-granules") persistSolver = true;
       persistMetaLds = !sv || (std::string(sv) != "persist-global" && std::string(sv) != "persist-granules");   // persist-global: slot data always from global memory (the variant larger problems get automatically)
@@ -394,6 +401,13 @@ int mi_world::init(int dev) {
       if (const char* pi = getenv("MI_ISLAND_PRIVATE")) privateIslandsEnabled = pi[0] != '0';   // development / tests: every island through the dataflow
       if (const char* px = getenv("MI_PERSIST_XCD_SINGLE")) persistXcdSingle = px[0] != '0';   // 0: small piles on all XCDs, every body through memory
       xcdFaultTest = getenv("MI_PERSIST_XCD_FAULT") != nullptr;
+      blockSolver = !sv || std::string(sv) == "blocks";   // default; any other MI_SOLVER value keeps the block path off
+      if (const char* bb = getenv("MI_BLOCKS")) blockSolver = blockSolver && bb[0] != '0';
+      blockFaultTest = getenv("MI_BLOCK_FAULT") != nullptr;
+      blkMaxBlocks = std::max(1u, persistWaves / kBlockWaves);
+      if (const char* bn = getenv("MI_BLOCKS_MAX")) blkMaxBlocks = std::max(1u, (uint32_t)strtoul(bn, nullptr, 0));
+      mail.flags = hipDeviceMallocUncached;
+      (void)hipFuncSetAttribute((const void*)k_contact_solve_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
       flowFaultTest = getenv("MI_FLOW_FAULT") != nullptr;
       if (const char* pm = getenv("MI_PERSIST_XCD_MIN")) xcdMinManifolds = (uint32_t)strtoul(pm, nullptr, 0); }   // smallest manifold count that is partitioned (tests: 1)   // MI_PERSIST_XCD=0: no XCD partitioning (every body through memory)   // development experiment: one XCD's workgroups do all the work
     if (flowLds > 65536) (void)hipFuncSetAttribute((const void*)k_contact_solve_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flowLds);
@@ -574,6 +588,7 @@ int mi_world::upload() {
     HIP_TRY(bodyTop.ensure(2 * ((size_t)nb + 1))); HIP_TRY(bodyUsed.ensure(nb + 1));
     HIP_TRY(hipMemsetAsync(bodyTop.p, 0, 2 * ((size_t)nb + 1) * sizeof(unsigned long long), stream));   // from here on k_integrate_velocities leaves both cleared for the next step
     HIP_TRY(hipMemsetAsync(bodyUsed.p, 0, ((size_t)nb + 1) * sizeof(unsigned long long), stream));
+    HIP_TRY(bndMask.ensure(nb + 1)); HIP_TRY(hipMemsetAsync(bndMask.p, 0, ((size_t)nb + 1) * sizeof(unsigned long long), stream));   // (k_integrate_velocities leaves it cleared)
     HIP_TRY(gVelL.ensure(2 * ((size_t)nb + 1))); HIP_TRY(bodyOwner.ensure(nb + 1)); HIP_TRY(xcdBase.ensure(kSchedBins * 8)); HIP_TRY(keyCount.ensure(kSpatialKeys));
 
     usesGjk = false;
@@ -818,6 +833,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     }
     if (rc == STEP_RETRY) return fail(MI_ERR_DEVICE, "step could not be completed on any solver path");
     if (rc == MI_OK && launchFallbackSteps) --launchFallbackSteps;
+    if (rc == MI_OK && blkDisabledSteps) --blkDisabledSteps;
     debugOrderPending = false; debugOrder.clear();   // (one step only, whatever became of it)
     if (rc == MI_OK && shard.enabled) rc = shardExchange();
     if (rc == MI_OK && !cloths.empty()) rc = stepCloths(dt);   // after the rigid bodies (physics.cpp:1352-1358); once per VALID step: cloth state is updated in place
@@ -1155,7 +1171,10 @@ enqueue_section:
     bool shardCounted = false;   // sharded world: this rank's manifolds / contacts are counted inside k_manifold_keys when that runs, else by k_shard_count
     // XCD partitioning pays once the pile is big enough to keep eight L2s busy; it needs the persistent kernel (no joints)
     const bool exactSeamStep = shard.enabled && shard.exact;   // every sweep ends in an exchange with the neighbours: one launch per sweep (the generic dataflow path), nothing persistent
-    const bool xcdAble = flowSolver && persistSolver && persistXcd && !xcdOnly && joints.count() == 0 && (persistWaves & 7u) == 0u && !debugOrderPending && !exactSeamStep;
+    // spatial blocks in LDS (blocks.hpp): speculative steps of a contact-only, unsharded world; sized from the previous block step (planBlocks); any other step takes the classic schedule
+    const bool blockPlan = spec && flowSolver && blockSolver && !blkDisabledSteps && joints.count() == 0 && !xcdOnly && !debugOrderPending && !exactSeamStep && !shard.enabled && !seamOn &&
+                           !launchFallbackSteps && nmBound && planBlocks(last.numManifolds, nb);
+    const bool xcdAble = !blockPlan && flowSolver && persistSolver && persistXcd && !xcdOnly && joints.count() == 0 && (persistWaves & 7u) == 0u && !debugOrderPending && !exactSeamStep;
     // small piles: the 128 waves of ONE XCD run the whole solve, every body hand-over goes through that XCD's L2 (tileOwner(..., single))
     const bool xcdSingle = xcdAble && persistXcdSingle && nmBound && nmBound < xcdMinManifolds && divUp(divUp(nmBound, 64) + kSchedBins + 8, persistWaves / 8u) <= 16u;
     const bool xcdPlan = xcdAble && (nmBound >= xcdMinManifolds || xcdSingle);
@@ -1166,10 +1185,25 @@ enqueue_section:
                                                   : std::min<uint32_t>(96u, last.colorRounds + std::max(colorMargin, last.colorRounds / 4u));
     if (nmBound) {
         tilesCap = divUp(nmBound, 64) + kSchedBins + 8; ctCap = divUp(conBound, 64) + 4 * kSchedBins + 8;
+        if (blockPlan) { tilesCap = blkCaps.nbe * blkCaps.tiles; ctCap = tilesCap * 4u; }   // every block owns `tiles` tiles of 4 contact-tiles, dense from its first one
         const uint32_t binBlocks = divUp(nmBound, kBinItems);
-        HIP_TRY(order.ensure((size_t)binBlocks * kBinItems)); HIP_TRY(orderTmp.ensure((size_t)binBlocks * kBinItems));
+        HIP_TRY(order.ensure(std::max((size_t)binBlocks * kBinItems, (size_t)tilesCap * 64u))); HIP_TRY(orderTmp.ensure((size_t)binBlocks * kBinItems));
         HIP_TRY(blockHist.ensure((size_t)kColorBins * binBlocks)); HIP_TRY(blockScan.ensure((size_t)kColorBins * binBlocks));
         HIP_TRY(tileInfo.ensure(tilesCap)); HIP_TRY(tileDesc.ensure(tilesCap));
+        if (blockPlan) {   // cells -> blocks, the manifolds in cell order, boundary manifolds into the neighbour's list (blocks.hpp)
+            const BlockCaps& bc = blkCaps;
+            HIP_TRY(blkKeys.ensure(nmBound)); HIP_TRY(blkRanks.ensure(nmBound)); HIP_TRY(blkPerm.ensure(nmBound)); HIP_TRY(blkStart.ensure(bc.nbe + 1u)); HIP_TRY(blkCell.ensure(kBlockCells));
+            HIP_TRY(blkExtra.ensure((size_t)bc.nbe * bc.extraCap)); HIP_TRY(blkExtraCount.ensure(bc.nbe));
+            const size_t mailWords = ((size_t)nb + 1u) * kMailRanks * 4u;
+            if (mail.cap < mailWords || blkLaunches >= 30000u) {   // fresh memory, or the 16-bit launch stamp of the tags is half way round: no record may look current
+                HIP_TRY(mail.ensure(mailWords));
+                HIP_TRY(L.memsetAsync(mail.p, 0xFF, mail.cap * sizeof(float4), st));
+                if (!L.dry) blkLaunches = 0;
+            }
+            if (!L.dry) ++blkLaunches;
+            L.launch(k_block_keys, dim3(divUp(nmBound, kKeyItems)), dim3(256), 0, st, nmBound, sc, grid.p + gridCur, manBodies.p, gPos.p, blkKeys.p, blkRanks.p, keyCount.p, bc.nbe, blkExtraCount.p, &sc->blk);
+            L.launch(k_block_place, dim3(divUp(nmBound, kKeyItems)), dim3(256), 0, st, nmBound, sc, blkKeys.p, blkRanks.p, keyCount.p, blkPerm.p, bc.nbe, blkStart.p, blkCell.p, blkExtra.p, bc.extraCap, blkExtraCount.p);
+        } else
         if (xcdPlan) {   // slots in spatial order inside every bin + per-XCD tile lists (k_contact_solve_persist<.., true>)
             xcdListCap = xcdSingle ? tilesCap + kSchedBins : divUp(tilesCap, 8) + kSchedBins;
             HIP_TRY(sortKeys[0].ensure(nmBound)); for (int k = 0; k < 2; ++k) HIP_TRY(sortVals[k].ensure(nmBound));
@@ -1189,6 +1223,12 @@ enqueue_section:
         while (true) {
             for (uint32_t r = 0; r < colorBatch; ++r, ++round)
                 L.launch(k_color_round, dim3(divUp(nmBound, B)), dim3(B), 0, st, sc, round, colWork.p, color.p, top[round & 1], top[(round + 1) & 1], bodyUsed.p, roundFlagsPtr(), seamOn ? 1u : 0u);
+            if (blockPlan) {   // every block sorts its own list into dense tiles: no global bins, no scan (k_block_sched)
+                const int ntab = tabCur ^ 1;
+                L.launch(k_block_sched, dim3(blkCaps.nbe), dim3(256), 0, st, round - 1, roundFlagsPtr(), blkPerm.p, blkKeys.p, blkStart.p, blkCell.p, blkExtra.p, blkCaps.extraCap, blkExtraCount.p, blkCaps.tiles,
+                         color.p, manInfo.p, colWork.p, order.p, tileInfo.p, tileDesc.p, bndMask.p, sc, &sc->blk, nc, manPair.p, pairKeys.p, pairKeysS.p, tab[ntab].p, tabMask[ntab], manKept.p);
+                break;   // (speculative steps only)
+            }
             // schedule bins -> tiles (valid once the last round left nothing uncoloured: StepScalars::colorPending)
             L.launch(k_bin_hist, dim3(binBlocks), dim3(256), 0, st, sc, binBlocks, perm, color.p, manInfo.p, blockHist.p);
             HIP_TRY(scanBins.run(L, blockHist.p, blockScan.p, kColorBins * binBlocks, st));
@@ -1250,11 +1290,12 @@ enqueue_section:
         return divUp(std::max(longest, 1u), persistWaves / 8u);
     };
     // the persistent kernel keeps the accumulated impulses in LDS while they fit: k_contact_init then need not write the impulse granules
-    const bool persistPlan = !fused && useFlow && persistSolver && joints.count() == 0 && tilesLaunch && !exactSeamStep;
+    const bool blocksRun = blockPlan && useFlow && !fused && tilesLaunch;
+    const bool persistPlan = !blocksRun && !fused && useFlow && persistSolver && joints.count() == 0 && tilesLaunch && !exactSeamStep;
     const uint32_t persistMaxSlots = persistPlan ? persistSlots(tilesLaunch, xcdPlan, spec) : 0u;
     const bool privateIslands = fused && privateIslandsEnabled && !shard.enabled && joints.dBodyIsland && nmBound && tilesLaunch;
     const IslandPrivate islandPriv = privateIslands ? joints.islandPrivate() : IslandPrivate{nullptr, nullptr, nullptr, nullptr, nullptr};
-    const bool impNeeded = !(persistPlan && persistImpLds && persistMaxSlots * (4u * 512u + 20u) <= 38u * 1024u);
+    const bool impNeeded = !blocksRun && !(persistPlan && persistImpLds && persistMaxSlots * (4u * 512u + 20u) <= 38u * 1024u);
     if (nmBound) {
         HIP_TRY(slotMeta.ensure((size_t)tilesCap * 64)); HIP_TRY(slotNormal.ensure((size_t)tilesCap * 64)); HIP_TRY(slotMass.ensure((size_t)tilesCap * 64));
         HIP_TRY(rows.ensure((size_t)ctCap * kRows * 64)); HIP_TRY(imp.ensure((size_t)ctCap * 64));
@@ -1265,16 +1306,17 @@ enqueue_section:
         if (tilesLaunch)
             L.launch(k_contact_init, dim3(xcdPlan ? 8u * xcdListCap : tilesLaunch), dim3(64), 0, st, sc, nb, dt, xcdPlan ? xcdInfo.p : tileInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
                                                       gPos.p, gInvI.p, xcdPlan ? gVelL.p : gVel.p /* same content here; the cached copy */, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, impNeeded ? imp.p : nullptr, slotMeta.p, slotNormal.p, slotMass.p,
-                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, xcdListCap, xcdPlan ? 8u * xcdListCap : tilesCap, islandPriv);
+                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, xcdListCap, xcdPlan ? 8u * xcdListCap : tilesCap, islandPriv,
+                                                      blocksRun ? bndMask.p : nullptr, &sc->blk);
     }
     int rc = joints.initialize(*this, dt, st);   // (through L)
     if (rc != MI_OK) return rc;
     mark();  // 6
     bool solveAttached = false;
-    const bool willPersist = !fused && persistPlan && persistMaxSlots * 20u <= 38u * 1024u;
+    const bool willPersist = blocksRun || (!fused && persistPlan && persistMaxSlots * 20u <= 38u * 1024u);
     if (attached && !willPersist) (void)hipEventRecord(ev[6], st);   // another solver path (several launches): classic recorded events
     const uint32_t iters = settings.num_rigid_solver_iterations;
-    usedFlow = useFlow; usedPersist = false; usedFused = fused; usedXcd = false; usedXcdSingle = false;
+    usedFlow = useFlow; usedPersist = false; usedFused = fused; usedXcd = false; usedXcdSingle = false; usedBlocks = false;
     uint64_t mainContacts = 0;
     if (fused) {
         // contacts and joint islands of every sweep in one launch (k_solve_flow_islands)
@@ -1294,6 +1336,25 @@ enqueue_section:
                                                                                    tileDesc.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, imp.p, sc, islandPriv, iters);
             if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
         }
+    } else if (blocksRun) {
+        // one workgroup per spatial block: home bodies, slot constants and impulses in LDS, boundary manifolds solved on both sides (k_contact_solve_blocks)
+        const BlockCaps& bc = blkCaps;
+        solveLaunches = 1; usedBlocks = true;
+        if (profileSolve) {
+            size_t e = 2 * (size_t)profLaunches;
+            while (profEvents.size() < e + 2) { hipEvent_t ev_; HIP_TRY(hipEventCreate(&ev_)); profEvents.push_back(ev_); }
+            (void)hipEventRecord(profEvents[e], st);
+        }
+        const uint32_t fault = blockFaultTest && !blockFaultFired ? 1u : 0u;   // tests: one block gives up once
+        if (fault && !L.dry) blockFaultFired = true;
+        const uint32_t maxSlots = divUp(bc.tiles, kBlockWaves);
+        hipEvent_t e6 = attached && (stepEventsMode || stageEvents) ? ev[6] : nullptr, e7 = attached && (stepEventsMode || stageEvents) ? ev[7] : nullptr;
+        solveAttached = attached;
+#define MI_BLOCK_ARGS iters, bc.tiles, bc.hashSize, bc.bodyCap, maxSlots, bc.maxPasses, bc.impCap, tileInfo.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, gVelL.p, mail.p, sc, &sc->blk, fault
+        if (attached) hipExtLaunchKernelGGL(k_contact_solve_blocks, dim3(bc.nbe), dim3(kBlockWaves * 64), (uint32_t)bc.lds, st, e6, e7, 0, MI_BLOCK_ARGS);
+        else L.launch(k_contact_solve_blocks, dim3(bc.nbe), dim3(kBlockWaves * 64), bc.lds, st, MI_BLOCK_ARGS);
+#undef MI_BLOCK_ARGS
+        if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
     } else if (persistPlan && persistMaxSlots * 20u <= 38u * 1024u) {
         // persistent waves: one workgroup per SIMD owns its tiles through all sweeps, impulses (and, while they fit, the constant slot data) in LDS (k_contact_solve_persist)
         const uint32_t maxSlots = persistMaxSlots;
@@ -1386,12 +1447,12 @@ enqueue_section:
     if (shard.enabled && pairBound && !shardCounted) L.launch(k_shard_count, dim3(divUp(nmBound ? nmBound : 1u, B)), dim3(B), 0, st, nb, manBodies.p, manInfo.p, bCogInvMass.p, shard.active.p, sc, shards.p);
     mark();  // 7
     if (attached && !solveAttached) (void)hipEventRecord(ev[7], st);
-    if (attached && (stepEventsMode == 2 || stageEvents)) hipExtLaunchKernelGGL(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nullptr, ev[8], 0, nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
+    if (attached && (stepEventsMode == 2 || stageEvents)) hipExtLaunchKernelGGL(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nullptr, ev[8], 0, nb, dt, gPos.p, usedBlocks ? gVelL.p : gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
                                       gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p,
-                                      shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p, shard.activePrev.p, shards.p, sc);
-    else L.launch(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nb, dt, gPos.p, gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
+                                      shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p, shard.activePrev.p, shards.p, sc, bndMask.p);
+    else L.launch(k_integrate_velocities, dim3(divUp(nb + 1, B)), dim3(B), 0, st, nb, dt, gPos.p, usedBlocks ? gVelL.p : gVel.p, bCogInvMass.p, bRot.p, bPosN.p, bRotN.p, bLinVelN.p, bAngVelN.p, bForceN.p, bTorqueN.p,
                                                       gVelL.p, usedXcd ? bodyOwner.p : nullptr, bodyUsed.p, bodyTop.p,
-                                                      shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p, shard.activePrev.p, shards.p, sc);
+                                                      shard.enabled ? shard.active.p : nullptr, bPos.p, bLinVel.p, bAngVel.p, bForce.p, bTorque.p, shard.activePrev.p, shards.p, sc, bndMask.p);
     mark();  // 8
     // ---------------------------------------------------------------------------------------------- end of step: the one read-back
     {
@@ -1454,6 +1515,19 @@ enqueue_section:
     hs = hsPinned->sc;
     const uint32_t* flagsHost = hsPinned->flags;
     HIP_TRY(hipGetLastError());
+    if (blockPlan) {   // the blocks wrote COUNTS per (colour, contacts) bin: the prefix the host mirrors; and what the next block step is sized from
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < kColorBins; ++b) { const uint32_t c = hs.binStart[b]; hs.binStart[b] = run; run += c; }
+        hs.binStart[kColorBins] = run;
+        lastBlk = hs.blk; haveBlkEstimate = true; ++blkSteps;
+        const bool failed = hs.blk.overflow != 0u || (usedBlocks && hs.solveError != 0u);
+        if (failed) {
+            if (usedBlocks && hs.solveError == 1u) blkDisabledSteps = 256u;          // a wait ran out of budget (shared device, or the test injection): the classic path for a while
+            else if (++blkFailures >= 3u) { blkDisabledSteps = 512u; blkFailures = 0u; }   // capacities that do not settle
+            return STEP_RETRY;   // nothing persistent has been written: the synchronous re-run takes the classic schedule
+        }
+        blkFailures = 0u;
+    }
     if (spec) {
         const uint32_t ovfCount = hs.binStart[kColorBins] - hs.binStart[kSchedBins - 1];
         const bool valid = hs.numPairs <= pairBound && hs.numManifolds <= nmBound && hs.specOverflow == 0 && hs.colorPending == 0 && ovfCount == 0 &&
@@ -1672,6 +1746,43 @@ MI_API int mi_debug_set_solve_order(mi_world* w, const uint32_t* pairs, uint32_t
     w->debugOrderPending = true;
     return MI_OK;
 }
+}
+
+// Sizes of the next block step (blocks.hpp): blocks, tiles per block, LDS carve-up — from what the previous block step needed (BlockState), with slack, and STICKY:
+// the numbers only move when a need outgrows them or falls far below, so consecutive steps enqueue identical launches (step graphs).  false: the scene does not fit the
+// block path (more than 64 tiles or 160 KiB of LDS per block), the step takes the classic schedule.
+bool mi_world::planBlocks(uint32_t nmLast, uint32_t nbBodies) {
+    if (!nmLast) return false;
+    BlockCaps c = blkCaps;
+    const uint32_t per = c.nbe ? nmLast / c.nbe : 0u;
+    if (!c.nbe || c.nbe > blkMaxBlocks || per < 160u || (per > 640u && c.nbe < blkMaxBlocks)) {
+        const uint32_t nbe = std::min(blkMaxBlocks, std::max(1u, nmLast / 320u));
+        if (nbe != c.nbe) { c = BlockCaps{}; c.nbe = nbe; haveBlkEstimate = false; }
+    }
+    const uint32_t perBlock = divUp(nmLast, c.nbe);
+    auto sticky = [](uint32_t cap, uint32_t need, uint32_t slack, uint32_t quantum) {
+        if (cap >= need + slack / 2u && cap <= 2u * need + 2u * slack) return cap;
+        const uint32_t want = need + need / 8u + slack;
+        return (want + quantum - 1u) / quantum * quantum;
+    };
+    const bool have = haveBlkEstimate;
+    const uint32_t needEntries = have && lastBlk.need ? lastBlk.need : perBlock + perBlock / 4u + 32u;
+    c.tiles = sticky(c.tiles * 64u, needEntries, 64u, 64u) / 64u;
+    if (c.tiles > 16u * kBlockWaves) return false;
+    const uint32_t maxSlots = divUp(c.tiles, kBlockWaves);
+    c.extraCap = sticky(c.extraCap, have ? lastBlk.needExtra : std::max(32u, perBlock / 6u), 32u, 32u);
+    c.bodyCap = sticky(c.bodyCap, have && lastBlk.needBodies ? lastBlk.needBodies : std::min(nbBodies + 1u, nbBodies / c.nbe * 3u / 2u + 64u), 64u, 64u);
+    if (c.bodyCap > 16384u) return false;
+    c.hashSize = 256u; while (c.hashSize < 2u * c.bodyCap) c.hashSize <<= 1;
+    c.maxPasses = sticky(c.maxPasses, have && lastBlk.needPasses ? lastBlk.needPasses : maxSlots * 3u + 16u, 8u, 8u);
+    c.impCap = std::min(maxSlots * 256u, sticky(c.impCap, have && lastBlk.needImp ? lastBlk.needImp : (perBlock * 4u) / kBlockWaves + 128u, 64u, 64u));
+    const size_t recBytes = ((size_t)c.bodyCap * 36u + 15u) & ~(size_t)15u;
+    const size_t uniBytes = (std::max((size_t)c.hashSize * 6u, (size_t)kBlockWaves * c.impCap * 8u) + 15u) & ~(size_t)15u;   // hash during set-up, impulses afterwards
+    const size_t waveBytes = ((size_t)maxSlots * 64u * 16u + (size_t)c.maxPasses * 16u + (size_t)maxSlots * 64u * 2u + 15u) & ~(size_t)15u;
+    c.lds = recBytes + uniBytes + kBlockWaves * waveBytes;
+    if (c.lds > 160u * 1024u - 64u) return false;
+    blkCaps = c;
+    return true;
 }
 
 // Host mirror of the device schedule (bins -> tiles), from the binStart table read back in StepScalars.
@@ -3303,15 +3414,25 @@ MI_API int mi_world_get_accumulated_stage_times(mi_world* w, mi_stage_times* out
     return MI_OK;
 }
 // Which contact-solver kernel the last internal step ran: 0 k_contact_solve (one launch per colour per sweep), 1 k_contact_solve_flow,
-// 2 k_contact_solve_persist, 3 k_solve_flow_islands (contacts + joint islands fused), 4 k_contact_solve_persist XCD-partitioned.
+// 2 k_contact_solve_persist, 3 k_solve_flow_islands (contacts + joint islands fused), 4 k_contact_solve_persist XCD-partitioned, 5 the same on one XCD,
+// 6 k_contact_solve_blocks (spatial blocks in LDS).
 MI_API int mi_debug_step_graph_stats(mi_world* w, uint32_t* out4) {
     if (!w || !out4) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     out4[0] = w->graphsEnabled ? 1u : 0u; out4[1] = w->graphHits; out4[2] = w->graphCaptures; out4[3] = w->graphPlain;
     return MI_OK;
 }
+// The block solver's sizes and what the last block step needed (blocks.hpp): out16 = { blocks, tiles per block, extra capacity, body capacity, hash slots, passes per wave,
+// impulses per wave, LDS bytes, entries needed, extras needed, bodies needed, passes needed, impulses needed, boundary entries, block steps so far, steps the path is switched off for }.
+MI_API int mi_debug_block_stats(mi_world* w, uint32_t* out16) {
+    if (!w || !out16) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    const auto& c = w->blkCaps; const BlockState& b = w->lastBlk;
+    const uint32_t v[16] = {c.nbe, c.tiles, c.extraCap, c.bodyCap, c.hashSize, c.maxPasses, c.impCap, (uint32_t)c.lds, b.need, b.needExtra, b.needBodies, b.needPasses, b.needImp, b.ghostLanes, w->blkSteps, w->blkDisabledSteps};
+    for (int i = 0; i < 16; ++i) out16[i] = v[i];
+    return MI_OK;
+}
 MI_API int mi_world_get_solver_kind(mi_world* w, uint32_t* out) {
     if (!w || !out) return fail(MI_ERR_INVALID_ARGUMENT, "null");
-    *out = w->usedFused ? 3u : w->usedPersist ? (w->usedXcdSingle ? 5u : w->usedXcd ? 4u : 2u) : w->usedFlow ? 1u : 0u;
+    *out = w->usedBlocks ? 6u : w->usedFused ? 3u : w->usedPersist ? (w->usedXcdSingle ? 5u : w->usedXcd ? 4u : 2u) : w->usedFlow ? 1u : 0u;
     return MI_OK;
 }
 // Host-side evaluation of the tile -> XCD assignment the XCD-partitioned solver uses on the device (tests: the per-XCD shares of

@@ -290,6 +290,10 @@ MI_API int mi_world_get_solver_kind(mi_world* world, uint32_t* out_kind);
  * (HIP runtime >= 7.2; MI_GRAPH=0 / force / all).  out[0] = enabled, out[1] = steps replayed, out[2] = graphs captured,
  * out[3] = speculative steps launched plainly. */
 MI_API int mi_debug_step_graph_stats(mi_world* world, uint32_t* out4);
+/* Development / tests: the block solver's sizes and what its last step needed (csrc/blocks.hpp).  out16 = { blocks, tiles per block, extra capacity, body capacity,
+   hash slots, passes per wave, impulses per wave, LDS bytes, entries needed, extras needed, bodies needed, passes needed, impulses needed, boundary entries,
+   block steps so far, steps the path is switched off for }.  No reference counterpart. */
+MI_API int mi_debug_block_stats(mi_world* world, uint32_t* out16);
 /* Sum of the per-stage device times and of the contact updates (contacts x solver iterations) over the internal steps since
  * the last reset (so a benchmark loop does not have to call back into the library after every step). */
 MI_API int mi_world_get_accumulated_stage_times(mi_world* world, mi_stage_times* out_sum, uint32_t* out_steps,
