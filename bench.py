@@ -338,7 +338,8 @@ def main():
                          "message_bytes_per_neighbour": ex["message_bytes"], "neighbours": ex["neighbour_rank"],
                          "records_per_exchange": [v / max(1, ex["exchanges"]) for v in ex["records_sum"]],
                          "payload_bytes_per_exchange": [56 * v / max(1, ex["exchanges"]) for v in ex["records_sum"]],
-                         "seam": args.seam, "sweep_exchanges_timed": ex["sweep_exchanges"], "sweep_message_bytes_per_neighbour": ex["sweep_message_bytes"],
+                         "seam": args.seam, "seam_stats": sw.check_seam() if args.seam == "exact" else None,   # (raises when a manifold violated the seam classes: the ranks would no longer equal one world)
+                         "sweep_exchanges_timed": ex["sweep_exchanges"], "sweep_message_bytes_per_neighbour": ex["sweep_message_bytes"],
                          "sweep_payload_bytes_per_exchange": [32 * v for v in ex["sweep_records_last"]]},
         }
         gathered = [None] * world_size

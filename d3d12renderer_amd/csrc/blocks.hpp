@@ -306,10 +306,9 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
                 mySlots = s + 1u;
                 if (lane < count) {
                     const uint4 m = slotMeta[(size_t)ti.x * 64u + lane];
-                    const float2 mass = slotMass[(size_t)ti.x * 64u + lane];
                     const bool bnd = (m.w >> 9) & 1u, homeB = (m.w >> 10) & 1u;
                     const bool ghostA = bnd && homeB, ghostB = bnd && !homeB;
-                    const bool homeA = mass.x != 0.f && !ghostA, homeBd = mass.y != 0.f && !ghostB;
+                    const bool homeA = !ghostA, homeBd = !ghostB;   // (also the bodies nobody updates — the static dummy, a kinematic body: a read-only copy, so every lane reads its bodies the same way)
                     auto insert = [&](uint32_t body) -> uint32_t {
                         uint32_t h = (body * 0x9E3779B1u) >> 8;
 #pragma unroll 1
@@ -436,7 +435,8 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
             const uint32_t degA = (pk >> 7) & 127u, degB = (pk >> 21) & 127u;
             const uint32_t expA = it * degA + (pk & 127u), expB = it * degB + ((pk >> 14) & 127u);
             const bool ghostA = act && bndG && homeIsB, ghostB = act && bndG && !homeIsB;
-            const bool ldsA = act && degA != 0u && !ghostA, ldsB = act && degB != 0u && !ghostB;
+            const bool ldsA = act && !ghostA, ldsB = act && !ghostB;                 // the body's record is in LDS ...
+            const bool updA = ldsA && degA != 0u, updB = ldsB && degB != 0u;         // ... and this manifold updates it (a dynamic body at home here)
             // the ghost of a boundary lane: its state before this manifold's turn — the initial state (tag 0) straight from gVel, anything later from the
             // mailbox slot its home block exports it into
             const uint32_t gBody = ghostA ? meta.x : meta.y, gExp = ghostA ? expA : expB, gRank = (meta.w >> 21) & 7u;
@@ -467,8 +467,8 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
                 }
                 landed(g0); landed(g1);
             }
-            bool okA = !ldsA || (__float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA);
-            bool okB = !ldsB || (__float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB);
+            bool okA = !updA || (__float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA);
+            bool okB = !updB || (__float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB);
             bool okG = !(ghostA || ghostB) || (__float_as_uint(g0.w) == gTag && __float_as_uint(g1.w) == gTag);
             uint32_t budget = bndG ? kBlockSpinMem : kBlockSpinLds;
             while (__ballot(!(okA && okB && okG)) != 0ull) {
@@ -506,18 +506,18 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
             }
             // publish: home bodies into LDS; exports write-through into the mailbox of the boundary manifold that comes next on the body
             const uint32_t nA = expA + 1u, nB = expB + 1u;
-            if (ldsA) { f32x4 h0 = {pv.x.x, pv.y.x, pv.z.x, __uint_as_float(nA)}, h1 = {pw.x.x, pw.y.x, pw.z.x, __uint_as_float(nA)}; ldsStoreBody(adA, h0, h1); }
-            if (ldsB) { f32x4 h0 = {pv.x.y, pv.y.y, pv.z.y, __uint_as_float(nB)}, h1 = {pw.x.y, pw.y.y, pw.z.y, __uint_as_float(nB)}; ldsStoreBody(adB, h0, h1); }
+            if (updA) { f32x4 h0 = {pv.x.x, pv.y.x, pv.z.x, __uint_as_float(nA)}, h1 = {pw.x.x, pw.y.x, pw.z.x, __uint_as_float(nA)}; ldsStoreBody(adA, h0, h1); }
+            if (updB) { f32x4 h0 = {pv.x.y, pv.y.y, pv.z.y, __uint_as_float(nB)}, h1 = {pw.x.y, pw.y.y, pw.z.y, __uint_as_float(nB)}; ldsStoreBody(adB, h0, h1); }
             const uint32_t eA = (meta.w >> 11) & 31u, eB = (meta.w >> 16) & 31u;
-            pendingStores = (__ballot(ldsA && (eA & 1u)) != 0ull ? 2u : 0u) + (__ballot(ldsB && (eB & 1u)) != 0ull ? 2u : 0u);   // (a branch no lane takes issues nothing)
-            if (ldsA && (eA & 1u)) {
+            pendingStores = (__ballot(updA && (eA & 1u)) != 0ull ? 2u : 0u) + (__ballot(updB && (eB & 1u)) != 0ull ? 2u : 0u);   // (a branch no lane takes issues nothing)
+            if (updA && (eA & 1u)) {
                 const uint32_t par = (eA & 2u) ? (it & 1u) : ((it + 1u) & 1u);
                 float4* dst = mail + ((((size_t)recBody[meta.x] * kMailRanks + (eA >> 2)) * 2u + par) * 2u);
                 const float t = __uint_as_float(stamp | nA);
                 f32x4 h0 = {pv.x.x, pv.y.x, pv.z.x, t}, h1 = {pw.x.x, pw.y.x, pw.z.x, t};
                 storeGranuleSc1(dst, h0); storeGranuleSc1(dst + 1, h1);
             }
-            if (ldsB && (eB & 1u)) {
+            if (updB && (eB & 1u)) {
                 const uint32_t par = (eB & 2u) ? (it & 1u) : ((it + 1u) & 1u);
                 float4* dst = mail + ((((size_t)recBody[meta.y] * kMailRanks + (eB >> 2)) * 2u + par) * 2u);
                 const float t = __uint_as_float(stamp | nB);

@@ -819,7 +819,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     if (bodies.empty()) return cloths.empty() ? MI_OK : stepCloths(dt);   // physics.cpp:1184-1189: cloth alone still steps
     if (shard.stepOpen) shard.prevValid = false;   // the previous step ended in an error: what its kernels left behind is not what the flags describe
     shard.stepOpen = true;
-    if (debugOrderPending && (heightmap || shard.enabled)) return fail(MI_ERR_UNSUPPORTED, "mi_debug_set_solve_order: not with heightmap terrain or sharding");
+    if (debugOrderPending && (heightmap || shard.enabled)) { debugOrderPending = false; debugOrder.clear(); shard.stepOpen = false; return fail(MI_ERR_UNSUPPORTED, "mi_debug_set_solve_order: not with heightmap terrain or sharding"); }   // (terrain / sharding came after the order was set: the order is dropped, later steps run)
     const bool exactSeam = shard.enabled && shard.exact;   // every rank must take the same path through the step (its sweeps end in an exchange): no speculation
     shard.sweepsDone = 0;
     const bool spec = specEnabled && haveEstimates && flowSolver && !launchFallbackSteps && !debugOrderPending && !exactSeam && (!usesInteractions || last.numInteractions <= 32768u);   // (triggers / force fields: ordered and applied on the device while there are at most 32 k interactions)
@@ -1520,6 +1520,10 @@ enqueue_section:
         for (uint32_t b = 0; b < kColorBins; ++b) { const uint32_t c = hs.binStart[b]; hs.binStart[b] = run; run += c; }
         hs.binStart[kColorBins] = run;
         lastBlk = hs.blk; haveBlkEstimate = true; ++blkSteps;
+        static const bool blockDebug = std::getenv("MI_BLOCK_DEBUG") != nullptr;   // development: one line per block step
+        if (blockDebug) std::fprintf(stderr, "[mi_physics] step %llu blocks %u x %u tiles (extra %u, bodies %u, hash %u, passes %u, impulses %u, lds %zu): needed entries %u extras %u bodies %u passes %u impulses %u; boundary entries %u; manifolds %u; overflow %u solveError %u specOverflow %u\n",
+                                     (unsigned long long)totalSteps, blkCaps.nbe, blkCaps.tiles, blkCaps.extraCap, blkCaps.bodyCap, blkCaps.hashSize, blkCaps.maxPasses, blkCaps.impCap, blkCaps.lds,
+                                     hs.blk.need, hs.blk.needExtra, hs.blk.needBodies, hs.blk.needPasses, hs.blk.needImp, hs.blk.ghostLanes, hs.numManifolds, hs.blk.overflow, hs.solveError, hs.specOverflow);
         const bool failed = hs.blk.overflow != 0u || (usedBlocks && hs.solveError != 0u);
         if (failed) {
             if (usedBlocks && hs.solveError == 1u) blkDisabledSteps = 256u;          // a wait ran out of budget (shared device, or the test injection): the classic path for a while
@@ -1661,6 +1665,7 @@ enqueue_section:
     // the step's device times: read from its events LATER (finishTimes), the next step records into the other set
     finishTimes();   // (normally done already, at the start of this step)
     timesPending = stepEventsMode == 2 || stageEvents; timesPendingSet = evSet; timesPendingStages = stageEvents; timesPendingUpdates = (uint64_t)counts.num_contacts * iters;
+    if (!timesPending) { times = mi_stage_times{}; ++timesSteps; contactUpdatesSum += timesPendingUpdates; }   // timing off: no stale times, and the step / contact-update counts still add up
     evSet ^= 1; ev = evSets[evSet];
     static const bool eagerTimes = std::getenv("MI_EAGER_TIMES") != nullptr;   // development: read them right here, as before
     if (eagerTimes) finishTimes();
@@ -1738,6 +1743,7 @@ MI_API int mi_debug_set_sweep_axis(mi_world* w, uint32_t axis) {
 }
 MI_API int mi_debug_set_solve_order(mi_world* w, const uint32_t* pairs, uint32_t count) {
     if (!w || (count && !pairs)) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    if (w->heightmap || w->shard.enabled) return fail(MI_ERR_UNSUPPORTED, "mi_debug_set_solve_order: not with heightmap terrain or sharding");   // (here, not in the step: a pending order would fail every later step)
     w->debugOrder.resize(count);
     for (uint32_t i = 0; i < count; ++i) {
         if (pairs[2 * i] >= (1u << 29) || pairs[2 * i + 1] >= (1u << 29)) return fail(MI_ERR_INVALID_ARGUMENT, "collider index out of range");
@@ -2696,7 +2702,8 @@ int mi_world::shardSweepExchange(uint32_t sweep) {
         return MI_OK;
     }
     HIP_TRY(hipStreamSynchronize(st));   // the messages are complete
-    if (sh.sweepFn) { const int rc = sh.sweepFn(sh.sweepUser, this, sweep); if (rc != MI_OK) return fail(MI_ERR_DEVICE, "exact seam: the caller's sweep exchange failed"); }
+    if (!sh.sweepFn) return fail(MI_ERR_INVALID_ARGUMENT, "exact seam: neither the library transport is attached nor a sweep exchange callback set — the seam would silently run as block Jacobi");
+    { const int rc = sh.sweepFn(sh.sweepUser, this, sweep); if (rc != MI_OK) return fail(MI_ERR_DEVICE, "exact seam: the caller's sweep exchange failed"); }
     return MI_OK;
 }
 MI_API int mi_world_set_seam_tiling(mi_world* w, const mi_shard_desc* d) {
@@ -2723,6 +2730,12 @@ MI_API int mi_world_shard_set_exact_seam(mi_world* w, uint32_t enable, mi_shard_
     mi_world::ShardState& sh = w->shard;
     if (enable && sh.desc.tiles_x > 1u && sh.desc.tiles_z > 1u) return fail(MI_ERR_UNSUPPORTED, "exact seam: x- or z-slabs only (at a corner a shared body is seen by four tiles)");
     if (enable && (2.f * sh.desc.ghost_margin > sh.desc.tile_size_x || 2.f * sh.desc.ghost_margin > sh.desc.tile_size_z)) return fail(MI_ERR_INVALID_ARGUMENT, "exact seam: tiles must be at least two ghost margins wide");
+    if (enable && !fn && !sh.rccl) return fail(MI_ERR_INVALID_ARGUMENT, "exact seam: with the caller's transport a sweep exchange callback is needed");
+    if (enable) {   // ... also the tiles a load balance has cut (borders in force and pending): a body must never lie within the margin of two borders
+        const float m2 = 2.f * sh.desc.ghost_margin;
+        for (const std::vector<float>* b : {&sh.bordersX, &sh.bordersZ, &sh.nextX, &sh.nextZ})
+            for (size_t i = 1; i < b->size(); ++i) if (!((*b)[i] - (*b)[i - 1] > m2)) return fail(MI_ERR_INVALID_ARGUMENT, "exact seam: a tile of the current borders is narrower than two ghost margins");
+    }
     HIP_TRY(hipSetDevice(w->device));
     if (sh.exact != (enable != 0u)) { w->tabValid = false; w->haveEstimates = false; }   // the colour ranges mean something else from here on
     sh.exact = enable != 0u; sh.sweepFn = fn; sh.sweepUser = user;
@@ -2787,6 +2800,7 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
     if (!(d->tile_size_x > 0.f) || !(d->tile_size_z > 0.f) || !(d->ghost_margin > 0.f) || d->ghost_margin >= d->tile_size_x || d->ghost_margin >= d->tile_size_z) return fail(MI_ERR_INVALID_ARGUMENT, "0 < ghost_margin < tile size");
     HIP_TRY(hipSetDevice(w->device));
     mi_world::ShardState& sh = w->shard;
+    if (w->seamTiling.on) { w->seamTiling.on = false; w->tabValid = false; w->haveEstimates = false; }   // a told tiling (mi_world_set_seam_tiling) ends here: a sharded world takes its seam colouring from mi_world_shard_set_exact_seam only
     sh.desc = *d;
     const std::vector<uint32_t> order = tilesInRankOrder(d->tiles_x, d->tiles_z);
     ShardParams& sp = sh.sp;
@@ -2839,10 +2853,10 @@ namespace {
 // What ONE change of the borders may do.  A body's new owner, and every rank that newly holds it as a ghost, must be the old owner's tile or one of
 // its neighbours (only those exchange messages): new border i stays within [old border i-1 + margin, old border i+1 - margin]; and a tile stays
 // wider than the margin (its ghost region must not reach past its neighbours).
-bool shardBordersValid(const std::vector<float>& cur, const float* nb, uint32_t n, float m) {
+bool shardBordersValid(const std::vector<float>& cur, const float* nb, uint32_t n, float m, float minWidth) {   // minWidth: m, or 2 m under the exact seam (a body within the margin of TWO borders has no seam class)
     for (uint32_t i = 0; i < n; ++i) {
         if (!(nb[i] == nb[i])) return false;
-        if (i > 0 && !(nb[i] - nb[i - 1] > m)) return false;
+        if (i > 0 && !(nb[i] - nb[i - 1] > minWidth)) return false;
         if (i > 0 && nb[i] < cur[i - 1] + m) return false;
         if (i + 1 < n && nb[i] > cur[i + 1] - m) return false;
     }
@@ -2860,8 +2874,9 @@ MI_API int mi_world_shard_set_borders(mi_world* w, const float* bx, const float*
     if (!w || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
     mi_world::ShardState& sh = w->shard;
     const float m = sh.desc.ghost_margin;
-    if ((bx && !shardBordersValid(sh.bordersX, bx, (uint32_t)sh.bordersX.size(), m)) || (bz && !shardBordersValid(sh.bordersZ, bz, (uint32_t)sh.bordersZ.size(), m)))
-        return fail(MI_ERR_INVALID_ARGUMENT, "borders: ascending, tiles wider than ghost_margin, and border i within [old border i-1 + margin, old border i+1 - margin]");
+    const float minWidth = sh.exact ? 2.f * m : m;
+    if ((bx && !shardBordersValid(sh.bordersX, bx, (uint32_t)sh.bordersX.size(), m, minWidth)) || (bz && !shardBordersValid(sh.bordersZ, bz, (uint32_t)sh.bordersZ.size(), m, minWidth)))
+        return fail(MI_ERR_INVALID_ARGUMENT, "borders: ascending, tiles wider than ghost_margin (two margins under the exact seam), and border i within [old border i-1 + margin, old border i+1 - margin]");
     sh.nextX = bx ? std::vector<float>(bx, bx + sh.bordersX.size()) : sh.bordersX;
     sh.nextZ = bz ? std::vector<float>(bz, bz + sh.bordersZ.size()) : sh.bordersZ;
     sh.spNext = sh.sp; w->shardFillBorders(sh.spNext, sh.nextX, sh.nextZ);
@@ -2912,7 +2927,7 @@ MI_API int mi_shard_balance_borders(const uint64_t* hist, uint32_t bins, float l
             nb[i] = (float)v;
         }
     }
-    const bool ok = shardBordersValid(c, nb.data(), n, margin);
+    const bool ok = shardBordersValid(c, nb.data(), n, margin, margin);
     for (uint32_t i = 0; i < n; ++i) out[i] = ok ? nb[i] : c[i];
     return MI_OK;
 }
@@ -2947,6 +2962,12 @@ MI_API int mi_world_shard_rebalance(mi_world* w, uint32_t bins) {
     std::vector<float> nx(w->shard.bordersX), nz(w->shard.bordersZ);
     rc = mi_shard_balance_borders(h.data(), bins, lo[0], hi[0], d.tiles_x, w->shard.bordersX.data(), d.ghost_margin, nx.data()); if (rc != MI_OK) return rc;
     rc = mi_shard_balance_borders(h.data() + bins, bins, lo[1], hi[1], d.tiles_z, w->shard.bordersZ.data(), d.ghost_margin, nz.data()); if (rc != MI_OK) return rc;
+    if (w->shard.exact) {   // exact seam: a tile stays wider than TWO margins (a body within the margin of two borders has no seam class); a proposal that would not is not taken
+        const float m2 = 2.f * d.ghost_margin;
+        auto wide = [&](const std::vector<float>& b) { for (size_t i = 1; i < b.size(); ++i) if (!(b[i] - b[i - 1] > m2)) return false; return true; };
+        if (!wide(nx)) nx = w->shard.bordersX;
+        if (!wide(nz)) nz = w->shard.bordersZ;
+    }
     return mi_world_shard_set_borders(w, nx.empty() ? nullptr : nx.data(), nz.empty() ? nullptr : nz.data());
 }
 MI_API int mi_world_shard_owned_entities(mi_world* w, uint32_t* out, uint32_t cap, uint32_t* count) {
@@ -2982,6 +3003,7 @@ MI_API int mi_world_shard_detach_rccl(mi_world* w) {
     if (!w || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "not a sharded world");
     HIP_TRY(hipSetDevice(w->device));
     HIP_TRY(hipStreamSynchronize(w->stream));
+    if (w->shard.exact && !w->shard.sweepFn) return fail(MI_ERR_INVALID_ARGUMENT, "exact seam: detaching the library transport needs a sweep exchange callback (mi_world_shard_set_exact_seam) first");
     w->shardReleaseComm(); w->shard.rccl = false;
     { int rc = w->shardSyncAxis(); if (rc != MI_OK) return rc; }
     return w->shardCheckOverflow(false);
@@ -3442,8 +3464,8 @@ MI_API int mi_debug_tile_owner(uint32_t tile_in_bin, uint32_t tiles_in_bin, uint
     out[0] = tileOwner(tile_in_bin, tiles_in_bin, bin); out[1] = tileOwnerRank(tile_in_bin, tiles_in_bin, bin); out[2] = tileOwnerCount(query_xcd, tiles_in_bin, bin);
     return MI_OK;
 }
-// Event pairs around every stage cost a few microseconds of device time per step each: off by default (the whole step and the
-// solve stage are always timed), on for profiling.
+// Event pairs around every stage cost a few microseconds of device time per step each: NOTHING is timed by default (level 0: the stage times read 0, the
+// accumulated step and contact-update counts still count every valid step); level 2 = the whole step and the solve stage, level 1 = every stage.
 MI_API int mi_world_set_stage_timing(mi_world* w, uint32_t level) {
     if (!w || level > 2u) return fail(MI_ERR_INVALID_ARGUMENT, "level: 0 off, 1 every stage, 2 the whole step and the solve stage");
     w->stageEvents = level == 1u; w->stepEvents = level == 2u; return MI_OK;

@@ -97,6 +97,15 @@ class ShardedWorld:
             self.world.shard_set_exact_seam(enable, self._sweep_dist if enable else None)
         else:
             raise RuntimeError("virtual ranks step side by side: sharding.step_local_exact(ranks, ...)")
+        self.exact = bool(enable)
+
+    def check_seam(self):
+        """Exact seam only: the step's seam statistics; raises when a manifold violated the seam classes (a body within the margin of two borders, a tile
+        narrower than two margins): the ranks would no longer equal the single world told the tiling."""
+        st = self.world.seam_stats()
+        if getattr(self, "exact", False) and st["violations"]:
+            raise RuntimeError(f"exact seam: {st['violations']} manifolds violate the seam classes this step (tiles must stay wider than two ghost margins)")
+        return st
 
     def _sweep_dist(self, sweep):
         import torch
@@ -163,6 +172,9 @@ class ShardedWorld:
         cur_x, cur_z = self.world.shard_get_borders(d.tiles_x, d.tiles_z)
         nx = self.world.L.shard_balance_borders(global_hist[0], *self._extent(0), d.tiles_x, cur_x, d.ghost_margin)
         nz = self.world.L.shard_balance_borders(global_hist[1], *self._extent(1), d.tiles_z, cur_z, d.ghost_margin)
+        if getattr(self, "exact", False):     # exact seam: tiles stay wider than two margins; a proposal that would not is not taken (the same decision on every rank)
+            if len(nx) > 1 and np.any(np.diff(nx) <= 2.0 * d.ghost_margin): nx = cur_x
+            if len(nz) > 1 and np.any(np.diff(nz) <= 2.0 * d.ghost_margin): nz = cur_z
         self.world.shard_set_borders(nx, nz)
         return nx, nz
 
