@@ -580,6 +580,17 @@ class World:
         assert len(buf) == 128
         self.L.check(self.L.fn("world_shard_attach_rccl")(self.h, _ptr(buf)), "world_shard_attach_rccl")
 
+    def shard_attach_loopback(self):
+        """mi_debug_shard_attach_loopback: the library transport on ONE rank — a one-rank communicator, every neighbour is this rank itself (tests)."""
+        self.L.check(self.L.fn("debug_shard_attach_loopback")(self.h), "debug_shard_attach_loopback")
+
+    def shard_peek_received(self, slot, sweep_message=False):
+        """mi_debug_shard_peek_received: the message last received in neighbour slot `slot` (library transport)."""
+        n = (self.shard_sweep_message_bytes() if sweep_message else self.shard_message_bytes()) // 4
+        out = np.zeros(n, np.float32)
+        self.L.check(self.L.fn("debug_shard_peek_received")(self.h, C.c_uint32(slot), C.c_uint32(1 if sweep_message else 0), _ptr(out)), "debug_shard_peek_received")
+        return out
+
     # --- ghost-region exchange (13 floats per body: pos3, rot4, lin3, ang3)
     def get_body_states(self, entities):
         ents = np.ascontiguousarray(entities, dtype=np.uint32)

@@ -211,7 +211,7 @@ struct mi_world {
     DBuf<uint32_t> blkKeys, blkRanks, blkPerm, blkStart, blkExtra, blkExtraCount; DBuf<uint16_t> blkCell; DBuf<unsigned long long> bndMask; DBuf<float4> mail;
     bool blockSolver = true, usedBlocks = false, blockFaultTest = false, blockFaultFired = false;
     struct BlockCaps { uint32_t nbe = 0, tiles = 0, extraCap = 0, bodyCap = 0, hashSize = 0, maxPasses = 0, impCap = 0; size_t lds = 0; } blkCaps;   // sticky: the same launches step after step (step graphs)
-    BlockState lastBlk{}; bool haveBlkEstimate = false; uint32_t blkFailures = 0, blkDisabledSteps = 0, blkLaunches = 0, blkMaxBlocks = 256, blkSteps = 0;
+    BlockState lastBlk{}; bool haveBlkEstimate = false, blkLastFailed = false; uint32_t blkFailHistory = 0, blkFailures = 0, blkDisabledSteps = 0, blkLaunches = 0, blkMaxBlocks = 256, blkSteps = 0;
     bool planBlocks(uint32_t nmLast, uint32_t nbBodies);
     bool persistXcd = true, persistXcdSingle = true, usedXcd = false, usedXcdSingle = false, lastXcdSingle = false, haveXcdEstimate = false, xcdFaultFired = false, xcdFaultTest = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
     // device: colliders
@@ -1525,12 +1525,13 @@ enqueue_section:
                                      (unsigned long long)totalSteps, blkCaps.nbe, blkCaps.tiles, blkCaps.extraCap, blkCaps.bodyCap, blkCaps.hashSize, blkCaps.maxPasses, blkCaps.impCap, blkCaps.lds,
                                      hs.blk.need, hs.blk.needExtra, hs.blk.needBodies, hs.blk.needPasses, hs.blk.needImp, hs.blk.ghostLanes, hs.numManifolds, hs.blk.overflow, hs.solveError, hs.specOverflow);
         const bool failed = hs.blk.overflow != 0u || (usedBlocks && hs.solveError != 0u);
+        blkFailHistory = (blkFailHistory << 1) | (failed ? 1u : 0u);
+        blkLastFailed = failed;
         if (failed) {
             if (usedBlocks && hs.solveError == 1u) blkDisabledSteps = 256u;          // a wait ran out of budget (shared device, or the test injection): the classic path for a while
-            else if (++blkFailures >= 3u) { blkDisabledSteps = 512u; blkFailures = 0u; }   // capacities that do not settle
+            else if (__builtin_popcount(blkFailHistory & 0xFFFFu) >= 8) { blkDisabledSteps = 128u; blkFailHistory = 0u; }   // capacities that do not settle (a pile landing outgrows them step after step: the sizes follow with x 1.5 per failure)
             return STEP_RETRY;   // nothing persistent has been written: the synchronous re-run takes the classic schedule
         }
-        blkFailures = 0u;
     }
     if (spec) {
         const uint32_t ovfCount = hs.binStart[kColorBins] - hs.binStart[kSchedBins - 1];
@@ -1772,6 +1773,11 @@ bool mi_world::planBlocks(uint32_t nmLast, uint32_t nbBodies) {
         return (want + quantum - 1u) / quantum * quantum;
     };
     const bool have = haveBlkEstimate;
+    if (blkLastFailed) {   // the previous block step outgrew a capacity: the scene is changing fast (a pile landing), take a bigger stride than the usual slack
+        BlockState& b = lastBlk;
+        b.need += b.need / 2u; b.needExtra += b.needExtra / 2u + 16u; b.needBodies += b.needBodies / 2u; b.needPasses += b.needPasses / 2u + 4u; b.needImp += b.needImp / 2u;
+        blkLastFailed = false;
+    }
     const uint32_t needEntries = have && lastBlk.need ? lastBlk.need : perBlock + perBlock / 4u + 32u;
     c.tiles = sticky(c.tiles * 64u, needEntries, 64u, 64u) / 64u;
     if (c.tiles > 16u * kBlockWaves) return false;
@@ -2997,6 +3003,33 @@ MI_API int mi_world_shard_attach_rccl(mi_world* w, const void* id) {
     const int e = r->CommInitRank(&w->shard.comm, (int)w->shard.desc.num_ranks, uid, (int)w->shard.desc.rank);
     if (e) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e) : "ncclCommInitRank failed");
     w->shard.rccl = true;
+    return MI_OK;
+}
+// Development / tests: the library transport on ONE rank.  A one-rank communicator whose every neighbour is this rank itself: the exchange then runs
+// ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, the unpack kernels and the all-reduce with real records on one GPU — each message comes back to its sender.
+// (What a rank receives are the records it packed for the neighbouring tile: states of bodies it holds anyway, so the world goes on exactly like one on the
+// caller's transport that is handed its own messages back: tests/test_gpu_sharding.py.)
+MI_API int mi_debug_shard_attach_loopback(mi_world* w) {
+    if (!w || !w->shard.enabled) return fail(MI_ERR_INVALID_ARGUMENT, "enable sharding first");
+    Rccl* r = rccl(); if (!r) return fail(MI_ERR_UNSUPPORTED, "librccl.so.1 not found");
+    HIP_TRY(hipSetDevice(w->device));
+    Id128 uid; std::memset(&uid, 0, sizeof(uid));
+    int e = r->GetUniqueId(&uid);
+    if (!e) e = r->CommInitRank(&w->shard.comm, 1, uid, 0);
+    if (e) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e) : "ncclCommInitRank failed");
+    for (uint32_t& p : w->shard.peerRanks) p = 0u;
+    w->shard.rccl = true;
+    return MI_OK;
+}
+// ... and the message last RECEIVED in slot `slot` (library transport), so a test can hold it against what was sent
+MI_API int mi_debug_shard_peek_received(mi_world* w, uint32_t slot, uint32_t sweep_message, void* out) {
+    if (!w || !out || !w->shard.enabled || slot >= w->shard.sp.numPeers) return fail(MI_ERR_INVALID_ARGUMENT, "bad slot");
+    HIP_TRY(hipSetDevice(w->device));
+    HIP_TRY(hipStreamSynchronize(w->stream));
+    const DBuf<float>& b = sweep_message ? w->shard.sweepRecv[slot] : w->shard.recvBuf[slot];
+    const size_t n = sweep_message ? w->shard.sweepFloats() : w->shard.messageFloats();
+    if (!b.p || b.cap < n) return fail(MI_ERR_INVALID_ARGUMENT, "nothing received in this slot yet");
+    HIP_TRY(hipMemcpy(out, b.p, n * sizeof(float), hipMemcpyDeviceToHost));
     return MI_OK;
 }
 MI_API int mi_world_shard_detach_rccl(mi_world* w) {

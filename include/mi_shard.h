@@ -166,6 +166,13 @@ MI_API int mi_world_shard_import_sweep(mi_world* world, const void* message);
 /* Of the last internal step: manifolds in the seam class, colours they used, violations of the conditions above since the mode was set. */
 MI_API int mi_world_seam_stats(mi_world* world, uint32_t* out_seam_manifolds, uint32_t* out_seam_colors, uint32_t* out_violations);
 
+/* Development / tests: the library transport on ONE rank.  A one-rank communicator whose every neighbour is this rank itself, so the exchange runs
+ * ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd, the unpack kernels and the all-reduce with real records on one GPU: each message comes back to
+ * its sender.  mi_debug_shard_peek_received copies the message last received in a slot (sweep_message != 0: the exact seam's sweep message).
+ * No reference counterpart. */
+MI_API int mi_debug_shard_attach_loopback(mi_world* world);
+MI_API int mi_debug_shard_peek_received(mi_world* world, uint32_t slot, uint32_t sweep_message, void* out_message);
+
 #ifdef __cplusplus
 }
 #endif

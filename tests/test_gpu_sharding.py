@@ -196,6 +196,51 @@ def test_gpu_library_rccl_transport_comes_up(mi_lib):
     w.close()
 
 
+@pytest.mark.parametrize("exact", [False, True], ids=["block-Jacobi seam", "exact seam: one hand-over per sweep"])
+def test_gpu_library_transport_loops_back_on_one_gpu(mi_lib, exact):
+    """The library's RCCL path with REAL records on one GPU: rank 0 of a two-tile grid on a one-rank communicator whose neighbour is the
+    rank itself (mi_debug_shard_attach_loopback).  Every exchange runs pack -> ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd ->
+    k_shard_unpack -> ncclAllReduce on the world's stream (with the exact seam also the per-sweep k_seam_sweep_pack -> send / receive ->
+    k_seam_sweep_unpack), and what arrives is, bit for bit, what was sent.  A second world on the CALLER's transport is handed its own
+    messages back by this test; the two must stay bit-identical step after step: the transports are interchangeable."""
+    sc = scenes.obb_pile(16, 4, 8, spacing=1.0)
+    desc = sharding._desc_for(sharding.tile_grid(sc, 2, 1, 2.5), 0)
+    a = sc.populate(mi_lib.create_world(0)); b = sc.populate(mi_lib.create_world(0))
+    a.shard_enable(desc); b.shard_enable(desc)
+    a.shard_attach_loopback()
+    assert a.shard_neighbours() == [0], "rank 0 of two x tiles has one neighbour; looped back, it is rank 0 itself"
+    sweeps_seen = []
+    if exact:
+        a.shard_set_exact_seam(True, None)
+        def hand_back(sweep):
+            sweeps_seen.append(sweep)
+            b.shard_import_sweep(b.shard_export_sweep(0))
+        b.shard_set_exact_seam(True, hand_back)
+    s = sc.settings()
+    moved = 0
+    for i in range(60):
+        a.step_fixed(s, sc.dt, 1)
+        b.step_fixed(s, sc.dt, 1)
+        msg = b.shard_export(0); b.shard_import(msg); b.shard_set_axis_sums(b.shard_axis_sums())
+        sent = a.shard_export(0); got = a.shard_peek_received(0)
+        n = int(sent[:1].view(np.uint32)[0])
+        assert n == int(msg[:1].view(np.uint32)[0])
+        used = (n + 1) * (len(sent) // (desc.max_records + 1))
+        assert sent[:used].tobytes() == got[:used].tobytes() == msg[:used].tobytes(), f"step {i}: what RCCL delivered is not what was packed"
+        moved += n
+        assert a.counts() == b.counts(), f"step {i}"
+        pa, qa = a.physics_transforms(); pb, qb = b.physics_transforms()
+        assert pa.tobytes() == pb.tobytes() and qa.tobytes() == qb.tobytes(), f"step {i}"
+        if exact:
+            sw = a.shard_peek_received(0, sweep_message=True)
+            assert sw[:8 * (int(sw[:1].view(np.uint32)[0]) + 1)].tobytes() == b.shard_export_sweep(0).tobytes(), f"step {i}: sweep message"
+    assert moved > 60, "the seam strip holds bodies: records must have travelled"
+    if exact:
+        assert len(sweeps_seen) == 60 * s.num_rigid_solver_iterations
+    assert a.shard_exchange_stats()["exchanges"] == 60
+    a.close(); b.close()
+
+
 def test_gpu_global_sweep_axis_and_independent_islands_under_any_tiling(mi_lib, oracle_mod):
     """include/mi_shard.h "Global sweep axis": the 9 integer centre statistics summed over the ranks equal the single world's exactly, so all
     ranks sweep along the single world's axis and independent islands (cfg4: ragdolls on the ground; cfg5: vehicles on hull tiles, whose
