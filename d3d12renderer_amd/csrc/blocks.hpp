@@ -104,12 +104,13 @@ __global__ __launch_bounds__(256) void k_block_place(uint32_t n, const StepScala
         __syncthreads();
     }
     const uint32_t total = part[255];
+    const uint32_t perBlock = max(1u, (total + nbe - 1u) / nbe);
     uint32_t run = part[threadIdx.x] - sum;
 #pragma unroll
     for (uint32_t k = 0; k < per; ++k) {
         const uint32_t c = threadIdx.x * per + k;
         lower[c] = run;
-        blk[c] = (uint16_t)(total ? min(nbe - 1u, (uint32_t)(((unsigned long long)run * nbe) / total)) : 0u);
+        blk[c] = (uint16_t)min(nbe - 1u, run / perBlock);   // (the block of the cell's first manifold; 32-bit division by a uniform value)
         run += v[k];
     }
     __syncthreads();
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(256) void k_block_sched(uint32_t lastRound, const u
     __shared__ uint32_t hist[kBlockSortBins];     // counts, then the first slot of every bin
     __shared__ uint32_t cls[kColorBins];          // (colour, contacts) counts of the manifolds this block owns (the host's bins)
     __shared__ uint32_t part[256];
+    __shared__ uint16_t lutS[kBlockCells];   // cell -> block
     const uint32_t J = blockIdx.x, T = tilesPerBlock;
     for (uint32_t b = threadIdx.x; b < kBlockSortBins; b += 256) hist[b] = 0u;
     for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) cls[b] = 0u;
@@ -166,17 +168,30 @@ __global__ __launch_bounds__(256) void k_block_sched(uint32_t lastRound, const u
     if (threadIdx.x == 0) { atomicMax(&bs->need, nP + nEall); atomicMax(&bs->needExtra, nEall); if (!ok) { bs->overflow = 1u; sc->specOverflow = 1u; } if (nE) atomicAdd(&bs->ghostLanes, 2u * nE); }
     if (!ok) n = 0u;
     __syncthreads();
-    uint32_t eM[kBlockMaxPer], eBin[kBlockMaxPer], eRank[kBlockMaxPer];
+    // (three passes over the thread's entries so that the loads of one pass are all in flight together: the kernel is a chain of dependent gathers otherwise)
+    uint32_t eM[kBlockMaxPer], eBin[kBlockMaxPer], eRank[kBlockMaxPer], eC[kBlockMaxPer], eK[kBlockMaxPer];
 #pragma unroll
     for (uint32_t i = 0; i < kBlockMaxPer; ++i) {
         const uint32_t idx = i * 256u + threadIdx.x;
+        eM[i] = 0xFFFFFFFFu;
+        if (idx < n) eM[i] = idx < nP ? perm[p0 + idx] : (extra[(size_t)J * extraCap + (idx - nP)] | 0x80000000u);
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < kBlockMaxPer; ++i) {
+        eC[i] = 0u; eK[i] = 0u;
+        if (eM[i] != 0xFFFFFFFFu) { const uint32_t m = eM[i] & kOrderMask; eC[i] = (color[m] & 0xFFFFu) | ((manInfo[m].x & 7u) << 16) | (manKept[m] ? 1u << 24 : 0u); eK[i] = keys[m]; }
+    }
+    for (uint32_t k = threadIdx.x; k < kBlockCells; k += 256) lutS[k] = cellBlock[k];
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < kBlockMaxPer; ++i) {
         eBin[i] = 0xFFFFFFFFu;
-        if (idx < n) {
-            const bool own = idx < nP;
-            const uint32_t m = own ? perm[p0 + idx] : extra[(size_t)J * extraCap + (idx - nP)];
-            const uint32_t c = color[m], cnt = manInfo[m].x & 7u;
-            const uint32_t k = keys[m];
-            const bool bnd = (k >> 24) != 0u && cellBlock[k & 0xFFFu] != cellBlock[(k >> 12) & 0xFFFu];
+        if (eM[i] != 0xFFFFFFFFu) {
+            const bool own = (eM[i] >> 31) == 0u;
+            const uint32_t m = eM[i] & kOrderMask;
+            const uint32_t craw = eC[i] & 0xFFFFu, c = craw == 0xFFFFu ? kUncolored : craw, cnt = (eC[i] >> 16) & 7u;
+            const uint32_t k = eK[i];
+            const bool bnd = (k >> 24) != 0u && lutS[k & 0xFFFu] != lutS[(k >> 12) & 0xFFFu];
             eM[i] = m | (bnd ? 0x40000000u : 0u) | (own ? 0u : 0x80000000u);
             if (c <= kOverflowColor && cnt >= 1u && cnt <= 4u) {
                 if (own) atomicAdd(&cls[binOf(c, cnt)], 1u);
@@ -190,7 +205,7 @@ __global__ __launch_bounds__(256) void k_block_sched(uint32_t lastRound, const u
                     }
                 }
             }
-            if (own && !manKept[m] && c <= kOverflowColor) {   // kept colours were entered by k_emit_manifolds
+            if (own && !((eC[i] >> 24) & 1u) && c <= kOverflowColor) {   // kept colours were entered by k_emit_manifolds
                 const uint64_t pk = (sc->partitioned ? pairsB : pairsA)[manPair[m]];
                 tableInsert(tab, tabMask, historyKey(nc, (uint32_t)((pk >> 29) & 0x1FFFFFFFull), (uint32_t)(pk & 0x1FFFFFFFull)), c);
             }
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(256) void k_block_sched(uint32_t lastRound, const u
 // pass's rows in flight into fixed ACC registers a152 .. a255, which the compiler never allocates: tests/test_capi_symbols.py).
 // meta (k_contact_init, block mode) = (bodyA, bodyB, packed versions, w); w: blockMetaW (kernels.hpp).
 // ------------------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kBlockWaves = 4;
+constexpr uint32_t kBlockWaves = 4;       // (the one-wave-per-SIMD variant; k_contact_solve_blocks8 runs 8 waves, two per SIMD)
 constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kBlockSpinLds = 1u << 22, kBlockSpinMem = 1u << 17;
 #define MI_ACC_LOAD2(A0, A1, addr) asm volatile("global_load_dwordx2 a[" #A0 ":" #A1 "], %0, off" : : "v"(addr) : "memory", "a" #A0, "a" #A1)
@@ -244,31 +259,43 @@ constexpr uint32_t kBlockSpinLds = 1u << 22, kBlockSpinMem = 1u << 17;
 // A home body's record in LDS, two 16-byte granules (v, tag), (w, tag).  Single ds_read_b128 / ds_write_b128 instructions (a lane's 16 bytes move in one LDS cycle),
 // issued by inline asm: the compiler must neither split them into 8-byte halves nor cache or reorder them — other waves of the workgroup poll these records.
 __device__ __forceinline__ uint32_t ldsAddr(const void* p) { return (uint32_t)(uintptr_t)p; }   // (a flat address of LDS carries the LDS offset in its low half)
-__device__ __forceinline__ void ldsLoadBody(uint32_t addr, f32x4& g0, f32x4& g1) {
-    asm volatile("ds_read_b128 %0, %2\n\tds_read_b128 %1, %2 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(g0), "=&v"(g1) : "v"(addr) : "memory");
+// The hand-over word of a record is a SEPARATE dword (recTag): the writer stores the two data granules, waits for them, then stores the tag; a reader loads the tag
+// FIRST and the granules behind it (LDS serves a wave's requests in order) — a tag that reads as expected means the data behind it is complete, whatever the LDS does
+// with the four dwords of a 16-byte access that runs into bank conflicts.
+__device__ __forceinline__ void ldsLoadBody(uint32_t addr, uint32_t tagAddr, f32x4& g0, f32x4& g1, uint32_t& tag) {
+    asm volatile("ds_read_b32 %2, %4\n\tds_read_b128 %0, %3\n\tds_read_b128 %1, %3 offset:16\n\ts_waitcnt lgkmcnt(0)" : "=&v"(g0), "=&v"(g1), "=&v"(tag) : "v"(addr), "v"(tagAddr) : "memory");
 }
-__device__ __forceinline__ void ldsLoadBodies(uint32_t addrA, uint32_t addrB, f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1) {
-    asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %4 offset:16\n\tds_read_b128 %2, %5\n\tds_read_b128 %3, %5 offset:16\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1) : "v"(addrA), "v"(addrB) : "memory");
+__device__ __forceinline__ void ldsLoadBodies(uint32_t addrA, uint32_t tagAddrA, uint32_t addrB, uint32_t tagAddrB, f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1, uint32_t& tagA, uint32_t& tagB) {
+    asm volatile("ds_read_b32 %4, %8\n\tds_read_b32 %5, %9\n\tds_read_b128 %0, %6\n\tds_read_b128 %1, %6 offset:16\n\tds_read_b128 %2, %7\n\tds_read_b128 %3, %7 offset:16\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(b0), "=&v"(b1), "=&v"(tagA), "=&v"(tagB) : "v"(addrA), "v"(addrB), "v"(tagAddrA), "v"(tagAddrB) : "memory");
 }
-__device__ __forceinline__ void ldsStoreBody(uint32_t addr, f32x4 g0, f32x4 g1) {   // (v, tag) first, (w, tag) second: LDS serves a wave's requests in order
-    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16" : : "v"(addr), "v"(g0), "v"(g1) : "memory");
+__device__ __forceinline__ void ldsStoreBody(uint32_t addr, uint32_t tagAddr, f32x4 g0, f32x4 g1, uint32_t tag) {
+    asm volatile("ds_write_b128 %0, %1\n\tds_write_b128 %0, %2 offset:16\n\ts_waitcnt lgkmcnt(0)\n\tds_write_b32 %3, %4" : : "v"(addr), "v"(g0), "v"(g1), "v"(tagAddr), "v"(tag) : "memory");
 }
-
-__device__ __forceinline__ void waitVmcntSmall(uint32_t n) {
-    switch (n) {
+__device__ __forceinline__ void waitVmcntSmall(uint32_t n) {   // wait until at most n (even; more than 14: 14 — waiting for more than needed is always safe) of the newest requests are outstanding
+    switch (n < 14u ? n : 14u) {
         case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
         case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 }
-__global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_contact_solve_blocks(
+template <uint32_t WAVES>
+__device__ __forceinline__ void blockSolver(
     uint32_t sweeps, uint32_t tilesPerBlock, uint32_t hashSize /* power of two */, uint32_t bodyCap, uint32_t maxSlots /* tiles per wave, <= 16 */, uint32_t maxPasses /* per wave */,
     uint32_t impCap /* accumulated impulses (contacts) per wave */,
     const uint4* __restrict__ tileInfo, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal, const float2* __restrict__ slotMass,
     const float4* __restrict__ rows, const float4* gVel /* initial velocities, tag 0 (k_integrate_forces) */, float4* gVelOut /* final velocities */,
-    float4* mail /* [bodies + 1][kMailRanks][2 parities][2] */, StepScalars* sc, BlockState* bs, uint32_t faultInject) {
+    float4* mail /* [bodies + 1][kMailRanks][2 parities][2] */, StepScalars* sc, BlockState* bs, uint32_t faultInject,
+    uint32_t dbg /* development knock-outs (timing only, results are garbage): 1 no dependency waits, 2 no ghost loads, 4 no row loads, 8 no arithmetic, 16 no exports */,
+    unsigned long long* dbgTimes /* development: [block][wave][8] wall-clock stamps (100 MHz), or null */) {
+    unsigned long long* stampAt = dbgTimes ? dbgTimes + ((size_t)blockIdx.x * WAVES + (threadIdx.x >> 6)) * 8u : nullptr;
+#define MI_BSTAMP(i) do { if (stampAt && (threadIdx.x & 63u) == 0u) stampAt[i] = wall_clock64(); } while (0)
+    MI_BSTAMP(0);
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
     __shared__ uint32_t sCount, sErr;
     const uint32_t J = blockIdx.x, T = tilesPerBlock;
@@ -276,17 +303,19 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
     // ---- LDS carve-up
     float4* rec = reinterpret_cast<float4*>(ldsRaw);                                   // [bodyCap][2]: (v, tag), (w, tag)
     uint32_t* recBody = reinterpret_cast<uint32_t*>(rec + 2u * (size_t)bodyCap);        // [bodyCap] body of the record
+    uint32_t* recTag = recBody + bodyCap;                                               // [bodyCap] version of the record = updates its body has received (the hand-over word)
     // the hash (body -> record) is only needed while the lists are set up: it shares its bytes with the accumulated impulses of the four waves
-    unsigned char* uni = ldsRaw + (((size_t)bodyCap * 36u + 15u) & ~(size_t)15u);
+    unsigned char* uni = ldsRaw + (((size_t)bodyCap * 40u + 15u) & ~(size_t)15u);
     uint32_t* hKey = reinterpret_cast<uint32_t*>(uni);                                  // [hashSize] body of the slot
     uint16_t* hVal = reinterpret_cast<uint16_t*>(hKey + hashSize);                      // [hashSize] record of the slot
-    const size_t uniBytes = (((size_t)hashSize * 6u > (size_t)kBlockWaves * impCap * 8u ? (size_t)hashSize * 6u : (size_t)kBlockWaves * impCap * 8u) + 15u) & ~(size_t)15u;
+    const size_t uniBytes = (((size_t)hashSize * 6u > (size_t)WAVES * impCap * 8u ? (size_t)hashSize * 6u : (size_t)WAVES * impCap * 8u) + 15u) & ~(size_t)15u;
     float2* lImp = reinterpret_cast<float2*>(uni) + (size_t)wave * impCap;              // [impCap] lane-contiguous: a lane's contacts at lOff .. lOff + cnt
-    const size_t waveBytes = ((size_t)maxSlots * 64u * 16u + (size_t)maxPasses * 16u + (size_t)maxSlots * 64u * 2u + 15u) & ~(size_t)15u;
+    const size_t waveBytes = ((size_t)maxSlots * 64u * 16u + (size_t)maxPasses * 16u + (size_t)maxSlots * 64u * 2u + (size_t)maxSlots * 16u + 15u) & ~(size_t)15u;
     unsigned char* wb = uni + uniBytes + (size_t)wave * waveBytes;
     uint4* lMeta = reinterpret_cast<uint4*>(wb);                                        // [maxSlots][64]
-    uint4* lPass = lMeta + (size_t)maxSlots * 64u;                                      // [maxPasses] (slot | lo << 8 | hi << 16 | maxcnt << 24, first contact-tile, boundary, tile)
+    uint4* lPass = lMeta + (size_t)maxSlots * 64u;                                      // [maxPasses] (slot | lo << 8 | hi << 16 | most contacts of the group << 24, -, boundary | most contacts of the tile << 8, tile)
     uint16_t* lOff = reinterpret_cast<uint16_t*>(lPass + maxPasses);                    // [maxSlots][64] first impulse of the lane
+    uint4* lSlot = reinterpret_cast<uint4*>(lOff + (size_t)maxSlots * 64u);             // [maxSlots] (tile, most contacts of a lane, first pass, passes)
     for (uint32_t k = threadIdx.x; k < hashSize; k += blockDim.x) hKey[k] = kHashEmpty;
     if (threadIdx.x == 0) { sCount = 0u; sErr = 0u; }
     __syncthreads();
@@ -294,11 +323,11 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
     // ---- prologue 1: this wave's tiles (t = wave, wave + 4, ...), their lanes' home bodies into the hash
     uint32_t mySlots = 0;
     uint32_t hsA[16], hsB[16];   // hash slot of the lane's home bodies per tile slot (compile-time indexed)
-    bool fail = T > 16u * kBlockWaves || maxSlots > 16u;
+    bool fail = T > 16u * WAVES || maxSlots > 16u;
 #pragma unroll
     for (uint32_t s = 0; s < 16; ++s) {
         hsA[s] = kHashEmpty; hsB[s] = kHashEmpty;
-        const uint32_t t = wave + s * kBlockWaves;
+        const uint32_t t = wave + s * WAVES;
         if (t < T && s < maxSlots && !fail) {
             const uint4 ti = tileInfo[(size_t)J * T + t];
             const uint32_t count = ti.z & 0xFFu;
@@ -328,6 +357,7 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
         }
     }
     if (fail) sErr = 4u;
+    MI_BSTAMP(1);
     __syncthreads();
     // ---- prologue 2: hash slots -> records, initial velocities
     for (uint32_t k = threadIdx.x; k < hashSize; k += blockDim.x) {
@@ -336,22 +366,23 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
             const uint32_t idx = atomicAdd(&sCount, 1u);
             hVal[k] = (uint16_t)idx;
             if (idx < bodyCap) {
-                recBody[idx] = body;
+                recBody[idx] = body; recTag[idx] = 0u;
                 const float4 v = gVel[2 * (size_t)body], w = gVel[2 * (size_t)body + 1];
                 rec[2u * idx] = make_float4(v.x, v.y, v.z, __uint_as_float(0u));
                 rec[2u * idx + 1u] = make_float4(w.x, w.y, w.z, __uint_as_float(0u));
             }
         }
     }
+    MI_BSTAMP(2);
     __syncthreads();
     if (threadIdx.x == 0) { atomicMax(&bs->needBodies, sCount); if (sCount > bodyCap) sErr = 5u; }
     // ---- prologue 3: per-slot constants into LDS (home bodies as LDS addresses of their records), impulse offsets, the passes of this wave
     uint32_t numPasses = 0, impUsed = 0;
-    const uint32_t recBase = ldsAddr(rec);
+    const uint32_t recBase = ldsAddr(rec), tagBase = ldsAddr(recTag);
 #pragma unroll
     for (uint32_t s = 0; s < 16; ++s) {
         if (s < mySlots) {
-            const uint32_t t = wave + s * kBlockWaves;
+            const uint32_t t = wave + s * WAVES;
             const uint4 ti = tileInfo[(size_t)J * T + t];
             const uint32_t count = ti.z & 0xFFu;
             uint4 m = make_uint4(0u, 0u, 0u, 0u);
@@ -371,42 +402,154 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
             const uint32_t prev = (uint32_t)__shfl_up((int)gk, 1, 64);
             const bool start = lane < count && (lane == 0u || prev != gk);
             unsigned long long starts = __ballot(start);
+            const uint32_t tmc = __ballot(cnt >= 4u) ? 4u : __ballot(cnt >= 3u) ? 3u : __ballot(cnt >= 2u) ? 2u : 1u;
+            const uint32_t passBegin = numPasses;
             while (starts) {
                 const uint32_t lo = (uint32_t)__ffsll((long long)starts) - 1u;
                 starts &= starts - 1ull;
                 const uint32_t hi = starts ? (uint32_t)__ffsll((long long)starts) - 1u : count;
                 const uint32_t mc = (uint32_t)__shfl((int)cnt, (int)lo, 64);
                 const uint32_t bndG = (uint32_t)__shfl((int)((m.w >> 9) & 1u), (int)lo, 64);
-                if (lane == 0 && numPasses < maxPasses) lPass[numPasses] = make_uint4(s | (lo << 8) | (hi << 16) | (mc << 24), ti.w, bndG, ti.x);
+                if (lane == 0 && numPasses < maxPasses) lPass[numPasses] = make_uint4(s | (lo << 8) | (hi << 16) | (mc << 24), ti.w, bndG | (tmc << 8), ti.x);
                 ++numPasses;
             }
+            if (lane == 0) lSlot[s] = make_uint4(ti.x, tmc, passBegin, numPasses - passBegin);
         }
     }
     if (lane == 0) { atomicMax(&bs->needPasses, numPasses); atomicMax(&bs->needImp, impUsed); if (numPasses > maxPasses || impUsed > impCap) sErr = 6u; }
+    MI_BSTAMP(3);
     __syncthreads();   // (every wave is done with the hash: its bytes become the impulses)
     for (uint32_t k = lane; k < impCap; k += 64u) lImp[k] = make_float2(0.f, 0.f);
     __syncthreads();
     if (sErr || (faultInject && J == 1u)) { if (threadIdx.x == 0) { sc->solveError = sErr ? sErr : 1u; bs->overflow = 1u; } return; }   // nothing persistent has been written: the host re-runs the step on another path
+    MI_BSTAMP(4);
     if (numPasses) {
+    if constexpr (WAVES == 8u) {
+    // ---- main loop, two waves per SIMD (256 registers each): a tile's rows stay in the ACC registers a0 .. a103 while its passes run and are read contact by contact;
+    // the next tile's rows are requested when the last pass is through — the wave then waits a memory round trip, which is the other wave's time on the SIMD.
+    auto fetchRows = [&](uint32_t slot) {
+        const uint4 sd = lSlot[slot];
+        const uint32_t tmc = sd.y;
+        const uint32_t cnt = lMeta[slot * 64u + lane].w & 7u;           // (0: padding lane; some lane has tmc contacts: none of the predicated groups below is empty)
+        const size_t at = (size_t)sd.x * 64u + lane;
+        const float4* row = rows + (size_t)sd.x * 4u * (kRows * 64u) + lane;
+        if (0u < cnt) { MI_ACC_LOAD(0, 1, 2, 3, slotNormal + at); MI_ACC_LOAD2(4, 5, slotMass + at); }
+        if (0u < tmc) { if (0u < cnt) { MI_ACC_LOAD(8, 9, 10, 11, row + 0u * 64u); MI_ACC_LOAD(12, 13, 14, 15, row + 1u * 64u); MI_ACC_LOAD(16, 17, 18, 19, row + 2u * 64u); MI_ACC_LOAD(20, 21, 22, 23, row + 3u * 64u); MI_ACC_LOAD(24, 25, 26, 27, row + 4u * 64u); MI_ACC_LOAD(28, 29, 30, 31, row + 5u * 64u); } }
+        if (1u < tmc) { if (1u < cnt) { MI_ACC_LOAD(32, 33, 34, 35, row + 6u * 64u); MI_ACC_LOAD(36, 37, 38, 39, row + 7u * 64u); MI_ACC_LOAD(40, 41, 42, 43, row + 8u * 64u); MI_ACC_LOAD(44, 45, 46, 47, row + 9u * 64u); MI_ACC_LOAD(48, 49, 50, 51, row + 10u * 64u); MI_ACC_LOAD(52, 53, 54, 55, row + 11u * 64u); } }
+        if (2u < tmc) { if (2u < cnt) { MI_ACC_LOAD(56, 57, 58, 59, row + 12u * 64u); MI_ACC_LOAD(60, 61, 62, 63, row + 13u * 64u); MI_ACC_LOAD(64, 65, 66, 67, row + 14u * 64u); MI_ACC_LOAD(68, 69, 70, 71, row + 15u * 64u); MI_ACC_LOAD(72, 73, 74, 75, row + 16u * 64u); MI_ACC_LOAD(76, 77, 78, 79, row + 17u * 64u); } }
+        if (3u < tmc) { if (3u < cnt) { MI_ACC_LOAD(80, 81, 82, 83, row + 18u * 64u); MI_ACC_LOAD(84, 85, 86, 87, row + 19u * 64u); MI_ACC_LOAD(88, 89, 90, 91, row + 20u * 64u); MI_ACC_LOAD(92, 93, 94, 95, row + 21u * 64u); MI_ACC_LOAD(96, 97, 98, 99, row + 22u * 64u); MI_ACC_LOAD(100, 101, 102, 103, row + 23u * 64u); } }
+    };
+    if (!(dbg & (4u | 0x20u))) fetchRows(0);
+    bool dead = false;
+    for (uint32_t it = 0; it < sweeps && !dead; ++it)
+        for (uint32_t s = 0; s < mySlots && !dead; ++s) {
+            const uint4 sd = lSlot[s];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's rows (requested a tile ago) — and everything older
+            float4 nf; float2 mass;
+            if (dbg & 0x20u) { fetchRows(s); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+            MI_ACC_READ(nf, 0, 1, 2, 3); MI_ACC_READ2(mass, 4, 5);
+            const uint4 meta = lMeta[s * 64u + lane];
+            float2* li = lImp + lOff[s * 64u + lane];
+            const bool homeIsB = (meta.w >> 10) & 1u;
+            const uint32_t pk = meta.z;
+            const uint32_t degA = (pk >> 7) & 127u, degB = (pk >> 21) & 127u;
+            const uint32_t expA = it * degA + (pk & 127u), expB = it * degB + ((pk >> 14) & 127u);
+            for (uint32_t pass = sd.z; pass < sd.z + sd.w && !dead; ++pass) {
+                const uint4 pd = lPass[pass];
+                const uint32_t lo = (pd.x >> 8) & 0xFFu, hi = (pd.x >> 16) & 0xFFu, mc = pd.x >> 24;
+                const bool bndG = (pd.z & 1u) != 0u;
+                const bool act = lane >= lo && lane < hi;
+                if (dbg & 0x20u) { fetchRows(s); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MI_ACC_READ(nf, 0, 1, 2, 3); MI_ACC_READ2(mass, 4, 5); }
+                const uint32_t cnt = act ? (meta.w & 7u) : 0u;
+                const bool ghostA = act && bndG && homeIsB, ghostB = act && bndG && !homeIsB;
+                const bool ldsA = act && !ghostA, ldsB = act && !ghostB;
+                const bool updA = ldsA && degA != 0u, updB = ldsB && degB != 0u;
+                const uint32_t gBody = ghostA ? meta.x : meta.y, gExp = ghostA ? expA : expB, gRank = (meta.w >> 21) & 7u;
+                const float4* gSrc = gExp == 0u ? gVel + 2 * (size_t)gBody : mail + ((((size_t)gBody * kMailRanks + gRank) * 2u + (it & 1u)) * 2u);
+                const uint32_t gTag = gExp == 0u ? 0u : (stamp | gExp);
+                f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
+                const bool ghostLoads = bndG && !(dbg & 2u);
+                if (ghostLoads) { if (act) { issueGranuleSc1(gSrc, g0); issueGranuleSc1(gSrc + 1, g1); } }
+                f32x4 a0, a1, b0, b1;
+                const uint32_t adA = recBase + 32u * (ldsA ? meta.x : 0u), adB = recBase + 32u * (ldsB ? meta.y : 0u);
+                uint32_t tA, tB;
+                const uint32_t taA = tagBase + 4u * (ldsA ? meta.x : 0u), taB = tagBase + 4u * (ldsB ? meta.y : 0u);
+                ldsLoadBodies(adA, taA, adB, taB, a0, a1, b0, b1, tA, tB);
+                if (ghostLoads) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); landed(g0); landed(g1); }
+                bool okA = !updA || tA == expA;
+                bool okB = !updB || tB == expB;
+                bool okG = !(ghostA || ghostB) || (__float_as_uint(g0.w) == gTag && __float_as_uint(g1.w) == gTag);
+                uint32_t budget = bndG ? kBlockSpinMem : kBlockSpinLds;
+                if (dbg & 1u) { okA = okB = okG = true; }
+                if (dbg & 2u) okG = true;
+                while (__ballot(!(okA && okB && okG)) != 0ull) {
+                    if (!okA) { ldsLoadBody(adA, taA, a0, a1, tA); okA = tA == expA; }
+                    if (!okB) { ldsLoadBody(adB, taB, b0, b1, tB); okB = tB == expB; }
+                    if (bndG) {
+                        if (!okG) { issueGranuleSc1(gSrc, g0); issueGranuleSc1(gSrc + 1, g1); }
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                        landed(g0); landed(g1);
+                        if (!okG) okG = __float_as_uint(g0.w) == gTag && __float_as_uint(g1.w) == gTag;
+                    } else __builtin_amdgcn_s_sleep(1);   // (the other wave of this SIMD may be the one this one waits for)
+                    if ((--budget & 255u) == 0u) {
+                        if (budget == 0u) { sc->solveError = 1u; __hip_atomic_store(&sErr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+                        if (budget == 0u || __hip_atomic_load(&sErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || __hip_atomic_load(&sc->solveError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { dead = true; break; }
+                    }
+                }
+                if (dead) break;
+                if (ghostA) { a0 = g0; a1 = g1; }
+                if (ghostB) { b0 = g0; b1 = g1; }
+                P3 pv, pw;
+                pv.x = pk2(a0.x, b0.x); pv.y = pk2(a0.y, b0.y); pv.z = pk2(a0.z, b0.z);
+                pw.x = pk2(a1.x, b1.x); pw.y = pk2(a1.y, b1.y); pw.z = pk2(a1.z, b1.z);
+                const f32x2 sMass = pk2(-mass.x, mass.y);
+                    if (0u < mc && !(dbg & 8u)) { if (0u < cnt) { ContactRows c; MI_ACC_READ(c.r[0], 8, 9, 10, 11); MI_ACC_READ(c.r[1], 12, 13, 14, 15); MI_ACC_READ(c.r[2], 16, 17, 18, 19); MI_ACC_READ(c.r[3], 20, 21, 22, 23); MI_ACC_READ(c.r[4], 24, 25, 26, 27); MI_ACC_READ(c.r[5], 28, 29, 30, 31); float2 im = li[0]; solveOnePk(c, nf, im, sMass, pv, pw); li[0] = im; } }
+                    if (1u < mc && !(dbg & 8u)) { if (1u < cnt) { ContactRows c; MI_ACC_READ(c.r[0], 32, 33, 34, 35); MI_ACC_READ(c.r[1], 36, 37, 38, 39); MI_ACC_READ(c.r[2], 40, 41, 42, 43); MI_ACC_READ(c.r[3], 44, 45, 46, 47); MI_ACC_READ(c.r[4], 48, 49, 50, 51); MI_ACC_READ(c.r[5], 52, 53, 54, 55); float2 im = li[1]; solveOnePk(c, nf, im, sMass, pv, pw); li[1] = im; } }
+                    if (2u < mc && !(dbg & 8u)) { if (2u < cnt) { ContactRows c; MI_ACC_READ(c.r[0], 56, 57, 58, 59); MI_ACC_READ(c.r[1], 60, 61, 62, 63); MI_ACC_READ(c.r[2], 64, 65, 66, 67); MI_ACC_READ(c.r[3], 68, 69, 70, 71); MI_ACC_READ(c.r[4], 72, 73, 74, 75); MI_ACC_READ(c.r[5], 76, 77, 78, 79); float2 im = li[2]; solveOnePk(c, nf, im, sMass, pv, pw); li[2] = im; } }
+                    if (3u < mc && !(dbg & 8u)) { if (3u < cnt) { ContactRows c; MI_ACC_READ(c.r[0], 80, 81, 82, 83); MI_ACC_READ(c.r[1], 84, 85, 86, 87); MI_ACC_READ(c.r[2], 88, 89, 90, 91); MI_ACC_READ(c.r[3], 92, 93, 94, 95); MI_ACC_READ(c.r[4], 96, 97, 98, 99); MI_ACC_READ(c.r[5], 100, 101, 102, 103); float2 im = li[3]; solveOnePk(c, nf, im, sMass, pv, pw); li[3] = im; } }
+                const uint32_t nA = expA + 1u, nB = expB + 1u;
+                if (updA) { f32x4 h0 = {pv.x.x, pv.y.x, pv.z.x, __uint_as_float(nA)}, h1 = {pw.x.x, pw.y.x, pw.z.x, __uint_as_float(nA)}; ldsStoreBody(adA, taA, h0, h1, nA); }
+                if (updB) { f32x4 h0 = {pv.x.y, pv.y.y, pv.z.y, __uint_as_float(nB)}, h1 = {pw.x.y, pw.y.y, pw.z.y, __uint_as_float(nB)}; ldsStoreBody(adB, taB, h0, h1, nB); }
+                const uint32_t eA = (meta.w >> 11) & 31u, eB = (meta.w >> 16) & 31u;
+                const bool exports = !(dbg & 16u);
+                if (exports && updA && (eA & 1u)) {
+                    const uint32_t par = (eA & 2u) ? (it & 1u) : ((it + 1u) & 1u);
+                    float4* dst = mail + ((((size_t)recBody[meta.x] * kMailRanks + (eA >> 2)) * 2u + par) * 2u);
+                    const float t = __uint_as_float(stamp | nA);
+                    f32x4 h0 = {pv.x.x, pv.y.x, pv.z.x, t}, h1 = {pw.x.x, pw.y.x, pw.z.x, t};
+                    storeGranuleSc1(dst, h0); storeGranuleSc1(dst + 1, h1);
+                }
+                if (exports && updB && (eB & 1u)) {
+                    const uint32_t par = (eB & 2u) ? (it & 1u) : ((it + 1u) & 1u);
+                    float4* dst = mail + ((((size_t)recBody[meta.y] * kMailRanks + (eB >> 2)) * 2u + par) * 2u);
+                    const float t = __uint_as_float(stamp | nB);
+                    f32x4 h0 = {pv.x.y, pv.y.y, pv.z.y, t}, h1 = {pw.x.y, pw.y.y, pw.z.y, t};
+                    storeGranuleSc1(dst, h0); storeGranuleSc1(dst + 1, h1);
+                }
+            }
+            // the next tile's rows: the ACC registers are free again
+            if (!dead && !(dbg & (4u | 0x20u)) && (mySlots > 1u || it + 1u < sweeps)) fetchRows(s + 1u < mySlots ? s + 1u : 0u);
+        }
+    } else {
     // ---- main loop: software pipeline over (sweep, pass); the next pass's rows are requested while this pass waits for its bodies.
     // Everything the loop reads from global memory goes through inline asm into fixed ACC registers, so the only vmcnt arithmetic is the one written here.
-    auto fetchRows = [&](uint32_t pass) -> uint32_t {
-        const uint4 pd = lPass[pass];
-        const uint32_t s = pd.x & 0xFFu, lo = (pd.x >> 8) & 0xFFu, hi = (pd.x >> 16) & 0xFFu, mc = pd.x >> 24;
-        const bool act = lane >= lo && lane < hi;
-        const uint32_t cnt = act ? (lMeta[s * 64u + lane].w & 7u) : 0u;   // (the first lane of the range has mc contacts: none of the predicated groups below is empty)
-        const size_t at = (size_t)pd.w * 64u + lane;
-        const float4* row = rows + (size_t)pd.y * (kRows * 64u) + lane;
-        if (act) { MI_ACC_LOAD(152, 153, 154, 155, slotNormal + at); MI_ACC_LOAD2(156, 157, slotMass + at); }
-        if (0u < mc) { if (0u < cnt) { MI_ACC_LOAD(160, 161, 162, 163, row + 0u * 64u); MI_ACC_LOAD(164, 165, 166, 167, row + 1u * 64u); MI_ACC_LOAD(168, 169, 170, 171, row + 2u * 64u);
-                                       MI_ACC_LOAD(172, 173, 174, 175, row + 3u * 64u); MI_ACC_LOAD(176, 177, 178, 179, row + 4u * 64u); MI_ACC_LOAD(180, 181, 182, 183, row + 5u * 64u); } }
-        if (1u < mc) { if (1u < cnt) { MI_ACC_LOAD(184, 185, 186, 187, row + 6u * 64u); MI_ACC_LOAD(188, 189, 190, 191, row + 7u * 64u); MI_ACC_LOAD(192, 193, 194, 195, row + 8u * 64u);
-                                       MI_ACC_LOAD(196, 197, 198, 199, row + 9u * 64u); MI_ACC_LOAD(200, 201, 202, 203, row + 10u * 64u); MI_ACC_LOAD(204, 205, 206, 207, row + 11u * 64u); } }
-        if (2u < mc) { if (2u < cnt) { MI_ACC_LOAD(208, 209, 210, 211, row + 12u * 64u); MI_ACC_LOAD(212, 213, 214, 215, row + 13u * 64u); MI_ACC_LOAD(216, 217, 218, 219, row + 14u * 64u);
-                                       MI_ACC_LOAD(220, 221, 222, 223, row + 15u * 64u); MI_ACC_LOAD(224, 225, 226, 227, row + 16u * 64u); MI_ACC_LOAD(228, 229, 230, 231, row + 17u * 64u); } }
-        if (3u < mc) { if (3u < cnt) { MI_ACC_LOAD(232, 233, 234, 235, row + 18u * 64u); MI_ACC_LOAD(236, 237, 238, 239, row + 19u * 64u); MI_ACC_LOAD(240, 241, 242, 243, row + 20u * 64u);
-                                       MI_ACC_LOAD(244, 245, 246, 247, row + 21u * 64u); MI_ACC_LOAD(248, 249, 250, 251, row + 22u * 64u); MI_ACC_LOAD(252, 253, 254, 255, row + 23u * 64u); } }
-        return mc * kRows + 2u;
+    uint32_t dbgLo = 0u, dbgHi = 64u;
+    auto fetchRows = [&](uint32_t slot) -> uint32_t {
+        const uint4 sd = lSlot[slot];                                   // (tile, most contacts of a lane, ..)
+        const uint32_t tmc = sd.y;
+        const uint32_t cnt = (lane >= dbgLo && lane < dbgHi) ? lMeta[slot * 64u + lane].w & 7u : 0u;           // (0: padding lane; some lane has tmc contacts: none of the predicated groups below is empty)
+        const size_t at = (size_t)sd.x * 64u + lane;
+        const float4* row = rows + (size_t)sd.x * 4u * (kRows * 64u) + lane;
+        if (0u < cnt) { MI_ACC_LOAD(152, 153, 154, 155, slotNormal + at); MI_ACC_LOAD2(156, 157, slotMass + at); }
+        if (0u < tmc) { if (0u < cnt) { MI_ACC_LOAD(160, 161, 162, 163, row + 0u * 64u); MI_ACC_LOAD(164, 165, 166, 167, row + 1u * 64u); MI_ACC_LOAD(168, 169, 170, 171, row + 2u * 64u);
+                                        MI_ACC_LOAD(172, 173, 174, 175, row + 3u * 64u); MI_ACC_LOAD(176, 177, 178, 179, row + 4u * 64u); MI_ACC_LOAD(180, 181, 182, 183, row + 5u * 64u); } }
+        if (1u < tmc) { if (1u < cnt) { MI_ACC_LOAD(184, 185, 186, 187, row + 6u * 64u); MI_ACC_LOAD(188, 189, 190, 191, row + 7u * 64u); MI_ACC_LOAD(192, 193, 194, 195, row + 8u * 64u);
+                                        MI_ACC_LOAD(196, 197, 198, 199, row + 9u * 64u); MI_ACC_LOAD(200, 201, 202, 203, row + 10u * 64u); MI_ACC_LOAD(204, 205, 206, 207, row + 11u * 64u); } }
+        if (2u < tmc) { if (2u < cnt) { MI_ACC_LOAD(208, 209, 210, 211, row + 12u * 64u); MI_ACC_LOAD(212, 213, 214, 215, row + 13u * 64u); MI_ACC_LOAD(216, 217, 218, 219, row + 14u * 64u);
+                                        MI_ACC_LOAD(220, 221, 222, 223, row + 15u * 64u); MI_ACC_LOAD(224, 225, 226, 227, row + 16u * 64u); MI_ACC_LOAD(228, 229, 230, 231, row + 17u * 64u); } }
+        if (3u < tmc) { if (3u < cnt) { MI_ACC_LOAD(232, 233, 234, 235, row + 18u * 64u); MI_ACC_LOAD(236, 237, 238, 239, row + 19u * 64u); MI_ACC_LOAD(240, 241, 242, 243, row + 20u * 64u);
+                                        MI_ACC_LOAD(244, 245, 246, 247, row + 21u * 64u); MI_ACC_LOAD(248, 249, 250, 251, row + 22u * 64u); MI_ACC_LOAD(252, 253, 254, 255, row + 23u * 64u); } }
+        return tmc * kRows + 2u;
     };
     auto readRows = [&](ContactRows* cur, uint32_t mc, float4& nf, float2& mass) {
         MI_ACC_READ(nf, 152, 153, 154, 155); MI_ACC_READ2(mass, 156, 157);
@@ -419,14 +562,16 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
         if (3u < mc) { MI_ACC_READ(cur[3].r[0], 232, 233, 234, 235); MI_ACC_READ(cur[3].r[1], 236, 237, 238, 239); MI_ACC_READ(cur[3].r[2], 240, 241, 242, 243);
                        MI_ACC_READ(cur[3].r[3], 244, 245, 246, 247); MI_ACC_READ(cur[3].r[4], 248, 249, 250, 251); MI_ACC_READ(cur[3].r[5], 252, 253, 254, 255); }
     };
-    (void)fetchRows(0);
+    (void)fetchRows(lPass[0].x & 0xFFu);
     bool dead = false;
+    ContactRows cur[4]; float4 nf = make_float4(0.f, 0.f, 0.f, 0.f); float2 mass = make_float2(0.f, 0.f);
+    uint32_t curSlot = 0xFFFFFFFFu; bool firstOfTile = false;
     uint32_t pendingStores = 0;   // export store instructions the previous pass issued
     for (uint32_t it = 0; it < sweeps && !dead; ++it)
         for (uint32_t pass = 0; pass < numPasses && !dead; ++pass) {
             const uint4 pd = lPass[pass];
             const uint32_t s = pd.x & 0xFFu, lo = (pd.x >> 8) & 0xFFu, hi = (pd.x >> 16) & 0xFFu, mc = pd.x >> 24;
-            const bool bndG = pd.z != 0u;
+            const bool bndG = (pd.z & 1u) != 0u;
             const bool act = lane >= lo && lane < hi;
             const uint4 meta = lMeta[s * 64u + lane];
             const uint32_t cnt = act ? (meta.w & 7u) : 0u;
@@ -446,34 +591,29 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
             // the rows of this pass are the OLDEST requests in flight; behind them the export stores of the previous pass (write-through: their
             // acknowledgements take a memory round trip and nothing here needs them) and, in a boundary pass, the two ghost loads of every lane
             if (bndG) { if (act) { issueGranuleSc1(gSrc, g0); issueGranuleSc1(gSrc + 1, g1); } }
-            waitVmcntSmall(pendingStores + (bndG ? 2u : 0u));
-            ContactRows cur[4]; float4 nf; float2 mass;
-            readRows(cur, mc, nf, mass);
+            firstOfTile = s != curSlot || numPasses == 1u || lPass[pass == 0u ? numPasses - 1u : pass - 1u].x % 256u != s;
+            if (firstOfTile) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); readRows(cur, pd.z >> 8, nf, mass); curSlot = s; }
             const bool more = pass + 1u < numPasses || it + 1u < sweeps;
             uint32_t inFlight = 0;
-            if (more) inFlight = fetchRows(pass + 1u < numPasses ? pass + 1u : 0u);
+            if (more && firstOfTile) inFlight = fetchRows(s + 1u < mySlots ? s + 1u : 0u);
             // home bodies from LDS
             f32x4 a0, a1, b0, b1;
             const uint32_t adA = recBase + 32u * (ldsA ? meta.x : 0u), adB = recBase + 32u * (ldsB ? meta.y : 0u);
-            ldsLoadBodies(adA, adB, a0, a1, b0, b1);
+            uint32_t tA, tB;
+            const uint32_t taA = tagBase + 4u * (ldsA ? meta.x : 0u), taB = tagBase + 4u * (ldsB ? meta.y : 0u);
+            ldsLoadBodies(adA, taA, adB, taB, a0, a1, b0, b1, tA, tB);
             if (bndG) {
                 // the ghost loads are older than the prefetch: they have landed once at most `inFlight` loads are outstanding
-                switch (inFlight) {
-                    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-                    case 14: asm volatile("s_waitcnt vmcnt(14)" ::: "memory"); break;
-                    case 20: asm volatile("s_waitcnt vmcnt(20)" ::: "memory"); break;
-                    case 26: asm volatile("s_waitcnt vmcnt(26)" ::: "memory"); break;
-                    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 landed(g0); landed(g1);
             }
-            bool okA = !updA || (__float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA);
-            bool okB = !updB || (__float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB);
+            bool okA = !updA || tA == expA;
+            bool okB = !updB || tB == expB;
             bool okG = !(ghostA || ghostB) || (__float_as_uint(g0.w) == gTag && __float_as_uint(g1.w) == gTag);
             uint32_t budget = bndG ? kBlockSpinMem : kBlockSpinLds;
             while (__ballot(!(okA && okB && okG)) != 0ull) {
-                if (!okA) { ldsLoadBody(adA, a0, a1); okA = __float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA; }
-                if (!okB) { ldsLoadBody(adB, b0, b1); okB = __float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB; }
+                if (!okA) { ldsLoadBody(adA, taA, a0, a1, tA); okA = tA == expA; }
+                if (!okB) { ldsLoadBody(adB, taB, b0, b1, tB); okB = tB == expB; }
                 if (bndG) {
                     if (!okG) { issueGranuleSc1(gSrc, g0); issueGranuleSc1(gSrc + 1, g1); }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -506,8 +646,8 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
             }
             // publish: home bodies into LDS; exports write-through into the mailbox of the boundary manifold that comes next on the body
             const uint32_t nA = expA + 1u, nB = expB + 1u;
-            if (updA) { f32x4 h0 = {pv.x.x, pv.y.x, pv.z.x, __uint_as_float(nA)}, h1 = {pw.x.x, pw.y.x, pw.z.x, __uint_as_float(nA)}; ldsStoreBody(adA, h0, h1); }
-            if (updB) { f32x4 h0 = {pv.x.y, pv.y.y, pv.z.y, __uint_as_float(nB)}, h1 = {pw.x.y, pw.y.y, pw.z.y, __uint_as_float(nB)}; ldsStoreBody(adB, h0, h1); }
+            if (updA) { f32x4 h0 = {pv.x.x, pv.y.x, pv.z.x, __uint_as_float(nA)}, h1 = {pw.x.x, pw.y.x, pw.z.x, __uint_as_float(nA)}; ldsStoreBody(adA, taA, h0, h1, nA); }
+            if (updB) { f32x4 h0 = {pv.x.y, pv.y.y, pv.z.y, __uint_as_float(nB)}, h1 = {pw.x.y, pw.y.y, pw.z.y, __uint_as_float(nB)}; ldsStoreBody(adB, taB, h0, h1, nB); }
             const uint32_t eA = (meta.w >> 11) & 31u, eB = (meta.w >> 16) & 31u;
             pendingStores = (__ballot(updA && (eA & 1u)) != 0ull ? 2u : 0u) + (__ballot(updB && (eB & 1u)) != 0ull ? 2u : 0u);   // (a branch no lane takes issues nothing)
             if (updA && (eA & 1u)) {
@@ -526,7 +666,10 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
             }
         }
     }
+    }
+    MI_BSTAMP(5);
     __syncthreads();
+    MI_BSTAMP(6);
     // ---- epilogue: the home bodies' final velocities
     const uint32_t nRec = min(sCount, bodyCap);
     for (uint32_t k = threadIdx.x; k < nRec; k += blockDim.x) {
@@ -535,6 +678,18 @@ __global__ __launch_bounds__(kBlockWaves * 64) __attribute__((amdgpu_waves_per_e
         gVelOut[2 * (size_t)body] = make_float4(v.x, v.y, v.z, 0.f);
         gVelOut[2 * (size_t)body + 1] = make_float4(w.x, w.y, w.z, 0.f);
     }
+    MI_BSTAMP(7);
+#undef MI_BSTAMP
 }
+#define MI_BLOCK_PARAMS uint32_t sweeps, uint32_t tilesPerBlock, uint32_t hashSize, uint32_t bodyCap, uint32_t maxSlots, uint32_t maxPasses, uint32_t impCap, const uint4* __restrict__ tileInfo, \
+    const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal, const float2* __restrict__ slotMass, const float4* __restrict__ rows, const float4* gVel, float4* gVelOut, float4* mail, \
+    StepScalars* sc, BlockState* bs, uint32_t faultInject, uint32_t dbg, unsigned long long* dbgTimes
+#define MI_BLOCK_FORWARD sweeps, tilesPerBlock, hashSize, bodyCap, maxSlots, maxPasses, impCap, tileInfo, slotMeta, slotNormal, slotMass, rows, gVel, gVelOut, mail, sc, bs, faultInject, dbg, dbgTimes
+// one wave per SIMD, the rows a tile ahead in a152 .. a255
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_contact_solve_blocks(MI_BLOCK_PARAMS) { blockSolver<4u>(MI_BLOCK_FORWARD); }
+// two waves per SIMD, the current tile's rows in a0 .. a103
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_contact_solve_blocks8(MI_BLOCK_PARAMS) { blockSolver<8u>(MI_BLOCK_FORWARD); }
+#undef MI_BLOCK_PARAMS
+#undef MI_BLOCK_FORWARD
 
 }  // namespace mi

@@ -1892,7 +1892,12 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
     // XCD-partitioned: the workgroups that land on XCD x (blockIdx % 8, a speed assumption only) prepare the tiles XCD x will solve,
     // i.e. gather the bodies of ONE slab of the scene — they fit that XCD's L2 instead of streaming all bodies through every L2
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
-    const uint32_t entry = bodyOwner ? x * listCap + j : blockIdx.x;
+    uint32_t entry = bodyOwner ? x * listCap + j : blockIdx.x;
+    if (bndMask) {   // block mode: listCap = number of blocks, infoCap = blocks * tiles per block; the workgroups of XCD x prepare the tiles of ITS eighth of the blocks
+        const uint32_t nbe = listCap, T = infoCap / listCap, b0 = (x * nbe) >> 3, b1 = ((x + 1u) * nbe) >> 3;
+        if (j >= (b1 - b0) * T) return;
+        entry = b0 * T + j;
+    }
     const uint4 te = entry < infoCap ? tileInfo[entry] : make_uint4(0u, 0u, 0u, 0u);   // (requested before the validity checks below: their loads run beside it)
     if (bodyOwner) { if (!sc->totalTiles || j >= sc->xcdCount[x] || j >= listCap) return; }
     else if (entry >= sc->totalTiles) return;

@@ -211,7 +211,7 @@ struct mi_world {
     DBuf<uint32_t> blkKeys, blkRanks, blkPerm, blkStart, blkExtra, blkExtraCount; DBuf<uint16_t> blkCell; DBuf<unsigned long long> bndMask; DBuf<float4> mail;
     bool blockSolver = true, usedBlocks = false, blockFaultTest = false, blockFaultFired = false;
     struct BlockCaps { uint32_t nbe = 0, tiles = 0, extraCap = 0, bodyCap = 0, hashSize = 0, maxPasses = 0, impCap = 0; size_t lds = 0; } blkCaps;   // sticky: the same launches step after step (step graphs)
-    BlockState lastBlk{}; bool haveBlkEstimate = false, blkLastFailed = false; uint32_t blkFailHistory = 0, blkFailures = 0, blkDisabledSteps = 0, blkLaunches = 0, blkMaxBlocks = 256, blkSteps = 0;
+    BlockState lastBlk{}; bool haveBlkEstimate = false, blkLastFailed = false; uint32_t blkWaves = 4 /* waves per block: 4 = one per SIMD, 8 = two per SIMD (k_contact_solve_blocks8) */, blkFailHistory = 0, blkFailures = 0, blkDisabledSteps = 0, blkLaunches = 0, blkMaxBlocks = 256, blkSteps = 0;
     bool planBlocks(uint32_t nmLast, uint32_t nbBodies);
     bool persistXcd = true, persistXcdSingle = true, usedXcd = false, usedXcdSingle = false, lastXcdSingle = false, haveXcdEstimate = false, xcdFaultFired = false, xcdFaultTest = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
     // device: colliders
@@ -401,13 +401,15 @@ int mi_world::init(int dev) {
       if (const char* pi = getenv("MI_ISLAND_PRIVATE")) privateIslandsEnabled = pi[0] != '0';   // development / tests: every island through the dataflow
       if (const char* px = getenv("MI_PERSIST_XCD_SINGLE")) persistXcdSingle = px[0] != '0';   // 0: small piles on all XCDs, every body through memory
       xcdFaultTest = getenv("MI_PERSIST_XCD_FAULT") != nullptr;
-      blockSolver = !sv || std::string(sv) == "blocks";   // default; any other MI_SOLVER value keeps the block path off
+      blockSolver = sv && std::string(sv) == "blocks";   // opt-in (MI_SOLVER=blocks): bit-identical to the persistent kernel, but not faster yet (DESIGN.md "Spatial blocks in LDS": measured)
       if (const char* bb = getenv("MI_BLOCKS")) blockSolver = blockSolver && bb[0] != '0';
       blockFaultTest = getenv("MI_BLOCK_FAULT") != nullptr;
-      blkMaxBlocks = std::max(1u, persistWaves / kBlockWaves);
+      blkMaxBlocks = std::max(1u, persistWaves / 4u);   // one block per CU
+      if (const char* bw = getenv("MI_BLOCK_WAVES")) blkWaves = atoi(bw) == 4 ? 4u : 8u;
       if (const char* bn = getenv("MI_BLOCKS_MAX")) blkMaxBlocks = std::max(1u, (uint32_t)strtoul(bn, nullptr, 0));
       mail.flags = hipDeviceMallocUncached;
       (void)hipFuncSetAttribute((const void*)k_contact_solve_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      (void)hipFuncSetAttribute((const void*)k_contact_solve_blocks8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
       flowFaultTest = getenv("MI_FLOW_FAULT") != nullptr;
       if (const char* pm = getenv("MI_PERSIST_XCD_MIN")) xcdMinManifolds = (uint32_t)strtoul(pm, nullptr, 0); }   // smallest manifold count that is partitioned (tests: 1)   // MI_PERSIST_XCD=0: no XCD partitioning (every body through memory)   // development experiment: one XCD's workgroups do all the work
     if (flowLds > 65536) (void)hipFuncSetAttribute((const void*)k_contact_solve_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flowLds);
@@ -1304,9 +1306,9 @@ enqueue_section:
             L.launch(k_island_classify, dim3(divUp(nmBound, B)), dim3(B), 0, st, sc, colWork.p, color.p, islandPriv);
         }
         if (tilesLaunch)
-            L.launch(k_contact_init, dim3(xcdPlan ? 8u * xcdListCap : tilesLaunch), dim3(64), 0, st, sc, nb, dt, xcdPlan ? xcdInfo.p : tileInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
+            L.launch(k_contact_init, dim3(xcdPlan ? 8u * xcdListCap : blocksRun ? 8u * divUp(blkCaps.nbe, 8u) * blkCaps.tiles : tilesLaunch), dim3(64), 0, st, sc, nb, dt, xcdPlan ? xcdInfo.p : tileInfo.p, order.p, manPair.p, manBodies.p, manInfo.p, npNormal.p, npPoints.p,
                                                       gPos.p, gInvI.p, xcdPlan ? gVelL.p : gVel.p /* same content here; the cached copy */, color.p, bodyUsed.p, fused ? joints.dBodyJ : nullptr, rows.p, impNeeded ? imp.p : nullptr, slotMeta.p, slotNormal.p, slotMass.p,
-                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, xcdListCap, xcdPlan ? 8u * xcdListCap : tilesCap, islandPriv,
+                                                      xcdPlan ? reinterpret_cast<uint8_t*>(bodyOwner.p) : nullptr, blocksRun ? blkCaps.nbe : xcdListCap, xcdPlan ? 8u * xcdListCap : tilesCap, islandPriv,
                                                       blocksRun ? bndMask.p : nullptr, &sc->blk);
     }
     int rc = joints.initialize(*this, dt, st);   // (through L)
@@ -1347,13 +1349,54 @@ enqueue_section:
         }
         const uint32_t fault = blockFaultTest && !blockFaultFired ? 1u : 0u;   // tests: one block gives up once
         if (fault && !L.dry) blockFaultFired = true;
-        const uint32_t maxSlots = divUp(bc.tiles, kBlockWaves);
+        const uint32_t maxSlots = divUp(bc.tiles, blkWaves);
+        auto* blockKernel = blkWaves == 8u ? k_contact_solve_blocks8 : k_contact_solve_blocks;
+        static DBuf<unsigned long long> trapBuf;   // development (MI_BLOCK_MODE & 0x100): records of lanes with wild values, printed when the first ones appear
+        static bool trapPrinted = false;
+        if (std::getenv("MI_BLOCK_MODE") && (strtoul(std::getenv("MI_BLOCK_MODE"), nullptr, 0) & 0x100u)) {
+            if (!trapBuf.p) { HIP_TRY(trapBuf.ensure(8 + 256 * 8)); HIP_TRY(hipMemsetAsync(trapBuf.p, 0, trapBuf.cap * 8, st)); }
+            else if (!trapPrinted) {
+                std::vector<unsigned long long> h(8 + 256 * 8); HIP_TRY(hipMemcpy(h.data(), trapBuf.p, h.size() * 8, hipMemcpyDeviceToHost));
+                if (h[0]) { trapPrinted = true; std::fprintf(stderr, "[mi_physics] trap: %llu wild lanes by step %llu\n", h[0], (unsigned long long)totalSteps);
+                    for (unsigned long long k = 0; k < std::min<unsigned long long>(h[0], 40ull); ++k) { const uint32_t* r = reinterpret_cast<const uint32_t*>(&h[8 + k * 8]);
+                        std::fprintf(stderr, "  block %u wave %u lane %u pass %u it %u slot %u | bnd %u ghostA %u ghostB %u updA %u updB %u | wild inA %u inB %u out %u rows %u | mc %u cnt %u lo %u hi %u | meta %u %u %08x | a0.x %g b0.x %g g0.x %g g0.w %08x want %08x | row %g nf %g mass %g | tagA %u/%u tagB %u/%u\n",
+                                     r[0] & 0xFFFF, (r[0] >> 16) & 0xFF, r[0] >> 24, r[1] & 0xFF, (r[1] >> 8) & 0xFF, r[1] >> 16, r[2] & 1, (r[2] >> 1) & 1, (r[2] >> 2) & 1, (r[2] >> 3) & 1, (r[2] >> 4) & 1, (r[2] >> 5) & 1, (r[2] >> 6) & 1, (r[2] >> 7) & 1, (r[2] >> 8) & 1,
+                                     (r[2] >> 12) & 15, (r[2] >> 16) & 15, (r[2] >> 20) & 63, (r[2] >> 26) & 127, r[3], r[4], r[5], *(const float*)&r[6], *(const float*)&r[7], *(const float*)&r[8], r[9], r[10], *(const float*)&r[11], *(const float*)&r[12], *(const float*)&r[13],
+                                     r[14] & 0xFFFF, r[14] >> 16, r[15] & 0xFFFF, r[15] >> 16); } }
+            }
+        }
+        static const uint32_t blockMode = std::getenv("MI_BLOCK_MODE") ? (uint32_t)strtoul(std::getenv("MI_BLOCK_MODE"), nullptr, 0) : 0u;   // development: 0x20 rows fetched at every pass (no prefetch), 0x40 full waits
+        static const std::vector<uint32_t> blockDbgList = [] { std::vector<uint32_t> v; if (const char* e = std::getenv("MI_BLOCK_DBG")) { const char* p = e; while (*p) { char* q; v.push_back((uint32_t)strtoul(p, &q, 0)); p = (*q == ',') ? q + 1 : q; if (q == p && *q) break; } } return v; }();
         hipEvent_t e6 = attached && (stepEventsMode || stageEvents) ? ev[6] : nullptr, e7 = attached && (stepEventsMode || stageEvents) ? ev[7] : nullptr;
         solveAttached = attached;
-#define MI_BLOCK_ARGS iters, bc.tiles, bc.hashSize, bc.bodyCap, maxSlots, bc.maxPasses, bc.impCap, tileInfo.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, gVelL.p, mail.p, sc, &sc->blk, fault
-        if (attached) hipExtLaunchKernelGGL(k_contact_solve_blocks, dim3(bc.nbe), dim3(kBlockWaves * 64), (uint32_t)bc.lds, st, e6, e7, 0, MI_BLOCK_ARGS);
-        else L.launch(k_contact_solve_blocks, dim3(bc.nbe), dim3(kBlockWaves * 64), bc.lds, st, MI_BLOCK_ARGS);
+#define MI_BLOCK_ARGS iters, bc.tiles, bc.hashSize, bc.bodyCap, maxSlots, bc.maxPasses, bc.impCap, tileInfo.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, gVelL.p, mail.p, sc, &sc->blk, fault, blockMode, trapBuf.p
+        if (attached) hipExtLaunchKernelGGL(blockKernel, dim3(bc.nbe), dim3(blkWaves * 64), (uint32_t)bc.lds, st, e6, e7, 0, MI_BLOCK_ARGS);
+        else L.launch(blockKernel, dim3(bc.nbe), dim3(blkWaves * 64), bc.lds, st, MI_BLOCK_ARGS);
 #undef MI_BLOCK_ARGS
+        static const uint64_t blockDbgAfter = std::getenv("MI_BLOCK_DBG_AFTER") ? strtoull(std::getenv("MI_BLOCK_DBG_AFTER"), nullptr, 0) : 0ull;
+        if (!blockDbgList.empty() && pass == PASS_PLAIN && totalSteps > blockDbgAfter) {   // development: the same launch once more with knock-outs, into scratch outputs (the step's results stay right), timed by its own event pair;
+                                                              // MI_BLOCK_DBG=a,b,c: 20 steps with each value in turn
+            static DBuf<unsigned long long> dbgTimes; HIP_TRY(dbgTimes.ensure((size_t)bc.nbe * blkWaves * 8u));
+            static DBuf<float4> scratchVel, scratchMail; static hipEvent_t dbgEv[2] = {nullptr, nullptr}; static double dbgSum = 0; static uint32_t dbgN = 0;
+            HIP_TRY(scratchVel.ensure(2 * ((size_t)nb + 1))); scratchMail.flags = hipDeviceMallocUncached;
+            if (scratchMail.cap < mail.cap) { HIP_TRY(scratchMail.ensure(mail.cap)); HIP_TRY(hipMemsetAsync(scratchMail.p, 0xFF, scratchMail.cap * sizeof(float4), st)); }
+            if (!dbgEv[0]) { HIP_TRY(hipEventCreate(&dbgEv[0])); HIP_TRY(hipEventCreate(&dbgEv[1])); }
+            else { HIP_TRY(hipEventSynchronize(dbgEv[1])); float ms = 0; if (hipEventElapsedTime(&ms, dbgEv[0], dbgEv[1]) == hipSuccess) { dbgSum += ms; if (++dbgN % 20u == 0u) {
+                std::fprintf(stderr, "[mi_physics] block knock-outs %u: extra launch %.1f us (mean of 20; step %llu, %u contacts)\n", blockDbgList[((dbgN - 1u) / 20u) % blockDbgList.size()], dbgSum / 20.0 * 1e3, (unsigned long long)totalSteps, last.numContacts); dbgSum = 0; } } }
+            const uint32_t dbgNow = blockDbgList[(dbgN / 20u) % blockDbgList.size()];
+            hipExtLaunchKernelGGL(blockKernel, dim3(bc.nbe), dim3(blkWaves * 64), (uint32_t)bc.lds, st, dbgEv[0], dbgEv[1], 0, iters, bc.tiles, bc.hashSize, bc.bodyCap, maxSlots, bc.maxPasses, bc.impCap,
+                                  tileInfo.p, slotMeta.p, slotNormal.p, slotMass.p, rows.p, gVel.p, scratchVel.p, scratchMail.p, sc, &sc->blk, 0u, dbgNow | 0x200u, dbgTimes.p);
+            if (dbgN % 20u == 19u) {   // phases of this launch, over all waves: mean and max of (hash, records, lists, impulses zeroed, main loop, barrier, epilogue) in us
+                HIP_TRY(hipStreamSynchronize(st));
+                std::vector<unsigned long long> h((size_t)bc.nbe * blkWaves * 8u);
+                HIP_TRY(hipMemcpy(h.data(), dbgTimes.p, h.size() * 8u, hipMemcpyDeviceToHost));
+                double mean[7] = {0}, mx[7] = {0}; unsigned long long t0 = ~0ull, t1 = 0;
+                for (size_t w_ = 0; w_ < (size_t)bc.nbe * blkWaves; ++w_) { const unsigned long long* t = &h[w_ * 8u]; t0 = std::min(t0, t[0]); t1 = std::max(t1, t[7]);
+                    for (int k = 0; k < 7; ++k) { const double d = (double)(t[k + 1] - t[k]) * 0.01; mean[k] += d / ((double)bc.nbe * blkWaves); mx[k] = std::max(mx[k], d); } }
+                std::fprintf(stderr, "[mi_physics] block phases (knock-outs %u): span %.1f us; mean / max us: hash %.1f / %.1f, records %.1f / %.1f, lists %.1f / %.1f, zero %.1f / %.1f, main %.1f / %.1f, barrier %.1f / %.1f, epilogue %.1f / %.1f\n",
+                             dbgNow, (double)(t1 - t0) * 0.01, mean[0], mx[0], mean[1], mx[1], mean[2], mx[2], mean[3], mx[3], mean[4], mx[4], mean[5], mx[5], mean[6], mx[6]);
+            }
+        }
         if (profileSolve) { (void)hipEventRecord(profEvents[2 * (size_t)profLaunches + 1], st); ++profLaunches; }
     } else if (persistPlan && persistMaxSlots * 20u <= 38u * 1024u) {
         // persistent waves: one workgroup per SIMD owns its tiles through all sweeps, impulses (and, while they fit, the constant slot data) in LDS (k_contact_solve_persist)
@@ -1780,18 +1823,18 @@ bool mi_world::planBlocks(uint32_t nmLast, uint32_t nbBodies) {
     }
     const uint32_t needEntries = have && lastBlk.need ? lastBlk.need : perBlock + perBlock / 4u + 32u;
     c.tiles = sticky(c.tiles * 64u, needEntries, 64u, 64u) / 64u;
-    if (c.tiles > 16u * kBlockWaves) return false;
-    const uint32_t maxSlots = divUp(c.tiles, kBlockWaves);
+    if (c.tiles > 64u) return false;
+    const uint32_t maxSlots = divUp(c.tiles, blkWaves);
     c.extraCap = sticky(c.extraCap, have ? lastBlk.needExtra : std::max(32u, perBlock / 6u), 32u, 32u);
     c.bodyCap = sticky(c.bodyCap, have && lastBlk.needBodies ? lastBlk.needBodies : std::min(nbBodies + 1u, nbBodies / c.nbe * 3u / 2u + 64u), 64u, 64u);
     if (c.bodyCap > 16384u) return false;
     c.hashSize = 256u; while (c.hashSize < 2u * c.bodyCap) c.hashSize <<= 1;
     c.maxPasses = sticky(c.maxPasses, have && lastBlk.needPasses ? lastBlk.needPasses : maxSlots * 3u + 16u, 8u, 8u);
-    c.impCap = std::min(maxSlots * 256u, sticky(c.impCap, have && lastBlk.needImp ? lastBlk.needImp : (perBlock * 4u) / kBlockWaves + 128u, 64u, 64u));
-    const size_t recBytes = ((size_t)c.bodyCap * 36u + 15u) & ~(size_t)15u;
-    const size_t uniBytes = (std::max((size_t)c.hashSize * 6u, (size_t)kBlockWaves * c.impCap * 8u) + 15u) & ~(size_t)15u;   // hash during set-up, impulses afterwards
-    const size_t waveBytes = ((size_t)maxSlots * 64u * 16u + (size_t)c.maxPasses * 16u + (size_t)maxSlots * 64u * 2u + 15u) & ~(size_t)15u;
-    c.lds = recBytes + uniBytes + kBlockWaves * waveBytes;
+    c.impCap = std::min(maxSlots * 256u, sticky(c.impCap, have && lastBlk.needImp ? lastBlk.needImp : (perBlock * 4u) / blkWaves + 128u, 64u, 64u));
+    const size_t recBytes = ((size_t)c.bodyCap * 40u + 15u) & ~(size_t)15u;   // records (32 B), their bodies, their hand-over words
+    const size_t uniBytes = (std::max((size_t)c.hashSize * 6u, (size_t)blkWaves * c.impCap * 8u) + 15u) & ~(size_t)15u;   // hash during set-up, impulses afterwards
+    const size_t waveBytes = ((size_t)maxSlots * 64u * 16u + (size_t)c.maxPasses * 16u + (size_t)maxSlots * 64u * 2u + (size_t)maxSlots * 16u + 15u) & ~(size_t)15u;
+    c.lds = recBytes + uniBytes + blkWaves * waveBytes;
     if (c.lds > 160u * 1024u - 64u) return false;
     blkCaps = c;
     return true;

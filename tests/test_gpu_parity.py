@@ -73,7 +73,6 @@ def test_gpu_xcd_partitioned_solver_on_other_scene_types(mi_lib, oracle_mod, mon
     """The XCD-partitioned persistent solver (forced on for these small scenes; default from 16 384 manifolds) with the other
     manifold sources: same trajectory as the oracle, bit for bit."""
     monkeypatch.setenv("MI_PERSIST_XCD_MIN", "1")
-    monkeypatch.setenv("MI_BLOCKS", "0")   # (the default for contact-only scenes is the block solver: its turn with these scenes comes below)
     sc = make()
     g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     s = sc.settings()
@@ -98,6 +97,7 @@ def test_gpu_block_solver_on_other_scene_types(mi_lib, oracle_mod, monkeypatch, 
     """The block solver (blocks.hpp: spatial blocks with their home bodies in LDS, boundary manifolds solved on both sides, exports through
     mailboxes) with the other manifold sources and with block counts that cut these small scenes in different places: same trajectory as the
     oracle, bit for bit; it must be the path that ran, and not keep falling back."""
+    monkeypatch.setenv("MI_SOLVER", "blocks")
     if blocks:
         monkeypatch.setenv("MI_BLOCKS_MAX", blocks)
     sc = make()
@@ -387,8 +387,8 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
     assert g2.cloth_state(0, 144)[0].tobytes() == o2.cloth_state(0, 144)[0].tobytes()
 
 
-@pytest.mark.parametrize("env,kind", [({}, 6), ({"MI_BLOCKS_MAX": "3"}, 6), ({"MI_BLOCKS_MAX": "2"}, 6), ({"MI_BLOCK_FAULT": "1"}, 5),
-                                      ({"MI_SOLVER": "persist"}, 5), ({"MI_SOLVER": "flow"}, 1), ({"MI_SOLVER": "persist-global"}, 5), ({"MI_PERSIST_XCD": "0"}, 2), ({"MI_PERSIST_XCD_SINGLE": "0"}, 2),
+@pytest.mark.parametrize("env,kind", [({}, 5), ({"MI_SOLVER": "blocks"}, 6), ({"MI_SOLVER": "blocks", "MI_BLOCKS_MAX": "3"}, 6), ({"MI_SOLVER": "blocks", "MI_BLOCKS_MAX": "2"}, 6),
+                                      ({"MI_SOLVER": "blocks", "MI_BLOCK_FAULT": "1"}, 5), ({"MI_SOLVER": "persist"}, 5), ({"MI_SOLVER": "flow"}, 1), ({"MI_SOLVER": "persist-global"}, 5), ({"MI_PERSIST_XCD": "0"}, 2), ({"MI_PERSIST_XCD_SINGLE": "0"}, 2),
                                       ({"MI_PERSIST_XCD_SINGLE": "0", "MI_SOLVER": "persist-global"}, 2), ({"MI_PERSIST_XCD_SINGLE": "0", "MI_SOLVER": "persist-granules"}, 2),
                                       ({"MI_PERSIST_XCD_MIN": "1"}, 4), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-global"}, 4),
                                       ({"MI_SOLVER": "persist-granules"}, 5), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-granules"}, 4),
@@ -412,8 +412,6 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
     data and then the impulses out of LDS (the choices it makes for piles of 0.5 M / 1.2 M manifolds and more)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
-    if env and "MI_SOLVER" not in env and not any(k.startswith("MI_BLOCK") for k in env):
-        monkeypatch.setenv("MI_BLOCKS", "0")   # the variants of the persistent kernel: the block solver (the default) stands aside
     sc = scenes.obb_pile(14, 8, 14, spacing=1.05)
     g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     s = sc.settings()
@@ -595,13 +593,14 @@ def test_gpu_private_islands_match_oracle_and_the_dataflow_path(mi_lib, oracle_m
 
 
 def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
-    """BASELINE's 262 144-body pile, far beyond the oracle's reach: the default solver (spatial blocks in LDS, one per CU) must end
-    bit-identical to the XCD-partitioned persistent kernel (eight tile lists, ~95 % of the bodies handed over through an XCD's L2), to
-    the dispatch-ordered flow kernel and to the unpartitioned persistent kernel, which the small cases pin to the oracle."""
+    """BASELINE's 262 144-body pile, far beyond the oracle's reach: the default solver (XCD-partitioned persistent kernel: eight tile
+    lists, ~95 % of the bodies handed over through an XCD's L2, the seam bodies through memory) must end bit-identical to the
+    dispatch-ordered flow kernel, to the unpartitioned persistent kernel — which the small cases pin to the oracle — and to the block
+    solver (MI_SOLVER=blocks: 256 spatial blocks with their home bodies in LDS, boundary manifolds solved on both sides)."""
     import hashlib
     sc = scenes.obb_pile(128, 16, 128)
     out = {}
-    for name, env in (("default", {}), ("flow", {"MI_SOLVER": "flow"}), ("unpartitioned", {"MI_PERSIST_XCD": "0", "MI_BLOCKS": "0"}), ("persist", {"MI_SOLVER": "persist"})):
+    for name, env in (("default", {}), ("flow", {"MI_SOLVER": "flow"}), ("unpartitioned", {"MI_PERSIST_XCD": "0"}), ("blocks", {"MI_SOLVER": "blocks"})):
         for k in ("MI_SOLVER", "MI_PERSIST_XCD", "MI_BLOCKS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
@@ -611,8 +610,8 @@ def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
         p, q = w.physics_transforms()
         out[name] = (hashlib.sha1(p.tobytes() + q.tobytes()).hexdigest(), w.counts()["num_contacts"], w.solver_kind(), w.step_mode_stats()[2])
         w.close()
-    assert out["default"][2] == 6 and out["flow"][2] == 1 and out["unpartitioned"][2] == 2 and out["persist"][2] == 4, out
-    assert out["default"][:2] == out["flow"][:2] == out["unpartitioned"][:2] == out["persist"][:2], out
+    assert out["default"][2] == 4 and out["flow"][2] == 1 and out["unpartitioned"][2] == 2 and out["blocks"][2] == 6, out
+    assert out["default"][:2] == out["flow"][:2] == out["unpartitioned"][:2] == out["blocks"][:2], out
     assert out["default"][1] > 150000
     assert out["default"][3] <= 12, "speculative retries while the pile lands are fine; a solver that keeps falling back is not"
 

@@ -1,0 +1,18 @@
+#!/bin/bash
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+ulimit -c 0
+cat > /tmp/pile.py <<'PY'
+import sys, time, os, hashlib
+sys.path.insert(0, os.getcwd())
+import torch; torch.cuda.init()
+import d3d12renderer_amd as mi
+from d3d12renderer_amd import scenes
+nx, ny, nz, steps = map(int, sys.argv[1:5])
+sc = scenes.obb_pile(nx, ny, nz); w = sc.populate(mi.create_world(0)); s = sc.settings()
+t0 = time.time()
+for i in range(steps): w.step_fixed(s, sc.dt, 1)
+p, q = w.physics_transforms()
+print("pile", nx, ny, nz, "ms/step", round((time.time() - t0) / steps * 1e3, 3), "kind", w.solver_kind(), "modes", w.step_mode_stats(), "contacts", w.counts()["num_contacts"], "sha", hashlib.sha1(p.tobytes() + q.tobytes()).hexdigest()[:12], flush=True)
+PY
+for wv in 4 8; do MI_BLOCK_DEBUG=1 MI_BLOCK_WAVES=$wv timeout 100 python /tmp/pile.py 32 8 32 200 > gpurun_out/r4h_pile_$wv.log 2>&1; grep -v "overflow 0 solveError 0" gpurun_out/r4h_pile_$wv.log | cut -c1-400 | tail -12; done
