@@ -96,7 +96,8 @@ class ShardExchangeStats(C.Structure):
     """mi_shard_exchange_stats (include/mi_shard.h)."""
     _fields_ = [("exchanges", C.c_uint64), ("device_ms_sum", C.c_double), ("message_bytes", C.c_uint64), ("num_neighbours", C.c_uint32), ("library_transport", C.c_uint32),
                 ("neighbour_rank", C.c_uint32 * 8), ("records_last", C.c_uint32 * 8), ("records_sum", C.c_uint64 * 8), ("owned_bodies", C.c_uint32), ("ghost_bodies", C.c_uint32),
-                ("sweep_exchanges", C.c_uint64), ("sweep_message_bytes", C.c_uint64), ("sweep_records_last", C.c_uint32 * 8)]
+                ("sweep_exchanges", C.c_uint64), ("sweep_message_bytes", C.c_uint64), ("sweep_records_last", C.c_uint32 * 8),
+                ("message_records_last", C.c_uint32 * 8), ("message_bytes_sum", C.c_uint64)]
 
 
 SHARD_RECORD_FLOATS = 14
@@ -528,7 +529,8 @@ class World:
         return {"exchanges": st.exchanges, "device_ms_sum": st.device_ms_sum, "message_bytes": st.message_bytes, "num_neighbours": n,
                 "library_transport": bool(st.library_transport), "neighbour_rank": list(st.neighbour_rank[:n]), "records_last": list(st.records_last[:n]),
                 "records_sum": list(st.records_sum[:n]), "owned_bodies": st.owned_bodies, "ghost_bodies": st.ghost_bodies,
-                "sweep_exchanges": st.sweep_exchanges, "sweep_message_bytes": st.sweep_message_bytes, "sweep_records_last": list(st.sweep_records_last[:n])}
+                "sweep_exchanges": st.sweep_exchanges, "sweep_message_bytes": st.sweep_message_bytes, "sweep_records_last": list(st.sweep_records_last[:n]),
+                "message_records_last": list(st.message_records_last[:n]), "message_bytes_sum": st.message_bytes_sum}
 
     # --- exact seam (include/mi_shard.h "Exact seam")
     def set_seam_tiling(self, desc):

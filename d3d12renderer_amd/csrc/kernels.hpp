@@ -82,6 +82,7 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numDead;              // sharded world: colliders of bodies this rank does not simulate this step (they take no part in the broad phase)
     uint32_t shardOwned[3];        // sharded world: bodies / manifolds / contacts OWNED by this rank (owner rule: the manifold's first dynamic body)
     uint32_t shardSent[8];         // sharded world: records packed for each neighbour this step (slot order of ShardParams::peers)
+    uint32_t shardRecv[8];         // ... records the neighbours packed for this rank (the headers of the received messages); [.] = 0xFFFFFFFF: that message was cut short (library transport, adaptive sizes)
     uint32_t seamStats[3];         // exact seam (include/mi_shard.h): manifolds of the seam class, colours they use, violations of this step (k_seam_stats)
     unsigned long long axisSums[9]; // centre statistics of the colliders this world counts (k_pair_finish): S1[3], S2lo[3], S2hi[3]; a sharded world's are added over the ranks
     BlockState blk;                 // spatial blocks in LDS (blocks.hpp)
@@ -2785,10 +2786,14 @@ __global__ void k_shard_pack_headers(uint32_t numPeers, const StepScalars* __res
     if (axisOwn && threadIdx.x == 63) *axisOwn = axisFromSums(sc->axisSums, nc);
 }
 // blockIdx.y = neighbour slot (a body has one owner: the messages never touch the same body)
+struct ShardCaps { uint32_t c[8]; };   // records each received message can hold as it travelled (library transport: sized from the previous exchange)
 __global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, ShardBufs in, uint32_t capacity, float4* __restrict__ bPos, float4* __restrict__ bRot,
-                                                      float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, uint8_t* __restrict__ known) {
+                                                      float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, uint8_t* __restrict__ known,
+                                                      ShardCaps caps = ShardCaps{{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}}, uint32_t* __restrict__ recvCounts = nullptr) {
     const float* msg = in.p[blockIdx.y];
-    const uint32_t count = min(__float_as_uint(msg[0]), capacity);
+    const uint32_t sent = __float_as_uint(msg[0]), cap = min(capacity, caps.c[blockIdx.y]);
+    if (recvCounts && blockIdx.x == 0 && threadIdx.x == 0) recvCounts[blockIdx.y] = sent > cap && sent <= capacity ? 0xFFFFFFFFu : sent;   // (more than travelled: the tail is missing — reported, never silent)
+    const uint32_t count = min(sent, cap);
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= count) return;
     const float* s = msg + (size_t)(r + 1u) * kShardRecordFloats;

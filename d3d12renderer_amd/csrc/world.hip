@@ -170,6 +170,9 @@ struct mi_world {
         bool sentPending = false;
         hipEvent_t exEv[2] = {nullptr, nullptr}; bool exchangeTimed = false; double exchangeMsSum = 0.0; uint64_t exchangesTimed = 0;   // device time of the exchanges (pack -> send / receive -> unpack -> axis)
         uint32_t sentLast[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t sentSum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        // library transport: a neighbour message travels as long as the previous exchange made it in EITHER direction (x 1.5 + 512 records) — both ends know both numbers, so
+        // they agree on the size without talking; full size for the exchanges after anything that moves many bodies at once (enable, attach, new borders, a restore)
+        uint32_t* recvHost = nullptr; uint32_t recvLast[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sizedLast[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool recvValid = false, adaptive = true; uint32_t fullExchanges = 2; uint64_t bytesSentSum = 0;
         uint32_t owned[3] = {0, 0, 0};
         void* comm = nullptr;                    // ncclComm_t
         size_t messageFloats() const { return (size_t)(capacity + 1u) * kShardRecordFloats; }
@@ -422,6 +425,7 @@ mi_world::~mi_world() {
     if (hsPinned) (void)hipHostFree(hsPinned);
     if (downloadStage) (void)hipHostFree(downloadStage);
     if (shard.sentHost) (void)hipHostFree(shard.sentHost);
+    if (shard.recvHost) (void)hipHostFree(shard.recvHost);
     for (hipEvent_t& e : shard.exEv) if (e) (void)hipEventDestroy(e);
     shardReleaseComm();
     if (graphDebug) std::fprintf(stderr, "[mi_physics] GJK bucket span of the last step (sticky bound): %u pairs\n", last.gjkSpan);
@@ -1180,7 +1184,7 @@ enqueue_section:
     // small piles: the 128 waves of ONE XCD run the whole solve, every body hand-over goes through that XCD's L2 (tileOwner(..., single))
     const bool xcdSingle = xcdAble && persistXcdSingle && nmBound && nmBound < xcdMinManifolds && divUp(divUp(nmBound, 64) + kSchedBins + 8, persistWaves / 8u) <= 16u;
     const bool xcdPlan = xcdAble && (nmBound >= xcdMinManifolds || xcdSingle);
-    static const uint32_t colorMargin = std::getenv("MI_COLOR_MARGIN") ? (uint32_t)atoi(std::getenv("MI_COLOR_MARGIN")) : 3u;   // extra rounds enqueued beyond the previous step's count
+    static const uint32_t colorMargin = std::getenv("MI_COLOR_MARGIN") ? (uint32_t)atoi(std::getenv("MI_COLOR_MARGIN")) : 1u;   // extra rounds enqueued beyond the previous step's count
     // converged rounds exit at once, but every enqueued round costs its launch slot (~4.6 us): a scene that replays its steps as graphs wants the same
     // launches step after step (a multiple of 4), a large one exactly what the previous step needed plus the margin
     uint32_t colorBatch = !spec ? 20u : graphStep ? std::min<uint32_t>(96u, (last.colorRounds + std::max(colorMargin, last.colorRounds / 4u) + 3u) & ~3u)
@@ -2668,6 +2672,13 @@ int mi_world::shardCheckOverflow(bool sync) {
     sh.sentPending = false;
     if (sh.exchangeTimed) { sh.exchangeMsSum += (double)elapsedMs(sh.exEv[0], sh.exEv[1]); ++sh.exchangesTimed; sh.exchangeTimed = false; }
     for (uint32_t k = 0; k < sh.sp.numPeers; ++k) { sh.sentLast[k] = sh.sentHost[k]; sh.sentSum[k] += sh.sentHost[k]; }
+    if (sh.rccl && sh.recvHost) {   // what the neighbours sent in that exchange (the headers of their messages)
+        for (uint32_t k = 0; k < sh.sp.numPeers; ++k) {
+            if (sh.recvHost[k] == 0xFFFFFFFFu) return fail(MI_ERR_CAPACITY, "a neighbour message outgrew the size both ranks had derived from the previous exchange (more than 1.5 x + 512 records in one step): set MI_SHARD_ADAPTIVE=0 on all ranks for fixed-size messages");
+            sh.recvLast[k] = sh.recvHost[k];
+        }
+        sh.recvValid = true;
+    }
     for (uint32_t k = 0; k < sh.sp.numPeers; ++k) if (sh.sentHost[k] > sh.capacity) return fail(MI_ERR_CAPACITY, "shard message overflow: raise mi_shard_desc::max_records (equal on all ranks)");
     return MI_OK;
 }
@@ -2688,7 +2699,7 @@ int mi_world::shardExchange() {
                                                                                                                     // summed over all ranks (mi_world_shard_set_axis_sums), the next step's sweep axis is the one of this rank's own sums
     HIP_TRY(hipMemcpyAsync(sh.sentHost, &sc->shardSent[0], 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     sh.sentPending = true; sh.exchangeTimed = true;
-    if (sh.bordersPending) { sh.sp = sh.spNext; sh.bordersX = sh.nextX; sh.bordersZ = sh.nextZ; sh.bordersPending = false; }   // the next step classifies with the new borders
+    if (sh.bordersPending) { sh.sp = sh.spNext; sh.bordersX = sh.nextX; sh.bordersZ = sh.nextZ; sh.bordersPending = false; sh.fullExchanges = 2; }   // the next step classifies with the new borders (this exchange hands bodies over: full-size messages, on every rank)
     if (!sh.rccl) {
         // (the axis of this rank's own sums is also what k_pair_finish computed: hs.axisNext, already in sapAxis)
         HIP_TRY(hipEventRecord(sh.exEv[1], st));
@@ -2697,15 +2708,27 @@ int mi_world::shardExchange() {
         return shardCheckOverflow(false);
     }
     Rccl* r = rccl();
-    const size_t n = sh.messageFloats();
+    ShardCaps caps{}; uint32_t maxRecs = 0;
+    const bool sized = sh.adaptive && sh.fullExchanges == 0u && sh.recvValid;
+    for (uint32_t k = 0; k < 8u; ++k) {
+        const uint32_t m = std::max(sh.sentLast[k], sh.recvLast[k]);
+        caps.c[k] = sized && k < sh.sp.numPeers ? std::min(sh.capacity, m + m / 2u + 512u) : sh.capacity;
+        if (k < sh.sp.numPeers) { sh.sizedLast[k] = caps.c[k]; maxRecs = std::max(maxRecs, caps.c[k]); sh.bytesSentSum += (uint64_t)(caps.c[k] + 1u) * kShardRecordFloats * sizeof(float); }
+    }
+    if (sh.fullExchanges) --sh.fullExchanges;
     int e = r->GroupStart(); if (e) return fail(MI_ERR_DEVICE, "ncclGroupStart failed");
     for (uint32_t k = 0; k < sh.sp.numPeers && !e; ++k) {
+        const size_t n = (size_t)(caps.c[k] + 1u) * kShardRecordFloats;   // header + the records both ends expect at most
         e = r->Send(sh.sendBuf[k].p, n, kNcclFloat32, (int)sh.peerRanks[k], sh.comm, st);
         if (!e) e = r->Recv(sh.recvBuf[k].p, n, kNcclFloat32, (int)sh.peerRanks[k], sh.comm, st);
     }
     const int e2 = r->GroupEnd();
     if (e || e2) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e ? e : e2) : "RCCL send / receive failed");
-    if (sh.sp.numPeers) k_shard_unpack<<<dim3(divUp(sh.capacity, 256), sh.sp.numPeers), 256, 0, st>>>(nb, recvBufs, sh.capacity, bPos.p, bRot.p, bLinVel.p, bAngVel.p, sh.known.p);
+    if (sh.sp.numPeers) {
+        k_shard_unpack<<<dim3(divUp(std::max(maxRecs, 1u), 256), sh.sp.numPeers), 256, 0, st>>>(nb, recvBufs, sh.capacity, bPos.p, bRot.p, bLinVel.p, bAngVel.p, sh.known.p, caps, &sc->shardRecv[0]);
+        if (!sh.recvHost) { HIP_TRY(hipHostMalloc((void**)&sh.recvHost, 8 * sizeof(uint32_t))); std::memset(sh.recvHost, 0, 8 * sizeof(uint32_t)); }
+        HIP_TRY(hipMemcpyAsync(sh.recvHost, &sc->shardRecv[0], 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));   // (read at the next exchange, like the sent counts)
+    }
     // global sweep axis: the centre statistics of the colliders every rank owns, summed over all ranks (72 bytes), stay on the device
     if (r->AllReduce) {
         const int e3 = r->AllReduce(sc->axisSums, sh.axisGlobal.p, kAxisSums, kNcclUint64, kNcclSum, sh.comm, st);
@@ -2877,6 +2900,7 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
     }
     if (!sh.sentHost) HIP_TRY(hipHostMalloc((void**)&sh.sentHost, 8 * sizeof(uint32_t)));
     std::memset(sh.sentHost, 0, 8 * sizeof(uint32_t)); sh.sentPending = false; sh.exchangeTimed = false;
+    sh.fullExchanges = 2; sh.recvValid = false; if (const char* ad = getenv("MI_SHARD_ADAPTIVE")) sh.adaptive = ad[0] != '0';
     HIP_TRY(sh.axisDev.ensure(1)); HIP_TRY(sh.axisGlobal.ensure(kAxisSums)); HIP_TRY(sh.importBuf.ensure(sh.messageFloats()));
     HIP_TRY(hipMemcpy(sh.axisDev.p, &w->sapAxis, sizeof(uint32_t), hipMemcpyHostToDevice)); sh.axisHostCurrent = true;
     sh.enabled = true;
@@ -3045,7 +3069,7 @@ MI_API int mi_world_shard_attach_rccl(mi_world* w, const void* id) {
     Id128 uid; std::memcpy(uid.bytes, id, sizeof(uid.bytes));
     const int e = r->CommInitRank(&w->shard.comm, (int)w->shard.desc.num_ranks, uid, (int)w->shard.desc.rank);
     if (e) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e) : "ncclCommInitRank failed");
-    w->shard.rccl = true;
+    w->shard.rccl = true; w->shard.fullExchanges = 2; w->shard.recvValid = false;
     return MI_OK;
 }
 // Development / tests: the library transport on ONE rank.  A one-rank communicator whose every neighbour is this rank itself: the exchange then runs
@@ -3061,7 +3085,7 @@ MI_API int mi_debug_shard_attach_loopback(mi_world* w) {
     if (!e) e = r->CommInitRank(&w->shard.comm, 1, uid, 0);
     if (e) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e) : "ncclCommInitRank failed");
     for (uint32_t& p : w->shard.peerRanks) p = 0u;
-    w->shard.rccl = true;
+    w->shard.rccl = true; w->shard.fullExchanges = 2; w->shard.recvValid = false;
     return MI_OK;
 }
 // ... and the message last RECEIVED in slot `slot` (library transport), so a test can hold it against what was sent
@@ -3137,6 +3161,8 @@ MI_API int mi_world_shard_exchange_stats(mi_world* w, mi_shard_exchange_stats* o
     std::memset(out, 0, sizeof(*out));
     out->exchanges = sh.exchangesTimed; out->device_ms_sum = sh.exchangeMsSum; out->num_neighbours = sh.sp.numPeers;
     out->message_bytes = (uint64_t)sh.messageFloats() * sizeof(float); out->library_transport = sh.rccl ? 1u : 0u;
+    for (uint32_t k = 0; k < 8u; ++k) out->message_records_last[k] = k < sh.sp.numPeers ? (sh.rccl ? sh.sizedLast[k] : sh.capacity) : 0u;
+    out->message_bytes_sum = sh.bytesSentSum;
     for (uint32_t k = 0; k < sh.sp.numPeers; ++k) { out->neighbour_rank[k] = sh.peerRanks[k]; out->records_last[k] = sh.sentLast[k]; out->records_sum[k] = sh.sentSum[k]; }
     const uint32_t nb = (uint32_t)w->bodies.size();
     if (nb && sh.flagsOfAStep && !w->topologyDirty) {
@@ -3146,7 +3172,7 @@ MI_API int mi_world_shard_exchange_stats(mi_world* w, mi_shard_exchange_stats* o
     }
     out->sweep_exchanges = sh.sweepExchanges; out->sweep_message_bytes = sh.exact ? (uint64_t)sh.sweepFloats() * sizeof(float) : 0ull;
     for (uint32_t k = 0; k < sh.sp.numPeers; ++k) out->sweep_records_last[k] = sh.exact ? sh.sweepCounts[k] : 0u;
-    if (reset) { sh.exchangesTimed = 0; sh.exchangeMsSum = 0.0; for (uint64_t& v : sh.sentSum) v = 0; sh.sweepExchanges = 0; }
+    if (reset) { sh.exchangesTimed = 0; sh.exchangeMsSum = 0.0; for (uint64_t& v : sh.sentSum) v = 0; sh.sweepExchanges = 0; sh.bytesSentSum = 0; }
     return rc;
 }
 

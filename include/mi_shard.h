@@ -96,13 +96,17 @@ MI_API int mi_world_shard_set_axis_sums(mi_world* world, const uint64_t* global9
  * kernel to the end of the unpack / axis kernels (library transport: including the RCCL sends and receives), summed over `exchanges`. */
 typedef struct mi_shard_exchange_stats {
     uint64_t exchanges; double device_ms_sum;
-    uint64_t message_bytes;               /* one neighbour message, as it travels (fixed size) */
+    uint64_t message_bytes;               /* one neighbour message at full size (max_records + 1 records) */
     uint32_t num_neighbours, library_transport;
     uint32_t neighbour_rank[8], records_last[8]; uint64_t records_sum[8];   /* per neighbour slot: records (56 B) packed in the last exchange / since the last reset */
     uint32_t owned_bodies, ghost_bodies;  /* of the last internal step */
     uint64_t sweep_exchanges;             /* exact seam: hand-overs after a sweep since the last reset (iterations per internal step each) */
     uint64_t sweep_message_bytes;         /* ... one sweep message as the library transport sends it (fixed size) */
     uint32_t sweep_records_last[8];       /* ... records (32 B) per neighbour message of the last internal step */
+    uint32_t message_records_last[8];     /* library transport: records each neighbour message of the last exchange could hold AS IT TRAVELLED: max(sent, received) of the
+                                             exchange before x 1.5 + 512 — both ends derive the same number from the same two counts —, max_records right after enable / attach /
+                                             new borders, always with MI_SHARD_ADAPTIVE=0, and with the caller's transport (mi_world_shard_export hands out whole messages) */
+    uint64_t message_bytes_sum;           /* library transport: bytes sent since the last reset (all neighbours, headers included) */
 } mi_shard_exchange_stats;
 MI_API int mi_world_shard_exchange_stats(mi_world* world, mi_shard_exchange_stats* out, uint32_t reset);
 
