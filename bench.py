@@ -336,6 +336,7 @@ def main():
             "exchange": {"transport": "library RCCL (ncclSend / ncclRecv + 72-byte ncclAllReduce on the world's stream)" if ex["library_transport"] else "caller's (torch.distributed via host)",
                          "exchanges_timed": ex["exchanges"], "device_ms_per_exchange": ex["device_ms_sum"] / max(1, ex["exchanges"]),
                          "message_bytes_per_neighbour": ex["message_bytes"], "neighbours": ex["neighbour_rank"],
+                         "message_records_travelled_last": ex.get("message_records_last"), "bytes_sent_timed": ex.get("message_bytes_sum"),   # library transport: messages sized from the previous exchange (include/mi_shard.h)
                          "records_per_exchange": [v / max(1, ex["exchanges"]) for v in ex["records_sum"]],
                          "payload_bytes_per_exchange": [56 * v / max(1, ex["exchanges"]) for v in ex["records_sum"]],
                          "seam": args.seam, "seam_stats": sw.check_seam() if args.seam == "exact" else None,   # (raises when a manifold violated the seam classes: the ranks would no longer equal one world)

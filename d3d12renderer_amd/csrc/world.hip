@@ -173,6 +173,8 @@ struct mi_world {
         // library transport: a neighbour message travels as long as the previous exchange made it in EITHER direction (x 1.5 + 512 records) — both ends know both numbers, so
         // they agree on the size without talking; full size for the exchanges after anything that moves many bodies at once (enable, attach, new borders, a restore)
         uint32_t* recvHost = nullptr; uint32_t recvLast[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sizedLast[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool recvValid = false, adaptive = true; uint32_t fullExchanges = 2; uint64_t bytesSentSum = 0;
+        // ... the sweep messages of the exact seam likewise, from the previous STEP's list lengths in both directions (x 1.5 + 64)
+        uint32_t sweepPrevOwn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sweepPeerHdr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sweepSized[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool sweepRecvValid = false, sweepCut = false; uint32_t sweepFullSteps = 2;
         uint32_t owned[3] = {0, 0, 0};
         void* comm = nullptr;                    // ncclComm_t
         size_t messageFloats() const { return (size_t)(capacity + 1u) * kShardRecordFloats; }
@@ -2699,7 +2701,7 @@ int mi_world::shardExchange() {
                                                                                                                     // summed over all ranks (mi_world_shard_set_axis_sums), the next step's sweep axis is the one of this rank's own sums
     HIP_TRY(hipMemcpyAsync(sh.sentHost, &sc->shardSent[0], 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
     sh.sentPending = true; sh.exchangeTimed = true;
-    if (sh.bordersPending) { sh.sp = sh.spNext; sh.bordersX = sh.nextX; sh.bordersZ = sh.nextZ; sh.bordersPending = false; sh.fullExchanges = 2; }   // the next step classifies with the new borders (this exchange hands bodies over: full-size messages, on every rank)
+    if (sh.bordersPending) { sh.sp = sh.spNext; sh.bordersX = sh.nextX; sh.bordersZ = sh.nextZ; sh.bordersPending = false; sh.fullExchanges = 2; sh.sweepFullSteps = 2; }   // the next step classifies with the new borders (this exchange hands bodies over: full-size messages, on every rank)
     if (!sh.rccl) {
         // (the axis of this rank's own sums is also what k_pair_finish computed: hs.axisNext, already in sapAxis)
         HIP_TRY(hipEventRecord(sh.exEv[1], st));
@@ -2759,18 +2761,33 @@ int mi_world::shardSweepExchange(uint32_t sweep) {
         HIP_TRY(hipMemcpyAsync(counts, sh.sweepCount.p, 8 * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (uint32_t k = 0; k < sh.sp.numPeers; ++k) if (counts[k] > sh.capacity) return fail(MI_ERR_CAPACITY, "exact seam: more shared bodies than a neighbour message holds (mi_shard_desc::max_records)");
+        if (sh.sweepCut) { sh.sweepCut = false; return fail(MI_ERR_CAPACITY, "exact seam: a sweep message outgrew the size both ranks had derived from the previous step (more than 1.5 x + 64 shared bodies in one step): set MI_SHARD_ADAPTIVE=0 on all ranks"); }
+        if (sh.rccl) {   // this step's message sizes: both ends know both list lengths of the PREVIOUS step (their own, and the header of the last message they received)
+            const bool sized = sh.adaptive && sh.sweepFullSteps == 0u && sh.sweepRecvValid;
+            if (sh.sweepRecvValid) { for (uint32_t k = 0; k < sh.sp.numPeers; ++k) HIP_TRY(hipMemcpyAsync(&sh.sweepPeerHdr[k], sh.sweepRecv[k].p, sizeof(uint32_t), hipMemcpyDeviceToHost, st)); HIP_TRY(hipStreamSynchronize(st)); }
+            for (uint32_t k = 0; k < sh.sp.numPeers; ++k) {
+                const uint32_t m = std::max(sh.sweepPrevOwn[k], sh.sweepPeerHdr[k]);
+                sh.sweepSized[k] = sized ? std::min(sh.capacity, m + m / 2u + 64u) : sh.capacity;
+                if (counts[k] > sh.sweepSized[k] || (sized && sh.sweepPeerHdr[k] > sh.capacity)) sh.sweepCut = true;   // (sent cut short all the same — the neighbour is already waiting for exactly that many floats —, reported at the next step)
+                sh.sweepPrevOwn[k] = counts[k];
+            }
+            if (sh.sweepFullSteps) --sh.sweepFullSteps;
+        }
     }
     if (sh.rccl) {
         Rccl* r = rccl();
-        const size_t n = sh.sweepFloats();
         int e = r->GroupStart(); if (e) return fail(MI_ERR_DEVICE, "ncclGroupStart failed");
+        ShardCaps caps{};
+        for (uint32_t k = 0; k < 8u; ++k) caps.c[k] = k < sh.sp.numPeers ? sh.sweepSized[k] : sh.capacity;
         for (uint32_t k = 0; k < sh.sp.numPeers && !e; ++k) {
+            const size_t n = (size_t)(sh.sweepSized[k] + 1u) * kSweepRecordFloats;   // header + the records both ends expect at most
             e = r->Send(sh.sweepSend[k].p, n, kNcclFloat32, (int)sh.peerRanks[k], sh.comm, st);
             if (!e) e = r->Recv(sh.sweepRecv[k].p, n, kNcclFloat32, (int)sh.peerRanks[k], sh.comm, st);
         }
         const int e2 = r->GroupEnd();
         if (e || e2) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e ? e : e2) : "RCCL send / receive failed");
-        if (sh.sp.numPeers) k_seam_sweep_unpack<<<dim3(divUp(sh.capacity, 256), sh.sp.numPeers), 256, 0, st>>>(nb, recv, sh.capacity, sh.active.p, gVel.p);
+        if (sh.sp.numPeers) k_seam_sweep_unpack<<<dim3(divUp(sh.capacity, 256), sh.sp.numPeers), 256, 0, st>>>(nb, recv, sh.capacity, sh.active.p, gVel.p, caps);
+        sh.sweepRecvValid = true;
         return MI_OK;
     }
     HIP_TRY(hipStreamSynchronize(st));   // the messages are complete
@@ -2810,7 +2827,7 @@ MI_API int mi_world_shard_set_exact_seam(mi_world* w, uint32_t enable, mi_shard_
     }
     HIP_TRY(hipSetDevice(w->device));
     if (sh.exact != (enable != 0u)) { w->tabValid = false; w->haveEstimates = false; }   // the colour ranges mean something else from here on
-    sh.exact = enable != 0u; sh.sweepFn = fn; sh.sweepUser = user;
+    sh.exact = enable != 0u; sh.sweepFn = fn; sh.sweepUser = user; sh.sweepFullSteps = 2; sh.sweepRecvValid = false;
     if (sh.exact) { HIP_TRY(sh.sweepImport.ensure(sh.sweepFloats())); HIP_TRY(w->seamId.ensure(std::max<size_t>(w->bodies.size(), 1))); }
     return MI_OK;
 }
@@ -2900,7 +2917,7 @@ MI_API int mi_world_shard_enable(mi_world* w, const mi_shard_desc* d) {
     }
     if (!sh.sentHost) HIP_TRY(hipHostMalloc((void**)&sh.sentHost, 8 * sizeof(uint32_t)));
     std::memset(sh.sentHost, 0, 8 * sizeof(uint32_t)); sh.sentPending = false; sh.exchangeTimed = false;
-    sh.fullExchanges = 2; sh.recvValid = false; if (const char* ad = getenv("MI_SHARD_ADAPTIVE")) sh.adaptive = ad[0] != '0';
+    sh.fullExchanges = 2; sh.recvValid = false; sh.sweepFullSteps = 2; sh.sweepRecvValid = false; if (const char* ad = getenv("MI_SHARD_ADAPTIVE")) sh.adaptive = ad[0] != '0';
     HIP_TRY(sh.axisDev.ensure(1)); HIP_TRY(sh.axisGlobal.ensure(kAxisSums)); HIP_TRY(sh.importBuf.ensure(sh.messageFloats()));
     HIP_TRY(hipMemcpy(sh.axisDev.p, &w->sapAxis, sizeof(uint32_t), hipMemcpyHostToDevice)); sh.axisHostCurrent = true;
     sh.enabled = true;
@@ -3069,7 +3086,7 @@ MI_API int mi_world_shard_attach_rccl(mi_world* w, const void* id) {
     Id128 uid; std::memcpy(uid.bytes, id, sizeof(uid.bytes));
     const int e = r->CommInitRank(&w->shard.comm, (int)w->shard.desc.num_ranks, uid, (int)w->shard.desc.rank);
     if (e) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e) : "ncclCommInitRank failed");
-    w->shard.rccl = true; w->shard.fullExchanges = 2; w->shard.recvValid = false;
+    w->shard.rccl = true; w->shard.fullExchanges = 2; w->shard.recvValid = false; w->shard.sweepFullSteps = 2; w->shard.sweepRecvValid = false;
     return MI_OK;
 }
 // Development / tests: the library transport on ONE rank.  A one-rank communicator whose every neighbour is this rank itself: the exchange then runs
@@ -3085,7 +3102,7 @@ MI_API int mi_debug_shard_attach_loopback(mi_world* w) {
     if (!e) e = r->CommInitRank(&w->shard.comm, 1, uid, 0);
     if (e) return fail(MI_ERR_DEVICE, r->GetErrorString ? r->GetErrorString(e) : "ncclCommInitRank failed");
     for (uint32_t& p : w->shard.peerRanks) p = 0u;
-    w->shard.rccl = true; w->shard.fullExchanges = 2; w->shard.recvValid = false;
+    w->shard.rccl = true; w->shard.fullExchanges = 2; w->shard.recvValid = false; w->shard.sweepFullSteps = 2; w->shard.sweepRecvValid = false;
     return MI_OK;
 }
 // ... and the message last RECEIVED in slot `slot` (library transport), so a test can hold it against what was sent
@@ -3170,7 +3187,7 @@ MI_API int mi_world_shard_exchange_stats(mi_world* w, mi_shard_exchange_stats* o
         HIP_TRY(hipMemcpy(act.data(), sh.active.p, nb, hipMemcpyDeviceToHost));
         for (uint8_t a : act) { out->owned_bodies += a == 1u; out->ghost_bodies += a == 2u; }
     }
-    out->sweep_exchanges = sh.sweepExchanges; out->sweep_message_bytes = sh.exact ? (uint64_t)sh.sweepFloats() * sizeof(float) : 0ull;
+    out->sweep_exchanges = sh.sweepExchanges; out->sweep_message_bytes = sh.exact ? (uint64_t)((sh.rccl && sh.sp.numPeers ? sh.sweepSized[0] : sh.capacity) + 1u) * kSweepRecordFloats * sizeof(float) : 0ull;
     for (uint32_t k = 0; k < sh.sp.numPeers; ++k) out->sweep_records_last[k] = sh.exact ? sh.sweepCounts[k] : 0u;
     if (reset) { sh.exchangesTimed = 0; sh.exchangeMsSum = 0.0; for (uint64_t& v : sh.sentSum) v = 0; sh.sweepExchanges = 0; sh.bytesSentSum = 0; }
     return rc;

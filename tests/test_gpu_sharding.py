@@ -249,6 +249,8 @@ def test_gpu_library_transport_loops_back_on_one_gpu(mi_lib, exact):
     # the messages travel as long as the previous exchange made them (either direction) x 1.5 + 512, full size only right after attach: both ends derive the same number
     assert st["message_records_last"] == [min(desc.max_records, prev_n + prev_n // 2 + 512)], (st["message_records_last"], prev_n, desc.max_records)
     assert st["message_records_last"][0] < desc.max_records
+    if exact:
+        assert 0 < st["sweep_message_bytes"] < (desc.max_records + 1) * 32, "the sweep messages are sized from the previous step's lists as well"
     assert st["message_bytes_sum"] <= 60 * (desc.max_records + 1) * 56
     a.close(); b.close()
 
