@@ -53,13 +53,45 @@ def manifold_order(contacts):
     return ab[keep]
 
 
-def _same_counts(cc, cr, i):
+def overlap_census(aabbs, axis):
+    """From the world AABBs (min xyz, max xyz per collider): (closed, touching) = the number of unordered pairs whose boxes overlap as CLOSED intervals on all
+    three axes (bounding_volumes.h:352-358: what `aabbVsAABB` accepts), and how many of those merely TOUCH on the sweep axis (one box ends exactly where the
+    other starts).  Sort-and-sweep along `axis`, vectorised per start point."""
+    mn = aabbs[:, 0:3]; mx = aabbs[:, 3:6]
+    order = np.argsort(mn[:, axis], kind="stable")
+    mn = mn[order]; mx = mx[order]
+    starts = mn[:, axis]
+    closed = touching = 0
+    for i in range(len(mn) - 1):
+        j1 = np.searchsorted(starts, mx[i, axis], side="right")          # candidates: start <= my end
+        if j1 <= i + 1:
+            continue
+        c = slice(i + 1, j1)
+        hit = np.ones(j1 - i - 1, bool)
+        for a in range(3):
+            if a != axis:
+                hit &= (mx[i, a] >= mn[c, a]) & (mn[i, a] <= mx[c, a])
+        closed += int(hit.sum())
+        touching += int((hit & (starts[c] == mx[i, axis])).sum())
+    return closed, touching
+
+
+def _same_counts(cc, cr, i, aabbs=None, axis=None):
     """Bodies, colliders, collisions (manifolds) and contacts: bit-exact.  AABB overlaps: the reference's sweep misses a pair whose intervals
-    touch EXACTLY on the sweep axis when the end point happens to sort before the start point (collision_broad.cpp:87-166; terrain tiles laid
-    edge to edge do that — static against static, never a collision pair); the grid finds every closed-interval overlap."""
+    touch EXACTLY on the sweep axis when the end point happens to sort before the start point (collision_broad.cpp:87-166, 386-398: which way such
+    a tie sorts depends on the history of its persistent endpoint array; terrain tiles laid edge to edge do that — static against static, never a
+    collision pair); the grid finds every closed-interval overlap.  With the AABBs at hand the gap is BOUNDED exactly: the candidate
+    counts every closed overlap, the reference at least all of them that do more than touch on the sweep axis."""
     for k in ("num_rigid_bodies", "num_colliders", "num_collisions", "num_contacts"):
         assert cc[k] == cr[k], f"step {i}: {k} {cc[k]} != reference {cr[k]}"
     assert cc["num_broadphase_overlaps"] >= cr["num_broadphase_overlaps"], f"step {i}: AABB overlaps {cc['num_broadphase_overlaps']} < reference {cr['num_broadphase_overlaps']}"
+    if aabbs is not None and len(aabbs) <= 6000:
+        closed, touching = overlap_census(aabbs, axis)
+        assert cc["num_broadphase_overlaps"] == closed, f"step {i}: candidate counts {cc['num_broadphase_overlaps']} overlaps, the AABBs hold {closed} closed-interval ones"
+        assert closed - touching <= cr["num_broadphase_overlaps"] <= closed, (f"step {i}: reference counts {cr['num_broadphase_overlaps']} overlaps; of the {closed} closed-interval "
+                                                                               f"ones only {touching} merely touch on the sweep axis")
+        return cc["num_broadphase_overlaps"] - cr["num_broadphase_overlaps"], touching
+    return cc["num_broadphase_overlaps"] - cr["num_broadphase_overlaps"], None
 
 
 def _same_contacts_up_to_sweep_ties(cand, ref, aabbs, axis, i):
@@ -105,8 +137,12 @@ def teacher_forced(make_candidate, make_reference, sc, steps, check_every=1):
         cand.debug_set_sweep_axis(cr["sorting_axis"])
         cand.step_fixed(s, sc.dt, 1)
         cc = cand.counts()
-        _same_counts(cc, cr, i)
-        if i % check_every == 0 or i == steps - 1:
+        check = i % check_every == 0 or i == steps - 1
+        surplus, touching = _same_counts(cc, cr, i, ref.aabbs() if check else None, cr["sorting_axis"])
+        out["surplus_overlaps"] = out.get("surplus_overlaps", 0) + surplus
+        if touching is not None:
+            out["touching_pairs_max"] = max(out.get("touching_pairs_max", 0), touching)
+        if check:
             out["tie_flips"] = out.get("tie_flips", 0) + _same_contacts_up_to_sweep_ties(cand.contacts(), ref.contacts(), ref.aabbs(), cr["sorting_axis"], i)
         a = cand.get_body_states(ids).astype(np.float64); b = ref.get_body_states(ids).astype(np.float64)
         assert np.isfinite(a).all() and np.isfinite(b).all()
@@ -135,7 +171,7 @@ def replay_reference_order(make_candidate, make_reference, sc, steps):
         cand.debug_set_solve_order(manifold_order(con))
         cand.step_fixed(s, sc.dt, 1)
         cc = cand.counts()
-        _same_counts(cc, cr, i)
+        _same_counts(cc, cr, i, ref.aabbs() if i % 8 == 0 else None, cr["sorting_axis"])
         assert contact_set(cand.contacts()) == contact_set(con), f"step {i}: contact lists"
         assert cand.get_body_states(ids).tobytes() == ref.get_body_states(ids).tobytes(), f"step {i}: body states differ from the reference's"
         most = max(most, cr["num_contacts"])
