@@ -317,7 +317,7 @@ __device__ __forceinline__ void blockSolver(
     uint16_t* lOff = reinterpret_cast<uint16_t*>(lPass + maxPasses);                    // [maxSlots][64] first impulse of the lane
     uint4* lSlot = reinterpret_cast<uint4*>(lOff + (size_t)maxSlots * 64u);             // [maxSlots] (tile, most contacts of a lane, first pass, passes)
     for (uint32_t k = threadIdx.x; k < hashSize; k += blockDim.x) hKey[k] = kHashEmpty;
-    if (threadIdx.x == 0) { sCount = 0u; sErr = 0u; }
+    if (threadIdx.x == 0) { sCount = 0u; sErr = bs->overflow ? 7u : 0u; }   // (7: the schedule already voided the step — a body with more boundary colours than mailbox slots, a list beyond its capacity: nothing to wait for)
     __syncthreads();
     const uint32_t stamp = bs->stamp << 16;
     // ---- prologue 1: this wave's tiles (t = wave, wave + 4, ...), their lanes' home bodies into the hash
