@@ -415,6 +415,22 @@ class World:
     def physics_transforms(self):
         return self._get2("world_get_physics_transforms", 3, 4)
 
+    def transforms_view(self, physics=False):
+        """mi_world_view_transforms / mi_world_view_physics_transforms: (positions [n, 3], rotations [n, 4]) as read-only numpy views of the
+        library's pinned host rows — no copy on the host side; valid until the second next stepping call (product library only)."""
+        pp = C.POINTER(C.c_float)(); rr = C.POINTER(C.c_float)(); n = C.c_uint32()
+        name = "world_view_physics_transforms" if physics else "world_view_transforms"
+        self.L.check(self.L.fn(name)(self.h, C.byref(pp), C.byref(rr), C.byref(n)), name)
+        p = np.ctypeslib.as_array(pp, shape=(n.value, 3)); r = np.ctypeslib.as_array(rr, shape=(n.value, 4))
+        p.flags.writeable = False; r.flags.writeable = False
+        return p, r
+
+    def pose_stream_stats(self):
+        """mi_debug_pose_stream_stats: (rows enqueued by a step itself, rows enqueued only when asked)."""
+        a = C.c_uint32(); d = C.c_uint32()
+        self.L.check(self.L.fn("debug_pose_stream_stats")(self.h, C.byref(a), C.byref(d)), "debug_pose_stream_stats")
+        return a.value, d.value
+
     def velocities(self):
         return self._get2("world_get_velocities", 3, 3)
 

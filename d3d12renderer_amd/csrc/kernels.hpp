@@ -3029,4 +3029,28 @@ __global__ __launch_bounds__(kScanThreads) void k_exclusive_scan(T* __restrict__
     for (uint32_t k = 0; k < kScanItems; ++k) if (base + k < n) out[base + k] = off + v[k];
 }
 
+// ------------------------------------------------------------------------------------------------ poses for the caller
+// The transforms the caller reads after a step (transform_component of every entity with a rigid body), produced where the bodies live:
+// one lane per entity, out as [n][3] positions followed by [n][4] rotations — the layout of mi_world_get_transforms — so that ONE
+// device-to-host copy of 28 B per entity follows instead of 2-4 arrays of 16 B per body and a host pass over them.
+// lerpT < 0: transform = physics_transform1 (physics.cpp:1408-1411); else lerp(transform0, transform1, t), nlerp on the rotation
+// (physics.cpp:1392-1406, src/core/math.h:673-682) — the same expressions as the host path (download()), bit for bit.
+// Entities without a rigid body keep their host-side transform: their rows are left alone here and filled in by the host.
+__global__ __launch_bounds__(256) void k_entity_poses(uint32_t n, const int* __restrict__ entBody, const float4* __restrict__ pos, const float4* __restrict__ rot,
+                                                      const float4* __restrict__ pos0, const float4* __restrict__ rot0, float lerpT, float* __restrict__ outP, float* __restrict__ outR) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int b = entBody[i];
+    if (b < 0) return;
+    const float4 p1 = pos[b], r1 = rot[b];
+    V3 ps(p1.x, p1.y, p1.z); Q4 rt(r1.x, r1.y, r1.z, r1.w);
+    if (lerpT >= 0.f) {
+        const float4 p0 = pos0[b], r0 = rot0[b]; const float t = lerpT;
+        ps = lerp(V3(p0.x, p0.y, p0.z), ps, t);
+        rt = normalize(Q4(r0.x + t * (r1.x - r0.x), r0.y + t * (r1.y - r0.y), r0.z + t * (r1.z - r0.z), r0.w + t * (r1.w - r0.w)));
+    }
+    outP[3 * (size_t)i] = ps.x; outP[3 * (size_t)i + 1] = ps.y; outP[3 * (size_t)i + 2] = ps.z;
+    *reinterpret_cast<float4*>(outR + 4 * (size_t)i) = make_float4(rt.x, rt.y, rt.z, rt.w);
+}
+
 }  // namespace mi

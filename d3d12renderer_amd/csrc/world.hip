@@ -12,6 +12,7 @@
 #include <vector>
 #include <unordered_map>
 #include <chrono>
+#include <atomic>
 #include <thread>
 #include <string>
 #include <algorithm>
@@ -202,6 +203,29 @@ struct mi_world {
     // whole body state twice per call: at 57 k bodies that was most of a batched learning step)
     bool lerpPending = false, p0OnDevice = false; float lerpT = 0.f;
     float4* downloadStage = nullptr; size_t downloadStageCap = 0;   // pinned staging of download()
+    // Poses for a caller that reads them after every step (a renderer): k_entity_poses writes the entity transforms in the caller's layout, ONE copy
+    // per step brings them into pinned host memory in kPoseChunks pieces on a second stream, and once a caller has asked after a step the next
+    // step enqueues both by itself, before it returns — the copy is then under way while control goes back to the caller.
+    static constexpr uint32_t kPoseChunks = 4;
+    struct PoseStream {
+        bool enabled = true;                     // MI_POSE_STREAM=0: the per-array copies + host pass
+        DBuf<int> entBody; DBuf<float> out;      // entity -> rigid body (or -1); [n][4] rotations followed by [n][3] positions
+        float* host[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; size_t hostCap = 0;   // pinned; per flavour (entity transforms / physics transforms) two sets alternate: what mi_world_view_* hands out stays untouched by the next step
+        hipStream_t copyStream = nullptr; hipEvent_t produced = nullptr; hipEvent_t chunkEv[kPoseChunks] = {nullptr, nullptr, nullptr, nullptr};
+        size_t chunkOff[kPoseChunks + 1] = {0, 0, 0, 0, 0};
+        std::vector<uint32_t> noBody;            // entities without a rigid body: their transform is the host's
+        uint32_t tableCount = 0; bool tablesValid = false;
+        bool valid = false, copyInFlight = false; uint64_t steps = 0; float t = 0.f; uint32_t n = 0; int cur[2] = {0, 0}, flavour = 0;   // the last production
+        bool wanted = false, consumed = false, askedPhysics = false, retrySameStep = false;
+        uint32_t produced_ahead = 0, produced_on_demand = 0;
+    } pose;
+    struct PoseArm { bool armed = false, done = false; float t = 0.f; } poseArm;   // the stepping call wants the LAST of its internal steps to enqueue the rows itself, behind its kernels and ahead of the host's wait
+    bool posesPossible(bool physics, float* t) const;
+    bool posesWantedAhead();
+    void posesArm(bool lerpAfterwards, float lerpTAfterwards);
+    int posesProduce(float t, bool fromNextState);
+    int posesFetch(float* p, float* r, const float** viewP, const float** viewR);
+    int posesAfterStep();
     float timer = 0.f;
 
     // device: bodies
@@ -375,6 +399,7 @@ int mi_world::init(int dev) {
     if (const char* g = getenv("MI_GRAPH")) { const std::string v(g); if (v == "0") graphsEnabled = false; if (v == "force") graphsEnabled = true; graphsForAll = v == "all"; }   // 0: never replay steps as HIP graphs; all: also the large scenes
     if (const char* g = getenv("MI_GRAPH_MAX_COLLIDERS")) graphMaxColliders = (uint32_t)strtoul(g, nullptr, 0);
     graphDebug = getenv("MI_GRAPH_DEBUG") != nullptr; graphNoEvents = getenv("MI_GRAPH_NOEVENTS") != nullptr; graphNoCapture = getenv("MI_GRAPH_NOCAPTURE") != nullptr;
+    if (const char* ps = getenv("MI_POSE_STREAM")) pose.enabled = ps[0] != '0';
     if (const char* sr = getenv("MI_READBACK")) spinReadback = spinReadback && std::string(sr) != "copy";   // MI_READBACK=copy: hipMemcpyAsync + hipStreamSynchronize
     stageEvents = getenv("MI_STAGE_EVENTS") && getenv("MI_STAGE_EVENTS")[0] != '0';   // default: nothing is timed (mi_world_set_stage_timing)
     stepEvents = getenv("MI_STEP_EVENTS") && getenv("MI_STEP_EVENTS")[0] != '0';
@@ -426,6 +451,10 @@ mi_world::~mi_world() {
     (void)hipDeviceSynchronize();
     if (hsPinned) (void)hipHostFree(hsPinned);
     if (downloadStage) (void)hipHostFree(downloadStage);
+    for (auto& hh : pose.host) for (float*& h : hh) if (h) (void)hipHostFree(h);
+    if (pose.produced) (void)hipEventDestroy(pose.produced);
+    for (hipEvent_t& e : pose.chunkEv) if (e) (void)hipEventDestroy(e);
+    if (pose.copyStream) (void)hipStreamDestroy(pose.copyStream);
     if (shard.sentHost) (void)hipHostFree(shard.sentHost);
     if (shard.recvHost) (void)hipHostFree(shard.recvHost);
     for (hipEvent_t& e : shard.exEv) if (e) (void)hipEventDestroy(e);
@@ -571,6 +600,7 @@ static float4 h4(V3 v, float w) { return make_float4(v.x, v.y, v.z, w); }
 int mi_world::upload() {
     recalcProperties();
     dropStepGraphs();
+    pose.valid = false; pose.tablesValid = false;
     shard.prevValid = false; shard.flagsSwapPending = false; shard.flagsOfAStep = false;
     uint32_t nb = (uint32_t)bodies.size(), nc = (uint32_t)colliders.size();
     std::vector<float4> pos(nb), rot(nb), lv(nb), av(nb), fo(nb), to(nb), cim(nb), ii(3 * (size_t)nb), prm(nb);
@@ -719,6 +749,132 @@ int mi_world::uploadHeightmap() {
     return MI_OK;
 }
 
+// ---- poses for the caller (PoseStream)
+bool mi_world::posesPossible(bool physics, float* t) const {
+    const bool follow = physics || transformsFollowPhysics, lerpNow = !follow && lerpPending;
+    if (!pose.enabled || !hostStale || topologyDirty || bodies.empty() || shard.enabled) return false;
+    if (!follow && !(lerpNow && p0OnDevice)) return false;
+    *t = follow ? -1.f : lerpT;
+    return true;
+}
+int mi_world::posesProduce(float t, bool fromNextState) {
+    HIP_TRY(hipSetDevice(device));
+    PoseStream& ps = pose;
+    const uint32_t n = (uint32_t)entities.size();
+    if (!ps.copyStream) {
+        HIP_TRY(hipStreamCreateWithFlags(&ps.copyStream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ps.produced, hipEventDisableTiming));
+        for (hipEvent_t& e : ps.chunkEv) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    }
+    if (ps.copyInFlight) { HIP_TRY(hipStreamWaitEvent(stream, ps.chunkEv[kPoseChunks - 1], 0)); ps.copyInFlight = false; }   // the device-side rows are about to be rewritten
+    if (!ps.tablesValid || ps.tableCount != n) {
+        std::vector<int> eb(n); ps.noBody.clear();
+        for (uint32_t i = 0; i < n; ++i) { eb[i] = entities[i].rb; if (eb[i] < 0) ps.noBody.push_back(i); }
+        HIP_TRY(ps.entBody.ensure(std::max<size_t>(n, 1)));
+        HIP_TRY(hipMemcpyAsync(ps.entBody.p, eb.data(), (size_t)n * sizeof(int), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));   // (eb is pageable and goes away)
+        ps.tablesValid = true; ps.tableCount = n;
+    }
+    const size_t floats = 7u * (size_t)n;
+    HIP_TRY(ps.out.ensure(std::max<size_t>(floats, 4)));
+    if (floats > ps.hostCap) {
+        HIP_TRY(hipStreamSynchronize(ps.copyStream));
+        for (auto& hh : ps.host) for (float*& h : hh) { if (h) (void)hipHostFree(h); h = nullptr; }
+        ps.hostCap = 0;
+        const size_t cap = floats + floats / 4 + 16;
+        for (auto& hh : ps.host) for (float*& h : hh) HIP_TRY(hipHostMalloc((void**)&h, cap * sizeof(float)));
+        ps.hostCap = cap;
+    }
+    const int fl = t < 0.f ? 1 : 0;
+    if (!(ps.valid == false && ps.retrySameStep && ps.flavour == fl)) ps.cur[fl] ^= 1;   // (a step that is re-run produces into the same rows again: the other set may still be in a caller's hands)
+    ps.retrySameStep = false;
+    float* outR = ps.out.p; float* outP = ps.out.p + 4u * (size_t)n;
+    hipLaunchKernelGGL(k_entity_poses, dim3(divUp(n, 256u)), dim3(256), 0, stream, n, ps.entBody.p, fromNextState ? bPosN.p : bPos.p, fromNextState ? bRotN.p : bRot.p, bPos0.p, bRot0.p, t, outP, outR);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ps.produced, stream));
+    HIP_TRY(hipStreamWaitEvent(ps.copyStream, ps.produced, 0));
+    const size_t bytes = floats * sizeof(float);
+    for (uint32_t k = 0; k <= kPoseChunks; ++k) ps.chunkOff[k] = k == kPoseChunks ? bytes : std::min(bytes, ((bytes * k / kPoseChunks) + 4095u) & ~(size_t)4095u);
+    for (uint32_t k = 0; k < kPoseChunks; ++k) {
+        const size_t off = ps.chunkOff[k], len = ps.chunkOff[k + 1] - off;
+        if (len) HIP_TRY(hipMemcpyAsync(reinterpret_cast<char*>(ps.host[fl][ps.cur[fl]]) + off, reinterpret_cast<const char*>(ps.out.p) + off, len, hipMemcpyDeviceToHost, ps.copyStream));
+        HIP_TRY(hipEventRecord(ps.chunkEv[k], ps.copyStream));
+    }
+    ps.flavour = fl;
+    ps.valid = true; ps.copyInFlight = true; ps.steps = totalSteps; ps.t = t; ps.n = n; ps.consumed = false;
+    return MI_OK;
+}
+// p / r: the caller's arrays ([n][3], [n][4]; either may be null) — a few threads copy each piece as it lands; viewP / viewR: the pinned rows themselves
+int mi_world::posesFetch(float* p, float* r, const float** viewP, const float** viewR) {
+    PoseStream& ps = pose;
+    const uint32_t n = ps.n;
+    float* src = ps.host[ps.flavour][ps.cur[ps.flavour]];
+    const size_t rBytes = 16u * (size_t)n;
+    if (viewP || viewR) {
+        HIP_TRY(hipEventSynchronize(ps.chunkEv[kPoseChunks - 1]));
+        for (uint32_t i : ps.noBody) {
+            const HEntity& e = entities[i];
+            float* rr = src + 4u * (size_t)i; float* pp = src + 4u * (size_t)n + 3u * (size_t)i;
+            rr[0] = e.rot.x; rr[1] = e.rot.y; rr[2] = e.rot.z; rr[3] = e.rot.w; pp[0] = e.pos.x; pp[1] = e.pos.y; pp[2] = e.pos.z;
+        }
+        if (viewP) *viewP = src + 4u * (size_t)n;
+        if (viewR) *viewR = src;
+    }
+    if (p || r) {
+        const size_t total = ps.chunkOff[kPoseChunks];
+        const uint32_t threads = total >= (1u << 20) ? std::min<uint32_t>(4u, std::max(1u, std::thread::hardware_concurrency())) : 1u;
+        std::atomic<int> err{0};
+        auto work = [&](uint32_t tid) {
+            for (uint32_t k = 0; k < kPoseChunks; ++k) {
+                if (hipEventSynchronize(ps.chunkEv[k]) != hipSuccess) { err = 1; return; }
+                const size_t lo0 = ps.chunkOff[k], len = ps.chunkOff[k + 1] - lo0;
+                size_t lo = lo0 + ((len * tid / threads) & ~(size_t)63), hi = tid + 1 == threads ? lo0 + len : lo0 + ((len * (tid + 1) / threads) & ~(size_t)63);
+                if (lo < rBytes && r) { const size_t e = std::min(hi, rBytes); std::memcpy(reinterpret_cast<char*>(r) + lo, reinterpret_cast<const char*>(src) + lo, e - lo); }
+                if (hi > rBytes && p) { const size_t b = std::max(lo, rBytes); std::memcpy(reinterpret_cast<char*>(p) + (b - rBytes), reinterpret_cast<const char*>(src) + b, hi - b); }
+            }
+        };
+        std::vector<std::thread> pool;
+        for (uint32_t tdx = 1; tdx < threads; ++tdx) { try { pool.emplace_back(work, tdx); } catch (...) { for (std::thread& th : pool) th.join(); pool.clear(); for (uint32_t q = 1; q < threads; ++q) work(q); break; } }
+        work(0);
+        for (std::thread& th : pool) th.join();
+        if (err) return fail(MI_ERR_DEVICE, "pose copy");
+        for (uint32_t i : ps.noBody) {
+            const HEntity& e = entities[i];
+            if (p) { p[3 * (size_t)i] = e.pos.x; p[3 * (size_t)i + 1] = e.pos.y; p[3 * (size_t)i + 2] = e.pos.z; }
+            if (r) { r[4 * (size_t)i] = e.rot.x; r[4 * (size_t)i + 1] = e.rot.y; r[4 * (size_t)i + 2] = e.rot.z; r[4 * (size_t)i + 3] = e.rot.w; }
+        }
+    }
+    ps.consumed = true; ps.wanted = true;
+    return MI_OK;
+}
+// end of mi_world_step / mi_world_step_fixed: a caller that asked for the poses after the previous step gets this step's under way now
+bool mi_world::posesWantedAhead() {
+    PoseStream& ps = pose;
+    if (!ps.enabled || !ps.wanted) return false;
+    if (ps.valid && !ps.consumed) { ps.wanted = false; return false; }   // nobody read the last ones
+    return true;
+}
+// before the last internal step of a stepping call: what the poses will be afterwards is known (physics_transform1, or the lerp with the factor
+// the accumulator will leave), so that step enqueues them itself — the host's ~0.1 ms of launches and copies hides behind the step's kernels
+void mi_world::posesArm(bool lerpAfterwards, float lerpTAfterwards) {
+    poseArm = PoseArm{};
+    if (!posesWantedAhead() || topologyDirty || bodies.empty() || shard.enabled) return;
+    const bool follow = pose.askedPhysics || !lerpAfterwards;
+    poseArm.armed = true; poseArm.t = follow ? -1.f : lerpTAfterwards;
+}
+int mi_world::posesAfterStep() {
+    PoseStream& ps = pose;
+    const bool inside = poseArm.armed && poseArm.done;
+    poseArm = PoseArm{};
+    if (inside) return MI_OK;
+    if (!posesWantedAhead()) return MI_OK;
+    float t;
+    if (!posesPossible(ps.askedPhysics, &t)) return MI_OK;
+    if (ps.valid && ps.steps == totalSteps && ps.t == t && ps.n == (uint32_t)entities.size() && ps.tablesValid) return MI_OK;
+    ++ps.produced_ahead;
+    return posesProduce(t, false);
+}
+
 int mi_world::download() {
     if (!hostStale) return MI_OK;
     uint32_t nb = (uint32_t)bodies.size();
@@ -836,6 +992,7 @@ int mi_world::stepInternal(const mi_step_settings& settings, float dt) {
     // a step that asks to be re-run has written nothing persistent; each re-run is synchronous and one rung further down the ladder
     // speculative -> exact sizes -> unpartitioned -> dispatch-ordered dataflow kernel -> one launch per colour
     for (int attempt = 0; rc == STEP_RETRY && attempt < 6; ++attempt) {
+        if (poseArm.done) { poseArm.done = false; pose.valid = false; pose.retrySameStep = true; --pose.produced_ahead; }
         if (exactSeam && shard.sweepsDone) return fail(MI_ERR_DEVICE, "exact seam: the step would have to be re-run after sweeps were already exchanged with the neighbours");
         ++specRetries; rc = runStep(settings, dt, false);
     }
@@ -1543,6 +1700,11 @@ enqueue_section:
         }
         const uint64_t sig = graphLastSig;
         stepGraphs.push_back(StepGraph{sig, exec, ++graphUseClock}); ++graphCaptures;
+    }
+    if (poseArm.armed) {   // the poses of the state this step is producing, enqueued behind it (a step that turns out void produces them again)
+        ++pose.produced_ahead; poseArm.done = false;
+        int rcp = posesProduce(poseArm.t, true); if (rcp != MI_OK) return rcp;
+        poseArm.done = true;
     }
     if (spinReadback) {
         const uint32_t seq = readbackSeq + 1u ? readbackSeq + 1u : 1u;   // never 0; the device counts the same way (k_publish_readback)
@@ -2541,8 +2703,8 @@ MI_API int mi_world_step_fixed(mi_world* w, const mi_step_settings* s, float dt,
     if (!w || !s) return fail(MI_ERR_INVALID_ARGUMENT, "null argument");
     if (n > 1 && w->shard.enabled && !w->shard.rccl) return fail(MI_ERR_INVALID_ARGUMENT, "a sharded world with the caller's transport takes one internal step per call (exchange in between)");
     if (n) w->transformsFollowPhysics = true;
-    for (uint32_t i = 0; i < n; ++i) { int rc = w->stepInternal(*s, dt); if (rc != MI_OK) return rc; }
-    return MI_OK;
+    for (uint32_t i = 0; i < n; ++i) { if (i + 1 == n) w->posesArm(false, 0.f); int rc = w->stepInternal(*s, dt); if (rc != MI_OK) { w->poseArm = mi_world::PoseArm{}; return rc; } }
+    return n ? w->posesAfterStep() : MI_OK;
 }
 
 // One internal step with a HIP event pair around every k_contact_solve launch (roofline measurement; bench.py).
@@ -2579,15 +2741,18 @@ MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
                 HIP_TRY(hipMemcpyAsync(w->bRot0.p, w->bRot.p, (size_t)nb * sizeof(float4), hipMemcpyDeviceToDevice, w->stream));
                 w->p0OnDevice = true; w->hostStale = true;
             }
+            uint32_t willRun = 0; float timerAfter = w->timer;   // the loop below, run ahead: how many internal steps, and the interpolation factor they leave
+            { uint32_t it = 0; while (timerAfter >= fixedDt && it++ < s->max_physics_iterations_per_frame) { timerAfter -= fixedDt; ++willRun; } if (timerAfter >= fixedDt) timerAfter = fmodf(timerAfter, fixedDt); }
             while (w->timer >= fixedDt && iterations++ < s->max_physics_iterations_per_frame) {
-                int rc = w->stepInternal(*s, fixedDt); if (rc != MI_OK) return rc;
+                if (iterations == willRun && nb) w->posesArm(true, timerAfter / fixedDt);
+                int rc = w->stepInternal(*s, fixedDt); if (rc != MI_OK) { w->poseArm = mi_world::PoseArm{}; return rc; }
                 w->timer -= fixedDt;
             }
         }
         if (w->timer >= fixedDt) w->timer = fmodf(w->timer, fixedDt);
         // the interpolated transforms lerp(transform0, transform1, timer / fixedDt) are produced when somebody asks for them (download)
         w->lerpT = w->timer / fixedDt;
-        if (w->hostStale) { w->lerpPending = true; return MI_OK; }
+        if (w->hostStale) { w->lerpPending = true; return w->posesAfterStep(); }
         const float t = w->lerpT;   // nothing newer on the device (no sub-step in this call, host state current): interpolate right here
         for (HBody& b : w->bodies) {
             HEntity& e = w->entities[b.entity];
@@ -2596,9 +2761,10 @@ MI_API int mi_world_step(mi_world* w, const mi_step_settings* s, float dt) {
         }
         return MI_OK;
     }
-    int rc = w->stepInternal(*s, dt); if (rc != MI_OK) return rc;
+    w->posesArm(false, 0.f);
+    int rc = w->stepInternal(*s, dt); if (rc != MI_OK) { w->poseArm = mi_world::PoseArm{}; return rc; }
     w->transformsFollowPhysics = true;   // transform = physics_transform1, at the next download
-    return MI_OK;
+    return w->posesAfterStep();
 }
 
 // ================================================================================================ sharded world (include/mi_shard.h)
@@ -3436,6 +3602,15 @@ static int getTransforms(mi_world* w, float* p, float* r, uint32_t cap, bool phy
     if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     uint32_t n = (uint32_t)w->entities.size();
     if (cap < n) return fail(MI_ERR_CAPACITY, "capacity < num entities");
+    {   // the poses produced on the device in the caller's layout, one copy (PoseStream)
+        float t;
+        if (w->posesPossible(physics, &t)) {
+            mi_world::PoseStream& ps = w->pose;
+            if (!(ps.valid && ps.steps == w->totalSteps && ps.t == t && ps.n == n && ps.tablesValid && ps.tableCount == n)) { ++ps.produced_on_demand; int rc = w->posesProduce(t, false); if (rc != MI_OK) return rc; }
+            ps.askedPhysics = physics;
+            return w->posesFetch(p, r, nullptr, nullptr);
+        }
+    }
     {   // The caller that reads the poses after every step (a renderer): positions and rotations come straight from the device — 2 arrays (4 while an
         // interpolation is pending) instead of the 6-8 of a full download() — and the host mirror of the bodies is left alone (still stale: whoever
         // needs it downloads it).  Same arithmetic as download(), which keeps producing the same values later.
@@ -3492,6 +3667,32 @@ static int getTransforms(mi_world* w, float* p, float* r, uint32_t cap, bool phy
 }
 MI_API int mi_world_get_transforms(mi_world* w, float* p, float* r, uint32_t cap) { return getTransforms(w, p, r, cap, false); }
 MI_API int mi_world_get_physics_transforms(mi_world* w, float* p, float* r, uint32_t cap) { return getTransforms(w, p, r, cap, true); }
+// The same values without the last copy: pointers to the library's pinned rows ([n][3] positions, [n][4] rotations), valid until the
+// SECOND next stepping call on this world (two sets alternate).  MI_ERR_UNSUPPORTED when the poses are not coming from the device right now
+// (nothing stepped since the last download, topology changed, sharded world): mi_world_get_transforms covers every case.
+static int viewTransforms(mi_world* w, const float** p, const float** r, uint32_t* count, bool physics) {
+    if (!w || (!p && !r)) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    const uint32_t n = (uint32_t)w->entities.size();
+    float t;
+    if (!w->posesPossible(physics, &t)) return fail(MI_ERR_UNSUPPORTED, "no device-side poses to view (nothing stepped since the last download, topology change pending, or sharded world): mi_world_get_transforms");
+    mi_world::PoseStream& ps = w->pose;
+    if (!(ps.valid && ps.steps == w->totalSteps && ps.t == t && ps.n == n && ps.tablesValid && ps.tableCount == n)) { ++ps.produced_on_demand; int rc = w->posesProduce(t, false); if (rc != MI_OK) return rc; }
+    ps.askedPhysics = physics;
+    if (count) *count = n;
+    const float *vp = nullptr, *vr = nullptr;
+    int rc = w->posesFetch(nullptr, nullptr, &vp, &vr); if (rc != MI_OK) return rc;
+    if (p) *p = vp;
+    if (r) *r = vr;
+    return MI_OK;
+}
+MI_API int mi_world_view_transforms(mi_world* w, const float** p, const float** r, uint32_t* count) { return viewTransforms(w, p, r, count, false); }
+MI_API int mi_world_view_physics_transforms(mi_world* w, const float** p, const float** r, uint32_t* count) { return viewTransforms(w, p, r, count, true); }
+MI_API int mi_debug_pose_stream_stats(mi_world* w, uint32_t* ahead, uint32_t* on_demand) {
+    if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
+    if (ahead) *ahead = w->pose.produced_ahead;
+    if (on_demand) *on_demand = w->pose.produced_on_demand;
+    return MI_OK;
+}
 MI_API int mi_world_get_velocities(mi_world* w, float* lin, float* ang, uint32_t cap) {
     if (!w) return fail(MI_ERR_INVALID_ARGUMENT, "null");
     uint32_t n = (uint32_t)w->entities.size();

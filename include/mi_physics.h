@@ -267,6 +267,14 @@ MI_API int mi_world_get_step_mode_stats(mi_world* world, uint32_t* out_steps, ui
 MI_API int mi_world_num_entities(mi_world* world, uint32_t* out);
 MI_API int mi_world_get_transforms(mi_world* world, float* positions_xyz, float* rotations_xyzw, uint32_t capacity);
 MI_API int mi_world_get_physics_transforms(mi_world* world, float* positions_xyz, float* rotations_xyzw, uint32_t capacity);
+/* The same values without the last host copy, for a caller that reads every entity's transform after every step (the renderer
+ * reading transform_component, src/physics/physics.cpp:1392-1411): pointers to the library's pinned host rows, [count][3] positions
+ * and [count][4] rotations.  The rows are produced on the device in this layout and cross the bus as ONE copy which, once a caller
+ * has asked after a step, every later step enqueues itself before it returns.  Valid until the SECOND next stepping call on this
+ * world (two sets alternate); read-only.  MI_ERR_UNSUPPORTED when the poses are not coming from the device right now (nothing
+ * stepped since the last full download, a topology change is pending, a sharded world): mi_world_get_transforms covers every case. */
+MI_API int mi_world_view_transforms(mi_world* world, const float** positions_xyz, const float** rotations_xyzw, uint32_t* out_count);
+MI_API int mi_world_view_physics_transforms(mi_world* world, const float** positions_xyz, const float** rotations_xyzw, uint32_t* out_count);
 MI_API int mi_world_get_velocities(mi_world* world, float* linear_xyz, float* angular_xyz, uint32_t capacity);
 MI_API int mi_world_get_mass_properties(mi_world* world, float* inv_mass, float* inv_inertia_9, float* local_cog_xyz, uint32_t capacity);
 MI_API int mi_world_get_counts(mi_world* world, mi_step_counts* out);
@@ -294,6 +302,8 @@ MI_API int mi_debug_step_graph_stats(mi_world* world, uint32_t* out4);
    hash slots, passes per wave, impulses per wave, LDS bytes, entries needed, extras needed, bodies needed, passes needed, impulses needed, boundary entries,
    block steps so far, steps the path is switched off for }.  No reference counterpart. */
 MI_API int mi_debug_block_stats(mi_world* world, uint32_t* out16);
+/* Tests: how many times the pose rows (mi_world_view_transforms) were enqueued by a step itself, and how many times only when asked. */
+MI_API int mi_debug_pose_stream_stats(mi_world* world, uint32_t* out_ahead, uint32_t* out_on_demand);
 /* Sum of the per-stage device times and of the contact updates (contacts x solver iterations) over the internal steps since
  * the last reset (so a benchmark loop does not have to call back into the library after every step). */
 MI_API int mi_world_get_accumulated_stage_times(mi_world* world, mi_stage_times* out_sum, uint32_t* out_steps,

@@ -135,6 +135,47 @@ def test_gpu_physics_step_accumulator(mi_lib, oracle_mod):
         assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
 
 
+def test_gpu_pose_rows_for_a_caller_that_reads_them_after_every_step(mi_lib, oracle_mod, monkeypatch):
+    """The renderer's pattern: physicsStep, then the transform of every entity, frame after frame.  The rows are produced on the device in the
+    caller's layout (k_entity_poses: lerp / nlerp of physics_transform0 and 1, or physics_transform1 itself) and come over in one copy which the
+    step enqueues itself once somebody has asked after the previous step.  Same bytes as the oracle's transforms, as the copying call and as the
+    per-array path (MI_POSE_STREAM=0); entities without a rigid body (the static ground) keep the host's transform; a view stays intact for one
+    more step."""
+    sc = scenes.obb_pile(12, 5, 12, spacing=1.05)
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    monkeypatch.setenv("MI_POSE_STREAM", "0")
+    h = sc.populate(gpu_world(mi_lib))
+    monkeypatch.delenv("MI_POSE_STREAM")
+    s = sc.settings()
+    assert g.num_entities() > sc.num_bodies, "the scene has entities without a rigid body"
+    kept = None
+    for i in range(24):
+        dt = sc.dt * (1.15, 0.55, 0.75, 0.95, 1.35)[i % 5]   # 0, 1 or 2 internal steps per call, a different interpolation factor every time
+        for w in (g, o, h):
+            w.step(s, dt)
+        vp, vr = g.transforms_view()
+        if kept is not None:                          # the view handed out one step ago is still what it was
+            assert kept[0].tobytes() == kept[2] and kept[1].tobytes() == kept[3]
+        kept = (vp, vr, vp.tobytes(), vr.tobytes())
+        p, r = g.transforms(); po, ro = o.transforms(); ph, rh = h.transforms()
+        assert p.tobytes() == po.tobytes() == ph.tobytes() == vp.tobytes(), f"call {i}"
+        assert r.tobytes() == ro.tobytes() == rh.tobytes() == vr.tobytes(), f"call {i}"
+        if i % 4 == 3:
+            pp, pr = g.physics_transforms(); qp, qr = o.physics_transforms(); wp, wr = g.transforms_view(physics=True)
+            assert pp.tobytes() == qp.tobytes() == wp.tobytes() and pr.tobytes() == qr.tobytes() == wr.tobytes()
+    ahead, on_demand = g.pose_stream_stats()
+    assert ahead >= 12 and h.pose_stream_stats() == (0, 0)
+    for _ in range(6):                                # plain internal steps: transform = physics_transform1
+        for w in (g, o):
+            w.step_fixed(s, sc.dt, 2)
+        assert g.transforms()[1].tobytes() == o.transforms()[1].tobytes() and g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
+    assert g.pose_stream_stats()[0] > ahead
+    g.step(s, 0.0); o.step(s, 0.0)                    # physicsStep settles what the plain steps left pending (a full download) and runs no internal step: nothing newer on the device, no view to hand out
+    with pytest.raises(capi.PhysicsError):
+        g.transforms_view()
+    assert g.transforms()[0].tobytes() == o.transforms()[0].tobytes()
+
+
 def test_gpu_pose_and_velocity_readbacks_agree_with_a_full_download(mi_lib, oracle_mod):
     """mi_world_get_transforms / _physics_transforms / _velocities read straight from the device (2-4 arrays, host mirror untouched); everything
     else goes through a full download of the body state.  Both give the same bytes, in any order, interpolated or not, and equal the oracle."""
