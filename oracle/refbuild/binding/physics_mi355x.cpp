@@ -258,16 +258,28 @@ bool physicsStepMI355X(game_scene& scene, memory_arena& arena, float& timer, con
 	uint32 n = 0; mi_world_num_entities(world, &n);
 	static thread_local std::vector<float> pos, rot, ppos, prot, lin, ang;
 	pos.resize(3 * (size_t)n); rot.resize(4 * (size_t)n); ppos.resize(3 * (size_t)n); prot.resize(4 * (size_t)n); lin.resize(3 * (size_t)n); ang.resize(3 * (size_t)n);
-	if (!check(ctx, mi_world_get_transforms(world, pos.data(), rot.data(), n), "mi_world_get_transforms") || !check(ctx, mi_world_get_physics_transforms(world, ppos.data(), prot.data(), n), "mi_world_get_physics_transforms") ||
-		!check(ctx, mi_world_get_velocities(world, lin.data(), ang.data(), n), "mi_world_get_velocities")) { return false; }
+	// the poses come as views of the library's pinned rows when the step left them on the device (mi_world_view_*: produced there in this layout, one copy
+	// the step enqueued itself); the copying calls cover the rest (nothing stepped, topology edits pending)
+	const float *vPos = nullptr, *vRot = nullptr, *vPPos = nullptr, *vPRot = nullptr; uint32 vn = 0;
+	if (mi_world_view_transforms(world, &vPos, &vRot, &vn) != MI_OK || vn != n)
+	{
+		if (!check(ctx, mi_world_get_transforms(world, pos.data(), rot.data(), n), "mi_world_get_transforms")) { return false; }
+		vPos = pos.data(); vRot = rot.data();
+	}
+	if (mi_world_view_physics_transforms(world, &vPPos, &vPRot, &vn) != MI_OK || vn != n)
+	{
+		if (!check(ctx, mi_world_get_physics_transforms(world, ppos.data(), prot.data(), n), "mi_world_get_physics_transforms")) { return false; }
+		vPPos = ppos.data(); vPRot = prot.data();
+	}
+	if (!check(ctx, mi_world_get_velocities(world, lin.data(), ang.data(), n), "mi_world_get_velocities")) { return false; }
 	for (uint32 i = 0; i < (uint32)ctx.bodyEntityIds.size(); ++i)
 	{
 		const uint32 id = ctx.bodyEntityIds[i];
 		scene_entity e = { ctx.entityOfIndex[id], scene };
 		rigid_body_component& rb = scene.getComponentAtIndex<rigid_body_component>(i);
 		memcpy(&rb.linearVelocity, &lin[3 * (size_t)id], 12); memcpy(&rb.angularVelocity, &ang[3 * (size_t)id], 12);
-		if (transform_component* t = e.getComponentIfExists<transform_component>()) { memcpy(&t->position, &pos[3 * (size_t)id], 12); memcpy(&t->rotation, &rot[4 * (size_t)id], 16); }
-		if (physics_transform1_component* p1 = e.getComponentIfExists<physics_transform1_component>()) { memcpy(&p1->position, &ppos[3 * (size_t)id], 12); memcpy(&p1->rotation, &prot[4 * (size_t)id], 16); }
+		if (transform_component* t = e.getComponentIfExists<transform_component>()) { memcpy(&t->position, &vPos[3 * (size_t)id], 12); memcpy(&t->rotation, &vRot[4 * (size_t)id], 16); }
+		if (physics_transform1_component* p1 = e.getComponentIfExists<physics_transform1_component>()) { memcpy(&p1->position, &vPPos[3 * (size_t)id], 12); memcpy(&p1->rotation, &vPRot[4 * (size_t)id], 16); }
 		const trs& t1 = physicsPose(e);
 		ctx.written[i] = { t1.position, t1.rotation, rb.linearVelocity, rb.angularVelocity };
 	}
