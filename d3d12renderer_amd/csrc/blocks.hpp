@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256) void k_block_sched(uint32_t lastRound, const u
 // pass's rows in flight into fixed ACC registers a152 .. a255, which the compiler never allocates: tests/test_capi_symbols.py).
 // meta (k_contact_init, block mode) = (bodyA, bodyB, packed versions, w); w: blockMetaW (kernels.hpp).
 // ------------------------------------------------------------------------------------------------------------------------------
-constexpr uint32_t kBlockWaves = 4;       // (the one-wave-per-SIMD variant; k_contact_solve_blocks8 runs 8 waves, two per SIMD)
+constexpr uint32_t kBlockWaves = 4;       // one wave per SIMD
 constexpr uint32_t kHashEmpty = 0xFFFFFFFFu;
 constexpr uint32_t kBlockSpinLds = 1u << 22, kBlockSpinMem = 1u << 17;
 #define MI_ACC_LOAD2(A0, A1, addr) asm volatile("global_load_dwordx2 a[" #A0 ":" #A1 "], %0, off" : : "v"(addr) : "memory", "a" #A0, "a" #A1)
@@ -424,113 +424,6 @@ __device__ __forceinline__ void blockSolver(
     if (sErr || (faultInject && J == 1u)) { if (threadIdx.x == 0) { sc->solveError = sErr ? sErr : 1u; bs->overflow = 1u; } return; }   // nothing persistent has been written: the host re-runs the step on another path
     MI_BSTAMP(4);
     if (numPasses) {
-    if constexpr (WAVES == 8u) {
-    // ---- main loop, two waves per SIMD (256 registers each): a tile's rows stay in the ACC registers a0 .. a103 while its passes run and are read contact by contact;
-    // the next tile's rows are requested when the last pass is through — the wave then waits a memory round trip, which is the other wave's time on the SIMD.
-    auto fetchRows = [&](uint32_t slot) {
-        const uint4 sd = lSlot[slot];
-        const uint32_t tmc = sd.y;
-        const uint32_t cnt = lMeta[slot * 64u + lane].w & 7u;           // (0: padding lane; some lane has tmc contacts: none of the predicated groups below is empty)
-        const size_t at = (size_t)sd.x * 64u + lane;
-        const float4* row = rows + (size_t)sd.x * 4u * (kRows * 64u) + lane;
-        if (0u < cnt) { MI_ACC_LOAD(0, 1, 2, 3, slotNormal + at); MI_ACC_LOAD2(4, 5, slotMass + at); }
-        if (0u < tmc) { if (0u < cnt) { MI_ACC_LOAD(8, 9, 10, 11, row + 0u * 64u); MI_ACC_LOAD(12, 13, 14, 15, row + 1u * 64u); MI_ACC_LOAD(16, 17, 18, 19, row + 2u * 64u); MI_ACC_LOAD(20, 21, 22, 23, row + 3u * 64u); MI_ACC_LOAD(24, 25, 26, 27, row + 4u * 64u); MI_ACC_LOAD(28, 29, 30, 31, row + 5u * 64u); } }
-        if (1u < tmc) { if (1u < cnt) { MI_ACC_LOAD(32, 33, 34, 35, row + 6u * 64u); MI_ACC_LOAD(36, 37, 38, 39, row + 7u * 64u); MI_ACC_LOAD(40, 41, 42, 43, row + 8u * 64u); MI_ACC_LOAD(44, 45, 46, 47, row + 9u * 64u); MI_ACC_LOAD(48, 49, 50, 51, row + 10u * 64u); MI_ACC_LOAD(52, 53, 54, 55, row + 11u * 64u); } }
-        if (2u < tmc) { if (2u < cnt) { MI_ACC_LOAD(56, 57, 58, 59, row + 12u * 64u); MI_ACC_LOAD(60, 61, 62, 63, row + 13u * 64u); MI_ACC_LOAD(64, 65, 66, 67, row + 14u * 64u); MI_ACC_LOAD(68, 69, 70, 71, row + 15u * 64u); MI_ACC_LOAD(72, 73, 74, 75, row + 16u * 64u); MI_ACC_LOAD(76, 77, 78, 79, row + 17u * 64u); } }
-        if (3u < tmc) { if (3u < cnt) { MI_ACC_LOAD(80, 81, 82, 83, row + 18u * 64u); MI_ACC_LOAD(84, 85, 86, 87, row + 19u * 64u); MI_ACC_LOAD(88, 89, 90, 91, row + 20u * 64u); MI_ACC_LOAD(92, 93, 94, 95, row + 21u * 64u); MI_ACC_LOAD(96, 97, 98, 99, row + 22u * 64u); MI_ACC_LOAD(100, 101, 102, 103, row + 23u * 64u); } }
-    };
-    if (!(dbg & (4u | 0x20u))) fetchRows(0);
-    bool dead = false;
-    for (uint32_t it = 0; it < sweeps && !dead; ++it)
-        for (uint32_t s = 0; s < mySlots && !dead; ++s) {
-            const uint4 sd = lSlot[s];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the tile's rows (requested a tile ago) — and everything older
-            float4 nf; float2 mass;
-            if (dbg & 0x20u) { fetchRows(s); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-            MI_ACC_READ(nf, 0, 1, 2, 3); MI_ACC_READ2(mass, 4, 5);
-            const uint4 meta = lMeta[s * 64u + lane];
-            float2* li = lImp + lOff[s * 64u + lane];
-            const bool homeIsB = (meta.w >> 10) & 1u;
-            const uint32_t pk = meta.z;
-            const uint32_t degA = (pk >> 7) & 127u, degB = (pk >> 21) & 127u;
-            const uint32_t expA = it * degA + (pk & 127u), expB = it * degB + ((pk >> 14) & 127u);
-            for (uint32_t pass = sd.z; pass < sd.z + sd.w && !dead; ++pass) {
-                const uint4 pd = lPass[pass];
-                const uint32_t lo = (pd.x >> 8) & 0xFFu, hi = (pd.x >> 16) & 0xFFu, mc = pd.x >> 24;
-                const bool bndG = (pd.z & 1u) != 0u;
-                const bool act = lane >= lo && lane < hi;
-                if (dbg & 0x20u) { fetchRows(s); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); MI_ACC_READ(nf, 0, 1, 2, 3); MI_ACC_READ2(mass, 4, 5); }
-                const uint32_t cnt = act ? (meta.w & 7u) : 0u;
-                const bool ghostA = act && bndG && homeIsB, ghostB = act && bndG && !homeIsB;
-                const bool ldsA = act && !ghostA, ldsB = act && !ghostB;
-                const bool updA = ldsA && degA != 0u, updB = ldsB && degB != 0u;
-                const uint32_t gBody = ghostA ? meta.x : meta.y, gExp = ghostA ? expA : expB, gRank = (meta.w >> 21) & 7u;
-                const float4* gSrc = gExp == 0u ? gVel + 2 * (size_t)gBody : mail + ((((size_t)gBody * kMailRanks + gRank) * 2u + (it & 1u)) * 2u);
-                const uint32_t gTag = gExp == 0u ? 0u : (stamp | gExp);
-                f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
-                const bool ghostLoads = bndG && !(dbg & 2u);
-                if (ghostLoads) { if (act) { issueGranuleSc1(gSrc, g0); issueGranuleSc1(gSrc + 1, g1); } }
-                f32x4 a0, a1, b0, b1;
-                const uint32_t adA = recBase + 32u * (ldsA ? meta.x : 0u), adB = recBase + 32u * (ldsB ? meta.y : 0u);
-                uint32_t tA, tB;
-                const uint32_t taA = tagBase + 4u * (ldsA ? meta.x : 0u), taB = tagBase + 4u * (ldsB ? meta.y : 0u);
-                ldsLoadBodies(adA, taA, adB, taB, a0, a1, b0, b1, tA, tB);
-                if (ghostLoads) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); landed(g0); landed(g1); }
-                bool okA = !updA || tA == expA;
-                bool okB = !updB || tB == expB;
-                bool okG = !(ghostA || ghostB) || (__float_as_uint(g0.w) == gTag && __float_as_uint(g1.w) == gTag);
-                uint32_t budget = bndG ? kBlockSpinMem : kBlockSpinLds;
-                if (dbg & 1u) { okA = okB = okG = true; }
-                if (dbg & 2u) okG = true;
-                while (__ballot(!(okA && okB && okG)) != 0ull) {
-                    if (!okA) { ldsLoadBody(adA, taA, a0, a1, tA); okA = tA == expA; }
-                    if (!okB) { ldsLoadBody(adB, taB, b0, b1, tB); okB = tB == expB; }
-                    if (bndG) {
-                        if (!okG) { issueGranuleSc1(gSrc, g0); issueGranuleSc1(gSrc + 1, g1); }
-                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                        landed(g0); landed(g1);
-                        if (!okG) okG = __float_as_uint(g0.w) == gTag && __float_as_uint(g1.w) == gTag;
-                    } else __builtin_amdgcn_s_sleep(1);   // (the other wave of this SIMD may be the one this one waits for)
-                    if ((--budget & 255u) == 0u) {
-                        if (budget == 0u) { sc->solveError = 1u; __hip_atomic_store(&sErr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-                        if (budget == 0u || __hip_atomic_load(&sErr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u || __hip_atomic_load(&sc->solveError, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) { dead = true; break; }
-                    }
-                }
-                if (dead) break;
-                if (ghostA) { a0 = g0; a1 = g1; }
-                if (ghostB) { b0 = g0; b1 = g1; }
-                P3 pv, pw;
-                pv.x = pk2(a0.x, b0.x); pv.y = pk2(a0.y, b0.y); pv.z = pk2(a0.z, b0.z);
-                pw.x = pk2(a1.x, b1.x); pw.y = pk2(a1.y, b1.y); pw.z = pk2(a1.z, b1.z);
-                const f32x2 sMass = pk2(-mass.x, mass.y);
-                    if (0u < mc && !(dbg & 8u)) { if (0u < cnt) { ContactRows c; MI_ACC_READ(c.r[0], 8, 9, 10, 11); MI_ACC_READ(c.r[1], 12, 13, 14, 15); MI_ACC_READ(c.r[2], 16, 17, 18, 19); MI_ACC_READ(c.r[3], 20, 21, 22, 23); MI_ACC_READ(c.r[4], 24, 25, 26, 27); MI_ACC_READ(c.r[5], 28, 29, 30, 31); float2 im = li[0]; solveOnePk(c, nf, im, sMass, pv, pw); li[0] = im; } }
-                    if (1u < mc && !(dbg & 8u)) { if (1u < cnt) { ContactRows c; MI_ACC_READ(c.r[0], 32, 33, 34, 35); MI_ACC_READ(c.r[1], 36, 37, 38, 39); MI_ACC_READ(c.r[2], 40, 41, 42, 43); MI_ACC_READ(c.r[3], 44, 45, 46, 47); MI_ACC_READ(c.r[4], 48, 49, 50, 51); MI_ACC_READ(c.r[5], 52, 53, 54, 55); float2 im = li[1]; solveOnePk(c, nf, im, sMass, pv, pw); li[1] = im; } }
-                    if (2u < mc && !(dbg & 8u)) { if (2u < cnt) { ContactRows c; MI_ACC_READ(c.r[0], 56, 57, 58, 59); MI_ACC_READ(c.r[1], 60, 61, 62, 63); MI_ACC_READ(c.r[2], 64, 65, 66, 67); MI_ACC_READ(c.r[3], 68, 69, 70, 71); MI_ACC_READ(c.r[4], 72, 73, 74, 75); MI_ACC_READ(c.r[5], 76, 77, 78, 79); float2 im = li[2]; solveOnePk(c, nf, im, sMass, pv, pw); li[2] = im; } }
-                    if (3u < mc && !(dbg & 8u)) { if (3u < cnt) { ContactRows c; MI_ACC_READ(c.r[0], 80, 81, 82, 83); MI_ACC_READ(c.r[1], 84, 85, 86, 87); MI_ACC_READ(c.r[2], 88, 89, 90, 91); MI_ACC_READ(c.r[3], 92, 93, 94, 95); MI_ACC_READ(c.r[4], 96, 97, 98, 99); MI_ACC_READ(c.r[5], 100, 101, 102, 103); float2 im = li[3]; solveOnePk(c, nf, im, sMass, pv, pw); li[3] = im; } }
-                const uint32_t nA = expA + 1u, nB = expB + 1u;
-                if (updA) { f32x4 h0 = {pv.x.x, pv.y.x, pv.z.x, __uint_as_float(nA)}, h1 = {pw.x.x, pw.y.x, pw.z.x, __uint_as_float(nA)}; ldsStoreBody(adA, taA, h0, h1, nA); }
-                if (updB) { f32x4 h0 = {pv.x.y, pv.y.y, pv.z.y, __uint_as_float(nB)}, h1 = {pw.x.y, pw.y.y, pw.z.y, __uint_as_float(nB)}; ldsStoreBody(adB, taB, h0, h1, nB); }
-                const uint32_t eA = (meta.w >> 11) & 31u, eB = (meta.w >> 16) & 31u;
-                const bool exports = !(dbg & 16u);
-                if (exports && updA && (eA & 1u)) {
-                    const uint32_t par = (eA & 2u) ? (it & 1u) : ((it + 1u) & 1u);
-                    float4* dst = mail + ((((size_t)recBody[meta.x] * kMailRanks + (eA >> 2)) * 2u + par) * 2u);
-                    const float t = __uint_as_float(stamp | nA);
-                    f32x4 h0 = {pv.x.x, pv.y.x, pv.z.x, t}, h1 = {pw.x.x, pw.y.x, pw.z.x, t};
-                    storeGranuleSc1(dst, h0); storeGranuleSc1(dst + 1, h1);
-                }
-                if (exports && updB && (eB & 1u)) {
-                    const uint32_t par = (eB & 2u) ? (it & 1u) : ((it + 1u) & 1u);
-                    float4* dst = mail + ((((size_t)recBody[meta.y] * kMailRanks + (eB >> 2)) * 2u + par) * 2u);
-                    const float t = __uint_as_float(stamp | nB);
-                    f32x4 h0 = {pv.x.y, pv.y.y, pv.z.y, t}, h1 = {pw.x.y, pw.y.y, pw.z.y, t};
-                    storeGranuleSc1(dst, h0); storeGranuleSc1(dst + 1, h1);
-                }
-            }
-            // the next tile's rows: the ACC registers are free again
-            if (!dead && !(dbg & (4u | 0x20u)) && (mySlots > 1u || it + 1u < sweeps)) fetchRows(s + 1u < mySlots ? s + 1u : 0u);
-        }
-    } else {
     // ---- main loop: software pipeline over (sweep, pass); the next pass's rows are requested while this pass waits for its bodies.
     // Everything the loop reads from global memory goes through inline asm into fixed ACC registers, so the only vmcnt arithmetic is the one written here.
     uint32_t dbgLo = 0u, dbgHi = 64u;
@@ -666,7 +559,6 @@ __device__ __forceinline__ void blockSolver(
             }
         }
     }
-    }
     MI_BSTAMP(5);
     __syncthreads();
     MI_BSTAMP(6);
@@ -687,8 +579,6 @@ __device__ __forceinline__ void blockSolver(
 #define MI_BLOCK_FORWARD sweeps, tilesPerBlock, hashSize, bodyCap, maxSlots, maxPasses, impCap, tileInfo, slotMeta, slotNormal, slotMass, rows, gVel, gVelOut, mail, sc, bs, faultInject, dbg, dbgTimes
 // one wave per SIMD, the rows a tile ahead in a152 .. a255
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void k_contact_solve_blocks(MI_BLOCK_PARAMS) { blockSolver<4u>(MI_BLOCK_FORWARD); }
-// two waves per SIMD, the current tile's rows in a0 .. a103
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_contact_solve_blocks8(MI_BLOCK_PARAMS) { blockSolver<8u>(MI_BLOCK_FORWARD); }
 #undef MI_BLOCK_PARAMS
 #undef MI_BLOCK_FORWARD
 

@@ -240,7 +240,7 @@ struct mi_world {
     DBuf<uint32_t> blkKeys, blkRanks, blkPerm, blkStart, blkExtra, blkExtraCount; DBuf<uint16_t> blkCell; DBuf<unsigned long long> bndMask; DBuf<float4> mail;
     bool blockSolver = true, usedBlocks = false, blockFaultTest = false, blockFaultFired = false;
     struct BlockCaps { uint32_t nbe = 0, tiles = 0, extraCap = 0, bodyCap = 0, hashSize = 0, maxPasses = 0, impCap = 0; size_t lds = 0; } blkCaps;   // sticky: the same launches step after step (step graphs)
-    BlockState lastBlk{}; bool haveBlkEstimate = false, blkLastFailed = false; uint32_t blkWaves = 4 /* waves per block: 4 = one per SIMD, 8 = two per SIMD (k_contact_solve_blocks8) */, blkFailHistory = 0, blkFailures = 0, blkDisabledSteps = 0, blkLaunches = 0, blkMaxBlocks = 256, blkSteps = 0;
+    BlockState lastBlk{}; bool haveBlkEstimate = false, blkLastFailed = false; uint32_t blkWaves = 4 /* waves per block: one per SIMD */, blkFailHistory = 0, blkFailures = 0, blkDisabledSteps = 0, blkLaunches = 0, blkMaxBlocks = 256, blkSteps = 0;
     bool planBlocks(uint32_t nmLast, uint32_t nbBodies);
     bool persistXcd = true, persistXcdSingle = true, usedXcd = false, usedXcdSingle = false, lastXcdSingle = false, haveXcdEstimate = false, xcdFaultFired = false, xcdFaultTest = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
     // device: colliders
@@ -435,11 +435,9 @@ int mi_world::init(int dev) {
       if (const char* bb = getenv("MI_BLOCKS")) blockSolver = blockSolver && bb[0] != '0';
       blockFaultTest = getenv("MI_BLOCK_FAULT") != nullptr;
       blkMaxBlocks = std::max(1u, persistWaves / 4u);   // one block per CU
-      if (const char* bw = getenv("MI_BLOCK_WAVES")) blkWaves = atoi(bw) == 4 ? 4u : 8u;
       if (const char* bn = getenv("MI_BLOCKS_MAX")) blkMaxBlocks = std::max(1u, (uint32_t)strtoul(bn, nullptr, 0));
       mail.flags = hipDeviceMallocUncached;
       (void)hipFuncSetAttribute((const void*)k_contact_solve_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-      (void)hipFuncSetAttribute((const void*)k_contact_solve_blocks8, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
       flowFaultTest = getenv("MI_FLOW_FAULT") != nullptr;
       if (const char* pm = getenv("MI_PERSIST_XCD_MIN")) xcdMinManifolds = (uint32_t)strtoul(pm, nullptr, 0); }   // smallest manifold count that is partitioned (tests: 1)   // MI_PERSIST_XCD=0: no XCD partitioning (every body through memory)   // development experiment: one XCD's workgroups do all the work
     if (flowLds > 65536) (void)hipFuncSetAttribute((const void*)k_contact_solve_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flowLds);
@@ -1513,7 +1511,7 @@ enqueue_section:
         const uint32_t fault = blockFaultTest && !blockFaultFired ? 1u : 0u;   // tests: one block gives up once
         if (fault && !L.dry) blockFaultFired = true;
         const uint32_t maxSlots = divUp(bc.tiles, blkWaves);
-        auto* blockKernel = blkWaves == 8u ? k_contact_solve_blocks8 : k_contact_solve_blocks;
+        auto* blockKernel = k_contact_solve_blocks;
         static DBuf<unsigned long long> trapBuf;   // development (MI_BLOCK_MODE & 0x100): records of lanes with wild values, printed when the first ones appear
         static bool trapPrinted = false;
         if (std::getenv("MI_BLOCK_MODE") && (strtoul(std::getenv("MI_BLOCK_MODE"), nullptr, 0) & 0x100u)) {
