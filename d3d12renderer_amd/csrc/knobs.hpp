@@ -1,0 +1,91 @@
+// Every environment variable the library reads, in ONE place: read once per world (mi_world_create), typed, documented.
+// None of them is needed in production — the defaults are what is measured and shipped; they select the fallback paths the tests
+// pin against each other (every variant gives the same bits), inject the faults the fallback ladder is tested with, and switch
+// development output on.  No reference counterpart.
+#pragma once
+#include <cstdint>
+#include <cstdlib>
+#include <string>
+#include <vector>
+
+namespace mi {
+
+struct Knobs {
+    // ---- stepping
+    bool speculative = true;            // MI_ASYNC=0: every step synchronous (sizes read back inside the step)
+    bool spinReadback = true;           // MI_READBACK=copy: end-of-step read-back as hipMemcpyAsync + hipStreamSynchronize instead of the kernel-published record
+    bool stageEvents = false;           // MI_STAGE_EVENTS=1: per-stage events from the first step on (otherwise mi_world_set_stage_timing)
+    bool stepEvents = false;            // MI_STEP_EVENTS=1: step + solve-stage events from the first step on
+    bool poseStream = true;             // MI_POSE_STREAM=0: poses for the caller through the per-array copies + host pass
+    bool debugSync = false;             // MI_DEBUG_SYNC: synchronise after every stage and name the one a device fault comes from
+    bool eagerTimes = false;            // MI_EAGER_TIMES: read the step's event times at the end of the step (not one step later)
+    // ---- step graphs (launcher.hpp)
+    std::string graph;                  // MI_GRAPH=0 | force | all ("" = by runtime version)
+    uint32_t graphMaxColliders = 32768; // MI_GRAPH_MAX_COLLIDERS
+    bool graphDebug = false, graphNoEvents = false, graphNoCapture = false;   // MI_GRAPH_DEBUG / _NOEVENTS / _NOCAPTURE
+    // ---- broad / narrow phase
+    bool fuseWorld = true;              // MI_FUSE_WORLD=0: k_world_colliders as its own launch
+    bool skipPartition = true;          // MI_SKIP_PARTITION=0: always launch k_pair_partition
+    int gjkWave = -1;                   // MI_GJK_WAVE=0 / 1: force the lane / wave GJK variant
+    bool hmStash = true;                // MI_HM_STASH=0: terrain triangles recomputed instead of stashed
+    // ---- schedule
+    uint32_t colorMargin = 1;           // MI_COLOR_MARGIN: colour rounds enqueued beyond the previous step's count
+    bool xcdNoSort = false;             // MI_XCD_NOSORT: manifold order as emitted (development)
+    bool xcdStats = false;              // MI_XCD_STATS: how many bodies stayed XCD-local (development)
+    bool xcdSwizzle = false;            // MI_XCD_SWIZZLE=1
+    // ---- contact solver
+    std::string solver;                 // MI_SOLVER=launch | flow | persist | persist-global | persist-granules | blocks ("" = persist)
+    uint32_t flowLds = 0;               // MI_FLOW_LDS (bytes; 0 = default)
+    uint32_t persistWaves = 0;          // MI_PERSIST_WAVES (0 = 4 per CU)
+    bool persistXcdOnly = false;        // MI_PERSIST_XCD_ONLY (development)
+    int persistXcd = -1, persistXcdSingle = -1;   // MI_PERSIST_XCD / _SINGLE = 0 / 1 (-1 = default)
+    int xcdMinManifolds = -1;           // MI_PERSIST_XCD_MIN
+    bool xcdFault = false, flowFault = false, blockFault = false;   // MI_PERSIST_XCD_FAULT / MI_FLOW_FAULT / MI_BLOCK_FAULT: fault injection (tests)
+    std::string gvelAlloc, impAlloc;    // MI_GVEL_ALLOC / MI_IMP_ALLOC = plain | finegrained | uncached
+    // ---- block solver (blocks.hpp)
+    int blocks = -1;                    // MI_BLOCKS=0: off even with MI_SOLVER=blocks
+    uint32_t blocksMax = 0;             // MI_BLOCKS_MAX (0 = one per CU)
+    bool blockDebug = false;            // MI_BLOCK_DEBUG: one line per block step
+    uint32_t blockMode = 0;             // MI_BLOCK_MODE (development bits)
+    std::vector<uint32_t> blockDbg;     // MI_BLOCK_DBG=a,b,c: knock-out launches (development)
+    uint64_t blockDbgAfter = 0;         // MI_BLOCK_DBG_AFTER
+    // ---- joints
+    bool fuseJoints = true;             // MI_FUSE_JOINTS=0
+    bool jointIslands = true;           // MI_JOINT_ISLANDS=0
+    int islandPrivate = -1;             // MI_ISLAND_PRIVATE=0: every island through the dataflow
+    // ---- sharding
+    bool shardAdaptive = true;          // MI_SHARD_ADAPTIVE=0: neighbour messages always at full capacity
+    // ---- development dumps
+    std::string timelineOut; uint64_t timelineStep = 3;   // MI_DBG_TIMELINE_OUT / _STEP (-DMI_DBG_TIMELINE builds)
+
+    static Knobs fromEnvironment() {
+        Knobs k;
+        auto str = [](const char* n) { const char* v = std::getenv(n); return std::string(v ? v : ""); };
+        auto set = [](const char* n) { return std::getenv(n) != nullptr; };
+        auto off = [](const char* n) { const char* v = std::getenv(n); return v && v[0] == '0'; };   // "=0" switches a default-on feature off
+        auto on = [](const char* n) { const char* v = std::getenv(n); return v && v[0] != '0'; };
+        auto tri = [](const char* n) { const char* v = std::getenv(n); return !v ? -1 : (v[0] != '0' ? 1 : 0); };
+        auto num = [](const char* n, uint64_t d) { const char* v = std::getenv(n); return v ? (uint64_t)strtoull(v, nullptr, 0) : d; };
+        k.speculative = !off("MI_ASYNC"); k.spinReadback = str("MI_READBACK") != "copy"; k.stageEvents = on("MI_STAGE_EVENTS"); k.stepEvents = on("MI_STEP_EVENTS");
+        k.poseStream = !off("MI_POSE_STREAM"); k.debugSync = set("MI_DEBUG_SYNC"); k.eagerTimes = set("MI_EAGER_TIMES");
+        k.graph = str("MI_GRAPH"); k.graphMaxColliders = (uint32_t)num("MI_GRAPH_MAX_COLLIDERS", k.graphMaxColliders);
+        k.graphDebug = set("MI_GRAPH_DEBUG"); k.graphNoEvents = set("MI_GRAPH_NOEVENTS"); k.graphNoCapture = set("MI_GRAPH_NOCAPTURE");
+        k.fuseWorld = !off("MI_FUSE_WORLD"); k.skipPartition = !off("MI_SKIP_PARTITION"); k.hmStash = !off("MI_HM_STASH");
+        if (const char* v = std::getenv("MI_GJK_WAVE")) k.gjkWave = atoi(v);
+        k.colorMargin = (uint32_t)num("MI_COLOR_MARGIN", k.colorMargin); k.xcdNoSort = set("MI_XCD_NOSORT"); k.xcdStats = set("MI_XCD_STATS"); k.xcdSwizzle = str("MI_XCD_SWIZZLE") == "1";
+        k.solver = str("MI_SOLVER"); k.flowLds = (uint32_t)num("MI_FLOW_LDS", 0); k.persistWaves = (uint32_t)num("MI_PERSIST_WAVES", 0); k.persistXcdOnly = set("MI_PERSIST_XCD_ONLY");
+        k.persistXcd = tri("MI_PERSIST_XCD"); k.persistXcdSingle = tri("MI_PERSIST_XCD_SINGLE");
+        if (const char* v = std::getenv("MI_PERSIST_XCD_MIN")) k.xcdMinManifolds = (int)strtoul(v, nullptr, 0);
+        k.xcdFault = set("MI_PERSIST_XCD_FAULT"); k.flowFault = set("MI_FLOW_FAULT"); k.blockFault = set("MI_BLOCK_FAULT");
+        k.gvelAlloc = str("MI_GVEL_ALLOC"); k.impAlloc = str("MI_IMP_ALLOC");
+        k.blocks = tri("MI_BLOCKS"); k.blocksMax = (uint32_t)num("MI_BLOCKS_MAX", 0); k.blockDebug = set("MI_BLOCK_DEBUG"); k.blockMode = (uint32_t)num("MI_BLOCK_MODE", 0);
+        if (const char* e = std::getenv("MI_BLOCK_DBG")) { const char* p = e; while (*p) { char* q; k.blockDbg.push_back((uint32_t)strtoul(p, &q, 0)); if (q == p) break; p = (*q == ',') ? q + 1 : q; } }
+        k.blockDbgAfter = num("MI_BLOCK_DBG_AFTER", 0);
+        k.fuseJoints = !off("MI_FUSE_JOINTS"); k.jointIslands = !off("MI_JOINT_ISLANDS"); k.islandPrivate = tri("MI_ISLAND_PRIVATE");
+        k.shardAdaptive = !off("MI_SHARD_ADAPTIVE");
+        k.timelineOut = str("MI_DBG_TIMELINE_OUT"); k.timelineStep = num("MI_DBG_TIMELINE_STEP", 3);
+        return k;
+    }
+};
+
+}  // namespace mi
