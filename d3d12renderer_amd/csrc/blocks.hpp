@@ -421,7 +421,7 @@ __device__ __forceinline__ void blockSolver(
     __syncthreads();   // (every wave is done with the hash: its bytes become the impulses)
     for (uint32_t k = lane; k < impCap; k += 64u) lImp[k] = make_float2(0.f, 0.f);
     __syncthreads();
-    if (sErr || (faultInject && J == 1u)) { if (threadIdx.x == 0) { sc->solveError = sErr ? sErr : 1u; bs->overflow = 1u; } return; }   // nothing persistent has been written: the host re-runs the step on another path
+    if (sErr || (faultInject && J == 1u)) { if (threadIdx.x == 0) { if (faultInject && J == 1u) sc->solveError = 1u; else if (sErr != 7u) sc->solveError = sErr; bs->overflow = 1u; } return; }   // (7: the host sees the schedule's own flag)   // nothing persistent has been written: the host re-runs the step on another path
     MI_BSTAMP(4);
     if (numPasses) {
     // ---- main loop: software pipeline over (sweep, pass); the next pass's rows are requested while this pass waits for its bodies.

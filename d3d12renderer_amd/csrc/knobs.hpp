@@ -29,7 +29,8 @@ struct Knobs {
     int gjkWave = -1;                   // MI_GJK_WAVE=0 / 1: force the lane / wave GJK variant
     bool hmStash = true;                // MI_HM_STASH=0: terrain triangles recomputed instead of stashed
     // ---- schedule
-    uint32_t colorMargin = 1;           // MI_COLOR_MARGIN: colour rounds enqueued beyond the previous step's count
+    uint32_t colorMargin = 3;           // MI_COLOR_MARGIN: colour rounds enqueued beyond the previous step's count (1 is ~3 us faster at the bench state and costs a synchronous re-run
+                                        // whenever a growing scene needs two more rounds than the step before: measured in round 4, not kept)
     bool xcdNoSort = false;             // MI_XCD_NOSORT: manifold order as emitted (development)
     bool xcdStats = false;              // MI_XCD_STATS: how many bodies stayed XCD-local (development)
     bool xcdSwizzle = false;            // MI_XCD_SWIZZLE=1

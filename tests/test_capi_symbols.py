@@ -182,3 +182,22 @@ def test_tile_to_xcd_assignment_is_a_partition(mi_lib):
                 seen[out[0]].append(out[1])
             for x in range(8):
                 assert seen[x] == list(range(shares[x])), (nt, b, x)
+
+
+def test_every_environment_variable_is_read_in_one_place():
+    """csrc/knobs.hpp is the only place the physics library reads the environment (once per world, into one typed struct); every MI_* variable the
+    tests, the bench and the tools set is one it knows (a misspelt knob would silently test the default path)."""
+    import re
+    root = Path(__file__).resolve().parent.parent
+    csrc = root / "d3d12renderer_amd" / "csrc"
+    for f in sorted(csrc.iterdir()):
+        if f.name in ("knobs.hpp", "learning.cpp") or f.suffix not in (".hip", ".hpp", ".inc", ".cpp"):
+            continue
+        assert "getenv" not in f.read_text(), f"{f.name} reads the environment itself"
+    known = set(re.findall(r'"(MI_[A-Z0-9_]+)"', (csrc / "knobs.hpp").read_text())) | set(re.findall(r'"(MI_[A-Z0-9_]+)"', (csrc / "learning.cpp").read_text()))
+    known |= {"MI_PHYSICS_LIB", "MI_LEARNING_LIB", "MI_SHARD_TRANSPORT"}          # the Python side's own (which build of the library to load; bench.py's default transport)
+    used = set()
+    for f in list((root / "tests").glob("*.py")) + list((root / "tools").glob("*.py")) + list((root / "tools").glob("*.sh")) + [root / "bench.py", root / "__graft_entry__.py"]:
+        used |= set(re.findall(r'\b(MI_[A-Z0-9_]+)\b', f.read_text()))
+    used = {u for u in used if not u.startswith(("MI_ERR", "MI_OK", "MI_EVENT", "MI_CONSTRAINT", "MI_OBJECT", "MI_API", "MI_SEAM", "MI_SHAPE", "MI_COLLIDER", "MI_DBG_TIMELINE", "MI_CLIP", "MI_SHARD_RECORD", "MI_LEARNING_API"))}
+    assert used <= known, f"unknown knobs: {sorted(used - known)}"

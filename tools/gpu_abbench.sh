@@ -1,5 +1,5 @@
 #!/bin/bash
-# dev helper: A/B of one environment switch on the headline bench (the driver's flags), alternating runs:  AB_VAR=MI_KEYS_GUEST AB_VALS="unset 0 unset 0" bash tools/gpu_abbench.sh
+# dev helper: A/B of one environment switch on the headline bench (the driver's flags), alternating runs:  AB_VAR=MI_FUSE_WORLD AB_VALS="unset 0 unset 0" bash tools/gpu_abbench.sh
 ulimit -c 0; mkdir -p gpurun_out
 for v in ${AB_VALS:-unset 0 unset 0}; do
   if [ "$v" = unset ]; then unset $AB_VAR; else export $AB_VAR=$v; fi

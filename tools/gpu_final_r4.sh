@@ -32,3 +32,5 @@ MI_POSE_STREAM=0 timeout 400 python tools/gpu_pcie_rate.py > gpurun_out/fin_host
 bash tools/gpu_cfgs.sh 2>&1 | tail -9 | cut -c1-200
 cp gpurun_out/cfgs.json gpurun_out/fin_other_configs.json
 bash tools/gpu_learning.sh 2>&1 | tail -5 | cut -c1-200; cp gpurun_out/learning.json gpurun_out/fin_learning.json
+bash tools/gpu_two.sh 2>&1 | tail -6 | cut -c1-300
+timeout 600 python tools/exp_weak.py 1 8 > gpurun_out/fin_weak.log 2>&1; tail -2 gpurun_out/fin_weak.log | cut -c1-200
