@@ -425,6 +425,14 @@ class World:
         p.flags.writeable = False; r.flags.writeable = False
         return p, r
 
+    def velocities_view(self):
+        """mi_world_view_velocities: (linear [n, 3], angular [n, 3]) as read-only views of the library's pinned rows (product library only)."""
+        ll = C.POINTER(C.c_float)(); aa = C.POINTER(C.c_float)(); n = C.c_uint32()
+        self.L.check(self.L.fn("world_view_velocities")(self.h, C.byref(ll), C.byref(aa), C.byref(n)), "world_view_velocities")
+        l = np.ctypeslib.as_array(ll, shape=(n.value, 3)); a = np.ctypeslib.as_array(aa, shape=(n.value, 3))
+        l.flags.writeable = False; a.flags.writeable = False
+        return l, a
+
     def pose_stream_stats(self):
         """mi_debug_pose_stream_stats: (rows enqueued by a step itself, rows enqueued only when asked)."""
         a = C.c_uint32(); d = C.c_uint32()

@@ -3037,11 +3037,17 @@ __global__ __launch_bounds__(kScanThreads) void k_exclusive_scan(T* __restrict__
 // (physics.cpp:1392-1406, src/core/math.h:673-682) — the same expressions as the host path (download()), bit for bit.
 // Entities without a rigid body keep their host-side transform: their rows are left alone here and filled in by the host.
 __global__ __launch_bounds__(256) void k_entity_poses(uint32_t n, const int* __restrict__ entBody, const float4* __restrict__ pos, const float4* __restrict__ rot,
-                                                      const float4* __restrict__ pos0, const float4* __restrict__ rot0, float lerpT, float* __restrict__ outP, float* __restrict__ outR) {
+                                                      const float4* __restrict__ pos0, const float4* __restrict__ rot0, float lerpT, float* __restrict__ outP, float* __restrict__ outR,
+                                                      const float4* __restrict__ lin, const float4* __restrict__ ang, float* __restrict__ outL, float* __restrict__ outA /* [n][3] each, or null: the velocities ride along */) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const int b = entBody[i];
     if (b < 0) return;
+    if (outL) {
+        const float4 l = lin[b], a = ang[b];
+        outL[3 * (size_t)i] = l.x; outL[3 * (size_t)i + 1] = l.y; outL[3 * (size_t)i + 2] = l.z;
+        outA[3 * (size_t)i] = a.x; outA[3 * (size_t)i + 1] = a.y; outA[3 * (size_t)i + 2] = a.z;
+    }
     const float4 p1 = pos[b], r1 = rot[b];
     V3 ps(p1.x, p1.y, p1.z); Q4 rt(r1.x, r1.y, r1.z, r1.w);
     if (lerpT >= 0.f) {

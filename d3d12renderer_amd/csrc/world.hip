@@ -219,14 +219,15 @@ struct mi_world {
         uint32_t tableCount = 0; bool tablesValid = false;
         bool valid = false, copyInFlight = false; uint64_t steps = 0; float t = 0.f; uint32_t n = 0; int cur[2] = {0, 0}, flavour = 0;   // the last production
         bool wanted = false, consumed = false, askedPhysics = false, retrySameStep = false;
+        bool wantVel = false, hasVel = false, velConsumed = false;   // the velocities ride in the rows once a caller has read them after a step (and stop when nobody reads them)
         uint32_t produced_ahead = 0, produced_on_demand = 0;
     } pose;
     struct PoseArm { bool armed = false, done = false; float t = 0.f; } poseArm;   // the stepping call wants the LAST of its internal steps to enqueue the rows itself, behind its kernels and ahead of the host's wait
     bool posesPossible(bool physics, float* t) const;
     bool posesWantedAhead();
     void posesArm(bool lerpAfterwards, float lerpTAfterwards);
-    int posesProduce(float t, bool fromNextState);
-    int posesFetch(float* p, float* r, const float** viewP, const float** viewR);
+    int posesProduce(float t, bool fromNextState, bool ahead);
+    int posesFetch(float* p, float* r, const float** viewP, const float** viewR, float* lin = nullptr, float* ang = nullptr, const float** viewL = nullptr, const float** viewA = nullptr);
     int posesAfterStep();
     float timer = 0.f;
 

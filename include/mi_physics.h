@@ -271,10 +271,13 @@ MI_API int mi_world_get_physics_transforms(mi_world* world, float* positions_xyz
  * reading transform_component, src/physics/physics.cpp:1392-1411): pointers to the library's pinned host rows, [count][3] positions
  * and [count][4] rotations.  The rows are produced on the device in this layout and cross the bus as ONE copy which, once a caller
  * has asked after a step, every later step enqueues itself before it returns.  Valid until the SECOND next stepping call on this
- * world (two sets alternate); read-only.  MI_ERR_UNSUPPORTED when the poses are not coming from the device right now (nothing
+ * world (two sets alternate) or until entities are added; read-only.  MI_ERR_UNSUPPORTED when the poses are not coming from the device right now (nothing
  * stepped since the last full download, a topology change is pending, a sharded world): mi_world_get_transforms covers every case. */
 MI_API int mi_world_view_transforms(mi_world* world, const float** positions_xyz, const float** rotations_xyzw, uint32_t* out_count);
 MI_API int mi_world_view_physics_transforms(mi_world* world, const float** positions_xyz, const float** rotations_xyzw, uint32_t* out_count);
+/* ... and the linear / angular velocities of every entity's rigid body (rigid_body_component::linearVelocity / angularVelocity; zero for an entity without one),
+ * [count][3] each, out of the same rows: they ride along from the frame after the first request for velocities on (mi_world_get_velocities takes them from there too). */
+MI_API int mi_world_view_velocities(mi_world* world, const float** linear_xyz, const float** angular_xyz, uint32_t* out_count);
 MI_API int mi_world_get_velocities(mi_world* world, float* linear_xyz, float* angular_xyz, uint32_t capacity);
 MI_API int mi_world_get_mass_properties(mi_world* world, float* inv_mass, float* inv_inertia_9, float* local_cog_xyz, uint32_t capacity);
 MI_API int mi_world_get_counts(mi_world* world, mi_step_counts* out);

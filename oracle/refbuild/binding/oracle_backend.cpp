@@ -32,6 +32,7 @@ MI_API int mi_world_get_physics_transforms(mi_world* w, float* p, float* r, uint
 // (no device, no pinned rows to view: the stub falls back to the copying calls)
 MI_API int mi_world_view_transforms(mi_world*, const float**, const float**, uint32_t*) { return MI_ERR_UNSUPPORTED; }
 MI_API int mi_world_view_physics_transforms(mi_world*, const float**, const float**, uint32_t*) { return MI_ERR_UNSUPPORTED; }
+MI_API int mi_world_view_velocities(mi_world*, const float**, const float**, uint32_t*) { return MI_ERR_UNSUPPORTED; }
 MI_API int mi_world_get_velocities(mi_world* w, float* l, float* a, uint32_t cap) { return ora_world_get_velocities(W(w), l, a, cap); }
 MI_API int mi_world_get_counts(mi_world* w, mi_step_counts* out) { return ora_world_get_counts(W(w), out); }
 MI_API int mi_debug_set_sweep_axis(mi_world* w, uint32_t axis) { return ora_debug_set_sweep_axis(W(w), axis); }

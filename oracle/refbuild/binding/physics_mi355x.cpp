@@ -271,13 +271,18 @@ bool physicsStepMI355X(game_scene& scene, memory_arena& arena, float& timer, con
 		if (!check(ctx, mi_world_get_physics_transforms(world, ppos.data(), prot.data(), n), "mi_world_get_physics_transforms")) { return false; }
 		vPPos = ppos.data(); vPRot = prot.data();
 	}
-	if (!check(ctx, mi_world_get_velocities(world, lin.data(), ang.data(), n), "mi_world_get_velocities")) { return false; }
+	const float *vLin = nullptr, *vAng = nullptr;
+	if (mi_world_view_velocities(world, &vLin, &vAng, &vn) != MI_OK || vn != n)
+	{
+		if (!check(ctx, mi_world_get_velocities(world, lin.data(), ang.data(), n), "mi_world_get_velocities")) { return false; }
+		vLin = lin.data(); vAng = ang.data();
+	}
 	for (uint32 i = 0; i < (uint32)ctx.bodyEntityIds.size(); ++i)
 	{
 		const uint32 id = ctx.bodyEntityIds[i];
 		scene_entity e = { ctx.entityOfIndex[id], scene };
 		rigid_body_component& rb = scene.getComponentAtIndex<rigid_body_component>(i);
-		memcpy(&rb.linearVelocity, &lin[3 * (size_t)id], 12); memcpy(&rb.angularVelocity, &ang[3 * (size_t)id], 12);
+		memcpy(&rb.linearVelocity, &vLin[3 * (size_t)id], 12); memcpy(&rb.angularVelocity, &vAng[3 * (size_t)id], 12);
 		if (transform_component* t = e.getComponentIfExists<transform_component>()) { memcpy(&t->position, &vPos[3 * (size_t)id], 12); memcpy(&t->rotation, &vRot[4 * (size_t)id], 16); }
 		if (physics_transform1_component* p1 = e.getComponentIfExists<physics_transform1_component>()) { memcpy(&p1->position, &vPPos[3 * (size_t)id], 12); memcpy(&p1->rotation, &vPRot[4 * (size_t)id], 16); }
 		const trs& t1 = physicsPose(e);

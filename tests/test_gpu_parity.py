@@ -135,12 +135,15 @@ def test_gpu_physics_step_accumulator(mi_lib, oracle_mod):
         assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
 
 
-def test_gpu_pose_rows_for_a_caller_that_reads_them_after_every_step(mi_lib, oracle_mod, monkeypatch):
+@pytest.mark.parametrize("graphs", ["default", "force"])
+def test_gpu_pose_rows_for_a_caller_that_reads_them_after_every_step(mi_lib, oracle_mod, monkeypatch, graphs):
     """The renderer's pattern: physicsStep, then the transform of every entity, frame after frame.  The rows are produced on the device in the
     caller's layout (k_entity_poses: lerp / nlerp of physics_transform0 and 1, or physics_transform1 itself) and come over in one copy which the
     step enqueues itself once somebody has asked after the previous step.  Same bytes as the oracle's transforms, as the copying call and as the
     per-array path (MI_POSE_STREAM=0); entities without a rigid body (the static ground) keep the host's transform; a view stays intact for one
     more step."""
+    if graphs == "force":
+        monkeypatch.setenv("MI_GRAPH", "force")      # the steps of this small scene replayed as HIP graphs: the rows are enqueued behind the graph launch, outside any capture
     sc = scenes.obb_pile(12, 5, 12, spacing=1.05)
     g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     monkeypatch.setenv("MI_POSE_STREAM", "0")
@@ -163,6 +166,10 @@ def test_gpu_pose_rows_for_a_caller_that_reads_them_after_every_step(mi_lib, ora
         if i % 4 == 3:
             pp, pr = g.physics_transforms(); qp, qr = o.physics_transforms(); wp, wr = g.transforms_view(physics=True)
             assert pp.tobytes() == qp.tobytes() == wp.tobytes() and pr.tobytes() == qr.tobytes() == wr.tobytes()
+        if i >= 8:                                    # ... and from here on the caller reads the velocities every frame too: they ride in the same rows
+            lv, av = g.velocities(); lo, ao = o.velocities(); lw, aw = g.velocities_view()
+            assert lv.tobytes() == lo.tobytes() == lw.tobytes() and av.tobytes() == ao.tobytes() == aw.tobytes(), f"call {i}"
+            assert vp.tobytes() == p.tobytes()       # (the view of the poses is still what it was)
     ahead, on_demand = g.pose_stream_stats()
     assert ahead >= 12 and h.pose_stream_stats() == (0, 0)
     for _ in range(6):                                # plain internal steps: transform = physics_transform1
@@ -170,6 +177,10 @@ def test_gpu_pose_rows_for_a_caller_that_reads_them_after_every_step(mi_lib, ora
             w.step_fixed(s, sc.dt, 2)
         assert g.transforms()[1].tobytes() == o.transforms()[1].tobytes() and g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
     assert g.pose_stream_stats()[0] > ahead
+    ids = np.arange(sc.num_bodies, dtype=np.uint32)  # a state written from outside between two reads: the rows follow it
+    st = o.get_body_states(ids); st[:, 0] += 0.25
+    g.set_body_states(ids, st); o.set_body_states(ids, st)
+    assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes() and g.transforms_view(physics=True)[0].tobytes() == o.physics_transforms()[0].tobytes()
     g.step(s, 0.0); o.step(s, 0.0)                    # physicsStep settles what the plain steps left pending (a full download) and runs no internal step: nothing newer on the device, no view to hand out
     with pytest.raises(capi.PhysicsError):
         g.transforms_view()

@@ -48,10 +48,11 @@ variants = {
 }
 if stream:
     variants["physicsStep_plus_entity_transforms_viewed_in_pinned_rows"] = lambda w: (lambda: (w.step(s, sc.dt), w.transforms_view()))
+    variants["physicsStep_plus_transforms_plus_velocities_viewed_in_pinned_rows"] = lambda w: (lambda: (w.step(s, sc.dt), w.transforms_view(), w.velocities_view()))
 out = {"workload": f"cfg3 obb_pile 128x16x128 (262144 bodies); every variant on its own world, settled 240 steps, {FRAMES} timed frames", "pose_stream": stream}
 for k, v in variants.items():
     out[k] = run(v)
 base = out["resident_physicsStep"]["steps_per_s"]
 out["frame_time_over_resident_step"] = {k: round(base / v["steps_per_s"], 3) for k, v in out.items() if isinstance(v, dict) and "steps_per_s" in v}
-out["bytes_to_host_per_step"] = {"transforms": 7 * 4 * (sc.num_bodies + 5), "note": "28 B per entity (position 12 B, rotation 16 B)"}
+out["bytes_to_host_per_step"] = {"transforms": 7 * 4 * (sc.num_bodies + 5), "with_velocities": 13 * 4 * (sc.num_bodies + 5), "note": "28 B per entity (position 12 B, rotation 16 B), + 24 B with the velocities"}
 print(json.dumps(out))
