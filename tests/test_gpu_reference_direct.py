@@ -35,6 +35,7 @@ REPLAY = {
     "six joint types, limits, motors": (lambda: scenes.joint_zoo(), 200),
     "cfg4 ragdolls": (lambda: scenes.ragdolls(3, 2), 200),
     "cfg5 vehicles on hull tiles": (lambda: scenes.vehicles(2, 1), 150),
+    "cfg2 at 16 384 bodies, the first steps (27 816 manifolds of 1.5 contacts in the sequential bin: its tiles take four contact-tiles each)": (lambda: scenes.mixed_stack(32, 16, 32), 4),
 }
 REPLAY.update({f"edge: {k}": (v, 160) for k, v in scenes.EDGE_CASES.items()})
 
