@@ -446,7 +446,7 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
                                       ({"MI_SOLVER": "persist-granules"}, 5), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-granules"}, 4),
                                       ({"MI_PERSIST_XCD_MIN": "1", "MI_PERSIST_XCD_FAULT": "1"}, 2), ({"MI_PERSIST_XCD_FAULT": "1"}, 2), ({"MI_READBACK": "copy"}, 5),
                                       ({"MI_PERSIST_WAVES": "8"}, 2), ({"MI_PERSIST_WAVES": "2"}, 2),
-                                      ({"MI_SOLVER": "flow", "MI_FLOW_FAULT": "1"}, 0)])
+                                      ({"MI_SOLVER": "flow", "MI_FLOW_FAULT": "1"}, 0), ({"MI_ASYNC": "0"}, None)])
 def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch, env, kind):
     """Every dataflow contact solver gives the same results, bit for bit (which lane / wave / XCD runs a slot is invisible to the
     body-version dataflow):  MI_SOLVER=flow -> k_contact_solve_flow (one workgroup per (sweep, tile), dispatch-ordered; also the
@@ -472,7 +472,8 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
         assert g.counts() == o.counts(), f"step {i}"
     assert g.counts()["num_contacts"] > 3000
     assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
-    assert g.solver_kind() == kind
+    assert kind is None or g.solver_kind() == kind   # (MI_ASYNC=0: every step synchronous, whatever solver the exact sizes select)
+    if kind is None: assert g.step_mode_stats()[1] == 0
     assert g.step_mode_stats()[2] <= (8 if kind == 6 else 2), "the partitioned solver must not keep falling back"   # (the block solver sizes its lists from the previous step: a growing pile outgrows them a few times)
     # timing is opt-in: nothing by default; level 2 = the whole step and the solve stage; level 1 = every stage
     t = g.stage_times()
@@ -647,13 +648,14 @@ def test_gpu_private_islands_match_oracle_and_the_dataflow_path(mi_lib, oracle_m
 def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
     """BASELINE's 262 144-body pile, far beyond the oracle's reach: the default solver (XCD-partitioned persistent kernel: eight tile
     lists, ~95 % of the bodies handed over through an XCD's L2, the seam bodies through memory) must end bit-identical to the
-    dispatch-ordered flow kernel, to the unpartitioned persistent kernel — which the small cases pin to the oracle — and to the block
-    solver (MI_SOLVER=blocks: 256 spatial blocks with their home bodies in LDS, boundary manifolds solved on both sides)."""
+    dispatch-ordered flow kernel, to the unpartitioned persistent kernel — which the small cases pin to the oracle — to the block
+    solver (MI_SOLVER=blocks: 256 spatial blocks with their home bodies in LDS, boundary manifolds solved on both sides), and to a world
+    that takes every step synchronously (MI_ASYNC=0: exact sizes read back inside the step; the path of every re-run)."""
     import hashlib
     sc = scenes.obb_pile(128, 16, 128)
     out = {}
-    for name, env in (("default", {}), ("flow", {"MI_SOLVER": "flow"}), ("unpartitioned", {"MI_PERSIST_XCD": "0"}), ("blocks", {"MI_SOLVER": "blocks"})):
-        for k in ("MI_SOLVER", "MI_PERSIST_XCD", "MI_BLOCKS"):
+    for name, env in (("default", {}), ("flow", {"MI_SOLVER": "flow"}), ("unpartitioned", {"MI_PERSIST_XCD": "0"}), ("blocks", {"MI_SOLVER": "blocks"}), ("synchronous", {"MI_ASYNC": "0"})):
+        for k in ("MI_SOLVER", "MI_PERSIST_XCD", "MI_BLOCKS", "MI_ASYNC"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -663,7 +665,7 @@ def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
         out[name] = (hashlib.sha1(p.tobytes() + q.tobytes()).hexdigest(), w.counts()["num_contacts"], w.solver_kind(), w.step_mode_stats()[2])
         w.close()
     assert out["default"][2] == 4 and out["flow"][2] == 1 and out["unpartitioned"][2] == 2 and out["blocks"][2] == 6, out
-    assert out["default"][:2] == out["flow"][:2] == out["unpartitioned"][:2] == out["blocks"][:2], out
+    assert out["default"][:2] == out["flow"][:2] == out["unpartitioned"][:2] == out["blocks"][:2] == out["synchronous"][:2], out   # (synchronous: every step sized from read-backs inside the step — the path every re-run takes)
     assert out["default"][1] > 150000
     assert out["default"][3] <= 12, "speculative retries while the pile lands are fine; a solver that keeps falling back is not"
 
