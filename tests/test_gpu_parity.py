@@ -50,7 +50,12 @@ def test_gpu_matches_golden_bit_exact(mi_lib, name):
     (lambda: scenes.vehicles(3, 2), 160),
     (lambda: scenes.terrain_field(10, 2, 10), 260),     # heightmap terrain: quadtree walk + triangle tests + lowest-point contacts
 ])
-def test_gpu_vs_oracle_trajectory_and_contacts(mi_lib, oracle_mod, make, steps):
+@pytest.mark.parametrize("stepping", ["speculative", "synchronous"])
+def test_gpu_vs_oracle_trajectory_and_contacts(mi_lib, oracle_mod, monkeypatch, make, steps, stepping):
+    """Every scene type against the oracle, step by step; `synchronous` (MI_ASYNC=0): every step sized from read-backs inside the step — the path the first step of a
+    world and every re-run of a void speculative step take (joints through the per-type launches, triggers on the host, terrain counts read back, exact tile tables)."""
+    if stepping == "synchronous":
+        monkeypatch.setenv("MI_ASYNC", "0")
     sc = make()
     g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     s = sc.settings()
