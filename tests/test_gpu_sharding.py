@@ -324,6 +324,34 @@ def test_gpu_sharded_checkpoint_restores_every_ranks_view(mi_lib, oracle_mod):
         sc.populate(mi_lib.create_world(0)).load_checkpoint(blobs[0])
 
 
+def test_gpu_exact_seam_guard_rails(mi_lib):
+    """What the exact seam needs is checked where it is set up, not found out by a drifting simulation: a hand-over after every sweep (a transport or a callback),
+    tiles at least two ghost margins wide — when the mode is switched on AND whenever the borders move afterwards (a body within the margin of two borders has no
+    single seam class) —, and `ShardedWorld.check_seam` turns a violated seam class into an error."""
+    sc = scenes.obb_pile(24, 3, 6, spacing=1.0)
+    desc = sharding.tile_grid(sc, 4, 1, 1.5)                     # four x-slabs, 6 m each, margin 1.5 m
+    w = sc.populate(mi_lib.create_world(0))
+    sw = sharding.ShardedWorld(w, desc, 1, "local")
+    moves = lambda sweep: 0
+    with pytest.raises(capi.PhysicsError):
+        w.shard_set_exact_seam(True, None)                       # caller's transport and nobody to call after a sweep
+    bx, _ = w.shard_get_borders(desc.tiles_x, desc.tiles_z)
+    narrow = np.array([bx[0], bx[0] + 2.0, bx[2]], np.float32)   # tile 1 two metres wide: more than one margin (fine for block Jacobi), less than two
+    w.shard_set_borders(narrow, None)
+    s = sc.settings()
+    w.step_fixed(s, sc.dt, 1)                                    # (the step's exchange puts them in force)
+    with pytest.raises(capi.PhysicsError):
+        w.shard_set_exact_seam(True, moves)                      # borders in force (or pending) too close for the exact seam
+    w.shard_set_borders(bx, None)
+    w.step_fixed(s, sc.dt, 1)
+    w.shard_set_exact_seam(True, moves)
+    with pytest.raises(capi.PhysicsError):
+        w.shard_set_borders(narrow, None)                        # ... and they cannot get that close afterwards
+    sw.exact = True
+    assert sw.check_seam()["violations"] == 0
+    w.shard_set_exact_seam(False, None)
+
+
 def test_gpu_shard_entry_points_reject_misuse(mi_lib):
     """mi_world_shard_import on a tile without neighbours (its own staging buffer: a 1 x 1 grid has no receive buffer), on a world attached to
     the library transport (refused), mi_world_step with several sub-steps on the caller's transport (refused: the exchange lies in between)."""
