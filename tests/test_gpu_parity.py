@@ -141,7 +141,8 @@ def test_gpu_physics_step_accumulator(mi_lib, oracle_mod):
 
 
 @pytest.mark.parametrize("graphs", ["default", "force"])
-def test_gpu_pose_rows_for_a_caller_that_reads_them_after_every_step(mi_lib, oracle_mod, monkeypatch, graphs):
+@pytest.mark.parametrize("make", [lambda: scenes.obb_pile(12, 5, 12, spacing=1.05), lambda: scenes.ragdolls(3, 3), lambda: scenes.vehicles(2, 2)], ids=["pile", "ragdolls (joint islands)", "vehicles on hull tiles"])
+def test_gpu_pose_rows_for_a_caller_that_reads_them_after_every_step(mi_lib, oracle_mod, monkeypatch, graphs, make):
     """The renderer's pattern: physicsStep, then the transform of every entity, frame after frame.  The rows are produced on the device in the
     caller's layout (k_entity_poses: lerp / nlerp of physics_transform0 and 1, or physics_transform1 itself) and come over in one copy which the
     step enqueues itself once somebody has asked after the previous step.  Same bytes as the oracle's transforms, as the copying call and as the
@@ -149,7 +150,7 @@ def test_gpu_pose_rows_for_a_caller_that_reads_them_after_every_step(mi_lib, ora
     more step."""
     if graphs == "force":
         monkeypatch.setenv("MI_GRAPH", "force")      # the steps of this small scene replayed as HIP graphs: the rows are enqueued behind the graph launch, outside any capture
-    sc = scenes.obb_pile(12, 5, 12, spacing=1.05)
+    sc = make()
     g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
     monkeypatch.setenv("MI_POSE_STREAM", "0")
     h = sc.populate(gpu_world(mi_lib))
