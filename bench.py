@@ -421,7 +421,6 @@ def main():
                                  "note": "a speculative step sizes its launches from the previous step and reads back once; one whose bounds did not hold is re-run synchronously (counted here, timed like any step)"},
             "device_ms_per_step": total_dev_ms / args.steps,
             "solver_kind": sw.world.solver_kind(),
-            "block_solver": sw.world.block_stats() if sw.world.solver_kind() == 6 else None,
         }
         if per_rank is not None:
             out["per_rank"] = per_rank

@@ -657,7 +657,7 @@ class World:
         self.L.check(self.L.fn("world_get_stream")(self.h, C.byref(out)), "world_get_stream")
         return out.value or 0
 
-    SOLVER_KERNELS = ("k_contact_solve", "k_contact_solve_flow", "k_contact_solve_persist", "k_solve_flow_islands", "k_contact_solve_persist", "k_contact_solve_persist", "k_contact_solve_blocks")
+    SOLVER_KERNELS = ("k_contact_solve", "k_contact_solve_flow", "k_contact_solve_persist", "k_solve_flow_islands", "k_contact_solve_persist", "k_contact_solve_persist")
 
     def step_graph_stats(self):
         """mi_debug_step_graph_stats: (enabled, steps replayed as a HIP graph, graphs captured, speculative steps launched plainly)."""
@@ -666,18 +666,10 @@ class World:
         return tuple(int(x) for x in out)
 
     def solver_kind(self):
-        """mi_world_get_solver_kind: 0 per-colour launches, 1 flow, 2 persistent, 3 flow + joint islands, 4 persistent, XCD-partitioned, 5 persistent, all tiles on one XCD (small piles), 6 spatial blocks in LDS (k_contact_solve_blocks)."""
+        """mi_world_get_solver_kind: 0 per-colour launches, 1 flow, 2 persistent, 3 flow + joint islands, 4 persistent, XCD-partitioned, 5 persistent, all tiles on one XCD (small piles)."""
         k = C.c_uint32()
         self.L.check(self.L.fn("world_get_solver_kind")(self.h, C.byref(k)), "world_get_solver_kind")
         return k.value
-
-    def block_stats(self):
-        """mi_debug_block_stats: sizes of the block solver (blocks.hpp) and what its last step needed."""
-        out = (C.c_uint32 * 16)()
-        self.L.check(self.L.fn("debug_block_stats")(self.h, out), "debug_block_stats")
-        names = ("blocks", "tiles_per_block", "extra_cap", "body_cap", "hash_slots", "passes_per_wave", "impulses_per_wave", "lds_bytes", "entries_needed", "extras_needed",
-                 "bodies_needed", "passes_needed", "impulses_needed", "boundary_entries", "block_steps", "disabled_for_steps")
-        return {k: int(v) for k, v in zip(names, out)}
 
     def solver_kernel(self):
         """Name of the contact-solver kernel the last internal step ran."""

@@ -34,17 +34,6 @@ struct GridParams {   // written by k_bp_grid_setup, read by the broad-phase ker
     uint32_t pad;
 };
 
-struct BlockState {   // per-step words of the block path (device memory; the launches carry the same arguments every step: step graphs)
-    uint32_t stamp;        // launch stamp of the mailbox tags (k_block_sched increments it)
-    uint32_t need;         // largest list (entries) any block wanted this step
-    uint32_t needExtra;    // largest number of foreign boundary entries any block was sent
-    uint32_t needBodies;   // largest number of home bodies any block held
-    uint32_t needPasses;   // largest number of passes any wave ran per sweep
-    uint32_t needImp;      // largest number of accumulated impulses (contacts) any wave held
-    uint32_t overflow;     // 1: a capacity of the block path was exceeded (the step is void)
-    uint32_t ghostLanes;   // statistics: boundary entries of this step (both copies)
-};
-
 struct StepScalars {  // device-resident per-step scalars
     double extentSum;
     int boundsMin[3];     // ordered-int encoded floats
@@ -85,7 +74,6 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t shardRecv[8];         // ... records the neighbours packed for this rank (the headers of the received messages); [.] = 0xFFFFFFFF: that message was cut short (library transport, adaptive sizes)
     uint32_t seamStats[3];         // exact seam (include/mi_shard.h): manifolds of the seam class, colours they use, violations of this step (k_seam_stats)
     unsigned long long axisSums[9]; // centre statistics of the colliders this world counts (k_pair_finish): S1[3], S2lo[3], S2hi[3]; a sharded world's are added over the ranks
-    BlockState blk;                 // spatial blocks in LDS (blocks.hpp)
 };
 
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
@@ -1362,8 +1350,7 @@ __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float
                                                               const uint8_t* __restrict__ bodyActive /* sharded world (1 = owned), or null */, const float4* __restrict__ bPosIn,
                                                               const float4* __restrict__ bLinVelIn, const float4* __restrict__ bAngVelIn, const float4* __restrict__ bForceIn,
                                                               const float4* __restrict__ bTorqueIn,
-                                                              const uint8_t* __restrict__ bodyActivePrev /* the previous step's flags */, const Shards* __restrict__ sh, StepScalars* sc,
-                                                              unsigned long long* __restrict__ bndMask /* block solver: per-body boundary colours, cleared like bodyUsed; or null */) {
+                                                              const uint8_t* __restrict__ bodyActivePrev /* the previous step's flags */, const Shards* __restrict__ sh, StepScalars* sc) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (bodyActive && blockIdx.x == 0 && threadIdx.x < 3) {   // sharded world: this rank's owned bodies / manifolds / contacts, from the per-line counters
         uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].owned[threadIdx.x];
@@ -1375,7 +1362,6 @@ __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float
     if (idle) return;
     // the per-body colouring scratch of the NEXT step starts out cleared (saves two memset launches per step); launched over nb + 1
     bodyUsed[i] = 0ull; bodyTop[i] = 0ull; bodyTop[(size_t)nb + 1u + i] = 0ull;
-    if (bndMask) bndMask[i] = 0ull;
     if (i == nb) return;
     if (bodyActive && bodyActive[i] != 1u) {   // sharded world: only the OWNER advances a body; ghosts and bodies elsewhere keep their state (the owner's arrives by exchange)
         bPos[i] = bPosIn[i]; bRot[i] = bRotIn[i]; bLinVel[i] = bLinVelIn[i]; bAngVel[i] = bAngVelIn[i]; bForce[i] = bForceIn[i]; bTorque[i] = bTorqueIn[i];
@@ -1851,25 +1837,6 @@ struct IslandPrivate {
     uint4* entries;               // [islands][kIslandMaxContacts]: (slot, first contact-tile, colour | contacts << 8, -)
 };
 __device__ __forceinline__ bool islandIsPrivate(const IslandPrivate& ip, uint32_t island) { return ip.shared[island] == 0u && ip.count[island] <= kIslandMaxContacts; }
-// Spatial blocks in LDS (blocks.hpp): what the schedule and k_contact_init share with the block solver.
-constexpr uint32_t kMailRanks = 8;            // mailbox slots per body = boundary manifolds on one body (more: the step falls back)
-constexpr uint32_t kOrderMask = 0x3FFFFFFFu;  // block mode: order[slot] = manifold | boundary << 30 | home-is-B << 31
-// block-mode slot word: contacts [0:3] | colour [3:9] | boundary [9] | home-is-B [10] | export A: on [11] same sweep [12] rank [13:16] | export B [16] [17] [18:21] | ghost rank [21:24]
-__device__ __forceinline__ uint32_t blockMetaW(uint32_t cnt, uint32_t colour, bool bnd, bool homeB, uint32_t expA, uint32_t expB, uint32_t ghostRank) {
-    return cnt | (colour << 3) | (bnd ? 1u << 9 : 0u) | (homeB ? 1u << 10 : 0u) | (expA << 11) | (expB << 16) | (ghostRank << 21);
-}
-// export word of a home body (5 bits): on | same sweep << 1 | rank << 2.  A home body is exported right after the update that precedes a boundary manifold on it
-// (cyclically in colour order: the body's own colour again if it has one manifold) into that manifold's mailbox slot = its rank among the body's boundary colours.
-__device__ __forceinline__ uint32_t blockExportBits(unsigned long long used, unsigned long long bm, uint32_t c, bool& rankOverflow) {
-    if (!bm) return 0u;
-    const unsigned long long above = c >= 63u ? 0ull : used & ~((2ull << c) - 1ull);
-    const bool same = above != 0ull;
-    const uint32_t cn = (uint32_t)__ffsll((long long)(same ? above : used)) - 1u;
-    if (!((bm >> cn) & 1ull)) return 0u;
-    const uint32_t rank = (uint32_t)__popcll(bm & ((1ull << cn) - 1ull));
-    if (rank >= kMailRanks) { rankOverflow = true; return 0u; }
-    return 1u | (same ? 2u : 0u) | (rank << 2);
-}
 // K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379): one wave per tile, one lane per slot.
 __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restrict__ sc, uint32_t dummyBody, float dt, const uint4* __restrict__ tileInfo /* k_fill_tiles: per tile, or (XCD-partitioned) per entry of the XCD tile lists */,
                                                      const uint32_t* __restrict__ order,
@@ -1883,8 +1850,7 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
                                                      float4* __restrict__ slotNormal, float2* __restrict__ slotMass,
                                                      uint8_t* __restrict__ bodyOwner /* XCD-partitioned solver: [body][8] flags, 1 = a tile of that XCD touches the body; or null */,
                                                      uint32_t listCap /* with bodyOwner: workgroup b prepares entry b / 8 of XCD (b % 8)'s tile list */, uint32_t infoCap,
-                                                     IslandPrivate ip /* bodyIsland non-null: manifolds of private islands are handed to their island's workgroup, invalid for the tile solver */,
-                                                     const unsigned long long* __restrict__ bndMask /* block mode (blocks.hpp): per body, the colours of its boundary manifolds; or null */, BlockState* bs) {
+                                                     IslandPrivate ip /* bodyIsland non-null: manifolds of private islands are handed to their island's workgroup, invalid for the tile solver */) {
     // Measured and not kept: one wave per contact index (four waves per tile, the per-manifold gathers repeated): 52 -> 73 us; 5 or 6 waves per
     // SIMD instead of 4 by capping the registers (96 / 80 VGPRs, 96 / 164 bytes of scratch): 66 -> 84 / 94 us.  Everything the kernel needs of
     // its tile comes in ONE 16-byte entry (k_fill_tiles; was list -> tile -> bin -> bin info): no faster either — the kernel moves ~390 MB
@@ -1893,12 +1859,7 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
     // XCD-partitioned: the workgroups that land on XCD x (blockIdx % 8, a speed assumption only) prepare the tiles XCD x will solve,
     // i.e. gather the bodies of ONE slab of the scene — they fit that XCD's L2 instead of streaming all bodies through every L2
     const uint32_t x = blockIdx.x & 7u, j = blockIdx.x >> 3;
-    uint32_t entry = bodyOwner ? x * listCap + j : blockIdx.x;
-    if (bndMask) {   // block mode: listCap = number of blocks, infoCap = blocks * tiles per block; the workgroups of XCD x prepare the tiles of ITS eighth of the blocks
-        const uint32_t nbe = listCap, T = infoCap / listCap, b0 = (x * nbe) >> 3, b1 = ((x + 1u) * nbe) >> 3;
-        if (j >= (b1 - b0) * T) return;
-        entry = b0 * T + j;
-    }
+    const uint32_t entry = bodyOwner ? x * listCap + j : blockIdx.x;
     const uint4 te = entry < infoCap ? tileInfo[entry] : make_uint4(0u, 0u, 0u, 0u);   // (requested before the validity checks below: their loads run beside it)
     if (bodyOwner) { if (!sc->totalTiles || j >= sc->xcdCount[x] || j >= listCap) return; }
     else if (entry >= sc->totalTiles) return;
@@ -1912,8 +1873,7 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
         }
         return;
     }
-    const uint32_t ord = order[te.y + lane];
-    uint32_t m = bndMask ? ord & kOrderMask : ord;
+    const uint32_t m = order[te.y + lane];
     uint32_t p = manPair[m];
     uint2 bodies = manBodies[m];
     uint2 info = manInfo[m];
@@ -1942,21 +1902,7 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
             if (at < kIslandMaxContacts) ip.entries[(size_t)isl * kIslandMaxContacts + at] = make_uint4(tile * 64u + lane, (uint32_t)ctBase, color[m] | (cnt << 8), m);
         }
     }
-    uint32_t metaW = priv ? 0u : cnt;   // (.w = 0: not a slot of the tile solver)
-    if (bndMask) {   // block mode: colour, boundary flags, and which home body is exported after this manifold's update (blocks.hpp)
-        const uint32_t c = color[m];
-        const bool bnd = (ord >> 30) & 1u, homeB = (ord >> 31) != 0u;
-        const bool ghostA = bnd && homeB, ghostB = bnd && !homeB;
-        bool over = c >= kOverflowColor;
-        uint32_t expA = 0u, expB = 0u, gRank = 0u;
-        if (!over) {
-            if (imA != 0.f && !ghostA) expA = blockExportBits(bodyUsed[bodies.x], bndMask[bodies.x], c, over);
-            if (imB != 0.f && !ghostB) expB = blockExportBits(bodyUsed[bodies.y], bndMask[bodies.y], c, over);
-            if (bnd) { gRank = (uint32_t)__popcll(bndMask[ghostA ? bodies.x : bodies.y] & ((1ull << c) - 1ull)); if (gRank >= kMailRanks) { over = true; gRank = 0u; } }
-        }
-        if (over) { bs->overflow = 1u; const_cast<StepScalars*>(sc)->specOverflow = 1u; }
-        metaW = blockMetaW(cnt, c & 63u, bnd, homeB, expA, expB, gRank);
-    }
+    const uint32_t metaW = priv ? 0u : cnt;   // (.w = 0: not a slot of the tile solver)
     if (kw == 0) {
         slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, packed, metaW);
         slotMass[(size_t)tile * 64u + lane] = make_float2(imA, imB);
@@ -2780,19 +2726,25 @@ __global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp,
 // The next step's sweep axis of a sharded world, from centre statistics summed over all ranks (or, before / without that sum, this rank's own)
 __global__ void k_shard_axis(const unsigned long long* __restrict__ sums9, uint32_t nc, uint32_t* __restrict__ axisDev) { if (threadIdx.x == 0 && blockIdx.x == 0) *axisDev = axisFromSums(sums9, nc); }
 // (a done-ticket in k_shard_pack instead of this launch: 8 192 same-address atomics in a 2 M-body scene, ~90 us)
+constexpr uint32_t kShardFlagsMagic = 0x5A4D0000u;   // header word 1 = magic | the sender's message-size policy (bit 0: adaptive sizes): ranks that disagree about it would post sends and receives of different lengths
 __global__ void k_shard_pack_headers(uint32_t numPeers, const StepScalars* __restrict__ sc, ShardBufs out,
-                                     uint32_t nc, uint32_t* __restrict__ axisOwn /* caller's transport: the next sweep axis from this rank's own sums (k_shard_axis), or null */) {
-    if (threadIdx.x < numPeers) out.p[threadIdx.x][0] = __uint_as_float(sc->shardSent[threadIdx.x]);
+                                     uint32_t nc, uint32_t* __restrict__ axisOwn /* caller's transport: the next sweep axis from this rank's own sums (k_shard_axis), or null */, uint32_t flags) {
+    if (threadIdx.x < numPeers) { out.p[threadIdx.x][0] = __uint_as_float(sc->shardSent[threadIdx.x]); out.p[threadIdx.x][1] = __uint_as_float(kShardFlagsMagic | flags); }
     if (axisOwn && threadIdx.x == 63) *axisOwn = axisFromSums(sc->axisSums, nc);
 }
 // blockIdx.y = neighbour slot (a body has one owner: the messages never touch the same body)
 struct ShardCaps { uint32_t c[8]; };   // records each received message can hold as it travelled (library transport: sized from the previous exchange)
 __global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, ShardBufs in, uint32_t capacity, float4* __restrict__ bPos, float4* __restrict__ bRot,
                                                       float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, uint8_t* __restrict__ known,
-                                                      ShardCaps caps = ShardCaps{{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}}, uint32_t* __restrict__ recvCounts = nullptr) {
+                                                      ShardCaps caps = ShardCaps{{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}}, uint32_t* __restrict__ recvCounts = nullptr,
+                                                      uint32_t myFlags = 0u /* library transport: this rank's message-size policy, held against the sender's (header word 1) */) {
     const float* msg = in.p[blockIdx.y];
     const uint32_t sent = __float_as_uint(msg[0]), cap = min(capacity, caps.c[blockIdx.y]);
-    if (recvCounts && blockIdx.x == 0 && threadIdx.x == 0) recvCounts[blockIdx.y] = sent > cap && sent <= capacity ? 0xFFFFFFFFu : sent;   // (more than travelled: the tail is missing — reported, never silent)
+    if (recvCounts && blockIdx.x == 0 && threadIdx.x == 0) {
+        const uint32_t theirs = __float_as_uint(msg[1]);
+        recvCounts[blockIdx.y] = (theirs & 0xFFFF0000u) == kShardFlagsMagic && (theirs & 0xFFFFu) != myFlags ? 0xFFFFFFFEu   // the neighbour sizes its messages by another rule (MI_SHARD_ADAPTIVE differs between the ranks)
+                                 : sent > cap && sent <= capacity ? 0xFFFFFFFFu : sent;   // (more than travelled: the tail is missing — reported, never silent)
+    }
     const uint32_t count = min(sent, cap);
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= count) return;

@@ -1,4 +1,5 @@
-// Every environment variable the library reads, in ONE place: read once per world (mi_world_create), typed, documented.
+// Every environment variable the library reads, in ONE place: read once PER WORLD (mi_world_create — not once per process: two worlds created under
+// different environments differ), typed, documented.  Numeric knobs: 0 (or unset) means "the default", not the value 0 (MI_FLOW_LDS, MI_PERSIST_WAVES).
 // None of them is needed in production — the defaults are what is measured and shipped; they select the fallback paths the tests
 // pin against each other (every variant gives the same bits), inject the faults the fallback ladder is tested with, and switch
 // development output on.  No reference counterpart.
@@ -35,21 +36,14 @@ struct Knobs {
     bool xcdStats = false;              // MI_XCD_STATS: how many bodies stayed XCD-local (development)
     bool xcdSwizzle = false;            // MI_XCD_SWIZZLE=1
     // ---- contact solver
-    std::string solver;                 // MI_SOLVER=launch | flow | persist | persist-global | persist-granules | blocks ("" = persist)
+    std::string solver;                 // MI_SOLVER=launch | flow | persist | persist-global | persist-granules ("" = persist)
     uint32_t flowLds = 0;               // MI_FLOW_LDS (bytes; 0 = default)
     uint32_t persistWaves = 0;          // MI_PERSIST_WAVES (0 = 4 per CU)
     bool persistXcdOnly = false;        // MI_PERSIST_XCD_ONLY (development)
     int persistXcd = -1, persistXcdSingle = -1;   // MI_PERSIST_XCD / _SINGLE = 0 / 1 (-1 = default)
     int xcdMinManifolds = -1;           // MI_PERSIST_XCD_MIN
-    bool xcdFault = false, flowFault = false, blockFault = false;   // MI_PERSIST_XCD_FAULT / MI_FLOW_FAULT / MI_BLOCK_FAULT: fault injection (tests)
+    bool xcdFault = false, flowFault = false;   // MI_PERSIST_XCD_FAULT / MI_FLOW_FAULT: fault injection (tests)
     std::string gvelAlloc, impAlloc;    // MI_GVEL_ALLOC / MI_IMP_ALLOC = plain | finegrained | uncached
-    // ---- block solver (blocks.hpp)
-    int blocks = -1;                    // MI_BLOCKS=0: off even with MI_SOLVER=blocks
-    uint32_t blocksMax = 0;             // MI_BLOCKS_MAX (0 = one per CU)
-    bool blockDebug = false;            // MI_BLOCK_DEBUG: one line per block step
-    uint32_t blockMode = 0;             // MI_BLOCK_MODE (development bits)
-    std::vector<uint32_t> blockDbg;     // MI_BLOCK_DBG=a,b,c: knock-out launches (development)
-    uint64_t blockDbgAfter = 0;         // MI_BLOCK_DBG_AFTER
     // ---- joints
     bool fuseJoints = true;             // MI_FUSE_JOINTS=0
     bool jointIslands = true;           // MI_JOINT_ISLANDS=0
@@ -77,11 +71,8 @@ struct Knobs {
         k.solver = str("MI_SOLVER"); k.flowLds = (uint32_t)num("MI_FLOW_LDS", 0); k.persistWaves = (uint32_t)num("MI_PERSIST_WAVES", 0); k.persistXcdOnly = set("MI_PERSIST_XCD_ONLY");
         k.persistXcd = tri("MI_PERSIST_XCD"); k.persistXcdSingle = tri("MI_PERSIST_XCD_SINGLE");
         if (const char* v = std::getenv("MI_PERSIST_XCD_MIN")) k.xcdMinManifolds = (int)strtoul(v, nullptr, 0);
-        k.xcdFault = set("MI_PERSIST_XCD_FAULT"); k.flowFault = set("MI_FLOW_FAULT"); k.blockFault = set("MI_BLOCK_FAULT");
+        k.xcdFault = set("MI_PERSIST_XCD_FAULT"); k.flowFault = set("MI_FLOW_FAULT");
         k.gvelAlloc = str("MI_GVEL_ALLOC"); k.impAlloc = str("MI_IMP_ALLOC");
-        k.blocks = tri("MI_BLOCKS"); k.blocksMax = (uint32_t)num("MI_BLOCKS_MAX", 0); k.blockDebug = set("MI_BLOCK_DEBUG"); k.blockMode = (uint32_t)num("MI_BLOCK_MODE", 0);
-        if (const char* e = std::getenv("MI_BLOCK_DBG")) { const char* p = e; while (*p) { char* q; k.blockDbg.push_back((uint32_t)strtoul(p, &q, 0)); if (q == p) break; p = (*q == ',') ? q + 1 : q; } }
-        k.blockDbgAfter = num("MI_BLOCK_DBG_AFTER", 0);
         k.fuseJoints = !off("MI_FUSE_JOINTS"); k.jointIslands = !off("MI_JOINT_ISLANDS"); k.islandPrivate = tri("MI_ISLAND_PRIVATE");
         k.shardAdaptive = !off("MI_SHARD_ADAPTIVE");
         k.timelineOut = str("MI_DBG_TIMELINE_OUT"); k.timelineStep = num("MI_DBG_TIMELINE_STEP", 3);

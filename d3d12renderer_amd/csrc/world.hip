@@ -25,7 +25,6 @@
 #include <dlfcn.h>
 #include "../../include/mi_constraints.h"
 #include "kernels.hpp"
-#include "blocks.hpp"
 #include "gjk.hpp"
 #include "launcher.hpp"
 #include "joints.hpp"
@@ -176,6 +175,9 @@ struct mi_world {
         // library transport: a neighbour message travels as long as the previous exchange made it in EITHER direction (x 1.5 + 512 records) — both ends know both numbers, so
         // they agree on the size without talking; full size for the exchanges after anything that moves many bodies at once (enable, attach, new borders, a restore)
         uint32_t* recvHost = nullptr; uint32_t recvLast[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sizedLast[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool recvValid = false, adaptive = true; uint32_t fullExchanges = 2; uint64_t bytesSentSum = 0;
+        // anything that can put many bodies into a ghost strip at once (a restore, a re-upload, states written from outside) sends the next messages at full size again; with the
+        // library transport such a call is COLLECTIVE: every rank makes it between the same two steps (include/mi_shard.h), or the ranks disagree about the message sizes
+        void rearmFullSize() { fullExchanges = 2; sweepFullSteps = 2; }
         // ... the sweep messages of the exact seam likewise, from the previous STEP's list lengths in both directions (x 1.5 + 64)
         uint32_t sweepPrevOwn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sweepPeerHdr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sweepSized[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool sweepRecvValid = false, sweepCut = false; uint32_t sweepFullSteps = 2;
         uint32_t owned[3] = {0, 0, 0};
@@ -227,6 +229,7 @@ struct mi_world {
     bool posesWantedAhead();
     void posesArm(bool lerpAfterwards, float lerpTAfterwards);
     int posesProduce(float t, bool fromNextState, bool ahead);
+    void posesAbort();
     int posesFetch(float* p, float* r, const float** viewP, const float** viewR, float* lin = nullptr, float* ang = nullptr, const float** viewL = nullptr, const float** viewA = nullptr);
     int posesAfterStep();
     float timer = 0.f;
@@ -239,12 +242,6 @@ struct mi_world {
     // XCD-partitioned persistent solver: cached velocity copy for XCD-local bodies, per-body XCD set, spatial sort of the manifolds, per-XCD tile lists
     DBuf<float4> gVelL; DBuf<unsigned long long> bodyOwner; DBuf<uint32_t> sortKeys[2], sortVals[2], xcdBase, xcdTiles, keyCount;
     bool privateIslandsEnabled = true;
-    // spatial blocks in LDS (blocks.hpp): one workgroup per block of the scene, home bodies in LDS, boundary manifolds solved by both neighbours
-    DBuf<uint32_t> blkKeys, blkRanks, blkPerm, blkStart, blkExtra, blkExtraCount; DBuf<uint16_t> blkCell; DBuf<unsigned long long> bndMask; DBuf<float4> mail;
-    bool blockSolver = true, usedBlocks = false, blockFaultTest = false, blockFaultFired = false;
-    struct BlockCaps { uint32_t nbe = 0, tiles = 0, extraCap = 0, bodyCap = 0, hashSize = 0, maxPasses = 0, impCap = 0; size_t lds = 0; } blkCaps;   // sticky: the same launches step after step (step graphs)
-    BlockState lastBlk{}; bool haveBlkEstimate = false, blkLastFailed = false; uint32_t blkWaves = 4 /* waves per block: one per SIMD */, blkFailHistory = 0, blkFailures = 0, blkDisabledSteps = 0, blkLaunches = 0, blkMaxBlocks = 256, blkSteps = 0;
-    bool planBlocks(uint32_t nmLast, uint32_t nbBodies);
     bool persistXcd = true, persistXcdSingle = true, usedXcd = false, usedXcdSingle = false, lastXcdSingle = false, haveXcdEstimate = false, xcdFaultFired = false, xcdFaultTest = false; uint32_t lastXcdMax = 0, xcdMinManifolds = 16384;
     // device: colliders
     DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cEmit;
@@ -431,11 +428,7 @@ int mi_world::init(int dev) {
     if (kn.persistXcd >= 0) persistXcd = kn.persistXcd != 0;                 // 0: no XCD partitioning (every body through memory)
     if (kn.islandPrivate >= 0) privateIslandsEnabled = kn.islandPrivate != 0;   // development / tests: every island through the dataflow
     if (kn.persistXcdSingle >= 0) persistXcdSingle = kn.persistXcdSingle != 0;   // 0: small piles on all XCDs, every body through memory
-    xcdFaultTest = kn.xcdFault; flowFaultTest = kn.flowFault; blockFaultTest = kn.blockFault;
-    blockSolver = sv == "blocks" && kn.blocks != 0;   // opt-in (MI_SOLVER=blocks): bit-identical to the persistent kernel, but not faster (DESIGN.md "Spatial blocks in LDS": measured)
-    blkMaxBlocks = kn.blocksMax ? kn.blocksMax : std::max(1u, persistWaves / 4u);   // one block per CU
-    mail.flags = hipDeviceMallocUncached;
-    (void)hipFuncSetAttribute((const void*)k_contact_solve_blocks, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+    xcdFaultTest = kn.xcdFault; flowFaultTest = kn.flowFault;
     if (kn.xcdMinManifolds >= 0) xcdMinManifolds = (uint32_t)kn.xcdMinManifolds;   // smallest manifold count that is partitioned (tests: 1)
     if (flowLds > 65536) (void)hipFuncSetAttribute((const void*)k_contact_solve_flow, hipFuncAttributeMaxDynamicSharedMemorySize, (int)flowLds);
     return MI_OK;

@@ -301,10 +301,6 @@ MI_API int mi_world_get_solver_kind(mi_world* world, uint32_t* out_kind);
  * (HIP runtime >= 7.2; MI_GRAPH=0 / force / all).  out[0] = enabled, out[1] = steps replayed, out[2] = graphs captured,
  * out[3] = speculative steps launched plainly. */
 MI_API int mi_debug_step_graph_stats(mi_world* world, uint32_t* out4);
-/* Development / tests: the block solver's sizes and what its last step needed (csrc/blocks.hpp).  out16 = { blocks, tiles per block, extra capacity, body capacity,
-   hash slots, passes per wave, impulses per wave, LDS bytes, entries needed, extras needed, bodies needed, passes needed, impulses needed, boundary entries,
-   block steps so far, steps the path is switched off for }.  No reference counterpart. */
-MI_API int mi_debug_block_stats(mi_world* world, uint32_t* out16);
 /* Tests: how many times the pose rows (mi_world_view_transforms) were enqueued by a step itself, and how many times only when asked. */
 MI_API int mi_debug_pose_stream_stats(mi_world* world, uint32_t* out_ahead, uint32_t* out_on_demand);
 /* Sum of the per-stage device times and of the contact updates (contacts x solver iterations) over the internal steps since

@@ -121,42 +121,6 @@ def test_persistent_solver_keeps_its_acc_registers_to_itself(tmp_path, mi_lib):
         assert loads > 0 and loads % 24 == 0 and reads > 0 and reads % 24 == 0, (loads, reads)
 
 
-def test_block_solver_keeps_its_acc_registers_to_itself_and_polls_lds_with_whole_granules(tmp_path, mi_lib):
-    """k_contact_solve_blocks (spatial blocks in LDS) streams the next pass's rows, normal and masses into the FIXED accumulator registers
-    a152..a255 by inline asm — every reference to them must sit inside an #ASMSTART/#ASMEND block, nothing may go to scratch — and hands the
-    home bodies from wave to wave through LDS as two 16-byte granules each carrying its tag: those accesses must be single ds_read_b128 /
-    ds_write_b128 instructions (a compiler-split 2 x 8-byte access could be observed half written), and no flat access may sneak into the
-    kernel (a flat load counts in vmcnt AND lgkmcnt and would break the hand-counted waits)."""
-    from d3d12renderer_amd import build
-    asm = build.device_asm(tmp_path / "device.s").read_text().split("\n")
-    starts = [i for i, l in enumerate(asm) if re.match(r"^_ZN2mi22k_contact_solve_blocksE.*:", l)]
-    assert len(starts) == 1
-    in_asm, stray, loads, body_reads, body_writes, flat, split = False, [], 0, 0, 0, [], []
-    i = starts[0]
-    while ".amdhsa_kernel" not in asm[i]:
-        line = asm[i]; i += 1
-        if "#ASMSTART" in line:
-            in_asm = True; continue
-        if "#ASMEND" in line:
-            in_asm = False; continue
-        code = line.split(";")[0]
-        if in_asm:
-            loads += len(re.findall(r"global_load_dwordx4 a\[", code))
-            body_reads += len(re.findall(r"ds_read_b128", code)); body_writes += len(re.findall(r"ds_write_b128", code))
-        else:
-            if "scratch_" in code or any(int(n) >= 152 for n in re.findall(r"\ba\[?(\d+)", code)):
-                stray.append(line.strip())
-            if re.search(r"\bflat_", code):
-                flat.append(line.strip())
-            if re.search(r"ds_(read|write)2_b64", code):
-                split.append(line.strip())
-    assert not stray, stray[:5]
-    assert not flat, flat[:5]
-    assert not split, split[:5]
-    assert loads > 0 and loads % 25 == 0, loads        # 24 rows + the normal row per call site
-    assert body_reads >= 6 and body_writes >= 4, (body_reads, body_writes)
-
-
 def test_tile_to_xcd_assignment_is_a_partition(mi_lib):
     """The XCD-partitioned solver gives tile tl of a bin's nt tiles to XCD floor(8 tl / nt) (short bins round-robin) and finds a
     tile's place in that XCD's list from closed forms.  For every bin size up to 70 tiles (and a few large ones) and several bin

@@ -91,33 +91,6 @@ def test_gpu_xcd_partitioned_solver_on_other_scene_types(mi_lib, oracle_mod, mon
     assert 4 in kinds, kinds
 
 
-@pytest.mark.parametrize("make,steps", [
-    (lambda: scenes.shape_zoo(8, 5, 8), 150),
-    (lambda: scenes.terrain_field(10, 2, 10), 260),
-    (lambda: scenes.mixed_stack(12, 6, 12), 80),
-    (lambda: scenes.sphere_drop(12), 120),
-])
-@pytest.mark.parametrize("blocks", ["", "2", "7"], ids=["default block count", "two blocks", "seven blocks"])
-def test_gpu_block_solver_on_other_scene_types(mi_lib, oracle_mod, monkeypatch, make, steps, blocks):
-    """The block solver (blocks.hpp: spatial blocks with their home bodies in LDS, boundary manifolds solved on both sides, exports through
-    mailboxes) with the other manifold sources and with block counts that cut these small scenes in different places: same trajectory as the
-    oracle, bit for bit; it must be the path that ran, and not keep falling back."""
-    monkeypatch.setenv("MI_SOLVER", "blocks")
-    if blocks:
-        monkeypatch.setenv("MI_BLOCKS_MAX", blocks)
-    sc = make()
-    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
-    s = sc.settings()
-    kinds = {}
-    for i in range(steps):
-        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
-        assert g.counts() == o.counts(), f"step {i}"
-        kinds[g.solver_kind()] = kinds.get(g.solver_kind(), 0) + 1
-    pg, qg = g.physics_transforms(); po, qo = o.physics_transforms()
-    assert pg.tobytes() == po.tobytes() and qg.tobytes() == qo.tobytes()
-    assert kinds.get(6, 0) >= steps // 3, kinds
-
-
 def test_gpu_contact_set_equals_reference_order_oracle_first_step(mi_lib, oracle_mod):
     """The GPU's grid broad phase + canonical orientation must reproduce the SAP pipeline's manifolds."""
     sc = scenes.obb_pile(10, 4, 10, spacing=1.0)
@@ -445,8 +418,7 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
     assert g2.cloth_state(0, 144)[0].tobytes() == o2.cloth_state(0, 144)[0].tobytes()
 
 
-@pytest.mark.parametrize("env,kind", [({}, 5), ({"MI_SOLVER": "blocks"}, 6), ({"MI_SOLVER": "blocks", "MI_BLOCKS_MAX": "3"}, 6), ({"MI_SOLVER": "blocks", "MI_BLOCKS_MAX": "2"}, 6),
-                                      ({"MI_SOLVER": "blocks", "MI_BLOCK_FAULT": "1"}, 5), ({"MI_SOLVER": "persist"}, 5), ({"MI_SOLVER": "flow"}, 1), ({"MI_SOLVER": "persist-global"}, 5), ({"MI_PERSIST_XCD": "0"}, 2), ({"MI_PERSIST_XCD_SINGLE": "0"}, 2),
+@pytest.mark.parametrize("env,kind", [({}, 5), ({"MI_SOLVER": "persist"}, 5), ({"MI_SOLVER": "flow"}, 1), ({"MI_SOLVER": "persist-global"}, 5), ({"MI_PERSIST_XCD": "0"}, 2), ({"MI_PERSIST_XCD_SINGLE": "0"}, 2),
                                       ({"MI_PERSIST_XCD_SINGLE": "0", "MI_SOLVER": "persist-global"}, 2), ({"MI_PERSIST_XCD_SINGLE": "0", "MI_SOLVER": "persist-granules"}, 2),
                                       ({"MI_PERSIST_XCD_MIN": "1"}, 4), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-global"}, 4),
                                       ({"MI_SOLVER": "persist-granules"}, 5), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-granules"}, 4),
@@ -480,7 +452,7 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
     assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
     assert kind is None or g.solver_kind() == kind   # (MI_ASYNC=0: every step synchronous, whatever solver the exact sizes select)
     if kind is None: assert g.step_mode_stats()[1] == 0
-    assert g.step_mode_stats()[2] <= (8 if kind == 6 else 2), "the partitioned solver must not keep falling back"   # (the block solver sizes its lists from the previous step: a growing pile outgrows them a few times)
+    assert g.step_mode_stats()[2] <= 2, "the partitioned solver must not keep falling back"
     # timing is opt-in: nothing by default; level 2 = the whole step and the solve stage; level 1 = every stage
     t = g.stage_times()
     assert t["total"] == 0 and t["solve"] == 0
@@ -654,14 +626,13 @@ def test_gpu_private_islands_match_oracle_and_the_dataflow_path(mi_lib, oracle_m
 def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
     """BASELINE's 262 144-body pile, far beyond the oracle's reach: the default solver (XCD-partitioned persistent kernel: eight tile
     lists, ~95 % of the bodies handed over through an XCD's L2, the seam bodies through memory) must end bit-identical to the
-    dispatch-ordered flow kernel, to the unpartitioned persistent kernel — which the small cases pin to the oracle — to the block
-    solver (MI_SOLVER=blocks: 256 spatial blocks with their home bodies in LDS, boundary manifolds solved on both sides), and to a world
+    dispatch-ordered flow kernel, to the unpartitioned persistent kernel — which the small cases pin to the oracle — and to a world
     that takes every step synchronously (MI_ASYNC=0: exact sizes read back inside the step; the path of every re-run)."""
     import hashlib
     sc = scenes.obb_pile(128, 16, 128)
     out = {}
-    for name, env in (("default", {}), ("flow", {"MI_SOLVER": "flow"}), ("unpartitioned", {"MI_PERSIST_XCD": "0"}), ("blocks", {"MI_SOLVER": "blocks"}), ("synchronous", {"MI_ASYNC": "0"})):
-        for k in ("MI_SOLVER", "MI_PERSIST_XCD", "MI_BLOCKS", "MI_ASYNC"):
+    for name, env in (("default", {}), ("flow", {"MI_SOLVER": "flow"}), ("unpartitioned", {"MI_PERSIST_XCD": "0"}), ("synchronous", {"MI_ASYNC": "0"})):
+        for k in ("MI_SOLVER", "MI_PERSIST_XCD", "MI_ASYNC"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -670,8 +641,8 @@ def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
         p, q = w.physics_transforms()
         out[name] = (hashlib.sha1(p.tobytes() + q.tobytes()).hexdigest(), w.counts()["num_contacts"], w.solver_kind(), w.step_mode_stats()[2])
         w.close()
-    assert out["default"][2] == 4 and out["flow"][2] == 1 and out["unpartitioned"][2] == 2 and out["blocks"][2] == 6, out
-    assert out["default"][:2] == out["flow"][:2] == out["unpartitioned"][:2] == out["blocks"][:2] == out["synchronous"][:2], out   # (synchronous: every step sized from read-backs inside the step — the path every re-run takes)
+    assert out["default"][2] == 4 and out["flow"][2] == 1 and out["unpartitioned"][2] == 2, out
+    assert out["default"][:2] == out["flow"][:2] == out["unpartitioned"][:2] == out["synchronous"][:2], out   # (synchronous: every step sized from read-backs inside the step — the path every re-run takes)
     assert out["default"][1] > 150000
     assert out["default"][3] <= 12, "speculative retries while the pile lands are fine; a solver that keeps falling back is not"
 
