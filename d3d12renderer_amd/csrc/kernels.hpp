@@ -578,21 +578,25 @@ constexpr uint32_t kGridChunks = 2;   // a workgroup handles 2 x 256 consecutive
 // workgroup), the block prefix-sums the per-lane counts (wave shuffles), ONE returning atomic reserves the block's
 // output range for its 512 colliders and the keys are copied out; a lane with more than kPairBuf hits in one column
 // appends the excess directly (rare).  Sum-only counters go to the block's shard line.
-__global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blocksPerColumn, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
-                                                       const float4* __restrict__ sMin, const float4* __restrict__ sMax,
-                                                       const uint32_t* __restrict__ cellLower,
-                                                       const GridParams* __restrict__ gp, uint64_t* __restrict__ pairKeys, uint32_t pairCap,
-                                                       StepScalars* sc, Shards* sh, InterSink inter) {
-    __shared__ uint64_t buf[kGridChunks * 256 * kPairBuf];
-    __shared__ uint64_t ovf[kPairOverflow];   // second chance of a lane whose own kPairBuf slots are full (dense piles: ~3 % of the lane-columns); LDS atomics,
-    __shared__ uint32_t ovfCount;             // not one same-address GLOBAL atomic per excess pair (that serialised the kernel in the settled pile: 473 us)
-    __shared__ uint32_t waveTotals[4];
-    __shared__ uint32_t blockBase;
-    __shared__ uint32_t bhist[32];   // [0..20] bucket histogram, [31] overlaps
-    const uint32_t col = blockIdx.x / blocksPerColumn;
+// LDS of the pair kernels (one layout for both bodies, so that ONE launch can run them side by side: k_bp_pairs)
+struct PairLds {
+    uint64_t buf[kGridChunks * 256 * kPairBuf];
+    uint64_t ovf[kPairOverflow];   // second chance of a lane whose own kPairBuf slots are full (dense piles: ~3 % of the lane-columns); LDS atomics,
+    uint32_t ovfCount;             // not one same-address GLOBAL atomic per excess pair (that serialised the kernel in the settled pile: 473 us)
+    uint32_t waveTotals[4];
+    uint32_t blockBase;
+    uint32_t bhist[32];            // [0..20] bucket histogram, [31] overlaps
+};
+__device__ __forceinline__ void bpPairsGridBody(PairLds& L, const uint32_t blockId /* workgroup of the grid pass */, uint32_t nc, uint32_t blocksPerColumn, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                const float4* __restrict__ sMin, const float4* __restrict__ sMax,
+                                                const uint32_t* __restrict__ cellLower,
+                                                const GridParams* __restrict__ gp, uint64_t* __restrict__ pairKeys, uint32_t pairCap,
+                                                StepScalars* sc, Shards* sh, InterSink inter) {
+    uint64_t* const buf = L.buf; uint64_t* const ovf = L.ovf; uint32_t& ovfCount = L.ovfCount; uint32_t* const waveTotals = L.waveTotals; uint32_t& blockBase = L.blockBase; uint32_t* const bhist = L.bhist;
+    const uint32_t col = blockId / blocksPerColumn;
     // blocksPerColumn is a multiple of 8: the workgroups of one XCD (blockIdx % 8, a speed assumption only) walk ONE contiguous
     // eighth of the cell-sorted colliders instead of every eighth block of all of them, so the AABB rows they share stay in that XCD's L2
-    const uint32_t inCol = blockIdx.x % blocksPerColumn;
+    const uint32_t inCol = blockId % blocksPerColumn;
     const uint32_t dy = gp->dims[1], dz = gp->dims[2], dx = gp->dims[0];
     const uint32_t axis = sc->axisCur;
     const uint32_t numSmall = cellLower[gp->numCells];   // total of the cell histogram = this step's small colliders = the filled part of the sorted arrays
@@ -678,10 +682,17 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
         const uint64_t* mybuf = buf + (ch * 256u + threadIdx.x) * kPairBuf;
         for (uint32_t k = 0; k < nh[ch]; ++k, ++dst) if (dst < pairCap) pairKeys[dst] = mybuf[k];
     }
-    ShardCounters* shard = &sh->c[blockIdx.x & (kShards - 1u)];
+    ShardCounters* shard = &sh->c[blockId & (kShards - 1u)];
     if (threadIdx.x < kNumBuckets && bhist[threadIdx.x]) atomicAdd(&shard->bucketHist[threadIdx.x], bhist[threadIdx.x]);
     if (threadIdx.x == 31 && bhist[31]) atomicAdd(&shard->numOverlaps, bhist[31]);
     }
+}
+
+__global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blocksPerColumn, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                       const float4* __restrict__ sMin, const float4* __restrict__ sMax, const uint32_t* __restrict__ cellLower,
+                                                       const GridParams* __restrict__ gp, uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc, Shards* sh, InterSink inter) {
+    __shared__ PairLds L;
+    bpPairsGridBody(L, blockIdx.x, nc, blocksPerColumn, keys, vals, sMin, sMax, cellLower, gp, pairKeys, pairCap, sc, sh, inter);
 }
 
 // (Measured and not kept, round 3: the candidate rows of a workgroup's column staged in LDS — its colliders are consecutive in the cell-sorted order, so
@@ -690,19 +701,18 @@ __global__ __launch_bounds__(256) void k_bp_pairs_grid(uint32_t nc, uint32_t blo
 // conflict and the 48 KiB cut the occupancy from 5 to 3 workgroups per CU: 55 -> 115 us.)
 // Large colliders against everything: (large l) x (all colliders), grid-strided.  Large-large pairs
 // are emitted once (from the lower index).
-__global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint32_t* __restrict__ largeList,
-                                                        const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
-                                                        const uint32_t* __restrict__ vals, const float4* __restrict__ sMin, const float4* __restrict__ sMax,
-                                                        const uint32_t* __restrict__ cellLower, const GridParams* __restrict__ gp,
-                                                        uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc, Shards* sh, InterSink inter) {
+__device__ __forceinline__ void bpPairsLargeBody(PairLds& L, const uint32_t bx, const uint32_t by, const uint32_t gx, const uint32_t gy /* this workgroup in the (candidate chunk, large-list slice) grid of the pass */,
+                                                 uint32_t nc, const uint32_t* __restrict__ largeList,
+                                                 const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                 const uint32_t* __restrict__ vals, const float4* __restrict__ sMin, const float4* __restrict__ sMax,
+                                                 const uint32_t* __restrict__ cellLower, const GridParams* __restrict__ gp,
+                                                 uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc, Shards* sh, InterSink inter) {
     // hits are staged like in k_bp_pairs_grid (kLargeBuf slots per lane, then a block-shared overflow area, then — rare — a direct append)
     // and flushed with ONE returning atomic per workgroup: the ground of a settled pile touches tens of thousands of boxes, and a
     // same-address atomic per wave per hit-iteration made this kernel 40 us
     constexpr uint32_t kLargeBuf = 4;
-    __shared__ uint64_t buf[256 * kLargeBuf];
-    __shared__ uint64_t ovf[kPairOverflow];
-    __shared__ uint32_t ovfCount, blockBase, waveTotals[4];
-    __shared__ uint32_t bhist[32];   // [0..20] bucket histogram, [31] overlaps
+    static_assert(256 * kLargeBuf * 8 + 2 * 64 * 16 + 64 * 4 <= sizeof(L.buf), "the large pass's staging + its slice of the large list live in the grid pass's staging area");
+    uint64_t* const buf = L.buf; uint64_t* const ovf = L.ovf; uint32_t& ovfCount = L.ovfCount; uint32_t* const waveTotals = L.waveTotals; uint32_t& blockBase = L.blockBase; uint32_t* const bhist = L.bhist;
     if (threadIdx.x < 32) bhist[threadIdx.x] = 0;
     if (threadIdx.x == 32) ovfCount = 0;
     __syncthreads();
@@ -715,14 +725,14 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
     // nc colliders: the dead ones of a sharded world are in neither — which it loads once and tests against every large collider,
     // 256 of them staged in LDS at a time (a few walls and a ground in a pile; hundreds of terrain tiles under vehicles).
     constexpr uint32_t kSlice = 64;
-    __shared__ float4 lMin[kSlice], lMax[kSlice];
-    __shared__ uint32_t lIdx[kSlice];
-    for (uint32_t q0 = blockIdx.x * blockDim.x; q0 < numSmall + nl; q0 += gridDim.x * blockDim.x) {
+    float4* const lMin = reinterpret_cast<float4*>(L.buf + 256 * kLargeBuf); float4* const lMax = lMin + kSlice;
+    uint32_t* const lIdx = reinterpret_cast<uint32_t*>(lMax + kSlice);
+    for (uint32_t q0 = bx * blockDim.x; q0 < numSmall + nl; q0 += gx * blockDim.x) {
         const uint32_t q = q0 + threadIdx.x;
         const bool have = q < numSmall + nl, small = q < numSmall;
         uint32_t j = 0; float4 bmn = make_float4(0, 0, 0, 0), bmx = bmn;
         if (have) { j = small ? vals[q] : largeList[q - numSmall]; bmn = small ? sMin[q] : aabbMin[j]; bmx = small ? sMax[q] : aabbMax[j]; }
-        for (uint32_t l0 = blockIdx.y * kSlice; l0 < nl; l0 += gridDim.y * kSlice) {   // blockIdx.y: a 64-wide slice of the large list (more workgroups, shorter loops)
+        for (uint32_t l0 = by * kSlice; l0 < nl; l0 += gy * kSlice) {   // by: a 64-wide slice of the large list (more workgroups, shorter loops)
             __syncthreads();
             if (threadIdx.x < kSlice && l0 + threadIdx.x < nl) { const uint32_t i = largeList[l0 + threadIdx.x]; lIdx[threadIdx.x] = i; lMin[threadIdx.x] = aabbMin[i]; lMax[threadIdx.x] = aabbMax[i]; }
             __syncthreads();
@@ -773,11 +783,32 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
     for (uint32_t k = threadIdx.x; k < nOvf; k += 256u) { const uint32_t d = blockBase + staged + k; if (d < pairCap) pairKeys[d] = ovf[k]; }
     uint32_t dst = blockBase + wbase + incl - mine;
     for (uint32_t k = 0; k < mine; ++k, ++dst) if (dst < pairCap) pairKeys[dst] = mybuf[k];
-    ShardCounters* shard = &sh->c[(blockIdx.x + blockIdx.y) & (kShards - 1u)];
+    ShardCounters* shard = &sh->c[(bx + by) & (kShards - 1u)];
     if (threadIdx.x < kNumBuckets && bhist[threadIdx.x]) atomicAdd(&shard->bucketHist[threadIdx.x], bhist[threadIdx.x]);
     if (threadIdx.x == 31 && bhist[31]) atomicAdd(&shard->numOverlaps, bhist[31]);
 }
 
+__global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint32_t* __restrict__ largeList, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                        const uint32_t* __restrict__ vals, const float4* __restrict__ sMin, const float4* __restrict__ sMax,
+                                                        const uint32_t* __restrict__ cellLower, const GridParams* __restrict__ gp,
+                                                        uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc, Shards* sh, InterSink inter) {
+    __shared__ PairLds L;
+    bpPairsLargeBody(L, blockIdx.x, blockIdx.y, gridDim.x, gridDim.y, nc, largeList, aabbMin, aabbMax, vals, sMin, sMax, cellLower, gp, pairKeys, pairCap, sc, sh, inter);
+}
+// Both passes in ONE launch: they only meet in the pair list's append counter and the sharded sum-only counters.  The grid pass waits on L2 round trips with its
+// issue slots half empty, the large pass (a ground and four walls against every box of a pile) is 12 us of launch floor, gathers and a block flush: as the first workgroups
+// of the grid pass's launch it runs beside that pass instead of behind it.  largeBlocks = gx * gy rounded up to a multiple of 8 (the grid pass's workgroups keep their
+// blockIdx % 8 = XCD residue); workgroups in the padding find nothing to do.
+__global__ __launch_bounds__(256) void k_bp_pairs(uint32_t largeBlocks, uint32_t gx, uint32_t gy, uint32_t nc, uint32_t blocksPerColumn, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+                                                  const float4* __restrict__ sMin, const float4* __restrict__ sMax, const uint32_t* __restrict__ cellLower, const GridParams* __restrict__ gp,
+                                                  const uint32_t* __restrict__ largeList, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                  uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc, Shards* sh, InterSink inter) {
+    __shared__ PairLds L;
+    if (blockIdx.x < largeBlocks) {
+        if (blockIdx.x >= gx * gy) return;
+        bpPairsLargeBody(L, blockIdx.x % gx, blockIdx.x / gx, gx, gy, nc, largeList, aabbMin, aabbMax, vals, sMin, sMax, cellLower, gp, pairKeys, pairCap, sc, sh, inter);
+    } else bpPairsGridBody(L, blockIdx.x - largeBlocks, nc, blocksPerColumn, keys, vals, sMin, sMax, cellLower, gp, pairKeys, pairCap, sc, sh, inter);
+}
 // Shard totals -> StepScalars (read back by the host together with numPairs).
 // `pairBound`: what the launches / scans / buffers downstream are sized for.  A speculative step that found more pairs is
 // invalid as a whole (the host re-runs it synchronously): mark it and make everything downstream a no-op.
@@ -1030,6 +1061,16 @@ __device__ __forceinline__ void boxPairShapes(const float4* __restrict__ wShape,
     brot = sb.rot; bcen = sb.a; brad = sb.b;
 }
 constexpr uint32_t kBoxQueues = 16;
+struct ForcesArgs {   // k_integrate_forces' arguments (also handed to k_narrow_clip, whose guest workgroups run the same body); no padding bytes (the launcher hashes arguments bytewise)
+    const float4* bPos; const float4* bRot; const float4* bCogInvMass; const float4* bInvI; const float4* bParams; const float4* bLinVel;
+    const float4* bAngVel; const float4* bForce; const float4* bTorque; float4* gPos; float4* gInvI; float4* gVel;
+    float4* gVelL;                    // XCD-partitioned solver: cached copy for the XCD-local bodies, or null
+    unsigned long long* bodyOwner;    // ... and the per-body XCD flags (8 bytes), cleared here
+    const uint8_t* bodyActive;        // sharded world, or null
+    uint32_t nb; float dt; float globalForce[3]; uint32_t pad;
+};
+static_assert(sizeof(ForcesArgs) == 15 * 8 + 24, "ForcesArgs must not contain padding");
+__device__ __forceinline__ void integrateForcesBody(const uint32_t i, const ForcesArgs& fa);   // (Integrator section below)
 __global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queueRegion, StepScalars* sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                 const float4* __restrict__ wShape,
                                                 HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
@@ -1080,15 +1121,27 @@ __global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queue
     if (threadIdx.x < numHits) boxQueue[(size_t)q * queueRegion + queueBase + threadIdx.x] = hits[threadIdx.x];
 }
 
+// GUEST workgroups (guestBlocks > 0): force integration (integrateForcesBody) does not depend on anything the narrow phase produces and nothing before the schedule stage reads what it
+// writes; it streams ~80 MB while this kernel computes (a third of its cycles issue, 1 TB/s of traffic).  Every fourth of the first 4 * guestBlocks workgroups integrates 256 bodies
+// instead of clipping, so the two kinds of work are resident side by side from the start: a launch of its own (22 us) less.  (A guest only pays inside a kernel whose OWN work outlasts
+// it: as guests of k_emit_manifolds — bound by the same memory system — and of the colouring rounds — launch floor — the same workgroups gained nothing: round 3.)
 __global__ __launch_bounds__(256) void k_narrow_clip(uint32_t queueRegion, const StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                      const float4* __restrict__ wShape, const BoxHit* __restrict__ boxQueue,
-                                                     uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints) {
+                                                     uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints,
+                                                     uint32_t guestBlocks, ForcesArgs fa) {
 #ifdef MI_CLIP_PINGPONG
     __shared__ float4 polyMem[2 * kLdsPolyVerts * kLdsPolyStride];   // 64 KiB: two clip polygons per lane, [vertex][lane]
 #else
     __shared__ float4 polyMem[kLdsPolyVerts * kLdsPolyStride];       // 32 KiB: ONE clip polygon per lane, [vertex][lane], clipped in place (narrow.hpp clipPolygonLds)
 #endif
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t clipBlock = blockIdx.x;
+    if (guestBlocks) {
+        if (blockIdx.x < 4u * guestBlocks) {
+            if ((blockIdx.x & 3u) == 0u) { integrateForcesBody((blockIdx.x >> 2) * blockDim.x + threadIdx.x, fa); return; }
+            clipBlock = blockIdx.x - (blockIdx.x >> 2) - 1u;
+        } else clipBlock = blockIdx.x - guestBlocks;
+    }
+    const uint32_t t = clipBlock * blockDim.x + threadIdx.x;
     const uint32_t q = t / queueRegion, idx = t % queueRegion;       // queueRegion is a multiple of 256: a workgroup never straddles queues
     if (q >= kBoxQueues || idx >= sc->boxHitCount[q]) return;
     const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
@@ -1229,7 +1282,10 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
                                                         HistSlot* __restrict__ nextTab, uint32_t nextMask, uint8_t* __restrict__ manKept,
                                                         const Shards* __restrict__ statsShards /* non-null: workgroup 0 runs pairFinishStats instead */, uint32_t statsBlocks,
                                                         const unsigned long long* __restrict__ statsPartials, const int* __restrict__ statsBounds, GridParams* statsGridNext, uint32_t statsCellCap,
-                                                        const uint32_t* __restrict__ seamId /* exact seam: per body, the tile border it is shared across (0 = none); or null */) {
+                                                        const uint32_t* __restrict__ seamId /* exact seam: per body, the tile border it is shared across (0 = none); or null */,
+                                                        unsigned long long* __restrict__ topRound1 /* non-null: colouring round 0 happens right here — an uncoloured manifold proposes itself on its bodies
+                                                                                                       for round 1 (k_color_round's "lost" branch at round 0: every uncoloured manifold loses round 0) */,
+                                                        uint32_t* __restrict__ roundFlags) {
     // (workgroup 0, not the last one: dispatched first, it runs beside all the others; as the last one its ~4 us — 12 us over the 8 192 partial rows
     // of a 2 M-collider sharded scene — started when the kernel was all but over and became its tail)
     if (statsShards && blockIdx.x == 0u) { pairFinishStats(statsShards, sc, nc, statsBlocks, statsPartials, statsBounds, statsGridNext, statsCellCap); return; }
@@ -1275,7 +1331,15 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
         // its colour is final: it enters the NEXT step's history right here (k_color_table_insert then only has the few new manifolds left)
         tableInsert(nextTab, nextMask, hk, c);
         manKept[m] = 1u;
-    } else { c = kUncolored; manKept[m] = 0u; }
+    } else {
+        c = kUncolored; manKept[m] = 0u;
+        if (topRound1) {   // round 0 of the colouring (one launch less: the host starts its rounds at 1)
+            const unsigned long long key1 = (1ull << 52) | (unsigned long long)prio;
+            if (dynA) atomicMax(&topRound1[bA], key1);
+            if (dynB) atomicMax(&topRound1[bB], key1);
+            roundFlags[0] = 1u;
+        }
+    }
     color[m] = c;
 }
 
@@ -1291,15 +1355,13 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
 // 962 vs 987 steps/s.  The same with k_manifold_keys / k_manifold_place as guests of rounds 0 / 1: 17.6 + 10.9 us for the two rounds, i.e. guest time + the round's own
 // ~4.7 us — a kernel's launch floor is start-up and drain in series with its work, not a window other work can hide in.  A guest only pays inside a kernel whose OWN work
 // outlasts it (the statistics workgroup of k_emit_manifolds).)
-__global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt, float3 globalForce, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
-                                                          const float4* __restrict__ bCogInvMass, const float4* __restrict__ bInvI,
-                                                          const float4* __restrict__ bParams, const float4* __restrict__ bLinVel,
-                                                          const float4* __restrict__ bAngVel, const float4* __restrict__ bForce, const float4* __restrict__ bTorque,
-                                                          float4* __restrict__ gPos, float4* __restrict__ gInvI, float4* __restrict__ gVel,
-                                                          float4* __restrict__ gVelL /* XCD-partitioned solver: cached copy for the XCD-local bodies, or null */,
-                                                          unsigned long long* __restrict__ bodyOwner /* ... and the per-body XCD flags (8 bytes), cleared here */,
-                                                          const uint8_t* __restrict__ bodyActive /* sharded world, or null */) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void integrateForcesBody(const uint32_t i, const ForcesArgs& fa) {
+    const uint32_t nb = fa.nb; const float dt = fa.dt; const float3 globalForce = make_float3(fa.globalForce[0], fa.globalForce[1], fa.globalForce[2]);
+    const float4* __restrict__ bPos = fa.bPos; const float4* __restrict__ bRot = fa.bRot; const float4* __restrict__ bCogInvMass = fa.bCogInvMass; const float4* __restrict__ bInvI = fa.bInvI;
+    const float4* __restrict__ bParams = fa.bParams; const float4* __restrict__ bLinVel = fa.bLinVel; const float4* __restrict__ bAngVel = fa.bAngVel;
+    const float4* __restrict__ bForce = fa.bForce; const float4* __restrict__ bTorque = fa.bTorque;
+    float4* __restrict__ gPos = fa.gPos; float4* __restrict__ gInvI = fa.gInvI; float4* __restrict__ gVel = fa.gVel; float4* __restrict__ gVelL = fa.gVelL;
+    unsigned long long* __restrict__ bodyOwner = fa.bodyOwner; const uint8_t* __restrict__ bodyActive = fa.bodyActive;
     if (i > nb) return;
     if (bodyActive && i < nb && !bodyActive[i]) return;   // not simulated by this rank: no contact can reference it (nor its XCD flags: they are only ever read for
                                                           // bodies of this step's contacts and for owned bodies, all of which pass here first)
@@ -1337,6 +1399,7 @@ __global__ __launch_bounds__(256) void k_integrate_forces(uint32_t nb, float dt,
     gVel[2 * i] = f4(v, 0.f); gVel[2 * i + 1] = f4(w, 0.f);   // .w = update-version tag of the solver (0 at step start)
     if (gVelL) { gVelL[2 * i] = f4(v, 0.f); gVelL[2 * i + 1] = f4(w, 0.f); }
 }
+__global__ __launch_bounds__(256) void k_integrate_forces(ForcesArgs fa) { integrateForcesBody(blockIdx.x * blockDim.x + threadIdx.x, fa); }
 
 // K13 "Integrate rigid body velocities" (src/physics/rigid_body.cpp:126-142).
 // Writes the NEXT body state into the second buffer set (the host swaps the sets once the step is known to be valid).

@@ -20,18 +20,22 @@ struct Knobs {
     bool poseStream = true;             // MI_POSE_STREAM=0: poses for the caller through the per-array copies + host pass
     bool debugSync = false;             // MI_DEBUG_SYNC: synchronise after every stage and name the one a device fault comes from
     bool eagerTimes = false;            // MI_EAGER_TIMES: read the step's event times at the end of the step (not one step later)
+    bool fuseReset = true;              // MI_FUSE_RESET=0: k_reset_scalars as the first launch of every step (otherwise its work rides at the end of k_publish_readback)
     // ---- step graphs (launcher.hpp)
     std::string graph;                  // MI_GRAPH=0 | force | all ("" = by runtime version)
     uint32_t graphMaxColliders = 32768; // MI_GRAPH_MAX_COLLIDERS
     bool graphDebug = false, graphNoEvents = false, graphNoCapture = false;   // MI_GRAPH_DEBUG / _NOEVENTS / _NOCAPTURE
     // ---- broad / narrow phase
     bool fuseWorld = true;              // MI_FUSE_WORLD=0: k_world_colliders as its own launch
+    bool fuseLarge = true;              // MI_FUSE_LARGE=0: k_bp_pairs_grid and k_bp_pairs_large as two launches (otherwise k_bp_pairs runs the large pass in the first workgroups of the grid pass's launch)
+    bool forcesGuest = true;            // MI_FORCES_GUEST=0: k_integrate_forces as its own launch (otherwise guest workgroups of k_narrow_clip integrate the forces beside the clipping)
     bool skipPartition = true;          // MI_SKIP_PARTITION=0: always launch k_pair_partition
     int gjkWave = -1;                   // MI_GJK_WAVE=0 / 1: force the lane / wave GJK variant
     bool hmStash = true;                // MI_HM_STASH=0: terrain triangles recomputed instead of stashed
     // ---- schedule
     uint32_t colorMargin = 3;           // MI_COLOR_MARGIN: colour rounds enqueued beyond the previous step's count (1 is ~3 us faster at the bench state and costs a synchronous re-run
                                         // whenever a growing scene needs two more rounds than the step before: measured in round 4, not kept)
+    bool round0InEmit = true;           // MI_ROUND0_EMIT=0: colouring round 0 as its own launch (otherwise k_emit_manifolds makes the proposals of the manifolds it leaves uncoloured)
     bool xcdNoSort = false;             // MI_XCD_NOSORT: manifold order as emitted (development)
     bool xcdStats = false;              // MI_XCD_STATS: how many bodies stayed XCD-local (development)
     bool xcdSwizzle = false;            // MI_XCD_SWIZZLE=1
@@ -63,10 +67,12 @@ struct Knobs {
         auto num = [](const char* n, uint64_t d) { const char* v = std::getenv(n); return v ? (uint64_t)strtoull(v, nullptr, 0) : d; };
         k.speculative = !off("MI_ASYNC"); k.spinReadback = str("MI_READBACK") != "copy"; k.stageEvents = on("MI_STAGE_EVENTS"); k.stepEvents = on("MI_STEP_EVENTS");
         k.poseStream = !off("MI_POSE_STREAM"); k.debugSync = set("MI_DEBUG_SYNC"); k.eagerTimes = set("MI_EAGER_TIMES");
+        k.fuseReset = !off("MI_FUSE_RESET");
         k.graph = str("MI_GRAPH"); k.graphMaxColliders = (uint32_t)num("MI_GRAPH_MAX_COLLIDERS", k.graphMaxColliders);
         k.graphDebug = set("MI_GRAPH_DEBUG"); k.graphNoEvents = set("MI_GRAPH_NOEVENTS"); k.graphNoCapture = set("MI_GRAPH_NOCAPTURE");
-        k.fuseWorld = !off("MI_FUSE_WORLD"); k.skipPartition = !off("MI_SKIP_PARTITION"); k.hmStash = !off("MI_HM_STASH");
+        k.fuseWorld = !off("MI_FUSE_WORLD"); k.fuseLarge = !off("MI_FUSE_LARGE"); k.forcesGuest = !off("MI_FORCES_GUEST"); k.skipPartition = !off("MI_SKIP_PARTITION"); k.hmStash = !off("MI_HM_STASH");
         if (const char* v = std::getenv("MI_GJK_WAVE")) k.gjkWave = atoi(v);
+        k.round0InEmit = !off("MI_ROUND0_EMIT");
         k.colorMargin = (uint32_t)num("MI_COLOR_MARGIN", k.colorMargin); k.xcdNoSort = set("MI_XCD_NOSORT"); k.xcdStats = set("MI_XCD_STATS"); k.xcdSwizzle = str("MI_XCD_SWIZZLE") == "1";
         k.solver = str("MI_SOLVER"); k.flowLds = (uint32_t)num("MI_FLOW_LDS", 0); k.persistWaves = (uint32_t)num("MI_PERSIST_WAVES", 0); k.persistXcdOnly = set("MI_PERSIST_XCD_ONLY");
         k.persistXcd = tri("MI_PERSIST_XCD"); k.persistXcdSingle = tri("MI_PERSIST_XCD_SINGLE");
