@@ -1702,8 +1702,8 @@ __global__ __launch_bounds__(256) void k_sort_overflow(uint32_t s0, uint32_t n, 
 // its control flow is uniform (k is a template parameter).  96 B per contact (the reference's scalar
 // collision_constraint is 104 B):
 //   r0 = (rA, effMassN)  r1 = (rB, effMassT)  r2 = (tangent, bias)
-//   r3 = (tA.xyz, tB.x)  r4 = (tB.yz, nA.xy)  r5 = (nA.z, nB.xyz)
-//   with tA = I_A^-1 (rA x t), tB = I_B^-1 (rB x t), nA = I_A^-1 (rA x n), nB = I_B^-1 (rB x n)
+//   r3 = (-tA.xyz, tB.x)  r4 = (tB.yz, -nA.xy)  r5 = (-nA.z, nB.xyz)
+//   with tA = I_A^-1 (rA x t), tB = I_B^-1 (rB x t), nA = I_A^-1 (rA x n), nB = I_B^-1 (rB x n); body A's are stored negated (x - a * b == x + (-a) * b exactly)
 // ------------------------------------------------------------------------------------------------
 constexpr uint32_t kRows = 6;
 constexpr uint32_t kSchedBins = kOverflowColor * 4 + 1;   // 256 regular bins + the overflow colour as one bin (stride 4)
@@ -2009,9 +2009,15 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
         storeStream(row + 0 * 64, f4(rA, effN));
         storeStream(row + 1 * 64, f4(rB, effT));
         storeStream(row + 2 * 64, f4(t, bias));
+#ifdef MI_NO_DIET
         storeStream(row + 3 * 64, make_float4(tA.x, tA.y, tA.z, tB.x));
         storeStream(row + 4 * 64, make_float4(tB.y, tB.z, nA.x, nA.y));
         storeStream(row + 5 * 64, make_float4(nA.z, nB.x, nB.y, nB.z));
+#else   // body A's angular rows are stored NEGATED: the solver adds (-tA) * lambda instead of subtracting tA * lambda (the same IEEE result), and the sign flips leave its dependency chain
+        storeStream(row + 3 * 64, make_float4(-tA.x, -tA.y, -tA.z, tB.x));
+        storeStream(row + 4 * 64, make_float4(tB.y, tB.z, -nA.x, -nA.y));
+        storeStream(row + 5 * 64, make_float4(-nA.z, nB.x, nB.y, nB.z));
+#endif
         if (imp) imp[(ctBase + k) * 64u + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // no warm start (constraints.cpp:3312-3313); sweep tag 0 (null: the solver keeps the impulses in LDS)
     }
 }
@@ -2022,7 +2028,11 @@ struct ContactRows { float4 r[kRows]; float4 imp; };   // imp = (normal, tangent
 
 __device__ __forceinline__ void solveOne(const ContactRows& c, const float4 nf, float2& im, float imA, float imB, V3& vA, V3& wA, V3& vB, V3& wB) {
     V3 rA = xyz(c.r[0]), rB = xyz(c.r[1]), t = xyz(c.r[2]), n = xyz(nf);
-    V3 tA(c.r[3].x, c.r[3].y, c.r[3].z), tB(c.r[3].w, c.r[4].x, c.r[4].y), nA(c.r[4].z, c.r[4].w, c.r[5].x), nB(c.r[5].y, c.r[5].z, c.r[5].w);
+#ifdef MI_NO_DIET
+    V3 tA(-c.r[3].x, -c.r[3].y, -c.r[3].z), tB(c.r[3].w, c.r[4].x, c.r[4].y), nA(-c.r[4].z, -c.r[4].w, -c.r[5].x), nB(c.r[5].y, c.r[5].z, c.r[5].w);   // (tA, nA below are the NEGATED vectors, as the rows now store them)
+#else
+    V3 tA(c.r[3].x, c.r[3].y, c.r[3].z), tB(c.r[3].w, c.r[4].x, c.r[4].y), nA(c.r[4].z, c.r[4].w, c.r[5].x), nB(c.r[5].y, c.r[5].z, c.r[5].w);   // tA, nA: negated (k_contact_init)
+#endif
     {
         V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
         V3 rel = avB - avA;
@@ -2034,7 +2044,7 @@ __device__ __forceinline__ void solveOne(const ContactRows& c, const float4 nf, 
         im.y = ni;
         V3 P = lambda * t;
         vA = vA - imA * P;
-        wA = wA - tA * lambda;
+        wA = wA + tA * lambda;
         vB = vB + imB * P;
         wB = wB + tB * lambda;
     }
@@ -2048,7 +2058,7 @@ __device__ __forceinline__ void solveOne(const ContactRows& c, const float4 nf, 
         im.x = ni;
         V3 P = lambda * n;
         vA = vA - imA * P;
-        wA = wA - nA * lambda;
+        wA = wA + nA * lambda;
         vB = vB + imB * P;
         wB = wB + nB * lambda;
     }
@@ -2064,8 +2074,16 @@ __device__ __forceinline__ P3 pcross(const P3& a, const P3& b) { P3 r; r.x = a.y
 __device__ __forceinline__ void solveOnePk(const ContactRows& c, const float4 nf, float2& im, const f32x2 sMass /* (-imA, imB) */, P3& v, P3& w) {
     const V3 t = xyz(c.r[2]), n = xyz(nf);
     P3 r; r.x = pk2(c.r[0].x, c.r[1].x); r.y = pk2(c.r[0].y, c.r[1].y); r.z = pk2(c.r[0].z, c.r[1].z);
+#ifdef MI_NO_DIET
     P3 T; T.x = pk2(-c.r[3].x, c.r[3].w); T.y = pk2(-c.r[3].y, c.r[4].x); T.z = pk2(-c.r[3].z, c.r[4].y);
     P3 N; N.x = pk2(-c.r[4].z, c.r[5].y); N.y = pk2(-c.r[4].w, c.r[5].z); N.z = pk2(-c.r[5].x, c.r[5].w);
+#else   // (body A's halves come negated from k_contact_init.  They pass through an empty asm: without the sign flip in between, the optimiser merges these element picks into
+        // 4-wide shuffles that the backend then legalises THROUGH SCRATCH MEMORY — 16 bytes per contact stored and re-loaded on the tile's dependency chain)
+    float tAx = c.r[3].x, tAy = c.r[3].y, tAz = c.r[3].z, nAx = c.r[4].z, nAy = c.r[4].w, nAz = c.r[5].x;
+    asm("" : "+v"(tAx)); asm("" : "+v"(tAy)); asm("" : "+v"(tAz)); asm("" : "+v"(nAx)); asm("" : "+v"(nAy)); asm("" : "+v"(nAz));
+    P3 T; T.x = pk2(tAx, c.r[3].w); T.y = pk2(tAy, c.r[4].x); T.z = pk2(tAz, c.r[4].y);
+    P3 N; N.x = pk2(nAx, c.r[5].y); N.y = pk2(nAy, c.r[5].z); N.z = pk2(nAz, c.r[5].w);
+#endif
     {
         P3 cr = pcross(w, r);
         f32x2 ax = v.x + cr.x, ay = v.y + cr.y, az = v.z + cr.z;
@@ -2094,6 +2112,59 @@ __device__ __forceinline__ void solveOnePk(const ContactRows& c, const float4 nf
         w.x = w.x + N.x * lambda; w.y = w.y + N.y * lambda; w.z = w.z + N.z * lambda;
     }
 }
+
+#ifndef MI_NO_DIET
+// The rows of one contact as the packed update wants them — (body A, body B) side by side in 64-bit register pairs — built BEFORE a tile waits for its bodies (packRows), and
+// pinned there: the register moves that line the halves up then happen while the body loads are in flight, not between the bodies' arrival and the publish.
+struct PkRows { f32x2 rx, ry, rz, Tx, Ty, Tz, Nx, Ny, Nz; float tx, ty, tz, effN, effT, bias; };
+__device__ __forceinline__ void pinPair(f32x2& p) { asm volatile("" : "+v"(p)); }
+__device__ __forceinline__ PkRows packRows(const ContactRows& c) {
+    PkRows k;
+    k.rx = pk2(c.r[0].x, c.r[1].x); k.ry = pk2(c.r[0].y, c.r[1].y); k.rz = pk2(c.r[0].z, c.r[1].z);
+    // (body A's halves come negated from k_contact_init.  They pass through an empty asm: left alone, the optimiser merges these element picks into 4-wide shuffles that the
+    // backend legalises THROUGH SCRATCH MEMORY)
+    float tAx = c.r[3].x, tAy = c.r[3].y, tAz = c.r[3].z, nAx = c.r[4].z, nAy = c.r[4].w, nAz = c.r[5].x;
+    asm("" : "+v"(tAx)); asm("" : "+v"(tAy)); asm("" : "+v"(tAz)); asm("" : "+v"(nAx)); asm("" : "+v"(nAy)); asm("" : "+v"(nAz));
+    k.Tx = pk2(tAx, c.r[3].w); k.Ty = pk2(tAy, c.r[4].x); k.Tz = pk2(tAz, c.r[4].y);
+    k.Nx = pk2(nAx, c.r[5].y); k.Ny = pk2(nAy, c.r[5].z); k.Nz = pk2(nAz, c.r[5].w);
+    pinPair(k.rx); pinPair(k.ry); pinPair(k.rz); pinPair(k.Tx); pinPair(k.Ty); pinPair(k.Tz); pinPair(k.Nx); pinPair(k.Ny); pinPair(k.Nz);
+    k.tx = c.r[2].x; k.ty = c.r[2].y; k.tz = c.r[2].z; k.effN = c.r[0].w; k.effT = c.r[1].w; k.bias = c.r[2].w;
+    return k;
+}
+// hi - lo of a pair (body B - body A) as ONE scalar subtraction each (left to itself the SLP vectoriser packs two of the three and pays three register moves for it)
+__device__ __forceinline__ float subHiLo(const f32x2 p) { float d; asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(p.y), "v"(p.x)); return d; }
+__device__ __forceinline__ void solveOnePkRows(const PkRows& c, const float4 nf, float2& im, const f32x2 sMass /* (-imA, imB) */, P3& v, P3& w) {
+    const V3 t(c.tx, c.ty, c.tz), n = xyz(nf);
+    P3 r; r.x = c.rx; r.y = c.ry; r.z = c.rz;
+    {
+        P3 cr = pcross(w, r);
+        f32x2 ax = v.x + cr.x, ay = v.y + cr.y, az = v.z + cr.z;
+        V3 rel(subHiLo(ax), subHiLo(ay), subHiLo(az));
+        float vt = dot(rel, t);
+        float lambda = -c.effT * vt;
+        float maxF = nf.w * im.x;
+        float ni = clampr(im.y + lambda, -maxF, maxF);
+        lambda = ni - im.y;
+        im.y = ni;
+        V3 P = lambda * t;
+        v.x = v.x + sMass * P.x; v.y = v.y + sMass * P.y; v.z = v.z + sMass * P.z;
+        w.x = w.x + c.Tx * lambda; w.y = w.y + c.Ty * lambda; w.z = w.z + c.Tz * lambda;
+    }
+    {
+        P3 cr = pcross(w, r);
+        f32x2 ax = v.x + cr.x, ay = v.y + cr.y, az = v.z + cr.z;
+        V3 rel(subHiLo(ax), subHiLo(ay), subHiLo(az));
+        float vn = dot(rel, n);
+        float lambda = -c.effN * (vn - c.bias);
+        float ni = fmaxr(im.x + lambda, 0.f);
+        lambda = ni - im.x;
+        im.x = ni;
+        V3 P = lambda * n;
+        v.x = v.x + sMass * P.x; v.y = v.y + sMass * P.y; v.z = v.z + sMass * P.z;
+        w.x = w.x + c.Nx * lambda; w.y = w.y + c.Ny * lambda; w.z = w.z + c.Nz * lambda;
+    }
+}
+#endif
 
 // One tile, CNT contacts per manifold.  Latency structure: a colour launch has < 1 wave per SIMD, so it is bound by
 // dependent-load depth: all constraint rows are requested up front (they do not depend on the slot metadata), the
@@ -2242,10 +2313,37 @@ struct PairBody {   // addresses this lane touches in pass 0 / pass 1 for one bo
     }
 };
 // after both passes landed: r0 / r1 = what this lane loaded in pass 0 / 1 -> this lane's own (g0, g1)
+__device__ __forceinline__ void pairGather(bool odd, f32x4 r0, f32x4 r1, f32x4& g0, f32x4& g1);   // (below)
+#ifndef MI_NO_DIET
+// The lane-pair exchange of pairGather and of the publish in ONE instruction per word:  y0 = even lane ? x0 : the partner's x1,  y1 = odd lane ? x1 : the partner's x0
+// (v_cndmask_b32 whose first source is DPP quad-permuted [1,0,3,2]).  The compiler's own code for `odd ? swz1(a) : b` is v_mov_b32_dpp + v_cndmask_b32_e64 — gfx9 has no
+// VOP3 DPP, and it keeps the lane parity in an SGPR pair, not in VCC — i.e. three instructions per word where pairGather / storePair* need both directions; these sit between
+// a tile's bodies arriving and its publish, where every instruction is ~4 cycles of the dependency chain.  Both lanes of a pair are always active together.
+__device__ __forceinline__ void pairExchange(const f32x4 x0, const f32x4 x1, f32x4& y0, f32x4& y1) {
+    float a0, a1, a2, a3, b0, b1, b2, b3;
+    asm volatile("s_mov_b32 vcc_lo, 0x55555555\n\ts_mov_b32 vcc_hi, 0x55555555\n\ts_nop 1\n\t"
+                 "v_cndmask_b32_dpp %0, %12, %8, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_cndmask_b32_dpp %1, %13, %9, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_cndmask_b32_dpp %2, %14, %10, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_cndmask_b32_dpp %3, %15, %11, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "s_not_b64 vcc, vcc\n\t"
+                 "v_cndmask_b32_dpp %4, %8, %12, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_cndmask_b32_dpp %5, %9, %13, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_cndmask_b32_dpp %6, %10, %14, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_cndmask_b32_dpp %7, %11, %15, vcc quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "=&v"(a0), "=&v"(a1), "=&v"(a2), "=&v"(a3), "=&v"(b0), "=&v"(b1), "=&v"(b2), "=&v"(b3)
+                 : "v"(x0.x), "v"(x0.y), "v"(x0.z), "v"(x0.w), "v"(x1.x), "v"(x1.y), "v"(x1.z), "v"(x1.w) : "vcc", "scc");
+    y0.x = a0; y0.y = a1; y0.z = a2; y0.w = a3; y1.x = b0; y1.y = b1; y1.z = b2; y1.w = b3;
+}
+#endif
 __device__ __forceinline__ void pairGather(bool odd, f32x4 r0, f32x4 r1, f32x4& g0, f32x4& g1) {
+#ifdef MI_NO_DIET
     f32x4 p0 = swz1(r0), p1 = swz1(r1);
     g0 = odd ? p1 : r0;
     g1 = odd ? r1 : p0;
+#else
+    (void)odd; pairExchange(r0, r1, g0, g1);
+#endif
 }
 __device__ __forceinline__ void loadPair4Sc1(const PairBody& A, const PairBody& B, f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1) {
     asm volatile("global_load_dwordx4 %0, %4, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %1, %5, off" MI_SC_LOAD "\n\t"
@@ -2287,6 +2385,17 @@ __device__ __forceinline__ void storePairXcd(const PairBody& X, bool odd, bool n
     if (n1 && !l1) storeGranuleSc1(X.q1, d1);
 }
 
+#ifndef MI_NO_DIET
+// the four stores of one body slot under precomputed EXEC masks (plain / write-through for pass 0, then for pass 1); the wave is fully active on entry and on exit
+__device__ __forceinline__ void storePairMasked(float4* q0, float4* q1, f32x4 d0, f32x4 d1, unsigned long long plain0, unsigned long long sc0, unsigned long long plain1, unsigned long long sc1_) {
+    asm volatile("s_mov_b64 exec, %4\n\tglobal_store_dwordx4 %0, %2, off\n\t"
+                 "s_mov_b64 exec, %5\n\tglobal_store_dwordx4 %0, %2, off" MI_SC_STORE "\n\t"
+                 "s_mov_b64 exec, %6\n\tglobal_store_dwordx4 %1, %3, off\n\t"
+                 "s_mov_b64 exec, %7\n\tglobal_store_dwordx4 %1, %3, off" MI_SC_STORE "\n\t"
+                 "s_mov_b64 exec, -1"
+                 : : "v"(q0), "v"(q1), "v"(d0), "v"(d1), "s"(plain0), "s"(sc0), "s"(plain1), "s"(sc1_) : "memory");
+}
+#endif
 // LDSIMP: the accumulated impulses live in LDS (`ldsImp`, [k][lane]) because the same wave runs this tile in every sweep
 // (k_contact_solve_persist); otherwise they travel between sweeps as tagged granules in `imp`.
 #ifndef MI_LATE_PREFETCH
@@ -2334,6 +2443,7 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
 }
 // The tile proper, from data already requested (flowTile) or prefetched (k_contact_solve_persist): wait for the bodies (and the
 // impulse granules), solve, publish.
+#ifdef MI_NO_DIET
 template <int CNT, bool LDSIMP, bool XCD, class Hook>
 __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint32_t it, const uint4 meta, const float4 nf, const float2 mass, const ContactRows* c,
                                             float4* imp, float4* gVel, StepScalars* sc, float2* ldsImp, float4* gVelL, Hook hook) {
@@ -2454,6 +2564,140 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
         }
     }
 }
+#else
+// The tile proper (default build).  Same order of loads, waits, arithmetic and stores as the MI_NO_DIET form below; what differs is how few instructions sit between the
+// arrival of a tile's bodies and its publish, the part of a visit that is on the dependency chain between tiles (~4 cycles per instruction at one wave per SIMD):
+//   * which of the lane pair's four stores per body slot take place, and with which cache policy, is known from the slot's constants: four EXEC masks per body are
+//     computed BEFORE the wait and the publish is four stores under `s_mov_b64 exec, mask` (was: the predicates recomputed and exchanged after the solve, ~12 per store);
+//   * the lane-pair exchange is pairExchange (one v_cndmask_b32_dpp per word and direction), for the arriving bodies and for the publish;
+//   * ONE gather / tag check site: every poll round gathers all lanes from the raw load registers (lanes that did not poll again find their old words there),
+//     so the bodies the solve starts from are defined in one place and no copies merge two definitions at the loop's exit.
+// The whole wave is active here (processTile is only reached through wave-uniform control flow).
+template <int CNT, bool LDSIMP, bool XCD, class Hook>
+__device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint32_t it, const uint4 meta, const float4 nf, const float2 mass, const ContactRows* c,
+                                            float4* imp, float4* gVel, StepScalars* sc, float2* ldsImp, float4* gVelL, Hook hook) {
+    const uint32_t bA = meta.x, bB = meta.y, pk = meta.z;
+    const float imA = mass.x, imB = mass.y;
+    const bool valid = meta.w != 0u;
+#ifdef MI_DBG_ALLLOCAL
+    const bool locA = XCD, locB = XCD;
+#else
+    const bool locA = XCD && (meta.w & 0x100u) != 0u, locB = XCD && (meta.w & 0x200u) != 0u;
+#endif
+    const bool live = valid && (imA != 0.f || imB != 0.f);
+    const uint32_t degA = (pk >> 7) & 127u, degB = (pk >> 21) & 127u;
+    const uint32_t expA = it * degA + (pk & 127u), expB = it * degB + ((pk >> 14) & 127u);
+    const bool needA = valid && degA != 0u, needB = valid && degB != 0u;
+    float4* pA = (locA ? gVelL : gVel) + 2 * (size_t)bA; float4* pB = (locB ? gVelL : gVel) + 2 * (size_t)bB;
+    float4* pI = imp + (size_t)ctBase * 64u + lane;
+    f32x4 ig[CNT], a0, a1, b0, b1;
+    const bool odd = (lane & 1u) != 0u;
+    const PairBody PA(pA, odd), PB(pB, odd);
+    // EXEC masks of the publish (pass 0 moves the even lane's body, pass 1 the odd lane's; XCD-local bodies are published with plain stores, the others write-through)
+    unsigned long long mA[4], mB[4];
+    {
+        const unsigned long long E = 0x5555555555555555ull;
+        const unsigned long long nA = __ballot(needA), lA = __ballot(locA), nB = __ballot(needB), lB = __ballot(locB);
+        const unsigned long long nA0 = (nA & E) | ((nA & E) << 1), nA1 = (nA & ~E) | ((nA & ~E) >> 1), lA0 = (lA & E) | ((lA & E) << 1), lA1 = (lA & ~E) | ((lA & ~E) >> 1);
+        const unsigned long long nB0 = (nB & E) | ((nB & E) << 1), nB1 = (nB & ~E) | ((nB & ~E) >> 1), lB0 = (lB & E) | ((lB & E) << 1), lB1 = (lB & ~E) | ((lB & ~E) >> 1);
+        mA[0] = nA0 & lA0; mA[1] = nA0 & ~lA0; mA[2] = nA1 & lA1; mA[3] = nA1 & ~lA1;
+        mB[0] = nB0 & lB0; mB[1] = nB0 & ~lB0; mB[2] = nB1 & lB1; mB[3] = nB1 & ~lB1;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { asm volatile("" : "+s"(mA[k])); asm volatile("" : "+s"(mB[k])); }   // (pinned here: not recomputed behind the wait)
+    }
+    if (!LDSIMP) {
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) issueGranuleSc1(pI + (size_t)k * 64u, ig[k]);
+    }
+    f32x4 ra0, ra1, rb0, rb1;   // raw load destinations (pass 0 / pass 1 of bodies A and B)
+    issuePair4Sc1(PA, PB, ra0, ra1, rb0, rb1);
+    MI_STAMP(hook.rec, 2);
+    const uint32_t hookLoads = hook.early();   // (the persistent kernel: this tile's rows out of the prefetch registers, the next tile's requested)
+    PkRows pkr[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) pkr[k] = packRows(c[k]);
+    waitVmcnt(hookLoads);   // the hook's loads are younger than the body loads: they may stay in flight
+    float2 imIn[CNT];   // accumulated impulses this tile starts from
+    if (!LDSIMP) {
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) landed(ig[k]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) imIn[k] = ldsImp[k * 64 + lane];
+    }
+    bool okA, okB, okI = true, polled = false;
+    uint32_t budget = kSpinBudget;
+    MI_STAMP(hook.rec, 3);
+    for (;;) {
+        landed(ra0); landed(ra1); landed(rb0); landed(rb1);
+        pairExchange(ra0, ra1, a0, a1);
+        pairExchange(rb0, rb1, b0, b1);
+        okA = !needA || (__float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA);
+        okB = !needB || (__float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB);
+        if (!LDSIMP) {
+            okI = true;
+#pragma unroll
+            for (int k = 0; k < CNT; ++k) okI = okI && (!live || __float_as_uint(ig[k].z) == it);
+        }
+#ifdef MI_DBG_NOWAIT
+        okA = okB = okI = true;   // development knock-out: timing without dependency waits (results are garbage)
+#endif
+        if (__ballot(!(okA && okB && okI)) == 0ull) break;
+        polled = true;
+        if (--budget == 0u) { sc->solveError = 1u; break; }
+        // both lanes of a pair poll together (the exchange above needs both); tight polling measured fastest: only the pairs still waiting re-load, both bodies' polls
+        // in flight together (one round trip per round, not two)
+        const uint32_t partnerOkA = swz1(okA ? 1u : 0u), partnerOkB = swz1(okB ? 1u : 0u);
+        const bool pollA = !okA || partnerOkA == 0u, pollB = !okB || partnerOkB == 0u;
+        if (pollA) issuePair2Sc1(PA, ra0, ra1);
+        if (pollB) issuePair2Sc1(PB, rb0, rb1);
+        if (!LDSIMP && !okI) {
+#pragma unroll
+            for (int k = 0; k < CNT; ++k) issueGranuleSc1(pI + (size_t)k * 64u, ig[k]);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (!LDSIMP) {
+#pragma unroll
+            for (int k = 0; k < CNT; ++k) landed(ig[k]);
+        }
+    }
+    hook.late(polled);
+    MI_STAMP(hook.rec, 4);
+    P3 pv, pw;
+    pv.x = pk2(a0.x, b0.x); pv.y = pk2(a0.y, b0.y); pv.z = pk2(a0.z, b0.z);
+    pw.x = pk2(a1.x, b1.x); pw.y = pk2(a1.y, b1.y); pw.z = pk2(a1.z, b1.z);
+    const f32x2 sMass = pk2(-imA, imB);
+    float2 out[CNT];
+#pragma unroll
+    for (int k = 0; k < CNT; ++k) {
+        float2 im = LDSIMP ? imIn[k] : make_float2(ig[k].x, ig[k].y);
+        solveOnePkRows(pkr[k], nf, im, sMass, pv, pw);
+        out[k] = im;
+    }
+    // publish: bodies first (they are on the dependency chain), then the impulses; nothing to wait for afterwards
+    {
+        const float tA = __uint_as_float(expA + 1u), tB = __uint_as_float(expB + 1u);
+        const f32x4 hA0 = {pv.x.x, pv.y.x, pv.z.x, tA}, hA1 = {pw.x.x, pw.y.x, pw.z.x, tA}, hB0 = {pv.x.y, pv.y.y, pv.z.y, tB}, hB1 = {pw.x.y, pw.y.y, pw.z.y, tB};
+        MI_STAMP(hook.rec, 5);
+        f32x4 dA0, dA1, dB0, dB1;
+        pairExchange(hA0, hA1, dA0, dA1);
+        pairExchange(hB0, hB1, dB0, dB1);
+        storePairMasked(PA.q0, PA.q1, dA0, dA1, mA[0], mA[1], mA[2], mA[3]);
+        storePairMasked(PB.q0, PB.q1, dB0, dB1, mB[0], mB[1], mB[2], mB[3]);
+    }
+    if (LDSIMP) {
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) ldsImp[k * 64 + lane] = out[k];
+    } else if (live) {
+        float t = __uint_as_float(it + 1u);
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) {
+            f32x4 g = {out[k].x, out[k].y, t, 0.f};
+            storeGranuleSc1(pI + (size_t)k * 64u, g);
+        }
+    }
+}
+#endif
 
 // Block b runs sweep itBase + b / numTiles of tile b % numTiles (numTiles = StepScalars::totalTiles; schedule order, colour-major): with no joints between the
 // sweeps ALL iterations are one launch, so the latency-bound small colours of sweep i overlap the bandwidth-bound large

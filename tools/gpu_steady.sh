@@ -15,7 +15,7 @@ dur = collections.defaultdict(list)
 for r in rows: dur[r["Kernel_Name"].split("(")[0]].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 tot = 0
 for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1][-20:])):
-    n = min(20, len(v)); per_step = len(v) / max(1, len(dur["k_reset_scalars"]))
+    n = min(20, len(v)); per_step = len(v) / max(1, len(dur["k_publish_readback"]))
     m = sum(v[-n:]) / n; tot += m * per_step
     if m * per_step > 4: print(f"{m:8.1f} us x{per_step:5.2f}  {k[:60]}")
 print(f"sum of kernels per step: {tot:.1f} us")

@@ -10,8 +10,8 @@ import csv, glob
 f = glob.glob("/tmp/prof_tl/**/tl_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a step starts with k_reset_scalars: take the one full step before the profiled extra steps (5th from last)
-idx = [i for i, r in enumerate(rows) if "k_reset_scalars" in r["Kernel_Name"]]
+# a step ends with k_publish_readback (k_reset_scalars' work rides in it): take the one full step before the profiled extra steps (5th from last)
+idx = [i + 1 for i, r in enumerate(rows) if "k_publish_readback" in r["Kernel_Name"]]
 a, b = idx[-5], idx[-4]
 t0 = int(rows[a]["Start_Timestamp"])
 out = []

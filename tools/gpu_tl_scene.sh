@@ -23,8 +23,8 @@ import csv, glob
 f = glob.glob("/tmp/prof_tls/**/tl_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_reset_scalars" in r["Kernel_Name"]]
-a, b = idx[-3] + 1, idx[-2] + 1
+idx = [i + 1 for i, r in enumerate(rows) if "k_publish_readback" in r["Kernel_Name"]]
+a, b = idx[-3], idx[-2]
 t0 = int(rows[a]["Start_Timestamp"]); prev_end = t0; out = []
 for r in rows[a:b]:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])

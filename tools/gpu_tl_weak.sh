@@ -12,8 +12,8 @@ import csv, glob
 f = glob.glob("/tmp/prof_tlw/**/tl_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if "k_reset_scalars" in r["Kernel_Name"]]
-a, b = idx[-5] + 1, idx[-4] + 1
+idx = [i + 1 for i, r in enumerate(rows) if "k_publish_readback" in r["Kernel_Name"]]
+a, b = idx[-5], idx[-4]
 t0 = int(rows[a]["Start_Timestamp"])
 out = []
 prev_end = t0
