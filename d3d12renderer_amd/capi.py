@@ -425,6 +425,15 @@ class World:
         p.flags.writeable = False; r.flags.writeable = False
         return p, r
 
+    def transforms_view_landed(self, physics=False):
+        """mi_world_view_transforms_landed: (positions, rotations, internal step they belong to) — the newest pose rows that are complete in host memory, without waiting for
+        a copy still on the bus (one frame behind in a step -> view loop); read-only views, valid until the next stepping call (product library only)."""
+        pp = C.POINTER(C.c_float)(); rr = C.POINTER(C.c_float)(); n = C.c_uint32(); st = C.c_uint64()
+        self.L.check(self.L.fn("world_view_transforms_landed")(self.h, C.c_uint32(1 if physics else 0), C.byref(pp), C.byref(rr), C.byref(n), C.byref(st)), "world_view_transforms_landed")
+        p = np.ctypeslib.as_array(pp, shape=(n.value, 3)); r = np.ctypeslib.as_array(rr, shape=(n.value, 4))
+        p.flags.writeable = False; r.flags.writeable = False
+        return p, r, st.value
+
     def velocities_view(self):
         """mi_world_view_velocities: (linear [n, 3], angular [n, 3]) as read-only views of the library's pinned rows (product library only)."""
         ll = C.POINTER(C.c_float)(); aa = C.POINTER(C.c_float)(); n = C.c_uint32()

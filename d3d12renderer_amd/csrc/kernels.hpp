@@ -1061,16 +1061,6 @@ __device__ __forceinline__ void boxPairShapes(const float4* __restrict__ wShape,
     brot = sb.rot; bcen = sb.a; brad = sb.b;
 }
 constexpr uint32_t kBoxQueues = 16;
-struct ForcesArgs {   // k_integrate_forces' arguments (also handed to k_narrow_clip, whose guest workgroups run the same body); no padding bytes (the launcher hashes arguments bytewise)
-    const float4* bPos; const float4* bRot; const float4* bCogInvMass; const float4* bInvI; const float4* bParams; const float4* bLinVel;
-    const float4* bAngVel; const float4* bForce; const float4* bTorque; float4* gPos; float4* gInvI; float4* gVel;
-    float4* gVelL;                    // XCD-partitioned solver: cached copy for the XCD-local bodies, or null
-    unsigned long long* bodyOwner;    // ... and the per-body XCD flags (8 bytes), cleared here
-    const uint8_t* bodyActive;        // sharded world, or null
-    uint32_t nb; float dt; float globalForce[3]; uint32_t pad;
-};
-static_assert(sizeof(ForcesArgs) == 15 * 8 + 24, "ForcesArgs must not contain padding");
-__device__ __forceinline__ void integrateForcesBody(const uint32_t i, const ForcesArgs& fa);   // (Integrator section below)
 __global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queueRegion, StepScalars* sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                 const float4* __restrict__ wShape,
                                                 HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
@@ -1121,27 +1111,15 @@ __global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queue
     if (threadIdx.x < numHits) boxQueue[(size_t)q * queueRegion + queueBase + threadIdx.x] = hits[threadIdx.x];
 }
 
-// GUEST workgroups (guestBlocks > 0): force integration (integrateForcesBody) does not depend on anything the narrow phase produces and nothing before the schedule stage reads what it
-// writes; it streams ~80 MB while this kernel computes (a third of its cycles issue, 1 TB/s of traffic).  Every fourth of the first 4 * guestBlocks workgroups integrates 256 bodies
-// instead of clipping, so the two kinds of work are resident side by side from the start: a launch of its own (22 us) less.  (A guest only pays inside a kernel whose OWN work outlasts
-// it: as guests of k_emit_manifolds — bound by the same memory system — and of the colouring rounds — launch floor — the same workgroups gained nothing: round 3.)
 __global__ __launch_bounds__(256) void k_narrow_clip(uint32_t queueRegion, const StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                      const float4* __restrict__ wShape, const BoxHit* __restrict__ boxQueue,
-                                                     uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints,
-                                                     uint32_t guestBlocks, ForcesArgs fa) {
+                                                     uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints) {
 #ifdef MI_CLIP_PINGPONG
     __shared__ float4 polyMem[2 * kLdsPolyVerts * kLdsPolyStride];   // 64 KiB: two clip polygons per lane, [vertex][lane]
 #else
     __shared__ float4 polyMem[kLdsPolyVerts * kLdsPolyStride];       // 32 KiB: ONE clip polygon per lane, [vertex][lane], clipped in place (narrow.hpp clipPolygonLds)
 #endif
-    uint32_t clipBlock = blockIdx.x;
-    if (guestBlocks) {
-        if (blockIdx.x < 4u * guestBlocks) {
-            if ((blockIdx.x & 3u) == 0u) { integrateForcesBody((blockIdx.x >> 2) * blockDim.x + threadIdx.x, fa); return; }
-            clipBlock = blockIdx.x - (blockIdx.x >> 2) - 1u;
-        } else clipBlock = blockIdx.x - guestBlocks;
-    }
-    const uint32_t t = clipBlock * blockDim.x + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t q = t / queueRegion, idx = t % queueRegion;       // queueRegion is a multiple of 256: a workgroup never straddles queues
     if (q >= kBoxQueues || idx >= sc->boxHitCount[q]) return;
     const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
@@ -1354,7 +1332,18 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
 // the bodies per round made every round 9-10 us instead of 4.8 (the body rows are a chain of dependent gathers: ~5 us however few bodies), 8 x 5 us for the 19 saved:
 // 962 vs 987 steps/s.  The same with k_manifold_keys / k_manifold_place as guests of rounds 0 / 1: 17.6 + 10.9 us for the two rounds, i.e. guest time + the round's own
 // ~4.7 us — a kernel's launch floor is start-up and drain in series with its work, not a window other work can hide in.  A guest only pays inside a kernel whose OWN work
-// outlasts it (the statistics workgroup of k_emit_manifolds).)
+// outlasts it (the statistics workgroup of k_emit_manifolds).  Round 5: as every fourth of the first workgroups of k_narrow_clip — a kernel that computes, a third of its cycles
+// issuing, 1 TB/s of traffic —: that kernel 63 -> 84 us, i.e. exactly the 21 us saved; 1039.2 vs 1040.5 steps/s.  Its three waves per SIMD are what hides its own LDS latency:
+// a guest wave takes a slot, it does not fill a gap.)
+struct ForcesArgs {   // k_integrate_forces' arguments; no padding bytes (the launcher hashes arguments bytewise)
+    const float4* bPos; const float4* bRot; const float4* bCogInvMass; const float4* bInvI; const float4* bParams; const float4* bLinVel;
+    const float4* bAngVel; const float4* bForce; const float4* bTorque; float4* gPos; float4* gInvI; float4* gVel;
+    float4* gVelL;                    // XCD-partitioned solver: cached copy for the XCD-local bodies, or null
+    unsigned long long* bodyOwner;    // ... and the per-body XCD flags (8 bytes), cleared here
+    const uint8_t* bodyActive;        // sharded world, or null
+    uint32_t nb; float dt; float globalForce[3]; uint32_t pad;
+};
+static_assert(sizeof(ForcesArgs) == 15 * 8 + 24, "ForcesArgs must not contain padding");
 __device__ __forceinline__ void integrateForcesBody(const uint32_t i, const ForcesArgs& fa) {
     const uint32_t nb = fa.nb; const float dt = fa.dt; const float3 globalForce = make_float3(fa.globalForce[0], fa.globalForce[1], fa.globalForce[2]);
     const float4* __restrict__ bPos = fa.bPos; const float4* __restrict__ bRot = fa.bRot; const float4* __restrict__ bCogInvMass = fa.bCogInvMass; const float4* __restrict__ bInvI = fa.bInvI;
@@ -2287,6 +2276,9 @@ constexpr uint32_t kSpinBudget = 1u << 16;
 // single 16-byte granule: issue only (the next waiting asm block lands it), load + wait, store
 __device__ __forceinline__ void issueGranuleSc1(const float4* p, f32x4& g) { asm volatile("global_load_dwordx4 %0, %1, off" MI_SC_LOAD : "=&v"(g) : "v"(p) : "memory"); }
 __device__ __forceinline__ void landed(f32x4& g) { asm volatile("" : "+v"(g)); }   // orders every later use of g behind the waiting block
+// the same into a register that already holds a value ("+v": the asm reads AND writes g, so a value merged from a divergent branch stays in ONE register — with a pure output
+// the compiler may place a copy between the load's issue and the wait that lands it, and copy the old contents)
+__device__ __forceinline__ void issueGranuleSc1Keep(const float4* p, f32x4& g) { asm volatile("global_load_dwordx4 %0, %1, off" MI_SC_LOAD : "+v"(g) : "v"(p) : "memory"); }
 __device__ __forceinline__ void loadGranuleSc1(const float4* p, f32x4& g) { asm volatile("global_load_dwordx4 %0, %1, off" MI_SC_LOAD "\n\ts_waitcnt vmcnt(0)" : "=&v"(g) : "v"(p) : "memory"); }
 __device__ __forceinline__ void storeGranuleSc1(float4* p, f32x4 g) { asm volatile("global_store_dwordx4 %0, %1, off" MI_SC_STORE : : "v"(p), "v"(g) : "memory"); }
 
@@ -2593,7 +2585,14 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
     f32x4 ig[CNT], a0, a1, b0, b1;
     const bool odd = (lane & 1u) != 0u;
     const PairBody PA(pA, odd), PB(pB, odd);
-    // EXEC masks of the publish (pass 0 moves the even lane's body, pass 1 the odd lane's; XCD-local bodies are published with plain stores, the others write-through)
+    if (!LDSIMP) {
+#pragma unroll
+        for (int k = 0; k < CNT; ++k) issueGranuleSc1(pI + (size_t)k * 64u, ig[k]);
+    }
+    f32x4 ra0, ra1, rb0, rb1;   // raw load destinations (pass 0 / pass 1 of bodies A and B)
+    issuePair4Sc1(PA, PB, ra0, ra1, rb0, rb1);
+    MI_STAMP(hook.rec, 2);
+    // (while the body loads are in flight) EXEC masks of the publish (pass 0 moves the even lane's body, pass 1 the odd lane's; XCD-local bodies are published with plain stores, the others write-through)
     unsigned long long mA[4], mB[4];
     {
         const unsigned long long E = 0x5555555555555555ull;
@@ -2605,13 +2604,6 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
 #pragma unroll
         for (int k = 0; k < 4; ++k) { asm volatile("" : "+s"(mA[k])); asm volatile("" : "+s"(mB[k])); }   // (pinned here: not recomputed behind the wait)
     }
-    if (!LDSIMP) {
-#pragma unroll
-        for (int k = 0; k < CNT; ++k) issueGranuleSc1(pI + (size_t)k * 64u, ig[k]);
-    }
-    f32x4 ra0, ra1, rb0, rb1;   // raw load destinations (pass 0 / pass 1 of bodies A and B)
-    issuePair4Sc1(PA, PB, ra0, ra1, rb0, rb1);
-    MI_STAMP(hook.rec, 2);
     const uint32_t hookLoads = hook.early();   // (the persistent kernel: this tile's rows out of the prefetch registers, the next tile's requested)
     PkRows pkr[CNT];
 #pragma unroll
@@ -2653,7 +2645,7 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
         if (pollB) issuePair2Sc1(PB, rb0, rb1);
         if (!LDSIMP && !okI) {
 #pragma unroll
-            for (int k = 0; k < CNT; ++k) issueGranuleSc1(pI + (size_t)k * 64u, ig[k]);
+            for (int k = 0; k < CNT; ++k) issueGranuleSc1Keep(pI + (size_t)k * 64u, ig[k]);
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (!LDSIMP) {

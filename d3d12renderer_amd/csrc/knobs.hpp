@@ -28,7 +28,6 @@ struct Knobs {
     // ---- broad / narrow phase
     bool fuseWorld = true;              // MI_FUSE_WORLD=0: k_world_colliders as its own launch
     bool fuseLarge = true;              // MI_FUSE_LARGE=0: k_bp_pairs_grid and k_bp_pairs_large as two launches (otherwise k_bp_pairs runs the large pass in the first workgroups of the grid pass's launch)
-    bool forcesGuest = true;            // MI_FORCES_GUEST=0: k_integrate_forces as its own launch (otherwise guest workgroups of k_narrow_clip integrate the forces beside the clipping)
     bool skipPartition = true;          // MI_SKIP_PARTITION=0: always launch k_pair_partition
     int gjkWave = -1;                   // MI_GJK_WAVE=0 / 1: force the lane / wave GJK variant
     bool hmStash = true;                // MI_HM_STASH=0: terrain triangles recomputed instead of stashed
@@ -70,7 +69,7 @@ struct Knobs {
         k.fuseReset = !off("MI_FUSE_RESET");
         k.graph = str("MI_GRAPH"); k.graphMaxColliders = (uint32_t)num("MI_GRAPH_MAX_COLLIDERS", k.graphMaxColliders);
         k.graphDebug = set("MI_GRAPH_DEBUG"); k.graphNoEvents = set("MI_GRAPH_NOEVENTS"); k.graphNoCapture = set("MI_GRAPH_NOCAPTURE");
-        k.fuseWorld = !off("MI_FUSE_WORLD"); k.fuseLarge = !off("MI_FUSE_LARGE"); k.forcesGuest = !off("MI_FORCES_GUEST"); k.skipPartition = !off("MI_SKIP_PARTITION"); k.hmStash = !off("MI_HM_STASH");
+        k.fuseWorld = !off("MI_FUSE_WORLD"); k.fuseLarge = !off("MI_FUSE_LARGE"); k.skipPartition = !off("MI_SKIP_PARTITION"); k.hmStash = !off("MI_HM_STASH");
         if (const char* v = std::getenv("MI_GJK_WAVE")) k.gjkWave = atoi(v);
         k.round0InEmit = !off("MI_ROUND0_EMIT");
         k.colorMargin = (uint32_t)num("MI_COLOR_MARGIN", k.colorMargin); k.xcdNoSort = set("MI_XCD_NOSORT"); k.xcdStats = set("MI_XCD_STATS"); k.xcdSwizzle = str("MI_XCD_SWIZZLE") == "1";

@@ -223,6 +223,9 @@ struct mi_world {
         bool wanted = false, consumed = false, askedPhysics = false, retrySameStep = false;
         bool wantVel = false, hasVel = false, velConsumed = false;   // the velocities ride in the rows once a caller has read them after a step (and stop when nobody reads them)
         uint32_t produced_ahead = 0, produced_on_demand = 0;
+        // per (flavour, set): what the set holds and the event behind its last piece — mi_world_view_transforms_landed hands out the newest set that is COMPLETE in host memory
+        // without waiting for the one still on the bus (a renderer one frame behind: its frame then overlaps the copy of the step it has not seen yet)
+        struct SetInfo { hipEvent_t landed = nullptr; bool valid = false; uint64_t steps = 0; float t = 0.f; uint32_t n = 0; } sets[2][2];
     } pose;
     struct PoseArm { bool armed = false, done = false; float t = 0.f; } poseArm;   // the stepping call wants the LAST of its internal steps to enqueue the rows itself, behind its kernels and ahead of the host's wait
     bool posesPossible(bool physics, float* t) const;
@@ -230,6 +233,7 @@ struct mi_world {
     void posesArm(bool lerpAfterwards, float lerpTAfterwards);
     int posesProduce(float t, bool fromNextState, bool ahead);
     void posesAbort();
+    int posesViewLanded(bool physics, const float** p, const float** r, uint32_t* count, uint64_t* ofStep);
     int posesFetch(float* p, float* r, const float** viewP, const float** viewR, float* lin = nullptr, float* ang = nullptr, const float** viewL = nullptr, const float** viewA = nullptr);
     int posesAfterStep();
     float timer = 0.f;
@@ -443,6 +447,7 @@ mi_world::~mi_world() {
     for (auto& hh : pose.host) for (float*& h : hh) if (h) (void)hipHostFree(h);
     if (pose.produced) (void)hipEventDestroy(pose.produced);
     for (hipEvent_t& e : pose.chunkEv) if (e) (void)hipEventDestroy(e);
+    for (auto& ff : pose.sets) for (auto& si : ff) if (si.landed) (void)hipEventDestroy(si.landed);
     if (pose.copyStream) (void)hipStreamDestroy(pose.copyStream);
     if (shard.sentHost) (void)hipHostFree(shard.sentHost);
     if (shard.recvHost) (void)hipHostFree(shard.recvHost);

@@ -275,6 +275,12 @@ MI_API int mi_world_get_physics_transforms(mi_world* world, float* positions_xyz
  * stepped since the last full download, a topology change is pending, a sharded world): mi_world_get_transforms covers every case. */
 MI_API int mi_world_view_transforms(mi_world* world, const float** positions_xyz, const float** rotations_xyzw, uint32_t* out_count);
 MI_API int mi_world_view_physics_transforms(mi_world* world, const float** positions_xyz, const float** rotations_xyzw, uint32_t* out_count);
+/* The same rows WITHOUT waiting for a copy that is still on the bus: the NEWEST set that is complete in host memory — the last step's if its copy has landed, else the step's before
+ * (*out_of_step = the internal step whose state they are; mi_world_get_step_mode_stats counts the same steps).  For a renderer that accepts one frame of latency — the
+ * reference's own loop interpolates between the two last poses anyway (src/physics/physics.cpp:1395-1412): its next physicsStep then runs on the device while the rows of the
+ * step it has not seen yet cross the bus, and a frame costs max(step, copy) instead of their sum.  The call never blocks except for the very first rows of a world.  What it
+ * hands out stays intact until a stepping call produces into the same set: the rows of the step before the last are overwritten by the NEXT stepping call.  Read-only. */
+MI_API int mi_world_view_transforms_landed(mi_world* world, uint32_t physics_transforms, const float** positions_xyz, const float** rotations_xyzw, uint32_t* out_count, uint64_t* out_of_step);
 /* ... and the linear / angular velocities of every entity's rigid body (rigid_body_component::linearVelocity / angularVelocity; zero for an entity without one),
  * [count][3] each, out of the same rows: they ride along from the frame after the first request for velocities on (mi_world_get_velocities takes them from there too). */
 MI_API int mi_world_view_velocities(mi_world* world, const float** linear_xyz, const float** angular_xyz, uint32_t* out_count);

@@ -166,6 +166,31 @@ def test_gpu_pose_rows_for_a_caller_that_reads_them_after_every_step(mi_lib, ora
     assert g.transforms()[0].tobytes() == o.transforms()[0].tobytes()
 
 
+def test_gpu_pose_rows_one_frame_behind(mi_lib, oracle_mod):
+    """mi_world_view_transforms_landed: the newest pose rows that are COMPLETE in host memory, without waiting for a copy still on the bus.  Whatever step the call says the
+    rows belong to, they are that step's physics transforms bit for bit (the oracle's, recorded step by step); the step is the last one or the one before; a renderer's loop
+    (step, view) never falls further behind and the rows it was handed stay intact until its next stepping call."""
+    sc = scenes.obb_pile(16, 6, 16, spacing=1.05)
+    g = sc.populate(gpu_world(mi_lib)); o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings()
+    want = {}
+    behind = []
+    for i in range(40):
+        g.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+        po, ro = o.physics_transforms(); want[i + 1] = (po.tobytes(), ro.tobytes())
+        p, r, of = g.transforms_view_landed(physics=True)
+        assert of in (i, i + 1) and of >= 1, (i, of)
+        assert p.tobytes() == want[of][0] and r.tobytes() == want[of][1], f"call {i}: the rows of step {of}"
+        snap = (p.tobytes(), r.tobytes())
+        _ = g.counts()                                # (host work between the view and the next step)
+        assert (p.tobytes(), r.tobytes()) == snap     # intact until the next stepping call
+        behind.append(i + 1 - of)
+    assert g.pose_stream_stats()[0] >= 30             # the steps enqueue the rows themselves
+    # the blocking view still hands out the current step's rows
+    vp, vr = g.transforms_view(physics=True)
+    assert vp.tobytes() == want[40][0] and vr.tobytes() == want[40][1]
+
+
 def test_gpu_pose_and_velocity_readbacks_agree_with_a_full_download(mi_lib, oracle_mod):
     """mi_world_get_transforms / _physics_transforms / _velocities read straight from the device (2-4 arrays, host mirror untouched); everything
     else goes through a full download of the body state.  Both give the same bytes, in any order, interpolated or not, and equal the oracle."""

@@ -48,6 +48,7 @@ variants = {
 }
 if stream:
     variants["physicsStep_plus_entity_transforms_viewed_in_pinned_rows"] = lambda w: (lambda: (w.step(s, sc.dt), w.transforms_view()))
+    variants["physicsStep_plus_entity_transforms_viewed_one_frame_behind"] = lambda w: (lambda: (w.step(s, sc.dt), w.transforms_view_landed()))
     variants["physicsStep_plus_transforms_plus_velocities_viewed_in_pinned_rows"] = lambda w: (lambda: (w.step(s, sc.dt), w.transforms_view(), w.velocities_view()))
 out = {"workload": f"cfg3 obb_pile 128x16x128 (262144 bodies); every variant on its own world, settled 240 steps, {FRAMES} timed frames", "pose_stream": stream}
 for k, v in variants.items():
