@@ -4,6 +4,7 @@
 // float4 rows: a wave touching 64 consecutive bodies / contacts issues 1 KiB coalesced transactions.
 // No MFMA anywhere: there is no dense contraction on this path; the roofline is HBM bandwidth.
 #pragma once
+#include <type_traits>
 #include "dmath.hpp"
 #include "narrow.hpp"
 
@@ -2107,6 +2108,10 @@ __device__ __forceinline__ void solveOnePk(const ContactRows& c, const float4 nf
 // pinned there: the register moves that line the halves up then happen while the body loads are in flight, not between the bodies' arrival and the publish.
 struct PkRows { f32x2 rx, ry, rz, Tx, Ty, Tz, Nx, Ny, Nz; float tx, ty, tz, effN, effT, bias; };
 __device__ __forceinline__ void pinPair(f32x2& p) { asm volatile("" : "+v"(p)); }
+// PIN: the pairs are pinned where they are built (the persistent kernel, whose rows come out of its prefetch registers by inline asm).  NOT where the rows come from the
+// compiler's own loads (flowTile): there the pinned form gave wrong results on the device in every run (round 5; the unpinned form and the pinned persistent kernel are
+// bit-exact, the generated code of the failing form shows no hazard a static check finds) — not understood, so the dispatch-ordered kernels keep the compiler's placement.
+template <bool PIN>
 __device__ __forceinline__ PkRows packRows(const ContactRows& c) {
     PkRows k;
     k.rx = pk2(c.r[0].x, c.r[1].x); k.ry = pk2(c.r[0].y, c.r[1].y); k.rz = pk2(c.r[0].z, c.r[1].z);
@@ -2116,7 +2121,7 @@ __device__ __forceinline__ PkRows packRows(const ContactRows& c) {
     asm("" : "+v"(tAx)); asm("" : "+v"(tAy)); asm("" : "+v"(tAz)); asm("" : "+v"(nAx)); asm("" : "+v"(nAy)); asm("" : "+v"(nAz));
     k.Tx = pk2(tAx, c.r[3].w); k.Ty = pk2(tAy, c.r[4].x); k.Tz = pk2(tAz, c.r[4].y);
     k.Nx = pk2(nAx, c.r[5].y); k.Ny = pk2(nAy, c.r[5].z); k.Nz = pk2(nAz, c.r[5].w);
-    pinPair(k.rx); pinPair(k.ry); pinPair(k.rz); pinPair(k.Tx); pinPair(k.Ty); pinPair(k.Tz); pinPair(k.Nx); pinPair(k.Ny); pinPair(k.Nz);
+    if (PIN) { pinPair(k.rx); pinPair(k.ry); pinPair(k.rz); pinPair(k.Tx); pinPair(k.Ty); pinPair(k.Tz); pinPair(k.Nx); pinPair(k.Ny); pinPair(k.Nz); }
     k.tx = c.r[2].x; k.ty = c.r[2].y; k.tz = c.r[2].z; k.effN = c.r[0].w; k.effT = c.r[1].w; k.bias = c.r[2].w;
     return k;
 }
@@ -2402,7 +2407,7 @@ __device__ __forceinline__ void dbgStamp(unsigned long long* rec, int i) { if (r
 #endif
 // Hook of processTile: early() runs right after the body loads were issued and returns how many loads it issued itself (they
 // may stay in flight across the first tag check); late(waited) runs once the tags are satisfied, waited = the tile had to poll.
-struct NoHook { unsigned long long* rec = nullptr; __device__ __forceinline__ uint32_t early() const { return 0u; } __device__ __forceinline__ void late(bool) const {} };
+struct NoHook { enum : bool { kPinRows = false }; unsigned long long* rec = nullptr; __device__ __forceinline__ uint32_t early() const { return 0u; } __device__ __forceinline__ void late(bool) const {} };
 // wait until at most n of the newest vector-memory operations are outstanding (n = a count the caller issued itself)
 __device__ __forceinline__ void waitVmcnt(uint32_t n) {
     switch (n) {
@@ -2557,25 +2562,6 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
     }
 }
 #else
-#ifdef MI_POLL2
-// Two polls in flight (development build: -DMI_POLL2).  A waiting tile samples its bodies once per load round trip T, so a publish is seen T / 2 (phase) + T / 2 (way back)
-// after it lands; with a second poll issued half a period behind the first, the phase term halves.  The polls land in FIXED accumulator registers (set X: a128..a143, set Y:
-// a144..a159 — like the row prefetch, registers the compiler never allocates), so a poll still in flight when its tile moves on cannot land in a register that has been
-// given another value, and they are issued and read back under explicit EXEC masks: always four load instructions per poll, whatever lanes take part (vmcnt counts
-// instructions, and `s_waitcnt vmcnt(4)` = "the older poll has landed" needs the count to be exact).
-#define MI_POLL_ISSUE(R0, R1, R2, R3, R4, R5, R6, R7, R8, R9, R10, R11, R12, R13, R14, R15, qa0, qa1, qb0, qb1, maskA, maskB) \
-    asm volatile("s_mov_b64 exec, %4\n\tglobal_load_dwordx4 a[" #R0 ":" #R3 "], %0, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 a[" #R4 ":" #R7 "], %1, off" MI_SC_LOAD "\n\t" \
-                 "s_mov_b64 exec, %5\n\tglobal_load_dwordx4 a[" #R8 ":" #R11 "], %2, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 a[" #R12 ":" #R15 "], %3, off" MI_SC_LOAD "\n\t" \
-                 "s_mov_b64 exec, -1" : : "v"(qa0), "v"(qa1), "v"(qb0), "v"(qb1), "s"(maskA), "s"(maskB) \
-                 : "memory", "a" #R0, "a" #R1, "a" #R2, "a" #R3, "a" #R4, "a" #R5, "a" #R6, "a" #R7, "a" #R8, "a" #R9, "a" #R10, "a" #R11, "a" #R12, "a" #R13, "a" #R14, "a" #R15)
-#define MI_POLL_READ8(R0, R1, R2, R3, R4, R5, R6, R7, mask, g0, g1) \
-    asm volatile("s_mov_b64 exec, %8\n\tv_accvgpr_read_b32 %0, a" #R0 "\n\tv_accvgpr_read_b32 %1, a" #R1 "\n\tv_accvgpr_read_b32 %2, a" #R2 "\n\tv_accvgpr_read_b32 %3, a" #R3 "\n\t" \
-                 "v_accvgpr_read_b32 %4, a" #R4 "\n\tv_accvgpr_read_b32 %5, a" #R5 "\n\tv_accvgpr_read_b32 %6, a" #R6 "\n\tv_accvgpr_read_b32 %7, a" #R7 "\n\ts_mov_b64 exec, -1" \
-                 : "+v"(g0[0]), "+v"(g0[1]), "+v"(g0[2]), "+v"(g0[3]), "+v"(g1[0]), "+v"(g1[1]), "+v"(g1[2]), "+v"(g1[3]) : "s"(mask))
-#ifndef MI_POLL2_SLEEP
-#define MI_POLL2_SLEEP 10   // x 64 clocks between the first two polls (about half a loaded round trip)
-#endif
-#endif
 // The tile proper (default build).  Same order of loads, waits, arithmetic and stores as the MI_NO_DIET form below; what differs is how few instructions sit between the
 // arrival of a tile's bodies and its publish, the part of a visit that is on the dependency chain between tiles (~4 cycles per instruction at one wave per SIMD):
 //   * which of the lane pair's four stores per body slot take place, and with which cache policy, is known from the slot's constants: four EXEC masks per body are
@@ -2626,7 +2612,7 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
     const uint32_t hookLoads = hook.early();   // (the persistent kernel: this tile's rows out of the prefetch registers, the next tile's requested)
     PkRows pkr[CNT];
 #pragma unroll
-    for (int k = 0; k < CNT; ++k) pkr[k] = packRows(c[k]);
+    for (int k = 0; k < CNT; ++k) pkr[k] = packRows<std::remove_reference_t<Hook>::kPinRows>(c[k]);
     waitVmcnt(hookLoads);   // the hook's loads are younger than the body loads: they may stay in flight
     float2 imIn[CNT];   // accumulated impulses this tile starts from
     if (!LDSIMP) {
@@ -2639,51 +2625,6 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
     bool okA, okB, okI = true, polled = false;
     uint32_t budget = kSpinBudget;
     MI_STAMP(hook.rec, 3);
-#ifdef MI_POLL2
-    if (LDSIMP) {
-        landed(ra0); landed(ra1); landed(rb0); landed(rb1);
-        float wa0[4] = {ra0.x, ra0.y, ra0.z, ra0.w}, wa1[4] = {ra1.x, ra1.y, ra1.z, ra1.w}, wb0[4] = {rb0.x, rb0.y, rb0.z, rb0.w}, wb1[4] = {rb1.x, rb1.y, rb1.z, rb1.w};   // the raw words, lane by lane
-        auto check = [&]() -> bool {   // gather every lane from the raw words, compare the tags; true = every lane has its bodies
-            const f32x4 x0 = {wa0[0], wa0[1], wa0[2], wa0[3]}, x1 = {wa1[0], wa1[1], wa1[2], wa1[3]}, y0 = {wb0[0], wb0[1], wb0[2], wb0[3]}, y1 = {wb1[0], wb1[1], wb1[2], wb1[3]};
-            pairExchange(x0, x1, a0, a1);
-            pairExchange(y0, y1, b0, b1);
-            okA = !needA || (__float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA);
-            okB = !needB || (__float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB);
-#ifdef MI_DBG_NOWAIT
-            okA = okB = true;
-#endif
-            return __ballot(!(okA && okB)) == 0ull;
-        };
-        auto pollMasks = [&](unsigned long long& pmA, unsigned long long& pmB) {   // both lanes of a pair poll together
-            const uint32_t partnerOkA = swz1(okA ? 1u : 0u), partnerOkB = swz1(okB ? 1u : 0u);
-            pmA = __ballot(!okA || partnerOkA == 0u); pmB = __ballot(!okB || partnerOkB == 0u);
-        };
-        if (!check()) {
-            polled = true;
-            unsigned long long xA, xB, yA, yB;
-            pollMasks(xA, xB); yA = xA; yB = xB;
-            MI_POLL_ISSUE(128, 129, 130, 131, 132, 133, 134, 135, 136, 137, 138, 139, 140, 141, 142, 143, PA.q0, PA.q1, PB.q0, PB.q1, xA, xB);
-            __builtin_amdgcn_s_sleep(MI_POLL2_SLEEP);
-            MI_POLL_ISSUE(144, 145, 146, 147, 148, 149, 150, 151, 152, 153, 154, 155, 156, 157, 158, 159, PA.q0, PA.q1, PB.q0, PB.q1, yA, yB);
-            for (;;) {
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // set X has landed (set Y's four loads may still be in flight)
-                MI_POLL_READ8(128, 129, 130, 131, 132, 133, 134, 135, xA, wa0, wa1);
-                MI_POLL_READ8(136, 137, 138, 139, 140, 141, 142, 143, xB, wb0, wb1);
-                if (check()) break;
-                if (--budget == 0u) { sc->solveError = 1u; break; }
-                pollMasks(xA, xB);
-                MI_POLL_ISSUE(128, 129, 130, 131, 132, 133, 134, 135, 136, 137, 138, 139, 140, 141, 142, 143, PA.q0, PA.q1, PB.q0, PB.q1, xA, xB);
-                asm volatile("s_waitcnt vmcnt(4)" ::: "memory");   // set Y has landed
-                MI_POLL_READ8(144, 145, 146, 147, 148, 149, 150, 151, yA, wa0, wa1);
-                MI_POLL_READ8(152, 153, 154, 155, 156, 157, 158, 159, yB, wb0, wb1);
-                if (check()) break;
-                if (--budget == 0u) { sc->solveError = 1u; break; }
-                pollMasks(yA, yB);
-                MI_POLL_ISSUE(144, 145, 146, 147, 148, 149, 150, 151, 152, 153, 154, 155, 156, 157, 158, 159, PA.q0, PA.q1, PB.q0, PB.q1, yA, yB);
-            }
-        }
-    } else
-#endif
     for (;;) {
         landed(ra0); landed(ra1); landed(rb0); landed(rb1);
         pairExchange(ra0, ra1, a0, a1);
@@ -2943,6 +2884,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
             // (MI_LATE_PREFETCH: a tile that had to poll in the previous sweep prefetches after its wait, so that its polls do not
             // queue behind the prefetch.  Measured slower — 0.68 vs 0.63 ms — the rows arriving late costs more; off.)
             struct Prefetch {
+                enum : bool { kPinRows = true };
                 decltype(fetchRows)& fetch; decltype(readRows)& read; ContactRows* cur; uint32_t cnt; uint32_t* crit; uint32_t next; bool more, critical, issued; unsigned long long* rec;
                 __device__ __forceinline__ uint32_t early() { read(cur, cnt); MI_STAMP(rec, 1); if (more && !critical) { issued = true; return fetch(next); } return 0u; }
                 __device__ __forceinline__ void late(bool waited) { if (more && !issued) (void)fetch(next); if (threadIdx.x == 0) *crit = waited ? 1u : 0u; }
