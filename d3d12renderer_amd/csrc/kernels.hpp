@@ -800,10 +800,7 @@ __global__ __launch_bounds__(256) void k_bp_pairs_large(uint32_t nc, const uint3
 // issue slots half empty, the large pass (a ground and four walls against every box of a pile) is 12 us of launch floor, gathers and a block flush: as the first workgroups
 // of the grid pass's launch it runs beside that pass instead of behind it.  largeBlocks = gx * gy rounded up to a multiple of 8 (the grid pass's workgroups keep their
 // blockIdx % 8 = XCD residue); workgroups in the padding find nothing to do.
-#ifndef MI_PAIRS_ATTR
-#define MI_PAIRS_ATTR
-#endif
-__global__ __launch_bounds__(256) MI_PAIRS_ATTR void k_bp_pairs(uint32_t largeBlocks, uint32_t gx, uint32_t gy, uint32_t nc, uint32_t blocksPerColumn, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
+__global__ __launch_bounds__(256) void k_bp_pairs(uint32_t largeBlocks, uint32_t gx, uint32_t gy, uint32_t nc, uint32_t blocksPerColumn, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals,
                                                   const float4* __restrict__ sMin, const float4* __restrict__ sMax, const uint32_t* __restrict__ cellLower, const GridParams* __restrict__ gp,
                                                   const uint32_t* __restrict__ largeList, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
                                                   uint64_t* __restrict__ pairKeys, uint32_t pairCap, StepScalars* sc, Shards* sh, InterSink inter) {
@@ -1065,13 +1062,7 @@ __device__ __forceinline__ void boxPairShapes(const float4* __restrict__ wShape,
     brot = sb.rot; bcen = sb.a; brad = sb.b;
 }
 constexpr uint32_t kBoxQueues = 16;
-#ifndef MI_NARROW_ATTR
-#define MI_NARROW_ATTR
-#endif
-#ifndef MI_PAIRS_ATTR
-#define MI_PAIRS_ATTR
-#endif
-__global__ __launch_bounds__(256) MI_NARROW_ATTR void k_narrow(uint32_t scanLen, uint32_t queueRegion, StepScalars* sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
+__global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queueRegion, StepScalars* sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                 const float4* __restrict__ wShape,
                                                 HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
                                                 float4* __restrict__ npPoints, BoxHit* __restrict__ boxQueue,

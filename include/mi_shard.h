@@ -112,6 +112,10 @@ MI_API int mi_world_shard_exchange_stats(mi_world* world, mi_shard_exchange_stat
 
 /* Library transport: RCCL.  out_id128 / id128: the 128 bytes of an ncclUniqueId. */
 MI_API int mi_shard_get_unique_id(void* out_id128);
+/* Under the library transport three more calls are COLLECTIVE in effect: mi_world_load_checkpoint, a scene upload after an edit, and mi_world_set_body_states(_device).
+ * Each re-arms full-size messages for the next two exchanges on the rank that makes it (message sizes are otherwise derived from the previous exchange, identically on both
+ * ends, without talking) — so every rank of the grid has to make the same call between the same two steps, like mi_world_shard_set_borders.  A rank that did not sends and
+ * expects the smaller size; the mismatch is detected (header word 1 carries the sender's sizing policy and count) and reported as MI_ERR_CAPACITY on both ends, never a silent cut. */
 MI_API int mi_world_shard_attach_rccl(mi_world* world, const void* id128);
 /* 1 if this process can use the library transport (librccl found, all entry points resolved) — a cheap, NON-collective probe: agree on it over
  * all ranks BEFORE any rank calls mi_world_shard_attach_rccl (ncclCommInitRank blocks until every rank has entered it). */
