@@ -59,7 +59,7 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t specOverflow;         // a speculative bound (tiles / contact-tiles capacity) was exceeded on the device
     uint32_t numCells;             // cells of this step's broad-phase grid
     uint32_t numPairsFound;        // pair count of a step whose speculative pair bound was exceeded (numPairs is zeroed then)
-    uint32_t boxHitCount[16];      // box pairs that passed the SAT, per queue (k_narrow -> k_narrow_clip)
+    uint32_t boxHitCountUnused[16]; // (the box queues' counters live in Shards::c[q].boxHits)
     uint32_t numEvents;            // collision begin / end events of this step (when events are enabled)
     uint32_t numInterPairs;        // AABB overlaps between a rigid-body collider and a trigger / force-field collider
     uint32_t numInteractions;      // ... of which the boolean overlap test passed (non_collision_interaction records)
@@ -80,7 +80,10 @@ struct StepScalars {  // device-resident per-step scalars
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
 // chip (one L2 channel), so thousands of workgroups adding to ONE word serialise a whole kernel behind it.
 constexpr uint32_t kShards = 16;
-struct ShardCounters { uint32_t numOverlaps; uint32_t bucketHist[24]; uint32_t owned[3]; uint32_t pad[4]; };   // one 128-byte line per shard; owned: sharded world (bodies / manifolds / contacts of this rank)
+struct ShardCounters { uint32_t numOverlaps; uint32_t bucketHist[24]; uint32_t owned[3]; uint32_t boxHits; uint32_t pad[3]; };   // one 128-byte line per shard; owned: sharded world (bodies / manifolds / contacts of this rank);
+                                                                                                                                   // boxHits: box pairs that passed the SAT, per queue (k_narrow -> k_narrow_clip; queue q = shard q — its own line: the 16 counters side by side in
+                                                                                                                                   // ONE line of StepScalars took every workgroup's returning atomic through one L2 line)
+static_assert(sizeof(ShardCounters) == 128 && kShards == 16, "one line per shard; the box queues use the shards' lines");
 struct Shards { ShardCounters c[kShards]; uint32_t extentHist[kShards][256]; };
 
 __device__ __forceinline__ int orderedInt(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
@@ -906,35 +909,42 @@ __device__ inline void pairFinishStats(const Shards* __restrict__ sh, StepScalar
     for (uint32_t c = 0; c < kAxisSums; ++c) { s9[c] = sm[0][c] + sm[1][c] + sm[2][c] + sm[3][c]; sc->axisSums[c] = s9[c]; }
     sc->axisNext = axisFromSums(s9, nc);   // (sharded world: from this rank's own sums — the exchange replaces it by the axis of the sums over all ranks)
 }
+// The counts a step's pair list ends with (wave 0 of k_pair_finish; or, fused, wave 0 of the first workgroup of k_narrow): bucket histogram summed over the counter shards, bucket offsets, the GJK span, whether the list wants partitioning, and the
+// speculative step's guards.  Returns the number of pairs the step goes on with (0: the step is void).
+__device__ __forceinline__ uint32_t pairFinishCounts(const uint32_t t /* lane of wave 0 */, const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound, uint32_t allowPartition, uint32_t& partitionedOut) {
+    const uint32_t found = sc->numPairs;
+    bool voidStep = found > pairBound;
+    uint32_t v = 0;
+    if (t < kNumBuckets) { for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].bucketHist[t]; sc->bucketHist[t] = v; }
+    if (t == 31) { uint32_t o = 0; for (uint32_t k = 0; k < kShards; ++k) o += sh->c[k].numOverlaps; sc->numOverlaps = o; }
+    uint32_t off = 0, nonEmpty = 0, lo = 0xFFFFFFFFu, hi = 0, largest = 0;
+    for (uint32_t bk = 0; bk < kNumBuckets; ++bk) {   // every lane walks the buckets (the counts come over by shuffle), lane 0 writes
+        const uint32_t n = (uint32_t)__shfl((int)v, (int)bk, 64);
+        if (t == 0) sc->bucketOffset[bk] = off;
+        if (n) { ++nonEmpty; largest = max(largest, n); if (gjkModeOfBucket(bk) >= 0) { lo = min(lo, off); hi = max(hi, off + n); } }
+        off += n;
+    }
+    // the partition exists to make narrow-phase waves type-uniform and to give the GJK kernel its span; when nearly every pair is of
+    // ONE type (a box pile: box-box, plus the boxes on the ground) it only costs (a pass over the keys + a reservation per workgroup):
+    // partition if a GJK bucket is populated or more than an eighth of the pairs lies outside the largest bucket
+    uint32_t want = (nonEmpty > 1u && (hi > lo || (off - largest) * 8u > off)) ? 1u : 0u;
+    // a speculative step that left k_pair_partition out (its predecessor did not partition) must not go on with a partitioned list that was never
+    // written: everything downstream becomes a no-op, the step is invalid as a whole and is re-run
+    if (want && !allowPartition) { voidStep = true; want = 0u; }
+    if (t == 0) {
+        sc->gjkLo = (hi > lo && !voidStep) ? lo : 0u; sc->gjkHi = (hi > lo && !voidStep) ? hi : 0u;
+        sc->partitioned = want;
+        if (voidStep) { sc->specOverflow = 1u; sc->numPairsFound = found; sc->numPairs = 0u; }
+    }
+    partitionedOut = want;
+    return voidStep ? 0u : found;
+}
 __global__ __launch_bounds__(256) void k_pair_finish(const Shards* __restrict__ sh, StepScalars* sc, uint32_t pairBound, uint32_t nc, uint32_t numBlocks, const unsigned long long* __restrict__ partials,
                                                      const int* __restrict__ blockBounds, GridParams* gridNext /* the NEXT step's grid (null: not wanted) */, uint32_t cellCapNext,
                                                      uint32_t allowPartition /* 0: k_pair_partition is not going to run in this step */,
                                                      uint32_t doStats /* 0: an extra workgroup of k_emit_manifolds runs pairFinishStats */) {
     const uint32_t t = threadIdx.x;
-    if (t < 64u) {   // wave 0
-        if (t == 0 && sc->numPairs > pairBound) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; }
-        uint32_t v = 0;
-        if (t < kNumBuckets) { for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].bucketHist[t]; sc->bucketHist[t] = v; }
-        if (t == 31) { uint32_t o = 0; for (uint32_t k = 0; k < kShards; ++k) o += sh->c[k].numOverlaps; sc->numOverlaps = o; }
-        uint32_t off = 0, nonEmpty = 0, lo = 0xFFFFFFFFu, hi = 0, largest = 0;
-        for (uint32_t bk = 0; bk < kNumBuckets; ++bk) {   // every lane walks the buckets (the counts come over by shuffle), lane 0 writes
-            const uint32_t n = (uint32_t)__shfl((int)v, (int)bk, 64);
-            if (t == 0) sc->bucketOffset[bk] = off;
-            if (n) { ++nonEmpty; largest = max(largest, n); if (gjkModeOfBucket(bk) >= 0) { lo = min(lo, off); hi = max(hi, off + n); } }
-            off += n;
-        }
-        // the partition exists to make narrow-phase waves type-uniform and to give the GJK kernel its span; when nearly every pair is of
-        // ONE type (a box pile: box-box, plus the boxes on the ground) it only costs (a pass over the keys + a reservation per workgroup):
-        // partition if a GJK bucket is populated or more than an eighth of the pairs lies outside the largest bucket
-        if (t == 0) {
-            sc->gjkLo = hi > lo ? lo : 0u; sc->gjkHi = hi > lo ? hi : 0u;
-            const uint32_t want = (nonEmpty > 1u && (hi > lo || (off - largest) * 8u > off)) ? 1u : 0u;
-            sc->partitioned = want;
-            // a speculative step that left k_pair_partition out (its predecessor did not partition) must not go on with a partitioned list that was never
-            // written: everything downstream becomes a no-op, the step is invalid as a whole and is re-run
-            if (want && !allowPartition) { sc->specOverflow = 1u; sc->numPairsFound = sc->numPairs; sc->numPairs = 0u; sc->partitioned = 0u; sc->gjkLo = sc->gjkHi = 0u; }
-        }
-    }
+    if (t < 64u) { uint32_t part; (void)pairFinishCounts(t, sh, sc, pairBound, allowPartition, part); }
     if (!partials || !doStats) return;
     pairFinishStats(sh, sc, nc, numBlocks, partials, blockBounds, gridNext, cellCapNext);
 }
@@ -1062,19 +1072,40 @@ __device__ __forceinline__ void boxPairShapes(const float4* __restrict__ wShape,
     brot = sb.rot; bcen = sb.a; brad = sb.b;
 }
 constexpr uint32_t kBoxQueues = 16;
+// A word every workgroup reads, through the scalar cache — explicitly: after the stores of pairFinishCounts (other path, same kernel) the compiler no longer proves the
+// word unclobbered and reads it with a vector load, and 3 000 workgroups' vector loads of one line that the same workgroups hit with atomics (boxHitCount) queue up behind
+// those atomics in the L2: k_narrow 33 -> 99 us (measured, round 5).
+__device__ __forceinline__ uint32_t scalarLoadU32(const uint32_t* p /* uniform */) {
+    uint32_t v;
+    asm volatile("s_load_dword %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
+}
 __global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queueRegion, StepScalars* sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                 const float4* __restrict__ wShape,
                                                 HullSet hs, uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal,
                                                 float4* __restrict__ npPoints, BoxHit* __restrict__ boxQueue,
-                                                ulonglong2* __restrict__ clearTab /* the NEXT step's colour history, cleared here on the side (was a launch of its own) */, uint32_t clearSlots) {
+                                                ulonglong2* __restrict__ clearTab /* the NEXT step's colour history, cleared here on the side (was a launch of its own) */, uint32_t clearSlots,
+                                                const Shards* __restrict__ finishShards /* non-null: no k_pair_finish ran (a speculative step without k_pair_partition) — wave 0 of every workgroup
+                                                                                           derives the pair list's final counts itself (pairFinishCounts), workgroup 0 writes them */,
+                                                uint32_t finishBound, Shards* __restrict__ queueShards) {
     __shared__ BoxHit hits[256];
-    __shared__ uint32_t numHits, queueBase;
+    __shared__ uint32_t numHits, queueBase, sNumPairs, sPartitioned;
     if (threadIdx.x == 0) numHits = 0;
+    if (threadIdx.x < 64u) {   // (both modes leave the two words in LDS: a select between an LDS and a global ADDRESS compiles to a flat load, and that doubled this kernel's time)
+        uint32_t n, part = 0u;
+        if (finishShards) {
+            // workgroup 0 does k_pair_finish's work and writes its results; the others only need the count, guarded like there.  (Should workgroup 0 find that the list
+            // wants partitioning, the step is void anyway: the others walking the unpartitioned list in the meantime read valid memory and their output is discarded.)
+            if (blockIdx.x == 0u) n = pairFinishCounts(threadIdx.x, finishShards, sc, finishBound, 0u, part);
+            else { n = sc->numPairs; if (n > finishBound) n = 0u; }
+        } else { n = scalarLoadU32(&sc->numPairs); part = scalarLoadU32(&sc->partitioned); }
+        if (threadIdx.x == 0) { sNumPairs = n; sPartitioned = part; }
+    }
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < clearSlots; i += gridDim.x * blockDim.x) clearTab[i] = make_ulonglong2(0ull, 0ull);
     __syncthreads();
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t numPairs = sc->numPairs;
-    const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
+    const uint32_t numPairs = sNumPairs;
+    const uint64_t* __restrict__ pairKeys = sPartitioned ? pairsB : pairsA;
     bool boxHit = false; BoxHit mineHit{};
     if (p >= numPairs) { if (p < scanLen) npPacked[p] = 0ull; }
     else {
@@ -1107,14 +1138,14 @@ __global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queue
     }
     __syncthreads();
     const uint32_t q = blockIdx.x & (kBoxQueues - 1u);
-    if (threadIdx.x == 0 && numHits) queueBase = atomicAdd(&sc->boxHitCount[q], numHits);
+    if (threadIdx.x == 0 && numHits) queueBase = atomicAdd(&queueShards->c[q].boxHits, numHits);
     __syncthreads();
     if (threadIdx.x < numHits) boxQueue[(size_t)q * queueRegion + queueBase + threadIdx.x] = hits[threadIdx.x];
 }
 
 __global__ __launch_bounds__(256) void k_narrow_clip(uint32_t queueRegion, const StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                      const float4* __restrict__ wShape, const BoxHit* __restrict__ boxQueue,
-                                                     uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints) {
+                                                     uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints, const Shards* __restrict__ queueShards) {
 #ifdef MI_CLIP_PINGPONG
     __shared__ float4 polyMem[2 * kLdsPolyVerts * kLdsPolyStride];   // 64 KiB: two clip polygons per lane, [vertex][lane]
 #else
@@ -1122,7 +1153,7 @@ __global__ __launch_bounds__(256) void k_narrow_clip(uint32_t queueRegion, const
 #endif
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t q = t / queueRegion, idx = t % queueRegion;       // queueRegion is a multiple of 256: a workgroup never straddles queues
-    if (q >= kBoxQueues || idx >= sc->boxHitCount[q]) return;
+    if (q >= kBoxQueues || idx >= queueShards->c[q].boxHits) return;
     const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;
     BoxHit h = boxQueue[(size_t)q * queueRegion + idx];
     uint64_t key = pairKeys[h.pair];
@@ -1247,6 +1278,7 @@ __global__ __launch_bounds__(256) void k_events_end(uint32_t cap, StepScalars* s
     events[slot] = e;
 }
 
+constexpr uint32_t kSpatialKeys = 4096;   // levels of the manifolds' spatial counting sort (k_manifold_keys / k_manifold_place below)
 // After the scans: manifold m <- pair p (count > 0).  colWork = (bodyA | dynA << 31, bodyB | dynB << 31, priority lo, hi):
 // everything a colouring round needs in one 16-byte row.
 __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB, const uint64_t* __restrict__ npPacked,
@@ -1476,12 +1508,10 @@ __global__ __launch_bounds__(256) void k_scatter_states(uint32_t n, const uint32
 // top[(r+1) & 1]); a round whose predecessor left nothing uncoloured exits at once, so the host
 // enqueues a fixed batch of rounds without reading anything back in between.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_color_round(const StepScalars* __restrict__ sc, uint32_t round, const uint4* __restrict__ colWork, uint32_t* __restrict__ color,
-                                                     const unsigned long long* __restrict__ topCur, unsigned long long* __restrict__ topNext,
-                                                     unsigned long long* __restrict__ bodyUsed, uint32_t* __restrict__ roundFlags, uint32_t seamMode /* exact seam: two colour ranges */) {
-    if (round > 0 && roundFlags[round - 1] == 0) return;
-    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= sc->numManifolds || color[m] != kUncolored) return;
+__device__ __forceinline__ void colorRoundBody(const uint32_t m, const uint32_t round, const uint4* __restrict__ colWork, uint32_t* __restrict__ color,
+                                               const unsigned long long* __restrict__ topCur, unsigned long long* __restrict__ topNext,
+                                               unsigned long long* __restrict__ bodyUsed, uint32_t* __restrict__ roundFlags, const uint32_t seamMode) {
+    if (color[m] != kUncolored) return;
     uint4 w = colWork[m];
     bool dynA = (w.x >> 31) != 0, dynB = (w.y >> 31) != 0;
     const bool seam = (w.x & 0x40000000u) != 0u;
@@ -1508,6 +1538,71 @@ __global__ __launch_bounds__(256) void k_color_round(const StepScalars* __restri
         if (dynB) atomicMax(&topNext[bB], key);
         roundFlags[round] = 1u;
     }
+}
+__global__ __launch_bounds__(256) void k_color_round(const StepScalars* __restrict__ sc, uint32_t round, const uint4* __restrict__ colWork, uint32_t* __restrict__ color,
+                                                     const unsigned long long* __restrict__ topCur, unsigned long long* __restrict__ topNext,
+                                                     unsigned long long* __restrict__ bodyUsed, uint32_t* __restrict__ roundFlags, uint32_t seamMode /* exact seam: two colour ranges */) {
+    if (round > 0 && roundFlags[round - 1] == 0) return;
+    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= sc->numManifolds) return;
+    colorRoundBody(m, round, colWork, color, topCur, topNext, bodyUsed, roundFlags, seamMode);
+}
+// The colouring rounds the host did NOT enqueue (speculative steps): the host enqueues exactly as many k_color_round launches as the previous step needed; if the last of
+// them still left losers — a growing scene — the first workgroups of the NEXT kernel (k_bin_hist) run the remaining rounds themselves, with a device-wide barrier between two
+// rounds, and everybody else waits for them.  Same rounds, same results; what it replaces is a margin of launches that a steady scene paid every step (~4.5 us each) and the
+// synchronous re-run a scene paid that outgrew the margin.  In a steady step this is one load per workgroup.
+// Words behind the round flags: [kTailBar] barrier arrivals, [kTailDone] 1 + the last round run once the tail is through.
+constexpr uint32_t kTailBar = kMaxColorRounds + 2u, kTailDone = kMaxColorRounds + 3u, kTailGroups = 256u, kRoundFlagWords = kMaxColorRounds + 4u;
+struct ColorTail {   // (no padding: the launcher hashes arguments bytewise)
+    const uint4* colWork; uint32_t* color; unsigned long long* top0; unsigned long long* top1; unsigned long long* bodyUsed; uint32_t* roundFlags;
+    uint32_t from /* first round the host did not enqueue; 0: no tail */, seamMode;
+};
+static_assert(sizeof(ColorTail) == 6 * 8 + 8, "ColorTail must not contain padding");
+__device__ __forceinline__ void colorTail(const ColorTail& ct, StepScalars* sc) {
+    if (!ct.from || ct.roundFlags[ct.from - 1u] == 0u) return;   // the enqueued rounds coloured everything (the same word for every workgroup: written by the previous launch)
+    const uint32_t P = min(gridDim.x, kTailGroups);
+    uint32_t* flags = ct.roundFlags;
+    if (blockIdx.x >= P) {   // not taking part: wait for the tail (its workgroups have lower indices, i.e. were dispatched before this one)
+        if (threadIdx.x == 0) {
+            uint32_t budget = 1u << 22;
+            while (__hip_atomic_load(&flags[kTailDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) { __builtin_amdgcn_s_sleep(8); if (--budget == 0u) { sc->specOverflow = 1u; break; } }
+        }
+        __syncthreads();
+        __threadfence();
+        return;
+    }
+    const uint32_t nm = sc->numManifolds;
+    uint32_t arrivals = 0u;
+    bool failed = false;
+    uint32_t r = ct.from;
+    __shared__ uint32_t sMore;
+    for (;; ++r) {
+        const unsigned long long* topCur = (r & 1u) ? ct.top1 : ct.top0;
+        unsigned long long* topNext = (r & 1u) ? ct.top0 : ct.top1;
+        for (uint32_t m = blockIdx.x * 256u + threadIdx.x; m < nm; m += P * 256u) colorRoundBody(m, r, ct.colWork, ct.color, topCur, topNext, ct.bodyUsed, flags, ct.seamMode);
+        // device-wide barrier: everything this round wrote is visible to everybody before the next one reads it (eight L2s: write back, then invalidate)
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            arrivals += P;
+            atomicAdd(&flags[kTailBar], 1u);
+            uint32_t budget = 1u << 22;
+            while (__hip_atomic_load(&flags[kTailBar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals) { __builtin_amdgcn_s_sleep(2); if (--budget == 0u) { failed = true; break; } }
+            sMore = failed ? 2u : __hip_atomic_load(&flags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        __threadfence();
+        const uint32_t more = sMore;
+        __syncthreads();
+        if (more == 2u) { if (threadIdx.x == 0) sc->specOverflow = 1u; break; }   // (a participant never arrived: the step is void and re-run synchronously)
+        if (more == 0u || r + 2u >= kMaxColorRounds) break;                          // round r left no loser: everything is coloured (or: give up, colorPending tells)
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&flags[kTailDone], r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// which round's flag says whether the colouring is complete: the last one the host enqueued, or the last one the tail ran
+__device__ __forceinline__ uint32_t colorPendingOf(const uint32_t* __restrict__ roundFlags, uint32_t lastRound) {
+    const uint32_t t = roundFlags[kTailDone];
+    return roundFlags[t ? t - 1u : lastRound];
 }
 
 // Schedule slots: manifolds grouped by (colour, contacts per manifold) bin — one stable-enough radix pass
@@ -1549,21 +1644,27 @@ __host__ __device__ __forceinline__ uint32_t tileOwnerCount(uint32_t x, uint32_t
 //   k_manifold_keys   key + arrival rank.  Neighbouring manifolds mostly share a key, so the ranks are taken in an LDS
 //                     histogram per workgroup and only one global atomic per (workgroup, key present) reserves the range;
 //   k_manifold_place  every workgroup scans the 4096 counts itself (cheaper than a separate scan launch) and places its items.
-constexpr uint32_t kSpatialKeys = 4096;
 constexpr uint32_t kKeyItems = 1024;   // manifolds per workgroup of k_manifold_keys
-__global__ __launch_bounds__(256) void k_manifold_keys(uint32_t n, const StepScalars* __restrict__ sc, const GridParams* __restrict__ gp, const uint2* __restrict__ manBodies,
-                                                       const float4* __restrict__ gPos, uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks, uint32_t* __restrict__ keyCount,
-                                                       // sharded world (bodyActive non-null): also what k_shard_count counts — this rank's manifolds / contacts by the owner rule —
-                                                       // from the rows this kernel gathers anyway (gPos.w = inverse mass), one launch less
-                                                       uint32_t nb, const uint8_t* __restrict__ bodyActive, const uint2* __restrict__ manInfo, Shards* sh) {
+struct KeysArgs {   // k_manifold_keys' arguments; no padding bytes (the launcher hashes arguments bytewise)
+    uint32_t n, nb; const StepScalars* sc; const GridParams* gp; const uint2* manBodies;
+    const float4* bPos; const float4* bCogInvMass;   // the key comes from the body's origin at the start of the step (not from the centre of gravity k_integrate_forces computes: the two run side by side)
+    uint32_t* keys; uint32_t* ranks; uint32_t* keyCount;
+    // sharded world (bodyActive non-null): also what k_shard_count counts — this rank's manifolds / contacts by the owner rule — from the rows this kernel gathers anyway, one launch less
+    const uint8_t* bodyActive; const uint2* manInfo; Shards* sh;
+};
+static_assert(sizeof(KeysArgs) == 8 + 11 * 8, "KeysArgs must not contain padding");
+__device__ __forceinline__ void manifoldKeysBody(const uint32_t blockId, const KeysArgs& ka) {
     __shared__ uint32_t hist[kSpatialKeys];   // local count, then the global base of this workgroup's range
     __shared__ uint32_t ownedCnt[2];
+    const uint2* __restrict__ manBodies = ka.manBodies; const float4* __restrict__ bPos = ka.bPos; const float4* __restrict__ bCogInvMass = ka.bCogInvMass;
+    uint32_t* __restrict__ keys = ka.keys; uint32_t* __restrict__ ranks = ka.ranks; uint32_t* __restrict__ keyCount = ka.keyCount;
+    const uint8_t* __restrict__ bodyActive = ka.bodyActive; const uint2* __restrict__ manInfo = ka.manInfo; const uint32_t nb = ka.nb;
     if (threadIdx.x < 2) ownedCnt[threadIdx.x] = 0u;
     uint32_t mine = 0, contacts = 0;
     for (uint32_t k = threadIdx.x; k < kSpatialKeys; k += 256) hist[k] = 0u;
     __syncthreads();
-    const uint32_t nm = min(n, sc->numManifolds);
-    const GridParams g = *gp;
+    const uint32_t nm = min(ka.n, ka.sc->numManifolds);
+    const GridParams g = *ka.gp;
     const uint32_t axis = g.dims[0] >= g.dims[1] && g.dims[0] >= g.dims[2] ? 0u : g.dims[2] >= g.dims[1] ? 2u : 1u;
     const uint32_t dimA = axis == 0u ? g.dims[0] : axis == 1u ? g.dims[1] : g.dims[2];          // (selects, not g.dims[axis]: a dynamically indexed copy lives in scratch)
     const float originA = axis == 0u ? g.origin[0] : axis == 1u ? g.origin[1] : g.origin[2];
@@ -1571,19 +1672,17 @@ __global__ __launch_bounds__(256) void k_manifold_keys(uint32_t n, const StepSca
     uint32_t key[kKeyItems / 256], local[kKeyItems / 256];
 #pragma unroll
     for (uint32_t i = 0; i < kKeyItems / 256; ++i) {
-        const uint32_t m = blockIdx.x * kKeyItems + i * 256 + threadIdx.x;
+        const uint32_t m = blockId * kKeyItems + i * 256 + threadIdx.x;
         key[i] = 0xFFFFFFFFu;
         if (m < nm) {
             uint2 b = manBodies[m];
-            float4 pa = gPos[b.x], pb = gPos[b.y];
-            float4 p = pa.w != 0.f ? pa : pb;
-            float c = axis == 0u ? p.x : axis == 1u ? p.y : p.z;
+            const bool dynA = b.x < nb && bCogInvMass[b.x].w != 0.f;
+            const uint32_t first = dynA ? b.x : b.y;                     // the manifold's first dynamic body (a manifold has one)
+            float c = 0.f;
+            if (first < nb) { const float4 p = bPos[first]; c = axis == 0u ? p.x : axis == 1u ? p.y : p.z; }
             key[i] = (uint32_t)fminf(fmaxf((c - originA) * scale, 0.f), (float)(kSpatialKeys - 1u));
             local[i] = atomicAdd(&hist[key[i]], 1u);
-            if (bodyActive) {
-                const uint32_t first = (b.x < nb && pa.w != 0.f) ? b.x : b.y;
-                if (first < nb && bodyActive[first] == 1u) { ++mine; contacts += manInfo[m].x & 7u; }
-            }
+            if (bodyActive && first < nb && bodyActive[first] == 1u) { ++mine; contacts += manInfo[m].x & 7u; }
         }
     }
     if (bodyActive) {
@@ -1591,14 +1690,21 @@ __global__ __launch_bounds__(256) void k_manifold_keys(uint32_t n, const StepSca
         if ((threadIdx.x & 63u) == 0u && mine) { atomicAdd(&ownedCnt[0], mine); atomicAdd(&ownedCnt[1], contacts); }
     }
     __syncthreads();
-    if (bodyActive && threadIdx.x < 2 && ownedCnt[threadIdx.x]) atomicAdd(&sh->c[blockIdx.x & (kShards - 1u)].owned[1 + threadIdx.x], ownedCnt[threadIdx.x]);
+    if (bodyActive && threadIdx.x < 2 && ownedCnt[threadIdx.x]) atomicAdd(&ka.sh->c[blockId & (kShards - 1u)].owned[1 + threadIdx.x], ownedCnt[threadIdx.x]);
     for (uint32_t k = threadIdx.x; k < kSpatialKeys; k += 256) { uint32_t c = hist[k]; if (c) hist[k] = atomicAdd(&keyCount[k], c); }
     __syncthreads();
 #pragma unroll
     for (uint32_t i = 0; i < kKeyItems / 256; ++i) {
-        const uint32_t m = blockIdx.x * kKeyItems + i * 256 + threadIdx.x;
+        const uint32_t m = blockId * kKeyItems + i * 256 + threadIdx.x;
         if (key[i] != 0xFFFFFFFFu) { keys[m] = key[i]; ranks[m] = hist[key[i]] + local[i]; }
     }
+}
+__global__ __launch_bounds__(256) void k_manifold_keys(KeysArgs ka) { manifoldKeysBody(blockIdx.x, ka); }
+// k_integrate_forces and k_manifold_keys in one launch: neither reads what the other writes; the first `keyBlocks` workgroups take the keys (a chain of LDS and global
+// atomics: started first), the others stream the bodies behind them.
+__global__ __launch_bounds__(256) void k_forces_keys(uint32_t keyBlocks, ForcesArgs fa, KeysArgs ka) {
+    if (blockIdx.x < keyBlocks) manifoldKeysBody(blockIdx.x, ka);
+    else integrateForcesBody((blockIdx.x - keyBlocks) * blockDim.x + threadIdx.x, fa);
 }
 __global__ __launch_bounds__(256) void k_manifold_place(uint32_t n, const StepScalars* __restrict__ sc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ranks,
                                                         const uint32_t* __restrict__ keyCount, uint32_t* __restrict__ perm) {
@@ -1628,8 +1734,9 @@ __global__ __launch_bounds__(256) void k_manifold_place(uint32_t n, const StepSc
     }
 }
 __global__ __launch_bounds__(256) void k_bin_hist(const StepScalars* __restrict__ sc, uint32_t numBlocks, const uint32_t* __restrict__ perm /* spatially sorted manifold ids, or null */,
-                                                  const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo, uint32_t* __restrict__ blockHist) {
+                                                  const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo, uint32_t* __restrict__ blockHist, ColorTail tail, StepScalars* scw) {
     __shared__ uint32_t h[kColorBins];
+    colorTail(tail, scw);
     const uint32_t nm = sc->numManifolds;
     for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) h[b] = 0;
     __syncthreads();
@@ -1647,7 +1754,7 @@ __global__ __launch_bounds__(256) void k_bin_scatter(uint32_t lastRound, const u
                                                      const uint32_t* __restrict__ blockScan, uint32_t* __restrict__ order, StepScalars* sc) {
     __shared__ uint32_t cur[kColorBins];
     const uint32_t nm = sc->numManifolds;
-    if (blockIdx.x == 0 && threadIdx.x == 0) sc->colorPending = roundFlags[lastRound];
+    if (blockIdx.x == 0 && threadIdx.x == 0) sc->colorPending = colorPendingOf(roundFlags, lastRound);
     for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) {
         uint32_t v = blockScan[(size_t)b * numBlocks + blockIdx.x];
         cur[b] = v;
@@ -1795,7 +1902,7 @@ __global__ __launch_bounds__(256) void k_schedule_finish(uint32_t lastRound, con
     __shared__ uint32_t cur[kColorBins + 4];
     if (blockIdx.x < numBlocks) {   // ---- scatter (k_bin_scatter) + history insert (k_color_table_insert)
         const uint32_t nm = sc->numManifolds;
-        if (blockIdx.x == 0 && threadIdx.x == 0) sc->colorPending = roundFlags[lastRound];
+        if (blockIdx.x == 0 && threadIdx.x == 0) sc->colorPending = colorPendingOf(roundFlags, lastRound);
         for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) {
             uint32_t v = blockScan[(size_t)b * numBlocks + blockIdx.x];
             cur[b] = v;

@@ -28,12 +28,18 @@ struct Knobs {
     // ---- broad / narrow phase
     bool fuseWorld = true;              // MI_FUSE_WORLD=0: k_world_colliders as its own launch
     bool fuseLarge = true;              // MI_FUSE_LARGE=0: k_bp_pairs_grid and k_bp_pairs_large as two launches (otherwise k_bp_pairs runs the large pass in the first workgroups of the grid pass's launch)
+    bool finishInNarrow = true;         // MI_FINISH_IN_NARROW=0: k_pair_finish as its own launch also in steps without k_pair_partition
+    bool fuseKeys = true;               // MI_FUSE_KEYS=0: k_integrate_forces and k_manifold_keys as two launches (otherwise k_forces_keys)
     bool skipPartition = true;          // MI_SKIP_PARTITION=0: always launch k_pair_partition
     int gjkWave = -1;                   // MI_GJK_WAVE=0 / 1: force the lane / wave GJK variant
     bool hmStash = true;                // MI_HM_STASH=0: terrain triangles recomputed instead of stashed
     // ---- schedule
     uint32_t colorMargin = 3;           // MI_COLOR_MARGIN: colour rounds enqueued beyond the previous step's count (1 is ~3 us faster at the bench state and costs a synchronous re-run
                                         // whenever a growing scene needs two more rounds than the step before: measured in round 4, not kept)
+    bool colorTail = true;              // MI_COLOR_TAIL=0: a margin of colouring rounds enqueued every step (MI_COLOR_MARGIN) and a synchronous re-run beyond it, instead of the rounds the
+                                        // previous step needed + whatever is missing run inside k_bin_hist
+    uint32_t colorTailMargin = 1;       // MI_COLOR_TAIL_MARGIN: rounds enqueued beyond the previous step's count when the tail is on
+    uint32_t colorRoundsMax = 0;        // MI_COLOR_ROUNDS_MAX: at most so many colouring rounds enqueued per speculative step, the tail runs the rest (tests; 0 = no cap)
     bool round0InEmit = true;           // MI_ROUND0_EMIT=0: colouring round 0 as its own launch (otherwise k_emit_manifolds makes the proposals of the manifolds it leaves uncoloured)
     bool xcdNoSort = false;             // MI_XCD_NOSORT: manifold order as emitted (development)
     bool xcdStats = false;              // MI_XCD_STATS: how many bodies stayed XCD-local (development)
@@ -69,9 +75,9 @@ struct Knobs {
         k.fuseReset = !off("MI_FUSE_RESET");
         k.graph = str("MI_GRAPH"); k.graphMaxColliders = (uint32_t)num("MI_GRAPH_MAX_COLLIDERS", k.graphMaxColliders);
         k.graphDebug = set("MI_GRAPH_DEBUG"); k.graphNoEvents = set("MI_GRAPH_NOEVENTS"); k.graphNoCapture = set("MI_GRAPH_NOCAPTURE");
-        k.fuseWorld = !off("MI_FUSE_WORLD"); k.fuseLarge = !off("MI_FUSE_LARGE"); k.skipPartition = !off("MI_SKIP_PARTITION"); k.hmStash = !off("MI_HM_STASH");
+        k.fuseWorld = !off("MI_FUSE_WORLD"); k.fuseLarge = !off("MI_FUSE_LARGE"); k.skipPartition = !off("MI_SKIP_PARTITION"); k.finishInNarrow = !off("MI_FINISH_IN_NARROW"); k.fuseKeys = !off("MI_FUSE_KEYS"); k.hmStash = !off("MI_HM_STASH");
         if (const char* v = std::getenv("MI_GJK_WAVE")) k.gjkWave = atoi(v);
-        k.round0InEmit = !off("MI_ROUND0_EMIT");
+        k.round0InEmit = !off("MI_ROUND0_EMIT"); k.colorTail = !off("MI_COLOR_TAIL"); k.colorRoundsMax = (uint32_t)num("MI_COLOR_ROUNDS_MAX", 0); k.colorTailMargin = (uint32_t)num("MI_COLOR_TAIL_MARGIN", k.colorTailMargin);
         k.colorMargin = (uint32_t)num("MI_COLOR_MARGIN", k.colorMargin); k.xcdNoSort = set("MI_XCD_NOSORT"); k.xcdStats = set("MI_XCD_STATS"); k.xcdSwizzle = str("MI_XCD_SWIZZLE") == "1";
         k.solver = str("MI_SOLVER"); k.flowLds = (uint32_t)num("MI_FLOW_LDS", 0); k.persistWaves = (uint32_t)num("MI_PERSIST_WAVES", 0); k.persistXcdOnly = set("MI_PERSIST_XCD_ONLY");
         k.persistXcd = tri("MI_PERSIST_XCD"); k.persistXcdSingle = tri("MI_PERSIST_XCD_SINGLE");

@@ -322,7 +322,7 @@ struct mi_world {
 
     StepScalars hs{};            // host copy of the last step's scalars
     struct Readback { StepScalars sc; uint32_t flags[96]; uint32_t seq; uint32_t pad[3]; };   // seq: written last by k_publish_readback (the host spins on it)
-    uint32_t readbackSeq = 0; bool spinReadback = true, stageEvents = false /* time every stage */, stepEvents = false /* time the whole step and the solve stage */;
+    uint32_t readbackSeq = 0; bool spinReadback = true, stageEvents = false /* time every stage */, stepEvents = false /* time the whole step and the solve stage */, solveEventsOnly = false /* ... the solve stage alone */, timesPendingEnds = true;
     Readback* hsPinned = nullptr; // pinned staging for the end-of-step read-back (one async copy, no pageable bounce)
     mi_stage_times timesSum{}; uint32_t timesSteps = 0; uint64_t contactUpdatesSum = 0;   // accumulated since the last mi_world_get_accumulated_stage_times(reset)
     mi_step_counts counts{};
@@ -383,10 +383,10 @@ int mi_world::init(int dev) {
     HIP_TRY(hipSetDevice(dev));
     HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     for (auto& set : evSets) for (auto& e : set) HIP_TRY(hipEventCreate(&e));
-    HIP_TRY(scalarsRaw.ensure(sizeof(StepScalars) + (kMaxColorRounds + 2) * sizeof(uint32_t)));
+    HIP_TRY(scalarsRaw.ensure(sizeof(StepScalars) + kRoundFlagWords * sizeof(uint32_t)));
     HIP_TRY(grid.ensure(2));
     HIP_TRY(shards.ensure(1));
-    HIP_TRY(hipMemsetAsync(scalarsRaw.p, 0, sizeof(StepScalars) + (kMaxColorRounds + 2) * sizeof(uint32_t), stream));
+    HIP_TRY(hipMemsetAsync(scalarsRaw.p, 0, sizeof(StepScalars) + kRoundFlagWords * sizeof(uint32_t), stream));
     HIP_TRY(binInfo.ensure(kSchedBins));
     if (hipHostMalloc((void**)&hsPinned, sizeof(Readback), hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
         (void)hipGetLastError();   // no device-visible coherent host memory here: plain pinned staging and the copy path

@@ -295,7 +295,8 @@ MI_API int mi_world_get_contacts(mi_world* world, mi_contact* out, uint32_t capa
 MI_API int mi_debug_tile_owner(uint32_t tile_in_bin, uint32_t tiles_in_bin, uint32_t bin, uint32_t query_xcd, uint32_t* out);
 /* Per-stage device times of the last internal step (HIP events on the world's stream).  Nothing is timed by default — even events attached to a
  * kernel's dispatch leave the device idle for a few microseconds (the solver's start / stop pair: ~11 us of a 1 ms step).  level 2: the whole step
- * (`total`) and the solve stage; level 1: every stage (an event pair each); level 0: off. */
+ * (`total`) and the solve stage; level 3: the solve stage alone (`total` stays 0: the step's own start / stop events are two more such gaps — what bench.py runs its timed region
+ * with, its roofline needs the solver launch's duration only); level 1: every stage (an event pair each); level 0: off. */
 MI_API int mi_world_set_stage_timing(mi_world* world, uint32_t level);
 MI_API int mi_world_get_stage_times(mi_world* world, mi_stage_times* out);
 /* Contact-solver kernel of the last internal step: 0 k_contact_solve (a launch per colour per sweep), 1 k_contact_solve_flow,

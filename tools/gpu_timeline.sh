@@ -10,9 +10,9 @@ import csv, glob
 f = glob.glob("/tmp/prof_tl/**/tl_kernel_trace.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-# a step ends with k_publish_readback (k_reset_scalars' work rides in it): take the one full step before the profiled extra steps (5th from last)
+# a step ends with k_publish_readback (k_reset_scalars' work rides in it): take a full step of the timed region, before the six extra (stage-timed, step-timed) steps
 idx = [i + 1 for i, r in enumerate(rows) if "k_publish_readback" in r["Kernel_Name"]]
-a, b = idx[-5], idx[-4]
+a, b = idx[-8], idx[-7]
 t0 = int(rows[a]["Start_Timestamp"])
 out = []
 prev_end = t0

@@ -14,7 +14,7 @@ if ks.exists():
         for r in rows:
             r[0] = r[0][:110]
             w.writerow(r)
-# 1b. kernel trace of the same pass: per-kernel mean duration of the LAST 20 dispatches = the timed steps of `bench.py --steps 20` (+ its 3
+# 1b. kernel trace of the same pass: per-kernel mean duration of the LAST 20 dispatches = the timed steps of `bench.py --steps 20` (+ its 6 extra
 # profiled steps): the figure bench.py's roofline.avg_launch_us has to agree with (the stats csv above averages over the settle phase too)
 tr = sorted((raw / "stats").glob("*_kernel_trace.csv"))
 if tr:
@@ -40,7 +40,7 @@ for name in ("FETCH_SIZE", "WRITE_SIZE"):
             if r.get("Counter_Name") != name:
                 continue
             vals[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-    # steady state = the kernel's last 20 dispatches = the timed steps of `bench.py --steps 20` and its 3 profiled steps (the 240 settle steps come before)
+    # steady state = the kernel's last 20 dispatches = the timed steps of `bench.py --steps 20` and its 6 extra steps (the 240 settle steps come before)
     summary[name] = {k: {"mean": sum(v) / len(v), "steady_mean": sum(v[-min(20, len(v)):]) / min(20, len(v)),
                          "dispatches": len(v), "sum": sum(v)} for k, v in vals.items()}
 json.dump(summary, open(out / f"{prefix}_pmc_summary.json", "w"), indent=1)
