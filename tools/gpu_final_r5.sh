@@ -2,7 +2,7 @@
 # round 5, evidence run at HEAD: full GPU suite; the direct-against-the-reference harness with its printed deviations; smoke; rocprofv3 kernel stats + FETCH_SIZE / WRITE_SIZE
 # passes (tools/gpu_pmc.sh) and the default bench (with at_rest + cpu_baseline); the driver's flags; bench --pmc; the round-4 form of the solver's tile visit (-DMI_NO_DIET) and
 # every new switch off, on the same box; step timelines; the persistent solver's visit stamps; the host-boundary rates; the other configs; the learning DLL's throughput;
-# two ranks on one GPU; what a rank pays for the replicated scene
+# two ranks on one GPU; what a rank pays for the replicated scene; a soak with step graphs forced
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 ulimit -c 0
@@ -18,7 +18,7 @@ timeout 300 python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun
 timeout 900 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-at-rest --pmc 2>gpurun_out/fin_pmc_err.log | tail -1 > gpurun_out/fin_bench_pmc.json
 B="python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-at-rest"
 MI_PHYSICS_LIB=$PWD/build_exp/libmi_physics_nodiet.so timeout 300 $B 2>/dev/null | tail -1 > gpurun_out/fin_bench_nodiet.json
-MI_PHYSICS_LIB=$PWD/build_exp/libmi_physics_nodiet.so MI_FUSE_RESET=0 MI_ROUND0_EMIT=0 MI_FUSE_LARGE=0 timeout 300 $B 2>/dev/null | tail -1 > gpurun_out/fin_bench_round4_step.json
+MI_PHYSICS_LIB=$PWD/build_exp/libmi_physics_nodiet.so MI_FUSE_RESET=0 MI_ROUND0_EMIT=0 MI_FUSE_LARGE=0 MI_FINISH_IN_NARROW=0 MI_COLOR_TAIL=0 MI_FUSE_KEYS=0 timeout 300 $B 2>/dev/null | tail -1 > gpurun_out/fin_bench_round4_step.json
 timeout 300 $B 2>/dev/null | tail -1 > gpurun_out/fin_bench_driver_flags_again.json
 python - <<'PY'
 import json
@@ -42,4 +42,5 @@ bash tools/gpu_learning.sh 2>&1 | tail -5 | cut -c1-200; cp gpurun_out/learning.
 bash tools/gpu_two.sh 2>&1 | tail -6 | cut -c1-300
 timeout 600 python tools/exp_weak.py 1 8 > gpurun_out/fin_weak.log 2>&1; tail -2 gpurun_out/fin_weak.log | cut -c1-200
 timeout 300 python tools/gpu_sync_vs_spec.py > gpurun_out/fin_sync_vs_spec.txt 2>&1; tail -1 gpurun_out/fin_sync_vs_spec.txt
+MI_GRAPH=force timeout 500 python tools/gpu_soak.py 2>/dev/null | tail -1 > gpurun_out/fin_soak.json; cut -c1-400 gpurun_out/fin_soak.json
 echo "all done at $(( $(date +%s) - T0 )) s"
