@@ -679,12 +679,15 @@ def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
     """BASELINE's 262 144-body pile, far beyond the oracle's reach: the default solver (XCD-partitioned persistent kernel: eight tile
     lists, ~95 % of the bodies handed over through an XCD's L2, the seam bodies through memory) must end bit-identical to the
     dispatch-ordered flow kernel, to the unpartitioned persistent kernel — which the small cases pin to the oracle — and to a world
-    that takes every step synchronously (MI_ASYNC=0: exact sizes read back inside the step; the path of every re-run)."""
+    that takes every step synchronously (MI_ASYNC=0: exact sizes read back inside the step; the path of every re-run) — and to worlds stepping with round 4's
+    launches, or with the colouring rounds moved into the tail."""
     import hashlib
     sc = scenes.obb_pile(128, 16, 128)
     out = {}
-    for name, env in (("default", {}), ("flow", {"MI_SOLVER": "flow"}), ("unpartitioned", {"MI_PERSIST_XCD": "0"}), ("synchronous", {"MI_ASYNC": "0"})):
-        for k in ("MI_SOLVER", "MI_PERSIST_XCD", "MI_ASYNC"):
+    round4_step = {"MI_FUSE_RESET": "0", "MI_ROUND0_EMIT": "0", "MI_FUSE_LARGE": "0", "MI_FINISH_IN_NARROW": "0", "MI_COLOR_TAIL": "0", "MI_FUSE_KEYS": "0"}   # every launch round 5 removed, back
+    for name, env in (("default", {}), ("flow", {"MI_SOLVER": "flow"}), ("unpartitioned", {"MI_PERSIST_XCD": "0"}), ("synchronous", {"MI_ASYNC": "0"}),
+                      ("the tail colours", {"MI_COLOR_ROUNDS_MAX": "1"}), ("29 launches", round4_step)):
+        for k in ("MI_SOLVER", "MI_PERSIST_XCD", "MI_ASYNC", "MI_COLOR_ROUNDS_MAX", *round4_step):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -695,6 +698,9 @@ def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
         w.close()
     assert out["default"][2] == 4 and out["flow"][2] == 1 and out["unpartitioned"][2] == 2, out
     assert out["default"][:2] == out["flow"][:2] == out["unpartitioned"][:2] == out["synchronous"][:2], out   # (synchronous: every step sized from read-backs inside the step — the path every re-run takes)
+    # the launches a steady step no longer makes (knobs.hpp) change nothing either; nor does it matter who runs the colouring rounds (MI_COLOR_ROUNDS_MAX=1: all but
+    # one of them inside k_bin_hist, 256 workgroups striding over 360 k manifolds with a device-wide barrier in between)
+    assert out["the tail colours"][:2] == out["default"][:2] and out["29 launches"][:2] == out["default"][:2], out
     assert out["default"][1] > 150000
     assert out["default"][3] <= 12, "speculative retries while the pile lands are fine; a solver that keeps falling back is not"
 
