@@ -390,6 +390,12 @@ class World:
             self.L.check(self.L.fn("world_poll_events")(self.h, _ptr(out), C.c_uint32(n.value), C.byref(n)), "world_poll_events")
         return out
 
+    def color_tail_stats(self):
+        """(valid steps whose colouring was finished inside k_bin_hist, colouring rounds run there) since creation (product library only)."""
+        a = C.c_uint64(0); b = C.c_uint64(0)
+        self.L.check(self.L.fn("debug_color_tail_stats")(self.h, C.byref(a), C.byref(b)), "debug_color_tail_stats")
+        return a.value, b.value
+
     def step_mode_stats(self):
         """(internal steps, speculative steps, synchronous retries) since creation (product library only)."""
         a = C.c_uint32(0); b = C.c_uint32(0); c = C.c_uint32(0)

@@ -59,7 +59,8 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t specOverflow;         // a speculative bound (tiles / contact-tiles capacity) was exceeded on the device
     uint32_t numCells;             // cells of this step's broad-phase grid
     uint32_t numPairsFound;        // pair count of a step whose speculative pair bound was exceeded (numPairs is zeroed then)
-    uint32_t boxHitCountUnused[16]; // (the box queues' counters live in Shards::c[q].boxHits)
+    uint32_t tailRounds;           // colouring rounds k_bin_hist ran itself this step (colorTail; 0: the enqueued rounds were enough)
+    uint32_t reserved15[15];
     uint32_t numEvents;            // collision begin / end events of this step (when events are enabled)
     uint32_t numInterPairs;        // AABB overlaps between a rigid-body collider and a trigger / force-field collider
     uint32_t numInteractions;      // ... of which the boolean overlap test passed (non_collision_interaction records)
@@ -1597,7 +1598,7 @@ __device__ __forceinline__ void colorTail(const ColorTail& ct, StepScalars* sc) 
         if (more == 2u) { if (threadIdx.x == 0) sc->specOverflow = 1u; break; }   // (a participant never arrived: the step is void and re-run synchronously)
         if (more == 0u || r + 2u >= kMaxColorRounds) break;                          // round r left no loser: everything is coloured (or: give up, colorPending tells)
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(&flags[kTailDone], r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (blockIdx.x == 0 && threadIdx.x == 0) { sc->tailRounds = r + 1u - ct.from; __hip_atomic_store(&flags[kTailDone], r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 }
 // which round's flag says whether the colouring is complete: the last one the host enqueued, or the last one the tail ran
 __device__ __forceinline__ uint32_t colorPendingOf(const uint32_t* __restrict__ roundFlags, uint32_t lastRound) {

@@ -367,6 +367,7 @@ struct mi_world {
     uint32_t gjkWaveMaxPairs = 16384;   // GJK bucket span up to which k_narrow_gjk_wave (one wave per pair) beats lanes + EPA queue
     bool specEnabled = true, haveEstimates = false;
     uint32_t specRetries = 0, specSteps = 0, totalSteps = 0, colorRoundsLaunched = 0;
+    uint64_t tailSteps = 0, tailRoundsSum = 0;   // valid steps whose colouring was finished inside k_bin_hist, and the rounds it ran there (mi_debug_color_tail_stats)
     uint32_t colorBatchSticky = 0;   // colouring rounds a graph-replaying scene enqueues per step (runStep)
     bool scalarsClean = false;   // the device-side step scalars / counters are already cleared for the next attempt (k_publish_readback did k_reset_scalars' work)
     uint32_t sapAxis = 0;        // sorting axis for the next step (collision_broad.cpp:443-444), host copy

@@ -308,6 +308,9 @@ MI_API int mi_world_get_solver_kind(mi_world* world, uint32_t* out_kind);
  * (HIP runtime >= 7.2; MI_GRAPH=0 / force / all).  out[0] = enabled, out[1] = steps replayed, out[2] = graphs captured,
  * out[3] = speculative steps launched plainly. */
 MI_API int mi_debug_step_graph_stats(mi_world* world, uint32_t* out4);
+/* Tests: in how many valid steps the colouring was finished by the tail inside k_bin_hist (the colouring rounds the host enqueued — what the previous step needed + 1 — left
+ * manifolds uncoloured), and how many rounds ran there in total.  No reference counterpart (scheduleConstraintsSIMD is one serial pass, src/physics/constraints.cpp:51-184). */
+MI_API int mi_debug_color_tail_stats(mi_world* world, uint64_t* out_steps, uint64_t* out_rounds);
 /* Tests: how many times the pose rows (mi_world_view_transforms) were enqueued by a step itself, and how many times only when asked. */
 MI_API int mi_debug_pose_stream_stats(mi_world* world, uint32_t* out_ahead, uint32_t* out_on_demand);
 /* Sum of the per-stage device times and of the contact updates (contacts x solver iterations) over the internal steps since

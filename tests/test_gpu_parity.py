@@ -514,6 +514,9 @@ def test_gpu_step_launch_variants_match_oracle(mi_lib, oracle_mod, monkeypatch, 
     assert g.counts()["num_contacts"] > 3000
     assert g.physics_transforms()[0].tobytes() == o.physics_transforms()[0].tobytes()
     assert g.velocities()[0].tobytes() == o.velocities()[0].tobytes()
+    tail_steps, tail_rounds = g.color_tail_stats()
+    if env.get("MI_COLOR_TAIL") == "0": assert tail_steps == 0
+    if "MI_COLOR_ROUNDS_MAX" in env: assert tail_steps >= 30 and tail_rounds >= 2 * tail_steps, "with one or two rounds enqueued the tail has to colour nearly everything"
 
 
 @pytest.mark.parametrize("variant", ["0", "1"], ids=["GJK by lanes + EPA queue", "GJK and EPA by one wave per pair"])
