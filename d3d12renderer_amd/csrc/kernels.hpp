@@ -87,6 +87,28 @@ struct ShardCounters { uint32_t numOverlaps; uint32_t bucketHist[24]; uint32_t o
 static_assert(sizeof(ShardCounters) == 128 && kShards == 16, "one line per shard; the box queues use the shards' lines");
 struct Shards { ShardCounters c[kShards]; uint32_t extentHist[kShards][256]; };
 
+// Sharded world, "a rank pays for what it simulates" (round 5): the per-body and per-collider passes of a step visit BLOCKS of 256 bodies / colliders, and skip the blocks
+// in which this rank simulates nothing — in an 8-tile scene 7 of 8.  Per body block: `stamp` = the step in which it last held a simulated body or received a record
+// (k_shard_classify, k_shard_unpack; a block is RECENT for kShardRecentSteps steps after that: classification and packing only look at recent blocks — a body can only
+// become simulated here by moving while simulated or by a record arriving, and both body-flag arrays have seen their zeros by then), `live` = a body simulated in this
+// step or the one before (what the integrators and the collider pass ask).  Per collider block: the range of body blocks its colliders' bodies lie in (static, from the
+// upload) and `cbLive` = it holds a collider that is not dead (k_bp_prepare writes it; the sorted scatter and the centre statistics skip the rest).  A world that is not
+// sharded passes null pointers and launches one workgroup per block as before.
+constexpr uint32_t kShardRecentSteps = 2u, kShardGrid = 1024u;   // kShardGrid: workgroups of a pass that strides over the blocks
+__global__ __launch_bounds__(256) void k_fill_u32(uint32_t* __restrict__ p, uint32_t value, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = value; }
+__device__ __forceinline__ bool shardBlockRecent(const uint32_t* __restrict__ stamp, uint32_t blk, uint32_t step) { return !stamp || (int32_t)(step - stamp[blk]) <= (int32_t)kShardRecentSteps; }
+// Workgroup `first` of `stride` visits the blocks first, first + stride, ... < numBlocks that pass `live`: the tests of up to 64 candidates are made by the lanes of a wave
+// side by side (one round of loads instead of one dependent load per skipped block: 7 of 8 candidates are skipped in an 8-tile scene), then `visit(block)` runs for the
+// survivors, in order.  Every wave of the workgroup computes the same mask from the same words, so `visit` may contain workgroup barriers.
+template <class Live, class Visit>
+__device__ __forceinline__ void forLiveBlocks(const uint32_t first, const uint32_t stride, const uint32_t numBlocks, Live live, Visit visit) {
+    const uint32_t lane = threadIdx.x & 63u;
+    for (uint32_t base = first; base < numBlocks; base += 64u * stride) {
+        const uint32_t cand = base + lane * stride;
+        unsigned long long todo = __ballot(cand < numBlocks && live(cand));
+        while (todo) { const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u; todo &= todo - 1ull; visit(base + j * stride); }
+    }
+}
 __device__ __forceinline__ int orderedInt(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ __forceinline__ float fromOrderedInt(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
@@ -424,13 +446,26 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
                                                     uint32_t nb, const uint32_t* __restrict__ cTypeBody, const uint32_t* __restrict__ cObject, const float4* __restrict__ cShape,
                                                     const float4* __restrict__ cStaticPos, const float4* __restrict__ cStaticRot, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
                                                     const float4* __restrict__ hullAabb, float4* __restrict__ wShape, float4* __restrict__ aabbMinW, float4* __restrict__ aabbMaxW,
-                                                    uint32_t axisCur, const uint32_t* __restrict__ axisDev) {
+                                                    uint32_t axisCur, const uint32_t* __restrict__ axisDev,
+                                                    const uint2* __restrict__ cbRange /* sharded world: per collider block the body blocks its colliders' bodies lie in (x > y: always visited), or null */,
+                                                    const uint8_t* __restrict__ blockLive, uint8_t* __restrict__ cbLive) {
     __shared__ unsigned long long sm[4][kAxisSums];
     __shared__ uint32_t hist[256];
     __shared__ int sb[4][6];
+  // (one workgroup per collider block unless the world is sharded: then a collider block is skipped when nothing is simulated, now or in the previous step, in any body
+  // block it refers to — its rows already say "dead", its partial results are empty)
+  forLiveBlocks(blockIdx.x, gridDim.x, (nc + 255u) / 256u, [&](uint32_t cb) {
+        if (!cbRange) return true;
+        const uint2 rg = cbRange[cb];
+        bool any = rg.x > rg.y;
+        for (uint32_t b = rg.x; b <= rg.y && !any; ++b) any = blockLive[b] != 0u;
+        if (!any && cbLive[cb]) cbLive[cb] = 0u;
+        return any;
+    }, [&](uint32_t cb) {
+    __syncthreads();   // (the previous block's shared results have been read)
     hist[threadIdx.x] = 0;
     __syncthreads();
-    const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+    const uint32_t i = cb * 256 + threadIdx.x;
     if (cTypeBody && i == 0) { sc->axisCur = axisDev ? *axisDev : axisCur; }
     if (cTypeBody && bodyActive) {
         // sharded world: a workgroup whose colliders are all dead now and were dead in the previous step (7 of 8 workgroups of an 8-tile scene) has nothing to
@@ -438,8 +473,9 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
         bool stale = true;
         if (i < nc) { const uint32_t body = cTypeBody[2 * i + 1]; stale = body != kNoBody && !bodyActive[body] && !bodyActivePrev[body]; }
         if (!__syncthreads_or(stale ? 0 : 1)) {
-            if (threadIdx.x < kAxisSums) partials[blockIdx.x * kAxisSums + threadIdx.x] = 0ull;
-            if (threadIdx.x < 6) blockBounds[blockIdx.x * 6 + threadIdx.x] = threadIdx.x < 3 ? 0x7FFFFFFF : (int)0x80000000;
+            if (threadIdx.x < kAxisSums) partials[cb * kAxisSums + threadIdx.x] = 0ull;
+            if (threadIdx.x < 6) blockBounds[cb * 6 + threadIdx.x] = threadIdx.x < 3 ? 0x7FFFFFFF : (int)0x80000000;
+            if (cbLive && threadIdx.x == 0) cbLive[cb] = 0u;
             return;
         }
     }
@@ -481,14 +517,16 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
     }
     const uint32_t lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     if (lane == 0) { for (int a = 0; a < 3; ++a) { sb[wv][a] = lo[a]; sb[wv][3 + a] = hi[a]; } }
-    __syncthreads();
-    if (hist[threadIdx.x]) atomicAdd(&sh->extentHist[blockIdx.x & (kShards - 1u)][threadIdx.x], hist[threadIdx.x]);
-    if (threadIdx.x < kAxisSums) partials[blockIdx.x * kAxisSums + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    const int anyAlive = __syncthreads_or((i < nc && !dead) ? 1 : 0);
+    if (cbLive && threadIdx.x == 0) cbLive[cb] = anyAlive ? 1u : 0u;
+    if (hist[threadIdx.x]) atomicAdd(&sh->extentHist[cb & (kShards - 1u)][threadIdx.x], hist[threadIdx.x]);
+    if (threadIdx.x < kAxisSums) partials[cb * kAxisSums + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
     if (threadIdx.x < 6) {
         int x = sb[0][threadIdx.x];
         for (int w = 1; w < 4; ++w) x = threadIdx.x < 3 ? min(x, sb[w][threadIdx.x]) : max(x, sb[w][threadIdx.x]);
-        blockBounds[blockIdx.x * 6 + threadIdx.x] = x;
+        blockBounds[cb * 6 + threadIdx.x] = x;
     }
+  });
 }
 
 // Cell-sorted copies of the AABB rows (a column scan reads contiguous memory), the cell key and the collider index.
@@ -497,14 +535,17 @@ __global__ __launch_bounds__(256) void k_bp_scatter_sorted(uint32_t nc, const ui
                                                            const uint32_t* __restrict__ cellLower,
                                                            const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
                                                            uint32_t* __restrict__ keysS, uint32_t* __restrict__ valsS,
-                                                           float4* __restrict__ sMin, float4* __restrict__ sMax) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nc) return;
-    uint32_t key = keys[i];
-    if (key == 0xFFFFFFFFu) return;
-    uint32_t pos = cellLower[key] + ranks[i];
-    keysS[pos] = key; valsS[pos] = i;
-    sMin[pos] = aabbMin[i]; sMax[pos] = aabbMax[i];
+                                                           float4* __restrict__ sMin, float4* __restrict__ sMax, const uint8_t* __restrict__ cbLive /* sharded world: collider blocks with a live collider, or null */) {
+    const uint32_t numCb = (nc + blockDim.x - 1u) / blockDim.x;
+    forLiveBlocks(blockIdx.x, gridDim.x, numCb, [&](uint32_t cb) { return !cbLive || cbLive[cb] != 0u; }, [&](uint32_t cb) {
+        const uint32_t i = cb * blockDim.x + threadIdx.x;
+        if (i >= nc) return;
+        const uint32_t key = keys[i];
+        if (key == 0xFFFFFFFFu) return;
+        const uint32_t pos = cellLower[key] + ranks[i];
+        keysS[pos] = key; valsS[pos] = i;
+        sMin[pos] = aabbMin[i]; sMax[pos] = aabbMax[i];
+    });
 }
 
 // Prune + orient + key (collision_narrow.cpp:2346-2395) fused into pair emission.
@@ -829,15 +870,26 @@ __host__ __device__ __forceinline__ int gjkModeOfBucket(uint32_t bucket);
 // cell size, origin, dims) from this step's extent histogram and centre bounds.  One workgroup of 256; it used to be the tail of k_pair_finish, i.e. ~10 us
 // of single-workgroup work on the step's critical path — now an extra workgroup of k_emit_manifolds runs it beside that kernel's thousands.
 __device__ inline void pairFinishStats(const Shards* __restrict__ sh, StepScalars* sc, uint32_t nc, uint32_t numBlocks, const unsigned long long* __restrict__ partials,
-                                       const int* __restrict__ blockBounds, GridParams* gridNext, uint32_t cellCapNext) {
+                                       const int* __restrict__ blockBounds, GridParams* gridNext, uint32_t cellCapNext, const uint8_t* __restrict__ cbLive = nullptr /* sharded world: only these blocks' rows are not empty */) {
     const uint32_t t = threadIdx.x;
     __shared__ unsigned long long sm[4][kAxisSums];
     unsigned long long v[kAxisSums];
 #pragma unroll
     for (uint32_t c = 0; c < kAxisSums; ++c) v[c] = 0ull;
-    for (uint32_t b = t; b < numBlocks; b += 256) {
+    // (sharded world: first WHICH of a thread's rows are not empty — 32 independent flag loads —, then those rows: a flag load in front of every row's loads made this
+    // workgroup, 32 rows per thread in an 8-tile scene, the tail of k_emit_manifolds)
+    for (uint32_t b0 = t; b0 < numBlocks; b0 += 256u * 32u) {
+        uint32_t rowsLive = 0xFFFFFFFFu;
+        if (cbLive) { rowsLive = 0u;
 #pragma unroll
-        for (uint32_t c = 0; c < kAxisSums; ++c) v[c] += partials[(size_t)b * kAxisSums + c];
+            for (uint32_t k = 0; k < 32u; ++k) { const uint32_t b = b0 + 256u * k; if (b < numBlocks && cbLive[b]) rowsLive |= 1u << k; } }
+        for (uint32_t k = 0; k < 32u; ++k) {
+            const uint32_t b = b0 + 256u * k;
+            if (b >= numBlocks) break;
+            if (!((rowsLive >> k) & 1u)) continue;
+#pragma unroll
+            for (uint32_t c = 0; c < kAxisSums; ++c) v[c] += partials[(size_t)b * kAxisSums + c];
+        }
     }
     axisWaveReduce(v, sm);
     const uint32_t lane = t & 63, wv = t >> 6;
@@ -847,8 +899,18 @@ __device__ inline void pairFinishStats(const Shards* __restrict__ sh, StepScalar
         __shared__ int red[4][6];
         { uint32_t h = 0; for (uint32_t k = 0; k < kShards; ++k) h += sh->extentHist[k][t]; hist[t] = h; }
         int b6[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
-        for (uint32_t b = t; b < numBlocks; b += 256)
-            for (int a = 0; a < 6; ++a) { int x = blockBounds[b * 6 + a]; b6[a] = a < 3 ? min(b6[a], x) : max(b6[a], x); }
+        for (uint32_t b0 = t; b0 < numBlocks; b0 += 256u * 32u) {
+            uint32_t rowsLive = 0xFFFFFFFFu;
+            if (cbLive) { rowsLive = 0u;
+#pragma unroll
+                for (uint32_t k = 0; k < 32u; ++k) { const uint32_t b = b0 + 256u * k; if (b < numBlocks && cbLive[b]) rowsLive |= 1u << k; } }
+            for (uint32_t k = 0; k < 32u; ++k) {
+                const uint32_t b = b0 + 256u * k;
+                if (b >= numBlocks) break;
+                if (!((rowsLive >> k) & 1u)) continue;
+                for (int a = 0; a < 6; ++a) { int x = blockBounds[b * 6 + a]; b6[a] = a < 3 ? min(b6[a], x) : max(b6[a], x); }
+            }
+        }
 #pragma unroll
         for (int a = 0; a < 6; ++a)
 #pragma unroll
@@ -1293,14 +1355,14 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
                                                         float2 terrainMaterial /* (restitution, friction) of the heightmap */,
                                                         HistSlot* __restrict__ nextTab, uint32_t nextMask, uint8_t* __restrict__ manKept,
                                                         const Shards* __restrict__ statsShards /* non-null: workgroup 0 runs pairFinishStats instead */, uint32_t statsBlocks,
-                                                        const unsigned long long* __restrict__ statsPartials, const int* __restrict__ statsBounds, GridParams* statsGridNext, uint32_t statsCellCap,
+                                                        const unsigned long long* __restrict__ statsPartials, const int* __restrict__ statsBounds, GridParams* statsGridNext, uint32_t statsCellCap, const uint8_t* __restrict__ statsCbLive,
                                                         const uint32_t* __restrict__ seamId /* exact seam: per body, the tile border it is shared across (0 = none); or null */,
                                                         unsigned long long* __restrict__ topRound1 /* non-null: colouring round 0 happens right here — an uncoloured manifold proposes itself on its bodies
                                                                                                        for round 1 (k_color_round's "lost" branch at round 0: every uncoloured manifold loses round 0) */,
                                                         uint32_t* __restrict__ roundFlags) {
     // (workgroup 0, not the last one: dispatched first, it runs beside all the others; as the last one its ~4 us — 12 us over the 8 192 partial rows
     // of a 2 M-collider sharded scene — started when the kernel was all but over and became its tail)
-    if (statsShards && blockIdx.x == 0u) { pairFinishStats(statsShards, sc, nc, statsBlocks, statsPartials, statsBounds, statsGridNext, statsCellCap); return; }
+    if (statsShards && blockIdx.x == 0u) { pairFinishStats(statsShards, sc, nc, statsBlocks, statsPartials, statsBounds, statsGridNext, statsCellCap, statsCbLive); return; }
     uint32_t p = (blockIdx.x - (statsShards ? 1u : 0u)) * blockDim.x + threadIdx.x;
     const uint32_t numPairs = sc->numPairs;
     if (p >= numPairs) return;
@@ -1375,9 +1437,10 @@ struct ForcesArgs {   // k_integrate_forces' arguments; no padding bytes (the la
     float4* gVelL;                    // XCD-partitioned solver: cached copy for the XCD-local bodies, or null
     unsigned long long* bodyOwner;    // ... and the per-body XCD flags (8 bytes), cleared here
     const uint8_t* bodyActive;        // sharded world, or null
+    const uint8_t* blockLive;         // ... and its per-block summary (see shardBlockRecent above), or null
     uint32_t nb; float dt; float globalForce[3]; uint32_t pad;
 };
-static_assert(sizeof(ForcesArgs) == 15 * 8 + 24, "ForcesArgs must not contain padding");
+static_assert(sizeof(ForcesArgs) == 16 * 8 + 24, "ForcesArgs must not contain padding");
 __device__ __forceinline__ void integrateForcesBody(const uint32_t i, const ForcesArgs& fa) {
     const uint32_t nb = fa.nb; const float dt = fa.dt; const float3 globalForce = make_float3(fa.globalForce[0], fa.globalForce[1], fa.globalForce[2]);
     const float4* __restrict__ bPos = fa.bPos; const float4* __restrict__ bRot = fa.bRot; const float4* __restrict__ bCogInvMass = fa.bCogInvMass; const float4* __restrict__ bInvI = fa.bInvI;
@@ -1422,26 +1485,28 @@ __device__ __forceinline__ void integrateForcesBody(const uint32_t i, const Forc
     gVel[2 * i] = f4(v, 0.f); gVel[2 * i + 1] = f4(w, 0.f);   // .w = update-version tag of the solver (0 at step start)
     if (gVelL) { gVelL[2 * i] = f4(v, 0.f); gVelL[2 * i + 1] = f4(w, 0.f); }
 }
-__global__ __launch_bounds__(256) void k_integrate_forces(ForcesArgs fa) { integrateForcesBody(blockIdx.x * blockDim.x + threadIdx.x, fa); }
+// workgroup `first` of `stride` workgroups: the body blocks first, first + stride, ... (one block each unless the world is sharded)
+__device__ __forceinline__ void integrateForcesBlocks(const uint32_t first, const uint32_t stride, const ForcesArgs& fa) {
+    const uint32_t numBlocks = (fa.nb + 1u + 255u) / 256u;
+    forLiveBlocks(first, stride, numBlocks,
+                  [&](uint32_t blk) { return !fa.blockLive || blk + 1u >= numBlocks || fa.blockLive[blk] != 0u; },   // (nothing simulated in it, now or in the previous step: skipped; the last block holds the dummy body: always visited)
+                  [&](uint32_t blk) { integrateForcesBody(blk * 256u + threadIdx.x, fa); });
+}
+__global__ __launch_bounds__(256) void k_integrate_forces(ForcesArgs fa) { integrateForcesBlocks(blockIdx.x, gridDim.x, fa); }
 
 // K13 "Integrate rigid body velocities" (src/physics/rigid_body.cpp:126-142).
 // Writes the NEXT body state into the second buffer set (the host swaps the sets once the step is known to be valid).
-__global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float dt, const float4* __restrict__ gPos, const float4* __restrict__ gVel,
-                                                              const float4* __restrict__ bCogInvMass, const float4* __restrict__ bRotIn,
-                                                              float4* __restrict__ bPos, float4* __restrict__ bRot,
-                                                              float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, float4* __restrict__ bForce,
-                                                              float4* __restrict__ bTorque,
-                                                              const float4* __restrict__ gVelL, const unsigned long long* __restrict__ bodyOwner /* XCD-partitioned solver, or null */,
-                                                              unsigned long long* __restrict__ bodyUsed, unsigned long long* __restrict__ bodyTop,
-                                                              const uint8_t* __restrict__ bodyActive /* sharded world (1 = owned), or null */, const float4* __restrict__ bPosIn,
-                                                              const float4* __restrict__ bLinVelIn, const float4* __restrict__ bAngVelIn, const float4* __restrict__ bForceIn,
-                                                              const float4* __restrict__ bTorqueIn,
-                                                              const uint8_t* __restrict__ bodyActivePrev /* the previous step's flags */, const Shards* __restrict__ sh, StepScalars* sc) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (bodyActive && blockIdx.x == 0 && threadIdx.x < 3) {   // sharded world: this rank's owned bodies / manifolds / contacts, from the per-line counters
-        uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].owned[threadIdx.x];
-        sc->shardOwned[threadIdx.x] = v;
-    }
+__device__ __forceinline__ void integrateVelocitiesBody(const uint32_t i, uint32_t nb, float dt, const float4* __restrict__ gPos, const float4* __restrict__ gVel,
+                                                        const float4* __restrict__ bCogInvMass, const float4* __restrict__ bRotIn,
+                                                        float4* __restrict__ bPos, float4* __restrict__ bRot,
+                                                        float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, float4* __restrict__ bForce,
+                                                        float4* __restrict__ bTorque,
+                                                        const float4* __restrict__ gVelL, const unsigned long long* __restrict__ bodyOwner /* XCD-partitioned solver, or null */,
+                                                        unsigned long long* __restrict__ bodyUsed, unsigned long long* __restrict__ bodyTop,
+                                                        const uint8_t* __restrict__ bodyActive /* sharded world (1 = owned), or null */, const float4* __restrict__ bPosIn,
+                                                        const float4* __restrict__ bLinVelIn, const float4* __restrict__ bAngVelIn, const float4* __restrict__ bForceIn,
+                                                        const float4* __restrict__ bTorqueIn,
+                                                        const uint8_t* __restrict__ bodyActivePrev /* the previous step's flags */) {
     if (i > nb) return;
     // a body this rank neither simulates now nor simulated in the previous step: nothing of it was touched, both state sets already agree
     const bool idle = bodyActive && i < nb && bodyActive[i] == 0u && bodyActivePrev[i] == 0u;
@@ -1466,6 +1531,30 @@ __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float
     bForce[i] = z; bTorque[i] = z;
     bRot[i] = fromQ(nr);
     bPos[i] = f4(pos - rotate(nr, cog), 0.f);
+}
+__global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float dt, const float4* __restrict__ gPos, const float4* __restrict__ gVel,
+                                                              const float4* __restrict__ bCogInvMass, const float4* __restrict__ bRotIn,
+                                                              float4* __restrict__ bPos, float4* __restrict__ bRot,
+                                                              float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, float4* __restrict__ bForce,
+                                                              float4* __restrict__ bTorque,
+                                                              const float4* __restrict__ gVelL, const unsigned long long* __restrict__ bodyOwner /* XCD-partitioned solver, or null */,
+                                                              unsigned long long* __restrict__ bodyUsed, unsigned long long* __restrict__ bodyTop,
+                                                              const uint8_t* __restrict__ bodyActive /* sharded world (1 = owned), or null */, const float4* __restrict__ bPosIn,
+                                                              const float4* __restrict__ bLinVelIn, const float4* __restrict__ bAngVelIn, const float4* __restrict__ bForceIn,
+                                                              const float4* __restrict__ bTorqueIn,
+                                                              const uint8_t* __restrict__ bodyActivePrev /* the previous step's flags */, const Shards* __restrict__ sh, StepScalars* sc,
+                                                              const uint8_t* __restrict__ blockLive /* sharded world: body blocks with a body simulated in this step or the previous one (the others are skipped), or null */) {
+    if (bodyActive && blockIdx.x == 0 && threadIdx.x < 3) {   // sharded world: this rank's owned bodies / manifolds / contacts, from the per-line counters
+        uint32_t v = 0; for (uint32_t k = 0; k < kShards; ++k) v += sh->c[k].owned[threadIdx.x];
+        sc->shardOwned[threadIdx.x] = v;
+    }
+    const uint32_t numBlocks = (nb + 1u + 255u) / 256u;
+    forLiveBlocks(blockIdx.x, gridDim.x, numBlocks,   // (one block per workgroup unless the world is sharded)
+                  [&](uint32_t blk) { return !blockLive || blk + 1u >= numBlocks || blockLive[blk] != 0u; },   // (the last block holds the dummy body: always visited)
+                  [&](uint32_t blk) {
+        integrateVelocitiesBody(blk * 256u + threadIdx.x, nb, dt, gPos, gVel, bCogInvMass, bRotIn, bPos, bRot, bLinVel, bAngVel, bForce, bTorque, gVelL, bodyOwner, bodyUsed, bodyTop,
+                                bodyActive, bPosIn, bLinVelIn, bAngVelIn, bForceIn, bTorqueIn, bodyActivePrev);
+    });
 }
 
 __global__ __launch_bounds__(256) void k_iota(uint32_t n, uint32_t* __restrict__ out) {
@@ -1705,7 +1794,7 @@ __global__ __launch_bounds__(256) void k_manifold_keys(KeysArgs ka) { manifoldKe
 // atomics: started first), the others stream the bodies behind them.
 __global__ __launch_bounds__(256) void k_forces_keys(uint32_t keyBlocks, ForcesArgs fa, KeysArgs ka) {
     if (blockIdx.x < keyBlocks) manifoldKeysBody(blockIdx.x, ka);
-    else integrateForcesBody((blockIdx.x - keyBlocks) * blockDim.x + threadIdx.x, fa);
+    else integrateForcesBlocks(blockIdx.x - keyBlocks, gridDim.x - keyBlocks, fa);
 }
 __global__ __launch_bounds__(256) void k_manifold_place(uint32_t n, const StepScalars* __restrict__ sc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ranks,
                                                         const uint32_t* __restrict__ keyCount, uint32_t* __restrict__ perm) {
@@ -3045,32 +3134,41 @@ __device__ __forceinline__ bool shardInExtended(const ShardParams& sp, uint32_t 
 }
 __device__ __forceinline__ V3 shardCog(float4 pos, float4 rot, float4 cogInvMass) { return xyz(pos) + rotate(toQ(rot), xyz(cogInvMass)); }
 
-// start of a step: 1 = owned, 2 = ghost, 0 = not simulated here
+// start of a step: 1 = owned, 2 = ghost, 0 = not simulated here.  One workgroup per RECENT body block (see shardBlockRecent): the others hold nothing this rank
+// simulates, and their flags already say so in both flag arrays.
 __global__ __launch_bounds__(256) void k_shard_classify(uint32_t nb, ShardParams sp, const float4* __restrict__ bPos, const float4* __restrict__ bRot,
                                                         const float4* __restrict__ bCogInvMass, uint8_t* __restrict__ bodyActive, Shards* sh,
                                                         const uint32_t* __restrict__ root /* lowest body index of the body's articulated island: the island is classified as ONE */,
-                                                        const uint8_t* __restrict__ known /* 1 = this rank's copy of the body is current (owned in the last step, or a record arrived) */) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    bool owned = false;
-    if (i < nb) {
-        const uint32_t r = root[i];
-        const bool k = known[r] != 0u;      // a copy that is not current says nothing about where the body is (it may lie in a tile that has since grown)
-        uint8_t flag = 0u;
-        if (k) {                            // (most bodies of a many-tile scene are not known here: 5 bytes read for them instead of 53)
-            const V3 c = shardCog(bPos[r], bRot[r], bCogInvMass[r]);
-            owned = shardOwns(sp, c.x, c.z);
-            flag = owned ? 1u : shardInExtended(sp, sp.myTile, c.x, c.z) ? 2u : 0u;
-        }
-        bodyActive[i] = flag;
-    }
-    // counted per workgroup into one of kShards lines (summed by k_integrate_velocities): a same-address atomic per wave was 45 us of a 2 M-body scene
+                                                        const uint8_t* __restrict__ known /* 1 = this rank's copy of the body is current (owned in the last step, or a record arrived) */,
+                                                        const uint8_t* __restrict__ bodyActivePrev, uint32_t* __restrict__ blockStamp, uint8_t* __restrict__ blockLive, uint32_t step) {
     __shared__ uint32_t cnt;
-    if (threadIdx.x == 0) cnt = 0;
-    __syncthreads();
-    const unsigned long long m = __ballot(owned);
-    if (m && (threadIdx.x & 63u) == 0u) atomicAdd(&cnt, (uint32_t)__popcll(m));
-    __syncthreads();
-    if (threadIdx.x == 0 && cnt) atomicAdd(&sh->c[blockIdx.x & (kShards - 1u)].owned[0], cnt);
+    forLiveBlocks(blockIdx.x, gridDim.x, (nb + 255u) / 256u, [&](uint32_t blk) { return shardBlockRecent(blockStamp, blk, step); }, [&](uint32_t blk) {
+        const uint32_t i = blk * 256u + threadIdx.x;
+        bool owned = false;
+        uint8_t flag = 0u;
+        if (i < nb) {
+            const uint32_t r = root[i];
+            const bool k = known[r] != 0u;      // a copy that is not current says nothing about where the body is (it may lie in a tile that has since grown)
+            if (k) {                            // (most bodies of a many-tile scene are not known here: 5 bytes read for them instead of 53)
+                const V3 c = shardCog(bPos[r], bRot[r], bCogInvMass[r]);
+                owned = shardOwns(sp, c.x, c.z);
+                flag = owned ? 1u : shardInExtended(sp, sp.myTile, c.x, c.z) ? 2u : 0u;
+            }
+            bodyActive[i] = flag;
+        }
+        // counted per workgroup into one of kShards lines (summed by k_integrate_velocities): a same-address atomic per wave was 45 us of a 2 M-body scene
+        __syncthreads();   // (the previous block's count has been added)
+        if (threadIdx.x == 0) cnt = 0;
+        const int anyNow = __syncthreads_or(flag != 0u ? 1 : 0);
+        const int anyPrev = __syncthreads_or((i < nb && bodyActivePrev[i] != 0u) ? 1 : 0);
+        const unsigned long long m = __ballot(owned);
+        if (m && (threadIdx.x & 63u) == 0u) atomicAdd(&cnt, (uint32_t)__popcll(m));
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (cnt) atomicAdd(&sh->c[blk & (kShards - 1u)].owned[0], cnt);
+            if (blockStamp) { if (anyNow) blockStamp[blk] = step; blockLive[blk] = (anyNow || anyPrev) ? 1u : 0u; }
+        }
+    });
 }
 // owner rule for the counts: a manifold belongs to the rank that owns its first dynamic body (A unless A has no inverse mass / is the static dummy)
 __global__ __launch_bounds__(256) void k_shard_count(uint32_t nb, const uint2* __restrict__ manBodies, const uint2* __restrict__ manInfo,
@@ -3132,19 +3230,23 @@ __global__ __launch_bounds__(256) void k_shard_pack(uint32_t nb, ShardParams sp,
                                                     const float4* __restrict__ bPos, const float4* __restrict__ bRot, const float4* __restrict__ bLinVel,
                                                     const float4* __restrict__ bAngVel, const float4* __restrict__ bPosOld, const float4* __restrict__ bRotOld,
                                                     const float4* __restrict__ bCogInvMass, ShardBufs out, uint32_t capacity, StepScalars* sc,
-                                                    const uint32_t* __restrict__ root) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool owned = i < nb && bodyActive[i] == 1u;
-    if (i < nb) known[i] = owned ? 1u : 0u;   // what this rank knows from here on: the bodies it owned; the records about to arrive add the neighbours' (k_shard_unpack)
-    if (__ballot(owned)) shardPackWave(i, owned, sp, spNext, bordersPending, bPos, bRot, bLinVel, bAngVel, bPosOld, bRotOld, bCogInvMass, out, capacity, sc, root);
+                                                    const uint32_t* __restrict__ root, const uint32_t* __restrict__ blockStamp /* recent body blocks only (all when null): the others hold neither an owned body nor a copy marked current */, uint32_t step) {
+    forLiveBlocks(blockIdx.x, gridDim.x, (nb + 255u) / 256u, [&](uint32_t blk) { return shardBlockRecent(blockStamp, blk, step); }, [&](uint32_t blk) {
+        const uint32_t i = blk * 256u + threadIdx.x;
+        const bool owned = i < nb && bodyActive[i] == 1u;
+        if (i < nb) known[i] = owned ? 1u : 0u;   // what this rank knows from here on: the bodies it owned; the records about to arrive add the neighbours' (k_shard_unpack)
+        if (__ballot(owned)) shardPackWave(i, owned, sp, spNext, bordersPending, bPos, bRot, bLinVel, bAngVel, bPosOld, bRotOld, bCogInvMass, out, capacity, sc, root);
+    });
 }
 // The next step's sweep axis of a sharded world, from centre statistics summed over all ranks (or, before / without that sum, this rank's own)
 __global__ void k_shard_axis(const unsigned long long* __restrict__ sums9, uint32_t nc, uint32_t* __restrict__ axisDev) { if (threadIdx.x == 0 && blockIdx.x == 0) *axisDev = axisFromSums(sums9, nc); }
 // (a done-ticket in k_shard_pack instead of this launch: 8 192 same-address atomics in a 2 M-body scene, ~90 us)
 constexpr uint32_t kShardFlagsMagic = 0x5A4D0000u;   // header word 1 = magic | the sender's message-size policy (bit 0: adaptive sizes): ranks that disagree about it would post sends and receives of different lengths
 __global__ void k_shard_pack_headers(uint32_t numPeers, const StepScalars* __restrict__ sc, ShardBufs out,
-                                     uint32_t nc, uint32_t* __restrict__ axisOwn /* caller's transport: the next sweep axis from this rank's own sums (k_shard_axis), or null */, uint32_t flags) {
+                                     uint32_t nc, uint32_t* __restrict__ axisOwn /* caller's transport: the next sweep axis from this rank's own sums (k_shard_axis), or null */, uint32_t flags,
+                                     uint32_t* sentHost /* pinned host memory: the eight record counts, for the host's overflow check (was a copy of its own: a 4 us copy kernel) */) {
     if (threadIdx.x < numPeers) { out.p[threadIdx.x][0] = __uint_as_float(sc->shardSent[threadIdx.x]); out.p[threadIdx.x][1] = __uint_as_float(kShardFlagsMagic | flags); }
+    if (sentHost && threadIdx.x < 8u) { sentHost[threadIdx.x] = sc->shardSent[threadIdx.x]; __threadfence_system(); }
     if (axisOwn && threadIdx.x == 63) *axisOwn = axisFromSums(sc->axisSums, nc);
 }
 // blockIdx.y = neighbour slot (a body has one owner: the messages never touch the same body)
@@ -3152,7 +3254,8 @@ struct ShardCaps { uint32_t c[8]; };   // records each received message can hold
 __global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, ShardBufs in, uint32_t capacity, float4* __restrict__ bPos, float4* __restrict__ bRot,
                                                       float4* __restrict__ bLinVel, float4* __restrict__ bAngVel, uint8_t* __restrict__ known,
                                                       ShardCaps caps = ShardCaps{{0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu}}, uint32_t* __restrict__ recvCounts = nullptr,
-                                                      uint32_t myFlags = 0u /* library transport: this rank's message-size policy, held against the sender's (header word 1) */) {
+                                                      uint32_t myFlags = 0u /* library transport: this rank's message-size policy, held against the sender's (header word 1) */,
+                                                      uint32_t* __restrict__ blockStamp = nullptr /* the body blocks that received a record become recent (for the step numbered `stampStep`) */, uint32_t stampStep = 0u) {
     const float* msg = in.p[blockIdx.y];
     const uint32_t sent = __float_as_uint(msg[0]), cap = min(capacity, caps.c[blockIdx.y]);
     if (recvCounts && blockIdx.x == 0 && threadIdx.x == 0) {
@@ -3169,6 +3272,7 @@ __global__ __launch_bounds__(256) void k_shard_unpack(uint32_t nb, ShardBufs in,
     bPos[b] = make_float4(s[1], s[2], s[3], 0.f); bRot[b] = make_float4(s[4], s[5], s[6], s[7]);
     bLinVel[b] = make_float4(s[8], s[9], s[10], 0.f); bAngVel[b] = make_float4(s[11], s[12], s[13], 0.f);
     known[b] = 1u;
+    if (blockStamp) blockStamp[b >> 8] = stampStep;
 }
 // ---- exact seam (include/mi_shard.h "Exact seam")
 // Which tile border is v within the margin of?  b4 = the borders around this rank's column (ShardParams::bx / bz), mine = its index; 0 = none,

@@ -58,6 +58,7 @@ struct Knobs {
     bool jointIslands = true;           // MI_JOINT_ISLANDS=0
     int islandPrivate = -1;             // MI_ISLAND_PRIVATE=0: every island through the dataflow
     // ---- sharding
+    bool shardBlockSkip = true;         // MI_SHARD_BLOCK_SKIP=0: the per-body / per-collider passes of a sharded world visit every block of 256 (otherwise only those with something simulated in them)
     bool shardAdaptive = true;          // MI_SHARD_ADAPTIVE=0: neighbour messages always at full capacity
     // ---- development dumps
     std::string timelineOut; uint64_t timelineStep = 3;   // MI_DBG_TIMELINE_OUT / _STEP (-DMI_DBG_TIMELINE builds)
@@ -85,7 +86,7 @@ struct Knobs {
         k.xcdFault = set("MI_PERSIST_XCD_FAULT"); k.flowFault = set("MI_FLOW_FAULT");
         k.gvelAlloc = str("MI_GVEL_ALLOC"); k.impAlloc = str("MI_IMP_ALLOC");
         k.fuseJoints = !off("MI_FUSE_JOINTS"); k.jointIslands = !off("MI_JOINT_ISLANDS"); k.islandPrivate = tri("MI_ISLAND_PRIVATE");
-        k.shardAdaptive = !off("MI_SHARD_ADAPTIVE");
+        k.shardAdaptive = !off("MI_SHARD_ADAPTIVE"); k.shardBlockSkip = !off("MI_SHARD_BLOCK_SKIP");
         k.timelineOut = str("MI_DBG_TIMELINE_OUT"); k.timelineStep = num("MI_DBG_TIMELINE_STEP", 3);
         return k;
     }

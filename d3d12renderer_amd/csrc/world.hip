@@ -178,6 +178,10 @@ struct mi_world {
         // anything that can put many bodies into a ghost strip at once (a restore, a re-upload, states written from outside) sends the next messages at full size again; with the
         // library transport such a call is COLLECTIVE: every rank makes it between the same two steps (include/mi_shard.h), or the ranks disagree about the message sizes
         void rearmFullSize() { fullExchanges = 2; sweepFullSteps = 2; }
+        // "a rank pays for what it simulates" (kernels.hpp, shardBlockRecent): per 256-body block the step of its last activity / received record and whether anything in it was
+        // simulated in this step or the previous one; per 256-collider block whether it holds a live collider.  blocksAll: every block counts as recent in the next step (set by
+        // whatever can change a body's status behind the flags' back: enable, new borders; an upload / restore / outside state write does it through prevValid)
+        DBuf<uint32_t> blockStamp; DBuf<uint8_t> blockLive, cbLive; bool blocksAll = true;
         // ... the sweep messages of the exact seam likewise, from the previous STEP's list lengths in both directions (x 1.5 + 64)
         uint32_t sweepPrevOwn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sweepPeerHdr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sweepSized[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool sweepRecvValid = false, sweepCut = false; uint32_t sweepFullSteps = 2;
         uint32_t owned[3] = {0, 0, 0};
@@ -367,6 +371,7 @@ struct mi_world {
     uint32_t gjkWaveMaxPairs = 16384;   // GJK bucket span up to which k_narrow_gjk_wave (one wave per pair) beats lanes + EPA queue
     bool specEnabled = true, haveEstimates = false;
     uint32_t specRetries = 0, specSteps = 0, totalSteps = 0, colorRoundsLaunched = 0;
+    DBuf<uint2> cbRange;   // per 256-collider block: the range of 256-body blocks its colliders' bodies lie in (x > y: a static collider among them — always visited); upload()
     uint64_t tailSteps = 0, tailRoundsSum = 0;   // valid steps whose colouring was finished inside k_bin_hist, and the rounds it ran there (mi_debug_color_tail_stats)
     uint32_t colorBatchSticky = 0;   // colouring rounds a graph-replaying scene enqueues per step (runStep)
     bool scalarsClean = false;   // the device-side step scalars / counters are already cleared for the next attempt (k_publish_readback did k_reset_scalars' work)

@@ -86,6 +86,38 @@ def test_gpu_rebalanced_ranks_match_oracle(mi_lib, oracle_mod, n, tiles_z, make,
     assert max(owned) < max(first) - 0.1 * sc.num_bodies, f"load balance: {first} -> {owned}"
 
 
+@pytest.mark.parametrize("n,tiles_z,make,margin", [(4, 1, lambda: scenes.obb_pile(128, 4, 16, spacing=1.0), 1.5), (4, 2, lambda: scenes.obb_pile(48, 4, 48, spacing=1.0), 1.5)],
+                         ids=["4 slabs, 8 192 boxes", "2x2 tiles, 9 216 boxes"])
+def test_gpu_block_skipping_changes_nothing(mi_lib, monkeypatch, n, tiles_z, make, margin):
+    """A rank's per-body and per-collider passes visit only the blocks of 256 with something simulated in them (kernels.hpp, shardBlockRecent: classification and
+    packing look at the blocks that were active or received a record within the last two steps, the integrators and the collider pass at those with a body simulated
+    now or in the previous step).  Ranks that skip against ranks that visit every block (MI_SHARD_BLOCK_SKIP=0), over a badly laid out grid whose borders move every
+    8 steps — bodies change owner by the hundred, blocks fall dead and come back: every count, every owned state and every border bit-identical, every step."""
+    sc = make()
+    desc = _lopsided(sc, n, tiles_z, margin)
+    worlds = {}
+    for skip in ("1", "0"):
+        monkeypatch.setenv("MI_SHARD_BLOCK_SKIP", skip)
+        worlds[skip] = [sharding.ShardedWorld(sc.populate(mi_lib.create_world(0)), desc, r, "local") for r in range(n)]
+    a_, b_ = worlds["1"], worlds["0"]
+    s = sc.settings()
+    first = None
+    for i in range(72):
+        sharding.step_local(a_, s, sc.dt); sharding.step_local(b_, s, sc.dt)
+        owned = [a.world.shard_counts()["owned_bodies"] for a in a_]
+        assert sum(owned) == sc.num_bodies
+        first = first or owned
+        for a, b in zip(a_, b_):
+            assert a.world.counts() == b.world.counts(), f"step {i} rank {a.rank}: local counts"
+            assert a.world.shard_counts() == b.world.shard_counts(), f"step {i} rank {a.rank}: owned counts"
+            ea, sa = a.owned_states(); eb, sb = b.owned_states()
+            assert np.array_equal(ea, eb) and sa.tobytes() == sb.tobytes(), f"step {i} rank {a.rank}: owned states"
+        if i % 8 == 7:
+            ba = sharding.rebalance_local(a_); bb = sharding.rebalance_local(b_)
+            assert ba[0].tobytes() == bb[0].tobytes() and ba[1].tobytes() == bb[1].tobytes()
+    assert max(owned) < max(first), f"load balance moved bodies between the ranks: {first} -> {owned}"
+
+
 def test_gpu_rank_never_trusts_a_copy_that_is_not_current(mi_lib):
     """tests/test_distributed.py::test_a_rank_never_trusts_a_copy_that_is_not_current on the GPU: a border moves over the place where a rank last
     saw a body that has long left — the rank must not claim it.  Then entities are deleted on every rank (re-upload of everything, body indices
