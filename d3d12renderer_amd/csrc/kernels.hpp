@@ -100,8 +100,11 @@ __device__ __forceinline__ bool shardBlockRecent(const uint32_t* __restrict__ st
 // Workgroup `first` of `stride` visits the blocks first, first + stride, ... < numBlocks that pass `live`: the tests of up to 64 candidates are made by the lanes of a wave
 // side by side (one round of loads instead of one dependent load per skipped block: 7 of 8 candidates are skipped in an 8-tile scene), then `visit(block)` runs for the
 // survivors, in order.  Every wave of the workgroup computes the same mask from the same words, so `visit` may contain workgroup barriers.
-template <class Live, class Visit>
+// STRIDED = false: the launch has one workgroup per block (a world that is not sharded) — the pass is compiled without the loop (with it, k_bp_prepare needs 157 instead of
+// 128 registers and loses a quarter of its occupancy: 25.8 -> 31.4 us).
+template <bool STRIDED = true, class Live, class Visit>
 __device__ __forceinline__ void forLiveBlocks(const uint32_t first, const uint32_t stride, const uint32_t numBlocks, Live live, Visit visit) {
+    if constexpr (!STRIDED) { visit(first); return; }
     const uint32_t lane = threadIdx.x & 63u;
     for (uint32_t base = first; base < numBlocks; base += 64u * stride) {
         const uint32_t cand = base + lane * stride;
@@ -436,6 +439,7 @@ __global__ __launch_bounds__(256) void k_bp_cell_ids(uint32_t nc, const float4* 
 // neighbours neighbours.  That takes k_bp_threshold and k_bp_grid_setup off the step's critical path and lets ONE kernel do what
 // k_axis_partials, k_bp_classify and k_bp_cell_ids did: centre statistics (same fixed reduction shape), extent histogram,
 // dead / large / small classification, bounds of the small centres, cell id + arrival rank.
+template <bool STRIDED>
 __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax, const GridParams* __restrict__ gp,
                                                     unsigned long long* __restrict__ partials, Shards* sh, StepScalars* sc, uint32_t* __restrict__ largeList, uint32_t* __restrict__ isLarge,
                                                     int* __restrict__ blockBounds, uint32_t* __restrict__ keys, uint32_t* __restrict__ ranks, uint32_t* __restrict__ cellCount,
@@ -454,7 +458,7 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
     __shared__ int sb[4][6];
   // (one workgroup per collider block unless the world is sharded: then a collider block is skipped when nothing is simulated, now or in the previous step, in any body
   // block it refers to — its rows already say "dead", its partial results are empty)
-  forLiveBlocks(blockIdx.x, gridDim.x, (nc + 255u) / 256u, [&](uint32_t cb) {
+  forLiveBlocks<STRIDED>(blockIdx.x, gridDim.x, (nc + 255u) / 256u, [&](uint32_t cb) {
         if (!cbRange) return true;
         const uint2 rg = cbRange[cb];
         bool any = rg.x > rg.y;
@@ -531,13 +535,14 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
 
 // Cell-sorted copies of the AABB rows (a column scan reads contiguous memory), the cell key and the collider index.
 // Positions [numSmall, nc) keep the key 0xFFFFFFFF written by the host-side fill.
+template <bool STRIDED>
 __global__ __launch_bounds__(256) void k_bp_scatter_sorted(uint32_t nc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ranks,
                                                            const uint32_t* __restrict__ cellLower,
                                                            const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
                                                            uint32_t* __restrict__ keysS, uint32_t* __restrict__ valsS,
                                                            float4* __restrict__ sMin, float4* __restrict__ sMax, const uint8_t* __restrict__ cbLive /* sharded world: collider blocks with a live collider, or null */) {
     const uint32_t numCb = (nc + blockDim.x - 1u) / blockDim.x;
-    forLiveBlocks(blockIdx.x, gridDim.x, numCb, [&](uint32_t cb) { return !cbLive || cbLive[cb] != 0u; }, [&](uint32_t cb) {
+    forLiveBlocks<STRIDED>(blockIdx.x, gridDim.x, numCb, [&](uint32_t cb) { return !cbLive || cbLive[cb] != 0u; }, [&](uint32_t cb) {
         const uint32_t i = cb * blockDim.x + threadIdx.x;
         if (i >= nc) return;
         const uint32_t key = keys[i];
@@ -1486,13 +1491,15 @@ __device__ __forceinline__ void integrateForcesBody(const uint32_t i, const Forc
     if (gVelL) { gVelL[2 * i] = f4(v, 0.f); gVelL[2 * i + 1] = f4(w, 0.f); }
 }
 // workgroup `first` of `stride` workgroups: the body blocks first, first + stride, ... (one block each unless the world is sharded)
+template <bool STRIDED>
 __device__ __forceinline__ void integrateForcesBlocks(const uint32_t first, const uint32_t stride, const ForcesArgs& fa) {
     const uint32_t numBlocks = (fa.nb + 1u + 255u) / 256u;
-    forLiveBlocks(first, stride, numBlocks,
+    forLiveBlocks<STRIDED>(first, stride, numBlocks,
                   [&](uint32_t blk) { return !fa.blockLive || blk + 1u >= numBlocks || fa.blockLive[blk] != 0u; },   // (nothing simulated in it, now or in the previous step: skipped; the last block holds the dummy body: always visited)
                   [&](uint32_t blk) { integrateForcesBody(blk * 256u + threadIdx.x, fa); });
 }
-__global__ __launch_bounds__(256) void k_integrate_forces(ForcesArgs fa) { integrateForcesBlocks(blockIdx.x, gridDim.x, fa); }
+template <bool STRIDED>
+__global__ __launch_bounds__(256) void k_integrate_forces(ForcesArgs fa) { integrateForcesBlocks<STRIDED>(blockIdx.x, gridDim.x, fa); }
 
 // K13 "Integrate rigid body velocities" (src/physics/rigid_body.cpp:126-142).
 // Writes the NEXT body state into the second buffer set (the host swaps the sets once the step is known to be valid).
@@ -1532,6 +1539,7 @@ __device__ __forceinline__ void integrateVelocitiesBody(const uint32_t i, uint32
     bRot[i] = fromQ(nr);
     bPos[i] = f4(pos - rotate(nr, cog), 0.f);
 }
+template <bool STRIDED>
 __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float dt, const float4* __restrict__ gPos, const float4* __restrict__ gVel,
                                                               const float4* __restrict__ bCogInvMass, const float4* __restrict__ bRotIn,
                                                               float4* __restrict__ bPos, float4* __restrict__ bRot,
@@ -1549,7 +1557,7 @@ __global__ __launch_bounds__(256) void k_integrate_velocities(uint32_t nb, float
         sc->shardOwned[threadIdx.x] = v;
     }
     const uint32_t numBlocks = (nb + 1u + 255u) / 256u;
-    forLiveBlocks(blockIdx.x, gridDim.x, numBlocks,   // (one block per workgroup unless the world is sharded)
+    forLiveBlocks<STRIDED>(blockIdx.x, gridDim.x, numBlocks,   // (one block per workgroup unless the world is sharded)
                   [&](uint32_t blk) { return !blockLive || blk + 1u >= numBlocks || blockLive[blk] != 0u; },   // (the last block holds the dummy body: always visited)
                   [&](uint32_t blk) {
         integrateVelocitiesBody(blk * 256u + threadIdx.x, nb, dt, gPos, gVel, bCogInvMass, bRotIn, bPos, bRot, bLinVel, bAngVel, bForce, bTorque, gVelL, bodyOwner, bodyUsed, bodyTop,
@@ -1792,9 +1800,10 @@ __device__ __forceinline__ void manifoldKeysBody(const uint32_t blockId, const K
 __global__ __launch_bounds__(256) void k_manifold_keys(KeysArgs ka) { manifoldKeysBody(blockIdx.x, ka); }
 // k_integrate_forces and k_manifold_keys in one launch: neither reads what the other writes; the first `keyBlocks` workgroups take the keys (a chain of LDS and global
 // atomics: started first), the others stream the bodies behind them.
+template <bool STRIDED>
 __global__ __launch_bounds__(256) void k_forces_keys(uint32_t keyBlocks, ForcesArgs fa, KeysArgs ka) {
     if (blockIdx.x < keyBlocks) manifoldKeysBody(blockIdx.x, ka);
-    else integrateForcesBlocks(blockIdx.x - keyBlocks, gridDim.x - keyBlocks, fa);
+    else integrateForcesBlocks<STRIDED>(blockIdx.x - keyBlocks, gridDim.x - keyBlocks, fa);
 }
 __global__ __launch_bounds__(256) void k_manifold_place(uint32_t n, const StepScalars* __restrict__ sc, const uint32_t* __restrict__ keys, const uint32_t* __restrict__ ranks,
                                                         const uint32_t* __restrict__ keyCount, uint32_t* __restrict__ perm) {
