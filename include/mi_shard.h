@@ -25,6 +25,12 @@
  * migrate whole; ghost_margin then has to cover an island's reach as well.  Heightmap terrain is static and replicated (a collider of a
  * body this rank does not simulate takes no part in it); cloths do not interact with rigid bodies, every rank steps all of them identically.
  *
+ * Cost of the replicated scene.  A rank HOLDS every body (memory is O(scene) per rank) but its per-body and per-collider passes visit only the blocks of 256 in which it
+ * simulates something: per block the library keeps the step of its last activity or received record (classification and packing look at blocks active within the last two
+ * steps) and whether a body in it is simulated now or was in the previous step (the integrators, the collider pass).  One GPU as the middle rank of an 8-tile, 2 M-body scene
+ * steps 8.5 % slower than the 262 144-body world alone.  Anything that moves bodies behind the flags' back — a re-upload, a restore, states written from outside,
+ * new borders — makes every block count as active for the next step.
+ *
  * Transport.  Either the library's own: RCCL point-to-point (ncclSend / ncclRecv in one group per step, on the world's stream,
  * fixed-size messages so that no host read-back sits between the step and the exchange) — mi_shard_get_unique_id on rank 0,
  * distribute the 128 bytes by any means, mi_world_shard_attach_rccl everywhere.  Or the caller's: mi_world_shard_export /
