@@ -1,6 +1,6 @@
 """Development: what a rank's step costs as the REPLICATED scene grows (weak scaling without the transport): one GPU plays the middle
 tile of 1, 2, 4, 8 x-slabs of a pile 128*R x 16 x 128; the tile itself always holds ~262 144 bodies.  Prints per-stage times."""
-import json, sys, time
+import json, os, sys, time
 import numpy as np
 sys.path.insert(0, ".")
 import torch; torch.cuda.set_device(0)
@@ -13,7 +13,7 @@ for R in [int(x) for x in (sys.argv[1:] or ["1", "2", "4", "8"])]:
     w = sc.populate(mi.create_world(0))
     if R > 1:
         desc = sharding.tile_grid(sc, R, 1, 2.5)
-        sw = sharding.ShardedWorld(w, desc, R // 2, "local")
+        sw = sharding.ShardedWorld(w, desc, int(os.environ.get("WEAK_RANK") or R // 2), "local")   # (WEAK_RANK: another tile than the middle one, e.g. 0: the tile at the start of every array)
     s = sc.settings()
     for _ in range(240): w.step_fixed(s, sc.dt, 1)
     w.set_stage_timing(1)

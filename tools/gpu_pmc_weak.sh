@@ -1,9 +1,9 @@
 #!/bin/bash
 # dev helper: per-kernel PMC counters (one pass per counter) of the middle tile of an R-tile replicated pile against the single world (tools/exp_weak.py R)
 ulimit -c 0; mkdir -p gpurun_out; export TMPDIR=/tmp
-for R in 1 8; do for C in ${COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
+for R in ${RS:-1 8}; do for C in ${COUNTERS:-FETCH_SIZE WRITE_SIZE}; do
   RAW=/tmp/pmcw_${R}_$C; rm -rf $RAW; mkdir -p $RAW
-  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $RAW -o p -- python tools/exp_weak.py $R > /dev/null 2>&1
+  timeout 600 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $RAW -o p -- env WEAK_RANK=${WEAK_RANK:-} python tools/exp_weak.py $R > /dev/null 2>&1
   python - "$RAW" "$R" "$C" <<'PY'
 import csv, glob, sys, collections
 raw, R, C = sys.argv[1:]

@@ -5,7 +5,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 export R=${1:-8}
 RAW=/tmp/prof_tlw; rm -rf $RAW; mkdir -p $RAW
-timeout 600 rocprofv3 --kernel-trace --output-format csv -d $RAW -o tl -- python tools/exp_weak.py $R > gpurun_out/tlw.log 2>&1
+WEAK_RANK=${WEAK_RANK:-} timeout 600 rocprofv3 --kernel-trace --output-format csv -d $RAW -o tl -- python tools/exp_weak.py $R > gpurun_out/tlw.log 2>&1
 tail -2 gpurun_out/tlw.log
 python - <<'PY'
 import csv, glob
