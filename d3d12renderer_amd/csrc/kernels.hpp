@@ -1213,13 +1213,19 @@ __global__ __launch_bounds__(256) void k_narrow(uint32_t scanLen, uint32_t queue
 
 __global__ __launch_bounds__(256) void k_narrow_clip(uint32_t queueRegion, const StepScalars* __restrict__ sc, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
                                                      const float4* __restrict__ wShape, const BoxHit* __restrict__ boxQueue,
-                                                     uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints, const Shards* __restrict__ queueShards) {
+                                                     uint64_t* __restrict__ npPacked, float4* __restrict__ npNormal, float4* __restrict__ npPoints, const Shards* __restrict__ queueShards,
+                                                     // non-null: workgroup 0 runs pairFinishStats (centre statistics -> next sweep axis, the NEXT step's grid) beside the clipping — this kernel computes,
+                                                     // the statistics are a dozen dependent rounds of loads: beside k_emit_manifolds' atomics every round took several microseconds and that one
+                                                     // workgroup became the kernel's tail in a sharded world (8 192 partial rows: 74 instead of 57 us)
+                                                     const Shards* __restrict__ statsShards, StepScalars* statsSc, uint32_t statsNc, uint32_t statsBlocks, const unsigned long long* __restrict__ statsPartials,
+                                                     const int* __restrict__ statsBounds, GridParams* statsGridNext, uint32_t statsCellCap, const uint8_t* __restrict__ statsCbLive) {
+    if (statsShards && blockIdx.x == 0u) { pairFinishStats(statsShards, statsSc, statsNc, statsBlocks, statsPartials, statsBounds, statsGridNext, statsCellCap, statsCbLive); return; }
 #ifdef MI_CLIP_PINGPONG
     __shared__ float4 polyMem[2 * kLdsPolyVerts * kLdsPolyStride];   // 64 KiB: two clip polygons per lane, [vertex][lane]
 #else
     __shared__ float4 polyMem[kLdsPolyVerts * kLdsPolyStride];       // 32 KiB: ONE clip polygon per lane, [vertex][lane], clipped in place (narrow.hpp clipPolygonLds)
 #endif
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t t = (blockIdx.x - (statsShards ? 1u : 0u)) * blockDim.x + threadIdx.x;
     const uint32_t q = t / queueRegion, idx = t % queueRegion;       // queueRegion is a multiple of 256: a workgroup never straddles queues
     if (q >= kBoxQueues || idx >= queueShards->c[q].boxHits) return;
     const uint64_t* __restrict__ pairKeys = sc->partitioned ? pairsB : pairsA;

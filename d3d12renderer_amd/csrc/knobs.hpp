@@ -29,6 +29,7 @@ struct Knobs {
     bool fuseWorld = true;              // MI_FUSE_WORLD=0: k_world_colliders as its own launch
     bool fuseLarge = true;              // MI_FUSE_LARGE=0: k_bp_pairs_grid and k_bp_pairs_large as two launches (otherwise k_bp_pairs runs the large pass in the first workgroups of the grid pass's launch)
     bool finishInNarrow = true;         // MI_FINISH_IN_NARROW=0: k_pair_finish as its own launch also in steps without k_pair_partition
+    bool statsInEmit = true;            // MI_STATS_IN_EMIT=0: the centre statistics / next grid in k_pair_finish, on the step's critical path, instead of an extra workgroup of k_narrow_clip (development)
     bool fuseKeys = true;               // MI_FUSE_KEYS=0: k_integrate_forces and k_manifold_keys as two launches (otherwise k_forces_keys)
     bool skipPartition = true;          // MI_SKIP_PARTITION=0: always launch k_pair_partition
     int gjkWave = -1;                   // MI_GJK_WAVE=0 / 1: force the lane / wave GJK variant
@@ -76,7 +77,7 @@ struct Knobs {
         k.fuseReset = !off("MI_FUSE_RESET");
         k.graph = str("MI_GRAPH"); k.graphMaxColliders = (uint32_t)num("MI_GRAPH_MAX_COLLIDERS", k.graphMaxColliders);
         k.graphDebug = set("MI_GRAPH_DEBUG"); k.graphNoEvents = set("MI_GRAPH_NOEVENTS"); k.graphNoCapture = set("MI_GRAPH_NOCAPTURE");
-        k.fuseWorld = !off("MI_FUSE_WORLD"); k.fuseLarge = !off("MI_FUSE_LARGE"); k.skipPartition = !off("MI_SKIP_PARTITION"); k.finishInNarrow = !off("MI_FINISH_IN_NARROW"); k.fuseKeys = !off("MI_FUSE_KEYS"); k.hmStash = !off("MI_HM_STASH");
+        k.fuseWorld = !off("MI_FUSE_WORLD"); k.fuseLarge = !off("MI_FUSE_LARGE"); k.skipPartition = !off("MI_SKIP_PARTITION"); k.finishInNarrow = !off("MI_FINISH_IN_NARROW"); k.fuseKeys = !off("MI_FUSE_KEYS"); k.statsInEmit = !off("MI_STATS_IN_EMIT"); k.hmStash = !off("MI_HM_STASH");
         if (const char* v = std::getenv("MI_GJK_WAVE")) k.gjkWave = atoi(v);
         k.round0InEmit = !off("MI_ROUND0_EMIT"); k.colorTail = !off("MI_COLOR_TAIL"); k.colorRoundsMax = (uint32_t)num("MI_COLOR_ROUNDS_MAX", 0); k.colorTailMargin = (uint32_t)num("MI_COLOR_TAIL_MARGIN", k.colorTailMargin);
         k.colorMargin = (uint32_t)num("MI_COLOR_MARGIN", k.colorMargin); k.xcdNoSort = set("MI_XCD_NOSORT"); k.xcdStats = set("MI_XCD_STATS"); k.xcdSwizzle = str("MI_XCD_SWIZZLE") == "1";

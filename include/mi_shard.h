@@ -28,7 +28,7 @@
  * Cost of the replicated scene.  A rank HOLDS every body (memory is O(scene) per rank) but its per-body and per-collider passes visit only the blocks of 256 in which it
  * simulates something: per block the library keeps the step of its last activity or received record (classification and packing look at blocks active within the last two
  * steps) and whether a body in it is simulated now or was in the previous step (the integrators, the collider pass).  One GPU as the middle rank of an 8-tile, 2 M-body scene
- * steps 8.9 % slower than the 262 144-body world alone.  Anything that moves bodies behind the flags' back — a re-upload, a restore, states written from outside,
+ * steps 7.4 % slower than the 262 144-body world alone.  Anything that moves bodies behind the flags' back — a re-upload, a restore, states written from outside,
  * new borders — makes every block count as active for the next step.
  *
  * Transport.  Either the library's own: RCCL point-to-point (ncclSend / ncclRecv in one group per step, on the world's stream,
