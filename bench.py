@@ -311,6 +311,11 @@ def main():
         sw.step(settings, dt)
         total_dev_ms += sw.world.stage_times()["total"] / 3.0
     total_dev_ms *= args.steps           # (kept as a sum over the timed steps' count: the fields below divide by args.steps)
+    # the same number of steps once more with the events of rounds 2-4 (whole step + solve stage): what the protocol change of round 5 is worth on THIS box, in the line itself
+    elapsed_l2 = None
+    if world_size == 1:
+        elapsed_l2, _, acc_l2, _ = timed_region(sw, settings, dt, args.steps, barrier)
+        total_dev_ms_l2 = acc_l2.get("total", 0.0)
     sw.world.set_stage_timing(TIMED_LEVEL)
 
     # ---- second state: the same pile at rest (1500 steps in total)
@@ -383,12 +388,25 @@ def main():
             else:
                 traffic_note += f" (--pmc asked for but not measured: {note})"
         b_step = step_algorithmic_bytes(counts, args.iterations)
+        frac = achieved / HBM_PEAK_GBPS
+        traffic_frac = (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBPS) if traffic and avg_launch_s > 0 else None
+        # the serial chain of one launch: colours x sweeps hops (a body of maximal degree is a chain by itself: DESIGN.md §4); a launch covers all sweeps of a step
+        sweeps_per_launch = args.iterations / max(launches_per_step, 1)
+        hops = counts["num_colors"] * sweeps_per_launch
         roofline = {
-            "bound": "hbm", "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBPS, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBPS, "achievable": HBM_ACHIEVABLE_GBPS, "traffic": traffic,
+            # the memory interface is the resource this kernel class is priced against; when the algorithmic fraction exceeds what the counters see crossing it
+            # (bytes that stay in LDS / L2), bytes are not what bounds the launch: the chain below is
+            "bound": "latency (dependency chain)" if (traffic_frac is not None and frac > traffic_frac) else "hbm", "bound_resource": "hbm",
+            "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": frac, "frac_is_algorithmic": True, "frac_of_achievable": achieved / HBM_ACHIEVABLE_GBPS, "achievable": HBM_ACHIEVABLE_GBPS, "traffic": traffic,
             # what crosses the HBM interface is LESS than the algorithmic bytes (impulses stay in LDS, ~95 % of the body hand-overs in L2):
             # `frac` says how fast the algorithmic work is done, `traffic_frac` how busy the memory interface really is
-            "traffic_frac": (traffic / avg_launch_s / 1e9 / HBM_PEAK_GBPS) if traffic and avg_launch_s > 0 else None,
+            "traffic_frac": traffic_frac,
+            "chain": {"hops": hops, "colors": counts["num_colors"], "sweeps_per_launch": sweeps_per_launch,
+                      "us_per_hop": (avg_launch_s * 1e6 / hops) if hops else None,
+                      "round_trip_us": _committed_round_trip_us(),
+                      "note": "hops = colours x sweeps of one launch; us_per_hop = this run's launch time / hops; round_trip_us = 'body loads issued -> first tag check' of the "
+                              "committed per-visit stamps (profiles/solver_hop.json; a development build, not this run)"},
             "traffic_note": traffic_note, "traffic_source": traffic_source,
             "avg_launch_us": avg_launch_s * 1e6, "launches_per_step": launches_per_step,
             "algorithmic_bytes_per_launch": alg_per_launch,
@@ -429,6 +447,11 @@ def main():
             "step_modes_timed": {"internal_steps": mode1[0] - mode0[0], "speculative": mode1[1] - mode0[1], "synchronous_reruns": mode1[2] - mode0[2],
                                  "note": "a speculative step sizes its launches from the previous step and reads back once; one whose bounds did not hold is re-run synchronously (counted here, timed like any step)"},
             "device_ms_per_step": total_dev_ms / args.steps,
+            "device_ms_per_step_note": "mean of a 3-step sample taken AFTER the timed region with whole-step events on (not the timed steps themselves)",
+            "timed_region_events": "solver launch only (since r05; rounds 2-4 also bracketed the whole step: two more ~5 us gaps per step)",
+            "with_whole_step_events": ({"value": args.steps / elapsed_l2, "ms_per_step": elapsed_l2 / args.steps * 1e3, "device_ms_per_step": total_dev_ms_l2 / args.steps,
+                                        "note": "the same number of steps timed again right after the 3-step samples, with the rounds-2-4 event set (whole step + solver): compare with `value` for what measuring less is worth"}
+                                       if elapsed_l2 else None),
             "solver_kind": sw.world.solver_kind(),
         }
         if per_rank is not None:
@@ -496,6 +519,16 @@ def _measured_traffic(kernel, args):
     b = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0
     return b, (f"(2 x FETCH_SIZE {vals['FETCH_SIZE']:.0f} KiB + WRITE_SIZE {vals['WRITE_SIZE']:.0f} KiB) per launch, mean of the kernel's last {args.steps + 3} dispatches in two separate "
                f"rocprofv3 --pmc passes of this command (gfx950: FETCH_SIZE reports half of a wide coalesced read stream)")
+
+
+def _committed_round_trip_us():
+    """'body loads issued -> first tag check' of the persistent solver's per-visit wall-clock stamps (a -DMI_DBG_TIMELINE build, tools/gpu_timeline2.sh), as committed
+    in profiles/solver_hop.json; None if the file is absent."""
+    p = ROOT / "profiles" / "solver_hop.json"
+    try:
+        return json.loads(p.read_text())["issue_to_first_check_us"]
+    except Exception:   # noqa: BLE001
+        return None
 
 
 def _scaled_traffic(kernel, contact_sweeps_per_launch):

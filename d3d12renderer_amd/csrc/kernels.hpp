@@ -456,6 +456,9 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
     __shared__ unsigned long long sm[4][kAxisSums];
     __shared__ uint32_t hist[256];
     __shared__ int sb[4][6];
+  // the step's sweep axis: written by the first workgroup whatever blocks it goes on to visit (a sharded rank that simulates nothing in collider block 0 skips that block's
+  // body below; the axis word must follow the exchange's axisDev all the same, or this rank orients its pairs along a stale axis)
+  if (cTypeBody && blockIdx.x == 0 && threadIdx.x == 0) sc->axisCur = axisDev ? *axisDev : axisCur;
   // (one workgroup per collider block unless the world is sharded: then a collider block is skipped when nothing is simulated, now or in the previous step, in any body
   // block it refers to — its rows already say "dead", its partial results are empty)
   forLiveBlocks<STRIDED>(blockIdx.x, gridDim.x, (nc + 255u) / 256u, [&](uint32_t cb) {
@@ -470,7 +473,6 @@ __global__ __launch_bounds__(256) void k_bp_prepare(uint32_t nc, const float4* _
     hist[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t i = cb * 256 + threadIdx.x;
-    if (cTypeBody && i == 0) { sc->axisCur = axisDev ? *axisDev : axisCur; }
     if (cTypeBody && bodyActive) {
         // sharded world: a workgroup whose colliders are all dead now and were dead in the previous step (7 of 8 workgroups of an 8-tile scene) has nothing to
         // compute, nothing to reduce and nothing to rewrite but its own (empty) partial results
@@ -2211,15 +2213,9 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
         storeStream(row + 0 * 64, f4(rA, effN));
         storeStream(row + 1 * 64, f4(rB, effT));
         storeStream(row + 2 * 64, f4(t, bias));
-#ifdef MI_NO_DIET
-        storeStream(row + 3 * 64, make_float4(tA.x, tA.y, tA.z, tB.x));
-        storeStream(row + 4 * 64, make_float4(tB.y, tB.z, nA.x, nA.y));
-        storeStream(row + 5 * 64, make_float4(nA.z, nB.x, nB.y, nB.z));
-#else   // body A's angular rows are stored NEGATED: the solver adds (-tA) * lambda instead of subtracting tA * lambda (the same IEEE result), and the sign flips leave its dependency chain
         storeStream(row + 3 * 64, make_float4(-tA.x, -tA.y, -tA.z, tB.x));
         storeStream(row + 4 * 64, make_float4(tB.y, tB.z, -nA.x, -nA.y));
         storeStream(row + 5 * 64, make_float4(-nA.z, nB.x, nB.y, nB.z));
-#endif
         if (imp) imp[(ctBase + k) * 64u + lane] = make_float4(0.f, 0.f, 0.f, 0.f);   // no warm start (constraints.cpp:3312-3313); sweep tag 0 (null: the solver keeps the impulses in LDS)
     }
 }
@@ -2230,11 +2226,7 @@ struct ContactRows { float4 r[kRows]; float4 imp; };   // imp = (normal, tangent
 
 __device__ __forceinline__ void solveOne(const ContactRows& c, const float4 nf, float2& im, float imA, float imB, V3& vA, V3& wA, V3& vB, V3& wB) {
     V3 rA = xyz(c.r[0]), rB = xyz(c.r[1]), t = xyz(c.r[2]), n = xyz(nf);
-#ifdef MI_NO_DIET
-    V3 tA(-c.r[3].x, -c.r[3].y, -c.r[3].z), tB(c.r[3].w, c.r[4].x, c.r[4].y), nA(-c.r[4].z, -c.r[4].w, -c.r[5].x), nB(c.r[5].y, c.r[5].z, c.r[5].w);   // (tA, nA below are the NEGATED vectors, as the rows now store them)
-#else
     V3 tA(c.r[3].x, c.r[3].y, c.r[3].z), tB(c.r[3].w, c.r[4].x, c.r[4].y), nA(c.r[4].z, c.r[4].w, c.r[5].x), nB(c.r[5].y, c.r[5].z, c.r[5].w);   // tA, nA: negated (k_contact_init)
-#endif
     {
         V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
         V3 rel = avB - avA;
@@ -2276,16 +2268,11 @@ __device__ __forceinline__ P3 pcross(const P3& a, const P3& b) { P3 r; r.x = a.y
 __device__ __forceinline__ void solveOnePk(const ContactRows& c, const float4 nf, float2& im, const f32x2 sMass /* (-imA, imB) */, P3& v, P3& w) {
     const V3 t = xyz(c.r[2]), n = xyz(nf);
     P3 r; r.x = pk2(c.r[0].x, c.r[1].x); r.y = pk2(c.r[0].y, c.r[1].y); r.z = pk2(c.r[0].z, c.r[1].z);
-#ifdef MI_NO_DIET
-    P3 T; T.x = pk2(-c.r[3].x, c.r[3].w); T.y = pk2(-c.r[3].y, c.r[4].x); T.z = pk2(-c.r[3].z, c.r[4].y);
-    P3 N; N.x = pk2(-c.r[4].z, c.r[5].y); N.y = pk2(-c.r[4].w, c.r[5].z); N.z = pk2(-c.r[5].x, c.r[5].w);
-#else   // (body A's halves come negated from k_contact_init.  They pass through an empty asm: without the sign flip in between, the optimiser merges these element picks into
         // 4-wide shuffles that the backend then legalises THROUGH SCRATCH MEMORY — 16 bytes per contact stored and re-loaded on the tile's dependency chain)
     float tAx = c.r[3].x, tAy = c.r[3].y, tAz = c.r[3].z, nAx = c.r[4].z, nAy = c.r[4].w, nAz = c.r[5].x;
     asm("" : "+v"(tAx)); asm("" : "+v"(tAy)); asm("" : "+v"(tAz)); asm("" : "+v"(nAx)); asm("" : "+v"(nAy)); asm("" : "+v"(nAz));
     P3 T; T.x = pk2(tAx, c.r[3].w); T.y = pk2(tAy, c.r[4].x); T.z = pk2(tAz, c.r[4].y);
     P3 N; N.x = pk2(nAx, c.r[5].y); N.y = pk2(nAy, c.r[5].z); N.z = pk2(nAz, c.r[5].w);
-#endif
     {
         P3 cr = pcross(w, r);
         f32x2 ax = v.x + cr.x, ay = v.y + cr.y, az = v.z + cr.z;
@@ -2315,7 +2302,6 @@ __device__ __forceinline__ void solveOnePk(const ContactRows& c, const float4 nf
     }
 }
 
-#ifndef MI_NO_DIET
 // The rows of one contact as the packed update wants them — (body A, body B) side by side in 64-bit register pairs — built BEFORE a tile waits for its bodies (packRows), and
 // pinned there: the register moves that line the halves up then happen while the body loads are in flight, not between the bodies' arrival and the publish.
 struct PkRows { f32x2 rx, ry, rz, Tx, Ty, Tz, Nx, Ny, Nz; float tx, ty, tz, effN, effT, bias; };
@@ -2370,7 +2356,6 @@ __device__ __forceinline__ void solveOnePkRows(const PkRows& c, const float4 nf,
         w.x = w.x + c.Nx * lambda; w.y = w.y + c.Ny * lambda; w.z = w.z + c.Nz * lambda;
     }
 }
-#endif
 
 // One tile, CNT contacts per manifold.  Latency structure: a colour launch has < 1 wave per SIMD, so it is bound by
 // dependent-load depth: all constraint rows are requested up front (they do not depend on the slot metadata), the
@@ -2523,7 +2508,6 @@ struct PairBody {   // addresses this lane touches in pass 0 / pass 1 for one bo
 };
 // after both passes landed: r0 / r1 = what this lane loaded in pass 0 / 1 -> this lane's own (g0, g1)
 __device__ __forceinline__ void pairGather(bool odd, f32x4 r0, f32x4 r1, f32x4& g0, f32x4& g1);   // (below)
-#ifndef MI_NO_DIET
 // The lane-pair exchange of pairGather and of the publish in ONE instruction per word:  y0 = even lane ? x0 : the partner's x1,  y1 = odd lane ? x1 : the partner's x0
 // (v_cndmask_b32 whose first source is DPP quad-permuted [1,0,3,2]).  The compiler's own code for `odd ? swz1(a) : b` is v_mov_b32_dpp + v_cndmask_b32_e64 — gfx9 has no
 // VOP3 DPP, and it keeps the lane parity in an SGPR pair, not in VCC — i.e. three instructions per word where pairGather / storePair* need both directions; these sit between
@@ -2544,15 +2528,8 @@ __device__ __forceinline__ void pairExchange(const f32x4 x0, const f32x4 x1, f32
                  : "v"(x0.x), "v"(x0.y), "v"(x0.z), "v"(x0.w), "v"(x1.x), "v"(x1.y), "v"(x1.z), "v"(x1.w) : "vcc", "scc");
     y0.x = a0; y0.y = a1; y0.z = a2; y0.w = a3; y1.x = b0; y1.y = b1; y1.z = b2; y1.w = b3;
 }
-#endif
 __device__ __forceinline__ void pairGather(bool odd, f32x4 r0, f32x4 r1, f32x4& g0, f32x4& g1) {
-#ifdef MI_NO_DIET
-    f32x4 p0 = swz1(r0), p1 = swz1(r1);
-    g0 = odd ? p1 : r0;
-    g1 = odd ? r1 : p0;
-#else
     (void)odd; pairExchange(r0, r1, g0, g1);
-#endif
 }
 __device__ __forceinline__ void loadPair4Sc1(const PairBody& A, const PairBody& B, f32x4& a0, f32x4& a1, f32x4& b0, f32x4& b1) {
     asm volatile("global_load_dwordx4 %0, %4, off" MI_SC_LOAD "\n\tglobal_load_dwordx4 %1, %5, off" MI_SC_LOAD "\n\t"
@@ -2594,7 +2571,6 @@ __device__ __forceinline__ void storePairXcd(const PairBody& X, bool odd, bool n
     if (n1 && !l1) storeGranuleSc1(X.q1, d1);
 }
 
-#ifndef MI_NO_DIET
 // the four stores of one body slot under precomputed EXEC masks (plain / write-through for pass 0, then for pass 1); the wave is fully active on entry and on exit
 __device__ __forceinline__ void storePairMasked(float4* q0, float4* q1, f32x4 d0, f32x4 d1, unsigned long long plain0, unsigned long long sc0, unsigned long long plain1, unsigned long long sc1_) {
     asm volatile("s_mov_b64 exec, %4\n\tglobal_store_dwordx4 %0, %2, off\n\t"
@@ -2604,11 +2580,19 @@ __device__ __forceinline__ void storePairMasked(float4* q0, float4* q1, f32x4 d0
                  "s_mov_b64 exec, -1"
                  : : "v"(q0), "v"(q1), "v"(d0), "v"(d1), "s"(plain0), "s"(sc0), "s"(plain1), "s"(sc1_) : "memory");
 }
-#endif
 // LDSIMP: the accumulated impulses live in LDS (`ldsImp`, [k][lane]) because the same wave runs this tile in every sweep
 // (k_contact_solve_persist); otherwise they travel between sweeps as tagged granules in `imp`.
 #ifndef MI_LATE_PREFETCH
 #define MI_LATE_PREFETCH 0
+#endif
+#ifdef MI_DBG_KNOCKOUT
+// development (knock-out harness, tools/gpu_knockout.sh): the host launches k_contact_solve_persist a SECOND time per step on scratch copies of the velocity arrays with parts
+// of a tile visit removed, to price them: bit 0 = no row stream at all (nothing is prefetched; the update runs on whatever the registers hold — the tag protocol does not
+// depend on the values), bit 1 = every tile's rows come from contact-tile 0 (the same loads in the queue, served by the L2), bit 2 = no waiting for tags.
+__device__ uint32_t g_dbgKnock = 0u;
+#define MI_KNOCK(bit) ((g_dbgKnockLocal >> (bit)) & 1u)
+#else
+#define MI_KNOCK(bit) 0u
 #endif
 #ifdef MI_DBG_TIMELINE
 __device__ unsigned long long* g_dbgTimeline = nullptr;   // development: [wave][visit][8] wall-clock stamps of k_contact_solve_persist
@@ -2619,7 +2603,8 @@ __device__ __forceinline__ void dbgStamp(unsigned long long* rec, int i) { if (r
 #endif
 // Hook of processTile: early() runs right after the body loads were issued and returns how many loads it issued itself (they
 // may stay in flight across the first tag check); late(waited) runs once the tags are satisfied, waited = the tile had to poll.
-struct NoHook { enum : bool { kPinRows = false }; unsigned long long* rec = nullptr; __device__ __forceinline__ uint32_t early() const { return 0u; } __device__ __forceinline__ void late(bool) const {} };
+struct NoHook { enum : bool { kPinRows = false }; unsigned long long* rec = nullptr; __device__ __forceinline__ uint32_t early() const { return 0u; } __device__ __forceinline__ void late(bool) const {}
+                __device__ __forceinline__ bool knockNoWait() const { return false; } };
 // wait until at most n of the newest vector-memory operations are outstanding (n = a count the caller issued itself)
 __device__ __forceinline__ void waitVmcnt(uint32_t n) {
     switch (n) {
@@ -2652,129 +2637,7 @@ __device__ __forceinline__ void flowTile(uint32_t tile, uint32_t ctBase, uint32_
 }
 // The tile proper, from data already requested (flowTile) or prefetched (k_contact_solve_persist): wait for the bodies (and the
 // impulse granules), solve, publish.
-#ifdef MI_NO_DIET
-template <int CNT, bool LDSIMP, bool XCD, class Hook>
-__device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint32_t it, const uint4 meta, const float4 nf, const float2 mass, const ContactRows* c,
-                                            float4* imp, float4* gVel, StepScalars* sc, float2* ldsImp, float4* gVelL, Hook hook) {
-    const uint32_t bA = meta.x, bB = meta.y, pk = meta.z;
-    const float imA = mass.x, imB = mass.y;
-    const bool valid = meta.w != 0u;
-    // XCD: bits 8 / 9 of meta.w = body A / B is touched from this XCD only -> it lives in the cached copy and is handed
-    // over through this XCD's L2 (plain stores, L1-bypassing loads) instead of write-through transactions to memory
-#ifdef MI_DBG_ALLLOCAL
-    const bool locA = XCD, locB = XCD;   // development knock-out: every body through the L2 path (results are garbage)
-#else
-    const bool locA = XCD && (meta.w & 0x100u) != 0u, locB = XCD && (meta.w & 0x200u) != 0u;
-#endif
-    const bool live = valid && (imA != 0.f || imB != 0.f);
-    const uint32_t degA = (pk >> 7) & 127u, degB = (pk >> 21) & 127u;
-    const uint32_t expA = it * degA + (pk & 127u), expB = it * degB + ((pk >> 14) & 127u);
-    const bool needA = valid && degA != 0u, needB = valid && degB != 0u;
-    float4* pA = (locA ? gVelL : gVel) + 2 * (size_t)bA; float4* pB = (locB ? gVelL : gVel) + 2 * (size_t)bB;
-    float4* pI = imp + (size_t)ctBase * 64u + lane;
-    // Second (and last) memory round trip: the accumulated impulses (written by the wave that ran this tile in the
-    // previous sweep, tag = sweeps completed) and the two bodies, all agent-scope; the wait also lands the rows.
-    f32x4 ig[CNT], a0, a1, b0, b1;
-    const bool odd = (lane & 1u) != 0u;
-    const PairBody PA(pA, odd), PB(pB, odd);
-    if (!LDSIMP) {
-#pragma unroll
-        for (int k = 0; k < CNT; ++k) issueGranuleSc1(pI + (size_t)k * 64u, ig[k]);
-    }
-    {
-        f32x4 ra0, ra1, rb0, rb1;
-        issuePair4Sc1(PA, PB, ra0, ra1, rb0, rb1);
-        MI_STAMP(hook.rec, 2);
-        waitVmcnt(hook.early());   // the hook's loads are younger than the body loads: they may stay in flight
-        landed(ra0); landed(ra1); landed(rb0); landed(rb1);
-        pairGather(odd, ra0, ra1, a0, a1);
-        pairGather(odd, rb0, rb1, b0, b1);
-    }
-    if (!LDSIMP) {
-#pragma unroll
-        for (int k = 0; k < CNT; ++k) landed(ig[k]);
-    } else {
-#pragma unroll
-        for (int k = 0; k < CNT; ++k) { float2 v = ldsImp[k * 64 + lane]; ig[k].x = v.x; ig[k].y = v.y; ig[k].z = 0.f; ig[k].w = 0.f; }
-    }
-    bool okA = !needA || (__float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA);
-    bool okB = !needB || (__float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB);
-    bool okI = true;
-    if (!LDSIMP) {
-#pragma unroll
-        for (int k = 0; k < CNT; ++k) okI = okI && (!live || __float_as_uint(ig[k].z) == it);
-    }
-    uint32_t budget = kSpinBudget;
-#ifdef MI_DBG_NOWAIT
-    okA = okB = okI = true;   // development knock-out: timing without dependency waits (results are garbage)
-#endif
-    const bool polled = __ballot(!(okA && okB && okI)) != 0ull;
-    f32x4 ra0 = a0, ra1 = a1, rb0 = b0, rb1 = b1;   // raw poll destinations
-    MI_STAMP(hook.rec, 3);
-    while (__ballot(!(okA && okB && okI)) != 0ull) {   // tight polling measured fastest: only the pairs still waiting re-load
-        // both lanes of a pair must poll together; the partner flags are exchanged OUTSIDE any short-circuit so every lane
-        // takes part in the swap (inside `!okA || swap(...)` the swap would run with only the ready lanes active)
-        const uint32_t partnerOkA = swz1(okA ? 1u : 0u), partnerOkB = swz1(okB ? 1u : 0u);
-        bool pollA = !okA || partnerOkA == 0u, pollB = !okB || partnerOkB == 0u;
-        // both bodies' polls are in flight together: one round trip per iteration, not two (the raw registers are only read by the
-        // lanes that just loaded into them)
-        if (pollA) issuePair2Sc1(PA, ra0, ra1);
-        if (pollB) issuePair2Sc1(PB, rb0, rb1);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        landed(ra0); landed(ra1); landed(rb0); landed(rb1);
-        if (pollA) {
-            f32x4 g0, g1;
-            pairGather(odd, ra0, ra1, g0, g1);
-            if (!okA) { a0 = g0; a1 = g1; okA = __float_as_uint(a0.w) == expA && __float_as_uint(a1.w) == expA; }
-        }
-        if (pollB) {
-            f32x4 g0, g1;
-            pairGather(odd, rb0, rb1, g0, g1);
-            if (!okB) { b0 = g0; b1 = g1; okB = __float_as_uint(b0.w) == expB && __float_as_uint(b1.w) == expB; }
-        }
-        if (!okI) {
-            okI = true;
-#pragma unroll
-            for (int k = 0; k < CNT; ++k) { loadGranuleSc1(pI + (size_t)k * 64u, ig[k]); okI = okI && __float_as_uint(ig[k].z) == it; }
-        }
-        if (--budget == 0u) { sc->solveError = 1u; break; }
-    }
-    hook.late(polled);
-    MI_STAMP(hook.rec, 4);
-    P3 pv, pw;
-    pv.x = pk2(a0.x, b0.x); pv.y = pk2(a0.y, b0.y); pv.z = pk2(a0.z, b0.z);
-    pw.x = pk2(a1.x, b1.x); pw.y = pk2(a1.y, b1.y); pw.z = pk2(a1.z, b1.z);
-    const f32x2 sMass = pk2(-imA, imB);
-    float2 out[CNT];
-#pragma unroll
-    for (int k = 0; k < CNT; ++k) {
-        float2 im = make_float2(ig[k].x, ig[k].y);
-        solveOnePk(c[k], nf, im, sMass, pv, pw);
-        out[k] = im;
-    }
-    V3 vA(pv.x.x, pv.y.x, pv.z.x), wA(pw.x.x, pw.y.x, pw.z.x), vB(pv.x.y, pv.y.y, pv.z.y), wB(pw.x.y, pw.y.y, pw.z.y);
-    // publish: bodies first (they are on the dependency chain), then the impulses; nothing to wait for afterwards
-    {
-        float tA = __uint_as_float(expA + 1u), tB = __uint_as_float(expB + 1u);
-        f32x4 hA0 = {vA.x, vA.y, vA.z, tA}, hA1 = {wA.x, wA.y, wA.z, tA}, hB0 = {vB.x, vB.y, vB.z, tB}, hB1 = {wB.x, wB.y, wB.z, tB};
-        MI_STAMP(hook.rec, 5);
-        if (XCD) { storePairXcd(PA, odd, needA, locA, hA0, hA1); storePairXcd(PB, odd, needB, locB, hB0, hB1); }
-        else { storePairSc1(PA, odd, needA, hA0, hA1); storePairSc1(PB, odd, needB, hB0, hB1); }
-    }
-    if (LDSIMP) {
-#pragma unroll
-        for (int k = 0; k < CNT; ++k) ldsImp[k * 64 + lane] = out[k];
-    } else if (live) {
-        float t = __uint_as_float(it + 1u);
-#pragma unroll
-        for (int k = 0; k < CNT; ++k) {
-            f32x4 g = {out[k].x, out[k].y, t, 0.f};
-            storeGranuleSc1(pI + (size_t)k * 64u, g);
-        }
-    }
-}
-#else
-// The tile proper (default build).  Same order of loads, waits, arithmetic and stores as the MI_NO_DIET form below; what differs is how few instructions sit between the
+// The tile proper.  What shapes it is how few instructions sit between the
 // arrival of a tile's bodies and its publish, the part of a visit that is on the dependency chain between tiles (~4 cycles per instruction at one wave per SIMD):
 //   * which of the lane pair's four stores per body slot take place, and with which cache policy, is known from the slot's constants: four EXEC masks per body are
 //     computed BEFORE the wait and the publish is four stores under `s_mov_b64 exec, mask` (was: the predicates recomputed and exchanged after the solve, ~12 per store);
@@ -2848,8 +2711,8 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
 #pragma unroll
             for (int k = 0; k < CNT; ++k) okI = okI && (!live || __float_as_uint(ig[k].z) == it);
         }
-#ifdef MI_DBG_NOWAIT
-        okA = okB = okI = true;   // development knock-out: timing without dependency waits (results are garbage)
+#ifdef MI_DBG_KNOCKOUT
+        if (hook.knockNoWait()) okA = okB = okI = true;   // development knock-out: timing without dependency waits (results are garbage)
 #endif
         if (__ballot(!(okA && okB && okI)) == 0ull) break;
         polled = true;
@@ -2906,7 +2769,6 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
         }
     }
 }
-#endif
 
 // Block b runs sweep itBase + b / numTiles of tile b % numTiles (numTiles = StepScalars::totalTiles; schedule order, colour-major): with no joints between the
 // sweeps ALL iterations are one launch, so the latency-bound small colours of sweep i overlap the bandwidth-bound large
@@ -3014,12 +2876,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
     // inline asm, after the explicit vmcnt(0) at the top of the next iteration.  (Compiler-allocated registers do not
     // work here: the allocator copies in-flight values around at loop boundaries.)
     uint4 nxMeta = make_uint4(0u, 0u, 0u, 0u); float4 nxNf = make_float4(0.f, 0.f, 0.f, 0.f); float2 nxMass = make_float2(0.f, 0.f);
+#ifdef MI_DBG_KNOCKOUT
+    const uint32_t g_dbgKnockLocal = __builtin_amdgcn_readfirstlane(g_dbgKnock);
+#endif
     auto fetchRows = [&](uint32_t slot) -> uint32_t {
-        const uint32_t ct = lDesc[3 * slot], cnt = lDesc[3 * slot + 1];
+        uint32_t ct = lDesc[3 * slot]; const uint32_t cnt = lDesc[3 * slot + 1];
+        if (MI_KNOCK(1)) ct = 0u;
         if (!METALDS) {
             const size_t at = (size_t)lTile[slot] * 64u + lane;
             nxMeta = XCD ? slotMetaW[at] : slotMeta[at]; nxNf = slotNormal[at]; nxMass = slotMass[at];
         }
+        if (MI_KNOCK(0)) return 0u;
         {
             const float4* row = rows + (size_t)ct * (kRows * 64u) + lane;   // row (k, r) of the tile at + (k * kRows + r) * 64
             if (0u < cnt) MI_ACC_LOAD(160, 161, 162, 163, row + 0u * 64u);
@@ -3097,10 +2964,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
             // queue behind the prefetch.  Measured slower — 0.68 vs 0.63 ms — the rows arriving late costs more; off.)
             struct Prefetch {
                 enum : bool { kPinRows = true };
-                decltype(fetchRows)& fetch; decltype(readRows)& read; ContactRows* cur; uint32_t cnt; uint32_t* crit; uint32_t next; bool more, critical, issued; unsigned long long* rec;
+                decltype(fetchRows)& fetch; decltype(readRows)& read; ContactRows* cur; uint32_t cnt; uint32_t* crit; uint32_t next; bool more, critical, issued; unsigned long long* rec; bool noWait;
+                __device__ __forceinline__ bool knockNoWait() const { return noWait; }
                 __device__ __forceinline__ uint32_t early() { read(cur, cnt); MI_STAMP(rec, 1); if (more && !critical) { issued = true; return fetch(next); } return 0u; }
                 __device__ __forceinline__ void late(bool waited) { if (more && !issued) (void)fetch(next); if (threadIdx.x == 0) *crit = waited ? 1u : 0u; }
-            } prefetch{fetchRows, readRows, cur, cnt, &lCrit[slot], nextSlot, more, MI_LATE_PREFETCH && lCrit[slot] != 0u, false, rec};
+            } prefetch{fetchRows, readRows, cur, cnt, &lCrit[slot], nextSlot, more, MI_LATE_PREFETCH && lCrit[slot] != 0u, false, rec, MI_KNOCK(2) != 0u};
             float2* li = lImp + (size_t)io * 64u;
             // (the contact count of THIS tile as a literal in each case: the row read-back's `if (k < cnt)` guards fold, and no row register is "defined on some paths only" —
             // such values were kept alive around the loop: 61 register copies at the top of every visit)

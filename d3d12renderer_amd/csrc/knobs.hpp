@@ -63,6 +63,7 @@ struct Knobs {
     bool shardAdaptive = true;          // MI_SHARD_ADAPTIVE=0: neighbour messages always at full capacity
     // ---- development dumps
     std::string timelineOut; uint64_t timelineStep = 3;   // MI_DBG_TIMELINE_OUT / _STEP (-DMI_DBG_TIMELINE builds)
+    uint32_t knockout = 0;              // MI_DBG_KNOCKOUT=bits (-DMI_DBG_KNOCKOUT builds): a second, knocked-out launch of the persistent solver per step on scratch arrays (kernels.hpp, g_dbgKnock)
 
     static Knobs fromEnvironment() {
         Knobs k;
@@ -88,7 +89,7 @@ struct Knobs {
         k.gvelAlloc = str("MI_GVEL_ALLOC"); k.impAlloc = str("MI_IMP_ALLOC");
         k.fuseJoints = !off("MI_FUSE_JOINTS"); k.jointIslands = !off("MI_JOINT_ISLANDS"); k.islandPrivate = tri("MI_ISLAND_PRIVATE");
         k.shardAdaptive = !off("MI_SHARD_ADAPTIVE"); k.shardBlockSkip = !off("MI_SHARD_BLOCK_SKIP");
-        k.timelineOut = str("MI_DBG_TIMELINE_OUT"); k.timelineStep = num("MI_DBG_TIMELINE_STEP", 3);
+        k.timelineOut = str("MI_DBG_TIMELINE_OUT"); k.timelineStep = num("MI_DBG_TIMELINE_STEP", 3); k.knockout = (uint32_t)num("MI_DBG_KNOCKOUT", 0);
         return k;
     }
 };

@@ -8,9 +8,8 @@
 // independent environments per call (resetPhysicsBatch / updatePhysicsBatch): environment e lives at its own origin on its
 // own ground slab, entities [15 e, 15 e + 15), rays of the random pushes are restricted to that range.
 //
-// Host side only (no kernels here): it talks to the physics library through the C ABI of include/mi_physics.h.  The same
-// file compiles against the CPU oracle's ABI (-DLEARNING_BACKEND_ORACLE, tests only) so the parity tests run identical
-// environment code over both backends.
+// Host side only (no kernels here): it talks to the physics library through the C ABI of include/mi_physics.h (a test build
+// may put another implementation of those calls behind the same names: "The physics backend" below).
 //
 // Stated deviations: resetPhysics also WRITES the initial state to outState (the reference leaves the buffer untouched);
 // the push RNG is seeded with a fixed default instead of time(0) (setPhysicsSeed changes it); an episode reset puts the
@@ -29,28 +28,16 @@
 #include "../../include/mi_physics.h"
 #include "../../include/mi_constraints.h"
 
-#ifdef LEARNING_BACKEND_ORACLE
-#define PHYS(name) ora_##name
-namespace ora { struct World; }
-typedef ora::World phys_world;
-extern "C" {
-int ora_world_create(int order_mode, phys_world** out);
-void ora_world_destroy(phys_world*);
-int ora_entities_create(phys_world*, uint32_t, const mi_entity_desc*, uint32_t*);
-int ora_colliders_add(phys_world*, uint32_t, const uint32_t*, const mi_collider_desc*);
-int ora_constraint_create_from_global(phys_world*, uint32_t, uint32_t, uint32_t, const float*, const float*, float, float, uint32_t*);
-int ora_constraint_get(phys_world*, uint32_t, uint32_t, void*, uint32_t);
-int ora_constraints_update(phys_world*, uint32_t, uint32_t, const uint32_t*, const void*, uint32_t);
-int ora_world_step(phys_world*, const mi_step_settings*, float);
-int ora_world_get_transforms(phys_world*, float*, float*, uint32_t);
-int ora_world_get_velocities(phys_world*, float*, float*, uint32_t);
-int ora_world_get_mass_properties(phys_world*, float*, float*, float*, uint32_t);
-int ora_world_set_body_states(phys_world*, uint32_t, const uint32_t*, const float*);
-int ora_world_test_interactions(phys_world*, uint32_t, const float*, const float*, const float*, const uint32_t*);
-}
+// The physics backend.  The product build talks to libmi_physics.so through include/mi_physics.h.  A build may supply another implementation of the same calls through
+// a header of its own (-DMI_LEARNING_BACKEND_HEADER='"path"'; the parity tests do, to run this environment code over their checker): that header defines PHYS(name),
+// phys_world, physCreateWorld(device, out) and physLastError().  Nothing here knows what such a backend is.
+#ifdef MI_LEARNING_BACKEND_HEADER
+#include MI_LEARNING_BACKEND_HEADER
 #else
 #define PHYS(name) mi_##name
 typedef mi_world phys_world;
+static inline int physCreateWorld(int device, phys_world** out) { mi_world_desc desc{}; desc.device = device; return mi_world_create(&desc, out); }
+static inline const char* physLastError() { return mi_last_error(); }
 #endif
 
 #define EXPORT extern "C" __attribute__((visibility("default")))
@@ -172,9 +159,7 @@ const int g_threads = [] { const char* e = std::getenv("MI_LEARN_THREADS"); int 
 bool ok(int rc, const char* what) {
     if (rc == MI_OK) return true;
     g.error = std::string(what) + " failed with status " + std::to_string(rc);
-#ifndef LEARNING_BACKEND_ORACLE
-    g.error += std::string(": ") + mi_last_error();
-#endif
+    if (const char* detail = physLastError()) g.error += std::string(": ") + detail;
     return false;
 }
 uint32_t entityOf(int env, int part) { return (uint32_t)(env * kEntitiesPerEnv + 1 + part); }
@@ -314,14 +299,7 @@ void resetEnvState(int e) {
 bool buildWorld(int n) {
     destroyWorld();
     g.error.clear();
-#ifdef LEARNING_BACKEND_ORACLE
-    // canonical order = the schedule the device runs; MI_LEARNING_ORACLE_ORDER=0 (tests): the reference's own order, to compare with oracle/_ref
-    const char* om = std::getenv("MI_LEARNING_ORACLE_ORDER");
-    if (!ok(ora_world_create(om ? std::atoi(om) : 1, &g.world), "world_create")) return false;
-#else
-    mi_world_desc desc{}; desc.device = g.device;
-    if (!ok(mi_world_create(&desc, &g.world), "world_create")) return false;
-#endif
+    if (!ok(physCreateWorld(g.device, &g.world), "world_create")) return false;
     g.n = n;
     g.envs.assign(n, Env{});
     const int side = (int)std::ceil(std::sqrt((double)n));

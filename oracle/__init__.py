@@ -34,9 +34,9 @@ def build_learning():
     parity tests can run identical environment code over both physics backends.  Test infrastructure only."""
     build()
     src = HERE.parent / "d3d12renderer_amd" / "csrc" / "learning.cpp"
-    if not LEARNING_LIB.exists() or any(p.stat().st_mtime > LEARNING_LIB.stat().st_mtime for p in (src, LIB)):
+    if not LEARNING_LIB.exists() or any(p.stat().st_mtime > LEARNING_LIB.stat().st_mtime for p in (src, LIB, HERE / "ora_learning_backend.h")):
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-ffp-contract=off", "-fno-fast-math", "-fopenmp",
-                        "-DLEARNING_BACKEND_ORACLE", str(src), "-o", str(LEARNING_LIB), "-L", str(LIB.parent), "-l:liboracle.so", "-Wl,-rpath,$ORIGIN"],
+                        f'-DMI_LEARNING_BACKEND_HEADER="{HERE / "ora_learning_backend.h"}"', str(src), "-o", str(LEARNING_LIB), "-L", str(LIB.parent), "-l:liboracle.so", "-Wl,-rpath,$ORIGIN"],
                        check=True, capture_output=True)
     return LEARNING_LIB
 

@@ -160,6 +160,8 @@ def test_every_environment_variable_is_read_in_one_place():
         assert "getenv" not in f.read_text(), f"{f.name} reads the environment itself"
     known = set(re.findall(r'"(MI_[A-Z0-9_]+)"', (csrc / "knobs.hpp").read_text())) | set(re.findall(r'"(MI_[A-Z0-9_]+)"', (csrc / "learning.cpp").read_text()))
     known |= {"MI_PHYSICS_LIB", "MI_LEARNING_LIB", "MI_SHARD_TRANSPORT"}          # the Python side's own (which build of the library to load; bench.py's default transport)
+    known |= set(re.findall(r'"(MI_[A-Z0-9_]+)"', (root / "oracle" / "ora_learning_backend.h").read_text()))   # the checker's backend header for learning.cpp (test side)
+    assert "ora_" not in (csrc / "learning.cpp").read_text(), "the product's learning source names the checker's ABI"
     used = set()
     for f in list((root / "tests").glob("*.py")) + list((root / "tools").glob("*.py")) + list((root / "tools").glob("*.sh")) + [root / "bench.py", root / "__graft_entry__.py"]:
         used |= set(re.findall(r'\b(MI_[A-Z0-9_]+)\b', f.read_text()))

@@ -118,6 +118,42 @@ def test_gpu_block_skipping_changes_nothing(mi_lib, monkeypatch, n, tiles_z, mak
     assert max(owned) < max(first), f"load balance moved bodies between the ranks: {first} -> {owned}"
 
 
+def test_gpu_sweep_axis_follows_the_exchange_on_ranks_that_skip_collider_block_0(mi_lib, monkeypatch):
+    """The global sweep axis changes while three of four ranks simulate nothing in collider block 0 (round-5 advisor item: the step's axis word was written by the lane of
+    collider 0, inside the visit of a block a sharded rank may skip — such a rank kept sweeping along the old axis and reported it in counts().sorting_axis).  A long
+    line of boxes along x (last created = lowest collider indices = the right-most slab) and two flights of boxes closing in along z: the variance along z falls below
+    the one along x after a dozen steps.  Ranks that skip blocks == ranks that visit every block, every step, and every rank reports the same axis."""
+    box = [(capi.AABB, (-0.5, -0.5, -0.5, 0.5, 0.5, 0.5), {})]
+    parts = [(capi.ENTITY_STATIC, (0, -2.0, 0), (0, 0, 0, 1), [(capi.AABB, (-120, -2, -250, 120, 2, 250), {})], {})]
+    for k in range(320):     # the flights (created first: highest collider indices), over the left-most slab, no gravity
+        side = 1.0 if k % 2 else -1.0
+        parts.append((capi.ENTITY_DYNAMIC, (-80.0 + 0.11 * k, 6.0 + 1.2 * (k % 5), side * (150.0 + (k % 7))), (0, 0, 0, 1), box,
+                      {"linear_velocity": (0.0, 0.0, -side * 240.0), "gravity_factor": 0.0, "linear_damping": 0.0}))
+    for ix in range(160):    # the line, ascending x
+        for iz in range(8):
+            parts.append((capi.ENTITY_DYNAMIC, (-83.475 + 1.05 * ix, 0.5, -3.675 + 1.05 * iz), (0, 0, 0, 1), box, {}))
+    sc = scenes.scene_from_parts(parts, iterations=6)
+    d = capi.ShardDesc(); d.num_ranks = 4; d.tiles_x = 4; d.tiles_z = 1; d.origin_x = -84.0; d.origin_z = -400.0; d.tile_size_x = 42.0; d.tile_size_z = 800.0; d.ghost_margin = 1.5
+    worlds = {}
+    for skip in ("1", "0"):
+        monkeypatch.setenv("MI_SHARD_BLOCK_SKIP", skip)
+        worlds[skip] = [sharding.ShardedWorld(sc.populate(mi_lib.create_world(0)), d, r, "local") for r in range(4)]
+    a_, b_ = worlds["1"], worlds["0"]
+    s = sc.settings()
+    axes = []
+    for i in range(40):
+        sharding.step_local(a_, s, sc.dt); sharding.step_local(b_, s, sc.dt)
+        per_rank = [a.world.counts()["sorting_axis"] for a in a_]
+        assert len(set(per_rank)) == 1, f"step {i}: the ranks sweep along different axes: {per_rank}"
+        axes.append(per_rank[0])
+        for a, b in zip(a_, b_):
+            assert a.world.counts() == b.world.counts(), f"step {i} rank {a.rank}: local counts"
+            assert a.world.shard_counts() == b.world.shard_counts(), f"step {i} rank {a.rank}: owned counts"
+            ea, sa = a.owned_states(); eb, sb = b.owned_states()
+            assert np.array_equal(ea, eb) and sa.tobytes() == sb.tobytes(), f"step {i} rank {a.rank}: owned states"
+    assert len(set(axes)) > 1, f"the sweep axis never changed: {sorted(set(axes))}"
+
+
 def test_gpu_rank_never_trusts_a_copy_that_is_not_current(mi_lib):
     """tests/test_distributed.py::test_a_rank_never_trusts_a_copy_that_is_not_current on the GPU: a border moves over the place where a rank last
     saw a body that has long left — the rank must not claim it.  Then entities are deleted on every rank (re-upload of everything, body indices
