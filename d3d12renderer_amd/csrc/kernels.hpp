@@ -1354,6 +1354,14 @@ __global__ __launch_bounds__(256) void k_events_end(uint32_t cap, StepScalars* s
     events[slot] = e;
 }
 
+#ifdef MI_DBG_KNOCKOUT
+// development (knock-out harness, tools/gpu_knockout.sh).  Bits 0-2: k_contact_solve_persist (see there).  Bits 8-12: k_emit_manifolds launched a first time with its
+// read-modify-write targets redirected to scratch and parts removed: 8 no bodyUsed atomics, 9 no history insert, 10 no history probe, 11 no round-0 proposals, 12 no material gathers.
+__device__ uint32_t g_dbgKnock = 0u;
+#define MI_EMIT_KNOCK(bit) ((g_dbgKnock >> (bit)) & 1u)
+#else
+#define MI_EMIT_KNOCK(bit) 0u
+#endif
 constexpr uint32_t kSpatialKeys = 4096;   // levels of the manifolds' spatial counting sort (k_manifold_keys / k_manifold_place below)
 // After the scans: manifold m <- pair p (count > 0).  colWork = (bodyA | dynA << 31, bodyB | dynB << 31, priority lo, hi):
 // everything a colouring round needs in one 16-byte row.
@@ -1389,6 +1397,7 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
     uint32_t a = (uint32_t)((key >> 29) & 0x1FFFFFFFu), b = (uint32_t)(key & 0x1FFFFFFFu);
     const bool terrain = b >= kHeightmapVirtualBase;   // heightmap contact: body B = the static dummy, material of the heightmap
     float4 ma = cEmit[a], mb = terrain ? make_float4(terrainMaterial.x, terrainMaterial.y, __uint_as_float(nb), 0.f) : cEmit[b];
+    if (MI_EMIT_KNOCK(12)) { ma = make_float4(0.5f, 0.5f, __uint_as_float(a % nb), __uint_as_float(1u)); mb = make_float4(0.5f, 0.5f, __uint_as_float(b % nb), __uint_as_float(1u)); }
     float friction = clamp01(sqrtf(ma.y * mb.y));                      // collision_narrow.cpp:2232-2238
     float restitution = clamp01(fmaxr(ma.x, mb.x));
     uint32_t fr = ((uint32_t)(friction * 0xFFFF) << 16) | (uint32_t)(restitution * 0xFFFF);
@@ -1409,18 +1418,19 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
     colWork[m] = make_uint4(bA | dynA | seam, bB | dynB, (uint32_t)prio, (uint32_t)(prio >> 32));
     // a manifold of the previous step keeps its colour (colour 64 = overflow is re-coloured)
     const uint64_t hk = historyKey(nc, a, b);
-    uint32_t c = prevTab ? tableLookup(prevTab, prevMask, hk) : kUncolored;
+    uint32_t c = prevTab && !MI_EMIT_KNOCK(10) ? tableLookup(prevTab, prevMask, hk) : kUncolored;
+    if (MI_EMIT_KNOCK(10)) c = (uint32_t)(prio & 7u);
     if (isNew) isNew[m] = (c == kUncolored && !terrain) ? 1u : 0u;   // not in the previous step's collision list: collision-begin event
     if (seamId && c < kOverflowColor && (c < kSeamColors) != (seam != 0u)) c = kOverflowColor;   // it changed class: re-coloured
     if (c < kOverflowColor) {
-        if (dynA) atomicOr(&bodyUsed[bA], 1ull << c);
-        if (dynB) atomicOr(&bodyUsed[bB], 1ull << c);
+        if (dynA && !MI_EMIT_KNOCK(8)) atomicOr(&bodyUsed[bA], 1ull << c);
+        if (dynB && !MI_EMIT_KNOCK(8)) atomicOr(&bodyUsed[bB], 1ull << c);
         // its colour is final: it enters the NEXT step's history right here (k_color_table_insert then only has the few new manifolds left)
-        tableInsert(nextTab, nextMask, hk, c);
+        if (!MI_EMIT_KNOCK(9)) tableInsert(nextTab, nextMask, hk, c);
         manKept[m] = 1u;
     } else {
         c = kUncolored; manKept[m] = 0u;
-        if (topRound1) {   // round 0 of the colouring (one launch less: the host starts its rounds at 1)
+        if (topRound1 && !MI_EMIT_KNOCK(11)) {   // round 0 of the colouring (one launch less: the host starts its rounds at 1)
             const unsigned long long key1 = (1ull << 52) | (unsigned long long)prio;
             if (dynA) atomicMax(&topRound1[bA], key1);
             if (dynB) atomicMax(&topRound1[bB], key1);
@@ -2589,7 +2599,6 @@ __device__ __forceinline__ void storePairMasked(float4* q0, float4* q1, f32x4 d0
 // development (knock-out harness, tools/gpu_knockout.sh): the host launches k_contact_solve_persist a SECOND time per step on scratch copies of the velocity arrays with parts
 // of a tile visit removed, to price them: bit 0 = no row stream at all (nothing is prefetched; the update runs on whatever the registers hold — the tag protocol does not
 // depend on the values), bit 1 = every tile's rows come from contact-tile 0 (the same loads in the queue, served by the L2), bit 2 = no waiting for tags.
-__device__ uint32_t g_dbgKnock = 0u;
 #define MI_KNOCK(bit) ((g_dbgKnockLocal >> (bit)) & 1u)
 #else
 #define MI_KNOCK(bit) 0u
