@@ -1277,30 +1277,36 @@ __device__ __forceinline__ uint32_t tableSlot(uint64_t key, uint32_t mask) {
 }
 // One slot = one 16-byte row (key, colour): a probe touches ONE sector — key and colour used to live in two arrays, two random sectors per probe and
 // two more per insert, and k_emit_manifolds is bound by exactly those.
+//
+// POSITION-STABLE entries (round 6).  A manifold that keeps its colour keeps its SLOT: k_emit_manifolds copies its entry into the next step's table at the index it found
+// it at in the previous step's table — one plain 16-byte store, where a fresh insertion is a compare-and-swap on a cold line and a dependent store (measured with the
+// knock-out harness: 22 of the kernel's 58 us).  Kept entries have distinct slots, and the new manifolds are entered afterwards (k_schedule_finish)
+// by compare-and-swap into the first empty slot from their hash, so a table is a valid open-addressing table with ONE difference: an entry's probe
+// chain may have holes where its old neighbours vanished.  A lookup therefore does not stop at an empty slot; it probes the `maxDisp + 1` slots from the hash, maxDisp =
+// the largest displacement any insertion has ever had (one device word, only ever raised; zeroed when the history is dropped).  A hit ends at the first match as before
+// (displacement 0-1 nearly always); a miss — a NEW manifold, a few per cent of a settled pile's — costs maxDisp + 1 contiguous 16-byte probes (a few cache lines).
+// When the two tables differ in size (the manifold count crossed a power of two, a synchronous re-run) positions do not carry over and every entry is inserted afresh.
 struct alignas(16) HistSlot { unsigned long long key; unsigned long long val; };
-__device__ __forceinline__ uint32_t tableLookup(const HistSlot* __restrict__ tab, uint32_t mask, uint64_t key) {
-    for (uint32_t s = tableSlot(key, mask), n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
+struct HistHit { uint32_t colour, slot; };
+__device__ __forceinline__ HistHit tableFind(const HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, uint32_t maxDisp) {
+    uint32_t s = tableSlot(key, mask);
+    for (uint32_t n = 0; n <= maxDisp && n <= mask; ++n, s = (s + 1u) & mask) {
         const ulonglong2 e = *reinterpret_cast<const ulonglong2*>(tab + s);
-        if (e.x == key) return (uint32_t)e.y;
-        if (e.x == 0ull) break;
+        if (e.x == key) return HistHit{(uint32_t)e.y, s};
     }
-    return kUncolored;
+    return HistHit{kUncolored, 0u};
 }
-__device__ __forceinline__ void tableInsert(HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, uint32_t val) {
+__device__ __forceinline__ uint32_t tableLookup(const HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, uint32_t maxDisp) { return tableFind(tab, mask, key, maxDisp).colour; }
+__device__ __forceinline__ void tableInsert(HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, uint32_t val, uint32_t* __restrict__ maxDisp) {
     for (uint32_t s = tableSlot(key, mask), n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
         const unsigned long long old = atomicCAS(&tab[s].key, 0ull, (unsigned long long)key);
-        if (old == 0ull || old == key) { tab[s].val = val; return; }   // (the colour is read in the NEXT step only; the same key again — a schedule built twice in a synchronous step — overwrites)
+        if (old == 0ull || old == key) {   // (the colour is read in the NEXT step only; the same key again — a schedule built twice in a synchronous step — overwrites)
+            tab[s].val = val;
+            if (n > __hip_atomic_load(maxDisp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxDisp, n);
+            return;
+        }
     }
 }
-__global__ __launch_bounds__(256) void k_color_table_insert(uint32_t nc, const StepScalars* __restrict__ sc, const uint32_t* __restrict__ manPair,
-                                                            const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
-                                                            const uint32_t* __restrict__ color, HistSlot* __restrict__ tab, uint32_t mask, const uint8_t* __restrict__ manKept) {
-    uint32_t m = blockIdx.x * blockDim.x + threadIdx.x;
-    if (m >= sc->numManifolds || manKept[m]) return;      // kept colours were inserted by k_emit_manifolds
-    uint64_t pk = (sc->partitioned ? pairsB : pairsA)[manPair[m]];
-    tableInsert(tab, mask, historyKey(nc, (uint32_t)((pk >> 29) & 0x1FFFFFFFull), (uint32_t)(pk & 0x1FFFFFFFull)), color[m]);
-}
-
 // Collision events (handleCollisionCallbacks, src/physics/physics.cpp:1041-1178), device half.  A manifold whose oriented
 // collider pair is not in the previous step's history table begins (k_emit_manifolds flags it); a pair of the previous table
 // that is not in this step's table ended.  Begin records carry the mean contact point / normal and the relative point
@@ -1341,11 +1347,12 @@ __global__ __launch_bounds__(256) void k_events_begin(uint32_t nc, uint32_t cap,
 }
 __global__ __launch_bounds__(256) void k_events_end(uint32_t cap, StepScalars* sc, const HistSlot* __restrict__ prevTab, uint32_t prevMask,
                                                     const HistSlot* __restrict__ curTab, uint32_t curMask,
-                                                    DeviceEvent* __restrict__ events) {
+                                                    DeviceEvent* __restrict__ events, const uint32_t* __restrict__ histDisp) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long key = s <= prevMask ? prevTab[s].key : 0ull;
-    bool want = key != 0ull && ((key - 1ull) & ((1ull << kIndexBits) - 1ull)) < kHeightmapVirtualBase   // heightmap contacts raise no events
-                && tableLookup(curTab, curMask, key) == kUncolored;
+    bool want = key != 0ull && ((key - 1ull) & ((1ull << kIndexBits) - 1ull)) < kHeightmapVirtualBase;   // heightmap contacts raise no events
+    if (want && prevMask == curMask && curTab[s].key == key) want = false;                                  // it kept its colour, hence its slot
+    want = want && tableLookup(curTab, curMask, key, *histDisp) == kUncolored;
     uint32_t slot = waveAppendSlot(want, &sc->numEvents);
     if (!want) return;
     if (slot >= cap) { sc->specOverflow = 1u; return; }
@@ -1374,7 +1381,7 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
                                                         const HistSlot* __restrict__ prevTab, uint32_t prevMask,
                                                         unsigned long long* __restrict__ bodyUsed, uint8_t* __restrict__ isNew, StepScalars* sc,
                                                         float2 terrainMaterial /* (restitution, friction) of the heightmap */,
-                                                        HistSlot* __restrict__ nextTab, uint32_t nextMask, uint8_t* __restrict__ manKept,
+                                                        HistSlot* __restrict__ nextTab, uint32_t nextMask, uint8_t* __restrict__ manKept, uint32_t* __restrict__ histDisp /* the history's probe bound (tableFind) */,
                                                         const Shards* __restrict__ statsShards /* non-null: workgroup 0 runs pairFinishStats instead */, uint32_t statsBlocks,
                                                         const unsigned long long* __restrict__ statsPartials, const int* __restrict__ statsBounds, GridParams* statsGridNext, uint32_t statsCellCap, const uint8_t* __restrict__ statsCbLive,
                                                         const uint32_t* __restrict__ seamId /* exact seam: per body, the tile border it is shared across (0 = none); or null */,
@@ -1418,15 +1425,21 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
     colWork[m] = make_uint4(bA | dynA | seam, bB | dynB, (uint32_t)prio, (uint32_t)(prio >> 32));
     // a manifold of the previous step keeps its colour (colour 64 = overflow is re-coloured)
     const uint64_t hk = historyKey(nc, a, b);
-    uint32_t c = prevTab && !MI_EMIT_KNOCK(10) ? tableLookup(prevTab, prevMask, hk) : kUncolored;
+    HistHit hit{kUncolored, 0u};
+    if (prevTab && !MI_EMIT_KNOCK(10)) hit = tableFind(prevTab, prevMask, hk, *histDisp);
+    uint32_t c = hit.colour;
+    const bool found = c != kUncolored;
     if (MI_EMIT_KNOCK(10)) c = (uint32_t)(prio & 7u);
     if (isNew) isNew[m] = (c == kUncolored && !terrain) ? 1u : 0u;   // not in the previous step's collision list: collision-begin event
     if (seamId && c < kOverflowColor && (c < kSeamColors) != (seam != 0u)) c = kOverflowColor;   // it changed class: re-coloured
     if (c < kOverflowColor) {
         if (dynA && !MI_EMIT_KNOCK(8)) atomicOr(&bodyUsed[bA], 1ull << c);
         if (dynB && !MI_EMIT_KNOCK(8)) atomicOr(&bodyUsed[bB], 1ull << c);
-        // its colour is final: it enters the NEXT step's history right here (k_color_table_insert then only has the few new manifolds left)
-        if (!MI_EMIT_KNOCK(9)) tableInsert(nextTab, nextMask, hk, c);
+        // its colour is final: it enters the NEXT step's history right here (k_schedule_finish then only has the few new manifolds left)
+        // (its old slot when the two tables have one size: kept entries have distinct slots, the new manifolds are entered after this kernel)
+        if (MI_EMIT_KNOCK(9)) {}
+        else if (found && prevMask == nextMask) { ulonglong2 e; e.x = hk; e.y = c; *reinterpret_cast<ulonglong2*>(nextTab + hit.slot) = e; }
+        else tableInsert(nextTab, nextMask, hk, c, histDisp);
         manKept[m] = 1u;
     } else {
         c = kUncolored; manKept[m] = 0u;
@@ -2005,7 +2018,7 @@ __global__ __launch_bounds__(256) void k_fill_tiles(const StepScalars* __restric
     }
 }
 
-// k_bin_scatter + k_color_table_insert + k_build_tiles + k_fill_tiles in ONE launch (each was a 5-10 us launch doing ~1 us of work, one behind the
+// scatter + history insert of the new manifolds + k_build_tiles + k_fill_tiles in ONE launch (each was a 5-10 us launch doing ~1 us of work, one behind the
 // other): workgroups [0, numBlocks) scatter their manifolds into the schedule slots and enter the newly coloured ones into the next step's colour
 // history; workgroups [numBlocks, ...) turn the bins into tiles — every one of them derives the bin table itself (257 bins: three wave scans, from the
 // first column of the block scan, i.e. without waiting for the scatter) and then fills its 256 tiles; the first of them also publishes the table.
@@ -2013,11 +2026,11 @@ __global__ __launch_bounds__(256) void k_schedule_finish(uint32_t lastRound, con
                                                          const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo, const uint32_t* __restrict__ blockHist,
                                                          const uint32_t* __restrict__ blockScan, uint32_t* __restrict__ order, StepScalars* sc,
                                                          uint32_t nc, const uint32_t* __restrict__ manPair, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
-                                                         HistSlot* __restrict__ tab, uint32_t tabMask, const uint8_t* __restrict__ manKept,
+                                                         HistSlot* __restrict__ tab, uint32_t tabMask, const uint8_t* __restrict__ manKept, uint32_t* __restrict__ histDisp,
                                                          uint32_t tilesCap, uint32_t ctCap, BinInfo* __restrict__ binInfo, uint32_t* __restrict__ xcdBase /* [kSchedBins][8] or null */, uint32_t xcdSingle,
                                                          uint4* __restrict__ tileInfo, uint2* __restrict__ tileDesc, uint32_t* __restrict__ xcdTiles /* [8][listCap] or null */, uint4* __restrict__ xcdInfo, uint32_t listCap) {
     __shared__ uint32_t cur[kColorBins + 4];
-    if (blockIdx.x < numBlocks) {   // ---- scatter (k_bin_scatter) + history insert (k_color_table_insert)
+    if (blockIdx.x < numBlocks) {   // ---- scatter + history insert of the newly coloured manifolds
         const uint32_t nm = sc->numManifolds;
         if (blockIdx.x == 0 && threadIdx.x == 0) sc->colorPending = colorPendingOf(roundFlags, lastRound);
         for (uint32_t b = threadIdx.x; b < kColorBins; b += 256) {
@@ -2036,7 +2049,7 @@ __global__ __launch_bounds__(256) void k_schedule_finish(uint32_t lastRound, con
                 if (c <= kOverflowColor) order[atomicAdd(&cur[binOf(c, manInfo[m].x & 7u)], 1u)] = m;
                 if (!manKept[m]) {      // kept colours were entered by k_emit_manifolds
                     const uint64_t pk = pairKeys[manPair[m]];
-                    tableInsert(tab, tabMask, historyKey(nc, (uint32_t)((pk >> 29) & 0x1FFFFFFFull), (uint32_t)(pk & 0x1FFFFFFFull)), c);
+                    tableInsert(tab, tabMask, historyKey(nc, (uint32_t)((pk >> 29) & 0x1FFFFFFFull), (uint32_t)(pk & 0x1FFFFFFFull)), c, histDisp);
                 }
             }
         }
