@@ -2605,9 +2605,6 @@ __device__ __forceinline__ void storePairMasked(float4* q0, float4* q1, f32x4 d0
 }
 // LDSIMP: the accumulated impulses live in LDS (`ldsImp`, [k][lane]) because the same wave runs this tile in every sweep
 // (k_contact_solve_persist); otherwise they travel between sweeps as tagged granules in `imp`.
-#ifndef MI_LATE_PREFETCH
-#define MI_LATE_PREFETCH 0
-#endif
 #ifdef MI_DBG_KNOCKOUT
 // development (knock-out harness, tools/gpu_knockout.sh): the host launches k_contact_solve_persist a SECOND time per step on scratch copies of the velocity arrays with parts
 // of a tile visit removed, to price them: bit 0 = no row stream at all (nothing is prefetched; the update runs on whatever the registers hold — the tag protocol does not
@@ -2826,6 +2823,41 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_W
     asm volatile("v_accvgpr_read_b32 %0, a" #A0 "\n\tv_accvgpr_read_b32 %1, a" #A1 "\n\tv_accvgpr_read_b32 %2, a" #A2 "\n\tv_accvgpr_read_b32 %3, a" #A3 \
                  : "=v"(x_), "=v"(y_), "=v"(z_), "=v"(w_)); (dst) = make_float4(x_, y_, z_, w_); } while (0)
 
+// RESIDENT ROWS (round 6).  The knock-out harness prices the row stream of this kernel at 14 % of its launch (no stream at all: 471 -> 405 us at the bench state;
+// profiles/r06_knockout_solver_and_emit.txt): every wave's 24 x 1 KB row loads per tile sit in the same in-order memory queue as its body polls and publish stores.
+// The accumulator registers a0..a143 are free (the ring is a160..a255), i.e. six contact-tiles of 24 registers: the first tiles of a wave's list whose contacts fit
+// are RESIDENT there — loaded once, at the top of the launch — and "prefetching" such a tile is 24 register moves per contact (v_accvgpr_mov_b32) into the ring,
+// issued where the loads would have been: nothing enters the memory queue, and processTile still takes every tile's rows out of the ring, unchanged.
+// Register numbers are literals ("n" operands): position q = a[24 q .. 24 q + 23], ring contact k = a[160 + 24 k .. ].  The compiler itself never allocates an
+// accumulator register in this kernel (no spills: tests/test_capi_symbols.py reads the ISA); the ring's clobber lists make the descriptor cover a0..a255.
+constexpr uint32_t kResidentPositions = 6;
+template <int DST, int SRC> __device__ __forceinline__ void accMov() { asm volatile("v_accvgpr_mov_b32 a[%0], a[%1]" : : "n"(DST), "n"(SRC)); }
+template <int Q, int K, int... R> __device__ __forceinline__ void accCopyContactImpl(std::integer_sequence<int, R...>) { (accMov<160 + 24 * K + R, 24 * Q + R>(), ...); }
+template <int Q, int K> __device__ __forceinline__ void accCopyContact() { if constexpr (Q < (int)kResidentPositions) accCopyContactImpl<Q, K>(std::make_integer_sequence<int, 24>()); }
+template <int LO> __device__ __forceinline__ void accLoad4(const float4* p) { asm volatile("global_load_dwordx4 a[%0:%1], %2, off" : : "n"(LO), "n"(LO + 3), "v"(p) : "memory"); }
+template <int Q> __device__ __forceinline__ void accLoadContact(const float4* row) {   // the six rows of one contact of a tile -> position Q
+    accLoad4<24 * Q + 0>(row + 0u * 64u); accLoad4<24 * Q + 4>(row + 1u * 64u); accLoad4<24 * Q + 8>(row + 2u * 64u);
+    accLoad4<24 * Q + 12>(row + 3u * 64u); accLoad4<24 * Q + 16>(row + 4u * 64u); accLoad4<24 * Q + 20>(row + 5u * 64u);
+}
+__device__ __forceinline__ void accLoadResident(uint32_t q, const float4* row) {
+    switch (q) {
+        case 0: accLoadContact<0>(row); break; case 1: accLoadContact<1>(row); break; case 2: accLoadContact<2>(row); break;
+        case 3: accLoadContact<3>(row); break; case 4: accLoadContact<4>(row); break; default: accLoadContact<5>(row); break;
+    }
+}
+template <int Q> __device__ __forceinline__ void accCopyTile(uint32_t cnt) {   // resident positions Q .. Q + cnt - 1 -> ring contacts 0 .. cnt - 1
+    accCopyContact<Q, 0>();
+    if (1u < cnt) accCopyContact<Q + 1, 1>();
+    if (2u < cnt) accCopyContact<Q + 2, 2>();
+    if (3u < cnt) accCopyContact<Q + 3, 3>();
+}
+__device__ __forceinline__ void accCopyResident(uint32_t q, uint32_t cnt) {
+    switch (q) {
+        case 0: accCopyTile<0>(cnt); break; case 1: accCopyTile<1>(cnt); break; case 2: accCopyTile<2>(cnt); break;
+        case 3: accCopyTile<3>(cnt); break; case 4: accCopyTile<4>(cnt); break; default: accCopyTile<5>(cnt); break;
+    }
+}
+
 // METALDS = false (larger problems): only the impulses live in LDS (2060 B per slot instead of 4620); the constant slot data is
 // prefetched from global memory together with the rows of the next tile.
 // XCD = true (XCD-partitioned): workgroup w belongs to XCD w % 8 (verified against the hardware id: anything else is
@@ -2838,7 +2870,7 @@ template <bool METALDS, bool XCD, bool IMPLDS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIST_WPE))) void k_contact_solve_persist(
     uint32_t sweeps, uint32_t maxSlots, const uint2* __restrict__ tileDesc, const uint4* slotMeta, const float4* __restrict__ slotNormal,
     const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* gVel, StepScalars* sc, uint32_t xcdOnly,
-    const uint32_t* __restrict__ xcdTiles, uint32_t listCap, const unsigned long long* __restrict__ bodyOwner, float4* gVelL, uint4* slotMetaW, float4* imp, uint32_t xcdFault) {
+    const uint32_t* __restrict__ xcdTiles, uint32_t listCap, const unsigned long long* __restrict__ bodyOwner, float4* gVelL, uint4* slotMetaW, float4* imp, uint32_t xcdFault, uint32_t resident /* 1: rows of the first tiles stay in a0..a143 */) {
     // LDS per workgroup: [maxSlots] x { meta uint4[64], normal float4[64], mass float2[64] } (constant over the sweeps; METALDS only), then the
     // impulses float2[4 * maxSlots][64], then the per-slot (first contact-tile, contacts per manifold, impulse offset)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
@@ -2866,11 +2898,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
     }
     uint32_t* lTile = reinterpret_cast<uint32_t*>(lDesc + 3u * (size_t)maxSlots);   // [maxSlots] tile of every slot
     uint32_t* lCrit = lTile + maxSlots;                                             // [maxSlots] 1: the slot had to poll in the previous sweep
-    uint32_t mySlots = 0, off = 0;
+    uint32_t* lRes = lCrit + maxSlots;                                              // [maxSlots] first resident position of the slot's rows, or 0xFF: they stream
+    uint32_t mySlots = 0, off = 0, resNext = 0;
     for (uint32_t li = wid; li < numTiles && mySlots < maxSlots; li += numWaves, ++mySlots) {
         const uint32_t tile = XCD ? xcdTiles[li] : li;
         const uint2 d = tileDesc[tile];
-        if (lane == 0) { lTile[mySlots] = tile; lCrit[mySlots] = 0u; }
+        const bool res = resident && resNext + d.y <= kResidentPositions;
+        if (lane == 0) { lTile[mySlots] = tile; lCrit[mySlots] = 0u; lRes[mySlots] = res ? resNext : 0xFFu; }
+        if (res) {   // (issued here, landed by the vmcnt(0) behind the loop)
+            for (uint32_t k = 0; k < d.y; ++k) accLoadResident(resNext + k, rows + ((size_t)d.x + k) * (kRows * 64u) + lane);
+            resNext += d.y;
+        }
         if (XCD) {   // which of this slot's two bodies are XCD-local -> bits 8 / 9 of meta.w (read back from LDS or global below)
             uint4 m = slotMeta[(size_t)tile * 64u + lane];
             const unsigned long long mine = 1ull << (8u * xcd);
@@ -2887,6 +2925,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
         off += d.y;
     }
     if (wid + (size_t)mySlots * numWaves < numTiles) { if (lane == 0) sc->solveError = 2u; return; }   // more tiles than the host sized LDS for
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (!mySlots) return;
     // Software pipeline over (sweep, slot): the rows of the NEXT tile are requested while this tile waits for its bodies.
@@ -2901,7 +2940,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
 #ifdef MI_DBG_KNOCKOUT
     const uint32_t g_dbgKnockLocal = __builtin_amdgcn_readfirstlane(g_dbgKnock);
 #endif
-    auto fetchRows = [&](uint32_t slot) -> uint32_t {
+    auto fetchRows = [&](uint32_t slot) __attribute__((always_inline)) -> uint32_t {
         uint32_t ct = lDesc[3 * slot]; const uint32_t cnt = lDesc[3 * slot + 1];
         if (MI_KNOCK(1)) ct = 0u;
         if (!METALDS) {
@@ -2909,6 +2948,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
             nxMeta = XCD ? slotMetaW[at] : slotMeta[at]; nxNf = slotNormal[at]; nxMass = slotMass[at];
         }
         if (MI_KNOCK(0)) return 0u;
+        if (const uint32_t q = lRes[slot]; q != 0xFFu) { accCopyResident(q, cnt); return 0u; }   // resident: register moves, nothing enters the memory queue
         {
             const float4* row = rows + (size_t)ct * (kRows * 64u) + lane;   // row (k, r) of the tile at + (k * kRows + r) * 64
             if (0u < cnt) MI_ACC_LOAD(160, 161, 162, 163, row + 0u * 64u);
@@ -2939,7 +2979,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
         return cnt * kRows;
     };
     // this tile's rows out of the ACC registers; the body loads of the tile (4, issued just before) may still be in flight
-    auto readRows = [&](ContactRows* cur, uint32_t cnt) {
+    auto readRows = [&](ContactRows* cur, uint32_t cnt) __attribute__((always_inline)) {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         if (0u < cnt) MI_ACC_READ(cur[0].r[0], 160, 161, 162, 163);
         if (0u < cnt) MI_ACC_READ(cur[0].r[1], 164, 165, 166, 167);
@@ -2982,15 +3022,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
             else { meta = nxMeta; nf = nxNf; mass = nxMass; }
             const uint32_t nextSlot = slot + 1u < mySlots ? slot + 1u : 0u;
             const bool more = slot + 1u < mySlots || it + 1u < sweeps;
-            // (MI_LATE_PREFETCH: a tile that had to poll in the previous sweep prefetches after its wait, so that its polls do not
-            // queue behind the prefetch.  Measured slower — 0.68 vs 0.63 ms — the rows arriving late costs more; off.)
+            // (a tile that had to poll in the previous sweep prefetching AFTER its wait, so that its polls do not queue behind the prefetch, was measured slower —
+            // 0.68 vs 0.63 ms, round 3: the rows arriving late costs more)
             struct Prefetch {
                 enum : bool { kPinRows = true };
-                decltype(fetchRows)& fetch; decltype(readRows)& read; ContactRows* cur; uint32_t cnt; uint32_t* crit; uint32_t next; bool more, critical, issued; unsigned long long* rec; bool noWait;
+                decltype(fetchRows)& fetch; decltype(readRows)& read; ContactRows* cur; uint32_t cnt; uint32_t* crit; uint32_t next; bool more; unsigned long long* rec; bool noWait;
                 __device__ __forceinline__ bool knockNoWait() const { return noWait; }
-                __device__ __forceinline__ uint32_t early() { read(cur, cnt); MI_STAMP(rec, 1); if (more && !critical) { issued = true; return fetch(next); } return 0u; }
-                __device__ __forceinline__ void late(bool waited) { if (more && !issued) (void)fetch(next); if (threadIdx.x == 0) *crit = waited ? 1u : 0u; }
-            } prefetch{fetchRows, readRows, cur, cnt, &lCrit[slot], nextSlot, more, MI_LATE_PREFETCH && lCrit[slot] != 0u, false, rec, MI_KNOCK(2) != 0u};
+                __device__ __forceinline__ uint32_t early() { read(cur, cnt); MI_STAMP(rec, 1); return more ? fetch(next) : 0u; }
+                __device__ __forceinline__ void late(bool waited) { if (threadIdx.x == 0) *crit = waited ? 1u : 0u; }
+            } prefetch{fetchRows, readRows, cur, cnt, &lCrit[slot], nextSlot, more, rec, MI_KNOCK(2) != 0u};
             float2* li = lImp + (size_t)io * 64u;
             // (the contact count of THIS tile as a literal in each case: the row read-back's `if (k < cnt)` guards fold, and no row register is "defined on some paths only" —
             // such values were kept alive around the loop: 61 register copies at the top of every visit)

@@ -50,6 +50,7 @@ struct Knobs {
     uint32_t flowLds = 0;               // MI_FLOW_LDS (bytes; 0 = default)
     uint32_t persistWaves = 0;          // MI_PERSIST_WAVES (0 = 4 per CU)
     bool persistXcdOnly = false;        // MI_PERSIST_XCD_ONLY (development)
+    bool persistResident = true;        // MI_PERSIST_RESIDENT=0: every tile's rows stream (otherwise the first six contact-tiles of a wave stay in a0..a143)
     int persistXcd = -1, persistXcdSingle = -1;   // MI_PERSIST_XCD / _SINGLE = 0 / 1 (-1 = default)
     int xcdMinManifolds = -1;           // MI_PERSIST_XCD_MIN
     bool xcdFault = false, flowFault = false;   // MI_PERSIST_XCD_FAULT / MI_FLOW_FAULT: fault injection (tests)
@@ -82,7 +83,7 @@ struct Knobs {
         if (const char* v = std::getenv("MI_GJK_WAVE")) k.gjkWave = atoi(v);
         k.round0InEmit = !off("MI_ROUND0_EMIT"); k.colorTail = !off("MI_COLOR_TAIL"); k.colorRoundsMax = (uint32_t)num("MI_COLOR_ROUNDS_MAX", 0); k.colorTailMargin = (uint32_t)num("MI_COLOR_TAIL_MARGIN", k.colorTailMargin);
         k.colorMargin = (uint32_t)num("MI_COLOR_MARGIN", k.colorMargin); k.xcdNoSort = set("MI_XCD_NOSORT"); k.xcdStats = set("MI_XCD_STATS"); k.xcdSwizzle = str("MI_XCD_SWIZZLE") == "1";
-        k.solver = str("MI_SOLVER"); k.flowLds = (uint32_t)num("MI_FLOW_LDS", 0); k.persistWaves = (uint32_t)num("MI_PERSIST_WAVES", 0); k.persistXcdOnly = set("MI_PERSIST_XCD_ONLY");
+        k.solver = str("MI_SOLVER"); k.flowLds = (uint32_t)num("MI_FLOW_LDS", 0); k.persistWaves = (uint32_t)num("MI_PERSIST_WAVES", 0); k.persistXcdOnly = set("MI_PERSIST_XCD_ONLY"); k.persistResident = !off("MI_PERSIST_RESIDENT");
         k.persistXcd = tri("MI_PERSIST_XCD"); k.persistXcdSingle = tri("MI_PERSIST_XCD_SINGLE");
         if (const char* v = std::getenv("MI_PERSIST_XCD_MIN")) k.xcdMinManifolds = (int)strtoul(v, nullptr, 0);
         k.xcdFault = set("MI_PERSIST_XCD_FAULT"); k.flowFault = set("MI_FLOW_FAULT");

@@ -93,16 +93,16 @@ def test_cpp_facade_runs_on_gpu(tmp_path, mi_lib):
 
 def test_persistent_solver_keeps_its_acc_registers_to_itself(tmp_path, mi_lib):
     """k_contact_solve_persist prefetches the next tile's constraint rows with inline-asm loads into the FIXED accumulator
-    registers a160..a255 and reads them back with inline asm after an explicit wait.  That is only sound if the compiler never
-    touches those registers itself (it may spill into low ACC registers): every reference to a160 and above must sit inside an
-    #ASMSTART/#ASMEND block, nothing may go to scratch, and the prefetch / read-back come in whole tiles (24 loads, 24 moves per
-    contact)."""
+    registers a160..a255, keeps the rows of a wave's first tiles RESIDENT in a0..a143 (loaded once; handed to the ring by
+    v_accvgpr_mov_b32) and reads the ring back with inline asm after an explicit wait.  That is only sound if the compiler never
+    touches an accumulator register itself: every reference to one must sit inside an #ASMSTART/#ASMEND block (no spill copies),
+    nothing may go to scratch, and loads / moves / read-backs come in whole contacts (6 loads, 24 moves, 24 reads)."""
     from d3d12renderer_amd import build
     asm = build.device_asm(tmp_path / "device.s").read_text().split("\n")
     starts = [i for i, l in enumerate(asm) if re.match(r"^_ZN2mi23k_contact_solve_persistILb[01]ELb[01]ELb[01]EE.*:", l)]
     assert len(starts) == 6, "variants: slot data / impulses in LDS or not, XCD-partitioned or not"
     for st in starts:
-        in_asm, stray, loads, reads = False, [], 0, 0
+        in_asm, stray, ring_loads, res_loads, reads, moves = False, [], 0, 0, 0, 0
         i = st
         while ".amdhsa_kernel" not in asm[i]:
             line = asm[i]; i += 1
@@ -112,13 +112,18 @@ def test_persistent_solver_keeps_its_acc_registers_to_itself(tmp_path, mi_lib):
                 in_asm = False; continue
             code = line.split(";")[0]
             if in_asm:
-                loads += len(re.findall(r"global_load_dwordx4 a\[", code))
+                for lo in re.findall(r"global_load_dwordx4 a\[(0x[0-9a-f]+|\d+):", code):     # ("n" operands print as hex from 160 on)
+                    if int(lo, 0) >= 160: ring_loads += 1
+                    else: res_loads += 1
                 reads += len(re.findall(r"v_accvgpr_read_b32", code))
-            elif "scratch_" in code or any(int(n) >= 160 for n in re.findall(r"\ba\[?(\d+)", code)):
+                for dst, src in re.findall(r"v_accvgpr_mov_b32 a\[?(0x[0-9a-f]+|\d+)\]?, a\[?(0x[0-9a-f]+|\d+)\]?", code):
+                    assert int(dst, 0) >= 160 and int(src, 0) < 144 and (int(dst, 0) - 160) % 24 == int(src, 0) % 24, (dst, src)
+                    moves += 1
+            elif "scratch_" in code or "v_accvgpr" in code or re.search(r"\ba\[?\d+", code):
                 stray.append(line.strip())
         assert not stray, stray[:5]
-        # the prefetch is inlined once per call site (24 loads each); the read-back once per contact count (24 moves per contact)
-        assert loads > 0 and loads % 24 == 0 and reads > 0 and reads % 24 == 0, (loads, reads)
+        # the prefetch is inlined once per call site (24 loads each); the read-back once per contact count (24 moves per contact); six resident positions of six loads
+        assert ring_loads > 0 and ring_loads % 24 == 0 and reads > 0 and reads % 24 == 0 and res_loads == 36 and moves > 0 and moves % 24 == 0, (ring_loads, res_loads, reads, moves)
 
 
 def test_tile_to_xcd_assignment_is_a_partition(mi_lib):
