@@ -2825,36 +2825,51 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_W
 
 // RESIDENT ROWS (round 6).  The knock-out harness prices the row stream of this kernel at 14 % of its launch (no stream at all: 471 -> 405 us at the bench state;
 // profiles/r06_knockout_solver_and_emit.txt): every wave's 24 x 1 KB row loads per tile sit in the same in-order memory queue as its body polls and publish stores.
-// The accumulator registers a0..a143 are free (the ring is a160..a255), i.e. six contact-tiles of 24 registers: the first tiles of a wave's list whose contacts fit
+// The accumulator registers a0..a143 are free (the ring is a160..a255), i.e. six contact-tiles ("positions") of 24 registers: the first tiles of a wave's list whose contacts fit
 // are RESIDENT there — loaded once, at the top of the launch — and "prefetching" such a tile is 24 register moves per contact (v_accvgpr_mov_b32) into the ring,
 // issued where the loads would have been: nothing enters the memory queue, and processTile still takes every tile's rows out of the ring, unchanged.
 // Register numbers are literals ("n" operands): position q = a[24 q .. 24 q + 23], ring contact k = a[160 + 24 k .. ].  The compiler itself never allocates an
 // accumulator register in this kernel (no spills: tests/test_capi_symbols.py reads the ISA); the ring's clobber lists make the descriptor cover a0..a255.
-constexpr uint32_t kResidentPositions = 6;
+// Positions 6..8 live in the ARCHITECTURAL registers v184..v255 of the variants that fit into 184 allocatable VGPRs (slot data in LDS: amdgpu_num_vgpr keeps the
+// compiler out of v184 and above): the same scheme with v_accvgpr_write_b32 as the move (solver 444 -> 433 us).  The variants that need more registers keep six.
+constexpr uint32_t kResidentAcc = 6, kResidentVgprBase = 184;
 template <int DST, int SRC> __device__ __forceinline__ void accMov() { asm volatile("v_accvgpr_mov_b32 a[%0], a[%1]" : : "n"(DST), "n"(SRC)); }
-template <int Q, int K, int... R> __device__ __forceinline__ void accCopyContactImpl(std::integer_sequence<int, R...>) { (accMov<160 + 24 * K + R, 24 * Q + R>(), ...); }
-template <int Q, int K> __device__ __forceinline__ void accCopyContact() { if constexpr (Q < (int)kResidentPositions) accCopyContactImpl<Q, K>(std::make_integer_sequence<int, 24>()); }
-template <int LO> __device__ __forceinline__ void accLoad4(const float4* p) { asm volatile("global_load_dwordx4 a[%0:%1], %2, off" : : "n"(LO), "n"(LO + 3), "v"(p) : "memory"); }
-template <int Q> __device__ __forceinline__ void accLoadContact(const float4* row) {   // the six rows of one contact of a tile -> position Q
-    accLoad4<24 * Q + 0>(row + 0u * 64u); accLoad4<24 * Q + 4>(row + 1u * 64u); accLoad4<24 * Q + 8>(row + 2u * 64u);
-    accLoad4<24 * Q + 12>(row + 3u * 64u); accLoad4<24 * Q + 16>(row + 4u * 64u); accLoad4<24 * Q + 20>(row + 5u * 64u);
+template <int DST, int SRC> __device__ __forceinline__ void accFromV() { asm volatile("v_accvgpr_write_b32 a[%0], v[%1]" : : "n"(DST), "n"(SRC)); }
+template <int Q, int K, int... R> __device__ __forceinline__ void accCopyContactImpl(std::integer_sequence<int, R...>) {
+    if constexpr (Q < (int)kResidentAcc) (accMov<160 + 24 * K + R, 24 * Q + R>(), ...);
+    else (accFromV<160 + 24 * K + R, (int)kResidentVgprBase + 24 * (Q - (int)kResidentAcc) + R>(), ...);
 }
-__device__ __forceinline__ void accLoadResident(uint32_t q, const float4* row) {
-    switch (q) {
-        case 0: accLoadContact<0>(row); break; case 1: accLoadContact<1>(row); break; case 2: accLoadContact<2>(row); break;
-        case 3: accLoadContact<3>(row); break; case 4: accLoadContact<4>(row); break; default: accLoadContact<5>(row); break;
+template <int NPOS, int Q, int K> __device__ __forceinline__ void accCopyContact() { if constexpr (Q < NPOS) accCopyContactImpl<Q, K>(std::make_integer_sequence<int, 24>()); }
+template <int LO> __device__ __forceinline__ void accLoad4(const float4* p) { asm volatile("global_load_dwordx4 a[%0:%1], %2, off" : : "n"(LO), "n"(LO + 3), "v"(p) : "memory"); }
+template <int LO> __device__ __forceinline__ void vgprLoad4(const float4* p) { asm volatile("global_load_dwordx4 v[%0:%1], %2, off" : : "n"(LO), "n"(LO + 3), "v"(p) : "memory", "v255"); }
+template <int NPOS, int Q> __device__ __forceinline__ void accLoadContact(const float4* row) {   // the six rows of one contact of a tile -> position Q
+    if constexpr (Q < (int)kResidentAcc) {
+        accLoad4<24 * Q + 0>(row + 0u * 64u); accLoad4<24 * Q + 4>(row + 1u * 64u); accLoad4<24 * Q + 8>(row + 2u * 64u);
+        accLoad4<24 * Q + 12>(row + 3u * 64u); accLoad4<24 * Q + 16>(row + 4u * 64u); accLoad4<24 * Q + 20>(row + 5u * 64u);
+    } else if constexpr (Q < NPOS) {
+        constexpr int B = (int)kResidentVgprBase + 24 * (Q - (int)kResidentAcc);
+        vgprLoad4<B + 0>(row + 0u * 64u); vgprLoad4<B + 4>(row + 1u * 64u); vgprLoad4<B + 8>(row + 2u * 64u);
+        vgprLoad4<B + 12>(row + 3u * 64u); vgprLoad4<B + 16>(row + 4u * 64u); vgprLoad4<B + 20>(row + 5u * 64u);
     }
 }
-template <int Q> __device__ __forceinline__ void accCopyTile(uint32_t cnt) {   // resident positions Q .. Q + cnt - 1 -> ring contacts 0 .. cnt - 1
-    accCopyContact<Q, 0>();
-    if (1u < cnt) accCopyContact<Q + 1, 1>();
-    if (2u < cnt) accCopyContact<Q + 2, 2>();
-    if (3u < cnt) accCopyContact<Q + 3, 3>();
-}
-__device__ __forceinline__ void accCopyResident(uint32_t q, uint32_t cnt) {
+template <int NPOS> __device__ __forceinline__ void accLoadResident(uint32_t q, const float4* row) {
     switch (q) {
-        case 0: accCopyTile<0>(cnt); break; case 1: accCopyTile<1>(cnt); break; case 2: accCopyTile<2>(cnt); break;
-        case 3: accCopyTile<3>(cnt); break; case 4: accCopyTile<4>(cnt); break; default: accCopyTile<5>(cnt); break;
+        case 0: accLoadContact<NPOS, 0>(row); break; case 1: accLoadContact<NPOS, 1>(row); break; case 2: accLoadContact<NPOS, 2>(row); break;
+        case 3: accLoadContact<NPOS, 3>(row); break; case 4: accLoadContact<NPOS, 4>(row); break; case 5: accLoadContact<NPOS, 5>(row); break;
+        case 6: accLoadContact<NPOS, 6>(row); break; case 7: accLoadContact<NPOS, 7>(row); break; default: accLoadContact<NPOS, 8>(row); break;
+    }
+}
+template <int NPOS, int Q> __device__ __forceinline__ void accCopyTile(uint32_t cnt) {   // resident positions Q .. Q + cnt - 1 -> ring contacts 0 .. cnt - 1
+    accCopyContact<NPOS, Q, 0>();
+    if (1u < cnt) accCopyContact<NPOS, Q + 1, 1>();
+    if (2u < cnt) accCopyContact<NPOS, Q + 2, 2>();
+    if (3u < cnt) accCopyContact<NPOS, Q + 3, 3>();
+}
+template <int NPOS> __device__ __forceinline__ void accCopyResident(uint32_t q, uint32_t cnt) {
+    switch (q) {
+        case 0: accCopyTile<NPOS, 0>(cnt); break; case 1: accCopyTile<NPOS, 1>(cnt); break; case 2: accCopyTile<NPOS, 2>(cnt); break;
+        case 3: accCopyTile<NPOS, 3>(cnt); break; case 4: accCopyTile<NPOS, 4>(cnt); break; case 5: accCopyTile<NPOS, 5>(cnt); break;
+        case 6: accCopyTile<NPOS, 6>(cnt); break; case 7: accCopyTile<NPOS, 7>(cnt); break; default: accCopyTile<NPOS, 8>(cnt); break;
     }
 }
 
@@ -2866,11 +2881,13 @@ __device__ __forceinline__ void accCopyResident(uint32_t q, uint32_t cnt) {
 // handed over through the XCD's L2 in the cached array gVelL; all others through memory in gVel as before.
 // IMPLDS = false (piles beyond ~1.2 M manifolds): nothing per slot but a 20-byte descriptor stays in LDS; the accumulated
 // impulses travel as tagged granules in `imp` exactly as in k_contact_solve_flow (no size limit left).
+#define MI_PERSIST_PARAMS uint32_t sweeps, uint32_t maxSlots, const uint2* __restrict__ tileDesc, const uint4* slotMeta, const float4* __restrict__ slotNormal, \
+    const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* gVel, StepScalars* sc, uint32_t xcdOnly, \
+    const uint32_t* __restrict__ xcdTiles, uint32_t listCap, const unsigned long long* __restrict__ bodyOwner, float4* gVelL, uint4* slotMetaW, float4* imp, uint32_t xcdFault, \
+    uint32_t resident /* 1: rows of the first tiles stay in a0..a143 (and v184..v255) */
+#define MI_PERSIST_PASS sweeps, maxSlots, tileDesc, slotMeta, slotNormal, slotMass, rows, gVel, sc, xcdOnly, xcdTiles, listCap, bodyOwner, gVelL, slotMetaW, imp, xcdFault, resident
 template <bool METALDS, bool XCD, bool IMPLDS>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIST_WPE))) void k_contact_solve_persist(
-    uint32_t sweeps, uint32_t maxSlots, const uint2* __restrict__ tileDesc, const uint4* slotMeta, const float4* __restrict__ slotNormal,
-    const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* gVel, StepScalars* sc, uint32_t xcdOnly,
-    const uint32_t* __restrict__ xcdTiles, uint32_t listCap, const unsigned long long* __restrict__ bodyOwner, float4* gVelL, uint4* slotMetaW, float4* imp, uint32_t xcdFault, uint32_t resident /* 1: rows of the first tiles stay in a0..a143 */) {
+__device__ __forceinline__ void persistSolveBody(MI_PERSIST_PARAMS) {
     // LDS per workgroup: [maxSlots] x { meta uint4[64], normal float4[64], mass float2[64] } (constant over the sweeps; METALDS only), then the
     // impulses float2[4 * maxSlots][64], then the per-slot (first contact-tile, contacts per manifold, impulse offset)
     extern __shared__ __attribute__((aligned(16))) unsigned char ldsRaw[];
@@ -2898,6 +2915,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
     }
     uint32_t* lTile = reinterpret_cast<uint32_t*>(lDesc + 3u * (size_t)maxSlots);   // [maxSlots] tile of every slot
     uint32_t* lCrit = lTile + maxSlots;                                             // [maxSlots] 1: the slot had to poll in the previous sweep
+    constexpr int kResidentPositions = METALDS ? 9 : 6;
     uint32_t* lRes = lCrit + maxSlots;                                              // [maxSlots] first resident position of the slot's rows, or 0xFF: they stream
     uint32_t mySlots = 0, off = 0, resNext = 0;
     for (uint32_t li = wid; li < numTiles && mySlots < maxSlots; li += numWaves, ++mySlots) {
@@ -2906,7 +2924,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
         const bool res = resident && resNext + d.y <= kResidentPositions;
         if (lane == 0) { lTile[mySlots] = tile; lCrit[mySlots] = 0u; lRes[mySlots] = res ? resNext : 0xFFu; }
         if (res) {   // (issued here, landed by the vmcnt(0) behind the loop)
-            for (uint32_t k = 0; k < d.y; ++k) accLoadResident(resNext + k, rows + ((size_t)d.x + k) * (kRows * 64u) + lane);
+            for (uint32_t k = 0; k < d.y; ++k) accLoadResident<kResidentPositions>(resNext + k, rows + ((size_t)d.x + k) * (kRows * 64u) + lane);
             resNext += d.y;
         }
         if (XCD) {   // which of this slot's two bodies are XCD-local -> bits 8 / 9 of meta.w (read back from LDS or global below)
@@ -2948,7 +2966,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
             nxMeta = XCD ? slotMetaW[at] : slotMeta[at]; nxNf = slotNormal[at]; nxMass = slotMass[at];
         }
         if (MI_KNOCK(0)) return 0u;
-        if (const uint32_t q = lRes[slot]; q != 0xFFu) { accCopyResident(q, cnt); return 0u; }   // resident: register moves, nothing enters the memory queue
+        if (const uint32_t q = lRes[slot]; q != 0xFFu) { accCopyResident<kResidentPositions>(q, cnt); return 0u; }   // resident: register moves, nothing enters the memory queue
         {
             const float4* row = rows + (size_t)ct * (kRows * 64u) + lane;   // row (k, r) of the tile at + (k * kRows + r) * 64
             if (0u < cnt) MI_ACC_LOAD(160, 161, 162, 163, row + 0u * 64u);
@@ -3042,6 +3060,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIS
             }
         }
 }
+
+// The kernels proper.  The two variants with the slot data in LDS fit into 184 architectural registers: theirs are capped there (amdgpu_num_vgpr takes no template
+// argument, hence explicit specialisations) and v184..v255 hold three more resident positions.
+#define MI_PERSIST_KERNEL_ATTRS __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIST_WPE)))
+template <bool METALDS, bool XCD, bool IMPLDS>
+MI_PERSIST_KERNEL_ATTRS void k_contact_solve_persist(MI_PERSIST_PARAMS) { persistSolveBody<METALDS, XCD, IMPLDS>(MI_PERSIST_PASS); }
+template <> MI_PERSIST_KERNEL_ATTRS __attribute__((amdgpu_num_vgpr(184))) void k_contact_solve_persist<true, true, true>(MI_PERSIST_PARAMS) { persistSolveBody<true, true, true>(MI_PERSIST_PASS); }
+template <> MI_PERSIST_KERNEL_ATTRS __attribute__((amdgpu_num_vgpr(184))) void k_contact_solve_persist<true, false, true>(MI_PERSIST_PARAMS) { persistSolveBody<true, false, true>(MI_PERSIST_PASS); }
+static_assert(kResidentVgprBase == 184, "the cap of the specialisations above");
 
 // Overflow colour (a body with > 64 incident manifolds): sequential, one lane, slots in ascending pair-key order.
 __global__ void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
