@@ -342,6 +342,15 @@ class World:
         p = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
         self.L.check(self.L.fn("debug_set_solve_order")(self.h, _ptr(p) if len(p) else None, C.c_uint32(len(p))), "debug_set_solve_order")
 
+    def debug_set_solve_dataflow(self, enable=True):
+        """mi_debug_set_solve_dataflow: steps that follow a caller's order run it through the production contact solver (levels of the order as colours)."""
+        self.L.check(self.L.fn("debug_set_solve_dataflow")(self.h, C.c_uint32(1 if enable else 0)), "debug_set_solve_dataflow")
+
+    def debug_solve_order_depth(self):
+        d = C.c_uint32()
+        self.L.check(self.L.fn("debug_solve_order_depth")(self.h, C.byref(d)), "debug_solve_order_depth")
+        return d.value
+
     def save_checkpoint(self):
         size = C.c_uint64()
         self.L.check(self.L.fn("world_save_checkpoint")(self.h, None, C.c_uint64(0), C.byref(size)), "world_save_checkpoint")

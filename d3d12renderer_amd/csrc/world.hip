@@ -380,7 +380,7 @@ struct mi_world {
     bool scalarsClean = false;   // the device-side step scalars / counters are already cleared for the next attempt (k_publish_readback did k_reset_scalars' work)
     uint32_t sapAxis = 0;        // sorting axis for the next step (collision_broad.cpp:443-444), host copy
     // mi_debug_set_solve_order: the next internal step solves these oriented collider pairs (a << 29 | b) sequentially, in this order, and the joints in pool order
-    std::vector<uint64_t> debugOrder; std::vector<uint32_t> debugRank; bool debugOrderPending = false;
+    std::vector<uint64_t> debugOrder; std::vector<uint32_t> debugRank; bool debugOrderPending = false, debugOrderDataflow = false, debugOrderLevelled = false; uint32_t debugOrderDepth = 0, debugOrderDepthLast = 0;
     int applyDebugOrder();       // all manifolds into the sequential (overflow) colour; their slots in the caller's order
     int orientPairsLikeDebugOrder();   // equal-type pairs listed the other way round are turned (ties on the sweep axis: the reference's orientation follows its endpoint array's history)
 };

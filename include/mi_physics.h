@@ -340,6 +340,14 @@ MI_API int mi_world_get_manifold_colors(mi_world* world, uint32_t* out_colors, u
  *                              (MI_ERR_UNSUPPORTED). */
 MI_API int mi_debug_set_sweep_axis(mi_world* world, uint32_t axis);
 MI_API int mi_debug_set_solve_order(mi_world* world, const uint32_t* pairs, uint32_t count);
+/*   mi_debug_set_solve_dataflow (sticky switch)  a step that follows a caller's order runs it through the PRODUCTION contact solver instead of the one-lane kernel: every
+ *                              manifold is coloured with its level in the order's dependency graph (1 + the highest level among the earlier manifolds of its bodies),
+ *                              so the colour-major dataflow schedule — bins, tiles, version bookkeeping, k_contact_solve_persist's tile code — performs the caller's
+ *                              sequence of updates on every body: the caller's sequential result, bit for bit.  Needs an order at most 64 levels deep and no joints;
+ *                              otherwise that step uses the one-lane kernel as before.  mi_debug_solve_order_depth: the depth the last such step ran with (0: it did not).
+ *                              The reference's per-contact update it must reproduce: src/physics/constraints.cpp:3381-3449, its order 3748-3770. */
+MI_API int mi_debug_set_solve_dataflow(mi_world* world, uint32_t enable);
+MI_API int mi_debug_solve_order_depth(mi_world* world, uint32_t* out_depth);
 
 /*
  * Cloth — cloth_component (src/physics/cloth.h:5-60, cloth.cpp): a gridSizeX x gridSizeY particle grid (upper row fixed) with

@@ -157,13 +157,15 @@ def teacher_forced(make_candidate, make_reference, sc, steps, check_every=1):
     return out
 
 
-def replay_reference_order(make_candidate, make_reference, sc, steps):
+def replay_reference_order(make_candidate, make_reference, sc, steps, dataflow=False, stats=None):
     """Free-running, no state is ever copied: every step the candidate is told the axis the reference swept along and the order in which the
     reference emitted (= solves) its contact manifolds, and solves sequentially in that order (joints in pool order).  It must then BE the
     reference: every count, the contact list in order, every pose and velocity bit, every step."""
     ref = sc.populate(make_reference()); cand = sc.populate(make_candidate())
     s = sc.settings(); ids = np.arange(sc.num_bodies, dtype=np.uint32)
     most = 0
+    if dataflow:     # the order goes through the production solver (levels of the order as colours: include/mi_physics.h, mi_debug_set_solve_dataflow)
+        cand.debug_set_solve_dataflow(True)
     for i in range(steps):
         ref.step_fixed(s, sc.dt, 1)
         cr = ref.counts(); con = ref.contacts()
@@ -171,6 +173,9 @@ def replay_reference_order(make_candidate, make_reference, sc, steps):
         cand.debug_set_solve_order(manifold_order(con))
         cand.step_fixed(s, sc.dt, 1)
         cc = cand.counts()
+        if dataflow and stats is not None:
+            d = cand.debug_solve_order_depth()
+            stats.append((d, cand.solver_kind() if d else -1, cr["num_contacts"], cr["num_collisions"]))
         _same_counts(cc, cr, i, ref.aabbs() if i % 8 == 0 else None, cr["sorting_axis"])
         assert contact_set(cand.contacts()) == contact_set(con), f"step {i}: contact lists"
         assert cand.get_body_states(ids).tobytes() == ref.get_body_states(ids).tobytes(), f"step {i}: body states differ from the reference's"

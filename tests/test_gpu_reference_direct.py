@@ -47,6 +47,32 @@ def test_gpu_replaying_the_reference_order_is_the_reference_bit_for_bit(mi_lib, 
     assert most > 0 or "free flight" in name
 
 
+DATAFLOW_REPLAY = {   # small enough for the order's dependency graph to stay within the 64 colours; between them manifolds of 1, 2, 3 and 4 contacts
+    "cfg1 spheres on the ground (1 contact per manifold)": (lambda: scenes.sphere_drop(6), 200),
+    "cfg2 mixed sphere / box stack (1 - 4)": (lambda: scenes.mixed_stack(6, 4, 6), 200),
+    "cfg3 box pile (1 - 4, mostly 4 at rest)": (lambda: scenes.obb_pile(5, 3, 5, spacing=1.0), 240),
+    "cfg3 box pile, 256 boxes (the deeper steps fall back to the one-lane kernel)": (lambda: scenes.obb_pile(8, 4, 8, spacing=1.0), 120),
+    "all 21 shape pairs (1 - 4)": (lambda: scenes.shape_zoo(), 200),
+    "edge: aligned boxes": (scenes.EDGE_CASES["aligned boxes"], 160),
+    "edge: parallel capsules and cylinders (2 contacts)": (scenes.EDGE_CASES["parallel capsules and cylinders"], 160),
+}
+
+
+@pytest.mark.parametrize("name", list(DATAFLOW_REPLAY))
+def test_gpu_the_production_solver_replays_the_reference_order_bit_for_bit(mi_lib, ref_world, name):
+    """The replay above runs the reference's order through the one-lane kernel (k_contact_solve_serial); this one runs it through the PRODUCTION path — colours =
+    levels of the order's dependency graph, then the ordinary schedule, k_contact_init's version bookkeeping and k_contact_solve_persist's processTile — and must
+    again BE the reference, every bit of every step (src/physics/constraints.cpp:3381-3449 per contact, 3748-3770 per sweep)."""
+    make, steps = DATAFLOW_REPLAY[name]
+    stats = []
+    replay_reference_order(lambda: mi_lib.create_world(0), ref_world, make(), steps, dataflow=True, stats=stats)
+    ran = [t for t in stats if t[0] > 0]
+    with_contacts = [t for t in stats if t[3] > 0]
+    assert len(ran) > steps // 4, f"{len(ran)} of {len(with_contacts)} steps with contacts went through the dataflow solver"
+    assert all(t[1] in (2, 4, 5) for t in ran), f"solver kinds {sorted(set(t[1] for t in ran))}: not the persistent kernel"
+    print(f"\n[dataflow replay] {name}: {len(ran)} of {len(with_contacts)} steps with contacts through k_contact_solve_persist, order depth up to {max(t[0] for t in ran)} levels, up to {max(t[2] for t in ran)} contacts")
+
+
 TEACHER = {
     "cfg1 4096 spheres": (lambda: scenes.sphere_drop(16), 240, 1),
     "cfg2 16384 mixed": (lambda: scenes.mixed_stack(32, 16, 32), 200, 10),
