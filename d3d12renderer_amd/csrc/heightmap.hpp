@@ -302,10 +302,14 @@ __device__ __forceinline__ bool hmActive(uint32_t tag, uint32_t& type) {
 struct HmOut {   // where the WRITE passes put contact j of collider i
     StepScalars* sc; uint32_t pairCap; uint64_t* pairsA; uint64_t* pairsB; uint64_t* npPacked; float4* npNormal; float4* npPoints;
     __device__ bool ready() const { return !sc->specOverflow && sc->numPairs + sc->numHmContacts <= pairCap; }
-    __device__ void put(uint32_t first, uint32_t i, uint32_t j, const TriContact& t) const {
-        const uint32_t p = first + j;
-        (sc->partitioned ? pairsB : pairsA)[p] = ((uint64_t)kHmBucket << 58) | ((uint64_t)i << 29) | (uint64_t)(kHeightmapVirtualBase + j);
-        npPacked[p] = (1ull << 32) | 1ull;
+    // Contact j of the collider's `count` goes to pair record first + j (one record per contact: point, depth, ITS normal).  Four consecutive records are ONE manifold
+    // (round 6): the record of contact 4 g is the manifold's head (flag 1, contacts min(4, count - 4 g), key (collider, virtual index base + g)), the other three carry
+    // (flag 0, 0 contacts) and only lend their point and normal — k_contact_init reads contact k of a terrain manifold from record head + k.  A box resting on eight
+    // terrain contacts is two manifolds of one lane each, not eight colours.
+    __device__ void put(uint32_t first, uint32_t i, uint32_t j, uint32_t count, const TriContact& t) const {
+        const uint32_t p = first + j, g = j >> 2;
+        (sc->partitioned ? pairsB : pairsA)[p] = ((uint64_t)kHmBucket << 58) | ((uint64_t)i << 29) | (uint64_t)(kHeightmapVirtualBase + g);
+        npPacked[p] = (j & 3u) ? 0ull : ((1ull << 32) | (unsigned long long)min(4u, count - j));
         npNormal[p] = f4(t.normal, 0.f);
         npPoints[4 * (size_t)p] = f4(t.point, t.depth);
     }
@@ -382,7 +386,7 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
             }
             if (WRITE) {
 #pragma unroll
-                for (uint32_t b = 0; b < 2u; ++b) if (hit[b] && found + before[b] < count) out.put(first, i, found + before[b], tc[b]);
+                for (uint32_t b = 0; b < 2u; ++b) if (hit[b] && found + before[b] < count) out.put(first, i, found + before[b], count, tc[b]);
             } else {
 #pragma unroll
                 for (uint32_t b = 0; b < 2u; ++b) if (hit[b]) {
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
     if (lane != 0) return;
     if (WRITE) {
         TriContact t;
-        if (found < count && hmLowestPoint(hm, s, hulls, t)) out.put(first, i, found, t);
+        if (found < count && hmLowestPoint(hm, s, hulls, t)) out.put(first, i, found, count, t);
         return;
     }
     if (slow) { hmPacked[i] = 0ull; hmSlow[i] = 1; return; }
@@ -430,7 +434,7 @@ __global__ __launch_bounds__(256) void k_hm_write_stashed(uint32_t nc, Heightmap
         const V3 pe = tri ? hmVertex(hm, heights, chunkMin, qx + 1u, qz + 1u) : hmVertex(hm, heights, chunkMin, qx, qz);
         ok = tri ? ts.test(pc, pb, pe, tc) : ts.test(pe, pb, pc, tc);
     }
-    if (ok) out.put(out.sc->numPairs + (uint32_t)hmScan[i], i, j, tc);
+    if (ok) out.put(out.sc->numPairs + (uint32_t)hmScan[i], i, j, count, tc);
 }
 template <bool WRITE>
 __global__ __launch_bounds__(64) void k_hm_slow(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(64) void k_hm_slow(uint32_t nc, HeightmapParams hm,
         const uint32_t count = (uint32_t)hmPacked[i];
         if (!count || !out.ready()) return;
         const uint32_t first = out.sc->numPairs + (uint32_t)hmScan[i];
-        heightmapContacts(hm, s, hulls, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [&](uint32_t j, const TriContact& t) { if (j < count) out.put(first, i, j, t); });
+        heightmapContacts(hm, s, hulls, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [&](uint32_t j, const TriContact& t) { if (j < count) out.put(first, i, j, count, t); });
     } else {
         const uint32_t found = heightmapContacts(hm, s, hulls, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [](uint32_t, const TriContact&) {});
         hmPacked[i] = (unsigned long long)found | (found ? 1ull << 32 : 0ull);

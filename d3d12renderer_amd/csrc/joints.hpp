@@ -834,14 +834,14 @@ __device__ __forceinline__ void privateIsland(uint32_t sweeps, uint32_t island, 
     // this lane's manifold
     const uint32_t nPriv = min(ip.fill[island], kIslandMaxContacts);
     const bool hasContact = lane < nPriv;
-    uint32_t colour = 0xFFFFFFFFu, cnt = 0;
+    uint32_t colour = 0xFFFFFFFFu, cnt = 0; bool perContactNormal = false;   // (a terrain manifold: heightmap.hpp, HmOut::put)
     uint4 meta = make_uint4(0u, 0u, 0u, 0u); float4 nf = make_float4(0.f, 0.f, 0.f, 0.f); float2 mass = make_float2(0.f, 0.f);
     ContactRows c[4];
     float2 im[4] = {make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f), make_float2(0.f, 0.f)};   // no warm start (constraints.cpp:3312-3313)
     if (hasContact) {
         const uint4 e = ip.entries[(size_t)island * kIslandMaxContacts + lane];
         const uint32_t slot = e.x, ln = slot & 63u;
-        colour = e.z & 0xFFu; cnt = e.z >> 8;
+        colour = e.z & 0xFFu; cnt = (e.z >> 8) & 0xFFu; perContactNormal = ((e.z >> 16) & 1u) != 0u;
         meta = slotMeta[slot]; nf = slotNormal[slot]; mass = slotMass[slot];
 #pragma unroll
         for (uint32_t k = 0; k < 4u; ++k) if (k < cnt) {
@@ -878,7 +878,7 @@ __device__ __forceinline__ void privateIsland(uint32_t sweeps, uint32_t island, 
                 pv.x = pk2(a0.x, b0.x); pv.y = pk2(a0.y, b0.y); pv.z = pk2(a0.z, b0.z);
                 pw.x = pk2(a1.x, b1.x); pw.y = pk2(a1.y, b1.y); pw.z = pk2(a1.z, b1.z);
 #pragma unroll
-                for (uint32_t k = 0; k < 4u; ++k) if (k < cnt) solveOnePk(c[k], nf, im[k], sMass, pv, pw);
+                for (uint32_t k = 0; k < 4u; ++k) if (k < cnt) solveOnePk(c[k], contactNormal(c[k], nf, perContactNormal), im[k], sMass, pv, pw);
                 if (la >= 0 && mass.x != 0.f) { lds.v[la] = make_float4(pv.x.x, pv.y.x, pv.z.x, a0.w); lds.w[la] = make_float4(pw.x.x, pw.y.x, pw.z.x, a1.w); }
                 if (lb >= 0 && mass.y != 0.f) { lds.v[lb] = make_float4(pv.x.y, pv.y.y, pv.z.y, b0.w); lds.w[lb] = make_float4(pw.x.y, pw.y.y, pw.z.y, b1.w); }
             }

@@ -60,11 +60,12 @@ struct StepScalars {  // device-resident per-step scalars
     uint32_t numCells;             // cells of this step's broad-phase grid
     uint32_t numPairsFound;        // pair count of a step whose speculative pair bound was exceeded (numPairs is zeroed then)
     uint32_t tailRounds;           // colouring rounds k_bin_hist ran itself this step (colorTail; 0: the enqueued rounds were enough)
-    uint32_t reserved15[15];
+    uint32_t numHmManifolds;       // heightmap terrain: manifolds the terrain contacts were grouped into (up to four contacts of one collider each; k_emit_manifolds)
+    uint32_t reserved14[14];
     uint32_t numEvents;            // collision begin / end events of this step (when events are enabled)
     uint32_t numInterPairs;        // AABB overlaps between a rigid-body collider and a trigger / force-field collider
     uint32_t numInteractions;      // ... of which the boolean overlap test passed (non_collision_interaction records)
-    uint32_t numHmContacts;        // heightmap terrain: contacts of this step (each is a one-contact manifold) ...
+    uint32_t numHmContacts;        // heightmap terrain: contacts of this step (one pair record each; four consecutive ones of a collider form a manifold) ...
     uint32_t numHmColliders;       // ... and the colliders they belong to (= the reference's collision count for the terrain)
     uint32_t numEpa;               // intersecting GJK pairs queued for k_narrow_epa
     uint32_t xcdCount[8];          // XCD-partitioned solver: tiles owned by each XCD (k_build_tiles)
@@ -1411,7 +1412,8 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
     uint32_t bA = __float_as_uint(ma.z), bB = __float_as_uint(mb.z);
     manPair[m] = p;
     manBodies[m] = make_uint2(bA, bB);
-    manInfo[m] = make_uint2(cnt | (conOff << 3), fr);
+    manInfo[m] = make_uint2(cnt | (conOff << 3) | (terrain ? 0x80000000u : 0u), fr);   // bit 31: a terrain manifold — contact k and ITS normal live in pair record p + k (heightmap.hpp, HmOut::put)
+    if (const unsigned long long tm = __ballot(terrain); tm != 0ull && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)tm) - 1u) atomicAdd(&sc->numHmManifolds, (uint32_t)__popcll(tm));   // (part of the wave has returned: count by ballot)
     uint32_t dynA = __float_as_uint(ma.w) ? 0x80000000u : 0u;
     uint32_t dynB = __float_as_uint(mb.w) ? 0x80000000u : 0u;
     uint64_t prio = pairPriority(a, b);
@@ -2124,7 +2126,7 @@ struct IslandPrivate {
     uint32_t* shared;             // [islands] this step: 1 = some manifold couples the island to a dynamic body outside it (or is overflow-coloured)
     uint32_t* count;              // [islands] this step: manifolds touching the island
     uint32_t* fill;               // [islands] this step: entries appended by k_contact_init
-    uint4* entries;               // [islands][kIslandMaxContacts]: (slot, first contact-tile, colour | contacts << 8, -)
+    uint4* entries;               // [islands][kIslandMaxContacts]: (slot, first contact-tile, colour | contacts << 8 | per-contact normals << 16, manifold)
 };
 __device__ __forceinline__ bool islandIsPrivate(const IslandPrivate& ip, uint32_t island) { return ip.shared[island] == 0u && ip.count[island] <= kIslandMaxContacts; }
 // K11 "Initialize collision constraints" (src/physics/constraints.cpp:3307-3379): one wave per tile, one lane per slot.
@@ -2168,6 +2170,7 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
     uint2 bodies = manBodies[m];
     uint2 info = manInfo[m];
     uint32_t cnt = info.x & 7u;
+    const bool terrain = (info.x >> 31) != 0u;   // contact k and its OWN normal come from pair record p + k (heightmap.hpp, HmOut::put)
     float4 pa = gPos[bodies.x], pb = gPos[bodies.y];
     V3 xA = xyz(pa), xB = xyz(pb);
     float imA = pa.w, imB = pb.w;
@@ -2189,10 +2192,10 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
         if (isl != 0xFFFFFFFFu && islandIsPrivate(ip, isl)) {   // (a private island's manifolds have no dynamic body outside it: k_island_classify)
             priv = true;
             const uint32_t at = atomicAdd(&ip.fill[isl], 1u);
-            if (at < kIslandMaxContacts) ip.entries[(size_t)isl * kIslandMaxContacts + at] = make_uint4(tile * 64u + lane, (uint32_t)ctBase, color[m] | (cnt << 8), m);
+            if (at < kIslandMaxContacts) ip.entries[(size_t)isl * kIslandMaxContacts + at] = make_uint4(tile * 64u + lane, (uint32_t)ctBase, color[m] | (cnt << 8) | (terrain ? 1u << 16 : 0u), m);
         }
     }
-    const uint32_t metaW = priv ? 0u : cnt;   // (.w = 0: not a slot of the tile solver)
+    const uint32_t metaW = priv ? 0u : (cnt | (terrain ? 0x400u : 0u));   // (.w = 0: not a slot of the tile solver; bits 8 / 9: XCD-local bodies (the solver sets them); bit 10: per-contact normals)
     if (kw == 0) {
         slotMeta[(size_t)tile * 64u + lane] = make_uint4(bodies.x, bodies.y, packed, metaW);
         slotMass[(size_t)tile * 64u + lane] = make_float2(imA, imB);
@@ -2205,13 +2208,14 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
     M3 IA = loadM3(gInvI, bodies.x), IB = loadM3(gInvI, bodies.y);
     V3 vA = xyz(gVel[2 * bodies.x]), wA = xyz(gVel[2 * bodies.x + 1]);
     V3 vB = xyz(gVel[2 * bodies.y]), wB = xyz(gVel[2 * bodies.y + 1]);
-    V3 n = xyz(npNormal[p]);
+    V3 n = xyz(npNormal[p]);   // (a terrain manifold: the normal of its first contact; the others follow in the loop)
     float invDt = 1.f / dt;
     float friction = (float)(info.y >> 16) / (float)0xFFFF;
     float restitution = (float)(info.y & 0xFFFF) / (float)0xFFFF;
     if (kw == 0) slotNormal[(size_t)tile * 64u + lane] = f4(n, friction);
     for (uint32_t k = 0; k < cnt; ++k) {
-        float4 pd = npPoints[4 * p + k];
+        float4 pd = terrain ? npPoints[4 * ((size_t)p + k)] : npPoints[4 * (size_t)p + k];
+        if (terrain && k) n = xyz(npNormal[p + k]);
         V3 point = xyz(pd); float depth = pd.w;
         V3 rA = point - xA, rB = point - xB;
         V3 avA = vA + cross(wA, rA), avB = vB + cross(wB, rB);
@@ -2234,7 +2238,9 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
         }
         float4* __restrict__ row = rows + (ctBase + k) * (kRows * 64u) + lane;
         storeStream(row + 0 * 64, f4(rA, effN));
-        storeStream(row + 1 * 64, f4(rB, effT));
+        // (terrain: body B is the static dummy — zero velocity, zero inverse mass and inertia — so its lever arm only ever meets zeros (v_B + w_B x r_B = +0 whatever
+        // r_B is, finite); the contact's own normal travels in its place, where the solver's per-contact-normal path picks it up)
+        storeStream(row + 1 * 64, f4(terrain ? n : rB, effT));
         storeStream(row + 2 * 64, f4(t, bias));
         storeStream(row + 3 * 64, make_float4(-tA.x, -tA.y, -tA.z, tB.x));
         storeStream(row + 4 * 64, make_float4(tB.y, tB.z, -nA.x, -nA.y));
@@ -2246,6 +2252,12 @@ __global__ __launch_bounds__(64) void k_contact_init(const StepScalars* __restri
 // One PGS update of one contact (src/physics/constraints.cpp:3381-3449): friction first (clamped with the
 // previous normal impulse), then the normal row.
 struct ContactRows { float4 r[kRows]; float4 imp; };   // imp = (normal, tangent, sweep tag, -)
+// (normal, friction) of ONE contact: the slot's — every contact of a manifold shares the normal — except in a terrain manifold (slotMeta.w bit 10), whose contacts each
+// carry their own in the place of body B's lever arm (k_contact_init; src/physics/heightmap_collision.cpp:575-594: one contact per triangle hit, each with its normal)
+constexpr uint32_t kMetaPerContactNormal = 0x400u;
+__device__ __forceinline__ float4 contactNormal(const ContactRows& c, const float4 nf, const bool perContact) {
+    return perContact ? make_float4(c.r[1].x, c.r[1].y, c.r[1].z, nf.w) : nf;
+}
 
 __device__ __forceinline__ void solveOne(const ContactRows& c, const float4 nf, float2& im, float imA, float imB, V3& vA, V3& wA, V3& vB, V3& wB) {
     V3 rA = xyz(c.r[0]), rB = xyz(c.r[1]), t = xyz(c.r[2]), n = xyz(nf);
@@ -2327,14 +2339,15 @@ __device__ __forceinline__ void solveOnePk(const ContactRows& c, const float4 nf
 
 // The rows of one contact as the packed update wants them — (body A, body B) side by side in 64-bit register pairs — built BEFORE a tile waits for its bodies (packRows), and
 // pinned there: the register moves that line the halves up then happen while the body loads are in flight, not between the bodies' arrival and the publish.
-struct PkRows { f32x2 rx, ry, rz, Tx, Ty, Tz, Nx, Ny, Nz; float tx, ty, tz, effN, effT, bias; };
+struct PkRows { f32x2 rx, ry, rz, Tx, Ty, Tz, Nx, Ny, Nz; float tx, ty, tz, effN, effT, bias, nx, ny, nz; };   // (nx, ny, nz: the contact's normal — the slot's, or its own in a terrain manifold)
 __device__ __forceinline__ void pinPair(f32x2& p) { asm volatile("" : "+v"(p)); }
 // PIN: the pairs are pinned where they are built (the persistent kernel, whose rows come out of its prefetch registers by inline asm).  NOT where the rows come from the
 // compiler's own loads (flowTile): there the pinned form gave wrong results on the device in every run (round 5; the unpinned form and the pinned persistent kernel are
 // bit-exact, the generated code of the failing form shows no hazard a static check finds) — not understood, so the dispatch-ordered kernels keep the compiler's placement.
 template <bool PIN>
-__device__ __forceinline__ PkRows packRows(const ContactRows& c) {
+__device__ __forceinline__ PkRows packRows(const ContactRows& c, const float4 nf, const bool perContactNormal) {
     PkRows k;
+    k.nx = perContactNormal ? c.r[1].x : nf.x; k.ny = perContactNormal ? c.r[1].y : nf.y; k.nz = perContactNormal ? c.r[1].z : nf.z;   // (before the wait for the bodies: off the dependency chain)
     k.rx = pk2(c.r[0].x, c.r[1].x); k.ry = pk2(c.r[0].y, c.r[1].y); k.rz = pk2(c.r[0].z, c.r[1].z);
     // (body A's halves come negated from k_contact_init.  They pass through an empty asm: left alone, the optimiser merges these element picks into 4-wide shuffles that the
     // backend legalises THROUGH SCRATCH MEMORY)
@@ -2349,7 +2362,7 @@ __device__ __forceinline__ PkRows packRows(const ContactRows& c) {
 // hi - lo of a pair (body B - body A) as ONE scalar subtraction each (left to itself the SLP vectoriser packs two of the three and pays three register moves for it)
 __device__ __forceinline__ float subHiLo(const f32x2 p) { float d; asm("v_sub_f32 %0, %1, %2" : "=v"(d) : "v"(p.y), "v"(p.x)); return d; }
 __device__ __forceinline__ void solveOnePkRows(const PkRows& c, const float4 nf, float2& im, const f32x2 sMass /* (-imA, imB) */, P3& v, P3& w) {
-    const V3 t(c.tx, c.ty, c.tz), n = xyz(nf);
+    const V3 t(c.tx, c.ty, c.tz), n(c.nx, c.ny, c.nz);
     P3 r; r.x = c.rx; r.y = c.ry; r.z = c.rz;
     {
         P3 cr = pcross(w, r);
@@ -2409,7 +2422,7 @@ __device__ __forceinline__ void solveTile(uint32_t tile, uint32_t ctBase, uint32
 #pragma unroll
     for (int k = 0; k < CNT; ++k) {
         float2 im = make_float2(c[k].imp.x, c[k].imp.y);
-        solveOne(c[k], nf, im, imA, imB, vA, wA, vB, wB);
+        solveOne(c[k], contactNormal(c[k], nf, (meta.w & kMetaPerContactNormal) != 0u), im, imA, imB, vA, wA, vB, wB);
         if (live) imp[((size_t)ctBase + k) * 64u + lane] = make_float4(im.x, im.y, c[k].imp.z, c[k].imp.w);
     }
     if (live && imA != 0.f) { gVel[2 * bA] = f4(vA, a0.w); gVel[2 * bA + 1] = f4(wA, a1.w); }   // .w: version tags, untouched by this path
@@ -2706,7 +2719,7 @@ __device__ __forceinline__ void processTile(uint32_t ctBase, uint32_t lane, uint
     const uint32_t hookLoads = hook.early();   // (the persistent kernel: this tile's rows out of the prefetch registers, the next tile's requested)
     PkRows pkr[CNT];
 #pragma unroll
-    for (int k = 0; k < CNT; ++k) pkr[k] = packRows<std::remove_reference_t<Hook>::kPinRows>(c[k]);
+    for (int k = 0; k < CNT; ++k) pkr[k] = packRows<std::remove_reference_t<Hook>::kPinRows>(c[k], nf, k != 0 && (meta.w & kMetaPerContactNormal) != 0u);   // (contact 0: the slot's normal IS its own)
     waitVmcnt(hookLoads);   // the hook's loads are younger than the body loads: they may stay in flight
     float2 imIn[CNT];   // accumulated impulses this tile starts from
     if (!LDSIMP) {
@@ -2830,9 +2843,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_W
 // issued where the loads would have been: nothing enters the memory queue, and processTile still takes every tile's rows out of the ring, unchanged.
 // Register numbers are literals ("n" operands): position q = a[24 q .. 24 q + 23], ring contact k = a[160 + 24 k .. ].  The compiler itself never allocates an
 // accumulator register in this kernel (no spills: tests/test_capi_symbols.py reads the ISA); the ring's clobber lists make the descriptor cover a0..a255.
-// Positions 6..8 live in the ARCHITECTURAL registers v184..v255 of the variants that fit into 184 allocatable VGPRs (slot data in LDS: amdgpu_num_vgpr keeps the
-// compiler out of v184 and above): the same scheme with v_accvgpr_write_b32 as the move (solver 444 -> 433 us).  The variants that need more registers keep six.
-constexpr uint32_t kResidentAcc = 6, kResidentVgprBase = 184;
+// Positions 6 and 7 live in the ARCHITECTURAL registers v208..v255 of the variants that fit into 208 allocatable VGPRs (slot data in LDS: amdgpu_num_vgpr keeps the
+// compiler out of v208 and above): the same scheme with v_accvgpr_write_b32 as the move.  (Three such positions behind a cap of 184 were measured at 444 -> 433 us; the
+// per-contact normals of terrain manifolds then took the nine registers that made 184 enough.)  The variants that need more registers keep six.
+constexpr uint32_t kResidentAcc = 6, kResidentVgprBase = 208;
 template <int DST, int SRC> __device__ __forceinline__ void accMov() { asm volatile("v_accvgpr_mov_b32 a[%0], a[%1]" : : "n"(DST), "n"(SRC)); }
 template <int DST, int SRC> __device__ __forceinline__ void accFromV() { asm volatile("v_accvgpr_write_b32 a[%0], v[%1]" : : "n"(DST), "n"(SRC)); }
 template <int Q, int K, int... R> __device__ __forceinline__ void accCopyContactImpl(std::integer_sequence<int, R...>) {
@@ -2884,7 +2898,7 @@ template <int NPOS> __device__ __forceinline__ void accCopyResident(uint32_t q, 
 #define MI_PERSIST_PARAMS uint32_t sweeps, uint32_t maxSlots, const uint2* __restrict__ tileDesc, const uint4* slotMeta, const float4* __restrict__ slotNormal, \
     const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* gVel, StepScalars* sc, uint32_t xcdOnly, \
     const uint32_t* __restrict__ xcdTiles, uint32_t listCap, const unsigned long long* __restrict__ bodyOwner, float4* gVelL, uint4* slotMetaW, float4* imp, uint32_t xcdFault, \
-    uint32_t resident /* 1: rows of the first tiles stay in a0..a143 (and v184..v255) */
+    uint32_t resident /* 1: rows of the first tiles stay in a0..a143 (and v208..v255) */
 #define MI_PERSIST_PASS sweeps, maxSlots, tileDesc, slotMeta, slotNormal, slotMass, rows, gVel, sc, xcdOnly, xcdTiles, listCap, bodyOwner, gVelL, slotMetaW, imp, xcdFault, resident
 template <bool METALDS, bool XCD, bool IMPLDS>
 __device__ __forceinline__ void persistSolveBody(MI_PERSIST_PARAMS) {
@@ -2915,7 +2929,7 @@ __device__ __forceinline__ void persistSolveBody(MI_PERSIST_PARAMS) {
     }
     uint32_t* lTile = reinterpret_cast<uint32_t*>(lDesc + 3u * (size_t)maxSlots);   // [maxSlots] tile of every slot
     uint32_t* lCrit = lTile + maxSlots;                                             // [maxSlots] 1: the slot had to poll in the previous sweep
-    constexpr int kResidentPositions = METALDS ? 9 : 6;
+    constexpr int kResidentPositions = METALDS ? 8 : 6;
     uint32_t* lRes = lCrit + maxSlots;                                              // [maxSlots] first resident position of the slot's rows, or 0xFF: they stream
     uint32_t mySlots = 0, off = 0, resNext = 0;
     for (uint32_t li = wid; li < numTiles && mySlots < maxSlots; li += numWaves, ++mySlots) {
@@ -3061,14 +3075,14 @@ __device__ __forceinline__ void persistSolveBody(MI_PERSIST_PARAMS) {
         }
 }
 
-// The kernels proper.  The two variants with the slot data in LDS fit into 184 architectural registers: theirs are capped there (amdgpu_num_vgpr takes no template
-// argument, hence explicit specialisations) and v184..v255 hold three more resident positions.
+// The kernels proper.  The two variants with the slot data in LDS fit into 208 architectural registers: theirs are capped there (amdgpu_num_vgpr takes no template
+// argument, hence explicit specialisations) and v208..v255 hold two more resident positions.
 #define MI_PERSIST_KERNEL_ATTRS __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_PERSIST_WPE)))
 template <bool METALDS, bool XCD, bool IMPLDS>
 MI_PERSIST_KERNEL_ATTRS void k_contact_solve_persist(MI_PERSIST_PARAMS) { persistSolveBody<METALDS, XCD, IMPLDS>(MI_PERSIST_PASS); }
-template <> MI_PERSIST_KERNEL_ATTRS __attribute__((amdgpu_num_vgpr(184))) void k_contact_solve_persist<true, true, true>(MI_PERSIST_PARAMS) { persistSolveBody<true, true, true>(MI_PERSIST_PASS); }
-template <> MI_PERSIST_KERNEL_ATTRS __attribute__((amdgpu_num_vgpr(184))) void k_contact_solve_persist<true, false, true>(MI_PERSIST_PARAMS) { persistSolveBody<true, false, true>(MI_PERSIST_PASS); }
-static_assert(kResidentVgprBase == 184, "the cap of the specialisations above");
+template <> MI_PERSIST_KERNEL_ATTRS __attribute__((amdgpu_num_vgpr(208))) void k_contact_solve_persist<true, true, true>(MI_PERSIST_PARAMS) { persistSolveBody<true, true, true>(MI_PERSIST_PASS); }
+template <> MI_PERSIST_KERNEL_ATTRS __attribute__((amdgpu_num_vgpr(208))) void k_contact_solve_persist<true, false, true>(MI_PERSIST_PARAMS) { persistSolveBody<true, false, true>(MI_PERSIST_PASS); }
+static_assert(kResidentVgprBase == 208, "the cap of the specialisations above");
 
 // Overflow colour (a body with > 64 incident manifolds): sequential, one lane, slots in ascending pair-key order.
 __global__ void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
@@ -3077,7 +3091,7 @@ __global__ void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slo
     for (uint32_t j = 0; j < bi.count; ++j) {
         uint32_t tile = bi.tileStart + (j >> 6), lane = j & 63u, ctBase = bi.ctStart + (j >> 6) * 4u;
         uint4 meta = slotMeta[(size_t)tile * 64u + lane];
-        solveTileK(meta.w, tile, ctBase, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel);
+        solveTileK(meta.w & 7u, tile, ctBase, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel);
         __threadfence();
     }
 }

@@ -10,8 +10,9 @@
 //  * float -> uint32 conversions of possibly negative values (frac() of a negative coordinate, heightmap_collider.h:187-194)
 //    go through int64 like x86-64 code does, so they are defined and identical on the device;
 //  * a collider reports at most 255 contacts (the reference asserts numContacts < 256, heightmap_collision.cpp:591);
-//  * every heightmap contact is its own one-contact manifold {collider, kHeightmapVirtualBase + j} (contacts of one collider
-//    have different normals); counts.num_collisions still counts one collision per collider like the reference.
+//  * four consecutive heightmap contacts of a collider form one manifold {collider, kHeightmapVirtualBase + j / 4} (round 6; each contact keeps its own normal —
+//    the solver works per contact anyway — so the sequence of updates in the reference's order is unchanged; in the canonical order a box on eight terrain
+//    contacts is two manifolds, not eight colours); counts.num_collisions still counts one collision per collider like the reference.
 #include "ora_world.h"
 #include <algorithm>
 
@@ -233,7 +234,7 @@ static bool boxVsTriangle(vec3 center, vec3 radius, vec3 a, vec3 b, vec3 c, TriC
 
 // heightmapCollision — heightmap_collision.cpp:509-618 (for the world's heightmap; physics.cpp:1237-1248)
 void heightmapCollision(World& w) {
-    w.heightmapCollisions = 0; w.heightmapContacts = 0;
+    w.heightmapCollisions = 0; w.heightmapContacts = 0; w.heightmapManifolds = 0;
     if (!w.heightmap) return;
     const Heightmap& hm = *w.heightmap;
     const uint32_t dummy = (uint32_t)w.bodies.size();
@@ -293,8 +294,11 @@ void heightmapCollision(World& w) {
         uint32_t fr = ((uint32_t)(friction * 0xFFFF) << 16) | (uint32_t)(restitution * 0xFFFF);
         for (uint32_t j = 0; j < found.size(); ++j) {
             Contact c; c.point = found[j].point; c.penetrationDepth = found[j].depth; c.normal = found[j].normal; c.friction_restitution = fr;
-            w.colliderPairs.push_back(Pair{i, kHeightmapVirtualBase + j});
-            w.contactCounts.push_back(1);
+            if ((j & 3u) == 0u) {   // four consecutive contacts of a collider are one manifold {collider, kHeightmapVirtualBase + j / 4}: solved one after the other, each with its own normal
+                w.colliderPairs.push_back(Pair{i, kHeightmapVirtualBase + (j >> 2)});
+                w.contactCounts.push_back(std::min<uint32_t>(4u, (uint32_t)found.size() - j));
+                ++w.heightmapManifolds;
+            }
             w.contacts.push_back(c);
             w.bodyPairs.push_back(Pair{col.objectIndex, dummy});
         }

@@ -908,7 +908,7 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
     counts.num_rigid_bodies = nb;
     counts.num_colliders = (uint32_t)colliders.size();
     counts.num_broadphase_overlaps = (uint32_t)bpPairs.size();
-    counts.num_collisions = (uint32_t)colliderPairs.size() - heightmapContacts + heightmapCollisions;   // one collision per collider on the terrain
+    counts.num_collisions = (uint32_t)colliderPairs.size() - heightmapManifolds + heightmapCollisions;   // one collision per collider on the terrain
     counts.num_contacts = ncontacts;
     counts.num_colors = ncolors;
     counts.sorting_axis = axisUsed;

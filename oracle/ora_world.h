@@ -162,7 +162,7 @@ struct World {
     std::vector<Cloth*> cloths;
     uint32_t clothIterations[3] = {0, 1, 0};                      // velocity, position, drift (physics_settings defaults)
     Heightmap* heightmap = nullptr;                               // at most one per world
-    uint32_t heightmapCollisions = 0, heightmapContacts = 0;     // last step: colliders touching the terrain, their contacts
+    uint32_t heightmapCollisions = 0, heightmapContacts = 0, heightmapManifolds = 0;     // last step: colliders touching the terrain, their contacts, the manifolds (of up to four) these form
     bool eventsEnabled = false;
     std::vector<uint64_t> prevCollisionKeys;   // sorted (creationA << 26 | creationB) of the previous step's manifolds
     std::vector<mi_event> events;              // since the last poll
