@@ -446,6 +446,7 @@ def test_gpu_cloth_matches_oracle(mi_lib, oracle_mod, iters):
 @pytest.mark.parametrize("env,kind", [({}, 5), ({"MI_SOLVER": "persist"}, 5), ({"MI_SOLVER": "flow"}, 1), ({"MI_SOLVER": "persist-global"}, 5), ({"MI_PERSIST_XCD": "0"}, 2), ({"MI_PERSIST_XCD_SINGLE": "0"}, 2),
                                       ({"MI_PERSIST_XCD_SINGLE": "0", "MI_SOLVER": "persist-global"}, 2), ({"MI_PERSIST_XCD_SINGLE": "0", "MI_SOLVER": "persist-granules"}, 2),
                                       ({"MI_PERSIST_XCD_MIN": "1"}, 4), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-global"}, 4),
+                                      ({"MI_PERSIST_RESIDENT": "0"}, 5), ({"MI_PERSIST_XCD_MIN": "1", "MI_PERSIST_RESIDENT": "0"}, 4), ({"MI_PERSIST_XCD": "0", "MI_PERSIST_RESIDENT": "0"}, 2),
                                       ({"MI_SOLVER": "persist-granules"}, 5), ({"MI_PERSIST_XCD_MIN": "1", "MI_SOLVER": "persist-granules"}, 4),
                                       ({"MI_PERSIST_XCD_MIN": "1", "MI_PERSIST_XCD_FAULT": "1"}, 2), ({"MI_PERSIST_XCD_FAULT": "1"}, 2), ({"MI_READBACK": "copy"}, 5),
                                       ({"MI_PERSIST_WAVES": "8"}, 2), ({"MI_PERSIST_WAVES": "2"}, 2),
@@ -464,7 +465,8 @@ def test_gpu_other_contact_solvers_match_oracle(mi_lib, oracle_mod, monkeypatch,
     MI_FLOW_FAULT -> the dispatch-ordered kernel reports an exhausted spin budget once (what a shared device can cause): the step
     is re-run from untouched state with one launch per colour (solver kind 0) and stays there for the next 256 steps;
     MI_PERSIST_WAVES=8 / 2 -> so few persistent workgroups that each owns many tiles: the library itself then moves first the slot
-    data and then the impulses out of LDS (the choices it makes for piles of 0.5 M / 1.2 M manifolds and more)."""
+    data and then the impulses out of LDS (the choices it makes for piles of 0.5 M / 1.2 M manifolds and more);
+    MI_PERSIST_RESIDENT=0 -> every tile's rows stream through the ring (default: the rows of a wave's first tiles stay resident in registers)."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     sc = scenes.obb_pile(14, 8, 14, spacing=1.05)
@@ -689,8 +691,8 @@ def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
     out = {}
     round4_step = {"MI_FUSE_RESET": "0", "MI_ROUND0_EMIT": "0", "MI_FUSE_LARGE": "0", "MI_FINISH_IN_NARROW": "0", "MI_COLOR_TAIL": "0", "MI_FUSE_KEYS": "0"}   # every launch round 5 removed, back
     for name, env in (("default", {}), ("flow", {"MI_SOLVER": "flow"}), ("unpartitioned", {"MI_PERSIST_XCD": "0"}), ("synchronous", {"MI_ASYNC": "0"}),
-                      ("the tail colours", {"MI_COLOR_ROUNDS_MAX": "1"}), ("29 launches", round4_step)):
-        for k in ("MI_SOLVER", "MI_PERSIST_XCD", "MI_ASYNC", "MI_COLOR_ROUNDS_MAX", *round4_step):
+                      ("the tail colours", {"MI_COLOR_ROUNDS_MAX": "1"}), ("29 launches", round4_step), ("every tile's rows stream", {"MI_PERSIST_RESIDENT": "0"})):
+        for k in ("MI_SOLVER", "MI_PERSIST_XCD", "MI_ASYNC", "MI_COLOR_ROUNDS_MAX", "MI_PERSIST_RESIDENT", *round4_step):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
