@@ -8,7 +8,7 @@ HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libmi_physics.so"
 SOURCES = [CSRC / "world.hip"]
-HEADERS = [CSRC / n for n in ("dmath.hpp", "narrow.hpp", "kernels.hpp", "gjk.hpp", "joints.hpp", "heightmap.hpp", "cloth.hpp", "launcher.hpp", "knobs.hpp", "world_setup.inc", "world_step.inc", "world_joints.inc", "world_capi.inc", "world_shard.inc", "world_state.inc")] + \
+HEADERS = [CSRC / n for n in ("dmath.hpp", "narrow.hpp", "kernels.hpp", "kernels_common.hpp", "kernels_broad.hpp", "kernels_narrow.hpp", "kernels_integrate.hpp", "kernels_schedule.hpp", "kernels_contacts.hpp", "kernels_solve.hpp", "kernels_shard.hpp", "kernels_scan.hpp", "gjk.hpp", "joints.hpp", "heightmap.hpp", "cloth.hpp", "launcher.hpp", "knobs.hpp", "world_setup.inc", "world_step.inc", "world_joints.inc", "world_capi.inc", "world_shard.inc", "world_state.inc")] + \
           [HERE.parent / "include" / n for n in ("mi_physics.h", "mi_constraints.h", "mi_shard.h")]
 FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-fPIC", "-shared", "-fvisibility=hidden",
          "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math",
