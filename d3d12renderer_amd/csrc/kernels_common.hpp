@@ -92,6 +92,7 @@ struct Shards { ShardCounters c[kShards]; uint32_t extentHist[kShards][256]; };
 // sharded passes null pointers and launches one workgroup per block as before.
 constexpr uint32_t kShardRecentSteps = 2u, kShardGrid = 1024u;   // kShardGrid: workgroups of a pass that strides over the blocks
 __global__ __launch_bounds__(256) void k_fill_u32(uint32_t* __restrict__ p, uint32_t value, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = value; }
+__global__ __launch_bounds__(256) void k_fill_u32_from(uint32_t* __restrict__ p, const uint32_t* __restrict__ value, uint32_t n) { const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = *value; }
 __device__ __forceinline__ bool shardBlockRecent(const uint32_t* __restrict__ stamp, uint32_t blk, uint32_t step) { return !stamp || (int32_t)(step - stamp[blk]) <= (int32_t)kShardRecentSteps; }
 // Workgroup `first` of `stride` visits the blocks first, first + stride, ... < numBlocks that pass `live`: the tests of up to 64 candidates are made by the lanes of a wave
 // side by side (one round of loads instead of one dependent load per skipped block: 7 of 8 candidates are skipped in an 8-tile scene), then `visit(block)` runs for the

@@ -425,7 +425,14 @@ __device__ __forceinline__ void solveOnePk(const ContactRows& c, const float4 nf
 // The rows of one contact as the packed update wants them — (body A, body B) side by side in 64-bit register pairs — built BEFORE a tile waits for its bodies (packRows), and
 // pinned there: the register moves that line the halves up then happen while the body loads are in flight, not between the bodies' arrival and the publish.
 struct PkRows { f32x2 rx, ry, rz, Tx, Ty, Tz, Nx, Ny, Nz; float tx, ty, tz, effN, effT, bias, nx, ny, nz; };   // (nx, ny, nz: the contact's normal — the slot's, or its own in a terrain manifold)
+#ifdef MI_EXP_PIN_NONVOLATILE   // (tools/exp/pinned_pairs_repro.sh: variants of the unexplained wrong-result case of round 5)
+__device__ __forceinline__ void pinPair(f32x2& p) { asm("" : "+v"(p)); }
+#else
 __device__ __forceinline__ void pinPair(f32x2& p) { asm volatile("" : "+v"(p)); }
+#endif
+#ifndef MI_EXP_PIN_MASK
+#define MI_EXP_PIN_MASK 0x1FF
+#endif
 // PIN: the pairs are pinned where they are built (the persistent kernel, whose rows come out of its prefetch registers by inline asm).  NOT where the rows come from the
 // compiler's own loads (flowTile): there the pinned form gave wrong results on the device in every run (round 5; the unpinned form and the pinned persistent kernel are
 // bit-exact, the generated code of the failing form shows no hazard a static check finds) — not understood, so the dispatch-ordered kernels keep the compiler's placement.
@@ -440,7 +447,11 @@ __device__ __forceinline__ PkRows packRows(const ContactRows& c, const float4 nf
     asm("" : "+v"(tAx)); asm("" : "+v"(tAy)); asm("" : "+v"(tAz)); asm("" : "+v"(nAx)); asm("" : "+v"(nAy)); asm("" : "+v"(nAz));
     k.Tx = pk2(tAx, c.r[3].w); k.Ty = pk2(tAy, c.r[4].x); k.Tz = pk2(tAz, c.r[4].y);
     k.Nx = pk2(nAx, c.r[5].y); k.Ny = pk2(nAy, c.r[5].z); k.Nz = pk2(nAz, c.r[5].w);
-    if (PIN) { pinPair(k.rx); pinPair(k.ry); pinPair(k.rz); pinPair(k.Tx); pinPair(k.Ty); pinPair(k.Tz); pinPair(k.Nx); pinPair(k.Ny); pinPair(k.Nz); }
+    if (PIN) {
+        constexpr uint32_t M = MI_EXP_PIN_MASK;
+        if (M & 1u) pinPair(k.rx); if (M & 2u) pinPair(k.ry); if (M & 4u) pinPair(k.rz); if (M & 8u) pinPair(k.Tx); if (M & 16u) pinPair(k.Ty); if (M & 32u) pinPair(k.Tz);
+        if (M & 64u) pinPair(k.Nx); if (M & 128u) pinPair(k.Ny); if (M & 256u) pinPair(k.Nz);
+    }
     k.tx = c.r[2].x; k.ty = c.r[2].y; k.tz = c.r[2].z; k.effN = c.r[0].w; k.effT = c.r[1].w; k.bias = c.r[2].w;
     return k;
 }

@@ -61,6 +61,7 @@ __global__ __launch_bounds__(256) void k_color_round(const StepScalars* __restri
 // synchronous re-run a scene paid that outgrew the margin.  In a steady step this is one load per workgroup.
 // Words behind the round flags: [kTailBar] barrier arrivals, [kTailDone] 1 + the last round run once the tail is through.
 constexpr uint32_t kTailBar = kMaxColorRounds + 2u, kTailDone = kMaxColorRounds + 3u, kTailGroups = 256u, kRoundFlagWords = kMaxColorRounds + 4u;
+constexpr uint32_t kTailSpinBudget = 1u << 18, kTailTimedOut = 0xFFFFFFFFu;   // (~15-50 ms of polling; StepScalars::tailRounds = kTailTimedOut tells the host why the step is void)
 struct ColorTail {   // (no padding: the launcher hashes arguments bytewise)
     const uint4* colWork; uint32_t* color; unsigned long long* top0; unsigned long long* top1; unsigned long long* bodyUsed; uint32_t* roundFlags;
     uint32_t from /* first round the host did not enqueue; 0: no tail */, seamMode;
@@ -72,8 +73,8 @@ __device__ __forceinline__ void colorTail(const ColorTail& ct, StepScalars* sc) 
     uint32_t* flags = ct.roundFlags;
     if (blockIdx.x >= P) {   // not taking part: wait for the tail (its workgroups have lower indices, i.e. were dispatched before this one)
         if (threadIdx.x == 0) {
-            uint32_t budget = 1u << 22;
-            while (__hip_atomic_load(&flags[kTailDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) { __builtin_amdgcn_s_sleep(8); if (--budget == 0u) { sc->specOverflow = 1u; break; } }
+            uint32_t budget = kTailSpinBudget;
+            while (__hip_atomic_load(&flags[kTailDone], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) { __builtin_amdgcn_s_sleep(8); if (--budget == 0u) { sc->specOverflow = 1u; sc->tailRounds = kTailTimedOut; break; } }
         }
         __syncthreads();
         __threadfence();
@@ -94,7 +95,7 @@ __device__ __forceinline__ void colorTail(const ColorTail& ct, StepScalars* sc) 
         if (threadIdx.x == 0) {
             arrivals += P;
             atomicAdd(&flags[kTailBar], 1u);
-            uint32_t budget = 1u << 22;
+            uint32_t budget = kTailSpinBudget;
             while (__hip_atomic_load(&flags[kTailBar], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < arrivals) { __builtin_amdgcn_s_sleep(2); if (--budget == 0u) { failed = true; break; } }
             sMore = failed ? 2u : __hip_atomic_load(&flags[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -102,7 +103,9 @@ __device__ __forceinline__ void colorTail(const ColorTail& ct, StepScalars* sc) 
         __threadfence();
         const uint32_t more = sMore;
         __syncthreads();
-        if (more == 2u) { if (threadIdx.x == 0) sc->specOverflow = 1u; break; }   // (a participant never arrived: the step is void and re-run synchronously)
+        if (more == 2u) { if (threadIdx.x == 0) { sc->specOverflow = 1u; sc->tailRounds = kTailTimedOut; __hip_atomic_store(&flags[kTailDone], r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } return; }   // (a participant never arrived — the barrier assumes its <= 256 workgroups are co-resident,
+                                                                                                                          // which a shared or smaller device need not grant: the step is void, re-run synchronously, and the host
+                                                                                                                          // goes back to a margin of enqueued rounds for the next 256 steps)
         if (more == 0u || r + 2u >= kMaxColorRounds) break;                          // round r left no loser: everything is coloured (or: give up, colorPending tells)
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) { sc->tailRounds = r + 1u - ct.from; __hip_atomic_store(&flags[kTailDone], r + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -32,8 +32,10 @@ __global__ __launch_bounds__(256) void k_shard_classify(uint32_t nb, ShardParams
                                                         const float4* __restrict__ bCogInvMass, uint8_t* __restrict__ bodyActive, Shards* sh,
                                                         const uint32_t* __restrict__ root /* lowest body index of the body's articulated island: the island is classified as ONE */,
                                                         const uint8_t* __restrict__ known /* 1 = this rank's copy of the body is current (owned in the last step, or a record arrived) */,
-                                                        const uint8_t* __restrict__ bodyActivePrev, uint32_t* __restrict__ blockStamp, uint8_t* __restrict__ blockLive, uint32_t step) {
+                                                        const uint8_t* __restrict__ bodyActivePrev, uint32_t* __restrict__ blockStamp, uint8_t* __restrict__ blockLive,
+                                                        const uint32_t* __restrict__ stepPtr /* the step's number, through memory: a launch argument would change a sharded step's graph signature every step */) {
     __shared__ uint32_t cnt;
+    const uint32_t step = *stepPtr;
     forLiveBlocks(blockIdx.x, gridDim.x, (nb + 255u) / 256u, [&](uint32_t blk) { return shardBlockRecent(blockStamp, blk, step); }, [&](uint32_t blk) {
         const uint32_t i = blk * 256u + threadIdx.x;
         bool owned = false;

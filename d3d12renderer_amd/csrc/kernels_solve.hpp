@@ -160,7 +160,12 @@ __device__ __forceinline__ void dbgStamp(unsigned long long* rec, int i) { if (r
 #endif
 // Hook of processTile: early() runs right after the body loads were issued and returns how many loads it issued itself (they
 // may stay in flight across the first tag check); late(waited) runs once the tags are satisfied, waited = the tile had to poll.
-struct NoHook { enum : bool { kPinRows = false }; unsigned long long* rec = nullptr; __device__ __forceinline__ uint32_t early() const { return 0u; } __device__ __forceinline__ void late(bool) const {}
+#ifdef MI_EXP_PIN_FLOW
+#define MI_NOHOOK_PIN true    // (tools/exp/pinned_pairs_repro.sh: pinned register pairs in the dispatch-ordered kernels too — WRONG results there, round 5)
+#else
+#define MI_NOHOOK_PIN false
+#endif
+struct NoHook { enum : bool { kPinRows = MI_NOHOOK_PIN }; unsigned long long* rec = nullptr; __device__ __forceinline__ uint32_t early() const { return 0u; } __device__ __forceinline__ void late(bool) const {}
                 __device__ __forceinline__ bool knockNoWait() const { return false; } };
 // wait until at most n of the newest vector-memory operations are outstanding (n = a count the caller issued itself)
 __device__ __forceinline__ void waitVmcnt(uint32_t n) {

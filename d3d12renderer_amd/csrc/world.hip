@@ -182,6 +182,7 @@ struct mi_world {
         // simulated in this step or the previous one; per 256-collider block whether it holds a live collider.  blocksAll: every block counts as recent in the next step (set by
         // whatever can change a body's status behind the flags' back: enable, new borders; an upload / restore / outside state write does it through prevValid)
         DBuf<uint32_t> blockStamp; DBuf<uint8_t> blockLive, cbLive; bool blocksAll = true;
+        DBuf<uint32_t> stepDev; uint32_t* stepHost = nullptr;   // the step's number for k_shard_classify: a pinned host word copied to the device at the top of a step (same operation every step: a step graph replays it)
         // ... the sweep messages of the exact seam likewise, from the previous STEP's list lengths in both directions (x 1.5 + 64)
         uint32_t sweepPrevOwn[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sweepPeerHdr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, sweepSized[8] = {0, 0, 0, 0, 0, 0, 0, 0}; bool sweepRecvValid = false, sweepCut = false; uint32_t sweepFullSteps = 2;
         uint32_t owned[3] = {0, 0, 0};
@@ -377,6 +378,7 @@ struct mi_world {
     DBuf<uint2> cbRange;   // per 256-collider block: the range of 256-body blocks its colliders' bodies lie in (x > y: a static collider among them — always visited); upload()
     uint64_t tailSteps = 0, tailRoundsSum = 0;   // valid steps whose colouring was finished inside k_bin_hist, and the rounds it ran there (mi_debug_color_tail_stats)
     uint32_t colorBatchSticky = 0;   // colouring rounds a graph-replaying scene enqueues per step (runStep)
+    uint32_t colorTailHold = 0;  // steps left during which the colouring tail stays off (its barrier timed out: kernels_schedule.hpp)
     bool scalarsClean = false;   // the device-side step scalars / counters are already cleared for the next attempt (k_publish_readback did k_reset_scalars' work)
     uint32_t sapAxis = 0;        // sorting axis for the next step (collision_broad.cpp:443-444), host copy
     // mi_debug_set_solve_order: the next internal step solves these oriented collider pairs (a << 29 | b) sequentially, in this order, and the joints in pool order
@@ -460,6 +462,7 @@ mi_world::~mi_world() {
     for (auto& ff : pose.sets) for (auto& si : ff) if (si.landed) (void)hipEventDestroy(si.landed);
     if (pose.copyStream) (void)hipStreamDestroy(pose.copyStream);
     if (shard.sentHost) (void)hipHostFree(shard.sentHost);
+    if (shard.stepHost) (void)hipHostFree(shard.stepHost);
     if (shard.recvHost) (void)hipHostFree(shard.recvHost);
     for (hipEvent_t& e : shard.exEv) if (e) (void)hipEventDestroy(e);
     shardReleaseComm();
