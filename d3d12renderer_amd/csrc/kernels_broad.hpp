@@ -510,6 +510,10 @@ __device__ __forceinline__ bool aabbOverlap(const float4& amn, const float4& amx
 // range at the same time: loads are shared through L1 and candidates are fetched four at a time (8 loads in flight
 // per lane) instead of one dependent load pair per loop trip.
 constexpr uint32_t kPairOverflow = 512;   // block-shared overflow slots of k_bp_pairs_grid (4 KiB)
+#ifndef MI_PAIR_FETCH
+#define MI_PAIR_FETCH 4
+#endif
+constexpr uint32_t kPairFetch = MI_PAIR_FETCH;   // candidates of a column fetched per loop trip (2 loads each)
 constexpr uint32_t kPairBuf = 6;      // LDS-staged pair keys per collider-column before the block-level flush
 constexpr uint32_t kGridChunks = 2;   // a workgroup handles 2 x 256 consecutive sorted colliders for one column (24 KiB of staging: 6 workgroups per CU; measured 1: 168, 2: 148, 3: 154, 4: 171 us for the broad phase)
 
@@ -568,16 +572,18 @@ __device__ __forceinline__ void bpPairsGridBody(PairLds& L, const uint32_t block
                 uint32_t cbase = ((uint32_t)x * dy + (uint32_t)y) * dz;
                 uint32_t s = col == 0 ? i + 1u : cellLower[cbase + (uint32_t)z0];
                 uint32_t e = cellLower[cbase + (uint32_t)z1 + 1u];
+                if (MI_BP_KNOCK(16)) e = s;
                 float4 amn = sMin[i], amx = sMax[i];
                 uint32_t ci = vals[i];
-                for (uint32_t j = s; j < e; j += 4u) {
-                    float4 bmn[4], bmx[4];
+                for (uint32_t j = s; j < e; j += kPairFetch) {
+                    float4 bmn[kPairFetch], bmx[kPairFetch];
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) { uint32_t jj = min(j + u, e - 1u); bmn[u] = sMin[jj]; bmx[u] = sMax[jj]; }
+                    for (uint32_t u = 0; u < kPairFetch; ++u) { uint32_t jj = min(j + u, e - 1u); bmn[u] = sMin[jj]; bmx[u] = sMax[jj]; }
 #pragma unroll
-                    for (uint32_t u = 0; u < 4; ++u) {
+                    for (uint32_t u = 0; u < kPairFetch; ++u) {
                         if (j + u >= e || !aabbOverlap(amn, amx, bmn[u], bmx[u])) continue;
                         ++overlaps;
+                        if (MI_BP_KNOCK(17)) continue;
                         uint64_t pk;
                         if (!pairKey(ci, amn, amx, vals[j + u], bmn[u], bmx[u], axis, pk, inter)) continue;
                         if (nhit < kPairBuf) mybuf[nhit] = pk;
@@ -595,6 +601,7 @@ __device__ __forceinline__ void bpPairsGridBody(PairLds& L, const uint32_t block
         nh[ch] = min(nhit, kPairBuf);
     }
     if (runCount) atomicAdd(&bhist[runBucket], runCount);
+    if (MI_BP_KNOCK(18)) continue;
     // block exclusive scan of the staged counts
     uint32_t mine = 0;
 #pragma unroll

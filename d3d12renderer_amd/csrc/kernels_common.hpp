@@ -74,6 +74,18 @@ struct StepScalars {  // device-resident per-step scalars
     unsigned long long axisSums[9]; // centre statistics of the colliders this world counts (k_pair_finish): S1[3], S2lo[3], S2hi[3]; a sharded world's are added over the ranks
 };
 
+#ifdef MI_DBG_KNOCKOUT
+// development (knock-out harness, tools/gpu_knockout.sh).  Bits 0-2: k_contact_solve_persist (see there).  Bits 8-12: k_emit_manifolds launched a first time with its
+// read-modify-write targets redirected to scratch and parts removed: 8 no bodyUsed atomics, 9 no history insert, 10 no history probe, 11 no round-0 proposals, 12 no material gathers.
+// Bits 16-18: the grid part of k_bp_pairs a first time on a scratch pair list / scratch counters: 16 no candidate loop, 17 candidates tested but hits neither keyed nor
+// staged, 18 no block flush (reservation + copy-out).
+__device__ uint32_t g_dbgKnock = 0u;
+#define MI_EMIT_KNOCK(bit) ((g_dbgKnock >> (bit)) & 1u)
+#define MI_BP_KNOCK(bit) ((g_dbgKnock >> (bit)) & 1u)
+#else
+#define MI_EMIT_KNOCK(bit) 0u
+#define MI_BP_KNOCK(bit) 0u
+#endif
 // Sum-only counters are sharded over 16 cache lines: a same-address global atomic sustains only ~90 ops/us on this
 // chip (one L2 channel), so thousands of workgroups adding to ONE word serialise a whole kernel behind it.
 constexpr uint32_t kShards = 16;

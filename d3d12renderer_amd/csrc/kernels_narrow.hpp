@@ -324,14 +324,6 @@ __global__ __launch_bounds__(256) void k_events_end(uint32_t cap, StepScalars* s
     events[slot] = e;
 }
 
-#ifdef MI_DBG_KNOCKOUT
-// development (knock-out harness, tools/gpu_knockout.sh).  Bits 0-2: k_contact_solve_persist (see there).  Bits 8-12: k_emit_manifolds launched a first time with its
-// read-modify-write targets redirected to scratch and parts removed: 8 no bodyUsed atomics, 9 no history insert, 10 no history probe, 11 no round-0 proposals, 12 no material gathers.
-__device__ uint32_t g_dbgKnock = 0u;
-#define MI_EMIT_KNOCK(bit) ((g_dbgKnock >> (bit)) & 1u)
-#else
-#define MI_EMIT_KNOCK(bit) 0u
-#endif
 constexpr uint32_t kSpatialKeys = 4096;   // levels of the manifolds' spatial counting sort (k_manifold_keys / k_manifold_place below)
 // After the scans: manifold m <- pair p (count > 0).  colWork = (bodyA | dynA << 31, bodyB | dynB << 31, priority lo, hi):
 // everything a colouring round needs in one 16-byte row.

@@ -316,7 +316,7 @@ struct mi_world {
     bool usedFlow = false, skippedPartition = false, havePartitionFlag = false, lastPartitioned = false;
     bool usedFused = false;
 #if defined(MI_DBG_KNOCKOUT) || defined(MI_DBG_TIMELINE)
-    bool knockPending = false, knockPendingEmit = false; double knockMsSum = 0.0; uint32_t knockLaunches = 0; unsigned long long* dbgTimelineBuf = nullptr;   // development builds only (world_step.inc)
+    bool knockPending = false, knockPendingEmit = false, knockPendingBp = false; double knockMsSum = 0.0; uint32_t knockLaunches = 0; unsigned long long* dbgTimelineBuf = nullptr;   // development builds only (world_step.inc)
 #endif
     bool persistSolver = true, persistMetaLds = true, persistImpLds = true, usedPersist = false; uint32_t xcdOnly = 0; uint32_t persistWaves = 1024;   // one resident workgroup per SIMD owns its tiles through all sweeps (k_contact_solve_persist)
     uint32_t flowLds = 0;                  // dynamic LDS bytes per 64-lane workgroup: caps resident waves per CU (160 KiB / flowLds)

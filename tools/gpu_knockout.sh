@@ -33,6 +33,10 @@ for K in ${KO_EMIT_BITS:-0x8000 0x100 0x200 0x400 0x1000 0x300 0x700 0x1700}; do
   echo "== settle 245 emit MI_DBG_KNOCKOUT=$K (bits: 0x100 no bodyUsed atomics, 0x200 no history insert, 0x400 no history probe, 0x800 no round-0 proposals, 0x1000 no material gathers; 0x8000 nothing removed)" >> $OUT
   MI_DBG_KNOCKOUT=$K MI_PHYSICS_LIB=build_exp/libmi_physics_knock.so timeout 300 python /tmp/ko.py 245 2>&1 | grep -E "knockout|real solve" >> $OUT
 done
+for K in ${KO_BP_BITS:-0x800000 0x10000 0x20000 0x40000 0x60000}; do
+  echo "== settle 245 bp grid pass MI_DBG_KNOCKOUT=$K (bits: 0x10000 no candidate loop, 0x20000 hits neither keyed nor staged, 0x40000 no block flush; 0x800000 nothing removed)" >> $OUT
+  MI_DBG_KNOCKOUT=$K MI_PHYSICS_LIB=build_exp/libmi_physics_knock.so timeout 300 python /tmp/ko.py 245 2>&1 | grep -E "knockout|real solve" >> $OUT
+done
 cat $OUT
 if [ -f build_exp/libmi_physics_knocktl.so ]; then
   cat > /tmp/tlk.py <<'PY'
