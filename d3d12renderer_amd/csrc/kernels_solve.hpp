@@ -170,6 +170,7 @@ struct NoHook { enum : bool { kPinRows = MI_NOHOOK_PIN }; unsigned long long* re
 // wait until at most n of the newest vector-memory operations are outstanding (n = a count the caller issued itself)
 __device__ __forceinline__ void waitVmcnt(uint32_t n) {
     switch (n) {
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
         case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
         case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
         case 18: asm volatile("s_waitcnt vmcnt(18)" ::: "memory"); break;
@@ -510,7 +511,8 @@ __device__ __forceinline__ void persistSolveBody(MI_PERSIST_PARAMS) {
             nxMeta = XCD ? slotMetaW[at] : slotMeta[at]; nxNf = slotNormal[at]; nxMass = slotMass[at];
         }
         if (MI_KNOCK(0)) return 0u;
-        if (const uint32_t q = lRes[slot]; q != 0xFFu) { accCopyResident<kResidentPositions>(q, cnt); return 0u; }   // resident: register moves, nothing enters the memory queue
+        if (const uint32_t q = lRes[slot]; q != 0xFFu) { accCopyResident<kResidentPositions>(q, cnt); return (METALDS || !IMPLDS) ? 0u : 3u; }   // resident: register moves, nothing enters the memory queue
+                                                                                                                                   // (slot data not in LDS: its three loads, just issued, may stay in flight)
         {
             const float4* row = rows + (size_t)ct * (kRows * 64u) + lane;   // row (k, r) of the tile at + (k * kRows + r) * 64
             if (0u < cnt) MI_ACC_LOAD(160, 161, 162, 163, row + 0u * 64u);

@@ -136,6 +136,24 @@ def test_persistent_solver_keeps_its_acc_registers_to_itself(tmp_path, mi_lib):
         # the prefetch is inlined once per call site (24 loads each); the read-back once per contact count (24 moves per contact); six resident positions of six loads
         assert ring_loads > 0 and ring_loads % 24 == 0 and reads > 0 and reads % 24 == 0 and res_loads == 36 and moves > 0 and moves % 24 == 0, (ring_loads, res_loads, reads, moves)
         assert (vres_loads, vmoves > 0, vmoves % 24) == ((12, True, 0) if capped else (0, False, 0)), (vres_loads, vmoves)
+        if re.match(r"^_ZN2mi23k_contact_solve_persistILb0ELb[01]ELb1E", asm[st]):
+            # slot data not in LDS (impulses in LDS): a RESIDENT next tile leaves the three loads of its slot data in flight across the first tag check (`s_waitcnt vmcnt(3)`), which is only
+            # sound while the compiler issues exactly those three loads between the tile's four body loads and the counted waits — checked here for every contact count
+            seen = 0; j = st
+            while ".amdhsa_kernel" not in asm[j]:
+                if re.search(r"global_load_dwordx4 v\[\d+:\d+\], v\[\d+:\d+\], off sc1", asm[j]) and "sc1" in asm[j + 3] and "#ASMEND" in asm[j + 4]:   # the four body loads of a visit
+                    k, inside, mine = j + 5, False, 0
+                    while not (inside and "s_waitcnt vmcnt(" in asm[k] and "vmcnt(4)" not in asm[k]):
+                        if "#ASMSTART" in asm[k]: inside = True
+                        elif "#ASMEND" in asm[k]: inside = False
+                        elif not inside and asm[k].strip().startswith("global_load"): mine += 1
+                        k += 1
+                    assert mine == 3, (asm[st][:60], j, mine)
+                    seen += 1; j = k
+                j += 1
+            assert seen == 4, seen
+
+
 
 
 def test_tile_to_xcd_assignment_is_a_partition(mi_lib):
