@@ -12,7 +12,7 @@ rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 # a step ends with k_publish_readback (k_reset_scalars' work rides in it): take a full step of the timed region, before the six extra (stage-timed, step-timed) steps
 idx = [i + 1 for i, r in enumerate(rows) if "k_publish_readback" in r["Kernel_Name"]]
-a, b = idx[-8], idx[-7]
+a, b = idx[-36], idx[-35]   # (the run ends with 3 + 3 sampled steps and 20 steps of the whole-step-event region: this one lies in the timed region)
 t0 = int(rows[a]["Start_Timestamp"])
 out = []
 prev_end = t0
