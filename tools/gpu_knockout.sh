@@ -54,6 +54,7 @@ PY
     for F in gpurun_out/timeline_ko$K.bin gpurun_out/timeline_ko$K.bin.knock; do
       echo "== visit stamps $F (MI_DBG_KNOCKOUT=$K; .knock = the knock-out launch)" | tee -a $OUT
       python tools/visit_stamps.py $F | tee -a $OUT
+      rm -f $F      # (16 MB each: gpurun_out/ travels back only while it stays under 64 MiB)
     done
   done
 fi

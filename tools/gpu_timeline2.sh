@@ -34,3 +34,4 @@ d23 = (t[:, :, 3] - t[:, :, 2])[valid]; print("body loads issued -> first check:
 d34 = (t[:, :, 4] - t[:, :, 3])[valid]; print("polling: mean %.1f median %.1f, fraction > 300 ns: %.2f" % (d34.mean(), np.median(d34), (d34 > 300).mean()))
 print("span", (t[:, :, 5][valid].max() - t[:, :, 0][valid].min()))
 PY
+rm -f gpurun_out/timeline.bin gpurun_out/timeline.bin.knock   # (16 MB each: gpurun_out/ travels back only while it stays under 64 MiB)
