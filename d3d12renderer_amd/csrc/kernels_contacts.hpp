@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_schedule_finish(uint32_t lastRound, con
                                                          const uint32_t* __restrict__ color, const uint2* __restrict__ manInfo, const uint32_t* __restrict__ blockHist,
                                                          const uint32_t* __restrict__ blockScan, uint32_t* __restrict__ order, StepScalars* sc,
                                                          uint32_t nc, const uint32_t* __restrict__ manPair, const uint64_t* __restrict__ pairsA, const uint64_t* __restrict__ pairsB,
-                                                         HistSlot* __restrict__ tab, uint32_t tabMask, const uint8_t* __restrict__ manKept, uint32_t* __restrict__ histDisp,
+                                                         HistSlot* __restrict__ tab, uint32_t tabMask, const uint8_t* __restrict__ manKept, uint32_t* __restrict__ histHint,
                                                          uint32_t tilesCap, uint32_t ctCap, BinInfo* __restrict__ binInfo, uint32_t* __restrict__ xcdBase /* [kSchedBins][8] or null */, uint32_t xcdSingle,
                                                          uint4* __restrict__ tileInfo, uint2* __restrict__ tileDesc, uint32_t* __restrict__ xcdTiles /* [8][listCap] or null */, uint4* __restrict__ xcdInfo, uint32_t listCap) {
     __shared__ uint32_t cur[kColorBins + 4];
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(256) void k_schedule_finish(uint32_t lastRound, con
                 if (c <= kOverflowColor) order[atomicAdd(&cur[binOf(c, manInfo[m].x & 7u)], 1u)] = m;
                 if (!manKept[m]) {      // kept colours were entered by k_emit_manifolds
                     const uint64_t pk = pairKeys[manPair[m]];
-                    tableInsert(tab, tabMask, historyKey(nc, (uint32_t)((pk >> 29) & 0x1FFFFFFFull), (uint32_t)(pk & 0x1FFFFFFFull)), c, histDisp);
+                    tableInsert(tab, tabMask, historyKey(nc, (uint32_t)((pk >> 29) & 0x1FFFFFFFull), (uint32_t)(pk & 0x1FFFFFFFull)), c, histHint);
                 }
             }
         }

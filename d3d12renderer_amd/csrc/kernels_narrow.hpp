@@ -245,31 +245,40 @@ __device__ __forceinline__ uint32_t tableSlot(uint64_t key, uint32_t mask) {
 // it at in the previous step's table — one plain 16-byte store, where a fresh insertion is a compare-and-swap on a cold line and a dependent store (measured with the
 // knock-out harness: 22 of the kernel's 58 us).  Kept entries have distinct slots, and the new manifolds are entered afterwards (k_schedule_finish)
 // by compare-and-swap into the first empty slot from their hash, so a table is a valid open-addressing table with ONE difference: an entry's probe
-// chain may have holes where its old neighbours vanished.  A lookup therefore does not stop at an empty slot; it probes the `maxDisp + 1` slots from the hash, maxDisp =
-// the largest displacement any insertion has ever had (one device word, only ever raised; zeroed when the history is dropped).  A hit ends at the first match as before
-// (displacement 0-1 nearly always); a miss — a NEW manifold, a few per cent of a settled pile's — costs maxDisp + 1 contiguous 16-byte probes (a few cache lines).
-// When the two tables differ in size (the manifold count crossed a power of two, a synchronous re-run) positions do not carry over and every entry is inserted afresh.
+// chain may have holes where its old neighbours vanished.  A lookup therefore cannot stop at an empty slot.  What bounds it instead is a HINT per home slot: hint[h] = the
+// largest displacement any key with home h was ever inserted at (one word per slot in a side array that lives as long as the tables keep their size; raised by the
+// compare-and-swap insertions only, i.e. by the few NEW manifolds of a step).  A lookup loads the home slot and its hint together: a hit at home (four entries of five) and
+// a miss with hint 0 (nearly every new manifold) are ONE round trip, as they were when lookups stopped at empty slots.  (A single global bound was tried first: 24 at the
+// bench state, and every wave with a new manifold in it walked 25 dependent probes — the probe 10 -> 25 us.)
+// When the two tables differ in size (the manifold count crossed a power of two, a synchronous re-run) positions do not carry over: every entry is inserted afresh, into a
+// fresh hint array.
 struct alignas(16) HistSlot { unsigned long long key; unsigned long long val; };
 struct HistHit { uint32_t colour, slot; };
-__device__ __forceinline__ HistHit tableFind(const HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, uint32_t maxDisp) {
+__device__ __forceinline__ HistHit tableFind(const HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, const uint32_t* __restrict__ hint) {
     uint32_t s = tableSlot(key, mask);
-    for (uint32_t n = 0; n <= maxDisp && n <= mask; ++n, s = (s + 1u) & mask) {
+    const ulonglong2 e0 = *reinterpret_cast<const ulonglong2*>(tab + s);
+    const uint32_t bound = hint[s];
+    if (e0.x == key) return HistHit{(uint32_t)e0.y, s};
+    for (uint32_t n = 1; n <= bound && n <= mask; ++n) {
+        s = (s + 1u) & mask;
         const ulonglong2 e = *reinterpret_cast<const ulonglong2*>(tab + s);
         if (e.x == key) return HistHit{(uint32_t)e.y, s};
     }
     return HistHit{kUncolored, 0u};
 }
-__device__ __forceinline__ uint32_t tableLookup(const HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, uint32_t maxDisp) { return tableFind(tab, mask, key, maxDisp).colour; }
-__device__ __forceinline__ void tableInsert(HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, uint32_t val, uint32_t* __restrict__ maxDisp) {
-    for (uint32_t s = tableSlot(key, mask), n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
+__device__ __forceinline__ uint32_t tableLookup(const HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, const uint32_t* __restrict__ hint) { return tableFind(tab, mask, key, hint).colour; }
+__device__ __forceinline__ void tableInsert(HistSlot* __restrict__ tab, uint32_t mask, uint64_t key, uint32_t val, uint32_t* __restrict__ hint) {
+    const uint32_t home = tableSlot(key, mask);
+    for (uint32_t s = home, n = 0; n <= mask; s = (s + 1u) & mask, ++n) {
         const unsigned long long old = atomicCAS(&tab[s].key, 0ull, (unsigned long long)key);
         if (old == 0ull || old == key) {   // (the colour is read in the NEXT step only; the same key again — a schedule built twice in a synchronous step — overwrites)
             tab[s].val = val;
-            if (n > __hip_atomic_load(maxDisp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(maxDisp, n);
+            if (n && n > __hip_atomic_load(&hint[home], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&hint[home], n);
             return;
         }
     }
 }
+
 // Collision events (handleCollisionCallbacks, src/physics/physics.cpp:1041-1178), device half.  A manifold whose oriented
 // collider pair is not in the previous step's history table begins (k_emit_manifolds flags it); a pair of the previous table
 // that is not in this step's table ended.  Begin records carry the mean contact point / normal and the relative point
@@ -310,12 +319,12 @@ __global__ __launch_bounds__(256) void k_events_begin(uint32_t nc, uint32_t cap,
 }
 __global__ __launch_bounds__(256) void k_events_end(uint32_t cap, StepScalars* sc, const HistSlot* __restrict__ prevTab, uint32_t prevMask,
                                                     const HistSlot* __restrict__ curTab, uint32_t curMask,
-                                                    DeviceEvent* __restrict__ events, const uint32_t* __restrict__ histDisp) {
+                                                    DeviceEvent* __restrict__ events, const uint32_t* __restrict__ curHint /* the probe hints of curTab (tableFind) */) {
     uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     unsigned long long key = s <= prevMask ? prevTab[s].key : 0ull;
     bool want = key != 0ull && ((key - 1ull) & ((1ull << kIndexBits) - 1ull)) < kHeightmapVirtualBase;   // heightmap contacts raise no events
     if (want && prevMask == curMask && curTab[s].key == key) want = false;                                  // it kept its colour, hence its slot
-    want = want && tableLookup(curTab, curMask, key, *histDisp) == kUncolored;
+    want = want && tableLookup(curTab, curMask, key, curHint) == kUncolored;
     uint32_t slot = waveAppendSlot(want, &sc->numEvents);
     if (!want) return;
     if (slot >= cap) { sc->specOverflow = 1u; return; }
@@ -336,7 +345,7 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
                                                         const HistSlot* __restrict__ prevTab, uint32_t prevMask,
                                                         unsigned long long* __restrict__ bodyUsed, uint8_t* __restrict__ isNew, StepScalars* sc,
                                                         float2 terrainMaterial /* (restitution, friction) of the heightmap */,
-                                                        HistSlot* __restrict__ nextTab, uint32_t nextMask, uint8_t* __restrict__ manKept, uint32_t* __restrict__ histDisp /* the history's probe bound (tableFind) */,
+                                                        HistSlot* __restrict__ nextTab, uint32_t nextMask, uint8_t* __restrict__ manKept, const uint32_t* __restrict__ prevHint, uint32_t* __restrict__ nextHint /* the tables' probe hints (tableFind; one array while the tables keep their size) */,
                                                         const Shards* __restrict__ statsShards /* non-null: workgroup 0 runs pairFinishStats instead */, uint32_t statsBlocks,
                                                         const unsigned long long* __restrict__ statsPartials, const int* __restrict__ statsBounds, GridParams* statsGridNext, uint32_t statsCellCap, const uint8_t* __restrict__ statsCbLive,
                                                         const uint32_t* __restrict__ seamId /* exact seam: per body, the tile border it is shared across (0 = none); or null */,
@@ -382,7 +391,7 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
     // a manifold of the previous step keeps its colour (colour 64 = overflow is re-coloured)
     const uint64_t hk = historyKey(nc, a, b);
     HistHit hit{kUncolored, 0u};
-    if (prevTab && !MI_EMIT_KNOCK(10)) hit = tableFind(prevTab, prevMask, hk, *histDisp);
+    if (prevTab && !MI_EMIT_KNOCK(10)) hit = tableFind(prevTab, prevMask, hk, prevHint);
     uint32_t c = hit.colour;
     const bool found = c != kUncolored;
     if (MI_EMIT_KNOCK(10)) c = (uint32_t)(prio & 7u);
@@ -394,8 +403,8 @@ __global__ __launch_bounds__(256) void k_emit_manifolds(uint32_t nc, uint32_t nb
         // its colour is final: it enters the NEXT step's history right here (k_schedule_finish then only has the few new manifolds left)
         // (its old slot when the two tables have one size: kept entries have distinct slots, the new manifolds are entered after this kernel)
         if (MI_EMIT_KNOCK(9)) {}
-        else if (found && prevMask == nextMask) { ulonglong2 e; e.x = hk; e.y = c; *reinterpret_cast<ulonglong2*>(nextTab + hit.slot) = e; }
-        else tableInsert(nextTab, nextMask, hk, c, histDisp);
+        else if (found && prevMask == nextMask && prevHint == nextHint) { ulonglong2 e; e.x = hk; e.y = c; *reinterpret_cast<ulonglong2*>(nextTab + hit.slot) = e; }   // (same size AND the same hints: the slot means the same)
+        else tableInsert(nextTab, nextMask, hk, c, nextHint);
         manKept[m] = 1u;
     } else {
         c = kUncolored; manKept[m] = 0u;

@@ -273,7 +273,7 @@ struct mi_world {
     DBuf<uint32_t> color, order, orderTmp, blockHist, blockScan; DBuf<uint4> tileInfo, xcdInfo; DBuf<unsigned long long> bodyTop, bodyUsed;
     DBuf<BinInfo> binInfo;
     // colour history (pair -> colour of the previous step): two tables, the one written by a step becomes current only if the step is valid
-    DBuf<HistSlot> tab[2]; uint32_t tabMask[2] = {0, 0}; int tabCur = 0; bool tabValid = false; DBuf<uint32_t> histDisp; bool histDispZero = false;   // histDisp: the history's probe bound (kernels.hpp, tableFind)
+    DBuf<HistSlot> tab[2]; uint32_t tabMask[2] = {0, 0}; int tabCur = 0; bool tabValid = false; DBuf<uint32_t> histHint[2]; int hintOf[2] = {0, 0};   // histHint: the history tables' per-home-slot probe hints (kernels_narrow.hpp, tableFind); hintOf[t] = the array table t uses (both tables share one while they keep their size)
     // collision events (mi_world_enable_events / mi_world_poll_events)
     // triggers / force fields: entity lists by dense index, per-collider object tags, rotated forces, the pair pass's
     // rigid-body x (trigger | force field) AABB overlaps, the interactions that passed the boolean test, the per-step force accumulators
