@@ -342,6 +342,12 @@ class World:
         p = np.ascontiguousarray(pairs, np.uint32).reshape(-1, 2)
         self.L.check(self.L.fn("debug_set_solve_order")(self.h, _ptr(p) if len(p) else None, C.c_uint32(len(p))), "debug_set_solve_order")
 
+    def debug_step_ahead_stats(self):
+        """mi_debug_step_ahead_stats: (times the next step's first kernel was enqueued ahead, times the next step adopted it)."""
+        a, b = C.c_uint64(), C.c_uint64()
+        self.L.check(self.L.fn("debug_step_ahead_stats")(self.h, C.byref(a), C.byref(b)), "debug_step_ahead_stats")
+        return a.value, b.value
+
     def debug_set_solve_dataflow(self, enable=True):
         """mi_debug_set_solve_dataflow: steps that follow a caller's order run it through the production contact solver (levels of the order as colours)."""
         self.L.check(self.L.fn("debug_set_solve_dataflow")(self.h, C.c_uint32(1 if enable else 0)), "debug_set_solve_dataflow")

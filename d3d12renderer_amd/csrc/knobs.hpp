@@ -1,4 +1,4 @@
-// Every environment variable the library reads (29 since round 6: the switches whose A/B was settled became constants), in ONE place: read once PER WORLD (mi_world_create — not once per process: two worlds created under
+// Every environment variable the library reads (30 since round 6: the switches whose A/B was settled became constants), in ONE place: read once PER WORLD (mi_world_create — not once per process: two worlds created under
 // different environments differ), typed, documented.  Numeric knobs: 0 (or unset) means "the default", not the value 0 (MI_FLOW_LDS, MI_PERSIST_WAVES).
 // None of them is needed in production — the defaults are what is measured and shipped; they select the fallback paths the tests
 // pin against each other (every variant gives the same bits), inject the faults the fallback ladder is tested with, and switch
@@ -20,6 +20,7 @@ struct Knobs {
     bool poseStream = true;             // MI_POSE_STREAM=0: poses for the caller through the per-array copies + host pass
     bool debugSync = false;             // MI_DEBUG_SYNC: synchronise after every stage and name the one a device fault comes from
     bool eagerTimes = false;            // constant since round 6 (was MI_EAGER_TIMES; its A/B is settled: EXPERIMENTS.md): read the step's event times at the end of the step (not one step later)
+    bool stepAhead = true;              // MI_STEP_AHEAD=0: the next step's k_bp_prepare is not enqueued behind a speculative step's end-of-step record
     bool fuseReset = true;              // MI_FUSE_RESET=0: k_reset_scalars as the first launch of every step (otherwise its work rides at the end of k_publish_readback)
     // ---- step graphs (launcher.hpp)
     std::string graph;                  // MI_GRAPH=0 | force | all ("" = by runtime version)
@@ -76,7 +77,7 @@ struct Knobs {
         auto num = [](const char* n, uint64_t d) { const char* v = std::getenv(n); return v ? (uint64_t)strtoull(v, nullptr, 0) : d; };
         k.speculative = !off("MI_ASYNC"); k.spinReadback = str("MI_READBACK") != "copy";
         k.poseStream = !off("MI_POSE_STREAM"); k.debugSync = set("MI_DEBUG_SYNC");
-        k.fuseReset = !off("MI_FUSE_RESET");
+        k.fuseReset = !off("MI_FUSE_RESET"); k.stepAhead = !off("MI_STEP_AHEAD");
         k.graph = str("MI_GRAPH");
         k.graphDebug = set("MI_GRAPH_DEBUG");
         k.fuseWorld = !off("MI_FUSE_WORLD"); k.fuseLarge = !off("MI_FUSE_LARGE"); k.finishInNarrow = !off("MI_FINISH_IN_NARROW"); k.fuseKeys = !off("MI_FUSE_KEYS");

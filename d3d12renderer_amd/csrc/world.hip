@@ -255,6 +255,12 @@ struct mi_world {
     // device: colliders
     DBuf<uint32_t> cTypeBody; DBuf<float4> cShape, cStaticPos, cStaticRot, cEmit;
     DBuf<float4> wShape, aabbMin, aabbMax, hullAabb, hullVerts; DBuf<uint32_t> hullRanges;
+    // Step-ahead (round 6): a speculative step enqueues the NEXT step's first kernel (k_bp_prepare: world colliders + grid classification, ~27 us) right behind its own end-of-step
+    // record, on the state it has just produced, into the OTHER set of world-shape / AABB rows — the device then has work while the host validates this step, returns to the caller
+    // and comes back with the next step's launches (~25 us the device used to idle).  The next step adopts the result if nothing its inputs depend on has changed (same arrays, same
+    // grid, same axis, no outside write: `stale`), otherwise it clears what the kernel counted and starts as before.
+    DBuf<float4> wShapeAlt, aabbMinAlt, aabbMaxAlt;
+    struct Ahead { bool pending = false, stale = false; uint32_t nc = 0, nb = 0, gridIdx = 0, axis = 0; const void* pos = nullptr; const void* rot = nullptr; const void* shape = nullptr; } ahead; uint64_t aheadUsed = 0, aheadEnqueued = 0;
     // broad phase
     DBuf<unsigned long long> axisPartials;
     DBuf<uint32_t> largeList, isLarge, cellKeys, cellRanks, cellKeysS, cellValsS, cellCount, cellLower;

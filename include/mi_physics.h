@@ -313,6 +313,10 @@ MI_API int mi_debug_step_graph_stats(mi_world* world, uint32_t* out4);
 MI_API int mi_debug_color_tail_stats(mi_world* world, uint64_t* out_steps, uint64_t* out_rounds);
 /* Tests: how many times the pose rows (mi_world_view_transforms) were enqueued by a step itself, and how many times only when asked. */
 MI_API int mi_debug_pose_stream_stats(mi_world* world, uint32_t* out_ahead, uint32_t* out_on_demand);
+/* Step-ahead (no reference counterpart; what it takes off the path is the host's time between two physicsStep calls, src/physics/physics.cpp:1364-1413): a speculative step
+ * enqueues the NEXT step's first kernel (world colliders + broad-phase classification) behind its own end-of-step record, into a second set of world-shape / AABB rows; the next step
+ * adopts the result unless something its inputs depend on changed in between (a state write, an upload, another step mode, a void step).  How often it was enqueued / adopted. */
+MI_API int mi_debug_step_ahead_stats(mi_world* world, uint64_t* out_enqueued, uint64_t* out_adopted);
 /* Sum of the per-stage device times and of the contact updates (contacts x solver iterations) over the internal steps since
  * the last reset (so a benchmark loop does not have to call back into the library after every step). */
 MI_API int mi_world_get_accumulated_stage_times(mi_world* world, mi_stage_times* out_sum, uint32_t* out_steps,

@@ -691,8 +691,8 @@ def test_gpu_bench_size_solvers_agree(mi_lib, monkeypatch):
     out = {}
     round4_step = {"MI_FUSE_RESET": "0", "MI_ROUND0_EMIT": "0", "MI_FUSE_LARGE": "0", "MI_FINISH_IN_NARROW": "0", "MI_COLOR_TAIL": "0", "MI_FUSE_KEYS": "0"}   # every launch round 5 removed, back
     for name, env in (("default", {}), ("flow", {"MI_SOLVER": "flow"}), ("unpartitioned", {"MI_PERSIST_XCD": "0"}), ("synchronous", {"MI_ASYNC": "0"}),
-                      ("the tail colours", {"MI_COLOR_ROUNDS_MAX": "1"}), ("29 launches", round4_step), ("every tile's rows stream", {"MI_PERSIST_RESIDENT": "0"})):
-        for k in ("MI_SOLVER", "MI_PERSIST_XCD", "MI_ASYNC", "MI_COLOR_ROUNDS_MAX", "MI_PERSIST_RESIDENT", *round4_step):
+                      ("the tail colours", {"MI_COLOR_ROUNDS_MAX": "1"}), ("29 launches", round4_step), ("every tile's rows stream", {"MI_PERSIST_RESIDENT": "0"}), ("no step-ahead", {"MI_STEP_AHEAD": "0"})):
+        for k in ("MI_SOLVER", "MI_PERSIST_XCD", "MI_ASYNC", "MI_COLOR_ROUNDS_MAX", "MI_PERSIST_RESIDENT", "MI_STEP_AHEAD", *round4_step):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -793,3 +793,33 @@ def test_gpu_entity_deletion_matches_oracle(mi_lib, oracle_mod, make, victims):
         assert a.tobytes() == b.tobytes()
     with pytest.raises(mi_lib.PhysicsError):
         g.destroy_entity(victims[0])
+
+
+def test_gpu_step_ahead_is_adopted_or_dropped_and_never_seen(mi_lib, oracle_mod, monkeypatch):
+    """A speculative step enqueues the next step's first kernel (k_bp_prepare) behind its own end-of-step record (csrc/world.hip, "Step-ahead").  Free-running, the next step
+    adopts it; a state write between two steps (mi_world_set_body_states), an entity deletion (re-upload) and a step that is re-run make the next step drop it — and in
+    every case the world is, bit for bit, the oracle's and the world that never runs anything ahead (MI_STEP_AHEAD=0)."""
+    sc = scenes.obb_pile(24, 6, 24, spacing=1.0)         # 3 456 boxes: above the step-graph limit? no — graphs are off for this test (a replayed graph holds its own first kernel)
+    monkeypatch.setenv("MI_GRAPH", "0")
+    a = sc.populate(gpu_world(mi_lib))
+    monkeypatch.setenv("MI_STEP_AHEAD", "0")
+    b = sc.populate(gpu_world(mi_lib))
+    o = sc.populate(oracle_mod.create_world(oracle_mod.ORDER_CANONICAL))
+    s = sc.settings(); ids = np.arange(sc.num_bodies, dtype=np.uint32)
+    for i in range(90):
+        for w in (a, b, o):
+            w.step_fixed(s, sc.dt, 1)
+        assert a.counts() == o.counts() == b.counts(), f"step {i}"
+        if i % 10 == 9:
+            assert a.get_body_states(ids).tobytes() == o.get_body_states(ids).tobytes() == b.get_body_states(ids).tobytes(), f"step {i}"
+        if i == 40:      # an outside write: four boxes are thrown upwards
+            st = a.get_body_states(ids[:4]); st[:, 7:10] = (0.0, 9.0, 0.0)
+            for w in (a, b, o):
+                w.set_body_states(ids[:4], st)
+        if i == 60:      # a topology edit: everything is uploaded again
+            for w in (a, b, o):
+                w.destroy_entity(5)
+            ids = np.asarray([e for e in range(sc.num_bodies) if e != 5], dtype=np.uint32)
+    enq, adopted = a.debug_step_ahead_stats()
+    assert enq >= 60 and 0 < adopted < enq, (enq, adopted)                # adopted in the free-running stretches, dropped after the write / the upload / a re-run
+    assert b.debug_step_ahead_stats() == (0, 0)
