@@ -801,6 +801,7 @@ def test_gpu_step_ahead_is_adopted_or_dropped_and_never_seen(mi_lib, oracle_mod,
     every case the world is, bit for bit, the oracle's and the world that never runs anything ahead (MI_STEP_AHEAD=0)."""
     sc = scenes.obb_pile(24, 6, 24, spacing=1.0)         # 3 456 boxes: above the step-graph limit? no — graphs are off for this test (a replayed graph holds its own first kernel)
     monkeypatch.setenv("MI_GRAPH", "0")
+    monkeypatch.setenv("MI_STEP_AHEAD", "1")             # the default, stated: the suite is also run with the knob off
     a = sc.populate(gpu_world(mi_lib))
     monkeypatch.setenv("MI_STEP_AHEAD", "0")
     b = sc.populate(gpu_world(mi_lib))
