@@ -508,25 +508,32 @@ __device__ __forceinline__ uint16_t epaPushEdge(EpaState& s, uint16_t a, uint16_
     s.edges[i] = e;
     return i;
 }
+// Where the reference's code reads what it never wrote — on a degenerate polytope (zero-area faces have NaN normals and are never "seen", so the faces a new point sees need
+// not form one loop) a new face's third edge is looked up in newEdgePerPoint[] for a point no horizon edge started from, and an edge's first face may stay unset — the
+// reference's behaviour is undefined (it indexes its 1024-entry arrays with whatever the stack held).  Product and oracle (oracle/ora_gjk.cpp) define it the same way: such
+// an index is 0xFFFF, "no edge" / "no face": it is never dereferenced, counts no reference, and a missing face counts as inactive.  (No index leaves the polytope's arrays.)
+__device__ __forceinline__ bool epaEdgeIdx(uint16_t e) { return e < (uint16_t)kEpaEdges; }
+__device__ __forceinline__ bool epaTriIdx(uint16_t t) { return t < (uint16_t)kEpaTris; }
 __device__ inline bool epaAddPoint(EpaState& s, const SupPt& np) {  // collision_epa.cpp:117-240
     for (uint32_t i = 0; i < s.nEdges; ++i) s.refs[i] = 0;
     for (uint32_t i = 0; i < s.nTris; ++i) {
         if (!s.active[i]) continue;
         EpaTri& t = s.tris[i];
         float d = dot(t.n, np.m - s.pts[t.a].m);
-        if (d > 0.f) { ++s.refs[t.eA]; ++s.refs[t.eB]; ++s.refs[t.eC]; s.active[i] = 0; }
+        if (d > 0.f) { if (epaEdgeIdx(t.eA)) ++s.refs[t.eA]; if (epaEdgeIdx(t.eB)) ++s.refs[t.eB]; if (epaEdgeIdx(t.eC)) ++s.refs[t.eC]; s.active[i] = 0; }
     }
     uint16_t border[kEpaBorder]; uint32_t nb = 0;
     for (uint32_t i = 0; i < s.nEdges; ++i)
         if (s.refs[i] == 1) { if (nb >= (uint32_t)kEpaBorder) return false; border[nb++] = (uint16_t)i; }
     uint16_t newEdgePerPoint[kEpaPts];
+    for (int i = 0; i < kEpaPts; ++i) newEdgePerPoint[i] = 0xFFFF;
     uint16_t npi = epaPushPt(s, np);
     if (npi == 0xFFFF) return false;
     uint16_t triOffset = s.nTris;
     for (uint32_t i = 0; i < nb; ++i) {
         uint16_t ei = border[i];
         EpaEdge e = s.edges[ei];
-        bool aAct = s.active[e.tA] != 0, bAct = s.active[e.tB] != 0;
+        bool aAct = epaTriIdx(e.tA) && s.active[e.tA] != 0, bAct = epaTriIdx(e.tB) && s.active[e.tB] != 0;
         uint16_t connect = bAct ? e.a : e.b;
         uint16_t triIndex = s.nTris;
         uint16_t ne = epaPushEdge(s, connect, npi, 0xFFFF, s.nTris);
@@ -546,7 +553,7 @@ __device__ inline bool epaAddPoint(EpaState& s, const SupPt& np) {  // collision
         uint16_t other = newEdgePerPoint[connect];
         uint16_t triIndex = (uint16_t)(i + triOffset);
         s.tris[triIndex].eB = other;
-        s.edges[other].tA = triIndex;
+        if (epaEdgeIdx(other)) s.edges[other].tA = triIndex;
     }
     return true;
 }
@@ -637,12 +644,13 @@ __device__ inline SupPt supportPairWave(const Shape& A, const Shape& B, const Hu
 }
 __device__ inline bool epaAddPointWave(EpaLds& s, uint32_t& nTris, uint32_t& nPts, uint32_t& nEdges, const SupPt& np, uint32_t lane) {  // = epaAddPoint
     for (uint32_t i = lane; i < nEdges; i += 64u) s.refs[i] = 0u;
+    if (lane < (uint32_t)kEpaPts) s.newEdgePerPoint[lane] = 0xFFFF;
     waveSync();
     for (uint32_t i = lane; i < nTris; i += 64u) {
         if (!s.active[i]) continue;
         const EpaTri t = s.tris[i];
         const float d = dot(t.n, np.m - s.pts[t.a].m);
-        if (d > 0.f) { atomicAdd(&s.refs[t.eA], 1u); atomicAdd(&s.refs[t.eB], 1u); atomicAdd(&s.refs[t.eC], 1u); s.active[i] = 0; }
+        if (d > 0.f) { if (epaEdgeIdx(t.eA)) atomicAdd(&s.refs[t.eA], 1u); if (epaEdgeIdx(t.eB)) atomicAdd(&s.refs[t.eB], 1u); if (epaEdgeIdx(t.eC)) atomicAdd(&s.refs[t.eC], 1u); s.active[i] = 0; }
     }
     waveSync();
     uint32_t nb = 0;   // horizon = edges referenced once, in ascending edge order
@@ -666,7 +674,7 @@ __device__ inline bool epaAddPointWave(EpaLds& s, uint32_t& nTris, uint32_t& nPt
     if (lane < nb) {
         const uint16_t ei = s.border[lane];
         const EpaEdge e = s.edges[ei];
-        const bool bAct = s.active[e.tB] != 0;
+        const bool bAct = epaTriIdx(e.tB) && s.active[e.tB] != 0;
         const uint16_t connect = bAct ? e.a : e.b;
         const uint16_t triIndex = (uint16_t)(triOffset + lane), ne = (uint16_t)(edgeOffset + lane);
         EpaEdge nw; nw.a = connect; nw.b = npi; nw.tA = 0xFFFF; nw.tB = triIndex;
@@ -681,7 +689,7 @@ __device__ inline bool epaAddPointWave(EpaLds& s, uint32_t& nTris, uint32_t& nPt
     // The link updates of both sequential loops are order-sensitive only if a point is the `connect` of two horizon edges (a degenerate
     // polytope): with distinct points — a proper horizon loop — every lane links its own edge, else lane 0 replays the loops in order.
     uint32_t myConnect = 0xFFFFFFFFu, myOther = 0xFFFFFFFFu;   // the edge's end the new edge starts from (first loop) / the end whose new edge closes the face (second loop)
-    if (lane < nb) { const EpaEdge e = s.edges[s.border[lane]]; const bool aAct = s.active[e.tA] != 0, bAct = s.active[e.tB] != 0; myConnect = bAct ? e.a : e.b; myOther = aAct ? e.a : e.b; }
+    if (lane < nb) { const EpaEdge e = s.edges[s.border[lane]]; const bool aAct = epaTriIdx(e.tA) && s.active[e.tA] != 0, bAct = epaTriIdx(e.tB) && s.active[e.tB] != 0; myConnect = bAct ? e.a : e.b; myOther = aAct ? e.a : e.b; }
     unsigned int pointBits = lane < nb ? (1u << myConnect) : 0u, otherBits = lane < nb ? (1u << myOther) : 0u;   // kEpaPts = 24 points
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) { pointBits |= (unsigned int)__shfl_xor((int)pointBits, off, 64); otherBits |= (unsigned int)__shfl_xor((int)otherBits, off, 64); }
@@ -690,7 +698,7 @@ __device__ inline bool epaAddPointWave(EpaLds& s, uint32_t& nTris, uint32_t& nPt
         if (lane < nb) {
             const uint16_t ei = s.border[lane];
             const EpaEdge e = s.edges[ei];
-            const bool aAct = s.active[e.tA] != 0;
+            const bool aAct = epaTriIdx(e.tA) && s.active[e.tA] != 0;
             const uint16_t triIndex = (uint16_t)(triOffset + lane);
             s.newEdgePerPoint[myConnect] = (uint16_t)(edgeOffset + lane);
             if (aAct) s.edges[ei].tB = triIndex; else s.edges[ei].tA = triIndex;
@@ -704,13 +712,13 @@ __device__ inline bool epaAddPointWave(EpaLds& s, uint32_t& nTris, uint32_t& nPt
             const uint16_t other = s.newEdgePerPoint[connect];
             const uint16_t triIndex = (uint16_t)(lane + triOffset);
             s.tris[triIndex].eB = other;
-            s.edges[other].tA = triIndex;
+            if (epaEdgeIdx(other)) s.edges[other].tA = triIndex;
         }
     } else if (lane == 0) {
         for (uint32_t i = 0; i < nb; ++i) {
             const uint16_t ei = s.border[i];
             const EpaEdge e = s.edges[ei];
-            const bool aAct = s.active[e.tA] != 0, bAct = s.active[e.tB] != 0;
+            const bool aAct = epaTriIdx(e.tA) && s.active[e.tA] != 0, bAct = epaTriIdx(e.tB) && s.active[e.tB] != 0;
             const uint16_t connect = bAct ? e.a : e.b;
             const uint16_t triIndex = (uint16_t)(triOffset + i);
             s.newEdgePerPoint[connect] = (uint16_t)(edgeOffset + i);
@@ -724,7 +732,7 @@ __device__ inline bool epaAddPointWave(EpaLds& s, uint32_t& nTris, uint32_t& nPt
             const uint16_t other = s.newEdgePerPoint[connect];
             const uint16_t triIndex = (uint16_t)(i + triOffset);
             s.tris[triIndex].eB = other;
-            s.edges[other].tA = triIndex;
+            if (epaEdgeIdx(other)) s.edges[other].tA = triIndex;
         }
     }
     nTris += nb; nEdges += nb;

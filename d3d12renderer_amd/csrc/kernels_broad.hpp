@@ -261,6 +261,24 @@ __global__ __launch_bounds__(256) void k_bp_classify(uint32_t nc, const float4* 
     }
 }
 
+// Cell size >= `cell` (grown in steps of 1.3 x) and the grid dimensions over [lo, hi] that fit a table of cellCap cells.  The loop runs until they fit — a world
+// whose bodies have flown apart (found by tools/gpu_fuzz.py: unstable joints carried a body 2e11 m away; 64 growth steps, a factor 2e7, were not enough and the cell
+// histogram was indexed beyond its end) ends with few, huge cells, and one whose bounds are not numbers with a single cell; the indices are clamped to the dimensions anyway.
+__device__ inline float gridFit(const float lo[3], const float hi[3], float cell, uint32_t cellCap, uint32_t dims[3]) {
+    for (int it = 0; it < 512; ++it) {
+        double cells = 1.0;
+        for (int a = 0; a < 3; ++a) {
+            float q = (hi[a] - lo[a]) / cell;
+            if (!(q >= 0.f)) q = 0.f;                                   // (NaN bounds)
+            const uint32_t d = (uint32_t)fminr(q, 4.0e9f) + 2u;
+            dims[a] = d; cells *= (double)d;
+        }
+        if (cells <= (double)(cellCap - 1)) return cell;
+        cell *= 1.3f;                                                   // (reaches +inf after ~340 steps at the latest: q = 0, two cells per axis)
+    }
+    dims[0] = dims[1] = dims[2] = 1u;
+    return cell;
+}
 __global__ __launch_bounds__(256) void k_bp_grid_setup(uint32_t nc, uint32_t numBlocks, uint32_t cellCap, const int* __restrict__ blockBounds, StepScalars* sc, GridParams* g) {
     __shared__ int red[4][6];
     int v[6] = {0x7FFFFFFF, 0x7FFFFFFF, 0x7FFFFFFF, (int)0x80000000, (int)0x80000000, (int)0x80000000};
@@ -279,12 +297,7 @@ __global__ __launch_bounds__(256) void k_bp_grid_setup(uint32_t nc, uint32_t num
     float lo[3], hi[3];
     bool any = v[0] != 0x7FFFFFFF;
     for (int a = 0; a < 3; ++a) { lo[a] = any ? fromOrderedInt(v[a]) : 0.f; hi[a] = any ? fromOrderedInt(v[3 + a]) : 0.f; }
-    for (int it = 0; it < 64; ++it) {
-        double cells = 1.0;
-        for (int a = 0; a < 3; ++a) { uint32_t d = (uint32_t)((hi[a] - lo[a]) / cell) + 2u; g->dims[a] = d; cells *= (double)d; }
-        if (cells <= (double)(cellCap - 1)) break;   // the host sized the cell table (histogram + scan) for cellCap cells
-        cell *= 1.3f;
-    }
+    cell = gridFit(lo, hi, cell, cellCap, g->dims);   // the host sized the cell table (histogram + scan) for cellCap cells
     g->numCells = g->dims[0] * g->dims[1] * g->dims[2];
     sc->numCells = g->numCells;
     g->cell = cell; g->invCell = 1.f / cell;
@@ -855,12 +868,7 @@ __device__ inline void pairFinishStats(const Shards* __restrict__ sh, StepScalar
             float lo[3], hi[3];
             const bool any = b6[0] != 0x7FFFFFFF;
             for (int a = 0; a < 3; ++a) { lo[a] = any ? fromOrderedInt(b6[a]) : 0.f; hi[a] = any ? fromOrderedInt(b6[3 + a]) : 0.f; }
-            for (int it = 0; it < 64; ++it) {
-                double cells = 1.0;
-                for (int a = 0; a < 3; ++a) { uint32_t d = (uint32_t)((hi[a] - lo[a]) / cell) + 2u; gridNext->dims[a] = d; cells *= (double)d; }
-                if (cells <= (double)(cellCapNext - 1)) break;
-                cell *= 1.3f;
-            }
+            cell = gridFit(lo, hi, cell, cellCapNext, gridNext->dims);
             gridNext->numCells = gridNext->dims[0] * gridNext->dims[1] * gridNext->dims[2];
             sc->numCellsNext = gridNext->numCells;
             gridNext->cell = cell; gridNext->invCell = 1.f / cell;

@@ -8,6 +8,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <cstdio>
 #include <cstring>
 #include <tuple>
 #include <utility>
@@ -65,10 +66,13 @@ struct Launcher {
             opDone();
         }
         if (!dry) {
+            if (traceEach) { std::fprintf(stderr, "[mi_physics]   launch %u: grid %u x %u, block %u, lds %zu\n", traceOrdinal++, grid.x, grid.y, block.x, lds); std::fflush(stderr); }
             std::apply([&](auto&... a) { hipLaunchKernelGGL(kernel, grid, block, lds, st, a...); }, t);
             note(hipGetLastError());
+            if (traceEach) note(hipStreamSynchronize(st));   // (MI_DEBUG_SYNC: a memory fault ends the process inside this wait — the line above names the launch)
         }
     }
+    bool traceEach = false; uint32_t traceOrdinal = 0;
     hipError_t memsetAsync(void* p, int v, size_t n, hipStream_t st) {
         if (!n) return hipSuccess;
         const uint32_t blocks = (uint32_t)std::min<size_t>(2048, (n / 16 + 255) / 256 + 1);

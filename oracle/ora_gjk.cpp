@@ -191,26 +191,33 @@ static uint32_t findTriangleClosestToOrigin(const EpaSimplex& s) {  // collision
     return closest;
 }
 // addNewPointAndUpdate — collision_epa.cpp:117-240
+// Where the reference's code reads what it never wrote — on a degenerate polytope (zero-area faces have NaN normals and are never "seen", so the faces a new point sees need
+// not form one loop) a new face's third edge is looked up in newEdgePerPoint[] for a point no horizon edge started from, and an edge's first face may stay unset — the
+// reference's behaviour is undefined (it indexes its 1024-entry arrays with whatever the stack held).  Oracle and product define it the same way instead: such an index is
+// 0xFFFF, "no edge" / "no face": it is never dereferenced, counts no reference, and a missing face counts as inactive.
 static bool addNewPointAndUpdate(EpaSimplex& s, const GjkSimplexPoint& np) {
     uint8_t edgeRefs[EPA_MAX_EDGES];
     std::memset(edgeRefs, 0, sizeof(edgeRefs));
+    auto ref = [&](uint16_t e) { if (e < EPA_MAX_EDGES) ++edgeRefs[e]; };
+    auto isActive = [&](uint16_t t) { return t < EPA_MAX_TRIS && s.active[t]; };
     for (uint32_t i = 0; i < s.numTris; ++i) {
         if (!s.active[i]) continue;
         EpaTri& t = s.tris[i];
         float d = dot(t.normal, np.minkowski - s.points[t.a].minkowski);
-        if (d > 0.f) { ++edgeRefs[t.eA]; ++edgeRefs[t.eB]; ++edgeRefs[t.eC]; s.active[i] = false; }
+        if (d > 0.f) { ref(t.eA); ref(t.eB); ref(t.eC); s.active[i] = false; }
     }
     uint16_t border[EPA_MAX_BORDER]; uint32_t numBorder = 0;
     for (uint32_t i = 0; i < s.numEdges; ++i)
         if (edgeRefs[i] == 1) { if (numBorder >= EPA_MAX_BORDER) return false; border[numBorder++] = (uint16_t)i; }
     uint16_t newEdgePerPoint[EPA_MAX_POINTS];
+    for (uint16_t& e : newEdgePerPoint) e = UINT16_MAX;
     uint16_t npi = pushPoint(s, np);
     if (npi == UINT16_MAX) return false;
     uint16_t triOffset = s.numTris;
     for (uint32_t i = 0; i < numBorder; ++i) {
         uint16_t ei = border[i];
         EpaEdge& e = s.edges[ei];
-        bool triAActive = s.active[e.tA], triBActive = s.active[e.tB];
+        bool triAActive = isActive(e.tA), triBActive = isActive(e.tB);
         uint16_t pointToConnect = triBActive ? e.a : e.b;
         uint16_t triIndex = s.numTris;
         uint16_t newEdge = pushEdge(s, pointToConnect, npi, UINT16_MAX, s.numTris);
@@ -228,7 +235,7 @@ static bool addNewPointAndUpdate(EpaSimplex& s, const GjkSimplexPoint& np) {
         uint16_t other = newEdgePerPoint[pointToConnect];
         uint16_t triIndex = (uint16_t)(i + triOffset);
         s.tris[triIndex].eB = other;
-        s.edges[other].tA = triIndex;
+        if (other < EPA_MAX_EDGES) s.edges[other].tA = triIndex;
     }
     return true;
 }
