@@ -280,10 +280,13 @@ __device__ inline uint32_t heightmapContacts(const HeightmapParams& hm, const Sh
 //                 min/max-height test (an ancestor's box contains the quad's), in DESCENDING Morton order with x as the high
 //                 bit (children are pushed (0,0) (0,1) (1,0) (1,1) and popped in reverse), first triangle before second.  So
 //                 the lanes test their triangles independently and contact j = the number of hit triangles that precede it in
-//                 that order (found by comparing sort keys against the hit lanes only).  Colliders with a larger window are
-//                 flagged for k_hm_slow.  WRITE = false: count per collider.  WRITE = true: the same walk again, contacts
+//                 that order (found by comparing sort keys against the hit lanes only).  A larger window is taken in its
+//                 aligned 8 x 8 blocks (nodes of mip 3), blocks in descending Morton order, pruned by their height range
+//                 like the walk prunes them — the same order, 64 quads at a time (round 6; such colliders used to be
+//                 flagged for k_hm_slow).  WRITE = false: count per collider.  WRITE = true: the same walk again, contacts
 //                 written straight to their final slots.
-// k_hm_slow<WRITE>      one lane per flagged collider: the sequential walk.
+// k_hm_slow<WRITE>      one lane per flagged collider: the sequential walk (nothing flags a collider any more; kept as the
+//                 plain restatement of the reference's walk the wave kernel is checked against in development).
 // (exclusive scan of the packed counts on the stream: contact offsets + colliders touching the terrain)
 // k_hm_totals     StepScalars::numHmContacts / numHmColliders for the host's sizing read-back.
 // k_hm_finish     numPairs += numHmContacts (after the WRITE passes, which address slots relative to the collider pairs).
@@ -291,6 +294,10 @@ __device__ inline uint32_t heightmapContacts(const HeightmapParams& hm, const Sh
 // collider-pair narrow phase: slot = numPairs + offset(collider) + j — deterministic positions, no atomics.
 __device__ __forceinline__ uint32_t hmSpread7(uint32_t v) {   // bit i -> bit 2 i (7 bits)
     v = (v | (v << 4)) & 0x0F0Fu; v = (v | (v << 2)) & 0x3333u; v = (v | (v << 1)) & 0x5555u;
+    return v;
+}
+__device__ __forceinline__ uint32_t hmCompact4(uint32_t v) {   // bit 2 i -> bit i (4 bits)
+    v &= 0x55u; v = (v | (v >> 1)) & 0x33u; v = (v | (v >> 2)) & 0x0Fu;
     return v;
 }
 __device__ __forceinline__ bool hmActive(uint32_t tag, uint32_t& type) {
@@ -351,10 +358,11 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
             vol.window(x, z, x0, z0, x1, z1);
             x1 = min(x1, kHmSegs - 1u); z1 = min(z1, kHmSegs - 1u);
             if (x0 > x1 || z0 > z1) continue;
-            const uint32_t w = x1 - x0 + 1u, n = w * (z1 - z0 + 1u);
-            if (n > 64u) { slow = true; break; }
             const V3 chunkMin = V3((float)x * hm.chunkSize, 0.f, (float)z * hm.chunkSize) + vol.corner;
             const uint16_t* __restrict__ heights = hm.heights + (size_t)slot * kHmVerts * kHmVerts;
+            // one batch: the quads of the rectangle [rx0, rx1] x [rz0, rz1] (at most 64 of them), in the reference's order (descending Morton code, first triangle first)
+            auto batch = [&](const uint32_t x0, const uint32_t z0, const uint32_t x1, const uint32_t z1) {
+            const uint32_t w = x1 - x0 + 1u, n = w * (z1 - z0 + 1u);
             // item = 2 * quad + triangle, 64 items per batch, at most two batches
             uint32_t sk[2] = {0u, 0u}; bool hit[2] = {false, false}; TriContact tc[2];
 #pragma unroll
@@ -395,6 +403,21 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
                 }
             }
             found = min(found + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1), kHmMaxContacts);
+            };
+            if ((x1 - x0 + 1u) * (z1 - z0 + 1u) <= 64u) batch(x0, z0, x1, z1);
+            else {
+                // a larger window (round 6; one lane used to walk these alone in k_hm_slow — 35 ms for a collider spanning a chunk of fine terrain, found by tools/gpu_fuzz.py):
+                // its aligned 8 x 8 blocks in descending Morton order — which IS the order of the reference's walk down the mip pyramid (heightmap_collider.h:35-118), a block
+                // being one node of mip 3 — each block's part of the window as one batch; a block whose height range misses the collider's is skipped as the walk prunes it.
+                const uint32_t* __restrict__ mip3 = hm.mips + (size_t)slot * kHmMipEntries + hmMipOffset(3u);
+                for (int code = 255; code >= 0; --code) {
+                    const uint32_t bx = hmCompact4((uint32_t)code >> 1), bz = hmCompact4((uint32_t)code);
+                    if (bx < (x0 >> 3) || bx > (x1 >> 3) || bz < (z0 >> 3) || bz > (z1 >> 3)) continue;
+                    const uint32_t mm = mip3[bz * (kHmSegs >> 3) + bx];
+                    if ((mm >> 16) < vol.volMinY || (mm & 0xFFFFu) > vol.volMaxY) continue;
+                    batch(max(x0, bx << 3), max(z0, bz << 3), min(x1, (bx << 3) + 7u), min(z1, (bz << 3) + 7u));
+                }
+            }
         }
     if (lane != 0) return;
     if (WRITE) {

@@ -897,6 +897,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_W
     __shared__ PrivateLds pl;
     const uint32_t numTiles = sc->totalTiles, per = numIslands + numTiles;
     if (blockIdx.x >= per * sweeps) return;
+    if (stepIsVoid(sc)) return;
     const uint32_t it = itBase + blockIdx.x / per, idx = blockIdx.x % per;
     if (idx < numIslands) {
         if (bv.active && !bv.active[islandBodies[islands[idx].bodyBegin]]) return;

@@ -74,6 +74,14 @@ struct StepScalars {  // device-resident per-step scalars
     unsigned long long axisSums[9]; // centre statistics of the colliders this world counts (k_pair_finish): S1[3], S2lo[3], S2hi[3]; a sharded world's are added over the ranks
 };
 
+// A speculative step that is already known to be void by the time its solver starts — a bound was exceeded, the colouring did not finish, or an overflow colour appeared (only the
+// per-colour path solves that one) — is run again synchronously by the host, whatever the solver does.  The dataflow kernels look here first and leave: they would otherwise wait,
+// tile after tile, for updates of bodies that the missing manifolds never make, until the spin budget ends the launch (0.4-0.7 s; found by tools/gpu_fuzz.py on a heap of
+// bodies spawned into one another).
+__device__ __forceinline__ bool stepIsVoid(const StepScalars* sc) {
+    return (sc->specOverflow | sc->colorPending | (sc->binStart[kColorBins] - sc->binStart[kOverflowColor * 4u])) != 0u;
+}
+
 #ifdef MI_DBG_KNOCKOUT
 // development (knock-out harness, tools/gpu_knockout.sh).  Bits 0-2: k_contact_solve_persist (see there).  Bits 8-12: k_emit_manifolds launched a first time with its
 // read-modify-write targets redirected to scratch and parts removed: 8 no bodyUsed atomics, 9 no history insert, 10 no history probe, 11 no round-0 proposals, 12 no material gathers.

@@ -340,6 +340,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, MI_FLOW_W
     uint32_t itBase, uint32_t sweeps, const uint2* __restrict__ tileDesc, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
     const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* imp, float4* gVel, StepScalars* sc) {
     const uint32_t numTiles = sc->totalTiles;   // the grid is sized from an upper bound: surplus workgroups (all at the end) exit
+    if (stepIsVoid(sc)) return;
     if (blockIdx.x >= numTiles * sweeps) return;
     const uint32_t it = itBase + blockIdx.x / numTiles, tile = blockIdx.x % numTiles, lane = threadIdx.x;
     const uint2 d = tileDesc[tile];
@@ -443,6 +444,7 @@ __device__ __forceinline__ void persistSolveBody(MI_PERSIST_PARAMS) {
     float2* lImp = lMass + metaSlots * 64u;
     uint32_t* lDesc = reinterpret_cast<uint32_t*>(lImp + (IMPLDS ? (size_t)maxSlots * 4u * 64u : 0));   // [maxSlots][3]
     if (xcdOnly && (blockIdx.x & 7u) != 0u) return;   // development experiment: only the workgroups of one XCD work
+    if (stepIsVoid(sc)) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t xcd = blockIdx.x & 7u;
     uint32_t numTiles = sc->totalTiles, numWaves = xcdOnly ? gridDim.x / 8u : gridDim.x, wid = xcdOnly ? blockIdx.x / 8u : blockIdx.x;
@@ -616,16 +618,54 @@ template <> MI_PERSIST_KERNEL_ATTRS __attribute__((amdgpu_num_vgpr(208))) void k
 template <> MI_PERSIST_KERNEL_ATTRS __attribute__((amdgpu_num_vgpr(208))) void k_contact_solve_persist<true, false, true>(MI_PERSIST_PARAMS) { persistSolveBody<true, false, true>(MI_PERSIST_PASS); }
 static_assert(kResidentVgprBase == 208, "the cap of the specialisations above");
 
-// Overflow colour (a body with > 64 incident manifolds): sequential, one lane, slots in ascending pair-key order.
-__global__ void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
-                                       const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* __restrict__ imp, float4* __restrict__ gVel) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    for (uint32_t j = 0; j < bi.count; ++j) {
-        uint32_t tile = bi.tileStart + (j >> 6), lane = j & 63u, ctBase = bi.ctStart + (j >> 6) * 4u;
-        uint4 meta = slotMeta[(size_t)tile * 64u + lane];
-        solveTileK(meta.w & 7u, tile, ctBase, lane, slotMeta, slotNormal, slotMass, rows, imp, gVel);
-        __threadfence();
+// Overflow colour (manifolds the 64 colours could not take: a body with that many incident manifolds — bodies spawned into one another): sequential, slots in ascending
+// pair-key order, by ONE wave.  Round 6 (tools/gpu_fuzz.py: a 150-body heap of deeply overlapping shapes took 0.4 s per step): one lane used to walk the slots alone,
+// ~13 us each (four dependent loads, a device-scope fence).  Now the 64 lanes fetch the constants of 64 consecutive slots together — one round trip per 64 slots —
+// and then take their turns in slot order; a turn is the two bodies' loads, the solve, the stores and a workgroup-scope fence (the wave's L1 stays coherent with its own
+// write-through stores; nobody else touches these bodies during this launch).  Same arithmetic, same order: same bits.
+__global__ __launch_bounds__(64) void k_contact_solve_serial(BinInfo bi, const uint4* __restrict__ slotMeta, const float4* __restrict__ slotNormal,
+                                                             const float2* __restrict__ slotMass, const float4* __restrict__ rows, float4* imp, float4* gVel) {
+    if (blockIdx.x != 0) return;
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t base = 0; base < bi.count; base += 64u) {
+        const uint32_t tile = bi.tileStart + (base >> 6), ctBase = bi.ctStart + (base >> 6) * 4u;   // (the overflow bin's tiles hold four contact-tiles each)
+        const uint32_t n = min(64u, bi.count - base);
+        const uint4 meta = slotMeta[(size_t)tile * 64u + lane];
+        const float4 nf = slotNormal[(size_t)tile * 64u + lane];
+        const float2 mass = slotMass[(size_t)tile * 64u + lane];
+        const uint32_t cnt = lane < n ? (meta.w & 7u) : 0u;
+        ContactRows c[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if ((uint32_t)k < cnt) {
+                const float4* __restrict__ row = rows + ((size_t)ctBase + k) * (kRows * 64u) + lane;
+#pragma unroll
+                for (uint32_t r = 0; r < kRows; ++r) c[k].r[r] = row[r * 64u];
+                c[k].imp = imp[((size_t)ctBase + k) * 64u + lane];
+            }
+        }
+        const uint32_t bA = meta.x, bB = meta.y;
+        const float imA = mass.x, imB = mass.y;
+        const bool live = meta.w != 0u && (imA != 0.f || imB != 0.f);
+        for (uint32_t turn = 0; turn < n; ++turn) {
+            if (lane == turn && cnt) {
+                const float4 a0 = gVel[2 * bA], a1 = gVel[2 * bA + 1], b0 = gVel[2 * bB], b1 = gVel[2 * bB + 1];
+                V3 vA = xyz(a0), wA = xyz(a1), vB = xyz(b0), wB = xyz(b1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if ((uint32_t)k < cnt) {
+                        float2 im = make_float2(c[k].imp.x, c[k].imp.y);
+                        solveOne(c[k], contactNormal(c[k], nf, (meta.w & kMetaPerContactNormal) != 0u), im, imA, imB, vA, wA, vB, wB);
+                        if (live) imp[((size_t)ctBase + k) * 64u + lane] = make_float4(im.x, im.y, c[k].imp.z, c[k].imp.w);
+                    }
+                }
+                if (live && imA != 0.f) { gVel[2 * bA] = f4(vA, a0.w); gVel[2 * bA + 1] = f4(wA, a1.w); }   // .w: version tags, untouched by this path
+                if (live && imB != 0.f) { gVel[2 * bB] = f4(vB, b0.w); gVel[2 * bB + 1] = f4(wB, b1.w); }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");   // the next turn's loads come after these stores
+        }
     }
+    __threadfence();
 }
 
 }  // namespace mi

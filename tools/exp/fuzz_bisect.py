@@ -20,10 +20,10 @@ if "no-joints" in off:
     sc.global_constraints = []
 if "no-hulls" in off:
     h = sc.colliders["type"] == capi.HULL; sc.colliders["type"][h] = capi.SPHERE; sc.colliders["shape"][h, :4] = (0, 0, 0, 0.3)
-plan = gpu_fuzz.plan_actions(seed, 40, bodies)
+plan = gpu_fuzz.plan_actions(seed, 40)
 if "no-actions" in off:
-    plan = [(None, a) for _, a in plan]
+    plan = [(m, 1.0, r, v) for m, u, r, v in plan]
 w = sc.populate(mi.create_world(0))
 print("populated", flush=True)
-r = gpu_fuzz.run_world(w, sc, 40, [(None, a) for _, a in plan] if False else plan, events, bodies)
+r = gpu_fuzz.run_world(w, sc, 40, plan, events, bodies)
 print("ok", r[-1][0], flush=True)
