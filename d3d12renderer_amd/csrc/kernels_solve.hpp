@@ -444,10 +444,10 @@ __device__ __forceinline__ void persistSolveBody(MI_PERSIST_PARAMS) {
     float2* lImp = lMass + metaSlots * 64u;
     uint32_t* lDesc = reinterpret_cast<uint32_t*>(lImp + (IMPLDS ? (size_t)maxSlots * 4u * 64u : 0));   // [maxSlots][3]
     if (xcdOnly && (blockIdx.x & 7u) != 0u) return;   // development experiment: only the workgroups of one XCD work
-    if (stepIsVoid(sc)) return;
     const uint32_t lane = threadIdx.x;
     const uint32_t xcd = blockIdx.x & 7u;
-    uint32_t numTiles = sc->totalTiles, numWaves = xcdOnly ? gridDim.x / 8u : gridDim.x, wid = xcdOnly ? blockIdx.x / 8u : blockIdx.x;
+    const bool isVoid = stepIsVoid(sc);   // (a speculative step already known to be void: no tiles, the workgroup leaves — kernels_common.hpp; loaded beside the tile counts, no round trip of its own)
+    uint32_t numTiles = isVoid ? 0u : sc->totalTiles, numWaves = xcdOnly ? gridDim.x / 8u : gridDim.x, wid = xcdOnly ? blockIdx.x / 8u : blockIdx.x;
     if (XCD) {
         uint32_t hw;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));
@@ -456,7 +456,7 @@ __device__ __forceinline__ void persistSolveBody(MI_PERSIST_PARAMS) {
         if (lane == 0) { seen = atomicCAS(&sc->xccOf[xcd], 0xFFFFFFFFu, hw); if (seen == 0xFFFFFFFFu) seen = hw; }
         seen = (uint32_t)__shfl((int)seen, 0, 64);
         if (seen != hw || (xcdFault && blockIdx.x == 9u)) { if (lane == 0) sc->solveError = 3u; return; }   // blockIdx % 8 does not identify the XCD on this device (xcdFault: test injection)
-        numTiles = sc->totalTiles ? sc->xcdCount[xcd] : 0u; numWaves = gridDim.x / 8u; wid = blockIdx.x / 8u;
+        numTiles = (sc->totalTiles && !isVoid) ? sc->xcdCount[xcd] : 0u; numWaves = gridDim.x / 8u; wid = blockIdx.x / 8u;
         xcdTiles += (size_t)xcd * listCap;
         if (numTiles > listCap) { if (lane == 0) sc->solveError = 2u; return; }
     }
