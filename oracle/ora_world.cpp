@@ -829,6 +829,11 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
     else { broadphaseCanonical(*this); narrowphaseCanonical(*this, axisUsed); }
     heightmapCollision(*this);   // physics.cpp:1237-1248: after the narrow phase, into the same contact arrays
 
+    // sharded world: a localized force field acts on a ghost for THIS step's solver-side state only — its accumulator is the owner's business (the product keeps the step's
+    // forces in a buffer of their own, bForceStep).  Without the restore below a ghost inside a field gathered the field's force step after step (found by
+    // tools/gpu_fuzz_sharded.py; no test scene had a localized field in a sharded world).
+    std::vector<vec3> accBefore;
+    if (shard.enabled) { accBefore.resize(nb); for (uint32_t i = 0; i < nb; ++i) accBefore[i] = bodies[i].forceAccumulator; }
     vec3 globalForceField = nonCollisionInteractions(*this);   // force fields, triggers (physics.cpp:1253-1256)
     rb.resize(nb + 1);
     for (uint32_t i = nb; i-- > 0;) {                           // back to front (1266-1276)
@@ -839,6 +844,7 @@ void World::stepInternal(const mi_step_settings& settings, float dt) {
         bodies[i].forceAccumulator += globalForceField;         // physics.cpp:1273
         applyGravityAndIntegrateForces(bodies[i], rb[i], dt);
     }
+    if (shard.enabled) for (uint32_t i = 0; i < nb; ++i) if (shard.active[i] != 1) bodies[i].forceAccumulator = accBefore[i];
     std::memset((void*)&rb[nb], 0, sizeof(GlobalState));  // dummy (1279)
     if (eventsEnabled) collisionEvents(*this); else prevCollisionKeys.clear();
 
