@@ -21,6 +21,15 @@ def test_gpu_random_worlds_equal_the_oracle(mi_lib, oracle_mod, first, count, sc
     assert not bad, bad[:3]
 
 
+@pytest.mark.gpu
+def test_gpu_random_worlds_cut_into_tiles_equal_the_oracles_ranks(mi_lib, oracle_mod):
+    """The sharded sibling (tools/gpu_fuzz_sharded.py): the same random worlds as 2-4 virtual ranks on the GPU and in the oracle's sharding mirror — local counts, owned counts,
+    owned states bit for bit (localized force fields acting on ghosts included: what the long run found in the mirror)."""
+    import gpu_fuzz_sharded
+    bad = [r for r in (gpu_fuzz_sharded.run_seed(seed, 30, oracle_mod, 4) for seed in range(30, 70)) if r]
+    assert not bad, bad[:3]
+
+
 def test_fuzz_world_generator_is_deterministic_and_valid(oracle_mod):
     """(CPU) the same seed gives the same world and plan; what it generates is a world the oracle steps without a non-finite state in the first steps."""
     import numpy as np

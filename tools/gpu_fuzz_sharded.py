@@ -41,11 +41,6 @@ def run_seed(seed, steps, oracle, scale):
                 so = [r.owned_states() for r in o]
                 if not all((np.abs(st) < 1.0e6).all() for _, st in so):
                     return None                                     # the world flew apart (random joints): nothing to compare beyond here
-                # a body that crosses more than a tile in one step (an unstable joint throws bodies at 200 m/s) can land in a tile that is no neighbour of its owner's and is
-                # then owned by nobody — the limit of any spatial decomposition with nearest-neighbour exchange, on both sides alike: such a world ends here
-                reach = 0.4 * min(desc.tile_size_x if desc.tiles_x > 1 else 1e30, desc.tile_size_z if desc.tiles_z > 1 else 1e30)
-                if any(len(st) and float(np.abs(st[:, 7:10]).max()) * sc.dt * 5.0 > reach for _, st in so):
-                    return None
             sharding.step_local(g, s, sc.dt)
             for a, b in zip(g, o):
                 if a.world.counts() != b.world.counts():
@@ -60,7 +55,7 @@ def run_seed(seed, steps, oracle, scale):
                         return {"seed": seed, "step": i, "rank": a.rank, "what": "owned states", "ranks": n, "tiles_z": tiles_z,
                                 "entities_equal": bool(np.array_equal(ea, eb)), "max_abs_diff": float(np.nanmax(np.abs(sa - sb))) if sa.shape == sb.shape and len(sa) else None}
                 if owned != len(bodies):                             # GPU ranks == oracle ranks up to here, and BOTH lost a body: thrown across a whole tile in one step
-                    LOST.append({"seed": seed, "step": i, "owned": owned, "bodies": int(len(bodies))})   # (the protocol's limit, see above; reported, not a parity failure)
+                    LOST.append({"seed": seed, "step": i, "owned": owned, "bodies": int(len(bodies))})   # (an unstable joint moved it 4 m in a step; it landed in a tile that is no neighbour of its owner's — the limit of nearest-neighbour exchange; reported, not a parity failure)
                     return None
         return None
     finally:
