@@ -57,10 +57,34 @@ def run_seed(seed, steps, oracle, scale):
                 if owned != len(bodies):                             # GPU ranks == oracle ranks up to here, and BOTH lost a body: thrown across a whole tile in one step
                     LOST.append({"seed": seed, "step": i, "owned": owned, "bodies": int(len(bodies))})   # (an unstable joint moved it 4 m in a step; it landed in a tile that is no neighbour of its owner's — the limit of nearest-neighbour exchange; reported, not a parity failure)
                     return None
-        return None
+        return seam_told(seed, sc, bodies, desc, steps, oracle) if tiles_z == 1 else None
     finally:
         for r in g + o:
             r.world.close()
+
+
+def seam_told(seed, sc, bodies, desc, steps, oracle):
+    """Exact seam (slabs only), the single-world half of it: ONE GPU world told the tiling (mi_world_set_seam_tiling: the manifolds among bodies shared across a border take
+    the leading colours) against the oracle told the same — counts, seam statistics, every body state."""
+    a = sc.populate(mi.create_world(0)); a.set_seam_tiling(desc)
+    o = sc.populate(oracle.create_world(oracle.ORDER_CANONICAL)); o.set_seam_tiling(desc)
+    s = sc.settings()
+    try:
+        for i in range(steps):
+            a.step_fixed(s, sc.dt, 1); o.step_fixed(s, sc.dt, 1)
+            if a.counts() != o.counts():
+                return {"seed": seed, "step": i, "what": "seam world: counts", "gpu": a.counts(), "oracle": o.counts()}
+            if a.seam_stats() != o.seam_stats():
+                return {"seed": seed, "step": i, "what": "seam world: seam statistics", "gpu": a.seam_stats(), "oracle": o.seam_stats()}
+            if i % 5 == 4 or i == steps - 1:
+                sa, so = a.get_body_states(bodies), o.get_body_states(bodies)
+                if not (np.abs(so) < 1.0e6).all():
+                    return None
+                if sa.tobytes() != so.tobytes():
+                    return {"seed": seed, "step": i, "what": "seam world: states", "max_abs_diff": float(np.nanmax(np.abs(sa - so)))}
+        return None
+    finally:
+        a.close(); o.close()
 
 
 def main():
