@@ -224,69 +224,19 @@ __device__ inline bool hmLowestPoint(const HeightmapParams& hm, const Shape& s, 
     return true;
 }
 
-// One collider against the terrain, sequentially (the reference's stack walk, heightmap_collider.h:35-118).
-// `sink(j, contact)` receives contact j (j < 255) in the reference's order; returns the count.  The general path: used for
-// colliders whose cell window is too large for the wave-parallel kernel below.
-template <typename Sink>
-__device__ inline uint32_t heightmapContacts(const HeightmapParams& hm, const Shape& s, const HullSet& hulls, V3 mn, V3 mx, const Sink& sink) {
-    uint32_t found = 0;
-    const TriShape ts(s);
-    const HmVolume vol(hm, mn, mx);
-    auto triangle = [&](V3 a, V3 b, V3 c) {
-        TriContact t;
-        if (ts.test(a, b, c, t) && found < kHmMaxContacts) { sink(found, t); ++found; }
-    };
-    for (uint32_t z = vol.minCZ; z <= vol.maxCZ; ++z)
-        for (uint32_t x = vol.minCX; x <= vol.maxCX; ++x) {
-            const uint32_t slot = hm.chunkSlot[z * hm.chunksPerDim + x];
-            if (slot == 0xFFFFFFFFu) continue;
-            uint32_t volMinX, volMinZ, volMaxX, volMaxZ;
-            vol.window(x, z, volMinX, volMinZ, volMaxX, volMaxZ);
-            const V3 chunkMin = V3((float)x * hm.chunkSize, 0.f, (float)z * hm.chunkSize) + vol.corner;
-            const uint16_t* __restrict__ heights = hm.heights + (size_t)slot * kHmVerts * kHmVerts;
-            const uint32_t* __restrict__ mips = hm.mips + (size_t)slot * kHmMipEntries;
-            uint32_t stack[28]; uint32_t top = 0;   // node = mip << 16 | x << 8 | z
-            stack[top++] = 7u << 16;
-            while (top) {
-                const uint32_t e = stack[--top];
-                const uint32_t mip = e >> 16, ex = (e >> 8) & 0xFFu, ez = e & 0xFFu;
-                const uint32_t x0 = ex << mip, z0 = ez << mip, x1 = ((ex + 1u) << mip) - 1u, z1 = ((ez + 1u) << mip) - 1u;
-                if (x1 < volMinX || x0 > volMaxX) continue;
-                if (z1 < volMinZ || z0 > volMaxZ) continue;
-                const uint32_t mm = mips[hmMipOffset(mip) + ez * (kHmSegs >> mip) + ex];
-                if ((mm >> 16) < vol.volMinY || (mm & 0xFFFFu) > vol.volMaxY) continue;
-                if (mip == 0u) {
-                    V3 pa = hmVertex(hm, heights, chunkMin, ex, ez), pb = hmVertex(hm, heights, chunkMin, ex, ez + 1u);
-                    V3 pc = hmVertex(hm, heights, chunkMin, ex + 1u, ez), pd = hmVertex(hm, heights, chunkMin, ex + 1u, ez + 1u);
-                    triangle(pa, pb, pc);
-                    triangle(pc, pb, pd);
-                } else {
-                    const uint32_t m = (mip - 1u) << 16;
-                    stack[top++] = m | ((2u * ex) << 8) | (2u * ez);
-                    stack[top++] = m | ((2u * ex) << 8) | (2u * ez + 1u);
-                    stack[top++] = m | ((2u * ex + 1u) << 8) | (2u * ez);
-                    stack[top++] = m | ((2u * ex + 1u) << 8) | (2u * ez + 1u);
-                }
-            }
-        }
-    TriContact t;
-    if (hmLowestPoint(hm, s, hulls, t) && found < kHmMaxContacts) { sink(found, t); ++found; }
-    return found;
-}
-
 // ---- the device pipeline ------------------------------------------------------------------------------------------------
-// k_hm_contacts<WRITE>  one WAVE per collider, one lane per TRIANGLE of the collider's cell window (<= 64 quads per chunk; the
-//                 usual case: a body spans a few cells).  The stack walk visits exactly the quads that pass their own x/z and
-//                 min/max-height test (an ancestor's box contains the quad's), in DESCENDING Morton order with x as the high
-//                 bit (children are pushed (0,0) (0,1) (1,0) (1,1) and popped in reverse), first triangle before second.  So
-//                 the lanes test their triangles independently and contact j = the number of hit triangles that precede it in
-//                 that order (found by comparing sort keys against the hit lanes only).  A larger window is taken in its
-//                 aligned 8 x 8 blocks (nodes of mip 3), blocks in descending Morton order, pruned by their height range
-//                 like the walk prunes them — the same order, 64 quads at a time (round 6; such colliders used to be
-//                 flagged for k_hm_slow).  WRITE = false: count per collider.  WRITE = true: the same walk again, contacts
-//                 written straight to their final slots.
-// k_hm_slow<WRITE>      one lane per flagged collider: the sequential walk (nothing flags a collider any more; kept as the
-//                 plain restatement of the reference's walk the wave kernel is checked against in development).
+// k_hm_contacts<WRITE, LARGE>  one WAVE per collider, one lane per TRIANGLE of the collider's cell window.  The reference's stack walk
+//                 (heightmap_collider.h:35-118: root of the mip pyramid on a stack; a node is dropped when it misses the window or the
+//                 height range, a leaf tests its two triangles, an inner node pushes its children (0,0) (0,1) (1,0) (1,1)) visits exactly
+//                 the quads that pass their own x/z and min/max-height test (an ancestor's box contains the quad's), in DESCENDING Morton
+//                 order with x as the high bit, first triangle before second.  So the lanes test their triangles independently and
+//                 contact j = the number of hit triangles that precede it in that order (found by comparing sort keys against the hit
+//                 lanes only).  LARGE = false (every collider): windows of at most 64 cells per chunk — the usual case, a body spans a
+//                 few cells; a collider with a larger window is flagged.  LARGE = true (launched behind it, flagged colliders only, the
+//                 others' waves leave at once): the window's aligned 8 x 8 blocks (nodes of mip 3) in descending Morton order, pruned by
+//                 their height range like the walk prunes them — the same order, 64 quads at a time (round 6; such colliders used to be
+//                 walked by ONE lane in a kernel of their own).  WRITE = false: count per collider.  WRITE = true: the same again,
+//                 contacts written straight to their final slots.
 // (exclusive scan of the packed counts on the stream: contact offsets + colliders touching the terrain)
 // k_hm_totals     StepScalars::numHmContacts / numHmColliders for the host's sizing read-back.
 // k_hm_finish     numPairs += numHmContacts (after the WRITE passes, which address slots relative to the collider pairs).
@@ -328,7 +278,7 @@ struct HmOut {   // where the WRITE passes put contact j of collider i
 // needed the contact geometry: keeping the contacts themselves doubled its time).  A collider with more hits than the stash holds is walked again as before.
 constexpr uint32_t kHmStashLowest = 0xFFFFFFFFu;
 constexpr uint32_t kHmStash = 16;
-template <bool WRITE>
+template <bool WRITE, bool LARGE>
 __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
                                                      const float4* __restrict__ aabbMax, unsigned long long* __restrict__ hmPacked, uint8_t* __restrict__ hmSlow,
                                                      const unsigned long long* __restrict__ hmScan, HmOut out, HullSet hulls, uint32_t* __restrict__ stash) {
@@ -340,11 +290,12 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
     uint32_t count = 0, first = 0;
     if (WRITE) {
         count = active ? (uint32_t)hmPacked[i] : 0u;
-        if (!count || hmSlow[i] || !out.ready()) return;
+        if (!count || (hmSlow[i] != 0) != LARGE || !out.ready()) return;
         first = out.sc->numPairs + (uint32_t)hmScan[i];
-        if (stash && count <= kHmStash && hm.chunksPerDim <= 256u) return;   // every hit of this collider is in the stash: k_hm_write_stashed recomputes just those
-    } else if (!active) { if (lane == 0) { hmPacked[i] = 0ull; hmSlow[i] = 0; } return; }
-    auto keep = [&](uint32_t j, uint32_t id) { if (stash && j < kHmStash) stash[(size_t)i * kHmStash + j] = id; };
+        if (!LARGE && stash && count <= kHmStash && hm.chunksPerDim <= 256u) return;   // every hit of this collider is in the stash: k_hm_write_stashed recomputes just those
+    } else if (LARGE) { if (!active || !hmSlow[i]) return; }                            // (the flags are the plain instance's, launched before this one)
+    else if (!active) { if (lane == 0) { hmPacked[i] = 0ull; hmSlow[i] = 0; } return; }
+    auto keep = [&](uint32_t j, uint32_t id) { if (!LARGE && stash && j < kHmStash) stash[(size_t)i * kHmStash + j] = id; };
     const Shape s = loadShape(wShape, i, type);
     const TriShape ts(s);
     const HmVolume vol(hm, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z));
@@ -404,18 +355,27 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
             }
             found = min(found + (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1), kHmMaxContacts);
             };
-            if ((x1 - x0 + 1u) * (z1 - z0 + 1u) <= 64u) batch(x0, z0, x1, z1);
-            else {
-                // a larger window (round 6; one lane used to walk these alone in k_hm_slow — 35 ms for a collider spanning a chunk of fine terrain, found by tools/gpu_fuzz.py):
-                // its aligned 8 x 8 blocks in descending Morton order — which IS the order of the reference's walk down the mip pyramid (heightmap_collider.h:35-118), a block
-                // being one node of mip 3 — each block's part of the window as one batch; a block whose height range misses the collider's is skipped as the walk prunes it.
+            // A window of at most 64 cells is one batch.  A larger one flags the collider (plain instance) and is taken by the LARGE instance of this kernel, launched right
+            // behind it over the flagged colliders only (round 6; one lane used to walk these alone in k_hm_slow — 35 ms for a collider spanning a chunk of fine terrain, found
+            // by tools/gpu_fuzz.py): the window's aligned 8 x 8 blocks in descending Morton order — which IS the order of the reference's walk down the mip pyramid
+            // (heightmap_collider.h:35-118), a block being one node of mip 3 —, a block whose height range misses the collider's skipped as the walk prunes it.  (Two instances:
+            // the block loop costs the plain one, which every collider of a terrain scene runs, ten registers and with them a wave of occupancy.)
+            const bool whole = (x1 - x0 + 1u) * (z1 - z0 + 1u) <= 64u;
+            if (!LARGE) {
+                if (!whole) { slow = true; break; }
+                batch(x0, z0, x1, z1);
+            } else {
                 const uint32_t* __restrict__ mip3 = hm.mips + (size_t)slot * kHmMipEntries + hmMipOffset(3u);
-                for (int code = 255; code >= 0; --code) {
-                    const uint32_t bx = hmCompact4((uint32_t)code >> 1), bz = hmCompact4((uint32_t)code);
-                    if (bx < (x0 >> 3) || bx > (x1 >> 3) || bz < (z0 >> 3) || bz > (z1 >> 3)) continue;
-                    const uint32_t mm = mip3[bz * (kHmSegs >> 3) + bx];
-                    if ((mm >> 16) < vol.volMinY || (mm & 0xFFFFu) > vol.volMaxY) continue;
-                    batch(max(x0, bx << 3), max(z0, bz << 3), min(x1, (bx << 3) + 7u), min(z1, (bz << 3) + 7u));
+                for (int code = whole ? 0 : 255; code >= 0; --code) {
+                    uint32_t rx0 = x0, rz0 = z0, rx1 = x1, rz1 = z1;
+                    if (!whole) {
+                        const uint32_t bx = hmCompact4((uint32_t)code >> 1), bz = hmCompact4((uint32_t)code);
+                        if (bx < (x0 >> 3) || bx > (x1 >> 3) || bz < (z0 >> 3) || bz > (z1 >> 3)) continue;
+                        const uint32_t mm = mip3[bz * (kHmSegs >> 3) + bx];
+                        if ((mm >> 16) < vol.volMinY || (mm & 0xFFFFu) > vol.volMaxY) continue;
+                        rx0 = max(x0, bx << 3); rz0 = max(z0, bz << 3); rx1 = min(x1, (bx << 3) + 7u); rz1 = min(z1, (bz << 3) + 7u);
+                    }
+                    batch(rx0, rz0, rx1, rz1);
                 }
             }
         }
@@ -429,7 +389,7 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
     TriContact t;
     if (hmLowestPoint(hm, s, hulls, t) && found < kHmMaxContacts) { keep(found, kHmStashLowest); ++found; }
     hmPacked[i] = (unsigned long long)found | (found ? 1ull << 32 : 0ull);
-    hmSlow[i] = 0;
+    if (!LARGE) hmSlow[i] = 0;
 }
 // WRITE pass for the stashed colliders: one LANE per terrain contact.  Contact t belongs to the collider i with offset(i) <= t < offset(i) + count(i) (binary search
 // over the scanned counts) and is its hit number j = t - offset(i): the lane recomputes that one triangle (or the lowest point) and writes the contact to its final slot.
@@ -441,7 +401,7 @@ __global__ __launch_bounds__(256) void k_hm_write_stashed(uint32_t nc, Heightmap
     uint32_t lo = 0, hi = nc;                       // the last collider whose offset is <= t (colliders without contacts share their successor's offset)
     while (hi - lo > 1u) { const uint32_t mid = (lo + hi) >> 1; if ((uint32_t)hmScan[mid] <= t) lo = mid; else hi = mid; }
     const uint32_t i = lo, count = (uint32_t)hmPacked[i], j = t - (uint32_t)hmScan[i];
-    if (j >= count || count > kHmStash || hmSlow[i]) return;     // (the wave-per-collider pass / k_hm_slow write those)
+    if (j >= count || count > kHmStash || hmSlow[i]) return;     // (the wave-per-collider passes write those)
     const float4 mn = aabbMin[i], mx = aabbMax[i];
     const Shape s = loadShape(wShape, i, __float_as_uint(mn.w) & 0xFFu);
     const uint32_t id = stash[(size_t)i * kHmStash + j];
@@ -458,24 +418,6 @@ __global__ __launch_bounds__(256) void k_hm_write_stashed(uint32_t nc, Heightmap
         ok = tri ? ts.test(pc, pb, pe, tc) : ts.test(pe, pb, pc, tc);
     }
     if (ok) out.put(out.sc->numPairs + (uint32_t)hmScan[i], i, j, count, tc);
-}
-template <bool WRITE>
-__global__ __launch_bounds__(64) void k_hm_slow(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
-                                                const float4* __restrict__ aabbMax, unsigned long long* __restrict__ hmPacked, const uint8_t* __restrict__ hmSlow,
-                                                const unsigned long long* __restrict__ hmScan, HmOut out, HullSet hulls) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nc || !hmSlow[i]) return;
-    const float4 mn = aabbMin[i], mx = aabbMax[i];
-    const Shape s = loadShape(wShape, i, __float_as_uint(mn.w) & 0xFFu);
-    if (WRITE) {
-        const uint32_t count = (uint32_t)hmPacked[i];
-        if (!count || !out.ready()) return;
-        const uint32_t first = out.sc->numPairs + (uint32_t)hmScan[i];
-        heightmapContacts(hm, s, hulls, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [&](uint32_t j, const TriContact& t) { if (j < count) out.put(first, i, j, count, t); });
-    } else {
-        const uint32_t found = heightmapContacts(hm, s, hulls, xyz(mn), V3(mx.x, mx.y + 10.f, mx.z), [](uint32_t, const TriContact&) {});
-        hmPacked[i] = (unsigned long long)found | (found ? 1ull << 32 : 0ull);
-    }
 }
 __global__ void k_hm_totals(uint32_t nc, const unsigned long long* __restrict__ hmPacked, const unsigned long long* __restrict__ hmScan, StepScalars* sc) {
     const unsigned long long t = nc ? hmScan[nc - 1u] + hmPacked[nc - 1u] : 0ull;

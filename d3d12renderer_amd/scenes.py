@@ -708,6 +708,26 @@ def terrain_field(nx=10, ny=2, nz=10, seed=9, solver_iterations=20, spacing=1.6,
     return Scene(f"terrain_field_{n}", e, ents, c, solver_iterations, hulls=hulls, heightmap=rolling_heightmap(seed=seed))
 
 
+def terrain_wide_colliders(nx=4, nz=4, seed=9):
+    """Bodies several times wider than a terrain cell's 64-cell batch on FINE terrain (2 x 2 chunks of 8 m: 6.25 cm cells — a 1 m body spans some 300 cells and the larger
+    ones cross chunk borders): the colliders `k_hm_contacts`' large-window instance takes (aligned 8 x 8 blocks in the order of the reference's quadtree walk,
+    heightmap_collider.h:35-118), next to small ones the plain instance takes, in one world."""
+    sc = terrain_field(nx, 1, nz, seed=seed, spacing=3.4, with_unsupported=True)
+    sc.heightmap = rolling_heightmap(chunks_per_dim=2, chunk_size=8.0, amplitude=3.0, seed=seed)
+    c = sc.colliders
+    big = np.arange(len(c)) % 3 != 2                            # every third body keeps its size (a few cells)
+    scale = np.where(big, 3.0, 0.35).astype(np.float32)
+    for i in range(nx * nz):
+        t = int(c["type"][i])
+        if t == capi.SPHERE: c["shape"][i, 3] *= scale[i]
+        elif t == capi.CAPSULE: c["shape"][i, :7] *= scale[i]
+        elif t == capi.AABB: c["shape"][i, :6] *= scale[i]
+        else: c["shape"][i, 4:10] *= scale[i]
+    sc.entities["position"][0] = (-3.0, 6.0, 0.5); sc.entities["position"][1] = (2.5, 6.0, 3.0)      # (terrain_field parks these two beside ITS map: back over this one)
+    sc.name = f"terrain_wide_{nx * nz}"
+    return sc
+
+
 def terrain_big(nx=128, ny=4, nz=128):
     """65 536 mixed bodies on a 4 x 4-chunk (160 m) heightmap: the full-size terrain case."""
     sc = terrain_field(nx, ny, nz, spacing=1.1, with_unsupported=False)

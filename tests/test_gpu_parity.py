@@ -49,6 +49,7 @@ def test_gpu_matches_golden_bit_exact(mi_lib, name):
     (lambda: scenes.joint_zoo(copies=3), 200),
     (lambda: scenes.vehicles(3, 2), 160),
     (lambda: scenes.terrain_field(10, 2, 10), 260),     # heightmap terrain: quadtree walk + triangle tests + lowest-point contacts
+    (lambda: scenes.terrain_wide_colliders(), 300),     # colliders spanning hundreds of terrain cells and chunk borders (k_hm_contacts' large-window instance) among small ones
 ])
 @pytest.mark.parametrize("stepping", ["speculative", "synchronous"])
 def test_gpu_vs_oracle_trajectory_and_contacts(mi_lib, oracle_mod, monkeypatch, make, steps, stepping):
