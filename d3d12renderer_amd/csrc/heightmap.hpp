@@ -279,10 +279,9 @@ struct HmOut {   // where the WRITE passes put contact j of collider i
 constexpr uint32_t kHmStashLowest = 0xFFFFFFFFu;
 constexpr uint32_t kHmStash = 16;
 template <bool WRITE, bool LARGE>
-__global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
-                                                     const float4* __restrict__ aabbMax, unsigned long long* __restrict__ hmPacked, uint8_t* __restrict__ hmSlow,
-                                                     const unsigned long long* __restrict__ hmScan, HmOut out, HullSet hulls, uint32_t* __restrict__ stash) {
-    const uint32_t i = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+__device__ __forceinline__ void hmCollider(const uint32_t i, const uint32_t lane, uint32_t nc, const HeightmapParams& hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
+                                           const float4* __restrict__ aabbMax, unsigned long long* __restrict__ hmPacked, uint8_t* __restrict__ hmSlow,
+                                           const unsigned long long* __restrict__ hmScan, const HmOut& out, const HullSet& hulls, uint32_t* __restrict__ stash) {
     if (i >= nc) return;
     const float4 mn = aabbMin[i], mx = aabbMax[i];
     uint32_t type;
@@ -390,6 +389,27 @@ __global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParam
     if (hmLowestPoint(hm, s, hulls, t) && found < kHmMaxContacts) { keep(found, kHmStashLowest); ++found; }
     hmPacked[i] = (unsigned long long)found | (found ? 1ull << 32 : 0ull);
     if (!LARGE) hmSlow[i] = 0;
+}
+constexpr uint32_t kHmScanBlocks = 512;   // the flag-scanning launches (LARGE or WRITE): at most this many workgroups, whatever the collider count
+template <bool WRITE, bool LARGE>
+__global__ __launch_bounds__(256) void k_hm_contacts(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin,
+                                                     const float4* __restrict__ aabbMax, unsigned long long* __restrict__ hmPacked, uint8_t* __restrict__ hmSlow,
+                                                     const unsigned long long* __restrict__ hmScan, HmOut out, HullSet hulls, uint32_t* __restrict__ stash) {
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (!WRITE && !LARGE) { hmCollider<false, false>(wave, lane, nc, hm, wShape, aabbMin, aabbMax, hmPacked, hmSlow, hmScan, out, hulls, stash); return; }
+    // Every other instance has work for a few colliders only (the flagged ones; in the WRITE passes those with more hits than the stash holds): a wave reads what decides
+    // that for 64 colliders at a time and takes the ones that are its business one after the other.  (As launches of a wave per collider, all but a few of which left at once,
+    // these cost the 65 536-body terrain scene 8-35 us each: three waves of 216-243 registers per SIMD, sixteen thousand workgroups.)
+    for (uint32_t base = wave * 64u; base < nc; base += gridDim.x * 256u) {
+        const uint32_t k = base + lane;
+        bool mine = k < nc && (hmSlow[k] != 0) == LARGE;
+        if (WRITE && mine) {
+            const uint32_t count = (uint32_t)hmPacked[k];
+            mine = count && (LARGE || !(stash && count <= kHmStash && hm.chunksPerDim <= 256u));
+        }
+        for (unsigned long long m = __ballot(mine); m; m &= m - 1ull)
+            hmCollider<WRITE, LARGE>(base + (uint32_t)__ffsll((long long)m) - 1u, lane, nc, hm, wShape, aabbMin, aabbMax, hmPacked, hmSlow, hmScan, out, hulls, stash);
+    }
 }
 // WRITE pass for the stashed colliders: one LANE per terrain contact.  Contact t belongs to the collider i with offset(i) <= t < offset(i) + count(i) (binary search
 // over the scanned counts) and is its hit number j = t - offset(i): the lane recomputes that one triangle (or the lowest point) and writes the contact to its final slot.
