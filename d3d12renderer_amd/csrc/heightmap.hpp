@@ -276,6 +276,7 @@ struct HmOut {   // where the WRITE passes put contact j of collider i
 // lowest-point contact of a capsule / cylinder / hull as kHmStashLowest) and the WRITE pass recomputes just those — one lane per contact — instead of walking the
 // collider's whole window of triangles a second time (65 536 bodies on terrain: the second walk was 212 us).  The counting pass itself stays what it was (it never
 // needed the contact geometry: keeping the contacts themselves doubled its time).  A collider with more hits than the stash holds is walked again as before.
+constexpr uint32_t kHmLowBit = 2u;          // hmSlow[i]: bit 0 = large window (set by the plain count pass), bit 1 = the lowest point is under the surface (k_hm_lowest, for the count passes)
 constexpr uint32_t kHmStashLowest = 0xFFFFFFFFu;
 constexpr uint32_t kHmStash = 16;
 template <bool WRITE, bool LARGE>
@@ -284,6 +285,7 @@ __device__ __forceinline__ void hmCollider(const uint32_t i, const uint32_t lane
                                            const unsigned long long* __restrict__ hmScan, const HmOut& out, const HullSet& hulls, uint32_t* __restrict__ stash) {
     if (i >= nc) return;
     const float4 mn = aabbMin[i], mx = aabbMax[i];
+    const bool low = !WRITE && (hmSlow[i] & kHmLowBit) != 0;                       // k_hm_lowest's answer for this collider (count passes)
     uint32_t type;
     const bool active = hmActive(__float_as_uint(mn.w), type) && !(mx.x < mn.x);   // (inverted box: sharded world, a body this rank does not simulate this step)
     uint32_t count = 0, first = 0;
@@ -384,11 +386,25 @@ __device__ __forceinline__ void hmCollider(const uint32_t i, const uint32_t lane
         if (found < count && hmLowestPoint(hm, s, hulls, t)) out.put(first, i, found, count, t);
         return;
     }
-    if (slow) { hmPacked[i] = 0ull; hmSlow[i] = 1; return; }
-    TriContact t;
-    if (hmLowestPoint(hm, s, hulls, t) && found < kHmMaxContacts) { keep(found, kHmStashLowest); ++found; }
+    if (slow) { hmPacked[i] = 0ull; hmSlow[i] = (uint8_t)(1u | (low ? kHmLowBit : 0u)); return; }
+    if (low && found < kHmMaxContacts) { keep(found, kHmStashLowest); ++found; }
     hmPacked[i] = (unsigned long long)found | (found ? 1ull << 32 : 0ull);
     if (!LARGE) hmSlow[i] = 0;
+}
+// The lowest-point test of every collider (heightmap_collision.cpp:572-580), one LANE per collider, ahead of the count passes: its support point and its two dependent round
+// trips (chunk slot, four heights) used to sit at the end of every wave of the count pass, on one lane.
+__global__ __launch_bounds__(256) void k_hm_lowest(uint32_t nc, HeightmapParams hm, const float4* __restrict__ wShape, const float4* __restrict__ aabbMin, const float4* __restrict__ aabbMax,
+                                                   uint8_t* __restrict__ hmSlow, HullSet hulls) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    const float4 mn = aabbMin[i], mx = aabbMax[i];
+    uint32_t type, r = 0;
+    if (hmActive(__float_as_uint(mn.w), type) && !(mx.x < mn.x)) {
+        const Shape s = loadShape(wShape, i, type);
+        TriContact t;
+        if (hmLowestPoint(hm, s, hulls, t)) r = kHmLowBit;
+    }
+    hmSlow[i] = (uint8_t)r;
 }
 constexpr uint32_t kHmScanBlocks = 512;   // the flag-scanning launches (LARGE or WRITE): at most this many workgroups, whatever the collider count
 template <bool WRITE, bool LARGE>
