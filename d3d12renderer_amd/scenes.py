@@ -708,11 +708,11 @@ def terrain_field(nx=10, ny=2, nz=10, seed=9, solver_iterations=20, spacing=1.6,
     return Scene(f"terrain_field_{n}", e, ents, c, solver_iterations, hulls=hulls, heightmap=rolling_heightmap(seed=seed))
 
 
-def terrain_wide_colliders(nx=4, nz=4, seed=9):
+def terrain_wide_colliders(nx=4, nz=4, seed=9, with_unsupported=True):
     """Bodies several times wider than a terrain cell's 64-cell batch on FINE terrain (2 x 2 chunks of 8 m: 6.25 cm cells — a 1 m body spans some 300 cells and the larger
     ones cross chunk borders): the colliders `k_hm_contacts`' large-window instance takes (aligned 8 x 8 blocks in the order of the reference's quadtree walk,
     heightmap_collider.h:35-118), next to small ones the plain instance takes, in one world."""
-    sc = terrain_field(nx, 1, nz, seed=seed, spacing=3.4, with_unsupported=True)
+    sc = terrain_field(nx, 1, nz, seed=seed, spacing=3.4, with_unsupported=with_unsupported)
     sc.heightmap = rolling_heightmap(chunks_per_dim=2, chunk_size=8.0, amplitude=3.0, seed=seed)
     c = sc.colliders
     big = np.arange(len(c)) % 3 != 2                            # every third body keeps its size (a few cells)

@@ -65,6 +65,7 @@ SCENES = [
     ("cfg4 ragdolls", lambda: scenes.ragdolls(3, 3), 240),
     ("cfg5 vehicles on hull tiles", lambda: scenes.vehicles(2, 2), 200),
     ("heightmap terrain", lambda: scenes.terrain_field(with_unsupported=False), 160),
+    ("terrain colliders spanning hundreds of cells and chunk borders", lambda: scenes.terrain_wide_colliders(with_unsupported=False), 300),
 ]
 
 
